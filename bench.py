@@ -1,0 +1,49 @@
+#!/usr/bin/env python
+"""bench.py -- throughput of the relightable-3DGS hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+One "step" = one training iteration of the hot path on one synthetic 800x800 view over a ~300k-Gaussian scene
+(BASELINE.json metric): [stage 2] per-Gaussian shading integral (K=64) forward -> rasterize forward (S=16 feature
+channels) -> pixel loss -> rasterize backward -> shading backward -> fused Adam step on every Gaussian parameter.
+Views are sharded over ranks (one camera per rank per step, weak scaling); per-Gaussian gradients are summed with
+one RCCL all-reduce per step.  value = iterations/s summed over all ranks.  Inputs are resident in HBM before the
+timed region.  rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=40)
+    ap.add_argument("--warmup", type=int, default=8)
+    ap.add_argument("--points", type=int, default=300_000)
+    ap.add_argument("--res", type=int, default=800)
+    ap.add_argument("--sample-num", type=int, default=64)
+    ap.add_argument("--stage", type=int, default=2, choices=[1, 2])
+    ap.add_argument("--cpu-baseline-seconds", type=float, default=20.0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--relight-frames", type=int, default=20)
+    return ap.parse_args()
+
+
+def main():
+    args = parse()
+    from relightable3dgaussian_amd import bench_core
+    bench_core.run(args)
+
+
+if __name__ == "__main__":
+    main()

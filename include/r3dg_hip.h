@@ -1,0 +1,118 @@
+/*
+ * r3dg_hip.h -- C ABI of libr3dg_hip.so, the MI355X (gfx950) implementation of the relightable-3DGS
+ * hot path.  Plain pointers and sizes only; every pointer named d_* is DEVICE memory (HBM), everything
+ * is fp32 / int32 unless stated.  All entry points enqueue work on `stream` (a hipStream_t passed as
+ * void*; NULL = the null stream) and return 0 on success or a negative R3DG_E* code; the failing call's
+ * message is available from r3dg_last_error().
+ *
+ * Each entry point replaces one function of the reference's pybind boundary (file:line under
+ * NJU-3DV/Relightable3DGaussian):
+ *   r3dg_rasterize_forward   <- CudaRasterizer::Rasterizer::forward   (cuda_rasterizer/rasterizer.h:31-66,
+ *                               called from RasterizeGaussiansCUDA, rasterize_points.cu:36-141)
+ *   r3dg_rasterize_backward  <- CudaRasterizer::Rasterizer::backward  (cuda_rasterizer/rasterizer.h:68-98,
+ *                               called from RasterizeGaussiansBackwardCUDA, rasterize_points.cu:143-235)
+ *   r3dg_mark_visible        <- CudaRasterizer::Rasterizer::markVisible (rasterizer.h:24-29, rasterize_points.cu:237-255)
+ *   r3dg_shade_*             <- neilf.py:339-407 rendering_equation / GGX_specular (the LIVE stage-2 model)
+ *   r3dg_render_equation_*   <- render_equation.h:7-46 (RenderEquationForwardCUDA / _complex / BackwardCUDA)
+ *   r3dg_bvh_build           <- construct_bvh (bvh/include/construct.cuh, bvh/src/construct.cu:147-265)
+ *   r3dg_bvh_trace_opacity   <- trace_bvh_opacity_cuda (bvh/include/trace.cuh:50-55, bvh/src/trace.cu:196-286)
+ *   r3dg_knn_dist2           <- SimpleKNN::knn (submodules/simple-knn/simple_knn.cu:185-221)
+ */
+#ifndef R3DG_HIP_H
+#define R3DG_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define R3DG_OK 0
+#define R3DG_EINVAL (-1)   /* bad argument (shape / S limit / null pointer)  -> RuntimeError in the host mirror */
+#define R3DG_EHIP (-2)     /* a HIP runtime call or kernel launch failed                                      */
+#define R3DG_EALLOC (-3)   /* a resize callback returned NULL                                                 */
+
+/* Resize callback, the C form of the reference's std::function<char*(size_t)> (rasterizer.h:32-34):
+ * must return a DEVICE pointer to at least `bytes` bytes that stays valid until the matching backward. */
+typedef void* (*r3dg_alloc_fn)(void* user, size_t bytes);
+
+const char* r3dg_last_error(void);
+int r3dg_version(void);
+
+/* Limits (reference: forward F[33] forward.cu:312, backward 24 backward.cu:449). Ours: both 36. */
+int r3dg_max_features_forward(void);
+int r3dg_max_features_backward(void);
+
+/* Scratch sizes (bytes) of the three opaque state buffers (rasterizer_impl.h:213-265 `required<T>`). */
+size_t r3dg_geometry_state_bytes(int P);
+size_t r3dg_image_state_bytes(int width, int height);
+size_t r3dg_binning_state_bytes(int64_t num_rendered);
+/* Byte offsets of named sub-arrays inside the state buffers, for tests/debugging only.
+ * geometry: 0 depths f32[P], 1 clamped u8[3P], 2 radii i32[P], 3 means2D f32[2P], 4 cov3D f32[6P],
+ *           5 conic_opacity f32[4P], 6 rgb f32[3P], 7 tiles_touched u32[P], 8 point_offsets u32[P]
+ * image:    0 final_T f32[N], 1 n_contrib u32[N], 2 ranges u32[2T]
+ * binning:  0 keys_unsorted u64[R], 1 keys u64[R], 2 vals_unsorted u32[R], 3 point_list u32[R] */
+int r3dg_geometry_state_offsets(int P, size_t* offsets9);
+int r3dg_image_state_offsets(int width, int height, size_t* offsets3);
+int r3dg_binning_state_offsets(int64_t num_rendered, size_t* offsets4);
+
+/* Forward. Optional inputs (d_shs, d_colors_precomp, d_scales, d_rotations, d_cov3D_precomp) are NULL when
+ * absent, exactly like the reference's nullptr convention (forward.cu:206,242). Outputs must be zero-filled
+ * by the caller (the reference's torch::full(0), rasterize_points.cu:72-79).  `d_radii` may be NULL.
+ * Returns num_rendered in *num_rendered_out.  One device->host sync (rasterizer_impl.cu:291). */
+int r3dg_rasterize_forward(void* stream, r3dg_alloc_fn geometry_alloc, r3dg_alloc_fn binning_alloc,
+                           r3dg_alloc_fn image_alloc, void* alloc_user, int P, int S, int D, int M,
+                           const float* d_background, int width, int height, const float* d_means3D,
+                           const float* d_shs, const float* d_colors_precomp, const float* d_features,
+                           const float* d_opacities, const float* d_scales, float scale_modifier,
+                           const float* d_rotations, const float* d_cov3D_precomp, const float* d_viewmatrix,
+                           const float* d_projmatrix, const float* d_cam_pos, float tan_fovx, float tan_fovy,
+                           float cx, float cy, int prefiltered, int compute_pseudo_normal, float* d_out_color,
+                           float* d_out_opacity, float* d_out_depth, float* d_out_feature, float* d_out_normal,
+                           float* d_out_surface_xyz, float* d_out_weights, int32_t* d_radii, int debug,
+                           int* num_rendered_out);
+
+/* Backward. All dL_d* outputs must be zero-filled by the caller (rasterize_points.cu:179-188).
+ * d_dL_dmean2D is [P,3] (z = depth side channel), d_dL_dconic is [P,4] (x,y,-,w). */
+int r3dg_rasterize_backward(void* stream, int P, int S, int D, int M, int R, const float* d_background, int width,
+                            int height, const float* d_means3D, const float* d_shs, const float* d_features,
+                            const float* d_colors_precomp, const float* d_scales, float scale_modifier,
+                            const float* d_rotations, const float* d_cov3D_precomp, const float* d_viewmatrix,
+                            const float* d_projmatrix, const float* d_campos, float tan_fovx, float tan_fovy,
+                            const int32_t* d_radii, const void* d_geom_buffer, const void* d_binning_buffer,
+                            const void* d_img_buffer, const float* d_dL_dpix, const float* d_dL_dpix_o,
+                            const float* d_dL_dpix_d, const float* d_dL_dpix_f, float* d_dL_dmean2D,
+                            float* d_dL_dconic, float* d_dL_dopacity, float* d_dL_dcolor, float* d_dL_dfeature,
+                            float* d_dL_dmean3D, float* d_dL_dcov3D, float* d_dL_dsh, float* d_dL_dscale,
+                            float* d_dL_drot, int backward_geometry, int debug);
+
+int r3dg_mark_visible(void* stream, int P, const float* d_means3D, const float* d_viewmatrix,
+                      const float* d_projmatrix, uint8_t* d_present);
+
+/* Stable ascending radix sort of (u64 key, u32 value) pairs on key bits [0,end_bit) -- the semantics of
+ * cub::DeviceRadixSort::SortPairs as used at rasterizer_impl.cu:313-318. Exposed for tests/benchmarks.
+ * d_temp must hold r3dg_sort_temp_bytes(n) bytes. Inputs are clobbered (used as ping-pong space). */
+size_t r3dg_sort_temp_bytes(int64_t n);
+int r3dg_sort_pairs(void* stream, int64_t n, uint64_t* d_keys_in, uint32_t* d_vals_in, uint64_t* d_keys_out,
+                    uint32_t* d_vals_out, int end_bit, void* d_temp);
+
+/* Tuning / self-test hooks (not part of the drop-in surface).
+ * r3dg_set_tuning: pixels per lane of the forward / backward tile kernels (<=0 keeps the current value) and
+ * whether the backward uses the DPP/permlane-swap transposing wave reduction (1) or the __shfl_xor one (0; <0 keeps).
+ * r3dg_selftest_transpose_reduce: one wave reduces d_in[64][N] -> d_out[64] (+ channel / owner maps). */
+int r3dg_set_tuning(int fwd_pixels_per_lane, int bwd_pixels_per_lane, int bwd_dpp_reduce);
+int r3dg_selftest_transpose_reduce(void* stream, int N, int dpp, const float* d_in, float* d_out, int* d_chan,
+                                   int* d_owner);
+
+/* Per-stage kernel timing with HIP events recorded on the launch stream (used by bench.py for the roofline
+ * numbers).  Stages: see r3dg_profile_stage_name(0..r3dg_profile_num_stages()-1). */
+int r3dg_profile_enable(int on);
+int r3dg_profile_num_stages(void);
+const char* r3dg_profile_stage_name(int stage);
+int r3dg_profile_read(double* ms_out, int* count_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* R3DG_HIP_H */

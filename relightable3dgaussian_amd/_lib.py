@@ -1,0 +1,94 @@
+"""ctypes binding of libr3dg_hip.so (include/r3dg_hip.h).  There is NO fallback: if the HIP library is missing
+or a call fails, the op raises -- a silent CPU/eager path would void every parity claim."""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libr3dg_hip.so")
+
+ALLOC_FN = C.CFUNCTYPE(C.c_void_p, C.c_void_p, C.c_size_t)
+
+_lib = None
+
+_f = C.c_float
+_i = C.c_int
+_p = C.c_void_p
+
+_SIGNATURES = {
+    "r3dg_last_error": (C.c_char_p, []),
+    "r3dg_version": (_i, []),
+    "r3dg_max_features_forward": (_i, []),
+    "r3dg_max_features_backward": (_i, []),
+    "r3dg_geometry_state_bytes": (C.c_size_t, [_i]),
+    "r3dg_image_state_bytes": (C.c_size_t, [_i, _i]),
+    "r3dg_binning_state_bytes": (C.c_size_t, [C.c_int64]),
+    "r3dg_geometry_state_offsets": (_i, [_i, C.POINTER(C.c_size_t)]),
+    "r3dg_image_state_offsets": (_i, [_i, _i, C.POINTER(C.c_size_t)]),
+    "r3dg_binning_state_offsets": (_i, [C.c_int64, C.POINTER(C.c_size_t)]),
+    "r3dg_rasterize_forward": (_i, [_p, ALLOC_FN, ALLOC_FN, ALLOC_FN, _p, _i, _i, _i, _i, _p, _i, _i, _p, _p, _p, _p,
+                                    _p, _p, _f, _p, _p, _p, _p, _p, _f, _f, _f, _f, _i, _i, _p, _p, _p, _p, _p, _p,
+                                    _p, _p, _i, C.POINTER(_i)]),
+    "r3dg_rasterize_backward": (_i, [_p, _i, _i, _i, _i, _i, _p, _i, _i, _p, _p, _p, _p, _p, _f, _p, _p, _p, _p, _p,
+                                     _f, _f, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p,
+                                     _i, _i]),
+    "r3dg_mark_visible": (_i, [_p, _i, _p, _p, _p, _p]),
+    "r3dg_sort_temp_bytes": (C.c_size_t, [C.c_int64]),
+    "r3dg_sort_pairs": (_i, [_p, C.c_int64, _p, _p, _p, _p, _i, _p]),
+    "r3dg_set_tuning": (_i, [_i, _i, _i]),
+    "r3dg_selftest_transpose_reduce": (_i, [_p, _i, _i, _p, _p, _p, _p]),
+    "r3dg_profile_enable": (_i, [_i]),
+    "r3dg_profile_num_stages": (_i, []),
+    "r3dg_profile_stage_name": (C.c_char_p, [_i]),
+    "r3dg_profile_read": (_i, [C.POINTER(C.c_double), C.POINTER(_i)]),
+}
+
+# entry points added by later translation units register themselves here (shading, bvh, knn)
+EXTRA_SIGNATURES = {}
+
+
+def lib():
+    """Load the HIP library (once).  Raises RuntimeError with build instructions if it is absent."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                "libr3dg_hip.so not found at %s -- build it with `python -m relightable3dgaussian_amd.build` "
+                "(hipcc, gfx950). There is no CPU fallback." % LIB_PATH)
+        L = C.CDLL(LIB_PATH)
+        sigs = dict(_SIGNATURES)
+        sigs.update(EXTRA_SIGNATURES)
+        for name, (res, args) in sigs.items():
+            fn = getattr(L, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+def check(status, what):
+    if status != 0:
+        msg = lib().r3dg_last_error()
+        raise RuntimeError("%s failed (%d): %s" % (what, status, msg.decode() if msg else "?"))
+
+
+def ptr(t):
+    """Device pointer of a torch tensor, or None for an absent optional (numel()==0: the reference passes empty
+    CPU tensors for absent optionals, gaussian_renderer/r3dg_rasterization.py:235-245)."""
+    if t is None or t.numel() == 0:
+        return None
+    return t.data_ptr()
+
+
+def current_stream():
+    import torch
+    return torch.cuda.current_stream().cuda_stream
+
+
+def profile_read():
+    """{stage name: (total ms, launches)} since the last r3dg_profile_enable(1)."""
+    L = lib()
+    n = L.r3dg_profile_num_stages()
+    ms = (C.c_double * n)()
+    cnt = (C.c_int * n)()
+    check(L.r3dg_profile_read(ms, cnt), "profile_read")
+    return {L.r3dg_profile_stage_name(i).decode(): (ms[i], cnt[i]) for i in range(n)}

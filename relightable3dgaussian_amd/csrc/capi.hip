@@ -1,0 +1,444 @@
+// C ABI of libr3dg_hip.so (declared in include/r3dg_hip.h): orchestration of the rasterizer forward/backward,
+// state-buffer layouts, error plumbing.  Mirrors CudaRasterizer::Rasterizer::forward/backward
+// (rasterizer_impl.cu:199-380, :384-491) in the order of work, not in code.
+#include "common.hpp"
+#include "../../include/r3dg_hip.h"
+
+#include <mutex>
+#include <vector>
+
+namespace r3dg {
+
+static thread_local std::string g_last_error;
+void set_error(const std::string& msg) { g_last_error = msg; }
+
+// launchers implemented in the kernel translation units
+void launch_mark_visible(hipStream_t s, int P, const float* means3D, const float* vm, uint8_t* present);
+void launch_preprocess(hipStream_t s, int P, int D, int M, const float* means3D, const float* scales,
+                       float scale_modifier, const float* rotations, const float* opacities, const float* shs,
+                       uint8_t* clamped, const float* cov3D_precomp, const float* colors_precomp, const float* vm,
+                       const float* pm, const float* cam_pos, int W, int H, float tan_fovx, float tan_fovy,
+                       float focal_x, float focal_y, int* radii, float* means2D, float* depths, float* cov3Ds,
+                       float* rgb, float* conic_opacity, int gx, int gy, uint32_t* tiles_touched,
+                       uint32_t* block_sums, unsigned long long* total);
+void launch_duplicate_with_keys(hipStream_t s, int P, const float* means2D, const float* depths,
+                                const uint32_t* tiles_touched, const uint32_t* block_offsets,
+                                uint32_t* point_offsets, uint64_t* keys, uint32_t* values, const int* radii, int gx,
+                                int gy);
+void launch_identify_tile_ranges(hipStream_t s, int L, const uint64_t* keys, uint32_t* ranges);
+void launch_render_forward(hipStream_t s, int W, int H, int S, const uint32_t* ranges, const uint32_t* point_list,
+                           const float* means2D, const float* depths, const float* features, const float* colors,
+                           const float* conic_opacity, float* final_T, uint32_t* n_contrib, const float* bg,
+                           float* out_color, float* out_opacity, float* out_depth, float* out_feature,
+                           float* out_weights);
+void launch_pseudo_normal(hipStream_t s, int W, int H, const float* vm, float focal_x, float focal_y, float cx,
+                          float cy, const float* opacities, const float* depths, float* normals, float* surface_xyz,
+                          bool debug);
+void launch_render_backward(hipStream_t s, int W, int H, int S, const uint32_t* ranges, const uint32_t* point_list,
+                            const float* bg, const float* means2D, const float* depths, const float* conic_opacity,
+                            const float* colors, const float* features, const float* final_Ts,
+                            const uint32_t* n_contrib, const float* dL_dpix, const float* dL_dpix_o,
+                            const float* dL_dpix_d, const float* dL_dpix_f, float* dL_dmean2D, float* dL_dconic,
+                            float* dL_dopacity, float* dL_dcolor, float* dL_dfeature, int bg_geom);
+void launch_preprocess_backward(hipStream_t s, int P, int D, int M, const float* means, const int* radii,
+                                const float* shs, const uint8_t* clamped, const float* scales, const float* rotations,
+                                float scale_modifier, const float* cov3Ds, const float* vm, const float* proj, float h_x,
+                                float h_y, float tan_fovx, float tan_fovy, const float* campos, const float* dL_dmean2D,
+                                const float* dL_dconic, float* dL_dmeans, const float* dL_dcolor, float* dL_dcov3D,
+                                float* dL_dsh, float* dL_dscale, float* dL_drot);
+extern int g_fwd_ppl;
+extern int g_bwd_ppl;
+extern int g_bwd_dpp;
+void launch_transpose_selftest(hipStream_t s, int N, int dpp, const float* in, float* out, int* chan, int* owner);
+
+// ---- optional per-stage timing with HIP events on the launch stream (bench.py's roofline numbers) ----
+enum Stage { ST_PREPROCESS = 0, ST_DUPKEYS, ST_SORT, ST_RANGES, ST_RENDER_FWD, ST_NORMAL, ST_RENDER_BWD, ST_PREPROCESS_BWD,
+             ST_COUNT };
+static const char* kStageNames[ST_COUNT] = {"preprocess", "duplicate_with_keys", "sort_pairs", "identify_tile_ranges",
+                                            "render_forward", "pseudo_normal", "render_backward", "preprocess_backward"};
+static int g_profiling = 0;
+struct EventPair { hipEvent_t a, b; };
+static std::vector<EventPair> g_events[ST_COUNT];
+static std::mutex g_prof_mutex;
+
+struct StageTimer {
+    hipStream_t s;
+    int stage;
+    EventPair ev;
+    bool on;
+    StageTimer(hipStream_t s_, int stage_) : s(s_), stage(stage_), on(g_profiling != 0)
+    {
+        if (on) {
+            R3DG_HIP(hipEventCreate(&ev.a));
+            R3DG_HIP(hipEventCreate(&ev.b));
+            R3DG_HIP(hipEventRecord(ev.a, s));
+        }
+    }
+    void stop()
+    {
+        if (on) {
+            R3DG_HIP(hipEventRecord(ev.b, s));
+            std::lock_guard<std::mutex> lk(g_prof_mutex);
+            g_events[stage].push_back(ev);
+            on = false;
+        }
+    }
+};
+
+// ---- state layouts (opaque to callers; 256-byte aligned sub-arrays) ----
+GeometryLayout GeometryLayout::make(size_t P)
+{
+    GeometryLayout L;
+    size_t o = 0;
+    auto take = [&](size_t bytes) { size_t r = o; o = align_up(o + bytes, 256); return r; };
+    L.depths = take(P * 4);
+    L.clamped = take(P * 3);
+    L.radii = take(P * 4);
+    L.means2D = take(P * 8);
+    L.cov3D = take(P * 24);
+    L.conic_opacity = take(P * 16);
+    L.rgb = take(P * 12);
+    L.tiles_touched = take(P * 4);
+    L.point_offsets = take(P * 4);
+    L.block_sums = take(((P + 255) / 256 + 1) * 4);
+    L.total = take(8);
+    L.bytes = o;
+    return L;
+}
+ImageLayout ImageLayout::make(size_t N, size_t T)
+{
+    ImageLayout L;
+    size_t o = 0;
+    auto take = [&](size_t bytes) { size_t r = o; o = align_up(o + bytes, 256); return r; };
+    L.final_T = take(N * 4);
+    L.n_contrib = take(N * 4);
+    L.ranges = take(T * 8);
+    L.bytes = o;
+    return L;
+}
+BinningLayout BinningLayout::make(size_t R)
+{
+    BinningLayout L;
+    size_t o = 0;
+    auto take = [&](size_t bytes) { size_t r = o; o = align_up(o + bytes, 256); return r; };
+    L.keys_unsorted = take(R * 8);
+    L.keys = take(R * 8);
+    L.vals_unsorted = take(R * 4);
+    L.vals = take(R * 4);
+    L.sort_temp = take(sort_temp_bytes(R));
+    L.bytes = o;
+    return L;
+}
+
+// reference getHigherMsb (rasterizer_impl.cu:35-50): position of the bit above the MSB of n
+static uint32_t higher_msb(uint32_t n)
+{
+    uint32_t b = 0;
+    while (b < 32 && (n >> b)) b++;
+    return b;
+}
+
+template <typename F>
+static int guarded(F&& f)
+{
+    try {
+        return f();
+    } catch (const HipError& e) {
+        (void)hipGetLastError();
+        return e.code == -1 ? R3DG_EINVAL : R3DG_EHIP;
+    } catch (const std::exception& e) {
+        set_error(e.what());
+        return R3DG_EHIP;
+    }
+}
+
+static int invalid(const std::string& msg)
+{
+    set_error(msg);
+    return R3DG_EINVAL;
+}
+
+}  // namespace r3dg
+
+using namespace r3dg;
+
+extern "C" {
+
+const char* r3dg_last_error(void) { return g_last_error.c_str(); }
+int r3dg_version(void) { return 100; }
+int r3dg_max_features_forward(void) { return R3DG_MAX_S_FWD; }
+int r3dg_max_features_backward(void) { return R3DG_MAX_S_BWD; }
+
+// tuning knobs (pixels per lane of the two render kernels); not part of the drop-in surface
+int r3dg_set_tuning(int fwd_pixels_per_lane, int bwd_pixels_per_lane, int bwd_dpp_reduce)
+{
+    if (fwd_pixels_per_lane > 0) g_fwd_ppl = fwd_pixels_per_lane;
+    if (bwd_pixels_per_lane > 0) g_bwd_ppl = bwd_pixels_per_lane;
+    if (bwd_dpp_reduce >= 0) g_bwd_dpp = bwd_dpp_reduce;
+    return R3DG_OK;
+}
+
+int r3dg_selftest_transpose_reduce(void* stream_, int N, int dpp, const float* d_in, float* d_out, int* d_chan,
+                                   int* d_owner)
+{
+    if (N != 16 && N != 32 && N != 64) return invalid("selftest_transpose_reduce: N must be 16, 32 or 64");
+    return guarded([&]() -> int {
+        launch_transpose_selftest((hipStream_t)stream_, N, dpp, d_in, d_out, d_chan, d_owner);
+        check_launch((hipStream_t)stream_, true, "transpose_selftest");
+        return R3DG_OK;
+    });
+}
+
+// Per-stage HIP-event timing. r3dg_profile_enable(1) starts recording (and clears), r3dg_profile_read waits for
+// the recorded events and returns, per stage, the summed milliseconds and the number of timed launches.
+int r3dg_profile_enable(int on)
+{
+    std::lock_guard<std::mutex> lk(g_prof_mutex);
+    for (int s = 0; s < ST_COUNT; s++) {
+        for (auto& e : g_events[s]) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
+        g_events[s].clear();
+    }
+    g_profiling = on;
+    return R3DG_OK;
+}
+int r3dg_profile_num_stages(void) { return ST_COUNT; }
+const char* r3dg_profile_stage_name(int stage) { return (stage >= 0 && stage < ST_COUNT) ? kStageNames[stage] : ""; }
+int r3dg_profile_read(double* ms_out, int* count_out)
+{
+    return guarded([&]() -> int {
+        std::lock_guard<std::mutex> lk(g_prof_mutex);
+        for (int s = 0; s < ST_COUNT; s++) {
+            double total = 0;
+            for (auto& e : g_events[s]) {
+                R3DG_HIP(hipEventSynchronize(e.b));
+                float ms = 0;
+                R3DG_HIP(hipEventElapsedTime(&ms, e.a, e.b));
+                total += ms;
+            }
+            ms_out[s] = total;
+            count_out[s] = (int)g_events[s].size();
+        }
+        return R3DG_OK;
+    });
+}
+
+size_t r3dg_geometry_state_bytes(int P) { return GeometryLayout::make((size_t)(P > 0 ? P : 0)).bytes; }
+size_t r3dg_image_state_bytes(int width, int height)
+{
+    const size_t T = (size_t)((width + 15) / 16) * ((height + 15) / 16);
+    return ImageLayout::make((size_t)width * height, T).bytes;
+}
+size_t r3dg_binning_state_bytes(int64_t R) { return BinningLayout::make((size_t)(R > 0 ? R : 0)).bytes; }
+
+int r3dg_geometry_state_offsets(int P, size_t* o)
+{
+    GeometryLayout L = GeometryLayout::make((size_t)P);
+    o[0] = L.depths; o[1] = L.clamped; o[2] = L.radii; o[3] = L.means2D; o[4] = L.cov3D; o[5] = L.conic_opacity;
+    o[6] = L.rgb; o[7] = L.tiles_touched; o[8] = L.point_offsets;
+    return R3DG_OK;
+}
+int r3dg_image_state_offsets(int width, int height, size_t* o)
+{
+    const size_t T = (size_t)((width + 15) / 16) * ((height + 15) / 16);
+    ImageLayout L = ImageLayout::make((size_t)width * height, T);
+    o[0] = L.final_T; o[1] = L.n_contrib; o[2] = L.ranges;
+    return R3DG_OK;
+}
+int r3dg_binning_state_offsets(int64_t R, size_t* o)
+{
+    BinningLayout L = BinningLayout::make((size_t)R);
+    o[0] = L.keys_unsorted; o[1] = L.keys; o[2] = L.vals_unsorted; o[3] = L.vals;
+    return R3DG_OK;
+}
+
+int r3dg_rasterize_forward(void* stream_, r3dg_alloc_fn geometry_alloc, r3dg_alloc_fn binning_alloc,
+                           r3dg_alloc_fn image_alloc, void* user, int P, int S, int D, int M,
+                           const float* background, int width, int height, const float* means3D, const float* shs,
+                           const float* colors_precomp, const float* features, const float* opacities,
+                           const float* scales, float scale_modifier, const float* rotations,
+                           const float* cov3D_precomp, const float* viewmatrix, const float* projmatrix,
+                           const float* cam_pos, float tan_fovx, float tan_fovy, float cx, float cy, int prefiltered,
+                           int compute_pseudo_normal, float* out_color, float* out_opacity, float* out_depth,
+                           float* out_feature, float* out_normal, float* out_surface_xyz, float* out_weights,
+                           int32_t* radii, int debug_, int* num_rendered_out)
+{
+    (void)prefiltered;
+    if (num_rendered_out) *num_rendered_out = 0;
+    if (P < 0 || width <= 0 || height <= 0) return invalid("rasterize_forward: bad P/width/height");
+    if (S < 0 || S > R3DG_MAX_S_FWD) return invalid("rasterize_forward: feature channels S must be in [0,36]");
+    if (!geometry_alloc || !binning_alloc || !image_alloc) return invalid("rasterize_forward: null resize callback");
+    if (shs == nullptr && colors_precomp == nullptr)
+        return invalid("rasterize_forward: provide SHs or precomputed colours");
+    if (shs != nullptr && colors_precomp == nullptr && (M < (D + 1) * (D + 1) || D > 3 || D < 0))
+        return invalid("rasterize_forward: SH degree/coefficients mismatch");
+    if (cov3D_precomp == nullptr && (scales == nullptr || rotations == nullptr))
+        return invalid("rasterize_forward: provide scales+rotations or a precomputed 3D covariance");
+    if (P == 0) return R3DG_OK;
+
+    return guarded([&]() -> int {
+        hipStream_t stream = (hipStream_t)stream_;
+        const bool debug = debug_ != 0;
+        const float focal_y = height / (2.0f * tan_fovy);
+        const float focal_x = width / (2.0f * tan_fovx);
+        const int gx = (width + R3DG_TILE_X - 1) / R3DG_TILE_X, gy = (height + R3DG_TILE_Y - 1) / R3DG_TILE_Y;
+        const size_t T = (size_t)gx * gy, N = (size_t)width * height;
+
+        GeometryLayout G = GeometryLayout::make((size_t)P);
+        char* gbuf = (char*)geometry_alloc(user, G.bytes);
+        ImageLayout I = ImageLayout::make(N, T);
+        char* ibuf = (char*)image_alloc(user, I.bytes);
+        if (!gbuf || !ibuf) { set_error("rasterize_forward: resize callback returned NULL"); return R3DG_EALLOC; }
+
+        int* radii_p = radii ? radii : (int*)(gbuf + G.radii);
+        float* g_depths = (float*)(gbuf + G.depths);
+        float* g_means2D = (float*)(gbuf + G.means2D);
+        float* g_conic = (float*)(gbuf + G.conic_opacity);
+        float* g_rgb = (float*)(gbuf + G.rgb);
+        uint32_t* g_tiles = (uint32_t*)(gbuf + G.tiles_touched);
+        uint32_t* g_block = (uint32_t*)(gbuf + G.block_sums);
+        unsigned long long* g_total = (unsigned long long*)(gbuf + G.total);
+
+        StageTimer t_pre(stream, ST_PREPROCESS);
+        launch_preprocess(stream, P, D, M, means3D, scales, scale_modifier, rotations, opacities, shs,
+                          (uint8_t*)(gbuf + G.clamped), cov3D_precomp, colors_precomp, viewmatrix, projmatrix, cam_pos,
+                          width, height, tan_fovx, tan_fovy, focal_x, focal_y, radii_p, g_means2D, g_depths,
+                          (float*)(gbuf + G.cov3D), g_rgb, g_conic, gx, gy, g_tiles, g_block, g_total);
+        check_launch(stream, debug, "preprocess");
+        t_pre.stop();
+
+        // the one device->host sync of the forward (reference rasterizer_impl.cu:291)
+        unsigned long long total = 0;
+        R3DG_HIP(hipMemcpyAsync(&total, g_total, sizeof(total), hipMemcpyDeviceToHost, stream));
+        R3DG_HIP(hipStreamSynchronize(stream));
+        if (total > 0x7fffffffull) { set_error("rasterize_forward: num_rendered exceeds 2^31-1"); return R3DG_EINVAL; }
+        const int R = (int)total;
+
+        BinningLayout B = BinningLayout::make((size_t)R);
+        char* bbuf = (char*)binning_alloc(user, B.bytes);
+        if (!bbuf) { set_error("rasterize_forward: binning resize callback returned NULL"); return R3DG_EALLOC; }
+        uint64_t* keys_u = (uint64_t*)(bbuf + B.keys_unsorted);
+        uint64_t* keys = (uint64_t*)(bbuf + B.keys);
+        uint32_t* vals_u = (uint32_t*)(bbuf + B.vals_unsorted);
+        uint32_t* vals = (uint32_t*)(bbuf + B.vals);
+
+        StageTimer t_dup(stream, ST_DUPKEYS);
+        launch_duplicate_with_keys(stream, P, g_means2D, g_depths, g_tiles, g_block,
+                                   (uint32_t*)(gbuf + G.point_offsets), keys_u, vals_u, radii_p, gx, gy);
+        check_launch(stream, debug, "duplicate_with_keys");
+        t_dup.stop();
+
+        const int bit = (int)higher_msb((uint32_t)T);
+        StageTimer t_sort(stream, ST_SORT);
+        sort_pairs(stream, (size_t)R, keys_u, vals_u, keys, vals, 32 + bit, bbuf + B.sort_temp, debug);
+        t_sort.stop();
+
+        uint32_t* ranges = (uint32_t*)(ibuf + I.ranges);
+        StageTimer t_rng(stream, ST_RANGES);
+        R3DG_HIP(hipMemsetAsync(ranges, 0, T * 8, stream));
+        launch_identify_tile_ranges(stream, R, keys, ranges);
+        check_launch(stream, debug, "identify_tile_ranges");
+        t_rng.stop();
+
+        const float* colors_ptr = colors_precomp != nullptr ? colors_precomp : g_rgb;
+        StageTimer t_rf(stream, ST_RENDER_FWD);
+        launch_render_forward(stream, width, height, S, ranges, vals, g_means2D, g_depths, features, colors_ptr,
+                              g_conic, (float*)(ibuf + I.final_T), (uint32_t*)(ibuf + I.n_contrib), background,
+                              out_color, out_opacity, out_depth, out_feature, out_weights);
+        check_launch(stream, debug, "render_forward");
+        t_rf.stop();
+
+        if (compute_pseudo_normal) {
+            StageTimer t_n(stream, ST_NORMAL);
+            launch_pseudo_normal(stream, width, height, viewmatrix, focal_x, focal_y, cx, cy, out_opacity, out_depth,
+                                 out_normal, out_surface_xyz, debug);
+            t_n.stop();
+        }
+        if (num_rendered_out) *num_rendered_out = R;
+        return R3DG_OK;
+    });
+}
+
+int r3dg_rasterize_backward(void* stream_, int P, int S, int D, int M, int R, const float* background, int width,
+                            int height, const float* means3D, const float* shs, const float* features,
+                            const float* colors_precomp, const float* scales, float scale_modifier,
+                            const float* rotations, const float* cov3D_precomp, const float* viewmatrix,
+                            const float* projmatrix, const float* campos, float tan_fovx, float tan_fovy,
+                            const int32_t* radii, const void* geom_buffer, const void* binning_buffer,
+                            const void* img_buffer, const float* dL_dpix, const float* dL_dpix_o,
+                            const float* dL_dpix_d, const float* dL_dpix_f, float* dL_dmean2D, float* dL_dconic,
+                            float* dL_dopacity, float* dL_dcolor, float* dL_dfeature, float* dL_dmean3D,
+                            float* dL_dcov3D, float* dL_dsh, float* dL_dscale, float* dL_drot,
+                            int backward_geometry, int debug_)
+{
+    if (P < 0 || width <= 0 || height <= 0 || R < 0) return invalid("rasterize_backward: bad P/R/width/height");
+    if (S < 0 || S > R3DG_MAX_S_BWD) return invalid("rasterize_backward: feature channels S must be in [0,36]");
+    if (P == 0) return R3DG_OK;
+    if (!geom_buffer || !img_buffer || (R > 0 && !binning_buffer)) return invalid("rasterize_backward: null state buffer");
+
+    return guarded([&]() -> int {
+        hipStream_t stream = (hipStream_t)stream_;
+        const bool debug = debug_ != 0;
+        const float focal_y = height / (2.0f * tan_fovy);
+        const float focal_x = width / (2.0f * tan_fovx);
+        const int gx = (width + R3DG_TILE_X - 1) / R3DG_TILE_X, gy = (height + R3DG_TILE_Y - 1) / R3DG_TILE_Y;
+        const size_t T = (size_t)gx * gy, N = (size_t)width * height;
+        GeometryLayout G = GeometryLayout::make((size_t)P);
+        ImageLayout I = ImageLayout::make(N, T);
+        BinningLayout B = BinningLayout::make((size_t)R);
+        const char* gbuf = (const char*)geom_buffer;
+        const char* ibuf = (const char*)img_buffer;
+        const char* bbuf = (const char*)binning_buffer;
+        const int* radii_p = radii ? radii : (const int*)(gbuf + G.radii);
+        const float* color_ptr = colors_precomp != nullptr ? colors_precomp : (const float*)(gbuf + G.rgb);
+
+        if (R > 0) {
+            StageTimer t_rb(stream, ST_RENDER_BWD);
+            launch_render_backward(stream, width, height, S, (const uint32_t*)(ibuf + I.ranges),
+                                   (const uint32_t*)(bbuf + B.vals), background, (const float*)(gbuf + G.means2D),
+                                   (const float*)(gbuf + G.depths), (const float*)(gbuf + G.conic_opacity), color_ptr,
+                                   features, (const float*)(ibuf + I.final_T), (const uint32_t*)(ibuf + I.n_contrib),
+                                   dL_dpix, dL_dpix_o, dL_dpix_d, dL_dpix_f, dL_dmean2D, dL_dconic, dL_dopacity,
+                                   dL_dcolor, dL_dfeature, backward_geometry);
+            check_launch(stream, debug, "render_backward");
+            t_rb.stop();
+        }
+        const float* cov3D_ptr = cov3D_precomp != nullptr ? cov3D_precomp : (const float*)(gbuf + G.cov3D);
+        StageTimer t_pb(stream, ST_PREPROCESS_BWD);
+        launch_preprocess_backward(stream, P, D, M, means3D, radii_p, colors_precomp == nullptr ? shs : nullptr,
+                                   (const uint8_t*)(gbuf + G.clamped), cov3D_precomp == nullptr ? scales : nullptr,
+                                   rotations, scale_modifier, cov3D_ptr, viewmatrix, projmatrix, focal_x, focal_y,
+                                   tan_fovx, tan_fovy, campos, dL_dmean2D, dL_dconic, dL_dmean3D, dL_dcolor, dL_dcov3D,
+                                   dL_dsh, dL_dscale, dL_drot);
+        check_launch(stream, debug, "preprocess_backward");
+        t_pb.stop();
+        return R3DG_OK;
+    });
+}
+
+int r3dg_mark_visible(void* stream_, int P, const float* means3D, const float* viewmatrix, const float* projmatrix,
+                      uint8_t* present)
+{
+    (void)projmatrix;
+    if (P < 0) return invalid("mark_visible: bad P");
+    if (P == 0) return R3DG_OK;
+    return guarded([&]() -> int {
+        launch_mark_visible((hipStream_t)stream_, P, means3D, viewmatrix, present);
+        check_launch((hipStream_t)stream_, false, "mark_visible");
+        return R3DG_OK;
+    });
+}
+
+size_t r3dg_sort_temp_bytes(int64_t n) { return sort_temp_bytes((size_t)(n > 0 ? n : 0)); }
+
+int r3dg_sort_pairs(void* stream_, int64_t n, uint64_t* keys_in, uint32_t* vals_in, uint64_t* keys_out,
+                    uint32_t* vals_out, int end_bit, void* temp)
+{
+    if (n < 0 || end_bit < 1 || end_bit > 64) return invalid("sort_pairs: bad n/end_bit");
+    if (n == 0) return R3DG_OK;
+    return guarded([&]() -> int {
+        sort_pairs((hipStream_t)stream_, (size_t)n, keys_in, vals_in, keys_out, vals_out, end_bit, temp, false);
+        return R3DG_OK;
+    });
+}
+
+}  // extern "C"

@@ -1,0 +1,97 @@
+// Shared host/device helpers for libr3dg_hip.so (gfx950 only; wave = 64 lanes).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+#include <stdio.h>
+#include <string>
+
+#define R3DG_TILE_X 16
+#define R3DG_TILE_Y 16
+#define R3DG_TILE_PIX 256
+#define R3DG_MAX_S_FWD 36
+#define R3DG_MAX_S_BWD 36
+
+namespace r3dg {
+
+void set_error(const std::string& msg);
+
+struct HipError {
+    int code;
+};
+
+// Host-side error plumbing: every HIP call goes through R3DG_HIP; the C-ABI wrapper catches and maps to a
+// negative return code + r3dg_last_error().
+#define R3DG_HIP(expr)                                                                                   \
+    do {                                                                                                 \
+        hipError_t _e = (expr);                                                                          \
+        if (_e != hipSuccess) {                                                                          \
+            ::r3dg::set_error(std::string(#expr) + " failed: " + hipGetErrorString(_e) + " (" + __FILE__ + \
+                              ":" + std::to_string(__LINE__) + ")");                                     \
+            throw ::r3dg::HipError{(int)_e};                                                             \
+        }                                                                                                \
+    } while (0)
+
+// After a kernel launch: always check the launch; with debug also synchronise (reference CHECK_CUDA,
+// auxiliary.h:166-173: sync + throw only when debug).
+inline void check_launch(hipStream_t s, bool debug, const char* what)
+{
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess && debug) e = hipStreamSynchronize(s);
+    if (e != hipSuccess) {
+        set_error(std::string(what) + ": " + hipGetErrorString(e));
+        throw HipError{(int)e};
+    }
+}
+
+static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+struct GeometryLayout {  // byte offsets into the opaque geometry buffer
+    size_t depths, clamped, radii, means2D, cov3D, conic_opacity, rgb, tiles_touched, point_offsets, block_sums,
+        total, bytes;
+    static GeometryLayout make(size_t P);
+};
+struct ImageLayout {
+    size_t final_T, n_contrib, ranges, bytes;
+    static ImageLayout make(size_t N, size_t T);
+};
+struct BinningLayout {
+    size_t keys_unsorted, keys, vals_unsorted, vals, sort_temp, bytes;
+    static BinningLayout make(size_t R);
+};
+
+size_t sort_temp_bytes(size_t n);
+void sort_pairs(hipStream_t stream, size_t n, uint64_t* keys_in, uint32_t* vals_in, uint64_t* keys_out,
+                uint32_t* vals_out, int end_bit, void* temp, bool debug);
+
+// ---- device helpers -------------------------------------------------------------------------------------
+#ifdef __HIPCC__
+__device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63); }
+
+// Full-wave (64-lane) sum; result valid in every lane.
+__device__ __forceinline__ float wave_sum(float v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor((int)v, o, 64);
+    return v;
+}
+// Inclusive scan across the wave.
+__device__ __forceinline__ uint32_t wave_inclusive_scan_u32(uint32_t v)
+{
+    const int l = lane_id();
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        uint32_t n = (uint32_t)__shfl_up((int)v, o, 64);
+        if (l >= o) v += n;
+    }
+    return v;
+}
+#endif
+
+}  // namespace r3dg

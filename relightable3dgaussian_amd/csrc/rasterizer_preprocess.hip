@@ -1,0 +1,362 @@
+// Per-Gaussian stages of the rasterizer forward for gfx950: frustum mark (K1), preprocess (K2),
+// tiles_touched scan (K3), key duplication (K5), tile ranges (K7).
+//
+// This translation unit is compiled with -ffp-contract=off: radii, tile rectangles and depth bits decide
+// INTEGER outputs (tiles_touched, keys, sort order), which must be bit-identical to the CPU oracle, so every
+// fp32 operation keeps the reference's order (forward.cu:74-258, auxiliary.h:41-164) with no fused
+// multiply-add.  These kernels are HBM-bound (236 B read + ~75 B written per Gaussian); VALU cost is irrelevant.
+#include "common.hpp"
+
+namespace r3dg {
+
+// --- 3x3 helper with glm's evaluation order (column-major, R[j][i] = A[0][i]*B[j][0]+A[1][i]*B[j][1]+A[2][i]*B[j][2]) ---
+struct M3 {
+    float c[3][3];
+};
+__device__ __forceinline__ M3 m3mul(const M3& A, const M3& B)
+{
+    M3 R;
+#pragma unroll
+    for (int j = 0; j < 3; j++)
+#pragma unroll
+        for (int i = 0; i < 3; i++)
+            R.c[j][i] = A.c[0][i] * B.c[j][0] + A.c[1][i] * B.c[j][1] + A.c[2][i] * B.c[j][2];
+    return R;
+}
+__device__ __forceinline__ M3 m3t(const M3& A)
+{
+    M3 R;
+#pragma unroll
+    for (int j = 0; j < 3; j++)
+#pragma unroll
+        for (int i = 0; i < 3; i++) R.c[j][i] = A.c[i][j];
+    return R;
+}
+
+__device__ __forceinline__ float ndc_to_pix(float v, int S) { return (float)(((v + 1.0) * S - 1.0) * 0.5); }
+
+// float -> int, round toward zero, saturating, NaN -> 0 (what CUDA's cvt.rzi.s32.f32 and gfx950's
+// v_cvt_i32_f32 both do; spelled out because an out-of-range (int) cast is undefined in C++)
+__device__ __forceinline__ int f2i_sat(float v)
+{
+    if (v != v) return 0;
+    if (v >= 2147483648.0f) return 2147483647;
+    if (v <= -2147483648.0f) return (-2147483647 - 1);
+    return (int)v;
+}
+
+__device__ __forceinline__ void tile_rect(float px, float py, int max_radius, int gx, int gy, int& x0, int& y0,
+                                          int& x1, int& y1)
+{
+    x0 = min(gx, max(0, f2i_sat((px - max_radius) / R3DG_TILE_X)));
+    y0 = min(gy, max(0, f2i_sat((py - max_radius) / R3DG_TILE_Y)));
+    x1 = min(gx, max(0, f2i_sat((px + max_radius + R3DG_TILE_X - 1) / R3DG_TILE_X)));
+    y1 = min(gy, max(0, f2i_sat((py + max_radius + R3DG_TILE_Y - 1) / R3DG_TILE_Y)));
+}
+
+__constant__ float kSH_C0 = 0.28209479177387814f;
+__constant__ float kSH_C1 = 0.4886025119029199f;
+__constant__ float kSH_C2[5] = {1.0925484305920792f, -1.0925484305920792f, 0.31539156525252005f,
+                                -1.0925484305920792f, 0.5462742152960396f};
+__constant__ float kSH_C3[7] = {-0.5900435899266435f, 2.890611442640554f, -0.4570457994644658f,
+                                0.3731763325901154f, -0.4570457994644658f, 1.445305721320277f,
+                                -0.5900435899266435f};
+
+// K1: reference checkFrustum / in_frustum (rasterizer_impl.cu:54-66, auxiliary.h:139-164)
+__global__ void mark_visible_kernel(int P, const float* __restrict__ pts, const float* __restrict__ vm,
+                                    uint8_t* __restrict__ present)
+{
+    int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= P) return;
+    float x = pts[3 * idx], y = pts[3 * idx + 1], z = pts[3 * idx + 2];
+    float vz = vm[2] * x + vm[6] * y + vm[10] * z + vm[14];
+    present[idx] = vz > 0.2f;
+}
+
+// K2: reference preprocessCUDA (forward.cu:156-258).  One thread per Gaussian; each 256-thread block also
+// reduces its tiles_touched into block_sums[blockIdx] so the scan (K3) never re-reads the per-Gaussian array.
+__global__ void __launch_bounds__(256)
+preprocess_kernel(int P, int D, int M, const float* __restrict__ means3D, const float* __restrict__ scales,
+                  float scale_modifier, const float* __restrict__ rotations, const float* __restrict__ opacities,
+                  const float* __restrict__ shs, uint8_t* __restrict__ clamped, const float* __restrict__ cov3D_precomp,
+                  const float* __restrict__ colors_precomp, const float* __restrict__ vm,
+                  const float* __restrict__ pm, const float* __restrict__ cam_pos, int W, int H, float tan_fovx,
+                  float tan_fovy, float focal_x, float focal_y, int* __restrict__ radii,
+                  float2* __restrict__ means2D, float* __restrict__ depths, float* __restrict__ cov3Ds,
+                  float* __restrict__ rgb, float4* __restrict__ conic_opacity, int gx, int gy,
+                  uint32_t* __restrict__ tiles_touched, uint32_t* __restrict__ block_sums)
+{
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    uint32_t my_tiles = 0;
+    if (idx < P) {
+        int my_radius_i = 0;
+        do {
+            const float px = means3D[3 * idx], py = means3D[3 * idx + 1], pz = means3D[3 * idx + 2];
+            // view-space point (auxiliary.h:58-66) and near cull (auxiliary.h:154)
+            const float vx = vm[0] * px + vm[4] * py + vm[8] * pz + vm[12];
+            const float vy = vm[1] * px + vm[5] * py + vm[9] * pz + vm[13];
+            const float vz = vm[2] * px + vm[6] * py + vm[10] * pz + vm[14];
+            if (vz <= 0.2f) break;
+            const float hx = pm[0] * px + pm[4] * py + pm[8] * pz + pm[12];
+            const float hy = pm[1] * px + pm[5] * py + pm[9] * pz + pm[13];
+            const float hw = pm[3] * px + pm[7] * py + pm[11] * pz + pm[15];
+            const float p_w = 1.0f / (hw + 0.0000001f);
+            const float projx = hx * p_w, projy = hy * p_w;
+
+            float c3[6];
+            if (cov3D_precomp != nullptr) {
+#pragma unroll
+                for (int i = 0; i < 6; i++) c3[i] = cov3D_precomp[6 * idx + i];
+            } else {
+                // forward.cu:119-153; quaternion used as given
+                const float sx = scale_modifier * scales[3 * idx], sy = scale_modifier * scales[3 * idx + 1],
+                            sz = scale_modifier * scales[3 * idx + 2];
+                const float r = rotations[4 * idx], x = rotations[4 * idx + 1], y = rotations[4 * idx + 2],
+                            z = rotations[4 * idx + 3];
+                M3 S = {{{sx, 0, 0}, {0, sy, 0}, {0, 0, sz}}};
+                M3 R = {{{1.f - 2.f * (y * y + z * z), 2.f * (x * y - r * z), 2.f * (x * z + r * y)},
+                         {2.f * (x * y + r * z), 1.f - 2.f * (x * x + z * z), 2.f * (y * z - r * x)},
+                         {2.f * (x * z - r * y), 2.f * (y * z + r * x), 1.f - 2.f * (x * x + y * y)}}};
+                M3 Mm = m3mul(S, R);
+                M3 Sg = m3mul(m3t(Mm), Mm);
+                c3[0] = Sg.c[0][0]; c3[1] = Sg.c[0][1]; c3[2] = Sg.c[0][2];
+                c3[3] = Sg.c[1][1]; c3[4] = Sg.c[1][2]; c3[5] = Sg.c[2][2];
+#pragma unroll
+                for (int i = 0; i < 6; i++) cov3Ds[6 * idx + i] = c3[i];
+            }
+
+            // EWA 2D covariance (forward.cu:74-113)
+            float tx = vx, ty = vy;
+            const float tz = vz;
+            const float limx = 1.3f * tan_fovx, limy = 1.3f * tan_fovy;
+            const float txtz = tx / tz, tytz = ty / tz;
+            tx = fminf(limx, fmaxf(-limx, txtz)) * tz;
+            ty = fminf(limy, fmaxf(-limy, tytz)) * tz;
+            M3 J = {{{focal_x / tz, 0.0f, -(focal_x * tx) / (tz * tz)},
+                     {0.0f, focal_y / tz, -(focal_y * ty) / (tz * tz)},
+                     {0, 0, 0}}};
+            M3 Wm = {{{vm[0], vm[4], vm[8]}, {vm[1], vm[5], vm[9]}, {vm[2], vm[6], vm[10]}}};
+            M3 T = m3mul(Wm, J);
+            M3 V = {{{c3[0], c3[1], c3[2]}, {c3[1], c3[3], c3[4]}, {c3[2], c3[4], c3[5]}}};
+            M3 cov = m3mul(m3mul(m3t(T), m3t(V)), T);
+            const float ca = cov.c[0][0] + 0.3f, cb = cov.c[0][1], cc = cov.c[1][1] + 0.3f;
+
+            const float det = (ca * cc - cb * cb);
+            if (det == 0.0f) break;
+            const float det_inv = 1.f / det;
+            const float mid = 0.5f * (ca + cc);
+            const float lambda1 = mid + sqrtf(fmaxf(0.1f, mid * mid - det));
+            const float lambda2 = mid - sqrtf(fmaxf(0.1f, mid * mid - det));
+            const float my_radius = ceilf(3.f * sqrtf(fmaxf(lambda1, lambda2)));
+            const float pixx = ndc_to_pix(projx, W), pixy = ndc_to_pix(projy, H);
+            int x0, y0, x1, y1;
+            tile_rect(pixx, pixy, f2i_sat(my_radius), gx, gy, x0, y0, x1, y1);
+            if ((x1 - x0) * (y1 - y0) == 0) break;
+
+            if (colors_precomp == nullptr) {
+                // forward.cu:20-71
+                float dx = px - cam_pos[0], dy = py - cam_pos[1], dz = pz - cam_pos[2];
+                const float len = sqrtf(dx * dx + dy * dy + dz * dz);
+                dx = dx / len; dy = dy / len; dz = dz / len;
+                const float* sh = shs + (size_t)idx * M * 3;
+#pragma unroll
+                for (int ch = 0; ch < 3; ch++) {
+                    float result = kSH_C0 * sh[ch];
+                    if (D > 0) {
+                        const float x = dx, y = dy, z = dz;
+                        result = result - kSH_C1 * y * sh[3 + ch] + kSH_C1 * z * sh[6 + ch] - kSH_C1 * x * sh[9 + ch];
+                        if (D > 1) {
+                            const float xx = x * x, yy = y * y, zz = z * z;
+                            const float xy = x * y, yz = y * z, xz = x * z;
+                            result = result + kSH_C2[0] * xy * sh[12 + ch] + kSH_C2[1] * yz * sh[15 + ch] +
+                                     kSH_C2[2] * (2.0f * zz - xx - yy) * sh[18 + ch] + kSH_C2[3] * xz * sh[21 + ch] +
+                                     kSH_C2[4] * (xx - yy) * sh[24 + ch];
+                            if (D > 2) {
+                                result = result + kSH_C3[0] * y * (3.0f * xx - yy) * sh[27 + ch] +
+                                         kSH_C3[1] * xy * z * sh[30 + ch] +
+                                         kSH_C3[2] * y * (4.0f * zz - xx - yy) * sh[33 + ch] +
+                                         kSH_C3[3] * z * (2.0f * zz - 3.0f * xx - 3.0f * yy) * sh[36 + ch] +
+                                         kSH_C3[4] * x * (4.0f * zz - xx - yy) * sh[39 + ch] +
+                                         kSH_C3[5] * z * (xx - yy) * sh[42 + ch] +
+                                         kSH_C3[6] * x * (xx - 3.0f * yy) * sh[45 + ch];
+                            }
+                        }
+                    }
+                    result += 0.5f;
+                    clamped[3 * idx + ch] = (result < 0);
+                    rgb[3 * idx + ch] = fmaxf(result, 0.0f);
+                }
+            }
+            depths[idx] = vz;
+            my_radius_i = f2i_sat(my_radius);
+            means2D[idx] = make_float2(pixx, pixy);
+            conic_opacity[idx] = make_float4(cc * det_inv, -cb * det_inv, ca * det_inv, opacities[idx]);
+            my_tiles = (uint32_t)((y1 - y0) * (x1 - x0));
+        } while (0);
+        radii[idx] = my_radius_i;
+        tiles_touched[idx] = my_tiles;
+    }
+    // block reduction of tiles_touched -> block_sums
+    __shared__ uint32_t s_wave[4];
+    uint32_t ws = wave_sum_u32(my_tiles);
+    if ((threadIdx.x & 63) == 0) s_wave[threadIdx.x >> 6] = ws;
+    __syncthreads();
+    if (threadIdx.x == 0) block_sums[blockIdx.x] = s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
+}
+
+// K3: exclusive scan of the per-block sums (one 1024-thread block; nb = ceil(P/256) is ~1.2k at P=300k).
+// Writes block_sums[i] <- exclusive prefix and total[0] <- num_rendered (64-bit to detect u32 overflow).
+__global__ void __launch_bounds__(1024) scan_block_sums_kernel(int nb, uint32_t* __restrict__ block_sums,
+                                                               unsigned long long* __restrict__ total)
+{
+    __shared__ unsigned long long s_wave[16];
+    __shared__ unsigned long long s_carry;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid == 0) s_carry = 0;
+    __syncthreads();
+    for (int base = 0; base < nb; base += 1024) {
+        const int i = base + tid;
+        const uint32_t v = i < nb ? block_sums[i] : 0u;
+        unsigned long long inc = v;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            unsigned long long n = __shfl_up(inc, o, 64);
+            if (lane >= o) inc += n;
+        }
+        if (lane == 63) s_wave[wave] = inc;
+        __syncthreads();
+        unsigned long long wave_off = 0, chunk_total = 0;
+        for (int w = 0; w < 16; w++) {
+            if (w < wave) wave_off += s_wave[w];
+            chunk_total += s_wave[w];
+        }
+        const unsigned long long carry = s_carry;
+        if (i < nb) block_sums[i] = (uint32_t)(carry + wave_off + inc - v);
+        __syncthreads();
+        if (tid == 0) s_carry = carry + chunk_total;
+        __syncthreads();
+    }
+    if (tid == 0) total[0] = s_carry;
+}
+
+// K5: reference duplicateWithKeys (rasterizer_impl.cu:70-111).  Also materialises the inclusive prefix sum
+// point_offsets (K3's cub::DeviceScan::InclusiveSum output) from the block-local scan + scanned block sum.
+// Emission order inside one Gaussian is row-major over its tile rectangle; key = tile_id<<32 | bits(depth).
+// Rectangles larger than 32 tiles are expanded cooperatively by the whole wave so that one screen-filling
+// Gaussian cannot serialise a wave (the reference loops per thread).
+__global__ void __launch_bounds__(256)
+duplicate_with_keys_kernel(int P, const float2* __restrict__ means2D, const float* __restrict__ depths,
+                           const uint32_t* __restrict__ tiles_touched, const uint32_t* __restrict__ block_offsets,
+                           uint32_t* __restrict__ point_offsets, uint64_t* __restrict__ keys,
+                           uint32_t* __restrict__ values, const int* __restrict__ radii, int gx, int gy)
+{
+    __shared__ uint32_t s_wave[4];
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t cnt = idx < P ? tiles_touched[idx] : 0u;
+    const uint32_t inc = wave_inclusive_scan_u32(cnt);
+    if (lane == 63) s_wave[wave] = inc;
+    __syncthreads();
+    uint32_t off = block_offsets[blockIdx.x];
+    for (int w = 0; w < wave; w++) off += s_wave[w];
+    const uint32_t end = off + inc;      // inclusive prefix == reference point_offsets[idx]
+    uint32_t begin = end - cnt;
+    if (idx < P) point_offsets[idx] = end;
+
+    int x0 = 0, y0 = 0, x1 = 0, y1 = 0;
+    uint32_t dbits = 0;
+    const bool live = idx < P && radii[idx] > 0;
+    if (live) {
+        const float2 p = means2D[idx];
+        tile_rect(p.x, p.y, radii[idx], gx, gy, x0, y0, x1, y1);
+        dbits = __float_as_uint(depths[idx]);
+    }
+    const int w_rect = x1 - x0;
+    const bool big = live && cnt > 32u;
+    if (live && !big) {
+        for (int y = y0; y < y1; y++)
+            for (int x = x0; x < x1; x++) {
+                uint64_t key = (uint64_t)(uint32_t)(y * gx + x);
+                key = (key << 32) | dbits;
+                keys[begin] = key;
+                values[begin] = (uint32_t)idx;
+                begin++;
+            }
+    }
+    // wave-cooperative expansion of the big rectangles
+    unsigned long long todo = __ballot(big);
+    while (todo) {
+        const int src = __ffsll((long long)todo) - 1;
+        todo &= todo - 1;
+        const int bx0 = __shfl(x0, src, 64), by0 = __shfl(y0, src, 64), bw = __shfl(w_rect, src, 64);
+        const uint32_t bcnt = (uint32_t)__shfl((int)cnt, src, 64);
+        const uint32_t bbegin = (uint32_t)__shfl((int)(end - cnt), src, 64);
+        const uint32_t bbits = (uint32_t)__shfl((int)dbits, src, 64);
+        const uint32_t bid = (uint32_t)(blockIdx.x * 256 + wave * 64 + src);
+        for (uint32_t k = lane; k < bcnt; k += 64) {
+            const int y = by0 + (int)(k / (uint32_t)bw), x = bx0 + (int)(k % (uint32_t)bw);
+            uint64_t key = (uint64_t)(uint32_t)(y * gx + x);
+            key = (key << 32) | bbits;
+            keys[bbegin + k] = key;
+            values[bbegin + k] = bid;
+        }
+    }
+}
+
+// K7: reference identifyTileRanges (rasterizer_impl.cu:116-138); ranges pre-zeroed by hipMemsetAsync (:320).
+__global__ void identify_tile_ranges_kernel(int L, const uint64_t* __restrict__ keys, uint2* __restrict__ ranges)
+{
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= L) return;
+    const uint32_t currtile = (uint32_t)(keys[idx] >> 32);
+    if (idx == 0)
+        ranges[currtile].x = 0;
+    else {
+        const uint32_t prevtile = (uint32_t)(keys[idx - 1] >> 32);
+        if (currtile != prevtile) {
+            ranges[prevtile].y = idx;
+            ranges[currtile].x = idx;
+        }
+    }
+    if (idx == L - 1) ranges[currtile].y = L;
+}
+
+// ---- host launchers -------------------------------------------------------------------------------------
+void launch_mark_visible(hipStream_t s, int P, const float* means3D, const float* vm, uint8_t* present)
+{
+    if (P <= 0) return;
+    mark_visible_kernel<<<(P + 255) / 256, 256, 0, s>>>(P, means3D, vm, present);
+}
+
+void launch_preprocess(hipStream_t s, int P, int D, int M, const float* means3D, const float* scales,
+                       float scale_modifier, const float* rotations, const float* opacities, const float* shs,
+                       uint8_t* clamped, const float* cov3D_precomp, const float* colors_precomp, const float* vm,
+                       const float* pm, const float* cam_pos, int W, int H, float tan_fovx, float tan_fovy,
+                       float focal_x, float focal_y, int* radii, float* means2D, float* depths, float* cov3Ds,
+                       float* rgb, float* conic_opacity, int gx, int gy, uint32_t* tiles_touched,
+                       uint32_t* block_sums, unsigned long long* total)
+{
+    const int nb = (P + 255) / 256;
+    preprocess_kernel<<<nb, 256, 0, s>>>(P, D, M, means3D, scales, scale_modifier, rotations, opacities, shs, clamped,
+                                         cov3D_precomp, colors_precomp, vm, pm, cam_pos, W, H, tan_fovx, tan_fovy,
+                                         focal_x, focal_y, radii, (float2*)means2D, depths, cov3Ds, rgb,
+                                         (float4*)conic_opacity, gx, gy, tiles_touched, block_sums);
+    scan_block_sums_kernel<<<1, 1024, 0, s>>>(nb, block_sums, total);
+}
+
+void launch_duplicate_with_keys(hipStream_t s, int P, const float* means2D, const float* depths,
+                                const uint32_t* tiles_touched, const uint32_t* block_offsets,
+                                uint32_t* point_offsets, uint64_t* keys, uint32_t* values, const int* radii, int gx,
+                                int gy)
+{
+    duplicate_with_keys_kernel<<<(P + 255) / 256, 256, 0, s>>>(P, (const float2*)means2D, depths, tiles_touched,
+                                                             block_offsets, point_offsets, keys, values, radii, gx, gy);
+}
+
+void launch_identify_tile_ranges(hipStream_t s, int L, const uint64_t* keys, uint32_t* ranges)
+{
+    if (L <= 0) return;
+    identify_tile_ranges_kernel<<<(L + 255) / 256, 256, 0, s>>>(L, keys, (uint2*)ranges);
+}
+
+}  // namespace r3dg

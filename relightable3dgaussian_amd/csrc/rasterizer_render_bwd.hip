@@ -1,0 +1,413 @@
+// Per-tile alpha compositing backward (K11) for gfx950.  Reference semantics: renderCUDA backward.cu:401-614.
+//
+// The reference issues 10+S float atomics per contributing (pixel, Gaussian) pair.  Here:
+//   * same tile decomposition as the forward (256/PPL threads, PPL pixels per lane, LDS-staged batches that
+//     include colour/feature/depth payload, wave-uniform broadcast reads);
+//   * the back-to-front walk starts at the tile's deepest contributor (block max of n_contrib) instead of the
+//     end of the tile list -- entries behind every pixel's last contributor are never fetched;
+//   * the recursive "accum_rec" blend (backward.cu:538-577) is kept bit-for-bit but without the reference's
+//     last_color/last_feature/last_depth copies: accum is advanced with the current (alpha, value) right after use,
+//     which evaluates the same expression one iteration earlier;
+//   * per-Gaussian gradients (3 colour + 3 mean2D + 3 conic + 1 opacity + S feature = 10+S values per lane, already
+//     summed over the lane's PPL pixels) are reduced across the 64 lanes with a TRANSPOSING butterfly: after
+//     log2(NV) exchange levels lane l holds the wave total of channel chan(l), so the whole 10+S-vector costs
+//     ~NV shuffles (not 6*NV) and leaves as ONE atomic instruction with 10+S active lanes per (wave, Gaussian).
+#include "common.hpp"
+
+namespace r3dg {
+
+__device__ __forceinline__ float fast_exp_b(float x) { return __builtin_amdgcn_exp2f(x * 1.4426950408889634f); }
+
+template <int N>
+struct Log2 {
+    static constexpr int value = 1 + Log2<N / 2>::value;
+};
+template <>
+struct Log2<1> {
+    static constexpr int value = 0;
+};
+
+// ---- transposing wave reduction ---------------------------------------------------------------------------
+// Input: N (power of two, 16..64) partial values per lane.  Output: every lane holds the 64-lane total of ONE
+// channel, chan(lane) = sum_t bit_{5-t}(lane) * (N >> (t+1)), t < log2 N.  Exchange levels run at lane distance
+// 32,16,8,4,2,1: at each transposing level a pair of lanes (l, l^d) splits the remaining channels -- the lane with
+// bit d clear keeps the lower half, the other the upper half -- so the live value count halves every level
+// (N/2 + N/4 + ... exchanges instead of 6*N).  gfx950 specifics: distance 32/16 use v_permlane32_swap /
+// v_permlane16_swap (swap half-waves / odd-even rows of two registers: exchange + select in ONE instruction),
+// distance 8/4 use two bank-masked row_shl/row_shr DPP moves, distance 2/1 a quad_perm DPP move.  Everything
+// stays in the VALU; no LDS-crossbar (ds_bpermute) traffic and no long-latency results to keep live.
+template <int N>
+__device__ __forceinline__ int transposed_channel(int lane)
+{
+    int idx = 0;
+#pragma unroll
+    for (int t = 0; t < Log2<N>::value; t++)
+        if (lane & (32 >> t)) idx += N >> (t + 1);
+    return idx;
+}
+// true for the one lane per channel that owns the result (low, non-transposed lane bits are zero)
+template <int N>
+__device__ __forceinline__ bool transposed_owner(int lane)
+{
+    return (lane & ((64 / N) - 1)) == 0;
+}
+
+template <int D>
+__device__ __forceinline__ float lane_xor_dpp(float x)
+{
+    const int xi = __float_as_int(x);
+    int r;
+    if constexpr (D == 1) r = __builtin_amdgcn_update_dpp(0, xi, 0xB1, 0xF, 0xF, false);        // quad_perm [1,0,3,2]
+    else if constexpr (D == 2) r = __builtin_amdgcn_update_dpp(0, xi, 0x4E, 0xF, 0xF, false);   // quad_perm [2,3,0,1]
+    else if constexpr (D == 4) {
+        r = __builtin_amdgcn_update_dpp(0, xi, 0x104, 0xF, 0x5, false);   // banks 0,2 read lane+4 (row_shl:4)
+        r = __builtin_amdgcn_update_dpp(r, xi, 0x114, 0xF, 0xA, false);   // banks 1,3 read lane-4 (row_shr:4)
+    } else {
+        static_assert(D == 8, "DPP xor distance");
+        r = __builtin_amdgcn_update_dpp(0, xi, 0x108, 0xF, 0x3, false);   // banks 0,1 read lane+8
+        r = __builtin_amdgcn_update_dpp(r, xi, 0x118, 0xF, 0xC, false);   // banks 2,3 read lane-8
+    }
+    return __int_as_float(r);
+}
+
+template <int D, bool DPP>
+__device__ __forceinline__ float lane_xor(float x)
+{
+    if constexpr (DPP && D <= 8) return lane_xor_dpp<D>(x);
+    else return __shfl_xor(x, D, 64);
+}
+
+// one transposing exchange of the pair (lo-half value a, hi-half value b) at lane distance D
+template <int D, bool DPP>
+__device__ __forceinline__ float transpose_step(float a, float b, bool hi)
+{
+    if constexpr (DPP && D == 32) {
+        auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+        return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+    } else if constexpr (DPP && D == 16) {
+        auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+        return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+    } else {
+        const float send = hi ? a : b;
+        const float keep = hi ? b : a;
+        return keep + lane_xor<D, DPP>(send);
+    }
+}
+
+template <int N, int LVL, bool DPP>
+__device__ __forceinline__ void transpose_level(float (&v)[N], int lane)
+{
+    constexpr int D = 32 >> LVL;
+    constexpr int half = N >> (LVL + 1);
+    const bool hi = (lane & D) != 0;
+#pragma unroll
+    for (int k = 0; k < half; k++) v[k] = transpose_step<D, DPP>(v[k], v[k + half], hi);
+}
+
+template <int N, bool DPP>
+__device__ __forceinline__ float transpose_reduce(float (&v)[N])
+{
+    const int lane = lane_id();
+    constexpr int L = Log2<N>::value;
+    if constexpr (L > 0) transpose_level<N, 0, DPP>(v, lane);
+    if constexpr (L > 1) transpose_level<N, 1, DPP>(v, lane);
+    if constexpr (L > 2) transpose_level<N, 2, DPP>(v, lane);
+    if constexpr (L > 3) transpose_level<N, 3, DPP>(v, lane);
+    if constexpr (L > 4) transpose_level<N, 4, DPP>(v, lane);
+    if constexpr (L > 5) transpose_level<N, 5, DPP>(v, lane);
+    float r = v[0];
+    // remaining (non-transposing) distances: plain butterfly adds
+    if constexpr (L <= 2) r += lane_xor<8, DPP>(r);
+    if constexpr (L <= 3) r += lane_xor<4, DPP>(r);
+    if constexpr (L <= 4) r += lane_xor<2, DPP>(r);
+    if constexpr (L <= 5) r += lane_xor<1, DPP>(r);
+    return r;
+}
+
+// self-test kernel: out[lane] = transpose_reduce of in[lane*N + k]; host compares against a plain sum
+template <int N, bool DPP>
+__global__ void transpose_reduce_selftest_kernel(const float* __restrict__ in, float* __restrict__ out,
+                                                 int* __restrict__ chan_out, int* __restrict__ owner_out)
+{
+    float v[N];
+#pragma unroll
+    for (int k = 0; k < N; k++) v[k] = in[threadIdx.x * N + k];
+    out[threadIdx.x] = transpose_reduce<N, DPP>(v);
+    chan_out[threadIdx.x] = transposed_channel<N>(threadIdx.x);
+    owner_out[threadIdx.x] = transposed_owner<N>(threadIdx.x) ? 1 : 0;
+}
+
+void launch_transpose_selftest(hipStream_t s, int N, int dpp, const float* in, float* out, int* chan, int* owner)
+{
+#define R3DG_ST(NN)                                                                              \
+    if (dpp) transpose_reduce_selftest_kernel<NN, true><<<1, 64, 0, s>>>(in, out, chan, owner);  \
+    else transpose_reduce_selftest_kernel<NN, false><<<1, 64, 0, s>>>(in, out, chan, owner);
+    if (N == 16) { R3DG_ST(16) } else if (N == 32) { R3DG_ST(32) } else { R3DG_ST(64) }
+#undef R3DG_ST
+}
+
+constexpr int next_pow2(int v) { return v <= 16 ? 16 : (v <= 32 ? 32 : 64); }
+
+template <int SPAD, int PPL, bool DPP>
+__global__ void __launch_bounds__(256 / PPL)
+render_backward_kernel(const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list, int S, int W, int H,
+                       int tiles_x, int num_tiles, int xcd_chunk, const float* __restrict__ bg_color,
+                       const float2* __restrict__ means2D, const float* __restrict__ depths,
+                       const float4* __restrict__ conic_opacity, const float* __restrict__ colors,
+                       const float* __restrict__ features, const float* __restrict__ final_Ts,
+                       const uint32_t* __restrict__ n_contrib, const float* __restrict__ dL_dpixels,
+                       const float* __restrict__ dL_dpixels_o, const float* __restrict__ dL_dpixels_d,
+                       const float* __restrict__ dL_dpixels_f, float* __restrict__ dL_dmean2D,
+                       float* __restrict__ dL_dconic2D, float* __restrict__ dL_dopacity,
+                       float* __restrict__ dL_dcolors, float* __restrict__ dL_dfeature, int backward_geometry)
+{
+    constexpr int NT = 256 / PPL;
+    constexpr int PAY = 4 + SPAD;
+    constexpr int NV = 10 + SPAD;            // gradient channels per Gaussian
+    constexpr int NVP = next_pow2(NV);
+    constexpr int NW = NT / 64;
+
+    const int tile = (int)(blockIdx.x & 7u) * xcd_chunk + (int)(blockIdx.x >> 3);
+    if (tile >= num_tiles) return;
+    const int tile_x = tile % tiles_x, tile_y = tile / tiles_x;
+
+    __shared__ float4 s_geo0[NT];
+    __shared__ float4 s_geo1[NT];
+    __shared__ __attribute__((aligned(16))) float s_pay[NT * PAY];
+    __shared__ uint32_t s_max[NW];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int px = tile_x * R3DG_TILE_X + (lane & 15);
+    const int py0 = tile_y * R3DG_TILE_Y + wave * (4 * PPL) + (lane >> 4);
+    const float pxf = (float)px;
+    const size_t HW = (size_t)H * W;
+    const uint2 range = ranges[tile];
+
+    // Per-lane destination of the transposed reduction: channel -> (array, stride)
+    //   0..2 dL_dcolors[g*3+c] | 3..5 dL_dmean2D[g*3+c] | 6,7,8 dL_dconic2D[g*4+{0,1,3}] | 9 dL_dopacity[g] | 10.. dL_dfeature[g*S+c]
+    const int chan = transposed_channel<NVP>(lane);
+    float* dst_base = nullptr;
+    uint32_t dst_stride = 0;
+    if (transposed_owner<NVP>(lane)) {
+        if (chan < 3) { dst_base = dL_dcolors + chan; dst_stride = 3; }
+        else if (chan < 6) { dst_base = dL_dmean2D + (chan - 3); dst_stride = 3; }
+        else if (chan < 9) { dst_base = dL_dconic2D + (chan == 8 ? 3 : chan - 6); dst_stride = 4; }
+        else if (chan == 9) { dst_base = dL_dopacity; dst_stride = 1; }
+        else if (chan - 10 < S) { dst_base = dL_dfeature + (chan - 10); dst_stride = (uint32_t)S; }
+    }
+
+    float T[PPL], bgT[PPL], pyf[PPL];
+    float acc_c[PPL][3], acc_f[PPL][SPAD > 0 ? SPAD : 1], acc_d[PPL], acc_o[PPL];
+    float dLc[PPL][3], dLf[PPL][SPAD > 0 ? SPAD : 1], dLd[PPL], dLo[PPL];
+    uint32_t lastc[PPL];
+    uint32_t my_max = 0;
+#pragma unroll
+    for (int i = 0; i < PPL; i++) {
+        const int py = py0 + 4 * i;
+        const bool inside = px < W && py < H;
+        const size_t pix = (size_t)py * W + px;
+        pyf[i] = (float)py;
+        const float T_final = inside ? final_Ts[pix] : 0.f;
+        T[i] = T_final;
+        lastc[i] = inside ? n_contrib[pix] : 0u;
+        my_max = max(my_max, lastc[i]);
+        float bg_dot = 0.f;
+#pragma unroll
+        for (int ch = 0; ch < 3; ch++) {
+            dLc[i][ch] = inside ? dL_dpixels[ch * HW + pix] : 0.f;
+            bg_dot += bg_color[ch] * dLc[i][ch];
+            acc_c[i][ch] = 0.f;
+        }
+        bgT[i] = -T_final * bg_dot;
+        dLd[i] = inside ? dL_dpixels_d[pix] : 0.f;
+        dLo[i] = inside ? dL_dpixels_o[pix] : 0.f;
+        acc_d[i] = 0.f;
+        acc_o[i] = 0.f;
+#pragma unroll
+        for (int ch = 0; ch < SPAD; ch++) {
+            dLf[i][ch] = (inside && ch < S) ? dL_dpixels_f[(size_t)ch * HW + pix] : 0.f;
+            acc_f[i][ch] = 0.f;
+        }
+    }
+    // block max of last contributor: the walk covers front indices [0, m) back to front
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) my_max = max(my_max, (uint32_t)__shfl_xor((int)my_max, o, 64));
+    if (lane == 0) s_max[wave] = my_max;
+    __syncthreads();
+    uint32_t m = 0;
+#pragma unroll
+    for (int w = 0; w < NW; w++) m = max(m, s_max[w]);
+    const int n = (int)m;
+
+    const float ddelx_dx = 0.5f * W, ddely_dy = 0.5f * H;
+
+    for (int base = 0; base < n; base += NT) {
+        __syncthreads();
+        if (base + tid < n) {
+            const uint32_t g = point_list[range.x + (uint32_t)(n - 1 - (base + tid))];
+            const float2 xy = means2D[g];
+            const float4 co = conic_opacity[g];
+            s_geo0[tid] = make_float4(xy.x, xy.y, co.x, co.y);
+            s_geo1[tid] = make_float4(co.z, co.w, depths[g], __uint_as_float(g));
+            float* pay = s_pay + tid * PAY;
+            pay[0] = colors[3 * g]; pay[1] = colors[3 * g + 1]; pay[2] = colors[3 * g + 2]; pay[3] = 0.f;
+            if constexpr (SPAD > 0) {
+                const float* f = features + (size_t)g * S;
+                if ((S & 3) == 0) {
+#pragma unroll
+                    for (int q = 0; q < SPAD / 4; q++) {
+                        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                        if (4 * q < S) v = *reinterpret_cast<const float4*>(f + 4 * q);
+                        *reinterpret_cast<float4*>(pay + 4 + 4 * q) = v;
+                    }
+                } else {
+#pragma unroll
+                    for (int ch = 0; ch < SPAD; ch++) pay[4 + ch] = ch < S ? f[ch] : 0.f;
+                }
+            }
+        }
+        __syncthreads();
+
+        const int cnt = min(NT, n - base);
+        for (int j = 0; j < cnt; j++) {
+            const uint32_t front = (uint32_t)(n - 1 - (base + j));    // 0-based index from the front of the tile list
+            const float4 g0 = s_geo0[j];
+            const float4 g1 = s_geo1[j];
+            const float dx = g0.x - pxf;
+            float alpha[PPL], G[PPL], dy[PPL];
+            bool hit[PPL];
+            bool any_lane = false;
+#pragma unroll
+            for (int i = 0; i < PPL; i++) {
+                hit[i] = false;
+                alpha[i] = 0.f; G[i] = 0.f;
+                dy[i] = g0.y - pyf[i];
+                if (front < lastc[i]) {     // reference: skip while contributor >= last_contributor
+                    const float power = -0.5f * (g0.z * dx * dx + g1.x * dy[i] * dy[i]) - g0.w * dx * dy[i];
+                    if (!(power > 0.0f)) {
+                        G[i] = fast_exp_b(power);
+                        alpha[i] = fminf(0.99f, g1.y * G[i]);
+                        hit[i] = alpha[i] >= 1.0f / 255.0f;
+                    }
+                }
+                any_lane = any_lane || hit[i];
+            }
+            if (__ballot(any_lane) == 0ull) continue;
+
+            const float* pay = s_pay + j * PAY;
+            const float4 c4 = *reinterpret_cast<const float4*>(pay);
+            const float col[3] = {c4.x, c4.y, c4.z};
+            float v[NVP];
+#pragma unroll
+            for (int k = 0; k < NVP; k++) v[k] = 0.f;
+
+#pragma unroll
+            for (int i = 0; i < PPL; i++) {
+                if (PPL > 1 && __ballot(hit[i]) == 0ull) continue;
+                if (hit[i]) {
+                    const float one_m_a = 1.f - alpha[i];
+                    const float rcp = __builtin_amdgcn_rcpf(one_m_a);
+                    T[i] = T[i] * rcp;
+                    const float wgt = alpha[i] * T[i];
+                    float dL_dalpha = 0.f;
+#pragma unroll
+                    for (int ch = 0; ch < 3; ch++) {
+                        dL_dalpha += (col[ch] - acc_c[i][ch]) * dLc[i][ch];
+                        acc_c[i][ch] = alpha[i] * col[ch] + one_m_a * acc_c[i][ch];
+                        v[ch] += wgt * dLc[i][ch];
+                    }
+#pragma unroll
+                    for (int q = 0; q < SPAD / 4; q++) {
+                        const float4 f4 = *reinterpret_cast<const float4*>(pay + 4 + 4 * q);
+                        const float fv[4] = {f4.x, f4.y, f4.z, f4.w};
+#pragma unroll
+                        for (int e = 0; e < 4; e++) {
+                            const int ch = 4 * q + e;
+                            if (backward_geometry) dL_dalpha += (fv[e] - acc_f[i][ch]) * dLf[i][ch];
+                            acc_f[i][ch] = alpha[i] * fv[e] + one_m_a * acc_f[i][ch];
+                            v[10 + ch] += wgt * dLf[i][ch];
+                        }
+                    }
+                    dL_dalpha += (g1.z - acc_d[i]) * dLd[i];
+                    acc_d[i] = alpha[i] * g1.z + one_m_a * acc_d[i];
+                    dL_dalpha += (1.0f - acc_o[i]) * dLo[i];
+                    acc_o[i] = alpha[i] + one_m_a * acc_o[i];
+                    dL_dalpha *= T[i];
+                    dL_dalpha += bgT[i] * rcp;
+
+                    const float dL_dG = g1.y * dL_dalpha;
+                    const float gdx = G[i] * dx, gdy = G[i] * dy[i];
+                    const float dG_ddelx = -gdx * g0.z - gdy * g0.w;
+                    const float dG_ddely = -gdy * g1.x - gdx * g0.w;
+                    v[3] += dL_dG * dG_ddelx * ddelx_dx;
+                    v[4] += dL_dG * dG_ddely * ddely_dy;
+                    v[5] += dLd[i] * wgt;
+                    v[6] += -0.5f * gdx * dx * dL_dG;
+                    v[7] += -0.5f * gdx * dy[i] * dL_dG;
+                    v[8] += -0.5f * gdy * dy[i] * dL_dG;
+                    v[9] += G[i] * dL_dalpha;
+                }
+            }
+            const float total = transpose_reduce<NVP, DPP>(v);
+            if (dst_base != nullptr) atomicAdd(dst_base + (size_t)__float_as_uint(g1.w) * dst_stride, total);
+        }
+    }
+}
+
+int g_bwd_ppl = 2;
+int g_bwd_dpp = 1;   // 1: DPP/permlane-swap transposing reduction, 0: portable __shfl_xor version
+
+template <int SPAD, int PPL>
+static void launch_bwd_inst(hipStream_t s, int T, int tiles_x, const uint32_t* ranges, const uint32_t* point_list,
+                            int S, int W, int H, const float* bg, const float* means2D, const float* depths,
+                            const float* conic_opacity, const float* colors, const float* features,
+                            const float* final_Ts, const uint32_t* n_contrib, const float* dL_dpix,
+                            const float* dL_dpix_o, const float* dL_dpix_d, const float* dL_dpix_f, float* dL_dmean2D,
+                            float* dL_dconic, float* dL_dopacity, float* dL_dcolor, float* dL_dfeature, int bg_geom)
+{
+    const int chunk = (T + 7) / 8;
+    if (g_bwd_dpp)
+        render_backward_kernel<SPAD, PPL, true><<<chunk * 8, 256 / PPL, 0, s>>>(
+            (const uint2*)ranges, point_list, S, W, H, tiles_x, T, chunk, bg, (const float2*)means2D, depths,
+            (const float4*)conic_opacity, colors, features, final_Ts, n_contrib, dL_dpix, dL_dpix_o, dL_dpix_d,
+            dL_dpix_f, dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolor, dL_dfeature, bg_geom);
+    else
+        render_backward_kernel<SPAD, PPL, false><<<chunk * 8, 256 / PPL, 0, s>>>(
+            (const uint2*)ranges, point_list, S, W, H, tiles_x, T, chunk, bg, (const float2*)means2D, depths,
+            (const float4*)conic_opacity, colors, features, final_Ts, n_contrib, dL_dpix, dL_dpix_o, dL_dpix_d,
+            dL_dpix_f, dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolor, dL_dfeature, bg_geom);
+}
+
+void launch_render_backward(hipStream_t s, int W, int H, int S, const uint32_t* ranges, const uint32_t* point_list,
+                            const float* bg, const float* means2D, const float* depths, const float* conic_opacity,
+                            const float* colors, const float* features, const float* final_Ts,
+                            const uint32_t* n_contrib, const float* dL_dpix, const float* dL_dpix_o,
+                            const float* dL_dpix_d, const float* dL_dpix_f, float* dL_dmean2D, float* dL_dconic,
+                            float* dL_dopacity, float* dL_dcolor, float* dL_dfeature, int bg_geom)
+{
+    const int tiles_x = (W + R3DG_TILE_X - 1) / R3DG_TILE_X, tiles_y = (H + R3DG_TILE_Y - 1) / R3DG_TILE_Y;
+    const int T = tiles_x * tiles_y;
+#define R3DG_BWD_ARGS s, T, tiles_x, ranges, point_list, S, W, H, bg, means2D, depths, conic_opacity, colors, features, \
+                      final_Ts, n_contrib, dL_dpix, dL_dpix_o, dL_dpix_d, dL_dpix_f, dL_dmean2D, dL_dconic, dL_dopacity, \
+                      dL_dcolor, dL_dfeature, bg_geom
+#define R3DG_BWD_CASE(SP)                                                       \
+    if (g_bwd_ppl >= 2 && (SP) <= 20) launch_bwd_inst<SP, 2>(R3DG_BWD_ARGS);    \
+    else launch_bwd_inst<SP, 1>(R3DG_BWD_ARGS);                                 \
+    break;
+    switch ((S + 3) / 4) {
+        case 0: R3DG_BWD_CASE(0)
+        case 1: R3DG_BWD_CASE(4)
+        case 2: R3DG_BWD_CASE(8)
+        case 3: R3DG_BWD_CASE(12)
+        case 4: R3DG_BWD_CASE(16)
+        case 5: R3DG_BWD_CASE(20)
+        case 6: R3DG_BWD_CASE(24)
+        case 7: R3DG_BWD_CASE(28)
+        case 8: R3DG_BWD_CASE(32)
+        default: R3DG_BWD_CASE(36)
+    }
+#undef R3DG_BWD_CASE
+#undef R3DG_BWD_ARGS
+}
+
+}  // namespace r3dg

@@ -1,0 +1,298 @@
+// Per-tile alpha compositing forward (K8) + surface-xyz / pseudo-normal (K9, K10) for gfx950.
+// Reference semantics: renderCUDA forward.cu:263-395, renderSurfaceXYZCUDA :398-425, renderPseudoNormalCUDA :427-491.
+//
+// CDNA4 formulation (not the reference's 256-thread / 1-pixel-per-thread CUDA block):
+//   * one 16x16 tile = 256/PPL threads; each lane owns PPL pixels ("slots") in the same column, 4 rows apart
+//     inside its wave's 4*PPL-row band, so per-Gaussian LDS reads and the dx terms are shared by PPL pixels and
+//     a wave-uniform branch skips whole 4x16 sub-bands the Gaussian does not touch;
+//   * each round the block stages 256/PPL sorted Gaussians in LDS -- geometry (xy, conic, opacity, depth, id)
+//     AND the blend payload (rgb + S features, zero-padded to SPAD) -- with one gather per thread, so the inner
+//     loop never touches global memory (the reference re-reads colours/features/depths per pixel, forward.cu:364-370);
+//     inner-loop LDS reads are wave-uniform (broadcast) ds_read_b128;
+//   * S is a template parameter rounded up to a multiple of 4 (SPAD): accumulators live in VGPRs, loops unroll;
+//   * per-Gaussian `weights` are summed over the wave (64 lanes x PPL pixels) before ONE atomic per wave
+//     (the reference issues one atomic per contributing pixel, forward.cu:374);
+//   * early-out: a wave stops walking the batch when all its pixels are done (64-bit ballot); the block stops
+//     fetching when all waves are done (__syncthreads_and).
+#include "common.hpp"
+
+namespace r3dg {
+
+__device__ __forceinline__ float fast_exp(float x)
+{
+    // v_exp_f32 is 2^x: exp(x) = 2^(x*log2(e)); |x| < ~6 wherever the result matters (alpha >= 1/255)
+    return __builtin_amdgcn_exp2f(x * 1.4426950408889634f);
+}
+
+template <int SPAD, int PPL>
+__global__ void __launch_bounds__(256 / PPL)
+render_forward_kernel(const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list, int S, int W, int H,
+                      int tiles_x, int num_tiles, int xcd_chunk, const float2* __restrict__ means2D,
+                      const float* __restrict__ depths, const float* __restrict__ features,
+                      const float* __restrict__ colors, const float4* __restrict__ conic_opacity,
+                      float* __restrict__ final_T, uint32_t* __restrict__ n_contrib, const float* __restrict__ bg_color,
+                      float* __restrict__ out_color, float* __restrict__ out_opacity, float* __restrict__ out_depth,
+                      float* __restrict__ out_feature, float* __restrict__ out_weights)
+{
+    constexpr int NT = 256 / PPL;       // threads per block == Gaussians staged per round
+    constexpr int PAY = 4 + SPAD;       // payload floats per Gaussian: r,g,b,(pad), features[SPAD]
+
+    // XCD-aware tile order: hardware places block b on XCD b%8, so give each XCD a contiguous run of tiles
+    // (neighbouring tiles share Gaussians -> shared lines stay in one XCD's L2).
+    const int tile = (int)(blockIdx.x & 7u) * xcd_chunk + (int)(blockIdx.x >> 3);
+    if (tile >= num_tiles) return;
+    const int tile_x = tile % tiles_x, tile_y = tile / tiles_x;
+
+    __shared__ float4 s_geo0[NT];                 // mean.x, mean.y, conic.x, conic.y
+    __shared__ float4 s_geo1[NT];                 // conic.z, opacity, depth, id bits
+    __shared__ __attribute__((aligned(16))) float s_pay[NT * PAY];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int px = tile_x * R3DG_TILE_X + (lane & 15);
+    const int py0 = tile_y * R3DG_TILE_Y + wave * (4 * PPL) + (lane >> 4);
+    const float pxf = (float)px;
+
+    const uint2 range = ranges[tile];
+    const int n = (int)(range.y - range.x);
+
+    float T[PPL], C[PPL][3], F[PPL][SPAD > 0 ? SPAD : 1], Dp[PPL], Op[PPL], pyf[PPL];
+    uint32_t last[PPL];
+    bool done[PPL], inside[PPL];
+#pragma unroll
+    for (int i = 0; i < PPL; i++) {
+        const int py = py0 + 4 * i;
+        inside[i] = px < W && py < H;
+        done[i] = !inside[i];
+        pyf[i] = (float)py;
+        T[i] = 1.0f; Dp[i] = 0.f; Op[i] = 0.f; last[i] = 0;
+        C[i][0] = C[i][1] = C[i][2] = 0.f;
+#pragma unroll
+        for (int ch = 0; ch < SPAD; ch++) F[i][ch] = 0.f;
+    }
+
+    for (int base = 0; base < n; base += NT) {
+        bool all_done = true;
+#pragma unroll
+        for (int i = 0; i < PPL; i++) all_done = all_done && done[i];
+        // barrier (protects the staging buffers of the previous round) + block-wide vote
+        if (__syncthreads_and(all_done)) break;
+
+        // ---- stage one Gaussian per thread ----
+        if (base + tid < n) {
+            const uint32_t g = point_list[range.x + base + tid];
+            const float2 xy = means2D[g];
+            const float4 co = conic_opacity[g];
+            s_geo0[tid] = make_float4(xy.x, xy.y, co.x, co.y);
+            s_geo1[tid] = make_float4(co.z, co.w, depths[g], __uint_as_float(g));
+            float* pay = s_pay + tid * PAY;
+            pay[0] = colors[3 * g]; pay[1] = colors[3 * g + 1]; pay[2] = colors[3 * g + 2]; pay[3] = 0.f;
+            if constexpr (SPAD > 0) {
+                const float* f = features + (size_t)g * S;
+                if ((S & 3) == 0) {
+#pragma unroll
+                    for (int q = 0; q < SPAD / 4; q++) {
+                        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                        if (4 * q < S) v = *reinterpret_cast<const float4*>(f + 4 * q);
+                        *reinterpret_cast<float4*>(pay + 4 + 4 * q) = v;
+                    }
+                } else {
+#pragma unroll
+                    for (int ch = 0; ch < SPAD; ch++) pay[4 + ch] = ch < S ? f[ch] : 0.f;
+                }
+            }
+        }
+        __syncthreads();
+
+        const int cnt = min(NT, n - base);
+        for (int j = 0; j < cnt; j++) {
+            bool active = false;
+#pragma unroll
+            for (int i = 0; i < PPL; i++) active = active || !done[i];
+            if (__ballot(active) == 0ull) break;           // this wave's pixels are all finished
+
+            const float4 g0 = s_geo0[j];
+            const float4 g1 = s_geo1[j];
+            const float dx = g0.x - pxf;
+            float w[PPL];
+            bool any_lane = false;
+#pragma unroll
+            for (int i = 0; i < PPL; i++) {
+                w[i] = 0.f;
+                if (!done[i]) {
+                    const float dy = g0.y - pyf[i];
+                    const float power = -0.5f * (g0.z * dx * dx + g1.x * dy * dy) - g0.w * dx * dy;
+                    if (!(power > 0.0f)) {
+                        const float alpha = fminf(0.99f, g1.y * fast_exp(power));
+                        if (alpha >= 1.0f / 255.0f) {
+                            const float test_T = T[i] * (1.f - alpha);
+                            if (test_T < 0.0001f) {
+                                done[i] = true;
+                            } else {
+                                w[i] = alpha * T[i];
+                                T[i] = test_T;
+                                last[i] = (uint32_t)(base + j + 1);
+                                any_lane = true;
+                            }
+                        }
+                    }
+                }
+            }
+            if (__ballot(any_lane) == 0ull) continue;       // nobody in this wave blends this Gaussian
+
+            const float* pay = s_pay + j * PAY;
+            const float4 c4 = *reinterpret_cast<const float4*>(pay);
+            float wsum = 0.f;
+#pragma unroll
+            for (int i = 0; i < PPL; i++) {
+                if (PPL > 1 && __ballot(w[i] != 0.f) == 0ull) continue;   // this 4x16 sub-band is untouched
+                C[i][0] += c4.x * w[i];
+                C[i][1] += c4.y * w[i];
+                C[i][2] += c4.z * w[i];
+                Dp[i] += g1.z * w[i];
+                Op[i] += w[i];
+                wsum += w[i];
+#pragma unroll
+                for (int q = 0; q < SPAD / 4; q++) {
+                    const float4 f4 = *reinterpret_cast<const float4*>(pay + 4 + 4 * q);
+                    F[i][4 * q + 0] += f4.x * w[i];
+                    F[i][4 * q + 1] += f4.y * w[i];
+                    F[i][4 * q + 2] += f4.z * w[i];
+                    F[i][4 * q + 3] += f4.w * w[i];
+                }
+            }
+            wsum = wave_sum(wsum);
+            if (lane == 0) atomicAdd(&out_weights[__float_as_uint(g1.w)], wsum);
+        }
+    }
+
+    const size_t HW = (size_t)H * W;
+#pragma unroll
+    for (int i = 0; i < PPL; i++) {
+        if (inside[i]) {
+            const size_t pix = (size_t)(py0 + 4 * i) * W + px;
+            final_T[pix] = T[i];
+            n_contrib[pix] = last[i];
+            out_color[pix] = C[i][0] + T[i] * bg_color[0];
+            out_color[HW + pix] = C[i][1] + T[i] * bg_color[1];
+            out_color[2 * HW + pix] = C[i][2] + T[i] * bg_color[2];
+#pragma unroll
+            for (int ch = 0; ch < SPAD; ch++)
+                if (ch < S) out_feature[(size_t)ch * HW + pix] = F[i][ch];
+            out_depth[pix] = Dp[i];
+            out_opacity[pix] = Op[i];
+        }
+    }
+}
+
+// K9: surface point in camera space from the premultiplied depth / opacity buffers (forward.cu:398-425)
+__global__ void __launch_bounds__(256)
+surface_xyz_kernel(int W, int H, float focal_x, float focal_y, float cx, float cy, const float* __restrict__ opacities,
+                   const float* __restrict__ depths, float* __restrict__ surface_xyz)
+{
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= W || y >= H) return;
+    const size_t HW = (size_t)H * W, id = (size_t)y * W + x;
+    const float depth = depths[id] / fmaxf(opacities[id], 0.0000001f);
+    surface_xyz[id] = (x - cx) / focal_x * depth;
+    surface_xyz[HW + id] = (y - cy) / focal_y * depth;
+    surface_xyz[2 * HW + id] = depth;
+}
+
+// K10: pseudo normal from a 3x3 edge-clamped stencil on surface_xyz (forward.cu:427-491); needs K9 complete.
+__global__ void __launch_bounds__(256)
+pseudo_normal_kernel(int W, int H, const float* __restrict__ vm, float* __restrict__ normals,
+                     const float* __restrict__ surface_xyz)
+{
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= W || y >= H) return;
+    const size_t HW = (size_t)H * W;
+    const int ym = y == 0 ? 0 : y - 1, yp = y == H - 1 ? H - 1 : y + 1;
+    const int xm = x == 0 ? 0 : x - 1, xp = x == W - 1 ? W - 1 : x + 1;
+    const size_t i00 = (size_t)W * ym + xm, i01 = (size_t)W * ym + x, i02 = (size_t)W * ym + xp;
+    const size_t i10 = (size_t)W * y + xm, i11 = (size_t)W * y + x, i12 = (size_t)W * y + xp;
+    const size_t i20 = (size_t)W * yp + xm, i21 = (size_t)W * yp + x, i22 = (size_t)W * yp + xp;
+    float ga[3], gb[3];
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+        const float* s = surface_xyz + i * HW;
+        ga[i] = -0.125f * s[i00] + 0.125f * s[i02] - 0.25f * s[i10] + 0.25f * s[i12] - 0.125f * s[i20] + 0.125f * s[i22];
+        gb[i] = -0.125f * s[i00] - 0.25f * s[i01] - 0.125f * s[i02] + 0.125f * s[i20] + 0.25f * s[i21] + 0.125f * s[i22];
+    }
+    float nx = ga[1] * gb[2] - ga[2] * gb[1];
+    float ny = -ga[0] * gb[2] + ga[2] * gb[0];
+    float nz = ga[0] * gb[1] - ga[1] * gb[0];
+    const float norm = sqrtf(nx * nx + ny * ny + nz * nz);
+    if (norm <= 0.0f) return;      // leave the pre-zeroed output
+    nx = -nx / norm; ny = -ny / norm; nz = -nz / norm;
+    normals[i11] = vm[0] * nx + vm[1] * ny + vm[2] * nz;
+    normals[HW + i11] = vm[4] * nx + vm[5] * ny + vm[6] * nz;
+    normals[2 * HW + i11] = vm[8] * nx + vm[9] * ny + vm[10] * nz;
+}
+
+// ---- launchers ------------------------------------------------------------------------------------------
+int g_fwd_ppl = 2;   // pixels per lane; tunable through r3dg_set_tuning()
+
+template <int SPAD, int PPL>
+static void launch_fwd_inst(hipStream_t s, int T, int tiles_x, const uint32_t* ranges, const uint32_t* point_list,
+                            int S, int W, int H, const float* means2D, const float* depths, const float* features,
+                            const float* colors, const float* conic_opacity, float* final_T, uint32_t* n_contrib,
+                            const float* bg, float* out_color, float* out_opacity, float* out_depth,
+                            float* out_feature, float* out_weights)
+{
+    const int chunk = (T + 7) / 8;
+    render_forward_kernel<SPAD, PPL><<<chunk * 8, 256 / PPL, 0, s>>>(
+        (const uint2*)ranges, point_list, S, W, H, tiles_x, T, chunk, (const float2*)means2D, depths, features, colors,
+        (const float4*)conic_opacity, final_T, n_contrib, bg, out_color, out_opacity, out_depth, out_feature,
+        out_weights);
+}
+
+template <int SPAD>
+static void launch_fwd_ppl(int ppl, hipStream_t s, int T, int tiles_x, const uint32_t* ranges,
+                           const uint32_t* point_list, int S, int W, int H, const float* means2D, const float* depths,
+                           const float* features, const float* colors, const float* conic_opacity, float* final_T,
+                           uint32_t* n_contrib, const float* bg, float* out_color, float* out_opacity,
+                           float* out_depth, float* out_feature, float* out_weights)
+{
+#define R3DG_FWD_ARGS s, T, tiles_x, ranges, point_list, S, W, H, means2D, depths, features, colors, conic_opacity, \
+                      final_T, n_contrib, bg, out_color, out_opacity, out_depth, out_feature, out_weights
+    if (ppl >= 4 && SPAD <= 20) launch_fwd_inst<SPAD, 4>(R3DG_FWD_ARGS);
+    else if (ppl >= 2) launch_fwd_inst<SPAD, 2>(R3DG_FWD_ARGS);
+    else launch_fwd_inst<SPAD, 1>(R3DG_FWD_ARGS);
+}
+
+void launch_render_forward(hipStream_t s, int W, int H, int S, const uint32_t* ranges, const uint32_t* point_list,
+                           const float* means2D, const float* depths, const float* features, const float* colors,
+                           const float* conic_opacity, float* final_T, uint32_t* n_contrib, const float* bg,
+                           float* out_color, float* out_opacity, float* out_depth, float* out_feature,
+                           float* out_weights)
+{
+    const int tiles_x = (W + R3DG_TILE_X - 1) / R3DG_TILE_X, tiles_y = (H + R3DG_TILE_Y - 1) / R3DG_TILE_Y;
+    const int T = tiles_x * tiles_y;
+    const int ppl = g_fwd_ppl;
+    switch ((S + 3) / 4) {
+        case 0: launch_fwd_ppl<0>(ppl, R3DG_FWD_ARGS); break;
+        case 1: launch_fwd_ppl<4>(ppl, R3DG_FWD_ARGS); break;
+        case 2: launch_fwd_ppl<8>(ppl, R3DG_FWD_ARGS); break;
+        case 3: launch_fwd_ppl<12>(ppl, R3DG_FWD_ARGS); break;
+        case 4: launch_fwd_ppl<16>(ppl, R3DG_FWD_ARGS); break;
+        case 5: launch_fwd_ppl<20>(ppl, R3DG_FWD_ARGS); break;
+        case 6: launch_fwd_ppl<24>(ppl, R3DG_FWD_ARGS); break;
+        case 7: launch_fwd_ppl<28>(ppl, R3DG_FWD_ARGS); break;
+        case 8: launch_fwd_ppl<32>(ppl, R3DG_FWD_ARGS); break;
+        default: launch_fwd_ppl<36>(ppl, R3DG_FWD_ARGS); break;
+    }
+#undef R3DG_FWD_ARGS
+}
+
+void launch_pseudo_normal(hipStream_t s, int W, int H, const float* vm, float focal_x, float focal_y, float cx,
+                          float cy, const float* opacities, const float* depths, float* normals, float* surface_xyz,
+                          bool debug)
+{
+    dim3 grid((W + 63) / 64, (H + 3) / 4);
+    surface_xyz_kernel<<<grid, 256, 0, s>>>(W, H, focal_x, focal_y, cx, cy, opacities, depths, surface_xyz);
+    check_launch(s, debug, "surface_xyz_kernel");
+    pseudo_normal_kernel<<<grid, 256, 0, s>>>(W, H, vm, normals, surface_xyz);
+    check_launch(s, debug, "pseudo_normal_kernel");
+}
+
+}  // namespace r3dg

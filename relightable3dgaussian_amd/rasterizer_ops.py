@@ -1,0 +1,191 @@
+"""Host-side mirror of the reference's `r3dg_rasterization._C` pybind module (r3dg-rasterization/ext.cpp:15-19):
+same function names, argument order, return tuples and error behaviour (RuntimeError), implemented over the
+C ABI in libr3dg_hip.so.  PyTorch is used only for device memory and the current HIP stream.
+
+    rasterize_gaussians(...)          -> 13-tuple   (rasterize_points.h:18-42, rasterize_points.cu:36-141)
+    rasterize_gaussians_backward(...) -> 9-tuple    (rasterize_points.h:44-71, rasterize_points.cu:143-235)
+    mark_visible(means3D, viewmatrix, projmatrix) -> bool[P]   (rasterize_points.h:73-76)
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib
+
+NUM_CHANNELS = 3
+
+
+def _f32c(t):
+    """contiguous fp32 view on the device (the reference calls .contiguous().data_ptr<float>() on everything)."""
+    if t is None or t.numel() == 0:
+        return None
+    if t.dtype != torch.float32:
+        raise RuntimeError("expected a float32 tensor, got %s" % t.dtype)
+    if not t.is_cuda:
+        raise RuntimeError("expected a CUDA(HIP) tensor")
+    return t.contiguous()
+
+
+class _Resizer:
+    """The reference's resizeFunctional (rasterize_points.cu:28-34): three byte buffers grown on request."""
+
+    def __init__(self, device):
+        self.device = device
+        self.buffers = [torch.empty(0, dtype=torch.uint8, device=device) for _ in range(3)]
+        self.callbacks = [_lib.ALLOC_FN(self._make(i)) for i in range(3)]
+
+    def _make(self, i):
+        def cb(_user, nbytes):
+            try:
+                self.buffers[i] = torch.empty(int(nbytes), dtype=torch.uint8, device=self.device)
+                return self.buffers[i].data_ptr()
+            except Exception:          # surfaces as R3DG_EALLOC -> RuntimeError
+                return 0
+        return cb
+
+
+def _offsets(fn, n, *args):
+    arr = (C.c_size_t * n)()
+    fn(*args, arr)
+    return list(arr)
+
+
+def rasterize_gaussians(background, means3D, features, colors, opacity, scales, rotations, scale_modifier,
+                        cov3D_precomp, viewmatrix, projmatrix, tan_fovx, tan_fovy, cx, cy, image_height, image_width,
+                        sh, degree, campos, prefiltered, computer_pseudo_normal, debug):
+    L = _lib.lib()
+    if means3D.ndimension() != 2 or means3D.size(1) != 3:
+        raise RuntimeError("means3D must have dimensions (num_points, 3)")
+    if not means3D.is_cuda:
+        raise RuntimeError("means3D must be a CUDA(HIP) tensor")
+    P = means3D.size(0)
+    S = features.size(1)
+    H, W = int(image_height), int(image_width)
+    dev = means3D.device
+    fopt = dict(dtype=torch.float32, device=dev)
+
+    out_color = torch.zeros((NUM_CHANNELS, H, W), **fopt)
+    out_opacity = torch.zeros((1, H, W), **fopt)
+    out_depth = torch.zeros((1, H, W), **fopt)
+    out_feature = torch.zeros((S, H, W), **fopt)
+    out_normal = torch.zeros((3, H, W), **fopt)
+    out_surface_xyz = torch.zeros((3, H, W), **fopt)
+    out_weights = torch.zeros((P, 1), **fopt)
+    radii = torch.zeros((P,), dtype=torch.int32, device=dev)
+
+    rs = _Resizer(dev)
+    rendered = C.c_int(0)
+    if P != 0:
+        M = sh.size(1) if sh.size(0) != 0 else 0
+        t = [_f32c(x) for x in (background, means3D, sh, colors, features, opacity, scales, rotations, cov3D_precomp,
+                                viewmatrix, projmatrix, campos)]
+        bg_, means_, sh_, col_, feat_, op_, sc_, rot_, cov_, vm_, pm_, cam_ = t
+        with torch.cuda.device(dev):
+            st = L.r3dg_rasterize_forward(
+                _lib.current_stream(), rs.callbacks[0], rs.callbacks[1], rs.callbacks[2], None, P, S, int(degree), M,
+                _lib.ptr(bg_), W, H, _lib.ptr(means_), _lib.ptr(sh_), _lib.ptr(col_), _lib.ptr(feat_), _lib.ptr(op_),
+                _lib.ptr(sc_), float(scale_modifier), _lib.ptr(rot_), _lib.ptr(cov_), _lib.ptr(vm_), _lib.ptr(pm_),
+                _lib.ptr(cam_), float(tan_fovx), float(tan_fovy), float(cx), float(cy), int(bool(prefiltered)),
+                int(bool(computer_pseudo_normal)), out_color.data_ptr(), out_opacity.data_ptr(), out_depth.data_ptr(),
+                _lib.ptr(out_feature), out_normal.data_ptr(), out_surface_xyz.data_ptr(), out_weights.data_ptr(),
+                radii.data_ptr(), int(bool(debug)), C.byref(rendered))
+        _lib.check(st, "rasterize_gaussians")
+    geomBuffer, binningBuffer, imgBuffer = rs.buffers
+    if imgBuffer.numel() == 0:
+        imgBuffer = torch.zeros(int(L.r3dg_image_state_bytes(W, H)), dtype=torch.uint8, device=dev)
+    # n_contrib: int32 view into the image state (the reference returns a from_blob view, rasterize_points.cu:136-139)
+    off = _offsets(L.r3dg_image_state_offsets, 3, W, H)
+    n_contrib = imgBuffer[off[1]:off[1] + 4 * H * W].view(torch.int32).view(H, W)
+    return (rendered.value, n_contrib, out_color, out_opacity, out_depth, out_feature, out_normal, out_surface_xyz,
+            out_weights, radii, geomBuffer, binningBuffer, imgBuffer)
+
+
+def rasterize_gaussians_backward(background, means3D, features, radii, colors, scales, rotations, scale_modifier,
+                                 cov3D_precomp, viewmatrix, projmatrix, tan_fovx, tan_fovy, dL_dout_color,
+                                 dL_dout_opacity, dL_dout_depth, dL_dout_feature, sh, degree, campos, geomBuffer, R,
+                                 binningBuffer, imageBuffer, backward_geometry, debug):
+    L = _lib.lib()
+    P = means3D.size(0)
+    S = features.size(1)
+    H = dL_dout_color.size(1)
+    W = dL_dout_color.size(2)
+    M = sh.size(1) if sh.size(0) != 0 else 0
+    dev = means3D.device
+    fopt = dict(dtype=torch.float32, device=dev)
+
+    dL_dmeans3D = torch.zeros((P, 3), **fopt)
+    dL_dmeans2D = torch.zeros((P, 3), **fopt)
+    dL_dfeatures = torch.zeros((P, S), **fopt)
+    dL_dcolors = torch.zeros((P, NUM_CHANNELS), **fopt)
+    dL_dconic = torch.zeros((P, 2, 2), **fopt)
+    dL_dopacity = torch.zeros((P, 1), **fopt)
+    dL_dcov3D = torch.zeros((P, 6), **fopt)
+    dL_dsh = torch.zeros((P, M, 3), **fopt)
+    dL_dscales = torch.zeros((P, 3), **fopt)
+    dL_drotations = torch.zeros((P, 4), **fopt)
+
+    if P != 0:
+        t = [_f32c(x) for x in (background, means3D, sh, features, colors, scales, rotations, cov3D_precomp, viewmatrix,
+                                projmatrix, campos, dL_dout_color, dL_dout_opacity, dL_dout_depth, dL_dout_feature)]
+        bg_, means_, sh_, feat_, col_, sc_, rot_, cov_, vm_, pm_, cam_, gC, gO, gD, gF = t
+        radii_ = radii.contiguous()
+        with torch.cuda.device(dev):
+            st = L.r3dg_rasterize_backward(
+                _lib.current_stream(), P, S, int(degree), M, int(R), _lib.ptr(bg_), W, H, _lib.ptr(means_),
+                _lib.ptr(sh_), _lib.ptr(feat_), _lib.ptr(col_), _lib.ptr(sc_), float(scale_modifier), _lib.ptr(rot_),
+                _lib.ptr(cov_), _lib.ptr(vm_), _lib.ptr(pm_), _lib.ptr(cam_), float(tan_fovx), float(tan_fovy),
+                radii_.data_ptr(), _lib.ptr(geomBuffer), _lib.ptr(binningBuffer), _lib.ptr(imageBuffer), _lib.ptr(gC),
+                _lib.ptr(gO), _lib.ptr(gD), _lib.ptr(gF), dL_dmeans2D.data_ptr(), dL_dconic.data_ptr(),
+                dL_dopacity.data_ptr(), dL_dcolors.data_ptr(), _lib.ptr(dL_dfeatures), dL_dmeans3D.data_ptr(),
+                dL_dcov3D.data_ptr(), _lib.ptr(dL_dsh), dL_dscales.data_ptr(), dL_drotations.data_ptr(),
+                int(bool(backward_geometry)), int(bool(debug)))
+        _lib.check(st, "rasterize_gaussians_backward")
+    return (dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dmeans3D, dL_dfeatures, dL_dcov3D, dL_dsh, dL_dscales,
+            dL_drotations)
+
+
+def mark_visible(means3D, viewmatrix, projmatrix):
+    L = _lib.lib()
+    P = means3D.size(0)
+    present = torch.zeros((P,), dtype=torch.bool, device=means3D.device)
+    if P != 0:
+        m, v, p = _f32c(means3D), _f32c(viewmatrix), _f32c(projmatrix)
+        with torch.cuda.device(means3D.device):
+            st = L.r3dg_mark_visible(_lib.current_stream(), P, m.data_ptr(), v.data_ptr(), p.data_ptr(),
+                                     present.data_ptr())
+        _lib.check(st, "mark_visible")
+    return present
+
+
+# ---- helpers for tests / debugging: decode the opaque state buffers ---------------------------------------
+def decode_state(geomBuffer, binningBuffer, imgBuffer, P, R, H, W):
+    L = _lib.lib()
+    T = ((W + 15) // 16) * ((H + 15) // 16)
+    g = _offsets(L.r3dg_geometry_state_offsets, 9, P)
+    i = _offsets(L.r3dg_image_state_offsets, 3, W, H)
+    b = _offsets(L.r3dg_binning_state_offsets, 4, R)
+
+    def view(buf, off, count, dtype, shape):
+        nb = count * torch.empty((), dtype=dtype).element_size()
+        return buf[off:off + nb].view(dtype).view(*shape)
+    out = dict(
+        depths=view(geomBuffer, g[0], P, torch.float32, (P,)),
+        clamped=view(geomBuffer, g[1], 3 * P, torch.uint8, (P, 3)),
+        means2D=view(geomBuffer, g[3], 2 * P, torch.float32, (P, 2)),
+        cov3D=view(geomBuffer, g[4], 6 * P, torch.float32, (P, 6)),
+        conic_opacity=view(geomBuffer, g[5], 4 * P, torch.float32, (P, 4)),
+        rgb=view(geomBuffer, g[6], 3 * P, torch.float32, (P, 3)),
+        tiles_touched=view(geomBuffer, g[7], P, torch.int32, (P,)),
+        point_offsets=view(geomBuffer, g[8], P, torch.int32, (P,)),
+        final_T=view(imgBuffer, i[0], H * W, torch.float32, (H, W)),
+        n_contrib=view(imgBuffer, i[1], H * W, torch.int32, (H, W)),
+        ranges=view(imgBuffer, i[2], 2 * T, torch.int32, (T, 2)),
+    )
+    if R > 0:
+        out.update(
+            keys_unsorted=view(binningBuffer, b[0], R, torch.int64, (R,)),
+            keys=view(binningBuffer, b[1], R, torch.int64, (R,)),
+            vals_unsorted=view(binningBuffer, b[2], R, torch.int32, (R,)),
+            point_list=view(binningBuffer, b[3], R, torch.int32, (R,)),
+        )
+    return out

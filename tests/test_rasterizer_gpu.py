@@ -1,0 +1,307 @@
+"""GPU parity: HIP rasterizer (through the C ABI / `r3dg_rasterization._C`) vs the CPU oracle.
+
+Tolerances (stated per buffer):
+  * integer work -- radii, tiles_touched, point_offsets, sorted keys, point_list, ranges, num_rendered: BIT-EXACT
+  * n_contrib: exact except pixels whose oracle threshold margin is < 1e-4 (a decision that depends on the
+    last ulps of exp(); the oracle reports the margin per pixel)
+  * forward float buffers: |err| <= 1e-5 + 2e-5*max|ref|;  weights (float atomics): 1e-4 relative
+  * gradients (float atomics vs double-accumulated oracle): |err| <= 1e-6 + 2e-3*max|ref|
+"""
+import numpy as np
+import pytest
+import torch
+
+from tests.helpers import fwd_args, make_case, report, to_np
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda"
+
+
+def _run_forward(case, debug=False):
+    from r3dg_rasterization import _C
+    return _C.rasterize_gaussians(*fwd_args(case, DEV, debug))
+
+
+def _oracle_forward(case):
+    from oracle import rasterizer as orc
+    return orc.rasterize_gaussians(*fwd_args(case)[:-3], want_margin=True)
+
+
+def _check_forward(case, label=""):
+    from relightable3dgaussian_amd.rasterizer_ops import decode_state
+    out = _run_forward(case)
+    torch.cuda.synchronize()
+    ref = _oracle_forward(case)
+    st_ref = ref[-1]
+    P, H, W = case["P"], case["H"], case["W"]
+    R = out[0]
+    msgs, ok_all = [], True
+    assert R == ref[0], "%s num_rendered %d vs oracle %d" % (label, R, ref[0])
+    st = decode_state(out[10], out[11], out[12], P, R, H, W)
+
+    def exact(name, got, want):
+        nonlocal ok_all
+        got, want = to_np(got), np.asarray(want)
+        same = np.array_equal(got.astype(np.int64), want.astype(np.int64))
+        msgs.append("%-14s exact=%s%s" % (name, same, "" if same else "  mismatches=%d first=%s" % (
+            (got.astype(np.int64) != want.astype(np.int64)).sum(),
+            np.argwhere(got.astype(np.int64) != want.astype(np.int64))[:5].tolist())))
+        ok_all &= same
+
+    exact("radii", out[9], st_ref["radii"])
+    exact("tiles_touched", st["tiles_touched"], st_ref["tiles_touched"])
+    exact("point_offsets", st["point_offsets"], st_ref["offsets"] if "offsets" in st_ref else np.zeros(P))
+    vis = st_ref["radii"] > 0
+    # depth bits decide the sort order: must be bit-identical on visible Gaussians
+    exact("depth bits", to_np(st["depths"]).view(np.int32)[vis], st_ref["depths"].view(np.int32)[vis])
+    if R > 0:
+        exact("keys", st["keys"], st_ref["keys"].astype(np.int64))
+        exact("point_list", st["point_list"], st_ref["point_list"])
+    exact("ranges", st["ranges"], st_ref["ranges"])
+
+    def close(name, got, want, rtol, atol):
+        nonlocal ok_all
+        ok, m = report(name, got, want, rtol, atol)
+        msgs.append(m)
+        ok_all &= ok
+
+    close("means2D", to_np(st["means2D"])[vis], st_ref["means2D"][vis], 0, 0)     # same op order, no FMA: exact
+    close("conic_opacity", to_np(st["conic_opacity"])[vis], st_ref["conic_opacity"][vis], 0, 0)
+    if case["colors"] is None:
+        close("rgb", to_np(st["rgb"])[vis], st_ref["rgb"][vis], 0, 0)
+        exact("clamped", to_np(st["clamped"])[vis], st_ref["clamped"][vis])
+    if case["cov3D"] is None:
+        close("cov3D", to_np(st["cov3D"])[vis], st_ref["cov3D"][vis], 0, 0)
+
+    nc, nc_ref = to_np(out[1]), ref[1]
+    mism = nc != nc_ref
+    border = st_ref["margin"] < 1e-4
+    hard = mism & ~border
+    msgs.append("n_contrib      mismatches %d (borderline %d, hard %d)" % (mism.sum(), (mism & border).sum(), hard.sum()))
+    ok_all &= not hard.any()
+    good = ~mism       # float buffers are compared where the discrete outcome agrees
+    for name, idx in (("color", 2), ("opacity", 3), ("depth", 4), ("feature", 5)):
+        g_, r_ = to_np(out[idx]), ref[idx]
+        if g_.size:
+            close(name, g_[:, good], r_[:, good], 2e-5, 1e-5)
+    close("final_T", to_np(st["final_T"])[good], st_ref["final_T"][good], 2e-5, 1e-6)
+    # pseudo normal / surface xyz depend on neighbours: compare where the 3x3 neighbourhood agrees
+    nb = np.ones_like(good)
+    pad = np.pad(good, 1, mode="edge")
+    for dy in range(3):
+        for dx in range(3):
+            nb &= pad[dy:dy + H, dx:dx + W]
+    close("surface_xyz", to_np(out[7])[:, good], ref[7][:, good], 2e-5, 1e-5)
+    close("normal", to_np(out[6])[:, nb], ref[6][:, nb], 0, 2e-3)
+    close("weights", out[8], ref[8], 1e-4, 1e-6)
+    text = "\n".join(["[%s] P=%d %dx%d S=%d R=%d" % (label, P, W, H, case["S"], R)] + msgs)
+    print(text)
+    assert ok_all, text
+    return out, ref
+
+
+CASES = {
+    "sh_scale_rot_S5": dict(S=5),
+    "S0": dict(S=0),
+    "S16": dict(S=16, seed=2),
+    "S28": dict(S=28, seed=3),
+    "S33": dict(S=33, seed=4, P=1500),
+    "colors_precomp": dict(S=3, use_colors=True),
+    "cov_precomp": dict(S=4, use_cov=True),
+    "ragged_image": dict(S=5, W=200, H=120, seed=5),
+    "big_splats": dict(S=5, scale_log_mean=-1.5, P=800, seed=6),
+    "camera_inside": dict(S=5, eye=(0.2, 0.1, 0.0), seed=7),
+    "black_bg_deg1": dict(S=2, bg=(0.0, 0.0, 0.0), sh_degree=1),
+}
+
+
+@pytest.mark.parametrize("name", list(CASES))
+def test_forward_parity(name):
+    _check_forward(make_case(**CASES[name]), name)
+
+
+@pytest.mark.parametrize("ppl", [1, 2, 4])
+def test_forward_parity_pixels_per_lane(ppl, hip_lib):
+    hip_lib.r3dg_set_tuning(ppl, 0, -1)
+    try:
+        _check_forward(make_case(S=16, seed=11), "ppl%d" % ppl)
+    finally:
+        hip_lib.r3dg_set_tuning(2, 0, -1)
+
+
+def test_forward_empty_and_culled():
+    from r3dg_rasterization import _C
+    case = make_case(P=64, S=5)
+    # P == 0: kernels skipped, zero outputs (rasterize_points.cu:92)
+    empty = dict(case)
+    for k in ("means3D", "opacity", "scales", "rotations"):
+        empty[k] = case[k][:0]
+    empty["features"] = case["features"][:0]
+    empty["shs"] = case["shs"][:0]
+    empty["P"] = 0
+    out = _C.rasterize_gaussians(*fwd_args(empty, DEV))
+    assert out[0] == 0 and float(out[2].abs().sum()) == 0.0 and out[1].shape == (case["H"], case["W"])
+    # everything behind the camera: nothing rendered, colour == background
+    behind = dict(case)
+    behind["means3D"] = case["means3D"] + torch.tensor([100.0, 0, 0])
+    out = _C.rasterize_gaussians(*fwd_args(behind, DEV))
+    assert out[0] == 0
+    assert torch.allclose(out[2].cpu(), case["bg"][:, None, None].expand(3, case["H"], case["W"]))
+    assert int(out[9].abs().sum()) == 0
+
+
+def test_forward_bad_shape_raises():
+    from r3dg_rasterization import _C
+    case = make_case(P=64, S=5)
+    args = list(fwd_args(case, DEV))
+    args[1] = args[1][:, :2].contiguous()
+    with pytest.raises(RuntimeError):
+        _C.rasterize_gaussians(*args)
+    case = make_case(P=64, S=40)
+    with pytest.raises(RuntimeError):
+        _C.rasterize_gaussians(*fwd_args(case, DEV))
+
+
+def _check_backward(case, label, backward_geometry=True):
+    from oracle import rasterizer as orc
+    from r3dg_rasterization import _C
+    out, ref = _check_forward(case, label + "/fwd")
+    H, W, S = case["H"], case["W"], case["S"]
+    g = torch.Generator().manual_seed(123)
+    gC, gO, gD = torch.randn(3, H, W, generator=g), torch.randn(1, H, W, generator=g), torch.randn(1, H, W, generator=g)
+    gF = torch.randn(S, H, W, generator=g)
+    a = fwd_args(case, DEV)
+    grads = _C.rasterize_gaussians_backward(a[0], a[1], a[2], out[9], a[3], a[5], a[6], 1.0, a[8], a[9], a[10], a[11],
+                                            a[12], gC.to(DEV), gO.to(DEV), gD.to(DEV), gF.to(DEV), a[17], a[18], a[19],
+                                            out[10], out[0], out[11], out[12], backward_geometry, False)
+    torch.cuda.synchronize()
+    c = fwd_args(case)
+    # the oracle backward walks the ORACLE's forward state; n_contrib borderline pixels are zeroed in both
+    # upstream gradients so both sides differentiate the same discrete structure
+    nc_same = torch.from_numpy(to_np(out[1]) == ref[1])
+    if not bool(nc_same.all()):
+        mask = nc_same[None].float()
+        gC, gO, gD, gF = gC * mask, gO * mask, gD * mask, gF * mask
+        grads = _C.rasterize_gaussians_backward(a[0], a[1], a[2], out[9], a[3], a[5], a[6], 1.0, a[8], a[9], a[10],
+                                                a[11], a[12], gC.to(DEV), gO.to(DEV), gD.to(DEV), gF.to(DEV), a[17],
+                                                a[18], a[19], out[10], out[0], out[11], out[12], backward_geometry,
+                                                False)
+        torch.cuda.synchronize()
+    oref = orc.rasterize_gaussians_backward(c[0], c[1], c[2], ref[9], c[3], c[5], c[6], 1.0, c[8], c[9], c[10], c[11],
+                                            c[12], gC, gO, gD, gF, c[17], c[18], c[19], ref[-1], backward_geometry)
+    names = ["dL_dmeans2D", "dL_dcolors", "dL_dopacity", "dL_dmeans3D", "dL_dfeatures", "dL_dcov3D", "dL_dsh",
+             "dL_dscales", "dL_drotations"]
+    msgs, ok_all = [], True
+    for name, got, want in zip(names, grads, oref[:9]):
+        ok, m = report(name, got, np.asarray(want).reshape(tuple(got.shape)), 2e-3, 1e-6)
+        msgs.append(m)
+        ok_all &= ok
+    text = "\n".join(["[%s] backward" % label] + msgs)
+    print(text)
+    assert ok_all, text
+
+
+BWD_CASES = {
+    "S5": dict(S=5),
+    "S0": dict(S=0, seed=21),
+    "S16": dict(S=16, seed=22),
+    "S24": dict(S=24, seed=23, P=1500),
+    "S33": dict(S=33, seed=24, P=1000),
+    "colors_precomp": dict(S=3, use_colors=True, seed=25),
+    "cov_precomp": dict(S=4, use_cov=True, seed=26),
+    "ragged_image": dict(S=5, W=200, H=120, seed=27),
+    "big_splats": dict(S=5, scale_log_mean=-1.5, P=800, seed=28),
+}
+
+
+@pytest.mark.parametrize("name", list(BWD_CASES))
+def test_backward_parity(name):
+    _check_backward(make_case(**BWD_CASES[name]), name)
+
+
+def test_backward_no_geometry_flag():
+    _check_backward(make_case(S=5, seed=31), "bg_geom_off", backward_geometry=False)
+
+
+@pytest.mark.parametrize("ppl,dpp", [(1, 1), (2, 1), (1, 0), (2, 0)])
+def test_backward_parity_variants(ppl, dpp, hip_lib):
+    hip_lib.r3dg_set_tuning(0, ppl, dpp)
+    try:
+        _check_backward(make_case(S=16, seed=41), "bwd_ppl%d_dpp%d" % (ppl, dpp))
+    finally:
+        hip_lib.r3dg_set_tuning(0, 2, 1)
+
+
+@pytest.mark.parametrize("N", [16, 32, 64])
+@pytest.mark.parametrize("dpp", [0, 1])
+def test_transpose_reduce_selftest(N, dpp, hip_lib):
+    from relightable3dgaussian_amd import _lib
+    g = torch.Generator().manual_seed(N + dpp)
+    x = torch.randn(64, N, generator=g)
+    xin = x.to(DEV)
+    out = torch.zeros(64, device=DEV)
+    chan = torch.zeros(64, dtype=torch.int32, device=DEV)
+    owner = torch.zeros(64, dtype=torch.int32, device=DEV)
+    st = hip_lib.r3dg_selftest_transpose_reduce(_lib.current_stream(), N, dpp, xin.data_ptr(), out.data_ptr(),
+                                                chan.data_ptr(), owner.data_ptr())
+    _lib.check(st, "selftest")
+    torch.cuda.synchronize()
+    want = x.double().sum(0)
+    chan, owner, out = chan.cpu(), owner.cpu(), out.cpu()
+    assert sorted(chan[owner.bool()].tolist()) == list(range(N)), "owners must cover every channel exactly once"
+    err = (out.double() - want[chan.long()]).abs().max()
+    print("transpose_reduce N=%d dpp=%d max err %.3e" % (N, dpp, err))
+    assert err < 1e-4
+
+
+def test_radix_sort_stable(hip_lib):
+    from relightable3dgaussian_amd import _lib
+    for n, end_bit, seed in ((1, 44, 0), (63, 44, 1), (4097, 33, 2), (100_000, 44, 3), (1_000_003, 45, 4)):
+        g = torch.Generator().manual_seed(seed)
+        # few distinct keys -> many ties: stability is what is being tested
+        hi = torch.randint(0, 1 << (end_bit - 32), (n,), generator=g, dtype=torch.int64)
+        lo = torch.randint(0, 50, (n,), generator=g, dtype=torch.int64) * 0x01010101
+        keys = (hi << 32) | lo
+        vals = torch.arange(n, dtype=torch.int32)
+        order = torch.sort(keys, stable=True).indices
+        k_in, v_in = keys.to(DEV), vals.to(DEV)
+        k_out, v_out = torch.empty_like(k_in), torch.empty_like(v_in)
+        temp = torch.empty(int(hip_lib.r3dg_sort_temp_bytes(n)), dtype=torch.uint8, device=DEV)
+        st = hip_lib.r3dg_sort_pairs(_lib.current_stream(), n, k_in.data_ptr(), v_in.data_ptr(), k_out.data_ptr(),
+                                     v_out.data_ptr(), end_bit, temp.data_ptr())
+        _lib.check(st, "sort_pairs")
+        torch.cuda.synchronize()
+        assert torch.equal(k_out.cpu(), keys[order]), "keys not sorted (n=%d)" % n
+        assert torch.equal(v_out.cpu().long(), order), "sort not stable (n=%d)" % n
+
+
+def test_mark_visible():
+    from oracle import rasterizer as orc
+    from r3dg_rasterization import _C
+    case = make_case(P=5000, eye=(0.2, 0.1, 0.0))
+    cam = case["cam"]
+    got = _C.mark_visible(case["means3D"].to(DEV), cam.world_view_transform.to(DEV), cam.full_proj_transform.to(DEV))
+    want = orc.mark_visible(case["means3D"], cam.world_view_transform)
+    assert np.array_equal(got.cpu().numpy(), want)
+
+
+def test_autograd_wrapper_matches_ops():
+    """The nn.Module face (reference wrapper API) returns the op's outputs and routes gradients to every input."""
+    from r3dg_rasterization import GaussianRasterizationSettings, GaussianRasterizer
+    case = make_case(P=2000, S=5, seed=51)
+    cam = case["cam"].to(DEV)
+    rs = GaussianRasterizationSettings(case["H"], case["W"], cam.tanfovx, cam.tanfovy, cam.cx, cam.cy,
+                                       case["bg"].to(DEV), 1.0, cam.world_view_transform, cam.full_proj_transform,
+                                       3, cam.camera_center, False, True, True, False)
+    leaves = {k: case[k].to(DEV).requires_grad_(True) for k in ("means3D", "opacity", "scales", "rotations", "shs",
+                                                               "features")}
+    means2D = torch.zeros_like(leaves["means3D"], requires_grad=True)
+    outs = GaussianRasterizer(rs)(leaves["means3D"], means2D, leaves["opacity"], shs=leaves["shs"],
+                                  scales=leaves["scales"], rotations=leaves["rotations"], features=leaves["features"])
+    assert len(outs) == 10
+    loss = outs[2].sum() + outs[3].mean() + outs[4].mean() + outs[5].mean()
+    loss.backward()
+    for k, v in leaves.items():
+        assert v.grad is not None and torch.isfinite(v.grad).all(), k
+    assert means2D.grad is not None and means2D.grad.shape == (case["P"], 3)
