@@ -354,7 +354,7 @@ render_backward_kernel(const uint2* __restrict__ ranges, const uint32_t* __restr
     }
 }
 
-int g_bwd_ppl = 2;
+int g_bwd_ppl = 1;
 int g_bwd_dpp = 1;   // 1: DPP/permlane-swap transposing reduction, 0: portable __shfl_xor version
 
 template <int SPAD, int PPL>

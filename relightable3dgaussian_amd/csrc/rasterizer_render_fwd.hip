@@ -230,7 +230,7 @@ pseudo_normal_kernel(int W, int H, const float* __restrict__ vm, float* __restri
 }
 
 // ---- launchers ------------------------------------------------------------------------------------------
-int g_fwd_ppl = 2;   // pixels per lane; tunable through r3dg_set_tuning()
+int g_fwd_ppl = 1;   // pixels per lane; tunable through r3dg_set_tuning()
 
 template <int SPAD, int PPL>
 static void launch_fwd_inst(hipStream_t s, int T, int tiles_x, const uint32_t* ranges, const uint32_t* point_list,

@@ -93,7 +93,24 @@ def _check_forward(case, label=""):
         for dx in range(3):
             nb &= pad[dy:dy + H, dx:dx + W]
     close("surface_xyz", to_np(out[7])[:, good], ref[7][:, good], 2e-5, 1e-5)
-    close("normal", to_np(out[6])[:, nb], ref[6][:, nb], 0, 2e-3)
+    # The pseudo normal is normalize(ga x gb) of finite differences of surface_xyz: its conditioning is
+    # (|ga|+|gb|)/|ga x gb|.  With delta = the fp32 noise of the differences (3e-6 * max|xyz|) the admissible
+    # error per pixel is 2e-3 + 10*delta*(|ga|+|gb|)/|ga x gb|; flat/degenerate pixels are thereby exempt.
+    xyz = ref[7].astype(np.float64)
+    pz = np.pad(xyz, ((0, 0), (1, 1), (1, 1)), mode="edge")
+
+    def sh(dy, dx):
+        return pz[:, 1 + dy:1 + dy + H, 1 + dx:1 + dx + W]
+    ga = -0.125 * sh(-1, -1) + 0.125 * sh(-1, 1) - 0.25 * sh(0, -1) + 0.25 * sh(0, 1) - 0.125 * sh(1, -1) + 0.125 * sh(1, 1)
+    gb = -0.125 * sh(-1, -1) - 0.25 * sh(-1, 0) - 0.125 * sh(-1, 1) + 0.125 * sh(1, -1) + 0.25 * sh(1, 0) + 0.125 * sh(1, 1)
+    n0 = np.linalg.norm(np.cross(ga, gb, axis=0), axis=0)
+    delta = 3e-6 * max(np.abs(xyz).max(), 1e-30)
+    nbound = 2e-3 + 10 * delta * (np.linalg.norm(ga, axis=0) + np.linalg.norm(gb, axis=0)) / np.maximum(n0, 1e-300)
+    nerr = np.abs(to_np(out[6]).astype(np.float64) - ref[6]).max(0)
+    nbad = nb & (nerr > nbound) & (n0 > 0)
+    msgs.append("normal         bad %d/%d (max err on well-conditioned pixels %.3e)" % (
+        nbad.sum(), nb.sum(), nerr[nb & (nbound < 1e-2)].max() if (nb & (nbound < 1e-2)).any() else 0.0))
+    ok_all &= not nbad.any()
     close("weights", out[8], ref[8], 1e-4, 1e-6)
     text = "\n".join(["[%s] P=%d %dx%d S=%d R=%d" % (label, P, W, H, case["S"], R)] + msgs)
     print(text)
@@ -127,7 +144,7 @@ def test_forward_parity_pixels_per_lane(ppl, hip_lib):
     try:
         _check_forward(make_case(S=16, seed=11), "ppl%d" % ppl)
     finally:
-        hip_lib.r3dg_set_tuning(2, 0, -1)
+        hip_lib.r3dg_set_tuning(1, 0, -1)
 
 
 def test_forward_empty_and_culled():
@@ -230,7 +247,7 @@ def test_backward_parity_variants(ppl, dpp, hip_lib):
     try:
         _check_backward(make_case(S=16, seed=41), "bwd_ppl%d_dpp%d" % (ppl, dpp))
     finally:
-        hip_lib.r3dg_set_tuning(0, 2, 1)
+        hip_lib.r3dg_set_tuning(0, 1, 1)
 
 
 @pytest.mark.parametrize("N", [16, 32, 64])
