@@ -763,3 +763,15 @@ void r3dgo_preprocess_backward(int P, int D, int M, const float* means, const in
         }
     }
 }
+
+/* Thin entry points so the two per-Gaussian helpers can be pinned against the reference's Python twins
+ * (eval_sh, utils/sh_utils.py:71-128; build_scaling_rotation+strip_symmetric, utils/general_utils.py). */
+void r3dgo_sh_to_rgb(int P, int D, int M, const float* means, const float* campos, const float* shs,
+                     uint8_t* clamped, float* rgb)
+{
+    for (int i = 0; i < P; i++) computeColorFromSH(i, D, M, means, campos, shs, clamped, rgb + 3 * i);
+}
+void r3dgo_cov3d(int P, const float* scales, float mod, const float* rots, float* cov3D)
+{
+    for (int i = 0; i < P; i++) computeCov3D(scales + 3 * i, mod, rots + 4 * i, cov3D + 6 * i);
+}
