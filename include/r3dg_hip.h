@@ -90,6 +90,26 @@ int r3dg_rasterize_backward(void* stream, int P, int S, int D, int M, int R, con
 int r3dg_mark_visible(void* stream, int P, const float* d_means3D, const float* d_viewmatrix,
                       const float* d_projmatrix, uint8_t* d_present);
 
+/* Fused per-Gaussian shading integral, LIVE model (gaussian_renderer/neilf.py:339-407): for each Gaussian the mean
+ * over K cached samples of (albedo/pi + GGX) * (max(SH_local(d),0) + env(d)*vis) * area * max(n.d,0).
+ *   base_color[P,3] roughness[P] normals[P,3] viewdirs[P,3] incidents[P,M,3] (M = 1,4,9,16 SH coefficients)
+ *   env[He,We,3]: ACTIVATED lat-long environment texture (softplus(DirectLightMap.env) or EnvLight.envmap);
+ *   env_transform: optional row-major 3x3 light rotation applied to the lookup direction (envmap.py:39-42) or NULL
+ *   visibility[P,K] incident_dirs[P,K,3] incident_areas[P,K]  (GaussianModel.update_visibility caches)
+ * out[P,19] = pbr(3) diffuse_light(3) specular(3) mean_k incident_lights(3) mean_k local(3) mean_k global(3) mean_k vis(1)
+ * Backward: gradients of <pbr,dL_dpbr> + <diffuse_light,dL_ddiffuse_light>; dL_dbase_color[P,3], dL_droughness[P],
+ * dL_dviewdirs[P,3], dL_dincidents[P,M,3] are overwritten, dL_denv[He,We,3] is ACCUMULATED (zero it first). */
+int r3dg_shade_forward(void* stream, int P, int K, int M, const float* d_base_color, const float* d_roughness,
+                       const float* d_normals, const float* d_viewdirs, const float* d_incidents, const float* d_env,
+                       int He, int We, const float* d_env_transform, const float* d_visibility,
+                       const float* d_incident_dirs, const float* d_incident_areas, float* d_out);
+int r3dg_shade_backward(void* stream, int P, int K, int M, const float* d_base_color, const float* d_roughness,
+                        const float* d_normals, const float* d_viewdirs, const float* d_incidents, const float* d_env,
+                        int He, int We, const float* d_env_transform, const float* d_visibility,
+                        const float* d_incident_dirs, const float* d_incident_areas, const float* d_dL_dpbr,
+                        const float* d_dL_ddiffuse_light, float* d_dL_dbase_color, float* d_dL_droughness,
+                        float* d_dL_dviewdirs, float* d_dL_dincidents, float* d_dL_denv);
+
 /* Stable ascending radix sort of (u64 key, u32 value) pairs on key bits [0,end_bit) -- the semantics of
  * cub::DeviceRadixSort::SortPairs as used at rasterizer_impl.cu:313-318. Exposed for tests/benchmarks.
  * d_temp must hold r3dg_sort_temp_bytes(n) bytes. Inputs are clobbered (used as ping-pong space). */

@@ -36,6 +36,9 @@ _SIGNATURES = {
     "r3dg_sort_pairs": (_i, [_p, C.c_int64, _p, _p, _p, _p, _i, _p]),
     "r3dg_set_tuning": (_i, [_i, _i, _i]),
     "r3dg_selftest_transpose_reduce": (_i, [_p, _i, _i, _p, _p, _p, _p]),
+    "r3dg_shade_forward": (_i, [_p, _i, _i, _i, _p, _p, _p, _p, _p, _p, _i, _i, _p, _p, _p, _p, _p]),
+    "r3dg_shade_backward": (_i, [_p, _i, _i, _i, _p, _p, _p, _p, _p, _p, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p,
+                                 _p, _p]),
     "r3dg_profile_enable": (_i, [_i]),
     "r3dg_profile_num_stages": (_i, []),
     "r3dg_profile_stage_name": (C.c_char_p, [_i]),

@@ -46,6 +46,15 @@ void launch_preprocess_backward(hipStream_t s, int P, int D, int M, const float*
                                 float h_y, float tan_fovx, float tan_fovy, const float* campos, const float* dL_dmean2D,
                                 const float* dL_dconic, float* dL_dmeans, const float* dL_dcolor, float* dL_dcov3D,
                                 float* dL_dsh, float* dL_dscale, float* dL_drot);
+void launch_shade_forward(hipStream_t s, int P, int K, int M, const float* base_color, const float* roughness,
+                          const float* normals, const float* viewdirs, const float* incidents, const float* env, int He,
+                          int We, const float* tr, const float* visibility, const float* dirs, const float* areas,
+                          float* out);
+void launch_shade_backward(hipStream_t s, int P, int K, int M, const float* base_color, const float* roughness,
+                           const float* normals, const float* viewdirs, const float* incidents, const float* env,
+                           int He, int We, const float* tr, const float* visibility, const float* dirs,
+                           const float* areas, const float* g_pbr, const float* g_diff, float* d_base, float* d_rough,
+                           float* d_view, float* d_inc, float* d_env);
 extern int g_fwd_ppl;
 extern int g_bwd_ppl;
 extern int g_bwd_dpp;
@@ -53,9 +62,10 @@ void launch_transpose_selftest(hipStream_t s, int N, int dpp, const float* in, f
 
 // ---- optional per-stage timing with HIP events on the launch stream (bench.py's roofline numbers) ----
 enum Stage { ST_PREPROCESS = 0, ST_DUPKEYS, ST_SORT, ST_RANGES, ST_RENDER_FWD, ST_NORMAL, ST_RENDER_BWD, ST_PREPROCESS_BWD,
-             ST_COUNT };
+             ST_SHADE_FWD, ST_SHADE_BWD, ST_BVH_BUILD, ST_BVH_TRACE, ST_COUNT };
 static const char* kStageNames[ST_COUNT] = {"preprocess", "duplicate_with_keys", "sort_pairs", "identify_tile_ranges",
-                                            "render_forward", "pseudo_normal", "render_backward", "preprocess_backward"};
+                                            "render_forward", "pseudo_normal", "render_backward", "preprocess_backward",
+                                            "shade_forward", "shade_backward", "bvh_build", "bvh_trace"};
 static int g_profiling = 0;
 struct EventPair { hipEvent_t a, b; };
 static std::vector<EventPair> g_events[ST_COUNT];
@@ -424,6 +434,47 @@ int r3dg_mark_visible(void* stream_, int P, const float* means3D, const float* v
     return guarded([&]() -> int {
         launch_mark_visible((hipStream_t)stream_, P, means3D, viewmatrix, present);
         check_launch((hipStream_t)stream_, false, "mark_visible");
+        return R3DG_OK;
+    });
+}
+
+int r3dg_shade_forward(void* stream_, int P, int K, int M, const float* base_color, const float* roughness,
+                       const float* normals, const float* viewdirs, const float* incidents, const float* env, int He,
+                       int We, const float* env_transform, const float* visibility, const float* incident_dirs,
+                       const float* incident_areas, float* out)
+{
+    if (P < 0 || K <= 0 || He <= 0 || We <= 0) return invalid("shade_forward: bad P/K/env size");
+    if (M != 1 && M != 4 && M != 9 && M != 16) return invalid("shade_forward: incidents must hold 1, 4, 9 or 16 SH coefficients");
+    if (P == 0) return R3DG_OK;
+    return guarded([&]() -> int {
+        hipStream_t stream = (hipStream_t)stream_;
+        StageTimer t(stream, ST_SHADE_FWD);
+        launch_shade_forward(stream, P, K, M, base_color, roughness, normals, viewdirs, incidents, env, He, We,
+                             env_transform, visibility, incident_dirs, incident_areas, out);
+        check_launch(stream, false, "shade_forward");
+        t.stop();
+        return R3DG_OK;
+    });
+}
+
+int r3dg_shade_backward(void* stream_, int P, int K, int M, const float* base_color, const float* roughness,
+                        const float* normals, const float* viewdirs, const float* incidents, const float* env, int He,
+                        int We, const float* env_transform, const float* visibility, const float* incident_dirs,
+                        const float* incident_areas, const float* dL_dpbr, const float* dL_ddiffuse_light,
+                        float* dL_dbase_color, float* dL_droughness, float* dL_dviewdirs, float* dL_dincidents,
+                        float* dL_denv)
+{
+    if (P < 0 || K <= 0 || He <= 0 || We <= 0) return invalid("shade_backward: bad P/K/env size");
+    if (M != 1 && M != 4 && M != 9 && M != 16) return invalid("shade_backward: incidents must hold 1, 4, 9 or 16 SH coefficients");
+    if (P == 0) return R3DG_OK;
+    return guarded([&]() -> int {
+        hipStream_t stream = (hipStream_t)stream_;
+        StageTimer t(stream, ST_SHADE_BWD);
+        launch_shade_backward(stream, P, K, M, base_color, roughness, normals, viewdirs, incidents, env, He, We,
+                              env_transform, visibility, incident_dirs, incident_areas, dL_dpbr, dL_ddiffuse_light,
+                              dL_dbase_color, dL_droughness, dL_dviewdirs, dL_dincidents, dL_denv);
+        check_launch(stream, false, "shade_backward");
+        t.stop();
         return R3DG_OK;
     });
 }
