@@ -110,6 +110,20 @@ int r3dg_shade_backward(void* stream, int P, int K, int M, const float* d_base_c
                         const float* d_dL_ddiffuse_light, float* d_dL_dbase_color, float* d_dL_droughness,
                         float* d_dL_dviewdirs, float* d_dL_dincidents, float* d_dL_denv);
 
+/* LBVH over per-Gaussian leaf boxes + visibility trace (reference bvh/include/bvh.h:5-18).
+ * r3dg_bvh_build: d_nodes int32[2P-1,5] = (parent,left,right,object_id,leaf_count) and d_aabbs float[2P-1,6] =
+ *   (lower xyz, upper xyz) arrive initialised as bvh/__init__.py:31-57 prepares them (nodes -1, counts 0 internal /
+ *   1 leaf, leaf boxes in rows P-1..) and are completed IN PLACE; d_morton int64[P] receives the 64-bit codes.
+ * r3dg_bvh_trace_opacity: one ray per (rays_o, rays_d) row; covs3D is the 6-vector INVERSE covariance
+ *   (GaussianModel.get_inverse_covariance); outputs must be pre-set by the caller to 0 / 1 (bvh.cu:101-102);
+ *   *d_stack_overflow (zeroed by the caller) counts rays that needed more than the 64-entry traversal stack. */
+size_t r3dg_bvh_build_temp_bytes(int P);
+int r3dg_bvh_build(void* stream, int P, int32_t* d_nodes, float* d_aabbs, int64_t* d_morton, void* d_temp);
+int r3dg_bvh_trace_opacity(void* stream, int64_t num_rays, const int32_t* d_nodes, const float* d_aabbs,
+                           const float* d_rays_o, const float* d_rays_d, const float* d_means3D,
+                           const float* d_covs3D, const float* d_opacities, const float* d_normals,
+                           int32_t* d_num_contributes, float* d_rendered_opacity, int32_t* d_stack_overflow);
+
 /* Stable ascending radix sort of (u64 key, u32 value) pairs on key bits [0,end_bit) -- the semantics of
  * cub::DeviceRadixSort::SortPairs as used at rasterizer_impl.cu:313-318. Exposed for tests/benchmarks.
  * d_temp must hold r3dg_sort_temp_bytes(n) bytes. Inputs are clobbered (used as ping-pong space). */

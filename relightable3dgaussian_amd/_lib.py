@@ -39,6 +39,9 @@ _SIGNATURES = {
     "r3dg_shade_forward": (_i, [_p, _i, _i, _i, _p, _p, _p, _p, _p, _p, _i, _i, _p, _p, _p, _p, _p]),
     "r3dg_shade_backward": (_i, [_p, _i, _i, _i, _p, _p, _p, _p, _p, _p, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p,
                                  _p, _p]),
+    "r3dg_bvh_build_temp_bytes": (C.c_size_t, [_i]),
+    "r3dg_bvh_build": (_i, [_p, _i, _p, _p, _p, _p]),
+    "r3dg_bvh_trace_opacity": (_i, [_p, C.c_int64, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p]),
     "r3dg_profile_enable": (_i, [_i]),
     "r3dg_profile_num_stages": (_i, []),
     "r3dg_profile_stage_name": (C.c_char_p, [_i]),

@@ -1,0 +1,361 @@
+// LBVH build (K17) and visibility trace (K18) for gfx950.
+// Reference semantics: construct_bvh bvh/src/construct.cu:147-265 (Morton codes of leaf-box centroids, stable sort,
+// Karras ranges/splits, bottom-up box merge + leaf counts) and trace_bvh_opacity_cuda bvh/src/trace.cu:196-286
+// (stack traversal, per-leaf Gaussian attenuation, T < 0.9 -> 0).
+//
+// Compiled with -ffp-contract=off: Morton codes decide the (integer) tree topology and must equal the oracle's.
+// Differences from the reference's thrust pipeline:
+//   * the 30-bit Morton keys are sorted by this library's own stable LSD radix sort (3 passes of 10 bits);
+//   * the bottom-up merge publishes each child box with an agent-scope release before the arrival flag and the
+//     second arriver acquires before reading its sibling's box -- gfx950's per-XCD L2s are not coherent, so the
+//     reference's fence-free atomicCAS hand-off (construct.cu:243-258) would read stale boxes here;
+//   * the traversal stack holds 64 entries (reference: 32 with only a printf on overflow, trace.cuh:21-28); pushes
+//     beyond that are dropped and counted in *overflow so callers can detect it.
+#include "common.hpp"
+
+namespace r3dg {
+
+struct Box {
+    float lo[3], hi[3];
+};
+
+__device__ __forceinline__ uint32_t expand_bits(uint32_t v)
+{
+    v = (v * 0x00010001u) & 0xFF0000FFu;
+    v = (v * 0x00000101u) & 0x0F00F00Fu;
+    v = (v * 0x00000011u) & 0xC30C30C3u;
+    v = (v * 0x00000005u) & 0x49249249u;
+    return v;
+}
+__device__ __forceinline__ int common_upper_bits(uint64_t a, uint64_t b) { return __clzll((long long)(a ^ b)); }
+
+// ---- whole-scene box: per-block partials then one small block ----
+__global__ void __launch_bounds__(256) whole_box_partial_kernel(int P, const float* __restrict__ leaf, float* __restrict__ partial)
+{
+    __shared__ float s[4][6];
+    float b[6] = {100000.f, 100000.f, 100000.f, -100000.f, -100000.f, -100000.f};
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < P; i += gridDim.x * 256) {
+#pragma unroll
+        for (int a = 0; a < 3; a++) {
+            b[a] = fminf(b[a], leaf[6 * (size_t)i + a]);
+            b[3 + a] = fmaxf(b[3 + a], leaf[6 * (size_t)i + 3 + a]);
+        }
+    }
+#pragma unroll
+    for (int a = 0; a < 6; a++) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const float n = __shfl_xor(b[a], o, 64);
+            b[a] = a < 3 ? fminf(b[a], n) : fmaxf(b[a], n);
+        }
+    }
+    if ((threadIdx.x & 63) == 0)
+#pragma unroll
+        for (int a = 0; a < 6; a++) s[threadIdx.x >> 6][a] = b[a];
+    __syncthreads();
+    if (threadIdx.x < 6) {
+        const int a = threadIdx.x;
+        float v = s[0][a];
+        for (int w = 1; w < 4; w++) v = a < 3 ? fminf(v, s[w][a]) : fmaxf(v, s[w][a]);
+        partial[blockIdx.x * 6 + a] = v;
+    }
+}
+__global__ void whole_box_final_kernel(int nb, const float* __restrict__ partial, float* __restrict__ whole)
+{
+    const int a = threadIdx.x;
+    if (a >= 6) return;
+    float v = a < 3 ? 100000.f : -100000.f;
+    for (int i = 0; i < nb; i++) v = a < 3 ? fminf(v, partial[i * 6 + a]) : fmaxf(v, partial[i * 6 + a]);
+    whole[a] = v;
+}
+
+// Morton code of the leaf-box centroid (construct.cu:23-51); also copies the unsorted boxes aside
+__global__ void __launch_bounds__(256)
+morton_kernel(int P, const float* __restrict__ leaf, const float* __restrict__ whole, uint64_t* __restrict__ keys,
+              uint32_t* __restrict__ vals, float* __restrict__ leaf_copy)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= P) return;
+    float c[3];
+#pragma unroll
+    for (int a = 0; a < 3; a++) {
+        const float lo = leaf[6 * (size_t)i + a], hi = leaf[6 * (size_t)i + 3 + a];
+        leaf_copy[6 * (size_t)i + a] = lo;
+        leaf_copy[6 * (size_t)i + 3 + a] = hi;
+        float p = (float)((hi + lo) * 0.5);
+        p -= whole[a];
+        p /= (whole[3 + a] - whole[a]);
+        c[a] = fminf(fmaxf(p * 1024.0f, 0.0f), 1024.0f - 1.0f);
+    }
+    const uint32_t m = expand_bits((uint32_t)c[0]) * 4 + expand_bits((uint32_t)c[1]) * 2 + expand_bits((uint32_t)c[2]);
+    keys[i] = (uint64_t)m;
+    vals[i] = (uint32_t)i;
+}
+
+// sorted order -> leaf rows of aabbs, 64-bit codes (m << 31 | original index, sic), leaf object ids
+__global__ void __launch_bounds__(256)
+scatter_leaves_kernel(int P, const uint64_t* __restrict__ keys_sorted, const uint32_t* __restrict__ idx_sorted,
+                      const float* __restrict__ leaf_copy, float* __restrict__ aabbs, int32_t* __restrict__ nodes,
+                      uint64_t* __restrict__ morton)
+{
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= P) return;
+    const uint32_t src = idx_sorted[j];
+    const size_t row = (size_t)(P - 1 + j);
+#pragma unroll
+    for (int a = 0; a < 6; a++) aabbs[6 * row + a] = leaf_copy[6 * (size_t)src + a];
+    morton[j] = (keys_sorted[j] << 31) | (uint64_t)src;
+    nodes[5 * row + 3] = (int32_t)src;
+}
+
+// Karras internal nodes (construct.cu:54-145, 203-229)
+__global__ void __launch_bounds__(256)
+internal_nodes_kernel(int P, const uint64_t* __restrict__ code, int32_t* __restrict__ nodes)
+{
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= P - 1) return;
+    const int num_leaves = P;
+    int first, last;
+    if (idx == 0) {
+        first = 0;
+        last = num_leaves - 1;
+    } else {
+        const uint64_t self = code[idx];
+        const int L_delta = common_upper_bits(self, code[idx - 1]);
+        const int R_delta = common_upper_bits(self, code[idx + 1]);
+        const int d = (R_delta > L_delta) ? 1 : -1;
+        const int delta_min = min(L_delta, R_delta);
+        int l_max = 2;
+        int delta = -1;
+        int i_tmp = idx + d * l_max;
+        if (0 <= i_tmp && i_tmp < num_leaves) delta = common_upper_bits(self, code[i_tmp]);
+        while (delta > delta_min) {
+            l_max <<= 1;
+            i_tmp = idx + d * l_max;
+            delta = -1;
+            if (0 <= i_tmp && i_tmp < num_leaves) delta = common_upper_bits(self, code[i_tmp]);
+        }
+        int l = 0;
+        int t = l_max >> 1;
+        while (t > 0) {
+            i_tmp = idx + (l + t) * d;
+            delta = -1;
+            if (0 <= i_tmp && i_tmp < num_leaves) delta = common_upper_bits(self, code[i_tmp]);
+            if (delta > delta_min) l += t;
+            t >>= 1;
+        }
+        const int jdx = idx + l * d;
+        first = min(idx, jdx);
+        last = max(idx, jdx);
+    }
+    // find_split
+    int split;
+    {
+        const uint64_t first_code = code[first], last_code = code[last];
+        if (first_code == last_code) {
+            split = (first + last) >> 1;
+        } else {
+            const int delta_node = common_upper_bits(first_code, last_code);
+            split = first;
+            int stride = last - first;
+            do {
+                stride = (stride + 1) >> 1;
+                const int middle = split + stride;
+                if (middle < last) {
+                    const int delta = common_upper_bits(first_code, code[middle]);
+                    if (delta > delta_node) split = middle;
+                }
+            } while (stride > 1);
+        }
+    }
+    int left = split, right = split + 1;
+    if (first == split) left += P - 1;
+    if (last == split + 1) right += P - 1;
+    int32_t* node = nodes + 5 * (size_t)idx;
+    node[1] = left;
+    node[2] = right;
+    node[3] = -1;
+    nodes[5 * (size_t)left] = idx;
+    nodes[5 * (size_t)right] = idx;
+}
+
+// bottom-up merge (construct.cu:231-264) with explicit release/acquire around the arrival flag
+__global__ void __launch_bounds__(256)
+merge_boxes_kernel(int P, int32_t* __restrict__ nodes, float* __restrict__ aabbs, int* __restrict__ flags)
+{
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= P) return;
+    int idx = P - 1 + j;
+    int num = 1;
+    int parent = nodes[5 * (size_t)idx];
+    while (parent != -1) {
+        __threadfence();                                        // release my (or the leaf's) box before arriving
+        atomicAdd(&nodes[5 * (size_t)parent + 4], num);
+        const int old = atomicCAS(&flags[parent], 0, 1);
+        if (old == 0) return;                                   // first arrival: the sibling finishes this node
+        __threadfence();                                        // acquire the sibling's box
+        const int lidx = nodes[5 * (size_t)parent + 1], ridx = nodes[5 * (size_t)parent + 2];
+        volatile const float* lb = aabbs + 6 * (size_t)lidx;
+        volatile const float* rb = aabbs + 6 * (size_t)ridx;
+        float m[6];
+#pragma unroll
+        for (int a = 0; a < 3; a++) {
+            m[a] = fminf(lb[a], rb[a]);
+            m[3 + a] = fmaxf(lb[3 + a], rb[3 + a]);
+        }
+#pragma unroll
+        for (int a = 0; a < 6; a++) aabbs[6 * (size_t)parent + a] = m[a];
+        num = atomicAdd(&nodes[5 * (size_t)parent + 4], 0);
+        idx = parent;
+        parent = nodes[5 * (size_t)parent];
+    }
+}
+
+// ---- traversal ----
+__device__ __forceinline__ float slab_tmax(const float* __restrict__ box, float ox, float oy, float oz, float dx,
+                                           float dy, float dz)
+{
+    float tmin = (box[0] - ox) / dx;
+    float tmax = (box[3] - ox) / dx;
+    if (tmin > tmax) { const float t = tmin; tmin = tmax; tmax = t; }
+    float tymin = (box[1] - oy) / dy;
+    float tymax = (box[4] - oy) / dy;
+    if (tymin > tymax) { const float t = tymin; tymin = tymax; tymax = t; }
+    if (tmin > tymax || tymin > tmax) return -1.0f;
+    if (tymin > tmin) tmin = tymin;
+    if (tymax < tmax) tmax = tymax;
+    float tzmin = (box[2] - oz) / dz;
+    float tzmax = (box[5] - oz) / dz;
+    if (tzmin > tzmax) { const float t = tzmin; tzmin = tzmax; tzmax = t; }
+    if (tmin > tzmax || tzmin > tmax) return -1.0f;
+    if (tzmax < tmax) tmax = tzmax;
+    return tmax;
+}
+
+constexpr int TRACE_STACK = 64;
+
+__global__ void __launch_bounds__(256)
+trace_opacity_kernel(int num_rays, const int32_t* __restrict__ nodes, const float* __restrict__ aabbs,
+                     const float* __restrict__ rays_o, const float* __restrict__ rays_d,
+                     const float* __restrict__ means, const float* __restrict__ covs, const float* __restrict__ opac,
+                     const float* __restrict__ normals, int32_t* __restrict__ contributes, float* __restrict__ out,
+                     int* __restrict__ overflow)
+{
+    const int r = blockIdx.x * 256 + threadIdx.x;
+    if (r >= num_rays) return;
+    const float ox = rays_o[3 * (size_t)r], oy = rays_o[3 * (size_t)r + 1], oz = rays_o[3 * (size_t)r + 2];
+    const float dx = rays_d[3 * (size_t)r], dy = rays_d[3 * (size_t)r + 1], dz = rays_d[3 * (size_t)r + 2];
+    int stack[TRACE_STACK];
+    int sp = 0;
+    stack[sp++] = 0;
+    int count = 0;
+    float T = 1.0f;
+    bool lost = false;
+    while (sp > 0) {
+        const int node_id = stack[--sp];
+        const int32_t* node = nodes + 5 * (size_t)node_id;
+        if (node[4] <= 1) {
+            const int g = node[3];
+            const float op = opac[g];
+            if (op < 1.f / 255.f) continue;
+            const float nx = normals[3 * (size_t)g], ny = normals[3 * (size_t)g + 1], nz = normals[3 * (size_t)g + 2];
+            if (nx * dx + ny * dy + nz * dz > 0) continue;
+            const float* ci = covs + 6 * (size_t)g;
+            const float c0 = ci[0], c1 = ci[1], c2 = ci[2], c3 = ci[3], c4 = ci[4], c5 = ci[5];
+            const float mx = means[3 * (size_t)g], my = means[3 * (size_t)g + 1], mz = means[3 * (size_t)g + 2];
+            const float m0 = mx - ox, m1 = my - oy, m2 = mz - oz;
+            const float t1 = c0 * m0 * dx + c1 * m0 * dy + c2 * m0 * dz + c1 * m1 * dx + c3 * m1 * dy + c4 * m1 * dz +
+                             c2 * m2 * dx + c4 * m2 * dy + c5 * m2 * dz;
+            const float t2 = c0 * dx * dx + c1 * dx * dy + c2 * dx * dz + c1 * dy * dx + c3 * dy * dy + c4 * dy * dz +
+                             c2 * dz * dx + c4 * dz * dy + c5 * dz * dz;
+            const float t = t1 / t2;
+            if (t < 0.01) continue;
+            const float px = ox + t * dx, py = oy + t * dy, pz = oz + t * dz;
+            const float f0 = mx - px, f1 = my - py, f2 = mz - pz;
+            const float s = f0 * f0 * c0 + f1 * f1 * c3 + f2 * f2 * c5 + 2 * f0 * f1 * c1 + 2 * f0 * f2 * c2 +
+                            2 * f1 * f2 * c4;
+            const float power = -0.5f * s;
+            if (power > 0) continue;
+            count += 1;
+            const float alpha = op * __expf(power);
+            T *= 1 - alpha;
+            if (T < 0.9) {
+                out[r] = 0.0f;        // contributes[r] keeps its initial 0 (trace.cu:251-254)
+                return;
+            }
+        } else {
+            const int lid = node[1], rid = node[2];
+            const float tl = slab_tmax(aabbs + 6 * (size_t)lid, ox, oy, oz, dx, dy, dz);
+            const float tr = slab_tmax(aabbs + 6 * (size_t)rid, ox, oy, oz, dx, dy, dz);
+            const int first = tl > tr ? lid : rid, second = tl > tr ? rid : lid;
+            const float tf = tl > tr ? tl : tr, ts = tl > tr ? tr : tl;
+            if (tf > 0) { if (sp < TRACE_STACK) stack[sp++] = first; else lost = true; }
+            if (ts > 0) { if (sp < TRACE_STACK) stack[sp++] = second; else lost = true; }
+        }
+    }
+    contributes[r] = count;
+    out[r] = T;
+    if (lost) atomicAdd(overflow, 1);
+}
+
+// ---- host ----
+size_t bvh_build_temp_bytes(size_t P)
+{
+    size_t o = 0;
+    auto take = [&](size_t b) { o = align_up(o + b, 256); };
+    take(P * 24);        // leaf box copy
+    take(P * 8);         // keys in
+    take(P * 8);         // keys out
+    take(P * 4);         // vals in
+    take(P * 4);         // vals out
+    take(P * 4 + 4);     // flags
+    take(1024 * 6 * 4);  // partial boxes
+    take(256);           // whole box
+    take(sort_temp_bytes(P));
+    return o + 256;
+}
+
+void bvh_build(hipStream_t s, int P, int32_t* nodes, float* aabbs, uint64_t* morton, void* temp)
+{
+    char* base = (char*)temp;
+    size_t o = 0;
+    auto take = [&](size_t b) { char* p = base + o; o = align_up(o + b, 256); return p; };
+    float* leaf_copy = (float*)take((size_t)P * 24);
+    uint64_t* k_in = (uint64_t*)take((size_t)P * 8);
+    uint64_t* k_out = (uint64_t*)take((size_t)P * 8);
+    uint32_t* v_in = (uint32_t*)take((size_t)P * 4);
+    uint32_t* v_out = (uint32_t*)take((size_t)P * 4);
+    int* flags = (int*)take((size_t)P * 4 + 4);
+    float* partial = (float*)take(1024 * 6 * 4);
+    float* whole = (float*)take(256);
+    void* sort_temp = (void*)take(sort_temp_bytes((size_t)P));
+
+    float* leaf = aabbs + 6 * (size_t)(P - 1);
+    const int nb = min(1024, (P + 255) / 256);
+    whole_box_partial_kernel<<<nb, 256, 0, s>>>(P, leaf, partial);
+    whole_box_final_kernel<<<1, 64, 0, s>>>(nb, partial, whole);
+    const int g = (P + 255) / 256;
+    morton_kernel<<<g, 256, 0, s>>>(P, leaf, whole, k_in, v_in, leaf_copy);
+    check_launch(s, false, "bvh morton");
+    sort_pairs(s, (size_t)P, k_in, v_in, k_out, v_out, 30, sort_temp, false);
+    scatter_leaves_kernel<<<g, 256, 0, s>>>(P, k_out, v_out, leaf_copy, aabbs, nodes, morton);
+    check_launch(s, false, "bvh scatter_leaves");
+    if (P > 1) {
+        internal_nodes_kernel<<<(P - 1 + 255) / 256, 256, 0, s>>>(P, morton, nodes);
+        check_launch(s, false, "bvh internal_nodes");
+        R3DG_HIP(hipMemsetAsync(flags, 0, (size_t)P * 4, s));
+        merge_boxes_kernel<<<g, 256, 0, s>>>(P, nodes, aabbs, flags);
+        check_launch(s, false, "bvh merge_boxes");
+    }
+}
+
+void bvh_trace_opacity(hipStream_t s, int num_rays, const int32_t* nodes, const float* aabbs, const float* rays_o,
+                       const float* rays_d, const float* means, const float* covs, const float* opac,
+                       const float* normals, int32_t* contributes, float* out, int* overflow)
+{
+    if (num_rays <= 0) return;
+    trace_opacity_kernel<<<(num_rays + 255) / 256, 256, 0, s>>>(num_rays, nodes, aabbs, rays_o, rays_d, means, covs,
+                                                               opac, normals, contributes, out, overflow);
+}
+
+}  // namespace r3dg

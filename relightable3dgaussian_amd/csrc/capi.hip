@@ -55,6 +55,11 @@ void launch_shade_backward(hipStream_t s, int P, int K, int M, const float* base
                            int He, int We, const float* tr, const float* visibility, const float* dirs,
                            const float* areas, const float* g_pbr, const float* g_diff, float* d_base, float* d_rough,
                            float* d_view, float* d_inc, float* d_env);
+size_t bvh_build_temp_bytes(size_t P);
+void bvh_build(hipStream_t s, int P, int32_t* nodes, float* aabbs, uint64_t* morton, void* temp);
+void bvh_trace_opacity(hipStream_t s, int num_rays, const int32_t* nodes, const float* aabbs, const float* rays_o,
+                       const float* rays_d, const float* means, const float* covs, const float* opac,
+                       const float* normals, int32_t* contributes, float* out, int* overflow);
 extern int g_fwd_ppl;
 extern int g_bwd_ppl;
 extern int g_bwd_dpp;
@@ -474,6 +479,41 @@ int r3dg_shade_backward(void* stream_, int P, int K, int M, const float* base_co
                               env_transform, visibility, incident_dirs, incident_areas, dL_dpbr, dL_ddiffuse_light,
                               dL_dbase_color, dL_droughness, dL_dviewdirs, dL_dincidents, dL_denv);
         check_launch(stream, false, "shade_backward");
+        t.stop();
+        return R3DG_OK;
+    });
+}
+
+size_t r3dg_bvh_build_temp_bytes(int P) { return bvh_build_temp_bytes((size_t)(P > 0 ? P : 0)); }
+
+int r3dg_bvh_build(void* stream_, int P, int32_t* nodes, float* aabbs, int64_t* morton, void* temp)
+{
+    if (P < 0) return invalid("bvh_build: bad P");
+    if (P == 0) return R3DG_OK;
+    if (!nodes || !aabbs || !morton || !temp) return invalid("bvh_build: null buffer");
+    return guarded([&]() -> int {
+        hipStream_t stream = (hipStream_t)stream_;
+        StageTimer t(stream, ST_BVH_BUILD);
+        bvh_build(stream, P, nodes, aabbs, (uint64_t*)morton, temp);
+        t.stop();
+        return R3DG_OK;
+    });
+}
+
+int r3dg_bvh_trace_opacity(void* stream_, int64_t num_rays, const int32_t* nodes, const float* aabbs,
+                           const float* rays_o, const float* rays_d, const float* means3D, const float* covs3D,
+                           const float* opacities, const float* normals, int32_t* num_contributes,
+                           float* rendered_opacity, int32_t* stack_overflow)
+{
+    if (num_rays < 0 || num_rays > 0x7fffffffll) return invalid("bvh_trace_opacity: bad ray count");
+    if (num_rays == 0) return R3DG_OK;
+    if (!stack_overflow) return invalid("bvh_trace_opacity: null overflow counter");
+    return guarded([&]() -> int {
+        hipStream_t stream = (hipStream_t)stream_;
+        StageTimer t(stream, ST_BVH_TRACE);
+        bvh_trace_opacity(stream, (int)num_rays, nodes, aabbs, rays_o, rays_d, means3D, covs3D, opacities, normals,
+                          num_contributes, rendered_opacity, stack_overflow);
+        check_launch(stream, false, "bvh_trace_opacity");
         t.stop();
         return R3DG_OK;
     });

@@ -173,3 +173,53 @@ def test_host_mirror_rejects_bad_inputs_without_gpu():
                                            torch.zeros(10, 1), torch.zeros(10, 3), torch.zeros(10, 4), 1.0,
                                            torch.Tensor([]), torch.eye(4), torch.eye(4), 1.0, 1.0, 8.0, 8.0, 16, 16,
                                            torch.zeros(10, 16, 3), 3, torch.zeros(3), False, True, False)
+
+
+# ---------------------------------------------------------------- BVH
+def test_leaf_boxes_match_reference_raytracer_init():
+    from oracle import bvh as ob
+    from relightable3dgaussian_amd import bvh as host_bvh
+    gd = _gold("bvh_leaf_reference.npz")
+    nodes, aabbs = ob.leaf_boxes(gd["means3D"], gd["scales"], gd["rotations"])
+    assert np.array_equal(nodes, gd["nodes_init"]) and np.array_equal(aabbs, gd["aabbs_init"])
+    n2, a2 = host_bvh.leaf_boxes(*(torch.from_numpy(gd[k]) for k in ("means3D", "scales", "rotations")))
+    assert np.array_equal(n2.numpy(), gd["nodes_init"]) and np.array_equal(a2.numpy(), gd["aabbs_init"])
+
+
+def _bvh_case(P, seed, K=8, dup=False):
+    from oracle import bvh as ob, shading
+    from oracle.torch_rasterizer import cov3d_from_scale_rot
+    from relightable3dgaussian_amd import synthetic as syn
+    sc = syn.make_scene(P=max(P, 4), seed=seed, scale_log_mean=-3.2)
+    sc = {k: (v[:P] if torch.is_tensor(v) and v.shape[0] >= P and k != "env" else v) for k, v in sc.items()}
+    if dup and P > 10:                       # coincident Gaussians -> identical Morton codes (tie-break on index)
+        sc["xyz"][P // 2:P // 2 + 5] = sc["xyz"][0]
+        sc["scales"][P // 2:P // 2 + 5] = sc["scales"][0]
+        sc["rotations"][P // 2:P // 2 + 5] = sc["rotations"][0]
+    dirs, _ = shading.fibonacci_sphere_sampling(sc["normal"], K)
+    cinv = cov3d_from_scale_rot(1 / sc["scales"], 1.0, sc["rotations"]).contiguous()
+    rays_o = (sc["xyz"][:, None, :] + 0.05 * dirs).contiguous()
+    return sc, dirs.contiguous(), cinv, rays_o
+
+
+def test_bvh_oracle_tree_is_wellformed_and_trace_equals_bruteforce():
+    from oracle import bvh as ob
+    for P, seed, dup in ((1, 0, False), (2, 1, False), (3, 2, False), (1500, 3, True)):
+        sc, dirs, cinv, rays_o = _bvh_case(P, seed, dup=dup)
+        nodes, aabbs = ob.leaf_boxes(sc["xyz"].numpy(), sc["scales"].numpy(), sc["rotations"].numpy())
+        n2, a2, m = ob.create_bvh(nodes, aabbs)
+        assert n2[0, 0] == -1 and n2[0, 4] == P and (np.diff(m.astype(np.int64)) > 0).all()
+        if P > 1:
+            for i in range(P - 1):          # parent links, box containment, leaf counts
+                l, r = n2[i, 1], n2[i, 2]
+                assert n2[l, 0] == i and n2[r, 0] == i and n2[i, 4] == n2[l, 4] + n2[r, 4]
+                assert (a2[i, :3] <= np.minimum(a2[l, :3], a2[r, :3])).all() and (a2[i, 3:] >= np.maximum(a2[l, 3:], a2[r, 3:])).all()
+        assert sorted(n2[P - 1:, 3].tolist()) == list(range(P))
+        args = (n2, a2, rays_o.numpy(), dirs.numpy(), sc["xyz"].numpy(), cinv.numpy(), sc["opacity"][:, 0].numpy(),
+                sc["normal"].numpy())
+        cnt, vis = ob.trace_bvh_opacity(*args)
+        cb, prod = ob.trace_bruteforce(*args)
+        want = np.where(prod < 0.9, 0.0, prod)
+        near = np.abs(prod - 0.9) < 1e-5
+        assert np.abs(vis - want)[~near].max() < 1e-5
+        assert np.array_equal(cnt[vis > 0], cb[vis > 0])
