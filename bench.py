@@ -36,6 +36,7 @@ def parse():
     ap.add_argument("--cpu-baseline-seconds", type=float, default=20.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--relight-frames", type=int, default=20)
+    ap.add_argument("--relight-samples", type=int, default=384)
     return ap.parse_args()
 
 

@@ -125,6 +125,73 @@ def cpu_baseline(scene, cam, S, budget_s):
                        "fwd %.1fs + bwd %.1fs)" % (W, H, P, out[0], S, t_f, t_b))
 
 
+def env_background(cam, envmap):
+    """Per-pixel environment colour (Camera.get_world_directions cameras.py:79-91 + EnvLight.direct_light
+    envmap.py:35-53) as plain torch ops."""
+    H, W = cam.image_height, cam.image_width
+    dev = envmap.device
+    fx, fy = W / (2 * cam.tanfovx), H / (2 * cam.tanfovy)
+    v, u = torch.meshgrid(torch.arange(H, device=dev), torch.arange(W, device=dev), indexing="ij")
+    d = torch.stack([(u - cam.cx) / fx, (v - cam.cy) / fy, torch.ones_like(u, dtype=torch.float32)], 0)
+    d = torch.nn.functional.normalize(d, dim=0)
+    c2w_rot = cam.world_view_transform[:3, :3]            # (W2C^T)[:3,:3] = R_w2c^T = R_c2w
+    d = (c2w_rot @ d.reshape(3, -1)).t()
+    phi = torch.arccos(d[:, 2].clamp(-1, 1)) - 1e-6
+    theta = torch.atan2(d[:, 1], d[:, 0])
+    grid = torch.stack((-theta / math.pi, (phi / math.pi) * 2 - 1), -1)[None, None]
+    col = torch.nn.functional.grid_sample(envmap.permute(2, 0, 1)[None], grid, align_corners=True)
+    return col[0, :, 0].reshape(3, H, W)
+
+
+@torch.no_grad()
+def relight_bench(params, cams, dev, frames, K):
+    """Relight / eval rendering (relighting.py:114-170, neilf.py:98-130 eval branch): per frame the shading integral at
+    K samples under a fixed HDR environment map + rasterize forward with the S=28 eval feature row + env background."""
+    from . import train_step
+    from .shading_ops import shade
+    g = torch.Generator().manual_seed(7)
+    envmap = (3.0 * torch.rand(256, 512, 3, generator=g) ** 2).to(dev)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    vis, dirs, areas, tracer = train_step.update_visibility(params.xyz, params.get_scaling(), params.get_rotation(),
+                                                            params.get_opacity(), params.get_normal(), K)
+    torch.cuda.synchronize()
+    t_vis = time.perf_counter() - t0
+    base_color = 0.03 + 0.77 * torch.sigmoid(params.base_color)
+    roughness = 0.09 + 0.9 * torch.sigmoid(params.roughness)
+    normal = params.get_normal()
+    incidents = torch.cat([params.incidents_dc, params.incidents_rest], 1)
+    bg = torch.zeros(3, device=dev)
+    opacity_a, shs, scales, rot = params.get_opacity(), params.get_shs(), params.get_scaling(), params.get_rotation()
+
+    def frame(cam):
+        viewdirs = torch.nn.functional.normalize(cam.camera_center - params.xyz, dim=-1)
+        pbr, diffuse, rest = shade(base_color, roughness, normal, viewdirs, incidents, envmap, vis, dirs, areas)
+        xyz_h = torch.cat([params.xyz, torch.ones_like(params.xyz[:, :1])], -1)
+        depths = (xyz_h @ cam.world_view_transform)[:, 2:3]
+        feats = torch.cat([depths, depths.square(), pbr, normal, base_color, roughness, diffuse, rest], -1)   # S = 28
+        outs = GaussianRasterizer(raster_settings(cam, bg))(params.xyz, torch.zeros_like(params.xyz), opacity_a,
+                                                            shs=shs, scales=scales, rotations=rot, features=feats)
+        _, n_contrib, image, opacity, depth, feature, pn, sxyz, weights, radii = outs
+        feat = feature / opacity.clamp_min(1e-5) * (n_contrib > 0)
+        pbr_img = feat[2:5]
+        env_rgb = env_background(cam, envmap)
+        return pbr_img * opacity + (1 - opacity) * env_rgb
+
+    for i in range(3):
+        frame(cams[i])
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(frames):
+        frame(cams[(3 + i) % len(cams)])
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    P = params.xyz.shape[0]
+    return dict(relight_fps=round(frames / dt, 2), relight_ms_per_frame=round(1e3 * dt / frames, 3), relight_K=K,
+                relight_features=28, visibility_rays=P * K, visibility_seconds=round(t_vis, 3),
+                visibility_Mrays_per_s=round(P * K / t_vis / 1e6, 1))
+
+
 def run(args):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -162,8 +229,10 @@ def run(args):
             gts[v] = render_stage1(teacher, cams[v], bg)[2].clone()
         del teacher
     gt_views = list(gts.keys())
-    grad_numel = sum(p.numel() for p in params.parameters())
-    flat = torch.zeros(grad_numel, device=dev) if world > 1 else None
+    reducer = None
+    if world > 1:
+        from . import dp
+        reducer = dp.GradAllReducer(params.parameters())     # bucketed async all-reduce, overlaps the backward tail
 
     R_seen = []
 
@@ -177,22 +246,13 @@ def run(args):
             loss = loss_stage1(outs, gts[v])
         R_seen.append(outs[0])
         loss.backward()
-        if world > 1:
-            # one bucketed all-reduce of every per-Gaussian gradient
-            off = 0
-            for p in params.parameters():
-                n = p.numel()
-                flat[off:off + n].copy_(p.grad.reshape(-1))
-                off += n
-            dist.all_reduce(flat)
-            flat.div_(world)
-            off = 0
-            for p in params.parameters():
-                n = p.numel()
-                p.grad.copy_(flat[off:off + n].view_as(p.grad))
-                off += n
+        if reducer is not None:
+            reducer.finish()
         opt.step()
-        opt.zero_grad(set_to_none=False)
+        if reducer is not None:
+            reducer.zero_grad()
+        else:
+            opt.zero_grad(set_to_none=False)
         return loss
 
     for i in range(args.warmup):
@@ -219,6 +279,11 @@ def run(args):
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    relight = None
+    if stage2 and args.relight_frames > 0 and rank == 0:
+        step_fn.visibility = step_fn.incident_dirs = step_fn.incident_areas = None   # free the K=train caches
+        torch.cuda.empty_cache()
+        relight = relight_bench(params, cams, dev, args.relight_frames, args.relight_samples)
     result = None
     if rank == 0:
         P, N = args.points, args.res * args.res
@@ -254,9 +319,11 @@ def run(args):
                                    "1 view/rank/step, %d Gaussians, %dx%d, num_rendered~%.0f" % (
                                        args.stage, "shading fwd/bwd (K=%d) + " % args.sample_num if stage2 else "", S,
                                        P, args.res, args.res, R_mean),
-                       "parallelism": "dp%d (views sharded, 1 all-reduce of per-Gaussian grads/step)" % world},
+                       "parallelism": "dp%d (views sharded over ranks; bucketed async RCCL all-reduce of per-Gaussian grads)" % world},
             "roofline": roofline, "kernels": kernels,
         }
+        if relight is not None:
+            result["relight"] = relight
         if not args.no_cpu_baseline and world == 1:
             try:
                 result["cpu_baseline"] = cpu_baseline(scene, cams_cpu[0], S, args.cpu_baseline_seconds)

@@ -1,0 +1,111 @@
+"""Stage-2 (neilf) hot-path step, restating the op-level content of the reference's training iteration without its
+dataset / logging machinery:
+    GaussianModel.update_visibility      scene/gaussian_model.py:312-342   (BVH build + K rays per Gaussian, once)
+    render_view (is_training=True)       gaussian_renderer/neilf.py:15-209 (shading -> S=16 feature row -> rasterize)
+    calculate_loss (core terms)          gaussian_renderer/neilf.py:212-318
+Everything heavy runs in the HIP ops; the glue is plain PyTorch on the same stream."""
+import math
+
+import torch
+import torch.nn.functional as F
+
+from . import sampling
+from .bvh import RayTracer
+from .rasterizer import GaussianRasterizationSettings, GaussianRasterizer
+from .shading_ops import shade
+
+
+def inverse_covariance(scales, rotations):
+    """get_inverse_covariance (gaussian_model.py:257-260): R diag(1/s)^2 R^T as the 6-vector."""
+    q = F.normalize(rotations)
+    r, x, y, z = q[:, 0], q[:, 1], q[:, 2], q[:, 3]
+    R = torch.stack([1 - 2 * (y * y + z * z), 2 * (x * y - r * z), 2 * (x * z + r * y),
+                     2 * (x * y + r * z), 1 - 2 * (x * x + z * z), 2 * (y * z - r * x),
+                     2 * (x * z - r * y), 2 * (y * z + r * x), 1 - 2 * (x * x + y * y)], -1).reshape(-1, 3, 3)
+    L = R * (1.0 / scales)[:, None, :]
+    S = L @ L.transpose(1, 2)
+    return torch.stack([S[:, 0, 0], S[:, 0, 1], S[:, 0, 2], S[:, 1, 1], S[:, 1, 2], S[:, 2, 2]], -1).contiguous()
+
+
+@torch.no_grad()
+def update_visibility(xyz, scales, rotations, opacity, normal, sample_num):
+    """-> (visibility[P,K,1], incident_dirs[P,K,3], incident_areas[P,K,1]); chunked like the reference
+    (chunk = P // ((K-1)//24 + 1)) so the transient [chunk,K,3] ray tensors stay bounded."""
+    tracer = RayTracer(xyz, scales, rotations)
+    cinv = inverse_covariance(scales, rotations)
+    op = opacity[:, 0].contiguous()
+    P = xyz.shape[0]
+    chunk = max(1, P // ((sample_num - 1) // 24 + 1))
+    vis, dirs_all, areas_all = [], [], []
+    for off in range(0, P, chunk):
+        dirs, areas = sampling.fibonacci_sphere_sampling(normal[off:off + chunk], sample_num)
+        res = tracer.trace_visibility(xyz[off:off + chunk, None].expand_as(dirs), dirs, xyz, cinv, op, normal)
+        vis.append(res["visibility"])
+        dirs_all.append(dirs)
+        areas_all.append(areas)
+    return torch.cat(vis, 0), torch.cat(dirs_all, 0), torch.cat(areas_all, 0), tracer
+
+
+def tv_loss(x):
+    return (x[:, 1:] - x[:, :-1]).abs().mean() + (x[:, :, 1:] - x[:, :, :-1]).abs().mean()
+
+
+class Stage2Step:
+    def __init__(self, params, scene, device, sample_num):
+        self.p = params
+        self.K = sample_num
+        with torch.no_grad():
+            self.visibility, self.incident_dirs, self.incident_areas, self.tracer = update_visibility(
+                params.xyz.detach(), params.get_scaling().detach(), params.get_rotation().detach(),
+                params.get_opacity().detach(), params.get_normal().detach(), sample_num)
+        self.P = params.xyz.shape[0]
+
+    def render(self, cam, bg):
+        p = self.p
+        means3D = p.xyz
+        means2D = torch.zeros_like(means3D, requires_grad=True)
+        base_color = 0.03 + 0.77 * torch.sigmoid(p.base_color)          # gaussian_model.py:51
+        roughness = 0.09 + 0.9 * torch.sigmoid(p.roughness)             # gaussian_model.py:52
+        normal = p.get_normal()
+        incidents = torch.cat([p.incidents_dc, p.incidents_rest], 1)
+        viewdirs = F.normalize(cam.camera_center - means3D, dim=-1)
+        env = F.softplus(p.env)[0]                                       # DirectLightMap.get_env
+        pbr, diffuse_light, rest = shade(base_color, roughness, normal.detach(), viewdirs, incidents, env,
+                                         self.visibility, self.incident_dirs, self.incident_areas)
+        xyz_h = torch.cat([means3D, torch.ones_like(means3D[:, :1])], -1)
+        depths = (xyz_h @ cam.world_view_transform)[:, 2:3]
+        features = torch.cat([depths, depths.square(), pbr, normal, base_color, roughness, diffuse_light,
+                              rest[:, 12:13]], -1)                        # S = 16 (neilf.py:120-122)
+        rs = GaussianRasterizationSettings(cam.image_height, cam.image_width, cam.tanfovx, cam.tanfovy, cam.cx, cam.cy,
+                                           bg, 1.0, cam.world_view_transform, cam.full_proj_transform, 3,
+                                           cam.camera_center, False, True, True, False)
+        outs = GaussianRasterizer(rs)(means3D, means2D, p.get_opacity(), shs=p.get_shs(), scales=p.get_scaling(),
+                                      rotations=p.get_rotation(), features=features)
+        return outs, diffuse_light, env
+
+    def __call__(self, cam, bg, gt):
+        outs, diffuse_light, env = self.render(cam, bg)
+        num_rendered, n_contrib, image, opacity, depth, feature, pseudo_normal, xyz, weights, radii = outs
+        mask = n_contrib > 0
+        feat = feature / opacity.clamp_min(1e-5) * mask
+        r_depth, r_depth2, r_pbr, r_normal, r_base, r_rough, r_diffuse, r_vis = feat.split([1, 1, 3, 3, 3, 1, 3, 1], 0)
+        pbr_img = r_pbr * opacity + (1 - opacity) * bg[:, None, None]
+        pbr_srgb = torch.where(pbr_img <= 0.0031308, 12.92 * pbr_img,
+                               1.055 * pbr_img.clamp_min(0.0031308) ** (1 / 2.4) - 0.055)
+        loss = (image - gt).abs().mean() + 1.0 * (pbr_srgb - gt).abs().mean()                      # l1 + lambda_pbr l1
+        loss = loss + 0.01 * F.mse_loss(r_normal, pseudo_normal.detach())                            # normal_render_depth
+        mean_light = diffuse_light.mean(-1, keepdim=True).expand_as(diffuse_light)
+        loss = loss + 0.01 * F.l1_loss(diffuse_light, mean_light)                                    # lambda_light
+        loss = loss + 0.01 * tv_loss(env.permute(2, 0, 1))                                           # lambda_env_smooth
+        return loss, outs
+
+    # --- roofline bookkeeping for bench.py (live model fwd (260+16K) B, bwd (476+16K) B per Gaussian)
+    def stage_names(self):
+        return ("shade_forward", "shade_backward")
+
+    def algorithmic_bytes(self, name):
+        per = (260.0 + 16 * self.K) if name == "shade_forward" else (476.0 + 16 * self.K)
+        return per * self.P
+
+    def profile(self):
+        return {}
