@@ -110,6 +110,35 @@ int r3dg_shade_backward(void* stream, int P, int K, int M, const float* d_base_c
                         const float* d_dL_ddiffuse_light, float* d_dL_dbase_color, float* d_dL_droughness,
                         float* d_dL_dviewdirs, float* d_dL_dincidents, float* d_dL_denv);
 
+/* The reference's render_equation.{cu,h} contract model (render_equation.h:7-46): metallic BRDF with a spherical-
+ * Gaussian D, SH environment light direct_shs[Sd,3] (+0.5), SH visibility visibility_shs[P,Sv] (+0.5, clamped), SH local
+ * light incidents_shs[P,Si,3]; rays are the Fibonacci set rotated to the normal (no 10-degree floor), optionally with
+ * a per-sample random angle rand_float[P,K] in [0,1) (is_training; NULL otherwise).  Backward: dL_dbase_color[P,3],
+ * dL_droughness[P], dL_dmetallic[P], dL_dnormals[P,3], dL_dviewdirs[P,3], dL_dincidents_shs[P,Si,3],
+ * dL_dvisibility_shs[P,Sv] are overwritten, dL_ddirect_shs[Sd,3] is ACCUMULATED (zero it first).  The backward keeps
+ * the reference's quirks Q1-Q4 (see oracle/shading_oracle.c) and replaces its race on dL_ddirect_shs by the sum. */
+int r3dg_render_equation_forward(void* stream, int P, int Si, int Sd, int Sv, const float* d_base_color,
+                                 const float* d_roughness, const float* d_metallic, const float* d_normals,
+                                 const float* d_viewdirs, const float* d_incidents_shs, const float* d_direct_shs,
+                                 const float* d_visibility_shs, int sample_num, const float* d_rand_float,
+                                 float* d_incident_dirs, float* d_pbr, float* d_diffuse_light);
+int r3dg_render_equation_forward_complex(void* stream, int P, int Si, int Sd, int Sv, const float* d_base_color,
+                                         const float* d_roughness, const float* d_metallic, const float* d_normals,
+                                         const float* d_viewdirs, const float* d_incidents_shs,
+                                         const float* d_direct_shs, const float* d_visibility_shs, int sample_num,
+                                         float* d_incident_dirs, float* d_pbr, float* d_incident_lights,
+                                         float* d_local_incident_lights, float* d_global_incident_lights,
+                                         float* d_incident_visibility, float* d_diffuse_light,
+                                         float* d_local_diffuse_light, float* d_accum, float* d_rgb_d, float* d_rgb_s);
+int r3dg_render_equation_backward(void* stream, int P, int Si, int Sd, int Sv, const float* d_base_color,
+                                  const float* d_roughness, const float* d_metallic, const float* d_normals,
+                                  const float* d_viewdirs, const float* d_incidents_shs, const float* d_direct_shs,
+                                  const float* d_visibility_shs, int sample_num, const float* d_incident_dirs,
+                                  const float* d_dL_dpbr, const float* d_dL_ddiffuse_light, float* d_dL_dbase_color,
+                                  float* d_dL_droughness, float* d_dL_dmetallic, float* d_dL_dnormals,
+                                  float* d_dL_dviewdirs, float* d_dL_dincidents_shs, float* d_dL_ddirect_shs,
+                                  float* d_dL_dvisibility_shs);
+
 /* LBVH over per-Gaussian leaf boxes + visibility trace (reference bvh/include/bvh.h:5-18).
  * r3dg_bvh_build: d_nodes int32[2P-1,5] = (parent,left,right,object_id,leaf_count) and d_aabbs float[2P-1,6] =
  *   (lower xyz, upper xyz) arrive initialised as bvh/__init__.py:31-57 prepares them (nodes -1, counts 0 internal /

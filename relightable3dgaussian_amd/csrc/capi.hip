@@ -55,6 +55,17 @@ void launch_shade_backward(hipStream_t s, int P, int K, int M, const float* base
                            int He, int We, const float* tr, const float* visibility, const float* dirs,
                            const float* areas, const float* g_pbr, const float* g_diff, float* d_base, float* d_rough,
                            float* d_view, float* d_inc, float* d_env);
+void launch_re_forward(hipStream_t s, bool complex_, int P, int Si, int Sd, int Sv, const float* base_color,
+                       const float* roughness, const float* metallic, const float* normals, const float* viewdirs,
+                       const float* inc, const float* direct, const float* vis, int K, const float* rand_float,
+                       float* incident_dirs, float* out_pbr, float* out_lights, float* out_local, float* out_global,
+                       float* out_vis, float* out_diffuse, float* out_local_diffuse, float* out_accum, float* out_rgb_d,
+                       float* out_rgb_s);
+void launch_re_backward(hipStream_t s, int P, int Si, int Sd, int Sv, const float* base_color, const float* roughness,
+                        const float* metallic, const float* normals, const float* viewdirs, const float* inc,
+                        const float* direct, const float* vis, int K, const float* incident_dirs, const float* dL_dpbr,
+                        const float* dL_ddl, float* dL_dbase, float* dL_drough, float* dL_dmetal, float* dL_dnormals,
+                        float* dL_dviewdirs, float* dL_dinc, float* dL_ddirect, float* dL_dvis);
 size_t bvh_build_temp_bytes(size_t P);
 void bvh_build(hipStream_t s, int P, int32_t* nodes, float* aabbs, uint64_t* morton, void* temp);
 void bvh_trace_opacity(hipStream_t s, int num_rays, const int32_t* nodes, const float* aabbs, const float* rays_o,
@@ -480,6 +491,74 @@ int r3dg_shade_backward(void* stream_, int P, int K, int M, const float* base_co
                               dL_dbase_color, dL_droughness, dL_dviewdirs, dL_dincidents, dL_denv);
         check_launch(stream, false, "shade_backward");
         t.stop();
+        return R3DG_OK;
+    });
+}
+
+static int re_check(int P, int Si, int Sd, int Sv, int K)
+{
+    if (P < 0 || K <= 0) return invalid("render_equation: bad P/sample_num");
+    if (Si < 0 || Si > 16 || Sd < 0 || Sd > 16 || Sv < 0 || Sv > 16)
+        return invalid("render_equation: SH coefficient counts must be in [0,16]");
+    return R3DG_OK;
+}
+
+int r3dg_render_equation_forward(void* stream_, int P, int Si, int Sd, int Sv, const float* base_color,
+                                 const float* roughness, const float* metallic, const float* normals,
+                                 const float* viewdirs, const float* incidents_shs, const float* direct_shs,
+                                 const float* visibility_shs, int sample_num, const float* rand_float,
+                                 float* incident_dirs, float* pbr, float* diffuse_light)
+{
+    if (int e = re_check(P, Si, Sd, Sv, sample_num)) return e;
+    if (P == 0) return R3DG_OK;
+    return guarded([&]() -> int {
+        hipStream_t stream = (hipStream_t)stream_;
+        launch_re_forward(stream, false, P, Si, Sd, Sv, base_color, roughness, metallic, normals, viewdirs, incidents_shs,
+                          direct_shs, visibility_shs, sample_num, rand_float, incident_dirs, pbr, nullptr, nullptr,
+                          nullptr, nullptr, diffuse_light, nullptr, nullptr, nullptr, nullptr);
+        check_launch(stream, false, "render_equation_forward");
+        return R3DG_OK;
+    });
+}
+
+int r3dg_render_equation_forward_complex(void* stream_, int P, int Si, int Sd, int Sv, const float* base_color,
+                                         const float* roughness, const float* metallic, const float* normals,
+                                         const float* viewdirs, const float* incidents_shs, const float* direct_shs,
+                                         const float* visibility_shs, int sample_num, float* incident_dirs, float* pbr,
+                                         float* incident_lights, float* local_incident_lights,
+                                         float* global_incident_lights, float* incident_visibility, float* diffuse_light,
+                                         float* local_diffuse_light, float* accum, float* rgb_d, float* rgb_s)
+{
+    if (int e = re_check(P, Si, Sd, Sv, sample_num)) return e;
+    if (P == 0) return R3DG_OK;
+    return guarded([&]() -> int {
+        hipStream_t stream = (hipStream_t)stream_;
+        launch_re_forward(stream, true, P, Si, Sd, Sv, base_color, roughness, metallic, normals, viewdirs, incidents_shs,
+                          direct_shs, visibility_shs, sample_num, nullptr, incident_dirs, pbr, incident_lights,
+                          local_incident_lights, global_incident_lights, incident_visibility, diffuse_light,
+                          local_diffuse_light, accum, rgb_d, rgb_s);
+        check_launch(stream, false, "render_equation_forward_complex");
+        return R3DG_OK;
+    });
+}
+
+int r3dg_render_equation_backward(void* stream_, int P, int Si, int Sd, int Sv, const float* base_color,
+                                  const float* roughness, const float* metallic, const float* normals,
+                                  const float* viewdirs, const float* incidents_shs, const float* direct_shs,
+                                  const float* visibility_shs, int sample_num, const float* incident_dirs,
+                                  const float* dL_dpbr, const float* dL_ddiffuse_light, float* dL_dbase_color,
+                                  float* dL_droughness, float* dL_dmetallic, float* dL_dnormals, float* dL_dviewdirs,
+                                  float* dL_dincidents_shs, float* dL_ddirect_shs, float* dL_dvisibility_shs)
+{
+    if (int e = re_check(P, Si, Sd, Sv, sample_num)) return e;
+    if (P == 0) return R3DG_OK;
+    return guarded([&]() -> int {
+        hipStream_t stream = (hipStream_t)stream_;
+        launch_re_backward(stream, P, Si, Sd, Sv, base_color, roughness, metallic, normals, viewdirs, incidents_shs,
+                           direct_shs, visibility_shs, sample_num, incident_dirs, dL_dpbr, dL_ddiffuse_light,
+                           dL_dbase_color, dL_droughness, dL_dmetallic, dL_dnormals, dL_dviewdirs, dL_dincidents_shs,
+                           dL_ddirect_shs, dL_dvisibility_shs);
+        check_launch(stream, false, "render_equation_backward");
         return R3DG_OK;
     });
 }

@@ -13,116 +13,11 @@
 //     log2(NV) exchange levels lane l holds the wave total of channel chan(l), so the whole 10+S-vector costs
 //     ~NV shuffles (not 6*NV) and leaves as ONE atomic instruction with 10+S active lanes per (wave, Gaussian).
 #include "common.hpp"
+#include "wave_reduce.hpp"
 
 namespace r3dg {
 
 __device__ __forceinline__ float fast_exp_b(float x) { return __builtin_amdgcn_exp2f(x * 1.4426950408889634f); }
-
-template <int N>
-struct Log2 {
-    static constexpr int value = 1 + Log2<N / 2>::value;
-};
-template <>
-struct Log2<1> {
-    static constexpr int value = 0;
-};
-
-// ---- transposing wave reduction ---------------------------------------------------------------------------
-// Input: N (power of two, 16..64) partial values per lane.  Output: every lane holds the 64-lane total of ONE
-// channel, chan(lane) = sum_t bit_{5-t}(lane) * (N >> (t+1)), t < log2 N.  Exchange levels run at lane distance
-// 32,16,8,4,2,1: at each transposing level a pair of lanes (l, l^d) splits the remaining channels -- the lane with
-// bit d clear keeps the lower half, the other the upper half -- so the live value count halves every level
-// (N/2 + N/4 + ... exchanges instead of 6*N).  gfx950 specifics: distance 32/16 use v_permlane32_swap /
-// v_permlane16_swap (swap half-waves / odd-even rows of two registers: exchange + select in ONE instruction),
-// distance 8/4 use two bank-masked row_shl/row_shr DPP moves, distance 2/1 a quad_perm DPP move.  Everything
-// stays in the VALU; no LDS-crossbar (ds_bpermute) traffic and no long-latency results to keep live.
-template <int N>
-__device__ __forceinline__ int transposed_channel(int lane)
-{
-    int idx = 0;
-#pragma unroll
-    for (int t = 0; t < Log2<N>::value; t++)
-        if (lane & (32 >> t)) idx += N >> (t + 1);
-    return idx;
-}
-// true for the one lane per channel that owns the result (low, non-transposed lane bits are zero)
-template <int N>
-__device__ __forceinline__ bool transposed_owner(int lane)
-{
-    return (lane & ((64 / N) - 1)) == 0;
-}
-
-template <int D>
-__device__ __forceinline__ float lane_xor_dpp(float x)
-{
-    const int xi = __float_as_int(x);
-    int r;
-    if constexpr (D == 1) r = __builtin_amdgcn_update_dpp(0, xi, 0xB1, 0xF, 0xF, false);        // quad_perm [1,0,3,2]
-    else if constexpr (D == 2) r = __builtin_amdgcn_update_dpp(0, xi, 0x4E, 0xF, 0xF, false);   // quad_perm [2,3,0,1]
-    else if constexpr (D == 4) {
-        r = __builtin_amdgcn_update_dpp(0, xi, 0x104, 0xF, 0x5, false);   // banks 0,2 read lane+4 (row_shl:4)
-        r = __builtin_amdgcn_update_dpp(r, xi, 0x114, 0xF, 0xA, false);   // banks 1,3 read lane-4 (row_shr:4)
-    } else {
-        static_assert(D == 8, "DPP xor distance");
-        r = __builtin_amdgcn_update_dpp(0, xi, 0x108, 0xF, 0x3, false);   // banks 0,1 read lane+8
-        r = __builtin_amdgcn_update_dpp(r, xi, 0x118, 0xF, 0xC, false);   // banks 2,3 read lane-8
-    }
-    return __int_as_float(r);
-}
-
-template <int D, bool DPP>
-__device__ __forceinline__ float lane_xor(float x)
-{
-    if constexpr (DPP && D <= 8) return lane_xor_dpp<D>(x);
-    else return __shfl_xor(x, D, 64);
-}
-
-// one transposing exchange of the pair (lo-half value a, hi-half value b) at lane distance D
-template <int D, bool DPP>
-__device__ __forceinline__ float transpose_step(float a, float b, bool hi)
-{
-    if constexpr (DPP && D == 32) {
-        auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(a), __float_as_uint(b), false, false);
-        return __uint_as_float(r[0]) + __uint_as_float(r[1]);
-    } else if constexpr (DPP && D == 16) {
-        auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(a), __float_as_uint(b), false, false);
-        return __uint_as_float(r[0]) + __uint_as_float(r[1]);
-    } else {
-        const float send = hi ? a : b;
-        const float keep = hi ? b : a;
-        return keep + lane_xor<D, DPP>(send);
-    }
-}
-
-template <int N, int LVL, bool DPP>
-__device__ __forceinline__ void transpose_level(float (&v)[N], int lane)
-{
-    constexpr int D = 32 >> LVL;
-    constexpr int half = N >> (LVL + 1);
-    const bool hi = (lane & D) != 0;
-#pragma unroll
-    for (int k = 0; k < half; k++) v[k] = transpose_step<D, DPP>(v[k], v[k + half], hi);
-}
-
-template <int N, bool DPP>
-__device__ __forceinline__ float transpose_reduce(float (&v)[N])
-{
-    const int lane = lane_id();
-    constexpr int L = Log2<N>::value;
-    if constexpr (L > 0) transpose_level<N, 0, DPP>(v, lane);
-    if constexpr (L > 1) transpose_level<N, 1, DPP>(v, lane);
-    if constexpr (L > 2) transpose_level<N, 2, DPP>(v, lane);
-    if constexpr (L > 3) transpose_level<N, 3, DPP>(v, lane);
-    if constexpr (L > 4) transpose_level<N, 4, DPP>(v, lane);
-    if constexpr (L > 5) transpose_level<N, 5, DPP>(v, lane);
-    float r = v[0];
-    // remaining (non-transposing) distances: plain butterfly adds
-    if constexpr (L <= 2) r += lane_xor<8, DPP>(r);
-    if constexpr (L <= 3) r += lane_xor<4, DPP>(r);
-    if constexpr (L <= 4) r += lane_xor<2, DPP>(r);
-    if constexpr (L <= 5) r += lane_xor<1, DPP>(r);
-    return r;
-}
 
 // self-test kernel: out[lane] = transpose_reduce of in[lane*N + k]; host compares against a plain sum
 template <int N, bool DPP>

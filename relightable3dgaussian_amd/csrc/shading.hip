@@ -13,6 +13,7 @@
 //   * the K-mean of the 19 forward outputs / the 55 per-Gaussian gradients (48 SH + 3 albedo + 1 roughness +
 //     3 view direction) is a transposing wave reduction (see rasterizer_render_bwd.hip) ending in one store.
 #include "common.hpp"
+#include "wave_reduce.hpp"
 
 namespace r3dg {
 
@@ -20,91 +21,6 @@ constexpr float kPi = 3.14159265358979323846f;
 constexpr int SHADE_WAVES = 4;               // Gaussians in flight per block
 constexpr int ENV_LDS_MAX = 12288;           // floats (48 KB) -- larger maps are sampled from global/L2
 constexpr int SHADE_NOUT = 19;               // pbr3 diffuse3 specular3 lights3 local3 global3 vis1
-
-// ---- transposing wave reduction (same scheme as the rasterizer backward) ----
-template <int N>
-struct SLog2 {
-    static constexpr int value = 1 + SLog2<N / 2>::value;
-};
-template <>
-struct SLog2<1> {
-    static constexpr int value = 0;
-};
-template <int D>
-__device__ __forceinline__ float s_lane_xor(float x)
-{
-    const int xi = __float_as_int(x);
-    int r;
-    if constexpr (D == 1) r = __builtin_amdgcn_update_dpp(0, xi, 0xB1, 0xF, 0xF, false);
-    else if constexpr (D == 2) r = __builtin_amdgcn_update_dpp(0, xi, 0x4E, 0xF, 0xF, false);
-    else if constexpr (D == 4) {
-        r = __builtin_amdgcn_update_dpp(0, xi, 0x104, 0xF, 0x5, false);
-        r = __builtin_amdgcn_update_dpp(r, xi, 0x114, 0xF, 0xA, false);
-    } else if constexpr (D == 8) {
-        r = __builtin_amdgcn_update_dpp(0, xi, 0x108, 0xF, 0x3, false);
-        r = __builtin_amdgcn_update_dpp(r, xi, 0x118, 0xF, 0xC, false);
-    } else {
-        return __shfl_xor(x, D, 64);
-    }
-    return __int_as_float(r);
-}
-template <int D>
-__device__ __forceinline__ float s_transpose_step(float a, float b, bool hi)
-{
-    if constexpr (D == 32) {
-        auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(a), __float_as_uint(b), false, false);
-        return __uint_as_float(r[0]) + __uint_as_float(r[1]);
-    } else if constexpr (D == 16) {
-        auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(a), __float_as_uint(b), false, false);
-        return __uint_as_float(r[0]) + __uint_as_float(r[1]);
-    } else {
-        const float send = hi ? a : b;
-        const float keep = hi ? b : a;
-        return keep + s_lane_xor<D>(send);
-    }
-}
-template <int N, int LVL>
-__device__ __forceinline__ void s_transpose_level(float (&v)[N], int lane)
-{
-    constexpr int D = 32 >> LVL;
-    constexpr int half = N >> (LVL + 1);
-    const bool hi = (lane & D) != 0;
-#pragma unroll
-    for (int k = 0; k < half; k++) v[k] = s_transpose_step<D>(v[k], v[k + half], hi);
-}
-// every lane returns the wave total of channel chan(lane) = sum_t bit_{5-t}(lane) * (N >> (t+1))
-template <int N>
-__device__ __forceinline__ float s_transpose_reduce(float (&v)[N])
-{
-    const int lane = lane_id();
-    constexpr int L = SLog2<N>::value;
-    if constexpr (L > 0) s_transpose_level<N, 0>(v, lane);
-    if constexpr (L > 1) s_transpose_level<N, 1>(v, lane);
-    if constexpr (L > 2) s_transpose_level<N, 2>(v, lane);
-    if constexpr (L > 3) s_transpose_level<N, 3>(v, lane);
-    if constexpr (L > 4) s_transpose_level<N, 4>(v, lane);
-    if constexpr (L > 5) s_transpose_level<N, 5>(v, lane);
-    float r = v[0];
-    if constexpr (L <= 2) r += s_lane_xor<8>(r);
-    if constexpr (L <= 3) r += s_lane_xor<4>(r);
-    if constexpr (L <= 4) r += s_lane_xor<2>(r);
-    if constexpr (L <= 5) r += s_lane_xor<1>(r);
-    return r;
-}
-template <int N>
-__device__ __forceinline__ int s_transposed_channel(int lane)
-{
-    int idx = 0;
-#pragma unroll
-    for (int t = 0; t < SLog2<N>::value; t++)
-        if (lane & (32 >> t)) idx += N >> (t + 1);
-    return idx;
-}
-template <int N>
-__device__ __forceinline__ bool s_transposed_owner(int lane)
-{
-    return (lane & ((64 / N) - 1)) == 0;
-}
 
 // ---- real SH basis, degree 3, reference sign convention (sh_utils.py:92-127) ----
 __device__ __forceinline__ void sh_basis16(float x, float y, float z, int M, float (&Y)[16])
@@ -294,8 +210,8 @@ shade_forward_kernel(int P, int K, int M, const float* __restrict__ base_color, 
         __syncthreads();
     }
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int chan = s_transposed_channel<32>(lane);
-    const bool owner = s_transposed_owner<32>(lane) && chan < SHADE_NOUT;
+    const int chan = transposed_channel<32>(lane);
+    const bool owner = transposed_owner<32>(lane) && chan < SHADE_NOUT;
     const float invK = 1.0f / (float)K;
     for (int g0 = blockIdx.x * SHADE_WAVES + wave; g0 < P; g0 += gridDim.x * SHADE_WAVES) {
         const int g = __builtin_amdgcn_readfirstlane(g0);
@@ -322,7 +238,7 @@ shade_forward_kernel(int P, int K, int M, const float* __restrict__ base_color, 
             }
             v[18] += s.vis;
         }
-        const float total = s_transpose_reduce<32>(v);
+        const float total = transpose_reduce<32, true>(v);
         if (owner) out[(size_t)g * SHADE_NOUT + chan] = total * invK;
     }
 }
@@ -354,7 +270,7 @@ shade_backward_kernel(int P, int K, int M, const float* __restrict__ base_color,
     }
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     // channel map of the 64-wide transposed reduction: 0..47 incidents (i*3+c), 48..50 base, 51 roughness, 52..54 view
-    const int chan = s_transposed_channel<64>(lane);
+    const int chan = transposed_channel<64>(lane);
     const float invK = 1.0f / (float)K;
     for (int g0 = blockIdx.x * SHADE_WAVES + wave; g0 < P; g0 += gridDim.x * SHADE_WAVES) {
         const int g = __builtin_amdgcn_readfirstlane(g0);
@@ -437,7 +353,7 @@ shade_backward_kernel(int P, int K, int M, const float* __restrict__ base_color,
 #pragma unroll
             for (int c = 0; c < 3; c++) v[52 + c] += (dV[c] - G.V[c] * vd) / G.vlen;
         }
-        const float total = s_transpose_reduce<64>(v);
+        const float total = transpose_reduce<64, true>(v);
         if (chan < 48) {
             if (chan < M * 3) d_inc[(size_t)g * M * 3 + chan] = total;
         } else if (chan < 51) d_base[3 * g + (chan - 48)] = total;

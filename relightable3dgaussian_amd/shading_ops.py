@@ -119,3 +119,73 @@ def rendering_equation(base_color, roughness, normals, viewdirs, incidents, dire
         "specular": rest[:, 0:3],
     }
     return pbr, extra_results
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# The reference's render_equation.h contract model (never bound in the reference snapshot; names/signatures follow
+# RenderEquationForwardCUDA / RenderEquationForwardCUDA_complex / RenderEquationBackwardCUDA, render_equation.h:7-46)
+# ---------------------------------------------------------------------------------------------------------------
+def _re_common(base_color, incidents_shs, direct_shs, visibility_shs):
+    P = base_color.size(0)
+    return P, incidents_shs.size(1), direct_shs.size(1), visibility_shs.size(1)
+
+
+def render_equation_forward(base_color, roughness, metallic, normals, viewdirs, incidents_shs, direct_shs,
+                            visibility_shs, sample_num, is_training, debug=False):
+    """-> (pbr[P,3], incident_dirs[P,K,3], diffuse_light[P,3])"""
+    L = _lib.lib()
+    P, Si, Sd, Sv = _re_common(base_color, incidents_shs, direct_shs, visibility_shs)
+    dev = base_color.device
+    t = [_c(x) for x in (base_color, roughness, metallic, normals, viewdirs, incidents_shs, direct_shs, visibility_shs)]
+    pbr = torch.zeros((P, 3), dtype=torch.float32, device=dev)
+    incident_dirs = torch.zeros((P, sample_num, 3), dtype=torch.float32, device=dev)
+    diffuse_light = torch.zeros((P, 3), dtype=torch.float32, device=dev)
+    rand_float = torch.rand((P, sample_num, 1), dtype=torch.float32, device=dev)   # drawn even when unused, like the reference
+    with torch.cuda.device(dev):
+        st = L.r3dg_render_equation_forward(_lib.current_stream(), P, Si, Sd, Sv, *[x.data_ptr() for x in t],
+                                            int(sample_num), rand_float.data_ptr() if is_training else None,
+                                            incident_dirs.data_ptr(), pbr.data_ptr(), diffuse_light.data_ptr())
+    _lib.check(st, "render_equation_forward")
+    render_equation_forward.last_rand = rand_float
+    return pbr, incident_dirs, diffuse_light
+
+
+def render_equation_forward_complex(base_color, roughness, metallic, normals, viewdirs, incidents_shs, direct_shs,
+                                    visibility_shs, sample_num):
+    """-> (pbr, incident_dirs, incident_lights, local_incident_lights, global_incident_lights, incident_visibility,
+    diffuse_light, local_diffuse_light, accum, rgb_d, rgb_s)"""
+    L = _lib.lib()
+    P, Si, Sd, Sv = _re_common(base_color, incidents_shs, direct_shs, visibility_shs)
+    dev = base_color.device
+    K = int(sample_num)
+    t = [_c(x) for x in (base_color, roughness, metallic, normals, viewdirs, incidents_shs, direct_shs, visibility_shs)]
+
+    def z(*shape):
+        return torch.zeros(shape, dtype=torch.float32, device=dev)
+    pbr, incident_dirs, lights, local, glob = z(P, 3), z(P, K, 3), z(P, K, 3), z(P, K, 3), z(P, K, 3)
+    vis, diffuse, local_diffuse, accum, rgb_d, rgb_s = z(P, K, 1), z(P, 3), z(P, 3), z(P, 1), z(P, 3), z(P, 3)
+    with torch.cuda.device(dev):
+        st = L.r3dg_render_equation_forward_complex(
+            _lib.current_stream(), P, Si, Sd, Sv, *[x.data_ptr() for x in t], K, incident_dirs.data_ptr(),
+            pbr.data_ptr(), lights.data_ptr(), local.data_ptr(), glob.data_ptr(), vis.data_ptr(), diffuse.data_ptr(),
+            local_diffuse.data_ptr(), accum.data_ptr(), rgb_d.data_ptr(), rgb_s.data_ptr())
+    _lib.check(st, "render_equation_forward_complex")
+    return pbr, incident_dirs, lights, local, glob, vis, diffuse, local_diffuse, accum, rgb_d, rgb_s
+
+
+def render_equation_backward(base_color, roughness, metallic, normals, viewdirs, incidents, direct_shs, visibility_shs,
+                             sample_num, incident_dirs, dL_drgb, dL_ddiffuse_light, debug=False):
+    """-> (dL_dbase_color, dL_droughness, dL_dmetallic, dL_dnormals, dL_dviewdirs, dL_dincidents_shs, dL_ddirect_shs,
+    dL_dvisibility_shs)"""
+    L = _lib.lib()
+    P, Si, Sd, Sv = _re_common(base_color, incidents, direct_shs, visibility_shs)
+    dev = base_color.device
+    t = [_c(x) for x in (base_color, roughness, metallic, normals, viewdirs, incidents, direct_shs, visibility_shs)]
+    dirs, g_rgb, g_dl = _c(incident_dirs), _c(dL_drgb), _c(dL_ddiffuse_light)
+    outs = [torch.zeros_like(x) for x in (t[0], t[1], t[2], t[3], t[4], t[5], t[6], t[7])]
+    with torch.cuda.device(dev):
+        st = L.r3dg_render_equation_backward(_lib.current_stream(), P, Si, Sd, Sv, *[x.data_ptr() for x in t],
+                                             int(sample_num), dirs.data_ptr(), g_rgb.data_ptr(), g_dl.data_ptr(),
+                                             *[o.data_ptr() for o in outs])
+    _lib.check(st, "render_equation_backward")
+    return tuple(outs)
