@@ -165,6 +165,9 @@ int r3dg_sort_pairs(void* stream, int64_t n, uint64_t* d_keys_in, uint32_t* d_va
  * whether the backward uses the DPP/permlane-swap transposing wave reduction (1) or the __shfl_xor one (0; <0 keeps).
  * r3dg_selftest_transpose_reduce: one wave reduces d_in[64][N] -> d_out[64] (+ channel / owner maps). */
 int r3dg_set_tuning(int fwd_pixels_per_lane, int bwd_pixels_per_lane, int bwd_dpp_reduce);
+/* staged entries per inner-loop step of the forward / backward tile kernels (<=0 keeps) and block order
+ * (1 longest-tile-first, 0 XCD-contiguous natural order, <0 keeps) */
+int r3dg_set_tuning2(int fwd_unroll, int bwd_unroll, int tile_order);
 int r3dg_selftest_transpose_reduce(void* stream, int N, int dpp, const float* d_in, float* d_out, int* d_chan,
                                    int* d_owner);
 

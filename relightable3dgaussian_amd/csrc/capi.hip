@@ -26,7 +26,9 @@ void launch_duplicate_with_keys(hipStream_t s, int P, const float* means2D, cons
                                 uint32_t* point_offsets, uint64_t* keys, uint32_t* values, const int* radii, int gx,
                                 int gy);
 void launch_identify_tile_ranges(hipStream_t s, int L, const uint64_t* keys, uint32_t* ranges);
-void launch_render_forward(hipStream_t s, int W, int H, int S, const uint32_t* ranges, const uint32_t* point_list,
+void launch_tile_order(hipStream_t s, int T, const uint32_t* ranges, uint32_t* order);
+void launch_render_forward(hipStream_t s, int W, int H, int S, const uint32_t* tile_order, const uint32_t* ranges,
+                           const uint32_t* point_list,
                            const float* means2D, const float* depths, const float* features, const float* colors,
                            const float* conic_opacity, float* final_T, uint32_t* n_contrib, const float* bg,
                            float* out_color, float* out_opacity, float* out_depth, float* out_feature,
@@ -34,7 +36,8 @@ void launch_render_forward(hipStream_t s, int W, int H, int S, const uint32_t* r
 void launch_pseudo_normal(hipStream_t s, int W, int H, const float* vm, float focal_x, float focal_y, float cx,
                           float cy, const float* opacities, const float* depths, float* normals, float* surface_xyz,
                           bool debug);
-void launch_render_backward(hipStream_t s, int W, int H, int S, const uint32_t* ranges, const uint32_t* point_list,
+void launch_render_backward(hipStream_t s, int W, int H, int S, const uint32_t* tile_order, const uint32_t* ranges,
+                            const uint32_t* point_list,
                             const float* bg, const float* means2D, const float* depths, const float* conic_opacity,
                             const float* colors, const float* features, const float* final_Ts,
                             const uint32_t* n_contrib, const float* dL_dpix, const float* dL_dpix_o,
@@ -72,6 +75,9 @@ void bvh_trace_opacity(hipStream_t s, int num_rays, const int32_t* nodes, const 
                        const float* rays_d, const float* means, const float* covs, const float* opac,
                        const float* normals, int32_t* contributes, float* out, int* overflow);
 extern int g_fwd_ppl;
+extern int g_fwd_unroll;
+extern int g_bwd_unroll;
+int g_tile_order = 1;   // 1: longest-tile-first block order, 0: XCD-contiguous natural order
 extern int g_bwd_ppl;
 extern int g_bwd_dpp;
 void launch_transpose_selftest(hipStream_t s, int N, int dpp, const float* in, float* out, int* chan, int* owner);
@@ -139,6 +145,7 @@ ImageLayout ImageLayout::make(size_t N, size_t T)
     L.final_T = take(N * 4);
     L.n_contrib = take(N * 4);
     L.ranges = take(T * 8);
+    L.tile_order = take(T * 4);
     L.bytes = o;
     return L;
 }
@@ -196,6 +203,14 @@ int r3dg_max_features_forward(void) { return R3DG_MAX_S_FWD; }
 int r3dg_max_features_backward(void) { return R3DG_MAX_S_BWD; }
 
 // tuning knobs (pixels per lane of the two render kernels); not part of the drop-in surface
+int r3dg_set_tuning2(int fwd_unroll, int bwd_unroll, int tile_order)
+{
+    if (fwd_unroll > 0) g_fwd_unroll = fwd_unroll;
+    if (bwd_unroll > 0) g_bwd_unroll = bwd_unroll;
+    if (tile_order >= 0) g_tile_order = tile_order;
+    return R3DG_OK;
+}
+
 int r3dg_set_tuning(int fwd_pixels_per_lane, int bwd_pixels_per_lane, int bwd_dpp_reduce)
 {
     if (fwd_pixels_per_lane > 0) g_fwd_ppl = fwd_pixels_per_lane;
@@ -366,8 +381,14 @@ int r3dg_rasterize_forward(void* stream_, r3dg_alloc_fn geometry_alloc, r3dg_all
         t_rng.stop();
 
         const float* colors_ptr = colors_precomp != nullptr ? colors_precomp : g_rgb;
+        uint32_t* tile_order = nullptr;
+        if (g_tile_order) {
+            tile_order = (uint32_t*)(ibuf + I.tile_order);
+            launch_tile_order(stream, (int)T, ranges, tile_order);
+            check_launch(stream, debug, "tile_order");
+        }
         StageTimer t_rf(stream, ST_RENDER_FWD);
-        launch_render_forward(stream, width, height, S, ranges, vals, g_means2D, g_depths, features, colors_ptr,
+        launch_render_forward(stream, width, height, S, tile_order, ranges, vals, g_means2D, g_depths, features, colors_ptr,
                               g_conic, (float*)(ibuf + I.final_T), (uint32_t*)(ibuf + I.n_contrib), background,
                               out_color, out_opacity, out_depth, out_feature, out_weights);
         check_launch(stream, debug, "render_forward");
@@ -419,7 +440,9 @@ int r3dg_rasterize_backward(void* stream_, int P, int S, int D, int M, int R, co
 
         if (R > 0) {
             StageTimer t_rb(stream, ST_RENDER_BWD);
-            launch_render_backward(stream, width, height, S, (const uint32_t*)(ibuf + I.ranges),
+            launch_render_backward(stream, width, height, S,
+                                   g_tile_order ? (const uint32_t*)(ibuf + I.tile_order) : nullptr,
+                                   (const uint32_t*)(ibuf + I.ranges),
                                    (const uint32_t*)(bbuf + B.vals), background, (const float*)(gbuf + G.means2D),
                                    (const float*)(gbuf + G.depths), (const float*)(gbuf + G.conic_opacity), color_ptr,
                                    features, (const float*)(ibuf + I.final_T), (const uint32_t*)(ibuf + I.n_contrib),

@@ -52,7 +52,7 @@ struct GeometryLayout {  // byte offsets into the opaque geometry buffer
     static GeometryLayout make(size_t P);
 };
 struct ImageLayout {
-    size_t final_T, n_contrib, ranges, bytes;
+    size_t final_T, n_contrib, ranges, tile_order, bytes;
     static ImageLayout make(size_t N, size_t T);
 };
 struct BinningLayout {

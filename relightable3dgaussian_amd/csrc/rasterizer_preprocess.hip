@@ -321,7 +321,50 @@ __global__ void identify_tile_ranges_kernel(int L, const uint64_t* __restrict__ 
     if (idx == L - 1) ranges[currtile].y = L;
 }
 
+// Longest-tile-first block order for the two tile kernels: one block buckets the T tile lengths into 256 classes
+// (descending) with LDS counters.  Order inside a class is arbitrary -- it only affects scheduling, never results.
+__global__ void __launch_bounds__(1024)
+tile_order_kernel(int T, const uint2* __restrict__ ranges, uint32_t* __restrict__ order)
+{
+    __shared__ uint32_t s_cnt[256];
+    __shared__ uint32_t s_max;
+    const int tid = threadIdx.x;
+    if (tid < 256) s_cnt[tid] = 0;
+    if (tid == 0) s_max = 0;
+    __syncthreads();
+    uint32_t m = 0;
+    for (int t = tid; t < T; t += 1024) m = max(m, ranges[t].y - ranges[t].x);
+    atomicMax(&s_max, m);
+    __syncthreads();
+    const uint32_t scale = s_max + 1;
+    for (int t = tid; t < T; t += 1024) {
+        const uint32_t len = ranges[t].y - ranges[t].x;
+        const uint32_t cls = 255u - (uint32_t)(((uint64_t)len * 256u) / scale);
+        atomicAdd(&s_cnt[cls], 1u);
+    }
+    __syncthreads();
+    if (tid == 0) {
+        uint32_t run = 0;
+        for (int c = 0; c < 256; c++) {
+            const uint32_t n = s_cnt[c];
+            s_cnt[c] = run;
+            run += n;
+        }
+    }
+    __syncthreads();
+    for (int t = tid; t < T; t += 1024) {
+        const uint32_t len = ranges[t].y - ranges[t].x;
+        const uint32_t cls = 255u - (uint32_t)(((uint64_t)len * 256u) / scale);
+        order[atomicAdd(&s_cnt[cls], 1u)] = (uint32_t)t;
+    }
+}
+
 // ---- host launchers -------------------------------------------------------------------------------------
+void launch_tile_order(hipStream_t s, int T, const uint32_t* ranges, uint32_t* order)
+{
+    tile_order_kernel<<<1, 1024, 0, s>>>(T, (const uint2*)ranges, order);
+}
+
 void launch_mark_visible(hipStream_t s, int P, const float* means3D, const float* vm, uint8_t* present)
 {
     if (P <= 0) return;

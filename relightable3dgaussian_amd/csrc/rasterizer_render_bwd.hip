@@ -43,10 +43,11 @@ void launch_transpose_selftest(hipStream_t s, int N, int dpp, const float* in, f
 
 constexpr int next_pow2(int v) { return v <= 16 ? 16 : (v <= 32 ? 32 : 64); }
 
-template <int SPAD, int PPL, bool DPP>
+template <int SPAD, int PPL, int U>
 __global__ void __launch_bounds__(256 / PPL)
 render_backward_kernel(const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list, int S, int W, int H,
-                       int tiles_x, int num_tiles, int xcd_chunk, const float* __restrict__ bg_color,
+                       int tiles_x, int num_tiles, int xcd_chunk, const uint32_t* __restrict__ tile_order,
+                       const float* __restrict__ bg_color,
                        const float2* __restrict__ means2D, const float* __restrict__ depths,
                        const float4* __restrict__ conic_opacity, const float* __restrict__ colors,
                        const float* __restrict__ features, const float* __restrict__ final_Ts,
@@ -62,8 +63,14 @@ render_backward_kernel(const uint2* __restrict__ ranges, const uint32_t* __restr
     constexpr int NVP = next_pow2(NV);
     constexpr int NW = NT / 64;
 
-    const int tile = (int)(blockIdx.x & 7u) * xcd_chunk + (int)(blockIdx.x >> 3);
-    if (tile >= num_tiles) return;
+    int tile;
+    if (tile_order != nullptr) {
+        if ((int)blockIdx.x >= num_tiles) return;
+        tile = (int)tile_order[blockIdx.x];
+    } else {
+        tile = (int)(blockIdx.x & 7u) * xcd_chunk + (int)(blockIdx.x >> 3);
+        if (tile >= num_tiles) return;
+    }
     const int tile_x = tile % tiles_x, tile_y = tile / tiles_x;
 
     __shared__ float4 s_geo0[NT];
@@ -164,116 +171,135 @@ render_backward_kernel(const uint2* __restrict__ ranges, const uint32_t* __restr
         __syncthreads();
 
         const int cnt = min(NT, n - base);
-        for (int j = 0; j < cnt; j++) {
-            const uint32_t front = (uint32_t)(n - 1 - (base + j));    // 0-based index from the front of the tile list
-            const float4 g0 = s_geo0[j];
-            const float4 g1 = s_geo1[j];
-            const float dx = g0.x - pxf;
-            float alpha[PPL], G[PPL], dy[PPL];
-            bool hit[PPL];
-            bool any_lane = false;
+        // U staged entries per step: their LDS reads are issued together and the U x PPL (G, alpha) pairs are
+        // independent work; the accum_rec recursion and the gradient reduction stay serial per entry.
+        for (int j0 = 0; j0 < cnt; j0 += U) {
+            float4 g0[U], g1[U];
+            float alpha[U][PPL], G[U][PPL];
 #pragma unroll
-            for (int i = 0; i < PPL; i++) {
-                hit[i] = false;
-                alpha[i] = 0.f; G[i] = 0.f;
-                dy[i] = g0.y - pyf[i];
-                if (front < lastc[i]) {     // reference: skip while contributor >= last_contributor
-                    const float power = -0.5f * (g0.z * dx * dx + g1.x * dy[i] * dy[i]) - g0.w * dx * dy[i];
-                    if (!(power > 0.0f)) {
-                        G[i] = fast_exp_b(power);
-                        alpha[i] = fminf(0.99f, g1.y * G[i]);
-                        hit[i] = alpha[i] >= 1.0f / 255.0f;
-                    }
-                }
-                any_lane = any_lane || hit[i];
+            for (int u = 0; u < U; u++) {
+                const int j = min(j0 + u, cnt - 1);
+                g0[u] = s_geo0[j];
+                g1[u] = s_geo1[j];
             }
-            if (__ballot(any_lane) == 0ull) continue;
+            bool any_hit = false;
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                const uint32_t front = (uint32_t)(n - 1 - (base + j0 + u));   // 0-based index from the front of the list
+                const float dx = g0[u].x - pxf;
+#pragma unroll
+                for (int i = 0; i < PPL; i++) {
+                    const float dy = g0[u].y - pyf[i];
+                    const float power = -0.5f * (g0[u].z * dx * dx + g1[u].x * dy * dy) - g0[u].w * dx * dy;
+                    const float Gv = fast_exp_b(power);
+                    float a = fminf(0.99f, g1[u].y * Gv);
+                    // reference: skip while contributor >= last_contributor, power > 0, alpha < 1/255
+                    if (!(front < lastc[i]) || power > 0.0f || a < 1.0f / 255.0f || j0 + u >= cnt) a = 0.f;
+                    alpha[u][i] = a;
+                    G[u][i] = Gv;
+                    any_hit = any_hit || (a != 0.f);
+                }
+            }
+            if (__ballot(any_hit) == 0ull) continue;
 
-            const float* pay = s_pay + j * PAY;
-            const float4 c4 = *reinterpret_cast<const float4*>(pay);
-            const float col[3] = {c4.x, c4.y, c4.z};
-            float v[NVP];
 #pragma unroll
-            for (int k = 0; k < NVP; k++) v[k] = 0.f;
+            for (int u = 0; u < U; u++) {
+                bool any_lane = false;
+#pragma unroll
+                for (int i = 0; i < PPL; i++) any_lane = any_lane || (alpha[u][i] != 0.f);
+                if (__ballot(any_lane) == 0ull) continue;
+
+                const float dx = g0[u].x - pxf;
+                const float* pay = s_pay + min(j0 + u, cnt - 1) * PAY;
+                const float4 c4 = *reinterpret_cast<const float4*>(pay);
+                const float col[3] = {c4.x, c4.y, c4.z};
+                float v[NVP];
+#pragma unroll
+                for (int k = 0; k < NVP; k++) v[k] = 0.f;
 
 #pragma unroll
-            for (int i = 0; i < PPL; i++) {
-                if (PPL > 1 && __ballot(hit[i]) == 0ull) continue;
-                if (hit[i]) {
-                    const float one_m_a = 1.f - alpha[i];
-                    const float rcp = __builtin_amdgcn_rcpf(one_m_a);
-                    T[i] = T[i] * rcp;
-                    const float wgt = alpha[i] * T[i];
-                    float dL_dalpha = 0.f;
+                for (int i = 0; i < PPL; i++) {
+                    if (PPL > 1 && __ballot(alpha[u][i] != 0.f) == 0ull) continue;
+                    if (alpha[u][i] != 0.f) {
+                        const float al = alpha[u][i];
+                        const float dy = g0[u].y - pyf[i];
+                        const float one_m_a = 1.f - al;
+                        const float rcp = __builtin_amdgcn_rcpf(one_m_a);
+                        T[i] = T[i] * rcp;
+                        const float wgt = al * T[i];
+                        float dL_dalpha = 0.f;
 #pragma unroll
-                    for (int ch = 0; ch < 3; ch++) {
-                        dL_dalpha += (col[ch] - acc_c[i][ch]) * dLc[i][ch];
-                        acc_c[i][ch] = alpha[i] * col[ch] + one_m_a * acc_c[i][ch];
-                        v[ch] += wgt * dLc[i][ch];
-                    }
-#pragma unroll
-                    for (int q = 0; q < SPAD / 4; q++) {
-                        const float4 f4 = *reinterpret_cast<const float4*>(pay + 4 + 4 * q);
-                        const float fv[4] = {f4.x, f4.y, f4.z, f4.w};
-#pragma unroll
-                        for (int e = 0; e < 4; e++) {
-                            const int ch = 4 * q + e;
-                            if (backward_geometry) dL_dalpha += (fv[e] - acc_f[i][ch]) * dLf[i][ch];
-                            acc_f[i][ch] = alpha[i] * fv[e] + one_m_a * acc_f[i][ch];
-                            v[10 + ch] += wgt * dLf[i][ch];
+                        for (int ch = 0; ch < 3; ch++) {
+                            dL_dalpha += (col[ch] - acc_c[i][ch]) * dLc[i][ch];
+                            acc_c[i][ch] = al * col[ch] + one_m_a * acc_c[i][ch];
+                            v[ch] += wgt * dLc[i][ch];
                         }
-                    }
-                    dL_dalpha += (g1.z - acc_d[i]) * dLd[i];
-                    acc_d[i] = alpha[i] * g1.z + one_m_a * acc_d[i];
-                    dL_dalpha += (1.0f - acc_o[i]) * dLo[i];
-                    acc_o[i] = alpha[i] + one_m_a * acc_o[i];
-                    dL_dalpha *= T[i];
-                    dL_dalpha += bgT[i] * rcp;
+#pragma unroll
+                        for (int q = 0; q < SPAD / 4; q++) {
+                            const float4 f4 = *reinterpret_cast<const float4*>(pay + 4 + 4 * q);
+                            const float fv[4] = {f4.x, f4.y, f4.z, f4.w};
+#pragma unroll
+                            for (int e = 0; e < 4; e++) {
+                                const int ch = 4 * q + e;
+                                if (backward_geometry) dL_dalpha += (fv[e] - acc_f[i][ch]) * dLf[i][ch];
+                                acc_f[i][ch] = al * fv[e] + one_m_a * acc_f[i][ch];
+                                v[10 + ch] += wgt * dLf[i][ch];
+                            }
+                        }
+                        dL_dalpha += (g1[u].z - acc_d[i]) * dLd[i];
+                        acc_d[i] = al * g1[u].z + one_m_a * acc_d[i];
+                        dL_dalpha += (1.0f - acc_o[i]) * dLo[i];
+                        acc_o[i] = al + one_m_a * acc_o[i];
+                        dL_dalpha *= T[i];
+                        dL_dalpha += bgT[i] * rcp;
 
-                    const float dL_dG = g1.y * dL_dalpha;
-                    const float gdx = G[i] * dx, gdy = G[i] * dy[i];
-                    const float dG_ddelx = -gdx * g0.z - gdy * g0.w;
-                    const float dG_ddely = -gdy * g1.x - gdx * g0.w;
-                    v[3] += dL_dG * dG_ddelx * ddelx_dx;
-                    v[4] += dL_dG * dG_ddely * ddely_dy;
-                    v[5] += dLd[i] * wgt;
-                    v[6] += -0.5f * gdx * dx * dL_dG;
-                    v[7] += -0.5f * gdx * dy[i] * dL_dG;
-                    v[8] += -0.5f * gdy * dy[i] * dL_dG;
-                    v[9] += G[i] * dL_dalpha;
+                        const float dL_dG = g1[u].y * dL_dalpha;
+                        const float gdx = G[u][i] * dx, gdy = G[u][i] * dy;
+                        const float dG_ddelx = -gdx * g0[u].z - gdy * g0[u].w;
+                        const float dG_ddely = -gdy * g1[u].x - gdx * g0[u].w;
+                        v[3] += dL_dG * dG_ddelx * ddelx_dx;
+                        v[4] += dL_dG * dG_ddely * ddely_dy;
+                        v[5] += dLd[i] * wgt;
+                        v[6] += -0.5f * gdx * dx * dL_dG;
+                        v[7] += -0.5f * gdx * dy * dL_dG;
+                        v[8] += -0.5f * gdy * dy * dL_dG;
+                        v[9] += G[u][i] * dL_dalpha;
+                    }
                 }
+                const float total = transpose_reduce<NVP, true>(v);
+                if (dst_base != nullptr) atomicAdd(dst_base + (size_t)__float_as_uint(g1[u].w) * dst_stride, total);
             }
-            const float total = transpose_reduce<NVP, DPP>(v);
-            if (dst_base != nullptr) atomicAdd(dst_base + (size_t)__float_as_uint(g1.w) * dst_stride, total);
         }
     }
 }
 
 int g_bwd_ppl = 1;
-int g_bwd_dpp = 1;   // 1: DPP/permlane-swap transposing reduction, 0: portable __shfl_xor version
+int g_bwd_dpp = 1;      // kept for the self-test entry point; the tile kernel always uses the DPP/permlane reduction
+int g_bwd_unroll = 1;   // staged entries evaluated per inner-loop step
 
 template <int SPAD, int PPL>
-static void launch_bwd_inst(hipStream_t s, int T, int tiles_x, const uint32_t* ranges, const uint32_t* point_list,
-                            int S, int W, int H, const float* bg, const float* means2D, const float* depths,
-                            const float* conic_opacity, const float* colors, const float* features,
-                            const float* final_Ts, const uint32_t* n_contrib, const float* dL_dpix,
-                            const float* dL_dpix_o, const float* dL_dpix_d, const float* dL_dpix_f, float* dL_dmean2D,
-                            float* dL_dconic, float* dL_dopacity, float* dL_dcolor, float* dL_dfeature, int bg_geom)
+static void launch_bwd_inst(hipStream_t s, int T, int tiles_x, const uint32_t* tile_order, const uint32_t* ranges,
+                            const uint32_t* point_list, int S, int W, int H, const float* bg, const float* means2D,
+                            const float* depths, const float* conic_opacity, const float* colors,
+                            const float* features, const float* final_Ts, const uint32_t* n_contrib,
+                            const float* dL_dpix, const float* dL_dpix_o, const float* dL_dpix_d,
+                            const float* dL_dpix_f, float* dL_dmean2D, float* dL_dconic, float* dL_dopacity,
+                            float* dL_dcolor, float* dL_dfeature, int bg_geom)
 {
     const int chunk = (T + 7) / 8;
-    if (g_bwd_dpp)
-        render_backward_kernel<SPAD, PPL, true><<<chunk * 8, 256 / PPL, 0, s>>>(
-            (const uint2*)ranges, point_list, S, W, H, tiles_x, T, chunk, bg, (const float2*)means2D, depths,
-            (const float4*)conic_opacity, colors, features, final_Ts, n_contrib, dL_dpix, dL_dpix_o, dL_dpix_d,
-            dL_dpix_f, dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolor, dL_dfeature, bg_geom);
-    else
-        render_backward_kernel<SPAD, PPL, false><<<chunk * 8, 256 / PPL, 0, s>>>(
-            (const uint2*)ranges, point_list, S, W, H, tiles_x, T, chunk, bg, (const float2*)means2D, depths,
-            (const float4*)conic_opacity, colors, features, final_Ts, n_contrib, dL_dpix, dL_dpix_o, dL_dpix_d,
-            dL_dpix_f, dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolor, dL_dfeature, bg_geom);
+#define R3DG_BWD_LAUNCH(UU)                                                                                           \
+    render_backward_kernel<SPAD, PPL, UU><<<chunk * 8, 256 / PPL, 0, s>>>(                                            \
+        (const uint2*)ranges, point_list, S, W, H, tiles_x, T, chunk, tile_order, bg, (const float2*)means2D, depths, \
+        (const float4*)conic_opacity, colors, features, final_Ts, n_contrib, dL_dpix, dL_dpix_o, dL_dpix_d, dL_dpix_f, \
+        dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolor, dL_dfeature, bg_geom)
+    if (g_bwd_unroll >= 4) R3DG_BWD_LAUNCH(4);
+    else if (g_bwd_unroll >= 2) R3DG_BWD_LAUNCH(2);
+    else R3DG_BWD_LAUNCH(1);
+#undef R3DG_BWD_LAUNCH
 }
 
-void launch_render_backward(hipStream_t s, int W, int H, int S, const uint32_t* ranges, const uint32_t* point_list,
+void launch_render_backward(hipStream_t s, int W, int H, int S, const uint32_t* tile_order, const uint32_t* ranges,
+                            const uint32_t* point_list,
                             const float* bg, const float* means2D, const float* depths, const float* conic_opacity,
                             const float* colors, const float* features, const float* final_Ts,
                             const uint32_t* n_contrib, const float* dL_dpix, const float* dL_dpix_o,
@@ -282,7 +308,7 @@ void launch_render_backward(hipStream_t s, int W, int H, int S, const uint32_t* 
 {
     const int tiles_x = (W + R3DG_TILE_X - 1) / R3DG_TILE_X, tiles_y = (H + R3DG_TILE_Y - 1) / R3DG_TILE_Y;
     const int T = tiles_x * tiles_y;
-#define R3DG_BWD_ARGS s, T, tiles_x, ranges, point_list, S, W, H, bg, means2D, depths, conic_opacity, colors, features, \
+#define R3DG_BWD_ARGS s, T, tiles_x, tile_order, ranges, point_list, S, W, H, bg, means2D, depths, conic_opacity, colors, features, \
                       final_Ts, n_contrib, dL_dpix, dL_dpix_o, dL_dpix_d, dL_dpix_f, dL_dmean2D, dL_dconic, dL_dopacity, \
                       dL_dcolor, dL_dfeature, bg_geom
 #define R3DG_BWD_CASE(SP)                                                       \

@@ -24,10 +24,11 @@ __device__ __forceinline__ float fast_exp(float x)
     return __builtin_amdgcn_exp2f(x * 1.4426950408889634f);
 }
 
-template <int SPAD, int PPL>
+template <int SPAD, int PPL, int U>
 __global__ void __launch_bounds__(256 / PPL)
 render_forward_kernel(const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list, int S, int W, int H,
-                      int tiles_x, int num_tiles, int xcd_chunk, const float2* __restrict__ means2D,
+                      int tiles_x, int num_tiles, int xcd_chunk, const uint32_t* __restrict__ tile_order,
+                      const float2* __restrict__ means2D,
                       const float* __restrict__ depths, const float* __restrict__ features,
                       const float* __restrict__ colors, const float4* __restrict__ conic_opacity,
                       float* __restrict__ final_T, uint32_t* __restrict__ n_contrib, const float* __restrict__ bg_color,
@@ -39,8 +40,16 @@ render_forward_kernel(const uint2* __restrict__ ranges, const uint32_t* __restri
 
     // XCD-aware tile order: hardware places block b on XCD b%8, so give each XCD a contiguous run of tiles
     // (neighbouring tiles share Gaussians -> shared lines stay in one XCD's L2).
-    const int tile = (int)(blockIdx.x & 7u) * xcd_chunk + (int)(blockIdx.x >> 3);
-    if (tile >= num_tiles) return;
+    // ... or, when a tile_order is given, longest-tile-first (the hardware dispatches blocks in index order, so the
+    // long tiles start first and the short ones fill the tail).
+    int tile;
+    if (tile_order != nullptr) {
+        if ((int)blockIdx.x >= num_tiles) return;
+        tile = (int)tile_order[blockIdx.x];
+    } else {
+        tile = (int)(blockIdx.x & 7u) * xcd_chunk + (int)(blockIdx.x >> 3);
+        if (tile >= num_tiles) return;
+    }
     const int tile_x = tile % tiles_x, tile_y = tile / tiles_x;
 
     __shared__ float4 s_geo0[NT];                 // mean.x, mean.y, conic.x, conic.y
@@ -104,64 +113,85 @@ render_forward_kernel(const uint2* __restrict__ ranges, const uint32_t* __restri
         __syncthreads();
 
         const int cnt = min(NT, n - base);
-        for (int j = 0; j < cnt; j++) {
+        // Walk the staged batch U entries at a time: the U geometry records are fetched with back-to-back LDS reads
+        // and their U x PPL alphas are evaluated as independent work (ILP hides the LDS / exp latency); only the
+        // short transmittance update stays serial per entry.
+        for (int j0 = 0; j0 < cnt; j0 += U) {
             bool active = false;
 #pragma unroll
             for (int i = 0; i < PPL; i++) active = active || !done[i];
             if (__ballot(active) == 0ull) break;           // this wave's pixels are all finished
 
-            const float4 g0 = s_geo0[j];
-            const float4 g1 = s_geo1[j];
-            const float dx = g0.x - pxf;
-            float w[PPL];
-            bool any_lane = false;
+            float4 g0[U], g1[U];
+            float alpha[U][PPL];
 #pragma unroll
-            for (int i = 0; i < PPL; i++) {
-                w[i] = 0.f;
-                if (!done[i]) {
-                    const float dy = g0.y - pyf[i];
-                    const float power = -0.5f * (g0.z * dx * dx + g1.x * dy * dy) - g0.w * dx * dy;
-                    if (!(power > 0.0f)) {
-                        const float alpha = fminf(0.99f, g1.y * fast_exp(power));
-                        if (alpha >= 1.0f / 255.0f) {
-                            const float test_T = T[i] * (1.f - alpha);
-                            if (test_T < 0.0001f) {
-                                done[i] = true;
-                            } else {
-                                w[i] = alpha * T[i];
-                                T[i] = test_T;
-                                last[i] = (uint32_t)(base + j + 1);
-                                any_lane = true;
-                            }
+            for (int u = 0; u < U; u++) {
+                const int j = min(j0 + u, cnt - 1);       // tail entries are re-read and ignored below
+                g0[u] = s_geo0[j];
+                g1[u] = s_geo1[j];
+            }
+            bool any_alpha = false;
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                const float dx = g0[u].x - pxf;
+#pragma unroll
+                for (int i = 0; i < PPL; i++) {
+                    const float dy = g0[u].y - pyf[i];
+                    const float power = -0.5f * (g0[u].z * dx * dx + g1[u].x * dy * dy) - g0[u].w * dx * dy;
+                    float a = fminf(0.99f, g1[u].y * fast_exp(power));
+                    if (power > 0.0f || a < 1.0f / 255.0f) a = 0.f;      // a == 0 marks "skip" (a real alpha is >= 1/255)
+                    alpha[u][i] = a;
+                    any_alpha = any_alpha || (a != 0.f && !done[i]);
+                }
+            }
+            if (__ballot(any_alpha) == 0ull) continue;      // none of the U entries touches this wave's live pixels
+
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                if (j0 + u >= cnt) break;
+                float w[PPL];
+                bool any_lane = false;
+#pragma unroll
+                for (int i = 0; i < PPL; i++) {
+                    w[i] = 0.f;
+                    if (!done[i] && alpha[u][i] != 0.f) {
+                        const float test_T = T[i] * (1.f - alpha[u][i]);
+                        if (test_T < 0.0001f) {
+                            done[i] = true;
+                        } else {
+                            w[i] = alpha[u][i] * T[i];
+                            T[i] = test_T;
+                            last[i] = (uint32_t)(base + j0 + u + 1);
+                            any_lane = true;
                         }
                     }
                 }
-            }
-            if (__ballot(any_lane) == 0ull) continue;       // nobody in this wave blends this Gaussian
+                if (__ballot(any_lane) == 0ull) continue;   // nobody in this wave blends this Gaussian
 
-            const float* pay = s_pay + j * PAY;
-            const float4 c4 = *reinterpret_cast<const float4*>(pay);
-            float wsum = 0.f;
+                const float* pay = s_pay + (j0 + u) * PAY;
+                const float4 c4 = *reinterpret_cast<const float4*>(pay);
+                float wsum = 0.f;
 #pragma unroll
-            for (int i = 0; i < PPL; i++) {
-                if (PPL > 1 && __ballot(w[i] != 0.f) == 0ull) continue;   // this 4x16 sub-band is untouched
-                C[i][0] += c4.x * w[i];
-                C[i][1] += c4.y * w[i];
-                C[i][2] += c4.z * w[i];
-                Dp[i] += g1.z * w[i];
-                Op[i] += w[i];
-                wsum += w[i];
+                for (int i = 0; i < PPL; i++) {
+                    if (PPL > 1 && __ballot(w[i] != 0.f) == 0ull) continue;   // this 4x16 sub-band is untouched
+                    C[i][0] += c4.x * w[i];
+                    C[i][1] += c4.y * w[i];
+                    C[i][2] += c4.z * w[i];
+                    Dp[i] += g1[u].z * w[i];
+                    Op[i] += w[i];
+                    wsum += w[i];
 #pragma unroll
-                for (int q = 0; q < SPAD / 4; q++) {
-                    const float4 f4 = *reinterpret_cast<const float4*>(pay + 4 + 4 * q);
-                    F[i][4 * q + 0] += f4.x * w[i];
-                    F[i][4 * q + 1] += f4.y * w[i];
-                    F[i][4 * q + 2] += f4.z * w[i];
-                    F[i][4 * q + 3] += f4.w * w[i];
+                    for (int q = 0; q < SPAD / 4; q++) {
+                        const float4 f4 = *reinterpret_cast<const float4*>(pay + 4 + 4 * q);
+                        F[i][4 * q + 0] += f4.x * w[i];
+                        F[i][4 * q + 1] += f4.y * w[i];
+                        F[i][4 * q + 2] += f4.z * w[i];
+                        F[i][4 * q + 3] += f4.w * w[i];
+                    }
                 }
+                wsum = wave_sum(wsum);
+                if (lane == 0) atomicAdd(&out_weights[__float_as_uint(g1[u].w)], wsum);
             }
-            wsum = wave_sum(wsum);
-            if (lane == 0) atomicAdd(&out_weights[__float_as_uint(g1.w)], wsum);
         }
     }
 
@@ -231,36 +261,50 @@ pseudo_normal_kernel(int W, int H, const float* __restrict__ vm, float* __restri
 
 // ---- launchers ------------------------------------------------------------------------------------------
 int g_fwd_ppl = 1;   // pixels per lane; tunable through r3dg_set_tuning()
+int g_fwd_unroll = 4;   // staged entries evaluated per inner-loop step (1 = entry-at-a-time)
 
 template <int SPAD, int PPL>
-static void launch_fwd_inst(hipStream_t s, int T, int tiles_x, const uint32_t* ranges, const uint32_t* point_list,
+static void launch_fwd_inst(hipStream_t s, int T, int tiles_x, const uint32_t* tile_order, const uint32_t* ranges,
+                            const uint32_t* point_list,
                             int S, int W, int H, const float* means2D, const float* depths, const float* features,
                             const float* colors, const float* conic_opacity, float* final_T, uint32_t* n_contrib,
                             const float* bg, float* out_color, float* out_opacity, float* out_depth,
                             float* out_feature, float* out_weights)
 {
     const int chunk = (T + 7) / 8;
-    render_forward_kernel<SPAD, PPL><<<chunk * 8, 256 / PPL, 0, s>>>(
-        (const uint2*)ranges, point_list, S, W, H, tiles_x, T, chunk, (const float2*)means2D, depths, features, colors,
-        (const float4*)conic_opacity, final_T, n_contrib, bg, out_color, out_opacity, out_depth, out_feature,
-        out_weights);
+    if (g_fwd_unroll >= 4)
+        render_forward_kernel<SPAD, PPL, 4><<<chunk * 8, 256 / PPL, 0, s>>>(
+            (const uint2*)ranges, point_list, S, W, H, tiles_x, T, chunk, tile_order, (const float2*)means2D, depths,
+            features, colors, (const float4*)conic_opacity, final_T, n_contrib, bg, out_color, out_opacity, out_depth,
+            out_feature, out_weights);
+    else if (g_fwd_unroll >= 2)
+        render_forward_kernel<SPAD, PPL, 2><<<chunk * 8, 256 / PPL, 0, s>>>(
+            (const uint2*)ranges, point_list, S, W, H, tiles_x, T, chunk, tile_order, (const float2*)means2D, depths,
+            features, colors, (const float4*)conic_opacity, final_T, n_contrib, bg, out_color, out_opacity, out_depth,
+            out_feature, out_weights);
+    else
+        render_forward_kernel<SPAD, PPL, 1><<<chunk * 8, 256 / PPL, 0, s>>>(
+            (const uint2*)ranges, point_list, S, W, H, tiles_x, T, chunk, tile_order, (const float2*)means2D, depths,
+            features, colors, (const float4*)conic_opacity, final_T, n_contrib, bg, out_color, out_opacity, out_depth,
+            out_feature, out_weights);
 }
 
 template <int SPAD>
-static void launch_fwd_ppl(int ppl, hipStream_t s, int T, int tiles_x, const uint32_t* ranges,
-                           const uint32_t* point_list, int S, int W, int H, const float* means2D, const float* depths,
+static void launch_fwd_ppl(int ppl, hipStream_t s, int T, int tiles_x, const uint32_t* tile_order,
+                           const uint32_t* ranges, const uint32_t* point_list, int S, int W, int H, const float* means2D, const float* depths,
                            const float* features, const float* colors, const float* conic_opacity, float* final_T,
                            uint32_t* n_contrib, const float* bg, float* out_color, float* out_opacity,
                            float* out_depth, float* out_feature, float* out_weights)
 {
-#define R3DG_FWD_ARGS s, T, tiles_x, ranges, point_list, S, W, H, means2D, depths, features, colors, conic_opacity, \
+#define R3DG_FWD_ARGS s, T, tiles_x, tile_order, ranges, point_list, S, W, H, means2D, depths, features, colors, conic_opacity, \
                       final_T, n_contrib, bg, out_color, out_opacity, out_depth, out_feature, out_weights
     if (ppl >= 4 && SPAD <= 20) launch_fwd_inst<SPAD, 4>(R3DG_FWD_ARGS);
     else if (ppl >= 2) launch_fwd_inst<SPAD, 2>(R3DG_FWD_ARGS);
     else launch_fwd_inst<SPAD, 1>(R3DG_FWD_ARGS);
 }
 
-void launch_render_forward(hipStream_t s, int W, int H, int S, const uint32_t* ranges, const uint32_t* point_list,
+void launch_render_forward(hipStream_t s, int W, int H, int S, const uint32_t* tile_order, const uint32_t* ranges,
+                           const uint32_t* point_list,
                            const float* means2D, const float* depths, const float* features, const float* colors,
                            const float* conic_opacity, float* final_T, uint32_t* n_contrib, const float* bg,
                            float* out_color, float* out_opacity, float* out_depth, float* out_feature,

@@ -80,7 +80,9 @@ def _check_forward(case, label=""):
     hard = mism & ~border
     msgs.append("n_contrib      mismatches %d (borderline %d, hard %d)" % (mism.sum(), (mism & border).sum(), hard.sum()))
     ok_all &= not hard.any()
-    good = ~mism       # float buffers are compared where the discrete outcome agrees
+    # float buffers are compared where the discrete outcome provably agrees: a borderline alpha-vs-1/255 decision
+    # adds or drops a whole alpha*T*c term (up to 4e-3) without necessarily changing n_contrib
+    good = ~mism & ~border
     for name, idx in (("color", 2), ("opacity", 3), ("depth", 4), ("feature", 5)):
         g_, r_ = to_np(out[idx]), ref[idx]
         if g_.size:
@@ -194,9 +196,9 @@ def _check_backward(case, label, backward_geometry=True):
                                             out[10], out[0], out[11], out[12], backward_geometry, False)
     torch.cuda.synchronize()
     c = fwd_args(case)
-    # the oracle backward walks the ORACLE's forward state; n_contrib borderline pixels are zeroed in both
+    # the oracle backward walks the ORACLE's forward state; borderline pixels (threshold margin < 1e-4) are zeroed in both
     # upstream gradients so both sides differentiate the same discrete structure
-    nc_same = torch.from_numpy(to_np(out[1]) == ref[1])
+    nc_same = torch.from_numpy((to_np(out[1]) == ref[1]) & ~(ref[-1]["margin"] < 1e-4))
     if not bool(nc_same.all()):
         mask = nc_same[None].float()
         gC, gO, gD, gF = gC * mask, gO * mask, gD * mask, gF * mask
@@ -248,6 +250,16 @@ def test_backward_parity_variants(ppl, dpp, hip_lib):
         _check_backward(make_case(S=16, seed=41), "bwd_ppl%d_dpp%d" % (ppl, dpp))
     finally:
         hip_lib.r3dg_set_tuning(0, 1, 1)
+
+
+@pytest.mark.parametrize("fu,bu,order", [(1, 1, 0), (2, 2, 1), (4, 4, 1), (4, 2, 0)])
+def test_parity_inner_loop_unroll_and_tile_order(fu, bu, order, hip_lib):
+    """Scheduling knobs (entries per inner-loop step, longest-tile-first block order) must not change results."""
+    hip_lib.r3dg_set_tuning2(fu, bu, order)
+    try:
+        _check_backward(make_case(S=16, seed=61, P=4000), "unroll_f%d_b%d_order%d" % (fu, bu, order))
+    finally:
+        hip_lib.r3dg_set_tuning2(4, 1, 1)
 
 
 @pytest.mark.parametrize("N", [16, 32, 64])

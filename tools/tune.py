@@ -32,11 +32,15 @@ def run(S, fppl, bppl, dpp, iters=10):
     prof = _lib.profile_read(); L.r3dg_profile_enable(0)
     return out[0], {k: round(v[0] / max(v[1], 1), 4) for k, v in prof.items()}
 
-for S in (5, 16, 28):
-    for fppl in (1, 2, 4):
-        R, pr = run(S, fppl, 1, 1)
-        print("S=%d fwd_ppl=%d R=%d render_forward %.4f ms" % (S, fppl, R, pr["render_forward"]))
-    for bppl, dpp in ((1, 1), (2, 1), (1, 0), (2, 0)):
-        R, pr = run(S, 2, bppl, dpp)
-        print("S=%d bwd_ppl=%d dpp=%d render_backward %.4f ms" % (S, bppl, dpp, pr["render_backward"]))
+for S in (5, 16):
+    for fu in (1, 2, 4):
+        for order in (0, 1):
+            L.r3dg_set_tuning2(fu, 2, order)
+            R, pr = run(S, 1, 1, 1)
+            print("S=%d fwd_unroll=%d order=%d R=%d render_forward %.4f ms" % (S, fu, order, R, pr["render_forward"]))
+    for bu in (1, 2, 4):
+        for order in (0, 1):
+            L.r3dg_set_tuning2(4, bu, order)
+            R, pr = run(S, 1, 1, 1)
+            print("S=%d bwd_unroll=%d order=%d render_backward %.4f ms" % (S, bu, order, pr["render_backward"]))
     print("S=%d all stages:" % S, json.dumps(pr))
