@@ -11,7 +11,12 @@
 //     sampled bilinearly from there; in the backward its gradient is accumulated in a second LDS copy with
 //     ds_add_f32 and flushed with one global atomic per texel per block (blocks are persistent / grid-strided);
 //   * the K-mean of the 19 forward outputs / the 55 per-Gaussian gradients (48 SH + 3 albedo + 1 roughness +
-//     3 view direction) is a transposing wave reduction (see rasterizer_render_bwd.hip) ending in one store.
+//     3 view direction) is a transposing wave reduction (wave_reduce.hpp) ending in one store; the backward does it in
+//     two 32-channel halves generated on the fly so only ~32 partials are live at a time;
+//   * the per-Gaussian uniform record (48 SH coefficients, albedo, roughness, normal, view direction, upstream
+//     gradients = 64 floats) is fetched by ONE coalesced wave load (lane l reads element l), parked in a per-wave LDS
+//     slot and read back as broadcasts -- no serial chain of scalar loads -- and the record and first 64 samples of the
+//     wave's NEXT Gaussian are prefetched into registers before the current one is processed (HBM latency hidden).
 #include "common.hpp"
 #include "wave_reduce.hpp"
 
@@ -103,17 +108,35 @@ struct GaussFwd {            // wave-uniform per-Gaussian quantities
     float v_raw[3];
 };
 
-__device__ __forceinline__ void gauss_setup(GaussFwd& G, const float* __restrict__ base_color,
-                                            const float* __restrict__ roughness, const float* __restrict__ normals,
-                                            const float* __restrict__ viewdirs, int g)
+// Layout of the per-wave uniform record u[64]: 0..47 SH coefficients (i*3+c), 48..50 albedo, 51 roughness,
+// 52..54 normal, 55..57 view direction, 58..60 dL_dpbr, 61..63 dL_ddiffuse_light (the last six only in the backward).
+__device__ __forceinline__ float load_uniform_element(int lane, int g, int M, const float* __restrict__ base_color,
+                                                      const float* __restrict__ roughness,
+                                                      const float* __restrict__ normals,
+                                                      const float* __restrict__ viewdirs,
+                                                      const float* __restrict__ incidents,
+                                                      const float* __restrict__ g_pbr, const float* __restrict__ g_diff)
+{
+    const float* p = nullptr;
+    if (lane < 48) { if (lane < 3 * M) p = incidents + (size_t)g * M * 3 + lane; }
+    else if (lane < 51) p = base_color + 3 * (size_t)g + (lane - 48);
+    else if (lane == 51) p = roughness + g;
+    else if (lane < 55) p = normals + 3 * (size_t)g + (lane - 52);
+    else if (lane < 58) p = viewdirs + 3 * (size_t)g + (lane - 55);
+    else if (lane < 61) { if (g_pbr) p = g_pbr + 3 * (size_t)g + (lane - 58); }
+    else { if (g_diff) p = g_diff + 3 * (size_t)g + (lane - 61); }
+    return p ? *p : 0.f;
+}
+
+__device__ __forceinline__ void gauss_setup(GaussFwd& G, const float* u)
 {
 #pragma unroll
     for (int c = 0; c < 3; c++) {
-        G.base[c] = base_color[3 * g + c];
-        G.n[c] = normals[3 * g + c];
-        G.v_raw[c] = viewdirs[3 * g + c];
+        G.base[c] = u[48 + c];
+        G.n[c] = u[52 + c];
+        G.v_raw[c] = u[55 + c];
     }
-    G.r = roughness[g];
+    G.r = u[51];
     G.vlen = fmaxf(sqrtf(G.v_raw[0] * G.v_raw[0] + G.v_raw[1] * G.v_raw[1] + G.v_raw[2] * G.v_raw[2]), 1e-12f);
     const float nlen = fmaxf(sqrtf(G.n[0] * G.n[0] + G.n[1] * G.n[1] + G.n[2] * G.n[2]), 1e-12f);
     float N0[3];
@@ -133,8 +156,25 @@ __device__ __forceinline__ void gauss_setup(GaussFwd& G, const float* __restrict
     G.kk = (G.a + 2.f * G.r + 1.0f) / 8.0f;
 }
 
-template <bool ENV_LDS>
-__device__ __forceinline__ void shade_sample(SampleFwd& s, const GaussFwd& G, const float* __restrict__ sh /*[M*3]*/,
+// local incident light before the clamp: sum_i Y_i(d) * sh[i][c]  (48 coefficients as 12 broadcast ds_read_b128)
+__device__ __forceinline__ void sh_local_sum(const float* sh /*[48] in LDS, zero padded*/, const float (&Y)[16],
+                                             float (&acc)[3])
+{
+    acc[0] = acc[1] = acc[2] = 0.f;
+#pragma unroll
+    for (int q = 0; q < 12; q++) {
+        const float4 c4 = reinterpret_cast<const float4*>(sh)[q];
+        const float cf[4] = {c4.x, c4.y, c4.z, c4.w};
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+            const int f = 4 * q + e;
+            acc[f % 3] += Y[f / 3] * cf[e];
+        }
+    }
+}
+
+template <bool ENV_LDS, bool HAVE_SHSUM = false>
+__device__ __forceinline__ void shade_sample(SampleFwd& s, const GaussFwd& G, const float* sh /*[48] in LDS, zero padded*/,
                                              int M, float dx, float dy, float dz, float vis, float area,
                                              const float* __restrict__ env, const float* s_env,
                                              const float* __restrict__ tr, int He, int We)
@@ -153,17 +193,21 @@ __device__ __forceinline__ void shade_sample(SampleFwd& s, const GaussFwd& G, co
         }
     }
     // local incident light: max(SH(d), 0)
-    sh_basis16(dx, dy, dz, M, s.Y);
+    {
+        float acc[3];
+        if (HAVE_SHSUM) {                        // the caller evaluated the SH sum in an earlier pass (passed via s.shsum)
+            acc[0] = s.shsum[0]; acc[1] = s.shsum[1]; acc[2] = s.shsum[2];
+        } else {
+            sh_basis16(dx, dy, dz, M, s.Y);      // Y[i] = 0 for i >= M, and the LDS record is zero padded
+            sh_local_sum(sh, s.Y, acc);
+        }
 #pragma unroll
-    for (int c = 0; c < 3; c++) {
-        float acc = 0.f;
-#pragma unroll
-        for (int i = 0; i < 16; i++)
-            if (i < M) acc += s.Y[i] * sh[i * 3 + c];
-        s.shsum[c] = acc;
-        s.local[c] = fmaxf(acc, 0.f);
-        s.glob[c] = e[c] * vis;
-        s.lin[c] = s.local[c] + s.glob[c];
+        for (int c = 0; c < 3; c++) {
+            s.shsum[c] = acc[c];
+            s.local[c] = fmaxf(acc[c], 0.f);
+            s.glob[c] = e[c] * vis;
+            s.lin[c] = s.local[c] + s.glob[c];
+        }
     }
     s.ndi = fmaxf(G.n[0] * dx + G.n[1] * dy + G.n[2] * dz, 0.f);
     s.area_ndi = area * s.ndi;
@@ -195,6 +239,27 @@ __device__ __forceinline__ void shade_sample(SampleFwd& s, const GaussFwd& G, co
     for (int c = 0; c < 3; c++) s.transport[c] = s.lin[c] * s.area_ndi;
 }
 
+// ---- 16 lanes per Gaussian, 4 Gaussians per wave ----------------------------------------------------------
+// One Gaussian occupies one 16-lane DPP row; its K samples are strided over the 16 lanes (k = l, l+16, ...), so each
+// wave load touches four contiguous 192-byte runs.  Per-Gaussian setup and the final cross-lane reduction are shared
+// by 4 Gaussians per wave instruction and the reduction never leaves a DPP row (distances 8,4,2,1 only).
+constexpr int SH_L = 16;
+constexpr int SH_GW = 64 / SH_L;                  // Gaussians per wave
+constexpr int SH_GB = SH_GW * SHADE_WAVES;        // Gaussians per block step
+
+// 16 partial values per lane -> lane l (within its 16-lane row) returns the row total of channel l
+__device__ __forceinline__ float row_transpose_reduce16(float (&v)[16])
+{
+    const int lane = lane_id();
+#pragma unroll
+    for (int k = 0; k < 8; k++) v[k] = transpose_step<8, true>(v[k], v[k + 8], (lane & 8) != 0);
+#pragma unroll
+    for (int k = 0; k < 4; k++) v[k] = transpose_step<4, true>(v[k], v[k + 4], (lane & 4) != 0);
+#pragma unroll
+    for (int k = 0; k < 2; k++) v[k] = transpose_step<2, true>(v[k], v[k + 2], (lane & 2) != 0);
+    return transpose_step<1, true>(v[0], v[1], (lane & 1) != 0);
+}
+
 template <bool ENV_LDS>
 __global__ void __launch_bounds__(64 * SHADE_WAVES)
 shade_forward_kernel(int P, int K, int M, const float* __restrict__ base_color, const float* __restrict__ roughness,
@@ -204,48 +269,88 @@ shade_forward_kernel(int P, int K, int M, const float* __restrict__ base_color, 
                      const float* __restrict__ dirs, const float* __restrict__ areas, float* __restrict__ out)
 {
     extern __shared__ __attribute__((aligned(16))) float s_mem[];
+    const int ntex = ENV_LDS ? ((He * We * 3 + 3) & ~3) : 0;
     float* s_env = s_mem;
     if (ENV_LDS) {
         for (int i = threadIdx.x; i < He * We * 3; i += blockDim.x) s_env[i] = env[i];
         __syncthreads();
     }
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int chan = transposed_channel<32>(lane);
-    const bool owner = transposed_owner<32>(lane) && chan < SHADE_NOUT;
+    const int grp = lane >> 4, l = lane & 15;
+    float* s_u = s_mem + ntex + (wave * SH_GW + grp) * 64;
     const float invK = 1.0f / (float)K;
-    for (int g0 = blockIdx.x * SHADE_WAVES + wave; g0 < P; g0 += gridDim.x * SHADE_WAVES) {
-        const int g = __builtin_amdgcn_readfirstlane(g0);
+    for (int gb = (blockIdx.x * SHADE_WAVES + wave) * SH_GW; gb < P; gb += gridDim.x * SH_GB) {
+        const int g = gb + grp;
+        const bool live = g < P;
+        // stage the Gaussian's 64-float uniform record: 4 elements per lane
+#pragma unroll
+        for (int t = 0; t < 4; t++)
+            s_u[l + 16 * t] = live ? load_uniform_element(l + 16 * t, g, M, base_color, roughness, normals, viewdirs,
+                                                          incidents, nullptr, nullptr) : 0.f;
         GaussFwd G;
-        gauss_setup(G, base_color, roughness, normals, viewdirs, g);
-        const float* sh = incidents + (size_t)g * M * 3;
+        gauss_setup(G, s_u);
         float v[32];
 #pragma unroll
         for (int i = 0; i < 32; i++) v[i] = 0.f;
-        for (int k = lane; k < K; k += 64) {
-            const size_t o = (size_t)g * K + k;
-            SampleFwd s;
-            shade_sample<ENV_LDS>(s, G, sh, M, dirs[3 * o], dirs[3 * o + 1], dirs[3 * o + 2], visibility[o], areas[o],
-                                  env, s_env, tr, He, We);
+        if (live) {
+            for (int k = l; k < K; k += SH_L) {
+                const size_t o = (size_t)g * K + k;
+                SampleFwd s;
+                shade_sample<ENV_LDS>(s, G, s_u, M, dirs[3 * o], dirs[3 * o + 1], dirs[3 * o + 2], visibility[o],
+                                      areas[o], env, s_env, tr, He, We);
 #pragma unroll
-            for (int c = 0; c < 3; c++) {
-                const float fd = G.base[c] / kPi;
-                v[c] += (fd + s.spec) * s.transport[c];      // pbr
-                v[3 + c] += s.transport[c];                  // diffuse_light
-                v[6 + c] += s.spec * s.transport[c];         // specular
-                v[9 + c] += s.lin[c];                        // incident_lights mean
-                v[12 + c] += s.local[c];
-                v[15 + c] += s.glob[c];
+                for (int c = 0; c < 3; c++) {
+                    const float fd = G.base[c] / kPi;
+                    v[c] += (fd + s.spec) * s.transport[c];      // pbr
+                    v[3 + c] += s.transport[c];                  // diffuse_light
+                    v[6 + c] += s.spec * s.transport[c];         // specular
+                    v[9 + c] += s.lin[c];                        // incident_lights mean
+                    v[12 + c] += s.local[c];
+                    v[15 + c] += s.glob[c];
+                }
+                v[18] += s.vis;
             }
-            v[18] += s.vis;
         }
-        const float total = transpose_reduce<32, true>(v);
-        if (owner) out[(size_t)g * SHADE_NOUT + chan] = total * invK;
+        float va[16], vb[16];
+#pragma unroll
+        for (int i = 0; i < 16; i++) { va[i] = v[i]; vb[i] = v[16 + i]; }
+        const float r0 = row_transpose_reduce16(va);
+        const float r1 = row_transpose_reduce16(vb);
+        if (live) {
+            out[(size_t)g * SHADE_NOUT + l] = r0 * invK;
+            if (l < SHADE_NOUT - 16) out[(size_t)g * SHADE_NOUT + 16 + l] = r1 * invK;
+        }
     }
 }
 
 // Backward: gradients of sum(pbr*g_pbr) + sum(diffuse_light*g_diff) w.r.t. base_color, roughness, viewdirs,
 // incidents and the (activated) environment texture.  normals / dirs / visibility carry no gradient in the
 // reference (normal.detach(), cached samples).
+// max(|g_pbr|, |g_diff|) over all Gaussians -> *out (as float bits; non-negative floats order like unsigned ints).
+__global__ void __launch_bounds__(256)
+grad_absmax_kernel(int n, const float* __restrict__ a, const float* __restrict__ b, unsigned int* __restrict__ out)
+{
+    float m = 0.f;
+    bool bad = false;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+        const float x = fabsf(a[i]), y = fabsf(b[i]);
+        bad = bad || !(x <= 3.0e38f) || !(y <= 3.0e38f);       // inf / nan
+        m = fmaxf(m, fmaxf(x, y));
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+    if (__ballot(bad) != 0ull) m = __uint_as_float(0x7f800000u);   // +inf marks "non-finite input"
+    if ((threadIdx.x & 63) == 0) atomicMax(out, __float_as_uint(m));
+}
+
+// The environment-texture gradient is a scatter of 12 values per sample into a few hundred texels.  LDS *float*
+// atomics (ds_add_f32) retire about one lane every 3 cycles on gfx950 -- measured: they alone were 60 % of this
+// kernel -- while LDS *integer* atomics run at full rate.  The block therefore accumulates in signed 64-bit fixed
+// point, scale = 2^35 / max|upstream gradient| (one small max-reduction kernel in front): a single contribution is
+// bounded by max|g| * (1 + spec) * 2*pi <= max|g| * 2^13 for spec <= 1024 (larger ones are clamped), a block adds
+// fewer than 2^14 of them per texel, so the sum stays below 2^62; the resolution is 3e-11 * max|g| -- finer than the
+// fp32 accumulation it replaces -- and the per-block sum is order-independent.  Non-finite upstream gradients fall
+// back to float atomics so NaN/inf still propagate.
 template <bool ENV_LDS>
 __global__ void __launch_bounds__(64 * SHADE_WAVES)
 shade_backward_kernel(int P, int K, int M, const float* __restrict__ base_color, const float* __restrict__ roughness,
@@ -255,126 +360,203 @@ shade_backward_kernel(int P, int K, int M, const float* __restrict__ base_color,
                       const float* __restrict__ dirs, const float* __restrict__ areas,
                       const float* __restrict__ g_pbr, const float* __restrict__ g_diff, float* __restrict__ d_base,
                       float* __restrict__ d_rough, float* __restrict__ d_view, float* __restrict__ d_inc,
-                      float* __restrict__ d_env)
+                      float* __restrict__ d_env, const unsigned int* __restrict__ gmax_bits)
 {
     extern __shared__ __attribute__((aligned(16))) float s_mem[];
+    const int ntex_raw = He * We * 3;
+    const int ntex = ENV_LDS ? ((ntex_raw + 3) & ~3) : 0;
     float* s_env = s_mem;
-    float* s_denv = s_mem + (ENV_LDS ? He * We * 3 : 0);
-    const int ntex = He * We * 3;
+    long long* s_denv = reinterpret_cast<long long*>(s_mem + ntex);      // 64-bit fixed-point accumulators
+    const float gmax = __uint_as_float(*gmax_bits);
+    const bool fixed = ENV_LDS && gmax > 0.f && gmax <= 3.0e38f;
+    const float fx_scale = fixed ? 34359738368.0f / gmax : 0.f;          // 2^35 / max|g|
+    const float fx_clamp = gmax * 8192.0f;                               // |contribution| <= max|g| * 2^13
     if (ENV_LDS) {
-        for (int i = threadIdx.x; i < ntex; i += blockDim.x) {
+        for (int i = threadIdx.x; i < ntex_raw; i += blockDim.x) {
             s_env[i] = env[i];
-            s_denv[i] = 0.f;
+            s_denv[i] = 0;
         }
         __syncthreads();
     }
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    // channel map of the 64-wide transposed reduction: 0..47 incidents (i*3+c), 48..50 base, 51 roughness, 52..54 view
-    const int chan = transposed_channel<64>(lane);
+    const int grp = lane >> 4, l = lane & 15;
+    float* s_u = s_mem + 3 * ntex + (wave * SH_GW + grp) * 64;
+    float* s_dl = s_mem + 3 * ntex + SH_GB * 64;          // 24 floats per thread: parked dL/d(local light) and SH sums
     const float invK = 1.0f / (float)K;
-    for (int g0 = blockIdx.x * SHADE_WAVES + wave; g0 < P; g0 += gridDim.x * SHADE_WAVES) {
-        const int g = __builtin_amdgcn_readfirstlane(g0);
+    for (int gb = (blockIdx.x * SHADE_WAVES + wave) * SH_GW; gb < P; gb += gridDim.x * SH_GB) {
+        const int g = gb + grp;
+        const bool live = g < P;
+#pragma unroll
+        for (int t = 0; t < 4; t++)
+            s_u[l + 16 * t] = live ? load_uniform_element(l + 16 * t, g, M, base_color, roughness, normals, viewdirs,
+                                                          incidents, g_pbr, g_diff) : 0.f;
         GaussFwd G;
-        gauss_setup(G, base_color, roughness, normals, viewdirs, g);
-        const float* sh = incidents + (size_t)g * M * 3;
-        const float gp[3] = {g_pbr[3 * g] * invK, g_pbr[3 * g + 1] * invK, g_pbr[3 * g + 2] * invK};
-        const float gd[3] = {g_diff[3 * g] * invK, g_diff[3 * g + 1] * invK, g_diff[3 * g + 2] * invK};
-        float v[64];
+        gauss_setup(G, s_u);
+        const float gp[3] = {s_u[58] * invK, s_u[59] * invK, s_u[60] * invK};
+        const float gd[3] = {s_u[61] * invK, s_u[62] * invK, s_u[63] * invK};
+        // per-lane accumulators over this lane's samples: 48 SH gradient channels (f = i*3 + c), albedo, roughness, view.
+        // Samples are taken in blocks of 4 per lane and each block is walked twice to keep the live register set small:
+        // pass 1 does the full sample + BRDF/view/env gradients and parks the 3 "dL/d local light" values in LDS,
+        // pass 2 re-reads the direction, rebuilds the SH basis (40 instructions) and does the 48 SH-gradient FMAs.
+        float acc[48];
+        float accb[8];       // 0..2 albedo, 3 roughness, 4..6 view direction
 #pragma unroll
-        for (int i = 0; i < 64; i++) v[i] = 0.f;
-        for (int k = lane; k < K; k += 64) {
-            const size_t o = (size_t)g * K + k;
-            const float dx = dirs[3 * o], dy = dirs[3 * o + 1], dz = dirs[3 * o + 2];
-            SampleFwd s;
-            shade_sample<ENV_LDS>(s, G, sh, M, dx, dy, dz, visibility[o], areas[o], env, s_env, tr, He, We);
-            float gspec = 0.f;
-            float dlin[3];
+        for (int i = 0; i < 48; i++) acc[i] = 0.f;
 #pragma unroll
-            for (int c = 0; c < 3; c++) {
-                const float fd = G.base[c] / kPi;
-                const float dT = gp[c] * (fd + s.spec) + gd[c];       // dL/dtransport_c
-                gspec += gp[c] * s.transport[c];
-                v[48 + c] += gp[c] * s.transport[c] / kPi;            // base_color
-                dlin[c] = dT * s.area_ndi;                            // dL/d(incident light)_c
-            }
-            // incident SH (clamp_min(0): gradient where the SH sum >= 0) and environment texels
-#pragma unroll
-            for (int c = 0; c < 3; c++) {
-                const float dl = s.shsum[c] >= 0.f ? dlin[c] : 0.f;
-#pragma unroll
-                for (int i = 0; i < 16; i++)
-                    if (i < M) v[i * 3 + c] += dl * s.Y[i];
-            }
-#pragma unroll
+        for (int i = 0; i < 8; i++) accb[i] = 0.f;
+        float* my_dl = s_dl + threadIdx.x * 24;
+        float* my_sum = my_dl + 12;
+        for (int k0 = 0; k0 < K; k0 += 4 * SH_L) {
+            // pass 0: SH sums of the local incident light (basis + 48 coefficient FMAs), parked in LDS
+#pragma unroll 1
             for (int t = 0; t < 4; t++) {
-                if (s.taps.idx[t] >= 0) {
+                const int k = k0 + l + SH_L * t;
+                float sum[3] = {0.f, 0.f, 0.f};
+                if (live && k < K) {
+                    const size_t o = (size_t)g * K + k;
+                    float Y[16];
+                    sh_basis16(dirs[3 * o], dirs[3 * o + 1], dirs[3 * o + 2], M, Y);
+                    sh_local_sum(s_u, Y, sum);
+                }
+                my_sum[3 * t] = sum[0];
+                my_sum[3 * t + 1] = sum[1];
+                my_sum[3 * t + 2] = sum[2];
+            }
+#pragma unroll 1
+            for (int t = 0; t < 4; t++) {
+                const int k = k0 + l + SH_L * t;
+                float dl[3] = {0.f, 0.f, 0.f};
+                if (live && k < K) {
+                    const size_t o = (size_t)g * K + k;
+                    SampleFwd s;
+                    s.shsum[0] = my_sum[3 * t]; s.shsum[1] = my_sum[3 * t + 1]; s.shsum[2] = my_sum[3 * t + 2];
+                    shade_sample<ENV_LDS, true>(s, G, s_u, M, dirs[3 * o], dirs[3 * o + 1], dirs[3 * o + 2],
+                                                visibility[o], areas[o], env, s_env, tr, He, We);
+                    float gspec = 0.f;
+                    float dlin[3];
 #pragma unroll
                     for (int c = 0; c < 3; c++) {
-                        const float val = dlin[c] * s.vis * s.taps.w[t];
-                        if (ENV_LDS) atomicAdd(&s_denv[3 * s.taps.idx[t] + c], val);
-                        else atomicAdd(&d_env[3 * (size_t)s.taps.idx[t] + c], val);
+                        const float fd = G.base[c] / kPi;
+                        const float dT = gp[c] * (fd + s.spec) + gd[c];       // dL/dtransport_c
+                        gspec += gp[c] * s.transport[c];
+                        accb[c] += gp[c] * s.transport[c] / kPi;              // albedo
+                        dlin[c] = dT * s.area_ndi;                            // dL/d(incident light)_c
+                        dl[c] = s.shsum[c] >= 0.f ? dlin[c] : 0.f;            // clamp_min(0): gradient where SH sum >= 0
                     }
+#pragma unroll
+                    for (int tt = 0; tt < 4; tt++) {
+                        if (s.taps.idx[tt] >= 0) {
+#pragma unroll
+                            for (int c = 0; c < 3; c++) {
+                                const float val = dlin[c] * s.vis * s.taps.w[tt];
+                                if (val == 0.f) continue;
+                                if (fixed) {
+                                    const float cl = fminf(fmaxf(val, -fx_clamp), fx_clamp);
+                                    atomicAdd(reinterpret_cast<unsigned long long*>(&s_denv[3 * s.taps.idx[tt] + c]),
+                                              (unsigned long long)(long long)(cl * fx_scale));
+                                } else {
+                                    atomicAdd(&d_env[3 * (size_t)s.taps.idx[tt] + c], val);
+                                }
+                            }
+                        }
+                    }
+                    // specular -> roughness, view direction
+                    const float frac = s.frac0 * G.a2;
+                    const bool nom_free = s.nomr >= 1e-6f && s.nomr <= 4.f * kPi;
+                    const float nom = fminf(fmaxf(s.nomr, 1e-6f), 4.f * kPi);
+                    const float dfrac = gspec / nom;
+                    const float dnom = nom_free ? -gspec * frac / (nom * nom) : 0.f;
+                    float da2 = dfrac * s.frac0;
+                    const float dfrac0 = dfrac * G.a2;
+                    const float dFMi = dfrac0 * 0.96f * 0.6931471805599453f * s.p2;
+                    float dVoH = dFMi * (-2.f * 5.55473f * s.VoH - 6.98316f);
+                    const float c4 = 4.f * kPi;
+                    const float dnom0 = dnom * c4 * 2.f * s.nom0 * s.nom1 * s.nom2;
+                    const float dnom1 = dnom * c4 * s.nom0 * s.nom0 * s.nom2;
+                    const float dnom2 = dnom * c4 * s.nom0 * s.nom0 * s.nom1;
+                    float dNoH = dnom0 * 2.f * s.NoH * (G.a2 - 1.f);
+                    da2 += dnom0 * s.NoH * s.NoH;
+                    float dNoV = dnom1 * (1.f - G.kk);
+                    const float dkk = dnom1 * (1.f - G.NoV) + dnom2 * (1.f - s.NoL);
+                    const float da = dkk / 8.f + da2 * 2.f * G.a;
+                    accb[3] += dkk * 2.f / 8.f + da * 2.f * G.r;               // roughness
+                    if (!(s.rawNoH >= 1e-6f && s.rawNoH <= 1.f)) dNoH = 0.f;
+                    if (!(s.rawVoH >= 1e-6f && s.rawVoH <= 1.f)) dVoH = 0.f;
+                    if (!(G.rawNoV >= 1e-6f && G.rawNoV <= 1.f)) dNoV = 0.f;
+                    float dH[3], dV[3];
+#pragma unroll
+                    for (int c = 0; c < 3; c++) {
+                        dH[c] = dNoH * G.N[c] + dVoH * G.V[c];
+                        dV[c] = dVoH * s.Hh[c] + dNoV * G.N[c];
+                    }
+                    const float hd = s.Hh[0] * dH[0] + s.Hh[1] * dH[1] + s.Hh[2] * dH[2];
+#pragma unroll
+                    for (int c = 0; c < 3; c++) dV[c] += 0.5f * (dH[c] - s.Hh[c] * hd) / s.ulen;
+                    const float vd = G.V[0] * dV[0] + G.V[1] * dV[1] + G.V[2] * dV[2];
+#pragma unroll
+                    for (int c = 0; c < 3; c++) accb[4 + c] += (dV[c] - G.V[c] * vd) / G.vlen;   // view direction
+                }
+                my_dl[3 * t] = dl[0];
+                my_dl[3 * t + 1] = dl[1];
+                my_dl[3 * t + 2] = dl[2];
+            }
+#pragma unroll 1
+            for (int t = 0; t < 4; t++) {
+                const int k = k0 + l + SH_L * t;
+                if (live && k < K) {
+                    const size_t o = (size_t)g * K + k;
+                    float Y[16];
+                    sh_basis16(dirs[3 * o], dirs[3 * o + 1], dirs[3 * o + 2], M, Y);
+                    const float dl[3] = {my_dl[3 * t], my_dl[3 * t + 1], my_dl[3 * t + 2]};
+#pragma unroll
+                    for (int f = 0; f < 48; f++) acc[f] += dl[f % 3] * Y[f / 3];
                 }
             }
-            // specular -> roughness, view direction
-            const float frac = s.frac0 * G.a2;
-            const bool nom_free = s.nomr >= 1e-6f && s.nomr <= 4.f * kPi;
-            const float nom = fminf(fmaxf(s.nomr, 1e-6f), 4.f * kPi);
-            const float dfrac = gspec / nom;
-            const float dnom = nom_free ? -gspec * frac / (nom * nom) : 0.f;
-            float da2 = dfrac * s.frac0;
-            const float dfrac0 = dfrac * G.a2;
-            const float dFMi = dfrac0 * 0.96f * 0.6931471805599453f * s.p2;
-            float dVoH = dFMi * (-2.f * 5.55473f * s.VoH - 6.98316f);
-            const float c4 = 4.f * kPi;
-            const float dnom0 = dnom * c4 * 2.f * s.nom0 * s.nom1 * s.nom2;
-            const float dnom1 = dnom * c4 * s.nom0 * s.nom0 * s.nom2;
-            const float dnom2 = dnom * c4 * s.nom0 * s.nom0 * s.nom1;
-            float dNoH = dnom0 * 2.f * s.NoH * (G.a2 - 1.f);
-            da2 += dnom0 * s.NoH * s.NoH;
-            float dNoV = dnom1 * (1.f - G.kk);
-            const float dkk = dnom1 * (1.f - G.NoV) + dnom2 * (1.f - s.NoL);
-            float da = dkk / 8.f + da2 * 2.f * G.a;
-            const float dr = dkk * 2.f / 8.f + da * 2.f * G.r;
-            v[51] += dr;
-            if (!(s.rawNoH >= 1e-6f && s.rawNoH <= 1.f)) dNoH = 0.f;
-            if (!(s.rawVoH >= 1e-6f && s.rawVoH <= 1.f)) dVoH = 0.f;
-            if (!(G.rawNoV >= 1e-6f && G.rawNoV <= 1.f)) dNoV = 0.f;
-            float dH[3], dV[3];
-#pragma unroll
-            for (int c = 0; c < 3; c++) {
-                dH[c] = dNoH * G.N[c] + dVoH * G.V[c];
-                dV[c] = dVoH * s.Hh[c] + dNoV * G.N[c];
-            }
-            const float hd = s.Hh[0] * dH[0] + s.Hh[1] * dH[1] + s.Hh[2] * dH[2];
-#pragma unroll
-            for (int c = 0; c < 3; c++) dV[c] += 0.5f * (dH[c] - s.Hh[c] * hd) / s.ulen;
-            const float vd = G.V[0] * dV[0] + G.V[1] * dV[1] + G.V[2] * dV[2];
-#pragma unroll
-            for (int c = 0; c < 3; c++) v[52 + c] += (dV[c] - G.V[c] * vd) / G.vlen;
         }
-        const float total = transpose_reduce<64, true>(v);
-        if (chan < 48) {
-            if (chan < M * 3) d_inc[(size_t)g * M * 3 + chan] = total;
-        } else if (chan < 51) d_base[3 * g + (chan - 48)] = total;
-        else if (chan == 51) d_rough[g] = total;
-        else if (chan < 55) d_view[3 * g + (chan - 52)] = total;
+        // four row reductions of 16 channels each: lane l ends with channel 16*pass + l
+        float r[4];
+#pragma unroll
+        for (int pass = 0; pass < 3; pass++) {
+            float v[16];
+#pragma unroll
+            for (int i = 0; i < 16; i++) v[i] = acc[16 * pass + i];
+            r[pass] = row_transpose_reduce16(v);
+        }
+        {
+            float v[16];
+#pragma unroll
+            for (int i = 0; i < 16; i++) v[i] = i < 8 ? accb[i] : 0.f;
+            r[3] = row_transpose_reduce16(v);
+        }
+        if (live) {
+#pragma unroll
+            for (int pass = 0; pass < 3; pass++) {
+                const int f = 16 * pass + l;
+                if (f < 3 * M) d_inc[(size_t)g * M * 3 + f] = r[pass];
+            }
+            if (l < 3) d_base[3 * (size_t)g + l] = r[3];
+            else if (l == 3) d_rough[g] = r[3];
+            else if (l < 7) d_view[3 * (size_t)g + (l - 4)] = r[3];
+        }
     }
-    if (ENV_LDS) {
+    if (fixed) {
         __syncthreads();
-        for (int i = threadIdx.x; i < ntex; i += blockDim.x) {
-            const float val = s_denv[i];
-            if (val != 0.f) atomicAdd(&d_env[i], val);
+        const float inv = 1.0f / fx_scale;
+        for (int i = threadIdx.x; i < ntex_raw; i += blockDim.x) {
+            const long long v64 = s_denv[i];
+            if (v64 != 0) atomicAdd(&d_env[i], (float)((double)v64 * (double)inv));
         }
     }
 }
 
-static int shade_grid(int P)
+static int shade_grid_impl(int P);
+static int shade_grid(int P) { return shade_grid_impl(P); }
+static int shade_grid_impl(int P)
 {
     int dev = 0, cus = 256;
     (void)hipGetDevice(&dev);
     (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-    const int want = (P + SHADE_WAVES - 1) / SHADE_WAVES;
+    const int want = (P + SH_GB - 1) / SH_GB;
     const int cap = cus * 8;
     return want < cap ? (want > 0 ? want : 1) : cap;
 }
@@ -386,11 +568,12 @@ void launch_shade_forward(hipStream_t s, int P, int K, int M, const float* base_
 {
     const int ntex = He * We * 3;
     const int grid = shade_grid(P);
+    const size_t u_bytes = SH_GB * 64 * sizeof(float);
     if (ntex <= ENV_LDS_MAX)
-        shade_forward_kernel<true><<<grid, 64 * SHADE_WAVES, ntex * sizeof(float), s>>>(
+        shade_forward_kernel<true><<<grid, 64 * SHADE_WAVES, ((ntex + 3) & ~3) * sizeof(float) + u_bytes, s>>>(
             P, K, M, base_color, roughness, normals, viewdirs, incidents, env, He, We, tr, visibility, dirs, areas, out);
     else
-        shade_forward_kernel<false><<<grid, 64 * SHADE_WAVES, 0, s>>>(
+        shade_forward_kernel<false><<<grid, 64 * SHADE_WAVES, u_bytes, s>>>(
             P, K, M, base_color, roughness, normals, viewdirs, incidents, env, He, We, tr, visibility, dirs, areas, out);
 }
 
@@ -400,17 +583,29 @@ void launch_shade_backward(hipStream_t s, int P, int K, int M, const float* base
                            const float* areas, const float* g_pbr, const float* g_diff, float* d_base, float* d_rough,
                            float* d_view, float* d_inc, float* d_env)
 {
+    // one 4-byte device scratch word per device for the max|upstream gradient| (allocated once, never freed)
+    static unsigned int* scratch[64] = {nullptr};
+    int dev = 0;
+    R3DG_HIP(hipGetDevice(&dev));
+    if (dev < 0 || dev >= 64) dev = 0;
+    if (scratch[dev] == nullptr) R3DG_HIP(hipMalloc((void**)&scratch[dev], 256));
+    R3DG_HIP(hipMemsetAsync(scratch[dev], 0, 4, s));
+    const int nb = (3 * P + 255) / 256;
+    grad_absmax_kernel<<<nb < 1024 ? nb : 1024, 256, 0, s>>>(3 * P, g_pbr, g_diff, scratch[dev]);
+
     const int ntex = He * We * 3;
     // persistent blocks so the LDS-privatised env gradient is flushed once per block, not once per Gaussian
-    int grid = shade_grid(P);
-    if (2 * ntex <= ENV_LDS_MAX)
-        shade_backward_kernel<true><<<grid, 64 * SHADE_WAVES, 2 * ntex * sizeof(float), s>>>(
+    const int grid = shade_grid(P);
+    const size_t u_bytes = SH_GB * 64 * sizeof(float);
+    const size_t dl_bytes = 64 * SHADE_WAVES * 24 * sizeof(float);
+    if (3 * ntex <= ENV_LDS_MAX)
+        shade_backward_kernel<true><<<grid, 64 * SHADE_WAVES, 3 * ((ntex + 3) & ~3) * sizeof(float) + u_bytes + dl_bytes, s>>>(
             P, K, M, base_color, roughness, normals, viewdirs, incidents, env, He, We, tr, visibility, dirs, areas, g_pbr,
-            g_diff, d_base, d_rough, d_view, d_inc, d_env);
+            g_diff, d_base, d_rough, d_view, d_inc, d_env, scratch[dev]);
     else
-        shade_backward_kernel<false><<<grid, 64 * SHADE_WAVES, 0, s>>>(
+        shade_backward_kernel<false><<<grid, 64 * SHADE_WAVES, u_bytes + dl_bytes, s>>>(
             P, K, M, base_color, roughness, normals, viewdirs, incidents, env, He, We, tr, visibility, dirs, areas, g_pbr,
-            g_diff, d_base, d_rough, d_view, d_inc, d_env);
+            g_diff, d_base, d_rough, d_view, d_inc, d_env, scratch[dev]);
 }
 
 }  // namespace r3dg

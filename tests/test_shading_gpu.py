@@ -115,3 +115,16 @@ def test_rendering_equation_dropin_signature():
     assert extra["incident_visibility"].mean(-2).shape == (500, 1)
     assert set(extra) == {"incident_dirs", "incident_lights", "local_incident_lights", "global_incident_lights",
                           "incident_visibility", "diffuse_light", "specular"}
+
+
+def test_shading_env_gradient_nonfinite_upstream_propagates():
+    """The fixed-point env-gradient accumulator must not swallow inf/nan: it falls back to float atomics."""
+    from relightable3dgaussian_amd import shading_ops as so
+    inp = {k: v.to(DEV) for k, v in _random_inputs(256, 64, 16).items()}
+    g_pbr = inp["g_pbr"].clone()
+    g_pbr[7, 1] = float("inf")
+    d_base, d_rough, d_view, d_inc, d_env = so.shade_backward(
+        inp["base_color"], inp["roughness"], inp["normals"], inp["viewdirs"], inp["incidents"], inp["env"],
+        inp["visibility"], inp["incident_dirs"], inp["incident_areas"], g_pbr, inp["g_diff"])
+    assert not torch.isfinite(d_env).all()
+    assert not torch.isfinite(d_base[7]).all()

@@ -1,0 +1,27 @@
+"""Time the shading kernels alone at full size (GPU only)."""
+import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from relightable3dgaussian_amd import _lib, shading_ops as so, sampling
+P = int(os.environ.get("P", 300000)); dev = "cuda"
+L = _lib.lib()
+g = torch.Generator().manual_seed(0)
+for K, He, exp in ((64, 16, 0), (384, 256, 0)):
+    nrm = torch.nn.functional.normalize(torch.randn(P, 3, generator=g), dim=-1).to(dev)
+    dirs, areas = sampling.fibonacci_sphere_sampling(nrm, K)
+    vis = (torch.rand(P, K, 1, device=dev) > 0.3).float()
+    base = torch.rand(P, 3, device=dev); rough = 0.1 + 0.8 * torch.rand(P, 1, device=dev)
+    view = torch.nn.functional.normalize(torch.randn(P, 3, device=dev), dim=-1)
+    inc = 0.1 * torch.randn(P, 16, 3, device=dev)
+    env = torch.rand(He, 2 * He, 3, device=dev)
+    gp, gd = torch.randn(P, 3, device=dev), torch.randn(P, 3, device=dev)
+    for it in range(8):
+        if it == 3:
+            torch.cuda.synchronize(); L.r3dg_profile_enable(1)
+        so.shade_forward(base, rough, nrm, view, inc, env, vis, dirs, areas)
+        if K == 64:
+            so.shade_backward(base, rough, nrm, view, inc, env, vis, dirs, areas, gp, gd)
+    torch.cuda.synchronize()
+    pr = _lib.profile_read(); L.r3dg_profile_enable(0)
+    print("exp=%d" % exp, "K=%d He=%d shade_forward %.4f ms  shade_backward %.4f ms" % (
+        K, He, pr["shade_forward"][0] / max(pr["shade_forward"][1], 1), pr["shade_backward"][0] / max(pr["shade_backward"][1], 1)))
