@@ -33,7 +33,7 @@ def parse():
     ap.add_argument("--res", type=int, default=800)
     ap.add_argument("--sample-num", type=int, default=64)
     ap.add_argument("--stage", type=int, default=2, choices=[1, 2])
-    ap.add_argument("--cpu-baseline-seconds", type=float, default=20.0)
+    ap.add_argument("--cpu-baseline-seconds", type=float, default=15.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--relight-frames", type=int, default=20)
     ap.add_argument("--relight-samples", type=int, default=384)

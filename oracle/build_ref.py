@@ -1,0 +1,79 @@
+"""Build the REAL reference kernels for gfx950 as a GPU-side oracle (TEST INFRASTRUCTURE ONLY).
+
+    python -m oracle.build_ref        # needs /root/reference (this container); output: oracle/_ref/libr3dg_reference.so
+
+The reference's CUDA sources are compiled where they lie under /root/reference -- never copied into the repo -- with
+hipcc and the header shims in oracle/ref_shim/ (cuda_runtime.h -> HIP, cub -> hipcub, cooperative_groups -> HIP's, thrust
+is rocThrust).  The only source-level difference hipcc cannot digest is nvcc's tolerance for spaces inside the kernel
+launch chevrons (`<< <grid, block >> >`); those are closed up on the fly in a temporary directory that is deleted after
+the compile.  Sources built: r3dg-rasterization/cuda_rasterizer/{forward,backward,rasterizer_impl}.cu and
+bvh/src/{construct,trace}.cu (the torch-facing glue -- rasterize_points.cu, bvh.cu -- is replaced by
+oracle/ref_shim/ref_wrapper.cpp).  render_equation.cu is not part of the reference's own build.
+oracle/_ref/ is git-ignored but travels to the GPU box, where tests/test_reference_gpu.py uses it if present.
+"""
+import os
+import re
+import subprocess
+import sys
+import tempfile
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REF = "/root/reference"
+OUT_DIR = os.path.join(HERE, "_ref")
+OUT = os.path.join(OUT_DIR, "libr3dg_reference.so")
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+SHIM = os.path.join(HERE, "ref_shim")
+RAST = os.path.join(REF, "r3dg-rasterization")
+BVH = os.path.join(REF, "bvh")
+INCLUDES = ["-I", SHIM, "-I", os.path.join(RAST, "third_party", "glm"), "-I", os.path.join(RAST, "cuda_rasterizer"),
+            "-I", os.path.join(BVH, "include")]
+SOURCES = [os.path.join(RAST, "cuda_rasterizer", f) for f in ("forward.cu", "backward.cu", "rasterizer_impl.cu")] + \
+          [os.path.join(BVH, "src", f) for f in ("construct.cu", "trace.cu")]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-w"]
+
+
+def available():
+    return all(os.path.exists(s) for s in SOURCES)
+
+
+def _compile(args):
+    src, tmp = args
+    name = os.path.basename(os.path.dirname(os.path.dirname(src))) + "_" + os.path.basename(src)[:-3]
+    hip_src = os.path.join(tmp, name + ".hip")
+    text = open(src).read()
+    text = re.sub(r"<<\s+<", "<<<", text)
+    text = re.sub(r">>\s+>", ">>>", text)
+    with open(hip_src, "w") as f:
+        f.write(text)
+    obj = os.path.join(tmp, name + ".o")
+    r = subprocess.run([HIPCC] + FLAGS + INCLUDES + ["-c", hip_src, "-o", obj], capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("reference build failed for %s:\n%s" % (src, r.stderr[-4000:]))
+    return obj
+
+
+def build(force=False):
+    if not available():
+        return None
+    stamp = max(os.path.getmtime(p) for p in SOURCES + [os.path.join(SHIM, "ref_wrapper.cpp")])
+    if not force and os.path.exists(OUT) and os.path.getmtime(OUT) >= stamp:
+        return OUT
+    os.makedirs(OUT_DIR, exist_ok=True)
+    with tempfile.TemporaryDirectory() as tmp:
+        with ThreadPoolExecutor(max_workers=6) as ex:
+            objs = list(ex.map(_compile, [(s, tmp) for s in SOURCES]))
+        wobj = os.path.join(tmp, "ref_wrapper.o")
+        r = subprocess.run([HIPCC, "-x", "hip"] + FLAGS + INCLUDES + ["-c", os.path.join(SHIM, "ref_wrapper.cpp"), "-o", wobj],
+                           capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("reference wrapper build failed:\n%s" % r.stderr[-4000:])
+        r = subprocess.run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", OUT] + objs + [wobj],
+                           capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("reference link failed:\n%s" % r.stderr[-4000:])
+    return OUT
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv))

@@ -1,0 +1,108 @@
+"""ctypes face of oracle/_ref/libr3dg_reference.so -- the REAL reference kernels compiled for gfx950 (oracle/build_ref.py).
+TEST INFRASTRUCTURE ONLY: a GPU-side oracle ("kind: reference") used by tests/test_reference_gpu.py when the library
+is present.  Mirrors the call conventions of the reference's own glue (rasterize_points.cu:36-235, bvh.cu:8-116)."""
+import ctypes as C
+import os
+
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "_ref", "libr3dg_reference.so")
+ALLOC_FN = C.CFUNCTYPE(C.c_void_p, C.c_void_p, C.c_size_t)
+_lib = None
+
+
+def available():
+    return os.path.exists(LIB_PATH)
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        _lib = C.CDLL(LIB_PATH)
+        _lib.ref_rasterize_forward.restype = C.c_int
+    return _lib
+
+
+def _p(t):
+    return None if (t is None or t.numel() == 0) else C.c_void_p(t.data_ptr())
+
+
+def rasterize_forward(bg, means3D, features, colors, opacity, scales, rotations, scale_modifier, cov3D, viewmatrix,
+                      projmatrix, tan_fovx, tan_fovy, cx, cy, H, W, sh, degree, campos, pseudo_normal=True):
+    dev = means3D.device
+    P, S = means3D.shape[0], features.shape[1]
+    M = sh.shape[1] if (sh is not None and sh.numel()) else 0
+    f = dict(dtype=torch.float32, device=dev)
+    out = dict(color=torch.zeros(3, H, W, **f), opacity=torch.zeros(1, H, W, **f), depth=torch.zeros(1, H, W, **f),
+               feature=torch.zeros(S, H, W, **f), normal=torch.zeros(3, H, W, **f), xyz=torch.zeros(3, H, W, **f),
+               weights=torch.zeros(P, 1, **f), radii=torch.zeros(P, dtype=torch.int32, device=dev))
+    bufs = [None, None, None]
+
+    def mk(i):
+        def cb(_u, n):
+            bufs[i] = torch.empty(int(n) + 256, dtype=torch.uint8, device=dev)
+            return bufs[i].data_ptr()
+        return ALLOC_FN(cb)
+    cbs = [mk(i) for i in range(3)]
+    torch.cuda.synchronize()
+    R = lib().ref_rasterize_forward(cbs[0], cbs[1], cbs[2], None, P, S, int(degree), M, _p(bg), W, H, _p(means3D), _p(sh),
+                                    _p(colors), _p(features), _p(opacity), _p(scales), C.c_float(scale_modifier),
+                                    _p(rotations), _p(cov3D), _p(viewmatrix), _p(projmatrix), _p(campos),
+                                    C.c_float(tan_fovx), C.c_float(tan_fovy), C.c_float(cx), C.c_float(cy),
+                                    int(bool(pseudo_normal)), _p(out["color"]), _p(out["opacity"]), _p(out["depth"]),
+                                    _p(out["feature"]), _p(out["normal"]), _p(out["xyz"]), _p(out["weights"]),
+                                    _p(out["radii"]))
+    out["num_rendered"] = R
+    out["buffers"] = bufs
+    T = ((W + 15) // 16) * ((H + 15) // 16)
+    out["n_contrib"] = torch.zeros(H, W, dtype=torch.int32, device=dev)
+    out["final_T"] = torch.zeros(H, W, **f)
+    out["ranges"] = torch.zeros(T, 2, dtype=torch.int32, device=dev)
+    out["point_list"] = torch.zeros(max(R, 1), dtype=torch.int32, device=dev)
+    out["keys"] = torch.zeros(max(R, 1), dtype=torch.int64, device=dev)
+    lib().ref_decode_state(_p(bufs[2]), _p(bufs[1]) if R > 0 else None, W, H, R, _p(out["n_contrib"]), _p(out["final_T"]),
+                           _p(out["ranges"]), _p(out["point_list"]), _p(out["keys"]))
+    return out
+
+
+def rasterize_backward(fwd, bg, means3D, features, colors, scales, rotations, scale_modifier, cov3D, viewmatrix,
+                       projmatrix, tan_fovx, tan_fovy, gC, gO, gD, gF, sh, degree, campos, backward_geometry=True):
+    dev = means3D.device
+    P, S = means3D.shape[0], features.shape[1]
+    M = sh.shape[1] if (sh is not None and sh.numel()) else 0
+    H, W = gC.shape[1], gC.shape[2]
+    f = dict(dtype=torch.float32, device=dev)
+    g = dict(mean2D=torch.zeros(P, 3, **f), conic=torch.zeros(P, 2, 2, **f), opacity=torch.zeros(P, 1, **f),
+             color=torch.zeros(P, 3, **f), feature=torch.zeros(P, S, **f), mean3D=torch.zeros(P, 3, **f),
+             cov3D=torch.zeros(P, 6, **f), sh=torch.zeros(P, M, 3, **f), scale=torch.zeros(P, 3, **f),
+             rot=torch.zeros(P, 4, **f))
+    b = fwd["buffers"]
+    torch.cuda.synchronize()
+    lib().ref_rasterize_backward(P, S, int(degree), M, int(fwd["num_rendered"]), _p(bg), W, H, _p(means3D), _p(sh),
+                                 _p(features), _p(colors), _p(scales), C.c_float(scale_modifier), _p(rotations),
+                                 _p(cov3D), _p(viewmatrix), _p(projmatrix), _p(campos), C.c_float(tan_fovx),
+                                 C.c_float(tan_fovy), _p(fwd["radii"]), _p(b[0]), _p(b[1]), _p(b[2]), _p(gC), _p(gO),
+                                 _p(gD), _p(gF), _p(g["mean2D"]), _p(g["conic"]), _p(g["opacity"]), _p(g["color"]),
+                                 _p(g["feature"]), _p(g["mean3D"]), _p(g["cov3D"]), _p(g["sh"]), _p(g["scale"]),
+                                 _p(g["rot"]), int(bool(backward_geometry)))
+    return g
+
+
+def bvh_build(means3D, scales, rotations, nodes, aabbs):
+    P = means3D.shape[0]
+    morton = torch.zeros(P, dtype=torch.int64, device=means3D.device)
+    torch.cuda.synchronize()
+    lib().ref_bvh_build(P, _p(means3D), _p(scales), _p(rotations), _p(nodes), _p(aabbs), _p(morton))
+    return nodes, aabbs, morton
+
+
+def bvh_trace_opacity(nodes, aabbs, rays_o, rays_d, means3D, covs3D, opacities, normals):
+    shape = rays_o.shape[:-1]
+    n = rays_o.numel() // 3
+    cnt = torch.zeros(shape, dtype=torch.int32, device=rays_o.device)
+    opa = torch.ones(shape, dtype=torch.float32, device=rays_o.device)
+    t = [x.contiguous() for x in (nodes, aabbs, rays_o, rays_d, means3D, covs3D, opacities, normals)]
+    torch.cuda.synchronize()
+    lib().ref_bvh_trace_opacity(n, *[_p(x) for x in t], _p(cnt), _p(opa))
+    return cnt, opa
