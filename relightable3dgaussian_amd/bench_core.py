@@ -134,6 +134,25 @@ def cpu_baseline(scene, cams, S, budget_s):
                            views, W, H, P, R, S, t_f, t_b))
 
 
+def pmc_traffic(stage):
+    """HBM bytes per launch of `stage`'s kernel from the committed rocprofv3 PMC passes (profiles/*_pmc_traffic.json;
+    FETCH_SIZE / WRITE_SIZE collected in separate passes on the same workload), or None."""
+    import glob
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    files = sorted(glob.glob(os.path.join(root, "profiles", "*_pmc_traffic.json")))
+    if not files:
+        return None
+    try:
+        doc = json.load(open(files[-1]))
+        for name, v in doc["kernels"].items():
+            if name.startswith(stage + "_kernel") or name.startswith(stage):
+                return dict(bytes_corrected=v["hbm_bytes_corrected"], bytes_raw=v["hbm_bytes_raw"],
+                            source=os.path.basename(files[-1]))
+    except Exception:
+        return None
+    return None
+
+
 def env_background(cam, envmap):
     """Per-pixel environment colour (Camera.get_world_directions cameras.py:79-91 + EnvLight.direct_light
     envmap.py:35-53) as plain torch ops."""
@@ -312,8 +331,10 @@ def run(args):
                                  achieved_GBs=None if by is None else round(by / (avg_ms * 1e-3) / 1e9, 1))
         dom = max(kernels, key=lambda k: kernels[k]["avg_ms"])
         ach = kernels[dom]["achieved_GBs"]
+        tr = pmc_traffic(dom)
         roofline = dict(bound="hbm", kernel=dom, achieved=ach, peak=HBM_PEAK_GBS, unit="GB/s",
-                        frac=None if ach is None else round(ach / HBM_PEAK_GBS, 4), traffic=None,
+                        frac=None if ach is None else round(ach / HBM_PEAK_GBS, 4),
+                        traffic=None if tr is None else tr["bytes_corrected"], traffic_detail=tr,
                         avg_kernel_ms=kernels[dom]["avg_ms"],
                         note="achieved = SURVEY.md 8(d) algorithmic bytes per launch / HIP-event kernel time; this "
                              "kernel is VALU/atomic-bound, HBM fraction reported as required")
