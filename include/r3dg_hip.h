@@ -58,8 +58,9 @@ int r3dg_image_state_offsets(int width, int height, size_t* offsets3);
 int r3dg_binning_state_offsets(int64_t num_rendered, size_t* offsets4);
 
 /* Forward. Optional inputs (d_shs, d_colors_precomp, d_scales, d_rotations, d_cov3D_precomp) are NULL when
- * absent, exactly like the reference's nullptr convention (forward.cu:206,242). Outputs must be zero-filled
- * by the caller (the reference's torch::full(0), rasterize_points.cu:72-79).  `d_radii` may be NULL.
+ * absent, exactly like the reference's nullptr convention (forward.cu:206,242).  Every image output and d_radii is
+ * fully written (uninitialised memory is fine); only d_out_weights is accumulated and must be zero-filled by the
+ * caller (the reference zero-fills everything, rasterize_points.cu:72-79).  `d_radii` may be NULL.
  * Returns num_rendered in *num_rendered_out.  One device->host sync (rasterizer_impl.cu:291). */
 int r3dg_rasterize_forward(void* stream, r3dg_alloc_fn geometry_alloc, r3dg_alloc_fn binning_alloc,
                            r3dg_alloc_fn image_alloc, void* alloc_user, int P, int S, int D, int M,
@@ -73,8 +74,11 @@ int r3dg_rasterize_forward(void* stream, r3dg_alloc_fn geometry_alloc, r3dg_allo
                            float* d_out_surface_xyz, float* d_out_weights, int32_t* d_radii, int debug,
                            int* num_rendered_out);
 
-/* Backward. All dL_d* outputs must be zero-filled by the caller (rasterize_points.cu:179-188).
- * d_dL_dmean2D is [P,3] (z = depth side channel), d_dL_dconic is [P,4] (x,y,-,w). */
+/* Backward.  d_dL_dmean2D [P,3] (z = depth side channel), d_dL_dconic [P,4] (x,y,-,w), d_dL_dopacity, d_dL_dcolor and
+ * d_dL_dfeature are accumulated with atomics and must be zero-filled by the caller; d_dL_dmean3D, d_dL_dcov3D and --
+ * when SHs / scales+rotations are the active inputs -- d_dL_dsh, d_dL_dscale, d_dL_drot are fully written (zeros for
+ * invisible Gaussians) and may be uninitialised; otherwise they are left untouched (the reference zero-fills all ten,
+ * rasterize_points.cu:179-188). */
 int r3dg_rasterize_backward(void* stream, int P, int S, int D, int M, int R, const float* d_background, int width,
                             int height, const float* d_means3D, const float* d_shs, const float* d_features,
                             const float* d_colors_precomp, const float* d_scales, float scale_modifier,

@@ -50,7 +50,24 @@ preprocess_backward_kernel(int P, int D, int M, const float* __restrict__ means,
                            float* __restrict__ dL_drot)
 {
     const int idx = blockIdx.x * 256 + threadIdx.x;
-    if (idx >= P || !(radii[idx] > 0)) return;
+    if (idx >= P) return;
+    if (!(radii[idx] > 0)) {
+        // invisible Gaussian: the reference leaves its torch::zeros rows untouched; here the rows are written so the
+        // caller can hand in uninitialised memory (saves five zero-fill launches per backward)
+#pragma unroll
+        for (int i = 0; i < 3; i++) dL_dmeans[3 * idx + i] = 0.f;
+#pragma unroll
+        for (int i = 0; i < 6; i++) dL_dcov3D[6 * idx + i] = 0.f;
+        if (shs != nullptr)
+            for (int i = 0; i < 3 * M; i++) dL_dsh[(size_t)idx * M * 3 + i] = 0.f;
+        if (scales != nullptr) {
+#pragma unroll
+            for (int i = 0; i < 3; i++) dL_dscale[3 * idx + i] = 0.f;
+#pragma unroll
+            for (int i = 0; i < 4; i++) dL_drot[4 * idx + i] = 0.f;
+        }
+        return;
+    }
 
     const float mx = means[3 * idx], my = means[3 * idx + 1], mz = means[3 * idx + 2];
     const float g2x = dL_dmean2D[3 * idx], g2y = dL_dmean2D[3 * idx + 1], g2z = dL_dmean2D[3 * idx + 2];
@@ -154,6 +171,7 @@ preprocess_backward_kernel(int P, int D, int M, const float* __restrict__ means,
 #define DSH(k) dsh[(k) * 3 + ch]
             const float g = dL_dcolor[3 * idx + ch] * (clamped[3 * idx + ch] ? 0.f : 1.f);
             float dRx = 0, dRy = 0, dRz = 0;
+            for (int k = (D + 1) * (D + 1); k < M; k++) DSH(k) = 0.f;      // coefficients above the active degree
             DSH(0) = bSH_C0 * g;
             if (D > 0) {
                 DSH(1) = (-bSH_C1 * y) * g;

@@ -252,7 +252,12 @@ pseudo_normal_kernel(int W, int H, const float* __restrict__ vm, float* __restri
     float ny = -ga[0] * gb[2] + ga[2] * gb[0];
     float nz = ga[0] * gb[1] - ga[1] * gb[0];
     const float norm = sqrtf(nx * nx + ny * ny + nz * nz);
-    if (norm <= 0.0f) return;      // leave the pre-zeroed output
+    if (norm <= 0.0f) {            // the reference leaves its zero-initialised output untouched here
+        normals[i11] = 0.f;
+        normals[HW + i11] = 0.f;
+        normals[2 * HW + i11] = 0.f;
+        return;
+    }
     nx = -nx / norm; ny = -ny / norm; nz = -nz / norm;
     normals[i11] = vm[0] * nx + vm[1] * ny + vm[2] * nz;
     normals[HW + i11] = vm[4] * nx + vm[5] * ny + vm[6] * nz;

@@ -64,14 +64,16 @@ def rasterize_gaussians(background, means3D, features, colors, opacity, scales, 
     dev = means3D.device
     fopt = dict(dtype=torch.float32, device=dev)
 
-    out_color = torch.zeros((NUM_CHANNELS, H, W), **fopt)
-    out_opacity = torch.zeros((1, H, W), **fopt)
-    out_depth = torch.zeros((1, H, W), **fopt)
-    out_feature = torch.zeros((S, H, W), **fopt)
-    out_normal = torch.zeros((3, H, W), **fopt)
-    out_surface_xyz = torch.zeros((3, H, W), **fopt)
+    # Every pixel of every image buffer is written by the kernels, so one uninitialised slab suffices (the reference
+    # zero-fills eight tensors, rasterize_points.cu:72-79); only `weights` is accumulated with atomics and needs zeros.
+    # P == 0 launches nothing, so that case keeps the reference's all-zero outputs.
+    slab = (torch.zeros if P == 0 else torch.empty)((11 + S, H, W), **fopt)
+    out_color, out_opacity, out_depth = slab[0:3], slab[3:4], slab[4:5]
+    out_feature, out_normal, out_surface_xyz = slab[5:5 + S], slab[5 + S:8 + S], slab[8 + S:11 + S]
+    if not computer_pseudo_normal:
+        slab[5 + S:].zero_()
     out_weights = torch.zeros((P, 1), **fopt)
-    radii = torch.zeros((P,), dtype=torch.int32, device=dev)
+    radii = torch.empty((P,), dtype=torch.int32, device=dev)
 
     rs = _Resizer(dev)
     rendered = C.c_int(0)
@@ -113,16 +115,22 @@ def rasterize_gaussians_backward(background, means3D, features, radii, colors, s
     dev = means3D.device
     fopt = dict(dtype=torch.float32, device=dev)
 
-    dL_dmeans3D = torch.zeros((P, 3), **fopt)
-    dL_dmeans2D = torch.zeros((P, 3), **fopt)
-    dL_dfeatures = torch.zeros((P, S), **fopt)
-    dL_dcolors = torch.zeros((P, NUM_CHANNELS), **fopt)
-    dL_dconic = torch.zeros((P, 2, 2), **fopt)
-    dL_dopacity = torch.zeros((P, 1), **fopt)
-    dL_dcov3D = torch.zeros((P, 6), **fopt)
-    dL_dsh = torch.zeros((P, M, 3), **fopt)
-    dL_dscales = torch.zeros((P, 3), **fopt)
-    dL_drotations = torch.zeros((P, 4), **fopt)
+    # gradients accumulated with atomics share ONE zero-filled slab; the per-Gaussian outputs of the fused
+    # preprocess-backward kernel are fully written (zeros for invisible Gaussians) and start uninitialised
+    acc = torch.zeros((11 + S) * P, **fopt)
+    o = 0
+    dL_dmeans2D = acc[o:o + 3 * P].view(P, 3); o += 3 * P
+    dL_dconic = acc[o:o + 4 * P].view(P, 2, 2); o += 4 * P
+    dL_dopacity = acc[o:o + P].view(P, 1); o += P
+    dL_dcolors = acc[o:o + 3 * P].view(P, NUM_CHANNELS); o += 3 * P
+    dL_dfeatures = acc[o:o + S * P].view(P, S)
+    have_sh = sh.numel() != 0 and colors.numel() == 0
+    have_scale = scales.numel() != 0 and cov3D_precomp.numel() == 0
+    dL_dmeans3D = torch.empty((P, 3), **fopt)
+    dL_dcov3D = torch.empty((P, 6), **fopt)
+    dL_dsh = (torch.empty if have_sh else torch.zeros)((P, M, 3), **fopt)
+    dL_dscales = (torch.empty if have_scale else torch.zeros)((P, 3), **fopt)
+    dL_drotations = (torch.empty if have_scale else torch.zeros)((P, 4), **fopt)
 
     if P != 0:
         t = [_f32c(x) for x in (background, means3D, sh, features, colors, scales, rotations, cov3D_precomp, viewmatrix,
