@@ -143,6 +143,11 @@ int r3dg_render_equation_backward(void* stream, int P, int Si, int Sd, int Sv, c
                                   float* d_dL_dviewdirs, float* d_dL_dincidents_shs, float* d_dL_ddirect_shs,
                                   float* d_dL_dvisibility_shs);
 
+/* distCUDA2 (submodules/simple-knn/spatial.cu:14-26 -> SimpleKNN::knn, simple_knn.cu:185-221): d_mean_dist2[i] = mean of
+ * the squared distances from point i to its 3 nearest neighbours (FLT_MAX terms when P < 4, like the reference). */
+size_t r3dg_knn_temp_bytes(int P);
+int r3dg_knn_dist2(void* stream, int P, const float* d_points, float* d_mean_dist2, void* d_temp);
+
 /* LBVH over per-Gaussian leaf boxes + visibility trace (reference bvh/include/bvh.h:5-18).
  * r3dg_bvh_build: d_nodes int32[2P-1,5] = (parent,left,right,object_id,leaf_count) and d_aabbs float[2P-1,6] =
  *   (lower xyz, upper xyz) arrive initialised as bvh/__init__.py:31-57 prepares them (nodes -1, counts 0 internal /

@@ -7,7 +7,7 @@ hipcc and the header shims in oracle/ref_shim/ (cuda_runtime.h -> HIP, cub -> hi
 is rocThrust).  The only source-level difference hipcc cannot digest is nvcc's tolerance for spaces inside the kernel
 launch chevrons (`<< <grid, block >> >`); those are closed up on the fly in a temporary directory that is deleted after
 the compile.  Sources built: r3dg-rasterization/cuda_rasterizer/{forward,backward,rasterizer_impl}.cu and
-bvh/src/{construct,trace}.cu (the torch-facing glue -- rasterize_points.cu, bvh.cu -- is replaced by
+bvh/src/{construct,trace}.cu and submodules/simple-knn/simple_knn.cu (the torch-facing glue -- rasterize_points.cu, bvh.cu -- is replaced by
 oracle/ref_shim/ref_wrapper.cpp).  render_equation.cu is not part of the reference's own build.
 oracle/_ref/ is git-ignored but travels to the GPU box, where tests/test_reference_gpu.py uses it if present.
 """
@@ -26,10 +26,11 @@ HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 SHIM = os.path.join(HERE, "ref_shim")
 RAST = os.path.join(REF, "r3dg-rasterization")
 BVH = os.path.join(REF, "bvh")
+KNN = os.path.join(REF, "submodules", "simple-knn")
 INCLUDES = ["-I", SHIM, "-I", os.path.join(RAST, "third_party", "glm"), "-I", os.path.join(RAST, "cuda_rasterizer"),
-            "-I", os.path.join(BVH, "include")]
+            "-I", os.path.join(BVH, "include"), "-I", KNN]
 SOURCES = [os.path.join(RAST, "cuda_rasterizer", f) for f in ("forward.cu", "backward.cu", "rasterizer_impl.cu")] + \
-          [os.path.join(BVH, "src", f) for f in ("construct.cu", "trace.cu")]
+          [os.path.join(BVH, "src", f) for f in ("construct.cu", "trace.cu")] + [os.path.join(KNN, "simple_knn.cu")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-w"]
 
 
@@ -40,6 +41,7 @@ def available():
 def _compile(args):
     src, tmp = args
     name = os.path.basename(os.path.dirname(os.path.dirname(src))) + "_" + os.path.basename(src)[:-3]
+    name = name.replace("-", "_")
     hip_src = os.path.join(tmp, name + ".hip")
     text = open(src).read()
     text = re.sub(r"<<\s+<", "<<<", text)

@@ -3,6 +3,7 @@
  * (oracle/build_ref.py).  Nothing here ships in the product library. */
 #pragma once
 #include <hip/hip_runtime.h>
+#include <cfloat>
 #define cudaError_t hipError_t
 #define cudaSuccess hipSuccess
 #define cudaGetErrorString hipGetErrorString

@@ -1,7 +1,8 @@
 // TEST INFRASTRUCTURE ONLY -- C wrapper around the REAL reference kernels (compiled unmodified from /root/reference
 // for gfx950 by oracle/build_ref.py) so the GPU tests can compare this repo's HIP kernels with the reference's own
 // CUDA kernels on identical inputs.  Calls CudaRasterizer::Rasterizer::forward/backward (cuda_rasterizer/rasterizer.h),
-// construct_bvh (bvh/include/construct.cuh) and trace_bvh_opacity_cuda (bvh/include/trace.cuh).  Never linked into
+// construct_bvh (bvh/include/construct.cuh), trace_bvh_opacity_cuda (bvh/include/trace.cuh) and SimpleKNN::knn
+// (submodules/simple-knn/simple_knn.h).  Never linked into
 // libr3dg_hip.so; the reference launches on the null stream.
 #include <hip/hip_runtime.h>
 #include <functional>
@@ -10,6 +11,7 @@
 #include "rasterizer_impl.h"
 #include "construct.cuh"
 #include "trace.cuh"
+#include "simple_knn.h"
 
 typedef void* (*alloc_fn)(void* user, size_t bytes);
 
@@ -84,6 +86,13 @@ void ref_bvh_trace_opacity(int num_rays, int32_t* nodes, float* aabbs, float* ra
 {
     trace_bvh_opacity_cuda(num_rays, nodes, aabbs, (float3*)rays_o, (float3*)rays_d, (float3*)means3D, covs3D, opacities,
                            (float3*)normals, contributes, opacity);
+    (void)hipDeviceSynchronize();
+}
+
+// SimpleKNN::knn (submodules/simple-knn/simple_knn.cu:185)
+void ref_knn_dist2(int P, float* points, float* mean_dists)
+{
+    SimpleKNN::knn(P, (float3*)points, mean_dists);
     (void)hipDeviceSynchronize();
 }
 

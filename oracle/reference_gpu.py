@@ -106,3 +106,14 @@ def bvh_trace_opacity(nodes, aabbs, rays_o, rays_d, means3D, covs3D, opacities, 
     torch.cuda.synchronize()
     lib().ref_bvh_trace_opacity(n, *[_p(x) for x in t], _p(cnt), _p(opa))
     return cnt, opa
+
+
+def knn_dist2(points):
+    """SimpleKNN::knn of the real reference build; points [P,3] float32 on the GPU -> float32[P]."""
+    import torch
+    L = lib()
+    pts = points.contiguous()
+    out = torch.zeros(pts.size(0), dtype=torch.float32, device=pts.device)
+    torch.cuda.synchronize()
+    L.ref_knn_dist2(C.c_int(pts.size(0)), _p(pts), _p(out))
+    return out

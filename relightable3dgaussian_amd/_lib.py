@@ -43,6 +43,8 @@ _SIGNATURES = {
     "r3dg_render_equation_forward": (_i, [_p, _i, _i, _i, _i] + [_p] * 8 + [_i] + [_p] * 4),
     "r3dg_render_equation_forward_complex": (_i, [_p, _i, _i, _i, _i] + [_p] * 8 + [_i] + [_p] * 11),
     "r3dg_render_equation_backward": (_i, [_p, _i, _i, _i, _i] + [_p] * 8 + [_i] + [_p] * 11),
+    "r3dg_knn_temp_bytes": (C.c_size_t, [_i]),
+    "r3dg_knn_dist2": (_i, [_p, _i, _p, _p, _p]),
     "r3dg_bvh_build_temp_bytes": (C.c_size_t, [_i]),
     "r3dg_bvh_build": (_i, [_p, _i, _p, _p, _p, _p]),
     "r3dg_bvh_trace_opacity": (_i, [_p, C.c_int64, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p]),

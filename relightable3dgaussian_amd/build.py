@@ -26,6 +26,7 @@ COMMON = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno
 EXTRA = {
     "rasterizer_preprocess.hip": ["-ffp-contract=off"],
     "bvh.hip": ["-ffp-contract=off"],
+    "simple_knn.hip": ["-ffp-contract=off"],
     # shading: VALU-bound transcendental-heavy float math; fp32 tolerance is 1e-4, so reciprocal/sqrt approximations
     # (v_rcp_f32, v_sqrt_f32: 1 ulp) replace the IEEE division/sqrt expansions
     "shading.hip": ["-ffast-math"],

@@ -69,6 +69,8 @@ void launch_re_backward(hipStream_t s, int P, int Si, int Sd, int Sv, const floa
                         const float* direct, const float* vis, int K, const float* incident_dirs, const float* dL_dpbr,
                         const float* dL_ddl, float* dL_dbase, float* dL_drough, float* dL_dmetal, float* dL_dnormals,
                         float* dL_dviewdirs, float* dL_dinc, float* dL_ddirect, float* dL_dvis);
+size_t knn_temp_bytes(size_t P);
+void knn_dist2(hipStream_t s, int P, const float* pts, float* dists, void* temp);
 size_t bvh_build_temp_bytes(size_t P);
 void bvh_build(hipStream_t s, int P, int32_t* nodes, float* aabbs, uint64_t* morton, void* temp);
 void bvh_trace_opacity(hipStream_t s, int num_rays, const int32_t* nodes, const float* aabbs, const float* rays_o,
@@ -582,6 +584,19 @@ int r3dg_render_equation_backward(void* stream_, int P, int Si, int Sd, int Sv, 
                            dL_dbase_color, dL_droughness, dL_dmetallic, dL_dnormals, dL_dviewdirs, dL_dincidents_shs,
                            dL_ddirect_shs, dL_dvisibility_shs);
         check_launch(stream, false, "render_equation_backward");
+        return R3DG_OK;
+    });
+}
+
+size_t r3dg_knn_temp_bytes(int P) { return knn_temp_bytes((size_t)(P > 0 ? P : 0)); }
+
+int r3dg_knn_dist2(void* stream_, int P, const float* points, float* mean_dist2, void* temp)
+{
+    if (P < 0) return invalid("knn_dist2: bad P");
+    if (P == 0) return R3DG_OK;
+    if (!points || !mean_dist2 || !temp) return invalid("knn_dist2: null buffer");
+    return guarded([&]() -> int {
+        knn_dist2((hipStream_t)stream_, P, points, mean_dist2, temp);
         return R3DG_OK;
     });
 }

@@ -142,3 +142,19 @@ def test_bvh_matches_real_reference(P, seed):
     assert (v1 - v2)[~cls_diff].abs().max().item() < 5e-5      # __expf + FMA-contracted quadratic forms on both sides
     both = (v1 > 0) & (v2 > 0)
     assert torch.equal(c1[both], c2[both])
+
+
+@pytest.mark.parametrize("P,seed", [(5000, 0), (100000, 1)])
+def test_knn_dist2_matches_real_reference(P, seed):
+    """distCUDA2 vs SimpleKNN::knn of the real reference build.  Both are exact 3-NN means over fp32 squared distances;
+    the reference build contracts d.x*d.x + d.y*d.y + d.z*d.z into FMAs, hence a few-ulp tolerance rather than equality."""
+    rg = _need_ref()
+    from simple_knn._C import distCUDA2
+    g = torch.Generator().manual_seed(seed)
+    pts = (torch.randn(P, 3, generator=g) * 0.7).cuda()
+    ours = distCUDA2(pts)
+    theirs = rg.knn_dist2(pts)
+    torch.cuda.synchronize()
+    rel = ((ours - theirs).abs() / theirs.abs().clamp_min(1e-12)).max().item()
+    print("knn dist2 vs real reference P=%d: max rel diff %.3g" % (P, rel))
+    assert rel < 1e-5
