@@ -75,6 +75,21 @@ __device__ __forceinline__ float wave_sum(float v)
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
     return v;
 }
+// Full-wave sum that stays in the VALU (DPP row shifts + row broadcasts, no LDS-crossbar shuffles): the total is
+// valid in lane 63 ONLY.
+__device__ __forceinline__ float wave_sum_to_lane63(float v)
+{
+#define R3DG_DPP_ADD(ctrl, rmask)                                                                                 \
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), ctrl, rmask, 0xF, true))
+    R3DG_DPP_ADD(0x111, 0xF);   // row_shr:1
+    R3DG_DPP_ADD(0x112, 0xF);   // row_shr:2
+    R3DG_DPP_ADD(0x114, 0xF);   // row_shr:4
+    R3DG_DPP_ADD(0x118, 0xF);   // row_shr:8  -> lane 15 of each row holds the row total
+    R3DG_DPP_ADD(0x142, 0xA);   // row_bcast:15 into rows 1 and 3
+    R3DG_DPP_ADD(0x143, 0xC);   // row_bcast:31 into rows 2 and 3 -> lane 63 holds the wave total
+#undef R3DG_DPP_ADD
+    return v;
+}
 __device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v)
 {
 #pragma unroll

@@ -27,7 +27,7 @@ __device__ __forceinline__ float fast_exp(float x)
 template <int SPAD, int PPL, int U>
 __global__ void __launch_bounds__(256 / PPL)
 render_forward_kernel(const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list, int S, int W, int H,
-                      int tiles_x, int num_tiles, int xcd_chunk, const uint32_t* __restrict__ tile_order,
+                      int tiles_x, int num_tiles, int xcd_chunk, int wave8, const uint32_t* __restrict__ tile_order,
                       const float2* __restrict__ means2D,
                       const float* __restrict__ depths, const float* __restrict__ features,
                       const float* __restrict__ colors, const float4* __restrict__ conic_opacity,
@@ -57,8 +57,15 @@ render_forward_kernel(const uint2* __restrict__ ranges, const uint32_t* __restri
     __shared__ __attribute__((aligned(16))) float s_pay[NT * PAY];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int px = tile_x * R3DG_TILE_X + (lane & 15);
-    const int py0 = tile_y * R3DG_TILE_Y + wave * (4 * PPL) + (lane >> 4);
+    // lane -> pixel: PPL == 1 and wave8: each wave owns a compact 8x8 block (fewer waves touched per Gaussian than
+    // with 16x4 strips); otherwise 16-wide rows, PPL pixels per lane 4 rows apart
+    int lx = lane & 15, ly = wave * (4 * PPL) + (lane >> 4);
+    if (PPL == 1 && wave8) {
+        lx = (lane & 7) + 8 * (wave & 1);
+        ly = (lane >> 3) + 8 * (wave >> 1);
+    }
+    const int px = tile_x * R3DG_TILE_X + lx;
+    const int py0 = tile_y * R3DG_TILE_Y + ly;
     const float pxf = (float)px;
 
     const uint2 range = ranges[tile];
@@ -189,8 +196,8 @@ render_forward_kernel(const uint2* __restrict__ ranges, const uint32_t* __restri
                         F[i][4 * q + 3] += f4.w * w[i];
                     }
                 }
-                wsum = wave_sum(wsum);
-                if (lane == 0) atomicAdd(&out_weights[__float_as_uint(g1[u].w)], wsum);
+                wsum = wave_sum_to_lane63(wsum);
+                if (lane == 63) atomicAdd(&out_weights[__float_as_uint(g1[u].w)], wsum);
             }
         }
     }
@@ -265,6 +272,7 @@ pseudo_normal_kernel(int W, int H, const float* __restrict__ vm, float* __restri
 }
 
 // ---- launchers ------------------------------------------------------------------------------------------
+int g_fwd_wave8x8 = 0;  // 1-pixel-per-lane kernel: wave = 8x8 pixel block (1) or 16x4 strip (0); r3dg_set_tuning3()
 int g_fwd_ppl = 1;   // pixels per lane; tunable through r3dg_set_tuning()
 int g_fwd_unroll = 4;   // staged entries evaluated per inner-loop step (1 = entry-at-a-time)
 
@@ -279,17 +287,17 @@ static void launch_fwd_inst(hipStream_t s, int T, int tiles_x, const uint32_t* t
     const int chunk = (T + 7) / 8;
     if (g_fwd_unroll >= 4)
         render_forward_kernel<SPAD, PPL, 4><<<chunk * 8, 256 / PPL, 0, s>>>(
-            (const uint2*)ranges, point_list, S, W, H, tiles_x, T, chunk, tile_order, (const float2*)means2D, depths,
+            (const uint2*)ranges, point_list, S, W, H, tiles_x, T, chunk, g_fwd_wave8x8, tile_order, (const float2*)means2D, depths,
             features, colors, (const float4*)conic_opacity, final_T, n_contrib, bg, out_color, out_opacity, out_depth,
             out_feature, out_weights);
     else if (g_fwd_unroll >= 2)
         render_forward_kernel<SPAD, PPL, 2><<<chunk * 8, 256 / PPL, 0, s>>>(
-            (const uint2*)ranges, point_list, S, W, H, tiles_x, T, chunk, tile_order, (const float2*)means2D, depths,
+            (const uint2*)ranges, point_list, S, W, H, tiles_x, T, chunk, g_fwd_wave8x8, tile_order, (const float2*)means2D, depths,
             features, colors, (const float4*)conic_opacity, final_T, n_contrib, bg, out_color, out_opacity, out_depth,
             out_feature, out_weights);
     else
         render_forward_kernel<SPAD, PPL, 1><<<chunk * 8, 256 / PPL, 0, s>>>(
-            (const uint2*)ranges, point_list, S, W, H, tiles_x, T, chunk, tile_order, (const float2*)means2D, depths,
+            (const uint2*)ranges, point_list, S, W, H, tiles_x, T, chunk, g_fwd_wave8x8, tile_order, (const float2*)means2D, depths,
             features, colors, (const float4*)conic_opacity, final_T, n_contrib, bg, out_color, out_opacity, out_depth,
             out_feature, out_weights);
 }

@@ -64,11 +64,33 @@ __device__ __forceinline__ float lane_xor(float x)
     else return __shfl_xor(x, D, 64);
 }
 
+// Distance 8 / 4 transposing exchange in TWO instructions: lanes with bit D clear need a[l] + a[l+D], lanes with it set
+// b[l] + b[l-D]; inside a 16-lane row those two lane sets are whole DPP banks (4 lanes each), so a bank-masked
+// `v_add_f32_dpp r, a, a row_shl:D` fills the first set and `v_add_f32_dpp r, b, b row_shr:D` the second -- no selects.
+// (Inline asm: the compiler will not fold a bank-masked DPP move into the add; s_nop covers the VALU-write -> DPP-read
+// hazard that it cannot see through the asm.)
+template <int D>
+__device__ __forceinline__ float transpose_step_banked(float a, float b)
+{
+    float r;
+    if constexpr (D == 8)
+        asm("s_nop 1\n\tv_add_f32_dpp %0, %1, %1 row_shl:8 row_mask:0xf bank_mask:0x3\n\t"
+                     "v_add_f32_dpp %0, %2, %2 row_shr:8 row_mask:0xf bank_mask:0xc"
+                     : "=&v"(r) : "v"(a), "v"(b));
+    else
+        asm("s_nop 1\n\tv_add_f32_dpp %0, %1, %1 row_shl:4 row_mask:0xf bank_mask:0x5\n\t"
+                     "v_add_f32_dpp %0, %2, %2 row_shr:4 row_mask:0xf bank_mask:0xa"
+                     : "=&v"(r) : "v"(a), "v"(b));
+    return r;
+}
+
 // one transposing exchange of the pair (lo-half value a, hi-half value b) at lane distance D
 template <int D, bool DPP>
 __device__ __forceinline__ float transpose_step(float a, float b, bool hi)
 {
-    if constexpr (DPP && D == 32) {
+    if constexpr (DPP && (D == 8 || D == 4)) {
+        return transpose_step_banked<D>(a, b);
+    } else if constexpr (DPP && D == 32) {
         auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(a), __float_as_uint(b), false, false);
         return __uint_as_float(r[0]) + __uint_as_float(r[1]);
     } else if constexpr (DPP && D == 16) {

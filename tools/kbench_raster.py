@@ -13,7 +13,11 @@ d = {k: v.to(dev) for k, v in sc.items() if torch.is_tensor(v)}
 feat = torch.rand(P, S, device=dev)
 gC, gO, gD, gF = [torch.randn(c, RES, RES, device=dev) for c in (3, 1, 1, S)]
 L.r3dg_profile_enable(1)
-for it in range(int(os.environ.get("ITERS", 6))):
+if "WAVE8" in os.environ:
+    L.r3dg_set_tuning3(int(os.environ["WAVE8"]) & 1, int(os.environ["WAVE8"]) >> 1)
+for it in range(3 + int(os.environ.get("ITERS", 10))):
+    if it == 3:
+        torch.cuda.synchronize(); _lib.profile_read(); L.r3dg_profile_enable(1)
     out = _C.rasterize_gaussians(bg, d["xyz"], feat, empty, d["opacity"], d["scales"], d["rotations"], 1.0, empty,
                                  cam.world_view_transform, cam.full_proj_transform, cam.tanfovx, cam.tanfovy, cam.cx,
                                  cam.cy, RES, RES, d["shs"], 3, cam.camera_center, False, True, False)

@@ -1,0 +1,43 @@
+"""Per-step GPU timeline from a rocprofv3 rocpd database: for the last N training steps (delimited by consecutive
+render_backward_kernel launches) print wall time, GPU-busy time, idle gaps, launches per step and time by kernel.
+
+    python tools/rocpd_timeline.py <results.db> [N]
+"""
+import collections
+import sqlite3
+import sys
+
+
+def main():
+    db = sys.argv[1]
+    n = int(sys.argv[2]) if len(sys.argv) > 2 else 10
+    cur = sqlite3.connect(db).cursor()
+    rows = list(cur.execute("select name, start, end from kernels order by start"))
+    marks = [i for i, r in enumerate(rows) if "render_backward_kernel" in r[0]]
+    marks = marks[-(n + 1):]
+    if len(marks) < 2:
+        print("not enough steps")
+        return
+    per = collections.defaultdict(float)
+    cnt = collections.Counter()
+    wall = busy = 0.0
+    launches = 0
+    for a, b in zip(marks[:-1], marks[1:]):
+        seg = rows[a:b]
+        wall += rows[b][1] - rows[a][1]
+        for name, s, e in seg:
+            busy += e - s
+            per[name[:90]] += e - s
+            cnt[name[:90]] += 1
+        launches += len(seg)
+    k = len(marks) - 1
+    print("steps %d  wall %.3f ms/step  gpu busy %.3f ms/step  idle %.3f ms/step  launches/step %.1f" %
+          (k, wall / k / 1e6, busy / k / 1e6, (wall - busy) / k / 1e6, launches / k))
+    r3dg = sum(v for kname, v in per.items() if "r3dg::" in kname)
+    print("r3dg kernels %.3f ms/step, other (torch) kernels %.3f ms/step" % (r3dg / k / 1e6, (busy - r3dg) / k / 1e6))
+    for name, v in sorted(per.items(), key=lambda x: -x[1])[:45]:
+        print("%8.1f us  x%-5.1f %s" % (v / k / 1e3, cnt[name] / k, name))
+
+
+if __name__ == "__main__":
+    main()
