@@ -178,9 +178,10 @@ int r3dg_set_tuning(int fwd_pixels_per_lane, int bwd_pixels_per_lane, int bwd_dp
  * (1 longest-tile-first, 0 XCD-contiguous natural order, <0 keeps) */
 int r3dg_set_tuning2(int fwd_unroll, int bwd_unroll, int tile_order);
 /* r3dg_set_tuning3: lane->pixel map of the 1-pixel-per-lane forward / backward tile kernels: 1 = each wave owns an
- * 8x8 pixel block (backward default), 0 = a 16x4 strip (forward default); <0 keeps the current value.  Results do not
- * depend on it. */
-int r3dg_set_tuning3(int fwd_wave8x8, int bwd_wave8x8);
+ * 8x8 pixel block (backward default), 0 = a 16x4 strip (forward default); cull: 1 = skip, per wave, staged entries
+ * that provably stay below alpha 1/255 on all of the wave's pixels (default), 0 = evaluate every entry.  <0 keeps the
+ * current value.  Results do not depend on any of them. */
+int r3dg_set_tuning3(int fwd_wave8x8, int bwd_wave8x8, int cull);
 int r3dg_selftest_transpose_reduce(void* stream, int N, int dpp, const float* d_in, float* d_out, int* d_chan,
                                    int* d_owner);
 

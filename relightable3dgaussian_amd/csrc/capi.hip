@@ -76,6 +76,7 @@ void bvh_build(hipStream_t s, int P, int32_t* nodes, float* aabbs, uint64_t* mor
 void bvh_trace_opacity(hipStream_t s, int num_rays, const int32_t* nodes, const float* aabbs, const float* rays_o,
                        const float* rays_d, const float* means, const float* covs, const float* opac,
                        const float* normals, int32_t* contributes, float* out, int* overflow);
+extern int g_cull;
 extern int g_fwd_wave8x8;
 extern int g_bwd_wave8x8;
 extern int g_fwd_ppl;
@@ -207,8 +208,9 @@ int r3dg_max_features_forward(void) { return R3DG_MAX_S_FWD; }
 int r3dg_max_features_backward(void) { return R3DG_MAX_S_BWD; }
 
 // tuning knobs (pixels per lane of the two render kernels); not part of the drop-in surface
-int r3dg_set_tuning3(int fwd_wave8x8, int bwd_wave8x8)
+int r3dg_set_tuning3(int fwd_wave8x8, int bwd_wave8x8, int cull)
 {
+    if (cull >= 0) g_cull = cull;
     if (fwd_wave8x8 >= 0) g_fwd_wave8x8 = fwd_wave8x8;
     if (bwd_wave8x8 >= 0) g_bwd_wave8x8 = bwd_wave8x8;
     return R3DG_OK;

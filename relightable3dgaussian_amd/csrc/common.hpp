@@ -96,6 +96,40 @@ __device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v)
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor((int)v, o, 64);
     return v;
 }
+// Conservative sub-tile cull used by both tile kernels: can the Gaussian (mean m, conic (a, b, c), opacity op) reach
+// alpha >= 1/255 at ANY pixel centre of the box [x0,x1] x [y0,y1]?  alpha = op * exp(-q/2) with the convex quadratic
+// q(d) = a dx^2 + 2 b dx dy + c dy^2, so it is enough to bound q from below over the box: 0 if the mean is inside,
+// otherwise the smallest of the four edge minima (1-D parabolas, minimiser clamped to the edge).  A false answer
+// means every pixel of the box would take the reference's `alpha < 1/255 -> continue` branch (forward.cu:343-345,
+// backward.cu:529-531), so skipping the entry for the whole wave changes no result; slack terms keep borderline
+// entries (fp32 rounding of q, approximate exp) on the evaluated side.  Non positive-definite conics are never culled.
+__device__ __forceinline__ bool splat_may_touch(float mx, float my, float a, float b, float c, float op, float x0,
+                                                float x1, float y0, float y1)
+{
+    const float X0 = x0 - mx, X1 = x1 - mx, Y0 = y0 - my, Y1 = y1 - my;
+    if (!(a > 0.f && c > 0.f && a * c - b * b > 0.f)) return true;
+    if (X0 <= 0.f && X1 >= 0.f && Y0 <= 0.f && Y1 >= 0.f) return true;
+    const float ty = -b * __builtin_amdgcn_rcpf(c), tx = -b * __builtin_amdgcn_rcpf(a);
+    float qmin;
+    {
+        const float d0 = fminf(fmaxf(ty * X0, Y0), Y1), d1 = fminf(fmaxf(ty * X1, Y0), Y1);
+        const float q0 = a * X0 * X0 + 2.f * b * X0 * d0 + c * d0 * d0;
+        const float q1 = a * X1 * X1 + 2.f * b * X1 * d1 + c * d1 * d1;
+        qmin = fminf(q0, q1);
+    }
+    {
+        const float d0 = fminf(fmaxf(tx * Y0, X0), X1), d1 = fminf(fmaxf(tx * Y1, X0), X1);
+        const float q0 = a * d0 * d0 + 2.f * b * d0 * Y0 + c * Y0 * Y0;
+        const float q1 = a * d1 * d1 + 2.f * b * d1 * Y1 + c * Y1 * Y1;
+        qmin = fminf(qmin, fminf(q0, q1));
+    }
+    const float Xm = fmaxf(fabsf(X0), fabsf(X1)), Ym = fmaxf(fabsf(Y0), fabsf(Y1));
+    const float mag = a * Xm * Xm + c * Ym * Ym + 2.f * fabsf(b) * Xm * Ym;    // size of the cancelling terms
+    const float q = qmin - 1e-5f * mag;
+    const float amax = op * __builtin_amdgcn_exp2f(-0.5f * 1.4426950408889634f * q);
+    return !(amax < 0.98f / 255.0f);
+}
+
 // Inclusive scan across the wave.
 __device__ __forceinline__ uint32_t wave_inclusive_scan_u32(uint32_t v)
 {

@@ -48,7 +48,7 @@ constexpr int next_pow2(int v) { return v <= 16 ? 16 : (v <= 32 ? 32 : 64); }
 template <int SPAD, int PPL, int U>
 __global__ void __launch_bounds__(256 / PPL)
 render_backward_kernel(const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list, int S, int W, int H,
-                       int tiles_x, int num_tiles, int xcd_chunk, int wave8, const uint32_t* __restrict__ tile_order,
+                       int tiles_x, int num_tiles, int xcd_chunk, int wave8, int cull, const uint32_t* __restrict__ tile_order,
                        const float* __restrict__ bg_color,
                        const float2* __restrict__ means2D, const float* __restrict__ depths,
                        const float4* __restrict__ conic_opacity, const float* __restrict__ colors,
@@ -80,6 +80,7 @@ render_backward_kernel(const uint2* __restrict__ ranges, const uint32_t* __restr
     __shared__ float4 s_geo1[NT];
     __shared__ __attribute__((aligned(16))) float s_pay[NT * PAY];
     __shared__ uint32_t s_max[NW];
+    __shared__ unsigned long long s_cand[NW][NW];  // [pixel wave][64-entry group]: entries that may touch that wave's box
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     // lane -> pixel: PPL == 1 and wave8: each wave owns a compact 8x8 block (fewer waves touched per Gaussian than
@@ -159,12 +160,15 @@ render_backward_kernel(const uint2* __restrict__ ranges, const uint32_t* __restr
 
     for (int base = 0; base < n; base += NT) {
         __syncthreads();
+        float4 my_geo = make_float4(0.f, 0.f, 0.f, 0.f);   // mean.xy, conic.x, conic.y
+        float2 my_co = make_float2(0.f, 0.f);               // conic.z, opacity
         if (base + tid < n) {
             const uint32_t g = point_list[range.x + (uint32_t)(n - 1 - (base + tid))];
             const float2 xy = means2D[g];
             const float4 co = conic_opacity[g];
-            s_geo0[tid] = make_float4(xy.x, xy.y, co.x, co.y);
+            s_geo0[tid] = my_geo = make_float4(xy.x, xy.y, co.x, co.y);
             s_geo1[tid] = make_float4(co.z, co.w, depths[g], __uint_as_float(g));
+            my_co = make_float2(co.z, co.w);
             float* pay = s_pay + tid * PAY;
             pay[0] = colors[3 * g]; pay[1] = colors[3 * g + 1]; pay[2] = colors[3 * g + 2]; pay[3] = depths[g];
             if constexpr (SPAD > 0) {
@@ -182,24 +186,44 @@ render_backward_kernel(const uint2* __restrict__ ranges, const uint32_t* __restr
                 }
             }
         }
+        // per pixel-wave candidate masks: the entry must lie in front of that wave's deepest last contributor and pass
+        // the conservative alpha >= 1/255 box test (common.hpp splat_may_touch)
+#pragma unroll
+        for (int w = 0; w < NW; w++) {
+            int bx = 0, by = w * (4 * PPL), bw = 15, bh = 4 * PPL - 1;
+            if (PPL == 1 && wave8) { bx = 8 * (w & 1); by = 8 * (w >> 1); bw = 7; bh = 7; }
+            const float x0 = (float)(tile_x * R3DG_TILE_X + bx), y0 = (float)(tile_y * R3DG_TILE_Y + by);
+            bool c = base + tid < n && (uint32_t)(n - 1 - (base + tid)) < s_max[w];
+            if (cull) c = c && splat_may_touch(my_geo.x, my_geo.y, my_geo.z, my_geo.w, my_co.x, my_co.y, x0,
+                                               x0 + (float)bw, y0, y0 + (float)bh);
+            const unsigned long long mk = __ballot(c);
+            if (lane == 0) s_cand[w][wave] = mk;
+        }
         __syncthreads();
 
-        const int cnt = min(NT, n - base);
-        // U staged entries per step: their LDS reads are issued together and the U x PPL (G, alpha) pairs are
+        // U candidate entries per step: their LDS reads are issued together and the U x PPL (G, alpha) pairs are
         // independent work; the accum_rec recursion and the gradient reduction stay serial per entry.
-        for (int j0 = 0; j0 < cnt; j0 += U) {
+        for (int grp = 0; grp < NW; grp++) {
+          const unsigned long long mv = s_cand[wave][grp];
+          unsigned long long cm = ((unsigned long long)__builtin_amdgcn_readfirstlane((int)(mv >> 32)) << 32) |
+                                  (unsigned int)__builtin_amdgcn_readfirstlane((int)(unsigned int)mv);
+          while (cm != 0ull) {
             float4 g0[U], g1[U];
             float alpha[U][PPL], G[U][PPL];
+            int jj[U];
+            bool valid[U];
 #pragma unroll
             for (int u = 0; u < U; u++) {
-                const int j = min(j0 + u, cnt - 1);
-                g0[u] = s_geo0[j];
-                g1[u] = s_geo1[j];
+                valid[u] = cm != 0ull;
+                jj[u] = valid[u] ? grp * 64 + __builtin_ctzll(cm) : (u > 0 ? jj[u - 1] : 0);
+                if (valid[u]) cm &= cm - 1ull;
+                g0[u] = s_geo0[jj[u]];
+                g1[u] = s_geo1[jj[u]];
             }
             bool any_hit = false;
 #pragma unroll
             for (int u = 0; u < U; u++) {
-                const uint32_t front = (uint32_t)(n - 1 - (base + j0 + u));   // 0-based index from the front of the list
+                const uint32_t front = (uint32_t)(n - 1 - (base + jj[u]));   // 0-based index from the front of the list
                 const float dx = g0[u].x - pxf;
 #pragma unroll
                 for (int i = 0; i < PPL; i++) {
@@ -208,7 +232,7 @@ render_backward_kernel(const uint2* __restrict__ ranges, const uint32_t* __restr
                     const float Gv = fast_exp_b(power);
                     float a = fminf(0.99f, g1[u].y * Gv);
                     // reference: skip while contributor >= last_contributor, power > 0, alpha < 1/255
-                    if (!(front < lastc[i]) || power > 0.0f || a < 1.0f / 255.0f || j0 + u >= cnt) a = 0.f;
+                    if (!(front < lastc[i]) || power > 0.0f || a < 1.0f / 255.0f || !valid[u]) a = 0.f;
                     alpha[u][i] = a;
                     G[u][i] = Gv;
                     any_hit = any_hit || (a != 0.f);
@@ -224,7 +248,7 @@ render_backward_kernel(const uint2* __restrict__ ranges, const uint32_t* __restr
                 if (__ballot(any_lane) == 0ull) continue;
 
                 const float dx = g0[u].x - pxf;
-                const float* pay = s_pay + min(j0 + u, cnt - 1) * PAY;
+                const float* pay = s_pay + jj[u] * PAY;
                 // v[] = this lane's 10+S gradient contributions (summed over its PPL pixels): with one pixel per lane
                 // every used channel is assigned exactly once, so only the padding is zeroed
                 float v[NVP];
@@ -294,10 +318,12 @@ render_backward_kernel(const uint2* __restrict__ ranges, const uint32_t* __restr
                 // 32-bit element index: P * max(S, 4) < 2^32
                 if (dst_base != nullptr) atomicAdd(dst_base + (size_t)(__float_as_uint(g1[u].w) * dst_stride), total);
             }
+          }
         }
     }
 }
 
+extern int g_cull;
 int g_bwd_wave8x8 = 1;  // measured: 8x8 blocks -6% (fewer waves touched per Gaussian); the forward prefers strips
 int g_bwd_ppl = 1;
 int g_bwd_dpp = 1;      // kept for the self-test entry point; the tile kernel always uses the DPP/permlane reduction
@@ -315,7 +341,7 @@ static void launch_bwd_inst(hipStream_t s, int T, int tiles_x, const uint32_t* t
     const int chunk = (T + 7) / 8;
 #define R3DG_BWD_LAUNCH(UU)                                                                                           \
     render_backward_kernel<SPAD, PPL, UU><<<chunk * 8, 256 / PPL, 0, s>>>(                                            \
-        (const uint2*)ranges, point_list, S, W, H, tiles_x, T, chunk, g_bwd_wave8x8, tile_order, bg, (const float2*)means2D, depths, \
+        (const uint2*)ranges, point_list, S, W, H, tiles_x, T, chunk, g_bwd_wave8x8, g_cull, tile_order, bg, (const float2*)means2D, depths, \
         (const float4*)conic_opacity, colors, features, final_Ts, n_contrib, dL_dpix, dL_dpix_o, dL_dpix_d, dL_dpix_f, \
         dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolor, dL_dfeature, bg_geom)
     if (g_bwd_unroll >= 4) R3DG_BWD_LAUNCH(4);

@@ -27,7 +27,7 @@ __device__ __forceinline__ float fast_exp(float x)
 template <int SPAD, int PPL, int U>
 __global__ void __launch_bounds__(256 / PPL)
 render_forward_kernel(const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list, int S, int W, int H,
-                      int tiles_x, int num_tiles, int xcd_chunk, int wave8, const uint32_t* __restrict__ tile_order,
+                      int tiles_x, int num_tiles, int xcd_chunk, int wave8, int cull, const uint32_t* __restrict__ tile_order,
                       const float2* __restrict__ means2D,
                       const float* __restrict__ depths, const float* __restrict__ features,
                       const float* __restrict__ colors, const float4* __restrict__ conic_opacity,
@@ -55,6 +55,8 @@ render_forward_kernel(const uint2* __restrict__ ranges, const uint32_t* __restri
     __shared__ float4 s_geo0[NT];                 // mean.x, mean.y, conic.x, conic.y
     __shared__ float4 s_geo1[NT];                 // conic.z, opacity, depth, id bits
     __shared__ __attribute__((aligned(16))) float s_pay[NT * PAY];
+    constexpr int NW = NT / 64;
+    __shared__ unsigned long long s_cand[NW][NW];  // [pixel wave][64-entry group]: entries that may touch that wave's box
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     // lane -> pixel: PPL == 1 and wave8: each wave owns a compact 8x8 block (fewer waves touched per Gaussian than
@@ -94,12 +96,15 @@ render_forward_kernel(const uint2* __restrict__ ranges, const uint32_t* __restri
         if (__syncthreads_and(all_done)) break;
 
         // ---- stage one Gaussian per thread ----
+        float4 my_geo = make_float4(0.f, 0.f, 0.f, 0.f);   // mean.xy, conic.x, conic.y
+        float2 my_co = make_float2(0.f, 0.f);               // conic.z, opacity
         if (base + tid < n) {
             const uint32_t g = point_list[range.x + base + tid];
             const float2 xy = means2D[g];
             const float4 co = conic_opacity[g];
-            s_geo0[tid] = make_float4(xy.x, xy.y, co.x, co.y);
+            s_geo0[tid] = my_geo = make_float4(xy.x, xy.y, co.x, co.y);
             s_geo1[tid] = make_float4(co.z, co.w, depths[g], __uint_as_float(g));
+            my_co = make_float2(co.z, co.w);
             float* pay = s_pay + tid * PAY;
             pay[0] = colors[3 * g]; pay[1] = colors[3 * g + 1]; pay[2] = colors[3 * g + 2]; pay[3] = 0.f;
             if constexpr (SPAD > 0) {
@@ -117,25 +122,45 @@ render_forward_kernel(const uint2* __restrict__ ranges, const uint32_t* __restri
                 }
             }
         }
+        // per pixel-wave candidate masks: staging thread t tests its entry against the pixel box of every wave
+#pragma unroll
+        for (int w = 0; w < NW; w++) {
+            int bx = 0, by = w * (4 * PPL), bw = 15, bh = 4 * PPL - 1;
+            if (PPL == 1 && wave8) { bx = 8 * (w & 1); by = 8 * (w >> 1); bw = 7; bh = 7; }
+            const float x0 = (float)(tile_x * R3DG_TILE_X + bx), y0 = (float)(tile_y * R3DG_TILE_Y + by);
+            const bool c = cull == 0 || splat_may_touch(my_geo.x, my_geo.y, my_geo.z, my_geo.w, my_co.x, my_co.y, x0,
+                                                          x0 + (float)bw, y0, y0 + (float)bh);
+            const unsigned long long m = __ballot(c && base + tid < n);
+            if (lane == 0) s_cand[w][wave] = m;
+        }
         __syncthreads();
 
-        const int cnt = min(NT, n - base);
-        // Walk the staged batch U entries at a time: the U geometry records are fetched with back-to-back LDS reads
+        // Walk this wave's candidate entries U at a time: the U geometry records are fetched with back-to-back LDS reads
         // and their U x PPL alphas are evaluated as independent work (ILP hides the LDS / exp latency); only the
         // short transmittance update stays serial per entry.
-        for (int j0 = 0; j0 < cnt; j0 += U) {
+        bool wave_done = false;
+        for (int grp = 0; grp < NW && !wave_done; grp++) {
+          const unsigned long long mv = s_cand[wave][grp];
+          // the mask is wave-uniform: move it to SGPRs so the bit walk below runs on the scalar unit
+          unsigned long long m = ((unsigned long long)__builtin_amdgcn_readfirstlane((int)(mv >> 32)) << 32) |
+                                 (unsigned int)__builtin_amdgcn_readfirstlane((int)(unsigned int)mv);
+          while (m != 0ull) {
             bool active = false;
 #pragma unroll
             for (int i = 0; i < PPL; i++) active = active || !done[i];
-            if (__ballot(active) == 0ull) break;           // this wave's pixels are all finished
+            if (__ballot(active) == 0ull) { wave_done = true; break; }   // this wave's pixels are all finished
 
             float4 g0[U], g1[U];
             float alpha[U][PPL];
+            int jj[U];
+            bool valid[U];
 #pragma unroll
             for (int u = 0; u < U; u++) {
-                const int j = min(j0 + u, cnt - 1);       // tail entries are re-read and ignored below
-                g0[u] = s_geo0[j];
-                g1[u] = s_geo1[j];
+                valid[u] = m != 0ull;
+                jj[u] = valid[u] ? grp * 64 + __builtin_ctzll(m) : (u > 0 ? jj[u - 1] : 0);   // tail: re-read, ignored below
+                if (valid[u]) m &= m - 1ull;
+                g0[u] = s_geo0[jj[u]];
+                g1[u] = s_geo1[jj[u]];
             }
             bool any_alpha = false;
 #pragma unroll
@@ -146,7 +171,7 @@ render_forward_kernel(const uint2* __restrict__ ranges, const uint32_t* __restri
                     const float dy = g0[u].y - pyf[i];
                     const float power = -0.5f * (g0[u].z * dx * dx + g1[u].x * dy * dy) - g0[u].w * dx * dy;
                     float a = fminf(0.99f, g1[u].y * fast_exp(power));
-                    if (power > 0.0f || a < 1.0f / 255.0f) a = 0.f;      // a == 0 marks "skip" (a real alpha is >= 1/255)
+                    if (power > 0.0f || a < 1.0f / 255.0f || !valid[u]) a = 0.f;      // a == 0 marks "skip" (a real alpha is >= 1/255)
                     alpha[u][i] = a;
                     any_alpha = any_alpha || (a != 0.f && !done[i]);
                 }
@@ -155,27 +180,25 @@ render_forward_kernel(const uint2* __restrict__ ranges, const uint32_t* __restri
 
 #pragma unroll
             for (int u = 0; u < U; u++) {
-                if (j0 + u >= cnt) break;
+                if (!valid[u]) break;
                 float w[PPL];
                 bool any_lane = false;
 #pragma unroll
                 for (int i = 0; i < PPL; i++) {
-                    w[i] = 0.f;
-                    if (!done[i] && alpha[u][i] != 0.f) {
-                        const float test_T = T[i] * (1.f - alpha[u][i]);
-                        if (test_T < 0.0001f) {
-                            done[i] = true;
-                        } else {
-                            w[i] = alpha[u][i] * T[i];
-                            T[i] = test_T;
-                            last[i] = (uint32_t)(base + j0 + u + 1);
-                            any_lane = true;
-                        }
-                    }
+                    // select form (no EXEC-masked regions): a live pixel hit by this Gaussian either saturates
+                    // (T would drop below 1e-4 -> done, forward.cu:349-354) or blends it with weight alpha * T
+                    const float test_T = T[i] * (1.f - alpha[u][i]);
+                    const bool cand = !done[i] && alpha[u][i] != 0.f;
+                    const bool blend = cand && !(test_T < 0.0001f);
+                    done[i] = done[i] || (cand && !blend);
+                    w[i] = blend ? alpha[u][i] * T[i] : 0.f;
+                    T[i] = blend ? test_T : T[i];
+                    last[i] = blend ? (uint32_t)(base + jj[u] + 1) : last[i];
+                    any_lane = any_lane || blend;
                 }
                 if (__ballot(any_lane) == 0ull) continue;   // nobody in this wave blends this Gaussian
 
-                const float* pay = s_pay + (j0 + u) * PAY;
+                const float* pay = s_pay + jj[u] * PAY;
                 const float4 c4 = *reinterpret_cast<const float4*>(pay);
                 float wsum = 0.f;
 #pragma unroll
@@ -196,9 +219,12 @@ render_forward_kernel(const uint2* __restrict__ ranges, const uint32_t* __restri
                         F[i][4 * q + 3] += f4.w * w[i];
                     }
                 }
-                wsum = wave_sum_to_lane63(wsum);
-                if (lane == 63) atomicAdd(&out_weights[__float_as_uint(g1[u].w)], wsum);
+                // wave total -> SGPR -> one lane issues the atomic (a wave-uniform value keeps the compiler's
+                // uniform-address atomic rewrite down to a couple of scalar instructions)
+                const float wtot = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(wave_sum_to_lane63(wsum)), 63));
+                if (lane == 0) atomicAdd(&out_weights[__float_as_uint(g1[u].w)], wtot);
             }
+          }
         }
     }
 
@@ -273,6 +299,7 @@ pseudo_normal_kernel(int W, int H, const float* __restrict__ vm, float* __restri
 
 // ---- launchers ------------------------------------------------------------------------------------------
 int g_fwd_wave8x8 = 0;  // 1-pixel-per-lane kernel: wave = 8x8 pixel block (1) or 16x4 strip (0); r3dg_set_tuning3()
+int g_cull = 1;         // per-wave conservative sub-tile cull of staged entries (results do not depend on it)
 int g_fwd_ppl = 1;   // pixels per lane; tunable through r3dg_set_tuning()
 int g_fwd_unroll = 4;   // staged entries evaluated per inner-loop step (1 = entry-at-a-time)
 
@@ -287,17 +314,17 @@ static void launch_fwd_inst(hipStream_t s, int T, int tiles_x, const uint32_t* t
     const int chunk = (T + 7) / 8;
     if (g_fwd_unroll >= 4)
         render_forward_kernel<SPAD, PPL, 4><<<chunk * 8, 256 / PPL, 0, s>>>(
-            (const uint2*)ranges, point_list, S, W, H, tiles_x, T, chunk, g_fwd_wave8x8, tile_order, (const float2*)means2D, depths,
+            (const uint2*)ranges, point_list, S, W, H, tiles_x, T, chunk, g_fwd_wave8x8, g_cull, tile_order, (const float2*)means2D, depths,
             features, colors, (const float4*)conic_opacity, final_T, n_contrib, bg, out_color, out_opacity, out_depth,
             out_feature, out_weights);
     else if (g_fwd_unroll >= 2)
         render_forward_kernel<SPAD, PPL, 2><<<chunk * 8, 256 / PPL, 0, s>>>(
-            (const uint2*)ranges, point_list, S, W, H, tiles_x, T, chunk, g_fwd_wave8x8, tile_order, (const float2*)means2D, depths,
+            (const uint2*)ranges, point_list, S, W, H, tiles_x, T, chunk, g_fwd_wave8x8, g_cull, tile_order, (const float2*)means2D, depths,
             features, colors, (const float4*)conic_opacity, final_T, n_contrib, bg, out_color, out_opacity, out_depth,
             out_feature, out_weights);
     else
         render_forward_kernel<SPAD, PPL, 1><<<chunk * 8, 256 / PPL, 0, s>>>(
-            (const uint2*)ranges, point_list, S, W, H, tiles_x, T, chunk, g_fwd_wave8x8, tile_order, (const float2*)means2D, depths,
+            (const uint2*)ranges, point_list, S, W, H, tiles_x, T, chunk, g_fwd_wave8x8, g_cull, tile_order, (const float2*)means2D, depths,
             features, colors, (const float4*)conic_opacity, final_T, n_contrib, bg, out_color, out_opacity, out_depth,
             out_feature, out_weights);
 }

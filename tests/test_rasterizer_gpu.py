@@ -262,6 +262,37 @@ def test_parity_inner_loop_unroll_and_tile_order(fu, bu, order, hip_lib):
         hip_lib.r3dg_set_tuning2(4, 1, 1)
 
 
+@pytest.mark.parametrize("fw8,bw8,cull", [(0, 0, 0), (1, 1, 1), (0, 1, 0), (1, 0, 1)])
+def test_parity_wave_shape_and_cull(fw8, bw8, cull, hip_lib):
+    """Lane->pixel map (16x4 strips / 8x8 blocks) and the per-wave sub-tile cull must not change results."""
+    hip_lib.r3dg_set_tuning3(fw8, bw8, cull)
+    try:
+        _check_backward(make_case(S=16, seed=71, P=4000), "wave8_f%d_b%d_cull%d" % (fw8, bw8, cull))
+        _check_forward(make_case(S=5, seed=72, scale_log_mean=-2.0, P=1500), "wave8_f%d_cull%d_big" % (fw8, cull))
+    finally:
+        hip_lib.r3dg_set_tuning3(0, 1, 1)
+
+
+@pytest.mark.parametrize("name", ["S16", "big_splats", "ragged_image"])
+def test_cull_is_exact(name, hip_lib):
+    """The sub-tile cull only drops (wave, Gaussian) pairs whose every pixel fails alpha >= 1/255, so the forward
+    images must be bit-identical with and without it (weights: float atomics, order-dependent -> tolerance)."""
+    case = make_case(**CASES[name])
+    try:
+        hip_lib.r3dg_set_tuning3(-1, -1, 0)
+        a = _run_forward(case)
+        hip_lib.r3dg_set_tuning3(-1, -1, 1)
+        b = _run_forward(case)
+    finally:
+        hip_lib.r3dg_set_tuning3(0, 1, 1)
+    torch.cuda.synchronize()
+    assert a[0] == b[0]
+    for i, nm in ((1, "n_contrib"), (2, "color"), (3, "opacity"), (4, "depth"), (5, "feature"), (6, "normal"),
+                  (7, "surface_xyz")):
+        assert torch.equal(a[i], b[i]), nm
+    assert torch.allclose(a[8], b[8], rtol=1e-5, atol=1e-6)
+
+
 @pytest.mark.parametrize("N", [16, 32, 64])
 @pytest.mark.parametrize("dpp", [0, 1])
 def test_transpose_reduce_selftest(N, dpp, hip_lib):

@@ -13,8 +13,13 @@ d = {k: v.to(dev) for k, v in sc.items() if torch.is_tensor(v)}
 feat = torch.rand(P, S, device=dev)
 gC, gO, gD, gF = [torch.randn(c, RES, RES, device=dev) for c in (3, 1, 1, S)]
 L.r3dg_profile_enable(1)
+e = os.environ
+L.r3dg_set_tuning(int(e.get("FPPL", 0)), int(e.get("BPPL", 0)), -1)
+L.r3dg_set_tuning2(int(e.get("FU", 0)), int(e.get("BU", 0)), int(e.get("ORDER", -1)))
 if "WAVE8" in os.environ:
-    L.r3dg_set_tuning3(int(os.environ["WAVE8"]) & 1, int(os.environ["WAVE8"]) >> 1)
+    L.r3dg_set_tuning3(int(os.environ["WAVE8"]) & 1, int(os.environ["WAVE8"]) >> 1, -1)
+if "CULL" in os.environ:
+    L.r3dg_set_tuning3(-1, -1, int(os.environ["CULL"]))
 for it in range(3 + int(os.environ.get("ITERS", 10))):
     if it == 3:
         torch.cuda.synchronize(); _lib.profile_read(); L.r3dg_profile_enable(1)
