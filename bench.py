@@ -35,6 +35,8 @@ def parse():
     ap.add_argument("--stage", type=int, default=2, choices=[1, 2])
     ap.add_argument("--cpu-baseline-seconds", type=float, default=15.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--unfused", action="store_true",
+                    help="stage 2 through PyTorch autograd glue + torch.optim.Adam instead of the fused glue kernels")
     ap.add_argument("--relight-frames", type=int, default=20)
     ap.add_argument("--relight-samples", type=int, default=384)
     return ap.parse_args()

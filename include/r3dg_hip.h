@@ -143,6 +143,65 @@ int r3dg_render_equation_backward(void* stream, int P, int Si, int Sd, int Sv, c
                                   float* d_dL_dviewdirs, float* d_dL_dincidents_shs, float* d_dL_ddirect_shs,
                                   float* d_dL_dvisibility_shs);
 
+/* ---- Stage-2 iteration glue: the elementwise code around the hot ops, fused -------------------
+ * All tensors fp32, device, contiguous.  Shapes: xyz/scaling/normal/base_color raw [P,3], rotation raw [P,4],
+ * opacity/roughness raw [P]; viewmatrix = world_view_transform (16 floats, row-vector convention, scene/cameras.py:62),
+ * campos[3]; features [P,16]; shade_out [P,19] (r3dg_shade_forward).
+ * r3dg_stage2_activate: GaussianModel.get_scaling/get_rotation/get_opacity/get_normal/get_base_color/get_roughness
+ *   (scene/gaussian_model.py:183-232; exp, F.normalize, sigmoid, 0.03+0.77s, 0.09+0.9s) and
+ *   viewdirs = normalize(campos - xyz) (gaussian_renderer/neilf.py:74-76).  base_raw == NULL skips the stage-2 outputs.
+ * r3dg_stage2_pack_features: the S=16 feature row of neilf.py:115-122 = depth, depth^2, pbr, normal, base_color,
+ *   roughness, diffuse_light, mean visibility; *light_l1_sum (may be NULL) += sum_p sum_c |diffuse_c - mean_c diffuse|
+ *   (light-smoothness term, neilf.py:286-292).
+ * r3dg_stage2_unpack_gradients: dL_dfeatures[P,16] -> the shading op's upstream gradients dL_dpbr[P,3] and
+ *   dL_ddiffuse_light[P,3], the latter including light_weight * d(sum_c |diffuse_c - mean|)/d diffuse.
+ * r3dg_stage2_activate_backward: chain rule of every activation above; combines the rasterizer's dL_dscales, dL_drot,
+ *   dL_dopacity, dL_dmeans3D, dL_dfeatures and the shading op's dL_dbase_color, dL_droughness, dL_dviewdirs into the
+ *   raw-parameter gradients (all seven outputs fully written).
+ * r3dg_stage2_loss: image-space terms of calculate_loss (neilf.py:212-318) and their gradients in one pass:
+ *   sums[0] += sum |image - gt|, sums[1] += sum |srgb(pbr_img) - gt|, sums[2] += sum (normal_render - pseudo_normal)^2
+ *   with feat = feature / max(opacity,1e-5) * (n_contrib > 0), pbr_img = feat[2:5]*opacity + (1-opacity)*bg;
+ *   dL_dimage[3,HW], dL_dopacity[HW], dL_dfeature[16,HW] are fully written for weights w_* per element. */
+int r3dg_stage2_activate(void* stream, int P, const float* d_xyz, const float* d_scaling_raw,
+                         const float* d_rotation_raw, const float* d_opacity_raw, const float* d_normal_raw,
+                         const float* d_base_raw, const float* d_rough_raw, const float* d_campos, float* d_scales,
+                         float* d_rotations, float* d_opacity, float* d_normal, float* d_base_color,
+                         float* d_roughness, float* d_viewdirs);
+int r3dg_stage2_pack_features(void* stream, int P, const float* d_xyz, const float* d_viewmatrix, const float* d_normal,
+                              const float* d_base_color, const float* d_roughness, const float* d_shade_out,
+                              float* d_features, float* d_light_l1_sum);
+int r3dg_stage2_unpack_gradients(void* stream, int P, const float* d_dL_dfeatures, const float* d_shade_out,
+                                 float light_weight, float* d_dL_dpbr, float* d_dL_ddiffuse_light);
+int r3dg_stage2_activate_backward(void* stream, int P, const float* d_xyz, const float* d_scaling_raw,
+                                  const float* d_rotation_raw, const float* d_opacity_raw, const float* d_normal_raw,
+                                  const float* d_base_raw, const float* d_rough_raw, const float* d_viewmatrix,
+                                  const float* d_campos, const float* d_dL_dfeatures, const float* d_dL_dbase_color,
+                                  const float* d_dL_droughness, const float* d_dL_dviewdirs, const float* d_dL_dscales,
+                                  const float* d_dL_drotations, const float* d_dL_dopacity, const float* d_dL_dmeans3D,
+                                  float* d_g_xyz, float* d_g_scaling, float* d_g_rotation, float* d_g_opacity,
+                                  float* d_g_normal, float* d_g_base, float* d_g_rough);
+int r3dg_stage2_loss(void* stream, int width, int height, const float* d_image, const float* d_opacity,
+                     const float* d_feature, const float* d_pseudo_normal, const int32_t* d_n_contrib,
+                     const float* d_gt, const float* d_background, float w_l1, float w_pbr, float w_normal,
+                     float* d_dL_dimage, float* d_dL_dopacity, float* d_dL_dfeature, float* d_sums);
+
+/* Adam over up to R3DG_ADAM_MAX_GROUPS parameter groups in ONE launch (torch.optim.Adam semantics, no weight decay /
+ * amsgrad; GaussianModel.training_setup + step, scene/gaussian_model.py:465-497).  Elements whose index modulo `period`
+ * is >= `split` use lr_tail (period 0: one rate) -- e.g. a [P,16,3] SH tensor with period 48, split 3 carries the
+ * features_dc / features_rest rates.  `step` is the 1-based step count for the bias corrections. */
+#define R3DG_ADAM_MAX_GROUPS 16
+typedef struct r3dg_adam_group {
+    float* param;
+    const float* grad;
+    float* exp_avg;
+    float* exp_avg_sq;
+    uint64_t n;
+    float lr, lr_tail;
+    uint32_t period, split;
+} r3dg_adam_group;
+int r3dg_adam_step(void* stream, int n_groups, const r3dg_adam_group* groups, float beta1, float beta2, float eps,
+                   int step);
+
 /* distCUDA2 (submodules/simple-knn/spatial.cu:14-26 -> SimpleKNN::knn, simple_knn.cu:185-221): d_mean_dist2[i] = mean of
  * the squared distances from point i to its 3 nearest neighbours (FLT_MAX terms when P < 4, like the reference). */
 size_t r3dg_knn_temp_bytes(int P);
@@ -178,7 +237,7 @@ int r3dg_set_tuning(int fwd_pixels_per_lane, int bwd_pixels_per_lane, int bwd_dp
  * (1 longest-tile-first, 0 XCD-contiguous natural order, <0 keeps) */
 int r3dg_set_tuning2(int fwd_unroll, int bwd_unroll, int tile_order);
 /* r3dg_set_tuning3: lane->pixel map of the 1-pixel-per-lane forward / backward tile kernels: 1 = each wave owns an
- * 8x8 pixel block (backward default), 0 = a 16x4 strip (forward default); cull: 1 = skip, per wave, staged entries
+ * 8x8 pixel block (default), 0 = a 16x4 strip; cull: 1 = skip, per wave, staged entries
  * that provably stay below alpha 1/255 on all of the wave's pixels (default), 0 = evaluate every entry.  <0 keeps the
  * current value.  Results do not depend on any of them. */
 int r3dg_set_tuning3(int fwd_wave8x8, int bwd_wave8x8, int cull);

@@ -44,6 +44,12 @@ _SIGNATURES = {
     "r3dg_render_equation_forward": (_i, [_p, _i, _i, _i, _i] + [_p] * 8 + [_i] + [_p] * 4),
     "r3dg_render_equation_forward_complex": (_i, [_p, _i, _i, _i, _i] + [_p] * 8 + [_i] + [_p] * 11),
     "r3dg_render_equation_backward": (_i, [_p, _i, _i, _i, _i] + [_p] * 8 + [_i] + [_p] * 11),
+    "r3dg_stage2_activate": (_i, [_p, _i] + [_p] * 15),
+    "r3dg_stage2_pack_features": (_i, [_p, _i] + [_p] * 8),
+    "r3dg_stage2_unpack_gradients": (_i, [_p, _i, _p, _p, _f, _p, _p]),
+    "r3dg_stage2_activate_backward": (_i, [_p, _i] + [_p] * 24),
+    "r3dg_stage2_loss": (_i, [_p, _i, _i] + [_p] * 7 + [_f, _f, _f] + [_p] * 4),
+    "r3dg_adam_step": (_i, [_p, _i, _p, _f, _f, _f, _i]),
     "r3dg_knn_temp_bytes": (C.c_size_t, [_i]),
     "r3dg_knn_dist2": (_i, [_p, _i, _p, _p, _p]),
     "r3dg_bvh_build_temp_bytes": (C.c_size_t, [_i]),

@@ -87,7 +87,7 @@ def loss_stage1(outs, gt):
     return l1 + 0.1 * reg
 
 
-def _algorithmic_bytes(stage, P, R, N, S):
+def _algorithmic_bytes(stage, P, R, N, S, K=64):
     """SURVEY.md 8(d) per-unit figures x the units one launch processes (fp32)."""
     return {
         "preprocess": 311.0 * P + 8.0 * P,
@@ -98,6 +98,17 @@ def _algorithmic_bytes(stage, P, R, N, S):
         "pseudo_normal": 44.0 * N,
         "render_backward": (124.0 + 12 * S) * R + (28.0 + 4 * S) * N,
         "preprocess_backward": (679.0 + 4 * S) * P,
+        # live shading model: fwd (260+16K) B, bwd (476+16K) B per Gaussian
+        "shade_forward": (260.0 + 16 * K) * P,
+        "shade_backward": (476.0 + 16 * K) * P,
+        # Adam: 28 B per parameter float (p, g, m, v read; p, m, v written); 127 floats per Gaussian in stage 2
+        "adam_step": 28.0 * 127 * P,
+        # glue: activations 68 B read + 72 B written; feature row 40+76 read, 64 written; loss 27 maps read, 20 written
+        "stage2_activate": 140.0 * P,
+        "stage2_pack_features": 180.0 * P,
+        "stage2_unpack_gradients": 164.0 * P,
+        "stage2_activate_backward": (68.0 + 64 + 28 + 44 + 72) * P,
+        "stage2_loss": (27.0 + 20.0) * 4 * N,
     }[stage]
 
 
@@ -238,8 +249,15 @@ def run(args):
     cams = [c.to(dev) for c in cams_cpu]
     bg = torch.ones(3, device=dev)
     params = GaussianParams(scene, dev, stage2)
-    opt = torch.optim.Adam(params.parameters(), lr=1e-4, eps=1e-15, fused=True)
-    if stage2:
+    fused = stage2 and not getattr(args, "unfused", False)
+    opt = None if fused else torch.optim.Adam(params.parameters(), lr=1e-4, eps=1e-15, fused=True)
+    if fused:
+        # the whole iteration through the fused glue kernels + one-launch Adam (fused_step.py); gradients are averaged
+        # over ranks inside (two flat buckets, the first all-reduce overlapping the shading backward)
+        from . import fused_step
+        step_fn = fused_step.FusedStage2Step(params, args.sample_num, lr=1e-4)
+        S = 16
+    elif stage2:
         from . import train_step
         step_fn = train_step.Stage2Step(params, scene, dev, args.sample_num)
         S = 16
@@ -258,7 +276,7 @@ def run(args):
         del teacher
     gt_views = list(gts.keys())
     reducer = None
-    if world > 1:
+    if world > 1 and not fused:
         from . import dp
         reducer = dp.GradAllReducer(params.parameters())     # bucketed async all-reduce, overlaps the backward tail
 
@@ -267,6 +285,10 @@ def run(args):
     def one_step(i):
         v = gt_views[i % len(gt_views)]
         cam = cams[v]
+        if fused:
+            outs = step_fn(cam, bg, gts[v])                  # forward + loss + backward + all-reduce + Adam
+            R_seen.append(outs[0])
+            return None
         if stage2:
             loss, outs = step_fn(cam, bg, gts[v])
         else:
@@ -299,8 +321,6 @@ def run(args):
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     prof = _lib.profile_read()
-    if stage2:
-        prof.update(step_fn.profile())
     L.r3dg_profile_enable(0)
     if world > 1:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
@@ -311,7 +331,7 @@ def run(args):
     if stage2 and args.relight_frames > 0 and rank == 0:
         step_fn.visibility = step_fn.incident_dirs = step_fn.incident_areas = None   # free the K=train caches
         torch.cuda.empty_cache()
-        relight = relight_bench(params, cams, dev, args.relight_frames, args.relight_samples)
+        relight = relight_bench(step_fn if fused else params, cams, dev, args.relight_frames, args.relight_samples)
     result = None
     if rank == 0:
         P, N = args.points, args.res * args.res
@@ -322,8 +342,7 @@ def run(args):
                 continue
             avg_ms = ms / cnt
             try:
-                by = step_fn.algorithmic_bytes(name) if (stage2 and name in step_fn.stage_names()) else \
-                    _algorithmic_bytes(name, P, R_mean, N, S)
+                by = _algorithmic_bytes(name, P, R_mean, N, S, args.sample_num)
             except KeyError:
                 by = None
             kernels[name] = dict(avg_ms=round(avg_ms, 4), launches=cnt,
@@ -345,9 +364,10 @@ def run(args):
             "value": round(iters_s, 3), "unit": "iters/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "stage-%d train iteration: %srasterize fwd (S=%d) + loss + rasterize bwd + Adam; "
-                                   "1 view/rank/step, %d Gaussians, %dx%d, num_rendered~%.0f" % (
-                                       args.stage, "shading fwd/bwd (K=%d) + " % args.sample_num if stage2 else "", S,
+            "config": {"workload": ("stage-%d train iteration%s: %srasterize fwd (S=%d) + loss + rasterize bwd + Adam; "
+                                    "1 view/rank/step, %d Gaussians, %dx%d, num_rendered~%.0f") % (
+                                       args.stage, " (fused glue kernels + one-launch Adam)" if fused else "",
+                                       "shading fwd/bwd (K=%d) + " % args.sample_num if stage2 else "", S,
                                        P, args.res, args.res, R_mean),
                        "parallelism": "dp%d (views sharded over ranks; bucketed async RCCL all-reduce of per-Gaussian grads)" % world},
             "roofline": roofline, "kernels": kernels,

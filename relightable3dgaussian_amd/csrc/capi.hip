@@ -69,6 +69,28 @@ void launch_re_backward(hipStream_t s, int P, int Si, int Sd, int Sv, const floa
                         const float* direct, const float* vis, int K, const float* incident_dirs, const float* dL_dpbr,
                         const float* dL_ddl, float* dL_dbase, float* dL_drough, float* dL_dmetal, float* dL_dnormals,
                         float* dL_dviewdirs, float* dL_dinc, float* dL_ddirect, float* dL_dvis);
+void launch_s2_activate(hipStream_t s, int P, const float* xyz, const float* scaling_raw, const float* rotation_raw,
+                        const float* opacity_raw, const float* normal_raw, const float* base_raw,
+                        const float* rough_raw, const float* campos, float* scales, float* rot, float* opacity,
+                        float* normal, float* base_color, float* roughness, float* viewdirs);
+void launch_s2_pack(hipStream_t s, int P, const float* xyz, const float* viewmatrix, const float* normal,
+                    const float* base_color, const float* roughness, const float* shade_out, float* features,
+                    float* light_l1_sum);
+void launch_s2_unpack(hipStream_t s, int P, const float* dL_dfeatures, const float* shade_out, float light_weight,
+                      float* dL_dpbr, float* dL_ddiffuse);
+void launch_s2_activate_backward(hipStream_t s, int P, const float* xyz, const float* scaling_raw,
+                                 const float* rotation_raw, const float* opacity_raw, const float* normal_raw,
+                                 const float* base_raw, const float* rough_raw, const float* viewmatrix,
+                                 const float* campos, const float* dL_dfeatures, const float* dL_dbase_shade,
+                                 const float* dL_drough_shade, const float* dL_dviewdirs, const float* dL_dscales,
+                                 const float* dL_drot, const float* dL_dopacity, const float* dL_dmeans3D, float* g_xyz,
+                                 float* g_scaling, float* g_rotation, float* g_opacity, float* g_normal, float* g_base,
+                                 float* g_rough);
+void launch_s2_loss(hipStream_t s, int HW, const float* image, const float* opacity, const float* feature,
+                    const float* pseudo_normal, const int* n_contrib, const float* gt, const float* bg, float w_l1,
+                    float w_pbr, float w_normal, float* dL_dimage, float* dL_dopacity, float* dL_dfeature, float* sums);
+void launch_adam(hipStream_t s, int n_groups, const r3dg_adam_group* groups, float beta1, float beta2, float eps,
+                 int step);
 size_t knn_temp_bytes(size_t P);
 void knn_dist2(hipStream_t s, int P, const float* pts, float* dists, void* temp);
 size_t bvh_build_temp_bytes(size_t P);
@@ -89,10 +111,14 @@ void launch_transpose_selftest(hipStream_t s, int N, int dpp, const float* in, f
 
 // ---- optional per-stage timing with HIP events on the launch stream (bench.py's roofline numbers) ----
 enum Stage { ST_PREPROCESS = 0, ST_DUPKEYS, ST_SORT, ST_RANGES, ST_RENDER_FWD, ST_NORMAL, ST_RENDER_BWD, ST_PREPROCESS_BWD,
-             ST_SHADE_FWD, ST_SHADE_BWD, ST_BVH_BUILD, ST_BVH_TRACE, ST_COUNT };
+             ST_SHADE_FWD, ST_SHADE_BWD, ST_BVH_BUILD, ST_BVH_TRACE, ST_S2_ACTIVATE, ST_S2_PACK, ST_S2_LOSS,
+             ST_S2_UNPACK, ST_S2_ACTIVATE_BWD, ST_ADAM, ST_KNN, ST_COUNT };
 static const char* kStageNames[ST_COUNT] = {"preprocess", "duplicate_with_keys", "sort_pairs", "identify_tile_ranges",
                                             "render_forward", "pseudo_normal", "render_backward", "preprocess_backward",
-                                            "shade_forward", "shade_backward", "bvh_build", "bvh_trace"};
+                                            "shade_forward", "shade_backward", "bvh_build", "bvh_trace",
+                                            "stage2_activate", "stage2_pack_features", "stage2_loss",
+                                            "stage2_unpack_gradients", "stage2_activate_backward", "adam_step",
+                                            "knn_dist2"};
 static int g_profiling = 0;
 struct EventPair { hipEvent_t a, b; };
 static std::vector<EventPair> g_events[ST_COUNT];
@@ -110,6 +136,10 @@ struct StageTimer {
             R3DG_HIP(hipEventCreate(&ev.b));
             R3DG_HIP(hipEventRecord(ev.a, s));
         }
+    }
+    ~StageTimer()
+    {
+        try { stop(); } catch (...) {}
     }
     void stop()
     {
@@ -599,6 +629,117 @@ int r3dg_render_equation_backward(void* stream_, int P, int Si, int Sd, int Sv, 
     });
 }
 
+int r3dg_stage2_activate(void* stream_, int P, const float* xyz, const float* scaling_raw, const float* rotation_raw,
+                         const float* opacity_raw, const float* normal_raw, const float* base_raw,
+                         const float* rough_raw, const float* campos, float* scales, float* rot, float* opacity,
+                         float* normal, float* base_color, float* roughness, float* viewdirs)
+{
+    if (P < 0) return invalid("stage2_activate: bad P");
+    if (P == 0) return R3DG_OK;
+    if (!xyz || !scaling_raw || !rotation_raw || !opacity_raw || !normal_raw || !scales || !rot || !opacity || !normal)
+        return invalid("stage2_activate: null buffer");
+    if (base_raw && (!rough_raw || !campos || !base_color || !roughness || !viewdirs))
+        return invalid("stage2_activate: stage-2 inputs/outputs incomplete");
+    return guarded([&]() -> int {
+        StageTimer t((hipStream_t)stream_, ST_S2_ACTIVATE);
+        launch_s2_activate((hipStream_t)stream_, P, xyz, scaling_raw, rotation_raw, opacity_raw, normal_raw, base_raw,
+                           rough_raw, campos, scales, rot, opacity, normal, base_color, roughness, viewdirs);
+        return R3DG_OK;
+    });
+}
+
+int r3dg_stage2_pack_features(void* stream_, int P, const float* xyz, const float* viewmatrix, const float* normal,
+                              const float* base_color, const float* roughness, const float* shade_out, float* features,
+                              float* light_l1_sum)
+{
+    if (P < 0) return invalid("stage2_pack_features: bad P");
+    if (P == 0) return R3DG_OK;
+    if (!xyz || !viewmatrix || !normal || !base_color || !roughness || !shade_out || !features)
+        return invalid("stage2_pack_features: null buffer");
+    return guarded([&]() -> int {
+        StageTimer t((hipStream_t)stream_, ST_S2_PACK);
+        launch_s2_pack((hipStream_t)stream_, P, xyz, viewmatrix, normal, base_color, roughness, shade_out, features,
+                       light_l1_sum);
+        return R3DG_OK;
+    });
+}
+
+int r3dg_stage2_unpack_gradients(void* stream_, int P, const float* dL_dfeatures, const float* shade_out,
+                                 float light_weight, float* dL_dpbr, float* dL_ddiffuse)
+{
+    if (P < 0) return invalid("stage2_unpack_gradients: bad P");
+    if (P == 0) return R3DG_OK;
+    if (!dL_dfeatures || !shade_out || !dL_dpbr || !dL_ddiffuse) return invalid("stage2_unpack_gradients: null buffer");
+    return guarded([&]() -> int {
+        StageTimer t((hipStream_t)stream_, ST_S2_UNPACK);
+        launch_s2_unpack((hipStream_t)stream_, P, dL_dfeatures, shade_out, light_weight, dL_dpbr, dL_ddiffuse);
+        return R3DG_OK;
+    });
+}
+
+int r3dg_stage2_activate_backward(void* stream_, int P, const float* xyz, const float* scaling_raw,
+                                  const float* rotation_raw, const float* opacity_raw, const float* normal_raw,
+                                  const float* base_raw, const float* rough_raw, const float* viewmatrix,
+                                  const float* campos, const float* dL_dfeatures, const float* dL_dbase_shade,
+                                  const float* dL_drough_shade, const float* dL_dviewdirs, const float* dL_dscales,
+                                  const float* dL_drot, const float* dL_dopacity, const float* dL_dmeans3D, float* g_xyz,
+                                  float* g_scaling, float* g_rotation, float* g_opacity, float* g_normal, float* g_base,
+                                  float* g_rough)
+{
+    if (P < 0) return invalid("stage2_activate_backward: bad P");
+    if (P == 0) return R3DG_OK;
+    if (!xyz || !scaling_raw || !rotation_raw || !opacity_raw || !normal_raw || !base_raw || !rough_raw || !viewmatrix ||
+        !campos || !dL_dfeatures || !dL_dbase_shade || !dL_drough_shade || !dL_dviewdirs || !dL_dscales || !dL_drot ||
+        !dL_dopacity || !dL_dmeans3D || !g_xyz || !g_scaling || !g_rotation || !g_opacity || !g_normal || !g_base ||
+        !g_rough)
+        return invalid("stage2_activate_backward: null buffer");
+    return guarded([&]() -> int {
+        StageTimer t((hipStream_t)stream_, ST_S2_ACTIVATE_BWD);
+        launch_s2_activate_backward((hipStream_t)stream_, P, xyz, scaling_raw, rotation_raw, opacity_raw, normal_raw,
+                                    base_raw, rough_raw, viewmatrix, campos, dL_dfeatures, dL_dbase_shade,
+                                    dL_drough_shade, dL_dviewdirs, dL_dscales, dL_drot, dL_dopacity, dL_dmeans3D, g_xyz,
+                                    g_scaling, g_rotation, g_opacity, g_normal, g_base, g_rough);
+        return R3DG_OK;
+    });
+}
+
+int r3dg_stage2_loss(void* stream_, int width, int height, const float* image, const float* opacity,
+                     const float* feature, const float* pseudo_normal, const int32_t* n_contrib, const float* gt,
+                     const float* bg, float w_l1, float w_pbr, float w_normal, float* dL_dimage, float* dL_dopacity,
+                     float* dL_dfeature, float* sums)
+{
+    if (width < 0 || height < 0) return invalid("stage2_loss: bad image size");
+    if ((long long)width * height == 0) return R3DG_OK;
+    if (!image || !opacity || !feature || !pseudo_normal || !n_contrib || !gt || !bg || !dL_dimage || !dL_dopacity ||
+        !dL_dfeature || !sums)
+        return invalid("stage2_loss: null buffer");
+    return guarded([&]() -> int {
+        StageTimer t((hipStream_t)stream_, ST_S2_LOSS);
+        launch_s2_loss((hipStream_t)stream_, width * height, image, opacity, feature, pseudo_normal, n_contrib, gt, bg,
+                       w_l1, w_pbr, w_normal, dL_dimage, dL_dopacity, dL_dfeature, sums);
+        return R3DG_OK;
+    });
+}
+
+int r3dg_adam_step(void* stream_, int n_groups, const r3dg_adam_group* groups, float beta1, float beta2, float eps,
+                   int step)
+{
+    if (n_groups < 0 || n_groups > R3DG_ADAM_MAX_GROUPS) return invalid("adam_step: bad group count");
+    if (step < 1) return invalid("adam_step: step counts from 1");
+    if (n_groups == 0) return R3DG_OK;
+    if (!groups) return invalid("adam_step: null group table");
+    for (int i = 0; i < n_groups; i++) {
+        if (groups[i].n >= (1ull << 32)) return invalid("adam_step: group larger than 2^32 elements");
+        if (groups[i].n && (!groups[i].param || !groups[i].grad || !groups[i].exp_avg || !groups[i].exp_avg_sq))
+            return invalid("adam_step: null buffer in group");
+    }
+    return guarded([&]() -> int {
+        StageTimer t((hipStream_t)stream_, ST_ADAM);
+        launch_adam((hipStream_t)stream_, n_groups, groups, beta1, beta2, eps, step);
+        return R3DG_OK;
+    });
+}
+
 size_t r3dg_knn_temp_bytes(int P) { return knn_temp_bytes((size_t)(P > 0 ? P : 0)); }
 
 int r3dg_knn_dist2(void* stream_, int P, const float* points, float* mean_dist2, void* temp)
@@ -607,6 +748,7 @@ int r3dg_knn_dist2(void* stream_, int P, const float* points, float* mean_dist2,
     if (P == 0) return R3DG_OK;
     if (!points || !mean_dist2 || !temp) return invalid("knn_dist2: null buffer");
     return guarded([&]() -> int {
+        StageTimer t((hipStream_t)stream_, ST_KNN);
         knn_dist2((hipStream_t)stream_, P, points, mean_dist2, temp);
         return R3DG_OK;
     });

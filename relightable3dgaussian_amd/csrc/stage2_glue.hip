@@ -1,0 +1,409 @@
+// Fused glue of the stage-2 (neilf) training iteration for gfx950 -- SURVEY.md 8(f) rows n1/n2: the elementwise code the
+// reference runs as ~250 tiny PyTorch kernels per iteration either side of the hot ops, restated as seven HBM-bound
+// kernels (every one a single streaming pass, one thread per Gaussian / pixel / parameter):
+//   s2_activate_kernel            GaussianModel.get_* activations (scene/gaussian_model.py:183-232) + view directions
+//                                 (gaussian_renderer/neilf.py:74-76)
+//   s2_pack_features_kernel       the S=16 feature row (neilf.py:115-122) + the light-smoothness L1 (neilf.py:286-292)
+//   s2_unpack_kernel              its backward: rasterizer feature gradients -> shading-op upstream gradients
+//   s2_activate_backward_kernel   chain rule of every activation, summed with the rasterizer / shading gradients,
+//                                 straight into the raw-parameter gradient buffers
+//   s2_loss_kernel                image-space loss terms AND their gradients in one pass (neilf.py:212-318: L1 on the
+//                                 SH image, L1 on the sRGB-mapped PBR image, normal-vs-pseudo-normal MSE)
+//   adam_kernel                   multi-group Adam step, all parameter groups in one launch (gaussian_model.py:465-497)
+// Parity target: the plain-PyTorch restatement in relightable3dgaussian_amd/train_step.py (Stage2Step), fp32 tolerance.
+#include "common.hpp"
+#include "r3dg_hip.h"
+
+namespace r3dg {
+
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + __expf(-x)); }
+
+// F.normalize(v, eps): v / max(|v|, eps)
+__device__ __forceinline__ void normalize3(const float v[3], float eps, float out[3], float& inv)
+{
+    const float n = sqrtf(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
+    inv = 1.f / fmaxf(n, eps);
+    out[0] = v[0] * inv; out[1] = v[1] * inv; out[2] = v[2] * inv;
+}
+// backward of v / max(|v|, eps): (g - n (n.g)) / |v| when |v| >= eps, g / eps below it (clamp passes no gradient)
+__device__ __forceinline__ void normalize3_backward(const float v[3], float eps, const float g[3], float out[3])
+{
+    const float n = sqrtf(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
+    if (n > eps) {
+        const float inv = 1.f / n;
+        const float u[3] = {v[0] * inv, v[1] * inv, v[2] * inv};
+        const float d = u[0] * g[0] + u[1] * g[1] + u[2] * g[2];
+#pragma unroll
+        for (int c = 0; c < 3; c++) out[c] = (g[c] - u[c] * d) * inv;
+    } else {
+        const float inv = 1.f / eps;
+#pragma unroll
+        for (int c = 0; c < 3; c++) out[c] = g[c] * inv;
+    }
+}
+
+__global__ void __launch_bounds__(256)
+s2_activate_kernel(int P, const float* __restrict__ xyz, const float* __restrict__ scaling_raw,
+                   const float* __restrict__ rotation_raw, const float* __restrict__ opacity_raw,
+                   const float* __restrict__ normal_raw, const float* __restrict__ base_raw,
+                   const float* __restrict__ rough_raw, const float* __restrict__ campos,
+                   float* __restrict__ scales, float* __restrict__ rot, float* __restrict__ opacity,
+                   float* __restrict__ normal, float* __restrict__ base_color, float* __restrict__ roughness,
+                   float* __restrict__ viewdirs)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= P) return;
+    const size_t i3 = 3 * (size_t)i, i4 = 4 * (size_t)i;
+#pragma unroll
+    for (int c = 0; c < 3; c++) scales[i3 + c] = __expf(scaling_raw[i3 + c]);
+    {
+        const float q[4] = {rotation_raw[i4], rotation_raw[i4 + 1], rotation_raw[i4 + 2], rotation_raw[i4 + 3]};
+        const float inv = 1.f / fmaxf(sqrtf(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]), 1e-12f);
+#pragma unroll
+        for (int c = 0; c < 4; c++) rot[i4 + c] = q[c] * inv;
+    }
+    opacity[i] = sigmoidf_(opacity_raw[i]);
+    float inv;
+    {
+        const float v[3] = {normal_raw[i3], normal_raw[i3 + 1], normal_raw[i3 + 2]};
+        float o[3];
+        normalize3(v, 1e-3f, o, inv);
+        normal[i3] = o[0]; normal[i3 + 1] = o[1]; normal[i3 + 2] = o[2];
+    }
+    if (base_raw != nullptr) {
+#pragma unroll
+        for (int c = 0; c < 3; c++) base_color[i3 + c] = 0.03f + 0.77f * sigmoidf_(base_raw[i3 + c]);
+        roughness[i] = 0.09f + 0.9f * sigmoidf_(rough_raw[i]);
+        const float d[3] = {campos[0] - xyz[i3], campos[1] - xyz[i3 + 1], campos[2] - xyz[i3 + 2]};
+        float o[3];
+        normalize3(d, 1e-12f, o, inv);
+        viewdirs[i3] = o[0]; viewdirs[i3 + 1] = o[1]; viewdirs[i3 + 2] = o[2];
+    }
+}
+
+__device__ __forceinline__ float block_sum_256(float v, float* s_part)
+{
+    v = wave_sum(v);
+    if ((threadIdx.x & 63) == 0) s_part[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return s_part[0] + s_part[1] + s_part[2] + s_part[3];
+}
+
+// features[P,16] = depth, depth^2, pbr(3), normal(3), base_color(3), roughness, diffuse_light(3), mean visibility
+__global__ void __launch_bounds__(256)
+s2_pack_features_kernel(int P, const float* __restrict__ xyz, const float* __restrict__ viewmatrix,
+                        const float* __restrict__ normal, const float* __restrict__ base_color,
+                        const float* __restrict__ roughness, const float* __restrict__ shade_out,
+                        float* __restrict__ features, float* __restrict__ light_l1_sum)
+{
+    __shared__ float s_part[4];
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    float l1 = 0.f;
+    if (i < P) {
+        const size_t i3 = 3 * (size_t)i;
+        const float depth = xyz[i3] * viewmatrix[2] + xyz[i3 + 1] * viewmatrix[6] + xyz[i3 + 2] * viewmatrix[10] +
+                            viewmatrix[14];
+        const float* so = shade_out + 19 * (size_t)i;
+        const float dl[3] = {so[3], so[4], so[5]};
+        float4* f = reinterpret_cast<float4*>(features + 16 * (size_t)i);
+        f[0] = make_float4(depth, depth * depth, so[0], so[1]);
+        f[1] = make_float4(so[2], normal[i3], normal[i3 + 1], normal[i3 + 2]);
+        f[2] = make_float4(base_color[i3], base_color[i3 + 1], base_color[i3 + 2], roughness[i]);
+        f[3] = make_float4(dl[0], dl[1], dl[2], so[18]);
+        const float m = (dl[0] + dl[1] + dl[2]) / 3.f;
+        l1 = fabsf(dl[0] - m) + fabsf(dl[1] - m) + fabsf(dl[2] - m);
+    }
+    const float tot = block_sum_256(l1, s_part);
+    if (threadIdx.x == 0 && light_l1_sum != nullptr) atomicAdd(light_l1_sum, tot);
+}
+
+__device__ __forceinline__ float signf_(float x) { return x > 0.f ? 1.f : (x < 0.f ? -1.f : 0.f); }
+
+// dL_dpbr / dL_ddiffuse_light for the shading op: the rasterizer's feature gradients (cols 2-4 / 12-14) plus the gradient of
+// light_weight * sum_c |dl_c - mean(dl)|
+__global__ void __launch_bounds__(256)
+s2_unpack_kernel(int P, const float* __restrict__ dL_dfeatures, const float* __restrict__ shade_out, float light_weight,
+                 float* __restrict__ dL_dpbr, float* __restrict__ dL_ddiffuse)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= P) return;
+    const float4* g = reinterpret_cast<const float4*>(dL_dfeatures + 16 * (size_t)i);
+    const float4 g0 = g[0], g1 = g[1], g3 = g[3];
+    const size_t i3 = 3 * (size_t)i;
+    dL_dpbr[i3] = g0.z; dL_dpbr[i3 + 1] = g0.w; dL_dpbr[i3 + 2] = g1.x;
+    const float* so = shade_out + 19 * (size_t)i;
+    const float dl[3] = {so[3], so[4], so[5]};
+    const float m = (dl[0] + dl[1] + dl[2]) / 3.f;
+    const float s[3] = {signf_(dl[0] - m), signf_(dl[1] - m), signf_(dl[2] - m)};
+    const float sm = (s[0] + s[1] + s[2]) / 3.f;
+    dL_ddiffuse[i3] = g3.x + light_weight * (s[0] - sm);
+    dL_ddiffuse[i3 + 1] = g3.y + light_weight * (s[1] - sm);
+    dL_ddiffuse[i3 + 2] = g3.z + light_weight * (s[2] - sm);
+}
+
+__global__ void __launch_bounds__(256)
+s2_activate_backward_kernel(int P, const float* __restrict__ xyz, const float* __restrict__ scaling_raw,
+                            const float* __restrict__ rotation_raw, const float* __restrict__ opacity_raw,
+                            const float* __restrict__ normal_raw, const float* __restrict__ base_raw,
+                            const float* __restrict__ rough_raw, const float* __restrict__ viewmatrix,
+                            const float* __restrict__ campos, const float* __restrict__ dL_dfeatures,
+                            const float* __restrict__ dL_dbase_shade, const float* __restrict__ dL_drough_shade,
+                            const float* __restrict__ dL_dviewdirs, const float* __restrict__ dL_dscales,
+                            const float* __restrict__ dL_drot, const float* __restrict__ dL_dopacity,
+                            const float* __restrict__ dL_dmeans3D, float* __restrict__ g_xyz,
+                            float* __restrict__ g_scaling, float* __restrict__ g_rotation,
+                            float* __restrict__ g_opacity, float* __restrict__ g_normal, float* __restrict__ g_base,
+                            float* __restrict__ g_rough)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= P) return;
+    const size_t i3 = 3 * (size_t)i, i4 = 4 * (size_t)i;
+    const float4* gf = reinterpret_cast<const float4*>(dL_dfeatures + 16 * (size_t)i);
+    const float4 f0 = gf[0], f1 = gf[1], f2 = gf[2];
+
+    // scales = exp(raw)
+#pragma unroll
+    for (int c = 0; c < 3; c++) g_scaling[i3 + c] = dL_dscales[i3 + c] * __expf(scaling_raw[i3 + c]);
+    // rotation = q / max(|q|, 1e-12)
+    {
+        const float q[4] = {rotation_raw[i4], rotation_raw[i4 + 1], rotation_raw[i4 + 2], rotation_raw[i4 + 3]};
+        const float g[4] = {dL_drot[i4], dL_drot[i4 + 1], dL_drot[i4 + 2], dL_drot[i4 + 3]};
+        const float n = sqrtf(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+        if (n > 1e-12f) {
+            const float inv = 1.f / n;
+            const float d = (q[0] * g[0] + q[1] * g[1] + q[2] * g[2] + q[3] * g[3]) * inv * inv;
+#pragma unroll
+            for (int c = 0; c < 4; c++) g_rotation[i4 + c] = (g[c] - q[c] * d) * inv;
+        } else {
+#pragma unroll
+            for (int c = 0; c < 4; c++) g_rotation[i4 + c] = g[c] * 1e12f;
+        }
+    }
+    // opacity = sigmoid(raw)
+    {
+        const float s = sigmoidf_(opacity_raw[i]);
+        g_opacity[i] = dL_dopacity[i] * s * (1.f - s);
+    }
+    // normal = raw / max(|raw|, 1e-3); only the feature row carries its gradient (the shading op sees normal.detach())
+    {
+        const float v[3] = {normal_raw[i3], normal_raw[i3 + 1], normal_raw[i3 + 2]};
+        const float g[3] = {f1.y, f1.z, f1.w};
+        float o[3];
+        normalize3_backward(v, 1e-3f, g, o);
+        g_normal[i3] = o[0]; g_normal[i3 + 1] = o[1]; g_normal[i3 + 2] = o[2];
+    }
+    // base_color = 0.03 + 0.77 sigmoid(raw), roughness = 0.09 + 0.9 sigmoid(raw): feature row + shading op
+    {
+        const float gfeat[3] = {f2.x, f2.y, f2.z};
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+            const float s = sigmoidf_(base_raw[i3 + c]);
+            g_base[i3 + c] = (gfeat[c] + dL_dbase_shade[i3 + c]) * 0.77f * s * (1.f - s);
+        }
+        const float s = sigmoidf_(rough_raw[i]);
+        g_rough[i] = (f2.w + dL_drough_shade[i]) * 0.9f * s * (1.f - s);
+    }
+    // xyz: rasterizer + depth / depth^2 feature columns + view direction
+    {
+        const float p[3] = {xyz[i3], xyz[i3 + 1], xyz[i3 + 2]};
+        const float depth = p[0] * viewmatrix[2] + p[1] * viewmatrix[6] + p[2] * viewmatrix[10] + viewmatrix[14];
+        const float gd = f0.x + 2.f * depth * f0.y;
+        const float d[3] = {campos[0] - p[0], campos[1] - p[1], campos[2] - p[2]};
+        const float gv[3] = {dL_dviewdirs[i3], dL_dviewdirs[i3 + 1], dL_dviewdirs[i3 + 2]};
+        float gdd[3];
+        normalize3_backward(d, 1e-12f, gv, gdd);
+        g_xyz[i3] = dL_dmeans3D[i3] + gd * viewmatrix[2] - gdd[0];
+        g_xyz[i3 + 1] = dL_dmeans3D[i3 + 1] + gd * viewmatrix[6] - gdd[1];
+        g_xyz[i3 + 2] = dL_dmeans3D[i3 + 2] + gd * viewmatrix[10] - gdd[2];
+    }
+}
+
+// Image-space loss + gradient in one pass.  sums[0..2] += sum|image-gt|, sum|srgb(pbr)-gt|, sum (n_render - n_pseudo)^2
+// (unweighted); gradients carry the weights w_* (already divided by the element counts).
+__global__ void __launch_bounds__(256)
+s2_loss_kernel(int HW, const float* __restrict__ image, const float* __restrict__ opacity,
+               const float* __restrict__ feature, const float* __restrict__ pseudo_normal,
+               const int* __restrict__ n_contrib, const float* __restrict__ gt, const float* __restrict__ bg,
+               float w_l1, float w_pbr, float w_normal, float* __restrict__ dL_dimage,
+               float* __restrict__ dL_dopacity, float* __restrict__ dL_dfeature, float* __restrict__ sums)
+{
+    __shared__ float s_part[4];
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    float s_l1 = 0.f, s_pbr = 0.f, s_n = 0.f;
+    if (i < HW) {
+        const float op = opacity[i];
+        const bool mask = n_contrib[i] > 0;
+        const float opc = fmaxf(op, 1e-5f);
+        const float scale = mask ? 1.f / opc : 0.f;                 // feat = feature * scale
+        const float dscale_dop = (mask && op >= 1e-5f) ? -1.f / (opc * opc) : 0.f;
+        float g_op = 0.f;
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+            const float g = gt[(size_t)c * HW + i];
+            // L1 on the SH image
+            const float d0 = image[(size_t)c * HW + i] - g;
+            s_l1 += fabsf(d0);
+            dL_dimage[(size_t)c * HW + i] = w_l1 * signf_(d0);
+            // L1 on the sRGB-mapped PBR image: pbr_img = r_pbr * op + (1 - op) * bg
+            const float F = feature[(size_t)(2 + c) * HW + i];
+            const float r = F * scale;
+            const float x = r * op + (1.f - op) * bg[c];
+            const bool lin = x <= 0.0031308f;
+            const float xs = fmaxf(x, 0.0031308f);
+            const float srgb = lin ? 12.92f * x : 1.055f * __powf(xs, 1.f / 2.4f) - 0.055f;
+            const float d1 = srgb - g;
+            s_pbr += fabsf(d1);
+            const float dsrgb = lin ? 12.92f : 1.055f / 2.4f * __powf(xs, 1.f / 2.4f - 1.f);
+            const float gx = w_pbr * signf_(d1) * dsrgb;                 // dL/dx
+            dL_dfeature[(size_t)(2 + c) * HW + i] = gx * op * scale;
+            g_op += gx * (r - bg[c] + op * F * dscale_dop);
+            // normal consistency: mse(r_normal, pseudo_normal)
+            const float Fn = feature[(size_t)(5 + c) * HW + i];
+            const float dn = Fn * scale - pseudo_normal[(size_t)c * HW + i];
+            s_n += dn * dn;
+            const float gn = 2.f * w_normal * dn;
+            dL_dfeature[(size_t)(5 + c) * HW + i] = gn * scale;
+            g_op += gn * Fn * dscale_dop;
+        }
+        dL_dopacity[i] = g_op;
+        dL_dfeature[i] = 0.f;
+        dL_dfeature[(size_t)HW + i] = 0.f;
+#pragma unroll
+        for (int c = 8; c < 16; c++) dL_dfeature[(size_t)c * HW + i] = 0.f;
+    }
+    const float t0 = block_sum_256(s_l1, s_part);
+    __syncthreads();
+    const float t1 = block_sum_256(s_pbr, s_part);
+    __syncthreads();
+    const float t2 = block_sum_256(s_n, s_part);
+    if (threadIdx.x == 0) {
+        atomicAdd(sums + 0, t0);
+        atomicAdd(sums + 1, t1);
+        atomicAdd(sums + 2, t2);
+    }
+}
+
+// ---- multi-group Adam -----------------------------------------------------------------------------------------------
+struct AdamTable {
+    r3dg_adam_group g[R3DG_ADAM_MAX_GROUPS];
+    unsigned int first_block[R3DG_ADAM_MAX_GROUPS + 1];
+    int n_groups;
+};
+
+__global__ void __launch_bounds__(256)
+adam_kernel(AdamTable t, float beta1, float beta2, float eps, float bias1, float inv_sqrt_bias2)
+{
+    int gi = 0;
+#pragma unroll 1
+    while (gi + 1 < t.n_groups && blockIdx.x >= t.first_block[gi + 1]) gi++;
+    const r3dg_adam_group grp = t.g[gi];
+    const size_t base = (size_t)(blockIdx.x - t.first_block[gi]) * 1024 + threadIdx.x * 4;
+    if (base >= grp.n) return;
+    float* __restrict__ p = grp.param;
+    const float* __restrict__ g = grp.grad;
+    float* __restrict__ m = grp.exp_avg;
+    float* __restrict__ v = grp.exp_avg_sq;
+    float pv[4], gv[4], mv[4], vv[4];
+    const bool full = base + 4 <= grp.n;
+    if (full) {
+        *reinterpret_cast<float4*>(pv) = *reinterpret_cast<const float4*>(p + base);
+        *reinterpret_cast<float4*>(gv) = *reinterpret_cast<const float4*>(g + base);
+        *reinterpret_cast<float4*>(mv) = *reinterpret_cast<const float4*>(m + base);
+        *reinterpret_cast<float4*>(vv) = *reinterpret_cast<const float4*>(v + base);
+    } else {
+        for (int k = 0; k < 4; k++)
+            if (base + k < grp.n) { pv[k] = p[base + k]; gv[k] = g[base + k]; mv[k] = m[base + k]; vv[k] = v[base + k]; }
+    }
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        // two learning rates per group: elements whose index modulo `period` is below `split` use lr, the rest lr_tail
+        // (one [P,16,3] SH tensor = dc columns + rest columns with different rates, gaussian_model.py:470-471)
+        float lr = grp.lr;
+        if (grp.period != 0 && ((unsigned int)(base + k) % grp.period) >= grp.split) lr = grp.lr_tail;   // n < 2^32
+        mv[k] = mv[k] + (gv[k] - mv[k]) * (1.f - beta1);
+        vv[k] = beta2 * vv[k] + (1.f - beta2) * gv[k] * gv[k];
+        const float denom = sqrtf(vv[k]) * inv_sqrt_bias2 + eps;
+        pv[k] -= (lr / bias1) * (mv[k] / denom);
+    }
+    if (full) {
+        *reinterpret_cast<float4*>(p + base) = *reinterpret_cast<float4*>(pv);
+        *reinterpret_cast<float4*>(m + base) = *reinterpret_cast<float4*>(mv);
+        *reinterpret_cast<float4*>(v + base) = *reinterpret_cast<float4*>(vv);
+    } else {
+        for (int k = 0; k < 4; k++)
+            if (base + k < grp.n) { p[base + k] = pv[k]; m[base + k] = mv[k]; v[base + k] = vv[k]; }
+    }
+}
+
+// ---- launchers ------------------------------------------------------------------------------------------------------
+void launch_s2_activate(hipStream_t s, int P, const float* xyz, const float* scaling_raw, const float* rotation_raw,
+                        const float* opacity_raw, const float* normal_raw, const float* base_raw,
+                        const float* rough_raw, const float* campos, float* scales, float* rot, float* opacity,
+                        float* normal, float* base_color, float* roughness, float* viewdirs)
+{
+    s2_activate_kernel<<<(P + 255) / 256, 256, 0, s>>>(P, xyz, scaling_raw, rotation_raw, opacity_raw, normal_raw,
+                                                       base_raw, rough_raw, campos, scales, rot, opacity, normal,
+                                                       base_color, roughness, viewdirs);
+    check_launch(s, false, "s2_activate_kernel");
+}
+
+void launch_s2_pack(hipStream_t s, int P, const float* xyz, const float* viewmatrix, const float* normal,
+                    const float* base_color, const float* roughness, const float* shade_out, float* features,
+                    float* light_l1_sum)
+{
+    s2_pack_features_kernel<<<(P + 255) / 256, 256, 0, s>>>(P, xyz, viewmatrix, normal, base_color, roughness,
+                                                            shade_out, features, light_l1_sum);
+    check_launch(s, false, "s2_pack_features_kernel");
+}
+
+void launch_s2_unpack(hipStream_t s, int P, const float* dL_dfeatures, const float* shade_out, float light_weight,
+                      float* dL_dpbr, float* dL_ddiffuse)
+{
+    s2_unpack_kernel<<<(P + 255) / 256, 256, 0, s>>>(P, dL_dfeatures, shade_out, light_weight, dL_dpbr, dL_ddiffuse);
+    check_launch(s, false, "s2_unpack_kernel");
+}
+
+void launch_s2_activate_backward(hipStream_t s, int P, const float* xyz, const float* scaling_raw,
+                                 const float* rotation_raw, const float* opacity_raw, const float* normal_raw,
+                                 const float* base_raw, const float* rough_raw, const float* viewmatrix,
+                                 const float* campos, const float* dL_dfeatures, const float* dL_dbase_shade,
+                                 const float* dL_drough_shade, const float* dL_dviewdirs, const float* dL_dscales,
+                                 const float* dL_drot, const float* dL_dopacity, const float* dL_dmeans3D, float* g_xyz,
+                                 float* g_scaling, float* g_rotation, float* g_opacity, float* g_normal, float* g_base,
+                                 float* g_rough)
+{
+    s2_activate_backward_kernel<<<(P + 255) / 256, 256, 0, s>>>(
+        P, xyz, scaling_raw, rotation_raw, opacity_raw, normal_raw, base_raw, rough_raw, viewmatrix, campos,
+        dL_dfeatures, dL_dbase_shade, dL_drough_shade, dL_dviewdirs, dL_dscales, dL_drot, dL_dopacity, dL_dmeans3D, g_xyz,
+        g_scaling, g_rotation, g_opacity, g_normal, g_base, g_rough);
+    check_launch(s, false, "s2_activate_backward_kernel");
+}
+
+void launch_s2_loss(hipStream_t s, int HW, const float* image, const float* opacity, const float* feature,
+                    const float* pseudo_normal, const int* n_contrib, const float* gt, const float* bg, float w_l1,
+                    float w_pbr, float w_normal, float* dL_dimage, float* dL_dopacity, float* dL_dfeature, float* sums)
+{
+    s2_loss_kernel<<<(HW + 255) / 256, 256, 0, s>>>(HW, image, opacity, feature, pseudo_normal, n_contrib, gt, bg, w_l1,
+                                                    w_pbr, w_normal, dL_dimage, dL_dopacity, dL_dfeature, sums);
+    check_launch(s, false, "s2_loss_kernel");
+}
+
+void launch_adam(hipStream_t s, int n_groups, const r3dg_adam_group* groups, float beta1, float beta2, float eps,
+                 int step)
+{
+    AdamTable t;
+    t.n_groups = n_groups;
+    unsigned int blocks = 0;
+    for (int i = 0; i < n_groups; i++) {
+        t.g[i] = groups[i];
+        t.first_block[i] = blocks;
+        blocks += (unsigned int)((groups[i].n + 1023) / 1024);
+    }
+    t.first_block[n_groups] = blocks;
+    if (blocks == 0) return;
+    const double b1 = 1.0 - pow((double)beta1, (double)step), b2 = 1.0 - pow((double)beta2, (double)step);
+    adam_kernel<<<blocks, 256, 0, s>>>(t, beta1, beta2, eps, (float)b1, (float)(1.0 / sqrt(b2)));
+    check_launch(s, false, "adam_kernel");
+}
+
+}  // namespace r3dg

@@ -1,0 +1,264 @@
+"""Fused stage-2 training iteration: the same computation as train_step.Stage2Step + loss.backward()
++ Adam, but with the ~250 elementwise PyTorch launches around the hot ops replaced by the seven streaming HIP kernels of
+csrc/stage2_glue.hip and without an autograd graph: forward, loss, backward and optimizer are explicit calls in order.
+
+    GaussianModel activations + viewdirs      r3dg_stage2_activate            (scene/gaussian_model.py:183-232, neilf.py:74-76)
+    shading integral                          r3dg_shade_forward              (neilf.py:339-371)
+    S=16 feature row + light-smoothness sum   r3dg_stage2_pack_features       (neilf.py:115-122, 286-292)
+    rasterize                                 r3dg_rasterize_forward          (r3dg_rasterization.py:75-113)
+    image-space loss terms + their gradients  r3dg_stage2_loss                (neilf.py:212-318)
+    rasterize backward                        r3dg_rasterize_backward
+    feature grads -> shading upstream grads   r3dg_stage2_unpack_gradients
+    shading backward                          r3dg_shade_backward
+    activation chain rule -> parameter grads  r3dg_stage2_activate_backward
+    Adam, all groups in one launch            r3dg_adam_step                  (gaussian_model.py:465-497)
+
+The SH colour coefficients and the incident-light coefficients are each held as ONE [P,16,3] tensor (the reference
+concatenates features_dc / features_rest and incidents_dc / incidents_rest every iteration, gaussian_model.py:199-203);
+`features_dc` etc. are exposed as views, and the Adam kernel applies the dc / rest learning rates by column.
+Only the tiny environment texture (16x32x3: softplus + total-variation term) stays on PyTorch autograd.
+The parity target is the unfused path (tests/test_fused_step_gpu.py compares loss and every gradient)."""
+import ctypes as C
+
+import torch
+import torch.nn.functional as F
+
+from . import _lib, rasterizer_ops, shading_ops
+from .train_step import tv_loss, update_visibility
+
+
+class AdamGroup(C.Structure):
+    _fields_ = [("param", C.c_void_p), ("grad", C.c_void_p), ("exp_avg", C.c_void_p), ("exp_avg_sq", C.c_void_p),
+                ("n", C.c_uint64), ("lr", C.c_float), ("lr_tail", C.c_float), ("period", C.c_uint32),
+                ("split", C.c_uint32)]
+
+
+class FusedAdam:
+    """torch.optim.Adam semantics (no weight decay / amsgrad) over a fixed set of tensors, one kernel launch per step.
+    `groups`: list of dicts {param, grad (callable or tensor), lr, lr_tail=None, period=0, split=0}."""
+    MAX_GROUPS = 16
+
+    def __init__(self, groups, betas=(0.9, 0.999), eps=1e-15):
+        if len(groups) > self.MAX_GROUPS:
+            raise RuntimeError("FusedAdam supports at most %d groups" % self.MAX_GROUPS)
+        self.groups = groups
+        self.betas, self.eps = betas, eps
+        self.step_count = 0
+        for g in groups:
+            p = g["param"]
+            if not p.is_contiguous() or p.dtype != torch.float32:
+                raise RuntimeError("FusedAdam needs contiguous float32 parameters")
+            g["exp_avg"] = torch.zeros_like(p)
+            g["exp_avg_sq"] = torch.zeros_like(p)
+
+    def step(self, grads):
+        """grads: list of gradient tensors, one per group (same order)."""
+        L = _lib.lib()
+        self.step_count += 1
+        table = (AdamGroup * len(self.groups))()
+        for i, (g, gr) in enumerate(zip(self.groups, grads)):
+            p = g["param"]
+            if gr.shape != p.shape or not gr.is_contiguous() or gr.dtype != torch.float32:
+                raise RuntimeError("FusedAdam: gradient %d does not match its parameter" % i)
+            table[i] = AdamGroup(p.data_ptr(), gr.data_ptr(), g["exp_avg"].data_ptr(), g["exp_avg_sq"].data_ptr(),
+                                 p.numel(), g["lr"], g.get("lr_tail") if g.get("lr_tail") is not None else g["lr"],
+                                 g.get("period", 0), g.get("split", 0))
+        with torch.cuda.device(self.groups[0]["param"].device):
+            st = L.r3dg_adam_step(_lib.current_stream(), len(self.groups), C.cast(table, C.c_void_p), self.betas[0],
+                                  self.betas[1], self.eps, self.step_count)
+        _lib.check(st, "adam_step")
+
+
+PARAM_NAMES = ("xyz", "normal", "scaling", "rotation", "opacity", "shs", "base_color", "roughness", "incidents", "env")
+
+
+class FusedStage2Step:
+    """Owns the raw parameters (copied from a bench_core.GaussianParams) and runs whole iterations."""
+
+    def __init__(self, params, sample_num, lr=1e-4, lr_rest_scale=1.0, loss_weights=None, process_group=None):
+        dev = params.xyz.device
+        self.dev = dev
+        d = lambda t: t.detach().clone().contiguous()
+        self.xyz, self.normal = d(params.xyz), d(params.normal)
+        self.scaling, self.rotation, self.opacity = d(params.scaling), d(params.rotation), d(params.opacity)
+        self.shs = torch.cat([params.features_dc.detach(), params.features_rest.detach()], 1).contiguous()
+        self.base_color, self.roughness = d(params.base_color), d(params.roughness)
+        self.incidents = torch.cat([params.incidents_dc.detach(), params.incidents_rest.detach()], 1).contiguous()
+        self.env = d(params.env).requires_grad_(True)
+        self.P = P = self.xyz.shape[0]
+        self.K = sample_num
+        self.M = self.shs.shape[1]
+        self.w = dict(l1=1.0, pbr=1.0, normal=0.01, light=0.01, env_smooth=0.01)
+        if loss_weights:
+            self.w.update(loss_weights)
+        # activations / intermediates (persistent, overwritten every step)
+        f = dict(dtype=torch.float32, device=dev)
+        self.a_scales, self.a_rot = torch.empty(P, 3, **f), torch.empty(P, 4, **f)
+        self.a_opacity, self.a_normal = torch.empty(P, 1, **f), torch.empty(P, 3, **f)
+        self.a_base, self.a_rough = torch.empty(P, 3, **f), torch.empty(P, 1, **f)
+        self.a_viewdirs = torch.empty(P, 3, **f)
+        self.shade_out = torch.empty(P, shading_ops.NOUT, **f)
+        self.features = torch.empty(P, 16, **f)
+        self.sums = torch.zeros(4, **f)                       # l1, pbr l1, normal mse, light l1 (unweighted sums)
+        self.d_pbr, self.d_diffuse = torch.empty(P, 3, **f), torch.empty(P, 3, **f)
+        # flat gradient slab: [xyz3 normal3 scaling3 rotation4 opacity1 base3 rough1 | shs 3M | incidents 3M] per group
+        sizes = dict(xyz=3 * P, normal=3 * P, scaling=3 * P, rotation=4 * P, opacity=P, base_color=3 * P, roughness=P,
+                     shs=3 * self.M * P, incidents=3 * self.M * P)
+        self.grad_flat = torch.zeros(sum(sizes.values()), **f)
+        self.grads, o = {}, 0
+        for k in ("shs", "xyz", "normal", "scaling", "rotation", "opacity", "base_color", "roughness", "incidents"):
+            self.grads[k] = self.grad_flat[o:o + sizes[k]].view_as(getattr(self, k))
+            o += sizes[k]
+        self._bucket_a = self.grad_flat[:sizes["shs"]]          # final right after the rasterizer backward
+        self._bucket_b = self.grad_flat[sizes["shs"]:]          # final after the activation backward
+        self.grads["env"] = torch.zeros_like(self.env)
+        self._zero_depth_grad = None
+        self.group = process_group
+        self.world = torch.distributed.get_world_size(process_group) if (
+            torch.distributed.is_available() and torch.distributed.is_initialized()) else 1
+        with torch.no_grad():
+            self.refresh_activations()
+            self.visibility, self.incident_dirs, self.incident_areas, self.tracer = update_visibility(
+                self.xyz, self.a_scales, self.a_rot, self.a_opacity, self.a_normal, sample_num)
+        rest = lr * lr_rest_scale
+        self.opt = FusedAdam([
+            dict(param=self.xyz, lr=lr), dict(param=self.normal, lr=lr), dict(param=self.scaling, lr=lr),
+            dict(param=self.rotation, lr=lr), dict(param=self.opacity, lr=lr),
+            dict(param=self.shs, lr=lr, lr_tail=rest, period=3 * self.M, split=3),
+            dict(param=self.base_color, lr=lr), dict(param=self.roughness, lr=lr),
+            dict(param=self.incidents, lr=lr, lr_tail=rest, period=3 * self.M, split=3),
+            dict(param=self.env.detach(), lr=lr)])
+        self._opt_order = ("xyz", "normal", "scaling", "rotation", "opacity", "shs", "base_color", "roughness",
+                           "incidents", "env")
+        self.last_outs = None
+
+    # views with the reference's parameter names (gaussian_model.py:199-203, 232)
+    features_dc = property(lambda self: self.shs[:, :1])
+    features_rest = property(lambda self: self.shs[:, 1:])
+    incidents_dc = property(lambda self: self.incidents[:, :1])
+    incidents_rest = property(lambda self: self.incidents[:, 1:])
+
+    # GaussianModel-style accessors (plain PyTorch; used by eval / relight code, not by the fused iteration)
+    def get_scaling(self):
+        return torch.exp(self.scaling)
+
+    def get_rotation(self):
+        return F.normalize(self.rotation)
+
+    def get_opacity(self):
+        return torch.sigmoid(self.opacity)
+
+    def get_shs(self):
+        return self.shs
+
+    def get_normal(self):
+        return F.normalize(self.normal, dim=-1, eps=1e-3)
+
+    def refresh_activations(self, cam=None):
+        L = _lib.lib()
+        campos = cam.camera_center if cam is not None else torch.zeros(3, device=self.dev)
+        with torch.cuda.device(self.dev):
+            st = L.r3dg_stage2_activate(
+                _lib.current_stream(), self.P, self.xyz.data_ptr(), self.scaling.data_ptr(), self.rotation.data_ptr(),
+                self.opacity.data_ptr(), self.normal.data_ptr(), self.base_color.data_ptr(), self.roughness.data_ptr(),
+                campos.contiguous().data_ptr(), self.a_scales.data_ptr(), self.a_rot.data_ptr(),
+                self.a_opacity.data_ptr(), self.a_normal.data_ptr(), self.a_base.data_ptr(), self.a_rough.data_ptr(),
+                self.a_viewdirs.data_ptr())
+        _lib.check(st, "stage2_activate")
+
+    def forward_backward(self, cam, bg, gt):
+        """One forward + loss + backward; gradients land in self.grads.  Returns the rasterizer's 10 public outputs."""
+        L = _lib.lib()
+        P, dev = self.P, self.dev
+        H, W = cam.image_height, cam.image_width
+        N = H * W
+        stream = _lib.current_stream
+        vm = cam.world_view_transform.contiguous()
+        campos = cam.camera_center.contiguous()
+        empty = torch.Tensor([])
+        with torch.cuda.device(dev):
+            self.refresh_activations(cam)
+            env_act = F.softplus(self.env)[0]                                    # DirectLightMap.get_env
+            env_c = env_act.detach().contiguous()
+            He, We = env_c.shape[0], env_c.shape[1]
+            _lib.check(L.r3dg_shade_forward(
+                stream(), P, self.K, self.M, self.a_base.data_ptr(), self.a_rough.data_ptr(), self.a_normal.data_ptr(),
+                self.a_viewdirs.data_ptr(), self.incidents.data_ptr(), env_c.data_ptr(), He, We, None,
+                self.visibility.data_ptr(), self.incident_dirs.data_ptr(), self.incident_areas.data_ptr(),
+                self.shade_out.data_ptr()), "shade_forward")
+            self.sums.zero_()
+            _lib.check(L.r3dg_stage2_pack_features(
+                stream(), P, self.xyz.data_ptr(), vm.data_ptr(), self.a_normal.data_ptr(), self.a_base.data_ptr(),
+                self.a_rough.data_ptr(), self.shade_out.data_ptr(), self.features.data_ptr(),
+                self.sums[3:].data_ptr()), "stage2_pack_features")
+            fw = rasterizer_ops.rasterize_gaussians(
+                bg, self.xyz, self.features, empty, self.a_opacity, self.a_scales, self.a_rot, 1.0, empty, vm,
+                cam.full_proj_transform, cam.tanfovx, cam.tanfovy, cam.cx, cam.cy, H, W, self.shs, 3, campos, False,
+                True, False)
+            R, n_contrib, image, opacity, depth, feature, pseudo_normal, sxyz, weights, radii, geom, binning, img = fw
+            # image-space loss terms and their gradients (one slab: dL_dimage 3 | dL_dopacity 1 | dL_dfeature 16; the depth image carries no loss)
+            g = torch.empty((20, H, W), dtype=torch.float32, device=dev)
+            if self._zero_depth_grad is None or self._zero_depth_grad.shape[-2:] != (H, W):
+                self._zero_depth_grad = torch.zeros((1, H, W), dtype=torch.float32, device=dev)
+            _lib.check(L.r3dg_stage2_loss(
+                stream(), W, H, image.data_ptr(), opacity.data_ptr(), feature.data_ptr(), pseudo_normal.data_ptr(),
+                n_contrib.data_ptr(), gt.contiguous().data_ptr(), bg.contiguous().data_ptr(),
+                self.w["l1"] / (3.0 * N), self.w["pbr"] / (3.0 * N), self.w["normal"] / (3.0 * N), g[0:3].data_ptr(),
+                g[3:4].data_ptr(), g[4:20].data_ptr(), self.sums.data_ptr()), "stage2_loss")
+            bw = rasterizer_ops.rasterize_gaussians_backward(
+                bg, self.xyz, self.features, radii, empty, self.a_scales, self.a_rot, 1.0, empty, vm,
+                cam.full_proj_transform, cam.tanfovx, cam.tanfovy, g[0:3], g[3:4], self._zero_depth_grad, g[4:20], self.shs, 3,
+                campos, geom, R, binning, img, True, False, dL_dsh_out=self.grads["shs"])
+            dL_dmeans2D, _dcol, dL_dopacity, dL_dmeans3D, dL_dfeatures, _dcov, _dsh, dL_dscales, dL_drot = bw
+            handle_a = self._allreduce_async(self._bucket_a)
+            _lib.check(L.r3dg_stage2_unpack_gradients(
+                stream(), P, dL_dfeatures.data_ptr(), self.shade_out.data_ptr(), self.w["light"] / (3.0 * P),
+                self.d_pbr.data_ptr(), self.d_diffuse.data_ptr()), "stage2_unpack_gradients")
+            d_base, d_rough, d_view, _d_inc, d_env = shading_ops.shade_backward(
+                self.a_base, self.a_rough, self.a_normal, self.a_viewdirs, self.incidents, env_c, self.visibility,
+                self.incident_dirs, self.incident_areas, self.d_pbr, self.d_diffuse,
+                out_incidents=self.grads["incidents"])
+            gr = self.grads
+            _lib.check(L.r3dg_stage2_activate_backward(
+                stream(), P, self.xyz.data_ptr(), self.scaling.data_ptr(), self.rotation.data_ptr(),
+                self.opacity.data_ptr(), self.normal.data_ptr(), self.base_color.data_ptr(), self.roughness.data_ptr(),
+                vm.data_ptr(), campos.data_ptr(), dL_dfeatures.data_ptr(), d_base.data_ptr(), d_rough.data_ptr(),
+                d_view.data_ptr(), dL_dscales.data_ptr(), dL_drot.data_ptr(), dL_dopacity.data_ptr(),
+                dL_dmeans3D.data_ptr(), gr["xyz"].data_ptr(), gr["scaling"].data_ptr(), gr["rotation"].data_ptr(),
+                gr["opacity"].data_ptr(), gr["normal"].data_ptr(), gr["base_color"].data_ptr(),
+                gr["roughness"].data_ptr()), "stage2_activate_backward")
+            handle_b = self._allreduce_async(self._bucket_b)
+            # environment texture: softplus + total-variation term, 16x32x3 -- PyTorch autograd
+            self._tv = self.w["env_smooth"] * tv_loss(env_act.permute(2, 0, 1))
+            gr["env"], = torch.autograd.grad([env_act, self._tv], [self.env],
+                                             [d_env.view_as(env_act), torch.ones_like(self._tv)])
+            if self.world > 1:
+                torch.distributed.all_reduce(gr["env"], group=self.group)
+                for h in (handle_a, handle_b):
+                    h.wait()
+                self.grad_flat.mul_(1.0 / self.world)
+                gr["env"].mul_(1.0 / self.world)
+        self.viewspace_grad = dL_dmeans2D
+        self.last_outs = (R, n_contrib, image, opacity, depth, feature, pseudo_normal, sxyz, weights, radii)
+        self._N = N
+        return self.last_outs
+
+    def _allreduce_async(self, flat):
+        if self.world <= 1:
+            return None
+        return torch.distributed.all_reduce(flat, group=self.group, async_op=True)
+
+    def loss(self):
+        """Loss value of the last forward_backward (a 0-d tensor; costs a few tiny kernels, so it is on demand)."""
+        N, P = self._N, self.P
+        w = torch.tensor([self.w["l1"] / (3.0 * N), self.w["pbr"] / (3.0 * N), self.w["normal"] / (3.0 * N),
+                          self.w["light"] / (3.0 * P)], device=self.dev)
+        return (self.sums * w).sum() + self._tv.detach()
+
+    def optimizer_step(self):
+        self.opt.step([self.grads[k] for k in self._opt_order])
+
+    def __call__(self, cam, bg, gt):
+        outs = self.forward_backward(cam, bg, gt)
+        self.optimizer_step()
+        return outs

@@ -105,7 +105,9 @@ def rasterize_gaussians(background, means3D, features, colors, opacity, scales, 
 def rasterize_gaussians_backward(background, means3D, features, radii, colors, scales, rotations, scale_modifier,
                                  cov3D_precomp, viewmatrix, projmatrix, tan_fovx, tan_fovy, dL_dout_color,
                                  dL_dout_opacity, dL_dout_depth, dL_dout_feature, sh, degree, campos, geomBuffer, R,
-                                 binningBuffer, imageBuffer, backward_geometry, debug):
+                                 binningBuffer, imageBuffer, backward_geometry, debug, dL_dsh_out=None):
+    """`dL_dsh_out` (not in the reference signature): optional preallocated [P,M,3] buffer the SH gradient is written
+    into (every element is written), e.g. a view of a flat gradient bucket."""
     L = _lib.lib()
     P = means3D.size(0)
     S = features.size(1)
@@ -117,18 +119,24 @@ def rasterize_gaussians_backward(background, means3D, features, radii, colors, s
 
     # gradients accumulated with atomics share ONE zero-filled slab; the per-Gaussian outputs of the fused
     # preprocess-backward kernel are fully written (zeros for invisible Gaussians) and start uninitialised
+    # (dL_dfeatures first: its rows stay 16-byte aligned for S % 4 == 0 whatever P is)
     acc = torch.zeros((11 + S) * P, **fopt)
-    o = 0
-    dL_dmeans2D = acc[o:o + 3 * P].view(P, 3); o += 3 * P
+    dL_dfeatures = acc[0:S * P].view(P, S)
+    o = S * P
     dL_dconic = acc[o:o + 4 * P].view(P, 2, 2); o += 4 * P
+    dL_dmeans2D = acc[o:o + 3 * P].view(P, 3); o += 3 * P
     dL_dopacity = acc[o:o + P].view(P, 1); o += P
-    dL_dcolors = acc[o:o + 3 * P].view(P, NUM_CHANNELS); o += 3 * P
-    dL_dfeatures = acc[o:o + S * P].view(P, S)
+    dL_dcolors = acc[o:o + 3 * P].view(P, NUM_CHANNELS)
     have_sh = sh.numel() != 0 and colors.numel() == 0
     have_scale = scales.numel() != 0 and cov3D_precomp.numel() == 0
     dL_dmeans3D = torch.empty((P, 3), **fopt)
     dL_dcov3D = torch.empty((P, 6), **fopt)
-    dL_dsh = (torch.empty if have_sh else torch.zeros)((P, M, 3), **fopt)
+    if dL_dsh_out is not None and have_sh:
+        if tuple(dL_dsh_out.shape) != (P, M, 3) or not dL_dsh_out.is_contiguous() or dL_dsh_out.dtype != torch.float32:
+            raise RuntimeError("dL_dsh_out must be a contiguous float32 [P,M,3] tensor")
+        dL_dsh = dL_dsh_out
+    else:
+        dL_dsh = (torch.empty if have_sh else torch.zeros)((P, M, 3), **fopt)
     dL_dscales = (torch.empty if have_scale else torch.zeros)((P, 3), **fopt)
     dL_drotations = (torch.empty if have_scale else torch.zeros)((P, 4), **fopt)
 

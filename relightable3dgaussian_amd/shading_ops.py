@@ -40,7 +40,8 @@ def shade_forward(base_color, roughness, normals, viewdirs, incidents, env, visi
 
 
 def shade_backward(base_color, roughness, normals, viewdirs, incidents, env, visibility, incident_dirs, incident_areas,
-                   dL_dpbr, dL_ddiffuse_light, env_transform=None):
+                   dL_dpbr, dL_ddiffuse_light, env_transform=None, out_incidents=None):
+    """`out_incidents`: optional preallocated contiguous [P,M,3] buffer for dL_dincidents (fully overwritten)."""
     L = _lib.lib()
     P, K = incident_dirs.shape[0], incident_dirs.shape[1]
     M = incidents.shape[1]
@@ -52,7 +53,12 @@ def shade_backward(base_color, roughness, normals, viewdirs, incidents, env, vis
     d_base = torch.empty((P, 3), dtype=torch.float32, device=dev)
     d_rough = torch.empty((P, 1), dtype=torch.float32, device=dev)
     d_view = torch.empty((P, 3), dtype=torch.float32, device=dev)
-    d_inc = torch.empty((P, M, 3), dtype=torch.float32, device=dev)
+    if out_incidents is not None:
+        if tuple(out_incidents.shape) != (P, M, 3) or not out_incidents.is_contiguous():
+            raise RuntimeError("out_incidents must be a contiguous [P,M,3] tensor")
+        d_inc = out_incidents
+    else:
+        d_inc = torch.empty((P, M, 3), dtype=torch.float32, device=dev)
     d_env = torch.zeros_like(t[5])
     with torch.cuda.device(dev):
         st = L.r3dg_shade_backward(_lib.current_stream(), P, K, M, t[0].data_ptr(), t[1].data_ptr(), t[2].data_ptr(),

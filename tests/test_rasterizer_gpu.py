@@ -270,7 +270,7 @@ def test_parity_wave_shape_and_cull(fw8, bw8, cull, hip_lib):
         _check_backward(make_case(S=16, seed=71, P=4000), "wave8_f%d_b%d_cull%d" % (fw8, bw8, cull))
         _check_forward(make_case(S=5, seed=72, scale_log_mean=-2.0, P=1500), "wave8_f%d_cull%d_big" % (fw8, cull))
     finally:
-        hip_lib.r3dg_set_tuning3(0, 1, 1)
+        hip_lib.r3dg_set_tuning3(1, 1, 1)
 
 
 @pytest.mark.parametrize("name", ["S16", "big_splats", "ragged_image"])
@@ -284,7 +284,7 @@ def test_cull_is_exact(name, hip_lib):
         hip_lib.r3dg_set_tuning3(-1, -1, 1)
         b = _run_forward(case)
     finally:
-        hip_lib.r3dg_set_tuning3(0, 1, 1)
+        hip_lib.r3dg_set_tuning3(1, 1, 1)
     torch.cuda.synchronize()
     assert a[0] == b[0]
     for i, nm in ((1, "n_contrib"), (2, "color"), (3, "opacity"), (4, "depth"), (5, "feature"), (6, "normal"),

@@ -39,5 +39,19 @@ def main():
         print("%8.1f us  x%-5.1f %s" % (v / k / 1e3, cnt[name] / k, name))
 
 
+def sequence():
+    """Print the kernel sequence (name, us) of the last full step."""
+    cur = sqlite3.connect(sys.argv[1]).cursor()
+    rows = list(cur.execute("select name, start, end from kernels order by start"))
+    marks = [i for i, r in enumerate(rows) if "render_backward_kernel" in r[0]]
+    a, b = marks[-2], marks[-1]
+    t0 = rows[a][1]
+    for name, s, e in rows[a:b]:
+        print("%9.1f %7.1f  %s" % ((s - t0) / 1e3, (e - s) / 1e3, name[:150]))
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 2 and sys.argv[2] == "seq":
+        sequence()
+        sys.exit(0)
     main()
