@@ -185,6 +185,12 @@ int r3dg_stage2_loss(void* stream, int width, int height, const float* d_image, 
                      const float* d_gt, const float* d_background, float w_l1, float w_pbr, float w_normal,
                      float* d_dL_dimage, float* d_dL_dopacity, float* d_dL_dfeature, float* d_sums);
 
+/* Learnable environment texture (DirectLightMap, scene/direct_light_map.py:18-27): env = softplus(raw), [He,We,3].
+ * g_raw = (dL_denv + w_tv * dTV(env)/denv) * softplus'(raw) with TV = mean|d/dh| + mean|d/dw| (the env-smoothness term,
+ * neilf.py:294-300); *tv_sum (may be NULL) += TV(env). */
+int r3dg_stage2_env_backward(void* stream, int He, int We, const float* d_raw, const float* d_env,
+                             const float* d_dL_denv, float w_tv, float* d_g_raw, float* d_tv_sum);
+
 /* Adam over up to R3DG_ADAM_MAX_GROUPS parameter groups in ONE launch (torch.optim.Adam semantics, no weight decay /
  * amsgrad; GaussianModel.training_setup + step, scene/gaussian_model.py:465-497).  Elements whose index modulo `period`
  * is >= `split` use lr_tail (period 0: one rate) -- e.g. a [P,16,3] SH tensor with period 48, split 3 carries the

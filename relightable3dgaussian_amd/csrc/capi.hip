@@ -91,6 +91,8 @@ void launch_s2_loss(hipStream_t s, int HW, const float* image, const float* opac
                     float w_pbr, float w_normal, float* dL_dimage, float* dL_dopacity, float* dL_dfeature, float* sums);
 void launch_adam(hipStream_t s, int n_groups, const r3dg_adam_group* groups, float beta1, float beta2, float eps,
                  int step);
+void launch_s2_env_backward(hipStream_t s, int He, int We, const float* raw, const float* env, const float* dL_denv,
+                            float w_tv, float* g_raw, float* tv_sum);
 size_t knn_temp_bytes(size_t P);
 void knn_dist2(hipStream_t s, int P, const float* pts, float* dists, void* temp);
 size_t bvh_build_temp_bytes(size_t P);
@@ -717,6 +719,18 @@ int r3dg_stage2_loss(void* stream_, int width, int height, const float* image, c
         StageTimer t((hipStream_t)stream_, ST_S2_LOSS);
         launch_s2_loss((hipStream_t)stream_, width * height, image, opacity, feature, pseudo_normal, n_contrib, gt, bg,
                        w_l1, w_pbr, w_normal, dL_dimage, dL_dopacity, dL_dfeature, sums);
+        return R3DG_OK;
+    });
+}
+
+int r3dg_stage2_env_backward(void* stream_, int He, int We, const float* raw, const float* env, const float* dL_denv,
+                             float w_tv, float* g_raw, float* tv_sum)
+{
+    if (He < 0 || We < 0) return invalid("stage2_env_backward: bad texture size");
+    if (He * We == 0) return R3DG_OK;
+    if (!raw || !env || !dL_denv || !g_raw) return invalid("stage2_env_backward: null buffer");
+    return guarded([&]() -> int {
+        launch_s2_env_backward((hipStream_t)stream_, He, We, raw, env, dL_denv, w_tv, g_raw, tv_sum);
         return R3DG_OK;
     });
 }

@@ -228,9 +228,9 @@ s2_loss_kernel(int HW, const float* __restrict__ image, const float* __restrict_
                float* __restrict__ dL_dopacity, float* __restrict__ dL_dfeature, float* __restrict__ sums)
 {
     __shared__ float s_part[4];
-    const int i = blockIdx.x * 256 + threadIdx.x;
     float s_l1 = 0.f, s_pbr = 0.f, s_n = 0.f;
-    if (i < HW) {
+    // grid-stride: a few hundred blocks, so the three same-address atomics per block do not serialise the kernel
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < HW; i += gridDim.x * 256) {
         const float op = opacity[i];
         const bool mask = n_contrib[i] > 0;
         const float opc = fmaxf(op, 1e-5f);
@@ -281,6 +281,36 @@ s2_loss_kernel(int HW, const float* __restrict__ image, const float* __restrict_
         atomicAdd(sums + 1, t1);
         atomicAdd(sums + 2, t2);
     }
+}
+
+// DirectLightMap: env = softplus(raw) (direct_light_map.py:18-23) and the total-variation smoothness term on it
+// (neilf.py:294-300): g_raw = (dL_denv + w_tv * dTV/denv) * softplus'(raw); *tv_sum += TV(env) (unweighted).
+// env layout [He,We,3]; TV = mean |d/dh| + mean |d/dw| over the 3 x He x We image.
+__global__ void __launch_bounds__(256)
+s2_env_backward_kernel(int He, int We, const float* __restrict__ raw, const float* __restrict__ env,
+                       const float* __restrict__ dL_denv, float w_tv, float* __restrict__ g_raw,
+                       float* __restrict__ tv_sum)
+{
+    __shared__ float s_part[4];
+    const int n = He * We * 3;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    float tv = 0.f;
+    if (i < n) {
+        const int c = i % 3, w = (i / 3) % We, h = i / (3 * We);
+        (void)c;
+        const float inv_v = He > 1 ? 1.f / (3.f * (He - 1) * We) : 0.f, inv_h = We > 1 ? 1.f / (3.f * He * (We - 1)) : 0.f;
+        const float x = env[i];
+        float g = 0.f;
+        if (h > 0) g += inv_v * signf_(x - env[i - 3 * We]);
+        if (h < He - 1) { const float d = env[i + 3 * We] - x; g -= inv_v * signf_(d); tv += inv_v * fabsf(d); }
+        if (w > 0) g += inv_h * signf_(x - env[i - 3]);
+        if (w < We - 1) { const float d = env[i + 3] - x; g -= inv_h * signf_(d); tv += inv_h * fabsf(d); }
+        const float r = raw[i];
+        const float dsoft = r > 20.f ? 1.f : sigmoidf_(r);
+        g_raw[i] = (dL_denv[i] + w_tv * g) * dsoft;
+    }
+    const float tot = block_sum_256(tv, s_part);
+    if (threadIdx.x == 0 && tv_sum != nullptr) atomicAdd(tv_sum, tot);
 }
 
 // ---- multi-group Adam -----------------------------------------------------------------------------------------------
@@ -383,9 +413,16 @@ void launch_s2_loss(hipStream_t s, int HW, const float* image, const float* opac
                     const float* pseudo_normal, const int* n_contrib, const float* gt, const float* bg, float w_l1,
                     float w_pbr, float w_normal, float* dL_dimage, float* dL_dopacity, float* dL_dfeature, float* sums)
 {
-    s2_loss_kernel<<<(HW + 255) / 256, 256, 0, s>>>(HW, image, opacity, feature, pseudo_normal, n_contrib, gt, bg, w_l1,
+    s2_loss_kernel<<<min((HW + 255) / 256, 768), 256, 0, s>>>(HW, image, opacity, feature, pseudo_normal, n_contrib, gt, bg, w_l1,
                                                     w_pbr, w_normal, dL_dimage, dL_dopacity, dL_dfeature, sums);
     check_launch(s, false, "s2_loss_kernel");
+}
+
+void launch_s2_env_backward(hipStream_t s, int He, int We, const float* raw, const float* env, const float* dL_denv,
+                            float w_tv, float* g_raw, float* tv_sum)
+{
+    s2_env_backward_kernel<<<(He * We * 3 + 255) / 256, 256, 0, s>>>(He, We, raw, env, dL_denv, w_tv, g_raw, tv_sum);
+    check_launch(s, false, "s2_env_backward_kernel");
 }
 
 void launch_adam(hipStream_t s, int n_groups, const r3dg_adam_group* groups, float beta1, float beta2, float eps,

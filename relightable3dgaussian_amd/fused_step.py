@@ -11,12 +11,12 @@ csrc/stage2_glue.hip and without an autograd graph: forward, loss, backward and 
     feature grads -> shading upstream grads   r3dg_stage2_unpack_gradients
     shading backward                          r3dg_shade_backward
     activation chain rule -> parameter grads  r3dg_stage2_activate_backward
+    env texture: softplus' + TV term          r3dg_stage2_env_backward        (direct_light_map.py:18-27, neilf.py:294-300)
     Adam, all groups in one launch            r3dg_adam_step                  (gaussian_model.py:465-497)
 
 The SH colour coefficients and the incident-light coefficients are each held as ONE [P,16,3] tensor (the reference
 concatenates features_dc / features_rest and incidents_dc / incidents_rest every iteration, gaussian_model.py:199-203);
 `features_dc` etc. are exposed as views, and the Adam kernel applies the dc / rest learning rates by column.
-Only the tiny environment texture (16x32x3: softplus + total-variation term) stays on PyTorch autograd.
 The parity target is the unfused path (tests/test_fused_step_gpu.py compares loss and every gradient)."""
 import ctypes as C
 
@@ -84,7 +84,7 @@ class FusedStage2Step:
         self.shs = torch.cat([params.features_dc.detach(), params.features_rest.detach()], 1).contiguous()
         self.base_color, self.roughness = d(params.base_color), d(params.roughness)
         self.incidents = torch.cat([params.incidents_dc.detach(), params.incidents_rest.detach()], 1).contiguous()
-        self.env = d(params.env).requires_grad_(True)
+        self.env = d(params.env)
         self.P = P = self.xyz.shape[0]
         self.K = sample_num
         self.M = self.shs.shape[1]
@@ -99,7 +99,7 @@ class FusedStage2Step:
         self.a_viewdirs = torch.empty(P, 3, **f)
         self.shade_out = torch.empty(P, shading_ops.NOUT, **f)
         self.features = torch.empty(P, 16, **f)
-        self.sums = torch.zeros(4, **f)                       # l1, pbr l1, normal mse, light l1 (unweighted sums)
+        self.sums = torch.zeros(5, **f)                       # l1, pbr l1, normal mse, light l1 (unweighted sums), TV(env)
         self.d_pbr, self.d_diffuse = torch.empty(P, 3, **f), torch.empty(P, 3, **f)
         # flat gradient slab: [xyz3 normal3 scaling3 rotation4 opacity1 base3 rough1 | shs 3M | incidents 3M] per group
         sizes = dict(xyz=3 * P, normal=3 * P, scaling=3 * P, rotation=4 * P, opacity=P, base_color=3 * P, roughness=P,
@@ -127,7 +127,7 @@ class FusedStage2Step:
             dict(param=self.shs, lr=lr, lr_tail=rest, period=3 * self.M, split=3),
             dict(param=self.base_color, lr=lr), dict(param=self.roughness, lr=lr),
             dict(param=self.incidents, lr=lr, lr_tail=rest, period=3 * self.M, split=3),
-            dict(param=self.env.detach(), lr=lr)])
+            dict(param=self.env, lr=lr)])
         self._opt_order = ("xyz", "normal", "scaling", "rotation", "opacity", "shs", "base_color", "roughness",
                            "incidents", "env")
         self.last_outs = None
@@ -178,8 +178,7 @@ class FusedStage2Step:
         empty = torch.Tensor([])
         with torch.cuda.device(dev):
             self.refresh_activations(cam)
-            env_act = F.softplus(self.env)[0]                                    # DirectLightMap.get_env
-            env_c = env_act.detach().contiguous()
+            env_c = F.softplus(self.env)[0]                                      # DirectLightMap.get_env
             He, We = env_c.shape[0], env_c.shape[1]
             _lib.check(L.r3dg_shade_forward(
                 stream(), P, self.K, self.M, self.a_base.data_ptr(), self.a_rough.data_ptr(), self.a_normal.data_ptr(),
@@ -228,10 +227,10 @@ class FusedStage2Step:
                 gr["opacity"].data_ptr(), gr["normal"].data_ptr(), gr["base_color"].data_ptr(),
                 gr["roughness"].data_ptr()), "stage2_activate_backward")
             handle_b = self._allreduce_async(self._bucket_b)
-            # environment texture: softplus + total-variation term, 16x32x3 -- PyTorch autograd
-            self._tv = self.w["env_smooth"] * tv_loss(env_act.permute(2, 0, 1))
-            gr["env"], = torch.autograd.grad([env_act, self._tv], [self.env],
-                                             [d_env.view_as(env_act), torch.ones_like(self._tv)])
+            # environment texture: softplus chain rule + total-variation term
+            _lib.check(L.r3dg_stage2_env_backward(
+                stream(), He, We, self.env.data_ptr(), env_c.data_ptr(), d_env.data_ptr(), self.w["env_smooth"],
+                gr["env"].data_ptr(), self.sums[4:].data_ptr()), "stage2_env_backward")
             if self.world > 1:
                 torch.distributed.all_reduce(gr["env"], group=self.group)
                 for h in (handle_a, handle_b):
@@ -252,8 +251,8 @@ class FusedStage2Step:
         """Loss value of the last forward_backward (a 0-d tensor; costs a few tiny kernels, so it is on demand)."""
         N, P = self._N, self.P
         w = torch.tensor([self.w["l1"] / (3.0 * N), self.w["pbr"] / (3.0 * N), self.w["normal"] / (3.0 * N),
-                          self.w["light"] / (3.0 * P)], device=self.dev)
-        return (self.sums * w).sum() + self._tv.detach()
+                          self.w["light"] / (3.0 * P), self.w["env_smooth"]], device=self.dev)
+        return (self.sums * w).sum()
 
     def optimizer_step(self):
         self.opt.step([self.grads[k] for k in self._opt_order])
