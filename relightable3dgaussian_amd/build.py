@@ -50,7 +50,7 @@ def _stamp(path, flags):
 def _compile(src, force):
     path = os.path.join(CSRC, src)
     obj = os.path.join(OBJDIR, src[:-4] + ".o")
-    flags = COMMON + EXTRA.get(src, [])
+    flags = COMMON + EXTRA.get(src, []) + os.environ.get("R3DG_EXTRA_HIPCC_FLAGS", "").split()   # experiments only
     stamp_file = obj + ".stamp"
     stamp = _stamp(path, flags)
     if not force and os.path.exists(obj) and os.path.exists(stamp_file) and open(stamp_file).read() == stamp:

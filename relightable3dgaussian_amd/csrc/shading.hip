@@ -260,6 +260,100 @@ __device__ __forceinline__ float row_transpose_reduce16(float (&v)[16])
     return transpose_step<1, true>(v[0], v[1], (lane & 1) != 0);
 }
 
+// ---- register-free prefetch: global -> LDS DMA (global_load_lds), double buffered per wave -----------------------------
+// Every wave owns two copies of {4 uniform records (4x64 floats), its 4 Gaussians' next 64 sample directions (4x64x3),
+// visibilities (4x64), areas (4x64)}.  While the wave computes on one copy, the loads of its NEXT (Gaussian group,
+// 64-sample block) are in flight into the other: the HBM/L2 latency of the three [P,K,*] caches and of the per-Gaussian
+// record is hidden without spending VGPRs or extra waves (the kernels run at 2 waves/SIMD).  The LDS image of a DMA
+// load is wave base + lane * size, so the copies keep the global layout: dirs [grp][k][3], vis/area [grp][k],
+// record [grp][64].  With K % 4 == 0 every lane moves 16 bytes per instruction (9 DMA instructions per block),
+// otherwise 4 bytes (24 instructions).
+// The DMA is issued from inline assembly on purpose: the compiler's wait-count pass does not tell which LDS-DMA load
+// feeds which LDS read and drains the whole vector-memory queue (s_waitcnt vmcnt(0)) in front of the first LDS access
+// after a __builtin_amdgcn_global_load_lds -- including the prefetch that was just issued.  Loads it does not know
+// about can only make its own waits stricter, never too weak (vmcnt completes in order), and the one true dependency
+// -- "my previous prefetch has landed" -- is a single explicit s_waitcnt at the top of each block.  m0 (LDS base of
+// the DMA) is saved and restored inside the statement.
+template <int BYTES>
+__device__ __forceinline__ void lds_dma(const float* gptr, float* lds_base /* wave-uniform */)
+{
+    const unsigned int off = __builtin_amdgcn_readfirstlane(
+        (unsigned int)(size_t)(__attribute__((address_space(3))) float*)lds_base);
+    unsigned int saved;
+    if (BYTES == 16)
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\t"
+                     "s_mov_b32 m0, %0" : "=&s"(saved) : "v"(gptr), "s"(off) : "memory");
+    else
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\t"
+                     "s_mov_b32 m0, %0" : "=&s"(saved) : "v"(gptr), "s"(off) : "memory");
+}
+#define R3DG_GLDS(gp, lp, sz) lds_dma<sz>(gp, lp)
+
+constexpr int SB_USTRIDE = 68;
+constexpr int SB_U = 0, SB_DIRS = 272, SB_VIS = 1040, SB_AREA = 1296, SB_FLOATS = 1552;   // one buffer of one wave
+
+struct ShadeSrc {
+    const float *base_color, *roughness, *normals, *viewdirs, *incidents, *g_pbr, *g_diff, *zero;
+    const float *dirs, *vis, *areas;
+};
+
+__device__ __forceinline__ const float* uniform_src(int e, int g, int M, const ShadeSrc& p)
+{
+    const float* q = p.zero;
+    if (e < 48) { if (e < 3 * M) q = p.incidents + (size_t)g * M * 3 + e; }
+    else if (e < 51) q = p.base_color + 3 * (size_t)g + (e - 48);
+    else if (e == 51) q = p.roughness + g;
+    else if (e < 55) q = p.normals + 3 * (size_t)g + (e - 52);
+    else if (e < 58) q = p.viewdirs + 3 * (size_t)g + (e - 55);
+    else if (e < 61) { if (p.g_pbr) q = p.g_pbr + 3 * (size_t)g + (e - 58); }
+    else { if (p.g_diff) q = p.g_diff + 3 * (size_t)g + (e - 61); }
+    return q;
+}
+
+template <bool VEC16>
+__device__ __forceinline__ void issue_block_loads(int lane, int gb, int k0, int P, int K, int M, const ShadeSrc& p,
+                                                  float* sb /* one SB_FLOATS buffer of this wave */)
+{
+#pragma unroll
+    for (int t = 0; t < SH_GW; t++) R3DG_GLDS(uniform_src(lane, min(gb + t, P - 1), M, p), sb + SB_U + SB_USTRIDE * t, 4);
+    const size_t total = (size_t)P * K;
+    if (VEC16) {
+#pragma unroll
+        for (int j = 0; j < 3; j++) {
+            const int f = (j * 64 + lane) * 4, grp = f / 192, w = f % 192;
+            size_t idx = ((size_t)min(gb + grp, P - 1) * K + k0) * 3 + w;
+            idx = idx < 3 * total - 4 ? idx : 3 * total - 4;          // ragged last block: stay inside the array
+            R3DG_GLDS(p.dirs + idx, sb + SB_DIRS + 256 * j, 16);
+        }
+        const int f = lane * 4, grp = f / 64, w = f % 64;
+        size_t idx = (size_t)min(gb + grp, P - 1) * K + k0 + w;
+        idx = idx < total - 4 ? idx : total - 4;
+        R3DG_GLDS(p.vis + idx, sb + SB_VIS, 16);
+        R3DG_GLDS(p.areas + idx, sb + SB_AREA, 16);
+    } else {
+#pragma unroll
+        for (int j = 0; j < 12; j++) {
+            const int f = j * 64 + lane, grp = f / 192, w = f % 192;
+            size_t idx = ((size_t)min(gb + grp, P - 1) * K + k0) * 3 + w;
+            idx = idx < 3 * total - 1 ? idx : 3 * total - 1;
+            R3DG_GLDS(p.dirs + idx, sb + SB_DIRS + 64 * j, 4);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const int f = j * 64 + lane, grp = f / 64, w = f % 64;
+            size_t idx = (size_t)min(gb + grp, P - 1) * K + k0 + w;
+            idx = idx < total - 1 ? idx : total - 1;
+            R3DG_GLDS(p.vis + idx, sb + SB_VIS + 64 * j, 4);
+            R3DG_GLDS(p.areas + idx, sb + SB_AREA + 64 * j, 4);
+        }
+    }
+}
+
+// all DMA loads of this wave have landed (they are the only vector-memory loads in the steady-state loop)
+__device__ __forceinline__ void wait_block_loads() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
+// Forward: direct loads (its register budget allows more waves per SIMD than the backward, and measured faster than the
+// DMA-staged variant: 0.27 vs 0.34 ms at P=300k, K=64).
 template <bool ENV_LDS>
 __global__ void __launch_bounds__(64 * SHADE_WAVES)
 shade_forward_kernel(int P, int K, int M, const float* __restrict__ base_color, const float* __restrict__ roughness,
@@ -351,16 +445,12 @@ grad_absmax_kernel(int n, const float* __restrict__ a, const float* __restrict__
 // fewer than 2^14 of them per texel, so the sum stays below 2^62; the resolution is 3e-11 * max|g| -- finer than the
 // fp32 accumulation it replaces -- and the per-block sum is order-independent.  Non-finite upstream gradients fall
 // back to float atomics so NaN/inf still propagate.
-template <bool ENV_LDS>
+template <bool ENV_LDS, bool VEC16>
 __global__ void __launch_bounds__(64 * SHADE_WAVES)
-shade_backward_kernel(int P, int K, int M, const float* __restrict__ base_color, const float* __restrict__ roughness,
-                      const float* __restrict__ normals, const float* __restrict__ viewdirs,
-                      const float* __restrict__ incidents, const float* __restrict__ env, int He, int We,
-                      const float* __restrict__ tr, const float* __restrict__ visibility,
-                      const float* __restrict__ dirs, const float* __restrict__ areas,
-                      const float* __restrict__ g_pbr, const float* __restrict__ g_diff, float* __restrict__ d_base,
-                      float* __restrict__ d_rough, float* __restrict__ d_view, float* __restrict__ d_inc,
-                      float* __restrict__ d_env, const unsigned int* __restrict__ gmax_bits)
+shade_backward_kernel(int P, int K, int M, ShadeSrc src, const float* __restrict__ env, int He, int We,
+                      const float* __restrict__ tr, float* __restrict__ d_base, float* __restrict__ d_rough,
+                      float* __restrict__ d_view, float* __restrict__ d_inc, float* __restrict__ d_env,
+                      const unsigned int* __restrict__ gmax_bits)
 {
     extern __shared__ __attribute__((aligned(16))) float s_mem[];
     const int ntex_raw = He * We * 3;
@@ -380,164 +470,195 @@ shade_backward_kernel(int P, int K, int M, const float* __restrict__ base_color,
     }
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int grp = lane >> 4, l = lane & 15;
-    float* s_u = s_mem + 3 * ntex + (wave * SH_GW + grp) * 64;
-    float* s_dl = s_mem + 3 * ntex + SH_GB * 64;          // 24 floats per thread: parked dL/d(local light) and SH sums
+    __shared__ __attribute__((aligned(16))) float s_buf[SHADE_WAVES][2][SB_FLOATS];      // DMA double buffers
+    // 12 floats per thread: the 3 SH sums of each of the lane's 4 samples (pass 0 -> pass 1), overwritten in place by the
+    // 3 "dL/d local light" values (pass 1 -> pass 2); [slot][thread] so every access is lane-contiguous
+    constexpr int PARK = 64 * SHADE_WAVES;
+    __shared__ float s_park_all[12 * PARK];
+    float* s_park = s_park_all + threadIdx.x;
     const float invK = 1.0f / (float)K;
-    for (int gb = (blockIdx.x * SHADE_WAVES + wave) * SH_GW; gb < P; gb += gridDim.x * SH_GB) {
+    const int nblk = (K + 63) / 64;
+    const int g_stride = gridDim.x * SH_GB;
+    int gb = (blockIdx.x * SHADE_WAVES + wave) * SH_GW, kb = 0, buf = 0;
+    if (gb < P) issue_block_loads<VEC16>(lane, gb, 0, P, K, M, src, s_buf[wave][0]);
+    // per-lane accumulators over this lane's samples: 48 SH gradient channels (f = i*3 + c), albedo, roughness, view.
+    // Each 64-sample block (4 samples per lane) is walked three times to keep the live register set small: pass 0
+    // evaluates the SH sums of the local light, pass 1 the full sample + BRDF / view / env gradients, pass 2 rebuilds
+    // the SH basis (40 instructions) and does the 48 SH-gradient FMAs.
+    float acc[48];
+    float accb[8];       // 0..2 albedo, 3 roughness, 4..6 view direction
+#pragma unroll
+    for (int i = 0; i < 48; i++) acc[i] = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; i++) accb[i] = 0.f;
+    while (gb < P) {
+        wait_block_loads();
+        int ngb = gb, nkb = kb + 1;
+        if (nkb == nblk) { nkb = 0; ngb = gb + g_stride; }
+        if (ngb < P) issue_block_loads<VEC16>(lane, ngb, nkb * 64, P, K, M, src, s_buf[wave][buf ^ 1]);
+        const float* sb = s_buf[wave][buf];
+        const float* s_u = sb + SB_U + grp * SB_USTRIDE;
         const int g = gb + grp;
         const bool live = g < P;
-#pragma unroll
-        for (int t = 0; t < 4; t++)
-            s_u[l + 16 * t] = live ? load_uniform_element(l + 16 * t, g, M, base_color, roughness, normals, viewdirs,
-                                                          incidents, g_pbr, g_diff) : 0.f;
         GaussFwd G;
         gauss_setup(G, s_u);
         const float gp[3] = {s_u[58] * invK, s_u[59] * invK, s_u[60] * invK};
         const float gd[3] = {s_u[61] * invK, s_u[62] * invK, s_u[63] * invK};
-        // per-lane accumulators over this lane's samples: 48 SH gradient channels (f = i*3 + c), albedo, roughness, view.
-        // Samples are taken in blocks of 4 per lane and each block is walked twice to keep the live register set small:
-        // pass 1 does the full sample + BRDF/view/env gradients and parks the 3 "dL/d local light" values in LDS,
-        // pass 2 re-reads the direction, rebuilds the SH basis (40 instructions) and does the 48 SH-gradient FMAs.
-        float acc[48];
-        float accb[8];       // 0..2 albedo, 3 roughness, 4..6 view direction
-#pragma unroll
-        for (int i = 0; i < 48; i++) acc[i] = 0.f;
-#pragma unroll
-        for (int i = 0; i < 8; i++) accb[i] = 0.f;
-        float* my_dl = s_dl + threadIdx.x * 24;
-        float* my_sum = my_dl + 12;
-        for (int k0 = 0; k0 < K; k0 += 4 * SH_L) {
-            // pass 0: SH sums of the local incident light (basis + 48 coefficient FMAs), parked in LDS
+        // pass 0: SH sums of the local incident light (basis + 48 coefficient FMAs), parked in LDS
 #pragma unroll 1
-            for (int t = 0; t < 4; t++) {
-                const int k = k0 + l + SH_L * t;
-                float sum[3] = {0.f, 0.f, 0.f};
-                if (live && k < K) {
-                    const size_t o = (size_t)g * K + k;
-                    float Y[16];
-                    sh_basis16(dirs[3 * o], dirs[3 * o + 1], dirs[3 * o + 2], M, Y);
-                    sh_local_sum(s_u, Y, sum);
-                }
-                my_sum[3 * t] = sum[0];
-                my_sum[3 * t + 1] = sum[1];
-                my_sum[3 * t + 2] = sum[2];
+        for (int t = 0; t < 4; t++) {
+            const int kl = l + SH_L * t, k = kb * 64 + kl;
+            float sum[3] = {0.f, 0.f, 0.f};
+            if (live && k < K) {
+                const float* d = sb + SB_DIRS + (grp * 64 + kl) * 3;
+                float Y[16];
+                sh_basis16(d[0], d[1], d[2], M, Y);
+                sh_local_sum(s_u, Y, sum);
             }
+            s_park[(3 * t) * PARK] = sum[0];
+            s_park[(3 * t + 1) * PARK] = sum[1];
+            s_park[(3 * t + 2) * PARK] = sum[2];
+        }
 #pragma unroll 1
-            for (int t = 0; t < 4; t++) {
-                const int k = k0 + l + SH_L * t;
-                float dl[3] = {0.f, 0.f, 0.f};
-                if (live && k < K) {
-                    const size_t o = (size_t)g * K + k;
-                    SampleFwd s;
-                    s.shsum[0] = my_sum[3 * t]; s.shsum[1] = my_sum[3 * t + 1]; s.shsum[2] = my_sum[3 * t + 2];
-                    shade_sample<ENV_LDS, true>(s, G, s_u, M, dirs[3 * o], dirs[3 * o + 1], dirs[3 * o + 2],
-                                                visibility[o], areas[o], env, s_env, tr, He, We);
-                    float gspec = 0.f;
-                    float dlin[3];
+        for (int t = 0; t < 4; t++) {
+            const int kl = l + SH_L * t, k = kb * 64 + kl;
+            float dl[3] = {0.f, 0.f, 0.f};
+            if (live && k < K) {
+                const float* d = sb + SB_DIRS + (grp * 64 + kl) * 3;
+                SampleFwd s;
+                s.shsum[0] = s_park[(3 * t) * PARK];
+                s.shsum[1] = s_park[(3 * t + 1) * PARK];
+                s.shsum[2] = s_park[(3 * t + 2) * PARK];
+                shade_sample<ENV_LDS, true>(s, G, s_u, M, d[0], d[1], d[2], sb[SB_VIS + grp * 64 + kl],
+                                            sb[SB_AREA + grp * 64 + kl], env, s_env, tr, He, We);
+                float gspec = 0.f;
+                float dlin[3];
 #pragma unroll
-                    for (int c = 0; c < 3; c++) {
-                        const float fd = G.base[c] / kPi;
-                        const float dT = gp[c] * (fd + s.spec) + gd[c];       // dL/dtransport_c
-                        gspec += gp[c] * s.transport[c];
-                        accb[c] += gp[c] * s.transport[c] / kPi;              // albedo
-                        dlin[c] = dT * s.area_ndi;                            // dL/d(incident light)_c
-                        dl[c] = s.shsum[c] >= 0.f ? dlin[c] : 0.f;            // clamp_min(0): gradient where SH sum >= 0
-                    }
+                for (int c = 0; c < 3; c++) {
+                    const float fd = G.base[c] / kPi;
+                    const float dT = gp[c] * (fd + s.spec) + gd[c];       // dL/dtransport_c
+                    gspec += gp[c] * s.transport[c];
+                    accb[c] += gp[c] * s.transport[c] / kPi;              // albedo
+                    dlin[c] = dT * s.area_ndi;                            // dL/d(incident light)_c
+                    dl[c] = s.shsum[c] >= 0.f ? dlin[c] : 0.f;            // clamp_min(0): gradient where SH sum >= 0
+                }
+                // environment-texture gradient: 4 taps x 3 channels.  One (wave-divergent) branch per sample on the
+                // visibility, nothing per tap: an out-of-range tap contributes weight 0 to texel 0.
+                if (s.vis != 0.f) {
+                    const float ev[3] = {dlin[0] * s.vis, dlin[1] * s.vis, dlin[2] * s.vis};
+                    if (fixed) {
+                        // float -> 64-bit fixed point in three instructions: in double, x * scale + 1.5 * 2^52 has the
+                        // integer round(x * scale) in its low mantissa bits (two's complement, |.| < 2^51), and the
+                        // bit pattern of the magic constant (0x4338 << 48) only occupies the high dword
+                        const double scale_d = (double)fx_scale;
 #pragma unroll
-                    for (int tt = 0; tt < 4; tt++) {
-                        if (s.taps.idx[tt] >= 0) {
+                        for (int tt = 0; tt < 4; tt++) {
+                            const int tex = s.taps.idx[tt] >= 0 ? s.taps.idx[tt] : 0;
+                            const float w = s.taps.idx[tt] >= 0 ? s.taps.w[tt] : 0.f;
 #pragma unroll
                             for (int c = 0; c < 3; c++) {
-                                const float val = dlin[c] * s.vis * s.taps.w[tt];
-                                if (val == 0.f) continue;
-                                if (fixed) {
-                                    const float cl = fminf(fmaxf(val, -fx_clamp), fx_clamp);
-                                    atomicAdd(reinterpret_cast<unsigned long long*>(&s_denv[3 * s.taps.idx[tt] + c]),
-                                              (unsigned long long)(long long)(cl * fx_scale));
-                                } else {
-                                    atomicAdd(&d_env[3 * (size_t)s.taps.idx[tt] + c], val);
-                                }
+                                const float cl = __builtin_amdgcn_fmed3f(ev[c] * w, -fx_clamp, fx_clamp);
+                                const double dsum = __builtin_fma((double)cl, scale_d, 6755399441055744.0);
+                                const unsigned long long bits =
+                                    (unsigned long long)__double_as_longlong(dsum) - 0x4338000000000000ull;
+                                atomicAdd(reinterpret_cast<unsigned long long*>(&s_denv[3 * tex + c]), bits);
+                            }
+                        }
+                    } else {
+#pragma unroll
+                        for (int tt = 0; tt < 4; tt++) {
+                            if (s.taps.idx[tt] >= 0) {
+#pragma unroll
+                                for (int c = 0; c < 3; c++)
+                                    atomicAdd(&d_env[3 * (size_t)s.taps.idx[tt] + c], ev[c] * s.taps.w[tt]);
                             }
                         }
                     }
-                    // specular -> roughness, view direction
-                    const float frac = s.frac0 * G.a2;
-                    const bool nom_free = s.nomr >= 1e-6f && s.nomr <= 4.f * kPi;
-                    const float nom = fminf(fmaxf(s.nomr, 1e-6f), 4.f * kPi);
-                    const float dfrac = gspec / nom;
-                    const float dnom = nom_free ? -gspec * frac / (nom * nom) : 0.f;
-                    float da2 = dfrac * s.frac0;
-                    const float dfrac0 = dfrac * G.a2;
-                    const float dFMi = dfrac0 * 0.96f * 0.6931471805599453f * s.p2;
-                    float dVoH = dFMi * (-2.f * 5.55473f * s.VoH - 6.98316f);
-                    const float c4 = 4.f * kPi;
-                    const float dnom0 = dnom * c4 * 2.f * s.nom0 * s.nom1 * s.nom2;
-                    const float dnom1 = dnom * c4 * s.nom0 * s.nom0 * s.nom2;
-                    const float dnom2 = dnom * c4 * s.nom0 * s.nom0 * s.nom1;
-                    float dNoH = dnom0 * 2.f * s.NoH * (G.a2 - 1.f);
-                    da2 += dnom0 * s.NoH * s.NoH;
-                    float dNoV = dnom1 * (1.f - G.kk);
-                    const float dkk = dnom1 * (1.f - G.NoV) + dnom2 * (1.f - s.NoL);
-                    const float da = dkk / 8.f + da2 * 2.f * G.a;
-                    accb[3] += dkk * 2.f / 8.f + da * 2.f * G.r;               // roughness
-                    if (!(s.rawNoH >= 1e-6f && s.rawNoH <= 1.f)) dNoH = 0.f;
-                    if (!(s.rawVoH >= 1e-6f && s.rawVoH <= 1.f)) dVoH = 0.f;
-                    if (!(G.rawNoV >= 1e-6f && G.rawNoV <= 1.f)) dNoV = 0.f;
-                    float dH[3], dV[3];
-#pragma unroll
-                    for (int c = 0; c < 3; c++) {
-                        dH[c] = dNoH * G.N[c] + dVoH * G.V[c];
-                        dV[c] = dVoH * s.Hh[c] + dNoV * G.N[c];
-                    }
-                    const float hd = s.Hh[0] * dH[0] + s.Hh[1] * dH[1] + s.Hh[2] * dH[2];
-#pragma unroll
-                    for (int c = 0; c < 3; c++) dV[c] += 0.5f * (dH[c] - s.Hh[c] * hd) / s.ulen;
-                    const float vd = G.V[0] * dV[0] + G.V[1] * dV[1] + G.V[2] * dV[2];
-#pragma unroll
-                    for (int c = 0; c < 3; c++) accb[4 + c] += (dV[c] - G.V[c] * vd) / G.vlen;   // view direction
                 }
-                my_dl[3 * t] = dl[0];
-                my_dl[3 * t + 1] = dl[1];
-                my_dl[3 * t + 2] = dl[2];
+                // specular -> roughness, view direction
+                const float frac = s.frac0 * G.a2;
+                const bool nom_free = s.nomr >= 1e-6f && s.nomr <= 4.f * kPi;
+                const float nom = fminf(fmaxf(s.nomr, 1e-6f), 4.f * kPi);
+                const float dfrac = gspec / nom;
+                const float dnom = nom_free ? -gspec * frac / (nom * nom) : 0.f;
+                float da2 = dfrac * s.frac0;
+                const float dfrac0 = dfrac * G.a2;
+                const float dFMi = dfrac0 * 0.96f * 0.6931471805599453f * s.p2;
+                float dVoH = dFMi * (-2.f * 5.55473f * s.VoH - 6.98316f);
+                const float c4 = 4.f * kPi;
+                const float dnom0 = dnom * c4 * 2.f * s.nom0 * s.nom1 * s.nom2;
+                const float dnom1 = dnom * c4 * s.nom0 * s.nom0 * s.nom2;
+                const float dnom2 = dnom * c4 * s.nom0 * s.nom0 * s.nom1;
+                float dNoH = dnom0 * 2.f * s.NoH * (G.a2 - 1.f);
+                da2 += dnom0 * s.NoH * s.NoH;
+                float dNoV = dnom1 * (1.f - G.kk);
+                const float dkk = dnom1 * (1.f - G.NoV) + dnom2 * (1.f - s.NoL);
+                const float da = dkk / 8.f + da2 * 2.f * G.a;
+                accb[3] += dkk * 2.f / 8.f + da * 2.f * G.r;               // roughness
+                if (!(s.rawNoH >= 1e-6f && s.rawNoH <= 1.f)) dNoH = 0.f;
+                if (!(s.rawVoH >= 1e-6f && s.rawVoH <= 1.f)) dVoH = 0.f;
+                if (!(G.rawNoV >= 1e-6f && G.rawNoV <= 1.f)) dNoV = 0.f;
+                float dH[3], dV[3];
+#pragma unroll
+                for (int c = 0; c < 3; c++) {
+                    dH[c] = dNoH * G.N[c] + dVoH * G.V[c];
+                    dV[c] = dVoH * s.Hh[c] + dNoV * G.N[c];
+                }
+                const float hd = s.Hh[0] * dH[0] + s.Hh[1] * dH[1] + s.Hh[2] * dH[2];
+#pragma unroll
+                for (int c = 0; c < 3; c++) dV[c] += 0.5f * (dH[c] - s.Hh[c] * hd) / s.ulen;
+                const float vd = G.V[0] * dV[0] + G.V[1] * dV[1] + G.V[2] * dV[2];
+#pragma unroll
+                for (int c = 0; c < 3; c++) accb[4 + c] += (dV[c] - G.V[c] * vd) / G.vlen;   // view direction
             }
+            s_park[(3 * t) * PARK] = dl[0];
+            s_park[(3 * t + 1) * PARK] = dl[1];
+            s_park[(3 * t + 2) * PARK] = dl[2];
+        }
 #pragma unroll 1
-            for (int t = 0; t < 4; t++) {
-                const int k = k0 + l + SH_L * t;
-                if (live && k < K) {
-                    const size_t o = (size_t)g * K + k;
-                    float Y[16];
-                    sh_basis16(dirs[3 * o], dirs[3 * o + 1], dirs[3 * o + 2], M, Y);
-                    const float dl[3] = {my_dl[3 * t], my_dl[3 * t + 1], my_dl[3 * t + 2]};
+        for (int t = 0; t < 4; t++) {
+            const int kl = l + SH_L * t, k = kb * 64 + kl;
+            if (live && k < K) {
+                const float* d = sb + SB_DIRS + (grp * 64 + kl) * 3;
+                float Y[16];
+                sh_basis16(d[0], d[1], d[2], M, Y);
+                const float dl[3] = {s_park[(3 * t) * PARK], s_park[(3 * t + 1) * PARK], s_park[(3 * t + 2) * PARK]};
 #pragma unroll
-                    for (int f = 0; f < 48; f++) acc[f] += dl[f % 3] * Y[f / 3];
-                }
+                for (int f = 0; f < 48; f++) acc[f] += dl[f % 3] * Y[f / 3];
             }
         }
-        // four row reductions of 16 channels each: lane l ends with channel 16*pass + l
-        float r[4];
-#pragma unroll
-        for (int pass = 0; pass < 3; pass++) {
-            float v[16];
-#pragma unroll
-            for (int i = 0; i < 16; i++) v[i] = acc[16 * pass + i];
-            r[pass] = row_transpose_reduce16(v);
-        }
-        {
-            float v[16];
-#pragma unroll
-            for (int i = 0; i < 16; i++) v[i] = i < 8 ? accb[i] : 0.f;
-            r[3] = row_transpose_reduce16(v);
-        }
-        if (live) {
+        if (kb == nblk - 1) {
+            // four row reductions of 16 channels each: lane l ends with channel 16*pass + l
+            float r[4];
 #pragma unroll
             for (int pass = 0; pass < 3; pass++) {
-                const int f = 16 * pass + l;
-                if (f < 3 * M) d_inc[(size_t)g * M * 3 + f] = r[pass];
+                float v[16];
+#pragma unroll
+                for (int i = 0; i < 16; i++) v[i] = acc[16 * pass + i];
+                r[pass] = row_transpose_reduce16(v);
             }
-            if (l < 3) d_base[3 * (size_t)g + l] = r[3];
-            else if (l == 3) d_rough[g] = r[3];
-            else if (l < 7) d_view[3 * (size_t)g + (l - 4)] = r[3];
+            {
+                float v[16];
+#pragma unroll
+                for (int i = 0; i < 16; i++) v[i] = i < 8 ? accb[i] : 0.f;
+                r[3] = row_transpose_reduce16(v);
+            }
+            if (live) {
+#pragma unroll
+                for (int pass = 0; pass < 3; pass++) {
+                    const int f = 16 * pass + l;
+                    if (f < 3 * M) d_inc[(size_t)g * M * 3 + f] = r[pass];
+                }
+                if (l < 3) d_base[3 * (size_t)g + l] = r[3];
+                else if (l == 3) d_rough[g] = r[3];
+                else if (l < 7) d_view[3 * (size_t)g + (l - 4)] = r[3];
+            }
+#pragma unroll
+            for (int i = 0; i < 48; i++) acc[i] = 0.f;
+#pragma unroll
+            for (int i = 0; i < 8; i++) accb[i] = 0.f;
         }
+        gb = ngb; kb = nkb; buf ^= 1;
     }
     if (fixed) {
         __syncthreads();
@@ -559,6 +680,21 @@ static int shade_grid_impl(int P)
     const int want = (P + SH_GB - 1) / SH_GB;
     const int cap = cus * 8;
     return want < cap ? (want > 0 ? want : 1) : cap;
+}
+
+// per-device 256-byte scratch, allocated once and never freed: word 0 = max|upstream gradient| of the backward (reset per
+// launch), bytes 64.. stay zero (the DMA source for absent elements of the uniform record)
+static unsigned int* shade_scratch()
+{
+    static unsigned int* scratch[64] = {nullptr};
+    int dev = 0;
+    R3DG_HIP(hipGetDevice(&dev));
+    if (dev < 0 || dev >= 64) dev = 0;
+    if (scratch[dev] == nullptr) {
+        R3DG_HIP(hipMalloc((void**)&scratch[dev], 256));
+        R3DG_HIP(hipMemset(scratch[dev], 0, 256));
+    }
+    return scratch[dev];
 }
 
 void launch_shade_forward(hipStream_t s, int P, int K, int M, const float* base_color, const float* roughness,
@@ -583,29 +719,30 @@ void launch_shade_backward(hipStream_t s, int P, int K, int M, const float* base
                            const float* areas, const float* g_pbr, const float* g_diff, float* d_base, float* d_rough,
                            float* d_view, float* d_inc, float* d_env)
 {
-    // one 4-byte device scratch word per device for the max|upstream gradient| (allocated once, never freed)
-    static unsigned int* scratch[64] = {nullptr};
-    int dev = 0;
-    R3DG_HIP(hipGetDevice(&dev));
-    if (dev < 0 || dev >= 64) dev = 0;
-    if (scratch[dev] == nullptr) R3DG_HIP(hipMalloc((void**)&scratch[dev], 256));
-    R3DG_HIP(hipMemsetAsync(scratch[dev], 0, 4, s));
+    unsigned int* scratch = shade_scratch();
+    R3DG_HIP(hipMemsetAsync(scratch, 0, 4, s));
     const int nb = (3 * P + 255) / 256;
-    grad_absmax_kernel<<<nb < 1024 ? nb : 1024, 256, 0, s>>>(3 * P, g_pbr, g_diff, scratch[dev]);
+    grad_absmax_kernel<<<nb < 1024 ? nb : 1024, 256, 0, s>>>(3 * P, g_pbr, g_diff, scratch);
 
+    const ShadeSrc src = {base_color, roughness, normals, viewdirs, incidents, g_pbr, g_diff,
+                          reinterpret_cast<const float*>(scratch + 16), dirs, visibility, areas};
     const int ntex = He * We * 3;
     // persistent blocks so the LDS-privatised env gradient is flushed once per block, not once per Gaussian
     const int grid = shade_grid(P);
-    const size_t u_bytes = SH_GB * 64 * sizeof(float);
-    const size_t dl_bytes = 64 * SHADE_WAVES * 24 * sizeof(float);
-    if (3 * ntex <= ENV_LDS_MAX)
-        shade_backward_kernel<true><<<grid, 64 * SHADE_WAVES, 3 * ((ntex + 3) & ~3) * sizeof(float) + u_bytes + dl_bytes, s>>>(
-            P, K, M, base_color, roughness, normals, viewdirs, incidents, env, He, We, tr, visibility, dirs, areas, g_pbr,
-            g_diff, d_base, d_rough, d_view, d_inc, d_env, scratch[dev]);
-    else
-        shade_backward_kernel<false><<<grid, 64 * SHADE_WAVES, u_bytes + dl_bytes, s>>>(
-            P, K, M, base_color, roughness, normals, viewdirs, incidents, env, He, We, tr, visibility, dirs, areas, g_pbr,
-            g_diff, d_base, d_rough, d_view, d_inc, d_env, scratch[dev]);
+    const bool lds = 3 * ntex <= ENV_LDS_MAX, vec = (K % 4) == 0 && (size_t)P * K >= 4;
+    const size_t smem = lds ? 3 * ((ntex + 3) & ~3) * sizeof(float) : 0;  // + the static DMA buffers and parking slots
+#define R3DG_SB(L, V)                                                                                                 \
+    do {                                                                                                              \
+        if (smem > 65536)                                                                                             \
+            R3DG_HIP(hipFuncSetAttribute((const void*)shade_backward_kernel<L, V>,                                    \
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));                     \
+        shade_backward_kernel<L, V><<<grid, 64 * SHADE_WAVES, smem, s>>>(P, K, M, src, env, He, We, tr, d_base,       \
+                                                                       d_rough, d_view, d_inc, d_env, scratch);       \
+    } while (0)
+    if (lds) { if (vec) R3DG_SB(true, true); else R3DG_SB(true, false); }
+    else { if (vec) R3DG_SB(false, true); else R3DG_SB(false, false); }
+#undef R3DG_SB
+    check_launch(s, false, "shade_backward_kernel");
 }
 
 }  // namespace r3dg

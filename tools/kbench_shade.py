@@ -6,7 +6,8 @@ from relightable3dgaussian_amd import _lib, shading_ops as so, sampling
 P = int(os.environ.get("P", 300000)); dev = "cuda"
 L = _lib.lib()
 g = torch.Generator().manual_seed(0)
-for K, He, exp in ((64, 16, 0), (384, 256, 0)):
+CASES = ((64, 16, 0),) if os.environ.get("ONLY64") else ((64, 16, 0), (384, 256, 0))
+for K, He, exp in CASES:
     nrm = torch.nn.functional.normalize(torch.randn(P, 3, generator=g), dim=-1).to(dev)
     dirs, areas = sampling.fibonacci_sphere_sampling(nrm, K)
     vis = (torch.rand(P, K, 1, device=dev) > 0.3).float()
