@@ -424,6 +424,7 @@ shade_forward_kernel(int P, int K, int M, const float* __restrict__ base_color, 
 __global__ void __launch_bounds__(256)
 grad_absmax_kernel(int n, const float* __restrict__ a, const float* __restrict__ b, unsigned int* __restrict__ out)
 {
+    __shared__ float s_m[4];
     float m = 0.f;
     bool bad = false;
     for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
@@ -434,7 +435,10 @@ grad_absmax_kernel(int n, const float* __restrict__ a, const float* __restrict__
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
     if (__ballot(bad) != 0ull) m = __uint_as_float(0x7f800000u);   // +inf marks "non-finite input"
-    if ((threadIdx.x & 63) == 0) atomicMax(out, __float_as_uint(m));
+    if ((threadIdx.x & 63) == 0) s_m[threadIdx.x >> 6] = m;
+    __syncthreads();
+    // one atomic per block (a few hundred same-address atomics, not thousands)
+    if (threadIdx.x == 0) atomicMax(out, __float_as_uint(fmaxf(fmaxf(s_m[0], s_m[1]), fmaxf(s_m[2], s_m[3]))));
 }
 
 // The environment-texture gradient is a scatter of 12 values per sample into a few hundred texels.  LDS *float*
@@ -722,7 +726,7 @@ void launch_shade_backward(hipStream_t s, int P, int K, int M, const float* base
     unsigned int* scratch = shade_scratch();
     R3DG_HIP(hipMemsetAsync(scratch, 0, 4, s));
     const int nb = (3 * P + 255) / 256;
-    grad_absmax_kernel<<<nb < 1024 ? nb : 1024, 256, 0, s>>>(3 * P, g_pbr, g_diff, scratch);
+    grad_absmax_kernel<<<nb < 256 ? nb : 256, 256, 0, s>>>(3 * P, g_pbr, g_diff, scratch);
 
     const ShadeSrc src = {base_color, roughness, normals, viewdirs, incidents, g_pbr, g_diff,
                           reinterpret_cast<const float*>(scratch + 16), dirs, visibility, areas};

@@ -62,15 +62,16 @@ def test_fused_forward_backward_matches_autograd():
     chk("loss", fused.loss().reshape(1), loss_ref.detach().reshape(1), 1e-5)
     g = fused.grads
     chk("g xyz", g["xyz"], params.xyz.grad, 2e-4, outliers=2e-3)
-    chk("g normal", g["normal"], params.normal.grad, 2e-4)
+    chk("g normal", g["normal"], params.normal.grad, 2e-4, outliers=2e-3)
     chk("g scaling", g["scaling"], params.scaling.grad, 2e-4, outliers=2e-3)
     chk("g rotation", g["rotation"], params.rotation.grad, 2e-4, outliers=2e-3)
     chk("g opacity", g["opacity"], params.opacity.grad, 2e-4, outliers=2e-3)
-    chk("g shs", g["shs"], torch.cat([params.features_dc.grad, params.features_rest.grad], 1), 2e-4)
-    chk("g base_color", g["base_color"], params.base_color.grad, 2e-4)
-    chk("g roughness", g["roughness"], params.roughness.grad, 2e-4)
-    chk("g incidents", g["incidents"], torch.cat([params.incidents_dc.grad, params.incidents_rest.grad], 1), 2e-4)
-    chk("g env", g["env"], params.env.grad, 2e-4)
+    chk("g shs", g["shs"], torch.cat([params.features_dc.grad, params.features_rest.grad], 1), 2e-4, outliers=2e-3)
+    chk("g base_color", g["base_color"], params.base_color.grad, 2e-4, outliers=2e-3)
+    chk("g roughness", g["roughness"], params.roughness.grad, 2e-4, outliers=2e-3)
+    chk("g incidents", g["incidents"], torch.cat([params.incidents_dc.grad, params.incidents_rest.grad], 1), 2e-4,
+        outliers=2e-3)
+    chk("g env", g["env"], params.env.grad, 1e-3)        # sum over all Gaussians: inherits the outliers above
     print("\n".join(msgs))
     assert ok_all, "\n".join(msgs)
     for k in ("xyz", "shs", "incidents", "base_color"):
