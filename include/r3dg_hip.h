@@ -91,6 +91,23 @@ int r3dg_rasterize_backward(void* stream, int P, int S, int D, int M, int R, con
                             float* d_dL_dmean3D, float* d_dL_dcov3D, float* d_dL_dsh, float* d_dL_dscale,
                             float* d_dL_drot, int backward_geometry, int debug);
 
+/* Same as r3dg_rasterize_backward, but the per-Gaussian geometry backward (K12+K13: d_dL_dmean3D, d_dL_dcov3D, d_dL_dsh,
+ * d_dL_dscale, d_dL_drot) is launched on `geometry_stream`, ordered after the tile kernel by an event, so work that
+ * only needs the tile kernel's outputs (d_dL_dfeature, ...) can follow on `stream` concurrently.  The caller joins the
+ * two streams before reading the geometry outputs.  geometry_stream == stream is exactly r3dg_rasterize_backward. */
+int r3dg_rasterize_backward_split(void* stream, void* geometry_stream, int P, int S, int D, int M, int R,
+                                  const float* d_background, int width, int height, const float* d_means3D,
+                                  const float* d_shs, const float* d_features, const float* d_colors_precomp,
+                                  const float* d_scales, float scale_modifier, const float* d_rotations,
+                                  const float* d_cov3D_precomp, const float* d_viewmatrix, const float* d_projmatrix,
+                                  const float* d_campos, float tan_fovx, float tan_fovy, const int32_t* d_radii,
+                                  const void* d_geom_buffer, const void* d_binning_buffer, const void* d_img_buffer,
+                                  const float* d_dL_dpix, const float* d_dL_dpix_o, const float* d_dL_dpix_d,
+                                  const float* d_dL_dpix_f, float* d_dL_dmean2D, float* d_dL_dconic,
+                                  float* d_dL_dopacity, float* d_dL_dcolor, float* d_dL_dfeature, float* d_dL_dmean3D,
+                                  float* d_dL_dcov3D, float* d_dL_dsh, float* d_dL_dscale, float* d_dL_drot,
+                                  int backward_geometry, int debug);
+
 int r3dg_mark_visible(void* stream, int P, const float* d_means3D, const float* d_viewmatrix,
                       const float* d_projmatrix, uint8_t* d_present);
 

@@ -450,6 +450,7 @@ int r3dg_rasterize_forward(void* stream_, r3dg_alloc_fn geometry_alloc, r3dg_all
     });
 }
 
+// (defined below)
 int r3dg_rasterize_backward(void* stream_, int P, int S, int D, int M, int R, const float* background, int width,
                             int height, const float* means3D, const float* shs, const float* features,
                             const float* colors_precomp, const float* scales, float scale_modifier,
@@ -461,6 +462,26 @@ int r3dg_rasterize_backward(void* stream_, int P, int S, int D, int M, int R, co
                             float* dL_dopacity, float* dL_dcolor, float* dL_dfeature, float* dL_dmean3D,
                             float* dL_dcov3D, float* dL_dsh, float* dL_dscale, float* dL_drot,
                             int backward_geometry, int debug_)
+{
+    return r3dg_rasterize_backward_split(stream_, stream_, P, S, D, M, R, background, width, height, means3D, shs,
+                                         features, colors_precomp, scales, scale_modifier, rotations, cov3D_precomp,
+                                         viewmatrix, projmatrix, campos, tan_fovx, tan_fovy, radii, geom_buffer,
+                                         binning_buffer, img_buffer, dL_dpix, dL_dpix_o, dL_dpix_d, dL_dpix_f, dL_dmean2D,
+                                         dL_dconic, dL_dopacity, dL_dcolor, dL_dfeature, dL_dmean3D, dL_dcov3D, dL_dsh,
+                                         dL_dscale, dL_drot, backward_geometry, debug_);
+}
+
+int r3dg_rasterize_backward_split(void* stream_, void* geometry_stream_, int P, int S, int D, int M, int R,
+                                  const float* background, int width, int height, const float* means3D,
+                                  const float* shs, const float* features, const float* colors_precomp,
+                                  const float* scales, float scale_modifier, const float* rotations,
+                                  const float* cov3D_precomp, const float* viewmatrix, const float* projmatrix,
+                                  const float* campos, float tan_fovx, float tan_fovy, const int32_t* radii,
+                                  const void* geom_buffer, const void* binning_buffer, const void* img_buffer,
+                                  const float* dL_dpix, const float* dL_dpix_o, const float* dL_dpix_d,
+                                  const float* dL_dpix_f, float* dL_dmean2D, float* dL_dconic, float* dL_dopacity,
+                                  float* dL_dcolor, float* dL_dfeature, float* dL_dmean3D, float* dL_dcov3D,
+                                  float* dL_dsh, float* dL_dscale, float* dL_drot, int backward_geometry, int debug_)
 {
     if (P < 0 || width <= 0 || height <= 0 || R < 0) return invalid("rasterize_backward: bad P/R/width/height");
     if (S < 0 || S > R3DG_MAX_S_BWD) return invalid("rasterize_backward: feature channels S must be in [0,36]");
@@ -497,6 +518,16 @@ int r3dg_rasterize_backward(void* stream_, int P, int S, int D, int M, int R, co
             t_rb.stop();
         }
         const float* cov3D_ptr = cov3D_precomp != nullptr ? cov3D_precomp : (const float*)(gbuf + G.cov3D);
+        // the per-Gaussian geometry backward may run on a second stream, ordered after the tile kernel by an event
+        hipStream_t gstream = (hipStream_t)geometry_stream_;
+        if (gstream != stream) {
+            hipEvent_t ev;
+            R3DG_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+            R3DG_HIP(hipEventRecord(ev, stream));
+            R3DG_HIP(hipStreamWaitEvent(gstream, ev, 0));
+            R3DG_HIP(hipEventDestroy(ev));
+        }
+        stream = gstream;
         StageTimer t_pb(stream, ST_PREPROCESS_BWD);
         launch_preprocess_backward(stream, P, D, M, means3D, radii_p, colors_precomp == nullptr ? shs : nullptr,
                                    (const uint8_t*)(gbuf + G.clamped), cov3D_precomp == nullptr ? scales : nullptr,

@@ -75,7 +75,8 @@ PARAM_NAMES = ("xyz", "normal", "scaling", "rotation", "opacity", "shs", "base_c
 class FusedStage2Step:
     """Owns the raw parameters (copied from a bench_core.GaussianParams) and runs whole iterations."""
 
-    def __init__(self, params, sample_num, lr=1e-4, lr_rest_scale=1.0, loss_weights=None, process_group=None):
+    def __init__(self, params, sample_num, lr=1e-4, lr_rest_scale=1.0, loss_weights=None, process_group=None,
+                 overlap_geometry=False):
         dev = params.xyz.device
         self.dev = dev
         d = lambda t: t.detach().clone().contiguous()
@@ -113,6 +114,9 @@ class FusedStage2Step:
         self._bucket_b = self.grad_flat[sizes["shs"]:]          # final after the activation backward
         self.grads["env"] = torch.zeros_like(self.env)
         self._zero_depth_grad = None
+        # Optional second stream for the per-Gaussian geometry backward.  Measured on MI355X: no gain -- the shading
+        # backward already fills the register file (2 waves/SIMD x 221 VGPRs), so the geometry kernel cannot co-run.
+        self._side = torch.cuda.Stream(device=dev) if overlap_geometry else None
         self.group = process_group
         self.world = torch.distributed.get_world_size(process_group) if (
             torch.distributed.is_available() and torch.distributed.is_initialized()) else 1
@@ -207,9 +211,8 @@ class FusedStage2Step:
             bw = rasterizer_ops.rasterize_gaussians_backward(
                 bg, self.xyz, self.features, radii, empty, self.a_scales, self.a_rot, 1.0, empty, vm,
                 cam.full_proj_transform, cam.tanfovx, cam.tanfovy, g[0:3], g[3:4], self._zero_depth_grad, g[4:20], self.shs, 3,
-                campos, geom, R, binning, img, True, False, dL_dsh_out=self.grads["shs"])
+                campos, geom, R, binning, img, True, False, dL_dsh_out=self.grads["shs"], geometry_stream=self._side)
             dL_dmeans2D, _dcol, dL_dopacity, dL_dmeans3D, dL_dfeatures, _dcov, _dsh, dL_dscales, dL_drot = bw
-            handle_a = self._allreduce_async(self._bucket_a)
             _lib.check(L.r3dg_stage2_unpack_gradients(
                 stream(), P, dL_dfeatures.data_ptr(), self.shade_out.data_ptr(), self.w["light"] / (3.0 * P),
                 self.d_pbr.data_ptr(), self.d_diffuse.data_ptr()), "stage2_unpack_gradients")
@@ -218,6 +221,9 @@ class FusedStage2Step:
                 self.incident_dirs, self.incident_areas, self.d_pbr, self.d_diffuse,
                 out_incidents=self.grads["incidents"])
             gr = self.grads
+            if self._side is not None:          # join the geometry backward
+                torch.cuda.current_stream().wait_stream(self._side)
+            handle_a = self._allreduce_async(self._bucket_a)
             _lib.check(L.r3dg_stage2_activate_backward(
                 stream(), P, self.xyz.data_ptr(), self.scaling.data_ptr(), self.rotation.data_ptr(),
                 self.opacity.data_ptr(), self.normal.data_ptr(), self.base_color.data_ptr(), self.roughness.data_ptr(),

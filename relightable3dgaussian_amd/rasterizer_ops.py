@@ -105,9 +105,12 @@ def rasterize_gaussians(background, means3D, features, colors, opacity, scales, 
 def rasterize_gaussians_backward(background, means3D, features, radii, colors, scales, rotations, scale_modifier,
                                  cov3D_precomp, viewmatrix, projmatrix, tan_fovx, tan_fovy, dL_dout_color,
                                  dL_dout_opacity, dL_dout_depth, dL_dout_feature, sh, degree, campos, geomBuffer, R,
-                                 binningBuffer, imageBuffer, backward_geometry, debug, dL_dsh_out=None):
+                                 binningBuffer, imageBuffer, backward_geometry, debug, dL_dsh_out=None,
+                                 geometry_stream=None):
     """`dL_dsh_out` (not in the reference signature): optional preallocated [P,M,3] buffer the SH gradient is written
-    into (every element is written), e.g. a view of a flat gradient bucket."""
+    into (every element is written), e.g. a view of a flat gradient bucket.  `geometry_stream`: optional torch stream
+    for the per-Gaussian geometry backward (dL_dmeans3D, dL_dcov3D, dL_dsh, dL_dscales, dL_drotations are then only
+    valid after the caller joins that stream; see r3dg_rasterize_backward_split)."""
     L = _lib.lib()
     P = means3D.size(0)
     S = features.size(1)
@@ -146,8 +149,10 @@ def rasterize_gaussians_backward(background, means3D, features, radii, colors, s
         bg_, means_, sh_, feat_, col_, sc_, rot_, cov_, vm_, pm_, cam_, gC, gO, gD, gF = t
         radii_ = radii.contiguous()
         with torch.cuda.device(dev):
-            st = L.r3dg_rasterize_backward(
-                _lib.current_stream(), P, S, int(degree), M, int(R), _lib.ptr(bg_), W, H, _lib.ptr(means_),
+            cur = _lib.current_stream()
+            gs = cur if geometry_stream is None else C.c_void_p(geometry_stream.cuda_stream)
+            st = L.r3dg_rasterize_backward_split(
+                cur, gs, P, S, int(degree), M, int(R), _lib.ptr(bg_), W, H, _lib.ptr(means_),
                 _lib.ptr(sh_), _lib.ptr(feat_), _lib.ptr(col_), _lib.ptr(sc_), float(scale_modifier), _lib.ptr(rot_),
                 _lib.ptr(cov_), _lib.ptr(vm_), _lib.ptr(pm_), _lib.ptr(cam_), float(tan_fovx), float(tan_fovy),
                 radii_.data_ptr(), _lib.ptr(geomBuffer), _lib.ptr(binningBuffer), _lib.ptr(imageBuffer), _lib.ptr(gC),
