@@ -264,6 +264,10 @@ int r3dg_set_tuning2(int fwd_unroll, int bwd_unroll, int tile_order);
  * that provably stay below alpha 1/255 on all of the wave's pixels (default), 0 = evaluate every entry.  <0 keeps the
  * current value.  Results do not depend on any of them. */
 int r3dg_set_tuning3(int fwd_wave8x8, int bwd_wave8x8, int cull);
+/* r3dg_set_tuning4: ordering of the (tile, depth) instances: 1 = bin per tile with integer tickets, then sort each tile's
+ * list inside LDS (default); 0 = the reference's formulation, one global radix sort of all 44-45-bit keys (K5-K7).  The
+ * sorted keys, point list and tile ranges are bit-identical either way; <0 keeps the current value. */
+int r3dg_set_tuning4(int tile_binning);
 int r3dg_selftest_transpose_reduce(void* stream, int N, int dpp, const float* d_in, float* d_out, int* d_chan,
                                    int* d_owner);
 

@@ -26,7 +26,8 @@ void launch_duplicate_with_keys(hipStream_t s, int P, const float* means2D, cons
                                 uint32_t* point_offsets, uint64_t* keys, uint32_t* values, const int* radii, int gx,
                                 int gy);
 void launch_identify_tile_ranges(hipStream_t s, int L, const uint64_t* keys, uint32_t* ranges);
-void launch_tile_order(hipStream_t s, int T, const uint32_t* ranges, uint32_t* order);
+void launch_tile_order(hipStream_t s, int T, const uint32_t* ranges, uint32_t* order, uint32_t small_cap,
+                       uint32_t* big_list, uint32_t* big_count);
 void launch_render_forward(hipStream_t s, int W, int H, int S, const uint32_t* tile_order, const uint32_t* ranges,
                            const uint32_t* point_list,
                            const float* means2D, const float* depths, const float* features, const float* colors,
@@ -93,6 +94,9 @@ void launch_adam(hipStream_t s, int n_groups, const r3dg_adam_group* groups, flo
                  int step);
 void launch_s2_env_backward(hipStream_t s, int He, int We, const float* raw, const float* env, const float* dL_denv,
                             float w_tv, float* g_raw, float* tv_sum);
+uint32_t tile_sort_small_cap();
+void launch_tile_sort(hipStream_t s, int T, const uint32_t* tile_order, const uint32_t* ranges, const uint32_t* big_list,
+                      const uint32_t* big_count, uint64_t* keys, uint32_t* vals, uint64_t* scratch);
 size_t knn_temp_bytes(size_t P);
 void knn_dist2(hipStream_t s, int P, const float* pts, float* dists, void* temp);
 size_t bvh_build_temp_bytes(size_t P);
@@ -101,6 +105,7 @@ void bvh_trace_opacity(hipStream_t s, int num_rays, const int32_t* nodes, const 
                        const float* rays_d, const float* means, const float* covs, const float* opac,
                        const float* normals, int32_t* contributes, float* out, int* overflow);
 extern int g_cull;
+int g_tile_binning = 1;   // 1: bin per tile + per-tile LDS sort; 0: the reference's global (tile|depth) radix sort
 extern int g_fwd_wave8x8;
 extern int g_bwd_wave8x8;
 extern int g_fwd_ppl;
@@ -183,6 +188,8 @@ ImageLayout ImageLayout::make(size_t N, size_t T)
     L.n_contrib = take(N * 4);
     L.ranges = take(T * 8);
     L.tile_order = take(T * 4);
+    L.big_list = take(T * 4);        // tile-binned ordering: tiles too long for the small in-LDS sort
+    L.big_count = take(256);
     L.bytes = o;
     return L;
 }
@@ -240,6 +247,12 @@ int r3dg_max_features_forward(void) { return R3DG_MAX_S_FWD; }
 int r3dg_max_features_backward(void) { return R3DG_MAX_S_BWD; }
 
 // tuning knobs (pixels per lane of the two render kernels); not part of the drop-in surface
+int r3dg_set_tuning4(int tile_binning)
+{
+    if (tile_binning >= 0) g_tile_binning = tile_binning;
+    return R3DG_OK;
+}
+
 int r3dg_set_tuning3(int fwd_wave8x8, int bwd_wave8x8, int cull)
 {
     if (cull >= 0) g_cull = cull;
@@ -407,30 +420,53 @@ int r3dg_rasterize_forward(void* stream_, r3dg_alloc_fn geometry_alloc, r3dg_all
         uint32_t* vals_u = (uint32_t*)(bbuf + B.vals_unsorted);
         uint32_t* vals = (uint32_t*)(bbuf + B.vals);
 
-        StageTimer t_dup(stream, ST_DUPKEYS);
-        launch_duplicate_with_keys(stream, P, g_means2D, g_depths, g_tiles, g_block,
-                                   (uint32_t*)(gbuf + G.point_offsets), keys_u, vals_u, radii_p, gx, gy);
-        check_launch(stream, debug, "duplicate_with_keys");
-        t_dup.stop();
-
-        const int bit = (int)higher_msb((uint32_t)T);
-        StageTimer t_sort(stream, ST_SORT);
-        sort_pairs(stream, (size_t)R, keys_u, vals_u, keys, vals, 32 + bit, bbuf + B.sort_temp, debug);
-        t_sort.stop();
-
         uint32_t* ranges = (uint32_t*)(ibuf + I.ranges);
-        StageTimer t_rng(stream, ST_RANGES);
-        R3DG_HIP(hipMemsetAsync(ranges, 0, T * 8, stream));
-        launch_identify_tile_ranges(stream, R, keys, ranges);
-        check_launch(stream, debug, "identify_tile_ranges");
-        t_rng.stop();
-
         const float* colors_ptr = colors_precomp != nullptr ? colors_precomp : g_rgb;
-        uint32_t* tile_order = nullptr;
-        if (g_tile_order) {
-            tile_order = (uint32_t*)(ibuf + I.tile_order);
-            launch_tile_order(stream, (int)T, ranges, tile_order);
+        uint32_t* tile_order = g_tile_order ? (uint32_t*)(ibuf + I.tile_order) : nullptr;
+        if (g_tile_binning) {
+            // stable partition by tile id (one radix pass over the tile bits), then a per-tile depth sort in LDS: same
+            // final order as the global 44-bit sort (radix_sort.hip)
+            uint32_t* big_list = (uint32_t*)(ibuf + I.big_list);
+            uint32_t* big_count = (uint32_t*)(ibuf + I.big_count);
+            StageTimer t_dup(stream, ST_DUPKEYS);
+            launch_duplicate_with_keys(stream, P, g_means2D, g_depths, g_tiles, g_block,
+                                       (uint32_t*)(gbuf + G.point_offsets), keys_u, vals_u, radii_p, gx, gy);
+            check_launch(stream, debug, "duplicate_with_keys");
+            t_dup.stop();
+            const int bit = (int)higher_msb((uint32_t)T);
+            StageTimer t_sort(stream, ST_SORT);
+            sort_pairs_range(stream, (size_t)R, keys_u, vals_u, keys, vals, 32, 32 + bit, bbuf + B.sort_temp, debug,
+                             /*stable=*/false);
+            R3DG_HIP(hipMemsetAsync(ranges, 0, T * 8, stream));
+            launch_identify_tile_ranges(stream, R, keys, ranges);
+            check_launch(stream, debug, "identify_tile_ranges");
+            uint32_t* order = tile_order ? tile_order : (uint32_t*)(ibuf + I.tile_order);
+            launch_tile_order(stream, (int)T, ranges, order, tile_sort_small_cap(), big_list, big_count);
             check_launch(stream, debug, "tile_order");
+            launch_tile_sort(stream, (int)T, order, ranges, big_list, big_count, keys, vals, keys_u);
+            check_launch(stream, debug, "tile_sort");
+            t_sort.stop();
+        } else {
+            StageTimer t_dup(stream, ST_DUPKEYS);
+            launch_duplicate_with_keys(stream, P, g_means2D, g_depths, g_tiles, g_block,
+                                       (uint32_t*)(gbuf + G.point_offsets), keys_u, vals_u, radii_p, gx, gy);
+            check_launch(stream, debug, "duplicate_with_keys");
+            t_dup.stop();
+
+            const int bit = (int)higher_msb((uint32_t)T);
+            StageTimer t_sort(stream, ST_SORT);
+            sort_pairs(stream, (size_t)R, keys_u, vals_u, keys, vals, 32 + bit, bbuf + B.sort_temp, debug);
+            t_sort.stop();
+
+            StageTimer t_rng(stream, ST_RANGES);
+            R3DG_HIP(hipMemsetAsync(ranges, 0, T * 8, stream));
+            launch_identify_tile_ranges(stream, R, keys, ranges);
+            check_launch(stream, debug, "identify_tile_ranges");
+            t_rng.stop();
+            if (tile_order) {
+                launch_tile_order(stream, (int)T, ranges, tile_order, 0u, nullptr, nullptr);
+                check_launch(stream, debug, "tile_order");
+            }
         }
         StageTimer t_rf(stream, ST_RENDER_FWD);
         launch_render_forward(stream, width, height, S, tile_order, ranges, vals, g_means2D, g_depths, features, colors_ptr,

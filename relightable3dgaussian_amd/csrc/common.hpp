@@ -52,7 +52,7 @@ struct GeometryLayout {  // byte offsets into the opaque geometry buffer
     static GeometryLayout make(size_t P);
 };
 struct ImageLayout {
-    size_t final_T, n_contrib, ranges, tile_order, bytes;
+    size_t final_T, n_contrib, ranges, tile_order, big_list, big_count, bytes;
     static ImageLayout make(size_t N, size_t T);
 };
 struct BinningLayout {
@@ -63,6 +63,8 @@ struct BinningLayout {
 size_t sort_temp_bytes(size_t n);
 void sort_pairs(hipStream_t stream, size_t n, uint64_t* keys_in, uint32_t* vals_in, uint64_t* keys_out,
                 uint32_t* vals_out, int end_bit, void* temp, bool debug);
+void sort_pairs_range(hipStream_t stream, size_t n, uint64_t* keys_in, uint32_t* vals_in, uint64_t* keys_out,
+                      uint32_t* vals_out, int begin_bit, int end_bit, void* temp, bool debug, bool stable);
 
 // ---- device helpers -------------------------------------------------------------------------------------
 #ifdef __HIPCC__

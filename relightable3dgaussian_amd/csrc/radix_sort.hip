@@ -4,7 +4,8 @@
 // ascending Gaussian index).
 //
 // Pure integer work; wave64 formulation:
-//   * digit width is chosen per call (<= 11 bits) so 44-45 key bits (800x800 .. 1600x1200) need 4 passes;
+//   * digit width is chosen per call (<= 12 bits) so 44-45 key bits (800x800 .. 1600x1200) need 4 passes, and the
+//     12 tile-id bits of an 800x800 frame are ONE pass (tile-binned ordering, below);
 //   * per pass: (1) per-block digit histogram, (2) one block per digit scans that digit's per-block counts
 //     (plus the digit's global base), (3) scatter with a wave-synchronous stable rank: each wave matches
 //     equal digits with one 64-bit __ballot per digit bit, ranks by popcount below the lane, and keeps
@@ -17,7 +18,7 @@ constexpr int SORT_THREADS = 256;
 constexpr int SORT_WAVES = SORT_THREADS / 64;
 constexpr int SORT_ITEMS = 16;                                   // keys per thread
 constexpr int SORT_TILE = SORT_THREADS * SORT_ITEMS;             // 4096 keys per block
-constexpr int SORT_MAX_BITS = 11;
+constexpr int SORT_MAX_BITS = 12;
 constexpr int SORT_MAX_BINS = 1 << SORT_MAX_BITS;
 
 __device__ __forceinline__ uint32_t digit_of(uint64_t key, int shift, uint32_t mask)
@@ -88,7 +89,7 @@ sort_scatter_kernel(size_t n, const uint64_t* __restrict__ keys_in, const uint32
                     uint64_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out, int shift, int bits,
                     uint32_t nblocks, const uint32_t* __restrict__ hist)
 {
-    __shared__ uint32_t s_cnt[SORT_WAVES * SORT_MAX_BINS];
+    extern __shared__ uint32_t s_cnt[];           // [SORT_WAVES][bins]
     const int bins = 1 << bits;
     const uint32_t mask = (uint32_t)bins - 1u;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -149,13 +150,39 @@ sort_scatter_kernel(size_t n, const uint64_t* __restrict__ keys_in, const uint32
     }
 }
 
+// (3') UNSTABLE scatter for partitions whose order inside a bucket does not matter (the tile-binned ordering sorts
+// every bucket by a unique key afterwards): the rank inside the block is one integer LDS atomic per key -- no ballots,
+// one counter array per block instead of one per wave.
+__global__ void __launch_bounds__(SORT_THREADS)
+partition_scatter_kernel(size_t n, const uint64_t* __restrict__ keys_in, const uint32_t* __restrict__ vals_in,
+                         uint64_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out, int shift, int bits,
+                         uint32_t nblocks, const uint32_t* __restrict__ hist)
+{
+    extern __shared__ uint32_t s_cnt[];           // [bins]: running position of each digit for this block
+    const int bins = 1 << bits;
+    const uint32_t mask = (uint32_t)bins - 1u;
+    for (int d = threadIdx.x; d < bins; d += SORT_THREADS) s_cnt[d] = hist[(size_t)d * nblocks + blockIdx.x];
+    __syncthreads();
+    const size_t base = (size_t)blockIdx.x * SORT_TILE;
+#pragma unroll 4
+    for (int r = 0; r < SORT_ITEMS; r++) {
+        const size_t i = base + (size_t)r * SORT_THREADS + threadIdx.x;
+        if (i < n) {
+            const uint64_t k = keys_in[i];
+            const uint32_t pos = atomicAdd(&s_cnt[digit_of(k, shift, mask)], 1u);
+            keys_out[pos] = k;
+            vals_out[pos] = vals_in[i];
+        }
+    }
+}
+
 static inline uint32_t sort_nblocks(size_t n) { return (uint32_t)((n + SORT_TILE - 1) / SORT_TILE); }
 
-static void sort_plan(int end_bit, int& passes, int& bits)
+static void sort_plan(int nbits, int& passes, int& bits)
 {
-    if (end_bit < 1) end_bit = 1;
-    passes = (end_bit + SORT_MAX_BITS - 1) / SORT_MAX_BITS;
-    bits = (end_bit + passes - 1) / passes;
+    if (nbits < 1) nbits = 1;
+    passes = (nbits + SORT_MAX_BITS - 1) / SORT_MAX_BITS;
+    bits = (nbits + passes - 1) / passes;
 }
 
 size_t sort_temp_bytes(size_t n)
@@ -168,9 +195,17 @@ size_t sort_temp_bytes(size_t n)
 void sort_pairs(hipStream_t stream, size_t n, uint64_t* keys_in, uint32_t* vals_in, uint64_t* keys_out,
                 uint32_t* vals_out, int end_bit, void* temp, bool debug)
 {
+    sort_pairs_range(stream, n, keys_in, vals_in, keys_out, vals_out, 0, end_bit, temp, debug, true);
+}
+
+// sort on key bits [begin_bit, end_bit) only; stable == false: equal keys end up in arbitrary order (single-pass
+// partitions only -- a multi-pass LSD sort needs stable passes)
+void sort_pairs_range(hipStream_t stream, size_t n, uint64_t* keys_in, uint32_t* vals_in, uint64_t* keys_out,
+                      uint32_t* vals_out, int begin_bit, int end_bit, void* temp, bool debug, bool stable)
+{
     if (n == 0) return;
     int passes, bits;
-    sort_plan(end_bit, passes, bits);
+    sort_plan(end_bit - begin_bit, passes, bits);
     if (passes > 8) {
         set_error("sort_pairs: end_bit too large");
         throw HipError{-1};
@@ -191,18 +226,210 @@ void sort_pairs(hipStream_t stream, size_t n, uint64_t* keys_in, uint32_t* vals_
         ksrc = keys_out; vsrc = vals_out; kdst = keys_in; vdst = vals_in;
     }
     for (int p = 0; p < passes; p++) {
-        const int shift = p * bits;
+        const int shift = begin_bit + p * bits;
         const int pbits = (end_bit - shift) < bits ? (end_bit - shift) : bits;
         uint32_t* tot = digit_total + (size_t)p * SORT_MAX_BINS;
         sort_hist_kernel<<<nb, SORT_THREADS, 0, stream>>>(n, ksrc, shift, pbits, nb, hist, tot);
         check_launch(stream, debug, "sort_hist_kernel");
         sort_scan_kernel<<<1 << pbits, 256, 0, stream>>>(1 << pbits, nb, hist, tot);
         check_launch(stream, debug, "sort_scan_kernel");
-        sort_scatter_kernel<<<nb, SORT_THREADS, 0, stream>>>(n, ksrc, vsrc, kdst, vdst, shift, pbits, nb, hist);
+        if (!stable && passes == 1)
+            partition_scatter_kernel<<<nb, SORT_THREADS, sizeof(uint32_t) << pbits, stream>>>(n, ksrc, vsrc, kdst, vdst,
+                                                                                              shift, pbits, nb, hist);
+        else
+            sort_scatter_kernel<<<nb, SORT_THREADS, (size_t)SORT_WAVES * sizeof(uint32_t) << pbits, stream>>>(
+                n, ksrc, vsrc, kdst, vdst, shift, pbits, nb, hist);
         check_launch(stream, debug, "sort_scatter_kernel");
         uint64_t* tk = ksrc; ksrc = kdst; kdst = tk;
         uint32_t* tv = vsrc; vsrc = vdst; vdst = tv;
     }
+}
+
+// ---- tile-binned ordering: per-tile depth sort ---------------------------------------------------------------------
+// The reference sorts all R (tile | depth) keys globally (rasterizer_impl.cu:313-318: 4 radix passes over 44 bits here).
+// Same final order with less memory traffic: ONE stable radix pass on the tile-id bits only (sort_pairs_range), which
+// leaves every tile's instances contiguous and in Gaussian-index order, then one workgroup per tile sorts its list by
+// (depth, index) -- a unique key, so any comparison sort reproduces the reference's stable order bit for bit.
+// One workgroup sorts one tile's (depth bits << 32 | Gaussian index) entries ascending with a bitonic network
+// ("flip" first step, so every compare-exchange is ascending and +inf padding never moves) -- in LDS for lists up to
+// the launch's capacity, in place in global memory (fences between stages) for the rare longer ones -- and writes the
+// reference's sorted key (tile << 32 | depth) and point-list arrays.
+template <typename Mem>
+__device__ __forceinline__ void bitonic_ascending(Mem& m, uint32_t n, uint32_t n_pad, int nt)
+{
+    for (uint32_t k = 2; k <= n_pad; k <<= 1) {
+        for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+            for (uint32_t t = threadIdx.x; t < n_pad / 2; t += nt) {
+                uint32_t lo, hi;
+                if (j == (k >> 1)) {                       // flip: i <-> mirror inside its k-block
+                    const uint32_t blk = t / j, off = t % j;
+                    lo = blk * k + off;
+                    hi = blk * k + (k - 1 - off);
+                } else {
+                    lo = ((t & ~(j - 1)) << 1) | (t & (j - 1));
+                    hi = lo | j;
+                }
+                if (hi < n) {                              // virtual +inf padding: pairs reaching past n never swap
+                    const uint64_t a = m.load(lo), b = m.load(hi);
+                    if (a > b) { m.store(lo, b); m.store(hi, a); }
+                }
+            }
+            m.stage_sync();
+        }
+    }
+}
+
+// LDS bitonic sort of n_pad (power of two, padded with +inf) keys by NT/64 waves with few workgroup barriers: every
+// wave owns a contiguous chunk of C = n_pad / waves keys; all compare-exchange stages at distance < C stay inside one
+// wave's chunk and need no barrier (LDS operations of one wave execute in order), only the distance >= C stages of the
+// merges across chunks are separated by __syncthreads -- 6 barriers instead of 55 for 1024 keys on 4 waves.
+template <int NT>
+__device__ __forceinline__ void bitonic_lds_waves(uint64_t* s, uint32_t n_pad)
+{
+    constexpr uint32_t NW = NT / 64;
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    // chunk per wave; tiny lists are sorted by wave 0 alone
+    const uint32_t C = n_pad >= 128u * NW ? n_pad / NW : n_pad;
+    const bool mine = n_pad >= 128u * NW || wave == 0;
+    uint64_t* c = s + (n_pad >= 128u * NW ? wave * C : 0u);
+    auto local_stage = [&](uint32_t k, uint32_t j, bool flip) {
+        for (uint32_t t = lane; t < C / 2; t += 64) {
+            uint32_t lo, hi;
+            if (flip) {
+                const uint32_t blk = t / j, off = t % j;
+                lo = blk * k + off;
+                hi = blk * k + (k - 1 - off);
+            } else {
+                lo = ((t & ~(j - 1)) << 1) | (t & (j - 1));
+                hi = lo | j;
+            }
+            const uint64_t a = c[lo], b = c[hi];
+            if (a > b) { c[lo] = b; c[hi] = a; }
+        }
+    };
+    if (mine)
+        for (uint32_t k = 2; k <= C; k <<= 1)
+            for (uint32_t j = k >> 1; j > 0; j >>= 1) local_stage(k, j, j == (k >> 1));
+    for (uint32_t k = 2 * C; k <= n_pad; k <<= 1) {
+        for (uint32_t j = k >> 1; j >= C; j >>= 1) {           // cross-chunk stages
+            __syncthreads();
+            for (uint32_t t = threadIdx.x; t < n_pad / 2; t += NT) {
+                uint32_t lo, hi;
+                if (j == (k >> 1)) {
+                    const uint32_t blk = t / j, off = t % j;
+                    lo = blk * k + off;
+                    hi = blk * k + (k - 1 - off);
+                } else {
+                    lo = ((t & ~(j - 1)) << 1) | (t & (j - 1));
+                    hi = lo | j;
+                }
+                const uint64_t a = s[lo], b = s[hi];
+                if (a > b) { s[lo] = b; s[hi] = a; }
+            }
+        }
+        __syncthreads();
+        for (uint32_t j = C >> 1; j > 0; j >>= 1) local_stage(2 * j, j, false);   // plain i <-> i^j inside the chunk
+    }
+    __syncthreads();
+}
+
+struct LdsMem {
+    uint64_t* p;
+    __device__ __forceinline__ uint64_t load(uint32_t i) const { return p[i]; }
+    __device__ __forceinline__ void store(uint32_t i, uint64_t v) const { p[i] = v; }
+    __device__ __forceinline__ void stage_sync() const { __syncthreads(); }
+};
+struct GlobalMem {
+    uint64_t* p;
+    __device__ __forceinline__ uint64_t load(uint32_t i) const { return p[i]; }
+    __device__ __forceinline__ void store(uint32_t i, uint64_t v) const { p[i] = v; }
+    __device__ __forceinline__ void stage_sync() const { __threadfence(); __syncthreads(); }
+};
+
+__device__ __forceinline__ uint32_t next_pow2_u32(uint32_t n)
+{
+    return n <= 1u ? 1u : 1u << (32 - __builtin_clz(n - 1u));
+}
+
+// keys/vals hold the tile's instances (tile << 32 | depth, Gaussian index) in index order (stable partition by tile);
+// they are replaced in place by the same instances in ascending (depth, index) order.
+template <int NT>
+__device__ __forceinline__ void sort_one_tile(uint2 rg, uint64_t* __restrict__ keys, uint32_t* __restrict__ vals,
+                                              uint64_t* __restrict__ scratch, uint64_t* s_buf, uint32_t cap)
+{
+    const uint32_t n = rg.y - rg.x;
+    const uint32_t n_pad = next_pow2_u32(n);
+    const uint64_t tile_hi = keys[rg.x] & 0xffffffff00000000ull;
+    if (n <= cap) {
+        for (uint32_t i = threadIdx.x; i < n_pad; i += NT)
+            s_buf[i] = i < n ? (keys[rg.x + i] << 32) | vals[rg.x + i] : ~0ull;      // real +inf padding in LDS
+        __syncthreads();
+        bitonic_lds_waves<NT>(s_buf, n_pad);
+        for (uint32_t i = threadIdx.x; i < n; i += NT) {
+            const uint64_t e = s_buf[i];
+            keys[rg.x + i] = tile_hi | (e >> 32);
+            vals[rg.x + i] = (uint32_t)e;
+        }
+        __syncthreads();
+    } else {
+        uint64_t* seg = scratch + rg.x;
+        __syncthreads();                              // tile_hi read by every thread before keys are overwritten
+        for (uint32_t i = threadIdx.x; i < n; i += NT) seg[i] = (keys[rg.x + i] << 32) | vals[rg.x + i];
+        GlobalMem m{seg};
+        m.stage_sync();
+        bitonic_ascending(m, n, n_pad, NT);
+        for (uint32_t i = threadIdx.x; i < n; i += NT) {
+            const uint64_t e = seg[i];
+            keys[rg.x + i] = tile_hi | (e >> 32);
+            vals[rg.x + i] = (uint32_t)e;
+        }
+        __syncthreads();
+    }
+}
+
+// small tiles: one 256-thread workgroup per tile (longest first), lists up to `cap` entries in dynamic LDS
+__global__ void __launch_bounds__(256)
+tile_sort_small_kernel(int T, const uint32_t* __restrict__ tile_order, const uint2* __restrict__ ranges, uint32_t cap,
+                       uint64_t* __restrict__ keys, uint32_t* __restrict__ vals, uint64_t* __restrict__ scratch)
+{
+    extern __shared__ __attribute__((aligned(16))) uint64_t s_sort[];
+    const uint32_t tile = tile_order ? tile_order[blockIdx.x] : blockIdx.x;
+    const uint2 rg = ranges[tile];
+    const uint32_t n = rg.y - rg.x;
+    if (n < 2 || n > cap) return;
+    sort_one_tile<256>(rg, keys, vals, scratch, s_sort, cap);
+}
+
+// long tiles: a few persistent 1024-thread workgroups walk the list written by tile_order_kernel
+__global__ void __launch_bounds__(1024)
+tile_sort_big_kernel(const uint32_t* __restrict__ big_list, const uint32_t* __restrict__ big_count,
+                     const uint2* __restrict__ ranges, uint32_t cap, uint64_t* __restrict__ keys,
+                     uint32_t* __restrict__ vals, uint64_t* __restrict__ scratch)
+{
+    extern __shared__ __attribute__((aligned(16))) uint64_t s_sort[];
+    const uint32_t nbig = *big_count;
+    for (uint32_t b = blockIdx.x; b < nbig; b += gridDim.x)
+        sort_one_tile<1024>(ranges[big_list[b]], keys, vals, scratch, s_sort, cap);
+}
+
+constexpr uint32_t TILE_SORT_SMALL_CAP = 4096;     // 32 KB of LDS per workgroup
+constexpr uint32_t TILE_SORT_BIG_CAP = 16384;      // 128 KB
+
+uint32_t tile_sort_small_cap() { return TILE_SORT_SMALL_CAP; }
+
+void launch_tile_sort(hipStream_t s, int T, const uint32_t* tile_order, const uint32_t* ranges, const uint32_t* big_list,
+                      const uint32_t* big_count, uint64_t* keys, uint32_t* vals, uint64_t* scratch)
+{
+    tile_sort_small_kernel<<<T, 256, TILE_SORT_SMALL_CAP * 8, s>>>(T, tile_order, (const uint2*)ranges,
+                                                                   TILE_SORT_SMALL_CAP, keys, vals, scratch);
+    static bool attr_set = false;
+    if (!attr_set) {
+        R3DG_HIP(hipFuncSetAttribute((const void*)tile_sort_big_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                     (int)(TILE_SORT_BIG_CAP * 8)));
+        attr_set = true;
+    }
+    tile_sort_big_kernel<<<64, 1024, TILE_SORT_BIG_CAP * 8, s>>>(big_list, big_count, (const uint2*)ranges,
+                                                                TILE_SORT_BIG_CAP, keys, vals, scratch);
 }
 
 }  // namespace r3dg

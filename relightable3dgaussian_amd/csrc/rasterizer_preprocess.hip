@@ -324,16 +324,23 @@ __global__ void identify_tile_ranges_kernel(int L, const uint64_t* __restrict__ 
 // Longest-tile-first block order for the two tile kernels: one block buckets the T tile lengths into 256 classes
 // (descending) with LDS counters.  Order inside a class is arbitrary -- it only affects scheduling, never results.
 __global__ void __launch_bounds__(1024)
-tile_order_kernel(int T, const uint2* __restrict__ ranges, uint32_t* __restrict__ order)
+tile_order_kernel(int T, const uint2* __restrict__ ranges, uint32_t* __restrict__ order, uint32_t small_cap,
+                  uint32_t* __restrict__ big_list, uint32_t* __restrict__ big_count)
 {
+    __shared__ uint32_t s_nbig;
     __shared__ uint32_t s_cnt[256];
     __shared__ uint32_t s_max;
     const int tid = threadIdx.x;
     if (tid < 256) s_cnt[tid] = 0;
-    if (tid == 0) s_max = 0;
+    if (tid == 0) { s_max = 0; s_nbig = 0; }
     __syncthreads();
     uint32_t m = 0;
-    for (int t = tid; t < T; t += 1024) m = max(m, ranges[t].y - ranges[t].x);
+    for (int t = tid; t < T; t += 1024) {
+        const uint32_t len = ranges[t].y - ranges[t].x;
+        m = max(m, len);
+        // tiles too long for the small in-LDS depth sort (tile-binned ordering, radix_sort.hip)
+        if (big_list != nullptr && len > small_cap) big_list[atomicAdd(&s_nbig, 1u)] = (uint32_t)t;
+    }
     atomicMax(&s_max, m);
     __syncthreads();
     const uint32_t scale = s_max + 1;
@@ -357,12 +364,14 @@ tile_order_kernel(int T, const uint2* __restrict__ ranges, uint32_t* __restrict_
         const uint32_t cls = 255u - (uint32_t)(((uint64_t)len * 256u) / scale);
         order[atomicAdd(&s_cnt[cls], 1u)] = (uint32_t)t;
     }
+    if (tid == 0 && big_count != nullptr) *big_count = s_nbig;
 }
 
 // ---- host launchers -------------------------------------------------------------------------------------
-void launch_tile_order(hipStream_t s, int T, const uint32_t* ranges, uint32_t* order)
+void launch_tile_order(hipStream_t s, int T, const uint32_t* ranges, uint32_t* order, uint32_t small_cap,
+                       uint32_t* big_list, uint32_t* big_count)
 {
-    tile_order_kernel<<<1, 1024, 0, s>>>(T, (const uint2*)ranges, order);
+    tile_order_kernel<<<1, 1024, 0, s>>>(T, (const uint2*)ranges, order, small_cap, big_list, big_count);
 }
 
 void launch_mark_visible(hipStream_t s, int P, const float* means3D, const float* vm, uint8_t* present)

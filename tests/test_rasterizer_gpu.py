@@ -273,6 +273,40 @@ def test_parity_wave_shape_and_cull(fw8, bw8, cull, hip_lib):
         hip_lib.r3dg_set_tuning3(1, 1, 1)
 
 
+@pytest.mark.parametrize("name", ["S16", "big_splats", "ragged_image", "camera_inside", "S0"])
+@pytest.mark.parametrize("binning", [0, 1])
+def test_tile_binned_order_equals_global_sort(name, binning, hip_lib):
+    """Both orderings (global radix sort of (tile|depth) keys / per-tile tickets + per-tile LDS sort) must give the
+    oracle's sorted keys, point list and ranges bit for bit (checked inside _check_forward)."""
+    hip_lib.r3dg_set_tuning4(binning)
+    try:
+        _check_forward(make_case(**CASES[name]), "%s_binning%d" % (name, binning))
+    finally:
+        hip_lib.r3dg_set_tuning4(1)
+
+
+def test_tile_binned_order_long_tiles(hip_lib):
+    """Tiles longer than the small (4096) and the big (16384) in-LDS capacities: few pixels, many large splats."""
+    case = make_case(P=40000, W=64, H=48, S=2, scale_log_mean=-1.2, seed=91)
+    a = _run_forward(case)
+    hip_lib.r3dg_set_tuning4(0)
+    try:
+        b = _run_forward(case)
+    finally:
+        hip_lib.r3dg_set_tuning4(1)
+    torch.cuda.synchronize()
+    from relightable3dgaussian_amd.rasterizer_ops import decode_state
+    P, H, W = case["P"], case["H"], case["W"]
+    assert a[0] == b[0]
+    sa, sb = decode_state(a[10], a[11], a[12], P, a[0], H, W), decode_state(b[10], b[11], b[12], P, b[0], H, W)
+    lens = (sa["ranges"][:, 1] - sa["ranges"][:, 0])
+    assert int(lens.max()) > 16384, "case no longer exercises the global-memory tile sort (max %d)" % int(lens.max())
+    for k in ("keys", "point_list", "ranges"):
+        assert torch.equal(torch.as_tensor(sa[k]), torch.as_tensor(sb[k])), k
+    for i in (1, 2, 3, 4, 5):
+        assert torch.equal(a[i], b[i]), i
+
+
 @pytest.mark.parametrize("name", ["S16", "big_splats", "ragged_image"])
 def test_cull_is_exact(name, hip_lib):
     """The sub-tile cull only drops (wave, Gaussian) pairs whose every pixel fails alpha >= 1/255, so the forward

@@ -18,6 +18,8 @@ L.r3dg_set_tuning(int(e.get("FPPL", 0)), int(e.get("BPPL", 0)), -1)
 L.r3dg_set_tuning2(int(e.get("FU", 0)), int(e.get("BU", 0)), int(e.get("ORDER", -1)))
 if "WAVE8" in os.environ:
     L.r3dg_set_tuning3(int(os.environ["WAVE8"]) & 1, int(os.environ["WAVE8"]) >> 1, -1)
+if "BIN" in os.environ:
+    L.r3dg_set_tuning4(int(os.environ["BIN"]))
 if "CULL" in os.environ:
     L.r3dg_set_tuning3(-1, -1, int(os.environ["CULL"]))
 for it in range(3 + int(os.environ.get("ITERS", 10))):
