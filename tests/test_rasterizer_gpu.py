@@ -307,6 +307,81 @@ def test_tile_binned_order_long_tiles(hip_lib):
         assert torch.equal(a[i], b[i]), i
 
 
+def test_tile_binned_order_many_tiles(hip_lib):
+    """1600x1200 (DTU size, BASELINE config 3): 7500 tiles = 13 tile-id bits, i.e. the two-pass (stable) partition."""
+    case = make_case(P=20000, W=1600, H=1200, S=3, scale_log_mean=-2.6, seed=93)
+    a = _run_forward(case)
+    hip_lib.r3dg_set_tuning4(0)
+    try:
+        b = _run_forward(case)
+    finally:
+        hip_lib.r3dg_set_tuning4(1)
+    torch.cuda.synchronize()
+    from relightable3dgaussian_amd.rasterizer_ops import decode_state
+    P, H, W = case["P"], case["H"], case["W"]
+    assert a[0] == b[0] and a[0] > 0
+    sa, sb = decode_state(a[10], a[11], a[12], P, a[0], H, W), decode_state(b[10], b[11], b[12], P, b[0], H, W)
+    for k in ("keys", "point_list", "ranges"):
+        assert torch.equal(torch.as_tensor(sa[k]), torch.as_tensor(sb[k])), k
+    for i in (1, 2, 3, 4, 5):
+        assert torch.equal(a[i], b[i]), i
+
+
+def test_full_size_properties(hip_lib):
+    """BASELINE size (300k Gaussians, 800x800, S=16): size-independent properties of the forward state and outputs, and
+    linearity of the backward in its upstream gradient."""
+    from relightable3dgaussian_amd import synthetic as syn
+    from relightable3dgaussian_amd.rasterizer_ops import decode_state
+    from r3dg_rasterization import _C
+    P, RES, S = 300_000, 800, 16
+    sc = syn.make_scene(P=P, seed=0, stage2=False)
+    cam = syn.orbit_cameras(100, width=RES, height=RES)[3].to(DEV)
+    d = {k: v.to(DEV) for k, v in sc.items() if torch.is_tensor(v)}
+    g = torch.Generator().manual_seed(1)
+    feat = torch.rand(P, S, generator=g).to(DEV)
+    empty, bg = torch.Tensor([]), torch.ones(3, device=DEV)
+    out = _C.rasterize_gaussians(bg, d["xyz"], feat, empty, d["opacity"], d["scales"], d["rotations"], 1.0, empty,
+                                 cam.world_view_transform, cam.full_proj_transform, cam.tanfovx, cam.tanfovy, cam.cx,
+                                 cam.cy, RES, RES, d["shs"], 3, cam.camera_center, False, True, False)
+    R, n_contrib, color, opacity, depth, feature, normal, sxyz, weights, radii, geom, binning, img = out
+    st = decode_state(geom, binning, img, P, R, RES, RES)
+    keys = st["keys"]
+    assert R == int(st["point_offsets"][-1]) == int(st["tiles_touched"].long().sum())
+    assert bool((keys[1:] >= keys[:-1]).all()), "sorted keys not ascending"
+    tiles = (keys >> 32)
+    rng = st["ranges"].long()
+    lens = rng[:, 1] - rng[:, 0]
+    assert int(lens.sum()) == R
+    counts = torch.bincount(tiles, minlength=rng.shape[0])
+    assert torch.equal(counts, lens), "tile ranges do not match the key histogram"
+    # every instance belongs to a visible Gaussian, each Gaussian appears tiles_touched times
+    inst = torch.bincount(st["point_list"].long(), minlength=P)
+    assert torch.equal(inst, st["tiles_touched"].long())
+    # per pixel: contributors never exceed the tile list; transmittance and opacity are consistent
+    tx = (torch.arange(RES, device=DEV) // 16)
+    tile_of_pix = (tx[:, None] * ((RES + 15) // 16) + tx[None, :])
+    assert bool((n_contrib.long() <= lens[tile_of_pix]).all())
+    T_final = st["final_T"]
+    assert bool(((T_final >= 0) & (T_final <= 1)).all())
+    assert torch.allclose(opacity[0], 1 - T_final, atol=2e-5)
+    assert all(bool(torch.isfinite(t).all()) for t in (color, opacity, depth, feature, normal))
+    # checksum of checksums: sum of per-Gaussian blending weights == sum of the opacity image
+    assert abs(float(weights.double().sum()) - float(opacity.double().sum())) <= 1e-4 * float(opacity.double().sum())
+    # backward is linear in the upstream gradients
+    gC, gO, gD, gF = [torch.randn(c, RES, RES, generator=g).to(DEV) for c in (3, 1, 1, S)]
+
+    def bwd(scale):
+        return _C.rasterize_gaussians_backward(bg, d["xyz"], feat, radii, empty, d["scales"], d["rotations"], 1.0, empty,
+                                               cam.world_view_transform, cam.full_proj_transform, cam.tanfovx,
+                                               cam.tanfovy, scale * gC, scale * gO, scale * gD, scale * gF, d["shs"], 3,
+                                               cam.camera_center, geom, R, binning, img, True, False)
+    g1, g3 = bwd(1.0), bwd(3.0)
+    for a, b in zip(g1, g3):
+        scale = float(b.abs().max())
+        assert float((3.0 * a - b).abs().max()) <= 2e-4 * scale + 1e-12
+        assert bool(torch.isfinite(a).all())
+
+
 @pytest.mark.parametrize("name", ["S16", "big_splats", "ragged_image"])
 def test_cull_is_exact(name, hip_lib):
     """The sub-tile cull only drops (wave, Gaussian) pairs whose every pixel fails alpha >= 1/255, so the forward

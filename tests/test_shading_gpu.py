@@ -68,7 +68,9 @@ def _random_inputs(P, K, He, M=16, seed=0, hdr=False):
 
 @pytest.mark.parametrize("P,K,He,M,transform", [(3000, 64, 16, 16, False), (1500, 32, 16, 16, False),
                                                 (700, 384, 16, 16, False), (2000, 64, 64, 16, True),
-                                                (2000, 24, 8, 4, False), (1, 64, 16, 16, False)])
+                                                (2000, 24, 8, 4, False), (1, 64, 16, 16, False),
+                                                (800, 30, 16, 16, False),     # K % 4 != 0: 4-byte LDS-DMA path
+                                                (600, 100, 16, 9, False)])    # ragged last 64-sample block
 def test_shading_matches_oracle(P, K, He, M, transform):
     from oracle import shading
     from relightable3dgaussian_amd import shading_ops as so
