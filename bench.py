@@ -37,6 +37,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--unfused", action="store_true",
                     help="stage 2 through PyTorch autograd glue + torch.optim.Adam instead of the fused glue kernels")
+    ap.add_argument("--no-other-configs", action="store_true", help="skip the short stage-1 / K=384 side measurements")
     ap.add_argument("--relight-frames", type=int, default=20)
     ap.add_argument("--relight-samples", type=int, default=384)
     return ap.parse_args()

@@ -231,6 +231,42 @@ def relight_bench(params, cams, dev, frames, K):
                 visibility_Mrays_per_s=round(P * K / t_vis / 1e6, 1))
 
 
+def quick_rate(stage, points, res, sample_num, dev, steps=20, warmup=4):
+    """iters/s of another BASELINE configuration on the same synthetic scene (single GPU, short run): stage 1
+    (configs[1]; drop-in ops + PyTorch autograd glue + torch.optim.Adam) or stage 2 at another sample count (configs[2]
+    trains at sample_num=384)."""
+    scene = syn.make_scene(P=points, seed=0, stage2=stage == 2)
+    cams = [c.to(dev) for c in syn.orbit_cameras(100, width=res, height=res)[:4]]
+    bg = torch.ones(3, device=dev)
+    params = GaussianParams(scene, dev, stage == 2)
+    with torch.no_grad():
+        teacher = GaussianParams(syn.make_scene(P=points, seed=0, stage2=False), dev, False)
+        teacher.features_dc.add_(0.05 * torch.randn_like(teacher.features_dc))
+        gts = [render_stage1(teacher, c, bg)[2].clone() for c in cams]
+        del teacher
+    if stage == 2:
+        from . import fused_step
+        step_fn = fused_step.FusedStage2Step(params, sample_num, lr=1e-4)
+
+        def one(i):
+            step_fn(cams[i % 4], bg, gts[i % 4])
+    else:
+        opt = torch.optim.Adam(params.parameters(), lr=1e-4, eps=1e-15, fused=True)
+
+        def one(i):
+            loss_stage1(render_stage1(params, cams[i % 4], bg), gts[i % 4]).backward()
+            opt.step()
+            opt.zero_grad(set_to_none=False)
+    for i in range(warmup):
+        one(i)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        one(warmup + i)
+    torch.cuda.synchronize()
+    return round(steps / (time.perf_counter() - t0), 2)
+
+
 def run(args):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -374,6 +410,19 @@ def run(args):
         }
         if relight is not None:
             result["relight"] = relight
+        if stage2 and world == 1 and not getattr(args, "no_other_configs", False):
+            # the other single-GPU BASELINE configurations on the same scene (short runs; the headline stays `value`)
+            try:
+                del step_fn, params
+                torch.cuda.empty_cache()
+                result["other_configs"] = {
+                    "stage1_train_iters_per_s (configs[1]: drop-in ops + autograd glue + torch Adam)":
+                        quick_rate(1, args.points, args.res, 0, dev),
+                    "stage2_train_iters_per_s_sample_num_384 (configs[2])":
+                        quick_rate(2, args.points, args.res, 384, dev),
+                }
+            except Exception as e:
+                result["other_configs"] = {"failed": repr(e)}
         if not args.no_cpu_baseline and world == 1:
             try:
                 result["cpu_baseline"] = cpu_baseline(scene, cams_cpu, S, args.cpu_baseline_seconds)

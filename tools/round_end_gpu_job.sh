@@ -3,11 +3,11 @@ cd /root/repo
 timeout 900 python -m pytest tests -m gpu -q -p no:cacheprovider < /dev/null > gpurun_out/pytest_gpu.log 2>&1; tail -3 gpurun_out/pytest_gpu.log
 export TMPDIR=/tmp
 cd /tmp
-CMD="python /root/repo/bench.py --steps 20 --warmup 5 --no-cpu-baseline --relight-frames 0"
+CMD="python /root/repo/bench.py --steps 20 --warmup 5 --no-cpu-baseline --relight-frames 0 --no-other-configs"
 timeout 300 rocprofv3 --kernel-trace --stats -d /tmp/prof -o bench -- $CMD < /dev/null > /root/repo/gpurun_out/prof_bench.log 2>&1
 f=$(find /tmp/prof -name "*.db" | head -1)
 cd /root/repo
-python tools/rocpd_summary.py "$f" gpurun_out/stage2_fused_stats.md "rocprofv3 --kernel-trace --stats -- python bench.py --steps 20 --warmup 5 --no-cpu-baseline --relight-frames 0" < /dev/null
+python tools/rocpd_summary.py "$f" gpurun_out/stage2_fused_stats.md "rocprofv3 --kernel-trace --stats -- python bench.py --steps 20 --warmup 5 --no-cpu-baseline --relight-frames 0 --no-other-configs" < /dev/null
 python tools/rocpd_timeline.py "$f" 15 < /dev/null > gpurun_out/timeline.txt 2>&1
 cd /tmp
 dbs=""
