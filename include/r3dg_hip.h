@@ -74,6 +74,25 @@ int r3dg_rasterize_forward(void* stream, r3dg_alloc_fn geometry_alloc, r3dg_allo
                            float* d_out_surface_xyz, float* d_out_weights, int32_t* d_radii, int debug,
                            int* num_rendered_out);
 
+/* The forward in two halves.  _begin takes the arguments of r3dg_rasterize_forward, runs the projection and starts the
+ * asynchronous read-back of num_rendered (an event is recorded on `stream`); _finish waits for that event only, sizes the
+ * binning state, orders the instances and renders.  Kernels the caller enqueues on `stream` between the two calls run
+ * while the host waits for the count -- `d_features` (and every other pointer) is only dereferenced by the device, so the
+ * feature rows may be produced in between.  *ticket is NULL when P == 0; _finish(NULL) is a no-op.  Every ticket must be
+ * finished exactly once.  r3dg_rasterize_forward == _begin immediately followed by _finish. */
+int r3dg_rasterize_forward_begin(void* stream, r3dg_alloc_fn geometry_alloc, r3dg_alloc_fn binning_alloc,
+                                 r3dg_alloc_fn image_alloc, void* alloc_user, int P, int S, int D, int M,
+                                 const float* d_background, int width, int height, const float* d_means3D,
+                                 const float* d_shs, const float* d_colors_precomp, const float* d_features,
+                                 const float* d_opacities, const float* d_scales, float scale_modifier,
+                                 const float* d_rotations, const float* d_cov3D_precomp, const float* d_viewmatrix,
+                                 const float* d_projmatrix, const float* d_cam_pos, float tan_fovx, float tan_fovy,
+                                 float cx, float cy, int prefiltered, int compute_pseudo_normal, float* d_out_color,
+                                 float* d_out_opacity, float* d_out_depth, float* d_out_feature, float* d_out_normal,
+                                 float* d_out_surface_xyz, float* d_out_weights, int32_t* d_radii, int debug,
+                                 void** ticket);
+int r3dg_rasterize_forward_finish(void* ticket, int* num_rendered_out);
+
 /* Backward.  d_dL_dmean2D [P,3] (z = depth side channel), d_dL_dconic [P,4] (x,y,-,w), d_dL_dopacity, d_dL_dcolor and
  * d_dL_dfeature are accumulated with atomics and must be zero-filled by the caller; d_dL_dmean3D, d_dL_dcov3D and --
  * when SHs / scales+rotations are the active inputs -- d_dL_dsh, d_dL_dscale, d_dL_drot are fully written (zeros for
@@ -274,6 +293,7 @@ int r3dg_selftest_transpose_reduce(void* stream, int N, int dpp, const float* d_
 /* Per-stage kernel timing with HIP events recorded on the launch stream (used by bench.py for the roofline
  * numbers).  Stages: see r3dg_profile_stage_name(0..r3dg_profile_num_stages()-1). */
 int r3dg_profile_enable(int on);
+int r3dg_profile_pause(int paused);   /* suspend (1) / resume (0) recording without clearing */
 int r3dg_profile_num_stages(void);
 const char* r3dg_profile_stage_name(int stage);
 int r3dg_profile_read(double* ms_out, int* count_out);

@@ -28,6 +28,10 @@ _SIGNATURES = {
     "r3dg_rasterize_forward": (_i, [_p, ALLOC_FN, ALLOC_FN, ALLOC_FN, _p, _i, _i, _i, _i, _p, _i, _i, _p, _p, _p, _p,
                                     _p, _p, _f, _p, _p, _p, _p, _p, _f, _f, _f, _f, _i, _i, _p, _p, _p, _p, _p, _p,
                                     _p, _p, _i, C.POINTER(_i)]),
+    "r3dg_rasterize_forward_begin": (_i, [_p, ALLOC_FN, ALLOC_FN, ALLOC_FN, _p, _i, _i, _i, _i, _p, _i, _i, _p, _p, _p, _p,
+                                    _p, _p, _f, _p, _p, _p, _p, _p, _f, _f, _f, _f, _i, _i, _p, _p, _p, _p, _p, _p,
+                                    _p, _p, _i, C.POINTER(_p)]),
+    "r3dg_rasterize_forward_finish": (_i, [_p, C.POINTER(_i)]),
     "r3dg_rasterize_backward": (_i, [_p, _i, _i, _i, _i, _i, _p, _i, _i, _p, _p, _p, _p, _p, _f, _p, _p, _p, _p, _p,
                                      _f, _f, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p,
                                      _i, _i]),
@@ -61,6 +65,7 @@ _SIGNATURES = {
     "r3dg_bvh_build": (_i, [_p, _i, _p, _p, _p, _p]),
     "r3dg_bvh_trace_opacity": (_i, [_p, C.c_int64, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p]),
     "r3dg_profile_enable": (_i, [_i]),
+    "r3dg_profile_pause": (_i, [_i]),
     "r3dg_profile_num_stages": (_i, []),
     "r3dg_profile_stage_name": (C.c_char_p, [_i]),
     "r3dg_profile_read": (_i, [C.POINTER(C.c_double), C.POINTER(_i)]),

@@ -300,6 +300,14 @@ int r3dg_profile_enable(int on)
     g_profiling = on;
     return R3DG_OK;
 }
+// suspend / resume the recording without discarding what was recorded (sampled profiling: the event pairs cost ~2 us of
+// host time each, so a caller may time every n-th iteration only)
+int r3dg_profile_pause(int paused)
+{
+    std::lock_guard<std::mutex> lk(g_prof_mutex);
+    g_profiling = paused ? 0 : 1;
+    return R3DG_OK;
+}
 int r3dg_profile_num_stages(void) { return ST_COUNT; }
 const char* r3dg_profile_stage_name(int stage) { return (stage >= 0 && stage < ST_COUNT) ? kStageNames[stage] : ""; }
 int r3dg_profile_read(double* ms_out, int* count_out)
@@ -350,7 +358,50 @@ int r3dg_binning_state_offsets(int64_t R, size_t* o)
     return R3DG_OK;
 }
 
-int r3dg_rasterize_forward(void* stream_, r3dg_alloc_fn geometry_alloc, r3dg_alloc_fn binning_alloc,
+// ---- forward, in two halves -----------------------------------------------------------------------------------------
+// begin : validation, state allocation, preprocess (K2/K3), asynchronous read-back of num_rendered (event recorded)
+// finish: waits for THAT event only (not for the stream), sizes the binning state, orders the instances, renders.
+// Work the caller enqueues on the stream between the two halves (e.g. the shading kernels that produce the feature
+// rows) keeps the GPU busy while the host waits for the count and enqueues the second half.
+struct ForwardTicket {
+    hipStream_t stream;
+    r3dg_alloc_fn binning_alloc;
+    void* user;
+    int P, S, D, M, width, height, compute_pseudo_normal, debug;
+    const float *background, *means3D, *features, *colors_precomp, *viewmatrix;
+    float tan_fovx, tan_fovy, cx, cy, focal_x, focal_y;
+    float *out_color, *out_opacity, *out_depth, *out_feature, *out_normal, *out_surface_xyz, *out_weights;
+    int32_t* radii_p;
+    char *gbuf, *ibuf;
+    hipEvent_t ready;
+    unsigned long long* host_total;      // pinned
+};
+
+static std::mutex g_ticket_mutex;
+static std::vector<ForwardTicket*> g_ticket_pool;
+
+static ForwardTicket* ticket_acquire()
+{
+    {
+        std::lock_guard<std::mutex> lk(g_ticket_mutex);
+        if (!g_ticket_pool.empty()) {
+            ForwardTicket* t = g_ticket_pool.back();
+            g_ticket_pool.pop_back();
+            return t;
+        }
+    }
+    ForwardTicket* t = new ForwardTicket();
+    R3DG_HIP(hipEventCreateWithFlags(&t->ready, hipEventDisableTiming));
+    R3DG_HIP(hipHostMalloc((void**)&t->host_total, sizeof(unsigned long long), hipHostMallocDefault));
+    return t;
+}
+static void ticket_release(ForwardTicket* t)
+{
+    std::lock_guard<std::mutex> lk(g_ticket_mutex);
+    g_ticket_pool.push_back(t);
+}
+
+int r3dg_rasterize_forward_begin(void* stream_, r3dg_alloc_fn geometry_alloc, r3dg_alloc_fn binning_alloc,
                            r3dg_alloc_fn image_alloc, void* user, int P, int S, int D, int M,
                            const float* background, int width, int height, const float* means3D, const float* shs,
                            const float* colors_precomp, const float* features, const float* opacities,
@@ -359,10 +410,11 @@ int r3dg_rasterize_forward(void* stream_, r3dg_alloc_fn geometry_alloc, r3dg_all
                            const float* cam_pos, float tan_fovx, float tan_fovy, float cx, float cy, int prefiltered,
                            int compute_pseudo_normal, float* out_color, float* out_opacity, float* out_depth,
                            float* out_feature, float* out_normal, float* out_surface_xyz, float* out_weights,
-                           int32_t* radii, int debug_, int* num_rendered_out)
+                           int32_t* radii, int debug_, void** ticket_out)
 {
     (void)prefiltered;
-    if (num_rendered_out) *num_rendered_out = 0;
+    if (!ticket_out) return invalid("rasterize_forward_begin: null ticket pointer");
+    *ticket_out = nullptr;
     if (P < 0 || width <= 0 || height <= 0) return invalid("rasterize_forward: bad P/width/height");
     if (S < 0 || S > R3DG_MAX_S_FWD) return invalid("rasterize_forward: feature channels S must be in [0,36]");
     if (!geometry_alloc || !binning_alloc || !image_alloc) return invalid("rasterize_forward: null resize callback");
@@ -372,7 +424,7 @@ int r3dg_rasterize_forward(void* stream_, r3dg_alloc_fn geometry_alloc, r3dg_all
         return invalid("rasterize_forward: SH degree/coefficients mismatch");
     if (cov3D_precomp == nullptr && (scales == nullptr || rotations == nullptr))
         return invalid("rasterize_forward: provide scales+rotations or a precomputed 3D covariance");
-    if (P == 0) return R3DG_OK;
+    if (P == 0) return R3DG_OK;                  // no ticket: nothing was launched (finish accepts NULL)
 
     return guarded([&]() -> int {
         hipStream_t stream = (hipStream_t)stream_;
@@ -405,10 +457,60 @@ int r3dg_rasterize_forward(void* stream_, r3dg_alloc_fn geometry_alloc, r3dg_all
         check_launch(stream, debug, "preprocess");
         t_pre.stop();
 
-        // the one device->host sync of the forward (reference rasterizer_impl.cu:291)
-        unsigned long long total = 0;
-        R3DG_HIP(hipMemcpyAsync(&total, g_total, sizeof(total), hipMemcpyDeviceToHost, stream));
-        R3DG_HIP(hipStreamSynchronize(stream));
+        ForwardTicket* t = ticket_acquire();
+        t->stream = stream; t->binning_alloc = binning_alloc; t->user = user;
+        t->P = P; t->S = S; t->D = D; t->M = M; t->width = width; t->height = height;
+        t->compute_pseudo_normal = compute_pseudo_normal; t->debug = debug_;
+        t->background = background; t->means3D = means3D; t->features = features; t->colors_precomp = colors_precomp;
+        t->viewmatrix = viewmatrix;
+        t->tan_fovx = tan_fovx; t->tan_fovy = tan_fovy; t->cx = cx; t->cy = cy; t->focal_x = focal_x; t->focal_y = focal_y;
+        t->out_color = out_color; t->out_opacity = out_opacity; t->out_depth = out_depth; t->out_feature = out_feature;
+        t->out_normal = out_normal; t->out_surface_xyz = out_surface_xyz; t->out_weights = out_weights;
+        t->radii_p = radii_p; t->gbuf = gbuf; t->ibuf = ibuf;
+        // the one device->host read-back of the forward (reference rasterizer_impl.cu:291), asynchronous here
+        R3DG_HIP(hipMemcpyAsync(t->host_total, g_total, sizeof(unsigned long long), hipMemcpyDeviceToHost, stream));
+        R3DG_HIP(hipEventRecord(t->ready, stream));
+        *ticket_out = t;
+        return R3DG_OK;
+    });
+}
+
+int r3dg_rasterize_forward_finish(void* ticket_, int* num_rendered_out)
+{
+    if (num_rendered_out) *num_rendered_out = 0;
+    if (!ticket_) return R3DG_OK;                // P == 0
+    ForwardTicket* t = (ForwardTicket*)ticket_;
+    const int st = guarded([&]() -> int {
+        hipStream_t stream = t->stream;
+        const bool debug = t->debug != 0;
+        const int P = t->P, S = t->S, width = t->width, height = t->height;
+        const int gx = (width + R3DG_TILE_X - 1) / R3DG_TILE_X, gy = (height + R3DG_TILE_Y - 1) / R3DG_TILE_Y;
+        const size_t T = (size_t)gx * gy, N = (size_t)width * height;
+        GeometryLayout G = GeometryLayout::make((size_t)P);
+        ImageLayout I = ImageLayout::make(N, T);
+        char* gbuf = t->gbuf;
+        char* ibuf = t->ibuf;
+        int* radii_p = t->radii_p;
+        float* g_depths = (float*)(gbuf + G.depths);
+        float* g_means2D = (float*)(gbuf + G.means2D);
+        float* g_conic = (float*)(gbuf + G.conic_opacity);
+        float* g_rgb = (float*)(gbuf + G.rgb);
+        uint32_t* g_tiles = (uint32_t*)(gbuf + G.tiles_touched);
+        uint32_t* g_block = (uint32_t*)(gbuf + G.block_sums);
+        r3dg_alloc_fn binning_alloc = t->binning_alloc;
+        void* user = t->user;
+        const float* colors_precomp = t->colors_precomp;
+        const float* features = t->features;
+        const float* background = t->background;
+        const float* viewmatrix = t->viewmatrix;
+        const float focal_x = t->focal_x, focal_y = t->focal_y, cx = t->cx, cy = t->cy;
+        float *out_color = t->out_color, *out_opacity = t->out_opacity, *out_depth = t->out_depth,
+              *out_feature = t->out_feature, *out_normal = t->out_normal, *out_surface_xyz = t->out_surface_xyz,
+              *out_weights = t->out_weights;
+        const int compute_pseudo_normal = t->compute_pseudo_normal;
+
+        R3DG_HIP(hipEventSynchronize(t->ready));
+        const unsigned long long total = *t->host_total;
         if (total > 0x7fffffffull) { set_error("rasterize_forward: num_rendered exceeds 2^31-1"); return R3DG_EINVAL; }
         const int R = (int)total;
 
@@ -484,6 +586,31 @@ int r3dg_rasterize_forward(void* stream_, r3dg_alloc_fn geometry_alloc, r3dg_all
         if (num_rendered_out) *num_rendered_out = R;
         return R3DG_OK;
     });
+    ticket_release(t);
+    return st;
+}
+
+int r3dg_rasterize_forward(void* stream_, r3dg_alloc_fn geometry_alloc, r3dg_alloc_fn binning_alloc,
+                           r3dg_alloc_fn image_alloc, void* user, int P, int S, int D, int M,
+                           const float* background, int width, int height, const float* means3D, const float* shs,
+                           const float* colors_precomp, const float* features, const float* opacities,
+                           const float* scales, float scale_modifier, const float* rotations,
+                           const float* cov3D_precomp, const float* viewmatrix, const float* projmatrix,
+                           const float* cam_pos, float tan_fovx, float tan_fovy, float cx, float cy, int prefiltered,
+                           int compute_pseudo_normal, float* out_color, float* out_opacity, float* out_depth,
+                           float* out_feature, float* out_normal, float* out_surface_xyz, float* out_weights,
+                           int32_t* radii, int debug_, int* num_rendered_out)
+{
+    if (num_rendered_out) *num_rendered_out = 0;
+    void* ticket = nullptr;
+    const int st = r3dg_rasterize_forward_begin(stream_, geometry_alloc, binning_alloc, image_alloc, user, P, S, D, M,
+                                                background, width, height, means3D, shs, colors_precomp, features,
+                                                opacities, scales, scale_modifier, rotations, cov3D_precomp, viewmatrix,
+                                                projmatrix, cam_pos, tan_fovx, tan_fovy, cx, cy, prefiltered,
+                                                compute_pseudo_normal, out_color, out_opacity, out_depth, out_feature,
+                                                out_normal, out_surface_xyz, out_weights, radii, debug_, &ticket);
+    if (st != R3DG_OK) return st;
+    return r3dg_rasterize_forward_finish(ticket, num_rendered_out);
 }
 
 // (defined below)

@@ -182,6 +182,12 @@ class FusedStage2Step:
         empty = torch.Tensor([])
         with torch.cuda.device(dev):
             self.refresh_activations(cam)
+            # first half of the rasterizer (projection + async read-back of num_rendered): the shading kernels below run
+            # while the host waits for the count and enqueues the second half
+            pending = rasterizer_ops.rasterize_gaussians_begin(
+                bg, self.xyz, self.features, empty, self.a_opacity, self.a_scales, self.a_rot, 1.0, empty, vm,
+                cam.full_proj_transform, cam.tanfovx, cam.tanfovy, cam.cx, cam.cy, H, W, self.shs, 3, campos, False,
+                True, False)
             env_c = F.softplus(self.env)[0]                                      # DirectLightMap.get_env
             He, We = env_c.shape[0], env_c.shape[1]
             _lib.check(L.r3dg_shade_forward(
@@ -194,10 +200,7 @@ class FusedStage2Step:
                 stream(), P, self.xyz.data_ptr(), vm.data_ptr(), self.a_normal.data_ptr(), self.a_base.data_ptr(),
                 self.a_rough.data_ptr(), self.shade_out.data_ptr(), self.features.data_ptr(),
                 self.sums[3:].data_ptr()), "stage2_pack_features")
-            fw = rasterizer_ops.rasterize_gaussians(
-                bg, self.xyz, self.features, empty, self.a_opacity, self.a_scales, self.a_rot, 1.0, empty, vm,
-                cam.full_proj_transform, cam.tanfovx, cam.tanfovy, cam.cx, cam.cy, H, W, self.shs, 3, campos, False,
-                True, False)
+            fw = pending.finish()
             R, n_contrib, image, opacity, depth, feature, pseudo_normal, sxyz, weights, radii, geom, binning, img = fw
             # image-space loss terms and their gradients (one slab: dL_dimage 3 | dL_dopacity 1 | dL_dfeature 16; the depth image carries no loss)
             g = torch.empty((20, H, W), dtype=torch.float32, device=dev)

@@ -50,9 +50,37 @@ def _offsets(fn, n, *args):
     return list(arr)
 
 
-def rasterize_gaussians(background, means3D, features, colors, opacity, scales, rotations, scale_modifier,
-                        cov3D_precomp, viewmatrix, projmatrix, tan_fovx, tan_fovy, cx, cy, image_height, image_width,
-                        sh, degree, campos, prefiltered, computer_pseudo_normal, debug):
+class _PendingForward:
+    """Second half of a split forward (see rasterize_gaussians_begin): call .finish() exactly once."""
+
+    def __init__(self, ticket, rs, outs, dev, H, W):
+        self.ticket, self.rs, self.outs, self.dev, self.H, self.W = ticket, rs, outs, dev, H, W
+
+    def finish(self):
+        L = _lib.lib()
+        rendered = C.c_int(0)
+        with torch.cuda.device(self.dev):
+            st = L.r3dg_rasterize_forward_finish(self.ticket, C.byref(rendered))
+        self.ticket = None
+        _lib.check(st, "rasterize_gaussians")
+        out_color, out_opacity, out_depth, out_feature, out_normal, out_surface_xyz, out_weights, radii = self.outs
+        geomBuffer, binningBuffer, imgBuffer = self.rs.buffers
+        H, W = self.H, self.W
+        if imgBuffer.numel() == 0:
+            imgBuffer = torch.zeros(int(L.r3dg_image_state_bytes(W, H)), dtype=torch.uint8, device=self.dev)
+        # n_contrib: int32 view into the image state (the reference returns a from_blob view, rasterize_points.cu:136-139)
+        off = _offsets(L.r3dg_image_state_offsets, 3, W, H)
+        n_contrib = imgBuffer[off[1]:off[1] + 4 * H * W].view(torch.int32).view(H, W)
+        return (rendered.value, n_contrib, out_color, out_opacity, out_depth, out_feature, out_normal, out_surface_xyz,
+                out_weights, radii, geomBuffer, binningBuffer, imgBuffer)
+
+
+def rasterize_gaussians_begin(background, means3D, features, colors, opacity, scales, rotations, scale_modifier,
+                              cov3D_precomp, viewmatrix, projmatrix, tan_fovx, tan_fovy, cx, cy, image_height,
+                              image_width, sh, degree, campos, prefiltered, computer_pseudo_normal, debug):
+    """First half of rasterize_gaussians (same arguments): projection + asynchronous read-back of num_rendered.  Returns
+    an object whose .finish() completes the call and returns the 13-tuple.  Kernels launched on the current stream in
+    between (e.g. the ones that fill `features`, whose CONTENTS are first read by .finish()'s kernels) overlap the wait."""
     L = _lib.lib()
     if means3D.ndimension() != 2 or means3D.size(1) != 3:
         raise RuntimeError("means3D must have dimensions (num_points, 3)")
@@ -76,30 +104,36 @@ def rasterize_gaussians(background, means3D, features, colors, opacity, scales, 
     radii = torch.empty((P,), dtype=torch.int32, device=dev)
 
     rs = _Resizer(dev)
-    rendered = C.c_int(0)
+    ticket = C.c_void_p(None)
     if P != 0:
         M = sh.size(1) if sh.size(0) != 0 else 0
         t = [_f32c(x) for x in (background, means3D, sh, colors, features, opacity, scales, rotations, cov3D_precomp,
                                 viewmatrix, projmatrix, campos)]
         bg_, means_, sh_, col_, feat_, op_, sc_, rot_, cov_, vm_, pm_, cam_ = t
+        if feat_ is not None and feat_.data_ptr() != features.data_ptr():
+            raise RuntimeError("rasterize_gaussians_begin needs contiguous features (their contents are read later)")
+        rs.keep = t                                   # inputs stay alive until finish()
         with torch.cuda.device(dev):
-            st = L.r3dg_rasterize_forward(
+            st = L.r3dg_rasterize_forward_begin(
                 _lib.current_stream(), rs.callbacks[0], rs.callbacks[1], rs.callbacks[2], None, P, S, int(degree), M,
                 _lib.ptr(bg_), W, H, _lib.ptr(means_), _lib.ptr(sh_), _lib.ptr(col_), _lib.ptr(feat_), _lib.ptr(op_),
                 _lib.ptr(sc_), float(scale_modifier), _lib.ptr(rot_), _lib.ptr(cov_), _lib.ptr(vm_), _lib.ptr(pm_),
                 _lib.ptr(cam_), float(tan_fovx), float(tan_fovy), float(cx), float(cy), int(bool(prefiltered)),
                 int(bool(computer_pseudo_normal)), out_color.data_ptr(), out_opacity.data_ptr(), out_depth.data_ptr(),
                 _lib.ptr(out_feature), out_normal.data_ptr(), out_surface_xyz.data_ptr(), out_weights.data_ptr(),
-                radii.data_ptr(), int(bool(debug)), C.byref(rendered))
+                radii.data_ptr(), int(bool(debug)), C.byref(ticket))
         _lib.check(st, "rasterize_gaussians")
-    geomBuffer, binningBuffer, imgBuffer = rs.buffers
-    if imgBuffer.numel() == 0:
-        imgBuffer = torch.zeros(int(L.r3dg_image_state_bytes(W, H)), dtype=torch.uint8, device=dev)
-    # n_contrib: int32 view into the image state (the reference returns a from_blob view, rasterize_points.cu:136-139)
-    off = _offsets(L.r3dg_image_state_offsets, 3, W, H)
-    n_contrib = imgBuffer[off[1]:off[1] + 4 * H * W].view(torch.int32).view(H, W)
-    return (rendered.value, n_contrib, out_color, out_opacity, out_depth, out_feature, out_normal, out_surface_xyz,
-            out_weights, radii, geomBuffer, binningBuffer, imgBuffer)
+    return _PendingForward(ticket, rs, (out_color, out_opacity, out_depth, out_feature, out_normal, out_surface_xyz,
+                                        out_weights, radii), dev, H, W)
+
+
+def rasterize_gaussians(background, means3D, features, colors, opacity, scales, rotations, scale_modifier,
+                        cov3D_precomp, viewmatrix, projmatrix, tan_fovx, tan_fovy, cx, cy, image_height, image_width,
+                        sh, degree, campos, prefiltered, computer_pseudo_normal, debug):
+    return rasterize_gaussians_begin(background, means3D, features, colors, opacity, scales, rotations, scale_modifier,
+                                     cov3D_precomp, viewmatrix, projmatrix, tan_fovx, tan_fovy, cx, cy, image_height,
+                                     image_width, sh, degree, campos, prefiltered, computer_pseudo_normal,
+                                     debug).finish()
 
 
 def rasterize_gaussians_backward(background, means3D, features, radii, colors, scales, rotations, scale_modifier,
