@@ -230,7 +230,8 @@ int r3dg_stage2_env_backward(void* stream, int He, int We, const float* d_raw, c
 /* Adam over up to R3DG_ADAM_MAX_GROUPS parameter groups in ONE launch (torch.optim.Adam semantics, no weight decay /
  * amsgrad; GaussianModel.training_setup + step, scene/gaussian_model.py:465-497).  Elements whose index modulo `period`
  * is >= `split` use lr_tail (period 0: one rate) -- e.g. a [P,16,3] SH tensor with period 48, split 3 carries the
- * features_dc / features_rest rates.  `step` is the 1-based step count for the bias corrections. */
+ * features_dc / features_rest rates.  `step` is the 1-based step count for the bias corrections; every gradient is
+ * multiplied by `grad_scale` first (1/world_size after a sum all-reduce, 1 otherwise). */
 #define R3DG_ADAM_MAX_GROUPS 16
 typedef struct r3dg_adam_group {
     float* param;
@@ -242,7 +243,7 @@ typedef struct r3dg_adam_group {
     uint32_t period, split;
 } r3dg_adam_group;
 int r3dg_adam_step(void* stream, int n_groups, const r3dg_adam_group* groups, float beta1, float beta2, float eps,
-                   int step);
+                   int step, float grad_scale);
 
 /* distCUDA2 (submodules/simple-knn/spatial.cu:14-26 -> SimpleKNN::knn, simple_knn.cu:185-221): d_mean_dist2[i] = mean of
  * the squared distances from point i to its 3 nearest neighbours (FLT_MAX terms when P < 4, like the reference). */

@@ -354,6 +354,8 @@ def run(args):
     for i in range(args.steps):
         L.r3dg_profile_pause(0 if (i % 4 == 0 and not os.environ.get("R3DG_BENCH_NOPROFILE")) else 1)
         one_step(args.warmup + i)
+    if fused:
+        step_fn.flush()                  # (world > 1) the last iteration's deferred incident-light update
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()

@@ -91,7 +91,7 @@ void launch_s2_loss(hipStream_t s, int HW, const float* image, const float* opac
                     const float* pseudo_normal, const int* n_contrib, const float* gt, const float* bg, float w_l1,
                     float w_pbr, float w_normal, float* dL_dimage, float* dL_dopacity, float* dL_dfeature, float* sums);
 void launch_adam(hipStream_t s, int n_groups, const r3dg_adam_group* groups, float beta1, float beta2, float eps,
-                 int step);
+                 int step, float grad_scale);
 void launch_s2_env_backward(hipStream_t s, int He, int We, const float* raw, const float* env, const float* dL_denv,
                             float w_tv, float* g_raw, float* tv_sum);
 uint32_t tile_sort_small_cap();
@@ -930,7 +930,7 @@ int r3dg_stage2_env_backward(void* stream_, int He, int We, const float* raw, co
 }
 
 int r3dg_adam_step(void* stream_, int n_groups, const r3dg_adam_group* groups, float beta1, float beta2, float eps,
-                   int step)
+                   int step, float grad_scale)
 {
     if (n_groups < 0 || n_groups > R3DG_ADAM_MAX_GROUPS) return invalid("adam_step: bad group count");
     if (step < 1) return invalid("adam_step: step counts from 1");
@@ -943,7 +943,7 @@ int r3dg_adam_step(void* stream_, int n_groups, const r3dg_adam_group* groups, f
     }
     return guarded([&]() -> int {
         StageTimer t((hipStream_t)stream_, ST_ADAM);
-        launch_adam((hipStream_t)stream_, n_groups, groups, beta1, beta2, eps, step);
+        launch_adam((hipStream_t)stream_, n_groups, groups, beta1, beta2, eps, step, grad_scale);
         return R3DG_OK;
     });
 }

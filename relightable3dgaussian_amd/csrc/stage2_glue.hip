@@ -321,7 +321,7 @@ struct AdamTable {
 };
 
 __global__ void __launch_bounds__(256)
-adam_kernel(AdamTable t, float beta1, float beta2, float eps, float bias1, float inv_sqrt_bias2)
+adam_kernel(AdamTable t, float beta1, float beta2, float eps, float bias1, float inv_sqrt_bias2, float grad_scale)
 {
     int gi = 0;
 #pragma unroll 1
@@ -350,6 +350,7 @@ adam_kernel(AdamTable t, float beta1, float beta2, float eps, float bias1, float
         // (one [P,16,3] SH tensor = dc columns + rest columns with different rates, gaussian_model.py:470-471)
         float lr = grp.lr;
         if (grp.period != 0 && ((unsigned int)(base + k) % grp.period) >= grp.split) lr = grp.lr_tail;   // n < 2^32
+        gv[k] *= grad_scale;                  // e.g. 1 / world_size after a sum all-reduce
         mv[k] = mv[k] + (gv[k] - mv[k]) * (1.f - beta1);
         vv[k] = beta2 * vv[k] + (1.f - beta2) * gv[k] * gv[k];
         const float denom = sqrtf(vv[k]) * inv_sqrt_bias2 + eps;
@@ -426,7 +427,7 @@ void launch_s2_env_backward(hipStream_t s, int He, int We, const float* raw, con
 }
 
 void launch_adam(hipStream_t s, int n_groups, const r3dg_adam_group* groups, float beta1, float beta2, float eps,
-                 int step)
+                 int step, float grad_scale)
 {
     AdamTable t;
     t.n_groups = n_groups;
@@ -439,7 +440,7 @@ void launch_adam(hipStream_t s, int n_groups, const r3dg_adam_group* groups, flo
     t.first_block[n_groups] = blocks;
     if (blocks == 0) return;
     const double b1 = 1.0 - pow((double)beta1, (double)step), b2 = 1.0 - pow((double)beta2, (double)step);
-    adam_kernel<<<blocks, 256, 0, s>>>(t, beta1, beta2, eps, (float)b1, (float)(1.0 / sqrt(b2)));
+    adam_kernel<<<blocks, 256, 0, s>>>(t, beta1, beta2, eps, (float)b1, (float)(1.0 / sqrt(b2)), grad_scale);
     check_launch(s, false, "adam_kernel");
 }
 

@@ -51,21 +51,31 @@ class FusedAdam:
             g["exp_avg"] = torch.zeros_like(p)
             g["exp_avg_sq"] = torch.zeros_like(p)
 
-    def step(self, grads):
-        """grads: list of gradient tensors, one per group (same order)."""
-        L = _lib.lib()
+    def step(self, grads, grad_scale=1.0):
+        """grads: list of gradient tensors, one per group (same order).  One launch for all groups."""
+        self.begin_step()
+        self.step_groups(range(len(self.groups)), grads, grad_scale)
+
+    def begin_step(self):
         self.step_count += 1
-        table = (AdamGroup * len(self.groups))()
-        for i, (g, gr) in enumerate(zip(self.groups, grads)):
+
+    def step_groups(self, indices, grads, grad_scale=1.0):
+        """Adam update of a subset of the groups for the current step (begin_step() first); `grads[i]` belongs to group i.
+        Lets a data-parallel caller update each gradient bucket as soon as its all-reduce has landed."""
+        L = _lib.lib()
+        indices = list(indices)
+        table = (AdamGroup * len(indices))()
+        for j, i in enumerate(indices):
+            g, gr = self.groups[i], grads[i]
             p = g["param"]
             if gr.shape != p.shape or not gr.is_contiguous() or gr.dtype != torch.float32:
                 raise RuntimeError("FusedAdam: gradient %d does not match its parameter" % i)
-            table[i] = AdamGroup(p.data_ptr(), gr.data_ptr(), g["exp_avg"].data_ptr(), g["exp_avg_sq"].data_ptr(),
+            table[j] = AdamGroup(p.data_ptr(), gr.data_ptr(), g["exp_avg"].data_ptr(), g["exp_avg_sq"].data_ptr(),
                                  p.numel(), g["lr"], g.get("lr_tail") if g.get("lr_tail") is not None else g["lr"],
                                  g.get("period", 0), g.get("split", 0))
         with torch.cuda.device(self.groups[0]["param"].device):
-            st = L.r3dg_adam_step(_lib.current_stream(), len(self.groups), C.cast(table, C.c_void_p), self.betas[0],
-                                  self.betas[1], self.eps, self.step_count)
+            st = L.r3dg_adam_step(_lib.current_stream(), len(indices), C.cast(table, C.c_void_p), self.betas[0],
+                                  self.betas[1], self.eps, self.step_count, float(grad_scale))
         _lib.check(st, "adam_step")
 
 
@@ -110,8 +120,15 @@ class FusedStage2Step:
         for k in ("shs", "xyz", "normal", "scaling", "rotation", "opacity", "base_color", "roughness", "incidents"):
             self.grads[k] = self.grad_flat[o:o + sizes[k]].view_as(getattr(self, k))
             o += sizes[k]
-        self._bucket_a = self.grad_flat[:sizes["shs"]]          # final right after the rasterizer backward
-        self._bucket_b = self.grad_flat[sizes["shs"]:]          # final after the activation backward
+        # three all-reduce buckets (world > 1): A = SH colour grads, final right after the rasterizer backward (reduced
+        # under the shading backward); C = the small per-Gaussian groups, final after the activation chain rule;
+        # B = incident-light grads, final after the shading backward -- reduced LAST and only waited for right before
+        # the NEXT iteration's shading forward, so it travels under that iteration's projection + binning
+        n_inc = sizes["incidents"]
+        self._bucket_a = self.grad_flat[:sizes["shs"]]
+        self._bucket_c = self.grad_flat[sizes["shs"]:self.grad_flat.numel() - n_inc]
+        self._bucket_b = self.grad_flat[self.grad_flat.numel() - n_inc:]
+        self._pending_b = None
         self.grads["env"] = torch.zeros_like(self.env)
         self._zero_depth_grad = None
         # Optional second stream for the per-Gaussian geometry backward.  Measured on MI355X: no gain -- the shading
@@ -188,6 +205,7 @@ class FusedStage2Step:
                 bg, self.xyz, self.features, empty, self.a_opacity, self.a_scales, self.a_rot, 1.0, empty, vm,
                 cam.full_proj_transform, cam.tanfovx, cam.tanfovy, cam.cx, cam.cy, H, W, self.shs, 3, campos, False,
                 True, False)
+            self.flush()        # (world > 1) the previous iteration's incident-light update lands here
             env_c = F.softplus(self.env)[0]                                      # DirectLightMap.get_env
             He, We = env_c.shape[0], env_c.shape[1]
             _lib.check(L.r3dg_shade_forward(
@@ -216,6 +234,9 @@ class FusedStage2Step:
                 cam.full_proj_transform, cam.tanfovx, cam.tanfovy, g[0:3], g[3:4], self._zero_depth_grad, g[4:20], self.shs, 3,
                 campos, geom, R, binning, img, True, False, dL_dsh_out=self.grads["shs"], geometry_stream=self._side)
             dL_dmeans2D, _dcol, dL_dopacity, dL_dmeans3D, dL_dfeatures, _dcov, _dsh, dL_dscales, dL_drot = bw
+            handle_a = None
+            if self._side is None:
+                handle_a = self._allreduce_async(self._bucket_a)     # travels under the shading backward
             _lib.check(L.r3dg_stage2_unpack_gradients(
                 stream(), P, dL_dfeatures.data_ptr(), self.shade_out.data_ptr(), self.w["light"] / (3.0 * P),
                 self.d_pbr.data_ptr(), self.d_diffuse.data_ptr()), "stage2_unpack_gradients")
@@ -226,7 +247,7 @@ class FusedStage2Step:
             gr = self.grads
             if self._side is not None:          # join the geometry backward
                 torch.cuda.current_stream().wait_stream(self._side)
-            handle_a = self._allreduce_async(self._bucket_a)
+                handle_a = self._allreduce_async(self._bucket_a)
             _lib.check(L.r3dg_stage2_activate_backward(
                 stream(), P, self.xyz.data_ptr(), self.scaling.data_ptr(), self.rotation.data_ptr(),
                 self.opacity.data_ptr(), self.normal.data_ptr(), self.base_color.data_ptr(), self.roughness.data_ptr(),
@@ -235,17 +256,16 @@ class FusedStage2Step:
                 dL_dmeans3D.data_ptr(), gr["xyz"].data_ptr(), gr["scaling"].data_ptr(), gr["rotation"].data_ptr(),
                 gr["opacity"].data_ptr(), gr["normal"].data_ptr(), gr["base_color"].data_ptr(),
                 gr["roughness"].data_ptr()), "stage2_activate_backward")
-            handle_b = self._allreduce_async(self._bucket_b)
             # environment texture: softplus chain rule + total-variation term
             _lib.check(L.r3dg_stage2_env_backward(
                 stream(), He, We, self.env.data_ptr(), env_c.data_ptr(), d_env.data_ptr(), self.w["env_smooth"],
                 gr["env"].data_ptr(), self.sums[4:].data_ptr()), "stage2_env_backward")
+            self._handles = None
             if self.world > 1:
-                torch.distributed.all_reduce(gr["env"], group=self.group)
-                for h in (handle_a, handle_b):
-                    h.wait()
-                self.grad_flat.mul_(1.0 / self.world)
-                gr["env"].mul_(1.0 / self.world)
+                handle_c = self._allreduce_async(self._bucket_c)
+                handle_e = torch.distributed.all_reduce(gr["env"], group=self.group, async_op=True)
+                handle_b = self._allreduce_async(self._bucket_b)
+                self._handles = (handle_a, handle_c, handle_e, handle_b)
         self.viewspace_grad = dL_dmeans2D
         self.last_outs = (R, n_contrib, image, opacity, depth, feature, pseudo_normal, sxyz, weights, radii)
         self._N = N
@@ -263,8 +283,33 @@ class FusedStage2Step:
                           self.w["light"] / (3.0 * P), self.w["env_smooth"]], device=self.dev)
         return (self.sums * w).sum()
 
+    _GROUPS_A = (5,)                       # indices into self.opt.groups: shs
+    _GROUPS_C = (0, 1, 2, 3, 4, 6, 7, 9)   # xyz normal scaling rotation opacity base_color roughness env
+    _GROUPS_B = (8,)                       # incidents
+
     def optimizer_step(self):
-        self.opt.step([self.grads[k] for k in self._opt_order])
+        grads = [self.grads[k] for k in self._opt_order]
+        if self.world <= 1:
+            self.opt.step(grads)
+            return
+        # data parallel: update each bucket when its (sum) all-reduce has landed; 1/world is applied inside the kernel
+        scale = 1.0 / self.world
+        handle_a, handle_c, handle_e, handle_b = self._handles
+        self.opt.begin_step()
+        handle_a.wait()
+        self.opt.step_groups(self._GROUPS_A, grads, scale)
+        handle_c.wait()
+        handle_e.wait()
+        self.opt.step_groups(self._GROUPS_C, grads, scale)
+        self._pending_b = (handle_b, grads, scale)
+
+    def flush(self):
+        """Complete a deferred incident-light update (data-parallel runs only; a no-op otherwise)."""
+        if self._pending_b is not None:
+            handle_b, grads, scale = self._pending_b
+            self._pending_b = None
+            handle_b.wait()
+            self.opt.step_groups(self._GROUPS_B, grads, scale)
 
     def __call__(self, cam, bg, gt):
         outs = self.forward_backward(cam, bg, gt)

@@ -1,7 +1,7 @@
 """Data-parallel path of the fused stage-2 iteration: two ranks (two processes sharing the one GPU of the test box,
 `gloo` backend on device tensors -- RCCL refuses two ranks on one device) render different cameras; after the two-bucket
-all-reduce both must hold the SAME averaged gradients, equal to the mean of two single-process backward passes, and stay
-bit-identical replicas after the Adam step."""
+all-reduces (three buckets, the last one deferred into the next iteration) both must hold the SAME summed gradients,
+equal to the sum of two single-process backward passes, and stay bit-identical replicas after the Adam steps."""
 import os
 import socket
 
@@ -46,10 +46,13 @@ def _worker(rank, world, port, out_dir):
     step = FusedStage2Step(params, K, lr=1e-3)
     assert step.world == 2
     step.forward_backward(cams[rank], bg, gts[rank])
+    step.optimizer_step()                    # waits for buckets A and C; the incident-light bucket B stays in flight
+    assert step._pending_b is not None
+    step.flush()
     torch.cuda.synchronize()
-    grads = {k: v.detach().cpu().clone() for k, v in step.grads.items()}
-    step.optimizer_step()
+    grads = {k: v.detach().cpu().clone() for k, v in step.grads.items()}      # all-reduced SUMS over the two ranks
     step(cams[rank], bg, gts[rank])          # a second full iteration on the updated parameters
+    step.flush()
     torch.cuda.synchronize()
     pars = {k: getattr(step, k).detach().cpu().clone() for k in ("xyz", "shs", "incidents", "env", "opacity")}
     torch.save(dict(grads=grads, pars=pars), os.path.join(out_dir, "rank%d.pt" % rank))
@@ -74,7 +77,7 @@ def test_fused_step_two_ranks(tmp_path):
         g = {k: v.detach().clone() for k, v in single.grads.items()}
         acc = g if acc is None else {k: acc[k] + g[k] for k in g}
     for k, v in acc.items():
-        want = (0.5 * v).cpu()
+        want = v.cpu()                       # the ranks hold the SUM; 1/world is applied inside the Adam kernel
         got = r0["grads"][k]
         scale = float(want.abs().max())
         err = float((got - want).abs().max())
