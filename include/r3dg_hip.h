@@ -221,6 +221,23 @@ int r3dg_stage2_loss(void* stream, int width, int height, const float* d_image, 
                      const float* d_gt, const float* d_background, float w_l1, float w_pbr, float w_normal,
                      float* d_dL_dimage, float* d_dL_dopacity, float* d_dL_dfeature, float* d_sums);
 
+/* Stage-1 counterparts (plain 3DGS + normals, gaussian_renderer/render.py:15-130; r3dg_stage2_activate with
+ * d_base_raw == NULL provides the activations): features [P,5] = normal(3), depth, depth^2;
+ * loss = w_l1 sum|image-gt| + w_normal sum (feat[0:3] - pseudo_normal)^2 + w_opacity sum opacity(1-opacity) with feat as
+ * in r3dg_stage2_loss; sums[0..2] += the three unweighted sums; dL_dfeature is [5,HW]. */
+int r3dg_stage1_pack_features(void* stream, int P, const float* d_xyz, const float* d_viewmatrix, const float* d_normal,
+                              float* d_features);
+int r3dg_stage1_loss(void* stream, int width, int height, const float* d_image, const float* d_opacity,
+                     const float* d_feature, const float* d_pseudo_normal, const int32_t* d_n_contrib, const float* d_gt,
+                     float w_l1, float w_normal, float w_opacity, float* d_dL_dimage, float* d_dL_dopacity,
+                     float* d_dL_dfeature, float* d_sums);
+int r3dg_stage1_activate_backward(void* stream, int P, const float* d_xyz, const float* d_scaling_raw,
+                                  const float* d_rotation_raw, const float* d_opacity_raw, const float* d_normal_raw,
+                                  const float* d_viewmatrix, const float* d_dL_dfeatures, const float* d_dL_dscales,
+                                  const float* d_dL_drotations, const float* d_dL_dopacity, const float* d_dL_dmeans3D,
+                                  float* d_g_xyz, float* d_g_scaling, float* d_g_rotation, float* d_g_opacity,
+                                  float* d_g_normal);
+
 /* Learnable environment texture (DirectLightMap, scene/direct_light_map.py:18-27): env = softplus(raw), [He,We,3].
  * g_raw = (dL_denv + w_tv * dTV(env)/denv) * softplus'(raw) with TV = mean|d/dh| + mean|d/dw| (the env-smoothness term,
  * neilf.py:294-300); *tv_sum (may be NULL) += TV(env). */

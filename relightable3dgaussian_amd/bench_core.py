@@ -233,7 +233,7 @@ def relight_bench(params, cams, dev, frames, K):
 
 def quick_rate(stage, points, res, sample_num, dev, steps=20, warmup=4):
     """iters/s of another BASELINE configuration on the same synthetic scene (single GPU, short run): stage 1
-    (configs[1]; drop-in ops + PyTorch autograd glue + torch.optim.Adam) or stage 2 at another sample count (configs[2]
+    (configs[1]; fused stage-1 iteration) or stage 2 at another sample count (configs[2]
     trains at sample_num=384)."""
     scene = syn.make_scene(P=points, seed=0, stage2=stage == 2)
     cams = [c.to(dev) for c in syn.orbit_cameras(100, width=res, height=res)[:4]]
@@ -251,12 +251,11 @@ def quick_rate(stage, points, res, sample_num, dev, steps=20, warmup=4):
         def one(i):
             step_fn(cams[i % 4], bg, gts[i % 4])
     else:
-        opt = torch.optim.Adam(params.parameters(), lr=1e-4, eps=1e-15, fused=True)
+        from . import fused_step
+        step1 = fused_step.FusedStage1Step(params, lr=1e-4)
 
         def one(i):
-            loss_stage1(render_stage1(params, cams[i % 4], bg), gts[i % 4]).backward()
-            opt.step()
-            opt.zero_grad(set_to_none=False)
+            step1(cams[i % 4], bg, gts[i % 4])
     for i in range(warmup):
         one(i)
     torch.cuda.synchronize()
@@ -285,9 +284,13 @@ def run(args):
     cams = [c.to(dev) for c in cams_cpu]
     bg = torch.ones(3, device=dev)
     params = GaussianParams(scene, dev, stage2)
-    fused = stage2 and not getattr(args, "unfused", False)
+    fused = not getattr(args, "unfused", False)
     opt = None if fused else torch.optim.Adam(params.parameters(), lr=1e-4, eps=1e-15, fused=True)
-    if fused:
+    if fused and not stage2:
+        from . import fused_step
+        step_fn = fused_step.FusedStage1Step(params, lr=1e-4)
+        S = 5
+    elif fused:
         # the whole iteration through the fused glue kernels + one-launch Adam (fused_step.py); gradients are averaged
         # over ranks inside (two flat buckets, the first all-reduce overlapping the shading backward)
         from . import fused_step
@@ -423,7 +426,7 @@ def run(args):
                 del step_fn, params
                 torch.cuda.empty_cache()
                 result["other_configs"] = {
-                    "stage1_train_iters_per_s (configs[1]: drop-in ops + autograd glue + torch Adam)":
+                    "stage1_train_iters_per_s (configs[1], fused stage-1 iteration)":
                         quick_rate(1, args.points, args.res, 0, dev),
                     "stage2_train_iters_per_s_sample_num_384 (configs[2])":
                         quick_rate(2, args.points, args.res, 384, dev),

@@ -92,6 +92,15 @@ void launch_s2_loss(hipStream_t s, int HW, const float* image, const float* opac
                     float w_pbr, float w_normal, float* dL_dimage, float* dL_dopacity, float* dL_dfeature, float* sums);
 void launch_adam(hipStream_t s, int n_groups, const r3dg_adam_group* groups, float beta1, float beta2, float eps,
                  int step, float grad_scale);
+void launch_s1_pack(hipStream_t s, int P, const float* xyz, const float* viewmatrix, const float* normal, float* features);
+void launch_s1_loss(hipStream_t s, int HW, const float* image, const float* opacity, const float* feature,
+                    const float* pseudo_normal, const int* n_contrib, const float* gt, float w_l1, float w_normal,
+                    float w_opacity, float* dL_dimage, float* dL_dopacity, float* dL_dfeature, float* sums);
+void launch_s1_activate_backward(hipStream_t s, int P, const float* xyz, const float* scaling_raw,
+                                 const float* rotation_raw, const float* opacity_raw, const float* normal_raw,
+                                 const float* viewmatrix, const float* dL_dfeatures, const float* dL_dscales,
+                                 const float* dL_drot, const float* dL_dopacity, const float* dL_dmeans3D, float* g_xyz,
+                                 float* g_scaling, float* g_rotation, float* g_opacity, float* g_normal);
 void launch_s2_env_backward(hipStream_t s, int He, int We, const float* raw, const float* env, const float* dL_denv,
                             float w_tv, float* g_raw, float* tv_sum);
 uint32_t tile_sort_small_cap();
@@ -913,6 +922,58 @@ int r3dg_stage2_loss(void* stream_, int width, int height, const float* image, c
         StageTimer t((hipStream_t)stream_, ST_S2_LOSS);
         launch_s2_loss((hipStream_t)stream_, width * height, image, opacity, feature, pseudo_normal, n_contrib, gt, bg,
                        w_l1, w_pbr, w_normal, dL_dimage, dL_dopacity, dL_dfeature, sums);
+        return R3DG_OK;
+    });
+}
+
+int r3dg_stage1_pack_features(void* stream_, int P, const float* xyz, const float* viewmatrix, const float* normal,
+                              float* features)
+{
+    if (P < 0) return invalid("stage1_pack_features: bad P");
+    if (P == 0) return R3DG_OK;
+    if (!xyz || !viewmatrix || !normal || !features) return invalid("stage1_pack_features: null buffer");
+    return guarded([&]() -> int {
+        StageTimer t((hipStream_t)stream_, ST_S2_PACK);
+        launch_s1_pack((hipStream_t)stream_, P, xyz, viewmatrix, normal, features);
+        return R3DG_OK;
+    });
+}
+
+int r3dg_stage1_loss(void* stream_, int width, int height, const float* image, const float* opacity,
+                     const float* feature, const float* pseudo_normal, const int32_t* n_contrib, const float* gt,
+                     float w_l1, float w_normal, float w_opacity, float* dL_dimage, float* dL_dopacity,
+                     float* dL_dfeature, float* sums)
+{
+    if (width < 0 || height < 0) return invalid("stage1_loss: bad image size");
+    if ((long long)width * height == 0) return R3DG_OK;
+    if (!image || !opacity || !feature || !pseudo_normal || !n_contrib || !gt || !dL_dimage || !dL_dopacity ||
+        !dL_dfeature || !sums)
+        return invalid("stage1_loss: null buffer");
+    return guarded([&]() -> int {
+        StageTimer t((hipStream_t)stream_, ST_S2_LOSS);
+        launch_s1_loss((hipStream_t)stream_, width * height, image, opacity, feature, pseudo_normal, n_contrib, gt, w_l1,
+                       w_normal, w_opacity, dL_dimage, dL_dopacity, dL_dfeature, sums);
+        return R3DG_OK;
+    });
+}
+
+int r3dg_stage1_activate_backward(void* stream_, int P, const float* xyz, const float* scaling_raw,
+                                  const float* rotation_raw, const float* opacity_raw, const float* normal_raw,
+                                  const float* viewmatrix, const float* dL_dfeatures, const float* dL_dscales,
+                                  const float* dL_drot, const float* dL_dopacity, const float* dL_dmeans3D, float* g_xyz,
+                                  float* g_scaling, float* g_rotation, float* g_opacity, float* g_normal)
+{
+    if (P < 0) return invalid("stage1_activate_backward: bad P");
+    if (P == 0) return R3DG_OK;
+    if (!xyz || !scaling_raw || !rotation_raw || !opacity_raw || !normal_raw || !viewmatrix || !dL_dfeatures ||
+        !dL_dscales || !dL_drot || !dL_dopacity || !dL_dmeans3D || !g_xyz || !g_scaling || !g_rotation || !g_opacity ||
+        !g_normal)
+        return invalid("stage1_activate_backward: null buffer");
+    return guarded([&]() -> int {
+        StageTimer t((hipStream_t)stream_, ST_S2_ACTIVATE_BWD);
+        launch_s1_activate_backward((hipStream_t)stream_, P, xyz, scaling_raw, rotation_raw, opacity_raw, normal_raw,
+                                    viewmatrix, dL_dfeatures, dL_dscales, dL_drot, dL_dopacity, dL_dmeans3D, g_xyz,
+                                    g_scaling, g_rotation, g_opacity, g_normal);
         return R3DG_OK;
     });
 }

@@ -313,6 +313,118 @@ s2_env_backward_kernel(int He, int We, const float* __restrict__ raw, const floa
     if (threadIdx.x == 0 && tv_sum != nullptr) atomicAdd(tv_sum, tot);
 }
 
+// ---- stage 1 (plain 3DGS + normals, gaussian_renderer/render.py:15-130): S = 5 feature row [normal, depth, depth^2] ---
+__global__ void __launch_bounds__(256)
+s1_pack_features_kernel(int P, const float* __restrict__ xyz, const float* __restrict__ viewmatrix,
+                        const float* __restrict__ normal, float* __restrict__ features)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= P) return;
+    const size_t i3 = 3 * (size_t)i;
+    const float depth = xyz[i3] * viewmatrix[2] + xyz[i3 + 1] * viewmatrix[6] + xyz[i3 + 2] * viewmatrix[10] +
+                        viewmatrix[14];
+    float* f = features + 5 * (size_t)i;
+    f[0] = normal[i3]; f[1] = normal[i3 + 1]; f[2] = normal[i3 + 2];
+    f[3] = depth; f[4] = depth * depth;
+}
+
+// loss = w_l1 sum|image-gt| + w_normal sum (feat[0:3] - pseudo_normal)^2 + w_opacity sum op(1-op), feat as in s2_loss
+__global__ void __launch_bounds__(256)
+s1_loss_kernel(int HW, const float* __restrict__ image, const float* __restrict__ opacity,
+               const float* __restrict__ feature, const float* __restrict__ pseudo_normal,
+               const int* __restrict__ n_contrib, const float* __restrict__ gt, float w_l1, float w_normal,
+               float w_opacity, float* __restrict__ dL_dimage, float* __restrict__ dL_dopacity,
+               float* __restrict__ dL_dfeature, float* __restrict__ sums)
+{
+    __shared__ float s_part[4];
+    float s_l1 = 0.f, s_n = 0.f, s_o = 0.f;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < HW; i += gridDim.x * 256) {
+        const float op = opacity[i];
+        const bool mask = n_contrib[i] > 0;
+        const float opc = fmaxf(op, 1e-5f);
+        const float scale = mask ? 1.f / opc : 0.f;
+        const float dscale_dop = (mask && op >= 1e-5f) ? -1.f / (opc * opc) : 0.f;
+        float g_op = w_opacity * (1.f - 2.f * op);
+        s_o += op * (1.f - op);
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+            const float d0 = image[(size_t)c * HW + i] - gt[(size_t)c * HW + i];
+            s_l1 += fabsf(d0);
+            dL_dimage[(size_t)c * HW + i] = w_l1 * signf_(d0);
+            const float Fn = feature[(size_t)c * HW + i];
+            const float dn = Fn * scale - pseudo_normal[(size_t)c * HW + i];
+            s_n += dn * dn;
+            const float gn = 2.f * w_normal * dn;
+            dL_dfeature[(size_t)c * HW + i] = gn * scale;
+            g_op += gn * Fn * dscale_dop;
+        }
+        dL_dopacity[i] = g_op;
+        dL_dfeature[(size_t)3 * HW + i] = 0.f;
+        dL_dfeature[(size_t)4 * HW + i] = 0.f;
+    }
+    const float t0 = block_sum_256(s_l1, s_part);
+    __syncthreads();
+    const float t1 = block_sum_256(s_n, s_part);
+    __syncthreads();
+    const float t2 = block_sum_256(s_o, s_part);
+    if (threadIdx.x == 0) {
+        atomicAdd(sums + 0, t0);
+        atomicAdd(sums + 1, t1);
+        atomicAdd(sums + 2, t2);
+    }
+}
+
+__global__ void __launch_bounds__(256)
+s1_activate_backward_kernel(int P, const float* __restrict__ xyz, const float* __restrict__ scaling_raw,
+                            const float* __restrict__ rotation_raw, const float* __restrict__ opacity_raw,
+                            const float* __restrict__ normal_raw, const float* __restrict__ viewmatrix,
+                            const float* __restrict__ dL_dfeatures, const float* __restrict__ dL_dscales,
+                            const float* __restrict__ dL_drot, const float* __restrict__ dL_dopacity,
+                            const float* __restrict__ dL_dmeans3D, float* __restrict__ g_xyz,
+                            float* __restrict__ g_scaling, float* __restrict__ g_rotation,
+                            float* __restrict__ g_opacity, float* __restrict__ g_normal)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= P) return;
+    const size_t i3 = 3 * (size_t)i, i4 = 4 * (size_t)i;
+    const float* gf = dL_dfeatures + 5 * (size_t)i;
+#pragma unroll
+    for (int c = 0; c < 3; c++) g_scaling[i3 + c] = dL_dscales[i3 + c] * __expf(scaling_raw[i3 + c]);
+    {
+        const float q[4] = {rotation_raw[i4], rotation_raw[i4 + 1], rotation_raw[i4 + 2], rotation_raw[i4 + 3]};
+        const float g[4] = {dL_drot[i4], dL_drot[i4 + 1], dL_drot[i4 + 2], dL_drot[i4 + 3]};
+        const float n = sqrtf(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+        if (n > 1e-12f) {
+            const float inv = 1.f / n;
+            const float d = (q[0] * g[0] + q[1] * g[1] + q[2] * g[2] + q[3] * g[3]) * inv * inv;
+#pragma unroll
+            for (int c = 0; c < 4; c++) g_rotation[i4 + c] = (g[c] - q[c] * d) * inv;
+        } else {
+#pragma unroll
+            for (int c = 0; c < 4; c++) g_rotation[i4 + c] = g[c] * 1e12f;
+        }
+    }
+    {
+        const float sg = sigmoidf_(opacity_raw[i]);
+        g_opacity[i] = dL_dopacity[i] * sg * (1.f - sg);
+    }
+    {
+        const float v[3] = {normal_raw[i3], normal_raw[i3 + 1], normal_raw[i3 + 2]};
+        const float g[3] = {gf[0], gf[1], gf[2]};
+        float o[3];
+        normalize3_backward(v, 1e-3f, g, o);
+        g_normal[i3] = o[0]; g_normal[i3 + 1] = o[1]; g_normal[i3 + 2] = o[2];
+    }
+    {
+        const float depth = xyz[i3] * viewmatrix[2] + xyz[i3 + 1] * viewmatrix[6] + xyz[i3 + 2] * viewmatrix[10] +
+                            viewmatrix[14];
+        const float gd = gf[3] + 2.f * depth * gf[4];
+        g_xyz[i3] = dL_dmeans3D[i3] + gd * viewmatrix[2];
+        g_xyz[i3 + 1] = dL_dmeans3D[i3 + 1] + gd * viewmatrix[6];
+        g_xyz[i3 + 2] = dL_dmeans3D[i3 + 2] + gd * viewmatrix[10];
+    }
+}
+
 // ---- multi-group Adam -----------------------------------------------------------------------------------------------
 struct AdamTable {
     r3dg_adam_group g[R3DG_ADAM_MAX_GROUPS];
@@ -424,6 +536,35 @@ void launch_s2_env_backward(hipStream_t s, int He, int We, const float* raw, con
 {
     s2_env_backward_kernel<<<(He * We * 3 + 255) / 256, 256, 0, s>>>(He, We, raw, env, dL_denv, w_tv, g_raw, tv_sum);
     check_launch(s, false, "s2_env_backward_kernel");
+}
+
+void launch_s1_pack(hipStream_t s, int P, const float* xyz, const float* viewmatrix, const float* normal, float* features)
+{
+    s1_pack_features_kernel<<<(P + 255) / 256, 256, 0, s>>>(P, xyz, viewmatrix, normal, features);
+    check_launch(s, false, "s1_pack_features_kernel");
+}
+
+void launch_s1_loss(hipStream_t s, int HW, const float* image, const float* opacity, const float* feature,
+                    const float* pseudo_normal, const int* n_contrib, const float* gt, float w_l1, float w_normal,
+                    float w_opacity, float* dL_dimage, float* dL_dopacity, float* dL_dfeature, float* sums)
+{
+    s1_loss_kernel<<<min((HW + 255) / 256, 768), 256, 0, s>>>(HW, image, opacity, feature, pseudo_normal, n_contrib, gt,
+                                                            w_l1, w_normal, w_opacity, dL_dimage, dL_dopacity,
+                                                            dL_dfeature, sums);
+    check_launch(s, false, "s1_loss_kernel");
+}
+
+void launch_s1_activate_backward(hipStream_t s, int P, const float* xyz, const float* scaling_raw,
+                                 const float* rotation_raw, const float* opacity_raw, const float* normal_raw,
+                                 const float* viewmatrix, const float* dL_dfeatures, const float* dL_dscales,
+                                 const float* dL_drot, const float* dL_dopacity, const float* dL_dmeans3D, float* g_xyz,
+                                 float* g_scaling, float* g_rotation, float* g_opacity, float* g_normal)
+{
+    s1_activate_backward_kernel<<<(P + 255) / 256, 256, 0, s>>>(P, xyz, scaling_raw, rotation_raw, opacity_raw,
+                                                              normal_raw, viewmatrix, dL_dfeatures, dL_dscales, dL_drot,
+                                                              dL_dopacity, dL_dmeans3D, g_xyz, g_scaling, g_rotation,
+                                                              g_opacity, g_normal);
+    check_launch(s, false, "s1_activate_backward_kernel");
 }
 
 void launch_adam(hipStream_t s, int n_groups, const r3dg_adam_group* groups, float beta1, float beta2, float eps,

@@ -315,3 +315,116 @@ class FusedStage2Step:
         outs = self.forward_backward(cam, bg, gt)
         self.optimizer_step()
         return outs
+
+
+class FusedStage1Step:
+    """Stage-1 (plain 3DGS + normals) iteration without an autograd graph: activations -> S=5 feature row -> rasterize ->
+    image-space loss + gradients -> rasterize backward -> activation chain rule -> one-launch Adam.  Same computation as
+    bench_core.render_stage1 + loss_stage1 + torch.optim.Adam (the parity target, tests/test_fused_step_gpu.py);
+    single-bucket gradient all-reduce under data parallelism."""
+
+    def __init__(self, params, lr=1e-4, lr_rest_scale=1.0, process_group=None):
+        dev = params.xyz.device
+        self.dev = dev
+        d = lambda t: t.detach().clone().contiguous()
+        self.xyz, self.normal = d(params.xyz), d(params.normal)
+        self.scaling, self.rotation, self.opacity = d(params.scaling), d(params.rotation), d(params.opacity)
+        self.shs = torch.cat([params.features_dc.detach(), params.features_rest.detach()], 1).contiguous()
+        self.P = P = self.xyz.shape[0]
+        self.M = self.shs.shape[1]
+        f = dict(dtype=torch.float32, device=dev)
+        self.a_scales, self.a_rot = torch.empty(P, 3, **f), torch.empty(P, 4, **f)
+        self.a_opacity, self.a_normal = torch.empty(P, 1, **f), torch.empty(P, 3, **f)
+        self.features = torch.empty(P, 5, **f)
+        self.sums = torch.zeros(3, **f)
+        names = ("shs", "xyz", "normal", "scaling", "rotation", "opacity")
+        sizes = {k: getattr(self, k).numel() for k in names}
+        self.grad_flat = torch.zeros(sum(sizes.values()), **f)
+        self.grads, o = {}, 0
+        for k in names:
+            self.grads[k] = self.grad_flat[o:o + sizes[k]].view_as(getattr(self, k))
+            o += sizes[k]
+        self._zero_depth_grad = None
+        self.group = process_group
+        self.world = torch.distributed.get_world_size(process_group) if (
+            torch.distributed.is_available() and torch.distributed.is_initialized()) else 1
+        rest = lr * lr_rest_scale
+        self._opt_order = ("xyz", "normal", "scaling", "rotation", "opacity", "shs")
+        self.opt = FusedAdam([dict(param=self.xyz, lr=lr), dict(param=self.normal, lr=lr),
+                              dict(param=self.scaling, lr=lr), dict(param=self.rotation, lr=lr),
+                              dict(param=self.opacity, lr=lr),
+                              dict(param=self.shs, lr=lr, lr_tail=rest, period=3 * self.M, split=3)])
+        self.last_outs = None
+
+    features_dc = property(lambda self: self.shs[:, :1])
+    features_rest = property(lambda self: self.shs[:, 1:])
+
+    def forward_backward(self, cam, bg, gt):
+        L = _lib.lib()
+        P, dev = self.P, self.dev
+        H, W = cam.image_height, cam.image_width
+        N = H * W
+        stream = _lib.current_stream
+        vm = cam.world_view_transform.contiguous()
+        campos = cam.camera_center.contiguous()
+        empty = torch.Tensor([])
+        with torch.cuda.device(dev):
+            _lib.check(L.r3dg_stage2_activate(
+                stream(), P, self.xyz.data_ptr(), self.scaling.data_ptr(), self.rotation.data_ptr(),
+                self.opacity.data_ptr(), self.normal.data_ptr(), None, None, None, self.a_scales.data_ptr(),
+                self.a_rot.data_ptr(), self.a_opacity.data_ptr(), self.a_normal.data_ptr(), None, None, None),
+                "stage2_activate")
+            pending = rasterizer_ops.rasterize_gaussians_begin(
+                bg, self.xyz, self.features, empty, self.a_opacity, self.a_scales, self.a_rot, 1.0, empty, vm,
+                cam.full_proj_transform, cam.tanfovx, cam.tanfovy, cam.cx, cam.cy, H, W, self.shs, 3, campos, False,
+                True, False)
+            _lib.check(L.r3dg_stage1_pack_features(stream(), P, self.xyz.data_ptr(), vm.data_ptr(),
+                                                   self.a_normal.data_ptr(), self.features.data_ptr()),
+                       "stage1_pack_features")
+            self.sums.zero_()
+            fw = pending.finish()
+            R, n_contrib, image, opacity, depth, feature, pseudo_normal, sxyz, weights, radii, geom, binning, img = fw
+            g = torch.empty((9, H, W), dtype=torch.float32, device=dev)      # dL_dimage 3 | dL_dopacity 1 | dL_dfeature 5
+            if self._zero_depth_grad is None or self._zero_depth_grad.shape[-2:] != (H, W):
+                self._zero_depth_grad = torch.zeros((1, H, W), dtype=torch.float32, device=dev)
+            _lib.check(L.r3dg_stage1_loss(
+                stream(), W, H, image.data_ptr(), opacity.data_ptr(), feature.data_ptr(), pseudo_normal.data_ptr(),
+                n_contrib.data_ptr(), gt.contiguous().data_ptr(), 1.0 / (3.0 * N), 0.1 / (3.0 * N), 0.001 / N,
+                g[0:3].data_ptr(), g[3:4].data_ptr(), g[4:9].data_ptr(), self.sums.data_ptr()), "stage1_loss")
+            bw = rasterizer_ops.rasterize_gaussians_backward(
+                bg, self.xyz, self.features, radii, empty, self.a_scales, self.a_rot, 1.0, empty, vm,
+                cam.full_proj_transform, cam.tanfovx, cam.tanfovy, g[0:3], g[3:4], self._zero_depth_grad, g[4:9],
+                self.shs, 3, campos, geom, R, binning, img, True, False, dL_dsh_out=self.grads["shs"])
+            dL_dmeans2D, _dcol, dL_dopacity, dL_dmeans3D, dL_dfeatures, _dcov, _dsh, dL_dscales, dL_drot = bw
+            gr = self.grads
+            _lib.check(L.r3dg_stage1_activate_backward(
+                stream(), P, self.xyz.data_ptr(), self.scaling.data_ptr(), self.rotation.data_ptr(),
+                self.opacity.data_ptr(), self.normal.data_ptr(), vm.data_ptr(), dL_dfeatures.data_ptr(),
+                dL_dscales.data_ptr(), dL_drot.data_ptr(), dL_dopacity.data_ptr(), dL_dmeans3D.data_ptr(),
+                gr["xyz"].data_ptr(), gr["scaling"].data_ptr(), gr["rotation"].data_ptr(), gr["opacity"].data_ptr(),
+                gr["normal"].data_ptr()), "stage1_activate_backward")
+            self._handle = None
+            if self.world > 1:
+                self._handle = torch.distributed.all_reduce(self.grad_flat, group=self.group, async_op=True)
+        self.viewspace_grad = dL_dmeans2D
+        self.last_outs = (R, n_contrib, image, opacity, depth, feature, pseudo_normal, sxyz, weights, radii)
+        self._N = N
+        return self.last_outs
+
+    def loss(self):
+        N = self._N
+        w = torch.tensor([1.0 / (3.0 * N), 0.1 / (3.0 * N), 0.001 / N], device=self.dev)
+        return (self.sums * w).sum()
+
+    def optimizer_step(self):
+        if self._handle is not None:
+            self._handle.wait()
+        self.opt.step([self.grads[k] for k in self._opt_order], 1.0 / self.world)
+
+    def flush(self):
+        pass
+
+    def __call__(self, cam, bg, gt):
+        outs = self.forward_backward(cam, bg, gt)
+        self.optimizer_step()
+        return outs

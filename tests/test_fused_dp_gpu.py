@@ -25,6 +25,7 @@ def _make(dev, P=2500, res=128, K=8, seed=11):
     from relightable3dgaussian_amd import synthetic as syn
     from relightable3dgaussian_amd.bench_core import GaussianParams, render_stage1
     from relightable3dgaussian_amd.fused_step import FusedStage2Step
+    torch.manual_seed(1234)
     scene = syn.make_scene(P=P, seed=seed, stage2=True, scale_log_mean=-3.2)
     cams = [c.to(dev) for c in syn.orbit_cameras(8, width=res, height=res)[:2]]
     bg = torch.tensor([1.0, 1.0, 1.0], device=dev)
