@@ -139,7 +139,25 @@ def cpu_baseline(scene, cams, S, budget_s):
         t_b += time.time() - t0
         views += 1
         R = out[0]
-    return dict(value=views / (t_f + t_b), unit="iters/s", cores=1, kind="port",
+    extra = {}
+    try:        # configs[0]: the reference's own CPU-runnable plumbing case through the pure-PyTorch restatement
+        from oracle import torch_rasterizer as tr
+        torch.set_num_threads(os.cpu_count() or 1)
+        sc0 = syn.make_scene(P=2000, seed=0, stage2=False, scale_log_mean=-3.0)
+        cam0 = syn.orbit_cameras(4, width=400, height=400)[0]
+        f0 = torch.rand(2000, 5)
+        t0 = time.time()
+        with torch.no_grad():
+            o0 = tr.rasterize(torch.ones(3), sc0["xyz"], f0, None, sc0["opacity"], sc0["scales"], sc0["rotations"], 1.0,
+                              None, cam0.world_view_transform, cam0.full_proj_transform, cam0.tanfovx, cam0.tanfovy,
+                              cam0.cx, cam0.cy, 400, 400, sc0["shs"], 3, cam0.camera_center)
+        extra["pytorch_cpu_config0"] = dict(
+            seconds_per_view=round(time.time() - t0, 3), threads=os.cpu_count(),
+            what="pure-PyTorch CPU rasterize forward (oracle/torch_rasterizer.py), 2000 Gaussians, one 400x400 view, "
+                 "num_rendered=%d" % int(o0["num_rendered"]))
+    except Exception as e:
+        extra["pytorch_cpu_config0"] = {"failed": repr(e)}
+    return dict(value=views / (t_f + t_b), unit="iters/s", cores=1, kind="port", **extra,
                 sample="%d views %dx%d, %d Gaussians, R~%d, rasterize fwd+bwd S=%d only (oracle C port, fp32, 1 thread; "
                        "fwd %.1fs + bwd %.1fs of CPU time); shading/Adam not included" % (
                            views, W, H, P, R, S, t_f, t_b))
