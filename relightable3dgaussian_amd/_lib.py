@@ -86,6 +86,10 @@ def lib():
             raise RuntimeError(
                 "libr3dg_hip.so not found at %s -- build it with `python -m relightable3dgaussian_amd.build` "
                 "(hipcc, gfx950). There is no CPU fallback." % LIB_PATH)
+        # PyTorch-ROCm ships its own HIP runtime; it must be in the process BEFORE this library is loaded so that both
+        # resolve to ONE runtime instance (loaded the other way round, the library's kernels see "no ROCm-capable
+        # device" once torch has initialised its copy)
+        import torch  # noqa: F401
         L = C.CDLL(LIB_PATH)
         sigs = dict(_SIGNATURES)
         sigs.update(EXTRA_SIGNATURES)

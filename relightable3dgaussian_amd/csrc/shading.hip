@@ -4,19 +4,19 @@
 //
 // The reference evaluates this with dozens of unfused elementwise passes over [P,K,3] temporaries (230 MB each at
 // K=64) plus autograd saved tensors.  Here ONE kernel reads each cached sample once -- dirs [P,K,3], visibility
-// [P,K], areas [P,K], 16 B per sample -- and writes 19 floats per Gaussian:
-//   * one wave per Gaussian, lanes across the K samples (K=64: exactly one sample per lane; K=384: six), so the
-//     three [P,K,*] caches are read with fully coalesced 256-768 B wave accesses;
-//   * the environment texture (activated, lat-long) is staged in LDS when it fits (16x32x3 fp32 = 6 KB) and
-//     sampled bilinearly from there; in the backward its gradient is accumulated in a second LDS copy with
-//     ds_add_f32 and flushed with one global atomic per texel per block (blocks are persistent / grid-strided);
-//   * the K-mean of the 19 forward outputs / the 55 per-Gaussian gradients (48 SH + 3 albedo + 1 roughness +
-//     3 view direction) is a transposing wave reduction (wave_reduce.hpp) ending in one store; the backward does it in
-//     two 32-channel halves generated on the fly so only ~32 partials are live at a time;
+// [P,K], areas [P,K], 20 B per sample -- and writes 19 floats per Gaussian (forward) / 55 gradients (backward):
+//   * 16 lanes per Gaussian, 4 Gaussians per wave, the K samples strided over the 16 lanes; per-Gaussian setup and the
+//     final cross-lane reduction (a transposing butterfly that never leaves a 16-lane DPP row) are shared by four
+//     Gaussians per instruction;
+//   * the environment texture (activated, lat-long) is staged in LDS when it fits (16x32x3 fp32 = 6 KB) and sampled
+//     bilinearly from there; in the backward its gradient is accumulated in a second LDS copy in 64-bit fixed point
+//     (integer ds_add_u64: LDS float atomics retire ~1 lane / 3 cycles on gfx950) and flushed with one global atomic
+//     per texel per persistent block;
 //   * the per-Gaussian uniform record (48 SH coefficients, albedo, roughness, normal, view direction, upstream
-//     gradients = 64 floats) is fetched by ONE coalesced wave load (lane l reads element l), parked in a per-wave LDS
-//     slot and read back as broadcasts -- no serial chain of scalar loads -- and the record and first 64 samples of the
-//     wave's NEXT Gaussian are prefetched into registers before the current one is processed (HBM latency hidden).
+//     gradients = 64 floats) is fetched by ONE coalesced wave load (lane l reads element l) into a per-wave LDS slot and
+//     read back as broadcasts;
+//   * backward only: record + samples of the wave's NEXT 64-sample block arrive by LDS-DMA (global_load_lds_dwordx4),
+//     double buffered, while the current block is computed (three passes per block, 12 parked floats per lane).
 #include "common.hpp"
 #include "wave_reduce.hpp"
 
