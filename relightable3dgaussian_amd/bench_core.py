@@ -288,11 +288,18 @@ def run(args):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # one process per GPU; R3DG_DIST_BACKEND=gloo lets the multi-rank path be exercised on a box with fewer GPUs than
+    # ranks (ranks then share devices) -- test use only, the measured configuration is nccl (= RCCL)
+    backend = os.environ.get("R3DG_DIST_BACKEND", "nccl")
+    dev_index = local_rank % max(1, torch.cuda.device_count()) if world > 1 else 0
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    dev = torch.device("cuda", local_rank if world > 1 else 0)
+        torch.cuda.set_device(dev_index)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index))
+        else:
+            dist.init_process_group(backend)
+    dev = torch.device("cuda", dev_index)
     torch.cuda.set_device(dev)
     L = _lib.lib()
 
