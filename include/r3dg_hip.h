@@ -92,6 +92,11 @@ int r3dg_rasterize_forward_begin(void* stream, r3dg_alloc_fn geometry_alloc, r3d
                                  float* d_out_surface_xyz, float* d_out_weights, int32_t* d_radii, int debug,
                                  void** ticket);
 int r3dg_rasterize_forward_finish(void* ticket, int* num_rendered_out);
+/* _finish with the instance ordering (key duplication, sort, tile ranges) on `ordering_stream` (NULL = the forward's
+ * stream): it waits for the projection only and is joined before the tile kernel, so it can run concurrently with
+ * whatever the caller queued on the forward's stream after _begin.  The binning state buffer is first touched on
+ * `ordering_stream`. */
+int r3dg_rasterize_forward_finish_on(void* ticket, void* ordering_stream, int* num_rendered_out);
 
 /* Backward.  d_dL_dmean2D [P,3] (z = depth side channel), d_dL_dconic [P,4] (x,y,-,w), d_dL_dopacity, d_dL_dcolor and
  * d_dL_dfeature are accumulated with atomics and must be zero-filled by the caller; d_dL_dmean3D, d_dL_dcov3D and --

@@ -486,11 +486,20 @@ int r3dg_rasterize_forward_begin(void* stream_, r3dg_alloc_fn geometry_alloc, r3
 
 int r3dg_rasterize_forward_finish(void* ticket_, int* num_rendered_out)
 {
+    return r3dg_rasterize_forward_finish_on(ticket_, nullptr, num_rendered_out);
+}
+
+int r3dg_rasterize_forward_finish_on(void* ticket_, void* ordering_stream_, int* num_rendered_out)
+{
     if (num_rendered_out) *num_rendered_out = 0;
     if (!ticket_) return R3DG_OK;                // P == 0
     ForwardTicket* t = (ForwardTicket*)ticket_;
     const int st = guarded([&]() -> int {
-        hipStream_t stream = t->stream;
+        const hipStream_t main_stream = t->stream;
+        // instance ordering (K5-K7) may run on its own stream: it depends on the projection only, so it can overlap the
+        // kernels the caller queued on the main stream after _begin (the shading that produces the feature rows)
+        const hipStream_t order_stream = ordering_stream_ ? (hipStream_t)ordering_stream_ : main_stream;
+        hipStream_t stream = order_stream;
         const bool debug = t->debug != 0;
         const int P = t->P, S = t->S, width = t->width, height = t->height;
         const int gx = (width + R3DG_TILE_X - 1) / R3DG_TILE_X, gy = (height + R3DG_TILE_Y - 1) / R3DG_TILE_Y;
@@ -520,6 +529,7 @@ int r3dg_rasterize_forward_finish(void* ticket_, int* num_rendered_out)
 
         R3DG_HIP(hipEventSynchronize(t->ready));
         const unsigned long long total = *t->host_total;
+        if (order_stream != main_stream) R3DG_HIP(hipStreamWaitEvent(order_stream, t->ready, 0));
         if (total > 0x7fffffffull) { set_error("rasterize_forward: num_rendered exceeds 2^31-1"); return R3DG_EINVAL; }
         const int R = (int)total;
 
@@ -579,6 +589,14 @@ int r3dg_rasterize_forward_finish(void* ticket_, int* num_rendered_out)
                 check_launch(stream, debug, "tile_order");
             }
         }
+        if (order_stream != main_stream) {          // join: the tile kernel needs the ordering AND the feature rows
+            hipEvent_t ev;
+            R3DG_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+            R3DG_HIP(hipEventRecord(ev, order_stream));
+            R3DG_HIP(hipStreamWaitEvent(main_stream, ev, 0));
+            R3DG_HIP(hipEventDestroy(ev));
+        }
+        stream = main_stream;
         StageTimer t_rf(stream, ST_RENDER_FWD);
         launch_render_forward(stream, width, height, S, tile_order, ranges, vals, g_means2D, g_depths, features, colors_ptr,
                               g_conic, (float*)(ibuf + I.final_T), (uint32_t*)(ibuf + I.n_contrib), background,

@@ -401,7 +401,7 @@ __device__ __forceinline__ void wait_block_loads() { asm volatile("s_waitcnt vmc
 // Forward: direct loads (its register budget allows more waves per SIMD than the backward, and measured faster than the
 // DMA-staged variant: 0.27 vs 0.34 ms at P=300k, K=64).
 template <bool ENV_LDS>
-__global__ void __launch_bounds__(64 * SHADE_WAVES, 3)
+__global__ void __launch_bounds__(64 * SHADE_WAVES, 2)
 shade_forward_kernel(int P, int K, int M, const float* __restrict__ base_color, const float* __restrict__ roughness,
                      const float* __restrict__ normals, const float* __restrict__ viewdirs,
                      const float* __restrict__ incidents, const float* __restrict__ env, int He, int We,
@@ -728,7 +728,7 @@ static int shade_grid_impl(int P)
     (void)hipGetDevice(&dev);
     (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
     const int want = (P + SH_GB - 1) / SH_GB;
-    const int cap = cus * 8;
+    const int cap = cus * 2;      // resident at 2 waves/SIMD: persistent blocks, nothing queued behind them
     return want < cap ? (want > 0 ? want : 1) : cap;
 }
 

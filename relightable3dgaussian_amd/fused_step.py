@@ -86,7 +86,7 @@ class FusedStage2Step:
     """Owns the raw parameters (copied from a bench_core.GaussianParams) and runs whole iterations."""
 
     def __init__(self, params, sample_num, lr=1e-4, lr_rest_scale=1.0, loss_weights=None, process_group=None,
-                 overlap_geometry=False):
+                 overlap_geometry=False, overlap_ordering=True):
         dev = params.xyz.device
         self.dev = dev
         d = lambda t: t.detach().clone().contiguous()
@@ -131,6 +131,9 @@ class FusedStage2Step:
         self._pending_b = None
         self.grads["env"] = torch.zeros_like(self.env)
         self._zero_depth_grad = None
+        # instance ordering of the rasterizer runs here, under the shading forward (register-light, latency-bound kernels
+        # next to a VALU-bound one)
+        self._order_stream = torch.cuda.Stream(device=dev) if overlap_ordering else None
         # Optional second stream for the per-Gaussian geometry backward.  Measured on MI355X: no gain -- the shading
         # backward already fills the register file (2 waves/SIMD x 221 VGPRs), so the geometry kernel cannot co-run.
         self._side = torch.cuda.Stream(device=dev) if overlap_geometry else None
@@ -218,7 +221,7 @@ class FusedStage2Step:
                 stream(), P, self.xyz.data_ptr(), vm.data_ptr(), self.a_normal.data_ptr(), self.a_base.data_ptr(),
                 self.a_rough.data_ptr(), self.shade_out.data_ptr(), self.features.data_ptr(),
                 self.sums[3:].data_ptr()), "stage2_pack_features")
-            fw = pending.finish()
+            fw = pending.finish(self._order_stream)
             R, n_contrib, image, opacity, depth, feature, pseudo_normal, sxyz, weights, radii, geom, binning, img = fw
             # image-space loss terms and their gradients (one slab: dL_dimage 3 | dL_dopacity 1 | dL_dfeature 16; the depth image carries no loss)
             g = torch.empty((20, H, W), dtype=torch.float32, device=dev)

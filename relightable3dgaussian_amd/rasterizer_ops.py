@@ -56,11 +56,18 @@ class _PendingForward:
     def __init__(self, ticket, rs, outs, dev, H, W):
         self.ticket, self.rs, self.outs, self.dev, self.H, self.W = ticket, rs, outs, dev, H, W
 
-    def finish(self):
+    def finish(self, ordering_stream=None):
+        """`ordering_stream`: optional torch stream for the instance ordering (sort) part, which then overlaps whatever
+        was queued on the forward's stream since begin; the binning buffer is allocated from that stream's pool."""
         L = _lib.lib()
         rendered = C.c_int(0)
         with torch.cuda.device(self.dev):
-            st = L.r3dg_rasterize_forward_finish(self.ticket, C.byref(rendered))
+            if ordering_stream is None:
+                st = L.r3dg_rasterize_forward_finish(self.ticket, C.byref(rendered))
+            else:
+                with torch.cuda.stream(ordering_stream):        # resize callback allocates on that stream
+                    st = L.r3dg_rasterize_forward_finish_on(self.ticket, C.c_void_p(ordering_stream.cuda_stream),
+                                                            C.byref(rendered))
         self.ticket = None
         _lib.check(st, "rasterize_gaussians")
         out_color, out_opacity, out_depth, out_feature, out_normal, out_surface_xyz, out_weights, radii = self.outs
