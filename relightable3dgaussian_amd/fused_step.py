@@ -134,8 +134,11 @@ class FusedStage2Step:
         # instance ordering of the rasterizer runs here, under the shading forward (register-light, latency-bound kernels
         # next to a VALU-bound one)
         self._order_stream = torch.cuda.Stream(device=dev) if overlap_ordering else None
-        # Optional second stream for the per-Gaussian geometry backward.  Measured on MI355X: no gain -- the shading
-        # backward already fills the register file (2 waves/SIMD x 221 VGPRs), so the geometry kernel cannot co-run.
+        self._adam_stream = None
+        self._early = False
+        # Optional second stream for the per-Gaussian geometry backward.  Measured on MI355X: a loss -- the shading
+        # backward fills the register file (2 waves/SIMD x 221 VGPRs); capping the geometry kernel at 64 VGPRs so that it
+        # fits beside it spills 35 registers and slows both (2.13 -> 2.20 ms/step).  Off by default.
         self._side = torch.cuda.Stream(device=dev) if overlap_geometry else None
         self.group = process_group
         self.world = torch.distributed.get_world_size(process_group) if (
@@ -190,8 +193,11 @@ class FusedStage2Step:
                 self.a_viewdirs.data_ptr())
         _lib.check(st, "stage2_activate")
 
-    def forward_backward(self, cam, bg, gt):
-        """One forward + loss + backward; gradients land in self.grads.  Returns the rasterizer's 10 public outputs."""
+    def forward_backward(self, cam, bg, gt, early_adam=False):
+        """One forward + loss + backward; gradients land in self.grads.  Returns the rasterizer's 10 public outputs.
+        `early_adam` (single-GPU whole iterations only, see __call__): the SH colour coefficients, whose gradient is final
+        after the rasterizer backward, get their Adam update on a side stream UNDER the shading backward (an HBM-bound,
+        register-light kernel next to a VALU-bound one); optimizer_step() then updates the remaining groups."""
         L = _lib.lib()
         P, dev = self.P, self.dev
         H, W = cam.image_height, cam.image_width
@@ -240,6 +246,20 @@ class FusedStage2Step:
             handle_a = None
             if self._side is None:
                 handle_a = self._allreduce_async(self._bucket_a)     # travels under the shading backward
+            self._early = False
+            if early_adam and self.world <= 1:
+                # Adam of the SH group on a side stream, behind the geometry backward that produces its gradient
+                side = self._side
+                if side is None:
+                    if self._adam_stream is None:
+                        self._adam_stream = torch.cuda.Stream(device=dev)
+                    side = self._adam_stream
+                    side.wait_stream(torch.cuda.current_stream())
+                self.opt.begin_step()
+                with torch.cuda.stream(side):
+                    self.opt.step_groups(self._GROUPS_A, [self.grads[k] for k in self._opt_order])
+                self._early_stream = side
+                self._early = True
             _lib.check(L.r3dg_stage2_unpack_gradients(
                 stream(), P, dL_dfeatures.data_ptr(), self.shade_out.data_ptr(), self.w["light"] / (3.0 * P),
                 self.d_pbr.data_ptr(), self.d_diffuse.data_ptr()), "stage2_unpack_gradients")
@@ -293,7 +313,12 @@ class FusedStage2Step:
     def optimizer_step(self):
         grads = [self.grads[k] for k in self._opt_order]
         if self.world <= 1:
-            self.opt.step(grads)
+            if self._early:              # the SH group was updated under the shading backward (forward_backward)
+                torch.cuda.current_stream().wait_stream(self._early_stream)
+                self.opt.step_groups(self._GROUPS_C + self._GROUPS_B, grads)
+                self._early = False
+            else:
+                self.opt.step(grads)
             return
         # data parallel: update each bucket when its (sum) all-reduce has landed; 1/world is applied inside the kernel
         scale = 1.0 / self.world
@@ -315,7 +340,7 @@ class FusedStage2Step:
             self.opt.step_groups(self._GROUPS_B, grads, scale)
 
     def __call__(self, cam, bg, gt):
-        outs = self.forward_backward(cam, bg, gt)
+        outs = self.forward_backward(cam, bg, gt, early_adam=True)
         self.optimizer_step()
         return outs
 
