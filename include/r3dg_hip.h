@@ -118,7 +118,11 @@ int r3dg_rasterize_backward(void* stream, int P, int S, int D, int M, int R, con
 /* Same as r3dg_rasterize_backward, but the per-Gaussian geometry backward (K12+K13: d_dL_dmean3D, d_dL_dcov3D, d_dL_dsh,
  * d_dL_dscale, d_dL_drot) is launched on `geometry_stream`, ordered after the tile kernel by an event, so work that
  * only needs the tile kernel's outputs (d_dL_dfeature, ...) can follow on `stream` concurrently.  The caller joins the
- * two streams before reading the geometry outputs.  geometry_stream == stream is exactly r3dg_rasterize_backward. */
+ * two streams before reading the geometry outputs.  geometry_stream == stream is exactly r3dg_rasterize_backward.
+ * active_features (HOST array of n_active_features distinct channel indices, or n_active_features < 0 for "all"): the
+ * caller's promise that every OTHER channel of d_dL_dpix_f is zero everywhere; those channels are then not carried
+ * through the tile kernel at all (their d_dL_dfeature columns keep the caller's zero fill).  Same results, less work:
+ * a loss normally reads a few of the S feature maps. */
 int r3dg_rasterize_backward_split(void* stream, void* geometry_stream, int P, int S, int D, int M, int R,
                                   const float* d_background, int width, int height, const float* d_means3D,
                                   const float* d_shs, const float* d_features, const float* d_colors_precomp,
@@ -130,7 +134,8 @@ int r3dg_rasterize_backward_split(void* stream, void* geometry_stream, int P, in
                                   const float* d_dL_dpix_f, float* d_dL_dmean2D, float* d_dL_dconic,
                                   float* d_dL_dopacity, float* d_dL_dcolor, float* d_dL_dfeature, float* d_dL_dmean3D,
                                   float* d_dL_dcov3D, float* d_dL_dsh, float* d_dL_dscale, float* d_dL_drot,
-                                  int backward_geometry, int debug);
+                                  int backward_geometry, int debug, int n_active_features,
+                                  const int* active_features);
 
 int r3dg_mark_visible(void* stream, int P, const float* d_means3D, const float* d_viewmatrix,
                       const float* d_projmatrix, uint8_t* d_present);

@@ -37,7 +37,8 @@ void launch_render_forward(hipStream_t s, int W, int H, int S, const uint32_t* t
 void launch_pseudo_normal(hipStream_t s, int W, int H, const float* vm, float focal_x, float focal_y, float cx,
                           float cy, const float* opacities, const float* depths, float* normals, float* surface_xyz,
                           bool debug);
-void launch_render_backward(hipStream_t s, int W, int H, int S, const uint32_t* tile_order, const uint32_t* ranges,
+void launch_render_backward(hipStream_t s, int W, int H, int S, int n_active, const int* active,
+                            const uint32_t* tile_order, const uint32_t* ranges,
                             const uint32_t* point_list,
                             const float* bg, const float* means2D, const float* depths, const float* conic_opacity,
                             const float* colors, const float* features, const float* final_Ts,
@@ -658,7 +659,7 @@ int r3dg_rasterize_backward(void* stream_, int P, int S, int D, int M, int R, co
                                          viewmatrix, projmatrix, campos, tan_fovx, tan_fovy, radii, geom_buffer,
                                          binning_buffer, img_buffer, dL_dpix, dL_dpix_o, dL_dpix_d, dL_dpix_f, dL_dmean2D,
                                          dL_dconic, dL_dopacity, dL_dcolor, dL_dfeature, dL_dmean3D, dL_dcov3D, dL_dsh,
-                                         dL_dscale, dL_drot, backward_geometry, debug_);
+                                         dL_dscale, dL_drot, backward_geometry, debug_, -1, nullptr);
 }
 
 int r3dg_rasterize_backward_split(void* stream_, void* geometry_stream_, int P, int S, int D, int M, int R,
@@ -671,12 +672,19 @@ int r3dg_rasterize_backward_split(void* stream_, void* geometry_stream_, int P, 
                                   const float* dL_dpix, const float* dL_dpix_o, const float* dL_dpix_d,
                                   const float* dL_dpix_f, float* dL_dmean2D, float* dL_dconic, float* dL_dopacity,
                                   float* dL_dcolor, float* dL_dfeature, float* dL_dmean3D, float* dL_dcov3D,
-                                  float* dL_dsh, float* dL_dscale, float* dL_drot, int backward_geometry, int debug_)
+                                  float* dL_dsh, float* dL_dscale, float* dL_drot, int backward_geometry, int debug_,
+                                  int n_active_features, const int* active_features)
 {
     if (P < 0 || width <= 0 || height <= 0 || R < 0) return invalid("rasterize_backward: bad P/R/width/height");
     if (S < 0 || S > R3DG_MAX_S_BWD) return invalid("rasterize_backward: feature channels S must be in [0,36]");
     if (P == 0) return R3DG_OK;
     if (!geom_buffer || !img_buffer || (R > 0 && !binning_buffer)) return invalid("rasterize_backward: null state buffer");
+    if (n_active_features >= 0) {
+        if (n_active_features > S || !active_features) return invalid("rasterize_backward: bad active feature list");
+        for (int i = 0; i < n_active_features; i++)
+            if (active_features[i] < 0 || active_features[i] >= S)
+                return invalid("rasterize_backward: active feature index out of range");
+    }
 
     return guarded([&]() -> int {
         hipStream_t stream = (hipStream_t)stream_;
@@ -696,7 +704,7 @@ int r3dg_rasterize_backward_split(void* stream_, void* geometry_stream_, int P, 
 
         if (R > 0) {
             StageTimer t_rb(stream, ST_RENDER_BWD);
-            launch_render_backward(stream, width, height, S,
+            launch_render_backward(stream, width, height, S, n_active_features, active_features,
                                    g_tile_order ? (const uint32_t*)(ibuf + I.tile_order) : nullptr,
                                    (const uint32_t*)(ibuf + I.ranges),
                                    (const uint32_t*)(bbuf + B.vals), background, (const float*)(gbuf + G.means2D),

@@ -45,9 +45,19 @@ void launch_transpose_selftest(hipStream_t s, int N, int dpp, const float* in, f
 
 constexpr int next_pow2(int v) { return v <= 16 ? 16 : (v <= 32 ? 32 : 64); }
 
-template <int SPAD, int PPL, int U>
+// Feature channels the kernel processes: by default all S; a caller that knows which channels of dL_dout_feature are
+// non-zero (a loss usually reads a few of them) passes that subset -- channels with a zero upstream gradient contribute
+// neither to dL_dalpha nor to dL_dfeature, so they need no recursion, no payload and no slot in the reduction.
+struct ChannelList {
+    int n;               // processed channels (<= SPAD)
+    int identity;        // 1: channel j is feature j and n == S
+    int c[R3DG_MAX_S_BWD];
+};
+
+template <int SPAD, int PPL, int U, bool SMALLV>
 __global__ void __launch_bounds__(256 / PPL)
-render_backward_kernel(const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list, int S, int W, int H,
+render_backward_kernel(const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list, int S,
+                       ChannelList chan_list, int W, int H,
                        int tiles_x, int num_tiles, int xcd_chunk, int wave8, int cull, const uint32_t* __restrict__ tile_order,
                        const float* __restrict__ bg_color,
                        const float2* __restrict__ means2D, const float* __restrict__ depths,
@@ -61,8 +71,9 @@ render_backward_kernel(const uint2* __restrict__ ranges, const uint32_t* __restr
 {
     constexpr int NT = 256 / PPL;
     constexpr int PAY = 4 + SPAD;
-    constexpr int NV = 10 + SPAD;            // gradient channels per Gaussian
-    constexpr int NVP = next_pow2(NV);
+    constexpr int NV = 10 + SPAD;            // gradient channels per Gaussian (SMALLV: only the first 16 are non-zero)
+    constexpr int NVP = SMALLV ? 16 : next_pow2(NV);
+    const int SA = chan_list.n;
     constexpr int NW = NT / 64;
     constexpr int NC = 4 + SPAD;             // blended channels per pixel: rgb, depth, features
 
@@ -106,7 +117,7 @@ render_backward_kernel(const uint2* __restrict__ ranges, const uint32_t* __restr
         else if (chan < 6) { dst_base = dL_dmean2D + (chan - 3); dst_stride = 3; }
         else if (chan < 9) { dst_base = dL_dconic2D + (chan == 8 ? 3 : chan - 6); dst_stride = 4; }
         else if (chan == 9) { dst_base = dL_dopacity; dst_stride = 1; }
-        else if (chan - 10 < S) { dst_base = dL_dfeature + (chan - 10); dst_stride = (uint32_t)S; }
+        else if (chan - 10 < SA) { dst_base = dL_dfeature + chan_list.c[chan - 10]; dst_stride = (uint32_t)S; }
     }
 
     // Per-pixel state as float2 pairs so the per-channel recursions compile to packed fp32 ops (v_pk_fma_f32 /
@@ -139,7 +150,8 @@ render_backward_kernel(const uint2* __restrict__ ranges, const uint32_t* __restr
         dLo[i] = inside ? dL_dpixels_o[pix] : 0.f;
         acc_o[i] = 0.f;
 #pragma unroll
-        for (int ch = 0; ch < SPAD; ch++) dl[4 + ch] = (inside && ch < S) ? dL_dpixels_f[(size_t)ch * HW + pix] : 0.f;
+        for (int ch = 0; ch < SPAD; ch++)
+            dl[4 + ch] = (inside && ch < SA) ? dL_dpixels_f[(size_t)chan_list.c[ch] * HW + pix] : 0.f;
 #pragma unroll
         for (int q = 0; q < NC / 2; q++) {
             dL2[i][q] = f2{dl[2 * q], dl[2 * q + 1]};
@@ -173,7 +185,7 @@ render_backward_kernel(const uint2* __restrict__ ranges, const uint32_t* __restr
             pay[0] = colors[3 * g]; pay[1] = colors[3 * g + 1]; pay[2] = colors[3 * g + 2]; pay[3] = depths[g];
             if constexpr (SPAD > 0) {
                 const float* f = features + (size_t)g * S;
-                if ((S & 3) == 0) {
+                if (chan_list.identity && (S & 3) == 0) {
 #pragma unroll
                     for (int q = 0; q < SPAD / 4; q++) {
                         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -182,7 +194,7 @@ render_backward_kernel(const uint2* __restrict__ ranges, const uint32_t* __restr
                     }
                 } else {
 #pragma unroll
-                    for (int ch = 0; ch < SPAD; ch++) pay[4 + ch] = ch < S ? f[ch] : 0.f;
+                    for (int ch = 0; ch < SPAD; ch++) pay[4 + ch] = ch < SA ? f[chan_list.c[ch]] : 0.f;
                 }
             }
         }
@@ -251,9 +263,10 @@ render_backward_kernel(const uint2* __restrict__ ranges, const uint32_t* __restr
                 const float* pay = s_pay + jj[u] * PAY;
                 // v[] = this lane's 10+S gradient contributions (summed over its PPL pixels): with one pixel per lane
                 // every used channel is assigned exactly once, so only the padding is zeroed
-                float v[NVP];
+                constexpr int NVA = NV > NVP ? NV : NVP;     // SMALLV: NV = 18 slots are written, the last 2 are padding
+                float v[NVA];
 #pragma unroll
-                for (int k = (PPL == 1 ? NV : 0); k < NVP; k++) v[k] = 0.f;
+                for (int k = (PPL == 1 ? NV : 0); k < NVA; k++) v[k] = 0.f;
 #define R3DG_ACC(k, x) do { if (PPL == 1) v[k] = (x); else v[k] += (x); } while (0)
 
                 // Branch-free over the lanes: a lane that does not blend this Gaussian has alpha == 0, which leaves its
@@ -314,7 +327,10 @@ render_backward_kernel(const uint2* __restrict__ ranges, const uint32_t* __restr
                     R3DG_ACC(9, Gv * dL_dalpha);
                 }
 #undef R3DG_ACC
-                const float total = transpose_reduce<NVP, true>(v);
+                float vr[NVP];
+#pragma unroll
+                for (int k = 0; k < NVP; k++) vr[k] = v[k];
+                const float total = transpose_reduce<NVP, true>(vr);
                 // 32-bit element index: P * max(S, 4) < 2^32
                 if (dst_base != nullptr) atomicAdd(dst_base + (size_t)(__float_as_uint(g1[u].w) * dst_stride), total);
             }
@@ -331,27 +347,35 @@ int g_bwd_unroll = 1;   // staged entries evaluated per inner-loop step
 
 template <int SPAD, int PPL>
 static void launch_bwd_inst(hipStream_t s, int T, int tiles_x, const uint32_t* tile_order, const uint32_t* ranges,
-                            const uint32_t* point_list, int S, int W, int H, const float* bg, const float* means2D,
-                            const float* depths, const float* conic_opacity, const float* colors,
+                            const uint32_t* point_list, int S, const ChannelList& cl, int W, int H, const float* bg,
+                            const float* means2D, const float* depths, const float* conic_opacity, const float* colors,
                             const float* features, const float* final_Ts, const uint32_t* n_contrib,
                             const float* dL_dpix, const float* dL_dpix_o, const float* dL_dpix_d,
                             const float* dL_dpix_f, float* dL_dmean2D, float* dL_dconic, float* dL_dopacity,
                             float* dL_dcolor, float* dL_dfeature, int bg_geom)
 {
     const int chunk = (T + 7) / 8;
-#define R3DG_BWD_LAUNCH(UU)                                                                                           \
-    render_backward_kernel<SPAD, PPL, UU><<<chunk * 8, 256 / PPL, 0, s>>>(                                            \
-        (const uint2*)ranges, point_list, S, W, H, tiles_x, T, chunk, g_bwd_wave8x8, g_cull, tile_order, bg, (const float2*)means2D, depths, \
-        (const float4*)conic_opacity, colors, features, final_Ts, n_contrib, dL_dpix, dL_dpix_o, dL_dpix_d, dL_dpix_f, \
-        dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolor, dL_dfeature, bg_geom)
-    if (g_bwd_unroll >= 4) R3DG_BWD_LAUNCH(4);
-    else if (g_bwd_unroll >= 2) R3DG_BWD_LAUNCH(2);
-    else R3DG_BWD_LAUNCH(1);
+#define R3DG_BWD_LAUNCH(UU, SV)                                                                                       \
+    render_backward_kernel<SPAD, PPL, UU, SV><<<chunk * 8, 256 / PPL, 0, s>>>(                                        \
+        (const uint2*)ranges, point_list, S, cl, W, H, tiles_x, T, chunk, g_bwd_wave8x8, g_cull, tile_order, bg,       \
+        (const float2*)means2D, depths, (const float4*)conic_opacity, colors, features, final_Ts, n_contrib, dL_dpix,   \
+        dL_dpix_o, dL_dpix_d, dL_dpix_f, dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolor, dL_dfeature, bg_geom)
+    // 10 + n <= 16 gradient channels: half-size reduction (only instantiated where it can occur: SPAD 4 and 8)
+    if constexpr (SPAD == 4 || SPAD == 8) {
+        if (cl.n <= 6 && PPL == 1) {
+            if (g_bwd_unroll >= 2) R3DG_BWD_LAUNCH(2, true);
+            else R3DG_BWD_LAUNCH(1, true);
+            return;
+        }
+    }
+    if (g_bwd_unroll >= 4) R3DG_BWD_LAUNCH(4, false);
+    else if (g_bwd_unroll >= 2) R3DG_BWD_LAUNCH(2, false);
+    else R3DG_BWD_LAUNCH(1, false);
 #undef R3DG_BWD_LAUNCH
 }
 
-void launch_render_backward(hipStream_t s, int W, int H, int S, const uint32_t* tile_order, const uint32_t* ranges,
-                            const uint32_t* point_list,
+void launch_render_backward(hipStream_t s, int W, int H, int S, int n_active, const int* active,
+                            const uint32_t* tile_order, const uint32_t* ranges, const uint32_t* point_list,
                             const float* bg, const float* means2D, const float* depths, const float* conic_opacity,
                             const float* colors, const float* features, const float* final_Ts,
                             const uint32_t* n_contrib, const float* dL_dpix, const float* dL_dpix_o,
@@ -360,14 +384,25 @@ void launch_render_backward(hipStream_t s, int W, int H, int S, const uint32_t* 
 {
     const int tiles_x = (W + R3DG_TILE_X - 1) / R3DG_TILE_X, tiles_y = (H + R3DG_TILE_Y - 1) / R3DG_TILE_Y;
     const int T = tiles_x * tiles_y;
-#define R3DG_BWD_ARGS s, T, tiles_x, tile_order, ranges, point_list, S, W, H, bg, means2D, depths, conic_opacity, colors, features, \
-                      final_Ts, n_contrib, dL_dpix, dL_dpix_o, dL_dpix_d, dL_dpix_f, dL_dmean2D, dL_dconic, dL_dopacity, \
-                      dL_dcolor, dL_dfeature, bg_geom
-#define R3DG_BWD_CASE(SP)                                                       \
-    if (g_bwd_ppl >= 2 && (SP) <= 20) launch_bwd_inst<SP, 2>(R3DG_BWD_ARGS);    \
-    else launch_bwd_inst<SP, 1>(R3DG_BWD_ARGS);                                 \
+    ChannelList cl;
+    if (n_active < 0 || active == nullptr) {
+        cl.n = S;
+        cl.identity = 1;
+        for (int i = 0; i < R3DG_MAX_S_BWD; i++) cl.c[i] = i < S ? i : 0;
+    } else {
+        cl.n = n_active;
+        cl.identity = 0;
+        for (int i = 0; i < R3DG_MAX_S_BWD; i++) cl.c[i] = i < n_active ? active[i] : 0;
+    }
+    const int SP = cl.n;                 // channels the kernel carries
+#define R3DG_BWD_ARGS s, T, tiles_x, tile_order, ranges, point_list, S, cl, W, H, bg, means2D, depths, conic_opacity, colors, \
+                      features, final_Ts, n_contrib, dL_dpix, dL_dpix_o, dL_dpix_d, dL_dpix_f, dL_dmean2D, dL_dconic,         \
+                      dL_dopacity, dL_dcolor, dL_dfeature, bg_geom
+#define R3DG_BWD_CASE(SP_)                                                       \
+    if (g_bwd_ppl >= 2 && (SP_) <= 20) launch_bwd_inst<SP_, 2>(R3DG_BWD_ARGS);   \
+    else launch_bwd_inst<SP_, 1>(R3DG_BWD_ARGS);                                 \
     break;
-    switch ((S + 3) / 4) {
+    switch ((SP + 3) / 4) {
         case 0: R3DG_BWD_CASE(0)
         case 1: R3DG_BWD_CASE(4)
         case 2: R3DG_BWD_CASE(8)

@@ -241,7 +241,8 @@ class FusedStage2Step:
             bw = rasterizer_ops.rasterize_gaussians_backward(
                 bg, self.xyz, self.features, radii, empty, self.a_scales, self.a_rot, 1.0, empty, vm,
                 cam.full_proj_transform, cam.tanfovx, cam.tanfovy, g[0:3], g[3:4], self._zero_depth_grad, g[4:20], self.shs, 3,
-                campos, geom, R, binning, img, True, False, dL_dsh_out=self.grads["shs"], geometry_stream=self._side)
+                campos, geom, R, binning, img, True, False, dL_dsh_out=self.grads["shs"], geometry_stream=self._side,
+                active_features=(2, 3, 4, 5, 6, 7))      # r3dg_stage2_loss only reads the pbr and normal maps
             dL_dmeans2D, _dcol, dL_dopacity, dL_dmeans3D, dL_dfeatures, _dcov, _dsh, dL_dscales, dL_drot = bw
             handle_a = None
             if self._side is None:
@@ -422,7 +423,8 @@ class FusedStage1Step:
             bw = rasterizer_ops.rasterize_gaussians_backward(
                 bg, self.xyz, self.features, radii, empty, self.a_scales, self.a_rot, 1.0, empty, vm,
                 cam.full_proj_transform, cam.tanfovx, cam.tanfovy, g[0:3], g[3:4], self._zero_depth_grad, g[4:9],
-                self.shs, 3, campos, geom, R, binning, img, True, False, dL_dsh_out=self.grads["shs"])
+                self.shs, 3, campos, geom, R, binning, img, True, False, dL_dsh_out=self.grads["shs"],
+                active_features=(0, 1, 2))               # r3dg_stage1_loss only reads the normal maps
             dL_dmeans2D, _dcol, dL_dopacity, dL_dmeans3D, dL_dfeatures, _dcov, _dsh, dL_dscales, dL_drot = bw
             gr = self.grads
             _lib.check(L.r3dg_stage1_activate_backward(

@@ -147,11 +147,13 @@ def rasterize_gaussians_backward(background, means3D, features, radii, colors, s
                                  cov3D_precomp, viewmatrix, projmatrix, tan_fovx, tan_fovy, dL_dout_color,
                                  dL_dout_opacity, dL_dout_depth, dL_dout_feature, sh, degree, campos, geomBuffer, R,
                                  binningBuffer, imageBuffer, backward_geometry, debug, dL_dsh_out=None,
-                                 geometry_stream=None):
+                                 geometry_stream=None, active_features=None):
     """`dL_dsh_out` (not in the reference signature): optional preallocated [P,M,3] buffer the SH gradient is written
     into (every element is written), e.g. a view of a flat gradient bucket.  `geometry_stream`: optional torch stream
     for the per-Gaussian geometry backward (dL_dmeans3D, dL_dcov3D, dL_dsh, dL_dscales, dL_drotations are then only
-    valid after the caller joins that stream; see r3dg_rasterize_backward_split)."""
+    valid after the caller joins that stream; see r3dg_rasterize_backward_split).  `active_features`: optional list of
+    the feature channels whose upstream gradient can be non-zero -- the caller's promise that all other channels of
+    dL_dout_feature are zero; they are then skipped by the tile kernel (same results)."""
     L = _lib.lib()
     P = means3D.size(0)
     S = features.size(1)
@@ -192,6 +194,11 @@ def rasterize_gaussians_backward(background, means3D, features, radii, colors, s
         with torch.cuda.device(dev):
             cur = _lib.current_stream()
             gs = cur if geometry_stream is None else C.c_void_p(geometry_stream.cuda_stream)
+            if active_features is None:
+                n_act, act = -1, None
+            else:
+                n_act = len(active_features)
+                act = (C.c_int * max(1, n_act))(*[int(a) for a in active_features])
             st = L.r3dg_rasterize_backward_split(
                 cur, gs, P, S, int(degree), M, int(R), _lib.ptr(bg_), W, H, _lib.ptr(means_),
                 _lib.ptr(sh_), _lib.ptr(feat_), _lib.ptr(col_), _lib.ptr(sc_), float(scale_modifier), _lib.ptr(rot_),
@@ -200,7 +207,7 @@ def rasterize_gaussians_backward(background, means3D, features, radii, colors, s
                 _lib.ptr(gO), _lib.ptr(gD), _lib.ptr(gF), dL_dmeans2D.data_ptr(), dL_dconic.data_ptr(),
                 dL_dopacity.data_ptr(), dL_dcolors.data_ptr(), _lib.ptr(dL_dfeatures), dL_dmeans3D.data_ptr(),
                 dL_dcov3D.data_ptr(), _lib.ptr(dL_dsh), dL_dscales.data_ptr(), dL_drotations.data_ptr(),
-                int(bool(backward_geometry)), int(bool(debug)))
+                int(bool(backward_geometry)), int(bool(debug)), n_act, act)
         _lib.check(st, "rasterize_gaussians_backward")
     return (dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dmeans3D, dL_dfeatures, dL_dcov3D, dL_dsh, dL_dscales,
             dL_drotations)

@@ -382,6 +382,40 @@ def test_full_size_properties(hip_lib):
         assert bool(torch.isfinite(a).all())
 
 
+@pytest.mark.parametrize("S,active", [(16, (2, 3, 4, 5, 6, 7)), (16, (15, 0, 9)), (5, (0, 1, 2)), (28, tuple(range(3, 20))),
+                                      (16, ()), (7, (6,))])
+def test_backward_active_feature_subset(S, active):
+    """`active_features`: with the upstream gradient of every other feature channel zero, the subset kernel must give the
+    same nine gradients as the full kernel (the skipped channels' dL_dfeatures columns stay zero)."""
+    from r3dg_rasterization import _C
+    from relightable3dgaussian_amd import rasterizer_ops
+    case = make_case(S=S, seed=81 + S, P=4000)
+    a = fwd_args(case, DEV)
+    out = _C.rasterize_gaussians(*a)
+    H, W = case["H"], case["W"]
+    g = torch.Generator().manual_seed(5)
+    gC, gO, gD = [torch.randn(c, H, W, generator=g).to(DEV) for c in (3, 1, 1)]
+    gF = torch.zeros(S, H, W, device=DEV)
+    for ch in active:
+        gF[ch] = torch.randn(H, W, generator=g).to(DEV)
+
+    def run(act):
+        return rasterizer_ops.rasterize_gaussians_backward(
+            a[0], a[1], a[2], out[9], a[3], a[5], a[6], 1.0, a[8], a[9], a[10], a[11], a[12], gC, gO, gD, gF, a[17],
+            a[18], a[19], out[10], out[0], out[11], out[12], True, False, active_features=act)
+    full, sub = run(None), run(active)
+    torch.cuda.synchronize()
+    names = ("dL_dmeans2D", "dL_dcolors", "dL_dopacity", "dL_dmeans3D", "dL_dfeatures", "dL_dcov3D", "dL_dsh",
+             "dL_dscales", "dL_drotations")
+    for nm, x, y in zip(names, full, sub):
+        ok, msg = report(nm, y, x, 1e-4, 1e-9)        # float-atomic summation order differs between the two kernels
+        assert ok, msg
+    inactive = [c for c in range(S) if c not in active]
+    assert float(sub[4][:, inactive].abs().max()) == 0.0 if inactive else True
+    with pytest.raises(RuntimeError):
+        run((S,))
+
+
 @pytest.mark.parametrize("name", ["S16", "big_splats", "ragged_image"])
 def test_cull_is_exact(name, hip_lib):
     """The sub-tile cull only drops (wave, Gaussian) pairs whose every pixel fails alpha >= 1/255, so the forward
