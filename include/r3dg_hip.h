@@ -207,7 +207,9 @@ int r3dg_render_equation_backward(void* stream, int P, int Si, int Sd, int Sv, c
  * r3dg_stage2_loss: image-space terms of calculate_loss (neilf.py:212-318) and their gradients in one pass:
  *   sums[0] += sum |image - gt|, sums[1] += sum |srgb(pbr_img) - gt|, sums[2] += sum (normal_render - pseudo_normal)^2
  *   with feat = feature / max(opacity,1e-5) * (n_contrib > 0), pbr_img = feat[2:5]*opacity + (1-opacity)*bg;
- *   dL_dimage[3,HW], dL_dopacity[HW], dL_dfeature[16,HW] are fully written for weights w_* per element. */
+ *   dL_dimage[3,HW], dL_dopacity[HW], dL_dfeature[16,HW] are fully written for weights w_* per element;
+ *   d_extra_dL_dimage / d_extra_dL_dsrgb (may be NULL): gradients of further terms w.r.t. the image and the sRGB PBR
+ *   image (the SSIM terms), added before the chain rule. */
 int r3dg_stage2_activate(void* stream, int P, const float* d_xyz, const float* d_scaling_raw,
                          const float* d_rotation_raw, const float* d_opacity_raw, const float* d_normal_raw,
                          const float* d_base_raw, const float* d_rough_raw, const float* d_campos, float* d_scales,
@@ -229,7 +231,20 @@ int r3dg_stage2_activate_backward(void* stream, int P, const float* d_xyz, const
 int r3dg_stage2_loss(void* stream, int width, int height, const float* d_image, const float* d_opacity,
                      const float* d_feature, const float* d_pseudo_normal, const int32_t* d_n_contrib,
                      const float* d_gt, const float* d_background, float w_l1, float w_pbr, float w_normal,
-                     float* d_dL_dimage, float* d_dL_dopacity, float* d_dL_dfeature, float* d_sums);
+                     const float* d_extra_dL_dimage, const float* d_extra_dL_dsrgb, float* d_dL_dimage,
+                     float* d_dL_dopacity, float* d_dL_dfeature, float* d_sums);
+/* sRGB-mapped PBR image [3,HW] exactly as r3dg_stage2_loss forms it (input of the SSIM term on the PBR image). */
+int r3dg_stage2_pbr_srgb(void* stream, int width, int height, const float* d_opacity, const float* d_feature,
+                         const int32_t* d_n_contrib, const float* d_background, float* d_srgb);
+
+/* SSIM (utils/loss_utils.py:20-63: 11x11 Gaussian window, sigma 1.5, zero padding) of x against y, both [C,H,W].
+ * _forward: *d_sum += sum of the SSIM map (divide by C*H*W for the reference's mean); d_partials [C,3,H,W] receives the
+ * per-pixel partial derivatives the backward needs.  _backward: d_grad_x [C,H,W] = scale * d(sum SSIM)/dx (overwritten);
+ * scale = -lambda_dssim / (C*H*W) for the loss term lambda_dssim * (1 - ssim). */
+int r3dg_ssim_forward(void* stream, int width, int height, int channels, const float* d_x, const float* d_y,
+                      float* d_partials, float* d_sum);
+int r3dg_ssim_backward(void* stream, int width, int height, int channels, const float* d_x, const float* d_y,
+                       const float* d_partials, float scale, float* d_grad_x);
 
 /* Stage-1 counterparts (plain 3DGS + normals, gaussian_renderer/render.py:15-130; r3dg_stage2_activate with
  * d_base_raw == NULL provides the activations): features [P,5] = normal(3), depth, depth^2;
@@ -239,8 +254,8 @@ int r3dg_stage1_pack_features(void* stream, int P, const float* d_xyz, const flo
                               float* d_features);
 int r3dg_stage1_loss(void* stream, int width, int height, const float* d_image, const float* d_opacity,
                      const float* d_feature, const float* d_pseudo_normal, const int32_t* d_n_contrib, const float* d_gt,
-                     float w_l1, float w_normal, float w_opacity, float* d_dL_dimage, float* d_dL_dopacity,
-                     float* d_dL_dfeature, float* d_sums);
+                     float w_l1, float w_normal, float w_opacity, const float* d_extra_dL_dimage, float* d_dL_dimage,
+                     float* d_dL_dopacity, float* d_dL_dfeature, float* d_sums);
 int r3dg_stage1_activate_backward(void* stream, int P, const float* d_xyz, const float* d_scaling_raw,
                                   const float* d_rotation_raw, const float* d_opacity_raw, const float* d_normal_raw,
                                   const float* d_viewmatrix, const float* d_dL_dfeatures, const float* d_dL_dscales,

@@ -81,7 +81,8 @@ def loss_stage1(outs, gt):
     num_rendered, n_contrib, color, opacity, depth, feature, normal, xyz, weights, radii = outs
     mask = (n_contrib > 0)
     feat = feature / opacity.clamp_min(1e-5) * mask
-    l1 = (color - gt).abs().mean()
+    from .train_step import image_loss
+    l1 = image_loss(color, gt)              # (1 - lambda_dssim) L1 + lambda_dssim (1 - SSIM), render.py
     # normal-consistency and opacity regularisers stand in for the reference's extra loss terms (render.py:150-230)
     reg = (feat[:3] - normal.detach()).square().mean() + 0.01 * (opacity * (1 - opacity)).mean()
     return l1 + 0.1 * reg

@@ -90,13 +90,20 @@ void launch_s2_activate_backward(hipStream_t s, int P, const float* xyz, const f
                                  float* g_rough);
 void launch_s2_loss(hipStream_t s, int HW, const float* image, const float* opacity, const float* feature,
                     const float* pseudo_normal, const int* n_contrib, const float* gt, const float* bg, float w_l1,
-                    float w_pbr, float w_normal, float* dL_dimage, float* dL_dopacity, float* dL_dfeature, float* sums);
+                    float w_pbr, float w_normal, const float* extra_dimage, const float* extra_dsrgb, float* dL_dimage,
+                    float* dL_dopacity, float* dL_dfeature, float* sums);
+void launch_s2_pbr_srgb(hipStream_t s, int HW, const float* opacity, const float* feature, const int* n_contrib,
+                        const float* bg, float* srgb);
+void launch_ssim_forward(hipStream_t s, int W, int H, int C, const float* x, const float* y, float* partials, float* sum);
+void launch_ssim_backward(hipStream_t s, int W, int H, int C, const float* x, const float* y, const float* partials,
+                          float scale, float* grad_x);
 void launch_adam(hipStream_t s, int n_groups, const r3dg_adam_group* groups, float beta1, float beta2, float eps,
                  int step, float grad_scale);
 void launch_s1_pack(hipStream_t s, int P, const float* xyz, const float* viewmatrix, const float* normal, float* features);
 void launch_s1_loss(hipStream_t s, int HW, const float* image, const float* opacity, const float* feature,
                     const float* pseudo_normal, const int* n_contrib, const float* gt, float w_l1, float w_normal,
-                    float w_opacity, float* dL_dimage, float* dL_dopacity, float* dL_dfeature, float* sums);
+                    float w_opacity, const float* extra_dimage, float* dL_dimage, float* dL_dopacity, float* dL_dfeature,
+                    float* sums);
 void launch_s1_activate_backward(hipStream_t s, int P, const float* xyz, const float* scaling_raw,
                                  const float* rotation_raw, const float* opacity_raw, const float* normal_raw,
                                  const float* viewmatrix, const float* dL_dfeatures, const float* dL_dscales,
@@ -129,13 +136,13 @@ void launch_transpose_selftest(hipStream_t s, int N, int dpp, const float* in, f
 // ---- optional per-stage timing with HIP events on the launch stream (bench.py's roofline numbers) ----
 enum Stage { ST_PREPROCESS = 0, ST_DUPKEYS, ST_SORT, ST_RANGES, ST_RENDER_FWD, ST_NORMAL, ST_RENDER_BWD, ST_PREPROCESS_BWD,
              ST_SHADE_FWD, ST_SHADE_BWD, ST_BVH_BUILD, ST_BVH_TRACE, ST_S2_ACTIVATE, ST_S2_PACK, ST_S2_LOSS,
-             ST_S2_UNPACK, ST_S2_ACTIVATE_BWD, ST_ADAM, ST_KNN, ST_COUNT };
+             ST_S2_UNPACK, ST_S2_ACTIVATE_BWD, ST_ADAM, ST_KNN, ST_SSIM, ST_COUNT };
 static const char* kStageNames[ST_COUNT] = {"preprocess", "duplicate_with_keys", "sort_pairs", "identify_tile_ranges",
                                             "render_forward", "pseudo_normal", "render_backward", "preprocess_backward",
                                             "shade_forward", "shade_backward", "bvh_build", "bvh_trace",
                                             "stage2_activate", "stage2_pack_features", "stage2_loss",
                                             "stage2_unpack_gradients", "stage2_activate_backward", "adam_step",
-                                            "knn_dist2"};
+                                            "knn_dist2", "ssim"};
 static int g_profiling = 0;
 struct EventPair { hipEvent_t a, b; };
 static std::vector<EventPair> g_events[ST_COUNT];
@@ -936,8 +943,8 @@ int r3dg_stage2_activate_backward(void* stream_, int P, const float* xyz, const 
 
 int r3dg_stage2_loss(void* stream_, int width, int height, const float* image, const float* opacity,
                      const float* feature, const float* pseudo_normal, const int32_t* n_contrib, const float* gt,
-                     const float* bg, float w_l1, float w_pbr, float w_normal, float* dL_dimage, float* dL_dopacity,
-                     float* dL_dfeature, float* sums)
+                     const float* bg, float w_l1, float w_pbr, float w_normal, const float* extra_dimage,
+                     const float* extra_dsrgb, float* dL_dimage, float* dL_dopacity, float* dL_dfeature, float* sums)
 {
     if (width < 0 || height < 0) return invalid("stage2_loss: bad image size");
     if ((long long)width * height == 0) return R3DG_OK;
@@ -947,7 +954,7 @@ int r3dg_stage2_loss(void* stream_, int width, int height, const float* image, c
     return guarded([&]() -> int {
         StageTimer t((hipStream_t)stream_, ST_S2_LOSS);
         launch_s2_loss((hipStream_t)stream_, width * height, image, opacity, feature, pseudo_normal, n_contrib, gt, bg,
-                       w_l1, w_pbr, w_normal, dL_dimage, dL_dopacity, dL_dfeature, sums);
+                       w_l1, w_pbr, w_normal, extra_dimage, extra_dsrgb, dL_dimage, dL_dopacity, dL_dfeature, sums);
         return R3DG_OK;
     });
 }
@@ -967,8 +974,8 @@ int r3dg_stage1_pack_features(void* stream_, int P, const float* xyz, const floa
 
 int r3dg_stage1_loss(void* stream_, int width, int height, const float* image, const float* opacity,
                      const float* feature, const float* pseudo_normal, const int32_t* n_contrib, const float* gt,
-                     float w_l1, float w_normal, float w_opacity, float* dL_dimage, float* dL_dopacity,
-                     float* dL_dfeature, float* sums)
+                     float w_l1, float w_normal, float w_opacity, const float* extra_dimage, float* dL_dimage,
+                     float* dL_dopacity, float* dL_dfeature, float* sums)
 {
     if (width < 0 || height < 0) return invalid("stage1_loss: bad image size");
     if ((long long)width * height == 0) return R3DG_OK;
@@ -978,7 +985,7 @@ int r3dg_stage1_loss(void* stream_, int width, int height, const float* image, c
     return guarded([&]() -> int {
         StageTimer t((hipStream_t)stream_, ST_S2_LOSS);
         launch_s1_loss((hipStream_t)stream_, width * height, image, opacity, feature, pseudo_normal, n_contrib, gt, w_l1,
-                       w_normal, w_opacity, dL_dimage, dL_dopacity, dL_dfeature, sums);
+                       w_normal, w_opacity, extra_dimage, dL_dimage, dL_dopacity, dL_dfeature, sums);
         return R3DG_OK;
     });
 }
@@ -1000,6 +1007,44 @@ int r3dg_stage1_activate_backward(void* stream_, int P, const float* xyz, const 
         launch_s1_activate_backward((hipStream_t)stream_, P, xyz, scaling_raw, rotation_raw, opacity_raw, normal_raw,
                                     viewmatrix, dL_dfeatures, dL_dscales, dL_drot, dL_dopacity, dL_dmeans3D, g_xyz,
                                     g_scaling, g_rotation, g_opacity, g_normal);
+        return R3DG_OK;
+    });
+}
+
+int r3dg_stage2_pbr_srgb(void* stream_, int width, int height, const float* opacity, const float* feature,
+                         const int32_t* n_contrib, const float* bg, float* srgb)
+{
+    if (width < 0 || height < 0) return invalid("stage2_pbr_srgb: bad image size");
+    if ((long long)width * height == 0) return R3DG_OK;
+    if (!opacity || !feature || !n_contrib || !bg || !srgb) return invalid("stage2_pbr_srgb: null buffer");
+    return guarded([&]() -> int {
+        launch_s2_pbr_srgb((hipStream_t)stream_, width * height, opacity, feature, n_contrib, bg, srgb);
+        return R3DG_OK;
+    });
+}
+
+int r3dg_ssim_forward(void* stream_, int width, int height, int channels, const float* x, const float* y,
+                      float* partials, float* sum)
+{
+    if (width < 0 || height < 0 || channels < 0) return invalid("ssim_forward: bad shape");
+    if ((long long)width * height * channels == 0) return R3DG_OK;
+    if (!x || !y || !partials) return invalid("ssim_forward: null buffer");
+    return guarded([&]() -> int {
+        StageTimer t((hipStream_t)stream_, ST_SSIM);
+        launch_ssim_forward((hipStream_t)stream_, width, height, channels, x, y, partials, sum);
+        return R3DG_OK;
+    });
+}
+
+int r3dg_ssim_backward(void* stream_, int width, int height, int channels, const float* x, const float* y,
+                       const float* partials, float scale, float* grad_x)
+{
+    if (width < 0 || height < 0 || channels < 0) return invalid("ssim_backward: bad shape");
+    if ((long long)width * height * channels == 0) return R3DG_OK;
+    if (!x || !y || !partials || !grad_x) return invalid("ssim_backward: null buffer");
+    return guarded([&]() -> int {
+        StageTimer t((hipStream_t)stream_, ST_SSIM);
+        launch_ssim_backward((hipStream_t)stream_, width, height, channels, x, y, partials, scale, grad_x);
         return R3DG_OK;
     });
 }

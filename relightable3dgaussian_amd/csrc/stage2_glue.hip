@@ -218,13 +218,32 @@ s2_activate_backward_kernel(int P, const float* __restrict__ xyz, const float* _
     }
 }
 
+// sRGB-mapped PBR image (neilf.py:190-200: feat = feature / max(opacity,1e-5) * mask, pbr_img = feat[2:5]*op + (1-op)*bg,
+// linear -> sRGB), materialised for the SSIM term
+__global__ void __launch_bounds__(256)
+s2_pbr_srgb_kernel(int HW, const float* __restrict__ opacity, const float* __restrict__ feature,
+                   const int* __restrict__ n_contrib, const float* __restrict__ bg, float* __restrict__ srgb)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= HW) return;
+    const float op = opacity[i];
+    const float scale = n_contrib[i] > 0 ? 1.f / fmaxf(op, 1e-5f) : 0.f;
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+        const float x = feature[(size_t)(2 + c) * HW + i] * scale * op + (1.f - op) * bg[c];
+        srgb[(size_t)c * HW + i] = x <= 0.0031308f ? 12.92f * x
+                                                   : 1.055f * __powf(fmaxf(x, 0.0031308f), 1.f / 2.4f) - 0.055f;
+    }
+}
+
 // Image-space loss + gradient in one pass.  sums[0..2] += sum|image-gt|, sum|srgb(pbr)-gt|, sum (n_render - n_pseudo)^2
 // (unweighted); gradients carry the weights w_* (already divided by the element counts).
 __global__ void __launch_bounds__(256)
 s2_loss_kernel(int HW, const float* __restrict__ image, const float* __restrict__ opacity,
                const float* __restrict__ feature, const float* __restrict__ pseudo_normal,
                const int* __restrict__ n_contrib, const float* __restrict__ gt, const float* __restrict__ bg,
-               float w_l1, float w_pbr, float w_normal, float* __restrict__ dL_dimage,
+               float w_l1, float w_pbr, float w_normal, const float* __restrict__ extra_dimage,
+               const float* __restrict__ extra_dsrgb, float* __restrict__ dL_dimage,
                float* __restrict__ dL_dopacity, float* __restrict__ dL_dfeature, float* __restrict__ sums)
 {
     __shared__ float s_part[4];
@@ -243,7 +262,8 @@ s2_loss_kernel(int HW, const float* __restrict__ image, const float* __restrict_
             // L1 on the SH image
             const float d0 = image[(size_t)c * HW + i] - g;
             s_l1 += fabsf(d0);
-            dL_dimage[(size_t)c * HW + i] = w_l1 * signf_(d0);
+            // extra_*: gradients of further terms on the same two images (the SSIM terms, r3dg_ssim_backward)
+            dL_dimage[(size_t)c * HW + i] = w_l1 * signf_(d0) + (extra_dimage ? extra_dimage[(size_t)c * HW + i] : 0.f);
             // L1 on the sRGB-mapped PBR image: pbr_img = r_pbr * op + (1 - op) * bg
             const float F = feature[(size_t)(2 + c) * HW + i];
             const float r = F * scale;
@@ -254,7 +274,7 @@ s2_loss_kernel(int HW, const float* __restrict__ image, const float* __restrict_
             const float d1 = srgb - g;
             s_pbr += fabsf(d1);
             const float dsrgb = lin ? 12.92f : 1.055f / 2.4f * __powf(xs, 1.f / 2.4f - 1.f);
-            const float gx = w_pbr * signf_(d1) * dsrgb;                 // dL/dx
+            const float gx = (w_pbr * signf_(d1) + (extra_dsrgb ? extra_dsrgb[(size_t)c * HW + i] : 0.f)) * dsrgb;   // dL/dx
             dL_dfeature[(size_t)(2 + c) * HW + i] = gx * op * scale;
             g_op += gx * (r - bg[c] + op * F * dscale_dop);
             // normal consistency: mse(r_normal, pseudo_normal)
@@ -333,8 +353,8 @@ __global__ void __launch_bounds__(256)
 s1_loss_kernel(int HW, const float* __restrict__ image, const float* __restrict__ opacity,
                const float* __restrict__ feature, const float* __restrict__ pseudo_normal,
                const int* __restrict__ n_contrib, const float* __restrict__ gt, float w_l1, float w_normal,
-               float w_opacity, float* __restrict__ dL_dimage, float* __restrict__ dL_dopacity,
-               float* __restrict__ dL_dfeature, float* __restrict__ sums)
+               float w_opacity, const float* __restrict__ extra_dimage, float* __restrict__ dL_dimage,
+               float* __restrict__ dL_dopacity, float* __restrict__ dL_dfeature, float* __restrict__ sums)
 {
     __shared__ float s_part[4];
     float s_l1 = 0.f, s_n = 0.f, s_o = 0.f;
@@ -350,7 +370,7 @@ s1_loss_kernel(int HW, const float* __restrict__ image, const float* __restrict_
         for (int c = 0; c < 3; c++) {
             const float d0 = image[(size_t)c * HW + i] - gt[(size_t)c * HW + i];
             s_l1 += fabsf(d0);
-            dL_dimage[(size_t)c * HW + i] = w_l1 * signf_(d0);
+            dL_dimage[(size_t)c * HW + i] = w_l1 * signf_(d0) + (extra_dimage ? extra_dimage[(size_t)c * HW + i] : 0.f);
             const float Fn = feature[(size_t)c * HW + i];
             const float dn = Fn * scale - pseudo_normal[(size_t)c * HW + i];
             s_n += dn * dn;
@@ -522,12 +542,21 @@ void launch_s2_activate_backward(hipStream_t s, int P, const float* xyz, const f
     check_launch(s, false, "s2_activate_backward_kernel");
 }
 
+void launch_s2_pbr_srgb(hipStream_t s, int HW, const float* opacity, const float* feature, const int* n_contrib,
+                        const float* bg, float* srgb)
+{
+    s2_pbr_srgb_kernel<<<(HW + 255) / 256, 256, 0, s>>>(HW, opacity, feature, n_contrib, bg, srgb);
+    check_launch(s, false, "s2_pbr_srgb_kernel");
+}
+
 void launch_s2_loss(hipStream_t s, int HW, const float* image, const float* opacity, const float* feature,
                     const float* pseudo_normal, const int* n_contrib, const float* gt, const float* bg, float w_l1,
-                    float w_pbr, float w_normal, float* dL_dimage, float* dL_dopacity, float* dL_dfeature, float* sums)
+                    float w_pbr, float w_normal, const float* extra_dimage, const float* extra_dsrgb, float* dL_dimage,
+                    float* dL_dopacity, float* dL_dfeature, float* sums)
 {
-    s2_loss_kernel<<<min((HW + 255) / 256, 768), 256, 0, s>>>(HW, image, opacity, feature, pseudo_normal, n_contrib, gt, bg, w_l1,
-                                                    w_pbr, w_normal, dL_dimage, dL_dopacity, dL_dfeature, sums);
+    s2_loss_kernel<<<min((HW + 255) / 256, 768), 256, 0, s>>>(HW, image, opacity, feature, pseudo_normal, n_contrib, gt,
+                                                            bg, w_l1, w_pbr, w_normal, extra_dimage, extra_dsrgb,
+                                                            dL_dimage, dL_dopacity, dL_dfeature, sums);
     check_launch(s, false, "s2_loss_kernel");
 }
 
@@ -546,11 +575,12 @@ void launch_s1_pack(hipStream_t s, int P, const float* xyz, const float* viewmat
 
 void launch_s1_loss(hipStream_t s, int HW, const float* image, const float* opacity, const float* feature,
                     const float* pseudo_normal, const int* n_contrib, const float* gt, float w_l1, float w_normal,
-                    float w_opacity, float* dL_dimage, float* dL_dopacity, float* dL_dfeature, float* sums)
+                    float w_opacity, const float* extra_dimage, float* dL_dimage, float* dL_dopacity, float* dL_dfeature,
+                    float* sums)
 {
     s1_loss_kernel<<<min((HW + 255) / 256, 768), 256, 0, s>>>(HW, image, opacity, feature, pseudo_normal, n_contrib, gt,
-                                                            w_l1, w_normal, w_opacity, dL_dimage, dL_dopacity,
-                                                            dL_dfeature, sums);
+                                                            w_l1, w_normal, w_opacity, extra_dimage, dL_dimage,
+                                                            dL_dopacity, dL_dfeature, sums);
     check_launch(s, false, "s1_loss_kernel");
 }
 

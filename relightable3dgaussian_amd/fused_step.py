@@ -24,7 +24,7 @@ import torch
 import torch.nn.functional as F
 
 from . import _lib, rasterizer_ops, shading_ops
-from .train_step import tv_loss, update_visibility
+from .train_step import LAMBDA_DSSIM, update_visibility
 
 
 class AdamGroup(C.Structure):
@@ -110,7 +110,8 @@ class FusedStage2Step:
         self.a_viewdirs = torch.empty(P, 3, **f)
         self.shade_out = torch.empty(P, shading_ops.NOUT, **f)
         self.features = torch.empty(P, 16, **f)
-        self.sums = torch.zeros(5, **f)                       # l1, pbr l1, normal mse, light l1 (unweighted sums), TV(env)
+        # unweighted sums: l1, pbr l1, normal mse, light l1, TV(env), SSIM(image), SSIM(pbr)
+        self.sums = torch.zeros(7, **f)
         self.d_pbr, self.d_diffuse = torch.empty(P, 3, **f), torch.empty(P, 3, **f)
         # flat gradient slab: [xyz3 normal3 scaling3 rotation4 opacity1 base3 rough1 | shs 3M | incidents 3M] per group
         sizes = dict(xyz=3 * P, normal=3 * P, scaling=3 * P, rotation=4 * P, opacity=P, base_color=3 * P, roughness=P,
@@ -229,15 +230,26 @@ class FusedStage2Step:
                 self.sums[3:].data_ptr()), "stage2_pack_features")
             fw = pending.finish(self._order_stream)
             R, n_contrib, image, opacity, depth, feature, pseudo_normal, sxyz, weights, radii, geom, binning, img = fw
-            # image-space loss terms and their gradients (one slab: dL_dimage 3 | dL_dopacity 1 | dL_dfeature 16; the depth image carries no loss)
-            g = torch.empty((20, H, W), dtype=torch.float32, device=dev)
+            # image-space loss terms and their gradients.  One slab: dL_dimage 3 | dL_dopacity 1 | dL_dfeature 16 | sRGB PBR
+            # image 3 | SSIM partials 2x9 | SSIM gradients 2x3 (the depth image carries no loss)
+            g = torch.empty((47, H, W), dtype=torch.float32, device=dev)
             if self._zero_depth_grad is None or self._zero_depth_grad.shape[-2:] != (H, W):
                 self._zero_depth_grad = torch.zeros((1, H, W), dtype=torch.float32, device=dev)
+            gt_c, bg_c = gt.contiguous(), bg.contiguous()
+            srgb, part_i, part_p, gs_i, gs_p = g[20:23], g[23:32], g[32:41], g[41:44], g[44:47]
+            lam = LAMBDA_DSSIM
+            _lib.check(L.r3dg_stage2_pbr_srgb(stream(), W, H, opacity.data_ptr(), feature.data_ptr(),
+                                              n_contrib.data_ptr(), bg_c.data_ptr(), srgb.data_ptr()), "stage2_pbr_srgb")
+            for x_img, part, gs, slot, wt in ((image, part_i, gs_i, 5, 1.0), (srgb, part_p, gs_p, 6, self.w["pbr"])):
+                _lib.check(L.r3dg_ssim_forward(stream(), W, H, 3, x_img.data_ptr(), gt_c.data_ptr(), part.data_ptr(),
+                                               self.sums[slot:].data_ptr()), "ssim_forward")
+                _lib.check(L.r3dg_ssim_backward(stream(), W, H, 3, x_img.data_ptr(), gt_c.data_ptr(), part.data_ptr(),
+                                                -wt * lam / (3.0 * N), gs.data_ptr()), "ssim_backward")
             _lib.check(L.r3dg_stage2_loss(
                 stream(), W, H, image.data_ptr(), opacity.data_ptr(), feature.data_ptr(), pseudo_normal.data_ptr(),
-                n_contrib.data_ptr(), gt.contiguous().data_ptr(), bg.contiguous().data_ptr(),
-                self.w["l1"] / (3.0 * N), self.w["pbr"] / (3.0 * N), self.w["normal"] / (3.0 * N), g[0:3].data_ptr(),
-                g[3:4].data_ptr(), g[4:20].data_ptr(), self.sums.data_ptr()), "stage2_loss")
+                n_contrib.data_ptr(), gt_c.data_ptr(), bg_c.data_ptr(), self.w["l1"] * (1.0 - lam) / (3.0 * N),
+                self.w["pbr"] * (1.0 - lam) / (3.0 * N), self.w["normal"] / (3.0 * N), gs_i.data_ptr(), gs_p.data_ptr(),
+                g[0:3].data_ptr(), g[3:4].data_ptr(), g[4:20].data_ptr(), self.sums.data_ptr()), "stage2_loss")
             bw = rasterizer_ops.rasterize_gaussians_backward(
                 bg, self.xyz, self.features, radii, empty, self.a_scales, self.a_rot, 1.0, empty, vm,
                 cam.full_proj_transform, cam.tanfovx, cam.tanfovy, g[0:3], g[3:4], self._zero_depth_grad, g[4:20], self.shs, 3,
@@ -303,9 +315,11 @@ class FusedStage2Step:
     def loss(self):
         """Loss value of the last forward_backward (a 0-d tensor; costs a few tiny kernels, so it is on demand)."""
         N, P = self._N, self.P
-        w = torch.tensor([self.w["l1"] / (3.0 * N), self.w["pbr"] / (3.0 * N), self.w["normal"] / (3.0 * N),
-                          self.w["light"] / (3.0 * P), self.w["env_smooth"]], device=self.dev)
-        return (self.sums * w).sum()
+        lam = LAMBDA_DSSIM
+        w = torch.tensor([self.w["l1"] * (1 - lam) / (3.0 * N), self.w["pbr"] * (1 - lam) / (3.0 * N),
+                          self.w["normal"] / (3.0 * N), self.w["light"] / (3.0 * P), self.w["env_smooth"],
+                          -lam / (3.0 * N), -self.w["pbr"] * lam / (3.0 * N)], device=self.dev)
+        return (self.sums * w).sum() + lam * (1.0 + self.w["pbr"])
 
     _GROUPS_A = (5,)                       # indices into self.opt.groups: shs
     _GROUPS_C = (0, 1, 2, 3, 4, 6, 7, 9)   # xyz normal scaling rotation opacity base_color roughness env
@@ -365,7 +379,7 @@ class FusedStage1Step:
         self.a_scales, self.a_rot = torch.empty(P, 3, **f), torch.empty(P, 4, **f)
         self.a_opacity, self.a_normal = torch.empty(P, 1, **f), torch.empty(P, 3, **f)
         self.features = torch.empty(P, 5, **f)
-        self.sums = torch.zeros(3, **f)
+        self.sums = torch.zeros(4, **f)          # l1, normal mse, opacity reg, SSIM(image)
         names = ("shs", "xyz", "normal", "scaling", "rotation", "opacity")
         sizes = {k: getattr(self, k).numel() for k in names}
         self.grad_flat = torch.zeros(sum(sizes.values()), **f)
@@ -413,13 +427,21 @@ class FusedStage1Step:
             self.sums.zero_()
             fw = pending.finish()
             R, n_contrib, image, opacity, depth, feature, pseudo_normal, sxyz, weights, radii, geom, binning, img = fw
-            g = torch.empty((9, H, W), dtype=torch.float32, device=dev)      # dL_dimage 3 | dL_dopacity 1 | dL_dfeature 5
+            # dL_dimage 3 | dL_dopacity 1 | dL_dfeature 5 | SSIM partials 9 | SSIM gradient 3
+            g = torch.empty((21, H, W), dtype=torch.float32, device=dev)
             if self._zero_depth_grad is None or self._zero_depth_grad.shape[-2:] != (H, W):
                 self._zero_depth_grad = torch.zeros((1, H, W), dtype=torch.float32, device=dev)
+            gt_c = gt.contiguous()
+            lam = LAMBDA_DSSIM
+            _lib.check(L.r3dg_ssim_forward(stream(), W, H, 3, image.data_ptr(), gt_c.data_ptr(), g[9:18].data_ptr(),
+                                           self.sums[3:].data_ptr()), "ssim_forward")
+            _lib.check(L.r3dg_ssim_backward(stream(), W, H, 3, image.data_ptr(), gt_c.data_ptr(), g[9:18].data_ptr(),
+                                            -lam / (3.0 * N), g[18:21].data_ptr()), "ssim_backward")
             _lib.check(L.r3dg_stage1_loss(
                 stream(), W, H, image.data_ptr(), opacity.data_ptr(), feature.data_ptr(), pseudo_normal.data_ptr(),
-                n_contrib.data_ptr(), gt.contiguous().data_ptr(), 1.0 / (3.0 * N), 0.1 / (3.0 * N), 0.001 / N,
-                g[0:3].data_ptr(), g[3:4].data_ptr(), g[4:9].data_ptr(), self.sums.data_ptr()), "stage1_loss")
+                n_contrib.data_ptr(), gt_c.data_ptr(), (1.0 - lam) / (3.0 * N), 0.1 / (3.0 * N), 0.001 / N,
+                g[18:21].data_ptr(), g[0:3].data_ptr(), g[3:4].data_ptr(), g[4:9].data_ptr(), self.sums.data_ptr()),
+                "stage1_loss")
             bw = rasterizer_ops.rasterize_gaussians_backward(
                 bg, self.xyz, self.features, radii, empty, self.a_scales, self.a_rot, 1.0, empty, vm,
                 cam.full_proj_transform, cam.tanfovx, cam.tanfovy, g[0:3], g[3:4], self._zero_depth_grad, g[4:9],
@@ -443,8 +465,9 @@ class FusedStage1Step:
 
     def loss(self):
         N = self._N
-        w = torch.tensor([1.0 / (3.0 * N), 0.1 / (3.0 * N), 0.001 / N], device=self.dev)
-        return (self.sums * w).sum()
+        lam = LAMBDA_DSSIM
+        w = torch.tensor([(1.0 - lam) / (3.0 * N), 0.1 / (3.0 * N), 0.001 / N, -lam / (3.0 * N)], device=self.dev)
+        return (self.sums * w).sum() + lam
 
     def optimizer_step(self):
         if self._handle is not None:

@@ -46,6 +46,34 @@ def update_visibility(xyz, scales, rotations, opacity, normal, sample_num):
     return torch.cat(vis, 0), torch.cat(dirs_all, 0), torch.cat(areas_all, 0), tracer
 
 
+LAMBDA_DSSIM = 0.2          # arguments/__init__.py:125
+
+
+def ssim(img1, img2, window_size=11):
+    """utils/loss_utils.py:20-63 restated: Gaussian window (sigma 1.5), zero padding, mean over channels and pixels."""
+    C = img1.size(-3)
+    g = torch.tensor([math.exp(-(x - window_size // 2) ** 2 / (2 * 1.5 ** 2)) for x in range(window_size)],
+                     dtype=torch.float32)
+    g = (g / g.sum()).to(img1.device)
+    window = (g[:, None] @ g[None, :])[None, None].expand(C, 1, window_size, window_size).contiguous()
+    x, y = img1[None] if img1.dim() == 3 else img1, img2[None] if img2.dim() == 3 else img2
+    pad = window_size // 2
+    mu1 = F.conv2d(x, window, padding=pad, groups=C)
+    mu2 = F.conv2d(y, window, padding=pad, groups=C)
+    mu1_sq, mu2_sq, mu1_mu2 = mu1.pow(2), mu2.pow(2), mu1 * mu2
+    sigma1_sq = F.conv2d(x * x, window, padding=pad, groups=C) - mu1_sq
+    sigma2_sq = F.conv2d(y * y, window, padding=pad, groups=C) - mu2_sq
+    sigma12 = F.conv2d(x * y, window, padding=pad, groups=C) - mu1_mu2
+    C1, C2 = 0.01 ** 2, 0.03 ** 2
+    ssim_map = ((2 * mu1_mu2 + C1) * (2 * sigma12 + C2)) / ((mu1_sq + mu2_sq + C1) * (sigma1_sq + sigma2_sq + C2))
+    return ssim_map.mean()
+
+
+def image_loss(img, gt):
+    """(1 - lambda_dssim) * L1 + lambda_dssim * (1 - SSIM)  (neilf.py:225-239, render.py likewise)."""
+    return (1.0 - LAMBDA_DSSIM) * (img - gt).abs().mean() + LAMBDA_DSSIM * (1.0 - ssim(img, gt))
+
+
 def tv_loss(x):
     return (x[:, 1:] - x[:, :-1]).abs().mean() + (x[:, :, 1:] - x[:, :, :-1]).abs().mean()
 
@@ -92,7 +120,7 @@ class Stage2Step:
         pbr_img = r_pbr * opacity + (1 - opacity) * bg[:, None, None]
         pbr_srgb = torch.where(pbr_img <= 0.0031308, 12.92 * pbr_img,
                                1.055 * pbr_img.clamp_min(0.0031308) ** (1 / 2.4) - 0.055)
-        loss = (image - gt).abs().mean() + 1.0 * (pbr_srgb - gt).abs().mean()                      # l1 + lambda_pbr l1
+        loss = image_loss(image, gt) + 1.0 * image_loss(pbr_srgb, gt)          # L1/SSIM mix on both images, lambda_pbr 1
         loss = loss + 0.01 * F.mse_loss(r_normal, pseudo_normal.detach())                            # normal_render_depth
         mean_light = diffuse_light.mean(-1, keepdim=True).expand_as(diffuse_light)
         loss = loss + 0.01 * F.l1_loss(diffuse_light, mean_light)                                    # lambda_light
