@@ -1,7 +1,7 @@
 // SSIM term of the training loss (utils/loss_utils.py:20-63: 11x11 Gaussian window, sigma 1.5, zero padding, C1 = 0.01^2,
 // C2 = 0.03^2, mean over all channels and pixels), forward and backward w.r.t. the rendered image, for gfx950.
 // The reference runs five grouped conv2d calls plus a dozen elementwise kernels and their autograd twins; here:
-//   ssim_forward_kernel   one 16x16 tile (+5 pixel halo) per workgroup: both images staged in LDS, separable window
+//   ssim_forward_kernel   one 32x32 tile (+5 pixel halo) per workgroup, 4 outputs per thread per pass: both images staged in LDS, separable window
 //                         (11 horizontal taps into LDS, 11 vertical taps from it) for mu1, mu2, E[x^2], E[y^2], E[xy];
 //                         writes the three per-pixel partial derivatives dS/dmu1, dS/dE[x^2], dS/dE[xy] and adds the tile's
 //                         SSIM sum to *sum (one atomic per workgroup);
@@ -13,8 +13,9 @@
 namespace r3dg {
 
 constexpr int SSIM_R = 5;                    // window radius (window_size 11)
-constexpr int SSIM_T = 16;                   // tile edge
-constexpr int SSIM_E = SSIM_T + 2 * SSIM_R;  // 26: tile + halo
+constexpr int SSIM_T = 32;                   // tile edge (outputs)
+constexpr int SSIM_E = SSIM_T + 2 * SSIM_R;  // 42: tile + halo
+constexpr int SSIM_B = 4;                    // outputs per thread along the filtered axis (sliding window in registers)
 
 // gaussian(11, 1.5) / sum, the fp32 values the reference's create_window produces (loss_utils.py:20-29)
 __constant__ float kSsimWin[11] = {1.028380124e-03f, 7.598758209e-03f, 3.600077331e-02f, 1.093606874e-01f,
@@ -29,6 +30,9 @@ __device__ __forceinline__ float block_sum_256s(float v, float* s_part)
     return s_part[0] + s_part[1] + s_part[2] + s_part[3];
 }
 
+// Both kernels: one 32x32 output tile per 256-thread workgroup.  Horizontal pass: a work item = (row of the 42-row
+// halo region, group of 4 adjacent columns): 14 LDS reads per map feed 4 outputs.  Vertical pass: a work item = (column,
+// group of 4 adjacent rows), exactly one per thread.
 __global__ void __launch_bounds__(256)
 ssim_forward_kernel(int W, int H, const float* __restrict__ x, const float* __restrict__ y,
                     float* __restrict__ partials, float* __restrict__ sum)
@@ -45,50 +49,71 @@ ssim_forward_kernel(int W, int H, const float* __restrict__ x, const float* __re
         const int r = i / SSIM_E, q = i % SSIM_E;
         const int gy = by + r - SSIM_R, gx = bx + q - SSIM_R;
         const bool in = gx >= 0 && gx < W && gy >= 0 && gy < H;                 // zero padding
-        s_x[r][q] = in ? xc[(size_t)gy * W + gx] : 0.f;
-        s_y[r][q] = in ? yc[(size_t)gy * W + gx] : 0.f;
+        const size_t o = (size_t)(in ? gy : 0) * W + (in ? gx : 0);
+        s_x[r][q] = in ? xc[o] : 0.f;
+        s_y[r][q] = in ? yc[o] : 0.f;
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < SSIM_E * SSIM_T; i += 256) {               // horizontal taps
-        const int r = i / SSIM_T, q = i % SSIM_T;
-        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f, a4 = 0.f;
+    float w[11];
 #pragma unroll
-        for (int k = 0; k < 11; k++) {
-            const float w = kSsimWin[k], xv = s_x[r][q + k], yv = s_y[r][q + k];
-            a0 += w * xv; a1 += w * yv; a2 += w * xv * xv; a3 += w * yv * yv; a4 += w * xv * yv;
+    for (int k = 0; k < 11; k++) w[k] = kSsimWin[k];
+    for (int i = threadIdx.x; i < SSIM_E * (SSIM_T / SSIM_B); i += 256) {     // horizontal taps
+        const int r = i / (SSIM_T / SSIM_B), q0 = (i % (SSIM_T / SSIM_B)) * SSIM_B;
+        float xv[SSIM_B + 10], yv[SSIM_B + 10];
+#pragma unroll
+        for (int k = 0; k < SSIM_B + 10; k++) { xv[k] = s_x[r][q0 + k]; yv[k] = s_y[r][q0 + k]; }
+#pragma unroll
+        for (int o = 0; o < SSIM_B; o++) {
+            float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f, a4 = 0.f;
+#pragma unroll
+            for (int k = 0; k < 11; k++) {
+                const float wx = w[k] * xv[o + k], wy = w[k] * yv[o + k];
+                a0 += wx; a1 += wy; a2 += wx * xv[o + k]; a3 += wy * yv[o + k]; a4 += wx * yv[o + k];
+            }
+            s_h[0][r][q0 + o] = a0; s_h[1][r][q0 + o] = a1; s_h[2][r][q0 + o] = a2; s_h[3][r][q0 + o] = a3;
+            s_h[4][r][q0 + o] = a4;
         }
-        s_h[0][r][q] = a0; s_h[1][r][q] = a1; s_h[2][r][q] = a2; s_h[3][r][q] = a3; s_h[4][r][q] = a4;
     }
     __syncthreads();
-    const int tx = threadIdx.x % SSIM_T, ty = threadIdx.x / SSIM_T;
-    const int px = bx + tx, py = by + ty;
-    float ssim = 0.f;
-    if (px < W && py < H) {
-        float mu1 = 0.f, mu2 = 0.f, e11 = 0.f, e22 = 0.f, e12 = 0.f;
+    const int tx = threadIdx.x % SSIM_T, ty0 = (threadIdx.x / SSIM_T) * SSIM_B;
+    const int px = bx + tx;
+    float acc[5][SSIM_B];
 #pragma unroll
-        for (int k = 0; k < 11; k++) {                                           // vertical taps
-            const float w = kSsimWin[k];
-            mu1 += w * s_h[0][ty + k][tx]; mu2 += w * s_h[1][ty + k][tx];
-            e11 += w * s_h[2][ty + k][tx]; e22 += w * s_h[3][ty + k][tx]; e12 += w * s_h[4][ty + k][tx];
+    for (int m = 0; m < 5; m++) {
+        float col[SSIM_B + 10];
+#pragma unroll
+        for (int k = 0; k < SSIM_B + 10; k++) col[k] = s_h[m][ty0 + k][tx];
+#pragma unroll
+        for (int o = 0; o < SSIM_B; o++) {
+            float a = 0.f;
+#pragma unroll
+            for (int k = 0; k < 11; k++) a += w[k] * col[o + k];
+            acc[m][o] = a;
         }
-        const float C1 = 0.01f * 0.01f, C2 = 0.03f * 0.03f;
-        const float A = 2.f * mu1 * mu2 + C1;
-        const float B = 2.f * (e12 - mu1 * mu2) + C2;
-        const float C = mu1 * mu1 + mu2 * mu2 + C1;
-        const float D = (e11 - mu1 * mu1) + (e22 - mu2 * mu2) + C2;
-        const float inv = 1.f / (C * D);
-        ssim = A * B * inv;
-        // partial derivatives of ssim w.r.t. mu1, E[x^2], E[xy] (treated as independent window averages)
-        const float d_mu1 = 2.f * mu2 * (B - A) * inv - ssim * 2.f * mu1 * (D - C) * inv;
-        const float d_e11 = -ssim / D;
-        const float d_e12 = 2.f * A * inv;
-        const size_t o = (size_t)py * W + px;
-        float* pc = partials + (size_t)c * 3 * HW;
-        pc[o] = d_mu1;
-        pc[HW + o] = d_e11;
-        pc[2 * HW + o] = d_e12;
     }
-    const float tot = block_sum_256s(ssim, s_part);
+    float ssim_sum = 0.f;
+    float* pc = partials + (size_t)c * 3 * HW;
+#pragma unroll
+    for (int o = 0; o < SSIM_B; o++) {
+        const int py = by + ty0 + o;
+        if (px < W && py < H) {
+            const float mu1 = acc[0][o], mu2 = acc[1][o], e11 = acc[2][o], e22 = acc[3][o], e12 = acc[4][o];
+            const float C1 = 0.01f * 0.01f, C2 = 0.03f * 0.03f;
+            const float A = 2.f * mu1 * mu2 + C1;
+            const float B = 2.f * (e12 - mu1 * mu2) + C2;
+            const float C = mu1 * mu1 + mu2 * mu2 + C1;
+            const float D = (e11 - mu1 * mu1) + (e22 - mu2 * mu2) + C2;
+            const float inv = 1.f / (C * D);
+            const float ssim = A * B * inv;
+            ssim_sum += ssim;
+            // partial derivatives of ssim w.r.t. mu1, E[x^2], E[xy] (treated as independent window averages)
+            const size_t off = (size_t)py * W + px;
+            pc[off] = 2.f * mu2 * (B - A) * inv - ssim * 2.f * mu1 * (D - C) * inv;
+            pc[HW + off] = -ssim / D;
+            pc[2 * HW + off] = 2.f * A * inv;
+        }
+    }
+    const float tot = block_sum_256s(ssim_sum, s_part);
     if (threadIdx.x == 0 && sum != nullptr) atomicAdd(sum, tot);
 }
 
@@ -106,35 +131,56 @@ ssim_backward_kernel(int W, int H, const float* __restrict__ x, const float* __r
         const int r = i / SSIM_E, q = i % SSIM_E;
         const int gy = by + r - SSIM_R, gx = bx + q - SSIM_R;
         const bool in = gx >= 0 && gx < W && gy >= 0 && gy < H;      // windows centred outside the image do not exist
-        const size_t o = (size_t)gy * W + gx;
+        const size_t o = (size_t)(in ? gy : 0) * W + (in ? gx : 0);
         s_p[0][r][q] = in ? pc[o] : 0.f;
         s_p[1][r][q] = in ? pc[HW + o] : 0.f;
         s_p[2][r][q] = in ? pc[2 * HW + o] : 0.f;
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < SSIM_E * SSIM_T; i += 256) {
-        const int r = i / SSIM_T, q = i % SSIM_T;
-        float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+    float w[11];
 #pragma unroll
-        for (int k = 0; k < 11; k++) {
-            const float w = kSsimWin[k];
-            a0 += w * s_p[0][r][q + k]; a1 += w * s_p[1][r][q + k]; a2 += w * s_p[2][r][q + k];
+    for (int k = 0; k < 11; k++) w[k] = kSsimWin[k];
+    for (int i = threadIdx.x; i < SSIM_E * (SSIM_T / SSIM_B); i += 256) {
+        const int r = i / (SSIM_T / SSIM_B), q0 = (i % (SSIM_T / SSIM_B)) * SSIM_B;
+#pragma unroll
+        for (int m = 0; m < 3; m++) {
+            float v[SSIM_B + 10];
+#pragma unroll
+            for (int k = 0; k < SSIM_B + 10; k++) v[k] = s_p[m][r][q0 + k];
+#pragma unroll
+            for (int o = 0; o < SSIM_B; o++) {
+                float a = 0.f;
+#pragma unroll
+                for (int k = 0; k < 11; k++) a += w[k] * v[o + k];
+                s_h[m][r][q0 + o] = a;
+            }
         }
-        s_h[0][r][q] = a0; s_h[1][r][q] = a1; s_h[2][r][q] = a2;
     }
     __syncthreads();
-    const int tx = threadIdx.x % SSIM_T, ty = threadIdx.x / SSIM_T;
-    const int px = bx + tx, py = by + ty;
-    if (px < W && py < H) {
-        float c0 = 0.f, c1 = 0.f, c2 = 0.f;
+    const int tx = threadIdx.x % SSIM_T, ty0 = (threadIdx.x / SSIM_T) * SSIM_B;
+    const int px = bx + tx;
+    float acc[3][SSIM_B];
 #pragma unroll
-        for (int k = 0; k < 11; k++) {
-            const float w = kSsimWin[k];
-            c0 += w * s_h[0][ty + k][tx]; c1 += w * s_h[1][ty + k][tx]; c2 += w * s_h[2][ty + k][tx];
+    for (int m = 0; m < 3; m++) {
+        float col[SSIM_B + 10];
+#pragma unroll
+        for (int k = 0; k < SSIM_B + 10; k++) col[k] = s_h[m][ty0 + k][tx];
+#pragma unroll
+        for (int o = 0; o < SSIM_B; o++) {
+            float a = 0.f;
+#pragma unroll
+            for (int k = 0; k < 11; k++) a += w[k] * col[o + k];
+            acc[m][o] = a;
         }
-        const size_t o = (size_t)py * W + px;
-        const float xv = x[c * HW + o], yv = y[c * HW + o];
-        grad_x[c * HW + o] = scale * (c0 + 2.f * xv * c1 + yv * c2);
+    }
+#pragma unroll
+    for (int o = 0; o < SSIM_B; o++) {
+        const int py = by + ty0 + o;
+        if (px < W && py < H) {
+            const size_t off = (size_t)py * W + px;
+            const float xv = x[c * HW + off], yv = y[c * HW + off];
+            grad_x[c * HW + off] = scale * (acc[0][o] + 2.f * xv * acc[1][o] + yv * acc[2][o]);
+        }
     }
 }
 
