@@ -17,6 +17,8 @@
  *   r3dg_bvh_build           <- construct_bvh (bvh/include/construct.cuh, bvh/src/construct.cu:147-265)
  *   r3dg_bvh_trace_opacity   <- trace_bvh_opacity_cuda (bvh/include/trace.cuh:50-55, bvh/src/trace.cu:196-286)
  *   r3dg_knn_dist2           <- SimpleKNN::knn (submodules/simple-knn/simple_knn.cu:185-221)
+ *   r3dg_densify_*           <- GaussianModel.add_densification_stats / densify_and_prune / prune / reset_opacity
+ *                               (scene/gaussian_model.py:931-937, :893-915, :917-929, :563-566; train.py:158-175)
  */
 #ifndef R3DG_HIP_H
 #define R3DG_HIP_H
@@ -286,6 +288,68 @@ typedef struct r3dg_adam_group {
 } r3dg_adam_group;
 int r3dg_adam_step(void* stream, int n_groups, const r3dg_adam_group* groups, float beta1, float beta2, float eps,
                    int step, float grad_scale);
+
+/* ---- densification bookkeeping -------------------------------------------------------------------
+ * r3dg_densify_accumulate: GaussianModel.add_densification_stats (scene/gaussian_model.py:931-937) + the max-radii
+ *   update of train.py:164-165, one pass.  The visibility filter is radii > 0 (render.py / neilf.py `visibility_filter`).
+ *   d_viewspace_grad [P,3] is the gradient slot of the screen-space dummy (dL_dmeans2D); d_normal_grad [P,3] is the
+ *   gradient of the raw normal parameter (NULL: the normal statistic is left alone); d_weights [P] are the rasterizer's
+ *   per-Gaussian blend weights.  All five statistics are [P] floats updated in place. */
+int r3dg_densify_accumulate(void* stream, int P, const float* d_viewspace_grad, const float* d_normal_grad,
+                            const int32_t* d_radii, const float* d_weights, float* d_xyz_gradient_accum,
+                            float* d_normal_gradient_accum, float* d_denom, float* d_weights_accum,
+                            float* d_max_radii2D);
+
+/* Thresholds of one densify_and_prune (mode 0, gaussian_model.py:893-915) or prune (mode 1, :917-929) call.  The
+ * products the reference forms in Python doubles are passed already rounded to fp32:
+ *   dense_size = percent_dense * scene_extent (:855, :804), world_size_limit = 0.1 * extent (:909),
+ *   split_divisor = 0.8 * n_split (:814).  max_screen_size 0 = None (no screen / world size tests). */
+typedef struct r3dg_densify_config {
+    int32_t mode;
+    int32_t n_split;
+    float grad_threshold, grad_normal_threshold, min_opacity, weights_threshold;
+    float dense_size, world_size_limit, split_divisor, max_screen_size;
+} r3dg_densify_config;
+
+/* r3dg_densify_plan: every decision of the call as ONE row map.  d_src_row / d_kind need max(2, n_split) * P entries;
+ *   on return entries [0, d_counts[0]) hold, in the reference's output order (surviving originals, surviving clones,
+ *   n_split blocks of surviving split children), the source row and its kind: -1 original (Adam moments travel with
+ *   it), -2 clone (moments 0), k >= 0 split child that uses row k of the caller's standard-normal table
+ *   [n_split * d_counts[3], 3] (row b * d_counts[3] + rank of the parent among ALL split Gaussians -- the row
+ *   torch.normal would have filled, so the random stream is consumed exactly as in the reference).
+ *   d_counts int32[8]: [0] rows out, [1] surviving originals, [2] surviving clones, [3] split Gaussians,
+ *   [4] split Gaussians whose children survive.  d_temp: r3dg_densify_temp_bytes(P).  Statistics are [P] floats. */
+size_t r3dg_densify_temp_bytes(int P);
+int r3dg_densify_plan(void* stream, int P, const r3dg_densify_config* config, const float* d_scaling_raw,
+                      const float* d_opacity_raw, const float* d_xyz_gradient_accum,
+                      const float* d_normal_gradient_accum, const float* d_denom, const float* d_weights_accum,
+                      const float* d_max_radii2D, int32_t* d_src_row, int32_t* d_kind, int32_t* d_counts, void* d_temp);
+
+/* r3dg_densify_gather: builds every output tensor from the row map in ONE launch (the reference runs cat + cat +
+ *   mask + mask over each parameter and both Adam moments: cat_tensors_to_optimizer :721-744, _prune_optimizer :681-698).
+ *   Groups are [rows, row_floats] fp32; exp_avg pointers may be NULL (no optimizer state).  Split children: the
+ *   ROLE_XYZ group receives R(q) (exp(scaling) * z) + xyz, the ROLE_SCALING group log(exp(scaling) / split_divisor)
+ *   (densify_and_split :806-814); d_xyz / d_scaling_raw / d_rotation_raw are the SOURCE tensors of those formulas. */
+#define R3DG_DENSIFY_MAX_GROUPS 24
+#define R3DG_DENSIFY_ROLE_COPY 0
+#define R3DG_DENSIFY_ROLE_XYZ 1
+#define R3DG_DENSIFY_ROLE_SCALING 2
+typedef struct r3dg_densify_group {
+    const float* src_param;
+    const float* src_exp_avg;
+    const float* src_exp_avg_sq;
+    float* dst_param;
+    float* dst_exp_avg;
+    float* dst_exp_avg_sq;
+    uint32_t row_floats, role;
+} r3dg_densify_group;
+int r3dg_densify_gather(void* stream, int rows_out, const int32_t* d_src_row, const int32_t* d_kind, int n_groups,
+                        const r3dg_densify_group* groups, const float* d_xyz, const float* d_scaling_raw,
+                        const float* d_rotation_raw, const float* d_normal_table, float split_divisor);
+
+/* GaussianModel.reset_opacity (:563-566): raw opacity <- inverse_sigmoid(min(sigmoid(raw), 0.01)) and zeroed Adam
+ * moments (replace_tensor_to_optimizer :667-679; moment pointers may be NULL). */
+int r3dg_reset_opacity(void* stream, int P, float* d_opacity_raw, float* d_exp_avg, float* d_exp_avg_sq);
 
 /* distCUDA2 (submodules/simple-knn/spatial.cu:14-26 -> SimpleKNN::knn, simple_knn.cu:185-221): d_mean_dist2[i] = mean of
  * the squared distances from point i to its 3 nearest neighbours (FLT_MAX terms when P < 4, like the reference). */

@@ -66,6 +66,11 @@ _SIGNATURES = {
     "r3dg_stage1_activate_backward": (_i, [_p, _i] + [_p] * 16),
     "r3dg_stage2_env_backward": (_i, [_p, _i, _i, _p, _p, _p, _f, _p, _p]),
     "r3dg_adam_step": (_i, [_p, _i, _p, _f, _f, _f, _i, _f]),
+    "r3dg_densify_accumulate": (_i, [_p, _i] + [_p] * 9),
+    "r3dg_densify_temp_bytes": (C.c_size_t, [_i]),
+    "r3dg_densify_plan": (_i, [_p, _i] + [_p] * 12),
+    "r3dg_densify_gather": (_i, [_p, _i, _p, _p, _i, _p, _p, _p, _p, _p, _f]),
+    "r3dg_reset_opacity": (_i, [_p, _i, _p, _p, _p]),
     "r3dg_knn_temp_bytes": (C.c_size_t, [_i]),
     "r3dg_knn_dist2": (_i, [_p, _i, _p, _p, _p]),
     "r3dg_bvh_build_temp_bytes": (C.c_size_t, [_i]),

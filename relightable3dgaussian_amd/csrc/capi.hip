@@ -114,6 +114,18 @@ void launch_s2_env_backward(hipStream_t s, int He, int We, const float* raw, con
 uint32_t tile_sort_small_cap();
 void launch_tile_sort(hipStream_t s, int T, const uint32_t* tile_order, const uint32_t* ranges, const uint32_t* big_list,
                       const uint32_t* big_count, uint64_t* keys, uint32_t* vals, uint64_t* scratch);
+void launch_densify_accumulate(hipStream_t s, int P, const float* viewspace_grad, const float* normal_grad,
+                               const int* radii, const float* weights, float* xyz_accum, float* normal_accum,
+                               float* denom, float* weights_accum, float* max_radii2D);
+size_t densify_temp_bytes(size_t P);
+void launch_densify_plan(hipStream_t s, int P, const r3dg_densify_config& cfg, const float* scaling_raw,
+                         const float* opacity_raw, const float* xyz_accum, const float* normal_accum,
+                         const float* denom, const float* weights_accum, const float* max_radii2D, int32_t* src_row,
+                         int32_t* kind, int32_t* counts, void* temp);
+void launch_densify_gather(hipStream_t s, int P_out, const int32_t* src_row, const int32_t* kind, int n_groups,
+                           const r3dg_densify_group* groups, const float* xyz, const float* scaling_raw,
+                           const float* rotation_raw, const float* normal_table, float split_divisor);
+void launch_reset_opacity(hipStream_t s, int P, float cap, float* opacity_raw, float* exp_avg, float* exp_avg_sq);
 size_t knn_temp_bytes(size_t P);
 void knn_dist2(hipStream_t s, int P, const float* pts, float* dists, void* temp);
 size_t bvh_build_temp_bytes(size_t P);
@@ -136,13 +148,13 @@ void launch_transpose_selftest(hipStream_t s, int N, int dpp, const float* in, f
 // ---- optional per-stage timing with HIP events on the launch stream (bench.py's roofline numbers) ----
 enum Stage { ST_PREPROCESS = 0, ST_DUPKEYS, ST_SORT, ST_RANGES, ST_RENDER_FWD, ST_NORMAL, ST_RENDER_BWD, ST_PREPROCESS_BWD,
              ST_SHADE_FWD, ST_SHADE_BWD, ST_BVH_BUILD, ST_BVH_TRACE, ST_S2_ACTIVATE, ST_S2_PACK, ST_S2_LOSS,
-             ST_S2_UNPACK, ST_S2_ACTIVATE_BWD, ST_ADAM, ST_KNN, ST_SSIM, ST_COUNT };
+             ST_S2_UNPACK, ST_S2_ACTIVATE_BWD, ST_ADAM, ST_KNN, ST_SSIM, ST_DENSIFY, ST_COUNT };
 static const char* kStageNames[ST_COUNT] = {"preprocess", "duplicate_with_keys", "sort_pairs", "identify_tile_ranges",
                                             "render_forward", "pseudo_normal", "render_backward", "preprocess_backward",
                                             "shade_forward", "shade_backward", "bvh_build", "bvh_trace",
                                             "stage2_activate", "stage2_pack_features", "stage2_loss",
                                             "stage2_unpack_gradients", "stage2_activate_backward", "adam_step",
-                                            "knn_dist2", "ssim"};
+                                            "knn_dist2", "ssim", "densify"};
 static int g_profiling = 0;
 struct EventPair { hipEvent_t a, b; };
 static std::vector<EventPair> g_events[ST_COUNT];
@@ -1076,6 +1088,92 @@ int r3dg_adam_step(void* stream_, int n_groups, const r3dg_adam_group* groups, f
     return guarded([&]() -> int {
         StageTimer t((hipStream_t)stream_, ST_ADAM);
         launch_adam((hipStream_t)stream_, n_groups, groups, beta1, beta2, eps, step, grad_scale);
+        return R3DG_OK;
+    });
+}
+
+int r3dg_densify_accumulate(void* stream_, int P, const float* viewspace_grad, const float* normal_grad,
+                            const int32_t* radii, const float* weights, float* xyz_accum, float* normal_accum,
+                            float* denom, float* weights_accum, float* max_radii2D)
+{
+    if (P < 0) return invalid("densify_accumulate: bad P");
+    if (P == 0) return R3DG_OK;
+    if (!viewspace_grad || !radii || !weights || !xyz_accum || !normal_accum || !denom || !weights_accum || !max_radii2D)
+        return invalid("densify_accumulate: null buffer");
+    return guarded([&]() -> int {
+        StageTimer t((hipStream_t)stream_, ST_DENSIFY);
+        launch_densify_accumulate((hipStream_t)stream_, P, viewspace_grad, normal_grad, radii, weights, xyz_accum,
+                                  normal_accum, denom, weights_accum, max_radii2D);
+        return R3DG_OK;
+    });
+}
+
+size_t r3dg_densify_temp_bytes(int P) { return densify_temp_bytes((size_t)(P > 0 ? P : 0)); }
+
+int r3dg_densify_plan(void* stream_, int P, const r3dg_densify_config* cfg, const float* scaling_raw,
+                      const float* opacity_raw, const float* xyz_accum, const float* normal_accum, const float* denom,
+                      const float* weights_accum, const float* max_radii2D, int32_t* src_row, int32_t* kind,
+                      int32_t* counts, void* temp)
+{
+    if (P < 0) return invalid("densify_plan: bad P");
+    if (!cfg || !counts) return invalid("densify_plan: null config / counts");
+    if (cfg->mode != 0 && cfg->mode != 1) return invalid("densify_plan: mode is 0 (densify_and_prune) or 1 (prune)");
+    if (cfg->n_split < 1 || cfg->n_split > 8) return invalid("densify_plan: n_split out of range");
+    if (cfg->mode == 0 && !(cfg->split_divisor > 0.f)) return invalid("densify_plan: split_divisor must be positive");
+    if ((int64_t)P * (cfg->n_split > 2 ? cfg->n_split : 2) >= (1ll << 31)) return invalid("densify_plan: row map too large");
+    if (P > 0 && (!scaling_raw || !opacity_raw || !xyz_accum || !normal_accum || !denom || !weights_accum ||
+                  !max_radii2D || !src_row || !kind || !temp))
+        return invalid("densify_plan: null buffer");
+    return guarded([&]() -> int {
+        hipStream_t s = (hipStream_t)stream_;
+        if (P == 0) {
+            R3DG_HIP(hipMemsetAsync(counts, 0, 8 * sizeof(int32_t), s));
+            return R3DG_OK;
+        }
+        StageTimer t(s, ST_DENSIFY);
+        launch_densify_plan(s, P, *cfg, scaling_raw, opacity_raw, xyz_accum, normal_accum, denom, weights_accum,
+                            max_radii2D, src_row, kind, counts, temp);
+        return R3DG_OK;
+    });
+}
+
+int r3dg_densify_gather(void* stream_, int rows_out, const int32_t* src_row, const int32_t* kind, int n_groups,
+                        const r3dg_densify_group* groups, const float* xyz, const float* scaling_raw,
+                        const float* rotation_raw, const float* normal_table, float split_divisor)
+{
+    if (rows_out < 0) return invalid("densify_gather: bad row count");
+    if (n_groups < 0 || n_groups > R3DG_DENSIFY_MAX_GROUPS) return invalid("densify_gather: bad group count");
+    if (rows_out == 0 || n_groups == 0) return R3DG_OK;
+    if (!groups || !src_row || !kind) return invalid("densify_gather: null table / row map");
+    for (int i = 0; i < n_groups; i++) {
+        const r3dg_densify_group& g = groups[i];
+        if (g.row_floats == 0 || !g.src_param || !g.dst_param) return invalid("densify_gather: empty group");
+        if ((g.src_exp_avg != nullptr) != (g.src_exp_avg_sq != nullptr) ||
+            (g.src_exp_avg && (!g.dst_exp_avg || !g.dst_exp_avg_sq)))
+            return invalid("densify_gather: moments must be given as complete source/destination pairs");
+        if (g.role == R3DG_DENSIFY_ROLE_XYZ && g.row_floats != 3) return invalid("densify_gather: xyz rows are 3 floats");
+        if (g.role == R3DG_DENSIFY_ROLE_SCALING && g.row_floats != 3)
+            return invalid("densify_gather: scaling rows are 3 floats");
+        if (g.role > R3DG_DENSIFY_ROLE_SCALING) return invalid("densify_gather: unknown role");
+        if (g.role != R3DG_DENSIFY_ROLE_COPY && (!xyz || !scaling_raw || !rotation_raw || !(split_divisor > 0.f)))
+            return invalid("densify_gather: split sources missing");
+        if ((uint64_t)rows_out * g.row_floats >= (1ull << 41)) return invalid("densify_gather: group too large");
+    }
+    return guarded([&]() -> int {
+        StageTimer t((hipStream_t)stream_, ST_DENSIFY);
+        launch_densify_gather((hipStream_t)stream_, rows_out, src_row, kind, n_groups, groups, xyz, scaling_raw,
+                              rotation_raw, normal_table, split_divisor);
+        return R3DG_OK;
+    });
+}
+
+int r3dg_reset_opacity(void* stream_, int P, float* opacity_raw, float* exp_avg, float* exp_avg_sq)
+{
+    if (P < 0) return invalid("reset_opacity: bad P");
+    if (P == 0) return R3DG_OK;
+    if (!opacity_raw) return invalid("reset_opacity: null buffer");
+    return guarded([&]() -> int {
+        launch_reset_opacity((hipStream_t)stream_, P, 0.01f, opacity_raw, exp_avg, exp_avg_sq);
         return R3DG_OK;
     });
 }

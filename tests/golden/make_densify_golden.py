@@ -1,0 +1,143 @@
+"""Golden vectors for the densify / prune / reset-opacity row, produced by running the REFERENCE's own
+`GaussianModel` (scene/gaussian_model.py:465-497, 563-566, 667-937) on CPU in this container.
+
+    python tests/golden/make_densify_golden.py      # needs /root/reference; writes tests/golden/densify_reference_*.npz
+
+The model is driven exactly as train.py:158-175 drives it: real `torch.optim.Adam` groups from `training_setup`, two Adam
+steps so every group carries non-trivial moments, `add_densification_stats` + the max-radii update for a few views,
+then `densify_and_prune` (or `prune`, or `reset_opacity`).  The only intervention is `torch.normal`, which is replaced
+by `mean + std * Z` with a stored standard-normal table Z so the split children are reproducible without the CUDA
+Philox stream.  Only inputs and outputs are stored; nothing of the reference's source is copied.
+"""
+import os
+import sys
+import types
+from unittest import mock
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+import make_golden as mg  # noqa: E402  (auto-mock finder + CPU factory patches)
+
+GROUPS_STAGE1 = ["xyz", "normal", "rotation", "scaling", "opacity", "f_dc", "f_rest"]
+GROUPS_STAGE2 = GROUPS_STAGE1 + ["base_color", "roughness", "incidents_dc", "incidents_rest", "visibility_dc",
+                                 "visibility_rest"]
+ATTR = dict(xyz="_xyz", normal="_normal", rotation="_rotation", scaling="_scaling", opacity="_opacity", f_dc="_shs_dc",
+            f_rest="_shs_rest", base_color="_base_color", roughness="_roughness", incidents_dc="_incidents_dc",
+            incidents_rest="_incidents_rest", visibility_dc="_visibility_dc", visibility_rest="_visibility_rest")
+SHAPES = dict(xyz=(3,), normal=(3,), rotation=(4,), scaling=(3,), opacity=(1,), f_dc=(1, 3), f_rest=(15, 3),
+              base_color=(3,), roughness=(1,), incidents_dc=(1, 3), incidents_rest=(15, 3), visibility_dc=(1, 1),
+              visibility_rest=(15, 1))
+
+
+def build_model(GaussianModel, P, stage2, g, extent):
+    from torch import nn
+    m = GaussianModel(3, render_type="neilf" if stage2 else "render")
+    names = GROUPS_STAGE2 if stage2 else GROUPS_STAGE1
+
+    def rnd(*s):
+        return torch.randn(*s, generator=g)
+    vals = {n: 0.5 * rnd(P, *SHAPES[n]) for n in names}
+    vals["xyz"] = 1.3 * rnd(P, 3)
+    # log-scales straddling percent_dense*extent (clone vs split) with a few above 0.1*extent (world-size prune)
+    vals["scaling"] = np.log(0.01 * extent) + 1.2 * rnd(P, 3)
+    vals["opacity"] = 2.5 * rnd(P, 1) - 1.0         # some sigmoid(opacity) < 0.005
+    for n in names:
+        setattr(m, ATTR[n], nn.Parameter(vals[n].clone().contiguous().requires_grad_(True)))
+    m.max_radii2D = torch.zeros(P)
+    m.spatial_lr_scale = 1.0
+    args = types.SimpleNamespace(percent_dense=0.01, position_lr_init=1.6e-4, position_lr_final=1.6e-6,
+                                 position_lr_delay_mult=0.01, position_lr_max_steps=30000, normal_lr=2e-3,
+                                 rotation_lr=1e-3, scaling_lr=5e-3, opacity_lr=5e-2, sh_lr=2.5e-3, base_color_lr=1e-2,
+                                 roughness_lr=1e-2, light_lr=1e-3, light_rest_lr=-1, visibility_lr=2.5e-3,
+                                 visibility_rest_lr=-1)
+    m.training_setup(args)
+    # two Adam steps with random gradients: non-trivial exp_avg / exp_avg_sq in every group
+    for _ in range(2):
+        for grp in m.optimizer.param_groups:
+            p = grp["params"][0]
+            p.grad = 0.1 * rnd(*p.shape)
+        m.step()
+    return m, names
+
+
+def snapshot(m, names, prefix):
+    out = {}
+    for grp in m.optimizer.param_groups:
+        n = grp["name"]
+        p = grp["params"][0]
+        st = m.optimizer.state[p]
+        out["%s_%s" % (prefix, n)] = p.detach().numpy().copy()
+        out["%s_%s_exp_avg" % (prefix, n)] = st["exp_avg"].numpy().copy()
+        out["%s_%s_exp_avg_sq" % (prefix, n)] = st["exp_avg_sq"].numpy().copy()
+    for s in ("weights_accum", "xyz_gradient_accum", "normal_gradient_accum", "denom", "max_radii2D"):
+        out["%s_%s" % (prefix, s)] = getattr(m, s).numpy().copy()
+    return out
+
+
+def accumulate_views(m, P, g, views, rec):
+    """train.py:160-165 for `views` synthetic views; the per-view inputs are stored so the HIP accumulate kernel can be
+    replayed on them."""
+    for v in range(views):
+        radii = torch.randint(0, 24, (P,), generator=g, dtype=torch.int32)
+        radii[torch.rand(P, generator=g) < 0.3] = 0
+        vis = radii > 0
+        vsp = torch.zeros(P, 3)
+        vsp.grad = 4e-4 * torch.randn(P, 3, generator=g) * (torch.rand(P, 1, generator=g) < 0.7)
+        m._normal.grad = 3e-9 * torch.randn(P, 3, generator=g)
+        weights = torch.rand(P, 1, generator=g) * (torch.rand(P, 1, generator=g) < 0.8) * 2e-4
+        m.add_densification_stats(vsp, vis, weights)
+        m.max_radii2D[vis] = torch.max(m.max_radii2D[vis], radii[vis])
+        rec["view%d_radii" % v] = radii.numpy().copy()
+        rec["view%d_viewspace_grad" % v] = vsp.grad.numpy().copy()
+        rec["view%d_normal_grad" % v] = m._normal.grad.numpy().copy()
+        rec["view%d_weights" % v] = weights.numpy().copy()
+    m._normal.grad = None
+
+
+def case(GaussianModel, name, P, stage2, seed, op, max_screen_size, extent=4.0, tg=2e-4, tn=2e-9, views=3):
+    g = torch.Generator().manual_seed(seed)
+    m, names = build_model(GaussianModel, P, stage2, g, extent)
+    rec = dict(op=op, stage2=int(stage2), extent=extent, grad_threshold=tg, grad_normal_threshold=tn,
+               min_opacity=0.005, max_screen_size=0.0 if max_screen_size is None else float(max_screen_size),
+               percent_dense=m.percent_dense, weights_threshold=1e-4, views=views, group_names=np.array(names))
+    rec.update(snapshot(m, names, "pre"))          # state before the view statistics
+    accumulate_views(m, P, g, views, rec)
+    rec.update({k: v for k, v in snapshot(m, names, "in").items() if not any(
+        k == "in_%s%s" % (n, s) for n in names for s in ("", "_exp_avg", "_exp_avg_sq"))})   # stats after the views
+    Z = torch.randn(2 * P, 3, generator=g)
+    rec["normal_table"] = Z.numpy().copy()
+
+    def fake_normal(mean, std, **kw):
+        n = std.shape[0]
+        return mean + std * Z[:n]
+    with mock.patch.object(torch, "normal", fake_normal):
+        if op == "densify_and_prune":
+            m.densify_and_prune(tg, 0.005, extent, max_screen_size, tn)
+        elif op == "prune":
+            m.prune(0.005, extent, max_screen_size)
+        elif op == "reset_opacity":
+            m.reset_opacity()
+    rec.update(snapshot(m, names, "out"))
+    path = os.path.join(HERE, "densify_reference_%s.npz" % name)
+    np.savez_compressed(path, **rec)
+    print("%-28s P %d -> %d  (%d KB)" % (name, P, m._xyz.shape[0], os.path.getsize(path) // 1024))
+
+
+def main():
+    sys.meta_path.append(mg._Finder())
+    sys.path.insert(0, mg.REF)
+    for p in mg._cpu_factories():
+        p.start()
+    from scene.gaussian_model import GaussianModel
+    case(GaussianModel, "stage1_densify", 192, False, 11, "densify_and_prune", 20)
+    case(GaussianModel, "stage1_densify_nosize", 128, False, 12, "densify_and_prune", None)
+    case(GaussianModel, "stage2_densify", 64, True, 13, "densify_and_prune", 20)
+    case(GaussianModel, "stage1_prune", 160, False, 14, "prune", 20)
+    case(GaussianModel, "stage1_reset_opacity", 96, False, 15, "reset_opacity", None)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,69 @@
+"""CPU: the densification oracle (oracle/densify.py) against the outputs of the reference's own GaussianModel
+(tests/golden/densify_reference_*.npz, made by tests/golden/make_densify_golden.py)."""
+import glob
+import os
+
+import numpy as np
+import pytest
+
+from oracle import densify as od
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+CASES = sorted(glob.glob(os.path.join(GOLDEN, "densify_reference_*.npz")))
+STATS = ("weights_accum", "xyz_gradient_accum", "normal_gradient_accum", "denom", "max_radii2D")
+
+
+def load_case(path):
+    z = np.load(path)
+    names = [str(n) for n in z["group_names"]]
+    return z, names
+
+
+def oracle_model(z, names, stats_prefix):
+    return od.Model({n: z["pre_" + n] for n in names}, {n: z["pre_%s_exp_avg" % n] for n in names},
+                    {n: z["pre_%s_exp_avg_sq" % n] for n in names}, {s: z["%s_%s" % (stats_prefix, s)] for s in STATS})
+
+
+def run_op(m, z):
+    op = str(z["op"])
+    mss = float(z["max_screen_size"]) or None
+    if op == "densify_and_prune":
+        m.densify_and_prune(float(z["grad_threshold"]), float(z["min_opacity"]), float(z["extent"]), mss,
+                            float(z["grad_normal_threshold"]), float(z["percent_dense"]), z["normal_table"],
+                            float(z["weights_threshold"]))
+    elif op == "prune":
+        m.prune(float(z["min_opacity"]), float(z["extent"]), mss, float(z["weights_threshold"]))
+    else:
+        m.reset_opacity()
+
+
+def test_fixtures_present():
+    assert len(CASES) >= 5
+
+
+@pytest.mark.parametrize("path", CASES, ids=[os.path.basename(p)[18:-4] for p in CASES])
+def test_accumulate_matches_reference(path):
+    z, names = load_case(path)
+    m = oracle_model(z, names, "pre")
+    for v in range(int(z["views"])):
+        od.accumulate(m.s, z["view%d_viewspace_grad" % v], z["view%d_normal_grad" % v], z["view%d_radii" % v],
+                      z["view%d_weights" % v])
+    for s in STATS:
+        np.testing.assert_allclose(m.s[s], z["in_" + s], rtol=2e-7, atol=0, err_msg=s)
+
+
+@pytest.mark.parametrize("path", CASES, ids=[os.path.basename(p)[18:-4] for p in CASES])
+def test_operation_matches_reference(path):
+    z, names = load_case(path)
+    m = oracle_model(z, names, "in")
+    run_op(m, z)
+    assert m.min_margin > 1e-5, "fixture has a value on a threshold (margin %.1e)" % m.min_margin
+    assert m.P == z["out_xyz"].shape[0]
+    generated = ("xyz", "scaling", "opacity")          # touched by float math (children / reset); the rest is moved
+    for n in names:
+        tol = dict(rtol=3e-6, atol=1e-6) if n in generated else dict(rtol=0, atol=0)
+        np.testing.assert_allclose(m.p[n], z["out_" + n], err_msg=n, **tol)
+        np.testing.assert_array_equal(m.m[n], z["out_%s_exp_avg" % n], err_msg=n + " exp_avg")
+        np.testing.assert_array_equal(m.v[n], z["out_%s_exp_avg_sq" % n], err_msg=n + " exp_avg_sq")
+    for s in STATS:
+        np.testing.assert_array_equal(m.s[s], z["out_" + s], err_msg=s)
