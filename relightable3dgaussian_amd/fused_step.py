@@ -147,7 +147,7 @@ class FusedStage2Step:
         with torch.no_grad():
             self.refresh_activations()
             self.visibility, self.incident_dirs, self.incident_areas, self.tracer = update_visibility(
-                self.xyz, self.a_scales, self.a_rot, self.a_opacity, self.a_normal, sample_num)
+                self.xyz, self.a_scales, self.a_rot, self.a_opacity, self.a_normal, sample_num, group=process_group)
         rest = lr * lr_rest_scale
         self.opt = FusedAdam([
             dict(param=self.xyz, lr=lr), dict(param=self.normal, lr=lr), dict(param=self.scaling, lr=lr),
@@ -373,8 +373,25 @@ class FusedStage1Step:
         self.xyz, self.normal = d(params.xyz), d(params.normal)
         self.scaling, self.rotation, self.opacity = d(params.scaling), d(params.rotation), d(params.opacity)
         self.shs = torch.cat([params.features_dc.detach(), params.features_rest.detach()], 1).contiguous()
-        self.P = P = self.xyz.shape[0]
         self.M = self.shs.shape[1]
+        self._zero_depth_grad = None
+        self.group = process_group
+        self.world = torch.distributed.get_world_size(process_group) if (
+            torch.distributed.is_available() and torch.distributed.is_initialized()) else 1
+        rest = lr * lr_rest_scale
+        self._opt_order = ("xyz", "normal", "scaling", "rotation", "opacity", "shs")
+        self.opt = FusedAdam([dict(param=self.xyz, lr=lr), dict(param=self.normal, lr=lr),
+                              dict(param=self.scaling, lr=lr), dict(param=self.rotation, lr=lr),
+                              dict(param=self.opacity, lr=lr),
+                              dict(param=self.shs, lr=lr, lr_tail=rest, period=3 * self.M, split=3)])
+        self.stats = None                  # densification statistics (enable_densification)
+        self.last_outs = None
+        self._allocate()
+
+    def _allocate(self):
+        """Per-Gaussian work buffers for the current number of Gaussians (again after every densify / prune)."""
+        dev = self.dev
+        self.P = P = self.xyz.shape[0]
         f = dict(dtype=torch.float32, device=dev)
         self.a_scales, self.a_rot = torch.empty(P, 3, **f), torch.empty(P, 4, **f)
         self.a_opacity, self.a_normal = torch.empty(P, 1, **f), torch.empty(P, 3, **f)
@@ -387,17 +404,57 @@ class FusedStage1Step:
         for k in names:
             self.grads[k] = self.grad_flat[o:o + sizes[k]].view_as(getattr(self, k))
             o += sizes[k]
-        self._zero_depth_grad = None
-        self.group = process_group
-        self.world = torch.distributed.get_world_size(process_group) if (
-            torch.distributed.is_available() and torch.distributed.is_initialized()) else 1
-        rest = lr * lr_rest_scale
-        self._opt_order = ("xyz", "normal", "scaling", "rotation", "opacity", "shs")
-        self.opt = FusedAdam([dict(param=self.xyz, lr=lr), dict(param=self.normal, lr=lr),
-                              dict(param=self.scaling, lr=lr), dict(param=self.rotation, lr=lr),
-                              dict(param=self.opacity, lr=lr),
-                              dict(param=self.shs, lr=lr, lr_tail=rest, period=3 * self.M, split=3)])
         self.last_outs = None
+
+    # ---- densification (train.py:158-175; kernels in csrc/densify.hip, host mirror densify.py) ----------------------
+    def enable_densification(self):
+        """Start collecting the densification statistics: every forward_backward adds its view (add_densification_stats +
+        max radii, train.py:160-165), from this rank's own gradients, before the gradient all-reduce is launched."""
+        from . import densify
+        self.stats = densify.DensificationStats(self.P, self.dev)
+
+    def _groups(self):
+        import collections
+        return collections.OrderedDict(
+            (k, dict(param=getattr(self, k), exp_avg=self.opt.groups[i]["exp_avg"],
+                     exp_avg_sq=self.opt.groups[i]["exp_avg_sq"])) for i, k in enumerate(self._opt_order))
+
+    def _rebind(self, new, new_stats):
+        for i, k in enumerate(self._opt_order):
+            setattr(self, k, new[k]["param"])
+            g = self.opt.groups[i]
+            g["param"], g["exp_avg"], g["exp_avg_sq"] = new[k]["param"], new[k]["exp_avg"], new[k]["exp_avg_sq"]
+        self.stats = new_stats
+        self._allocate()
+
+    def densify_and_prune(self, max_grad, min_opacity, extent, max_screen_size, max_grad_normal, percent_dense=0.01,
+                          generator=None):
+        """GaussianModel.densify_and_prune on the raw parameters and their Adam moments.  Under data parallelism the
+        statistics are summed over ranks first (max for the radii) and every rank must pass a generator in the same state,
+        so the replicas stay identical."""
+        from . import densify
+        if self.stats is None:
+            raise RuntimeError("densify_and_prune: call enable_densification() first")
+        self.stats.all_reduce(self.group)
+        new, new_stats, info = densify.densify_and_prune(self._groups(), self.stats, max_grad, min_opacity, extent,
+                                                         max_screen_size, max_grad_normal, percent_dense,
+                                                         generator=generator)
+        self._rebind(new, new_stats)
+        return info
+
+    def prune(self, min_opacity, extent, max_screen_size):
+        from . import densify
+        if self.stats is None:
+            raise RuntimeError("prune: call enable_densification() first")
+        self.stats.all_reduce(self.group)
+        new, new_stats, info = densify.prune(self._groups(), self.stats, min_opacity, extent, max_screen_size)
+        self._rebind(new, new_stats)
+        return info
+
+    def reset_opacity(self):
+        from . import densify
+        g = self.opt.groups[self._opt_order.index("opacity")]
+        densify.reset_opacity(self.opacity, g["exp_avg"], g["exp_avg_sq"])
 
     features_dc = property(lambda self: self.shs[:, :1])
     features_rest = property(lambda self: self.shs[:, 1:])
@@ -455,6 +512,8 @@ class FusedStage1Step:
                 dL_dscales.data_ptr(), dL_drot.data_ptr(), dL_dopacity.data_ptr(), dL_dmeans3D.data_ptr(),
                 gr["xyz"].data_ptr(), gr["scaling"].data_ptr(), gr["rotation"].data_ptr(), gr["opacity"].data_ptr(),
                 gr["normal"].data_ptr()), "stage1_activate_backward")
+            if self.stats is not None:           # this view's densification statistics, from the LOCAL gradients
+                self.stats.add(dL_dmeans2D, gr["normal"], radii, weights)
             self._handle = None
             if self.world > 1:
                 self._handle = torch.distributed.all_reduce(self.grad_flat, group=self.group, async_op=True)

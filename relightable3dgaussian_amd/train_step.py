@@ -28,22 +28,46 @@ def inverse_covariance(scales, rotations):
 
 
 @torch.no_grad()
-def update_visibility(xyz, scales, rotations, opacity, normal, sample_num):
-    """-> (visibility[P,K,1], incident_dirs[P,K,3], incident_areas[P,K,1]); chunked like the reference
-    (chunk = P // ((K-1)//24 + 1)) so the transient [chunk,K,3] ray tensors stay bounded."""
-    tracer = RayTracer(xyz, scales, rotations)
+def update_visibility(xyz, scales, rotations, opacity, normal, sample_num, group=None, tracer_cls=None):
+    """-> (visibility[P,K,1], incident_dirs[P,K,3], incident_areas[P,K,1], tracer); chunked like the reference
+    (chunk = P // ((K-1)//24 + 1)) so the transient [chunk,K,3] ray tensors stay bounded.
+
+    Data parallel: with an initialised process group of W > 1 ranks every rank builds the same BVH
+    (replicated, deterministic), traces only the ray bundles of ITS contiguous block of ceil(P/W) Gaussians and ONE
+    all-gather assembles the [P,K,1] visibility on every rank; directions and areas are pure functions of the normals
+    and are evaluated locally for all rows.  `tracer_cls` (tests) replaces bvh.RayTracer."""
+    import torch.distributed as dist
+    world = rank = None
+    if dist.is_available() and dist.is_initialized():
+        world, rank = dist.get_world_size(group), dist.get_rank(group)
+    if not world or world == 1:
+        world, rank = 1, 0
+    tracer = (tracer_cls or RayTracer)(xyz, scales, rotations)
     cinv = inverse_covariance(scales, rotations)
     op = opacity[:, 0].contiguous()
     P = xyz.shape[0]
+    per = -(-P // world)                                   # rows per rank (the last block may be short or empty)
+    lo, hi = min(P, rank * per), min(P, (rank + 1) * per)
     chunk = max(1, P // ((sample_num - 1) // 24 + 1))
     vis, dirs_all, areas_all = [], [], []
     for off in range(0, P, chunk):
         dirs, areas = sampling.fibonacci_sphere_sampling(normal[off:off + chunk], sample_num)
-        res = tracer.trace_visibility(xyz[off:off + chunk, None].expand_as(dirs), dirs, xyz, cinv, op, normal)
-        vis.append(res["visibility"])
         dirs_all.append(dirs)
         areas_all.append(areas)
-    return torch.cat(vis, 0), torch.cat(dirs_all, 0), torch.cat(areas_all, 0), tracer
+        a, b = max(off, lo), min(off + dirs.shape[0], hi)
+        if a < b:
+            d = dirs[a - off:b - off]
+            res = tracer.trace_visibility(xyz[a:b, None].expand_as(d), d, xyz, cinv, op, normal)
+            vis.append(res["visibility"])
+    dirs_all, areas_all = torch.cat(dirs_all, 0), torch.cat(areas_all, 0)
+    if world == 1:
+        return torch.cat(vis, 0), dirs_all, areas_all, tracer
+    mine = torch.zeros(per, sample_num, 1, dtype=torch.float32, device=xyz.device)
+    if hi > lo:
+        mine[:hi - lo] = torch.cat(vis, 0)
+    full = torch.empty(world * per, sample_num, 1, dtype=torch.float32, device=xyz.device)
+    dist.all_gather(list(full.view(world, per, sample_num, 1).unbind(0)), mine, group=group)
+    return full[:P].contiguous(), dirs_all, areas_all, tracer
 
 
 LAMBDA_DSSIM = 0.2          # arguments/__init__.py:125

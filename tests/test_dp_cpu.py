@@ -61,6 +61,14 @@ def _worker(rank, world, port, steps, out_dir):
     stats = [torch.full((5,), float(rank + 1)) for _ in range(4)] + [torch.tensor([rank * 3.0, 7.0 - rank])]
     dp.reduce_densification_stats(*stats)
     assert torch.equal(stats[0], torch.full((5,), 3.0)) and torch.equal(stats[4], torch.tensor([3.0, 7.0]))
+    # the fused path's statistics object: sum of the four accumulators, max of the radii
+    from relightable3dgaussian_amd.densify import DensificationStats
+    st = DensificationStats(7, torch.device("cpu"))
+    st._slab[:4] = float(rank + 1)
+    st.max_radii2D.copy_(torch.arange(7.0) * (1 if rank == 0 else -1) + 3 * rank)
+    st.all_reduce()
+    assert torch.equal(st._slab[:4], torch.full((4, 7), 3.0))
+    assert torch.equal(st.max_radii2D, torch.maximum(torch.arange(7.0), 3 - torch.arange(7.0)))
     torch.save([p.detach().clone() for p in model.parameters()], os.path.join(out_dir, "rank%d.pt" % rank))
     dist.destroy_process_group()
 
@@ -86,3 +94,56 @@ def test_shard_views_partition():
     views = list(range(10))
     parts = [dp.shard_views(views, r, 4) for r in range(4)]
     assert sorted(sum(parts, [])) == views and all(len(p) in (2, 3) for p in parts)
+
+
+class _FakeTracer:
+    """Stands in for bvh.RayTracer on CPU: visibility is a deterministic function of the ray alone, so the sharded
+    result can be compared with the single-process one exactly."""
+
+    def __init__(self, means3D, scales, rotations):
+        self.calls = 0
+
+    def trace_visibility(self, rays_o, rays_d, means3D, symm_inv, opacity, normals):
+        self.calls += rays_o.shape[0]
+        v = torch.sin(7.0 * (rays_o * rays_d).sum(-1) + 3.0 * rays_d[..., 0])
+        return {"visibility": torch.where(v > 0, 0.9 + 0.1 * v, torch.zeros_like(v)).unsqueeze(-1)}
+
+
+def _visibility_inputs(P):
+    g = torch.Generator().manual_seed(5)
+    xyz = torch.randn(P, 3, generator=g)
+    scales = torch.rand(P, 3, generator=g) * 0.05 + 0.01
+    rot = torch.nn.functional.normalize(torch.randn(P, 4, generator=g), dim=-1)
+    opacity = torch.rand(P, 1, generator=g)
+    normal = torch.nn.functional.normalize(torch.randn(P, 3, generator=g), dim=-1)
+    return xyz, scales, rot, opacity, normal
+
+
+def _visibility_worker(rank, world, port, P, K, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from relightable3dgaussian_amd.train_step import update_visibility
+    vis, dirs, areas, tracer = update_visibility(*_visibility_inputs(P), K, tracer_cls=_FakeTracer)
+    torch.save(dict(vis=vis, dirs=dirs, areas=areas, traced=tracer.calls), os.path.join(out_dir, "vis%d.pt" % rank))
+    dist.destroy_process_group()
+
+
+def test_sharded_update_visibility_equals_single_process(tmp_path):
+    """ray bundles sharded over ranks against a replicated BVH + one all-gather.  Ragged split (P not a
+    multiple of the world size, chunk boundaries inside a rank's block), world 2 and 3."""
+    from relightable3dgaussian_amd.train_step import update_visibility
+    P, K = 103, 30                       # K=30 -> 2 chunks of 51 rows (+1)
+    want = update_visibility(*_visibility_inputs(P), K, tracer_cls=_FakeTracer)
+    assert want[3].calls == P
+    for world in (2, 3):
+        d = tmp_path / ("w%d" % world)
+        d.mkdir()
+        mp.spawn(_visibility_worker, args=(world, _free_port(), P, K, str(d)), nprocs=world, join=True)
+        traced = 0
+        for r in range(world):
+            got = torch.load(os.path.join(d, "vis%d.pt" % r))
+            assert torch.equal(got["vis"], want[0]) and got["vis"].shape == (P, K, 1)
+            assert torch.equal(got["dirs"], want[1]) and torch.equal(got["areas"], want[2])
+            traced += got["traced"]
+        assert traced == P               # every bundle traced exactly once across the ranks

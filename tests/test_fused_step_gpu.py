@@ -221,6 +221,75 @@ def test_fused_stage1_matches_autograd():
     assert float(fused.loss()) < l0
 
 
+def test_fused_stage1_training_with_densification():
+    """train.py:158-175 on the fused stage-1 iteration: statistics every step (checked against a torch restatement of
+    add_densification_stats on this step's tensors), densify_and_prune / reset_opacity in between; the Adam moments of
+    surviving rows travel with them and training goes on at the new size."""
+    from relightable3dgaussian_amd import synthetic as syn
+    from relightable3dgaussian_amd.bench_core import GaussianParams, render_stage1
+    from relightable3dgaussian_amd.fused_step import FusedStage1Step
+    P, res = 6000, 160
+    torch.manual_seed(99)
+    scene = syn.make_scene(P=P, seed=6, stage2=False, scale_log_mean=-3.2)
+    cams = [c.to(DEV) for c in syn.orbit_cameras(8, width=res, height=res)[:3]]
+    bg = torch.tensor([1.0, 1.0, 1.0], device=DEV)
+    params = GaussianParams(scene, DEV, False)
+    with torch.no_grad():
+        teacher = GaussianParams(syn.make_scene(P=P, seed=6, stage2=False, scale_log_mean=-3.2), DEV, False)
+        teacher.features_dc.add_(0.2 * torch.randn_like(teacher.features_dc))
+        gts = [render_stage1(teacher, c, bg)[2].clone() for c in cams]
+    step = FusedStage1Step(params, lr=2e-3)
+    step.enable_densification()
+    want = dict(xyz=torch.zeros(P, device=DEV), normal=torch.zeros(P, device=DEV), denom=torch.zeros(P, device=DEV),
+                weights=torch.zeros(P, device=DEV), radii=torch.zeros(P, device=DEV))
+    for i in range(6):
+        outs = step.forward_backward(cams[i % 3], bg, gts[i % 3])
+        radii, weights = outs[9], outs[8]
+        vis = radii > 0
+        want["weights"] += weights[:, 0]
+        want["xyz"][vis] += step.viewspace_grad[vis, :2].norm(dim=-1)
+        want["normal"][vis] += step.grads["normal"][vis].norm(dim=-1)
+        want["denom"][vis] += 1
+        want["radii"][vis] = torch.max(want["radii"][vis], radii[vis].float())
+        step.optimizer_step()
+    st = step.stats
+    for got, ref in ((st.xyz_gradient_accum, want["xyz"]), (st.normal_gradient_accum, want["normal"]),
+                     (st.denom, want["denom"]), (st.weights_accum, want["weights"]), (st.max_radii2D, want["radii"])):
+        torch.testing.assert_close(got, ref, rtol=1e-5, atol=1e-12)
+    assert float(st.denom.max()) > 0 and float(st.xyz_gradient_accum.max()) > 0
+    # thresholds chosen from the statistics so that both branches fire
+    mean_grad = (st.xyz_gradient_accum / st.denom.clamp_min(1)).cpu()
+    thr = float(mean_grad[mean_grad > 0].median())
+    exp_avg_before = step.opt.groups[0]["exp_avg"].clone()
+    steps_before = step.opt.step_count
+    gen = torch.Generator(device=DEV).manual_seed(3)
+    info = step.densify_and_prune(thr, 0.005, 2.6, 20, 1e9, percent_dense=0.01, generator=gen)
+    assert info["cloned"] > 0 and info["split"] > 0
+    assert step.P == info["rows_out"] == step.xyz.shape[0] == step.opt.groups[0]["exp_avg"].shape[0] != P
+    assert step.grads["shs"].shape == (step.P, 16, 3) and step.stats.P == step.P
+    assert step.opt.step_count == steps_before
+    kept = info["kind"] == -1
+    src = info["src_row"][kept].long()
+    assert torch.equal(step.opt.groups[0]["exp_avg"][:int(kept.sum())], exp_avg_before[src])
+    assert float(step.opt.groups[0]["exp_avg"][int(kept.sum()):].abs().max()) == 0.0
+    assert float(step.stats._slab.abs().sum()) == 0.0
+    for i in range(4):
+        step(cams[i % 3], bg, gts[i % 3])
+    assert np.isfinite(float(step.loss()))
+    assert float(step.stats.denom.max()) > 0
+    P1 = step.P
+    info = step.prune(0.005, 2.6, 20)
+    assert 0 < step.P == info["rows_out"] <= P1 and step.stats.P == step.P
+    step(cams[0], bg, gts[0])
+    assert np.isfinite(float(step.loss()))
+    step.reset_opacity()
+    assert float(torch.sigmoid(step.opacity).max()) <= 0.01 + 1e-6
+    g = step.opt.groups[step._opt_order.index("opacity")]
+    assert float(g["exp_avg"].abs().max()) == 0.0 and float(g["exp_avg_sq"].abs().max()) == 0.0
+    step(cams[1], bg, gts[1])
+    assert np.isfinite(float(step.loss()))
+
+
 @pytest.mark.parametrize("H,W", [(64, 64), (37, 50), (16, 200), (5, 7)])
 def test_ssim_kernels_match_reference_formula(H, W):
     """r3dg_ssim_forward/backward vs the conv2d restatement of utils/loss_utils.py:20-63 under autograd."""
