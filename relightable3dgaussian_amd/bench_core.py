@@ -285,6 +285,41 @@ def quick_rate(stage, points, res, sample_num, dev, steps=20, warmup=4):
     return round(steps / (time.perf_counter() - t0), 2)
 
 
+def densify_bench(points, res, dev, views=8):
+    """One densify_and_prune of the stage-1 model after `views` iterations of statistics: wall time
+    of the whole call (plan + count read-back + normal table + one-launch gather + buffer re-allocation) and the gather's
+    algorithmic bytes (every surviving parameter / Adam-moment float read once and written once)."""
+    from . import fused_step
+    scene = syn.make_scene(P=points, seed=0, stage2=False)
+    cams = [c.to(dev) for c in syn.orbit_cameras(100, width=res, height=res)[:views]]
+    bg = torch.ones(3, device=dev)
+    params = GaussianParams(scene, dev, False)
+    with torch.no_grad():
+        teacher = GaussianParams(syn.make_scene(P=points, seed=0, stage2=False), dev, False)
+        teacher.features_dc.add_(0.05 * torch.randn_like(teacher.features_dc))
+        gts = [render_stage1(teacher, c, bg)[2].clone() for c in cams]
+        del teacher
+    step = fused_step.FusedStage1Step(params, lr=1e-4)
+    step.enable_densification()
+    for i in range(views):
+        step(cams[i], bg, gts[i])
+    st = step.stats
+    mean_grad = st.xyz_gradient_accum / st.denom.clamp_min(1)
+    thr = float(mean_grad[mean_grad > 0].median())          # half of the visible Gaussians clone or split
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    info = step.densify_and_prune(thr, 0.005, 2.6, 20, 99999, percent_dense=0.01,
+                                  generator=torch.Generator(device=dev).manual_seed(0))
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    floats = 3 + 3 + 3 + 4 + 1 + 48
+    moved = info["rows_out"] * floats * 4 * 3 * 2
+    step(cams[0], bg, gts[0])                                 # the loop goes on at the new size
+    torch.cuda.synchronize()
+    return dict(rows_in=points, rows_out=info["rows_out"], cloned=info["cloned"], split=info["split"],
+                call_ms=round(1e3 * dt, 3), gather_algorithmic_MB=round(moved / 1e6, 1))
+
+
 def run(args):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -456,6 +491,7 @@ def run(args):
                         quick_rate(1, args.points, args.res, 0, dev),
                     "stage2_train_iters_per_s_sample_num_384 (configs[2])":
                         quick_rate(2, args.points, args.res, 384, dev),
+                    "stage1_densify_and_prune (one call at the bench size)": densify_bench(args.points, args.res, dev),
                 }
             except Exception as e:
                 result["other_configs"] = {"failed": repr(e)}

@@ -366,7 +366,10 @@ class FusedStage1Step:
     bench_core.render_stage1 + loss_stage1 + torch.optim.Adam (the parity target, tests/test_fused_step_gpu.py);
     single-bucket gradient all-reduce under data parallelism."""
 
-    def __init__(self, params, lr=1e-4, lr_rest_scale=1.0, process_group=None):
+    def __init__(self, params, lr=1e-4, lr_rest_scale=1.0, process_group=None, lrs=None):
+        """`lrs`: optional per-group learning rates {xyz, normal, scaling, rotation, opacity, shs, shs_rest} as in
+        GaussianModel.training_setup (gaussian_model.py:465-472); missing names use `lr` (`lr * lr_rest_scale` for the
+        non-dc SH columns)."""
         dev = params.xyz.device
         self.dev = dev
         d = lambda t: t.detach().clone().contiguous()
@@ -378,12 +381,14 @@ class FusedStage1Step:
         self.group = process_group
         self.world = torch.distributed.get_world_size(process_group) if (
             torch.distributed.is_available() and torch.distributed.is_initialized()) else 1
-        rest = lr * lr_rest_scale
+        lrs = dict(lrs or {})
+        rate = lambda k: float(lrs.get(k, lr))
+        rest = float(lrs.get("shs_rest", rate("shs") * lr_rest_scale))
         self._opt_order = ("xyz", "normal", "scaling", "rotation", "opacity", "shs")
-        self.opt = FusedAdam([dict(param=self.xyz, lr=lr), dict(param=self.normal, lr=lr),
-                              dict(param=self.scaling, lr=lr), dict(param=self.rotation, lr=lr),
-                              dict(param=self.opacity, lr=lr),
-                              dict(param=self.shs, lr=lr, lr_tail=rest, period=3 * self.M, split=3)])
+        self.opt = FusedAdam([dict(param=self.xyz, lr=rate("xyz")), dict(param=self.normal, lr=rate("normal")),
+                              dict(param=self.scaling, lr=rate("scaling")), dict(param=self.rotation, lr=rate("rotation")),
+                              dict(param=self.opacity, lr=rate("opacity")),
+                              dict(param=self.shs, lr=rate("shs"), lr_tail=rest, period=3 * self.M, split=3)])
         self.stats = None                  # densification statistics (enable_densification)
         self.last_outs = None
         self._allocate()
@@ -419,7 +424,15 @@ class FusedStage1Step:
             (k, dict(param=getattr(self, k), exp_avg=self.opt.groups[i]["exp_avg"],
                      exp_avg_sq=self.opt.groups[i]["exp_avg_sq"])) for i, k in enumerate(self._opt_order))
 
+    def _drain(self):
+        """Complete a gradient all-reduce that is still in flight (data parallel) before its buffers are replaced."""
+        h = getattr(self, "_handle", None)
+        if h is not None:
+            h.wait()
+            self._handle = None
+
     def _rebind(self, new, new_stats):
+        self._drain()
         for i, k in enumerate(self._opt_order):
             setattr(self, k, new[k]["param"])
             g = self.opt.groups[i]
@@ -452,9 +465,14 @@ class FusedStage1Step:
         return info
 
     def reset_opacity(self):
+        """GaussianModel.reset_opacity.  The reference swaps in a fresh parameter object, so the optimizer step of the same
+        iteration leaves the opacity alone (its .grad is None): the pending opacity gradient is cleared here, which with
+        zeroed moments makes that Adam update exactly zero."""
         from . import densify
         g = self.opt.groups[self._opt_order.index("opacity")]
         densify.reset_opacity(self.opacity, g["exp_avg"], g["exp_avg_sq"])
+        self._drain()
+        self.grads["opacity"].zero_()
 
     features_dc = property(lambda self: self.shs[:, :1])
     features_rest = property(lambda self: self.shs[:, 1:])
@@ -529,8 +547,7 @@ class FusedStage1Step:
         return (self.sums * w).sum() + lam
 
     def optimizer_step(self):
-        if self._handle is not None:
-            self._handle.wait()
+        self._drain()
         self.opt.step([self.grads[k] for k in self._opt_order], 1.0 / self.world)
 
     def flush(self):

@@ -1,0 +1,96 @@
+"""Stage-1 training loop around the fused iteration: the densification schedule of the reference's train.py:158-175
+(statistics every iteration, densify_and_prune every `densification_interval` after `densify_from_iter`, size threshold
+once past the first opacity reset, reset_opacity every `opacity_reset_interval`) and its from-scratch initialisation
+(`GaussianModel.create_from_pcd`, scene/gaussian_model.py:409-441: isotropic log-scale from the mean squared 3-NN
+distance via distCUDA2, identity rotations, opacity 0.1, SH dc from the point colours).
+
+Only what the hot path needs: no dataset readers, logging, checkpoints or evaluation -- cameras and ground-truth images
+are whatever the caller hands in (synthetic.py in the tests and tools).  Data parallel: every rank runs this loop on its
+own view shard; gradients and densification statistics are reduced inside FusedStage1Step, and the split's random
+table comes from a generator seeded identically on all ranks, so the replicas stay identical.
+"""
+import math
+import types
+
+import torch
+
+from .fused_step import FusedStage1Step
+from .knn_ops import distCUDA2
+
+C0 = 0.28209479177387814          # RGB2SH (utils/sh_utils.py:130-131)
+
+
+class Schedule(types.SimpleNamespace):
+    """The OptimizationParams fields the loop reads (arguments/__init__.py:70-106), same defaults."""
+
+    def __init__(self, **kw):
+        super().__init__(iterations=30_000, position_lr_init=0.00016, normal_lr=0.01, sh_lr=0.0025, opacity_lr=0.05,
+                         scaling_lr=0.005, rotation_lr=0.001, percent_dense=0.001, densification_interval=100,
+                         opacity_reset_interval=3000, densify_from_iter=500, densify_until_iter=10_000,
+                         densify_grad_threshold=0.0002, densify_grad_normal_threshold=2e-9, normal_densify_from_iter=0,
+                         min_opacity=0.005)
+        self.__dict__.update(kw)
+
+
+def create_from_points(points, colors, normals=None, device="cuda"):
+    """Raw parameters of a fresh model (create_from_pcd): -> namespace with xyz, normal, scaling, rotation, opacity,
+    features_dc [P,1,3], features_rest [P,15,3]."""
+    xyz = points.to(device=device, dtype=torch.float32).contiguous()
+    P = xyz.shape[0]
+    dist2 = distCUDA2(xyz).clamp_min(1e-7)                                  # mean squared distance to the 3 NN
+    scaling = torch.log(torch.sqrt(dist2))[:, None].repeat(1, 3).contiguous()
+    rotation = torch.zeros(P, 4, device=device)
+    rotation[:, 0] = 1
+    opacity = torch.full((P, 1), math.log(0.1 / 0.9), device=device)        # inverse_sigmoid(0.1)
+    dc = ((colors.to(device=device, dtype=torch.float32) - 0.5) / C0)[:, None, :].contiguous()
+    rest = torch.zeros(P, 15, 3, device=device)
+    if normals is None:
+        normals = torch.zeros(P, 3, device=device)
+        normals[:, 2] = 1
+    return types.SimpleNamespace(xyz=xyz, normal=normals.to(device=device, dtype=torch.float32).contiguous(),
+                                 scaling=scaling, rotation=rotation, opacity=opacity, features_dc=dc,
+                                 features_rest=rest)
+
+
+def train_stage1(init, cameras, images, background, extent, schedule=None, iterations=None, seed=0,
+                 white_background=True, process_group=None, on_iteration=None):
+    """Runs `iterations` fused stage-1 iterations over the (camera, image) pairs in round-robin order (the reference
+    draws a random permutation, train.py:115-119; the order is the caller's) with the reference's densification
+    schedule.  Returns (FusedStage1Step, history) where history lists (iteration, event, rows) for every
+    densify / reset."""
+    sch = schedule or Schedule()
+    n_iter = sch.iterations if iterations is None else iterations
+    step = FusedStage1Step(init, lr=sch.sh_lr, lr_rest_scale=1.0 / 20.0, process_group=process_group,
+                           lrs=dict(xyz=sch.position_lr_init * extent, normal=sch.normal_lr, scaling=sch.scaling_lr,
+                                    rotation=sch.rotation_lr, opacity=sch.opacity_lr, shs=sch.sh_lr))
+    step.enable_densification()
+    gen = torch.Generator(device=step.dev).manual_seed(seed)
+    history = []
+    for it in range(1, n_iter + 1):
+        v = (it - 1) % len(cameras)
+        collecting = it < sch.densify_until_iter
+        if not collecting and step.stats is not None:
+            step.stats = None                                                # train.py:160: statistics only while densifying
+        step.forward_backward(cameras[v], background, images[v])
+        if collecting:
+            if it > sch.densify_from_iter and it % sch.densification_interval == 0:
+                size_threshold = 20 if it > sch.opacity_reset_interval else None
+                normal_thr = sch.densify_grad_normal_threshold if it > sch.normal_densify_from_iter else 99999
+                # the optimizer step of this iteration runs on the NEW tensors' moments in the reference as well
+                # (densify precedes gaussians.step(), train.py:167-177): gradients of the old rows are dropped
+                info = step.densify_and_prune(sch.densify_grad_threshold, sch.min_opacity, extent, size_threshold,
+                                              normal_thr, percent_dense=sch.percent_dense, generator=gen)
+                history.append((it, "densify", info["rows_out"]))
+                skip_step = True
+            else:
+                skip_step = False
+            if it % sch.opacity_reset_interval == 0 or (white_background and it == sch.densify_from_iter):
+                step.reset_opacity()
+                history.append((it, "reset_opacity", step.P))
+        else:
+            skip_step = False
+        if not skip_step:
+            step.optimizer_step()
+        if on_iteration is not None:
+            on_iteration(it, step)
+    return step, history

@@ -56,7 +56,7 @@ def _worker(rank, world, port, out_dir):
     step.flush()
     torch.cuda.synchronize()
     pars = {k: getattr(step, k).detach().cpu().clone() for k in ("xyz", "shs", "incidents", "env", "opacity")}
-    torch.save(dict(grads=grads, pars=pars), os.path.join(out_dir, "rank%d.pt" % rank))
+    torch.save(dict(grads=grads, pars=pars, visibility=step.visibility.cpu()), os.path.join(out_dir, "rank%d.pt" % rank))
     dist.destroy_process_group()
 
 
@@ -72,6 +72,8 @@ def test_fused_step_two_ranks(tmp_path):
     dev = torch.device("cuda", 0)
     params, cams, bg, gts, K, FusedStage2Step = _make(dev)
     single = FusedStage2Step(params, K, lr=1e-3)
+    # the ranks traced half of the ray bundles each and all-gathered them (train_step.update_visibility)
+    assert torch.equal(r0["visibility"], single.visibility.cpu()) and torch.equal(r1["visibility"], r0["visibility"])
     acc = None
     for i in range(2):
         single.forward_backward(cams[i], bg, gts[i])
