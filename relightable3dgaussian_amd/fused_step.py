@@ -113,24 +113,27 @@ class FusedStage2Step:
         # unweighted sums: l1, pbr l1, normal mse, light l1, TV(env), SSIM(image), SSIM(pbr)
         self.sums = torch.zeros(7, **f)
         self.d_pbr, self.d_diffuse = torch.empty(P, 3, **f), torch.empty(P, 3, **f)
-        # flat gradient slab: [xyz3 normal3 scaling3 rotation4 opacity1 base3 rough1 | shs 3M | incidents 3M] per group
+        # flat gradient slab: [shs 3M | xyz3 normal3 scaling3 rotation4 opacity1 base3 rough1 per Gaussian, env texture |
+        # incidents 3M]; every group starts on a 16-byte boundary (float4 accesses in the Adam kernel)
         sizes = dict(xyz=3 * P, normal=3 * P, scaling=3 * P, rotation=4 * P, opacity=P, base_color=3 * P, roughness=P,
-                     shs=3 * self.M * P, incidents=3 * self.M * P)
-        self.grad_flat = torch.zeros(sum(sizes.values()), **f)
-        self.grads, o = {}, 0
-        for k in ("shs", "xyz", "normal", "scaling", "rotation", "opacity", "base_color", "roughness", "incidents"):
+                     shs=3 * self.M * P, incidents=3 * self.M * P, env=self.env.numel())
+        order = ("shs", "xyz", "normal", "scaling", "rotation", "opacity", "base_color", "roughness", "env", "incidents")
+        pad4 = lambda n: (n + 3) // 4 * 4
+        self.grad_flat = torch.zeros(sum(pad4(sizes[k]) for k in order), **f)
+        self.grads, o, start = {}, 0, {}
+        for k in order:
+            start[k] = o
             self.grads[k] = self.grad_flat[o:o + sizes[k]].view_as(getattr(self, k))
-            o += sizes[k]
+            o += pad4(sizes[k])
         # three all-reduce buckets (world > 1): A = SH colour grads, final right after the rasterizer backward (reduced
         # under the shading backward); C = the small per-Gaussian groups, final after the activation chain rule;
         # B = incident-light grads, final after the shading backward -- reduced LAST and only waited for right before
         # the NEXT iteration's shading forward, so it travels under that iteration's projection + binning
-        n_inc = sizes["incidents"]
-        self._bucket_a = self.grad_flat[:sizes["shs"]]
-        self._bucket_c = self.grad_flat[sizes["shs"]:self.grad_flat.numel() - n_inc]
-        self._bucket_b = self.grad_flat[self.grad_flat.numel() - n_inc:]
+        # (the env texture's gradient rides in bucket C: one collective instead of a separate 6 KB all-reduce)
+        self._bucket_a = self.grad_flat[:start["xyz"]]
+        self._bucket_c = self.grad_flat[start["xyz"]:start["incidents"]]
+        self._bucket_b = self.grad_flat[start["incidents"]:]
         self._pending_b = None
-        self.grads["env"] = torch.zeros_like(self.env)
         self._zero_depth_grad = None
         # instance ordering of the rasterizer runs here, under the shading forward (register-light, latency-bound kernels
         # next to a VALU-bound one)
@@ -299,9 +302,8 @@ class FusedStage2Step:
             self._handles = None
             if self.world > 1:
                 handle_c = self._allreduce_async(self._bucket_c)
-                handle_e = torch.distributed.all_reduce(gr["env"], group=self.group, async_op=True)
                 handle_b = self._allreduce_async(self._bucket_b)
-                self._handles = (handle_a, handle_c, handle_e, handle_b)
+                self._handles = (handle_a, handle_c, handle_b)
         self.viewspace_grad = dL_dmeans2D
         self.last_outs = (R, n_contrib, image, opacity, depth, feature, pseudo_normal, sxyz, weights, radii)
         self._N = N
@@ -337,12 +339,11 @@ class FusedStage2Step:
             return
         # data parallel: update each bucket when its (sum) all-reduce has landed; 1/world is applied inside the kernel
         scale = 1.0 / self.world
-        handle_a, handle_c, handle_e, handle_b = self._handles
+        handle_a, handle_c, handle_b = self._handles
         self.opt.begin_step()
         handle_a.wait()
         self.opt.step_groups(self._GROUPS_A, grads, scale)
         handle_c.wait()
-        handle_e.wait()
         self.opt.step_groups(self._GROUPS_C, grads, scale)
         self._pending_b = (handle_b, grads, scale)
 
