@@ -394,6 +394,9 @@ int r3dg_set_tuning3(int fwd_wave8x8, int bwd_wave8x8, int cull);
  * list inside LDS (default); 0 = the reference's formulation, one global radix sort of all 44-45-bit keys (K5-K7).  The
  * sorted keys, point list and tile ranges are bit-identical either way; <0 keeps the current value. */
 int r3dg_set_tuning4(int tile_binning);
+/* r3dg_set_tuning5: 1 = the per-Gaussian kernels (projection forward / backward) move their SH and dL_dsh rows through
+ * LDS with coalesced 16-byte accesses (default); 0 = every thread walks its own row in HBM.  Results are identical. */
+int r3dg_set_tuning5(int stage_sh_rows);
 int r3dg_selftest_transpose_reduce(void* stream, int N, int dpp, const float* d_in, float* d_out, int* d_chan,
                                    int* d_owner);
 

@@ -134,6 +134,7 @@ void bvh_trace_opacity(hipStream_t s, int num_rays, const int32_t* nodes, const 
                        const float* rays_d, const float* means, const float* covs, const float* opac,
                        const float* normals, int32_t* contributes, float* out, int* overflow);
 extern int g_cull;
+extern int g_stage_sh_rows;
 int g_tile_binning = 1;   // 1: bin per tile + per-tile LDS sort; 0: the reference's global (tile|depth) radix sort
 extern int g_fwd_wave8x8;
 extern int g_bwd_wave8x8;
@@ -276,6 +277,12 @@ int r3dg_max_features_forward(void) { return R3DG_MAX_S_FWD; }
 int r3dg_max_features_backward(void) { return R3DG_MAX_S_BWD; }
 
 // tuning knobs (pixels per lane of the two render kernels); not part of the drop-in surface
+int r3dg_set_tuning5(int stage_sh_rows)
+{
+    if (stage_sh_rows >= 0) g_stage_sh_rows = stage_sh_rows;
+    return R3DG_OK;
+}
+
 int r3dg_set_tuning4(int tile_binning)
 {
     if (tile_binning >= 0) g_tile_binning = tile_binning;

@@ -132,6 +132,64 @@ __device__ __forceinline__ bool splat_may_touch(float mx, float my, float a, flo
     return !(amax < 0.98f / 255.0f);
 }
 
+// ---- block-cooperative row staging (256-thread blocks, one item per thread) ---------------------------------------------
+// A thread-per-Gaussian kernel that walks its own [row_floats] row (e.g. the 48 SH coefficients, 192 B) makes every
+// wave-level load touch 64 different cache lines.  These helpers move the block's 256 rows between HBM and LDS with
+// fully coalesced 16-byte accesses instead; rows sit in LDS with an odd stride (row_floats + 1 words), so the per-thread
+// walk afterwards is bank-conflict free.  Arithmetic is untouched -- results stay bit-identical.
+__device__ __forceinline__ int staged_row_stride(int row_floats) { return row_floats | 1; }
+
+// rows [first, first + 256) ∩ [0, P) of g -> s_rows; rows whose s_live byte is 0 are skipped (never read from HBM)
+__device__ __forceinline__ void stage_rows_in_256(const float* __restrict__ g, int first, int P, int row_floats,
+                                                  const uint8_t* s_live, float* s_rows)
+{
+    const int stride = staged_row_stride(row_floats);
+    const int nrows = min(256, P - first);
+    const float* __restrict__ src = g + (size_t)first * row_floats;
+    if ((row_floats & 3) == 0 && ((size_t)src & 15) == 0) {
+        const int q_per_row = row_floats >> 2, nq = nrows * q_per_row;
+#pragma unroll 4
+        for (int q = threadIdx.x; q < nq; q += 256) {
+            const int row = q / q_per_row, c = (q - row * q_per_row) * 4;
+            if (s_live[row]) {
+                const float4 v = *reinterpret_cast<const float4*>(src + 4 * (size_t)q);
+                float* d = s_rows + row * stride + c;
+                d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+            }
+        }
+    } else {
+        const int n = nrows * row_floats;
+        for (int f = threadIdx.x; f < n; f += 256) {
+            const int row = f / row_floats, c = f - row * row_floats;
+            if (s_live[row]) s_rows[row * stride + c] = src[f];
+        }
+    }
+}
+
+// s_rows -> rows [first, first + 256) ∩ [0, P) of g (every row is written)
+__device__ __forceinline__ void stage_rows_out_256(float* __restrict__ g, int first, int P, int row_floats,
+                                                   const float* s_rows)
+{
+    const int stride = staged_row_stride(row_floats);
+    const int nrows = min(256, P - first);
+    float* __restrict__ dst = g + (size_t)first * row_floats;
+    if ((row_floats & 3) == 0 && ((size_t)dst & 15) == 0) {
+        const int q_per_row = row_floats >> 2, nq = nrows * q_per_row;
+#pragma unroll 4
+        for (int q = threadIdx.x; q < nq; q += 256) {
+            const int row = q / q_per_row, c = (q - row * q_per_row) * 4;
+            const float* d = s_rows + row * stride + c;
+            *reinterpret_cast<float4*>(dst + 4 * (size_t)q) = make_float4(d[0], d[1], d[2], d[3]);
+        }
+    } else {
+        const int n = nrows * row_floats;
+        for (int f = threadIdx.x; f < n; f += 256) {
+            const int row = f / row_floats, c = f - row * row_floats;
+            dst[f] = s_rows[row * stride + c];
+        }
+    }
+}
+
 // Inclusive scan across the wave.
 __device__ __forceinline__ uint32_t wave_inclusive_scan_u32(uint32_t v)
 {

@@ -75,6 +75,10 @@ __global__ void mark_visible_kernel(int P, const float* __restrict__ pts, const 
 
 // K2: reference preprocessCUDA (forward.cu:156-258).  One thread per Gaussian; each 256-thread block also
 // reduces its tiles_touched into block_sums[blockIdx] so the scan (K3) never re-reads the per-Gaussian array.
+// STAGED: the SH rows of the block's surviving Gaussians (192 B each, the bulk of this kernel's HBM reads) arrive through
+// LDS with coalesced 16-byte loads (common.hpp stage_rows_in_256) after the cull decisions are known, instead of every
+// thread walking its own row in HBM; rows of culled Gaussians are never fetched.  Same arithmetic, same results.
+template <bool STAGED>
 __global__ void __launch_bounds__(256)
 preprocess_kernel(int P, int D, int M, const float* __restrict__ means3D, const float* __restrict__ scales,
                   float scale_modifier, const float* __restrict__ rotations, const float* __restrict__ opacities,
@@ -86,12 +90,16 @@ preprocess_kernel(int P, int D, int M, const float* __restrict__ means3D, const 
                   float* __restrict__ rgb, float4* __restrict__ conic_opacity, int gx, int gy,
                   uint32_t* __restrict__ tiles_touched, uint32_t* __restrict__ block_sums)
 {
+    extern __shared__ float s_rows[];                  // STAGED: 256 SH rows
+    __shared__ uint8_t s_live[256];
     const int idx = blockIdx.x * 256 + threadIdx.x;
     uint32_t my_tiles = 0;
+    bool shade = false;                                // survived every cull and needs its colour from SH
+    float px = 0.f, py = 0.f, pz = 0.f;
     if (idx < P) {
         int my_radius_i = 0;
         do {
-            const float px = means3D[3 * idx], py = means3D[3 * idx + 1], pz = means3D[3 * idx + 2];
+            px = means3D[3 * idx]; py = means3D[3 * idx + 1]; pz = means3D[3 * idx + 2];
             // view-space point (auxiliary.h:58-66) and near cull (auxiliary.h:154)
             const float vx = vm[0] * px + vm[4] * py + vm[8] * pz + vm[12];
             const float vy = vm[1] * px + vm[5] * py + vm[9] * pz + vm[13];
@@ -153,40 +161,7 @@ preprocess_kernel(int P, int D, int M, const float* __restrict__ means3D, const 
             tile_rect(pixx, pixy, f2i_sat(my_radius), gx, gy, x0, y0, x1, y1);
             if ((x1 - x0) * (y1 - y0) == 0) break;
 
-            if (colors_precomp == nullptr) {
-                // forward.cu:20-71
-                float dx = px - cam_pos[0], dy = py - cam_pos[1], dz = pz - cam_pos[2];
-                const float len = sqrtf(dx * dx + dy * dy + dz * dz);
-                dx = dx / len; dy = dy / len; dz = dz / len;
-                const float* sh = shs + (size_t)idx * M * 3;
-#pragma unroll
-                for (int ch = 0; ch < 3; ch++) {
-                    float result = kSH_C0 * sh[ch];
-                    if (D > 0) {
-                        const float x = dx, y = dy, z = dz;
-                        result = result - kSH_C1 * y * sh[3 + ch] + kSH_C1 * z * sh[6 + ch] - kSH_C1 * x * sh[9 + ch];
-                        if (D > 1) {
-                            const float xx = x * x, yy = y * y, zz = z * z;
-                            const float xy = x * y, yz = y * z, xz = x * z;
-                            result = result + kSH_C2[0] * xy * sh[12 + ch] + kSH_C2[1] * yz * sh[15 + ch] +
-                                     kSH_C2[2] * (2.0f * zz - xx - yy) * sh[18 + ch] + kSH_C2[3] * xz * sh[21 + ch] +
-                                     kSH_C2[4] * (xx - yy) * sh[24 + ch];
-                            if (D > 2) {
-                                result = result + kSH_C3[0] * y * (3.0f * xx - yy) * sh[27 + ch] +
-                                         kSH_C3[1] * xy * z * sh[30 + ch] +
-                                         kSH_C3[2] * y * (4.0f * zz - xx - yy) * sh[33 + ch] +
-                                         kSH_C3[3] * z * (2.0f * zz - 3.0f * xx - 3.0f * yy) * sh[36 + ch] +
-                                         kSH_C3[4] * x * (4.0f * zz - xx - yy) * sh[39 + ch] +
-                                         kSH_C3[5] * z * (xx - yy) * sh[42 + ch] +
-                                         kSH_C3[6] * x * (xx - 3.0f * yy) * sh[45 + ch];
-                            }
-                        }
-                    }
-                    result += 0.5f;
-                    clamped[3 * idx + ch] = (result < 0);
-                    rgb[3 * idx + ch] = fmaxf(result, 0.0f);
-                }
-            }
+            shade = colors_precomp == nullptr;
             depths[idx] = vz;
             my_radius_i = f2i_sat(my_radius);
             means2D[idx] = make_float2(pixx, pixy);
@@ -195,6 +170,46 @@ preprocess_kernel(int P, int D, int M, const float* __restrict__ means3D, const 
         } while (0);
         radii[idx] = my_radius_i;
         tiles_touched[idx] = my_tiles;
+    }
+    if (STAGED) {
+        s_live[threadIdx.x] = shade;
+        __syncthreads();
+        stage_rows_in_256(shs, blockIdx.x * 256, P, 3 * M, s_live, s_rows);
+        __syncthreads();
+    }
+    if (shade) {
+        // forward.cu:20-71
+        float dx = px - cam_pos[0], dy = py - cam_pos[1], dz = pz - cam_pos[2];
+        const float len = sqrtf(dx * dx + dy * dy + dz * dz);
+        dx = dx / len; dy = dy / len; dz = dz / len;
+        const float* sh = STAGED ? s_rows + threadIdx.x * staged_row_stride(3 * M) : shs + (size_t)idx * M * 3;
+#pragma unroll
+        for (int ch = 0; ch < 3; ch++) {
+            float result = kSH_C0 * sh[ch];
+            if (D > 0) {
+                const float x = dx, y = dy, z = dz;
+                result = result - kSH_C1 * y * sh[3 + ch] + kSH_C1 * z * sh[6 + ch] - kSH_C1 * x * sh[9 + ch];
+                if (D > 1) {
+                    const float xx = x * x, yy = y * y, zz = z * z;
+                    const float xy = x * y, yz = y * z, xz = x * z;
+                    result = result + kSH_C2[0] * xy * sh[12 + ch] + kSH_C2[1] * yz * sh[15 + ch] +
+                             kSH_C2[2] * (2.0f * zz - xx - yy) * sh[18 + ch] + kSH_C2[3] * xz * sh[21 + ch] +
+                             kSH_C2[4] * (xx - yy) * sh[24 + ch];
+                    if (D > 2) {
+                        result = result + kSH_C3[0] * y * (3.0f * xx - yy) * sh[27 + ch] +
+                                 kSH_C3[1] * xy * z * sh[30 + ch] +
+                                 kSH_C3[2] * y * (4.0f * zz - xx - yy) * sh[33 + ch] +
+                                 kSH_C3[3] * z * (2.0f * zz - 3.0f * xx - 3.0f * yy) * sh[36 + ch] +
+                                 kSH_C3[4] * x * (4.0f * zz - xx - yy) * sh[39 + ch] +
+                                 kSH_C3[5] * z * (xx - yy) * sh[42 + ch] +
+                                 kSH_C3[6] * x * (xx - 3.0f * yy) * sh[45 + ch];
+                    }
+                }
+            }
+            result += 0.5f;
+            clamped[3 * idx + ch] = (result < 0);
+            rgb[3 * idx + ch] = fmaxf(result, 0.0f);
+        }
     }
     // block reduction of tiles_touched -> block_sums
     __shared__ uint32_t s_wave[4];
@@ -380,6 +395,8 @@ void launch_mark_visible(hipStream_t s, int P, const float* means3D, const float
     mark_visible_kernel<<<(P + 255) / 256, 256, 0, s>>>(P, means3D, vm, present);
 }
 
+extern int g_stage_sh_rows;     // rasterizer_preprocess_bwd.hip (r3dg_set_tuning5)
+
 void launch_preprocess(hipStream_t s, int P, int D, int M, const float* means3D, const float* scales,
                        float scale_modifier, const float* rotations, const float* opacities, const float* shs,
                        uint8_t* clamped, const float* cov3D_precomp, const float* colors_precomp, const float* vm,
@@ -389,10 +406,17 @@ void launch_preprocess(hipStream_t s, int P, int D, int M, const float* means3D,
                        uint32_t* block_sums, unsigned long long* total)
 {
     const int nb = (P + 255) / 256;
-    preprocess_kernel<<<nb, 256, 0, s>>>(P, D, M, means3D, scales, scale_modifier, rotations, opacities, shs, clamped,
-                                         cov3D_precomp, colors_precomp, vm, pm, cam_pos, W, H, tan_fovx, tan_fovy,
-                                         focal_x, focal_y, radii, (float2*)means2D, depths, cov3Ds, rgb,
-                                         (float4*)conic_opacity, gx, gy, tiles_touched, block_sums);
+    const bool staged = g_stage_sh_rows && shs != nullptr && colors_precomp == nullptr && M >= 1 && M <= 16;
+    if (staged)
+        preprocess_kernel<true><<<nb, 256, 256 * ((3 * M) | 1) * sizeof(float), s>>>(
+            P, D, M, means3D, scales, scale_modifier, rotations, opacities, shs, clamped, cov3D_precomp, colors_precomp,
+            vm, pm, cam_pos, W, H, tan_fovx, tan_fovy, focal_x, focal_y, radii, (float2*)means2D, depths, cov3Ds, rgb,
+            (float4*)conic_opacity, gx, gy, tiles_touched, block_sums);
+    else
+        preprocess_kernel<false><<<nb, 256, 0, s>>>(
+            P, D, M, means3D, scales, scale_modifier, rotations, opacities, shs, clamped, cov3D_precomp, colors_precomp,
+            vm, pm, cam_pos, W, H, tan_fovx, tan_fovy, focal_x, focal_y, radii, (float2*)means2D, depths, cov3Ds, rgb,
+            (float4*)conic_opacity, gx, gy, tiles_touched, block_sums);
     scan_block_sums_kernel<<<1, 1024, 0, s>>>(nb, block_sums, total);
 }
 

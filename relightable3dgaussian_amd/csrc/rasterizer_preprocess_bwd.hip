@@ -2,7 +2,10 @@
 // Reference semantics: computeCov2DCUDA backward.cu:144-276, preprocessCUDA backward.cu:348-398,
 // SH backward :20-139, cov3D backward :280-343.  The reference launches two kernels because of code length;
 // both are one-thread-per-Gaussian and touch the same rows, so one pass halves the HBM traffic on
-// means/radii/dL_dmean2D (the pass is HBM-bound: ~104 + 531 B per Gaussian, dominated by the 192 B dL_dsh row).
+// means/radii/dL_dmean2D (the pass is HBM-bound: ~104 + 531 B per Gaussian, dominated by the 192 B SH row read and the
+// 192 B dL_dsh row written).  Those two rows travel through LDS (STAGED): the block moves its 256 rows with coalesced
+// 16-byte accesses (common.hpp stage_rows_*), each thread walks its own row in LDS; a thread-per-Gaussian walk straight
+// in HBM makes every wave load/store touch 64 different cache lines.
 #include "common.hpp"
 
 namespace r3dg {
@@ -38,6 +41,7 @@ __device__ const float bSH_C3[7] = {-0.5900435899266435f, 2.890611442640554f, -0
                                     0.3731763325901154f, -0.4570457994644658f, 1.445305721320277f,
                                     -0.5900435899266435f};
 
+template <bool STAGED>
 __global__ void __launch_bounds__(256)
 preprocess_backward_kernel(int P, int D, int M, const float* __restrict__ means, const int* __restrict__ radii,
                            const float* __restrict__ shs, const uint8_t* __restrict__ clamped,
@@ -49,24 +53,39 @@ preprocess_backward_kernel(int P, int D, int M, const float* __restrict__ means,
                            float* __restrict__ dL_dcov3D, float* __restrict__ dL_dsh, float* __restrict__ dL_dscale,
                            float* __restrict__ dL_drot)
 {
+    extern __shared__ float s_rows[];                  // STAGED: 256 SH rows in, the same 256 dL_dsh rows out
+    __shared__ uint8_t s_live[256];
     const int idx = blockIdx.x * 256 + threadIdx.x;
-    if (idx >= P) return;
-    if (!(radii[idx] > 0)) {
+    const bool in_range = idx < P;
+    const bool visible = in_range && radii[idx] > 0;
+    float* row = nullptr;
+    if (STAGED) {
+        s_live[threadIdx.x] = visible;
+        __syncthreads();
+        stage_rows_in_256(shs, blockIdx.x * 256, P, 3 * M, s_live, s_rows);
+        __syncthreads();
+        row = s_rows + threadIdx.x * staged_row_stride(3 * M);
+    }
+    do {
+    if (!in_range) break;
+    if (!visible) {
         // invisible Gaussian: the reference leaves its torch::zeros rows untouched; here the rows are written so the
         // caller can hand in uninitialised memory (saves five zero-fill launches per backward)
 #pragma unroll
         for (int i = 0; i < 3; i++) dL_dmeans[3 * idx + i] = 0.f;
 #pragma unroll
         for (int i = 0; i < 6; i++) dL_dcov3D[6 * idx + i] = 0.f;
-        if (shs != nullptr)
-            for (int i = 0; i < 3 * M; i++) dL_dsh[(size_t)idx * M * 3 + i] = 0.f;
+        if (shs != nullptr) {
+            float* z = STAGED ? row : dL_dsh + (size_t)idx * M * 3;
+            for (int i = 0; i < 3 * M; i++) z[i] = 0.f;
+        }
         if (scales != nullptr) {
 #pragma unroll
             for (int i = 0; i < 3; i++) dL_dscale[3 * idx + i] = 0.f;
 #pragma unroll
             for (int i = 0; i < 4; i++) dL_drot[4 * idx + i] = 0.f;
         }
-        return;
+        break;
     }
 
     const float mx = means[3 * idx], my = means[3 * idx + 1], mz = means[3 * idx + 2];
@@ -162,12 +181,18 @@ preprocess_backward_kernel(int P, int D, int M, const float* __restrict__ means,
         const float len = sqrtf(ox * ox + oy * oy + oz * oz);
         const float x = ox / len, y = oy / len, z = oz / len;
         const float* sh = shs + (size_t)idx * M * 3;
-        float* dsh = dL_dsh + (size_t)idx * M * 3;
+        float* dsh = STAGED ? row : dL_dsh + (size_t)idx * M * 3;
+        // STAGED: dL_dsh overwrites the SH row in place, so the coefficients are lifted into registers first
+        float shv[48];
+        if (STAGED) {
+#pragma unroll
+            for (int i = 0; i < 48; i++) shv[i] = i < 3 * M ? row[i] : 0.f;
+        }
         float ddx = 0, ddy = 0, ddz = 0;
         const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
 #pragma unroll
         for (int ch = 0; ch < 3; ch++) {
-#define SH(k) sh[(k) * 3 + ch]
+#define SH(k) (STAGED ? shv[(k) * 3 + ch] : sh[(k) * 3 + ch])
 #define DSH(k) dsh[(k) * 3 + ch]
             const float g = dL_dcolor[3 * idx + ch] * (clamped[3 * idx + ch] ? 0.f : 1.f);
             float dRx = 0, dRy = 0, dRz = 0;
@@ -262,7 +287,15 @@ preprocess_backward_kernel(int P, int D, int M, const float* __restrict__ means,
         dL_drot[4 * idx + 3] = 2 * r * (D_(0, 1) - D_(1, 0)) + 2 * x * (D_(2, 0) + D_(0, 2)) + 2 * y * (D_(1, 2) + D_(2, 1)) - 4 * z * (D_(1, 1) + D_(0, 0));
 #undef D_
     }
+    } while (0);
+    if (STAGED) {
+        __syncthreads();
+        stage_rows_out_256(dL_dsh, blockIdx.x * 256, P, 3 * M, s_rows);
+    }
 }
+
+int g_stage_sh_rows = 1;        // r3dg_set_tuning5: 1 = SH / dL_dsh rows through LDS (default), 0 = direct per-thread walks
+static inline int staged_row_stride_host(int row_floats) { return row_floats | 1; }
 
 void launch_preprocess_backward(hipStream_t s, int P, int D, int M, const float* means, const int* radii,
                                 const float* shs, const uint8_t* clamped, const float* scales, const float* rotations,
@@ -272,10 +305,16 @@ void launch_preprocess_backward(hipStream_t s, int P, int D, int M, const float*
                                 float* dL_dsh, float* dL_dscale, float* dL_drot)
 {
     if (P <= 0) return;
-    preprocess_backward_kernel<<<(P + 255) / 256, 256, 0, s>>>(P, D, M, means, radii, shs, clamped, scales, rotations,
-                                                              scale_modifier, cov3Ds, vm, proj, h_x, h_y, tan_fovx,
-                                                              tan_fovy, campos, dL_dmean2D, dL_dconic, dL_dmeans,
-                                                              dL_dcolor, dL_dcov3D, dL_dsh, dL_dscale, dL_drot);
+    // SH rows through LDS when there are SH coefficients of at most degree 3 (256 x 49 words = 49 KB per block)
+    const bool staged = g_stage_sh_rows && shs != nullptr && M >= 1 && M <= 16;
+    if (staged)
+        preprocess_backward_kernel<true><<<(P + 255) / 256, 256, 256 * staged_row_stride_host(3 * M) * sizeof(float), s>>>(
+            P, D, M, means, radii, shs, clamped, scales, rotations, scale_modifier, cov3Ds, vm, proj, h_x, h_y, tan_fovx,
+            tan_fovy, campos, dL_dmean2D, dL_dconic, dL_dmeans, dL_dcolor, dL_dcov3D, dL_dsh, dL_dscale, dL_drot);
+    else
+        preprocess_backward_kernel<false><<<(P + 255) / 256, 256, 0, s>>>(
+            P, D, M, means, radii, shs, clamped, scales, rotations, scale_modifier, cov3Ds, vm, proj, h_x, h_y, tan_fovx,
+            tan_fovy, campos, dL_dmean2D, dL_dconic, dL_dmeans, dL_dcolor, dL_dcov3D, dL_dsh, dL_dscale, dL_drot);
 }
 
 }  // namespace r3dg

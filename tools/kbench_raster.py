@@ -20,6 +20,8 @@ if "WAVE8" in os.environ:
     L.r3dg_set_tuning3(int(os.environ["WAVE8"]) & 1, int(os.environ["WAVE8"]) >> 1, -1)
 if "BIN" in os.environ:
     L.r3dg_set_tuning4(int(os.environ["BIN"]))
+if "STAGE" in os.environ:
+    L.r3dg_set_tuning5(int(os.environ["STAGE"]))
 if "CULL" in os.environ:
     L.r3dg_set_tuning3(-1, -1, int(os.environ["CULL"]))
 for it in range(3 + int(os.environ.get("ITERS", 10))):
