@@ -247,6 +247,13 @@ int r3dg_ssim_forward(void* stream, int width, int height, int channels, const f
                       float* d_partials, float* d_sum);
 int r3dg_ssim_backward(void* stream, int width, int height, int channels, const float* d_x, const float* d_y,
                        const float* d_partials, float scale, float* d_grad_x);
+/* The same for TWO images against one target in one launch each (the SH image and the sRGB PBR image of a stage-2
+ * iteration, neilf.py:225-239): image 1 is optional (d_x1 NULL = the single-image call). */
+int r3dg_ssim_forward_pair(void* stream, int width, int height, int channels, const float* d_x0, const float* d_x1,
+                           const float* d_y, float* d_partials0, float* d_partials1, float* d_sum0, float* d_sum1);
+int r3dg_ssim_backward_pair(void* stream, int width, int height, int channels, const float* d_x0, const float* d_x1,
+                            const float* d_y, const float* d_partials0, const float* d_partials1, float scale0,
+                            float scale1, float* d_grad_x0, float* d_grad_x1);
 
 /* Stage-1 counterparts (plain 3DGS + normals, gaussian_renderer/render.py:15-130; r3dg_stage2_activate with
  * d_base_raw == NULL provides the activations): features [P,5] = normal(3), depth, depth^2;

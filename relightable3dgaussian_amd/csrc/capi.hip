@@ -94,9 +94,10 @@ void launch_s2_loss(hipStream_t s, int HW, const float* image, const float* opac
                     float* dL_dopacity, float* dL_dfeature, float* sums);
 void launch_s2_pbr_srgb(hipStream_t s, int HW, const float* opacity, const float* feature, const int* n_contrib,
                         const float* bg, float* srgb);
-void launch_ssim_forward(hipStream_t s, int W, int H, int C, const float* x, const float* y, float* partials, float* sum);
-void launch_ssim_backward(hipStream_t s, int W, int H, int C, const float* x, const float* y, const float* partials,
-                          float scale, float* grad_x);
+void launch_ssim_forward(hipStream_t s, int W, int H, int C, int n_images, const float* const* x, const float* y,
+                         float* const* partials, float* const* sum);
+void launch_ssim_backward(hipStream_t s, int W, int H, int C, int n_images, const float* const* x, const float* y,
+                          float* const* partials, const float* scale, float* const* grad_x);
 void launch_adam(hipStream_t s, int n_groups, const r3dg_adam_group* groups, float beta1, float beta2, float eps,
                  int step, float grad_scale);
 void launch_s1_pack(hipStream_t s, int P, const float* xyz, const float* viewmatrix, const float* normal, float* features);
@@ -1042,30 +1043,53 @@ int r3dg_stage2_pbr_srgb(void* stream_, int width, int height, const float* opac
     });
 }
 
-int r3dg_ssim_forward(void* stream_, int width, int height, int channels, const float* x, const float* y,
-                      float* partials, float* sum)
+int r3dg_ssim_forward_pair(void* stream_, int width, int height, int channels, const float* x0, const float* x1,
+                           const float* y, float* partials0, float* partials1, float* sum0, float* sum1)
 {
     if (width < 0 || height < 0 || channels < 0) return invalid("ssim_forward: bad shape");
     if ((long long)width * height * channels == 0) return R3DG_OK;
-    if (!x || !y || !partials) return invalid("ssim_forward: null buffer");
+    if (!x0 || !y || !partials0 || (x1 && !partials1)) return invalid("ssim_forward: null buffer");
+    if ((long long)channels * 2 > 65535) return invalid("ssim_forward: too many channels");
     return guarded([&]() -> int {
         StageTimer t((hipStream_t)stream_, ST_SSIM);
-        launch_ssim_forward((hipStream_t)stream_, width, height, channels, x, y, partials, sum);
+        const float* x[2] = {x0, x1};
+        float* partials[2] = {partials0, partials1};
+        float* sum[2] = {sum0, sum1};
+        launch_ssim_forward((hipStream_t)stream_, width, height, channels, x1 ? 2 : 1, x, y, partials, sum);
         return R3DG_OK;
     });
+}
+
+int r3dg_ssim_backward_pair(void* stream_, int width, int height, int channels, const float* x0, const float* x1,
+                            const float* y, const float* partials0, const float* partials1, float scale0, float scale1,
+                            float* grad_x0, float* grad_x1)
+{
+    if (width < 0 || height < 0 || channels < 0) return invalid("ssim_backward: bad shape");
+    if ((long long)width * height * channels == 0) return R3DG_OK;
+    if (!x0 || !y || !partials0 || !grad_x0 || (x1 && (!partials1 || !grad_x1))) return invalid("ssim_backward: null buffer");
+    if ((long long)channels * 2 > 65535) return invalid("ssim_backward: too many channels");
+    return guarded([&]() -> int {
+        StageTimer t((hipStream_t)stream_, ST_SSIM);
+        const float* x[2] = {x0, x1};
+        float* partials[2] = {const_cast<float*>(partials0), const_cast<float*>(partials1)};
+        const float scale[2] = {scale0, scale1};
+        float* grad[2] = {grad_x0, grad_x1};
+        launch_ssim_backward((hipStream_t)stream_, width, height, channels, x1 ? 2 : 1, x, y, partials, scale, grad);
+        return R3DG_OK;
+    });
+}
+
+int r3dg_ssim_forward(void* stream_, int width, int height, int channels, const float* x, const float* y,
+                      float* partials, float* sum)
+{
+    return r3dg_ssim_forward_pair(stream_, width, height, channels, x, nullptr, y, partials, nullptr, sum, nullptr);
 }
 
 int r3dg_ssim_backward(void* stream_, int width, int height, int channels, const float* x, const float* y,
                        const float* partials, float scale, float* grad_x)
 {
-    if (width < 0 || height < 0 || channels < 0) return invalid("ssim_backward: bad shape");
-    if ((long long)width * height * channels == 0) return R3DG_OK;
-    if (!x || !y || !partials || !grad_x) return invalid("ssim_backward: null buffer");
-    return guarded([&]() -> int {
-        StageTimer t((hipStream_t)stream_, ST_SSIM);
-        launch_ssim_backward((hipStream_t)stream_, width, height, channels, x, y, partials, scale, grad_x);
-        return R3DG_OK;
-    });
+    return r3dg_ssim_backward_pair(stream_, width, height, channels, x, nullptr, y, partials, nullptr, scale, 0.f, grad_x,
+                                   nullptr);
 }
 
 int r3dg_stage2_env_backward(void* stream_, int He, int We, const float* raw, const float* env, const float* dL_denv,

@@ -33,15 +33,34 @@ __device__ __forceinline__ float block_sum_256s(float v, float* s_part)
 // Both kernels: one 32x32 output tile per 256-thread workgroup.  Horizontal pass: a work item = (row of the 42-row
 // halo region, group of 4 adjacent columns): 14 LDS reads per map feed 4 outputs.  Vertical pass: a work item = (column,
 // group of 4 adjacent rows), exactly one per thread.
+// One launch serves one or two images against the same target shape (the SH image and the sRGB PBR image of a stage-2
+// iteration): blockIdx.z = image * C + channel.  Twice the workgroups per launch halve the share of the partially filled
+// last wave of workgroups (a 800x800x3 image is 1875 of them, 768 resident) and the number of launches.
+struct SsimImage {
+    const float* x;
+    const float* y;
+    float* partials;       // forward: written, backward: read
+    float* sum;            // forward only
+    float* grad_x;         // backward only
+    float scale;           // backward only
+};
+struct SsimBatch {
+    SsimImage im[2];
+};
+
 __global__ void __launch_bounds__(256)
-ssim_forward_kernel(int W, int H, const float* __restrict__ x, const float* __restrict__ y,
-                    float* __restrict__ partials, float* __restrict__ sum)
+ssim_forward_kernel(int W, int H, int C, SsimBatch batch)
 {
+    const SsimImage I = batch.im[blockIdx.z / C];
+    const float* __restrict__ x = I.x;
+    const float* __restrict__ y = I.y;
+    float* __restrict__ partials = I.partials;
+    float* __restrict__ sum = I.sum;
     __shared__ float s_x[SSIM_E][SSIM_E + 1], s_y[SSIM_E][SSIM_E + 1];
     __shared__ float s_h[5][SSIM_E][SSIM_T + 1];
     __shared__ float s_part[4];
     const size_t HW = (size_t)H * W;
-    const int c = blockIdx.z;
+    const int c = blockIdx.z % C;
     const float* xc = x + c * HW;
     const float* yc = y + c * HW;
     const int bx = blockIdx.x * SSIM_T, by = blockIdx.y * SSIM_T;
@@ -118,13 +137,18 @@ ssim_forward_kernel(int W, int H, const float* __restrict__ x, const float* __re
 }
 
 __global__ void __launch_bounds__(256)
-ssim_backward_kernel(int W, int H, const float* __restrict__ x, const float* __restrict__ y,
-                     const float* __restrict__ partials, float scale, float* __restrict__ grad_x)
+ssim_backward_kernel(int W, int H, int C, SsimBatch batch)
 {
+    const SsimImage I = batch.im[blockIdx.z / C];
+    const float* __restrict__ x = I.x;
+    const float* __restrict__ y = I.y;
+    const float* __restrict__ partials = I.partials;
+    const float scale = I.scale;
+    float* __restrict__ grad_x = I.grad_x;
     __shared__ float s_p[3][SSIM_E][SSIM_E + 1];
     __shared__ float s_h[3][SSIM_E][SSIM_T + 1];
     const size_t HW = (size_t)H * W;
-    const int c = blockIdx.z;
+    const int c = blockIdx.z % C;
     const float* pc = partials + (size_t)c * 3 * HW;
     const int bx = blockIdx.x * SSIM_T, by = blockIdx.y * SSIM_T;
     for (int i = threadIdx.x; i < SSIM_E * SSIM_E; i += 256) {
@@ -184,18 +208,23 @@ ssim_backward_kernel(int W, int H, const float* __restrict__ x, const float* __r
     }
 }
 
-void launch_ssim_forward(hipStream_t s, int W, int H, int C, const float* x, const float* y, float* partials, float* sum)
+void launch_ssim_forward(hipStream_t s, int W, int H, int C, int n_images, const float* const* x, const float* y,
+                         float* const* partials, float* const* sum)
 {
-    dim3 grid((W + SSIM_T - 1) / SSIM_T, (H + SSIM_T - 1) / SSIM_T, C);
-    ssim_forward_kernel<<<grid, 256, 0, s>>>(W, H, x, y, partials, sum);
+    SsimBatch b = {};
+    for (int i = 0; i < n_images; i++) b.im[i] = SsimImage{x[i], y, partials[i], sum[i], nullptr, 0.f};
+    dim3 grid((W + SSIM_T - 1) / SSIM_T, (H + SSIM_T - 1) / SSIM_T, C * n_images);
+    ssim_forward_kernel<<<grid, 256, 0, s>>>(W, H, C, b);
     check_launch(s, false, "ssim_forward_kernel");
 }
 
-void launch_ssim_backward(hipStream_t s, int W, int H, int C, const float* x, const float* y, const float* partials,
-                          float scale, float* grad_x)
+void launch_ssim_backward(hipStream_t s, int W, int H, int C, int n_images, const float* const* x, const float* y,
+                          float* const* partials, const float* scale, float* const* grad_x)
 {
-    dim3 grid((W + SSIM_T - 1) / SSIM_T, (H + SSIM_T - 1) / SSIM_T, C);
-    ssim_backward_kernel<<<grid, 256, 0, s>>>(W, H, x, y, partials, scale, grad_x);
+    SsimBatch b = {};
+    for (int i = 0; i < n_images; i++) b.im[i] = SsimImage{x[i], y, partials[i], nullptr, grad_x[i], scale[i]};
+    dim3 grid((W + SSIM_T - 1) / SSIM_T, (H + SSIM_T - 1) / SSIM_T, C * n_images);
+    ssim_backward_kernel<<<grid, 256, 0, s>>>(W, H, C, b);
     check_launch(s, false, "ssim_backward_kernel");
 }
 

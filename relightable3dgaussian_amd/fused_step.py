@@ -243,11 +243,14 @@ class FusedStage2Step:
             lam = LAMBDA_DSSIM
             _lib.check(L.r3dg_stage2_pbr_srgb(stream(), W, H, opacity.data_ptr(), feature.data_ptr(),
                                               n_contrib.data_ptr(), bg_c.data_ptr(), srgb.data_ptr()), "stage2_pbr_srgb")
-            for x_img, part, gs, slot, wt in ((image, part_i, gs_i, 5, 1.0), (srgb, part_p, gs_p, 6, self.w["pbr"])):
-                _lib.check(L.r3dg_ssim_forward(stream(), W, H, 3, x_img.data_ptr(), gt_c.data_ptr(), part.data_ptr(),
-                                               self.sums[slot:].data_ptr()), "ssim_forward")
-                _lib.check(L.r3dg_ssim_backward(stream(), W, H, 3, x_img.data_ptr(), gt_c.data_ptr(), part.data_ptr(),
-                                                -wt * lam / (3.0 * N), gs.data_ptr()), "ssim_backward")
+            # SSIM terms of both images: one forward and one backward launch for the pair
+            _lib.check(L.r3dg_ssim_forward_pair(stream(), W, H, 3, image.data_ptr(), srgb.data_ptr(), gt_c.data_ptr(),
+                                                part_i.data_ptr(), part_p.data_ptr(), self.sums[5:].data_ptr(),
+                                                self.sums[6:].data_ptr()), "ssim_forward")
+            _lib.check(L.r3dg_ssim_backward_pair(stream(), W, H, 3, image.data_ptr(), srgb.data_ptr(), gt_c.data_ptr(),
+                                                 part_i.data_ptr(), part_p.data_ptr(), -lam / (3.0 * N),
+                                                 -self.w["pbr"] * lam / (3.0 * N), gs_i.data_ptr(), gs_p.data_ptr()),
+                       "ssim_backward")
             _lib.check(L.r3dg_stage2_loss(
                 stream(), W, H, image.data_ptr(), opacity.data_ptr(), feature.data_ptr(), pseudo_normal.data_ptr(),
                 n_contrib.data_ptr(), gt_c.data_ptr(), bg_c.data_ptr(), self.w["l1"] * (1.0 - lam) / (3.0 * N),
