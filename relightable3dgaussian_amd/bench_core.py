@@ -140,28 +140,61 @@ def cpu_baseline(scene, cams, S, budget_s):
         t_b += time.time() - t0
         views += 1
         R = out[0]
-    extra = {}
-    try:        # configs[0]: the reference's own CPU-runnable plumbing case through the pure-PyTorch restatement
-        from oracle import torch_rasterizer as tr
-        torch.set_num_threads(os.cpu_count() or 1)
-        sc0 = syn.make_scene(P=2000, seed=0, stage2=False, scale_log_mean=-3.0)
-        cam0 = syn.orbit_cameras(4, width=400, height=400)[0]
-        f0 = torch.rand(2000, 5)
-        t0 = time.time()
-        with torch.no_grad():
-            o0 = tr.rasterize(torch.ones(3), sc0["xyz"], f0, None, sc0["opacity"], sc0["scales"], sc0["rotations"], 1.0,
-                              None, cam0.world_view_transform, cam0.full_proj_transform, cam0.tanfovx, cam0.tanfovy,
-                              cam0.cx, cam0.cy, 400, 400, sc0["shs"], 3, cam0.camera_center)
-        extra["pytorch_cpu_config0"] = dict(
-            seconds_per_view=round(time.time() - t0, 3), threads=os.cpu_count(),
-            what="pure-PyTorch CPU rasterize forward (oracle/torch_rasterizer.py), 2000 Gaussians, one 400x400 view, "
-                 "num_rendered=%d" % int(o0["num_rendered"]))
-    except Exception as e:
-        extra["pytorch_cpu_config0"] = {"failed": repr(e)}
+    extra = {"pytorch_cpu_config0": pytorch_cpu_config0()}
     return dict(value=views / (t_f + t_b), unit="iters/s", cores=1, kind="port", **extra,
                 sample="%d views %dx%d, %d Gaussians, R~%d, rasterize fwd+bwd S=%d only (oracle C port, fp32, 1 thread; "
                        "fwd %.1fs + bwd %.1fs of CPU time); shading/Adam not included" % (
                            views, W, H, P, R, S, t_f, t_b))
+
+
+_CONFIG0_SCRIPT = """
+import json, os, sys, time
+sys.path.insert(0, %r)
+import torch
+from oracle import torch_rasterizer as tr
+from relightable3dgaussian_amd import synthetic as syn
+torch.set_num_threads(%d)
+sc0 = syn.make_scene(P=2000, seed=0, stage2=False, scale_log_mean=-3.0)
+cam0 = syn.orbit_cameras(4, width=400, height=400)[0]
+f0 = torch.rand(2000, 5)
+t0 = time.time()
+with torch.no_grad():
+    o0 = tr.rasterize(torch.ones(3), sc0["xyz"], f0, None, sc0["opacity"], sc0["scales"], sc0["rotations"], 1.0, None,
+                      cam0.world_view_transform, cam0.full_proj_transform, cam0.tanfovx, cam0.tanfovy, cam0.cx, cam0.cy,
+                      400, 400, sc0["shs"], 3, cam0.camera_center)
+print(json.dumps(dict(seconds_per_view=round(time.time() - t0, 3), num_rendered=int(o0["num_rendered"]))))
+"""
+
+
+def pytorch_cpu_config0(timeout_s=60):
+    """configs[0]: the reference's own CPU-runnable plumbing case (2k random Gaussians, one 400x400 view) through the
+    pure-PyTorch restatement (oracle/torch_rasterizer.py), timed on the host cores.  Runs in a child process with a hard
+    time limit and a thread count taken from the CPU affinity mask (capped at 8): on a box whose container sees more
+    logical CPUs than it may use, os.cpu_count() OpenMP threads make the thousands of tiny tensor ops of the tile loop
+    crawl for minutes -- a reported baseline must never be able to stall the bench."""
+    import subprocess
+    import sys
+    try:
+        usable = len(os.sched_getaffinity(0))
+    except AttributeError:
+        usable = os.cpu_count() or 1
+    threads = max(1, min(8, usable))
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, OMP_NUM_THREADS=str(threads), MKL_NUM_THREADS=str(threads), HIP_VISIBLE_DEVICES="")
+    what = "pure-PyTorch CPU rasterize forward (oracle/torch_rasterizer.py), 2000 Gaussians, one 400x400 view"
+    try:
+        r = subprocess.run([sys.executable, "-c", _CONFIG0_SCRIPT % (root, threads)], capture_output=True, text=True,
+                           timeout=timeout_s, env=env, stdin=subprocess.DEVNULL)
+        line = [x for x in r.stdout.splitlines() if x.startswith("{")]
+        if r.returncode != 0 or not line:
+            return {"failed": (r.stderr or r.stdout)[-300:], "threads": threads}
+        doc = json.loads(line[-1])
+        return dict(seconds_per_view=doc["seconds_per_view"], threads=threads, logical_cpus=os.cpu_count(),
+                    what=what + ", num_rendered=%d" % doc["num_rendered"])
+    except subprocess.TimeoutExpired:
+        return {"failed": "no result within %d s" % timeout_s, "threads": threads, "logical_cpus": os.cpu_count()}
+    except Exception as e:
+        return {"failed": repr(e)}
 
 
 def pmc_traffic(stage):

@@ -67,3 +67,30 @@ def test_operation_matches_reference(path):
         np.testing.assert_array_equal(m.v[n], z["out_%s_exp_avg_sq" % n], err_msg=n + " exp_avg_sq")
     for s in STATS:
         np.testing.assert_array_equal(m.s[s], z["out_" + s], err_msg=s)
+
+
+def test_host_mirror_structs_and_argument_checks():
+    """Host logic that needs no GPU: the ctypes mirrors of r3dg_densify_config / r3dg_densify_group have the C layout,
+    and the mirror refuses CPU tensors (there is no fallback path) and incomplete group sets before touching the library."""
+    import collections
+    import ctypes as C
+    import torch
+    from relightable3dgaussian_amd import densify as D
+    assert C.sizeof(D.DensifyConfig) == 2 * 4 + 8 * 4
+    assert C.sizeof(D.DensifyGroup) == 6 * C.sizeof(C.c_void_p) + 2 * 4
+    assert D.MAX_GROUPS + 4 <= 24            # R3DG_DENSIFY_MAX_GROUPS, prune() appends four statistics rows
+    P = 8
+    groups = collections.OrderedDict(
+        (n, dict(param=torch.zeros((P,) + s), exp_avg=None, exp_avg_sq=None))
+        for n, s in (("xyz", (3,)), ("scaling", (3,)), ("rotation", (4,)), ("opacity", (1,))))
+    st = D.DensificationStats(P, torch.device("cpu"))
+    assert st.column("denom").shape == (P, 1) and st.max_radii2D.shape == (P,)
+    with pytest.raises(RuntimeError, match="device tensor"):
+        D.densify_and_prune(groups, st, 2e-4, 0.005, 4.0, 20, 2e-9, 0.01)
+    with pytest.raises(RuntimeError, match="device tensor"):
+        D.reset_opacity(groups["opacity"]["param"])
+    with pytest.raises(RuntimeError, match="device tensor"):
+        st.add(torch.zeros(P, 3), None, torch.zeros(P, dtype=torch.int32), torch.zeros(P, 1))
+    del groups["rotation"]
+    with pytest.raises(RuntimeError, match="rotation"):
+        D.prune(groups, st, 0.005, 4.0, 20)

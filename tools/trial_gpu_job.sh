@@ -1,8 +1,13 @@
 cd /root/repo
-timeout 600 python -m pytest tests/test_fused_step_gpu.py -q -x -p no:cacheprovider < /dev/null > gpurun_out/trial_pytest.log 2>&1
-tail -3 gpurun_out/trial_pytest.log
-python bench.py --no-cpu-baseline --relight-frames 0 --no-other-configs > gpurun_out/b3.log 2>&1; python - <<EOF
-import json
-l=[x for x in open("gpurun_out/b3.log") if x.startswith("{")][-1]
-d=json.loads(l); print(d["value"], d["ms_per_step"]); print({k:v["ms_per_iteration"] for k,v in d["kernels"].items()})
-EOF
+run() { # name, args...
+  name=$1; shift
+  timeout 120 python -c "
+import faulthandler, sys, runpy
+faulthandler.dump_traceback_later(75, exit=True)
+sys.argv = ['bench.py'] + '$*'.split()
+runpy.run_path('bench.py', run_name='__main__')
+" > gpurun_out/diag_$name.log 2>&1
+  echo "== $name rc=$?"; tail -c 1200 gpurun_out/diag_$name.log | tail -25
+}
+run relight --steps 8 --warmup 4 --no-other-configs --no-cpu-baseline --relight-frames 5
+run cpu --steps 8 --warmup 4 --no-other-configs --relight-frames 0 --cpu-baseline-seconds 5
