@@ -296,6 +296,25 @@ typedef struct r3dg_adam_group {
 int r3dg_adam_step(void* stream, int n_groups, const r3dg_adam_group* groups, float beta1, float beta2, float eps,
                    int step, float grad_scale);
 
+/* ---- relight / eval frame glue (relighting.py:114-170 -> gaussian_renderer/neilf.py:74-209 with is_training=False) -----
+ * r3dg_relight_pack_features: the S=28 eval feature row (neilf.py:124-130) from the activated parameters and the 19
+ *   outputs of r3dg_shade_forward: depth, depth^2, pbr3, normal3, base_color3, roughness, diffuse3, specular3, incident /
+ *   local / global light means (3 each), mean visibility.  d_features [P,28] must be 16-byte aligned.
+ * r3dg_relight_compose: per pixel the camera ray in world space (Camera.get_world_directions, scene/cameras.py:79-91;
+ *   d_viewmatrix = world_view_transform, whose upper-left 3x3 is the camera-to-world rotation), the lat-long lookup of the
+ *   HDR environment map d_envmap [He,We,3] (EnvLight.direct_light, scene/envmap.py:35-53; d_light_transform = row-major
+ *   3x3 rotation applied as dirs @ T^T, or NULL) and the composites of neilf.py:203-207 -- any output may be NULL:
+ *     d_pbr_env = srgb(pbr * opacity + (1 - opacity) * env), d_render_env = image + (1 - opacity) * srgb(env),
+ *     d_env_only = srgb(env), all [3,H,W].  d_feature is the rasterizer's [S>=5,H,W] feature image (pbr in channels 2..4,
+ *   un-normalised: it is divided by max(opacity, 1e-5) and masked by n_contrib > 0 here, neilf.py:146-147). */
+int r3dg_relight_pack_features(void* stream, int P, const float* d_xyz, const float* d_viewmatrix, const float* d_normal,
+                               const float* d_base_color, const float* d_roughness, const float* d_shade_out,
+                               float* d_features);
+int r3dg_relight_compose(void* stream, int width, int height, float focal_x, float focal_y, float cx, float cy,
+                         const float* d_viewmatrix, const float* d_light_transform, const float* d_envmap, int He, int We,
+                         const float* d_image, const float* d_opacity, const float* d_feature,
+                         const int32_t* d_n_contrib, float* d_pbr_env, float* d_render_env, float* d_env_only);
+
 /* ---- densification bookkeeping -------------------------------------------------------------------
  * r3dg_densify_accumulate: GaussianModel.add_densification_stats (scene/gaussian_model.py:931-937) + the max-radii
  *   update of train.py:164-165, one pass.  The visibility filter is radii > 0 (render.py / neilf.py `visibility_filter`).

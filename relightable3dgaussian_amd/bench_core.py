@@ -216,71 +216,38 @@ def pmc_traffic(stage):
     return None
 
 
-def env_background(cam, envmap):
-    """Per-pixel environment colour (Camera.get_world_directions cameras.py:79-91 + EnvLight.direct_light
-    envmap.py:35-53) as plain torch ops."""
-    H, W = cam.image_height, cam.image_width
-    dev = envmap.device
-    fx, fy = W / (2 * cam.tanfovx), H / (2 * cam.tanfovy)
-    v, u = torch.meshgrid(torch.arange(H, device=dev), torch.arange(W, device=dev), indexing="ij")
-    d = torch.stack([(u - cam.cx) / fx, (v - cam.cy) / fy, torch.ones_like(u, dtype=torch.float32)], 0)
-    d = torch.nn.functional.normalize(d, dim=0)
-    c2w_rot = cam.world_view_transform[:3, :3]            # (W2C^T)[:3,:3] = R_w2c^T = R_c2w
-    d = (c2w_rot @ d.reshape(3, -1)).t()
-    phi = torch.arccos(d[:, 2].clamp(-1, 1)) - 1e-6
-    theta = torch.atan2(d[:, 1], d[:, 0])
-    grid = torch.stack((-theta / math.pi, (phi / math.pi) * 2 - 1), -1)[None, None]
-    col = torch.nn.functional.grid_sample(envmap.permute(2, 0, 1)[None], grid, align_corners=True)
-    return col[0, :, 0].reshape(3, H, W)
-
-
 @torch.no_grad()
 def relight_bench(params, cams, dev, frames, K):
-    """Relight / eval rendering (relighting.py:114-170, neilf.py:98-130 eval branch): per frame the shading integral at
-    K samples under a fixed HDR environment map + rasterize forward with the S=28 eval feature row + env background."""
-    from . import train_step
-    from .shading_ops import shade
+    """Relight / eval rendering (relighting.py:114-170, neilf.py:98-209 eval branch): per frame the shading integral at
+    K samples under a fixed HDR environment map + rasterize forward with the S=28 eval feature row + the environment
+    composite, through relight.RelightRenderer (all glue in HIP); the same frames through the drop-in ops + PyTorch glue
+    (relight.frame_reference, the shape the reference's render_view has) are timed beside it."""
+    from . import relight
     g = torch.Generator().manual_seed(7)
     envmap = (3.0 * torch.rand(256, 512, 3, generator=g) ** 2).to(dev)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    vis, dirs, areas, tracer = train_step.update_visibility(params.xyz, params.get_scaling(), params.get_rotation(),
-                                                            params.get_opacity(), params.get_normal(), K)
+    renderer = relight.RelightRenderer(params, envmap, K)              # builds the BVH and traces P x K visibility rays
     torch.cuda.synchronize()
     t_vis = time.perf_counter() - t0
-    base_color = 0.03 + 0.77 * torch.sigmoid(params.base_color)
-    roughness = 0.09 + 0.9 * torch.sigmoid(params.roughness)
-    normal = params.get_normal()
-    incidents = torch.cat([params.incidents_dc, params.incidents_rest], 1)
     bg = torch.zeros(3, device=dev)
-    opacity_a, shs, scales, rot = params.get_opacity(), params.get_shs(), params.get_scaling(), params.get_rotation()
 
-    def frame(cam):
-        viewdirs = torch.nn.functional.normalize(cam.camera_center - params.xyz, dim=-1)
-        pbr, diffuse, rest = shade(base_color, roughness, normal, viewdirs, incidents, envmap, vis, dirs, areas)
-        xyz_h = torch.cat([params.xyz, torch.ones_like(params.xyz[:, :1])], -1)
-        depths = (xyz_h @ cam.world_view_transform)[:, 2:3]
-        feats = torch.cat([depths, depths.square(), pbr, normal, base_color, roughness, diffuse, rest], -1)   # S = 28
-        outs = GaussianRasterizer(raster_settings(cam, bg))(params.xyz, torch.zeros_like(params.xyz), opacity_a,
-                                                            shs=shs, scales=scales, rotations=rot, features=feats)
-        _, n_contrib, image, opacity, depth, feature, pn, sxyz, weights, radii = outs
-        feat = feature / opacity.clamp_min(1e-5) * (n_contrib > 0)
-        pbr_img = feat[2:5]
-        env_rgb = env_background(cam, envmap)
-        return pbr_img * opacity + (1 - opacity) * env_rgb
+    def timed(fn, n):
+        for i in range(3):
+            fn(cams[i])
+        torch.cuda.synchronize()
+        t = time.perf_counter()
+        for i in range(n):
+            fn(cams[(3 + i) % len(cams)])
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t) / n
 
-    for i in range(3):
-        frame(cams[i])
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for i in range(frames):
-        frame(cams[(3 + i) % len(cams)])
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
+    dt = timed(lambda cam: renderer.frame(cam, bg), frames)
+    dt_ref = timed(lambda cam: relight.frame_reference(renderer, cam, bg), max(3, frames // 4))
     P = params.xyz.shape[0]
-    return dict(relight_fps=round(frames / dt, 2), relight_ms_per_frame=round(1e3 * dt / frames, 3), relight_K=K,
-                relight_features=28, visibility_rays=P * K, visibility_seconds=round(t_vis, 3),
-                visibility_Mrays_per_s=round(P * K / t_vis / 1e6, 1))
+    return dict(relight_fps=round(1.0 / dt, 2), relight_ms_per_frame=round(1e3 * dt, 3), relight_K=K,
+                relight_features=28, relight_fps_pytorch_glue=round(1.0 / dt_ref, 2), visibility_rays=P * K,
+                visibility_seconds=round(t_vis, 3), visibility_Mrays_per_s=round(P * K / t_vis / 1e6, 1))
 
 
 def quick_rate(stage, points, res, sample_num, dev, steps=20, warmup=4):

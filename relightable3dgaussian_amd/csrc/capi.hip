@@ -127,6 +127,12 @@ void launch_densify_gather(hipStream_t s, int P_out, const int32_t* src_row, con
                            const r3dg_densify_group* groups, const float* xyz, const float* scaling_raw,
                            const float* rotation_raw, const float* normal_table, float split_divisor);
 void launch_reset_opacity(hipStream_t s, int P, float cap, float* opacity_raw, float* exp_avg, float* exp_avg_sq);
+void launch_relight_pack(hipStream_t s, int P, const float* xyz, const float* viewmatrix, const float* normal,
+                         const float* base_color, const float* roughness, const float* shade_out, float* features);
+void launch_relight_compose(hipStream_t s, int W, int H, float fx, float fy, float cx, float cy,
+                            const float* viewmatrix, const float* tr, const float* env, int He, int We,
+                            const float* image, const float* opacity, const float* feature, const int* n_contrib,
+                            float* pbr_env, float* render_env, float* env_only);
 size_t knn_temp_bytes(size_t P);
 void knn_dist2(hipStream_t s, int P, const float* pts, float* dists, void* temp);
 size_t bvh_build_temp_bytes(size_t P);
@@ -1119,6 +1125,39 @@ int r3dg_adam_step(void* stream_, int n_groups, const r3dg_adam_group* groups, f
     return guarded([&]() -> int {
         StageTimer t((hipStream_t)stream_, ST_ADAM);
         launch_adam((hipStream_t)stream_, n_groups, groups, beta1, beta2, eps, step, grad_scale);
+        return R3DG_OK;
+    });
+}
+
+int r3dg_relight_pack_features(void* stream_, int P, const float* xyz, const float* viewmatrix, const float* normal,
+                               const float* base_color, const float* roughness, const float* shade_out, float* features)
+{
+    if (P < 0) return invalid("relight_pack_features: bad P");
+    if (P == 0) return R3DG_OK;
+    if (!xyz || !viewmatrix || !normal || !base_color || !roughness || !shade_out || !features)
+        return invalid("relight_pack_features: null buffer");
+    if ((size_t)features & 15) return invalid("relight_pack_features: features must be 16-byte aligned");
+    return guarded([&]() -> int {
+        StageTimer t((hipStream_t)stream_, ST_S2_PACK);
+        launch_relight_pack((hipStream_t)stream_, P, xyz, viewmatrix, normal, base_color, roughness, shade_out, features);
+        return R3DG_OK;
+    });
+}
+
+int r3dg_relight_compose(void* stream_, int width, int height, float focal_x, float focal_y, float cx, float cy,
+                         const float* viewmatrix, const float* light_transform, const float* envmap, int He, int We,
+                         const float* image, const float* opacity, const float* feature, const int32_t* n_contrib,
+                         float* pbr_env, float* render_env, float* env_only)
+{
+    if (width < 0 || height < 0 || He < 1 || We < 1) return invalid("relight_compose: bad shape");
+    if ((long long)width * height == 0) return R3DG_OK;
+    if ((long long)width * height >= (1ll << 31)) return invalid("relight_compose: image too large");
+    if (!viewmatrix || !envmap || !opacity || !feature || !n_contrib) return invalid("relight_compose: null buffer");
+    if (render_env && !image) return invalid("relight_compose: render_env needs the rendered image");
+    if (!(focal_x > 0.f) || !(focal_y > 0.f)) return invalid("relight_compose: focal lengths must be positive");
+    return guarded([&]() -> int {
+        launch_relight_compose((hipStream_t)stream_, width, height, focal_x, focal_y, cx, cy, viewmatrix, light_transform,
+                               envmap, He, We, image, opacity, feature, n_contrib, pbr_env, render_env, env_only);
         return R3DG_OK;
     });
 }

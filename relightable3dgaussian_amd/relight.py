@@ -1,0 +1,180 @@
+"""Relight / eval frames (relighting.py:114-170 -> gaussian_renderer/neilf.py:74-209 with is_training=False): per frame the
+shading integral at K samples under a fixed HDR environment map (EnvLight, optional rotation), the S=28 eval feature
+row, the rasterizer forward and the environment composites.
+
+`RelightRenderer.frame` runs the whole frame through the C ABI -- activations + view directions (r3dg_stage2_activate),
+r3dg_shade_forward, r3dg_relight_pack_features, the rasterizer forward, r3dg_relight_compose -- five streaming passes
+around the two hot kernels where the reference (and `frame_reference` below, the parity target) spends a few dozen
+PyTorch elementwise launches.  Replicas only under multi-GPU: frames are independent, no collective.
+"""
+import math
+
+import torch
+import torch.nn.functional as F
+
+from . import _lib, rasterizer_ops, shading_ops
+from .train_step import update_visibility
+
+
+def _shs_of(model):
+    if hasattr(model, "shs"):
+        return model.shs
+    return torch.cat([model.features_dc.detach(), model.features_rest.detach()], 1).contiguous()
+
+
+def _incidents_of(model):
+    if hasattr(model, "incidents"):
+        return model.incidents
+    return torch.cat([model.incidents_dc.detach(), model.incidents_rest.detach()], 1).contiguous()
+
+
+class RelightRenderer:
+    """`model`: anything holding the RAW parameters xyz, normal, scaling, rotation, opacity, base_color, roughness,
+    SH colour (`shs` or `features_dc`/`features_rest`) and incident light (`incidents` or `incidents_dc`/`_rest`) --
+    bench_core.GaussianParams and fused_step.FusedStage2Step both do.  `envmap` [He,We,3] HDR (EnvLight.envmap)."""
+
+    def __init__(self, model, envmap, sample_num, process_group=None):
+        d = lambda t: t.detach().contiguous()
+        self.xyz, self.normal = d(model.xyz), d(model.normal)
+        self.scaling, self.rotation, self.opacity = d(model.scaling), d(model.rotation), d(model.opacity)
+        self.base_color, self.roughness = d(model.base_color), d(model.roughness)
+        self.shs, self.incidents = d(_shs_of(model)), d(_incidents_of(model))
+        self.envmap = d(envmap)
+        if self.envmap.dim() != 3 or self.envmap.shape[2] != 3:
+            raise RuntimeError("envmap must be [He,We,3]")
+        for t in (self.xyz, self.envmap):
+            if not t.is_cuda:
+                raise RuntimeError("RelightRenderer needs device tensors (there is no CPU path)")
+        self.dev = dev = self.xyz.device
+        self.P = P = self.xyz.shape[0]
+        self.K, self.M = sample_num, self.shs.shape[1]
+        f = dict(dtype=torch.float32, device=dev)
+        self.a_scales, self.a_rot = torch.empty(P, 3, **f), torch.empty(P, 4, **f)
+        self.a_opacity, self.a_normal = torch.empty(P, 1, **f), torch.empty(P, 3, **f)
+        self.a_base, self.a_rough = torch.empty(P, 3, **f), torch.empty(P, 1, **f)
+        self.a_viewdirs = torch.empty(P, 3, **f)
+        self.shade_out = torch.empty(P, shading_ops.NOUT, **f)
+        self.features = torch.empty(P, 28, **f)
+        with torch.no_grad():
+            self._activate(torch.zeros(3, device=dev))
+            self.visibility, self.incident_dirs, self.incident_areas, self.tracer = update_visibility(
+                self.xyz, self.a_scales, self.a_rot, self.a_opacity, self.a_normal, sample_num, group=process_group)
+
+    def _activate(self, campos):
+        with torch.cuda.device(self.dev):
+            st = _lib.lib().r3dg_stage2_activate(
+                _lib.current_stream(), self.P, self.xyz.data_ptr(), self.scaling.data_ptr(), self.rotation.data_ptr(),
+                self.opacity.data_ptr(), self.normal.data_ptr(), self.base_color.data_ptr(), self.roughness.data_ptr(),
+                campos.contiguous().data_ptr(), self.a_scales.data_ptr(), self.a_rot.data_ptr(),
+                self.a_opacity.data_ptr(), self.a_normal.data_ptr(), self.a_base.data_ptr(), self.a_rough.data_ptr(),
+                self.a_viewdirs.data_ptr())
+        _lib.check(st, "stage2_activate")
+
+    @torch.no_grad()
+    def frame(self, cam, bg, env_transform=None, outputs=("pbr_env",)):
+        """-> dict with the rasterizer's public outputs ("render", "opacity", "depth", "feature", "pseudo_normal",
+        "num_rendered", "num_contrib", "radii") and the requested composites out of "pbr_env", "render_env", "env_only"
+        (neilf.py:203-207), each [3,H,W]."""
+        L = _lib.lib()
+        P, dev = self.P, self.dev
+        H, W = cam.image_height, cam.image_width
+        vm = cam.world_view_transform.contiguous()
+        campos = cam.camera_center.contiguous()
+        tr = None if env_transform is None else env_transform.to(dev, torch.float32).contiguous()
+        He, We = self.envmap.shape[0], self.envmap.shape[1]
+        empty = torch.Tensor([])
+        stream = _lib.current_stream
+        with torch.cuda.device(dev):
+            self._activate(campos)
+            _lib.check(L.r3dg_shade_forward(
+                stream(), P, self.K, self.M, self.a_base.data_ptr(), self.a_rough.data_ptr(), self.a_normal.data_ptr(),
+                self.a_viewdirs.data_ptr(), self.incidents.data_ptr(), self.envmap.data_ptr(), He, We, _lib.ptr(tr),
+                self.visibility.data_ptr(), self.incident_dirs.data_ptr(), self.incident_areas.data_ptr(),
+                self.shade_out.data_ptr()), "shade_forward")
+            _lib.check(L.r3dg_relight_pack_features(
+                stream(), P, self.xyz.data_ptr(), vm.data_ptr(), self.a_normal.data_ptr(), self.a_base.data_ptr(),
+                self.a_rough.data_ptr(), self.shade_out.data_ptr(), self.features.data_ptr()), "relight_pack_features")
+            fw = rasterizer_ops.rasterize_gaussians(
+                bg, self.xyz, self.features, empty, self.a_opacity, self.a_scales, self.a_rot, 1.0, empty, vm,
+                cam.full_proj_transform, cam.tanfovx, cam.tanfovy, cam.cx, cam.cy, H, W, self.shs, 3, campos, False,
+                True, False)
+            R, n_contrib, image, opacity, depth, feature, pseudo_normal, sxyz, weights, radii = fw[:10]
+            res = dict(num_rendered=R, num_contrib=n_contrib, render=image, opacity=opacity, depth=depth, feature=feature,
+                       pseudo_normal=pseudo_normal, surface_xyz=sxyz, radii=radii)
+            want = {k: torch.empty(3, H, W, dtype=torch.float32, device=dev) for k in outputs}
+            for k in want:
+                if k not in ("pbr_env", "render_env", "env_only"):
+                    raise RuntimeError("unknown relight output %r" % k)
+            if want:
+                g = lambda k: want[k].data_ptr() if k in want else None
+                _lib.check(L.r3dg_relight_compose(
+                    stream(), W, H, W / (2.0 * cam.tanfovx), H / (2.0 * cam.tanfovy), cam.cx, cam.cy, vm.data_ptr(),
+                    _lib.ptr(tr), self.envmap.data_ptr(), He, We, image.data_ptr(), opacity.data_ptr(),
+                    feature.data_ptr(), n_contrib.data_ptr(), g("pbr_env"), g("render_env"), g("env_only")),
+                    "relight_compose")
+            res.update(want)
+        return res
+
+
+def rgb_to_srgb(img):
+    """utils/graphics_utils.py:207-213 (clip=True)."""
+    out = torch.where(img > 0.0031308, torch.pow(torch.clamp_min(img, 0.0031308), 1.0 / 2.4) * 1.055 - 0.055, 12.92 * img)
+    return out.clamp(0.0, 1.0)
+
+
+def env_directions(cam, envmap, env_transform=None):
+    """Per-pixel environment colour [3,H,W]: Camera.get_world_directions (scene/cameras.py:79-91) +
+    EnvLight.direct_light (scene/envmap.py:35-53) as plain torch ops."""
+    H, W = cam.image_height, cam.image_width
+    dev = envmap.device
+    fx, fy = W / (2 * cam.tanfovx), H / (2 * cam.tanfovy)
+    v, u = torch.meshgrid(torch.arange(H, device=dev), torch.arange(W, device=dev), indexing="ij")
+    d = torch.stack([(u - cam.cx) / fx, (v - cam.cy) / fy, torch.ones_like(u, dtype=torch.float32)], 0)
+    d = F.normalize(d, dim=0)
+    c2w_rot = cam.world_view_transform[:3, :3]            # (W2C^T)[:3,:3] = R_w2c^T = R_c2w
+    d = (c2w_rot @ d.reshape(3, -1)).t()
+    if env_transform is not None:
+        d = d @ env_transform.to(dev).t()
+    phi = torch.arccos(d[:, 2].clamp(-1, 1)) - 1e-6
+    theta = torch.atan2(d[:, 1], d[:, 0])
+    grid = torch.stack((-theta / math.pi, (phi / math.pi) * 2 - 1), -1)[None, None]
+    col = F.grid_sample(envmap.permute(2, 0, 1)[None], grid, align_corners=True)
+    return col[0, :, 0].reshape(3, H, W)
+
+
+@torch.no_grad()
+def frame_reference(renderer, cam, bg, env_transform=None, exact_activations=False):
+    """The same frame through the drop-in ops + PyTorch glue, shaped like the reference's render_view(is_training=False):
+    the parity target of RelightRenderer.frame (tests) and the 'before' of the relight measurement.
+    `exact_activations`: take the activated parameters / view directions from the renderer's activation kernel instead
+    of torch (exp / sigmoid differ in the last bit, which the rasterizer's alpha >= 1/255 test can turn into a visible
+    difference on a few pixels) -- isolates the glue under test."""
+    from .rasterizer import GaussianRasterizationSettings, GaussianRasterizer
+    r = renderer
+    if exact_activations:
+        r._activate(cam.camera_center)
+        base_color, roughness, normal = r.a_base.clone(), r.a_rough.clone(), r.a_normal.clone()
+        opacity_a, scales, rot, viewdirs = r.a_opacity.clone(), r.a_scales.clone(), r.a_rot.clone(), r.a_viewdirs.clone()
+    else:
+        base_color = 0.03 + 0.77 * torch.sigmoid(r.base_color)
+        roughness = 0.09 + 0.9 * torch.sigmoid(r.roughness)
+        normal = F.normalize(r.normal, dim=-1, eps=1e-3)
+        opacity_a, scales, rot = torch.sigmoid(r.opacity), torch.exp(r.scaling), F.normalize(r.rotation)
+        viewdirs = F.normalize(cam.camera_center - r.xyz, dim=-1)
+    tr = None if env_transform is None else env_transform.to(r.dev, torch.float32).contiguous()
+    pbr, diffuse, rest = shading_ops.shade(base_color, roughness, normal, viewdirs, r.incidents, r.envmap, r.visibility,
+                                           r.incident_dirs, r.incident_areas, tr)
+    xyz_h = torch.cat([r.xyz, torch.ones_like(r.xyz[:, :1])], -1)
+    depths = (xyz_h @ cam.world_view_transform)[:, 2:3]
+    feats = torch.cat([depths, depths.square(), pbr, normal, base_color, roughness, diffuse, rest], -1)      # S = 28
+    rs = GaussianRasterizationSettings(cam.image_height, cam.image_width, cam.tanfovx, cam.tanfovy, cam.cx, cam.cy, bg,
+                                       1.0, cam.world_view_transform, cam.full_proj_transform, 3, cam.camera_center,
+                                       False, True, True, False)
+    outs = GaussianRasterizer(rs)(r.xyz, torch.zeros_like(r.xyz), opacity_a, shs=r.shs, scales=scales, rotations=rot,
+                                  features=feats)
+    _, n_contrib, image, opacity, depth, feature, pn, sxyz, weights, radii = outs
+    feat = feature / opacity.clamp_min(1e-5) * (n_contrib > 0)
+    env_rgb = env_directions(cam, r.envmap, tr)
+    return dict(render=image, opacity=opacity, feature=feature, num_rendered=outs[0],
+                pbr_env=rgb_to_srgb(feat[2:5] * opacity + (1 - opacity) * env_rgb),
+                render_env=image + (1 - opacity) * rgb_to_srgb(env_rgb), env_only=rgb_to_srgb(env_rgb))

@@ -1,13 +1,9 @@
 cd /root/repo
-run() { # name, args...
-  name=$1; shift
-  timeout 120 python -c "
-import faulthandler, sys, runpy
-faulthandler.dump_traceback_later(75, exit=True)
-sys.argv = ['bench.py'] + '$*'.split()
-runpy.run_path('bench.py', run_name='__main__')
-" > gpurun_out/diag_$name.log 2>&1
-  echo "== $name rc=$?"; tail -c 1200 gpurun_out/diag_$name.log | tail -25
-}
-run relight --steps 8 --warmup 4 --no-other-configs --no-cpu-baseline --relight-frames 5
-run cpu --steps 8 --warmup 4 --no-other-configs --relight-frames 0 --cpu-baseline-seconds 5
+timeout 300 python -m pytest tests/test_relight_gpu.py -q -p no:cacheprovider < /dev/null > gpurun_out/trial_pytest.log 2>&1
+tail -25 gpurun_out/trial_pytest.log
+timeout 150 python bench.py --steps 8 --warmup 4 --no-cpu-baseline --no-other-configs --relight-frames 12 < /dev/null > gpurun_out/b4.log 2>&1
+python - <<EOF
+import json
+l=[x for x in open("gpurun_out/b4.log") if x.startswith("{")]
+print(json.loads(l[-1])["relight"] if l else open("gpurun_out/b4.log").read()[-1500:])
+EOF
