@@ -94,3 +94,59 @@ def test_host_mirror_structs_and_argument_checks():
     del groups["rotation"]
     with pytest.raises(RuntimeError, match="rotation"):
         D.prune(groups, st, 0.005, 4.0, 20)
+
+
+def test_training_loop_follows_the_reference_schedule(monkeypatch):
+    """train_loop.train_stage1 against train.py:158-175, with the fused iteration replaced by a recorder (no GPU): which
+    iterations collect statistics, densify (with which size / normal thresholds), reset the opacity, and skip the
+    optimizer step (the reference's step() finds .grad = None on the freshly replaced parameters)."""
+    import types
+    import torch
+    from relightable3dgaussian_amd import train_loop
+
+    log = []
+
+    class FakeStep:
+        def __init__(self, init, lr, lr_rest_scale, process_group, lrs):
+            self.dev, self.P, self.stats, self.lrs = torch.device("cpu"), 10, None, lrs
+
+        def enable_densification(self):
+            self.stats = object()
+
+        def forward_backward(self, cam, bg, gt):
+            log.append(("fb", cam, self.stats is not None))
+
+        def densify_and_prune(self, max_grad, min_opacity, extent, max_screen_size, max_grad_normal, percent_dense,
+                              generator):
+            log.append(("densify", max_grad, min_opacity, extent, max_screen_size, max_grad_normal, percent_dense))
+            self.P += 1
+            return dict(rows_out=self.P)
+
+        def reset_opacity(self):
+            log.append(("reset",))
+
+        def optimizer_step(self):
+            log.append(("step",))
+
+    monkeypatch.setattr(train_loop, "FusedStage1Step", FakeStep)
+    monkeypatch.setattr(torch, "Generator", lambda device=None: types.SimpleNamespace(manual_seed=lambda s: None))
+    sch = train_loop.Schedule(densify_from_iter=4, densification_interval=3, densify_until_iter=14,
+                              opacity_reset_interval=8, normal_densify_from_iter=7)
+    step, history = train_loop.train_stage1(None, ["c0", "c1", "c2"], [0, 1, 2], None, extent=2.0, schedule=sch,
+                                            iterations=16, white_background=True)
+    # reference: for it in 1..16: stats while it < 14; densify if it > 4 and it % 3 == 0 (and it < 14): 6, 9, 12;
+    # reset if it % 8 == 0 or (white and it == 4), only while it < 14: 4, 8
+    assert [(i, e) for i, e, _ in history] == [(4, "reset_opacity"), (6, "densify"), (8, "reset_opacity"),
+                                               (9, "densify"), (12, "densify")]
+    fb = [x for x in log if x[0] == "fb"]
+    assert [c for _, c, _ in fb] == ["c0", "c1", "c2"] * 5 + ["c0"]              # round robin over the views
+    assert [s for _, _, s in fb] == [True] * 13 + [False] * 3                    # statistics stop at densify_until_iter
+    dens = [x for x in log if x[0] == "densify"]
+    # size threshold 20 only after the first opacity-reset interval; normal threshold 99999 until normal_densify_from_iter
+    assert [(d[4], d[5]) for d in dens] == [(None, 99999), (20, 2e-9), (20, 2e-9)]
+    assert all(d[1:4] == (0.0002, 0.005, 2.0) and d[6] == 0.001 for d in dens)
+    # 16 iterations, 3 of them densify -> 13 optimizer steps; a reset alone does not skip the step
+    assert sum(1 for x in log if x == ("step",)) == 13
+    i6 = log.index(dens[0])
+    assert log[i6 + 1][0] == "fb"                                                # no optimizer step after the densify
+    assert step.lrs["xyz"] == sch.position_lr_init * 2.0 and step.lrs["opacity"] == 0.05

@@ -20,5 +20,5 @@ for c in FETCH_SIZE WRITE_SIZE; do
 done
 cd /root/repo
 python tools/pmc_traffic.py gpurun_out/pmc_traffic.json "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE collected in SEPARATE passes (tools/kbench_raster.py S=16, tools/kbench_shade.py K=64; P=300000, 800x800, R~1.77M), mean per launch" $dbs < /dev/null
-timeout 600 python bench.py < /dev/null 2>&1 | tail -1 > gpurun_out/bench_default.json
+timeout 240 python bench.py < /dev/null > gpurun_out/bench_default.log 2>&1; tail -1 gpurun_out/bench_default.log > gpurun_out/bench_default.json
 cut -c1-200 gpurun_out/bench_default.json
