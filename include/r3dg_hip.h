@@ -423,6 +423,8 @@ int r3dg_set_tuning4(int tile_binning);
 /* r3dg_set_tuning5: 1 = the per-Gaussian kernels (projection forward / backward) move their SH and dL_dsh rows through
  * LDS with coalesced 16-byte accesses (default); 0 = every thread walks its own row in HBM.  Results are identical. */
 int r3dg_set_tuning5(int stage_sh_rows);
+/* r3dg_set_tuning6: persistent workgroups per CU of the shading forward kernel (1..8; its 162 VGPRs allow 3 per CU). */
+int r3dg_set_tuning6(int shade_forward_blocks_per_cu);
 int r3dg_selftest_transpose_reduce(void* stream, int N, int dpp, const float* d_in, float* d_out, int* d_chan,
                                    int* d_owner);
 

@@ -142,6 +142,7 @@ void bvh_trace_opacity(hipStream_t s, int num_rays, const int32_t* nodes, const 
                        const float* normals, int32_t* contributes, float* out, int* overflow);
 extern int g_cull;
 extern int g_stage_sh_rows;
+extern int g_shade_fwd_blocks_per_cu;
 int g_tile_binning = 1;   // 1: bin per tile + per-tile LDS sort; 0: the reference's global (tile|depth) radix sort
 extern int g_fwd_wave8x8;
 extern int g_bwd_wave8x8;
@@ -284,6 +285,13 @@ int r3dg_max_features_forward(void) { return R3DG_MAX_S_FWD; }
 int r3dg_max_features_backward(void) { return R3DG_MAX_S_BWD; }
 
 // tuning knobs (pixels per lane of the two render kernels); not part of the drop-in surface
+int r3dg_set_tuning6(int shade_forward_blocks_per_cu)
+{
+    if (shade_forward_blocks_per_cu >= 1 && shade_forward_blocks_per_cu <= 8)
+        g_shade_fwd_blocks_per_cu = shade_forward_blocks_per_cu;
+    return R3DG_OK;
+}
+
 int r3dg_set_tuning5(int stage_sh_rows)
 {
     if (stage_sh_rows >= 0) g_stage_sh_rows = stage_sh_rows;

@@ -720,15 +720,15 @@ shade_backward_kernel(int P, int K, int M, ShadeSrc src, const float* __restrict
     }
 }
 
-static int shade_grid_impl(int P);
-static int shade_grid(int P) { return shade_grid_impl(P); }
-static int shade_grid_impl(int P)
+int g_shade_fwd_blocks_per_cu = 2;   // r3dg_set_tuning6: persistent workgroups per CU of the shading forward
+
+static int shade_grid(int P, int blocks_per_cu = 2)
 {
     int dev = 0, cus = 256;
     (void)hipGetDevice(&dev);
     (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
     const int want = (P + SH_GB - 1) / SH_GB;
-    const int cap = cus * 2;      // resident at 2 waves/SIMD: persistent blocks, nothing queued behind them
+    const int cap = cus * blocks_per_cu;      // persistent blocks, all resident: nothing queued behind them
     return want < cap ? (want > 0 ? want : 1) : cap;
 }
 
@@ -753,7 +753,7 @@ void launch_shade_forward(hipStream_t s, int P, int K, int M, const float* base_
                           float* out)
 {
     const int ntex = He * We * 3;
-    const int grid = shade_grid(P);
+    const int grid = shade_grid(P, g_shade_fwd_blocks_per_cu);
     const size_t u_bytes = SH_GB * 64 * sizeof(float);
     if (ntex <= ENV_LDS_MAX)
         shade_forward_kernel<true><<<grid, 64 * SHADE_WAVES, ((ntex + 3) & ~3) * sizeof(float) + u_bytes, s>>>(

@@ -5,6 +5,8 @@ import torch
 from relightable3dgaussian_amd import _lib, shading_ops as so, sampling
 P = int(os.environ.get("P", 300000)); dev = "cuda"
 L = _lib.lib()
+if "FWD_BPC" in os.environ:
+    L.r3dg_set_tuning6(int(os.environ["FWD_BPC"]))
 g = torch.Generator().manual_seed(0)
 CASES = ((64, 16, 0),) if os.environ.get("ONLY64") else ((64, 16, 0), (384, 256, 0))
 for K, He, exp in CASES:
