@@ -5,7 +5,5 @@ render_equation.h (never bound in the reference snapshot) are exposed under the 
 from relightable3dgaussian_amd.rasterizer_ops import (mark_visible, rasterize_gaussians,  # noqa: F401
                                                       rasterize_gaussians_backward)
 
-try:  # shading ops are added once their kernels exist; the rasterizer names above never depend on them
-    from relightable3dgaussian_amd.shading_ops import *  # noqa: F401,F403
-except ImportError:  # pragma: no cover
-    pass
+from relightable3dgaussian_amd.shading_ops import (render_equation_backward, render_equation_forward,  # noqa: F401
+                                                   render_equation_forward_complex, rendering_equation, shade)

@@ -86,3 +86,66 @@ def test_fused_step_two_ranks(tmp_path):
         err = float((got - want).abs().max())
         assert err <= 1e-4 * scale + 1e-9, "%s: err %.3e scale %.3e" % (k, err, scale)
         assert scale > 0, k
+
+
+def _densify_worker(rank, world, port, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    from relightable3dgaussian_amd import synthetic as syn
+    from relightable3dgaussian_amd.bench_core import GaussianParams, render_stage1
+    from relightable3dgaussian_amd.fused_step import FusedStage1Step
+    torch.manual_seed(4321)
+    P, res = 3000, 128
+    scene = syn.make_scene(P=P, seed=21, stage2=False, scale_log_mean=-3.0)
+    cams = [c.to(dev) for c in syn.orbit_cameras(8, width=res, height=res)[:4]]
+    bg = torch.ones(3, device=dev)
+    params = GaussianParams(scene, dev, False)
+    with torch.no_grad():
+        teacher = GaussianParams(syn.make_scene(P=P, seed=21, stage2=False, scale_log_mean=-3.0), dev, False)
+        gts = [render_stage1(teacher, c, bg)[2].clone() * 0.8 for c in cams]
+    step = FusedStage1Step(params, lr=1e-3)
+    assert step.world == 2
+    step.enable_densification()
+    for i in range(3):                                   # each rank renders its own views
+        v = (2 * i + rank) % 4
+        step(cams[v], bg, gts[v])
+    local_denom = step.stats.denom.clone()
+    # the threshold must be the same number on both ranks: take it from a reduced COPY of the statistics
+    # (densify_and_prune reduces the real ones itself)
+    tmp = step.stats._slab[:4].clone()
+    dist.all_reduce(tmp)
+    mean_grad = tmp[0] / tmp[2].clamp_min(1)
+    thr = float(mean_grad[mean_grad > 0].median())
+    reduced_denom = tmp[2].clone()
+    info = step.densify_and_prune(thr, 0.005, 2.6, 20, 1e9, percent_dense=0.03,
+                                  generator=torch.Generator(device=dev).manual_seed(77))
+    v = rank % 4
+    step(cams[v], bg, gts[v])
+    torch.cuda.synchronize()
+    pars = {k: getattr(step, k).detach().cpu().clone() for k in step._opt_order}
+    moms = {k: step.opt.groups[i]["exp_avg"].detach().cpu().clone() for i, k in enumerate(step._opt_order)}
+    torch.save(dict(pars=pars, moms=moms, rows=info["rows_out"], cloned=info["cloned"], split=info["split"],
+                    local_denom=local_denom.cpu(), reduced_denom=reduced_denom.cpu()),
+               os.path.join(out_dir, "dens%d.pt" % rank))
+    dist.destroy_process_group()
+
+
+def test_densification_keeps_replicas_identical(tmp_path):
+    """Data-parallel stage-1 training with a densify_and_prune in the middle: per-rank statistics (own views, own
+    gradients) are reduced before the decisions and the split draws from identically seeded generators, so both ranks
+    end with the same number of rows and bit-identical parameters / Adam moments, also after a further iteration."""
+    mp.spawn(_densify_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    r0 = torch.load(os.path.join(tmp_path, "dens0.pt"))
+    r1 = torch.load(os.path.join(tmp_path, "dens1.pt"))
+    assert r0["rows"] == r1["rows"] and r0["cloned"] == r1["cloned"] > 0 and r0["split"] == r1["split"]
+    assert not torch.equal(r0["local_denom"], r1["local_denom"])             # the ranks really saw different views
+    assert torch.equal(r0["reduced_denom"], r1["reduced_denom"])
+    assert torch.equal(r0["reduced_denom"], r0["local_denom"] + r1["local_denom"])
+    for k in r0["pars"]:
+        assert r0["pars"][k].shape[0] == r0["rows"]
+        assert torch.equal(r0["pars"][k], r1["pars"][k]), "replicas diverged: " + k
+        assert torch.equal(r0["moms"][k], r1["moms"][k]), "Adam moments diverged: " + k
