@@ -34,10 +34,18 @@ class _Resizer:
         self.buffers = [torch.empty(0, dtype=torch.uint8, device=device) for _ in range(3)]
         self.callbacks = [_lib.ALLOC_FN(self._make(i)) for i in range(3)]
 
+    # Large requests are rounded up to 16 MiB steps: the binning buffer's size follows num_rendered, which changes with
+    # every view, and a caching allocator serves a handful of recurring sizes from its free lists where an ever-new size
+    # sooner or later costs a hipMalloc (milliseconds, in the middle of an iteration).  The state buffers are opaque.
+    _STEP = 16 << 20
+
     def _make(self, i):
         def cb(_user, nbytes):
             try:
-                self.buffers[i] = torch.empty(int(nbytes), dtype=torch.uint8, device=self.device)
+                n = int(nbytes)
+                if n > (4 << 20):
+                    n = (n + self._STEP - 1) // self._STEP * self._STEP
+                self.buffers[i] = torch.empty(n, dtype=torch.uint8, device=self.device)
                 return self.buffers[i].data_ptr()
             except Exception:          # surfaces as R3DG_EALLOC -> RuntimeError
                 return 0
