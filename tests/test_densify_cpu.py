@@ -150,3 +150,44 @@ def test_training_loop_follows_the_reference_schedule(monkeypatch):
     i6 = log.index(dens[0])
     assert log[i6 + 1][0] == "fb"                                                # no optimizer step after the densify
     assert step.lrs["xyz"] == sch.position_lr_init * 2.0 and step.lrs["opacity"] == 0.05
+
+
+def test_c_abi_argument_validation_without_a_gpu():
+    """The new entry points reject bad arguments before any HIP call (R3DG_EINVAL + a message), so this runs on the
+    CPU-only box: error behaviour is part of the boundary."""
+    import ctypes as C
+    from relightable3dgaussian_amd import _lib, densify as D
+    L = _lib.lib()
+    EINVAL = -1
+    cfg = D.DensifyConfig(0, 9, 2e-4, 2e-9, 0.005, 1e-4, 0.04, 0.4, 1.6, 20.0)
+    counts = (C.c_int32 * 8)()
+    assert L.r3dg_densify_plan(None, 16, C.addressof(cfg), 1, 1, 1, 1, 1, 1, 1, 1, 1, C.addressof(counts), 1) == EINVAL
+    assert b"n_split" in L.r3dg_last_error()
+    cfg.n_split, cfg.mode = 2, 7
+    assert L.r3dg_densify_plan(None, 16, C.addressof(cfg), 1, 1, 1, 1, 1, 1, 1, 1, 1, C.addressof(counts), 1) == EINVAL
+    cfg.mode = 0
+    assert L.r3dg_densify_plan(None, 16, C.addressof(cfg), None, 1, 1, 1, 1, 1, 1, 1, 1, C.addressof(counts), 1) == EINVAL
+    assert b"null" in L.r3dg_last_error()
+    assert L.r3dg_densify_plan(None, -1, C.addressof(cfg), 1, 1, 1, 1, 1, 1, 1, 1, 1, C.addressof(counts), 1) == EINVAL
+    assert L.r3dg_densify_accumulate(None, 8, None, None, 1, 1, 1, 1, 1, 1, 1) == EINVAL
+    assert L.r3dg_densify_accumulate(None, 0, None, None, None, None, None, None, None, None, None) == 0      # P == 0
+    grp = (D.DensifyGroup * 1)(D.DensifyGroup(1, None, None, 1, None, None, 4, 1))     # role xyz with 4-float rows
+    assert L.r3dg_densify_gather(None, 8, 1, 1, 1, C.cast(grp, C.c_void_p), 1, 1, 1, None, 1.6) == EINVAL
+    assert b"xyz rows" in L.r3dg_last_error()
+    grp[0] = D.DensifyGroup(1, 1, None, 1, 1, 1, 3, 0)                                   # exp_avg without exp_avg_sq
+    assert L.r3dg_densify_gather(None, 8, 1, 1, 1, C.cast(grp, C.c_void_p), 1, 1, 1, None, 1.6) == EINVAL
+    assert L.r3dg_densify_gather(None, 8, 1, 1, 25, C.cast(grp, C.c_void_p), 1, 1, 1, None, 1.6) == EINVAL
+    assert L.r3dg_densify_gather(None, 0, None, None, 0, None, None, None, None, None, 1.6) == 0               # nothing to do
+    assert L.r3dg_reset_opacity(None, 4, None, None, None) == EINVAL
+    assert L.r3dg_densify_temp_bytes(300000) >= 300000 + 4 * 4 * ((300000 + 255) // 256)
+    # relight glue
+    assert L.r3dg_relight_pack_features(None, 4, 1, 1, 1, 1, 1, 1, None) == EINVAL
+    assert L.r3dg_relight_pack_features(None, 4, 16, 16, 16, 16, 16, 16, 20) == EINVAL                      # misaligned rows
+    assert b"aligned" in L.r3dg_last_error()
+    assert L.r3dg_relight_compose(None, 8, 8, 0.0, 10.0, 4.0, 4.0, 1, None, 1, 16, 32, None, 1, 1, 1, 1, None,
+                                  None) == EINVAL                                                          # focal 0
+    assert L.r3dg_relight_compose(None, 8, 8, 10.0, 10.0, 4.0, 4.0, 1, None, 1, 16, 32, None, 1, 1, 1, None, 1,
+                                  None) == EINVAL                                                          # render_env w/o image
+    assert L.r3dg_relight_compose(None, 0, 8, 10.0, 10.0, 4.0, 4.0, None, None, None, 16, 32, None, None, None, None,
+                                  None, None, None) == 0                                                    # empty image
+    assert L.r3dg_ssim_forward_pair(None, 8, 8, 3, 1, 1, 1, 1, None, None, None) == EINVAL                  # image 1 w/o partials
