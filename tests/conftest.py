@@ -12,6 +12,16 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with `-m gpu` through gpurun)")
 
 
+@pytest.fixture(scope="session", autouse=True)
+def _built_library():
+    """The tests bind the in-tree libr3dg_hip.so.  A fresh checkout has none (built artefacts are git-ignored): build it
+    once per session when hipcc is there (it cross-compiles gfx950 without a GPU).  Building is not a fallback -- with
+    no library and no compiler the tests that need it fail loudly."""
+    from relightable3dgaussian_amd import _lib, build
+    if not os.path.exists(_lib.LIB_PATH) and os.path.exists(build.HIPCC):
+        build.build(verbose=False)
+
+
 @pytest.fixture(scope="session")
 def hip_lib():
     from relightable3dgaussian_amd import _lib
