@@ -355,7 +355,7 @@ def run(args):
         S = 5
     elif fused:
         # the whole iteration through the fused glue kernels + one-launch Adam (fused_step.py); gradients are averaged
-        # over ranks inside (two flat buckets, the first all-reduce overlapping the shading backward)
+        # over ranks inside (three buckets of one flat slab; see fused_step.py and DESIGN.md section 5)
         from . import fused_step
         step_fn = fused_step.FusedStage2Step(params, args.sample_num, lr=1e-4)
         S = 16

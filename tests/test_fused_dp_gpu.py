@@ -1,5 +1,5 @@
 """Data-parallel path of the fused stage-2 iteration: two ranks (two processes sharing the one GPU of the test box,
-`gloo` backend on device tensors -- RCCL refuses two ranks on one device) render different cameras; after the two-bucket
+`gloo` backend on device tensors -- RCCL refuses two ranks on one device) render different cameras; after the bucketed
 all-reduces (three buckets, the last one deferred into the next iteration) both must hold the SAME summed gradients,
 equal to the sum of two single-process backward passes, and stay bit-identical replicas after the Adam steps."""
 import os
