@@ -20,11 +20,27 @@ from .knn_ops import distCUDA2
 C0 = 0.28209479177387814          # RGB2SH (utils/sh_utils.py:130-131)
 
 
+def position_lr(step, lr_init, lr_final, lr_delay_mult=0.01, max_steps=30_000, lr_delay_steps=0):
+    """The xyz learning rate of iteration `step` (get_expon_lr_func, utils/general_utils.py:30-63, as
+    GaussianModel.training_setup instantiates it, scene/gaussian_model.py:488-491): log-linear interpolation from lr_init
+    to lr_final over max_steps, optionally eased in over lr_delay_steps."""
+    if step < 0 or (lr_init == 0.0 and lr_final == 0.0):
+        return 0.0
+    if lr_delay_steps > 0:
+        delay_rate = lr_delay_mult + (1 - lr_delay_mult) * math.sin(0.5 * math.pi * min(max(step / lr_delay_steps, 0), 1))
+    else:
+        delay_rate = 1.0
+    t = min(max(step / max_steps, 0), 1)
+    return delay_rate * math.exp(math.log(lr_init) * (1 - t) + math.log(lr_final) * t)
+
+
 class Schedule(types.SimpleNamespace):
     """The OptimizationParams fields the loop reads (arguments/__init__.py:70-106), same defaults."""
 
     def __init__(self, **kw):
-        super().__init__(iterations=30_000, position_lr_init=0.00016, normal_lr=0.01, sh_lr=0.0025, opacity_lr=0.05,
+        super().__init__(iterations=30_000, position_lr_init=0.00016, position_lr_final=0.0000016,
+                         position_lr_delay_mult=0.01, position_lr_max_steps=30_000, normal_lr=0.01, sh_lr=0.0025,
+                         opacity_lr=0.05,
                          scaling_lr=0.005, rotation_lr=0.001, percent_dense=0.001, densification_interval=100,
                          opacity_reset_interval=3000, densify_from_iter=500, densify_until_iter=10_000,
                          densify_grad_threshold=0.0002, densify_grad_normal_threshold=2e-9, normal_densify_from_iter=0,
@@ -66,7 +82,11 @@ def train_stage1(init, cameras, images, background, extent, schedule=None, itera
     step.enable_densification()
     gen = torch.Generator(device=step.dev).manual_seed(seed)
     history = []
+    xyz_group = step.opt.groups[step._opt_order.index("xyz")]
     for it in range(1, n_iter + 1):
+        # gaussians.update_learning_rate(iteration) (train.py:101): the position rate decays log-linearly
+        xyz_group["lr"] = position_lr(it, sch.position_lr_init * extent, sch.position_lr_final * extent,
+                                      sch.position_lr_delay_mult, sch.position_lr_max_steps)
         v = (it - 1) % len(cameras)
         collecting = it < sch.densify_until_iter
         if not collecting and step.stats is not None:
@@ -76,8 +96,8 @@ def train_stage1(init, cameras, images, background, extent, schedule=None, itera
             if it > sch.densify_from_iter and it % sch.densification_interval == 0:
                 size_threshold = 20 if it > sch.opacity_reset_interval else None
                 normal_thr = sch.densify_grad_normal_threshold if it > sch.normal_densify_from_iter else 99999
-                # the optimizer step of this iteration runs on the NEW tensors' moments in the reference as well
-                # (densify precedes gaussians.step(), train.py:167-177): gradients of the old rows are dropped
+                # densify precedes gaussians.step() (train.py:167-177), which then finds .grad = None on the freshly
+                # replaced parameters and updates nothing: the optimizer step of this iteration is skipped
                 info = step.densify_and_prune(sch.densify_grad_threshold, sch.min_opacity, extent, size_threshold,
                                               normal_thr, percent_dense=sch.percent_dense, generator=gen)
                 history.append((it, "densify", info["rows_out"]))

@@ -137,7 +137,24 @@ def main():
     case(GaussianModel, "stage2_densify", 64, True, 13, "densify_and_prune", 20)
     case(GaussianModel, "stage1_prune", 160, False, 14, "prune", 20)
     case(GaussianModel, "stage1_reset_opacity", 96, False, 15, "reset_opacity", None)
+    lr_schedule_fixture()
 
 
 if __name__ == "__main__":
     main()
+
+
+def lr_schedule_fixture():
+    """tests/golden/lr_schedule_reference.npz: values of the reference's get_expon_lr_func (utils/general_utils.py:30-63)
+    for the position learning rate; call after main()'s import setup."""
+    from utils.general_utils import get_expon_lr_func
+    steps = np.array([0, 1, 10, 100, 999, 1000, 5000, 15000, 29999, 30000, 40000, -3])
+    out = {}
+    for name, args in (("default", dict(lr_init=0.00016 * 4.0, lr_final=0.0000016 * 4.0, lr_delay_mult=0.01, max_steps=30000)),
+                       ("delayed", dict(lr_init=1e-3, lr_final=1e-5, lr_delay_steps=500, lr_delay_mult=0.1, max_steps=2000)),
+                       ("disabled", dict(lr_init=0.0, lr_final=0.0, max_steps=100))):
+        f = get_expon_lr_func(**args)
+        out[name] = np.array([f(int(s)) for s in steps], dtype=np.float64)
+        out[name + "_args"] = np.array([args.get("lr_init"), args.get("lr_final"), args.get("lr_delay_mult", 1.0),
+                                        args.get("max_steps"), args.get("lr_delay_steps", 0)], dtype=np.float64)
+    np.savez(os.path.join(HERE, "lr_schedule_reference.npz"), steps=steps, **out)

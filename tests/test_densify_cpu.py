@@ -107,14 +107,19 @@ def test_training_loop_follows_the_reference_schedule(monkeypatch):
     log = []
 
     class FakeStep:
+        _opt_order = ("xyz", "normal")
+
         def __init__(self, init, lr, lr_rest_scale, process_group, lrs):
             self.dev, self.P, self.stats, self.lrs = torch.device("cpu"), 10, None, lrs
+            self.opt = types.SimpleNamespace(groups=[dict(lr=lrs["xyz"]), dict(lr=lrs["normal"])])
+            self.xyz_lrs = []
 
         def enable_densification(self):
             self.stats = object()
 
         def forward_backward(self, cam, bg, gt):
             log.append(("fb", cam, self.stats is not None))
+            self.xyz_lrs.append(self.opt.groups[0]["lr"])
 
         def densify_and_prune(self, max_grad, min_opacity, extent, max_screen_size, max_grad_normal, percent_dense,
                               generator):
@@ -150,6 +155,21 @@ def test_training_loop_follows_the_reference_schedule(monkeypatch):
     i6 = log.index(dens[0])
     assert log[i6 + 1][0] == "fb"                                                # no optimizer step after the densify
     assert step.lrs["xyz"] == sch.position_lr_init * 2.0 and step.lrs["opacity"] == 0.05
+    # update_learning_rate(iteration) before every iteration: log-linear decay of the position rate, scaled by the extent
+    want = [train_loop.position_lr(i, 0.00016 * 2.0, 0.0000016 * 2.0, 0.01, 30000) for i in range(1, 17)]
+    assert step.xyz_lrs == want and want[0] > want[-1] > 0
+
+
+def test_position_lr_matches_the_reference_schedule():
+    """train_loop.position_lr against values of the reference's get_expon_lr_func (tests/golden/lr_schedule_reference.npz,
+    written by tests/golden/make_densify_golden.py)."""
+    from relightable3dgaussian_amd import train_loop
+    z = np.load(os.path.join(GOLDEN, "lr_schedule_reference.npz"))
+    for name in ("default", "delayed", "disabled"):
+        lr_init, lr_final, delay_mult, max_steps, delay_steps = z[name + "_args"]
+        got = [train_loop.position_lr(int(s), lr_init, lr_final, delay_mult, int(max_steps), int(delay_steps))
+               for s in z["steps"]]
+        np.testing.assert_allclose(got, z[name], rtol=1e-12, atol=0, err_msg=name)
 
 
 def test_c_abi_argument_validation_without_a_gpu():
