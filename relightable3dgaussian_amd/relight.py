@@ -178,3 +178,61 @@ def frame_reference(renderer, cam, bg, env_transform=None, exact_activations=Fal
     return dict(render=image, opacity=opacity, feature=feature, num_rendered=outs[0],
                 pbr_env=rgb_to_srgb(feat[2:5] * opacity + (1 - opacity) * env_rgb),
                 render_env=image + (1 - opacity) * rgb_to_srgb(env_rgb), env_only=rgb_to_srgb(env_rgb))
+
+
+# ---- multi-object composition (relighting.py:28-52 scene_composition; GaussianModel.set_transform
+# scene/gaussian_model.py:84-95, create_from_gaussians :344-356) -----------------------------------------------------------
+def _quaternion_of(R):
+    """Unit quaternion (w, x, y, z) of rotation matrices [n,3,3] the way the reference extracts it
+    (utils/general_utils.py:105-117: w from the trace, clamped at 1e-7, then normalised)."""
+    qw = torch.sqrt((1 + R[:, 0, 0] + R[:, 1, 1] + R[:, 2, 2]).clamp_min(1e-7)) / 2
+    q = torch.stack((qw, (R[:, 2, 1] - R[:, 1, 2]) / (4 * qw), (R[:, 0, 2] - R[:, 2, 0]) / (4 * qw),
+                     (R[:, 1, 0] - R[:, 0, 1]) / (4 * qw)), dim=-1)
+    return F.normalize(q, dim=-1)
+
+
+def _quaternion_product(a, b):
+    """Hamilton product a * b of (w, x, y, z) rows (utils/general_utils.py:141-151); `a` broadcasts over `b`."""
+    w1, x1, y1, z1 = a[:, 0], a[:, 1], a[:, 2], a[:, 3]
+    w2, x2, y2, z2 = b[:, 0], b[:, 1], b[:, 2], b[:, 3]
+    return torch.stack((w1 * w2 - x1 * x2 - y1 * y2 - z1 * z2, w1 * x2 + x1 * w2 + y1 * z2 - z1 * y2,
+                        w1 * y2 - x1 * z2 + y1 * w2 + z1 * x2, w1 * z2 + x1 * y2 - y1 * x2 + z1 * w2), dim=1)
+
+
+TRANSFORMED = ("xyz", "normal", "scaling", "rotation")
+
+
+@torch.no_grad()
+def transform_object(params, transform):
+    """GaussianModel.set_transform(transform=T) on a dict of RAW parameter tensors (xyz, normal, scaling, rotation + any
+    others, which pass through): similarity transform T [4,4] -- per-axis scale = row norms of T[:3,:3], rotation =
+    T[:3,:3] / scale; positions x T^T, log-scales + log(scale), normals x R^T, rotation quaternions pre-multiplied."""
+    T = transform.to(params["xyz"].device, torch.float32).reshape(4, 4)
+    scale = T[:3, :3].norm(dim=-1)
+    out = dict(params)
+    out["scaling"] = torch.log(torch.exp(params["scaling"]) * scale)
+    xyz_h = torch.cat([params["xyz"], torch.ones_like(params["xyz"][:, :1])], dim=-1)
+    out["xyz"] = (xyz_h @ T.T)[:, :3].contiguous()
+    R = T[:3, :3] / scale[:, None]
+    out["normal"] = params["normal"] @ R.T
+    out["rotation"] = _quaternion_product(_quaternion_of(R[None]), params["rotation"])
+    return out
+
+
+@torch.no_grad()
+def compose_scenes(objects, transforms):
+    """scene_composition (relighting.py:28-52): every object's parameters under its own 4x4 transform, concatenated row
+    wise in the order given; the incident-light coefficients of the composite are zeroed (:49-50).  `objects`: dicts of
+    raw parameter tensors with identical keys.  Returns one dict (feed it to RelightRenderer through a namespace)."""
+    if not objects or len(objects) != len(transforms):
+        raise RuntimeError("compose_scenes needs one transform per object")
+    moved = [transform_object(o, t) for o, t in zip(objects, transforms)]
+    keys = list(objects[0].keys())
+    for m in moved:
+        if list(m.keys()) != keys:
+            raise RuntimeError("compose_scenes: objects must hold the same parameter names in the same order")
+    out = {k: torch.cat([m[k] for m in moved], dim=0).contiguous() for k in keys}
+    for k in out:
+        if k.startswith("incidents"):
+            out[k].zero_()
+    return out

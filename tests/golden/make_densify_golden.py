@@ -138,10 +138,9 @@ def main():
     case(GaussianModel, "stage1_prune", 160, False, 14, "prune", 20)
     case(GaussianModel, "stage1_reset_opacity", 96, False, 15, "reset_opacity", None)
     lr_schedule_fixture()
+    composition_fixture()
 
 
-if __name__ == "__main__":
-    main()
 
 
 def lr_schedule_fixture():
@@ -158,3 +157,41 @@ def lr_schedule_fixture():
         out[name + "_args"] = np.array([args.get("lr_init"), args.get("lr_final"), args.get("lr_delay_mult", 1.0),
                                         args.get("max_steps"), args.get("lr_delay_steps", 0)], dtype=np.float64)
     np.savez(os.path.join(HERE, "lr_schedule_reference.npz"), steps=steps, **out)
+
+
+def composition_fixture():
+    """tests/golden/composition_reference.npz: GaussianModel.set_transform + create_from_gaussians + the incident reset of
+    scene_composition (relighting.py:28-52) on two small stage-2 models; call after main()'s import setup."""
+    from torch import nn
+    from scene.gaussian_model import GaussianModel
+    g = torch.Generator().manual_seed(42)
+    names = GROUPS_STAGE2
+    rec, models = {}, []
+    for j, P in enumerate((40, 25)):
+        m = GaussianModel(3, render_type="neilf")
+        for n in names:
+            v = 0.5 * torch.randn(P, *SHAPES[n], generator=g)
+            if n == "rotation":
+                v = torch.nn.functional.normalize(torch.randn(P, 4, generator=g), dim=-1)
+            setattr(m, ATTR[n], nn.Parameter(v.clone().requires_grad_(True)))
+            rec["obj%d_%s" % (j, n)] = v.numpy().copy()
+        A = torch.linalg.qr(torch.randn(3, 3, generator=g)).Q
+        if torch.det(A) < 0:
+            A[:, 0] = -A[:, 0]
+        T = torch.eye(4)
+        T[:3, :3] = A * (0.5 + j)                         # rotation x uniform scale
+        T[:3, 3] = torch.randn(3, generator=g)
+        rec["obj%d_transform" % j] = T.numpy().copy()
+        m.set_transform(transform=T)
+        models.append(m)
+    comp = GaussianModel.create_from_gaussians(models, types.SimpleNamespace(sh_degree=3))
+    comp._incidents_dc.data[:] = 0
+    comp._incidents_rest.data[:] = 0
+    for n in names:
+        rec["out_" + n] = getattr(comp, ATTR[n]).detach().numpy().copy()
+    rec["group_names"] = np.array(names)
+    np.savez_compressed(os.path.join(HERE, "composition_reference.npz"), **rec)
+
+
+if __name__ == "__main__":
+    main()

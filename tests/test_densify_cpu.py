@@ -211,3 +211,24 @@ def test_c_abi_argument_validation_without_a_gpu():
     assert L.r3dg_relight_compose(None, 0, 8, 10.0, 10.0, 4.0, 4.0, None, None, None, 16, 32, None, None, None, None,
                                   None, None, None) == 0                                                    # empty image
     assert L.r3dg_ssim_forward_pair(None, 8, 8, 3, 1, 1, 1, 1, None, None, None) == EINVAL                  # image 1 w/o partials
+
+
+def test_scene_composition_matches_reference():
+    """relight.compose_scenes (set_transform + create_from_gaussians + incident reset, relighting.py:28-52) against the
+    reference's own GaussianModel on two objects under rotation x scale x translation (tests/golden/composition_reference.npz)."""
+    import collections
+    import torch
+    from relightable3dgaussian_amd import relight
+    z = np.load(os.path.join(GOLDEN, "composition_reference.npz"))
+    names = [str(n) for n in z["group_names"]]
+    objs = [collections.OrderedDict((n, torch.from_numpy(z["obj%d_%s" % (j, n)])) for n in names) for j in range(2)]
+    trs = [torch.from_numpy(z["obj%d_transform" % j]) for j in range(2)]
+    out = relight.compose_scenes(objs, trs)
+    assert list(out.keys()) == names and out["xyz"].shape[0] == 65
+    for n in names:
+        tol = dict(rtol=2e-6, atol=2e-6) if n in relight.TRANSFORMED else dict(rtol=0, atol=0)
+        np.testing.assert_allclose(out[n].numpy(), z["out_" + n], err_msg=n, **tol)
+    assert float(out["incidents_dc"].abs().max()) == 0.0 and float(out["incidents_rest"].abs().max()) == 0.0
+    assert float(out["base_color"].abs().max()) > 0.0
+    with pytest.raises(RuntimeError):
+        relight.compose_scenes(objs, trs[:1])
