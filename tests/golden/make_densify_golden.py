@@ -139,6 +139,7 @@ def main():
     case(GaussianModel, "stage1_reset_opacity", 96, False, 15, "reset_opacity", None)
     lr_schedule_fixture()
     composition_fixture()
+    checkpoint_fixtures()
 
 
 
@@ -191,6 +192,50 @@ def composition_fixture():
         rec["out_" + n] = getattr(comp, ATTR[n]).detach().numpy().copy()
     rec["group_names"] = np.array(names)
     np.savez_compressed(os.path.join(HERE, "composition_reference.npz"), **rec)
+
+
+def checkpoint_fixtures():
+    """tests/golden/checkpoint_reference_stage{1,2}.pth: `(GaussianModel.capture(), iteration)` exactly as train.py:194-195
+    saves it, from small models with two Adam steps and three views of densification statistics.  Also checks, here where
+    the reference is importable, that the reference's own restore() + optimizer.load_state_dict() accept what
+    relightable3dgaussian_amd.checkpoint.capture() writes (the round trip through this repo's fused step object)."""
+    sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+    from scene.gaussian_model import GaussianModel
+    from relightable3dgaussian_amd import checkpoint as ck
+    from relightable3dgaussian_amd.fused_step import FusedStage1Step
+    from relightable3dgaussian_amd.densify import DensificationStats
+    for stage2, P, seed in ((False, 24, 51), (True, 16, 52)):
+        g = torch.Generator().manual_seed(seed)
+        m, names = build_model(GaussianModel, P, stage2, g, 4.0)
+        accumulate_views(m, P, g, 3, {})
+        obj = (m.capture(), 777)
+        path = os.path.join(HERE, "checkpoint_reference_stage%d.pth" % (2 if stage2 else 1))
+        torch.save(obj, path)
+        if not stage2:
+            r = ck.restore(path)
+            step = FusedStage1Step(r)                       # CPU tensors: construction launches nothing
+            ck.load_moments(step, r)
+            step.stats = DensificationStats(P, torch.device("cpu"))
+            for n in ck.STAT_NAMES:
+                getattr(step.stats, n).copy_(r.stats[n])
+            step.stats.max_radii2D.copy_(r.max_radii2D)
+            lrs = {grp["name"]: grp["lr"] for grp in m.optimizer.param_groups}
+            ours = ck.capture(step, 777, spatial_lr_scale=r.spatial_lr_scale, learning_rates=lrs)
+            fresh = GaussianModel(3, render_type="render")
+            args = types.SimpleNamespace(percent_dense=0.01, position_lr_init=1.6e-4, position_lr_final=1.6e-6,
+                                         position_lr_delay_mult=0.01, position_lr_max_steps=30000, normal_lr=2e-3,
+                                         rotation_lr=1e-3, scaling_lr=5e-3, opacity_lr=5e-2, sh_lr=2.5e-3)
+            fresh.restore(ours[0], args, is_training=True, restore_optimizer=False)
+            fresh.optimizer.load_state_dict(ours[0][13])     # restore() swallows exceptions: call it in the open
+            for grp_a, grp_b in zip(fresh.optimizer.param_groups, m.optimizer.param_groups):
+                assert grp_a["name"] == grp_b["name"]
+                pa, pb = grp_a["params"][0], grp_b["params"][0]
+                assert torch.equal(pa.data, pb.data), grp_a["name"]
+                sa, sb = fresh.optimizer.state[pa], m.optimizer.state[pb]
+                assert torch.equal(sa["exp_avg"], sb["exp_avg"]) and torch.equal(sa["exp_avg_sq"], sb["exp_avg_sq"])
+                assert float(sa["step"]) == float(sb["step"]) == 2.0
+            assert torch.equal(fresh.denom, m.denom) and torch.equal(fresh.max_radii2D, m.max_radii2D)
+            print("reference restore() + load_state_dict() accept checkpoint.capture():", path)
 
 
 if __name__ == "__main__":

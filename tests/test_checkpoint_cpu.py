@@ -1,0 +1,106 @@
+"""The reference's checkpoint format (train.py:190-203, GaussianModel.capture / restore) through
+relightable3dgaussian_amd.checkpoint, on the files the reference's own GaussianModel wrote
+(tests/golden/checkpoint_reference_stage{1,2}.pth, tests/golden/make_densify_golden.py -- which also verified, with the
+reference importable, that its restore() + optimizer.load_state_dict() accept what capture() writes)."""
+import os
+import types
+
+import pytest
+import torch
+
+from relightable3dgaussian_amd import checkpoint as ck
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def _load(stage):
+    path = os.path.join(GOLDEN, "checkpoint_reference_stage%d.pth" % stage)
+    return path, torch.load(path, map_location="cpu", weights_only=False)
+
+
+@pytest.mark.parametrize("stage", [1, 2])
+def test_restore_reads_the_reference_file(stage):
+    path, (captured, iteration) = _load(stage)
+    r = ck.restore(path)
+    assert r.iteration == iteration == 777 and r.active_sh_degree == captured[0] == 3
+    assert r.spatial_lr_scale == captured[14] and r.adam_steps == 2
+    for name, idx in (("xyz", 1), ("normal", 2), ("features_dc", 3), ("features_rest", 4), ("scaling", 5), ("rotation", 6),
+                      ("opacity", 7)):
+        assert torch.equal(getattr(r, name), captured[idx].data) and not getattr(r, name).requires_grad
+    P = r.xyz.shape[0]
+    assert r.features_dc.shape == (P, 1, 3) and r.features_rest.shape == (P, 15, 3)
+    assert torch.equal(r.max_radii2D, captured[8]) and float(r.max_radii2D.max()) > 0
+    for i, n in enumerate(ck.STAT_NAMES):
+        assert torch.equal(r.stats[n], captured[9 + i].reshape(-1))
+    names = list(ck.STAGE1_GROUPS) + (list(ck.PBR_GROUPS) if stage == 2 else [])
+    assert r.group_names == names and sorted(r.moments) == sorted(names)
+    opt = captured[13]
+    for g in opt["param_groups"]:
+        st = opt["state"][g["params"][0]]
+        assert torch.equal(r.moments[g["name"]][0], st["exp_avg"]) and torch.equal(r.moments[g["name"]][1], st["exp_avg_sq"])
+        assert float(r.moments[g["name"]][0].abs().max()) > 0
+    if stage == 2:
+        assert r.base_color.shape == (P, 3) and r.incidents_rest.shape == (P, 15, 3) and r.visibility_rest.shape == (P, 15, 1)
+    with pytest.raises(RuntimeError):
+        ck.restore((captured[:7], 1))
+
+
+def test_capture_round_trip_through_the_fused_stage1_step():
+    """restore -> FusedStage1Step (CPU tensors; construction launches nothing) -> load_moments -> capture reproduces the
+    reference's object entry by entry, including the optimizer state_dict layout."""
+    from relightable3dgaussian_amd.densify import DensificationStats
+    from relightable3dgaussian_amd.fused_step import FusedStage1Step
+    path, (captured, iteration) = _load(1)
+    r = ck.restore(path)
+    step = FusedStage1Step(r)
+    ck.load_moments(step, r)
+    assert step.opt.step_count == 2 and step.shs.shape == (r.xyz.shape[0], 16, 3)
+    step.stats = DensificationStats(r.xyz.shape[0], torch.device("cpu"))
+    for n in ck.STAT_NAMES:
+        getattr(step.stats, n).copy_(r.stats[n])
+    step.stats.max_radii2D.copy_(r.max_radii2D)
+    lrs = {g["name"]: g["lr"] for g in captured[13]["param_groups"]}
+    ours, it = ck.capture(step, iteration, spatial_lr_scale=r.spatial_lr_scale, learning_rates=lrs)
+    assert it == iteration and len(ours) == len(captured) == 15 and ours[0] == captured[0] and ours[14] == captured[14]
+    for idx in range(1, 13):
+        a, b = ours[idx], captured[idx]
+        assert a.shape == b.shape and torch.equal(a.detach(), b.detach()), idx
+    for idx in range(1, 8):
+        assert isinstance(ours[idx], torch.nn.Parameter) and ours[idx].requires_grad          # what restore() assigns
+    oa, ob = ours[13], captured[13]
+    assert [g["name"] for g in oa["param_groups"]] == [g["name"] for g in ob["param_groups"]]
+    for ga, gb in zip(oa["param_groups"], ob["param_groups"]):
+        assert ga["lr"] == gb["lr"] and ga["eps"] == gb["eps"] == 1e-15 and ga["betas"] == gb["betas"]
+        sa, sb = oa["state"][ga["params"][0]], ob["state"][gb["params"][0]]
+        assert float(sa["step"]) == float(sb["step"])
+        assert torch.equal(sa["exp_avg"], sb["exp_avg"]) and torch.equal(sa["exp_avg_sq"], sb["exp_avg_sq"])
+
+
+def test_capture_of_a_stage2_holder_has_the_reference_layout():
+    """Stage-2 layout (21 entries) from a duck-typed holder with this repo's joined [P,16,3] tensors: dc / rest halves land
+    in the reference's groups, the untrained baked-visibility groups are zeros of the reference's shapes."""
+    _, (captured, _) = _load(2)
+    r = ck.restore((captured, 5))
+    P = r.xyz.shape[0]
+    order = ("xyz", "normal", "scaling", "rotation", "opacity", "shs", "base_color", "roughness", "incidents", "env")
+    joined = dict(shs=torch.cat([r.features_dc, r.features_rest], 1), incidents=torch.cat([r.incidents_dc, r.incidents_rest], 1),
+                  env=torch.zeros(1, 4, 8, 3))
+    tensors = {k: joined.get(k, getattr(r, k, None)) for k in order}
+    g = torch.Generator().manual_seed(0)
+    groups = [dict(exp_avg=torch.randn(tensors[k].shape, generator=g), exp_avg_sq=torch.rand(tensors[k].shape, generator=g))
+              for k in order]
+    holder = types.SimpleNamespace(_opt_order=order, opt=types.SimpleNamespace(groups=groups, step_count=9), stats=None,
+                                   **tensors)
+    ours, it = ck.capture(holder, 40000, spatial_lr_scale=2.5)
+    assert it == 40000 and len(ours) == 21 and ours[14] == 2.5
+    for idx in range(15, 21):
+        assert ours[idx].shape == captured[idx].shape
+    assert torch.equal(ours[17].detach(), r.incidents_dc) and torch.equal(ours[18].detach(), r.incidents_rest)
+    assert float(ours[19].detach().abs().max()) == 0.0 and float(ours[20].detach().abs().max()) == 0.0
+    names = [gr["name"] for gr in ours[13]["param_groups"]]
+    assert names == list(ck.STAGE1_GROUPS + ck.PBR_GROUPS)
+    st = ours[13]["state"]
+    i_rest = names.index("incidents_rest")
+    assert torch.equal(st[i_rest]["exp_avg"], groups[order.index("incidents")]["exp_avg"][:, 1:]) and float(st[i_rest]["step"]) == 9
+    back = ck.restore((ours, it))
+    assert back.adam_steps == 9 and torch.equal(back.base_color, r.base_color) and float(back.stats["denom"].sum()) == 0.0
