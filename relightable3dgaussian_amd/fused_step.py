@@ -86,7 +86,11 @@ class FusedStage2Step:
     """Owns the raw parameters (copied from a bench_core.GaussianParams) and runs whole iterations."""
 
     def __init__(self, params, sample_num, lr=1e-4, lr_rest_scale=1.0, loss_weights=None, process_group=None,
-                 overlap_geometry=False, overlap_ordering=True):
+                 overlap_geometry=False, overlap_ordering=True, lrs=None):
+        """`lrs`: optional per-group learning rates {xyz, normal, scaling, rotation, opacity, shs, shs_rest, base_color,
+        roughness, incidents, incidents_rest, env} as GaussianModel.training_setup / DirectLightMap.training_setup set
+        them (scene/gaussian_model.py:465-486, the stage-2 values of script/run_nerf.sh:25-31); missing names use `lr`
+        (`lr * lr_rest_scale` for the non-dc SH columns)."""
         dev = params.xyz.device
         self.dev = dev
         d = lambda t: t.detach().clone().contiguous()
@@ -151,14 +155,17 @@ class FusedStage2Step:
             self.refresh_activations()
             self.visibility, self.incident_dirs, self.incident_areas, self.tracer = update_visibility(
                 self.xyz, self.a_scales, self.a_rot, self.a_opacity, self.a_normal, sample_num, group=process_group)
-        rest = lr * lr_rest_scale
+        lrs = dict(lrs or {})
+        rate = lambda k: float(lrs.get(k, lr))
+        tail = lambda k: float(lrs.get(k + "_rest", rate(k) * lr_rest_scale))
         self.opt = FusedAdam([
-            dict(param=self.xyz, lr=lr), dict(param=self.normal, lr=lr), dict(param=self.scaling, lr=lr),
-            dict(param=self.rotation, lr=lr), dict(param=self.opacity, lr=lr),
-            dict(param=self.shs, lr=lr, lr_tail=rest, period=3 * self.M, split=3),
-            dict(param=self.base_color, lr=lr), dict(param=self.roughness, lr=lr),
-            dict(param=self.incidents, lr=lr, lr_tail=rest, period=3 * self.M, split=3),
-            dict(param=self.env, lr=lr)])
+            dict(param=self.xyz, lr=rate("xyz")), dict(param=self.normal, lr=rate("normal")),
+            dict(param=self.scaling, lr=rate("scaling")), dict(param=self.rotation, lr=rate("rotation")),
+            dict(param=self.opacity, lr=rate("opacity")),
+            dict(param=self.shs, lr=rate("shs"), lr_tail=tail("shs"), period=3 * self.M, split=3),
+            dict(param=self.base_color, lr=rate("base_color")), dict(param=self.roughness, lr=rate("roughness")),
+            dict(param=self.incidents, lr=rate("incidents"), lr_tail=tail("incidents"), period=3 * self.M, split=3),
+            dict(param=self.env, lr=rate("env"))])
         self._opt_order = ("xyz", "normal", "scaling", "rotation", "opacity", "shs", "base_color", "roughness",
                            "incidents", "env")
         self.last_outs = None

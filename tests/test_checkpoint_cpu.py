@@ -104,3 +104,57 @@ def test_capture_of_a_stage2_holder_has_the_reference_layout():
     assert torch.equal(st[i_rest]["exp_avg"], groups[order.index("incidents")]["exp_avg"][:, 1:]) and float(st[i_rest]["step"]) == 9
     back = ck.restore((ours, it))
     assert back.adam_steps == 9 and torch.equal(back.base_color, r.base_color) and float(back.stats["denom"].sum()) == 0.0
+
+
+def test_fused_stage2_step_takes_the_reference_learning_rates(monkeypatch):
+    """Constructor logic only (the visibility trace and the activation kernel are stubbed, nothing runs on a GPU): per-group
+    rates as run_nerf.sh sets them for stage 2, dc / rest split of the joined SH tensors, one shared slab for the gradients."""
+    from relightable3dgaussian_amd import fused_step
+    _, (captured, _) = _load(2)
+    r = ck.restore((captured, 30000))
+    r.env = torch.zeros(1, 16, 32, 3)
+    P = r.xyz.shape[0]
+    monkeypatch.setattr(fused_step, "update_visibility", lambda *a, **k: (None, None, None, None))
+    monkeypatch.setattr(fused_step.FusedStage2Step, "refresh_activations", lambda self, cam=None: None)
+    monkeypatch.setattr(torch.cuda, "Stream", lambda device=None: None)
+    lrs = dict(xyz=0.000016 * 2.6, normal=0.001, shs=0.00025, opacity=0.005, scaling=0.0005, rotation=0.0001,
+               base_color=0.01, roughness=0.01, incidents=0.001, incidents_rest=0.0001, env=0.1)
+    step = fused_step.FusedStage2Step(r, 8, lr=1e-4, lr_rest_scale=1.0 / 20.0, lrs=lrs)
+    g = {k: step.opt.groups[i] for i, k in enumerate(step._opt_order)}
+    assert g["xyz"]["lr"] == lrs["xyz"] and g["opacity"]["lr"] == 0.005 and g["env"]["lr"] == 0.1
+    assert g["shs"]["lr"] == 0.00025 and g["shs"]["lr_tail"] == 0.00025 / 20.0 and g["shs"]["period"] == 48 and g["shs"]["split"] == 3
+    assert g["incidents"]["lr"] == 0.001 and g["incidents"]["lr_tail"] == 0.0001
+    assert step.shs.shape == (P, 16, 3) and torch.equal(step.features_rest, r.features_rest)
+    # gradient slab: [shs | per-Gaussian groups + env | incidents], every group 16-byte aligned, env inside bucket C
+    total = sum((x.numel() + 3) // 4 * 4 for x in (step.shs, step.xyz, step.normal, step.scaling, step.rotation,
+                                                   step.opacity, step.base_color, step.roughness, step.env, step.incidents))
+    assert step.grad_flat.numel() == total
+    assert step._bucket_a.numel() == step.shs.numel() and step._bucket_b.numel() == step.incidents.numel()
+    assert step._bucket_a.numel() + step._bucket_b.numel() + step._bucket_c.numel() == total
+    for k, gr in step.grads.items():
+        assert gr.shape == getattr(step, k).shape and gr.data_ptr() % 16 == 0, k
+    lo, hi = step._bucket_c.data_ptr(), step._bucket_c.data_ptr() + 4 * step._bucket_c.numel()
+    assert lo <= step.grads["env"].data_ptr() < hi and lo <= step.grads["xyz"].data_ptr() < hi
+    ck.load_moments(step, r)
+    assert step.opt.step_count == 2
+    assert torch.equal(step.opt.groups[step._opt_order.index("incidents")]["exp_avg"][:, 1:], r.moments["incidents_rest"][0])
+
+
+def test_committed_bench_line_follows_the_contract():
+    """profiles/r01_bench_default.json is the line `python bench.py` printed on the MI355X: the keys the driver and the judge
+    read are there, with the types and relations the contract states."""
+    import json
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    d = json.load(open(os.path.join(root, "profiles", "r01_bench_default.json")))
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["unit"] == "iters/s" and d["higher_is_better"] is True and d["scaling"] == "weak" and d["vs_baseline"] is None
+    assert d["dtype"] == "f32" and d["data"] == "synthetic" and d["n_gpus"] == 1 and "workload" in d["config"]
+    assert abs(d["value"] - d["n_gpus"] * 1e3 / d["ms_per_step"]) / d["value"] < 1e-3
+    r = d["roofline"]
+    assert r["bound"] in ("hbm", "mfma") and r["unit"] == "GB/s" and r["peak"] == 8000.0
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3 and (r["traffic"] is None or r["traffic"] > 0)
+    c = d["cpu_baseline"]
+    assert c["kind"] in ("reference", "port") and c["cores"] >= 1 and c["value"] > 0 and c["unit"] == "iters/s" and c["sample"]
+    assert d["value"] >= 40.0 and d["relight"]["relight_fps"] >= 60.0            # BASELINE.json targets on 1x MI355X
