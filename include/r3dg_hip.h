@@ -273,7 +273,7 @@ int r3dg_stage1_activate_backward(void* stream, int P, const float* d_xyz, const
                                   float* d_g_normal);
 
 /* Learnable environment texture (DirectLightMap, scene/direct_light_map.py:18-27): env = softplus(raw), [He,We,3].
- * g_raw = (dL_denv + w_tv * dTV(env)/denv) * softplus'(raw) with TV = mean|d/dh| + mean|d/dw| (the env-smoothness term,
+ * g_raw = (dL_denv + w_tv * dTV(env)/denv) * softplus'(raw) with TV = mean (d/dh)^2 + mean (d/dw)^2 (tv_loss, utils/loss_utils.py:113-117: the env-smoothness term,
  * neilf.py:294-300); *tv_sum (may be NULL) += TV(env). */
 int r3dg_stage2_env_backward(void* stream, int He, int We, const float* d_raw, const float* d_env,
                              const float* d_dL_denv, float w_tv, float* d_g_raw, float* d_tv_sum);

@@ -305,7 +305,8 @@ s2_loss_kernel(int HW, const float* __restrict__ image, const float* __restrict_
 
 // DirectLightMap: env = softplus(raw) (direct_light_map.py:18-23) and the total-variation smoothness term on it
 // (neilf.py:294-300): g_raw = (dL_denv + w_tv * dTV/denv) * softplus'(raw); *tv_sum += TV(env) (unweighted).
-// env layout [He,We,3]; TV = mean |d/dh| + mean |d/dw| over the 3 x He x We image.
+// env layout [He,We,3]; TV = mean (d/dh)^2 + mean (d/dw)^2 over the 3 x He x We image (the reference's tv_loss,
+// utils/loss_utils.py:113-117, pinned by tests/golden/ssim_reference.npz).
 __global__ void __launch_bounds__(256)
 s2_env_backward_kernel(int He, int We, const float* __restrict__ raw, const float* __restrict__ env,
                        const float* __restrict__ dL_denv, float w_tv, float* __restrict__ g_raw,
@@ -321,10 +322,11 @@ s2_env_backward_kernel(int He, int We, const float* __restrict__ raw, const floa
         const float inv_v = He > 1 ? 1.f / (3.f * (He - 1) * We) : 0.f, inv_h = We > 1 ? 1.f / (3.f * He * (We - 1)) : 0.f;
         const float x = env[i];
         float g = 0.f;
-        if (h > 0) g += inv_v * signf_(x - env[i - 3 * We]);
-        if (h < He - 1) { const float d = env[i + 3 * We] - x; g -= inv_v * signf_(d); tv += inv_v * fabsf(d); }
-        if (w > 0) g += inv_h * signf_(x - env[i - 3]);
-        if (w < We - 1) { const float d = env[i + 3] - x; g -= inv_h * signf_(d); tv += inv_h * fabsf(d); }
+        // tv_loss (utils/loss_utils.py:113-117): mean SQUARED forward difference along h plus the same along w
+        if (h > 0) g += inv_v * 2.f * (x - env[i - 3 * We]);
+        if (h < He - 1) { const float d = env[i + 3 * We] - x; g -= inv_v * 2.f * d; tv += inv_v * d * d; }
+        if (w > 0) g += inv_h * 2.f * (x - env[i - 3]);
+        if (w < We - 1) { const float d = env[i + 3] - x; g -= inv_h * 2.f * d; tv += inv_h * d * d; }
         const float r = raw[i];
         const float dsoft = r > 20.f ? 1.f : sigmoidf_(r);
         g_raw[i] = (dL_denv[i] + w_tv * g) * dsoft;

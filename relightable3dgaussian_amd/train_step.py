@@ -99,7 +99,9 @@ def image_loss(img, gt):
 
 
 def tv_loss(x):
-    return (x[:, 1:] - x[:, :-1]).abs().mean() + (x[:, :, 1:] - x[:, :, :-1]).abs().mean()
+    """utils/loss_utils.py:113-117: mean squared forward difference along the last two axes (pinned by
+    tests/golden/ssim_reference.npz)."""
+    return (x[..., 1:, :] - x[..., :-1, :]).square().mean() + (x[..., :, 1:] - x[..., :, :-1]).square().mean()
 
 
 class Stage2Step:

@@ -140,6 +140,7 @@ def main():
     lr_schedule_fixture()
     composition_fixture()
     checkpoint_fixtures()
+    ssim_fixture()
 
 
 
@@ -236,6 +237,27 @@ def checkpoint_fixtures():
                 assert float(sa["step"]) == float(sb["step"]) == 2.0
             assert torch.equal(fresh.denom, m.denom) and torch.equal(fresh.max_radii2D, m.max_radii2D)
             print("reference restore() + load_state_dict() accept checkpoint.capture():", path)
+
+
+def ssim_fixture():
+    """tests/golden/ssim_reference.npz: the reference's SSIM (utils/loss_utils.py:20-63) and L1 on two random images, with
+    the gradient w.r.t. the rendered image -- the pin of train_step.ssim / image_loss, which in turn are the parity
+    targets of the HIP SSIM kernels.  (kornia, imported by that module, is auto-mocked; ssim does not use it.)"""
+    from utils.loss_utils import ssim, tv_loss
+    l1_loss = torch.nn.functional.l1_loss               # neilf.py:226: Ll1 = F.l1_loss(rendered_image, gt_image)
+    g = torch.Generator().manual_seed(77)
+    rec = {}
+    for name, (H, W) in (("a", (40, 56)), ("b", (13, 9))):          # b: smaller than the window in one direction
+        x = torch.rand(3, H, W, generator=g).requires_grad_(True)
+        y = (x.detach() + 0.2 * torch.randn(3, H, W, generator=g)).clamp(0, 1)
+        s = ssim(x, y)
+        l1 = l1_loss(x, y)
+        loss = (1.0 - 0.2) * l1 + 0.2 * (1.0 - s)                   # train.py / render.py: lambda_dssim = 0.2
+        loss.backward()
+        rec[name + "_tv"] = float(tv_loss(x.detach()))
+        rec.update({name + "_x": x.detach().numpy().copy(), name + "_y": y.numpy().copy(), name + "_ssim": float(s),
+                    name + "_l1": float(l1), name + "_loss": float(loss), name + "_grad": x.grad.numpy().copy()})
+    np.savez_compressed(os.path.join(HERE, "ssim_reference.npz"), **rec)
 
 
 if __name__ == "__main__":

@@ -158,3 +158,30 @@ def test_committed_bench_line_follows_the_contract():
     c = d["cpu_baseline"]
     assert c["kind"] in ("reference", "port") and c["cores"] >= 1 and c["value"] > 0 and c["unit"] == "iters/s" and c["sample"]
     assert d["value"] >= 40.0 and d["relight"]["relight_fps"] >= 60.0            # BASELINE.json targets on 1x MI355X
+
+
+def test_ssim_and_image_loss_match_the_reference():
+    """train_step.ssim / image_loss -- the parity targets of the HIP SSIM kernels and of the fused iterations' image terms --
+    against the reference's utils/loss_utils.ssim + l1_loss and their gradient (tests/golden/ssim_reference.npz)."""
+    import numpy as np
+    from relightable3dgaussian_amd import train_step
+    z = np.load(os.path.join(GOLDEN, "ssim_reference.npz"))
+    for name in ("a", "b"):
+        x = torch.from_numpy(z[name + "_x"]).requires_grad_(True)
+        y = torch.from_numpy(z[name + "_y"])
+        s = train_step.ssim(x, y)
+        assert abs(float(s) - float(z[name + "_ssim"])) < 2e-6
+        loss = train_step.image_loss(x, y)
+        assert abs(float(loss) - float(z[name + "_loss"])) < 2e-6
+        assert abs(float((x - y).abs().mean()) - float(z[name + "_l1"])) < 1e-7
+        loss.backward()
+        np.testing.assert_allclose(x.grad.numpy(), z[name + "_grad"], rtol=1e-4, atol=2e-7)
+
+
+def test_tv_loss_matches_the_reference():
+    """The env-smoothness term (neilf.py:303-307 -> utils/loss_utils.tv_loss: mean SQUARED differences)."""
+    import numpy as np
+    from relightable3dgaussian_amd import train_step
+    z = np.load(os.path.join(GOLDEN, "ssim_reference.npz"))
+    for name in ("a", "b"):
+        assert abs(float(train_step.tv_loss(torch.from_numpy(z[name + "_x"]))) - float(z[name + "_tv"])) < 1e-7
