@@ -231,8 +231,8 @@ s2_pbr_srgb_kernel(int HW, const float* __restrict__ opacity, const float* __res
 #pragma unroll
     for (int c = 0; c < 3; c++) {
         const float x = feature[(size_t)(2 + c) * HW + i] * scale * op + (1.f - op) * bg[c];
-        srgb[(size_t)c * HW + i] = x <= 0.0031308f ? 12.92f * x
-                                                   : 1.055f * __powf(fmaxf(x, 0.0031308f), 1.f / 2.4f) - 0.055f;
+        const float v = x <= 0.0031308f ? 12.92f * x : 1.055f * __powf(fmaxf(x, 0.0031308f), 1.f / 2.4f) - 0.055f;
+        srgb[(size_t)c * HW + i] = fminf(fmaxf(v, 0.f), 1.f);      // rgb_to_srgb clips (utils/graphics_utils.py:211-212)
     }
 }
 
@@ -270,10 +270,14 @@ s2_loss_kernel(int HW, const float* __restrict__ image, const float* __restrict_
             const float x = r * op + (1.f - op) * bg[c];
             const bool lin = x <= 0.0031308f;
             const float xs = fmaxf(x, 0.0031308f);
-            const float srgb = lin ? 12.92f * x : 1.055f * __powf(xs, 1.f / 2.4f) - 0.055f;
+            // rgb_to_srgb with clip=True (utils/graphics_utils.py:207-213): the curve, then clamp to [0,1]; the clamp passes
+            // the gradient only where 0 <= curve <= 1 (torch.clamp), so saturated HDR highlights stop pulling
+            const float curve = lin ? 12.92f * x : 1.055f * __powf(xs, 1.f / 2.4f) - 0.055f;
+            const bool unclipped = curve >= 0.f && curve <= 1.f;
+            const float srgb = fminf(fmaxf(curve, 0.f), 1.f);
             const float d1 = srgb - g;
             s_pbr += fabsf(d1);
-            const float dsrgb = lin ? 12.92f : 1.055f / 2.4f * __powf(xs, 1.f / 2.4f - 1.f);
+            const float dsrgb = !unclipped ? 0.f : (lin ? 12.92f : 1.055f / 2.4f * __powf(xs, 1.f / 2.4f - 1.f));
             const float gx = (w_pbr * signf_(d1) + (extra_dsrgb ? extra_dsrgb[(size_t)c * HW + i] : 0.f)) * dsrgb;   // dL/dx
             dL_dfeature[(size_t)(2 + c) * HW + i] = gx * op * scale;
             g_op += gx * (r - bg[c] + op * F * dscale_dop);

@@ -98,6 +98,13 @@ def image_loss(img, gt):
     return (1.0 - LAMBDA_DSSIM) * (img - gt).abs().mean() + LAMBDA_DSSIM * (1.0 - ssim(img, gt))
 
 
+def rgb_to_srgb(img):
+    """utils/graphics_utils.py:207-213 with clip=True (what render_view puts into results["pbr"], neilf.py:179): the sRGB
+    curve, then clamp to [0,1] -- the clamp stops the gradient of saturated pixels.  Pinned by tests/golden/ssim_reference.npz."""
+    curve = torch.where(img > 0.0031308, torch.pow(torch.clamp_min(img, 0.0031308), 1.0 / 2.4) * 1.055 - 0.055, 12.92 * img)
+    return curve.clamp(0.0, 1.0)
+
+
 def tv_loss(x):
     """utils/loss_utils.py:113-117: mean squared forward difference along the last two axes (pinned by
     tests/golden/ssim_reference.npz)."""
@@ -144,8 +151,7 @@ class Stage2Step:
         feat = feature / opacity.clamp_min(1e-5) * mask
         r_depth, r_depth2, r_pbr, r_normal, r_base, r_rough, r_diffuse, r_vis = feat.split([1, 1, 3, 3, 3, 1, 3, 1], 0)
         pbr_img = r_pbr * opacity + (1 - opacity) * bg[:, None, None]
-        pbr_srgb = torch.where(pbr_img <= 0.0031308, 12.92 * pbr_img,
-                               1.055 * pbr_img.clamp_min(0.0031308) ** (1 / 2.4) - 0.055)
+        pbr_srgb = rgb_to_srgb(pbr_img)
         loss = image_loss(image, gt) + 1.0 * image_loss(pbr_srgb, gt)          # L1/SSIM mix on both images, lambda_pbr 1
         loss = loss + 0.01 * F.mse_loss(r_normal, pseudo_normal.detach())                            # normal_render_depth
         mean_light = diffuse_light.mean(-1, keepdim=True).expand_as(diffuse_light)

@@ -257,6 +257,15 @@ def ssim_fixture():
         rec[name + "_tv"] = float(tv_loss(x.detach()))
         rec.update({name + "_x": x.detach().numpy().copy(), name + "_y": y.numpy().copy(), name + "_ssim": float(s),
                     name + "_l1": float(l1), name + "_loss": float(loss), name + "_grad": x.grad.numpy().copy()})
+    # rgb_to_srgb (clip=True) with its gradient: values below 0, around the linear/power knee, inside (0,1) and above 1
+    from utils.graphics_utils import rgb_to_srgb
+    v = torch.cat([torch.linspace(-0.2, 0.01, 40), torch.linspace(0.002, 0.005, 40), torch.linspace(0.01, 2.5, 112)])
+    v = v.reshape(3, 8, 8).clone().requires_grad_(True)
+    w = torch.rand(3, 8, 8, generator=g) + 0.5
+    out = rgb_to_srgb(v)
+    (out * w).sum().backward()
+    rec.update(srgb_in=v.detach().numpy().copy(), srgb_out=out.detach().numpy().copy(), srgb_w=w.numpy().copy(),
+               srgb_grad=v.grad.numpy().copy())
     np.savez_compressed(os.path.join(HERE, "ssim_reference.npz"), **rec)
 
 
