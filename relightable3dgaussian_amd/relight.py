@@ -13,7 +13,7 @@ import torch
 import torch.nn.functional as F
 
 from . import _lib, rasterizer_ops, shading_ops
-from .train_step import update_visibility
+from .train_step import rgb_to_srgb, update_visibility   # noqa: F401  (rgb_to_srgb: part of this module's surface)
 
 
 def _shs_of(model):
@@ -114,12 +114,6 @@ class RelightRenderer:
                     "relight_compose")
             res.update(want)
         return res
-
-
-def rgb_to_srgb(img):
-    """utils/graphics_utils.py:207-213 (clip=True)."""
-    out = torch.where(img > 0.0031308, torch.pow(torch.clamp_min(img, 0.0031308), 1.0 / 2.4) * 1.055 - 0.055, 12.92 * img)
-    return out.clamp(0.0, 1.0)
 
 
 def env_directions(cam, envmap, env_transform=None):
