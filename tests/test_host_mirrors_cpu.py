@@ -1,7 +1,6 @@
-"""The reference's checkpoint format (train.py:190-203, GaussianModel.capture / restore) through
-relightable3dgaussian_amd.checkpoint, on the files the reference's own GaussianModel wrote
-(tests/golden/checkpoint_reference_stage{1,2}.pth, tests/golden/make_densify_golden.py -- which also verified, with the
-reference importable, that its restore() + optimizer.load_state_dict() accept what capture() writes)."""
+"""CPU tests of the host-side mirrors against outputs of the reference's own Python (fixtures under tests/golden/, written by
+tests/golden/make_densify_golden.py and make_golden.py): checkpoint format (train.py:190-203, GaussianModel.capture /
+restore), learning rates, loss terms (SSIM, L1, TV, clipped sRGB), visibility inputs, and the committed bench line."""
 import os
 import types
 
@@ -200,3 +199,21 @@ def test_rgb_to_srgb_matches_the_reference_including_the_clip():
         (out * torch.from_numpy(z["srgb_w"])).sum().backward()
         np.testing.assert_allclose(v.grad.numpy(), z["srgb_grad"], rtol=1e-5, atol=1e-7)
     assert float((z["srgb_grad"] == 0).mean()) > 0.3 and float(z["srgb_out"].max()) == 1.0 and float(z["srgb_out"].min()) == 0.0
+
+
+def test_host_side_visibility_inputs_match_the_reference():
+    """The pure-PyTorch host functions that feed the BVH trace and the shading caches, on the reference's own outputs:
+    train_step.inverse_covariance vs GaussianModel.get_inverse_covariance (covariance_reference.npz) and
+    sampling.fibonacci_sphere_sampling vs utils/graphics_utils.fibonacci_sphere_sampling incl. the n_z = -1 branch of
+    rotation_between_z (fibonacci_reference.npz)."""
+    import numpy as np
+    from relightable3dgaussian_amd import sampling, train_step
+    z = np.load(os.path.join(GOLDEN, "covariance_reference.npz"))
+    inv = train_step.inverse_covariance(torch.from_numpy(z["scales"]), torch.from_numpy(z["rotations"]))
+    ref = z["cov3D_inverse"]
+    np.testing.assert_allclose(inv.numpy(), ref, rtol=2e-5, atol=2e-5 * float(np.abs(ref).max()))
+    f = np.load(os.path.join(GOLDEN, "fibonacci_reference.npz"))
+    dirs, areas = sampling.fibonacci_sphere_sampling(torch.from_numpy(f["normals"]), f["dirs"].shape[1])
+    np.testing.assert_allclose(dirs.numpy(), f["dirs"], rtol=0, atol=2e-6)
+    np.testing.assert_allclose(areas.numpy(), f["areas"], rtol=0, atol=1e-6)
+    assert dirs.shape == (f["normals"].shape[0], f["dirs"].shape[1], 3) and areas.shape[-1] == 1
