@@ -169,10 +169,10 @@ def test_ssim_and_image_loss_match_the_reference():
         x = torch.from_numpy(z[name + "_x"]).requires_grad_(True)
         y = torch.from_numpy(z[name + "_y"])
         s = train_step.ssim(x, y)
-        assert abs(float(s) - float(z[name + "_ssim"])) < 2e-6
+        assert abs(float(s.detach()) - float(z[name + "_ssim"])) < 2e-6
         loss = train_step.image_loss(x, y)
-        assert abs(float(loss) - float(z[name + "_loss"])) < 2e-6
-        assert abs(float((x - y).abs().mean()) - float(z[name + "_l1"])) < 1e-7
+        assert abs(float(loss.detach()) - float(z[name + "_loss"])) < 2e-6
+        assert abs(float((x - y).abs().mean().detach()) - float(z[name + "_l1"])) < 1e-7
         loss.backward()
         np.testing.assert_allclose(x.grad.numpy(), z[name + "_grad"], rtol=1e-4, atol=2e-7)
 
