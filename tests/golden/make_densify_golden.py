@@ -141,6 +141,7 @@ def main():
     composition_fixture()
     checkpoint_fixtures()
     ssim_fixture()
+    wrapper_trace_fixture()
 
 
 
@@ -267,6 +268,23 @@ def ssim_fixture():
     rec.update(srgb_in=v.detach().numpy().copy(), srgb_out=out.detach().numpy().copy(), srgb_w=w.numpy().copy(),
                srgb_grad=v.grad.numpy().copy())
     np.savez_compressed(os.path.join(HERE, "ssim_reference.npz"), **rec)
+
+
+def wrapper_trace_fixture():
+    """tests/golden/wrapper_trace_reference.json: what the reference's autograd wrapper
+    (gaussian_renderer/r3dg_rasterization.py:58-261) hands to `_C.rasterize_gaussians` / `_backward` and where it routes the
+    nine gradients, recorded by tests/wrapper_trace.py with a fake `_C`."""
+    import json
+    sys.path.insert(0, os.path.dirname(HERE))
+    import wrapper_trace
+    import gaussian_renderer.r3dg_rasterization as ref
+
+    def install(fwd, bwd):
+        ref._C = types.SimpleNamespace(rasterize_gaussians=fwd, rasterize_gaussians_backward=bwd)
+    doc = {v: wrapper_trace.run(ref.GaussianRasterizationSettings, ref.GaussianRasterizer, install, v)
+           for v in ("sh_scale", "color_cov")}
+    with open(os.path.join(HERE, "wrapper_trace_reference.json"), "w") as fh:
+        json.dump(doc, fh, indent=1, sort_keys=True)
 
 
 if __name__ == "__main__":

@@ -217,3 +217,30 @@ def test_host_side_visibility_inputs_match_the_reference():
     np.testing.assert_allclose(dirs.numpy(), f["dirs"], rtol=0, atol=2e-6)
     np.testing.assert_allclose(areas.numpy(), f["areas"], rtol=0, atol=1e-6)
     assert dirs.shape == (f["normals"].shape[0], f["dirs"].shape[1], 3) and areas.shape[-1] == 1
+
+
+@pytest.mark.parametrize("variant", ["sh_scale", "color_cov"])
+def test_autograd_wrapper_calls_the_backend_like_the_reference(variant, monkeypatch):
+    """relightable3dgaussian_amd.rasterizer (GaussianRasterizationSettings / GaussianRasterizer /
+    autograd Function) against the call trace of the reference's gaussian_renderer/r3dg_rasterization.py recorded with a
+    fake `_C` (tests/wrapper_trace.py -> tests/golden/wrapper_trace_reference.json): same 23 / 26 positional arguments in
+    the same order (absent optionals as empty CPU tensors), same 10 outputs, same routing of the nine gradients."""
+    import json
+    from relightable3dgaussian_amd import rasterizer
+    from tests import wrapper_trace
+    want = json.load(open(os.path.join(GOLDEN, "wrapper_trace_reference.json")))[variant]
+
+    def install(fwd, bwd):
+        monkeypatch.setattr(rasterizer._ops, "rasterize_gaussians", fwd)
+        monkeypatch.setattr(rasterizer._ops, "rasterize_gaussians_backward", bwd)
+    got = wrapper_trace.run(rasterizer.GaussianRasterizationSettings, rasterizer.GaussianRasterizer, install, variant)
+    assert got["n_outputs"] == want["n_outputs"] == 10 and got["num_rendered"] == want["num_rendered"] == 7
+    assert len(got["forward_args"]) == len(want["forward_args"]) == 23
+    assert len(got["backward_args"]) == len(want["backward_args"]) == 26
+    for which in ("forward_args", "backward_args"):
+        for i, (a, b) in enumerate(zip(got[which], want[which])):
+            assert a == b, "%s[%d]: %r vs reference %r" % (which, i, a, b)
+    assert got["grad_routing"] == want["grad_routing"]
+    assert tuple(rasterizer.GaussianRasterizationSettings._fields) == (
+        "image_height", "image_width", "tanfovx", "tanfovy", "cx", "cy", "bg", "scale_modifier", "viewmatrix", "projmatrix",
+        "sh_degree", "campos", "prefiltered", "backward_geometry", "computer_pseudo_normal", "debug")
