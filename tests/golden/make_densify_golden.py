@@ -283,6 +283,12 @@ def wrapper_trace_fixture():
         ref._C = types.SimpleNamespace(rasterize_gaussians=fwd, rasterize_gaussians_backward=bwd)
     doc = {v: wrapper_trace.run(ref.GaussianRasterizationSettings, ref.GaussianRasterizer, install, v)
            for v in ("sh_scale", "color_cov")}
+    import bvh as ref_bvh
+
+    def install_bvh(create, trace):
+        ref_bvh._C.create_bvh = create
+        ref_bvh._C.trace_bvh_opacity = trace
+    doc["raytracer"] = wrapper_trace.run_raytracer(ref_bvh.RayTracer, install_bvh)
     with open(os.path.join(HERE, "wrapper_trace_reference.json"), "w") as fh:
         json.dump(doc, fh, indent=1, sort_keys=True)
 

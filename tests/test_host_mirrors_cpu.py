@@ -244,3 +244,24 @@ def test_autograd_wrapper_calls_the_backend_like_the_reference(variant, monkeypa
     assert tuple(rasterizer.GaussianRasterizationSettings._fields) == (
         "image_height", "image_width", "tanfovx", "tanfovy", "cx", "cy", "bg", "scale_modifier", "viewmatrix", "projmatrix",
         "sh_degree", "campos", "prefiltered", "backward_geometry", "computer_pseudo_normal", "debug")
+
+
+def test_raytracer_wrapper_calls_the_backend_like_the_reference(monkeypatch):
+    """SURVEY.md 8 rows a13/a14 (Python side): relightable3dgaussian_amd.bvh.RayTracer against the call trace of the
+    reference's bvh/__init__.py:28-71 -- create_bvh's five arguments, trace_bvh_opacity's eight (ray origins offset by
+    0.05 d), the {visibility, contribute} result with a trailing singleton axis."""
+    import json
+    from relightable3dgaussian_amd import bvh
+    from tests import wrapper_trace
+    want = json.load(open(os.path.join(GOLDEN, "wrapper_trace_reference.json")))["raytracer"]
+
+    def install(create, trace):
+        monkeypatch.setattr(bvh.bvh_ops, "create_bvh", create)
+        monkeypatch.setattr(bvh.bvh_ops, "trace_bvh_opacity", trace)
+    got = wrapper_trace.run_raytracer(bvh.RayTracer, install)
+    assert got["offset_ok"] and want["offset_ok"]
+    assert got["create_args"] == want["create_args"]
+    assert len(got["trace_args"]) == len(want["trace_args"]) == 8
+    for i, (a, b) in enumerate(zip(got["trace_args"], want["trace_args"])):
+        assert a["shape"] == b["shape"] and a["dtype"] == b["dtype"] and abs(a["first"] - b["first"]) < 1e-6, (i, a, b)
+    assert got["result"] == want["result"]

@@ -75,3 +75,36 @@ def run(settings_cls, rasterizer_cls, install_backend, variant):
         routing[k] = None if g is None else float(g.flatten()[0]) if g.numel() else "empty"
     trace["grad_routing"] = routing
     return trace
+
+
+def run_raytracer(raytracer_cls, install_backend):
+    """The same for `RayTracer` (bvh/__init__.py:28-71): what `create_bvh` and `trace_bvh_opacity` receive (the ray origins
+    already offset by 0.05 d) and how the result dict is shaped."""
+    g = torch.Generator().manual_seed(9)
+    n, R, K = 12, 5, 3
+    means = torch.randn(n, 3, generator=g)
+    scales = torch.rand(n, 3, generator=g) * 0.1 + 0.02
+    rot = torch.nn.functional.normalize(torch.randn(n, 4, generator=g), dim=-1)
+    trace = {}
+
+    def fake_create(means3D, scales_, rotations, nodes, aabbs):
+        trace["create_args"] = [dict(shape=list(a.shape), dtype=str(a.dtype)) for a in (means3D, scales_, rotations, nodes, aabbs)]
+        return torch.full((2 * n - 1, 5), 7, dtype=torch.int32), torch.full((2 * n - 1, 6), 8.0), torch.full((n,), 9)
+
+    def fake_trace(*args):
+        trace["trace_args"] = [dict(shape=list(a.shape), dtype=str(a.dtype), first=float(a.flatten()[0])) for a in args]
+        trace["rays_o_seen"] = args[2].clone()
+        lead = args[2].shape[:-1]
+        return torch.full(lead, 2, dtype=torch.int32), torch.full(lead, 0.5)
+
+    install_backend(fake_create, fake_trace)
+    tracer = raytracer_cls(means, scales, rot)
+    rays_o = torch.randn(R, K, 3, generator=g)
+    rays_d = torch.nn.functional.normalize(torch.randn(R, K, 3, generator=g), dim=-1)
+    symm = torch.rand(n, 6, generator=g)
+    opac = torch.rand(n, generator=g)
+    normals = torch.nn.functional.normalize(torch.randn(n, 3, generator=g), dim=-1)
+    res = tracer.trace_visibility(rays_o, rays_d, means, symm, opac, normals)
+    trace["offset_ok"] = bool(torch.allclose(trace.pop("rays_o_seen"), rays_o + 0.05 * rays_d, rtol=0, atol=1e-7))
+    trace["result"] = {k: dict(shape=list(v.shape), dtype=str(v.dtype), first=float(v.flatten()[0])) for k, v in sorted(res.items())}
+    return trace
