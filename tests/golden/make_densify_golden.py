@@ -142,6 +142,7 @@ def main():
     checkpoint_fixtures()
     ssim_fixture()
     wrapper_trace_fixture()
+    camera_fixture()
 
 
 
@@ -291,6 +292,39 @@ def wrapper_trace_fixture():
     doc["raytracer"] = wrapper_trace.run_raytracer(ref_bvh.RayTracer, install_bvh)
     with open(os.path.join(HERE, "wrapper_trace_reference.json"), "w") as fh:
         json.dump(doc, fh, indent=1, sort_keys=True)
+
+
+def camera_fixture():
+    """tests/golden/camera_reference.npz: world_view_transform / full_proj_transform / camera_center / c2w of the reference's
+    `Camera` (scene/cameras.py:8-73, built the way relighting.py:150-158 builds it: R = w2c[:3,:3]^T, T = w2c[:3,3], FoV)
+    for a few poses and image sizes -- the pin of synthetic.look_at_camera, whose matrices every benchmark and parity test
+    hands to the ops."""
+    from scene.cameras import Camera
+    rec = {}
+    poses = [((3.2, 1.0, 1.5), (0.0, 0.0, 0.0), 800, 800), ((-2.0, 3.1, 0.4), (0.2, -0.1, 0.3), 640, 400),
+             ((0.5, -4.0, 2.5), (0.0, 0.0, 0.0), 1800, 700)]
+    for j, (eye, target, W, H) in enumerate(poses):
+        e, t = np.asarray(eye, np.float64), np.asarray(target, np.float64)
+        fwd = (t - e) / np.linalg.norm(t - e)
+        right = np.cross(fwd, np.array([0.0, 0.0, 1.0]))
+        right /= np.linalg.norm(right)
+        down = np.cross(fwd, right)
+        Rw2c = np.stack([right, down, fwd], 0)
+        w2c = np.eye(4)
+        w2c[:3, :3] = Rw2c
+        w2c[:3, 3] = -Rw2c @ e
+        fovx = 0.6911112070083618
+        fovy = 2 * np.arctan(H / (2 * (W / (2 * np.tan(fovx / 2)))))
+        cam = Camera(colmap_id=0, R=w2c[:3, :3].T.astype(np.float32), T=w2c[:3, 3].astype(np.float32), FoVx=fovx,
+                     FoVy=fovy, fx=None, fy=None, cx=None, cy=None, image=torch.zeros(3, H, W), image_name=None, uid=0,
+                     data_device="cpu")
+        rec.update({"cam%d_eye" % j: e, "cam%d_target" % j: t, "cam%d_size" % j: np.array([W, H]),
+                    "cam%d_world_view_transform" % j: cam.world_view_transform.numpy().copy(),
+                    "cam%d_full_proj_transform" % j: cam.full_proj_transform.numpy().copy(),
+                    "cam%d_camera_center" % j: cam.camera_center.numpy().copy(),
+                    "cam%d_fovy" % j: np.array(fovy)})
+    rec["n"] = np.array(len(poses))
+    np.savez(os.path.join(HERE, "camera_reference.npz"), **rec)
 
 
 if __name__ == "__main__":

@@ -265,3 +265,20 @@ def test_raytracer_wrapper_calls_the_backend_like_the_reference(monkeypatch):
     for i, (a, b) in enumerate(zip(got["trace_args"], want["trace_args"])):
         assert a["shape"] == b["shape"] and a["dtype"] == b["dtype"] and abs(a["first"] - b["first"]) < 1e-6, (i, a, b)
     assert got["result"] == want["result"]
+
+
+def test_synthetic_cameras_follow_the_reference_camera_class():
+    """synthetic.look_at_camera against the reference's Camera (scene/cameras.py:8-73 + utils/graphics_utils
+    getWorld2View2 / getProjectionMatrix), built as relighting.py:150-158 builds it: the matrices every benchmark and parity
+    test hands to the ops have the reference's conventions (W2C transposed, full projection, camera centre, FoVy from FoVx)."""
+    import numpy as np
+    from relightable3dgaussian_amd import synthetic as syn
+    z = np.load(os.path.join(GOLDEN, "camera_reference.npz"))
+    for j in range(int(z["n"])):
+        W, H = [int(v) for v in z["cam%d_size" % j]]
+        cam = syn.look_at_camera(tuple(z["cam%d_eye" % j]), target=tuple(z["cam%d_target" % j]), width=W, height=H)
+        np.testing.assert_allclose(cam.world_view_transform.numpy(), z["cam%d_world_view_transform" % j], rtol=0, atol=2e-6)
+        np.testing.assert_allclose(cam.full_proj_transform.numpy(), z["cam%d_full_proj_transform" % j], rtol=2e-6, atol=2e-6)
+        np.testing.assert_allclose(cam.camera_center.numpy(), z["cam%d_camera_center" % j], rtol=0, atol=5e-6)
+        assert abs(cam.FoVy - float(z["cam%d_fovy" % j])) < 1e-9 and cam.image_width == W and cam.image_height == H
+        assert abs(cam.tanfovx - np.tan(0.5 * cam.FoVx)) < 1e-12 and cam.cx == W / 2.0 and cam.cy == H / 2.0
