@@ -153,3 +153,35 @@ def make_random_init_scene(P=2000, seed=0, device="cpu"):
     scene = dict(xyz=xyz, normal=_normalize(torch.randn(P, 3, generator=g)), scales=scales, rotations=rot,
                  opacity=torch.full((P, 1), 0.1), shs=shs, sh_degree=0, M=16)
     return {k: (v.to(device) if torch.is_tensor(v) else v) for k, v in scene.items()}
+
+
+def write_blender_dataset(root, cameras, images, split="train", name_format="r_%d"):
+    """Write views in the NeRF-synthetic (Blender) layout the reference reads (scene/dataset_readers.py:215-270,
+    readCamerasFromTransforms): `<root>/transforms_<split>.json` with `camera_angle_x` and one frame per view
+    (`file_path` without extension, `transform_matrix` = camera-to-world in the OpenGL/Blender axes: the reader flips the
+    Y and Z columns to get back to the OpenCV axes these cameras use) plus `<root>/<split>/<name>.png` (8-bit RGB).
+    `cameras`: SynthCamera list sharing one FoVx; `images`: [3,H,W] float tensors in [0,1].  Square images only: the reader
+    derives FovY from FovX with the image HEIGHT as the focal-length base (:266), which is the true FovY only when H == W."""
+    import json
+    import os
+    from PIL import Image
+    if len(cameras) != len(images) or not cameras:
+        raise RuntimeError("write_blender_dataset needs one image per camera")
+    fovx = cameras[0].FoVx
+    os.makedirs(os.path.join(root, split), exist_ok=True)
+    frames = []
+    for i, (cam, img) in enumerate(zip(cameras, images)):
+        if abs(cam.FoVx - fovx) > 1e-12:
+            raise RuntimeError("all views of a Blender-format split share camera_angle_x")
+        if cam.image_height != cam.image_width:
+            raise RuntimeError("square images only (the reference reader's FovY quirk, dataset_readers.py:266)")
+        w2c = cam.world_view_transform.detach().cpu().double().t()            # world_view_transform is W2C transposed
+        c2w = torch.linalg.inv(w2c)
+        c2w[:3, 1:3] *= -1                                                    # OpenCV -> OpenGL/Blender camera axes
+        name = name_format % i
+        arr = (img.detach().cpu().clamp(0, 1).permute(1, 2, 0) * 255.0).round().to(torch.uint8).numpy()
+        Image.fromarray(arr, "RGB").save(os.path.join(root, split, name + ".png"))
+        frames.append({"file_path": "./%s/%s" % (split, name), "transform_matrix": c2w.tolist()})
+    with open(os.path.join(root, "transforms_%s.json" % split), "w") as fh:
+        json.dump({"camera_angle_x": fovx, "frames": frames}, fh, indent=1)
+    return os.path.join(root, "transforms_%s.json" % split)

@@ -143,6 +143,7 @@ def main():
     ssim_fixture()
     wrapper_trace_fixture()
     camera_fixture()
+    dataset_fixture()
 
 
 
@@ -325,6 +326,34 @@ def camera_fixture():
                     "cam%d_fovy" % j: np.array(fovy)})
     rec["n"] = np.array(len(poses))
     np.savez(os.path.join(HERE, "camera_reference.npz"), **rec)
+
+
+def dataset_fixture():
+    """tests/golden/blender_dataset_reference.npz: a small split written by synthetic.write_blender_dataset and read back by
+    the reference's own readCamerasFromTransforms (scene/dataset_readers.py:215-270; imageio, absent here, is shimmed
+    with PIL for the PNG read): R, T, FovX, FovY and the image arrays the reference ends up with."""
+    import tempfile
+    from PIL import Image
+    sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+    from relightable3dgaussian_amd import synthetic as syn
+    import scene.utils as scene_utils
+    import scene.dataset_readers as readers
+    scene_utils.imageio.imread = lambda path, **kw: np.asarray(Image.open(path))
+    readers.load_img_rgb = scene_utils.load_img_rgb
+    g = torch.Generator().manual_seed(5)
+    cams = syn.orbit_cameras(5, width=24, height=24)[:3]
+    imgs = [torch.rand(3, 24, 24, generator=g) for _ in cams]
+    rec = {}
+    with tempfile.TemporaryDirectory() as root:
+        syn.write_blender_dataset(root, cams, imgs, split="train")
+        infos = readers.readCamerasFromTransforms(root, "transforms_train.json", True)
+    assert len(infos) == 3
+    for j, (ci, img) in enumerate(zip(infos, imgs)):
+        rec.update({"v%d_R" % j: np.asarray(ci.R, np.float64), "v%d_T" % j: np.asarray(ci.T, np.float64),
+                    "v%d_fov" % j: np.array([ci.FovX, ci.FovY]), "v%d_image" % j: np.asarray(ci.image, np.float64),
+                    "v%d_written" % j: img.numpy().copy(), "v%d_name" % j: np.array(ci.image_name)})
+    rec["n"] = np.array(3)
+    np.savez_compressed(os.path.join(HERE, "blender_dataset_reference.npz"), **rec)
 
 
 if __name__ == "__main__":

@@ -282,3 +282,37 @@ def test_synthetic_cameras_follow_the_reference_camera_class():
         np.testing.assert_allclose(cam.camera_center.numpy(), z["cam%d_camera_center" % j], rtol=0, atol=5e-6)
         assert abs(cam.FoVy - float(z["cam%d_fovy" % j])) < 1e-9 and cam.image_width == W and cam.image_height == H
         assert abs(cam.tanfovx - np.tan(0.5 * cam.FoVx)) < 1e-12 and cam.cx == W / 2.0 and cam.cy == H / 2.0
+
+
+def test_blender_dataset_writer_is_read_back_by_the_reference_reader(tmp_path):
+    """synthetic.write_blender_dataset: the same split written again here must give the reference's readCamerasFromTransforms
+    (scene/dataset_readers.py:215-270) what tests/golden/blender_dataset_reference.npz recorded from it -- R (stored
+    transposed, as the reader does), T, FovX / FovY and the 8-bit image content -- i.e. our camera poses survive the
+    OpenCV <-> Blender axis flip and the JSON layout."""
+    import json
+    import numpy as np
+    from PIL import Image
+    from relightable3dgaussian_amd import synthetic as syn
+    z = np.load(os.path.join(GOLDEN, "blender_dataset_reference.npz"))
+    cams = syn.orbit_cameras(5, width=24, height=24)[:3]
+    imgs = [torch.from_numpy(z["v%d_written" % j]) for j in range(3)]
+    path = syn.write_blender_dataset(str(tmp_path), cams, imgs, split="train")
+    doc = json.load(open(path))
+    assert abs(doc["camera_angle_x"] - cams[0].FoVx) < 1e-15 and len(doc["frames"]) == 3
+    for j, (cam, frame) in enumerate(zip(cams, doc["frames"])):
+        assert frame["file_path"] == "./train/r_%d" % j and str(z["v%d_name" % j]) == "r_%d" % j
+        # what the reference reader derives from this frame (its arithmetic restated: flip, invert, transpose)
+        c2w = np.array(frame["transform_matrix"])
+        c2w[:3, 1:3] *= -1
+        w2c = np.linalg.inv(c2w)
+        np.testing.assert_allclose(np.transpose(w2c[:3, :3]), z["v%d_R" % j], rtol=0, atol=1e-12)
+        np.testing.assert_allclose(w2c[:3, 3], z["v%d_T" % j], rtol=0, atol=1e-12)
+        # ... and that equals the camera we started from
+        ours = cam.world_view_transform.double().t().numpy()
+        np.testing.assert_allclose(w2c, ours, rtol=0, atol=1e-6)
+        assert abs(z["v%d_fov" % j][0] - cam.FoVx) < 1e-12 and abs(z["v%d_fov" % j][1] - cam.FoVy) < 1e-9
+        png = np.asarray(Image.open(os.path.join(tmp_path, "train", "r_%d.png" % j))) / 255
+        np.testing.assert_array_equal(png, z["v%d_image" % j])
+        assert np.abs(png - imgs[j].permute(1, 2, 0).numpy()).max() <= 0.5 / 255 + 1e-7
+    with pytest.raises(RuntimeError):
+        syn.write_blender_dataset(str(tmp_path), syn.orbit_cameras(2, width=32, height=24), [torch.zeros(3, 24, 32)] * 2)
