@@ -185,3 +185,13 @@ def write_blender_dataset(root, cameras, images, split="train", name_format="r_%
     with open(os.path.join(root, "transforms_%s.json" % split), "w") as fh:
         json.dump({"camera_angle_x": fovx, "frames": frames}, fh, indent=1)
     return os.path.join(root, "transforms_%s.json" % split)
+
+
+def cameras_extent(cameras):
+    """`scene.cameras_extent` (scene/__init__.py -> getNerfppNorm, scene/dataset_readers.py:45-66): 1.1 x the largest
+    distance of a camera centre from the mean camera centre -- the `extent` every densification threshold is scaled by
+    (train.py:170).  Returns (radius, translate) with translate = -mean centre."""
+    centers = torch.stack([c.camera_center.detach().cpu().double() for c in cameras], 0)
+    mean = centers.mean(0)
+    radius = float((centers - mean).norm(dim=-1).max()) * 1.1
+    return radius, (-mean).numpy()

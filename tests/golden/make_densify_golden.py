@@ -352,6 +352,9 @@ def dataset_fixture():
         rec.update({"v%d_R" % j: np.asarray(ci.R, np.float64), "v%d_T" % j: np.asarray(ci.T, np.float64),
                     "v%d_fov" % j: np.array([ci.FovX, ci.FovY]), "v%d_image" % j: np.asarray(ci.image, np.float64),
                     "v%d_written" % j: img.numpy().copy(), "v%d_name" % j: np.array(ci.image_name)})
+    norm = readers.getNerfppNorm(infos)                      # scene.cameras_extent = norm["radius"]
+    rec["extent_radius"] = np.array(norm["radius"])
+    rec["extent_translate"] = np.asarray(norm["translate"], np.float64)
     rec["n"] = np.array(3)
     np.savez_compressed(os.path.join(HERE, "blender_dataset_reference.npz"), **rec)
 

@@ -316,3 +316,7 @@ def test_blender_dataset_writer_is_read_back_by_the_reference_reader(tmp_path):
         assert np.abs(png - imgs[j].permute(1, 2, 0).numpy()).max() <= 0.5 / 255 + 1e-7
     with pytest.raises(RuntimeError):
         syn.write_blender_dataset(str(tmp_path), syn.orbit_cameras(2, width=32, height=24), [torch.zeros(3, 24, 32)] * 2)
+    # scene.cameras_extent of the same views (getNerfppNorm on what the reader returned)
+    radius, translate = syn.cameras_extent(cams)
+    assert abs(radius - float(z["extent_radius"])) < 1e-5 * radius
+    np.testing.assert_allclose(translate, z["extent_translate"], rtol=0, atol=1e-5)
