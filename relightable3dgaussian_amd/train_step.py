@@ -98,6 +98,13 @@ def image_loss(img, gt):
     return (1.0 - LAMBDA_DSSIM) * (img - gt).abs().mean() + LAMBDA_DSSIM * (1.0 - ssim(img, gt))
 
 
+def psnr(img1, img2):
+    """utils/image_utils.py:25-30: one value per slice of the leading axis (the reference logs `.mean()` of it,
+    neilf.py:229): 20 log10(1 / sqrt(mean squared error of that slice))."""
+    mse = ((img1 - img2) ** 2).reshape(img1.shape[0], -1).mean(1, keepdim=True)
+    return 20 * torch.log10(1.0 / torch.sqrt(mse))
+
+
 def rgb_to_srgb(img):
     """utils/graphics_utils.py:207-213 with clip=True (what render_view puts into results["pbr"], neilf.py:179): the sRGB
     curve, then clamp to [0,1] -- the clamp stops the gradient of saturated pixels.  Pinned by tests/golden/ssim_reference.npz."""

@@ -258,6 +258,8 @@ def ssim_fixture():
         loss = (1.0 - 0.2) * l1 + 0.2 * (1.0 - s)                   # train.py / render.py: lambda_dssim = 0.2
         loss.backward()
         rec[name + "_tv"] = float(tv_loss(x.detach()))
+        from utils.image_utils import psnr
+        rec[name + "_psnr"] = psnr(x.detach(), y).numpy().copy()
         rec.update({name + "_x": x.detach().numpy().copy(), name + "_y": y.numpy().copy(), name + "_ssim": float(s),
                     name + "_l1": float(l1), name + "_loss": float(loss), name + "_grad": x.grad.numpy().copy()})
     # rgb_to_srgb (clip=True) with its gradient: values below 0, around the linear/power knee, inside (0,1) and above 1

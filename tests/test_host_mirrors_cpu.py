@@ -184,6 +184,9 @@ def test_tv_loss_matches_the_reference():
     z = np.load(os.path.join(GOLDEN, "ssim_reference.npz"))
     for name in ("a", "b"):
         assert abs(float(train_step.tv_loss(torch.from_numpy(z[name + "_x"]))) - float(z[name + "_tv"])) < 1e-7
+        got = train_step.psnr(torch.from_numpy(z[name + "_x"]), torch.from_numpy(z[name + "_y"]))       # image_utils.psnr
+        np.testing.assert_allclose(got.numpy(), z[name + "_psnr"], rtol=1e-6, atol=1e-5)
+        assert got.shape == (3, 1)
 
 
 def test_rgb_to_srgb_matches_the_reference_including_the_clip():
