@@ -40,11 +40,43 @@ def parse():
     ap.add_argument("--no-other-configs", action="store_true", help="skip the short stage-1 / K=384 side measurements")
     ap.add_argument("--relight-frames", type=int, default=20)
     ap.add_argument("--relight-samples", type=int, default=384)
+    ap.add_argument("--repeats", type=int, default=5,
+                    help="N=1 only: extra timed blocks of --steps iterations after the headline block (min/median/max)")
+    ap.add_argument("--plumbing-only", action="store_true",
+                    help="launch/rendezvous/reduction path only, no kernels (CPU test of the --gpus N launcher)")
     return ap.parse_args()
+
+
+def _free_port():
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def spawn_ranks(args):
+    """`python bench.py --gpus N` with no launcher around it: start N ranks ourselves, one process per GPU, exactly as the
+    driver's `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ...` would, and let
+    rank 0's JSON line through.  Fails loudly when the node has fewer than N GPUs (R3DG_DIST_BACKEND=gloo, the test
+    backend, lets ranks share devices)."""
+    import subprocess
+    backend = os.environ.get("R3DG_DIST_BACKEND", "nccl")
+    if backend == "nccl" and not args.plumbing_only and torch.cuda.device_count() < args.gpus:
+        sys.exit("bench.py: --gpus %d requested but only %d GPU(s) are visible" % (args.gpus, torch.cuda.device_count()))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"),
+               OMP_NUM_THREADS=os.environ.get("OMP_NUM_THREADS", "4"))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    sys.exit(subprocess.run(cmd, env=env, stdin=subprocess.DEVNULL).returncode)
 
 
 def main():
     args = parse()
+    world = os.environ.get("WORLD_SIZE")
+    if world is None and args.gpus > 1:
+        spawn_ranks(args)
+    if world is not None and int(world) != args.gpus:
+        sys.exit("bench.py: --gpus %d but the launcher started WORLD_SIZE=%s ranks" % (args.gpus, world))
     from relightable3dgaussian_amd import bench_core
     bench_core.run(args)
 

@@ -117,3 +117,75 @@ def knn_dist2(points):
     torch.cuda.synchronize()
     L.ref_knn_dist2(C.c_int(pts.size(0)), _p(pts), _p(out))
     return out
+
+
+# ---- render_equation.cu (the contract model), oracle/_ref/libr3dg_reference_shading.so ----------------------------------
+SHADING_LIB_PATH = os.path.join(HERE, "_ref", "libr3dg_reference_shading.so")
+_shading_lib = None
+
+
+def shading_available():
+    return os.path.exists(SHADING_LIB_PATH)
+
+
+def shading_lib():
+    global _shading_lib
+    if _shading_lib is None:
+        _shading_lib = C.CDLL(SHADING_LIB_PATH)       # linked against libtorch (rpath); torch is imported above
+    return _shading_lib
+
+
+def _re_sizes(a):
+    return a[0].shape[0], a[5].shape[1], a[6].shape[1], a[7].shape[1]
+
+
+def render_equation_forward(base_color, roughness, metallic, normals, viewdirs, incidents_shs, direct_shs, visibility_shs,
+                            sample_num, is_training=False, rand_float=None):
+    """render_equation_forward_cuda of the real reference (render_equation.cu:668-688) -> (pbr, incident_dirs, diffuse_light).
+    `rand_float` [P,K,1] replaces the torch::rand table RenderEquationForwardCUDA draws (:711)."""
+    a = [x.contiguous() for x in (base_color, roughness, metallic, normals, viewdirs, incidents_shs, direct_shs,
+                                  visibility_shs)]
+    P, Si, Sd, Sv = _re_sizes(a)
+    K = int(sample_num)
+    f = dict(dtype=torch.float32, device=base_color.device)
+    pbr, dirs, dl = torch.zeros(P, 3, **f), torch.zeros(P, K, 3, **f), torch.zeros(P, 3, **f)
+    rnd = rand_float.contiguous() if rand_float is not None else torch.zeros(P, K, 1, **f)
+    torch.cuda.synchronize()
+    shading_lib().ref_render_equation_forward(P, Si, Sd, Sv, *[_p(x) for x in a], K, int(bool(is_training)), _p(rnd),
+                                              _p(dirs), _p(pbr), _p(dl))
+    return pbr, dirs, dl
+
+
+def render_equation_forward_complex(base_color, roughness, metallic, normals, viewdirs, incidents_shs, direct_shs,
+                                    visibility_shs, sample_num):
+    """render_equation_forward_complex_cuda (render_equation.cu:192-220) -> the 11-tuple of RenderEquationForwardCUDA_complex."""
+    a = [x.contiguous() for x in (base_color, roughness, metallic, normals, viewdirs, incidents_shs, direct_shs,
+                                  visibility_shs)]
+    P, Si, Sd, Sv = _re_sizes(a)
+    K = int(sample_num)
+    dev = base_color.device
+
+    def z(*s):
+        return torch.zeros(*s, dtype=torch.float32, device=dev)
+    pbr, dirs, lights, local, glob = z(P, 3), z(P, K, 3), z(P, K, 3), z(P, K, 3), z(P, K, 3)
+    vis, diffuse, local_diffuse, accum, rgb_d, rgb_s = z(P, K, 1), z(P, 3), z(P, 3), z(P, 1), z(P, 3), z(P, 3)
+    torch.cuda.synchronize()
+    shading_lib().ref_render_equation_forward_complex(P, Si, Sd, Sv, *[_p(x) for x in a], K, _p(dirs), _p(pbr), _p(lights),
+                                                      _p(local), _p(glob), _p(vis), _p(diffuse), _p(local_diffuse),
+                                                      _p(accum), _p(rgb_d), _p(rgb_s))
+    return pbr, dirs, lights, local, glob, vis, diffuse, local_diffuse, accum, rgb_d, rgb_s
+
+
+def render_equation_backward(base_color, roughness, metallic, normals, viewdirs, incidents_shs, direct_shs, visibility_shs,
+                             sample_num, incident_dirs, dL_dpbr, dL_ddiffuse_light):
+    """render_equation_backward_cuda (render_equation.cu:465-495) -> the 8 gradients of RenderEquationBackwardCUDA.
+    dL_ddirect_shs is a plain (non-atomic) read-modify-write from every thread in the reference (quirk Q5): racy."""
+    a = [x.contiguous() for x in (base_color, roughness, metallic, normals, viewdirs, incidents_shs, direct_shs,
+                                  visibility_shs)]
+    P, Si, Sd, Sv = _re_sizes(a)
+    outs = [torch.zeros_like(x) for x in a]
+    torch.cuda.synchronize()
+    shading_lib().ref_render_equation_backward(P, Si, Sd, Sv, *[_p(x) for x in a], int(sample_num),
+                                               _p(incident_dirs.contiguous()), _p(dL_dpbr.contiguous()),
+                                               _p(dL_ddiffuse_light.contiguous()), *[_p(o) for o in outs])
+    return tuple(outs)

@@ -320,6 +320,29 @@ def densify_bench(points, res, dev, views=8):
                 call_ms=round(1e3 * dt, 3), gather_algorithmic_MB=round(moved / 1e6, 1))
 
 
+def _plumbing_only(args, world, rank, backend):
+    """The launcher / rendezvous / max-over-ranks reduction / rank-0 print path of run() with no kernels: what a CPU box
+    can check of `bench.py --gpus N` (tests/test_dp_cpu.py).  value is null: nothing was measured."""
+    if world > 1:
+        dist.init_process_group("gloo" if not torch.cuda.is_available() else backend)
+        dist.barrier()
+    t0 = time.perf_counter()
+    t = torch.tensor([time.perf_counter() - t0 + 1e-3 * rank], dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        seen = torch.ones(1, dtype=torch.float64)
+        dist.all_reduce(seen)
+        assert int(seen.item()) == world
+    result = None
+    if rank == 0:
+        result = {"metric": "plumbing only (no kernels run)", "value": None, "unit": "iters/s", "n_gpus": world,
+                  "steps": args.steps, "warmup": args.warmup, "plumbing_only": True}
+        print(json.dumps(result), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+    return result
+
+
 def run(args):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -327,6 +350,8 @@ def run(args):
     # one process per GPU; R3DG_DIST_BACKEND=gloo lets the multi-rank path be exercised on a box with fewer GPUs than
     # ranks (ranks then share devices) -- test use only, the measured configuration is nccl (= RCCL)
     backend = os.environ.get("R3DG_DIST_BACKEND", "nccl")
+    if getattr(args, "plumbing_only", False):
+        return _plumbing_only(args, world, rank, backend)
     dev_index = local_rank % max(1, torch.cuda.device_count()) if world > 1 else 0
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")

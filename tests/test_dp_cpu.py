@@ -3,6 +3,8 @@ replicas stay bit-identical and equal a single-process run that averages both vi
 import os
 import socket
 
+import pytest
+
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
@@ -147,3 +149,44 @@ def test_sharded_update_visibility_equals_single_process(tmp_path):
             assert torch.equal(got["dirs"], want[1]) and torch.equal(got["areas"], want[2])
             traced += got["traced"]
         assert traced == P               # every bundle traced exactly once across the ranks
+
+
+# --- bench.py --gpus N launches N ranks itself (the flag used to be parsed and ignored) -------------------
+def _run_bench(extra, env=None, timeout=240):
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    e = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        e.pop(k, None)
+    e.update(env or {})
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py")] + extra, capture_output=True, text=True,
+                       timeout=timeout, env=e, stdin=subprocess.DEVNULL, cwd="/tmp")
+    lines = [x for x in r.stdout.splitlines() if x.startswith("{")]
+    return r, (json.loads(lines[-1]) if lines else None)
+
+
+def test_bench_gpus_flag_starts_that_many_ranks():
+    """`python bench.py --gpus 2` (the driver's literal command shape, no launcher around it) must start 2 ranks,
+    rendezvous on 127.0.0.1, reduce over ranks and print ONE line with n_gpus 2.  No GPU here: the kernels are skipped
+    (--plumbing-only); tests/test_fused_dp_gpu.py runs the same command with the kernels on the GPU box."""
+    r, doc = _run_bench(["--gpus", "2", "--steps", "3", "--warmup", "1", "--plumbing-only"],
+                        env={"R3DG_DIST_BACKEND": "gloo"})
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert doc is not None and doc["n_gpus"] == 2 and doc["steps"] == 3
+    assert sum(1 for x in r.stdout.splitlines() if x.startswith("{")) == 1
+
+
+def test_bench_gpus_flag_fails_loudly_without_enough_devices():
+    import torch
+    if torch.cuda.device_count() >= 2:
+        pytest.skip("this box has the devices")
+    r, doc = _run_bench(["--gpus", "2", "--steps", "1", "--warmup", "0"], env={"R3DG_DIST_BACKEND": "nccl"})
+    assert r.returncode != 0 and doc is None
+    assert "--gpus 2 requested" in (r.stderr + r.stdout)
+
+
+def test_bench_rejects_world_size_mismatch():
+    r, doc = _run_bench(["--gpus", "4", "--plumbing-only"], env={"WORLD_SIZE": "1", "RANK": "0"})
+    assert r.returncode != 0 and "WORLD_SIZE" in (r.stderr + r.stdout)

@@ -149,3 +149,39 @@ def test_densification_keeps_replicas_identical(tmp_path):
         assert r0["pars"][k].shape[0] == r0["rows"]
         assert torch.equal(r0["pars"][k], r1["pars"][k]), "replicas diverged: " + k
         assert torch.equal(r0["moms"][k], r1["moms"][k]), "Adam moments diverged: " + k
+
+
+def _bench(extra, env, timeout=420):
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    e = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        e.pop(k, None)
+    e.update(env)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py")] + extra, capture_output=True, text=True,
+                       timeout=timeout, env=e, stdin=subprocess.DEVNULL, cwd="/tmp")
+    lines = [x for x in r.stdout.splitlines() if x.startswith("{")]
+    return r, (json.loads(lines[-1]) if lines else None)
+
+
+SMALL = ["--steps", "3", "--warmup", "1", "--points", "20000", "--res", "160", "--sample-num", "16", "--no-cpu-baseline",
+         "--relight-frames", "0", "--no-other-configs", "--repeats", "0"]
+
+
+def test_bench_gpus_2_runs_two_ranks_on_the_gpu():
+    """The driver's literal `python bench.py --gpus 2 ...` (no launcher): two ranks, real kernels, one JSON line with
+    n_gpus 2.  The test box has ONE GPU, so the ranks share it through the gloo test backend (RCCL refuses two ranks on
+    one device); the RCCL variant below runs wherever two devices exist."""
+    r, doc = _bench(["--gpus", "2"] + SMALL, {"R3DG_DIST_BACKEND": "gloo"})
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert doc["n_gpus"] == 2 and doc["value"] > 0 and "dp2" in doc["config"]["parallelism"]
+    assert sum(1 for x in r.stdout.splitlines() if x.startswith("{")) == 1
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="RCCL needs one device per rank")
+def test_bench_gpus_2_rccl():
+    r, doc = _bench(["--gpus", "2"] + SMALL, {"R3DG_DIST_BACKEND": "nccl"})
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert doc["n_gpus"] == 2 and doc["value"] > 0

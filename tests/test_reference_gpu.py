@@ -34,10 +34,33 @@ def _ok(name, got, ref, rtol, atol, msgs):
                                      ("colors_cov_S3", dict(S=3, P=8000, W=200, H=120, seed=73, use_colors=True, use_cov=True)),
                                      ("S0", dict(S=0, P=5000, W=128, H=128, seed=74))])
 def test_rasterizer_matches_real_reference(name, kw):
+    _compare_rasterizer(name, make_case(**kw), backward=True)
+
+
+# The BASELINE configurations themselves (BASELINE.json configs / SURVEY 8d), against forward.cu:263-395 and
+# backward.cu:401-614 of the real reference build.  Scene = bench.py's (make_scene seed 0, scale_log_mean -4.6), camera =
+# orbit view 0 of bench.py (radius 4.03, 15 deg elevation).  At these sizes the multi-chunk scans, the persistent
+# 1024-thread tile sorts, the longest-tile-first order and (1600x1200) the 13-bit tile ids are live.  The reference's
+# backward is limited to S <= 24 (backward.cu:449), so the S=28 relight row is forward-only, like the relight frame.
+ORBIT0 = (4.03 * 0.9659258262890683, 0.0, 4.03 * 0.25881904510252074)
+BASELINE_CASES = [
+    ("train_300k_800x800_S16", dict(S=16, P=300_000, W=800, H=800, seed=0, scale_log_mean=-4.6, eye=ORBIT0), True),
+    ("stage1_300k_800x800_S5", dict(S=5, P=300_000, W=800, H=800, seed=0, scale_log_mean=-4.6, eye=ORBIT0), True),
+    ("relight_300k_800x800_S28", dict(S=28, P=300_000, W=800, H=800, seed=0, scale_log_mean=-4.6, eye=ORBIT0), False),
+    ("dtu_300k_1600x1200_S16", dict(S=16, P=300_000, W=1600, H=1200, seed=0, scale_log_mean=-4.6, eye=ORBIT0), True),
+    ("teaser_2M_1800x700_S28", dict(S=28, P=2_000_000, W=1800, H=700, seed=0, scale_log_mean=-5.0, eye=ORBIT0), False),
+]
+
+
+@pytest.mark.parametrize("name,kw,backward", BASELINE_CASES, ids=[c[0] for c in BASELINE_CASES])
+def test_rasterizer_matches_real_reference_at_baseline_sizes(name, kw, backward):
+    _compare_rasterizer(name, make_case(**kw), backward=backward)
+
+
+def _compare_rasterizer(name, case, backward=True):
     rg = _need_ref()
     from r3dg_rasterization import _C
     from relightable3dgaussian_amd.rasterizer_ops import decode_state
-    case = make_case(**kw)
     a = fwd_args(case, DEV)
     P, H, W, S = case["P"], case["H"], case["W"], case["S"]
     ours = _C.rasterize_gaussians(*a)
@@ -73,6 +96,11 @@ def test_rasterizer_matches_real_reference(name, kw):
             msgs.append("%-12s max|err| %.3e scale %.3e, pixels beyond 2e-5: %d" % (nm, np.abs(o_ - r_).max(), scale, bad.sum()))
             ok &= bad.mean() <= 1e-3 and np.abs(o_ - r_).max() <= 8e-3 * max(scale, 1.0)
     ok &= _ok("weights", ours[8], ref["weights"], 2e-4, 1e-5, msgs)
+    if not backward:
+        text = "\n".join(["[real reference / %s] P=%d %dx%d S=%d (forward only)" % (name, P, W, H, S)] + msgs)
+        print(text)
+        assert ok, text
+        return
     # backward: upstream gradients zeroed where the discrete outcome differs
     g = torch.Generator().manual_seed(5)
     mask = nc_same[None].float().cpu()
@@ -100,12 +128,14 @@ def test_rasterizer_matches_real_reference(name, kw):
     assert ok, text
 
 
-@pytest.mark.parametrize("P,seed", [(3, 0), (2000, 1), (50000, 2)])
-def test_bvh_matches_real_reference(P, seed):
+# (300 000, K=64) is the BASELINE stage-2 visibility pass (run_nerf.sh:37): construct.cu:147-265 + trace.cu:196-286 at
+# full size, 19.2 M rays
+@pytest.mark.parametrize("P,seed,K", [(3, 0, 16), (2000, 1, 16), (50000, 2, 16), (300_000, 0, 64)])
+def test_bvh_matches_real_reference(P, seed, K):
     rg = _need_ref()
     from relightable3dgaussian_amd import bvh as hb, bvh_ops
     from tests.test_oracle_cpu import _bvh_case
-    sc, dirs, cinv, rays_o = _bvh_case(P, seed, K=16, dup=P > 100)
+    sc, dirs, cinv, rays_o = _bvh_case(P, seed, K=K, dup=P > 100)
     d = {k: v.to(DEV) for k, v in sc.items() if torch.is_tensor(v)}
     n1, a1 = hb.leaf_boxes(d["xyz"], d["scales"], d["rotations"])
     n2, a2 = n1.clone(), a1.clone()
