@@ -113,7 +113,20 @@ def _algorithmic_bytes(stage, P, R, N, S, K=64):
     }[stage]
 
 
-def cpu_baseline(scene, cams, S, budget_s):
+def cpu_baseline(scene, cams, S, budget_s, points=300_000, res=800):
+    """The reported CPU baseline (north_star): a pure-PyTorch rasterize forward of the SAME view of the SAME scene
+    (oracle/torch_rasterizer.py, the autograd restatement of forward.cu) timed on the host cores in a bounded child
+    process; core count stated.  `extra.c_port` keeps the round-1 figure: the oracle C port (1 thread) doing rasterize
+    forward+backward view after view for ~budget_s seconds."""
+    same_view = pytorch_cpu_rasterize(points, res, S, timeout_s=240)
+    extra = {"c_port": c_port_baseline(scene, cams, S, budget_s), "pytorch_cpu_config0": pytorch_cpu_rasterize(2000, 400, 5, 60, config0=True)}
+    sec = same_view.get("seconds_per_view")
+    return dict(value=None if sec is None else round(1.0 / sec, 4), unit="views/s (rasterize forward)",
+                cores=same_view.get("threads"), kind="port", seconds_per_view=sec if sec is not None else ">240",
+                sample=same_view.get("what", same_view.get("failed")), logical_cpus=os.cpu_count(), extra=extra)
+
+
+def c_port_baseline(scene, cams, S, budget_s):
     """Oracle (C port of the reference algorithm, 1 thread) rasterize forward+backward of the SAME scene, one view
     after another until ~budget_s seconds of CPU work are spent (a bounded sample of the GPU workload)."""
     import numpy as np
@@ -140,38 +153,42 @@ def cpu_baseline(scene, cams, S, budget_s):
         t_b += time.time() - t0
         views += 1
         R = out[0]
-    extra = {"pytorch_cpu_config0": pytorch_cpu_config0()}
-    return dict(value=views / (t_f + t_b), unit="iters/s", cores=1, kind="port", **extra,
+    return dict(value=round(views / (t_f + t_b), 4), unit="iters/s", cores=1,
                 sample="%d views %dx%d, %d Gaussians, R~%d, rasterize fwd+bwd S=%d only (oracle C port, fp32, 1 thread; "
                        "fwd %.1fs + bwd %.1fs of CPU time); shading/Adam not included" % (
                            views, W, H, P, R, S, t_f, t_b))
 
 
-_CONFIG0_SCRIPT = """
+_CPU_RASTERIZE_SCRIPT = """
 import json, os, sys, time
-sys.path.insert(0, %r)
+sys.path.insert(0, %(root)r)
 import torch
 from oracle import torch_rasterizer as tr
 from relightable3dgaussian_amd import synthetic as syn
-torch.set_num_threads(%d)
-sc0 = syn.make_scene(P=2000, seed=0, stage2=False, scale_log_mean=-3.0)
-cam0 = syn.orbit_cameras(4, width=400, height=400)[0]
-f0 = torch.rand(2000, 5)
+torch.set_num_threads(%(threads)d)
+P, RES, S = %(P)d, %(res)d, %(S)d
+if %(config0)r:
+    sc0 = syn.make_scene(P=P, seed=0, stage2=False, scale_log_mean=-3.0)
+    cam0 = syn.orbit_cameras(4, width=RES, height=RES)[0]
+else:                                      # the bench's own scene and its view 0
+    sc0 = syn.make_scene(P=P, seed=0, stage2=False)
+    cam0 = syn.orbit_cameras(100, width=RES, height=RES)[0]
+f0 = torch.rand(P, S)
 t0 = time.time()
 with torch.no_grad():
     o0 = tr.rasterize(torch.ones(3), sc0["xyz"], f0, None, sc0["opacity"], sc0["scales"], sc0["rotations"], 1.0, None,
                       cam0.world_view_transform, cam0.full_proj_transform, cam0.tanfovx, cam0.tanfovy, cam0.cx, cam0.cy,
-                      400, 400, sc0["shs"], 3, cam0.camera_center)
+                      RES, RES, sc0["shs"], 3, cam0.camera_center)
 print(json.dumps(dict(seconds_per_view=round(time.time() - t0, 3), num_rendered=int(o0["num_rendered"]))))
 """
 
 
-def pytorch_cpu_config0(timeout_s=60):
-    """configs[0]: the reference's own CPU-runnable plumbing case (2k random Gaussians, one 400x400 view) through the
-    pure-PyTorch restatement (oracle/torch_rasterizer.py), timed on the host cores.  Runs in a child process with a hard
-    time limit and a thread count taken from the CPU affinity mask (capped at 8): on a box whose container sees more
-    logical CPUs than it may use, os.cpu_count() OpenMP threads make the thousands of tiny tensor ops of the tile loop
-    crawl for minutes -- a reported baseline must never be able to stall the bench."""
+def pytorch_cpu_rasterize(points, res, S, timeout_s=60, config0=False):
+    """Pure-PyTorch CPU rasterize forward (oracle/torch_rasterizer.py) of one view, timed on the host cores.  Runs in a
+    child process with a hard time limit and a thread count taken from the CPU affinity mask (capped at 8): on a box
+    whose container sees more logical CPUs than it may use, os.cpu_count() OpenMP threads make the thousands of tiny
+    tensor ops of the tile loop crawl for minutes -- a reported baseline must never be able to stall the bench.
+    config0=True is BASELINE configs[0] (2k random Gaussians, 400x400), else the bench's own scene, view 0."""
     import subprocess
     import sys
     try:
@@ -181,9 +198,11 @@ def pytorch_cpu_config0(timeout_s=60):
     threads = max(1, min(8, usable))
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, OMP_NUM_THREADS=str(threads), MKL_NUM_THREADS=str(threads), HIP_VISIBLE_DEVICES="")
-    what = "pure-PyTorch CPU rasterize forward (oracle/torch_rasterizer.py), 2000 Gaussians, one 400x400 view"
+    what = "pure-PyTorch CPU rasterize forward (oracle/torch_rasterizer.py), %d Gaussians, one %dx%d view, S=%d, %d threads" % (
+        points, res, res, S, threads)
+    script = _CPU_RASTERIZE_SCRIPT % dict(root=root, threads=threads, P=points, res=res, S=S, config0=bool(config0))
     try:
-        r = subprocess.run([sys.executable, "-c", _CONFIG0_SCRIPT % (root, threads)], capture_output=True, text=True,
+        r = subprocess.run([sys.executable, "-c", script], capture_output=True, text=True,
                            timeout=timeout_s, env=env, stdin=subprocess.DEVNULL)
         line = [x for x in r.stdout.splitlines() if x.startswith("{")]
         if r.returncode != 0 or not line:
@@ -192,7 +211,7 @@ def pytorch_cpu_config0(timeout_s=60):
         return dict(seconds_per_view=doc["seconds_per_view"], threads=threads, logical_cpus=os.cpu_count(),
                     what=what + ", num_rendered=%d" % doc["num_rendered"])
     except subprocess.TimeoutExpired:
-        return {"failed": "no result within %d s" % timeout_s, "threads": threads, "logical_cpus": os.cpu_count()}
+        return {"failed": what + ": no result within %d s" % timeout_s, "threads": threads, "logical_cpus": os.cpu_count()}
     except Exception as e:
         return {"failed": repr(e)}
 
@@ -214,6 +233,65 @@ def pmc_traffic(stage):
     except Exception:
         return None
     return None
+
+
+def pmc_valu(stage):
+    """VALU-issue evidence for `stage`'s kernel from the committed rocprofv3 SQ-counter passes (profiles/*_pmc_valu.json,
+    tools/pmc_valu.py): fraction of the kernel's duration the SIMDs spend issuing VALU instructions, occupancy, LDS bank
+    conflicts -- shown beside every HBM fraction because the tile and shading kernels are VALU-bound -- or None."""
+    import glob
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    files = sorted(glob.glob(os.path.join(root, "profiles", "*_pmc_valu.json")))
+    if not files:
+        return None
+    try:
+        doc = json.load(open(files[-1]))
+        for name, v in doc["kernels"].items():
+            if name.startswith(stage + "_kernel") or name == stage:
+                out = {k: v[k] for k in ("valu_issue_frac", "valu_busy_frac", "waves_per_simd", "lds_bank_conflict_frac",
+                                         "vgprs", "lds_bytes") if k in v}
+                out["source"] = os.path.basename(files[-1])
+                return out
+    except Exception:
+        return None
+    return None
+
+
+def kernel_table(prof, n_sampled, P, R, N, S, K):
+    """{stage: avg_ms, launches, ms per iteration/frame, algorithmic MB, achieved GB/s, fraction of the 8 TB/s HBM peak,
+    VALU-issue fraction (committed PMC evidence)} from the in-library HIP-event timing."""
+    kernels = {}
+    for name, (ms, cnt) in prof.items():
+        if cnt == 0:
+            continue
+        # a stage may take several launches per iteration (the Adam groups go out in two or three launches, SSIM in
+        # four): `algorithmic_MB` is the stage's bytes per ITERATION, so it is divided by the stage's time per iteration
+        per_iter = max(1, round(cnt / n_sampled))
+        avg_ms = ms / cnt
+        step_ms = avg_ms * per_iter
+        try:
+            by = _algorithmic_bytes(name, P, R, N, S, K)
+        except KeyError:
+            by = None
+        row = dict(avg_ms=round(avg_ms, 4), launches=cnt, launches_per_iteration=per_iter,
+                   ms_per_iteration=round(step_ms, 4), algorithmic_MB=None if by is None else round(by / 1e6, 1),
+                   achieved_GBs=None if by is None else round(by / (step_ms * 1e-3) / 1e9, 1),
+                   hbm_frac=None if by is None else round(by / (step_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4))
+        v = pmc_valu(name)
+        if v is not None:
+            row["valu"] = v
+        kernels[name] = row
+    return kernels
+
+
+def roofline_of(kernels, note):
+    dom = max(kernels, key=lambda k: kernels[k].get("ms_per_iteration", 0.0))
+    ach = kernels[dom]["achieved_GBs"]
+    tr = pmc_traffic(dom)
+    return dict(bound="hbm", kernel=dom, achieved=ach, peak=HBM_PEAK_GBS, unit="GB/s",
+                frac=None if ach is None else round(ach / HBM_PEAK_GBS, 4),
+                traffic=None if tr is None else tr["bytes_corrected"], traffic_detail=tr,
+                valu=kernels[dom].get("valu"), avg_kernel_ms=kernels[dom]["ms_per_iteration"], note=note)
 
 
 @torch.no_grad()
@@ -242,12 +320,32 @@ def relight_bench(params, cams, dev, frames, K):
         torch.cuda.synchronize()
         return (time.perf_counter() - t) / n
 
-    dt = timed(lambda cam: renderer.frame(cam, bg), frames)
+    L = _lib.lib()
+    for i in range(3):
+        renderer.frame(cams[i], bg)
+    torch.cuda.synchronize()
+    L.r3dg_profile_enable(1)
+    torch.cuda.synchronize()
+    R_seen = []
+    t = time.perf_counter()
+    for i in range(frames):
+        L.r3dg_profile_pause(0 if i % 4 == 0 else 1)          # per-kernel HIP events on every 4th frame
+        R_seen.append(renderer.frame(cams[(3 + i) % len(cams)], bg)["num_rendered"])
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t) / frames
+    prof = _lib.profile_read()
+    L.r3dg_profile_enable(0)
     dt_ref = timed(lambda cam: relight.frame_reference(renderer, cam, bg), max(3, frames // 4))
     P = params.xyz.shape[0]
+    H, W = cams[0].image_height, cams[0].image_width
+    R_mean = float(sum(R_seen)) / max(1, len(R_seen))
+    kernels = kernel_table(prof, max(1, sum(1 for i in range(frames) if i % 4 == 0)), P, R_mean, H * W, 28, K)
+    roof = roofline_of(kernels, "relight frame (shading forward at K=%d + rasterize forward S=28 + composite): achieved = "
+                       "algorithmic bytes per launch / HIP-event kernel time" % K)
     return dict(relight_fps=round(1.0 / dt, 2), relight_ms_per_frame=round(1e3 * dt, 3), relight_K=K,
                 relight_features=28, relight_fps_pytorch_glue=round(1.0 / dt_ref, 2), visibility_rays=P * K,
-                visibility_seconds=round(t_vis, 3), visibility_Mrays_per_s=round(P * K / t_vis / 1e6, 1))
+                visibility_seconds=round(t_vis, 3), visibility_Mrays_per_s=round(P * K / t_vis / 1e6, 1),
+                num_rendered=R_mean, roofline_relight=roof, kernels=kernels)
 
 
 def quick_rate(stage, points, res, sample_num, dev, steps=20, warmup=4):
@@ -459,6 +557,25 @@ def run(args):
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    # spread of the headline number: the same block of --steps iterations repeated (N=1; event timing off)
+    blocks = [world * args.steps / elapsed]
+    if world == 1 and getattr(args, "repeats", 0) > 0:
+        L.r3dg_profile_pause(1)
+        for r in range(args.repeats):
+            torch.cuda.synchronize()
+            tb = time.perf_counter()
+            for i in range(args.steps):
+                one_step(args.warmup + (r + 1) * args.steps + i)
+            if fused:
+                step_fn.flush()
+            torch.cuda.synchronize()
+            blocks.append(args.steps / (time.perf_counter() - tb))
+    blocks_sorted = sorted(blocks)
+    spread = dict(blocks=len(blocks), steps_per_block=args.steps, min=round(blocks_sorted[0], 2),
+                  median=round(blocks_sorted[len(blocks) // 2], 2), max=round(blocks_sorted[-1], 2),
+                  note="iters/s of the timed block (`value`, event timing on every 4th step) and of %d more blocks "
+                       "(event timing off)" % (len(blocks) - 1))
+
     relight = None
     if stage2 and args.relight_frames > 0 and world == 1:       # relight: replicas only -- measured at N=1
         step_fn.visibility = step_fn.incident_dirs = step_fn.incident_areas = None   # free the K=train caches
@@ -468,35 +585,14 @@ def run(args):
     if rank == 0:
         P, N = args.points, args.res * args.res
         R_mean = float(sum(R_seen[-args.steps:])) / max(1, args.steps)
-        kernels = {}
         n_sampled = max(1, sum(1 for i in range(args.steps) if i % 4 == 0))     # steps whose launches were timed
-        for name, (ms, cnt) in prof.items():
-            if cnt == 0:
-                continue
-            # a stage may take several launches per iteration (the Adam groups go out in two or three launches, SSIM in
-            # four): `algorithmic_MB` is the stage's bytes per ITERATION, so it is divided by the stage's time per iteration
-            per_iter = max(1, round(cnt / n_sampled))
-            avg_ms = ms / cnt
-            step_ms = avg_ms * per_iter
-            try:
-                by = _algorithmic_bytes(name, P, R_mean, N, S, args.sample_num)
-            except KeyError:
-                by = None
-            kernels[name] = dict(avg_ms=round(avg_ms, 4), launches=cnt, launches_per_iteration=per_iter,
-                                 ms_per_iteration=round(step_ms, 4),
-                                 algorithmic_MB=None if by is None else round(by / 1e6, 1),
-                                 achieved_GBs=None if by is None else round(by / (step_ms * 1e-3) / 1e9, 1))
+        kernels = kernel_table(prof, n_sampled, P, R_mean, N, S, args.sample_num)
         if not kernels:                   # experiments with the in-library event timing switched off
             kernels = {"none": dict(avg_ms=0.0, launches=0, ms_per_iteration=0.0, algorithmic_MB=None, achieved_GBs=None)}
-        dom = max(kernels, key=lambda k: kernels[k].get("ms_per_iteration", 0.0))
-        ach = kernels[dom]["achieved_GBs"]
-        tr = pmc_traffic(dom)
-        roofline = dict(bound="hbm", kernel=dom, achieved=ach, peak=HBM_PEAK_GBS, unit="GB/s",
-                        frac=None if ach is None else round(ach / HBM_PEAK_GBS, 4),
-                        traffic=None if tr is None else tr["bytes_corrected"], traffic_detail=tr,
-                        avg_kernel_ms=kernels[dom]["ms_per_iteration"],
-                        note="achieved = SURVEY.md 8(d) algorithmic bytes per launch / HIP-event kernel time; this "
-                             "kernel is VALU/atomic-bound, HBM fraction reported as required")
+        roofline = roofline_of(kernels, "achieved = SURVEY.md 8(d) algorithmic bytes per launch / HIP-event kernel time, "
+                               "measured inside the iteration (kernels of the ordering stream run beside the shading "
+                               "forward, so its time here includes that sharing); the kernel is VALU-bound (`valu`), the "
+                               "HBM fraction is reported as required")
         iters_s = world * args.steps / elapsed
         result = {
             "metric": "train iters/s, synthetic lego-like %dx%d, %d Gaussians (stage-%d hot path)" % (
@@ -510,8 +606,10 @@ def run(args):
                                        "shading fwd/bwd (K=%d) + " % args.sample_num if stage2 else "", S,
                                        P, args.res, args.res, R_mean),
                        "parallelism": "dp%d (views sharded over ranks; bucketed async RCCL all-reduce of per-Gaussian grads)" % world},
-            "roofline": roofline, "kernels": kernels,
+            "roofline": roofline, "kernels": kernels, "spread_iters_per_s": spread,
         }
+        if relight is not None:
+            result["roofline_relight"] = relight.pop("roofline_relight")
         if relight is not None:
             result["relight"] = relight
         if stage2 and world == 1 and not getattr(args, "no_other_configs", False):
@@ -530,9 +628,9 @@ def run(args):
                 result["other_configs"] = {"failed": repr(e)}
         if not args.no_cpu_baseline and world == 1:
             try:
-                result["cpu_baseline"] = cpu_baseline(scene, cams_cpu, S, args.cpu_baseline_seconds)
+                result["cpu_baseline"] = cpu_baseline(scene, cams_cpu, S, args.cpu_baseline_seconds, args.points, args.res)
             except Exception as e:  # the oracle is only a reported baseline; never fail the bench on it
-                result["cpu_baseline"] = {"value": None, "unit": "iters/s", "cores": 1, "kind": "port",
+                result["cpu_baseline"] = {"value": None, "unit": "views/s (rasterize forward)", "cores": None, "kind": "port",
                                           "sample": "failed: %r" % (e,)}
         print(json.dumps(result))
     if world > 1:

@@ -15,7 +15,8 @@ DEV = "cuda"
 
 
 def _ok(name, got, ref, rtol, atol):
-    ok, msg = report(name, got, np.asarray(ref).reshape(tuple(got.shape)), rtol, atol)
+    from tests.helpers import to_np
+    ok, msg = report(name, got, to_np(ref).reshape(tuple(got.shape)), rtol, atol)
     print(msg)
     assert ok, msg
 
