@@ -256,14 +256,24 @@ int r3dg_ssim_backward_pair(void* stream, int width, int height, int channels, c
                             float scale1, float* d_grad_x0, float* d_grad_x1);
 
 /* Stage-1 counterparts (plain 3DGS + normals, gaussian_renderer/render.py:15-130; r3dg_stage2_activate with
- * d_base_raw == NULL provides the activations): features [P,5] = normal(3), depth, depth^2;
- * loss = w_l1 sum|image-gt| + w_normal sum (feat[0:3] - pseudo_normal)^2 + w_opacity sum opacity(1-opacity) with feat as
- * in r3dg_stage2_loss; sums[0..2] += the three unweighted sums; dL_dfeature is [5,HW]. */
+ * d_base_raw == NULL provides the activations): features [P,5] = normal(3), depth, depth^2.
+ * r3dg_stage1_loss = the image-space terms of calculate_loss (gaussian_renderer/render.py:137-223) that script/run_nerf.sh:7-14
+ * enables, values AND gradients in one call, with [normal, depth, depth2] = feature / max(opacity,1e-5) * (n_contrib > 0):
+ *   w_l1 sum|image-gt| + w_mask_entropy sum -(m log o + (1-m) log(1-o)), o = clamp(opacity,1e-6,1-1e-6)      (:156-160)
+ *   + w_normal sum (m normal - m pseudo_normal)^2                                                              (:162-167)
+ *   + w_normal_smooth sum_{c,d} |G_d normal_c| exp(-|G_d gt_c|), G = 3x3 Sobel / 8, replicate padding (kornia 0.6.12
+ *     spatial_gradient, utils/loss_utils.py:104-105)                                                           (:169-173)
+ *   + w_depth_var sum sqrt(max(depth2 - depth^2, 1e-6))                                                        (:199-205)
+ * d_image_mask [HW] may be NULL (all ones); d_edge_scratch [6*HW] floats is required when w_normal_smooth != 0;
+ * d_extra_dL_dimage (may be NULL) is added to dL_dimage (the SSIM gradient).  The weights carry the 1/count of the
+ * reference's means.  sums[0] += L1 sum, [1] += normal sum, [2] += entropy sum, [4] += edge-aware sum, [5] += sqrt-variance
+ * sum (slot 3 is left to r3dg_ssim_forward); dL_dfeature is [5,HW]. */
 int r3dg_stage1_pack_features(void* stream, int P, const float* d_xyz, const float* d_viewmatrix, const float* d_normal,
                               float* d_features);
 int r3dg_stage1_loss(void* stream, int width, int height, const float* d_image, const float* d_opacity,
                      const float* d_feature, const float* d_pseudo_normal, const int32_t* d_n_contrib, const float* d_gt,
-                     float w_l1, float w_normal, float w_opacity, const float* d_extra_dL_dimage, float* d_dL_dimage,
+                     const float* d_image_mask, float w_l1, float w_mask_entropy, float w_normal, float w_normal_smooth,
+                     float w_depth_var, const float* d_extra_dL_dimage, float* d_edge_scratch, float* d_dL_dimage,
                      float* d_dL_dopacity, float* d_dL_dfeature, float* d_sums);
 int r3dg_stage1_activate_backward(void* stream, int P, const float* d_xyz, const float* d_scaling_raw,
                                   const float* d_rotation_raw, const float* d_opacity_raw, const float* d_normal_raw,

@@ -56,7 +56,7 @@ def env_lookup(env, dirs, transform=None):
     x0, y0 = torch.floor(ix), torch.floor(iy)
     wx1, wy1 = ix - x0, iy - y0
     wx0, wy0 = 1 - wx1, 1 - wy1
-    out = torch.zeros(d.shape[0], 3, dtype=env.dtype)
+    out = torch.zeros(d.shape[0], 3, dtype=env.dtype, device=env.device)
     for yy, wy in ((y0, wy0), (y0 + 1, wy1)):
         for xx, wx in ((x0, wx0), (x0 + 1, wx1)):
             ok = (xx >= 0) & (xx <= We - 1) & (yy >= 0) & (yy <= He - 1)
@@ -82,7 +82,7 @@ def ggx_specular(normal, pts2c, pts2l, roughness, fresnel=0.04):
     alpha2 = alpha * alpha
     k = (alpha + 2 * roughness + 1.0) / 8.0
     FMi = ((-5.55473) * VoH - 6.98316) * VoH
-    frac0 = fresnel + (1 - fresnel) * torch.pow(torch.tensor(2.0, dtype=VoH.dtype), FMi)
+    frac0 = fresnel + (1 - fresnel) * torch.pow(torch.tensor(2.0, dtype=VoH.dtype, device=VoH.device), FMi)
     frac = frac0 * alpha2[:, None, :]
     nom0 = NoH * NoH * (alpha2[:, None, :] - 1) + 1
     nom1 = NoV * (1 - k) + k
@@ -117,7 +117,7 @@ def rotation_between_z(vec):
     v1, v2 = -vec[..., 1], vec[..., 0]
     v3 = torch.zeros_like(v1)
     cos_p_1 = (vec[..., 2] + 1).clamp_min(1e-7)
-    R = torch.zeros(vec.shape[:-1] + (3, 3), dtype=vec.dtype)
+    R = torch.zeros(vec.shape[:-1] + (3, 3), dtype=vec.dtype, device=vec.device)
     R[..., 0, 0] = 1 + (-v3 * v3 - v2 * v2) / cos_p_1
     R[..., 0, 1] = -v3 + v1 * v2 / cos_p_1
     R[..., 0, 2] = v2 + v1 * v3 / cos_p_1
@@ -127,13 +127,13 @@ def rotation_between_z(vec):
     R[..., 2, 0] = -v2 + v1 * v3 / cos_p_1
     R[..., 2, 1] = v1 + v2 * v3 / cos_p_1
     R[..., 2, 2] = 1 + (-v2 * v2 - v1 * v1) / cos_p_1
-    return torch.where((vec[..., 2] + 1 > 0)[..., None, None], R, -torch.eye(3, dtype=vec.dtype).expand_as(R))
+    return torch.where((vec[..., 2] + 1 > 0)[..., None, None], R, -torch.eye(3, dtype=vec.dtype, device=vec.device).expand_as(R))
 
 
 def fibonacci_sphere_sampling(normals, sample_num):
     """random_rotate=False variant (the only one the visibility caches use, gaussian_model.py:305-310)."""
     delta = math.pi * (3.0 - math.sqrt(5.0))
-    idx = torch.arange(sample_num, dtype=torch.float32)[None]
+    idx = torch.arange(sample_num, dtype=torch.float32, device=normals.device)[None]
     z = (1 - 2 * idx / (2 * sample_num - 1)).clamp_min(math.sin(10 / 180 * math.pi))
     rad = torch.sqrt(1 - z ** 2)
     theta = delta * idx

@@ -66,7 +66,7 @@ _SIGNATURES = {
     "r3dg_ssim_forward_pair": (_i, [_p, _i, _i, _i] + [_p] * 7),
     "r3dg_ssim_backward_pair": (_i, [_p, _i, _i, _i] + [_p] * 5 + [_f, _f, _p, _p]),
     "r3dg_stage1_pack_features": (_i, [_p, _i, _p, _p, _p, _p]),
-    "r3dg_stage1_loss": (_i, [_p, _i, _i] + [_p] * 6 + [_f, _f, _f] + [_p] * 5),
+    "r3dg_stage1_loss": (_i, [_p, _i, _i] + [_p] * 7 + [_f] * 5 + [_p] * 6),
     "r3dg_stage1_activate_backward": (_i, [_p, _i] + [_p] * 16),
     "r3dg_stage2_env_backward": (_i, [_p, _i, _i, _p, _p, _p, _f, _p, _p]),
     "r3dg_adam_step": (_i, [_p, _i, _p, _f, _f, _f, _i, _f]),

@@ -77,15 +77,10 @@ def render_stage1(params, cam, bg):
     return outs
 
 
-def loss_stage1(outs, gt):
-    num_rendered, n_contrib, color, opacity, depth, feature, normal, xyz, weights, radii = outs
-    mask = (n_contrib > 0)
-    feat = feature / opacity.clamp_min(1e-5) * mask
-    from .train_step import image_loss
-    l1 = image_loss(color, gt)              # (1 - lambda_dssim) L1 + lambda_dssim (1 - SSIM), render.py
-    # normal-consistency and opacity regularisers stand in for the reference's extra loss terms (render.py:150-230)
-    reg = (feat[:3] - normal.detach()).square().mean() + 0.01 * (opacity * (1 - opacity)).mean()
-    return l1 + 0.1 * reg
+def loss_stage1(outs, gt, image_mask=None, weights=None, iteration=0):
+    """The reference's stage-1 objective (gaussian_renderer/render.py:137-223, flags of script/run_nerf.sh:7-14)."""
+    from .train_step import stage1_loss
+    return stage1_loss(outs, gt, image_mask, weights, iteration)
 
 
 def _algorithmic_bytes(stage, P, R, N, S, K=64):

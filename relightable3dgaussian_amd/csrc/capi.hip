@@ -101,10 +101,12 @@ void launch_ssim_backward(hipStream_t s, int W, int H, int C, int n_images, cons
 void launch_adam(hipStream_t s, int n_groups, const r3dg_adam_group* groups, float beta1, float beta2, float eps,
                  int step, float grad_scale);
 void launch_s1_pack(hipStream_t s, int P, const float* xyz, const float* viewmatrix, const float* normal, float* features);
-void launch_s1_loss(hipStream_t s, int HW, const float* image, const float* opacity, const float* feature,
-                    const float* pseudo_normal, const int* n_contrib, const float* gt, float w_l1, float w_normal,
-                    float w_opacity, const float* extra_dimage, float* dL_dimage, float* dL_dopacity, float* dL_dfeature,
-                    float* sums);
+void launch_s1_edge(hipStream_t s, int W, int H, const float* feature, const float* opacity, const int* n_contrib,
+                    const float* gt, float* edge_g, float* sum_out);
+void launch_s1_loss(hipStream_t s, int W, int H, const float* image, const float* opacity, const float* feature,
+                    const float* pseudo_normal, const int* n_contrib, const float* gt, const float* image_mask, float w_l1,
+                    float w_entropy, float w_normal, float w_smooth, float w_var, const float* extra_dimage,
+                    const float* edge_g, float* dL_dimage, float* dL_dopacity, float* dL_dfeature, float* sums);
 void launch_s1_activate_backward(hipStream_t s, int P, const float* xyz, const float* scaling_raw,
                                  const float* rotation_raw, const float* opacity_raw, const float* normal_raw,
                                  const float* viewmatrix, const float* dL_dfeatures, const float* dL_dscales,
@@ -1008,7 +1010,8 @@ int r3dg_stage1_pack_features(void* stream_, int P, const float* xyz, const floa
 
 int r3dg_stage1_loss(void* stream_, int width, int height, const float* image, const float* opacity,
                      const float* feature, const float* pseudo_normal, const int32_t* n_contrib, const float* gt,
-                     float w_l1, float w_normal, float w_opacity, const float* extra_dimage, float* dL_dimage,
+                     const float* image_mask, float w_l1, float w_mask_entropy, float w_normal, float w_normal_smooth,
+                     float w_depth_var, const float* extra_dimage, float* edge_scratch, float* dL_dimage,
                      float* dL_dopacity, float* dL_dfeature, float* sums)
 {
     if (width < 0 || height < 0) return invalid("stage1_loss: bad image size");
@@ -1016,10 +1019,14 @@ int r3dg_stage1_loss(void* stream_, int width, int height, const float* image, c
     if (!image || !opacity || !feature || !pseudo_normal || !n_contrib || !gt || !dL_dimage || !dL_dopacity ||
         !dL_dfeature || !sums)
         return invalid("stage1_loss: null buffer");
+    if (w_normal_smooth != 0.f && !edge_scratch) return invalid("stage1_loss: the normal-smoothness term needs edge_scratch");
     return guarded([&]() -> int {
         StageTimer t((hipStream_t)stream_, ST_S2_LOSS);
-        launch_s1_loss((hipStream_t)stream_, width * height, image, opacity, feature, pseudo_normal, n_contrib, gt, w_l1,
-                       w_normal, w_opacity, extra_dimage, dL_dimage, dL_dopacity, dL_dfeature, sums);
+        if (w_normal_smooth != 0.f)
+            launch_s1_edge((hipStream_t)stream_, width, height, feature, opacity, n_contrib, gt, edge_scratch, sums + 4);
+        launch_s1_loss((hipStream_t)stream_, width, height, image, opacity, feature, pseudo_normal, n_contrib, gt, image_mask,
+                       w_l1, w_mask_entropy, w_normal, w_normal_smooth, w_depth_var, extra_dimage,
+                       w_normal_smooth != 0.f ? edge_scratch : nullptr, dL_dimage, dL_dopacity, dL_dfeature, sums);
         return R3DG_OK;
     });
 }

@@ -354,49 +354,156 @@ s1_pack_features_kernel(int P, const float* __restrict__ xyz, const float* __res
     f[3] = depth; f[4] = depth * depth;
 }
 
-// loss = w_l1 sum|image-gt| + w_normal sum (feat[0:3] - pseudo_normal)^2 + w_opacity sum op(1-op), feat as in s2_loss
+// ---- stage-1 objective (gaussian_renderer/render.py:137-223 with the flags of script/run_nerf.sh:7-14) ---------------------
+//   L = (1-l)*L1(image, gt) [+ l*(1-SSIM): csrc/ssim.hip, gradient arrives in extra_dimage]
+//     + lambda_mask_entropy        * -mean(m log o + (1-m) log(1-o)),  o = clamp(opacity, 1e-6, 1-1e-6)      (:156-160)
+//     + lambda_normal_render_depth * mse(normal*m, pseudo_normal*m)                                           (:162-167)
+//     + lambda_normal_smooth       * first_order_edge_aware_loss(normal, gt)                                  (:169-173)
+//     + lambda_depth_var(iter)     * mean sqrt(max(depth2 - depth^2, 1e-6))                                   (:199-205)
+// with [normal, depth, depth2] = feature / max(opacity, 1e-5) * (n_contrib > 0) (:107-112) and m the view's object mask.
+// first_order_edge_aware_loss (utils/loss_utils.py:104-105) = mean_{c,y,x} sum_{d in {x,y}} |G_d normal_c| exp(-|G_d gt_c|) with
+// G = kornia.filters.spatial_gradient(order=1) of kornia 0.6.12 (readme.md:31-32; the package is not in this image, its
+// published algorithm is restated): 3x3 Sobel cross-correlation, kernels [[-1,0,1],[-2,0,2],[-1,0,1]] and its transpose,
+// normalised by the sum of absolute values (/8), replicate padding.
+// Pass A (s1_edge_kernel): per pixel the six values sign(G_d normal_c) * exp(-|G_d gt_c|) and the loss sum.
+// Pass B (inside s1_loss_kernel): the adjoint of the replicate-padded stencil, gathered (no atomics).
+__device__ __forceinline__ float s1_rendered(const float* __restrict__ feature, const float* __restrict__ opacity,
+                                             const int* __restrict__ n_contrib, size_t HW, int ch, size_t pix)
+{
+    const float opc = fmaxf(opacity[pix], 1e-5f);
+    return n_contrib[pix] > 0 ? feature[(size_t)ch * HW + pix] / opc : 0.f;
+}
+
 __global__ void __launch_bounds__(256)
-s1_loss_kernel(int HW, const float* __restrict__ image, const float* __restrict__ opacity,
+s1_edge_kernel(int W, int H, const float* __restrict__ feature, const float* __restrict__ opacity,
+               const int* __restrict__ n_contrib, const float* __restrict__ gt, float* __restrict__ edge_g /*[3][2][HW]*/,
+               float* __restrict__ sum_out)
+{
+    __shared__ float s_part[4];
+    const size_t HW = (size_t)W * H;
+    float acc = 0.f;
+    for (size_t i = blockIdx.x * 256 + threadIdx.x; i < HW; i += (size_t)gridDim.x * 256) {
+        const int y = (int)(i / W), x = (int)(i % W);
+        const int ys[3] = {y > 0 ? y - 1 : 0, y, y < H - 1 ? y + 1 : H - 1};
+        const int xs[3] = {x > 0 ? x - 1 : 0, x, x < W - 1 ? x + 1 : W - 1};
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+            float n[3][3], g[3][3];
+#pragma unroll
+            for (int a = 0; a < 3; a++)
+#pragma unroll
+                for (int b = 0; b < 3; b++) {
+                    const size_t q = (size_t)ys[a] * W + xs[b];
+                    n[a][b] = s1_rendered(feature, opacity, n_contrib, HW, c, q);
+                    g[a][b] = gt[(size_t)c * HW + q];
+                }
+            const float nx = ((n[0][2] - n[0][0]) + 2.f * (n[1][2] - n[1][0]) + (n[2][2] - n[2][0])) * 0.125f;
+            const float ny = ((n[2][0] - n[0][0]) + 2.f * (n[2][1] - n[0][1]) + (n[2][2] - n[0][2])) * 0.125f;
+            const float gx = ((g[0][2] - g[0][0]) + 2.f * (g[1][2] - g[1][0]) + (g[2][2] - g[2][0])) * 0.125f;
+            const float gy = ((g[2][0] - g[0][0]) + 2.f * (g[2][1] - g[0][1]) + (g[2][2] - g[0][2])) * 0.125f;
+            const float ex = __expf(-fabsf(gx)), ey = __expf(-fabsf(gy));
+            acc += fabsf(nx) * ex + fabsf(ny) * ey;
+            edge_g[(size_t)(2 * c) * HW + i] = signf_(nx) * ex;
+            edge_g[(size_t)(2 * c + 1) * HW + i] = signf_(ny) * ey;
+        }
+    }
+    const float t = block_sum_256(acc, s_part);
+    if (threadIdx.x == 0) atomicAdd(sum_out, t);
+}
+
+// sum_d [clamp(q + d, 0, n-1) == p] * k[d+1]: weight with which position q's replicate-padded 1-D stencil reads position p
+__device__ __forceinline__ float s1_adj1(int q, int p, int n, float km, float k0, float kp)
+{
+    float w = (q == p) ? k0 : 0.f;
+    const int qm = q > 0 ? q - 1 : 0, qp = q < n - 1 ? q + 1 : n - 1;
+    w += (qm == p) ? km : 0.f;
+    w += (qp == p) ? kp : 0.f;
+    return w;
+}
+
+// sums[0] += sum|image-gt|, [1] += sum m^2 (normal - pseudo)^2, [2] += sum -(m log o + (1-m) log(1-o)), [5] += sum sqrt(var)
+// (sums[3] is the SSIM slot, sums[4] the edge-aware sum of s1_edge_kernel); image_mask == nullptr means all ones.
+__global__ void __launch_bounds__(256)
+s1_loss_kernel(int W, int H, const float* __restrict__ image, const float* __restrict__ opacity,
                const float* __restrict__ feature, const float* __restrict__ pseudo_normal,
-               const int* __restrict__ n_contrib, const float* __restrict__ gt, float w_l1, float w_normal,
-               float w_opacity, const float* __restrict__ extra_dimage, float* __restrict__ dL_dimage,
+               const int* __restrict__ n_contrib, const float* __restrict__ gt, const float* __restrict__ image_mask,
+               float w_l1, float w_entropy, float w_normal, float w_smooth, float w_var,
+               const float* __restrict__ extra_dimage, const float* __restrict__ edge_g, float* __restrict__ dL_dimage,
                float* __restrict__ dL_dopacity, float* __restrict__ dL_dfeature, float* __restrict__ sums)
 {
     __shared__ float s_part[4];
-    float s_l1 = 0.f, s_n = 0.f, s_o = 0.f;
-    for (int i = blockIdx.x * 256 + threadIdx.x; i < HW; i += gridDim.x * 256) {
+    const size_t HW = (size_t)W * H;
+    float s_l1 = 0.f, s_n = 0.f, s_e = 0.f, s_v = 0.f;
+    for (size_t i = blockIdx.x * 256 + threadIdx.x; i < HW; i += (size_t)gridDim.x * 256) {
         const float op = opacity[i];
         const bool mask = n_contrib[i] > 0;
         const float opc = fmaxf(op, 1e-5f);
         const float scale = mask ? 1.f / opc : 0.f;
         const float dscale_dop = (mask && op >= 1e-5f) ? -1.f / (opc * opc) : 0.f;
-        float g_op = w_opacity * (1.f - 2.f * op);
-        s_o += op * (1.f - op);
+        const float m = image_mask ? image_mask[i] : 1.f;
+        // mask entropy
+        const float o = fminf(fmaxf(op, 1e-6f), 1.f - 1e-6f);
+        s_e -= m * __logf(o) + (1.f - m) * __logf(1.f - o);
+        float g_op = (op >= 1e-6f && op <= 1.f - 1e-6f) ? -w_entropy * (m / o - (1.f - m) / (1.f - o)) : 0.f;
+        // adjoint of the edge-aware stencil: weights of the (up to) 9 neighbours q whose stencil reads this pixel
+        float dsm[3] = {0.f, 0.f, 0.f};
+        if (edge_g != nullptr && w_smooth != 0.f) {
+            const int y = (int)(i / W), x = (int)(i % W);
+#pragma unroll
+            for (int a = -1; a <= 1; a++) {
+                const int qy = y + a;
+                if (qy < 0 || qy >= H) continue;
+                const float sy = s1_adj1(qy, y, H, 1.f, 2.f, 1.f), dy = s1_adj1(qy, y, H, -1.f, 0.f, 1.f);
+#pragma unroll
+                for (int b = -1; b <= 1; b++) {
+                    const int qx = x + b;
+                    if (qx < 0 || qx >= W) continue;
+                    const float sx = s1_adj1(qx, x, W, 1.f, 2.f, 1.f), dx = s1_adj1(qx, x, W, -1.f, 0.f, 1.f);
+                    const float wx = sy * dx * 0.125f, wy = dy * sx * 0.125f;
+                    const size_t q = (size_t)qy * W + qx;
+#pragma unroll
+                    for (int c = 0; c < 3; c++)
+                        dsm[c] += wx * edge_g[(size_t)(2 * c) * HW + q] + wy * edge_g[(size_t)(2 * c + 1) * HW + q];
+                }
+            }
+        }
 #pragma unroll
         for (int c = 0; c < 3; c++) {
             const float d0 = image[(size_t)c * HW + i] - gt[(size_t)c * HW + i];
             s_l1 += fabsf(d0);
             dL_dimage[(size_t)c * HW + i] = w_l1 * signf_(d0) + (extra_dimage ? extra_dimage[(size_t)c * HW + i] : 0.f);
             const float Fn = feature[(size_t)c * HW + i];
-            const float dn = Fn * scale - pseudo_normal[(size_t)c * HW + i];
+            const float dn = (Fn * scale - pseudo_normal[(size_t)c * HW + i]) * m;
             s_n += dn * dn;
-            const float gn = 2.f * w_normal * dn;
+            const float gn = 2.f * w_normal * dn * m + w_smooth * dsm[c];       // dL / d rendered_normal_c
             dL_dfeature[(size_t)c * HW + i] = gn * scale;
             g_op += gn * Fn * dscale_dop;
         }
+        // depth variance
+        const float F3 = feature[(size_t)3 * HW + i], F4 = feature[(size_t)4 * HW + i];
+        const float D = F3 * scale, D2 = F4 * scale;
+        const float var = D2 - D * D;
+        const float sd = sqrtf(fmaxf(var, 1e-6f));
+        s_v += sd;
+        const float dvar = var >= 1e-6f ? w_var * 0.5f / sd : 0.f;
+        const float gD = -2.f * D * dvar;
+        dL_dfeature[(size_t)3 * HW + i] = gD * scale;
+        dL_dfeature[(size_t)4 * HW + i] = dvar * scale;
+        g_op += (gD * F3 + dvar * F4) * dscale_dop;
         dL_dopacity[i] = g_op;
-        dL_dfeature[(size_t)3 * HW + i] = 0.f;
-        dL_dfeature[(size_t)4 * HW + i] = 0.f;
     }
     const float t0 = block_sum_256(s_l1, s_part);
     __syncthreads();
     const float t1 = block_sum_256(s_n, s_part);
     __syncthreads();
-    const float t2 = block_sum_256(s_o, s_part);
+    const float t2 = block_sum_256(s_e, s_part);
+    __syncthreads();
+    const float t3 = block_sum_256(s_v, s_part);
     if (threadIdx.x == 0) {
         atomicAdd(sums + 0, t0);
         atomicAdd(sums + 1, t1);
         atomicAdd(sums + 2, t2);
+        atomicAdd(sums + 5, t3);
     }
 }
 
@@ -579,14 +686,24 @@ void launch_s1_pack(hipStream_t s, int P, const float* xyz, const float* viewmat
     check_launch(s, false, "s1_pack_features_kernel");
 }
 
-void launch_s1_loss(hipStream_t s, int HW, const float* image, const float* opacity, const float* feature,
-                    const float* pseudo_normal, const int* n_contrib, const float* gt, float w_l1, float w_normal,
-                    float w_opacity, const float* extra_dimage, float* dL_dimage, float* dL_dopacity, float* dL_dfeature,
-                    float* sums)
+void launch_s1_edge(hipStream_t s, int W, int H, const float* feature, const float* opacity, const int* n_contrib,
+                    const float* gt, float* edge_g, float* sum_out)
 {
-    s1_loss_kernel<<<min((HW + 255) / 256, 768), 256, 0, s>>>(HW, image, opacity, feature, pseudo_normal, n_contrib, gt,
-                                                            w_l1, w_normal, w_opacity, extra_dimage, dL_dimage,
-                                                            dL_dopacity, dL_dfeature, sums);
+    const long long HW = (long long)W * H;
+    s1_edge_kernel<<<(int)min((HW + 255) / 256, (long long)4096), 256, 0, s>>>(W, H, feature, opacity, n_contrib, gt, edge_g,
+                                                                           sum_out);
+    check_launch(s, false, "s1_edge_kernel");
+}
+
+void launch_s1_loss(hipStream_t s, int W, int H, const float* image, const float* opacity, const float* feature,
+                    const float* pseudo_normal, const int* n_contrib, const float* gt, const float* image_mask, float w_l1,
+                    float w_entropy, float w_normal, float w_smooth, float w_var, const float* extra_dimage,
+                    const float* edge_g, float* dL_dimage, float* dL_dopacity, float* dL_dfeature, float* sums)
+{
+    const long long HW = (long long)W * H;
+    s1_loss_kernel<<<(int)min((HW + 255) / 256, (long long)2048), 256, 0, s>>>(
+        W, H, image, opacity, feature, pseudo_normal, n_contrib, gt, image_mask, w_l1, w_entropy, w_normal, w_smooth, w_var,
+        extra_dimage, edge_g, dL_dimage, dL_dopacity, dL_dfeature, sums);
     check_launch(s, false, "s1_loss_kernel");
 }
 

@@ -103,7 +103,10 @@ class FusedStage2Step:
         self.P = P = self.xyz.shape[0]
         self.K = sample_num
         self.M = self.shs.shape[1]
-        self.w = dict(l1=1.0, pbr=1.0, normal=0.01, light=0.01, env_smooth=0.01)
+        # script/run_nerf.sh:20-39 (stage 2): lambda_pbr 1, lambda_light 0.01, lambda_env_smooth 0.01; the command does not
+        # pass --lambda_normal_render_depth, so that term is off (arguments/__init__.py:115) -- opt in with
+        # loss_weights={"normal": 0.01}
+        self.w = dict(l1=1.0, pbr=1.0, normal=0.0, light=0.01, env_smooth=0.01)
         if loss_weights:
             self.w.update(loss_weights)
         # activations / intermediates (persistent, overwritten every step)
@@ -267,7 +270,8 @@ class FusedStage2Step:
                 bg, self.xyz, self.features, radii, empty, self.a_scales, self.a_rot, 1.0, empty, vm,
                 cam.full_proj_transform, cam.tanfovx, cam.tanfovy, g[0:3], g[3:4], self._zero_depth_grad, g[4:20], self.shs, 3,
                 campos, geom, R, binning, img, True, False, dL_dsh_out=self.grads["shs"], geometry_stream=self._side,
-                active_features=(2, 3, 4, 5, 6, 7))      # r3dg_stage2_loss only reads the pbr and normal maps
+                # r3dg_stage2_loss only reads the pbr maps and -- when that term is on -- the normal maps
+                active_features=(2, 3, 4, 5, 6, 7) if self.w["normal"] != 0.0 else (2, 3, 4))
             dL_dmeans2D, _dcol, dL_dopacity, dL_dmeans3D, dL_dfeatures, _dcov, _dsh, dL_dscales, dL_drot = bw
             handle_a = None
             if self._side is None:
@@ -377,12 +381,19 @@ class FusedStage1Step:
     bench_core.render_stage1 + loss_stage1 + torch.optim.Adam (the parity target, tests/test_fused_step_gpu.py);
     single-bucket gradient all-reduce under data parallelism."""
 
-    def __init__(self, params, lr=1e-4, lr_rest_scale=1.0, process_group=None, lrs=None):
+    def __init__(self, params, lr=1e-4, lr_rest_scale=1.0, process_group=None, lrs=None, loss_weights=None):
         """`lrs`: optional per-group learning rates {xyz, normal, scaling, rotation, opacity, shs, shs_rest} as in
         GaussianModel.training_setup (gaussian_model.py:465-472); missing names use `lr` (`lr * lr_rest_scale` for the
-        non-dc SH columns)."""
+        non-dc SH columns).  `loss_weights`: overrides of train_step.STAGE1_WEIGHTS (the lambdas of script/run_nerf.sh:7-14).
+        `self.iteration` (the reference's 1-based iteration, advanced by __call__) drives the depth-variance schedule
+        (render.py:202)."""
+        from .train_step import STAGE1_WEIGHTS
         dev = params.xyz.device
         self.dev = dev
+        self.w = dict(STAGE1_WEIGHTS)
+        if loss_weights:
+            self.w.update(loss_weights)
+        self.iteration = 0
         d = lambda t: t.detach().clone().contiguous()
         self.xyz, self.normal = d(params.xyz), d(params.normal)
         self.scaling, self.rotation, self.opacity = d(params.scaling), d(params.rotation), d(params.opacity)
@@ -412,14 +423,15 @@ class FusedStage1Step:
         self.a_scales, self.a_rot = torch.empty(P, 3, **f), torch.empty(P, 4, **f)
         self.a_opacity, self.a_normal = torch.empty(P, 1, **f), torch.empty(P, 3, **f)
         self.features = torch.empty(P, 5, **f)
-        self.sums = torch.zeros(4, **f)          # l1, normal mse, opacity reg, SSIM(image)
+        self.sums = torch.zeros(6, **f)          # l1, normal mse, mask entropy, SSIM(image), edge-aware normal, sqrt depth var
         names = ("shs", "xyz", "normal", "scaling", "rotation", "opacity")
         sizes = {k: getattr(self, k).numel() for k in names}
-        self.grad_flat = torch.zeros(sum(sizes.values()), **f)
+        pad4 = lambda n: (n + 3) // 4 * 4         # every group starts on a 16-byte boundary (float4 accesses in the Adam kernel)
+        self.grad_flat = torch.zeros(sum(pad4(v) for v in sizes.values()), **f)
         self.grads, o = {}, 0
         for k in names:
             self.grads[k] = self.grad_flat[o:o + sizes[k]].view_as(getattr(self, k))
-            o += sizes[k]
+            o += pad4(sizes[k])
         self.last_outs = None
 
     # ---- densification (train.py:158-175; kernels in csrc/densify.hip, host mirror densify.py) ----------------------
@@ -488,7 +500,15 @@ class FusedStage1Step:
     features_dc = property(lambda self: self.shs[:, :1])
     features_rest = property(lambda self: self.shs[:, 1:])
 
-    def forward_backward(self, cam, bg, gt):
+    def _weights(self, N):
+        """The five weights of r3dg_stage1_loss / loss(), each already divided by the element count of its mean."""
+        from .train_step import depth_var_weight
+        w = self.w
+        return ((1.0 - LAMBDA_DSSIM) * w["l1"] / (3.0 * N), w["mask_entropy"] / N, w["normal_render_depth"] / (3.0 * N),
+                w["normal_smooth"] / (3.0 * N), depth_var_weight(w["depth_var"], self.iteration) / N)
+
+    def forward_backward(self, cam, bg, gt, image_mask=None):
+        """`image_mask` [1,H,W] (the view's object mask, scene/cameras.py image_mask; None = all ones)."""
         L = _lib.lib()
         P, dev = self.P, self.dev
         H, W = cam.image_height, cam.image_width
@@ -513,8 +533,8 @@ class FusedStage1Step:
             self.sums.zero_()
             fw = pending.finish()
             R, n_contrib, image, opacity, depth, feature, pseudo_normal, sxyz, weights, radii, geom, binning, img = fw
-            # dL_dimage 3 | dL_dopacity 1 | dL_dfeature 5 | SSIM partials 9 | SSIM gradient 3
-            g = torch.empty((21, H, W), dtype=torch.float32, device=dev)
+            # dL_dimage 3 | dL_dopacity 1 | dL_dfeature 5 | SSIM partials 9 | SSIM gradient 3 | edge-aware scratch 6
+            g = torch.empty((27, H, W), dtype=torch.float32, device=dev)
             if self._zero_depth_grad is None or self._zero_depth_grad.shape[-2:] != (H, W):
                 self._zero_depth_grad = torch.zeros((1, H, W), dtype=torch.float32, device=dev)
             gt_c = gt.contiguous()
@@ -522,17 +542,20 @@ class FusedStage1Step:
             _lib.check(L.r3dg_ssim_forward(stream(), W, H, 3, image.data_ptr(), gt_c.data_ptr(), g[9:18].data_ptr(),
                                            self.sums[3:].data_ptr()), "ssim_forward")
             _lib.check(L.r3dg_ssim_backward(stream(), W, H, 3, image.data_ptr(), gt_c.data_ptr(), g[9:18].data_ptr(),
-                                            -lam / (3.0 * N), g[18:21].data_ptr()), "ssim_backward")
+                                            -lam * self.w["l1"] / (3.0 * N), g[18:21].data_ptr()), "ssim_backward")
+            w_l1, w_ent, w_nrm, w_smooth, w_var = self._weights(N)
+            mask_c = None if image_mask is None else image_mask.contiguous()
             _lib.check(L.r3dg_stage1_loss(
                 stream(), W, H, image.data_ptr(), opacity.data_ptr(), feature.data_ptr(), pseudo_normal.data_ptr(),
-                n_contrib.data_ptr(), gt_c.data_ptr(), (1.0 - lam) / (3.0 * N), 0.1 / (3.0 * N), 0.001 / N,
-                g[18:21].data_ptr(), g[0:3].data_ptr(), g[3:4].data_ptr(), g[4:9].data_ptr(), self.sums.data_ptr()),
-                "stage1_loss")
+                n_contrib.data_ptr(), gt_c.data_ptr(), _lib.ptr(mask_c), w_l1, w_ent, w_nrm, w_smooth, w_var,
+                g[18:21].data_ptr(), g[21:27].data_ptr(), g[0:3].data_ptr(), g[3:4].data_ptr(), g[4:9].data_ptr(),
+                self.sums.data_ptr()), "stage1_loss")
             bw = rasterizer_ops.rasterize_gaussians_backward(
                 bg, self.xyz, self.features, radii, empty, self.a_scales, self.a_rot, 1.0, empty, vm,
                 cam.full_proj_transform, cam.tanfovx, cam.tanfovy, g[0:3], g[3:4], self._zero_depth_grad, g[4:9],
                 self.shs, 3, campos, geom, R, binning, img, True, False, dL_dsh_out=self.grads["shs"],
-                active_features=(0, 1, 2))               # r3dg_stage1_loss only reads the normal maps
+                # the normal maps carry the two normal terms, depth / depth^2 the variance term
+                active_features=(0, 1, 2, 3, 4) if w_var != 0.0 else (0, 1, 2))
             dL_dmeans2D, _dcol, dL_dopacity, dL_dmeans3D, dL_dfeatures, _dcov, _dsh, dL_dscales, dL_drot = bw
             gr = self.grads
             _lib.check(L.r3dg_stage1_activate_backward(
@@ -554,8 +577,9 @@ class FusedStage1Step:
     def loss(self):
         N = self._N
         lam = LAMBDA_DSSIM
-        w = torch.tensor([(1.0 - lam) / (3.0 * N), 0.1 / (3.0 * N), 0.001 / N, -lam / (3.0 * N)], device=self.dev)
-        return (self.sums * w).sum() + lam
+        w_l1, w_ent, w_nrm, w_smooth, w_var = self._weights(N)
+        w = torch.tensor([w_l1, w_nrm, w_ent, -lam * self.w["l1"] / (3.0 * N), w_smooth, w_var], device=self.dev)
+        return (self.sums * w).sum() + lam * self.w["l1"]
 
     def optimizer_step(self):
         self._drain()
@@ -564,7 +588,8 @@ class FusedStage1Step:
     def flush(self):
         pass
 
-    def __call__(self, cam, bg, gt):
-        outs = self.forward_backward(cam, bg, gt)
+    def __call__(self, cam, bg, gt, image_mask=None):
+        self.iteration += 1
+        outs = self.forward_backward(cam, bg, gt, image_mask)
         self.optimizer_step()
         return outs

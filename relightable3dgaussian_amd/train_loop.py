@@ -69,16 +69,19 @@ def create_from_points(points, colors, normals=None, device="cuda"):
 
 
 def train_stage1(init, cameras, images, background, extent, schedule=None, iterations=None, seed=0,
-                 white_background=True, process_group=None, on_iteration=None):
+                 white_background=True, process_group=None, on_iteration=None, masks=None, loss_weights=None):
     """Runs `iterations` fused stage-1 iterations over the (camera, image) pairs in round-robin order (the reference
     draws a random permutation, train.py:115-119; the order is the caller's) with the reference's densification
     schedule.  Returns (FusedStage1Step, history) where history lists (iteration, event, rows) for every
-    densify / reset."""
+    densify / reset.  The objective is the reference's stage-1 loss with the lambdas of script/run_nerf.sh:7-14
+    (train_step.STAGE1_WEIGHTS; `loss_weights` overrides them); `masks[v]` [1,H,W] is view v's object mask
+    (Camera.image_mask; None = all ones)."""
     sch = schedule or Schedule()
     n_iter = sch.iterations if iterations is None else iterations
     step = FusedStage1Step(init, lr=sch.sh_lr, lr_rest_scale=1.0 / 20.0, process_group=process_group,
                            lrs=dict(xyz=sch.position_lr_init * extent, normal=sch.normal_lr, scaling=sch.scaling_lr,
-                                    rotation=sch.rotation_lr, opacity=sch.opacity_lr, shs=sch.sh_lr))
+                                    rotation=sch.rotation_lr, opacity=sch.opacity_lr, shs=sch.sh_lr),
+                           loss_weights=loss_weights)
     step.enable_densification()
     gen = torch.Generator(device=step.dev).manual_seed(seed)
     history = []
@@ -91,7 +94,8 @@ def train_stage1(init, cameras, images, background, extent, schedule=None, itera
         collecting = it < sch.densify_until_iter
         if not collecting and step.stats is not None:
             step.stats = None                                                # train.py:160: statistics only while densifying
-        step.forward_backward(cameras[v], background, images[v])
+        step.iteration = it                                                  # depth-variance schedule, render.py:202
+        step.forward_backward(cameras[v], background, images[v], None if masks is None else masks[v])
         if collecting:
             if it > sch.densify_from_iter and it % sch.densification_interval == 0:
                 size_threshold = 20 if it > sch.opacity_reset_interval else None

@@ -118,10 +118,67 @@ def tv_loss(x):
     return (x[..., 1:, :] - x[..., :-1, :]).square().mean() + (x[..., :, 1:] - x[..., :, :-1]).square().mean()
 
 
+def spatial_gradient(x):
+    """kornia.filters.spatial_gradient(x[B,C,H,W], mode='sobel', order=1, normalized=True) of kornia 0.6.12 (the version
+    readme.md:31-32 pins; the package is not in this image, so its published algorithm is restated): cross-correlation
+    with the 3x3 Sobel kernel [[-1,0,1],[-2,0,2],[-1,0,1]] (x) and its transpose (y), each divided by the sum of its
+    absolute values (8), on a replicate-padded input -> [B,C,2,H,W]."""
+    b, c, h, w = x.shape
+    kx = torch.tensor([[-1.0, 0.0, 1.0], [-2.0, 0.0, 2.0], [-1.0, 0.0, 1.0]], dtype=x.dtype, device=x.device) / 8.0
+    k = torch.stack([kx, kx.t()])[:, None]
+    out = F.conv2d(F.pad(x.reshape(b * c, 1, h, w), (1, 1, 1, 1), mode="replicate"), k)
+    return out.reshape(b, c, 2, h, w)
+
+
+def first_order_edge_aware_loss(data, img):
+    """utils/loss_utils.py:104-105."""
+    return (spatial_gradient(data[None])[0].abs() * torch.exp(-spatial_gradient(img[None])[0].abs())).sum(1).mean()
+
+
+# script/run_nerf.sh:7-14 (stage 1): --lambda_normal_render_depth 0.01 --lambda_normal_smooth 0.01 --lambda_mask_entropy 0.1
+# --lambda_depth_var 1e-2; lambda_dssim 0.2 (arguments/__init__.py:125)
+STAGE1_WEIGHTS = dict(l1=1.0, mask_entropy=0.1, normal_render_depth=0.01, normal_smooth=0.01, depth_var=1e-2)
+
+
+def depth_var_weight(lambda_depth_var, iteration):
+    """render.py:202: lambda_depth_var * min(10^(iteration/5000), 100)."""
+    return lambda_depth_var * min(math.pow(10, iteration / 5000), 100)
+
+
+def stage1_loss(outs, gt, image_mask=None, weights=None, iteration=0):
+    """calculate_loss of gaussian_renderer/render.py:137-223 on the rasterizer's 10 public outputs (render_view :107-115):
+    the parity target of fused_step.FusedStage1Step (plain PyTorch, autograd)."""
+    w = dict(STAGE1_WEIGHTS)
+    if weights:
+        w.update(weights)
+    num_rendered, n_contrib, image, opacity, depth, feature, pseudo_normal, xyz, weights_, radii = outs
+    mask = (n_contrib > 0)
+    feat = feature / opacity.clamp_min(1e-5) * mask
+    normal, r_depth, r_depth2 = feat[:3], feat[3:4], feat[4:5]
+    m = torch.ones_like(opacity) if image_mask is None else image_mask
+    loss = w["l1"] * image_loss(image, gt)
+    if w["mask_entropy"] > 0:
+        o = opacity.clamp(1e-6, 1 - 1e-6)
+        loss = loss + w["mask_entropy"] * -(m * torch.log(o) + (1 - m) * torch.log(1 - o)).mean()
+    if w["normal_render_depth"] > 0:
+        loss = loss + w["normal_render_depth"] * F.mse_loss(normal * m, pseudo_normal.detach() * m)
+    if w["normal_smooth"] > 0:
+        loss = loss + w["normal_smooth"] * first_order_edge_aware_loss(normal, gt)
+    if w["depth_var"] > 0:
+        var = r_depth2 - r_depth.square()
+        loss = loss + depth_var_weight(w["depth_var"], iteration) * var.clamp_min(1e-6).sqrt().mean()
+    return loss
+
+
 class Stage2Step:
-    def __init__(self, params, scene, device, sample_num):
+    def __init__(self, params, scene, device, sample_num, loss_weights=None):
+        """`loss_weights`: as fused_step.FusedStage2Step (defaults = script/run_nerf.sh:20-39, i.e. the
+        normal_render_depth term off)."""
         self.p = params
         self.K = sample_num
+        self.w = dict(l1=1.0, pbr=1.0, normal=0.0, light=0.01, env_smooth=0.01)
+        if loss_weights:
+            self.w.update(loss_weights)
         with torch.no_grad():
             self.visibility, self.incident_dirs, self.incident_areas, self.tracer = update_visibility(
                 params.xyz.detach(), params.get_scaling().detach(), params.get_rotation().detach(),
@@ -159,11 +216,13 @@ class Stage2Step:
         r_depth, r_depth2, r_pbr, r_normal, r_base, r_rough, r_diffuse, r_vis = feat.split([1, 1, 3, 3, 3, 1, 3, 1], 0)
         pbr_img = r_pbr * opacity + (1 - opacity) * bg[:, None, None]
         pbr_srgb = rgb_to_srgb(pbr_img)
-        loss = image_loss(image, gt) + 1.0 * image_loss(pbr_srgb, gt)          # L1/SSIM mix on both images, lambda_pbr 1
-        loss = loss + 0.01 * F.mse_loss(r_normal, pseudo_normal.detach())                            # normal_render_depth
+        w = self.w
+        loss = w["l1"] * image_loss(image, gt) + w["pbr"] * image_loss(pbr_srgb, gt)      # L1/SSIM mix on both images
+        if w["normal"] != 0.0:
+            loss = loss + w["normal"] * F.mse_loss(r_normal, pseudo_normal.detach())                 # normal_render_depth
         mean_light = diffuse_light.mean(-1, keepdim=True).expand_as(diffuse_light)
-        loss = loss + 0.01 * F.l1_loss(diffuse_light, mean_light)                                    # lambda_light
-        loss = loss + 0.01 * tv_loss(env.permute(2, 0, 1))                                           # lambda_env_smooth
+        loss = loss + w["light"] * F.l1_loss(diffuse_light, mean_light)                              # lambda_light
+        loss = loss + w["env_smooth"] * tv_loss(env.permute(2, 0, 1))                                # lambda_env_smooth
         return loss, outs
 
     # --- roofline bookkeeping for bench.py (live model fwd (260+16K) B, bwd (476+16K) B per Gaussian)

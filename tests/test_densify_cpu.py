@@ -109,7 +109,7 @@ def test_training_loop_follows_the_reference_schedule(monkeypatch):
     class FakeStep:
         _opt_order = ("xyz", "normal")
 
-        def __init__(self, init, lr, lr_rest_scale, process_group, lrs):
+        def __init__(self, init, lr, lr_rest_scale, process_group, lrs, loss_weights=None):
             self.dev, self.P, self.stats, self.lrs = torch.device("cpu"), 10, None, lrs
             self.opt = types.SimpleNamespace(groups=[dict(lr=lrs["xyz"]), dict(lr=lrs["normal"])])
             self.xyz_lrs = []
@@ -117,7 +117,7 @@ def test_training_loop_follows_the_reference_schedule(monkeypatch):
         def enable_densification(self):
             self.stats = object()
 
-        def forward_backward(self, cam, bg, gt):
+        def forward_backward(self, cam, bg, gt, image_mask=None):
             log.append(("fb", cam, self.stats is not None))
             self.xyz_lrs.append(self.opt.groups[0]["lr"])
 

@@ -44,7 +44,7 @@ def _worker(rank, world, port, out_dir):
     dev = torch.device("cuda", 0)
     torch.cuda.set_device(dev)
     params, cams, bg, gts, K, FusedStage2Step = _make(dev)
-    step = FusedStage2Step(params, K, lr=1e-3)
+    step = FusedStage2Step(params, K, lr=1e-3, loss_weights={"normal": 0.01})     # every parameter group gets a gradient
     assert step.world == 2
     step.forward_backward(cams[rank], bg, gts[rank])
     step.optimizer_step()                    # waits for buckets A and C; the incident-light bucket B stays in flight
@@ -71,7 +71,7 @@ def test_fused_step_two_ranks(tmp_path):
     # single process: mean of the two cameras' gradients
     dev = torch.device("cuda", 0)
     params, cams, bg, gts, K, FusedStage2Step = _make(dev)
-    single = FusedStage2Step(params, K, lr=1e-3)
+    single = FusedStage2Step(params, K, lr=1e-3, loss_weights={"normal": 0.01})
     # the ranks traced half of the ray bundles each and all-gathered them (train_step.update_visibility)
     assert torch.equal(r0["visibility"], single.visibility.cpu()) and torch.equal(r1["visibility"], r0["visibility"])
     acc = None

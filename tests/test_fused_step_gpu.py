@@ -12,7 +12,7 @@ pytestmark = pytest.mark.gpu
 DEV = "cuda"
 
 
-def _setup(P=4000, res=160, K=8, seed=3):
+def _setup(P=4000, res=160, K=8, seed=3, weights=None):
     from relightable3dgaussian_amd import synthetic as syn
     from relightable3dgaussian_amd.bench_core import GaussianParams, render_stage1
     from relightable3dgaussian_amd.train_step import Stage2Step
@@ -26,15 +26,18 @@ def _setup(P=4000, res=160, K=8, seed=3):
         teacher = GaussianParams(syn.make_scene(P=P, seed=seed, stage2=False, scale_log_mean=-3.2), DEV, False)
         teacher.features_dc.add_(0.2 * torch.randn_like(teacher.features_dc))
         gt = render_stage1(teacher, cam, bg)[2].clone()
-    ref = Stage2Step(params, scene, DEV, K)
-    fused = FusedStage2Step(params, K)
+    ref = Stage2Step(params, scene, DEV, K, loss_weights=weights)
+    fused = FusedStage2Step(params, K, loss_weights=weights)
     # identical visibility caches (the BVH inputs differ in the last bits between the two activation paths)
     fused.visibility, fused.incident_dirs, fused.incident_areas = ref.visibility, ref.incident_dirs, ref.incident_areas
     return params, ref, fused, cam, bg, gt
 
 
-def test_fused_forward_backward_matches_autograd():
-    params, ref, fused, cam, bg, gt = _setup()
+# default = the objective of script/run_nerf.sh:20-39 (only the render and pbr maps carry a loss: 3 active feature channels);
+# {"normal": 0.01} adds the normal_render_depth term (6 active channels)
+@pytest.mark.parametrize("weights", [None, {"normal": 0.01}], ids=["run_nerf_stage2", "with_normal_term"])
+def test_fused_forward_backward_matches_autograd(weights):
+    params, ref, fused, cam, bg, gt = _setup(weights=weights)
     loss_ref, outs_ref = ref(cam, bg, gt)
     loss_ref.backward()
     outs = fused.forward_backward(cam, bg, gt)
@@ -172,8 +175,13 @@ def test_fused_training_tracks_autograd_training_psnr():
     assert min(pb_db) > first - 1.0
 
 
-def test_fused_stage1_matches_autograd():
-    """Stage-1 fused iteration vs bench_core.render_stage1 + loss_stage1 under autograd."""
+@pytest.mark.parametrize("with_mask,iteration,weights", [(False, 0, None), (True, 7000, None),
+                                                         (True, 3000, dict(depth_var=0.0, normal_smooth=0.05))],
+                         ids=["run_nerf_stage1", "object_mask_iter7000", "no_depth_var"])
+def test_fused_stage1_matches_autograd(with_mask, iteration, weights):
+    """Stage-1 fused iteration vs bench_core.render_stage1 + train_step.stage1_loss (the reference's calculate_loss,
+    render.py:137-223, restated in PyTorch) under autograd: L1+SSIM, mask entropy, normal_render_depth, edge-aware normal
+    smoothness (Sobel stencil and its adjoint), depth variance with its iteration schedule."""
     from relightable3dgaussian_amd import synthetic as syn
     from relightable3dgaussian_amd.bench_core import GaussianParams, render_stage1, loss_stage1
     from relightable3dgaussian_amd.fused_step import FusedStage1Step
@@ -187,11 +195,16 @@ def test_fused_stage1_matches_autograd():
         teacher = GaussianParams(syn.make_scene(P=P, seed=4, stage2=False, scale_log_mean=-3.2), DEV, False)
         teacher.features_dc.add_(0.2 * torch.randn_like(teacher.features_dc))
         gt = render_stage1(teacher, cam, bg)[2].clone()
+    mask = None
+    if with_mask:                      # object mask with a soft edge (the datasets' alpha channel is not binary)
+        yy, xx = torch.meshgrid(torch.linspace(-1, 1, res, device=DEV), torch.linspace(-1, 1, res, device=DEV), indexing="ij")
+        mask = (1.2 - 2.0 * (xx * xx + yy * yy).sqrt()).clamp(0, 1)[None].contiguous()
     outs_ref = render_stage1(params, cam, bg)
-    loss_ref = loss_stage1(outs_ref, gt)
+    loss_ref = loss_stage1(outs_ref, gt, mask, weights, iteration)
     loss_ref.backward()
-    fused = FusedStage1Step(params)
-    outs = fused.forward_backward(cam, bg, gt)
+    fused = FusedStage1Step(params, loss_weights=weights)
+    fused.iteration = iteration
+    outs = fused.forward_backward(cam, bg, gt, mask)
     torch.cuda.synchronize()
     assert outs[0] == outs_ref[0]
     msgs, ok_all = [], True
@@ -217,7 +230,8 @@ def test_fused_stage1_matches_autograd():
     assert ok_all, "\n".join(msgs)
     l0 = float(fused.loss())
     for _ in range(5):
-        fused(cam, bg, gt)
+        fused.forward_backward(cam, bg, gt, mask)
+        fused.optimizer_step()
     assert float(fused.loss()) < l0
 
 
