@@ -155,6 +155,20 @@ int r3dg_shade_forward(void* stream, int P, int K, int M, const float* d_base_co
                        const float* d_normals, const float* d_viewdirs, const float* d_incidents, const float* d_env,
                        int He, int We, const float* d_env_transform, const float* d_visibility,
                        const float* d_incident_dirs, const float* d_incident_areas, float* d_out);
+/* The same forward with two optional savings for callers that own the sample caches (fused iteration, relight renderer):
+ *   d_taps [P*K*3] uint32: the lat-long lookup of every cached direction (texel corner + two bilinear weights, 12 bytes per
+ *     sample), built ONCE per visibility update by r3dg_shade_build_taps for the SAME incident_dirs, env size and
+ *     env_transform -- the directions are frozen between updates (gaussian_model.py:312-342), so acos/atan2 need not be
+ *     re-evaluated per iteration; NULL = evaluate the lookup in the kernel;
+ *   train_outputs_only != 0: write only pbr (out[:,0:3]), diffuse_light (out[:,3:6]) and the mean visibility (out[:,18]),
+ *     the columns the training feature row reads (neilf.py:120-122); the other 12 columns are left untouched. */
+int r3dg_shade_forward_cached(void* stream, int P, int K, int M, const float* d_base_color, const float* d_roughness,
+                              const float* d_normals, const float* d_viewdirs, const float* d_incidents,
+                              const float* d_env, int He, int We, const float* d_env_transform,
+                              const float* d_visibility, const float* d_incident_dirs, const float* d_incident_areas,
+                              const uint32_t* d_taps, int train_outputs_only, float* d_out);
+int r3dg_shade_build_taps(void* stream, int64_t num_samples, const float* d_incident_dirs, const float* d_env_transform,
+                          int He, int We, uint32_t* d_taps);
 int r3dg_shade_backward(void* stream, int P, int K, int M, const float* d_base_color, const float* d_roughness,
                         const float* d_normals, const float* d_viewdirs, const float* d_incidents, const float* d_env,
                         int He, int We, const float* d_env_transform, const float* d_visibility,
@@ -435,6 +449,9 @@ int r3dg_set_tuning4(int tile_binning);
 int r3dg_set_tuning5(int stage_sh_rows);
 /* r3dg_set_tuning6: persistent workgroups per CU of the shading forward kernel (1..8; its 162 VGPRs allow 3 per CU). */
 int r3dg_set_tuning6(int shade_forward_blocks_per_cu);
+/* r3dg_set_tuning7: shading forward formulation: 1 (default) = row kernels (one wave per Gaussian, lane = sample, per-Gaussian
+ * records through scalar loads), 0 = the round-1 kernel (16 lanes per Gaussian).  Same results within fp32 rounding. */
+int r3dg_set_tuning7(int shade_forward_rows);
 int r3dg_selftest_transpose_reduce(void* stream, int N, int dpp, const float* d_in, float* d_out, int* d_chan,
                                    int* d_owner);
 

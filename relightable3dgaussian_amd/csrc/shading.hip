@@ -463,6 +463,225 @@ shade_forward_kernel(int P, int K, int M, const float* __restrict__ base_color, 
     }
 }
 
+// =====================================================================================================================
+// Forward, second formulation ("row" kernels): ONE WAVE PER GAUSSIAN, lane = sample.
+//   * everything that is uniform per Gaussian -- the 48 SH coefficients and the view/normal/roughness-derived factors of
+//     the GGX term -- is precomputed into a 64-float record by shade_prepare_kernel (thread per Gaussian) and arrives in
+//     SGPRs through scalar loads (the Gaussian index is wave-uniform): no LDS staging, no per-sample ds_read of the
+//     coefficients (the 16-lane kernel above issues 12 ds_read_b128 per SAMPLE), no redundant per-lane setup; the 48
+//     local-light FMAs take their coefficient operand straight from an SGPR;
+//   * the K samples of the Gaussian are one coalesced row per array (lane k reads sample kb+k);
+//   * the lat-long lookup of a cached direction never changes between visibility updates, so its result -- texel corner
+//     and the two bilinear weights, 12 bytes per sample -- can be cached by the caller (r3dg_shade_build_taps, one pass
+//     per visibility update): acos / atan2 / floor, a fifth of the 16-lane kernel's instructions, disappear;
+//   * the training iteration reads only pbr, diffuse_light and the mean visibility of the 19 outputs (neilf.py:120-122):
+//     NOUT = 7 accumulates and reduces just those;
+//   * the environment texture is staged as one float4 per texel: a tap is ONE ds_read_b128 instead of three ds_read_b32.
+// Measured (P=300k): K=64 0.27 -> see DESIGN.md; K=384 (relight) 2.4 ms -> see DESIGN.md.
+// =====================================================================================================================
+constexpr int REC = 64;      // floats per Gaussian record
+// record layout: 0..47 SH coefficients (i*3+c, zero padded beyond M), 48..50 albedo, 51 roughness, 52..54 normal (as given),
+// 55..57 V = normalize(viewdir), 58..60 N = normalize(normal) * sign(N.V), 61 NoV (clamped), 62 alpha^2, 63 k
+__global__ void __launch_bounds__(256)
+shade_prepare_kernel(int P, int M, const float* __restrict__ base_color, const float* __restrict__ roughness,
+                     const float* __restrict__ normals, const float* __restrict__ viewdirs,
+                     const float* __restrict__ incidents, float* __restrict__ rec)
+{
+    const int g = blockIdx.x * 256 + threadIdx.x;
+    if (g >= P) return;
+    float u[64];
+#pragma unroll
+    for (int e = 0; e < 48; e++) u[e] = e < 3 * M ? incidents[(size_t)g * M * 3 + e] : 0.f;
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+        u[48 + c] = base_color[3 * (size_t)g + c];
+        u[52 + c] = normals[3 * (size_t)g + c];
+        u[55 + c] = viewdirs[3 * (size_t)g + c];
+    }
+    u[51] = roughness[g];
+    GaussFwd G;
+    gauss_setup(G, u);
+    float4* o = reinterpret_cast<float4*>(rec + (size_t)g * REC);
+#pragma unroll
+    for (int q = 0; q < 13; q++) o[q] = make_float4(u[4 * q], u[4 * q + 1], u[4 * q + 2], u[4 * q + 3]);
+    o[13] = make_float4(G.n[0], G.n[1], G.n[2], G.V[0]);
+    o[14] = make_float4(G.V[1], G.V[2], G.N[0], G.N[1]);
+    o[15] = make_float4(G.N[2], G.NoV, G.a2, G.kk);
+}
+
+struct PackedTap {           // 12 bytes per cached sample
+    uint32_t xy;             // (x0 + 1) | (y0 + 1) << 16, (x0, y0) = floor of the lat-long pixel coordinate (>= -1)
+    float wx1, wy1;          // bilinear weights of column x0 + 1 / row y0 + 1
+};
+
+__device__ __forceinline__ PackedTap make_tap(float dx, float dy, float dz, const float* __restrict__ tr, int He, int We)
+{
+    if (tr != nullptr) {
+        const float tx = dx * tr[0] + dy * tr[1] + dz * tr[2];
+        const float ty = dx * tr[3] + dy * tr[4] + dz * tr[5];
+        const float tz = dx * tr[6] + dy * tr[7] + dz * tr[8];
+        dx = tx; dy = ty; dz = tz;
+    }
+    const float phi = fast_acosf(dz) - 1e-6f;
+    const float theta = fast_atan2f(dy, dx);
+    const float qy = (phi / kPi) * 2.f - 1.f;
+    const float qx = -theta / kPi;
+    const float ix = (qx + 1.f) * 0.5f * (float)(We - 1);
+    const float iy = (qy + 1.f) * 0.5f * (float)(He - 1);
+    const float x0f = floorf(ix), y0f = floorf(iy);
+    PackedTap t;
+    t.wx1 = ix - x0f;
+    t.wy1 = iy - y0f;
+    const int x0 = max((int)x0f, -1), y0 = max((int)y0f, -1);
+    t.xy = (uint32_t)(x0 + 1) | ((uint32_t)(y0 + 1) << 16);
+    return t;
+}
+
+__global__ void __launch_bounds__(256)
+shade_build_taps_kernel(size_t n, const float* __restrict__ dirs, const float* __restrict__ tr, int He, int We,
+                        uint32_t* __restrict__ taps)
+{
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const PackedTap t = make_tap(dirs[3 * i], dirs[3 * i + 1], dirs[3 * i + 2], tr, He, We);
+    taps[3 * i] = t.xy;
+    taps[3 * i + 1] = __float_as_uint(t.wx1);
+    taps[3 * i + 2] = __float_as_uint(t.wy1);
+}
+
+// bilinear sample with zero padding (grid_sample align_corners=True, padding_mode zeros) from a packed tap
+template <bool ENV_LDS>
+__device__ __forceinline__ void env_fetch(const PackedTap& t, const float* __restrict__ env, const float4* s_env4, int He,
+                                          int We, float (&e)[3], int (&tex)[4], float (&w)[4])
+{
+    const int x0 = (int)(t.xy & 0xffffu) - 1, y0 = (int)(t.xy >> 16) - 1;
+    const float wx0 = 1.f - t.wx1, wy0 = 1.f - t.wy1;
+    const bool xa = x0 >= 0, xb = x0 + 1 <= We - 1, ya = y0 >= 0, yb = y0 + 1 <= He - 1;    // x0 <= We-1, y0 <= He-1 always
+    const int xc0 = xa ? x0 : 0, xc1 = xb ? x0 + 1 : We - 1, yc0 = ya ? y0 : 0, yc1 = yb ? y0 + 1 : He - 1;
+    const float fx0 = xa ? wx0 : 0.f, fx1 = xb ? t.wx1 : 0.f, fy0 = ya ? wy0 : 0.f, fy1 = yb ? t.wy1 : 0.f;
+    tex[0] = yc0 * We + xc0; tex[1] = yc0 * We + xc1; tex[2] = yc1 * We + xc0; tex[3] = yc1 * We + xc1;
+    w[0] = fy0 * fx0; w[1] = fy0 * fx1; w[2] = fy1 * fx0; w[3] = fy1 * fx1;
+    e[0] = e[1] = e[2] = 0.f;
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        float px, py, pz;
+        if (ENV_LDS) {
+            const float4 v = s_env4[tex[q]];
+            px = v.x; py = v.y; pz = v.z;
+        } else {
+            const float3 v = *reinterpret_cast<const float3*>(env + 3 * (size_t)tex[q]);
+            px = v.x; py = v.y; pz = v.z;
+        }
+        e[0] += px * w[q]; e[1] += py * w[q]; e[2] += pz * w[q];
+    }
+}
+
+constexpr int ROW_WAVES = 4;
+
+template <int NOUT, bool ENV_LDS, bool TAPS>
+__global__ void __launch_bounds__(64 * ROW_WAVES)
+shade_forward_row_kernel(int P, int K, int M, const float* __restrict__ rec, const float* __restrict__ env, int He, int We,
+                         const float* __restrict__ tr, const float* __restrict__ visibility,
+                         const float* __restrict__ dirs, const float* __restrict__ areas,
+                         const uint32_t* __restrict__ taps, float* __restrict__ out)
+{
+    static_assert(NOUT == 7 || NOUT == 19, "training (pbr, diffuse_light, mean visibility) or all 19 outputs");
+    constexpr int NV = NOUT == 7 ? 8 : 32;
+    extern __shared__ __attribute__((aligned(16))) float s_mem[];
+    float4* s_env4 = reinterpret_cast<float4*>(s_mem);
+    if (ENV_LDS) {
+        for (int i = threadIdx.x; i < He * We; i += blockDim.x)
+            s_env4[i] = make_float4(env[3 * i], env[3 * i + 1], env[3 * i + 2], 0.f);
+        __syncthreads();
+    }
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const float invK = 1.0f / (float)K;
+    for (int g = blockIdx.x * ROW_WAVES + wave; g < P; g += gridDim.x * ROW_WAVES) {
+        const float* __restrict__ u = rec + (size_t)g * REC;          // wave-uniform address: scalar loads
+        const float Vx = u[55], Vy = u[56], Vz = u[57], Nx = u[58], Ny = u[59], Nz = u[60];
+        const float nx = u[52], ny = u[53], nz = u[54];
+        const float NoV = u[61], a2 = u[62], kk = u[63];
+        const float fd0 = u[48] / kPi, fd1 = u[49] / kPi, fd2 = u[50] / kPi;
+        const float nom1 = NoV * (1.f - kk) + kk;
+        float v[NV];
+#pragma unroll
+        for (int i = 0; i < NV; i++) v[i] = 0.f;
+        for (int kb = 0; kb < K; kb += 64) {
+            const int k = kb + lane;
+            if (k < K) {
+                const size_t o = (size_t)g * K + k;
+                const float dx = dirs[3 * o], dy = dirs[3 * o + 1], dz = dirs[3 * o + 2];
+                const float vis = visibility[o], area = areas[o];
+                PackedTap t;
+                if (TAPS) {
+                    t.xy = taps[3 * o];
+                    t.wx1 = __uint_as_float(taps[3 * o + 1]);
+                    t.wy1 = __uint_as_float(taps[3 * o + 2]);
+                } else {
+                    t = make_tap(dx, dy, dz, tr, He, We);
+                }
+                float e[3], w4[4];
+                int tex[4];
+                env_fetch<ENV_LDS>(t, env, s_env4, He, We, e, tex, w4);
+                // local incident light: max(sum_i Y_i(d) c_i, 0), coefficients straight from SGPRs
+                float Y[16];
+                sh_basis16(dx, dy, dz, M, Y);
+                float l0 = 0.f, l1 = 0.f, l2 = 0.f;
+#pragma unroll
+                for (int i = 0; i < 16; i++) {
+                    l0 += Y[i] * u[3 * i];
+                    l1 += Y[i] * u[3 * i + 1];
+                    l2 += Y[i] * u[3 * i + 2];
+                }
+                const float loc[3] = {fmaxf(l0, 0.f), fmaxf(l1, 0.f), fmaxf(l2, 0.f)};
+                const float glob[3] = {e[0] * vis, e[1] * vis, e[2] * vis};
+                const float ndi = fmaxf(nx * dx + ny * dy + nz * dz, 0.f);
+                const float area_ndi = area * ndi;
+                // GGX specular (neilf.py:374-407)
+                const float dlen = fmaxf(sqrtf(dx * dx + dy * dy + dz * dz), 1e-12f);
+                const float Lx = dx / dlen, Ly = dy / dlen, Lz = dz / dlen;
+                const float ux = (Lx + Vx) / 2.0f, uy = (Ly + Vy) / 2.0f, uz = (Lz + Vz) / 2.0f;
+                const float ulen = fmaxf(sqrtf(ux * ux + uy * uy + uz * uz), 1e-12f);
+                const float Hx = ux / ulen, Hy = uy / ulen, Hz = uz / ulen;
+                const float NoL = fminf(fmaxf(Nx * Lx + Ny * Ly + Nz * Lz, 1e-6f), 1.f);
+                const float NoH = fminf(fmaxf(Nx * Hx + Ny * Hy + Nz * Hz, 1e-6f), 1.f);
+                const float VoH = fminf(fmaxf(Vx * Hx + Vy * Hy + Vz * Hz, 1e-6f), 1.f);
+                const float p2 = exp2f((-5.55473f * VoH - 6.98316f) * VoH);
+                const float frac = (0.04f + 0.96f * p2) * a2;
+                const float nom0 = NoH * NoH * (a2 - 1.f) + 1.f;
+                const float nom2 = NoL * (1.f - kk) + kk;
+                const float nom = fminf(fmaxf(4.f * kPi * nom0 * nom0 * nom1 * nom2, 1e-6f), 4.f * kPi);
+                const float spec = frac / nom;
+                const float fd[3] = {fd0, fd1, fd2};
+#pragma unroll
+                for (int c = 0; c < 3; c++) {
+                    const float lin = loc[c] + glob[c];
+                    const float transport = lin * area_ndi;
+                    v[c] += (fd[c] + spec) * transport;        // pbr
+                    v[3 + c] += transport;                     // diffuse_light
+                    if (NOUT == 19) {
+                        v[6 + c] += spec * transport;          // specular
+                        v[9 + c] += lin;                       // mean incident light
+                        v[12 + c] += loc[c];
+                        v[15 + c] += glob[c];
+                    }
+                }
+                v[NOUT == 19 ? 18 : 6] += vis;
+            }
+        }
+        const float r = transpose_reduce<NV, true>(v);
+        const int ch = transposed_channel<NV>(lane);
+        if (transposed_owner<NV>(lane)) {
+            if (NOUT == 19) {
+                if (ch < 19) out[(size_t)g * SHADE_NOUT + ch] = r * invK;
+            } else if (ch < 7) {
+                out[(size_t)g * SHADE_NOUT + (ch < 6 ? ch : 18)] = r * invK;
+            }
+        }
+    }
+}
+
 // Backward: gradients of sum(pbr*g_pbr) + sum(diffuse_light*g_diff) w.r.t. base_color, roughness, viewdirs,
 // incidents and the (activated) environment texture.  normals / dirs / visibility carry no gradient in the
 // reference (normal.detach(), cached samples).
@@ -747,20 +966,77 @@ static unsigned int* shade_scratch()
     return scratch[dev];
 }
 
+// per-device scratch for the per-Gaussian records of the row kernels (grow-only; P * 256 bytes)
+static float* shade_records(size_t P)
+{
+    static float* buf[64] = {nullptr};
+    static size_t cap[64] = {0};
+    int dev = 0;
+    R3DG_HIP(hipGetDevice(&dev));
+    if (dev < 0 || dev >= 64) dev = 0;
+    if (cap[dev] < P) {
+        if (buf[dev] != nullptr) {
+            R3DG_HIP(hipDeviceSynchronize());
+            R3DG_HIP(hipFree(buf[dev]));
+        }
+        const size_t want = P + P / 8 + 1024;
+        R3DG_HIP(hipMalloc((void**)&buf[dev], want * REC * sizeof(float)));
+        cap[dev] = want;
+    }
+    return buf[dev];
+}
+
+int g_shade_fwd_rows = 1;    // r3dg_set_tuning7: 1 = row kernels (wave per Gaussian), 0 = the 16-lane kernel
+
+void launch_shade_build_taps(hipStream_t s, size_t n, const float* dirs, const float* tr, int He, int We, uint32_t* taps)
+{
+    if (n == 0) return;
+    shade_build_taps_kernel<<<(unsigned)((n + 255) / 256), 256, 0, s>>>(n, dirs, tr, He, We, taps);
+    check_launch(s, false, "shade_build_taps_kernel");
+}
+
+// `taps`: optional cache of r3dg_shade_build_taps for THESE dirs / env size / transform; `train_outputs`: write only
+// pbr (0..2), diffuse_light (3..5) and the mean visibility (18) of the 19 outputs
 void launch_shade_forward(hipStream_t s, int P, int K, int M, const float* base_color, const float* roughness,
                           const float* normals, const float* viewdirs, const float* incidents, const float* env, int He,
                           int We, const float* tr, const float* visibility, const float* dirs, const float* areas,
-                          float* out)
+                          float* out, const uint32_t* taps, bool train_outputs)
 {
+    if (P == 0) return;
     const int ntex = He * We * 3;
-    const int grid = shade_grid(P, g_shade_fwd_blocks_per_cu);
-    const size_t u_bytes = SH_GB * 64 * sizeof(float);
-    if (ntex <= ENV_LDS_MAX)
-        shade_forward_kernel<true><<<grid, 64 * SHADE_WAVES, ((ntex + 3) & ~3) * sizeof(float) + u_bytes, s>>>(
-            P, K, M, base_color, roughness, normals, viewdirs, incidents, env, He, We, tr, visibility, dirs, areas, out);
-    else
-        shade_forward_kernel<false><<<grid, 64 * SHADE_WAVES, u_bytes, s>>>(
-            P, K, M, base_color, roughness, normals, viewdirs, incidents, env, He, We, tr, visibility, dirs, areas, out);
+    if (!g_shade_fwd_rows) {
+        const int grid = shade_grid(P, g_shade_fwd_blocks_per_cu);
+        const size_t u_bytes = SH_GB * 64 * sizeof(float);
+        if (ntex <= ENV_LDS_MAX)
+            shade_forward_kernel<true><<<grid, 64 * SHADE_WAVES, ((ntex + 3) & ~3) * sizeof(float) + u_bytes, s>>>(
+                P, K, M, base_color, roughness, normals, viewdirs, incidents, env, He, We, tr, visibility, dirs, areas, out);
+        else
+            shade_forward_kernel<false><<<grid, 64 * SHADE_WAVES, u_bytes, s>>>(
+                P, K, M, base_color, roughness, normals, viewdirs, incidents, env, He, We, tr, visibility, dirs, areas, out);
+        return;
+    }
+    float* rec = shade_records((size_t)P);
+    shade_prepare_kernel<<<(P + 255) / 256, 256, 0, s>>>(P, M, base_color, roughness, normals, viewdirs, incidents, rec);
+    int dev = 0, cus = 256;
+    (void)hipGetDevice(&dev);
+    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    const bool lds = He * We * 4 <= ENV_LDS_MAX;                      // float4 per texel
+    const size_t smem = lds ? (size_t)He * We * sizeof(float4) : 0;
+    const int want = (P + ROW_WAVES - 1) / ROW_WAVES;
+    const int cap = cus * (lds ? 6 : 8);                              // persistent blocks: the LDS texture is staged once per block
+    const int grid = want < cap ? want : cap;
+#define R3DG_ROW(N, L, T)                                                                                             \
+    shade_forward_row_kernel<N, L, T><<<grid, 64 * ROW_WAVES, smem, s>>>(P, K, M, rec, env, He, We, tr, visibility,   \
+                                                                         dirs, areas, taps, out)
+    const bool have = taps != nullptr;
+    if (train_outputs) {
+        if (lds) { if (have) R3DG_ROW(7, true, true); else R3DG_ROW(7, true, false); }
+        else { if (have) R3DG_ROW(7, false, true); else R3DG_ROW(7, false, false); }
+    } else {
+        if (lds) { if (have) R3DG_ROW(19, true, true); else R3DG_ROW(19, true, false); }
+        else { if (have) R3DG_ROW(19, false, true); else R3DG_ROW(19, false, false); }
+    }
+#undef R3DG_ROW
 }
 
 void launch_shade_backward(hipStream_t s, int P, int K, int M, const float* base_color, const float* roughness,

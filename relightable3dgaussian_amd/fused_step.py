@@ -158,6 +158,7 @@ class FusedStage2Step:
             self.refresh_activations()
             self.visibility, self.incident_dirs, self.incident_areas, self.tracer = update_visibility(
                 self.xyz, self.a_scales, self.a_rot, self.a_opacity, self.a_normal, sample_num, group=process_group)
+        self._taps, self._taps_key = None, None
         lrs = dict(lrs or {})
         rate = lambda k: float(lrs.get(k, lr))
         tail = lambda k: float(lrs.get(k + "_rest", rate(k) * lr_rest_scale))
@@ -207,6 +208,15 @@ class FusedStage2Step:
                 self.a_viewdirs.data_ptr())
         _lib.check(st, "stage2_activate")
 
+    def taps(self, He, We):
+        """Lat-long lookup cache of the incident directions for a He x We environment texture (shading_ops.build_taps):
+        rebuilt only when the direction cache is replaced (a visibility update) or the texture size changes."""
+        key = (self.incident_dirs.data_ptr(), tuple(self.incident_dirs.shape), He, We)
+        if self._taps is None or self._taps_key != key:
+            self._taps = shading_ops.build_taps(self.incident_dirs, He, We)
+            self._taps_key = key
+        return self._taps
+
     def forward_backward(self, cam, bg, gt, early_adam=False):
         """One forward + loss + backward; gradients land in self.grads.  Returns the rasterizer's 10 public outputs.
         `early_adam` (single-GPU whole iterations only, see __call__): the SH colour coefficients, whose gradient is final
@@ -231,11 +241,12 @@ class FusedStage2Step:
             self.flush()        # (world > 1) the previous iteration's incident-light update lands here
             env_c = F.softplus(self.env)[0]                                      # DirectLightMap.get_env
             He, We = env_c.shape[0], env_c.shape[1]
-            _lib.check(L.r3dg_shade_forward(
+            taps = self.taps(He, We)
+            _lib.check(L.r3dg_shade_forward_cached(
                 stream(), P, self.K, self.M, self.a_base.data_ptr(), self.a_rough.data_ptr(), self.a_normal.data_ptr(),
                 self.a_viewdirs.data_ptr(), self.incidents.data_ptr(), env_c.data_ptr(), He, We, None,
                 self.visibility.data_ptr(), self.incident_dirs.data_ptr(), self.incident_areas.data_ptr(),
-                self.shade_out.data_ptr()), "shade_forward")
+                taps.data_ptr(), 1, self.shade_out.data_ptr()), "shade_forward")   # pbr, diffuse_light, mean visibility
             self.sums.zero_()
             _lib.check(L.r3dg_stage2_pack_features(
                 stream(), P, self.xyz.data_ptr(), vm.data_ptr(), self.a_normal.data_ptr(), self.a_base.data_ptr(),

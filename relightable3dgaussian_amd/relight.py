@@ -60,6 +60,17 @@ class RelightRenderer:
             self.visibility, self.incident_dirs, self.incident_areas, self.tracer = update_visibility(
                 self.xyz, self.a_scales, self.a_rot, self.a_opacity, self.a_normal, sample_num, group=process_group)
 
+    def _taps_for(self, tr, He, We):
+        """shading_ops.build_taps of the direction cache for this light rotation (None = identity); one entry is kept, so
+        a static light costs one build and a rotating light (relighting.py's light trajectories) one build per frame --
+        the same acos/atan2 the kernel would otherwise evaluate, written once instead of recomputed."""
+        # (no read-back of the matrix: the key is the tensor's identity + version counter)
+        key = (None if tr is None else (tr.data_ptr(), tr._version), He, We, self.incident_dirs.data_ptr())
+        if getattr(self, "_taps_key", None) != key:
+            self._taps = shading_ops.build_taps(self.incident_dirs, He, We, tr)
+            self._taps_key = key
+        return self._taps
+
     def _activate(self, campos):
         with torch.cuda.device(self.dev):
             st = _lib.lib().r3dg_stage2_activate(
@@ -86,11 +97,13 @@ class RelightRenderer:
         stream = _lib.current_stream
         with torch.cuda.device(dev):
             self._activate(campos)
-            _lib.check(L.r3dg_shade_forward(
+            # the lat-long lookups of the cached directions are constant for a fixed light rotation: cached per transform
+            taps = self._taps_for(tr, He, We)
+            _lib.check(L.r3dg_shade_forward_cached(
                 stream(), P, self.K, self.M, self.a_base.data_ptr(), self.a_rough.data_ptr(), self.a_normal.data_ptr(),
                 self.a_viewdirs.data_ptr(), self.incidents.data_ptr(), self.envmap.data_ptr(), He, We, _lib.ptr(tr),
                 self.visibility.data_ptr(), self.incident_dirs.data_ptr(), self.incident_areas.data_ptr(),
-                self.shade_out.data_ptr()), "shade_forward")
+                taps.data_ptr(), 0, self.shade_out.data_ptr()), "shade_forward")
             _lib.check(L.r3dg_relight_pack_features(
                 stream(), P, self.xyz.data_ptr(), vm.data_ptr(), self.a_normal.data_ptr(), self.a_base.data_ptr(),
                 self.a_rough.data_ptr(), self.shade_out.data_ptr(), self.features.data_ptr()), "relight_pack_features")

@@ -19,9 +19,26 @@ def _c(t):
     return t.contiguous()
 
 
+def build_taps(incident_dirs, He, We, env_transform=None):
+    """Lat-long lookup of every cached direction (texel corner + two bilinear weights; int32 [..., 3] holding the 12-byte
+    records of r3dg_shade_build_taps) for an environment texture of He x We texels and this `env_transform`.  Valid as
+    long as `incident_dirs` is (the directions are frozen between visibility updates, gaussian_model.py:312-342)."""
+    L = _lib.lib()
+    d = _c(incident_dirs)
+    tr = _c(env_transform) if env_transform is not None else None
+    taps = torch.empty(d.shape, dtype=torch.int32, device=d.device)
+    with torch.cuda.device(d.device):
+        st = L.r3dg_shade_build_taps(_lib.current_stream(), d.numel() // 3, d.data_ptr(),
+                                     tr.data_ptr() if tr is not None else None, int(He), int(We), taps.data_ptr())
+    _lib.check(st, "shade_build_taps")
+    return taps
+
+
 def shade_forward(base_color, roughness, normals, viewdirs, incidents, env, visibility, incident_dirs, incident_areas,
-                  env_transform=None):
-    """-> out[P,19] = pbr3 diffuse3 specular3 lights3 local3 global3 vis1 (see include/r3dg_hip.h)."""
+                  env_transform=None, taps=None, train_outputs=False, out=None):
+    """-> out[P,19] = pbr3 diffuse3 specular3 lights3 local3 global3 vis1 (see include/r3dg_hip.h).
+    `taps`: build_taps(incident_dirs, He, We, env_transform) of THESE directions (skips the per-sample acos/atan2);
+    `train_outputs`: only columns 0..5 and 18 are written (what the training feature row reads)."""
     L = _lib.lib()
     P, K = incident_dirs.shape[0], incident_dirs.shape[1]
     M = incidents.shape[1]
@@ -29,12 +46,16 @@ def shade_forward(base_color, roughness, normals, viewdirs, incidents, env, visi
     t = [_c(x) for x in (base_color, roughness, normals, viewdirs, incidents, env, visibility, incident_dirs,
                          incident_areas)]
     tr = _c(env_transform) if env_transform is not None else None
-    out = torch.empty((P, NOUT), dtype=torch.float32, device=base_color.device)
+    if taps is not None and (taps.dtype != torch.int32 or taps.numel() != 3 * P * K or not taps.is_contiguous()):
+        raise RuntimeError("taps must be the contiguous int32 [P,K,3] tensor of build_taps for these directions")
+    if out is None:
+        out = torch.empty((P, NOUT), dtype=torch.float32, device=base_color.device)
     with torch.cuda.device(base_color.device):
-        st = L.r3dg_shade_forward(_lib.current_stream(), P, K, M, t[0].data_ptr(), t[1].data_ptr(), t[2].data_ptr(),
-                                  t[3].data_ptr(), t[4].data_ptr(), t[5].data_ptr(), He, We,
-                                  tr.data_ptr() if tr is not None else None, t[6].data_ptr(), t[7].data_ptr(),
-                                  t[8].data_ptr(), out.data_ptr())
+        st = L.r3dg_shade_forward_cached(_lib.current_stream(), P, K, M, t[0].data_ptr(), t[1].data_ptr(),
+                                         t[2].data_ptr(), t[3].data_ptr(), t[4].data_ptr(), t[5].data_ptr(), He, We,
+                                         tr.data_ptr() if tr is not None else None, t[6].data_ptr(), t[7].data_ptr(),
+                                         t[8].data_ptr(), taps.data_ptr() if taps is not None else None,
+                                         1 if train_outputs else 0, out.data_ptr())
     _lib.check(st, "shade_forward")
     return out
 
@@ -96,7 +117,14 @@ class _Shade(torch.autograd.Function):
 
 def shade(base_color, roughness, normals, viewdirs, incidents, env, visibility, incident_dirs, incident_areas,
           env_transform=None):
-    """Differentiable fused integral -> (pbr[P,3], diffuse_light[P,3], rest[P,13] = specular3 lights3 local3 global3 vis1)."""
+    """Differentiable fused integral -> (pbr[P,3], diffuse_light[P,3], rest[P,13] = specular3 lights3 local3 global3 vis1).
+    Gradients flow to base_color, roughness, viewdirs, incidents and env -- what the reference's callers differentiate
+    (normal.detach(), cached samples: neilf.py:115-118); asking for any other one is an error, not a silent zero."""
+    for name, t in (("normals", normals), ("visibility", visibility), ("incident_dirs", incident_dirs),
+                    ("incident_areas", incident_areas), ("env_transform", env_transform)):
+        if t is not None and t.requires_grad:
+            raise RuntimeError("shading_ops.shade: no gradient is implemented for `%s` (the reference passes it detached); "
+                               "detach it" % name)
     return _Shade.apply(base_color, roughness, normals, viewdirs, incidents, env, visibility, incident_dirs,
                         incident_areas, env_transform)
 

@@ -130,3 +130,59 @@ def test_shading_env_gradient_nonfinite_upstream_propagates():
         inp["visibility"], inp["incident_dirs"], inp["incident_areas"], g_pbr, inp["g_diff"])
     assert not torch.isfinite(d_env).all()
     assert not torch.isfinite(d_base[7]).all()
+
+
+@pytest.mark.parametrize("P,K,He,transform", [(1200, 64, 16, False), (500, 384, 64, True), (300, 30, 8, False),
+                                              (64, 100, 256, False)])
+def test_shading_forward_variants_agree(P, K, He, transform):
+    """The forward formulations -- row kernels with the lat-long lookup evaluated in the kernel, with the cached lookup
+    (r3dg_shade_build_taps), with only the training outputs, and the round-1 16-lane kernel -- against the float64 oracle
+    and each other.  Directions exactly on the poles / the +-pi seam exercise the zero-padding corners of the lookup."""
+    from oracle import shading
+    from relightable3dgaussian_amd import _lib, shading_ops as so
+    inp = _random_inputs(P, K, He, 16, seed=3 * P + K, hdr=transform)
+    inp["incident_dirs"][0, 0] = torch.tensor([0.0, 0.0, 1.0])
+    inp["incident_dirs"][0, 1] = torch.tensor([0.0, 0.0, -1.0])
+    inp["incident_dirs"][0, 2] = torch.tensor([-1.0, 0.0, 0.0])
+    inp["incident_dirs"][0, 3] = torch.tensor([-1.0, -0.0, 0.0])
+    inp["incident_dirs"][0, 4] = torch.tensor([1.0, 0.0, 0.0])
+    tr = torch.linalg.qr(torch.randn(3, 3, generator=torch.Generator().manual_seed(7))).Q.contiguous() if transform else None
+    o = {k: v.double() for k, v in inp.items()}
+    ref = shading.rendering_equation(o["base_color"], o["roughness"], o["normals"], o["viewdirs"], o["incidents"], o["env"],
+                                     o["visibility"], o["incident_dirs"], o["incident_areas"],
+                                     tr.double() if tr is not None else None)
+    want = torch.cat([ref[k] for k in ("pbr", "diffuse_light", "specular", "incident_lights", "local_incident_lights",
+                                       "global_incident_lights", "incident_visibility")], -1)
+    d = {k: v.to(DEV) for k, v in inp.items()}
+    trd = tr.to(DEV) if tr is not None else None
+    args = (d["base_color"], d["roughness"], d["normals"], d["viewdirs"], d["incidents"], d["env"], d["visibility"],
+            d["incident_dirs"], d["incident_areas"], trd)
+    taps = so.build_taps(d["incident_dirs"], He, 2 * He, trd)
+    outs = {"rows": so.shade_forward(*args), "rows+taps": so.shade_forward(*args, taps=taps)}
+    sentinel = torch.full((P, so.NOUT), -7.0, device=DEV)
+    outs["rows+taps+train"] = so.shade_forward(*args, taps=taps, train_outputs=True, out=sentinel.clone())
+    try:
+        _lib.lib().r3dg_set_tuning7(0)
+        outs["16-lane"] = so.shade_forward(*args)
+    finally:
+        _lib.lib().r3dg_set_tuning7(1)
+    torch.cuda.synchronize()
+    cols = [0, 1, 2, 3, 4, 5, 18]
+    for name, got in outs.items():
+        if name.endswith("train"):
+            untouched = [c for c in range(so.NOUT) if c not in cols]
+            assert (got[:, untouched] == -7.0).all(), "train-outputs variant wrote a column it must leave alone"
+            _ok(name + " [pbr,diffuse,vis]", got[:, cols], want[:, cols], 5e-4, 1e-6)
+        else:
+            _ok(name + " pbr/spec", got[:, [0, 1, 2, 6, 7, 8]], want[:, [0, 1, 2, 6, 7, 8]], 5e-4, 1e-6)
+            _ok(name + " rest", got[:, [3, 4, 5] + list(range(9, 19))], want[:, [3, 4, 5] + list(range(9, 19))], 1e-4, 1e-6)
+    # the cached lookup is the same arithmetic as the in-kernel one
+    assert (outs["rows"] - outs["rows+taps"]).abs().max().item() <= 1e-6 * max(1.0, want.abs().max().item())
+
+
+def test_shade_refuses_gradients_it_does_not_implement():
+    from relightable3dgaussian_amd import shading_ops as so
+    inp = {k: v.to(DEV) for k, v in _random_inputs(64, 24, 8).items()}
+    with pytest.raises(RuntimeError):
+        so.shade(inp["base_color"], inp["roughness"], inp["normals"].clone().requires_grad_(True), inp["viewdirs"],
+                 inp["incidents"], inp["env"], inp["visibility"], inp["incident_dirs"], inp["incident_areas"])

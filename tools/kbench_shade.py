@@ -1,4 +1,4 @@
-"""Time the shading kernels alone at full size (GPU only)."""
+"""Time the shading kernels alone at full size (GPU only).  ROWS=0 selects the round-1 16-lane forward kernel."""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -7,9 +7,11 @@ P = int(os.environ.get("P", 300000)); dev = "cuda"
 L = _lib.lib()
 if "FWD_BPC" in os.environ:
     L.r3dg_set_tuning6(int(os.environ["FWD_BPC"]))
+if "ROWS" in os.environ:
+    L.r3dg_set_tuning7(int(os.environ["ROWS"]))
 g = torch.Generator().manual_seed(0)
-CASES = ((64, 16, 0),) if os.environ.get("ONLY64") else ((64, 16, 0), (384, 256, 0))
-for K, He, exp in CASES:
+CASES = ((64, 16),) if os.environ.get("ONLY64") else ((64, 16), (384, 256))
+for K, He in CASES:
     nrm = torch.nn.functional.normalize(torch.randn(P, 3, generator=g), dim=-1).to(dev)
     dirs, areas = sampling.fibonacci_sphere_sampling(nrm, K)
     vis = (torch.rand(P, K, 1, device=dev) > 0.3).float()
@@ -18,13 +20,23 @@ for K, He, exp in CASES:
     inc = 0.1 * torch.randn(P, 16, 3, device=dev)
     env = torch.rand(He, 2 * He, 3, device=dev)
     gp, gd = torch.randn(P, 3, device=dev), torch.randn(P, 3, device=dev)
-    for it in range(8):
-        if it == 3:
-            torch.cuda.synchronize(); L.r3dg_profile_enable(1)
-        so.shade_forward(base, rough, nrm, view, inc, env, vis, dirs, areas)
-        if K == 64:
+    taps = so.build_taps(dirs, He, 2 * He)
+    res = {}
+    for name, kw in (("forward (all 19 outputs, lookup in kernel)", {}), ("forward (19 outputs, cached taps)", dict(taps=taps)),
+                     ("forward (train outputs, cached taps)", dict(taps=taps, train_outputs=True))):
+        for it in range(8):
+            if it == 3:
+                torch.cuda.synchronize(); L.r3dg_profile_enable(1)
+            so.shade_forward(base, rough, nrm, view, inc, env, vis, dirs, areas, **kw)
+        torch.cuda.synchronize()
+        pr = _lib.profile_read(); L.r3dg_profile_enable(0)
+        res[name] = pr["shade_forward"][0] / max(pr["shade_forward"][1], 1)
+    if K == 64:
+        for it in range(8):
+            if it == 3:
+                torch.cuda.synchronize(); L.r3dg_profile_enable(1)
             so.shade_backward(base, rough, nrm, view, inc, env, vis, dirs, areas, gp, gd)
-    torch.cuda.synchronize()
-    pr = _lib.profile_read(); L.r3dg_profile_enable(0)
-    print("exp=%d" % exp, "K=%d He=%d shade_forward %.4f ms  shade_backward %.4f ms" % (
-        K, He, pr["shade_forward"][0] / max(pr["shade_forward"][1], 1), pr["shade_backward"][0] / max(pr["shade_backward"][1], 1)))
+        torch.cuda.synchronize()
+        pr = _lib.profile_read(); L.r3dg_profile_enable(0)
+        res["backward"] = pr["shade_backward"][0] / max(pr["shade_backward"][1], 1)
+    print("K=%d He=%d  " % (K, He) + "  ".join("%s %.4f ms" % kv for kv in res.items()))
