@@ -30,7 +30,7 @@ EXTRA = {
     "densify.hip": ["-ffp-contract=off"],         # clone / split / prune decisions are fp32 comparisons
     # shading: VALU-bound transcendental-heavy float math; fp32 tolerance is 1e-4, so reciprocal/sqrt approximations
     # (v_rcp_f32, v_sqrt_f32: 1 ulp) replace the IEEE division/sqrt expansions
-    "shading.hip": ["-ffast-math"],
+    "shading.hip": ["-ffast-math", "-fno-slp-vectorize"],
 }
 
 

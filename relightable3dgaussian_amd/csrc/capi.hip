@@ -54,7 +54,7 @@ void launch_preprocess_backward(hipStream_t s, int P, int D, int M, const float*
 void launch_shade_forward(hipStream_t s, int P, int K, int M, const float* base_color, const float* roughness,
                           const float* normals, const float* viewdirs, const float* incidents, const float* env, int He,
                           int We, const float* tr, const float* visibility, const float* dirs, const float* areas,
-                          float* out, const uint32_t* taps, bool train_outputs);
+                          float* out, const uint32_t* taps, bool train_outputs, float uniform_area);
 void launch_shade_build_taps(hipStream_t s, size_t n, const float* dirs, const float* tr, int He, int We, uint32_t* taps);
 extern int g_shade_fwd_rows;
 void launch_shade_backward(hipStream_t s, int P, int K, int M, const float* base_color, const float* roughness,
@@ -799,21 +799,21 @@ int r3dg_mark_visible(void* stream_, int P, const float* means3D, const float* v
 int r3dg_shade_forward_cached(void* stream_, int P, int K, int M, const float* base_color, const float* roughness,
                               const float* normals, const float* viewdirs, const float* incidents, const float* env,
                               int He, int We, const float* env_transform, const float* visibility,
-                              const float* incident_dirs, const float* incident_areas, const uint32_t* taps,
-                              int train_outputs_only, float* out)
+                              const float* incident_dirs, const float* incident_areas, float uniform_area,
+                              const uint32_t* taps, int train_outputs_only, float* out)
 {
     if (P < 0 || K <= 0 || He <= 0 || We <= 0) return invalid("shade_forward: bad P/K/env size");
     if (He > 32767 || We > 32767) return invalid("shade_forward: environment map larger than 32767 texels per side");
     if (M != 1 && M != 4 && M != 9 && M != 16) return invalid("shade_forward: incidents must hold 1, 4, 9 or 16 SH coefficients");
     if (P == 0) return R3DG_OK;
-    if (!base_color || !roughness || !normals || !viewdirs || !incidents || !env || !visibility || !incident_dirs ||
-        !incident_areas || !out)
+    if (!base_color || !roughness || !normals || !viewdirs || !incidents || !env || !visibility || !incident_dirs || !out)
         return invalid("shade_forward: null buffer");
     return guarded([&]() -> int {
         hipStream_t stream = (hipStream_t)stream_;
         StageTimer t(stream, ST_SHADE_FWD);
         launch_shade_forward(stream, P, K, M, base_color, roughness, normals, viewdirs, incidents, env, He, We,
-                             env_transform, visibility, incident_dirs, incident_areas, out, taps, train_outputs_only != 0);
+                             env_transform, visibility, incident_dirs, incident_areas, out, taps, train_outputs_only != 0,
+                             uniform_area);
         check_launch(stream, false, "shade_forward");
         t.stop();
         return R3DG_OK;
@@ -826,7 +826,7 @@ int r3dg_shade_forward(void* stream_, int P, int K, int M, const float* base_col
                        const float* incident_areas, float* out)
 {
     return r3dg_shade_forward_cached(stream_, P, K, M, base_color, roughness, normals, viewdirs, incidents, env, He, We,
-                                     env_transform, visibility, incident_dirs, incident_areas, nullptr, 0, out);
+                                     env_transform, visibility, incident_dirs, incident_areas, 0.f, nullptr, 0, out);
 }
 
 int r3dg_shade_build_taps(void* stream_, int64_t num_samples, const float* incident_dirs, const float* env_transform,

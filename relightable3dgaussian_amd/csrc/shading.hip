@@ -466,10 +466,11 @@ shade_forward_kernel(int P, int K, int M, const float* __restrict__ base_color, 
 // =====================================================================================================================
 // Forward, second formulation ("row" kernels): ONE WAVE PER GAUSSIAN, lane = sample.
 //   * everything that is uniform per Gaussian -- the 48 SH coefficients and the view/normal/roughness-derived factors of
-//     the GGX term -- is precomputed into a 64-float record by shade_prepare_kernel (thread per Gaussian) and arrives in
-//     SGPRs through scalar loads (the Gaussian index is wave-uniform): no LDS staging, no per-sample ds_read of the
-//     coefficients (the 16-lane kernel above issues 12 ds_read_b128 per SAMPLE), no redundant per-lane setup; the 48
-//     local-light FMAs take their coefficient operand straight from an SGPR;
+//     the GGX term -- is precomputed into a 64-float record by shade_prepare_kernel (thread per Gaussian); the wave fetches
+//     it with ONE coalesced load (lane l reads element l, prefetched with the samples), parks it in LDS and reads it back as
+//     wave-uniform broadcasts: 16 ds_read_b128 per 64 SAMPLES where the 16-lane kernel above issues 12 per sample, and no
+//     redundant per-lane setup.  (Scalar loads into SGPRs were tried first: the three s_load_dwordx16 sit behind the same
+//     lgkmcnt as the LDS texture reads and their latency was exposed once per row -- slower than the 16-lane kernel.)
 //   * the K samples of the Gaussian are one coalesced row per array (lane k reads sample kb+k);
 //   * the lat-long lookup of a cached direction never changes between visibility updates, so its result -- texel corner
 //     and the two bilinear weights, 12 bytes per sample -- can be cached by the caller (r3dg_shade_build_taps, one pass
@@ -482,31 +483,39 @@ shade_forward_kernel(int P, int K, int M, const float* __restrict__ base_color, 
 constexpr int REC = 64;      // floats per Gaussian record
 // record layout: 0..47 SH coefficients (i*3+c, zero padded beyond M), 48..50 albedo, 51 roughness, 52..54 normal (as given),
 // 55..57 V = normalize(viewdir), 58..60 N = normalize(normal) * sign(N.V), 61 NoV (clamped), 62 alpha^2, 63 k
+// 64 Gaussians per 256-thread block: the 48 coefficient floats of each are copied with coalesced loads / stores by the whole
+// block, then thread t < 64 derives Gaussian t's 16 remaining record entries (thread-per-Gaussian copying 58 strided floats
+// was 0.07 ms at P=300k; this is ~0.015 ms).
 __global__ void __launch_bounds__(256)
 shade_prepare_kernel(int P, int M, const float* __restrict__ base_color, const float* __restrict__ roughness,
                      const float* __restrict__ normals, const float* __restrict__ viewdirs,
                      const float* __restrict__ incidents, float* __restrict__ rec)
 {
-    const int g = blockIdx.x * 256 + threadIdx.x;
-    if (g >= P) return;
-    float u[64];
-#pragma unroll
-    for (int e = 0; e < 48; e++) u[e] = e < 3 * M ? incidents[(size_t)g * M * 3 + e] : 0.f;
-#pragma unroll
-    for (int c = 0; c < 3; c++) {
-        u[48 + c] = base_color[3 * (size_t)g + c];
-        u[52 + c] = normals[3 * (size_t)g + c];
-        u[55 + c] = viewdirs[3 * (size_t)g + c];
+    const int g0 = blockIdx.x * 64;
+    const int ng = min(64, P - g0);
+    const int row = 3 * M;                       // floats per Gaussian in `incidents`
+    for (int i = threadIdx.x; i < ng * 48; i += 256) {
+        const int gl = i / 48, e = i - gl * 48;
+        rec[(size_t)(g0 + gl) * REC + e] = e < row ? incidents[(size_t)(g0 + gl) * row + e] : 0.f;
     }
-    u[51] = roughness[g];
-    GaussFwd G;
-    gauss_setup(G, u);
-    float4* o = reinterpret_cast<float4*>(rec + (size_t)g * REC);
+    if ((int)threadIdx.x < ng) {
+        const int g = g0 + threadIdx.x;
+        float u[64];
 #pragma unroll
-    for (int q = 0; q < 13; q++) o[q] = make_float4(u[4 * q], u[4 * q + 1], u[4 * q + 2], u[4 * q + 3]);
-    o[13] = make_float4(G.n[0], G.n[1], G.n[2], G.V[0]);
-    o[14] = make_float4(G.V[1], G.V[2], G.N[0], G.N[1]);
-    o[15] = make_float4(G.N[2], G.NoV, G.a2, G.kk);
+        for (int c = 0; c < 3; c++) {
+            u[48 + c] = base_color[3 * (size_t)g + c];
+            u[52 + c] = normals[3 * (size_t)g + c];
+            u[55 + c] = viewdirs[3 * (size_t)g + c];
+        }
+        u[51] = roughness[g];
+        GaussFwd G;
+        gauss_setup(G, u);
+        float4* o = reinterpret_cast<float4*>(rec + (size_t)g * REC + 48);
+        o[0] = make_float4(u[48], u[49], u[50], u[51]);
+        o[1] = make_float4(G.n[0], G.n[1], G.n[2], G.V[0]);
+        o[2] = make_float4(G.V[1], G.V[2], G.N[0], G.N[1]);
+        o[3] = make_float4(G.N[2], G.NoV, G.a2, G.kk);
+    }
 }
 
 struct PackedTap {           // 12 bytes per cached sample
@@ -549,137 +558,204 @@ shade_build_taps_kernel(size_t n, const float* __restrict__ dirs, const float* _
     taps[3 * i + 2] = __float_as_uint(t.wy1);
 }
 
-// bilinear sample with zero padding (grid_sample align_corners=True, padding_mode zeros) from a packed tap
-template <bool ENV_LDS>
-__device__ __forceinline__ void env_fetch(const PackedTap& t, const float* __restrict__ env, const float4* s_env4, int He,
-                                          int We, float (&e)[3], int (&tex)[4], float (&w)[4])
+// bilinear sample with zero padding (grid_sample align_corners=True, padding_mode zeros) from a packed tap; the texture
+// holds one float4 per texel (LDS or global)
+__device__ __forceinline__ void env_fetch(const PackedTap& t, const float4* tex4, int He, int We, float (&e)[3],
+                                          int (&tex)[4], float (&w)[4])
 {
     const int x0 = (int)(t.xy & 0xffffu) - 1, y0 = (int)(t.xy >> 16) - 1;
     const float wx0 = 1.f - t.wx1, wy0 = 1.f - t.wy1;
     const bool xa = x0 >= 0, xb = x0 + 1 <= We - 1, ya = y0 >= 0, yb = y0 + 1 <= He - 1;    // x0 <= We-1, y0 <= He-1 always
     const int xc0 = xa ? x0 : 0, xc1 = xb ? x0 + 1 : We - 1, yc0 = ya ? y0 : 0, yc1 = yb ? y0 + 1 : He - 1;
     const float fx0 = xa ? wx0 : 0.f, fx1 = xb ? t.wx1 : 0.f, fy0 = ya ? wy0 : 0.f, fy1 = yb ? t.wy1 : 0.f;
-    tex[0] = yc0 * We + xc0; tex[1] = yc0 * We + xc1; tex[2] = yc1 * We + xc0; tex[3] = yc1 * We + xc1;
+    const int r0 = __mul24(yc0, We), r1 = __mul24(yc1, We);          // 24-bit operands (He, We <= 32767): full-rate multiply
+    tex[0] = r0 + xc0; tex[1] = r0 + xc1; tex[2] = r1 + xc0; tex[3] = r1 + xc1;
     w[0] = fy0 * fx0; w[1] = fy0 * fx1; w[2] = fy1 * fx0; w[3] = fy1 * fx1;
     e[0] = e[1] = e[2] = 0.f;
 #pragma unroll
     for (int q = 0; q < 4; q++) {
-        float px, py, pz;
-        if (ENV_LDS) {
-            const float4 v = s_env4[tex[q]];
-            px = v.x; py = v.y; pz = v.z;
-        } else {
-            const float3 v = *reinterpret_cast<const float3*>(env + 3 * (size_t)tex[q]);
-            px = v.x; py = v.y; pz = v.z;
-        }
-        e[0] += px * w[q]; e[1] += py * w[q]; e[2] += pz * w[q];
+        const float4 v = tex4[tex[q]];
+        e[0] += v.x * w[q]; e[1] += v.y * w[q]; e[2] += v.z * w[q];
     }
 }
 
 constexpr int ROW_WAVES = 4;
 
-template <int NOUT, bool ENV_LDS, bool TAPS>
+struct RowSample {            // one lane's share of a (Gaussian, 64-sample block): prefetched one block ahead (registers)
+    float dx, dy, dz, vis, area;
+    PackedTap t;
+    float rec;                // element `lane` of the Gaussian's 64-float record
+};
+
+// `g` is wave-uniform (callers derive it from readfirstlane'd values): the row bases are computed on the scalar unit and the
+// loads address SGPR base + 32-bit lane offset
+template <bool TAPS>
+__device__ __forceinline__ RowSample load_row_sample(bool live, int g, int lane, unsigned k, int K,
+                                                     const float* __restrict__ rec, const float* __restrict__ dirs,
+                                                     const float* __restrict__ visibility,
+                                                     const float* __restrict__ areas, float uniform_area,
+                                                     const uint32_t* __restrict__ taps)
+{
+    RowSample r;
+    r.dx = 0.f; r.dy = 0.f; r.dz = 1.f; r.vis = 0.f; r.area = 0.f;
+    r.t.xy = 0x00010001u; r.t.wx1 = 0.f; r.t.wy1 = 0.f;
+    const size_t row = (size_t)g * (size_t)K;
+    const float* __restrict__ rrow = rec + (size_t)g * REC;
+    const float* __restrict__ drow = dirs + 3 * row;
+    const float* __restrict__ vrow = visibility + row;
+    r.rec = rrow[(unsigned)lane];
+    if (live) {
+        const float3 d = *reinterpret_cast<const float3*>(drow + 3u * k);
+        r.dx = d.x; r.dy = d.y; r.dz = d.z;
+        r.vis = vrow[k];
+        r.area = areas != nullptr ? (areas + row)[k] : uniform_area;
+        if (TAPS) {
+            const uint3 t = *reinterpret_cast<const uint3*>(taps + 3 * row + 3u * k);
+            r.t.xy = t.x; r.t.wx1 = __uint_as_float(t.y); r.t.wy1 = __uint_as_float(t.z);
+        }
+    }
+    return r;
+}
+
+// env4: the environment texture as one float4 per texel (launch_shade_forward pads it) -- in LDS when it fits (ENV_LDS),
+// else read from global / L2 with ONE aligned 16-byte load per tap.
+// Software pipeline per wave: [wait for block i's samples] -> [issue the loads of block i+1: they fly during the ~250
+// instructions below] -> [record of block i: one ds_write_b32 per lane, read back as wave-uniform broadcasts] -> compute ->
+// (last block of the Gaussian) transposing wave reduction + store.
+template <int NOUT, bool ENV_LDS, bool TAPS, bool M16>
 __global__ void __launch_bounds__(64 * ROW_WAVES)
-shade_forward_row_kernel(int P, int K, int M, const float* __restrict__ rec, const float* __restrict__ env, int He, int We,
+shade_forward_row_kernel(int P, int K, int M_, const float* __restrict__ rec, const float4* __restrict__ env4, int He, int We,
                          const float* __restrict__ tr, const float* __restrict__ visibility,
-                         const float* __restrict__ dirs, const float* __restrict__ areas,
+                         const float* __restrict__ dirs, const float* __restrict__ areas, float uniform_area,
                          const uint32_t* __restrict__ taps, float* __restrict__ out)
 {
     static_assert(NOUT == 7 || NOUT == 19, "training (pbr, diffuse_light, mean visibility) or all 19 outputs");
     constexpr int NV = NOUT == 7 ? 8 : 32;
+    const int M = M16 ? 16 : M_;                 // degree-3 incident light (the reference's only configuration) folds the
+                                                 // degree branches of the basis away
     extern __shared__ __attribute__((aligned(16))) float s_mem[];
+    __shared__ __attribute__((aligned(16))) float s_rec[ROW_WAVES][REC];
     float4* s_env4 = reinterpret_cast<float4*>(s_mem);
     if (ENV_LDS) {
-        for (int i = threadIdx.x; i < He * We; i += blockDim.x)
-            s_env4[i] = make_float4(env[3 * i], env[3 * i + 1], env[3 * i + 2], 0.f);
+        for (int i = threadIdx.x; i < He * We; i += blockDim.x) s_env4[i] = env4[i];
         __syncthreads();
     }
+    const float4* tex4 = ENV_LDS ? s_env4 : env4;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    float* u = s_rec[wave];
     const float invK = 1.0f / (float)K;
-    for (int g = blockIdx.x * ROW_WAVES + wave; g < P; g += gridDim.x * ROW_WAVES) {
-        const float* __restrict__ u = rec + (size_t)g * REC;          // wave-uniform address: scalar loads
-        const float Vx = u[55], Vy = u[56], Vz = u[57], Nx = u[58], Ny = u[59], Nz = u[60];
-        const float nx = u[52], ny = u[53], nz = u[54];
-        const float NoV = u[61], a2 = u[62], kk = u[63];
-        const float fd0 = u[48] / kPi, fd1 = u[49] / kPi, fd2 = u[50] / kPi;
+    const int nblk = (K + 63) / 64;
+    const int g_stride = gridDim.x * ROW_WAVES;
+    // the wave walks (Gaussian, 64-sample block) pairs; two blocks are in flight ahead of the one being computed
+    int g = blockIdx.x * ROW_WAVES + wave, kb = 0;
+    auto advance = [&](int& ag, int& akb) {
+        if (++akb == nblk) { akb = 0; ag += g_stride; }
+    };
+    auto fetch = [&](int ag, int akb) {
+        const int k = akb * 64 + lane;
+        const int gg = min(ag, P - 1);
+        return load_row_sample<TAPS>(ag < P && k < K, gg, lane, (unsigned)k, K, rec, dirs, visibility, areas,
+                                     uniform_area, taps);
+    };
+    int g1 = g, kb1 = kb;
+    advance(g1, kb1);
+    RowSample cur = fetch(g, kb);
+    RowSample nx1 = fetch(g1, kb1);
+    float v[NV];
+#pragma unroll
+    for (int i = 0; i < NV; i++) v[i] = 0.f;
+    while (g < P) {
+        // the current block's registers are complete past this point (its loads were issued two iterations ago); the
+        // statement also keeps the compiler from hoisting the prefetch below above the wait
+        asm volatile("" : "+v"(cur.dx), "+v"(cur.dy), "+v"(cur.dz), "+v"(cur.vis), "+v"(cur.area), "+v"(cur.t.xy),
+                     "+v"(cur.t.wx1), "+v"(cur.t.wy1), "+v"(cur.rec) :: "memory");
+        int g2 = g1, kb2 = kb1;
+        advance(g2, kb2);
+        const RowSample nx2 = fetch(g2, kb2);
+        u[lane] = cur.rec;                          // same wave, in-order LDS: no barrier needed
+        const float4 ga = *reinterpret_cast<const float4*>(u + 48);     // albedo, roughness
+        const float4 gb = *reinterpret_cast<const float4*>(u + 52);     // n, V.x
+        const float4 gc = *reinterpret_cast<const float4*>(u + 56);     // V.yz, N.xy
+        const float4 gd = *reinterpret_cast<const float4*>(u + 60);     // N.z, NoV, a2, kk
+        const float nx = gb.x, ny = gb.y, nz = gb.z, Vx = gb.w, Vy = gc.x, Vz = gc.y, Nx = gc.z, Ny = gc.w, Nz = gd.x;
+        const float NoV = gd.y, a2 = gd.z, kk = gd.w;
+        const float fd[3] = {ga.x / kPi, ga.y / kPi, ga.z / kPi};
         const float nom1 = NoV * (1.f - kk) + kk;
-        float v[NV];
+        {
+            const float dx = cur.dx, dy = cur.dy, dz = cur.dz, vis = cur.vis, area = cur.area;
+            const bool live = kb * 64 + lane < K;
+            PackedTap t = cur.t;
+            if (!TAPS) t = make_tap(dx, dy, dz, tr, He, We);
+            float e[3], w4[4];
+            int tex[4];
+            env_fetch(t, tex4, He, We, e, tex, w4);
+            // local incident light: max(sum_i Y_i(d) c_i, 0); coefficients = wave-uniform broadcast reads (12 per 64 samples)
+            float Y[16];
+            sh_basis16(dx, dy, dz, M, Y);
+            float l[3];
+            sh_local_sum(u, Y, l);
+            const float lv = live ? 1.f : 0.f;               // lanes beyond K contribute nothing (their area is 0 as well)
+            const float loc[3] = {fmaxf(l[0], 0.f) * lv, fmaxf(l[1], 0.f) * lv, fmaxf(l[2], 0.f) * lv};
+            const float glob[3] = {e[0] * vis, e[1] * vis, e[2] * vis};
+            const float ndi = fmaxf(nx * dx + ny * dy + nz * dz, 0.f);
+            const float area_ndi = area * ndi;
+            // GGX specular (neilf.py:374-407)
+            // x / max(|x|, 1e-12) (F.normalize) as x * rsq(max(|x|^2, 1e-24)): one transcendental instead of two
+            const float dinv = __builtin_amdgcn_rsqf(fmaxf(dx * dx + dy * dy + dz * dz, 1e-24f));
+            const float Lx = dx * dinv, Ly = dy * dinv, Lz = dz * dinv;
+            const float ux = (Lx + Vx) / 2.0f, uy = (Ly + Vy) / 2.0f, uz = (Lz + Vz) / 2.0f;
+            const float uinv = __builtin_amdgcn_rsqf(fmaxf(ux * ux + uy * uy + uz * uz, 1e-24f));
+            const float Hx = ux * uinv, Hy = uy * uinv, Hz = uz * uinv;
+            const float NoL = fminf(fmaxf(Nx * Lx + Ny * Ly + Nz * Lz, 1e-6f), 1.f);
+            const float NoH = fminf(fmaxf(Nx * Hx + Ny * Hy + Nz * Hz, 1e-6f), 1.f);
+            const float VoH = fminf(fmaxf(Vx * Hx + Vy * Hy + Vz * Hz, 1e-6f), 1.f);
+            const float p2 = exp2f((-5.55473f * VoH - 6.98316f) * VoH);
+            const float frac = (0.04f + 0.96f * p2) * a2;
+            const float nom0 = NoH * NoH * (a2 - 1.f) + 1.f;
+            const float nom2 = NoL * (1.f - kk) + kk;
+            const float nom = fminf(fmaxf(4.f * kPi * nom0 * nom0 * nom1 * nom2, 1e-6f), 4.f * kPi);
+            const float spec = frac / nom;
 #pragma unroll
-        for (int i = 0; i < NV; i++) v[i] = 0.f;
-        for (int kb = 0; kb < K; kb += 64) {
-            const int k = kb + lane;
-            if (k < K) {
-                const size_t o = (size_t)g * K + k;
-                const float dx = dirs[3 * o], dy = dirs[3 * o + 1], dz = dirs[3 * o + 2];
-                const float vis = visibility[o], area = areas[o];
-                PackedTap t;
-                if (TAPS) {
-                    t.xy = taps[3 * o];
-                    t.wx1 = __uint_as_float(taps[3 * o + 1]);
-                    t.wy1 = __uint_as_float(taps[3 * o + 2]);
-                } else {
-                    t = make_tap(dx, dy, dz, tr, He, We);
+            for (int c = 0; c < 3; c++) {
+                const float lin = loc[c] + glob[c];
+                const float transport = lin * area_ndi;
+                v[c] += (fd[c] + spec) * transport;        // pbr
+                v[3 + c] += transport;                     // diffuse_light
+                if (NOUT == 19) {
+                    v[6 + c] += spec * transport;          // specular
+                    v[9 + c] += lin;                       // mean incident light
+                    v[12 + c] += loc[c];
+                    v[15 + c] += glob[c];
                 }
-                float e[3], w4[4];
-                int tex[4];
-                env_fetch<ENV_LDS>(t, env, s_env4, He, We, e, tex, w4);
-                // local incident light: max(sum_i Y_i(d) c_i, 0), coefficients straight from SGPRs
-                float Y[16];
-                sh_basis16(dx, dy, dz, M, Y);
-                float l0 = 0.f, l1 = 0.f, l2 = 0.f;
-#pragma unroll
-                for (int i = 0; i < 16; i++) {
-                    l0 += Y[i] * u[3 * i];
-                    l1 += Y[i] * u[3 * i + 1];
-                    l2 += Y[i] * u[3 * i + 2];
-                }
-                const float loc[3] = {fmaxf(l0, 0.f), fmaxf(l1, 0.f), fmaxf(l2, 0.f)};
-                const float glob[3] = {e[0] * vis, e[1] * vis, e[2] * vis};
-                const float ndi = fmaxf(nx * dx + ny * dy + nz * dz, 0.f);
-                const float area_ndi = area * ndi;
-                // GGX specular (neilf.py:374-407)
-                const float dlen = fmaxf(sqrtf(dx * dx + dy * dy + dz * dz), 1e-12f);
-                const float Lx = dx / dlen, Ly = dy / dlen, Lz = dz / dlen;
-                const float ux = (Lx + Vx) / 2.0f, uy = (Ly + Vy) / 2.0f, uz = (Lz + Vz) / 2.0f;
-                const float ulen = fmaxf(sqrtf(ux * ux + uy * uy + uz * uz), 1e-12f);
-                const float Hx = ux / ulen, Hy = uy / ulen, Hz = uz / ulen;
-                const float NoL = fminf(fmaxf(Nx * Lx + Ny * Ly + Nz * Lz, 1e-6f), 1.f);
-                const float NoH = fminf(fmaxf(Nx * Hx + Ny * Hy + Nz * Hz, 1e-6f), 1.f);
-                const float VoH = fminf(fmaxf(Vx * Hx + Vy * Hy + Vz * Hz, 1e-6f), 1.f);
-                const float p2 = exp2f((-5.55473f * VoH - 6.98316f) * VoH);
-                const float frac = (0.04f + 0.96f * p2) * a2;
-                const float nom0 = NoH * NoH * (a2 - 1.f) + 1.f;
-                const float nom2 = NoL * (1.f - kk) + kk;
-                const float nom = fminf(fmaxf(4.f * kPi * nom0 * nom0 * nom1 * nom2, 1e-6f), 4.f * kPi);
-                const float spec = frac / nom;
-                const float fd[3] = {fd0, fd1, fd2};
-#pragma unroll
-                for (int c = 0; c < 3; c++) {
-                    const float lin = loc[c] + glob[c];
-                    const float transport = lin * area_ndi;
-                    v[c] += (fd[c] + spec) * transport;        // pbr
-                    v[3 + c] += transport;                     // diffuse_light
-                    if (NOUT == 19) {
-                        v[6 + c] += spec * transport;          // specular
-                        v[9 + c] += lin;                       // mean incident light
-                        v[12 + c] += loc[c];
-                        v[15 + c] += glob[c];
-                    }
-                }
-                v[NOUT == 19 ? 18 : 6] += vis;
             }
+            v[NOUT == 19 ? 18 : 6] += vis;
         }
-        const float r = transpose_reduce<NV, true>(v);
-        const int ch = transposed_channel<NV>(lane);
-        if (transposed_owner<NV>(lane)) {
-            if (NOUT == 19) {
-                if (ch < 19) out[(size_t)g * SHADE_NOUT + ch] = r * invK;
-            } else if (ch < 7) {
-                out[(size_t)g * SHADE_NOUT + (ch < 6 ? ch : 18)] = r * invK;
+        if (kb == nblk - 1) {
+            const float r = transpose_reduce<NV, true>(v);
+            const int ch = transposed_channel<NV>(lane);
+            if (transposed_owner<NV>(lane)) {
+                if (NOUT == 19) {
+                    if (ch < 19) out[(size_t)g * SHADE_NOUT + ch] = r * invK;
+                } else if (ch < 7) {
+                    out[(size_t)g * SHADE_NOUT + (ch < 6 ? ch : 18)] = r * invK;
+                }
             }
+#pragma unroll
+            for (int i = 0; i < NV; i++) v[i] = 0.f;
         }
+        cur = nx1;
+        nx1 = nx2;
+        g = g1; kb = kb1;
+        g1 = g2; kb1 = kb2;
     }
+}
+
+__global__ void __launch_bounds__(256)
+shade_pad_env_kernel(int n, const float* __restrict__ env, float4* __restrict__ env4)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) env4[i] = make_float4(env[3 * i], env[3 * i + 1], env[3 * i + 2], 0.f);
 }
 
 // Backward: gradients of sum(pbr*g_pbr) + sum(diffuse_light*g_diff) w.r.t. base_color, roughness, viewdirs,
@@ -941,11 +1017,17 @@ shade_backward_kernel(int P, int K, int M, ShadeSrc src, const float* __restrict
 
 int g_shade_fwd_blocks_per_cu = 2;   // r3dg_set_tuning6: persistent workgroups per CU of the shading forward
 
-static int shade_grid(int P, int blocks_per_cu = 2)
+static int shade_cus()
 {
     int dev = 0, cus = 256;
     (void)hipGetDevice(&dev);
     (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    return cus;
+}
+
+static int shade_grid(int P, int blocks_per_cu = 2)
+{
+    const int cus = shade_cus();
     const int want = (P + SH_GB - 1) / SH_GB;
     const int cap = cus * blocks_per_cu;      // persistent blocks, all resident: nothing queued behind them
     return want < cap ? (want > 0 ? want : 1) : cap;
@@ -1000,9 +1082,10 @@ void launch_shade_build_taps(hipStream_t s, size_t n, const float* dirs, const f
 void launch_shade_forward(hipStream_t s, int P, int K, int M, const float* base_color, const float* roughness,
                           const float* normals, const float* viewdirs, const float* incidents, const float* env, int He,
                           int We, const float* tr, const float* visibility, const float* dirs, const float* areas,
-                          float* out, const uint32_t* taps, bool train_outputs)
+                          float* out, const uint32_t* taps, bool train_outputs, float uniform_area)
 {
     if (P == 0) return;
+    if (areas == nullptr && !g_shade_fwd_rows) throw std::runtime_error("shade_forward: the 16-lane kernel needs incident_areas");
     const int ntex = He * We * 3;
     if (!g_shade_fwd_rows) {
         const int grid = shade_grid(P, g_shade_fwd_blocks_per_cu);
@@ -1015,19 +1098,38 @@ void launch_shade_forward(hipStream_t s, int P, int K, int M, const float* base_
                 P, K, M, base_color, roughness, normals, viewdirs, incidents, env, He, We, tr, visibility, dirs, areas, out);
         return;
     }
-    float* rec = shade_records((size_t)P);
-    shade_prepare_kernel<<<(P + 255) / 256, 256, 0, s>>>(P, M, base_color, roughness, normals, viewdirs, incidents, rec);
-    int dev = 0, cus = 256;
-    (void)hipGetDevice(&dev);
-    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    const size_t ntexel = (size_t)He * We;
+    float* rec = shade_records((size_t)P + (ntexel * 4 + REC - 1) / REC + 1);      // records, then the float4-padded texture
+    float4* env4 = reinterpret_cast<float4*>(rec + (size_t)P * REC);
+    shade_prepare_kernel<<<(P + 63) / 64, 256, 0, s>>>(P, M, base_color, roughness, normals, viewdirs, incidents, rec);
+    shade_pad_env_kernel<<<(int)((ntexel + 255) / 256), 256, 0, s>>>((int)ntexel, env, env4);
     const bool lds = He * We * 4 <= ENV_LDS_MAX;                      // float4 per texel
-    const size_t smem = lds ? (size_t)He * We * sizeof(float4) : 0;
+    const size_t smem = lds ? ntexel * sizeof(float4) : 0;
     const int want = (P + ROW_WAVES - 1) / ROW_WAVES;
-    const int cap = cus * (lds ? 6 : 8);                              // persistent blocks: the LDS texture is staged once per block
-    const int grid = want < cap ? want : cap;
 #define R3DG_ROW(N, L, T)                                                                                             \
-    shade_forward_row_kernel<N, L, T><<<grid, 64 * ROW_WAVES, smem, s>>>(P, K, M, rec, env, He, We, tr, visibility,   \
-                                                                         dirs, areas, taps, out)
+    do {                                                                                                              \
+        /* persistent blocks: exactly as many as are resident at once (a larger grid runs a second, nearly empty wave of \
+           blocks; the API can be one block per CU high at this SGPR count -- a spare block only costs a short tail) */ \
+        static int per_cu[2] = {0, 0};                                                                                \
+        if (per_cu[L] == 0) {                                                                                         \
+            int nb = 0;                                                                                               \
+            R3DG_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, shade_forward_row_kernel<N, L, T, true>,       \
+                                                                  64 * ROW_WAVES, smem));                            \
+            hipFuncAttributes fa;                                                                                     \
+            R3DG_HIP(hipFuncGetAttributes(&fa, (const void*)shade_forward_row_kernel<N, L, T, true>));                \
+            const int by_vgpr = 512 / (((fa.numRegs + 7) / 8) * 8);                                                   \
+            nb = nb < by_vgpr ? nb : by_vgpr;                                                                         \
+            per_cu[L] = nb > 0 ? (nb < 8 ? nb : 8) : 1;                                                               \
+        }                                                                                                             \
+        const int cap = shade_cus() * per_cu[L];                                                                      \
+        const int grid = want < cap ? want : cap;                                                                     \
+        if (M == 16)                                                                                                  \
+            shade_forward_row_kernel<N, L, T, true><<<grid, 64 * ROW_WAVES, smem, s>>>(                               \
+                P, K, M, rec, env4, He, We, tr, visibility, dirs, areas, uniform_area, taps, out);                    \
+        else                                                                                                          \
+            shade_forward_row_kernel<N, L, T, false><<<grid, 64 * ROW_WAVES, smem, s>>>(                              \
+                P, K, M, rec, env4, He, We, tr, visibility, dirs, areas, uniform_area, taps, out);                    \
+    } while (0)
     const bool have = taps != nullptr;
     if (train_outputs) {
         if (lds) { if (have) R3DG_ROW(7, true, true); else R3DG_ROW(7, true, false); }

@@ -215,6 +215,9 @@ class FusedStage2Step:
         if self._taps is None or self._taps_key != key:
             self._taps = shading_ops.build_taps(self.incident_dirs, He, We)
             self._taps_key = key
+            # fibonacci_sphere_sampling gives every sample the area 2 pi: then the area cache need not be read at all
+            lo, hi = float(self.incident_areas.min()), float(self.incident_areas.max())
+            self._uniform_area = lo if lo == hi else None
         return self._taps
 
     def forward_backward(self, cam, bg, gt, early_adam=False):
@@ -245,7 +248,8 @@ class FusedStage2Step:
             _lib.check(L.r3dg_shade_forward_cached(
                 stream(), P, self.K, self.M, self.a_base.data_ptr(), self.a_rough.data_ptr(), self.a_normal.data_ptr(),
                 self.a_viewdirs.data_ptr(), self.incidents.data_ptr(), env_c.data_ptr(), He, We, None,
-                self.visibility.data_ptr(), self.incident_dirs.data_ptr(), self.incident_areas.data_ptr(),
+                self.visibility.data_ptr(), self.incident_dirs.data_ptr(),
+                None if self._uniform_area is not None else self.incident_areas.data_ptr(), self._uniform_area or 0.0,
                 taps.data_ptr(), 1, self.shade_out.data_ptr()), "shade_forward")   # pbr, diffuse_light, mean visibility
             self.sums.zero_()
             _lib.check(L.r3dg_stage2_pack_features(

@@ -69,6 +69,11 @@ class RelightRenderer:
         if getattr(self, "_taps_key", None) != key:
             self._taps = shading_ops.build_taps(self.incident_dirs, He, We, tr)
             self._taps_key = key
+            if getattr(self, "_area_key", None) != self.incident_areas.data_ptr():
+                # fibonacci_sphere_sampling gives every sample the area 2 pi: then the area cache need not be read at all
+                lo, hi = float(self.incident_areas.min()), float(self.incident_areas.max())
+                self._uniform_area = lo if lo == hi else None
+                self._area_key = self.incident_areas.data_ptr()
         return self._taps
 
     def _activate(self, campos):
@@ -102,7 +107,8 @@ class RelightRenderer:
             _lib.check(L.r3dg_shade_forward_cached(
                 stream(), P, self.K, self.M, self.a_base.data_ptr(), self.a_rough.data_ptr(), self.a_normal.data_ptr(),
                 self.a_viewdirs.data_ptr(), self.incidents.data_ptr(), self.envmap.data_ptr(), He, We, _lib.ptr(tr),
-                self.visibility.data_ptr(), self.incident_dirs.data_ptr(), self.incident_areas.data_ptr(),
+                self.visibility.data_ptr(), self.incident_dirs.data_ptr(),
+                None if self._uniform_area is not None else self.incident_areas.data_ptr(), self._uniform_area or 0.0,
                 taps.data_ptr(), 0, self.shade_out.data_ptr()), "shade_forward")
             _lib.check(L.r3dg_relight_pack_features(
                 stream(), P, self.xyz.data_ptr(), vm.data_ptr(), self.a_normal.data_ptr(), self.a_base.data_ptr(),

@@ -35,10 +35,11 @@ def build_taps(incident_dirs, He, We, env_transform=None):
 
 
 def shade_forward(base_color, roughness, normals, viewdirs, incidents, env, visibility, incident_dirs, incident_areas,
-                  env_transform=None, taps=None, train_outputs=False, out=None):
+                  env_transform=None, taps=None, train_outputs=False, out=None, uniform_area=None):
     """-> out[P,19] = pbr3 diffuse3 specular3 lights3 local3 global3 vis1 (see include/r3dg_hip.h).
     `taps`: build_taps(incident_dirs, He, We, env_transform) of THESE directions (skips the per-sample acos/atan2);
-    `train_outputs`: only columns 0..5 and 18 are written (what the training feature row reads)."""
+    `train_outputs`: only columns 0..5 and 18 are written (what the training feature row reads);
+    `uniform_area`: every sample's area (then `incident_areas` is not read: fibonacci_sphere_sampling gives 2*pi to all)."""
     L = _lib.lib()
     P, K = incident_dirs.shape[0], incident_dirs.shape[1]
     M = incidents.shape[1]
@@ -54,7 +55,8 @@ def shade_forward(base_color, roughness, normals, viewdirs, incidents, env, visi
         st = L.r3dg_shade_forward_cached(_lib.current_stream(), P, K, M, t[0].data_ptr(), t[1].data_ptr(),
                                          t[2].data_ptr(), t[3].data_ptr(), t[4].data_ptr(), t[5].data_ptr(), He, We,
                                          tr.data_ptr() if tr is not None else None, t[6].data_ptr(), t[7].data_ptr(),
-                                         t[8].data_ptr(), taps.data_ptr() if taps is not None else None,
+                                         None if uniform_area is not None else t[8].data_ptr(),
+                                         float(uniform_area or 0.0), taps.data_ptr() if taps is not None else None,
                                          1 if train_outputs else 0, out.data_ptr())
     _lib.check(st, "shade_forward")
     return out

@@ -23,7 +23,8 @@ for K, He in CASES:
     taps = so.build_taps(dirs, He, 2 * He)
     res = {}
     for name, kw in (("forward (all 19 outputs, lookup in kernel)", {}), ("forward (19 outputs, cached taps)", dict(taps=taps)),
-                     ("forward (train outputs, cached taps)", dict(taps=taps, train_outputs=True))):
+                     ("forward (train outputs, cached taps)", dict(taps=taps, train_outputs=True)),
+                     ("forward (train outputs, cached taps, uniform area)", dict(taps=taps, train_outputs=True, uniform_area=6.283185307179586))):
         for it in range(8):
             if it == 3:
                 torch.cuda.synchronize(); L.r3dg_profile_enable(1)
