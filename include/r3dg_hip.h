@@ -160,17 +160,22 @@ int r3dg_shade_forward(void* stream, int P, int K, int M, const float* d_base_co
  *     sample), built ONCE per visibility update by r3dg_shade_build_taps for the SAME incident_dirs, env size and
  *     env_transform -- the directions are frozen between updates (gaussian_model.py:312-342), so acos/atan2 need not be
  *     re-evaluated per iteration; NULL = evaluate the lookup in the kernel;
- *   train_outputs_only != 0: write only pbr (out[:,0:3]), diffuse_light (out[:,3:6]) and the mean visibility (out[:,18]),
+ *   flags & R3DG_SHADE_TRAIN_OUTPUTS: write only pbr (out[:,0:3]), diffuse_light (out[:,3:6]) and the mean visibility (out[:,18]),
  *     the columns the training feature row reads (neilf.py:120-122); the other 12 columns are left untouched;
  *   d_incident_areas == NULL: every sample has the area `uniform_area` (fibonacci_sphere_sampling assigns 2*pi to all of
  *     them, graphics_utils.py:36) -- saves the 4 bytes per sample of the area cache. */
+#define R3DG_SHADE_TRAIN_OUTPUTS 1
+#define R3DG_SHADE_TAPS_ARE_RADIANCE 2
 int r3dg_shade_forward_cached(void* stream, int P, int K, int M, const float* d_base_color, const float* d_roughness,
                               const float* d_normals, const float* d_viewdirs, const float* d_incidents,
                               const float* d_env, int He, int We, const float* d_env_transform,
                               const float* d_visibility, const float* d_incident_dirs, const float* d_incident_areas,
-                              float uniform_area, const uint32_t* d_taps, int train_outputs_only, float* d_out);
+                              float uniform_area, const uint32_t* d_taps, int flags, float* d_out);
+/* d_env_radiance == NULL: lookup records.  d_env_radiance = an env[He,We,3] that is NOT being trained (relighting under a fixed
+ * HDR map, envmap.py:35-53): the records hold the bilinearly sampled RADIANCE of every cached direction instead -- pass them
+ * with R3DG_SHADE_TAPS_ARE_RADIANCE and the shading kernel touches no texture at all. */
 int r3dg_shade_build_taps(void* stream, int64_t num_samples, const float* d_incident_dirs, const float* d_env_transform,
-                          int He, int We, uint32_t* d_taps);
+                          int He, int We, const float* d_env_radiance, uint32_t* d_taps);
 int r3dg_shade_backward(void* stream, int P, int K, int M, const float* d_base_color, const float* d_roughness,
                         const float* d_normals, const float* d_viewdirs, const float* d_incidents, const float* d_env,
                         int He, int We, const float* d_env_transform, const float* d_visibility,

@@ -54,8 +54,9 @@ void launch_preprocess_backward(hipStream_t s, int P, int D, int M, const float*
 void launch_shade_forward(hipStream_t s, int P, int K, int M, const float* base_color, const float* roughness,
                           const float* normals, const float* viewdirs, const float* incidents, const float* env, int He,
                           int We, const float* tr, const float* visibility, const float* dirs, const float* areas,
-                          float* out, const uint32_t* taps, bool train_outputs, float uniform_area);
-void launch_shade_build_taps(hipStream_t s, size_t n, const float* dirs, const float* tr, int He, int We, uint32_t* taps);
+                          float* out, const uint32_t* taps, bool train_outputs, float uniform_area, bool taps_are_radiance);
+void launch_shade_build_taps(hipStream_t s, size_t n, const float* dirs, const float* tr, int He, int We, const float* env,
+                             uint32_t* taps);
 extern int g_shade_fwd_rows;
 void launch_shade_backward(hipStream_t s, int P, int K, int M, const float* base_color, const float* roughness,
                            const float* normals, const float* viewdirs, const float* incidents, const float* env,
@@ -800,7 +801,7 @@ int r3dg_shade_forward_cached(void* stream_, int P, int K, int M, const float* b
                               const float* normals, const float* viewdirs, const float* incidents, const float* env,
                               int He, int We, const float* env_transform, const float* visibility,
                               const float* incident_dirs, const float* incident_areas, float uniform_area,
-                              const uint32_t* taps, int train_outputs_only, float* out)
+                              const uint32_t* taps, int flags, float* out)
 {
     if (P < 0 || K <= 0 || He <= 0 || We <= 0) return invalid("shade_forward: bad P/K/env size");
     if (He > 32767 || We > 32767) return invalid("shade_forward: environment map larger than 32767 texels per side");
@@ -812,8 +813,8 @@ int r3dg_shade_forward_cached(void* stream_, int P, int K, int M, const float* b
         hipStream_t stream = (hipStream_t)stream_;
         StageTimer t(stream, ST_SHADE_FWD);
         launch_shade_forward(stream, P, K, M, base_color, roughness, normals, viewdirs, incidents, env, He, We,
-                             env_transform, visibility, incident_dirs, incident_areas, out, taps, train_outputs_only != 0,
-                             uniform_area);
+                             env_transform, visibility, incident_dirs, incident_areas, out, taps,
+                             (flags & R3DG_SHADE_TRAIN_OUTPUTS) != 0, uniform_area, (flags & R3DG_SHADE_TAPS_ARE_RADIANCE) != 0);
         check_launch(stream, false, "shade_forward");
         t.stop();
         return R3DG_OK;
@@ -830,13 +831,14 @@ int r3dg_shade_forward(void* stream_, int P, int K, int M, const float* base_col
 }
 
 int r3dg_shade_build_taps(void* stream_, int64_t num_samples, const float* incident_dirs, const float* env_transform,
-                          int He, int We, uint32_t* taps)
+                          int He, int We, const float* env_radiance, uint32_t* taps)
 {
     if (num_samples < 0 || He <= 0 || We <= 0 || He > 32767 || We > 32767) return invalid("shade_build_taps: bad sizes");
     if (num_samples == 0) return R3DG_OK;
     if (!incident_dirs || !taps) return invalid("shade_build_taps: null buffer");
     return guarded([&]() -> int {
-        launch_shade_build_taps((hipStream_t)stream_, (size_t)num_samples, incident_dirs, env_transform, He, We, taps);
+        launch_shade_build_taps((hipStream_t)stream_, (size_t)num_samples, incident_dirs, env_transform, He, We,
+                                env_radiance, taps);
         return R3DG_OK;
     });
 }

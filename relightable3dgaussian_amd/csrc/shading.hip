@@ -92,7 +92,7 @@ __device__ __forceinline__ float fast_atan2f(float y, float x)
     r = hi ? r + 0.7853981633974483f : r;
     r = ay > ax ? 1.5707963267948966f - r : r;
     r = x < 0.f ? 3.14159265358979323846f - r : r;
-    return y < 0.f ? -r : r;
+    return __uint_as_float(__float_as_uint(r) | (__float_as_uint(y) & 0x80000000u));     // copysign: atan2(-0, x<0) = -pi
 }
 
 struct EnvTap {
@@ -546,16 +546,39 @@ __device__ __forceinline__ PackedTap make_tap(float dx, float dy, float dz, cons
     return t;
 }
 
+// env == nullptr: the 12-byte lookup record (texel corner + weights).  env != nullptr: the looked-up RADIANCE itself (three
+// floats) -- for a light that is not being trained (relighting under a fixed HDR map) the bilinear sample of every cached
+// direction is a constant too, and the shading kernel then needs no texture access at all.
 __global__ void __launch_bounds__(256)
 shade_build_taps_kernel(size_t n, const float* __restrict__ dirs, const float* __restrict__ tr, int He, int We,
-                        uint32_t* __restrict__ taps)
+                        const float* __restrict__ env, uint32_t* __restrict__ taps)
 {
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
     const PackedTap t = make_tap(dirs[3 * i], dirs[3 * i + 1], dirs[3 * i + 2], tr, He, We);
-    taps[3 * i] = t.xy;
-    taps[3 * i + 1] = __float_as_uint(t.wx1);
-    taps[3 * i + 2] = __float_as_uint(t.wy1);
+    if (env == nullptr) {
+        taps[3 * i] = t.xy;
+        taps[3 * i + 1] = __float_as_uint(t.wx1);
+        taps[3 * i + 2] = __float_as_uint(t.wy1);
+        return;
+    }
+    const int x0 = (int)(t.xy & 0xffffu) - 1, y0 = (int)(t.xy >> 16) - 1;
+    const float wx[2] = {1.f - t.wx1, t.wx1}, wy[2] = {1.f - t.wy1, t.wy1};
+    float e[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+    for (int a = 0; a < 2; a++)
+#pragma unroll
+        for (int b = 0; b < 2; b++) {
+            const int x = x0 + b, y = y0 + a;
+            if (x >= 0 && x <= We - 1 && y >= 0 && y <= He - 1) {
+                const float* px = env + 3 * ((size_t)y * We + x);
+                const float w = wy[a] * wx[b];
+                e[0] += px[0] * w; e[1] += px[1] * w; e[2] += px[2] * w;
+            }
+        }
+    taps[3 * i] = __float_as_uint(e[0]);
+    taps[3 * i + 1] = __float_as_uint(e[1]);
+    taps[3 * i + 2] = __float_as_uint(e[2]);
 }
 
 // bilinear sample with zero padding (grid_sample align_corners=True, padding_mode zeros) from a packed tap; the texture
@@ -589,7 +612,7 @@ struct RowSample {            // one lane's share of a (Gaussian, 64-sample bloc
 
 // `g` is wave-uniform (callers derive it from readfirstlane'd values): the row bases are computed on the scalar unit and the
 // loads address SGPR base + 32-bit lane offset
-template <bool TAPS>
+template <int TAPS>
 __device__ __forceinline__ RowSample load_row_sample(bool live, int g, int lane, unsigned k, int K,
                                                      const float* __restrict__ rec, const float* __restrict__ dirs,
                                                      const float* __restrict__ visibility,
@@ -622,7 +645,7 @@ __device__ __forceinline__ RowSample load_row_sample(bool live, int g, int lane,
 // Software pipeline per wave: [wait for block i's samples] -> [issue the loads of block i+1: they fly during the ~250
 // instructions below] -> [record of block i: one ds_write_b32 per lane, read back as wave-uniform broadcasts] -> compute ->
 // (last block of the Gaussian) transposing wave reduction + store.
-template <int NOUT, bool ENV_LDS, bool TAPS, bool M16>
+template <int NOUT, bool ENV_LDS, int TAPS /* 0 lookup in kernel, 1 cached lookup, 2 cached radiance */, bool M16>
 __global__ void __launch_bounds__(64 * ROW_WAVES)
 shade_forward_row_kernel(int P, int K, int M_, const float* __restrict__ rec, const float4* __restrict__ env4, int He, int We,
                          const float* __restrict__ tr, const float* __restrict__ visibility,
@@ -636,7 +659,7 @@ shade_forward_row_kernel(int P, int K, int M_, const float* __restrict__ rec, co
     extern __shared__ __attribute__((aligned(16))) float s_mem[];
     __shared__ __attribute__((aligned(16))) float s_rec[ROW_WAVES][REC];
     float4* s_env4 = reinterpret_cast<float4*>(s_mem);
-    if (ENV_LDS) {
+    if (ENV_LDS && TAPS != 2) {
         for (int i = threadIdx.x; i < He * We; i += blockDim.x) s_env4[i] = env4[i];
         __syncthreads();
     }
@@ -686,10 +709,14 @@ shade_forward_row_kernel(int P, int K, int M_, const float* __restrict__ rec, co
             const float dx = cur.dx, dy = cur.dy, dz = cur.dz, vis = cur.vis, area = cur.area;
             const bool live = kb * 64 + lane < K;
             PackedTap t = cur.t;
-            if (!TAPS) t = make_tap(dx, dy, dz, tr, He, We);
+            if (TAPS == 0) t = make_tap(dx, dy, dz, tr, He, We);
             float e[3], w4[4];
             int tex[4];
-            env_fetch(t, tex4, He, We, e, tex, w4);
+            if (TAPS == 2) {
+                e[0] = __uint_as_float(t.xy); e[1] = t.wx1; e[2] = t.wy1;
+            } else {
+                env_fetch(t, tex4, He, We, e, tex, w4);
+            }
             // local incident light: max(sum_i Y_i(d) c_i, 0); coefficients = wave-uniform broadcast reads (12 per 64 samples)
             float Y[16];
             sh_basis16(dx, dy, dz, M, Y);
@@ -1070,10 +1097,11 @@ static float* shade_records(size_t P)
 
 int g_shade_fwd_rows = 1;    // r3dg_set_tuning7: 1 = row kernels (wave per Gaussian), 0 = the 16-lane kernel
 
-void launch_shade_build_taps(hipStream_t s, size_t n, const float* dirs, const float* tr, int He, int We, uint32_t* taps)
+void launch_shade_build_taps(hipStream_t s, size_t n, const float* dirs, const float* tr, int He, int We, const float* env,
+                             uint32_t* taps)
 {
     if (n == 0) return;
-    shade_build_taps_kernel<<<(unsigned)((n + 255) / 256), 256, 0, s>>>(n, dirs, tr, He, We, taps);
+    shade_build_taps_kernel<<<(unsigned)((n + 255) / 256), 256, 0, s>>>(n, dirs, tr, He, We, env, taps);
     check_launch(s, false, "shade_build_taps_kernel");
 }
 
@@ -1082,7 +1110,7 @@ void launch_shade_build_taps(hipStream_t s, size_t n, const float* dirs, const f
 void launch_shade_forward(hipStream_t s, int P, int K, int M, const float* base_color, const float* roughness,
                           const float* normals, const float* viewdirs, const float* incidents, const float* env, int He,
                           int We, const float* tr, const float* visibility, const float* dirs, const float* areas,
-                          float* out, const uint32_t* taps, bool train_outputs, float uniform_area)
+                          float* out, const uint32_t* taps, bool train_outputs, float uniform_area, bool taps_are_radiance)
 {
     if (P == 0) return;
     if (areas == nullptr && !g_shade_fwd_rows) throw std::runtime_error("shade_forward: the 16-lane kernel needs incident_areas");
@@ -1103,7 +1131,8 @@ void launch_shade_forward(hipStream_t s, int P, int K, int M, const float* base_
     float4* env4 = reinterpret_cast<float4*>(rec + (size_t)P * REC);
     shade_prepare_kernel<<<(P + 63) / 64, 256, 0, s>>>(P, M, base_color, roughness, normals, viewdirs, incidents, rec);
     shade_pad_env_kernel<<<(int)((ntexel + 255) / 256), 256, 0, s>>>((int)ntexel, env, env4);
-    const bool lds = He * We * 4 <= ENV_LDS_MAX;                      // float4 per texel
+    const int mode = taps == nullptr ? 0 : (taps_are_radiance ? 2 : 1);
+    const bool lds = mode != 2 && He * We * 4 <= ENV_LDS_MAX;          // float4 per texel
     const size_t smem = lds ? ntexel * sizeof(float4) : 0;
     const int want = (P + ROW_WAVES - 1) / ROW_WAVES;
 #define R3DG_ROW(N, L, T)                                                                                             \
@@ -1130,14 +1159,13 @@ void launch_shade_forward(hipStream_t s, int P, int K, int M, const float* base_
             shade_forward_row_kernel<N, L, T, false><<<grid, 64 * ROW_WAVES, smem, s>>>(                              \
                 P, K, M, rec, env4, He, We, tr, visibility, dirs, areas, uniform_area, taps, out);                    \
     } while (0)
-    const bool have = taps != nullptr;
-    if (train_outputs) {
-        if (lds) { if (have) R3DG_ROW(7, true, true); else R3DG_ROW(7, true, false); }
-        else { if (have) R3DG_ROW(7, false, true); else R3DG_ROW(7, false, false); }
-    } else {
-        if (lds) { if (have) R3DG_ROW(19, true, true); else R3DG_ROW(19, true, false); }
-        else { if (have) R3DG_ROW(19, false, true); else R3DG_ROW(19, false, false); }
-    }
+#define R3DG_ROW_MODE(N, L)                                                                                           \
+    do {                                                                                                              \
+        if (mode == 0) R3DG_ROW(N, L, 0); else if (mode == 1) R3DG_ROW(N, L, 1); else R3DG_ROW(N, L, 2);              \
+    } while (0)
+    if (train_outputs) { if (lds) R3DG_ROW_MODE(7, true); else R3DG_ROW_MODE(7, false); }
+    else { if (lds) R3DG_ROW_MODE(19, true); else R3DG_ROW_MODE(19, false); }
+#undef R3DG_ROW_MODE
 #undef R3DG_ROW
 }
 

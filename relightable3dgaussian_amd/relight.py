@@ -65,9 +65,12 @@ class RelightRenderer:
         a static light costs one build and a rotating light (relighting.py's light trajectories) one build per frame --
         the same acos/atan2 the kernel would otherwise evaluate, written once instead of recomputed."""
         # (no read-back of the matrix: the key is the tensor's identity + version counter)
-        key = (None if tr is None else (tr.data_ptr(), tr._version), He, We, self.incident_dirs.data_ptr())
+        key = (None if tr is None else (tr.data_ptr(), tr._version), He, We, self.incident_dirs.data_ptr(),
+               self.envmap.data_ptr(), self.envmap._version)
         if getattr(self, "_taps_key", None) != key:
-            self._taps = shading_ops.build_taps(self.incident_dirs, He, We, tr)
+            # the HDR map is fixed while relighting, so the SAMPLED RADIANCE of every cached direction is cached (not just
+            # the lookup coordinates): the shading kernel then reads 12 bytes per sample and no texture
+            self._taps = shading_ops.build_taps(self.incident_dirs, He, We, tr, radiance_of=self.envmap)
             self._taps_key = key
             if getattr(self, "_area_key", None) != self.incident_areas.data_ptr():
                 # fibonacci_sphere_sampling gives every sample the area 2 pi: then the area cache need not be read at all
@@ -109,7 +112,7 @@ class RelightRenderer:
                 self.a_viewdirs.data_ptr(), self.incidents.data_ptr(), self.envmap.data_ptr(), He, We, _lib.ptr(tr),
                 self.visibility.data_ptr(), self.incident_dirs.data_ptr(),
                 None if self._uniform_area is not None else self.incident_areas.data_ptr(), self._uniform_area or 0.0,
-                taps.data_ptr(), 0, self.shade_out.data_ptr()), "shade_forward")
+                taps.data_ptr(), 2, self.shade_out.data_ptr()), "shade_forward")       # 2 = R3DG_SHADE_TAPS_ARE_RADIANCE
             _lib.check(L.r3dg_relight_pack_features(
                 stream(), P, self.xyz.data_ptr(), vm.data_ptr(), self.a_normal.data_ptr(), self.a_base.data_ptr(),
                 self.a_rough.data_ptr(), self.shade_out.data_ptr(), self.features.data_ptr()), "relight_pack_features")

@@ -19,23 +19,27 @@ def _c(t):
     return t.contiguous()
 
 
-def build_taps(incident_dirs, He, We, env_transform=None):
+def build_taps(incident_dirs, He, We, env_transform=None, radiance_of=None):
     """Lat-long lookup of every cached direction (texel corner + two bilinear weights; int32 [..., 3] holding the 12-byte
     records of r3dg_shade_build_taps) for an environment texture of He x We texels and this `env_transform`.  Valid as
-    long as `incident_dirs` is (the directions are frozen between visibility updates, gaussian_model.py:312-342)."""
+    long as `incident_dirs` is (the directions are frozen between visibility updates, gaussian_model.py:312-342).
+    `radiance_of` = a FIXED env[He,We,3] (not trained: relighting): the records hold the sampled radiance instead; pass them
+    to shade_forward with taps_are_radiance=True."""
     L = _lib.lib()
     d = _c(incident_dirs)
     tr = _c(env_transform) if env_transform is not None else None
     taps = torch.empty(d.shape, dtype=torch.int32, device=d.device)
     with torch.cuda.device(d.device):
+        env = _c(radiance_of) if radiance_of is not None else None
         st = L.r3dg_shade_build_taps(_lib.current_stream(), d.numel() // 3, d.data_ptr(),
-                                     tr.data_ptr() if tr is not None else None, int(He), int(We), taps.data_ptr())
+                                     tr.data_ptr() if tr is not None else None, int(He), int(We),
+                                     env.data_ptr() if env is not None else None, taps.data_ptr())
     _lib.check(st, "shade_build_taps")
     return taps
 
 
 def shade_forward(base_color, roughness, normals, viewdirs, incidents, env, visibility, incident_dirs, incident_areas,
-                  env_transform=None, taps=None, train_outputs=False, out=None, uniform_area=None):
+                  env_transform=None, taps=None, train_outputs=False, out=None, uniform_area=None, taps_are_radiance=False):
     """-> out[P,19] = pbr3 diffuse3 specular3 lights3 local3 global3 vis1 (see include/r3dg_hip.h).
     `taps`: build_taps(incident_dirs, He, We, env_transform) of THESE directions (skips the per-sample acos/atan2);
     `train_outputs`: only columns 0..5 and 18 are written (what the training feature row reads);
@@ -57,7 +61,7 @@ def shade_forward(base_color, roughness, normals, viewdirs, incidents, env, visi
                                          tr.data_ptr() if tr is not None else None, t[6].data_ptr(), t[7].data_ptr(),
                                          None if uniform_area is not None else t[8].data_ptr(),
                                          float(uniform_area or 0.0), taps.data_ptr() if taps is not None else None,
-                                         1 if train_outputs else 0, out.data_ptr())
+                                         (1 if train_outputs else 0) | (2 if taps_are_radiance else 0), out.data_ptr())
     _lib.check(st, "shade_forward")
     return out
 

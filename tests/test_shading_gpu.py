@@ -158,7 +158,9 @@ def test_shading_forward_variants_agree(P, K, He, transform):
     args = (d["base_color"], d["roughness"], d["normals"], d["viewdirs"], d["incidents"], d["env"], d["visibility"],
             d["incident_dirs"], d["incident_areas"], trd)
     taps = so.build_taps(d["incident_dirs"], He, 2 * He, trd)
-    outs = {"rows": so.shade_forward(*args), "rows+taps": so.shade_forward(*args, taps=taps)}
+    outs = {"rows": so.shade_forward(*args), "rows+taps": so.shade_forward(*args, taps=taps),
+            "rows+radiance": so.shade_forward(*args, taps=so.build_taps(d["incident_dirs"], He, 2 * He, trd, radiance_of=d["env"]),
+                                              taps_are_radiance=True)}
     sentinel = torch.full((P, so.NOUT), -7.0, device=DEV)
     outs["rows+taps+train"] = so.shade_forward(*args, taps=taps, train_outputs=True, out=sentinel.clone())
     try:

@@ -21,10 +21,12 @@ for K, He in CASES:
     env = torch.rand(He, 2 * He, 3, device=dev)
     gp, gd = torch.randn(P, 3, device=dev), torch.randn(P, 3, device=dev)
     taps = so.build_taps(dirs, He, 2 * He)
+    rad = so.build_taps(dirs, He, 2 * He, radiance_of=env)
     res = {}
     for name, kw in (("forward (all 19 outputs, lookup in kernel)", {}), ("forward (19 outputs, cached taps)", dict(taps=taps)),
                      ("forward (train outputs, cached taps)", dict(taps=taps, train_outputs=True)),
-                     ("forward (train outputs, cached taps, uniform area)", dict(taps=taps, train_outputs=True, uniform_area=6.283185307179586))):
+                     ("forward (train outputs, cached taps, uniform area)", dict(taps=taps, train_outputs=True, uniform_area=6.283185307179586)),
+                     ("forward (19 outputs, cached radiance, uniform area)", dict(taps=rad, taps_are_radiance=True, uniform_area=6.283185307179586))):
         for it in range(8):
             if it == 3:
                 torch.cuda.synchronize(); L.r3dg_profile_enable(1)
