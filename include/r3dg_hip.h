@@ -166,6 +166,7 @@ int r3dg_shade_forward(void* stream, int P, int K, int M, const float* d_base_co
  *     them, graphics_utils.py:36) -- saves the 4 bytes per sample of the area cache. */
 #define R3DG_SHADE_TRAIN_OUTPUTS 1
 #define R3DG_SHADE_TAPS_ARE_RADIANCE 2
+#define R3DG_SHADE_LEAVE_ROOM 4      /* the caller runs other kernels beside this one: occupy half of each CU */
 int r3dg_shade_forward_cached(void* stream, int P, int K, int M, const float* d_base_color, const float* d_roughness,
                               const float* d_normals, const float* d_viewdirs, const float* d_incidents,
                               const float* d_env, int He, int We, const float* d_env_transform,
@@ -457,8 +458,10 @@ int r3dg_set_tuning5(int stage_sh_rows);
 /* r3dg_set_tuning6: persistent workgroups per CU of the shading forward kernel (1..8; its 162 VGPRs allow 3 per CU). */
 int r3dg_set_tuning6(int shade_forward_blocks_per_cu);
 /* r3dg_set_tuning7: shading forward formulation: 1 (default) = row kernels (one wave per Gaussian, lane = sample, per-Gaussian
- * records through scalar loads), 0 = the round-1 kernel (16 lanes per Gaussian).  Same results within fp32 rounding. */
-int r3dg_set_tuning7(int shade_forward_rows);
+ * records), 0 = the round-1 kernel (16 lanes per Gaussian); same results within fp32 rounding.  row_blocks_per_cu: persistent
+ * row-kernel workgroups per CU (0 = as many as fit; fewer leave room for the instance ordering that runs beside it).
+ * Negative arguments leave a setting unchanged. */
+int r3dg_set_tuning7(int shade_forward_rows, int row_blocks_per_cu);
 int r3dg_selftest_transpose_reduce(void* stream, int N, int dpp, const float* d_in, float* d_out, int* d_chan,
                                    int* d_owner);
 

@@ -457,7 +457,7 @@ def run(args):
     torch.cuda.set_device(dev)
     L = _lib.lib()
     if os.environ.get("R3DG_SHADE_FWD_BPC"):             # tuning experiments only
-        L.r3dg_set_tuning6(int(os.environ["R3DG_SHADE_FWD_BPC"]))
+        L.r3dg_set_tuning7(-1, int(os.environ["R3DG_SHADE_FWD_BPC"]))
 
     stage2 = args.stage == 2
     scene = syn.make_scene(P=args.points, seed=0, stage2=stage2)

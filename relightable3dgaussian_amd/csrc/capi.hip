@@ -54,10 +54,12 @@ void launch_preprocess_backward(hipStream_t s, int P, int D, int M, const float*
 void launch_shade_forward(hipStream_t s, int P, int K, int M, const float* base_color, const float* roughness,
                           const float* normals, const float* viewdirs, const float* incidents, const float* env, int He,
                           int We, const float* tr, const float* visibility, const float* dirs, const float* areas,
-                          float* out, const uint32_t* taps, bool train_outputs, float uniform_area, bool taps_are_radiance);
+                          float* out, const uint32_t* taps, bool train_outputs, float uniform_area, bool taps_are_radiance,
+                          bool leave_room);
 void launch_shade_build_taps(hipStream_t s, size_t n, const float* dirs, const float* tr, int He, int We, const float* env,
                              uint32_t* taps);
 extern int g_shade_fwd_rows;
+extern int g_shade_row_blocks_per_cu;
 void launch_shade_backward(hipStream_t s, int P, int K, int M, const float* base_color, const float* roughness,
                            const float* normals, const float* viewdirs, const float* incidents, const float* env,
                            int He, int We, const float* tr, const float* visibility, const float* dirs,
@@ -814,7 +816,8 @@ int r3dg_shade_forward_cached(void* stream_, int P, int K, int M, const float* b
         StageTimer t(stream, ST_SHADE_FWD);
         launch_shade_forward(stream, P, K, M, base_color, roughness, normals, viewdirs, incidents, env, He, We,
                              env_transform, visibility, incident_dirs, incident_areas, out, taps,
-                             (flags & R3DG_SHADE_TRAIN_OUTPUTS) != 0, uniform_area, (flags & R3DG_SHADE_TAPS_ARE_RADIANCE) != 0);
+                             (flags & R3DG_SHADE_TRAIN_OUTPUTS) != 0, uniform_area, (flags & R3DG_SHADE_TAPS_ARE_RADIANCE) != 0,
+                             (flags & R3DG_SHADE_LEAVE_ROOM) != 0);
         check_launch(stream, false, "shade_forward");
         t.stop();
         return R3DG_OK;
@@ -843,9 +846,10 @@ int r3dg_shade_build_taps(void* stream_, int64_t num_samples, const float* incid
     });
 }
 
-int r3dg_set_tuning7(int shade_forward_rows)
+int r3dg_set_tuning7(int shade_forward_rows, int row_blocks_per_cu)
 {
     if (shade_forward_rows >= 0) g_shade_fwd_rows = shade_forward_rows ? 1 : 0;
+    if (row_blocks_per_cu >= 0) g_shade_row_blocks_per_cu = row_blocks_per_cu;
     return R3DG_OK;
 }
 

@@ -1096,6 +1096,7 @@ static float* shade_records(size_t P)
 }
 
 int g_shade_fwd_rows = 1;    // r3dg_set_tuning7: 1 = row kernels (wave per Gaussian), 0 = the 16-lane kernel
+int g_shade_row_blocks_per_cu = 0;   // r3dg_set_tuning7 (second argument): persistent row blocks per CU, 0 = all that fit
 
 void launch_shade_build_taps(hipStream_t s, size_t n, const float* dirs, const float* tr, int He, int We, const float* env,
                              uint32_t* taps)
@@ -1110,7 +1111,8 @@ void launch_shade_build_taps(hipStream_t s, size_t n, const float* dirs, const f
 void launch_shade_forward(hipStream_t s, int P, int K, int M, const float* base_color, const float* roughness,
                           const float* normals, const float* viewdirs, const float* incidents, const float* env, int He,
                           int We, const float* tr, const float* visibility, const float* dirs, const float* areas,
-                          float* out, const uint32_t* taps, bool train_outputs, float uniform_area, bool taps_are_radiance)
+                          float* out, const uint32_t* taps, bool train_outputs, float uniform_area, bool taps_are_radiance,
+                          bool leave_room)
 {
     if (P == 0) return;
     if (areas == nullptr && !g_shade_fwd_rows) throw std::runtime_error("shade_forward: the 16-lane kernel needs incident_areas");
@@ -1150,7 +1152,12 @@ void launch_shade_forward(hipStream_t s, int P, int K, int M, const float* base_
             nb = nb < by_vgpr ? nb : by_vgpr;                                                                         \
             per_cu[L] = nb > 0 ? (nb < 8 ? nb : 8) : 1;                                                               \
         }                                                                                                             \
-        const int cap = shade_cus() * per_cu[L];                                                                      \
+        int bpc = g_shade_row_blocks_per_cu > 0 && g_shade_row_blocks_per_cu < per_cu[L] ? g_shade_row_blocks_per_cu   \
+                                                                                         : per_cu[L];                 \
+        /* beside the instance ordering (fused iteration): 3 of the ~6 resident blocks per CU measured best for the     \
+           iteration as a whole (2.05 -> 1.97 ms: the ordering kernels get CU time earlier) */                        \
+        if (leave_room && g_shade_row_blocks_per_cu == 0 && bpc > 3) bpc = 3;                                         \
+        const int cap = shade_cus() * bpc;                                                                            \
         const int grid = want < cap ? want : cap;                                                                     \
         if (M == 16)                                                                                                  \
             shade_forward_row_kernel<N, L, T, true><<<grid, 64 * ROW_WAVES, smem, s>>>(                               \

@@ -250,7 +250,8 @@ class FusedStage2Step:
                 self.a_viewdirs.data_ptr(), self.incidents.data_ptr(), env_c.data_ptr(), He, We, None,
                 self.visibility.data_ptr(), self.incident_dirs.data_ptr(),
                 None if self._uniform_area is not None else self.incident_areas.data_ptr(), self._uniform_area or 0.0,
-                taps.data_ptr(), 1, self.shade_out.data_ptr()), "shade_forward")   # pbr, diffuse_light, mean visibility
+                taps.data_ptr(), 1 | (4 if self._order_stream is not None else 0),         # train outputs | leave room
+                self.shade_out.data_ptr()), "shade_forward")
             self.sums.zero_()
             _lib.check(L.r3dg_stage2_pack_features(
                 stream(), P, self.xyz.data_ptr(), vm.data_ptr(), self.a_normal.data_ptr(), self.a_base.data_ptr(),

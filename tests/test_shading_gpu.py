@@ -164,10 +164,10 @@ def test_shading_forward_variants_agree(P, K, He, transform):
     sentinel = torch.full((P, so.NOUT), -7.0, device=DEV)
     outs["rows+taps+train"] = so.shade_forward(*args, taps=taps, train_outputs=True, out=sentinel.clone())
     try:
-        _lib.lib().r3dg_set_tuning7(0)
+        _lib.lib().r3dg_set_tuning7(0, -1)
         outs["16-lane"] = so.shade_forward(*args)
     finally:
-        _lib.lib().r3dg_set_tuning7(1)
+        _lib.lib().r3dg_set_tuning7(1, -1)
     torch.cuda.synchronize()
     cols = [0, 1, 2, 3, 4, 5, 18]
     for name, got in outs.items():

@@ -8,7 +8,7 @@ L = _lib.lib()
 if "FWD_BPC" in os.environ:
     L.r3dg_set_tuning6(int(os.environ["FWD_BPC"]))
 if "ROWS" in os.environ:
-    L.r3dg_set_tuning7(int(os.environ["ROWS"]))
+    L.r3dg_set_tuning7(int(os.environ["ROWS"]), -1)
 g = torch.Generator().manual_seed(0)
 CASES = ((64, 16),) if os.environ.get("ONLY64") else ((64, 16), (384, 256))
 for K, He in CASES:
