@@ -184,6 +184,16 @@ int r3dg_shade_backward(void* stream, int P, int K, int M, const float* d_base_c
                         const float* d_dL_ddiffuse_light, float* d_dL_dbase_color, float* d_dL_droughness,
                         float* d_dL_dviewdirs, float* d_dL_dincidents, float* d_dL_denv);
 
+/* r3dg_shade_backward with the cached lookup records of r3dg_shade_build_taps (lookup mode, NOT radiance: the texture's
+ * gradient needs the texel indices); d_taps == NULL = r3dg_shade_backward. */
+int r3dg_shade_backward_cached(void* stream, int P, int K, int M, const float* d_base_color, const float* d_roughness,
+                               const float* d_normals, const float* d_viewdirs, const float* d_incidents,
+                               const float* d_env, int He, int We, const float* d_env_transform,
+                               const float* d_visibility, const float* d_incident_dirs, const float* d_incident_areas,
+                               const uint32_t* d_taps, const float* d_dL_dpbr, const float* d_dL_ddiffuse_light,
+                               float* d_dL_dbase_color, float* d_dL_droughness, float* d_dL_dviewdirs,
+                               float* d_dL_dincidents, float* d_dL_denv);
+
 /* The reference's render_equation.{cu,h} contract model (render_equation.h:7-46): metallic BRDF with a spherical-
  * Gaussian D, SH environment light direct_shs[Sd,3] (+0.5), SH visibility visibility_shs[P,Sv] (+0.5, clamped), SH local
  * light incidents_shs[P,Si,3]; rays are the Fibonacci set rotated to the normal (no 10-degree floor), optionally with

@@ -55,6 +55,8 @@ _SIGNATURES = {
     "r3dg_shade_build_taps": (_i, [_p, C.c_int64, _p, _p, _i, _i, _p, _p]),
     "r3dg_shade_backward": (_i, [_p, _i, _i, _i, _p, _p, _p, _p, _p, _p, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p,
                                  _p, _p]),
+    "r3dg_shade_backward_cached": (_i, [_p, _i, _i, _i, _p, _p, _p, _p, _p, _p, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p,
+                                        _p, _p, _p]),
     "r3dg_render_equation_forward": (_i, [_p, _i, _i, _i, _i] + [_p] * 8 + [_i] + [_p] * 4),
     "r3dg_render_equation_forward_complex": (_i, [_p, _i, _i, _i, _i] + [_p] * 8 + [_i] + [_p] * 11),
     "r3dg_render_equation_backward": (_i, [_p, _i, _i, _i, _i] + [_p] * 8 + [_i] + [_p] * 11),

@@ -64,7 +64,7 @@ void launch_shade_backward(hipStream_t s, int P, int K, int M, const float* base
                            const float* normals, const float* viewdirs, const float* incidents, const float* env,
                            int He, int We, const float* tr, const float* visibility, const float* dirs,
                            const float* areas, const float* g_pbr, const float* g_diff, float* d_base, float* d_rough,
-                           float* d_view, float* d_inc, float* d_env);
+                           float* d_view, float* d_inc, float* d_env, const uint32_t* taps);
 void launch_re_forward(hipStream_t s, bool complex_, int P, int Si, int Sd, int Sv, const float* base_color,
                        const float* roughness, const float* metallic, const float* normals, const float* viewdirs,
                        const float* inc, const float* direct, const float* vis, int K, const float* rand_float,
@@ -853,14 +853,15 @@ int r3dg_set_tuning7(int shade_forward_rows, int row_blocks_per_cu)
     return R3DG_OK;
 }
 
-int r3dg_shade_backward(void* stream_, int P, int K, int M, const float* base_color, const float* roughness,
-                        const float* normals, const float* viewdirs, const float* incidents, const float* env, int He,
-                        int We, const float* env_transform, const float* visibility, const float* incident_dirs,
-                        const float* incident_areas, const float* dL_dpbr, const float* dL_ddiffuse_light,
-                        float* dL_dbase_color, float* dL_droughness, float* dL_dviewdirs, float* dL_dincidents,
-                        float* dL_denv)
+int r3dg_shade_backward_cached(void* stream_, int P, int K, int M, const float* base_color, const float* roughness,
+                               const float* normals, const float* viewdirs, const float* incidents, const float* env,
+                               int He, int We, const float* env_transform, const float* visibility,
+                               const float* incident_dirs, const float* incident_areas, const uint32_t* taps,
+                               const float* dL_dpbr, const float* dL_ddiffuse_light, float* dL_dbase_color,
+                               float* dL_droughness, float* dL_dviewdirs, float* dL_dincidents, float* dL_denv)
 {
     if (P < 0 || K <= 0 || He <= 0 || We <= 0) return invalid("shade_backward: bad P/K/env size");
+    if (He > 32767 || We > 32767) return invalid("shade_backward: environment map larger than 32767 texels per side");
     if (M != 1 && M != 4 && M != 9 && M != 16) return invalid("shade_backward: incidents must hold 1, 4, 9 or 16 SH coefficients");
     if (P == 0) return R3DG_OK;
     return guarded([&]() -> int {
@@ -868,11 +869,23 @@ int r3dg_shade_backward(void* stream_, int P, int K, int M, const float* base_co
         StageTimer t(stream, ST_SHADE_BWD);
         launch_shade_backward(stream, P, K, M, base_color, roughness, normals, viewdirs, incidents, env, He, We,
                               env_transform, visibility, incident_dirs, incident_areas, dL_dpbr, dL_ddiffuse_light,
-                              dL_dbase_color, dL_droughness, dL_dviewdirs, dL_dincidents, dL_denv);
+                              dL_dbase_color, dL_droughness, dL_dviewdirs, dL_dincidents, dL_denv, taps);
         check_launch(stream, false, "shade_backward");
         t.stop();
         return R3DG_OK;
     });
+}
+
+int r3dg_shade_backward(void* stream_, int P, int K, int M, const float* base_color, const float* roughness,
+                        const float* normals, const float* viewdirs, const float* incidents, const float* env, int He,
+                        int We, const float* env_transform, const float* visibility, const float* incident_dirs,
+                        const float* incident_areas, const float* dL_dpbr, const float* dL_ddiffuse_light,
+                        float* dL_dbase_color, float* dL_droughness, float* dL_dviewdirs, float* dL_dincidents,
+                        float* dL_denv)
+{
+    return r3dg_shade_backward_cached(stream_, P, K, M, base_color, roughness, normals, viewdirs, incidents, env, He, We,
+                                      env_transform, visibility, incident_dirs, incident_areas, nullptr, dL_dpbr,
+                                      dL_ddiffuse_light, dL_dbase_color, dL_droughness, dL_dviewdirs, dL_dincidents, dL_denv);
 }
 
 static int re_check(int P, int Si, int Sd, int Sv, int K)

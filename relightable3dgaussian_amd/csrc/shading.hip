@@ -132,6 +132,52 @@ __device__ __forceinline__ EnvTap env_taps(float dx, float dy, float dz, const f
     return t;
 }
 
+struct PackedTap {           // 12 bytes per cached sample
+    uint32_t xy;             // (x0 + 1) | (y0 + 1) << 16, (x0, y0) = floor of the lat-long pixel coordinate (>= -1)
+    float wx1, wy1;          // bilinear weights of column x0 + 1 / row y0 + 1
+};
+
+__device__ __forceinline__ PackedTap make_tap(float dx, float dy, float dz, const float* __restrict__ tr, int He, int We)
+{
+    if (tr != nullptr) {
+        const float tx = dx * tr[0] + dy * tr[1] + dz * tr[2];
+        const float ty = dx * tr[3] + dy * tr[4] + dz * tr[5];
+        const float tz = dx * tr[6] + dy * tr[7] + dz * tr[8];
+        dx = tx; dy = ty; dz = tz;
+    }
+    const float phi = fast_acosf(dz) - 1e-6f;
+    const float theta = fast_atan2f(dy, dx);
+    const float qy = (phi / kPi) * 2.f - 1.f;
+    const float qx = -theta / kPi;
+    const float ix = (qx + 1.f) * 0.5f * (float)(We - 1);
+    const float iy = (qy + 1.f) * 0.5f * (float)(He - 1);
+    const float x0f = floorf(ix), y0f = floorf(iy);
+    PackedTap t;
+    t.wx1 = ix - x0f;
+    t.wy1 = iy - y0f;
+    const int x0 = max((int)x0f, -1), y0 = max((int)y0f, -1);
+    t.xy = (uint32_t)(x0 + 1) | ((uint32_t)(y0 + 1) << 16);
+    return t;
+}
+
+// cached lookup record -> the four (texel, weight) taps of env_taps (texel -1 = zero padding)
+__device__ __forceinline__ EnvTap taps_from_packed(const PackedTap& t, int He, int We)
+{
+    const int x0 = (int)(t.xy & 0xffffu) - 1, y0 = (int)(t.xy >> 16) - 1;
+    const float wx[2] = {1.f - t.wx1, t.wx1}, wy[2] = {1.f - t.wy1, t.wy1};
+    EnvTap o;
+#pragma unroll
+    for (int a = 0; a < 2; a++)
+#pragma unroll
+        for (int b = 0; b < 2; b++) {
+            const int x = x0 + b, y = y0 + a;
+            const bool ok = x >= 0 && x <= We - 1 && y >= 0 && y <= He - 1;
+            o.idx[a * 2 + b] = ok ? __mul24(y, We) + x : -1;
+            o.w[a * 2 + b] = wy[a] * wx[b];
+        }
+    return o;
+}
+
 struct SampleFwd {
     float local[3], glob[3], lin[3], transport[3];
     float spec, ndi, area_ndi;
@@ -212,14 +258,15 @@ __device__ __forceinline__ void sh_local_sum(const float* sh /*[48] in LDS, zero
     }
 }
 
-template <bool ENV_LDS, bool HAVE_SHSUM = false>
+template <bool ENV_LDS, bool HAVE_SHSUM = false, bool HAVE_TAP = false>
 __device__ __forceinline__ void shade_sample(SampleFwd& s, const GaussFwd& G, const float* sh /*[48] in LDS, zero padded*/,
                                              int M, float dx, float dy, float dz, float vis, float area,
                                              const float* __restrict__ env, const float* s_env,
-                                             const float* __restrict__ tr, int He, int We)
+                                             const float* __restrict__ tr, int He, int We, const PackedTap* cached = nullptr)
 {
     // environment light (global) * visibility
-    s.taps = env_taps(dx, dy, dz, tr, He, We);
+    if (HAVE_TAP) s.taps = taps_from_packed(*cached, He, We);
+    else s.taps = env_taps(dx, dy, dz, tr, He, We);
     s.vis = vis;
     float e[3] = {0.f, 0.f, 0.f};
 #pragma unroll
@@ -518,34 +565,6 @@ shade_prepare_kernel(int P, int M, const float* __restrict__ base_color, const f
     }
 }
 
-struct PackedTap {           // 12 bytes per cached sample
-    uint32_t xy;             // (x0 + 1) | (y0 + 1) << 16, (x0, y0) = floor of the lat-long pixel coordinate (>= -1)
-    float wx1, wy1;          // bilinear weights of column x0 + 1 / row y0 + 1
-};
-
-__device__ __forceinline__ PackedTap make_tap(float dx, float dy, float dz, const float* __restrict__ tr, int He, int We)
-{
-    if (tr != nullptr) {
-        const float tx = dx * tr[0] + dy * tr[1] + dz * tr[2];
-        const float ty = dx * tr[3] + dy * tr[4] + dz * tr[5];
-        const float tz = dx * tr[6] + dy * tr[7] + dz * tr[8];
-        dx = tx; dy = ty; dz = tz;
-    }
-    const float phi = fast_acosf(dz) - 1e-6f;
-    const float theta = fast_atan2f(dy, dx);
-    const float qy = (phi / kPi) * 2.f - 1.f;
-    const float qx = -theta / kPi;
-    const float ix = (qx + 1.f) * 0.5f * (float)(We - 1);
-    const float iy = (qy + 1.f) * 0.5f * (float)(He - 1);
-    const float x0f = floorf(ix), y0f = floorf(iy);
-    PackedTap t;
-    t.wx1 = ix - x0f;
-    t.wy1 = iy - y0f;
-    const int x0 = max((int)x0f, -1), y0 = max((int)y0f, -1);
-    t.xy = (uint32_t)(x0 + 1) | ((uint32_t)(y0 + 1) << 16);
-    return t;
-}
-
 // env == nullptr: the 12-byte lookup record (texel corner + weights).  env != nullptr: the looked-up RADIANCE itself (three
 // floats) -- for a light that is not being trained (relighting under a fixed HDR map) the bilinear sample of every cached
 // direction is a constant too, and the shading kernel then needs no texture access at all.
@@ -817,12 +836,12 @@ grad_absmax_kernel(int n, const float* __restrict__ a, const float* __restrict__
 // fewer than 2^14 of them per texel, so the sum stays below 2^62; the resolution is 3e-11 * max|g| -- finer than the
 // fp32 accumulation it replaces -- and the per-block sum is order-independent.  Non-finite upstream gradients fall
 // back to float atomics so NaN/inf still propagate.
-template <bool ENV_LDS, bool VEC16>
+template <bool ENV_LDS, bool VEC16, bool TAPS>
 __global__ void __launch_bounds__(64 * SHADE_WAVES)
 shade_backward_kernel(int P, int K, int M, ShadeSrc src, const float* __restrict__ env, int He, int We,
                       const float* __restrict__ tr, float* __restrict__ d_base, float* __restrict__ d_rough,
                       float* __restrict__ d_view, float* __restrict__ d_inc, float* __restrict__ d_env,
-                      const unsigned int* __restrict__ gmax_bits)
+                      const unsigned int* __restrict__ gmax_bits, const uint32_t* __restrict__ taps)
 {
     extern __shared__ __attribute__((aligned(16))) float s_mem[];
     const int ntex_raw = He * We * 3;
@@ -876,6 +895,20 @@ shade_backward_kernel(int P, int K, int M, ShadeSrc src, const float* __restrict
         gauss_setup(G, s_u);
         const float gp[3] = {s_u[58] * invK, s_u[59] * invK, s_u[60] * invK};
         const float gd[3] = {s_u[61] * invK, s_u[62] * invK, s_u[63] * invK};
+        // cached lat-long lookups of this lane's four samples (r3dg_shade_build_taps): straight from global into registers,
+        // issued here so that pass 0 below covers their latency
+        PackedTap ct[4];
+        if (TAPS) {
+#pragma unroll
+            for (int t = 0; t < 4; t++) {
+                const int k = kb * 64 + l + SH_L * t;
+                ct[t].xy = 0x00010001u; ct[t].wx1 = 0.f; ct[t].wy1 = 0.f;
+                if (live && k < K) {
+                    const uint3 q = *reinterpret_cast<const uint3*>(taps + 3 * ((size_t)g * K + k));
+                    ct[t].xy = q.x; ct[t].wx1 = __uint_as_float(q.y); ct[t].wy1 = __uint_as_float(q.z);
+                }
+            }
+        }
         // pass 0: SH sums of the local incident light (basis + 48 coefficient FMAs), parked in LDS
 #pragma unroll 1
         for (int t = 0; t < 4; t++) {
@@ -901,8 +934,14 @@ shade_backward_kernel(int P, int K, int M, ShadeSrc src, const float* __restrict
                 s.shsum[0] = s_park[(3 * t) * PARK];
                 s.shsum[1] = s_park[(3 * t + 1) * PARK];
                 s.shsum[2] = s_park[(3 * t + 2) * PARK];
-                shade_sample<ENV_LDS, true>(s, G, s_u, M, d[0], d[1], d[2], sb[SB_VIS + grp * 64 + kl],
-                                            sb[SB_AREA + grp * 64 + kl], env, s_env, tr, He, We);
+                PackedTap mine = ct[0];                  // t is a run-time loop index (unroll 1): select, no scratch
+                if (TAPS) {
+                    if (t == 1) mine = ct[1];
+                    if (t == 2) mine = ct[2];
+                    if (t == 3) mine = ct[3];
+                }
+                shade_sample<ENV_LDS, true, TAPS>(s, G, s_u, M, d[0], d[1], d[2], sb[SB_VIS + grp * 64 + kl],
+                                                  sb[SB_AREA + grp * 64 + kl], env, s_env, tr, He, We, &mine);
                 float gspec = 0.f;
                 float dlin[3];
 #pragma unroll
@@ -1180,7 +1219,7 @@ void launch_shade_backward(hipStream_t s, int P, int K, int M, const float* base
                            const float* normals, const float* viewdirs, const float* incidents, const float* env,
                            int He, int We, const float* tr, const float* visibility, const float* dirs,
                            const float* areas, const float* g_pbr, const float* g_diff, float* d_base, float* d_rough,
-                           float* d_view, float* d_inc, float* d_env)
+                           float* d_view, float* d_inc, float* d_env, const uint32_t* taps)
 {
     unsigned int* scratch = shade_scratch();
     R3DG_HIP(hipMemsetAsync(scratch, 0, 4, s));
@@ -1194,17 +1233,23 @@ void launch_shade_backward(hipStream_t s, int P, int K, int M, const float* base
     const int grid = shade_grid(P);
     const bool lds = 3 * ntex <= ENV_LDS_MAX, vec = (K % 4) == 0 && (size_t)P * K >= 4;
     const size_t smem = lds ? 3 * ((ntex + 3) & ~3) * sizeof(float) : 0;  // + the static DMA buffers and parking slots
-#define R3DG_SB(L, V)                                                                                                 \
+#define R3DG_SB3(L, V, T)                                                                                             \
     do {                                                                                                              \
         if (smem > 65536)                                                                                             \
-            R3DG_HIP(hipFuncSetAttribute((const void*)shade_backward_kernel<L, V>,                                    \
+            R3DG_HIP(hipFuncSetAttribute((const void*)shade_backward_kernel<L, V, T>,                                 \
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));                     \
-        shade_backward_kernel<L, V><<<grid, 64 * SHADE_WAVES, smem, s>>>(P, K, M, src, env, He, We, tr, d_base,       \
-                                                                       d_rough, d_view, d_inc, d_env, scratch);       \
+        shade_backward_kernel<L, V, T><<<grid, 64 * SHADE_WAVES, smem, s>>>(P, K, M, src, env, He, We, tr, d_base,    \
+                                                                          d_rough, d_view, d_inc, d_env, scratch,     \
+                                                                          taps);                                      \
+    } while (0)
+#define R3DG_SB(L, V)                                                                                                 \
+    do {                                                                                                              \
+        if (taps != nullptr) R3DG_SB3(L, V, true); else R3DG_SB3(L, V, false);                                        \
     } while (0)
     if (lds) { if (vec) R3DG_SB(true, true); else R3DG_SB(true, false); }
     else { if (vec) R3DG_SB(false, true); else R3DG_SB(false, false); }
 #undef R3DG_SB
+#undef R3DG_SB3
     check_launch(s, false, "shade_backward_kernel");
 }
 

@@ -312,7 +312,7 @@ class FusedStage2Step:
             d_base, d_rough, d_view, _d_inc, d_env = shading_ops.shade_backward(
                 self.a_base, self.a_rough, self.a_normal, self.a_viewdirs, self.incidents, env_c, self.visibility,
                 self.incident_dirs, self.incident_areas, self.d_pbr, self.d_diffuse,
-                out_incidents=self.grads["incidents"])
+                out_incidents=self.grads["incidents"], taps=taps)
             gr = self.grads
             if self._side is not None:          # join the geometry backward
                 torch.cuda.current_stream().wait_stream(self._side)

@@ -67,8 +67,9 @@ def shade_forward(base_color, roughness, normals, viewdirs, incidents, env, visi
 
 
 def shade_backward(base_color, roughness, normals, viewdirs, incidents, env, visibility, incident_dirs, incident_areas,
-                   dL_dpbr, dL_ddiffuse_light, env_transform=None, out_incidents=None):
-    """`out_incidents`: optional preallocated contiguous [P,M,3] buffer for dL_dincidents (fully overwritten)."""
+                   dL_dpbr, dL_ddiffuse_light, env_transform=None, out_incidents=None, taps=None):
+    """`out_incidents`: optional preallocated contiguous [P,M,3] buffer for dL_dincidents (fully overwritten);
+    `taps`: build_taps(incident_dirs, He, We, env_transform) (lookup records, not radiance)."""
     L = _lib.lib()
     P, K = incident_dirs.shape[0], incident_dirs.shape[1]
     M = incidents.shape[1]
@@ -88,10 +89,11 @@ def shade_backward(base_color, roughness, normals, viewdirs, incidents, env, vis
         d_inc = torch.empty((P, M, 3), dtype=torch.float32, device=dev)
     d_env = torch.zeros_like(t[5])
     with torch.cuda.device(dev):
-        st = L.r3dg_shade_backward(_lib.current_stream(), P, K, M, t[0].data_ptr(), t[1].data_ptr(), t[2].data_ptr(),
+        st = L.r3dg_shade_backward_cached(_lib.current_stream(), P, K, M, t[0].data_ptr(), t[1].data_ptr(), t[2].data_ptr(),
                                    t[3].data_ptr(), t[4].data_ptr(), t[5].data_ptr(), He, We,
                                    tr.data_ptr() if tr is not None else None, t[6].data_ptr(), t[7].data_ptr(),
-                                   t[8].data_ptr(), t[9].data_ptr(), t[10].data_ptr(), d_base.data_ptr(),
+                                   t[8].data_ptr(), taps.data_ptr() if taps is not None else None,
+                                   t[9].data_ptr(), t[10].data_ptr(), d_base.data_ptr(),
                                    d_rough.data_ptr(), d_view.data_ptr(), d_inc.data_ptr(), d_env.data_ptr())
     _lib.check(st, "shade_backward")
     return d_base, d_rough, d_view, d_inc, d_env

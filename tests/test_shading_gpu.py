@@ -184,6 +184,20 @@ def test_shading_forward_variants_agree(P, K, He, transform):
     assert (outs["rows"] - outs["rows+taps"]).abs().max().item() <= 1e-6 * max(1.0, want.abs().max().item())
 
 
+@pytest.mark.parametrize("P,K,He,transform", [(1500, 64, 16, False), (400, 100, 64, True), (300, 30, 16, False)])
+def test_shading_backward_with_cached_taps_equals_in_kernel_lookup(P, K, He, transform):
+    from relightable3dgaussian_amd import shading_ops as so
+    inp = {k: v.to(DEV) for k, v in _random_inputs(P, K, He, 16, seed=11 * P + K, hdr=transform).items()}
+    tr = torch.linalg.qr(torch.randn(3, 3, generator=torch.Generator().manual_seed(9))).Q.contiguous().to(DEV) if transform else None
+    args = (inp["base_color"], inp["roughness"], inp["normals"], inp["viewdirs"], inp["incidents"], inp["env"],
+            inp["visibility"], inp["incident_dirs"], inp["incident_areas"], inp["g_pbr"], inp["g_diff"])
+    a = so.shade_backward(*args, env_transform=tr)
+    b = so.shade_backward(*args, env_transform=tr, taps=so.build_taps(inp["incident_dirs"], He, 2 * He, tr))
+    torch.cuda.synchronize()
+    for name, x, y in zip(("d_base", "d_rough", "d_view", "d_inc", "d_env"), a, b):
+        _ok(name + " cached vs in-kernel lookup", y, x, 2e-6, 1e-7)
+
+
 def test_shade_refuses_gradients_it_does_not_implement():
     from relightable3dgaussian_amd import shading_ops as so
     inp = {k: v.to(DEV) for k, v in _random_inputs(64, 24, 8).items()}

@@ -42,4 +42,11 @@ for K, He in CASES:
         torch.cuda.synchronize()
         pr = _lib.profile_read(); L.r3dg_profile_enable(0)
         res["backward"] = pr["shade_backward"][0] / max(pr["shade_backward"][1], 1)
+        for it in range(8):
+            if it == 3:
+                torch.cuda.synchronize(); L.r3dg_profile_enable(1)
+            so.shade_backward(base, rough, nrm, view, inc, env, vis, dirs, areas, gp, gd, taps=taps)
+        torch.cuda.synchronize()
+        pr = _lib.profile_read(); L.r3dg_profile_enable(0)
+        res["backward (cached taps)"] = pr["shade_backward"][0] / max(pr["shade_backward"][1], 1)
     print("K=%d He=%d  " % (K, He) + "  ".join("%s %.4f ms" % kv for kv in res.items()))
