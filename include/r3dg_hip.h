@@ -430,10 +430,13 @@ int r3dg_knn_dist2(void* stream, int P, const float* d_points, float* d_mean_dis
  *   1 leaf, leaf boxes in rows P-1..) and are completed IN PLACE; d_morton int64[P] receives the 64-bit codes.
  * r3dg_bvh_trace_opacity: one ray per (rays_o, rays_d) row; covs3D is the 6-vector INVERSE covariance
  *   (GaussianModel.get_inverse_covariance); outputs must be pre-set by the caller to 0 / 1 (bvh.cu:101-102);
- *   *d_stack_overflow (zeroed by the caller) counts rays that needed more than the 64-entry traversal stack. */
+ *   *d_stack_overflow (zeroed by the caller) counts rays that needed more than the 64-entry traversal stack;
+ *   num_gaussians = P of the tree (rows of d_means3D): lets the library repack the tree into one 64-byte record per node for
+ *   the walk (<= 0: unknown, the arrays are walked as they are).  Rays are traced in blocks of 256 consecutive rows; callers
+ *   that can should order them so that consecutive rays start near each other (train_step.update_visibility does). */
 size_t r3dg_bvh_build_temp_bytes(int P);
 int r3dg_bvh_build(void* stream, int P, int32_t* d_nodes, float* d_aabbs, int64_t* d_morton, void* d_temp);
-int r3dg_bvh_trace_opacity(void* stream, int64_t num_rays, const int32_t* d_nodes, const float* d_aabbs,
+int r3dg_bvh_trace_opacity(void* stream, int64_t num_rays, int num_gaussians, const int32_t* d_nodes, const float* d_aabbs,
                            const float* d_rays_o, const float* d_rays_d, const float* d_means3D,
                            const float* d_covs3D, const float* d_opacities, const float* d_normals,
                            int32_t* d_num_contributes, float* d_rendered_opacity, int32_t* d_stack_overflow);
@@ -472,6 +475,10 @@ int r3dg_set_tuning6(int shade_forward_blocks_per_cu);
  * row-kernel workgroups per CU (0 = as many as fit; fewer leave room for the instance ordering that runs beside it).
  * Negative arguments leave a setting unchanged. */
 int r3dg_set_tuning7(int shade_forward_rows, int row_blocks_per_cu);
+/* r3dg_set_tuning8: visibility trace formulation: 2 (default) = persistent waves, a lane whose ray has finished fetches the
+ * next ray (per-ray semantics and visit order of the reference); 1 = wave-cooperative (64 rays share one traversal stack and
+ * visit the union of their nodes: measured slower, kept for comparison); 0 = one fixed ray per thread (round 1). */
+int r3dg_set_tuning8(int trace_packet);
 int r3dg_selftest_transpose_reduce(void* stream, int N, int dpp, const float* d_in, float* d_out, int* d_chan,
                                    int* d_owner);
 

@@ -49,6 +49,7 @@ _SIGNATURES = {
     "r3dg_set_tuning5": (_i, [_i]),
     "r3dg_set_tuning6": (_i, [_i]),
     "r3dg_set_tuning7": (_i, [_i, _i]),
+    "r3dg_set_tuning8": (_i, [_i]),
     "r3dg_selftest_transpose_reduce": (_i, [_p, _i, _i, _p, _p, _p, _p]),
     "r3dg_shade_forward": (_i, [_p, _i, _i, _i, _p, _p, _p, _p, _p, _p, _i, _i, _p, _p, _p, _p, _p]),
     "r3dg_shade_forward_cached": (_i, [_p, _i, _i, _i, _p, _p, _p, _p, _p, _p, _i, _i, _p, _p, _p, _p, _f, _p, _i, _p]),
@@ -86,7 +87,7 @@ _SIGNATURES = {
     "r3dg_knn_dist2": (_i, [_p, _i, _p, _p, _p]),
     "r3dg_bvh_build_temp_bytes": (C.c_size_t, [_i]),
     "r3dg_bvh_build": (_i, [_p, _i, _p, _p, _p, _p]),
-    "r3dg_bvh_trace_opacity": (_i, [_p, C.c_int64, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p]),
+    "r3dg_bvh_trace_opacity": (_i, [_p, C.c_int64, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p]),
     "r3dg_profile_enable": (_i, [_i]),
     "r3dg_profile_pause": (_i, [_i]),
     "r3dg_profile_num_stages": (_i, []),

@@ -39,7 +39,8 @@ def trace_bvh_opacity(nodes, aabbs, rays_o, rays_d, means3D, covs3D, opacities, 
         overflow = torch.zeros(1, dtype=torch.int32, device=dev)
         t = [x.contiguous() for x in (nodes, aabbs, rays_o, rays_d, means3D, covs3D, opacities, normals)]
         with torch.cuda.device(dev):
-            st = L.r3dg_bvh_trace_opacity(_lib.current_stream(), num_rays, *[x.data_ptr() for x in t],
+            P = means3D.shape[0] if nodes.shape[0] == 2 * means3D.shape[0] - 1 else 0
+            st = L.r3dg_bvh_trace_opacity(_lib.current_stream(), num_rays, P, *[x.data_ptr() for x in t],
                                           num_contributes.data_ptr(), rendered_opacity.data_ptr(),
                                           overflow.data_ptr())
         _lib.check(st, "trace_bvh_opacity")

@@ -298,6 +298,349 @@ trace_opacity_kernel(int num_rays, const int32_t* __restrict__ nodes, const floa
     if (lost) atomicAdd(overflow, 1);
 }
 
+// ---- wave-cooperative ("packet") traversal ---------------------------------------------------------------------------------
+// One wave = 64 consecutive rays (the K rays of one Gaussian's visibility bundle share their origin, gaussian_model.py:312-342,
+// but nothing below assumes it).  The wave keeps ONE traversal stack (LDS; node id + the 64-bit mask of the rays that hit
+// that node's box) and visits the UNION of the nodes its rays reach, each once: node record, child boxes and leaf Gaussian
+// are wave-uniform -> scalar loads, shared by the 64 slab tests / attenuation evaluations of one VALU pass.  The thread-per-
+// ray kernel above gathers 17 words from up to 64 different nodes per step and idles the lanes whose ray finished early.
+// Per-ray semantics are those of the reference (trace.cu:208-280): a ray meets a node iff tmax > 0 for that node's box
+// (mask bit), every Gaussian it meets goes through the same accept chain, T < 0.9 retires the ray with 0.  The visit ORDER
+// differs from a single ray's, which can only matter for a ray whose product crosses 0.9 within rounding.
+constexpr int PACKET_STACK = 96;
+
+__global__ void __launch_bounds__(256)
+trace_opacity_packet_kernel(int num_rays, const int32_t* __restrict__ nodes, const float* __restrict__ aabbs,
+                            const float* __restrict__ rays_o, const float* __restrict__ rays_d,
+                            const float* __restrict__ means, const float* __restrict__ covs,
+                            const float* __restrict__ opac, const float* __restrict__ normals,
+                            int32_t* __restrict__ contributes, float* __restrict__ out, int* __restrict__ overflow)
+{
+    __shared__ int s_node[4][PACKET_STACK];
+    __shared__ unsigned long long s_mask[4][PACKET_STACK];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int r = blockIdx.x * 256 + threadIdx.x;
+    const bool valid = r < num_rays;
+    const int rr = valid ? r : num_rays - 1;
+    const float ox = rays_o[3 * (size_t)rr], oy = rays_o[3 * (size_t)rr + 1], oz = rays_o[3 * (size_t)rr + 2];
+    const float dx = rays_d[3 * (size_t)rr], dy = rays_d[3 * (size_t)rr + 1], dz = rays_d[3 * (size_t)rr + 2];
+    int* st_node = s_node[wave];
+    unsigned long long* st_mask = s_mask[wave];
+    int sp = 0;
+    const unsigned long long all = __ballot(valid);
+    if (all == 0ull) return;
+    if (lane == 0) { st_node[0] = 0; st_mask[0] = all; }
+    sp = 1;
+    int count = 0;
+    float T = 1.0f;
+    bool alive = valid;
+    bool lost = false;
+    while (sp > 0) {
+        --sp;
+        const int node_id = __builtin_amdgcn_readfirstlane(st_node[sp]);
+        const unsigned long long m = st_mask[sp];
+        const unsigned long long mask = ((unsigned long long)__builtin_amdgcn_readfirstlane((int)(m >> 32)) << 32) |
+                                        (unsigned int)__builtin_amdgcn_readfirstlane((int)(unsigned int)m);
+        const unsigned long long live = mask & __ballot(alive);
+        if (live == 0ull) continue;
+        const bool me = ((live >> lane) & 1ull) != 0ull;
+        const int32_t* node = nodes + 5 * (size_t)node_id;
+        if (node[4] <= 1) {
+            const int g = node[3];
+            const float op = opac[g];
+            if (op < 1.f / 255.f) continue;
+            const float nx = normals[3 * (size_t)g], ny = normals[3 * (size_t)g + 1], nz = normals[3 * (size_t)g + 2];
+            const float* ci = covs + 6 * (size_t)g;
+            const float c0 = ci[0], c1 = ci[1], c2 = ci[2], c3 = ci[3], c4 = ci[4], c5 = ci[5];
+            const float mx = means[3 * (size_t)g], my = means[3 * (size_t)g + 1], mz = means[3 * (size_t)g + 2];
+            if (me && !(nx * dx + ny * dy + nz * dz > 0)) {
+                const float m0 = mx - ox, m1 = my - oy, m2 = mz - oz;
+                const float t1 = c0 * m0 * dx + c1 * m0 * dy + c2 * m0 * dz + c1 * m1 * dx + c3 * m1 * dy + c4 * m1 * dz +
+                                 c2 * m2 * dx + c4 * m2 * dy + c5 * m2 * dz;
+                const float t2 = c0 * dx * dx + c1 * dx * dy + c2 * dx * dz + c1 * dy * dx + c3 * dy * dy + c4 * dy * dz +
+                                 c2 * dz * dx + c4 * dz * dy + c5 * dz * dz;
+                const float t = t1 / t2;
+                if (!(t < 0.01)) {
+                    const float px = ox + t * dx, py = oy + t * dy, pz = oz + t * dz;
+                    const float f0 = mx - px, f1 = my - py, f2 = mz - pz;
+                    const float s = f0 * f0 * c0 + f1 * f1 * c3 + f2 * f2 * c5 + 2 * f0 * f1 * c1 + 2 * f0 * f2 * c2 +
+                                    2 * f1 * f2 * c4;
+                    const float power = -0.5f * s;
+                    if (!(power > 0)) {
+                        count += 1;
+                        const float alpha = op * __expf(power);
+                        T *= 1 - alpha;
+                        if (T < 0.9) alive = false;          // retired: the result is 0 and the count stays 0 (trace.cu:251-254)
+                    }
+                }
+            }
+        } else {
+            const int lid = node[1], rid = node[2];
+            float tl = -1.0f, tr = -1.0f;
+            if (me) {
+                tl = slab_tmax(aabbs + 6 * (size_t)lid, ox, oy, oz, dx, dy, dz);
+                tr = slab_tmax(aabbs + 6 * (size_t)rid, ox, oy, oz, dx, dy, dz);
+            }
+            const unsigned long long ml = __ballot(me && tl > 0), mr = __ballot(me && tr > 0);
+            // the child more of the wave's rays want is popped first (pushed last)
+            const bool left_first = __popcll(ml) >= __popcll(mr);
+            const int n0 = left_first ? rid : lid, n1 = left_first ? lid : rid;
+            const unsigned long long m0 = left_first ? mr : ml, m1 = left_first ? ml : mr;
+            if (m0 != 0ull) {
+                if (sp < PACKET_STACK) { if (lane == 0) { st_node[sp] = n0; st_mask[sp] = m0; } sp++; } else lost = true;
+            }
+            if (m1 != 0ull) {
+                if (sp < PACKET_STACK) { if (lane == 0) { st_node[sp] = n1; st_mask[sp] = m1; } sp++; } else lost = true;
+            }
+        }
+    }
+    if (valid) {
+        contributes[r] = alive ? count : 0;
+        out[r] = alive ? T : 0.0f;
+    }
+    if (lost && lane == 0) atomicAdd(overflow, 1);
+}
+
+// ---- packed traversal records + XCD-aware thread-per-ray traversal -----------------------------------------------------------
+// rocprofv3 on the thread-per-ray kernel above (P=300k, K=64; profiles/r02_pmc_trace.json): 12.7e9 L2 requests per 6.4 M rays,
+// 45 % of them L2 misses (3.3 TB/s of 64-byte lines from the Infinity Cache), VALU busy 37 %, lanes 26 % utilised -- the walk
+// is bound by memory transactions, not by issue.  Every step touches 3 lines (node record 20 B, two child boxes 24 B each at
+// unrelated rows) or 5 (leaf: node + opacity + normal + covariance + mean from five arrays), the 42 MB working set is ten
+// times one XCD's 4 MB L2, and consecutive blocks -- dispatched round-robin over the 8 XCDs -- carry unrelated origins.
+//   * pack_traversal_kernel rewrites the tree once per trace call into one 64-byte record per internal node (both child ids
+//     and both child boxes) and one per leaf IN MORTON ORDER (mean, inverse covariance, opacity, normal): one line per step;
+//   * the host traces the ray bundles in Morton order of their origin Gaussian (train_step.update_visibility), and the kernel
+//     hands each XCD a contiguous run of blocks, so an XCD's L2 serves one region of the scene (its subtree + the shared top
+//     levels) instead of 1/8 of everything;
+//   * per-ray semantics, arithmetic and visit order are unchanged (trace.cu:208-280): results are bit-identical.
+// The wave-cooperative variant (shared stack, union of the 64 rays' nodes) and persistent waves with dynamic ray fetch were
+// measured too: 37 and 49 vs 56 Mrays/s at K=64 -- fewer instructions (lanes 48 % utilised with refill) but MORE L2 misses.
+struct __attribute__((aligned(16))) TNode {
+    int left, right;
+    float lb[6], rb[6];
+    int pad[2];
+};
+struct __attribute__((aligned(16))) TLeaf {
+    float mean[3], cov[6], op, n[3];
+    float pad[3];
+};
+static_assert(sizeof(TNode) == 64 && sizeof(TLeaf) == 64, "one cache line per traversal record");
+
+__global__ void __launch_bounds__(256)
+pack_traversal_kernel(int P, const int32_t* __restrict__ nodes, const float* __restrict__ aabbs,
+                      const float* __restrict__ means, const float* __restrict__ covs, const float* __restrict__ opac,
+                      const float* __restrict__ normals, TNode* __restrict__ tn, TLeaf* __restrict__ tl)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < P - 1) {
+        TNode o;
+        o.left = nodes[5 * (size_t)i + 1];
+        o.right = nodes[5 * (size_t)i + 2];
+#pragma unroll
+        for (int a = 0; a < 6; a++) {
+            o.lb[a] = aabbs[6 * (size_t)o.left + a];
+            o.rb[a] = aabbs[6 * (size_t)o.right + a];
+        }
+        o.pad[0] = o.pad[1] = 0;
+        tn[i] = o;
+    }
+    if (i < P) {
+        const int g = nodes[5 * (size_t)(P - 1 + i) + 3];
+        TLeaf o;
+#pragma unroll
+        for (int a = 0; a < 3; a++) {
+            o.mean[a] = means[3 * (size_t)g + a];
+            o.n[a] = normals[3 * (size_t)g + a];
+            o.pad[a] = 0.f;
+        }
+#pragma unroll
+        for (int a = 0; a < 6; a++) o.cov[a] = covs[6 * (size_t)g + a];
+        o.op = opac[g];
+        tl[i] = o;
+    }
+}
+
+__global__ void __launch_bounds__(256)
+trace_opacity_packed_kernel(int num_rays, int P, int xcd_chunk, const TNode* __restrict__ tn, const TLeaf* __restrict__ tl,
+                            const float* __restrict__ rays_o, const float* __restrict__ rays_d,
+                            int32_t* __restrict__ contributes, float* __restrict__ out, int* __restrict__ overflow)
+{
+    // hardware places block b on XCD b % 8: give every XCD a contiguous run of ray blocks (= a region of the scene when the
+    // bundles arrive in Morton order)
+    const int blk = (int)(blockIdx.x & 7u) * xcd_chunk + (int)(blockIdx.x >> 3);
+    const long long r = (long long)blk * 256 + threadIdx.x;
+    if (r >= num_rays) return;
+    const float ox = rays_o[3 * (size_t)r], oy = rays_o[3 * (size_t)r + 1], oz = rays_o[3 * (size_t)r + 2];
+    const float dx = rays_d[3 * (size_t)r], dy = rays_d[3 * (size_t)r + 1], dz = rays_d[3 * (size_t)r + 2];
+    int stack[TRACE_STACK];
+    int sp = 0;
+    stack[sp++] = 0;
+    int count = 0;
+    float T = 1.0f;
+    bool lost = false;
+    const int first_leaf = P - 1;
+    while (sp > 0) {
+        const int node_id = stack[--sp];
+        if (node_id >= first_leaf) {
+            const float4* q = reinterpret_cast<const float4*>(tl + (node_id - first_leaf));
+            const float4 q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3];
+            const float op = q2.y;
+            if (op < 1.f / 255.f) continue;
+            const float nx = q2.z, ny = q2.w, nz = q3.x;
+            if (nx * dx + ny * dy + nz * dz > 0) continue;
+            const float c0 = q0.w, c1 = q1.x, c2 = q1.y, c3 = q1.z, c4 = q1.w, c5 = q2.x;
+            const float mx = q0.x, my = q0.y, mz = q0.z;
+            const float m0 = mx - ox, m1 = my - oy, m2 = mz - oz;
+            const float t1 = c0 * m0 * dx + c1 * m0 * dy + c2 * m0 * dz + c1 * m1 * dx + c3 * m1 * dy + c4 * m1 * dz +
+                             c2 * m2 * dx + c4 * m2 * dy + c5 * m2 * dz;
+            const float t2 = c0 * dx * dx + c1 * dx * dy + c2 * dx * dz + c1 * dy * dx + c3 * dy * dy + c4 * dy * dz +
+                             c2 * dz * dx + c4 * dz * dy + c5 * dz * dz;
+            const float t = t1 / t2;
+            if (t < 0.01) continue;
+            const float px = ox + t * dx, py = oy + t * dy, pz = oz + t * dz;
+            const float f0 = mx - px, f1 = my - py, f2 = mz - pz;
+            const float s = f0 * f0 * c0 + f1 * f1 * c3 + f2 * f2 * c5 + 2 * f0 * f1 * c1 + 2 * f0 * f2 * c2 +
+                            2 * f1 * f2 * c4;
+            const float power = -0.5f * s;
+            if (power > 0) continue;
+            count += 1;
+            const float alpha = op * __expf(power);
+            T *= 1 - alpha;
+            if (T < 0.9) {
+                out[r] = 0.0f;        // contributes[r] keeps its initial 0 (trace.cu:251-254)
+                return;
+            }
+        } else {
+            const float4* q = reinterpret_cast<const float4*>(tn + node_id);
+            const float4 q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3];
+            const int lid = __float_as_int(q0.x), rid = __float_as_int(q0.y);
+            const float lb[6] = {q0.z, q0.w, q1.x, q1.y, q1.z, q1.w};
+            const float rb[6] = {q2.x, q2.y, q2.z, q2.w, q3.x, q3.y};
+            const float tl_ = slab_tmax(lb, ox, oy, oz, dx, dy, dz);
+            const float tr_ = slab_tmax(rb, ox, oy, oz, dx, dy, dz);
+            const int first = tl_ > tr_ ? lid : rid, second = tl_ > tr_ ? rid : lid;
+            const float tf = tl_ > tr_ ? tl_ : tr_, ts = tl_ > tr_ ? tr_ : tl_;
+            if (tf > 0) { if (sp < TRACE_STACK) stack[sp++] = first; else lost = true; }
+            if (ts > 0) { if (sp < TRACE_STACK) stack[sp++] = second; else lost = true; }
+        }
+    }
+    contributes[r] = count;
+    out[r] = T;
+    if (lost) atomicAdd(overflow, 1);
+}
+
+// The same walk with PERSISTENT waves: a lane whose ray has finished (83 % of the visibility rays are occluded after a handful of
+// leaves while the rest walk thousands of nodes, so a fixed assignment leaves ~3/4 of the lanes idle) pulls the next ray from
+// a per-XCD queue -- each XCD owns a contiguous eighth of the (Morton-ordered) ray set, so the locality argument above holds --
+// with one wave-aggregated atomic per refill.  Per-ray arithmetic and visit order are unchanged.
+constexpr int REFILL_MIN_IDLE = 16;      // refill when at least this many lanes are idle (or the whole wave is)
+
+__global__ void __launch_bounds__(256)
+trace_opacity_persistent_kernel(int num_rays, int P, const TNode* __restrict__ tn, const TLeaf* __restrict__ tl,
+                                const float* __restrict__ rays_o, const float* __restrict__ rays_d,
+                                int32_t* __restrict__ contributes, float* __restrict__ out, int* __restrict__ overflow,
+                                int* __restrict__ queues /* 8 x 16 ints, zeroed */)
+{
+    const int lane = threadIdx.x & 63;
+    const int xcd = (int)(blockIdx.x & 7u);
+    const int per = (num_rays + 7) / 8;
+    const int q_lo = xcd * per, q_hi = min(num_rays, q_lo + per);
+    int* next_ray = queues + 16 * xcd;
+    int stack[TRACE_STACK];
+    int sp = 0, ray = -1, count = 0;
+    float ox = 0.f, oy = 0.f, oz = 0.f, dx = 0.f, dy = 0.f, dz = 1.f, T = 1.0f;
+    bool lost = false, exhausted = false;
+    const int first_leaf = P - 1;
+    while (true) {
+        const unsigned long long idle = __ballot(ray < 0);
+        if (idle != 0ull && !exhausted) {
+            const int n_idle = __popcll(idle);
+            if (n_idle >= REFILL_MIN_IDLE || idle == __ballot(true)) {
+                int base = 0;
+                const int leader = __builtin_ctzll(idle);
+                if (lane == leader) base = atomicAdd(next_ray, n_idle);
+                base = q_lo + __builtin_amdgcn_readlane(base, leader);
+                if (base + n_idle >= q_hi) exhausted = true;
+                if (ray < 0) {
+                    const int idx = base + __popcll(idle & ((1ull << lane) - 1ull));
+                    if (idx < q_hi) {
+                        ray = idx;
+                        ox = rays_o[3 * (size_t)idx]; oy = rays_o[3 * (size_t)idx + 1]; oz = rays_o[3 * (size_t)idx + 2];
+                        dx = rays_d[3 * (size_t)idx]; dy = rays_d[3 * (size_t)idx + 1]; dz = rays_d[3 * (size_t)idx + 2];
+                        stack[0] = 0;
+                        sp = 1;
+                        count = 0;
+                        T = 1.0f;
+                    }
+                }
+            }
+        }
+        if (__ballot(ray >= 0) == 0ull) {
+            if (exhausted) break;
+            continue;
+        }
+        if (ray >= 0) {
+            bool finished = false;
+            const int node_id = stack[--sp];
+            if (node_id >= first_leaf) {
+                const float4* q = reinterpret_cast<const float4*>(tl + (node_id - first_leaf));
+                const float4 q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3];
+                const float op = q2.y;
+                const float nx = q2.z, ny = q2.w, nz = q3.x;
+                if (!(op < 1.f / 255.f) && !(nx * dx + ny * dy + nz * dz > 0)) {
+                    const float c0 = q0.w, c1 = q1.x, c2 = q1.y, c3 = q1.z, c4 = q1.w, c5 = q2.x;
+                    const float mx = q0.x, my = q0.y, mz = q0.z;
+                    const float m0 = mx - ox, m1 = my - oy, m2 = mz - oz;
+                    const float t1 = c0 * m0 * dx + c1 * m0 * dy + c2 * m0 * dz + c1 * m1 * dx + c3 * m1 * dy + c4 * m1 * dz +
+                                     c2 * m2 * dx + c4 * m2 * dy + c5 * m2 * dz;
+                    const float t2 = c0 * dx * dx + c1 * dx * dy + c2 * dx * dz + c1 * dy * dx + c3 * dy * dy + c4 * dy * dz +
+                                     c2 * dz * dx + c4 * dz * dy + c5 * dz * dz;
+                    const float t = t1 / t2;
+                    if (!(t < 0.01)) {
+                        const float px = ox + t * dx, py = oy + t * dy, pz = oz + t * dz;
+                        const float f0 = mx - px, f1 = my - py, f2 = mz - pz;
+                        const float s = f0 * f0 * c0 + f1 * f1 * c3 + f2 * f2 * c5 + 2 * f0 * f1 * c1 + 2 * f0 * f2 * c2 +
+                                        2 * f1 * f2 * c4;
+                        const float power = -0.5f * s;
+                        if (!(power > 0)) {
+                            count += 1;
+                            const float alpha = op * __expf(power);
+                            T *= 1 - alpha;
+                            if (T < 0.9) {          // retired with 0; contributes keeps 0 (trace.cu:251-254)
+                                T = 0.0f;
+                                count = 0;
+                                finished = true;
+                            }
+                        }
+                    }
+                }
+            } else {
+                const float4* q = reinterpret_cast<const float4*>(tn + node_id);
+                const float4 q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3];
+                const int lid = __float_as_int(q0.x), rid = __float_as_int(q0.y);
+                const float lb[6] = {q0.z, q0.w, q1.x, q1.y, q1.z, q1.w};
+                const float rb[6] = {q2.x, q2.y, q2.z, q2.w, q3.x, q3.y};
+                const float tl_ = slab_tmax(lb, ox, oy, oz, dx, dy, dz);
+                const float tr_ = slab_tmax(rb, ox, oy, oz, dx, dy, dz);
+                const int first = tl_ > tr_ ? lid : rid, second = tl_ > tr_ ? rid : lid;
+                const float tf = tl_ > tr_ ? tl_ : tr_, ts = tl_ > tr_ ? tr_ : tl_;
+                if (tf > 0) { if (sp < TRACE_STACK) stack[sp++] = first; else lost = true; }
+                if (ts > 0) { if (sp < TRACE_STACK) stack[sp++] = second; else lost = true; }
+            }
+            if (finished || sp == 0) {
+                contributes[ray] = count;
+                out[ray] = T;
+                ray = -1;
+                sp = 0;
+            }
+        }
+    }
+    if (lost) atomicAdd(overflow, 1);
+}
+
+int g_trace_packet = 3;    // r3dg_set_tuning8: 3 = packed records + persistent waves, 2 = packed records, 1 = wave-cooperative, 0 = round-1 kernel
+
 // ---- host ----
 size_t bvh_build_temp_bytes(size_t P)
 {
@@ -349,13 +692,58 @@ void bvh_build(hipStream_t s, int P, int32_t* nodes, float* aabbs, uint64_t* mor
     }
 }
 
-void bvh_trace_opacity(hipStream_t s, int num_rays, const int32_t* nodes, const float* aabbs, const float* rays_o,
+// per-device scratch for the packed traversal records (grow-only; 128 bytes per Gaussian)
+static char* trace_records(size_t P)
+{
+    static char* buf[64] = {nullptr};
+    static size_t cap[64] = {0};
+    int dev = 0;
+    R3DG_HIP(hipGetDevice(&dev));
+    if (dev < 0 || dev >= 64) dev = 0;
+    if (cap[dev] < P) {
+        if (buf[dev] != nullptr) {
+            R3DG_HIP(hipDeviceSynchronize());
+            R3DG_HIP(hipFree(buf[dev]));
+        }
+        const size_t want = P + P / 8 + 1024;
+        R3DG_HIP(hipMalloc((void**)&buf[dev], want * 128));
+        cap[dev] = want;
+    }
+    return buf[dev];
+}
+
+// P = number of Gaussians (rows of means / leaves of the tree); P <= 0: unknown -> the round-1 kernel
+void bvh_trace_opacity(hipStream_t s, int num_rays, int P, const int32_t* nodes, const float* aabbs, const float* rays_o,
                        const float* rays_d, const float* means, const float* covs, const float* opac,
                        const float* normals, int32_t* contributes, float* out, int* overflow)
 {
     if (num_rays <= 0) return;
-    trace_opacity_kernel<<<(num_rays + 255) / 256, 256, 0, s>>>(num_rays, nodes, aabbs, rays_o, rays_d, means, covs,
-                                                               opac, normals, contributes, out, overflow);
+    if (g_trace_packet >= 2 && P > 0) {
+        char* rec = trace_records((size_t)P + 8);
+        TNode* tn = reinterpret_cast<TNode*>(rec);
+        TLeaf* tl = reinterpret_cast<TLeaf*>(rec + (size_t)P * 64);
+        int* queues = reinterpret_cast<int*>(rec + (size_t)P * 128);           // 8 x 64 bytes behind the records
+        pack_traversal_kernel<<<(P + 255) / 256, 256, 0, s>>>(P, nodes, aabbs, means, covs, opac, normals, tn, tl);
+        const int nblk = (num_rays + 255) / 256, chunk = (nblk + 7) / 8;
+        if (g_trace_packet == 3) {
+            int dev = 0, cus = 256;
+            R3DG_HIP(hipGetDevice(&dev));
+            (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+            R3DG_HIP(hipMemsetAsync(queues, 0, 8 * 64, s));
+            const int cap = cus * 8;                                                // 8 waves per SIMD, all resident
+            const int grid = chunk * 8 < cap ? chunk * 8 : cap;
+            trace_opacity_persistent_kernel<<<grid, 256, 0, s>>>(num_rays, P, tn, tl, rays_o, rays_d, contributes, out,
+                                                                overflow, queues);
+        } else {
+            trace_opacity_packed_kernel<<<chunk * 8, 256, 0, s>>>(num_rays, P, chunk, tn, tl, rays_o, rays_d, contributes,
+                                                                 out, overflow);
+        }
+    } else if (g_trace_packet == 1)
+        trace_opacity_packet_kernel<<<(num_rays + 255) / 256, 256, 0, s>>>(num_rays, nodes, aabbs, rays_o, rays_d, means,
+                                                                          covs, opac, normals, contributes, out, overflow);
+    else
+        trace_opacity_kernel<<<(num_rays + 255) / 256, 256, 0, s>>>(num_rays, nodes, aabbs, rays_o, rays_d, means, covs,
+                                                                   opac, normals, contributes, out, overflow);
 }
 
 }  // namespace r3dg

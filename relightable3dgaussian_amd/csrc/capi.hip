@@ -58,6 +58,7 @@ void launch_shade_forward(hipStream_t s, int P, int K, int M, const float* base_
                           bool leave_room);
 void launch_shade_build_taps(hipStream_t s, size_t n, const float* dirs, const float* tr, int He, int We, const float* env,
                              uint32_t* taps);
+extern int g_trace_packet;
 extern int g_shade_fwd_rows;
 extern int g_shade_row_blocks_per_cu;
 void launch_shade_backward(hipStream_t s, int P, int K, int M, const float* base_color, const float* roughness,
@@ -144,7 +145,7 @@ size_t knn_temp_bytes(size_t P);
 void knn_dist2(hipStream_t s, int P, const float* pts, float* dists, void* temp);
 size_t bvh_build_temp_bytes(size_t P);
 void bvh_build(hipStream_t s, int P, int32_t* nodes, float* aabbs, uint64_t* morton, void* temp);
-void bvh_trace_opacity(hipStream_t s, int num_rays, const int32_t* nodes, const float* aabbs, const float* rays_o,
+void bvh_trace_opacity(hipStream_t s, int num_rays, int P, const int32_t* nodes, const float* aabbs, const float* rays_o,
                        const float* rays_d, const float* means, const float* covs, const float* opac,
                        const float* normals, int32_t* contributes, float* out, int* overflow);
 extern int g_cull;
@@ -296,6 +297,12 @@ int r3dg_set_tuning6(int shade_forward_blocks_per_cu)
 {
     if (shade_forward_blocks_per_cu >= 1 && shade_forward_blocks_per_cu <= 8)
         g_shade_fwd_blocks_per_cu = shade_forward_blocks_per_cu;
+    return R3DG_OK;
+}
+
+int r3dg_set_tuning8(int trace_packet)
+{
+    if (trace_packet >= 0 && trace_packet <= 3) g_trace_packet = trace_packet;
     return R3DG_OK;
 }
 
@@ -1346,7 +1353,7 @@ int r3dg_bvh_build(void* stream_, int P, int32_t* nodes, float* aabbs, int64_t* 
     });
 }
 
-int r3dg_bvh_trace_opacity(void* stream_, int64_t num_rays, const int32_t* nodes, const float* aabbs,
+int r3dg_bvh_trace_opacity(void* stream_, int64_t num_rays, int num_gaussians, const int32_t* nodes, const float* aabbs,
                            const float* rays_o, const float* rays_d, const float* means3D, const float* covs3D,
                            const float* opacities, const float* normals, int32_t* num_contributes,
                            float* rendered_opacity, int32_t* stack_overflow)
@@ -1357,8 +1364,8 @@ int r3dg_bvh_trace_opacity(void* stream_, int64_t num_rays, const int32_t* nodes
     return guarded([&]() -> int {
         hipStream_t stream = (hipStream_t)stream_;
         StageTimer t(stream, ST_BVH_TRACE);
-        bvh_trace_opacity(stream, (int)num_rays, nodes, aabbs, rays_o, rays_d, means3D, covs3D, opacities, normals,
-                          num_contributes, rendered_opacity, stack_overflow);
+        bvh_trace_opacity(stream, (int)num_rays, num_gaussians, nodes, aabbs, rays_o, rays_d, means3D, covs3D, opacities,
+                          normals, num_contributes, rendered_opacity, stack_overflow);
         check_launch(stream, false, "bvh_trace_opacity");
         t.stop();
         return R3DG_OK;

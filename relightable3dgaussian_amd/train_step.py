@@ -33,9 +33,9 @@ def update_visibility(xyz, scales, rotations, opacity, normal, sample_num, group
     (chunk = P // ((K-1)//24 + 1)) so the transient [chunk,K,3] ray tensors stay bounded.
 
     Data parallel: with an initialised process group of W > 1 ranks every rank builds the same BVH
-    (replicated, deterministic), traces only the ray bundles of ITS contiguous block of ceil(P/W) Gaussians and ONE
-    all-gather assembles the [P,K,1] visibility on every rank; directions and areas are pure functions of the normals
-    and are evaluated locally for all rows.  `tracer_cls` (tests) replaces bvh.RayTracer."""
+    (replicated, deterministic), traces only ITS contiguous block of ceil(P/W) ray bundles (of the Morton-ordered bundle
+    list, see below) and ONE all-gather assembles the [P,K,1] visibility on every rank; directions and areas are pure
+    functions of the normals and are evaluated locally for all rows.  `tracer_cls` (tests) replaces bvh.RayTracer."""
     import torch.distributed as dist
     world = rank = None
     if dist.is_available() and dist.is_initialized():
@@ -49,25 +49,36 @@ def update_visibility(xyz, scales, rotations, opacity, normal, sample_num, group
     per = -(-P // world)                                   # rows per rank (the last block may be short or empty)
     lo, hi = min(P, rank * per), min(P, (rank + 1) * per)
     chunk = max(1, P // ((sample_num - 1) // 24 + 1))
-    vis, dirs_all, areas_all = [], [], []
+    # The bundles are traced in MORTON order of their origin Gaussian (the leaf order of the tree just built): consecutive
+    # ray blocks then start next to each other and walk the same subtrees, which is what the trace kernel's per-XCD L2s
+    # need (csrc/bvh.hip).  Results are scattered back to the caller's order; values are those of any other order.
+    order = getattr(tracer, "tree", None)
+    order = order[P - 1:, 3].long() if (order is not None and P > 1) else torch.arange(P, device=xyz.device)
+    dirs_all, areas_all = [], []
     for off in range(0, P, chunk):
         dirs, areas = sampling.fibonacci_sphere_sampling(normal[off:off + chunk], sample_num)
         dirs_all.append(dirs)
         areas_all.append(areas)
-        a, b = max(off, lo), min(off + dirs.shape[0], hi)
-        if a < b:
-            d = dirs[a - off:b - off]
-            res = tracer.trace_visibility(xyz[a:b, None].expand_as(d), d, xyz, cinv, op, normal)
-            vis.append(res["visibility"])
     dirs_all, areas_all = torch.cat(dirs_all, 0), torch.cat(areas_all, 0)
+    mine = order[lo:hi]                                        # this rank's share of the Morton-ordered bundles
+    vis_mine = torch.empty(mine.numel(), sample_num, 1, dtype=torch.float32, device=xyz.device)
+    for a in range(0, mine.numel(), chunk):
+        sel = mine[a:a + chunk]
+        d = dirs_all[sel]
+        res = tracer.trace_visibility(xyz[sel][:, None].expand_as(d), d, xyz, cinv, op, normal)
+        vis_mine[a:a + sel.numel()] = res["visibility"]
     if world == 1:
-        return torch.cat(vis, 0), dirs_all, areas_all, tracer
-    mine = torch.zeros(per, sample_num, 1, dtype=torch.float32, device=xyz.device)
-    if hi > lo:
-        mine[:hi - lo] = torch.cat(vis, 0)
-    full = torch.empty(world * per, sample_num, 1, dtype=torch.float32, device=xyz.device)
-    dist.all_gather(list(full.view(world, per, sample_num, 1).unbind(0)), mine, group=group)
-    return full[:P].contiguous(), dirs_all, areas_all, tracer
+        full = torch.empty(P, sample_num, 1, dtype=torch.float32, device=xyz.device)
+        full[order] = vis_mine
+        return full, dirs_all, areas_all, tracer
+    padded = torch.zeros(per, sample_num, 1, dtype=torch.float32, device=xyz.device)
+    padded[:mine.numel()] = vis_mine
+    gathered = torch.empty(world * per, sample_num, 1, dtype=torch.float32, device=xyz.device)
+    dist.all_gather(list(gathered.view(world, per, sample_num, 1).unbind(0)), padded, group=group)
+    # rank r traced order[r*per : (r+1)*per]: the first P gathered rows are the visibilities in Morton order
+    full = torch.empty(P, sample_num, 1, dtype=torch.float32, device=xyz.device)
+    full[order] = gathered[:P]
+    return full, dirs_all, areas_all, tracer
 
 
 LAMBDA_DSSIM = 0.2          # arguments/__init__.py:125
