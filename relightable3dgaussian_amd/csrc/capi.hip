@@ -19,7 +19,7 @@ void launch_preprocess(hipStream_t s, int P, int D, int M, const float* means3D,
                        uint8_t* clamped, const float* cov3D_precomp, const float* colors_precomp, const float* vm,
                        const float* pm, const float* cam_pos, int W, int H, float tan_fovx, float tan_fovy,
                        float focal_x, float focal_y, int* radii, float* means2D, float* depths, float* cov3Ds,
-                       float* rgb, float* conic_opacity, int gx, int gy, uint32_t* tiles_touched,
+                       float* rgb, float* conic_opacity, float* splat, int gx, int gy, uint32_t* tiles_touched,
                        uint32_t* block_sums, unsigned long long* total);
 void launch_duplicate_with_keys(hipStream_t s, int P, const float* means2D, const float* depths,
                                 const uint32_t* tiles_touched, const uint32_t* block_offsets,
@@ -29,19 +29,16 @@ void launch_identify_tile_ranges(hipStream_t s, int L, const uint64_t* keys, uin
 void launch_tile_order(hipStream_t s, int T, const uint32_t* ranges, uint32_t* order, uint32_t small_cap,
                        uint32_t* big_list, uint32_t* big_count);
 void launch_render_forward(hipStream_t s, int W, int H, int S, const uint32_t* tile_order, const uint32_t* ranges,
-                           const uint32_t* point_list,
-                           const float* means2D, const float* depths, const float* features, const float* colors,
-                           const float* conic_opacity, float* final_T, uint32_t* n_contrib, const float* bg,
-                           float* out_color, float* out_opacity, float* out_depth, float* out_feature,
-                           float* out_weights);
+                           const uint32_t* point_list, const float* splat, const float* features, float* final_T,
+                           uint32_t* n_contrib, const float* bg, float* out_color, float* out_opacity, float* out_depth,
+                           float* out_feature, float* out_weights);
 void launch_pseudo_normal(hipStream_t s, int W, int H, const float* vm, float focal_x, float focal_y, float cx,
                           float cy, const float* opacities, const float* depths, float* normals, float* surface_xyz,
                           bool debug);
 void launch_render_backward(hipStream_t s, int W, int H, int S, int n_active, const int* active,
                             const uint32_t* tile_order, const uint32_t* ranges,
                             const uint32_t* point_list,
-                            const float* bg, const float* means2D, const float* depths, const float* conic_opacity,
-                            const float* colors, const float* features, const float* final_Ts,
+                            const float* bg, const float* splat, const float* features, const float* final_Ts,
                             const uint32_t* n_contrib, const float* dL_dpix, const float* dL_dpix_o,
                             const float* dL_dpix_d, const float* dL_dpix_f, float* dL_dmean2D, float* dL_dconic,
                             float* dL_dopacity, float* dL_dcolor, float* dL_dfeature, int bg_geom);
@@ -222,6 +219,9 @@ GeometryLayout GeometryLayout::make(size_t P)
     L.point_offsets = take(P * 4);
     L.block_sums = take(((P + 255) / 256 + 1) * 4);
     L.total = take(8);
+    // packed per-Gaussian record read by the tile kernels (64-byte stride = one line per staged instance):
+    // [mean.x mean.y conic.x conic.y | conic.z opacity depth 0 | r g b 0 | unused]
+    L.splat = take(P * 64);
     L.bytes = o;
     return L;
 }
@@ -518,7 +518,7 @@ int r3dg_rasterize_forward_begin(void* stream_, r3dg_alloc_fn geometry_alloc, r3
         launch_preprocess(stream, P, D, M, means3D, scales, scale_modifier, rotations, opacities, shs,
                           (uint8_t*)(gbuf + G.clamped), cov3D_precomp, colors_precomp, viewmatrix, projmatrix, cam_pos,
                           width, height, tan_fovx, tan_fovy, focal_x, focal_y, radii_p, g_means2D, g_depths,
-                          (float*)(gbuf + G.cov3D), g_rgb, g_conic, gx, gy, g_tiles, g_block, g_total);
+                          (float*)(gbuf + G.cov3D), g_rgb, g_conic, (float*)(gbuf + G.splat), gx, gy, g_tiles, g_block, g_total);
         check_launch(stream, debug, "preprocess");
         t_pre.stop();
 
@@ -567,13 +567,11 @@ int r3dg_rasterize_forward_finish_on(void* ticket_, void* ordering_stream_, int*
         int* radii_p = t->radii_p;
         float* g_depths = (float*)(gbuf + G.depths);
         float* g_means2D = (float*)(gbuf + G.means2D);
-        float* g_conic = (float*)(gbuf + G.conic_opacity);
-        float* g_rgb = (float*)(gbuf + G.rgb);
+        const float* g_splat = (const float*)(gbuf + G.splat);
         uint32_t* g_tiles = (uint32_t*)(gbuf + G.tiles_touched);
         uint32_t* g_block = (uint32_t*)(gbuf + G.block_sums);
         r3dg_alloc_fn binning_alloc = t->binning_alloc;
         void* user = t->user;
-        const float* colors_precomp = t->colors_precomp;
         const float* features = t->features;
         const float* background = t->background;
         const float* viewmatrix = t->viewmatrix;
@@ -598,7 +596,6 @@ int r3dg_rasterize_forward_finish_on(void* ticket_, void* ordering_stream_, int*
         uint32_t* vals = (uint32_t*)(bbuf + B.vals);
 
         uint32_t* ranges = (uint32_t*)(ibuf + I.ranges);
-        const float* colors_ptr = colors_precomp != nullptr ? colors_precomp : g_rgb;
         uint32_t* tile_order = g_tile_order ? (uint32_t*)(ibuf + I.tile_order) : nullptr;
         if (g_tile_binning) {
             // stable partition by tile id (one radix pass over the tile bits), then a per-tile depth sort in LDS: same
@@ -654,8 +651,8 @@ int r3dg_rasterize_forward_finish_on(void* ticket_, void* ordering_stream_, int*
         }
         stream = main_stream;
         StageTimer t_rf(stream, ST_RENDER_FWD);
-        launch_render_forward(stream, width, height, S, tile_order, ranges, vals, g_means2D, g_depths, features, colors_ptr,
-                              g_conic, (float*)(ibuf + I.final_T), (uint32_t*)(ibuf + I.n_contrib), background,
+        launch_render_forward(stream, width, height, S, tile_order, ranges, vals, g_splat, features,
+                              (float*)(ibuf + I.final_T), (uint32_t*)(ibuf + I.n_contrib), background,
                               out_color, out_opacity, out_depth, out_feature, out_weights);
         check_launch(stream, debug, "render_forward");
         t_rf.stop();
@@ -755,15 +752,13 @@ int r3dg_rasterize_backward_split(void* stream_, void* geometry_stream_, int P, 
         const char* ibuf = (const char*)img_buffer;
         const char* bbuf = (const char*)binning_buffer;
         const int* radii_p = radii ? radii : (const int*)(gbuf + G.radii);
-        const float* color_ptr = colors_precomp != nullptr ? colors_precomp : (const float*)(gbuf + G.rgb);
 
         if (R > 0) {
             StageTimer t_rb(stream, ST_RENDER_BWD);
             launch_render_backward(stream, width, height, S, n_active_features, active_features,
                                    g_tile_order ? (const uint32_t*)(ibuf + I.tile_order) : nullptr,
                                    (const uint32_t*)(ibuf + I.ranges),
-                                   (const uint32_t*)(bbuf + B.vals), background, (const float*)(gbuf + G.means2D),
-                                   (const float*)(gbuf + G.depths), (const float*)(gbuf + G.conic_opacity), color_ptr,
+                                   (const uint32_t*)(bbuf + B.vals), background, (const float*)(gbuf + G.splat),
                                    features, (const float*)(ibuf + I.final_T), (const uint32_t*)(ibuf + I.n_contrib),
                                    dL_dpix, dL_dpix_o, dL_dpix_d, dL_dpix_f, dL_dmean2D, dL_dconic, dL_dopacity,
                                    dL_dcolor, dL_dfeature, backward_geometry);

@@ -48,7 +48,7 @@ static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; 
 
 struct GeometryLayout {  // byte offsets into the opaque geometry buffer
     size_t depths, clamped, radii, means2D, cov3D, conic_opacity, rgb, tiles_touched, point_offsets, block_sums,
-        total, bytes;
+        total, splat, bytes;
     static GeometryLayout make(size_t P);
 };
 struct ImageLayout {

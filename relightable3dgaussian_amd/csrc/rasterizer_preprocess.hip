@@ -87,7 +87,7 @@ preprocess_kernel(int P, int D, int M, const float* __restrict__ means3D, const 
                   const float* __restrict__ pm, const float* __restrict__ cam_pos, int W, int H, float tan_fovx,
                   float tan_fovy, float focal_x, float focal_y, int* __restrict__ radii,
                   float2* __restrict__ means2D, float* __restrict__ depths, float* __restrict__ cov3Ds,
-                  float* __restrict__ rgb, float4* __restrict__ conic_opacity, int gx, int gy,
+                  float* __restrict__ rgb, float4* __restrict__ conic_opacity, float4* __restrict__ splat, int gx, int gy,
                   uint32_t* __restrict__ tiles_touched, uint32_t* __restrict__ block_sums)
 {
     extern __shared__ float s_rows[];                  // STAGED: 256 SH rows
@@ -96,6 +96,7 @@ preprocess_kernel(int P, int D, int M, const float* __restrict__ means3D, const 
     uint32_t my_tiles = 0;
     bool shade = false;                                // survived every cull and needs its colour from SH
     float px = 0.f, py = 0.f, pz = 0.f;
+    float4 rec0 = make_float4(0.f, 0.f, 0.f, 0.f), rec1 = rec0;   // packed record of a surviving Gaussian (GeometryLayout::splat)
     if (idx < P) {
         int my_radius_i = 0;
         do {
@@ -165,7 +166,10 @@ preprocess_kernel(int P, int D, int M, const float* __restrict__ means3D, const 
             depths[idx] = vz;
             my_radius_i = f2i_sat(my_radius);
             means2D[idx] = make_float2(pixx, pixy);
-            conic_opacity[idx] = make_float4(cc * det_inv, -cb * det_inv, ca * det_inv, opacities[idx]);
+            const float4 co = make_float4(cc * det_inv, -cb * det_inv, ca * det_inv, opacities[idx]);
+            conic_opacity[idx] = co;
+            rec0 = make_float4(pixx, pixy, co.x, co.y);
+            rec1 = make_float4(co.z, co.w, vz, 0.f);
             my_tiles = (uint32_t)((y1 - y0) * (x1 - x0));
         } while (0);
         radii[idx] = my_radius_i;
@@ -177,6 +181,7 @@ preprocess_kernel(int P, int D, int M, const float* __restrict__ means3D, const 
         stage_rows_in_256(shs, blockIdx.x * 256, P, 3 * M, s_live, s_rows);
         __syncthreads();
     }
+    float col[3] = {0.f, 0.f, 0.f};
     if (shade) {
         // forward.cu:20-71
         float dx = px - cam_pos[0], dy = py - cam_pos[1], dz = pz - cam_pos[2];
@@ -209,7 +214,20 @@ preprocess_kernel(int P, int D, int M, const float* __restrict__ means3D, const 
             result += 0.5f;
             clamped[3 * idx + ch] = (result < 0);
             rgb[3 * idx + ch] = fmaxf(result, 0.0f);
+            col[ch] = fmaxf(result, 0.0f);
         }
+    }
+    // the tile kernels stage one 48-byte record per instance from a 64-byte-aligned row instead of gathering xy, conic +
+    // opacity, depth and colour from four arrays (four sub-line touches per instance; rocprofv3 showed render_forward
+    // fetching 2.5x its algorithmic bytes)
+    if (my_tiles != 0u) {
+        if (colors_precomp != nullptr) {
+            col[0] = colors_precomp[3 * idx]; col[1] = colors_precomp[3 * idx + 1]; col[2] = colors_precomp[3 * idx + 2];
+        }
+        float4* r = splat + 4 * (size_t)idx;
+        r[0] = rec0;
+        r[1] = rec1;
+        r[2] = make_float4(col[0], col[1], col[2], 0.f);
     }
     // block reduction of tiles_touched -> block_sums
     __shared__ uint32_t s_wave[4];
@@ -402,7 +420,7 @@ void launch_preprocess(hipStream_t s, int P, int D, int M, const float* means3D,
                        uint8_t* clamped, const float* cov3D_precomp, const float* colors_precomp, const float* vm,
                        const float* pm, const float* cam_pos, int W, int H, float tan_fovx, float tan_fovy,
                        float focal_x, float focal_y, int* radii, float* means2D, float* depths, float* cov3Ds,
-                       float* rgb, float* conic_opacity, int gx, int gy, uint32_t* tiles_touched,
+                       float* rgb, float* conic_opacity, float* splat, int gx, int gy, uint32_t* tiles_touched,
                        uint32_t* block_sums, unsigned long long* total)
 {
     const int nb = (P + 255) / 256;
@@ -411,12 +429,12 @@ void launch_preprocess(hipStream_t s, int P, int D, int M, const float* means3D,
         preprocess_kernel<true><<<nb, 256, 256 * ((3 * M) | 1) * sizeof(float), s>>>(
             P, D, M, means3D, scales, scale_modifier, rotations, opacities, shs, clamped, cov3D_precomp, colors_precomp,
             vm, pm, cam_pos, W, H, tan_fovx, tan_fovy, focal_x, focal_y, radii, (float2*)means2D, depths, cov3Ds, rgb,
-            (float4*)conic_opacity, gx, gy, tiles_touched, block_sums);
+            (float4*)conic_opacity, (float4*)splat, gx, gy, tiles_touched, block_sums);
     else
         preprocess_kernel<false><<<nb, 256, 0, s>>>(
             P, D, M, means3D, scales, scale_modifier, rotations, opacities, shs, clamped, cov3D_precomp, colors_precomp,
             vm, pm, cam_pos, W, H, tan_fovx, tan_fovy, focal_x, focal_y, radii, (float2*)means2D, depths, cov3Ds, rgb,
-            (float4*)conic_opacity, gx, gy, tiles_touched, block_sums);
+            (float4*)conic_opacity, (float4*)splat, gx, gy, tiles_touched, block_sums);
     scan_block_sums_kernel<<<1, 1024, 0, s>>>(nb, block_sums, total);
 }
 

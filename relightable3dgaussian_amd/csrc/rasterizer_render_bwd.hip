@@ -60,8 +60,7 @@ render_backward_kernel(const uint2* __restrict__ ranges, const uint32_t* __restr
                        ChannelList chan_list, int W, int H,
                        int tiles_x, int num_tiles, int xcd_chunk, int wave8, int cull, const uint32_t* __restrict__ tile_order,
                        const float* __restrict__ bg_color,
-                       const float2* __restrict__ means2D, const float* __restrict__ depths,
-                       const float4* __restrict__ conic_opacity, const float* __restrict__ colors,
+                       const float4* __restrict__ splat,
                        const float* __restrict__ features, const float* __restrict__ final_Ts,
                        const uint32_t* __restrict__ n_contrib, const float* __restrict__ dL_dpixels,
                        const float* __restrict__ dL_dpixels_o, const float* __restrict__ dL_dpixels_d,
@@ -176,13 +175,14 @@ render_backward_kernel(const uint2* __restrict__ ranges, const uint32_t* __restr
         float2 my_co = make_float2(0.f, 0.f);               // conic.z, opacity
         if (base + tid < n) {
             const uint32_t g = point_list[range.x + (uint32_t)(n - 1 - (base + tid))];
-            const float2 xy = means2D[g];
-            const float4 co = conic_opacity[g];
-            s_geo0[tid] = my_geo = make_float4(xy.x, xy.y, co.x, co.y);
-            s_geo1[tid] = make_float4(co.z, co.w, depths[g], __uint_as_float(g));
-            my_co = make_float2(co.z, co.w);
+            // ONE 64-byte-aligned record per instance (preprocess_kernel packs xy, conic, opacity, depth and colour)
+            const float4* rec = splat + 4 * (size_t)g;
+            const float4 r0 = rec[0], r1 = rec[1], r2 = rec[2];
+            s_geo0[tid] = my_geo = r0;
+            s_geo1[tid] = make_float4(r1.x, r1.y, r1.z, __uint_as_float(g));
+            my_co = make_float2(r1.x, r1.y);
             float* pay = s_pay + tid * PAY;
-            pay[0] = colors[3 * g]; pay[1] = colors[3 * g + 1]; pay[2] = colors[3 * g + 2]; pay[3] = depths[g];
+            *reinterpret_cast<float4*>(pay) = make_float4(r2.x, r2.y, r2.z, r1.z);
             if constexpr (SPAD > 0) {
                 const float* f = features + (size_t)g * S;
                 if (chan_list.identity && (S & 3) == 0) {
@@ -348,7 +348,7 @@ int g_bwd_unroll = 1;   // staged entries evaluated per inner-loop step
 template <int SPAD, int PPL>
 static void launch_bwd_inst(hipStream_t s, int T, int tiles_x, const uint32_t* tile_order, const uint32_t* ranges,
                             const uint32_t* point_list, int S, const ChannelList& cl, int W, int H, const float* bg,
-                            const float* means2D, const float* depths, const float* conic_opacity, const float* colors,
+                            const float* splat,
                             const float* features, const float* final_Ts, const uint32_t* n_contrib,
                             const float* dL_dpix, const float* dL_dpix_o, const float* dL_dpix_d,
                             const float* dL_dpix_f, float* dL_dmean2D, float* dL_dconic, float* dL_dopacity,
@@ -358,7 +358,7 @@ static void launch_bwd_inst(hipStream_t s, int T, int tiles_x, const uint32_t* t
 #define R3DG_BWD_LAUNCH(UU, SV)                                                                                       \
     render_backward_kernel<SPAD, PPL, UU, SV><<<chunk * 8, 256 / PPL, 0, s>>>(                                        \
         (const uint2*)ranges, point_list, S, cl, W, H, tiles_x, T, chunk, g_bwd_wave8x8, g_cull, tile_order, bg,       \
-        (const float2*)means2D, depths, (const float4*)conic_opacity, colors, features, final_Ts, n_contrib, dL_dpix,   \
+        (const float4*)splat, features, final_Ts, n_contrib, dL_dpix,   \
         dL_dpix_o, dL_dpix_d, dL_dpix_f, dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolor, dL_dfeature, bg_geom)
     // 10 + n <= 16 gradient channels: half-size reduction (only instantiated where it can occur: SPAD 4 and 8)
     if constexpr (SPAD == 4 || SPAD == 8) {
@@ -376,8 +376,7 @@ static void launch_bwd_inst(hipStream_t s, int T, int tiles_x, const uint32_t* t
 
 void launch_render_backward(hipStream_t s, int W, int H, int S, int n_active, const int* active,
                             const uint32_t* tile_order, const uint32_t* ranges, const uint32_t* point_list,
-                            const float* bg, const float* means2D, const float* depths, const float* conic_opacity,
-                            const float* colors, const float* features, const float* final_Ts,
+                            const float* bg, const float* splat, const float* features, const float* final_Ts,
                             const uint32_t* n_contrib, const float* dL_dpix, const float* dL_dpix_o,
                             const float* dL_dpix_d, const float* dL_dpix_f, float* dL_dmean2D, float* dL_dconic,
                             float* dL_dopacity, float* dL_dcolor, float* dL_dfeature, int bg_geom)
@@ -395,7 +394,7 @@ void launch_render_backward(hipStream_t s, int W, int H, int S, int n_active, co
         for (int i = 0; i < R3DG_MAX_S_BWD; i++) cl.c[i] = i < n_active ? active[i] : 0;
     }
     const int SP = cl.n;                 // channels the kernel carries
-#define R3DG_BWD_ARGS s, T, tiles_x, tile_order, ranges, point_list, S, cl, W, H, bg, means2D, depths, conic_opacity, colors, \
+#define R3DG_BWD_ARGS s, T, tiles_x, tile_order, ranges, point_list, S, cl, W, H, bg, splat, \
                       features, final_Ts, n_contrib, dL_dpix, dL_dpix_o, dL_dpix_d, dL_dpix_f, dL_dmean2D, dL_dconic,         \
                       dL_dopacity, dL_dcolor, dL_dfeature, bg_geom
 #define R3DG_BWD_CASE(SP_)                                                       \

@@ -28,9 +28,7 @@ template <int SPAD, int PPL, int U>
 __global__ void __launch_bounds__(256 / PPL)
 render_forward_kernel(const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list, int S, int W, int H,
                       int tiles_x, int num_tiles, int xcd_chunk, int wave8, int cull, const uint32_t* __restrict__ tile_order,
-                      const float2* __restrict__ means2D,
-                      const float* __restrict__ depths, const float* __restrict__ features,
-                      const float* __restrict__ colors, const float4* __restrict__ conic_opacity,
+                      const float4* __restrict__ splat, const float* __restrict__ features,
                       float* __restrict__ final_T, uint32_t* __restrict__ n_contrib, const float* __restrict__ bg_color,
                       float* __restrict__ out_color, float* __restrict__ out_opacity, float* __restrict__ out_depth,
                       float* __restrict__ out_feature, float* __restrict__ out_weights)
@@ -100,13 +98,14 @@ render_forward_kernel(const uint2* __restrict__ ranges, const uint32_t* __restri
         float2 my_co = make_float2(0.f, 0.f);               // conic.z, opacity
         if (base + tid < n) {
             const uint32_t g = point_list[range.x + base + tid];
-            const float2 xy = means2D[g];
-            const float4 co = conic_opacity[g];
-            s_geo0[tid] = my_geo = make_float4(xy.x, xy.y, co.x, co.y);
-            s_geo1[tid] = make_float4(co.z, co.w, depths[g], __uint_as_float(g));
-            my_co = make_float2(co.z, co.w);
+            // ONE 64-byte-aligned record per instance (preprocess_kernel packs xy, conic, opacity, depth and colour)
+            const float4* rec = splat + 4 * (size_t)g;
+            const float4 r0 = rec[0], r1 = rec[1], r2 = rec[2];
+            s_geo0[tid] = my_geo = r0;
+            s_geo1[tid] = make_float4(r1.x, r1.y, r1.z, __uint_as_float(g));
+            my_co = make_float2(r1.x, r1.y);
             float* pay = s_pay + tid * PAY;
-            pay[0] = colors[3 * g]; pay[1] = colors[3 * g + 1]; pay[2] = colors[3 * g + 2]; pay[3] = 0.f;
+            *reinterpret_cast<float4*>(pay) = make_float4(r2.x, r2.y, r2.z, 0.f);
             if constexpr (SPAD > 0) {
                 const float* f = features + (size_t)g * S;
                 if ((S & 3) == 0) {
@@ -305,50 +304,40 @@ int g_fwd_unroll = 4;   // staged entries evaluated per inner-loop step (1 = ent
 
 template <int SPAD, int PPL>
 static void launch_fwd_inst(hipStream_t s, int T, int tiles_x, const uint32_t* tile_order, const uint32_t* ranges,
-                            const uint32_t* point_list,
-                            int S, int W, int H, const float* means2D, const float* depths, const float* features,
-                            const float* colors, const float* conic_opacity, float* final_T, uint32_t* n_contrib,
-                            const float* bg, float* out_color, float* out_opacity, float* out_depth,
-                            float* out_feature, float* out_weights)
+                            const uint32_t* point_list, int S, int W, int H, const float* splat, const float* features,
+                            float* final_T, uint32_t* n_contrib, const float* bg, float* out_color, float* out_opacity,
+                            float* out_depth, float* out_feature, float* out_weights)
 {
     const int chunk = (T + 7) / 8;
-    if (g_fwd_unroll >= 4)
-        render_forward_kernel<SPAD, PPL, 4><<<chunk * 8, 256 / PPL, 0, s>>>(
-            (const uint2*)ranges, point_list, S, W, H, tiles_x, T, chunk, g_fwd_wave8x8, g_cull, tile_order, (const float2*)means2D, depths,
-            features, colors, (const float4*)conic_opacity, final_T, n_contrib, bg, out_color, out_opacity, out_depth,
-            out_feature, out_weights);
-    else if (g_fwd_unroll >= 2)
-        render_forward_kernel<SPAD, PPL, 2><<<chunk * 8, 256 / PPL, 0, s>>>(
-            (const uint2*)ranges, point_list, S, W, H, tiles_x, T, chunk, g_fwd_wave8x8, g_cull, tile_order, (const float2*)means2D, depths,
-            features, colors, (const float4*)conic_opacity, final_T, n_contrib, bg, out_color, out_opacity, out_depth,
-            out_feature, out_weights);
-    else
-        render_forward_kernel<SPAD, PPL, 1><<<chunk * 8, 256 / PPL, 0, s>>>(
-            (const uint2*)ranges, point_list, S, W, H, tiles_x, T, chunk, g_fwd_wave8x8, g_cull, tile_order, (const float2*)means2D, depths,
-            features, colors, (const float4*)conic_opacity, final_T, n_contrib, bg, out_color, out_opacity, out_depth,
-            out_feature, out_weights);
+#define R3DG_FWD_LAUNCH(U)                                                                                            \
+    render_forward_kernel<SPAD, PPL, U><<<chunk * 8, 256 / PPL, 0, s>>>(                                              \
+        (const uint2*)ranges, point_list, S, W, H, tiles_x, T, chunk, g_fwd_wave8x8, g_cull, tile_order,              \
+        (const float4*)splat, features, final_T, n_contrib, bg, out_color, out_opacity, out_depth, out_feature,       \
+        out_weights)
+    if (g_fwd_unroll >= 4) R3DG_FWD_LAUNCH(4);
+    else if (g_fwd_unroll >= 2) R3DG_FWD_LAUNCH(2);
+    else R3DG_FWD_LAUNCH(1);
+#undef R3DG_FWD_LAUNCH
 }
 
 template <int SPAD>
 static void launch_fwd_ppl(int ppl, hipStream_t s, int T, int tiles_x, const uint32_t* tile_order,
-                           const uint32_t* ranges, const uint32_t* point_list, int S, int W, int H, const float* means2D, const float* depths,
-                           const float* features, const float* colors, const float* conic_opacity, float* final_T,
-                           uint32_t* n_contrib, const float* bg, float* out_color, float* out_opacity,
-                           float* out_depth, float* out_feature, float* out_weights)
+                           const uint32_t* ranges, const uint32_t* point_list, int S, int W, int H, const float* splat,
+                           const float* features, float* final_T, uint32_t* n_contrib, const float* bg, float* out_color,
+                           float* out_opacity, float* out_depth, float* out_feature, float* out_weights)
 {
-#define R3DG_FWD_ARGS s, T, tiles_x, tile_order, ranges, point_list, S, W, H, means2D, depths, features, colors, conic_opacity, \
-                      final_T, n_contrib, bg, out_color, out_opacity, out_depth, out_feature, out_weights
+#define R3DG_FWD_ARGS s, T, tiles_x, tile_order, ranges, point_list, S, W, H, splat, features, final_T, n_contrib, bg, \
+                      out_color, out_opacity, out_depth, out_feature, out_weights
     if (ppl >= 4 && SPAD <= 20) launch_fwd_inst<SPAD, 4>(R3DG_FWD_ARGS);
     else if (ppl >= 2) launch_fwd_inst<SPAD, 2>(R3DG_FWD_ARGS);
     else launch_fwd_inst<SPAD, 1>(R3DG_FWD_ARGS);
 }
 
+// `splat`: the packed per-Gaussian records of preprocess_kernel (GeometryLayout::splat, 64-byte stride)
 void launch_render_forward(hipStream_t s, int W, int H, int S, const uint32_t* tile_order, const uint32_t* ranges,
-                           const uint32_t* point_list,
-                           const float* means2D, const float* depths, const float* features, const float* colors,
-                           const float* conic_opacity, float* final_T, uint32_t* n_contrib, const float* bg,
-                           float* out_color, float* out_opacity, float* out_depth, float* out_feature,
-                           float* out_weights)
+                           const uint32_t* point_list, const float* splat, const float* features, float* final_T,
+                           uint32_t* n_contrib, const float* bg, float* out_color, float* out_opacity, float* out_depth,
+                           float* out_feature, float* out_weights)
 {
     const int tiles_x = (W + R3DG_TILE_X - 1) / R3DG_TILE_X, tiles_y = (H + R3DG_TILE_Y - 1) / R3DG_TILE_Y;
     const int T = tiles_x * tiles_y;
