@@ -441,6 +441,20 @@ int r3dg_bvh_trace_opacity(void* stream, int64_t num_rays, int num_gaussians, co
                            const float* d_covs3D, const float* d_opacities, const float* d_normals,
                            int32_t* d_num_contributes, float* d_rendered_opacity, int32_t* d_stack_overflow);
 
+/* trace_bvh (bvh/include/bvh.h:8-12, bvh/src/trace.cu:8-192; no caller in the reference's Python): per-ray hit lists.
+ *   r3dg_bvh_trace_count: num_contributes[r] = number of leaves in the <=4-leaf subtrees ray r reaches (trace.cu:21-58);
+ *   (caller: inclusive scan of the counts into int64 offsets, allocation of the n = last offset entries)
+ *   r3dg_bvh_trace_fill: the entries of every ray in traversal order: key = ray << 32 | bits(t), point id (-1 = rejected,
+ *     t = 1e6), position = o + t d, ray id (trace.cu:88-166);
+ *   (caller: stable sort by key -- r3dg_sort_pairs -- and the gather of point_list / position_list, trace.cu:171-175). */
+int r3dg_bvh_trace_count(void* stream, int64_t num_rays, const int32_t* d_nodes, const float* d_aabbs,
+                         const float* d_rays_o, const float* d_rays_d, int32_t* d_num_contributes,
+                         int32_t* d_stack_overflow);
+int r3dg_bvh_trace_fill(void* stream, int64_t num_rays, const int32_t* d_nodes, const float* d_aabbs,
+                        const float* d_rays_o, const float* d_rays_d, const float* d_means3D,
+                        const int32_t* d_num_contributes, const int64_t* d_offsets_inclusive, uint64_t* d_keys,
+                        int32_t* d_point_list, float* d_position_list, int32_t* d_ray_id_list);
+
 /* Stable ascending radix sort of (u64 key, u32 value) pairs on key bits [0,end_bit) -- the semantics of
  * cub::DeviceRadixSort::SortPairs as used at rasterizer_impl.cu:313-318. Exposed for tests/benchmarks.
  * d_temp must hold r3dg_sort_temp_bytes(n) bytes. Inputs are clobbered (used as ping-pong space). */

@@ -1,7 +1,7 @@
 // TEST INFRASTRUCTURE ONLY -- C wrapper around the REAL reference kernels (compiled unmodified from /root/reference
 // for gfx950 by oracle/build_ref.py) so the GPU tests can compare this repo's HIP kernels with the reference's own
 // CUDA kernels on identical inputs.  Calls CudaRasterizer::Rasterizer::forward/backward (cuda_rasterizer/rasterizer.h),
-// construct_bvh (bvh/include/construct.cuh), trace_bvh_opacity_cuda (bvh/include/trace.cuh) and SimpleKNN::knn
+// construct_bvh (bvh/include/construct.cuh), trace_bvh_opacity_cuda / trace_bvh_cuda (bvh/include/trace.cuh) and SimpleKNN::knn
 // (submodules/simple-knn/simple_knn.h).  Never linked into
 // libr3dg_hip.so; the reference launches on the null stream.
 #include <hip/hip_runtime.h>
@@ -87,6 +87,25 @@ void ref_bvh_trace_opacity(int num_rays, int32_t* nodes, float* aabbs, float* ra
     trace_bvh_opacity_cuda(num_rays, nodes, aabbs, (float3*)rays_o, (float3*)rays_d, (float3*)means3D, covs3D, opacities,
                            (float3*)normals, contributes, opacity);
     (void)hipDeviceSynchronize();
+}
+
+// trace_bvh_cuda (bvh/src/trace.cu:8-192): returns num_rendered; copies the lists when they fit into `capacity` entries
+int ref_bvh_trace(int num_rays, int32_t* nodes, float* aabbs, float* rays_o, float* rays_d, float* means3D, float* covs3D,
+                  float* opacities, int32_t* num_contributes, int capacity, int32_t* point_list, float* position_list,
+                  int32_t* ray_id_list)
+{
+    auto res = trace_bvh_cuda(num_rays, nodes, aabbs, (float3*)rays_o, (float3*)rays_d, (float3*)means3D, covs3D, opacities,
+                              num_contributes);
+    (void)hipDeviceSynchronize();
+    const int n = std::get<0>(res);
+    if (n > 0 && n <= capacity) {
+        (void)hipMemcpy(point_list, thrust::raw_pointer_cast(std::get<1>(res).data()), sizeof(int32_t) * n, hipMemcpyDeviceToDevice);
+        (void)hipMemcpy(position_list, thrust::raw_pointer_cast(std::get<2>(res).data()), sizeof(float) * 3 * n,
+                        hipMemcpyDeviceToDevice);
+        (void)hipMemcpy(ray_id_list, thrust::raw_pointer_cast(std::get<3>(res).data()), sizeof(int32_t) * n, hipMemcpyDeviceToDevice);
+        (void)hipDeviceSynchronize();
+    }
+    return n;
 }
 
 // SimpleKNN::knn (submodules/simple-knn/simple_knn.cu:185)

@@ -108,6 +108,22 @@ def bvh_trace_opacity(nodes, aabbs, rays_o, rays_d, means3D, covs3D, opacities, 
     return cnt, opa
 
 
+def bvh_trace(nodes, aabbs, rays_o, rays_d, means3D, covs3D, opacities, capacity):
+    """trace_bvh_cuda of the real reference build (trace.cu:8-192) -> (num_rendered, num_contributes[N], point_list[n],
+    position_list[n,3], ray_id_list[n]); `capacity` bounds the copied list length."""
+    n_rays = rays_o.shape[0]
+    dev = rays_o.device
+    cnt = torch.zeros(n_rays, dtype=torch.int32, device=dev)
+    pts = torch.zeros(max(capacity, 1), dtype=torch.int32, device=dev)
+    pos = torch.zeros(max(capacity, 1), 3, dtype=torch.float32, device=dev)
+    rid = torch.zeros(max(capacity, 1), dtype=torch.int32, device=dev)
+    t = [x.contiguous() for x in (nodes, aabbs, rays_o, rays_d, means3D, covs3D, opacities)]
+    torch.cuda.synchronize()
+    lib().ref_bvh_trace.restype = C.c_int
+    n = lib().ref_bvh_trace(n_rays, *[_p(x) for x in t], _p(cnt), int(capacity), _p(pts), _p(pos), _p(rid))
+    return n, cnt, pts[:n], pos[:n], rid[:n]
+
+
 def knn_dist2(points):
     """SimpleKNN::knn of the real reference build; points [P,3] float32 on the GPU -> float32[P]."""
     import torch

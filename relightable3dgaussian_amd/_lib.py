@@ -40,6 +40,8 @@ _SIGNATURES = {
                                            _p, _f, _f, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p,
                                            _p, _p, _i, _i, _i, C.POINTER(_i)]),
     "r3dg_mark_visible": (_i, [_p, _i, _p, _p, _p, _p]),
+    "r3dg_bvh_trace_count": (_i, [_p, C.c_int64, _p, _p, _p, _p, _p, _p]),
+    "r3dg_bvh_trace_fill": (_i, [_p, C.c_int64] + [_p] * 11),
     "r3dg_sort_temp_bytes": (C.c_size_t, [C.c_int64]),
     "r3dg_sort_pairs": (_i, [_p, C.c_int64, _p, _p, _p, _p, _i, _p]),
     "r3dg_set_tuning": (_i, [_i, _i, _i]),

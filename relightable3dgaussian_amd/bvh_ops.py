@@ -2,8 +2,9 @@
 over the C ABI:
     create_bvh(means3D, scales, rotations, nodes, aabbs) -> (nodes, aabbs, mortons)      [nodes/aabbs mutated in place]
     trace_bvh_opacity(nodes, aabbs, rays_o, rays_d, means3D, covs3D, opacities, normals) -> (num_contributes, rendered_opacity)
-`trace_bvh` (per-ray hit lists, bvh/src/trace.cu:8-192) has no Python caller in the reference (bvh/__init__.py only
-uses the two above) and is not provided; calling it raises NotImplementedError."""
+    trace_bvh(nodes, aabbs, rays_o, rays_d, means3D, covs3D, opacities) -> (num_contributes, point_list, position_list, ray_id_list)
+`trace_bvh` (per-ray hit lists, bvh/src/trace.cu:8-192) has no Python caller in the reference (bvh/__init__.py only uses the
+two above); it is provided for completeness of the binding surface."""
 import torch
 
 from . import _lib
@@ -48,5 +49,43 @@ def trace_bvh_opacity(nodes, aabbs, rays_o, rays_d, means3D, covs3D, opacities, 
     return num_contributes, rendered_opacity
 
 
-def trace_bvh(*_args, **_kwargs):
-    raise NotImplementedError("trace_bvh (hit lists) has no caller in the reference's Python and is not provided")
+def trace_bvh(nodes, aabbs, rays_o, rays_d, means3D, covs3D, opacities):
+    """bvh/src/bvh.cu:28-86 + trace.cu:8-192: rays_o / rays_d [N,3] -> (num_contributes int32[N,1], point_list int32[n,1],
+    position_list float32[n,3], ray_id_list int32[n,1]); the entries of each ray sorted by t, rejected hits last with
+    id -1 (t = 1e6).  With no entries the reference returns zeros of shapes [0,1] int32, [0,3] float32 and -- sic --
+    [0,3] float32 for the ray ids (trace.cu:219-224); reproduced.  covs3D / opacities are accepted and unused, as in the
+    reference (its covariance-weighted t is commented out, trace.cu:121)."""
+    L = _lib.lib()
+    N = rays_o.size(0)
+    dev = rays_o.device
+    t = [x.contiguous() for x in (nodes, aabbs, rays_o, rays_d, means3D)]
+    counts = torch.zeros((N, 1), dtype=torch.int32, device=dev)
+    overflow = torch.zeros(1, dtype=torch.int32, device=dev)
+    with torch.cuda.device(dev):
+        _lib.check(L.r3dg_bvh_trace_count(_lib.current_stream(), N, t[0].data_ptr(), t[1].data_ptr(), t[2].data_ptr(),
+                                          t[3].data_ptr(), counts.data_ptr(), overflow.data_ptr()), "trace_bvh (count)")
+        offsets = torch.cumsum(counts.view(-1), 0, dtype=torch.int64)
+        n = int(offsets[-1].item()) if N > 0 else 0                      # the reference reads it back too (trace.cu:69)
+        trace_bvh.last_overflow = overflow
+        if n == 0:
+            return (counts, torch.zeros((0, 1), dtype=torch.int32, device=dev),
+                    torch.zeros((0, 3), dtype=torch.float32, device=dev), torch.zeros((0, 3), dtype=torch.float32, device=dev))
+        keys = torch.empty(n, dtype=torch.int64, device=dev)
+        points = torch.empty(n, dtype=torch.int32, device=dev)
+        positions = torch.empty((n, 3), dtype=torch.float32, device=dev)
+        ray_ids = torch.empty(n, dtype=torch.int32, device=dev)
+        _lib.check(L.r3dg_bvh_trace_fill(_lib.current_stream(), N, t[0].data_ptr(), t[1].data_ptr(), t[2].data_ptr(),
+                                         t[3].data_ptr(), t[4].data_ptr(), counts.data_ptr(), offsets.data_ptr(),
+                                         keys.data_ptr(), points.data_ptr(), positions.data_ptr(), ray_ids.data_ptr()),
+                   "trace_bvh (fill)")
+        # stable sort by (ray, bits of t): t >= 0.01 or 1e6, so the float bits order like the values
+        perm_in = torch.arange(n, dtype=torch.int32, device=dev)
+        keys_out, perm = torch.empty_like(keys), torch.empty_like(perm_in)
+        temp = torch.empty(int(L.r3dg_sort_temp_bytes(n)), dtype=torch.uint8, device=dev)
+        end_bit = 32 + max(1, int(N - 1).bit_length())
+        _lib.check(L.r3dg_sort_pairs(_lib.current_stream(), n, keys.data_ptr(), perm_in.data_ptr(), keys_out.data_ptr(),
+                                     perm.data_ptr(), min(64, end_bit), temp.data_ptr()), "trace_bvh (sort)")
+        idx = perm.long()
+        # thrust::stable_sort_by_key permutes point_list and position_list with the keys; ray_id_list is not part of the
+        # zip and stays in emission order -- which is already grouped by ray (trace.cu:171-175)
+        return counts, points[idx].unsqueeze(-1), positions[idx], ray_ids.unsqueeze(-1)

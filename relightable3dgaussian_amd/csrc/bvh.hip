@@ -641,6 +641,144 @@ trace_opacity_persistent_kernel(int num_rays, int P, const TNode* __restrict__ t
 
 int g_trace_packet = 3;    // r3dg_set_tuning8: 3 = packed records + persistent waves, 2 = packed records, 1 = wave-cooperative, 0 = round-1 kernel
 
+// ---- trace_bvh: per-ray hit lists (K19; bvh/src/trace.cu:8-192, bound at bvh/src/bindings.cpp:11) ----------------------------
+// Pass 1 counts, per ray, the leaves of every subtree of <= 4 leaves whose box the ray reaches (tmax > 0 on the way down);
+// the caller scans the counts; pass 2 repeats the walk carrying each node's (tmin, tmax) and writes one entry per such leaf:
+// t = (mean - o) . d (the POINT form of ray_intersects, utility.cuh:84-88), rejected (t = 1e6, id = -1) unless
+// 0.01 <= t and tmin <= t <= tmax of the collapsed subtree's box; key = ray << 32 | bits(t), position = o + t d.
+// The caller then sorts the entries of each ray by t (stable sort on the key).  No Python caller exists in the reference.
+__device__ __forceinline__ float2 slab_interval(const float* __restrict__ box, float ox, float oy, float oz, float dx,
+                                                float dy, float dz)
+{
+    float tmin = (box[0] - ox) / dx;
+    float tmax = (box[3] - ox) / dx;
+    if (tmin > tmax) { const float t = tmin; tmin = tmax; tmax = t; }
+    float tymin = (box[1] - oy) / dy;
+    float tymax = (box[4] - oy) / dy;
+    if (tymin > tymax) { const float t = tymin; tymin = tymax; tymax = t; }
+    if (tmin > tymax || tymin > tmax) return make_float2(-1.0f, -1.0f);
+    if (tymin > tmin) tmin = tymin;
+    if (tymax < tmax) tmax = tymax;
+    float tzmin = (box[2] - oz) / dz;
+    float tzmax = (box[5] - oz) / dz;
+    if (tzmin > tzmax) { const float t = tzmin; tzmin = tzmax; tzmax = t; }
+    if (tmin > tzmax || tzmin > tmax) return make_float2(-1.0f, -1.0f);
+    if (tzmin > tmin) tmin = tzmin;
+    if (tzmax < tmax) tmax = tzmax;
+    return make_float2(tmin, tmax);
+}
+
+__global__ void __launch_bounds__(256)
+trace_count_kernel(int num_rays, const int32_t* __restrict__ nodes, const float* __restrict__ aabbs,
+                   const float* __restrict__ rays_o, const float* __restrict__ rays_d, int32_t* __restrict__ counts,
+                   int* __restrict__ overflow)
+{
+    const int r = blockIdx.x * 256 + threadIdx.x;
+    if (r >= num_rays) return;
+    const float ox = rays_o[3 * (size_t)r], oy = rays_o[3 * (size_t)r + 1], oz = rays_o[3 * (size_t)r + 2];
+    const float dx = rays_d[3 * (size_t)r], dy = rays_d[3 * (size_t)r + 1], dz = rays_d[3 * (size_t)r + 2];
+    int stack[TRACE_STACK];
+    int sp = 0, count = 0;
+    bool lost = false;
+    stack[sp++] = 0;
+    while (sp > 0) {
+        const int32_t* node = nodes + 5 * (size_t)stack[--sp];
+        if (node[4] <= 4) {
+            count += node[4];
+        } else {
+            const int lid = node[1], rid = node[2];
+            const float tl = slab_interval(aabbs + 6 * (size_t)lid, ox, oy, oz, dx, dy, dz).y;
+            const float tr = slab_interval(aabbs + 6 * (size_t)rid, ox, oy, oz, dx, dy, dz).y;
+            const int first = tl > tr ? lid : rid, second = tl > tr ? rid : lid;
+            const float tf = tl > tr ? tl : tr, ts = tl > tr ? tr : tl;
+            if (tf > 0) { if (sp < TRACE_STACK) stack[sp++] = first; else lost = true; }
+            if (ts > 0) { if (sp < TRACE_STACK) stack[sp++] = second; else lost = true; }
+        }
+    }
+    counts[r] = count;
+    if (lost) atomicAdd(overflow, 1);
+}
+
+__global__ void __launch_bounds__(256)
+trace_fill_kernel(int num_rays, const int32_t* __restrict__ nodes, const float* __restrict__ aabbs,
+                  const float* __restrict__ rays_o, const float* __restrict__ rays_d, const float* __restrict__ means,
+                  const int32_t* __restrict__ counts, const int64_t* __restrict__ offsets_inclusive,
+                  uint64_t* __restrict__ keys, int32_t* __restrict__ points, float* __restrict__ positions,
+                  int32_t* __restrict__ ray_ids)
+{
+    const int r = blockIdx.x * 256 + threadIdx.x;
+    if (r >= num_rays) return;
+    if (counts[r] == 0) return;
+    const size_t offset = r == 0 ? 0 : (size_t)offsets_inclusive[r - 1];
+    const float ox = rays_o[3 * (size_t)r], oy = rays_o[3 * (size_t)r + 1], oz = rays_o[3 * (size_t)r + 2];
+    const float dx = rays_d[3 * (size_t)r], dy = rays_d[3 * (size_t)r + 1], dz = rays_d[3 * (size_t)r + 2];
+    int stack[TRACE_STACK];
+    float2 stack_t[TRACE_STACK];
+    int sp = 0, count = 0;
+    stack[0] = 0;
+    stack_t[0] = make_float2(-1000.f, 1000.f);
+    sp = 1;
+    while (sp > 0) {
+        --sp;
+        const int node_id = stack[sp];
+        const float2 iv = stack_t[sp];
+        const int32_t* node = nodes + 5 * (size_t)node_id;
+        if (node[4] <= 4) {
+            int stack2[8];
+            int sp2 = 0;
+            stack2[sp2++] = node_id;
+            while (sp2 > 0) {
+                const int32_t* n2 = nodes + 5 * (size_t)stack2[--sp2];
+                if (n2[3] >= 0) {
+                    int object_id = n2[3];
+                    float t = (means[3 * (size_t)object_id] - ox) * dx + (means[3 * (size_t)object_id + 1] - oy) * dy +
+                              (means[3 * (size_t)object_id + 2] - oz) * dz;
+                    if (t < 0.01 || t < iv.x || t > iv.y) {
+                        t = 1000000.f;
+                        object_id = -1;
+                    }
+                    const size_t w = offset + (size_t)count;
+                    keys[w] = ((uint64_t)(uint32_t)r << 32) | (uint64_t)__float_as_uint(t);
+                    points[w] = object_id;
+                    ray_ids[w] = r;
+                    positions[3 * w] = ox + t * dx;
+                    positions[3 * w + 1] = oy + t * dy;
+                    positions[3 * w + 2] = oz + t * dz;
+                    ++count;
+                } else if (sp2 + 2 <= 8) {
+                    stack2[sp2++] = n2[1];
+                    stack2[sp2++] = n2[2];
+                }
+            }
+        } else {
+            const int lid = node[1], rid = node[2];
+            const float2 il = slab_interval(aabbs + 6 * (size_t)lid, ox, oy, oz, dx, dy, dz);
+            const float2 ir = slab_interval(aabbs + 6 * (size_t)rid, ox, oy, oz, dx, dy, dz);
+            const bool lf = il.y > ir.y;
+            const int first = lf ? lid : rid, second = lf ? rid : lid;
+            const float2 i1 = lf ? il : ir, i2 = lf ? ir : il;
+            if (i1.y > 0 && sp < TRACE_STACK) { stack[sp] = first; stack_t[sp] = i1; sp++; }
+            if (i2.y > 0 && sp < TRACE_STACK) { stack[sp] = second; stack_t[sp] = i2; sp++; }
+        }
+    }
+}
+
+void bvh_trace_count(hipStream_t s, int num_rays, const int32_t* nodes, const float* aabbs, const float* rays_o,
+                     const float* rays_d, int32_t* counts, int* overflow)
+{
+    if (num_rays <= 0) return;
+    trace_count_kernel<<<(num_rays + 255) / 256, 256, 0, s>>>(num_rays, nodes, aabbs, rays_o, rays_d, counts, overflow);
+}
+
+void bvh_trace_fill(hipStream_t s, int num_rays, const int32_t* nodes, const float* aabbs, const float* rays_o,
+                    const float* rays_d, const float* means, const int32_t* counts, const int64_t* offsets_inclusive,
+                    uint64_t* keys, int32_t* points, float* positions, int32_t* ray_ids)
+{
+    if (num_rays <= 0) return;
+    trace_fill_kernel<<<(num_rays + 255) / 256, 256, 0, s>>>(num_rays, nodes, aabbs, rays_o, rays_d, means, counts,
+                                                            offsets_inclusive, keys, points, positions, ray_ids);
+}
+
 // ---- host ----
 size_t bvh_build_temp_bytes(size_t P)
 {

@@ -142,6 +142,11 @@ size_t knn_temp_bytes(size_t P);
 void knn_dist2(hipStream_t s, int P, const float* pts, float* dists, void* temp);
 size_t bvh_build_temp_bytes(size_t P);
 void bvh_build(hipStream_t s, int P, int32_t* nodes, float* aabbs, uint64_t* morton, void* temp);
+void bvh_trace_count(hipStream_t s, int num_rays, const int32_t* nodes, const float* aabbs, const float* rays_o,
+                     const float* rays_d, int32_t* counts, int* overflow);
+void bvh_trace_fill(hipStream_t s, int num_rays, const int32_t* nodes, const float* aabbs, const float* rays_o,
+                    const float* rays_d, const float* means, const int32_t* counts, const int64_t* offsets_inclusive,
+                    uint64_t* keys, int32_t* points, float* positions, int32_t* ray_ids);
 void bvh_trace_opacity(hipStream_t s, int num_rays, int P, const int32_t* nodes, const float* aabbs, const float* rays_o,
                        const float* rays_d, const float* means, const float* covs, const float* opac,
                        const float* normals, int32_t* contributes, float* out, int* overflow);
@@ -1368,6 +1373,38 @@ int r3dg_bvh_trace_opacity(void* stream_, int64_t num_rays, int num_gaussians, c
 }
 
 size_t r3dg_sort_temp_bytes(int64_t n) { return sort_temp_bytes((size_t)(n > 0 ? n : 0)); }
+
+int r3dg_bvh_trace_count(void* stream_, int64_t num_rays, const int32_t* nodes, const float* aabbs, const float* rays_o,
+                         const float* rays_d, int32_t* num_contributes, int32_t* stack_overflow)
+{
+    if (num_rays < 0 || num_rays > 0x7fffffffll) return invalid("bvh_trace_count: bad ray count");
+    if (num_rays == 0) return R3DG_OK;
+    if (!nodes || !aabbs || !rays_o || !rays_d || !num_contributes || !stack_overflow)
+        return invalid("bvh_trace_count: null buffer");
+    return guarded([&]() -> int {
+        bvh_trace_count((hipStream_t)stream_, (int)num_rays, nodes, aabbs, rays_o, rays_d, num_contributes, stack_overflow);
+        check_launch((hipStream_t)stream_, false, "bvh_trace_count");
+        return R3DG_OK;
+    });
+}
+
+int r3dg_bvh_trace_fill(void* stream_, int64_t num_rays, const int32_t* nodes, const float* aabbs, const float* rays_o,
+                        const float* rays_d, const float* means3D, const int32_t* num_contributes,
+                        const int64_t* offsets_inclusive, uint64_t* keys, int32_t* point_list, float* position_list,
+                        int32_t* ray_id_list)
+{
+    if (num_rays < 0 || num_rays > 0x7fffffffll) return invalid("bvh_trace_fill: bad ray count");
+    if (num_rays == 0) return R3DG_OK;
+    if (!nodes || !aabbs || !rays_o || !rays_d || !means3D || !num_contributes || !offsets_inclusive || !keys ||
+        !point_list || !position_list || !ray_id_list)
+        return invalid("bvh_trace_fill: null buffer");
+    return guarded([&]() -> int {
+        bvh_trace_fill((hipStream_t)stream_, (int)num_rays, nodes, aabbs, rays_o, rays_d, means3D, num_contributes,
+                       offsets_inclusive, keys, point_list, position_list, ray_id_list);
+        check_launch((hipStream_t)stream_, false, "bvh_trace_fill");
+        return R3DG_OK;
+    });
+}
 
 int r3dg_sort_pairs(void* stream_, int64_t n, uint64_t* keys_in, uint32_t* vals_in, uint64_t* keys_out,
                     uint32_t* vals_out, int end_bit, void* temp)

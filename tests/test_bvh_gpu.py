@@ -66,5 +66,53 @@ def test_bvh_ops_shapes_and_errors():
     with pytest.raises(RuntimeError):
         _C.create_bvh(sc["xyz"].to(DEV), sc["scales"].to(DEV), sc["rotations"].to(DEV),
                       torch.zeros(10, 5, dtype=torch.int32, device=DEV), torch.zeros(10, 6, device=DEV))
-    with pytest.raises(NotImplementedError):
-        _C.trace_bvh()
+
+
+
+@pytest.mark.parametrize("P,seed,K", [(1, 0, 4), (3, 1, 8), (40, 2, 16), (3000, 3, 8)])
+def test_trace_bvh_hit_lists_are_consistent(P, seed, K):
+    """trace_bvh (bvh/src/trace.cu:8-192): per-ray hit lists.  Properties that hold by construction: the list length is the
+    sum of the counts; every ray's segment is sorted by t with the rejected entries (id -1, t = 1e6) last; accepted
+    entries satisfy t = (mean - o).d >= 0.01 and position = o + t d; the candidate set of a ray contains every Gaussian
+    whose own leaf box the ray hits with tmax > 0 (brute force)."""
+    from bvh_tracing import _C
+    from relightable3dgaussian_amd import bvh as hb
+    sc, dirs, cinv, rays_o = _bvh_case(P, seed, K=K, dup=P > 100)
+    d = {k: v.to(DEV) for k, v in sc.items() if torch.is_tensor(v)}
+    nodes, aabbs = hb.leaf_boxes(d["xyz"], d["scales"], d["rotations"])
+    nodes, aabbs, _ = _C.create_bvh(d["xyz"], d["scales"], d["rotations"], nodes, aabbs)
+    ro, rd = rays_o.reshape(-1, 3).to(DEV), dirs.reshape(-1, 3).to(DEV)
+    cnt, pts, pos, rid = _C.trace_bvh(nodes, aabbs, ro, rd, d["xyz"], cinv.to(DEV), d["opacity"][:, 0].contiguous())
+    torch.cuda.synchronize()
+    N = ro.shape[0]
+    assert cnt.shape == (N, 1) and cnt.dtype == torch.int32
+    n = int(cnt.sum())
+    if n == 0:
+        assert pts.shape == (0, 1) and pos.shape == (0, 3) and rid.shape == (0, 3)
+        return
+    assert pts.shape == (n, 1) and pos.shape == (n, 3) and rid.shape == (n, 1)
+    assert torch.equal(rid[:, 0].long(), torch.repeat_interleave(torch.arange(N, device=DEV), cnt[:, 0].long()))
+    r = rid[:, 0].long()
+    t = ((pos - ro[r]) * rd[r]).sum(-1) / (rd[r] * rd[r]).sum(-1)           # position = o + t d
+    ok = pts[:, 0] >= 0
+    g = pts[ok, 0].long()
+    t_mean = ((d["xyz"][g] - ro[r[ok]]) * rd[r[ok]]).sum(-1)
+    if g.numel():
+        assert (t_mean >= 0.01 - 1e-6).all() and (t[ok] - t_mean).abs().max().item() < 1e-4 * max(1.0, t_mean.abs().max().item())
+    assert (t[~ok] > 1e5).all()
+    same = r[1:] == r[:-1]
+    assert (t[1:][same] >= t[:-1][same] - 1e-4 * t[:-1][same].abs().clamp_min(1.0)).all(), "a ray's entries are not sorted by t"
+    # brute force: a Gaussian whose own leaf box is hit (tmax > 0) and whose projected distance passes must be listed
+    if P <= 100:
+        leaf = aabbs[P - 1:]
+        obj = nodes[P - 1:, 3].long()
+        for ray in range(0, N, max(1, N // 24)):
+            o, dd = ro[ray].cpu().double(), rd[ray].cpu().double()
+            listed = set(pts[r == ray, 0].tolist())
+            for j in range(P):
+                lo, hi = leaf[j, :3].cpu().double(), leaf[j, 3:].cpu().double()
+                t0, t1 = (lo - o) / dd, (hi - o) / dd
+                tmin, tmax = torch.minimum(t0, t1).max().item(), torch.maximum(t0, t1).min().item()
+                tm = float(((d["xyz"][obj[j]].cpu().double() - o) * dd).sum())
+                if tmax > 1e-4 and tmin < tmax - 1e-6 and tm > 0.011 and tmin + 1e-5 < tm < tmax - 1e-5:
+                    assert int(obj[j]) in listed, (ray, j)
