@@ -323,3 +323,26 @@ def test_blender_dataset_writer_is_read_back_by_the_reference_reader(tmp_path):
     radius, translate = syn.cameras_extent(cams)
     assert abs(radius - float(z["extent_radius"])) < 1e-5 * radius
     np.testing.assert_allclose(translate, z["extent_translate"], rtol=0, atol=1e-5)
+
+
+def test_stage1_loss_restatement_equals_the_reference_calculate_loss():
+    """train_step.stage1_loss (the parity target of the fused stage-1 iteration, incl. the restated kornia Sobel stencil) on the
+    maps the reference's own render_view produced = the loss its own calculate_loss returned, term by term
+    (tests/golden/pipeline_reference_stage1.npz, made by tests/golden/make_pipeline_golden.py from the unmodified reference)."""
+    import numpy as np
+    from relightable3dgaussian_amd import train_step as ts
+    z = np.load(os.path.join(GOLDEN, "pipeline_reference_stage1.npz"))
+    t = lambda k: torch.from_numpy(z[k])
+    opacity, image, gt, mask = t("map_opacity"), t("map_render"), t("gt"), t("mask")
+    normal, depth, var = t("map_normal"), t("map_depth"), t("map_depth_var")
+    # rebuild the rasterizer's premultiplied feature row from the divided maps (the division is undone exactly where it happened)
+    n_contrib = (opacity[0] > 0).int()
+    feature = torch.cat([normal, depth, var + depth.square()], 0) * opacity.clamp_min(1e-5)
+    outs = (0, n_contrib, image, opacity, None, feature, t("map_pseudo_normal"), None, None, None)
+    it = int(z["iteration"])
+    loss = ts.stage1_loss(outs, gt, mask, None, it)
+    assert abs(float(loss) - float(z["loss"])) < 2e-6 * max(1.0, abs(float(z["loss"])))
+    l1, ssim_v, ent, nrd, nsm, dvar = [float(v) for v in z["tb"]]
+    assert abs(float((image - gt).abs().mean()) - l1) < 1e-6 and abs(float(ts.ssim(image, gt)) - ssim_v) < 2e-6
+    assert abs(float(ts.first_order_edge_aware_loss(normal, gt)) - nsm) < 2e-6
+    assert abs(float(var.clamp_min(1e-6).sqrt().mean()) - dvar) < 2e-6
