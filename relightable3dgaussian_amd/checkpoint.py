@@ -22,6 +22,15 @@ PBR_GROUPS = ("base_color", "roughness", "incidents_dc", "incidents_rest", "visi
 STAT_NAMES = ("weights_accum", "xyz_gradient_accum", "normal_gradient_accum", "denom")
 
 
+def reference_learning_rates(spatial_lr_scale=1.0):
+    """The param_group rates GaussianModel.training_setup installs (scene/gaussian_model.py:465-486) from the defaults of
+    arguments/__init__.py:70-97 (position_lr_init 1.6e-4 * spatial_lr_scale, normal 0.01, rotation 0.001, scaling 0.005,
+    opacity 0.05, sh 0.0025 and /20, base_color / roughness 0.01, light 0.001 / 0.0001, visibility 0.0025)."""
+    return dict(xyz=0.00016 * spatial_lr_scale, normal=0.01, rotation=0.001, scaling=0.005, opacity=0.05, f_dc=0.0025,
+                f_rest=0.0025 / 20.0, base_color=0.01, roughness=0.01, incidents_dc=0.001, incidents_rest=0.0001,
+                visibility_dc=0.0025, visibility_rest=0.0025)
+
+
 def _named_tensors(step):
     """Reference group name -> (parameter, exp_avg, exp_avg_sq) views of a fused step object (its single [P,16,3] SH /
     incident tensors are split into the dc / rest groups the reference keeps)."""
@@ -42,7 +51,10 @@ def _named_tensors(step):
 def capture(step, iteration, spatial_lr_scale=1.0, active_sh_degree=3, learning_rates=None):
     """-> the object train.py saves: `(GaussianModel.capture() list, iteration)`.  `step`: FusedStage1Step or
     FusedStage2Step (stage 2 adds the six PBR entries; the baked-visibility SH groups this repo does not train are
-    written as zeros of the reference's shapes).  `learning_rates`: optional {group name: lr} for the param_groups."""
+    written as zeros of the reference's shapes).  `learning_rates`: {group name: lr} for the param_groups -- torch's
+    Optimizer.load_state_dict ADOPTS the saved groups' hyper-parameters, so a reference GaussianModel.restore(is_training=
+    True) on this file trains with exactly these rates; the default is the reference's own training_setup values
+    (reference_learning_rates), never zero."""
     named = _named_tensors(step)
     P = step.xyz.shape[0]
     dev = step.xyz.device
@@ -53,8 +65,9 @@ def capture(step, iteration, spatial_lr_scale=1.0, active_sh_degree=3, learning_
         named["visibility_rest"] = (z(P, 15, 1), z(P, 15, 1), z(P, 15, 1))
     names = STAGE1_GROUPS + (PBR_GROUPS if pbr else ())
     params = {n: nn.Parameter(named[n][0].detach().clone().contiguous().requires_grad_(True)) for n in names}
-    lrs = dict(learning_rates or {})
-    optimizer = torch.optim.Adam([{"params": [params[n]], "lr": float(lrs.get(n, 0.0)), "name": n} for n in names],
+    lrs = reference_learning_rates(spatial_lr_scale)
+    lrs.update(learning_rates or {})
+    optimizer = torch.optim.Adam([{"params": [params[n]], "lr": float(lrs[n]), "name": n} for n in names],
                                  lr=0.0, eps=1e-15)
     steps = float(step.opt.step_count)
     for n in names:
@@ -74,15 +87,24 @@ def capture(step, iteration, spatial_lr_scale=1.0, active_sh_degree=3, learning_
     return captured, int(iteration)
 
 
-def restore(checkpoint, device=None):
+def restore(checkpoint, device=None, pbr=False):
     """`checkpoint`: the `(captured list, iteration)` object (or a path to one).  -> namespace with the raw parameters
     under this repo's names (xyz, normal, scaling, rotation, opacity, features_dc, features_rest [, base_color, roughness,
     incidents_dc, incidents_rest, visibility_dc, visibility_rest]), `moments` {reference group name: (exp_avg, exp_avg_sq)}
     (empty without optimizer state), `adam_steps`, `stats` {name: [P] tensor} + `max_radii2D`, `active_sh_degree`,
-    `spatial_lr_scale`, `iteration`.  It can be handed to FusedStage1Step / FusedStage2Step as their `params`;
-    `load_moments` then puts the Adam state in place."""
+    `spatial_lr_scale`, `iteration`.  A stage-1 file (15 entries) can be handed to FusedStage1Step as its `params`.
+    `pbr=True` is the stage-1 -> stage-2 hand-off of every run script (`train.py -t neilf -c .../3dgs/chkpnt30000.pth`):
+    as GaussianModel.create_from_ckpt does for a 15-entry file (scene/gaussian_model.py:381-403), base_color, roughness,
+    incidents and the visibility SH groups are ZERO-initialised, so the result (+ an `env` of the caller's,
+    DirectLightMap) can be handed to FusedStage2Step.  The reference-faithful hand-off does NOT carry the Adam state over:
+    train.py calls create_from_ckpt(restore_optimizer=True) before training_setup, when `optimizer` is still None, and
+    swallows the exception -- stage 2 starts with fresh moments and step count.  `load_moments` is for resuming the SAME
+    stage from this repo's own checkpoints."""
     if isinstance(checkpoint, (str, bytes)) or hasattr(checkpoint, "__fspath__"):
-        checkpoint = torch.load(checkpoint, map_location="cpu", weights_only=False)
+        try:            # tensors, Parameters, dicts, lists: loadable without arbitrary unpickling
+            checkpoint = torch.load(checkpoint, map_location="cpu", weights_only=True)
+        except Exception:
+            checkpoint = torch.load(checkpoint, map_location="cpu", weights_only=False)
     captured, iteration = checkpoint
     if len(captured) not in (15, 21):
         raise RuntimeError("not a GaussianModel checkpoint: %d entries" % len(captured))
@@ -99,6 +121,12 @@ def restore(checkpoint, device=None):
         for j, n in enumerate(PBR_GROUPS):
             setattr(out, n, to(captured[15 + j]).clone().contiguous())
         names = STAGE1_GROUPS + PBR_GROUPS
+    elif pbr:
+        P = out.xyz.shape[0]
+        z = lambda *s: torch.zeros(*s, dtype=torch.float32, device=out.xyz.device)
+        out.base_color, out.roughness = z(P, 3), z(P, 1)
+        out.incidents_dc, out.incidents_rest = z(P, 1, 3), z(P, 15, 3)
+        out.visibility_dc, out.visibility_rest = z(P, 1, 1), z(P, 15, 1)
     opt = captured[13]
     out.moments, out.adam_steps = {}, 0
     group_names = [g.get("name") for g in opt.get("param_groups", [])]
@@ -114,7 +142,8 @@ def restore(checkpoint, device=None):
 
 def load_moments(step, restored):
     """Adam state of a restored checkpoint into a fused step built from it (`FusedStageNStep(restored, ...)`): exp_avg /
-    exp_avg_sq of every group the optimizer knows, dc / rest halves re-joined, and the shared step count."""
+    exp_avg_sq of every group the optimizer knows, dc / rest halves re-joined, and the shared step count.  For resuming
+    the same stage; the reference's stage-1 -> stage-2 hand-off starts from fresh moments (see restore)."""
     order = step._opt_order
     slot = {k: step.opt.groups[i] for i, k in enumerate(order)}
     m = restored.moments

@@ -346,3 +346,26 @@ def test_stage1_loss_restatement_equals_the_reference_calculate_loss():
     assert abs(float((image - gt).abs().mean()) - l1) < 1e-6 and abs(float(ts.ssim(image, gt)) - ssim_v) < 2e-6
     assert abs(float(ts.first_order_edge_aware_loss(normal, gt)) - nsm) < 2e-6
     assert abs(float(var.clamp_min(1e-6).sqrt().mean()) - dvar) < 2e-6
+
+
+def test_checkpoint_defaults_follow_the_reference_flow():
+    """(a) capture() without learning_rates writes the reference's training_setup rates (Optimizer.load_state_dict adopts the saved
+    groups' hyper-parameters: lr 0 would freeze a reference GaussianModel restored from the file); (b) restore(pbr=True) of a
+    15-entry stage-1 file zero-initialises the PBR parameters exactly as GaussianModel.create_from_ckpt does
+    (scene/gaussian_model.py:381-403)."""
+    from relightable3dgaussian_amd import checkpoint as ck
+    r = ck.restore(os.path.join(GOLDEN, "checkpoint_reference_stage1.pth"))
+    P = r.xyz.shape[0]
+    holder = types.SimpleNamespace(
+        xyz=r.xyz, normal=r.normal, scaling=r.scaling, rotation=r.rotation, opacity=r.opacity,
+        shs=torch.cat([r.features_dc, r.features_rest], 1), _opt_order=("xyz", "normal", "scaling", "rotation", "opacity", "shs"),
+        opt=types.SimpleNamespace(step_count=0, groups=[dict(exp_avg=torch.zeros_like(t), exp_avg_sq=torch.zeros_like(t)) for t in (
+            r.xyz, r.normal, r.scaling, r.rotation, r.opacity, torch.cat([r.features_dc, r.features_rest], 1))]))
+    captured, it = ck.capture(holder, 123, spatial_lr_scale=2.0)
+    lrs = {g["name"]: g["lr"] for g in captured[13]["param_groups"]}
+    assert lrs == {"xyz": 0.00016 * 2.0, "normal": 0.01, "rotation": 0.001, "scaling": 0.005, "opacity": 0.05, "f_dc": 0.0025,
+                   "f_rest": 0.0025 / 20.0}
+    s2 = ck.restore(os.path.join(GOLDEN, "checkpoint_reference_stage1.pth"), pbr=True)
+    assert s2.base_color.shape == (P, 3) and s2.roughness.shape == (P, 1) and s2.incidents_dc.shape == (P, 1, 3)
+    assert s2.incidents_rest.shape == (P, 15, 3) and s2.visibility_rest.shape == (P, 15, 1)
+    assert all(float(t.abs().max()) == 0.0 for t in (s2.base_color, s2.roughness, s2.incidents_dc, s2.incidents_rest))
