@@ -493,6 +493,10 @@ int r3dg_set_tuning7(int shade_forward_rows, int row_blocks_per_cu);
  * next ray (per-ray semantics and visit order of the reference); 1 = wave-cooperative (64 rays share one traversal stack and
  * visit the union of their nodes: measured slower, kept for comparison); 0 = one fixed ray per thread (round 1). */
 int r3dg_set_tuning8(int trace_packet);
+/* r3dg_set_tuning9: shading backward formulation: 0 (default) = 16 lanes per Gaussian, three passes; 1 = row kernel (one wave
+ * per Gaussian, lane = sample, the 55 per-Gaussian sums through an LDS role exchange) -- measured equal (0.46 ms), kept for
+ * comparison. */
+int r3dg_set_tuning9(int shade_backward_rows);
 int r3dg_selftest_transpose_reduce(void* stream, int N, int dpp, const float* d_in, float* d_out, int* d_chan,
                                    int* d_owner);
 

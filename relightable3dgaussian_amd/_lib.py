@@ -52,6 +52,7 @@ _SIGNATURES = {
     "r3dg_set_tuning6": (_i, [_i]),
     "r3dg_set_tuning7": (_i, [_i, _i]),
     "r3dg_set_tuning8": (_i, [_i]),
+    "r3dg_set_tuning9": (_i, [_i]),
     "r3dg_selftest_transpose_reduce": (_i, [_p, _i, _i, _p, _p, _p, _p]),
     "r3dg_shade_forward": (_i, [_p, _i, _i, _i, _p, _p, _p, _p, _p, _p, _i, _i, _p, _p, _p, _p, _p]),
     "r3dg_shade_forward_cached": (_i, [_p, _i, _i, _i, _p, _p, _p, _p, _p, _p, _i, _i, _p, _p, _p, _p, _f, _p, _i, _p]),

@@ -105,6 +105,9 @@ def _algorithmic_bytes(stage, P, R, N, S, K=64):
         "stage2_unpack_gradients": 164.0 * P,
         "stage2_activate_backward": (68.0 + 64 + 28 + 44 + 72) * P,
         "stage2_loss": (27.0 + 20.0) * 4 * N,
+        # relight frame glue: S=28 feature row (19 + 13 floats read, 28 written); composite (19 maps read ... 76 B / pixel)
+        "relight_pack_features": 188.0 * P,
+        "relight_compose": 76.0 * N,
     }[stage]
 
 

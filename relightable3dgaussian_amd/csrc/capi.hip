@@ -57,6 +57,7 @@ void launch_shade_build_taps(hipStream_t s, size_t n, const float* dirs, const f
                              uint32_t* taps);
 extern int g_trace_packet;
 extern int g_shade_fwd_rows;
+extern int g_shade_bwd_rows;
 extern int g_shade_row_blocks_per_cu;
 void launch_shade_backward(hipStream_t s, int P, int K, int M, const float* base_color, const float* roughness,
                            const float* normals, const float* viewdirs, const float* incidents, const float* env,
@@ -167,13 +168,14 @@ void launch_transpose_selftest(hipStream_t s, int N, int dpp, const float* in, f
 // ---- optional per-stage timing with HIP events on the launch stream (bench.py's roofline numbers) ----
 enum Stage { ST_PREPROCESS = 0, ST_DUPKEYS, ST_SORT, ST_RANGES, ST_RENDER_FWD, ST_NORMAL, ST_RENDER_BWD, ST_PREPROCESS_BWD,
              ST_SHADE_FWD, ST_SHADE_BWD, ST_BVH_BUILD, ST_BVH_TRACE, ST_S2_ACTIVATE, ST_S2_PACK, ST_S2_LOSS,
-             ST_S2_UNPACK, ST_S2_ACTIVATE_BWD, ST_ADAM, ST_KNN, ST_SSIM, ST_DENSIFY, ST_COUNT };
+             ST_S2_UNPACK, ST_S2_ACTIVATE_BWD, ST_ADAM, ST_KNN, ST_SSIM, ST_DENSIFY, ST_RELIGHT_PACK, ST_RELIGHT_COMPOSE,
+             ST_COUNT };
 static const char* kStageNames[ST_COUNT] = {"preprocess", "duplicate_with_keys", "sort_pairs", "identify_tile_ranges",
                                             "render_forward", "pseudo_normal", "render_backward", "preprocess_backward",
                                             "shade_forward", "shade_backward", "bvh_build", "bvh_trace",
                                             "stage2_activate", "stage2_pack_features", "stage2_loss",
                                             "stage2_unpack_gradients", "stage2_activate_backward", "adam_step",
-                                            "knn_dist2", "ssim", "densify"};
+                                            "knn_dist2", "ssim", "densify", "relight_pack_features", "relight_compose"};
 static int g_profiling = 0;
 struct EventPair { hipEvent_t a, b; };
 static std::vector<EventPair> g_events[ST_COUNT];
@@ -308,6 +310,12 @@ int r3dg_set_tuning6(int shade_forward_blocks_per_cu)
 int r3dg_set_tuning8(int trace_packet)
 {
     if (trace_packet >= 0 && trace_packet <= 3) g_trace_packet = trace_packet;
+    return R3DG_OK;
+}
+
+int r3dg_set_tuning9(int shade_backward_rows)
+{
+    if (shade_backward_rows >= 0) g_shade_bwd_rows = shade_backward_rows ? 1 : 0;
     return R3DG_OK;
 }
 
@@ -1213,7 +1221,7 @@ int r3dg_relight_pack_features(void* stream_, int P, const float* xyz, const flo
         return invalid("relight_pack_features: null buffer");
     if ((size_t)features & 15) return invalid("relight_pack_features: features must be 16-byte aligned");
     return guarded([&]() -> int {
-        StageTimer t((hipStream_t)stream_, ST_S2_PACK);
+        StageTimer t((hipStream_t)stream_, ST_RELIGHT_PACK);
         launch_relight_pack((hipStream_t)stream_, P, xyz, viewmatrix, normal, base_color, roughness, shade_out, features);
         return R3DG_OK;
     });
@@ -1231,6 +1239,7 @@ int r3dg_relight_compose(void* stream_, int width, int height, float focal_x, fl
     if (render_env && !image) return invalid("relight_compose: render_env needs the rendered image");
     if (!(focal_x > 0.f) || !(focal_y > 0.f)) return invalid("relight_compose: focal lengths must be positive");
     return guarded([&]() -> int {
+        StageTimer t((hipStream_t)stream_, ST_RELIGHT_COMPOSE);
         launch_relight_compose((hipStream_t)stream_, width, height, focal_x, focal_y, cx, cy, viewmatrix, light_transform,
                                envmap, He, We, image, opacity, feature, n_contrib, pbr_env, render_env, env_only);
         return R3DG_OK;

@@ -636,13 +636,13 @@ __device__ __forceinline__ RowSample load_row_sample(bool live, int g, int lane,
                                                      const float* __restrict__ rec, const float* __restrict__ dirs,
                                                      const float* __restrict__ visibility,
                                                      const float* __restrict__ areas, float uniform_area,
-                                                     const uint32_t* __restrict__ taps)
+                                                     const uint32_t* __restrict__ taps, int rec_stride = REC)
 {
     RowSample r;
     r.dx = 0.f; r.dy = 0.f; r.dz = 1.f; r.vis = 0.f; r.area = 0.f;
     r.t.xy = 0x00010001u; r.t.wx1 = 0.f; r.t.wy1 = 0.f;
     const size_t row = (size_t)g * (size_t)K;
-    const float* __restrict__ rrow = rec + (size_t)g * REC;
+    const float* __restrict__ rrow = rec + (size_t)g * rec_stride;
     const float* __restrict__ drow = dirs + 3 * row;
     const float* __restrict__ vrow = visibility + row;
     r.rec = rrow[(unsigned)lane];
@@ -1081,6 +1081,282 @@ shade_backward_kernel(int P, int K, int M, ShadeSrc src, const float* __restrict
     }
 }
 
+// =====================================================================================================================
+// Backward, row formulation: ONE WAVE PER GAUSSIAN, lane = sample (the forward row kernel's layout).
+// The 16-lane kernel above spends its instructions on three passes over every sample (the live state of one pass is all the
+// registers allow), recomputes the SH basis twice and re-reads the 48 coefficients from LDS per sample.  Here a lane does its
+// one sample in a single pass and keeps the basis in registers; what the 16-lane layout got for free -- the sum over a
+// Gaussian's samples of 48 + 7 per-sample products -- becomes a [55 x 64] . [64] contraction per Gaussian and is done by
+// EXCHANGING ROLES THROUGH LDS instead of a 64-lane butterfly (63 exchange steps for 64 channels ~ 130 VALU instructions +
+// 48 multiplies per row): every lane writes its 16 basis values, its 3 "dL / d local light" values and its 7 scalar
+// gradients into a per-wave LDS tile ([channel][sample], row stride 68 floats = conflict-free for 16-byte reads), then lane
+// j < 55 OWNS output channel j and walks the 64 samples with 2 x 16 ds_read_b128 + 64 FMAs (the 7 scalar sums multiply a
+// row of ones, so all 55 lanes run the same instruction stream).  K > 64: the owner lane accumulates over the blocks.
+// Per-Gaussian constants come from an 80-float record (shade_prepare_bwd_kernel), the lat-long lookups from the cached
+// taps, the texture gradient goes through the same 64-bit fixed-point LDS accumulators as before.
+// =====================================================================================================================
+constexpr int RECB = 80;
+// record: 0..63 as the forward's, 64 |viewdir|, 65 alpha, 66 raw N.V, 68..70 dL_dpbr / K, 72..74 dL_ddiffuse_light / K
+__global__ void __launch_bounds__(256)
+shade_prepare_bwd_kernel(int P, int K, int M, const float* __restrict__ base_color, const float* __restrict__ roughness,
+                         const float* __restrict__ normals, const float* __restrict__ viewdirs,
+                         const float* __restrict__ incidents, const float* __restrict__ g_pbr,
+                         const float* __restrict__ g_diff, float* __restrict__ rec)
+{
+    const int g0 = blockIdx.x * 64;
+    const int ng = min(64, P - g0);
+    const int row = 3 * M;
+    for (int i = threadIdx.x; i < ng * 48; i += 256) {
+        const int gl = i / 48, e = i - gl * 48;
+        rec[(size_t)(g0 + gl) * RECB + e] = e < row ? incidents[(size_t)(g0 + gl) * row + e] : 0.f;
+    }
+    if ((int)threadIdx.x < ng) {
+        const int g = g0 + threadIdx.x;
+        float u[64];
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+            u[48 + c] = base_color[3 * (size_t)g + c];
+            u[52 + c] = normals[3 * (size_t)g + c];
+            u[55 + c] = viewdirs[3 * (size_t)g + c];
+        }
+        u[51] = roughness[g];
+        GaussFwd G;
+        gauss_setup(G, u);
+        const float invK = 1.0f / (float)K;
+        float4* o = reinterpret_cast<float4*>(rec + (size_t)g * RECB + 48);
+        o[0] = make_float4(u[48], u[49], u[50], u[51]);
+        o[1] = make_float4(G.n[0], G.n[1], G.n[2], G.V[0]);
+        o[2] = make_float4(G.V[1], G.V[2], G.N[0], G.N[1]);
+        o[3] = make_float4(G.N[2], G.NoV, G.a2, G.kk);
+        o[4] = make_float4(G.vlen, G.a, G.rawNoV, 0.f);
+        o[5] = make_float4(g_pbr[3 * (size_t)g] * invK, g_pbr[3 * (size_t)g + 1] * invK, g_pbr[3 * (size_t)g + 2] * invK, 0.f);
+        o[6] = make_float4(g_diff[3 * (size_t)g] * invK, g_diff[3 * (size_t)g + 1] * invK, g_diff[3 * (size_t)g + 2] * invK, 0.f);
+        o[7] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+}
+
+constexpr int RB_WAVES = 4;
+constexpr int RB_STRIDE = 68;                 // floats per [channel] row of the exchange tile (64 samples + 4: bank spread)
+constexpr int RB_ROWS = 16 + 3 + 7 + 1;       // basis, dL/dlocal, scalar gradients, ones
+constexpr int RB_TILE = RB_ROWS * RB_STRIDE;  // floats per wave
+
+template <bool ENV_LDS, bool TAPS, bool M16>
+__global__ void __launch_bounds__(64 * RB_WAVES)
+shade_backward_row_kernel(int P, int K, int M_, const float* __restrict__ rec, const float4* __restrict__ env4, int He, int We,
+                          const float* __restrict__ tr, const float* __restrict__ visibility,
+                          const float* __restrict__ dirs, const float* __restrict__ areas, float uniform_area,
+                          const uint32_t* __restrict__ taps, float* __restrict__ d_base, float* __restrict__ d_rough,
+                          float* __restrict__ d_view, float* __restrict__ d_inc, float* __restrict__ d_env,
+                          const unsigned int* __restrict__ gmax_bits)
+{
+    const int M = M16 ? 16 : M_;
+    extern __shared__ __attribute__((aligned(16))) float s_mem[];
+    __shared__ __attribute__((aligned(16))) float s_rec[RB_WAVES][RECB];
+    __shared__ __attribute__((aligned(16))) float s_tile[RB_WAVES][RB_TILE];
+    const int ntexel = He * We;
+    float4* s_env4 = reinterpret_cast<float4*>(s_mem);
+    long long* s_denv = reinterpret_cast<long long*>(s_mem + (ENV_LDS ? 4 * ntexel : 0));     // [texel][3] fixed point
+    const float gmax = __uint_as_float(*gmax_bits);
+    const bool fixed = ENV_LDS && gmax > 0.f && gmax <= 3.0e38f;
+    const float fx_scale = fixed ? 34359738368.0f / gmax : 0.f;          // 2^35 / max|g|
+    const float fx_clamp = gmax * 8192.0f;
+    if (ENV_LDS) {
+        for (int i = threadIdx.x; i < ntexel; i += blockDim.x) s_env4[i] = env4[i];
+        for (int i = threadIdx.x; i < 3 * ntexel; i += blockDim.x) s_denv[i] = 0;
+        __syncthreads();
+    }
+    const float4* tex4 = ENV_LDS ? s_env4 : env4;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    float* u = s_rec[wave];
+    float* tile = s_tile[wave];
+    tile[(RB_ROWS - 1) * RB_STRIDE + lane] = 1.0f;             // the row of ones (the 4 pad floats are never read)
+    const int nblk = (K + 63) / 64;
+    const int g_stride = gridDim.x * RB_WAVES;
+    int g = blockIdx.x * RB_WAVES + wave, kb = 0;
+    auto advance = [&](int& ag, int& akb) {
+        if (++akb == nblk) { akb = 0; ag += g_stride; }
+    };
+    struct Pre { RowSample s; float rec2; };
+    auto fetch = [&](int ag, int akb) {
+        const int k = akb * 64 + lane;
+        const int gg = min(ag, P - 1);
+        Pre p;
+        p.s = load_row_sample<TAPS ? 1 : 0>(ag < P && k < K, gg, lane, (unsigned)k, K, rec, dirs, visibility, areas,
+                                            uniform_area, taps, RECB);
+        p.rec2 = rec[(size_t)gg * RECB + 64 + (lane & 15)];
+        return p;
+    };
+    Pre cur = fetch(g, kb);
+    // owner-lane mapping: lane j < 48 -> basis row j / 3 x dL/dlocal row j % 3; 48 <= j < 55 -> scalar row j - 48 x ones
+    const int rowA = lane < 48 ? lane / 3 : (lane < 55 ? 19 + (lane - 48) : 0);
+    const int rowB = lane < 48 ? 16 + lane % 3 : RB_ROWS - 1;
+    float outacc = 0.f;
+    while (g < P) {
+        asm volatile("" : "+v"(cur.s.dx), "+v"(cur.s.dy), "+v"(cur.s.dz), "+v"(cur.s.vis), "+v"(cur.s.area), "+v"(cur.s.t.xy),
+                     "+v"(cur.s.t.wx1), "+v"(cur.s.t.wy1), "+v"(cur.s.rec), "+v"(cur.rec2) :: "memory");
+        int g1 = g, kb1 = kb;
+        advance(g1, kb1);
+        const Pre nx1 = fetch(g1, kb1);                  // flies during the ~450 instructions below
+        u[lane] = cur.s.rec;
+        if (lane < 16) u[64 + lane] = cur.rec2;
+        const float4 ga = *reinterpret_cast<const float4*>(u + 48);     // albedo, roughness
+        const float4 gb = *reinterpret_cast<const float4*>(u + 52);     // n, V.x
+        const float4 gc = *reinterpret_cast<const float4*>(u + 56);     // V.yz, N.xy
+        const float4 gd4 = *reinterpret_cast<const float4*>(u + 60);    // N.z, NoV, a2, kk
+        const float4 ge = *reinterpret_cast<const float4*>(u + 64);     // vlen, a, rawNoV
+        const float4 gpv = *reinterpret_cast<const float4*>(u + 68);    // dL_dpbr / K
+        const float4 gdv = *reinterpret_cast<const float4*>(u + 72);    // dL_ddiffuse / K
+        const float nx = gb.x, ny = gb.y, nz = gb.z, Vx = gb.w, Vy = gc.x, Vz = gc.y, Nx = gc.z, Ny = gc.w, Nz = gd4.x;
+        const float NoV = gd4.y, a2 = gd4.z, kk = gd4.w, rough = ga.w, vlen = ge.x, alpha = ge.y, rawNoV = ge.z;
+        const float fd[3] = {ga.x / kPi, ga.y / kPi, ga.z / kPi};
+        const float gp[3] = {gpv.x, gpv.y, gpv.z}, gd[3] = {gdv.x, gdv.y, gdv.z};
+        const float nom1 = NoV * (1.f - kk) + kk;
+        float dl[3] = {0.f, 0.f, 0.f}, sc[7] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        {
+            const float dx = cur.s.dx, dy = cur.s.dy, dz = cur.s.dz, vis = cur.s.vis, area = cur.s.area;
+            const bool live = kb * 64 + lane < K;
+            PackedTap t = cur.s.t;
+            if (!TAPS) t = make_tap(dx, dy, dz, tr, He, We);
+            float e[3], w4[4];
+            int tex[4];
+            env_fetch(t, tex4, He, We, e, tex, w4);
+            float l[3];
+            {
+                float Y[16];
+                sh_basis16(dx, dy, dz, M, Y);
+                sh_local_sum(u, Y, l);
+                // basis rows of the exchange tile now: the 16 registers are free for the gradient chain below
+#pragma unroll
+                for (int i = 0; i < 16; i++) tile[i * RB_STRIDE + lane] = Y[i];
+            }
+            const float ndi = fmaxf(nx * dx + ny * dy + nz * dz, 0.f);
+            const float area_ndi = live ? area * ndi : 0.f;
+            const float dinv = __builtin_amdgcn_rsqf(fmaxf(dx * dx + dy * dy + dz * dz, 1e-24f));
+            const float Lx = dx * dinv, Ly = dy * dinv, Lz = dz * dinv;
+            const float ux = (Lx + Vx) / 2.0f, uy = (Ly + Vy) / 2.0f, uz = (Lz + Vz) / 2.0f;
+            const float uinv = __builtin_amdgcn_rsqf(fmaxf(ux * ux + uy * uy + uz * uz, 1e-24f));
+            const float Hx = ux * uinv, Hy = uy * uinv, Hz = uz * uinv;
+            const float NoL = fminf(fmaxf(Nx * Lx + Ny * Ly + Nz * Lz, 1e-6f), 1.f);
+            const float rawNoH = Nx * Hx + Ny * Hy + Nz * Hz, rawVoH = Vx * Hx + Vy * Hy + Vz * Hz;
+            const float NoH = fminf(fmaxf(rawNoH, 1e-6f), 1.f), VoH = fminf(fmaxf(rawVoH, 1e-6f), 1.f);
+            const float p2 = exp2f((-5.55473f * VoH - 6.98316f) * VoH);
+            const float frac0 = 0.04f + 0.96f * p2;
+            const float frac = frac0 * a2;
+            const float nom0 = NoH * NoH * (a2 - 1.f) + 1.f;
+            const float nom2 = NoL * (1.f - kk) + kk;
+            const float nomr = 4.f * kPi * nom0 * nom0 * nom1 * nom2;
+            const float nom = fminf(fmaxf(nomr, 1e-6f), 4.f * kPi);
+            const float spec = frac / nom;
+            float gspec = 0.f, dlin[3];
+#pragma unroll
+            for (int c = 0; c < 3; c++) {
+                const float lin = fmaxf(l[c], 0.f) + e[c] * vis;
+                const float transport = lin * area_ndi;
+                const float dT = gp[c] * (fd[c] + spec) + gd[c];      // dL / d transport_c
+                gspec += gp[c] * transport;
+                sc[c] = gp[c] * transport / kPi;                      // albedo
+                dlin[c] = dT * area_ndi;                              // dL / d (incident light)_c
+                dl[c] = l[c] >= 0.f ? dlin[c] : 0.f;                  // clamp_min(0): gradient where the SH sum >= 0
+            }
+            // environment-texture gradient: 4 taps x 3 channels (an out-of-range tap carries weight 0)
+            if (vis != 0.f && area_ndi != 0.f) {
+                const float ev[3] = {dlin[0] * vis, dlin[1] * vis, dlin[2] * vis};
+                if (fixed) {
+                    const double scale_d = (double)fx_scale;
+#pragma unroll
+                    for (int q = 0; q < 4; q++) {
+#pragma unroll
+                        for (int c = 0; c < 3; c++) {
+                            const float cl = __builtin_amdgcn_fmed3f(ev[c] * w4[q], -fx_clamp, fx_clamp);
+                            const double dsum = __builtin_fma((double)cl, scale_d, 6755399441055744.0);
+                            const unsigned long long bits =
+                                (unsigned long long)__double_as_longlong(dsum) - 0x4338000000000000ull;
+                            atomicAdd(reinterpret_cast<unsigned long long*>(&s_denv[3 * tex[q] + c]), bits);
+                        }
+                    }
+                } else {
+#pragma unroll
+                    for (int q = 0; q < 4; q++)
+                        if (w4[q] != 0.f)
+#pragma unroll
+                            for (int c = 0; c < 3; c++) atomicAdd(&d_env[3 * (size_t)tex[q] + c], ev[c] * w4[q]);
+                }
+            }
+            // specular -> roughness, view direction
+            const bool nom_free = nomr >= 1e-6f && nomr <= 4.f * kPi;
+            const float dfrac = gspec / nom;
+            const float dnom = nom_free ? -gspec * frac / (nom * nom) : 0.f;
+            float da2 = dfrac * frac0;
+            const float dfrac0 = dfrac * a2;
+            const float dFMi = dfrac0 * 0.96f * 0.6931471805599453f * p2;
+            float dVoH = dFMi * (-2.f * 5.55473f * VoH - 6.98316f);
+            const float c4 = 4.f * kPi;
+            const float dnom0 = dnom * c4 * 2.f * nom0 * nom1 * nom2;
+            const float dnom1 = dnom * c4 * nom0 * nom0 * nom2;
+            const float dnom2 = dnom * c4 * nom0 * nom0 * nom1;
+            float dNoH = dnom0 * 2.f * NoH * (a2 - 1.f);
+            da2 += dnom0 * NoH * NoH;
+            float dNoV = dnom1 * (1.f - kk);
+            const float dkk = dnom1 * (1.f - NoV) + dnom2 * (1.f - NoL);
+            const float da = dkk / 8.f + da2 * 2.f * alpha;
+            sc[3] = dkk * 2.f / 8.f + da * 2.f * rough;                 // roughness
+            if (!(rawNoH >= 1e-6f && rawNoH <= 1.f)) dNoH = 0.f;
+            if (!(rawVoH >= 1e-6f && rawVoH <= 1.f)) dVoH = 0.f;
+            if (!(rawNoV >= 1e-6f && rawNoV <= 1.f)) dNoV = 0.f;
+            const float dHx = dNoH * Nx + dVoH * Vx, dHy = dNoH * Ny + dVoH * Vy, dHz = dNoH * Nz + dVoH * Vz;
+            float dVx = dVoH * Hx + dNoV * Nx, dVy = dVoH * Hy + dNoV * Ny, dVz = dVoH * Hz + dNoV * Nz;
+            const float hd = Hx * dHx + Hy * dHy + Hz * dHz;
+            dVx += 0.5f * (dHx - Hx * hd) * uinv;
+            dVy += 0.5f * (dHy - Hy * hd) * uinv;
+            dVz += 0.5f * (dHz - Hz * hd) * uinv;
+            const float vd = Vx * dVx + Vy * dVy + Vz * dVz;
+            sc[4] = (dVx - Vx * vd) / vlen;
+            sc[5] = (dVy - Vy * vd) / vlen;
+            sc[6] = (dVz - Vz * vd) / vlen;
+        }
+        // exchange tile: [channel][sample]
+#pragma unroll
+        for (int c = 0; c < 3; c++) tile[(16 + c) * RB_STRIDE + lane] = dl[c];
+#pragma unroll
+        for (int j = 0; j < 7; j++) tile[(19 + j) * RB_STRIDE + lane] = sc[j];
+        // owner lanes: one output channel each, 64 samples
+        {
+            const float4* A = reinterpret_cast<const float4*>(tile + rowA * RB_STRIDE);
+            const float4* B = reinterpret_cast<const float4*>(tile + rowB * RB_STRIDE);
+            float a0 = 0.f, a1 = 0.f, a2s = 0.f, a3 = 0.f;
+#pragma unroll
+            for (int q = 0; q < 16; q++) {
+                const float4 x = A[q], y = B[q];
+                a0 += x.x * y.x; a1 += x.y * y.y; a2s += x.z * y.z; a3 += x.w * y.w;
+            }
+            outacc += (a0 + a1) + (a2s + a3);
+        }
+        if (kb == nblk - 1) {
+            if (lane < 48) { if (lane < 3 * M) d_inc[(size_t)g * M * 3 + lane] = outacc; }
+            else if (lane < 51) d_base[3 * (size_t)g + (lane - 48)] = outacc;
+            else if (lane == 51) d_rough[g] = outacc;
+            else if (lane < 55) d_view[3 * (size_t)g + (lane - 52)] = outacc;
+            outacc = 0.f;
+        }
+        cur = nx1;
+        g = g1; kb = kb1;
+    }
+    if (fixed) {
+        __syncthreads();
+        const float inv = 1.0f / fx_scale;
+        for (int i = threadIdx.x; i < 3 * ntexel; i += blockDim.x) {
+            const long long v64 = s_denv[i];
+            if (v64 != 0) atomicAdd(&d_env[i], (float)((double)v64 * (double)inv));
+        }
+    }
+}
+
+// Measured (P=300k, K=64, cached taps): 0.456-0.460 ms vs 0.458 ms for the 16-lane kernel -- no gain: the single pass needs
+// ~204 VGPRs (2 waves/SIMD, like the three-pass kernel), and forcing 3 waves/SIMD spills (0.51 ms).  The 16-lane kernel stays
+// the default; this one is kept selectable (r3dg_set_tuning9) and tested against it.
+int g_shade_bwd_rows = 0;    // r3dg_set_tuning9: 1 = row kernel (wave per Gaussian), 0 = the 16-lane kernel (default)
+
 int g_shade_fwd_blocks_per_cu = 2;   // r3dg_set_tuning6: persistent workgroups per CU of the shading forward
 
 static int shade_cus()
@@ -1226,9 +1502,49 @@ void launch_shade_backward(hipStream_t s, int P, int K, int M, const float* base
     const int nb = (3 * P + 255) / 256;
     grad_absmax_kernel<<<nb < 256 ? nb : 256, 256, 0, s>>>(3 * P, g_pbr, g_diff, scratch);
 
+    const int ntex = He * We * 3;
+    if (g_shade_bwd_rows) {
+        const size_t ntexel = (size_t)He * We;
+        float* rec = shade_records(((size_t)P * RECB + ntexel * 4) / REC + 2);       // 80-float records, then the padded texture
+        float4* env4 = reinterpret_cast<float4*>(rec + (size_t)P * RECB);
+        shade_prepare_bwd_kernel<<<(P + 63) / 64, 256, 0, s>>>(P, K, M, base_color, roughness, normals, viewdirs, incidents,
+                                                              g_pbr, g_diff, rec);
+        shade_pad_env_kernel<<<(int)((ntexel + 255) / 256), 256, 0, s>>>((int)ntexel, env, env4);
+        const bool lds_r = ntexel * (16 + 24) <= (size_t)ENV_LDS_MAX * 4;              // float4 texture + 3 x int64 accumulators
+        const size_t smem_r = lds_r ? ntexel * (16 + 24) : 0;
+        const int want = (P + RB_WAVES - 1) / RB_WAVES;
+#define R3DG_RB(L, T)                                                                                                 \
+    do {                                                                                                              \
+        static int per_cu = 0;                                                                                        \
+        if (per_cu == 0) {                                                                                            \
+            int nb2 = 0;                                                                                              \
+            R3DG_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb2, shade_backward_row_kernel<L, T, true>,        \
+                                                                  64 * RB_WAVES, smem_r));                           \
+            hipFuncAttributes fa;                                                                                     \
+            R3DG_HIP(hipFuncGetAttributes(&fa, (const void*)shade_backward_row_kernel<L, T, true>));                  \
+            const int by_vgpr = 512 / (((fa.numRegs + 7) / 8) * 8);                                                   \
+            nb2 = nb2 < by_vgpr ? nb2 : by_vgpr;                                                                      \
+            per_cu = nb2 > 0 ? (nb2 < 8 ? nb2 : 8) : 1;                                                               \
+        }                                                                                                             \
+        const int cap = shade_cus() * per_cu;                                                                         \
+        const int grid_r = want < cap ? want : cap;                                                                   \
+        if (M == 16)                                                                                                  \
+            shade_backward_row_kernel<L, T, true><<<grid_r, 64 * RB_WAVES, smem_r, s>>>(                              \
+                P, K, M, rec, env4, He, We, tr, visibility, dirs, areas, 0.f, taps, d_base, d_rough, d_view, d_inc,   \
+                d_env, scratch);                                                                                      \
+        else                                                                                                          \
+            shade_backward_row_kernel<L, T, false><<<grid_r, 64 * RB_WAVES, smem_r, s>>>(                             \
+                P, K, M, rec, env4, He, We, tr, visibility, dirs, areas, 0.f, taps, d_base, d_rough, d_view, d_inc,   \
+                d_env, scratch);                                                                                      \
+    } while (0)
+        if (lds_r) { if (taps != nullptr) R3DG_RB(true, true); else R3DG_RB(true, false); }
+        else { if (taps != nullptr) R3DG_RB(false, true); else R3DG_RB(false, false); }
+#undef R3DG_RB
+        check_launch(s, false, "shade_backward_row_kernel");
+        return;
+    }
     const ShadeSrc src = {base_color, roughness, normals, viewdirs, incidents, g_pbr, g_diff,
                           reinterpret_cast<const float*>(scratch + 16), dirs, visibility, areas};
-    const int ntex = He * We * 3;
     // persistent blocks so the LDS-privatised env gradient is flushed once per block, not once per Gaussian
     const int grid = shade_grid(P);
     const bool lds = 3 * ntex <= ENV_LDS_MAX, vec = (K % 4) == 0 && (size_t)P * K >= 4;

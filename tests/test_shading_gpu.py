@@ -204,3 +204,25 @@ def test_shade_refuses_gradients_it_does_not_implement():
     with pytest.raises(RuntimeError):
         so.shade(inp["base_color"], inp["roughness"], inp["normals"].clone().requires_grad_(True), inp["viewdirs"],
                  inp["incidents"], inp["env"], inp["visibility"], inp["incident_dirs"], inp["incident_areas"])
+
+
+@pytest.mark.parametrize("P,K,He,M,transform", [(2500, 64, 16, 16, False), (300, 384, 16, 16, False), (400, 100, 64, 16, True),
+                                                (500, 30, 8, 4, False)])
+def test_shading_backward_formulations_agree(P, K, He, M, transform):
+    """Row kernel (r3dg_set_tuning9(1)) vs the default 16-lane kernel, which test_shading_matches_oracle pins to the float64
+    oracle: same gradients."""
+    from relightable3dgaussian_amd import _lib, shading_ops as so
+    inp = {k: v.to(DEV) for k, v in _random_inputs(P, K, He, M, seed=5 * P + K, hdr=transform).items()}
+    tr = torch.linalg.qr(torch.randn(3, 3, generator=torch.Generator().manual_seed(3))).Q.contiguous().to(DEV) if transform else None
+    args = (inp["base_color"], inp["roughness"], inp["normals"], inp["viewdirs"], inp["incidents"], inp["env"],
+            inp["visibility"], inp["incident_dirs"], inp["incident_areas"], inp["g_pbr"], inp["g_diff"])
+    old = so.shade_backward(*args, env_transform=tr)
+    try:
+        _lib.lib().r3dg_set_tuning9(1)
+        rows = so.shade_backward(*args, env_transform=tr)
+    finally:
+        _lib.lib().r3dg_set_tuning9(0)
+    torch.cuda.synchronize()
+    for name, x, y in zip(("d_base", "d_rough", "d_view", "d_inc", "d_env"), rows, old):
+        # (roughness / view: the fp32 GGX denominator is ill-conditioned -- two evaluation orders differ by up to ~1e-3)
+        _ok(name + " row vs 16-lane", x, y, 2e-3 if name in ("d_rough", "d_view") else 2e-4, 1e-7)
