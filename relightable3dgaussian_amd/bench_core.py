@@ -214,6 +214,14 @@ def pytorch_cpu_rasterize(points, res, S, timeout_s=60, config0=False):
         return {"failed": repr(e)}
 
 
+def _kernel_names(stage):
+    """Kernel(s) a profile stage times, dominant first (names as tools/pmc_*.py shorten them)."""
+    return {"sort_pairs": ["tile_sort_small_kernel", "partition_scatter_kernel"],
+            "shade_forward": ["shade_forward_row_kernel", "shade_forward_kernel"],
+            "adam_step": ["adam_kernel"], "bvh_trace": ["trace_opacity_persistent_kernel"],
+            }.get(stage, [stage + "_kernel", stage])
+
+
 def pmc_traffic(stage):
     """HBM bytes per launch of `stage`'s kernel from the committed rocprofv3 PMC passes (profiles/*_pmc_traffic.json;
     FETCH_SIZE / WRITE_SIZE collected in separate passes on the same workload), or None."""
@@ -224,10 +232,15 @@ def pmc_traffic(stage):
         return None
     try:
         doc = json.load(open(files[-1]))
-        for name, v in doc["kernels"].items():
-            if name.startswith(stage + "_kernel") or name.startswith(stage):
-                return dict(bytes_corrected=v["hbm_bytes_corrected"], bytes_raw=v["hbm_bytes_raw"],
-                            source=os.path.basename(files[-1]))
+        for name in _kernel_names(stage):
+            v = doc["kernels"].get(name)
+            if v is not None:
+                return dict(bytes_corrected=v["hbm_bytes_corrected"], bytes_raw=v["hbm_bytes_raw"], kernel=name,
+                            source=os.path.basename(files[-1]),
+                            note="corrected = 2 x FETCH_SIZE + WRITE_SIZE (MI355X_MICROARCH.md); profiles/r02_pmc_calibration.json: "
+                                 "the factor 2 holds for streaming reads, random sub-line gathers are counted at 64 B per "
+                                 "request (factor 1) and a 4-byte atomic as 32 written bytes, so for the gather / atomic "
+                                 "heavy tile kernels the truth lies between bytes_raw and bytes_corrected")
     except Exception:
         return None
     return None
@@ -244,10 +257,12 @@ def pmc_valu(stage):
         return None
     try:
         doc = json.load(open(files[-1]))
-        for name, v in doc["kernels"].items():
-            if name.startswith(stage + "_kernel") or name == stage:
+        for name in _kernel_names(stage):
+            v = doc["kernels"].get(name)
+            if v is not None:
                 out = {k: v[k] for k in ("valu_issue_frac", "valu_busy_frac", "waves_per_simd", "lds_bank_conflict_frac",
                                          "vgprs", "lds_bytes") if k in v}
+                out["kernel"] = name
                 out["source"] = os.path.basename(files[-1])
                 return out
     except Exception:

@@ -530,39 +530,30 @@ shade_forward_kernel(int P, int K, int M, const float* __restrict__ base_color, 
 constexpr int REC = 64;      // floats per Gaussian record
 // record layout: 0..47 SH coefficients (i*3+c, zero padded beyond M), 48..50 albedo, 51 roughness, 52..54 normal (as given),
 // 55..57 V = normalize(viewdir), 58..60 N = normalize(normal) * sign(N.V), 61 NoV (clamped), 62 alpha^2, 63 k
-// 64 Gaussians per 256-thread block: the 48 coefficient floats of each are copied with coalesced loads / stores by the whole
-// block, then thread t < 64 derives Gaussian t's 16 remaining record entries (thread-per-Gaussian copying 58 strided floats
-// was 0.07 ms at P=300k; this is ~0.015 ms).
+// thread per Gaussian: the 16 derived entries 48..63 of the record ([P][16] floats).  The 48 coefficient entries are NOT
+// copied: the row kernel's lanes 0..47 read them straight from `incidents` (one coalesced 192-byte run per Gaussian),
+// lanes 48..63 read these 16 (a copying version of this kernel cost 0.05 ms per iteration for 115 MB of pure copy).
 __global__ void __launch_bounds__(256)
-shade_prepare_kernel(int P, int M, const float* __restrict__ base_color, const float* __restrict__ roughness,
-                     const float* __restrict__ normals, const float* __restrict__ viewdirs,
-                     const float* __restrict__ incidents, float* __restrict__ rec)
+shade_prepare_kernel(int P, const float* __restrict__ base_color, const float* __restrict__ roughness,
+                     const float* __restrict__ normals, const float* __restrict__ viewdirs, float* __restrict__ rec16)
 {
-    const int g0 = blockIdx.x * 64;
-    const int ng = min(64, P - g0);
-    const int row = 3 * M;                       // floats per Gaussian in `incidents`
-    for (int i = threadIdx.x; i < ng * 48; i += 256) {
-        const int gl = i / 48, e = i - gl * 48;
-        rec[(size_t)(g0 + gl) * REC + e] = e < row ? incidents[(size_t)(g0 + gl) * row + e] : 0.f;
-    }
-    if ((int)threadIdx.x < ng) {
-        const int g = g0 + threadIdx.x;
-        float u[64];
+    const int g = blockIdx.x * 256 + threadIdx.x;
+    if (g >= P) return;
+    float u[64];
 #pragma unroll
-        for (int c = 0; c < 3; c++) {
-            u[48 + c] = base_color[3 * (size_t)g + c];
-            u[52 + c] = normals[3 * (size_t)g + c];
-            u[55 + c] = viewdirs[3 * (size_t)g + c];
-        }
-        u[51] = roughness[g];
-        GaussFwd G;
-        gauss_setup(G, u);
-        float4* o = reinterpret_cast<float4*>(rec + (size_t)g * REC + 48);
-        o[0] = make_float4(u[48], u[49], u[50], u[51]);
-        o[1] = make_float4(G.n[0], G.n[1], G.n[2], G.V[0]);
-        o[2] = make_float4(G.V[1], G.V[2], G.N[0], G.N[1]);
-        o[3] = make_float4(G.N[2], G.NoV, G.a2, G.kk);
+    for (int c = 0; c < 3; c++) {
+        u[48 + c] = base_color[3 * (size_t)g + c];
+        u[52 + c] = normals[3 * (size_t)g + c];
+        u[55 + c] = viewdirs[3 * (size_t)g + c];
     }
+    u[51] = roughness[g];
+    GaussFwd G;
+    gauss_setup(G, u);
+    float4* o = reinterpret_cast<float4*>(rec16 + (size_t)g * 16);
+    o[0] = make_float4(u[48], u[49], u[50], u[51]);
+    o[1] = make_float4(G.n[0], G.n[1], G.n[2], G.V[0]);
+    o[2] = make_float4(G.V[1], G.V[2], G.N[0], G.N[1]);
+    o[3] = make_float4(G.N[2], G.NoV, G.a2, G.kk);
 }
 
 // env == nullptr: the 12-byte lookup record (texel corner + weights).  env != nullptr: the looked-up RADIANCE itself (three
@@ -636,16 +627,23 @@ __device__ __forceinline__ RowSample load_row_sample(bool live, int g, int lane,
                                                      const float* __restrict__ rec, const float* __restrict__ dirs,
                                                      const float* __restrict__ visibility,
                                                      const float* __restrict__ areas, float uniform_area,
-                                                     const uint32_t* __restrict__ taps, int rec_stride = REC)
+                                                     const uint32_t* __restrict__ taps, int rec_stride = REC,
+                                                     const float* __restrict__ incidents = nullptr, int M = 16)
 {
     RowSample r;
     r.dx = 0.f; r.dy = 0.f; r.dz = 1.f; r.vis = 0.f; r.area = 0.f;
     r.t.xy = 0x00010001u; r.t.wx1 = 0.f; r.t.wy1 = 0.f;
     const size_t row = (size_t)g * (size_t)K;
-    const float* __restrict__ rrow = rec + (size_t)g * rec_stride;
     const float* __restrict__ drow = dirs + 3 * row;
     const float* __restrict__ vrow = visibility + row;
-    r.rec = rrow[(unsigned)lane];
+    if (incidents != nullptr) {
+        // forward: lanes 0..47 <- the Gaussian's SH coefficients where they live, lanes 48..63 <- its 16 derived floats
+        const int row3 = 3 * M;
+        const float* __restrict__ src = lane < 48 ? incidents + (size_t)g * row3 + lane : rec + (size_t)g * 16 + (lane - 48);
+        r.rec = (lane < 48 && lane >= row3) ? 0.f : *src;
+    } else {
+        r.rec = (rec + (size_t)g * rec_stride)[(unsigned)lane];
+    }
     if (live) {
         const float3 d = *reinterpret_cast<const float3*>(drow + 3u * k);
         r.dx = d.x; r.dy = d.y; r.dz = d.z;
@@ -666,7 +664,8 @@ __device__ __forceinline__ RowSample load_row_sample(bool live, int g, int lane,
 // (last block of the Gaussian) transposing wave reduction + store.
 template <int NOUT, bool ENV_LDS, int TAPS /* 0 lookup in kernel, 1 cached lookup, 2 cached radiance */, bool M16>
 __global__ void __launch_bounds__(64 * ROW_WAVES)
-shade_forward_row_kernel(int P, int K, int M_, const float* __restrict__ rec, const float4* __restrict__ env4, int He, int We,
+shade_forward_row_kernel(int P, int K, int M_, const float* __restrict__ rec, const float* __restrict__ incidents,
+                         const float4* __restrict__ env4, int He, int We,
                          const float* __restrict__ tr, const float* __restrict__ visibility,
                          const float* __restrict__ dirs, const float* __restrict__ areas, float uniform_area,
                          const uint32_t* __restrict__ taps, float* __restrict__ out)
@@ -698,7 +697,7 @@ shade_forward_row_kernel(int P, int K, int M_, const float* __restrict__ rec, co
         const int k = akb * 64 + lane;
         const int gg = min(ag, P - 1);
         return load_row_sample<TAPS>(ag < P && k < K, gg, lane, (unsigned)k, K, rec, dirs, visibility, areas,
-                                     uniform_area, taps);
+                                     uniform_area, taps, 16, incidents, M);
     };
     int g1 = g, kb1 = kb;
     advance(g1, kb1);
@@ -1444,9 +1443,9 @@ void launch_shade_forward(hipStream_t s, int P, int K, int M, const float* base_
         return;
     }
     const size_t ntexel = (size_t)He * We;
-    float* rec = shade_records((size_t)P + (ntexel * 4 + REC - 1) / REC + 1);      // records, then the float4-padded texture
-    float4* env4 = reinterpret_cast<float4*>(rec + (size_t)P * REC);
-    shade_prepare_kernel<<<(P + 63) / 64, 256, 0, s>>>(P, M, base_color, roughness, normals, viewdirs, incidents, rec);
+    float* rec = shade_records((size_t)P / 4 + (ntexel * 4 + REC - 1) / REC + 2);  // [P][16] derived floats, then the padded texture
+    float4* env4 = reinterpret_cast<float4*>(rec + (((size_t)P * 16 + 3) & ~(size_t)3));
+    shade_prepare_kernel<<<(P + 255) / 256, 256, 0, s>>>(P, base_color, roughness, normals, viewdirs, rec);
     shade_pad_env_kernel<<<(int)((ntexel + 255) / 256), 256, 0, s>>>((int)ntexel, env, env4);
     const int mode = taps == nullptr ? 0 : (taps_are_radiance ? 2 : 1);
     const bool lds = mode != 2 && He * We * 4 <= ENV_LDS_MAX;          // float4 per texel
@@ -1476,10 +1475,10 @@ void launch_shade_forward(hipStream_t s, int P, int K, int M, const float* base_
         const int grid = want < cap ? want : cap;                                                                     \
         if (M == 16)                                                                                                  \
             shade_forward_row_kernel<N, L, T, true><<<grid, 64 * ROW_WAVES, smem, s>>>(                               \
-                P, K, M, rec, env4, He, We, tr, visibility, dirs, areas, uniform_area, taps, out);                    \
+                P, K, M, rec, incidents, env4, He, We, tr, visibility, dirs, areas, uniform_area, taps, out);         \
         else                                                                                                          \
             shade_forward_row_kernel<N, L, T, false><<<grid, 64 * ROW_WAVES, smem, s>>>(                              \
-                P, K, M, rec, env4, He, We, tr, visibility, dirs, areas, uniform_area, taps, out);                    \
+                P, K, M, rec, incidents, env4, He, We, tr, visibility, dirs, areas, uniform_area, taps, out);         \
     } while (0)
 #define R3DG_ROW_MODE(N, L)                                                                                           \
     do {                                                                                                              \

@@ -1,24 +1,66 @@
+# Round-end evidence job (MI355X, via gpurun): full GPU suite, rocprofv3 kernel stats (training iteration and relight frame),
+# PMC passes (VALU/LDS evidence, HBM traffic, trace kernels: ONE counter group per pass, --kernel-trace only), default bench.
+# Outputs land in gpurun_out/; the round's summaries are copied to profiles/ by hand (see profiles/README.md).
 set -x
 cd /root/repo
-timeout 900 python -m pytest tests -m gpu -q -p no:cacheprovider < /dev/null > gpurun_out/pytest_gpu.log 2>&1; tail -3 gpurun_out/pytest_gpu.log
+mkdir -p gpurun_out
+timeout 1500 python -m pytest tests -m gpu -q -p no:cacheprovider < /dev/null > gpurun_out/pytest_gpu.log 2>&1; tail -3 gpurun_out/pytest_gpu.log
 export TMPDIR=/tmp
 cd /tmp
-CMD="python /root/repo/bench.py --steps 20 --warmup 5 --no-cpu-baseline --relight-frames 0 --no-other-configs"
+CMD="python /root/repo/bench.py --steps 20 --warmup 5 --no-cpu-baseline --relight-frames 0 --no-other-configs --repeats 0"
+rm -rf /tmp/prof
 timeout 300 rocprofv3 --kernel-trace --stats -d /tmp/prof -o bench -- $CMD < /dev/null > /root/repo/gpurun_out/prof_bench.log 2>&1
 f=$(find /tmp/prof -name "*.db" | head -1)
 cd /root/repo
-python tools/rocpd_summary.py "$f" gpurun_out/stage2_fused_stats.md "rocprofv3 --kernel-trace --stats -- python bench.py --steps 20 --warmup 5 --no-cpu-baseline --relight-frames 0 --no-other-configs" < /dev/null
+python tools/rocpd_summary.py "$f" gpurun_out/stage2_fused_stats.md "rocprofv3 --kernel-trace --stats -- python bench.py --steps 20 --warmup 5 --no-cpu-baseline --relight-frames 0 --no-other-configs --repeats 0" < /dev/null
 python tools/rocpd_timeline.py "$f" 15 < /dev/null > gpurun_out/timeline.txt 2>&1
 cd /tmp
+CMD2="python /root/repo/bench.py --steps 2 --warmup 1 --no-cpu-baseline --relight-frames 40 --no-other-configs --repeats 0"
+rm -rf /tmp/prof2
+timeout 300 rocprofv3 --kernel-trace --stats -d /tmp/prof2 -o bench -- $CMD2 < /dev/null > /root/repo/gpurun_out/prof_relight.log 2>&1
+f2=$(find /tmp/prof2 -name "*.db" | head -1)
+cd /root/repo
+python tools/rocpd_summary.py "$f2" gpurun_out/relight_stats.md "rocprofv3 --kernel-trace --stats -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline --relight-frames 40 --no-other-configs --repeats 0  (43 relight frames at K=384, S=28 + the visibility trace + 3 training steps)" < /dev/null
+cd /tmp
+# HBM traffic: FETCH_SIZE and WRITE_SIZE in separate passes
 dbs=""
 for c in FETCH_SIZE WRITE_SIZE; do
   for w in raster shade; do
     rm -rf /tmp/pmc_${c}_${w}
-    ONLY64=1 timeout 250 rocprofv3 --pmc $c -d /tmp/pmc_${c}_${w} -o p -- python /root/repo/tools/kbench_${w}.py < /dev/null > /tmp/pmc.log 2>&1
+    ONLY64=1 ITERS=4 timeout 250 rocprofv3 --pmc $c --kernel-trace -d /tmp/pmc_${c}_${w} -o p -- python /root/repo/tools/kbench_${w}.py < /dev/null > /tmp/pmc.log 2>&1
     dbs="$dbs $(find /tmp/pmc_${c}_${w} -name '*.db' | head -1)"
   done
 done
 cd /root/repo
 python tools/pmc_traffic.py gpurun_out/pmc_traffic.json "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE collected in SEPARATE passes (tools/kbench_raster.py S=16, tools/kbench_shade.py K=64; P=300000, 800x800, R~1.77M), mean per launch" $dbs < /dev/null
-timeout 240 python bench.py < /dev/null > gpurun_out/bench_default.log 2>&1; tail -1 gpurun_out/bench_default.log > gpurun_out/bench_default.json
-cut -c1-200 gpurun_out/bench_default.json
+cd /tmp
+# VALU / LDS evidence: one SQ counter group per pass
+GA="SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_ANY GRBM_GUI_ACTIVE"
+GB="SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_INSTS_SALU SQ_INSTS_VMEM SQ_INSTS_VALU_TRANS_F32 SQ_WAIT_INST_LDS GRBM_GUI_ACTIVE"
+dbs=""
+i=0
+for grp in "$GA" "$GB"; do
+  i=$((i+1))
+  for w in raster shade; do
+    rm -rf /tmp/pv_${i}_${w}
+    ONLY64=1 ITERS=4 timeout 250 rocprofv3 --pmc $grp --kernel-trace -d /tmp/pv_${i}_${w} -o p -- python /root/repo/tools/kbench_${w}.py < /dev/null > /tmp/pv.log 2>&1
+    dbs="$dbs $(find /tmp/pv_${i}_${w} -name '*.db' | head -1)"
+  done
+done
+cd /root/repo
+python tools/kernel_resources.py gpurun_out/kernel_resources.json < /dev/null
+python tools/pmc_valu.py gpurun_out/pmc_valu.json "rocprofv3 --pmc <one SQ counter group per pass> --kernel-trace on tools/kbench_raster.py (S=16) and tools/kbench_shade.py (K=64); P=300000, 800x800, R~1.77M; mean per dispatch" --resources gpurun_out/kernel_resources.json $dbs < /dev/null
+cd /tmp
+GC="TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum GRBM_GUI_ACTIVE"
+dbs=""
+i=0
+for grp in "$GA" "$GC"; do
+  i=$((i+1))
+  rm -rf /tmp/pt_${i}
+  timeout 250 rocprofv3 --pmc $grp --kernel-trace -d /tmp/pt_${i} -o p -- python /root/repo/tools/kbench_trace.py < /dev/null > /tmp/pt.log 2>&1
+  dbs="$dbs $(find /tmp/pt_${i} -name '*.db' | head -1)"
+done
+cd /root/repo
+python tools/pmc_valu.py gpurun_out/pmc_trace.json "visibility trace kernels, tools/kbench_trace.py (P=300000, K=64; tuning8 = 3, 2, 0 in turn), mean per dispatch (3 dispatches of 100k bundles per update)" $dbs < /dev/null
+timeout 600 python bench.py < /dev/null > gpurun_out/bench_default.log 2>&1; tail -1 gpurun_out/bench_default.log > gpurun_out/bench_default.json
+cut -c1-300 gpurun_out/bench_default.json
