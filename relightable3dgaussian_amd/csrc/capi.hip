@@ -120,7 +120,13 @@ void launch_s2_env_backward(hipStream_t s, int He, int We, const float* raw, con
                             float w_tv, float* g_raw, float* tv_sum);
 uint32_t tile_sort_small_cap();
 void launch_tile_sort(hipStream_t s, int T, const uint32_t* tile_order, const uint32_t* ranges, const uint32_t* big_list,
-                      const uint32_t* big_count, uint64_t* keys, uint32_t* vals, uint64_t* scratch);
+                      const uint32_t* big_count, uint64_t* keys, uint32_t* vals, uint64_t* scratch, bool entries);
+void launch_tile_binning(hipStream_t s, int P, int T, const float* means2D, const float* depths, const int* radii,
+                         const uint32_t* tiles_touched, const uint32_t* block_offsets, int gx, int gy,
+                         uint32_t* tile_counts, uint32_t* cursor, uint32_t* ranges, uint32_t* point_offsets,
+                         uint64_t* entries);
+int tile_binning_max_tiles();
+extern int g_bin_iters;
 void launch_densify_accumulate(hipStream_t s, int P, const float* viewspace_grad, const float* normal_grad,
                                const int* radii, const float* weights, float* xyz_accum, float* normal_accum,
                                float* denom, float* weights_accum, float* max_radii2D);
@@ -154,7 +160,8 @@ void bvh_trace_opacity(hipStream_t s, int num_rays, int P, const int32_t* nodes,
 extern int g_cull;
 extern int g_stage_sh_rows;
 extern int g_shade_fwd_blocks_per_cu;
-int g_tile_binning = 1;   // 1: bin per tile + per-tile LDS sort; 0: the reference's global (tile|depth) radix sort
+int g_tile_binning = 2;   // 2: instances emitted straight into their tile's segment + per-tile LDS sort; 1: emitted in Gaussian
+                          // order, radix-partitioned by tile, per-tile LDS sort; 0: the reference's global (tile|depth) radix sort
 extern int g_fwd_wave8x8;
 extern int g_bwd_wave8x8;
 extern int g_fwd_ppl;
@@ -327,7 +334,10 @@ int r3dg_set_tuning5(int stage_sh_rows)
 
 int r3dg_set_tuning4(int tile_binning)
 {
-    if (tile_binning >= 0) g_tile_binning = tile_binning;
+    if (tile_binning >= 0) {
+        g_tile_binning = tile_binning & 0xff;
+        if (tile_binning >> 8) g_bin_iters = tile_binning >> 8;      // experiments: Gaussians per binning block / 1024
+    }
     return R3DG_OK;
 }
 
@@ -610,7 +620,25 @@ int r3dg_rasterize_forward_finish_on(void* ticket_, void* ordering_stream_, int*
 
         uint32_t* ranges = (uint32_t*)(ibuf + I.ranges);
         uint32_t* tile_order = g_tile_order ? (uint32_t*)(ibuf + I.tile_order) : nullptr;
-        if (g_tile_binning) {
+        if (g_tile_binning == 2 && (int)T <= tile_binning_max_tiles()) {
+            // direct binning (rasterizer_preprocess.hip): count -> scan (= the tile ranges) -> emit into the segments, then
+            // the per-tile sort by (depth, index): same final lists as the global stable sort
+            uint32_t* big_list = (uint32_t*)(ibuf + I.big_list);
+            uint32_t* big_count = (uint32_t*)(ibuf + I.big_count);
+            uint32_t* tile_counts = (uint32_t*)(bbuf + B.sort_temp);
+            StageTimer t_dup(stream, ST_DUPKEYS);
+            launch_tile_binning(stream, P, (int)T, g_means2D, g_depths, radii_p, g_tiles, g_block, gx, gy, tile_counts,
+                                tile_counts + T, ranges, (uint32_t*)(gbuf + G.point_offsets), keys_u);
+            check_launch(stream, debug, "tile_binning");
+            t_dup.stop();
+            StageTimer t_sort(stream, ST_SORT);
+            uint32_t* order = tile_order ? tile_order : (uint32_t*)(ibuf + I.tile_order);
+            launch_tile_order(stream, (int)T, ranges, order, tile_sort_small_cap(), big_list, big_count);
+            check_launch(stream, debug, "tile_order");
+            launch_tile_sort(stream, (int)T, order, ranges, big_list, big_count, keys, vals, keys_u, true);
+            check_launch(stream, debug, "tile_sort");
+            t_sort.stop();
+        } else if (g_tile_binning) {
             // stable partition by tile id (one radix pass over the tile bits), then a per-tile depth sort in LDS: same
             // final order as the global 44-bit sort (radix_sort.hip)
             uint32_t* big_list = (uint32_t*)(ibuf + I.big_list);
@@ -630,7 +658,7 @@ int r3dg_rasterize_forward_finish_on(void* ticket_, void* ordering_stream_, int*
             uint32_t* order = tile_order ? tile_order : (uint32_t*)(ibuf + I.tile_order);
             launch_tile_order(stream, (int)T, ranges, order, tile_sort_small_cap(), big_list, big_count);
             check_launch(stream, debug, "tile_order");
-            launch_tile_sort(stream, (int)T, order, ranges, big_list, big_count, keys, vals, keys_u);
+            launch_tile_sort(stream, (int)T, order, ranges, big_list, big_count, keys, vals, keys_u, false);
             check_launch(stream, debug, "tile_sort");
             t_sort.stop();
         } else {

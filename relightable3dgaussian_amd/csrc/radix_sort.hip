@@ -353,16 +353,20 @@ __device__ __forceinline__ uint32_t next_pow2_u32(uint32_t n)
 
 // keys/vals hold the tile's instances (tile << 32 | depth, Gaussian index) in index order (stable partition by tile);
 // they are replaced in place by the same instances in ascending (depth, index) order.
-template <int NT>
+// ENTRIES: `scratch` already holds the tile's (depth << 32 | index) sort entries (direct tile binning,
+// rasterizer_preprocess.hip) and `tile` names the tile; otherwise keys/vals hold the partitioned (tile | depth, index) pairs.
+template <int NT, bool ENTRIES = false>
 __device__ __forceinline__ void sort_one_tile(uint2 rg, uint64_t* __restrict__ keys, uint32_t* __restrict__ vals,
-                                              uint64_t* __restrict__ scratch, uint64_t* s_buf, uint32_t cap)
+                                              uint64_t* __restrict__ scratch, uint64_t* s_buf, uint32_t cap,
+                                              uint32_t tile = 0)
 {
     const uint32_t n = rg.y - rg.x;
     const uint32_t n_pad = next_pow2_u32(n);
-    const uint64_t tile_hi = keys[rg.x] & 0xffffffff00000000ull;
+    const uint64_t tile_hi = ENTRIES ? ((uint64_t)tile << 32) : (keys[rg.x] & 0xffffffff00000000ull);
     if (n <= cap) {
         for (uint32_t i = threadIdx.x; i < n_pad; i += NT)
-            s_buf[i] = i < n ? (keys[rg.x + i] << 32) | vals[rg.x + i] : ~0ull;      // real +inf padding in LDS
+            s_buf[i] = i < n ? (ENTRIES ? scratch[rg.x + i] : (keys[rg.x + i] << 32) | vals[rg.x + i])
+                             : ~0ull;      // real +inf padding in LDS
         __syncthreads();
         bitonic_lds_waves<NT>(s_buf, n_pad);
         for (uint32_t i = threadIdx.x; i < n; i += NT) {
@@ -374,7 +378,8 @@ __device__ __forceinline__ void sort_one_tile(uint2 rg, uint64_t* __restrict__ k
     } else {
         uint64_t* seg = scratch + rg.x;
         __syncthreads();                              // tile_hi read by every thread before keys are overwritten
-        for (uint32_t i = threadIdx.x; i < n; i += NT) seg[i] = (keys[rg.x + i] << 32) | vals[rg.x + i];
+        if (!ENTRIES)
+            for (uint32_t i = threadIdx.x; i < n; i += NT) seg[i] = (keys[rg.x + i] << 32) | vals[rg.x + i];
         GlobalMem m{seg};
         m.stage_sync();
         bitonic_ascending(m, n, n_pad, NT);
@@ -388,6 +393,7 @@ __device__ __forceinline__ void sort_one_tile(uint2 rg, uint64_t* __restrict__ k
 }
 
 // small tiles: one 256-thread workgroup per tile (longest first), lists up to `cap` entries in dynamic LDS
+template <bool ENTRIES>
 __global__ void __launch_bounds__(256)
 tile_sort_small_kernel(int T, const uint32_t* __restrict__ tile_order, const uint2* __restrict__ ranges, uint32_t cap,
                        uint64_t* __restrict__ keys, uint32_t* __restrict__ vals, uint64_t* __restrict__ scratch)
@@ -396,11 +402,13 @@ tile_sort_small_kernel(int T, const uint32_t* __restrict__ tile_order, const uin
     const uint32_t tile = tile_order ? tile_order[blockIdx.x] : blockIdx.x;
     const uint2 rg = ranges[tile];
     const uint32_t n = rg.y - rg.x;
-    if (n < 2 || n > cap) return;
-    sort_one_tile<256>(rg, keys, vals, scratch, s_sort, cap);
+    if (n > cap || n == 0) return;
+    if (n < 2 && !ENTRIES) return;                     // (a single partitioned pair is already in place)
+    sort_one_tile<256, ENTRIES>(rg, keys, vals, scratch, s_sort, cap, tile);
 }
 
 // long tiles: a few persistent 1024-thread workgroups walk the list written by tile_order_kernel
+template <bool ENTRIES>
 __global__ void __launch_bounds__(1024)
 tile_sort_big_kernel(const uint32_t* __restrict__ big_list, const uint32_t* __restrict__ big_count,
                      const uint2* __restrict__ ranges, uint32_t cap, uint64_t* __restrict__ keys,
@@ -409,7 +417,7 @@ tile_sort_big_kernel(const uint32_t* __restrict__ big_list, const uint32_t* __re
     extern __shared__ __attribute__((aligned(16))) uint64_t s_sort[];
     const uint32_t nbig = *big_count;
     for (uint32_t b = blockIdx.x; b < nbig; b += gridDim.x)
-        sort_one_tile<1024>(ranges[big_list[b]], keys, vals, scratch, s_sort, cap);
+        sort_one_tile<1024, ENTRIES>(ranges[big_list[b]], keys, vals, scratch, s_sort, cap, big_list[b]);
 }
 
 constexpr uint32_t TILE_SORT_SMALL_CAP = 4096;     // 32 KB of LDS per workgroup
@@ -417,19 +425,29 @@ constexpr uint32_t TILE_SORT_BIG_CAP = 16384;      // 128 KB
 
 uint32_t tile_sort_small_cap() { return TILE_SORT_SMALL_CAP; }
 
+// entries == true: `scratch` holds the (depth << 32 | index) entries of the direct tile binning, already in their tiles' segments
 void launch_tile_sort(hipStream_t s, int T, const uint32_t* tile_order, const uint32_t* ranges, const uint32_t* big_list,
-                      const uint32_t* big_count, uint64_t* keys, uint32_t* vals, uint64_t* scratch)
+                      const uint32_t* big_count, uint64_t* keys, uint32_t* vals, uint64_t* scratch, bool entries)
 {
-    tile_sort_small_kernel<<<T, 256, TILE_SORT_SMALL_CAP * 8, s>>>(T, tile_order, (const uint2*)ranges,
-                                                                   TILE_SORT_SMALL_CAP, keys, vals, scratch);
     static bool attr_set = false;
     if (!attr_set) {
-        R3DG_HIP(hipFuncSetAttribute((const void*)tile_sort_big_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+        R3DG_HIP(hipFuncSetAttribute((const void*)tile_sort_big_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                     (int)(TILE_SORT_BIG_CAP * 8)));
+        R3DG_HIP(hipFuncSetAttribute((const void*)tile_sort_big_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                      (int)(TILE_SORT_BIG_CAP * 8)));
         attr_set = true;
     }
-    tile_sort_big_kernel<<<64, 1024, TILE_SORT_BIG_CAP * 8, s>>>(big_list, big_count, (const uint2*)ranges,
-                                                                TILE_SORT_BIG_CAP, keys, vals, scratch);
+    if (entries) {
+        tile_sort_small_kernel<true><<<T, 256, TILE_SORT_SMALL_CAP * 8, s>>>(T, tile_order, (const uint2*)ranges,
+                                                                             TILE_SORT_SMALL_CAP, keys, vals, scratch);
+        tile_sort_big_kernel<true><<<64, 1024, TILE_SORT_BIG_CAP * 8, s>>>(big_list, big_count, (const uint2*)ranges,
+                                                                          TILE_SORT_BIG_CAP, keys, vals, scratch);
+    } else {
+        tile_sort_small_kernel<false><<<T, 256, TILE_SORT_SMALL_CAP * 8, s>>>(T, tile_order, (const uint2*)ranges,
+                                                                              TILE_SORT_SMALL_CAP, keys, vals, scratch);
+        tile_sort_big_kernel<false><<<64, 1024, TILE_SORT_BIG_CAP * 8, s>>>(big_list, big_count, (const uint2*)ranges,
+                                                                           TILE_SORT_BIG_CAP, keys, vals, scratch);
+    }
 }
 
 }  // namespace r3dg

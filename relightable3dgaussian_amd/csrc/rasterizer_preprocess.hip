@@ -400,6 +400,171 @@ tile_order_kernel(int T, const uint2* __restrict__ ranges, uint32_t* __restrict_
     if (tid == 0 && big_count != nullptr) *big_count = s_nbig;
 }
 
+// ---- direct tile binning (r3dg_set_tuning4(2), default) ---------------------------------------------------------------------
+// The reference emits (tile | depth, index) pairs in Gaussian order and sorts them globally; the round-1 formulation emitted
+// them the same way, then histogrammed and partitioned them by tile id (duplicate -> hist -> scan -> scatter: the pairs are
+// written, read, read, written again before any tile sort sees them -- 0.17 ms inside the iteration).  Here the instances
+// go straight into their tile's segment:
+//   tile_count_kernel   per block of 256 Gaussians an LDS histogram of the tiles their rectangles cover, flushed with one
+//                       global atomic per (block, touched tile);
+//   tile_scan_kernel    exclusive scan of the T tile counts = the tile RANGES (identifyTileRanges' result) + the cursors;
+//   tile_emit_kernel    the same LDS histogram again, ONE global atomic per (block, touched tile) reserves a run inside the
+//                       tile's segment, then every instance takes its slot with an LDS atomic and is written ONCE, as the
+//                       sort entry (depth bits << 32 | Gaussian index) the per-tile sort wants.
+// Order inside a tile is arbitrary here; the per-tile sort by the unique (depth, index) key makes the final lists
+// bit-identical to the reference's stable global sort.  Falls back to the round-1 path when T exceeds the LDS histogram.
+constexpr int BIN_MAX_TILES = 16384;           // 64 KB of LDS counters
+
+constexpr int BIN_THREADS = 1024;
+
+// the tiles of Gaussian `idx` (one per lane; whole waves call this together)
+template <typename F>
+__device__ __forceinline__ void for_each_tile(int idx, int P, const float2* __restrict__ means2D,
+                                              const int* __restrict__ radii, int gx, int gy, F&& f)
+{
+    const int lane = threadIdx.x & 63;
+    int x0 = 0, y0 = 0, x1 = 0, y1 = 0;
+    const bool live = idx < P && radii[idx] > 0;
+    if (live) {
+        const float2 p = means2D[idx];
+        tile_rect(p.x, p.y, radii[idx], gx, gy, x0, y0, x1, y1);
+    }
+    const int w_rect = x1 - x0;
+    const uint32_t cnt = (uint32_t)(w_rect * (y1 - y0));
+    const bool big = live && cnt > 32u;
+    if (live && !big)
+        for (int y = y0; y < y1; y++)
+            for (int x = x0; x < x1; x++) f((uint32_t)(y * gx + x), (uint32_t)idx);
+    // rectangles larger than 32 tiles are expanded by the whole wave (one screen-filling Gaussian cannot serialise it)
+    unsigned long long todo = __ballot(big);
+    while (todo) {
+        const int src = __ffsll((long long)todo) - 1;
+        todo &= todo - 1;
+        const int bx0 = __shfl(x0, src, 64), by0 = __shfl(y0, src, 64), bw = __shfl(w_rect, src, 64);
+        const uint32_t bcnt = (uint32_t)__shfl((int)cnt, src, 64);
+        const uint32_t bid = (uint32_t)((idx & ~63) + src);
+        for (uint32_t k = lane; k < bcnt; k += 64)
+            f((uint32_t)((by0 + (int)(k / (uint32_t)bw)) * gx + bx0 + (int)(k % (uint32_t)bw)), bid);
+    }
+}
+
+// each block takes `iters` x 1024 consecutive Gaussians: the more Gaussians share one LDS histogram, the fewer global
+// atomics (one per block and touched tile; an unordered cloud touches nearly every tile from every block)
+__global__ void __launch_bounds__(BIN_THREADS)
+tile_count_kernel(int P, int T, int iters, const float2* __restrict__ means2D, const int* __restrict__ radii, int gx, int gy,
+                  uint32_t* __restrict__ tile_counts)
+{
+    extern __shared__ uint32_t s_bins[];
+    for (int t = threadIdx.x; t < T; t += BIN_THREADS) s_bins[t] = 0;
+    __syncthreads();
+    const int base = blockIdx.x * iters * BIN_THREADS + threadIdx.x;
+    for (int it = 0; it < iters; it++)
+        for_each_tile(base + it * BIN_THREADS, P, means2D, radii, gx, gy,
+                      [&](uint32_t tile, uint32_t) { atomicAdd(&s_bins[tile], 1u); });
+    __syncthreads();
+    for (int t = threadIdx.x; t < T; t += BIN_THREADS) {
+        const uint32_t c = s_bins[t];
+        if (c) atomicAdd(&tile_counts[t], c);
+    }
+}
+
+// one 1024-thread block: ranges[t] = (start, end), cursor[t] = start
+__global__ void __launch_bounds__(1024)
+tile_scan_kernel(int T, const uint32_t* __restrict__ tile_counts, uint2* __restrict__ ranges, uint32_t* __restrict__ cursor)
+{
+    __shared__ uint32_t s_wave[16];
+    __shared__ uint32_t s_carry;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid == 0) s_carry = 0;
+    __syncthreads();
+    for (int base = 0; base < T; base += 1024) {
+        const int t = base + tid;
+        const uint32_t v = t < T ? tile_counts[t] : 0u;
+        const uint32_t inc = wave_inclusive_scan_u32(v);
+        if (lane == 63) s_wave[wave] = inc;
+        __syncthreads();
+        uint32_t off = s_carry;
+        for (int w = 0; w < wave; w++) off += s_wave[w];
+        if (t < T) {
+            const uint32_t start = off + inc - v;
+            // an empty tile keeps (0,0) like the reference's zero-initialised ranges (rasterizer_impl.cu:320)
+            ranges[t] = v ? make_uint2(start, start + v) : make_uint2(0u, 0u);
+            cursor[t] = start;
+        }
+        __syncthreads();
+        if (tid == 1023) s_carry = off + inc;
+        __syncthreads();
+    }
+}
+
+__global__ void __launch_bounds__(BIN_THREADS)
+tile_emit_kernel(int P, int T, int iters, const float2* __restrict__ means2D, const float* __restrict__ depths,
+                 const int* __restrict__ radii, const uint32_t* __restrict__ tiles_touched,
+                 const uint32_t* __restrict__ block_offsets, int gx, int gy, uint32_t* __restrict__ cursor,
+                 uint32_t* __restrict__ point_offsets, uint64_t* __restrict__ entries)
+{
+    extern __shared__ uint32_t s_bins[];
+    __shared__ uint32_t s_wave[BIN_THREADS / 64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int t = threadIdx.x; t < T; t += BIN_THREADS) s_bins[t] = 0;
+    const int base = blockIdx.x * iters * BIN_THREADS + threadIdx.x;
+    // GeometryState::point_offsets (inclusive scan of tiles_touched, rasterizer_impl.cu:283-287): part of the state parity.
+    // block_offsets are preprocess' exclusive sums per 256 Gaussians = 4 waves.
+    for (int it = 0; it < iters; it++) {
+        const int idx = base + it * BIN_THREADS;
+        const uint32_t cnt = idx < P ? tiles_touched[idx] : 0u;
+        const uint32_t inc = wave_inclusive_scan_u32(cnt);
+        __syncthreads();
+        if (lane == 63) s_wave[wave] = inc;
+        __syncthreads();
+        if (idx < P) {
+            uint32_t off = block_offsets[idx >> 8];
+            for (int w = wave & ~3; w < wave; w++) off += s_wave[w];
+            point_offsets[idx] = off + inc;
+        }
+    }
+    for (int it = 0; it < iters; it++)
+        for_each_tile(base + it * BIN_THREADS, P, means2D, radii, gx, gy,
+                      [&](uint32_t tile, uint32_t) { atomicAdd(&s_bins[tile], 1u); });
+    __syncthreads();
+    for (int t = threadIdx.x; t < T; t += BIN_THREADS) {
+        const uint32_t c = s_bins[t];
+        if (c) s_bins[t] = atomicAdd(&cursor[t], c);           // this block's run inside tile t's segment
+    }
+    __syncthreads();
+    for (int it = 0; it < iters; it++)
+        for_each_tile(base + it * BIN_THREADS, P, means2D, radii, gx, gy, [&](uint32_t tile, uint32_t g) {
+            const uint32_t pos = atomicAdd(&s_bins[tile], 1u);
+            entries[pos] = ((uint64_t)__float_as_uint(depths[g]) << 32) | (uint64_t)g;
+        });
+}
+
+int g_bin_iters = 2;
+
+void launch_tile_binning(hipStream_t s, int P, int T, const float* means2D, const float* depths, const int* radii,
+                         const uint32_t* tiles_touched, const uint32_t* block_offsets, int gx, int gy,
+                         uint32_t* tile_counts /* T, scratch */, uint32_t* cursor /* T, scratch */, uint32_t* ranges,
+                         uint32_t* point_offsets, uint64_t* entries)
+{
+    R3DG_HIP(hipMemsetAsync(tile_counts, 0, (size_t)T * 4, s));
+    const int iters = g_bin_iters;
+    const int per_block = iters * BIN_THREADS;
+    const int nb = (P + per_block - 1) / per_block;
+    const size_t smem = (size_t)T * 4;
+    static bool attr = false;
+    if (!attr) {
+        R3DG_HIP(hipFuncSetAttribute((const void*)tile_count_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, BIN_MAX_TILES * 4));
+        R3DG_HIP(hipFuncSetAttribute((const void*)tile_emit_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, BIN_MAX_TILES * 4));
+        attr = true;
+    }
+    tile_count_kernel<<<nb, BIN_THREADS, smem, s>>>(P, T, iters, (const float2*)means2D, radii, gx, gy, tile_counts);
+    tile_scan_kernel<<<1, 1024, 0, s>>>(T, tile_counts, (uint2*)ranges, cursor);
+    tile_emit_kernel<<<nb, BIN_THREADS, smem, s>>>(P, T, iters, (const float2*)means2D, depths, radii, tiles_touched,
+                                                  block_offsets, gx, gy, cursor, point_offsets, entries);
+}
+
+int tile_binning_max_tiles() { return BIN_MAX_TILES; }
+
 // ---- host launchers -------------------------------------------------------------------------------------
 void launch_tile_order(hipStream_t s, int T, const uint32_t* ranges, uint32_t* order, uint32_t small_cap,
                        uint32_t* big_list, uint32_t* big_count)

@@ -274,34 +274,39 @@ def test_parity_wave_shape_and_cull(fw8, bw8, cull, hip_lib):
 
 
 @pytest.mark.parametrize("name", ["S16", "big_splats", "ragged_image", "camera_inside", "S0"])
-@pytest.mark.parametrize("binning", [0, 1])
+@pytest.mark.parametrize("binning", [0, 1, 2])
 def test_tile_binned_order_equals_global_sort(name, binning, hip_lib):
-    """Both orderings (global radix sort of (tile|depth) keys / per-tile tickets + per-tile LDS sort) must give the
-    oracle's sorted keys, point list and ranges bit for bit (checked inside _check_forward)."""
+    """All three orderings (0: global radix sort of (tile|depth) keys; 1: radix partition by tile + per-tile LDS sort; 2, the
+    default: instances emitted straight into their tile's segment + per-tile LDS sort) must give the oracle's sorted keys,
+    point list, ranges and point offsets bit for bit (checked inside _check_forward)."""
     hip_lib.r3dg_set_tuning4(binning)
     try:
         _check_forward(make_case(**CASES[name]), "%s_binning%d" % (name, binning))
     finally:
-        hip_lib.r3dg_set_tuning4(1)
+        hip_lib.r3dg_set_tuning4(2)
 
 
 def test_tile_binned_order_long_tiles(hip_lib):
     """Tiles longer than the small (4096) and the big (16384) in-LDS capacities: few pixels, many large splats."""
     case = make_case(P=40000, W=64, H=48, S=2, scale_log_mean=-1.2, seed=91)
     a = _run_forward(case)
-    hip_lib.r3dg_set_tuning4(0)
     try:
+        hip_lib.r3dg_set_tuning4(1)
+        a1 = _run_forward(case)
+        hip_lib.r3dg_set_tuning4(0)
         b = _run_forward(case)
     finally:
-        hip_lib.r3dg_set_tuning4(1)
+        hip_lib.r3dg_set_tuning4(2)
     torch.cuda.synchronize()
+    for i in (1, 2, 3, 4, 5):
+        assert torch.equal(a1[i], b[i]), i
     from relightable3dgaussian_amd.rasterizer_ops import decode_state
     P, H, W = case["P"], case["H"], case["W"]
     assert a[0] == b[0]
     sa, sb = decode_state(a[10], a[11], a[12], P, a[0], H, W), decode_state(b[10], b[11], b[12], P, b[0], H, W)
     lens = (sa["ranges"][:, 1] - sa["ranges"][:, 0])
     assert int(lens.max()) > 16384, "case no longer exercises the global-memory tile sort (max %d)" % int(lens.max())
-    for k in ("keys", "point_list", "ranges"):
+    for k in ("keys", "point_list", "ranges", "point_offsets"):
         assert torch.equal(torch.as_tensor(sa[k]), torch.as_tensor(sb[k])), k
     for i in (1, 2, 3, 4, 5):
         assert torch.equal(a[i], b[i]), i
@@ -315,16 +320,35 @@ def test_tile_binned_order_many_tiles(hip_lib):
     try:
         b = _run_forward(case)
     finally:
-        hip_lib.r3dg_set_tuning4(1)
+        hip_lib.r3dg_set_tuning4(2)
     torch.cuda.synchronize()
     from relightable3dgaussian_amd.rasterizer_ops import decode_state
     P, H, W = case["P"], case["H"], case["W"]
     assert a[0] == b[0] and a[0] > 0
     sa, sb = decode_state(a[10], a[11], a[12], P, a[0], H, W), decode_state(b[10], b[11], b[12], P, b[0], H, W)
-    for k in ("keys", "point_list", "ranges"):
+    for k in ("keys", "point_list", "ranges", "point_offsets"):
         assert torch.equal(torch.as_tensor(sa[k]), torch.as_tensor(sb[k])), k
     for i in (1, 2, 3, 4, 5):
         assert torch.equal(a[i], b[i]), i
+
+
+def test_tile_binned_order_falls_back_above_the_lds_histogram(hip_lib):
+    """2064x2048 = 16512 tiles: more than the direct binning's LDS histogram holds, so the radix-partition path runs
+    under the default setting -- same lists as the global sort."""
+    case = make_case(P=6000, W=2064, H=2048, S=0, scale_log_mean=-2.2, seed=97)
+    a = _run_forward(case)
+    hip_lib.r3dg_set_tuning4(0)
+    try:
+        b = _run_forward(case)
+    finally:
+        hip_lib.r3dg_set_tuning4(2)
+    torch.cuda.synchronize()
+    from relightable3dgaussian_amd.rasterizer_ops import decode_state
+    P, H, W = case["P"], case["H"], case["W"]
+    assert a[0] == b[0] and a[0] > 0
+    sa, sb = decode_state(a[10], a[11], a[12], P, a[0], H, W), decode_state(b[10], b[11], b[12], P, b[0], H, W)
+    for k in ("keys", "point_list", "ranges", "point_offsets"):
+        assert torch.equal(torch.as_tensor(sa[k]), torch.as_tensor(sb[k])), k
 
 
 def test_full_size_properties(hip_lib):
