@@ -416,6 +416,62 @@ trace_opacity_packet_kernel(int num_rays, const int32_t* __restrict__ nodes, con
 //   * per-ray semantics, arithmetic and visit order are unchanged (trace.cu:208-280): results are bit-identical.
 // The wave-cooperative variant (shared stack, union of the 64 rays' nodes) and persistent waves with dynamic ray fetch were
 // measured too: 37 and 49 vs 56 Mrays/s at K=64 -- fewer instructions (lanes 48 % utilised with refill) but MORE L2 misses.
+// ---- exact quotients without the division expansion ---------------------------------------------------------------------------
+// A slab test divides six differences by the ray direction; hipcc expands each IEEE fp32 division into 11 instructions
+// (2 v_div_scale, v_rcp, 5 FMA/mul, v_div_fmas, v_div_fixup): 12 divisions = two thirds of a node step's VALU work, all by
+// the SAME three divisors for the whole life of the ray.  The expansion is r = rcp(d); r += (1 - d r) r; q = a r;
+// q += (a - d q) r; q += (a - d q) r, wrapped in a power-of-two pre/post scaling that only engages for extreme exponents
+// and a fix-up for zeros / infinities / NaNs.  Outside those cases the scaling is the identity, so keeping the refined
+// reciprocal per ray and running the five remaining operations gives the SAME bits (same operations on the same values).
+// Sufficient for "no scaling, no fix-up" (ISA, V_DIV_SCALE_F32): 2^-63 <= |d| <= 2 and the numerator 0 or
+// 2^-103 <= |a| < 2^32; the latter holds for every difference of two TAME coordinates (0, or 2^-60 <= |x| < 2^31).
+// Rays or nodes that are not tame (never in practice) take the compiler's division.  The sign of a zero quotient may
+// differ; quotients are only compared.
+__device__ __forceinline__ bool tame_coordinate(float x)
+{
+    const uint32_t e = (__float_as_uint(x) >> 23) & 0xffu;
+    return x == 0.0f || (e >= 127u - 60u && e < 127u + 31u);
+}
+__device__ __forceinline__ bool tame_direction(float d)
+{
+    const uint32_t e = (__float_as_uint(d) >> 23) & 0xffu;
+    return e >= 127u - 63u && e <= 127u;            // 2^-63 <= |d| < 2
+}
+__device__ __forceinline__ float refined_reciprocal(float d)
+{
+    const float r = __builtin_amdgcn_rcpf(d);
+    const float e = __builtin_fmaf(-d, r, 1.0f);
+    return __builtin_fmaf(e, r, r);
+}
+__device__ __forceinline__ float exact_quotient(float a, float neg_d, float r)
+{
+    const float q0 = a * r;
+    const float e0 = __builtin_fmaf(neg_d, q0, a);
+    const float q1 = __builtin_fmaf(e0, r, q0);
+    const float e1 = __builtin_fmaf(neg_d, q1, a);
+    return __builtin_fmaf(e1, r, q1);
+}
+// slab_tmax with the quotients above (same comparisons, same order)
+__device__ __forceinline__ float slab_tmax_tame(const float* __restrict__ box, float ox, float oy, float oz, float ndx,
+                                                float ndy, float ndz, float rx, float ry, float rz)
+{
+    float tmin = exact_quotient(box[0] - ox, ndx, rx);
+    float tmax = exact_quotient(box[3] - ox, ndx, rx);
+    if (tmin > tmax) { const float t = tmin; tmin = tmax; tmax = t; }
+    float tymin = exact_quotient(box[1] - oy, ndy, ry);
+    float tymax = exact_quotient(box[4] - oy, ndy, ry);
+    if (tymin > tymax) { const float t = tymin; tymin = tymax; tymax = t; }
+    if (tmin > tymax || tymin > tmax) return -1.0f;
+    if (tymin > tmin) tmin = tymin;
+    if (tymax < tmax) tmax = tymax;
+    float tzmin = exact_quotient(box[2] - oz, ndz, rz);
+    float tzmax = exact_quotient(box[5] - oz, ndz, rz);
+    if (tzmin > tzmax) { const float t = tzmin; tzmin = tzmax; tzmax = t; }
+    if (tmin > tzmax || tzmin > tmax) return -1.0f;
+    if (tzmax < tmax) tmax = tzmax;
+    return tmax;
+}
+
 struct __attribute__((aligned(16))) TNode {
     int left, right;
     float lb[6], rb[6];
@@ -442,7 +498,12 @@ pack_traversal_kernel(int P, const int32_t* __restrict__ nodes, const float* __r
             o.lb[a] = aabbs[6 * (size_t)o.left + a];
             o.rb[a] = aabbs[6 * (size_t)o.right + a];
         }
-        o.pad[0] = o.pad[1] = 0;
+        // pad[0] = 1: every box coordinate is 0 or has 2^-60 <= |x| < 2^31 (see exact_quotient)
+        bool tame = true;
+#pragma unroll
+        for (int a = 0; a < 6; a++) tame = tame && tame_coordinate(o.lb[a]) && tame_coordinate(o.rb[a]);
+        o.pad[0] = tame ? 1 : 0;
+        o.pad[1] = 0;
         tn[i] = o;
     }
     if (i < P) {
@@ -639,7 +700,149 @@ trace_opacity_persistent_kernel(int num_rays, int P, const TNode* __restrict__ t
     if (lost) atomicAdd(overflow, 1);
 }
 
-int g_trace_packet = 3;    // r3dg_set_tuning8: 3 = packed records + persistent waves, 2 = packed records, 1 = wave-cooperative, 0 = round-1 kernel
+// ---- phase-separated persistent traversal (r3dg_set_tuning8(4), default) -----------------------------------------------------
+// In the kernel above every loop iteration executes BOTH the leaf body (Gaussian response, ~60 VALU) and the node body (two
+// slab tests, ~70 VALU) whenever a wave holds lanes of either kind, which is nearly always: each lane advances one step for
+// the price of two.  Here each lane keeps its current node in a register and the wave VOTES per iteration: the body with
+// more ready lanes runs, the other lanes wait one turn.  The register also halves the stack traffic (a node whose children
+// are both hit pushes one and continues with the other instead of push, push, pop).  Per-ray visit order, arithmetic and
+// the overflow accounting are those of the kernels above, so results are identical.
+__global__ void __launch_bounds__(256)
+trace_opacity_phased_kernel(int num_rays, int P, const TNode* __restrict__ tn, const TLeaf* __restrict__ tl,
+                            const float* __restrict__ rays_o, const float* __restrict__ rays_d,
+                            int32_t* __restrict__ contributes, float* __restrict__ out, int* __restrict__ overflow,
+                            int* __restrict__ queues /* 8 x 16 ints, zeroed */)
+{
+    const int lane = threadIdx.x & 63;
+    const int xcd = (int)(blockIdx.x & 7u);
+    const int per = (num_rays + 7) / 8;
+    const int q_lo = xcd * per, q_hi = min(num_rays, q_lo + per);
+    int* next_ray = queues + 16 * xcd;
+    int stack[TRACE_STACK];
+    int sp = 0, ray = -1, count = 0, cur = -1;
+    float ox = 0.f, oy = 0.f, oz = 0.f, dx = 0.f, dy = 0.f, dz = 1.f, T = 1.0f;
+    float rx = 0.f, ry = 0.f, rz = 1.f;          // refined reciprocals of the direction (exact_quotient)
+    bool lost = false, exhausted = false, tame_ray = false;
+    const int first_leaf = P - 1;
+    while (true) {
+        const unsigned long long idle = __ballot(ray < 0);
+        if (idle != 0ull && !exhausted) {
+            const int n_idle = __popcll(idle);
+            if (n_idle >= REFILL_MIN_IDLE || idle == __ballot(true)) {
+                int base = 0;
+                const int leader = __builtin_ctzll(idle);
+                if (lane == leader) base = atomicAdd(next_ray, n_idle);
+                base = q_lo + __builtin_amdgcn_readlane(base, leader);
+                if (base + n_idle >= q_hi) exhausted = true;
+                if (ray < 0) {
+                    const int idx = base + __popcll(idle & ((1ull << lane) - 1ull));
+                    if (idx < q_hi) {
+                        ray = idx;
+                        ox = rays_o[3 * (size_t)idx]; oy = rays_o[3 * (size_t)idx + 1]; oz = rays_o[3 * (size_t)idx + 2];
+                        dx = rays_d[3 * (size_t)idx]; dy = rays_d[3 * (size_t)idx + 1]; dz = rays_d[3 * (size_t)idx + 2];
+                        rx = refined_reciprocal(dx); ry = refined_reciprocal(dy); rz = refined_reciprocal(dz);
+                        tame_ray = tame_direction(dx) && tame_direction(dy) && tame_direction(dz) && tame_coordinate(ox) &&
+                                   tame_coordinate(oy) && tame_coordinate(oz);
+                        cur = 0;
+                        sp = 0;
+                        count = 0;
+                        T = 1.0f;
+                    }
+                }
+            }
+        }
+        const bool at_leaf = ray >= 0 && cur >= first_leaf;
+        const bool at_node = ray >= 0 && cur < first_leaf;
+        const unsigned long long leaf_m = __ballot(at_leaf), node_m = __ballot(at_node);
+        if ((leaf_m | node_m) == 0ull) {
+            if (exhausted) break;
+            continue;
+        }
+        bool finished = false, stepped = false;
+        if (__popcll(node_m) >= __popcll(leaf_m)) {
+            float4 q0 = {}, q1 = {}, q2 = {}, q3 = {};
+            if (at_node) {
+                const float4* q = reinterpret_cast<const float4*>(tn + cur);
+                q0 = q[0]; q1 = q[1]; q2 = q[2]; q3 = q[3];
+            }
+            const float lb[6] = {q0.z, q0.w, q1.x, q1.y, q1.z, q1.w};
+            const float rb[6] = {q2.x, q2.y, q2.z, q2.w, q3.x, q3.y};
+            float tl_ = -1.0f, tr_ = -1.0f;
+            if (__ballot(at_node && !(tame_ray && __float_as_int(q3.z) != 0)) == 0ull) {
+                if (at_node) {
+                    tl_ = slab_tmax_tame(lb, ox, oy, oz, -dx, -dy, -dz, rx, ry, rz);
+                    tr_ = slab_tmax_tame(rb, ox, oy, oz, -dx, -dy, -dz, rx, ry, rz);
+                }
+            } else if (at_node) {
+                tl_ = slab_tmax(lb, ox, oy, oz, dx, dy, dz);
+                tr_ = slab_tmax(rb, ox, oy, oz, dx, dy, dz);
+            }
+            if (at_node) {
+                stepped = true;
+                const int lid = __float_as_int(q0.x), rid = __float_as_int(q0.y);
+                const int first = tl_ > tr_ ? lid : rid, second = tl_ > tr_ ? rid : lid;
+                const float tf = tl_ > tr_ ? tl_ : tr_, ts = tl_ > tr_ ? tr_ : tl_;
+                // the kernels above push `first`, then `second`, and pop `second` next: it stays in the register instead
+                cur = -1;
+                if (tf > 0) {
+                    if (ts > 0) {
+                        if (sp < TRACE_STACK) stack[sp++] = first; else lost = true;
+                        if (sp < TRACE_STACK) cur = second; else lost = true;
+                    } else {
+                        if (sp < TRACE_STACK) cur = first; else lost = true;
+                    }
+                }
+            }
+        } else if (at_leaf) {
+            stepped = true;
+            const float4* q = reinterpret_cast<const float4*>(tl + (cur - first_leaf));
+            const float4 q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3];
+            const float op = q2.y;
+            const float nx = q2.z, ny = q2.w, nz = q3.x;
+            if (!(op < 1.f / 255.f) && !(nx * dx + ny * dy + nz * dz > 0)) {
+                const float c0 = q0.w, c1 = q1.x, c2 = q1.y, c3 = q1.z, c4 = q1.w, c5 = q2.x;
+                const float mx = q0.x, my = q0.y, mz = q0.z;
+                const float m0 = mx - ox, m1 = my - oy, m2 = mz - oz;
+                const float t1 = c0 * m0 * dx + c1 * m0 * dy + c2 * m0 * dz + c1 * m1 * dx + c3 * m1 * dy + c4 * m1 * dz +
+                                 c2 * m2 * dx + c4 * m2 * dy + c5 * m2 * dz;
+                const float t2 = c0 * dx * dx + c1 * dx * dy + c2 * dx * dz + c1 * dy * dx + c3 * dy * dy + c4 * dy * dz +
+                                 c2 * dz * dx + c4 * dz * dy + c5 * dz * dz;
+                const float t = t1 / t2;
+                if (!(t < 0.01)) {
+                    const float px = ox + t * dx, py = oy + t * dy, pz = oz + t * dz;
+                    const float f0 = mx - px, f1 = my - py, f2 = mz - pz;
+                    const float s = f0 * f0 * c0 + f1 * f1 * c3 + f2 * f2 * c5 + 2 * f0 * f1 * c1 + 2 * f0 * f2 * c2 +
+                                    2 * f1 * f2 * c4;
+                    const float power = -0.5f * s;
+                    if (!(power > 0)) {
+                        count += 1;
+                        const float alpha = op * __expf(power);
+                        T *= 1 - alpha;
+                        if (T < 0.9) {          // retired with 0; contributes keeps 0 (trace.cu:251-254)
+                            T = 0.0f;
+                            count = 0;
+                            finished = true;
+                        }
+                    }
+                }
+            }
+            cur = -1;
+        }
+        if (stepped) {
+            if (!finished && cur < 0 && sp > 0) cur = stack[--sp];
+            if (finished || cur < 0) {
+                contributes[ray] = count;
+                out[ray] = T;
+                ray = -1;
+                sp = 0;
+                cur = -1;
+            }
+        }
+    }
+    if (lost) atomicAdd(overflow, 1);
+}
+
+int g_trace_packet = 4;    // r3dg_set_tuning8: 4 = 3 + phase-separated bodies, 3 = packed records + persistent waves, 2 = packed records, 1 = wave-cooperative, 0 = round-1 kernel
 
 // ---- trace_bvh: per-ray hit lists (K19; bvh/src/trace.cu:8-192, bound at bvh/src/bindings.cpp:11) ----------------------------
 // Pass 1 counts, per ray, the leaves of every subtree of <= 4 leaves whose box the ray reaches (tmax > 0 on the way down);
@@ -863,15 +1066,19 @@ void bvh_trace_opacity(hipStream_t s, int num_rays, int P, const int32_t* nodes,
         int* queues = reinterpret_cast<int*>(rec + (size_t)P * 128);           // 8 x 64 bytes behind the records
         pack_traversal_kernel<<<(P + 255) / 256, 256, 0, s>>>(P, nodes, aabbs, means, covs, opac, normals, tn, tl);
         const int nblk = (num_rays + 255) / 256, chunk = (nblk + 7) / 8;
-        if (g_trace_packet == 3) {
+        if (g_trace_packet >= 3) {
             int dev = 0, cus = 256;
             R3DG_HIP(hipGetDevice(&dev));
             (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
             R3DG_HIP(hipMemsetAsync(queues, 0, 8 * 64, s));
             const int cap = cus * 8;                                                // 8 waves per SIMD, all resident
             const int grid = chunk * 8 < cap ? chunk * 8 : cap;
-            trace_opacity_persistent_kernel<<<grid, 256, 0, s>>>(num_rays, P, tn, tl, rays_o, rays_d, contributes, out,
+            if (g_trace_packet == 4)
+                trace_opacity_phased_kernel<<<grid, 256, 0, s>>>(num_rays, P, tn, tl, rays_o, rays_d, contributes, out,
                                                                 overflow, queues);
+            else
+                trace_opacity_persistent_kernel<<<grid, 256, 0, s>>>(num_rays, P, tn, tl, rays_o, rays_d, contributes, out,
+                                                                    overflow, queues);
         } else {
             trace_opacity_packed_kernel<<<chunk * 8, 256, 0, s>>>(num_rays, P, chunk, tn, tl, rays_o, rays_d, contributes,
                                                                  out, overflow);

@@ -316,7 +316,7 @@ int r3dg_set_tuning6(int shade_forward_blocks_per_cu)
 
 int r3dg_set_tuning8(int trace_packet)
 {
-    if (trace_packet >= 0 && trace_packet <= 3) g_trace_packet = trace_packet;
+    if (trace_packet >= 0 && trace_packet <= 4) g_trace_packet = trace_packet;
     return R3DG_OK;
 }
 
