@@ -711,12 +711,16 @@ __global__ void __launch_bounds__(256)
 trace_opacity_phased_kernel(int num_rays, int P, const TNode* __restrict__ tn, const TLeaf* __restrict__ tl,
                             const float* __restrict__ rays_o, const float* __restrict__ rays_d,
                             int32_t* __restrict__ contributes, float* __restrict__ out, int* __restrict__ overflow,
-                            int* __restrict__ queues /* 8 x 16 ints, zeroed */)
+                            int* __restrict__ queues /* 8 x 16 ints, zeroed */, int refill_min_idle, int node_weight,
+                            int leaf_weight)
 {
     const int lane = threadIdx.x & 63;
     const int xcd = (int)(blockIdx.x & 7u);
     const int per = (num_rays + 7) / 8;
-    const int q_lo = xcd * per, q_hi = min(num_rays, q_lo + per);
+    // own queue first (locality); once it is empty the wave helps the next XCD's queue, and so on round the ring, so
+    // an XCD whose eighth of the scene is cheap does not idle while a dense eighth finishes
+    int q_turn = 0;
+    int q_lo = min(num_rays, xcd * per), q_hi = min(num_rays, q_lo + per);
     int* next_ray = queues + 16 * xcd;
     int stack[TRACE_STACK];
     int sp = 0, ray = -1, count = 0, cur = -1;
@@ -728,12 +732,12 @@ trace_opacity_phased_kernel(int num_rays, int P, const TNode* __restrict__ tn, c
         const unsigned long long idle = __ballot(ray < 0);
         if (idle != 0ull && !exhausted) {
             const int n_idle = __popcll(idle);
-            if (n_idle >= REFILL_MIN_IDLE || idle == __ballot(true)) {
+            if (n_idle >= refill_min_idle || idle == __ballot(true)) {
                 int base = 0;
                 const int leader = __builtin_ctzll(idle);
                 if (lane == leader) base = atomicAdd(next_ray, n_idle);
                 base = q_lo + __builtin_amdgcn_readlane(base, leader);
-                if (base + n_idle >= q_hi) exhausted = true;
+                const bool drained = base + n_idle >= q_hi;
                 if (ray < 0) {
                     const int idx = base + __popcll(idle & ((1ull << lane) - 1ull));
                     if (idx < q_hi) {
@@ -749,6 +753,15 @@ trace_opacity_phased_kernel(int num_rays, int P, const TNode* __restrict__ tn, c
                         T = 1.0f;
                     }
                 }
+                if (drained) {
+                    if (++q_turn == 8) exhausted = true;
+                    else {
+                        const int q = (xcd + q_turn) & 7;
+                        q_lo = min(num_rays, q * per);
+                        q_hi = min(num_rays, q_lo + per);
+                        next_ray = queues + 16 * q;
+                    }
+                }
             }
         }
         const bool at_leaf = ray >= 0 && cur >= first_leaf;
@@ -759,7 +772,7 @@ trace_opacity_phased_kernel(int num_rays, int P, const TNode* __restrict__ tn, c
             continue;
         }
         bool finished = false, stepped = false;
-        if (__popcll(node_m) >= __popcll(leaf_m)) {
+        if (__popcll(node_m) * node_weight >= __popcll(leaf_m) * leaf_weight) {
             float4 q0 = {}, q1 = {}, q2 = {}, q3 = {};
             if (at_node) {
                 const float4* q = reinterpret_cast<const float4*>(tn + cur);
@@ -842,7 +855,8 @@ trace_opacity_phased_kernel(int num_rays, int P, const TNode* __restrict__ tn, c
     if (lost) atomicAdd(overflow, 1);
 }
 
-int g_trace_packet = 4;    // r3dg_set_tuning8: 4 = 3 + phase-separated bodies, 3 = packed records + persistent waves, 2 = packed records, 1 = wave-cooperative, 0 = round-1 kernel
+int g_trace_packet = 4;
+int g_trace_refill = REFILL_MIN_IDLE, g_trace_node_weight = 1, g_trace_leaf_weight = 1;     // experiments (r3dg_set_tuning8)    // r3dg_set_tuning8: 4 = 3 + phase-separated bodies, 3 = packed records + persistent waves, 2 = packed records, 1 = wave-cooperative, 0 = round-1 kernel
 
 // ---- trace_bvh: per-ray hit lists (K19; bvh/src/trace.cu:8-192, bound at bvh/src/bindings.cpp:11) ----------------------------
 // Pass 1 counts, per ray, the leaves of every subtree of <= 4 leaves whose box the ray reaches (tmax > 0 on the way down);
@@ -1075,7 +1089,8 @@ void bvh_trace_opacity(hipStream_t s, int num_rays, int P, const int32_t* nodes,
             const int grid = chunk * 8 < cap ? chunk * 8 : cap;
             if (g_trace_packet == 4)
                 trace_opacity_phased_kernel<<<grid, 256, 0, s>>>(num_rays, P, tn, tl, rays_o, rays_d, contributes, out,
-                                                                overflow, queues);
+                                                                overflow, queues, g_trace_refill, g_trace_node_weight,
+                                                                g_trace_leaf_weight);
             else
                 trace_opacity_persistent_kernel<<<grid, 256, 0, s>>>(num_rays, P, tn, tl, rays_o, rays_d, contributes, out,
                                                                     overflow, queues);

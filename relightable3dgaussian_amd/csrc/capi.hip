@@ -55,7 +55,7 @@ void launch_shade_forward(hipStream_t s, int P, int K, int M, const float* base_
                           bool leave_room);
 void launch_shade_build_taps(hipStream_t s, size_t n, const float* dirs, const float* tr, int He, int We, const float* env,
                              uint32_t* taps);
-extern int g_trace_packet;
+extern int g_trace_packet, g_trace_refill, g_trace_node_weight, g_trace_leaf_weight;
 extern int g_shade_fwd_rows;
 extern int g_shade_bwd_rows;
 extern int g_shade_row_blocks_per_cu;
@@ -316,7 +316,13 @@ int r3dg_set_tuning6(int shade_forward_blocks_per_cu)
 
 int r3dg_set_tuning8(int trace_packet)
 {
-    if (trace_packet >= 0 && trace_packet <= 4) g_trace_packet = trace_packet;
+    if (trace_packet >= 0) {
+        // low byte: formulation; experiments: bits 8-15 refill threshold, 16-19 node weight, 20-23 leaf weight of the vote
+        if ((trace_packet & 0xff) <= 4) g_trace_packet = trace_packet & 0xff;
+        if ((trace_packet >> 8) & 0xff) g_trace_refill = (trace_packet >> 8) & 0xff;
+        if ((trace_packet >> 16) & 0xf) g_trace_node_weight = (trace_packet >> 16) & 0xf;
+        if ((trace_packet >> 20) & 0xf) g_trace_leaf_weight = (trace_packet >> 20) & 0xf;
+    }
     return R3DG_OK;
 }
 
