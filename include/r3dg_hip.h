@@ -185,14 +185,18 @@ int r3dg_shade_backward(void* stream, int P, int K, int M, const float* d_base_c
                         float* d_dL_dviewdirs, float* d_dL_dincidents, float* d_dL_denv);
 
 /* r3dg_shade_backward with the cached lookup records of r3dg_shade_build_taps (lookup mode, NOT radiance: the texture's
- * gradient needs the texel indices); d_taps == NULL = r3dg_shade_backward. */
+ * gradient needs the texel indices); d_taps == NULL = r3dg_shade_backward.
+ * d_block_absmax (may be NULL) / n_block_absmax: non-negative floats whose maximum is max(|dL_dpbr|, |dL_ddiffuse_light|)
+ * over all elements, +inf if any element is not finite -- the scale of the texture gradient's fixed-point accumulation.
+ * r3dg_stage2_unpack_gradients writes them as it produces the two gradients; NULL: reduced here by an extra pass. */
 int r3dg_shade_backward_cached(void* stream, int P, int K, int M, const float* d_base_color, const float* d_roughness,
                                const float* d_normals, const float* d_viewdirs, const float* d_incidents,
                                const float* d_env, int He, int We, const float* d_env_transform,
                                const float* d_visibility, const float* d_incident_dirs, const float* d_incident_areas,
                                const uint32_t* d_taps, const float* d_dL_dpbr, const float* d_dL_ddiffuse_light,
                                float* d_dL_dbase_color, float* d_dL_droughness, float* d_dL_dviewdirs,
-                               float* d_dL_dincidents, float* d_dL_denv);
+                               float* d_dL_dincidents, float* d_dL_denv, const float* d_block_absmax,
+                               int n_block_absmax);
 
 /* The reference's render_equation.{cu,h} contract model (render_equation.h:7-46): metallic BRDF with a spherical-
  * Gaussian D, SH environment light direct_shs[Sd,3] (+0.5), SH visibility visibility_shs[P,Sv] (+0.5, clamped), SH local
@@ -234,7 +238,9 @@ int r3dg_render_equation_backward(void* stream, int P, int Si, int Sd, int Sv, c
  *   roughness, diffuse_light, mean visibility; *light_l1_sum (may be NULL) += sum_p sum_c |diffuse_c - mean_c diffuse|
  *   (light-smoothness term, neilf.py:286-292).
  * r3dg_stage2_unpack_gradients: dL_dfeatures[P,16] -> the shading op's upstream gradients dL_dpbr[P,3] and
- *   dL_ddiffuse_light[P,3], the latter including light_weight * d(sum_c |diffuse_c - mean|)/d diffuse.
+ *   dL_ddiffuse_light[P,3], the latter including light_weight * d(sum_c |diffuse_c - mean|)/d diffuse;
+ *   d_block_absmax (may be NULL): [ceil(P/256)] floats, max |.| of the rows written by each block (+inf: not finite),
+ *   for r3dg_shade_backward_cached.
  * r3dg_stage2_activate_backward: chain rule of every activation above; combines the rasterizer's dL_dscales, dL_drot,
  *   dL_dopacity, dL_dmeans3D, dL_dfeatures and the shading op's dL_dbase_color, dL_droughness, dL_dviewdirs into the
  *   raw-parameter gradients (all seven outputs fully written).
@@ -253,7 +259,8 @@ int r3dg_stage2_pack_features(void* stream, int P, const float* d_xyz, const flo
                               const float* d_base_color, const float* d_roughness, const float* d_shade_out,
                               float* d_features, float* d_light_l1_sum);
 int r3dg_stage2_unpack_gradients(void* stream, int P, const float* d_dL_dfeatures, const float* d_shade_out,
-                                 float light_weight, float* d_dL_dpbr, float* d_dL_ddiffuse_light);
+                                 float light_weight, float* d_dL_dpbr, float* d_dL_ddiffuse_light,
+                                 float* d_block_absmax);
 int r3dg_stage2_activate_backward(void* stream, int P, const float* d_xyz, const float* d_scaling_raw,
                                   const float* d_rotation_raw, const float* d_opacity_raw, const float* d_normal_raw,
                                   const float* d_base_raw, const float* d_rough_raw, const float* d_viewmatrix,
@@ -316,9 +323,10 @@ int r3dg_stage1_activate_backward(void* stream, int P, const float* d_xyz, const
 
 /* Learnable environment texture (DirectLightMap, scene/direct_light_map.py:18-27): env = softplus(raw), [He,We,3].
  * g_raw = (dL_denv + w_tv * dTV(env)/denv) * softplus'(raw) with TV = mean (d/dh)^2 + mean (d/dw)^2 (tv_loss, utils/loss_utils.py:113-117: the env-smoothness term,
- * neilf.py:294-300); *tv_sum (may be NULL) += TV(env). */
-int r3dg_stage2_env_backward(void* stream, int He, int We, const float* d_raw, const float* d_env,
-                             const float* d_dL_denv, float w_tv, float* d_g_raw, float* d_tv_sum);
+ * neilf.py:294-300); *tv_sum (may be NULL) += TV(env).  consume != 0: dL_denv is zeroed after it was read, so the
+ * buffer can be handed to the next r3dg_shade_backward (which accumulates into it) without a fill. */
+int r3dg_stage2_env_backward(void* stream, int He, int We, const float* d_raw, const float* d_env, float* d_dL_denv,
+                             float w_tv, float* d_g_raw, float* d_tv_sum, int consume);
 
 /* Adam over up to R3DG_ADAM_MAX_GROUPS parameter groups in ONE launch (torch.optim.Adam semantics, no weight decay /
  * amsgrad; GaussianModel.training_setup + step, scene/gaussian_model.py:465-497).  Elements whose index modulo `period`

@@ -60,13 +60,13 @@ _SIGNATURES = {
     "r3dg_shade_backward": (_i, [_p, _i, _i, _i, _p, _p, _p, _p, _p, _p, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p,
                                  _p, _p]),
     "r3dg_shade_backward_cached": (_i, [_p, _i, _i, _i, _p, _p, _p, _p, _p, _p, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p,
-                                        _p, _p, _p]),
+                                        _p, _p, _p, _p, _i]),
     "r3dg_render_equation_forward": (_i, [_p, _i, _i, _i, _i] + [_p] * 8 + [_i] + [_p] * 4),
     "r3dg_render_equation_forward_complex": (_i, [_p, _i, _i, _i, _i] + [_p] * 8 + [_i] + [_p] * 11),
     "r3dg_render_equation_backward": (_i, [_p, _i, _i, _i, _i] + [_p] * 8 + [_i] + [_p] * 11),
     "r3dg_stage2_activate": (_i, [_p, _i] + [_p] * 15),
     "r3dg_stage2_pack_features": (_i, [_p, _i] + [_p] * 8),
-    "r3dg_stage2_unpack_gradients": (_i, [_p, _i, _p, _p, _f, _p, _p]),
+    "r3dg_stage2_unpack_gradients": (_i, [_p, _i, _p, _p, _f, _p, _p, _p]),
     "r3dg_stage2_activate_backward": (_i, [_p, _i] + [_p] * 24),
     "r3dg_stage2_loss": (_i, [_p, _i, _i] + [_p] * 7 + [_f, _f, _f] + [_p] * 6),
     "r3dg_stage2_pbr_srgb": (_i, [_p, _i, _i] + [_p] * 5),
@@ -77,7 +77,7 @@ _SIGNATURES = {
     "r3dg_stage1_pack_features": (_i, [_p, _i, _p, _p, _p, _p]),
     "r3dg_stage1_loss": (_i, [_p, _i, _i] + [_p] * 7 + [_f] * 5 + [_p] * 6),
     "r3dg_stage1_activate_backward": (_i, [_p, _i] + [_p] * 16),
-    "r3dg_stage2_env_backward": (_i, [_p, _i, _i, _p, _p, _p, _f, _p, _p]),
+    "r3dg_stage2_env_backward": (_i, [_p, _i, _i, _p, _p, _p, _f, _p, _p, _i]),
     "r3dg_adam_step": (_i, [_p, _i, _p, _f, _f, _f, _i, _f]),
     "r3dg_relight_pack_features": (_i, [_p, _i] + [_p] * 7),
     "r3dg_relight_compose": (_i, [_p, _i, _i, _f, _f, _f, _f, _p, _p, _p, _i, _i] + [_p] * 7),

@@ -63,7 +63,7 @@ void launch_shade_backward(hipStream_t s, int P, int K, int M, const float* base
                            const float* normals, const float* viewdirs, const float* incidents, const float* env,
                            int He, int We, const float* tr, const float* visibility, const float* dirs,
                            const float* areas, const float* g_pbr, const float* g_diff, float* d_base, float* d_rough,
-                           float* d_view, float* d_inc, float* d_env, const uint32_t* taps);
+                           float* d_view, float* d_inc, float* d_env, const uint32_t* taps, const float* block_absmax, int n_block_absmax);
 void launch_re_forward(hipStream_t s, bool complex_, int P, int Si, int Sd, int Sv, const float* base_color,
                        const float* roughness, const float* metallic, const float* normals, const float* viewdirs,
                        const float* inc, const float* direct, const float* vis, int K, const float* rand_float,
@@ -83,7 +83,7 @@ void launch_s2_pack(hipStream_t s, int P, const float* xyz, const float* viewmat
                     const float* base_color, const float* roughness, const float* shade_out, float* features,
                     float* light_l1_sum);
 void launch_s2_unpack(hipStream_t s, int P, const float* dL_dfeatures, const float* shade_out, float light_weight,
-                      float* dL_dpbr, float* dL_ddiffuse);
+                      float* dL_dpbr, float* dL_ddiffuse, float* block_absmax);
 void launch_s2_activate_backward(hipStream_t s, int P, const float* xyz, const float* scaling_raw,
                                  const float* rotation_raw, const float* opacity_raw, const float* normal_raw,
                                  const float* base_raw, const float* rough_raw, const float* viewmatrix,
@@ -116,8 +116,8 @@ void launch_s1_activate_backward(hipStream_t s, int P, const float* xyz, const f
                                  const float* viewmatrix, const float* dL_dfeatures, const float* dL_dscales,
                                  const float* dL_drot, const float* dL_dopacity, const float* dL_dmeans3D, float* g_xyz,
                                  float* g_scaling, float* g_rotation, float* g_opacity, float* g_normal);
-void launch_s2_env_backward(hipStream_t s, int He, int We, const float* raw, const float* env, const float* dL_denv,
-                            float w_tv, float* g_raw, float* tv_sum);
+void launch_s2_env_backward(hipStream_t s, int He, int We, const float* raw, const float* env, float* dL_denv,
+                            float w_tv, float* g_raw, float* tv_sum, int consume);
 uint32_t tile_sort_small_cap();
 void launch_tile_sort(hipStream_t s, int T, const uint32_t* tile_order, const uint32_t* ranges, const uint32_t* big_list,
                       const uint32_t* big_count, uint64_t* keys, uint32_t* vals, uint64_t* scratch, bool entries);
@@ -907,9 +907,11 @@ int r3dg_shade_backward_cached(void* stream_, int P, int K, int M, const float* 
                                int He, int We, const float* env_transform, const float* visibility,
                                const float* incident_dirs, const float* incident_areas, const uint32_t* taps,
                                const float* dL_dpbr, const float* dL_ddiffuse_light, float* dL_dbase_color,
-                               float* dL_droughness, float* dL_dviewdirs, float* dL_dincidents, float* dL_denv)
+                               float* dL_droughness, float* dL_dviewdirs, float* dL_dincidents, float* dL_denv,
+                               const float* block_absmax, int n_block_absmax)
 {
     if (P < 0 || K <= 0 || He <= 0 || We <= 0) return invalid("shade_backward: bad P/K/env size");
+    if (n_block_absmax < 0) return invalid("shade_backward: bad block_absmax count");
     if (He > 32767 || We > 32767) return invalid("shade_backward: environment map larger than 32767 texels per side");
     if (M != 1 && M != 4 && M != 9 && M != 16) return invalid("shade_backward: incidents must hold 1, 4, 9 or 16 SH coefficients");
     if (P == 0) return R3DG_OK;
@@ -918,7 +920,8 @@ int r3dg_shade_backward_cached(void* stream_, int P, int K, int M, const float* 
         StageTimer t(stream, ST_SHADE_BWD);
         launch_shade_backward(stream, P, K, M, base_color, roughness, normals, viewdirs, incidents, env, He, We,
                               env_transform, visibility, incident_dirs, incident_areas, dL_dpbr, dL_ddiffuse_light,
-                              dL_dbase_color, dL_droughness, dL_dviewdirs, dL_dincidents, dL_denv, taps);
+                              dL_dbase_color, dL_droughness, dL_dviewdirs, dL_dincidents, dL_denv, taps, block_absmax,
+                              n_block_absmax);
         check_launch(stream, false, "shade_backward");
         t.stop();
         return R3DG_OK;
@@ -934,7 +937,8 @@ int r3dg_shade_backward(void* stream_, int P, int K, int M, const float* base_co
 {
     return r3dg_shade_backward_cached(stream_, P, K, M, base_color, roughness, normals, viewdirs, incidents, env, He, We,
                                       env_transform, visibility, incident_dirs, incident_areas, nullptr, dL_dpbr,
-                                      dL_ddiffuse_light, dL_dbase_color, dL_droughness, dL_dviewdirs, dL_dincidents, dL_denv);
+                                      dL_ddiffuse_light, dL_dbase_color, dL_droughness, dL_dviewdirs, dL_dincidents, dL_denv,
+                                      nullptr, 0);
 }
 
 static int re_check(int P, int Si, int Sd, int Sv, int K)
@@ -1041,14 +1045,14 @@ int r3dg_stage2_pack_features(void* stream_, int P, const float* xyz, const floa
 }
 
 int r3dg_stage2_unpack_gradients(void* stream_, int P, const float* dL_dfeatures, const float* shade_out,
-                                 float light_weight, float* dL_dpbr, float* dL_ddiffuse)
+                                 float light_weight, float* dL_dpbr, float* dL_ddiffuse, float* block_absmax)
 {
     if (P < 0) return invalid("stage2_unpack_gradients: bad P");
     if (P == 0) return R3DG_OK;
     if (!dL_dfeatures || !shade_out || !dL_dpbr || !dL_ddiffuse) return invalid("stage2_unpack_gradients: null buffer");
     return guarded([&]() -> int {
         StageTimer t((hipStream_t)stream_, ST_S2_UNPACK);
-        launch_s2_unpack((hipStream_t)stream_, P, dL_dfeatures, shade_out, light_weight, dL_dpbr, dL_ddiffuse);
+        launch_s2_unpack((hipStream_t)stream_, P, dL_dfeatures, shade_out, light_weight, dL_dpbr, dL_ddiffuse, block_absmax);
         return R3DG_OK;
     });
 }
@@ -1215,14 +1219,14 @@ int r3dg_ssim_backward(void* stream_, int width, int height, int channels, const
                                    nullptr);
 }
 
-int r3dg_stage2_env_backward(void* stream_, int He, int We, const float* raw, const float* env, const float* dL_denv,
-                             float w_tv, float* g_raw, float* tv_sum)
+int r3dg_stage2_env_backward(void* stream_, int He, int We, const float* raw, const float* env, float* dL_denv,
+                             float w_tv, float* g_raw, float* tv_sum, int consume)
 {
     if (He < 0 || We < 0) return invalid("stage2_env_backward: bad texture size");
     if (He * We == 0) return R3DG_OK;
     if (!raw || !env || !dL_denv || !g_raw) return invalid("stage2_env_backward: null buffer");
     return guarded([&]() -> int {
-        launch_s2_env_backward((hipStream_t)stream_, He, We, raw, env, dL_denv, w_tv, g_raw, tv_sum);
+        launch_s2_env_backward((hipStream_t)stream_, He, We, raw, env, dL_denv, w_tv, g_raw, tv_sum, consume);
         return R3DG_OK;
     });
 }

@@ -806,6 +806,17 @@ shade_pad_env_kernel(int n, const float* __restrict__ env, float4* __restrict__ 
 // Backward: gradients of sum(pbr*g_pbr) + sum(diffuse_light*g_diff) w.r.t. base_color, roughness, viewdirs,
 // incidents and the (activated) environment texture.  normals / dirs / visibility carry no gradient in the
 // reference (normal.detach(), cached samples).
+// the largest of `n` non-negative floats (the block maxima of max|upstream gradient|; n == 1: grad_absmax_kernel's word),
+// +inf = "some upstream gradient is not finite"; uniform over the wave
+__device__ __forceinline__ float wave_gmax(const unsigned int* __restrict__ gmax_bits, int n)
+{
+    float m = 0.f;
+    for (int i = threadIdx.x & 63; i < n; i += 64) m = fmaxf(m, __uint_as_float(gmax_bits[i]));
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+    return m;
+}
+
 // max(|g_pbr|, |g_diff|) over all Gaussians -> *out (as float bits; non-negative floats order like unsigned ints).
 __global__ void __launch_bounds__(256)
 grad_absmax_kernel(int n, const float* __restrict__ a, const float* __restrict__ b, unsigned int* __restrict__ out)
@@ -840,14 +851,14 @@ __global__ void __launch_bounds__(64 * SHADE_WAVES)
 shade_backward_kernel(int P, int K, int M, ShadeSrc src, const float* __restrict__ env, int He, int We,
                       const float* __restrict__ tr, float* __restrict__ d_base, float* __restrict__ d_rough,
                       float* __restrict__ d_view, float* __restrict__ d_inc, float* __restrict__ d_env,
-                      const unsigned int* __restrict__ gmax_bits, const uint32_t* __restrict__ taps)
+                      const unsigned int* __restrict__ gmax_bits, int gmax_n, const uint32_t* __restrict__ taps)
 {
     extern __shared__ __attribute__((aligned(16))) float s_mem[];
     const int ntex_raw = He * We * 3;
     const int ntex = ENV_LDS ? ((ntex_raw + 3) & ~3) : 0;
     float* s_env = s_mem;
     long long* s_denv = reinterpret_cast<long long*>(s_mem + ntex);      // 64-bit fixed-point accumulators
-    const float gmax = __uint_as_float(*gmax_bits);
+    const float gmax = wave_gmax(gmax_bits, gmax_n);
     const bool fixed = ENV_LDS && gmax > 0.f && gmax <= 3.0e38f;
     const float fx_scale = fixed ? 34359738368.0f / gmax : 0.f;          // 2^35 / max|g|
     const float fx_clamp = gmax * 8192.0f;                               // |contribution| <= max|g| * 2^13
@@ -1146,7 +1157,7 @@ shade_backward_row_kernel(int P, int K, int M_, const float* __restrict__ rec, c
                           const float* __restrict__ dirs, const float* __restrict__ areas, float uniform_area,
                           const uint32_t* __restrict__ taps, float* __restrict__ d_base, float* __restrict__ d_rough,
                           float* __restrict__ d_view, float* __restrict__ d_inc, float* __restrict__ d_env,
-                          const unsigned int* __restrict__ gmax_bits)
+                          const unsigned int* __restrict__ gmax_bits, int gmax_n)
 {
     const int M = M16 ? 16 : M_;
     extern __shared__ __attribute__((aligned(16))) float s_mem[];
@@ -1155,7 +1166,7 @@ shade_backward_row_kernel(int P, int K, int M_, const float* __restrict__ rec, c
     const int ntexel = He * We;
     float4* s_env4 = reinterpret_cast<float4*>(s_mem);
     long long* s_denv = reinterpret_cast<long long*>(s_mem + (ENV_LDS ? 4 * ntexel : 0));     // [texel][3] fixed point
-    const float gmax = __uint_as_float(*gmax_bits);
+    const float gmax = wave_gmax(gmax_bits, gmax_n);
     const bool fixed = ENV_LDS && gmax > 0.f && gmax <= 3.0e38f;
     const float fx_scale = fixed ? 34359738368.0f / gmax : 0.f;          // 2^35 / max|g|
     const float fx_clamp = gmax * 8192.0f;
@@ -1494,12 +1505,22 @@ void launch_shade_backward(hipStream_t s, int P, int K, int M, const float* base
                            const float* normals, const float* viewdirs, const float* incidents, const float* env,
                            int He, int We, const float* tr, const float* visibility, const float* dirs,
                            const float* areas, const float* g_pbr, const float* g_diff, float* d_base, float* d_rough,
-                           float* d_view, float* d_inc, float* d_env, const uint32_t* taps)
+                           float* d_view, float* d_inc, float* d_env, const uint32_t* taps, const float* block_absmax,
+                           int n_block_absmax)
 {
     unsigned int* scratch = shade_scratch();
-    R3DG_HIP(hipMemsetAsync(scratch, 0, 4, s));
-    const int nb = (3 * P + 255) / 256;
-    grad_absmax_kernel<<<nb < 256 ? nb : 256, 256, 0, s>>>(3 * P, g_pbr, g_diff, scratch);
+    // scale of the fixed-point texture accumulation: max |upstream gradient|, either handed over as block maxima by the
+    // producer of g_pbr / g_diff (r3dg_stage2_unpack_gradients) or reduced here
+    const unsigned int* gmax = scratch;
+    int gmax_n = 1;
+    if (block_absmax != nullptr && n_block_absmax > 0) {
+        gmax = reinterpret_cast<const unsigned int*>(block_absmax);
+        gmax_n = n_block_absmax;
+    } else {
+        R3DG_HIP(hipMemsetAsync(scratch, 0, 4, s));
+        const int nb = (3 * P + 255) / 256;
+        grad_absmax_kernel<<<nb < 256 ? nb : 256, 256, 0, s>>>(3 * P, g_pbr, g_diff, scratch);
+    }
 
     const int ntex = He * We * 3;
     if (g_shade_bwd_rows) {
@@ -1530,11 +1551,11 @@ void launch_shade_backward(hipStream_t s, int P, int K, int M, const float* base
         if (M == 16)                                                                                                  \
             shade_backward_row_kernel<L, T, true><<<grid_r, 64 * RB_WAVES, smem_r, s>>>(                              \
                 P, K, M, rec, env4, He, We, tr, visibility, dirs, areas, 0.f, taps, d_base, d_rough, d_view, d_inc,   \
-                d_env, scratch);                                                                                      \
+                d_env, gmax, gmax_n);                                                                                 \
         else                                                                                                          \
             shade_backward_row_kernel<L, T, false><<<grid_r, 64 * RB_WAVES, smem_r, s>>>(                             \
                 P, K, M, rec, env4, He, We, tr, visibility, dirs, areas, 0.f, taps, d_base, d_rough, d_view, d_inc,   \
-                d_env, scratch);                                                                                      \
+                d_env, gmax, gmax_n);                                                                                 \
     } while (0)
         if (lds_r) { if (taps != nullptr) R3DG_RB(true, true); else R3DG_RB(true, false); }
         else { if (taps != nullptr) R3DG_RB(false, true); else R3DG_RB(false, false); }
@@ -1554,8 +1575,8 @@ void launch_shade_backward(hipStream_t s, int P, int K, int M, const float* base
             R3DG_HIP(hipFuncSetAttribute((const void*)shade_backward_kernel<L, V, T>,                                 \
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));                     \
         shade_backward_kernel<L, V, T><<<grid, 64 * SHADE_WAVES, smem, s>>>(P, K, M, src, env, He, We, tr, d_base,    \
-                                                                          d_rough, d_view, d_inc, d_env, scratch,     \
-                                                                          taps);                                      \
+                                                                          d_rough, d_view, d_inc, d_env, gmax,        \
+                                                                          gmax_n, taps);                              \
     } while (0)
 #define R3DG_SB(L, V)                                                                                                 \
     do {                                                                                                              \

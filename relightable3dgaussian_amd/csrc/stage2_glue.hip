@@ -121,24 +121,43 @@ __device__ __forceinline__ float signf_(float x) { return x > 0.f ? 1.f : (x < 0
 
 // dL_dpbr / dL_ddiffuse_light for the shading op: the rasterizer's feature gradients (cols 2-4 / 12-14) plus the gradient of
 // light_weight * sum_c |dl_c - mean(dl)|
+// block_absmax (may be NULL): [gridDim.x] floats, max |upstream gradient| of the block's rows, +inf if any is not finite --
+// the scale of the shading backward's fixed-point texture accumulation (shading.hip), so that op needs no reduction pass
 __global__ void __launch_bounds__(256)
 s2_unpack_kernel(int P, const float* __restrict__ dL_dfeatures, const float* __restrict__ shade_out, float light_weight,
-                 float* __restrict__ dL_dpbr, float* __restrict__ dL_ddiffuse)
+                 float* __restrict__ dL_dpbr, float* __restrict__ dL_ddiffuse, float* __restrict__ block_absmax)
 {
+    __shared__ float s_m[4];
     const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= P) return;
-    const float4* g = reinterpret_cast<const float4*>(dL_dfeatures + 16 * (size_t)i);
-    const float4 g0 = g[0], g1 = g[1], g3 = g[3];
-    const size_t i3 = 3 * (size_t)i;
-    dL_dpbr[i3] = g0.z; dL_dpbr[i3 + 1] = g0.w; dL_dpbr[i3 + 2] = g1.x;
-    const float* so = shade_out + 19 * (size_t)i;
-    const float dl[3] = {so[3], so[4], so[5]};
-    const float m = (dl[0] + dl[1] + dl[2]) / 3.f;
-    const float s[3] = {signf_(dl[0] - m), signf_(dl[1] - m), signf_(dl[2] - m)};
-    const float sm = (s[0] + s[1] + s[2]) / 3.f;
-    dL_ddiffuse[i3] = g3.x + light_weight * (s[0] - sm);
-    dL_ddiffuse[i3 + 1] = g3.y + light_weight * (s[1] - sm);
-    dL_ddiffuse[i3 + 2] = g3.z + light_weight * (s[2] - sm);
+    float m = 0.f;
+    bool bad = false;
+    if (i < P) {
+        const float4* g = reinterpret_cast<const float4*>(dL_dfeatures + 16 * (size_t)i);
+        const float4 g0 = g[0], g1 = g[1], g3 = g[3];
+        const size_t i3 = 3 * (size_t)i;
+        dL_dpbr[i3] = g0.z; dL_dpbr[i3 + 1] = g0.w; dL_dpbr[i3 + 2] = g1.x;
+        const float* so = shade_out + 19 * (size_t)i;
+        const float dl[3] = {so[3], so[4], so[5]};
+        const float mean = (dl[0] + dl[1] + dl[2]) / 3.f;
+        const float s[3] = {signf_(dl[0] - mean), signf_(dl[1] - mean), signf_(dl[2] - mean)};
+        const float sm = (s[0] + s[1] + s[2]) / 3.f;
+        const float d0 = g3.x + light_weight * (s[0] - sm), d1 = g3.y + light_weight * (s[1] - sm),
+                    d2 = g3.z + light_weight * (s[2] - sm);
+        dL_ddiffuse[i3] = d0; dL_ddiffuse[i3 + 1] = d1; dL_ddiffuse[i3 + 2] = d2;
+        const float v[6] = {fabsf(g0.z), fabsf(g0.w), fabsf(g1.x), fabsf(d0), fabsf(d1), fabsf(d2)};
+#pragma unroll
+        for (int c = 0; c < 6; c++) {
+            bad = bad || !(v[c] <= 3.0e38f);
+            m = fmaxf(m, v[c]);
+        }
+    }
+    if (block_absmax == nullptr) return;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+    if (__ballot(bad) != 0ull) m = __uint_as_float(0x7f800000u);
+    if ((threadIdx.x & 63) == 0) s_m[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) block_absmax[blockIdx.x] = fmaxf(fmaxf(s_m[0], s_m[1]), fmaxf(s_m[2], s_m[3]));
 }
 
 __global__ void __launch_bounds__(256)
@@ -313,8 +332,8 @@ s2_loss_kernel(int HW, const float* __restrict__ image, const float* __restrict_
 // utils/loss_utils.py:113-117, pinned by tests/golden/ssim_reference.npz).
 __global__ void __launch_bounds__(256)
 s2_env_backward_kernel(int He, int We, const float* __restrict__ raw, const float* __restrict__ env,
-                       const float* __restrict__ dL_denv, float w_tv, float* __restrict__ g_raw,
-                       float* __restrict__ tv_sum)
+                       float* __restrict__ dL_denv, float w_tv, float* __restrict__ g_raw,
+                       float* __restrict__ tv_sum, int consume)
 {
     __shared__ float s_part[4];
     const int n = He * We * 3;
@@ -334,6 +353,7 @@ s2_env_backward_kernel(int He, int We, const float* __restrict__ raw, const floa
         const float r = raw[i];
         const float dsoft = r > 20.f ? 1.f : sigmoidf_(r);
         g_raw[i] = (dL_denv[i] + w_tv * g) * dsoft;
+        if (consume) dL_denv[i] = 0.f;            // the accumulator is handed back zeroed for the next shading backward
     }
     const float tot = block_sum_256(tv, s_part);
     if (threadIdx.x == 0 && tv_sum != nullptr) atomicAdd(tv_sum, tot);
@@ -633,9 +653,10 @@ void launch_s2_pack(hipStream_t s, int P, const float* xyz, const float* viewmat
 }
 
 void launch_s2_unpack(hipStream_t s, int P, const float* dL_dfeatures, const float* shade_out, float light_weight,
-                      float* dL_dpbr, float* dL_ddiffuse)
+                      float* dL_dpbr, float* dL_ddiffuse, float* block_absmax)
 {
-    s2_unpack_kernel<<<(P + 255) / 256, 256, 0, s>>>(P, dL_dfeatures, shade_out, light_weight, dL_dpbr, dL_ddiffuse);
+    s2_unpack_kernel<<<(P + 255) / 256, 256, 0, s>>>(P, dL_dfeatures, shade_out, light_weight, dL_dpbr, dL_ddiffuse,
+                                                    block_absmax);
     check_launch(s, false, "s2_unpack_kernel");
 }
 
@@ -673,10 +694,11 @@ void launch_s2_loss(hipStream_t s, int HW, const float* image, const float* opac
     check_launch(s, false, "s2_loss_kernel");
 }
 
-void launch_s2_env_backward(hipStream_t s, int He, int We, const float* raw, const float* env, const float* dL_denv,
-                            float w_tv, float* g_raw, float* tv_sum)
+void launch_s2_env_backward(hipStream_t s, int He, int We, const float* raw, const float* env, float* dL_denv,
+                            float w_tv, float* g_raw, float* tv_sum, int consume)
 {
-    s2_env_backward_kernel<<<(He * We * 3 + 255) / 256, 256, 0, s>>>(He, We, raw, env, dL_denv, w_tv, g_raw, tv_sum);
+    s2_env_backward_kernel<<<(He * We * 3 + 255) / 256, 256, 0, s>>>(He, We, raw, env, dL_denv, w_tv, g_raw, tv_sum,
+                                                                    consume);
     check_launch(s, false, "s2_env_backward_kernel");
 }
 

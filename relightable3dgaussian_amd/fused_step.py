@@ -120,6 +120,8 @@ class FusedStage2Step:
         # unweighted sums: l1, pbr l1, normal mse, light l1, TV(env), SSIM(image), SSIM(pbr)
         self.sums = torch.zeros(7, **f)
         self.d_pbr, self.d_diffuse = torch.empty(P, 3, **f), torch.empty(P, 3, **f)
+        self._absmax = torch.zeros((P + 255) // 256, **f)       # block maxima of |d_pbr|, |d_diffuse| (unpack kernel)
+        self._d_env = None
         # flat gradient slab: [shs 3M | xyz3 normal3 scaling3 rotation4 opacity1 base3 rough1 per Gaussian, env texture |
         # incidents 3M]; every group starts on a 16-byte boundary (float4 accesses in the Adam kernel)
         sizes = dict(xyz=3 * P, normal=3 * P, scaling=3 * P, rotation=4 * P, opacity=P, base_color=3 * P, roughness=P,
@@ -308,11 +310,15 @@ class FusedStage2Step:
                 self._early = True
             _lib.check(L.r3dg_stage2_unpack_gradients(
                 stream(), P, dL_dfeatures.data_ptr(), self.shade_out.data_ptr(), self.w["light"] / (3.0 * P),
-                self.d_pbr.data_ptr(), self.d_diffuse.data_ptr()), "stage2_unpack_gradients")
+                self.d_pbr.data_ptr(), self.d_diffuse.data_ptr(), self._absmax.data_ptr()), "stage2_unpack_gradients")
+            # the texture-gradient accumulator comes back zeroed from r3dg_stage2_env_backward (consume), the gradient
+            # scale from the unpack kernel: nothing sits between that kernel and the shading backward
+            if self._d_env is None or self._d_env.shape != env_c.shape:
+                self._d_env = torch.zeros_like(env_c)
             d_base, d_rough, d_view, _d_inc, d_env = shading_ops.shade_backward(
                 self.a_base, self.a_rough, self.a_normal, self.a_viewdirs, self.incidents, env_c, self.visibility,
                 self.incident_dirs, self.incident_areas, self.d_pbr, self.d_diffuse,
-                out_incidents=self.grads["incidents"], taps=taps)
+                out_incidents=self.grads["incidents"], taps=taps, out_env=self._d_env, block_absmax=self._absmax)
             gr = self.grads
             if self._side is not None:          # join the geometry backward
                 torch.cuda.current_stream().wait_stream(self._side)
@@ -328,7 +334,7 @@ class FusedStage2Step:
             # environment texture: softplus chain rule + total-variation term
             _lib.check(L.r3dg_stage2_env_backward(
                 stream(), He, We, self.env.data_ptr(), env_c.data_ptr(), d_env.data_ptr(), self.w["env_smooth"],
-                gr["env"].data_ptr(), self.sums[4:].data_ptr()), "stage2_env_backward")
+                gr["env"].data_ptr(), self.sums[4:].data_ptr(), 1), "stage2_env_backward")
             self._handles = None
             if self.world > 1:
                 handle_c = self._allreduce_async(self._bucket_c)

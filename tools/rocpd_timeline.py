@@ -20,11 +20,21 @@ def main():
         return
     per = collections.defaultdict(float)
     cnt = collections.Counter()
-    wall = busy = 0.0
+    wall = busy = covered = 0.0
     launches = 0
+    gaps = []
     for a, b in zip(marks[:-1], marks[1:]):
         seg = rows[a:b]
         wall += rows[b][1] - rows[a][1]
+        # union of the kernel intervals (kernels on different streams overlap): what is left is time with NO kernel running
+        hi = rows[a][1]
+        for name, s, e in seg:
+            if s > hi:
+                gaps.append((s - hi, name[:60]))
+                hi = s
+            if e > hi:
+                covered += min(e, rows[b][1]) - hi
+                hi = e
         for name, s, e in seg:
             busy += e - s
             per[name[:90]] += e - s
@@ -33,6 +43,13 @@ def main():
     k = len(marks) - 1
     print("steps %d  wall %.3f ms/step  gpu busy %.3f ms/step  idle %.3f ms/step  launches/step %.1f" %
           (k, wall / k / 1e6, busy / k / 1e6, (wall - busy) / k / 1e6, launches / k))
+    print("some kernel running %.3f ms/step; nothing running %.3f ms/step (%.1f %% of the step), in %d gaps/step" %
+          (covered / k / 1e6, (wall - covered) / k / 1e6, 100.0 * (wall - covered) / wall, len(gaps) / k))
+    by = collections.defaultdict(float)
+    for g, name in gaps:
+        by[name] += g
+    for name, v in sorted(by.items(), key=lambda x: -x[1])[:8]:
+        print("   gap before %-60s %7.1f us/step" % (name, v / k / 1e3))
     r3dg = sum(v for kname, v in per.items() if "r3dg::" in kname)
     print("r3dg kernels %.3f ms/step, other (torch) kernels %.3f ms/step" % (r3dg / k / 1e6, (busy - r3dg) / k / 1e6))
     for name, v in sorted(per.items(), key=lambda x: -x[1])[:45]:
