@@ -56,6 +56,8 @@ size_t r3dg_binning_state_bytes(int64_t num_rendered);
  * image:    0 final_T f32[N], 1 n_contrib u32[N], 2 ranges u32[2T]
  * binning:  0 keys_unsorted u64[R], 1 keys u64[R], 2 vals_unsorted u32[R], 3 point_list u32[R] */
 int r3dg_geometry_state_offsets(int P, size_t* offsets9);
+/* byte offset of the uint64 instance count (num_rendered) of the last forward inside the geometry state */
+size_t r3dg_geometry_state_total_offset(int P);
 int r3dg_image_state_offsets(int width, int height, size_t* offsets3);
 int r3dg_binning_state_offsets(int64_t num_rendered, size_t* offsets4);
 
@@ -99,6 +101,32 @@ int r3dg_rasterize_forward_finish(void* ticket, int* num_rendered_out);
  * whatever the caller queued on the forward's stream after _begin.  The binning state buffer is first touched on
  * `ordering_stream`. */
 int r3dg_rasterize_forward_finish_on(void* ticket, void* ordering_stream, int* num_rendered_out);
+
+/* The forward WITHOUT the host read-back of num_rendered (the reference's one synchronisation per forward,
+ * rasterizer_impl.cu:291).  _begin_bounded queues the projection on `stream` AND the instance ordering behind it on
+ * `ordering_stream` (NULL = `stream`) at once, with the binning state laid out for `capacity` instances (the value to pass
+ * as num_rendered to the backward, whose state layout it selects); _finish_bounded makes `main_stream` wait for the
+ * ordering and renders there -- kernels the caller queued on `stream` after _begin_ (the feature rows) run beside the
+ * ordering when the two streams differ.
+ * A frame that needs MORE than `capacity` instances is dropped on the device: every tile list comes out empty (the
+ * images are background only, n_contrib 0, all gradients of that frame zero) and *d_overflow_flag = 1.0f; otherwise the
+ * flag is set to 0.0f (may be NULL); *d_overflow_count (may be NULL) is incremented for every dropped frame and never
+ * reset by the library, so a caller that polls rarely still hears about it.  The true count stays readable in the geometry state
+ * (r3dg_geometry_state_total_offset).  Needs the direct tile binning (the default, at most 16384 tiles): its launches do not depend on the count. */
+int r3dg_rasterize_forward_begin_bounded(void* stream, r3dg_alloc_fn geometry_alloc, r3dg_alloc_fn binning_alloc,
+                                         r3dg_alloc_fn image_alloc, void* alloc_user, int P, int S, int D, int M,
+                                         const float* d_background, int width, int height, const float* d_means3D,
+                                         const float* d_shs, const float* d_colors_precomp, const float* d_features,
+                                         const float* d_opacities, const float* d_scales, float scale_modifier,
+                                         const float* d_rotations, const float* d_cov3D_precomp,
+                                         const float* d_viewmatrix, const float* d_projmatrix, const float* d_cam_pos,
+                                         float tan_fovx, float tan_fovy, float cx, float cy, int prefiltered,
+                                         int compute_pseudo_normal, float* d_out_color, float* d_out_opacity,
+                                         float* d_out_depth, float* d_out_feature, float* d_out_normal,
+                                         float* d_out_surface_xyz, float* d_out_weights, int32_t* d_radii, int debug,
+                                         void* ordering_stream, long long capacity, float* d_overflow_flag,
+                                         unsigned int* d_overflow_count, void** ticket);
+int r3dg_rasterize_forward_finish_bounded(void* ticket, void* main_stream);
 
 /* Backward.  d_dL_dmean2D [P,3] (z = depth side channel), d_dL_dconic [P,4] (x,y,-,w), d_dL_dopacity, d_dL_dcolor and
  * d_dL_dfeature are accumulated with atomics and must be zero-filled by the caller; d_dL_dmean3D, d_dL_dcov3D and --
@@ -332,7 +360,8 @@ int r3dg_stage2_env_backward(void* stream, int He, int We, const float* d_raw, c
  * amsgrad; GaussianModel.training_setup + step, scene/gaussian_model.py:465-497).  Elements whose index modulo `period`
  * is >= `split` use lr_tail (period 0: one rate) -- e.g. a [P,16,3] SH tensor with period 48, split 3 carries the
  * features_dc / features_rest rates.  `step` is the 1-based step count for the bias corrections; every gradient is
- * multiplied by `grad_scale` first (1/world_size after a sum all-reduce, 1 otherwise). */
+ * multiplied by `grad_scale` first (1/world_size after a sum all-reduce, 1 otherwise).  d_skip_flag (may be NULL): when the
+ * float it points to is non-zero on the device the launch updates nothing (the overflow flag of a bounded forward). */
 #define R3DG_ADAM_MAX_GROUPS 16
 typedef struct r3dg_adam_group {
     float* param;
@@ -344,7 +373,7 @@ typedef struct r3dg_adam_group {
     uint32_t period, split;
 } r3dg_adam_group;
 int r3dg_adam_step(void* stream, int n_groups, const r3dg_adam_group* groups, float beta1, float beta2, float eps,
-                   int step, float grad_scale);
+                   int step, float grad_scale, const float* d_skip_flag);
 
 /* ---- relight / eval frame glue (relighting.py:114-170 -> gaussian_renderer/neilf.py:74-209 with is_training=False) -----
  * r3dg_relight_pack_features: the S=28 eval feature row (neilf.py:124-130) from the activated parameters and the 19

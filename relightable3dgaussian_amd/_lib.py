@@ -23,6 +23,7 @@ _SIGNATURES = {
     "r3dg_image_state_bytes": (C.c_size_t, [_i, _i]),
     "r3dg_binning_state_bytes": (C.c_size_t, [C.c_int64]),
     "r3dg_geometry_state_offsets": (_i, [_i, C.POINTER(C.c_size_t)]),
+    "r3dg_geometry_state_total_offset": (C.c_size_t, [_i]),
     "r3dg_image_state_offsets": (_i, [_i, _i, C.POINTER(C.c_size_t)]),
     "r3dg_binning_state_offsets": (_i, [C.c_int64, C.POINTER(C.c_size_t)]),
     "r3dg_rasterize_forward": (_i, [_p, ALLOC_FN, ALLOC_FN, ALLOC_FN, _p, _i, _i, _i, _i, _p, _i, _i, _p, _p, _p, _p,
@@ -31,6 +32,10 @@ _SIGNATURES = {
     "r3dg_rasterize_forward_begin": (_i, [_p, ALLOC_FN, ALLOC_FN, ALLOC_FN, _p, _i, _i, _i, _i, _p, _i, _i, _p, _p, _p, _p,
                                     _p, _p, _f, _p, _p, _p, _p, _p, _f, _f, _f, _f, _i, _i, _p, _p, _p, _p, _p, _p,
                                     _p, _p, _i, C.POINTER(_p)]),
+    "r3dg_rasterize_forward_begin_bounded": (_i, [_p, ALLOC_FN, ALLOC_FN, ALLOC_FN, _p, _i, _i, _i, _i, _p, _i, _i, _p, _p, _p,
+                                            _p, _p, _p, _f, _p, _p, _p, _p, _p, _f, _f, _f, _f, _i, _i, _p, _p, _p, _p,
+                                            _p, _p, _p, _p, _i, _p, C.c_longlong, _p, _p, C.POINTER(_p)]),
+    "r3dg_rasterize_forward_finish_bounded": (_i, [_p, _p]),
     "r3dg_rasterize_forward_finish": (_i, [_p, C.POINTER(_i)]),
     "r3dg_rasterize_forward_finish_on": (_i, [_p, _p, C.POINTER(_i)]),
     "r3dg_rasterize_backward": (_i, [_p, _i, _i, _i, _i, _i, _p, _i, _i, _p, _p, _p, _p, _p, _f, _p, _p, _p, _p, _p,
@@ -78,7 +83,7 @@ _SIGNATURES = {
     "r3dg_stage1_loss": (_i, [_p, _i, _i] + [_p] * 7 + [_f] * 5 + [_p] * 6),
     "r3dg_stage1_activate_backward": (_i, [_p, _i] + [_p] * 16),
     "r3dg_stage2_env_backward": (_i, [_p, _i, _i, _p, _p, _p, _f, _p, _p, _i]),
-    "r3dg_adam_step": (_i, [_p, _i, _p, _f, _f, _f, _i, _f]),
+    "r3dg_adam_step": (_i, [_p, _i, _p, _f, _f, _f, _i, _f, _p]),
     "r3dg_relight_pack_features": (_i, [_p, _i] + [_p] * 7),
     "r3dg_relight_compose": (_i, [_p, _i, _i, _f, _f, _f, _f, _p, _p, _p, _i, _i] + [_p] * 7),
     "r3dg_densify_accumulate": (_i, [_p, _i] + [_p] * 9),

@@ -495,7 +495,8 @@ def run(args):
         # the whole iteration through the fused glue kernels + one-launch Adam (fused_step.py); gradients are averaged
         # over ranks inside (three buckets of one flat slab; see fused_step.py and DESIGN.md section 5)
         from . import fused_step
-        step_fn = fused_step.FusedStage2Step(params, args.sample_num, lr=1e-4)
+        step_fn = fused_step.FusedStage2Step(params, args.sample_num, lr=1e-4,
+                                             bounded=os.environ.get("R3DG_BOUNDED", "1") != "0")      # (A/B experiments)
         S = 16
     elif stage2:
         from . import train_step
@@ -527,7 +528,8 @@ def run(args):
         cam = cams[v]
         if fused:
             outs = step_fn(cam, bg, gts[v])                  # forward + loss + backward + all-reduce + Adam
-            R_seen.append(outs[0])
+            if not hasattr(step_fn, "rendered_counts"):      # (the bounded forward keeps the count off the host)
+                R_seen.append(outs[0])
             return None
         if stage2:
             loss, outs = step_fn(cam, bg, gts[v])
@@ -567,6 +569,11 @@ def run(args):
     elapsed = time.perf_counter() - t0
     prof = _lib.profile_read()
     L.r3dg_profile_enable(0)
+    if fused and hasattr(step_fn, "rendered_counts"):
+        R_seen = step_fn.rendered_counts(args.steps)
+        dropped = step_fn.poll_overflow()
+        if dropped:
+            raise RuntimeError("bench: %d timed iterations were dropped by the bounded forward (capacity too small)" % dropped)
     if world > 1:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)

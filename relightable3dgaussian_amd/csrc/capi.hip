@@ -103,7 +103,7 @@ void launch_ssim_forward(hipStream_t s, int W, int H, int C, int n_images, const
 void launch_ssim_backward(hipStream_t s, int W, int H, int C, int n_images, const float* const* x, const float* y,
                           float* const* partials, const float* scale, float* const* grad_x);
 void launch_adam(hipStream_t s, int n_groups, const r3dg_adam_group* groups, float beta1, float beta2, float eps,
-                 int step, float grad_scale);
+                 int step, float grad_scale, const float* skip_flag);
 void launch_s1_pack(hipStream_t s, int P, const float* xyz, const float* viewmatrix, const float* normal, float* features);
 void launch_s1_edge(hipStream_t s, int W, int H, const float* feature, const float* opacity, const int* n_contrib,
                     const float* gt, float* edge_g, float* sum_out);
@@ -124,7 +124,8 @@ void launch_tile_sort(hipStream_t s, int T, const uint32_t* tile_order, const ui
 void launch_tile_binning(hipStream_t s, int P, int T, const float* means2D, const float* depths, const int* radii,
                          const uint32_t* tiles_touched, const uint32_t* block_offsets, int gx, int gy,
                          uint32_t* tile_counts, uint32_t* cursor, uint32_t* ranges, uint32_t* point_offsets,
-                         uint64_t* entries);
+                         uint64_t* entries, const unsigned long long* total, long long capacity, float* overflow_flag,
+                         unsigned int* overflow_count);
 int tile_binning_max_tiles();
 extern int g_bin_iters;
 void launch_densify_accumulate(hipStream_t s, int P, const float* viewspace_grad, const float* normal_grad,
@@ -438,6 +439,10 @@ int r3dg_geometry_state_offsets(int P, size_t* o)
     o[6] = L.rgb; o[7] = L.tiles_touched; o[8] = L.point_offsets;
     return R3DG_OK;
 }
+size_t r3dg_geometry_state_total_offset(int P)
+{
+    return GeometryLayout::make((size_t)(P < 0 ? 0 : P)).total;
+}
 int r3dg_image_state_offsets(int width, int height, size_t* o)
 {
     const size_t T = (size_t)((width + 15) / 16) * ((height + 15) / 16);
@@ -469,6 +474,12 @@ struct ForwardTicket {
     char *gbuf, *ibuf;
     hipEvent_t ready;
     unsigned long long* host_total;      // pinned
+    // bounded forward (r3dg_rasterize_forward_begin_bounded): the binning state is laid out for `capacity` instances, the
+    // ordering was enqueued by _begin_ and `ready` marks its end; capacity < 0: the exact two-phase forward
+    long long capacity;
+    float* overflow_flag;
+    unsigned int* overflow_count;
+    char* bbuf;
 };
 
 static std::mutex g_ticket_mutex;
@@ -495,7 +506,9 @@ static void ticket_release(ForwardTicket* t)
     g_ticket_pool.push_back(t);
 }
 
-int r3dg_rasterize_forward_begin(void* stream_, r3dg_alloc_fn geometry_alloc, r3dg_alloc_fn binning_alloc,
+static int enqueue_ordering(ForwardTicket* t, hipStream_t stream, int R);
+
+static int forward_begin_impl(void* stream_, r3dg_alloc_fn geometry_alloc, r3dg_alloc_fn binning_alloc,
                            r3dg_alloc_fn image_alloc, void* user, int P, int S, int D, int M,
                            const float* background, int width, int height, const float* means3D, const float* shs,
                            const float* colors_precomp, const float* features, const float* opacities,
@@ -504,7 +517,8 @@ int r3dg_rasterize_forward_begin(void* stream_, r3dg_alloc_fn geometry_alloc, r3
                            const float* cam_pos, float tan_fovx, float tan_fovy, float cx, float cy, int prefiltered,
                            int compute_pseudo_normal, float* out_color, float* out_opacity, float* out_depth,
                            float* out_feature, float* out_normal, float* out_surface_xyz, float* out_weights,
-                           int32_t* radii, int debug_, void** ticket_out)
+                           int32_t* radii, int debug_, void** ticket_out, long long capacity,
+                           float* overflow_flag, unsigned int* overflow_count, void* ordering_stream_)
 {
     (void)prefiltered;
     if (!ticket_out) return invalid("rasterize_forward_begin: null ticket pointer");
@@ -561,6 +575,21 @@ int r3dg_rasterize_forward_begin(void* stream_, r3dg_alloc_fn geometry_alloc, r3
         t->out_color = out_color; t->out_opacity = out_opacity; t->out_depth = out_depth; t->out_feature = out_feature;
         t->out_normal = out_normal; t->out_surface_xyz = out_surface_xyz; t->out_weights = out_weights;
         t->radii_p = radii_p; t->gbuf = gbuf; t->ibuf = ibuf;
+        t->capacity = capacity; t->overflow_flag = overflow_flag; t->overflow_count = overflow_count; t->bbuf = nullptr;
+        if (capacity >= 0) {
+            // bounded: nobody reads the count; the ordering follows the projection right away, on its own stream if the
+            // caller has one for it (so that it runs beside what the caller queues on `stream` next)
+            const hipStream_t order_stream = ordering_stream_ ? (hipStream_t)ordering_stream_ : stream;
+            if (order_stream != stream) {
+                R3DG_HIP(hipEventRecord(t->ready, stream));
+                R3DG_HIP(hipStreamWaitEvent(order_stream, t->ready, 0));
+            }
+            const int st_order = enqueue_ordering(t, order_stream, (int)capacity);
+            if (st_order != R3DG_OK) { ticket_release(t); return st_order; }
+            R3DG_HIP(hipEventRecord(t->ready, order_stream));
+            *ticket_out = t;
+            return R3DG_OK;
+        }
         // the one device->host read-back of the forward (reference rasterizer_impl.cu:291), asynchronous here
         R3DG_HIP(hipMemcpyAsync(t->host_total, g_total, sizeof(unsigned long long), hipMemcpyDeviceToHost, stream));
         R3DG_HIP(hipEventRecord(t->ready, stream));
@@ -569,55 +598,111 @@ int r3dg_rasterize_forward_begin(void* stream_, r3dg_alloc_fn geometry_alloc, r3
     });
 }
 
-int r3dg_rasterize_forward_finish(void* ticket_, int* num_rendered_out)
+#define R3DG_FORWARD_ARGS                                                                                              \
+    stream_, geometry_alloc, binning_alloc, image_alloc, user, P, S, D, M, background, width, height, means3D, shs,    \
+        colors_precomp, features, opacities, scales, scale_modifier, rotations, cov3D_precomp, viewmatrix, projmatrix, \
+        cam_pos, tan_fovx, tan_fovy, cx, cy, prefiltered, compute_pseudo_normal, out_color, out_opacity, out_depth,    \
+        out_feature, out_normal, out_surface_xyz, out_weights, radii, debug_, ticket_out
+
+int r3dg_rasterize_forward_begin(void* stream_, r3dg_alloc_fn geometry_alloc, r3dg_alloc_fn binning_alloc,
+                           r3dg_alloc_fn image_alloc, void* user, int P, int S, int D, int M,
+                           const float* background, int width, int height, const float* means3D, const float* shs,
+                           const float* colors_precomp, const float* features, const float* opacities,
+                           const float* scales, float scale_modifier, const float* rotations,
+                           const float* cov3D_precomp, const float* viewmatrix, const float* projmatrix,
+                           const float* cam_pos, float tan_fovx, float tan_fovy, float cx, float cy, int prefiltered,
+                           int compute_pseudo_normal, float* out_color, float* out_opacity, float* out_depth,
+                           float* out_feature, float* out_normal, float* out_surface_xyz, float* out_weights,
+                           int32_t* radii, int debug_, void** ticket_out)
 {
-    return r3dg_rasterize_forward_finish_on(ticket_, nullptr, num_rendered_out);
+    return forward_begin_impl(R3DG_FORWARD_ARGS, -1, nullptr, nullptr, nullptr);
 }
 
-int r3dg_rasterize_forward_finish_on(void* ticket_, void* ordering_stream_, int* num_rendered_out)
+int r3dg_rasterize_forward_begin_bounded(void* stream_, r3dg_alloc_fn geometry_alloc, r3dg_alloc_fn binning_alloc,
+                           r3dg_alloc_fn image_alloc, void* user, int P, int S, int D, int M,
+                           const float* background, int width, int height, const float* means3D, const float* shs,
+                           const float* colors_precomp, const float* features, const float* opacities,
+                           const float* scales, float scale_modifier, const float* rotations,
+                           const float* cov3D_precomp, const float* viewmatrix, const float* projmatrix,
+                           const float* cam_pos, float tan_fovx, float tan_fovy, float cx, float cy, int prefiltered,
+                           int compute_pseudo_normal, float* out_color, float* out_opacity, float* out_depth,
+                           float* out_feature, float* out_normal, float* out_surface_xyz, float* out_weights,
+                           int32_t* radii, int debug_, void* ordering_stream, long long capacity,
+                           float* overflow_flag, unsigned int* overflow_count, void** ticket_out)
 {
-    if (num_rendered_out) *num_rendered_out = 0;
+    if (capacity < 0 || capacity > 0x7fffffffll) return invalid("rasterize_forward (bounded): capacity must be in [0, 2^31)");
+    return forward_begin_impl(R3DG_FORWARD_ARGS, capacity, overflow_flag, overflow_count, ordering_stream);
+}
+#undef R3DG_FORWARD_ARGS
+
+int r3dg_rasterize_forward_finish_bounded(void* ticket_, void* main_stream_)
+{
     if (!ticket_) return R3DG_OK;                // P == 0
     ForwardTicket* t = (ForwardTicket*)ticket_;
+    if (t->capacity < 0) return invalid("rasterize_forward_finish_bounded: not a bounded ticket");
     const int st = guarded([&]() -> int {
-        const hipStream_t main_stream = t->stream;
-        // instance ordering (K5-K7) may run on its own stream: it depends on the projection only, so it can overlap the
-        // kernels the caller queued on the main stream after _begin (the shading that produces the feature rows)
-        const hipStream_t order_stream = ordering_stream_ ? (hipStream_t)ordering_stream_ : main_stream;
-        hipStream_t stream = order_stream;
+        const hipStream_t stream = (hipStream_t)main_stream_;
         const bool debug = t->debug != 0;
         const int P = t->P, S = t->S, width = t->width, height = t->height;
         const int gx = (width + R3DG_TILE_X - 1) / R3DG_TILE_X, gy = (height + R3DG_TILE_Y - 1) / R3DG_TILE_Y;
         const size_t T = (size_t)gx * gy, N = (size_t)width * height;
         GeometryLayout G = GeometryLayout::make((size_t)P);
         ImageLayout I = ImageLayout::make(N, T);
-        char* gbuf = t->gbuf;
-        char* ibuf = t->ibuf;
-        int* radii_p = t->radii_p;
-        float* g_depths = (float*)(gbuf + G.depths);
-        float* g_means2D = (float*)(gbuf + G.means2D);
-        const float* g_splat = (const float*)(gbuf + G.splat);
-        uint32_t* g_tiles = (uint32_t*)(gbuf + G.tiles_touched);
-        uint32_t* g_block = (uint32_t*)(gbuf + G.block_sums);
-        r3dg_alloc_fn binning_alloc = t->binning_alloc;
-        void* user = t->user;
-        const float* features = t->features;
-        const float* background = t->background;
-        const float* viewmatrix = t->viewmatrix;
-        const float focal_x = t->focal_x, focal_y = t->focal_y, cx = t->cx, cy = t->cy;
-        float *out_color = t->out_color, *out_opacity = t->out_opacity, *out_depth = t->out_depth,
-              *out_feature = t->out_feature, *out_normal = t->out_normal, *out_surface_xyz = t->out_surface_xyz,
-              *out_weights = t->out_weights;
-        const int compute_pseudo_normal = t->compute_pseudo_normal;
+        BinningLayout B = BinningLayout::make((size_t)t->capacity);
+        // join: the tile kernel needs the ordering (begin's stream) AND whatever the caller queued on `stream` (feature rows)
+        R3DG_HIP(hipStreamWaitEvent(stream, t->ready, 0));
+        StageTimer t_rf(stream, ST_RENDER_FWD);
+        launch_render_forward(stream, width, height, S, g_tile_order ? (uint32_t*)(t->ibuf + I.tile_order) : nullptr,
+                              (uint32_t*)(t->ibuf + I.ranges), (uint32_t*)(t->bbuf + B.vals),
+                              (const float*)(t->gbuf + G.splat), t->features, (float*)(t->ibuf + I.final_T),
+                              (uint32_t*)(t->ibuf + I.n_contrib), t->background, t->out_color, t->out_opacity,
+                              t->out_depth, t->out_feature, t->out_weights);
+        check_launch(stream, debug, "render_forward");
+        t_rf.stop();
+        if (t->compute_pseudo_normal) {
+            StageTimer t_n(stream, ST_NORMAL);
+            launch_pseudo_normal(stream, width, height, t->viewmatrix, t->focal_x, t->focal_y, t->cx, t->cy, t->out_opacity,
+                                 t->out_depth, t->out_normal, t->out_surface_xyz, debug);
+            t_n.stop();
+        }
+        return R3DG_OK;
+    });
+    ticket_release(t);
+    return st;
+}
 
-        R3DG_HIP(hipEventSynchronize(t->ready));
-        const unsigned long long total = *t->host_total;
-        if (order_stream != main_stream) R3DG_HIP(hipStreamWaitEvent(order_stream, t->ready, 0));
-        if (total > 0x7fffffffull) { set_error("rasterize_forward: num_rendered exceeds 2^31-1"); return R3DG_EINVAL; }
-        const int R = (int)total;
+int r3dg_rasterize_forward_finish(void* ticket_, int* num_rendered_out)
+{
+    return r3dg_rasterize_forward_finish_on(ticket_, nullptr, num_rendered_out);
+}
 
+// Instance ordering (K5-K7) of a forward whose projection has run: binning state for R instance slots, tile ranges, the
+// depth-sorted per-tile lists.  Bounded tickets (capacity >= 0) need the direct tile binning -- the only formulation whose
+// launches do not depend on the count.
+static int enqueue_ordering(ForwardTicket* t, hipStream_t stream, int R)
+{
+    const bool debug = t->debug != 0;
+    const int P = t->P, width = t->width, height = t->height;
+    const int gx = (width + R3DG_TILE_X - 1) / R3DG_TILE_X, gy = (height + R3DG_TILE_Y - 1) / R3DG_TILE_Y;
+    const size_t T = (size_t)gx * gy, N = (size_t)width * height;
+    GeometryLayout G = GeometryLayout::make((size_t)P);
+    ImageLayout I = ImageLayout::make(N, T);
+    char* gbuf = t->gbuf;
+    char* ibuf = t->ibuf;
+    int* radii_p = t->radii_p;
+    float* g_depths = (float*)(gbuf + G.depths);
+    float* g_means2D = (float*)(gbuf + G.means2D);
+    uint32_t* g_tiles = (uint32_t*)(gbuf + G.tiles_touched);
+    uint32_t* g_block = (uint32_t*)(gbuf + G.block_sums);
+    r3dg_alloc_fn binning_alloc = t->binning_alloc;
+    void* user = t->user;
+    if (t->capacity >= 0 && !(g_tile_binning == 2 && (int)T <= tile_binning_max_tiles())) {
+        set_error("rasterize_forward (bounded): needs the direct tile binning (r3dg_set_tuning4(2), at most 16384 tiles)");
+        return R3DG_EINVAL;
+    }
         BinningLayout B = BinningLayout::make((size_t)R);
         char* bbuf = (char*)binning_alloc(user, B.bytes);
+        t->bbuf = bbuf;
         if (!bbuf) { set_error("rasterize_forward: binning resize callback returned NULL"); return R3DG_EALLOC; }
         uint64_t* keys_u = (uint64_t*)(bbuf + B.keys_unsorted);
         uint64_t* keys = (uint64_t*)(bbuf + B.keys);
@@ -634,7 +719,9 @@ int r3dg_rasterize_forward_finish_on(void* ticket_, void* ordering_stream_, int*
             uint32_t* tile_counts = (uint32_t*)(bbuf + B.sort_temp);
             StageTimer t_dup(stream, ST_DUPKEYS);
             launch_tile_binning(stream, P, (int)T, g_means2D, g_depths, radii_p, g_tiles, g_block, gx, gy, tile_counts,
-                                tile_counts + T, ranges, (uint32_t*)(gbuf + G.point_offsets), keys_u);
+                                tile_counts + T, ranges, (uint32_t*)(gbuf + G.point_offsets), keys_u,
+                                (const unsigned long long*)(gbuf + G.total), t->capacity, t->overflow_flag,
+                                t->overflow_count);
             check_launch(stream, debug, "tile_binning");
             t_dup.stop();
             StageTimer t_sort(stream, ST_SORT);
@@ -689,6 +776,60 @@ int r3dg_rasterize_forward_finish_on(void* ticket_, void* ordering_stream_, int*
                 check_launch(stream, debug, "tile_order");
             }
         }
+    return R3DG_OK;
+}
+
+int r3dg_rasterize_forward_finish_on(void* ticket_, void* ordering_stream_, int* num_rendered_out)
+{
+    if (num_rendered_out) *num_rendered_out = 0;
+    if (!ticket_) return R3DG_OK;                // P == 0
+    ForwardTicket* t = (ForwardTicket*)ticket_;
+    if (t->capacity >= 0) return invalid("rasterize_forward_finish: bounded ticket (use r3dg_rasterize_forward_finish_bounded)");
+    const int st = guarded([&]() -> int {
+        const hipStream_t main_stream = t->stream;
+        // instance ordering (K5-K7) may run on its own stream: it depends on the projection only, so it can overlap the
+        // kernels the caller queued on the main stream after _begin (the shading that produces the feature rows)
+        const hipStream_t order_stream = ordering_stream_ ? (hipStream_t)ordering_stream_ : main_stream;
+        hipStream_t stream = order_stream;
+        const bool debug = t->debug != 0;
+        const int P = t->P, S = t->S, width = t->width, height = t->height;
+        const int gx = (width + R3DG_TILE_X - 1) / R3DG_TILE_X, gy = (height + R3DG_TILE_Y - 1) / R3DG_TILE_Y;
+        const size_t T = (size_t)gx * gy, N = (size_t)width * height;
+        GeometryLayout G = GeometryLayout::make((size_t)P);
+        ImageLayout I = ImageLayout::make(N, T);
+        char* gbuf = t->gbuf;
+        char* ibuf = t->ibuf;
+        int* radii_p = t->radii_p;
+        float* g_depths = (float*)(gbuf + G.depths);
+        float* g_means2D = (float*)(gbuf + G.means2D);
+        const float* g_splat = (const float*)(gbuf + G.splat);
+        uint32_t* g_tiles = (uint32_t*)(gbuf + G.tiles_touched);
+        uint32_t* g_block = (uint32_t*)(gbuf + G.block_sums);
+        r3dg_alloc_fn binning_alloc = t->binning_alloc;
+        void* user = t->user;
+        const float* features = t->features;
+        const float* background = t->background;
+        const float* viewmatrix = t->viewmatrix;
+        const float focal_x = t->focal_x, focal_y = t->focal_y, cx = t->cx, cy = t->cy;
+        float *out_color = t->out_color, *out_opacity = t->out_opacity, *out_depth = t->out_depth,
+              *out_feature = t->out_feature, *out_normal = t->out_normal, *out_surface_xyz = t->out_surface_xyz,
+              *out_weights = t->out_weights;
+        const int compute_pseudo_normal = t->compute_pseudo_normal;
+
+        R3DG_HIP(hipEventSynchronize(t->ready));
+        const unsigned long long total = *t->host_total;
+        if (order_stream != main_stream) R3DG_HIP(hipStreamWaitEvent(order_stream, t->ready, 0));
+        if (total > 0x7fffffffull) { set_error("rasterize_forward: num_rendered exceeds 2^31-1"); return R3DG_EINVAL; }
+        const int R = (int)total;
+
+        {
+            const int st_order = enqueue_ordering(t, stream, R);
+            if (st_order != R3DG_OK) return st_order;
+        }
+        BinningLayout B = BinningLayout::make((size_t)R);
+        uint32_t* vals = (uint32_t*)(t->bbuf + B.vals);
+        uint32_t* ranges = (uint32_t*)(ibuf + I.ranges);
+        uint32_t* tile_order = g_tile_order ? (uint32_t*)(ibuf + I.tile_order) : nullptr;
         if (order_stream != main_stream) {          // join: the tile kernel needs the ordering AND the feature rows
             hipEvent_t ev;
             R3DG_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
@@ -1232,7 +1373,7 @@ int r3dg_stage2_env_backward(void* stream_, int He, int We, const float* raw, co
 }
 
 int r3dg_adam_step(void* stream_, int n_groups, const r3dg_adam_group* groups, float beta1, float beta2, float eps,
-                   int step, float grad_scale)
+                   int step, float grad_scale, const float* skip_flag)
 {
     if (n_groups < 0 || n_groups > R3DG_ADAM_MAX_GROUPS) return invalid("adam_step: bad group count");
     if (step < 1) return invalid("adam_step: step counts from 1");
@@ -1245,7 +1386,7 @@ int r3dg_adam_step(void* stream_, int n_groups, const r3dg_adam_group* groups, f
     }
     return guarded([&]() -> int {
         StageTimer t((hipStream_t)stream_, ST_ADAM);
-        launch_adam((hipStream_t)stream_, n_groups, groups, beta1, beta2, eps, step, grad_scale);
+        launch_adam((hipStream_t)stream_, n_groups, groups, beta1, beta2, eps, step, grad_scale, skip_flag);
         return R3DG_OK;
     });
 }

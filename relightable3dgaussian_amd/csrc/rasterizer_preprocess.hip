@@ -470,11 +470,18 @@ tile_count_kernel(int P, int T, int iters, const float2* __restrict__ means2D, c
 
 // one 1024-thread block: ranges[t] = (start, end), cursor[t] = start
 __global__ void __launch_bounds__(1024)
-tile_scan_kernel(int T, const uint32_t* __restrict__ tile_counts, uint2* __restrict__ ranges, uint32_t* __restrict__ cursor)
+tile_scan_kernel(int T, const uint32_t* __restrict__ tile_counts, uint2* __restrict__ ranges, uint32_t* __restrict__ cursor,
+                 const unsigned long long* __restrict__ total, long long capacity, float* __restrict__ overflow_flag,
+                 unsigned int* __restrict__ overflow_count)
 {
     __shared__ uint32_t s_wave[16];
     __shared__ uint32_t s_carry;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // bounded forward (capacity >= 0): the binning state holds `capacity` instance slots and the host did NOT look at the
+    // count; a frame that needs more is dropped on the device -- every tile list empty, *overflow_flag = 1 for the caller
+    const bool over = capacity >= 0 && *total > (unsigned long long)capacity;
+    if (tid == 0 && overflow_flag != nullptr) *overflow_flag = over ? 1.0f : 0.0f;
+    if (tid == 0 && over && overflow_count != nullptr) *overflow_count += 1u;       // running count, never reset here
     if (tid == 0) s_carry = 0;
     __syncthreads();
     for (int base = 0; base < T; base += 1024) {
@@ -488,8 +495,8 @@ tile_scan_kernel(int T, const uint32_t* __restrict__ tile_counts, uint2* __restr
         if (t < T) {
             const uint32_t start = off + inc - v;
             // an empty tile keeps (0,0) like the reference's zero-initialised ranges (rasterizer_impl.cu:320)
-            ranges[t] = v ? make_uint2(start, start + v) : make_uint2(0u, 0u);
-            cursor[t] = start;
+            ranges[t] = (v && !over) ? make_uint2(start, start + v) : make_uint2(0u, 0u);
+            cursor[t] = over ? 0u : start;
         }
         __syncthreads();
         if (tid == 1023) s_carry = off + inc;
@@ -501,10 +508,12 @@ __global__ void __launch_bounds__(BIN_THREADS)
 tile_emit_kernel(int P, int T, int iters, const float2* __restrict__ means2D, const float* __restrict__ depths,
                  const int* __restrict__ radii, const uint32_t* __restrict__ tiles_touched,
                  const uint32_t* __restrict__ block_offsets, int gx, int gy, uint32_t* __restrict__ cursor,
-                 uint32_t* __restrict__ point_offsets, uint64_t* __restrict__ entries)
+                 uint32_t* __restrict__ point_offsets, uint64_t* __restrict__ entries,
+                 const unsigned long long* __restrict__ total, long long capacity)
 {
     extern __shared__ uint32_t s_bins[];
     __shared__ uint32_t s_wave[BIN_THREADS / 64];
+    const bool over = capacity >= 0 && *total > (unsigned long long)capacity;      // see tile_scan_kernel
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     for (int t = threadIdx.x; t < T; t += BIN_THREADS) s_bins[t] = 0;
     const int base = blockIdx.x * iters * BIN_THREADS + threadIdx.x;
@@ -523,6 +532,7 @@ tile_emit_kernel(int P, int T, int iters, const float2* __restrict__ means2D, co
             point_offsets[idx] = off + inc;
         }
     }
+    if (over) return;
     for (int it = 0; it < iters; it++)
         for_each_tile(base + it * BIN_THREADS, P, means2D, radii, gx, gy,
                       [&](uint32_t tile, uint32_t) { atomicAdd(&s_bins[tile], 1u); });
@@ -544,7 +554,8 @@ int g_bin_iters = 2;
 void launch_tile_binning(hipStream_t s, int P, int T, const float* means2D, const float* depths, const int* radii,
                          const uint32_t* tiles_touched, const uint32_t* block_offsets, int gx, int gy,
                          uint32_t* tile_counts /* T, scratch */, uint32_t* cursor /* T, scratch */, uint32_t* ranges,
-                         uint32_t* point_offsets, uint64_t* entries)
+                         uint32_t* point_offsets, uint64_t* entries, const unsigned long long* total, long long capacity,
+                         float* overflow_flag, unsigned int* overflow_count)
 {
     R3DG_HIP(hipMemsetAsync(tile_counts, 0, (size_t)T * 4, s));
     const int iters = g_bin_iters;
@@ -558,9 +569,10 @@ void launch_tile_binning(hipStream_t s, int P, int T, const float* means2D, cons
         attr = true;
     }
     tile_count_kernel<<<nb, BIN_THREADS, smem, s>>>(P, T, iters, (const float2*)means2D, radii, gx, gy, tile_counts);
-    tile_scan_kernel<<<1, 1024, 0, s>>>(T, tile_counts, (uint2*)ranges, cursor);
+    tile_scan_kernel<<<1, 1024, 0, s>>>(T, tile_counts, (uint2*)ranges, cursor, total, capacity, overflow_flag,
+                                        overflow_count);
     tile_emit_kernel<<<nb, BIN_THREADS, smem, s>>>(P, T, iters, (const float2*)means2D, depths, radii, tiles_touched,
-                                                  block_offsets, gx, gy, cursor, point_offsets, entries);
+                                                  block_offsets, gx, gy, cursor, point_offsets, entries, total, capacity);
 }
 
 int tile_binning_max_tiles() { return BIN_MAX_TILES; }

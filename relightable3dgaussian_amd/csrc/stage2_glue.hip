@@ -586,8 +586,12 @@ struct AdamTable {
 };
 
 __global__ void __launch_bounds__(256)
-adam_kernel(AdamTable t, float beta1, float beta2, float eps, float bias1, float inv_sqrt_bias2, float grad_scale)
+adam_kernel(AdamTable t, float beta1, float beta2, float eps, float bias1, float inv_sqrt_bias2, float grad_scale,
+            const float* __restrict__ skip_flag)
 {
+    // the gradients belong to a frame the bounded forward dropped on the device (r3dg_rasterize_forward_begin_bounded):
+    // no update; the host hears about it later and does not count the step
+    if (skip_flag != nullptr && *skip_flag != 0.0f) return;
     int gi = 0;
 #pragma unroll 1
     while (gi + 1 < t.n_groups && blockIdx.x >= t.first_block[gi + 1]) gi++;
@@ -743,7 +747,7 @@ void launch_s1_activate_backward(hipStream_t s, int P, const float* xyz, const f
 }
 
 void launch_adam(hipStream_t s, int n_groups, const r3dg_adam_group* groups, float beta1, float beta2, float eps,
-                 int step, float grad_scale)
+                 int step, float grad_scale, const float* skip_flag)
 {
     AdamTable t;
     t.n_groups = n_groups;
@@ -756,7 +760,7 @@ void launch_adam(hipStream_t s, int n_groups, const r3dg_adam_group* groups, flo
     t.first_block[n_groups] = blocks;
     if (blocks == 0) return;
     const double b1 = 1.0 - pow((double)beta1, (double)step), b2 = 1.0 - pow((double)beta2, (double)step);
-    adam_kernel<<<blocks, 256, 0, s>>>(t, beta1, beta2, eps, (float)b1, (float)(1.0 / sqrt(b2)), grad_scale);
+    adam_kernel<<<blocks, 256, 0, s>>>(t, beta1, beta2, eps, (float)b1, (float)(1.0 / sqrt(b2)), grad_scale, skip_flag);
     check_launch(s, false, "adam_kernel");
 }
 

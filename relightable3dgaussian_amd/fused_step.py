@@ -51,17 +51,18 @@ class FusedAdam:
             g["exp_avg"] = torch.zeros_like(p)
             g["exp_avg_sq"] = torch.zeros_like(p)
 
-    def step(self, grads, grad_scale=1.0):
+    def step(self, grads, grad_scale=1.0, skip_flag=None):
         """grads: list of gradient tensors, one per group (same order).  One launch for all groups."""
         self.begin_step()
-        self.step_groups(range(len(self.groups)), grads, grad_scale)
+        self.step_groups(range(len(self.groups)), grads, grad_scale, skip_flag)
 
     def begin_step(self):
         self.step_count += 1
 
-    def step_groups(self, indices, grads, grad_scale=1.0):
+    def step_groups(self, indices, grads, grad_scale=1.0, skip_flag=None):
         """Adam update of a subset of the groups for the current step (begin_step() first); `grads[i]` belongs to group i.
-        Lets a data-parallel caller update each gradient bucket as soon as its all-reduce has landed."""
+        Lets a data-parallel caller update each gradient bucket as soon as its all-reduce has landed.  `skip_flag`: float32
+        device tensor; a non-zero first element (read on the device) turns the launch into a no-op."""
         L = _lib.lib()
         indices = list(indices)
         table = (AdamGroup * len(indices))()
@@ -75,7 +76,8 @@ class FusedAdam:
                                  g.get("period", 0), g.get("split", 0))
         with torch.cuda.device(self.groups[0]["param"].device):
             st = L.r3dg_adam_step(_lib.current_stream(), len(indices), C.cast(table, C.c_void_p), self.betas[0],
-                                  self.betas[1], self.eps, self.step_count, float(grad_scale))
+                                  self.betas[1], self.eps, self.step_count, float(grad_scale),
+                                  skip_flag.data_ptr() if skip_flag is not None else None)
         _lib.check(st, "adam_step")
 
 
@@ -86,11 +88,16 @@ class FusedStage2Step:
     """Owns the raw parameters (copied from a bench_core.GaussianParams) and runs whole iterations."""
 
     def __init__(self, params, sample_num, lr=1e-4, lr_rest_scale=1.0, loss_weights=None, process_group=None,
-                 overlap_geometry=False, overlap_ordering=True, lrs=None):
+                 overlap_geometry=False, overlap_ordering=True, lrs=None, bounded=True):
         """`lrs`: optional per-group learning rates {xyz, normal, scaling, rotation, opacity, shs, shs_rest, base_color,
         roughness, incidents, incidents_rest, env} as GaussianModel.training_setup / DirectLightMap.training_setup set
         them (scene/gaussian_model.py:465-486, the stage-2 values of script/run_nerf.sh:25-31); missing names use `lr`
-        (`lr * lr_rest_scale` for the non-dc SH columns)."""
+        (`lr * lr_rest_scale` for the non-dc SH columns).
+        `bounded`: after the first iteration (which reads num_rendered like the reference) the rasterizer forward runs
+        WITHOUT the host read-back: binning state sized for twice the largest count seen, projection + instance ordering
+        queued at once beside the shading forward.  A view that needs more is dropped on the device (its Adam launches
+        read the flag and update nothing); `poll_overflow()` -- called by loss() -- then doubles the capacity and counts
+        it in `dropped_steps`."""
         dev = params.xyz.device
         self.dev = dev
         d = lambda t: t.detach().clone().contiguous()
@@ -125,15 +132,32 @@ class FusedStage2Step:
         # flat gradient slab: [shs 3M | xyz3 normal3 scaling3 rotation4 opacity1 base3 rough1 per Gaussian, env texture |
         # incidents 3M]; every group starts on a 16-byte boundary (float4 accesses in the Adam kernel)
         sizes = dict(xyz=3 * P, normal=3 * P, scaling=3 * P, rotation=4 * P, opacity=P, base_color=3 * P, roughness=P,
-                     shs=3 * self.M * P, incidents=3 * self.M * P, env=self.env.numel())
-        order = ("shs", "xyz", "normal", "scaling", "rotation", "opacity", "base_color", "roughness", "env", "incidents")
+                     shs=3 * self.M * P, incidents=3 * self.M * P, env=self.env.numel(), flag=4)
+        # `flag`: the bounded forward's overflow flag rides at the end of bucket A, so that under data parallelism the
+        # first all-reduce tells every rank whether ANY rank dropped its view (sum > 0) before the first Adam launch
+        order = ("shs", "flag", "xyz", "normal", "scaling", "rotation", "opacity", "base_color", "roughness", "env",
+                 "incidents")
         pad4 = lambda n: (n + 3) // 4 * 4
         self.grad_flat = torch.zeros(sum(pad4(sizes[k]) for k in order), **f)
         self.grads, o, start = {}, 0, {}
         for k in order:
             start[k] = o
-            self.grads[k] = self.grad_flat[o:o + sizes[k]].view_as(getattr(self, k))
+            if k == "flag":
+                self._flag = self.grad_flat[o:o + 4]
+            else:
+                self.grads[k] = self.grad_flat[o:o + sizes[k]].view_as(getattr(self, k))
             o += pad4(sizes[k])
+        self.bounded = bool(bounded)
+        self._capacity = None                       # instance slots of the bounded forward (None: not known yet)
+        self._overflow_count = torch.zeros(1, dtype=torch.int32, device=dev)
+        self._overflow_seen = 0
+        self.dropped_steps = 0
+        self._skip = torch.zeros(2, 4, **f)        # per-iteration snapshots of the (reduced) flag for the Adam launches
+        self._skip_cur = None
+        self._iter = 0
+        self._count_ring = torch.zeros(4096, dtype=torch.int64)                 # num_rendered of the last iterations
+        if dev.type == "cuda":
+            self._count_ring = self._count_ring.pin_memory()
         # three all-reduce buckets (world > 1): A = SH colour grads, final right after the rasterizer backward (reduced
         # under the shading backward); C = the small per-Gaussian groups, final after the activation chain rule;
         # B = incident-light grads, final after the shading backward -- reduced LAST and only waited for right before
@@ -237,12 +261,24 @@ class FusedStage2Step:
         empty = torch.Tensor([])
         with torch.cuda.device(dev):
             self.refresh_activations(cam)
-            # first half of the rasterizer (projection + async read-back of num_rendered): the shading kernels below run
-            # while the host waits for the count and enqueues the second half
-            pending = rasterizer_ops.rasterize_gaussians_begin(
-                bg, self.xyz, self.features, empty, self.a_opacity, self.a_scales, self.a_rot, 1.0, empty, vm,
-                cam.full_proj_transform, cam.tanfovx, cam.tanfovy, cam.cx, cam.cy, H, W, self.shs, 3, campos, False,
-                True, False)
+            self._iter += 1
+            use_bounded = self.bounded and self._capacity is not None
+            if use_bounded:
+                # bounded forward: projection + instance ordering go to the ordering stream NOW and run beside the
+                # shading kernels queued below; nobody waits for the count
+                pending = rasterizer_ops.rasterize_gaussians_begin(
+                    bg, self.xyz, self.features, empty, self.a_opacity, self.a_scales, self.a_rot, 1.0, empty, vm,
+                    cam.full_proj_transform, cam.tanfovx, cam.tanfovy, cam.cx, cam.cy, H, W, self.shs, 3, campos, False,
+                    True, False, capacity=self._capacity, overflow_flag=self._flag,
+                    overflow_count=self._overflow_count, ordering_stream=self._order_stream)
+            else:
+                # first half of the rasterizer (projection + async read-back of num_rendered): the shading kernels below
+                # run while the host waits for the count and enqueues the second half
+                self._flag.zero_()
+                pending = rasterizer_ops.rasterize_gaussians_begin(
+                    bg, self.xyz, self.features, empty, self.a_opacity, self.a_scales, self.a_rot, 1.0, empty, vm,
+                    cam.full_proj_transform, cam.tanfovx, cam.tanfovy, cam.cx, cam.cy, H, W, self.shs, 3, campos, False,
+                    True, False)
             self.flush()        # (world > 1) the previous iteration's incident-light update lands here
             env_c = F.softplus(self.env)[0]                                      # DirectLightMap.get_env
             He, We = env_c.shape[0], env_c.shape[1]
@@ -261,6 +297,11 @@ class FusedStage2Step:
                 self.sums[3:].data_ptr()), "stage2_pack_features")
             fw = pending.finish(self._order_stream)
             R, n_contrib, image, opacity, depth, feature, pseudo_normal, sxyz, weights, radii, geom, binning, img = fw
+            if self.bounded and not use_bounded:
+                self._capacity = self._capacity_for(R)
+            # the Adam launches of this iteration skip themselves when the view was dropped; under data parallelism they
+            # read a snapshot of the flag taken after bucket A's all-reduce (optimizer_step)
+            self._skip_cur = self._flag if self.world <= 1 else self._skip[self._iter & 1]
             # image-space loss terms and their gradients.  One slab: dL_dimage 3 | dL_dopacity 1 | dL_dfeature 16 | sRGB PBR
             # image 3 | SSIM partials 2x9 | SSIM gradients 2x3 (the depth image carries no loss)
             g = torch.empty((47, H, W), dtype=torch.float32, device=dev)
@@ -305,7 +346,8 @@ class FusedStage2Step:
                     side.wait_stream(torch.cuda.current_stream())
                 self.opt.begin_step()
                 with torch.cuda.stream(side):
-                    self.opt.step_groups(self._GROUPS_A, [self.grads[k] for k in self._opt_order])
+                    self.opt.step_groups(self._GROUPS_A, [self.grads[k] for k in self._opt_order],
+                                         skip_flag=self._skip_cur)
                 self._early_stream = side
                 self._early = True
             _lib.check(L.r3dg_stage2_unpack_gradients(
@@ -341,6 +383,14 @@ class FusedStage2Step:
                 handle_b = self._allreduce_async(self._bucket_b)
                 self._handles = (handle_a, handle_c, handle_b)
         self.viewspace_grad = dL_dmeans2D
+        # a bounded forward returned its capacity as R (the backward's layout); the count itself goes to a pinned ring
+        # without anybody waiting for it (rendered_counts)
+        self._geom = geom
+        slot = self._count_ring[(self._iter - 1) % self._count_ring.numel()]
+        if use_bounded:
+            slot.copy_(rasterizer_ops.num_rendered_of(geom, P), non_blocking=True)
+        else:
+            slot.fill_(int(R))
         self.last_outs = (R, n_contrib, image, opacity, depth, feature, pseudo_normal, sxyz, weights, radii)
         self._N = N
         return self.last_outs
@@ -350,8 +400,36 @@ class FusedStage2Step:
             return None
         return torch.distributed.all_reduce(flat, group=self.group, async_op=True)
 
+    @staticmethod
+    def _capacity_for(R):
+        return int(min(2 ** 31 - 1, max(2 * int(R), int(R) + (1 << 20))))
+
+    def poll_overflow(self):
+        """Host-side half of the bounded forward: did the device drop a view since the last call?  (One 4-byte read-back;
+        synchronises.)  If so the capacity is doubled -- at least to twice the count that did not fit -- the dropped
+        iterations are counted in `dropped_steps` and taken back from Adam's step count."""
+        if not self.bounded or self._capacity is None:
+            return 0
+        count = int(self._overflow_count.item())
+        new = count - self._overflow_seen
+        if new > 0:
+            self._overflow_seen = count
+            self.dropped_steps += new
+            self.opt.step_count = max(0, self.opt.step_count - new)
+            needed = int(rasterizer_ops.num_rendered_of(self._geom, self.P).item())
+            self._capacity = self._capacity_for(max(needed, self._capacity))
+        return new
+
+    def rendered_counts(self, n=1):
+        """num_rendered of the last `n` iterations (python ints, oldest first).  Synchronises: a bounded forward never
+        hands the count to the host on its own; last_outs[0] is then the CAPACITY the state buffers were laid out for."""
+        torch.cuda.synchronize(self.dev)
+        n = max(0, min(int(n), self._iter, self._count_ring.numel()))
+        return [int(self._count_ring[(self._iter - 1 - k) % self._count_ring.numel()]) for k in range(n - 1, -1, -1)]
+
     def loss(self):
         """Loss value of the last forward_backward (a 0-d tensor; costs a few tiny kernels, so it is on demand)."""
+        self.poll_overflow()
         N, P = self._N, self.P
         lam = LAMBDA_DSSIM
         w = torch.tensor([self.w["l1"] * (1 - lam) / (3.0 * N), self.w["pbr"] * (1 - lam) / (3.0 * N),
@@ -368,28 +446,29 @@ class FusedStage2Step:
         if self.world <= 1:
             if self._early:              # the SH group was updated under the shading backward (forward_backward)
                 torch.cuda.current_stream().wait_stream(self._early_stream)
-                self.opt.step_groups(self._GROUPS_C + self._GROUPS_B, grads)
+                self.opt.step_groups(self._GROUPS_C + self._GROUPS_B, grads, skip_flag=self._skip_cur)
                 self._early = False
             else:
-                self.opt.step(grads)
+                self.opt.step(grads, skip_flag=self._skip_cur)
             return
         # data parallel: update each bucket when its (sum) all-reduce has landed; 1/world is applied inside the kernel
         scale = 1.0 / self.world
         handle_a, handle_c, handle_b = self._handles
         self.opt.begin_step()
         handle_a.wait()
-        self.opt.step_groups(self._GROUPS_A, grads, scale)
+        self._skip_cur.copy_(self._flag)            # > 0 on every rank when any rank dropped its view
+        self.opt.step_groups(self._GROUPS_A, grads, scale, skip_flag=self._skip_cur)
         handle_c.wait()
-        self.opt.step_groups(self._GROUPS_C, grads, scale)
-        self._pending_b = (handle_b, grads, scale)
+        self.opt.step_groups(self._GROUPS_C, grads, scale, skip_flag=self._skip_cur)
+        self._pending_b = (handle_b, grads, scale, self._skip_cur)
 
     def flush(self):
         """Complete a deferred incident-light update (data-parallel runs only; a no-op otherwise)."""
         if self._pending_b is not None:
-            handle_b, grads, scale = self._pending_b
+            handle_b, grads, scale, skip = self._pending_b
             self._pending_b = None
             handle_b.wait()
-            self.opt.step_groups(self._GROUPS_B, grads, scale)
+            self.opt.step_groups(self._GROUPS_B, grads, scale, skip_flag=skip)
 
     def __call__(self, cam, bg, gt):
         outs = self.forward_backward(cam, bg, gt, early_adam=True)

@@ -61,16 +61,22 @@ def _offsets(fn, n, *args):
 class _PendingForward:
     """Second half of a split forward (see rasterize_gaussians_begin): call .finish() exactly once."""
 
-    def __init__(self, ticket, rs, outs, dev, H, W):
+    def __init__(self, ticket, rs, outs, dev, H, W, capacity=None):
         self.ticket, self.rs, self.outs, self.dev, self.H, self.W = ticket, rs, outs, dev, H, W
+        self.capacity = capacity
 
     def finish(self, ordering_stream=None):
         """`ordering_stream`: optional torch stream for the instance ordering (sort) part, which then overlaps whatever
-        was queued on the forward's stream since begin; the binning buffer is allocated from that stream's pool."""
+        was queued on the forward's stream since begin; the binning buffer is allocated from that stream's pool.
+        A bounded forward (rasterize_gaussians_begin(capacity=...)) has its ordering queued already: finish() renders on
+        the current stream and returns `capacity` in the num_rendered slot (the value the backward's state layout needs)."""
         L = _lib.lib()
         rendered = C.c_int(0)
         with torch.cuda.device(self.dev):
-            if ordering_stream is None:
+            if self.capacity is not None:
+                st = L.r3dg_rasterize_forward_finish_bounded(self.ticket, _lib.current_stream())
+                rendered = C.c_int(int(self.capacity))
+            elif ordering_stream is None:
                 st = L.r3dg_rasterize_forward_finish(self.ticket, C.byref(rendered))
             else:
                 with torch.cuda.stream(ordering_stream):        # resize callback allocates on that stream
@@ -92,10 +98,17 @@ class _PendingForward:
 
 def rasterize_gaussians_begin(background, means3D, features, colors, opacity, scales, rotations, scale_modifier,
                               cov3D_precomp, viewmatrix, projmatrix, tan_fovx, tan_fovy, cx, cy, image_height,
-                              image_width, sh, degree, campos, prefiltered, computer_pseudo_normal, debug):
+                              image_width, sh, degree, campos, prefiltered, computer_pseudo_normal, debug,
+                              capacity=None, overflow_flag=None, overflow_count=None, ordering_stream=None):
     """First half of rasterize_gaussians (same arguments): projection + asynchronous read-back of num_rendered.  Returns
     an object whose .finish() completes the call and returns the 13-tuple.  Kernels launched on the current stream in
-    between (e.g. the ones that fill `features`, whose CONTENTS are first read by .finish()'s kernels) overlap the wait."""
+    between (e.g. the ones that fill `features`, whose CONTENTS are first read by .finish()'s kernels) overlap the wait.
+
+    `capacity` (not in the reference): the BOUNDED forward (r3dg_rasterize_forward_begin_bounded) -- no host read-back;
+    the projection is queued on the current stream and the instance ordering behind it on `ordering_stream` (default:
+    the current stream) at once, with the binning state sized for `capacity` instances.
+    `overflow_flag` (float32 tensor, >= 1 element) is set to 1 when the frame needed more and was dropped, else 0;
+    `overflow_count` (int32 tensor) counts dropped frames.  All tensors are allocated on the current stream."""
     L = _lib.lib()
     if means3D.ndimension() != 2 or means3D.size(1) != 3:
         raise RuntimeError("means3D must have dimensions (num_points, 3)")
@@ -128,18 +141,32 @@ def rasterize_gaussians_begin(background, means3D, features, colors, opacity, sc
         if feat_ is not None and feat_.data_ptr() != features.data_ptr():
             raise RuntimeError("rasterize_gaussians_begin needs contiguous features (their contents are read later)")
         rs.keep = t                                   # inputs stay alive until finish()
+        common = (rs.callbacks[0], rs.callbacks[1], rs.callbacks[2], None, P, S, int(degree), M,
+                  _lib.ptr(bg_), W, H, _lib.ptr(means_), _lib.ptr(sh_), _lib.ptr(col_), _lib.ptr(feat_), _lib.ptr(op_),
+                  _lib.ptr(sc_), float(scale_modifier), _lib.ptr(rot_), _lib.ptr(cov_), _lib.ptr(vm_), _lib.ptr(pm_),
+                  _lib.ptr(cam_), float(tan_fovx), float(tan_fovy), float(cx), float(cy), int(bool(prefiltered)),
+                  int(bool(computer_pseudo_normal)), out_color.data_ptr(), out_opacity.data_ptr(), out_depth.data_ptr(),
+                  _lib.ptr(out_feature), out_normal.data_ptr(), out_surface_xyz.data_ptr(), out_weights.data_ptr(),
+                  radii.data_ptr(), int(bool(debug)))
         with torch.cuda.device(dev):
-            st = L.r3dg_rasterize_forward_begin(
-                _lib.current_stream(), rs.callbacks[0], rs.callbacks[1], rs.callbacks[2], None, P, S, int(degree), M,
-                _lib.ptr(bg_), W, H, _lib.ptr(means_), _lib.ptr(sh_), _lib.ptr(col_), _lib.ptr(feat_), _lib.ptr(op_),
-                _lib.ptr(sc_), float(scale_modifier), _lib.ptr(rot_), _lib.ptr(cov_), _lib.ptr(vm_), _lib.ptr(pm_),
-                _lib.ptr(cam_), float(tan_fovx), float(tan_fovy), float(cx), float(cy), int(bool(prefiltered)),
-                int(bool(computer_pseudo_normal)), out_color.data_ptr(), out_opacity.data_ptr(), out_depth.data_ptr(),
-                _lib.ptr(out_feature), out_normal.data_ptr(), out_surface_xyz.data_ptr(), out_weights.data_ptr(),
-                radii.data_ptr(), int(bool(debug)), C.byref(ticket))
+            if capacity is None:
+                st = L.r3dg_rasterize_forward_begin(_lib.current_stream(), *common, C.byref(ticket))
+            else:
+                if overflow_flag is not None and (overflow_flag.dtype != torch.float32 or not overflow_flag.is_cuda):
+                    raise RuntimeError("overflow_flag must be a float32 device tensor")
+                if overflow_count is not None and (overflow_count.dtype != torch.int32 or not overflow_count.is_cuda):
+                    raise RuntimeError("overflow_count must be an int32 device tensor")
+                rs.keep.append((overflow_flag, overflow_count))
+                st = L.r3dg_rasterize_forward_begin_bounded(
+                    _lib.current_stream(), *common,
+                    C.c_void_p(ordering_stream.cuda_stream) if ordering_stream is not None else None, int(capacity),
+                    overflow_flag.data_ptr() if overflow_flag is not None else None,
+                    overflow_count.data_ptr() if overflow_count is not None else None, C.byref(ticket))
         _lib.check(st, "rasterize_gaussians")
+    elif capacity is not None and overflow_flag is not None:
+        overflow_flag[:1].zero_()
     return _PendingForward(ticket, rs, (out_color, out_opacity, out_depth, out_feature, out_normal, out_surface_xyz,
-                                        out_weights, radii), dev, H, W)
+                                        out_weights, radii), dev, H, W, capacity=capacity)
 
 
 def rasterize_gaussians(background, means3D, features, colors, opacity, scales, rotations, scale_modifier,
@@ -232,6 +259,13 @@ def mark_visible(means3D, viewmatrix, projmatrix):
                                      present.data_ptr())
         _lib.check(st, "mark_visible")
     return present
+
+
+def num_rendered_of(geomBuffer, P):
+    """0-d int64 DEVICE tensor viewing the instance count of the forward that wrote `geomBuffer` (what a bounded forward
+    does not hand to the host)."""
+    off = int(_lib.lib().r3dg_geometry_state_total_offset(int(P)))
+    return geomBuffer[off:off + 8].view(torch.int64)[0]
 
 
 # ---- helpers for tests / debugging: decode the opaque state buffers ---------------------------------------

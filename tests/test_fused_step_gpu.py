@@ -328,3 +328,62 @@ def test_ssim_kernels_match_reference_formula(H, W):
     assert abs(float(total) / (3 * H * W) - float(val)) < 2e-6
     ok, msg = report("ssim grad", grad, xr.grad, 2e-4, 1e-9)
     assert ok, msg
+
+
+def test_bounded_iterations_equal_two_phase_iterations():
+    """FusedStage2Step(bounded=True) -- from the second iteration on the rasterizer forward runs without the host
+    read-back of num_rendered -- trains like bounded=False: same loss trajectory and parameters up to the order of the
+    float atomics."""
+    from relightable3dgaussian_amd.fused_step import FusedStage2Step
+    P, res, K = 4000, 128, 8
+    runs = {}
+    for bounded in (False, True):
+        params, ref, fused, cam, bg, gt = _setup(P=P, res=res, K=K, seed=11)
+        step = FusedStage2Step(params, K, bounded=bounded)
+        step.visibility, step.incident_dirs, step.incident_areas = ref.visibility, ref.incident_dirs, ref.incident_areas
+        losses = []
+        for it in range(5):
+            outs = step(cam, bg, gt)
+            losses.append(float(step.loss()))
+        assert step.dropped_steps == 0
+        counts = step.rendered_counts(5)
+        assert len(counts) == 5 and all(c > 0 for c in counts)
+        if bounded:
+            assert outs[0] == step._capacity and outs[0] >= 2 * counts[0]
+        else:
+            assert outs[0] == counts[-1]
+        runs[bounded] = (losses, step.xyz.clone(), step.shs.clone(), step.incidents.clone(), counts)
+    la, lb = runs[False][0], runs[True][0]
+    assert np.allclose(la, lb, rtol=2e-5), (la, lb)
+    assert runs[False][4] == runs[True][4], "num_rendered differs"
+    for i in (1, 2, 3):
+        ok, msg = report("param %d" % i, runs[True][i], runs[False][i], 1e-4, 1e-6)
+        assert ok, msg
+
+
+def test_bounded_iteration_that_overflows_is_dropped_not_applied():
+    """A view that needs more instance slots than the bounded forward has: the iteration's Adam launches update nothing,
+    poll_overflow() reports it, takes the step count back and doubles the capacity; the next iteration trains again."""
+    from relightable3dgaussian_amd.fused_step import FusedStage2Step
+    params, ref, fused, cam, bg, gt = _setup(P=4000, res=128, K=8, seed=12)
+    step = FusedStage2Step(params, 8, bounded=True)
+    step.visibility, step.incident_dirs, step.incident_areas = ref.visibility, ref.incident_dirs, ref.incident_areas
+    step(cam, bg, gt)                                   # learns the count
+    n = step.rendered_counts(1)[0]
+    step._capacity = n - 5                              # the next view will not fit
+    before = {k: getattr(step, k).clone() for k in ("xyz", "shs", "incidents", "env", "opacity")}
+    moments = [g["exp_avg"].clone() for g in step.opt.groups]
+    count_before = step.opt.step_count
+    step(cam, bg, gt)
+    torch.cuda.synchronize()
+    for k, v in before.items():
+        assert torch.equal(getattr(step, k), v), "%s was updated by a dropped iteration" % k
+    for g, m in zip(step.opt.groups, moments):
+        assert torch.equal(g["exp_avg"], m)
+    assert step.poll_overflow() == 1 and step.dropped_steps == 1
+    assert step.opt.step_count == count_before and step._capacity >= 2 * n
+    step(cam, bg, gt)
+    torch.cuda.synchronize()
+    assert step.poll_overflow() == 0
+    assert not torch.equal(step.xyz, before["xyz"])
+    assert step.rendered_counts(1)[0] > 0

@@ -124,11 +124,13 @@ def test_fused_stage2_step_takes_the_reference_learning_rates(monkeypatch):
     assert g["shs"]["lr"] == 0.00025 and g["shs"]["lr_tail"] == 0.00025 / 20.0 and g["shs"]["period"] == 48 and g["shs"]["split"] == 3
     assert g["incidents"]["lr"] == 0.001 and g["incidents"]["lr_tail"] == 0.0001
     assert step.shs.shape == (P, 16, 3) and torch.equal(step.features_rest, r.features_rest)
-    # gradient slab: [shs | per-Gaussian groups + env | incidents], every group 16-byte aligned, env inside bucket C
-    total = sum((x.numel() + 3) // 4 * 4 for x in (step.shs, step.xyz, step.normal, step.scaling, step.rotation,
-                                                   step.opacity, step.base_color, step.roughness, step.env, step.incidents))
+    # gradient slab: [shs, overflow flag | per-Gaussian groups + env | incidents], every group 16-byte aligned, env inside
+    # bucket C, the bounded forward's flag (4 floats) at the end of bucket A
+    total = 4 + sum((x.numel() + 3) // 4 * 4 for x in (step.shs, step.xyz, step.normal, step.scaling, step.rotation,
+                                                       step.opacity, step.base_color, step.roughness, step.env, step.incidents))
     assert step.grad_flat.numel() == total
-    assert step._bucket_a.numel() == step.shs.numel() and step._bucket_b.numel() == step.incidents.numel()
+    assert step._bucket_a.numel() == step.shs.numel() + 4 and step._bucket_b.numel() == step.incidents.numel()
+    assert step._flag.data_ptr() == step._bucket_a.data_ptr() + 4 * step.shs.numel() and step._flag.numel() == 4
     assert step._bucket_a.numel() + step._bucket_b.numel() + step._bucket_c.numel() == total
     for k, gr in step.grads.items():
         assert gr.shape == getattr(step, k).shape and gr.data_ptr() % 16 == 0, k

@@ -532,3 +532,78 @@ def test_autograd_wrapper_matches_ops():
     for k, v in leaves.items():
         assert v.grad is not None and torch.isfinite(v.grad).all(), k
     assert means2D.grad is not None and means2D.grad.shape == (case["P"], 3)
+
+
+@pytest.mark.parametrize("name", ["S16", "big_splats", "ragged_image"])
+@pytest.mark.parametrize("side_stream", [False, True])
+def test_bounded_forward_equals_the_two_phase_forward(name, side_stream, hip_lib):
+    """r3dg_rasterize_forward_begin_bounded / _finish_bounded (no host read-back of num_rendered; binning state laid out
+    for a capacity) give the same images, n_contrib, tile ranges and per-tile lists, bit for bit, as the reference-shaped
+    forward -- with the ordering on the caller's stream or on a second one -- and the count stays readable on the device."""
+    from relightable3dgaussian_amd import rasterizer_ops as ro
+    case = make_case(**CASES[name])
+    a = _run_forward(case)
+    R = a[0]
+    cap = R + 1000
+    flag = torch.full((4,), 7.0, device=DEV)
+    count = torch.zeros(1, dtype=torch.int32, device=DEV)
+    order = torch.cuda.Stream() if side_stream else None
+    pending = ro.rasterize_gaussians_begin(*fwd_args(case, DEV, False), capacity=cap, overflow_flag=flag,
+                                           overflow_count=count, ordering_stream=order)
+    b = pending.finish()
+    torch.cuda.synchronize()
+    assert b[0] == cap
+    P, H, W = case["P"], case["H"], case["W"]
+    assert int(ro.num_rendered_of(b[10], P)) == R
+    assert float(flag[0]) == 0.0 and int(count) == 0
+    for i in (1, 2, 3, 4, 5, 6, 7, 9):
+        assert torch.equal(a[i], b[i]), "output %d differs" % i
+    assert float((a[8] - b[8]).abs().max()) <= 1e-5 * float(a[8].abs().max())      # weights: float atomics, order only
+    sa, sb = ro.decode_state(a[10], a[11], a[12], P, R, H, W), ro.decode_state(b[10], b[11], b[12], P, cap, H, W)
+    assert torch.equal(torch.as_tensor(sa["ranges"]), torch.as_tensor(sb["ranges"]))
+    for k in ("keys", "point_list"):
+        assert torch.equal(torch.as_tensor(sa[k])[:R], torch.as_tensor(sb[k])[:R]), k
+    assert torch.equal(torch.as_tensor(sa["point_offsets"]), torch.as_tensor(sb["point_offsets"]))
+    # the backward takes the capacity where the reference passes num_rendered (it selects the state layout)
+    from r3dg_rasterization import _C
+    gC, gO, gD, gF = [torch.randn(c, H, W, device=DEV) for c in (3, 1, 1, a[5].shape[0])]
+    args = fwd_args(case, DEV, False)
+
+    def bwd(o, Rb):
+        return _C.rasterize_gaussians_backward(args[0], args[1], args[2], o[9], args[3], args[5], args[6], 1.0, args[8],
+                                               args[9], args[10], args[11], args[12], gC, gO, gD, gF, args[17], args[18],
+                                               args[19], o[10], Rb, o[11], o[12], True, False)
+    ga, gb = bwd(a, R), bwd(b, cap)
+    torch.cuda.synchronize()
+    for i, (x, y) in enumerate(zip(ga, gb)):
+        scale = float(x.abs().max()) + 1e-30
+        assert float((x - y).abs().max()) <= 1e-5 * scale, "gradient %d differs (atomics order only)" % i
+
+
+def test_bounded_forward_drops_a_frame_that_does_not_fit(hip_lib):
+    """capacity < num_rendered: nothing is written out of bounds, the frame comes out empty (background, n_contrib 0), the
+    flag is raised and the running count incremented; the next frame with enough room is complete again."""
+    from relightable3dgaussian_amd import rasterizer_ops as ro
+    case = make_case(**CASES["S16"])
+    a = _run_forward(case)
+    R = a[0]
+    flag = torch.zeros(4, device=DEV)
+    count = torch.zeros(1, dtype=torch.int32, device=DEV)
+    b = ro.rasterize_gaussians_begin(*fwd_args(case, DEV, False), capacity=R - 1, overflow_flag=flag,
+                                     overflow_count=count).finish()
+    torch.cuda.synchronize()
+    P, H, W = case["P"], case["H"], case["W"]
+    assert float(flag[0]) == 1.0 and int(count) == 1
+    assert int(ro.num_rendered_of(b[10], P)) == R
+    assert int(b[1].abs().max()) == 0                                   # n_contrib
+    bg = fwd_args(case, DEV, False)[0]
+    assert torch.equal(b[2], bg[:, None, None].expand_as(b[2]).contiguous())
+    assert float(b[3].abs().max()) == 0.0                               # opacity
+    st = ro.decode_state(b[10], b[11], b[12], P, R - 1, H, W)
+    assert int(torch.as_tensor(st["ranges"]).abs().max()) == 0
+    c = ro.rasterize_gaussians_begin(*fwd_args(case, DEV, False), capacity=R, overflow_flag=flag,
+                                     overflow_count=count).finish()
+    torch.cuda.synchronize()
+    assert float(flag[0]) == 0.0 and int(count) == 1
+    for i in (1, 2, 3, 4, 5):
+        assert torch.equal(a[i], c[i]), i
