@@ -476,6 +476,8 @@ def run(args):
     L = _lib.lib()
     if os.environ.get("R3DG_SHADE_FWD_BPC"):             # tuning experiments only
         L.r3dg_set_tuning7(-1, int(os.environ["R3DG_SHADE_FWD_BPC"]))
+    if os.environ.get("R3DG_SHADE_ROWS"):
+        L.r3dg_set_tuning7(int(os.environ["R3DG_SHADE_ROWS"]), -1)
     if os.environ.get("R3DG_BIN"):
         L.r3dg_set_tuning4(int(os.environ["R3DG_BIN"]))
 

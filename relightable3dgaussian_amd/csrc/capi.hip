@@ -1038,7 +1038,7 @@ int r3dg_shade_build_taps(void* stream_, int64_t num_samples, const float* incid
 
 int r3dg_set_tuning7(int shade_forward_rows, int row_blocks_per_cu)
 {
-    if (shade_forward_rows >= 0) g_shade_fwd_rows = shade_forward_rows ? 1 : 0;
+    if (shade_forward_rows >= 0 && shade_forward_rows <= 2) g_shade_fwd_rows = shade_forward_rows;
     if (row_blocks_per_cu >= 0) g_shade_row_blocks_per_cu = row_blocks_per_cu;
     return R3DG_OK;
 }

@@ -796,6 +796,250 @@ shade_forward_row_kernel(int P, int K, int M_, const float* __restrict__ rec, co
     }
 }
 
+// =====================================================================================================================
+// Forward, third formulation ("pair" kernel): the row kernel with TWO SAMPLES PER LANE.
+// The row kernel is saturated on VALU issue (PMC: SQ busy 1.0; 290 instructions per 64 samples, 176 of them plain fp32
+// multiplies / adds / FMAs).  gfx950 executes v_pk_{mul,add,fma}_f32 -- two fp32 operations per lane -- at the rate of the
+// scalar forms, so the arithmetic is done on float2 values holding samples k and k+32 of the lane's Gaussian: a wave
+// carries two Gaussians (lanes 0..31 / 32..63), each lane two of the 64 samples of a block.  Per-Gaussian factors stay
+// scalar broadcasts (the packed forms take them through op_sel), the texture taps, reciprocal square roots, exp2 and
+// clamps have no packed form and run once per sample, the reduction runs inside each half-wave.  Same arithmetic per
+// sample as the row kernel (sums are formed in a different order).  Cached lookups only (TAPS 1 / 2), degree-3 light.
+// MEASURED, NOT THE DEFAULT (r3dg_set_tuning7(2) selects it): 372 instead of 2 x 290 VALU instructions per 128 samples
+// (-36 %), but 0.190 vs 0.194 ms stand-alone, 551 vs 553 it/s inside the iteration and 711 vs 749 relight FPS -- on this
+// part v_pk_fma_f32 issues at only 1.27x the lane rate of v_fma_f32 (tools/pk_rate.hip: 90 vs 71 lane-FMAs per clock
+// and CU), and the kernel pays for its 178 VGPRs with one wave per SIMD less.
+// =====================================================================================================================
+typedef float f2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f2 splat2(float x) { return (f2){x, x}; }
+__device__ __forceinline__ f2 max2(f2 a, float b) { return (f2){fmaxf(a.x, b), fmaxf(a.y, b)}; }
+__device__ __forceinline__ f2 clamp2(f2 a, float lo, float hi)
+{
+    return (f2){fminf(fmaxf(a.x, lo), hi), fminf(fmaxf(a.y, lo), hi)};
+}
+__device__ __forceinline__ f2 rsq2(f2 a) { return (f2){__builtin_amdgcn_rsqf(a.x), __builtin_amdgcn_rsqf(a.y)}; }
+
+__device__ __forceinline__ void sh_basis16_pair(f2 x, f2 y, f2 z, f2 (&Y)[16])
+{
+    const float C0 = 0.28209479177387814f, C1 = 0.4886025119029199f;
+    Y[0] = splat2(C0);
+    Y[1] = -C1 * y; Y[2] = C1 * z; Y[3] = -C1 * x;
+    const f2 xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+    Y[4] = 1.0925484305920792f * xy;
+    Y[5] = -1.0925484305920792f * yz;
+    Y[6] = 0.31539156525252005f * (2.0f * zz - xx - yy);
+    Y[7] = -1.0925484305920792f * xz;
+    Y[8] = 0.5462742152960396f * (xx - yy);
+    Y[9] = -0.5900435899266435f * y * (3.f * xx - yy);
+    Y[10] = 2.890611442640554f * xy * z;
+    Y[11] = -0.4570457994644658f * y * (4.f * zz - xx - yy);
+    Y[12] = 0.3731763325901154f * z * (2.f * zz - 3.f * xx - 3.f * yy);
+    Y[13] = -0.4570457994644658f * x * (4.f * zz - xx - yy);
+    Y[14] = 1.445305721320277f * z * (xx - yy);
+    Y[15] = -0.5900435899266435f * x * (xx - 3.f * yy);
+}
+
+struct PairSample {           // one lane's share of a (Gaussian pair, 64-sample block): samples k (.x) and k + 32 (.y)
+    f2 dx, dy, dz, vis, area;
+    uint32_t ta[3], tb[3];    // the two cached lookups (TAPS 1: packed tap; TAPS 2: radiance bits)
+    f2 rec;                   // elements l and l + 32 of the lane's Gaussian's 64-float record
+};
+
+// Branch-free: lanes beyond K or P read a clamped (valid) address and the caller masks their contribution -- zero-filled
+// defaults behind EXEC-masked loads cost ~35 moves per block here.
+template <int TAPS>
+__device__ __forceinline__ PairSample load_pair_sample(int g /* wave-uniform pair base, < P */, int akb, int lane, int P,
+                                                       int K, const float* __restrict__ rec16,
+                                                       const float* __restrict__ incidents,
+                                                       const float* __restrict__ dirs,
+                                                       const float* __restrict__ visibility,
+                                                       const float* __restrict__ areas, float uniform_area,
+                                                       const uint32_t* __restrict__ taps)
+{
+    PairSample r;
+    const unsigned l = (unsigned)lane & 31u;
+    const unsigned h = ((unsigned)lane >> 5) & (g + 1 < P ? 1u : 0u);       // a missing partner re-reads the first Gaussian
+    // rows of the pair's FIRST Gaussian on the scalar unit; the second one is K samples / one record further
+    const size_t row = (size_t)g * (size_t)K;
+    const unsigned ka = min((unsigned)akb * 64u + l, (unsigned)K - 1u), kb = min((unsigned)akb * 64u + l + 32u, (unsigned)K - 1u);
+    const unsigned oa = h * (unsigned)K + ka, ob = h * (unsigned)K + kb;
+    const float* __restrict__ inc = incidents + (size_t)g * 48;
+    r.rec.x = inc[h * 48u + l];
+    const float* __restrict__ second = l < 16u ? inc + (h * 48u + 32u + l) : rec16 + (size_t)g * 16 + (h * 16u + (l - 16u));
+    r.rec.y = *second;
+    const float* __restrict__ drow = dirs + 3 * row;
+    const float* __restrict__ vrow = visibility + row;
+    const float3 da = *reinterpret_cast<const float3*>(drow + 3u * oa);
+    const float3 db = *reinterpret_cast<const float3*>(drow + 3u * ob);
+    r.dx = (f2){da.x, db.x}; r.dy = (f2){da.y, db.y}; r.dz = (f2){da.z, db.z};
+    r.vis = (f2){vrow[oa], vrow[ob]};
+    r.area = areas != nullptr ? (f2){(areas + row)[oa], (areas + row)[ob]} : splat2(uniform_area);
+    const uint3 ta = *reinterpret_cast<const uint3*>(taps + 3 * row + 3u * oa);
+    const uint3 tb = *reinterpret_cast<const uint3*>(taps + 3 * row + 3u * ob);
+    r.ta[0] = ta.x; r.ta[1] = ta.y; r.ta[2] = ta.z;
+    r.tb[0] = tb.x; r.tb[1] = tb.y; r.tb[2] = tb.z;
+    return r;
+}
+
+template <int NOUT, bool ENV_LDS, int TAPS /* 1 cached lookup, 2 cached radiance */>
+__global__ void __launch_bounds__(64 * ROW_WAVES)
+shade_forward_pair_kernel(int P, int K, const float* __restrict__ rec16, const float* __restrict__ incidents,
+                          const float4* __restrict__ env4, int He, int We, const float* __restrict__ visibility,
+                          const float* __restrict__ dirs, const float* __restrict__ areas, float uniform_area,
+                          const uint32_t* __restrict__ taps, float* __restrict__ out)
+{
+    static_assert(NOUT == 7 || NOUT == 19, "training (pbr, diffuse_light, mean visibility) or all 19 outputs");
+    static_assert(TAPS == 1 || TAPS == 2, "cached lookups only");
+    constexpr int NV = NOUT == 7 ? 8 : 32;
+    extern __shared__ __attribute__((aligned(16))) float s_mem[];
+    __shared__ __attribute__((aligned(16))) float s_rec[ROW_WAVES][2][REC];
+    float4* s_env4 = reinterpret_cast<float4*>(s_mem);
+    if (ENV_LDS && TAPS != 2) {
+        for (int i = threadIdx.x; i < He * We; i += blockDim.x) s_env4[i] = env4[i];
+        __syncthreads();
+    }
+    const float4* tex4 = ENV_LDS ? s_env4 : env4;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int h = lane >> 5, l = lane & 31;
+    float* u = s_rec[wave][h];
+    const float invK = 1.0f / (float)K;
+    const int nblk = (K + 63) / 64;
+    const int g_stride = 2 * gridDim.x * ROW_WAVES;
+    int g = 2 * (blockIdx.x * ROW_WAVES + wave), kb = 0;
+    auto advance = [&](int& ag, int& akb) {
+        if (++akb == nblk) { akb = 0; ag += g_stride; }
+    };
+    auto fetch = [&](int ag, int akb) {          // past the end: a valid address whose values nobody uses
+        return load_pair_sample<TAPS>(min(ag, P - 1), akb, lane, P, K, rec16, incidents, dirs, visibility, areas,
+                                      uniform_area, taps);
+    };
+    int g1 = g, kb1 = kb;
+    advance(g1, kb1);
+    PairSample blk_a = fetch(g, kb);
+    PairSample blk_b = fetch(g1, kb1);
+    PairSample blk_c = blk_b;
+    f2 v[NV];
+#pragma unroll
+    for (int i = 0; i < NV; i++) v[i] = splat2(0.f);
+    // one pipeline step: the block in `cur` is computed while `refill` receives the block after next; the three register
+    // sets take turns through a 3x unrolled loop instead of being copied (35 moves per block otherwise)
+    auto step = [&](PairSample& cur, PairSample& refill) {
+        asm volatile("" : "+v"(cur.dx), "+v"(cur.dy), "+v"(cur.dz), "+v"(cur.vis), "+v"(cur.area), "+v"(cur.ta[0]),
+                     "+v"(cur.ta[1]), "+v"(cur.ta[2]), "+v"(cur.tb[0]), "+v"(cur.tb[1]), "+v"(cur.tb[2]), "+v"(cur.rec)
+                     :: "memory");
+        int g2 = g1, kb2 = kb1;
+        advance(g2, kb2);
+        refill = fetch(g2, kb2);
+        u[l] = cur.rec.x;                           // same wave, in-order LDS: no barrier needed
+        u[l + 32] = cur.rec.y;
+        const float4 ga = *reinterpret_cast<const float4*>(u + 48);     // albedo, roughness
+        const float4 gb = *reinterpret_cast<const float4*>(u + 52);     // n, V.x
+        const float4 gc = *reinterpret_cast<const float4*>(u + 56);     // V.yz, N.xy
+        const float4 gd = *reinterpret_cast<const float4*>(u + 60);     // N.z, NoV, a2, kk
+        const float nx = gb.x, ny = gb.y, nz = gb.z, Vx = gb.w, Vy = gc.x, Vz = gc.y, Nx = gc.z, Ny = gc.w, Nz = gd.x;
+        const float NoV = gd.y, a2 = gd.z, kk = gd.w;
+        const float fd[3] = {ga.x / kPi, ga.y / kPi, ga.z / kPi};
+        const float nom1 = NoV * (1.f - kk) + kk;
+        {
+            const int k0 = kb * 64 + l;
+            const bool have_g = g + h < P;
+            const f2 lv = {have_g && k0 < K ? 1.f : 0.f, have_g && k0 + 32 < K ? 1.f : 0.f};
+            const f2 dx = cur.dx, dy = cur.dy, dz = cur.dz, vis = cur.vis * lv, area = cur.area * lv;
+            f2 e[3];
+            if (TAPS == 2) {
+                e[0] = (f2){__uint_as_float(cur.ta[0]), __uint_as_float(cur.tb[0])};
+                e[1] = (f2){__uint_as_float(cur.ta[1]), __uint_as_float(cur.tb[1])};
+                e[2] = (f2){__uint_as_float(cur.ta[2]), __uint_as_float(cur.tb[2])};
+            } else {
+                float ea[3], eb[3], w4[4];
+                int tex[4];
+                PackedTap t;
+                t.xy = cur.ta[0]; t.wx1 = __uint_as_float(cur.ta[1]); t.wy1 = __uint_as_float(cur.ta[2]);
+                env_fetch(t, tex4, He, We, ea, tex, w4);
+                t.xy = cur.tb[0]; t.wx1 = __uint_as_float(cur.tb[1]); t.wy1 = __uint_as_float(cur.tb[2]);
+                env_fetch(t, tex4, He, We, eb, tex, w4);
+                e[0] = (f2){ea[0], eb[0]}; e[1] = (f2){ea[1], eb[1]}; e[2] = (f2){ea[2], eb[2]};
+            }
+            // local incident light: max(sum_i Y_i(d) c_i, 0); the coefficients are half-wave-uniform broadcast reads
+            f2 Y[16];
+            sh_basis16_pair(dx, dy, dz, Y);
+            f2 acc[3] = {splat2(0.f), splat2(0.f), splat2(0.f)};
+#pragma unroll
+            for (int q = 0; q < 12; q++) {
+                const float4 c4 = reinterpret_cast<const float4*>(u)[q];
+                const float cf[4] = {c4.x, c4.y, c4.z, c4.w};
+#pragma unroll
+                for (int t = 0; t < 4; t++) {
+                    const int f = 4 * q + t;
+                    acc[f % 3] += Y[f / 3] * cf[t];
+                }
+            }
+            const f2 loc[3] = {max2(acc[0], 0.f) * lv, max2(acc[1], 0.f) * lv, max2(acc[2], 0.f) * lv};
+            const f2 glob[3] = {e[0] * vis, e[1] * vis, e[2] * vis};
+            const f2 ndi = max2(nx * dx + ny * dy + nz * dz, 0.f);
+            const f2 area_ndi = area * ndi;
+            // GGX specular (neilf.py:374-407), as in the row kernel
+            const f2 dinv = rsq2(max2(dx * dx + dy * dy + dz * dz, 1e-24f));
+            const f2 Lx = dx * dinv, Ly = dy * dinv, Lz = dz * dinv;
+            const f2 ux = (Lx + Vx) * 0.5f, uy = (Ly + Vy) * 0.5f, uz = (Lz + Vz) * 0.5f;
+            const f2 uinv = rsq2(max2(ux * ux + uy * uy + uz * uz, 1e-24f));
+            const f2 Hx = ux * uinv, Hy = uy * uinv, Hz = uz * uinv;
+            const f2 NoL = clamp2(Nx * Lx + Ny * Ly + Nz * Lz, 1e-6f, 1.f);
+            const f2 NoH = clamp2(Nx * Hx + Ny * Hy + Nz * Hz, 1e-6f, 1.f);
+            const f2 VoH = clamp2(Vx * Hx + Vy * Hy + Vz * Hz, 1e-6f, 1.f);
+            const f2 pe = (-5.55473f * VoH - 6.98316f) * VoH;
+            const f2 p2 = {exp2f(pe.x), exp2f(pe.y)};
+            const f2 frac = (0.04f + 0.96f * p2) * a2;
+            const f2 nom0 = NoH * NoH * (a2 - 1.f) + 1.f;
+            const f2 nom2 = NoL * (1.f - kk) + kk;
+            const f2 nom = clamp2(4.f * kPi * nom0 * nom0 * nom1 * nom2, 1e-6f, 4.f * kPi);
+            const f2 spec = {frac.x / nom.x, frac.y / nom.y};
+#pragma unroll
+            for (int c = 0; c < 3; c++) {
+                const f2 lin = loc[c] + glob[c];
+                const f2 transport = lin * area_ndi;
+                v[c] += (fd[c] + spec) * transport;        // pbr
+                v[3 + c] += transport;                     // diffuse_light
+                if (NOUT == 19) {
+                    v[6 + c] += spec * transport;          // specular
+                    v[9 + c] += lin;                       // mean incident light
+                    v[12 + c] += loc[c];
+                    v[15 + c] += glob[c];
+                }
+            }
+            v[NOUT == 19 ? 18 : 6] += vis;
+        }
+        if (kb == nblk - 1) {
+            float vs[NV];
+#pragma unroll
+            for (int i = 0; i < NV; i++) vs[i] = v[i].x + v[i].y;
+            const float r = transpose_reduce_half<NV>(vs);
+            const int ch = transposed_channel_half<NV>(lane);
+            const int gg = g + h;
+            if (transposed_owner_half<NV>(lane) && gg < P) {
+                if (NOUT == 19) {
+                    if (ch < 19) out[(size_t)gg * SHADE_NOUT + ch] = r * invK;
+                } else if (ch < 7) {
+                    out[(size_t)gg * SHADE_NOUT + (ch < 6 ? ch : 18)] = r * invK;
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < NV; i++) v[i] = splat2(0.f);
+        }
+        g = g1; kb = kb1;
+        g1 = g2; kb1 = kb2;
+    };
+    while (true) {
+        if (g >= P) break;
+        step(blk_a, blk_c);
+        if (g >= P) break;
+        step(blk_b, blk_a);
+        if (g >= P) break;
+        step(blk_c, blk_b);
+    }
+}
+
 __global__ void __launch_bounds__(256)
 shade_pad_env_kernel(int n, const float* __restrict__ env, float4* __restrict__ env4)
 {
@@ -1420,7 +1664,8 @@ static float* shade_records(size_t P)
     return buf[dev];
 }
 
-int g_shade_fwd_rows = 1;    // r3dg_set_tuning7: 1 = row kernels (wave per Gaussian), 0 = the 16-lane kernel
+int g_shade_fwd_rows = 1;    // r3dg_set_tuning7: 2 = pair kernel (two samples per lane; cached lookups, degree-3 light; else 1),
+                             // 1 = row kernels (wave per Gaussian), 0 = the 16-lane kernel
 int g_shade_row_blocks_per_cu = 0;   // r3dg_set_tuning7 (second argument): persistent row blocks per CU, 0 = all that fit
 
 void launch_shade_build_taps(hipStream_t s, size_t n, const float* dirs, const float* tr, int He, int We, const float* env,
@@ -1461,6 +1706,40 @@ void launch_shade_forward(hipStream_t s, int P, int K, int M, const float* base_
     const int mode = taps == nullptr ? 0 : (taps_are_radiance ? 2 : 1);
     const bool lds = mode != 2 && He * We * 4 <= ENV_LDS_MAX;          // float4 per texel
     const size_t smem = lds ? ntexel * sizeof(float4) : 0;
+    if (g_shade_fwd_rows == 2 && mode != 0 && M == 16) {
+        // pair kernel: two samples per lane, two Gaussians per wave
+        const int want2 = ((P + 1) / 2 + ROW_WAVES - 1) / ROW_WAVES;
+#define R3DG_PAIR(N, L, T)                                                                                            \
+    do {                                                                                                              \
+        static int per_cu[2] = {0, 0};                                                                                \
+        if (per_cu[L] == 0) {                                                                                         \
+            int nb = 0;                                                                                               \
+            R3DG_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, shade_forward_pair_kernel<N, L, T>,            \
+                                                                  64 * ROW_WAVES, smem));                            \
+            hipFuncAttributes fa;                                                                                     \
+            R3DG_HIP(hipFuncGetAttributes(&fa, (const void*)shade_forward_pair_kernel<N, L, T>));                     \
+            const int by_vgpr = 512 / (((fa.numRegs + 7) / 8) * 8);                                                   \
+            nb = nb < by_vgpr ? nb : by_vgpr;                                                                         \
+            per_cu[L] = nb > 0 ? (nb < 8 ? nb : 8) : 1;                                                               \
+        }                                                                                                             \
+        int bpc = g_shade_row_blocks_per_cu > 0 && g_shade_row_blocks_per_cu < per_cu[L] ? g_shade_row_blocks_per_cu   \
+                                                                                         : per_cu[L];                 \
+        if (leave_room && g_shade_row_blocks_per_cu == 0 && bpc > 3) bpc = 3;                                         \
+        const int cap = shade_cus() * bpc;                                                                            \
+        const int grid = want2 < cap ? want2 : cap;                                                                   \
+        shade_forward_pair_kernel<N, L, T><<<grid, 64 * ROW_WAVES, smem, s>>>(                                        \
+            P, K, rec, incidents, env4, He, We, visibility, dirs, areas, uniform_area, taps, out);                    \
+    } while (0)
+#define R3DG_PAIR_MODE(N, L)                                                                                          \
+    do {                                                                                                              \
+        if (mode == 1) R3DG_PAIR(N, L, 1); else R3DG_PAIR(N, L, 2);                                                   \
+    } while (0)
+        if (train_outputs) { if (lds) R3DG_PAIR_MODE(7, true); else R3DG_PAIR_MODE(7, false); }
+        else { if (lds) R3DG_PAIR_MODE(19, true); else R3DG_PAIR_MODE(19, false); }
+#undef R3DG_PAIR_MODE
+#undef R3DG_PAIR
+        return;
+    }
     const int want = (P + ROW_WAVES - 1) / ROW_WAVES;
 #define R3DG_ROW(N, L, T)                                                                                             \
     do {                                                                                                              \

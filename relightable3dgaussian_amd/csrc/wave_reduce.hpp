@@ -133,4 +133,49 @@ __device__ __forceinline__ float transpose_reduce(float (&v)[N])
     return r;
 }
 
+// ---- the same within each HALF-wave (32 lanes): lanes 0..31 and 32..63 reduce independent value sets --------------------
+// N (power of two, 2..32) values per lane; every lane ends with the 32-lane total of channel
+// chan(lane) = sum_t bit_{4-t}(lane) * (N >> (t+1)), t < log2 N; exchange distances 16, 8, 4, 2, 1 (no distance-32 level).
+template <int N>
+__device__ __forceinline__ int transposed_channel_half(int lane)
+{
+    int idx = 0;
+#pragma unroll
+    for (int t = 0; t < Log2<N>::value; t++)
+        if (lane & (16 >> t)) idx += N >> (t + 1);
+    return idx;
+}
+template <int N>
+__device__ __forceinline__ bool transposed_owner_half(int lane)
+{
+    return (lane & ((32 / N) - 1)) == 0;
+}
+template <int N, int LVL>
+__device__ __forceinline__ void transpose_level_half(float (&v)[N], int lane)
+{
+    constexpr int D = 16 >> LVL;
+    constexpr int half = N >> (LVL + 1);
+    const bool hi = (lane & D) != 0;
+#pragma unroll
+    for (int k = 0; k < half; k++) v[k] = transpose_step<D, true>(v[k], v[k + half], hi);
+}
+template <int N>
+__device__ __forceinline__ float transpose_reduce_half(float (&v)[N])
+{
+    static_assert(N >= 2 && N <= 32, "half-wave transposing reduction: 2..32 values");
+    const int lane = lane_id();
+    constexpr int L = Log2<N>::value;
+    if constexpr (L > 0) transpose_level_half<N, 0>(v, lane);
+    if constexpr (L > 1) transpose_level_half<N, 1>(v, lane);
+    if constexpr (L > 2) transpose_level_half<N, 2>(v, lane);
+    if constexpr (L > 3) transpose_level_half<N, 3>(v, lane);
+    if constexpr (L > 4) transpose_level_half<N, 4>(v, lane);
+    float r = v[0];
+    if constexpr (L <= 1) r += lane_xor<8, true>(r);
+    if constexpr (L <= 2) r += lane_xor<4, true>(r);
+    if constexpr (L <= 3) r += lane_xor<2, true>(r);
+    if constexpr (L <= 4) r += lane_xor<1, true>(r);
+    return r;
+}
+
 }  // namespace r3dg

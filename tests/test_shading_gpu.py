@@ -133,7 +133,7 @@ def test_shading_env_gradient_nonfinite_upstream_propagates():
 
 
 @pytest.mark.parametrize("P,K,He,transform", [(1200, 64, 16, False), (500, 384, 64, True), (300, 30, 8, False),
-                                              (64, 100, 256, False)])
+                                              (64, 100, 256, False), (1201, 64, 16, False), (1, 40, 8, False)])
 def test_shading_forward_variants_agree(P, K, He, transform):
     """The forward formulations -- row kernels with the lat-long lookup evaluated in the kernel, with the cached lookup
     (r3dg_shade_build_taps), with only the training outputs, and the round-1 16-lane kernel -- against the float64 oracle
@@ -158,12 +158,17 @@ def test_shading_forward_variants_agree(P, K, He, transform):
     args = (d["base_color"], d["roughness"], d["normals"], d["viewdirs"], d["incidents"], d["env"], d["visibility"],
             d["incident_dirs"], d["incident_areas"], trd)
     taps = so.build_taps(d["incident_dirs"], He, 2 * He, trd)
-    outs = {"rows": so.shade_forward(*args), "rows+taps": so.shade_forward(*args, taps=taps),
-            "rows+radiance": so.shade_forward(*args, taps=so.build_taps(d["incident_dirs"], He, 2 * He, trd, radiance_of=d["env"]),
-                                              taps_are_radiance=True)}
+    rad = so.build_taps(d["incident_dirs"], He, 2 * He, trd, radiance_of=d["env"])
     sentinel = torch.full((P, so.NOUT), -7.0, device=DEV)
-    outs["rows+taps+train"] = so.shade_forward(*args, taps=taps, train_outputs=True, out=sentinel.clone())
+    outs = {"rows": so.shade_forward(*args), "rows+taps": so.shade_forward(*args, taps=taps),
+            "rows+radiance": so.shade_forward(*args, taps=rad, taps_are_radiance=True),
+            "rows+taps+train": so.shade_forward(*args, taps=taps, train_outputs=True, out=sentinel.clone())}
     try:
+        # r3dg_set_tuning7(2): cached lookups + degree-3 light run the pair kernel (two samples per lane)
+        _lib.lib().r3dg_set_tuning7(2, -1)
+        outs["pair+taps"] = so.shade_forward(*args, taps=taps)
+        outs["pair+radiance"] = so.shade_forward(*args, taps=rad, taps_are_radiance=True)
+        outs["pair+taps+train"] = so.shade_forward(*args, taps=taps, train_outputs=True, out=sentinel.clone())
         _lib.lib().r3dg_set_tuning7(0, -1)
         outs["16-lane"] = so.shade_forward(*args)
     finally:
@@ -182,6 +187,8 @@ def test_shading_forward_variants_agree(P, K, He, transform):
             _ok(name + " rest", got[:, [3, 4, 5] + list(range(9, 19))], want[:, [3, 4, 5] + list(range(9, 19))], 1e-4, 1e-6)
     # the cached lookup is the same arithmetic as the in-kernel one
     assert (outs["rows"] - outs["rows+taps"]).abs().max().item() <= 1e-6 * max(1.0, want.abs().max().item())
+    # two samples per lane: the same per-sample arithmetic, sums formed in another order
+    assert (outs["pair+taps"] - outs["rows+taps"]).abs().max().item() <= 2e-5 * max(1.0, want.abs().max().item())
 
 
 @pytest.mark.parametrize("P,K,He,transform", [(1500, 64, 16, False), (400, 100, 64, True), (300, 30, 16, False)])
