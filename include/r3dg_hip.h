@@ -255,6 +255,13 @@ int r3dg_render_equation_backward(void* stream, int P, int Si, int Sd, int Sv, c
                                   float* d_dL_dviewdirs, float* d_dL_dincidents_shs, float* d_dL_ddirect_shs,
                                   float* d_dL_dvisibility_shs);
 
+/* Scalar accumulators ("sum" arguments of r3dg_stage2_pack_features, r3dg_stage2_loss, r3dg_stage1_loss, r3dg_ssim_forward,
+ * r3dg_stage2_env_backward): every quantity is R3DG_SUM_SLOTS consecutive floats and its value is the SUM of them -- each
+ * workgroup adds its total to one slot (same-address float atomics serialise at ~35 ns each on MI355X; thousands of
+ * workgroups on one word take longer than the kernels themselves).  `d_sums` arrays hold quantity q at
+ * d_sums + q * R3DG_SUM_SLOTS.  Callers zero them before the first kernel of an iteration. */
+#define R3DG_SUM_SLOTS 32
+
 /* ---- Stage-2 iteration glue: the elementwise code around the hot ops, fused -------------------
  * All tensors fp32, device, contiguous.  Shapes: xyz/scaling/normal/base_color raw [P,3], rotation raw [P,4],
  * opacity/roughness raw [P]; viewmatrix = world_view_transform (16 floats, row-vector convention, scene/cameras.py:62),
@@ -277,7 +284,10 @@ int r3dg_render_equation_backward(void* stream, int P, int Si, int Sd, int Sv, c
  *   with feat = feature / max(opacity,1e-5) * (n_contrib > 0), pbr_img = feat[2:5]*opacity + (1-opacity)*bg;
  *   dL_dimage[3,HW], dL_dopacity[HW], dL_dfeature[16,HW] are fully written for weights w_* per element;
  *   d_extra_dL_dimage / d_extra_dL_dsrgb (may be NULL): gradients of further terms w.r.t. the image and the sRGB PBR
- *   image (the SSIM terms), added before the chain rule. */
+ *   image (the SSIM terms), added before the chain rule.  sparse_feature_gradients != 0: only the maps that carry a loss
+ *   term are written (channels 2-4, and 5-7 when w_normal != 0; the others are left untouched and, with w_normal == 0,
+ *   the normal maps are not read and sums[2] is not accumulated) -- for a rasterizer backward restricted to those
+ *   channels (active_features). */
 int r3dg_stage2_activate(void* stream, int P, const float* d_xyz, const float* d_scaling_raw,
                          const float* d_rotation_raw, const float* d_opacity_raw, const float* d_normal_raw,
                          const float* d_base_raw, const float* d_rough_raw, const float* d_campos, float* d_scales,
@@ -301,7 +311,8 @@ int r3dg_stage2_loss(void* stream, int width, int height, const float* d_image, 
                      const float* d_feature, const float* d_pseudo_normal, const int32_t* d_n_contrib,
                      const float* d_gt, const float* d_background, float w_l1, float w_pbr, float w_normal,
                      const float* d_extra_dL_dimage, const float* d_extra_dL_dsrgb, float* d_dL_dimage,
-                     float* d_dL_dopacity, float* d_dL_dfeature, float* d_sums);
+                     float* d_dL_dopacity, float* d_dL_dfeature, float* d_sums,
+                     int sparse_feature_gradients);
 /* sRGB-mapped PBR image [3,HW] exactly as r3dg_stage2_loss forms it (input of the SSIM term on the PBR image). */
 int r3dg_stage2_pbr_srgb(void* stream, int width, int height, const float* d_opacity, const float* d_feature,
                          const int32_t* d_n_contrib, const float* d_background, float* d_srgb);

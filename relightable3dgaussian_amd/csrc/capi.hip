@@ -95,7 +95,7 @@ void launch_s2_activate_backward(hipStream_t s, int P, const float* xyz, const f
 void launch_s2_loss(hipStream_t s, int HW, const float* image, const float* opacity, const float* feature,
                     const float* pseudo_normal, const int* n_contrib, const float* gt, const float* bg, float w_l1,
                     float w_pbr, float w_normal, const float* extra_dimage, const float* extra_dsrgb, float* dL_dimage,
-                    float* dL_dopacity, float* dL_dfeature, float* sums);
+                    float* dL_dopacity, float* dL_dfeature, float* sums, int sparse);
 void launch_s2_pbr_srgb(hipStream_t s, int HW, const float* opacity, const float* feature, const int* n_contrib,
                         const float* bg, float* srgb);
 void launch_ssim_forward(hipStream_t s, int W, int H, int C, int n_images, const float* const* x, const float* y,
@@ -1227,7 +1227,8 @@ int r3dg_stage2_activate_backward(void* stream_, int P, const float* xyz, const 
 int r3dg_stage2_loss(void* stream_, int width, int height, const float* image, const float* opacity,
                      const float* feature, const float* pseudo_normal, const int32_t* n_contrib, const float* gt,
                      const float* bg, float w_l1, float w_pbr, float w_normal, const float* extra_dimage,
-                     const float* extra_dsrgb, float* dL_dimage, float* dL_dopacity, float* dL_dfeature, float* sums)
+                     const float* extra_dsrgb, float* dL_dimage, float* dL_dopacity, float* dL_dfeature, float* sums,
+                     int sparse_feature_gradients)
 {
     if (width < 0 || height < 0) return invalid("stage2_loss: bad image size");
     if ((long long)width * height == 0) return R3DG_OK;
@@ -1237,7 +1238,8 @@ int r3dg_stage2_loss(void* stream_, int width, int height, const float* image, c
     return guarded([&]() -> int {
         StageTimer t((hipStream_t)stream_, ST_S2_LOSS);
         launch_s2_loss((hipStream_t)stream_, width * height, image, opacity, feature, pseudo_normal, n_contrib, gt, bg,
-                       w_l1, w_pbr, w_normal, extra_dimage, extra_dsrgb, dL_dimage, dL_dopacity, dL_dfeature, sums);
+                       w_l1, w_pbr, w_normal, extra_dimage, extra_dsrgb, dL_dimage, dL_dopacity, dL_dfeature, sums,
+                       sparse_feature_gradients);
         return R3DG_OK;
     });
 }
@@ -1270,7 +1272,7 @@ int r3dg_stage1_loss(void* stream_, int width, int height, const float* image, c
     return guarded([&]() -> int {
         StageTimer t((hipStream_t)stream_, ST_S2_LOSS);
         if (w_normal_smooth != 0.f)
-            launch_s1_edge((hipStream_t)stream_, width, height, feature, opacity, n_contrib, gt, edge_scratch, sums + 4);
+            launch_s1_edge((hipStream_t)stream_, width, height, feature, opacity, n_contrib, gt, edge_scratch, sums + 4 * R3DG_SUM_SLOTS);
         launch_s1_loss((hipStream_t)stream_, width, height, image, opacity, feature, pseudo_normal, n_contrib, gt, image_mask,
                        w_l1, w_mask_entropy, w_normal, w_normal_smooth, w_depth_var, extra_dimage,
                        w_normal_smooth != 0.f ? edge_scratch : nullptr, dL_dimage, dL_dopacity, dL_dfeature, sums);

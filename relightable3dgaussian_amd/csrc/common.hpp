@@ -1,5 +1,6 @@
 // Shared host/device helpers for libr3dg_hip.so (gfx950 only; wave = 64 lanes).
 #pragma once
+#include "r3dg_hip.h"
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stddef.h>
@@ -68,6 +69,15 @@ void sort_pairs_range(hipStream_t stream, size_t n, uint64_t* keys_in, uint32_t*
 
 // ---- device helpers -------------------------------------------------------------------------------------
 #ifdef __HIPCC__
+// Scalar accumulators of the glue kernels (loss sums): R3DG_SUM_SLOTS consecutive floats per quantity, the value is the sum
+// of the slots.  A float atomic on ONE address retires every ~35 ns on this part (measured: the stage-2 loss kernel got
+// 27 us slower for every 768 additional workgroups); a few thousand workgroups adding to one word serialise for longer
+// than the kernel runs.  Each workgroup adds to the slot of its linear index instead.
+__device__ __forceinline__ float* sum_slot(float* sum)
+{
+    const unsigned b = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+    return sum + (b & (unsigned)(R3DG_SUM_SLOTS - 1));
+}
 __device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63); }
 
 // Full-wave (64-lane) sum; result valid in every lane.

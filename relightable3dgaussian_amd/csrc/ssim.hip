@@ -56,8 +56,13 @@ ssim_forward_kernel(int W, int H, int C, SsimBatch batch)
     const float* __restrict__ y = I.y;
     float* __restrict__ partials = I.partials;
     float* __restrict__ sum = I.sum;
-    __shared__ float s_x[SSIM_E][SSIM_E + 1], s_y[SSIM_E][SSIM_E + 1];
-    __shared__ float s_h[5][SSIM_E][SSIM_T + 1];
+    // the row-filtered maps take the place of the staged inputs (results wait in registers across a barrier): 27 KB
+    // instead of 42 KB per workgroup = 5 resident workgroups per CU instead of 3 for a kernel that lives on latency hiding
+    constexpr int IN_FLOATS = 2 * SSIM_E * (SSIM_E + 1), H_FLOATS = 5 * SSIM_E * (SSIM_T + 1);
+    __shared__ float s_raw[IN_FLOATS > H_FLOATS ? IN_FLOATS : H_FLOATS];
+    float (*s_x)[SSIM_E + 1] = reinterpret_cast<float (*)[SSIM_E + 1]>(s_raw);
+    float (*s_y)[SSIM_E + 1] = reinterpret_cast<float (*)[SSIM_E + 1]>(s_raw + SSIM_E * (SSIM_E + 1));
+    float (*s_h)[SSIM_E][SSIM_T + 1] = reinterpret_cast<float (*)[SSIM_E][SSIM_T + 1]>(s_raw);
     __shared__ float s_part[4];
     const size_t HW = (size_t)H * W;
     const int c = blockIdx.z % C;
@@ -76,21 +81,38 @@ ssim_forward_kernel(int W, int H, int C, SsimBatch batch)
     float w[11];
 #pragma unroll
     for (int k = 0; k < 11; k++) w[k] = kSsimWin[k];
-    for (int i = threadIdx.x; i < SSIM_E * (SSIM_T / SSIM_B); i += 256) {     // horizontal taps
-        const int r = i / (SSIM_T / SSIM_B), q0 = (i % (SSIM_T / SSIM_B)) * SSIM_B;
-        float xv[SSIM_B + 10], yv[SSIM_B + 10];
+    constexpr int ITEMS = SSIM_E * (SSIM_T / SSIM_B), ROUNDS = (ITEMS + 255) / 256;     // horizontal taps
+    float hres[ROUNDS][5][SSIM_B];
 #pragma unroll
-        for (int k = 0; k < SSIM_B + 10; k++) { xv[k] = s_x[r][q0 + k]; yv[k] = s_y[r][q0 + k]; }
+    for (int rd = 0; rd < ROUNDS; rd++) {
+        const int i = threadIdx.x + rd * 256;
+        if (i < ITEMS) {
+            const int r = i / (SSIM_T / SSIM_B), q0 = (i % (SSIM_T / SSIM_B)) * SSIM_B;
+            float xv[SSIM_B + 10], yv[SSIM_B + 10];
 #pragma unroll
-        for (int o = 0; o < SSIM_B; o++) {
-            float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f, a4 = 0.f;
+            for (int k = 0; k < SSIM_B + 10; k++) { xv[k] = s_x[r][q0 + k]; yv[k] = s_y[r][q0 + k]; }
 #pragma unroll
-            for (int k = 0; k < 11; k++) {
-                const float wx = w[k] * xv[o + k], wy = w[k] * yv[o + k];
-                a0 += wx; a1 += wy; a2 += wx * xv[o + k]; a3 += wy * yv[o + k]; a4 += wx * yv[o + k];
+            for (int o = 0; o < SSIM_B; o++) {
+                float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f, a4 = 0.f;
+#pragma unroll
+                for (int k = 0; k < 11; k++) {
+                    const float wx = w[k] * xv[o + k], wy = w[k] * yv[o + k];
+                    a0 += wx; a1 += wy; a2 += wx * xv[o + k]; a3 += wy * yv[o + k]; a4 += wx * yv[o + k];
+                }
+                hres[rd][0][o] = a0; hres[rd][1][o] = a1; hres[rd][2][o] = a2; hres[rd][3][o] = a3; hres[rd][4][o] = a4;
             }
-            s_h[0][r][q0 + o] = a0; s_h[1][r][q0 + o] = a1; s_h[2][r][q0 + o] = a2; s_h[3][r][q0 + o] = a3;
-            s_h[4][r][q0 + o] = a4;
+        }
+    }
+    __syncthreads();                                   // every read of the staged inputs is done: reuse their storage
+#pragma unroll
+    for (int rd = 0; rd < ROUNDS; rd++) {
+        const int i = threadIdx.x + rd * 256;
+        if (i < ITEMS) {
+            const int r = i / (SSIM_T / SSIM_B), q0 = (i % (SSIM_T / SSIM_B)) * SSIM_B;
+#pragma unroll
+            for (int m = 0; m < 5; m++)
+#pragma unroll
+                for (int o = 0; o < SSIM_B; o++) s_h[m][r][q0 + o] = hres[rd][m][o];
         }
     }
     __syncthreads();
@@ -133,7 +155,7 @@ ssim_forward_kernel(int W, int H, int C, SsimBatch batch)
         }
     }
     const float tot = block_sum_256s(ssim_sum, s_part);
-    if (threadIdx.x == 0 && sum != nullptr) atomicAdd(sum, tot);
+    if (threadIdx.x == 0 && sum != nullptr) atomicAdd(sum_slot(sum), tot);
 }
 
 __global__ void __launch_bounds__(256)
@@ -145,8 +167,10 @@ ssim_backward_kernel(int W, int H, int C, SsimBatch batch)
     const float* __restrict__ partials = I.partials;
     const float scale = I.scale;
     float* __restrict__ grad_x = I.grad_x;
-    __shared__ float s_p[3][SSIM_E][SSIM_E + 1];
-    __shared__ float s_h[3][SSIM_E][SSIM_T + 1];
+    constexpr int IN_FLOATS = 3 * SSIM_E * (SSIM_E + 1);                       // (row-filtered maps alias the inputs)
+    __shared__ float s_raw[IN_FLOATS];
+    float (*s_p)[SSIM_E][SSIM_E + 1] = reinterpret_cast<float (*)[SSIM_E][SSIM_E + 1]>(s_raw);
+    float (*s_h)[SSIM_E][SSIM_T + 1] = reinterpret_cast<float (*)[SSIM_E][SSIM_T + 1]>(s_raw);
     const size_t HW = (size_t)H * W;
     const int c = blockIdx.z % C;
     const float* pc = partials + (size_t)c * 3 * HW;
@@ -164,20 +188,38 @@ ssim_backward_kernel(int W, int H, int C, SsimBatch batch)
     float w[11];
 #pragma unroll
     for (int k = 0; k < 11; k++) w[k] = kSsimWin[k];
-    for (int i = threadIdx.x; i < SSIM_E * (SSIM_T / SSIM_B); i += 256) {
-        const int r = i / (SSIM_T / SSIM_B), q0 = (i % (SSIM_T / SSIM_B)) * SSIM_B;
+    constexpr int ITEMS = SSIM_E * (SSIM_T / SSIM_B), ROUNDS = (ITEMS + 255) / 256;
+    float hres[ROUNDS][3][SSIM_B];
 #pragma unroll
-        for (int m = 0; m < 3; m++) {
-            float v[SSIM_B + 10];
+    for (int rd = 0; rd < ROUNDS; rd++) {
+        const int i = threadIdx.x + rd * 256;
+        if (i < ITEMS) {
+            const int r = i / (SSIM_T / SSIM_B), q0 = (i % (SSIM_T / SSIM_B)) * SSIM_B;
 #pragma unroll
-            for (int k = 0; k < SSIM_B + 10; k++) v[k] = s_p[m][r][q0 + k];
+            for (int m = 0; m < 3; m++) {
+                float v[SSIM_B + 10];
 #pragma unroll
-            for (int o = 0; o < SSIM_B; o++) {
-                float a = 0.f;
+                for (int k = 0; k < SSIM_B + 10; k++) v[k] = s_p[m][r][q0 + k];
 #pragma unroll
-                for (int k = 0; k < 11; k++) a += w[k] * v[o + k];
-                s_h[m][r][q0 + o] = a;
+                for (int o = 0; o < SSIM_B; o++) {
+                    float a = 0.f;
+#pragma unroll
+                    for (int k = 0; k < 11; k++) a += w[k] * v[o + k];
+                    hres[rd][m][o] = a;
+                }
             }
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int rd = 0; rd < ROUNDS; rd++) {
+        const int i = threadIdx.x + rd * 256;
+        if (i < ITEMS) {
+            const int r = i / (SSIM_T / SSIM_B), q0 = (i % (SSIM_T / SSIM_B)) * SSIM_B;
+#pragma unroll
+            for (int m = 0; m < 3; m++)
+#pragma unroll
+                for (int o = 0; o < SSIM_B; o++) s_h[m][r][q0 + o] = hres[rd][m][o];
         }
     }
     __syncthreads();

@@ -11,6 +11,7 @@
 //                                 SH image, L1 on the sRGB-mapped PBR image, normal-vs-pseudo-normal MSE)
 //   adam_kernel                   multi-group Adam step, all parameter groups in one launch (gaussian_model.py:465-497)
 // Parity target: the plain-PyTorch restatement in relightable3dgaussian_amd/train_step.py (Stage2Step), fp32 tolerance.
+#include <cstdlib>
 #include "common.hpp"
 #include "r3dg_hip.h"
 
@@ -114,7 +115,7 @@ s2_pack_features_kernel(int P, const float* __restrict__ xyz, const float* __res
         l1 = fabsf(dl[0] - m) + fabsf(dl[1] - m) + fabsf(dl[2] - m);
     }
     const float tot = block_sum_256(l1, s_part);
-    if (threadIdx.x == 0 && light_l1_sum != nullptr) atomicAdd(light_l1_sum, tot);
+    if (threadIdx.x == 0 && light_l1_sum != nullptr) atomicAdd(sum_slot(light_l1_sum), tot);
 }
 
 __device__ __forceinline__ float signf_(float x) { return x > 0.f ? 1.f : (x < 0.f ? -1.f : 0.f); }
@@ -257,6 +258,9 @@ s2_pbr_srgb_kernel(int HW, const float* __restrict__ opacity, const float* __res
 
 // Image-space loss + gradient in one pass.  sums[0..2] += sum|image-gt|, sum|srgb(pbr)-gt|, sum (n_render - n_pseudo)^2
 // (unweighted); gradients carry the weights w_* (already divided by the element counts).
+// SPARSE: only the feature-gradient maps that carry a loss term are written (2-4; 5-7 when w_normal != 0) -- for callers
+// whose rasterizer backward reads exactly those (active_features); with w_normal == 0 the normal maps are not even read.
+template <bool SPARSE>
 __global__ void __launch_bounds__(256)
 s2_loss_kernel(int HW, const float* __restrict__ image, const float* __restrict__ opacity,
                const float* __restrict__ feature, const float* __restrict__ pseudo_normal,
@@ -301,18 +305,22 @@ s2_loss_kernel(int HW, const float* __restrict__ image, const float* __restrict_
             dL_dfeature[(size_t)(2 + c) * HW + i] = gx * op * scale;
             g_op += gx * (r - bg[c] + op * F * dscale_dop);
             // normal consistency: mse(r_normal, pseudo_normal)
-            const float Fn = feature[(size_t)(5 + c) * HW + i];
-            const float dn = Fn * scale - pseudo_normal[(size_t)c * HW + i];
-            s_n += dn * dn;
-            const float gn = 2.f * w_normal * dn;
-            dL_dfeature[(size_t)(5 + c) * HW + i] = gn * scale;
-            g_op += gn * Fn * dscale_dop;
+            if (!SPARSE || w_normal != 0.f) {
+                const float Fn = feature[(size_t)(5 + c) * HW + i];
+                const float dn = Fn * scale - pseudo_normal[(size_t)c * HW + i];
+                s_n += dn * dn;
+                const float gn = 2.f * w_normal * dn;
+                dL_dfeature[(size_t)(5 + c) * HW + i] = gn * scale;
+                g_op += gn * Fn * dscale_dop;
+            }
         }
         dL_dopacity[i] = g_op;
-        dL_dfeature[i] = 0.f;
-        dL_dfeature[(size_t)HW + i] = 0.f;
+        if (!SPARSE) {
+            dL_dfeature[i] = 0.f;
+            dL_dfeature[(size_t)HW + i] = 0.f;
 #pragma unroll
-        for (int c = 8; c < 16; c++) dL_dfeature[(size_t)c * HW + i] = 0.f;
+            for (int c = 8; c < 16; c++) dL_dfeature[(size_t)c * HW + i] = 0.f;
+        }
     }
     const float t0 = block_sum_256(s_l1, s_part);
     __syncthreads();
@@ -320,9 +328,9 @@ s2_loss_kernel(int HW, const float* __restrict__ image, const float* __restrict_
     __syncthreads();
     const float t2 = block_sum_256(s_n, s_part);
     if (threadIdx.x == 0) {
-        atomicAdd(sums + 0, t0);
-        atomicAdd(sums + 1, t1);
-        atomicAdd(sums + 2, t2);
+        atomicAdd(sum_slot(sums + 0 * R3DG_SUM_SLOTS), t0);
+        atomicAdd(sum_slot(sums + 1 * R3DG_SUM_SLOTS), t1);
+        atomicAdd(sum_slot(sums + 2 * R3DG_SUM_SLOTS), t2);
     }
 }
 
@@ -356,7 +364,7 @@ s2_env_backward_kernel(int He, int We, const float* __restrict__ raw, const floa
         if (consume) dL_denv[i] = 0.f;            // the accumulator is handed back zeroed for the next shading backward
     }
     const float tot = block_sum_256(tv, s_part);
-    if (threadIdx.x == 0 && tv_sum != nullptr) atomicAdd(tv_sum, tot);
+    if (threadIdx.x == 0 && tv_sum != nullptr) atomicAdd(sum_slot(tv_sum), tot);
 }
 
 // ---- stage 1 (plain 3DGS + normals, gaussian_renderer/render.py:15-130): S = 5 feature row [normal, depth, depth^2] ---
@@ -428,7 +436,7 @@ s1_edge_kernel(int W, int H, const float* __restrict__ feature, const float* __r
         }
     }
     const float t = block_sum_256(acc, s_part);
-    if (threadIdx.x == 0) atomicAdd(sum_out, t);
+    if (threadIdx.x == 0) atomicAdd(sum_slot(sum_out), t);
 }
 
 // sum_d [clamp(q + d, 0, n-1) == p] * k[d+1]: weight with which position q's replicate-padded 1-D stencil reads position p
@@ -520,10 +528,10 @@ s1_loss_kernel(int W, int H, const float* __restrict__ image, const float* __res
     __syncthreads();
     const float t3 = block_sum_256(s_v, s_part);
     if (threadIdx.x == 0) {
-        atomicAdd(sums + 0, t0);
-        atomicAdd(sums + 1, t1);
-        atomicAdd(sums + 2, t2);
-        atomicAdd(sums + 5, t3);
+        atomicAdd(sum_slot(sums + 0 * R3DG_SUM_SLOTS), t0);
+        atomicAdd(sum_slot(sums + 1 * R3DG_SUM_SLOTS), t1);
+        atomicAdd(sum_slot(sums + 2 * R3DG_SUM_SLOTS), t2);
+        atomicAdd(sum_slot(sums + 5 * R3DG_SUM_SLOTS), t3);
     }
 }
 
@@ -687,14 +695,26 @@ void launch_s2_pbr_srgb(hipStream_t s, int HW, const float* opacity, const float
     check_launch(s, false, "s2_pbr_srgb_kernel");
 }
 
+int g_loss_blocks = 768;      // (experiments: R3DG_LOSS_BLOCKS)
+
 void launch_s2_loss(hipStream_t s, int HW, const float* image, const float* opacity, const float* feature,
                     const float* pseudo_normal, const int* n_contrib, const float* gt, const float* bg, float w_l1,
                     float w_pbr, float w_normal, const float* extra_dimage, const float* extra_dsrgb, float* dL_dimage,
-                    float* dL_dopacity, float* dL_dfeature, float* sums)
+                    float* dL_dopacity, float* dL_dfeature, float* sums, int sparse)
 {
-    s2_loss_kernel<<<min((HW + 255) / 256, 768), 256, 0, s>>>(HW, image, opacity, feature, pseudo_normal, n_contrib, gt,
-                                                            bg, w_l1, w_pbr, w_normal, extra_dimage, extra_dsrgb,
-                                                            dL_dimage, dL_dopacity, dL_dfeature, sums);
+    static bool env_read = false;
+    if (!env_read) {
+        env_read = true;
+        if (const char* e = getenv("R3DG_LOSS_BLOCKS")) g_loss_blocks = atoi(e) > 0 ? atoi(e) : g_loss_blocks;
+    }
+    if (sparse)
+        s2_loss_kernel<true><<<min((HW + 255) / 256, g_loss_blocks), 256, 0, s>>>(HW, image, opacity, feature, pseudo_normal, n_contrib,
+                                                                      gt, bg, w_l1, w_pbr, w_normal, extra_dimage,
+                                                                      extra_dsrgb, dL_dimage, dL_dopacity, dL_dfeature, sums);
+    else
+        s2_loss_kernel<false><<<min((HW + 255) / 256, g_loss_blocks), 256, 0, s>>>(HW, image, opacity, feature, pseudo_normal, n_contrib,
+                                                                       gt, bg, w_l1, w_pbr, w_normal, extra_dimage,
+                                                                       extra_dsrgb, dL_dimage, dL_dopacity, dL_dfeature, sums);
     check_launch(s, false, "s2_loss_kernel");
 }
 

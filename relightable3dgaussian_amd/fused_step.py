@@ -26,6 +26,8 @@ import torch.nn.functional as F
 from . import _lib, rasterizer_ops, shading_ops
 from .train_step import LAMBDA_DSSIM, update_visibility
 
+SUM_SLOTS = 32           # R3DG_SUM_SLOTS (include/r3dg_hip.h): floats per scalar accumulator of the glue kernels
+
 
 class AdamGroup(C.Structure):
     _fields_ = [("param", C.c_void_p), ("grad", C.c_void_p), ("exp_avg", C.c_void_p), ("exp_avg_sq", C.c_void_p),
@@ -125,7 +127,7 @@ class FusedStage2Step:
         self.shade_out = torch.empty(P, shading_ops.NOUT, **f)
         self.features = torch.empty(P, 16, **f)
         # unweighted sums: l1, pbr l1, normal mse, light l1, TV(env), SSIM(image), SSIM(pbr)
-        self.sums = torch.zeros(7, **f)
+        self.sums = torch.zeros(7, SUM_SLOTS, **f)        # R3DG_SUM_SLOTS floats per quantity (include/r3dg_hip.h)
         self.d_pbr, self.d_diffuse = torch.empty(P, 3, **f), torch.empty(P, 3, **f)
         self._absmax = torch.zeros((P + 255) // 256, **f)       # block maxima of |d_pbr|, |d_diffuse| (unpack kernel)
         self._d_env = None
@@ -294,7 +296,7 @@ class FusedStage2Step:
             _lib.check(L.r3dg_stage2_pack_features(
                 stream(), P, self.xyz.data_ptr(), vm.data_ptr(), self.a_normal.data_ptr(), self.a_base.data_ptr(),
                 self.a_rough.data_ptr(), self.shade_out.data_ptr(), self.features.data_ptr(),
-                self.sums[3:].data_ptr()), "stage2_pack_features")
+                self.sums[3].data_ptr()), "stage2_pack_features")
             fw = pending.finish(self._order_stream)
             R, n_contrib, image, opacity, depth, feature, pseudo_normal, sxyz, weights, radii, geom, binning, img = fw
             if self.bounded and not use_bounded:
@@ -314,8 +316,8 @@ class FusedStage2Step:
                                               n_contrib.data_ptr(), bg_c.data_ptr(), srgb.data_ptr()), "stage2_pbr_srgb")
             # SSIM terms of both images: one forward and one backward launch for the pair
             _lib.check(L.r3dg_ssim_forward_pair(stream(), W, H, 3, image.data_ptr(), srgb.data_ptr(), gt_c.data_ptr(),
-                                                part_i.data_ptr(), part_p.data_ptr(), self.sums[5:].data_ptr(),
-                                                self.sums[6:].data_ptr()), "ssim_forward")
+                                                part_i.data_ptr(), part_p.data_ptr(), self.sums[5].data_ptr(),
+                                                self.sums[6].data_ptr()), "ssim_forward")
             _lib.check(L.r3dg_ssim_backward_pair(stream(), W, H, 3, image.data_ptr(), srgb.data_ptr(), gt_c.data_ptr(),
                                                  part_i.data_ptr(), part_p.data_ptr(), -lam / (3.0 * N),
                                                  -self.w["pbr"] * lam / (3.0 * N), gs_i.data_ptr(), gs_p.data_ptr()),
@@ -324,7 +326,7 @@ class FusedStage2Step:
                 stream(), W, H, image.data_ptr(), opacity.data_ptr(), feature.data_ptr(), pseudo_normal.data_ptr(),
                 n_contrib.data_ptr(), gt_c.data_ptr(), bg_c.data_ptr(), self.w["l1"] * (1.0 - lam) / (3.0 * N),
                 self.w["pbr"] * (1.0 - lam) / (3.0 * N), self.w["normal"] / (3.0 * N), gs_i.data_ptr(), gs_p.data_ptr(),
-                g[0:3].data_ptr(), g[3:4].data_ptr(), g[4:20].data_ptr(), self.sums.data_ptr()), "stage2_loss")
+                g[0:3].data_ptr(), g[3:4].data_ptr(), g[4:20].data_ptr(), self.sums.data_ptr(), 1), "stage2_loss")
             bw = rasterizer_ops.rasterize_gaussians_backward(
                 bg, self.xyz, self.features, radii, empty, self.a_scales, self.a_rot, 1.0, empty, vm,
                 cam.full_proj_transform, cam.tanfovx, cam.tanfovy, g[0:3], g[3:4], self._zero_depth_grad, g[4:20], self.shs, 3,
@@ -376,7 +378,7 @@ class FusedStage2Step:
             # environment texture: softplus chain rule + total-variation term
             _lib.check(L.r3dg_stage2_env_backward(
                 stream(), He, We, self.env.data_ptr(), env_c.data_ptr(), d_env.data_ptr(), self.w["env_smooth"],
-                gr["env"].data_ptr(), self.sums[4:].data_ptr(), 1), "stage2_env_backward")
+                gr["env"].data_ptr(), self.sums[4].data_ptr(), 1), "stage2_env_backward")
             self._handles = None
             if self.world > 1:
                 handle_c = self._allreduce_async(self._bucket_c)
@@ -435,7 +437,7 @@ class FusedStage2Step:
         w = torch.tensor([self.w["l1"] * (1 - lam) / (3.0 * N), self.w["pbr"] * (1 - lam) / (3.0 * N),
                           self.w["normal"] / (3.0 * N), self.w["light"] / (3.0 * P), self.w["env_smooth"],
                           -lam / (3.0 * N), -self.w["pbr"] * lam / (3.0 * N)], device=self.dev)
-        return (self.sums * w).sum() + lam * (1.0 + self.w["pbr"])
+        return (self.sums.sum(1) * w).sum() + lam * (1.0 + self.w["pbr"])
 
     _GROUPS_A = (5,)                       # indices into self.opt.groups: shs
     _GROUPS_C = (0, 1, 2, 3, 4, 6, 7, 9)   # xyz normal scaling rotation opacity base_color roughness env
@@ -524,7 +526,7 @@ class FusedStage1Step:
         self.a_scales, self.a_rot = torch.empty(P, 3, **f), torch.empty(P, 4, **f)
         self.a_opacity, self.a_normal = torch.empty(P, 1, **f), torch.empty(P, 3, **f)
         self.features = torch.empty(P, 5, **f)
-        self.sums = torch.zeros(6, **f)          # l1, normal mse, mask entropy, SSIM(image), edge-aware normal, sqrt depth var
+        self.sums = torch.zeros(6, SUM_SLOTS, **f)          # (R3DG_SUM_SLOTS floats each) l1, normal mse, mask entropy, SSIM(image), edge-aware normal, sqrt depth var
         names = ("shs", "xyz", "normal", "scaling", "rotation", "opacity")
         sizes = {k: getattr(self, k).numel() for k in names}
         pad4 = lambda n: (n + 3) // 4 * 4         # every group starts on a 16-byte boundary (float4 accesses in the Adam kernel)
@@ -641,7 +643,7 @@ class FusedStage1Step:
             gt_c = gt.contiguous()
             lam = LAMBDA_DSSIM
             _lib.check(L.r3dg_ssim_forward(stream(), W, H, 3, image.data_ptr(), gt_c.data_ptr(), g[9:18].data_ptr(),
-                                           self.sums[3:].data_ptr()), "ssim_forward")
+                                           self.sums[3].data_ptr()), "ssim_forward")
             _lib.check(L.r3dg_ssim_backward(stream(), W, H, 3, image.data_ptr(), gt_c.data_ptr(), g[9:18].data_ptr(),
                                             -lam * self.w["l1"] / (3.0 * N), g[18:21].data_ptr()), "ssim_backward")
             w_l1, w_ent, w_nrm, w_smooth, w_var = self._weights(N)
@@ -680,7 +682,7 @@ class FusedStage1Step:
         lam = LAMBDA_DSSIM
         w_l1, w_ent, w_nrm, w_smooth, w_var = self._weights(N)
         w = torch.tensor([w_l1, w_nrm, w_ent, -lam * self.w["l1"] / (3.0 * N), w_smooth, w_var], device=self.dev)
-        return (self.sums * w).sum() + lam * self.w["l1"]
+        return (self.sums.sum(1) * w).sum() + lam * self.w["l1"]
 
     def optimizer_step(self):
         self._drain()

@@ -318,14 +318,14 @@ def test_ssim_kernels_match_reference_formula(H, W):
     val = ssim(xr, y)
     val.backward()
     part = torch.empty(3, 3, H, W, device=DEV)
-    total = torch.zeros(1, device=DEV)
+    total = torch.zeros(32, device=DEV)              # R3DG_SUM_SLOTS floats per accumulator
     grad = torch.empty(3, H, W, device=DEV)
     st = _lib.current_stream()
     _lib.check(L.r3dg_ssim_forward(st, W, H, 3, x.data_ptr(), y.data_ptr(), part.data_ptr(), total.data_ptr()), "f")
     _lib.check(L.r3dg_ssim_backward(st, W, H, 3, x.data_ptr(), y.data_ptr(), part.data_ptr(), 1.0 / (3 * H * W),
                                     grad.data_ptr()), "b")
     torch.cuda.synchronize()
-    assert abs(float(total) / (3 * H * W) - float(val)) < 2e-6
+    assert abs(float(total.sum()) / (3 * H * W) - float(val)) < 2e-6
     ok, msg = report("ssim grad", grad, xr.grad, 2e-4, 1e-9)
     assert ok, msg
 
