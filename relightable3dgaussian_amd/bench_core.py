@@ -217,8 +217,9 @@ def pytorch_cpu_rasterize(points, res, S, timeout_s=60, config0=False):
 def _kernel_names(stage):
     """Kernel(s) a profile stage times, dominant first (names as tools/pmc_*.py shorten them)."""
     return {"sort_pairs": ["tile_sort_small_kernel", "partition_scatter_kernel"],
+            "duplicate_with_keys": ["tile_emit_kernel", "duplicate_with_keys_kernel"],      # (stage name kept from K5)
             "shade_forward": ["shade_forward_row_kernel", "shade_forward_kernel"],
-            "adam_step": ["adam_kernel"], "bvh_trace": ["trace_opacity_persistent_kernel"],
+            "adam_step": ["adam_kernel"], "bvh_trace": ["trace_opacity_phased_kernel", "trace_opacity_persistent_kernel"],
             }.get(stage, [stage + "_kernel", stage])
 
 
@@ -557,10 +558,10 @@ def run(args):
     L.r3dg_profile_enable(0 if os.environ.get("R3DG_BENCH_NOPROFILE") else 1)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    # per-kernel HIP-event timing is live inside the timed region but sampled (every 4th step): each event pair costs
-    # ~2 us of host time, ~40 pairs per step
+    # per-kernel HIP-event timing is live inside the timed region but sampled (every 8th step): each event pair costs
+    # ~2 us of host time, ~40 pairs per step, and the events themselves sit between the kernels on the stream
     for i in range(args.steps):
-        L.r3dg_profile_pause(0 if (i % 4 == 0 and not os.environ.get("R3DG_BENCH_NOPROFILE")) else 1)
+        L.r3dg_profile_pause(0 if (i % 8 == 0 and not os.environ.get("R3DG_BENCH_NOPROFILE")) else 1)
         one_step(args.warmup + i)
     if fused:
         step_fn.flush()                  # (world > 1) the last iteration's deferred incident-light update
@@ -597,7 +598,7 @@ def run(args):
     blocks_sorted = sorted(blocks)
     spread = dict(blocks=len(blocks), steps_per_block=args.steps, min=round(blocks_sorted[0], 2),
                   median=round(blocks_sorted[len(blocks) // 2], 2), max=round(blocks_sorted[-1], 2),
-                  note="iters/s of the timed block (`value`, event timing on every 4th step) and of %d more blocks "
+                  note="iters/s of the timed block (`value`, event timing on every 8th step) and of %d more blocks "
                        "(event timing off)" % (len(blocks) - 1))
 
     relight = None
@@ -609,7 +610,7 @@ def run(args):
     if rank == 0:
         P, N = args.points, args.res * args.res
         R_mean = float(sum(R_seen[-args.steps:])) / max(1, args.steps)
-        n_sampled = max(1, sum(1 for i in range(args.steps) if i % 4 == 0))     # steps whose launches were timed
+        n_sampled = max(1, sum(1 for i in range(args.steps) if i % 8 == 0))     # steps whose launches were timed
         kernels = kernel_table(prof, n_sampled, P, R_mean, N, S, args.sample_num)
         if not kernels:                   # experiments with the in-library event timing switched off
             kernels = {"none": dict(avg_ms=0.0, launches=0, ms_per_iteration=0.0, algorithmic_MB=None, achieved_GBs=None)}

@@ -61,6 +61,8 @@ for grp in "$GA" "$GC"; do
   dbs="$dbs $(find /tmp/pt_${i} -name '*.db' | head -1)"
 done
 cd /root/repo
-python tools/pmc_valu.py gpurun_out/pmc_trace.json "visibility trace kernels, tools/kbench_trace.py (P=300000, K=64; tuning8 = 3, 2, 0 in turn), mean per dispatch (3 dispatches of 100k bundles per update)" $dbs < /dev/null
+python tools/pmc_valu.py gpurun_out/pmc_trace.json "visibility trace kernels, tools/kbench_trace.py (P=300000, K=64; tuning8 = 4, 3, 2, 0 in turn), mean per dispatch (3 dispatches of 100k bundles per update)" $dbs < /dev/null
+[ -x tools/pk_rate ] || /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -o tools/pk_rate tools/pk_rate.hip > /dev/null 2>&1
+./tools/pk_rate > gpurun_out/pk_rate.txt 2>&1
 timeout 600 python bench.py < /dev/null > gpurun_out/bench_default.log 2>&1; tail -1 gpurun_out/bench_default.log > gpurun_out/bench_default.json
 cut -c1-300 gpurun_out/bench_default.json
