@@ -422,6 +422,9 @@ tile_sort_big_kernel(const uint32_t* __restrict__ big_list, const uint32_t* __re
 
 constexpr uint32_t TILE_SORT_SMALL_CAP = 4096;     // 32 KB of LDS per workgroup
 constexpr uint32_t TILE_SORT_BIG_CAP = 16384;      // 128 KB
+// persistent workgroups of the long-tile kernel: one per CU (128 KB of LDS each).  64 were enough for the handful of long
+// tiles of a 300k-Gaussian frame; at 2M Gaussians half of the tiles are long and 64 workgroups took 4.4 ms of an 11 ms step
+constexpr int TILE_SORT_BIG_BLOCKS = 256;
 
 uint32_t tile_sort_small_cap() { return TILE_SORT_SMALL_CAP; }
 
@@ -440,12 +443,12 @@ void launch_tile_sort(hipStream_t s, int T, const uint32_t* tile_order, const ui
     if (entries) {
         tile_sort_small_kernel<true><<<T, 256, TILE_SORT_SMALL_CAP * 8, s>>>(T, tile_order, (const uint2*)ranges,
                                                                              TILE_SORT_SMALL_CAP, keys, vals, scratch);
-        tile_sort_big_kernel<true><<<64, 1024, TILE_SORT_BIG_CAP * 8, s>>>(big_list, big_count, (const uint2*)ranges,
+        tile_sort_big_kernel<true><<<TILE_SORT_BIG_BLOCKS, 1024, TILE_SORT_BIG_CAP * 8, s>>>(big_list, big_count, (const uint2*)ranges,
                                                                           TILE_SORT_BIG_CAP, keys, vals, scratch);
     } else {
         tile_sort_small_kernel<false><<<T, 256, TILE_SORT_SMALL_CAP * 8, s>>>(T, tile_order, (const uint2*)ranges,
                                                                               TILE_SORT_SMALL_CAP, keys, vals, scratch);
-        tile_sort_big_kernel<false><<<64, 1024, TILE_SORT_BIG_CAP * 8, s>>>(big_list, big_count, (const uint2*)ranges,
+        tile_sort_big_kernel<false><<<TILE_SORT_BIG_BLOCKS, 1024, TILE_SORT_BIG_CAP * 8, s>>>(big_list, big_count, (const uint2*)ranges,
                                                                            TILE_SORT_BIG_CAP, keys, vals, scratch);
     }
 }
