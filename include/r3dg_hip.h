@@ -410,11 +410,13 @@ int r3dg_relight_compose(void* stream, int width, int height, float focal_x, flo
  *   update of train.py:164-165, one pass.  The visibility filter is radii > 0 (render.py / neilf.py `visibility_filter`).
  *   d_viewspace_grad [P,3] is the gradient slot of the screen-space dummy (dL_dmeans2D); d_normal_grad [P,3] is the
  *   gradient of the raw normal parameter (NULL: the normal statistic is left alone); d_weights [P] are the rasterizer's
- *   per-Gaussian blend weights.  All five statistics are [P] floats updated in place. */
+ *   per-Gaussian blend weights.  All five statistics are [P] floats updated in place.  d_skip_flag (may be NULL): a
+ *   non-zero float on the device turns the call into a no-op (the overflow flag of a bounded forward). */
 int r3dg_densify_accumulate(void* stream, int P, const float* d_viewspace_grad, const float* d_normal_grad,
                             const int32_t* d_radii, const float* d_weights, float* d_xyz_gradient_accum,
                             float* d_normal_gradient_accum, float* d_denom, float* d_weights_accum,
-                            float* d_max_radii2D);
+                            float* d_max_radii2D,
+                            const float* d_skip_flag);
 
 /* Thresholds of one densify_and_prune (mode 0, gaussian_model.py:893-915) or prune (mode 1, :917-929) call.  The
  * products the reference forms in Python doubles are passed already rounded to fp32:

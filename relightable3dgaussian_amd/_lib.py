@@ -86,7 +86,7 @@ _SIGNATURES = {
     "r3dg_adam_step": (_i, [_p, _i, _p, _f, _f, _f, _i, _f, _p]),
     "r3dg_relight_pack_features": (_i, [_p, _i] + [_p] * 7),
     "r3dg_relight_compose": (_i, [_p, _i, _i, _f, _f, _f, _f, _p, _p, _p, _i, _i] + [_p] * 7),
-    "r3dg_densify_accumulate": (_i, [_p, _i] + [_p] * 9),
+    "r3dg_densify_accumulate": (_i, [_p, _i] + [_p] * 10),
     "r3dg_densify_temp_bytes": (C.c_size_t, [_i]),
     "r3dg_densify_plan": (_i, [_p, _i] + [_p] * 12),
     "r3dg_densify_gather": (_i, [_p, _i, _p, _p, _i, _p, _p, _p, _p, _p, _f]),

@@ -130,7 +130,7 @@ int tile_binning_max_tiles();
 extern int g_bin_iters;
 void launch_densify_accumulate(hipStream_t s, int P, const float* viewspace_grad, const float* normal_grad,
                                const int* radii, const float* weights, float* xyz_accum, float* normal_accum,
-                               float* denom, float* weights_accum, float* max_radii2D);
+                               float* denom, float* weights_accum, float* max_radii2D, const float* skip_flag);
 size_t densify_temp_bytes(size_t P);
 void launch_densify_plan(hipStream_t s, int P, const r3dg_densify_config& cfg, const float* scaling_raw,
                          const float* opacity_raw, const float* xyz_accum, const float* normal_accum,
@@ -1429,7 +1429,7 @@ int r3dg_relight_compose(void* stream_, int width, int height, float focal_x, fl
 
 int r3dg_densify_accumulate(void* stream_, int P, const float* viewspace_grad, const float* normal_grad,
                             const int32_t* radii, const float* weights, float* xyz_accum, float* normal_accum,
-                            float* denom, float* weights_accum, float* max_radii2D)
+                            float* denom, float* weights_accum, float* max_radii2D, const float* skip_flag)
 {
     if (P < 0) return invalid("densify_accumulate: bad P");
     if (P == 0) return R3DG_OK;
@@ -1438,7 +1438,7 @@ int r3dg_densify_accumulate(void* stream_, int P, const float* viewspace_grad, c
     return guarded([&]() -> int {
         StageTimer t((hipStream_t)stream_, ST_DENSIFY);
         launch_densify_accumulate((hipStream_t)stream_, P, viewspace_grad, normal_grad, radii, weights, xyz_accum,
-                                  normal_accum, denom, weights_accum, max_radii2D);
+                                  normal_accum, denom, weights_accum, max_radii2D, skip_flag);
         return R3DG_OK;
     });
 }

@@ -27,8 +27,11 @@ __global__ void __launch_bounds__(256)
 densify_accumulate_kernel(int P, const float* __restrict__ viewspace_grad, const float* __restrict__ normal_grad,
                           const int* __restrict__ radii, const float* __restrict__ weights,
                           float* __restrict__ xyz_accum, float* __restrict__ normal_accum, float* __restrict__ denom,
-                          float* __restrict__ weights_accum, float* __restrict__ max_radii2D)
+                          float* __restrict__ weights_accum, float* __restrict__ max_radii2D,
+                          const float* __restrict__ skip_flag)
 {
+    // a view the bounded forward dropped on the device (r3dg_rasterize_forward_begin_bounded) is no observation
+    if (skip_flag != nullptr && *skip_flag != 0.0f) return;
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= P) return;
     weights_accum[i] += weights[i];
@@ -285,10 +288,10 @@ reset_opacity_kernel(int P, float cap, float* __restrict__ opacity_raw, float* _
 // ---- launchers ------------------------------------------------------------------------------------------------------
 void launch_densify_accumulate(hipStream_t s, int P, const float* viewspace_grad, const float* normal_grad,
                                const int* radii, const float* weights, float* xyz_accum, float* normal_accum,
-                               float* denom, float* weights_accum, float* max_radii2D)
+                               float* denom, float* weights_accum, float* max_radii2D, const float* skip_flag)
 {
     densify_accumulate_kernel<<<(P + 255) / 256, 256, 0, s>>>(P, viewspace_grad, normal_grad, radii, weights, xyz_accum,
-                                                              normal_accum, denom, weights_accum, max_radii2D);
+                                                              normal_accum, denom, weights_accum, max_radii2D, skip_flag);
     check_launch(s, false, "densify_accumulate_kernel");
 }
 

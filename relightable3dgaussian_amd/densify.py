@@ -66,8 +66,10 @@ class DensificationStats:
     def column(self, name):
         return getattr(self, name).view(-1, 1)
 
-    def add(self, viewspace_grad, normal_grad, radii, weights):
-        """One view's contribution.  viewspace_grad [P,3] = gradient slot of the screen-space dummy, normal_grad [P,3] =
+    def add(self, viewspace_grad, normal_grad, radii, weights, skip_flag=None):
+        """`skip_flag`: float32 device tensor; non-zero (read on the device) = this view was dropped by a bounded forward and
+        is no observation.
+        One view's contribution.  viewspace_grad [P,3] = gradient slot of the screen-space dummy, normal_grad [P,3] =
         gradient of the raw normals (or None), radii int32 [P], weights [P,1] | [P] from the rasterizer."""
         P = self.P
         _need_device(viewspace_grad, "viewspace_grad")
@@ -84,7 +86,8 @@ class DensificationStats:
             st = L.r3dg_densify_accumulate(
                 _lib.current_stream(), P, viewspace_grad.data_ptr(), _lib.ptr(normal_grad), radii.data_ptr(),
                 weights.data_ptr(), self.xyz_gradient_accum.data_ptr(), self.normal_gradient_accum.data_ptr(),
-                self.denom.data_ptr(), self.weights_accum.data_ptr(), self.max_radii2D.data_ptr())
+                self.denom.data_ptr(), self.weights_accum.data_ptr(), self.max_radii2D.data_ptr(),
+                skip_flag.data_ptr() if skip_flag is not None else None)
         _lib.check(st, "densify_accumulate")
 
     def all_reduce(self, group=None):

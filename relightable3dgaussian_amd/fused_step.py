@@ -86,7 +86,63 @@ class FusedAdam:
 PARAM_NAMES = ("xyz", "normal", "scaling", "rotation", "opacity", "shs", "base_color", "roughness", "incidents", "env")
 
 
-class FusedStage2Step:
+class _BoundedForward:
+    """Host side of the bounded rasterizer forward (r3dg_rasterize_forward_begin_bounded), shared by the fused iterations:
+    capacity bookkeeping, the pinned ring the counts go to, and the poll that notices dropped views."""
+
+    def _init_bounded(self, bounded, flag):
+        self.bounded = bool(bounded)
+        self._flag = flag                          # 4 floats inside the gradient slab (summed by the first all-reduce)
+        self._capacity = None                      # instance slots of the bounded forward (None: not known yet)
+        self._overflow_count = torch.zeros(1, dtype=torch.int32, device=self.dev)
+        self._overflow_seen = 0
+        self.dropped_steps = 0
+        self._iter = 0
+        self._geom = None
+        self._count_ring = torch.zeros(4096, dtype=torch.int64)                 # num_rendered of the last iterations
+        if self.dev.type == "cuda":
+            self._count_ring = self._count_ring.pin_memory()
+
+    @staticmethod
+    def _capacity_for(R):
+        return int(min(2 ** 31 - 1, max(2 * int(R), int(R) + (1 << 20))))
+
+    def _note_count(self, geom, R, used_bounded):
+        """After a forward: remember the state buffer and send the count to the ring without waiting for it."""
+        self._geom = geom
+        slot = self._count_ring[(self._iter - 1) % self._count_ring.numel()]
+        if used_bounded:
+            slot.copy_(rasterizer_ops.num_rendered_of(geom, self.P), non_blocking=True)
+        else:
+            slot.fill_(int(R))
+            if self.bounded:
+                self._capacity = self._capacity_for(R)
+
+    def poll_overflow(self):
+        """Did the device drop a view since the last call?  (One 4-byte read-back; synchronises.)  If so the capacity is
+        doubled -- at least to twice the count that did not fit -- the dropped iterations are counted in `dropped_steps`
+        and taken back from Adam's step count."""
+        if not self.bounded or self._capacity is None:
+            return 0
+        count = int(self._overflow_count.item())
+        new = count - self._overflow_seen
+        if new > 0:
+            self._overflow_seen = count
+            self.dropped_steps += new
+            self.opt.step_count = max(0, self.opt.step_count - new)
+            needed = int(rasterizer_ops.num_rendered_of(self._geom, self.P).item())
+            self._capacity = self._capacity_for(max(needed, self._capacity))
+        return new
+
+    def rendered_counts(self, n=1):
+        """num_rendered of the last `n` iterations (python ints, oldest first).  Synchronises: a bounded forward never
+        hands the count to the host on its own; last_outs[0] is then the CAPACITY the state buffers were laid out for."""
+        torch.cuda.synchronize(self.dev)
+        n = max(0, min(int(n), self._iter, self._count_ring.numel()))
+        return [int(self._count_ring[(self._iter - 1 - k) % self._count_ring.numel()]) for k in range(n - 1, -1, -1)]
+
+
+class FusedStage2Step(_BoundedForward):
     """Owns the raw parameters (copied from a bench_core.GaussianParams) and runs whole iterations."""
 
     def __init__(self, params, sample_num, lr=1e-4, lr_rest_scale=1.0, loss_weights=None, process_group=None,
@@ -149,17 +205,9 @@ class FusedStage2Step:
             else:
                 self.grads[k] = self.grad_flat[o:o + sizes[k]].view_as(getattr(self, k))
             o += pad4(sizes[k])
-        self.bounded = bool(bounded)
-        self._capacity = None                       # instance slots of the bounded forward (None: not known yet)
-        self._overflow_count = torch.zeros(1, dtype=torch.int32, device=dev)
-        self._overflow_seen = 0
-        self.dropped_steps = 0
+        self._init_bounded(bounded, self._flag)
         self._skip = torch.zeros(2, 4, **f)        # per-iteration snapshots of the (reduced) flag for the Adam launches
         self._skip_cur = None
-        self._iter = 0
-        self._count_ring = torch.zeros(4096, dtype=torch.int64)                 # num_rendered of the last iterations
-        if dev.type == "cuda":
-            self._count_ring = self._count_ring.pin_memory()
         # three all-reduce buckets (world > 1): A = SH colour grads, final right after the rasterizer backward (reduced
         # under the shading backward); C = the small per-Gaussian groups, final after the activation chain rule;
         # B = incident-light grads, final after the shading backward -- reduced LAST and only waited for right before
@@ -299,8 +347,6 @@ class FusedStage2Step:
                 self.sums[3].data_ptr()), "stage2_pack_features")
             fw = pending.finish(self._order_stream)
             R, n_contrib, image, opacity, depth, feature, pseudo_normal, sxyz, weights, radii, geom, binning, img = fw
-            if self.bounded and not use_bounded:
-                self._capacity = self._capacity_for(R)
             # the Adam launches of this iteration skip themselves when the view was dropped; under data parallelism they
             # read a snapshot of the flag taken after bucket A's all-reduce (optimizer_step)
             self._skip_cur = self._flag if self.world <= 1 else self._skip[self._iter & 1]
@@ -387,12 +433,7 @@ class FusedStage2Step:
         self.viewspace_grad = dL_dmeans2D
         # a bounded forward returned its capacity as R (the backward's layout); the count itself goes to a pinned ring
         # without anybody waiting for it (rendered_counts)
-        self._geom = geom
-        slot = self._count_ring[(self._iter - 1) % self._count_ring.numel()]
-        if use_bounded:
-            slot.copy_(rasterizer_ops.num_rendered_of(geom, P), non_blocking=True)
-        else:
-            slot.fill_(int(R))
+        self._note_count(geom, R, use_bounded)
         self.last_outs = (R, n_contrib, image, opacity, depth, feature, pseudo_normal, sxyz, weights, radii)
         self._N = N
         return self.last_outs
@@ -401,33 +442,6 @@ class FusedStage2Step:
         if self.world <= 1:
             return None
         return torch.distributed.all_reduce(flat, group=self.group, async_op=True)
-
-    @staticmethod
-    def _capacity_for(R):
-        return int(min(2 ** 31 - 1, max(2 * int(R), int(R) + (1 << 20))))
-
-    def poll_overflow(self):
-        """Host-side half of the bounded forward: did the device drop a view since the last call?  (One 4-byte read-back;
-        synchronises.)  If so the capacity is doubled -- at least to twice the count that did not fit -- the dropped
-        iterations are counted in `dropped_steps` and taken back from Adam's step count."""
-        if not self.bounded or self._capacity is None:
-            return 0
-        count = int(self._overflow_count.item())
-        new = count - self._overflow_seen
-        if new > 0:
-            self._overflow_seen = count
-            self.dropped_steps += new
-            self.opt.step_count = max(0, self.opt.step_count - new)
-            needed = int(rasterizer_ops.num_rendered_of(self._geom, self.P).item())
-            self._capacity = self._capacity_for(max(needed, self._capacity))
-        return new
-
-    def rendered_counts(self, n=1):
-        """num_rendered of the last `n` iterations (python ints, oldest first).  Synchronises: a bounded forward never
-        hands the count to the host on its own; last_outs[0] is then the CAPACITY the state buffers were laid out for."""
-        torch.cuda.synchronize(self.dev)
-        n = max(0, min(int(n), self._iter, self._count_ring.numel()))
-        return [int(self._count_ring[(self._iter - 1 - k) % self._count_ring.numel()]) for k in range(n - 1, -1, -1)]
 
     def loss(self):
         """Loss value of the last forward_backward (a 0-d tensor; costs a few tiny kernels, so it is on demand)."""
@@ -478,14 +492,17 @@ class FusedStage2Step:
         return outs
 
 
-class FusedStage1Step:
+class FusedStage1Step(_BoundedForward):
     """Stage-1 (plain 3DGS + normals) iteration without an autograd graph: activations -> S=5 feature row -> rasterize ->
     image-space loss + gradients -> rasterize backward -> activation chain rule -> one-launch Adam.  Same computation as
     bench_core.render_stage1 + loss_stage1 + torch.optim.Adam (the parity target, tests/test_fused_step_gpu.py);
     single-bucket gradient all-reduce under data parallelism."""
 
-    def __init__(self, params, lr=1e-4, lr_rest_scale=1.0, process_group=None, lrs=None, loss_weights=None):
-        """`lrs`: optional per-group learning rates {xyz, normal, scaling, rotation, opacity, shs, shs_rest} as in
+    def __init__(self, params, lr=1e-4, lr_rest_scale=1.0, process_group=None, lrs=None, loss_weights=None, bounded=True):
+        """`bounded`: as FusedStage2Step -- after the first iteration (and again after every densify / prune, which changes
+        the count) the rasterizer forward runs without the host read-back of num_rendered; a dropped view updates nothing
+        and adds nothing to the densification statistics.
+        `lrs`: optional per-group learning rates {xyz, normal, scaling, rotation, opacity, shs, shs_rest} as in
         GaussianModel.training_setup (gaussian_model.py:465-472); missing names use `lr` (`lr * lr_rest_scale` for the
         non-dc SH columns).  `loss_weights`: overrides of train_step.STAGE1_WEIGHTS (the lambdas of script/run_nerf.sh:7-14).
         `self.iteration` (the reference's 1-based iteration, advanced by __call__) drives the depth-variance schedule
@@ -517,6 +534,7 @@ class FusedStage1Step:
         self.stats = None                  # densification statistics (enable_densification)
         self.last_outs = None
         self._allocate()
+        self._init_bounded(bounded, self._flag)
 
     def _allocate(self):
         """Per-Gaussian work buffers for the current number of Gaussians (again after every densify / prune)."""
@@ -530,11 +548,13 @@ class FusedStage1Step:
         names = ("shs", "xyz", "normal", "scaling", "rotation", "opacity")
         sizes = {k: getattr(self, k).numel() for k in names}
         pad4 = lambda n: (n + 3) // 4 * 4         # every group starts on a 16-byte boundary (float4 accesses in the Adam kernel)
-        self.grad_flat = torch.zeros(sum(pad4(v) for v in sizes.values()), **f)
+        self.grad_flat = torch.zeros(sum(pad4(v) for v in sizes.values()) + 4, **f)
         self.grads, o = {}, 0
         for k in names:
             self.grads[k] = self.grad_flat[o:o + sizes[k]].view_as(getattr(self, k))
             o += pad4(sizes[k])
+        self._flag = self.grad_flat[o:o + 4]       # overflow flag of the bounded forward: reduced with the gradients
+        self._capacity = None                      # (a new Gaussian count means a new instance count: learn it again)
         self.last_outs = None
 
     # ---- densification (train.py:158-175; kernels in csrc/densify.hip, host mirror densify.py) ----------------------
@@ -626,10 +646,15 @@ class FusedStage1Step:
                 self.opacity.data_ptr(), self.normal.data_ptr(), None, None, None, self.a_scales.data_ptr(),
                 self.a_rot.data_ptr(), self.a_opacity.data_ptr(), self.a_normal.data_ptr(), None, None, None),
                 "stage2_activate")
+            self._iter += 1
+            use_bounded = self.bounded and self._capacity is not None
+            if not use_bounded:
+                self._flag.zero_()
             pending = rasterizer_ops.rasterize_gaussians_begin(
                 bg, self.xyz, self.features, empty, self.a_opacity, self.a_scales, self.a_rot, 1.0, empty, vm,
                 cam.full_proj_transform, cam.tanfovx, cam.tanfovy, cam.cx, cam.cy, H, W, self.shs, 3, campos, False,
-                True, False)
+                True, False, **(dict(capacity=self._capacity, overflow_flag=self._flag,
+                                     overflow_count=self._overflow_count) if use_bounded else {}))
             _lib.check(L.r3dg_stage1_pack_features(stream(), P, self.xyz.data_ptr(), vm.data_ptr(),
                                                    self.a_normal.data_ptr(), self.features.data_ptr()),
                        "stage1_pack_features")
@@ -668,16 +693,18 @@ class FusedStage1Step:
                 gr["xyz"].data_ptr(), gr["scaling"].data_ptr(), gr["rotation"].data_ptr(), gr["opacity"].data_ptr(),
                 gr["normal"].data_ptr()), "stage1_activate_backward")
             if self.stats is not None:           # this view's densification statistics, from the LOCAL gradients
-                self.stats.add(dL_dmeans2D, gr["normal"], radii, weights)
+                self.stats.add(dL_dmeans2D, gr["normal"], radii, weights, skip_flag=self._flag)
             self._handle = None
             if self.world > 1:
                 self._handle = torch.distributed.all_reduce(self.grad_flat, group=self.group, async_op=True)
         self.viewspace_grad = dL_dmeans2D
+        self._note_count(geom, R, use_bounded)
         self.last_outs = (R, n_contrib, image, opacity, depth, feature, pseudo_normal, sxyz, weights, radii)
         self._N = N
         return self.last_outs
 
     def loss(self):
+        self.poll_overflow()
         N = self._N
         lam = LAMBDA_DSSIM
         w_l1, w_ent, w_nrm, w_smooth, w_var = self._weights(N)
@@ -686,7 +713,7 @@ class FusedStage1Step:
 
     def optimizer_step(self):
         self._drain()
-        self.opt.step([self.grads[k] for k in self._opt_order], 1.0 / self.world)
+        self.opt.step([self.grads[k] for k in self._opt_order], 1.0 / self.world, skip_flag=self._flag)
 
     def flush(self):
         pass

@@ -387,3 +387,50 @@ def test_bounded_iteration_that_overflows_is_dropped_not_applied():
     assert step.poll_overflow() == 0
     assert not torch.equal(step.xyz, before["xyz"])
     assert step.rendered_counts(1)[0] > 0
+
+
+def test_bounded_stage1_iterations_equal_two_phase_iterations():
+    """FusedStage1Step(bounded=True) vs bounded=False: same losses, same parameters (up to the order of float atomics), same
+    densification statistics; a view that does not fit updates neither parameters nor statistics."""
+    from relightable3dgaussian_amd import synthetic as syn
+    from relightable3dgaussian_amd.bench_core import GaussianParams, render_stage1
+    from relightable3dgaussian_amd.fused_step import FusedStage1Step
+    P, res = 5000, 128
+    cam = syn.orbit_cameras(8, width=res, height=res)[3].to(DEV)
+    bg = torch.tensor([0.2, 0.9, 0.4], device=DEV)
+    with torch.no_grad():
+        teacher = GaussianParams(syn.make_scene(P=P, seed=21, stage2=False, scale_log_mean=-3.2), DEV, False)
+        teacher.features_dc.add_(0.2 * torch.randn_like(teacher.features_dc))
+        gt = render_stage1(teacher, cam, bg)[2].clone()
+    runs = {}
+    for bounded in (False, True):
+        params = GaussianParams(syn.make_scene(P=P, seed=21, stage2=False, scale_log_mean=-3.2), DEV, False)
+        step = FusedStage1Step(params, bounded=bounded)
+        step.enable_densification()
+        losses = []
+        for it in range(5):
+            outs = step(cam, bg, gt)
+            losses.append(float(step.loss()))
+        assert step.dropped_steps == 0
+        counts = step.rendered_counts(5)
+        assert (outs[0] == step._capacity) if bounded else (outs[0] == counts[-1])
+        runs[bounded] = (losses, step.xyz.clone(), step.shs.clone(), step.stats.denom.clone(),
+                         step.stats.xyz_gradient_accum.clone(), counts)
+    assert np.allclose(runs[False][0], runs[True][0], rtol=2e-5), (runs[False][0], runs[True][0])
+    assert runs[False][5] == runs[True][5]
+    assert torch.equal(runs[False][3], runs[True][3])
+    for i in (1, 2, 4):
+        ok, msg = report("stage-1 tensor %d" % i, runs[True][i], runs[False][i], 1e-4, 1e-7)
+        assert ok, msg
+    # overflow: nothing moves
+    step._capacity = runs[True][5][-1] - 3
+    before = (step.xyz.clone(), step.shs.clone(), step.stats.denom.clone(), step.stats.weights_accum.clone())
+    n_steps = step.opt.step_count
+    step(cam, bg, gt)
+    torch.cuda.synchronize()
+    assert torch.equal(step.xyz, before[0]) and torch.equal(step.shs, before[1])
+    assert torch.equal(step.stats.denom, before[2]) and torch.equal(step.stats.weights_accum, before[3])
+    assert step.poll_overflow() == 1 and step.opt.step_count == n_steps and step._capacity >= 2 * runs[True][5][-1]
+    step(cam, bg, gt)
+    torch.cuda.synchronize()
+    assert step.poll_overflow() == 0 and not torch.equal(step.xyz, before[0])
