@@ -190,7 +190,7 @@ def test_c_abi_argument_validation_without_a_gpu():
     assert b"null" in L.r3dg_last_error()
     assert L.r3dg_densify_plan(None, -1, C.addressof(cfg), 1, 1, 1, 1, 1, 1, 1, 1, 1, C.addressof(counts), 1) == EINVAL
     assert L.r3dg_densify_accumulate(None, 8, None, None, 1, 1, 1, 1, 1, 1, 1, None) == EINVAL
-    assert L.r3dg_densify_accumulate(None, 0, None, None, None, None, None, None, None, None, None) == 0      # P == 0
+    assert L.r3dg_densify_accumulate(None, 0, None, None, None, None, None, None, None, None, None, None) == 0      # P == 0
     grp = (D.DensifyGroup * 1)(D.DensifyGroup(1, None, None, 1, None, None, 4, 1))     # role xyz with 4-float rows
     assert L.r3dg_densify_gather(None, 8, 1, 1, 1, C.cast(grp, C.c_void_p), 1, 1, 1, None, 1.6) == EINVAL
     assert b"xyz rows" in L.r3dg_last_error()
