@@ -97,6 +97,10 @@ class _BoundedForward:
         self._overflow_count = torch.zeros(1, dtype=torch.int32, device=self.dev)
         self._overflow_seen = 0
         self.dropped_steps = 0
+        # data parallel: a step is dropped on EVERY rank when any rank's view did not fit; each rank counts those steps from
+        # the reduced flag (identical everywhere), so Adam's step counts stay in lockstep
+        self._dropped_dev = torch.zeros(1, dtype=torch.int32, device=self.dev)
+        self._dropped_seen = 0
         self._iter = 0
         self._geom = None
         self._count_ring = torch.zeros(4096, dtype=torch.int64)                 # num_rendered of the last iterations
@@ -118,20 +122,31 @@ class _BoundedForward:
             if self.bounded:
                 self._capacity = self._capacity_for(R)
 
+    def _count_dropped_step(self, reduced_flag):
+        """(world > 1, after the all-reduce that carries the flag) one more dropped step if any rank raised it."""
+        self._dropped_dev += (reduced_flag[:1] != 0).to(torch.int32)
+
     def poll_overflow(self):
-        """Did the device drop a view since the last call?  (One 4-byte read-back; synchronises.)  If so the capacity is
-        doubled -- at least to twice the count that did not fit -- the dropped iterations are counted in `dropped_steps`
-        and taken back from Adam's step count."""
+        """Did the device drop a view since the last call?  (One 4-byte read-back; synchronises.)  If THIS rank's view did
+        not fit, its capacity is doubled -- at least to twice the count that did not fit; every dropped iteration (under
+        data parallelism: dropped on all ranks together) is counted in `dropped_steps` and taken back from Adam's step
+        count.  Returns the number of newly dropped iterations."""
         if not self.bounded or self._capacity is None:
             return 0
         count = int(self._overflow_count.item())
-        new = count - self._overflow_seen
-        if new > 0:
+        new_local = count - self._overflow_seen
+        if new_local > 0:
             self._overflow_seen = count
-            self.dropped_steps += new
-            self.opt.step_count = max(0, self.opt.step_count - new)
             needed = int(rasterizer_ops.num_rendered_of(self._geom, self.P).item())
             self._capacity = self._capacity_for(max(needed, self._capacity))
+        new = new_local
+        if getattr(self, "world", 1) > 1:
+            total = int(self._dropped_dev.item())
+            new = total - self._dropped_seen
+            self._dropped_seen = total
+        if new > 0:
+            self.dropped_steps += new
+            self.opt.step_count = max(0, self.opt.step_count - new)
         return new
 
     def rendered_counts(self, n=1):
@@ -473,6 +488,8 @@ class FusedStage2Step(_BoundedForward):
         self.opt.begin_step()
         handle_a.wait()
         self._skip_cur.copy_(self._flag)            # > 0 on every rank when any rank dropped its view
+        if self.bounded:
+            self._count_dropped_step(self._skip_cur)
         self.opt.step_groups(self._GROUPS_A, grads, scale, skip_flag=self._skip_cur)
         handle_c.wait()
         self.opt.step_groups(self._GROUPS_C, grads, scale, skip_flag=self._skip_cur)
@@ -713,6 +730,8 @@ class FusedStage1Step(_BoundedForward):
 
     def optimizer_step(self):
         self._drain()
+        if self.world > 1 and self.bounded:
+            self._count_dropped_step(self._flag)
         self.opt.step([self.grads[k] for k in self._opt_order], 1.0 / self.world, skip_flag=self._flag)
 
     def flush(self):

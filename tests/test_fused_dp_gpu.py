@@ -185,3 +185,51 @@ def test_bench_gpus_2_rccl():
     r, doc = _bench(["--gpus", "2"] + SMALL, {"R3DG_DIST_BACKEND": "nccl"})
     assert r.returncode == 0, r.stderr[-3000:]
     assert doc["n_gpus"] == 2 and doc["value"] > 0
+
+
+def _overflow_worker(rank, world, port, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    params, cams, bg, gts, K, FusedStage2Step = _make(dev)
+    step = FusedStage2Step(params, K, lr=1e-3, bounded=True)
+    step(cams[rank], bg, gts[rank])                      # two-phase iteration: learns the count
+    step.flush()
+    n = step.rendered_counts(1)[0]
+    if rank == 1:
+        step._capacity = n - 7                           # rank 1's next view will not fit; rank 0's will
+    before = {k: getattr(step, k).detach().clone() for k in ("xyz", "shs", "incidents", "env")}
+    steps_before, cap_before = step.opt.step_count, step._capacity
+    step(cams[rank], bg, gts[rank])
+    step.flush()
+    torch.cuda.synchronize()
+    unchanged = all(torch.equal(getattr(step, k), v) for k, v in before.items())
+    dropped = step.poll_overflow()
+    grew = step._capacity > cap_before and step._capacity >= 2 * n
+    step(cams[rank], bg, gts[rank])                      # trains again
+    step.flush()
+    torch.cuda.synchronize()
+    pars = {k: getattr(step, k).detach().cpu().clone() for k in ("xyz", "shs", "incidents", "env")}
+    torch.save(dict(unchanged=unchanged, dropped=dropped, grew=grew, steps=(steps_before, step.opt.step_count),
+                    moved=not torch.equal(step.xyz, before["xyz"]), pars=pars, later=step.poll_overflow()),
+               os.path.join(out_dir, "ovf%d.pt" % rank))
+    dist.destroy_process_group()
+
+
+def test_a_view_that_does_not_fit_on_one_rank_drops_the_step_on_all_ranks(tmp_path):
+    """Bounded forward under data parallelism: the overflow flag rides in the first all-reduce bucket, so when ONE rank's
+    view needs more instance slots than it has, EVERY rank's Adam launches skip the step, every rank takes it back from its
+    step count, only the rank concerned grows its capacity, and the replicas stay bit-identical."""
+    mp.spawn(_overflow_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    r0 = torch.load(os.path.join(tmp_path, "ovf0.pt"))
+    r1 = torch.load(os.path.join(tmp_path, "ovf1.pt"))
+    for r in (r0, r1):
+        assert r["unchanged"], "a dropped step updated parameters"
+        assert r["dropped"] == 1 and r["later"] == 0 and r["moved"]
+        assert r["steps"][1] == r["steps"][0] + 1        # three iterations launched, one dropped
+    assert r1["grew"] and not r0["grew"]
+    for k in r0["pars"]:
+        assert torch.equal(r0["pars"][k], r1["pars"][k]), "replicas diverged: " + k
