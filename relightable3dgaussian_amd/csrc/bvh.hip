@@ -110,7 +110,8 @@ scatter_leaves_kernel(int P, const uint64_t* __restrict__ keys_sorted, const uin
 
 // Karras internal nodes (construct.cu:54-145, 203-229)
 __global__ void __launch_bounds__(256)
-internal_nodes_kernel(int P, const uint64_t* __restrict__ code, int32_t* __restrict__ nodes)
+internal_nodes_kernel(int P, const uint64_t* __restrict__ code, int32_t* __restrict__ nodes, int2* __restrict__ ranges,
+                      int* __restrict__ nonzero_count_seen)
 {
     const int idx = blockIdx.x * 256 + threadIdx.x;
     if (idx >= P - 1) return;
@@ -177,12 +178,17 @@ internal_nodes_kernel(int P, const uint64_t* __restrict__ code, int32_t* __restr
     node[3] = -1;
     nodes[5 * (size_t)left] = idx;
     nodes[5 * (size_t)right] = idx;
+    ranges[idx] = make_int2(first, last);                  // the leaves below this node (range_boxes_kernel)
+    if (node[4] != 0) atomicOr(nonzero_count_seen, 1);     // caller-initialised leaf counter (bvh/__init__.py:29-57 puts 0)
 }
 
 // bottom-up merge (construct.cu:231-264) with explicit release/acquire around the arrival flag
 __global__ void __launch_bounds__(256)
-merge_boxes_kernel(int P, int32_t* __restrict__ nodes, float* __restrict__ aabbs, int* __restrict__ flags)
+merge_boxes_kernel(int P, int32_t* __restrict__ nodes, float* __restrict__ aabbs, int* __restrict__ flags,
+                   const int* __restrict__ nonzero_count_seen)
 {
+    // (only for a node table whose internal leaf counters were not zero on entry: the counters then depend on the walk)
+    if (nonzero_count_seen != nullptr && *nonzero_count_seen == 0) return;
     const int j = blockIdx.x * 256 + threadIdx.x;
     if (j >= P) return;
     int idx = P - 1 + j;
@@ -209,6 +215,76 @@ merge_boxes_kernel(int P, int32_t* __restrict__ nodes, float* __restrict__ aabbs
         idx = parent;
         parent = nodes[5 * (size_t)parent];
     }
+}
+
+// ---- boxes of the internal nodes without inter-thread synchronisation ----------------------------------------------------------
+// The reference walks up from every leaf; the second thread to arrive at a node merges its children's boxes
+// (construct.cu:231-264).  That needs a release/acquire pair per level and thread, and on this part a device-scope fence is
+// an L2 write-back + invalidate across the 8 XCDs: merge_boxes_kernel below spends 2.06 ms on 300k leaves, 93 % of it
+// waiting.  But the box of a node is just min / max over the leaves of its RANGE [first, last] (Karras ranges are
+// contiguous in Morton order), and min / max give the same bits in any order.  So: boxes of aligned runs of 256 leaves and
+// of 256 such runs (two tiny tables), then every internal node reduces its range from at most 2 x 255 leaves + 2 x 255 runs
+// + the super-runs between them -- independent threads, no atomics, no fences.  The leaf counter of the node table
+// (column 4: the reference adds the children's counters into whatever the caller put there) is last - first + 1 when the
+// caller's internal rows hold 0 as the reference's own RayTracer prepares them; any other initial content is detected on
+// the device and routed through the reference-shaped walk.
+constexpr int BOX_RUN = 256;
+
+__device__ __forceinline__ void box_include(float (&b)[6], const float* __restrict__ o)
+{
+#pragma unroll
+    for (int a = 0; a < 3; a++) {
+        b[a] = fminf(b[a], o[a]);
+        b[3 + a] = fmaxf(b[3 + a], o[3 + a]);
+    }
+}
+
+// level 0 -> 1: one thread per run of 256 consecutive boxes (n boxes in, ceil(n/256) out)
+__global__ void __launch_bounds__(256)
+run_boxes_kernel(int n, const float* __restrict__ in, float* __restrict__ out)
+{
+    __shared__ float s_b[4][6];
+    const int run = blockIdx.x, i = run * BOX_RUN + threadIdx.x;
+    float b[6] = {3.0e38f, 3.0e38f, 3.0e38f, -3.0e38f, -3.0e38f, -3.0e38f};
+    if (i < n) box_include(b, in + 6 * (size_t)i);
+#pragma unroll
+    for (int a = 0; a < 6; a++) {
+        float v = b[a];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const float w = __shfl_xor(v, o, 64);
+            v = a < 3 ? fminf(v, w) : fmaxf(v, w);
+        }
+        if ((threadIdx.x & 63) == 0) s_b[threadIdx.x >> 6][a] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < 6) {
+        const int a = threadIdx.x;
+        const float v0 = s_b[0][a], v1 = s_b[1][a], v2 = s_b[2][a], v3 = s_b[3][a];
+        out[6 * (size_t)run + a] = a < 3 ? fminf(fminf(v0, v1), fminf(v2, v3)) : fmaxf(fmaxf(v0, v1), fmaxf(v2, v3));
+    }
+}
+
+__global__ void __launch_bounds__(256)
+range_boxes_kernel(int P, const int2* __restrict__ ranges, const float* __restrict__ leaf /* Morton order */,
+                   const float* __restrict__ run1, const float* __restrict__ run2, const int* __restrict__ nonzero_count_seen,
+                   int32_t* __restrict__ nodes, float* __restrict__ aabbs)
+{
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= P - 1) return;
+    const int2 r = ranges[idx];
+    int i = r.x;
+    const int last = r.y;
+    float b[6] = {3.0e38f, 3.0e38f, 3.0e38f, -3.0e38f, -3.0e38f, -3.0e38f};
+    // leaves up to the next run boundary, whole runs up to the next super-run boundary, whole super-runs, and down again
+    while (i <= last && (i % BOX_RUN) != 0) { box_include(b, leaf + 6 * (size_t)i); i++; }
+    while (i + BOX_RUN - 1 <= last && ((i / BOX_RUN) % BOX_RUN) != 0) { box_include(b, run1 + 6 * (size_t)(i / BOX_RUN)); i += BOX_RUN; }
+    while (i + BOX_RUN * BOX_RUN - 1 <= last) { box_include(b, run2 + 6 * (size_t)(i / (BOX_RUN * BOX_RUN))); i += BOX_RUN * BOX_RUN; }
+    while (i + BOX_RUN - 1 <= last) { box_include(b, run1 + 6 * (size_t)(i / BOX_RUN)); i += BOX_RUN; }
+    while (i <= last) { box_include(b, leaf + 6 * (size_t)i); i++; }
+#pragma unroll
+    for (int a = 0; a < 6; a++) aabbs[6 * (size_t)idx + a] = b[a];
+    if (*nonzero_count_seen == 0) nodes[5 * (size_t)idx + 4] = last - r.x + 1;
 }
 
 // ---- traversal ----
@@ -1039,10 +1115,22 @@ void bvh_build(hipStream_t s, int P, int32_t* nodes, float* aabbs, uint64_t* mor
     scatter_leaves_kernel<<<g, 256, 0, s>>>(P, k_out, v_out, leaf_copy, aabbs, nodes, morton);
     check_launch(s, false, "bvh scatter_leaves");
     if (P > 1) {
-        internal_nodes_kernel<<<(P - 1 + 255) / 256, 256, 0, s>>>(P, morton, nodes);
+        R3DG_HIP(hipMemsetAsync(flags, 0, (size_t)P * 4 + 4, s));
+        int* nonzero_count_seen = flags + P;
+        int2* ranges = reinterpret_cast<int2*>(k_in);                    // (the unsorted keys are dead after the sort)
+        internal_nodes_kernel<<<(P - 1 + 255) / 256, 256, 0, s>>>(P, morton, nodes, ranges, nonzero_count_seen);
         check_launch(s, false, "bvh internal_nodes");
-        R3DG_HIP(hipMemsetAsync(flags, 0, (size_t)P * 4, s));
-        merge_boxes_kernel<<<g, 256, 0, s>>>(P, nodes, aabbs, flags);
+        // run tables in the (equally dead) unsorted-value buffer: ceil(P/256) + ceil(P/65536) boxes of 24 bytes <= 4 P bytes
+        float* run1 = reinterpret_cast<float*>(v_in);
+        const int n1 = (P + BOX_RUN - 1) / BOX_RUN, n2 = (n1 + BOX_RUN - 1) / BOX_RUN;
+        float* run2 = run1 + 6 * (size_t)n1;
+        const float* leaf_sorted = aabbs + 6 * (size_t)(P - 1);
+        run_boxes_kernel<<<n1, 256, 0, s>>>(P, leaf_sorted, run1);
+        run_boxes_kernel<<<n2, 256, 0, s>>>(n1, run1, run2);
+        range_boxes_kernel<<<(P - 1 + 255) / 256, 256, 0, s>>>(P, ranges, leaf_sorted, run1, run2, nonzero_count_seen, nodes,
+                                                              aabbs);
+        check_launch(s, false, "bvh range_boxes");
+        merge_boxes_kernel<<<g, 256, 0, s>>>(P, nodes, aabbs, flags, nonzero_count_seen);
         check_launch(s, false, "bvh merge_boxes");
     }
 }

@@ -143,3 +143,28 @@ def test_trace_formulations_give_identical_results(P, seed, K):
     for mode in (2, 3, 4):
         assert torch.equal(got[mode][0], got[0][0]), "visibility differs in mode %d" % mode
         assert torch.equal(got[mode][1], got[0][1]), "hit counts differ in mode %d" % mode
+
+
+@pytest.mark.parametrize("P", [2, 700, 70_000])
+def test_bvh_build_with_caller_initialised_leaf_counters(P):
+    """The reference ADDS the children's leaf counters into column 4 of whatever node table it is handed
+    (construct.cu:246-262); its own RayTracer hands zeros, which the build answers from the Karras ranges without any
+    inter-thread synchronisation.  Any other content takes the reference-shaped walk: same table as the oracle either way,
+    same boxes in both."""
+    from oracle import bvh as ob
+    from relightable3dgaussian_amd import bvh as B, bvh_ops
+    sc, dirs, cinv, rays_o = _bvh_case(P, 17, K=4, dup=True)
+    nodes0, aabbs0 = ob.leaf_boxes(sc["xyz"].numpy(), sc["scales"].numpy(), sc["rotations"].numpy())
+    got = {}
+    for init in (0, 3):
+        n_in = nodes0.copy()
+        n_in[:P - 1, 4] = init
+        n_ref, a_ref, m_ref = ob.create_bvh(n_in.copy(), aabbs0.copy())
+        nodes, aabbs = B.leaf_boxes(sc["xyz"].to(DEV), sc["scales"].to(DEV), sc["rotations"].to(DEV))
+        nodes[:P - 1, 4] = init
+        tree, box, morton = bvh_ops.create_bvh(sc["xyz"].to(DEV), sc["scales"].to(DEV), sc["rotations"].to(DEV), nodes, aabbs)
+        torch.cuda.synchronize()
+        assert np.array_equal(tree.cpu().numpy(), n_ref), "node table differs (initial counter %d)" % init
+        assert np.array_equal(box.cpu().numpy(), a_ref), "boxes differ (initial counter %d)" % init
+        got[init] = box.clone()
+    assert torch.equal(got[0], got[3])
