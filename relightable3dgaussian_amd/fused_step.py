@@ -99,8 +99,8 @@ class _BoundedForward:
         self.dropped_steps = 0
         # data parallel: a step is dropped on EVERY rank when any rank's view did not fit; each rank counts those steps from
         # the reduced flag (identical everywhere), so Adam's step counts stay in lockstep
-        self._dropped_dev = torch.zeros(1, dtype=torch.int32, device=self.dev)
-        self._dropped_seen = 0
+        self._skip = torch.zeros(self._SKIP_RING, 4, dtype=torch.float32, device=self.dev)   # snapshots of the reduced flag
+        self._skip_polled = 0                      # iterations [1, _skip_polled] are accounted for
         self._iter = 0
         self._geom = None
         self._count_ring = torch.zeros(4096, dtype=torch.int64)                 # num_rendered of the last iterations
@@ -122,9 +122,15 @@ class _BoundedForward:
             if self.bounded:
                 self._capacity = self._capacity_for(R)
 
-    def _count_dropped_step(self, reduced_flag):
-        """(world > 1, after the all-reduce that carries the flag) one more dropped step if any rank raised it."""
-        self._dropped_dev += (reduced_flag[:1] != 0).to(torch.int32)
+    _SKIP_RING = 1024
+
+    def _snapshot_flag(self):
+        """(world > 1, after the all-reduce that carries the flag) this iteration's REDUCED flag, kept in a ring: what the
+        iteration's Adam launches read (the slab's slot is rewritten by the next forward while a deferred update may still
+        be pending) and what poll_overflow counts the dropped steps from -- one 16-byte copy, nothing else per step."""
+        slot = self._skip[self._iter % self._SKIP_RING]
+        slot.copy_(self._flag)
+        return slot
 
     def poll_overflow(self):
         """Did the device drop a view since the last call?  (One 4-byte read-back; synchronises.)  If THIS rank's view did
@@ -141,9 +147,10 @@ class _BoundedForward:
             self._capacity = self._capacity_for(max(needed, self._capacity))
         new = new_local
         if getattr(self, "world", 1) > 1:
-            total = int(self._dropped_dev.item())
-            new = total - self._dropped_seen
-            self._dropped_seen = total
+            lo = max(self._skip_polled, self._iter - self._SKIP_RING)          # (older snapshots were overwritten)
+            idx = torch.arange(lo + 1, self._iter + 1, device=self.dev) % self._SKIP_RING
+            new = int((self._skip[idx, 0] != 0).sum().item()) if idx.numel() else 0
+            self._skip_polled = self._iter
         if new > 0:
             self.dropped_steps += new
             self.opt.step_count = max(0, self.opt.step_count - new)
@@ -221,7 +228,6 @@ class FusedStage2Step(_BoundedForward):
                 self.grads[k] = self.grad_flat[o:o + sizes[k]].view_as(getattr(self, k))
             o += pad4(sizes[k])
         self._init_bounded(bounded, self._flag)
-        self._skip = torch.zeros(2, 4, **f)        # per-iteration snapshots of the (reduced) flag for the Adam launches
         self._skip_cur = None
         # three all-reduce buckets (world > 1): A = SH colour grads, final right after the rasterizer backward (reduced
         # under the shading backward); C = the small per-Gaussian groups, final after the activation chain rule;
@@ -364,7 +370,7 @@ class FusedStage2Step(_BoundedForward):
             R, n_contrib, image, opacity, depth, feature, pseudo_normal, sxyz, weights, radii, geom, binning, img = fw
             # the Adam launches of this iteration skip themselves when the view was dropped; under data parallelism they
             # read a snapshot of the flag taken after bucket A's all-reduce (optimizer_step)
-            self._skip_cur = self._flag if self.world <= 1 else self._skip[self._iter & 1]
+            self._skip_cur = self._flag            # (world > 1: replaced by the reduced snapshot in optimizer_step)
             # image-space loss terms and their gradients.  One slab: dL_dimage 3 | dL_dopacity 1 | dL_dfeature 16 | sRGB PBR
             # image 3 | SSIM partials 2x9 | SSIM gradients 2x3 (the depth image carries no loss)
             g = torch.empty((47, H, W), dtype=torch.float32, device=dev)
@@ -487,9 +493,7 @@ class FusedStage2Step(_BoundedForward):
         handle_a, handle_c, handle_b = self._handles
         self.opt.begin_step()
         handle_a.wait()
-        self._skip_cur.copy_(self._flag)            # > 0 on every rank when any rank dropped its view
-        if self.bounded:
-            self._count_dropped_step(self._skip_cur)
+        self._skip_cur = self._snapshot_flag()      # > 0 on every rank when any rank dropped its view
         self.opt.step_groups(self._GROUPS_A, grads, scale, skip_flag=self._skip_cur)
         handle_c.wait()
         self.opt.step_groups(self._GROUPS_C, grads, scale, skip_flag=self._skip_cur)
@@ -730,9 +734,8 @@ class FusedStage1Step(_BoundedForward):
 
     def optimizer_step(self):
         self._drain()
-        if self.world > 1 and self.bounded:
-            self._count_dropped_step(self._flag)
-        self.opt.step([self.grads[k] for k in self._opt_order], 1.0 / self.world, skip_flag=self._flag)
+        skip = self._snapshot_flag() if (self.world > 1 and self.bounded) else self._flag
+        self.opt.step([self.grads[k] for k in self._opt_order], 1.0 / self.world, skip_flag=skip)
 
     def flush(self):
         pass
