@@ -1,4 +1,7 @@
 cd /root/repo
-timeout 900 python -m pytest tests/test_rasterizer_gpu.py -m gpu -x -q -p no:cacheprovider 2>&1 | tail -3
-ITERS=10 python tools/kbench_raster.py 2>&1 | tail -1
-S=28 ITERS=6 python tools/kbench_raster.py 2>&1 | tail -1
+for d in 0 1 0 1; do
+R3DG_DEFER_B=$d python bench.py --steps 40 --warmup 8 --no-cpu-baseline --relight-frames 0 --no-other-configs --repeats 4 2>/dev/null | python -c "
+import json,sys
+d=json.loads(sys.stdin.readlines()[-1]); k=d['kernels']
+print('defer=$d', d['spread_iters_per_s']['min'], d['spread_iters_per_s']['median'], d['spread_iters_per_s']['max'], d['ms_per_step'])"
+done
