@@ -465,8 +465,17 @@ def run(args):
     if getattr(args, "plumbing_only", False):
         return _plumbing_only(args, world, rank, backend)
     dev_index = local_rank % max(1, torch.cuda.device_count()) if world > 1 else 0
-    if world > 1:
+    # R3DG_DP_SINGLE_RANK=1: a ONE-rank process group whose iteration still takes the data-parallel path
+    # (fused_step._world_of) -- the RCCL calls of `--gpus N` exercised on a box with one GPU; the collectives are identities
+    dp = world > 1 or os.environ.get("R3DG_DP_SINGLE_RANK") == "1"
+    if dp:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        if world == 1 and "MASTER_PORT" not in os.environ:           # not under a launcher: rendezvous with ourselves
+            import socket
+            with socket.socket() as sock:
+                sock.bind(("127.0.0.1", 0))
+                port = sock.getsockname()[1]
+            os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1")
         torch.cuda.set_device(dev_index)
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index))
@@ -521,8 +530,8 @@ def run(args):
     gt_views = list(gts.keys())
     reducer = None
     if world > 1 and not fused:
-        from . import dp
-        reducer = dp.GradAllReducer(params.parameters())     # bucketed async all-reduce, overlaps the backward tail
+        from . import dp as dp_autograd
+        reducer = dp_autograd.GradAllReducer(params.parameters())     # bucketed async all-reduce, overlaps the backward tail
 
     R_seen = []
 
@@ -553,7 +562,7 @@ def run(args):
     for i in range(args.warmup):
         one_step(i)
     torch.cuda.synchronize()
-    if world > 1:
+    if dp:
         dist.barrier()
     L.r3dg_profile_enable(0 if os.environ.get("R3DG_BENCH_NOPROFILE") else 1)
     torch.cuda.synchronize()
@@ -566,7 +575,7 @@ def run(args):
     if fused:
         step_fn.flush()                  # (world > 1) the last iteration's deferred incident-light update
     torch.cuda.synchronize()
-    if world > 1:
+    if dp:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
@@ -577,7 +586,7 @@ def run(args):
         dropped = step_fn.poll_overflow()
         if dropped:
             raise RuntimeError("bench: %d timed iterations were dropped by the bounded forward (capacity too small)" % dropped)
-    if world > 1:
+    if dp:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -658,6 +667,6 @@ def run(args):
                 result["cpu_baseline"] = {"value": None, "unit": "views/s (rasterize forward)", "cores": None, "kind": "port",
                                           "sample": "failed: %r" % (e,)}
         print(json.dumps(result))
-    if world > 1:
+    if dp:
         dist.destroy_process_group()
     return result

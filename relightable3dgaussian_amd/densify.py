@@ -18,6 +18,7 @@ identical: the standard-normal table is drawn with `torch.randn(n_split * n_sele
 reference would draw, in the same order -- and scaled by the Gaussian's own scale inside the gather kernel.
 """
 import ctypes as C
+import os
 
 import torch
 
@@ -94,7 +95,9 @@ class DensificationStats:
         """Data parallel: make the statistics (and hence every densify decision) identical on all ranks -- one sum over
         the four accumulators and one max over the radii."""
         import torch.distributed as dist
-        if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        if not (dist.is_available() and dist.is_initialized()):
+            return
+        if dist.get_world_size(group) == 1 and os.environ.get("R3DG_DP_SINGLE_RANK") != "1":     # (fused_step._world_of)
             return
         h = dist.all_reduce(self._slab[:4], group=group, async_op=True)
         dist.all_reduce(self._slab[4], op=dist.ReduceOp.MAX, group=group)

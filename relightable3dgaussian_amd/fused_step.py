@@ -19,6 +19,7 @@ concatenates features_dc / features_rest and incidents_dc / incidents_rest every
 `features_dc` etc. are exposed as views, and the Adam kernel applies the dc / rest learning rates by column.
 The parity target is the unfused path (tests/test_fused_step_gpu.py compares loss and every gradient)."""
 import ctypes as C
+import os
 
 import torch
 import torch.nn.functional as F
@@ -86,6 +87,19 @@ class FusedAdam:
 PARAM_NAMES = ("xyz", "normal", "scaling", "rotation", "opacity", "shs", "base_color", "roughness", "incidents", "env")
 
 
+def _world_of(process_group):
+    """-> (world size, run the data-parallel path?).  The data-parallel path (bucketed async all-reduces, reduced skip
+    flag, deferred incident-light update) runs whenever the group has more than one rank -- and, for a smoke test of the
+    RCCL calls on a box with ONE GPU (RCCL refuses two ranks on one device), also on a one-rank group when
+    R3DG_DP_SINGLE_RANK=1: the collectives are then identities and the result must equal the plain single-GPU iteration
+    bit for bit (tests/test_fused_dp_gpu.py)."""
+    td = torch.distributed
+    if not (td.is_available() and td.is_initialized()):
+        return 1, False
+    world = td.get_world_size(process_group)
+    return world, world > 1 or os.environ.get("R3DG_DP_SINGLE_RANK") == "1"
+
+
 class _BoundedForward:
     """Host side of the bounded rasterizer forward (r3dg_rasterize_forward_begin_bounded), shared by the fused iterations:
     capacity bookkeeping, the pinned ring the counts go to, and the poll that notices dropped views."""
@@ -146,7 +160,7 @@ class _BoundedForward:
             needed = int(rasterizer_ops.num_rendered_of(self._geom, self.P).item())
             self._capacity = self._capacity_for(max(needed, self._capacity))
         new = new_local
-        if getattr(self, "world", 1) > 1:
+        if getattr(self, "dp", False):
             lo = max(self._skip_polled, self._iter - self._SKIP_RING)          # (older snapshots were overwritten)
             idx = torch.arange(lo + 1, self._iter + 1, device=self.dev) % self._SKIP_RING
             new = int((self._skip[idx, 0] != 0).sum().item()) if idx.numel() else 0
@@ -249,8 +263,7 @@ class FusedStage2Step(_BoundedForward):
         # fits beside it spills 35 registers and slows both (2.13 -> 2.20 ms/step).  Off by default.
         self._side = torch.cuda.Stream(device=dev) if overlap_geometry else None
         self.group = process_group
-        self.world = torch.distributed.get_world_size(process_group) if (
-            torch.distributed.is_available() and torch.distributed.is_initialized()) else 1
+        self.world, self.dp = _world_of(process_group)
         with torch.no_grad():
             self.refresh_activations()
             self.visibility, self.incident_dirs, self.incident_areas, self.tracer = update_visibility(
@@ -405,7 +418,7 @@ class FusedStage2Step(_BoundedForward):
             if self._side is None:
                 handle_a = self._allreduce_async(self._bucket_a)     # travels under the shading backward
             self._early = False
-            if early_adam and self.world <= 1:
+            if early_adam and not self.dp:
                 # Adam of the SH group on a side stream, behind the geometry backward that produces its gradient
                 side = self._side
                 if side is None:
@@ -447,7 +460,7 @@ class FusedStage2Step(_BoundedForward):
                 stream(), He, We, self.env.data_ptr(), env_c.data_ptr(), d_env.data_ptr(), self.w["env_smooth"],
                 gr["env"].data_ptr(), self.sums[4].data_ptr(), 1), "stage2_env_backward")
             self._handles = None
-            if self.world > 1:
+            if self.dp:
                 handle_c = self._allreduce_async(self._bucket_c)
                 handle_b = self._allreduce_async(self._bucket_b)
                 self._handles = (handle_a, handle_c, handle_b)
@@ -460,7 +473,7 @@ class FusedStage2Step(_BoundedForward):
         return self.last_outs
 
     def _allreduce_async(self, flat):
-        if self.world <= 1:
+        if not self.dp:
             return None
         return torch.distributed.all_reduce(flat, group=self.group, async_op=True)
 
@@ -480,7 +493,7 @@ class FusedStage2Step(_BoundedForward):
 
     def optimizer_step(self):
         grads = [self.grads[k] for k in self._opt_order]
-        if self.world <= 1:
+        if not self.dp:
             if self._early:              # the SH group was updated under the shading backward (forward_backward)
                 torch.cuda.current_stream().wait_stream(self._early_stream)
                 self.opt.step_groups(self._GROUPS_C + self._GROUPS_B, grads, skip_flag=self._skip_cur)
@@ -542,8 +555,7 @@ class FusedStage1Step(_BoundedForward):
         self.M = self.shs.shape[1]
         self._zero_depth_grad = None
         self.group = process_group
-        self.world = torch.distributed.get_world_size(process_group) if (
-            torch.distributed.is_available() and torch.distributed.is_initialized()) else 1
+        self.world, self.dp = _world_of(process_group)
         lrs = dict(lrs or {})
         rate = lambda k: float(lrs.get(k, lr))
         rest = float(lrs.get("shs_rest", rate("shs") * lr_rest_scale))
@@ -716,7 +728,7 @@ class FusedStage1Step(_BoundedForward):
             if self.stats is not None:           # this view's densification statistics, from the LOCAL gradients
                 self.stats.add(dL_dmeans2D, gr["normal"], radii, weights, skip_flag=self._flag)
             self._handle = None
-            if self.world > 1:
+            if self.dp:
                 self._handle = torch.distributed.all_reduce(self.grad_flat, group=self.group, async_op=True)
         self.viewspace_grad = dL_dmeans2D
         self._note_count(geom, R, use_bounded)
@@ -734,7 +746,7 @@ class FusedStage1Step(_BoundedForward):
 
     def optimizer_step(self):
         self._drain()
-        skip = self._snapshot_flag() if (self.world > 1 and self.bounded) else self._flag
+        skip = self._snapshot_flag() if (self.dp and self.bounded) else self._flag
         self.opt.step([self.grads[k] for k in self._opt_order], 1.0 / self.world, skip_flag=skip)
 
     def flush(self):

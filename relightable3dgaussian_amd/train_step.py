@@ -5,6 +5,7 @@ dataset / logging machinery:
     calculate_loss (core terms)          gaussian_renderer/neilf.py:212-318
 Everything heavy runs in the HIP ops; the glue is plain PyTorch on the same stream."""
 import math
+import os
 
 import torch
 import torch.nn.functional as F
@@ -40,6 +41,8 @@ def update_visibility(xyz, scales, rotations, opacity, normal, sample_num, group
     world = rank = None
     if dist.is_available() and dist.is_initialized():
         world, rank = dist.get_world_size(group), dist.get_rank(group)
+    # a one-rank group takes the all-gather path only for the single-GPU RCCL smoke test (fused_step._world_of)
+    gather = bool(world) and (world > 1 or os.environ.get("R3DG_DP_SINGLE_RANK") == "1")
     if not world or world == 1:
         world, rank = 1, 0
     tracer = (tracer_cls or RayTracer)(xyz, scales, rotations)
@@ -67,7 +70,7 @@ def update_visibility(xyz, scales, rotations, opacity, normal, sample_num, group
         d = dirs_all[sel]
         res = tracer.trace_visibility(xyz[sel][:, None].expand_as(d), d, xyz, cinv, op, normal)
         vis_mine[a:a + sel.numel()] = res["visibility"]
-    if world == 1:
+    if not gather:
         full = torch.empty(P, sample_num, 1, dtype=torch.float32, device=xyz.device)
         full[order] = vis_mine
         return full, dirs_all, areas_all, tracer

@@ -233,3 +233,92 @@ def test_a_view_that_does_not_fit_on_one_rank_drops_the_step_on_all_ranks(tmp_pa
     assert r1["grew"] and not r0["grew"]
     for k in r0["pars"]:
         assert torch.equal(r0["pars"][k], r1["pars"][k]), "replicas diverged: " + k
+
+
+def _single_rank_rccl_worker(rank, world, port, out_dir):
+    """One rank, backend nccl (= RCCL): with R3DG_DP_SINGLE_RANK=1 the iteration takes the data-parallel path -- three
+    async all-reduce buckets on RCCL's stream, the reduced skip flag, the deferred incident-light update, the all-gather
+    of update_visibility, the statistics all-reduce of the densification -- with collectives that are identities."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), R3DG_DP_SINGLE_RANK="1")
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    params, cams, bg, gts, K, FusedStage2Step = _make(dev)
+    step = FusedStage2Step(params, K, lr=1e-3, loss_weights={"normal": 0.01})
+    assert step.world == 1 and step.dp
+    for i in range(4):                       # iteration 1 learns the count, 2..4 run the bounded forward
+        step(cams[i % 2], bg, gts[i % 2])
+        assert step._pending_b is not None   # the incident-light bucket stays in flight into the next iteration
+    step.flush()
+    torch.cuda.synchronize()
+    out = {k: getattr(step, k).detach().cpu().clone() for k in ("xyz", "shs", "incidents", "env", "opacity", "base_color")}
+    out["visibility"] = step.visibility.cpu()
+    out["dropped"] = step.poll_overflow()
+    out["steps"] = step.opt.step_count
+    # stage 1 with a densification: one bucket, statistics reduced before the decisions
+    from relightable3dgaussian_amd import synthetic as syn
+    from relightable3dgaussian_amd.bench_core import GaussianParams
+    from relightable3dgaussian_amd.fused_step import FusedStage1Step
+    p1 = GaussianParams(syn.make_scene(P=2500, seed=11, stage2=False, scale_log_mean=-3.2), dev, False)
+    s1 = FusedStage1Step(p1, lr=1e-3)
+    assert s1.dp
+    s1.enable_densification()
+    for i in range(3):
+        s1(cams[i % 2], bg, gts[i % 2])
+    info = s1.densify_and_prune(1e-7, 0.005, 2.6, 20, 1e9, percent_dense=0.03,
+                                generator=torch.Generator(device=dev).manual_seed(77))
+    s1(cams[0], bg, gts[0])
+    torch.cuda.synchronize()
+    out["s1_xyz"], out["s1_rows"] = s1.xyz.detach().cpu().clone(), info["rows_out"]
+    torch.save(out, os.path.join(out_dir, "rccl1.pt"))
+    dist.destroy_process_group()
+
+
+def test_single_rank_rccl_path_equals_the_plain_iteration(tmp_path):
+    """The RCCL calls of the data-parallel path on the one GPU of the test box (RCCL refuses two ranks on one device, so the
+    two-rank tests above use gloo): a one-rank nccl group, R3DG_DP_SINGLE_RANK=1.  Every collective is an identity, so four
+    iterations must leave the parameters the plain single-GPU iteration leaves (up to the order of the float atomics)."""
+    mp.spawn(_single_rank_rccl_worker, args=(1, _free_port(), str(tmp_path)), nprocs=1, join=True)
+    got = torch.load(os.path.join(tmp_path, "rccl1.pt"))
+    assert got["dropped"] == 0 and got["steps"] == 4
+    dev = torch.device("cuda", 0)
+    params, cams, bg, gts, K, FusedStage2Step = _make(dev)
+    plain = FusedStage2Step(params, K, lr=1e-3, loss_weights={"normal": 0.01})
+    assert not plain.dp
+    start = {k: getattr(plain, k).detach().cpu().clone() for k in ("xyz", "shs", "incidents", "env", "opacity", "base_color")}
+    for i in range(4):
+        plain(cams[i % 2], bg, gts[i % 2])
+    torch.cuda.synchronize()
+    assert torch.equal(got["visibility"], plain.visibility.cpu())
+    # (the per-Gaussian gradient sums are float atomics: two runs agree up to their order, and Adam turns a sign flip of a
+    # rounding-level gradient into a step of 2 lr -- so: all but a sliver of the elements equal to 1e-5, none off by more
+    # than the 4 steps could move it; a bucket that was not reduced / waited for / applied fails both by a wide margin)
+    for k in ("xyz", "shs", "incidents", "env", "opacity", "base_color"):
+        a, b = got[k], getattr(plain, k).detach().cpu()
+        diff = (a - b).abs()
+        assert torch.isfinite(a).all() and float(diff.max()) <= 4 * 2e-3, (k, float(diff.max()))
+        assert float((diff > 1e-5).float().mean()) < 0.05, "RCCL path differs from the plain iteration: " + k
+        assert not torch.equal(a, start[k]), k + " did not train"
+    from relightable3dgaussian_amd import synthetic as syn
+    from relightable3dgaussian_amd.bench_core import GaussianParams
+    from relightable3dgaussian_amd.fused_step import FusedStage1Step
+    p1 = GaussianParams(syn.make_scene(P=2500, seed=11, stage2=False, scale_log_mean=-3.2), dev, False)
+    s1 = FusedStage1Step(p1, lr=1e-3)
+    s1.enable_densification()
+    for i in range(3):
+        s1(cams[i % 2], bg, gts[i % 2])
+    info = s1.densify_and_prune(1e-7, 0.005, 2.6, 20, 1e9, percent_dense=0.03,
+                                generator=torch.Generator(device=dev).manual_seed(77))
+    s1(cams[0], bg, gts[0])
+    torch.cuda.synchronize()
+    assert info["rows_out"] > 2500 and abs(info["rows_out"] - got["s1_rows"]) <= 0.01 * info["rows_out"]
+    assert got["s1_xyz"].shape[0] == got["s1_rows"] and torch.isfinite(got["s1_xyz"]).all()
+
+
+def test_bench_single_rank_over_rccl():
+    """`bench.py` with a one-rank RCCL group around the data-parallel iteration (barriers, max-over-ranks reduction of the
+    elapsed time, destroy_process_group included)."""
+    r, doc = _bench(["--gpus", "1"] + SMALL, {"R3DG_DIST_BACKEND": "nccl", "R3DG_DP_SINGLE_RANK": "1"})
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert doc["n_gpus"] == 1 and doc["value"] > 0
