@@ -1,0 +1,115 @@
+"""the reference's OWN `train.py`, byte for byte, run end to end across this repo's extension
+boundary -- in this container, where /root/reference exists and no GPU does, so the three extension modules are backed by
+the CPU oracle (tools/run_reference.py --cpu-oracle; tests/reference_cpu_backend.py).  What this proves is the seam, not
+the kernels (those are pinned on the GPU by tests/test_reference_gpu.py and test_reference_pipeline_gpu.py): the module
+names, call signatures, tuple layouts, opaque state buffers, dtype / shape conventions and the data formats either side
+(Blender-format dataset written by synthetic.write_blender_dataset, `points3d.ply`, `chkpnt*.pth`) are what an unmodified
+reference checkout needs -- through create_from_pcd (distCUDA2), the training loop with densify_and_prune / reset_opacity /
+Adam, checkpoint capture, then stage 2 (`-t neilf -c chkpnt`): create_from_ckpt, update_visibility (create_bvh +
+trace_bvh_opacity), the shading integral, env light, and this repo's checkpoint reader on the files train.py wrote.
+Skipped where the reference tree is absent (the GPU box)."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+REF = "/root/reference"
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+pytestmark = pytest.mark.skipif(not os.path.isfile(os.path.join(REF, "train.py")), reason="needs the reference checkout")
+
+
+def _write_dataset(root, n_views=6, res=40, P=900):
+    """A Blender-format scene the reference's loader accepts: views of a small teacher scene rendered by the CPU oracle,
+    plus points3d.ply (so readNerfSyntheticInfo does not draw its 100 000 random points, dataset_readers.py:288-299)."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import reference_shims as shims
+    from oracle import rasterizer as orc
+    from relightable3dgaussian_amd import synthetic as syn
+    from tests.helpers import fwd_args
+    sc = syn.make_scene(P=P, seed=5, stage2=False, scale_log_mean=-2.4)
+    cams = syn.orbit_cameras(n_views, width=res, height=res)
+    images = []
+    for cam in cams:
+        case = dict(P=P, W=res, H=res, S=0, bg=torch.ones(3), means3D=sc["xyz"], features=torch.zeros(P, 0),
+                    opacity=sc["opacity"], scales=sc["scales"], rotations=sc["rotations"], shs=sc["shs"], degree=3, cam=cam,
+                    colors=None, cov3D=None)
+        out = orc.rasterize_gaussians(*fwd_args(case)[:-3])
+        images.append(torch.from_numpy(np.asarray(out[2], np.float32)).clamp(0, 1))
+    syn.write_blender_dataset(root, cams, images, split="train")
+    syn.write_blender_dataset(root, cams[:2], images[:2], split="test")
+    g = np.random.default_rng(3)
+    keep = g.permutation(P)[:600]
+    xyz = sc["xyz"].numpy()[keep] + 0.02 * g.standard_normal((600, 3)).astype(np.float32)
+    data = np.empty(600, dtype=[("x", "f4"), ("y", "f4"), ("z", "f4"), ("nx", "f4"), ("ny", "f4"), ("nz", "f4"),
+                                ("red", "u1"), ("green", "u1"), ("blue", "u1")])
+    nrm = sc["normal"].numpy()[keep]
+    for i, n in enumerate(("x", "y", "z")):
+        data[n], data["n" + n] = xyz[:, i], nrm[:, i]
+    rgb = (255 * g.random((600, 3))).astype(np.uint8)
+    data["red"], data["green"], data["blue"] = rgb[:, 0], rgb[:, 1], rgb[:, 2]
+    shims.PlyData([shims.PlyElement.describe(data, "vertex")]).write(os.path.join(root, "points3d.ply"))
+    return len(cams)
+
+
+def _run(args, timeout=900):
+    cmd = [sys.executable, os.path.join(ROOT, "tools", "run_reference.py"), "--reference", REF, "--cpu-oracle", "--"] + args
+    env = dict(os.environ, OMP_NUM_THREADS="4", PYTHONPATH=ROOT)
+    return subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, env=env, cwd=ROOT, stdin=subprocess.DEVNULL)
+
+
+def test_ply_stand_in_round_trip(tmp_path):
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import reference_shims as shims
+    data = np.zeros(5, dtype=[("x", "f4"), ("f_dc_0", "f4"), ("red", "u1")])
+    data["x"], data["f_dc_0"], data["red"] = np.arange(5), np.linspace(-1, 1, 5), [0, 1, 2, 254, 255]
+    for text in (False, True):
+        path = os.path.join(tmp_path, "t%d.ply" % text)
+        shims.PlyData([shims.PlyElement.describe(data, "vertex")], text=text).write(path)
+        back = shims.PlyData.read(path)
+        v = back["vertex"]
+        assert [p.name for p in back.elements[0].properties] == ["x", "f_dc_0", "red"]
+        assert np.array_equal(v["x"], data["x"]) and np.allclose(v["f_dc_0"], data["f_dc_0"]) and v["red"].dtype == np.uint8
+        assert np.array_equal(v["red"], data["red"])
+
+
+def test_reference_train_py_runs_unchanged_stage1_then_stage2(tmp_path):
+    data, out1, out2 = (os.path.join(tmp_path, d) for d in ("data", "stage1", "stage2"))
+    os.makedirs(data)
+    _write_dataset(data)
+    # stage 1 (script/run_nerf.sh:7-14 flags; a short schedule that still reaches densify_and_prune and reset_opacity)
+    r = _run(["train.py", "-s", data, "-m", out1, "--data_device", "cpu", "--lambda_normal_render_depth", "0.01",
+              "--lambda_normal_smooth", "0.01", "--lambda_mask_entropy", "0.1", "--lambda_depth_var", "1e-2",
+              "--iterations", "14", "--densify_from_iter", "3", "--densification_interval", "4",
+              "--opacity_reset_interval", "9", "--test_interval", "7", "--checkpoint_interval", "14", "--save_interval", "14",
+              "--save_training_vis", "--save_training_vis_iteration", "7"])
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    assert "Training complete." in r.stdout
+    ck1 = os.path.join(out1, "chkpnt14.pth")
+    assert os.path.isfile(ck1) and os.path.isfile(os.path.join(out1, "point_cloud", "iteration_14", "point_cloud.ply"))
+    assert os.path.isfile(os.path.join(out1, "visualize", "000007.png"))
+    from relightable3dgaussian_amd import checkpoint
+    st1 = checkpoint.restore(ck1)
+    assert st1.iteration == 14 and st1.xyz.shape[0] != 600, "densify_and_prune never changed the row count"
+    assert all(torch.isfinite(getattr(st1, k)).all() for k in ("xyz", "normal", "features_dc", "scaling", "opacity"))
+    assert st1.moments and st1.adam_steps > 0                        # the optimizer state train.py captured
+    # stage 2 (script/run_nerf.sh:20-39): from the stage-1 checkpoint, K = 16 rays per Gaussian
+    r = _run(["train.py", "-s", data, "-m", out2, "-c", ck1, "--data_device", "cpu", "-t", "neilf", "--sample_num", "16",
+              "--position_lr_init", "0.000016", "--position_lr_final", "0.00000016", "--normal_lr", "0.001", "--sh_lr",
+              "0.00025", "--opacity_lr", "0.005", "--scaling_lr", "0.0005", "--rotation_lr", "0.0001", "--iterations", "18",
+              "--lambda_base_color_smooth", "0", "--lambda_roughness_smooth", "0", "--lambda_light_smooth", "0",
+              "--lambda_light", "0.01", "--lambda_env_smooth", "0.01", "--test_interval", "1000", "--checkpoint_interval",
+              "18", "--save_interval", "18", "--save_training_vis", "--save_training_vis_iteration", "2",
+              # in the real schedule stage 2 starts at iteration 30001, past densify_until_iter (15000): the neilf render
+              # package has no 'weights' entry for add_densification_stats (train.py:161-162)
+              "--densify_until_iter", "10"])
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    assert "Training complete." in r.stdout
+    ck2 = os.path.join(out2, "chkpnt18.pth")
+    assert os.path.isfile(ck2) and os.path.isfile(os.path.join(out2, "env_light_chkpnt18.pth"))
+    st2 = checkpoint.restore(ck2)
+    assert st2.iteration == 18 and st2.xyz.shape[0] == st1.xyz.shape[0]          # (no densification in stage 2)
+    assert st2.base_color.shape == (st2.xyz.shape[0], 3) and st2.incidents_rest.shape[1:] == (15, 3)
+    assert float(st2.base_color.abs().max()) > 0 and float(st2.incidents_dc.abs().max()) > 0, "PBR groups never trained"
