@@ -92,7 +92,7 @@ def _world_of(process_group):
     flag, deferred incident-light update) runs whenever the group has more than one rank -- and, for a smoke test of the
     RCCL calls on a box with ONE GPU (RCCL refuses two ranks on one device), also on a one-rank group when
     R3DG_DP_SINGLE_RANK=1: the collectives are then identities and the result must equal the plain single-GPU iteration
-    bit for bit (tests/test_fused_dp_gpu.py)."""
+    up to the order of the float atomics (tests/test_fused_dp_gpu.py)."""
     td = torch.distributed
     if not (td.is_available() and td.is_initialized()):
         return 1, False
@@ -432,6 +432,22 @@ class FusedStage2Step(_BoundedForward):
                                          skip_flag=self._skip_cur)
                 self._early_stream = side
                 self._early = True
+            elif early_adam and handle_a is not None:
+                # data parallel: the same update on the side stream, behind bucket A's all-reduce -- whenever that lands
+                # while the shading backward is still running, the SH group's Adam runs under it too (measured with a
+                # one-rank RCCL group: 510 -> see DESIGN.md section 5).  The reduced overflow flag is snapshotted there,
+                # right after the all-reduce that carries it.
+                if self._adam_stream is None:
+                    self._adam_stream = torch.cuda.Stream(device=dev)
+                side = self._adam_stream
+                self.opt.begin_step()
+                with torch.cuda.stream(side):
+                    handle_a.wait()                       # the SIDE stream waits for RCCL's stream
+                    self._skip_cur = self._snapshot_flag()
+                    self.opt.step_groups(self._GROUPS_A, [self.grads[k] for k in self._opt_order], 1.0 / self.world,
+                                         skip_flag=self._skip_cur)
+                self._early_stream = side
+                self._early = True
             _lib.check(L.r3dg_stage2_unpack_gradients(
                 stream(), P, dL_dfeatures.data_ptr(), self.shade_out.data_ptr(), self.w["light"] / (3.0 * P),
                 self.d_pbr.data_ptr(), self.d_diffuse.data_ptr(), self._absmax.data_ptr()), "stage2_unpack_gradients")
@@ -504,10 +520,14 @@ class FusedStage2Step(_BoundedForward):
         # data parallel: update each bucket when its (sum) all-reduce has landed; 1/world is applied inside the kernel
         scale = 1.0 / self.world
         handle_a, handle_c, handle_b = self._handles
-        self.opt.begin_step()
-        handle_a.wait()
-        self._skip_cur = self._snapshot_flag()      # > 0 on every rank when any rank dropped its view
-        self.opt.step_groups(self._GROUPS_A, grads, scale, skip_flag=self._skip_cur)
+        if self._early:                  # bucket A was waited for and applied on the side stream (forward_backward)
+            torch.cuda.current_stream().wait_stream(self._early_stream)
+            self._early = False
+        else:
+            self.opt.begin_step()
+            handle_a.wait()
+            self._skip_cur = self._snapshot_flag()      # > 0 on every rank when any rank dropped its view
+            self.opt.step_groups(self._GROUPS_A, grads, scale, skip_flag=self._skip_cur)
         handle_c.wait()
         self.opt.step_groups(self._GROUPS_C, grads, scale, skip_flag=self._skip_cur)
         self._pending_b = (handle_b, grads, scale, self._skip_cur)

@@ -67,6 +67,15 @@ class RelightRenderer:
         # (no read-back of the matrix: the key is the tensor's identity + version counter)
         key = (None if tr is None else (tr.data_ptr(), tr._version), He, We, self.incident_dirs.data_ptr(),
                self.envmap.data_ptr(), self.envmap._version)
+        # A light that turns with EVERY frame (configs/nerf_syn_light, configs/tnt): writing the cache costs what the lookup
+        # inside the shading kernel costs and the kernel would then still have to read it back -- from the second
+        # consecutive change on, no cache: None = r3dg_shade_forward_cached evaluates the lookup itself (measured: 3.6 ms
+        # per frame with a rebuild).  A light that stops turning gets its cache on the next frame.
+        changed = getattr(self, "_light_key", None) != key
+        self._light_key = key
+        self._light_changes = (getattr(self, "_light_changes", 0) + 1) if changed else 0
+        if self._light_changes >= 2 and getattr(self, "_uniform_area", "unset") != "unset":
+            return None
         if getattr(self, "_taps_key", None) != key:
             # the HDR map is fixed while relighting, so the SAMPLED RADIANCE of every cached direction is cached (not just
             # the lookup coordinates): the shading kernel then reads 12 bytes per sample and no texture
@@ -112,7 +121,9 @@ class RelightRenderer:
                 self.a_viewdirs.data_ptr(), self.incidents.data_ptr(), self.envmap.data_ptr(), He, We, _lib.ptr(tr),
                 self.visibility.data_ptr(), self.incident_dirs.data_ptr(),
                 None if self._uniform_area is not None else self.incident_areas.data_ptr(), self._uniform_area or 0.0,
-                taps.data_ptr(), 2, self.shade_out.data_ptr()), "shade_forward")       # 2 = R3DG_SHADE_TAPS_ARE_RADIANCE
+                # 2 = R3DG_SHADE_TAPS_ARE_RADIANCE; no cache (a light that changes every frame): lookup in the kernel
+                taps.data_ptr() if taps is not None else None, 2 if taps is not None else 0,
+                self.shade_out.data_ptr()), "shade_forward")
             _lib.check(L.r3dg_relight_pack_features(
                 stream(), P, self.xyz.data_ptr(), vm.data_ptr(), self.a_normal.data_ptr(), self.a_base.data_ptr(),
                 self.a_rough.data_ptr(), self.shade_out.data_ptr(), self.features.data_ptr()), "relight_pack_features")

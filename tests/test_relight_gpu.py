@@ -54,6 +54,32 @@ def test_fused_frame_matches_pytorch_glue(res, with_transform):
     assert float((got["opacity"] < 0.5).float().mean()) > 0.05          # the environment is visible somewhere
 
 
+def test_a_light_that_turns_every_frame_takes_the_uncached_lookup_and_a_stopped_one_is_cached_again():
+    """RelightRenderer keeps ONE lookup cache (per light rotation).  A rotation that changes with every frame
+    (relighting.py:162-163 with a light_transform.json) stops building it from the second consecutive change on -- the
+    shading kernel evaluates the lookup itself -- and a light that stops gets its cache back: all frames equal the
+    PyTorch-glue frame."""
+    import math
+    from relightable3dgaussian_amd import synthetic as syn
+    r, relight = _renderer()
+    cam = syn.orbit_cameras(8, width=96, height=96)[2].to(DEV)
+    bg = torch.zeros(3, device=DEV)
+
+    def rot(a):
+        return torch.tensor([[math.cos(a), -math.sin(a), 0.0], [math.sin(a), math.cos(a), 0.0], [0.0, 0.0, 1.0]], device=DEV)
+    trs = [rot(0.1), rot(0.7), rot(1.3), rot(1.9)]
+    trs += [trs[-1], trs[-1]]                       # the light stops: cached again from the second repeat on
+    cached = []
+    for tr in trs:
+        got = r.frame(cam, bg, env_transform=tr, outputs=("pbr_env",))
+        cached.append(r._taps_key == r._light_key)
+        want = relight.frame_reference(r, cam, bg, env_transform=tr, exact_activations=True)
+        for k, rtol, atol in (("feature", 2e-5, 1e-6), ("pbr_env", 0.0, 2e-4)):
+            ok, msg = report(k, got[k], want[k], rtol, atol)
+            assert ok, msg
+    assert cached == [True, False, False, False, True, True], cached
+
+
 def test_feature_row_layout_and_errors():
     from relightable3dgaussian_amd import synthetic as syn
     r, relight = _renderer(P=500, K=8)
