@@ -205,6 +205,24 @@ int r3dg_shade_forward_cached(void* stream, int P, int K, int M, const float* d_
  * with R3DG_SHADE_TAPS_ARE_RADIANCE and the shading kernel touches no texture at all. */
 int r3dg_shade_build_taps(void* stream, int64_t num_samples, const float* d_incident_dirs, const float* d_env_transform,
                           int He, int We, const float* d_env_radiance, uint32_t* d_taps);
+/* Relighting under a FIXED light with static Gaussians (relighting.py:114-170 with configs/teaser, configs/nerf_syn: only the
+ * camera moves): the view-independent part of rendering_equation (neilf.py:339-371) as a cache.
+ * r3dg_shade_build_transport: d_radiance_inout [P*K*3] holds the sampled radiance of every cached direction
+ *   (r3dg_shade_build_taps with d_env_radiance) and is REWRITTEN IN PLACE with the sample's transport
+ *   (max(SH_incident(d), 0) + radiance * visibility) * area * max(n . d, 0); d_consts [P*16] receives per Gaussian
+ *   diffuse_light 3 | mean incident light 3 | mean local light 3 | mean global light 3 | mean visibility 1 | 3 unused.
+ *   Rebuild whenever the light, its rotation, the incident-light coefficients, the normals or the visibility cache change.
+ * r3dg_shade_forward_transport: the per-frame remainder -- the GGX lobe of every sample against the cached transport --
+ *   writes the same 19 columns per Gaussian as r3dg_shade_forward.  Directions: d_incident_dirs [P,K,3] as cached, or NULL
+ *   to regenerate them from the normal and d_zsamples [K,3], the Fibonacci set around +z (graphics_utils.py:9-37 before
+ *   the rotation; sh_utils.py:36-68): 12 instead of 24 bytes per sample. */
+int r3dg_shade_build_transport(void* stream, int P, int K, int M, const float* d_normals, const float* d_incidents,
+                               const float* d_visibility, const float* d_incident_dirs, const float* d_incident_areas,
+                               float uniform_area, float* d_radiance_inout, float* d_consts);
+int r3dg_shade_forward_transport(void* stream, int P, int K, const float* d_base_color, const float* d_roughness,
+                                 const float* d_normals, const float* d_viewdirs, const float* d_transport,
+                                 const float* d_consts, const float* d_zsamples, const float* d_incident_dirs,
+                                 float* d_out);
 int r3dg_shade_backward(void* stream, int P, int K, int M, const float* d_base_color, const float* d_roughness,
                         const float* d_normals, const float* d_viewdirs, const float* d_incidents, const float* d_env,
                         int He, int We, const float* d_env_transform, const float* d_visibility,

@@ -319,7 +319,10 @@ def relight_bench(params, cams, dev, frames, K):
     envmap = (3.0 * torch.rand(256, 512, 3, generator=g) ** 2).to(dev)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    renderer = relight.RelightRenderer(params, envmap, K)              # builds the BVH and traces P x K visibility rays
+    # (R3DG_RELIGHT_CACHE=transport: experiments with the opt-in view-independent cache of relight.RelightRenderer)
+    renderer = relight.RelightRenderer(params, envmap, K,             # builds the BVH and traces P x K visibility rays
+                                       cache=os.environ.get("R3DG_RELIGHT_CACHE", "radiance"),
+                                       regenerate_dirs=os.environ.get("R3DG_RELIGHT_DIRS", "regen") != "load")
     torch.cuda.synchronize()
     t_vis = time.perf_counter() - t0
     bg = torch.zeros(3, device=dev)

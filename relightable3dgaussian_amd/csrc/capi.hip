@@ -55,6 +55,12 @@ void launch_shade_forward(hipStream_t s, int P, int K, int M, const float* base_
                           bool leave_room);
 void launch_shade_build_taps(hipStream_t s, size_t n, const float* dirs, const float* tr, int He, int We, const float* env,
                              uint32_t* taps);
+void launch_shade_build_transport(hipStream_t s, int P, int K, int M, const float* normals, const float* incidents,
+                                  const float* visibility, const float* dirs, const float* areas, float uniform_area,
+                                  float* radiance_to_transport, float* consts);
+void launch_shade_forward_transport(hipStream_t s, int P, int K, const float* base_color, const float* roughness,
+                                    const float* normals, const float* viewdirs, const float* transport, const float* consts,
+                                    const float* zsamples, const float* dirs, float* out);
 extern int g_trace_packet, g_trace_refill, g_trace_node_weight, g_trace_leaf_weight;
 extern int g_shade_fwd_rows;
 extern int g_shade_bwd_rows;
@@ -1032,6 +1038,41 @@ int r3dg_shade_build_taps(void* stream_, int64_t num_samples, const float* incid
     return guarded([&]() -> int {
         launch_shade_build_taps((hipStream_t)stream_, (size_t)num_samples, incident_dirs, env_transform, He, We,
                                 env_radiance, taps);
+        return R3DG_OK;
+    });
+}
+
+int r3dg_shade_build_transport(void* stream_, int P, int K, int M, const float* normals, const float* incidents,
+                               const float* visibility, const float* incident_dirs, const float* incident_areas,
+                               float uniform_area, float* radiance_inout, float* consts)
+{
+    if (P < 0 || K <= 0) return invalid("shade_build_transport: bad P/K");
+    if (M != 1 && M != 4 && M != 9 && M != 16) return invalid("shade_build_transport: incidents must hold 1, 4, 9 or 16 SH coefficients");
+    if (P == 0) return R3DG_OK;
+    if (!normals || !incidents || !visibility || !incident_dirs || !radiance_inout || !consts)
+        return invalid("shade_build_transport: null buffer");
+    return guarded([&]() -> int {
+        launch_shade_build_transport((hipStream_t)stream_, P, K, M, normals, incidents, visibility, incident_dirs,
+                                     incident_areas, uniform_area, radiance_inout, consts);
+        return R3DG_OK;
+    });
+}
+
+int r3dg_shade_forward_transport(void* stream_, int P, int K, const float* base_color, const float* roughness,
+                                 const float* normals, const float* viewdirs, const float* transport, const float* consts,
+                                 const float* zsamples, const float* incident_dirs, float* out)
+{
+    if (P < 0 || K <= 0) return invalid("shade_forward_transport: bad P/K");
+    if (P == 0) return R3DG_OK;
+    if (!base_color || !roughness || !normals || !viewdirs || !transport || !consts || !out)
+        return invalid("shade_forward_transport: null buffer");
+    if (!zsamples && !incident_dirs) return invalid("shade_forward_transport: needs d_zsamples or d_incident_dirs");
+    return guarded([&]() -> int {
+        hipStream_t stream = (hipStream_t)stream_;
+        StageTimer t(stream, ST_SHADE_FWD);
+        launch_shade_forward_transport(stream, P, K, base_color, roughness, normals, viewdirs, transport, consts, zsamples,
+                                       incident_dirs, out);
+        t.stop();
         return R3DG_OK;
     });
 }

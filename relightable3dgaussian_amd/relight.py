@@ -12,7 +12,7 @@ import math
 import torch
 import torch.nn.functional as F
 
-from . import _lib, rasterizer_ops, shading_ops
+from . import _lib, rasterizer_ops, sampling, shading_ops
 from .train_step import rgb_to_srgb, update_visibility   # noqa: F401  (rgb_to_srgb: part of this module's surface)
 
 
@@ -33,7 +33,17 @@ class RelightRenderer:
     SH colour (`shs` or `features_dc`/`features_rest`) and incident light (`incidents` or `incidents_dc`/`_rest`) --
     bench_core.GaussianParams and fused_step.FusedStage2Step both do.  `envmap` [He,We,3] HDR (EnvLight.envmap)."""
 
-    def __init__(self, model, envmap, sample_num, process_group=None):
+    def __init__(self, model, envmap, sample_num, process_group=None, cache="radiance", regenerate_dirs=True):
+        """`cache` -- what is kept between frames while the light does not change:
+        "radiance" (default): the sampled environment radiance of every cached direction (12 bytes per sample);
+        "transport": the whole view-independent part of the integral -- per sample (local + global light) x area x n.d in
+            place of the radiance, per Gaussian diffuse_light and the mean light / visibility columns -- so that a frame
+            evaluates only the GGX lobe (r3dg_shade_forward_transport).  Valid while parameters, light and visibility are
+            unchanged, which is what this class assumes anyway (it snapshots the parameters).  `regenerate_dirs`: that
+            kernel rebuilds each direction from the normal and the Fibonacci table instead of reading the direction cache."""
+        if cache not in ("radiance", "transport"):
+            raise RuntimeError("RelightRenderer: cache must be 'radiance' or 'transport'")
+        self.cache, self.regenerate_dirs = cache, bool(regenerate_dirs)
         d = lambda t: t.detach().contiguous()
         self.xyz, self.normal = d(model.xyz), d(model.normal)
         self.scaling, self.rotation, self.opacity = d(model.scaling), d(model.rotation), d(model.opacity)
@@ -60,19 +70,27 @@ class RelightRenderer:
             self.visibility, self.incident_dirs, self.incident_areas, self.tracer = update_visibility(
                 self.xyz, self.a_scales, self.a_rot, self.a_opacity, self.a_normal, sample_num, group=process_group)
 
-    def _taps_for(self, tr, He, We):
+    def _taps_for(self, tr, He, We, given=None):
         """shading_ops.build_taps of the direction cache for this light rotation (None = identity); one entry is kept, so
-        a static light costs one build and a rotating light (relighting.py's light trajectories) one build per frame --
-        the same acos/atan2 the kernel would otherwise evaluate, written once instead of recomputed."""
-        # (no read-back of the matrix: the key is the tensor's identity + version counter)
-        key = (None if tr is None else (tr.data_ptr(), tr._version), He, We, self.incident_dirs.data_ptr(),
-               self.envmap.data_ptr(), self.envmap._version)
+        a static light costs one build.  `tr`: the rotation on the device, `given`: the caller's tensor it came from."""
+        # Identity of the light WITHOUT reading device memory back: a host tensor is keyed by its nine values; a device
+        # tensor by its storage address + version counter -- and a reference to it is kept for as long as it is the key, so
+        # that the allocator cannot hand the same address to the NEXT frame's matrix (relighting.py:162-163 builds a new
+        # tensor per frame: without the reference a recycled address would read as "the light did not move").
+        if tr is None:
+            ident = None
+        elif given is not None and not given.is_cuda:
+            ident = tuple(float(x) for x in given.detach().reshape(-1).tolist())
+        else:
+            ident = (tr.data_ptr(), tr._version)
+        key = (ident, He, We, self.incident_dirs.data_ptr(), self.envmap.data_ptr(), self.envmap._version)
         # A light that turns with EVERY frame (configs/nerf_syn_light, configs/tnt): writing the cache costs what the lookup
         # inside the shading kernel costs and the kernel would then still have to read it back -- from the second
         # consecutive change on, no cache: None = r3dg_shade_forward_cached evaluates the lookup itself (measured: 3.6 ms
-        # per frame with a rebuild, see DESIGN.md section 6).  A light that stops turning gets its cache on the next frame.
+        # per frame with a rebuild, 2.5 without; DESIGN.md section 6).  A light that stops turning gets its cache back on
+        # the next frame.
         changed = getattr(self, "_light_key", None) != key
-        self._light_key = key
+        self._light_key, self._light_ref = key, tr
         self._light_changes = (getattr(self, "_light_changes", 0) + 1) if changed else 0
         if self._light_changes >= 2 and getattr(self, "_uniform_area", "unset") != "unset":
             return None
@@ -80,12 +98,24 @@ class RelightRenderer:
             # the HDR map is fixed while relighting, so the SAMPLED RADIANCE of every cached direction is cached (not just
             # the lookup coordinates): the shading kernel then reads 12 bytes per sample and no texture
             self._taps = shading_ops.build_taps(self.incident_dirs, He, We, tr, radiance_of=self.envmap)
-            self._taps_key = key
+            self._taps_key, self._taps_ref = key, tr
             if getattr(self, "_area_key", None) != self.incident_areas.data_ptr():
                 # fibonacci_sphere_sampling gives every sample the area 2 pi: then the area cache need not be read at all
                 lo, hi = float(self.incident_areas.min()), float(self.incident_areas.max())
                 self._uniform_area = lo if lo == hi else None
                 self._area_key = self.incident_areas.data_ptr()
+            if self.cache == "transport":
+                # radiance -> transport in place, + the per-Gaussian constants (the buffer must not be handed to
+                # r3dg_shade_forward_cached any more: frame() takes the transport kernel whenever this cache is live)
+                if getattr(self, "_consts", None) is None:
+                    self._consts = torch.empty(self.P, 16, dtype=torch.float32, device=self.dev)
+                    self._zsamples = sampling.fibonacci_z_samples(self.K, self.dev)[0].t().contiguous()      # [K,3]
+                with torch.cuda.device(self.dev):
+                    _lib.check(_lib.lib().r3dg_shade_build_transport(
+                        _lib.current_stream(), self.P, self.K, self.M, self.a_normal.data_ptr(), self.incidents.data_ptr(),
+                        self.visibility.data_ptr(), self.incident_dirs.data_ptr(),
+                        None if self._uniform_area is not None else self.incident_areas.data_ptr(),
+                        self._uniform_area or 0.0, self._taps.data_ptr(), self._consts.data_ptr()), "shade_build_transport")
         return self._taps
 
     def _activate(self, campos):
@@ -97,6 +127,16 @@ class RelightRenderer:
                 self.a_opacity.data_ptr(), self.a_normal.data_ptr(), self.a_base.data_ptr(), self.a_rough.data_ptr(),
                 self.a_viewdirs.data_ptr())
         _lib.check(st, "stage2_activate")
+
+    def _shade_cached(self, L, stream, P, He, We, tr, taps):
+        _lib.check(L.r3dg_shade_forward_cached(
+            stream(), P, self.K, self.M, self.a_base.data_ptr(), self.a_rough.data_ptr(), self.a_normal.data_ptr(),
+            self.a_viewdirs.data_ptr(), self.incidents.data_ptr(), self.envmap.data_ptr(), He, We, _lib.ptr(tr),
+            self.visibility.data_ptr(), self.incident_dirs.data_ptr(),
+            None if self._uniform_area is not None else self.incident_areas.data_ptr(), self._uniform_area or 0.0,
+            # 2 = R3DG_SHADE_TAPS_ARE_RADIANCE; no cache (a light that changes every frame): lookup in the kernel
+            taps.data_ptr() if taps is not None else None, 2 if taps is not None else 0,
+            self.shade_out.data_ptr()), "shade_forward")
 
     @torch.no_grad()
     def frame(self, cam, bg, env_transform=None, outputs=("pbr_env",)):
@@ -115,15 +155,15 @@ class RelightRenderer:
         with torch.cuda.device(dev):
             self._activate(campos)
             # the lat-long lookups of the cached directions are constant for a fixed light rotation: cached per transform
-            taps = self._taps_for(tr, He, We)
-            _lib.check(L.r3dg_shade_forward_cached(
-                stream(), P, self.K, self.M, self.a_base.data_ptr(), self.a_rough.data_ptr(), self.a_normal.data_ptr(),
-                self.a_viewdirs.data_ptr(), self.incidents.data_ptr(), self.envmap.data_ptr(), He, We, _lib.ptr(tr),
-                self.visibility.data_ptr(), self.incident_dirs.data_ptr(),
-                None if self._uniform_area is not None else self.incident_areas.data_ptr(), self._uniform_area or 0.0,
-                # 2 = R3DG_SHADE_TAPS_ARE_RADIANCE; no cache (a light that changes every frame): lookup in the kernel
-                taps.data_ptr() if taps is not None else None, 2 if taps is not None else 0,
-                self.shade_out.data_ptr()), "shade_forward")
+            taps = self._taps_for(tr, He, We, env_transform)
+            if taps is not None and self.cache == "transport":
+                _lib.check(L.r3dg_shade_forward_transport(
+                    stream(), P, self.K, self.a_base.data_ptr(), self.a_rough.data_ptr(), self.a_normal.data_ptr(),
+                    self.a_viewdirs.data_ptr(), taps.data_ptr(), self._consts.data_ptr(), self._zsamples.data_ptr(),
+                    None if self.regenerate_dirs else self.incident_dirs.data_ptr(), self.shade_out.data_ptr()),
+                    "shade_forward_transport")
+            else:
+                self._shade_cached(L, stream, P, He, We, tr, taps)
             _lib.check(L.r3dg_relight_pack_features(
                 stream(), P, self.xyz.data_ptr(), vm.data_ptr(), self.a_normal.data_ptr(), self.a_base.data_ptr(),
                 self.a_rough.data_ptr(), self.shade_out.data_ptr(), self.features.data_ptr()), "relight_pack_features")

@@ -19,14 +19,19 @@ def rotation_between_z(vec):
     return torch.where((vec[..., 2] + 1 > 0)[..., None, None], R, eye)
 
 
-def fibonacci_sphere_sampling(normals, sample_num):
+def fibonacci_z_samples(sample_num, device):
+    """The Fibonacci set around +z before it is rotated to a normal: [1,3,K] (graphics_utils.py:14-24, random_rotate=False)."""
     delta = math.pi * (3.0 - math.sqrt(5.0))
-    idx = torch.arange(sample_num, dtype=torch.float32, device=normals.device)[None]
+    idx = torch.arange(sample_num, dtype=torch.float32, device=device)[None]
     z = (1 - 2 * idx / (2 * sample_num - 1)).clamp_min(math.sin(10 / 180 * math.pi))
     rad = torch.sqrt(1 - z ** 2)
     theta = delta * idx
     y, x = torch.cos(theta) * rad, torch.sin(theta) * rad
-    z_samples = torch.stack([x, y, z.expand_as(y)], dim=-2)                         # [1,3,K]
+    return torch.stack([x, y, z.expand_as(y)], dim=-2)
+
+
+def fibonacci_sphere_sampling(normals, sample_num):
+    z_samples = fibonacci_z_samples(sample_num, normals.device)                     # [1,3,K]
     dirs = rotation_between_z(normals) @ z_samples                                  # [P,3,K]
     dirs = F.normalize(dirs, dim=-2).transpose(-1, -2).contiguous()
     areas = torch.ones_like(dirs[..., 0:1]) * 2 * math.pi

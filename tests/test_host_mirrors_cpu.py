@@ -141,6 +141,91 @@ def test_fused_stage2_step_takes_the_reference_learning_rates(monkeypatch):
     assert torch.equal(step.opt.groups[step._opt_order.index("incidents")]["exp_avg"][:, 1:], r.moments["incidents_rest"][0])
 
 
+def test_relight_renderer_host_logic_with_a_recording_library(monkeypatch):
+    """RelightRenderer.frame's host side only (every C-ABI entry point replaced by a recorder, nothing runs on a GPU): which
+    shading entry point a frame takes and with which cache -- radiance cache (default), transport cache (opt-in), and no
+    cache once the light turns with every frame."""
+    import types
+    from relightable3dgaussian_amd import _lib, rasterizer_ops, relight, shading_ops
+    calls = []
+
+    class Recorder:
+        def __getattr__(self, name):
+            def fn(*args):
+                calls.append((name, args))
+                return 0
+            return fn
+
+    class DeviceTensor(torch.Tensor):            # a CPU tensor that claims to be a device tensor
+        is_cuda = property(lambda self: True)
+
+    dt = lambda t: t.as_subclass(DeviceTensor)
+    P, K = 7, 5
+    monkeypatch.setattr(_lib, "lib", lambda: Recorder())
+    monkeypatch.setattr(_lib, "current_stream", lambda: 0)
+    import contextlib
+    monkeypatch.setattr(torch.cuda, "device", lambda d: contextlib.nullcontext())
+    monkeypatch.setattr(relight, "update_visibility", lambda *a, **k: (torch.ones(P, K, 1), torch.ones(P, K, 3),
+                                                                       torch.full((P, K, 1), 2.0), None))
+    built = []
+    monkeypatch.setattr(shading_ops, "build_taps", lambda dirs, He, We, tr=None, radiance_of=None:
+                        built.append(tr) or torch.zeros(P * K * 3))
+    z = torch.zeros
+    monkeypatch.setattr(rasterizer_ops, "rasterize_gaussians", lambda *a: (3, z(1), z(3, 4, 4), z(1, 4, 4), z(1, 4, 4),
+                                                                           z(28, 4, 4), z(3, 4, 4), z(3, 4, 4), z(P, 1), z(P)))
+    model = types.SimpleNamespace(xyz=dt(z(P, 3)), normal=z(P, 3), scaling=z(P, 3), rotation=z(P, 4), opacity=z(P, 1),
+                                  base_color=z(P, 3), roughness=z(P, 1), shs=z(P, 16, 3), incidents=z(P, 16, 3))
+    cam = types.SimpleNamespace(image_height=4, image_width=4, world_view_transform=torch.eye(4), full_proj_transform=torch.eye(4),
+                                camera_center=z(3), tanfovx=0.5, tanfovy=0.5, cx=2.0, cy=2.0)
+    env = dt(z(8, 16, 3))
+    names = lambda: [c[0] for c in calls]
+    # default: radiance cache, built once for a fixed light
+    r = relight.RelightRenderer(model, env, K)
+    calls.clear()
+    for _ in range(3):
+        out = r.frame(cam, z(3))
+    assert len(built) == 1 and names().count("r3dg_shade_forward_cached") == 3 and "r3dg_shade_forward_transport" not in names()
+    cached = [c for c in calls if c[0] == "r3dg_shade_forward_cached"][-1][1]
+    assert cached[-2] == 2 and cached[-3] is not None and cached[16] == 2.0 and cached[15] is None     # radiance taps, uniform area
+    assert set(out) >= {"render", "feature", "pbr_env", "num_rendered"} and out["num_rendered"] == 3
+    # a light that turns with every frame: cache on the first change only, in-kernel lookup afterwards
+    calls.clear()
+    del built[:]
+    for i in range(4):
+        r.frame(cam, z(3), env_transform=torch.eye(3) * (1.0 + i))
+    flags = [c[1][-2] for c in calls if c[0] == "r3dg_shade_forward_cached"]
+    assert len(built) == 1 and flags == [2, 0, 0, 0], (len(built), flags)
+    # the same with DEVICE matrices built per frame (relighting.py:162-163): keyed by storage identity, and the renderer keeps
+    # the tensors it keyed on alive, so a recycled address cannot pass for "the light did not move"
+    r2 = relight.RelightRenderer(model, env, K)
+    calls.clear()
+    del built[:]
+    for i in range(6):
+        r2.frame(cam, z(3), env_transform=dt(torch.eye(3) * (1.0 + i)))
+    flags = [c[1][-2] for c in calls if c[0] == "r3dg_shade_forward_cached"]
+    assert len(built) == 1 and flags == [2, 0, 0, 0, 0, 0], (len(built), flags)
+    fixed = dt(torch.eye(3) * 9.0)
+    for i in range(3):
+        r2.frame(cam, z(3), env_transform=fixed)
+    flags = [c[1][-2] for c in calls if c[0] == "r3dg_shade_forward_cached"][6:]
+    assert len(built) == 2 and flags == [0, 2, 2], (len(built), flags)       # stopped: cached again from its second frame
+    # opt-in transport cache: one build (radiance -> transport in place + constants), then the transport kernel per frame
+    r = relight.RelightRenderer(model, env, K, cache="transport")
+    calls.clear()
+    for _ in range(3):
+        r.frame(cam, z(3))
+    n = names()
+    assert n.count("r3dg_shade_build_transport") == 1 and n.count("r3dg_shade_forward_transport") == 3
+    assert "r3dg_shade_forward_cached" not in n
+    tr_args = [c for c in calls if c[0] == "r3dg_shade_forward_transport"][0][1]
+    assert len(tr_args) == 12 and tr_args[1:3] == (P, K) and tr_args[10] is None and tr_args[9] == r._zsamples.data_ptr()
+    assert r._zsamples.shape == (K, 3) and r._consts.shape == (P, 16)
+    b_args = [c for c in calls if c[0] == "r3dg_shade_build_transport"][0][1]
+    assert len(b_args) == 12 and b_args[1:4] == (P, K, 16) and b_args[8] is None and b_args[9] == 2.0
+    with pytest.raises(RuntimeError):
+        relight.RelightRenderer(model, env, K, cache="everything")
+
+
 def test_committed_bench_line_follows_the_contract():
     """profiles/r02_bench_default.json is the line `python bench.py` printed on the MI355X: the keys the driver and the judge
     read are there, with the types and relations the contract states."""

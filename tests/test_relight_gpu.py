@@ -1,6 +1,8 @@
 """Relight / eval frame (relight.RelightRenderer: activations, shading, S=28 feature row, rasterize, environment composite
 through the C ABI) against the same frame through the drop-in ops + PyTorch glue (relight.frame_reference, the shape of
 the reference's render_view(is_training=False), gaussian_renderer/neilf.py:74-209 + scene/envmap.py:35-53)."""
+import os
+
 import pytest
 import torch
 
@@ -78,6 +80,37 @@ def test_a_light_that_turns_every_frame_takes_the_uncached_lookup_and_a_stopped_
             ok, msg = report(k, got[k], want[k], rtol, atol)
             assert ok, msg
     assert cached == [True, False, False, False, True, True], cached
+
+
+@pytest.mark.skipif(os.environ.get("R3DG_EXPERIMENTAL") != "1",
+                    reason="opt-in kernels written without GPU access; first run them with R3DG_EXPERIMENTAL=1")
+@pytest.mark.parametrize("regenerate_dirs", [True, False])
+def test_transport_cache_frames_equal_radiance_cache_frames(regenerate_dirs):
+    """RelightRenderer(cache="transport"): the view-independent part of the integral cached per sample / per Gaussian, the
+    GGX lobe per frame (r3dg_shade_build_transport, r3dg_shade_forward_transport) -- the same 19 shading outputs and the
+    same frames as the default renderer, for several cameras against ONE cache."""
+    from relightable3dgaussian_amd import relight, synthetic as syn
+    from relightable3dgaussian_amd.bench_core import GaussianParams
+    scene = syn.make_scene(P=3000, seed=5, stage2=True, scale_log_mean=-3.0)
+    g = torch.Generator().manual_seed(11)
+    envmap = (3.0 * torch.rand(32, 64, 3, generator=g) ** 2).to(DEV)
+    for K in (16, 100):
+        a = relight.RelightRenderer(GaussianParams(scene, DEV, True), envmap, K)
+        b = relight.RelightRenderer(GaussianParams(scene, DEV, True), envmap, K, cache="transport",
+                                    regenerate_dirs=regenerate_dirs)
+        bg = torch.zeros(3, device=DEV)
+        for i in (1, 4, 6):
+            cam = syn.orbit_cameras(8, width=96, height=80)[i].to(DEV)
+            fa = a.frame(cam, bg)
+            sa = a.shade_out.clone()
+            fb = b.frame(cam, bg)
+            assert fa["num_rendered"] == fb["num_rendered"]
+            for c0, c1, name in ((0, 3, "pbr"), (3, 6, "diffuse_light"), (6, 9, "specular"), (9, 18, "lights"), (18, 19, "vis")):
+                ok, msg = report(name, b.shade_out[:, c0:c1], sa[:, c0:c1], 2e-5, 1e-6)
+                assert ok, msg
+            for k, rtol, atol in (("feature", 2e-5, 1e-6), ("pbr_env", 0.0, 2e-4)):
+                ok, msg = report(k, fb[k], fa[k], rtol, atol)
+                assert ok, msg
 
 
 def test_feature_row_layout_and_errors():
