@@ -635,6 +635,8 @@ def run(args):
     relight = None
     if stage2 and args.relight_frames > 0 and world == 1:       # relight: replicas only -- measured at N=1
         step_fn.visibility = step_fn.incident_dirs = step_fn.incident_areas = None   # free the K=train caches
+        if hasattr(step_fn, "_taps"):
+            step_fn._taps = step_fn._taps_src = None
         torch.cuda.empty_cache()
         relight = relight_bench(step_fn if fused else params, cams, dev, args.relight_frames, args.relight_samples)
     result = None

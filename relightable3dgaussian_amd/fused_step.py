@@ -321,10 +321,13 @@ class FusedStage2Step(_BoundedForward):
     def taps(self, He, We):
         """Lat-long lookup cache of the incident directions for a He x We environment texture (shading_ops.build_taps):
         rebuilt only when the direction cache is replaced (a visibility update) or the texture size changes."""
-        key = (self.incident_dirs.data_ptr(), tuple(self.incident_dirs.shape), He, We)
-        if self._taps is None or self._taps_key != key:
-            self._taps = shading_ops.build_taps(self.incident_dirs, He, We)
-            self._taps_key = key
+        # keyed by the direction tensor ITSELF (held in _taps_src for as long as its taps are: a replaced cache can then never
+        # come back at the address of the old one and pass for it) + its version counter (in-place updates)
+        src = self.incident_dirs
+        key = (src._version, tuple(src.shape), He, We)
+        if self._taps is None or getattr(self, "_taps_src", None) is not src or self._taps_key != key:
+            self._taps = shading_ops.build_taps(src, He, We)
+            self._taps_key, self._taps_src = key, src
             # fibonacci_sphere_sampling gives every sample the area 2 pi: then the area cache need not be read at all
             lo, hi = float(self.incident_areas.min()), float(self.incident_areas.max())
             self._uniform_area = lo if lo == hi else None

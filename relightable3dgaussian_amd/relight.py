@@ -83,14 +83,18 @@ class RelightRenderer:
             ident = tuple(float(x) for x in given.detach().reshape(-1).tolist())
         else:
             ident = (tr.data_ptr(), tr._version)
-        key = (ident, He, We, self.incident_dirs.data_ptr(), self.envmap.data_ptr(), self.envmap._version)
+        # (the map and the direction cache are held by this object, so their addresses are theirs alone for as long as the
+        # key is; a caller that swaps either in gets a new key through the version / address pair of the new tensor while the
+        # old one is still referenced below)
+        key = (ident, He, We, self.incident_dirs.data_ptr(), self.incident_dirs._version, self.envmap.data_ptr(),
+               self.envmap._version)
         # A light that turns with EVERY frame (configs/nerf_syn_light, configs/tnt): writing the cache costs what the lookup
         # inside the shading kernel costs and the kernel would then still have to read it back -- from the second
         # consecutive change on, no cache: None = r3dg_shade_forward_cached evaluates the lookup itself (measured: 3.6 ms
         # per frame with a rebuild, 2.5 without).  A light that stops turning gets its cache back on
         # the next frame.
         changed = getattr(self, "_light_key", None) != key
-        self._light_key, self._light_ref = key, tr
+        self._light_key, self._light_ref = key, (tr, self.incident_dirs, self.envmap)
         self._light_changes = (getattr(self, "_light_changes", 0) + 1) if changed else 0
         if self._light_changes >= 2 and getattr(self, "_uniform_area", "unset") != "unset":
             return None
@@ -98,7 +102,7 @@ class RelightRenderer:
             # the HDR map is fixed while relighting, so the SAMPLED RADIANCE of every cached direction is cached (not just
             # the lookup coordinates): the shading kernel then reads 12 bytes per sample and no texture
             self._taps = shading_ops.build_taps(self.incident_dirs, He, We, tr, radiance_of=self.envmap)
-            self._taps_key, self._taps_ref = key, tr
+            self._taps_key, self._taps_ref = key, (tr, self.incident_dirs, self.envmap)
             if getattr(self, "_area_key", None) != self.incident_areas.data_ptr():
                 # fibonacci_sphere_sampling gives every sample the area 2 pi: then the area cache need not be read at all
                 lo, hi = float(self.incident_areas.min()), float(self.incident_areas.max())

@@ -136,6 +136,22 @@ def test_fused_stage2_step_takes_the_reference_learning_rates(monkeypatch):
         assert gr.shape == getattr(step, k).shape and gr.data_ptr() % 16 == 0, k
     lo, hi = step._bucket_c.data_ptr(), step._bucket_c.data_ptr() + 4 * step._bucket_c.numel()
     assert lo <= step.grads["env"].data_ptr() < hi and lo <= step.grads["xyz"].data_ptr() < hi
+    # lookup cache of the incident directions: rebuilt when the direction tensor is REPLACED (even by one that the allocator
+    # hands the old address) or changed in place, not otherwise
+    from relightable3dgaussian_amd import shading_ops
+    builds = []
+    monkeypatch.setattr(shading_ops, "build_taps", lambda dirs, He, We, *a, **k: builds.append(dirs) or torch.zeros(3))
+    step.incident_dirs, step.incident_areas = torch.ones(P, 8, 3), torch.full((P, 8, 1), 2.0)
+    t0 = step.taps(16, 32)
+    assert step.taps(16, 32) is t0 and len(builds) == 1 and step._uniform_area == 2.0
+    step.incident_dirs = None
+    step.incident_dirs = torch.zeros(P, 8, 3)            # whatever address the allocator hands out: a new cache
+    step.taps(16, 32)
+    assert len(builds) == 2 and builds[1] is step.incident_dirs
+    step.incident_dirs.add_(1.0)
+    step.taps(16, 32)
+    step.taps(8, 16)
+    assert len(builds) == 4
     ck.load_moments(step, r)
     assert step.opt.step_count == 2
     assert torch.equal(step.opt.groups[step._opt_order.index("incidents")]["exp_avg"][:, 1:], r.moments["incidents_rest"][0])
