@@ -102,7 +102,7 @@ def test_reference_train_py_runs_unchanged_stage1_then_stage2(tmp_path):
               "--lambda_base_color_smooth", "0", "--lambda_roughness_smooth", "0", "--lambda_light_smooth", "0",
               "--lambda_light", "0.01", "--lambda_env_smooth", "0.01", "--test_interval", "1000", "--checkpoint_interval",
               "18", "--save_interval", "18", "--save_training_vis", "--save_training_vis_iteration", "2",
-              # in the real schedule stage 2 starts at iteration 30001, past densify_until_iter (15000): the neilf render
+              # in the real schedule stage 2 starts at iteration 30001, past densify_until_iter (10 000): the neilf render
               # package has no 'weights' entry for add_densification_stats (train.py:161-162)
               "--densify_until_iter", "10"])
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
