@@ -223,3 +223,83 @@ def test_bvh_oracle_tree_is_wellformed_and_trace_equals_bruteforce():
         near = np.abs(prod - 0.9) < 1e-5
         assert np.abs(vis - want)[~near].max() < 1e-5
         assert np.array_equal(cnt[vis > 0], cb[vis > 0])
+
+
+def test_transport_cache_formulation_equals_the_rendering_equation():
+    """The opt-in relight cache (csrc/shading.hip: shade_build_transport_kernel / shade_forward_transport_kernel) regroups
+    rendering_equation (neilf.py:339-371) into a view-independent part and a per-frame GGX sum and regenerates each direction
+    from the normal and the K-entry Fibonacci table.  This is that arithmetic, statement for statement, in torch on the CPU
+    (the kernels themselves run in tests/test_relight_gpu.py): it must reproduce the oracle's 19 shading outputs, and the
+    regenerated directions must be the cached ones -- including the table's [K,3] layout and the rotation's orientation."""
+    import math
+    from oracle import shading as osh
+    from relightable3dgaussian_amd import sampling
+    g = torch.Generator().manual_seed(3)
+    P, K = 300, 37
+    normals = torch.nn.functional.normalize(torch.randn(P, 3, generator=g), dim=-1, eps=1e-3)
+    normals[0] = torch.tensor([0.0, 0.0, -1.0])                      # the n_z + 1 <= 0 branch of rotation_between_z
+    normals[1] = torch.tensor([0.0, 0.0, 1.0])
+    base = 0.03 + 0.77 * torch.rand(P, 3, generator=g)
+    rough = 0.09 + 0.9 * torch.rand(P, 1, generator=g)
+    view = torch.nn.functional.normalize(torch.randn(P, 3, generator=g), dim=-1)
+    inc = 0.4 * torch.randn(P, 16, 3, generator=g)
+    env = 2.0 * torch.rand(16, 32, 3, generator=g)
+    vis = (torch.rand(P, K, 1, generator=g) > 0.3).float() * torch.rand(P, K, 1, generator=g)
+    dirs, areas = sampling.fibonacci_sphere_sampling(normals, K)
+    want = osh.rendering_equation(base, rough, normals, view, inc, env, vis, dirs, areas)
+
+    # --- shade_build_transport_kernel: radiance -> transport in place, 13 constants per Gaussian
+    radiance = osh.env_lookup(env, dirs)                                           # what r3dg_shade_build_taps caches
+    Y = osh.sh_basis(3, dirs)
+    loc = torch.einsum("pkm,pmc->pkc", Y, inc).clamp_min(0)
+    glob = radiance * vis
+    lin = loc + glob
+    area_ndi = areas * (normals[:, None] * dirs).sum(-1, keepdim=True).clamp_min(0)
+    transport = lin * area_ndi
+    consts = torch.cat([transport.mean(1), lin.mean(1), loc.mean(1), glob.mean(1), vis.mean(1)], -1)     # [P,13]
+
+    # --- shade_forward_transport_kernel: per-Gaussian setup (gauss_setup), the rotation, the loop over the table
+    zs = sampling.fibonacci_z_samples(K, "cpu")[0].t().contiguous()               # [K,3], row k = (x_k, y_k, z_k)
+    n = normals
+    v1, v2, cp = -n[:, 1], n[:, 0], (n[:, 2] + 1).clamp_min(1e-7)
+    regular = n[:, 2] + 1 > 0
+    one, zero = torch.ones(P), torch.zeros(P)
+    R = [torch.where(regular, 1 + (-v2 * v2) / cp, -one), torch.where(regular, v1 * v2 / cp, zero), torch.where(regular, v2, zero),
+         None, torch.where(regular, 1 + (-v1 * v1) / cp, -one), torch.where(regular, -v1, zero),
+         torch.where(regular, -v2, zero), torch.where(regular, v1, zero),
+         torch.where(regular, 1 + (-v2 * v2 - v1 * v1) / cp, -one)]
+    R[3] = R[1]
+    rx = R[0][:, None] * zs[None, :, 0] + R[1][:, None] * zs[None, :, 1] + R[2][:, None] * zs[None, :, 2]
+    ry = R[3][:, None] * zs[None, :, 0] + R[4][:, None] * zs[None, :, 1] + R[5][:, None] * zs[None, :, 2]
+    rz = R[6][:, None] * zs[None, :, 0] + R[7][:, None] * zs[None, :, 1] + R[8][:, None] * zs[None, :, 2]
+    raw = torch.stack([rx, ry, rz], -1)
+    L = raw * torch.rsqrt((raw * raw).sum(-1, keepdim=True).clamp_min(1e-24))
+    assert float((L - dirs).abs().max()) < 2e-6, "regenerated directions differ from the cached ones"
+    V = view / view.norm(dim=-1, keepdim=True).clamp_min(1e-12)
+    N0 = n / n.norm(dim=-1, keepdim=True).clamp_min(1e-12)
+    N = N0 * torch.sign((V * N0).sum(-1, keepdim=True))
+    NoV = (N * V).sum(-1).clamp(1e-6, 1.0)
+    a = rough[:, 0] ** 2
+    a2, kk = a * a, (a + 2 * rough[:, 0] + 1.0) / 8.0
+    nom1 = NoV * (1 - kk) + kk
+    u = (L + V[:, None]) / 2.0
+    Hh = u * torch.rsqrt((u * u).sum(-1, keepdim=True).clamp_min(1e-24))
+    NoL = (N[:, None] * L).sum(-1).clamp(1e-6, 1.0)
+    NoH = (N[:, None] * Hh).sum(-1).clamp(1e-6, 1.0)
+    VoH = (V[:, None] * Hh).sum(-1).clamp(1e-6, 1.0)
+    p2 = torch.exp2((-5.55473 * VoH - 6.98316) * VoH)
+    frac = (0.04 + 0.96 * p2) * a2[:, None]
+    nom0 = NoH * NoH * (a2[:, None] - 1) + 1
+    nom2 = NoL * (1 - kk[:, None]) + kk[:, None]
+    nom = (4 * math.pi * nom0 * nom0 * nom1[:, None] * nom2).clamp(1e-6, 4 * math.pi)
+    spec = frac / nom
+    S = (spec[..., None] * transport).mean(1)
+    out = torch.cat([base / math.pi * consts[:, 0:3] + S, consts[:, 0:3], S, consts[:, 3:6], consts[:, 6:9], consts[:, 9:12],
+                     consts[:, 12:13]], -1)
+    ref = torch.cat([want["pbr"], want["diffuse_light"], want["specular"], want["incident_lights"],
+                     want["local_incident_lights"], want["global_incident_lights"], want["incident_visibility"]], -1)
+    err = (out - ref).abs().max(0).values / ref.abs().max(0).values.clamp_min(1e-6)
+    # the view-independent columns are the same sums; the GGX columns see the regenerated directions (1e-7 off the cached
+    # ones) through an ill-conditioned lobe: 1e-4, the bound the shading parity tests use for that term
+    assert out.shape == (P, 19) and float(err[[3, 4, 5] + list(range(9, 19))].max()) < 2e-6, err
+    assert float(err[[0, 1, 2, 6, 7, 8]].max()) < 1e-4, err
