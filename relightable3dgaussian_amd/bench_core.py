@@ -478,6 +478,8 @@ def _plumbing_only(args, world, rank, backend):
 
 
 def run(args):
+    # the host driver only supports dmabuf IPC: must be in the environment before the first HIP call initialises the runtime
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
