@@ -19,42 +19,12 @@
 //     double buffered, while the current block is computed (three passes per block, 12 parked floats per lane).
 #include "common.hpp"
 #include "wave_reduce.hpp"
+#include "shading_math.hpp"
 
 namespace r3dg {
 
-constexpr float kPi = 3.14159265358979323846f;
 constexpr int SHADE_WAVES = 4;               // Gaussians in flight per block
 constexpr int ENV_LDS_MAX = 12288;           // floats (48 KB) -- larger maps are sampled from global/L2
-constexpr int SHADE_NOUT = 19;               // pbr3 diffuse3 specular3 lights3 local3 global3 vis1
-
-// ---- real SH basis, degree 3, reference sign convention (sh_utils.py:92-127) ----
-__device__ __forceinline__ void sh_basis16(float x, float y, float z, int M, float (&Y)[16])
-{
-    const float C0 = 0.28209479177387814f, C1 = 0.4886025119029199f;
-    Y[0] = C0;
-#pragma unroll
-    for (int i = 1; i < 16; i++) Y[i] = 0.f;
-    if (M > 1) {
-        Y[1] = -C1 * y; Y[2] = C1 * z; Y[3] = -C1 * x;
-        if (M > 4) {
-            const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
-            Y[4] = 1.0925484305920792f * xy;
-            Y[5] = -1.0925484305920792f * yz;
-            Y[6] = 0.31539156525252005f * (2.0f * zz - xx - yy);
-            Y[7] = -1.0925484305920792f * xz;
-            Y[8] = 0.5462742152960396f * (xx - yy);
-            if (M > 9) {
-                Y[9] = -0.5900435899266435f * y * (3.f * xx - yy);
-                Y[10] = 2.890611442640554f * xy * z;
-                Y[11] = -0.4570457994644658f * y * (4.f * zz - xx - yy);
-                Y[12] = 0.3731763325901154f * z * (2.f * zz - 3.f * xx - 3.f * yy);
-                Y[13] = -0.4570457994644658f * x * (4.f * zz - xx - yy);
-                Y[14] = 1.445305721320277f * z * (xx - yy);
-                Y[15] = -0.5900435899266435f * x * (xx - 3.f * yy);
-            }
-        }
-    }
-}
 
 // acos / atan2 for the lat-long lookup, branch-free (Cephes single-precision minimax polynomials, ~1 ulp like the libm
 // versions they replace at about a third of the instructions: the lookup runs once per cached sample, forward and
@@ -188,11 +158,6 @@ struct SampleFwd {
     float vis;
 };
 
-struct GaussFwd {            // wave-uniform per-Gaussian quantities
-    float base[3], r, n[3], V[3], vlen, N[3], NoV, rawNoV, a, a2, kk;
-    float v_raw[3];
-};
-
 // Layout of the per-wave uniform record u[64]: 0..47 SH coefficients (i*3+c), 48..50 albedo, 51 roughness,
 // 52..54 normal, 55..57 view direction, 58..60 dL_dpbr, 61..63 dL_ddiffuse_light (the last six only in the backward).
 __device__ __forceinline__ float load_uniform_element(int lane, int g, int M, const float* __restrict__ base_color,
@@ -211,51 +176,6 @@ __device__ __forceinline__ float load_uniform_element(int lane, int g, int M, co
     else if (lane < 61) { if (g_pbr) p = g_pbr + 3 * (size_t)g + (lane - 58); }
     else { if (g_diff) p = g_diff + 3 * (size_t)g + (lane - 61); }
     return p ? *p : 0.f;
-}
-
-__device__ __forceinline__ void gauss_setup(GaussFwd& G, const float* u)
-{
-#pragma unroll
-    for (int c = 0; c < 3; c++) {
-        G.base[c] = u[48 + c];
-        G.n[c] = u[52 + c];
-        G.v_raw[c] = u[55 + c];
-    }
-    G.r = u[51];
-    G.vlen = fmaxf(sqrtf(G.v_raw[0] * G.v_raw[0] + G.v_raw[1] * G.v_raw[1] + G.v_raw[2] * G.v_raw[2]), 1e-12f);
-    const float nlen = fmaxf(sqrtf(G.n[0] * G.n[0] + G.n[1] * G.n[1] + G.n[2] * G.n[2]), 1e-12f);
-    float N0[3];
-#pragma unroll
-    for (int c = 0; c < 3; c++) {
-        G.V[c] = G.v_raw[c] / G.vlen;
-        N0[c] = G.n[c] / nlen;
-    }
-    const float d0 = G.V[0] * N0[0] + G.V[1] * N0[1] + G.V[2] * N0[2];
-    const float sgn = d0 > 0.f ? 1.f : (d0 < 0.f ? -1.f : 0.f);
-#pragma unroll
-    for (int c = 0; c < 3; c++) G.N[c] = N0[c] * sgn;
-    G.rawNoV = G.N[0] * G.V[0] + G.N[1] * G.V[1] + G.N[2] * G.V[2];
-    G.NoV = fminf(fmaxf(G.rawNoV, 1e-6f), 1.f);
-    G.a = G.r * G.r;
-    G.a2 = G.a * G.a;
-    G.kk = (G.a + 2.f * G.r + 1.0f) / 8.0f;
-}
-
-// local incident light before the clamp: sum_i Y_i(d) * sh[i][c]  (48 coefficients as 12 broadcast ds_read_b128)
-__device__ __forceinline__ void sh_local_sum(const float* sh /*[48] in LDS, zero padded*/, const float (&Y)[16],
-                                             float (&acc)[3])
-{
-    acc[0] = acc[1] = acc[2] = 0.f;
-#pragma unroll
-    for (int q = 0; q < 12; q++) {
-        const float4 c4 = reinterpret_cast<const float4*>(sh)[q];
-        const float cf[4] = {c4.x, c4.y, c4.z, c4.w};
-#pragma unroll
-        for (int e = 0; e < 4; e++) {
-            const int f = 4 * q + e;
-            acc[f % 3] += Y[f / 3] * cf[e];
-        }
-    }
 }
 
 template <bool ENV_LDS, bool HAVE_SHSUM = false, bool HAVE_TAP = false>
@@ -1868,171 +1788,9 @@ void launch_shade_backward(hipStream_t s, int P, int K, int M, const float* base
     check_launch(s, false, "shade_backward_kernel");
 }
 
-// =====================================================================================================================
-// Relighting under a FIXED light ("transport" cache; opt-in, relight.RelightRenderer(cache="transport")).
-// While neither the Gaussians nor the light change -- a camera flying through a relit scene, relighting.py with
-// configs/teaser or configs/nerf_syn -- everything of the integral that does not depend on the view is a constant:
-//     transport_k = (max(SH_incident(d_k), 0) + radiance(d_k) * visibility_k) * area_k * max(n . d_k, 0)     per sample,
-//     diffuse_light, mean incident / local / global light, mean visibility                                       per Gaussian,
-// and per frame only the GGX lobe is left:  specular = mean_k f_s(n, v, d_k) transport_k,  pbr = albedo / pi * diffuse_light
-// + specular (rendering_equation, neilf.py:339-371 with the sums regrouped).  shade_build_transport_kernel turns the cached
-// RADIANCE of every sample (r3dg_shade_build_taps with a radiance map) into its transport IN PLACE and writes the 13
-// per-Gaussian constants; shade_forward_transport_kernel reads 12 bytes per sample (the transport) -- the direction is
-// regenerated from the Gaussian's normal and the K-entry Fibonacci table (rotation_between_z, utils/sh_utils.py:36-68;
-// graphics_utils.py:9-37), or read from the cache when the caller passes it -- and evaluates ~80 instead of ~290
-// instructions per sample.  One wave per Gaussian, lane = sample; plain (non-persistent) launches.
-// =====================================================================================================================
-constexpr int TR_WAVES = 4;
-constexpr int TR_CONSTS = 16;     // floats per Gaussian: diffuse_light 3 | incident light 3 | local 3 | global 3 | visibility 1 | pad
-
-__device__ __forceinline__ float wave_sum64(float x)
-{
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) x += __shfl_xor(x, o, 64);
-    return x;
-}
-
-__global__ void __launch_bounds__(64 * TR_WAVES)
-shade_build_transport_kernel(int P, int K, int M, const float* __restrict__ normals, const float* __restrict__ incidents,
-                             const float* __restrict__ visibility, const float* __restrict__ dirs,
-                             const float* __restrict__ areas, float uniform_area, float* radiance_to_transport,
-                             float* __restrict__ consts)
-{
-    __shared__ __attribute__((aligned(16))) float s_sh[TR_WAVES][48];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int g = blockIdx.x * TR_WAVES + wave;
-    if (g >= P) return;                                       // whole waves leave; no block-wide barrier below
-    float* sh = s_sh[wave];
-    if (lane < 48) sh[lane] = lane < 3 * M ? incidents[(size_t)g * 3 * M + lane] : 0.f;     // same wave: in-order LDS
-    const float nx = normals[3 * (size_t)g], ny = normals[3 * (size_t)g + 1], nz = normals[3 * (size_t)g + 2];
-    const size_t row = (size_t)g * (size_t)K;
-    float acc[13];
-#pragma unroll
-    for (int i = 0; i < 13; i++) acc[i] = 0.f;
-    const int kend = (K + 63) & ~63;
-    for (int k = lane; k < kend; k += 64) {
-        if (k < K) {
-            const float dx = dirs[3 * (row + k)], dy = dirs[3 * (row + k) + 1], dz = dirs[3 * (row + k) + 2];
-            const float vis = visibility[row + k];
-            const float area = areas != nullptr ? areas[row + k] : uniform_area;
-            float* e = radiance_to_transport + 3 * (row + k);
-            float Y[16];
-            sh_basis16(dx, dy, dz, M, Y);
-            float l[3];
-            sh_local_sum(sh, Y, l);
-            const float area_ndi = area * fmaxf(nx * dx + ny * dy + nz * dz, 0.f);
-#pragma unroll
-            for (int c = 0; c < 3; c++) {
-                const float loc = fmaxf(l[c], 0.f), glob = e[c] * vis, lin = loc + glob, t = lin * area_ndi;
-                e[c] = t;
-                acc[c] += t;
-                acc[3 + c] += lin;
-                acc[6 + c] += loc;
-                acc[9 + c] += glob;
-            }
-            acc[12] += vis;
-        }
-    }
-    const float invK = 1.0f / (float)K;
-#pragma unroll
-    for (int i = 0; i < 13; i++) acc[i] = wave_sum64(acc[i]) * invK;
-    if (lane == 0) {
-        float* o = consts + (size_t)g * TR_CONSTS;
-#pragma unroll
-        for (int i = 0; i < TR_CONSTS; i++) o[i] = i < 13 ? acc[i] : 0.f;
-    }
-}
-
-__global__ void __launch_bounds__(64 * TR_WAVES)
-shade_forward_transport_kernel(int P, int K, const float* __restrict__ base_color, const float* __restrict__ roughness,
-                               const float* __restrict__ normals, const float* __restrict__ viewdirs,
-                               const float* __restrict__ transport, const float* __restrict__ consts,
-                               const float* __restrict__ zsamples, const float* __restrict__ dirs, float* __restrict__ out)
-{
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int g = blockIdx.x * TR_WAVES + wave;
-    if (g >= P) return;
-    float u[64];
-#pragma unroll
-    for (int c = 0; c < 3; c++) {
-        u[48 + c] = base_color[3 * (size_t)g + c];
-        u[52 + c] = normals[3 * (size_t)g + c];
-        u[55 + c] = viewdirs[3 * (size_t)g + c];
-    }
-    u[51] = roughness[g];
-    GaussFwd G;
-    gauss_setup(G, u);
-    // rotation_between_z(normal): the rotation that takes +z to the normal (the identity's negative when n_z + 1 <= 0)
-    float R[9];
-    {
-        const float v1 = -G.n[1], v2 = G.n[0], cp = fmaxf(G.n[2] + 1.f, 1e-7f);
-        const bool regular = G.n[2] + 1.f > 0.f;
-        R[0] = regular ? 1.f + (-v2 * v2) / cp : -1.f;
-        R[1] = regular ? v1 * v2 / cp : 0.f;
-        R[2] = regular ? v2 : 0.f;
-        R[3] = R[1];
-        R[4] = regular ? 1.f + (-v1 * v1) / cp : -1.f;
-        R[5] = regular ? -v1 : 0.f;
-        R[6] = regular ? -v2 : 0.f;
-        R[7] = regular ? v1 : 0.f;
-        R[8] = regular ? 1.f + (-v2 * v2 - v1 * v1) / cp : -1.f;
-    }
-    const float a2 = G.a2, kk = G.kk;
-    const float nom1 = G.NoV * (1.f - kk) + kk;
-    const size_t row = (size_t)g * (size_t)K;
-    float S[3] = {0.f, 0.f, 0.f};
-    const int kend = (K + 63) & ~63;
-    for (int k = lane; k < kend; k += 64) {
-        if (k < K) {
-            float rx, ry, rz;
-            if (dirs != nullptr) {
-                rx = dirs[3 * (row + k)]; ry = dirs[3 * (row + k) + 1]; rz = dirs[3 * (row + k) + 2];
-            } else {
-                const float zx = zsamples[3 * k], zy = zsamples[3 * k + 1], zz = zsamples[3 * k + 2];
-                rx = R[0] * zx + R[1] * zy + R[2] * zz;
-                ry = R[3] * zx + R[4] * zy + R[5] * zz;
-                rz = R[6] * zx + R[7] * zy + R[8] * zz;
-            }
-            const float* t = transport + 3 * (row + k);
-            const float t0 = t[0], t1 = t[1], t2 = t[2];
-            // GGX lobe exactly as in the row kernel (neilf.py:374-407)
-            const float dinv = __builtin_amdgcn_rsqf(fmaxf(rx * rx + ry * ry + rz * rz, 1e-24f));
-            const float Lx = rx * dinv, Ly = ry * dinv, Lz = rz * dinv;
-            const float ux = (Lx + G.V[0]) / 2.0f, uy = (Ly + G.V[1]) / 2.0f, uz = (Lz + G.V[2]) / 2.0f;
-            const float uinv = __builtin_amdgcn_rsqf(fmaxf(ux * ux + uy * uy + uz * uz, 1e-24f));
-            const float Hx = ux * uinv, Hy = uy * uinv, Hz = uz * uinv;
-            const float NoL = fminf(fmaxf(G.N[0] * Lx + G.N[1] * Ly + G.N[2] * Lz, 1e-6f), 1.f);
-            const float NoH = fminf(fmaxf(G.N[0] * Hx + G.N[1] * Hy + G.N[2] * Hz, 1e-6f), 1.f);
-            const float VoH = fminf(fmaxf(G.V[0] * Hx + G.V[1] * Hy + G.V[2] * Hz, 1e-6f), 1.f);
-            const float p2 = exp2f((-5.55473f * VoH - 6.98316f) * VoH);
-            const float frac = (0.04f + 0.96f * p2) * a2;
-            const float nom0 = NoH * NoH * (a2 - 1.f) + 1.f;
-            const float nom2 = NoL * (1.f - kk) + kk;
-            const float nom = fminf(fmaxf(4.f * kPi * nom0 * nom0 * nom1 * nom2, 1e-6f), 4.f * kPi);
-            const float spec = frac / nom;
-            S[0] += spec * t0;
-            S[1] += spec * t1;
-            S[2] += spec * t2;
-        }
-    }
-    const float invK = 1.0f / (float)K;
-#pragma unroll
-    for (int c = 0; c < 3; c++) S[c] = wave_sum64(S[c]) * invK;
-    if (lane == 0) {
-        const float* cst = consts + (size_t)g * TR_CONSTS;
-        float* o = out + (size_t)g * SHADE_NOUT;
-#pragma unroll
-        for (int c = 0; c < 3; c++) {
-            o[c] = G.base[c] / kPi * cst[c] + S[c];     // pbr
-            o[3 + c] = cst[c];                          // diffuse_light
-            o[6 + c] = S[c];                            // specular
-            o[9 + c] = cst[3 + c];                      // mean incident light
-            o[12 + c] = cst[6 + c];                     // local
-            o[15 + c] = cst[9 + c];                     // global
-        }
-        o[18] = cst[12];                                // mean visibility
-    }
-}
+}  // namespace r3dg
+#include "shading_transport.hpp"
+namespace r3dg {
 
 void launch_shade_build_transport(hipStream_t s, int P, int K, int M, const float* normals, const float* incidents,
                                   const float* visibility, const float* dirs, const float* areas, float uniform_area,

@@ -6,6 +6,7 @@ import os
 import re
 
 import numpy as np
+import pytest
 import torch
 
 from tests.helpers import fwd_args, make_case, report
@@ -225,17 +226,9 @@ def test_bvh_oracle_tree_is_wellformed_and_trace_equals_bruteforce():
         assert np.array_equal(cnt[vis > 0], cb[vis > 0])
 
 
-def test_transport_cache_formulation_equals_the_rendering_equation():
-    """The opt-in relight cache (csrc/shading.hip: shade_build_transport_kernel / shade_forward_transport_kernel) regroups
-    rendering_equation (neilf.py:339-371) into a view-independent part and a per-frame GGX sum and regenerates each direction
-    from the normal and the K-entry Fibonacci table.  This is that arithmetic, statement for statement, in torch on the CPU
-    (the kernels themselves run in tests/test_relight_gpu.py): it must reproduce the oracle's 19 shading outputs, and the
-    regenerated directions must be the cached ones -- including the table's [K,3] layout and the rotation's orientation."""
-    import math
-    from oracle import shading as osh
+def _transport_case(P, K, seed=3):
     from relightable3dgaussian_amd import sampling
-    g = torch.Generator().manual_seed(3)
-    P, K = 300, 37
+    g = torch.Generator().manual_seed(seed)
     normals = torch.nn.functional.normalize(torch.randn(P, 3, generator=g), dim=-1, eps=1e-3)
     normals[0] = torch.tensor([0.0, 0.0, -1.0])                      # the n_z + 1 <= 0 branch of rotation_between_z
     normals[1] = torch.tensor([0.0, 0.0, 1.0])
@@ -246,21 +239,26 @@ def test_transport_cache_formulation_equals_the_rendering_equation():
     env = 2.0 * torch.rand(16, 32, 3, generator=g)
     vis = (torch.rand(P, K, 1, generator=g) > 0.3).float() * torch.rand(P, K, 1, generator=g)
     dirs, areas = sampling.fibonacci_sphere_sampling(normals, K)
-    want = osh.rendering_equation(base, rough, normals, view, inc, env, vis, dirs, areas)
+    zs = sampling.fibonacci_z_samples(K, "cpu")[0].t().contiguous()               # [K,3], row k = (x_k, y_k, z_k)
+    return dict(normals=normals, base=base, rough=rough, view=view, inc=inc, env=env, vis=vis, dirs=dirs, areas=areas, zs=zs)
 
-    # --- shade_build_transport_kernel: radiance -> transport in place, 13 constants per Gaussian
-    radiance = osh.env_lookup(env, dirs)                                           # what r3dg_shade_build_taps caches
+
+def _transport_in_torch(c):
+    """shade_build_transport_kernel + shade_forward_transport_kernel (csrc/shading_transport.hpp), statement for statement."""
+    import math
+    from oracle import shading as osh
+    n, dirs, vis, areas, inc, zs = c["normals"], c["dirs"], c["vis"], c["areas"], c["inc"], c["zs"]
+    P = n.shape[0]
+    # --- builder: radiance -> transport in place, 13 constants per Gaussian
+    radiance = osh.env_lookup(c["env"], dirs)                                      # what r3dg_shade_build_taps caches
     Y = osh.sh_basis(3, dirs)
     loc = torch.einsum("pkm,pmc->pkc", Y, inc).clamp_min(0)
     glob = radiance * vis
     lin = loc + glob
-    area_ndi = areas * (normals[:, None] * dirs).sum(-1, keepdim=True).clamp_min(0)
+    area_ndi = areas * (n[:, None] * dirs).sum(-1, keepdim=True).clamp_min(0)
     transport = lin * area_ndi
     consts = torch.cat([transport.mean(1), lin.mean(1), loc.mean(1), glob.mean(1), vis.mean(1)], -1)     # [P,13]
-
-    # --- shade_forward_transport_kernel: per-Gaussian setup (gauss_setup), the rotation, the loop over the table
-    zs = sampling.fibonacci_z_samples(K, "cpu")[0].t().contiguous()               # [K,3], row k = (x_k, y_k, z_k)
-    n = normals
+    # --- frame kernel: per-Gaussian setup (gauss_setup), the rotation, the loop over the table
     v1, v2, cp = -n[:, 1], n[:, 0], (n[:, 2] + 1).clamp_min(1e-7)
     regular = n[:, 2] + 1 > 0
     one, zero = torch.ones(P), torch.zeros(P)
@@ -274,7 +272,7 @@ def test_transport_cache_formulation_equals_the_rendering_equation():
     rz = R[6][:, None] * zs[None, :, 0] + R[7][:, None] * zs[None, :, 1] + R[8][:, None] * zs[None, :, 2]
     raw = torch.stack([rx, ry, rz], -1)
     L = raw * torch.rsqrt((raw * raw).sum(-1, keepdim=True).clamp_min(1e-24))
-    assert float((L - dirs).abs().max()) < 2e-6, "regenerated directions differ from the cached ones"
+    view, rough, base = c["view"], c["rough"], c["base"]
     V = view / view.norm(dim=-1, keepdim=True).clamp_min(1e-12)
     N0 = n / n.norm(dim=-1, keepdim=True).clamp_min(1e-12)
     N = N0 * torch.sign((V * N0).sum(-1, keepdim=True))
@@ -296,10 +294,67 @@ def test_transport_cache_formulation_equals_the_rendering_equation():
     S = (spec[..., None] * transport).mean(1)
     out = torch.cat([base / math.pi * consts[:, 0:3] + S, consts[:, 0:3], S, consts[:, 3:6], consts[:, 6:9], consts[:, 9:12],
                      consts[:, 12:13]], -1)
+    return radiance, transport, consts, L, out
+
+
+def test_transport_cache_formulation_equals_the_rendering_equation():
+    """The opt-in relight cache (csrc/shading_transport.hpp) regroups rendering_equation (neilf.py:339-371) into a
+    view-independent part and a per-frame GGX sum and regenerates each direction from the normal and the K-entry Fibonacci
+    table.  That arithmetic, transcribed in torch, must reproduce the oracle's 19 shading outputs, and the regenerated
+    directions must be the cached ones -- including the table's [K,3] layout and the rotation's orientation."""
+    from oracle import shading as osh
+    c = _transport_case(300, 37)
+    want = osh.rendering_equation(c["base"], c["rough"], c["normals"], c["view"], c["inc"], c["env"], c["vis"], c["dirs"],
+                                  c["areas"])
+    _rad, _tr, _consts, L, out = _transport_in_torch(c)
+    assert float((L - c["dirs"]).abs().max()) < 2e-6, "regenerated directions differ from the cached ones"
     ref = torch.cat([want["pbr"], want["diffuse_light"], want["specular"], want["incident_lights"],
                      want["local_incident_lights"], want["global_incident_lights"], want["incident_visibility"]], -1)
     err = (out - ref).abs().max(0).values / ref.abs().max(0).values.clamp_min(1e-6)
     # the view-independent columns are the same sums; the GGX columns see the regenerated directions (1e-7 off the cached
     # ones) through an ill-conditioned lobe: 1e-4, the bound the shading parity tests use for that term
-    assert out.shape == (P, 19) and float(err[[3, 4, 5] + list(range(9, 19))].max()) < 2e-6, err
+    assert out.shape == (300, 19) and float(err[[3, 4, 5] + list(range(9, 19))].max()) < 2e-6, err
     assert float(err[[0, 1, 2, 6, 7, 8]].max()) < 1e-4, err
+
+
+@pytest.mark.parametrize("P,K,uniform,regen", [(130, 37, True, True), (9, 100, False, False), (64, 64, True, False)])
+def test_transport_kernels_source_runs_in_the_cpu_wave_emulation(tmp_path, P, K, uniform, regen):
+    """The two kernels of csrc/shading_transport.hpp -- the files hipcc compiles for gfx950 -- compiled for the HOST against
+    tests/emu/hip_emu.hpp (every lane a thread, __shfl_xor / __shared__ emulated in lock step) and run on the CPU: indexing,
+    the in-place radiance -> transport rewrite, partially filled last waves and workgroups, the wave reductions and the 19
+    output columns, against the torch transcription above.  (Written without GPU access; the hardware run of the same source
+    is tests/test_relight_gpu.py.)"""
+    import ctypes as C
+    import shutil
+    import subprocess
+    if shutil.which("g++") is None:
+        pytest.skip("needs g++ (C++20)")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    lib_path = os.path.join(tmp_path, "libtransport_emu.so")
+    r = subprocess.run(["g++", "-std=c++20", "-O1", "-pthread", "-shared", "-fPIC", "-w",
+                        "-I", os.path.join(root, "relightable3dgaussian_amd", "csrc"),
+                        os.path.join(root, "tests", "emu", "transport_emu.cpp"), "-o", lib_path], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lib = C.CDLL(lib_path)
+    c = _transport_case(P, K, seed=5)
+    if not uniform:
+        c["areas"] = c["areas"] * (0.5 + torch.rand(P, K, 1, generator=torch.Generator().manual_seed(1)))
+    radiance, transport, consts, _L, out = _transport_in_torch(c)
+    f = lambda t: np.ascontiguousarray(t.detach().numpy(), np.float32)
+    p = lambda a: a.ctypes.data_as(C.c_void_p)
+    buf = f(radiance).copy()                                        # [P,K,3]: radiance in, transport out
+    got_consts = np.full((P, 16), np.nan, np.float32)
+    normals, inc, vis, dirs, areas = f(c["normals"]), f(c["inc"]), f(c["vis"]), f(c["dirs"]), f(c["areas"])
+    lib.emu_shade_build_transport(C.c_int(P), C.c_int(K), C.c_int(16), p(normals), p(inc), p(vis), p(dirs),
+                                  None if uniform else p(areas), C.c_float(float(c["areas"][0, 0, 0])), p(buf), p(got_consts))
+    scale = float(transport.abs().max())
+    assert np.abs(buf - f(transport)).max() <= 2e-6 * scale, "transport"
+    assert np.abs(got_consts[:, :13] - f(consts)).max() <= 2e-6 * float(consts.abs().max()) and (got_consts[:, 13:] == 0).all()
+    base, rough, view, zs = f(c["base"]), f(c["rough"]), f(c["view"]), f(c["zs"])
+    got = np.full((P, 19), np.nan, np.float32)
+    lib.emu_shade_forward_transport(C.c_int(P), C.c_int(K), p(base), p(rough), p(normals), p(view), p(buf), p(got_consts),
+                                    p(zs), None if regen else p(dirs), p(got))
+    want = f(out)
+    err = np.abs(got - want).max(0) / np.maximum(np.abs(want).max(0), 1e-6)
+    assert np.isfinite(got).all() and err[[3, 4, 5] + list(range(9, 19))].max() < 2e-6, err        # copied constants
+    assert err[[0, 1, 2, 6, 7, 8]].max() < 1e-4, err                # the GGX columns (ill-conditioned lobe, other rsqrt / exp2)
