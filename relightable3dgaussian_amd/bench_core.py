@@ -384,6 +384,105 @@ def relight_bench(params, cams, dev, frames, K):
                              "of every cached direction is reused across frames; relight_rotating_light: rebuilt per frame")
 
 
+_TRANSPORT_CHILD_SCRIPT = """
+import json, sys, time
+sys.path.insert(0, %(root)r)
+import torch
+from relightable3dgaussian_amd import relight, synthetic as syn
+from relightable3dgaussian_amd.bench_core import GaussianParams
+P, res, K, frames = %(P)d, %(res)d, %(K)d, %(frames)d
+dev = torch.device("cuda", 0)
+scene = syn.make_scene(P=P, seed=0, stage2=True)
+cams = [c.to(dev) for c in syn.orbit_cameras(100, width=res, height=res)[:frames + 6]]
+envmap = (3.0 * torch.rand(256, 512, 3, generator=torch.Generator().manual_seed(7)) ** 2).to(dev)
+bg = torch.zeros(3, device=dev)
+base = relight.RelightRenderer(GaussianParams(scene, dev, True), envmap, K)
+out = {}
+for name, regen in (("regenerated_directions", True), ("cached_directions", False)):
+    r = relight.RelightRenderer(GaussianParams(scene, dev, True), envmap, K, cache="transport", regenerate_dirs=regen)
+    worst = {}
+    for cam in cams[:3]:                                   # parity on the device first: shading outputs and the frame
+        fa = base.frame(cam, bg)
+        sa = base.shade_out.clone()
+        fb = r.frame(cam, bg)
+        for key, a, b in (("shade_out", sa, r.shade_out), ("feature", fa["feature"], fb["feature"]),
+                          ("pbr_env", fa["pbr_env"], fb["pbr_env"])):
+            e = float((a - b).abs().max() / a.abs().max().clamp_min(1e-12))
+            worst[key] = max(worst.get(key, 0.0), e)
+        assert fa["num_rendered"] == fb["num_rendered"]
+    ok = all(v == v and v < 5e-4 for v in worst.values())
+    torch.cuda.synchronize()
+    t = time.perf_counter()
+    for i in range(frames):
+        r.frame(cams[3 + i], bg)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t) / frames
+    out[name] = dict(parity_vs_default_renderer=ok, max_rel_err=worst, fps=round(1.0 / dt, 2), ms_per_frame=round(1e3 * dt, 3))
+    del r
+    torch.cuda.empty_cache()
+torch.cuda.synchronize()
+t = time.perf_counter()
+for i in range(frames):
+    base.frame(cams[3 + i], bg)
+torch.cuda.synchronize()
+out["default_renderer_fps_same_process"] = round(frames / (time.perf_counter() - t), 2)
+print(json.dumps(out))
+"""
+
+
+def relight_transport_child(points, res, K, frames, timeout_s=150):
+    """relight.RelightRenderer(cache="transport") -- the opt-in cache of the frame's view-independent part -- measured in a
+    CHILD process: first checked on the device against the default renderer (shading outputs, feature image, composite),
+    then timed.  Isolated because those kernels had not run on hardware when this was written: whatever
+    happens in the child, the numbers of the parent (`relight_fps`, the default renderer) stand."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = _TRANSPORT_CHILD_SCRIPT % dict(root=root, P=points, res=res, K=K, frames=frames)
+    try:
+        r = subprocess.run([sys.executable, "-c", script], capture_output=True, text=True, timeout=timeout_s,
+                           stdin=subprocess.DEVNULL)
+        line = [x for x in r.stdout.splitlines() if x.startswith("{")]
+        if r.returncode != 0 or not line:
+            return {"failed": (r.stderr or r.stdout)[-400:]}
+        doc = json.loads(line[-1])
+        doc["what"] = ("relight.RelightRenderer(cache='transport'): per-sample transport + per-Gaussian constants cached while "
+                       "light and Gaussians stand still, GGX lobe per frame (r3dg_shade_forward_transport); child process, "
+                       "%d Gaussians, %dx%d, K=%d, %d frames; reported only as a side measurement" % (points, res, res, K, frames))
+        return doc
+    except subprocess.TimeoutExpired:
+        return {"failed": "no result within %d s" % timeout_s}
+    except Exception as e:
+        return {"failed": repr(e)}
+
+
+def dp_path_one_rank(args, timeout_s=180):
+    """The data-parallel iteration (bucketed async all-reduces on RCCL's stream, reduced skip flag, deferred incident-light
+    update) over a ONE-rank RCCL group -- what the path's own structure costs before any byte crosses xGMI -- measured by a
+    child `bench.py` with R3DG_DP_SINGLE_RANK=1 (fused_step._world_of) on the same workload."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, R3DG_DP_SINGLE_RANK="1", R3DG_DIST_BACKEND="nccl")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--steps", str(args.steps), "--warmup",
+           str(args.warmup), "--points", str(args.points), "--res", str(args.res), "--sample-num", str(args.sample_num),
+           "--no-cpu-baseline", "--no-other-configs", "--relight-frames", "0", "--repeats", "0"]
+    try:
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout_s, env=env, stdin=subprocess.DEVNULL)
+        line = [x for x in r.stdout.splitlines() if x.startswith("{")]
+        if r.returncode != 0 or not line:
+            return {"failed": (r.stderr or r.stdout)[-400:]}
+        doc = json.loads(line[-1])
+        return dict(iters_per_s=doc["value"], ms_per_step=doc["ms_per_step"],
+                    what="the same iteration through the data-parallel path over a ONE-rank RCCL group (identity collectives)")
+    except subprocess.TimeoutExpired:
+        return {"failed": "no result within %d s" % timeout_s}
+    except Exception as e:
+        return {"failed": repr(e)}
+
+
 def quick_rate(stage, points, res, sample_num, dev, steps=20, warmup=4):
     """iters/s of another BASELINE configuration on the same synthetic scene (single GPU, short run): stage 1
     (configs[1]; fused stage-1 iteration) or stage 2 at another sample count (configs[2]
@@ -684,8 +783,13 @@ def run(args):
                         quick_rate(2, args.points, args.res, 384, dev),
                     "stage1_densify_and_prune (one call at the bench size)": densify_bench(args.points, args.res, dev),
                 }
+                if args.stage == 2 and not getattr(args, "unfused", False):
+                    result["other_configs"]["data_parallel_path_one_rank_rccl"] = dp_path_one_rank(args)
             except Exception as e:
                 result["other_configs"] = {"failed": repr(e)}
+        if relight is not None and world == 1 and not getattr(args, "no_other_configs", False):
+            result["relight"]["relight_transport_cache"] = relight_transport_child(
+                args.points, args.res, args.relight_samples, max(4, args.relight_frames // 2))
         if not args.no_cpu_baseline and world == 1:
             try:
                 result["cpu_baseline"] = cpu_baseline(scene, cams_cpu, S, args.cpu_baseline_seconds, args.points, args.res)
