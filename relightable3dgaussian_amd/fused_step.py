@@ -204,6 +204,8 @@ class FusedStage2Step(_BoundedForward):
         self.P = P = self.xyz.shape[0]
         self.K = sample_num
         self.M = self.shs.shape[1]
+        if self.incidents.shape[1] != self.M:      # the reference gives both the same degree (gaussian_model.py:421, :450)
+            raise RuntimeError("FusedStage2Step: colour and incident-light SH must hold the same number of coefficients")
         # script/run_nerf.sh:20-39 (stage 2): lambda_pbr 1, lambda_light 0.01, lambda_env_smooth 0.01; the command does not
         # pass --lambda_normal_render_depth, so that term is off (arguments/__init__.py:115) -- opt in with
         # loss_weights={"normal": 0.01}

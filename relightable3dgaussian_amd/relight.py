@@ -58,6 +58,8 @@ class RelightRenderer:
         self.dev = dev = self.xyz.device
         self.P = P = self.xyz.shape[0]
         self.K, self.M = sample_num, self.shs.shape[1]
+        if self.incidents.shape[1] != self.M:      # the reference gives both the same degree (gaussian_model.py:421, :450)
+            raise RuntimeError("RelightRenderer: colour and incident-light SH must hold the same number of coefficients")
         f = dict(dtype=torch.float32, device=dev)
         self.a_scales, self.a_rot = torch.empty(P, 3, **f), torch.empty(P, 4, **f)
         self.a_opacity, self.a_normal = torch.empty(P, 1, **f), torch.empty(P, 3, **f)
