@@ -46,9 +46,12 @@ def install():
     torch.cuda.empty_cache = lambda: None
     to = torch.Tensor.to
 
-    def to_cpu(self, *a, **k):                           # `.to("cuda")` (train.py:349, eval only)
-        a = tuple("cpu" if (isinstance(x, str) and x.startswith("cuda")) else x for x in a)
-        if isinstance(k.get("device"), str) and k["device"].startswith("cuda"):
+    def _is_cuda(x):
+        return (isinstance(x, str) and x.startswith("cuda")) or (isinstance(x, torch.device) and x.type == "cuda")
+
+    def to_cpu(self, *a, **k):       # `.to("cuda")` (train.py:349), `.to(torch.device("cuda"))` (scene/cameras.py:27-35)
+        a = tuple("cpu" if _is_cuda(x) else x for x in a)
+        if _is_cuda(k.get("device")):
             k["device"] = "cpu"
         return to(self, *a, **k)
     torch.Tensor.to = to_cpu

@@ -75,7 +75,7 @@ def test_ply_stand_in_round_trip(tmp_path):
         assert np.array_equal(v["red"], data["red"])
 
 
-def test_reference_train_py_runs_unchanged_stage1_then_stage2(tmp_path):
+def test_reference_train_py_and_relighting_py_run_unchanged(tmp_path):
     data, out1, out2 = (os.path.join(tmp_path, d) for d in ("data", "stage1", "stage2"))
     os.makedirs(data)
     _write_dataset(data)
@@ -113,3 +113,32 @@ def test_reference_train_py_runs_unchanged_stage1_then_stage2(tmp_path):
     assert st2.iteration == 18 and st2.xyz.shape[0] == st1.xyz.shape[0]          # (no densification in stage 2)
     assert st2.base_color.shape == (st2.xyz.shape[0], 3) and st2.incidents_rest.shape[1:] == (15, 3)
     assert float(st2.base_color.abs().max()) > 0 and float(st2.incidents_dc.abs().max()) > 0, "PBR groups never trained"
+    # relighting.py (composition + relight under an environment map, :102-170): two copies of the trained object from the
+    # point_cloud.ply train.py wrote (GaussianModel.save_ply -> load_ply), each under its own similarity transform, a camera
+    # trajectory, a light that turns with the frames -- update_visibility at K rays, render_neilf(is_training=False), EnvLight
+    import json
+    ply = os.path.join(out2, "point_cloud", "iteration_18", "point_cloud.ply")
+    assert os.path.isfile(ply)
+    cfg, cap = os.path.join(tmp_path, "relight_cfg"), os.path.join(tmp_path, "capture")
+    os.makedirs(cfg)
+    eye = [1.0, 0, 0, 0, 0, 1.0, 0, 0, 0, 0, 1.0, 0, 0, 0, 0, 1.0]
+    moved = [0.6, 0, 0, 1.1, 0, 0.6, 0, 0.2, 0, 0, 0.6, 0, 0, 0, 0, 1.0]
+    json.dump({"a": {"path": ply, "transform": eye}, "b": {"path": ply, "transform": moved}},
+              open(os.path.join(cfg, "transform.json"), "w"))
+    from relightable3dgaussian_amd import synthetic as syn
+    traj, lights = {}, {}
+    for i, cam in enumerate(syn.orbit_cameras(3, width=40, height=32)):
+        traj[str(i)] = cam.world_view_transform.t().reshape(-1).tolist()                  # W2C, row major
+        a = 0.4 * i
+        lights[str(i)] = [float(np.cos(a)), float(-np.sin(a)), 0.0, float(np.sin(a)), float(np.cos(a)), 0.0, 0.0, 0.0, 1.0]
+    json.dump({"camera": {"width": 40, "height": 32, "fov": 40}, "trajectory": traj}, open(os.path.join(cfg, "trajectory.json"), "w"))
+    json.dump({"transform": lights}, open(os.path.join(cfg, "light_transform.json"), "w"))
+    r = _run(["relighting.py", "-co", cfg, "-e", os.path.join(REF, "env_map", "envmap3.png"), "--output", cap, "--sample_num",
+              "16", "--capture_list", "pbr_env,render_env,base_color,normal", "-bg", "0"])
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    assert "Totally %d points loaded." % (2 * st2.xyz.shape[0]) in r.stdout
+    from PIL import Image
+    for kind in ("pbr_env", "render_env", "base_color", "normal"):
+        for i in range(3):
+            img = np.asarray(Image.open(os.path.join(cap, kind, "frame_%d.png" % i)))
+            assert img.shape[:2] == (32, 40) and img.std() > 0, (kind, i)

@@ -153,6 +153,8 @@ def _imageio_module():
     v2 = types.ModuleType("imageio.v2")
     v2.imread, v2.imwrite = imread, imwrite
     m.v2 = v2
+    # scene/envmap.py:8 calls imageio.plugins.freeimage.download() at import (a downloader for the HDR codec)
+    m.plugins = types.SimpleNamespace(freeimage=types.SimpleNamespace(download=lambda: None))
     m.__path__ = []
     return {"imageio": m, "imageio.v2": v2}
 

@@ -1,6 +1,7 @@
 #!/usr/bin/env python
 """Evidence run for SURVEY.md 8(f) n4 (this container only: needs /root/reference; no GPU here, so `--cpu-oracle`):
-the reference's unmodified train.py, stage 1 then stage 2 from its checkpoint, on a small synthetic Blender-format scene.
+the reference's unmodified train.py, stage 1 then stage 2 from its checkpoint, on a small synthetic Blender-format scene, then
+its unmodified relighting.py on a composition of the trained result.
 
     python tools/reference_train_py_cpu_demo.py > profiles/r02_reference_train_py_unchanged_cpu.txt
 """
@@ -60,6 +61,39 @@ def main():
             sys.exit(1)
         out = s1 if "stage 1" in title else s2
         print("  files: " + ", ".join(sorted(f for f in os.listdir(out))))
+    # relighting.py: two copies of the trained object composed under different transforms, a turning light, three frames
+    import json
+    import numpy as np
+    from relightable3dgaussian_amd import synthetic as syn
+    cfg, cap = os.path.join(tmp, "relight_cfg"), os.path.join(tmp, "capture")
+    os.makedirs(cfg)
+    ply = os.path.join(s2, "point_cloud", "iteration_250", "point_cloud.ply")
+    eye = [1.0, 0, 0, 0, 0, 1.0, 0, 0, 0, 0, 1.0, 0, 0, 0, 0, 1.0]
+    moved = [0.6, 0, 0, 1.1, 0, 0.6, 0, 0.2, 0, 0, 0.6, 0, 0, 0, 0, 1.0]
+    json.dump({"a": {"path": ply, "transform": eye}, "b": {"path": ply, "transform": moved}},
+              open(os.path.join(cfg, "transform.json"), "w"))
+    traj, lights = {}, {}
+    for i, cam in enumerate(syn.orbit_cameras(3, width=64, height=48)):
+        traj[str(i)] = cam.world_view_transform.t().reshape(-1).tolist()
+        a = 0.4 * i
+        lights[str(i)] = [float(np.cos(a)), float(-np.sin(a)), 0.0, float(np.sin(a)), float(np.cos(a)), 0.0, 0.0, 0.0, 1.0]
+    json.dump({"camera": {"width": 64, "height": 48, "fov": 40}, "trajectory": traj}, open(os.path.join(cfg, "trajectory.json"), "w"))
+    json.dump({"transform": lights}, open(os.path.join(cfg, "light_transform.json"), "w"))
+    args = ["relighting.py", "-co", cfg, "-e", os.path.join(REF, "env_map", "envmap3.png"), "--output", cap, "--sample_num", "24",
+            "--capture_list", "pbr_env,render_env,base_color,normal,visibility", "-bg", "0"]
+    t0 = time.time()
+    r = t._run(args, timeout=3000)
+    print("\n== relighting.py (relighting.py:102-170): composition of two objects from the point_cloud.ply train.py wrote, "
+          "envmap3.png, a light that turns with the frames ==\n$ python tools/run_reference.py --reference %s --cpu-oracle -- %s"
+          % (REF, " ".join(a.replace(tmp, "$TMP") for a in args)))
+    print("exit code %d, %.1f s" % (r.returncode, time.time() - t0))
+    for line in r.stdout.splitlines():
+        if re.search(r"Totally|stand-ins", line):
+            print("  " + line.strip())
+    if r.returncode != 0:
+        print(r.stderr[-3000:])
+        sys.exit(1)
+    print("  files: " + ", ".join("%s/%s" % (d, f) for d in sorted(os.listdir(cap)) for f in sorted(os.listdir(os.path.join(cap, d)))))
     shutil.rmtree(tmp, ignore_errors=True)
 
 
