@@ -44,6 +44,12 @@ class RelightRenderer:
         if cache not in ("radiance", "transport"):
             raise RuntimeError("RelightRenderer: cache must be 'radiance' or 'transport'")
         self.cache, self.regenerate_dirs = cache, bool(regenerate_dirs)
+        # lookup cache of the direction set for ONE light (see _taps_for)
+        self._taps = self._taps_key = self._taps_ref = None
+        self._light_key = self._light_ref = None
+        self._light_changes = 0
+        self._area_key, self._uniform_area = None, None
+        self._consts = self._zsamples = None
         d = lambda t: t.detach().contiguous()
         self.xyz, self.normal = d(model.xyz), d(model.normal)
         self.scaling, self.rotation, self.opacity = d(model.scaling), d(model.rotation), d(model.opacity)
@@ -95,17 +101,17 @@ class RelightRenderer:
         # consecutive change on, no cache: None = r3dg_shade_forward_cached evaluates the lookup itself (measured: 3.6 ms
         # per frame with a rebuild, 2.5 without).  A light that stops turning gets its cache back on
         # the next frame.
-        changed = getattr(self, "_light_key", None) != key
+        changed = self._light_key != key
         self._light_key, self._light_ref = key, (tr, self.incident_dirs, self.envmap)
-        self._light_changes = (getattr(self, "_light_changes", 0) + 1) if changed else 0
-        if self._light_changes >= 2 and getattr(self, "_uniform_area", "unset") != "unset":
+        self._light_changes = (self._light_changes + 1) if changed else 0
+        if self._light_changes >= 2 and self._area_key is not None:          # (the first frame always builds)
             return None
-        if getattr(self, "_taps_key", None) != key:
+        if self._taps_key != key:
             # the HDR map is fixed while relighting, so the SAMPLED RADIANCE of every cached direction is cached (not just
             # the lookup coordinates): the shading kernel then reads 12 bytes per sample and no texture
             self._taps = shading_ops.build_taps(self.incident_dirs, He, We, tr, radiance_of=self.envmap)
             self._taps_key, self._taps_ref = key, (tr, self.incident_dirs, self.envmap)
-            if getattr(self, "_area_key", None) != self.incident_areas.data_ptr():
+            if self._area_key != self.incident_areas.data_ptr():
                 # fibonacci_sphere_sampling gives every sample the area 2 pi: then the area cache need not be read at all
                 lo, hi = float(self.incident_areas.min()), float(self.incident_areas.max())
                 self._uniform_area = lo if lo == hi else None
@@ -113,7 +119,7 @@ class RelightRenderer:
             if self.cache == "transport":
                 # radiance -> transport in place, + the per-Gaussian constants (the buffer must not be handed to
                 # r3dg_shade_forward_cached any more: frame() takes the transport kernel whenever this cache is live)
-                if getattr(self, "_consts", None) is None:
+                if self._consts is None:
                     self._consts = torch.empty(self.P, 16, dtype=torch.float32, device=self.dev)
                     self._zsamples = sampling.fibonacci_z_samples(self.K, self.dev)[0].t().contiguous()      # [K,3]
                 with torch.cuda.device(self.dev):
