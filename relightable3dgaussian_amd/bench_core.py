@@ -456,6 +456,88 @@ def relight_transport_child(points, res, K, frames, timeout_s=150):
         return {"failed": repr(e)}
 
 
+_SHADE_SAVE_CHILD_SCRIPT = """
+import json, sys, time
+sys.path.insert(0, %(root)r)
+import torch
+from relightable3dgaussian_amd import _lib, synthetic as syn
+from relightable3dgaussian_amd.bench_core import GaussianParams, render_stage1
+from relightable3dgaussian_amd.fused_step import FusedStage2Step
+P, res, K, steps, warmup = %(P)d, %(res)d, %(K)d, %(steps)d, %(warmup)d
+dev = torch.device("cuda", 0)
+scene = syn.make_scene(P=P, seed=0, stage2=True)
+cams = [c.to(dev) for c in syn.orbit_cameras(100, width=res, height=res)[:8]]
+bg = torch.ones(3, device=dev)
+with torch.no_grad():
+    teacher = GaussianParams(syn.make_scene(P=P, seed=0, stage2=False), dev, False)
+    teacher.features_dc.add_(0.05 * torch.randn_like(teacher.features_dc))
+    gts = [render_stage1(teacher, c, bg)[2].clone() for c in cams]
+    del teacher
+params = GaussianParams(scene, dev, True)
+a = FusedStage2Step(params, K, lr=1e-4, save_shading=False)
+b = FusedStage2Step(params, K, lr=1e-4, save_shading=True)
+b.visibility, b.incident_dirs, b.incident_areas = a.visibility, a.incident_dirs, a.incident_areas
+worst = {}
+for v in (0, 3):                                # parity on the device first: outputs, loss, every gradient
+    a.forward_backward(cams[v], bg, gts[v])
+    b.forward_backward(cams[v], bg, gts[v])
+    torch.cuda.synchronize()
+    cols = [0, 1, 2, 3, 4, 5, 18]
+    pairs = [("shade_out", a.shade_out[:, cols], b.shade_out[:, cols])] + [("grad_" + k, a.grads[k], b.grads[k]) for k in a.grads]
+    for key, x, y in pairs:
+        e = float((x - y).abs().max() / x.abs().max().clamp_min(1e-30))
+        worst[key] = max(worst.get(key, 0.0), e)
+    worst["loss"] = max(worst.get("loss", 0.0), abs(float(a.loss()) - float(b.loss())) / abs(float(a.loss())))
+ok = b._shade_saved is not None and all(v == v and v < 1e-4 for v in worst.values())
+L = _lib.lib()
+out = dict(parity_vs_default_iteration=ok, max_rel_err=worst)
+for name, st in (("default", a), ("saved_intermediates", b), ("default_again", a)):
+    for i in range(warmup):
+        st(cams[i %% 8], bg, gts[i %% 8])
+    torch.cuda.synchronize()
+    L.r3dg_profile_enable(1)
+    L.r3dg_profile_pause(1)
+    t = time.perf_counter()
+    for i in range(steps):
+        L.r3dg_profile_pause(0 if i %% 8 == 0 else 1)
+        st(cams[i %% 8], bg, gts[i %% 8])
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t) / steps
+    prof = _lib.profile_read()
+    L.r3dg_profile_enable(0)
+    ms = lambda k: round(prof[k][0] / max(1, prof[k][1]), 4) if k in prof and prof[k][1] else None
+    out[name] = dict(iters_per_s=round(1.0 / dt, 2), ms_per_step=round(1e3 * dt, 4), shade_forward_ms=ms("shade_forward"),
+                     shade_backward_ms=ms("shade_backward"), dropped=st.poll_overflow())
+print(json.dumps(out))
+"""
+
+
+def shade_save_child(points, res, K, steps, warmup, timeout_s=180):
+    """FusedStage2Step(save_shading=True) -- the shading forward saves the per-sample SH sums and radiance, the backward reads
+    them instead of recomputing them (r3dg_shade_forward_saving / r3dg_shade_backward_saved) -- in a CHILD process: parity
+    with the default iteration checked on the device (outputs, loss, every gradient), then both timed on the same workload.
+    Isolated for the reason relight_transport_child is: the parent's numbers stand whatever happens here."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = _SHADE_SAVE_CHILD_SCRIPT % dict(root=root, P=points, res=res, K=K, steps=steps, warmup=warmup)
+    try:
+        r = subprocess.run([sys.executable, "-c", script], capture_output=True, text=True, timeout=timeout_s,
+                           stdin=subprocess.DEVNULL)
+        line = [x for x in r.stdout.splitlines() if x.startswith("{")]
+        if r.returncode != 0 or not line:
+            return {"failed": (r.stderr or r.stdout)[-400:]}
+        doc = json.loads(line[-1])
+        doc["what"] = ("stage-2 iteration with the shading intermediates saved by the forward (24 bytes per sample) and read by "
+                       "the backward; child process, %d Gaussians, %dx%d, K=%d, %d steps per variant; a side measurement -- "
+                       "`value` is the default iteration" % (points, res, res, K, steps))
+        return doc
+    except subprocess.TimeoutExpired:
+        return {"failed": "no result within %d s" % timeout_s}
+    except Exception as e:
+        return {"failed": repr(e)}
+
+
 def dp_path_one_rank(args, timeout_s=180):
     """The data-parallel iteration (bucketed async all-reduces on RCCL's stream, reduced skip flag, deferred incident-light
     update) over a ONE-rank RCCL group -- what the path's own structure costs before any byte crosses xGMI -- measured by a
@@ -785,6 +867,8 @@ def run(args):
                 }
                 if args.stage == 2 and not getattr(args, "unfused", False):
                     result["other_configs"]["data_parallel_path_one_rank_rccl"] = dp_path_one_rank(args)
+                    result["other_configs"]["saved_shading_intermediates"] = shade_save_child(
+                        args.points, args.res, args.sample_num, args.steps, args.warmup)
             except Exception as e:
                 result["other_configs"] = {"failed": repr(e)}
         if relight is not None and world == 1 and not getattr(args, "no_other_configs", False):
