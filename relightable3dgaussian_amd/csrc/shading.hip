@@ -590,12 +590,11 @@ __device__ __forceinline__ RowSample load_row_sample(bool live, int g, int lane,
 // (last block of the Gaussian) transposing wave reduction + store.
 // SAVE (opt-in, r3dg_shade_forward_saving): additionally write what the backward would otherwise recompute per sample --
 // the three pre-clamp SH sums of the local light and the looked-up radiance -- as six coalesced rows of K floats per
-// Gaussian, saved[(g * 6 + c) * K + k].  The pointer travels in a struct that is EMPTY for SAVE = false, so that the
-// instruction stream of every other instance stays exactly what it was.
-template <bool SAVE> struct ShadeSaveArg { float* p; };
-template <> struct ShadeSaveArg<false> {};
-__device__ __forceinline__ float* shade_save_ptr(const ShadeSaveArg<true>& a) { return a.p; }
-__device__ __forceinline__ float* shade_save_ptr(const ShadeSaveArg<false>&) { return nullptr; }
+// Gaussian, saved[(g * 6 + c) * K + k].  The buffer's address travels in a __device__ variable (set on the launch stream
+// right before the launch), NOT in the kernel arguments: the signature and the code of every other instance stay
+// exactly what they were (checked by diffing the assembly).
+__device__ float* g_shade_saved_fwd = nullptr;
+__device__ const float* g_shade_saved_bwd = nullptr;
 
 template <int NOUT, bool ENV_LDS, int TAPS /* 0 lookup in kernel, 1 cached lookup, 2 cached radiance */, bool M16,
           bool SAVE = false>
@@ -604,9 +603,9 @@ shade_forward_row_kernel(int P, int K, int M_, const float* __restrict__ rec, co
                          const float4* __restrict__ env4, int He, int We,
                          const float* __restrict__ tr, const float* __restrict__ visibility,
                          const float* __restrict__ dirs, const float* __restrict__ areas, float uniform_area,
-                         const uint32_t* __restrict__ taps, float* __restrict__ out, ShadeSaveArg<SAVE> save_arg)
+                         const uint32_t* __restrict__ taps, float* __restrict__ out)
 {
-    float* const saved = shade_save_ptr(save_arg);
+    float* const saved = SAVE ? g_shade_saved_fwd : nullptr;
     static_assert(NOUT == 7 || NOUT == 19, "training (pbr, diffuse_light, mean visibility) or all 19 outputs");
     constexpr int NV = NOUT == 7 ? 8 : 32;
     const int M = M16 ? 16 : M_;                 // degree-3 incident light (the reference's only configuration) folds the
@@ -1045,10 +1044,9 @@ __global__ void __launch_bounds__(64 * SHADE_WAVES)
 shade_backward_kernel(int P, int K, int M, ShadeSrc src, const float* __restrict__ env, int He, int We,
                       const float* __restrict__ tr, float* __restrict__ d_base, float* __restrict__ d_rough,
                       float* __restrict__ d_view, float* __restrict__ d_inc, float* __restrict__ d_env,
-                      const unsigned int* __restrict__ gmax_bits, int gmax_n, const uint32_t* __restrict__ taps,
-                      ShadeSaveArg<SAVED> save_arg)
+                      const unsigned int* __restrict__ gmax_bits, int gmax_n, const uint32_t* __restrict__ taps)
 {
-    const float* const saved = shade_save_ptr(save_arg);
+    const float* const saved = SAVED ? g_shade_saved_bwd : nullptr;      // (set on the stream in front of the launch)
     extern __shared__ __attribute__((aligned(16))) float s_mem[];
     const int ntex_raw = He * We * 3;
     const int ntex = ENV_LDS ? ((ntex_raw + 3) & ~3) : 0;
@@ -1747,18 +1745,17 @@ void launch_shade_forward(hipStream_t s, int P, int K, int M, const float* base_
         if (leave_room && g_shade_row_blocks_per_cu == 0 && bpc > 3) bpc = 3;                                         \
         const int cap = shade_cus() * bpc;                                                                            \
         const int grid = want < cap ? want : cap;                                                                     \
-        if (saved != nullptr && N == 7 && T == 1)                                                                     \
+        if (saved != nullptr && N == 7 && T == 1) {                                                                   \
+            R3DG_HIP(hipMemcpyToSymbolAsync(HIP_SYMBOL(g_shade_saved_fwd), &saved, sizeof(saved), 0,                  \
+                                            hipMemcpyHostToDevice, s));                                               \
             shade_forward_row_kernel<7, L, 1, true, true><<<grid, 64 * ROW_WAVES, smem, s>>>(                         \
-                P, K, M, rec, incidents, env4, He, We, tr, visibility, dirs, areas, uniform_area, taps, out,          \
-                ShadeSaveArg<true>{saved});                                                                           \
-        else if (M == 16)                                                                                             \
+                P, K, M, rec, incidents, env4, He, We, tr, visibility, dirs, areas, uniform_area, taps, out);         \
+        } else if (M == 16)                                                                                             \
             shade_forward_row_kernel<N, L, T, true><<<grid, 64 * ROW_WAVES, smem, s>>>(                               \
-                P, K, M, rec, incidents, env4, He, We, tr, visibility, dirs, areas, uniform_area, taps, out,          \
-                ShadeSaveArg<false>{});                                                                               \
+                P, K, M, rec, incidents, env4, He, We, tr, visibility, dirs, areas, uniform_area, taps, out);         \
         else                                                                                                          \
             shade_forward_row_kernel<N, L, T, false><<<grid, 64 * ROW_WAVES, smem, s>>>(                              \
-                P, K, M, rec, incidents, env4, He, We, tr, visibility, dirs, areas, uniform_area, taps, out,          \
-                ShadeSaveArg<false>{});                                                                               \
+                P, K, M, rec, incidents, env4, He, We, tr, visibility, dirs, areas, uniform_area, taps, out);         \
     } while (0)
 #define R3DG_ROW_MODE(N, L)                                                                                           \
     do {                                                                                                              \
@@ -1845,7 +1842,7 @@ void launch_shade_backward(hipStream_t s, int P, int K, int M, const float* base
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));                     \
         shade_backward_kernel<L, V, T><<<grid, 64 * SHADE_WAVES, smem, s>>>(P, K, M, src, env, He, We, tr, d_base,    \
                                                                           d_rough, d_view, d_inc, d_env, gmax,        \
-                                                                          gmax_n, taps, ShadeSaveArg<false>{});       \
+                                                                          gmax_n, taps);                              \
     } while (0)
 #define R3DG_SB(L, V)                                                                                                 \
     do {                                                                                                              \
@@ -1860,9 +1857,9 @@ void launch_shade_backward(hipStream_t s, int P, int K, int M, const float* base
         if (smem > 65536)
             R3DG_HIP(hipFuncSetAttribute((const void*)shade_backward_kernel<true, true, true, true>,
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+        R3DG_HIP(hipMemcpyToSymbolAsync(HIP_SYMBOL(g_shade_saved_bwd), &saved, sizeof(saved), 0, hipMemcpyHostToDevice, s));
         shade_backward_kernel<true, true, true, true><<<grid, 64 * SHADE_WAVES, smem, s>>>(
-            P, K, M, src, env, He, We, tr, d_base, d_rough, d_view, d_inc, d_env, gmax, gmax_n, taps,
-            ShadeSaveArg<true>{const_cast<float*>(saved)});
+            P, K, M, src, env, He, We, tr, d_base, d_rough, d_view, d_inc, d_env, gmax, gmax_n, taps);
     } else if (lds) { if (vec) R3DG_SB(true, true); else R3DG_SB(true, false); }
     else { if (vec) R3DG_SB(false, true); else R3DG_SB(false, false); }
 #undef R3DG_SB
