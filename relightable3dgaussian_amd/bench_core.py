@@ -661,6 +661,15 @@ def _plumbing_only(args, world, rank, backend):
 def run(args):
     # the host driver only supports dmabuf IPC: must be in the environment before the first HIP call initialises the runtime
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    t_start = time.perf_counter()
+
+    def side_budget(want_s):
+        """Seconds a side measurement in a child process may still take: the default run is meant to finish within minutes,
+        so the children share what is left of ~4 minutes since the start (0 = skip it); R3DG_BENCH_NO_CHILDREN=1 skips all."""
+        if os.environ.get("R3DG_BENCH_NO_CHILDREN") == "1":
+            return 0
+        left = 240.0 - (time.perf_counter() - t_start)
+        return int(min(want_s, left)) if left >= 45.0 else 0
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -866,14 +875,19 @@ def run(args):
                     "stage1_densify_and_prune (one call at the bench size)": densify_bench(args.points, args.res, dev),
                 }
                 if args.stage == 2 and not getattr(args, "unfused", False):
-                    result["other_configs"]["data_parallel_path_one_rank_rccl"] = dp_path_one_rank(args)
+                    skipped = {"skipped": "time budget of the default run used up (or R3DG_BENCH_NO_CHILDREN=1)"}
+                    b = side_budget(150)
                     result["other_configs"]["saved_shading_intermediates"] = shade_save_child(
-                        args.points, args.res, args.sample_num, args.steps, args.warmup)
+                        args.points, args.res, args.sample_num, args.steps, args.warmup, timeout_s=b) if b else skipped
+                    b = side_budget(150)
+                    result["other_configs"]["data_parallel_path_one_rank_rccl"] = dp_path_one_rank(args, timeout_s=b) if b else skipped
             except Exception as e:
                 result["other_configs"] = {"failed": repr(e)}
         if relight is not None and world == 1 and not getattr(args, "no_other_configs", False):
+            b = side_budget(150)
             result["relight"]["relight_transport_cache"] = relight_transport_child(
-                args.points, args.res, args.relight_samples, max(4, args.relight_frames // 2))
+                args.points, args.res, args.relight_samples, max(4, args.relight_frames // 2), timeout_s=b) if b else {
+                    "skipped": "time budget of the default run used up (or R3DG_BENCH_NO_CHILDREN=1)"}
         if not args.no_cpu_baseline and world == 1:
             try:
                 result["cpu_baseline"] = cpu_baseline(scene, cams_cpu, S, args.cpu_baseline_seconds, args.points, args.res)
