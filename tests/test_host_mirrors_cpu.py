@@ -477,3 +477,83 @@ def test_checkpoint_defaults_follow_the_reference_flow():
     assert s2.base_color.shape == (P, 3) and s2.roughness.shape == (P, 1) and s2.incidents_dc.shape == (P, 1, 3)
     assert s2.incidents_rest.shape == (P, 15, 3) and s2.visibility_rest.shape == (P, 15, 1)
     assert all(float(t.abs().max()) == 0.0 for t in (s2.base_color, s2.roughness, s2.incidents_dc, s2.incidents_rest))
+
+
+@pytest.mark.parametrize("save_shading", [False, True])
+def test_fused_stage2_iteration_host_logic_with_a_recording_library(monkeypatch, save_shading):
+    """The Python side of FusedStage2Step.__call__ with every C-ABI entry point and the rasterizer replaced by recorders
+    (nothing runs on a GPU): the order of the calls of one iteration, the bounded forward from the second iteration on, and
+    -- opt-in -- the saved-activation pair (r3dg_shade_forward_saving / r3dg_shade_backward_saved) with ONE buffer of
+    P * 6 * K floats handed from the forward to the backward."""
+    import contextlib
+    import types
+    from relightable3dgaussian_amd import _lib, fused_step, rasterizer_ops, shading_ops
+    calls = []
+
+    class Recorder:
+        def __getattr__(self, name):
+            def fn(*args):
+                calls.append((name, args))
+                return 0
+            return fn
+
+    P, K, H, W = 6, 8, 4, 4
+    z = torch.zeros
+    monkeypatch.setattr(_lib, "lib", lambda: Recorder())
+    monkeypatch.setattr(_lib, "current_stream", lambda: 0)
+    monkeypatch.setattr(torch.cuda, "device", lambda d: contextlib.nullcontext())
+    monkeypatch.setattr(torch.cuda, "stream", lambda s: contextlib.nullcontext())
+
+    class FakeStream:
+        def wait_stream(self, other):
+            pass
+    monkeypatch.setattr(torch.cuda, "Stream", lambda device=None: FakeStream())
+    monkeypatch.setattr(torch.cuda, "current_stream", lambda *a: FakeStream())
+    monkeypatch.setattr(fused_step, "update_visibility", lambda *a, **k: (torch.ones(P, K, 1), torch.ones(P, K, 3),
+                                                                          torch.full((P, K, 1), 2.0), None))
+    monkeypatch.setattr(shading_ops, "build_taps", lambda dirs, He, We, *a, **k: z(P * K * 3))
+    monkeypatch.setattr(shading_ops, "_c", lambda t: t.contiguous())             # (its device check is not under test)
+    begun = []
+
+    class Pending:
+        def finish(self, ordering_stream=None):
+            return (17, z(H, W, dtype=torch.int32), z(3, H, W), z(1, H, W), z(1, H, W), z(16, H, W), z(3, H, W), z(3, H, W),
+                    z(P, 1), z(P, dtype=torch.int32), z(64, dtype=torch.uint8), z(8, dtype=torch.uint8), z(8, dtype=torch.uint8))
+
+    def begin(*a, **k):
+        begun.append(k.get("capacity"))
+        return Pending()
+    monkeypatch.setattr(rasterizer_ops, "rasterize_gaussians_begin", begin)
+    monkeypatch.setattr(rasterizer_ops, "rasterize_gaussians_backward", lambda *a, **k: (
+        z(P, 3), z(P, 3), z(P, 1), z(P, 3), z(P, 16), z(P, 6), z(P, 16, 3), z(P, 3), z(P, 4)))
+    monkeypatch.setattr(rasterizer_ops, "num_rendered_of", lambda geom, P_: torch.tensor(17))
+    params = types.SimpleNamespace(xyz=z(P, 3), normal=z(P, 3), scaling=z(P, 3), rotation=z(P, 4), opacity=z(P, 1),
+                                   features_dc=z(P, 1, 3), features_rest=z(P, 15, 3), base_color=z(P, 3), roughness=z(P, 1),
+                                   incidents_dc=z(P, 1, 3), incidents_rest=z(P, 15, 3), env=z(1, 16, 32, 3))
+    cam = types.SimpleNamespace(image_height=H, image_width=W, world_view_transform=torch.eye(4), full_proj_transform=torch.eye(4),
+                                camera_center=z(3), tanfovx=0.5, tanfovy=0.5, cx=2.0, cy=2.0)
+    step = fused_step.FusedStage2Step(params, K, save_shading=save_shading)
+    calls.clear()
+    for _ in range(3):
+        step(cam, torch.ones(3), z(3, H, W))
+    names = [c[0] for c in calls]
+    assert begun[0] is None and begun[1] == begun[2] == step._capacity_for(17)      # two-phase first, bounded afterwards
+    fwd, bwd = ("r3dg_shade_forward_saving", "r3dg_shade_backward_saved") if save_shading else (
+        "r3dg_shade_forward_cached", "r3dg_shade_backward_cached")
+    assert names.count(fwd) == 3 and names.count(bwd) == 3 and names.count("r3dg_adam_step") == 6
+    other = ("r3dg_shade_forward_cached", "r3dg_shade_backward_cached") if save_shading else (
+        "r3dg_shade_forward_saving", "r3dg_shade_backward_saved")
+    assert not any(n in names for n in other)
+    one = names[names.index("r3dg_stage2_activate"):]
+    order = [n for n in one if n in (fwd, "r3dg_stage2_pack_features", "r3dg_ssim_forward_pair", "r3dg_stage2_loss",
+                                     "r3dg_stage2_unpack_gradients", bwd, "r3dg_stage2_activate_backward", "r3dg_adam_step")][:9]
+    assert order == [fwd, "r3dg_stage2_pack_features", "r3dg_ssim_forward_pair", "r3dg_stage2_loss", "r3dg_adam_step",
+                     "r3dg_stage2_unpack_gradients", bwd, "r3dg_stage2_activate_backward", "r3dg_adam_step"], order
+    if save_shading:
+        f_args = [c[1] for c in calls if c[0] == fwd][0]
+        b_args = [c[1] for c in calls if c[0] == bwd][0]
+        assert len(f_args) == 20 and len(b_args) == 26
+        assert f_args[-1] == b_args[16] == step._shade_saved.data_ptr() and step._shade_saved.numel() == P * 6 * K
+        assert f_args[16] == b_args[15] and f_args[17] & 1                          # the same lookup records; training outputs
+    else:
+        assert step._shade_saved is None
