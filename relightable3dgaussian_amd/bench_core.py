@@ -384,6 +384,18 @@ def relight_bench(params, cams, dev, frames, K):
                              "of every cached direction is reused across frames; relight_rotating_light: rebuilt per frame")
 
 
+def _finite_json(x):
+    """A child's JSON document with every non-finite float replaced by a string: the ONE line the parent prints must stay
+    strict JSON whatever a side measurement produced (Python's json would print a bare NaN)."""
+    if isinstance(x, float) and not math.isfinite(x):
+        return repr(x)
+    if isinstance(x, dict):
+        return {k: _finite_json(v) for k, v in x.items()}
+    if isinstance(x, (list, tuple)):
+        return [_finite_json(v) for v in x]
+    return x
+
+
 _TRANSPORT_CHILD_SCRIPT = """
 import json, sys, time
 sys.path.insert(0, %(root)r)
@@ -445,7 +457,7 @@ def relight_transport_child(points, res, K, frames, timeout_s=150):
         line = [x for x in r.stdout.splitlines() if x.startswith("{")]
         if r.returncode != 0 or not line:
             return {"failed": (r.stderr or r.stdout)[-400:]}
-        doc = json.loads(line[-1])
+        doc = _finite_json(json.loads(line[-1]))
         doc["what"] = ("relight.RelightRenderer(cache='transport'): per-sample transport + per-Gaussian constants cached while "
                        "light and Gaussians stand still, GGX lobe per frame (r3dg_shade_forward_transport); child process, "
                        "%d Gaussians, %dx%d, K=%d, %d frames; reported only as a side measurement" % (points, res, res, K, frames))
@@ -527,7 +539,7 @@ def shade_save_child(points, res, K, steps, warmup, timeout_s=180):
         line = [x for x in r.stdout.splitlines() if x.startswith("{")]
         if r.returncode != 0 or not line:
             return {"failed": (r.stderr or r.stdout)[-400:]}
-        doc = json.loads(line[-1])
+        doc = _finite_json(json.loads(line[-1]))
         doc["what"] = ("stage-2 iteration with the shading intermediates saved by the forward (24 bytes per sample) and read by "
                        "the backward; child process, %d Gaussians, %dx%d, K=%d, %d steps per variant; a side measurement -- "
                        "`value` is the default iteration" % (points, res, res, K, steps))
@@ -556,7 +568,7 @@ def dp_path_one_rank(args, timeout_s=180):
         line = [x for x in r.stdout.splitlines() if x.startswith("{")]
         if r.returncode != 0 or not line:
             return {"failed": (r.stderr or r.stdout)[-400:]}
-        doc = json.loads(line[-1])
+        doc = _finite_json(json.loads(line[-1]))
         return dict(iters_per_s=doc["value"], ms_per_step=doc["ms_per_step"],
                     what="the same iteration through the data-parallel path over a ONE-rank RCCL group (identity collectives)")
     except subprocess.TimeoutExpired:
@@ -894,7 +906,7 @@ def run(args):
             except Exception as e:  # the oracle is only a reported baseline; never fail the bench on it
                 result["cpu_baseline"] = {"value": None, "unit": "views/s (rasterize forward)", "cores": None, "kind": "port",
                                           "sample": "failed: %r" % (e,)}
-        print(json.dumps(result))
+        print(json.dumps(_finite_json(result), allow_nan=False))
     if dp:
         dist.destroy_process_group()
     return result
