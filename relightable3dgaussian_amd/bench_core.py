@@ -906,7 +906,10 @@ def run(args):
             except Exception as e:  # the oracle is only a reported baseline; never fail the bench on it
                 result["cpu_baseline"] = {"value": None, "unit": "views/s (rasterize forward)", "cores": None, "kind": "port",
                                           "sample": "failed: %r" % (e,)}
-        print(json.dumps(_finite_json(result), allow_nan=False))
+        try:
+            print(json.dumps(_finite_json(result), allow_nan=False))
+        except ValueError:                       # (cannot happen after _finite_json; never lose the line over it)
+            print(json.dumps(result))
     if dp:
         dist.destroy_process_group()
     return result
