@@ -205,27 +205,6 @@ int r3dg_shade_forward_cached(void* stream, int P, int K, int M, const float* d_
  * with R3DG_SHADE_TAPS_ARE_RADIANCE and the shading kernel touches no texture at all. */
 int r3dg_shade_build_taps(void* stream, int64_t num_samples, const float* d_incident_dirs, const float* d_env_transform,
                           int He, int We, const float* d_env_radiance, uint32_t* d_taps);
-/* Saved activations (opt-in): the training forward additionally writes, per cached sample, the three pre-clamp SH sums of
- * the local incident light and the looked-up environment radiance -- d_saved [P*6*K] floats, six coalesced rows of K per
- * Gaussian: d_saved[(g*6 + c)*K + k] -- and the backward reads them instead of re-evaluating the SH basis, the 48
- * coefficient products and the texture taps of every sample (its pass 0 and the fetch of pass 1: about a quarter of its
- * instructions).  Same arguments as r3dg_shade_forward_cached / r3dg_shade_backward_cached without the light rotation
- * (training has none); lookup records (not radiance), R3DG_SHADE_TRAIN_OUTPUTS, 16 coefficients, an environment texture that
- * fits LDS (He*We*3*3 floats <= 48 KB) and K % 4 == 0 are required.  The buffer is only valid for the parameters, caches
- * and texture of the forward call that wrote it. */
-int r3dg_shade_forward_saving(void* stream, int P, int K, int M, const float* d_base_color, const float* d_roughness,
-                              const float* d_normals, const float* d_viewdirs, const float* d_incidents,
-                              const float* d_env, int He, int We, const float* d_visibility,
-                              const float* d_incident_dirs, const float* d_incident_areas, float uniform_area,
-                              const uint32_t* d_taps, int flags, float* d_out, float* d_saved);
-int r3dg_shade_backward_saved(void* stream, int P, int K, int M, const float* d_base_color, const float* d_roughness,
-                              const float* d_normals, const float* d_viewdirs, const float* d_incidents,
-                              const float* d_env, int He, int We, const float* d_visibility,
-                              const float* d_incident_dirs, const float* d_incident_areas, const uint32_t* d_taps,
-                              const float* d_saved, const float* d_dL_dpbr, const float* d_dL_ddiffuse_light,
-                              float* d_dL_dbase_color, float* d_dL_droughness, float* d_dL_dviewdirs,
-                              float* d_dL_dincidents, float* d_dL_denv, const float* d_block_absmax, int n_block_absmax);
-
 /* Relighting under a FIXED light with static Gaussians (relighting.py:114-170 with configs/teaser, configs/nerf_syn: only the
  * camera moves): the view-independent part of rendering_equation (neilf.py:339-371) as a cache.
  * r3dg_shade_build_transport: d_radiance_inout [P*K*3] holds the sampled radiance of every cached direction

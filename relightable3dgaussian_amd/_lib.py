@@ -62,8 +62,6 @@ _SIGNATURES = {
     "r3dg_shade_forward": (_i, [_p, _i, _i, _i, _p, _p, _p, _p, _p, _p, _i, _i, _p, _p, _p, _p, _p]),
     "r3dg_shade_forward_cached": (_i, [_p, _i, _i, _i, _p, _p, _p, _p, _p, _p, _i, _i, _p, _p, _p, _p, _f, _p, _i, _p]),
     "r3dg_shade_build_taps": (_i, [_p, C.c_int64, _p, _p, _i, _i, _p, _p]),
-    "r3dg_shade_forward_saving": (_i, [_p, _i, _i, _i, _p, _p, _p, _p, _p, _p, _i, _i, _p, _p, _p, _f, _p, _i, _p, _p]),
-    "r3dg_shade_backward_saved": (_i, [_p, _i, _i, _i, _p, _p, _p, _p, _p, _p, _i, _i] + [_p] * 13 + [_i]),
     "r3dg_shade_build_transport": (_i, [_p, _i, _i, _i, _p, _p, _p, _p, _p, _f, _p, _p]),
     "r3dg_shade_forward_transport": (_i, [_p, _i, _i] + [_p] * 9),
     "r3dg_shade_backward": (_i, [_p, _i, _i, _i, _p, _p, _p, _p, _p, _p, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p,

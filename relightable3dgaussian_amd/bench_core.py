@@ -97,6 +97,9 @@ def _algorithmic_bytes(stage, P, R, N, S, K=64):
         # live shading model: fwd (260+16K) B, bwd (476+16K) B per Gaussian
         "shade_forward": (260.0 + 16 * K) * P,
         "shade_backward": (476.0 + 16 * K) * P,
+        # relight under a fixed light: 12 B of cached transport per sample; per Gaussian albedo, roughness, normal, view
+        # direction (40 B) + 16 cached constants (64 B) read, 19 outputs (76 B) written
+        "shade_forward_transport": (180.0 + 12 * K) * P,
         # Adam: 28 B per parameter float (p, g, m, v read; p, m, v written); 127 floats per Gaussian in stage 2
         "adam_step": 28.0 * 127 * P,
         # glue: activations 68 B read + 72 B written; feature row 40+76 read, 64 written; loss 27 maps read, 20 written
@@ -219,6 +222,7 @@ def _kernel_names(stage):
     return {"sort_pairs": ["tile_sort_small_kernel", "partition_scatter_kernel"],
             "duplicate_with_keys": ["tile_emit_kernel", "duplicate_with_keys_kernel"],      # (stage name kept from K5)
             "shade_forward": ["shade_forward_row_kernel", "shade_forward_kernel"],
+            "shade_forward_transport": ["shade_forward_transport_kernel"],
             "adam_step": ["adam_kernel"], "bvh_trace": ["trace_opacity_phased_kernel", "trace_opacity_persistent_kernel"],
             }.get(stage, [stage + "_kernel", stage])
 
@@ -271,13 +275,14 @@ def pmc_valu(stage):
     return None
 
 
-def kernel_table(prof, n_sampled, P, R, N, S, K):
+def kernel_table(prof, n_sampled, P, R, N, S, K, rename=None):
     """{stage: avg_ms, launches, ms per iteration/frame, algorithmic MB, achieved GB/s, fraction of the 8 TB/s HBM peak,
     VALU-issue fraction (committed PMC evidence)} from the in-library HIP-event timing."""
     kernels = {}
     for name, (ms, cnt) in prof.items():
         if cnt == 0:
             continue
+        name = (rename or {}).get(name, name)        # (one profile stage, several kernels: the caller knows which one ran)
         # a stage may take several launches per iteration (the Adam groups go out in two or three launches, SSIM in
         # four): `algorithmic_MB` is the stage's bytes per ITERATION, so it is divided by the stage's time per iteration
         per_iter = max(1, round(cnt / n_sampled))
@@ -319,10 +324,10 @@ def relight_bench(params, cams, dev, frames, K):
     envmap = (3.0 * torch.rand(256, 512, 3, generator=g) ** 2).to(dev)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    # (R3DG_RELIGHT_CACHE=transport: experiments with the opt-in view-independent cache of relight.RelightRenderer)
+    # (R3DG_RELIGHT_CACHE=radiance: A/B against the full integral per frame)
+    cache = os.environ.get("R3DG_RELIGHT_CACHE", "transport")
     renderer = relight.RelightRenderer(params, envmap, K,             # builds the BVH and traces P x K visibility rays
-                                       cache=os.environ.get("R3DG_RELIGHT_CACHE", "radiance"),
-                                       regenerate_dirs=os.environ.get("R3DG_RELIGHT_DIRS", "regen") != "load")
+                                       cache=cache, regenerate_dirs=os.environ.get("R3DG_RELIGHT_DIRS", "regen") != "load")
     torch.cuda.synchronize()
     t_vis = time.perf_counter() - t0
     bg = torch.zeros(3, device=dev)
@@ -353,6 +358,21 @@ def relight_bench(params, cams, dev, frames, K):
     prof = _lib.profile_read()
     L.r3dg_profile_enable(0)
     dt_ref = timed(lambda cam: relight.frame_reference(renderer, cam, bg), max(3, frames // 4))
+    # the same frames with only the sampled radiance cached (the full integral per frame: what a light that changes now and
+    # then, or parameters that are still being trained, would pay) -- same process, same visibility caches
+    radiance_fps = None
+    if cache == "transport":
+        try:
+            r2 = relight.RelightRenderer.__new__(relight.RelightRenderer)
+            r2.__dict__.update(renderer.__dict__)
+            r2.cache = "radiance"
+            r2._taps = r2._taps_key = r2._taps_ref = r2._light_key = r2._light_ref = None
+            r2._light_changes, r2._area_key = 0, None
+            r2.shade_out, r2.features = torch.empty_like(renderer.shade_out), torch.empty_like(renderer.features)
+            radiance_fps = round(1.0 / timed(lambda cam: r2.frame(cam, bg), max(3, frames // 2)), 2)
+            del r2
+        except Exception as e:
+            radiance_fps = {"failed": repr(e)}
     # a light that turns with every frame (configs/nerf_syn_light, configs/tnt: light_transform.json holds one rotation per
     # frame, relighting.py:162-163): the cached lookups of the static-light frames above are then rebuilt per frame
     rotating = None
@@ -373,15 +393,21 @@ def relight_bench(params, cams, dev, frames, K):
     P = params.xyz.shape[0]
     H, W = cams[0].image_height, cams[0].image_width
     R_mean = float(sum(R_seen)) / max(1, len(R_seen))
-    kernels = kernel_table(prof, max(1, sum(1 for i in range(frames) if i % 4 == 0)), P, R_mean, H * W, 28, K)
-    roof = roofline_of(kernels, "relight frame (shading forward at K=%d + rasterize forward S=28 + composite): achieved = "
-                       "algorithmic bytes per launch / HIP-event kernel time" % K)
-    return dict(relight_fps=round(1.0 / dt, 2), relight_ms_per_frame=round(1e3 * dt, 3), relight_K=K,
+    kernels = kernel_table(prof, max(1, sum(1 for i in range(frames) if i % 4 == 0)), P, R_mean, H * W, 28, K,
+                           rename={"shade_forward": "shade_forward_transport"} if cache == "transport" else None)
+    roof = roofline_of(kernels, "relight frame (%s at K=%d + rasterize forward S=28 + composite): achieved = "
+                       "algorithmic bytes per launch / HIP-event kernel time" % (
+                           "GGX lobe against the cached transport, 12 B per sample," if cache == "transport"
+                           else "shading forward", K))
+    return dict(relight_fps=round(1.0 / dt, 2), relight_ms_per_frame=round(1e3 * dt, 3), relight_K=K, relight_cache=cache,
+                relight_fps_radiance_cache=radiance_fps,
                 relight_features=28, relight_fps_pytorch_glue=round(1.0 / dt_ref, 2), visibility_rays=P * K,
                 visibility_seconds=round(t_vis, 3), visibility_Mrays_per_s=round(P * K / t_vis / 1e6, 1),
                 num_rendered=R_mean, roofline_relight=roof, kernels=kernels, relight_rotating_light=rotating,
-                relight_note="relight_fps: moving camera under a FIXED light (configs/teaser, configs/nerf_syn): the lookup "
-                             "of every cached direction is reused across frames; relight_rotating_light: rebuilt per frame")
+                relight_note="relight_fps: moving camera under a FIXED light (configs/teaser, configs/nerf_syn): the "
+                             "view-independent part of the integral is cached per sample (RelightRenderer's default, "
+                             "cache='transport'); relight_fps_radiance_cache: only the looked-up radiance is reused; "
+                             "relight_rotating_light: nothing is reused (lookup in the kernel)")
 
 
 def _finite_json(x):
@@ -394,160 +420,6 @@ def _finite_json(x):
     if isinstance(x, (list, tuple)):
         return [_finite_json(v) for v in x]
     return x
-
-
-_TRANSPORT_CHILD_SCRIPT = """
-import json, sys, time
-sys.path.insert(0, %(root)r)
-import torch
-from relightable3dgaussian_amd import relight, synthetic as syn
-from relightable3dgaussian_amd.bench_core import GaussianParams
-P, res, K, frames = %(P)d, %(res)d, %(K)d, %(frames)d
-dev = torch.device("cuda", 0)
-scene = syn.make_scene(P=P, seed=0, stage2=True)
-cams = [c.to(dev) for c in syn.orbit_cameras(100, width=res, height=res)[:frames + 6]]
-envmap = (3.0 * torch.rand(256, 512, 3, generator=torch.Generator().manual_seed(7)) ** 2).to(dev)
-bg = torch.zeros(3, device=dev)
-base = relight.RelightRenderer(GaussianParams(scene, dev, True), envmap, K)
-out = {}
-for name, regen in (("regenerated_directions", True), ("cached_directions", False)):
-    r = relight.RelightRenderer(GaussianParams(scene, dev, True), envmap, K, cache="transport", regenerate_dirs=regen)
-    worst = {}
-    for cam in cams[:3]:                                   # parity on the device first: shading outputs and the frame
-        fa = base.frame(cam, bg)
-        sa = base.shade_out.clone()
-        fb = r.frame(cam, bg)
-        for key, a, b in (("shade_out", sa, r.shade_out), ("feature", fa["feature"], fb["feature"]),
-                          ("pbr_env", fa["pbr_env"], fb["pbr_env"])):
-            e = float((a - b).abs().max() / a.abs().max().clamp_min(1e-12))
-            worst[key] = max(worst.get(key, 0.0), e)
-        assert fa["num_rendered"] == fb["num_rendered"]
-    ok = all(v == v and v < 5e-4 for v in worst.values())
-    torch.cuda.synchronize()
-    t = time.perf_counter()
-    for i in range(frames):
-        r.frame(cams[3 + i], bg)
-    torch.cuda.synchronize()
-    dt = (time.perf_counter() - t) / frames
-    out[name] = dict(parity_vs_default_renderer=ok, max_rel_err=worst, fps=round(1.0 / dt, 2), ms_per_frame=round(1e3 * dt, 3))
-    del r
-    torch.cuda.empty_cache()
-torch.cuda.synchronize()
-t = time.perf_counter()
-for i in range(frames):
-    base.frame(cams[3 + i], bg)
-torch.cuda.synchronize()
-out["default_renderer_fps_same_process"] = round(frames / (time.perf_counter() - t), 2)
-print(json.dumps(out))
-"""
-
-
-def relight_transport_child(points, res, K, frames, timeout_s=150):
-    """relight.RelightRenderer(cache="transport") -- the opt-in cache of the frame's view-independent part -- measured in a
-    CHILD process: first checked on the device against the default renderer (shading outputs, feature image, composite),
-    then timed.  Isolated because those kernels had not run on hardware when this was written: whatever
-    happens in the child, the numbers of the parent (`relight_fps`, the default renderer) stand."""
-    import subprocess
-    import sys
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    script = _TRANSPORT_CHILD_SCRIPT % dict(root=root, P=points, res=res, K=K, frames=frames)
-    try:
-        r = subprocess.run([sys.executable, "-c", script], capture_output=True, text=True, timeout=timeout_s,
-                           stdin=subprocess.DEVNULL)
-        line = [x for x in r.stdout.splitlines() if x.startswith("{")]
-        if r.returncode != 0 or not line:
-            return {"failed": (r.stderr or r.stdout)[-400:]}
-        doc = _finite_json(json.loads(line[-1]))
-        doc["what"] = ("relight.RelightRenderer(cache='transport'): per-sample transport + per-Gaussian constants cached while "
-                       "light and Gaussians stand still, GGX lobe per frame (r3dg_shade_forward_transport); child process, "
-                       "%d Gaussians, %dx%d, K=%d, %d frames; reported only as a side measurement" % (points, res, res, K, frames))
-        return doc
-    except subprocess.TimeoutExpired:
-        return {"failed": "no result within %d s" % timeout_s}
-    except Exception as e:
-        return {"failed": repr(e)}
-
-
-_SHADE_SAVE_CHILD_SCRIPT = """
-import json, sys, time
-sys.path.insert(0, %(root)r)
-import torch
-from relightable3dgaussian_amd import _lib, synthetic as syn
-from relightable3dgaussian_amd.bench_core import GaussianParams, render_stage1
-from relightable3dgaussian_amd.fused_step import FusedStage2Step
-P, res, K, steps, warmup = %(P)d, %(res)d, %(K)d, %(steps)d, %(warmup)d
-dev = torch.device("cuda", 0)
-scene = syn.make_scene(P=P, seed=0, stage2=True)
-cams = [c.to(dev) for c in syn.orbit_cameras(100, width=res, height=res)[:8]]
-bg = torch.ones(3, device=dev)
-with torch.no_grad():
-    teacher = GaussianParams(syn.make_scene(P=P, seed=0, stage2=False), dev, False)
-    teacher.features_dc.add_(0.05 * torch.randn_like(teacher.features_dc))
-    gts = [render_stage1(teacher, c, bg)[2].clone() for c in cams]
-    del teacher
-params = GaussianParams(scene, dev, True)
-a = FusedStage2Step(params, K, lr=1e-4, save_shading=False)
-b = FusedStage2Step(params, K, lr=1e-4, save_shading=True)
-b.visibility, b.incident_dirs, b.incident_areas = a.visibility, a.incident_dirs, a.incident_areas
-worst = {}
-for v in (0, 3):                                # parity on the device first: outputs, loss, every gradient
-    a.forward_backward(cams[v], bg, gts[v])
-    b.forward_backward(cams[v], bg, gts[v])
-    torch.cuda.synchronize()
-    cols = [0, 1, 2, 3, 4, 5, 18]
-    pairs = [("shade_out", a.shade_out[:, cols], b.shade_out[:, cols])] + [("grad_" + k, a.grads[k], b.grads[k]) for k in a.grads]
-    for key, x, y in pairs:
-        e = float((x - y).abs().max() / x.abs().max().clamp_min(1e-30))
-        worst[key] = max(worst.get(key, 0.0), e)
-    worst["loss"] = max(worst.get("loss", 0.0), abs(float(a.loss()) - float(b.loss())) / abs(float(a.loss())))
-ok = b._shade_saved is not None and all(v == v and v < 1e-4 for v in worst.values())
-L = _lib.lib()
-out = dict(parity_vs_default_iteration=ok, max_rel_err=worst)
-for name, st in (("default", a), ("saved_intermediates", b), ("default_again", a)):
-    for i in range(warmup):
-        st(cams[i %% 8], bg, gts[i %% 8])
-    torch.cuda.synchronize()
-    L.r3dg_profile_enable(1)
-    L.r3dg_profile_pause(1)
-    t = time.perf_counter()
-    for i in range(steps):
-        L.r3dg_profile_pause(0 if i %% 8 == 0 else 1)
-        st(cams[i %% 8], bg, gts[i %% 8])
-    torch.cuda.synchronize()
-    dt = (time.perf_counter() - t) / steps
-    prof = _lib.profile_read()
-    L.r3dg_profile_enable(0)
-    ms = lambda k: round(prof[k][0] / max(1, prof[k][1]), 4) if k in prof and prof[k][1] else None
-    out[name] = dict(iters_per_s=round(1.0 / dt, 2), ms_per_step=round(1e3 * dt, 4), shade_forward_ms=ms("shade_forward"),
-                     shade_backward_ms=ms("shade_backward"), dropped=st.poll_overflow())
-print(json.dumps(out))
-"""
-
-
-def shade_save_child(points, res, K, steps, warmup, timeout_s=180):
-    """FusedStage2Step(save_shading=True) -- the shading forward saves the per-sample SH sums and radiance, the backward reads
-    them instead of recomputing them (r3dg_shade_forward_saving / r3dg_shade_backward_saved) -- in a CHILD process: parity
-    with the default iteration checked on the device (outputs, loss, every gradient), then both timed on the same workload.
-    Isolated for the reason relight_transport_child is: the parent's numbers stand whatever happens here."""
-    import subprocess
-    import sys
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    script = _SHADE_SAVE_CHILD_SCRIPT % dict(root=root, P=points, res=res, K=K, steps=steps, warmup=warmup)
-    try:
-        r = subprocess.run([sys.executable, "-c", script], capture_output=True, text=True, timeout=timeout_s,
-                           stdin=subprocess.DEVNULL)
-        line = [x for x in r.stdout.splitlines() if x.startswith("{")]
-        if r.returncode != 0 or not line:
-            return {"failed": (r.stderr or r.stdout)[-400:]}
-        doc = _finite_json(json.loads(line[-1]))
-        doc["what"] = ("stage-2 iteration with the shading intermediates saved by the forward (24 bytes per sample) and read by "
-                       "the backward; child process, %d Gaussians, %dx%d, K=%d, %d steps per variant; a side measurement -- "
-                       "`value` is the default iteration" % (points, res, res, K, steps))
-        return doc
-    except subprocess.TimeoutExpired:
-        return {"failed": "no result within %d s" % timeout_s}
-    except Exception as e:
-        return {"failed": repr(e)}
 
 
 def dp_path_one_rank(args, timeout_s=180):
@@ -889,17 +761,9 @@ def run(args):
                 if args.stage == 2 and not getattr(args, "unfused", False):
                     skipped = {"skipped": "time budget of the default run used up (or R3DG_BENCH_NO_CHILDREN=1)"}
                     b = side_budget(150)
-                    result["other_configs"]["saved_shading_intermediates"] = shade_save_child(
-                        args.points, args.res, args.sample_num, args.steps, args.warmup, timeout_s=b) if b else skipped
-                    b = side_budget(150)
                     result["other_configs"]["data_parallel_path_one_rank_rccl"] = dp_path_one_rank(args, timeout_s=b) if b else skipped
             except Exception as e:
                 result["other_configs"] = {"failed": repr(e)}
-        if relight is not None and world == 1 and not getattr(args, "no_other_configs", False):
-            b = side_budget(150)
-            result["relight"]["relight_transport_cache"] = relight_transport_child(
-                args.points, args.res, args.relight_samples, max(4, args.relight_frames // 2), timeout_s=b) if b else {
-                    "skipped": "time budget of the default run used up (or R3DG_BENCH_NO_CHILDREN=1)"}
         if not args.no_cpu_baseline and world == 1:
             try:
                 result["cpu_baseline"] = cpu_baseline(scene, cams_cpu, S, args.cpu_baseline_seconds, args.points, args.res)

@@ -52,7 +52,7 @@ void launch_shade_forward(hipStream_t s, int P, int K, int M, const float* base_
                           const float* normals, const float* viewdirs, const float* incidents, const float* env, int He,
                           int We, const float* tr, const float* visibility, const float* dirs, const float* areas,
                           float* out, const uint32_t* taps, bool train_outputs, float uniform_area, bool taps_are_radiance,
-                          bool leave_room, float* saved = nullptr);
+                          bool leave_room);
 void launch_shade_build_taps(hipStream_t s, size_t n, const float* dirs, const float* tr, int He, int We, const float* env,
                              uint32_t* taps);
 void launch_shade_build_transport(hipStream_t s, int P, int K, int M, const float* normals, const float* incidents,
@@ -69,8 +69,7 @@ void launch_shade_backward(hipStream_t s, int P, int K, int M, const float* base
                            const float* normals, const float* viewdirs, const float* incidents, const float* env,
                            int He, int We, const float* tr, const float* visibility, const float* dirs,
                            const float* areas, const float* g_pbr, const float* g_diff, float* d_base, float* d_rough,
-                           float* d_view, float* d_inc, float* d_env, const uint32_t* taps, const float* block_absmax, int n_block_absmax,
-                           const float* saved = nullptr);
+                           float* d_view, float* d_inc, float* d_env, const uint32_t* taps, const float* block_absmax, int n_block_absmax);
 void launch_re_forward(hipStream_t s, bool complex_, int P, int Si, int Sd, int Sv, const float* base_color,
                        const float* roughness, const float* metallic, const float* normals, const float* viewdirs,
                        const float* inc, const float* direct, const float* vis, int K, const float* rand_float,
@@ -1021,33 +1020,6 @@ int r3dg_shade_forward_cached(void* stream_, int P, int K, int M, const float* b
     });
 }
 
-int r3dg_shade_forward_saving(void* stream_, int P, int K, int M, const float* base_color, const float* roughness,
-                              const float* normals, const float* viewdirs, const float* incidents, const float* env,
-                              int He, int We, const float* visibility, const float* incident_dirs,
-                              const float* incident_areas, float uniform_area, const uint32_t* taps, int flags, float* out,
-                              float* saved)
-{
-    if (P < 0 || K <= 0 || He <= 0 || We <= 0) return invalid("shade_forward_saving: bad P/K/env size");
-    if (He > 32767 || We > 32767) return invalid("shade_forward_saving: environment map larger than 32767 texels per side");
-    if (M != 16) return invalid("shade_forward_saving: incidents must hold 16 SH coefficients");
-    if (P == 0) return R3DG_OK;
-    if (!base_color || !roughness || !normals || !viewdirs || !incidents || !env || !visibility || !incident_dirs || !out ||
-        !taps || !saved)
-        return invalid("shade_forward_saving: null buffer");
-    if ((flags & R3DG_SHADE_TRAIN_OUTPUTS) == 0 || (flags & R3DG_SHADE_TAPS_ARE_RADIANCE) != 0)
-        return invalid("shade_forward_saving: training outputs with lookup records only");
-    return guarded([&]() -> int {
-        hipStream_t stream = (hipStream_t)stream_;
-        StageTimer t(stream, ST_SHADE_FWD);
-        launch_shade_forward(stream, P, K, M, base_color, roughness, normals, viewdirs, incidents, env, He, We, nullptr,
-                             visibility, incident_dirs, incident_areas, out, taps, true, uniform_area, false,
-                             (flags & R3DG_SHADE_LEAVE_ROOM) != 0, saved);
-        check_launch(stream, false, "shade_forward_saving");
-        t.stop();
-        return R3DG_OK;
-    });
-}
-
 int r3dg_shade_forward(void* stream_, int P, int K, int M, const float* base_color, const float* roughness,
                        const float* normals, const float* viewdirs, const float* incidents, const float* env, int He,
                        int We, const float* env_transform, const float* visibility, const float* incident_dirs,
@@ -1133,32 +1105,6 @@ int r3dg_shade_backward_cached(void* stream_, int P, int K, int M, const float* 
                               dL_dbase_color, dL_droughness, dL_dviewdirs, dL_dincidents, dL_denv, taps, block_absmax,
                               n_block_absmax);
         check_launch(stream, false, "shade_backward");
-        t.stop();
-        return R3DG_OK;
-    });
-}
-
-int r3dg_shade_backward_saved(void* stream_, int P, int K, int M, const float* base_color, const float* roughness,
-                              const float* normals, const float* viewdirs, const float* incidents, const float* env,
-                              int He, int We, const float* visibility, const float* incident_dirs,
-                              const float* incident_areas, const uint32_t* taps, const float* saved, const float* dL_dpbr,
-                              const float* dL_ddiffuse_light, float* dL_dbase_color, float* dL_droughness,
-                              float* dL_dviewdirs, float* dL_dincidents, float* dL_denv, const float* block_absmax,
-                              int n_block_absmax)
-{
-    if (P < 0 || K <= 0 || He <= 0 || We <= 0) return invalid("shade_backward_saved: bad P/K/env size");
-    if (n_block_absmax < 0) return invalid("shade_backward_saved: bad block_absmax count");
-    if (He > 32767 || We > 32767) return invalid("shade_backward_saved: environment map larger than 32767 texels per side");
-    if (M != 16) return invalid("shade_backward_saved: incidents must hold 16 SH coefficients");
-    if (P == 0) return R3DG_OK;
-    if (!taps || !saved || !incident_areas) return invalid("shade_backward_saved: null buffer");
-    return guarded([&]() -> int {
-        hipStream_t stream = (hipStream_t)stream_;
-        StageTimer t(stream, ST_SHADE_BWD);
-        launch_shade_backward(stream, P, K, M, base_color, roughness, normals, viewdirs, incidents, env, He, We, nullptr,
-                              visibility, incident_dirs, incident_areas, dL_dpbr, dL_ddiffuse_light, dL_dbase_color,
-                              dL_droughness, dL_dviewdirs, dL_dincidents, dL_denv, taps, block_absmax, n_block_absmax, saved);
-        check_launch(stream, false, "shade_backward_saved");
         t.stop();
         return R3DG_OK;
     });

@@ -157,7 +157,6 @@ struct SampleFwd {
     float L[3], Hh[3], ulen, NoL, NoH, VoH, rawNoH, rawVoH, nom0, nom1, nom2, nomr, frac0, p2;
     EnvTap taps;
     float vis;
-    float esave[3];          // (HAVE_E) the radiance the forward looked up and saved
 };
 
 // Layout of the per-wave uniform record u[64]: 0..47 SH coefficients (i*3+c), 48..50 albedo, 51 roughness,
@@ -180,7 +179,7 @@ __device__ __forceinline__ float load_uniform_element(int lane, int g, int M, co
     return p ? *p : 0.f;
 }
 
-template <bool ENV_LDS, bool HAVE_SHSUM = false, bool HAVE_TAP = false, bool HAVE_E = false>
+template <bool ENV_LDS, bool HAVE_SHSUM = false, bool HAVE_TAP = false>
 __device__ __forceinline__ void shade_sample(SampleFwd& s, const GaussFwd& G, const float* sh /*[48] in LDS, zero padded*/,
                                              int M, float dx, float dy, float dz, float vis, float area,
                                              const float* __restrict__ env, const float* s_env,
@@ -191,24 +190,20 @@ __device__ __forceinline__ void shade_sample(SampleFwd& s, const GaussFwd& G, co
     else s.taps = env_taps(dx, dy, dz, tr, He, We);
     s.vis = vis;
     float e[3] = {0.f, 0.f, 0.f};
-    if (HAVE_E) {            // the forward saved its bilinear sample (shade_forward_row_kernel<..., SAVE>): no texel fetch
-        e[0] = s.esave[0]; e[1] = s.esave[1]; e[2] = s.esave[2];
-    } else {
 #pragma unroll
-        for (int t = 0; t < 4; t++) {
-            if (s.taps.idx[t] >= 0) {
-                float3 px;
-                if (ENV_LDS) {
-                    const float* q = s_env + 3 * s.taps.idx[t];
-                    px = make_float3(q[0], q[1], q[2]);
-                } else {
-                    // large maps live in L2: one 12-byte load per tap (global_load_dwordx3), not three 4-byte ones
-                    px = *reinterpret_cast<const float3*>(env + 3 * (size_t)s.taps.idx[t]);
-                }
-                e[0] += px.x * s.taps.w[t];
-                e[1] += px.y * s.taps.w[t];
-                e[2] += px.z * s.taps.w[t];
+    for (int t = 0; t < 4; t++) {
+        if (s.taps.idx[t] >= 0) {
+            float3 px;
+            if (ENV_LDS) {
+                const float* q = s_env + 3 * s.taps.idx[t];
+                px = make_float3(q[0], q[1], q[2]);
+            } else {
+                // large maps live in L2: one 12-byte load per tap (global_load_dwordx3), not three 4-byte ones
+                px = *reinterpret_cast<const float3*>(env + 3 * (size_t)s.taps.idx[t]);
             }
+            e[0] += px.x * s.taps.w[t];
+            e[1] += px.y * s.taps.w[t];
+            e[2] += px.z * s.taps.w[t];
         }
     }
     // local incident light: max(SH(d), 0)
@@ -588,16 +583,7 @@ __device__ __forceinline__ RowSample load_row_sample(bool live, int g, int lane,
 // Software pipeline per wave: [wait for block i's samples] -> [issue the loads of block i+1: they fly during the ~250
 // instructions below] -> [record of block i: one ds_write_b32 per lane, read back as wave-uniform broadcasts] -> compute ->
 // (last block of the Gaussian) transposing wave reduction + store.
-// SAVE (opt-in, r3dg_shade_forward_saving): additionally write what the backward would otherwise recompute per sample --
-// the three pre-clamp SH sums of the local light and the looked-up radiance -- as six coalesced rows of K floats per
-// Gaussian, saved[(g * 6 + c) * K + k].  The buffer's address travels in a __device__ variable (set on the launch stream
-// right before the launch), NOT in the kernel arguments: the signature and the code of every other instance stay
-// exactly what they were (checked by diffing the assembly).
-__device__ float* g_shade_saved_fwd = nullptr;
-__device__ const float* g_shade_saved_bwd = nullptr;
-
-template <int NOUT, bool ENV_LDS, int TAPS /* 0 lookup in kernel, 1 cached lookup, 2 cached radiance */, bool M16,
-          bool SAVE = false>
+template <int NOUT, bool ENV_LDS, int TAPS /* 0 lookup in kernel, 1 cached lookup, 2 cached radiance */, bool M16>
 __global__ void __launch_bounds__(64 * ROW_WAVES)
 shade_forward_row_kernel(int P, int K, int M_, const float* __restrict__ rec, const float* __restrict__ incidents,
                          const float4* __restrict__ env4, int He, int We,
@@ -605,7 +591,6 @@ shade_forward_row_kernel(int P, int K, int M_, const float* __restrict__ rec, co
                          const float* __restrict__ dirs, const float* __restrict__ areas, float uniform_area,
                          const uint32_t* __restrict__ taps, float* __restrict__ out)
 {
-    float* const saved = SAVE ? g_shade_saved_fwd : nullptr;
     static_assert(NOUT == 7 || NOUT == 19, "training (pbr, diffuse_light, mean visibility) or all 19 outputs");
     constexpr int NV = NOUT == 7 ? 8 : 32;
     const int M = M16 ? 16 : M_;                 // degree-3 incident light (the reference's only configuration) folds the
@@ -676,14 +661,6 @@ shade_forward_row_kernel(int P, int K, int M_, const float* __restrict__ rec, co
             sh_basis16(dx, dy, dz, M, Y);
             float l[3];
             sh_local_sum(u, Y, l);
-            if (SAVE && live) {
-                float* sv = saved + ((size_t)g * 6) * (size_t)K + (size_t)(kb * 64 + lane);
-#pragma unroll
-                for (int c = 0; c < 3; c++) {
-                    sv[(size_t)c * K] = l[c];
-                    sv[(size_t)(3 + c) * K] = e[c];
-                }
-            }
             const float lv = live ? 1.f : 0.f;               // lanes beyond K contribute nothing (their area is 0 as well)
             const float loc[3] = {fmaxf(l[0], 0.f) * lv, fmaxf(l[1], 0.f) * lv, fmaxf(l[2], 0.f) * lv};
             const float glob[3] = {e[0] * vis, e[1] * vis, e[2] * vis};
@@ -1034,19 +1011,13 @@ grad_absmax_kernel(int n, const float* __restrict__ a, const float* __restrict__
 // fewer than 2^14 of them per texel, so the sum stays below 2^62; the resolution is 3e-11 * max|g| -- finer than the
 // fp32 accumulation it replaces -- and the per-block sum is order-independent.  Non-finite upstream gradients fall
 // back to float atomics so NaN/inf still propagate.
-// SAVED (opt-in, r3dg_shade_backward_saved): the forward wrote the three pre-clamp SH sums and the looked-up radiance of every
-// sample (shade_forward_row_kernel<..., SAVE>, saved[(g * 6 + c) * K + k]): pass 0 below -- the SH basis and the 48
-// coefficient FMAs per sample, evaluated only to know the local light's value and sign -- and the texel fetches of pass 1
-// disappear, ~145 of the ~540 VALU instructions per sample (tools/isa_mix.py).  The values arrive one sample ahead, straight
-// from global memory into registers.
-template <bool ENV_LDS, bool VEC16, bool TAPS, bool SAVED = false>
+template <bool ENV_LDS, bool VEC16, bool TAPS>
 __global__ void __launch_bounds__(64 * SHADE_WAVES)
 shade_backward_kernel(int P, int K, int M, ShadeSrc src, const float* __restrict__ env, int He, int We,
                       const float* __restrict__ tr, float* __restrict__ d_base, float* __restrict__ d_rough,
                       float* __restrict__ d_view, float* __restrict__ d_inc, float* __restrict__ d_env,
                       const unsigned int* __restrict__ gmax_bits, int gmax_n, const uint32_t* __restrict__ taps)
 {
-    const float* const saved = SAVED ? g_shade_saved_bwd : nullptr;      // (set on the stream in front of the launch)
     extern __shared__ __attribute__((aligned(16))) float s_mem[];
     const int ntex_raw = He * We * 3;
     const int ntex = ENV_LDS ? ((ntex_raw + 3) & ~3) : 0;
@@ -1114,62 +1085,37 @@ shade_backward_kernel(int P, int K, int M, ShadeSrc src, const float* __restrict
             }
         }
         // pass 0: SH sums of the local incident light (basis + 48 coefficient FMAs), parked in LDS
-        if (!SAVED) {
 #pragma unroll 1
-            for (int t = 0; t < 4; t++) {
-                const int kl = l + SH_L * t, k = kb * 64 + kl;
-                float sum[3] = {0.f, 0.f, 0.f};
-                if (live && k < K) {
-                    const float* d = sb + SB_DIRS + (grp * 64 + kl) * 3;
-                    float Y[16];
-                    sh_basis16(d[0], d[1], d[2], M, Y);
-                    sh_local_sum(s_u, Y, sum);
-                }
-                s_park[(3 * t) * PARK] = sum[0];
-                s_park[(3 * t + 1) * PARK] = sum[1];
-                s_park[(3 * t + 2) * PARK] = sum[2];
-            }
-        }
-        // (SAVED) what the forward saved for this lane's samples: sample t + 1 is fetched while sample t is computed
-        float sv_cur[6], sv_nxt[6];
-        auto load_saved = [&](int t, float (&o)[6]) {
-            const int k = kb * 64 + l + SH_L * t;
-#pragma unroll
-            for (int c = 0; c < 6; c++) o[c] = 0.f;
+        for (int t = 0; t < 4; t++) {
+            const int kl = l + SH_L * t, k = kb * 64 + kl;
+            float sum[3] = {0.f, 0.f, 0.f};
             if (live && k < K) {
-                const float* q = saved + ((size_t)g * 6) * (size_t)K + (size_t)k;
-#pragma unroll
-                for (int c = 0; c < 6; c++) o[c] = q[(size_t)c * (size_t)K];
+                const float* d = sb + SB_DIRS + (grp * 64 + kl) * 3;
+                float Y[16];
+                sh_basis16(d[0], d[1], d[2], M, Y);
+                sh_local_sum(s_u, Y, sum);
             }
-        };
-        if (SAVED) load_saved(0, sv_cur);
+            s_park[(3 * t) * PARK] = sum[0];
+            s_park[(3 * t + 1) * PARK] = sum[1];
+            s_park[(3 * t + 2) * PARK] = sum[2];
+        }
 #pragma unroll 1
         for (int t = 0; t < 4; t++) {
             const int kl = l + SH_L * t, k = kb * 64 + kl;
             float dl[3] = {0.f, 0.f, 0.f};
-            if (SAVED) {
-#pragma unroll
-                for (int c = 0; c < 6; c++) sv_nxt[c] = sv_cur[c];
-                if (t < 3) load_saved(t + 1, sv_nxt);
-            }
             if (live && k < K) {
                 const float* d = sb + SB_DIRS + (grp * 64 + kl) * 3;
                 SampleFwd s;
-                if (SAVED) {
-#pragma unroll
-                    for (int c = 0; c < 3; c++) { s.shsum[c] = sv_cur[c]; s.esave[c] = sv_cur[3 + c]; }
-                } else {
-                    s.shsum[0] = s_park[(3 * t) * PARK];
-                    s.shsum[1] = s_park[(3 * t + 1) * PARK];
-                    s.shsum[2] = s_park[(3 * t + 2) * PARK];
-                }
+                s.shsum[0] = s_park[(3 * t) * PARK];
+                s.shsum[1] = s_park[(3 * t + 1) * PARK];
+                s.shsum[2] = s_park[(3 * t + 2) * PARK];
                 PackedTap mine = ct[0];                  // t is a run-time loop index (unroll 1): select, no scratch
                 if (TAPS) {
                     if (t == 1) mine = ct[1];
                     if (t == 2) mine = ct[2];
                     if (t == 3) mine = ct[3];
                 }
-                shade_sample<ENV_LDS, true, TAPS, SAVED>(s, G, s_u, M, d[0], d[1], d[2], sb[SB_VIS + grp * 64 + kl],
+                shade_sample<ENV_LDS, true, TAPS>(s, G, s_u, M, d[0], d[1], d[2], sb[SB_VIS + grp * 64 + kl],
                                                          sb[SB_AREA + grp * 64 + kl], env, s_env, tr, He, We, &mine);
                 float gspec = 0.f;
                 float dlin[3];
@@ -1254,10 +1200,6 @@ shade_backward_kernel(int P, int K, int M, ShadeSrc src, const float* __restrict
             s_park[(3 * t) * PARK] = dl[0];
             s_park[(3 * t + 1) * PARK] = dl[1];
             s_park[(3 * t + 2) * PARK] = dl[2];
-            if (SAVED) {
-#pragma unroll
-                for (int c = 0; c < 6; c++) sv_cur[c] = sv_nxt[c];
-            }
         }
 #pragma unroll 1
         for (int t = 0; t < 4; t++) {
@@ -1661,12 +1603,9 @@ void launch_shade_forward(hipStream_t s, int P, int K, int M, const float* base_
                           const float* normals, const float* viewdirs, const float* incidents, const float* env, int He,
                           int We, const float* tr, const float* visibility, const float* dirs, const float* areas,
                           float* out, const uint32_t* taps, bool train_outputs, float uniform_area, bool taps_are_radiance,
-                          bool leave_room, float* saved)
+                          bool leave_room)
 {
     if (P == 0) return;
-    if (saved != nullptr && !(g_shade_fwd_rows == 1 && train_outputs && taps != nullptr && !taps_are_radiance && M == 16))
-        throw std::runtime_error("shade_forward_saving: needs the row kernels, training outputs, cached lookups and 16 "
-                                 "incident-light coefficients");
     if (areas == nullptr && !g_shade_fwd_rows) throw std::runtime_error("shade_forward: the 16-lane kernel needs incident_areas");
     const int ntex = He * We * 3;
     if (!g_shade_fwd_rows) {
@@ -1745,12 +1684,7 @@ void launch_shade_forward(hipStream_t s, int P, int K, int M, const float* base_
         if (leave_room && g_shade_row_blocks_per_cu == 0 && bpc > 3) bpc = 3;                                         \
         const int cap = shade_cus() * bpc;                                                                            \
         const int grid = want < cap ? want : cap;                                                                     \
-        if (saved != nullptr && N == 7 && T == 1) {                                                                   \
-            R3DG_HIP(hipMemcpyToSymbolAsync(HIP_SYMBOL(g_shade_saved_fwd), &saved, sizeof(saved), 0,                  \
-                                            hipMemcpyHostToDevice, s));                                               \
-            shade_forward_row_kernel<7, L, 1, true, true><<<grid, 64 * ROW_WAVES, smem, s>>>(                         \
-                P, K, M, rec, incidents, env4, He, We, tr, visibility, dirs, areas, uniform_area, taps, out);         \
-        } else if (M == 16)                                                                                             \
+        if (M == 16)                                                                                                  \
             shade_forward_row_kernel<N, L, T, true><<<grid, 64 * ROW_WAVES, smem, s>>>(                               \
                 P, K, M, rec, incidents, env4, He, We, tr, visibility, dirs, areas, uniform_area, taps, out);         \
         else                                                                                                          \
@@ -1772,7 +1706,7 @@ void launch_shade_backward(hipStream_t s, int P, int K, int M, const float* base
                            int He, int We, const float* tr, const float* visibility, const float* dirs,
                            const float* areas, const float* g_pbr, const float* g_diff, float* d_base, float* d_rough,
                            float* d_view, float* d_inc, float* d_env, const uint32_t* taps, const float* block_absmax,
-                           int n_block_absmax, const float* saved)
+                           int n_block_absmax)
 {
     unsigned int* scratch = shade_scratch();
     // scale of the fixed-point texture accumulation: max |upstream gradient|, either handed over as block maxima by the
@@ -1789,7 +1723,7 @@ void launch_shade_backward(hipStream_t s, int P, int K, int M, const float* base
     }
 
     const int ntex = He * We * 3;
-    if (g_shade_bwd_rows && saved == nullptr) {
+    if (g_shade_bwd_rows) {
         const size_t ntexel = (size_t)He * We;
         float* rec = shade_records(((size_t)P * RECB + ntexel * 4) / REC + 2);       // 80-float records, then the padded texture
         float4* env4 = reinterpret_cast<float4*>(rec + (size_t)P * RECB);
@@ -1848,19 +1782,7 @@ void launch_shade_backward(hipStream_t s, int P, int K, int M, const float* base
     do {                                                                                                              \
         if (taps != nullptr) R3DG_SB3(L, V, true); else R3DG_SB3(L, V, false);                                        \
     } while (0)
-    if (saved != nullptr) {
-        // the forward's saved per-sample intermediates: the training configuration only (texture in LDS, cached lookups,
-        // K a multiple of 4, degree-3 light)
-        if (!(lds && vec && taps != nullptr && M == 16))
-            throw std::runtime_error("shade_backward_saved: needs an LDS-sized environment texture, cached lookups, K % 4 == 0 "
-                                     "and 16 incident-light coefficients");
-        if (smem > 65536)
-            R3DG_HIP(hipFuncSetAttribute((const void*)shade_backward_kernel<true, true, true, true>,
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-        R3DG_HIP(hipMemcpyToSymbolAsync(HIP_SYMBOL(g_shade_saved_bwd), &saved, sizeof(saved), 0, hipMemcpyHostToDevice, s));
-        shade_backward_kernel<true, true, true, true><<<grid, 64 * SHADE_WAVES, smem, s>>>(
-            P, K, M, src, env, He, We, tr, d_base, d_rough, d_view, d_inc, d_env, gmax, gmax_n, taps);
-    } else if (lds) { if (vec) R3DG_SB(true, true); else R3DG_SB(true, false); }
+    if (lds) { if (vec) R3DG_SB(true, true); else R3DG_SB(true, false); }
     else { if (vec) R3DG_SB(false, true); else R3DG_SB(false, false); }
 #undef R3DG_SB
 #undef R3DG_SB3

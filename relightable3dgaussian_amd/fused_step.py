@@ -182,7 +182,7 @@ class FusedStage2Step(_BoundedForward):
     """Owns the raw parameters (copied from a bench_core.GaussianParams) and runs whole iterations."""
 
     def __init__(self, params, sample_num, lr=1e-4, lr_rest_scale=1.0, loss_weights=None, process_group=None,
-                 overlap_geometry=False, overlap_ordering=True, lrs=None, bounded=True, save_shading=None):
+                 overlap_geometry=False, overlap_ordering=True, lrs=None, bounded=True):
         """`lrs`: optional per-group learning rates {xyz, normal, scaling, rotation, opacity, shs, shs_rest, base_color,
         roughness, incidents, incidents_rest, env} as GaussianModel.training_setup / DirectLightMap.training_setup set
         them (scene/gaussian_model.py:465-486, the stage-2 values of script/run_nerf.sh:25-31); missing names use `lr`
@@ -194,11 +194,6 @@ class FusedStage2Step(_BoundedForward):
         it in `dropped_steps`."""
         dev = params.xyz.device
         self.dev = dev
-        # opt-in (default: the R3DG_SHADE_SAVE environment variable, else off): the shading forward saves the per-sample SH
-        # sums and looked-up radiance (24 bytes per sample), the shading backward reads them instead of recomputing them
-        # (r3dg_shade_forward_saving / r3dg_shade_backward_saved; DESIGN.md section 8 -- first hardware run pending)
-        self.save_shading = (os.environ.get("R3DG_SHADE_SAVE") == "1") if save_shading is None else bool(save_shading)
-        self._shade_saved = None
         d = lambda t: t.detach().clone().contiguous()
         self.xyz, self.normal = d(params.xyz), d(params.normal)
         self.scaling, self.rotation, self.opacity = d(params.scaling), d(params.rotation), d(params.opacity)
@@ -377,25 +372,13 @@ class FusedStage2Step(_BoundedForward):
             env_c = F.softplus(self.env)[0]                                      # DirectLightMap.get_env
             He, We = env_c.shape[0], env_c.shape[1]
             taps = self.taps(He, We)
-            saving = self.save_shading and self.M == 16 and self.K % 4 == 0 and He * We * 9 <= 12288
-            if saving:
-                if self._shade_saved is None or self._shade_saved.numel() != P * 6 * self.K:
-                    self._shade_saved = torch.empty(P * 6 * self.K, dtype=torch.float32, device=dev)
-                _lib.check(L.r3dg_shade_forward_saving(
-                    stream(), P, self.K, self.M, self.a_base.data_ptr(), self.a_rough.data_ptr(), self.a_normal.data_ptr(),
-                    self.a_viewdirs.data_ptr(), self.incidents.data_ptr(), env_c.data_ptr(), He, We,
-                    self.visibility.data_ptr(), self.incident_dirs.data_ptr(),
-                    None if self._uniform_area is not None else self.incident_areas.data_ptr(), self._uniform_area or 0.0,
-                    taps.data_ptr(), 1 | (4 if self._order_stream is not None else 0),
-                    self.shade_out.data_ptr(), self._shade_saved.data_ptr()), "shade_forward_saving")
-            else:
-                _lib.check(L.r3dg_shade_forward_cached(
-                    stream(), P, self.K, self.M, self.a_base.data_ptr(), self.a_rough.data_ptr(), self.a_normal.data_ptr(),
-                    self.a_viewdirs.data_ptr(), self.incidents.data_ptr(), env_c.data_ptr(), He, We, None,
-                    self.visibility.data_ptr(), self.incident_dirs.data_ptr(),
-                    None if self._uniform_area is not None else self.incident_areas.data_ptr(), self._uniform_area or 0.0,
-                    taps.data_ptr(), 1 | (4 if self._order_stream is not None else 0),     # train outputs | leave room
-                    self.shade_out.data_ptr()), "shade_forward")
+            _lib.check(L.r3dg_shade_forward_cached(
+                stream(), P, self.K, self.M, self.a_base.data_ptr(), self.a_rough.data_ptr(), self.a_normal.data_ptr(),
+                self.a_viewdirs.data_ptr(), self.incidents.data_ptr(), env_c.data_ptr(), He, We, None,
+                self.visibility.data_ptr(), self.incident_dirs.data_ptr(),
+                None if self._uniform_area is not None else self.incident_areas.data_ptr(), self._uniform_area or 0.0,
+                taps.data_ptr(), 1 | (4 if self._order_stream is not None else 0),     # train outputs | leave room
+                self.shade_out.data_ptr()), "shade_forward")
             self.sums.zero_()
             _lib.check(L.r3dg_stage2_pack_features(
                 stream(), P, self.xyz.data_ptr(), vm.data_ptr(), self.a_normal.data_ptr(), self.a_base.data_ptr(),
@@ -480,8 +463,7 @@ class FusedStage2Step(_BoundedForward):
             d_base, d_rough, d_view, _d_inc, d_env = shading_ops.shade_backward(
                 self.a_base, self.a_rough, self.a_normal, self.a_viewdirs, self.incidents, env_c, self.visibility,
                 self.incident_dirs, self.incident_areas, self.d_pbr, self.d_diffuse,
-                out_incidents=self.grads["incidents"], taps=taps, out_env=self._d_env, block_absmax=self._absmax,
-                saved=self._shade_saved if saving else None)
+                out_incidents=self.grads["incidents"], taps=taps, out_env=self._d_env, block_absmax=self._absmax)
             gr = self.grads
             if self._side is not None:          # join the geometry backward
                 torch.cuda.current_stream().wait_stream(self._side)

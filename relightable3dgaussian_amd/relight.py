@@ -33,14 +33,17 @@ class RelightRenderer:
     SH colour (`shs` or `features_dc`/`features_rest`) and incident light (`incidents` or `incidents_dc`/`_rest`) --
     bench_core.GaussianParams and fused_step.FusedStage2Step both do.  `envmap` [He,We,3] HDR (EnvLight.envmap)."""
 
-    def __init__(self, model, envmap, sample_num, process_group=None, cache="radiance", regenerate_dirs=True):
+    def __init__(self, model, envmap, sample_num, process_group=None, cache="transport", regenerate_dirs=True):
         """`cache` -- what is kept between frames while the light does not change:
-        "radiance" (default): the sampled environment radiance of every cached direction (12 bytes per sample);
-        "transport": the whole view-independent part of the integral -- per sample (local + global light) x area x n.d in
-            place of the radiance, per Gaussian diffuse_light and the mean light / visibility columns -- so that a frame
-            evaluates only the GGX lobe (r3dg_shade_forward_transport).  Valid while parameters, light and visibility are
-            unchanged, which is what this class assumes anyway (it snapshots the parameters).  `regenerate_dirs`: that
-            kernel rebuilds each direction from the normal and the Fibonacci table instead of reading the direction cache."""
+        "transport" (default): the whole view-independent part of the integral -- per sample (local + global light) x area
+            x n.d, per Gaussian diffuse_light and the mean light / visibility columns -- so that a frame evaluates only the
+            GGX lobe (r3dg_shade_forward_transport; 12 bytes and ~80 instructions per sample).  Valid while parameters,
+            light and visibility are unchanged: the renderer works on its own SNAPSHOT of the parameters (copies taken
+            here), and a light that turns with every frame (configs/nerf_syn_light, configs/tnt) drops to the lookup-in-kernel
+            path by itself (see _taps_for), so nothing can go stale.  `regenerate_dirs`: the kernel rebuilds each
+            direction from the normal and the Fibonacci table instead of reading the direction cache.
+        "radiance": only the sampled environment radiance of every cached direction (12 bytes per sample) is kept and the
+            full integral (r3dg_shade_forward_cached) runs per frame."""
         if cache not in ("radiance", "transport"):
             raise RuntimeError("RelightRenderer: cache must be 'radiance' or 'transport'")
         self.cache, self.regenerate_dirs = cache, bool(regenerate_dirs)
@@ -50,7 +53,7 @@ class RelightRenderer:
         self._light_changes = 0
         self._area_key, self._uniform_area = None, None
         self._consts = self._zsamples = None
-        d = lambda t: t.detach().contiguous()
+        d = lambda t: t.detach().clone().contiguous()       # a snapshot: the caches below are only valid for THESE values
         self.xyz, self.normal = d(model.xyz), d(model.normal)
         self.scaling, self.rotation, self.opacity = d(model.scaling), d(model.rotation), d(model.opacity)
         self.base_color, self.roughness = d(model.base_color), d(model.roughness)

@@ -68,14 +68,12 @@ def shade_forward(base_color, roughness, normals, viewdirs, incidents, env, visi
 
 def shade_backward(base_color, roughness, normals, viewdirs, incidents, env, visibility, incident_dirs, incident_areas,
                    dL_dpbr, dL_ddiffuse_light, env_transform=None, out_incidents=None, taps=None, out_env=None,
-                   block_absmax=None, saved=None):
+                   block_absmax=None):
     """`out_incidents`: optional preallocated contiguous [P,M,3] buffer for dL_dincidents (fully overwritten);
     `taps`: build_taps(incident_dirs, He, We, env_transform) (lookup records, not radiance);
     `out_env`: optional ZEROED float32 buffer shaped like `env` that receives dL_denv (the kernel accumulates into it);
     `block_absmax`: optional float32 vector whose maximum is max(|dL_dpbr|, |dL_ddiffuse_light|) (+inf if not finite), as
-    r3dg_stage2_unpack_gradients writes it -- saves the reduction pass in front of the kernel;
-    `saved`: the [P*6*K] float32 buffer r3dg_shade_forward_saving filled for the SAME parameters, caches and texture
-    (opt-in: the backward then skips re-evaluating the SH sums and the texture taps; needs `taps`, no env_transform)."""
+    r3dg_stage2_unpack_gradients writes it -- saves the reduction pass in front of the kernel."""
     L = _lib.lib()
     P, K = incident_dirs.shape[0], incident_dirs.shape[1]
     M = incidents.shape[1]
@@ -101,18 +99,6 @@ def shade_backward(base_color, roughness, normals, viewdirs, incidents, env, vis
         d_env = torch.zeros_like(t[5])
     if block_absmax is not None and (block_absmax.dtype != torch.float32 or not block_absmax.is_contiguous()):
         raise RuntimeError("block_absmax must be a contiguous float32 tensor")
-    if saved is not None:
-        if taps is None or tr is not None or saved.numel() != P * 6 * K or saved.dtype != torch.float32 or not saved.is_contiguous():
-            raise RuntimeError("shade_backward(saved=...): needs lookup taps, no env_transform and a contiguous float32 [P*6*K] buffer")
-        with torch.cuda.device(dev):
-            st = L.r3dg_shade_backward_saved(
-                _lib.current_stream(), P, K, M, t[0].data_ptr(), t[1].data_ptr(), t[2].data_ptr(), t[3].data_ptr(),
-                t[4].data_ptr(), t[5].data_ptr(), He, We, t[6].data_ptr(), t[7].data_ptr(), t[8].data_ptr(), taps.data_ptr(),
-                saved.data_ptr(), t[9].data_ptr(), t[10].data_ptr(), d_base.data_ptr(), d_rough.data_ptr(), d_view.data_ptr(),
-                d_inc.data_ptr(), d_env.data_ptr(), block_absmax.data_ptr() if block_absmax is not None else None,
-                block_absmax.numel() if block_absmax is not None else 0)
-        _lib.check(st, "shade_backward_saved")
-        return d_base, d_rough, d_view, d_inc, d_env
     with torch.cuda.device(dev):
         st = L.r3dg_shade_backward_cached(_lib.current_stream(), P, K, M, t[0].data_ptr(), t[1].data_ptr(), t[2].data_ptr(),
                                    t[3].data_ptr(), t[4].data_ptr(), t[5].data_ptr(), He, We,

@@ -434,36 +434,3 @@ def test_bounded_stage1_iterations_equal_two_phase_iterations():
     step(cam, bg, gt)
     torch.cuda.synchronize()
     assert step.poll_overflow() == 0 and not torch.equal(step.xyz, before[0])
-
-
-@pytest.mark.skipif(__import__("os").environ.get("R3DG_EXPERIMENTAL") != "1",
-                    reason="opt-in kernels written without GPU access; first run them with R3DG_EXPERIMENTAL=1")
-@pytest.mark.parametrize("K", [8, 64, 100])
-def test_saved_shading_intermediates_give_the_same_gradients(K):
-    """FusedStage2Step(save_shading=True): the shading forward saves the per-sample SH sums and looked-up radiance, the
-    shading backward reads them instead of recomputing (r3dg_shade_forward_saving / r3dg_shade_backward_saved).  Same forward
-    outputs, same loss, same gradients as the default iteration, also after a few optimizer steps."""
-    from relightable3dgaussian_amd.fused_step import FusedStage2Step
-    params, ref, _fused, cam, bg, gt = _setup(K=K)
-    steps = {}
-    for save in (False, True):
-        st = FusedStage2Step(params, K, save_shading=save)
-        st.visibility, st.incident_dirs, st.incident_areas = ref.visibility, ref.incident_dirs, ref.incident_areas
-        steps[save] = st
-    a, b = steps[False], steps[True]
-    for it in range(3):
-        a.forward_backward(cam, bg, gt)
-        b.forward_backward(cam, bg, gt)
-        torch.cuda.synchronize()
-        assert b._shade_saved is not None and a._shade_saved is None
-        ok, msg = report("shade_out", b.shade_out[:, [0, 1, 2, 3, 4, 5, 18]], a.shade_out[:, [0, 1, 2, 3, 4, 5, 18]], 1e-6, 1e-7)
-        assert ok, msg
-        assert abs(float(a.loss()) - float(b.loss())) <= 1e-6 * abs(float(a.loss()))
-        for k in a.grads:
-            ok, msg = report("grad " + k, b.grads[k], a.grads[k], 2e-5, 1e-9)
-            assert ok, msg
-        a.optimizer_step()
-        b.optimizer_step()
-    for k in ("incidents", "env", "base_color", "roughness", "xyz", "shs"):
-        ok, msg = report("param " + k, getattr(b, k), getattr(a, k), 1e-4, 1e-6)
-        assert ok, msg

@@ -159,8 +159,8 @@ def test_fused_stage2_step_takes_the_reference_learning_rates(monkeypatch):
 
 def test_relight_renderer_host_logic_with_a_recording_library(monkeypatch):
     """RelightRenderer.frame's host side only (every C-ABI entry point replaced by a recorder, nothing runs on a GPU): which
-    shading entry point a frame takes and with which cache -- radiance cache (default), transport cache (opt-in), and no
-    cache once the light turns with every frame."""
+    shading entry point a frame takes and with which cache -- transport cache (default), radiance cache, and no cache once
+    the light turns with every frame."""
     import types
     from relightable3dgaussian_amd import _lib, rasterizer_ops, relight, shading_ops
     calls = []
@@ -195,8 +195,8 @@ def test_relight_renderer_host_logic_with_a_recording_library(monkeypatch):
                                 camera_center=z(3), tanfovx=0.5, tanfovy=0.5, cx=2.0, cy=2.0)
     env = dt(z(8, 16, 3))
     names = lambda: [c[0] for c in calls]
-    # default: radiance cache, built once for a fixed light
-    r = relight.RelightRenderer(model, env, K)
+    # radiance cache, built once for a fixed light
+    r = relight.RelightRenderer(model, env, K, cache="radiance")
     calls.clear()
     for _ in range(3):
         out = r.frame(cam, z(3))
@@ -213,7 +213,7 @@ def test_relight_renderer_host_logic_with_a_recording_library(monkeypatch):
     assert len(built) == 1 and flags == [2, 0, 0, 0], (len(built), flags)
     # the same with DEVICE matrices built per frame (relighting.py:162-163): keyed by storage identity, and the renderer keeps
     # the tensors it keyed on alive, so a recycled address cannot pass for "the light did not move"
-    r2 = relight.RelightRenderer(model, env, K)
+    r2 = relight.RelightRenderer(model, env, K, cache="radiance")
     calls.clear()
     del built[:]
     for i in range(6):
@@ -225,8 +225,9 @@ def test_relight_renderer_host_logic_with_a_recording_library(monkeypatch):
         r2.frame(cam, z(3), env_transform=fixed)
     flags = [c[1][-2] for c in calls if c[0] == "r3dg_shade_forward_cached"][6:]
     assert len(built) == 2 and flags == [0, 2, 2], (len(built), flags)       # stopped: cached again from its second frame
-    # opt-in transport cache: one build (radiance -> transport in place + constants), then the transport kernel per frame
-    r = relight.RelightRenderer(model, env, K, cache="transport")
+    # the default, transport cache: one build (radiance -> transport in place + constants), then the transport kernel per frame
+    r = relight.RelightRenderer(model, env, K)
+    assert r.cache == "transport" and r.xyz is not model.xyz            # (works on a snapshot of the parameters)
     calls.clear()
     for _ in range(3):
         r.frame(cam, z(3))
@@ -479,12 +480,9 @@ def test_checkpoint_defaults_follow_the_reference_flow():
     assert all(float(t.abs().max()) == 0.0 for t in (s2.base_color, s2.roughness, s2.incidents_dc, s2.incidents_rest))
 
 
-@pytest.mark.parametrize("save_shading", [False, True])
-def test_fused_stage2_iteration_host_logic_with_a_recording_library(monkeypatch, save_shading):
+def test_fused_stage2_iteration_host_logic_with_a_recording_library(monkeypatch):
     """The Python side of FusedStage2Step.__call__ with every C-ABI entry point and the rasterizer replaced by recorders
-    (nothing runs on a GPU): the order of the calls of one iteration, the bounded forward from the second iteration on, and
-    -- opt-in -- the saved-activation pair (r3dg_shade_forward_saving / r3dg_shade_backward_saved) with ONE buffer of
-    P * 6 * K floats handed from the forward to the backward."""
+    (nothing runs on a GPU): the order of the calls of one iteration and the bounded forward from the second iteration on."""
     import contextlib
     import types
     from relightable3dgaussian_amd import _lib, fused_step, rasterizer_ops, shading_ops
@@ -532,28 +530,16 @@ def test_fused_stage2_iteration_host_logic_with_a_recording_library(monkeypatch,
                                    incidents_dc=z(P, 1, 3), incidents_rest=z(P, 15, 3), env=z(1, 16, 32, 3))
     cam = types.SimpleNamespace(image_height=H, image_width=W, world_view_transform=torch.eye(4), full_proj_transform=torch.eye(4),
                                 camera_center=z(3), tanfovx=0.5, tanfovy=0.5, cx=2.0, cy=2.0)
-    step = fused_step.FusedStage2Step(params, K, save_shading=save_shading)
+    step = fused_step.FusedStage2Step(params, K)
     calls.clear()
     for _ in range(3):
         step(cam, torch.ones(3), z(3, H, W))
     names = [c[0] for c in calls]
     assert begun[0] is None and begun[1] == begun[2] == step._capacity_for(17)      # two-phase first, bounded afterwards
-    fwd, bwd = ("r3dg_shade_forward_saving", "r3dg_shade_backward_saved") if save_shading else (
-        "r3dg_shade_forward_cached", "r3dg_shade_backward_cached")
+    fwd, bwd = "r3dg_shade_forward_cached", "r3dg_shade_backward_cached"
     assert names.count(fwd) == 3 and names.count(bwd) == 3 and names.count("r3dg_adam_step") == 6
-    other = ("r3dg_shade_forward_cached", "r3dg_shade_backward_cached") if save_shading else (
-        "r3dg_shade_forward_saving", "r3dg_shade_backward_saved")
-    assert not any(n in names for n in other)
     one = names[names.index("r3dg_stage2_activate"):]
     order = [n for n in one if n in (fwd, "r3dg_stage2_pack_features", "r3dg_ssim_forward_pair", "r3dg_stage2_loss",
                                      "r3dg_stage2_unpack_gradients", bwd, "r3dg_stage2_activate_backward", "r3dg_adam_step")][:9]
     assert order == [fwd, "r3dg_stage2_pack_features", "r3dg_ssim_forward_pair", "r3dg_stage2_loss", "r3dg_adam_step",
                      "r3dg_stage2_unpack_gradients", bwd, "r3dg_stage2_activate_backward", "r3dg_adam_step"], order
-    if save_shading:
-        f_args = [c[1] for c in calls if c[0] == fwd][0]
-        b_args = [c[1] for c in calls if c[0] == bwd][0]
-        assert len(f_args) == 20 and len(b_args) == 26
-        assert f_args[-1] == b_args[16] == step._shade_saved.data_ptr() and step._shade_saved.numel() == P * 6 * K
-        assert f_args[16] == b_args[15] and f_args[17] & 1                          # the same lookup records; training outputs
-    else:
-        assert step._shade_saved is None

@@ -12,20 +12,25 @@ pytestmark = pytest.mark.gpu
 DEV = "cuda"
 
 
-def _renderer(P=3000, K=16, He=32, seed=5):
+def _renderer(P=3000, K=16, He=32, seed=5, cache="radiance"):
     from relightable3dgaussian_amd import relight, synthetic as syn
     from relightable3dgaussian_amd.bench_core import GaussianParams
     scene = syn.make_scene(P=P, seed=seed, stage2=True, scale_log_mean=-3.0)
     params = GaussianParams(scene, DEV, True)
     g = torch.Generator().manual_seed(11)
     envmap = (3.0 * torch.rand(He, 2 * He, 3, generator=g) ** 2).to(DEV)
-    return relight.RelightRenderer(params, envmap, K), relight
+    return relight.RelightRenderer(params, envmap, K, cache=cache), relight
 
 
+@pytest.mark.parametrize("cache", ["radiance", "transport"])
 @pytest.mark.parametrize("res,with_transform", [((96, 128), False), ((128, 96), True)])
-def test_fused_frame_matches_pytorch_glue(res, with_transform):
+def test_fused_frame_matches_pytorch_glue(res, with_transform, cache):
+    """Both caches against the PyTorch-glue frame.  The default ("transport") regenerates each direction from the normal and
+    the Fibonacci table (1e-7 off the cached one) and the GGX lobe is ill-conditioned: 2e-4 on the feature image there (the
+    bound of the shading parity tests for that term), 2e-5 with the radiance cache."""
     from relightable3dgaussian_amd import synthetic as syn
-    r, relight = _renderer()
+    r, relight = _renderer(cache=cache)
+    f_tol = 2e-4 if cache == "transport" else 2e-5
     H, W = res
     cam = syn.orbit_cameras(8, width=W, height=H)[3].to(DEV)
     bg = torch.zeros(3, device=DEV)
@@ -40,8 +45,8 @@ def test_fused_frame_matches_pytorch_glue(res, with_transform):
     want = relight.frame_reference(r, cam, bg, env_transform=tr, exact_activations=True)
     assert got["num_rendered"] == want["num_rendered"]
     msgs, ok_all = [], True
-    for k, rtol, atol in (("render", 1e-5, 1e-6), ("opacity", 1e-5, 1e-6), ("feature", 2e-5, 1e-6),
-                          ("env_only", 0.0, 2e-4), ("render_env", 1e-5, 2e-4), ("pbr_env", 0.0, 2e-4)):
+    for k, rtol, atol in (("render", 1e-5, 1e-6), ("opacity", 1e-5, 1e-6), ("feature", f_tol, 1e-6),
+                          ("env_only", 0.0, 2e-4), ("render_env", 1e-5, 2e-4), ("pbr_env", 0.0, 4e-4 if cache == "transport" else 2e-4)):
         ok, msg = report(k, got[k], want[k], rtol, atol)
         msgs.append(msg)
         ok_all &= ok
@@ -82,11 +87,9 @@ def test_a_light_that_turns_every_frame_takes_the_uncached_lookup_and_a_stopped_
     assert cached == [True, False, False, False, True, True], cached
 
 
-@pytest.mark.skipif(os.environ.get("R3DG_EXPERIMENTAL") != "1",
-                    reason="opt-in kernels written without GPU access; first run them with R3DG_EXPERIMENTAL=1")
 @pytest.mark.parametrize("regenerate_dirs", [True, False])
 def test_transport_cache_frames_equal_radiance_cache_frames(regenerate_dirs):
-    """RelightRenderer(cache="transport"): the view-independent part of the integral cached per sample / per Gaussian, the
+    """RelightRenderer(cache="transport"), the default: the view-independent part of the integral cached per sample / per Gaussian, the
     GGX lobe per frame (r3dg_shade_build_transport, r3dg_shade_forward_transport) -- the same 19 shading outputs and the
     same frames as the default renderer, for several cameras against ONE cache."""
     from relightable3dgaussian_amd import relight, synthetic as syn
@@ -95,7 +98,7 @@ def test_transport_cache_frames_equal_radiance_cache_frames(regenerate_dirs):
     g = torch.Generator().manual_seed(11)
     envmap = (3.0 * torch.rand(32, 64, 3, generator=g) ** 2).to(DEV)
     for K in (16, 100):
-        a = relight.RelightRenderer(GaussianParams(scene, DEV, True), envmap, K)
+        a = relight.RelightRenderer(GaussianParams(scene, DEV, True), envmap, K, cache="radiance")
         b = relight.RelightRenderer(GaussianParams(scene, DEV, True), envmap, K, cache="transport",
                                     regenerate_dirs=regenerate_dirs)
         bg = torch.zeros(3, device=DEV)
