@@ -112,7 +112,10 @@ int r3dg_rasterize_forward_finish_on(void* ticket, void* ordering_stream, int* n
  * images are background only, n_contrib 0, all gradients of that frame zero) and *d_overflow_flag = 1.0f; otherwise the
  * flag is set to 0.0f (may be NULL); *d_overflow_count (may be NULL) is incremented for every dropped frame and never
  * reset by the library, so a caller that polls rarely still hears about it.  The true count stays readable in the geometry state
- * (r3dg_geometry_state_total_offset).  Needs the direct tile binning (the default, at most 16384 tiles): its launches do not depend on the count. */
+ * (r3dg_geometry_state_total_offset).  Needs the direct tile binning (the default) and at most 16384 tiles (a 2048x2048
+ * image): its launches do not depend on the count.  r3dg_bounded_forward_supported(width, height) answers 1 when both hold
+ * -- callers take the two-phase forward otherwise (_begin_bounded returns R3DG_EINVAL from _finish_bounded if asked anyway). */
+int r3dg_bounded_forward_supported(int width, int height);
 int r3dg_rasterize_forward_begin_bounded(void* stream, r3dg_alloc_fn geometry_alloc, r3dg_alloc_fn binning_alloc,
                                          r3dg_alloc_fn image_alloc, void* alloc_user, int P, int S, int D, int M,
                                          const float* d_background, int width, int height, const float* d_means3D,
@@ -508,6 +511,20 @@ int r3dg_bvh_trace_opacity(void* stream, int64_t num_rays, int num_gaussians, co
                            const float* d_rays_o, const float* d_rays_d, const float* d_means3D,
                            const float* d_covs3D, const float* d_opacities, const float* d_normals,
                            int32_t* d_num_contributes, float* d_rendered_opacity, int32_t* d_stack_overflow);
+
+/* The same trace for callers that keep a tracer around (bvh.RayTracer; update_visibility traces the ray bundles in chunks
+ * against ONE tree): the 64-byte traversal records r3dg_bvh_trace_opacity rebuilds on every call are packed ONCE into a buffer
+ * the caller owns -- r3dg_bvh_trace_records_bytes(P) bytes, valid while the tree and the four per-Gaussian arrays are
+ * unchanged -- and traced any number of times.  The buffer also holds the per-XCD ray-queue heads of a trace in flight: one
+ * trace at a time per buffer (tracers on different streams use their own buffers; r3dg_bvh_trace_opacity keeps one private
+ * scratch per device and stream).  Results are bit-identical to r3dg_bvh_trace_opacity. */
+size_t r3dg_bvh_trace_records_bytes(int num_gaussians);
+int r3dg_bvh_pack_traversal(void* stream, int num_gaussians, const int32_t* d_nodes, const float* d_aabbs,
+                            const float* d_means3D, const float* d_covs3D, const float* d_opacities,
+                            const float* d_normals, void* d_records);
+int r3dg_bvh_trace_opacity_packed(void* stream, int64_t num_rays, int num_gaussians, void* d_records, const float* d_rays_o,
+                                  const float* d_rays_d, int32_t* d_num_contributes, float* d_rendered_opacity,
+                                  int32_t* d_stack_overflow);
 
 /* trace_bvh (bvh/include/bvh.h:8-12, bvh/src/trace.cu:8-192; no caller in the reference's Python): per-ray hit lists.
  *   r3dg_bvh_trace_count: num_contributes[r] = number of leaves in the <=4-leaf subtrees ray r reaches (trace.cu:21-58);

@@ -19,6 +19,7 @@ _SIGNATURES = {
     "r3dg_version": (_i, []),
     "r3dg_max_features_forward": (_i, []),
     "r3dg_max_features_backward": (_i, []),
+    "r3dg_bounded_forward_supported": (_i, [_i, _i]),
     "r3dg_geometry_state_bytes": (C.c_size_t, [_i]),
     "r3dg_image_state_bytes": (C.c_size_t, [_i, _i]),
     "r3dg_binning_state_bytes": (C.c_size_t, [C.c_int64]),
@@ -98,6 +99,9 @@ _SIGNATURES = {
     "r3dg_bvh_build_temp_bytes": (C.c_size_t, [_i]),
     "r3dg_bvh_build": (_i, [_p, _i, _p, _p, _p, _p]),
     "r3dg_bvh_trace_opacity": (_i, [_p, C.c_int64, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p]),
+    "r3dg_bvh_trace_records_bytes": (C.c_size_t, [_i]),
+    "r3dg_bvh_pack_traversal": (_i, [_p, _i] + [_p] * 7),
+    "r3dg_bvh_trace_opacity_packed": (_i, [_p, C.c_int64, _i] + [_p] * 6),
     "r3dg_profile_enable": (_i, [_i]),
     "r3dg_profile_pause": (_i, [_i]),
     "r3dg_profile_num_stages": (_i, []),

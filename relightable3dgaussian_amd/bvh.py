@@ -45,10 +45,24 @@ class RayTracer:
     def __init__(self, means3D, scales, rotations):
         nodes, aabbs = leaf_boxes(means3D, scales, rotations)
         self.tree, self.aabb, self.morton = bvh_ops.create_bvh(means3D, scales, rotations, nodes, aabbs)
+        # packed traversal records of the arrays the LAST trace_visibility call was given (update_visibility traces its
+        # ray bundles chunk by chunk against the same arrays: packed once, owned by this tracer)
+        self._records = self._records_key = self._records_ref = None
+
+    def _records_for(self, means3D, symm_inv, opacity, normals):
+        if self.tree.shape[0] != 2 * means3D.shape[0] - 1 or means3D.shape[0] == 0:
+            return None
+        arrays = (means3D, symm_inv, opacity, normals)
+        key = tuple((t.data_ptr(), t._version, tuple(t.shape)) for t in arrays)
+        if self._records is None or key != self._records_key:
+            self._records = bvh_ops.trace_records(self.tree, self.aabb, *arrays)
+            # (references kept: an address cannot be recycled for other values while it is part of the key)
+            self._records_key, self._records_ref = key, arrays
+        return self._records
 
     @torch.no_grad()
     def trace_visibility(self, rays_o, rays_d, means3D, symm_inv, opacity, normals):
         rays_o = rays_o + rays_d * 0.05
         contrib, opa = bvh_ops.trace_bvh_opacity(self.tree, self.aabb, rays_o, rays_d, means3D, symm_inv, opacity,
-                                                 normals)
+                                                 normals, records=self._records_for(means3D, symm_inv, opacity, normals))
         return {"visibility": opa.unsqueeze(-1), "contribute": contrib.unsqueeze(-1)}

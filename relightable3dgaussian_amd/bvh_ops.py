@@ -29,7 +29,25 @@ def create_bvh(means3D, scales, rotations, nodes, aabbs):
     return nodes, aabbs, mortons
 
 
-def trace_bvh_opacity(nodes, aabbs, rays_o, rays_d, means3D, covs3D, opacities, normals):
+def trace_records(nodes, aabbs, means3D, covs3D, opacities, normals):
+    """The tree and the per-Gaussian arrays packed into 64-byte traversal records (r3dg_bvh_pack_traversal), for
+    trace_bvh_opacity(..., records=...): pack once, trace many ray chunks.  Valid while the six tensors are unchanged."""
+    L = _lib.lib()
+    P = means3D.shape[0]
+    if nodes.shape[0] != 2 * P - 1:
+        raise RuntimeError("trace_records: nodes must be the [2P-1,5] table of a tree over these Gaussians")
+    dev = means3D.device
+    rec = torch.empty(int(L.r3dg_bvh_trace_records_bytes(P)), dtype=torch.uint8, device=dev)
+    t = [x.contiguous() for x in (nodes, aabbs, means3D, covs3D, opacities, normals)]
+    with torch.cuda.device(dev):
+        _lib.check(L.r3dg_bvh_pack_traversal(_lib.current_stream(), P, *[x.data_ptr() for x in t], rec.data_ptr()),
+                   "trace_records")
+    return rec
+
+
+def trace_bvh_opacity(nodes, aabbs, rays_o, rays_d, means3D, covs3D, opacities, normals, records=None):
+    """`records` (not in the reference): trace_records(...) of the SAME six tensors -- the per-call repacking of the tree
+    is skipped (one trace at a time per records buffer)."""
     L = _lib.lib()
     shape = rays_o.shape[:-1]
     num_rays = rays_o.numel() // rays_o.size(-1)
@@ -38,12 +56,18 @@ def trace_bvh_opacity(nodes, aabbs, rays_o, rays_d, means3D, covs3D, opacities, 
     rendered_opacity = torch.ones(shape, dtype=torch.float32, device=dev)
     if num_rays > 0:
         overflow = torch.zeros(1, dtype=torch.int32, device=dev)
-        t = [x.contiguous() for x in (nodes, aabbs, rays_o, rays_d, means3D, covs3D, opacities, normals)]
         with torch.cuda.device(dev):
-            P = means3D.shape[0] if nodes.shape[0] == 2 * means3D.shape[0] - 1 else 0
-            st = L.r3dg_bvh_trace_opacity(_lib.current_stream(), num_rays, P, *[x.data_ptr() for x in t],
-                                          num_contributes.data_ptr(), rendered_opacity.data_ptr(),
-                                          overflow.data_ptr())
+            if records is not None:
+                ro, rd = rays_o.contiguous(), rays_d.contiguous()
+                st = L.r3dg_bvh_trace_opacity_packed(_lib.current_stream(), num_rays, means3D.shape[0], records.data_ptr(),
+                                                     ro.data_ptr(), rd.data_ptr(), num_contributes.data_ptr(),
+                                                     rendered_opacity.data_ptr(), overflow.data_ptr())
+            else:
+                t = [x.contiguous() for x in (nodes, aabbs, rays_o, rays_d, means3D, covs3D, opacities, normals)]
+                P = means3D.shape[0] if nodes.shape[0] == 2 * means3D.shape[0] - 1 else 0
+                st = L.r3dg_bvh_trace_opacity(_lib.current_stream(), num_rays, P, *[x.data_ptr() for x in t],
+                                              num_contributes.data_ptr(), rendered_opacity.data_ptr(),
+                                              overflow.data_ptr())
         _lib.check(st, "trace_bvh_opacity")
         trace_bvh_opacity.last_overflow = overflow
     return num_contributes, rendered_opacity

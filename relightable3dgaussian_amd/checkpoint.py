@@ -48,13 +48,34 @@ def _named_tensors(step):
     return out
 
 
+def step_learning_rates(step):
+    """{reference group name: lr} of the groups a fused step owns, read from its optimizer (FusedAdam.groups): the joined
+    [P,16,3] SH tensors split back into the dc / rest rates (`lr` / `lr_tail`)."""
+    out = {}
+    opt = getattr(step, "opt", None)
+    if opt is None:
+        return out
+    for k, g in zip(step._opt_order, opt.groups):
+        if g.get("lr") is None:
+            continue
+        tail = g.get("lr_tail")
+        if k == "shs":
+            out["f_dc"], out["f_rest"] = float(g["lr"]), float(g["lr"] if tail is None else tail)
+        elif k == "incidents":
+            out["incidents_dc"], out["incidents_rest"] = float(g["lr"]), float(g["lr"] if tail is None else tail)
+        elif k != "env":
+            out[k] = float(g["lr"])
+    return out
+
+
 def capture(step, iteration, spatial_lr_scale=1.0, active_sh_degree=3, learning_rates=None):
     """-> the object train.py saves: `(GaussianModel.capture() list, iteration)`.  `step`: FusedStage1Step or
     FusedStage2Step (stage 2 adds the six PBR entries; the baked-visibility SH groups this repo does not train are
     written as zeros of the reference's shapes).  `learning_rates`: {group name: lr} for the param_groups -- torch's
     Optimizer.load_state_dict ADOPTS the saved groups' hyper-parameters, so a reference GaussianModel.restore(is_training=
-    True) on this file trains with exactly these rates; the default is the reference's own training_setup values
-    (reference_learning_rates), never zero."""
+    True) on this file trains with exactly these rates; the default is what the step itself trains with
+    (step_learning_rates: the scheduled xyz rate, the stage-2 rates of the run script), and the reference's own training_setup
+    values (reference_learning_rates) for the groups the step does not own."""
     named = _named_tensors(step)
     P = step.xyz.shape[0]
     dev = step.xyz.device
@@ -66,6 +87,7 @@ def capture(step, iteration, spatial_lr_scale=1.0, active_sh_degree=3, learning_
     names = STAGE1_GROUPS + (PBR_GROUPS if pbr else ())
     params = {n: nn.Parameter(named[n][0].detach().clone().contiguous().requires_grad_(True)) for n in names}
     lrs = reference_learning_rates(spatial_lr_scale)
+    lrs.update(step_learning_rates(step))          # what the step actually trains with (scheduled xyz rate, stage-2 rates)
     lrs.update(learning_rates or {})
     optimizer = torch.optim.Adam([{"params": [params[n]], "lr": float(lrs[n]), "name": n} for n in names],
                                  lr=0.0, eps=1e-15)
@@ -87,7 +109,7 @@ def capture(step, iteration, spatial_lr_scale=1.0, active_sh_degree=3, learning_
     return captured, int(iteration)
 
 
-def restore(checkpoint, device=None, pbr=False):
+def restore(checkpoint, device=None, pbr=False, allow_unsafe=False):
     """`checkpoint`: the `(captured list, iteration)` object (or a path to one).  -> namespace with the raw parameters
     under this repo's names (xyz, normal, scaling, rotation, opacity, features_dc, features_rest [, base_color, roughness,
     incidents_dc, incidents_rest, visibility_dc, visibility_rest]), `moments` {reference group name: (exp_avg, exp_avg_sq)}
@@ -99,11 +121,25 @@ def restore(checkpoint, device=None, pbr=False):
     DirectLightMap) can be handed to FusedStage2Step.  The reference-faithful hand-off does NOT carry the Adam state over:
     train.py calls create_from_ckpt(restore_optimizer=True) before training_setup, when `optimizer` is still None, and
     swallows the exception -- stage 2 starts with fresh moments and step count.  `load_moments` is for resuming the SAME
-    stage from this repo's own checkpoints."""
+    stage from this repo's own checkpoints.
+    `allow_unsafe`: retry a file that torch's weights-only loader refuses with full unpickling (trusted files only)."""
     if isinstance(checkpoint, (str, bytes)) or hasattr(checkpoint, "__fspath__"):
-        try:            # tensors, Parameters, dicts, lists: loadable without arbitrary unpickling
-            checkpoint = torch.load(checkpoint, map_location="cpu", weights_only=True)
-        except Exception:
+        # tensors, Parameters, dicts, lists -- everything GaussianModel.capture() writes -- load without arbitrary
+        # unpickling.  A file the safe loader refuses is NOT retried with the unsafe one (a malicious file would only have
+        # to fail the first attempt) unless the caller says so for a file it trusts; a corrupt file raises either way.
+        import pickle
+        try:
+            # train.py stores spatial_lr_scale as the numpy float64 the dataset reader computed (scene/__init__.py:86,
+            # train.py:190-203): numpy's scalar reconstructor and dtype are allow-listed for this load, nothing else is
+            import numpy as np
+            extra = [np.dtype, type(np.dtype(np.float64)), type(np.dtype(np.float32))]
+            core = getattr(np, "_core", None) or getattr(np, "core")
+            extra.append(core.multiarray.scalar)
+            with torch.serialization.safe_globals(extra):
+                checkpoint = torch.load(checkpoint, map_location="cpu", weights_only=True)
+        except pickle.UnpicklingError:
+            if not allow_unsafe:
+                raise
             checkpoint = torch.load(checkpoint, map_location="cpu", weights_only=False)
     captured, iteration = checkpoint
     if len(captured) not in (15, 21):

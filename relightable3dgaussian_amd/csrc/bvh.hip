@@ -12,6 +12,9 @@
 //   * the traversal stack holds 64 entries (reference: 32 with only a printf on overflow, trace.cuh:21-28); pushes
 //     beyond that are dropped and counted in *overflow so callers can detect it.
 #include "common.hpp"
+#include <map>
+#include <mutex>
+#include <utility>
 
 namespace r3dg {
 
@@ -1135,24 +1138,75 @@ void bvh_build(hipStream_t s, int P, int32_t* nodes, float* aabbs, uint64_t* mor
     }
 }
 
-// per-device scratch for the packed traversal records (grow-only; 128 bytes per Gaussian)
-static char* trace_records(size_t P)
+// Packed traversal records: 64 bytes per internal node + 64 bytes per leaf + the 8 per-XCD ray-queue heads (8 x 64 bytes).
+// The buffer belongs to the CALLER (r3dg_bvh_pack_traversal / r3dg_bvh_trace_opacity_packed: one per tracer, packed once per
+// set of Gaussian arrays); the reference-shaped entry point r3dg_bvh_trace_opacity packs per call into a scratch buffer that
+// is private to its (device, stream) pair, so tracers on different streams or threads never share records or queue heads.
+size_t bvh_trace_records_bytes(size_t P) { return (P + 8) * 128 + 8 * 64; }
+
+void bvh_pack_traversal(hipStream_t s, int P, const int32_t* nodes, const float* aabbs, const float* means, const float* covs,
+                        const float* opac, const float* normals, void* records)
 {
-    static char* buf[64] = {nullptr};
-    static size_t cap[64] = {0};
+    if (P <= 0) return;
+    char* rec = reinterpret_cast<char*>(records);
+    TNode* tn = reinterpret_cast<TNode*>(rec);
+    TLeaf* tl = reinterpret_cast<TLeaf*>(rec + (size_t)P * 64);
+    pack_traversal_kernel<<<(P + 255) / 256, 256, 0, s>>>(P, nodes, aabbs, means, covs, opac, normals, tn, tl);
+}
+
+// the packed formulations (g_trace_packet 2, 3, 4) over records written by bvh_pack_traversal
+void bvh_trace_opacity_packed(hipStream_t s, int num_rays, int P, void* records, const float* rays_o, const float* rays_d,
+                              int32_t* contributes, float* out, int* overflow)
+{
+    if (num_rays <= 0 || P <= 0) return;
+    char* rec = reinterpret_cast<char*>(records);
+    TNode* tn = reinterpret_cast<TNode*>(rec);
+    TLeaf* tl = reinterpret_cast<TLeaf*>(rec + (size_t)P * 64);
+    int* queues = reinterpret_cast<int*>(rec + (size_t)P * 128);               // 8 x 64 bytes behind the records
+    const int nblk = (num_rays + 255) / 256, chunk = (nblk + 7) / 8;
+    if (g_trace_packet >= 3 || g_trace_packet < 2) {
+        int dev = 0, cus = 256;
+        R3DG_HIP(hipGetDevice(&dev));
+        (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+        cus = cus > g_reserve_cus ? cus - g_reserve_cus : 1;                    // leave CUs to a concurrent collective
+        R3DG_HIP(hipMemsetAsync(queues, 0, 8 * 64, s));
+        const int cap = cus * 8;                                                // 8 waves per SIMD, all resident
+        const int grid = chunk * 8 < cap ? chunk * 8 : cap;
+        if (g_trace_packet == 3)
+            trace_opacity_persistent_kernel<<<grid, 256, 0, s>>>(num_rays, P, tn, tl, rays_o, rays_d, contributes, out,
+                                                                overflow, queues);
+        else
+            trace_opacity_phased_kernel<<<grid, 256, 0, s>>>(num_rays, P, tn, tl, rays_o, rays_d, contributes, out,
+                                                            overflow, queues, g_trace_refill, g_trace_node_weight,
+                                                            g_trace_leaf_weight);
+    } else {
+        trace_opacity_packed_kernel<<<chunk * 8, 256, 0, s>>>(num_rays, P, chunk, tn, tl, rays_o, rays_d, contributes,
+                                                             out, overflow);
+    }
+}
+
+// scratch records of the reference-shaped entry point: one grow-only buffer per (device, stream)
+static void* trace_scratch(hipStream_t s, size_t bytes)
+{
+    struct Buf { void* p = nullptr; size_t cap = 0; };
+    static std::mutex mu;
+    static std::map<std::pair<int, hipStream_t>, Buf> bufs;
     int dev = 0;
     R3DG_HIP(hipGetDevice(&dev));
-    if (dev < 0 || dev >= 64) dev = 0;
-    if (cap[dev] < P) {
-        if (buf[dev] != nullptr) {
-            R3DG_HIP(hipDeviceSynchronize());
-            R3DG_HIP(hipFree(buf[dev]));
+    std::lock_guard<std::mutex> lk(mu);
+    Buf& b = bufs[std::make_pair(dev, s)];
+    if (b.cap < bytes) {
+        if (b.p != nullptr) {
+            R3DG_HIP(hipStreamSynchronize(s));        // only THIS stream ever used the old buffer
+            R3DG_HIP(hipFree(b.p));
+            b.p = nullptr;
+            b.cap = 0;
         }
-        const size_t want = P + P / 8 + 1024;
-        R3DG_HIP(hipMalloc((void**)&buf[dev], want * 128));
-        cap[dev] = want;
+        const size_t want = bytes + bytes / 8 + 4096;
+        R3DG_HIP(hipMalloc(&b.p, want));
+        b.cap = want;
     }
-    return buf[dev];
+    return b.p;
 }
 
 // P = number of Gaussians (rows of means / leaves of the tree); P <= 0: unknown -> the round-1 kernel
@@ -1162,30 +1216,9 @@ void bvh_trace_opacity(hipStream_t s, int num_rays, int P, const int32_t* nodes,
 {
     if (num_rays <= 0) return;
     if (g_trace_packet >= 2 && P > 0) {
-        char* rec = trace_records((size_t)P + 8);
-        TNode* tn = reinterpret_cast<TNode*>(rec);
-        TLeaf* tl = reinterpret_cast<TLeaf*>(rec + (size_t)P * 64);
-        int* queues = reinterpret_cast<int*>(rec + (size_t)P * 128);           // 8 x 64 bytes behind the records
-        pack_traversal_kernel<<<(P + 255) / 256, 256, 0, s>>>(P, nodes, aabbs, means, covs, opac, normals, tn, tl);
-        const int nblk = (num_rays + 255) / 256, chunk = (nblk + 7) / 8;
-        if (g_trace_packet >= 3) {
-            int dev = 0, cus = 256;
-            R3DG_HIP(hipGetDevice(&dev));
-            (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-            R3DG_HIP(hipMemsetAsync(queues, 0, 8 * 64, s));
-            const int cap = cus * 8;                                                // 8 waves per SIMD, all resident
-            const int grid = chunk * 8 < cap ? chunk * 8 : cap;
-            if (g_trace_packet == 4)
-                trace_opacity_phased_kernel<<<grid, 256, 0, s>>>(num_rays, P, tn, tl, rays_o, rays_d, contributes, out,
-                                                                overflow, queues, g_trace_refill, g_trace_node_weight,
-                                                                g_trace_leaf_weight);
-            else
-                trace_opacity_persistent_kernel<<<grid, 256, 0, s>>>(num_rays, P, tn, tl, rays_o, rays_d, contributes, out,
-                                                                    overflow, queues);
-        } else {
-            trace_opacity_packed_kernel<<<chunk * 8, 256, 0, s>>>(num_rays, P, chunk, tn, tl, rays_o, rays_d, contributes,
-                                                                 out, overflow);
-        }
+        void* rec = trace_scratch(s, bvh_trace_records_bytes((size_t)P));
+        bvh_pack_traversal(s, P, nodes, aabbs, means, covs, opac, normals, rec);
+        bvh_trace_opacity_packed(s, num_rays, P, rec, rays_o, rays_d, contributes, out, overflow);
     } else if (g_trace_packet == 1)
         trace_opacity_packet_kernel<<<(num_rays + 255) / 256, 256, 0, s>>>(num_rays, nodes, aabbs, rays_o, rays_d, means,
                                                                           covs, opac, normals, contributes, out, overflow);

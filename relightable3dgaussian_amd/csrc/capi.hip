@@ -164,6 +164,12 @@ void bvh_trace_fill(hipStream_t s, int num_rays, const int32_t* nodes, const flo
 void bvh_trace_opacity(hipStream_t s, int num_rays, int P, const int32_t* nodes, const float* aabbs, const float* rays_o,
                        const float* rays_d, const float* means, const float* covs, const float* opac,
                        const float* normals, int32_t* contributes, float* out, int* overflow);
+size_t bvh_trace_records_bytes(size_t P);
+void bvh_pack_traversal(hipStream_t s, int P, const int32_t* nodes, const float* aabbs, const float* means, const float* covs,
+                        const float* opac, const float* normals, void* records);
+void bvh_trace_opacity_packed(hipStream_t s, int num_rays, int P, void* records, const float* rays_o, const float* rays_d,
+                              int32_t* contributes, float* out, int* overflow);
+int g_reserve_cus = 0;
 extern int g_cull;
 extern int g_stage_sh_rows;
 extern int g_shade_fwd_blocks_per_cu;
@@ -312,6 +318,12 @@ const char* r3dg_last_error(void) { return g_last_error.c_str(); }
 int r3dg_version(void) { return 100; }
 int r3dg_max_features_forward(void) { return R3DG_MAX_S_FWD; }
 int r3dg_max_features_backward(void) { return R3DG_MAX_S_BWD; }
+int r3dg_bounded_forward_supported(int width, int height)
+{
+    if (width <= 0 || height <= 0) return 0;
+    const long long gx = (width + R3DG_TILE_X - 1) / R3DG_TILE_X, gy = (height + R3DG_TILE_Y - 1) / R3DG_TILE_Y;
+    return g_tile_binning == 2 && gx * gy <= (long long)tile_binning_max_tiles() ? 1 : 0;
+}
 
 // tuning knobs (pixels per lane of the two render kernels); not part of the drop-in surface
 int r3dg_set_tuning6(int shade_forward_blocks_per_cu)
@@ -703,7 +715,7 @@ static int enqueue_ordering(ForwardTicket* t, hipStream_t stream, int R)
     r3dg_alloc_fn binning_alloc = t->binning_alloc;
     void* user = t->user;
     if (t->capacity >= 0 && !(g_tile_binning == 2 && (int)T <= tile_binning_max_tiles())) {
-        set_error("rasterize_forward (bounded): needs the direct tile binning (r3dg_set_tuning4(2), at most 16384 tiles)");
+        set_error("rasterize_forward (bounded): needs the direct tile binning and at most 16384 tiles: ask r3dg_bounded_forward_supported(width, height) first");
         return R3DG_EINVAL;
     }
         BinningLayout B = BinningLayout::make((size_t)R);
@@ -1598,6 +1610,45 @@ int r3dg_bvh_trace_opacity(void* stream_, int64_t num_rays, int num_gaussians, c
         bvh_trace_opacity(stream, (int)num_rays, num_gaussians, nodes, aabbs, rays_o, rays_d, means3D, covs3D, opacities,
                           normals, num_contributes, rendered_opacity, stack_overflow);
         check_launch(stream, false, "bvh_trace_opacity");
+        t.stop();
+        return R3DG_OK;
+    });
+}
+
+size_t r3dg_bvh_trace_records_bytes(int num_gaussians)
+{
+    return bvh_trace_records_bytes((size_t)(num_gaussians > 0 ? num_gaussians : 0));
+}
+
+int r3dg_bvh_pack_traversal(void* stream_, int num_gaussians, const int32_t* nodes, const float* aabbs, const float* means3D,
+                            const float* covs3D, const float* opacities, const float* normals, void* records)
+{
+    if (num_gaussians < 0) return invalid("bvh_pack_traversal: bad Gaussian count");
+    if (num_gaussians == 0) return R3DG_OK;
+    if (!nodes || !aabbs || !means3D || !covs3D || !opacities || !normals || !records)
+        return invalid("bvh_pack_traversal: null buffer");
+    return guarded([&]() -> int {
+        bvh_pack_traversal((hipStream_t)stream_, num_gaussians, nodes, aabbs, means3D, covs3D, opacities, normals, records);
+        check_launch((hipStream_t)stream_, false, "bvh_pack_traversal");
+        return R3DG_OK;
+    });
+}
+
+int r3dg_bvh_trace_opacity_packed(void* stream_, int64_t num_rays, int num_gaussians, void* records, const float* rays_o,
+                                  const float* rays_d, int32_t* num_contributes, float* rendered_opacity,
+                                  int32_t* stack_overflow)
+{
+    if (num_rays < 0 || num_rays > 0x7fffffffll) return invalid("bvh_trace_opacity_packed: bad ray count");
+    if (num_gaussians <= 0) return invalid("bvh_trace_opacity_packed: bad Gaussian count");
+    if (num_rays == 0) return R3DG_OK;
+    if (!records || !rays_o || !rays_d || !num_contributes || !rendered_opacity || !stack_overflow)
+        return invalid("bvh_trace_opacity_packed: null buffer");
+    return guarded([&]() -> int {
+        hipStream_t stream = (hipStream_t)stream_;
+        StageTimer t(stream, ST_BVH_TRACE);
+        bvh_trace_opacity_packed(stream, (int)num_rays, num_gaussians, records, rays_o, rays_d, num_contributes,
+                                 rendered_opacity, stack_overflow);
+        check_launch(stream, false, "bvh_trace_opacity_packed");
         t.stop();
         return R3DG_OK;
     });

@@ -47,6 +47,12 @@ inline void check_launch(hipStream_t s, bool debug, const char* what)
 
 static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
+// CUs the persistent kernels (shading forward / backward, visibility trace) leave unoccupied so that a collective running
+// beside them on another stream (RCCL's workgroups need LDS and registers on SOME CU) is not serialised behind them:
+// their grids are sized for (CUs - g_reserve_cus).  0 on a single GPU; set by the data-parallel iteration
+// (r3dg_set_option(R3DG_OPT_RESERVE_CUS)).
+extern int g_reserve_cus;
+
 struct GeometryLayout {  // byte offsets into the opaque geometry buffer
     size_t depths, clamped, radii, means2D, cov3D, conic_opacity, rgb, tiles_touched, point_offsets, block_sums,
         total, splat, bytes;

@@ -108,6 +108,7 @@ class _BoundedForward:
         self.bounded = bool(bounded)
         self._flag = flag                          # 4 floats inside the gradient slab (summed by the first all-reduce)
         self._capacity = None                      # instance slots of the bounded forward (None: not known yet)
+        self._bounded_ok = {}                      # (W, H) -> the library can run the bounded forward at this size
         self._overflow_count = torch.zeros(1, dtype=torch.int32, device=self.dev)
         self._overflow_seen = 0
         self.dropped_steps = 0
@@ -120,6 +121,17 @@ class _BoundedForward:
         self._count_ring = torch.zeros(4096, dtype=torch.int64)                 # num_rendered of the last iterations
         if self.dev.type == "cuda":
             self._count_ring = self._count_ring.pin_memory()
+
+    def _use_bounded(self, W, H):
+        """Bounded forward for this frame?  Only once a capacity is known, and only where the library can run it (direct
+        tile binning, at most 16384 tiles -- r3dg_bounded_forward_supported; a 2560x1664 view takes the exact two-phase
+        forward every time instead of raising on its second iteration)."""
+        if not (self.bounded and self._capacity is not None):
+            return False
+        key = (W, H)
+        if self._bounded_ok.get(key) is None:
+            self._bounded_ok[key] = bool(_lib.lib().r3dg_bounded_forward_supported(int(W), int(H)))
+        return self._bounded_ok[key]
 
     @staticmethod
     def _capacity_for(R):
@@ -351,7 +363,7 @@ class FusedStage2Step(_BoundedForward):
         with torch.cuda.device(dev):
             self.refresh_activations(cam)
             self._iter += 1
-            use_bounded = self.bounded and self._capacity is not None
+            use_bounded = self._use_bounded(W, H)
             if use_bounded:
                 # bounded forward: projection + instance ordering go to the ordering stream NOW and run beside the
                 # shading kernels queued below; nobody waits for the count
@@ -705,7 +717,7 @@ class FusedStage1Step(_BoundedForward):
                 self.a_rot.data_ptr(), self.a_opacity.data_ptr(), self.a_normal.data_ptr(), None, None, None),
                 "stage2_activate")
             self._iter += 1
-            use_bounded = self.bounded and self._capacity is not None
+            use_bounded = self._use_bounded(W, H)
             if not use_bounded:
                 self._flag.zero_()
             pending = rasterizer_ops.rasterize_gaussians_begin(

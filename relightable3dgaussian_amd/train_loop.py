@@ -69,13 +69,18 @@ def create_from_points(points, colors, normals=None, device="cuda"):
 
 
 def train_stage1(init, cameras, images, background, extent, schedule=None, iterations=None, seed=0,
-                 white_background=True, process_group=None, on_iteration=None, masks=None, loss_weights=None):
+                 white_background=True, process_group=None, on_iteration=None, masks=None, loss_weights=None,
+                 poll_interval=32):
     """Runs `iterations` fused stage-1 iterations over the (camera, image) pairs in round-robin order (the reference
     draws a random permutation, train.py:115-119; the order is the caller's) with the reference's densification
     schedule.  Returns (FusedStage1Step, history) where history lists (iteration, event, rows) for every
     densify / reset.  The objective is the reference's stage-1 loss with the lambdas of script/run_nerf.sh:7-14
     (train_step.STAGE1_WEIGHTS; `loss_weights` overrides them); `masks[v]` [1,H,W] is view v's object mask
-    (Camera.image_mask; None = all ones)."""
+    (Camera.image_mask; None = all ones).
+    The fused iteration's bounded forward drops a view on the device when it needs more tile instances than the capacity
+    learned so far (fused_step._BoundedForward): the loop asks every `poll_interval` iterations and before every densify
+    (`poll_overflow`: one 4-byte read-back, grows the capacity, takes the step back from Adam's count) and lists what was
+    dropped as (iteration, "dropped_views", n) in the history -- the reference trains on every view, so a run reports it."""
     sch = schedule or Schedule()
     n_iter = sch.iterations if iterations is None else iterations
     step = FusedStage1Step(init, lr=sch.sh_lr, lr_rest_scale=1.0 / 20.0, process_group=process_group,
@@ -96,8 +101,13 @@ def train_stage1(init, cameras, images, background, extent, schedule=None, itera
             step.stats = None                                                # train.py:160: statistics only while densifying
         step.iteration = it                                                  # depth-variance schedule, render.py:202
         step.forward_backward(cameras[v], background, images[v], None if masks is None else masks[v])
+        densify_now = collecting and it > sch.densify_from_iter and it % sch.densification_interval == 0
+        if densify_now or (poll_interval and it % poll_interval == 0) or it == n_iter:
+            dropped = step.poll_overflow()
+            if dropped:
+                history.append((it, "dropped_views", dropped))
         if collecting:
-            if it > sch.densify_from_iter and it % sch.densification_interval == 0:
+            if densify_now:
                 size_threshold = 20 if it > sch.opacity_reset_interval else None
                 normal_thr = sch.densify_grad_normal_threshold if it > sch.normal_densify_from_iter else 99999
                 # densify precedes gaussians.step() (train.py:167-177), which then finds .grad = None on the freshly

@@ -133,12 +133,24 @@ def test_training_loop_follows_the_reference_schedule(monkeypatch):
         def optimizer_step(self):
             log.append(("step",))
 
+        def poll_overflow(self):                    # (the bounded forward dropped one view around iteration 10)
+            n_fb = sum(1 for x in log if x[0] == "fb")
+            log.append(("poll", n_fb))
+            if n_fb >= 10 and not getattr(self, "_told", False):
+                self._told = True
+                return 1
+            return 0
+
     monkeypatch.setattr(train_loop, "FusedStage1Step", FakeStep)
     monkeypatch.setattr(torch, "Generator", lambda device=None: types.SimpleNamespace(manual_seed=lambda s: None))
     sch = train_loop.Schedule(densify_from_iter=4, densification_interval=3, densify_until_iter=14,
                               opacity_reset_interval=8, normal_densify_from_iter=7)
     step, history = train_loop.train_stage1(None, ["c0", "c1", "c2"], [0, 1, 2], None, extent=2.0, schedule=sch,
-                                            iterations=16, white_background=True)
+                                            iterations=16, white_background=True, poll_interval=5)
+    # dropped views are asked for every poll_interval iterations, before every densify and at the end, and reported
+    assert [n for tag, n in (x for x in log if x[0] == "poll")] == [5, 6, 9, 10, 12, 15, 16]
+    assert [h for h in history if h[1] == "dropped_views"] == [(10, "dropped_views", 1)]
+    history = [h for h in history if h[1] != "dropped_views"]
     # reference: for it in 1..16: stats while it < 14; densify if it > 4 and it % 3 == 0 (and it < 14): 6, 9, 12;
     # reset if it % 8 == 0 or (white and it == 4), only while it < 14: 4, 8
     assert [(i, e) for i, e, _ in history] == [(4, "reset_opacity"), (6, "densify"), (8, "reset_opacity"),

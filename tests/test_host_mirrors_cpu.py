@@ -367,10 +367,15 @@ def test_raytracer_wrapper_calls_the_backend_like_the_reference(monkeypatch):
     from tests import wrapper_trace
     want = json.load(open(os.path.join(GOLDEN, "wrapper_trace_reference.json")))["raytracer"]
 
+    packed = []
+
     def install(create, trace):
         monkeypatch.setattr(bvh.bvh_ops, "create_bvh", create)
-        monkeypatch.setattr(bvh.bvh_ops, "trace_bvh_opacity", trace)
+        # (this repo's tracer additionally hands over its packed traversal records: the eight reference arguments unchanged)
+        monkeypatch.setattr(bvh.bvh_ops, "trace_records", lambda *a: packed.append(len(a)) or "records")
+        monkeypatch.setattr(bvh.bvh_ops, "trace_bvh_opacity", lambda *a, records=None: packed.append(records) or trace(*a))
     got = wrapper_trace.run_raytracer(bvh.RayTracer, install)
+    assert packed == [6, "records"]
     assert got["offset_ok"] and want["offset_ok"]
     assert got["create_args"] == want["create_args"]
     assert len(got["trace_args"]) == len(want["trace_args"]) == 8
@@ -474,6 +479,15 @@ def test_checkpoint_defaults_follow_the_reference_flow():
     lrs = {g["name"]: g["lr"] for g in captured[13]["param_groups"]}
     assert lrs == {"xyz": 0.00016 * 2.0, "normal": 0.01, "rotation": 0.001, "scaling": 0.005, "opacity": 0.05, "f_dc": 0.0025,
                    "f_rest": 0.0025 / 20.0}
+    # a step that trains with its own rates (scheduled xyz rate, the 10x smaller stage-2 rates of run_nerf.sh): those are written
+    for g, lr in zip(holder.opt.groups, (3e-5, 0.001, 0.0005, 0.0001, 0.005, 0.00025)):
+        g["lr"] = lr
+    holder.opt.groups[5]["lr_tail"] = 0.00025 / 20.0
+    lrs = {g["name"]: g["lr"] for g in ck.capture(holder, 123, spatial_lr_scale=2.0)[0][13]["param_groups"]}
+    assert lrs == {"xyz": 3e-5, "normal": 0.001, "rotation": 0.0001, "scaling": 0.0005, "opacity": 0.005, "f_dc": 0.00025,
+                   "f_rest": 0.00025 / 20.0}
+    lrs = {g["name"]: g["lr"] for g in ck.capture(holder, 1, learning_rates={"xyz": 7.0})[0][13]["param_groups"]}
+    assert lrs["xyz"] == 7.0 and lrs["normal"] == 0.001
     s2 = ck.restore(os.path.join(GOLDEN, "checkpoint_reference_stage1.pth"), pbr=True)
     assert s2.base_color.shape == (P, 3) and s2.roughness.shape == (P, 1) and s2.incidents_dc.shape == (P, 1, 3)
     assert s2.incidents_rest.shape == (P, 15, 3) and s2.visibility_rest.shape == (P, 15, 1)
@@ -492,7 +506,7 @@ def test_fused_stage2_iteration_host_logic_with_a_recording_library(monkeypatch)
         def __getattr__(self, name):
             def fn(*args):
                 calls.append((name, args))
-                return 0
+                return 1 if name == "r3dg_bounded_forward_supported" else 0
             return fn
 
     P, K, H, W = 6, 8, 4, 4
