@@ -170,6 +170,17 @@ int r3dg_rasterize_backward_split(void* stream, void* geometry_stream, int P, in
                                   int backward_geometry, int debug, int n_active_features,
                                   const int* active_features);
 
+/* The backward for FROZEN GEOMETRY: only d_dL_dfeature [P,S] (ACCUMULATED with atomics: zero it first) from d_dL_dpix_f
+ * [S,H,W].  The stage-2 schedules of script/run_syn4.sh:27-33 and run_dtu.sh set the learning rates of positions, normals, SH
+ * colour, opacity, scaling and rotation to 0: every gradient r3dg_rasterize_backward produces except dL_dfeature
+ * (= sum over pixels of alpha * T * dL_dpixel_f, backward.cu:566) is then multiplied by 0 in the optimizer, so neither the
+ * alpha-gradient recursion of the tile kernel nor the per-Gaussian geometry backward (K12 + K13) needs to run.  Same state
+ * buffers, same active_features contract as r3dg_rasterize_backward_split; values equal that call's d_dL_dfeature up to the
+ * order of the float atomics. */
+int r3dg_rasterize_backward_features(void* stream, int P, int S, int R, int width, int height, const void* d_geom_buffer,
+                                     const void* d_binning_buffer, const void* d_img_buffer, const float* d_dL_dpix_f,
+                                     float* d_dL_dfeature, int n_active_features, const int* active_features, int debug);
+
 int r3dg_mark_visible(void* stream, int P, const float* d_means3D, const float* d_viewmatrix,
                       const float* d_projmatrix, uint8_t* d_present);
 
@@ -299,9 +310,12 @@ int r3dg_render_equation_backward(void* stream, int P, int Si, int Sd, int Sv, c
  *   for r3dg_shade_backward_cached.
  * r3dg_stage2_activate_backward: chain rule of every activation above; combines the rasterizer's dL_dscales, dL_drot,
  *   dL_dopacity, dL_dmeans3D, dL_dfeatures and the shading op's dL_dbase_color, dL_droughness, dL_dviewdirs into the
- *   raw-parameter gradients (all seven outputs fully written).
+ *   raw-parameter gradients (all seven outputs fully written).  d_g_xyz == NULL = frozen geometry (run_syn4.sh / run_dtu.sh:
+ *   learning rate 0 on everything but the PBR groups): only d_g_base / d_g_rough are written, from d_dL_dfeatures and the
+ *   shading op's two gradients; the geometry inputs and outputs are not touched and may be NULL.
  * r3dg_stage2_loss: image-space terms of calculate_loss (neilf.py:212-318) and their gradients in one pass:
- *   sums[0] += sum |image - gt|, sums[1] += sum |srgb(pbr_img) - gt|, sums[2] += sum (normal_render - pseudo_normal)^2
+ *   sums[0] += sum |image - gt|, sums[1] += sum |srgb(pbr_img) - gt|, sums[2] += sum m^2 (normal_render - pseudo_normal)^2
+ *   (m = d_image_mask [HW], the view's object mask of neilf.py:258-264; NULL = all ones)
  *   with feat = feature / max(opacity,1e-5) * (n_contrib > 0), pbr_img = feat[2:5]*opacity + (1-opacity)*bg;
  *   dL_dimage[3,HW], dL_dopacity[HW], dL_dfeature[16,HW] are fully written for weights w_* per element;
  *   d_extra_dL_dimage / d_extra_dL_dsrgb (may be NULL): gradients of further terms w.r.t. the image and the sRGB PBR
@@ -330,10 +344,29 @@ int r3dg_stage2_activate_backward(void* stream, int P, const float* d_xyz, const
                                   float* d_g_normal, float* d_g_base, float* d_g_rough);
 int r3dg_stage2_loss(void* stream, int width, int height, const float* d_image, const float* d_opacity,
                      const float* d_feature, const float* d_pseudo_normal, const int32_t* d_n_contrib,
-                     const float* d_gt, const float* d_background, float w_l1, float w_pbr, float w_normal,
-                     const float* d_extra_dL_dimage, const float* d_extra_dL_dsrgb, float* d_dL_dimage,
+                     const float* d_gt, const float* d_background, const float* d_image_mask, float w_l1, float w_pbr,
+                     float w_normal, const float* d_extra_dL_dimage, const float* d_extra_dL_dsrgb, float* d_dL_dimage,
                      float* d_dL_dopacity, float* d_dL_dfeature, float* d_sums,
                      int sparse_feature_gradients);
+/* The three edge-aware smoothness terms of the Synthetic4Relight / DTU objective (neilf.py:275-292 with
+ * script/run_syn4.sh:34-36 / run_dtu.sh:36-38; first_order_edge_aware_loss, utils/loss_utils.py:104-105 = kornia 0.6.12's
+ * Sobel / 8 with replicate padding):
+ *   w_base_color sum_{c,d} |G_d (base_color_c m)| exp(-|G_d gt_c|) + w_roughness sum_{c,d} |G_d (roughness m)| exp(-|G_d gt_c|)
+ *   + w_light sum_{c,d} |G_d (diffuse_c m)| exp(-|G_d normal_c|)          (the guide of the light term is the RENDERED normal
+ *   and carries a gradient), with X = feature_X / max(opacity, 1e-5) * (n_contrib > 0) on the S=16 training feature image and
+ *   m = d_image_mask [HW] (NULL = all ones).  The weights carry the 1 / (3 H W) of the reference's means; a zero weight
+ *   switches its term off.
+ * _forward: sums3[0..2] (R3DG_SUM_SLOTS floats each) += the three UNWEIGHTED sums; d_scratch [30 * H * W] floats receives
+ *   what _backward needs.  _backward (after r3dg_stage2_loss, same images): d_dL_dopacity is ADDED to; of d_dL_dfeature
+ *   [16,HW] the maps 8..10 / 11 / 12..14 of the active terms are written, and with the light term the normal maps 5..7 are
+ *   written (accumulate_normal == 0) or added to (!= 0: r3dg_stage2_loss wrote them, w_normal != 0). */
+int r3dg_stage2_smooth_forward(void* stream, int width, int height, const float* d_opacity, const float* d_feature,
+                               const int32_t* d_n_contrib, const float* d_gt, const float* d_image_mask,
+                               float w_base_color, float w_roughness, float w_light, float* d_scratch, float* d_sums3);
+int r3dg_stage2_smooth_backward(void* stream, int width, int height, const float* d_opacity, const float* d_feature,
+                                const int32_t* d_n_contrib, const float* d_image_mask, const float* d_scratch,
+                                float w_base_color, float w_roughness, float w_light, int accumulate_normal,
+                                float* d_dL_dopacity, float* d_dL_dfeature);
 /* sRGB-mapped PBR image [3,HW] exactly as r3dg_stage2_loss forms it (input of the SSIM term on the PBR image). */
 int r3dg_stage2_pbr_srgb(void* stream, int width, int height, const float* d_opacity, const float* d_feature,
                          const int32_t* d_n_contrib, const float* d_background, float* d_srgb);

@@ -45,6 +45,7 @@ _SIGNATURES = {
     "r3dg_rasterize_backward_split": (_i, [_p, _p, _i, _i, _i, _i, _i, _p, _i, _i, _p, _p, _p, _p, _p, _f, _p, _p, _p, _p,
                                            _p, _f, _f, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p,
                                            _p, _p, _i, _i, _i, C.POINTER(_i)]),
+    "r3dg_rasterize_backward_features": (_i, [_p, _i, _i, _i, _i, _i, _p, _p, _p, _p, _p, _i, C.POINTER(_i), _i]),
     "r3dg_mark_visible": (_i, [_p, _i, _p, _p, _p, _p]),
     "r3dg_bvh_trace_count": (_i, [_p, C.c_int64, _p, _p, _p, _p, _p, _p]),
     "r3dg_bvh_trace_fill": (_i, [_p, C.c_int64] + [_p] * 11),
@@ -76,7 +77,9 @@ _SIGNATURES = {
     "r3dg_stage2_pack_features": (_i, [_p, _i] + [_p] * 8),
     "r3dg_stage2_unpack_gradients": (_i, [_p, _i, _p, _p, _f, _p, _p, _p]),
     "r3dg_stage2_activate_backward": (_i, [_p, _i] + [_p] * 24),
-    "r3dg_stage2_loss": (_i, [_p, _i, _i] + [_p] * 7 + [_f, _f, _f] + [_p] * 6 + [_i]),
+    "r3dg_stage2_loss": (_i, [_p, _i, _i] + [_p] * 8 + [_f, _f, _f] + [_p] * 6 + [_i]),
+    "r3dg_stage2_smooth_forward": (_i, [_p, _i, _i] + [_p] * 5 + [_f, _f, _f, _p, _p]),
+    "r3dg_stage2_smooth_backward": (_i, [_p, _i, _i] + [_p] * 5 + [_f, _f, _f, _i, _p, _p]),
     "r3dg_stage2_pbr_srgb": (_i, [_p, _i, _i] + [_p] * 5),
     "r3dg_ssim_forward": (_i, [_p, _i, _i, _i, _p, _p, _p, _p]),
     "r3dg_ssim_backward": (_i, [_p, _i, _i, _i, _p, _p, _p, _f, _p]),

@@ -42,6 +42,10 @@ void launch_render_backward(hipStream_t s, int W, int H, int S, int n_active, co
                             const uint32_t* n_contrib, const float* dL_dpix, const float* dL_dpix_o,
                             const float* dL_dpix_d, const float* dL_dpix_f, float* dL_dmean2D, float* dL_dconic,
                             float* dL_dopacity, float* dL_dcolor, float* dL_dfeature, int bg_geom);
+void launch_render_backward_features(hipStream_t s, int W, int H, int S, int n_active, const int* active,
+                                     const uint32_t* tile_order, const uint32_t* ranges, const uint32_t* point_list,
+                                     const float* splat, const float* final_Ts, const uint32_t* n_contrib,
+                                     const float* dL_dpix_f, float* dL_dfeature);
 void launch_preprocess_backward(hipStream_t s, int P, int D, int M, const float* means, const int* radii,
                                 const float* shs, const uint8_t* clamped, const float* scales, const float* rotations,
                                 float scale_modifier, const float* cov3Ds, const float* vm, const float* proj, float h_x,
@@ -99,9 +103,16 @@ void launch_s2_activate_backward(hipStream_t s, int P, const float* xyz, const f
                                  float* g_scaling, float* g_rotation, float* g_opacity, float* g_normal, float* g_base,
                                  float* g_rough);
 void launch_s2_loss(hipStream_t s, int HW, const float* image, const float* opacity, const float* feature,
-                    const float* pseudo_normal, const int* n_contrib, const float* gt, const float* bg, float w_l1,
-                    float w_pbr, float w_normal, const float* extra_dimage, const float* extra_dsrgb, float* dL_dimage,
-                    float* dL_dopacity, float* dL_dfeature, float* sums, int sparse);
+                    const float* pseudo_normal, const int* n_contrib, const float* gt, const float* bg,
+                    const float* image_mask, float w_l1, float w_pbr, float w_normal, const float* extra_dimage,
+                    const float* extra_dsrgb, float* dL_dimage, float* dL_dopacity, float* dL_dfeature, float* sums,
+                    int sparse);
+void launch_s2_smooth_forward(hipStream_t s, int W, int H, const float* opacity, const float* feature, const int* n_contrib,
+                              const float* gt, const float* image_mask, float w_base, float w_rough, float w_light,
+                              float* scratch, float* sums3);
+void launch_s2_smooth_backward(hipStream_t s, int W, int H, const float* opacity, const float* feature, const int* n_contrib,
+                               const float* image_mask, const float* scratch, int has_base, int has_rough, int has_light,
+                               int accumulate_normal, float* dL_dopacity, float* dL_dfeature);
 void launch_s2_pbr_srgb(hipStream_t s, int HW, const float* opacity, const float* feature, const int* n_contrib,
                         const float* bg, float* srgb);
 void launch_ssim_forward(hipStream_t s, int W, int H, int C, int n_images, const float* const* x, const float* y,
@@ -994,6 +1005,43 @@ int r3dg_rasterize_backward_split(void* stream_, void* geometry_stream_, int P, 
     });
 }
 
+int r3dg_rasterize_backward_features(void* stream_, int P, int S, int R, int width, int height, const void* geom_buffer,
+                                     const void* binning_buffer, const void* img_buffer, const float* dL_dpix_f,
+                                     float* dL_dfeature, int n_active_features, const int* active_features, int debug_)
+{
+    if (P < 0 || width <= 0 || height <= 0 || R < 0) return invalid("rasterize_backward_features: bad P/R/width/height");
+    if (S <= 0 || S > R3DG_MAX_S_BWD) return invalid("rasterize_backward_features: feature channels S must be in [1,36]");
+    if (P == 0 || R == 0) return R3DG_OK;
+    if (!geom_buffer || !img_buffer || !binning_buffer || !dL_dpix_f || !dL_dfeature)
+        return invalid("rasterize_backward_features: null buffer");
+    if (n_active_features >= 0) {
+        if (n_active_features > S || !active_features) return invalid("rasterize_backward_features: bad active feature list");
+        for (int i = 0; i < n_active_features; i++)
+            if (active_features[i] < 0 || active_features[i] >= S)
+                return invalid("rasterize_backward_features: active feature index out of range");
+    }
+    return guarded([&]() -> int {
+        hipStream_t stream = (hipStream_t)stream_;
+        const int gx = (width + R3DG_TILE_X - 1) / R3DG_TILE_X, gy = (height + R3DG_TILE_Y - 1) / R3DG_TILE_Y;
+        const size_t T = (size_t)gx * gy, N = (size_t)width * height;
+        GeometryLayout G = GeometryLayout::make((size_t)P);
+        ImageLayout I = ImageLayout::make(N, T);
+        BinningLayout B = BinningLayout::make((size_t)R);
+        const char* gbuf = (const char*)geom_buffer;
+        const char* ibuf = (const char*)img_buffer;
+        const char* bbuf = (const char*)binning_buffer;
+        StageTimer t_rb(stream, ST_RENDER_BWD);
+        launch_render_backward_features(stream, width, height, S, n_active_features, active_features,
+                                        g_tile_order ? (const uint32_t*)(ibuf + I.tile_order) : nullptr,
+                                        (const uint32_t*)(ibuf + I.ranges), (const uint32_t*)(bbuf + B.vals),
+                                        (const float*)(gbuf + G.splat), (const float*)(ibuf + I.final_T),
+                                        (const uint32_t*)(ibuf + I.n_contrib), dL_dpix_f, dL_dfeature);
+        check_launch(stream, debug_ != 0, "render_backward_features");
+        t_rb.stop();
+        return R3DG_OK;
+    });
+}
+
 int r3dg_mark_visible(void* stream_, int P, const float* means3D, const float* viewmatrix, const float* projmatrix,
                       uint8_t* present)
 {
@@ -1262,10 +1310,12 @@ int r3dg_stage2_activate_backward(void* stream_, int P, const float* xyz, const 
 {
     if (P < 0) return invalid("stage2_activate_backward: bad P");
     if (P == 0) return R3DG_OK;
-    if (!xyz || !scaling_raw || !rotation_raw || !opacity_raw || !normal_raw || !base_raw || !rough_raw || !viewmatrix ||
-        !campos || !dL_dfeatures || !dL_dbase_shade || !dL_drough_shade || !dL_dviewdirs || !dL_dscales || !dL_drot ||
-        !dL_dopacity || !dL_dmeans3D || !g_xyz || !g_scaling || !g_rotation || !g_opacity || !g_normal || !g_base ||
-        !g_rough)
+    if (!base_raw || !rough_raw || !dL_dfeatures || !dL_dbase_shade || !dL_drough_shade || !g_base || !g_rough)
+        return invalid("stage2_activate_backward: null buffer");
+    // g_xyz == NULL: frozen geometry -- only g_base / g_rough are produced and the geometry inputs are not read
+    if (g_xyz != nullptr &&
+        (!xyz || !scaling_raw || !rotation_raw || !opacity_raw || !normal_raw || !viewmatrix || !campos || !dL_dviewdirs ||
+         !dL_dscales || !dL_drot || !dL_dopacity || !dL_dmeans3D || !g_scaling || !g_rotation || !g_opacity || !g_normal))
         return invalid("stage2_activate_backward: null buffer");
     return guarded([&]() -> int {
         StageTimer t((hipStream_t)stream_, ST_S2_ACTIVATE_BWD);
@@ -1279,9 +1329,9 @@ int r3dg_stage2_activate_backward(void* stream_, int P, const float* xyz, const 
 
 int r3dg_stage2_loss(void* stream_, int width, int height, const float* image, const float* opacity,
                      const float* feature, const float* pseudo_normal, const int32_t* n_contrib, const float* gt,
-                     const float* bg, float w_l1, float w_pbr, float w_normal, const float* extra_dimage,
-                     const float* extra_dsrgb, float* dL_dimage, float* dL_dopacity, float* dL_dfeature, float* sums,
-                     int sparse_feature_gradients)
+                     const float* bg, const float* image_mask, float w_l1, float w_pbr, float w_normal,
+                     const float* extra_dimage, const float* extra_dsrgb, float* dL_dimage, float* dL_dopacity,
+                     float* dL_dfeature, float* sums, int sparse_feature_gradients)
 {
     if (width < 0 || height < 0) return invalid("stage2_loss: bad image size");
     if ((long long)width * height == 0) return R3DG_OK;
@@ -1291,8 +1341,41 @@ int r3dg_stage2_loss(void* stream_, int width, int height, const float* image, c
     return guarded([&]() -> int {
         StageTimer t((hipStream_t)stream_, ST_S2_LOSS);
         launch_s2_loss((hipStream_t)stream_, width * height, image, opacity, feature, pseudo_normal, n_contrib, gt, bg,
-                       w_l1, w_pbr, w_normal, extra_dimage, extra_dsrgb, dL_dimage, dL_dopacity, dL_dfeature, sums,
+                       image_mask, w_l1, w_pbr, w_normal, extra_dimage, extra_dsrgb, dL_dimage, dL_dopacity, dL_dfeature, sums,
                        sparse_feature_gradients);
+        return R3DG_OK;
+    });
+}
+
+int r3dg_stage2_smooth_forward(void* stream_, int width, int height, const float* opacity, const float* feature,
+                               const int32_t* n_contrib, const float* gt, const float* image_mask, float w_base_color,
+                               float w_roughness, float w_light, float* scratch, float* sums3)
+{
+    if (width < 0 || height < 0) return invalid("stage2_smooth_forward: bad image size");
+    if ((long long)width * height == 0) return R3DG_OK;
+    if (!opacity || !feature || !n_contrib || !gt || !scratch || !sums3) return invalid("stage2_smooth_forward: null buffer");
+    return guarded([&]() -> int {
+        StageTimer t((hipStream_t)stream_, ST_S2_LOSS);
+        launch_s2_smooth_forward((hipStream_t)stream_, width, height, opacity, feature, n_contrib, gt, image_mask,
+                                 w_base_color, w_roughness, w_light, scratch, sums3);
+        return R3DG_OK;
+    });
+}
+
+int r3dg_stage2_smooth_backward(void* stream_, int width, int height, const float* opacity, const float* feature,
+                                const int32_t* n_contrib, const float* image_mask, const float* scratch, float w_base_color,
+                                float w_roughness, float w_light, int accumulate_normal, float* dL_dopacity,
+                                float* dL_dfeature)
+{
+    if (width < 0 || height < 0) return invalid("stage2_smooth_backward: bad image size");
+    if ((long long)width * height == 0) return R3DG_OK;
+    if (!opacity || !feature || !n_contrib || !scratch || !dL_dopacity || !dL_dfeature)
+        return invalid("stage2_smooth_backward: null buffer");
+    return guarded([&]() -> int {
+        StageTimer t((hipStream_t)stream_, ST_S2_LOSS);
+        launch_s2_smooth_backward((hipStream_t)stream_, width, height, opacity, feature, n_contrib, image_mask, scratch,
+                                  w_base_color != 0.f, w_roughness != 0.f, w_light != 0.f, accumulate_normal, dL_dopacity,
+                                  dL_dfeature);
         return R3DG_OK;
     });
 }

@@ -340,6 +340,172 @@ render_backward_kernel(const uint2* __restrict__ ranges, const uint32_t* __restr
 }
 
 extern int g_cull;
+extern int g_bwd_wave8x8;
+static inline int g_bwd_wave8x8_for_features() { return g_bwd_wave8x8; }
+
+// ---- feature gradients only (frozen geometry) -------------------------------------------------------------------------
+// The Synthetic4Relight / DTU stage-2 schedule (script/run_syn4.sh:27-33, run_dtu.sh) freezes positions, covariances, opacities
+// and SH colour (learning rate 0) and trains only what reaches the image through the FEATURE maps (base colour, roughness,
+// incident light).  Of the reference's backward (backward.cu:401-614) only
+//     dL_dfeature[g, c] += alpha * T * dL_dpixel_f[c]                                                   (backward.cu:566)
+// is then ever used: no accum_rec recursion, no dL_dalpha, no mean / conic / opacity / colour atomics, no payload staging
+// (the feature VALUES do not enter) and no per-Gaussian geometry backward behind it.  Same tiling, back-to-front walk, cull
+// masks and transposing wave reduction as render_backward_kernel; alpha and T are evaluated exactly as there.
+template <int SPAD, int U>
+__global__ void __launch_bounds__(256)
+render_backward_features_kernel(const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list, int S,
+                                ChannelList chan_list, int W, int H, int tiles_x, int num_tiles, int xcd_chunk, int wave8,
+                                int cull, const uint32_t* __restrict__ tile_order, const float4* __restrict__ splat,
+                                const float* __restrict__ final_Ts, const uint32_t* __restrict__ n_contrib,
+                                const float* __restrict__ dL_dpixels_f, float* __restrict__ dL_dfeature)
+{
+    constexpr int NT = 256, NW = 4;
+    constexpr int NVP = next_pow2(SPAD);
+    const int SA = chan_list.n;
+    int tile;
+    if (tile_order != nullptr) {
+        if ((int)blockIdx.x >= num_tiles) return;
+        tile = (int)tile_order[blockIdx.x];
+    } else {
+        tile = (int)(blockIdx.x & 7u) * xcd_chunk + (int)(blockIdx.x >> 3);
+        if (tile >= num_tiles) return;
+    }
+    const int tile_x = tile % tiles_x, tile_y = tile / tiles_x;
+    __shared__ float4 s_geo0[NT];
+    __shared__ float4 s_geo1[NT];
+    __shared__ uint32_t s_max[NW];
+    __shared__ unsigned long long s_cand[NW][NW];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    int lx = lane & 15, ly = wave * 4 + (lane >> 4);
+    if (wave8) {
+        lx = (lane & 7) + 8 * (wave & 1);
+        ly = (lane >> 3) + 8 * (wave >> 1);
+    }
+    const int px = tile_x * R3DG_TILE_X + lx, py = tile_y * R3DG_TILE_Y + ly;
+    const float pxf = (float)px, pyf = (float)py;
+    const size_t HW = (size_t)H * W;
+    const uint2 range = ranges[tile];
+    const int chan = transposed_channel<NVP>(lane);
+    float* dst_base = nullptr;
+    if (transposed_owner<NVP>(lane) && chan < SA) dst_base = dL_dfeature + chan_list.c[chan];
+    const bool inside = px < W && py < H;
+    const size_t pix = (size_t)py * W + px;
+    float T = inside ? final_Ts[pix] : 0.f;
+    const uint32_t lastc = inside ? n_contrib[pix] : 0u;
+    float dl[SPAD];
+#pragma unroll
+    for (int ch = 0; ch < SPAD; ch++) dl[ch] = (inside && ch < SA) ? dL_dpixels_f[(size_t)chan_list.c[ch] * HW + pix] : 0.f;
+    uint32_t my_max = lastc;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) my_max = max(my_max, (uint32_t)__shfl_xor((int)my_max, o, 64));
+    if (lane == 0) s_max[wave] = my_max;
+    __syncthreads();
+    uint32_t m = 0;
+#pragma unroll
+    for (int w = 0; w < NW; w++) m = max(m, s_max[w]);
+    const int n = (int)m;
+    for (int base = 0; base < n; base += NT) {
+        __syncthreads();
+        float4 my_geo = make_float4(0.f, 0.f, 0.f, 0.f);
+        float2 my_co = make_float2(0.f, 0.f);
+        if (base + tid < n) {
+            const uint32_t g = point_list[range.x + (uint32_t)(n - 1 - (base + tid))];
+            const float4* rec = splat + 4 * (size_t)g;
+            const float4 r0 = rec[0], r1 = rec[1];
+            s_geo0[tid] = my_geo = r0;
+            s_geo1[tid] = make_float4(r1.x, r1.y, r1.z, __uint_as_float(g));
+            my_co = make_float2(r1.x, r1.y);
+        }
+#pragma unroll
+        for (int w = 0; w < NW; w++) {
+            int bx = 0, by = w * 4, bw = 15, bh = 3;
+            if (wave8) { bx = 8 * (w & 1); by = 8 * (w >> 1); bw = 7; bh = 7; }
+            const float x0 = (float)(tile_x * R3DG_TILE_X + bx), y0 = (float)(tile_y * R3DG_TILE_Y + by);
+            bool c = base + tid < n && (uint32_t)(n - 1 - (base + tid)) < s_max[w];
+            if (cull) c = c && splat_may_touch(my_geo.x, my_geo.y, my_geo.z, my_geo.w, my_co.x, my_co.y, x0,
+                                               x0 + (float)bw, y0, y0 + (float)bh);
+            const unsigned long long mk = __ballot(c);
+            if (lane == 0) s_cand[w][wave] = mk;
+        }
+        __syncthreads();
+        for (int grp = 0; grp < NW; grp++) {
+            const unsigned long long mv = s_cand[wave][grp];
+            unsigned long long cm = ((unsigned long long)__builtin_amdgcn_readfirstlane((int)(mv >> 32)) << 32) |
+                                    (unsigned int)__builtin_amdgcn_readfirstlane((int)(unsigned int)mv);
+            while (cm != 0ull) {
+                float4 g1[U];
+                float alpha[U];
+                bool any_hit = false;
+#pragma unroll
+                for (int u = 0; u < U; u++) {
+                    const bool valid = cm != 0ull;
+                    const int jj = valid ? grp * 64 + __builtin_ctzll(cm) : 0;
+                    if (valid) cm &= cm - 1ull;
+                    const float4 g0 = s_geo0[jj];
+                    g1[u] = s_geo1[jj];
+                    const uint32_t front = (uint32_t)(n - 1 - (base + jj));
+                    const float dx = g0.x - pxf, dy = g0.y - pyf;
+                    const float power = -0.5f * (g0.z * dx * dx + g1[u].x * dy * dy) - g0.w * dx * dy;
+                    float a = fminf(0.99f, g1[u].y * fast_exp_b(power));
+                    if (!(front < lastc) || power > 0.0f || a < 1.0f / 255.0f || !valid) a = 0.f;
+                    alpha[u] = a;
+                    any_hit = any_hit || (a != 0.f);
+                }
+                if (__ballot(any_hit) == 0ull) continue;
+#pragma unroll
+                for (int u = 0; u < U; u++) {
+                    if (__ballot(alpha[u] != 0.f) == 0ull) continue;
+                    // back to front: T before this Gaussian = T after it / (1 - alpha)   (backward.cu:533)
+                    T = T * __builtin_amdgcn_rcpf(1.f - alpha[u]);
+                    const float wgt = alpha[u] * T;
+                    float vr[NVP];
+#pragma unroll
+                    for (int k = 0; k < NVP; k++) vr[k] = k < SPAD ? wgt * dl[k] : 0.f;
+                    const float total = transpose_reduce<NVP, true>(vr);
+                    if (dst_base != nullptr) atomicAdd(dst_base + (size_t)__float_as_uint(g1[u].w) * (size_t)S, total);
+                }
+            }
+        }
+    }
+}
+
+void launch_render_backward_features(hipStream_t s, int W, int H, int S, int n_active, const int* active,
+                                     const uint32_t* tile_order, const uint32_t* ranges, const uint32_t* point_list,
+                                     const float* splat, const float* final_Ts, const uint32_t* n_contrib,
+                                     const float* dL_dpix_f, float* dL_dfeature)
+{
+    const int tiles_x = (W + R3DG_TILE_X - 1) / R3DG_TILE_X, tiles_y = (H + R3DG_TILE_Y - 1) / R3DG_TILE_Y;
+    const int T = tiles_x * tiles_y, chunk = (T + 7) / 8;
+    ChannelList cl;
+    if (n_active < 0 || active == nullptr) {
+        cl.n = S;
+        cl.identity = 1;
+        for (int i = 0; i < R3DG_MAX_S_BWD; i++) cl.c[i] = i < S ? i : 0;
+    } else {
+        cl.n = n_active;
+        cl.identity = 0;
+        for (int i = 0; i < R3DG_MAX_S_BWD; i++) cl.c[i] = i < n_active ? active[i] : 0;
+    }
+    if (cl.n == 0) return;
+#define R3DG_BF(SP_)                                                                                                   \
+    render_backward_features_kernel<SP_, 2><<<chunk * 8, 256, 0, s>>>(                                                 \
+        (const uint2*)ranges, point_list, S, cl, W, H, tiles_x, T, chunk, g_bwd_wave8x8_for_features(), g_cull, tile_order, \
+        (const float4*)splat, final_Ts, n_contrib, dL_dpix_f, dL_dfeature)
+    switch ((cl.n + 3) / 4) {
+        case 1: R3DG_BF(4); break;
+        case 2: R3DG_BF(8); break;
+        case 3: R3DG_BF(12); break;
+        case 4: R3DG_BF(16); break;
+        case 5: R3DG_BF(20); break;
+        case 6: R3DG_BF(24); break;
+        case 7: R3DG_BF(28); break;
+        case 8: R3DG_BF(32); break;
+        default: R3DG_BF(36); break;
+    }
+#undef R3DG_BF
+}
+
+extern int g_cull;
 int g_bwd_wave8x8 = 1;  // measured: 8x8 blocks -6% (fewer waves touched per Gaussian); the forward prefers strips
 int g_bwd_ppl = 1;
 int g_bwd_dpp = 1;      // kept for the self-test entry point; the tile kernel always uses the DPP/permlane reduction

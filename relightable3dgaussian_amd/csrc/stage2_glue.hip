@@ -179,6 +179,19 @@ s2_activate_backward_kernel(int P, const float* __restrict__ xyz, const float* _
     const size_t i3 = 3 * (size_t)i, i4 = 4 * (size_t)i;
     const float4* gf = reinterpret_cast<const float4*>(dL_dfeatures + 16 * (size_t)i);
     const float4 f0 = gf[0], f1 = gf[1], f2 = gf[2];
+    // base_color = 0.03 + 0.77 sigmoid(raw), roughness = 0.09 + 0.9 sigmoid(raw): feature row + shading op
+    {
+        const float gfeat[3] = {f2.x, f2.y, f2.z};
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+            const float s = sigmoidf_(base_raw[i3 + c]);
+            g_base[i3 + c] = (gfeat[c] + dL_dbase_shade[i3 + c]) * 0.77f * s * (1.f - s);
+        }
+        const float s = sigmoidf_(rough_raw[i]);
+        g_rough[i] = (f2.w + dL_drough_shade[i]) * 0.9f * s * (1.f - s);
+    }
+    // frozen geometry (g_xyz == NULL, wave-uniform): base colour and roughness are the only per-Gaussian groups that train
+    if (g_xyz == nullptr) return;
 
     // scales = exp(raw)
 #pragma unroll
@@ -210,17 +223,6 @@ s2_activate_backward_kernel(int P, const float* __restrict__ xyz, const float* _
         float o[3];
         normalize3_backward(v, 1e-3f, g, o);
         g_normal[i3] = o[0]; g_normal[i3 + 1] = o[1]; g_normal[i3 + 2] = o[2];
-    }
-    // base_color = 0.03 + 0.77 sigmoid(raw), roughness = 0.09 + 0.9 sigmoid(raw): feature row + shading op
-    {
-        const float gfeat[3] = {f2.x, f2.y, f2.z};
-#pragma unroll
-        for (int c = 0; c < 3; c++) {
-            const float s = sigmoidf_(base_raw[i3 + c]);
-            g_base[i3 + c] = (gfeat[c] + dL_dbase_shade[i3 + c]) * 0.77f * s * (1.f - s);
-        }
-        const float s = sigmoidf_(rough_raw[i]);
-        g_rough[i] = (f2.w + dL_drough_shade[i]) * 0.9f * s * (1.f - s);
     }
     // xyz: rasterizer + depth / depth^2 feature columns + view direction
     {
@@ -264,7 +266,8 @@ __global__ void __launch_bounds__(256)
 s2_loss_kernel(int HW, const float* __restrict__ image, const float* __restrict__ opacity,
                const float* __restrict__ feature, const float* __restrict__ pseudo_normal,
                const int* __restrict__ n_contrib, const float* __restrict__ gt, const float* __restrict__ bg,
-               float w_l1, float w_pbr, float w_normal, const float* __restrict__ extra_dimage,
+               const float* __restrict__ image_mask, float w_l1, float w_pbr, float w_normal,
+               const float* __restrict__ extra_dimage,
                const float* __restrict__ extra_dsrgb, float* __restrict__ dL_dimage,
                float* __restrict__ dL_dopacity, float* __restrict__ dL_dfeature, float* __restrict__ sums)
 {
@@ -305,10 +308,12 @@ s2_loss_kernel(int HW, const float* __restrict__ image, const float* __restrict_
             g_op += gx * (r - bg[c] + op * F * dscale_dop);
             // normal consistency: mse(r_normal, pseudo_normal)
             if (!SPARSE || w_normal != 0.f) {
+                // mse(normal * m, pseudo_normal * m), m = the view's object mask (neilf.py:258-264; NULL = all ones)
+                const float mk = image_mask ? image_mask[i] : 1.f;
                 const float Fn = feature[(size_t)(5 + c) * HW + i];
-                const float dn = Fn * scale - pseudo_normal[(size_t)c * HW + i];
+                const float dn = (Fn * scale - pseudo_normal[(size_t)c * HW + i]) * mk;
                 s_n += dn * dn;
-                const float gn = 2.f * w_normal * dn;
+                const float gn = 2.f * w_normal * dn * mk;
                 dL_dfeature[(size_t)(5 + c) * HW + i] = gn * scale;
                 g_op += gn * Fn * dscale_dop;
             }
@@ -534,6 +539,188 @@ s1_loss_kernel(int W, int H, const float* __restrict__ image, const float* __res
     }
 }
 
+// ---- stage-2 edge-aware smoothness terms (Synthetic4Relight / DTU objective) ------------------------------------------
+// neilf.py:275-292 with the flags of script/run_syn4.sh:34-36 / run_dtu.sh:36-38:
+//   lambda_base_color_smooth * first_order_edge_aware_loss(base_color * m, gt)
+// + lambda_roughness_smooth  * first_order_edge_aware_loss(roughness  * m, gt)        (1 channel against 3: broadcast)
+// + lambda_light_smooth      * first_order_edge_aware_loss(diffuse    * m, rendered_normal)   (the guide is NOT detached)
+// first_order_edge_aware_loss(data, img) = mean_{c,y,x} sum_d |G_d data_c| exp(-|G_d img_c|), G = Sobel / 8 with replicate
+// padding (see the stage-1 comment above); X = feature_X / max(opacity, 1e-5) * (n_contrib > 0), m = the view's object mask.
+// Three passes: (0) s2_smooth_maps_kernel materialises the ten divided (and masked) maps the stencils read; (A)
+// s2_smooth_edge_kernel evaluates the stencils, adds the three sums and writes, per pixel, the 20 values the adjoint needs
+// (weights folded in); (B) s2_smooth_backward_kernel gathers the adjoint of the replicate-padded stencil (no atomics) and
+// applies the chain rule of the division into the feature-gradient maps and the opacity gradient r3dg_stage2_loss left.
+// rend layout [10][HW]: base_color*m 0..2 | roughness*m 3 | diffuse*m 4..6 | normal 7..9
+// edge layout [20][HW]: base 2c+d (0..5) | roughness d (6,7) | diffuse 8+2c+d | normal guide 14+2c+d      (d: 0 = x, 1 = y)
+__global__ void __launch_bounds__(256)
+s2_smooth_maps_kernel(int HW, const float* __restrict__ opacity, const float* __restrict__ feature,
+                      const int* __restrict__ n_contrib, const float* __restrict__ image_mask, float* __restrict__ rend)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= HW) return;
+    const float scale = n_contrib[i] > 0 ? 1.f / fmaxf(opacity[i], 1e-5f) : 0.f;
+    const float m = image_mask ? image_mask[i] : 1.f;
+#pragma unroll
+    for (int c = 0; c < 7; c++) rend[(size_t)c * HW + i] = feature[(size_t)(8 + c) * HW + i] * scale * m;
+#pragma unroll
+    for (int c = 0; c < 3; c++) rend[(size_t)(7 + c) * HW + i] = feature[(size_t)(5 + c) * HW + i] * scale;
+}
+
+__device__ __forceinline__ void sobel3(const float* __restrict__ map, int W, const int (&ys)[3], const int (&xs)[3],
+                                       float& gx, float& gy)
+{
+    float v[3][3];
+#pragma unroll
+    for (int a = 0; a < 3; a++)
+#pragma unroll
+        for (int b = 0; b < 3; b++) v[a][b] = map[(size_t)ys[a] * W + xs[b]];
+    gx = ((v[0][2] - v[0][0]) + 2.f * (v[1][2] - v[1][0]) + (v[2][2] - v[2][0])) * 0.125f;
+    gy = ((v[2][0] - v[0][0]) + 2.f * (v[2][1] - v[0][1]) + (v[2][2] - v[0][2])) * 0.125f;
+}
+
+__global__ void __launch_bounds__(256)
+s2_smooth_edge_kernel(int W, int H, const float* __restrict__ rend, const float* __restrict__ gt, float w_base,
+                      float w_rough, float w_light, float* __restrict__ edge, float* __restrict__ sums3)
+{
+    __shared__ float s_part[4];
+    const size_t HW = (size_t)W * H;
+    float a_base = 0.f, a_rough = 0.f, a_light = 0.f;
+    for (size_t i = blockIdx.x * 256 + threadIdx.x; i < HW; i += (size_t)gridDim.x * 256) {
+        const int y = (int)(i / W), x = (int)(i % W);
+        const int ys[3] = {y > 0 ? y - 1 : 0, y, y < H - 1 ? y + 1 : H - 1};
+        const int xs[3] = {x > 0 ? x - 1 : 0, x, x < W - 1 ? x + 1 : W - 1};
+        float ex[3], ey[3];                       // exp(-|G_d gt_c|)
+        if (w_base != 0.f || w_rough != 0.f) {
+#pragma unroll
+            for (int c = 0; c < 3; c++) {
+                float gx, gy;
+                sobel3(gt + (size_t)c * HW, W, ys, xs, gx, gy);
+                ex[c] = __expf(-fabsf(gx));
+                ey[c] = __expf(-fabsf(gy));
+            }
+        }
+        if (w_base != 0.f) {
+#pragma unroll
+            for (int c = 0; c < 3; c++) {
+                float dx, dy;
+                sobel3(rend + (size_t)c * HW, W, ys, xs, dx, dy);
+                a_base += fabsf(dx) * ex[c] + fabsf(dy) * ey[c];
+                edge[(size_t)(2 * c) * HW + i] = w_base * signf_(dx) * ex[c];
+                edge[(size_t)(2 * c + 1) * HW + i] = w_base * signf_(dy) * ey[c];
+            }
+        }
+        if (w_rough != 0.f) {
+            float dx, dy;
+            sobel3(rend + (size_t)3 * HW, W, ys, xs, dx, dy);
+            const float sx = ex[0] + ex[1] + ex[2], sy = ey[0] + ey[1] + ey[2];
+            a_rough += fabsf(dx) * sx + fabsf(dy) * sy;
+            edge[(size_t)6 * HW + i] = w_rough * signf_(dx) * sx;
+            edge[(size_t)7 * HW + i] = w_rough * signf_(dy) * sy;
+        }
+        if (w_light != 0.f) {
+#pragma unroll
+            for (int c = 0; c < 3; c++) {
+                float dx, dy, nx, ny;
+                sobel3(rend + (size_t)(4 + c) * HW, W, ys, xs, dx, dy);
+                sobel3(rend + (size_t)(7 + c) * HW, W, ys, xs, nx, ny);
+                const float gx = __expf(-fabsf(nx)), gy = __expf(-fabsf(ny));
+                a_light += fabsf(dx) * gx + fabsf(dy) * gy;
+                edge[(size_t)(8 + 2 * c) * HW + i] = w_light * signf_(dx) * gx;
+                edge[(size_t)(9 + 2 * c) * HW + i] = w_light * signf_(dy) * gy;
+                // d/d(G_d n_c) of |G_d dl_c| exp(-|G_d n_c|)
+                edge[(size_t)(14 + 2 * c) * HW + i] = -w_light * fabsf(dx) * gx * signf_(nx);
+                edge[(size_t)(15 + 2 * c) * HW + i] = -w_light * fabsf(dy) * gy * signf_(ny);
+            }
+        }
+    }
+    const float t0 = block_sum_256(a_base, s_part);
+    __syncthreads();
+    const float t1 = block_sum_256(a_rough, s_part);
+    __syncthreads();
+    const float t2 = block_sum_256(a_light, s_part);
+    if (threadIdx.x == 0) {
+        atomicAdd(sum_slot(sums3 + 0 * R3DG_SUM_SLOTS), t0);
+        atomicAdd(sum_slot(sums3 + 1 * R3DG_SUM_SLOTS), t1);
+        atomicAdd(sum_slot(sums3 + 2 * R3DG_SUM_SLOTS), t2);
+    }
+}
+
+__global__ void __launch_bounds__(256)
+s2_smooth_backward_kernel(int W, int H, const float* __restrict__ opacity, const float* __restrict__ feature,
+                          const int* __restrict__ n_contrib, const float* __restrict__ image_mask,
+                          const float* __restrict__ edge, int has_base, int has_rough, int has_light,
+                          int accumulate_normal, float* __restrict__ dL_dopacity, float* __restrict__ dL_dfeature)
+{
+    const size_t HW = (size_t)W * H;
+    for (size_t i = blockIdx.x * 256 + threadIdx.x; i < HW; i += (size_t)gridDim.x * 256) {
+        const int y = (int)(i / W), x = (int)(i % W);
+        // adjoint of the replicate-padded stencils: d[k] = dL / d rend_k at this pixel
+        float d[10];
+#pragma unroll
+        for (int k = 0; k < 10; k++) d[k] = 0.f;
+#pragma unroll
+        for (int a = -1; a <= 1; a++) {
+            const int qy = y + a;
+            if (qy < 0 || qy >= H) continue;
+            const float sy = s1_adj1(qy, y, H, 1.f, 2.f, 1.f), dy = s1_adj1(qy, y, H, -1.f, 0.f, 1.f);
+#pragma unroll
+            for (int b = -1; b <= 1; b++) {
+                const int qx = x + b;
+                if (qx < 0 || qx >= W) continue;
+                const float sx = s1_adj1(qx, x, W, 1.f, 2.f, 1.f), dx = s1_adj1(qx, x, W, -1.f, 0.f, 1.f);
+                const float wx = sy * dx * 0.125f, wy = dy * sx * 0.125f;
+                const size_t q = (size_t)qy * W + qx;
+                if (has_base) {
+#pragma unroll
+                    for (int c = 0; c < 3; c++)
+                        d[c] += wx * edge[(size_t)(2 * c) * HW + q] + wy * edge[(size_t)(2 * c + 1) * HW + q];
+                }
+                if (has_rough) d[3] += wx * edge[(size_t)6 * HW + q] + wy * edge[(size_t)7 * HW + q];
+                if (has_light) {
+#pragma unroll
+                    for (int c = 0; c < 3; c++) {
+                        d[4 + c] += wx * edge[(size_t)(8 + 2 * c) * HW + q] + wy * edge[(size_t)(9 + 2 * c) * HW + q];
+                        d[7 + c] += wx * edge[(size_t)(14 + 2 * c) * HW + q] + wy * edge[(size_t)(15 + 2 * c) * HW + q];
+                    }
+                }
+            }
+        }
+        const float op = opacity[i];
+        const bool mask = n_contrib[i] > 0;
+        const float opc = fmaxf(op, 1e-5f);
+        const float scale = mask ? 1.f / opc : 0.f;
+        const float dscale_dop = (mask && op >= 1e-5f) ? -1.f / (opc * opc) : 0.f;
+        const float m = image_mask ? image_mask[i] : 1.f;
+        float g_op = 0.f;
+        if (has_base) {
+#pragma unroll
+            for (int c = 0; c < 3; c++) {
+                const float g = d[c] * m;
+                dL_dfeature[(size_t)(8 + c) * HW + i] = g * scale;
+                g_op += g * feature[(size_t)(8 + c) * HW + i] * dscale_dop;
+            }
+        }
+        if (has_rough) {
+            const float g = d[3] * m;
+            dL_dfeature[(size_t)11 * HW + i] = g * scale;
+            g_op += g * feature[(size_t)11 * HW + i] * dscale_dop;
+        }
+        if (has_light) {
+#pragma unroll
+            for (int c = 0; c < 3; c++) {
+                const float g = d[4 + c] * m;
+                dL_dfeature[(size_t)(12 + c) * HW + i] = g * scale;
+                g_op += g * feature[(size_t)(12 + c) * HW + i] * dscale_dop;
+                const float gn = d[7 + c];
+                const size_t o = (size_t)(5 + c) * HW + i;
+                dL_dfeature[o] = (accumulate_normal ? dL_dfeature[o] : 0.f) + gn * scale;
+                g_op += gn * feature[o] * dscale_dop;
+            }
+        }
+        dL_dopacity[i] += g_op;
+    }
+}
+
 __global__ void __launch_bounds__(256)
 s1_activate_backward_kernel(int P, const float* __restrict__ xyz, const float* __restrict__ scaling_raw,
                             const float* __restrict__ rotation_raw, const float* __restrict__ opacity_raw,
@@ -698,18 +885,19 @@ void launch_s2_pbr_srgb(hipStream_t s, int HW, const float* opacity, const float
 constexpr int LOSS_BLOCKS = 768;
 
 void launch_s2_loss(hipStream_t s, int HW, const float* image, const float* opacity, const float* feature,
-                    const float* pseudo_normal, const int* n_contrib, const float* gt, const float* bg, float w_l1,
-                    float w_pbr, float w_normal, const float* extra_dimage, const float* extra_dsrgb, float* dL_dimage,
-                    float* dL_dopacity, float* dL_dfeature, float* sums, int sparse)
+                    const float* pseudo_normal, const int* n_contrib, const float* gt, const float* bg,
+                    const float* image_mask, float w_l1, float w_pbr, float w_normal, const float* extra_dimage,
+                    const float* extra_dsrgb, float* dL_dimage, float* dL_dopacity, float* dL_dfeature, float* sums,
+                    int sparse)
 {
     if (sparse)
-        s2_loss_kernel<true><<<min((HW + 255) / 256, LOSS_BLOCKS), 256, 0, s>>>(HW, image, opacity, feature, pseudo_normal, n_contrib,
-                                                                      gt, bg, w_l1, w_pbr, w_normal, extra_dimage,
-                                                                      extra_dsrgb, dL_dimage, dL_dopacity, dL_dfeature, sums);
+        s2_loss_kernel<true><<<min((HW + 255) / 256, LOSS_BLOCKS), 256, 0, s>>>(
+            HW, image, opacity, feature, pseudo_normal, n_contrib, gt, bg, image_mask, w_l1, w_pbr, w_normal, extra_dimage,
+            extra_dsrgb, dL_dimage, dL_dopacity, dL_dfeature, sums);
     else
-        s2_loss_kernel<false><<<min((HW + 255) / 256, LOSS_BLOCKS), 256, 0, s>>>(HW, image, opacity, feature, pseudo_normal, n_contrib,
-                                                                       gt, bg, w_l1, w_pbr, w_normal, extra_dimage,
-                                                                       extra_dsrgb, dL_dimage, dL_dopacity, dL_dfeature, sums);
+        s2_loss_kernel<false><<<min((HW + 255) / 256, LOSS_BLOCKS), 256, 0, s>>>(
+            HW, image, opacity, feature, pseudo_normal, n_contrib, gt, bg, image_mask, w_l1, w_pbr, w_normal, extra_dimage,
+            extra_dsrgb, dL_dimage, dL_dopacity, dL_dfeature, sums);
     check_launch(s, false, "s2_loss_kernel");
 }
 
@@ -719,6 +907,31 @@ void launch_s2_env_backward(hipStream_t s, int He, int We, const float* raw, con
     s2_env_backward_kernel<<<(He * We * 3 + 255) / 256, 256, 0, s>>>(He, We, raw, env, dL_denv, w_tv, g_raw, tv_sum,
                                                                     consume);
     check_launch(s, false, "s2_env_backward_kernel");
+}
+
+void launch_s2_smooth_forward(hipStream_t s, int W, int H, const float* opacity, const float* feature, const int* n_contrib,
+                              const float* gt, const float* image_mask, float w_base, float w_rough, float w_light,
+                              float* scratch, float* sums3)
+{
+    const long long HW = (long long)W * H;
+    float* rend = scratch;
+    float* edge = scratch + 10 * HW;
+    s2_smooth_maps_kernel<<<(int)((HW + 255) / 256), 256, 0, s>>>((int)HW, opacity, feature, n_contrib, image_mask, rend);
+    check_launch(s, false, "s2_smooth_maps_kernel");
+    s2_smooth_edge_kernel<<<(int)min((HW + 255) / 256, (long long)2048), 256, 0, s>>>(W, H, rend, gt, w_base, w_rough, w_light,
+                                                                                 edge, sums3);
+    check_launch(s, false, "s2_smooth_edge_kernel");
+}
+
+void launch_s2_smooth_backward(hipStream_t s, int W, int H, const float* opacity, const float* feature, const int* n_contrib,
+                               const float* image_mask, const float* scratch, int has_base, int has_rough, int has_light,
+                               int accumulate_normal, float* dL_dopacity, float* dL_dfeature)
+{
+    const long long HW = (long long)W * H;
+    s2_smooth_backward_kernel<<<(int)min((HW + 255) / 256, (long long)2048), 256, 0, s>>>(
+        W, H, opacity, feature, n_contrib, image_mask, scratch + 10 * HW, has_base, has_rough, has_light, accumulate_normal,
+        dL_dopacity, dL_dfeature);
+    check_launch(s, false, "s2_smooth_backward_kernel");
 }
 
 void launch_s1_pack(hipStream_t s, int P, const float* xyz, const float* viewmatrix, const float* normal, float* features)

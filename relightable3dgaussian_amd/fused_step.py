@@ -25,7 +25,7 @@ import torch
 import torch.nn.functional as F
 
 from . import _lib, rasterizer_ops, shading_ops
-from .train_step import LAMBDA_DSSIM, update_visibility
+from .train_step import FROZEN_GEOMETRY_GROUPS, LAMBDA_DSSIM, STAGE2_WEIGHTS, update_visibility
 
 SUM_SLOTS = 32           # R3DG_SUM_SLOTS (include/r3dg_hip.h): floats per scalar accumulator of the glue kernels
 
@@ -203,7 +203,14 @@ class FusedStage2Step(_BoundedForward):
         WITHOUT the host read-back: binning state sized for twice the largest count seen, projection + instance ordering
         queued at once beside the shading forward.  A view that needs more is dropped on the device (its Adam launches
         read the flag and update nothing); `poll_overflow()` -- called by loss() -- then doubles the capacity and counts
-        it in `dropped_steps`."""
+        it in `dropped_steps`.
+        `loss_weights`: overrides of train_step.STAGE2_WEIGHTS (the lambdas of script/run_nerf.sh:20-39);
+        train_step.STAGE2_WEIGHTS_SYN4 adds the three edge-aware smoothness terms of script/run_syn4.sh / run_dtu.sh.
+        FROZEN GEOMETRY: a group whose learning rate(s) are 0 gets no Adam launch; when ALL of xyz, normal, scaling,
+        rotation, opacity and shs are frozen (run_syn4.sh:27-33, run_dtu.sh:29-35) the iteration also skips what only they
+        would consume -- the alpha-gradient half of the tile backward and the whole per-Gaussian geometry backward
+        (r3dg_rasterize_backward_features instead), the geometry half of the activation chain rule, their all-reduce
+        buckets -- and their entries of `grads` stay zero."""
         dev = params.xyz.device
         self.dev = dev
         d = lambda t: t.detach().clone().contiguous()
@@ -220,10 +227,19 @@ class FusedStage2Step(_BoundedForward):
             raise RuntimeError("FusedStage2Step: colour and incident-light SH must hold the same number of coefficients")
         # script/run_nerf.sh:20-39 (stage 2): lambda_pbr 1, lambda_light 0.01, lambda_env_smooth 0.01; the command does not
         # pass --lambda_normal_render_depth, so that term is off (arguments/__init__.py:115) -- opt in with
-        # loss_weights={"normal": 0.01}
-        self.w = dict(l1=1.0, pbr=1.0, normal=0.0, light=0.01, env_smooth=0.01)
+        # loss_weights={"normal": 0.01}; the edge-aware smoothness terms are 0 there and 1 / 0.5 / 1 in run_syn4.sh / run_dtu.sh
+        self.w = dict(STAGE2_WEIGHTS)
         if loss_weights:
+            unknown = set(loss_weights) - set(self.w)
+            if unknown:
+                raise RuntimeError("FusedStage2Step: unknown loss weights %s" % sorted(unknown))
             self.w.update(loss_weights)
+        lrs = dict(lrs or {})
+        rate = lambda k: float(lrs.get(k, lr))
+        tail = lambda k: float(lrs.get(k + "_rest", rate(k) * lr_rest_scale))
+        # groups that do not train (both rates 0 for the two SH tensors)
+        self.frozen = {k for k in PARAM_NAMES if rate(k) == 0.0 and (k not in ("shs", "incidents") or tail(k) == 0.0)}
+        self.frozen_geometry = all(k in self.frozen for k in FROZEN_GEOMETRY_GROUPS)
         # activations / intermediates (persistent, overwritten every step)
         f = dict(dtype=torch.float32, device=dev)
         self.a_scales, self.a_rot = torch.empty(P, 3, **f), torch.empty(P, 4, **f)
@@ -232,8 +248,10 @@ class FusedStage2Step(_BoundedForward):
         self.a_viewdirs = torch.empty(P, 3, **f)
         self.shade_out = torch.empty(P, shading_ops.NOUT, **f)
         self.features = torch.empty(P, 16, **f)
-        # unweighted sums: l1, pbr l1, normal mse, light l1, TV(env), SSIM(image), SSIM(pbr)
-        self.sums = torch.zeros(7, SUM_SLOTS, **f)        # R3DG_SUM_SLOTS floats per quantity (include/r3dg_hip.h)
+        # unweighted sums: l1, pbr l1, normal mse, light l1, TV(env), SSIM(image), SSIM(pbr), and the three edge-aware
+        # smoothness sums (base colour, roughness, diffuse light)
+        self.sums = torch.zeros(10, SUM_SLOTS, **f)       # R3DG_SUM_SLOTS floats per quantity (include/r3dg_hip.h)
+        self._smooth_scratch = None
         self.d_pbr, self.d_diffuse = torch.empty(P, 3, **f), torch.empty(P, 3, **f)
         self._absmax = torch.zeros((P + 255) // 256, **f)       # block maxima of |d_pbr|, |d_diffuse| (unpack kernel)
         self._d_env = None
@@ -243,8 +261,13 @@ class FusedStage2Step(_BoundedForward):
                      shs=3 * self.M * P, incidents=3 * self.M * P, env=self.env.numel(), flag=4)
         # `flag`: the bounded forward's overflow flag rides at the end of bucket A, so that under data parallelism the
         # first all-reduce tells every rank whether ANY rank dropped its view (sum > 0) before the first Adam launch
-        order = ("shs", "flag", "xyz", "normal", "scaling", "rotation", "opacity", "base_color", "roughness", "env",
-                 "incidents")
+        if self.frozen_geometry:
+            # nothing of the frozen groups is reduced or updated: [flag, base_color, roughness, env | incidents | the rest]
+            order = ("flag", "base_color", "roughness", "env", "incidents", "shs", "xyz", "normal", "scaling", "rotation",
+                     "opacity")
+        else:
+            order = ("shs", "flag", "xyz", "normal", "scaling", "rotation", "opacity", "base_color", "roughness", "env",
+                     "incidents")
         pad4 = lambda n: (n + 3) // 4 * 4
         self.grad_flat = torch.zeros(sum(pad4(sizes[k]) for k in order), **f)
         self.grads, o, start = {}, 0, {}
@@ -262,9 +285,14 @@ class FusedStage2Step(_BoundedForward):
         # B = incident-light grads, final after the shading backward -- reduced LAST and only waited for right before
         # the NEXT iteration's shading forward, so it travels under that iteration's projection + binning
         # (the env texture's gradient rides in bucket C: one collective instead of a separate 6 KB all-reduce)
-        self._bucket_a = self.grad_flat[:start["xyz"]]
-        self._bucket_c = self.grad_flat[start["xyz"]:start["incidents"]]
-        self._bucket_b = self.grad_flat[start["incidents"]:]
+        if self.frozen_geometry:
+            self._bucket_a = None                                               # (no SH colour gradient to send early)
+            self._bucket_c = self.grad_flat[:start["incidents"]]                # flag + base colour, roughness, env texture
+            self._bucket_b = self.grad_flat[start["incidents"]:start["shs"]]
+        else:
+            self._bucket_a = self.grad_flat[:start["xyz"]]
+            self._bucket_c = self.grad_flat[start["xyz"]:start["incidents"]]
+            self._bucket_b = self.grad_flat[start["incidents"]:]
         self._pending_b = None
         self._zero_depth_grad = None
         # instance ordering of the rasterizer runs here, under the shading forward (register-light, latency-bound kernels
@@ -283,9 +311,6 @@ class FusedStage2Step(_BoundedForward):
             self.visibility, self.incident_dirs, self.incident_areas, self.tracer = update_visibility(
                 self.xyz, self.a_scales, self.a_rot, self.a_opacity, self.a_normal, sample_num, group=process_group)
         self._taps, self._taps_key = None, None
-        lrs = dict(lrs or {})
-        rate = lambda k: float(lrs.get(k, lr))
-        tail = lambda k: float(lrs.get(k + "_rest", rate(k) * lr_rest_scale))
         self.opt = FusedAdam([
             dict(param=self.xyz, lr=rate("xyz")), dict(param=self.normal, lr=rate("normal")),
             dict(param=self.scaling, lr=rate("scaling")), dict(param=self.rotation, lr=rate("rotation")),
@@ -296,6 +321,9 @@ class FusedStage2Step(_BoundedForward):
             dict(param=self.env, lr=rate("env"))])
         self._opt_order = ("xyz", "normal", "scaling", "rotation", "opacity", "shs", "base_color", "roughness",
                            "incidents", "env")
+        # Adam launches of an iteration: the groups of each gradient bucket that train
+        live = lambda idx: tuple(i for i in idx if self._opt_order[i] not in self.frozen)
+        self._groups_a, self._groups_c, self._groups_b = live((5,)), live((0, 1, 2, 3, 4, 6, 7, 9)), live((8,))
         self.last_outs = None
 
     # views with the reference's parameter names (gaussian_model.py:199-203, 232)
@@ -347,8 +375,9 @@ class FusedStage2Step(_BoundedForward):
             self._uniform_area = lo if lo == hi else None
         return self._taps
 
-    def forward_backward(self, cam, bg, gt, early_adam=False):
+    def forward_backward(self, cam, bg, gt, early_adam=False, image_mask=None):
         """One forward + loss + backward; gradients land in self.grads.  Returns the rasterizer's 10 public outputs.
+        `image_mask` [1,H,W]: the view's object mask (Camera.image_mask; None = all ones) of the normal and smoothness terms.
         `early_adam` (single-GPU whole iterations only, see __call__): the SH colour coefficients, whose gradient is final
         after the rasterizer backward, get their Adam update on a side stream UNDER the shading backward (an HBM-bound,
         register-light kernel next to a VALU-bound one); optimizer_step() then updates the remaining groups."""
@@ -416,26 +445,52 @@ class FusedStage2Step(_BoundedForward):
                                                 part_i.data_ptr(), part_p.data_ptr(), self.sums[5].data_ptr(),
                                                 self.sums[6].data_ptr()), "ssim_forward")
             _lib.check(L.r3dg_ssim_backward_pair(stream(), W, H, 3, image.data_ptr(), srgb.data_ptr(), gt_c.data_ptr(),
-                                                 part_i.data_ptr(), part_p.data_ptr(), -lam / (3.0 * N),
+                                                 part_i.data_ptr(), part_p.data_ptr(), -self.w["l1"] * lam / (3.0 * N),
                                                  -self.w["pbr"] * lam / (3.0 * N), gs_i.data_ptr(), gs_p.data_ptr()),
                        "ssim_backward")
+            mask_c = None if image_mask is None else image_mask.contiguous()
             _lib.check(L.r3dg_stage2_loss(
                 stream(), W, H, image.data_ptr(), opacity.data_ptr(), feature.data_ptr(), pseudo_normal.data_ptr(),
-                n_contrib.data_ptr(), gt_c.data_ptr(), bg_c.data_ptr(), self.w["l1"] * (1.0 - lam) / (3.0 * N),
-                self.w["pbr"] * (1.0 - lam) / (3.0 * N), self.w["normal"] / (3.0 * N), gs_i.data_ptr(), gs_p.data_ptr(),
+                n_contrib.data_ptr(), gt_c.data_ptr(), bg_c.data_ptr(), _lib.ptr(mask_c),
+                self.w["l1"] * (1.0 - lam) / (3.0 * N), self.w["pbr"] * (1.0 - lam) / (3.0 * N),
+                self.w["normal"] / (3.0 * N), gs_i.data_ptr(), gs_p.data_ptr(),
                 g[0:3].data_ptr(), g[3:4].data_ptr(), g[4:20].data_ptr(), self.sums.data_ptr(), 1), "stage2_loss")
-            bw = rasterizer_ops.rasterize_gaussians_backward(
-                bg, self.xyz, self.features, radii, empty, self.a_scales, self.a_rot, 1.0, empty, vm,
-                cam.full_proj_transform, cam.tanfovx, cam.tanfovy, g[0:3], g[3:4], self._zero_depth_grad, g[4:20], self.shs, 3,
-                campos, geom, R, binning, img, True, False, dL_dsh_out=self.grads["shs"], geometry_stream=self._side,
-                # r3dg_stage2_loss only reads the pbr maps and -- when that term is on -- the normal maps
-                active_features=(2, 3, 4, 5, 6, 7) if self.w["normal"] != 0.0 else (2, 3, 4))
-            dL_dmeans2D, _dcol, dL_dopacity, dL_dmeans3D, dL_dfeatures, _dcov, _dsh, dL_dscales, dL_drot = bw
+            # r3dg_stage2_loss only writes the pbr maps and -- when that term is on -- the normal maps; the smoothness terms
+            # add base colour / roughness / diffuse light (and, through the light term's guide, the normal maps)
+            active = [2, 3, 4] + ([5, 6, 7] if self.w["normal"] != 0.0 else [])
+            w_bc, w_r, w_ls = (self.w[k] / (3.0 * N) for k in ("base_color_smooth", "roughness_smooth", "light_smooth"))
+            if w_bc != 0.0 or w_r != 0.0 or w_ls != 0.0:
+                if self._smooth_scratch is None or self._smooth_scratch.numel() != 30 * N:
+                    self._smooth_scratch = torch.empty(30 * N, dtype=torch.float32, device=dev)
+                sc = self._smooth_scratch
+                _lib.check(L.r3dg_stage2_smooth_forward(
+                    stream(), W, H, opacity.data_ptr(), feature.data_ptr(), n_contrib.data_ptr(), gt_c.data_ptr(),
+                    _lib.ptr(mask_c), w_bc, w_r, w_ls, sc.data_ptr(), self.sums[7].data_ptr()), "stage2_smooth_forward")
+                _lib.check(L.r3dg_stage2_smooth_backward(
+                    stream(), W, H, opacity.data_ptr(), feature.data_ptr(), n_contrib.data_ptr(), _lib.ptr(mask_c),
+                    sc.data_ptr(), w_bc, w_r, w_ls, 1 if self.w["normal"] != 0.0 else 0, g[3:4].data_ptr(),
+                    g[4:20].data_ptr()), "stage2_smooth_backward")
+                active += ([8, 9, 10] if w_bc != 0.0 else []) + ([11] if w_r != 0.0 else [])
+                if w_ls != 0.0:
+                    active += [12, 13, 14] + ([5, 6, 7] if self.w["normal"] == 0.0 else [])
+            if self.frozen_geometry:
+                # nothing but the feature gradients is consumed (the normal maps' gradient belongs to the frozen normal)
+                active = [a for a in active if a not in (5, 6, 7)]
+                dL_dfeatures = rasterizer_ops.rasterize_gaussians_backward_features(
+                    P, 16, H, W, g[4:20], geom, R, binning, img, active_features=sorted(active))
+                dL_dmeans2D = None
+            else:
+                bw = rasterizer_ops.rasterize_gaussians_backward(
+                    bg, self.xyz, self.features, radii, empty, self.a_scales, self.a_rot, 1.0, empty, vm,
+                    cam.full_proj_transform, cam.tanfovx, cam.tanfovy, g[0:3], g[3:4], self._zero_depth_grad, g[4:20],
+                    self.shs, 3, campos, geom, R, binning, img, True, False, dL_dsh_out=self.grads["shs"],
+                    geometry_stream=self._side, active_features=sorted(active))
+                dL_dmeans2D, _dcol, dL_dopacity, dL_dmeans3D, dL_dfeatures, _dcov, _dsh, dL_dscales, dL_drot = bw
             handle_a = None
-            if self._side is None:
+            if self._side is None and self._bucket_a is not None:
                 handle_a = self._allreduce_async(self._bucket_a)     # travels under the shading backward
             self._early = False
-            if early_adam and not self.dp:
+            if early_adam and not self.dp and self._groups_a:
                 # Adam of the SH group on a side stream, behind the geometry backward that produces its gradient
                 side = self._side
                 if side is None:
@@ -445,11 +500,11 @@ class FusedStage2Step(_BoundedForward):
                     side.wait_stream(torch.cuda.current_stream())
                 self.opt.begin_step()
                 with torch.cuda.stream(side):
-                    self.opt.step_groups(self._GROUPS_A, [self.grads[k] for k in self._opt_order],
+                    self.opt.step_groups(self._groups_a, [self.grads[k] for k in self._opt_order],
                                          skip_flag=self._skip_cur)
                 self._early_stream = side
                 self._early = True
-            elif early_adam and handle_a is not None:
+            elif early_adam and handle_a is not None and self._groups_a:
                 # data parallel: the same update on the side stream, behind bucket A's all-reduce -- whenever that lands
                 # while the shading backward is still running, the SH group's Adam runs under it too (measured with a
                 # one-rank RCCL group: 510 -> see DESIGN.md section 5).  The reduced overflow flag is snapshotted there,
@@ -461,7 +516,7 @@ class FusedStage2Step(_BoundedForward):
                 with torch.cuda.stream(side):
                     handle_a.wait()                       # the SIDE stream waits for RCCL's stream
                     self._skip_cur = self._snapshot_flag()
-                    self.opt.step_groups(self._GROUPS_A, [self.grads[k] for k in self._opt_order], 1.0 / self.world,
+                    self.opt.step_groups(self._groups_a, [self.grads[k] for k in self._opt_order], 1.0 / self.world,
                                          skip_flag=self._skip_cur)
                 self._early_stream = side
                 self._early = True
@@ -477,17 +532,24 @@ class FusedStage2Step(_BoundedForward):
                 self.incident_dirs, self.incident_areas, self.d_pbr, self.d_diffuse,
                 out_incidents=self.grads["incidents"], taps=taps, out_env=self._d_env, block_absmax=self._absmax)
             gr = self.grads
-            if self._side is not None:          # join the geometry backward
+            if self._side is not None and not self.frozen_geometry:          # join the geometry backward
                 torch.cuda.current_stream().wait_stream(self._side)
                 handle_a = self._allreduce_async(self._bucket_a)
-            _lib.check(L.r3dg_stage2_activate_backward(
-                stream(), P, self.xyz.data_ptr(), self.scaling.data_ptr(), self.rotation.data_ptr(),
-                self.opacity.data_ptr(), self.normal.data_ptr(), self.base_color.data_ptr(), self.roughness.data_ptr(),
-                vm.data_ptr(), campos.data_ptr(), dL_dfeatures.data_ptr(), d_base.data_ptr(), d_rough.data_ptr(),
-                d_view.data_ptr(), dL_dscales.data_ptr(), dL_drot.data_ptr(), dL_dopacity.data_ptr(),
-                dL_dmeans3D.data_ptr(), gr["xyz"].data_ptr(), gr["scaling"].data_ptr(), gr["rotation"].data_ptr(),
-                gr["opacity"].data_ptr(), gr["normal"].data_ptr(), gr["base_color"].data_ptr(),
-                gr["roughness"].data_ptr()), "stage2_activate_backward")
+            if self.frozen_geometry:
+                _lib.check(L.r3dg_stage2_activate_backward(
+                    stream(), P, None, None, None, None, None, self.base_color.data_ptr(), self.roughness.data_ptr(), None,
+                    None, dL_dfeatures.data_ptr(), d_base.data_ptr(), d_rough.data_ptr(), None, None, None, None, None,
+                    None, None, None, None, None, gr["base_color"].data_ptr(), gr["roughness"].data_ptr()),
+                    "stage2_activate_backward")
+            else:
+                _lib.check(L.r3dg_stage2_activate_backward(
+                    stream(), P, self.xyz.data_ptr(), self.scaling.data_ptr(), self.rotation.data_ptr(),
+                    self.opacity.data_ptr(), self.normal.data_ptr(), self.base_color.data_ptr(), self.roughness.data_ptr(),
+                    vm.data_ptr(), campos.data_ptr(), dL_dfeatures.data_ptr(), d_base.data_ptr(), d_rough.data_ptr(),
+                    d_view.data_ptr(), dL_dscales.data_ptr(), dL_drot.data_ptr(), dL_dopacity.data_ptr(),
+                    dL_dmeans3D.data_ptr(), gr["xyz"].data_ptr(), gr["scaling"].data_ptr(), gr["rotation"].data_ptr(),
+                    gr["opacity"].data_ptr(), gr["normal"].data_ptr(), gr["base_color"].data_ptr(),
+                    gr["roughness"].data_ptr()), "stage2_activate_backward")
             # environment texture: softplus chain rule + total-variation term
             _lib.check(L.r3dg_stage2_env_backward(
                 stream(), He, We, self.env.data_ptr(), env_c.data_ptr(), d_env.data_ptr(), self.w["env_smooth"],
@@ -517,22 +579,25 @@ class FusedStage2Step(_BoundedForward):
         lam = LAMBDA_DSSIM
         w = torch.tensor([self.w["l1"] * (1 - lam) / (3.0 * N), self.w["pbr"] * (1 - lam) / (3.0 * N),
                           self.w["normal"] / (3.0 * N), self.w["light"] / (3.0 * P), self.w["env_smooth"],
-                          -lam / (3.0 * N), -self.w["pbr"] * lam / (3.0 * N)], device=self.dev)
-        return (self.sums.sum(1) * w).sum() + lam * (1.0 + self.w["pbr"])
-
-    _GROUPS_A = (5,)                       # indices into self.opt.groups: shs
-    _GROUPS_C = (0, 1, 2, 3, 4, 6, 7, 9)   # xyz normal scaling rotation opacity base_color roughness env
-    _GROUPS_B = (8,)                       # incidents
+                          -self.w["l1"] * lam / (3.0 * N), -self.w["pbr"] * lam / (3.0 * N),
+                          self.w["base_color_smooth"] / (3.0 * N), self.w["roughness_smooth"] / (3.0 * N),
+                          self.w["light_smooth"] / (3.0 * N)], device=self.dev)
+        return (self.sums.sum(1) * w).sum() + lam * (self.w["l1"] + self.w["pbr"])
 
     def optimizer_step(self):
+        """Adam on every group that trains (groups with learning rate 0 get no launch): _groups_a = shs, _groups_c = the small
+        per-Gaussian groups + env, _groups_b = incidents -- indices into self.opt.groups, one tuple per gradient bucket."""
         grads = [self.grads[k] for k in self._opt_order]
         if not self.dp:
             if self._early:              # the SH group was updated under the shading backward (forward_backward)
                 torch.cuda.current_stream().wait_stream(self._early_stream)
-                self.opt.step_groups(self._GROUPS_C + self._GROUPS_B, grads, skip_flag=self._skip_cur)
                 self._early = False
+                todo = self._groups_c + self._groups_b
             else:
-                self.opt.step(grads, skip_flag=self._skip_cur)
+                self.opt.begin_step()
+                todo = self._groups_a + self._groups_c + self._groups_b
+            if todo:                     # ONE launch for every remaining group
+                self.opt.step_groups(todo, grads, skip_flag=self._skip_cur)
             return
         # data parallel: update each bucket when its (sum) all-reduce has landed; 1/world is applied inside the kernel
         scale = 1.0 / self.world
@@ -540,13 +605,18 @@ class FusedStage2Step(_BoundedForward):
         if self._early:                  # bucket A was waited for and applied on the side stream (forward_backward)
             torch.cuda.current_stream().wait_stream(self._early_stream)
             self._early = False
+            handle_c.wait()
         else:
             self.opt.begin_step()
-            handle_a.wait()
+            # the overflow flag rides in the first bucket that is reduced: A, or C when the geometry is frozen
+            (handle_a if handle_a is not None else handle_c).wait()
             self._skip_cur = self._snapshot_flag()      # > 0 on every rank when any rank dropped its view
-            self.opt.step_groups(self._GROUPS_A, grads, scale, skip_flag=self._skip_cur)
-        handle_c.wait()
-        self.opt.step_groups(self._GROUPS_C, grads, scale, skip_flag=self._skip_cur)
+            if handle_a is not None:
+                if self._groups_a:
+                    self.opt.step_groups(self._groups_a, grads, scale, skip_flag=self._skip_cur)
+                handle_c.wait()
+        if self._groups_c:
+            self.opt.step_groups(self._groups_c, grads, scale, skip_flag=self._skip_cur)
         self._pending_b = (handle_b, grads, scale, self._skip_cur)
 
     def flush(self):
@@ -555,10 +625,11 @@ class FusedStage2Step(_BoundedForward):
             handle_b, grads, scale, skip = self._pending_b
             self._pending_b = None
             handle_b.wait()
-            self.opt.step_groups(self._GROUPS_B, grads, scale, skip_flag=skip)
+            if self._groups_b:
+                self.opt.step_groups(self._groups_b, grads, scale, skip_flag=skip)
 
-    def __call__(self, cam, bg, gt):
-        outs = self.forward_backward(cam, bg, gt, early_adam=True)
+    def __call__(self, cam, bg, gt, image_mask=None):
+        outs = self.forward_backward(cam, bg, gt, early_adam=True, image_mask=image_mask)
         self.optimizer_step()
         return outs
 

@@ -248,6 +248,31 @@ def rasterize_gaussians_backward(background, means3D, features, radii, colors, s
             dL_drotations)
 
 
+def rasterize_gaussians_backward_features(P, S, image_height, image_width, dL_dout_feature, geomBuffer, R, binningBuffer,
+                                          imageBuffer, debug=False, active_features=None):
+    """The backward for FROZEN geometry (not in the reference; r3dg_rasterize_backward_features): only dL_dfeatures [P,S]
+    from dL_dout_feature [S,H,W] -- what is left of rasterize_gaussians_backward when positions, covariances, opacities and
+    SH colour have learning rate 0 (script/run_syn4.sh:27-33, run_dtu.sh).  Same state buffers and `active_features`
+    contract; equals that call's dL_dfeatures up to the order of the float atomics."""
+    L = _lib.lib()
+    dev = dL_dout_feature.device
+    dL_dfeatures = torch.zeros((P, S), dtype=torch.float32, device=dev)
+    if P != 0 and int(R) != 0:
+        gF = _f32c(dL_dout_feature)
+        if active_features is None:
+            n_act, act = -1, None
+        else:
+            n_act = len(active_features)
+            act = (C.c_int * max(1, n_act))(*[int(a) for a in active_features])
+        with torch.cuda.device(dev):
+            st = L.r3dg_rasterize_backward_features(
+                _lib.current_stream(), int(P), int(S), int(R), int(image_width), int(image_height), _lib.ptr(geomBuffer),
+                _lib.ptr(binningBuffer), _lib.ptr(imageBuffer), gF.data_ptr(), dL_dfeatures.data_ptr(), n_act, act,
+                int(bool(debug)))
+        _lib.check(st, "rasterize_gaussians_backward_features")
+    return dL_dfeatures
+
+
 def mark_visible(means3D, viewmatrix, projmatrix):
     L = _lib.lib()
     P = means3D.size(0)

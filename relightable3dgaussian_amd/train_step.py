@@ -184,13 +184,41 @@ def stage1_loss(outs, gt, image_mask=None, weights=None, iteration=0):
     return loss
 
 
+# The stage-2 objectives of the three run scripts (lambda_* of neilf.py:212-318; lambda_dssim 0.2 and lambda_pbr 1 are the
+# defaults of arguments/__init__.py:125-126):
+#   script/run_nerf.sh:20-39   lambda_light 0.01, lambda_env_smooth 0.01, the three edge-aware smoothness terms 0
+#   script/run_syn4.sh:22-42   + lambda_base_color_smooth 1, lambda_roughness_smooth 0.5, lambda_light_smooth 1; every geometry
+#   script/run_dtu.sh:24-45      rate (position, normal, sh, opacity, scaling, rotation) 0: only base colour, roughness,
+#                                incident light and the environment texture train
+STAGE2_WEIGHTS = dict(l1=1.0, pbr=1.0, normal=0.0, light=0.01, env_smooth=0.01, base_color_smooth=0.0, roughness_smooth=0.0,
+                      light_smooth=0.0)
+STAGE2_WEIGHTS_SYN4 = dict(STAGE2_WEIGHTS, base_color_smooth=1.0, roughness_smooth=0.5, light_smooth=1.0)
+# parameter groups the frozen-geometry schedules leave at learning rate 0 (run_syn4.sh:27-33 / run_dtu.sh:29-35)
+FROZEN_GEOMETRY_GROUPS = ("xyz", "normal", "scaling", "rotation", "opacity", "shs")
+
+
+def stage2_smoothness(feat, gt, image_mask, w):
+    """The three edge-aware terms of calculate_loss (neilf.py:275-292) on the divided feature maps `feat` [16,H,W]:
+    base colour and roughness against the target image, diffuse light against the RENDERED NORMAL (not detached: the term
+    also pulls on the normal map).  `image_mask` [1,H,W] or None (all ones)."""
+    m = 1.0 if image_mask is None else image_mask
+    loss = feat.new_zeros(())
+    if w["base_color_smooth"] != 0.0:
+        loss = loss + w["base_color_smooth"] * first_order_edge_aware_loss(feat[8:11] * m, gt)
+    if w["roughness_smooth"] != 0.0:
+        loss = loss + w["roughness_smooth"] * first_order_edge_aware_loss(feat[11:12] * m, gt)
+    if w["light_smooth"] != 0.0:
+        loss = loss + w["light_smooth"] * first_order_edge_aware_loss(feat[12:15] * m, feat[5:8])
+    return loss
+
+
 class Stage2Step:
     def __init__(self, params, scene, device, sample_num, loss_weights=None):
         """`loss_weights`: as fused_step.FusedStage2Step (defaults = script/run_nerf.sh:20-39, i.e. the
-        normal_render_depth term off)."""
+        normal_render_depth term and the three smoothness terms off; STAGE2_WEIGHTS_SYN4 = run_syn4.sh / run_dtu.sh)."""
         self.p = params
         self.K = sample_num
-        self.w = dict(l1=1.0, pbr=1.0, normal=0.0, light=0.01, env_smooth=0.01)
+        self.w = dict(STAGE2_WEIGHTS)
         if loss_weights:
             self.w.update(loss_weights)
         with torch.no_grad():
@@ -222,7 +250,7 @@ class Stage2Step:
                                       rotations=p.get_rotation(), features=features)
         return outs, diffuse_light, env
 
-    def __call__(self, cam, bg, gt):
+    def __call__(self, cam, bg, gt, image_mask=None):
         outs, diffuse_light, env = self.render(cam, bg)
         num_rendered, n_contrib, image, opacity, depth, feature, pseudo_normal, xyz, weights, radii = outs
         mask = n_contrib > 0
@@ -232,8 +260,10 @@ class Stage2Step:
         pbr_srgb = rgb_to_srgb(pbr_img)
         w = self.w
         loss = w["l1"] * image_loss(image, gt) + w["pbr"] * image_loss(pbr_srgb, gt)      # L1/SSIM mix on both images
-        if w["normal"] != 0.0:
-            loss = loss + w["normal"] * F.mse_loss(r_normal, pseudo_normal.detach())                 # normal_render_depth
+        if w["normal"] != 0.0:                                                                         # normal_render_depth
+            m = 1.0 if image_mask is None else image_mask
+            loss = loss + w["normal"] * F.mse_loss(r_normal * m, pseudo_normal.detach() * m)
+        loss = loss + stage2_smoothness(feat, gt, image_mask, w)                                       # neilf.py:275-292
         mean_light = diffuse_light.mean(-1, keepdim=True).expand_as(diffuse_light)
         loss = loss + w["light"] * F.l1_loss(diffuse_light, mean_light)                              # lambda_light
         loss = loss + w["env_smooth"] * tv_loss(env.permute(2, 0, 1))                                # lambda_env_smooth

@@ -1,6 +1,6 @@
 """End-to-end golden fixtures from the REFERENCE'S OWN, UNMODIFIED Python (this container only).
 
-    python tests/golden/make_pipeline_golden.py     # needs /root/reference; writes tests/golden/pipeline_reference_stage{1,2}.npz
+    python tests/golden/make_pipeline_golden.py     # needs /root/reference; writes tests/golden/pipeline_reference_stage{1,2,2_syn4}.npz
 
 What runs, unmodified, from /root/reference:
     scene/gaussian_model.py      GaussianModel (activations, get_* properties, update_visibility :312-342)
@@ -217,6 +217,31 @@ def main():
     np.savez_compressed(os.path.join(HERE, "pipeline_reference_stage2.npz"), **out)
     print("stage 2: loss %.6f, num_rendered %d, visible fraction %.3f" % (loss.item(), results["num_rendered"],
                                                                           (pc._visibility_tracing > 0).float().mean()))
+
+    # ---------------- stage 2 with the Synthetic4Relight / DTU objective: script/run_syn4.sh:22-42, run_dtu.sh:24-45 ----------------
+    # Same inputs, camera, target, mask and visibility caches as the fixture above; only the lambdas differ
+    # (--lambda_base_color_smooth 1 --lambda_roughness_smooth 0.5 --lambda_light_smooth 1): the fixture stores the loss, its
+    # terms and the gradient of every parameter (the scripts freeze the geometry groups through learning rate 0; autograd
+    # still produces their gradients, which pin the smoothness terms' pull on opacity and on the rendered normal).
+    pc = to_model(GaussianModel, raw, True)
+    light = DirectLightMap(16)
+    light.env = torch.nn.Parameter(raw["env"].clone().requires_grad_(True))
+    opt, pipe = options(True, dict(lambda_light=0.01, lambda_env_smooth=0.01, lambda_base_color_smooth=1,
+                                   lambda_roughness_smooth=0.5, lambda_light_smooth=1))
+    pc.update_visibility(K)
+    assert torch.equal(pc._visibility_tracing, torch.from_numpy(out["visibility"]))
+    results = nf.render_view(rcam, pc, pipe, bg, is_training=True, dict_params={"env_light": light})
+    loss, tb = nf.calculate_loss(rcam, pc, results, opt, light)
+    loss.backward()
+    syn4 = grads_of(pc, names)
+    syn4.update(g_env=light.env.grad.numpy().copy(), loss=np.float64(loss.item()),
+                tb=np.array([tb[k] for k in ("l1", "ssim", "l1_pbr", "ssim_pbr", "loss_light", "loss_env_smooth",
+                                             "loss_base_color_smooth", "loss_roughness_smooth", "loss_light_smooth")],
+                            np.float64),
+                lambdas=np.array([1.0, 0.5, 1.0], np.float64))
+    np.savez_compressed(os.path.join(HERE, "pipeline_reference_stage2_syn4.npz"), **syn4)
+    print("stage 2 (run_syn4 objective): loss %.6f; smoothness terms %.5f %.5f %.5f" % (
+        loss.item(), tb["loss_base_color_smooth"], tb["loss_roughness_smooth"], tb["loss_light_smooth"]))
 
     # ---------------- stage 1: script/run_nerf.sh:7-14 ----------------
     raw, cam, gt, mask, bg = make_inputs(P, res, seed=43, stage2=False)

@@ -12,7 +12,7 @@ pytestmark = pytest.mark.gpu
 DEV = "cuda"
 
 
-def _setup(P=4000, res=160, K=8, seed=3, weights=None):
+def _setup(P=4000, res=160, K=8, seed=3, weights=None, lrs=None):
     from relightable3dgaussian_amd import synthetic as syn
     from relightable3dgaussian_amd.bench_core import GaussianParams, render_stage1
     from relightable3dgaussian_amd.train_step import Stage2Step
@@ -27,7 +27,7 @@ def _setup(P=4000, res=160, K=8, seed=3, weights=None):
         teacher.features_dc.add_(0.2 * torch.randn_like(teacher.features_dc))
         gt = render_stage1(teacher, cam, bg)[2].clone()
     ref = Stage2Step(params, scene, DEV, K, loss_weights=weights)
-    fused = FusedStage2Step(params, K, loss_weights=weights)
+    fused = FusedStage2Step(params, K, loss_weights=weights, lrs=lrs)
     # identical visibility caches (the BVH inputs differ in the last bits between the two activation paths)
     fused.visibility, fused.incident_dirs, fused.incident_areas = ref.visibility, ref.incident_dirs, ref.incident_areas
     return params, ref, fused, cam, bg, gt
@@ -35,12 +35,27 @@ def _setup(P=4000, res=160, K=8, seed=3, weights=None):
 
 # default = the objective of script/run_nerf.sh:20-39 (only the render and pbr maps carry a loss: 3 active feature channels);
 # {"normal": 0.01} adds the normal_render_depth term (6 active channels)
-@pytest.mark.parametrize("weights", [None, {"normal": 0.01}], ids=["run_nerf_stage2", "with_normal_term"])
-def test_fused_forward_backward_matches_autograd(weights):
+def _object_mask(res):
+    """A soft object mask with values strictly between 0 and 1 somewhere (Camera.image_mask is the image's alpha channel)."""
+    yy, xx = torch.meshgrid(torch.linspace(-1, 1, res), torch.linspace(-1, 1, res), indexing="ij")
+    return (1.3 - 1.5 * (xx * xx + yy * yy).sqrt()).clamp(0, 1)[None].contiguous().to(DEV)
+
+
+# default = the objective of script/run_nerf.sh:20-39 (only the render and pbr maps carry a loss: 3 active feature channels);
+# {"normal": 0.01} adds the normal_render_depth term (6 active channels); run_syn4 = script/run_syn4.sh:34-36 / run_dtu.sh: the
+# three edge-aware smoothness terms (13 active channels) -- alone and on top of the normal term (the light term's guide is
+# the rendered normal: both write the normal maps' gradient), each with a non-trivial object mask
+_SYN4 = dict(base_color_smooth=1.0, roughness_smooth=0.5, light_smooth=1.0)
+@pytest.mark.parametrize("weights,masked", [(None, False), ({"normal": 0.01}, False), ({"normal": 0.01}, True), (_SYN4, True),
+                                            (dict(_SYN4, normal=0.01), True), ({"roughness_smooth": 0.5}, False)],
+                         ids=["run_nerf_stage2", "with_normal_term", "normal_term_masked", "run_syn4_objective",
+                              "run_syn4_plus_normal", "one_smoothness_term"])
+def test_fused_forward_backward_matches_autograd(weights, masked):
     params, ref, fused, cam, bg, gt = _setup(weights=weights)
-    loss_ref, outs_ref = ref(cam, bg, gt)
+    mask = _object_mask(gt.shape[-1]) if masked else None
+    loss_ref, outs_ref = ref(cam, bg, gt, mask)
     loss_ref.backward()
-    outs = fused.forward_backward(cam, bg, gt)
+    outs = fused.forward_backward(cam, bg, gt, image_mask=mask)
     torch.cuda.synchronize()
     msgs, ok_all = [], True
 
@@ -80,6 +95,53 @@ def test_fused_forward_backward_matches_autograd(weights):
     assert ok_all, "\n".join(msgs)
     for k in ("xyz", "shs", "incidents", "base_color"):
         assert float(g[k].abs().max()) > 0, k
+
+
+def test_frozen_geometry_iteration_equals_the_full_one_on_the_groups_that_train():
+    """script/run_syn4.sh:27-33 / run_dtu.sh: learning rate 0 on positions, normals, SH colour, opacity, scaling, rotation.
+    The frozen-geometry iteration (feature-only tile backward, no per-Gaussian geometry backward, no geometry chain rule, one
+    Adam launch over four groups) must produce the same loss and the same gradients for base colour, roughness, incident
+    light and the environment texture as the full iteration, leave the frozen groups' gradients at zero -- and after a
+    few steps the frozen parameters are bit-identical to where they started while the trained ones moved exactly as in a
+    full iteration whose frozen groups have learning rate 0 in Adam only."""
+    from relightable3dgaussian_amd.fused_step import FusedStage2Step
+    frozen = dict(xyz=0.0, normal=0.0, scaling=0.0, rotation=0.0, opacity=0.0, shs=0.0, shs_rest=0.0, base_color=0.01,
+                  roughness=0.01, incidents=0.001, incidents_rest=0.0001, env=0.1)
+    params, ref, full, cam, bg, gt = _setup(weights=_SYN4)
+    mask = _object_mask(gt.shape[-1])
+    fr = FusedStage2Step(params, ref.K, loss_weights=_SYN4, lrs=frozen)
+    assert fr.frozen_geometry and not full.frozen_geometry
+    fr.visibility, fr.incident_dirs, fr.incident_areas = ref.visibility, ref.incident_dirs, ref.incident_areas
+    full.forward_backward(cam, bg, gt, image_mask=mask)
+    fr.forward_backward(cam, bg, gt, image_mask=mask)
+    torch.cuda.synchronize()
+    assert abs(float(fr.loss()) - float(full.loss())) <= 1e-6 * abs(float(full.loss()))
+    for k in ("base_color", "roughness", "incidents", "env"):
+        ok, msg = report("frozen g " + k, fr.grads[k], full.grads[k], 2e-5, 1e-9)       # (order of the float atomics only)
+        assert ok, msg
+        assert float(fr.grads[k].abs().max()) > 0
+    for k in ("xyz", "normal", "scaling", "rotation", "opacity", "shs"):
+        assert float(fr.grads[k].abs().max()) == 0.0, k
+    # the full iteration with the SAME rates (Adam multiplies the frozen groups' updates by 0) as the trajectory to match
+    slow = FusedStage2Step(params, ref.K, loss_weights=_SYN4, lrs=frozen)
+    slow.frozen, slow.frozen_geometry = set(), False           # (force the full path; buckets are only used under DP)
+    slow._groups_a, slow._groups_c, slow._groups_b = (5,), (0, 1, 2, 3, 4, 6, 7, 9), (8,)
+    slow.visibility, slow.incident_dirs, slow.incident_areas = ref.visibility, ref.incident_dirs, ref.incident_areas
+    fr2 = FusedStage2Step(params, ref.K, loss_weights=_SYN4, lrs=frozen)
+    fr2.visibility, fr2.incident_dirs, fr2.incident_areas = ref.visibility, ref.incident_dirs, ref.incident_areas
+    start = {k: getattr(fr2, k).clone() for k in ("xyz", "normal", "scaling", "rotation", "opacity", "shs")}
+    for it in range(4):
+        slow(cam, bg, gt, image_mask=mask)
+        fr2(cam, bg, gt, image_mask=mask)
+    torch.cuda.synchronize()
+    for k, v in start.items():
+        assert torch.equal(getattr(fr2, k), v), k
+    for k in ("base_color", "roughness", "incidents", "env"):
+        ok, msg = report("frozen param " + k, getattr(fr2, k), getattr(slow, k), 1e-4, 1e-6)
+        assert ok, msg
+        assert not torch.equal(getattr(fr2, k), getattr(params, k).detach() if k != "incidents" else
+                               torch.cat([params.incidents_dc, params.incidents_rest], 1).detach())
+    assert fr2.opt.step_count == 4 and fr2.poll_overflow() == 0
 
 
 def test_fused_adam_matches_torch_adam():

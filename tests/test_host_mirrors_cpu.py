@@ -462,6 +462,31 @@ def test_stage1_loss_restatement_equals_the_reference_calculate_loss():
     assert abs(float(var.clamp_min(1e-6).sqrt().mean()) - dvar) < 2e-6
 
 
+def test_stage2_smoothness_restatement_equals_the_reference_calculate_loss():
+    """train_step.stage2_smoothness (the three edge-aware terms of script/run_syn4.sh / run_dtu.sh, neilf.py:275-292) on the maps
+    the reference's own render_view produced = the terms its own calculate_loss logged with those flags
+    (tests/golden/pipeline_reference_stage2_syn4.npz; maps and mask from pipeline_reference_stage2.npz, same inputs)."""
+    import numpy as np
+    from relightable3dgaussian_amd import train_step as ts
+    z = np.load(os.path.join(GOLDEN, "pipeline_reference_stage2.npz"))
+    y = np.load(os.path.join(GOLDEN, "pipeline_reference_stage2_syn4.npz"))
+    t = lambda k: torch.from_numpy(z[k])
+    feat = torch.zeros(16, *z["gt"].shape[1:])
+    feat[5:8], feat[8:11], feat[11:12], feat[12:15] = t("map_normal"), t("map_base_color"), t("map_roughness"), t("map_diffuse")
+    gt, mask = t("gt"), t("mask")
+    bcs, rs, ls = [float(v) for v in y["tb"][6:9]]
+    one = lambda **kw: float(ts.stage2_smoothness(feat, gt, mask, dict(ts.STAGE2_WEIGHTS, **kw)))
+    assert abs(one(base_color_smooth=1.0) - bcs) < 2e-6 and abs(one(roughness_smooth=1.0) - rs) < 2e-6
+    assert abs(one(light_smooth=1.0) - ls) < 2e-6
+    assert min(bcs, rs, ls) > 1e-3                                    # (the terms are not trivially zero on this scene)
+    w = ts.STAGE2_WEIGHTS_SYN4
+    assert (w["base_color_smooth"], w["roughness_smooth"], w["light_smooth"]) == tuple(float(v) for v in y["lambdas"])
+    both = float(ts.stage2_smoothness(feat, gt, mask, w))
+    assert abs(both - (bcs + 0.5 * rs + ls)) < 3e-6
+    # the whole objective differs from run_nerf.sh's by exactly these terms (same maps, same other lambdas)
+    assert abs((float(y["loss"]) - float(z["loss"])) - (bcs + 0.5 * rs + ls)) < 3e-6
+
+
 def test_checkpoint_defaults_follow_the_reference_flow():
     """(a) capture() without learning_rates writes the reference's training_setup rates (Optimizer.load_state_dict adopts the saved
     groups' hyper-parameters: lr 0 would freeze a reference GaussianModel restored from the file); (b) restore(pbr=True) of a
@@ -557,3 +582,49 @@ def test_fused_stage2_iteration_host_logic_with_a_recording_library(monkeypatch)
                                      "r3dg_stage2_unpack_gradients", bwd, "r3dg_stage2_activate_backward", "r3dg_adam_step")][:9]
     assert order == [fwd, "r3dg_stage2_pack_features", "r3dg_ssim_forward_pair", "r3dg_stage2_loss", "r3dg_adam_step",
                      "r3dg_stage2_unpack_gradients", bwd, "r3dg_stage2_activate_backward", "r3dg_adam_step"], order
+    assert "r3dg_stage2_smooth_forward" not in names                          # run_nerf.sh's objective has no smoothness terms
+    # ---- the Synthetic4Relight / DTU schedule (run_syn4.sh:22-42): smoothness terms on, every geometry rate 0 ----------------
+    from relightable3dgaussian_amd import train_step
+    feats = []
+    monkeypatch.setattr(rasterizer_ops, "rasterize_gaussians_backward_features",
+                        lambda P_, S_, H_, W_, gF, geom, R, binning, img, debug=False, active_features=None:
+                        feats.append(tuple(active_features)) or z(P, 16))
+    monkeypatch.setattr(rasterizer_ops, "rasterize_gaussians_backward", lambda *a, **k: pytest.fail("geometry backward ran"))
+    frozen_lrs = dict(xyz=0.0, normal=0.0, scaling=0.0, rotation=0.0, opacity=0.0, shs=0.0, shs_rest=0.0, base_color=0.01,
+                      roughness=0.01, incidents=0.001, incidents_rest=0.0001, env=0.1)
+    step = fused_step.FusedStage2Step(params, K, lrs=frozen_lrs, loss_weights=train_step.STAGE2_WEIGHTS_SYN4)
+    assert step.frozen_geometry and step.frozen == {"xyz", "normal", "scaling", "rotation", "opacity", "shs"}
+    calls.clear()
+    mask = torch.ones(1, H, W)
+    for _ in range(2):
+        step(cam, torch.ones(3), z(3, H, W), image_mask=mask)
+    names = [c[0] for c in calls]
+    assert names.count("r3dg_stage2_smooth_forward") == 2 and names.count("r3dg_stage2_smooth_backward") == 2
+    assert names.index("r3dg_stage2_loss") < names.index("r3dg_stage2_smooth_forward") < names.index("r3dg_stage2_smooth_backward")
+    # pbr 2-4, base colour 8-10, roughness 11, diffuse light 12-14; the normal maps' gradient has no consumer
+    assert feats == [(2, 3, 4, 8, 9, 10, 11, 12, 13, 14)] * 2
+    adam = [c[1] for c in calls if c[0] == "r3dg_adam_step"]
+    assert len(adam) == 2 and all(a[1] == 4 for a in adam)                     # ONE launch per iteration, four groups that train
+    ab = [c[1] for c in calls if c[0] == "r3dg_stage2_activate_backward"][0]
+    assert ab[2] is None and ab[19] is None and ab[24] == step.grads["base_color"].data_ptr()   # no geometry in or out
+    sm = [c[1] for c in calls if c[0] == "r3dg_stage2_smooth_forward"][0]
+    N_ = H * W
+    assert sm[7] == mask.data_ptr() and abs(sm[8] - 1.0 / (3 * N_)) < 1e-9 and abs(sm[9] - 0.5 / (3 * N_)) < 1e-9
+    loss_args = [c[1] for c in calls if c[0] == "r3dg_stage2_loss"][0]
+    assert loss_args[10] == mask.data_ptr()
+    # gradient slab: what is reduced under data parallelism is [flag, base colour, roughness, env] and [incidents] only
+    assert step._bucket_a is None
+    assert step._bucket_c.numel() == 4 + 4 * ((3 * P + 3) // 4) + 4 * ((P + 3) // 4) + 16 * 32 * 3
+    assert step._bucket_b.numel() == 48 * P and step._bucket_b.data_ptr() == step.grads["incidents"].data_ptr()
+    assert float(step.grads["xyz"].abs().max()) == 0.0 and float(step.grads["shs"].abs().max()) == 0.0
+    # a single frozen group (not the whole geometry): the full backward runs, that group just gets no Adam launch
+    monkeypatch.setattr(rasterizer_ops, "rasterize_gaussians_backward", lambda *a, **k: (
+        z(P, 3), z(P, 3), z(P, 1), z(P, 3), z(P, 16), z(P, 6), z(P, 16, 3), z(P, 3), z(P, 4)))
+    step = fused_step.FusedStage2Step(params, K, lrs=dict(xyz=0.0))
+    assert not step.frozen_geometry and step.frozen == {"xyz"}
+    calls.clear()
+    step(cam, torch.ones(3), z(3, H, W))
+    adam = [c[1] for c in calls if c[0] == "r3dg_adam_step"]
+    assert [a[1] for a in adam] == [1, 8]                                      # shs early, then the other nine minus xyz
+    with pytest.raises(RuntimeError):
+        fused_step.FusedStage2Step(params, K, loss_weights={"no_such_term": 1.0})

@@ -440,6 +440,41 @@ def test_backward_active_feature_subset(S, active):
         run((S,))
 
 
+@pytest.mark.parametrize("S,active,size", [(16, None, (128, 128)), (16, (2, 3, 4, 8, 9, 10, 11, 12, 13, 14), (150, 97)),
+                                           (5, (0,), (128, 128)), (28, tuple(range(3, 20)), (64, 200)), (36, None, (96, 96)),
+                                           (16, (), (128, 128))])
+def test_backward_features_only_equals_the_full_backward(S, active, size):
+    """r3dg_rasterize_backward_features (frozen geometry, script/run_syn4.sh:27-33): dL_dfeatures alone, without the
+    alpha-gradient recursion -- the same values as the full backward's dL_dfeatures (backward.cu:566 does not depend on
+    backward_geometry, colours, opacity or depth gradients), on ragged images and for any active-channel subset."""
+    from r3dg_rasterization import _C
+    from relightable3dgaussian_amd import rasterizer_ops
+    W, H = size
+    case = make_case(S=S, seed=31 + S, P=5000, W=W, H=H)
+    a = fwd_args(case, DEV)
+    out = _C.rasterize_gaussians(*a)
+    g = torch.Generator().manual_seed(6)
+    gC, gO, gD = [torch.randn(c, H, W, generator=g).to(DEV) for c in (3, 1, 1)]
+    gF = torch.zeros(S, H, W, device=DEV)
+    for ch in (range(S) if active is None else active):
+        gF[ch] = torch.randn(H, W, generator=g).to(DEV)
+    full = rasterizer_ops.rasterize_gaussians_backward(
+        a[0], a[1], a[2], out[9], a[3], a[5], a[6], 1.0, a[8], a[9], a[10], a[11], a[12], gC, gO, gD, gF, a[17], a[18], a[19],
+        out[10], out[0], out[11], out[12], True, False, active_features=active)[4]
+    only = rasterizer_ops.rasterize_gaussians_backward_features(case["P"], S, H, W, gF, out[10], out[0], out[11], out[12],
+                                                                active_features=active)
+    torch.cuda.synchronize()
+    ok, msg = report("dL_dfeatures", only, full, 2e-5, 1e-9)          # float-atomic summation order differs
+    assert ok, msg
+    if active is None or len(active):
+        assert float(only.abs().max()) > 0
+    else:
+        assert float(only.abs().max()) == 0.0
+    with pytest.raises(RuntimeError):
+        rasterizer_ops.rasterize_gaussians_backward_features(case["P"], S, H, W, gF, out[10], out[0], out[11], out[12],
+                                                             active_features=(S,))
+
+
 @pytest.mark.parametrize("name", ["S16", "big_splats", "ragged_image"])
 def test_cull_is_exact(name, hip_lib):
     """The sub-tile cull only drops (wave, Gaussian) pairs whose every pixel fails alpha >= 1/255, so the forward

@@ -123,6 +123,62 @@ def test_stage2_iteration_matches_the_reference_python():
     chk.done()
 
 
+def test_stage2_syn4_objective_matches_the_reference_python():
+    """script/run_syn4.sh:22-42 / run_dtu.sh: the stage-2 objective with the three edge-aware smoothness terms
+    (--lambda_base_color_smooth 1 --lambda_roughness_smooth 0.5 --lambda_light_smooth 1) through the reference's own
+    calculate_loss (tests/golden/pipeline_reference_stage2_syn4.npz: same inputs, camera, target, object mask and visibility
+    caches as the run_nerf.sh fixture) vs the autograd restatement, the fused iteration, and the fused FROZEN-GEOMETRY
+    iteration those scripts' learning rates select."""
+    from relightable3dgaussian_amd.fused_step import FusedStage2Step
+    from relightable3dgaussian_amd.train_step import STAGE2_WEIGHTS_SYN4, Stage2Step
+    z, y = _load(2), np.load(os.path.join(GOLD, "pipeline_reference_stage2_syn4.npz"))
+    K = int(z["K"])
+    cam = _camera(z)
+    bg, gt, mask = (torch.from_numpy(z[k]).to(DEV) for k in ("bg", "gt", "mask"))
+    vis, dirs, areas = (torch.from_numpy(z[k]).to(DEV) for k in ("visibility", "incident_dirs", "incident_areas"))
+    chk = _Checker()
+    p = _params(z, True)
+    step = Stage2Step(p, None, DEV, K, loss_weights=STAGE2_WEIGHTS_SYN4)
+    step.visibility, step.incident_dirs, step.incident_areas = vis, dirs, areas
+    loss, outs = step(cam, bg, gt, mask)
+    loss.backward()
+    chk("loss", loss.detach().reshape(1), np.array([y["loss"]], np.float32), 1e-5)
+    names = {"xyz": p.xyz, "normal": p.normal, "scaling": p.scaling, "rotation": p.rotation, "opacity": p.opacity,
+             "shs_dc": p.features_dc, "shs_rest": p.features_rest, "base_color": p.base_color, "roughness": p.roughness,
+             "incidents_dc": p.incidents_dc, "incidents_rest": p.incidents_rest, "env": p.env}
+    for k, t in names.items():
+        chk("autograd g_" + k, t.grad, y["g_" + k], 2e-3, 1e-9, outliers=4e-3)
+    cat = lambda a, b: np.concatenate([y[a], y[b]], 1)
+    # fused iteration, everything trains: every gradient
+    fused = FusedStage2Step(_params(z, True), K, loss_weights=STAGE2_WEIGHTS_SYN4)
+    fused.visibility, fused.incident_dirs, fused.incident_areas = vis, dirs, areas
+    fused.forward_backward(cam, bg, gt, image_mask=mask)
+    torch.cuda.synchronize()
+    chk("fused loss", fused.loss().reshape(1), np.array([y["loss"]], np.float32), 1e-5)
+    tb = y["tb"]
+    N = gt.shape[-1] * gt.shape[-2]
+    sm = fused.sums.sum(1)[7:10].cpu().numpy() / (3.0 * N)
+    chk("fused smoothness terms", torch.from_numpy(sm), tb[6:9].astype(np.float32), 1e-4)
+    for k in ("xyz", "normal", "scaling", "rotation", "opacity", "base_color", "roughness", "env"):
+        chk("fused g_" + k, fused.grads[k], y["g_" + k], 2e-3, 1e-9, outliers=4e-3)
+    chk("fused g_shs", fused.grads["shs"], cat("g_shs_dc", "g_shs_rest"), 2e-3, 1e-9, outliers=4e-3)
+    chk("fused g_incidents", fused.grads["incidents"], cat("g_incidents_dc", "g_incidents_rest"), 2e-3, 1e-9, outliers=4e-3)
+    # frozen geometry (the scripts' learning rates): the groups that train get the reference's gradients, the others none
+    lrs = dict(xyz=0.0, normal=0.0, scaling=0.0, rotation=0.0, opacity=0.0, shs=0.0, shs_rest=0.0, base_color=0.01,
+               roughness=0.01, incidents=0.001, incidents_rest=0.0001, env=0.1)
+    fr = FusedStage2Step(_params(z, True), K, loss_weights=STAGE2_WEIGHTS_SYN4, lrs=lrs)
+    assert fr.frozen_geometry
+    fr.visibility, fr.incident_dirs, fr.incident_areas = vis, dirs, areas
+    fr.forward_backward(cam, bg, gt, image_mask=mask)
+    torch.cuda.synchronize()
+    chk("frozen loss", fr.loss().reshape(1), np.array([y["loss"]], np.float32), 1e-5)
+    for k in ("base_color", "roughness", "env"):
+        chk("frozen g_" + k, fr.grads[k], y["g_" + k], 2e-3, 1e-9, outliers=4e-3)
+    chk("frozen g_incidents", fr.grads["incidents"], cat("g_incidents_dc", "g_incidents_rest"), 2e-3, 1e-9, outliers=4e-3)
+    assert all(float(fr.grads[k].abs().max()) == 0.0 for k in ("xyz", "normal", "scaling", "rotation", "opacity", "shs"))
+    chk.done()
+
+
 def test_stage1_iteration_matches_the_reference_python():
     from relightable3dgaussian_amd.bench_core import render_stage1
     from relightable3dgaussian_amd.fused_step import FusedStage1Step
