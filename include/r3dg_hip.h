@@ -353,7 +353,9 @@ int r3dg_stage2_loss(void* stream, int width, int height, const float* d_image, 
  * Sobel / 8 with replicate padding):
  *   w_base_color sum_{c,d} |G_d (base_color_c m)| exp(-|G_d gt_c|) + w_roughness sum_{c,d} |G_d (roughness m)| exp(-|G_d gt_c|)
  *   + w_light sum_{c,d} |G_d (diffuse_c m)| exp(-|G_d normal_c|)          (the guide of the light term is the RENDERED normal
- *   and carries a gradient), with X = feature_X / max(opacity, 1e-5) * (n_contrib > 0) on the S=16 training feature image and
+ *   and carries a gradient), with X = feature_X / max(opacity, 1e-5) * (n_contrib > 0) on the S=16 training feature image --
+ *   base_color and diffuse additionally through rgb_to_srgb with its clip to [0,1] (they are results["base_color"] /
+ *   results["diffuse"], neilf.py:153-155; utils/graphics_utils.py:207-213), roughness and normal as rendered -- and
  *   m = d_image_mask [HW] (NULL = all ones).  The weights carry the 1 / (3 H W) of the reference's means; a zero weight
  *   switches its term off.
  * _forward: sums3[0..2] (R3DG_SUM_SLOTS floats each) += the three UNWEIGHTED sums; d_scratch [30 * H * W] floats receives

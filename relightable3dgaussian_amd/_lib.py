@@ -4,7 +4,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libr3dg_hip.so")
+# R3DG_LIB_PATH: an experiment build of the SAME library (tools/build_variant.py) for A/B measurements; never a fallback
+LIB_PATH = os.environ.get("R3DG_LIB_PATH") or os.path.join(_HERE, "lib", "libr3dg_hip.so")
 
 ALLOC_FN = C.CFUNCTYPE(C.c_void_p, C.c_void_p, C.c_size_t)
 

@@ -550,8 +550,26 @@ s1_loss_kernel(int W, int H, const float* __restrict__ image, const float* __res
 // s2_smooth_edge_kernel evaluates the stencils, adds the three sums and writes, per pixel, the 20 values the adjoint needs
 // (weights folded in); (B) s2_smooth_backward_kernel gathers the adjoint of the replicate-padded stencil (no atomics) and
 // applies the chain rule of the division into the feature-gradient maps and the opacity gradient r3dg_stage2_loss left.
-// rend layout [10][HW]: base_color*m 0..2 | roughness*m 3 | diffuse*m 4..6 | normal 7..9
+// The base-colour and diffuse-light maps enter through the sRGB curve and its clip to [0,1] -- the loss reads
+// results["base_color"] = rgb_to_srgb(rendered_base_color), results["diffuse"] likewise (neilf.py:153-155); the clip passes no
+// gradient outside [0,1] -- the roughness map as rendered.
+// rend layout [10][HW]: srgb(base_color)*m 0..2 | roughness*m 3 | srgb(diffuse)*m 4..6 | normal 7..9
 // edge layout [20][HW]: base 2c+d (0..5) | roughness d (6,7) | diffuse 8+2c+d | normal guide 14+2c+d      (d: 0 = x, 1 = y)
+// rgb_to_srgb with clip=True (utils/graphics_utils.py:207-213) and its derivative (0 where the clamp is active)
+__device__ __forceinline__ float srgb_clip(float x)
+{
+    const float curve = x <= 0.0031308f ? 12.92f * x : 1.055f * __powf(fmaxf(x, 0.0031308f), 1.f / 2.4f) - 0.055f;
+    return fminf(fmaxf(curve, 0.f), 1.f);
+}
+__device__ __forceinline__ float srgb_clip_derivative(float x)
+{
+    const bool lin = x <= 0.0031308f;
+    const float xs = fmaxf(x, 0.0031308f);
+    const float curve = lin ? 12.92f * x : 1.055f * __powf(xs, 1.f / 2.4f) - 0.055f;
+    if (!(curve >= 0.f && curve <= 1.f)) return 0.f;
+    return lin ? 12.92f : 1.055f / 2.4f * __powf(xs, 1.f / 2.4f - 1.f);
+}
+
 __global__ void __launch_bounds__(256)
 s2_smooth_maps_kernel(int HW, const float* __restrict__ opacity, const float* __restrict__ feature,
                       const int* __restrict__ n_contrib, const float* __restrict__ image_mask, float* __restrict__ rend)
@@ -561,7 +579,11 @@ s2_smooth_maps_kernel(int HW, const float* __restrict__ opacity, const float* __
     const float scale = n_contrib[i] > 0 ? 1.f / fmaxf(opacity[i], 1e-5f) : 0.f;
     const float m = image_mask ? image_mask[i] : 1.f;
 #pragma unroll
-    for (int c = 0; c < 7; c++) rend[(size_t)c * HW + i] = feature[(size_t)(8 + c) * HW + i] * scale * m;
+    for (int c = 0; c < 7; c++) {
+        const float x = feature[(size_t)(8 + c) * HW + i] * scale;
+        // results["base_color"] / results["diffuse"] are rgb_to_srgb(.) with its clip to [0,1] (neilf.py:153-155); roughness is not
+        rend[(size_t)c * HW + i] = (c == 3 ? x : srgb_clip(x)) * m;
+    }
 #pragma unroll
     for (int c = 0; c < 3; c++) rend[(size_t)(7 + c) * HW + i] = feature[(size_t)(5 + c) * HW + i] * scale;
 }
@@ -695,9 +717,10 @@ s2_smooth_backward_kernel(int W, int H, const float* __restrict__ opacity, const
         if (has_base) {
 #pragma unroll
             for (int c = 0; c < 3; c++) {
-                const float g = d[c] * m;
+                const float F = feature[(size_t)(8 + c) * HW + i];
+                const float g = d[c] * m * srgb_clip_derivative(F * scale);       // dL / d (linear base colour map)
                 dL_dfeature[(size_t)(8 + c) * HW + i] = g * scale;
-                g_op += g * feature[(size_t)(8 + c) * HW + i] * dscale_dop;
+                g_op += g * F * dscale_dop;
             }
         }
         if (has_rough) {
@@ -708,9 +731,10 @@ s2_smooth_backward_kernel(int W, int H, const float* __restrict__ opacity, const
         if (has_light) {
 #pragma unroll
             for (int c = 0; c < 3; c++) {
-                const float g = d[4 + c] * m;
+                const float Fd = feature[(size_t)(12 + c) * HW + i];
+                const float g = d[4 + c] * m * srgb_clip_derivative(Fd * scale);   // dL / d (linear diffuse map)
                 dL_dfeature[(size_t)(12 + c) * HW + i] = g * scale;
-                g_op += g * feature[(size_t)(12 + c) * HW + i] * dscale_dop;
+                g_op += g * Fd * dscale_dop;
                 const float gn = d[7 + c];
                 const size_t o = (size_t)(5 + c) * HW + i;
                 dL_dfeature[o] = (accumulate_normal ? dL_dfeature[o] : 0.f) + gn * scale;

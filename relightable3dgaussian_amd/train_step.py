@@ -197,18 +197,22 @@ STAGE2_WEIGHTS_SYN4 = dict(STAGE2_WEIGHTS, base_color_smooth=1.0, roughness_smoo
 FROZEN_GEOMETRY_GROUPS = ("xyz", "normal", "scaling", "rotation", "opacity", "shs")
 
 
-def stage2_smoothness(feat, gt, image_mask, w):
+def stage2_smoothness(feat, gt, image_mask, w, maps_are_srgb=False):
     """The three edge-aware terms of calculate_loss (neilf.py:275-292) on the divided feature maps `feat` [16,H,W]:
     base colour and roughness against the target image, diffuse light against the RENDERED NORMAL (not detached: the term
-    also pulls on the normal map).  `image_mask` [1,H,W] or None (all ones)."""
+    also pulls on the normal map).  The base-colour and diffuse-light maps the loss sees are results["base_color"] /
+    results["diffuse"] = rgb_to_srgb(.) of the rendered maps -- the sRGB curve AND its clip to [0,1] (neilf.py:153-155) --
+    the roughness map is used as rendered.  `image_mask` [1,H,W] or None (all ones); `maps_are_srgb`: feat[8:11] and
+    feat[12:15] already hold the sRGB-mapped maps (the reference's result dict)."""
     m = 1.0 if image_mask is None else image_mask
+    curve = (lambda x: x) if maps_are_srgb else rgb_to_srgb
     loss = feat.new_zeros(())
     if w["base_color_smooth"] != 0.0:
-        loss = loss + w["base_color_smooth"] * first_order_edge_aware_loss(feat[8:11] * m, gt)
+        loss = loss + w["base_color_smooth"] * first_order_edge_aware_loss(curve(feat[8:11]) * m, gt)
     if w["roughness_smooth"] != 0.0:
         loss = loss + w["roughness_smooth"] * first_order_edge_aware_loss(feat[11:12] * m, gt)
     if w["light_smooth"] != 0.0:
-        loss = loss + w["light_smooth"] * first_order_edge_aware_loss(feat[12:15] * m, feat[5:8])
+        loss = loss + w["light_smooth"] * first_order_edge_aware_loss(curve(feat[12:15]) * m, feat[5:8])
     return loss
 
 

@@ -475,13 +475,20 @@ def test_stage2_smoothness_restatement_equals_the_reference_calculate_loss():
     feat[5:8], feat[8:11], feat[11:12], feat[12:15] = t("map_normal"), t("map_base_color"), t("map_roughness"), t("map_diffuse")
     gt, mask = t("gt"), t("mask")
     bcs, rs, ls = [float(v) for v in y["tb"][6:9]]
-    one = lambda **kw: float(ts.stage2_smoothness(feat, gt, mask, dict(ts.STAGE2_WEIGHTS, **kw)))
+    # (the result dict holds rgb_to_srgb of the base-colour and diffuse maps: what the loss consumes, neilf.py:153-155)
+    one = lambda **kw: float(ts.stage2_smoothness(feat, gt, mask, dict(ts.STAGE2_WEIGHTS, **kw), maps_are_srgb=True))
     assert abs(one(base_color_smooth=1.0) - bcs) < 2e-6 and abs(one(roughness_smooth=1.0) - rs) < 2e-6
     assert abs(one(light_smooth=1.0) - ls) < 2e-6
     assert min(bcs, rs, ls) > 1e-3                                    # (the terms are not trivially zero on this scene)
     w = ts.STAGE2_WEIGHTS_SYN4
     assert (w["base_color_smooth"], w["roughness_smooth"], w["light_smooth"]) == tuple(float(v) for v in y["lambdas"])
-    both = float(ts.stage2_smoothness(feat, gt, mask, w))
+    both = float(ts.stage2_smoothness(feat, gt, mask, w, maps_are_srgb=True))
+    # and on linear maps the curve is applied here: a map inside (0.0031308, 1) goes through 1.055 x^(1/2.4) - 0.055
+    lin = feat.clone()
+    lin[8:11] = ((feat[8:11] + 0.055) / 1.055).clamp_min(0) ** 2.4
+    lin[12:15] = ((feat[12:15] + 0.055) / 1.055).clamp_min(0) ** 2.4
+    ok = (feat[8:11] > 0.05) & (feat[8:11] < 0.999)
+    assert float((ts.rgb_to_srgb(lin[8:11]) - feat[8:11])[ok].abs().max()) < 1e-5
     assert abs(both - (bcs + 0.5 * rs + ls)) < 3e-6
     # the whole objective differs from run_nerf.sh's by exactly these terms (same maps, same other lambdas)
     assert abs((float(y["loss"]) - float(z["loss"])) - (bcs + 0.5 * rs + ls)) < 3e-6
