@@ -64,7 +64,8 @@ int r3dg_binning_state_offsets(int64_t num_rendered, size_t* offsets4);
 /* Forward. Optional inputs (d_shs, d_colors_precomp, d_scales, d_rotations, d_cov3D_precomp) are NULL when
  * absent, exactly like the reference's nullptr convention (forward.cu:206,242).  Every image output and d_radii is
  * fully written (uninitialised memory is fine); only d_out_weights is accumulated and must be zero-filled by the
- * caller (the reference zero-fills everything, rasterize_points.cu:72-79).  `d_radii` may be NULL.
+ * caller (the reference zero-fills everything, rasterize_points.cu:72-79).  `d_radii` may be NULL; so may d_out_weights
+ * (the per-Gaussian blend weights, read by the densification statistics only: then they are not computed).
  * Returns num_rendered in *num_rendered_out.  One device->host sync (rasterizer_impl.cu:291). */
 int r3dg_rasterize_forward(void* stream, r3dg_alloc_fn geometry_alloc, r3dg_alloc_fn binning_alloc,
                            r3dg_alloc_fn image_alloc, void* alloc_user, int P, int S, int D, int M,
@@ -237,6 +238,41 @@ int r3dg_shade_forward_transport(void* stream, int P, int K, const float* d_base
                                  const float* d_normals, const float* d_viewdirs, const float* d_transport,
                                  const float* d_consts, const float* d_zsamples, const float* d_incident_dirs,
                                  float* d_out);
+/* ---- the same integral over a FIXED RAY SET (csrc/shading_frs.hpp) -----------------------------------------------------------
+ * For callers whose cached directions are the Fibonacci set rotated to each Gaussian's normal, d_k = normalize(R(n) z_k) --
+ * what GaussianModel.update_visibility produces (scene/gaussian_model.py:312-342 -> utils/graphics_utils.py:9-37,
+ * rotation_between_z utils/sh_utils.py:36-68).  The local incident light sum_i c_i Y_i(R z_k) equals sum_i c'_i Y_i(z_k) for the
+ * ROTATED coefficients c', and Y_i(z_k) is one K x 16 table for all Gaussians: the two SH contractions of the integral run on
+ * the matrix cores against that constant table instead of ~225 VALU instructions per sample.  Same inputs, outputs and values
+ * (fp32 rounding) as r3dg_shade_forward_cached / r3dg_shade_backward_cached with R3DG_SHADE_TRAIN_OUTPUTS, lookup-record taps
+ * and no light rotation; 16 incident-light coefficients, K % 4 == 0, a texture that fits LDS: r3dg_shade_frs_supported.
+ *   d_ray_normals [P,3]: the normals the ray set was GENERATED from (the snapshot update_visibility used, not the trained
+ *     normal); d_tables: r3dg_shade_frs_build_tables(K, d_zsamples [K,3] = the z set, r3dg_shade_frs_tables_bytes(K) bytes);
+ *   d_valid [P] bytes from r3dg_shade_frs_classify: 1 where R(n) is orthonormal to 2e-5 in fp32 -- normals within ~2.5 degrees of
+ *     -z lose that to cancellation, their cached directions are not a rigid copy of the z set, and those Gaussians (d_invalid_list
+ *     [n_invalid] int32 row indices, built by the caller from d_valid) go through the general kernels inside the same call;
+ *   d_cprime [P,48]: scratch written by _forward (the rotated coefficients) and read by _backward of the same parameters;
+ *   d_dcprime [P,48]: scratch of _backward.  d_incident_areas may be NULL with uniform_area > 0. */
+int r3dg_shade_frs_supported(int K, int M, int He, int We);
+size_t r3dg_shade_frs_tables_bytes(int K);
+int r3dg_shade_frs_build_tables(void* stream, int K, const float* d_zsamples, float* d_tables);
+int r3dg_shade_frs_classify(void* stream, int P, const float* d_ray_normals, uint8_t* d_valid);
+int r3dg_shade_frs_forward(void* stream, int P, int K, const float* d_base_color, const float* d_roughness,
+                           const float* d_normals, const float* d_viewdirs, const float* d_incidents, const float* d_env,
+                           int He, int We, const float* d_visibility, const float* d_incident_dirs,
+                           const float* d_incident_areas, float uniform_area, const uint32_t* d_taps,
+                           const float* d_ray_normals, const float* d_tables, const uint8_t* d_valid,
+                           const int32_t* d_invalid_list, int n_invalid, float* d_cprime, int flags, float* d_out);
+int r3dg_shade_frs_backward(void* stream, int P, int K, const float* d_base_color, const float* d_roughness,
+                            const float* d_normals, const float* d_viewdirs, const float* d_incidents, const float* d_env,
+                            int He, int We, const float* d_visibility, const float* d_incident_dirs,
+                            const float* d_incident_areas, float uniform_area, const uint32_t* d_taps,
+                            const float* d_ray_normals, const float* d_tables, const uint8_t* d_valid,
+                            const int32_t* d_invalid_list, int n_invalid, const float* d_cprime, float* d_dcprime,
+                            const float* d_dL_dpbr, const float* d_dL_ddiffuse_light, float* d_dL_dbase_color,
+                            float* d_dL_droughness, float* d_dL_dviewdirs, float* d_dL_dincidents, float* d_dL_denv,
+                            const float* d_block_absmax, int n_block_absmax);
+
 int r3dg_shade_backward(void* stream, int P, int K, int M, const float* d_base_color, const float* d_roughness,
                         const float* d_normals, const float* d_viewdirs, const float* d_incidents, const float* d_env,
                         int He, int We, const float* d_env_transform, const float* d_visibility,
@@ -582,41 +618,35 @@ size_t r3dg_sort_temp_bytes(int64_t n);
 int r3dg_sort_pairs(void* stream, int64_t n, uint64_t* d_keys_in, uint32_t* d_vals_in, uint64_t* d_keys_out,
                     uint32_t* d_vals_out, int end_bit, void* d_temp);
 
-/* Tuning / self-test hooks (not part of the drop-in surface).
- * r3dg_set_tuning: pixels per lane of the forward / backward tile kernels (<=0 keeps the current value) and
- * whether the backward uses the DPP/permlane-swap transposing wave reduction (1) or the __shfl_xor one (0; <0 keeps).
- * r3dg_selftest_transpose_reduce: one wave reduces d_in[64][N] -> d_out[64] (+ channel / owner maps). */
-int r3dg_set_tuning(int fwd_pixels_per_lane, int bwd_pixels_per_lane, int bwd_dpp_reduce);
-/* staged entries per inner-loop step of the forward / backward tile kernels (<=0 keeps) and block order
- * (1 longest-tile-first, 0 XCD-contiguous natural order, <0 keeps) */
-int r3dg_set_tuning2(int fwd_unroll, int bwd_unroll, int tile_order);
-/* r3dg_set_tuning3: lane->pixel map of the 1-pixel-per-lane forward / backward tile kernels: 1 = each wave owns an
- * 8x8 pixel block (default), 0 = a 16x4 strip; cull: 1 = skip, per wave, staged entries
- * that provably stay below alpha 1/255 on all of the wave's pixels (default), 0 = evaluate every entry.  <0 keeps the
- * current value.  Results do not depend on any of them. */
-int r3dg_set_tuning3(int fwd_wave8x8, int bwd_wave8x8, int cull);
-/* r3dg_set_tuning4: ordering of the (tile, depth) instances: 1 = bin per tile with integer tickets, then sort each tile's
- * list inside LDS (default); 0 = the reference's formulation, one global radix sort of all 44-45-bit keys (K5-K7).  The
- * sorted keys, point list and tile ranges are bit-identical either way; <0 keeps the current value. */
-int r3dg_set_tuning4(int tile_binning);
-/* r3dg_set_tuning5: 1 = the per-Gaussian kernels (projection forward / backward) move their SH and dL_dsh rows through
- * LDS with coalesced 16-byte accesses (default); 0 = every thread walks its own row in HBM.  Results are identical. */
-int r3dg_set_tuning5(int stage_sh_rows);
-/* r3dg_set_tuning6: persistent workgroups per CU of the shading forward kernel (1..8; its 162 VGPRs allow 3 per CU). */
-int r3dg_set_tuning6(int shade_forward_blocks_per_cu);
-/* r3dg_set_tuning7: shading forward formulation: 1 (default) = row kernels (one wave per Gaussian, lane = sample, per-Gaussian
- * records), 0 = the round-1 kernel (16 lanes per Gaussian); same results within fp32 rounding.  row_blocks_per_cu: persistent
- * row-kernel workgroups per CU (0 = as many as fit; fewer leave room for the instance ordering that runs beside it).
- * Negative arguments leave a setting unchanged. */
-int r3dg_set_tuning7(int shade_forward_rows, int row_blocks_per_cu);
-/* r3dg_set_tuning8: visibility trace formulation: 2 (default) = persistent waves, a lane whose ray has finished fetches the
- * next ray (per-ray semantics and visit order of the reference); 1 = wave-cooperative (64 rays share one traversal stack and
- * visit the union of their nodes: measured slower, kept for comparison); 0 = one fixed ray per thread (round 1). */
-int r3dg_set_tuning8(int trace_packet);
-/* r3dg_set_tuning9: shading backward formulation: 0 (default) = 16 lanes per Gaussian, three passes; 1 = row kernel (one wave
- * per Gaussian, lane = sample, the 55 per-Gaussian sums through an LDS role exchange) -- measured equal (0.46 ms), kept for
- * comparison. */
-int r3dg_set_tuning9(int shade_backward_rows);
+/* Tuning / experiment knobs (NOT part of the drop-in surface; defaults are the measured best, results never depend on them
+ * beyond the order of float atomics).  r3dg_set_option returns R3DG_EINVAL for an unknown option or a value out of range. */
+enum r3dg_option {
+    R3DG_OPT_FWD_PIXELS_PER_LANE = 0,   /* forward tile kernel: pixels per lane, 1 (default) / 2 / 4 */
+    R3DG_OPT_BWD_PIXELS_PER_LANE,       /* backward tile kernel: 1 (default) / 2 */
+    R3DG_OPT_FWD_UNROLL,                /* staged entries evaluated per inner-loop step of the forward: 1 / 2 / 4 (default) */
+    R3DG_OPT_BWD_UNROLL,                /* ... of the backward: 1 (default) / 2 / 4 */
+    R3DG_OPT_TILE_ORDER,                /* block -> tile map: 1 longest tile list first (default), 0 XCD-contiguous natural order */
+    R3DG_OPT_FWD_WAVE8X8,               /* 1-pixel-per-lane forward: 1 = each wave owns an 8x8 pixel block (default), 0 = a 16x4 strip */
+    R3DG_OPT_BWD_WAVE8X8,               /* the same for the backward */
+    R3DG_OPT_CULL,                      /* 1 = per-wave conservative sub-tile cull of staged entries (default), 0 = evaluate every entry */
+    R3DG_OPT_TILE_BINNING,              /* instance ordering: 2 = direct tile binning + per-tile sort (default), 1 = radix partition by
+                                         * tile + per-tile sort, 0 = the reference's one global radix sort; identical lists either way */
+    R3DG_OPT_BINNING_BLOCK_K,           /* direct binning: Gaussians per workgroup / 1024 (default 2) */
+    R3DG_OPT_STAGE_SH_ROWS,             /* per-Gaussian kernels move SH / dL_dsh rows through LDS (1, default) or walk them in HBM (0) */
+    R3DG_OPT_SHADE_FWD_BLOCKS_PER_CU,   /* persistent workgroups per CU of the general shading forward; 0 = as many as fit (default) */
+    R3DG_OPT_TRACE_FORMULATION,         /* visibility trace: 4 = phase-separated persistent waves (default), 3 = persistent waves,
+                                         * 2 = packed records, 1 = wave-cooperative packets, 0 = one fixed ray per thread */
+    R3DG_OPT_TRACE_REFILL,              /* idle lanes at which a persistent trace wave refills (default 16) */
+    R3DG_OPT_TRACE_NODE_WEIGHT,         /* vote weights of the phased trace */
+    R3DG_OPT_TRACE_LEAF_WEIGHT,
+    R3DG_OPT_RESERVE_CUS,               /* CUs the persistent kernels (shading, trace) leave free for a collective running beside them
+                                         * (default 0; the data-parallel iteration sets it) */
+    R3DG_OPT_COUNT
+};
+int r3dg_set_option(int option, int value);
+int r3dg_get_option(int option, int* value);
+/* r3dg_selftest_transpose_reduce: one wave reduces d_in[64][N] -> d_out[64] (+ channel / owner maps) with the transposing
+ * DPP / permlane reduction (dpp != 0) or the __shfl_xor one. */
 int r3dg_selftest_transpose_reduce(void* stream, int N, int dpp, const float* d_in, float* d_out, int* d_chan,
                                    int* d_owner);
 

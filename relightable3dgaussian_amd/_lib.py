@@ -52,19 +52,18 @@ _SIGNATURES = {
     "r3dg_bvh_trace_fill": (_i, [_p, C.c_int64] + [_p] * 11),
     "r3dg_sort_temp_bytes": (C.c_size_t, [C.c_int64]),
     "r3dg_sort_pairs": (_i, [_p, C.c_int64, _p, _p, _p, _p, _i, _p]),
-    "r3dg_set_tuning": (_i, [_i, _i, _i]),
-    "r3dg_set_tuning2": (_i, [_i, _i, _i]),
-    "r3dg_set_tuning3": (_i, [_i, _i, _i]),
-    "r3dg_set_tuning4": (_i, [_i]),
-    "r3dg_set_tuning5": (_i, [_i]),
-    "r3dg_set_tuning6": (_i, [_i]),
-    "r3dg_set_tuning7": (_i, [_i, _i]),
-    "r3dg_set_tuning8": (_i, [_i]),
-    "r3dg_set_tuning9": (_i, [_i]),
+    "r3dg_set_option": (_i, [_i, _i]),
+    "r3dg_get_option": (_i, [_i, C.POINTER(_i)]),
     "r3dg_selftest_transpose_reduce": (_i, [_p, _i, _i, _p, _p, _p, _p]),
     "r3dg_shade_forward": (_i, [_p, _i, _i, _i, _p, _p, _p, _p, _p, _p, _i, _i, _p, _p, _p, _p, _p]),
     "r3dg_shade_forward_cached": (_i, [_p, _i, _i, _i, _p, _p, _p, _p, _p, _p, _i, _i, _p, _p, _p, _p, _f, _p, _i, _p]),
     "r3dg_shade_build_taps": (_i, [_p, C.c_int64, _p, _p, _i, _i, _p, _p]),
+    "r3dg_shade_frs_supported": (_i, [_i, _i, _i, _i]),
+    "r3dg_shade_frs_tables_bytes": (C.c_size_t, [_i]),
+    "r3dg_shade_frs_build_tables": (_i, [_p, _i, _p, _p]),
+    "r3dg_shade_frs_classify": (_i, [_p, _i, _p, _p]),
+    "r3dg_shade_frs_forward": (_i, [_p, _i, _i] + [_p] * 6 + [_i, _i, _p, _p, _p, _f] + [_p] * 5 + [_i, _p, _i, _p]),
+    "r3dg_shade_frs_backward": (_i, [_p, _i, _i] + [_p] * 6 + [_i, _i, _p, _p, _p, _f] + [_p] * 5 + [_i] + [_p] * 10 + [_i]),
     "r3dg_shade_build_transport": (_i, [_p, _i, _i, _i, _p, _p, _p, _p, _p, _f, _p, _p]),
     "r3dg_shade_forward_transport": (_i, [_p, _i, _i] + [_p] * 9),
     "r3dg_shade_backward": (_i, [_p, _i, _i, _i, _p, _p, _p, _p, _p, _p, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p,
@@ -138,6 +137,23 @@ def lib():
             fn.argtypes = args
         _lib = L
     return _lib
+
+
+# enum r3dg_option (include/r3dg_hip.h); tests/test_oracle_cpu.py checks the numbering against the header
+OPTIONS = ("FWD_PIXELS_PER_LANE", "BWD_PIXELS_PER_LANE", "FWD_UNROLL", "BWD_UNROLL", "TILE_ORDER", "FWD_WAVE8X8", "BWD_WAVE8X8",
+           "CULL", "TILE_BINNING", "BINNING_BLOCK_K", "STAGE_SH_ROWS", "SHADE_FWD_BLOCKS_PER_CU", "TRACE_FORMULATION",
+           "TRACE_REFILL", "TRACE_NODE_WEIGHT", "TRACE_LEAF_WEIGHT", "RESERVE_CUS")
+
+
+def set_option(name, value):
+    """r3dg_set_option by name (experiments / tests): set_option("CULL", 0)."""
+    check(lib().r3dg_set_option(OPTIONS.index(name), int(value)), "set_option(%s)" % name)
+
+
+def get_option(name):
+    v = C.c_int(0)
+    check(lib().r3dg_get_option(OPTIONS.index(name), C.byref(v)), "get_option(%s)" % name)
+    return v.value
 
 
 def check(status, what):

@@ -582,12 +582,9 @@ def run(args):
     dev = torch.device("cuda", dev_index)
     torch.cuda.set_device(dev)
     L = _lib.lib()
-    if os.environ.get("R3DG_SHADE_FWD_BPC"):             # tuning experiments only
-        L.r3dg_set_tuning7(-1, int(os.environ["R3DG_SHADE_FWD_BPC"]))
-    if os.environ.get("R3DG_SHADE_ROWS"):
-        L.r3dg_set_tuning7(int(os.environ["R3DG_SHADE_ROWS"]), -1)
-    if os.environ.get("R3DG_BIN"):
-        L.r3dg_set_tuning4(int(os.environ["R3DG_BIN"]))
+    for name in _lib.OPTIONS:                            # tuning experiments only: R3DG_OPT_<NAME>=<value>
+        if os.environ.get("R3DG_OPT_" + name):
+            _lib.set_option(name, int(os.environ["R3DG_OPT_" + name]))
 
     stage2 = args.stage == 2
     scene = syn.make_scene(P=args.points, seed=0, stage2=stage2)

@@ -3,7 +3,7 @@ boxes of the Gaussians and traces visibility rays.  Leaf-box construction follow
 tests/golden/bvh_leaf_reference.npz); build and trace run the HIP kernels through `bvh_ops`."""
 import torch
 
-from . import bvh_ops
+from . import _lib, bvh_ops
 
 
 def build_rotation(r):
@@ -51,6 +51,8 @@ class RayTracer:
 
     def _records_for(self, means3D, symm_inv, opacity, normals):
         if self.tree.shape[0] != 2 * means3D.shape[0] - 1 or means3D.shape[0] == 0:
+            return None
+        if _lib.get_option("TRACE_FORMULATION") < 2:         # (experiments: the formulations that walk the reference's tables)
             return None
         arrays = (means3D, symm_inv, opacity, normals)
         key = tuple((t.data_ptr(), t._version, tuple(t.shape)) for t in arrays)

@@ -12,9 +12,6 @@
 //   * the traversal stack holds 64 entries (reference: 32 with only a printf on overflow, trace.cuh:21-28); pushes
 //     beyond that are dropped and counted in *overflow so callers can detect it.
 #include "common.hpp"
-#include <map>
-#include <mutex>
-#include <utility>
 
 namespace r3dg {
 
@@ -935,7 +932,7 @@ trace_opacity_phased_kernel(int num_rays, int P, const TNode* __restrict__ tn, c
 }
 
 int g_trace_packet = 4;
-int g_trace_refill = REFILL_MIN_IDLE, g_trace_node_weight = 1, g_trace_leaf_weight = 1;     // experiments (r3dg_set_tuning8)    // r3dg_set_tuning8: 4 = 3 + phase-separated bodies, 3 = packed records + persistent waves, 2 = packed records, 1 = wave-cooperative, 0 = round-1 kernel
+int g_trace_refill = REFILL_MIN_IDLE, g_trace_node_weight = 1, g_trace_leaf_weight = 1;     // R3DG_OPT_TRACE_*: 4 = 3 + phase-separated bodies, 3 = packed records + persistent waves, 2 = packed records, 1 = wave-cooperative, 0 = round-1 kernel
 
 // ---- trace_bvh: per-ray hit lists (K19; bvh/src/trace.cu:8-192, bound at bvh/src/bindings.cpp:11) ----------------------------
 // Pass 1 counts, per ray, the leaves of every subtree of <= 4 leaves whose box the ray reaches (tmax > 0 on the way down);
@@ -1185,29 +1182,8 @@ void bvh_trace_opacity_packed(hipStream_t s, int num_rays, int P, void* records,
     }
 }
 
-// scratch records of the reference-shaped entry point: one grow-only buffer per (device, stream)
-static void* trace_scratch(hipStream_t s, size_t bytes)
-{
-    struct Buf { void* p = nullptr; size_t cap = 0; };
-    static std::mutex mu;
-    static std::map<std::pair<int, hipStream_t>, Buf> bufs;
-    int dev = 0;
-    R3DG_HIP(hipGetDevice(&dev));
-    std::lock_guard<std::mutex> lk(mu);
-    Buf& b = bufs[std::make_pair(dev, s)];
-    if (b.cap < bytes) {
-        if (b.p != nullptr) {
-            R3DG_HIP(hipStreamSynchronize(s));        // only THIS stream ever used the old buffer
-            R3DG_HIP(hipFree(b.p));
-            b.p = nullptr;
-            b.cap = 0;
-        }
-        const size_t want = bytes + bytes / 8 + 4096;
-        R3DG_HIP(hipMalloc(&b.p, want));
-        b.cap = want;
-    }
-    return b.p;
-}
+// scratch records of the reference-shaped entry point: one grow-only buffer per (device, stream) (common.hpp stream_scratch)
+static void* trace_scratch(hipStream_t s, size_t bytes) { return stream_scratch(s, 2, bytes); }
 
 // P = number of Gaussians (rows of means / leaves of the tree); P <= 0: unknown -> the round-1 kernel
 void bvh_trace_opacity(hipStream_t s, int num_rays, int P, const int32_t* nodes, const float* aabbs, const float* rays_o,

@@ -4,7 +4,9 @@
 #include "common.hpp"
 #include "../../include/r3dg_hip.h"
 
+#include <map>
 #include <mutex>
+#include <tuple>
 #include <vector>
 
 namespace r3dg {
@@ -56,7 +58,23 @@ void launch_shade_forward(hipStream_t s, int P, int K, int M, const float* base_
                           const float* normals, const float* viewdirs, const float* incidents, const float* env, int He,
                           int We, const float* tr, const float* visibility, const float* dirs, const float* areas,
                           float* out, const uint32_t* taps, bool train_outputs, float uniform_area, bool taps_are_radiance,
-                          bool leave_room);
+                          bool leave_room, const int* list = nullptr, int n_list = 0);
+size_t shade_frs_table_floats(int K);
+bool shade_frs_supported(int K, int M, int He, int We);
+void launch_shade_frs_build_tables(hipStream_t s, int K, const float* zsamples, float* tables);
+void launch_shade_frs_classify(hipStream_t s, int P, const float* ray_normals, uint8_t* valid);
+void launch_shade_frs_forward(hipStream_t s, int P, int K, const float* base_color, const float* roughness,
+                              const float* normals, const float* viewdirs, const float* incidents, const float* env, int He,
+                              int We, const float* visibility, const float* dirs, const float* areas, float uniform_area,
+                              const uint32_t* taps, const float* ray_normals, const float* tables, const uint8_t* valid,
+                              const int* invalid_list, int n_invalid, float* cprime, bool leave_room, float* out);
+void launch_shade_frs_backward(hipStream_t s, int P, int K, const float* base_color, const float* roughness,
+                               const float* normals, const float* viewdirs, const float* incidents, const float* env, int He,
+                               int We, const float* visibility, const float* dirs, const float* areas, float uniform_area,
+                               const uint32_t* taps, const float* ray_normals, const float* tables, const uint8_t* valid,
+                               const int* invalid_list, int n_invalid, const float* cprime, float* dcp, const float* g_pbr,
+                               const float* g_diff, float* d_base, float* d_rough, float* d_view, float* d_inc, float* d_env,
+                               const float* block_absmax, int n_block_absmax);
 void launch_shade_build_taps(hipStream_t s, size_t n, const float* dirs, const float* tr, int He, int We, const float* env,
                              uint32_t* taps);
 void launch_shade_build_transport(hipStream_t s, int P, int K, int M, const float* normals, const float* incidents,
@@ -66,14 +84,13 @@ void launch_shade_forward_transport(hipStream_t s, int P, int K, const float* ba
                                     const float* normals, const float* viewdirs, const float* transport, const float* consts,
                                     const float* zsamples, const float* dirs, float* out);
 extern int g_trace_packet, g_trace_refill, g_trace_node_weight, g_trace_leaf_weight;
-extern int g_shade_fwd_rows;
-extern int g_shade_bwd_rows;
 extern int g_shade_row_blocks_per_cu;
 void launch_shade_backward(hipStream_t s, int P, int K, int M, const float* base_color, const float* roughness,
                            const float* normals, const float* viewdirs, const float* incidents, const float* env,
                            int He, int We, const float* tr, const float* visibility, const float* dirs,
                            const float* areas, const float* g_pbr, const float* g_diff, float* d_base, float* d_rough,
-                           float* d_view, float* d_inc, float* d_env, const uint32_t* taps, const float* block_absmax, int n_block_absmax);
+                           float* d_view, float* d_inc, float* d_env, const uint32_t* taps, const float* block_absmax, int n_block_absmax,
+                           const int* list = nullptr, int n_list = 0);
 void launch_re_forward(hipStream_t s, bool complex_, int P, int Si, int Sd, int Sv, const float* base_color,
                        const float* roughness, const float* metallic, const float* normals, const float* viewdirs,
                        const float* inc, const float* direct, const float* vis, int K, const float* rand_float,
@@ -183,7 +200,6 @@ void bvh_trace_opacity_packed(hipStream_t s, int num_rays, int P, void* records,
 int g_reserve_cus = 0;
 extern int g_cull;
 extern int g_stage_sh_rows;
-extern int g_shade_fwd_blocks_per_cu;
 int g_tile_binning = 2;   // 2: instances emitted straight into their tile's segment + per-tile LDS sort; 1: emitted in Gaussian
                           // order, radix-partitioned by tile, per-tile LDS sort; 0: the reference's global (tile|depth) radix sort
 extern int g_fwd_wave8x8;
@@ -193,7 +209,6 @@ extern int g_fwd_unroll;
 extern int g_bwd_unroll;
 int g_tile_order = 1;   // 1: longest-tile-first block order, 0: XCD-contiguous natural order
 extern int g_bwd_ppl;
-extern int g_bwd_dpp;
 void launch_transpose_selftest(hipStream_t s, int N, int dpp, const float* in, float* out, int* chan, int* owner);
 
 // ---- optional per-stage timing with HIP events on the launch stream (bench.py's roofline numbers) ----
@@ -319,6 +334,29 @@ static int invalid(const std::string& msg)
     return R3DG_EINVAL;
 }
 
+void* stream_scratch(hipStream_t stream, int slot, size_t bytes)
+{
+    struct Buf { void* p = nullptr; size_t cap = 0; };
+    static std::mutex mu;
+    static std::map<std::tuple<int, hipStream_t, int>, Buf> bufs;
+    int dev = 0;
+    R3DG_HIP(hipGetDevice(&dev));
+    std::lock_guard<std::mutex> lk(mu);
+    Buf& b = bufs[std::make_tuple(dev, stream, slot)];
+    if (b.cap < bytes) {
+        if (b.p != nullptr) {
+            R3DG_HIP(hipStreamSynchronize(stream));        // only this stream ever used the old buffer
+            R3DG_HIP(hipFree(b.p));
+            b.p = nullptr;
+            b.cap = 0;
+        }
+        const size_t want = bytes + bytes / 8 + 4096;
+        R3DG_HIP(hipMalloc(&b.p, want));
+        b.cap = want;
+    }
+    return b.p;
+}
+
 }  // namespace r3dg
 
 using namespace r3dg;
@@ -336,68 +374,55 @@ int r3dg_bounded_forward_supported(int width, int height)
     return g_tile_binning == 2 && gx * gy <= (long long)tile_binning_max_tiles() ? 1 : 0;
 }
 
-// tuning knobs (pixels per lane of the two render kernels); not part of the drop-in surface
-int r3dg_set_tuning6(int shade_forward_blocks_per_cu)
-{
-    if (shade_forward_blocks_per_cu >= 1 && shade_forward_blocks_per_cu <= 8)
-        g_shade_fwd_blocks_per_cu = shade_forward_blocks_per_cu;
-    return R3DG_OK;
-}
 
-int r3dg_set_tuning8(int trace_packet)
+
+
+
+
+
+
+
+// tuning / experiment knobs; not part of the drop-in surface (include/r3dg_hip.h "r3dg_option")
+static int* option_slot(int option)
 {
-    if (trace_packet >= 0) {
-        // low byte: formulation; experiments: bits 8-15 refill threshold, 16-19 node weight, 20-23 leaf weight of the vote
-        if ((trace_packet & 0xff) <= 4) g_trace_packet = trace_packet & 0xff;
-        if ((trace_packet >> 8) & 0xff) g_trace_refill = (trace_packet >> 8) & 0xff;
-        if ((trace_packet >> 16) & 0xf) g_trace_node_weight = (trace_packet >> 16) & 0xf;
-        if ((trace_packet >> 20) & 0xf) g_trace_leaf_weight = (trace_packet >> 20) & 0xf;
+    switch (option) {
+        case R3DG_OPT_FWD_PIXELS_PER_LANE: return &g_fwd_ppl;
+        case R3DG_OPT_BWD_PIXELS_PER_LANE: return &g_bwd_ppl;
+        case R3DG_OPT_FWD_UNROLL: return &g_fwd_unroll;
+        case R3DG_OPT_BWD_UNROLL: return &g_bwd_unroll;
+        case R3DG_OPT_TILE_ORDER: return &g_tile_order;
+        case R3DG_OPT_FWD_WAVE8X8: return &g_fwd_wave8x8;
+        case R3DG_OPT_BWD_WAVE8X8: return &g_bwd_wave8x8;
+        case R3DG_OPT_CULL: return &g_cull;
+        case R3DG_OPT_TILE_BINNING: return &g_tile_binning;
+        case R3DG_OPT_BINNING_BLOCK_K: return &g_bin_iters;
+        case R3DG_OPT_STAGE_SH_ROWS: return &g_stage_sh_rows;
+        case R3DG_OPT_SHADE_FWD_BLOCKS_PER_CU: return &g_shade_row_blocks_per_cu;
+        case R3DG_OPT_TRACE_FORMULATION: return &g_trace_packet;
+        case R3DG_OPT_TRACE_REFILL: return &g_trace_refill;
+        case R3DG_OPT_TRACE_NODE_WEIGHT: return &g_trace_node_weight;
+        case R3DG_OPT_TRACE_LEAF_WEIGHT: return &g_trace_leaf_weight;
+        case R3DG_OPT_RESERVE_CUS: return &g_reserve_cus;
+        default: return nullptr;
     }
+}
+
+int r3dg_set_option(int option, int value)
+{
+    static const int lo[R3DG_OPT_COUNT] = {1, 1, 1, 1, 0, 0, 0, 0, 0, 1, 0, 0, 0, 1, 1, 1, 0};
+    static const int hi[R3DG_OPT_COUNT] = {4, 2, 4, 4, 1, 1, 1, 1, 2, 64, 1, 8, 4, 64, 15, 15, 128};
+    int* slot = option_slot(option);
+    if (slot == nullptr) return invalid("set_option: unknown option");
+    if (value < lo[option] || value > hi[option]) return invalid("set_option: value out of range");
+    *slot = value;
     return R3DG_OK;
 }
 
-int r3dg_set_tuning9(int shade_backward_rows)
+int r3dg_get_option(int option, int* value)
 {
-    if (shade_backward_rows >= 0) g_shade_bwd_rows = shade_backward_rows ? 1 : 0;
-    return R3DG_OK;
-}
-
-int r3dg_set_tuning5(int stage_sh_rows)
-{
-    if (stage_sh_rows >= 0) g_stage_sh_rows = stage_sh_rows;
-    return R3DG_OK;
-}
-
-int r3dg_set_tuning4(int tile_binning)
-{
-    if (tile_binning >= 0) {
-        g_tile_binning = tile_binning & 0xff;
-        if (tile_binning >> 8) g_bin_iters = tile_binning >> 8;      // experiments: Gaussians per binning block / 1024
-    }
-    return R3DG_OK;
-}
-
-int r3dg_set_tuning3(int fwd_wave8x8, int bwd_wave8x8, int cull)
-{
-    if (cull >= 0) g_cull = cull;
-    if (fwd_wave8x8 >= 0) g_fwd_wave8x8 = fwd_wave8x8;
-    if (bwd_wave8x8 >= 0) g_bwd_wave8x8 = bwd_wave8x8;
-    return R3DG_OK;
-}
-
-int r3dg_set_tuning2(int fwd_unroll, int bwd_unroll, int tile_order)
-{
-    if (fwd_unroll > 0) g_fwd_unroll = fwd_unroll;
-    if (bwd_unroll > 0) g_bwd_unroll = bwd_unroll;
-    if (tile_order >= 0) g_tile_order = tile_order;
-    return R3DG_OK;
-}
-
-int r3dg_set_tuning(int fwd_pixels_per_lane, int bwd_pixels_per_lane, int bwd_dpp_reduce)
-{
-    if (fwd_pixels_per_lane > 0) g_fwd_ppl = fwd_pixels_per_lane;
-    if (bwd_pixels_per_lane > 0) g_bwd_ppl = bwd_pixels_per_lane;
-    if (bwd_dpp_reduce >= 0) g_bwd_dpp = bwd_dpp_reduce;
+    int* slot = option_slot(option);
+    if (slot == nullptr || value == nullptr) return invalid("get_option: unknown option or null pointer");
+    *value = *slot;
     return R3DG_OK;
 }
 
@@ -1137,12 +1162,6 @@ int r3dg_shade_forward_transport(void* stream_, int P, int K, const float* base_
     });
 }
 
-int r3dg_set_tuning7(int shade_forward_rows, int row_blocks_per_cu)
-{
-    if (shade_forward_rows >= 0 && shade_forward_rows <= 2) g_shade_fwd_rows = shade_forward_rows;
-    if (row_blocks_per_cu >= 0) g_shade_row_blocks_per_cu = row_blocks_per_cu;
-    return R3DG_OK;
-}
 
 int r3dg_shade_backward_cached(void* stream_, int P, int K, int M, const float* base_color, const float* roughness,
                                const float* normals, const float* viewdirs, const float* incidents, const float* env,
@@ -1165,6 +1184,86 @@ int r3dg_shade_backward_cached(void* stream_, int P, int K, int M, const float* 
                               dL_dbase_color, dL_droughness, dL_dviewdirs, dL_dincidents, dL_denv, taps, block_absmax,
                               n_block_absmax);
         check_launch(stream, false, "shade_backward");
+        t.stop();
+        return R3DG_OK;
+    });
+}
+
+size_t r3dg_shade_frs_tables_bytes(int K) { return K > 0 ? shade_frs_table_floats(K) * sizeof(float) : 0; }
+
+int r3dg_shade_frs_supported(int K, int M, int He, int We) { return shade_frs_supported(K, M, He, We) ? 1 : 0; }
+
+int r3dg_shade_frs_build_tables(void* stream_, int K, const float* zsamples, float* tables)
+{
+    if (K <= 0 || !zsamples || !tables) return invalid("shade_frs_build_tables: bad K or null buffer");
+    return guarded([&]() -> int {
+        launch_shade_frs_build_tables((hipStream_t)stream_, K, zsamples, tables);
+        return R3DG_OK;
+    });
+}
+
+int r3dg_shade_frs_classify(void* stream_, int P, const float* ray_normals, uint8_t* valid)
+{
+    if (P < 0) return invalid("shade_frs_classify: bad P");
+    if (P == 0) return R3DG_OK;
+    if (!ray_normals || !valid) return invalid("shade_frs_classify: null buffer");
+    return guarded([&]() -> int {
+        launch_shade_frs_classify((hipStream_t)stream_, P, ray_normals, valid);
+        return R3DG_OK;
+    });
+}
+
+int r3dg_shade_frs_forward(void* stream_, int P, int K, const float* base_color, const float* roughness,
+                           const float* normals, const float* viewdirs, const float* incidents, const float* env, int He,
+                           int We, const float* visibility, const float* incident_dirs, const float* incident_areas,
+                           float uniform_area, const uint32_t* taps, const float* ray_normals, const float* tables,
+                           const uint8_t* valid, const int32_t* invalid_list, int n_invalid, float* cprime, int flags,
+                           float* out)
+{
+    if (P < 0 || K <= 0 || He <= 0 || We <= 0 || n_invalid < 0 || n_invalid > P) return invalid("shade_frs_forward: bad sizes");
+    if (!shade_frs_supported(K, 16, He, We))
+        return invalid("shade_frs_forward: needs K % 4 == 0 and an environment texture that fits LDS (r3dg_shade_frs_supported)");
+    if (P == 0) return R3DG_OK;
+    if (!base_color || !roughness || !normals || !viewdirs || !incidents || !env || !visibility || !incident_dirs || !taps ||
+        !ray_normals || !tables || !valid || !cprime || !out || (n_invalid > 0 && !invalid_list))
+        return invalid("shade_frs_forward: null buffer");
+    if (n_invalid > 0 && !incident_areas && !(uniform_area > 0.f)) return invalid("shade_frs_forward: no sample areas");
+    return guarded([&]() -> int {
+        hipStream_t stream = (hipStream_t)stream_;
+        StageTimer t(stream, ST_SHADE_FWD);
+        launch_shade_frs_forward(stream, P, K, base_color, roughness, normals, viewdirs, incidents, env, He, We, visibility,
+                                 incident_dirs, incident_areas, uniform_area, taps, ray_normals, tables, valid, invalid_list,
+                                 n_invalid, cprime, (flags & R3DG_SHADE_LEAVE_ROOM) != 0, out);
+        t.stop();
+        return R3DG_OK;
+    });
+}
+
+int r3dg_shade_frs_backward(void* stream_, int P, int K, const float* base_color, const float* roughness,
+                            const float* normals, const float* viewdirs, const float* incidents, const float* env, int He,
+                            int We, const float* visibility, const float* incident_dirs, const float* incident_areas,
+                            float uniform_area, const uint32_t* taps, const float* ray_normals, const float* tables,
+                            const uint8_t* valid, const int32_t* invalid_list, int n_invalid, const float* cprime,
+                            float* dcprime, const float* dL_dpbr, const float* dL_ddiffuse_light, float* dL_dbase_color,
+                            float* dL_droughness, float* dL_dviewdirs, float* dL_dincidents, float* dL_denv,
+                            const float* block_absmax, int n_block_absmax)
+{
+    if (P < 0 || K <= 0 || He <= 0 || We <= 0 || n_invalid < 0 || n_invalid > P || n_block_absmax < 0)
+        return invalid("shade_frs_backward: bad sizes");
+    if (!shade_frs_supported(K, 16, He, We))
+        return invalid("shade_frs_backward: needs K % 4 == 0 and an environment texture that fits LDS (r3dg_shade_frs_supported)");
+    if (P == 0) return R3DG_OK;
+    if (!base_color || !roughness || !normals || !viewdirs || !incidents || !env || !visibility || !incident_dirs || !taps ||
+        !ray_normals || !tables || !valid || !cprime || !dcprime || !dL_dpbr || !dL_ddiffuse_light || !dL_dbase_color ||
+        !dL_droughness || !dL_dviewdirs || !dL_dincidents || !dL_denv || (n_invalid > 0 && (!invalid_list || !incident_areas)))
+        return invalid("shade_frs_backward: null buffer");
+    return guarded([&]() -> int {
+        hipStream_t stream = (hipStream_t)stream_;
+        StageTimer t(stream, ST_SHADE_BWD);
+        launch_shade_frs_backward(stream, P, K, base_color, roughness, normals, viewdirs, incidents, env, He, We, visibility,
+                                  incident_dirs, incident_areas, uniform_area, taps, ray_normals, tables, valid, invalid_list,
+                                  n_invalid, cprime, dcprime, dL_dpbr, dL_ddiffuse_light, dL_dbase_color, dL_droughness,
+                                  dL_dviewdirs, dL_dincidents, dL_denv, block_absmax, n_block_absmax);
         t.stop();
         return R3DG_OK;
     });

@@ -53,6 +53,11 @@ static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; 
 // (r3dg_set_option(R3DG_OPT_RESERVE_CUS)).
 extern int g_reserve_cus;
 
+// Library-internal device scratch: one grow-only buffer per (device, stream, slot); the pointer stays valid until the next
+// call with the same key asks for more (growth synchronises THAT stream only, so nothing else can still be using the old
+// buffer).  Kernels of different streams or host threads never share scratch.  (capi.hip)
+void* stream_scratch(hipStream_t stream, int slot, size_t bytes);
+
 struct GeometryLayout {  // byte offsets into the opaque geometry buffer
     size_t depths, clamped, radii, means2D, cov3D, conic_opacity, rgb, tiles_touched, point_offsets, block_sums,
         total, splat, bytes;

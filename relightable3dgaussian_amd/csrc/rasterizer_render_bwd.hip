@@ -508,7 +508,6 @@ void launch_render_backward_features(hipStream_t s, int W, int H, int S, int n_a
 extern int g_cull;
 int g_bwd_wave8x8 = 1;  // measured: 8x8 blocks -6% (fewer waves touched per Gaussian); the forward prefers strips
 int g_bwd_ppl = 1;
-int g_bwd_dpp = 1;      // kept for the self-test entry point; the tile kernel always uses the DPP/permlane reduction
 int g_bwd_unroll = 1;   // staged entries evaluated per inner-loop step
 
 template <int SPAD, int PPL>

@@ -219,9 +219,12 @@ render_forward_kernel(const uint2* __restrict__ ranges, const uint32_t* __restri
                     }
                 }
                 // wave total -> SGPR -> one lane issues the atomic (a wave-uniform value keeps the compiler's
-                // uniform-address atomic rewrite down to a couple of scalar instructions)
-                const float wtot = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(wave_sum_to_lane63(wsum)), 63));
-                if (lane == 0) atomicAdd(&out_weights[__float_as_uint(g1[u].w)], wtot);
+                // uniform-address atomic rewrite down to a couple of scalar instructions).  out_weights == NULL (a caller
+                // that does not read the per-Gaussian blend weights -- only densification does): nothing to reduce
+                if (out_weights != nullptr) {
+                    const float wtot = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(wave_sum_to_lane63(wsum)), 63));
+                    if (lane == 0) atomicAdd(&out_weights[__float_as_uint(g1[u].w)], wtot);
+                }
             }
           }
         }

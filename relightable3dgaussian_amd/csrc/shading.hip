@@ -18,6 +18,8 @@
 //   * backward only: record + samples of the wave's NEXT 64-sample block arrive by LDS-DMA (global_load_lds_dwordx4),
 //     double buffered, while the current block is computed (three passes per block, 12 parked floats per lane).
 #include "common.hpp"
+#include <map>
+#include <mutex>
 #include <stdexcept>
 #include "wave_reduce.hpp"
 #include "shading_math.hpp"
@@ -161,24 +163,6 @@ struct SampleFwd {
 
 // Layout of the per-wave uniform record u[64]: 0..47 SH coefficients (i*3+c), 48..50 albedo, 51 roughness,
 // 52..54 normal, 55..57 view direction, 58..60 dL_dpbr, 61..63 dL_ddiffuse_light (the last six only in the backward).
-__device__ __forceinline__ float load_uniform_element(int lane, int g, int M, const float* __restrict__ base_color,
-                                                      const float* __restrict__ roughness,
-                                                      const float* __restrict__ normals,
-                                                      const float* __restrict__ viewdirs,
-                                                      const float* __restrict__ incidents,
-                                                      const float* __restrict__ g_pbr, const float* __restrict__ g_diff)
-{
-    const float* p = nullptr;
-    if (lane < 48) { if (lane < 3 * M) p = incidents + (size_t)g * M * 3 + lane; }
-    else if (lane < 51) p = base_color + 3 * (size_t)g + (lane - 48);
-    else if (lane == 51) p = roughness + g;
-    else if (lane < 55) p = normals + 3 * (size_t)g + (lane - 52);
-    else if (lane < 58) p = viewdirs + 3 * (size_t)g + (lane - 55);
-    else if (lane < 61) { if (g_pbr) p = g_pbr + 3 * (size_t)g + (lane - 58); }
-    else { if (g_diff) p = g_diff + 3 * (size_t)g + (lane - 61); }
-    return p ? *p : 0.f;
-}
-
 template <bool ENV_LDS, bool HAVE_SHSUM = false, bool HAVE_TAP = false>
 __device__ __forceinline__ void shade_sample(SampleFwd& s, const GaussFwd& G, const float* sh /*[48] in LDS, zero padded*/,
                                              int M, float dx, float dy, float dz, float vis, float area,
@@ -309,7 +293,9 @@ constexpr int SB_U = 0, SB_DIRS = 272, SB_VIS = 1040, SB_AREA = 1296, SB_FLOATS 
 struct ShadeSrc {
     const float *base_color, *roughness, *normals, *viewdirs, *incidents, *g_pbr, *g_diff, *zero;
     const float *dirs, *vis, *areas;
+    const int* list;         // optional: the kernel's Gaussian i is row list[i] of every array (a subset of the Gaussians)
 };
+__device__ __forceinline__ int shade_row_of(const ShadeSrc& p, int i) { return p.list != nullptr ? p.list[i] : i; }
 
 __device__ __forceinline__ const float* uniform_src(int e, int g, int M, const ShadeSrc& p)
 {
@@ -326,21 +312,21 @@ __device__ __forceinline__ const float* uniform_src(int e, int g, int M, const S
 
 template <bool VEC16>
 __device__ __forceinline__ void issue_block_loads(int lane, int gb, int k0, int P, int K, int M, const ShadeSrc& p,
-                                                  float* sb /* one SB_FLOATS buffer of this wave */)
+                                                  float* sb /* one SB_FLOATS buffer of this wave */, size_t total /* samples in the arrays */)
 {
 #pragma unroll
-    for (int t = 0; t < SH_GW; t++) R3DG_GLDS(uniform_src(lane, min(gb + t, P - 1), M, p), sb + SB_U + SB_USTRIDE * t, 4);
-    const size_t total = (size_t)P * K;
+    for (int t = 0; t < SH_GW; t++)
+        R3DG_GLDS(uniform_src(lane, shade_row_of(p, min(gb + t, P - 1)), M, p), sb + SB_U + SB_USTRIDE * t, 4);
     if (VEC16) {
 #pragma unroll
         for (int j = 0; j < 3; j++) {
             const int f = (j * 64 + lane) * 4, grp = f / 192, w = f % 192;
-            size_t idx = ((size_t)min(gb + grp, P - 1) * K + k0) * 3 + w;
+            size_t idx = ((size_t)shade_row_of(p, min(gb + grp, P - 1)) * K + k0) * 3 + w;
             idx = idx < 3 * total - 4 ? idx : 3 * total - 4;          // ragged last block: stay inside the array
             R3DG_GLDS(p.dirs + idx, sb + SB_DIRS + 256 * j, 16);
         }
         const int f = lane * 4, grp = f / 64, w = f % 64;
-        size_t idx = (size_t)min(gb + grp, P - 1) * K + k0 + w;
+        size_t idx = (size_t)shade_row_of(p, min(gb + grp, P - 1)) * K + k0 + w;
         idx = idx < total - 4 ? idx : total - 4;
         R3DG_GLDS(p.vis + idx, sb + SB_VIS, 16);
         R3DG_GLDS(p.areas + idx, sb + SB_AREA, 16);
@@ -348,14 +334,14 @@ __device__ __forceinline__ void issue_block_loads(int lane, int gb, int k0, int 
 #pragma unroll
         for (int j = 0; j < 12; j++) {
             const int f = j * 64 + lane, grp = f / 192, w = f % 192;
-            size_t idx = ((size_t)min(gb + grp, P - 1) * K + k0) * 3 + w;
+            size_t idx = ((size_t)shade_row_of(p, min(gb + grp, P - 1)) * K + k0) * 3 + w;
             idx = idx < 3 * total - 1 ? idx : 3 * total - 1;
             R3DG_GLDS(p.dirs + idx, sb + SB_DIRS + 64 * j, 4);
         }
 #pragma unroll
         for (int j = 0; j < 4; j++) {
             const int f = j * 64 + lane, grp = f / 64, w = f % 64;
-            size_t idx = (size_t)min(gb + grp, P - 1) * K + k0 + w;
+            size_t idx = (size_t)shade_row_of(p, min(gb + grp, P - 1)) * K + k0 + w;
             idx = idx < total - 1 ? idx : total - 1;
             R3DG_GLDS(p.vis + idx, sb + SB_VIS + 64 * j, 4);
             R3DG_GLDS(p.areas + idx, sb + SB_AREA + 64 * j, 4);
@@ -365,71 +351,6 @@ __device__ __forceinline__ void issue_block_loads(int lane, int gb, int k0, int 
 
 // all DMA loads of this wave have landed (they are the only vector-memory loads in the steady-state loop)
 __device__ __forceinline__ void wait_block_loads() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
-
-// Forward: direct loads (its register budget allows more waves per SIMD than the backward, and measured faster than the
-// DMA-staged variant: 0.27 vs 0.34 ms at P=300k, K=64).
-template <bool ENV_LDS>
-__global__ void __launch_bounds__(64 * SHADE_WAVES, 2)
-shade_forward_kernel(int P, int K, int M, const float* __restrict__ base_color, const float* __restrict__ roughness,
-                     const float* __restrict__ normals, const float* __restrict__ viewdirs,
-                     const float* __restrict__ incidents, const float* __restrict__ env, int He, int We,
-                     const float* __restrict__ tr, const float* __restrict__ visibility,
-                     const float* __restrict__ dirs, const float* __restrict__ areas, float* __restrict__ out)
-{
-    extern __shared__ __attribute__((aligned(16))) float s_mem[];
-    const int ntex = ENV_LDS ? ((He * We * 3 + 3) & ~3) : 0;
-    float* s_env = s_mem;
-    if (ENV_LDS) {
-        for (int i = threadIdx.x; i < He * We * 3; i += blockDim.x) s_env[i] = env[i];
-        __syncthreads();
-    }
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int grp = lane >> 4, l = lane & 15;
-    float* s_u = s_mem + ntex + (wave * SH_GW + grp) * 64;
-    const float invK = 1.0f / (float)K;
-    for (int gb = (blockIdx.x * SHADE_WAVES + wave) * SH_GW; gb < P; gb += gridDim.x * SH_GB) {
-        const int g = gb + grp;
-        const bool live = g < P;
-        // stage the Gaussian's 64-float uniform record: 4 elements per lane
-#pragma unroll
-        for (int t = 0; t < 4; t++)
-            s_u[l + 16 * t] = live ? load_uniform_element(l + 16 * t, g, M, base_color, roughness, normals, viewdirs,
-                                                          incidents, nullptr, nullptr) : 0.f;
-        GaussFwd G;
-        gauss_setup(G, s_u);
-        float v[32];
-#pragma unroll
-        for (int i = 0; i < 32; i++) v[i] = 0.f;
-        if (live) {
-            for (int k = l; k < K; k += SH_L) {
-                const size_t o = (size_t)g * K + k;
-                SampleFwd s;
-                shade_sample<ENV_LDS>(s, G, s_u, M, dirs[3 * o], dirs[3 * o + 1], dirs[3 * o + 2], visibility[o],
-                                      areas[o], env, s_env, tr, He, We);
-#pragma unroll
-                for (int c = 0; c < 3; c++) {
-                    const float fd = G.base[c] / kPi;
-                    v[c] += (fd + s.spec) * s.transport[c];      // pbr
-                    v[3 + c] += s.transport[c];                  // diffuse_light
-                    v[6 + c] += s.spec * s.transport[c];         // specular
-                    v[9 + c] += s.lin[c];                        // incident_lights mean
-                    v[12 + c] += s.local[c];
-                    v[15 + c] += s.glob[c];
-                }
-                v[18] += s.vis;
-            }
-        }
-        float va[16], vb[16];
-#pragma unroll
-        for (int i = 0; i < 16; i++) { va[i] = v[i]; vb[i] = v[16 + i]; }
-        const float r0 = row_transpose_reduce16(va);
-        const float r1 = row_transpose_reduce16(vb);
-        if (live) {
-            out[(size_t)g * SHADE_NOUT + l] = r0 * invK;
-            if (l < SHADE_NOUT - 16) out[(size_t)g * SHADE_NOUT + 16 + l] = r1 * invK;
-        }
-    }
-}
 
 // =====================================================================================================================
 // Forward, second formulation ("row" kernels): ONE WAVE PER GAUSSIAN, lane = sample.
@@ -539,6 +460,7 @@ struct RowSample {            // one lane's share of a (Gaussian, 64-sample bloc
     float dx, dy, dz, vis, area;
     PackedTap t;
     float rec;                // element `lane` of the Gaussian's 64-float record
+    int row;                  // the Gaussian's row in every array (wave-uniform)
 };
 
 // `g` is wave-uniform (callers derive it from readfirstlane'd values): the row bases are computed on the scalar unit and the
@@ -552,6 +474,7 @@ __device__ __forceinline__ RowSample load_row_sample(bool live, int g, int lane,
                                                      const float* __restrict__ incidents = nullptr, int M = 16)
 {
     RowSample r;
+    r.row = g;
     r.dx = 0.f; r.dy = 0.f; r.dz = 1.f; r.vis = 0.f; r.area = 0.f;
     r.t.xy = 0x00010001u; r.t.wx1 = 0.f; r.t.wy1 = 0.f;
     const size_t row = (size_t)g * (size_t)K;
@@ -589,8 +512,9 @@ shade_forward_row_kernel(int P, int K, int M_, const float* __restrict__ rec, co
                          const float4* __restrict__ env4, int He, int We,
                          const float* __restrict__ tr, const float* __restrict__ visibility,
                          const float* __restrict__ dirs, const float* __restrict__ areas, float uniform_area,
-                         const uint32_t* __restrict__ taps, float* __restrict__ out)
+                         const uint32_t* __restrict__ taps, float* __restrict__ out, const int* __restrict__ list)
 {
+    // `list` != nullptr: P counts the listed Gaussians and Gaussian i of this launch is row list[i] of every array
     static_assert(NOUT == 7 || NOUT == 19, "training (pbr, diffuse_light, mean visibility) or all 19 outputs");
     constexpr int NV = NOUT == 7 ? 8 : 32;
     const int M = M16 ? 16 : M_;                 // degree-3 incident light (the reference's only configuration) folds the
@@ -616,7 +540,8 @@ shade_forward_row_kernel(int P, int K, int M_, const float* __restrict__ rec, co
     };
     auto fetch = [&](int ag, int akb) {
         const int k = akb * 64 + lane;
-        const int gg = min(ag, P - 1);
+        int gg = min(ag, P - 1);
+        if (list != nullptr) gg = __builtin_amdgcn_readfirstlane(list[gg]);
         return load_row_sample<TAPS>(ag < P && k < K, gg, lane, (unsigned)k, K, rec, dirs, visibility, areas,
                                      uniform_area, taps, 16, incidents, M);
     };
@@ -702,9 +627,9 @@ shade_forward_row_kernel(int P, int K, int M_, const float* __restrict__ rec, co
             const int ch = transposed_channel<NV>(lane);
             if (transposed_owner<NV>(lane)) {
                 if (NOUT == 19) {
-                    if (ch < 19) out[(size_t)g * SHADE_NOUT + ch] = r * invK;
+                    if (ch < 19) out[(size_t)cur.row * SHADE_NOUT + ch] = r * invK;
                 } else if (ch < 7) {
-                    out[(size_t)g * SHADE_NOUT + (ch < 6 ? ch : 18)] = r * invK;
+                    out[(size_t)cur.row * SHADE_NOUT + (ch < 6 ? ch : 18)] = r * invK;
                 }
             }
 #pragma unroll
@@ -714,250 +639,6 @@ shade_forward_row_kernel(int P, int K, int M_, const float* __restrict__ rec, co
         nx1 = nx2;
         g = g1; kb = kb1;
         g1 = g2; kb1 = kb2;
-    }
-}
-
-// =====================================================================================================================
-// Forward, third formulation ("pair" kernel): the row kernel with TWO SAMPLES PER LANE.
-// The row kernel is saturated on VALU issue (PMC: SQ busy 1.0; 290 instructions per 64 samples, 176 of them plain fp32
-// multiplies / adds / FMAs).  gfx950 executes v_pk_{mul,add,fma}_f32 -- two fp32 operations per lane -- at the rate of the
-// scalar forms, so the arithmetic is done on float2 values holding samples k and k+32 of the lane's Gaussian: a wave
-// carries two Gaussians (lanes 0..31 / 32..63), each lane two of the 64 samples of a block.  Per-Gaussian factors stay
-// scalar broadcasts (the packed forms take them through op_sel), the texture taps, reciprocal square roots, exp2 and
-// clamps have no packed form and run once per sample, the reduction runs inside each half-wave.  Same arithmetic per
-// sample as the row kernel (sums are formed in a different order).  Cached lookups only (TAPS 1 / 2), degree-3 light.
-// MEASURED, NOT THE DEFAULT (r3dg_set_tuning7(2) selects it): 372 instead of 2 x 290 VALU instructions per 128 samples
-// (-36 %), but 0.190 vs 0.194 ms stand-alone, 551 vs 553 it/s inside the iteration and 711 vs 749 relight FPS -- on this
-// part v_pk_fma_f32 issues at only 1.27x the lane rate of v_fma_f32 (tools/pk_rate.hip: 90 vs 71 lane-FMAs per clock
-// and CU), and the kernel pays for its 178 VGPRs with one wave per SIMD less.
-// =====================================================================================================================
-typedef float f2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ f2 splat2(float x) { return (f2){x, x}; }
-__device__ __forceinline__ f2 max2(f2 a, float b) { return (f2){fmaxf(a.x, b), fmaxf(a.y, b)}; }
-__device__ __forceinline__ f2 clamp2(f2 a, float lo, float hi)
-{
-    return (f2){fminf(fmaxf(a.x, lo), hi), fminf(fmaxf(a.y, lo), hi)};
-}
-__device__ __forceinline__ f2 rsq2(f2 a) { return (f2){__builtin_amdgcn_rsqf(a.x), __builtin_amdgcn_rsqf(a.y)}; }
-
-__device__ __forceinline__ void sh_basis16_pair(f2 x, f2 y, f2 z, f2 (&Y)[16])
-{
-    const float C0 = 0.28209479177387814f, C1 = 0.4886025119029199f;
-    Y[0] = splat2(C0);
-    Y[1] = -C1 * y; Y[2] = C1 * z; Y[3] = -C1 * x;
-    const f2 xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
-    Y[4] = 1.0925484305920792f * xy;
-    Y[5] = -1.0925484305920792f * yz;
-    Y[6] = 0.31539156525252005f * (2.0f * zz - xx - yy);
-    Y[7] = -1.0925484305920792f * xz;
-    Y[8] = 0.5462742152960396f * (xx - yy);
-    Y[9] = -0.5900435899266435f * y * (3.f * xx - yy);
-    Y[10] = 2.890611442640554f * xy * z;
-    Y[11] = -0.4570457994644658f * y * (4.f * zz - xx - yy);
-    Y[12] = 0.3731763325901154f * z * (2.f * zz - 3.f * xx - 3.f * yy);
-    Y[13] = -0.4570457994644658f * x * (4.f * zz - xx - yy);
-    Y[14] = 1.445305721320277f * z * (xx - yy);
-    Y[15] = -0.5900435899266435f * x * (xx - 3.f * yy);
-}
-
-struct PairSample {           // one lane's share of a (Gaussian pair, 64-sample block): samples k (.x) and k + 32 (.y)
-    f2 dx, dy, dz, vis, area;
-    uint32_t ta[3], tb[3];    // the two cached lookups (TAPS 1: packed tap; TAPS 2: radiance bits)
-    f2 rec;                   // elements l and l + 32 of the lane's Gaussian's 64-float record
-};
-
-// Branch-free: lanes beyond K or P read a clamped (valid) address and the caller masks their contribution -- zero-filled
-// defaults behind EXEC-masked loads cost ~35 moves per block here.
-template <int TAPS>
-__device__ __forceinline__ PairSample load_pair_sample(int g /* wave-uniform pair base, < P */, int akb, int lane, int P,
-                                                       int K, const float* __restrict__ rec16,
-                                                       const float* __restrict__ incidents,
-                                                       const float* __restrict__ dirs,
-                                                       const float* __restrict__ visibility,
-                                                       const float* __restrict__ areas, float uniform_area,
-                                                       const uint32_t* __restrict__ taps)
-{
-    PairSample r;
-    const unsigned l = (unsigned)lane & 31u;
-    const unsigned h = ((unsigned)lane >> 5) & (g + 1 < P ? 1u : 0u);       // a missing partner re-reads the first Gaussian
-    // rows of the pair's FIRST Gaussian on the scalar unit; the second one is K samples / one record further
-    const size_t row = (size_t)g * (size_t)K;
-    const unsigned ka = min((unsigned)akb * 64u + l, (unsigned)K - 1u), kb = min((unsigned)akb * 64u + l + 32u, (unsigned)K - 1u);
-    const unsigned oa = h * (unsigned)K + ka, ob = h * (unsigned)K + kb;
-    const float* __restrict__ inc = incidents + (size_t)g * 48;
-    r.rec.x = inc[h * 48u + l];
-    const float* __restrict__ second = l < 16u ? inc + (h * 48u + 32u + l) : rec16 + (size_t)g * 16 + (h * 16u + (l - 16u));
-    r.rec.y = *second;
-    const float* __restrict__ drow = dirs + 3 * row;
-    const float* __restrict__ vrow = visibility + row;
-    const float3 da = *reinterpret_cast<const float3*>(drow + 3u * oa);
-    const float3 db = *reinterpret_cast<const float3*>(drow + 3u * ob);
-    r.dx = (f2){da.x, db.x}; r.dy = (f2){da.y, db.y}; r.dz = (f2){da.z, db.z};
-    r.vis = (f2){vrow[oa], vrow[ob]};
-    r.area = areas != nullptr ? (f2){(areas + row)[oa], (areas + row)[ob]} : splat2(uniform_area);
-    const uint3 ta = *reinterpret_cast<const uint3*>(taps + 3 * row + 3u * oa);
-    const uint3 tb = *reinterpret_cast<const uint3*>(taps + 3 * row + 3u * ob);
-    r.ta[0] = ta.x; r.ta[1] = ta.y; r.ta[2] = ta.z;
-    r.tb[0] = tb.x; r.tb[1] = tb.y; r.tb[2] = tb.z;
-    return r;
-}
-
-template <int NOUT, bool ENV_LDS, int TAPS /* 1 cached lookup, 2 cached radiance */>
-__global__ void __launch_bounds__(64 * ROW_WAVES)
-shade_forward_pair_kernel(int P, int K, const float* __restrict__ rec16, const float* __restrict__ incidents,
-                          const float4* __restrict__ env4, int He, int We, const float* __restrict__ visibility,
-                          const float* __restrict__ dirs, const float* __restrict__ areas, float uniform_area,
-                          const uint32_t* __restrict__ taps, float* __restrict__ out)
-{
-    static_assert(NOUT == 7 || NOUT == 19, "training (pbr, diffuse_light, mean visibility) or all 19 outputs");
-    static_assert(TAPS == 1 || TAPS == 2, "cached lookups only");
-    constexpr int NV = NOUT == 7 ? 8 : 32;
-    extern __shared__ __attribute__((aligned(16))) float s_mem[];
-    __shared__ __attribute__((aligned(16))) float s_rec[ROW_WAVES][2][REC];
-    float4* s_env4 = reinterpret_cast<float4*>(s_mem);
-    if (ENV_LDS && TAPS != 2) {
-        for (int i = threadIdx.x; i < He * We; i += blockDim.x) s_env4[i] = env4[i];
-        __syncthreads();
-    }
-    const float4* tex4 = ENV_LDS ? s_env4 : env4;
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int h = lane >> 5, l = lane & 31;
-    float* u = s_rec[wave][h];
-    const float invK = 1.0f / (float)K;
-    const int nblk = (K + 63) / 64;
-    const int g_stride = 2 * gridDim.x * ROW_WAVES;
-    int g = 2 * (blockIdx.x * ROW_WAVES + wave), kb = 0;
-    auto advance = [&](int& ag, int& akb) {
-        if (++akb == nblk) { akb = 0; ag += g_stride; }
-    };
-    auto fetch = [&](int ag, int akb) {          // past the end: a valid address whose values nobody uses
-        return load_pair_sample<TAPS>(min(ag, P - 1), akb, lane, P, K, rec16, incidents, dirs, visibility, areas,
-                                      uniform_area, taps);
-    };
-    int g1 = g, kb1 = kb;
-    advance(g1, kb1);
-    PairSample blk_a = fetch(g, kb);
-    PairSample blk_b = fetch(g1, kb1);
-    PairSample blk_c = blk_b;
-    f2 v[NV];
-#pragma unroll
-    for (int i = 0; i < NV; i++) v[i] = splat2(0.f);
-    // one pipeline step: the block in `cur` is computed while `refill` receives the block after next; the three register
-    // sets take turns through a 3x unrolled loop instead of being copied (35 moves per block otherwise)
-    auto step = [&](PairSample& cur, PairSample& refill) {
-        asm volatile("" : "+v"(cur.dx), "+v"(cur.dy), "+v"(cur.dz), "+v"(cur.vis), "+v"(cur.area), "+v"(cur.ta[0]),
-                     "+v"(cur.ta[1]), "+v"(cur.ta[2]), "+v"(cur.tb[0]), "+v"(cur.tb[1]), "+v"(cur.tb[2]), "+v"(cur.rec)
-                     :: "memory");
-        int g2 = g1, kb2 = kb1;
-        advance(g2, kb2);
-        refill = fetch(g2, kb2);
-        u[l] = cur.rec.x;                           // same wave, in-order LDS: no barrier needed
-        u[l + 32] = cur.rec.y;
-        const float4 ga = *reinterpret_cast<const float4*>(u + 48);     // albedo, roughness
-        const float4 gb = *reinterpret_cast<const float4*>(u + 52);     // n, V.x
-        const float4 gc = *reinterpret_cast<const float4*>(u + 56);     // V.yz, N.xy
-        const float4 gd = *reinterpret_cast<const float4*>(u + 60);     // N.z, NoV, a2, kk
-        const float nx = gb.x, ny = gb.y, nz = gb.z, Vx = gb.w, Vy = gc.x, Vz = gc.y, Nx = gc.z, Ny = gc.w, Nz = gd.x;
-        const float NoV = gd.y, a2 = gd.z, kk = gd.w;
-        const float fd[3] = {ga.x / kPi, ga.y / kPi, ga.z / kPi};
-        const float nom1 = NoV * (1.f - kk) + kk;
-        {
-            const int k0 = kb * 64 + l;
-            const bool have_g = g + h < P;
-            const f2 lv = {have_g && k0 < K ? 1.f : 0.f, have_g && k0 + 32 < K ? 1.f : 0.f};
-            const f2 dx = cur.dx, dy = cur.dy, dz = cur.dz, vis = cur.vis * lv, area = cur.area * lv;
-            f2 e[3];
-            if (TAPS == 2) {
-                e[0] = (f2){__uint_as_float(cur.ta[0]), __uint_as_float(cur.tb[0])};
-                e[1] = (f2){__uint_as_float(cur.ta[1]), __uint_as_float(cur.tb[1])};
-                e[2] = (f2){__uint_as_float(cur.ta[2]), __uint_as_float(cur.tb[2])};
-            } else {
-                float ea[3], eb[3], w4[4];
-                int tex[4];
-                PackedTap t;
-                t.xy = cur.ta[0]; t.wx1 = __uint_as_float(cur.ta[1]); t.wy1 = __uint_as_float(cur.ta[2]);
-                env_fetch(t, tex4, He, We, ea, tex, w4);
-                t.xy = cur.tb[0]; t.wx1 = __uint_as_float(cur.tb[1]); t.wy1 = __uint_as_float(cur.tb[2]);
-                env_fetch(t, tex4, He, We, eb, tex, w4);
-                e[0] = (f2){ea[0], eb[0]}; e[1] = (f2){ea[1], eb[1]}; e[2] = (f2){ea[2], eb[2]};
-            }
-            // local incident light: max(sum_i Y_i(d) c_i, 0); the coefficients are half-wave-uniform broadcast reads
-            f2 Y[16];
-            sh_basis16_pair(dx, dy, dz, Y);
-            f2 acc[3] = {splat2(0.f), splat2(0.f), splat2(0.f)};
-#pragma unroll
-            for (int q = 0; q < 12; q++) {
-                const float4 c4 = reinterpret_cast<const float4*>(u)[q];
-                const float cf[4] = {c4.x, c4.y, c4.z, c4.w};
-#pragma unroll
-                for (int t = 0; t < 4; t++) {
-                    const int f = 4 * q + t;
-                    acc[f % 3] += Y[f / 3] * cf[t];
-                }
-            }
-            const f2 loc[3] = {max2(acc[0], 0.f) * lv, max2(acc[1], 0.f) * lv, max2(acc[2], 0.f) * lv};
-            const f2 glob[3] = {e[0] * vis, e[1] * vis, e[2] * vis};
-            const f2 ndi = max2(nx * dx + ny * dy + nz * dz, 0.f);
-            const f2 area_ndi = area * ndi;
-            // GGX specular (neilf.py:374-407), as in the row kernel
-            const f2 dinv = rsq2(max2(dx * dx + dy * dy + dz * dz, 1e-24f));
-            const f2 Lx = dx * dinv, Ly = dy * dinv, Lz = dz * dinv;
-            const f2 ux = (Lx + Vx) * 0.5f, uy = (Ly + Vy) * 0.5f, uz = (Lz + Vz) * 0.5f;
-            const f2 uinv = rsq2(max2(ux * ux + uy * uy + uz * uz, 1e-24f));
-            const f2 Hx = ux * uinv, Hy = uy * uinv, Hz = uz * uinv;
-            const f2 NoL = clamp2(Nx * Lx + Ny * Ly + Nz * Lz, 1e-6f, 1.f);
-            const f2 NoH = clamp2(Nx * Hx + Ny * Hy + Nz * Hz, 1e-6f, 1.f);
-            const f2 VoH = clamp2(Vx * Hx + Vy * Hy + Vz * Hz, 1e-6f, 1.f);
-            const f2 pe = (-5.55473f * VoH - 6.98316f) * VoH;
-            const f2 p2 = {exp2f(pe.x), exp2f(pe.y)};
-            const f2 frac = (0.04f + 0.96f * p2) * a2;
-            const f2 nom0 = NoH * NoH * (a2 - 1.f) + 1.f;
-            const f2 nom2 = NoL * (1.f - kk) + kk;
-            const f2 nom = clamp2(4.f * kPi * nom0 * nom0 * nom1 * nom2, 1e-6f, 4.f * kPi);
-            const f2 spec = {frac.x / nom.x, frac.y / nom.y};
-#pragma unroll
-            for (int c = 0; c < 3; c++) {
-                const f2 lin = loc[c] + glob[c];
-                const f2 transport = lin * area_ndi;
-                v[c] += (fd[c] + spec) * transport;        // pbr
-                v[3 + c] += transport;                     // diffuse_light
-                if (NOUT == 19) {
-                    v[6 + c] += spec * transport;          // specular
-                    v[9 + c] += lin;                       // mean incident light
-                    v[12 + c] += loc[c];
-                    v[15 + c] += glob[c];
-                }
-            }
-            v[NOUT == 19 ? 18 : 6] += vis;
-        }
-        if (kb == nblk - 1) {
-            float vs[NV];
-#pragma unroll
-            for (int i = 0; i < NV; i++) vs[i] = v[i].x + v[i].y;
-            const float r = transpose_reduce_half<NV>(vs);
-            const int ch = transposed_channel_half<NV>(lane);
-            const int gg = g + h;
-            if (transposed_owner_half<NV>(lane) && gg < P) {
-                if (NOUT == 19) {
-                    if (ch < 19) out[(size_t)gg * SHADE_NOUT + ch] = r * invK;
-                } else if (ch < 7) {
-                    out[(size_t)gg * SHADE_NOUT + (ch < 6 ? ch : 18)] = r * invK;
-                }
-            }
-#pragma unroll
-            for (int i = 0; i < NV; i++) v[i] = splat2(0.f);
-        }
-        g = g1; kb = kb1;
-        g1 = g2; kb1 = kb2;
-    };
-    while (true) {
-        if (g >= P) break;
-        step(blk_a, blk_c);
-        if (g >= P) break;
-        step(blk_b, blk_a);
-        if (g >= P) break;
-        step(blk_c, blk_b);
     }
 }
 
@@ -1016,7 +697,8 @@ __global__ void __launch_bounds__(64 * SHADE_WAVES)
 shade_backward_kernel(int P, int K, int M, ShadeSrc src, const float* __restrict__ env, int He, int We,
                       const float* __restrict__ tr, float* __restrict__ d_base, float* __restrict__ d_rough,
                       float* __restrict__ d_view, float* __restrict__ d_inc, float* __restrict__ d_env,
-                      const unsigned int* __restrict__ gmax_bits, int gmax_n, const uint32_t* __restrict__ taps)
+                      const unsigned int* __restrict__ gmax_bits, int gmax_n, const uint32_t* __restrict__ taps,
+                      size_t total_samples)
 {
     extern __shared__ __attribute__((aligned(16))) float s_mem[];
     const int ntex_raw = He * We * 3;
@@ -1046,7 +728,7 @@ shade_backward_kernel(int P, int K, int M, ShadeSrc src, const float* __restrict
     const int nblk = (K + 63) / 64;
     const int g_stride = gridDim.x * SH_GB;
     int gb = (blockIdx.x * SHADE_WAVES + wave) * SH_GW, kb = 0, buf = 0;
-    if (gb < P) issue_block_loads<VEC16>(lane, gb, 0, P, K, M, src, s_buf[wave][0]);
+    if (gb < P) issue_block_loads<VEC16>(lane, gb, 0, P, K, M, src, s_buf[wave][0], total_samples);
     // per-lane accumulators over this lane's samples: 48 SH gradient channels (f = i*3 + c), albedo, roughness, view.
     // Each 64-sample block (4 samples per lane) is walked three times to keep the live register set small: pass 0
     // evaluates the SH sums of the local light, pass 1 the full sample + BRDF / view / env gradients, pass 2 rebuilds
@@ -1061,11 +743,11 @@ shade_backward_kernel(int P, int K, int M, ShadeSrc src, const float* __restrict
         wait_block_loads();
         int ngb = gb, nkb = kb + 1;
         if (nkb == nblk) { nkb = 0; ngb = gb + g_stride; }
-        if (ngb < P) issue_block_loads<VEC16>(lane, ngb, nkb * 64, P, K, M, src, s_buf[wave][buf ^ 1]);
+        if (ngb < P) issue_block_loads<VEC16>(lane, ngb, nkb * 64, P, K, M, src, s_buf[wave][buf ^ 1], total_samples);
         const float* sb = s_buf[wave][buf];
         const float* s_u = sb + SB_U + grp * SB_USTRIDE;
-        const int g = gb + grp;
-        const bool live = g < P;
+        const bool live = gb + grp < P;
+        const int g = shade_row_of(src, min(gb + grp, P - 1));       // row of this 16-lane group's Gaussian in every array
         GaussFwd G;
         gauss_setup(G, s_u);
         const float gp[3] = {s_u[58] * invK, s_u[59] * invK, s_u[60] * invK};
@@ -1256,290 +938,13 @@ shade_backward_kernel(int P, int K, int M, ShadeSrc src, const float* __restrict
     }
 }
 
-// =====================================================================================================================
-// Backward, row formulation: ONE WAVE PER GAUSSIAN, lane = sample (the forward row kernel's layout).
-// The 16-lane kernel above spends its instructions on three passes over every sample (the live state of one pass is all the
-// registers allow), recomputes the SH basis twice and re-reads the 48 coefficients from LDS per sample.  Here a lane does its
-// one sample in a single pass and keeps the basis in registers; what the 16-lane layout got for free -- the sum over a
-// Gaussian's samples of 48 + 7 per-sample products -- becomes a [55 x 64] . [64] contraction per Gaussian and is done by
-// EXCHANGING ROLES THROUGH LDS instead of a 64-lane butterfly (63 exchange steps for 64 channels ~ 130 VALU instructions +
-// 48 multiplies per row): every lane writes its 16 basis values, its 3 "dL / d local light" values and its 7 scalar
-// gradients into a per-wave LDS tile ([channel][sample], row stride 68 floats = conflict-free for 16-byte reads), then lane
-// j < 55 OWNS output channel j and walks the 64 samples with 2 x 16 ds_read_b128 + 64 FMAs (the 7 scalar sums multiply a
-// row of ones, so all 55 lanes run the same instruction stream).  K > 64: the owner lane accumulates over the blocks.
-// Per-Gaussian constants come from an 80-float record (shade_prepare_bwd_kernel), the lat-long lookups from the cached
-// taps, the texture gradient goes through the same 64-bit fixed-point LDS accumulators as before.
-// =====================================================================================================================
-constexpr int RECB = 80;
-// record: 0..63 as the forward's, 64 |viewdir|, 65 alpha, 66 raw N.V, 68..70 dL_dpbr / K, 72..74 dL_ddiffuse_light / K
-__global__ void __launch_bounds__(256)
-shade_prepare_bwd_kernel(int P, int K, int M, const float* __restrict__ base_color, const float* __restrict__ roughness,
-                         const float* __restrict__ normals, const float* __restrict__ viewdirs,
-                         const float* __restrict__ incidents, const float* __restrict__ g_pbr,
-                         const float* __restrict__ g_diff, float* __restrict__ rec)
-{
-    const int g0 = blockIdx.x * 64;
-    const int ng = min(64, P - g0);
-    const int row = 3 * M;
-    for (int i = threadIdx.x; i < ng * 48; i += 256) {
-        const int gl = i / 48, e = i - gl * 48;
-        rec[(size_t)(g0 + gl) * RECB + e] = e < row ? incidents[(size_t)(g0 + gl) * row + e] : 0.f;
-    }
-    if ((int)threadIdx.x < ng) {
-        const int g = g0 + threadIdx.x;
-        float u[64];
-#pragma unroll
-        for (int c = 0; c < 3; c++) {
-            u[48 + c] = base_color[3 * (size_t)g + c];
-            u[52 + c] = normals[3 * (size_t)g + c];
-            u[55 + c] = viewdirs[3 * (size_t)g + c];
-        }
-        u[51] = roughness[g];
-        GaussFwd G;
-        gauss_setup(G, u);
-        const float invK = 1.0f / (float)K;
-        float4* o = reinterpret_cast<float4*>(rec + (size_t)g * RECB + 48);
-        o[0] = make_float4(u[48], u[49], u[50], u[51]);
-        o[1] = make_float4(G.n[0], G.n[1], G.n[2], G.V[0]);
-        o[2] = make_float4(G.V[1], G.V[2], G.N[0], G.N[1]);
-        o[3] = make_float4(G.N[2], G.NoV, G.a2, G.kk);
-        o[4] = make_float4(G.vlen, G.a, G.rawNoV, 0.f);
-        o[5] = make_float4(g_pbr[3 * (size_t)g] * invK, g_pbr[3 * (size_t)g + 1] * invK, g_pbr[3 * (size_t)g + 2] * invK, 0.f);
-        o[6] = make_float4(g_diff[3 * (size_t)g] * invK, g_diff[3 * (size_t)g + 1] * invK, g_diff[3 * (size_t)g + 2] * invK, 0.f);
-        o[7] = make_float4(0.f, 0.f, 0.f, 0.f);
-    }
-}
-
-constexpr int RB_WAVES = 4;
-constexpr int RB_STRIDE = 68;                 // floats per [channel] row of the exchange tile (64 samples + 4: bank spread)
-constexpr int RB_ROWS = 16 + 3 + 7 + 1;       // basis, dL/dlocal, scalar gradients, ones
-constexpr int RB_TILE = RB_ROWS * RB_STRIDE;  // floats per wave
-
-template <bool ENV_LDS, bool TAPS, bool M16>
-__global__ void __launch_bounds__(64 * RB_WAVES)
-shade_backward_row_kernel(int P, int K, int M_, const float* __restrict__ rec, const float4* __restrict__ env4, int He, int We,
-                          const float* __restrict__ tr, const float* __restrict__ visibility,
-                          const float* __restrict__ dirs, const float* __restrict__ areas, float uniform_area,
-                          const uint32_t* __restrict__ taps, float* __restrict__ d_base, float* __restrict__ d_rough,
-                          float* __restrict__ d_view, float* __restrict__ d_inc, float* __restrict__ d_env,
-                          const unsigned int* __restrict__ gmax_bits, int gmax_n)
-{
-    const int M = M16 ? 16 : M_;
-    extern __shared__ __attribute__((aligned(16))) float s_mem[];
-    __shared__ __attribute__((aligned(16))) float s_rec[RB_WAVES][RECB];
-    __shared__ __attribute__((aligned(16))) float s_tile[RB_WAVES][RB_TILE];
-    const int ntexel = He * We;
-    float4* s_env4 = reinterpret_cast<float4*>(s_mem);
-    long long* s_denv = reinterpret_cast<long long*>(s_mem + (ENV_LDS ? 4 * ntexel : 0));     // [texel][3] fixed point
-    const float gmax = wave_gmax(gmax_bits, gmax_n);
-    const bool fixed = ENV_LDS && gmax > 0.f && gmax <= 3.0e38f;
-    const float fx_scale = fixed ? 34359738368.0f / gmax : 0.f;          // 2^35 / max|g|
-    const float fx_clamp = gmax * 8192.0f;
-    if (ENV_LDS) {
-        for (int i = threadIdx.x; i < ntexel; i += blockDim.x) s_env4[i] = env4[i];
-        for (int i = threadIdx.x; i < 3 * ntexel; i += blockDim.x) s_denv[i] = 0;
-        __syncthreads();
-    }
-    const float4* tex4 = ENV_LDS ? s_env4 : env4;
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    float* u = s_rec[wave];
-    float* tile = s_tile[wave];
-    tile[(RB_ROWS - 1) * RB_STRIDE + lane] = 1.0f;             // the row of ones (the 4 pad floats are never read)
-    const int nblk = (K + 63) / 64;
-    const int g_stride = gridDim.x * RB_WAVES;
-    int g = blockIdx.x * RB_WAVES + wave, kb = 0;
-    auto advance = [&](int& ag, int& akb) {
-        if (++akb == nblk) { akb = 0; ag += g_stride; }
-    };
-    struct Pre { RowSample s; float rec2; };
-    auto fetch = [&](int ag, int akb) {
-        const int k = akb * 64 + lane;
-        const int gg = min(ag, P - 1);
-        Pre p;
-        p.s = load_row_sample<TAPS ? 1 : 0>(ag < P && k < K, gg, lane, (unsigned)k, K, rec, dirs, visibility, areas,
-                                            uniform_area, taps, RECB);
-        p.rec2 = rec[(size_t)gg * RECB + 64 + (lane & 15)];
-        return p;
-    };
-    Pre cur = fetch(g, kb);
-    // owner-lane mapping: lane j < 48 -> basis row j / 3 x dL/dlocal row j % 3; 48 <= j < 55 -> scalar row j - 48 x ones
-    const int rowA = lane < 48 ? lane / 3 : (lane < 55 ? 19 + (lane - 48) : 0);
-    const int rowB = lane < 48 ? 16 + lane % 3 : RB_ROWS - 1;
-    float outacc = 0.f;
-    while (g < P) {
-        asm volatile("" : "+v"(cur.s.dx), "+v"(cur.s.dy), "+v"(cur.s.dz), "+v"(cur.s.vis), "+v"(cur.s.area), "+v"(cur.s.t.xy),
-                     "+v"(cur.s.t.wx1), "+v"(cur.s.t.wy1), "+v"(cur.s.rec), "+v"(cur.rec2) :: "memory");
-        int g1 = g, kb1 = kb;
-        advance(g1, kb1);
-        const Pre nx1 = fetch(g1, kb1);                  // flies during the ~450 instructions below
-        u[lane] = cur.s.rec;
-        if (lane < 16) u[64 + lane] = cur.rec2;
-        const float4 ga = *reinterpret_cast<const float4*>(u + 48);     // albedo, roughness
-        const float4 gb = *reinterpret_cast<const float4*>(u + 52);     // n, V.x
-        const float4 gc = *reinterpret_cast<const float4*>(u + 56);     // V.yz, N.xy
-        const float4 gd4 = *reinterpret_cast<const float4*>(u + 60);    // N.z, NoV, a2, kk
-        const float4 ge = *reinterpret_cast<const float4*>(u + 64);     // vlen, a, rawNoV
-        const float4 gpv = *reinterpret_cast<const float4*>(u + 68);    // dL_dpbr / K
-        const float4 gdv = *reinterpret_cast<const float4*>(u + 72);    // dL_ddiffuse / K
-        const float nx = gb.x, ny = gb.y, nz = gb.z, Vx = gb.w, Vy = gc.x, Vz = gc.y, Nx = gc.z, Ny = gc.w, Nz = gd4.x;
-        const float NoV = gd4.y, a2 = gd4.z, kk = gd4.w, rough = ga.w, vlen = ge.x, alpha = ge.y, rawNoV = ge.z;
-        const float fd[3] = {ga.x / kPi, ga.y / kPi, ga.z / kPi};
-        const float gp[3] = {gpv.x, gpv.y, gpv.z}, gd[3] = {gdv.x, gdv.y, gdv.z};
-        const float nom1 = NoV * (1.f - kk) + kk;
-        float dl[3] = {0.f, 0.f, 0.f}, sc[7] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-        {
-            const float dx = cur.s.dx, dy = cur.s.dy, dz = cur.s.dz, vis = cur.s.vis, area = cur.s.area;
-            const bool live = kb * 64 + lane < K;
-            PackedTap t = cur.s.t;
-            if (!TAPS) t = make_tap(dx, dy, dz, tr, He, We);
-            float e[3], w4[4];
-            int tex[4];
-            env_fetch(t, tex4, He, We, e, tex, w4);
-            float l[3];
-            {
-                float Y[16];
-                sh_basis16(dx, dy, dz, M, Y);
-                sh_local_sum(u, Y, l);
-                // basis rows of the exchange tile now: the 16 registers are free for the gradient chain below
-#pragma unroll
-                for (int i = 0; i < 16; i++) tile[i * RB_STRIDE + lane] = Y[i];
-            }
-            const float ndi = fmaxf(nx * dx + ny * dy + nz * dz, 0.f);
-            const float area_ndi = live ? area * ndi : 0.f;
-            const float dinv = __builtin_amdgcn_rsqf(fmaxf(dx * dx + dy * dy + dz * dz, 1e-24f));
-            const float Lx = dx * dinv, Ly = dy * dinv, Lz = dz * dinv;
-            const float ux = (Lx + Vx) / 2.0f, uy = (Ly + Vy) / 2.0f, uz = (Lz + Vz) / 2.0f;
-            const float uinv = __builtin_amdgcn_rsqf(fmaxf(ux * ux + uy * uy + uz * uz, 1e-24f));
-            const float Hx = ux * uinv, Hy = uy * uinv, Hz = uz * uinv;
-            const float NoL = fminf(fmaxf(Nx * Lx + Ny * Ly + Nz * Lz, 1e-6f), 1.f);
-            const float rawNoH = Nx * Hx + Ny * Hy + Nz * Hz, rawVoH = Vx * Hx + Vy * Hy + Vz * Hz;
-            const float NoH = fminf(fmaxf(rawNoH, 1e-6f), 1.f), VoH = fminf(fmaxf(rawVoH, 1e-6f), 1.f);
-            const float p2 = exp2f((-5.55473f * VoH - 6.98316f) * VoH);
-            const float frac0 = 0.04f + 0.96f * p2;
-            const float frac = frac0 * a2;
-            const float nom0 = NoH * NoH * (a2 - 1.f) + 1.f;
-            const float nom2 = NoL * (1.f - kk) + kk;
-            const float nomr = 4.f * kPi * nom0 * nom0 * nom1 * nom2;
-            const float nom = fminf(fmaxf(nomr, 1e-6f), 4.f * kPi);
-            const float spec = frac / nom;
-            float gspec = 0.f, dlin[3];
-#pragma unroll
-            for (int c = 0; c < 3; c++) {
-                const float lin = fmaxf(l[c], 0.f) + e[c] * vis;
-                const float transport = lin * area_ndi;
-                const float dT = gp[c] * (fd[c] + spec) + gd[c];      // dL / d transport_c
-                gspec += gp[c] * transport;
-                sc[c] = gp[c] * transport / kPi;                      // albedo
-                dlin[c] = dT * area_ndi;                              // dL / d (incident light)_c
-                dl[c] = l[c] >= 0.f ? dlin[c] : 0.f;                  // clamp_min(0): gradient where the SH sum >= 0
-            }
-            // environment-texture gradient: 4 taps x 3 channels (an out-of-range tap carries weight 0)
-            if (vis != 0.f && area_ndi != 0.f) {
-                const float ev[3] = {dlin[0] * vis, dlin[1] * vis, dlin[2] * vis};
-                if (fixed) {
-                    const double scale_d = (double)fx_scale;
-#pragma unroll
-                    for (int q = 0; q < 4; q++) {
-#pragma unroll
-                        for (int c = 0; c < 3; c++) {
-                            const float cl = __builtin_amdgcn_fmed3f(ev[c] * w4[q], -fx_clamp, fx_clamp);
-                            const double dsum = __builtin_fma((double)cl, scale_d, 6755399441055744.0);
-                            const unsigned long long bits =
-                                (unsigned long long)__double_as_longlong(dsum) - 0x4338000000000000ull;
-                            atomicAdd(reinterpret_cast<unsigned long long*>(&s_denv[3 * tex[q] + c]), bits);
-                        }
-                    }
-                } else {
-#pragma unroll
-                    for (int q = 0; q < 4; q++)
-                        if (w4[q] != 0.f)
-#pragma unroll
-                            for (int c = 0; c < 3; c++) atomicAdd(&d_env[3 * (size_t)tex[q] + c], ev[c] * w4[q]);
-                }
-            }
-            // specular -> roughness, view direction
-            const bool nom_free = nomr >= 1e-6f && nomr <= 4.f * kPi;
-            const float dfrac = gspec / nom;
-            const float dnom = nom_free ? -gspec * frac / (nom * nom) : 0.f;
-            float da2 = dfrac * frac0;
-            const float dfrac0 = dfrac * a2;
-            const float dFMi = dfrac0 * 0.96f * 0.6931471805599453f * p2;
-            float dVoH = dFMi * (-2.f * 5.55473f * VoH - 6.98316f);
-            const float c4 = 4.f * kPi;
-            const float dnom0 = dnom * c4 * 2.f * nom0 * nom1 * nom2;
-            const float dnom1 = dnom * c4 * nom0 * nom0 * nom2;
-            const float dnom2 = dnom * c4 * nom0 * nom0 * nom1;
-            float dNoH = dnom0 * 2.f * NoH * (a2 - 1.f);
-            da2 += dnom0 * NoH * NoH;
-            float dNoV = dnom1 * (1.f - kk);
-            const float dkk = dnom1 * (1.f - NoV) + dnom2 * (1.f - NoL);
-            const float da = dkk / 8.f + da2 * 2.f * alpha;
-            sc[3] = dkk * 2.f / 8.f + da * 2.f * rough;                 // roughness
-            if (!(rawNoH >= 1e-6f && rawNoH <= 1.f)) dNoH = 0.f;
-            if (!(rawVoH >= 1e-6f && rawVoH <= 1.f)) dVoH = 0.f;
-            if (!(rawNoV >= 1e-6f && rawNoV <= 1.f)) dNoV = 0.f;
-            const float dHx = dNoH * Nx + dVoH * Vx, dHy = dNoH * Ny + dVoH * Vy, dHz = dNoH * Nz + dVoH * Vz;
-            float dVx = dVoH * Hx + dNoV * Nx, dVy = dVoH * Hy + dNoV * Ny, dVz = dVoH * Hz + dNoV * Nz;
-            const float hd = Hx * dHx + Hy * dHy + Hz * dHz;
-            dVx += 0.5f * (dHx - Hx * hd) * uinv;
-            dVy += 0.5f * (dHy - Hy * hd) * uinv;
-            dVz += 0.5f * (dHz - Hz * hd) * uinv;
-            const float vd = Vx * dVx + Vy * dVy + Vz * dVz;
-            sc[4] = (dVx - Vx * vd) / vlen;
-            sc[5] = (dVy - Vy * vd) / vlen;
-            sc[6] = (dVz - Vz * vd) / vlen;
-        }
-        // exchange tile: [channel][sample]
-#pragma unroll
-        for (int c = 0; c < 3; c++) tile[(16 + c) * RB_STRIDE + lane] = dl[c];
-#pragma unroll
-        for (int j = 0; j < 7; j++) tile[(19 + j) * RB_STRIDE + lane] = sc[j];
-        // owner lanes: one output channel each, 64 samples
-        {
-            const float4* A = reinterpret_cast<const float4*>(tile + rowA * RB_STRIDE);
-            const float4* B = reinterpret_cast<const float4*>(tile + rowB * RB_STRIDE);
-            float a0 = 0.f, a1 = 0.f, a2s = 0.f, a3 = 0.f;
-#pragma unroll
-            for (int q = 0; q < 16; q++) {
-                const float4 x = A[q], y = B[q];
-                a0 += x.x * y.x; a1 += x.y * y.y; a2s += x.z * y.z; a3 += x.w * y.w;
-            }
-            outacc += (a0 + a1) + (a2s + a3);
-        }
-        if (kb == nblk - 1) {
-            if (lane < 48) { if (lane < 3 * M) d_inc[(size_t)g * M * 3 + lane] = outacc; }
-            else if (lane < 51) d_base[3 * (size_t)g + (lane - 48)] = outacc;
-            else if (lane == 51) d_rough[g] = outacc;
-            else if (lane < 55) d_view[3 * (size_t)g + (lane - 52)] = outacc;
-            outacc = 0.f;
-        }
-        cur = nx1;
-        g = g1; kb = kb1;
-    }
-    if (fixed) {
-        __syncthreads();
-        const float inv = 1.0f / fx_scale;
-        for (int i = threadIdx.x; i < 3 * ntexel; i += blockDim.x) {
-            const long long v64 = s_denv[i];
-            if (v64 != 0) atomicAdd(&d_env[i], (float)((double)v64 * (double)inv));
-        }
-    }
-}
-
-// Measured (P=300k, K=64, cached taps): 0.456-0.460 ms vs 0.458 ms for the 16-lane kernel -- no gain: the single pass needs
-// ~204 VGPRs (2 waves/SIMD, like the three-pass kernel), and forcing 3 waves/SIMD spills (0.51 ms).  The 16-lane kernel stays
-// the default; this one is kept selectable (r3dg_set_tuning9) and tested against it.
-int g_shade_bwd_rows = 0;    // r3dg_set_tuning9: 1 = row kernel (wave per Gaussian), 0 = the 16-lane kernel (default)
-
-int g_shade_fwd_blocks_per_cu = 2;   // r3dg_set_tuning6: persistent workgroups per CU of the shading forward
-
 static int shade_cus()
 {
     int dev = 0, cus = 256;
     (void)hipGetDevice(&dev);
     (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-    return cus;
+    // persistent grids leave g_reserve_cus CUs to a collective running beside them (common.hpp)
+    return cus > g_reserve_cus ? cus - g_reserve_cus : 1;
 }
 
 static int shade_grid(int P, int blocks_per_cu = 2)
@@ -1554,40 +959,24 @@ static int shade_grid(int P, int blocks_per_cu = 2)
 // launch), bytes 64.. stay zero (the DMA source for absent elements of the uniform record)
 static unsigned int* shade_scratch()
 {
-    static unsigned int* scratch[64] = {nullptr};
+    static std::mutex mu;
+    static std::map<int, unsigned int*> scratch;
     int dev = 0;
     R3DG_HIP(hipGetDevice(&dev));
-    if (dev < 0 || dev >= 64) dev = 0;
-    if (scratch[dev] == nullptr) {
-        R3DG_HIP(hipMalloc((void**)&scratch[dev], 256));
-        R3DG_HIP(hipMemset(scratch[dev], 0, 256));
+    std::lock_guard<std::mutex> lk(mu);
+    unsigned int*& p = scratch[dev];
+    if (p == nullptr) {
+        R3DG_HIP(hipMalloc((void**)&p, 256));
+        R3DG_HIP(hipMemset(p, 0, 256));
     }
-    return scratch[dev];
+    return p;
 }
 
-// per-device scratch for the per-Gaussian records of the row kernels (grow-only; P * 256 bytes)
-static float* shade_records(size_t P)
-{
-    static float* buf[64] = {nullptr};
-    static size_t cap[64] = {0};
-    int dev = 0;
-    R3DG_HIP(hipGetDevice(&dev));
-    if (dev < 0 || dev >= 64) dev = 0;
-    if (cap[dev] < P) {
-        if (buf[dev] != nullptr) {
-            R3DG_HIP(hipDeviceSynchronize());
-            R3DG_HIP(hipFree(buf[dev]));
-        }
-        const size_t want = P + P / 8 + 1024;
-        R3DG_HIP(hipMalloc((void**)&buf[dev], want * REC * sizeof(float)));
-        cap[dev] = want;
-    }
-    return buf[dev];
-}
+// scratch of the row forward kernel ([P][16] derived floats + the float4-padded texture): one grow-only buffer per
+// (device, stream), so launches on different streams or threads never share it (common.hpp stream_scratch)
+static float* shade_records(hipStream_t s, size_t floats) { return (float*)stream_scratch(s, 0, floats * sizeof(float)); }
 
-int g_shade_fwd_rows = 1;    // r3dg_set_tuning7: 2 = pair kernel (two samples per lane; cached lookups, degree-3 light; else 1),
-                             // 1 = row kernels (wave per Gaussian), 0 = the 16-lane kernel
-int g_shade_row_blocks_per_cu = 0;   // r3dg_set_tuning7 (second argument): persistent row blocks per CU, 0 = all that fit
+int g_shade_row_blocks_per_cu = 0;   // R3DG_OPT_SHADE_FWD_BLOCKS_PER_CU: persistent row blocks per CU, 0 = all that fit
 
 void launch_shade_build_taps(hipStream_t s, size_t n, const float* dirs, const float* tr, int He, int We, const float* env,
                              uint32_t* taps)
@@ -1598,70 +987,26 @@ void launch_shade_build_taps(hipStream_t s, size_t n, const float* dirs, const f
 }
 
 // `taps`: optional cache of r3dg_shade_build_taps for THESE dirs / env size / transform; `train_outputs`: write only
-// pbr (0..2), diffuse_light (3..5) and the mean visibility (18) of the 19 outputs
+// pbr (0..2), diffuse_light (3..5) and the mean visibility (18) of the 19 outputs.
+// `list` / `n_list`: when list != nullptr only the Gaussians list[0 .. n_list) are shaded (rows of all arrays are indexed by
+// the listed ids; the other rows of `out` are left untouched)
 void launch_shade_forward(hipStream_t s, int P, int K, int M, const float* base_color, const float* roughness,
                           const float* normals, const float* viewdirs, const float* incidents, const float* env, int He,
                           int We, const float* tr, const float* visibility, const float* dirs, const float* areas,
                           float* out, const uint32_t* taps, bool train_outputs, float uniform_area, bool taps_are_radiance,
-                          bool leave_room)
+                          bool leave_room, const int* list, int n_list)
 {
-    if (P == 0) return;
-    if (areas == nullptr && !g_shade_fwd_rows) throw std::runtime_error("shade_forward: the 16-lane kernel needs incident_areas");
-    const int ntex = He * We * 3;
-    if (!g_shade_fwd_rows) {
-        const int grid = shade_grid(P, g_shade_fwd_blocks_per_cu);
-        const size_t u_bytes = SH_GB * 64 * sizeof(float);
-        if (ntex <= ENV_LDS_MAX)
-            shade_forward_kernel<true><<<grid, 64 * SHADE_WAVES, ((ntex + 3) & ~3) * sizeof(float) + u_bytes, s>>>(
-                P, K, M, base_color, roughness, normals, viewdirs, incidents, env, He, We, tr, visibility, dirs, areas, out);
-        else
-            shade_forward_kernel<false><<<grid, 64 * SHADE_WAVES, u_bytes, s>>>(
-                P, K, M, base_color, roughness, normals, viewdirs, incidents, env, He, We, tr, visibility, dirs, areas, out);
-        return;
-    }
+    if (P == 0 || (list != nullptr && n_list <= 0)) return;
     const size_t ntexel = (size_t)He * We;
-    float* rec = shade_records((size_t)P / 4 + (ntexel * 4 + REC - 1) / REC + 2);  // [P][16] derived floats, then the padded texture
+    float* rec = shade_records(s, (((size_t)P * 16 + 3) & ~(size_t)3) + ntexel * 4);   // [P][16] derived floats, then the padded texture
     float4* env4 = reinterpret_cast<float4*>(rec + (((size_t)P * 16 + 3) & ~(size_t)3));
     shade_prepare_kernel<<<(P + 255) / 256, 256, 0, s>>>(P, base_color, roughness, normals, viewdirs, rec);
     shade_pad_env_kernel<<<(int)((ntexel + 255) / 256), 256, 0, s>>>((int)ntexel, env, env4);
     const int mode = taps == nullptr ? 0 : (taps_are_radiance ? 2 : 1);
     const bool lds = mode != 2 && He * We * 4 <= ENV_LDS_MAX;          // float4 per texel
     const size_t smem = lds ? ntexel * sizeof(float4) : 0;
-    if (g_shade_fwd_rows == 2 && mode != 0 && M == 16) {
-        // pair kernel: two samples per lane, two Gaussians per wave
-        const int want2 = ((P + 1) / 2 + ROW_WAVES - 1) / ROW_WAVES;
-#define R3DG_PAIR(N, L, T)                                                                                            \
-    do {                                                                                                              \
-        static int per_cu[2] = {0, 0};                                                                                \
-        if (per_cu[L] == 0) {                                                                                         \
-            int nb = 0;                                                                                               \
-            R3DG_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, shade_forward_pair_kernel<N, L, T>,            \
-                                                                  64 * ROW_WAVES, smem));                            \
-            hipFuncAttributes fa;                                                                                     \
-            R3DG_HIP(hipFuncGetAttributes(&fa, (const void*)shade_forward_pair_kernel<N, L, T>));                     \
-            const int by_vgpr = 512 / (((fa.numRegs + 7) / 8) * 8);                                                   \
-            nb = nb < by_vgpr ? nb : by_vgpr;                                                                         \
-            per_cu[L] = nb > 0 ? (nb < 8 ? nb : 8) : 1;                                                               \
-        }                                                                                                             \
-        int bpc = g_shade_row_blocks_per_cu > 0 && g_shade_row_blocks_per_cu < per_cu[L] ? g_shade_row_blocks_per_cu   \
-                                                                                         : per_cu[L];                 \
-        if (leave_room && g_shade_row_blocks_per_cu == 0 && bpc > 3) bpc = 3;                                         \
-        const int cap = shade_cus() * bpc;                                                                            \
-        const int grid = want2 < cap ? want2 : cap;                                                                   \
-        shade_forward_pair_kernel<N, L, T><<<grid, 64 * ROW_WAVES, smem, s>>>(                                        \
-            P, K, rec, incidents, env4, He, We, visibility, dirs, areas, uniform_area, taps, out);                    \
-    } while (0)
-#define R3DG_PAIR_MODE(N, L)                                                                                          \
-    do {                                                                                                              \
-        if (mode == 1) R3DG_PAIR(N, L, 1); else R3DG_PAIR(N, L, 2);                                                   \
-    } while (0)
-        if (train_outputs) { if (lds) R3DG_PAIR_MODE(7, true); else R3DG_PAIR_MODE(7, false); }
-        else { if (lds) R3DG_PAIR_MODE(19, true); else R3DG_PAIR_MODE(19, false); }
-#undef R3DG_PAIR_MODE
-#undef R3DG_PAIR
-        return;
-    }
-    const int want = (P + ROW_WAVES - 1) / ROW_WAVES;
+    const int n = list != nullptr ? n_list : P;
+    const int want = (n + ROW_WAVES - 1) / ROW_WAVES;
 #define R3DG_ROW(N, L, T)                                                                                             \
     do {                                                                                                              \
         /* persistent blocks: exactly as many as are resident at once (a larger grid runs a second, nearly empty wave of \
@@ -1686,10 +1031,10 @@ void launch_shade_forward(hipStream_t s, int P, int K, int M, const float* base_
         const int grid = want < cap ? want : cap;                                                                     \
         if (M == 16)                                                                                                  \
             shade_forward_row_kernel<N, L, T, true><<<grid, 64 * ROW_WAVES, smem, s>>>(                               \
-                P, K, M, rec, incidents, env4, He, We, tr, visibility, dirs, areas, uniform_area, taps, out);         \
+                n, K, M, rec, incidents, env4, He, We, tr, visibility, dirs, areas, uniform_area, taps, out, list);   \
         else                                                                                                          \
             shade_forward_row_kernel<N, L, T, false><<<grid, 64 * ROW_WAVES, smem, s>>>(                              \
-                P, K, M, rec, incidents, env4, He, We, tr, visibility, dirs, areas, uniform_area, taps, out);         \
+                n, K, M, rec, incidents, env4, He, We, tr, visibility, dirs, areas, uniform_area, taps, out, list);   \
     } while (0)
 #define R3DG_ROW_MODE(N, L)                                                                                           \
     do {                                                                                                              \
@@ -1701,13 +1046,16 @@ void launch_shade_forward(hipStream_t s, int P, int K, int M, const float* base_
 #undef R3DG_ROW
 }
 
+// `list` / `n_list` as in launch_shade_forward (rows of d_base / d_rough / d_view / d_inc that are not listed stay untouched;
+// d_env is accumulated into either way)
 void launch_shade_backward(hipStream_t s, int P, int K, int M, const float* base_color, const float* roughness,
                            const float* normals, const float* viewdirs, const float* incidents, const float* env,
                            int He, int We, const float* tr, const float* visibility, const float* dirs,
                            const float* areas, const float* g_pbr, const float* g_diff, float* d_base, float* d_rough,
                            float* d_view, float* d_inc, float* d_env, const uint32_t* taps, const float* block_absmax,
-                           int n_block_absmax)
+                           int n_block_absmax, const int* list, int n_list)
 {
+    if (list != nullptr && n_list <= 0) return;
     unsigned int* scratch = shade_scratch();
     // scale of the fixed-point texture accumulation: max |upstream gradient|, either handed over as block maxima by the
     // producer of g_pbr / g_diff (r3dg_stage2_unpack_gradients) or reduced here
@@ -1721,52 +1069,12 @@ void launch_shade_backward(hipStream_t s, int P, int K, int M, const float* base
         const int nb = (3 * P + 255) / 256;
         grad_absmax_kernel<<<nb < 256 ? nb : 256, 256, 0, s>>>(3 * P, g_pbr, g_diff, scratch);
     }
-
     const int ntex = He * We * 3;
-    if (g_shade_bwd_rows) {
-        const size_t ntexel = (size_t)He * We;
-        float* rec = shade_records(((size_t)P * RECB + ntexel * 4) / REC + 2);       // 80-float records, then the padded texture
-        float4* env4 = reinterpret_cast<float4*>(rec + (size_t)P * RECB);
-        shade_prepare_bwd_kernel<<<(P + 63) / 64, 256, 0, s>>>(P, K, M, base_color, roughness, normals, viewdirs, incidents,
-                                                              g_pbr, g_diff, rec);
-        shade_pad_env_kernel<<<(int)((ntexel + 255) / 256), 256, 0, s>>>((int)ntexel, env, env4);
-        const bool lds_r = ntexel * (16 + 24) <= (size_t)ENV_LDS_MAX * 4;              // float4 texture + 3 x int64 accumulators
-        const size_t smem_r = lds_r ? ntexel * (16 + 24) : 0;
-        const int want = (P + RB_WAVES - 1) / RB_WAVES;
-#define R3DG_RB(L, T)                                                                                                 \
-    do {                                                                                                              \
-        static int per_cu = 0;                                                                                        \
-        if (per_cu == 0) {                                                                                            \
-            int nb2 = 0;                                                                                              \
-            R3DG_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb2, shade_backward_row_kernel<L, T, true>,        \
-                                                                  64 * RB_WAVES, smem_r));                           \
-            hipFuncAttributes fa;                                                                                     \
-            R3DG_HIP(hipFuncGetAttributes(&fa, (const void*)shade_backward_row_kernel<L, T, true>));                  \
-            const int by_vgpr = 512 / (((fa.numRegs + 7) / 8) * 8);                                                   \
-            nb2 = nb2 < by_vgpr ? nb2 : by_vgpr;                                                                      \
-            per_cu = nb2 > 0 ? (nb2 < 8 ? nb2 : 8) : 1;                                                               \
-        }                                                                                                             \
-        const int cap = shade_cus() * per_cu;                                                                         \
-        const int grid_r = want < cap ? want : cap;                                                                   \
-        if (M == 16)                                                                                                  \
-            shade_backward_row_kernel<L, T, true><<<grid_r, 64 * RB_WAVES, smem_r, s>>>(                              \
-                P, K, M, rec, env4, He, We, tr, visibility, dirs, areas, 0.f, taps, d_base, d_rough, d_view, d_inc,   \
-                d_env, gmax, gmax_n);                                                                                 \
-        else                                                                                                          \
-            shade_backward_row_kernel<L, T, false><<<grid_r, 64 * RB_WAVES, smem_r, s>>>(                             \
-                P, K, M, rec, env4, He, We, tr, visibility, dirs, areas, 0.f, taps, d_base, d_rough, d_view, d_inc,   \
-                d_env, gmax, gmax_n);                                                                                 \
-    } while (0)
-        if (lds_r) { if (taps != nullptr) R3DG_RB(true, true); else R3DG_RB(true, false); }
-        else { if (taps != nullptr) R3DG_RB(false, true); else R3DG_RB(false, false); }
-#undef R3DG_RB
-        check_launch(s, false, "shade_backward_row_kernel");
-        return;
-    }
+    const int n = list != nullptr ? n_list : P;
     const ShadeSrc src = {base_color, roughness, normals, viewdirs, incidents, g_pbr, g_diff,
-                          reinterpret_cast<const float*>(scratch + 16), dirs, visibility, areas};
+                          reinterpret_cast<const float*>(scratch + 16), dirs, visibility, areas, list};
     // persistent blocks so the LDS-privatised env gradient is flushed once per block, not once per Gaussian
-    const int grid = shade_grid(P);
+    const int grid = shade_grid(n);
     const bool lds = 3 * ntex <= ENV_LDS_MAX, vec = (K % 4) == 0 && (size_t)P * K >= 4;
     const size_t smem = lds ? 3 * ((ntex + 3) & ~3) * sizeof(float) : 0;  // + the static DMA buffers and parking slots
 #define R3DG_SB3(L, V, T)                                                                                             \
@@ -1774,9 +1082,9 @@ void launch_shade_backward(hipStream_t s, int P, int K, int M, const float* base
         if (smem > 65536)                                                                                             \
             R3DG_HIP(hipFuncSetAttribute((const void*)shade_backward_kernel<L, V, T>,                                 \
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));                     \
-        shade_backward_kernel<L, V, T><<<grid, 64 * SHADE_WAVES, smem, s>>>(P, K, M, src, env, He, We, tr, d_base,    \
+        shade_backward_kernel<L, V, T><<<grid, 64 * SHADE_WAVES, smem, s>>>(n, K, M, src, env, He, We, tr, d_base,    \
                                                                           d_rough, d_view, d_inc, d_env, gmax,        \
-                                                                          gmax_n, taps);                              \
+                                                                          gmax_n, taps, (size_t)P * K);               \
     } while (0)
 #define R3DG_SB(L, V)                                                                                                 \
     do {                                                                                                              \
@@ -1791,7 +1099,112 @@ void launch_shade_backward(hipStream_t s, int P, int K, int M, const float* base
 
 }  // namespace r3dg
 #include "shading_transport.hpp"
+#include "shading_frs.hpp"
 namespace r3dg {
+
+// ---- fixed ray set (shading_frs.hpp) -------------------------------------------------------------------------------------
+size_t shade_frs_table_floats(int K) { return (size_t)((K + 15) / 16) * 512; }
+
+void launch_shade_frs_build_tables(hipStream_t s, int K, const float* zsamples, float* tables)
+{
+    const int nblk = (K + 15) / 16;
+    frs_build_tables_kernel<<<(nblk * 512 + 255) / 256, 256, 0, s>>>(K, nblk, zsamples, tables);
+    check_launch(s, false, "frs_build_tables_kernel");
+}
+
+void launch_shade_frs_classify(hipStream_t s, int P, const float* ray_normals, uint8_t* valid)
+{
+    if (P == 0) return;
+    frs_classify_kernel<<<(P + 255) / 256, 256, 0, s>>>(P, ray_normals, valid);
+    check_launch(s, false, "frs_classify_kernel");
+}
+
+// can the fixed-ray-set kernels take this configuration?  (everything else goes through the general kernels)
+bool shade_frs_supported(int K, int M, int He, int We)
+{
+    return M == 16 && K >= 4 && (K % 4) == 0 && (size_t)He * We * (16 + 24) <= (size_t)ENV_LDS_MAX * 4;
+}
+
+static int frs_grid(int P, const void* kernel, size_t smem)
+{
+    int nb = 0;
+    R3DG_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kernel, 64 * FRS_WAVES, smem));
+    hipFuncAttributes fa;
+    R3DG_HIP(hipFuncGetAttributes(&fa, kernel));
+    const int by_vgpr = 512 / (((fa.numRegs + 7) / 8) * 8);           // waves per SIMD = 256-thread blocks per CU
+    nb = nb < by_vgpr ? nb : by_vgpr;
+    nb = nb > 0 ? (nb < 8 ? nb : 8) : 1;
+    const int want = ((P + FRS_G - 1) / FRS_G + FRS_WAVES - 1) / FRS_WAVES;
+    const int cap = shade_cus() * nb;
+    return want < cap ? (want > 0 ? want : 1) : cap;
+}
+
+// forward over a fixed ray set: rotate the coefficients (cprime [P,48] is kept for the backward), the MFMA kernel for the
+// Gaussians on the rotated path, the general row kernel for the listed rest
+void launch_shade_frs_forward(hipStream_t s, int P, int K, const float* base_color, const float* roughness,
+                              const float* normals, const float* viewdirs, const float* incidents, const float* env, int He,
+                              int We, const float* visibility, const float* dirs, const float* areas, float uniform_area,
+                              const uint32_t* taps, const float* ray_normals, const float* tables, const uint8_t* valid,
+                              const int* invalid_list, int n_invalid, float* cprime, bool leave_room, float* out)
+{
+    if (P == 0) return;
+    const size_t ntexel = (size_t)He * We;
+    float4* env4 = reinterpret_cast<float4*>(stream_scratch(s, 1, ntexel * sizeof(float4)));
+    shade_pad_env_kernel<<<(int)((ntexel + 255) / 256), 256, 0, s>>>((int)ntexel, env, env4);
+    frs_rotate_kernel<false><<<(P + 255) / 256, 256, 0, s>>>(P, ray_normals, incidents, cprime);
+    check_launch(s, false, "frs_rotate_kernel");
+    const size_t smem = ntexel * sizeof(float4);
+    static int grid_cache[2] = {0, 0};
+    (void)grid_cache;
+    int grid = frs_grid(P, (const void*)shade_forward_frs_kernel, smem);
+    if (leave_room) grid = grid > shade_cus() * 2 ? shade_cus() * 2 : grid;      // the instance ordering runs beside it
+    shade_forward_frs_kernel<<<grid, 64 * FRS_WAVES, smem, s>>>(P, K, base_color, roughness, normals, viewdirs, cprime, env4,
+                                                                He, We, visibility, dirs, uniform_area, taps, tables, valid, out);
+    check_launch(s, false, "shade_forward_frs_kernel");
+    if (n_invalid > 0)
+        launch_shade_forward(s, P, K, 16, base_color, roughness, normals, viewdirs, incidents, env, He, We, nullptr, visibility,
+                             dirs, areas, out, taps, true, uniform_area, false, leave_room, invalid_list, n_invalid);
+}
+
+void launch_shade_frs_backward(hipStream_t s, int P, int K, const float* base_color, const float* roughness,
+                               const float* normals, const float* viewdirs, const float* incidents, const float* env, int He,
+                               int We, const float* visibility, const float* dirs, const float* areas, float uniform_area,
+                               const uint32_t* taps, const float* ray_normals, const float* tables, const uint8_t* valid,
+                               const int* invalid_list, int n_invalid, const float* cprime, float* dcp, const float* g_pbr,
+                               const float* g_diff, float* d_base, float* d_rough, float* d_view, float* d_inc, float* d_env,
+                               const float* block_absmax, int n_block_absmax)
+{
+    if (P == 0) return;
+    unsigned int* scratch = shade_scratch();
+    const unsigned int* gmax = scratch;
+    int gmax_n = 1;
+    if (block_absmax != nullptr && n_block_absmax > 0) {
+        gmax = reinterpret_cast<const unsigned int*>(block_absmax);
+        gmax_n = n_block_absmax;
+    } else {
+        R3DG_HIP(hipMemsetAsync(scratch, 0, 4, s));
+        const int nb = (3 * P + 255) / 256;
+        grad_absmax_kernel<<<nb < 256 ? nb : 256, 256, 0, s>>>(3 * P, g_pbr, g_diff, scratch);
+    }
+    const size_t ntexel = (size_t)He * We;
+    float4* env4 = reinterpret_cast<float4*>(stream_scratch(s, 1, ntexel * sizeof(float4)));
+    shade_pad_env_kernel<<<(int)((ntexel + 255) / 256), 256, 0, s>>>((int)ntexel, env, env4);
+    const size_t smem = ntexel * (sizeof(float4) + 3 * sizeof(long long));
+    const int grid = frs_grid(P, (const void*)shade_backward_frs_kernel, smem);
+    shade_backward_frs_kernel<<<grid, 64 * FRS_WAVES, smem, s>>>(P, K, base_color, roughness, normals, viewdirs, cprime, g_pbr,
+                                                                 g_diff, env4, He, We, visibility, dirs, uniform_area, taps,
+                                                                 tables, valid, d_base, d_rough, d_view, dcp, d_env, gmax,
+                                                                 gmax_n);
+    check_launch(s, false, "shade_backward_frs_kernel");
+    // gradient back to the unrotated coefficients: every row of d_inc is written (garbage for Gaussians off the rotated
+    // path: the general kernel overwrites their rows next)
+    frs_rotate_kernel<true><<<(P + 255) / 256, 256, 0, s>>>(P, ray_normals, dcp, d_inc);
+    check_launch(s, false, "frs_rotate_kernel");
+    if (n_invalid > 0)
+        launch_shade_backward(s, P, K, 16, base_color, roughness, normals, viewdirs, incidents, env, He, We, nullptr, visibility,
+                              dirs, areas, g_pbr, g_diff, d_base, d_rough, d_view, d_inc, d_env, taps, block_absmax,
+                              n_block_absmax, invalid_list, n_invalid);
+}
 
 void launch_shade_build_transport(hipStream_t s, int P, int K, int M, const float* normals, const float* incidents,
                                   const float* visibility, const float* dirs, const float* areas, float uniform_area,

@@ -1,0 +1,531 @@
+// Shading integral over a FIXED RAY SET ("frs"): forward and backward kernels for callers whose cached incident directions
+// are the Fibonacci set rotated to each Gaussian's normal -- what GaussianModel.update_visibility produces
+// (scene/gaussian_model.py:312-342: sample_incident_rays(normal, False, K) = fibonacci_sphere_sampling(random_rotate=False),
+// utils/graphics_utils.py:9-37; d_k = normalize(R(n) z_k), R = rotation_between_z, utils/sh_utils.py:36-68).
+// Included by shading.hip (after the general kernels, whose per-sample code it reuses).
+//
+// Why.  The general kernels evaluate the 16 SH basis functions at every cached direction and contract them with the 48
+// incident-light coefficients -- forward: once; backward: twice (value and sign of the local light, then the gradient) --
+// 80 of the forward's 260 and 225 of the backward's 540 VALU instructions per sample, on kernels that are bound by VALU issue.
+// With d_k = R z_k the local light is   sum_i c_i Y_i(R z_k) = sum_i c'_i Y_i(z_k)   for the coefficients c' of the rotated
+// function (an orthogonal map per SH band), and Y_i(z_k) is ONE [K x 16] table for all Gaussians.  Both contractions
+//       l[k][c]   = sum_i Yz[k][i] c'[i][c]          (local light of sample k, channel c)
+//       dc'[i][c] = sum_k Yz[k][i] dl[k][c]          (gradient w.r.t. the rotated coefficients)
+// are then small dense products against a CONSTANT matrix and run on the matrix cores: v_mfma_f32_16x16x4_f32 -- exact fp32
+// FMA chains at the vector rate, on the MFMA pipe, BESIDE the VALU work of the other waves -- with the 16 columns of the
+// MFMA tile = 16 Gaussians.  That fixes the work split: lane (g = lane & 15, q = lane >> 4) owns samples 16 b + 4 q + v
+// (v < 4) of Gaussian g0 + g in every 16-sample block b, i.e. 4 lanes per Gaussian and 16 samples per lane per 64 samples
+// -- which also amortises the per-Gaussian set-up and the final cross-lane sums over 4x more samples than the 16-lane
+// kernel (they were a sixth of its time: profiles/r03_ablate_shade_backward.json).
+//
+// The rotation itself is done per Gaussian by two streaming kernels (coefficients there, gradient back) with the sampling
+// construction of tools/gen_sh_rotation_tables.py.  R is evaluated in fp32 exactly as the ray set was generated; where
+// cancellation makes it measurably non-orthonormal (normals within ~2.5 degrees of -z: 0.3 % of uniformly distributed
+// normals) the cached directions are not a rigid copy of the z set and the Gaussian is left to the general kernels, which
+// the launcher runs on the list of those Gaussians (same entry point, bit-for-bit the old path for them).
+#pragma once
+#include "sh_rotation_tables.hpp"
+
+namespace r3dg {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int FRS_WAVES = 4;                 // waves per workgroup
+constexpr int FRS_G = 16;                    // Gaussians per wave step (the N dimension of the MFMA tile)
+constexpr float FRS_MAX_DEFECT = 2e-5f;      // max |R R^T - I| for which a Gaussian takes the rotated path
+
+// rotation_between_z(n) (utils/sh_utils.py:36-68), fp32 operation for operation as sampling.rotation_between_z
+__device__ __forceinline__ void frs_rotation(const float n0, const float n1, const float n2, float (&R)[9])
+{
+    const float v1 = -n1, v2 = n0, cp = fmaxf(n2 + 1.f, 1e-7f);
+    const bool regular = n2 + 1.f > 0.f;
+    R[0] = regular ? 1.f + (-v2 * v2) / cp : -1.f;
+    R[1] = regular ? v1 * v2 / cp : 0.f;
+    R[2] = regular ? v2 : 0.f;
+    R[3] = R[1];
+    R[4] = regular ? 1.f + (-v1 * v1) / cp : -1.f;
+    R[5] = regular ? -v1 : 0.f;
+    R[6] = regular ? -v2 : 0.f;
+    R[7] = regular ? v1 : 0.f;
+    R[8] = regular ? 1.f + (-v2 * v2 - v1 * v1) / cp : -1.f;
+}
+
+// valid[g] = 1 when R(n_g) is orthonormal to FRS_MAX_DEFECT (then normalize(R z_k) is a rigid copy of the z set)
+__global__ void __launch_bounds__(256)
+frs_classify_kernel(int P, const float* __restrict__ ray_normals, uint8_t* __restrict__ valid)
+{
+    const int g = blockIdx.x * 256 + threadIdx.x;
+    if (g >= P) return;
+    float R[9];
+    frs_rotation(ray_normals[3 * (size_t)g], ray_normals[3 * (size_t)g + 1], ray_normals[3 * (size_t)g + 2], R);
+    float defect = 0.f;
+#pragma unroll
+    for (int a = 0; a < 3; a++)
+#pragma unroll
+        for (int b = 0; b < 3; b++) {
+            const float d = R[3 * a] * R[3 * b] + R[3 * a + 1] * R[3 * b + 1] + R[3 * a + 2] * R[3 * b + 2] - (a == b ? 1.f : 0.f);
+            defect = fmaxf(defect, fabsf(d));
+        }
+    valid[g] = defect <= FRS_MAX_DEFECT ? 1 : 0;            // (NaN normals compare false: invalid)
+}
+
+// Table of Y_i(z_k) in the two MFMA operand layouts.  Per 16-sample block b (samples 16 b .. 16 b + 15) eight 64-float
+// slots: slot s < 4 = A operand of the local-light product, lane (r = lane & 15, q = lane >> 4) holds Yz[16 b + r][4 s + q];
+// slot 4 + v = A operand of the gradient product, lane (i, q) holds Yz[16 b + 4 q + v][i].  Rows k >= K are zero.
+__global__ void __launch_bounds__(256)
+frs_build_tables_kernel(int K, int nblk, const float* __restrict__ zsamples /*[K,3]*/, float* __restrict__ tables)
+{
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= nblk * 512) return;
+    const int b = idx >> 9, slot = (idx >> 6) & 7, lane = idx & 63;
+    const int lo = lane & 15, q = lane >> 4;
+    int k, i;
+    if (slot < 4) { k = 16 * b + lo; i = 4 * slot + q; }
+    else { k = 16 * b + 4 * q + (slot - 4); i = lo; }
+    float val = 0.f;
+    if (k < K) {
+        float Y[16];
+        sh_basis16(zsamples[3 * k], zsamples[3 * k + 1], zsamples[3 * k + 2], 16, Y);
+        val = Y[0];
+#pragma unroll
+        for (int j = 1; j < 16; j++) val = i == j ? Y[j] : val;
+    }
+    tables[idx] = val;
+}
+
+// ---- coefficient rotation (thread per Gaussian; rows through LDS with coalesced 16-byte accesses, common.hpp) ---------------
+// band l of the function is sampled at the rotated points R p_j and re-expanded: c'_l = A_l^{-1} [sum_i c_{l,i} Y_{l,i}(R p_j)]_j
+template <int A0, int N, bool BACK>
+__device__ __forceinline__ void frs_rotate_band(const float (&R)[9], const float (*pts)[3], const float (*ainv)[N], float* row)
+{
+    float f[N][3];
+    if (!BACK) {
+        // f_j = band-l part of the function at R p_j
+#pragma unroll
+        for (int j = 0; j < N; j++) {
+            const float px = pts[j][0], py = pts[j][1], pz = pts[j][2];
+            float Y[16];
+            sh_basis16(R[0] * px + R[1] * py + R[2] * pz, R[3] * px + R[4] * py + R[5] * pz, R[6] * px + R[7] * py + R[8] * pz,
+                       16, Y);
+#pragma unroll
+            for (int c = 0; c < 3; c++) {
+                float acc = 0.f;
+#pragma unroll
+                for (int i = 0; i < N; i++) acc += Y[A0 + i] * row[(A0 + i) * 3 + c];
+                f[j][c] = acc;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < N; i++)
+#pragma unroll
+            for (int c = 0; c < 3; c++) {
+                float acc = 0.f;
+#pragma unroll
+                for (int j = 0; j < N; j++) acc += ainv[i][j] * f[j][c];
+                row[(A0 + i) * 3 + c] = acc;
+            }
+    } else {
+        // transpose of the map above: t = A^{-T} dc', dc_i = sum_j Y_{l,i}(R p_j) t_j
+#pragma unroll
+        for (int j = 0; j < N; j++)
+#pragma unroll
+            for (int c = 0; c < 3; c++) {
+                float acc = 0.f;
+#pragma unroll
+                for (int i = 0; i < N; i++) acc += ainv[i][j] * row[(A0 + i) * 3 + c];
+                f[j][c] = acc;
+            }
+        float out[N][3];
+#pragma unroll
+        for (int i = 0; i < N; i++) out[i][0] = out[i][1] = out[i][2] = 0.f;
+#pragma unroll
+        for (int j = 0; j < N; j++) {
+            const float px = pts[j][0], py = pts[j][1], pz = pts[j][2];
+            float Y[16];
+            sh_basis16(R[0] * px + R[1] * py + R[2] * pz, R[3] * px + R[4] * py + R[5] * pz, R[6] * px + R[7] * py + R[8] * pz,
+                       16, Y);
+#pragma unroll
+            for (int i = 0; i < N; i++)
+#pragma unroll
+                for (int c = 0; c < 3; c++) out[i][c] += Y[A0 + i] * f[j][c];
+        }
+#pragma unroll
+        for (int i = 0; i < N; i++)
+#pragma unroll
+            for (int c = 0; c < 3; c++) row[(A0 + i) * 3 + c] = out[i][c];
+    }
+}
+
+// BACK == false: src = incidents [P,16,3] -> dst = rotated coefficients c' [P,16,3]
+// BACK == true : src = dL/dc' [P,16,3]    -> dst = dL/d incidents [P,16,3]  (every row is written; rows of Gaussians that are
+//                not on the rotated path hold garbage and are overwritten by the general kernel afterwards)
+template <bool BACK>
+__global__ void __launch_bounds__(256)
+frs_rotate_kernel(int P, const float* __restrict__ ray_normals, const float* __restrict__ src, float* __restrict__ dst)
+{
+    __shared__ float s_rows[256 * 49];
+    __shared__ uint8_t s_live[256];
+    const int first = blockIdx.x * 256, g = first + (int)threadIdx.x;
+    s_live[threadIdx.x] = 1;
+    __syncthreads();
+    stage_rows_in_256(src, first, P, 48, s_live, s_rows);
+    __syncthreads();
+    if (g < P) {
+        float R[9];
+        frs_rotation(ray_normals[3 * (size_t)g], ray_normals[3 * (size_t)g + 1], ray_normals[3 * (size_t)g + 2], R);
+        float* row = s_rows + threadIdx.x * 49;                 // band 0 (the constant) is rotation invariant
+        frs_rotate_band<1, 3, BACK>(R, kShRotPoints1, kShRotAinv1, row);
+        frs_rotate_band<4, 5, BACK>(R, kShRotPoints2, kShRotAinv2, row);
+        frs_rotate_band<9, 7, BACK>(R, kShRotPoints3, kShRotAinv3, row);
+    }
+    __syncthreads();
+    stage_rows_out_256(dst, first, P, 48, s_rows);
+}
+
+// ---- per-lane sample block: 4 consecutive samples of one Gaussian ------------------------------------------------------------
+struct FrsBlock {
+    float4 d0, d1, d2;      // 4 directions (12 floats)
+    float4 vis;
+    uint4 t0, t1, t2;       // 4 lookup records (12 dwords)
+};
+
+__device__ __forceinline__ FrsBlock frs_load_block(size_t row /* g * K */, int k0, int K, const float* __restrict__ dirs,
+                                                   const float* __restrict__ visibility, const uint32_t* __restrict__ taps)
+{
+    FrsBlock b;
+    const int kc = k0 + 4 <= K ? k0 : K - 4;                         // (K % 4 == 0, K >= 4): clamped loads stay inside the row
+    const size_t o = row + (size_t)kc;
+    const float4* dp = reinterpret_cast<const float4*>(dirs + 3 * o);
+    b.d0 = dp[0]; b.d1 = dp[1]; b.d2 = dp[2];
+    b.vis = *reinterpret_cast<const float4*>(visibility + o);
+    const uint4* tp = reinterpret_cast<const uint4*>(taps + 3 * o);
+    b.t0 = tp[0]; b.t1 = tp[1]; b.t2 = tp[2];
+    return b;
+}
+
+__device__ __forceinline__ void frs_sample_of(const FrsBlock& b, int v, float& dx, float& dy, float& dz, float& vis,
+                                              PackedTap& t)
+{
+    const float d[12] = {b.d0.x, b.d0.y, b.d0.z, b.d0.w, b.d1.x, b.d1.y, b.d1.z, b.d1.w, b.d2.x, b.d2.y, b.d2.z, b.d2.w};
+    const uint32_t u[12] = {b.t0.x, b.t0.y, b.t0.z, b.t0.w, b.t1.x, b.t1.y, b.t1.z, b.t1.w, b.t2.x, b.t2.y, b.t2.z, b.t2.w};
+    const float vs[4] = {b.vis.x, b.vis.y, b.vis.z, b.vis.w};
+    dx = d[3 * v]; dy = d[3 * v + 1]; dz = d[3 * v + 2];
+    vis = vs[v];
+    t.xy = u[3 * v]; t.wx1 = __uint_as_float(u[3 * v + 1]); t.wy1 = __uint_as_float(u[3 * v + 2]);
+}
+
+__device__ __forceinline__ float frs_sum4(float x)       // sum over the 4 lanes of a Gaussian: lanes l, l^16, l^32, l^48
+{
+    x += __shfl_xor(x, 16, 64);
+    x += __shfl_xor(x, 32, 64);
+    return x;
+}
+
+// =====================================================================================================================
+// Forward (training outputs: pbr, diffuse_light, mean visibility -- columns 0..5 and 18 of the 19; neilf.py:120-122)
+// =====================================================================================================================
+__global__ void __launch_bounds__(64 * FRS_WAVES)
+shade_forward_frs_kernel(int P, int K, const float* __restrict__ base_color, const float* __restrict__ roughness,
+                         const float* __restrict__ normals, const float* __restrict__ viewdirs,
+                         const float* __restrict__ cprime, const float4* __restrict__ env4, int He, int We,
+                         const float* __restrict__ visibility, const float* __restrict__ dirs, float uniform_area,
+                         const uint32_t* __restrict__ taps, const float* __restrict__ tables,
+                         const uint8_t* __restrict__ valid, float* __restrict__ out)
+{
+    extern __shared__ __attribute__((aligned(16))) float s_mem[];
+    float4* s_env4 = reinterpret_cast<float4*>(s_mem);
+    for (int i = threadIdx.x; i < He * We; i += blockDim.x) s_env4[i] = env4[i];
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int gl = lane & 15, q = lane >> 4;
+    const int nblk = (K + 15) >> 4;
+    const float invK = 1.0f / (float)K;
+    const int ngroups = (P + FRS_G - 1) / FRS_G;
+    for (int grp = blockIdx.x * FRS_WAVES + wave; grp < ngroups; grp += gridDim.x * FRS_WAVES) {
+        const int g = grp * FRS_G + gl;
+        const int gc = min(g, P - 1);
+        const bool live_g = g < P && valid[gc] != 0;
+        // per-Gaussian record
+        float u[64];
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+            u[48 + c] = base_color[3 * (size_t)gc + c];
+            u[52 + c] = normals[3 * (size_t)gc + c];
+            u[55 + c] = viewdirs[3 * (size_t)gc + c];
+        }
+        u[51] = roughness[gc];
+        GaussFwd G;
+        gauss_setup(G, u);
+        const float fd[3] = {G.base[0] / kPi, G.base[1] / kPi, G.base[2] / kPi};
+        const float nom1 = G.NoV * (1.f - G.kk) + G.kk;
+        // B operand of the local-light product: rotated coefficients 4 s + q of the lane's Gaussian
+        float bc[4][3];
+#pragma unroll
+        for (int s = 0; s < 4; s++)
+#pragma unroll
+            for (int c = 0; c < 3; c++) bc[s][c] = cprime[(size_t)gc * 48 + (4 * s + q) * 3 + c];
+        float acc[7] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        const size_t row = (size_t)gc * (size_t)K;
+        FrsBlock nxt = frs_load_block(row, 4 * q, K, dirs, visibility, taps);
+        for (int b = 0; b < nblk; b++) {
+            const FrsBlock cur = nxt;
+            if (b + 1 < nblk) nxt = frs_load_block(row, 16 * (b + 1) + 4 * q, K, dirs, visibility, taps);
+            // local light of the 16 samples x 16 Gaussians of this block: l[c] = sum_i Yz[k][i] c'[i][c]
+            const float* tb = tables + (size_t)b * 512 + lane;
+            f32x4 l[3] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+            for (int s = 0; s < 4; s++) {
+                const float a = tb[64 * s];
+#pragma unroll
+                for (int c = 0; c < 3; c++) l[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bc[s][c], l[c], 0, 0, 0);
+            }
+#pragma unroll
+            for (int v = 0; v < 4; v++) {
+                const int k = 16 * b + 4 * q + v;
+                const bool ok = live_g && k < K;
+                float dx, dy, dz, vis;
+                PackedTap t;
+                frs_sample_of(cur, v, dx, dy, dz, vis, t);
+                float e[3], w4[4];
+                int tex[4];
+                env_fetch(t, s_env4, He, We, e, tex, w4);
+                const float lv = ok ? 1.f : 0.f;
+                const float ndi = fmaxf(G.n[0] * dx + G.n[1] * dy + G.n[2] * dz, 0.f);
+                const float area_ndi = uniform_area * ndi * lv;
+                const float dinv = __builtin_amdgcn_rsqf(fmaxf(dx * dx + dy * dy + dz * dz, 1e-24f));
+                const float Lx = dx * dinv, Ly = dy * dinv, Lz = dz * dinv;
+                const float ux = (Lx + G.V[0]) / 2.0f, uy = (Ly + G.V[1]) / 2.0f, uz = (Lz + G.V[2]) / 2.0f;
+                const float uinv = __builtin_amdgcn_rsqf(fmaxf(ux * ux + uy * uy + uz * uz, 1e-24f));
+                const float Hx = ux * uinv, Hy = uy * uinv, Hz = uz * uinv;
+                const float NoL = fminf(fmaxf(G.N[0] * Lx + G.N[1] * Ly + G.N[2] * Lz, 1e-6f), 1.f);
+                const float NoH = fminf(fmaxf(G.N[0] * Hx + G.N[1] * Hy + G.N[2] * Hz, 1e-6f), 1.f);
+                const float VoH = fminf(fmaxf(G.V[0] * Hx + G.V[1] * Hy + G.V[2] * Hz, 1e-6f), 1.f);
+                const float p2 = exp2f((-5.55473f * VoH - 6.98316f) * VoH);
+                const float frac = (0.04f + 0.96f * p2) * G.a2;
+                const float nom0 = NoH * NoH * (G.a2 - 1.f) + 1.f;
+                const float nom2 = NoL * (1.f - G.kk) + G.kk;
+                const float nom = fminf(fmaxf(4.f * kPi * nom0 * nom0 * nom1 * nom2, 1e-6f), 4.f * kPi);
+                const float spec = frac / nom;
+#pragma unroll
+                for (int c = 0; c < 3; c++) {
+                    const float lin = fmaxf(l[c][v], 0.f) + e[c] * vis;
+                    const float transport = lin * area_ndi;
+                    acc[c] += (fd[c] + spec) * transport;      // pbr
+                    acc[3 + c] += transport;                   // diffuse_light
+                }
+                acc[6] += vis * lv;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 7; i++) acc[i] = frs_sum4(acc[i]) * invK;
+        if (live_g && q == 0) {
+            float* o = out + (size_t)g * SHADE_NOUT;
+#pragma unroll
+            for (int i = 0; i < 6; i++) o[i] = acc[i];
+            o[18] = acc[6];
+        }
+    }
+}
+
+// =====================================================================================================================
+// Backward: gradients of <pbr, g_pbr> + <diffuse_light, g_diff> w.r.t. base colour, roughness, view direction, the ROTATED
+// incident-light coefficients (dcp [P,16,3]; frs_rotate_kernel<true> takes them back) and the environment texture.
+// Per-sample arithmetic = the general kernels' (neilf.py:339-407 differentiated); the texture gradient goes through the same
+// 64-bit fixed-point LDS accumulators.
+// =====================================================================================================================
+__global__ void __launch_bounds__(64 * FRS_WAVES)
+shade_backward_frs_kernel(int P, int K, const float* __restrict__ base_color, const float* __restrict__ roughness,
+                          const float* __restrict__ normals, const float* __restrict__ viewdirs,
+                          const float* __restrict__ cprime, const float* __restrict__ g_pbr,
+                          const float* __restrict__ g_diff, const float4* __restrict__ env4, int He, int We,
+                          const float* __restrict__ visibility, const float* __restrict__ dirs, float uniform_area,
+                          const uint32_t* __restrict__ taps, const float* __restrict__ tables,
+                          const uint8_t* __restrict__ valid, float* __restrict__ d_base, float* __restrict__ d_rough,
+                          float* __restrict__ d_view, float* __restrict__ dcp, float* __restrict__ d_env,
+                          const unsigned int* __restrict__ gmax_bits, int gmax_n)
+{
+    extern __shared__ __attribute__((aligned(16))) float s_mem[];
+    const int ntexel = He * We;
+    float4* s_env4 = reinterpret_cast<float4*>(s_mem);
+    long long* s_denv = reinterpret_cast<long long*>(s_mem + 4 * ntexel);        // [texel][3] 64-bit fixed point
+    const float gmax = wave_gmax(gmax_bits, gmax_n);
+    const bool fixed = gmax > 0.f && gmax <= 3.0e38f;
+    const float fx_scale = fixed ? 34359738368.0f / gmax : 0.f;                 // 2^35 / max|g|
+    const float fx_clamp = gmax * 8192.0f;
+    for (int i = threadIdx.x; i < ntexel; i += blockDim.x) s_env4[i] = env4[i];
+    for (int i = threadIdx.x; i < 3 * ntexel; i += blockDim.x) s_denv[i] = 0;
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int gl = lane & 15, q = lane >> 4;
+    const int nblk = (K + 15) >> 4;
+    const float invK = 1.0f / (float)K;
+    const int ngroups = (P + FRS_G - 1) / FRS_G;
+    for (int grp = blockIdx.x * FRS_WAVES + wave; grp < ngroups; grp += gridDim.x * FRS_WAVES) {
+        const int g = grp * FRS_G + gl;
+        const int gc = min(g, P - 1);
+        const bool live_g = g < P && valid[gc] != 0;
+        float u[64];
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+            u[48 + c] = base_color[3 * (size_t)gc + c];
+            u[52 + c] = normals[3 * (size_t)gc + c];
+            u[55 + c] = viewdirs[3 * (size_t)gc + c];
+        }
+        u[51] = roughness[gc];
+        GaussFwd G;
+        gauss_setup(G, u);
+        const float fd[3] = {G.base[0] / kPi, G.base[1] / kPi, G.base[2] / kPi};
+        const float gp[3] = {g_pbr[3 * (size_t)gc] * invK, g_pbr[3 * (size_t)gc + 1] * invK, g_pbr[3 * (size_t)gc + 2] * invK};
+        const float gd[3] = {g_diff[3 * (size_t)gc] * invK, g_diff[3 * (size_t)gc + 1] * invK, g_diff[3 * (size_t)gc + 2] * invK};
+        const float nom1 = G.NoV * (1.f - G.kk) + G.kk;
+        float bc[4][3];
+#pragma unroll
+        for (int s = 0; s < 4; s++)
+#pragma unroll
+            for (int c = 0; c < 3; c++) bc[s][c] = cprime[(size_t)gc * 48 + (4 * s + q) * 3 + c];
+        f32x4 dcq[3] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};   // dL/dc'[4 q + v'][c]
+        float accb[7] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};     // albedo 3, roughness, view direction 3
+        const size_t row = (size_t)gc * (size_t)K;
+        FrsBlock nxt = frs_load_block(row, 4 * q, K, dirs, visibility, taps);
+        for (int b = 0; b < nblk; b++) {
+            const FrsBlock cur = nxt;
+            if (b + 1 < nblk) nxt = frs_load_block(row, 16 * (b + 1) + 4 * q, K, dirs, visibility, taps);
+            const float* tb = tables + (size_t)b * 512 + lane;
+            f32x4 l[3] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+            for (int s = 0; s < 4; s++) {
+                const float a = tb[64 * s];
+#pragma unroll
+                for (int c = 0; c < 3; c++) l[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bc[s][c], l[c], 0, 0, 0);
+            }
+#pragma unroll
+            for (int v = 0; v < 4; v++) {
+                const int k = 16 * b + 4 * q + v;
+                const bool ok = live_g && k < K;
+                float dx, dy, dz, vis;
+                PackedTap t;
+                frs_sample_of(cur, v, dx, dy, dz, vis, t);
+                float e[3], w4[4];
+                int tex[4];
+                env_fetch(t, s_env4, He, We, e, tex, w4);
+                const float ndi = fmaxf(G.n[0] * dx + G.n[1] * dy + G.n[2] * dz, 0.f);
+                const float area_ndi = ok ? uniform_area * ndi : 0.f;
+                const float dinv = __builtin_amdgcn_rsqf(fmaxf(dx * dx + dy * dy + dz * dz, 1e-24f));
+                const float Lx = dx * dinv, Ly = dy * dinv, Lz = dz * dinv;
+                const float ux = (Lx + G.V[0]) / 2.0f, uy = (Ly + G.V[1]) / 2.0f, uz = (Lz + G.V[2]) / 2.0f;
+                const float uinv = __builtin_amdgcn_rsqf(fmaxf(ux * ux + uy * uy + uz * uz, 1e-24f));
+                const float Hx = ux * uinv, Hy = uy * uinv, Hz = uz * uinv;
+                const float NoL = fminf(fmaxf(G.N[0] * Lx + G.N[1] * Ly + G.N[2] * Lz, 1e-6f), 1.f);
+                const float rawNoH = G.N[0] * Hx + G.N[1] * Hy + G.N[2] * Hz, rawVoH = G.V[0] * Hx + G.V[1] * Hy + G.V[2] * Hz;
+                const float NoH = fminf(fmaxf(rawNoH, 1e-6f), 1.f), VoH = fminf(fmaxf(rawVoH, 1e-6f), 1.f);
+                const float p2 = exp2f((-5.55473f * VoH - 6.98316f) * VoH);
+                const float frac0 = 0.04f + 0.96f * p2;
+                const float frac = frac0 * G.a2;
+                const float nom0 = NoH * NoH * (G.a2 - 1.f) + 1.f;
+                const float nom2 = NoL * (1.f - G.kk) + G.kk;
+                const float nomr = 4.f * kPi * nom0 * nom0 * nom1 * nom2;
+                const float nom = fminf(fmaxf(nomr, 1e-6f), 4.f * kPi);
+                const float spec = frac / nom;
+                float gspec = 0.f, dlin[3], dl[3];
+#pragma unroll
+                for (int c = 0; c < 3; c++) {
+                    const float lc = l[c][v];
+                    const float lin = fmaxf(lc, 0.f) + e[c] * vis;
+                    const float transport = lin * area_ndi;
+                    const float dT = gp[c] * (fd[c] + spec) + gd[c];      // dL / d transport_c
+                    gspec += gp[c] * transport;
+                    accb[c] += gp[c] * transport / kPi;                   // albedo
+                    dlin[c] = dT * area_ndi;                              // dL / d (incident light)_c
+                    dl[c] = lc >= 0.f ? dlin[c] : 0.f;                    // clamp_min(0): gradient where the SH sum >= 0
+                }
+                // environment-texture gradient: 4 taps x 3 channels (an out-of-range tap carries weight 0)
+                if (vis != 0.f && area_ndi != 0.f) {
+                    const float ev[3] = {dlin[0] * vis, dlin[1] * vis, dlin[2] * vis};
+                    if (fixed) {
+                        const double scale_d = (double)fx_scale;
+#pragma unroll
+                        for (int tq = 0; tq < 4; tq++) {
+#pragma unroll
+                            for (int c = 0; c < 3; c++) {
+                                const float cl = __builtin_amdgcn_fmed3f(ev[c] * w4[tq], -fx_clamp, fx_clamp);
+                                const double dsum = __builtin_fma((double)cl, scale_d, 6755399441055744.0);
+                                const unsigned long long bits =
+                                    (unsigned long long)__double_as_longlong(dsum) - 0x4338000000000000ull;
+                                atomicAdd(reinterpret_cast<unsigned long long*>(&s_denv[3 * tex[tq] + c]), bits);
+                            }
+                        }
+                    } else {
+#pragma unroll
+                        for (int tq = 0; tq < 4; tq++)
+                            if (w4[tq] != 0.f)
+#pragma unroll
+                                for (int c = 0; c < 3; c++) atomicAdd(&d_env[3 * (size_t)tex[tq] + c], ev[c] * w4[tq]);
+                    }
+                }
+                // specular -> roughness, view direction
+                const bool nom_free = nomr >= 1e-6f && nomr <= 4.f * kPi;
+                const float dfrac = gspec / nom;
+                const float dnom = nom_free ? -gspec * frac / (nom * nom) : 0.f;
+                float da2 = dfrac * frac0;
+                const float dfrac0 = dfrac * G.a2;
+                const float dFMi = dfrac0 * 0.96f * 0.6931471805599453f * p2;
+                float dVoH = dFMi * (-2.f * 5.55473f * VoH - 6.98316f);
+                const float c4 = 4.f * kPi;
+                const float dnom0 = dnom * c4 * 2.f * nom0 * nom1 * nom2;
+                const float dnom1 = dnom * c4 * nom0 * nom0 * nom2;
+                const float dnom2 = dnom * c4 * nom0 * nom0 * nom1;
+                float dNoH = dnom0 * 2.f * NoH * (G.a2 - 1.f);
+                da2 += dnom0 * NoH * NoH;
+                float dNoV = dnom1 * (1.f - G.kk);
+                const float dkk = dnom1 * (1.f - G.NoV) + dnom2 * (1.f - NoL);
+                const float da = dkk / 8.f + da2 * 2.f * G.a;
+                accb[3] += dkk * 2.f / 8.f + da * 2.f * G.r;                // roughness
+                if (!(rawNoH >= 1e-6f && rawNoH <= 1.f)) dNoH = 0.f;
+                if (!(rawVoH >= 1e-6f && rawVoH <= 1.f)) dVoH = 0.f;
+                if (!(G.rawNoV >= 1e-6f && G.rawNoV <= 1.f)) dNoV = 0.f;
+                const float dHx = dNoH * G.N[0] + dVoH * G.V[0], dHy = dNoH * G.N[1] + dVoH * G.V[1],
+                            dHz = dNoH * G.N[2] + dVoH * G.V[2];
+                float dVx = dVoH * Hx + dNoV * G.N[0], dVy = dVoH * Hy + dNoV * G.N[1], dVz = dVoH * Hz + dNoV * G.N[2];
+                const float hd = Hx * dHx + Hy * dHy + Hz * dHz;
+                dVx += 0.5f * (dHx - Hx * hd) * uinv;
+                dVy += 0.5f * (dHy - Hy * hd) * uinv;
+                dVz += 0.5f * (dHz - Hz * hd) * uinv;
+                const float vd = G.V[0] * dVx + G.V[1] * dVy + G.V[2] * dVz;
+                accb[4] += (dVx - G.V[0] * vd) / G.vlen;
+                accb[5] += (dVy - G.V[1] * vd) / G.vlen;
+                accb[6] += (dVz - G.V[2] * vd) / G.vlen;
+                // gradient product: dc'[i][c] += Yz[k][i] dl[c] over the 4 samples (one per q) of this v
+                const float a2v = tb[64 * (4 + v)];
+#pragma unroll
+                for (int c = 0; c < 3; c++) dcq[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(a2v, dl[c], dcq[c], 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 7; i++) accb[i] = frs_sum4(accb[i]);
+        if (live_g) {
+            if (q == 0) {
+#pragma unroll
+                for (int c = 0; c < 3; c++) {
+                    d_base[3 * (size_t)g + c] = accb[c];
+                    d_view[3 * (size_t)g + c] = accb[4 + c];
+                }
+                d_rough[g] = accb[3];
+            }
+            // lane (g, q) holds dL/dc'[4 q + v'][c] in dcq[c][v']: 12 consecutive floats of the Gaussian's row
+            float4* o = reinterpret_cast<float4*>(dcp + (size_t)g * 48 + 12 * q);
+            o[0] = make_float4(dcq[0][0], dcq[1][0], dcq[2][0], dcq[0][1]);
+            o[1] = make_float4(dcq[1][1], dcq[2][1], dcq[0][2], dcq[1][2]);
+            o[2] = make_float4(dcq[2][2], dcq[0][3], dcq[1][3], dcq[2][3]);
+        }
+    }
+    if (fixed) {
+        __syncthreads();
+        const float inv = 1.0f / fx_scale;
+        for (int i = threadIdx.x; i < 3 * ntexel; i += blockDim.x) {
+            const long long v64 = s_denv[i];
+            if (v64 != 0) atomicAdd(&d_env[i], (float)((double)v64 * (double)inv));
+        }
+    }
+}
+
+}  // namespace r3dg

@@ -310,7 +310,10 @@ class FusedStage2Step(_BoundedForward):
             self.refresh_activations()
             self.visibility, self.incident_dirs, self.incident_areas, self.tracer = update_visibility(
                 self.xyz, self.a_scales, self.a_rot, self.a_opacity, self.a_normal, sample_num, group=process_group)
+            # the normals the ray set was generated from (the trained normal moves on; the cached directions do not)
+            self._ray_normals = self.a_normal.clone()
         self._taps, self._taps_key = None, None
+        self._frs = None                            # shading_ops.FixedRaySet of the current direction cache, or None
         self.opt = FusedAdam([
             dict(param=self.xyz, lr=rate("xyz")), dict(param=self.normal, lr=rate("normal")),
             dict(param=self.scaling, lr=rate("scaling")), dict(param=self.rotation, lr=rate("rotation")),
@@ -373,6 +376,13 @@ class FusedStage2Step(_BoundedForward):
             # fibonacci_sphere_sampling gives every sample the area 2 pi: then the area cache need not be read at all
             lo, hi = float(self.incident_areas.min()), float(self.incident_areas.max())
             self._uniform_area = lo if lo == hi else None
+            # fixed-ray-set kernels (SH contractions on the matrix cores, csrc/shading_frs.hpp) when the cache IS the
+            # Fibonacci set of the snapshot normals -- checked here, once per visibility update -- and fits their limits;
+            # otherwise (caches handed in from elsewhere, other K / texture sizes, R3DG_SHADE_FRS=0) the general kernels
+            self._frs = None
+            if (os.environ.get("R3DG_SHADE_FRS", "1") != "0" and self._uniform_area is not None and
+                    shading_ops.FixedRaySet.supported(self.K, self.M, He, We)):
+                self._frs = shading_ops.FixedRaySet.try_build(getattr(self, "_ray_normals", None), src)
         return self._taps
 
     def forward_backward(self, cam, bg, gt, early_adam=False, image_mask=None):
@@ -400,7 +410,7 @@ class FusedStage2Step(_BoundedForward):
                     bg, self.xyz, self.features, empty, self.a_opacity, self.a_scales, self.a_rot, 1.0, empty, vm,
                     cam.full_proj_transform, cam.tanfovx, cam.tanfovy, cam.cx, cam.cy, H, W, self.shs, 3, campos, False,
                     True, False, capacity=self._capacity, overflow_flag=self._flag,
-                    overflow_count=self._overflow_count, ordering_stream=self._order_stream)
+                    overflow_count=self._overflow_count, ordering_stream=self._order_stream, want_weights=False)
             else:
                 # first half of the rasterizer (projection + async read-back of num_rendered): the shading kernels below
                 # run while the host waits for the count and enqueues the second half
@@ -408,18 +418,23 @@ class FusedStage2Step(_BoundedForward):
                 pending = rasterizer_ops.rasterize_gaussians_begin(
                     bg, self.xyz, self.features, empty, self.a_opacity, self.a_scales, self.a_rot, 1.0, empty, vm,
                     cam.full_proj_transform, cam.tanfovx, cam.tanfovy, cam.cx, cam.cy, H, W, self.shs, 3, campos, False,
-                    True, False)
+                    True, False, want_weights=False)       # (stage 2 does not densify: nobody reads the blend weights)
             self.flush()        # (world > 1) the previous iteration's incident-light update lands here
             env_c = F.softplus(self.env)[0]                                      # DirectLightMap.get_env
             He, We = env_c.shape[0], env_c.shape[1]
             taps = self.taps(He, We)
-            _lib.check(L.r3dg_shade_forward_cached(
-                stream(), P, self.K, self.M, self.a_base.data_ptr(), self.a_rough.data_ptr(), self.a_normal.data_ptr(),
-                self.a_viewdirs.data_ptr(), self.incidents.data_ptr(), env_c.data_ptr(), He, We, None,
-                self.visibility.data_ptr(), self.incident_dirs.data_ptr(),
-                None if self._uniform_area is not None else self.incident_areas.data_ptr(), self._uniform_area or 0.0,
-                taps.data_ptr(), 1 | (4 if self._order_stream is not None else 0),     # train outputs | leave room
-                self.shade_out.data_ptr()), "shade_forward")
+            if self._frs is not None:
+                self._frs.forward(self.a_base, self.a_rough, self.a_normal, self.a_viewdirs, self.incidents, env_c,
+                                  self.visibility, self.incident_dirs, self.incident_areas, taps, self.shade_out,
+                                  uniform_area=self._uniform_area, leave_room=self._order_stream is not None)
+            else:
+                _lib.check(L.r3dg_shade_forward_cached(
+                    stream(), P, self.K, self.M, self.a_base.data_ptr(), self.a_rough.data_ptr(), self.a_normal.data_ptr(),
+                    self.a_viewdirs.data_ptr(), self.incidents.data_ptr(), env_c.data_ptr(), He, We, None,
+                    self.visibility.data_ptr(), self.incident_dirs.data_ptr(),
+                    None if self._uniform_area is not None else self.incident_areas.data_ptr(), self._uniform_area or 0.0,
+                    taps.data_ptr(), 1 | (4 if self._order_stream is not None else 0),     # train outputs | leave room
+                    self.shade_out.data_ptr()), "shade_forward")
             self.sums.zero_()
             _lib.check(L.r3dg_stage2_pack_features(
                 stream(), P, self.xyz.data_ptr(), vm.data_ptr(), self.a_normal.data_ptr(), self.a_base.data_ptr(),
@@ -527,10 +542,17 @@ class FusedStage2Step(_BoundedForward):
             # scale from the unpack kernel: nothing sits between that kernel and the shading backward
             if self._d_env is None or self._d_env.shape != env_c.shape:
                 self._d_env = torch.zeros_like(env_c)
-            d_base, d_rough, d_view, _d_inc, d_env = shading_ops.shade_backward(
-                self.a_base, self.a_rough, self.a_normal, self.a_viewdirs, self.incidents, env_c, self.visibility,
-                self.incident_dirs, self.incident_areas, self.d_pbr, self.d_diffuse,
-                out_incidents=self.grads["incidents"], taps=taps, out_env=self._d_env, block_absmax=self._absmax)
+            if self._frs is not None:
+                d_base, d_rough, d_view, _d_inc, d_env = self._frs.backward(
+                    self.a_base, self.a_rough, self.a_normal, self.a_viewdirs, self.incidents, env_c, self.visibility,
+                    self.incident_dirs, self.incident_areas, taps, self.d_pbr, self.d_diffuse,
+                    uniform_area=self._uniform_area, out_incidents=self.grads["incidents"], out_env=self._d_env,
+                    block_absmax=self._absmax)
+            else:
+                d_base, d_rough, d_view, _d_inc, d_env = shading_ops.shade_backward(
+                    self.a_base, self.a_rough, self.a_normal, self.a_viewdirs, self.incidents, env_c, self.visibility,
+                    self.incident_dirs, self.incident_areas, self.d_pbr, self.d_diffuse,
+                    out_incidents=self.grads["incidents"], taps=taps, out_env=self._d_env, block_absmax=self._absmax)
             gr = self.grads
             if self._side is not None and not self.frozen_geometry:          # join the geometry backward
                 torch.cuda.current_stream().wait_stream(self._side)

@@ -99,7 +99,8 @@ class _PendingForward:
 def rasterize_gaussians_begin(background, means3D, features, colors, opacity, scales, rotations, scale_modifier,
                               cov3D_precomp, viewmatrix, projmatrix, tan_fovx, tan_fovy, cx, cy, image_height,
                               image_width, sh, degree, campos, prefiltered, computer_pseudo_normal, debug,
-                              capacity=None, overflow_flag=None, overflow_count=None, ordering_stream=None):
+                              capacity=None, overflow_flag=None, overflow_count=None, ordering_stream=None,
+                              want_weights=True):
     """First half of rasterize_gaussians (same arguments): projection + asynchronous read-back of num_rendered.  Returns
     an object whose .finish() completes the call and returns the 13-tuple.  Kernels launched on the current stream in
     between (e.g. the ones that fill `features`, whose CONTENTS are first read by .finish()'s kernels) overlap the wait.
@@ -108,7 +109,9 @@ def rasterize_gaussians_begin(background, means3D, features, colors, opacity, sc
     the projection is queued on the current stream and the instance ordering behind it on `ordering_stream` (default:
     the current stream) at once, with the binning state sized for `capacity` instances.
     `overflow_flag` (float32 tensor, >= 1 element) is set to 1 when the frame needed more and was dropped, else 0;
-    `overflow_count` (int32 tensor) counts dropped frames.  All tensors are allocated on the current stream."""
+    `overflow_count` (int32 tensor) counts dropped frames.  All tensors are allocated on the current stream.
+    `want_weights=False` (not in the reference): the per-Gaussian blend weights -- which only the densification statistics
+    read -- are not computed; the `weights` slot of the result is None."""
     L = _lib.lib()
     if means3D.ndimension() != 2 or means3D.size(1) != 3:
         raise RuntimeError("means3D must have dimensions (num_points, 3)")
@@ -128,7 +131,7 @@ def rasterize_gaussians_begin(background, means3D, features, colors, opacity, sc
     out_feature, out_normal, out_surface_xyz = slab[5:5 + S], slab[5 + S:8 + S], slab[8 + S:11 + S]
     if not computer_pseudo_normal:
         slab[5 + S:].zero_()
-    out_weights = torch.zeros((P, 1), **fopt)
+    out_weights = torch.zeros((P, 1), **fopt) if want_weights else None
     radii = torch.empty((P,), dtype=torch.int32, device=dev)
 
     rs = _Resizer(dev)
@@ -146,7 +149,8 @@ def rasterize_gaussians_begin(background, means3D, features, colors, opacity, sc
                   _lib.ptr(sc_), float(scale_modifier), _lib.ptr(rot_), _lib.ptr(cov_), _lib.ptr(vm_), _lib.ptr(pm_),
                   _lib.ptr(cam_), float(tan_fovx), float(tan_fovy), float(cx), float(cy), int(bool(prefiltered)),
                   int(bool(computer_pseudo_normal)), out_color.data_ptr(), out_opacity.data_ptr(), out_depth.data_ptr(),
-                  _lib.ptr(out_feature), out_normal.data_ptr(), out_surface_xyz.data_ptr(), out_weights.data_ptr(),
+                  _lib.ptr(out_feature), out_normal.data_ptr(), out_surface_xyz.data_ptr(),
+                  out_weights.data_ptr() if out_weights is not None else None,
                   radii.data_ptr(), int(bool(debug)))
         with torch.cuda.device(dev):
             if capacity is None:

@@ -182,10 +182,10 @@ class RelightRenderer:
             _lib.check(L.r3dg_relight_pack_features(
                 stream(), P, self.xyz.data_ptr(), vm.data_ptr(), self.a_normal.data_ptr(), self.a_base.data_ptr(),
                 self.a_rough.data_ptr(), self.shade_out.data_ptr(), self.features.data_ptr()), "relight_pack_features")
-            fw = rasterizer_ops.rasterize_gaussians(
+            fw = rasterizer_ops.rasterize_gaussians_begin(
                 bg, self.xyz, self.features, empty, self.a_opacity, self.a_scales, self.a_rot, 1.0, empty, vm,
                 cam.full_proj_transform, cam.tanfovx, cam.tanfovy, cam.cx, cam.cy, H, W, self.shs, 3, campos, False,
-                True, False)
+                True, False, want_weights=False).finish()          # (a frame has no use for the per-Gaussian blend weights)
             R, n_contrib, image, opacity, depth, feature, pseudo_normal, sxyz, weights, radii = fw[:10]
             res = dict(num_rendered=R, num_contrib=n_contrib, render=image, opacity=opacity, depth=depth, feature=feature,
                        pseudo_normal=pseudo_normal, surface_xyz=sxyz, radii=radii)

@@ -112,6 +112,109 @@ def shade_backward(base_color, roughness, normals, viewdirs, incidents, env, vis
     return d_base, d_rough, d_view, d_inc, d_env
 
 
+class FixedRaySet:
+    """State of the fixed-ray-set shading kernels (include/r3dg_hip.h "fixed ray set", csrc/shading_frs.hpp) for ONE
+    visibility update: the normals the cached directions were generated from, the Y_i(z_k) tables, which Gaussians take
+    the rotated path, scratch for the rotated coefficients.  `forward` / `backward` compute what shade_forward(...,
+    train_outputs=True) / shade_backward(...) compute for the same caches -- for directions that ARE
+    sampling.fibonacci_sphere_sampling(ray_normals, K); `try_build` checks that and returns None otherwise."""
+
+    def __init__(self, ray_normals, K):
+        from . import sampling
+        L = _lib.lib()
+        self.ray_normals = _c(ray_normals).clone()
+        self.P, self.K = self.ray_normals.shape[0], int(K)
+        dev = self.ray_normals.device
+        z = sampling.fibonacci_z_samples(self.K, dev)[0].t().contiguous()                        # [K,3]
+        self.tables = torch.empty(int(L.r3dg_shade_frs_tables_bytes(self.K)) // 4, dtype=torch.float32, device=dev)
+        self.valid = torch.zeros(max(self.P, 1), dtype=torch.uint8, device=dev)
+        with torch.cuda.device(dev):
+            _lib.check(L.r3dg_shade_frs_build_tables(_lib.current_stream(), self.K, z.data_ptr(), self.tables.data_ptr()),
+                       "shade_frs_build_tables")
+            _lib.check(L.r3dg_shade_frs_classify(_lib.current_stream(), self.P, self.ray_normals.data_ptr(),
+                                                 self.valid.data_ptr()), "shade_frs_classify")
+        self.invalid_list = torch.nonzero(self.valid[:self.P] == 0).to(torch.int32).reshape(-1).contiguous()
+        self.n_invalid = int(self.invalid_list.numel())                   # (one read-back per visibility update)
+        self.cprime = torch.empty(self.P, 48, dtype=torch.float32, device=dev)
+        self.dcprime = torch.empty(self.P, 48, dtype=torch.float32, device=dev)
+
+    @staticmethod
+    def supported(K, M, He, We):
+        return bool(_lib.lib().r3dg_shade_frs_supported(int(K), int(M), int(He), int(We)))
+
+    @classmethod
+    def try_build(cls, ray_normals, incident_dirs, tol=2e-5, chunk=1 << 16):
+        """-> FixedRaySet, or None when `incident_dirs` [P,K,3] is not the Fibonacci set of `ray_normals` (checked once per
+        visibility update; chunked so that the transient stays small)."""
+        from . import sampling
+        P, K = incident_dirs.shape[0], incident_dirs.shape[1]
+        if ray_normals is None or ray_normals.shape[0] != P or K < 4 or K % 4 != 0:
+            return None
+        worst = torch.zeros((), dtype=torch.float32, device=incident_dirs.device)
+        for o in range(0, P, chunk):
+            want, _ = sampling.fibonacci_sphere_sampling(ray_normals[o:o + chunk], K)
+            worst = torch.maximum(worst, (want - incident_dirs[o:o + chunk]).abs().max())
+        if not float(worst) <= tol:
+            return None
+        return cls(ray_normals, K)
+
+    def _common(self, base_color, roughness, normals, viewdirs, incidents, env, visibility, incident_dirs, incident_areas,
+                uniform_area, taps):
+        t = [_c(x) for x in (base_color, roughness, normals, viewdirs, incidents, env, visibility, incident_dirs)]
+        if incidents.shape[1] != 16 or incident_dirs.shape[:2] != (self.P, self.K):
+            raise RuntimeError("FixedRaySet: needs [P,16,3] incident-light coefficients and the [P,K,3] caches it was built for")
+        if taps is None or taps.dtype != torch.int32 or taps.numel() != 3 * self.P * self.K or not taps.is_contiguous():
+            raise RuntimeError("FixedRaySet: taps must be build_taps(incident_dirs, He, We) (lookup records)")
+        areas = None if uniform_area is not None else _c(incident_areas)
+        He, We = env.shape[-3], env.shape[-2]
+        head = [self.P, self.K] + [x.data_ptr() for x in t[:6]] + [He, We, t[6].data_ptr(), t[7].data_ptr(),
+                                                                   areas.data_ptr() if areas is not None else None,
+                                                                   float(uniform_area or 0.0), taps.data_ptr(),
+                                                                   self.ray_normals.data_ptr(), self.tables.data_ptr(),
+                                                                   self.valid.data_ptr(),
+                                                                   self.invalid_list.data_ptr() if self.n_invalid else None,
+                                                                   self.n_invalid]
+        return head, t
+
+    def forward(self, base_color, roughness, normals, viewdirs, incidents, env, visibility, incident_dirs, incident_areas,
+                taps, out, uniform_area=None, leave_room=False):
+        """Writes columns 0..5 and 18 of out [P,19] (pbr, diffuse_light, mean visibility); keeps the rotated coefficients
+        for `backward`."""
+        head, _keep = self._common(base_color, roughness, normals, viewdirs, incidents, env, visibility, incident_dirs,
+                                   incident_areas, uniform_area, taps)
+        with torch.cuda.device(base_color.device):
+            st = _lib.lib().r3dg_shade_frs_forward(_lib.current_stream(), *head, self.cprime.data_ptr(),
+                                                   1 | (4 if leave_room else 0), out.data_ptr())
+        _lib.check(st, "shade_frs_forward")
+        return out
+
+    def backward(self, base_color, roughness, normals, viewdirs, incidents, env, visibility, incident_dirs, incident_areas,
+                 taps, dL_dpbr, dL_ddiffuse_light, uniform_area=None, out_incidents=None, out_env=None, block_absmax=None):
+        """-> (dL_dbase_color, dL_droughness, dL_dviewdirs, dL_dincidents, dL_denv) as shade_backward; `forward` must have run
+        on the same parameters (it left the rotated coefficients)."""
+        head, _keep = self._common(base_color, roughness, normals, viewdirs, incidents, env, visibility, incident_dirs,
+                                   incident_areas, uniform_area, taps)
+        if uniform_area is not None and self.n_invalid:
+            # the general kernel that takes the Gaussians off the rotated path reads per-sample areas in its backward
+            head[12] = _c(incident_areas).data_ptr()
+        dev = base_color.device
+        P = self.P
+        d_base = torch.empty((P, 3), dtype=torch.float32, device=dev)
+        d_rough = torch.empty((P, 1), dtype=torch.float32, device=dev)
+        d_view = torch.empty((P, 3), dtype=torch.float32, device=dev)
+        d_inc = out_incidents if out_incidents is not None else torch.empty((P, 16, 3), dtype=torch.float32, device=dev)
+        d_env = out_env if out_env is not None else torch.zeros_like(env)
+        gp, gd = _c(dL_dpbr), _c(dL_ddiffuse_light)
+        with torch.cuda.device(dev):
+            st = _lib.lib().r3dg_shade_frs_backward(
+                _lib.current_stream(), *head, self.cprime.data_ptr(), self.dcprime.data_ptr(), gp.data_ptr(), gd.data_ptr(),
+                d_base.data_ptr(), d_rough.data_ptr(), d_view.data_ptr(), d_inc.data_ptr(), d_env.data_ptr(),
+                block_absmax.data_ptr() if block_absmax is not None else None,
+                block_absmax.numel() if block_absmax is not None else 0)
+        _lib.check(st, "shade_frs_backward")
+        return d_base, d_rough, d_view, d_inc, d_env
+
+
 class _Shade(torch.autograd.Function):
     @staticmethod
     def forward(ctx, base_color, roughness, normals, viewdirs, incidents, env, visibility, incident_dirs,

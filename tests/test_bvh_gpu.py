@@ -120,7 +120,7 @@ def test_trace_bvh_hit_lists_are_consistent(P, seed, K):
 
 @pytest.mark.parametrize("P,seed,K", [(7, 3, 16), (5000, 5, 64), (60_000, 6, 16)])
 def test_trace_formulations_give_identical_results(P, seed, K):
-    """r3dg_set_tuning8: 0 thread-per-ray over the reference's tables, 2 packed 64-byte records, 3 persistent waves with
+    """R3DG_OPT_TRACE_FORMULATION: 0 thread-per-ray over the reference's tables, 2 packed 64-byte records, 3 persistent waves with
     per-XCD queues, 4 (default) phase-separated bodies with the current node in a register -- same per-ray visit order and
     arithmetic, so transmittance and hit counts are bit-identical (incl. a ray count that is not a multiple of 64)."""
     from bvh_tracing import RayTracer
@@ -133,13 +133,13 @@ def test_trace_formulations_give_identical_results(P, seed, K):
     got = {}
     try:
         for mode in (0, 2, 3, 4):
-            L.r3dg_set_tuning8(mode)
+            _lib.set_option("TRACE_FORMULATION", mode)
             res = rt.trace_visibility(o, d, sc["xyz"].to(DEV), cinv.to(DEV), sc["opacity"][:, 0].contiguous().to(DEV),
                                       sc["normal"].to(DEV))
             torch.cuda.synchronize()
             got[mode] = (res["visibility"].clone(), res["contribute"].clone())
     finally:
-        L.r3dg_set_tuning8(4)
+        _lib.set_option("TRACE_FORMULATION", 4)
     for mode in (2, 3, 4):
         assert torch.equal(got[mode][0], got[0][0]), "visibility differs in mode %d" % mode
         assert torch.equal(got[mode][1], got[0][1]), "hit counts differ in mode %d" % mode

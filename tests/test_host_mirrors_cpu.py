@@ -187,8 +187,12 @@ def test_relight_renderer_host_logic_with_a_recording_library(monkeypatch):
     monkeypatch.setattr(shading_ops, "build_taps", lambda dirs, He, We, tr=None, radiance_of=None:
                         built.append(tr) or torch.zeros(P * K * 3))
     z = torch.zeros
-    monkeypatch.setattr(rasterizer_ops, "rasterize_gaussians", lambda *a: (3, z(1), z(3, 4, 4), z(1, 4, 4), z(1, 4, 4),
-                                                                           z(28, 4, 4), z(3, 4, 4), z(3, 4, 4), z(P, 1), z(P)))
+    class _Pending:
+        def finish(self):
+            return (3, z(1), z(3, 4, 4), z(1, 4, 4), z(1, 4, 4), z(28, 4, 4), z(3, 4, 4), z(3, 4, 4), None, z(P))
+    wanted = []
+    monkeypatch.setattr(rasterizer_ops, "rasterize_gaussians_begin",
+                        lambda *a, want_weights=True, **k: wanted.append(want_weights) or _Pending())
     model = types.SimpleNamespace(xyz=dt(z(P, 3)), normal=z(P, 3), scaling=z(P, 3), rotation=z(P, 4), opacity=z(P, 1),
                                   base_color=z(P, 3), roughness=z(P, 1), shs=z(P, 16, 3), incidents=z(P, 16, 3))
     cam = types.SimpleNamespace(image_height=4, image_width=4, world_view_transform=torch.eye(4), full_proj_transform=torch.eye(4),
@@ -204,6 +208,7 @@ def test_relight_renderer_host_logic_with_a_recording_library(monkeypatch):
     cached = [c for c in calls if c[0] == "r3dg_shade_forward_cached"][-1][1]
     assert cached[-2] == 2 and cached[-3] is not None and cached[16] == 2.0 and cached[15] is None     # radiance taps, uniform area
     assert set(out) >= {"render", "feature", "pbr_env", "num_rendered"} and out["num_rendered"] == 3
+    assert wanted and not any(wanted)                       # frames never ask for the per-Gaussian blend weights
     # a light that turns with every frame: cache on the first change only, in-kernel lookup afterwards
     calls.clear()
     del built[:]
@@ -372,6 +377,7 @@ def test_raytracer_wrapper_calls_the_backend_like_the_reference(monkeypatch):
     def install(create, trace):
         monkeypatch.setattr(bvh.bvh_ops, "create_bvh", create)
         # (this repo's tracer additionally hands over its packed traversal records: the eight reference arguments unchanged)
+        monkeypatch.setattr(bvh._lib, "get_option", lambda name: 4)
         monkeypatch.setattr(bvh.bvh_ops, "trace_records", lambda *a: packed.append(len(a)) or "records")
         monkeypatch.setattr(bvh.bvh_ops, "trace_bvh_opacity", lambda *a, records=None: packed.append(records) or trace(*a))
     got = wrapper_trace.run_raytracer(bvh.RayTracer, install)

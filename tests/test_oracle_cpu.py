@@ -159,6 +159,20 @@ def test_hip_library_exports_every_declared_symbol():
     lib = _lib.lib()                                        # argtypes resolve for every bound symbol
     assert lib.r3dg_version() >= 100
     assert lib.r3dg_geometry_state_bytes(1000) > 0 and lib.r3dg_max_features_forward() >= 33
+    # enum r3dg_option <-> _lib.OPTIONS (host calls only: no device involved), range checks, round trip
+    hdr = open(os.path.join(root, "include", "r3dg_hip.h")).read()
+    enum = re.search(r"enum r3dg_option \{(.*?)\};", hdr, re.S).group(1)
+    declared = [n[len("R3DG_OPT_"):] for n in re.findall(r"\b(R3DG_OPT_\w+)\b", re.sub(r"/\*.*?\*/", "", enum, flags=re.S))]
+    assert declared[-1] == "COUNT" and tuple(declared[:-1]) == _lib.OPTIONS
+    assert _lib.get_option("TILE_BINNING") == 2 and _lib.get_option("CULL") == 1 and _lib.get_option("RESERVE_CUS") == 0
+    _lib.set_option("RESERVE_CUS", 8)
+    assert _lib.get_option("RESERVE_CUS") == 8
+    _lib.set_option("RESERVE_CUS", 0)
+    for bad in ((len(_lib.OPTIONS), 0), (-1, 0), (_lib.OPTIONS.index("TILE_BINNING"), 3), (_lib.OPTIONS.index("CULL"), -1)):
+        assert lib.r3dg_set_option(*bad) != 0
+    assert _lib.get_option("TILE_BINNING") == 2 and lib.r3dg_bounded_forward_supported(800, 800) == 1
+    assert lib.r3dg_bounded_forward_supported(2560, 1664) == 0 and lib.r3dg_shade_frs_supported(64, 16, 16, 32) == 1
+    assert lib.r3dg_shade_frs_supported(30, 16, 16, 32) == 0 and lib.r3dg_shade_frs_tables_bytes(64) == 4 * 512 * 4
 
 
 def test_host_mirror_rejects_bad_inputs_without_gpu():

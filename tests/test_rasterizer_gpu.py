@@ -18,6 +18,13 @@ pytestmark = pytest.mark.gpu
 DEV = "cuda"
 
 
+def _opt(**kw):
+    """r3dg_set_option by name (include/r3dg_hip.h enum r3dg_option)."""
+    from relightable3dgaussian_amd import _lib
+    for k, v in kw.items():
+        _lib.set_option(k, v)
+
+
 def _run_forward(case, debug=False):
     from r3dg_rasterization import _C
     return _C.rasterize_gaussians(*fwd_args(case, DEV, debug))
@@ -142,11 +149,11 @@ def test_forward_parity(name):
 
 @pytest.mark.parametrize("ppl", [1, 2, 4])
 def test_forward_parity_pixels_per_lane(ppl, hip_lib):
-    hip_lib.r3dg_set_tuning(ppl, 0, -1)
+    _opt(FWD_PIXELS_PER_LANE=ppl)
     try:
         _check_forward(make_case(S=16, seed=11), "ppl%d" % ppl)
     finally:
-        hip_lib.r3dg_set_tuning(1, 0, -1)
+        _opt(FWD_PIXELS_PER_LANE=1)
 
 
 def test_forward_empty_and_culled():
@@ -243,34 +250,34 @@ def test_backward_no_geometry_flag():
     _check_backward(make_case(S=5, seed=31), "bg_geom_off", backward_geometry=False)
 
 
-@pytest.mark.parametrize("ppl,dpp", [(1, 1), (2, 1), (1, 0), (2, 0)])
-def test_backward_parity_variants(ppl, dpp, hip_lib):
-    hip_lib.r3dg_set_tuning(0, ppl, dpp)
+@pytest.mark.parametrize("ppl", [1, 2])
+def test_backward_parity_variants(ppl, hip_lib):
+    _opt(BWD_PIXELS_PER_LANE=ppl)
     try:
-        _check_backward(make_case(S=16, seed=41), "bwd_ppl%d_dpp%d" % (ppl, dpp))
+        _check_backward(make_case(S=16, seed=41), "bwd_ppl%d" % ppl)
     finally:
-        hip_lib.r3dg_set_tuning(0, 1, 1)
+        _opt(BWD_PIXELS_PER_LANE=1)
 
 
 @pytest.mark.parametrize("fu,bu,order", [(1, 1, 0), (2, 2, 1), (4, 4, 1), (4, 2, 0)])
 def test_parity_inner_loop_unroll_and_tile_order(fu, bu, order, hip_lib):
     """Scheduling knobs (entries per inner-loop step, longest-tile-first block order) must not change results."""
-    hip_lib.r3dg_set_tuning2(fu, bu, order)
+    _opt(FWD_UNROLL=fu, BWD_UNROLL=bu, TILE_ORDER=order)
     try:
         _check_backward(make_case(S=16, seed=61, P=4000), "unroll_f%d_b%d_order%d" % (fu, bu, order))
     finally:
-        hip_lib.r3dg_set_tuning2(4, 1, 1)
+        _opt(FWD_UNROLL=4, BWD_UNROLL=1, TILE_ORDER=1)
 
 
 @pytest.mark.parametrize("fw8,bw8,cull", [(0, 0, 0), (1, 1, 1), (0, 1, 0), (1, 0, 1)])
 def test_parity_wave_shape_and_cull(fw8, bw8, cull, hip_lib):
     """Lane->pixel map (16x4 strips / 8x8 blocks) and the per-wave sub-tile cull must not change results."""
-    hip_lib.r3dg_set_tuning3(fw8, bw8, cull)
+    _opt(FWD_WAVE8X8=fw8, BWD_WAVE8X8=bw8, CULL=cull)
     try:
         _check_backward(make_case(S=16, seed=71, P=4000), "wave8_f%d_b%d_cull%d" % (fw8, bw8, cull))
         _check_forward(make_case(S=5, seed=72, scale_log_mean=-2.0, P=1500), "wave8_f%d_cull%d_big" % (fw8, cull))
     finally:
-        hip_lib.r3dg_set_tuning3(1, 1, 1)
+        _opt(FWD_WAVE8X8=1, BWD_WAVE8X8=1, CULL=1)
 
 
 @pytest.mark.parametrize("name", ["S16", "big_splats", "ragged_image", "camera_inside", "S0"])
@@ -279,11 +286,11 @@ def test_tile_binned_order_equals_global_sort(name, binning, hip_lib):
     """All three orderings (0: global radix sort of (tile|depth) keys; 1: radix partition by tile + per-tile LDS sort; 2, the
     default: instances emitted straight into their tile's segment + per-tile LDS sort) must give the oracle's sorted keys,
     point list, ranges and point offsets bit for bit (checked inside _check_forward)."""
-    hip_lib.r3dg_set_tuning4(binning)
+    _opt(TILE_BINNING=binning)
     try:
         _check_forward(make_case(**CASES[name]), "%s_binning%d" % (name, binning))
     finally:
-        hip_lib.r3dg_set_tuning4(2)
+        _opt(TILE_BINNING=2)
 
 
 def test_tile_binned_order_long_tiles(hip_lib):
@@ -291,12 +298,12 @@ def test_tile_binned_order_long_tiles(hip_lib):
     case = make_case(P=40000, W=64, H=48, S=2, scale_log_mean=-1.2, seed=91)
     a = _run_forward(case)
     try:
-        hip_lib.r3dg_set_tuning4(1)
+        _opt(TILE_BINNING=1)
         a1 = _run_forward(case)
-        hip_lib.r3dg_set_tuning4(0)
+        _opt(TILE_BINNING=0)
         b = _run_forward(case)
     finally:
-        hip_lib.r3dg_set_tuning4(2)
+        _opt(TILE_BINNING=2)
     torch.cuda.synchronize()
     for i in (1, 2, 3, 4, 5):
         assert torch.equal(a1[i], b[i]), i
@@ -316,11 +323,11 @@ def test_tile_binned_order_many_tiles(hip_lib):
     """1600x1200 (DTU size, BASELINE config 3): 7500 tiles = 13 tile-id bits, i.e. the two-pass (stable) partition."""
     case = make_case(P=20000, W=1600, H=1200, S=3, scale_log_mean=-2.6, seed=93)
     a = _run_forward(case)
-    hip_lib.r3dg_set_tuning4(0)
+    _opt(TILE_BINNING=0)
     try:
         b = _run_forward(case)
     finally:
-        hip_lib.r3dg_set_tuning4(2)
+        _opt(TILE_BINNING=2)
     torch.cuda.synchronize()
     from relightable3dgaussian_amd.rasterizer_ops import decode_state
     P, H, W = case["P"], case["H"], case["W"]
@@ -337,11 +344,11 @@ def test_tile_binned_order_falls_back_above_the_lds_histogram(hip_lib):
     under the default setting -- same lists as the global sort."""
     case = make_case(P=6000, W=2064, H=2048, S=0, scale_log_mean=-2.2, seed=97)
     a = _run_forward(case)
-    hip_lib.r3dg_set_tuning4(0)
+    _opt(TILE_BINNING=0)
     try:
         b = _run_forward(case)
     finally:
-        hip_lib.r3dg_set_tuning4(2)
+        _opt(TILE_BINNING=2)
     torch.cuda.synchronize()
     from relightable3dgaussian_amd.rasterizer_ops import decode_state
     P, H, W = case["P"], case["H"], case["W"]
@@ -481,12 +488,12 @@ def test_cull_is_exact(name, hip_lib):
     images must be bit-identical with and without it (weights: float atomics, order-dependent -> tolerance)."""
     case = make_case(**CASES[name])
     try:
-        hip_lib.r3dg_set_tuning3(-1, -1, 0)
+        _opt(CULL=0)
         a = _run_forward(case)
-        hip_lib.r3dg_set_tuning3(-1, -1, 1)
+        _opt(CULL=1)
         b = _run_forward(case)
     finally:
-        hip_lib.r3dg_set_tuning3(1, 1, 1)
+        _opt(FWD_WAVE8X8=1, BWD_WAVE8X8=1, CULL=1)
     torch.cuda.synchronize()
     assert a[0] == b[0]
     for i, nm in ((1, "n_contrib"), (2, "color"), (3, "opacity"), (4, "depth"), (5, "feature"), (6, "normal"),

@@ -139,7 +139,7 @@ def test_shading_forward_variants_agree(P, K, He, transform):
     (r3dg_shade_build_taps), with only the training outputs, and the round-1 16-lane kernel -- against the float64 oracle
     and each other.  Directions exactly on the poles / the +-pi seam exercise the zero-padding corners of the lookup."""
     from oracle import shading
-    from relightable3dgaussian_amd import _lib, shading_ops as so
+    from relightable3dgaussian_amd import shading_ops as so
     inp = _random_inputs(P, K, He, 16, seed=3 * P + K, hdr=transform)
     inp["incident_dirs"][0, 0] = torch.tensor([0.0, 0.0, 1.0])
     inp["incident_dirs"][0, 1] = torch.tensor([0.0, 0.0, -1.0])
@@ -163,16 +163,6 @@ def test_shading_forward_variants_agree(P, K, He, transform):
     outs = {"rows": so.shade_forward(*args), "rows+taps": so.shade_forward(*args, taps=taps),
             "rows+radiance": so.shade_forward(*args, taps=rad, taps_are_radiance=True),
             "rows+taps+train": so.shade_forward(*args, taps=taps, train_outputs=True, out=sentinel.clone())}
-    try:
-        # r3dg_set_tuning7(2): cached lookups + degree-3 light run the pair kernel (two samples per lane)
-        _lib.lib().r3dg_set_tuning7(2, -1)
-        outs["pair+taps"] = so.shade_forward(*args, taps=taps)
-        outs["pair+radiance"] = so.shade_forward(*args, taps=rad, taps_are_radiance=True)
-        outs["pair+taps+train"] = so.shade_forward(*args, taps=taps, train_outputs=True, out=sentinel.clone())
-        _lib.lib().r3dg_set_tuning7(0, -1)
-        outs["16-lane"] = so.shade_forward(*args)
-    finally:
-        _lib.lib().r3dg_set_tuning7(1, -1)
     torch.cuda.synchronize()
     cols = [0, 1, 2, 3, 4, 5, 18]
     for name, got in outs.items():
@@ -187,8 +177,6 @@ def test_shading_forward_variants_agree(P, K, He, transform):
             _ok(name + " rest", got[:, [3, 4, 5] + list(range(9, 19))], want[:, [3, 4, 5] + list(range(9, 19))], 1e-4, 1e-6)
     # the cached lookup is the same arithmetic as the in-kernel one
     assert (outs["rows"] - outs["rows+taps"]).abs().max().item() <= 1e-6 * max(1.0, want.abs().max().item())
-    # two samples per lane: the same per-sample arithmetic, sums formed in another order
-    assert (outs["pair+taps"] - outs["rows+taps"]).abs().max().item() <= 2e-5 * max(1.0, want.abs().max().item())
 
 
 @pytest.mark.parametrize("P,K,He,transform", [(1500, 64, 16, False), (400, 100, 64, True), (300, 30, 16, False)])
@@ -213,23 +201,108 @@ def test_shade_refuses_gradients_it_does_not_implement():
                  inp["incidents"], inp["env"], inp["visibility"], inp["incident_dirs"], inp["incident_areas"])
 
 
-@pytest.mark.parametrize("P,K,He,M,transform", [(2500, 64, 16, 16, False), (300, 384, 16, 16, False), (400, 100, 64, 16, True),
-                                                (500, 30, 8, 4, False)])
-def test_shading_backward_formulations_agree(P, K, He, M, transform):
-    """Row kernel (r3dg_set_tuning9(1)) vs the default 16-lane kernel, which test_shading_matches_oracle pins to the float64
-    oracle: same gradients."""
-    from relightable3dgaussian_amd import _lib, shading_ops as so
-    inp = {k: v.to(DEV) for k, v in _random_inputs(P, K, He, M, seed=5 * P + K, hdr=transform).items()}
-    tr = torch.linalg.qr(torch.randn(3, 3, generator=torch.Generator().manual_seed(3))).Q.contiguous().to(DEV) if transform else None
+def _frs_inputs(P, K, He, seed):
+    """Inputs whose cached directions ARE the Fibonacci set of the normals (what update_visibility produces), generated on
+    the device like the product does; a few normals on and next to -z, where rotation_between_z loses orthonormality to
+    cancellation and the Gaussian must take the general kernel (valid == 0)."""
+    from relightable3dgaussian_amd import sampling
+    inp = {k: v.to(DEV) for k, v in _random_inputs(P, K, He, 16, seed=seed).items()}
+    n = inp["normals"].clone()
+    special = torch.tensor([[0.0, 0.0, -1.0], [1e-4, 0.0, -1.0], [0.0, 3e-3, -1.0], [0.0, 0.0, 1.0], [2e-2, 1e-2, -1.0],
+                            [0.3, -0.2, -0.93]], device=DEV)
+    n[:special.shape[0]] = torch.nn.functional.normalize(special, dim=-1)[:min(P, special.shape[0])]
+    inp["normals"] = n
+    inp["incident_dirs"], inp["incident_areas"] = sampling.fibonacci_sphere_sampling(n, K)
+    return inp
+
+
+@pytest.mark.parametrize("P,K,He", [(2500, 64, 16), (1000, 384, 16), (333, 100, 16), (50, 8, 8), (17, 32, 16), (4097, 16, 4)])
+def test_fixed_ray_set_kernels_equal_the_general_kernels(P, K, He):
+    """shading_ops.FixedRaySet (csrc/shading_frs.hpp: rotated SH coefficients, both SH contractions on the matrix cores,
+    4 lanes per Gaussian) vs the general kernels on the same caches: the training outputs of the forward and all five
+    gradients of the backward.  P not a multiple of 16, K not a multiple of 16 or 64, Gaussians off the rotated path."""
+    from relightable3dgaussian_amd import shading_ops as so
+    inp = _frs_inputs(P, K, He, seed=7 * P + K)
+    assert so.FixedRaySet.supported(K, 16, He, 2 * He)
+    frs = so.FixedRaySet.try_build(inp["normals"], inp["incident_dirs"])
+    assert frs is not None and 3 <= frs.n_invalid <= 3 + P // 50 and frs.n_invalid == int((frs.valid[:P] == 0).sum())
+    assert [int(v) for v in frs.valid[:6]] == [1, 0, 0, 1, 0, 1]
+    # (n = -z exactly takes R = -I, which IS orthonormal -- an improper rotation, rotated like any other; n = +z: R = I)
+    taps = so.build_taps(inp["incident_dirs"], He, 2 * He)
     args = (inp["base_color"], inp["roughness"], inp["normals"], inp["viewdirs"], inp["incidents"], inp["env"],
-            inp["visibility"], inp["incident_dirs"], inp["incident_areas"], inp["g_pbr"], inp["g_diff"])
-    old = so.shade_backward(*args, env_transform=tr)
-    try:
-        _lib.lib().r3dg_set_tuning9(1)
-        rows = so.shade_backward(*args, env_transform=tr)
-    finally:
-        _lib.lib().r3dg_set_tuning9(0)
+            inp["visibility"], inp["incident_dirs"], inp["incident_areas"])
+    cols = [0, 1, 2, 3, 4, 5, 18]
+    for uniform in (None, 6.283185307179586):
+        want = so.shade_forward(*args, taps=taps, train_outputs=True, uniform_area=uniform)
+        got = frs.forward(*args, taps, torch.full((P, so.NOUT), -7.0, device=DEV), uniform_area=uniform)
+        torch.cuda.synchronize()
+        assert (got[:, [c for c in range(so.NOUT) if c not in cols]] == -7.0).all()
+        _ok("frs forward pbr", got[:, :3], want[:, :3], 2e-4, 1e-6)
+        _ok("frs forward diffuse / vis", got[:, [3, 4, 5, 18]], want[:, [3, 4, 5, 18]], 2e-5, 1e-6)
+        old = so.shade_backward(*args, inp["g_pbr"], inp["g_diff"], taps=taps)
+        new = frs.backward(*args, taps, inp["g_pbr"], inp["g_diff"], uniform_area=uniform)
+        torch.cuda.synchronize()
+        for name, x, y in zip(("d_base", "d_rough", "d_view", "d_inc", "d_env"), new, old):
+            # (roughness / view: the fp32 GGX denominator is ill-conditioned -- two evaluation orders differ by up to ~1e-3)
+            _ok("frs backward " + name, x, y, 2e-3 if name in ("d_rough", "d_view") else 2e-4, 1e-7)
+    # caches that are NOT the Fibonacci set of these normals are refused (the caller then keeps the general kernels)
+    assert so.FixedRaySet.try_build(torch.roll(inp["normals"], 1, 0), inp["incident_dirs"]) is None
+    assert not so.FixedRaySet.supported(K + 1, 16, He, 2 * He) and not so.FixedRaySet.supported(K, 9, He, 2 * He)
+    assert not so.FixedRaySet.supported(K, 16, 256, 512)
+
+
+def test_fixed_ray_set_tables_hold_the_basis_in_the_two_mfma_layouts():
+    """r3dg_shade_frs_build_tables vs the layout its consumers assume (csrc/shading_frs.hpp): per 16-sample block, slots 0..3 =
+    A operand of the local-light product (lane (r, q): Yz[16 b + r][4 s + q]), slots 4..7 = A operand of the gradient
+    product (lane (i, q): Yz[16 b + 4 q + v][i]); rows beyond K are zero."""
+    from oracle import shading
+    from relightable3dgaussian_amd import sampling, shading_ops as so
+    for K in (8, 64, 100):
+        frs = so.FixedRaySet(torch.nn.functional.normalize(torch.randn(5, 3), dim=-1).to(DEV), K)
+        z = sampling.fibonacci_z_samples(K, DEV)[0].t().contiguous()
+        Yz = shading.sh_basis(3, z.cpu().double())                                    # [K,16]
+        nblk = (K + 15) // 16
+        tab = frs.tables.cpu().view(nblk, 8, 64)
+        want = torch.zeros(nblk, 8, 64, dtype=torch.float64)
+        for b in range(nblk):
+            for lane in range(64):
+                lo, q = lane & 15, lane >> 4
+                for s_ in range(4):
+                    k = 16 * b + lo
+                    want[b, s_, lane] = Yz[k, 4 * s_ + q] if k < K else 0.0
+                    k2 = 16 * b + 4 * q + s_
+                    want[b, 4 + s_, lane] = Yz[k2, lo] if k2 < K else 0.0
+        assert float((tab.double() - want).abs().max()) < 2e-6
+
+
+@pytest.mark.parametrize("P,K,He", [(1200, 64, 16), (300, 100, 64)])
+def test_general_kernels_on_a_list_of_gaussians(P, K, He):
+    """The general forward / backward restricted to a list of Gaussians (what the fixed-ray-set entry points use for the
+    Gaussians off the rotated path): listed rows equal the full launch, all other rows stay untouched."""
+    import ctypes as C
+    from relightable3dgaussian_amd import _lib, shading_ops as so
+    inp = _frs_inputs(P, K, He, seed=3)
+    frs = so.FixedRaySet(inp["normals"], K)
+    lst = torch.tensor([5, 0, P - 1, 17, 18, 19, 400 % P], dtype=torch.int32, device=DEV)
+    frs.invalid_list, frs.n_invalid = lst, int(lst.numel())
+    frs.valid.fill_(0)                                    # nobody on the rotated path: only the listed rows are produced
+    taps = so.build_taps(inp["incident_dirs"], He, 2 * He)
+    args = (inp["base_color"], inp["roughness"], inp["normals"], inp["viewdirs"], inp["incidents"], inp["env"],
+            inp["visibility"], inp["incident_dirs"], inp["incident_areas"])
+    if not so.FixedRaySet.supported(K, 16, He, 2 * He):
+        pytest.skip("texture too large for the fixed-ray-set entry points")
+    want = so.shade_forward(*args, taps=taps, train_outputs=True)
+    got = frs.forward(*args, taps, torch.full((P, so.NOUT), -7.0, device=DEV))
     torch.cuda.synchronize()
-    for name, x, y in zip(("d_base", "d_rough", "d_view", "d_inc", "d_env"), rows, old):
-        # (roughness / view: the fp32 GGX denominator is ill-conditioned -- two evaluation orders differ by up to ~1e-3)
-        _ok(name + " row vs 16-lane", x, y, 2e-3 if name in ("d_rough", "d_view") else 2e-4, 1e-7)
+    rows = lst.long()
+    cols = [0, 1, 2, 3, 4, 5, 18]
+    assert torch.equal(got[rows][:, cols], want[rows][:, cols])
+    mask = torch.ones(P, dtype=torch.bool, device=DEV)
+    mask[rows] = False
+    assert (got[mask] == -7.0).all()
+    old = so.shade_backward(*args, inp["g_pbr"], inp["g_diff"], taps=taps)
+    new = frs.backward(*args, taps, inp["g_pbr"], inp["g_diff"])
+    torch.cuda.synchronize()
+    for name, x, y in zip(("d_base", "d_rough", "d_view"), new, old):
+        assert torch.equal(x[rows], y[rows]), name
+    assert torch.equal(new[3][rows], old[3][rows])        # d_inc rows of the listed Gaussians (the others hold the rotated path's)

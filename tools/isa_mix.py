@@ -21,6 +21,8 @@ from relightable3dgaussian_amd import build as B   # noqa: E402
 # (file, substring of the demangled kernel name): the template instances the default bench launches
 KERNELS = [
     ("shading.hip", "shade_backward_kernel<true, true, true>"),
+    ("shading.hip", "shade_backward_frs_kernel"),
+    ("shading.hip", "shade_forward_frs_kernel"),
     ("shading.hip", "shade_forward_row_kernel<7, true, 1, true>"),
     ("shading.hip", "shade_forward_row_kernel<19, false, 2, true>"),
     ("shading.hip", "shade_forward_transport_kernel"),

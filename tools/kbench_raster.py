@@ -13,17 +13,9 @@ d = {k: v.to(dev) for k, v in sc.items() if torch.is_tensor(v)}
 feat = torch.rand(P, S, device=dev)
 gC, gO, gD, gF = [torch.randn(c, RES, RES, device=dev) for c in (3, 1, 1, S)]
 L.r3dg_profile_enable(1)
-e = os.environ
-L.r3dg_set_tuning(int(e.get("FPPL", 0)), int(e.get("BPPL", 0)), -1)
-L.r3dg_set_tuning2(int(e.get("FU", 0)), int(e.get("BU", 0)), int(e.get("ORDER", -1)))
-if "WAVE8" in os.environ:
-    L.r3dg_set_tuning3(int(os.environ["WAVE8"]) & 1, int(os.environ["WAVE8"]) >> 1, -1)
-if "BIN" in os.environ:
-    L.r3dg_set_tuning4(int(os.environ["BIN"]))
-if "STAGE" in os.environ:
-    L.r3dg_set_tuning5(int(os.environ["STAGE"]))
-if "CULL" in os.environ:
-    L.r3dg_set_tuning3(-1, -1, int(os.environ["CULL"]))
+for name in _lib.OPTIONS:                                # R3DG_OPT_<NAME>=<value>, e.g. R3DG_OPT_CULL=0
+    if os.environ.get("R3DG_OPT_" + name):
+        _lib.set_option(name, int(os.environ["R3DG_OPT_" + name]))
 for it in range(3 + int(os.environ.get("ITERS", 10))):
     if it == 3:
         torch.cuda.synchronize(); _lib.profile_read(); L.r3dg_profile_enable(1)

@@ -5,10 +5,9 @@ import torch
 from relightable3dgaussian_amd import _lib, shading_ops as so, sampling
 P = int(os.environ.get("P", 300000)); dev = "cuda"
 L = _lib.lib()
-if "FWD_BPC" in os.environ:
-    L.r3dg_set_tuning6(int(os.environ["FWD_BPC"]))
-if "ROWS" in os.environ:
-    L.r3dg_set_tuning7(int(os.environ["ROWS"]), -1)
+for name in _lib.OPTIONS:
+    if os.environ.get("R3DG_OPT_" + name):
+        _lib.set_option(name, int(os.environ["R3DG_OPT_" + name]))
 g = torch.Generator().manual_seed(0)
 CASES = ((64, 16),) if os.environ.get("ONLY64") else ((64, 16), (384, 256))
 for K, He in CASES:
@@ -49,4 +48,25 @@ for K, He in CASES:
         torch.cuda.synchronize()
         pr = _lib.profile_read(); L.r3dg_profile_enable(0)
         res["backward (cached taps)"] = pr["shade_backward"][0] / max(pr["shade_backward"][1], 1)
+    # the fixed-ray-set kernels on the same caches (csrc/shading_frs.hpp): coefficient rotation + MFMA kernel (+ the
+    # general kernel on the few Gaussians off the rotated path) in one profiled stage each
+    if so.FixedRaySet.supported(K, 16, He, 2 * He):
+        frs = so.FixedRaySet.try_build(nrm, dirs)
+        out = torch.empty(P, so.NOUT, device=dev)
+        args = (base, rough, nrm, view, inc, env, vis, dirs, areas)
+        for it in range(8):
+            if it == 3:
+                torch.cuda.synchronize(); L.r3dg_profile_enable(1)
+            frs.forward(*args, taps, out, uniform_area=6.283185307179586)
+        torch.cuda.synchronize()
+        pr = _lib.profile_read(); L.r3dg_profile_enable(0)
+        res["frs forward (train outputs; %d Gaussians on the general kernel)" % frs.n_invalid] = pr["shade_forward"][0] / max(pr["shade_forward"][1], 1)
+        if K == 64:
+            for it in range(8):
+                if it == 3:
+                    torch.cuda.synchronize(); L.r3dg_profile_enable(1)
+                frs.backward(*args, taps, gp, gd, uniform_area=6.283185307179586)
+            torch.cuda.synchronize()
+            pr = _lib.profile_read(); L.r3dg_profile_enable(0)
+            res["frs backward"] = pr["shade_backward"][0] / max(pr["shade_backward"][1], 1)
     print("K=%d He=%d  " % (K, He) + "  ".join("%s %.4f ms" % kv for kv in res.items()))

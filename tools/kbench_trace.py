@@ -11,7 +11,7 @@ d = {k: v.to(dev) for k, v in sc.items() if torch.is_tensor(v)}
 res = {}
 MODES = tuple(int(m) for m in os.environ.get('MODES', '4,3,2,0').split(','))
 for packet in MODES:
-    L.r3dg_set_tuning8(packet)
+    _lib.set_option("TRACE_FORMULATION", packet)
     for it in range(2):
         torch.cuda.synchronize(); t0 = time.perf_counter()
         vis, dirs, areas, tracer = update_visibility(d["xyz"], d["scales"], d["rotations"], d["opacity"], d["normal"], K)

@@ -15,7 +15,8 @@ bg = torch.ones(3, device=dev)
 d = {k: v.to(dev) for k, v in sc.items() if torch.is_tensor(v)}
 
 def run(S, fppl, bppl, dpp, iters=10):
-    L.r3dg_set_tuning(fppl, bppl, dpp)
+    _lib.set_option("FWD_PIXELS_PER_LANE", fppl)
+    _lib.set_option("BWD_PIXELS_PER_LANE", bppl)
     feat = torch.rand(P, S, device=dev)
     gC, gO, gD, gF = [torch.randn(c, RES, RES, device=dev) for c in (3, 1, 1, S)]
     for it in range(iters + 3):
@@ -35,12 +36,12 @@ def run(S, fppl, bppl, dpp, iters=10):
 for S in (5, 16):
     for fu in (1, 2, 4):
         for order in (0, 1):
-            L.r3dg_set_tuning2(fu, 2, order)
+            _lib.set_option("FWD_UNROLL", fu); _lib.set_option("BWD_UNROLL", 2); _lib.set_option("TILE_ORDER", order)
             R, pr = run(S, 1, 1, 1)
             print("S=%d fwd_unroll=%d order=%d R=%d render_forward %.4f ms" % (S, fu, order, R, pr["render_forward"]))
     for bu in (1, 2, 4):
         for order in (0, 1):
-            L.r3dg_set_tuning2(4, bu, order)
+            _lib.set_option("FWD_UNROLL", 4); _lib.set_option("BWD_UNROLL", bu); _lib.set_option("TILE_ORDER", order)
             R, pr = run(S, 1, 1, 1)
             print("S=%d bwd_unroll=%d order=%d render_backward %.4f ms" % (S, bu, order, pr["render_backward"]))
     print("S=%d all stages:" % S, json.dumps(pr))
