@@ -30,14 +30,21 @@ def parse():
     ap.add_argument("--steps", type=int, default=40)
     ap.add_argument("--warmup", type=int, default=8)
     ap.add_argument("--points", type=int, default=300_000)
-    ap.add_argument("--res", type=int, default=800)
+    ap.add_argument("--res", type=int, default=800, help="square image size (the BASELINE headline: 800)")
+    ap.add_argument("--width", type=int, default=0, help="image width (default: --res); e.g. 1600 for the DTU configuration")
+    ap.add_argument("--height", type=int, default=0, help="image height (default: --res); e.g. 1200")
     ap.add_argument("--sample-num", type=int, default=64)
     ap.add_argument("--stage", type=int, default=2, choices=[1, 2])
     ap.add_argument("--cpu-baseline-seconds", type=float, default=15.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--unfused", action="store_true",
                     help="stage 2 through PyTorch autograd glue + torch.optim.Adam instead of the fused glue kernels")
-    ap.add_argument("--no-other-configs", action="store_true", help="skip the short stage-1 / K=384 side measurements")
+    ap.add_argument("--no-other-configs", action="store_true",
+                    help="skip the short side measurements of the other BASELINE configurations (stage 1, Syn4Relight / DTU "
+                         "objective, 2M-Gaussian composition)")
+    ap.add_argument("--objective", default="nerf", choices=["nerf", "syn4"],
+                    help="stage-2 objective and schedule: nerf = script/run_nerf.sh (default, the headline); syn4 = "
+                         "script/run_syn4.sh / run_dtu.sh (edge-aware smoothness terms, geometry frozen)")
     ap.add_argument("--relight-frames", type=int, default=20)
     ap.add_argument("--relight-samples", type=int, default=384)
     ap.add_argument("--repeats", type=int, default=5,

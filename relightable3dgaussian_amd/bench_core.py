@@ -84,11 +84,18 @@ def loss_stage1(outs, gt, image_mask=None, weights=None, iteration=0):
 
 
 def _algorithmic_bytes(stage, P, R, N, S, K=64):
-    """SURVEY.md 8(d) per-unit figures x the units one launch processes (fp32)."""
+    """SURVEY.md 8(d) per-unit figures x the units one launch processes (fp32).  The instance-ordering stages are priced with
+    the bytes of the formulation that RUNS (direct tile binning), not with the reference formulation's
+    (its 152 R for the global radix sort is kept in `reference_formulation_MB` of the bench line):
+      duplicate_with_keys (profile stage of tile_count + tile_scan + tile_emit): the projection outputs of every Gaussian are
+        read twice (count pass, emit pass: means2D 8 + depth 4 + radius 4 + tiles_touched 4 = 20 B each time) and every
+        instance is written ONCE as its 8-byte (depth | index) entry;
+      sort_pairs (tile_order + tile_sort): each entry is read and written once by the in-LDS sort (2 x 8 R) and leaves as the
+        4-byte point_list entry + the 8-byte sorted key the state layout promises (12 R)."""
     return {
         "preprocess": 311.0 * P + 8.0 * P,
-        "duplicate_with_keys": 20.0 * P + 12.0 * R,
-        "sort_pairs": 152.0 * R,
+        "duplicate_with_keys": 40.0 * P + 8.0 * R,
+        "sort_pairs": 28.0 * R,
         "identify_tile_ranges": 8.0 * R,
         "render_forward": (44.0 + 4 * S + 8.0) * R + (28.0 + 4 * S) * N,
         "pseudo_normal": 44.0 * N,
@@ -114,13 +121,14 @@ def _algorithmic_bytes(stage, P, R, N, S, K=64):
     }[stage]
 
 
-def cpu_baseline(scene, cams, S, budget_s, points=300_000, res=800):
+def cpu_baseline(scene, cams, S, budget_s, points=300_000, width=800, height=800):
     """The reported CPU baseline (north_star): a pure-PyTorch rasterize forward of the SAME view of the SAME scene
     (oracle/torch_rasterizer.py, the autograd restatement of forward.cu) timed on the host cores in a bounded child
     process; core count stated.  `extra.c_port` keeps the round-1 figure: the oracle C port (1 thread) doing rasterize
     forward+backward view after view for ~budget_s seconds."""
-    same_view = pytorch_cpu_rasterize(points, res, S, timeout_s=240)
-    extra = {"c_port": c_port_baseline(scene, cams, S, budget_s), "pytorch_cpu_config0": pytorch_cpu_rasterize(2000, 400, 5, 60, config0=True)}
+    same_view = pytorch_cpu_rasterize(points, width, height, S, timeout_s=240)
+    extra = {"c_port": c_port_baseline(scene, cams, S, budget_s),
+             "pytorch_cpu_config0": pytorch_cpu_rasterize(2000, 400, 400, 5, 60, config0=True)}
     sec = same_view.get("seconds_per_view")
     return dict(value=None if sec is None else round(1.0 / sec, 4), unit="views/s (rasterize forward)",
                 cores=same_view.get("threads"), kind="port", seconds_per_view=sec if sec is not None else ">240",
@@ -167,24 +175,24 @@ import torch
 from oracle import torch_rasterizer as tr
 from relightable3dgaussian_amd import synthetic as syn
 torch.set_num_threads(%(threads)d)
-P, RES, S = %(P)d, %(res)d, %(S)d
+P, WID, HEI, S = %(P)d, %(width)d, %(height)d, %(S)d
 if %(config0)r:
     sc0 = syn.make_scene(P=P, seed=0, stage2=False, scale_log_mean=-3.0)
-    cam0 = syn.orbit_cameras(4, width=RES, height=RES)[0]
+    cam0 = syn.orbit_cameras(4, width=WID, height=HEI)[0]
 else:                                      # the bench's own scene and its view 0
     sc0 = syn.make_scene(P=P, seed=0, stage2=False)
-    cam0 = syn.orbit_cameras(100, width=RES, height=RES)[0]
+    cam0 = syn.orbit_cameras(100, width=WID, height=HEI)[0]
 f0 = torch.rand(P, S)
 t0 = time.time()
 with torch.no_grad():
     o0 = tr.rasterize(torch.ones(3), sc0["xyz"], f0, None, sc0["opacity"], sc0["scales"], sc0["rotations"], 1.0, None,
                       cam0.world_view_transform, cam0.full_proj_transform, cam0.tanfovx, cam0.tanfovy, cam0.cx, cam0.cy,
-                      RES, RES, sc0["shs"], 3, cam0.camera_center)
+                      HEI, WID, sc0["shs"], 3, cam0.camera_center)
 print(json.dumps(dict(seconds_per_view=round(time.time() - t0, 3), num_rendered=int(o0["num_rendered"]))))
 """
 
 
-def pytorch_cpu_rasterize(points, res, S, timeout_s=60, config0=False):
+def pytorch_cpu_rasterize(points, width, height, S, timeout_s=60, config0=False):
     """Pure-PyTorch CPU rasterize forward (oracle/torch_rasterizer.py) of one view, timed on the host cores.  Runs in a
     child process with a hard time limit and a thread count taken from the CPU affinity mask (capped at 8): on a box
     whose container sees more logical CPUs than it may use, os.cpu_count() OpenMP threads make the thousands of tiny
@@ -200,8 +208,9 @@ def pytorch_cpu_rasterize(points, res, S, timeout_s=60, config0=False):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, OMP_NUM_THREADS=str(threads), MKL_NUM_THREADS=str(threads), HIP_VISIBLE_DEVICES="")
     what = "pure-PyTorch CPU rasterize forward (oracle/torch_rasterizer.py), %d Gaussians, one %dx%d view, S=%d, %d threads" % (
-        points, res, res, S, threads)
-    script = _CPU_RASTERIZE_SCRIPT % dict(root=root, threads=threads, P=points, res=res, S=S, config0=bool(config0))
+        points, width, height, S, threads)
+    script = _CPU_RASTERIZE_SCRIPT % dict(root=root, threads=threads, P=points, width=width, height=height, S=S,
+                                          config0=bool(config0))
     try:
         r = subprocess.run([sys.executable, "-c", script], capture_output=True, text=True,
                            timeout=timeout_s, env=env, stdin=subprocess.DEVNULL)
@@ -296,6 +305,9 @@ def kernel_table(prof, n_sampled, P, R, N, S, K, rename=None):
                    ms_per_iteration=round(step_ms, 4), algorithmic_MB=None if by is None else round(by / 1e6, 1),
                    achieved_GBs=None if by is None else round(by / (step_ms * 1e-3) / 1e9, 1),
                    hbm_frac=None if by is None else round(by / (step_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4))
+        if name == "sort_pairs":
+            # what the reference's formulation (one global radix sort of 44-bit keys, K6) would move for the same instances
+            row["reference_formulation_MB"] = round(152.0 * R / 1e6, 1)
         v = pmc_valu(name)
         if v is not None:
             row["valu"] = v
@@ -433,7 +445,8 @@ def dp_path_one_rank(args, timeout_s=180):
     for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
     cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--steps", str(args.steps), "--warmup",
-           str(args.warmup), "--points", str(args.points), "--res", str(args.res), "--sample-num", str(args.sample_num),
+           str(args.warmup), "--points", str(args.points), "--res", str(args.res), "--width", str(getattr(args, "width", 0)), "--height",
+           str(getattr(args, "height", 0)), "--objective", getattr(args, "objective", "nerf"), "--sample-num", str(args.sample_num),
            "--no-cpu-baseline", "--no-other-configs", "--relight-frames", "0", "--repeats", "0"]
     try:
         r = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout_s, env=env, stdin=subprocess.DEVNULL)
@@ -441,20 +454,31 @@ def dp_path_one_rank(args, timeout_s=180):
         if r.returncode != 0 or not line:
             return {"failed": (r.stderr or r.stdout)[-400:]}
         doc = _finite_json(json.loads(line[-1]))
-        return dict(iters_per_s=doc["value"], ms_per_step=doc["ms_per_step"],
-                    what="the same iteration through the data-parallel path over a ONE-rank RCCL group (identity collectives)")
+        return dict(iters_per_s=doc["value"], ms_per_step=doc["ms_per_step"], exposed_comm_ms=doc.get("exposed_comm_ms"),
+                    reserved_cus_for_comm=doc.get("reserved_cus_for_comm"),
+                    what="the same iteration through the data-parallel path over a ONE-rank RCCL group (identity collectives; "
+                         "the persistent kernels leave `reserved_cus_for_comm` CUs to RCCL)")
     except subprocess.TimeoutExpired:
         return {"failed": "no result within %d s" % timeout_s}
     except Exception as e:
         return {"failed": repr(e)}
 
 
-def quick_rate(stage, points, res, sample_num, dev, steps=20, warmup=4):
-    """iters/s of another BASELINE configuration on the same synthetic scene (single GPU, short run): stage 1
-    (configs[1]; fused stage-1 iteration) or stage 2 at another sample count (configs[2]
-    trains at sample_num=384)."""
+# learning rates of the stage-2 schedules (the bench's headline uses one small rate for every group: throughput does not depend
+# on the values, only on WHICH groups train).  run_syn4.sh:27-33 / run_dtu.sh:29-35 freeze the geometry groups.
+SYN4_LRS = dict(xyz=0.0, normal=0.0, scaling=0.0, rotation=0.0, opacity=0.0, shs=0.0, shs_rest=0.0, base_color=0.01,
+                roughness=0.01, incidents=0.001, incidents_rest=0.0001, env=0.1)
+
+
+def config_rate(dev, points, width, height, stage=2, sample_num=64, objective="nerf", steps=16, warmup=4, relight_samples=0,
+                relight_frames=0):
+    """One of the other BASELINE configurations on the synthetic scene (single GPU, short run): iters/s of the fused training
+    iteration with that configuration's objective and schedule (`objective`: "nerf" = script/run_nerf.sh, "syn4" =
+    script/run_syn4.sh / run_dtu.sh: edge-aware smoothness terms + frozen geometry), the measured num_rendered, and optionally
+    relight FPS at `relight_samples` rays per Gaussian."""
+    from . import fused_step, relight, train_step
     scene = syn.make_scene(P=points, seed=0, stage2=stage == 2)
-    cams = [c.to(dev) for c in syn.orbit_cameras(100, width=res, height=res)[:4]]
+    cams = [c.to(dev) for c in syn.orbit_cameras(100, width=width, height=height)[:4]]
     bg = torch.ones(3, device=dev)
     params = GaussianParams(scene, dev, stage == 2)
     with torch.no_grad():
@@ -462,26 +486,51 @@ def quick_rate(stage, points, res, sample_num, dev, steps=20, warmup=4):
         teacher.features_dc.add_(0.05 * torch.randn_like(teacher.features_dc))
         gts = [render_stage1(teacher, c, bg)[2].clone() for c in cams]
         del teacher
+    out = dict(points=points, image="%dx%d" % (width, height))
     if stage == 2:
-        from . import fused_step
-        step_fn = fused_step.FusedStage2Step(params, sample_num, lr=1e-4)
-
-        def one(i):
-            step_fn(cams[i % 4], bg, gts[i % 4])
+        syn4 = objective == "syn4"
+        step_fn = fused_step.FusedStage2Step(params, sample_num, lr=1e-4, lrs=SYN4_LRS if syn4 else None,
+                                             loss_weights=train_step.STAGE2_WEIGHTS_SYN4 if syn4 else None)
+        out.update(sample_num=sample_num, objective="script/run_syn4.sh + run_dtu.sh: smoothness terms, geometry frozen"
+                   if syn4 else "script/run_nerf.sh", frozen_geometry=step_fn.frozen_geometry)
     else:
-        from . import fused_step
-        step1 = fused_step.FusedStage1Step(params, lr=1e-4)
-
-        def one(i):
-            step1(cams[i % 4], bg, gts[i % 4])
+        step_fn = fused_step.FusedStage1Step(params, lr=1e-4)
+        out.update(objective="script/run_nerf.sh stage 1 (the reference's real regularisers)")
     for i in range(warmup):
-        one(i)
+        step_fn(cams[i % 4], bg, gts[i % 4])
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for i in range(steps):
-        one(warmup + i)
+        step_fn(cams[(warmup + i) % 4], bg, gts[(warmup + i) % 4])
+    step_fn.flush()
     torch.cuda.synchronize()
-    return round(steps / (time.perf_counter() - t0), 2)
+    dt = (time.perf_counter() - t0) / steps
+    counts = step_fn.rendered_counts(steps)
+    out.update(iters_per_s=round(1.0 / dt, 2), ms_per_step=round(1e3 * dt, 3), num_rendered=round(sum(counts) / max(1, len(counts))),
+               dropped_steps=step_fn.poll_overflow())
+    if stage == 2 and relight_samples and relight_frames:
+        step_fn.visibility = step_fn.incident_dirs = step_fn.incident_areas = None
+        step_fn._taps = step_fn._taps_src = step_fn._frs = None
+        torch.cuda.empty_cache()
+        envmap = (3.0 * torch.rand(256, 512, 3, generator=torch.Generator().manual_seed(7)) ** 2).to(dev)
+        t0 = time.perf_counter()
+        r = relight.RelightRenderer(step_fn, envmap, relight_samples)
+        torch.cuda.synchronize()
+        t_vis = time.perf_counter() - t0
+        zbg = torch.zeros(3, device=dev)
+        for i in range(2):
+            r.frame(cams[i], zbg)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        nr = 0
+        for i in range(relight_frames):
+            nr += r.frame(cams[i % 4], zbg)["num_rendered"]
+        torch.cuda.synchronize()
+        dtf = (time.perf_counter() - t0) / relight_frames
+        out.update(relight_fps=round(1.0 / dtf, 2), relight_ms_per_frame=round(1e3 * dtf, 3), relight_samples=relight_samples,
+                   relight_num_rendered=round(nr / relight_frames), visibility_rays=points * relight_samples,
+                   visibility_seconds=round(t_vis, 3))
+    return out
 
 
 def densify_bench(points, res, dev, views=8):
@@ -549,10 +598,10 @@ def run(args):
 
     def side_budget(want_s):
         """Seconds a side measurement in a child process may still take: the default run is meant to finish within minutes,
-        so the children share what is left of ~4 minutes since the start (0 = skip it); R3DG_BENCH_NO_CHILDREN=1 skips all."""
+        so the side measurements share what is left of ~5 minutes since the start (0 = skip it); R3DG_BENCH_NO_CHILDREN=1 skips all."""
         if os.environ.get("R3DG_BENCH_NO_CHILDREN") == "1":
             return 0
-        left = 240.0 - (time.perf_counter() - t_start)
+        left = 300.0 - (time.perf_counter() - t_start)
         return int(min(want_s, left)) if left >= 45.0 else 0
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -588,7 +637,9 @@ def run(args):
 
     stage2 = args.stage == 2
     scene = syn.make_scene(P=args.points, seed=0, stage2=stage2)
-    cams_cpu = syn.orbit_cameras(100, width=args.res, height=args.res)
+    W_img = getattr(args, "width", 0) or args.res
+    H_img = getattr(args, "height", 0) or args.res
+    cams_cpu = syn.orbit_cameras(100, width=W_img, height=H_img)
     cams = [c.to(dev) for c in cams_cpu]
     bg = torch.ones(3, device=dev)
     params = GaussianParams(scene, dev, stage2)
@@ -602,7 +653,10 @@ def run(args):
         # the whole iteration through the fused glue kernels + one-launch Adam (fused_step.py); gradients are averaged
         # over ranks inside (three buckets of one flat slab; see fused_step.py and DESIGN.md section 5)
         from . import fused_step
-        step_fn = fused_step.FusedStage2Step(params, args.sample_num, lr=1e-4,
+        syn4 = getattr(args, "objective", "nerf") == "syn4"
+        from . import train_step as _ts
+        step_fn = fused_step.FusedStage2Step(params, args.sample_num, lr=1e-4, lrs=SYN4_LRS if syn4 else None,
+                                             loss_weights=_ts.STAGE2_WEIGHTS_SYN4 if syn4 else None,
                                              bounded=os.environ.get("R3DG_BOUNDED", "1") != "0")      # (A/B experiments)
         S = 16
     elif stage2:
@@ -660,6 +714,8 @@ def run(args):
     if dp:
         dist.barrier()
     L.r3dg_profile_enable(0 if os.environ.get("R3DG_BENCH_NOPROFILE") else 1)
+    if dp and fused and hasattr(step_fn, "measure_comm"):
+        step_fn.measure_comm = True          # (two event records per waited bucket: what the compute stream stalls on)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     # per-kernel HIP-event timing is live inside the timed region but sampled (every 8th step): each event pair costs
@@ -676,6 +732,10 @@ def run(args):
     elapsed = time.perf_counter() - t0
     prof = _lib.profile_read()
     L.r3dg_profile_enable(0)
+    exposed_comm = None
+    if dp and fused and hasattr(step_fn, "exposed_comm_ms"):
+        exposed_comm = step_fn.exposed_comm_ms()
+        step_fn.measure_comm = False
     if fused and hasattr(step_fn, "rendered_counts"):
         R_seen = step_fn.rendered_counts(args.steps)
         dropped = step_fn.poll_overflow()
@@ -714,7 +774,7 @@ def run(args):
         relight = relight_bench(step_fn if fused else params, cams, dev, args.relight_frames, args.relight_samples)
     result = None
     if rank == 0:
-        P, N = args.points, args.res * args.res
+        P, N = args.points, W_img * H_img
         R_mean = float(sum(R_seen[-args.steps:])) / max(1, args.steps)
         n_sampled = max(1, sum(1 for i in range(args.steps) if i % 8 == 0))     # steps whose launches were timed
         kernels = kernel_table(prof, n_sampled, P, R_mean, N, S, args.sample_num)
@@ -727,18 +787,25 @@ def run(args):
         iters_s = world * args.steps / elapsed
         result = {
             "metric": "train iters/s, synthetic lego-like %dx%d, %d Gaussians (stage-%d hot path)" % (
-                args.res, args.res, P, args.stage),
+                W_img, H_img, P, args.stage),
             "value": round(iters_s, 3), "unit": "iters/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": ("stage-%d train iteration%s: %srasterize fwd (S=%d) + loss + rasterize bwd + Adam; "
-                                    "1 view/rank/step, %d Gaussians, %dx%d, num_rendered~%.0f") % (
+                                    "1 view/rank/step, %d Gaussians, %dx%d, num_rendered~%.0f" + (
+                                        "; objective + schedule of script/run_syn4.sh (smoothness terms, geometry frozen)"
+                                        if getattr(args, "objective", "nerf") == "syn4" else "")) % (
                                        args.stage, " (fused glue kernels + one-launch Adam)" if fused else "",
                                        "shading fwd/bwd (K=%d) + " % args.sample_num if stage2 else "", S,
-                                       P, args.res, args.res, R_mean),
+                                       P, W_img, H_img, R_mean),
                        "parallelism": "dp%d (views sharded over ranks; bucketed async RCCL all-reduce of per-Gaussian grads)" % world},
             "roofline": roofline, "kernels": kernels, "spread_iters_per_s": spread,
         }
+        if dp:
+            # rank 0's compute stream: mean time per iteration it stood waiting for gradient all-reduce buckets (C, then the
+            # deferred B in front of the next shading forward; A is waited for on a side stream, under the shading backward)
+            result["exposed_comm_ms"] = None if exposed_comm is None else round(exposed_comm, 4)
+            result["reserved_cus_for_comm"] = _lib.get_option("RESERVE_CUS")
         if relight is not None:
             result["roofline_relight"] = relight.pop("roofline_relight")
         if relight is not None:
@@ -748,22 +815,31 @@ def run(args):
             try:
                 del step_fn, params
                 torch.cuda.empty_cache()
-                result["other_configs"] = {
-                    "stage1_train_iters_per_s (configs[1], fused stage-1 iteration)":
-                        quick_rate(1, args.points, args.res, 0, dev),
-                    "stage2_train_iters_per_s_sample_num_384 (configs[2])":
-                        quick_rate(2, args.points, args.res, 384, dev),
-                    "stage1_densify_and_prune (one call at the bench size)": densify_bench(args.points, args.res, dev),
-                }
+                oc = result["other_configs"] = {}
+                oc["configs[1] stage-1 3DGS train, 800x800"] = config_rate(dev, args.points, W_img, H_img, stage=1)
+                oc["configs[2] Synthetic4Relight stage-2 (run_syn4.sh objective + schedule), sample_num 384 as BASELINE.json states"] = \
+                    config_rate(dev, args.points, W_img, H_img, sample_num=384, objective="syn4", steps=10, warmup=3)
+                oc["configs[2] the same at the script's own sample_num 64 (run_syn4.sh:39)"] = \
+                    config_rate(dev, args.points, W_img, H_img, sample_num=64, objective="syn4")
+                oc["stage-2 run_nerf.sh objective at sample_num 384"] = config_rate(
+                    dev, args.points, W_img, H_img, sample_num=384, steps=10, warmup=3)
+                if side_budget(60):
+                    oc["configs[3] DTU stage-2 (run_dtu.sh: 1600x1200, sample_num 32, env 16, geometry frozen), one view on one GPU"] = \
+                        config_rate(dev, args.points, 1600, 1200, sample_num=32, objective="syn4", steps=10, warmup=3)
+                if side_budget(60):
+                    oc["configs[4] composition scale: 2M Gaussians, 1800x700 (configs/teaser), train sample_num 64 + relight sample_num 384"] = \
+                        config_rate(dev, 2_000_000, 1800, 700, sample_num=64, steps=8, warmup=3, relight_samples=384,
+                                    relight_frames=6)
+                oc["stage1_densify_and_prune (one call at the bench size)"] = densify_bench(args.points, args.res, dev)
                 if args.stage == 2 and not getattr(args, "unfused", False):
                     skipped = {"skipped": "time budget of the default run used up (or R3DG_BENCH_NO_CHILDREN=1)"}
                     b = side_budget(150)
-                    result["other_configs"]["data_parallel_path_one_rank_rccl"] = dp_path_one_rank(args, timeout_s=b) if b else skipped
+                    oc["data_parallel_path_one_rank_rccl"] = dp_path_one_rank(args, timeout_s=b) if b else skipped
             except Exception as e:
                 result["other_configs"] = {"failed": repr(e)}
         if not args.no_cpu_baseline and world == 1:
             try:
-                result["cpu_baseline"] = cpu_baseline(scene, cams_cpu, S, args.cpu_baseline_seconds, args.points, args.res)
+                result["cpu_baseline"] = cpu_baseline(scene, cams_cpu, S, args.cpu_baseline_seconds, args.points, W_img, H_img)
             except Exception as e:  # the oracle is only a reported baseline; never fail the bench on it
                 result["cpu_baseline"] = {"value": None, "unit": "views/s (rasterize forward)", "cores": None, "kind": "port",
                                           "sample": "failed: %r" % (e,)}

@@ -306,6 +306,15 @@ class FusedStage2Step(_BoundedForward):
         self._side = torch.cuda.Stream(device=dev) if overlap_geometry else None
         self.group = process_group
         self.world, self.dp = _world_of(process_group)
+        if self.dp:
+            # The shading kernels and the visibility trace are PERSISTENT grids that fill every CU (the backward: 2 workgroups
+            # x ~60 KB LDS, ~2 x 230 VGPRs per SIMD); RCCL's workgroups could then only start when one of them retires and
+            # bucket A's "hidden" all-reduce would serialise behind the shading backward.  Under data parallelism the
+            # persistent grids leave a few CUs free (r3dg_set_option(R3DG_OPT_RESERVE_CUS); R3DG_RESERVE_CUS_FOR_COMM
+            # overrides, 0 = off); the cost on one rank is measured by bench.py (`data_parallel_path_one_rank_rccl`).
+            _lib.set_option("RESERVE_CUS", int(os.environ.get("R3DG_RESERVE_CUS_FOR_COMM", "8")))
+        self.measure_comm = False                   # bench.py: time the main stream spends waiting for all-reduce buckets
+        self._comm_events = []
         with torch.no_grad():
             self.refresh_activations()
             self.visibility, self.incident_dirs, self.incident_areas, self.tracer = update_visibility(
@@ -594,6 +603,30 @@ class FusedStage2Step(_BoundedForward):
             return None
         return torch.distributed.all_reduce(flat, group=self.group, async_op=True)
 
+    def _wait(self, handle):
+        """Make the current stream wait for a bucket's all-reduce; with `measure_comm` the wait is bracketed by events so that
+        the time the stream actually stalls on it (the EXPOSED communication) can be read back (exposed_comm_ms)."""
+        if not self.measure_comm:
+            handle.wait()
+            return
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        handle.wait()
+        e1.record()
+        self._comm_events.append((self._iter, e0, e1))
+
+    def exposed_comm_ms(self):
+        """Mean per iteration of the time the compute stream waited for gradient all-reduces since measure_comm was set
+        (synchronises).  The early bucket A is waited for on a side stream and is not part of it by construction."""
+        if not self._comm_events:
+            return None
+        torch.cuda.synchronize(self.dev)
+        per_iter = {}
+        for it, e0, e1 in self._comm_events:
+            per_iter[it] = per_iter.get(it, 0.0) + e0.elapsed_time(e1)
+        self._comm_events = []
+        return sum(per_iter.values()) / max(1, len(per_iter))
+
     def loss(self):
         """Loss value of the last forward_backward (a 0-d tensor; costs a few tiny kernels, so it is on demand)."""
         self.poll_overflow()
@@ -627,16 +660,16 @@ class FusedStage2Step(_BoundedForward):
         if self._early:                  # bucket A was waited for and applied on the side stream (forward_backward)
             torch.cuda.current_stream().wait_stream(self._early_stream)
             self._early = False
-            handle_c.wait()
+            self._wait(handle_c)
         else:
             self.opt.begin_step()
             # the overflow flag rides in the first bucket that is reduced: A, or C when the geometry is frozen
-            (handle_a if handle_a is not None else handle_c).wait()
+            self._wait(handle_a if handle_a is not None else handle_c)
             self._skip_cur = self._snapshot_flag()      # > 0 on every rank when any rank dropped its view
             if handle_a is not None:
                 if self._groups_a:
                     self.opt.step_groups(self._groups_a, grads, scale, skip_flag=self._skip_cur)
-                handle_c.wait()
+                self._wait(handle_c)
         if self._groups_c:
             self.opt.step_groups(self._groups_c, grads, scale, skip_flag=self._skip_cur)
         self._pending_b = (handle_b, grads, scale, self._skip_cur)
@@ -646,7 +679,7 @@ class FusedStage2Step(_BoundedForward):
         if self._pending_b is not None:
             handle_b, grads, scale, skip = self._pending_b
             self._pending_b = None
-            handle_b.wait()
+            self._wait(handle_b)
             if self._groups_b:
                 self.opt.step_groups(self._groups_b, grads, scale, skip_flag=skip)
 

@@ -235,6 +235,77 @@ def test_a_view_that_does_not_fit_on_one_rank_drops_the_step_on_all_ranks(tmp_pa
         assert torch.equal(r0["pars"][k], r1["pars"][k]), "replicas diverged: " + k
 
 
+def _world8_worker(rank, world, port, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    from relightable3dgaussian_amd import synthetic as syn
+    from relightable3dgaussian_amd.bench_core import SYN4_LRS, GaussianParams, render_stage1
+    from relightable3dgaussian_amd.fused_step import FusedStage2Step
+    from relightable3dgaussian_amd.train_step import STAGE2_WEIGHTS_SYN4
+    torch.manual_seed(99)
+    P, res, K = 1003, 96, 8                                  # ceil(1003 / 8) = 126: the last rank traces 121 ray bundles
+    scene = syn.make_scene(P=P, seed=13, stage2=True, scale_log_mean=-3.0)
+    cams = [c.to(dev) for c in syn.orbit_cameras(8, width=res, height=res)]
+    bg = torch.ones(3, device=dev)
+    with torch.no_grad():
+        teacher = GaussianParams(syn.make_scene(P=P, seed=13, stage2=False, scale_log_mean=-3.0), dev, False)
+        gts = [render_stage1(teacher, c, bg)[2].clone() * 0.9 for c in cams]
+    out = {}
+    for name, kw in (("nerf", dict(loss_weights={"normal": 0.01})), ("syn4", dict(loss_weights=STAGE2_WEIGHTS_SYN4, lrs=SYN4_LRS))):
+        step = FusedStage2Step(GaussianParams(scene, dev, True), K, lr=1e-3, bounded=True, **kw)
+        assert step.world == 8 and step.dp and step.frozen_geometry == (name == "syn4")
+        if name == "nerf":
+            out["visibility"] = step.visibility.cpu()
+        step(cams[rank], bg, gts[rank])                      # iteration 1: two-phase forward, learns the count
+        step.flush()
+        if rank == 5:
+            step._capacity = step.rendered_counts(1)[0] - 3  # rank 5's next view will not fit
+        before = {k: getattr(step, k).detach().clone() for k in ("xyz", "shs", "incidents", "env", "base_color")}
+        n_before = step.opt.step_count
+        step(cams[(rank + 3) % 8], bg, gts[(rank + 3) % 8])  # iteration 2: dropped on EVERY rank
+        step.flush()
+        torch.cuda.synchronize()
+        unchanged = all(torch.equal(getattr(step, k), v) for k, v in before.items())
+        dropped = step.poll_overflow()
+        step(cams[(rank + 5) % 8], bg, gts[(rank + 5) % 8])  # iteration 3 trains again
+        step.flush()
+        torch.cuda.synchronize()
+        out[name] = dict(unchanged=unchanged, dropped=dropped, steps=(n_before, step.opt.step_count),
+                         pars={k: getattr(step, k).detach().cpu().clone() for k in before}, later=step.poll_overflow())
+    torch.save(out, os.path.join(out_dir, "w8_%d.pt" % rank))
+    dist.destroy_process_group()
+
+
+def test_eight_ranks_rehearsal_on_one_gpu(tmp_path):
+    """The 8-rank launch the driver makes at round end, rehearsed on the one GPU of the test box (gloo on device tensors):
+    ragged ceil(P / 8) split of the visibility trace + all-gather, the three-bucket all-reduce schedule (and the two-bucket one
+    of the frozen-geometry schedule, whose flag rides in its first bucket), a view that does not fit on rank 5 dropping the
+    step on all eight ranks, replicas bit-identical afterwards."""
+    mp.spawn(_world8_worker, args=(8, _free_port(), str(tmp_path)), nprocs=8, join=True)
+    r = [torch.load(os.path.join(tmp_path, "w8_%d.pt" % i)) for i in range(8)]
+    from relightable3dgaussian_amd import synthetic as syn
+    from relightable3dgaussian_amd.bench_core import GaussianParams
+    from relightable3dgaussian_amd.fused_step import FusedStage2Step
+    dev = torch.device("cuda", 0)
+    single = FusedStage2Step(GaussianParams(syn.make_scene(P=1003, seed=13, stage2=True, scale_log_mean=-3.0), dev, True), 8)
+    for i in range(8):
+        assert torch.equal(r[i]["visibility"], single.visibility.cpu()), "gathered visibility differs on rank %d" % i
+        for name in ("nerf", "syn4"):
+            d = r[i][name]
+            assert d["unchanged"], "a dropped step updated parameters (%s, rank %d)" % (name, i)
+            assert d["dropped"] == 1 and d["later"] == 0 and d["steps"] == (1, 2), (name, i, d["dropped"], d["steps"])
+            for k, v in d["pars"].items():
+                assert torch.equal(v, r[0][name]["pars"][k]), "replicas diverged: %s %s rank %d" % (name, k, i)
+    start = GaussianParams(syn.make_scene(P=1003, seed=13, stage2=True, scale_log_mean=-3.0), dev, True)
+    assert not torch.equal(r[0]["nerf"]["pars"]["xyz"], start.xyz.detach().cpu())          # trained ...
+    assert torch.equal(r[0]["syn4"]["pars"]["xyz"], start.xyz.detach().cpu())              # ... frozen
+    assert not torch.equal(r[0]["syn4"]["pars"]["base_color"], start.base_color.detach().cpu())
+
+
 def _single_rank_rccl_worker(rank, world, port, out_dir):
     """One rank, backend nccl (= RCCL): with R3DG_DP_SINGLE_RANK=1 the iteration takes the data-parallel path -- three
     async all-reduce buckets on RCCL's stream, the reduced skip flag, the deferred incident-light update, the all-gather

@@ -108,9 +108,10 @@ def test_transport_cache_frames_equal_radiance_cache_frames(regenerate_dirs):
             sa = a.shade_out.clone()
             fb = b.frame(cam, bg)
             assert fa["num_rendered"] == fb["num_rendered"]
-            # regenerated directions are 1e-7 off the cached ones and the GGX lobe is ill-conditioned: 2e-4 on the columns
-            # that contain it (the bound of the shading parity tests for that term), 2e-5 on the view-independent ones
-            ggx = 2e-4 if regenerate_dirs else 2e-5
+            # the GGX lobe is ill-conditioned in fp32 (two evaluation orders differ by ~1e-4, regenerated directions are 1e-7 off
+            # the cached ones): 2e-4 on the columns that contain it (the bound of the shading parity tests for that term),
+            # 2e-5 on the view-independent ones
+            ggx = 2e-4
             for c0, c1, name, tol in ((0, 3, "pbr", ggx), (3, 6, "diffuse_light", 2e-5), (6, 9, "specular", ggx),
                                       (9, 18, "lights", 2e-5), (18, 19, "vis", 2e-5)):
                 ok, msg = report(name, b.shade_out[:, c0:c1], sa[:, c0:c1], tol, 1e-6)

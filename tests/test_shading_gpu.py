@@ -225,8 +225,10 @@ def test_fixed_ray_set_kernels_equal_the_general_kernels(P, K, He):
     inp = _frs_inputs(P, K, He, seed=7 * P + K)
     assert so.FixedRaySet.supported(K, 16, He, 2 * He)
     frs = so.FixedRaySet.try_build(inp["normals"], inp["incident_dirs"])
-    assert frs is not None and 3 <= frs.n_invalid <= 3 + P // 50 and frs.n_invalid == int((frs.valid[:P] == 0).sum())
-    assert [int(v) for v in frs.valid[:6]] == [1, 0, 0, 1, 0, 1]
+    assert frs is not None and 2 <= frs.n_invalid <= 2 + P // 50 and frs.n_invalid == int((frs.valid[:P] == 0).sum())
+    # n = -z (and the normalised (1e-4, 0, -1), whose z rounds to -1): R = -I, an improper rotation but orthonormal -> rotated
+    # like any other; (0, 3e-3, -1) and (2e-2, 1e-2, -1): cancellation in 1 + n_z -> the general kernel
+    assert [int(v) for v in frs.valid[:6]] == [1, 1, 0, 1, 0, 1]
     # (n = -z exactly takes R = -I, which IS orthonormal -- an improper rotation, rotated like any other; n = +z: R = I)
     taps = so.build_taps(inp["incident_dirs"], He, 2 * He)
     args = (inp["base_color"], inp["roughness"], inp["normals"], inp["viewdirs"], inp["incidents"], inp["env"],

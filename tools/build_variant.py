@@ -26,13 +26,16 @@ def build_variant(name, src, replacements=(), extra_flags=(), count=None):
     """-> path of the variant library.  `replacements`: (old, new) pairs, each `old` must occur exactly once (or `count`
     times when given as a third element)."""
     B.build(verbose=False)                                   # the product objects the variant links against
-    text = open(os.path.join(B.CSRC, src)).read()
+    texts = {}
     for rep in replacements:
         old, new = rep[0], rep[1]
-        n = rep[2] if len(rep) > 2 else 1
+        n = rep[2] if len(rep) > 2 and rep[2] is not None else 1
+        fname = rep[3] if len(rep) > 3 else src              # (a header of csrc/ the source includes, e.g. "shading_frs.hpp")
+        text = texts.get(fname) or open(os.path.join(B.CSRC, fname)).read()
         if text.count(old) != n:
-            raise RuntimeError("variant %s: %r occurs %d times in %s, expected %d" % (name, old[:60], text.count(old), src, n))
-        text = text.replace(old, new)
+            raise RuntimeError("variant %s: %r occurs %d times in %s, expected %d" % (name, old[:60], text.count(old), fname, n))
+        texts[fname] = text.replace(old, new)
+    texts.setdefault(src, open(os.path.join(B.CSRC, src)).read())
     out_dir = os.path.join(VARIANTS, name)
     os.makedirs(out_dir, exist_ok=True)
     with tempfile.TemporaryDirectory() as tmp:
@@ -40,9 +43,10 @@ def build_variant(name, src, replacements=(), extra_flags=(), count=None):
         for f in os.listdir(B.CSRC):
             if f.endswith(".hpp"):
                 shutil.copy(os.path.join(B.CSRC, f), tmp)
+        for fname, text in texts.items():
+            with open(os.path.join(tmp, fname), "w") as fh:
+                fh.write(text)
         path = os.path.join(tmp, src)
-        with open(path, "w") as fh:
-            fh.write(text)
         obj = os.path.join(tmp, src[:-4] + ".o")
         flags = B.COMMON + B.EXTRA.get(src, []) + list(extra_flags)
         r = subprocess.run([B.HIPCC] + flags + ["-c", path, "-o", obj], capture_output=True, text=True)
