@@ -252,7 +252,11 @@ int r3dg_shade_forward_transport(void* stream, int P, int K, const float* d_base
  *     -z lose that to cancellation, their cached directions are not a rigid copy of the z set, and those Gaussians (d_invalid_list
  *     [n_invalid] int32 row indices, built by the caller from d_valid) go through the general kernels inside the same call;
  *   d_cprime [P,48]: scratch written by _forward (the rotated coefficients) and read by _backward of the same parameters;
- *   d_dcprime [P,48]: scratch of _backward.  d_incident_areas may be NULL with uniform_area > 0. */
+ *   d_dcprime [P,48]: scratch of _backward.
+ *   Sample areas: the fixed ray set has ONE area for every sample -- uniform_area, or 2*pi (what fibonacci_sphere_sampling assigns,
+ *     utils/graphics_utils.py:36) when uniform_area == 0; d_incident_areas [P,K] is read only for the Gaussians of d_invalid_list:
+ *     _backward needs it when n_invalid > 0 (the general backward reads areas per sample), _forward takes uniform_area for them
+ *     when it is NULL. */
 int r3dg_shade_frs_supported(int K, int M, int He, int We);
 size_t r3dg_shade_frs_tables_bytes(int K);
 int r3dg_shade_frs_build_tables(void* stream, int K, const float* d_zsamples, float* d_tables);
@@ -641,6 +645,8 @@ enum r3dg_option {
     R3DG_OPT_TRACE_LEAF_WEIGHT,
     R3DG_OPT_RESERVE_CUS,               /* CUs the persistent kernels (shading, trace) leave free for a collective running beside them
                                          * (default 0; the data-parallel iteration sets it) */
+    R3DG_OPT_LONG_TILE_SORT,            /* tiles longer than 4096 instances: 1 (default) segmented radix sort on the depth bits,
+                                         * 0 the bitonic network */
     R3DG_OPT_COUNT
 };
 int r3dg_set_option(int option, int value);

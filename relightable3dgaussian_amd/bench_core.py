@@ -471,7 +471,7 @@ SYN4_LRS = dict(xyz=0.0, normal=0.0, scaling=0.0, rotation=0.0, opacity=0.0, shs
 
 
 def config_rate(dev, points, width, height, stage=2, sample_num=64, objective="nerf", steps=16, warmup=4, relight_samples=0,
-                relight_frames=0):
+                relight_frames=0, stage_ms=False):
     """One of the other BASELINE configurations on the synthetic scene (single GPU, short run): iters/s of the fused training
     iteration with that configuration's objective and schedule (`objective`: "nerf" = script/run_nerf.sh, "syn4" =
     script/run_syn4.sh / run_dtu.sh: edge-aware smoothness terms + frozen geometry), the measured num_rendered, and optionally
@@ -508,6 +508,17 @@ def config_rate(dev, points, width, height, stage=2, sample_num=64, objective="n
     counts = step_fn.rendered_counts(steps)
     out.update(iters_per_s=round(1.0 / dt, 2), ms_per_step=round(1e3 * dt, 3), num_rendered=round(sum(counts) / max(1, len(counts))),
                dropped_steps=step_fn.poll_overflow())
+    if stage_ms:
+        # per-stage HIP-event times of 3 more iterations (outside the timed region: the event pairs cost host time)
+        L = _lib.lib()
+        L.r3dg_profile_enable(1)
+        for i in range(3):
+            step_fn(cams[i % 4], bg, gts[i % 4])
+        step_fn.flush()
+        torch.cuda.synchronize()
+        prof = _lib.profile_read()
+        L.r3dg_profile_enable(0)
+        out["stage_ms"] = {k: round(ms / 3, 4) for k, (ms, n) in prof.items() if n}
     if stage == 2 and relight_samples and relight_frames:
         step_fn.visibility = step_fn.incident_dirs = step_fn.incident_areas = None
         step_fn._taps = step_fn._taps_src = step_fn._frs = None
@@ -825,11 +836,12 @@ def run(args):
                     dev, args.points, W_img, H_img, sample_num=384, steps=10, warmup=3)
                 if side_budget(60):
                     oc["configs[3] DTU stage-2 (run_dtu.sh: 1600x1200, sample_num 32, env 16, geometry frozen), one view on one GPU"] = \
-                        config_rate(dev, args.points, 1600, 1200, sample_num=32, objective="syn4", steps=10, warmup=3)
+                        config_rate(dev, args.points, 1600, 1200, sample_num=32, objective="syn4", steps=10, warmup=3,
+                                    stage_ms=True)
                 if side_budget(60):
                     oc["configs[4] composition scale: 2M Gaussians, 1800x700 (configs/teaser), train sample_num 64 + relight sample_num 384"] = \
                         config_rate(dev, 2_000_000, 1800, 700, sample_num=64, steps=8, warmup=3, relight_samples=384,
-                                    relight_frames=6)
+                                    relight_frames=6, stage_ms=True)
                 oc["stage1_densify_and_prune (one call at the bench size)"] = densify_bench(args.points, args.res, dev)
                 if args.stage == 2 and not getattr(args, "unfused", False):
                     skipped = {"skipped": "time budget of the default run used up (or R3DG_BENCH_NO_CHILDREN=1)"}

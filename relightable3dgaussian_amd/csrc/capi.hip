@@ -84,6 +84,7 @@ void launch_shade_forward_transport(hipStream_t s, int P, int K, const float* ba
                                     const float* normals, const float* viewdirs, const float* transport, const float* consts,
                                     const float* zsamples, const float* dirs, float* out);
 extern int g_trace_packet, g_trace_refill, g_trace_node_weight, g_trace_leaf_weight;
+extern int g_long_tile_sort;         // radix_sort.hip
 extern int g_shade_row_blocks_per_cu;
 void launch_shade_backward(hipStream_t s, int P, int K, int M, const float* base_color, const float* roughness,
                            const float* normals, const float* viewdirs, const float* incidents, const float* env,
@@ -154,7 +155,7 @@ void launch_s2_env_backward(hipStream_t s, int He, int We, const float* raw, con
                             float w_tv, float* g_raw, float* tv_sum, int consume);
 uint32_t tile_sort_small_cap();
 void launch_tile_sort(hipStream_t s, int T, const uint32_t* tile_order, const uint32_t* ranges, const uint32_t* big_list,
-                      const uint32_t* big_count, uint64_t* keys, uint32_t* vals, uint64_t* scratch, bool entries);
+                      uint32_t* big_count, uint64_t* keys, uint32_t* vals, uint64_t* scratch, bool entries);
 void launch_tile_binning(hipStream_t s, int P, int T, const float* means2D, const float* depths, const int* radii,
                          const uint32_t* tiles_touched, const uint32_t* block_offsets, int gx, int gy,
                          uint32_t* tile_counts, uint32_t* cursor, uint32_t* ranges, uint32_t* point_offsets,
@@ -403,14 +404,15 @@ static int* option_slot(int option)
         case R3DG_OPT_TRACE_NODE_WEIGHT: return &g_trace_node_weight;
         case R3DG_OPT_TRACE_LEAF_WEIGHT: return &g_trace_leaf_weight;
         case R3DG_OPT_RESERVE_CUS: return &g_reserve_cus;
+        case R3DG_OPT_LONG_TILE_SORT: return &g_long_tile_sort;
         default: return nullptr;
     }
 }
 
 int r3dg_set_option(int option, int value)
 {
-    static const int lo[R3DG_OPT_COUNT] = {1, 1, 1, 1, 0, 0, 0, 0, 0, 1, 0, 0, 0, 1, 1, 1, 0};
-    static const int hi[R3DG_OPT_COUNT] = {4, 2, 4, 4, 1, 1, 1, 1, 2, 64, 1, 8, 4, 64, 15, 15, 128};
+    static const int lo[R3DG_OPT_COUNT] = {1, 1, 1, 1, 0, 0, 0, 0, 0, 1, 0, 0, 0, 1, 1, 1, 0, 0};
+    static const int hi[R3DG_OPT_COUNT] = {4, 2, 4, 4, 1, 1, 1, 1, 2, 64, 1, 8, 4, 64, 15, 15, 128, 1};
     int* slot = option_slot(option);
     if (slot == nullptr) return invalid("set_option: unknown option");
     if (value < lo[option] || value > hi[option]) return invalid("set_option: value out of range");

@@ -420,17 +420,233 @@ tile_sort_big_kernel(const uint32_t* __restrict__ big_list, const uint32_t* __re
         sort_one_tile<1024, ENTRIES>(ranges[big_list[b]], keys, vals, scratch, s_sort, cap, big_list[b]);
 }
 
+// ---- long tiles: segmented LSD radix sort -------------------------------------------------------------------------------------
+// A bitonic network is O(n log^2 n): at 2 M Gaussians half of a 1800x700 frame's tiles hold more than 4096 instances and the
+// network (in 128 KB of LDS up to 16384 entries, in global memory with a fence per stage beyond) took 2.7 ms of a 9.6 ms
+// iteration.  One 1024-thread workgroup per long tile instead runs a STABLE least-significant-digit radix sort over the
+// depth bits that actually differ inside the tile (the common prefix -- sign, most of the exponent -- is found first:
+// typically 22-26 bits, 3-4 passes of <= 8 bits), ping-ponging the tile's (depth << 32 | index) entries between its scratch
+// segment and its slice of the output key array (both L2-resident).  Per pass: every wave owns a contiguous 1/16 of the
+// list; (1) per-wave digit histogram (LDS atomics), (2) exclusive scan over (digit, wave), (3) every wave walks its range in
+// order, 64 keys at a time, ranks equal digits with one ballot per digit bit (sort_scatter_kernel's scheme) and scatters --
+// no workgroup barrier inside (1) or (3).  The direct tile binning hands the entries over in ARBITRARY order, so equal depths
+// are ordered by Gaussian index afterwards: runs of equal depth are short in any real frame and each member counts the
+// smaller indices of its run; a run longer than LONG_TIE_RUN sends the tile to the bitonic network on the full
+// (depth, index) key, which needs no such assumption.
+constexpr int LONG_THREADS = 1024;
+constexpr int LONG_WAVES = LONG_THREADS / 64;
+constexpr int LONG_BATCH = 8;                 // keys per lane in registers at a time
+constexpr int LONG_BITS = 8;
+constexpr int LONG_BINS = 1 << LONG_BITS;
+constexpr uint32_t LONG_TIE_RUN = 64;
+
+// loads of entries that other waves of this workgroup wrote earlier in the kernel (a fence + barrier lies in between): relaxed
+// atomic loads at workgroup scope are ordinary global loads that the compiler may neither hoist nor keep in registers
+__device__ __forceinline__ uint64_t load_wg(const uint64_t* p)
+{
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+__device__ __forceinline__ uint32_t load_wg(const uint32_t* p)
+{
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
+struct LongSortLds {
+    uint32_t cnt[LONG_WAVES * LONG_BINS];
+    uint32_t base[LONG_BINS];
+    uint32_t wave_sum[LONG_BINS / 64];
+    uint32_t diff, ties, next;
+};
+
+template <bool ENTRIES>
+__device__ __forceinline__ void radix_sort_one_tile(uint2 rg, uint64_t* keys, uint32_t* vals, uint64_t* scratch, uint32_t tile,
+                                                    LongSortLds& L)
+{
+    const uint32_t n = rg.y - rg.x;
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    uint64_t* seg = scratch + rg.x;                 // the tile's entries (buffer A)
+    uint64_t* alt = keys + rg.x;                    // buffer B: the tile's slice of the output keys
+    const uint64_t tile_hi = ENTRIES ? ((uint64_t)tile << 32) : (keys[rg.x] & 0xffffffff00000000ull);
+    const uint32_t first = ENTRIES ? (uint32_t)(seg[0] >> 32) : (uint32_t)keys[rg.x];
+    if (tid == 0) { L.diff = 0; L.ties = 0; }
+    __syncthreads();
+    uint32_t diff = 0;
+    for (uint32_t i = tid; i < n; i += LONG_THREADS) {
+        uint64_t e;
+        if (ENTRIES) {
+            e = seg[i];
+        } else {
+            e = (keys[rg.x + i] << 32) | vals[rg.x + i];
+            seg[i] = e;
+        }
+        diff |= (uint32_t)(e >> 32) ^ first;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) diff |= (uint32_t)__shfl_xor((int)diff, o, 64);
+    if (lane == 0 && diff) atomicOr(&L.diff, diff);
+    __threadfence();
+    __syncthreads();
+    diff = L.diff;
+    const int nbits = diff ? 32 - __builtin_clz(diff) : 0;
+    const int passes = (nbits + LONG_BITS - 1) / LONG_BITS;
+    const int bits = passes ? (nbits + passes - 1) / passes : 0;
+    uint64_t* src = seg;
+    uint64_t* dst = alt;
+    if (passes & 1) {                               // the passes must END in seg: the output loop reads seg and writes the slice
+        for (uint32_t i = tid; i < n; i += LONG_THREADS) alt[i] = load_wg(seg + i);
+        __threadfence();
+        __syncthreads();
+        src = alt;
+        dst = seg;
+    }
+    const uint32_t chunk = ((n + LONG_THREADS - 1) / LONG_THREADS) * 64;       // keys per wave (a multiple of 64)
+    const uint32_t w_lo = min(n, wave * chunk), w_hi = min(n, w_lo + chunk);
+    const bool single = chunk <= 64u * LONG_BATCH;   // the wave's keys stay in registers between the histogram and the scatter
+    volatile uint32_t* cnt = L.cnt + wave * LONG_BINS;
+    for (int p = 0; p < passes; p++) {
+        const int shift = 32 + p * bits;
+        const int pb = (nbits - p * bits) < bits ? (nbits - p * bits) : bits;
+        const uint32_t bins = 1u << pb, mask = bins - 1u;
+        for (uint32_t i = tid; i < LONG_WAVES * LONG_BINS; i += LONG_THREADS) L.cnt[i] = 0;
+        __syncthreads();
+        uint64_t key[LONG_BATCH];
+        for (uint32_t b0 = w_lo; b0 < w_hi; b0 += 64u * LONG_BATCH) {
+#pragma unroll
+            for (int r = 0; r < LONG_BATCH; r++) {
+                const uint32_t i = b0 + r * 64 + lane;
+                key[r] = i < w_hi ? load_wg(src + i) : ~0ull;
+            }
+#pragma unroll
+            for (int r = 0; r < LONG_BATCH; r++)
+                if (b0 + r * 64 + lane < w_hi) atomicAdd(&L.cnt[wave * LONG_BINS + digit_of(key[r], shift, mask)], 1u);
+        }
+        __syncthreads();
+        // cnt[w][d] <- number of digit-d keys in waves before w; base[d] <- number of keys with a smaller digit
+        uint32_t total = 0, inc = 0;
+        if (tid < LONG_BINS) {
+            if (tid < bins) {
+                uint32_t run = 0;
+#pragma unroll
+                for (int w = 0; w < LONG_WAVES; w++) {
+                    const uint32_t c = L.cnt[w * LONG_BINS + tid];
+                    L.cnt[w * LONG_BINS + tid] = run;
+                    run += c;
+                }
+                total = run;
+            }
+            inc = wave_inclusive_scan_u32(total);
+            if (lane == 63) L.wave_sum[wave] = inc;
+        }
+        __syncthreads();
+        if (tid < LONG_BINS) {
+            uint32_t off = 0;
+            for (uint32_t w = 0; w < wave; w++) off += L.wave_sum[w];
+            L.base[tid] = off + inc - total;
+        }
+        __syncthreads();
+        for (uint32_t b0 = w_lo; b0 < w_hi; b0 += 64u * LONG_BATCH) {
+            if (!single) {
+#pragma unroll
+                for (int r = 0; r < LONG_BATCH; r++) {
+                    const uint32_t i = b0 + r * 64 + lane;
+                    key[r] = i < w_hi ? load_wg(src + i) : ~0ull;
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < LONG_BATCH; r++) {
+                if (b0 + r * 64 >= w_hi) break;                          // (wave-uniform)
+                const bool valid = b0 + r * 64 + lane < w_hi;
+                const uint32_t d = digit_of(key[r], shift, mask);
+                unsigned long long peers = __ballot(valid);
+                for (int b = 0; b < pb; b++) {
+                    const bool bit = (d >> b) & 1u;
+                    const unsigned long long bal = __ballot(bit);
+                    peers &= bit ? bal : ~bal;
+                }
+                const uint32_t below = __popcll(peers & ((1ull << lane) - 1ull));
+                const uint32_t count = __popcll(peers);
+                uint32_t old = 0, db = 0;
+                if (valid) { old = cnt[d]; db = L.base[d]; }
+                __builtin_amdgcn_wave_barrier();
+                if (valid && below == 0) cnt[d] = old + count;
+                __builtin_amdgcn_wave_barrier();
+                if (valid) dst[db + old + below] = key[r];
+            }
+        }
+        __threadfence();
+        __syncthreads();
+        uint64_t* t = src; src = dst; dst = t;
+    }
+    // seg holds the entries in ascending depth; equal depths in arbitrary order: each member of such a run takes the
+    // place of its index rank inside the run
+    const uint32_t* seg32 = reinterpret_cast<const uint32_t*>(seg);          // [2 i] = index, [2 i + 1] = depth bits
+    bool long_run = false;
+    for (uint32_t i = tid; i < n; i += LONG_THREADS) {
+        const uint64_t e = load_wg(seg + i);
+        const uint32_t d = (uint32_t)(e >> 32), idx = (uint32_t)e;
+        uint32_t pos = i;
+        const bool tie = (i > 0 && load_wg(seg32 + 2 * (i - 1) + 1) == d) || (i + 1 < n && load_wg(seg32 + 2 * (i + 1) + 1) == d);
+        if (tie) {
+            uint32_t lo = i, len = 1, rank = 0;
+            while (lo > 0 && len <= LONG_TIE_RUN && load_wg(seg32 + 2 * (lo - 1) + 1) == d) {
+                lo--; len++;
+                rank += load_wg(seg32 + 2 * lo) < idx;
+            }
+            for (uint32_t j = i + 1; j < n && len <= LONG_TIE_RUN && load_wg(seg32 + 2 * j + 1) == d; j++) {
+                len++;
+                rank += load_wg(seg32 + 2 * j) < idx;
+            }
+            long_run = long_run || len > LONG_TIE_RUN;
+            pos = lo + rank;
+        }
+        keys[rg.x + pos] = tile_hi | d;
+        vals[rg.x + pos] = idx;
+    }
+    if (long_run) L.ties = 1;
+    __syncthreads();
+    if (L.ties) {                                   // (rare) a long run of equal depths: the network on the unique 64-bit key
+        GlobalMem m{seg};
+        bitonic_ascending(m, n, next_pow2_u32(n), LONG_THREADS);
+        for (uint32_t i = tid; i < n; i += LONG_THREADS) {
+            const uint64_t e = load_wg(seg + i);
+            keys[rg.x + i] = tile_hi | (e >> 32);
+            vals[rg.x + i] = (uint32_t)e;
+        }
+    }
+    __syncthreads();
+}
+
+// persistent workgroups take the long tiles off big_list through a cursor (big_count[1], zeroed by tile_order_kernel)
+template <bool ENTRIES>
+__global__ void __launch_bounds__(LONG_THREADS)
+tile_sort_long_kernel(const uint32_t* __restrict__ big_list, uint32_t* __restrict__ big_count,
+                      const uint2* __restrict__ ranges, uint64_t* keys, uint32_t* vals, uint64_t* scratch)
+{
+    __shared__ LongSortLds L;
+    const uint32_t nbig = big_count[0];
+    for (;;) {
+        if (threadIdx.x == 0) L.next = atomicAdd(&big_count[1], 1u);
+        __syncthreads();
+        const uint32_t k = L.next;
+        __syncthreads();
+        if (k >= nbig) break;
+        const uint32_t tile = big_list[k];
+        radix_sort_one_tile<ENTRIES>(ranges[tile], keys, vals, scratch, tile, L);
+    }
+}
+
 constexpr uint32_t TILE_SORT_SMALL_CAP = 4096;     // 32 KB of LDS per workgroup
 constexpr uint32_t TILE_SORT_BIG_CAP = 16384;      // 128 KB
-// persistent workgroups of the long-tile kernel: one per CU (128 KB of LDS each).  64 were enough for the handful of long
-// tiles of a 300k-Gaussian frame; at 2M Gaussians half of the tiles are long and 64 workgroups took 4.4 ms of an 11 ms step
+// persistent workgroups of the bitonic long-tile kernel: one per CU (128 KB of LDS each)
 constexpr int TILE_SORT_BIG_BLOCKS = 256;
+
+int g_long_tile_sort = 1;     // R3DG_OPT_LONG_TILE_SORT: 0 = bitonic network (LDS up to 16384 entries, global beyond), 1 = radix
 
 uint32_t tile_sort_small_cap() { return TILE_SORT_SMALL_CAP; }
 
 // entries == true: `scratch` holds the (depth << 32 | index) entries of the direct tile binning, already in their tiles' segments
 void launch_tile_sort(hipStream_t s, int T, const uint32_t* tile_order, const uint32_t* ranges, const uint32_t* big_list,
-                      const uint32_t* big_count, uint64_t* keys, uint32_t* vals, uint64_t* scratch, bool entries)
+                      uint32_t* big_count, uint64_t* keys, uint32_t* vals, uint64_t* scratch, bool entries)
 {
     static bool attr_set = false;
     if (!attr_set) {
@@ -440,16 +656,21 @@ void launch_tile_sort(hipStream_t s, int T, const uint32_t* tile_order, const ui
                                      (int)(TILE_SORT_BIG_CAP * 8)));
         attr_set = true;
     }
-    if (entries) {
-        tile_sort_small_kernel<true><<<T, 256, TILE_SORT_SMALL_CAP * 8, s>>>(T, tile_order, (const uint2*)ranges,
-                                                                             TILE_SORT_SMALL_CAP, keys, vals, scratch);
-        tile_sort_big_kernel<true><<<TILE_SORT_BIG_BLOCKS, 1024, TILE_SORT_BIG_CAP * 8, s>>>(big_list, big_count, (const uint2*)ranges,
-                                                                          TILE_SORT_BIG_CAP, keys, vals, scratch);
+    const uint2* rg = (const uint2*)ranges;
+    if (entries)
+        tile_sort_small_kernel<true><<<T, 256, TILE_SORT_SMALL_CAP * 8, s>>>(T, tile_order, rg, TILE_SORT_SMALL_CAP, keys, vals, scratch);
+    else
+        tile_sort_small_kernel<false><<<T, 256, TILE_SORT_SMALL_CAP * 8, s>>>(T, tile_order, rg, TILE_SORT_SMALL_CAP, keys, vals, scratch);
+    if (g_long_tile_sort) {
+        const int grid = 2 * (256 - g_reserve_cus);
+        if (entries) tile_sort_long_kernel<true><<<grid, LONG_THREADS, 0, s>>>(big_list, big_count, rg, keys, vals, scratch);
+        else tile_sort_long_kernel<false><<<grid, LONG_THREADS, 0, s>>>(big_list, big_count, rg, keys, vals, scratch);
+    } else if (entries) {
+        tile_sort_big_kernel<true><<<TILE_SORT_BIG_BLOCKS, 1024, TILE_SORT_BIG_CAP * 8, s>>>(big_list, big_count, rg, TILE_SORT_BIG_CAP,
+                                                                                            keys, vals, scratch);
     } else {
-        tile_sort_small_kernel<false><<<T, 256, TILE_SORT_SMALL_CAP * 8, s>>>(T, tile_order, (const uint2*)ranges,
-                                                                              TILE_SORT_SMALL_CAP, keys, vals, scratch);
-        tile_sort_big_kernel<false><<<TILE_SORT_BIG_BLOCKS, 1024, TILE_SORT_BIG_CAP * 8, s>>>(big_list, big_count, (const uint2*)ranges,
-                                                                           TILE_SORT_BIG_CAP, keys, vals, scratch);
+        tile_sort_big_kernel<false><<<TILE_SORT_BIG_BLOCKS, 1024, TILE_SORT_BIG_CAP * 8, s>>>(big_list, big_count, rg, TILE_SORT_BIG_CAP,
+                                                                                             keys, vals, scratch);
     }
 }
 

@@ -397,7 +397,10 @@ tile_order_kernel(int T, const uint2* __restrict__ ranges, uint32_t* __restrict_
         const uint32_t cls = 255u - (uint32_t)(((uint64_t)len * 256u) / scale);
         order[atomicAdd(&s_cnt[cls], 1u)] = (uint32_t)t;
     }
-    if (tid == 0 && big_count != nullptr) *big_count = s_nbig;
+    if (tid == 0 && big_count != nullptr) {
+        big_count[0] = s_nbig;
+        big_count[1] = 0;               // the long-tile sort's work cursor (radix_sort.hip)
+    }
 }
 
 // ---- direct tile binning (r3dg_set_tuning4(2), default) ---------------------------------------------------------------------

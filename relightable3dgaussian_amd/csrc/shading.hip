@@ -1155,6 +1155,10 @@ static int frs_grid(int P, const void* kernel, size_t smem)
     return want < cap ? (want > 0 ? want : 1) : cap;
 }
 
+// every sample of the Fibonacci set carries the same area, 2 pi (fibonacci_sphere_sampling, utils/graphics_utils.py:26-37);
+// a caller that passes the per-sample array instead of the constant (uniform_area == 0) means that value
+static inline float frs_area(float uniform_area) { return uniform_area > 0.f ? uniform_area : 6.283185307179586f; }
+
 // forward over a fixed ray set: rotate the coefficients (cprime [P,48] is kept for the backward), the MFMA kernel for the
 // Gaussians on the rotated path, the general row kernel for the listed rest
 void launch_shade_frs_forward(hipStream_t s, int P, int K, const float* base_color, const float* roughness,
@@ -1175,7 +1179,8 @@ void launch_shade_frs_forward(hipStream_t s, int P, int K, const float* base_col
     int grid = frs_grid(P, (const void*)shade_forward_frs_kernel, smem);
     if (leave_room) grid = grid > shade_cus() * 2 ? shade_cus() * 2 : grid;      // the instance ordering runs beside it
     shade_forward_frs_kernel<<<grid, 64 * FRS_WAVES, smem, s>>>(P, K, base_color, roughness, normals, viewdirs, cprime, env4,
-                                                                He, We, visibility, dirs, uniform_area, taps, tables, valid, out);
+                                                                He, We, visibility, dirs, frs_area(uniform_area), taps, tables, valid,
+                                                                out);
     check_launch(s, false, "shade_forward_frs_kernel");
     if (n_invalid > 0)
         launch_shade_forward(s, P, K, 16, base_color, roughness, normals, viewdirs, incidents, env, He, We, nullptr, visibility,
@@ -1208,9 +1213,9 @@ void launch_shade_frs_backward(hipStream_t s, int P, int K, const float* base_co
     const size_t smem = ntexel * (sizeof(float4) + 3 * sizeof(long long));
     const int grid = frs_grid(P, (const void*)shade_backward_frs_kernel, smem);
     shade_backward_frs_kernel<<<grid, 64 * FRS_WAVES, smem, s>>>(P, K, base_color, roughness, normals, viewdirs, cprime, g_pbr,
-                                                                 g_diff, env4, He, We, visibility, dirs, uniform_area, taps,
-                                                                 tables, valid, d_base, d_rough, d_view, dcp, d_env, gmax,
-                                                                 gmax_n);
+                                                                 g_diff, env4, He, We, visibility, dirs, frs_area(uniform_area),
+                                                                 taps, tables, valid, d_base, d_rough, d_view, dcp, d_env,
+                                                                 gmax, gmax_n);
     check_launch(s, false, "shade_backward_frs_kernel");
     // gradient back to the unrotated coefficients: every row of d_inc is written (garbage for Gaussians off the rotated
     // path: the general kernel overwrites their rows next)

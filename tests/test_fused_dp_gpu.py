@@ -263,7 +263,7 @@ def _world8_worker(rank, world, port, out_dir):
         step(cams[rank], bg, gts[rank])                      # iteration 1: two-phase forward, learns the count
         step.flush()
         if rank == 5:
-            step._capacity = step.rendered_counts(1)[0] - 3  # rank 5's next view will not fit
+            step._capacity = step.rendered_counts(1)[0] // 2  # rank 5's next view (another camera of the orbit) will not fit
         before = {k: getattr(step, k).detach().clone() for k in ("xyz", "shs", "incidents", "env", "base_color")}
         n_before = step.opt.step_count
         step(cams[(rank + 3) % 8], bg, gts[(rank + 3) % 8])  # iteration 2: dropped on EVERY rank

@@ -319,6 +319,54 @@ def test_tile_binned_order_long_tiles(hip_lib):
         assert torch.equal(a[i], b[i]), i
 
 
+@pytest.mark.parametrize("ties", ["pairs", "long_run", "all_equal", "none"])
+@pytest.mark.parametrize("long_sort", [1, 0])
+def test_long_tile_sort_orders_equal_depths_by_index(ties, long_sort, hip_lib):
+    """The long-tile sort (csrc/radix_sort.hip: segmented radix over the depth bits that differ inside the tile; LONG_TILE_SORT=0:
+    the bitonic network) against the global radix sort of the reference formulation, with Gaussians at EXACTLY equal depth in
+    tiles longer than 4096 instances: pairs (the index-rank fix-up), a run of 300 (the fall-back to the network on the unique
+    (depth, index) key), and a frame whose every Gaussian has the same depth (no depth bit differs at all)."""
+    case = make_case(P=24000, W=64, H=48, S=2, scale_log_mean=-1.2, seed=191)
+    xyz = case["means3D"].clone()
+    if ties == "pairs":
+        xyz[12000:] = xyz[:12000]
+    elif ties == "long_run":
+        xyz[500:800] = xyz[500]
+        xyz[12000:13000] = xyz[:1000]
+    elif ties == "all_equal":
+        # every centre on one plane orthogonal to the viewing direction: view-space z is one value up to rounding, so force it
+        cam = case["cam"]
+        wv = cam.world_view_transform                                        # row-vector convention: p_view = [p 1] @ wv
+        zcol = wv[:3, 2]
+        depth = xyz @ zcol + wv[3, 2]
+        xyz = xyz - (depth - depth.mean())[:, None] * zcol[None] / (zcol @ zcol)
+    case["means3D"] = xyz.contiguous()
+    _opt(LONG_TILE_SORT=long_sort)
+    try:
+        a = _run_forward(case)
+        _opt(TILE_BINNING=1)
+        a1 = _run_forward(case)
+        _opt(TILE_BINNING=0)
+        b = _run_forward(case)
+    finally:
+        _opt(TILE_BINNING=2, LONG_TILE_SORT=1)
+    torch.cuda.synchronize()
+    from relightable3dgaussian_amd.rasterizer_ops import decode_state
+    P, H, W = case["P"], case["H"], case["W"]
+    assert a[0] == b[0] == a1[0]
+    sa, sa1, sb = (decode_state(o[10], o[11], o[12], P, o[0], H, W) for o in (a, a1, b))
+    lens = sa["ranges"][:, 1] - sa["ranges"][:, 0]
+    assert int(lens.max()) > 4096
+    keys = torch.as_tensor(sb["keys"]).to(torch.int64)
+    if ties != "none":
+        assert int((keys[1:] == keys[:-1]).sum()) > (100 if ties != "all_equal" else 1000), "case holds no equal (tile, depth) keys"
+    for k in ("keys", "point_list", "ranges", "point_offsets"):
+        assert torch.equal(torch.as_tensor(sa[k]), torch.as_tensor(sb[k])), (k, "direct binning")
+        assert torch.equal(torch.as_tensor(sa1[k]), torch.as_tensor(sb[k])), (k, "radix partition")
+    for i in (1, 2, 3, 4, 5):
+        assert torch.equal(a[i], b[i]), i
+
+
 def test_tile_binned_order_many_tiles(hip_lib):
     """1600x1200 (DTU size, BASELINE config 3): 7500 tiles = 13 tile-id bits, i.e. the two-pass (stable) partition."""
     case = make_case(P=20000, W=1600, H=1200, S=3, scale_log_mean=-2.6, seed=93)

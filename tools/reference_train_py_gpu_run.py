@@ -1,0 +1,161 @@
+#!/usr/bin/env python
+"""Evidence run for SURVEY.md 8(f) n4 ON HARDWARE: the reference's unmodified train.py -- stage 1, then stage 2 from its
+checkpoint -- and its unmodified relighting.py, executed through tools/run_reference.py against this repo's HIP-backed
+extension packages (no --cpu-oracle: every `_C.*` call is a HIP kernel) on a synthetic Blender-format scene.
+
+    python tools/reference_train_py_gpu_run.py --reference reference_scratch > gpurun_out/reference_train_py_gpu.txt
+
+`--reference` is a checkout of NJU-3DV/Relightable3DGaussian; on the GPU box that is the untracked copy of its Python which
+tools/stage_reference_scratch.sh stages (the box has no /root/reference).  The dataset is rendered here by the HIP rasterizer
+from a teacher scene (synthetic.py), so PSNR against it is meaningful; the run prints the reference's own log lines, the
+progress bar's first and last PSNR, wall time and iterations per second of the reference's Python loop."""
+import argparse
+import hashlib
+import json
+import os
+import re
+import shutil
+import subprocess
+import sys
+import tempfile
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+
+
+def write_dataset(root, n_views, res, P, n_points):
+    import reference_shims as shims
+    from relightable3dgaussian_amd import synthetic as syn
+    from relightable3dgaussian_amd.bench_core import GaussianParams, render_stage1
+    dev = torch.device("cuda", 0)
+    sc = syn.make_scene(P=P, seed=5, stage2=False, scale_log_mean=-3.4)
+    teacher = GaussianParams(sc, dev, False)
+    cams = syn.orbit_cameras(n_views, width=res, height=res)
+    bg = torch.ones(3, device=dev)
+    with torch.no_grad():
+        images = [render_stage1(teacher, c.to(dev), bg)[2].clamp(0, 1).cpu() for c in cams]
+    syn.write_blender_dataset(root, cams, images, split="train")
+    syn.write_blender_dataset(root, cams[::8], images[::8], split="test")
+    g = np.random.default_rng(3)
+    keep = g.permutation(P)[:n_points]
+    xyz = sc["xyz"].numpy()[keep] + 0.01 * g.standard_normal((n_points, 3)).astype(np.float32)
+    data = np.empty(n_points, dtype=[("x", "f4"), ("y", "f4"), ("z", "f4"), ("nx", "f4"), ("ny", "f4"), ("nz", "f4"),
+                                     ("red", "u1"), ("green", "u1"), ("blue", "u1")])
+    nrm = sc["normal"].numpy()[keep]
+    for i, n in enumerate(("x", "y", "z")):
+        data[n], data["n" + n] = xyz[:, i], nrm[:, i]
+    rgb = (255 * g.random((n_points, 3))).astype(np.uint8)
+    data["red"], data["green"], data["blue"] = rgb[:, 0], rgb[:, 1], rgb[:, 2]
+    shims.PlyData([shims.PlyElement.describe(data, "vertex")]).write(os.path.join(root, "points3d.ply"))
+    return len(cams)
+
+
+def run(reference, args, timeout):
+    cmd = [sys.executable, os.path.join(ROOT, "tools", "run_reference.py"), "--reference", reference, "--"] + args
+    env = dict(os.environ, PYTHONPATH=ROOT)
+    return subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, env=env, cwd=ROOT, stdin=subprocess.DEVNULL)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--reference", default=os.environ.get("R3DG_REFERENCE", os.path.join(ROOT, "reference_scratch")))
+    ap.add_argument("--res", type=int, default=256)
+    ap.add_argument("--views", type=int, default=48)
+    ap.add_argument("--teacher-points", type=int, default=30000)
+    ap.add_argument("--stage1-iterations", type=int, default=600)
+    ap.add_argument("--stage2-iterations", type=int, default=400)
+    ap.add_argument("--sample-num", type=int, default=24)
+    ap.add_argument("--timeout", type=int, default=600)
+    ns = ap.parse_args()
+    ref = os.path.abspath(ns.reference)
+    tmp = tempfile.mkdtemp(prefix="n4gpu_")
+    data, s1, s2 = (os.path.join(tmp, d) for d in ("data", "stage1", "stage2"))
+    os.makedirs(data)
+    n = write_dataset(data, ns.views, ns.res, ns.teacher_points, 4000)
+    from relightable3dgaussian_amd import _lib
+    print("device: %s   library: %s" % (torch.cuda.get_device_name(0), _lib.LIB_PATH))
+    print("reference checkout: %s  train.py sha256 %s (run as is through tools/run_reference.py, HIP extension packages)" % (
+        ns.reference, hashlib.sha256(open(os.path.join(ref, "train.py"), "rb").read()).hexdigest()[:16]))
+    print("dataset: %d train views %dx%d rendered by the HIP rasterizer from a %d-Gaussian teacher, points3d.ply with 4000 points"
+          % (n, ns.res, ns.res, ns.teacher_points))
+    i1, i2 = ns.stage1_iterations, ns.stage2_iterations
+    runs = [
+        ("stage 1 (script/run_nerf.sh:7-14 flags, short schedule)", s1, i1,
+         ["train.py", "-s", data, "-m", s1, "--lambda_normal_render_depth", "0.01",
+          "--lambda_normal_smooth", "0.01", "--lambda_mask_entropy", "0.1", "--lambda_depth_var", "1e-2", "--iterations", str(i1),
+          "--densify_from_iter", "100", "--densification_interval", "100", "--opacity_reset_interval", "300", "--test_interval",
+          str(i1 // 2), "--checkpoint_interval", str(i1), "--save_interval", str(i1), "--save_training_vis",
+          "--save_training_vis_iteration", str(i1 // 2)]),
+        ("stage 2 (script/run_nerf.sh:20-39 flags, from the stage-1 checkpoint, sample_num %d)" % ns.sample_num, s2, i2,
+         ["train.py", "-s", data, "-m", s2, "-c", os.path.join(s1, "chkpnt%d.pth" % i1), "-t", "neilf",
+          "--sample_num", str(ns.sample_num), "--position_lr_init", "0.000016", "--position_lr_final", "0.00000016", "--normal_lr",
+          "0.001", "--sh_lr", "0.00025", "--opacity_lr", "0.005", "--scaling_lr", "0.0005", "--rotation_lr", "0.0001",
+          "--iterations", str(i1 + i2), "--lambda_base_color_smooth", "0", "--lambda_roughness_smooth", "0", "--lambda_light_smooth",
+          "0", "--lambda_light", "0.01", "--lambda_env_smooth", "0.01", "--test_interval", str(i2 // 2), "--checkpoint_interval",
+          str(i1 + i2), "--save_interval", str(i1 + i2), "--save_training_vis", "--save_training_vis_iteration", str(i2 // 2),
+          "--densify_until_iter", "10"])]
+    for title, out, iters, args in runs:
+        t0 = time.time()
+        r = run(ref, args, ns.timeout)
+        dt = time.time() - t0
+        print("\n== %s ==\n$ python tools/run_reference.py --reference %s -- %s" % (
+            title, ns.reference, " ".join(a.replace(tmp, "$TMP") for a in args)))
+        print("exit code %d, %.1f s wall (process start + data loading + %d iterations + evaluation / saving)" % (r.returncode, dt, iters))
+        for line in r.stdout.splitlines():
+            if re.search(r"stand-ins|Evaluating|Saving|Training complete|Create Gaussians|Number of points|Found|\[ITER", line):
+                print("  " + line.strip().replace(tmp, "$TMP"))
+        bar = re.findall(r"(\d+)/(\d+) \[(\d+):(\d+)<[^,\]]*, *([0-9.]+)(it/s|s/it)[^\r\n]*?num=(\d+)[^\r\n]*?psnr=([0-9.]+)(?:, psnr_pbr=([0-9.]+))?",
+                         r.stderr)
+        if bar:
+            f, l = bar[0], bar[-1]
+            rate = float(l[4]) if l[5] == "it/s" else 1.0 / max(float(l[4]), 1e-9)
+            print("  progress bar, first -> last: num=%s psnr=%s%s  ->  num=%s psnr(ema)=%s%s   (%s/%s, tqdm rate %.1f it/s)" % (
+                f[6], f[7], (" psnr_pbr=" + f[8]) if f[8] else "", l[6], l[7], (" psnr_pbr(ema)=" + l[8]) if l[8] else "",
+                l[0], l[1], rate))
+        if r.returncode != 0:
+            print(r.stdout[-3000:])
+            print(r.stderr[-6000:])
+            sys.exit(1)
+        print("  files: " + ", ".join(sorted(os.listdir(out))))
+    # relighting.py: two copies of the trained object under different transforms, a turning light, three frames
+    from relightable3dgaussian_amd import synthetic as syn
+    cfg, cap = os.path.join(tmp, "relight_cfg"), os.path.join(tmp, "capture")
+    os.makedirs(cfg)
+    ply = os.path.join(s2, "point_cloud", "iteration_%d" % (i1 + i2), "point_cloud.ply")
+    eye = [1.0, 0, 0, 0, 0, 1.0, 0, 0, 0, 0, 1.0, 0, 0, 0, 0, 1.0]
+    moved = [0.6, 0, 0, 1.1, 0, 0.6, 0, 0.2, 0, 0, 0.6, 0, 0, 0, 0, 1.0]
+    json.dump({"a": {"path": ply, "transform": eye}, "b": {"path": ply, "transform": moved}},
+              open(os.path.join(cfg, "transform.json"), "w"))
+    traj, lights = {}, {}
+    for i, cam in enumerate(syn.orbit_cameras(3, width=400, height=300)):
+        traj[str(i)] = cam.world_view_transform.t().reshape(-1).tolist()
+        a = 0.4 * i
+        lights[str(i)] = [float(np.cos(a)), float(-np.sin(a)), 0.0, float(np.sin(a)), float(np.cos(a)), 0.0, 0.0, 0.0, 1.0]
+    json.dump({"camera": {"width": 400, "height": 300, "fov": 40}, "trajectory": traj}, open(os.path.join(cfg, "trajectory.json"), "w"))
+    json.dump({"transform": lights}, open(os.path.join(cfg, "light_transform.json"), "w"))
+    args = ["relighting.py", "-co", cfg, "-e", os.path.join(ref, "env_map", "envmap3.png"), "--output", cap, "--sample_num", "64",
+            "--capture_list", "pbr_env,render_env,base_color,normal,visibility", "-bg", "0"]
+    t0 = time.time()
+    r = run(ref, args, ns.timeout)
+    print("\n== relighting.py (relighting.py:102-170): composition of two objects from the point_cloud.ply train.py wrote, "
+          "envmap3.png, a light that turns with the frames ==\n$ python tools/run_reference.py --reference %s -- %s"
+          % (ns.reference, " ".join(a.replace(tmp, "$TMP").replace(ref, ns.reference) for a in args)))
+    print("exit code %d, %.1f s wall" % (r.returncode, time.time() - t0))
+    for line in r.stdout.splitlines():
+        if re.search(r"Totally|stand-ins", line):
+            print("  " + line.strip())
+    if r.returncode != 0:
+        print(r.stdout[-3000:])
+        print(r.stderr[-6000:])
+        sys.exit(1)
+    print("  files: " + ", ".join("%s/%s" % (d, f) for d in sorted(os.listdir(cap)) for f in sorted(os.listdir(os.path.join(cap, d)))))
+    shutil.rmtree(tmp, ignore_errors=True)
+
+
+if __name__ == "__main__":
+    main()
