@@ -658,15 +658,26 @@ shade_pad_env_kernel(int n, const float* __restrict__ env, float4* __restrict__ 
 // incidents and the (activated) environment texture.  normals / dirs / visibility carry no gradient in the
 // reference (normal.detach(), cached samples).
 // the largest of `n` non-negative floats (the block maxima of max|upstream gradient|; n == 1: grad_absmax_kernel's word),
-// +inf = "some upstream gradient is not finite"; uniform over the wave
-__device__ __forceinline__ float wave_gmax(const unsigned int* __restrict__ gmax_bits, int n)
+// +inf = "some upstream gradient is not finite"; uniform over the wave.  This file is compiled with -ffast-math, which lets the
+// compiler assume that no float is inf / nan and fold `x <= FLT_MAX` to true: everything that DECIDES on finiteness works on
+// the bit patterns (non-negative floats order like unsigned integers; exponent all ones = inf / nan).
+__device__ __forceinline__ bool not_finite_bits(unsigned int bits) { return (bits & 0x7f800000u) == 0x7f800000u; }
+__device__ __forceinline__ unsigned int wave_gmax_bits(const unsigned int* __restrict__ gmax_bits, int n)
 {
-    float m = 0.f;
-    for (int i = threadIdx.x & 63; i < n; i += 64) m = fmaxf(m, __uint_as_float(gmax_bits[i]));
+    unsigned int m = 0u;
+    for (int i = threadIdx.x & 63; i < n; i += 64) {
+        const unsigned int b = gmax_bits[i] & 0x7fffffffu;
+        m = not_finite_bits(b) ? 0x7f800000u : (b > m ? b : m);
+    }
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+    for (int o = 32; o > 0; o >>= 1) {
+        const unsigned int other = (unsigned int)__shfl_xor((int)m, o, 64);
+        m = other > m ? other : m;
+    }
     return m;
 }
+// fixed-point accumulation is possible for a positive, finite maximum
+__device__ __forceinline__ bool gmax_usable(unsigned int bits) { return bits != 0u && bits < 0x7f800000u; }
 
 // max(|g_pbr|, |g_diff|) over all Gaussians -> *out (as float bits; non-negative floats order like unsigned ints).
 __global__ void __launch_bounds__(256)
@@ -677,7 +688,7 @@ grad_absmax_kernel(int n, const float* __restrict__ a, const float* __restrict__
     bool bad = false;
     for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
         const float x = fabsf(a[i]), y = fabsf(b[i]);
-        bad = bad || !(x <= 3.0e38f) || !(y <= 3.0e38f);       // inf / nan
+        bad = bad || not_finite_bits(__float_as_uint(x)) || not_finite_bits(__float_as_uint(y));       // inf / nan
         m = fmaxf(m, fmaxf(x, y));
     }
 #pragma unroll
@@ -710,8 +721,9 @@ shade_backward_kernel(int P, int K, int M, ShadeSrc src, const float* __restrict
     const int ntex = ENV_LDS ? ((ntex_raw + 3) & ~3) : 0;
     float* s_env = s_mem;
     long long* s_denv = reinterpret_cast<long long*>(s_mem + ntex);      // 64-bit fixed-point accumulators
-    const float gmax = wave_gmax(gmax_bits, gmax_n);
-    const bool fixed = ENV_LDS && gmax > 0.f && gmax <= 3.0e38f;
+    const unsigned int gmax_word = wave_gmax_bits(gmax_bits, gmax_n);
+    const float gmax = __uint_as_float(gmax_word);
+    const bool fixed = ENV_LDS && gmax_usable(gmax_word);
     const float fx_scale = fixed ? 34359738368.0f / gmax : 0.f;          // 2^35 / max|g|
     const float fx_clamp = gmax * 8192.0f;                               // |contribution| <= max|g| * 2^13
     if (ENV_LDS) {

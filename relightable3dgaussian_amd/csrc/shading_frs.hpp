@@ -348,8 +348,9 @@ shade_backward_frs_kernel(int P, int K, const float* __restrict__ base_color, co
     const int ntexel = He * We;
     float4* s_env4 = reinterpret_cast<float4*>(s_mem);
     long long* s_denv = reinterpret_cast<long long*>(s_mem + 4 * ntexel);        // [texel][3] 64-bit fixed point
-    const float gmax = wave_gmax(gmax_bits, gmax_n);
-    const bool fixed = gmax > 0.f && gmax <= 3.0e38f;
+    const unsigned int gmax_word = wave_gmax_bits(gmax_bits, gmax_n);
+    const float gmax = __uint_as_float(gmax_word);
+    const bool fixed = gmax_usable(gmax_word);
     const float fx_scale = fixed ? 34359738368.0f / gmax : 0.f;                 // 2^35 / max|g|
     const float fx_clamp = gmax * 8192.0f;
     for (int i = threadIdx.x; i < ntexel; i += blockDim.x) s_env4[i] = env4[i];

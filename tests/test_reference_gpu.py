@@ -4,8 +4,9 @@ the CPU oracle -- to the reference itself on identical inputs.  Skipped when the
 
 Tolerances: the reference build uses hipcc's default FMA contraction (as nvcc does), this repo's preprocess does not, so
 radii / tile counts may differ on a vanishing fraction of Gaussians whose ceil(3*sqrt(lambda)) sits on an integer
-boundary: <= 2e-4 of them; everything downstream is compared on views where the sorted lists agree, with the same
-float tolerances as the oracle tests (forward 2e-5, gradients 2e-3 relative to the array scale)."""
+boundary: <= 2e-4 of them.  Every other difference has to be explained pixel by pixel (_compare_rasterizer): a pixel may
+differ from the reference beyond 2e-5 only where the CPU oracle's threshold margin is below 1e-4 or inside the tiles of a
+radius-mismatch Gaussian; gradients (upstream zeroed on those pixels) within 2e-3 of the array scale, no exceptions."""
 import numpy as np
 import pytest
 import torch
@@ -82,28 +83,57 @@ def _compare_rasterizer(name, case, backward=True):
         # keys = tile<<32 | depth bits: the reference build contracts the depth dot product to FMAs, this repo does not
         # (oracle bit-parity), so the low word may differ by an ulp while the ORDER (point_list) is identical
         assert torch.equal(st["keys"] >> 32, ref["keys"][:ours[0]] >> 32), "tile ids of the sorted keys differ"
+    # Every difference must be EXPLAINED, not merely rare.  The CPU oracle (bit-identical to the HIP path in every discrete
+    # decision) reports per pixel how close any of its threshold decisions (alpha vs 1/255, T vs 1e-4; forward.cu:343-352) came
+    # to the threshold; the reference build evaluates the same expressions with FMA contraction, so its decision can differ only
+    # where that margin is within rounding.  The second legitimate cause: a Gaussian whose integer radius differs between the
+    # two builds (same contraction, in the 2D covariance) is present in other tiles -- every pixel of the tiles either radius
+    # reaches is exempt.
+    from oracle import rasterizer as orc
+    o_ref = orc.rasterize_gaussians(*fwd_args(case)[:-3], want_margin=True)
+    assert o_ref[0] == ours[0] and np.array_equal(o_ref[1], ours[1].cpu().numpy()), "HIP path and CPU oracle disagree on n_contrib"
+    border = o_ref[-1]["margin"] < 1e-4
+    exempt = np.zeros((H, W), bool)
+    r_o, r_r = ours[9].cpu().numpy(), ref["radii"].cpu().numpy()
+    mism = np.nonzero(r_o != r_r)[0]
+    hom = np.concatenate([case["means3D"].numpy()[mism].astype(np.float64), np.ones((len(mism), 1))], 1) @ \
+        case["cam"].full_proj_transform.numpy().astype(np.float64)                     # (ndc2Pix, auxiliary.h:46-49)
+    m2 = np.zeros((P, 2))
+    m2[mism] = ((hom[:, :2] / (hom[:, 3:4] + 1e-7) + 1.0) * np.array([W, H]) - 1.0) * 0.5
+    for gidx in mism:
+        rad = int(max(r_o[gidx], r_r[gidx]))
+        x0, x1 = int((m2[gidx, 0] - rad) // 16) * 16, (int((m2[gidx, 0] + rad + 15) // 16) + 1) * 16
+        y0, y1 = int((m2[gidx, 1] - rad) // 16) * 16, (int((m2[gidx, 1] + rad + 15) // 16) + 1) * 16
+        exempt[max(y0, 0):max(y1, 0), max(x0, 0):max(x1, 0)] = True
+    explained = border | exempt
+    msgs.append("pixels with a threshold decision within 1e-4 of its threshold: %d, in tiles of a radius-mismatch Gaussian: %d (of %d)"
+                % (border.sum(), exempt.sum(), H * W))
     nc_same = (ours[1] == ref["n_contrib"])
-    msgs.append("n_contrib mismatching pixels %d / %d" % ((~nc_same).sum().item(), H * W))
-    ok &= (~nc_same).float().mean().item() <= 2e-3
+    nc_bad = (~nc_same).cpu().numpy()
+    msgs.append("n_contrib mismatching pixels %d / %d, unexplained %d" % (nc_bad.sum(), H * W, (nc_bad & ~explained).sum()))
+    ok &= not (nc_bad & ~explained).any()
     good = nc_same.cpu().numpy()
     for nm, o, r in (("color", ours[2], ref["color"]), ("opacity", ours[3], ref["opacity"]), ("depth", ours[4], ref["depth"]),
                      ("feature", ours[5], ref["feature"]), ("surface_xyz", ours[7], ref["xyz"])):
         if o.numel():
-            # borderline alpha decisions can add/drop a 1/255-weight term at isolated pixels: bound the bad fraction
-            o_, r_ = o.cpu().numpy()[:, good], r.cpu().numpy()[:, good]
+            o_, r_ = o.cpu().numpy(), r.cpu().numpy()
             scale = max(np.abs(r_).max(), 1e-30)
-            bad = (np.abs(o_ - r_) > 1e-5 + 2e-5 * scale)
-            msgs.append("%-12s max|err| %.3e scale %.3e, pixels beyond 2e-5: %d" % (nm, np.abs(o_ - r_).max(), scale, bad.sum()))
-            ok &= bad.mean() <= 1e-3 and np.abs(o_ - r_).max() <= 8e-3 * max(scale, 1.0)
+            err = np.abs(o_ - r_)
+            bad = (err > 1e-5 + 2e-5 * scale).any(0) & good
+            hard = bad & ~explained
+            msgs.append("%-12s max|err| %.3e (unexplained pixels: %.3e) scale %.3e, pixels beyond 2e-5: %d, unexplained: %d" % (
+                nm, err[:, good].max(), err[:, good & ~explained].max() if (good & ~explained).any() else 0.0, scale, bad.sum(),
+                hard.sum()))
+            ok &= not hard.any()
     ok &= _ok("weights", ours[8], ref["weights"], 2e-4, 1e-5, msgs)
     if not backward:
         text = "\n".join(["[real reference / %s] P=%d %dx%d S=%d (forward only)" % (name, P, W, H, S)] + msgs)
         print(text)
         assert ok, text
         return
-    # backward: upstream gradients zeroed where the discrete outcome differs
+    # backward: upstream gradients zeroed where the discrete outcome differs or may differ (see above)
     g = torch.Generator().manual_seed(5)
-    mask = nc_same[None].float().cpu()
+    mask = (nc_same.cpu() & torch.from_numpy(~explained))[None].float()
     gC, gO, gD, gF = [(torch.randn(c, H, W, generator=g) * mask).to(DEV) for c in (3, 1, 1, S)]
     go = _C.rasterize_gaussians_backward(a[0], a[1], a[2], ours[9], a[3], a[5], a[6], 1.0, a[8], a[9], a[10], a[11], a[12],
                                          gC, gO, gD, gF, a[17], a[18], a[19], ours[10], ours[0], ours[11], ours[12], True,
@@ -115,14 +145,16 @@ def _compare_rasterizer(name, case, backward=True):
                          "dL_dscales", "dL_drotations"), go,
                         (gr["mean2D"], gr["color"], gr["opacity"], gr["mean3D"], gr["feature"], gr["cov3D"], gr["sh"],
                          gr["scale"], gr["rot"])):
-        # a borderline-alpha pixel perturbs a handful of Gaussians: compare with a robust bound on the bad fraction
+        # (Gaussians whose radii differ between the builds see different tiles: their own gradients are exempt)
         o_, r_ = o.cpu().numpy().astype(np.float64), r.cpu().numpy().astype(np.float64)
         if r_.size == 0:
             continue
+        same_r = (r_o == r_r)
+        o_, r_ = o_.reshape(P, -1)[same_r], r_.reshape(P, -1)[same_r]
         scale = max(np.abs(r_).max(), 1e-30)
         bad = np.abs(o_ - r_) > 1e-6 + 2e-3 * scale
         msgs.append("%-14s max|err| %.3e scale %.3e bad %d/%d" % (nm, np.abs(o_ - r_).max(), scale, bad.sum(), r_.size))
-        ok &= bad.mean() <= 5e-4
+        ok &= not bad.any()
     text = "\n".join(["[real reference / %s] P=%d %dx%d S=%d" % (name, P, W, H, S)] + msgs)
     print(text)
     assert ok, text

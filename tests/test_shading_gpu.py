@@ -253,6 +253,46 @@ def test_fixed_ray_set_kernels_equal_the_general_kernels(P, K, He):
     assert not so.FixedRaySet.supported(K, 16, 256, 512)
 
 
+@pytest.mark.parametrize("poison", [float("nan"), float("inf"), float("-inf")])
+@pytest.mark.parametrize("path,row", [("general", 10), ("frs", 10), ("frs", 2)])
+def test_non_finite_upstream_gradient_is_propagated_not_hidden(poison, path, row):
+    """csrc/shading.hip is built with -ffast-math, which lets the compiler assume that no float is inf / nan -- so every decision
+    on finiteness in it works on bit patterns (the max |upstream gradient| word that scales the fixed-point texture
+    accumulation carries +inf as "not finite": the kernels then accumulate the texture gradient with float atomics).  The
+    contract, as torch.autograd gives it to the reference (neilf.py:339-371 under loss.backward()): one Gaussian with a
+    non-finite upstream gradient gets non-finite gradients, so does the texture it lit, and NO other Gaussian's gradients change
+    by a single bit.  Row 2 of the fixed-ray-set inputs is a Gaussian off the rotated path (general kernel on a list)."""
+    from relightable3dgaussian_amd import shading_ops as so
+    P, K, He = 700, 64, 16
+    inp = _frs_inputs(P, K, He, seed=23)
+    taps = so.build_taps(inp["incident_dirs"], He, 2 * He)
+    args = (inp["base_color"], inp["roughness"], inp["normals"], inp["viewdirs"], inp["incidents"], inp["env"],
+            inp["visibility"], inp["incident_dirs"], inp["incident_areas"])
+    g_bad = inp["g_pbr"].clone()
+    g_bad[row, 1] = poison
+    if path == "frs":
+        frs = so.FixedRaySet.try_build(inp["normals"], inp["incident_dirs"])
+        assert frs is not None and int(frs.valid[10]) == 1 and int(frs.valid[2]) == 0
+        frs.forward(*args, taps, torch.empty((P, so.NOUT), device=DEV))
+        clean = frs.backward(*args, taps, inp["g_pbr"], inp["g_diff"])
+        dirty = frs.backward(*args, taps, g_bad, inp["g_diff"])
+    else:
+        clean = so.shade_backward(*args, inp["g_pbr"], inp["g_diff"], taps=taps)
+        dirty = so.shade_backward(*args, g_bad, inp["g_diff"], taps=taps)
+    torch.cuda.synchronize()
+    others = torch.ones(P, dtype=torch.bool, device=DEV)
+    others[row] = False
+    for name, c, d in zip(("d_base", "d_rough", "d_view", "d_inc"), clean, dirty):
+        assert torch.isfinite(c).all(), name
+        assert torch.equal(c[others], d[others]), "%s of the other Gaussians changed" % name
+    assert not torch.isfinite(dirty[0][row]).all(), "d_base of the poisoned Gaussian is finite: %s" % dirty[0][row]
+    assert not torch.isfinite(dirty[3][row]).all(), "d_incidents of the poisoned Gaussian are finite"
+    assert torch.isfinite(clean[4]).all() and not torch.isfinite(dirty[4]).all(), "the texture gradient hides the poisoned sample"
+    texels_hit = ~torch.isfinite(dirty[4]).all(-1)
+    assert 0 < int(texels_hit.sum()) <= 4 * K, "non-finite texels: %d" % int(texels_hit.sum())
+    assert torch.allclose(dirty[4][~texels_hit], clean[4][~texels_hit], rtol=2e-5, atol=2e-5 * float(clean[4].abs().max()))
+
+
 def test_fixed_ray_set_tables_hold_the_basis_in_the_two_mfma_layouts():
     """r3dg_shade_frs_build_tables vs the layout its consumers assume (csrc/shading_frs.hpp): per 16-sample block, slots 0..3 =
     A operand of the local-light product (lane (r, q): Yz[16 b + r][4 s + q]), slots 4..7 = A operand of the gradient

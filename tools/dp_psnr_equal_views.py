@@ -7,7 +7,11 @@ view-averaged PSNR of the SH render and of the PBR render over all views:
     G ranks, N iterations each      data parallel: the SAME 2N views (rank r takes views G*i + r), G views per optimizer step
     1 rank,  N iterations           equal number of optimizer steps, half the views
 
-    python tools/dp_psnr_equal_views.py [--ranks 2] [--iters 240]  > profiles/rNN_dp_psnr_equal_views.txt
+    python tools/dp_psnr_equal_views.py [--ranks 2,4] [--iters 240]  > profiles/rNN_dp_psnr_equal_views.txt
+
+and, for every G, the data-parallel run again with the learning rate of every group scaled by sqrt(G) and by G (the two usual
+large-batch rules; Adam normalises the gradient's scale, so summing G views changes the direction's noise, not its length --
+what fewer steps lose has to come from the step size).
 
 The test box has one GPU: the ranks share it over the gloo test backend (RCCL refuses two ranks on one device); the
 arithmetic of the reduction is the same sum."""
@@ -60,7 +64,7 @@ def _evaluate(step, cams, bg, gts):
     return sum(render) / len(render), sum(pbr) / len(pbr)
 
 
-def _train(rank, world, iters, port, out):
+def _train(rank, world, iters, port, out, lr_scale=1.0):
     from relightable3dgaussian_amd.fused_step import FusedStage2Step
     dev = torch.device("cuda", 0)
     torch.cuda.set_device(dev)
@@ -69,7 +73,7 @@ def _train(rank, world, iters, port, out):
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group("gloo", rank=rank, world_size=world)
     params, cams, bg, gts = _setup(dev)
-    step = FusedStage2Step(params, K, lr=LR)
+    step = FusedStage2Step(params, K, lr=LR * lr_scale)
     before = _evaluate(step, cams, bg, gts)
     for it in range(iters):
         v = (world * it + rank) % VIEWS
@@ -94,30 +98,37 @@ def _free_port():
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--ranks", type=int, default=2)
-    ap.add_argument("--iters", type=int, default=240, help="iterations of the one-view-per-step schedule (2N)")
+    ap.add_argument("--ranks", default="2", help="comma-separated rank counts, e.g. 2,4")
+    ap.add_argument("--iters", type=int, default=240, help="iterations of the one-view-per-step schedule")
     a = ap.parse_args()
-    G, N2 = a.ranks, a.iters
-    runs = [("1 rank, %d iterations (one view per step: the reference's schedule)" % N2, 1, N2),
-            ("%d ranks, %d iterations each (the same %d views, %d per step)" % (G, N2 // G, N2, G), G, N2 // G),
-            ("1 rank, %d iterations (as many optimizer steps as the %d-rank run, 1/%d of the views)" % (N2 // G, G, G), 1, N2 // G)]
+    N2 = a.iters
     print("stage-2 objective of script/run_nerf.sh:20-39; %d Gaussians, %dx%d, sample_num %d, %d views, lr %g on every group"
           % (P, RES, RES, K, VIEWS, LR))
-    print("%-88s %10s %10s %8s" % ("run", "PSNR", "PSNR pbr", "steps"))
-    res = []
-    for title, world, iters in runs:
+    print("%-100s %10s %10s %8s" % ("run", "PSNR", "PSNR pbr", "steps"))
+
+    def run(title, world, iters, lr_scale=1.0, show_before=False):
         out = "/tmp/dp_psnr_%d_%d.pt" % (world, iters)
-        mp.spawn(_train, args=(world, iters, _free_port(), out), nprocs=world, join=True)
+        mp.spawn(_train, args=(world, iters, _free_port(), out, lr_scale), nprocs=world, join=True)
         r = torch.load(out)
-        if not res:
-            print("%-88s %10.3f %10.3f %8s" % ("before training", r["before"][0], r["before"][1], "-"))
-        print("%-88s %10.3f %10.3f %8d" % (title, r["after"][0], r["after"][1], r["steps"]))
+        if show_before:
+            print("%-100s %10.3f %10.3f %8s" % ("before training", r["before"][0], r["before"][1], "-"))
+        print("%-100s %10.3f %10.3f %8d" % (title, r["after"][0], r["after"][1], r["steps"]))
         assert r["dropped"] == 0
-        res.append(r)
-    print("equal views:  data parallel - single = %+.3f dB (render), %+.3f dB (pbr)" % (
-        res[1]["after"][0] - res[0]["after"][0], res[1]["after"][1] - res[0]["after"][1]))
-    print("equal steps:  data parallel - single = %+.3f dB (render), %+.3f dB (pbr)" % (
-        res[1]["after"][0] - res[2]["after"][0], res[1]["after"][1] - res[2]["after"][1]))
+        return r
+
+    base = run("1 rank, %d iterations (one view per step: the reference's schedule)" % N2, 1, N2, show_before=True)
+    lines = []
+    for G in [int(g) for g in a.ranks.split(",")]:
+        n = N2 // G
+        half = run("1 rank, %d iterations (as many optimizer steps as the %d-rank run, 1/%d of the views)" % (n, G, G), 1, n)
+        for name, scale in (("lr x 1", 1.0), ("lr x sqrt(G) = %.3f" % math.sqrt(G), math.sqrt(G)), ("lr x G = %d" % G, float(G))):
+            r = run("%d ranks, %d iterations each (the same %d views, %d per step), %s" % (G, n, N2, G, name), G, n, scale)
+            lines.append("G=%d %-22s equal views: data parallel - single = %+.3f dB (render) %+.3f dB (pbr);   equal steps: %+.3f dB "
+                         "(render) %+.3f dB (pbr)" % (G, name, r["after"][0] - base["after"][0], r["after"][1] - base["after"][1],
+                                                      r["after"][0] - half["after"][0], r["after"][1] - half["after"][1]))
+    print()
+    for ln in lines:
+        print(ln)
 
 
 if __name__ == "__main__":
