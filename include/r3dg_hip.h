@@ -645,8 +645,6 @@ enum r3dg_option {
     R3DG_OPT_TRACE_LEAF_WEIGHT,
     R3DG_OPT_RESERVE_CUS,               /* CUs the persistent kernels (shading, trace) leave free for a collective running beside them
                                          * (default 0; the data-parallel iteration sets it) */
-    R3DG_OPT_LONG_TILE_SORT,            /* tiles longer than 4096 instances: 1 (default) segmented radix sort on the depth bits,
-                                         * 0 the bitonic network */
     R3DG_OPT_COUNT
 };
 int r3dg_set_option(int option, int value);

@@ -104,6 +104,8 @@ def _algorithmic_bytes(stage, P, R, N, S, K=64):
         # live shading model: fwd (260+16K) B, bwd (476+16K) B per Gaussian
         "shade_forward": (260.0 + 16 * K) * P,
         "shade_backward": (476.0 + 16 * K) * P,
+        # fixed ray set: the coefficient rotation, once each way (48 floats + the normal read, 48 floats written)
+        "shade_frs_aux": 2 * (48.0 + 3 + 48) * 4 * P,
         # relight under a fixed light: 12 B of cached transport per sample; per Gaussian albedo, roughness, normal, view
         # direction (40 B) + 16 cached constants (64 B) read, 19 outputs (76 B) written
         "shade_forward_transport": (180.0 + 12 * K) * P,
@@ -230,7 +232,11 @@ def _kernel_names(stage):
     """Kernel(s) a profile stage times, dominant first (names as tools/pmc_*.py shorten them)."""
     return {"sort_pairs": ["tile_sort_small_kernel", "partition_scatter_kernel"],
             "duplicate_with_keys": ["tile_emit_kernel", "duplicate_with_keys_kernel"],      # (stage name kept from K5)
-            "shade_forward": ["shade_forward_row_kernel", "shade_forward_kernel"],
+            # (the training iteration runs the fixed-ray-set kernels, csrc/shading_frs.hpp; the row kernel is what a caller with
+            # other caches gets)
+            "shade_forward": ["shade_forward_frs_kernel", "shade_forward_row_kernel"],
+            "shade_backward": ["shade_backward_frs_kernel", "shade_backward_kernel"],
+            "shade_frs_aux": ["frs_rotate_kernel"],
             "shade_forward_transport": ["shade_forward_transport_kernel"],
             "adam_step": ["adam_kernel"], "bvh_trace": ["trace_opacity_phased_kernel", "trace_opacity_persistent_kernel"],
             }.get(stage, [stage + "_kernel", stage])

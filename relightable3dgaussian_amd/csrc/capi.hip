@@ -63,18 +63,31 @@ size_t shade_frs_table_floats(int K);
 bool shade_frs_supported(int K, int M, int He, int We);
 void launch_shade_frs_build_tables(hipStream_t s, int K, const float* zsamples, float* tables);
 void launch_shade_frs_classify(hipStream_t s, int P, const float* ray_normals, uint8_t* valid);
-void launch_shade_frs_forward(hipStream_t s, int P, int K, const float* base_color, const float* roughness,
-                              const float* normals, const float* viewdirs, const float* incidents, const float* env, int He,
-                              int We, const float* visibility, const float* dirs, const float* areas, float uniform_area,
-                              const uint32_t* taps, const float* ray_normals, const float* tables, const uint8_t* valid,
-                              const int* invalid_list, int n_invalid, float* cprime, bool leave_room, float* out);
-void launch_shade_frs_backward(hipStream_t s, int P, int K, const float* base_color, const float* roughness,
-                               const float* normals, const float* viewdirs, const float* incidents, const float* env, int He,
-                               int We, const float* visibility, const float* dirs, const float* areas, float uniform_area,
-                               const uint32_t* taps, const float* ray_normals, const float* tables, const uint8_t* valid,
-                               const int* invalid_list, int n_invalid, const float* cprime, float* dcp, const float* g_pbr,
-                               const float* g_diff, float* d_base, float* d_rough, float* d_view, float* d_inc, float* d_env,
-                               const float* block_absmax, int n_block_absmax);
+void launch_shade_frs_forward_aux(hipStream_t s, int P, const float* incidents, const float* env, int He, int We,
+                                  const float* ray_normals, float* cprime);
+void launch_shade_frs_forward_main(hipStream_t s, int P, int K, const float* base_color, const float* roughness,
+                                   const float* normals, const float* viewdirs, int He, int We, const float* visibility,
+                                   const float* dirs, float uniform_area, const uint32_t* taps, const float* tables,
+                                   const uint8_t* valid, const float* cprime, bool leave_room, float* out);
+void launch_shade_frs_forward_listed(hipStream_t s, int P, int K, const float* base_color, const float* roughness,
+                                     const float* normals, const float* viewdirs, const float* incidents, const float* env, int He,
+                                     int We, const float* visibility, const float* dirs, const float* areas, float uniform_area,
+                                     const uint32_t* taps, const int* invalid_list, int n_invalid, bool leave_room, float* out);
+const unsigned int* launch_shade_frs_backward_aux(hipStream_t s, int P, const float* env, int He, int We, const float* g_pbr,
+                                                  const float* g_diff, const float* block_absmax, int n_block_absmax,
+                                                  int* gmax_n);
+void launch_shade_frs_backward_main(hipStream_t s, int P, int K, const float* base_color, const float* roughness,
+                                    const float* normals, const float* viewdirs, int He, int We, const float* visibility,
+                                    const float* dirs, float uniform_area, const uint32_t* taps, const float* tables,
+                                    const uint8_t* valid, const float* cprime, float* dcp, const float* g_pbr, const float* g_diff,
+                                    float* d_base, float* d_rough, float* d_view, float* d_env, const unsigned int* gmax, int gmax_n);
+void launch_shade_frs_backward_rotate(hipStream_t s, int P, const float* ray_normals, const float* dcp, float* d_inc);
+void launch_shade_frs_backward_listed(hipStream_t s, int P, int K, const float* base_color, const float* roughness,
+                                      const float* normals, const float* viewdirs, const float* incidents, const float* env, int He,
+                                      int We, const float* visibility, const float* dirs, const float* areas, const uint32_t* taps,
+                                      const int* invalid_list, int n_invalid, const float* g_pbr, const float* g_diff,
+                                      float* d_base, float* d_rough, float* d_view, float* d_inc, float* d_env,
+                                      const float* block_absmax, int n_block_absmax);
 void launch_shade_build_taps(hipStream_t s, size_t n, const float* dirs, const float* tr, int He, int We, const float* env,
                              uint32_t* taps);
 void launch_shade_build_transport(hipStream_t s, int P, int K, int M, const float* normals, const float* incidents,
@@ -84,7 +97,6 @@ void launch_shade_forward_transport(hipStream_t s, int P, int K, const float* ba
                                     const float* normals, const float* viewdirs, const float* transport, const float* consts,
                                     const float* zsamples, const float* dirs, float* out);
 extern int g_trace_packet, g_trace_refill, g_trace_node_weight, g_trace_leaf_weight;
-extern int g_long_tile_sort;         // radix_sort.hip
 extern int g_shade_row_blocks_per_cu;
 void launch_shade_backward(hipStream_t s, int P, int K, int M, const float* base_color, const float* roughness,
                            const float* normals, const float* viewdirs, const float* incidents, const float* env,
@@ -214,12 +226,12 @@ void launch_transpose_selftest(hipStream_t s, int N, int dpp, const float* in, f
 
 // ---- optional per-stage timing with HIP events on the launch stream (bench.py's roofline numbers) ----
 enum Stage { ST_PREPROCESS = 0, ST_DUPKEYS, ST_SORT, ST_RANGES, ST_RENDER_FWD, ST_NORMAL, ST_RENDER_BWD, ST_PREPROCESS_BWD,
-             ST_SHADE_FWD, ST_SHADE_BWD, ST_BVH_BUILD, ST_BVH_TRACE, ST_S2_ACTIVATE, ST_S2_PACK, ST_S2_LOSS,
+             ST_SHADE_FWD, ST_SHADE_BWD, ST_SHADE_AUX, ST_SHADE_LISTED, ST_BVH_BUILD, ST_BVH_TRACE, ST_S2_ACTIVATE, ST_S2_PACK, ST_S2_LOSS,
              ST_S2_UNPACK, ST_S2_ACTIVATE_BWD, ST_ADAM, ST_KNN, ST_SSIM, ST_DENSIFY, ST_RELIGHT_PACK, ST_RELIGHT_COMPOSE,
              ST_COUNT };
 static const char* kStageNames[ST_COUNT] = {"preprocess", "duplicate_with_keys", "sort_pairs", "identify_tile_ranges",
                                             "render_forward", "pseudo_normal", "render_backward", "preprocess_backward",
-                                            "shade_forward", "shade_backward", "bvh_build", "bvh_trace",
+                                            "shade_forward", "shade_backward", "shade_frs_aux", "shade_frs_listed", "bvh_build", "bvh_trace",
                                             "stage2_activate", "stage2_pack_features", "stage2_loss",
                                             "stage2_unpack_gradients", "stage2_activate_backward", "adam_step",
                                             "knn_dist2", "ssim", "densify", "relight_pack_features", "relight_compose"};
@@ -404,15 +416,14 @@ static int* option_slot(int option)
         case R3DG_OPT_TRACE_NODE_WEIGHT: return &g_trace_node_weight;
         case R3DG_OPT_TRACE_LEAF_WEIGHT: return &g_trace_leaf_weight;
         case R3DG_OPT_RESERVE_CUS: return &g_reserve_cus;
-        case R3DG_OPT_LONG_TILE_SORT: return &g_long_tile_sort;
         default: return nullptr;
     }
 }
 
 int r3dg_set_option(int option, int value)
 {
-    static const int lo[R3DG_OPT_COUNT] = {1, 1, 1, 1, 0, 0, 0, 0, 0, 1, 0, 0, 0, 1, 1, 1, 0, 0};
-    static const int hi[R3DG_OPT_COUNT] = {4, 2, 4, 4, 1, 1, 1, 1, 2, 64, 1, 8, 4, 64, 15, 15, 128, 1};
+    static const int lo[R3DG_OPT_COUNT] = {1, 1, 1, 1, 0, 0, 0, 0, 0, 1, 0, 0, 0, 1, 1, 1, 0};
+    static const int hi[R3DG_OPT_COUNT] = {4, 2, 4, 4, 1, 1, 1, 1, 2, 64, 1, 8, 4, 64, 15, 15, 128};
     int* slot = option_slot(option);
     if (slot == nullptr) return invalid("set_option: unknown option");
     if (value < lo[option] || value > hi[option]) return invalid("set_option: value out of range");
@@ -1232,11 +1243,22 @@ int r3dg_shade_frs_forward(void* stream_, int P, int K, const float* base_color,
     if (n_invalid > 0 && !incident_areas && !(uniform_area > 0.f)) return invalid("shade_frs_forward: no sample areas");
     return guarded([&]() -> int {
         hipStream_t stream = (hipStream_t)stream_;
-        StageTimer t(stream, ST_SHADE_FWD);
-        launch_shade_frs_forward(stream, P, K, base_color, roughness, normals, viewdirs, incidents, env, He, We, visibility,
-                                 incident_dirs, incident_areas, uniform_area, taps, ray_normals, tables, valid, invalid_list,
-                                 n_invalid, cprime, (flags & R3DG_SHADE_LEAVE_ROOM) != 0, out);
-        t.stop();
+        const bool leave_room = (flags & R3DG_SHADE_LEAVE_ROOM) != 0;
+        {
+            StageTimer t(stream, ST_SHADE_AUX);
+            launch_shade_frs_forward_aux(stream, P, incidents, env, He, We, ray_normals, cprime);
+        }
+        {
+            StageTimer t(stream, ST_SHADE_FWD);
+            launch_shade_frs_forward_main(stream, P, K, base_color, roughness, normals, viewdirs, He, We, visibility, incident_dirs,
+                                          uniform_area, taps, tables, valid, cprime, leave_room, out);
+        }
+        if (n_invalid > 0) {
+            StageTimer t(stream, ST_SHADE_LISTED);
+            launch_shade_frs_forward_listed(stream, P, K, base_color, roughness, normals, viewdirs, incidents, env, He, We,
+                                            visibility, incident_dirs, incident_areas, uniform_area, taps, invalid_list, n_invalid,
+                                            leave_room, out);
+        }
         return R3DG_OK;
     });
 }
@@ -1261,12 +1283,30 @@ int r3dg_shade_frs_backward(void* stream_, int P, int K, const float* base_color
         return invalid("shade_frs_backward: null buffer");
     return guarded([&]() -> int {
         hipStream_t stream = (hipStream_t)stream_;
-        StageTimer t(stream, ST_SHADE_BWD);
-        launch_shade_frs_backward(stream, P, K, base_color, roughness, normals, viewdirs, incidents, env, He, We, visibility,
-                                  incident_dirs, incident_areas, uniform_area, taps, ray_normals, tables, valid, invalid_list,
-                                  n_invalid, cprime, dcprime, dL_dpbr, dL_ddiffuse_light, dL_dbase_color, dL_droughness,
-                                  dL_dviewdirs, dL_dincidents, dL_denv, block_absmax, n_block_absmax);
-        t.stop();
+        int gmax_n = 1;
+        const unsigned int* gmax;
+        {
+            StageTimer t(stream, ST_SHADE_AUX);
+            gmax = launch_shade_frs_backward_aux(stream, P, env, He, We, dL_dpbr, dL_ddiffuse_light, block_absmax, n_block_absmax,
+                                                 &gmax_n);
+        }
+        {
+            StageTimer t(stream, ST_SHADE_BWD);
+            launch_shade_frs_backward_main(stream, P, K, base_color, roughness, normals, viewdirs, He, We, visibility, incident_dirs,
+                                           uniform_area, taps, tables, valid, cprime, dcprime, dL_dpbr, dL_ddiffuse_light,
+                                           dL_dbase_color, dL_droughness, dL_dviewdirs, dL_denv, gmax, gmax_n);
+        }
+        {
+            StageTimer t(stream, ST_SHADE_AUX);
+            launch_shade_frs_backward_rotate(stream, P, ray_normals, dcprime, dL_dincidents);
+        }
+        if (n_invalid > 0) {
+            StageTimer t(stream, ST_SHADE_LISTED);
+            launch_shade_frs_backward_listed(stream, P, K, base_color, roughness, normals, viewdirs, incidents, env, He, We,
+                                             visibility, incident_dirs, incident_areas, taps, invalid_list, n_invalid, dL_dpbr,
+                                             dL_ddiffuse_light, dL_dbase_color, dL_droughness, dL_dviewdirs, dL_dincidents, dL_denv,
+                                             block_absmax, n_block_absmax);
+        }
         return R3DG_OK;
     });
 }

@@ -250,10 +250,10 @@ void sort_pairs_range(hipStream_t stream, size_t n, uint64_t* keys_in, uint32_t*
 // Same final order with less memory traffic: ONE stable radix pass on the tile-id bits only (sort_pairs_range), which
 // leaves every tile's instances contiguous and in Gaussian-index order, then one workgroup per tile sorts its list by
 // (depth, index) -- a unique key, so any comparison sort reproduces the reference's stable order bit for bit.
-// One workgroup sorts one tile's (depth bits << 32 | Gaussian index) entries ascending with a bitonic network
-// ("flip" first step, so every compare-exchange is ascending and +inf padding never moves) -- in LDS for lists up to
-// the launch's capacity, in place in global memory (fences between stages) for the rare longer ones -- and writes the
-// reference's sorted key (tile << 32 | depth) and point-list arrays.
+// One workgroup sorts one tile's (depth bits << 32 | Gaussian index) entries ascending and writes the reference's sorted key
+// (tile << 32 | depth) and point-list arrays: lists of up to 4096 entries with a bitonic network in LDS ("flip" first step, so
+// every compare-exchange is ascending and +inf padding never moves), longer ones with the segmented radix sort further down
+// (whose rare fall-back is the same network in place in global memory, a fence per stage).
 template <typename Mem>
 __device__ __forceinline__ void bitonic_ascending(Mem& m, uint32_t n, uint32_t n_pad, int nt)
 {
@@ -363,33 +363,17 @@ __device__ __forceinline__ void sort_one_tile(uint2 rg, uint64_t* __restrict__ k
     const uint32_t n = rg.y - rg.x;
     const uint32_t n_pad = next_pow2_u32(n);
     const uint64_t tile_hi = ENTRIES ? ((uint64_t)tile << 32) : (keys[rg.x] & 0xffffffff00000000ull);
-    if (n <= cap) {
-        for (uint32_t i = threadIdx.x; i < n_pad; i += NT)
-            s_buf[i] = i < n ? (ENTRIES ? scratch[rg.x + i] : (keys[rg.x + i] << 32) | vals[rg.x + i])
-                             : ~0ull;      // real +inf padding in LDS
-        __syncthreads();
-        bitonic_lds_waves<NT>(s_buf, n_pad);
-        for (uint32_t i = threadIdx.x; i < n; i += NT) {
-            const uint64_t e = s_buf[i];
-            keys[rg.x + i] = tile_hi | (e >> 32);
-            vals[rg.x + i] = (uint32_t)e;
-        }
-        __syncthreads();
-    } else {
-        uint64_t* seg = scratch + rg.x;
-        __syncthreads();                              // tile_hi read by every thread before keys are overwritten
-        if (!ENTRIES)
-            for (uint32_t i = threadIdx.x; i < n; i += NT) seg[i] = (keys[rg.x + i] << 32) | vals[rg.x + i];
-        GlobalMem m{seg};
-        m.stage_sync();
-        bitonic_ascending(m, n, n_pad, NT);
-        for (uint32_t i = threadIdx.x; i < n; i += NT) {
-            const uint64_t e = seg[i];
-            keys[rg.x + i] = tile_hi | (e >> 32);
-            vals[rg.x + i] = (uint32_t)e;
-        }
-        __syncthreads();
+    for (uint32_t i = threadIdx.x; i < n_pad; i += NT)
+        s_buf[i] = i < n ? (ENTRIES ? scratch[rg.x + i] : (keys[rg.x + i] << 32) | vals[rg.x + i])
+                         : ~0ull;      // real +inf padding in LDS
+    __syncthreads();
+    bitonic_lds_waves<NT>(s_buf, n_pad);
+    for (uint32_t i = threadIdx.x; i < n; i += NT) {
+        const uint64_t e = s_buf[i];
+        keys[rg.x + i] = tile_hi | (e >> 32);
+        vals[rg.x + i] = (uint32_t)e;
     }
+    __syncthreads();
 }
 
 // small tiles: one 256-thread workgroup per tile (longest first), lists up to `cap` entries in dynamic LDS
@@ -407,23 +391,11 @@ tile_sort_small_kernel(int T, const uint32_t* __restrict__ tile_order, const uin
     sort_one_tile<256, ENTRIES>(rg, keys, vals, scratch, s_sort, cap, tile);
 }
 
-// long tiles: a few persistent 1024-thread workgroups walk the list written by tile_order_kernel
-template <bool ENTRIES>
-__global__ void __launch_bounds__(1024)
-tile_sort_big_kernel(const uint32_t* __restrict__ big_list, const uint32_t* __restrict__ big_count,
-                     const uint2* __restrict__ ranges, uint32_t cap, uint64_t* __restrict__ keys,
-                     uint32_t* __restrict__ vals, uint64_t* __restrict__ scratch)
-{
-    extern __shared__ __attribute__((aligned(16))) uint64_t s_sort[];
-    const uint32_t nbig = *big_count;
-    for (uint32_t b = blockIdx.x; b < nbig; b += gridDim.x)
-        sort_one_tile<1024, ENTRIES>(ranges[big_list[b]], keys, vals, scratch, s_sort, cap, big_list[b]);
-}
-
 // ---- long tiles: segmented LSD radix sort -------------------------------------------------------------------------------------
-// A bitonic network is O(n log^2 n): at 2 M Gaussians half of a 1800x700 frame's tiles hold more than 4096 instances and the
-// network (in 128 KB of LDS up to 16384 entries, in global memory with a fence per stage beyond) took 2.7 ms of a 9.6 ms
-// iteration.  One 1024-thread workgroup per long tile instead runs a STABLE least-significant-digit radix sort over the
+// A bitonic network is O(n log^2 n): at 2 M Gaussians 2577 of a 1800x700 frame's 4972 tiles hold more than 4096 instances
+// (15.4 M of 19.0 M; longest 13410) and the network -- in 128 KB of LDS up to 16384 entries, one workgroup per CU -- took 884 us
+// of the forward (rounds 1-2; 2.7 ms before it had a workgroup on every CU).  This kernel: 378 us for the same lists
+// (profiles/r03_sort_long_tiles_kernel_stats.md), same bits.  One 1024-thread workgroup per long tile runs a STABLE least-significant-digit radix sort over the
 // depth bits that actually differ inside the tile (the common prefix -- sign, most of the exponent -- is found first:
 // typically 22-26 bits, 3-4 passes of <= 8 bits), ping-ponging the tile's (depth << 32 | index) entries between its scratch
 // segment and its slice of the output key array (both L2-resident).  Per pass: every wave owns a contiguous 1/16 of the
@@ -636,11 +608,6 @@ tile_sort_long_kernel(const uint32_t* __restrict__ big_list, uint32_t* __restric
 }
 
 constexpr uint32_t TILE_SORT_SMALL_CAP = 4096;     // 32 KB of LDS per workgroup
-constexpr uint32_t TILE_SORT_BIG_CAP = 16384;      // 128 KB
-// persistent workgroups of the bitonic long-tile kernel: one per CU (128 KB of LDS each)
-constexpr int TILE_SORT_BIG_BLOCKS = 256;
-
-int g_long_tile_sort = 1;     // R3DG_OPT_LONG_TILE_SORT: 0 = bitonic network (LDS up to 16384 entries, global beyond), 1 = radix
 
 uint32_t tile_sort_small_cap() { return TILE_SORT_SMALL_CAP; }
 
@@ -648,29 +615,14 @@ uint32_t tile_sort_small_cap() { return TILE_SORT_SMALL_CAP; }
 void launch_tile_sort(hipStream_t s, int T, const uint32_t* tile_order, const uint32_t* ranges, const uint32_t* big_list,
                       uint32_t* big_count, uint64_t* keys, uint32_t* vals, uint64_t* scratch, bool entries)
 {
-    static bool attr_set = false;
-    if (!attr_set) {
-        R3DG_HIP(hipFuncSetAttribute((const void*)tile_sort_big_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                     (int)(TILE_SORT_BIG_CAP * 8)));
-        R3DG_HIP(hipFuncSetAttribute((const void*)tile_sort_big_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                     (int)(TILE_SORT_BIG_CAP * 8)));
-        attr_set = true;
-    }
     const uint2* rg = (const uint2*)ranges;
-    if (entries)
+    const int grid = 2 * (256 - g_reserve_cus);       // 2 x 1024 threads fill a CU; most exit at once when few tiles are long
+    if (entries) {
         tile_sort_small_kernel<true><<<T, 256, TILE_SORT_SMALL_CAP * 8, s>>>(T, tile_order, rg, TILE_SORT_SMALL_CAP, keys, vals, scratch);
-    else
-        tile_sort_small_kernel<false><<<T, 256, TILE_SORT_SMALL_CAP * 8, s>>>(T, tile_order, rg, TILE_SORT_SMALL_CAP, keys, vals, scratch);
-    if (g_long_tile_sort) {
-        const int grid = 2 * (256 - g_reserve_cus);
-        if (entries) tile_sort_long_kernel<true><<<grid, LONG_THREADS, 0, s>>>(big_list, big_count, rg, keys, vals, scratch);
-        else tile_sort_long_kernel<false><<<grid, LONG_THREADS, 0, s>>>(big_list, big_count, rg, keys, vals, scratch);
-    } else if (entries) {
-        tile_sort_big_kernel<true><<<TILE_SORT_BIG_BLOCKS, 1024, TILE_SORT_BIG_CAP * 8, s>>>(big_list, big_count, rg, TILE_SORT_BIG_CAP,
-                                                                                            keys, vals, scratch);
+        tile_sort_long_kernel<true><<<grid, LONG_THREADS, 0, s>>>(big_list, big_count, rg, keys, vals, scratch);
     } else {
-        tile_sort_big_kernel<false><<<TILE_SORT_BIG_BLOCKS, 1024, TILE_SORT_BIG_CAP * 8, s>>>(big_list, big_count, rg, TILE_SORT_BIG_CAP,
-                                                                                             keys, vals, scratch);
+        tile_sort_small_kernel<false><<<T, 256, TILE_SORT_SMALL_CAP * 8, s>>>(T, tile_order, rg, TILE_SORT_SMALL_CAP, keys, vals, scratch);
+        tile_sort_long_kernel<false><<<grid, LONG_THREADS, 0, s>>>(big_list, big_count, rg, keys, vals, scratch);
     }
 }
 

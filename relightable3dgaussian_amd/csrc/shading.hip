@@ -679,25 +679,28 @@ __device__ __forceinline__ unsigned int wave_gmax_bits(const unsigned int* __res
 // fixed-point accumulation is possible for a positive, finite maximum
 __device__ __forceinline__ bool gmax_usable(unsigned int bits) { return bits != 0u && bits < 0x7f800000u; }
 
-// max(|g_pbr|, |g_diff|) over all Gaussians -> *out (as float bits; non-negative floats order like unsigned ints).
+// max(|g_pbr|, |g_diff|) over all Gaussians -> *out (as float bits; non-negative floats order like unsigned ints), +inf if any
+// element is inf / nan.  Integer arithmetic on the bit patterns from the load on: under -ffast-math every float operation carries
+// "no nan, no inf" flags and LLVM folds even the exponent-all-ones idiom on a float-derived value to false (measured: a NaN
+// upstream gradient left a finite texture gradient).
 __global__ void __launch_bounds__(256)
 grad_absmax_kernel(int n, const float* __restrict__ a, const float* __restrict__ b, unsigned int* __restrict__ out)
 {
-    __shared__ float s_m[4];
-    float m = 0.f;
-    bool bad = false;
+    __shared__ unsigned int s_m[4];
+    const unsigned int* ua = reinterpret_cast<const unsigned int*>(a);
+    const unsigned int* ub = reinterpret_cast<const unsigned int*>(b);
+    unsigned int m = 0u;
     for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
-        const float x = fabsf(a[i]), y = fabsf(b[i]);
-        bad = bad || not_finite_bits(__float_as_uint(x)) || not_finite_bits(__float_as_uint(y));       // inf / nan
-        m = fmaxf(m, fmaxf(x, y));
+        const unsigned int x = ua[i] & 0x7fffffffu, y = ub[i] & 0x7fffffffu;      // |.|; inf = 0x7f800000 < every nan
+        m = max(m, max(x, y));
     }
+    if (m > 0x7f800000u) m = 0x7f800000u;                                           // nan -> the "not finite" marker
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
-    if (__ballot(bad) != 0ull) m = __uint_as_float(0x7f800000u);   // +inf marks "non-finite input"
+    for (int o = 32; o > 0; o >>= 1) m = max(m, (unsigned int)__shfl_xor((int)m, o, 64));
     if ((threadIdx.x & 63) == 0) s_m[threadIdx.x >> 6] = m;
     __syncthreads();
     // one atomic per block (a few hundred same-address atomics, not thousands)
-    if (threadIdx.x == 0) atomicMax(out, __float_as_uint(fmaxf(fmaxf(s_m[0], s_m[1]), fmaxf(s_m[2], s_m[3]))));
+    if (threadIdx.x == 0) atomicMax(out, max(max(s_m[0], s_m[1]), max(s_m[2], s_m[3])));
 }
 
 // The environment-texture gradient is a scatter of 12 values per sample into a few hundred texels.  LDS *float*
@@ -1171,13 +1174,14 @@ static int frs_grid(int P, const void* kernel, size_t smem)
 // a caller that passes the per-sample array instead of the constant (uniform_area == 0) means that value
 static inline float frs_area(float uniform_area) { return uniform_area > 0.f ? uniform_area : 6.283185307179586f; }
 
-// forward over a fixed ray set: rotate the coefficients (cprime [P,48] is kept for the backward), the MFMA kernel for the
-// Gaussians on the rotated path, the general row kernel for the listed rest
-void launch_shade_frs_forward(hipStream_t s, int P, int K, const float* base_color, const float* roughness,
-                              const float* normals, const float* viewdirs, const float* incidents, const float* env, int He,
-                              int We, const float* visibility, const float* dirs, const float* areas, float uniform_area,
-                              const uint32_t* taps, const float* ray_normals, const float* tables, const uint8_t* valid,
-                              const int* invalid_list, int n_invalid, float* cprime, bool leave_room, float* out)
+// A fixed-ray-set call is three groups of launches, timed as three stages by the C ABI (capi.hip) so that the profile's
+// "shade_forward" / "shade_backward" rows are ONE kernel each:
+//   aux     the texture padded to float4 texels, the coefficient rotation (forward: incidents -> cprime, kept for the backward;
+//           backward: dcprime -> d_inc), the max |upstream gradient| reduction when the caller has none
+//   main    the MFMA kernel for the Gaussians on the rotated path
+//   listed  the general kernels for the listed rest
+void launch_shade_frs_forward_aux(hipStream_t s, int P, const float* incidents, const float* env, int He, int We,
+                                  const float* ray_normals, float* cprime)
 {
     if (P == 0) return;
     const size_t ntexel = (size_t)He * We;
@@ -1185,35 +1189,46 @@ void launch_shade_frs_forward(hipStream_t s, int P, int K, const float* base_col
     shade_pad_env_kernel<<<(int)((ntexel + 255) / 256), 256, 0, s>>>((int)ntexel, env, env4);
     frs_rotate_kernel<false><<<(P + 255) / 256, 256, 0, s>>>(P, ray_normals, incidents, cprime);
     check_launch(s, false, "frs_rotate_kernel");
+}
+
+void launch_shade_frs_forward_main(hipStream_t s, int P, int K, const float* base_color, const float* roughness,
+                                   const float* normals, const float* viewdirs, int He, int We, const float* visibility,
+                                   const float* dirs, float uniform_area, const uint32_t* taps, const float* tables,
+                                   const uint8_t* valid, const float* cprime, bool leave_room, float* out)
+{
+    if (P == 0) return;
+    const size_t ntexel = (size_t)He * We;
+    const float4* env4 = reinterpret_cast<const float4*>(stream_scratch(s, 1, ntexel * sizeof(float4)));   // (written by _aux)
     const size_t smem = ntexel * sizeof(float4);
-    static int grid_cache[2] = {0, 0};
-    (void)grid_cache;
     int grid = frs_grid(P, (const void*)shade_forward_frs_kernel, smem);
     if (leave_room) grid = grid > shade_cus() * 2 ? shade_cus() * 2 : grid;      // the instance ordering runs beside it
     shade_forward_frs_kernel<<<grid, 64 * FRS_WAVES, smem, s>>>(P, K, base_color, roughness, normals, viewdirs, cprime, env4,
                                                                 He, We, visibility, dirs, frs_area(uniform_area), taps, tables, valid,
                                                                 out);
     check_launch(s, false, "shade_forward_frs_kernel");
-    if (n_invalid > 0)
-        launch_shade_forward(s, P, K, 16, base_color, roughness, normals, viewdirs, incidents, env, He, We, nullptr, visibility,
-                             dirs, areas, out, taps, true, uniform_area, false, leave_room, invalid_list, n_invalid);
 }
 
-void launch_shade_frs_backward(hipStream_t s, int P, int K, const float* base_color, const float* roughness,
-                               const float* normals, const float* viewdirs, const float* incidents, const float* env, int He,
-                               int We, const float* visibility, const float* dirs, const float* areas, float uniform_area,
-                               const uint32_t* taps, const float* ray_normals, const float* tables, const uint8_t* valid,
-                               const int* invalid_list, int n_invalid, const float* cprime, float* dcp, const float* g_pbr,
-                               const float* g_diff, float* d_base, float* d_rough, float* d_view, float* d_inc, float* d_env,
-                               const float* block_absmax, int n_block_absmax)
+void launch_shade_frs_forward_listed(hipStream_t s, int P, int K, const float* base_color, const float* roughness,
+                                     const float* normals, const float* viewdirs, const float* incidents, const float* env, int He,
+                                     int We, const float* visibility, const float* dirs, const float* areas, float uniform_area,
+                                     const uint32_t* taps, const int* invalid_list, int n_invalid, bool leave_room, float* out)
 {
-    if (P == 0) return;
+    if (P == 0 || n_invalid <= 0) return;
+    launch_shade_forward(s, P, K, 16, base_color, roughness, normals, viewdirs, incidents, env, He, We, nullptr, visibility,
+                         dirs, areas, out, taps, true, uniform_area, false, leave_room, invalid_list, n_invalid);
+}
+
+// (before _main) -> the words the main kernel scales its fixed-point texture accumulation by
+const unsigned int* launch_shade_frs_backward_aux(hipStream_t s, int P, const float* env, int He, int We, const float* g_pbr,
+                                                  const float* g_diff, const float* block_absmax, int n_block_absmax,
+                                                  int* gmax_n)
+{
     unsigned int* scratch = shade_scratch();
     const unsigned int* gmax = scratch;
-    int gmax_n = 1;
+    *gmax_n = 1;
     if (block_absmax != nullptr && n_block_absmax > 0) {
         gmax = reinterpret_cast<const unsigned int*>(block_absmax);
-        gmax_n = n_block_absmax;
+        *gmax_n = n_block_absmax;
     } else {
         R3DG_HIP(hipMemsetAsync(scratch, 0, 4, s));
         const int nb = (3 * P + 255) / 256;
@@ -1222,6 +1237,18 @@ void launch_shade_frs_backward(hipStream_t s, int P, int K, const float* base_co
     const size_t ntexel = (size_t)He * We;
     float4* env4 = reinterpret_cast<float4*>(stream_scratch(s, 1, ntexel * sizeof(float4)));
     shade_pad_env_kernel<<<(int)((ntexel + 255) / 256), 256, 0, s>>>((int)ntexel, env, env4);
+    return gmax;
+}
+
+void launch_shade_frs_backward_main(hipStream_t s, int P, int K, const float* base_color, const float* roughness,
+                                    const float* normals, const float* viewdirs, int He, int We, const float* visibility,
+                                    const float* dirs, float uniform_area, const uint32_t* taps, const float* tables,
+                                    const uint8_t* valid, const float* cprime, float* dcp, const float* g_pbr, const float* g_diff,
+                                    float* d_base, float* d_rough, float* d_view, float* d_env, const unsigned int* gmax, int gmax_n)
+{
+    if (P == 0) return;
+    const size_t ntexel = (size_t)He * We;
+    const float4* env4 = reinterpret_cast<const float4*>(stream_scratch(s, 1, ntexel * sizeof(float4)));
     const size_t smem = ntexel * (sizeof(float4) + 3 * sizeof(long long));
     const int grid = frs_grid(P, (const void*)shade_backward_frs_kernel, smem);
     shade_backward_frs_kernel<<<grid, 64 * FRS_WAVES, smem, s>>>(P, K, base_color, roughness, normals, viewdirs, cprime, g_pbr,
@@ -1229,14 +1256,28 @@ void launch_shade_frs_backward(hipStream_t s, int P, int K, const float* base_co
                                                                  taps, tables, valid, d_base, d_rough, d_view, dcp, d_env,
                                                                  gmax, gmax_n);
     check_launch(s, false, "shade_backward_frs_kernel");
-    // gradient back to the unrotated coefficients: every row of d_inc is written (garbage for Gaussians off the rotated
-    // path: the general kernel overwrites their rows next)
+}
+
+// gradient back to the unrotated coefficients: every row of d_inc is written (garbage for Gaussians off the rotated path:
+// the general kernel overwrites their rows next)
+void launch_shade_frs_backward_rotate(hipStream_t s, int P, const float* ray_normals, const float* dcp, float* d_inc)
+{
+    if (P == 0) return;
     frs_rotate_kernel<true><<<(P + 255) / 256, 256, 0, s>>>(P, ray_normals, dcp, d_inc);
     check_launch(s, false, "frs_rotate_kernel");
-    if (n_invalid > 0)
-        launch_shade_backward(s, P, K, 16, base_color, roughness, normals, viewdirs, incidents, env, He, We, nullptr, visibility,
-                              dirs, areas, g_pbr, g_diff, d_base, d_rough, d_view, d_inc, d_env, taps, block_absmax,
-                              n_block_absmax, invalid_list, n_invalid);
+}
+
+void launch_shade_frs_backward_listed(hipStream_t s, int P, int K, const float* base_color, const float* roughness,
+                                      const float* normals, const float* viewdirs, const float* incidents, const float* env, int He,
+                                      int We, const float* visibility, const float* dirs, const float* areas, const uint32_t* taps,
+                                      const int* invalid_list, int n_invalid, const float* g_pbr, const float* g_diff,
+                                      float* d_base, float* d_rough, float* d_view, float* d_inc, float* d_env,
+                                      const float* block_absmax, int n_block_absmax)
+{
+    if (P == 0 || n_invalid <= 0) return;
+    launch_shade_backward(s, P, K, 16, base_color, roughness, normals, viewdirs, incidents, env, He, We, nullptr, visibility,
+                          dirs, areas, g_pbr, g_diff, d_base, d_rough, d_view, d_inc, d_env, taps, block_absmax,
+                          n_block_absmax, invalid_list, n_invalid);
 }
 
 void launch_shade_build_transport(hipStream_t s, int P, int K, int M, const float* normals, const float* incidents,

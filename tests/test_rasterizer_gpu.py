@@ -320,10 +320,9 @@ def test_tile_binned_order_long_tiles(hip_lib):
 
 
 @pytest.mark.parametrize("ties", ["pairs", "long_run", "all_equal", "none"])
-@pytest.mark.parametrize("long_sort", [1, 0])
-def test_long_tile_sort_orders_equal_depths_by_index(ties, long_sort, hip_lib):
-    """The long-tile sort (csrc/radix_sort.hip: segmented radix over the depth bits that differ inside the tile; LONG_TILE_SORT=0:
-    the bitonic network) against the global radix sort of the reference formulation, with Gaussians at EXACTLY equal depth in
+def test_long_tile_sort_orders_equal_depths_by_index(ties, hip_lib):
+    """The long-tile sort (csrc/radix_sort.hip: segmented radix over the depth bits that differ inside the tile) against the
+    global radix sort of the reference formulation, with Gaussians at EXACTLY equal depth in
     tiles longer than 4096 instances: pairs (the index-rank fix-up), a run of 300 (the fall-back to the network on the unique
     (depth, index) key), and a frame whose every Gaussian has the same depth (no depth bit differs at all)."""
     case = make_case(P=24000, W=64, H=48, S=2, scale_log_mean=-1.2, seed=191)
@@ -341,7 +340,6 @@ def test_long_tile_sort_orders_equal_depths_by_index(ties, long_sort, hip_lib):
         depth = xyz @ zcol + wv[3, 2]
         xyz = xyz - (depth - depth.mean())[:, None] * zcol[None] / (zcol @ zcol)
     case["means3D"] = xyz.contiguous()
-    _opt(LONG_TILE_SORT=long_sort)
     try:
         a = _run_forward(case)
         _opt(TILE_BINNING=1)
@@ -349,7 +347,7 @@ def test_long_tile_sort_orders_equal_depths_by_index(ties, long_sort, hip_lib):
         _opt(TILE_BINNING=0)
         b = _run_forward(case)
     finally:
-        _opt(TILE_BINNING=2, LONG_TILE_SORT=1)
+        _opt(TILE_BINNING=2)
     torch.cuda.synchronize()
     from relightable3dgaussian_amd.rasterizer_ops import decode_state
     P, H, W = case["P"], case["H"], case["W"]

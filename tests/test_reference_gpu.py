@@ -91,8 +91,10 @@ def _compare_rasterizer(name, case, backward=True):
     # reaches is exempt.
     from oracle import rasterizer as orc
     o_ref = orc.rasterize_gaussians(*fwd_args(case)[:-3], want_margin=True)
-    assert o_ref[0] == ours[0] and np.array_equal(o_ref[1], ours[1].cpu().numpy()), "HIP path and CPU oracle disagree on n_contrib"
     border = o_ref[-1]["margin"] < 1e-4
+    # (the HIP path itself -- v_exp_f32 instead of expf -- may differ from the oracle on such pixels, and only there)
+    assert o_ref[0] == ours[0] and not ((o_ref[1] != ours[1].cpu().numpy()) & ~border).any(), \
+        "HIP path and CPU oracle disagree on n_contrib away from a threshold"
     exempt = np.zeros((H, W), bool)
     r_o, r_r = ours[9].cpu().numpy(), ref["radii"].cpu().numpy()
     mism = np.nonzero(r_o != r_r)[0]

@@ -1,5 +1,5 @@
 """The instance-ordering stages of the rasterizer forward at the composition scale (BASELINE configs[4]: 2 M Gaussians,
-1800x700), once per setting of R3DG_OPT_LONG_TILE_SORT, with the distribution of tile lengths: HIP-event ms per stage."""
+1800x700) with the distribution of tile lengths: HIP-event ms per stage (under rocprofv3 --kernel-trace: the kernels)."""
 import json, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -23,29 +23,22 @@ def forward():
 
 
 doc = {"points": P, "image": "%dx%d" % (W, H)}
-lists = {}
-for mode in (1, 0):
-    _lib.set_option("LONG_TILE_SORT", mode)
-    for _ in range(3):
-        out = forward()
-    torch.cuda.synchronize()
-    L.r3dg_profile_enable(1)
-    for _ in range(8):
-        out = forward()
-    torch.cuda.synchronize()
-    pr = _lib.profile_read()
-    L.r3dg_profile_enable(0)
-    st = decode_state(out[10], out[11], out[12], P, out[0], H, W)
-    lists[mode] = (torch.as_tensor(st["point_list"]).clone(), torch.as_tensor(st["keys"]).clone())
-    doc["long_tile_sort=%d" % mode] = {k: round(v[0] / max(v[1], 1), 4) for k, v in pr.items() if v[1]}
-    if mode == 1:
-        lens = torch.as_tensor(st["ranges"]).long()
-        lens = (lens[:, 1] - lens[:, 0])
-        doc["num_rendered"] = int(out[0])
-        doc["tiles"] = int(lens.numel())
-        doc["tile_length"] = {"max": int(lens.max()), "mean": round(float(lens.float().mean()), 1),
-                              "over_4096": int((lens > 4096).sum()), "over_16384": int((lens > 16384).sum()),
-                              "instances_in_tiles_over_4096": int(lens[lens > 4096].sum())}
-_lib.set_option("LONG_TILE_SORT", 1)
-doc["identical_lists"] = bool(torch.equal(lists[0][0], lists[1][0]) and torch.equal(lists[0][1], lists[1][1]))
+for _ in range(3):
+    out = forward()
+torch.cuda.synchronize()
+L.r3dg_profile_enable(1)
+for _ in range(8):
+    out = forward()
+torch.cuda.synchronize()
+pr = _lib.profile_read()
+L.r3dg_profile_enable(0)
+st = decode_state(out[10], out[11], out[12], P, out[0], H, W)
+doc["stage_ms"] = {k: round(v[0] / max(v[1], 1), 4) for k, v in pr.items() if v[1]}
+lens = torch.as_tensor(st["ranges"]).long()
+lens = (lens[:, 1] - lens[:, 0])
+doc["num_rendered"] = int(out[0])
+doc["tiles"] = int(lens.numel())
+doc["tile_length"] = {"max": int(lens.max()), "mean": round(float(lens.float().mean()), 1),
+                      "over_4096": int((lens > 4096).sum()), "over_16384": int((lens > 16384).sum()),
+                      "instances_in_tiles_over_4096": int(lens[lens > 4096].sum())}
 print(json.dumps(doc, indent=1))

@@ -88,13 +88,15 @@ def build():
 def run(out):
     from tools.build_variant import VARIANTS as VDIR
     res = {}
-    for name in ["product"] + sorted(VARIANTS):
+    only = [v for v in os.environ.get("VARIANTS_ONLY", "").split(",") if v]
+    for name in ["product"] + sorted(only or VARIANTS):
         env = dict(os.environ, ONLY64="1")
         if name != "product":
             env["R3DG_LIB_PATH"] = os.path.join(VDIR, name, "libr3dg_hip.so")
         r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "kbench_shade.py")], capture_output=True, text=True,
                            env=env, timeout=300)
-        vals = dict(re.findall(r"(frs forward|frs backward|backward \(cached taps\)|forward \(train outputs, cached taps, uniform area\))[^0-9]*?([0-9.]+) ms", r.stdout))
+        vals = dict(re.findall(r"(frs forward|frs backward|backward \(cached taps\)|forward \(train outputs, cached taps, uniform area\))"
+                               r"(?: \([^)]*\))? +([0-9.]+) ms", r.stdout))
         res[name] = {k: float(v) for k, v in vals.items()} or {"err": (r.stderr or r.stdout)[-300:]}
         print(name, res[name], flush=True)
     json.dump(dict(note="tools/kbench_shade.py ONLY64=1 (P=300000, K=64) per variant of the fixed-ray-set kernels; ms per call "
