@@ -286,6 +286,23 @@ __device__ __forceinline__ void lds_dma(const float* gptr, float* lds_base /* wa
                      "s_mov_b32 m0, %0" : "=&s"(saved) : "v"(gptr), "s"(off) : "memory");
 }
 #define R3DG_GLDS(gp, lp, sz) lds_dma<sz>(gp, lp)
+// the same with the LDS byte address already in an SGPR (lds_address_of, computed once per wave): the generic-pointer form above
+// costs a 64-bit VGPR pair + a null test per destination, which the compiler hoists out of loops and keeps live
+__device__ __forceinline__ unsigned int lds_address_of(const float* lds_ptr /* wave-uniform */)
+{
+    return __builtin_amdgcn_readfirstlane((unsigned int)(size_t)(__attribute__((address_space(3))) const float*)lds_ptr);
+}
+template <int BYTES>
+__device__ __forceinline__ void lds_dma_at(const float* gptr, unsigned int lds_byte_address /* SGPR */)
+{
+    unsigned int saved;
+    if (BYTES == 16)
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\t"
+                     "s_mov_b32 m0, %0" : "=&s"(saved) : "v"(gptr), "s"(lds_byte_address) : "memory");
+    else
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\t"
+                     "s_mov_b32 m0, %0" : "=&s"(saved) : "v"(gptr), "s"(lds_byte_address) : "memory");
+}
 
 constexpr int SB_USTRIDE = 68;
 constexpr int SB_U = 0, SB_DIRS = 272, SB_VIS = 1040, SB_AREA = 1296, SB_FLOATS = 1552;   // one buffer of one wave
@@ -1156,8 +1173,23 @@ bool shade_frs_supported(int K, int M, int He, int We)
     return M == 16 && K >= 4 && (K % 4) == 0 && (size_t)He * We * (16 + 24) <= (size_t)ENV_LDS_MAX * 4;
 }
 
+// dynamic LDS of the two kernels: the texture as float4 texels (+ its 3 x 64-bit gradient accumulators), the per-wave staging
+// areas of the next group's per-Gaussian data, the backward's table words when they fit
+static size_t frs_forward_lds_bytes(int He, int We)
+{
+    return ((size_t)He * We * 4 + (size_t)FRS_WAVES * FRS_ST_FWD) * sizeof(float);
+}
+static size_t frs_backward_lds_bytes(int K, int He, int We)
+{
+    const size_t ntexel = (size_t)He * We, nblk = (size_t)(K + 15) / 16;
+    return (((10 * ntexel + 3) & ~(size_t)3) + (size_t)FRS_WAVES * FRS_ST_BWD + (K <= FRS_TAB_LDS_MAX_K ? nblk * 512 : 0)) *
+           sizeof(float);
+}
+
 static int frs_grid(int P, const void* kernel, size_t smem)
 {
+    if (smem > 65536)
+        R3DG_HIP(hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
     int nb = 0;
     R3DG_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kernel, 64 * FRS_WAVES, smem));
     hipFuncAttributes fa;
@@ -1199,7 +1231,7 @@ void launch_shade_frs_forward_main(hipStream_t s, int P, int K, const float* bas
     if (P == 0) return;
     const size_t ntexel = (size_t)He * We;
     const float4* env4 = reinterpret_cast<const float4*>(stream_scratch(s, 1, ntexel * sizeof(float4)));   // (written by _aux)
-    const size_t smem = ntexel * sizeof(float4);
+    const size_t smem = frs_forward_lds_bytes(He, We);
     int grid = frs_grid(P, (const void*)shade_forward_frs_kernel, smem);
     if (leave_room) grid = grid > shade_cus() * 2 ? shade_cus() * 2 : grid;      // the instance ordering runs beside it
     shade_forward_frs_kernel<<<grid, 64 * FRS_WAVES, smem, s>>>(P, K, base_color, roughness, normals, viewdirs, cprime, env4,
@@ -1249,12 +1281,19 @@ void launch_shade_frs_backward_main(hipStream_t s, int P, int K, const float* ba
     if (P == 0) return;
     const size_t ntexel = (size_t)He * We;
     const float4* env4 = reinterpret_cast<const float4*>(stream_scratch(s, 1, ntexel * sizeof(float4)));
-    const size_t smem = ntexel * (sizeof(float4) + 3 * sizeof(long long));
-    const int grid = frs_grid(P, (const void*)shade_backward_frs_kernel, smem);
-    shade_backward_frs_kernel<<<grid, 64 * FRS_WAVES, smem, s>>>(P, K, base_color, roughness, normals, viewdirs, cprime, g_pbr,
-                                                                 g_diff, env4, He, We, visibility, dirs, frs_area(uniform_area),
-                                                                 taps, tables, valid, d_base, d_rough, d_view, dcp, d_env,
-                                                                 gmax, gmax_n);
+    const bool tab_lds = K <= FRS_TAB_LDS_MAX_K;
+    const size_t smem = frs_backward_lds_bytes(K, He, We);
+    if (tab_lds) {
+        const int grid = frs_grid(P, (const void*)shade_backward_frs_kernel<true>, smem);
+        shade_backward_frs_kernel<true><<<grid, 64 * FRS_WAVES, smem, s>>>(
+            P, K, base_color, roughness, normals, viewdirs, cprime, g_pbr, g_diff, env4, He, We, visibility, dirs,
+            frs_area(uniform_area), taps, tables, valid, d_base, d_rough, d_view, dcp, d_env, gmax, gmax_n);
+    } else {
+        const int grid = frs_grid(P, (const void*)shade_backward_frs_kernel<false>, smem);
+        shade_backward_frs_kernel<false><<<grid, 64 * FRS_WAVES, smem, s>>>(
+            P, K, base_color, roughness, normals, viewdirs, cprime, g_pbr, g_diff, env4, He, We, visibility, dirs,
+            frs_area(uniform_area), taps, tables, valid, d_base, d_rough, d_view, dcp, d_env, gmax, gmax_n);
+    }
     check_launch(s, false, "shade_backward_frs_kernel");
 }
 

@@ -33,6 +33,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 constexpr int FRS_WAVES = 4;                 // waves per workgroup
 constexpr int FRS_G = 16;                    // Gaussians per wave step (the N dimension of the MFMA tile)
 constexpr float FRS_MAX_DEFECT = 2e-5f;      // max |R R^T - I| for which a Gaussian takes the rotated path
+constexpr int FRS_TAB_LDS_MAX_K = 128;       // backward: the Y_i(z_k) tables live in LDS up to this many samples (16 KB)
 
 // rotation_between_z(n) (utils/sh_utils.py:36-68), fp32 operation for operation as sampling.rotation_between_z
 __device__ __forceinline__ void frs_rotation(const float n0, const float n1, const float n2, float (&R)[9])
@@ -221,10 +222,83 @@ __device__ __forceinline__ float frs_sum4(float x)       // sum over the 4 lanes
     return x;
 }
 
+// ---- the NEXT group's per-Gaussian data, staged per wave by LDS-DMA -----------------------------------------------------------
+// A group of 16 Gaussians is only K / 16 sample blocks long (4 at K = 64), and its per-Gaussian data -- the material record and
+// the lane's 12 rotated coefficients -- sit in front of every sample of it: loaded at the top of the group, one memory latency
+// per group is exposed on a dependent chain.  Instead the wave issues them for the NEXT group during the LAST sample block of
+// the current one, straight into LDS (global_load_lds, no registers: the backward has none to spare), together with the next
+// group's first sample block (into the `nxt` registers the block loop already owns): the top of a group is one
+// s_waitcnt + a handful of LDS reads.  Issued there and not earlier on purpose: vmcnt completes in order and the compiler,
+// which does not see the DMA, waits with vmcnt(0) for its own sample-block loads at the top of every block -- anything issued
+// before that wait has to land by then.
+constexpr int FRS_ST_CP = 0, FRS_ST_DIRS = 768, FRS_ST_TAPS = 1536, FRS_ST_VIS = 2304, FRS_ST_BASE = 2560, FRS_ST_NRM = 2624,
+              FRS_ST_VIEW = 2688, FRS_ST_RGH = 2752, FRS_ST_GP = 2816, FRS_ST_GD = 2880;
+constexpr int FRS_ST_FWD = 2816, FRS_ST_BWD = 2944;          // floats per wave (11 / 11.5 KB)
+
+template <bool BWD>
+__device__ __forceinline__ void frs_stage_group(unsigned int sb /* LDS byte address of the wave's area, SGPR */, int grp, int P,
+                                                int lane, const float* __restrict__ cprime,
+                                                const float* __restrict__ base_color, const float* __restrict__ normals,
+                                                const float* __restrict__ viewdirs, const float* __restrict__ roughness,
+                                                const float* __restrict__ g_pbr, const float* __restrict__ g_diff,
+                                                int K, const float* __restrict__ dirs, const float* __restrict__ visibility,
+                                                const uint32_t* __restrict__ taps)
+{
+    const int g0 = grp * FRS_G;
+    // the group's FIRST sample block (16 samples of 16 rows): 48 direction floats, 48 lookup words, 16 visibilities per row, same
+    // [j][row][16] image as the coefficients.  K < 16: the chunks past the row's end belong to the next row (masked by k < K in the
+    // kernels); the very last rows of the arrays are clamped to stay inside them
+    {
+        const size_t total = (size_t)P * (size_t)K;
+        const size_t r0 = (size_t)min(g0 + (lane >> 2), P - 1) * (size_t)K;
+#pragma unroll
+        for (int j = 0; j < 3; j++) {
+            const size_t o = min(3 * r0 + 16 * j + 4 * (lane & 3), 3 * total - 4);
+            lds_dma_at<16>(dirs + o, sb + 4u * (FRS_ST_DIRS + 256 * j));
+            lds_dma_at<16>(reinterpret_cast<const float*>(taps) + o, sb + 4u * (FRS_ST_TAPS + 256 * j));
+        }
+        lds_dma_at<16>(visibility + min(r0 + 4 * (lane & 3), total - 4), sb + 4u * FRS_ST_VIS);
+    }
+    // 16 rows of 48 coefficients: DMA j moves floats [16 j, 16 j + 16) of every row, lane = (row, 16-byte chunk), so the LDS image
+    // is [j][row][16 floats]: coefficient float f of row t sits at (f >> 4) * 256 + t * 16 + (f & 15)
+    const float* cp = cprime + (size_t)min(g0 + (lane >> 2), P - 1) * 48 + 4 * (lane & 3);
+#pragma unroll
+    for (int j = 0; j < 3; j++) lds_dma_at<16>(cp + 16 * j, sb + 4u * (FRS_ST_CP + 256 * j));
+    const int l3 = lane < 48 ? lane : 47, t3 = l3 / 3, c3 = l3 - 3 * t3;
+    const size_t o3 = 3 * (size_t)min(g0 + t3, P - 1) + c3;
+    lds_dma_at<4>(base_color + o3, sb + 4u * FRS_ST_BASE);
+    lds_dma_at<4>(normals + o3, sb + 4u * FRS_ST_NRM);
+    lds_dma_at<4>(viewdirs + o3, sb + 4u * FRS_ST_VIEW);
+    lds_dma_at<4>(roughness + min(g0 + (lane & 15), P - 1), sb + 4u * FRS_ST_RGH);
+    if (BWD) {
+        lds_dma_at<4>(g_pbr + o3, sb + 4u * FRS_ST_GP);
+        lds_dma_at<4>(g_diff + o3, sb + 4u * FRS_ST_GD);
+    }
+}
+
+// the staged first block as the register image frs_load_block gives (lane (gl, q): samples 4 q .. 4 q + 3 = floats 12 q .. of row gl)
+__device__ __forceinline__ FrsBlock frs_staged_block(const float* st, int gl, int q, int K)
+{
+    FrsBlock b;
+    const int kq = 4 * q + 4 <= K ? q : (K >> 2) - 1;                 // K < 16: the same clamp as frs_load_block
+    float4 d[3];
+    uint4 t[3];
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+        const int c = 3 * kq + i, o = (c >> 2) * 256 + gl * 16 + (c & 3) * 4;
+        d[i] = *reinterpret_cast<const float4*>(st + FRS_ST_DIRS + o);
+        t[i] = *reinterpret_cast<const uint4*>(st + FRS_ST_TAPS + o);
+    }
+    b.d0 = d[0]; b.d1 = d[1]; b.d2 = d[2];
+    b.t0 = t[0]; b.t1 = t[1]; b.t2 = t[2];
+    b.vis = *reinterpret_cast<const float4*>(st + FRS_ST_VIS + gl * 16 + 4 * kq);
+    return b;
+}
+
 // =====================================================================================================================
 // Forward (training outputs: pbr, diffuse_light, mean visibility -- columns 0..5 and 18 of the 19; neilf.py:120-122)
 // =====================================================================================================================
-__global__ void __launch_bounds__(64 * FRS_WAVES)
+__global__ void __launch_bounds__(64 * FRS_WAVES, 3)
 shade_forward_frs_kernel(int P, int K, const float* __restrict__ base_color, const float* __restrict__ roughness,
                          const float* __restrict__ normals, const float* __restrict__ viewdirs,
                          const float* __restrict__ cprime, const float4* __restrict__ env4, int He, int We,
@@ -241,44 +315,77 @@ shade_forward_frs_kernel(int P, int K, const float* __restrict__ base_color, con
     const int nblk = (K + 15) >> 4;
     const float invK = 1.0f / (float)K;
     const int ngroups = (P + FRS_G - 1) / FRS_G;
-    for (int grp = blockIdx.x * FRS_WAVES + wave; grp < ngroups; grp += gridDim.x * FRS_WAVES) {
+    float* st = s_mem + 4 * He * We + wave * FRS_ST_FWD;                 // this wave's staging area
+    const unsigned int st_addr = lds_address_of(st);
+    const int gstride = gridDim.x * FRS_WAVES;
+    int grp = blockIdx.x * FRS_WAVES + wave;
+    uint8_t nvalid = 0;
+    if (grp < ngroups) {
+        nvalid = valid[min(grp * FRS_G + gl, P - 1)];
+        frs_stage_group<false>(st_addr, grp, P, lane, cprime, base_color, normals, viewdirs, roughness, nullptr, nullptr, K, dirs,
+                               visibility, taps);
+    }
+    for (; grp < ngroups; grp += gstride) {
         const int g = grp * FRS_G + gl;
         const int gc = min(g, P - 1);
-        const bool live_g = g < P && valid[gc] != 0;
+        const bool live_g = g < P && nvalid != 0;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                 // this group's staged data have landed
         // per-Gaussian record
         float u[64];
 #pragma unroll
         for (int c = 0; c < 3; c++) {
-            u[48 + c] = base_color[3 * (size_t)gc + c];
-            u[52 + c] = normals[3 * (size_t)gc + c];
-            u[55 + c] = viewdirs[3 * (size_t)gc + c];
+            u[48 + c] = st[FRS_ST_BASE + 3 * gl + c];
+            u[52 + c] = st[FRS_ST_NRM + 3 * gl + c];
+            u[55 + c] = st[FRS_ST_VIEW + 3 * gl + c];
         }
-        u[51] = roughness[gc];
-        GaussFwd G;
-        gauss_setup(G, u);
-        const float fd[3] = {G.base[0] / kPi, G.base[1] / kPi, G.base[2] / kPi};
-        const float nom1 = G.NoV * (1.f - G.kk) + G.kk;
+        u[51] = st[FRS_ST_RGH + gl];
         // B operand of the local-light product: rotated coefficients 4 s + q of the lane's Gaussian
         float bc[4][3];
 #pragma unroll
         for (int s = 0; s < 4; s++)
 #pragma unroll
-            for (int c = 0; c < 3; c++) bc[s][c] = cprime[(size_t)gc * 48 + (4 * s + q) * 3 + c];
+            for (int c = 0; c < 3; c++) {
+                const int f = (4 * s + q) * 3 + c;
+                bc[s][c] = st[FRS_ST_CP + (f >> 4) * 256 + gl * 16 + (f & 15)];
+            }
+        FrsBlock nxt = frs_staged_block(st, gl, q, K);
+        GaussFwd G;
+        gauss_setup(G, u);
+        const float fd[3] = {G.base[0] / kPi, G.base[1] / kPi, G.base[2] / kPi};
+        const float nom1 = G.NoV * (1.f - G.kk) + G.kk;
         float acc[7] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
         const size_t row = (size_t)gc * (size_t)K;
-        FrsBlock nxt = frs_load_block(row, 4 * q, K, dirs, visibility, taps);
+        int ngrp_l = min(grp + gstride, ngroups - 1);                    // (past the end: a harmless reload of the last group)
+        int ngc_l = min(ngrp_l * FRS_G + gl, P - 1);
         for (int b = 0; b < nblk; b++) {
             const FrsBlock cur = nxt;
-            if (b + 1 < nblk) nxt = frs_load_block(row, 16 * (b + 1) + 4 * q, K, dirs, visibility, taps);
-            // local light of the 16 samples x 16 Gaussians of this block: l[c] = sum_i Yz[k][i] c'[i][c]
+            // Issue order matters (vmcnt completes in order): the block's four table words FIRST, then the prefetch of the next
+            // sample block -- the wait for the table words in front of the matrix product then leaves the prefetch in flight
+            // (the other way round it drained it: the "prefetch" was waited for ~100 instructions after its issue).
             const float* tb = tables + (size_t)b * 512 + lane;
+            float a[4];
+#pragma unroll
+            for (int s = 0; s < 4; s++) a[s] = tb[64 * s];
+            const bool last = b + 1 == nblk;
+            if (!last) {
+                nxt = frs_load_block(row, 16 * (b + 1) + 4 * q, K, dirs, visibility, taps);
+            } else {
+                // (the empty asm keeps the compiler from hoisting the next group's address computations out of the block loop,
+                // where they would be live -- 2 VGPRs each -- through every block of the group)
+                asm volatile("" : "+v"(ngrp_l), "+v"(ngc_l));
+                nvalid = valid[ngc_l];
+            }
+            __builtin_amdgcn_sched_barrier(0);       // (the prefetch is issued HERE, not sunk into the block to save registers)
+            // local light of the 16 samples x 16 Gaussians of this block: l[c] = sum_i Yz[k][i] c'[i][c]
             f32x4 l[3] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
 #pragma unroll
-            for (int s = 0; s < 4; s++) {
-                const float a = tb[64 * s];
+            for (int s = 0; s < 4; s++)
 #pragma unroll
-                for (int c = 0; c < 3; c++) l[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bc[s][c], l[c], 0, 0, 0);
-            }
+                for (int c = 0; c < 3; c++) l[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s], bc[s][c], l[c], 0, 0, 0);
+            // the next group's per-Gaussian data: behind the last compiler-visible wait of the group (see frs_stage_group)
+            if (last)
+                frs_stage_group<false>(st_addr, ngrp_l, P, lane, cprime, base_color, normals, viewdirs, roughness, nullptr, nullptr, K,
+                                       dirs, visibility, taps);
 #pragma unroll
             for (int v = 0; v < 4; v++) {
                 const int k = 16 * b + 4 * q + v;
@@ -333,7 +440,8 @@ shade_forward_frs_kernel(int P, int K, const float* __restrict__ base_color, con
 // Per-sample arithmetic = the general kernels' (neilf.py:339-407 differentiated); the texture gradient goes through the same
 // 64-bit fixed-point LDS accumulators.
 // =====================================================================================================================
-__global__ void __launch_bounds__(64 * FRS_WAVES)
+template <bool TAB_LDS>
+__global__ void __launch_bounds__(64 * FRS_WAVES, 2)
 shade_backward_frs_kernel(int P, int K, const float* __restrict__ base_color, const float* __restrict__ roughness,
                           const float* __restrict__ normals, const float* __restrict__ viewdirs,
                           const float* __restrict__ cprime, const float* __restrict__ g_pbr,
@@ -353,52 +461,89 @@ shade_backward_frs_kernel(int P, int K, const float* __restrict__ base_color, co
     const bool fixed = gmax_usable(gmax_word);
     const float fx_scale = fixed ? 34359738368.0f / gmax : 0.f;                 // 2^35 / max|g|
     const float fx_clamp = gmax * 8192.0f;
+    const int nblk = (K + 15) >> 4;
+    float* s_stage = s_mem + ((10 * ntexel + 3) & ~3);                           // FRS_WAVES x FRS_ST_BWD floats (16-byte aligned)
+    float* s_tab = s_stage + FRS_WAVES * FRS_ST_BWD;                             // TAB_LDS: the nblk x 512 table words
     for (int i = threadIdx.x; i < ntexel; i += blockDim.x) s_env4[i] = env4[i];
     for (int i = threadIdx.x; i < 3 * ntexel; i += blockDim.x) s_denv[i] = 0;
+    if (TAB_LDS)
+        for (int i = threadIdx.x; i < nblk * 512; i += blockDim.x) s_tab[i] = tables[i];
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int gl = lane & 15, q = lane >> 4;
-    const int nblk = (K + 15) >> 4;
     const float invK = 1.0f / (float)K;
     const int ngroups = (P + FRS_G - 1) / FRS_G;
-    for (int grp = blockIdx.x * FRS_WAVES + wave; grp < ngroups; grp += gridDim.x * FRS_WAVES) {
+    float* st = s_stage + wave * FRS_ST_BWD;                                     // this wave's staging area (frs_stage_group)
+    const unsigned int st_addr = lds_address_of(st);
+    const int gstride = gridDim.x * FRS_WAVES;
+    int grp = blockIdx.x * FRS_WAVES + wave;
+    uint8_t nvalid = 0;
+    if (grp < ngroups) {
+        nvalid = valid[min(grp * FRS_G + gl, P - 1)];
+        frs_stage_group<true>(st_addr, grp, P, lane, cprime, base_color, normals, viewdirs, roughness, g_pbr, g_diff, K, dirs,
+                              visibility, taps);
+    }
+    for (; grp < ngroups; grp += gstride) {
         const int g = grp * FRS_G + gl;
         const int gc = min(g, P - 1);
-        const bool live_g = g < P && valid[gc] != 0;
+        const bool live_g = g < P && nvalid != 0;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                         // this group's staged data have landed
         float u[64];
 #pragma unroll
         for (int c = 0; c < 3; c++) {
-            u[48 + c] = base_color[3 * (size_t)gc + c];
-            u[52 + c] = normals[3 * (size_t)gc + c];
-            u[55 + c] = viewdirs[3 * (size_t)gc + c];
+            u[48 + c] = st[FRS_ST_BASE + 3 * gl + c];
+            u[52 + c] = st[FRS_ST_NRM + 3 * gl + c];
+            u[55 + c] = st[FRS_ST_VIEW + 3 * gl + c];
         }
-        u[51] = roughness[gc];
-        GaussFwd G;
-        gauss_setup(G, u);
-        const float fd[3] = {G.base[0] / kPi, G.base[1] / kPi, G.base[2] / kPi};
-        const float gp[3] = {g_pbr[3 * (size_t)gc] * invK, g_pbr[3 * (size_t)gc + 1] * invK, g_pbr[3 * (size_t)gc + 2] * invK};
-        const float gd[3] = {g_diff[3 * (size_t)gc] * invK, g_diff[3 * (size_t)gc + 1] * invK, g_diff[3 * (size_t)gc + 2] * invK};
-        const float nom1 = G.NoV * (1.f - G.kk) + G.kk;
+        u[51] = st[FRS_ST_RGH + gl];
+        const float gp[3] = {st[FRS_ST_GP + 3 * gl] * invK, st[FRS_ST_GP + 3 * gl + 1] * invK, st[FRS_ST_GP + 3 * gl + 2] * invK};
+        const float gd[3] = {st[FRS_ST_GD + 3 * gl] * invK, st[FRS_ST_GD + 3 * gl + 1] * invK, st[FRS_ST_GD + 3 * gl + 2] * invK};
         float bc[4][3];
 #pragma unroll
         for (int s = 0; s < 4; s++)
 #pragma unroll
-            for (int c = 0; c < 3; c++) bc[s][c] = cprime[(size_t)gc * 48 + (4 * s + q) * 3 + c];
+            for (int c = 0; c < 3; c++) {
+                const int f = (4 * s + q) * 3 + c;
+                bc[s][c] = st[FRS_ST_CP + (f >> 4) * 256 + gl * 16 + (f & 15)];
+            }
+        FrsBlock nxt = frs_staged_block(st, gl, q, K);
+        GaussFwd G;
+        gauss_setup(G, u);
+        const float fd[3] = {G.base[0] / kPi, G.base[1] / kPi, G.base[2] / kPi};
+        const float nom1 = G.NoV * (1.f - G.kk) + G.kk;
         f32x4 dcq[3] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};   // dL/dc'[4 q + v'][c]
         float accb[7] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};     // albedo 3, roughness, view direction 3
         const size_t row = (size_t)gc * (size_t)K;
-        FrsBlock nxt = frs_load_block(row, 4 * q, K, dirs, visibility, taps);
+        int ngrp_l = min(grp + gstride, ngroups - 1);                            // (past the end: a harmless reload of the last group)
+        int ngc_l = min(ngrp_l * FRS_G + gl, P - 1);
         for (int b = 0; b < nblk; b++) {
             const FrsBlock cur = nxt;
-            if (b + 1 < nblk) nxt = frs_load_block(row, 16 * (b + 1) + 4 * q, K, dirs, visibility, taps);
-            const float* tb = tables + (size_t)b * 512 + lane;
+            // table words first, then the prefetch (see the forward); with the tables in LDS (K <= FRS_TAB_LDS_MAX_K) no vector
+            // memory load at all sits between the prefetch and the end of the block
+            const float* tb = (TAB_LDS ? s_tab : tables) + (size_t)b * 512 + lane;
+            float a[4] = {0.f, 0.f, 0.f, 0.f};
+            if (!TAB_LDS) {
+#pragma unroll
+                for (int s = 0; s < 4; s++) a[s] = tb[64 * s];
+            }
+            const bool last = b + 1 == nblk;
+            if (!last) {
+                nxt = frs_load_block(row, 16 * (b + 1) + 4 * q, K, dirs, visibility, taps);
+            } else {
+                asm volatile("" : "+v"(ngrp_l), "+v"(ngc_l));         // (not hoisted out of the block loop: see the forward)
+                nvalid = valid[ngc_l];
+            }
+            __builtin_amdgcn_sched_barrier(0);
             f32x4 l[3] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
 #pragma unroll
             for (int s = 0; s < 4; s++) {
-                const float a = tb[64 * s];
+                const float av = TAB_LDS ? tb[64 * s] : a[s];
 #pragma unroll
-                for (int c = 0; c < 3; c++) l[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bc[s][c], l[c], 0, 0, 0);
+                for (int c = 0; c < 3; c++) l[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bc[s][c], l[c], 0, 0, 0);
             }
+            if (last)
+                frs_stage_group<true>(st_addr, ngrp_l, P, lane, cprime, base_color, normals, viewdirs, roughness, g_pbr, g_diff, K, dirs,
+                                      visibility, taps);
 #pragma unroll
             for (int v = 0; v < 4; v++) {
                 const int k = 16 * b + 4 * q + v;

@@ -12,77 +12,35 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 H = "shading_frs.hpp"
-FWD_SIG = "__global__ void __launch_bounds__(64 * FRS_WAVES)\nshade_forward_frs_kernel("
-BWD_SIG = "__global__ void __launch_bounds__(64 * FRS_WAVES)\nshade_backward_frs_kernel("
+
+
+def _head(path):
+    return subprocess.run(["git", "show", "HEAD:relightable3dgaussian_amd/csrc/" + path], capture_output=True, text=True,
+                          cwd=ROOT, check=True).stdout
+
+
+def _cur(path):
+    return open(os.path.join(ROOT, "relightable3dgaussian_amd", "csrc", path)).read()
+
+
+SB_FWD = "            __builtin_amdgcn_sched_barrier(0);       // (the prefetch is issued HERE, not sunk into the block to save registers)\n"
+SB_BWD = "            __builtin_amdgcn_sched_barrier(0);\n            f32x4 l[3]"
+FWD_SIG = "__global__ void __launch_bounds__(64 * FRS_WAVES, 3)\nshade_forward_frs_kernel("
 VARIANTS = {
-    # forward at 4 / 5 waves per SIMD instead of 3 (141 VGPRs today)
-    "frs_fwd_occ4": [(FWD_SIG, FWD_SIG.replace("(64 * FRS_WAVES)", "(64 * FRS_WAVES, 4)"), None, H)],
-    "frs_fwd_occ5": [(FWD_SIG, FWD_SIG.replace("(64 * FRS_WAVES)", "(64 * FRS_WAVES, 5)"), None, H)],
-    # backward at 3 waves per SIMD instead of 2 (256 registers today)
-    "frs_bwd_occ3": [(BWD_SIG, BWD_SIG.replace("(64 * FRS_WAVES)", "(64 * FRS_WAVES, 3)"), None, H)],
-    # the four samples of a block two at a time (less unrolling, fewer live registers)
-    "frs_unroll2": [("#pragma unroll\n            for (int v = 0; v < 4; v++) {\n                const int k = 16 * b + 4 * q + v;",
-                     "#pragma unroll 2\n            for (int v = 0; v < 4; v++) {\n                const int k = 16 * b + 4 * q + v;", 2, H)],
-    # texture-gradient scatter without double precision: per Gaussian a power-of-two scale brings the clamped contribution into
-    # int32 (v_rndne + v_cvt_i32), sign-extended and shifted back into the common 64-bit fixed-point unit
-    "frs_i32_fixed": [
-        ("""        const float nom1 = G.NoV * (1.f - G.kk) + G.kk;
-        float bc[4][3];
-#pragma unroll
-        for (int s = 0; s < 4; s++)
-#pragma unroll
-            for (int c = 0; c < 3; c++) bc[s][c] = cprime[(size_t)gc * 48 + (4 * s + q) * 3 + c];
-        f32x4 dcq[3]""", """        const float nom1 = G.NoV * (1.f - G.kk) + G.kk;
-        // exponent gap between the largest upstream gradient of the launch and this Gaussian's: its contributions are below
-        // gmax 2^(14 - E), i.e. 2^(49 - E) fixed-point units; with sh = max(0, 19 - E) and a clamp at 2^29 the value round(x S 2^-sh)
-        // fits int32 and one contribution stays below 2^48 units, as in the double-precision form
-        int sh;
-        float fx_scale_p;
-        {
-            const float gpmax = fmaxf(fmaxf(fmaxf(fabsf(gp[0]), fabsf(gp[1])), fabsf(gp[2])),
-                                      fmaxf(fmaxf(fabsf(gd[0]), fabsf(gd[1])), fabsf(gd[2]))) * (float)K;
-            const int E = (int)((__float_as_uint(gmax) >> 23) & 0xffu) - (int)((__float_as_uint(fmaxf(gpmax, 1e-37f)) >> 23) & 0xffu);
-            sh = E >= 19 ? 0 : (E < 0 ? 19 : 19 - E);
-            fx_scale_p = fx_scale * __uint_as_float((unsigned)(127 - sh) << 23);
-        }
-        float bc[4][3];
-#pragma unroll
-        for (int s = 0; s < 4; s++)
-#pragma unroll
-            for (int c = 0; c < 3; c++) bc[s][c] = cprime[(size_t)gc * 48 + (4 * s + q) * 3 + c];
-        f32x4 dcq[3]""", None, H),
-        ("""                    if (fixed) {
-                        const double scale_d = (double)fx_scale;
-#pragma unroll
-                        for (int tq = 0; tq < 4; tq++) {
-#pragma unroll
-                            for (int c = 0; c < 3; c++) {
-                                const float cl = __builtin_amdgcn_fmed3f(ev[c] * w4[tq], -fx_clamp, fx_clamp);
-                                const double dsum = __builtin_fma((double)cl, scale_d, 6755399441055744.0);
-                                const unsigned long long bits =
-                                    (unsigned long long)__double_as_longlong(dsum) - 0x4338000000000000ull;
-                                atomicAdd(reinterpret_cast<unsigned long long*>(&s_denv[3 * tex[tq] + c]), bits);
-                            }
-                        }
-                    } else {""", """                    if (fixed) {
-                        const float evs[3] = {ev[0] * fx_scale_p, ev[1] * fx_scale_p, ev[2] * fx_scale_p};
-#pragma unroll
-                        for (int tq = 0; tq < 4; tq++) {
-#pragma unroll
-                            for (int c = 0; c < 3; c++) {
-                                const float cl = __builtin_amdgcn_fmed3f(evs[c] * w4[tq], -536870912.0f, 536870912.0f);
-                                const long long v64 = (long long)(int)rintf(cl) << sh;
-                                atomicAdd(reinterpret_cast<unsigned long long*>(&s_denv[3 * tex[tq] + c]), (unsigned long long)v64);
-                            }
-                        }
-                    } else {""", None, H)],
+    # the committed kernels (git HEAD) beside the working tree's: same box, same run
+    "frs_head": lambda: [(_cur("shading.hip"), _head("shading.hip"), None, "shading.hip"), (_cur(H), _head(H), None, H)],
+    # the next block's prefetch left to the scheduler (it sinks the loads into the block to save registers)
+    "frs_fwd_no_sched_barrier": lambda: [(SB_FWD, "", None, H)],
+    "frs_bwd_no_sched_barrier": lambda: [(SB_BWD, "            f32x4 l[3]", None, H)],
+    # forward at 2 waves per SIMD (256 registers) instead of 3
+    "frs_fwd_occ2": lambda: [(FWD_SIG, FWD_SIG.replace("FRS_WAVES, 3)", "FRS_WAVES, 2)"), None, H)],
 }
 
 
 def build():
     from tools.build_variant import build_variant
     for name, reps in VARIANTS.items():
-        print(name, build_variant(name, "shading.hip", reps))
+        print(name, build_variant(name, "shading.hip", reps()))
 
 
 def run(out):
