@@ -21,6 +21,7 @@
 #include <map>
 #include <mutex>
 #include <stdexcept>
+#include <tuple>
 #include "wave_reduce.hpp"
 #include "shading_math.hpp"
 
@@ -397,11 +398,13 @@ constexpr int REC = 64;      // floats per Gaussian record
 // copied: the row kernel's lanes 0..47 read them straight from `incidents` (one coalesced 192-byte run per Gaussian),
 // lanes 48..63 read these 16 (a copying version of this kernel cost 0.05 ms per iteration for 115 MB of pure copy).
 __global__ void __launch_bounds__(256)
-shade_prepare_kernel(int P, const float* __restrict__ base_color, const float* __restrict__ roughness,
-                     const float* __restrict__ normals, const float* __restrict__ viewdirs, float* __restrict__ rec16)
+shade_prepare_kernel(int n, const float* __restrict__ base_color, const float* __restrict__ roughness,
+                     const float* __restrict__ normals, const float* __restrict__ viewdirs, float* __restrict__ rec16,
+                     const int* __restrict__ list /* optional: only these rows */)
 {
-    const int g = blockIdx.x * 256 + threadIdx.x;
-    if (g >= P) return;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const int g = list != nullptr ? list[i] : i;
     float u[64];
 #pragma unroll
     for (int c = 0; c < 3; c++) {
@@ -665,10 +668,11 @@ shade_forward_row_kernel(int P, int K, int M_, const float* __restrict__ rec, co
 }
 
 __global__ void __launch_bounds__(256)
-shade_pad_env_kernel(int n, const float* __restrict__ env, float4* __restrict__ env4)
+shade_pad_env_kernel(int n, const float* __restrict__ env, float4* __restrict__ env4, unsigned int* __restrict__ queue = nullptr)
 {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i < n) env4[i] = make_float4(env[3 * i], env[3 * i + 1], env[3 * i + 2], 0.f);
+    if (i == 0 && queue != nullptr) *queue = 0u;      // the group queue of the fixed-ray-set kernel launched next (shading_frs.hpp)
 }
 
 // Backward: gradients of sum(pbr*g_pbr) + sum(diffuse_light*g_diff) w.r.t. base_color, roughness, viewdirs,
@@ -1037,12 +1041,12 @@ void launch_shade_forward(hipStream_t s, int P, int K, int M, const float* base_
     const size_t ntexel = (size_t)He * We;
     float* rec = shade_records(s, (((size_t)P * 16 + 3) & ~(size_t)3) + ntexel * 4);   // [P][16] derived floats, then the padded texture
     float4* env4 = reinterpret_cast<float4*>(rec + (((size_t)P * 16 + 3) & ~(size_t)3));
-    shade_prepare_kernel<<<(P + 255) / 256, 256, 0, s>>>(P, base_color, roughness, normals, viewdirs, rec);
+    const int n = list != nullptr ? n_list : P;
+    shade_prepare_kernel<<<(n + 255) / 256, 256, 0, s>>>(n, base_color, roughness, normals, viewdirs, rec, list);
     shade_pad_env_kernel<<<(int)((ntexel + 255) / 256), 256, 0, s>>>((int)ntexel, env, env4);
     const int mode = taps == nullptr ? 0 : (taps_are_radiance ? 2 : 1);
     const bool lds = mode != 2 && He * We * 4 <= ENV_LDS_MAX;          // float4 per texel
     const size_t smem = lds ? ntexel * sizeof(float4) : 0;
-    const int n = list != nullptr ? n_list : P;
     const int want = (n + ROW_WAVES - 1) / ROW_WAVES;
 #define R3DG_ROW(N, L, T)                                                                                             \
     do {                                                                                                              \
@@ -1173,6 +1177,9 @@ bool shade_frs_supported(int K, int M, int He, int We)
     return M == 16 && K >= 4 && (K % 4) == 0 && (size_t)He * We * (16 + 24) <= (size_t)ENV_LDS_MAX * 4;
 }
 
+// the group queue of the fixed-ray-set kernels: one word per (device, stream), zeroed by the padding kernel in front of each launch
+static unsigned int* frs_queue(hipStream_t s) { return reinterpret_cast<unsigned int*>(stream_scratch(s, 3, 256)); }
+
 // dynamic LDS of the two kernels: the texture as float4 texels (+ its 3 x 64-bit gradient accumulators), the per-wave staging
 // areas of the next group's per-Gaussian data, the backward's table words when they fit
 static size_t frs_forward_lds_bytes(int He, int We)
@@ -1188,15 +1195,30 @@ static size_t frs_backward_lds_bytes(int K, int He, int We)
 
 static int frs_grid(int P, const void* kernel, size_t smem)
 {
-    if (smem > 65536)
-        R3DG_HIP(hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+    // resident workgroups per CU of (kernel, LDS size): asked once per device (the attribute / occupancy calls take the
+    // runtime's locks on every launch otherwise)
+    static std::mutex mu;
+    static std::map<std::tuple<int, const void*, size_t>, int> cache;
+    int dev = 0;
+    R3DG_HIP(hipGetDevice(&dev));
     int nb = 0;
-    R3DG_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kernel, 64 * FRS_WAVES, smem));
-    hipFuncAttributes fa;
-    R3DG_HIP(hipFuncGetAttributes(&fa, kernel));
-    const int by_vgpr = 512 / (((fa.numRegs + 7) / 8) * 8);           // waves per SIMD = 256-thread blocks per CU
-    nb = nb < by_vgpr ? nb : by_vgpr;
-    nb = nb > 0 ? (nb < 8 ? nb : 8) : 1;
+    {
+        std::lock_guard<std::mutex> lk(mu);
+        auto it = cache.find(std::make_tuple(dev, kernel, smem));
+        if (it != cache.end()) {
+            nb = it->second;
+        } else {
+            if (smem > 65536)
+                R3DG_HIP(hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+            R3DG_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kernel, 64 * FRS_WAVES, smem));
+            hipFuncAttributes fa;
+            R3DG_HIP(hipFuncGetAttributes(&fa, kernel));
+            const int by_vgpr = 512 / (((fa.numRegs + 7) / 8) * 8);   // waves per SIMD = 256-thread blocks per CU
+            nb = nb < by_vgpr ? nb : by_vgpr;
+            nb = nb > 0 ? (nb < 8 ? nb : 8) : 1;
+            cache[std::make_tuple(dev, kernel, smem)] = nb;
+        }
+    }
     const int want = ((P + FRS_G - 1) / FRS_G + FRS_WAVES - 1) / FRS_WAVES;
     const int cap = shade_cus() * nb;
     return want < cap ? (want > 0 ? want : 1) : cap;
@@ -1218,7 +1240,7 @@ void launch_shade_frs_forward_aux(hipStream_t s, int P, const float* incidents, 
     if (P == 0) return;
     const size_t ntexel = (size_t)He * We;
     float4* env4 = reinterpret_cast<float4*>(stream_scratch(s, 1, ntexel * sizeof(float4)));
-    shade_pad_env_kernel<<<(int)((ntexel + 255) / 256), 256, 0, s>>>((int)ntexel, env, env4);
+    shade_pad_env_kernel<<<(int)((ntexel + 255) / 256), 256, 0, s>>>((int)ntexel, env, env4, frs_queue(s));
     frs_rotate_kernel<false><<<(P + 255) / 256, 256, 0, s>>>(P, ray_normals, incidents, cprime);
     check_launch(s, false, "frs_rotate_kernel");
 }
@@ -1236,7 +1258,7 @@ void launch_shade_frs_forward_main(hipStream_t s, int P, int K, const float* bas
     if (leave_room) grid = grid > shade_cus() * 2 ? shade_cus() * 2 : grid;      // the instance ordering runs beside it
     shade_forward_frs_kernel<<<grid, 64 * FRS_WAVES, smem, s>>>(P, K, base_color, roughness, normals, viewdirs, cprime, env4,
                                                                 He, We, visibility, dirs, frs_area(uniform_area), taps, tables, valid,
-                                                                out);
+                                                                out, frs_queue(s));
     check_launch(s, false, "shade_forward_frs_kernel");
 }
 
@@ -1268,7 +1290,7 @@ const unsigned int* launch_shade_frs_backward_aux(hipStream_t s, int P, const fl
     }
     const size_t ntexel = (size_t)He * We;
     float4* env4 = reinterpret_cast<float4*>(stream_scratch(s, 1, ntexel * sizeof(float4)));
-    shade_pad_env_kernel<<<(int)((ntexel + 255) / 256), 256, 0, s>>>((int)ntexel, env, env4);
+    shade_pad_env_kernel<<<(int)((ntexel + 255) / 256), 256, 0, s>>>((int)ntexel, env, env4, frs_queue(s));
     return gmax;
 }
 
@@ -1287,12 +1309,12 @@ void launch_shade_frs_backward_main(hipStream_t s, int P, int K, const float* ba
         const int grid = frs_grid(P, (const void*)shade_backward_frs_kernel<true>, smem);
         shade_backward_frs_kernel<true><<<grid, 64 * FRS_WAVES, smem, s>>>(
             P, K, base_color, roughness, normals, viewdirs, cprime, g_pbr, g_diff, env4, He, We, visibility, dirs,
-            frs_area(uniform_area), taps, tables, valid, d_base, d_rough, d_view, dcp, d_env, gmax, gmax_n);
+            frs_area(uniform_area), taps, tables, valid, d_base, d_rough, d_view, dcp, d_env, gmax, gmax_n, frs_queue(s));
     } else {
         const int grid = frs_grid(P, (const void*)shade_backward_frs_kernel<false>, smem);
         shade_backward_frs_kernel<false><<<grid, 64 * FRS_WAVES, smem, s>>>(
             P, K, base_color, roughness, normals, viewdirs, cprime, g_pbr, g_diff, env4, He, We, visibility, dirs,
-            frs_area(uniform_area), taps, tables, valid, d_base, d_rough, d_view, dcp, d_env, gmax, gmax_n);
+            frs_area(uniform_area), taps, tables, valid, d_base, d_rough, d_view, dcp, d_env, gmax, gmax_n, frs_queue(s));
     }
     check_launch(s, false, "shade_backward_frs_kernel");
 }

@@ -29,11 +29,6 @@ FWD_SIG = "__global__ void __launch_bounds__(64 * FRS_WAVES, 3)\nshade_forward_f
 VARIANTS = {
     # the committed kernels (git HEAD) beside the working tree's: same box, same run
     "frs_head": lambda: [(_cur("shading.hip"), _head("shading.hip"), None, "shading.hip"), (_cur(H), _head(H), None, H)],
-    # the next block's prefetch left to the scheduler (it sinks the loads into the block to save registers)
-    "frs_fwd_no_sched_barrier": lambda: [(SB_FWD, "", None, H)],
-    "frs_bwd_no_sched_barrier": lambda: [(SB_BWD, "            f32x4 l[3]", None, H)],
-    # forward at 2 waves per SIMD (256 registers) instead of 3
-    "frs_fwd_occ2": lambda: [(FWD_SIG, FWD_SIG.replace("FRS_WAVES, 3)", "FRS_WAVES, 2)"), None, H)],
 }
 
 
