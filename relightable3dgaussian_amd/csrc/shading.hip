@@ -668,11 +668,10 @@ shade_forward_row_kernel(int P, int K, int M_, const float* __restrict__ rec, co
 }
 
 __global__ void __launch_bounds__(256)
-shade_pad_env_kernel(int n, const float* __restrict__ env, float4* __restrict__ env4, unsigned int* __restrict__ queue = nullptr)
+shade_pad_env_kernel(int n, const float* __restrict__ env, float4* __restrict__ env4)
 {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i < n) env4[i] = make_float4(env[3 * i], env[3 * i + 1], env[3 * i + 2], 0.f);
-    if (i == 0 && queue != nullptr) *queue = 0u;      // the group queue of the fixed-ray-set kernel launched next (shading_frs.hpp)
 }
 
 // Backward: gradients of sum(pbr*g_pbr) + sum(diffuse_light*g_diff) w.r.t. base_color, roughness, viewdirs,
@@ -1177,9 +1176,6 @@ bool shade_frs_supported(int K, int M, int He, int We)
     return M == 16 && K >= 4 && (K % 4) == 0 && (size_t)He * We * (16 + 24) <= (size_t)ENV_LDS_MAX * 4;
 }
 
-// the group queue of the fixed-ray-set kernels: one word per (device, stream), zeroed by the padding kernel in front of each launch
-static unsigned int* frs_queue(hipStream_t s) { return reinterpret_cast<unsigned int*>(stream_scratch(s, 3, 256)); }
-
 // dynamic LDS of the two kernels: the texture as float4 texels (+ its 3 x 64-bit gradient accumulators), the per-wave staging
 // areas of the next group's per-Gaussian data, the backward's table words when they fit
 static size_t frs_forward_lds_bytes(int He, int We)
@@ -1240,7 +1236,7 @@ void launch_shade_frs_forward_aux(hipStream_t s, int P, const float* incidents, 
     if (P == 0) return;
     const size_t ntexel = (size_t)He * We;
     float4* env4 = reinterpret_cast<float4*>(stream_scratch(s, 1, ntexel * sizeof(float4)));
-    shade_pad_env_kernel<<<(int)((ntexel + 255) / 256), 256, 0, s>>>((int)ntexel, env, env4, frs_queue(s));
+    shade_pad_env_kernel<<<(int)((ntexel + 255) / 256), 256, 0, s>>>((int)ntexel, env, env4);
     frs_rotate_kernel<false><<<(P + 255) / 256, 256, 0, s>>>(P, ray_normals, incidents, cprime);
     check_launch(s, false, "frs_rotate_kernel");
 }
@@ -1258,7 +1254,7 @@ void launch_shade_frs_forward_main(hipStream_t s, int P, int K, const float* bas
     if (leave_room) grid = grid > shade_cus() * 2 ? shade_cus() * 2 : grid;      // the instance ordering runs beside it
     shade_forward_frs_kernel<<<grid, 64 * FRS_WAVES, smem, s>>>(P, K, base_color, roughness, normals, viewdirs, cprime, env4,
                                                                 He, We, visibility, dirs, frs_area(uniform_area), taps, tables, valid,
-                                                                out, frs_queue(s));
+                                                                out);
     check_launch(s, false, "shade_forward_frs_kernel");
 }
 
@@ -1290,7 +1286,7 @@ const unsigned int* launch_shade_frs_backward_aux(hipStream_t s, int P, const fl
     }
     const size_t ntexel = (size_t)He * We;
     float4* env4 = reinterpret_cast<float4*>(stream_scratch(s, 1, ntexel * sizeof(float4)));
-    shade_pad_env_kernel<<<(int)((ntexel + 255) / 256), 256, 0, s>>>((int)ntexel, env, env4, frs_queue(s));
+    shade_pad_env_kernel<<<(int)((ntexel + 255) / 256), 256, 0, s>>>((int)ntexel, env, env4);
     return gmax;
 }
 
@@ -1309,12 +1305,12 @@ void launch_shade_frs_backward_main(hipStream_t s, int P, int K, const float* ba
         const int grid = frs_grid(P, (const void*)shade_backward_frs_kernel<true>, smem);
         shade_backward_frs_kernel<true><<<grid, 64 * FRS_WAVES, smem, s>>>(
             P, K, base_color, roughness, normals, viewdirs, cprime, g_pbr, g_diff, env4, He, We, visibility, dirs,
-            frs_area(uniform_area), taps, tables, valid, d_base, d_rough, d_view, dcp, d_env, gmax, gmax_n, frs_queue(s));
+            frs_area(uniform_area), taps, tables, valid, d_base, d_rough, d_view, dcp, d_env, gmax, gmax_n);
     } else {
         const int grid = frs_grid(P, (const void*)shade_backward_frs_kernel<false>, smem);
         shade_backward_frs_kernel<false><<<grid, 64 * FRS_WAVES, smem, s>>>(
             P, K, base_color, roughness, normals, viewdirs, cprime, g_pbr, g_diff, env4, He, We, visibility, dirs,
-            frs_area(uniform_area), taps, tables, valid, d_base, d_rough, d_view, dcp, d_env, gmax, gmax_n, frs_queue(s));
+            frs_area(uniform_area), taps, tables, valid, d_base, d_rough, d_view, dcp, d_env, gmax, gmax_n);
     }
     check_launch(s, false, "shade_backward_frs_kernel");
 }

@@ -276,14 +276,6 @@ __device__ __forceinline__ void frs_stage_group(unsigned int sb /* LDS byte addr
     }
 }
 
-// next group of 16 Gaussians off the device-wide queue (one atomic per wave), uniform over the wave; >= ngroups: none left
-__device__ __forceinline__ int frs_next_group(unsigned int* __restrict__ queue, int lane)
-{
-    unsigned int v = 0;
-    if (lane == 0) v = atomicAdd(queue, 1u);
-    return (int)min((unsigned int)__builtin_amdgcn_readfirstlane((int)v), 0x7fffffffu);
-}
-
 // the staged first block as the register image frs_load_block gives (lane (gl, q): samples 4 q .. 4 q + 3 = floats 12 q .. of row gl)
 __device__ __forceinline__ FrsBlock frs_staged_block(const float* st, int gl, int q, int K)
 {
@@ -312,7 +304,7 @@ shade_forward_frs_kernel(int P, int K, const float* __restrict__ base_color, con
                          const float* __restrict__ cprime, const float4* __restrict__ env4, int He, int We,
                          const float* __restrict__ visibility, const float* __restrict__ dirs, float uniform_area,
                          const uint32_t* __restrict__ taps, const float* __restrict__ tables,
-                         const uint8_t* __restrict__ valid, float* __restrict__ out, unsigned int* __restrict__ queue)
+                         const uint8_t* __restrict__ valid, float* __restrict__ out)
 {
     extern __shared__ __attribute__((aligned(16))) float s_mem[];
     float4* s_env4 = reinterpret_cast<float4*>(s_mem);
@@ -325,21 +317,23 @@ shade_forward_frs_kernel(int P, int K, const float* __restrict__ base_color, con
     const int ngroups = (P + FRS_G - 1) / FRS_G;
     float* st = s_mem + 4 * He * We + wave * FRS_ST_FWD;                 // this wave's staging area
     const unsigned int st_addr = lds_address_of(st);
-    // Groups are handed out by a device-wide counter (*queue, zeroed by the launcher's texture-padding kernel): a static split
-    // of 18750 groups over 3072 persistent waves leaves 6 or 7 groups per wave, i.e. the last seventh of the kernel half idle.
-    int grp = frs_next_group(queue, lane);
+    // Static split of the groups over the persistent waves.  (A device-wide queue -- one atomicAdd per wave and group -- was
+    // measured: 0.283 instead of 0.154 ms.  22 000 atomics on one address retire ~35 ns apart, and each one, being older than the
+    // next block's table loads, is waited for in order.  The static split's tail -- 18750 groups over 3072 waves: 318 waves run a
+    // seventh group -- is cheaper than it looks: those waves then have their SIMD to themselves.)
+    const int gstride = gridDim.x * FRS_WAVES;
+    int grp = blockIdx.x * FRS_WAVES + wave;
     uint8_t nvalid = 0;
     if (grp < ngroups) {
         nvalid = valid[min(grp * FRS_G + gl, P - 1)];
         frs_stage_group<false>(st_addr, grp, P, lane, cprime, base_color, normals, viewdirs, roughness, nullptr, nullptr, K, dirs,
                                visibility, taps);
     }
-    while (grp < ngroups) {
+    for (; grp < ngroups; grp += gstride) {
         const int g = grp * FRS_G + gl;
         const int gc = min(g, P - 1);
         const bool live_g = g < P && nvalid != 0;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                 // this group's staged data have landed
-        const int ngrp_raw = frs_next_group(queue, lane);                // (asked now, needed in the last block)
         // per-Gaussian record
         float u[64];
 #pragma unroll
@@ -365,7 +359,7 @@ shade_forward_frs_kernel(int P, int K, const float* __restrict__ base_color, con
         const float nom1 = G.NoV * (1.f - G.kk) + G.kk;
         float acc[7] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
         const size_t row = (size_t)gc * (size_t)K;
-        int ngrp_l = min(ngrp_raw, ngroups - 1);                         // (past the end: a harmless reload of the last group)
+        int ngrp_l = min(grp + gstride, ngroups - 1);                    // (past the end: a harmless reload of the last group)
         int ngc_l = min(ngrp_l * FRS_G + gl, P - 1);
         for (int b = 0; b < nblk; b++) {
             const FrsBlock cur = nxt;
@@ -441,7 +435,6 @@ shade_forward_frs_kernel(int P, int K, const float* __restrict__ base_color, con
             for (int i = 0; i < 6; i++) o[i] = acc[i];
             o[18] = acc[6];
         }
-        grp = ngrp_raw;
     }
 }
 
@@ -461,7 +454,7 @@ shade_backward_frs_kernel(int P, int K, const float* __restrict__ base_color, co
                           const uint32_t* __restrict__ taps, const float* __restrict__ tables,
                           const uint8_t* __restrict__ valid, float* __restrict__ d_base, float* __restrict__ d_rough,
                           float* __restrict__ d_view, float* __restrict__ dcp, float* __restrict__ d_env,
-                          const unsigned int* __restrict__ gmax_bits, int gmax_n, unsigned int* __restrict__ queue)
+                          const unsigned int* __restrict__ gmax_bits, int gmax_n)
 {
     extern __shared__ __attribute__((aligned(16))) float s_mem[];
     const int ntexel = He * We;
@@ -486,19 +479,19 @@ shade_backward_frs_kernel(int P, int K, const float* __restrict__ base_color, co
     const int ngroups = (P + FRS_G - 1) / FRS_G;
     float* st = s_stage + wave * FRS_ST_BWD;                                     // this wave's staging area (frs_stage_group)
     const unsigned int st_addr = lds_address_of(st);
-    int grp = frs_next_group(queue, lane);                                       // (device-wide group queue: see the forward)
+    const int gstride = gridDim.x * FRS_WAVES;
+    int grp = blockIdx.x * FRS_WAVES + wave;
     uint8_t nvalid = 0;
     if (grp < ngroups) {
         nvalid = valid[min(grp * FRS_G + gl, P - 1)];
         frs_stage_group<true>(st_addr, grp, P, lane, cprime, base_color, normals, viewdirs, roughness, g_pbr, g_diff, K, dirs,
                               visibility, taps);
     }
-    while (grp < ngroups) {
+    for (; grp < ngroups; grp += gstride) {
         const int g = grp * FRS_G + gl;
         const int gc = min(g, P - 1);
         const bool live_g = g < P && nvalid != 0;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                         // this group's staged data have landed
-        const int ngrp_raw = frs_next_group(queue, lane);
         float u[64];
 #pragma unroll
         for (int c = 0; c < 3; c++) {
@@ -525,7 +518,7 @@ shade_backward_frs_kernel(int P, int K, const float* __restrict__ base_color, co
         f32x4 dcq[3] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};   // dL/dc'[4 q + v'][c]
         float accb[7] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};     // albedo 3, roughness, view direction 3
         const size_t row = (size_t)gc * (size_t)K;
-        int ngrp_l = min(ngrp_raw, ngroups - 1);                                 // (past the end: a harmless reload of the last group)
+        int ngrp_l = min(grp + gstride, ngroups - 1);                            // (past the end: a harmless reload of the last group)
         int ngc_l = min(ngrp_l * FRS_G + gl, P - 1);
         for (int b = 0; b < nblk; b++) {
             const FrsBlock cur = nxt;
@@ -674,7 +667,6 @@ shade_backward_frs_kernel(int P, int K, const float* __restrict__ base_color, co
             o[1] = make_float4(dcq[1][1], dcq[2][1], dcq[0][2], dcq[1][2]);
             o[2] = make_float4(dcq[2][2], dcq[0][3], dcq[1][3], dcq[2][3]);
         }
-        grp = ngrp_raw;
     }
     if (fixed) {
         __syncthreads();
