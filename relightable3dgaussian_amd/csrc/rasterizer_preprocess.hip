@@ -403,19 +403,18 @@ tile_order_kernel(int T, const uint2* __restrict__ ranges, uint32_t* __restrict_
     }
 }
 
-// ---- direct tile binning (R3DG_OPT_TILE_BINNING = 2, default) -----------------------------------------------------------------
+// ---- direct tile binning (r3dg_set_tuning4(2), default) ---------------------------------------------------------------------
 // The reference emits (tile | depth, index) pairs in Gaussian order and sorts them globally; the round-1 formulation emitted
 // them the same way, then histogrammed and partitioned them by tile id (duplicate -> hist -> scan -> scatter: the pairs are
 // written, read, read, written again before any tile sort sees them -- 0.17 ms inside the iteration).  Here the instances
 // go straight into their tile's segment:
-//   tile_count_kernel        per block of 2048+ Gaussians an LDS histogram of the tiles their rectangles cover, written out as
-//                            the block's row of a [blocks][T] table;
-//   tile_column_scan_kernel  per tile the exclusive scan of its column (instances from earlier blocks) + the tile's count;
-//   tile_scan_kernel         exclusive scan of the T tile counts = the tile RANGES (identifyTileRanges' result);
-//   tile_emit_kernel         LDS cursors start at (segment start + column prefix); every instance takes its slot with an LDS
-//                            atomic and is written ONCE, as the sort entry (depth bits << 32 | Gaussian index) the per-tile
-//                            sort wants.  No global atomic anywhere.
-// Order inside a block's run is arbitrary; the per-tile sort by the unique (depth, index) key makes the final lists
+//   tile_count_kernel   per block of 256 Gaussians an LDS histogram of the tiles their rectangles cover, flushed with one
+//                       global atomic per (block, touched tile);
+//   tile_scan_kernel    exclusive scan of the T tile counts = the tile RANGES (identifyTileRanges' result) + the cursors;
+//   tile_emit_kernel    the same LDS histogram again, ONE global atomic per (block, touched tile) reserves a run inside the
+//                       tile's segment, then every instance takes its slot with an LDS atomic and is written ONCE, as the
+//                       sort entry (depth bits << 32 | Gaussian index) the per-tile sort wants.
+// Order inside a tile is arbitrary here; the per-tile sort by the unique (depth, index) key makes the final lists
 // bit-identical to the reference's stable global sort.  Falls back to the round-1 path when T exceeds the LDS histogram.
 constexpr int BIN_MAX_TILES = 16384;           // 64 KB of LDS counters
 
@@ -452,14 +451,11 @@ __device__ __forceinline__ void for_each_tile(int idx, int P, const float2* __re
     }
 }
 
-// Each block takes `iters` x 1024 consecutive Gaussians, counts the tiles their rectangles cover in an LDS histogram and writes
-// the histogram out as ITS ROW of a [blocks][T] table -- no global atomics.  (Rounds 1-2 flushed the histogram with one
-// device-scope atomic per block and touched tile, here and again -- returning -- in the emit kernel: an unordered cloud touches
-// nearly every tile from every block, 2 x 367 000 atomics per frame at 300k Gaussians, and those are served by the memory side
-// of the fabric at a few per nanosecond for the whole device: 50 + 85 us of the forward's critical chain, 0.48 ms at 2 M.)
+// each block takes `iters` x 1024 consecutive Gaussians: the more Gaussians share one LDS histogram, the fewer global
+// atomics (one per block and touched tile; an unordered cloud touches nearly every tile from every block)
 __global__ void __launch_bounds__(BIN_THREADS)
 tile_count_kernel(int P, int T, int iters, const float2* __restrict__ means2D, const int* __restrict__ radii, int gx, int gy,
-                  uint32_t* __restrict__ block_hist)
+                  uint32_t* __restrict__ tile_counts)
 {
     extern __shared__ uint32_t s_bins[];
     for (int t = threadIdx.x; t < T; t += BIN_THREADS) s_bins[t] = 0;
@@ -469,35 +465,10 @@ tile_count_kernel(int P, int T, int iters, const float2* __restrict__ means2D, c
         for_each_tile(base + it * BIN_THREADS, P, means2D, radii, gx, gy,
                       [&](uint32_t tile, uint32_t) { atomicAdd(&s_bins[tile], 1u); });
     __syncthreads();
-    uint32_t* row = block_hist + (size_t)blockIdx.x * T;
-    for (int t = threadIdx.x; t < T; t += BIN_THREADS) row[t] = s_bins[t];
-}
-
-// thread per tile: exclusive scan of the tile's column of the table (block b's entry becomes the number of the tile's instances
-// that come from blocks before b) and the tile's total
-__global__ void __launch_bounds__(64)
-tile_column_scan_kernel(int T, int nblocks, uint32_t* __restrict__ block_hist, uint32_t* __restrict__ tile_counts)
-{
-    const int t = blockIdx.x * 64 + threadIdx.x;
-    if (t >= T) return;
-    uint32_t run = 0;
-    int b = 0;
-    for (; b + 4 <= nblocks; b += 4) {                    // four loads in flight per thread
-        uint32_t* p = block_hist + (size_t)b * T + t;
-        const uint32_t c0 = p[0], c1 = p[(size_t)T], c2 = p[2 * (size_t)T], c3 = p[3 * (size_t)T];
-        p[0] = run;
-        p[(size_t)T] = run + c0;
-        p[2 * (size_t)T] = run + c0 + c1;
-        p[3 * (size_t)T] = run + c0 + c1 + c2;
-        run += c0 + c1 + c2 + c3;
+    for (int t = threadIdx.x; t < T; t += BIN_THREADS) {
+        const uint32_t c = s_bins[t];
+        if (c) atomicAdd(&tile_counts[t], c);
     }
-    for (; b < nblocks; b++) {
-        uint32_t* p = block_hist + (size_t)b * T + t;
-        const uint32_t c = *p;
-        *p = run;
-        run += c;
-    }
-    tile_counts[t] = run;
 }
 
 // one 1024-thread block: ranges[t] = (start, end), cursor[t] = start
@@ -539,14 +510,15 @@ tile_scan_kernel(int T, const uint32_t* __restrict__ tile_counts, uint2* __restr
 __global__ void __launch_bounds__(BIN_THREADS)
 tile_emit_kernel(int P, int T, int iters, const float2* __restrict__ means2D, const float* __restrict__ depths,
                  const int* __restrict__ radii, const uint32_t* __restrict__ tiles_touched,
-                 const uint32_t* __restrict__ block_offsets, int gx, int gy, const uint32_t* __restrict__ cursor,
-                 const uint32_t* __restrict__ block_hist, uint32_t* __restrict__ point_offsets,
-                 uint64_t* __restrict__ entries, const unsigned long long* __restrict__ total, long long capacity)
+                 const uint32_t* __restrict__ block_offsets, int gx, int gy, uint32_t* __restrict__ cursor,
+                 uint32_t* __restrict__ point_offsets, uint64_t* __restrict__ entries,
+                 const unsigned long long* __restrict__ total, long long capacity)
 {
     extern __shared__ uint32_t s_bins[];
     __shared__ uint32_t s_wave[BIN_THREADS / 64];
     const bool over = capacity >= 0 && *total > (unsigned long long)capacity;      // see tile_scan_kernel
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int t = threadIdx.x; t < T; t += BIN_THREADS) s_bins[t] = 0;
     const int base = blockIdx.x * iters * BIN_THREADS + threadIdx.x;
     // GeometryState::point_offsets (inclusive scan of tiles_touched, rasterizer_impl.cu:283-287): part of the state parity.
     // block_offsets are preprocess' exclusive sums per 256 Gaussians = 4 waves.
@@ -564,9 +536,14 @@ tile_emit_kernel(int P, int T, int iters, const float2* __restrict__ means2D, co
         }
     }
     if (over) return;
-    // this block's run inside tile t's segment starts at (start of the segment) + (instances of the tile from earlier blocks)
-    const uint32_t* row = block_hist + (size_t)blockIdx.x * T;
-    for (int t = threadIdx.x; t < T; t += BIN_THREADS) s_bins[t] = cursor[t] + row[t];
+    for (int it = 0; it < iters; it++)
+        for_each_tile(base + it * BIN_THREADS, P, means2D, radii, gx, gy,
+                      [&](uint32_t tile, uint32_t) { atomicAdd(&s_bins[tile], 1u); });
+    __syncthreads();
+    for (int t = threadIdx.x; t < T; t += BIN_THREADS) {
+        const uint32_t c = s_bins[t];
+        if (c) s_bins[t] = atomicAdd(&cursor[t], c);           // this block's run inside tile t's segment
+    }
     __syncthreads();
     for (int it = 0; it < iters; it++)
         for_each_tile(base + it * BIN_THREADS, P, means2D, radii, gx, gy, [&](uint32_t tile, uint32_t g) {
@@ -583,10 +560,8 @@ void launch_tile_binning(hipStream_t s, int P, int T, const float* means2D, cons
                          uint32_t* point_offsets, uint64_t* entries, const unsigned long long* total, long long capacity,
                          float* overflow_flag, unsigned int* overflow_count)
 {
-    // Gaussians per block: g_bin_iters x 1024, more when that would be more blocks than CUs (every block adds a row of T words to
-    // the table the column scan walks)
-    int iters = g_bin_iters;
-    while ((P + iters * BIN_THREADS - 1) / (iters * BIN_THREADS) > 256 && iters < 64) iters *= 2;
+    R3DG_HIP(hipMemsetAsync(tile_counts, 0, (size_t)T * 4, s));
+    const int iters = g_bin_iters;
     const int per_block = iters * BIN_THREADS;
     const int nb = (P + per_block - 1) / per_block;
     const size_t smem = (size_t)T * 4;
@@ -596,14 +571,11 @@ void launch_tile_binning(hipStream_t s, int P, int T, const float* means2D, cons
         R3DG_HIP(hipFuncSetAttribute((const void*)tile_emit_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, BIN_MAX_TILES * 4));
         attr = true;
     }
-    uint32_t* block_hist = (uint32_t*)stream_scratch(s, 4, (size_t)nb * T * 4);      // [blocks][T], lives for this call only
-    tile_count_kernel<<<nb, BIN_THREADS, smem, s>>>(P, T, iters, (const float2*)means2D, radii, gx, gy, block_hist);
-    tile_column_scan_kernel<<<(T + 63) / 64, 64, 0, s>>>(T, nb, block_hist, tile_counts);
+    tile_count_kernel<<<nb, BIN_THREADS, smem, s>>>(P, T, iters, (const float2*)means2D, radii, gx, gy, tile_counts);
     tile_scan_kernel<<<1, 1024, 0, s>>>(T, tile_counts, (uint2*)ranges, cursor, total, capacity, overflow_flag,
                                         overflow_count);
     tile_emit_kernel<<<nb, BIN_THREADS, smem, s>>>(P, T, iters, (const float2*)means2D, depths, radii, tiles_touched,
-                                                  block_offsets, gx, gy, cursor, block_hist, point_offsets, entries, total,
-                                                  capacity);
+                                                  block_offsets, gx, gy, cursor, point_offsets, entries, total, capacity);
 }
 
 int tile_binning_max_tiles() { return BIN_MAX_TILES; }
