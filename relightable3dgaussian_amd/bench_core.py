@@ -281,7 +281,8 @@ def pmc_valu(stage):
             v = doc["kernels"].get(name)
             if v is not None:
                 out = {k: v[k] for k in ("valu_issue_frac", "valu_busy_frac", "waves_per_simd", "lds_bank_conflict_frac",
-                                         "vgprs", "lds_bytes") if k in v}
+                                         "lds_issue_frac", "trans_frac", "mfma_busy_frac", "salu_issue_frac", "wait_frac",
+                                         "issue_stall_frac", "wait_lds_frac", "vgprs", "lds_bytes") if k in v}
                 out["kernel"] = name
                 out["source"] = os.path.basename(files[-1])
                 return out

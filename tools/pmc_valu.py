@@ -13,6 +13,9 @@ Derived figures (raw counter means are kept beside them so they can be recompute
   waves_per_simd          = 4*SQ_WAVE_CYCLES / (1024 * cycles)                 (mean resident waves per SIMD)
   wait_frac / issue_stall_frac / active_frac = SQ_WAIT_ANY, SQ_WAIT_INST_ANY, SQ_ACTIVE_INST_ANY over SQ_WAVE_CYCLES
   lds_bank_conflict_frac  = SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE           (conflict cycles per LDS-active cycle)
+  lds_issue_frac / trans_frac / mfma_busy_frac / salu_issue_frac = 4*SQ_ACTIVE_INST_LDS, 16*SQ_INSTS_VALU_TRANS_F32,
+                            SQ_VALU_MFMA_BUSY_CYCLES, SQ_INSTS_SALU over (1024 SIMDs * cycles); wait_lds_frac = SQ_WAIT_INST_LDS /
+                            SQ_WAVE_CYCLES
 with cycles = GRBM_GUI_ACTIVE of the same pass."""
 import json
 import re
@@ -83,6 +86,19 @@ def main():
             for key, c in (("wait_frac", "SQ_WAIT_ANY"), ("issue_stall_frac", "SQ_WAIT_INST_ANY"), ("active_frac", "SQ_ACTIVE_INST_ANY")):
                 if c in m:
                     row[key] = round(m[c] / m["SQ_WAVE_CYCLES"], 4)
+        if gui:
+            # shares of the SIMDs' time the other issue ports are busy: LDS instructions in flight, the
+            # quarter-rate transcendental unit (a wave64 v_exp / v_rcp / v_rsq occupies it 16 cycles), the matrix pipe
+            if "SQ_ACTIVE_INST_LDS" in m:
+                row["lds_issue_frac"] = round(4 * m["SQ_ACTIVE_INST_LDS"] / (simd * cyc), 4)
+            if "SQ_INSTS_VALU_TRANS_F32" in m:
+                row["trans_frac"] = round(16 * m["SQ_INSTS_VALU_TRANS_F32"] / (simd * cyc), 4)
+            if "SQ_VALU_MFMA_BUSY_CYCLES" in m:
+                row["mfma_busy_frac"] = round(m["SQ_VALU_MFMA_BUSY_CYCLES"] / (simd * cyc), 4)
+            if "SQ_INSTS_SALU" in m:
+                row["salu_issue_frac"] = round(m["SQ_INSTS_SALU"] / (simd * cyc), 4)
+        if m.get("SQ_WAVE_CYCLES") and "SQ_WAIT_INST_LDS" in m:
+            row["wait_lds_frac"] = round(m["SQ_WAIT_INST_LDS"] / m["SQ_WAVE_CYCLES"], 4)
         if m.get("SQ_LDS_IDX_ACTIVE") and "SQ_LDS_BANK_CONFLICT" in m:
             row["lds_bank_conflict_frac"] = round(m["SQ_LDS_BANK_CONFLICT"] / m["SQ_LDS_IDX_ACTIVE"], 4)
         if res is not None:

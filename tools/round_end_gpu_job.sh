@@ -1,11 +1,13 @@
-# Round-end evidence job (MI355X, via gpurun): full GPU suite, rocprofv3 kernel stats (training iteration and relight frame),
-# PMC passes (VALU/LDS evidence, HBM traffic, trace kernels: ONE counter group per pass, --kernel-trace only), default bench.
-# Outputs land in gpurun_out/; the round's summaries are copied to profiles/ by hand (see profiles/README.md).
+# Round-end evidence job (MI355X, via gpurun): full GPU suite, parity logs against the real reference build, rocprofv3 kernel stats
+# (training iteration and relight frame), PMC passes (SQ counters and HBM traffic: ONE counter group per pass, --kernel-trace only),
+# the default bench line.  Outputs land in gpurun_out/; the round's summaries are copied to profiles/ (see profiles/README.md).
 set -x
 cd /root/repo
 mkdir -p gpurun_out
+export TMPDIR=/tmp HSA_ENABLE_IPC_MODE_LEGACY=0
 timeout 1500 python -m pytest tests -m gpu -q -p no:cacheprovider < /dev/null > gpurun_out/pytest_gpu.log 2>&1; tail -3 gpurun_out/pytest_gpu.log
-export TMPDIR=/tmp
+timeout 600 python -m pytest tests/test_reference_gpu.py -q -s -p no:cacheprovider -k "baseline_sizes or bvh" < /dev/null > gpurun_out/parity_reference.log 2>&1; tail -2 gpurun_out/parity_reference.log
+timeout 600 python -m pytest tests/test_reference_pipeline_gpu.py tests/test_psnr_vs_reference_gpu.py -q -s -p no:cacheprovider < /dev/null > gpurun_out/parity_pipeline.log 2>&1; tail -2 gpurun_out/parity_pipeline.log
 cd /tmp
 CMD="python /root/repo/bench.py --steps 20 --warmup 5 --no-cpu-baseline --relight-frames 0 --no-other-configs --repeats 0"
 rm -rf /tmp/prof
@@ -34,12 +36,13 @@ done
 cd /root/repo
 python tools/pmc_traffic.py gpurun_out/pmc_traffic.json "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE collected in SEPARATE passes (tools/kbench_raster.py S=16, tools/kbench_shade.py K=64; P=300000, 800x800, R~1.77M), mean per launch" $dbs < /dev/null
 cd /tmp
-# VALU / LDS evidence: one SQ counter group per pass
+# SQ counters: one group per pass
 GA="SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_ANY GRBM_GUI_ACTIVE"
 GB="SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_INSTS_SALU SQ_INSTS_VMEM SQ_INSTS_VALU_TRANS_F32 SQ_WAIT_INST_LDS GRBM_GUI_ACTIVE"
+GC="SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_SCA SQ_INSTS_SMEM SQ_ACTIVE_INST_MISC SQ_INSTS_BRANCH SQ_WAVE_CYCLES GRBM_GUI_ACTIVE"
 dbs=""
 i=0
-for grp in "$GA" "$GB"; do
+for grp in "$GA" "$GB" "$GC"; do
   i=$((i+1))
   for w in raster shade; do
     rm -rf /tmp/pv_${i}_${w}
@@ -50,19 +53,7 @@ done
 cd /root/repo
 python tools/kernel_resources.py gpurun_out/kernel_resources.json < /dev/null
 python tools/pmc_valu.py gpurun_out/pmc_valu.json "rocprofv3 --pmc <one SQ counter group per pass> --kernel-trace on tools/kbench_raster.py (S=16) and tools/kbench_shade.py (K=64); P=300000, 800x800, R~1.77M; mean per dispatch" --resources gpurun_out/kernel_resources.json $dbs < /dev/null
-cd /tmp
-GC="TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum GRBM_GUI_ACTIVE"
-dbs=""
-i=0
-for grp in "$GA" "$GC"; do
-  i=$((i+1))
-  rm -rf /tmp/pt_${i}
-  timeout 250 rocprofv3 --pmc $grp --kernel-trace -d /tmp/pt_${i} -o p -- python /root/repo/tools/kbench_trace.py < /dev/null > /tmp/pt.log 2>&1
-  dbs="$dbs $(find /tmp/pt_${i} -name '*.db' | head -1)"
-done
-cd /root/repo
-python tools/pmc_valu.py gpurun_out/pmc_trace.json "visibility trace kernels, tools/kbench_trace.py (P=300000, K=64; tuning8 = 4, 3, 2, 0 in turn), mean per dispatch (3 dispatches of 100k bundles per update)" $dbs < /dev/null
-[ -x tools/pk_rate ] || /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -o tools/pk_rate tools/pk_rate.hip > /dev/null 2>&1
-./tools/pk_rate > gpurun_out/pk_rate.txt 2>&1
-timeout 600 python bench.py < /dev/null > gpurun_out/bench_default.log 2>&1; tail -1 gpurun_out/bench_default.log > gpurun_out/bench_default.json
+cp gpurun_out/pmc_valu.json profiles/r03_pmc_valu.json; cp gpurun_out/pmc_traffic.json profiles/r03_pmc_traffic.json   # (the bench line below quotes them)
+timeout 700 python bench.py < /dev/null > gpurun_out/bench_default.log 2>&1; tail -1 gpurun_out/bench_default.log > gpurun_out/bench_default.json
 cut -c1-300 gpurun_out/bench_default.json
+cp profiles/r03_pmc_valu.json gpurun_out/r03_pmc_valu.json
