@@ -776,7 +776,7 @@ trace_opacity_persistent_kernel(int num_rays, int P, const TNode* __restrict__ t
     if (lost) atomicAdd(overflow, 1);
 }
 
-// ---- phase-separated persistent traversal (r3dg_set_tuning8(4), default) -----------------------------------------------------
+// ---- phase-separated persistent traversal (R3DG_OPT_TRACE_FORMULATION = 4, default) -----------------------------------------------------
 // In the kernel above every loop iteration executes BOTH the leaf body (Gaussian response, ~60 VALU) and the node body (two
 // slab tests, ~70 VALU) whenever a wave holds lanes of either kind, which is nearly always: each lane advances one step for
 // the price of two.  Here each lane keeps its current node in a register and the wave VOTES per iteration: the body with

@@ -403,7 +403,7 @@ tile_order_kernel(int T, const uint2* __restrict__ ranges, uint32_t* __restrict_
     }
 }
 
-// ---- direct tile binning (r3dg_set_tuning4(2), default) ---------------------------------------------------------------------
+// ---- direct tile binning (R3DG_OPT_TILE_BINNING = 2, default) -----------------------------------------------------------------
 // The reference emits (tile | depth, index) pairs in Gaussian order and sorts them globally; the round-1 formulation emitted
 // them the same way, then histogrammed and partitioned them by tile id (duplicate -> hist -> scan -> scatter: the pairs are
 // written, read, read, written again before any tile sort sees them -- 0.17 ms inside the iteration).  Here the instances
@@ -593,7 +593,7 @@ void launch_mark_visible(hipStream_t s, int P, const float* means3D, const float
     mark_visible_kernel<<<(P + 255) / 256, 256, 0, s>>>(P, means3D, vm, present);
 }
 
-extern int g_stage_sh_rows;     // rasterizer_preprocess_bwd.hip (r3dg_set_tuning5)
+extern int g_stage_sh_rows;     // rasterizer_preprocess_bwd.hip (R3DG_OPT_STAGE_SH_ROWS)
 
 void launch_preprocess(hipStream_t s, int P, int D, int M, const float* means3D, const float* scales,
                        float scale_modifier, const float* rotations, const float* opacities, const float* shs,

@@ -294,7 +294,7 @@ preprocess_backward_kernel(int P, int D, int M, const float* __restrict__ means,
     }
 }
 
-int g_stage_sh_rows = 1;        // r3dg_set_tuning5: 1 = SH / dL_dsh rows through LDS (default), 0 = direct per-thread walks
+int g_stage_sh_rows = 1;        // R3DG_OPT_STAGE_SH_ROWS: 1 = SH / dL_dsh rows through LDS (default), 0 = direct per-thread walks
 static inline int staged_row_stride_host(int row_floats) { return row_floats | 1; }
 
 void launch_preprocess_backward(hipStream_t s, int P, int D, int M, const float* means, const int* radii,

@@ -300,9 +300,9 @@ pseudo_normal_kernel(int W, int H, const float* __restrict__ vm, float* __restri
 }
 
 // ---- launchers ------------------------------------------------------------------------------------------
-int g_fwd_wave8x8 = 1;  // 1-pixel-per-lane kernel: wave = 8x8 pixel block (1) or 16x4 strip (0); r3dg_set_tuning3()
+int g_fwd_wave8x8 = 1;  // 1-pixel-per-lane kernel: wave = 8x8 pixel block (1) or 16x4 strip (0); R3DG_OPT_FWD_WAVE8X8
 int g_cull = 1;         // per-wave conservative sub-tile cull of staged entries (results do not depend on it)
-int g_fwd_ppl = 1;   // pixels per lane; tunable through r3dg_set_tuning()
+int g_fwd_ppl = 1;   // pixels per lane; R3DG_OPT_FWD_PIXELS_PER_LANE
 int g_fwd_unroll = 4;   // staged entries evaluated per inner-loop step (1 = entry-at-a-time)
 
 template <int SPAD, int PPL>

@@ -10,8 +10,6 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with `-m gpu` through gpurun)")
-    # R3DG_EXPERIMENTAL=1 additionally runs the parity tests of opt-in kernels that were written without GPU access and have
-    # not had their first hardware run (they are default-off in the product; tools/gpu_job_experimental.sh is that first run)
 
 
 @pytest.fixture(scope="session", autouse=True)
