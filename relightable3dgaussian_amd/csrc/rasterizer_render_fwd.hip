@@ -249,6 +249,165 @@ render_forward_kernel(const uint2* __restrict__ ranges, const uint32_t* __restri
     }
 }
 
+// ---- the same blend with DECOUPLED waves (R3DG_OPT_FWD_DECOUPLED) ----------------------------------------------------------------
+// render_forward_kernel advances the four waves of a tile round by round: 256 entries staged by all, two workgroup barriers per
+// round, every wave waiting for the one whose 8x8 block has the most candidates.  PMC: the VALU is the
+// busiest unit at 54 %, the waves spend half their life in s_waitcnt, 2.8 resident per SIMD.  Here ONE WAVE IS ONE WORKGROUP:
+// it owns an 8x8 pixel block, walks the tile's sorted list 64 entries at a time by itself, culls every entry against its own
+// box while the records are still in registers and stages only the survivors (compacted, with their colour / feature rows) in
+// its private 7 KB of LDS -- no barrier anywhere, rounds of different blocks of a tile drift apart freely, 4x as many
+// workgroups for the dispatcher to balance.  Price: every block reads the 32 geometry bytes of every entry of its tile (4x; the
+// four blocks of a tile are placed on ONE XCD so the repeats are L2 hits) and the cull arithmetic is not shared.  Same
+// arithmetic per (pixel, entry) in the same order: identical outputs.
+template <int SPAD, int U>
+__global__ void __launch_bounds__(64)
+render_forward_wave_kernel(const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list, int S, int W, int H,
+                           int tiles_x, int num_tiles, int cull, const uint32_t* __restrict__ tile_order,
+                           const float4* __restrict__ splat, const float* __restrict__ features, float* __restrict__ final_T,
+                           uint32_t* __restrict__ n_contrib, const float* __restrict__ bg_color, float* __restrict__ out_color,
+                           float* __restrict__ out_opacity, float* __restrict__ out_depth, float* __restrict__ out_feature,
+                           float* __restrict__ out_weights)
+{
+    constexpr int PAY = 4 + SPAD;       // r, g, b, (position of the entry in its round), features[SPAD]
+    // workgroup b runs on XCD b % 8: the four blocks of a tile get workgroups 8 apart (same XCD, dispatched together)
+    const int xcd = (int)(blockIdx.x & 7u), j = (int)(blockIdx.x >> 3), sub = j & 3, rank = (j >> 2) * 8 + xcd;
+    if (rank >= num_tiles) return;
+    const int tile = tile_order != nullptr ? (int)tile_order[rank] : rank;
+    const int tile_x = tile % tiles_x, tile_y = tile / tiles_x;
+
+    __shared__ float4 s_geo0[64];                 // mean.x, mean.y, conic.x, conic.y
+    __shared__ float4 s_geo1[64];                 // conic.z, opacity, depth, id bits
+    __shared__ __attribute__((aligned(16))) float s_pay[64 * PAY];
+
+    const int lane = threadIdx.x;
+    const int bx = 8 * (sub & 1), by = 8 * (sub >> 1);
+    const int px = tile_x * R3DG_TILE_X + bx + (lane & 7);
+    const int py = tile_y * R3DG_TILE_Y + by + (lane >> 3);
+    const float pxf = (float)px, pyf = (float)py;
+    const float x0 = (float)(tile_x * R3DG_TILE_X + bx), y0 = (float)(tile_y * R3DG_TILE_Y + by);
+
+    const uint2 range = ranges[tile];
+    const int n = (int)(range.y - range.x);
+    const bool inside = px < W && py < H;
+    bool done = !inside;
+    float T = 1.0f, C[3] = {0.f, 0.f, 0.f}, F[SPAD > 0 ? SPAD : 1], Dp = 0.f, Op = 0.f;
+    uint32_t last = 0;
+#pragma unroll
+    for (int ch = 0; ch < SPAD; ch++) F[ch] = 0.f;
+
+    for (int base = 0; base < n; base += 64) {
+        if (__ballot(!done) == 0ull) break;                     // this block's pixels are all finished
+        // ---- one entry per lane: record, cull against this block's box, survivors compacted into LDS ----
+        const bool have = base + lane < n;
+        bool cand = false;
+        uint32_t g = 0;
+        float4 r0 = make_float4(0.f, 0.f, 0.f, 0.f), r1 = r0;
+        if (have) {
+            g = point_list[range.x + base + lane];
+            const float4* rec = splat + 4 * (size_t)g;
+            r0 = rec[0];
+            r1 = rec[1];
+            cand = cull == 0 || splat_may_touch(r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, x0, x0 + 7.f, y0, y0 + 7.f);
+        }
+        const unsigned long long m = __ballot(cand);
+        const int ncand = __popcll(m);
+        if (cand) {
+            const int slot = __popcll(m & ((1ull << lane) - 1ull));
+            const float4 r2 = splat[4 * (size_t)g + 2];
+            s_geo0[slot] = r0;
+            s_geo1[slot] = make_float4(r1.x, r1.y, r1.z, __uint_as_float(g));
+            float* pay = s_pay + slot * PAY;
+            *reinterpret_cast<float4*>(pay) = make_float4(r2.x, r2.y, r2.z, __uint_as_float((uint32_t)lane));
+            if constexpr (SPAD > 0) {
+                const float* f = features + (size_t)g * S;
+                if ((S & 3) == 0) {
+#pragma unroll
+                    for (int q = 0; q < SPAD / 4; q++) {
+                        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                        if (4 * q < S) v = *reinterpret_cast<const float4*>(f + 4 * q);
+                        *reinterpret_cast<float4*>(pay + 4 + 4 * q) = v;
+                    }
+                } else {
+#pragma unroll
+                    for (int ch = 0; ch < SPAD; ch++) pay[4 + ch] = ch < S ? f[ch] : 0.f;
+                }
+            }
+        }
+        __builtin_amdgcn_wave_barrier();          // (the wave's LDS operations execute in order: a compiler fence is all it takes)
+
+        for (int k0 = 0; k0 < ncand; k0 += U) {
+            if (__ballot(!done) == 0ull) break;
+            float4 g0[U], g1[U];
+            float alpha[U];
+            bool valid[U];
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                valid[u] = k0 + u < ncand;
+                const int jj = valid[u] ? k0 + u : k0;      // tail: re-read, ignored below
+                g0[u] = s_geo0[jj];
+                g1[u] = s_geo1[jj];
+            }
+            bool any_alpha = false;
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                const float dx = g0[u].x - pxf, dy = g0[u].y - pyf;
+                const float power = -0.5f * (g0[u].z * dx * dx + g1[u].x * dy * dy) - g0[u].w * dx * dy;
+                float a = fminf(0.99f, g1[u].y * fast_exp(power));
+                if (power > 0.0f || a < 1.0f / 255.0f || !valid[u]) a = 0.f;
+                alpha[u] = a;
+                any_alpha = any_alpha || (a != 0.f && !done);
+            }
+            if (__ballot(any_alpha) == 0ull) continue;
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                if (!valid[u]) break;
+                const float test_T = T * (1.f - alpha[u]);
+                const bool hit = !done && alpha[u] != 0.f;
+                const bool blend = hit && !(test_T < 0.0001f);
+                done = done || (hit && !blend);
+                const float w = blend ? alpha[u] * T : 0.f;
+                T = blend ? test_T : T;
+                if (__ballot(blend) == 0ull) continue;      // nobody in this block blends this Gaussian
+                const float* pay = s_pay + (k0 + u) * PAY;
+                const float4 c4 = *reinterpret_cast<const float4*>(pay);
+                last = blend ? (uint32_t)base + __float_as_uint(c4.w) + 1u : last;
+                C[0] += c4.x * w;
+                C[1] += c4.y * w;
+                C[2] += c4.z * w;
+                Dp += g1[u].z * w;
+                Op += w;
+#pragma unroll
+                for (int q = 0; q < SPAD / 4; q++) {
+                    const float4 f4 = *reinterpret_cast<const float4*>(pay + 4 + 4 * q);
+                    F[4 * q + 0] += f4.x * w;
+                    F[4 * q + 1] += f4.y * w;
+                    F[4 * q + 2] += f4.z * w;
+                    F[4 * q + 3] += f4.w * w;
+                }
+                if (out_weights != nullptr) {
+                    const float wtot = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(wave_sum_to_lane63(w)), 63));
+                    if (lane == 0) atomicAdd(&out_weights[__float_as_uint(g1[u].w)], wtot);
+                }
+            }
+        }
+        __builtin_amdgcn_wave_barrier();          // (reads of this round before the next round's staging writes)
+    }
+
+    if (inside) {
+        const size_t HW = (size_t)H * W, pix = (size_t)py * W + px;
+        final_T[pix] = T;
+        n_contrib[pix] = last;
+        out_color[pix] = C[0] + T * bg_color[0];
+        out_color[HW + pix] = C[1] + T * bg_color[1];
+        out_color[2 * HW + pix] = C[2] + T * bg_color[2];
+#pragma unroll
+        for (int ch = 0; ch < SPAD; ch++)
+            if (ch < S) out_feature[(size_t)ch * HW + pix] = F[ch];
+        out_depth[pix] = Dp;
+        out_opacity[pix] = Op;
+    }
+}
+
 // K9: surface point in camera space from the premultiplied depth / opacity buffers (forward.cu:398-425)
 __global__ void __launch_bounds__(256)
 surface_xyz_kernel(int W, int H, float focal_x, float focal_y, float cx, float cy, const float* __restrict__ opacities,
@@ -304,6 +463,7 @@ int g_fwd_wave8x8 = 1;  // 1-pixel-per-lane kernel: wave = 8x8 pixel block (1) o
 int g_cull = 1;         // per-wave conservative sub-tile cull of staged entries (results do not depend on it)
 int g_fwd_ppl = 1;   // pixels per lane; R3DG_OPT_FWD_PIXELS_PER_LANE
 int g_fwd_unroll = 4;   // staged entries evaluated per inner-loop step (1 = entry-at-a-time)
+int g_fwd_decoupled = 0;   // R3DG_OPT_FWD_DECOUPLED: 1 = one wave per 8x8 block walking the tile's list on its own (render_forward_wave_kernel)
 
 template <int SPAD, int PPL>
 static void launch_fwd_inst(hipStream_t s, int T, int tiles_x, const uint32_t* tile_order, const uint32_t* ranges,
@@ -312,6 +472,13 @@ static void launch_fwd_inst(hipStream_t s, int T, int tiles_x, const uint32_t* t
                             float* out_depth, float* out_feature, float* out_weights)
 {
     const int chunk = (T + 7) / 8;
+    if (PPL == 1 && g_fwd_decoupled) {
+        // 4 single-wave workgroups per tile, tile ranks padded to a multiple of 8 (see the kernel's index mapping)
+        render_forward_wave_kernel<SPAD, 4><<<chunk * 8 * 4, 64, 0, s>>>(
+            (const uint2*)ranges, point_list, S, W, H, tiles_x, T, g_cull, tile_order, (const float4*)splat, features, final_T,
+            n_contrib, bg, out_color, out_opacity, out_depth, out_feature, out_weights);
+        return;
+    }
 #define R3DG_FWD_LAUNCH(U)                                                                                            \
     render_forward_kernel<SPAD, PPL, U><<<chunk * 8, 256 / PPL, 0, s>>>(                                              \
         (const uint2*)ranges, point_list, S, W, H, tiles_x, T, chunk, g_fwd_wave8x8, g_cull, tile_order,              \

@@ -280,6 +280,26 @@ def test_parity_wave_shape_and_cull(fw8, bw8, cull, hip_lib):
         _opt(FWD_WAVE8X8=1, BWD_WAVE8X8=1, CULL=1)
 
 
+@pytest.mark.parametrize("name", ["S16", "big_splats", "ragged_image", "camera_inside", "S0", "S28", "S33"])
+@pytest.mark.parametrize("cull", [1, 0])
+def test_forward_with_decoupled_waves(name, cull, hip_lib):
+    """R3DG_OPT_FWD_DECOUPLED: one wave per 8x8 block walking the tile's list on its own (render_forward_wave_kernel) -- same
+    parity bar against the oracle as the default kernel, and the same outputs as the default kernel (same arithmetic per
+    (pixel, entry) in the same order: the blend buffers may differ by FMA contraction only)."""
+    case = make_case(**CASES[name])
+    ref = _run_forward(case)
+    _opt(FWD_DECOUPLED=1, CULL=cull)
+    try:
+        out, _ = _check_forward(case, "%s_decoupled_cull%d" % (name, cull))
+    finally:
+        _opt(FWD_DECOUPLED=0, CULL=1)
+    torch.cuda.synchronize()
+    assert torch.equal(out[1], ref[1]), "n_contrib differs from the default forward kernel"
+    for i in (2, 3, 4, 5, 8):
+        if ref[i].numel():
+            assert torch.allclose(out[i], ref[i], rtol=2e-6, atol=2e-6), (i, float((out[i] - ref[i]).abs().max()))
+
+
 @pytest.mark.parametrize("name", ["S16", "big_splats", "ragged_image", "camera_inside", "S0"])
 @pytest.mark.parametrize("binning", [0, 1, 2])
 def test_tile_binned_order_equals_global_sort(name, binning, hip_lib):
