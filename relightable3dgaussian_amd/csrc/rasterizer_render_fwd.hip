@@ -295,45 +295,85 @@ render_forward_wave_kernel(const uint2* __restrict__ ranges, const uint32_t* __r
 #pragma unroll
     for (int ch = 0; ch < SPAD; ch++) F[ch] = 0.f;
 
-    for (int base = 0; base < n; base += 64) {
-        if (__ballot(!done) == 0ull) break;                     // this block's pixels are all finished
-        // ---- one entry per lane: record, cull against this block's box, survivors compacted into LDS ----
-        const bool have = base + lane < n;
-        bool cand = false;
-        uint32_t g = 0;
-        float4 r0 = make_float4(0.f, 0.f, 0.f, 0.f), r1 = r0;
-        if (have) {
-            g = point_list[range.x + base + lane];
-            const float4* rec = splat + 4 * (size_t)g;
-            r0 = rec[0];
-            r1 = rec[1];
-            cand = cull == 0 || splat_may_touch(r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, x0, x0 + 7.f, y0, y0 + 7.f);
-        }
+    // Software pipeline over the rounds of 64 entries (all global latency sits behind the blend of the round before):
+    //   index of round r+2 and records of round r+1 are in flight / in registers while round r is blended;
+    //   the cull of round r+1 runs BEFORE the blend of round r, so that the colour / feature rows of its survivors load under it;
+    //   they are written to LDS (compacted) after the blend of round r.
+    auto load_index = [&](int base_) -> uint32_t {
+        return base_ + lane < n ? point_list[range.x + base_ + lane] : 0u;
+    };
+    uint32_t g_cur = load_index(0);                      // Gaussian of this lane's entry, round being staged
+    float4 r0 = splat[4 * (size_t)g_cur], r1 = splat[4 * (size_t)g_cur + 1];
+    uint32_t g_nxt = load_index(64);
+    // stage round 0
+    int ncand;
+    {
+        const bool cand = lane < n && (cull == 0 || splat_may_touch(r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, x0, x0 + 7.f, y0, y0 + 7.f));
         const unsigned long long m = __ballot(cand);
-        const int ncand = __popcll(m);
+        ncand = __popcll(m);
         if (cand) {
             const int slot = __popcll(m & ((1ull << lane) - 1ull));
-            const float4 r2 = splat[4 * (size_t)g + 2];
+            const float4 r2 = splat[4 * (size_t)g_cur + 2];
             s_geo0[slot] = r0;
-            s_geo1[slot] = make_float4(r1.x, r1.y, r1.z, __uint_as_float(g));
+            s_geo1[slot] = make_float4(r1.x, r1.y, r1.z, __uint_as_float(g_cur));
             float* pay = s_pay + slot * PAY;
             *reinterpret_cast<float4*>(pay) = make_float4(r2.x, r2.y, r2.z, __uint_as_float((uint32_t)lane));
             if constexpr (SPAD > 0) {
-                const float* f = features + (size_t)g * S;
-                if ((S & 3) == 0) {
+                const float* f = features + (size_t)g_cur * S;
 #pragma unroll
-                    for (int q = 0; q < SPAD / 4; q++) {
-                        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                        if (4 * q < S) v = *reinterpret_cast<const float4*>(f + 4 * q);
-                        *reinterpret_cast<float4*>(pay + 4 + 4 * q) = v;
+                for (int q = 0; q < SPAD / 4; q++) {
+                    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if ((S & 3) == 0) { if (4 * q < S) v = *reinterpret_cast<const float4*>(f + 4 * q); }
+                    else {
+                        v.x = 4 * q < S ? f[4 * q] : 0.f; v.y = 4 * q + 1 < S ? f[4 * q + 1] : 0.f;
+                        v.z = 4 * q + 2 < S ? f[4 * q + 2] : 0.f; v.w = 4 * q + 3 < S ? f[4 * q + 3] : 0.f;
                     }
-                } else {
-#pragma unroll
-                    for (int ch = 0; ch < SPAD; ch++) pay[4 + ch] = ch < S ? f[ch] : 0.f;
+                    *reinterpret_cast<float4*>(pay + 4 + 4 * q) = v;
                 }
             }
         }
-        __builtin_amdgcn_wave_barrier();          // (the wave's LDS operations execute in order: a compiler fence is all it takes)
+    }
+    // records of round 1 (its index has been requested above)
+    g_cur = g_nxt;
+    r0 = splat[4 * (size_t)g_cur];
+    r1 = splat[4 * (size_t)g_cur + 1];
+    g_nxt = load_index(128);
+    __builtin_amdgcn_wave_barrier();
+
+    for (int base = 0; base < n; base += 64) {
+        if (__ballot(!done) == 0ull) break;                     // this block's pixels are all finished
+        // ---- cull of the NEXT round (records in registers), its survivors' rows requested now ----
+        const bool more = base + 64 < n;
+        const bool cand1 = more && base + 64 + lane < n &&
+                           (cull == 0 || splat_may_touch(r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, x0, x0 + 7.f, y0, y0 + 7.f));
+        const unsigned long long m1 = __ballot(cand1);
+        const uint32_t g1n = g_cur;
+        const float4 n0 = r0, n1 = r1;
+        float4 n2 = make_float4(0.f, 0.f, 0.f, 0.f);
+        float4 nf[SPAD > 0 ? SPAD / 4 : 1];
+        if (cand1) {
+            n2 = splat[4 * (size_t)g1n + 2];
+            if constexpr (SPAD > 0) {
+                const float* f = features + (size_t)g1n * S;
+#pragma unroll
+                for (int q = 0; q < SPAD / 4; q++) {
+                    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if ((S & 3) == 0) { if (4 * q < S) v = *reinterpret_cast<const float4*>(f + 4 * q); }
+                    else {
+                        v.x = 4 * q < S ? f[4 * q] : 0.f; v.y = 4 * q + 1 < S ? f[4 * q + 1] : 0.f;
+                        v.z = 4 * q + 2 < S ? f[4 * q + 2] : 0.f; v.w = 4 * q + 3 < S ? f[4 * q + 3] : 0.f;
+                    }
+                    nf[q] = v;
+                }
+            }
+        }
+        // ---- records of the round after next, index of the one after that ----
+        g_cur = g_nxt;
+        if (base + 128 < n) {
+            r0 = splat[4 * (size_t)g_cur];
+            r1 = splat[4 * (size_t)g_cur + 1];
+            g_nxt = load_index(base + 192);
+        }
 
         for (int k0 = 0; k0 < ncand; k0 += U) {
             if (__ballot(!done) == 0ull) break;
@@ -391,6 +431,20 @@ render_forward_wave_kernel(const uint2* __restrict__ ranges, const uint32_t* __r
             }
         }
         __builtin_amdgcn_wave_barrier();          // (reads of this round before the next round's staging writes)
+        // ---- stage the next round: its survivors, compacted ----
+        ncand = __popcll(m1);
+        if (cand1) {
+            const int slot = __popcll(m1 & ((1ull << lane) - 1ull));
+            s_geo0[slot] = n0;
+            s_geo1[slot] = make_float4(n1.x, n1.y, n1.z, __uint_as_float(g1n));
+            float* pay = s_pay + slot * PAY;
+            *reinterpret_cast<float4*>(pay) = make_float4(n2.x, n2.y, n2.z, __uint_as_float((uint32_t)lane));
+            if constexpr (SPAD > 0) {
+#pragma unroll
+                for (int q = 0; q < SPAD / 4; q++) *reinterpret_cast<float4*>(pay + 4 + 4 * q) = nf[q];
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
     }
 
     if (inside) {
