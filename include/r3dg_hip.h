@@ -647,6 +647,7 @@ enum r3dg_option {
                                          * (default 0; the data-parallel iteration sets it) */
     R3DG_OPT_FWD_DECOUPLED,             /* tile forward: 1 = one wave per 8x8 block walks the tile's list on its own, no workgroup
                                          * barrier (render_forward_wave_kernel); 0 = four waves per tile, shared staging */
+    R3DG_OPT_BWD_DECOUPLED,             /* the same for the tile backward (render_backward_wave_kernel) */
     R3DG_OPT_COUNT
 };
 int r3dg_set_option(int option, int value);

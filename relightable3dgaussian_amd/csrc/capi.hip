@@ -220,6 +220,7 @@ extern int g_bwd_wave8x8;
 extern int g_fwd_ppl;
 extern int g_fwd_unroll;
 extern int g_fwd_decoupled;
+extern int g_bwd_decoupled;
 extern int g_bwd_unroll;
 int g_tile_order = 1;   // 1: longest-tile-first block order, 0: XCD-contiguous natural order
 extern int g_bwd_ppl;
@@ -418,14 +419,15 @@ static int* option_slot(int option)
         case R3DG_OPT_TRACE_LEAF_WEIGHT: return &g_trace_leaf_weight;
         case R3DG_OPT_RESERVE_CUS: return &g_reserve_cus;
         case R3DG_OPT_FWD_DECOUPLED: return &g_fwd_decoupled;
+        case R3DG_OPT_BWD_DECOUPLED: return &g_bwd_decoupled;
         default: return nullptr;
     }
 }
 
 int r3dg_set_option(int option, int value)
 {
-    static const int lo[R3DG_OPT_COUNT] = {1, 1, 1, 1, 0, 0, 0, 0, 0, 1, 0, 0, 0, 1, 1, 1, 0, 0};
-    static const int hi[R3DG_OPT_COUNT] = {4, 2, 4, 4, 1, 1, 1, 1, 2, 64, 1, 8, 4, 64, 15, 15, 128, 1};
+    static const int lo[R3DG_OPT_COUNT] = {1, 1, 1, 1, 0, 0, 0, 0, 0, 1, 0, 0, 0, 1, 1, 1, 0, 0, 0};
+    static const int hi[R3DG_OPT_COUNT] = {4, 2, 4, 4, 1, 1, 1, 1, 2, 64, 1, 8, 4, 64, 15, 15, 128, 1, 1};
     int* slot = option_slot(option);
     if (slot == nullptr) return invalid("set_option: unknown option");
     if (value < lo[option] || value > hi[option]) return invalid("set_option: value out of range");

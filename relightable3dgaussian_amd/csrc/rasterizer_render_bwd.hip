@@ -339,6 +339,247 @@ render_backward_kernel(const uint2* __restrict__ ranges, const uint32_t* __restr
     }
 }
 
+// ---- the same backward with DECOUPLED waves (R3DG_OPT_BWD_DECOUPLED; see render_forward_wave_kernel) ----------------------------
+// One wave = one workgroup = one 8x8 pixel block.  It walks the tile's list back to front from ITS OWN deepest contributor (the
+// four-wave kernel starts every wave at the tile's deepest one and masks), culls every entry against its own box, stages only the
+// survivors (compacted) in 7 KB of private LDS, and software-pipelines the rounds like the forward: no workgroup barrier.  Per
+// (pixel, entry) the arithmetic and its order are those of render_backward_kernel; the per-Gaussian sums leave through the same
+// transposing reduction + one atomic instruction per (wave, Gaussian).
+template <int SPAD, bool SMALLV>
+__global__ void __launch_bounds__(64)
+render_backward_wave_kernel(const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list, int S,
+                            ChannelList chan_list, int W, int H, int tiles_x, int num_tiles, int cull,
+                            const uint32_t* __restrict__ tile_order, const float* __restrict__ bg_color,
+                            const float4* __restrict__ splat, const float* __restrict__ features,
+                            const float* __restrict__ final_Ts, const uint32_t* __restrict__ n_contrib,
+                            const float* __restrict__ dL_dpixels, const float* __restrict__ dL_dpixels_o,
+                            const float* __restrict__ dL_dpixels_d, const float* __restrict__ dL_dpixels_f,
+                            float* __restrict__ dL_dmean2D, float* __restrict__ dL_dconic2D, float* __restrict__ dL_dopacity,
+                            float* __restrict__ dL_dcolors, float* __restrict__ dL_dfeature, int backward_geometry)
+{
+    constexpr int PAY = 4 + SPAD;
+    constexpr int NV = 10 + SPAD;
+    constexpr int NVP = SMALLV ? 16 : next_pow2(NV);
+    constexpr int NC = 4 + SPAD;
+    const int SA = chan_list.n;
+    const int xcd = (int)(blockIdx.x & 7u), j = (int)(blockIdx.x >> 3), sub = j & 3, rank = (j >> 2) * 8 + xcd;
+    if (rank >= num_tiles) return;
+    const int tile = tile_order != nullptr ? (int)tile_order[rank] : rank;
+    const int tile_x = tile % tiles_x, tile_y = tile / tiles_x;
+
+    __shared__ float4 s_geo0[64];
+    __shared__ float4 s_geo1[64];
+    __shared__ __attribute__((aligned(16))) float s_pay[64 * PAY];
+    __shared__ uint32_t s_front[64];              // index of the staged entry from the front of the tile's list
+
+    const int lane = threadIdx.x;
+    const int bx = 8 * (sub & 1), by = 8 * (sub >> 1);
+    const int px = tile_x * R3DG_TILE_X + bx + (lane & 7);
+    const int py = tile_y * R3DG_TILE_Y + by + (lane >> 3);
+    const float pxf = (float)px, pyf = (float)py;
+    const float x0 = (float)(tile_x * R3DG_TILE_X + bx), y0 = (float)(tile_y * R3DG_TILE_Y + by);
+    const size_t HW = (size_t)H * W;
+    const uint2 range = ranges[tile];
+
+    const int chan = transposed_channel<NVP>(lane);
+    float* dst_base = nullptr;
+    uint32_t dst_stride = 0;
+    if (transposed_owner<NVP>(lane)) {
+        if (chan < 3) { dst_base = dL_dcolors + chan; dst_stride = 3; }
+        else if (chan < 6) { dst_base = dL_dmean2D + (chan - 3); dst_stride = 3; }
+        else if (chan < 9) { dst_base = dL_dconic2D + (chan == 8 ? 3 : chan - 6); dst_stride = 4; }
+        else if (chan == 9) { dst_base = dL_dopacity; dst_stride = 1; }
+        else if (chan - 10 < SA) { dst_base = dL_dfeature + chan_list.c[chan - 10]; dst_stride = (uint32_t)S; }
+    }
+
+    const bool inside = px < W && py < H;
+    const size_t pix = (size_t)py * W + px;
+    float T = inside ? final_Ts[pix] : 0.f;
+    const uint32_t lastc = inside ? n_contrib[pix] : 0u;
+    f2 acc2[NC / 2], dL2[NC / 2];
+    float acc_o = 0.f, bgT, dLo;
+    {
+        float dl[NC];
+        float bg_dot = 0.f;
+#pragma unroll
+        for (int ch = 0; ch < 3; ch++) {
+            dl[ch] = inside ? dL_dpixels[ch * HW + pix] : 0.f;
+            bg_dot += bg_color[ch] * dl[ch];
+        }
+        bgT = -T * bg_dot;
+        dl[3] = inside ? dL_dpixels_d[pix] : 0.f;
+        dLo = inside ? dL_dpixels_o[pix] : 0.f;
+#pragma unroll
+        for (int ch = 0; ch < SPAD; ch++)
+            dl[4 + ch] = (inside && ch < SA) ? dL_dpixels_f[(size_t)chan_list.c[ch] * HW + pix] : 0.f;
+#pragma unroll
+        for (int q = 0; q < NC / 2; q++) {
+            dL2[q] = f2{dl[2 * q], dl[2 * q + 1]};
+            acc2[q] = f2{0.f, 0.f};
+        }
+    }
+    // this block's deepest last contributor: the walk covers front indices [0, n) back to front
+    uint32_t mx = lastc;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = max(mx, (uint32_t)__shfl_xor((int)mx, o, 64));
+    const int n = (int)mx;
+    const float ddelx_dx = 0.5f * W, ddely_dy = 0.5f * H;
+
+    // entry `e` of the walk (0 = deepest) is list position n - 1 - e
+    auto load_index = [&](int e0) -> uint32_t {
+        return e0 + lane < n ? point_list[range.x + (uint32_t)(n - 1 - (e0 + lane))] : 0u;
+    };
+    auto cull_ok = [&](const float4& a0, const float4& a1) -> bool {
+        return cull == 0 || splat_may_touch(a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, x0, x0 + 7.f, y0, y0 + 7.f);
+    };
+    auto load_payload = [&](uint32_t g, float4& c4, float4 (&f4)[SPAD > 0 ? SPAD / 4 : 1]) {
+        const float4 r2 = splat[4 * (size_t)g + 2];
+        c4 = make_float4(r2.x, r2.y, r2.z, 0.f);
+        if constexpr (SPAD > 0) {
+            const float* f = features + (size_t)g * S;
+            if (chan_list.identity && (S & 3) == 0) {
+#pragma unroll
+                for (int q = 0; q < SPAD / 4; q++) {
+                    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (4 * q < S) v = *reinterpret_cast<const float4*>(f + 4 * q);
+                    f4[q] = v;
+                }
+            } else {
+#pragma unroll
+                for (int q = 0; q < SPAD / 4; q++)
+                    f4[q] = make_float4(4 * q < SA ? f[chan_list.c[4 * q]] : 0.f, 4 * q + 1 < SA ? f[chan_list.c[4 * q + 1]] : 0.f,
+                                        4 * q + 2 < SA ? f[chan_list.c[4 * q + 2]] : 0.f,
+                                        4 * q + 3 < SA ? f[chan_list.c[4 * q + 3]] : 0.f);
+            }
+        }
+    };
+    auto stage = [&](bool cand, unsigned long long m, const float4& a0, const float4& a1, uint32_t g, const float4& c4,
+                     const float4 (&f4)[SPAD > 0 ? SPAD / 4 : 1], int e0) {
+        if (cand) {
+            const int slot = __popcll(m & ((1ull << lane) - 1ull));
+            s_geo0[slot] = a0;
+            s_geo1[slot] = make_float4(a1.x, a1.y, a1.z, __uint_as_float(g));
+            s_front[slot] = (uint32_t)(n - 1 - (e0 + lane));
+            float* pay = s_pay + slot * PAY;
+            *reinterpret_cast<float4*>(pay) = make_float4(c4.x, c4.y, c4.z, a1.z);       // rgb, depth
+            if constexpr (SPAD > 0) {
+#pragma unroll
+                for (int q = 0; q < SPAD / 4; q++) *reinterpret_cast<float4*>(pay + 4 + 4 * q) = f4[q];
+            }
+        }
+    };
+
+    // prologue: round 0 staged, records of round 1 in registers, index of round 2 requested
+    uint32_t g_cur = load_index(0);
+    float4 r0 = splat[4 * (size_t)g_cur], r1 = splat[4 * (size_t)g_cur + 1];
+    uint32_t g_nxt = load_index(64);
+    int ncand;
+    {
+        const bool cand = lane < n && cull_ok(r0, r1);
+        const unsigned long long m = __ballot(cand);
+        ncand = __popcll(m);
+        float4 c4 = make_float4(0.f, 0.f, 0.f, 0.f);
+        float4 f4[SPAD > 0 ? SPAD / 4 : 1];
+        if (cand) load_payload(g_cur, c4, f4);
+        stage(cand, m, r0, r1, g_cur, c4, f4, 0);
+    }
+    g_cur = g_nxt;
+    r0 = splat[4 * (size_t)g_cur];
+    r1 = splat[4 * (size_t)g_cur + 1];
+    g_nxt = load_index(128);
+    __builtin_amdgcn_wave_barrier();
+
+    for (int base = 0; base < n; base += 64) {
+        // cull of the next round, its survivors' rows requested now (they load under this round's arithmetic)
+        const bool cand1 = base + 64 + lane < n && cull_ok(r0, r1);
+        const unsigned long long m1 = __ballot(cand1);
+        const uint32_t g1n = g_cur;
+        const float4 n0 = r0, n1 = r1;
+        float4 nc4 = make_float4(0.f, 0.f, 0.f, 0.f);
+        float4 nf4[SPAD > 0 ? SPAD / 4 : 1];
+        if (cand1) load_payload(g1n, nc4, nf4);
+        g_cur = g_nxt;
+        if (base + 128 < n) {
+            r0 = splat[4 * (size_t)g_cur];
+            r1 = splat[4 * (size_t)g_cur + 1];
+            g_nxt = load_index(base + 192);
+        }
+
+        for (int k = 0; k < ncand; k++) {
+            const float4 g0 = s_geo0[k], g1 = s_geo1[k];
+            const uint32_t front = s_front[k];
+            const float dx = g0.x - pxf, dy = g0.y - pyf;
+            const float power = -0.5f * (g0.z * dx * dx + g1.x * dy * dy) - g0.w * dx * dy;
+            const float Gv0 = fast_exp_b(power);
+            float al = fminf(0.99f, g1.y * Gv0);
+            // reference: skip while contributor >= last_contributor, power > 0, alpha < 1/255
+            if (!(front < lastc) || power > 0.0f || al < 1.0f / 255.0f) al = 0.f;
+            if (__ballot(al != 0.f) == 0ull) continue;
+
+            const float* pay = s_pay + k * PAY;
+            constexpr int NVA = NV > NVP ? NV : NVP;
+            float v[NVA];
+#pragma unroll
+            for (int q = NV; q < NVA; q++) v[q] = 0.f;
+            const bool hit = al != 0.f;
+            const float rcp = __builtin_amdgcn_rcpf(1.f - al);
+            T = T * rcp;
+            const float wgt = al * T;
+            const f2 al2 = f2{al, al}, w2 = f2{wgt, wgt};
+            f2 sa = f2{0.f, 0.f}, sf = f2{0.f, 0.f};
+#pragma unroll
+            for (int q = 0; q < NC / 4; q++) {
+                const float4 p4 = *reinterpret_cast<const float4*>(pay + 4 * q);
+                const f2 da = f2{p4.x, p4.y} - acc2[2 * q], db = f2{p4.z, p4.w} - acc2[2 * q + 1];
+                if (q == 0) {
+                    sa += da * dL2[0];
+                    sa += db * dL2[1];
+                } else {
+                    sf += da * dL2[2 * q];
+                    sf += db * dL2[2 * q + 1];
+                }
+                acc2[2 * q] += al2 * da;
+                acc2[2 * q + 1] += al2 * db;
+                const f2 va = w2 * dL2[2 * q], vb = w2 * dL2[2 * q + 1];
+                if (q == 0) {
+                    v[0] = va.x; v[1] = va.y; v[2] = vb.x; v[5] = vb.y;          // rgb; depth -> dL_dmean2D.z
+                } else {
+                    v[10 + 4 * (q - 1) + 0] = va.x; v[10 + 4 * (q - 1) + 1] = va.y;
+                    v[10 + 4 * (q - 1) + 2] = vb.x; v[10 + 4 * (q - 1) + 3] = vb.y;
+                }
+            }
+            float dL_dalpha = sa.x + sa.y;
+            if (backward_geometry) dL_dalpha += sf.x + sf.y;
+            const float d_o = 1.0f - acc_o;
+            dL_dalpha += d_o * dLo;
+            acc_o += al * d_o;
+            dL_dalpha *= T;
+            dL_dalpha += bgT * rcp;
+            dL_dalpha = hit ? dL_dalpha : 0.f;
+            const float Gv = hit ? Gv0 : 0.f;
+            const float dL_dG = g1.y * dL_dalpha;
+            const float gdx = Gv * dx, gdy = Gv * dy;
+            const float dG_ddelx = -gdx * g0.z - gdy * g0.w;
+            const float dG_ddely = -gdy * g1.x - gdx * g0.w;
+            v[3] = dL_dG * dG_ddelx * ddelx_dx;
+            v[4] = dL_dG * dG_ddely * ddely_dy;
+            v[6] = -0.5f * gdx * dx * dL_dG;
+            v[7] = -0.5f * gdx * dy * dL_dG;
+            v[8] = -0.5f * gdy * dy * dL_dG;
+            v[9] = Gv * dL_dalpha;
+            float vr[NVP];
+#pragma unroll
+            for (int q = 0; q < NVP; q++) vr[q] = v[q];
+            const float total = transpose_reduce<NVP, true>(vr);
+            if (dst_base != nullptr) atomicAdd(dst_base + (size_t)(__float_as_uint(g1.w) * dst_stride), total);
+        }
+        __builtin_amdgcn_wave_barrier();          // (reads of this round before the next round's staging writes)
+        ncand = __popcll(m1);
+        stage(cand1, m1, n0, n1, g1n, nc4, nf4, base + 64);
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
 extern int g_cull;
 extern int g_bwd_wave8x8;
 static inline int g_bwd_wave8x8_for_features() { return g_bwd_wave8x8; }
@@ -509,6 +750,7 @@ extern int g_cull;
 int g_bwd_wave8x8 = 1;  // measured: 8x8 blocks -6% (fewer waves touched per Gaussian); the forward prefers strips
 int g_bwd_ppl = 1;
 int g_bwd_unroll = 1;   // staged entries evaluated per inner-loop step
+int g_bwd_decoupled = 0;   // R3DG_OPT_BWD_DECOUPLED: 1 = one wave per 8x8 block walks the list on its own (render_backward_wave_kernel)
 
 template <int SPAD, int PPL>
 static void launch_bwd_inst(hipStream_t s, int T, int tiles_x, const uint32_t* tile_order, const uint32_t* ranges,
@@ -520,6 +762,19 @@ static void launch_bwd_inst(hipStream_t s, int T, int tiles_x, const uint32_t* t
                             float* dL_dcolor, float* dL_dfeature, int bg_geom)
 {
     const int chunk = (T + 7) / 8;
+#define R3DG_BWD_WAVE(SV)                                                                                             \
+    render_backward_wave_kernel<SPAD, SV><<<chunk * 8 * 4, 64, 0, s>>>(                                               \
+        (const uint2*)ranges, point_list, S, cl, W, H, tiles_x, T, g_cull, tile_order, bg, (const float4*)splat, features,   \
+        final_Ts, n_contrib, dL_dpix, dL_dpix_o, dL_dpix_d, dL_dpix_f, dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolor,    \
+        dL_dfeature, bg_geom)
+    if (PPL == 1 && g_bwd_decoupled) {
+        if constexpr (SPAD == 4 || SPAD == 8) {
+            if (cl.n <= 6) { R3DG_BWD_WAVE(true); return; }
+        }
+        R3DG_BWD_WAVE(false);
+        return;
+    }
+#undef R3DG_BWD_WAVE
 #define R3DG_BWD_LAUNCH(UU, SV)                                                                                       \
     render_backward_kernel<SPAD, PPL, UU, SV><<<chunk * 8, 256 / PPL, 0, s>>>(                                        \
         (const uint2*)ranges, point_list, S, cl, W, H, tiles_x, T, chunk, g_bwd_wave8x8, g_cull, tile_order, bg,       \

@@ -300,6 +300,53 @@ def test_forward_with_decoupled_waves(name, cull, hip_lib):
             assert torch.allclose(out[i], ref[i], rtol=2e-6, atol=2e-6), (i, float((out[i] - ref[i]).abs().max()))
 
 
+@pytest.mark.parametrize("name", list(BWD_CASES))
+@pytest.mark.parametrize("cull", [1, 0])
+def test_backward_with_decoupled_waves(name, cull, hip_lib):
+    """R3DG_OPT_BWD_DECOUPLED (render_backward_wave_kernel): the oracle's gradients, like the default kernel."""
+    _opt(BWD_DECOUPLED=1, CULL=cull)
+    try:
+        _check_backward(make_case(**BWD_CASES[name]), "%s_decoupled_cull%d" % (name, cull))
+        if name == "S5":
+            _check_backward(make_case(S=5, seed=31), "bg_geom_off_decoupled", backward_geometry=False)
+    finally:
+        _opt(BWD_DECOUPLED=0, CULL=1)
+
+
+@pytest.mark.parametrize("S,active", [(16, (2, 3, 4)), (16, (2, 3, 4, 5, 6, 7)), (16, (15, 0, 9, 1, 2, 3, 4, 5)), (28, tuple(range(3, 20))),
+                                      (16, ()), (7, (6,))])
+def test_backward_with_decoupled_waves_active_subset(S, active, hip_lib):
+    """The decoupled backward with `active_features` (the half-size reduction for <= 6 channels included) against the default
+    four-wave kernel on the same state."""
+    from r3dg_rasterization import _C
+    from relightable3dgaussian_amd import rasterizer_ops
+    case = make_case(S=S, seed=181 + S, P=4000)
+    a = fwd_args(case, DEV)
+    out = _C.rasterize_gaussians(*a)
+    H, W = case["H"], case["W"]
+    g = torch.Generator().manual_seed(6)
+    gC, gO, gD = [torch.randn(c, H, W, generator=g).to(DEV) for c in (3, 1, 1)]
+    gF = torch.zeros(S, H, W, device=DEV)
+    for ch in active:
+        gF[ch] = torch.randn(H, W, generator=g).to(DEV)
+
+    def run():
+        return rasterizer_ops.rasterize_gaussians_backward(
+            a[0], a[1], a[2], out[9], a[3], a[5], a[6], 1.0, a[8], a[9], a[10], a[11], a[12], gC, gO, gD, gF, a[17],
+            a[18], a[19], out[10], out[0], out[11], out[12], True, False, active_features=active)
+    ref = run()
+    _opt(BWD_DECOUPLED=1)
+    try:
+        new = run()
+    finally:
+        _opt(BWD_DECOUPLED=0)
+    torch.cuda.synchronize()
+    for nm, x, y in zip(("dL_dmeans2D", "dL_dcolors", "dL_dopacity", "dL_dmeans3D", "dL_dfeatures", "dL_dcov3D", "dL_dsh",
+                         "dL_dscales", "dL_drotations"), ref, new):
+        ok, msg = report(nm, y, x, 1e-4, 1e-9)        # float-atomic summation order differs between the two kernels
+        assert ok, msg
+
+
 @pytest.mark.parametrize("name", ["S16", "big_splats", "ragged_image", "camera_inside", "S0"])
 @pytest.mark.parametrize("binning", [0, 1, 2])
 def test_tile_binned_order_equals_global_sort(name, binning, hip_lib):
