@@ -625,14 +625,9 @@ int r3dg_sort_pairs(void* stream, int64_t n, uint64_t* d_keys_in, uint32_t* d_va
 /* Tuning / experiment knobs (NOT part of the drop-in surface; defaults are the measured best, results never depend on them
  * beyond the order of float atomics).  r3dg_set_option returns R3DG_EINVAL for an unknown option or a value out of range. */
 enum r3dg_option {
-    R3DG_OPT_FWD_PIXELS_PER_LANE = 0,   /* forward tile kernel: pixels per lane, 1 (default) / 2 / 4 */
-    R3DG_OPT_BWD_PIXELS_PER_LANE,       /* backward tile kernel: 1 (default) / 2 */
-    R3DG_OPT_FWD_UNROLL,                /* staged entries evaluated per inner-loop step of the forward: 1 / 2 / 4 (default) */
-    R3DG_OPT_BWD_UNROLL,                /* ... of the backward: 1 (default) / 2 / 4 */
-    R3DG_OPT_TILE_ORDER,                /* block -> tile map: 1 longest tile list first (default), 0 XCD-contiguous natural order */
-    R3DG_OPT_FWD_WAVE8X8,               /* 1-pixel-per-lane forward: 1 = each wave owns an 8x8 pixel block (default), 0 = a 16x4 strip */
-    R3DG_OPT_BWD_WAVE8X8,               /* the same for the backward */
-    R3DG_OPT_CULL,                      /* 1 = per-wave conservative sub-tile cull of staged entries (default), 0 = evaluate every entry */
+    R3DG_OPT_TILE_ORDER = 0,            /* block -> tile map: 1 longest tile list first (default), 0 natural order */
+    R3DG_OPT_CULL,                      /* 1 = conservative per-block cull of the staged entries in the tile kernels (default), 0 = every
+                                         * entry is evaluated; identical results */
     R3DG_OPT_TILE_BINNING,              /* instance ordering: 2 = direct tile binning + per-tile sort (default), 1 = radix partition by
                                          * tile + per-tile sort, 0 = the reference's one global radix sort; identical lists either way */
     R3DG_OPT_BINNING_BLOCK_K,           /* direct binning: Gaussians per workgroup / 1024 (default 2) */
@@ -643,11 +638,8 @@ enum r3dg_option {
     R3DG_OPT_TRACE_REFILL,              /* idle lanes at which a persistent trace wave refills (default 16) */
     R3DG_OPT_TRACE_NODE_WEIGHT,         /* vote weights of the phased trace */
     R3DG_OPT_TRACE_LEAF_WEIGHT,
-    R3DG_OPT_RESERVE_CUS,               /* CUs the persistent kernels (shading, trace) leave free for a collective running beside them
-                                         * (default 0; the data-parallel iteration sets it) */
-    R3DG_OPT_FWD_DECOUPLED,             /* tile forward: 1 = one wave per 8x8 block walks the tile's list on its own, no workgroup
-                                         * barrier (render_forward_wave_kernel); 0 = four waves per tile, shared staging */
-    R3DG_OPT_BWD_DECOUPLED,             /* the same for the tile backward (render_backward_wave_kernel) */
+    R3DG_OPT_RESERVE_CUS,               /* CUs the persistent kernels (shading, trace, long-tile sort) leave free for a collective running
+                                         * beside them (default 0; the data-parallel iteration sets it) */
     R3DG_OPT_COUNT
 };
 int r3dg_set_option(int option, int value);

@@ -140,9 +140,8 @@ def lib():
 
 
 # enum r3dg_option (include/r3dg_hip.h); tests/test_oracle_cpu.py checks the numbering against the header
-OPTIONS = ("FWD_PIXELS_PER_LANE", "BWD_PIXELS_PER_LANE", "FWD_UNROLL", "BWD_UNROLL", "TILE_ORDER", "FWD_WAVE8X8", "BWD_WAVE8X8",
-           "CULL", "TILE_BINNING", "BINNING_BLOCK_K", "STAGE_SH_ROWS", "SHADE_FWD_BLOCKS_PER_CU", "TRACE_FORMULATION",
-           "TRACE_REFILL", "TRACE_NODE_WEIGHT", "TRACE_LEAF_WEIGHT", "RESERVE_CUS", "FWD_DECOUPLED", "BWD_DECOUPLED")
+OPTIONS = ("TILE_ORDER", "CULL", "TILE_BINNING", "BINNING_BLOCK_K", "STAGE_SH_ROWS", "SHADE_FWD_BLOCKS_PER_CU", "TRACE_FORMULATION",
+           "TRACE_REFILL", "TRACE_NODE_WEIGHT", "TRACE_LEAF_WEIGHT", "RESERVE_CUS")
 
 
 def set_option(name, value):

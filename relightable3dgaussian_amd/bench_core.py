@@ -237,6 +237,8 @@ def _kernel_names(stage):
             "shade_forward": ["shade_forward_frs_kernel", "shade_forward_row_kernel"],
             "shade_backward": ["shade_backward_frs_kernel", "shade_backward_kernel"],
             "shade_frs_aux": ["frs_rotate_kernel"],
+            "render_forward": ["render_forward_wave_kernel", "render_forward_kernel"],
+            "render_backward": ["render_backward_wave_kernel", "render_backward_kernel"],
             "shade_forward_transport": ["shade_forward_transport_kernel"],
             "adam_step": ["adam_kernel"], "bvh_trace": ["trace_opacity_phased_kernel", "trace_opacity_persistent_kernel"],
             }.get(stage, [stage + "_kernel", stage])

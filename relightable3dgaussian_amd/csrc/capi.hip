@@ -215,15 +215,7 @@ extern int g_cull;
 extern int g_stage_sh_rows;
 int g_tile_binning = 2;   // 2: instances emitted straight into their tile's segment + per-tile LDS sort; 1: emitted in Gaussian
                           // order, radix-partitioned by tile, per-tile LDS sort; 0: the reference's global (tile|depth) radix sort
-extern int g_fwd_wave8x8;
-extern int g_bwd_wave8x8;
-extern int g_fwd_ppl;
-extern int g_fwd_unroll;
-extern int g_fwd_decoupled;
-extern int g_bwd_decoupled;
-extern int g_bwd_unroll;
 int g_tile_order = 1;   // 1: longest-tile-first block order, 0: XCD-contiguous natural order
-extern int g_bwd_ppl;
 void launch_transpose_selftest(hipStream_t s, int N, int dpp, const float* in, float* out, int* chan, int* owner);
 
 // ---- optional per-stage timing with HIP events on the launch stream (bench.py's roofline numbers) ----
@@ -401,13 +393,7 @@ int r3dg_bounded_forward_supported(int width, int height)
 static int* option_slot(int option)
 {
     switch (option) {
-        case R3DG_OPT_FWD_PIXELS_PER_LANE: return &g_fwd_ppl;
-        case R3DG_OPT_BWD_PIXELS_PER_LANE: return &g_bwd_ppl;
-        case R3DG_OPT_FWD_UNROLL: return &g_fwd_unroll;
-        case R3DG_OPT_BWD_UNROLL: return &g_bwd_unroll;
         case R3DG_OPT_TILE_ORDER: return &g_tile_order;
-        case R3DG_OPT_FWD_WAVE8X8: return &g_fwd_wave8x8;
-        case R3DG_OPT_BWD_WAVE8X8: return &g_bwd_wave8x8;
         case R3DG_OPT_CULL: return &g_cull;
         case R3DG_OPT_TILE_BINNING: return &g_tile_binning;
         case R3DG_OPT_BINNING_BLOCK_K: return &g_bin_iters;
@@ -418,16 +404,14 @@ static int* option_slot(int option)
         case R3DG_OPT_TRACE_NODE_WEIGHT: return &g_trace_node_weight;
         case R3DG_OPT_TRACE_LEAF_WEIGHT: return &g_trace_leaf_weight;
         case R3DG_OPT_RESERVE_CUS: return &g_reserve_cus;
-        case R3DG_OPT_FWD_DECOUPLED: return &g_fwd_decoupled;
-        case R3DG_OPT_BWD_DECOUPLED: return &g_bwd_decoupled;
         default: return nullptr;
     }
 }
 
 int r3dg_set_option(int option, int value)
 {
-    static const int lo[R3DG_OPT_COUNT] = {1, 1, 1, 1, 0, 0, 0, 0, 0, 1, 0, 0, 0, 1, 1, 1, 0, 0, 0};
-    static const int hi[R3DG_OPT_COUNT] = {4, 2, 4, 4, 1, 1, 1, 1, 2, 64, 1, 8, 4, 64, 15, 15, 128, 1, 1};
+    static const int lo[R3DG_OPT_COUNT] = {0, 0, 0, 1, 0, 0, 0, 1, 1, 1, 0};
+    static const int hi[R3DG_OPT_COUNT] = {1, 1, 2, 64, 1, 8, 4, 64, 15, 15, 128};
     int* slot = option_slot(option);
     if (slot == nullptr) return invalid("set_option: unknown option");
     if (value < lo[option] || value > hi[option]) return invalid("set_option: value out of range");

@@ -54,297 +54,20 @@ struct ChannelList {
     int c[R3DG_MAX_S_BWD];
 };
 
-template <int SPAD, int PPL, int U, bool SMALLV>
-__global__ void __launch_bounds__(256 / PPL)
-render_backward_kernel(const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list, int S,
-                       ChannelList chan_list, int W, int H,
-                       int tiles_x, int num_tiles, int xcd_chunk, int wave8, int cull, const uint32_t* __restrict__ tile_order,
-                       const float* __restrict__ bg_color,
-                       const float4* __restrict__ splat,
-                       const float* __restrict__ features, const float* __restrict__ final_Ts,
-                       const uint32_t* __restrict__ n_contrib, const float* __restrict__ dL_dpixels,
-                       const float* __restrict__ dL_dpixels_o, const float* __restrict__ dL_dpixels_d,
-                       const float* __restrict__ dL_dpixels_f, float* __restrict__ dL_dmean2D,
-                       float* __restrict__ dL_dconic2D, float* __restrict__ dL_dopacity,
-                       float* __restrict__ dL_dcolors, float* __restrict__ dL_dfeature, int backward_geometry)
-{
-    constexpr int NT = 256 / PPL;
-    constexpr int PAY = 4 + SPAD;
-    constexpr int NV = 10 + SPAD;            // gradient channels per Gaussian (SMALLV: only the first 16 are non-zero)
-    constexpr int NVP = SMALLV ? 16 : next_pow2(NV);
-    const int SA = chan_list.n;
-    constexpr int NW = NT / 64;
-    constexpr int NC = 4 + SPAD;             // blended channels per pixel: rgb, depth, features
-
-    int tile;
-    if (tile_order != nullptr) {
-        if ((int)blockIdx.x >= num_tiles) return;
-        tile = (int)tile_order[blockIdx.x];
-    } else {
-        tile = (int)(blockIdx.x & 7u) * xcd_chunk + (int)(blockIdx.x >> 3);
-        if (tile >= num_tiles) return;
-    }
-    const int tile_x = tile % tiles_x, tile_y = tile / tiles_x;
-
-    __shared__ float4 s_geo0[NT];
-    __shared__ float4 s_geo1[NT];
-    __shared__ __attribute__((aligned(16))) float s_pay[NT * PAY];
-    __shared__ uint32_t s_max[NW];
-    __shared__ unsigned long long s_cand[NW][NW];  // [pixel wave][64-entry group]: entries that may touch that wave's box
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    // lane -> pixel: PPL == 1 and wave8: each wave owns a compact 8x8 block (fewer waves touched per Gaussian than
-    // with 16x4 strips); otherwise 16-wide rows, PPL pixels per lane 4 rows apart
-    int lx = lane & 15, ly = wave * (4 * PPL) + (lane >> 4);
-    if (PPL == 1 && wave8) {
-        lx = (lane & 7) + 8 * (wave & 1);
-        ly = (lane >> 3) + 8 * (wave >> 1);
-    }
-    const int px = tile_x * R3DG_TILE_X + lx;
-    const int py0 = tile_y * R3DG_TILE_Y + ly;
-    const float pxf = (float)px;
-    const size_t HW = (size_t)H * W;
-    const uint2 range = ranges[tile];
-
-    // Per-lane destination of the transposed reduction: channel -> (array, stride)
-    //   0..2 dL_dcolors[g*3+c] | 3..5 dL_dmean2D[g*3+c] | 6,7,8 dL_dconic2D[g*4+{0,1,3}] | 9 dL_dopacity[g] | 10.. dL_dfeature[g*S+c]
-    const int chan = transposed_channel<NVP>(lane);
-    float* dst_base = nullptr;
-    uint32_t dst_stride = 0;
-    if (transposed_owner<NVP>(lane)) {
-        if (chan < 3) { dst_base = dL_dcolors + chan; dst_stride = 3; }
-        else if (chan < 6) { dst_base = dL_dmean2D + (chan - 3); dst_stride = 3; }
-        else if (chan < 9) { dst_base = dL_dconic2D + (chan == 8 ? 3 : chan - 6); dst_stride = 4; }
-        else if (chan == 9) { dst_base = dL_dopacity; dst_stride = 1; }
-        else if (chan - 10 < SA) { dst_base = dL_dfeature + chan_list.c[chan - 10]; dst_stride = (uint32_t)S; }
-    }
-
-    // Per-pixel state as float2 pairs so the per-channel recursions compile to packed fp32 ops (v_pk_fma_f32 /
-    // v_pk_mul_f32 / v_pk_add_f32: two channels per instruction).  Channel vector = payload layout:
-    //   [rgb0, rgb1, rgb2, depth, feature 0 .. SPAD-1]  ->  NC/2 pairs.
-    float T[PPL], bgT[PPL], pyf[PPL];
-    f2 acc2[PPL][NC / 2], dL2[PPL][NC / 2];
-    float acc_o[PPL], dLo[PPL];
-    uint32_t lastc[PPL];
-    uint32_t my_max = 0;
-#pragma unroll
-    for (int i = 0; i < PPL; i++) {
-        const int py = py0 + 4 * i;
-        const bool inside = px < W && py < H;
-        const size_t pix = (size_t)py * W + px;
-        pyf[i] = (float)py;
-        const float T_final = inside ? final_Ts[pix] : 0.f;
-        T[i] = T_final;
-        lastc[i] = inside ? n_contrib[pix] : 0u;
-        my_max = max(my_max, lastc[i]);
-        float dl[NC];
-        float bg_dot = 0.f;
-#pragma unroll
-        for (int ch = 0; ch < 3; ch++) {
-            dl[ch] = inside ? dL_dpixels[ch * HW + pix] : 0.f;
-            bg_dot += bg_color[ch] * dl[ch];
-        }
-        bgT[i] = -T_final * bg_dot;
-        dl[3] = inside ? dL_dpixels_d[pix] : 0.f;
-        dLo[i] = inside ? dL_dpixels_o[pix] : 0.f;
-        acc_o[i] = 0.f;
-#pragma unroll
-        for (int ch = 0; ch < SPAD; ch++)
-            dl[4 + ch] = (inside && ch < SA) ? dL_dpixels_f[(size_t)chan_list.c[ch] * HW + pix] : 0.f;
-#pragma unroll
-        for (int q = 0; q < NC / 2; q++) {
-            dL2[i][q] = f2{dl[2 * q], dl[2 * q + 1]};
-            acc2[i][q] = f2{0.f, 0.f};
-        }
-    }
-    // block max of last contributor: the walk covers front indices [0, m) back to front
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) my_max = max(my_max, (uint32_t)__shfl_xor((int)my_max, o, 64));
-    if (lane == 0) s_max[wave] = my_max;
-    __syncthreads();
-    uint32_t m = 0;
-#pragma unroll
-    for (int w = 0; w < NW; w++) m = max(m, s_max[w]);
-    const int n = (int)m;
-
-    const float ddelx_dx = 0.5f * W, ddely_dy = 0.5f * H;
-
-    for (int base = 0; base < n; base += NT) {
-        __syncthreads();
-        float4 my_geo = make_float4(0.f, 0.f, 0.f, 0.f);   // mean.xy, conic.x, conic.y
-        float2 my_co = make_float2(0.f, 0.f);               // conic.z, opacity
-        if (base + tid < n) {
-            const uint32_t g = point_list[range.x + (uint32_t)(n - 1 - (base + tid))];
-            // ONE 64-byte-aligned record per instance (preprocess_kernel packs xy, conic, opacity, depth and colour)
-            const float4* rec = splat + 4 * (size_t)g;
-            const float4 r0 = rec[0], r1 = rec[1], r2 = rec[2];
-            s_geo0[tid] = my_geo = r0;
-            s_geo1[tid] = make_float4(r1.x, r1.y, r1.z, __uint_as_float(g));
-            my_co = make_float2(r1.x, r1.y);
-            float* pay = s_pay + tid * PAY;
-            *reinterpret_cast<float4*>(pay) = make_float4(r2.x, r2.y, r2.z, r1.z);
-            if constexpr (SPAD > 0) {
-                const float* f = features + (size_t)g * S;
-                if (chan_list.identity && (S & 3) == 0) {
-#pragma unroll
-                    for (int q = 0; q < SPAD / 4; q++) {
-                        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                        if (4 * q < S) v = *reinterpret_cast<const float4*>(f + 4 * q);
-                        *reinterpret_cast<float4*>(pay + 4 + 4 * q) = v;
-                    }
-                } else {
-#pragma unroll
-                    for (int ch = 0; ch < SPAD; ch++) pay[4 + ch] = ch < SA ? f[chan_list.c[ch]] : 0.f;
-                }
-            }
-        }
-        // per pixel-wave candidate masks: the entry must lie in front of that wave's deepest last contributor and pass
-        // the conservative alpha >= 1/255 box test (common.hpp splat_may_touch)
-#pragma unroll
-        for (int w = 0; w < NW; w++) {
-            int bx = 0, by = w * (4 * PPL), bw = 15, bh = 4 * PPL - 1;
-            if (PPL == 1 && wave8) { bx = 8 * (w & 1); by = 8 * (w >> 1); bw = 7; bh = 7; }
-            const float x0 = (float)(tile_x * R3DG_TILE_X + bx), y0 = (float)(tile_y * R3DG_TILE_Y + by);
-            bool c = base + tid < n && (uint32_t)(n - 1 - (base + tid)) < s_max[w];
-            if (cull) c = c && splat_may_touch(my_geo.x, my_geo.y, my_geo.z, my_geo.w, my_co.x, my_co.y, x0,
-                                               x0 + (float)bw, y0, y0 + (float)bh);
-            const unsigned long long mk = __ballot(c);
-            if (lane == 0) s_cand[w][wave] = mk;
-        }
-        __syncthreads();
-
-        // U candidate entries per step: their LDS reads are issued together and the U x PPL (G, alpha) pairs are
-        // independent work; the accum_rec recursion and the gradient reduction stay serial per entry.
-        for (int grp = 0; grp < NW; grp++) {
-          const unsigned long long mv = s_cand[wave][grp];
-          unsigned long long cm = ((unsigned long long)__builtin_amdgcn_readfirstlane((int)(mv >> 32)) << 32) |
-                                  (unsigned int)__builtin_amdgcn_readfirstlane((int)(unsigned int)mv);
-          while (cm != 0ull) {
-            float4 g0[U], g1[U];
-            float alpha[U][PPL], G[U][PPL];
-            int jj[U];
-            bool valid[U];
-#pragma unroll
-            for (int u = 0; u < U; u++) {
-                valid[u] = cm != 0ull;
-                jj[u] = valid[u] ? grp * 64 + __builtin_ctzll(cm) : (u > 0 ? jj[u - 1] : 0);
-                if (valid[u]) cm &= cm - 1ull;
-                g0[u] = s_geo0[jj[u]];
-                g1[u] = s_geo1[jj[u]];
-            }
-            bool any_hit = false;
-#pragma unroll
-            for (int u = 0; u < U; u++) {
-                const uint32_t front = (uint32_t)(n - 1 - (base + jj[u]));   // 0-based index from the front of the list
-                const float dx = g0[u].x - pxf;
-#pragma unroll
-                for (int i = 0; i < PPL; i++) {
-                    const float dy = g0[u].y - pyf[i];
-                    const float power = -0.5f * (g0[u].z * dx * dx + g1[u].x * dy * dy) - g0[u].w * dx * dy;
-                    const float Gv = fast_exp_b(power);
-                    float a = fminf(0.99f, g1[u].y * Gv);
-                    // reference: skip while contributor >= last_contributor, power > 0, alpha < 1/255
-                    if (!(front < lastc[i]) || power > 0.0f || a < 1.0f / 255.0f || !valid[u]) a = 0.f;
-                    alpha[u][i] = a;
-                    G[u][i] = Gv;
-                    any_hit = any_hit || (a != 0.f);
-                }
-            }
-            if (__ballot(any_hit) == 0ull) continue;
-
-#pragma unroll
-            for (int u = 0; u < U; u++) {
-                bool any_lane = false;
-#pragma unroll
-                for (int i = 0; i < PPL; i++) any_lane = any_lane || (alpha[u][i] != 0.f);
-                if (__ballot(any_lane) == 0ull) continue;
-
-                const float dx = g0[u].x - pxf;
-                const float* pay = s_pay + jj[u] * PAY;
-                // v[] = this lane's 10+S gradient contributions (summed over its PPL pixels): with one pixel per lane
-                // every used channel is assigned exactly once, so only the padding is zeroed
-                constexpr int NVA = NV > NVP ? NV : NVP;     // SMALLV: NV = 18 slots are written, the last 2 are padding
-                float v[NVA];
-#pragma unroll
-                for (int k = (PPL == 1 ? NV : 0); k < NVA; k++) v[k] = 0.f;
-#define R3DG_ACC(k, x) do { if (PPL == 1) v[k] = (x); else v[k] += (x); } while (0)
-
-                // Branch-free over the lanes: a lane that does not blend this Gaussian has alpha == 0, which leaves its
-                // recursions unchanged (T *= 1, acc += 0 * d) and zeroes every gradient term once dL_dalpha and G are
-                // masked -- no EXEC-masked region, no per-entry re-zeroing of the 10+S reduction inputs.
-#pragma unroll
-                for (int i = 0; i < PPL; i++) {
-                    if (PPL > 1 && __ballot(alpha[u][i] != 0.f) == 0ull) continue;
-                    const float al = alpha[u][i];
-                    const bool hit = al != 0.f;
-                    const float dy = g0[u].y - pyf[i];
-                    const float rcp = __builtin_amdgcn_rcpf(1.f - al);
-                    T[i] = T[i] * rcp;
-                    const float wgt = al * T[i];
-                    const f2 al2 = f2{al, al}, w2 = f2{wgt, wgt};
-                    f2 sa = f2{0.f, 0.f}, sf = f2{0.f, 0.f};
-#pragma unroll
-                    for (int q = 0; q < NC / 4; q++) {
-                        const float4 p4 = *reinterpret_cast<const float4*>(pay + 4 * q);
-                        const f2 da = f2{p4.x, p4.y} - acc2[i][2 * q], db = f2{p4.z, p4.w} - acc2[i][2 * q + 1];
-                        if (q == 0) {
-                            sa += da * dL2[i][0];
-                            sa += db * dL2[i][1];
-                        } else {
-                            sf += da * dL2[i][2 * q];
-                            sf += db * dL2[i][2 * q + 1];
-                        }
-                        // accum_rec' = alpha * value + (1 - alpha) * accum_rec, written as accum_rec + alpha * (value - accum_rec)
-                        acc2[i][2 * q] += al2 * da;
-                        acc2[i][2 * q + 1] += al2 * db;
-                        const f2 va = w2 * dL2[i][2 * q], vb = w2 * dL2[i][2 * q + 1];
-                        if (q == 0) {
-                            R3DG_ACC(0, va.x); R3DG_ACC(1, va.y); R3DG_ACC(2, vb.x); R3DG_ACC(5, vb.y);   // rgb; depth -> dL_dmean2D.z
-                        } else {
-                            R3DG_ACC(10 + 4 * (q - 1) + 0, va.x); R3DG_ACC(10 + 4 * (q - 1) + 1, va.y);
-                            R3DG_ACC(10 + 4 * (q - 1) + 2, vb.x); R3DG_ACC(10 + 4 * (q - 1) + 3, vb.y);
-                        }
-                    }
-                    float dL_dalpha = sa.x + sa.y;
-                    if (backward_geometry) dL_dalpha += sf.x + sf.y;
-                    const float d_o = 1.0f - acc_o[i];
-                    dL_dalpha += d_o * dLo[i];
-                    acc_o[i] += al * d_o;
-                    dL_dalpha *= T[i];
-                    dL_dalpha += bgT[i] * rcp;
-                    dL_dalpha = hit ? dL_dalpha : 0.f;
-                    const float Gv = hit ? G[u][i] : 0.f;
-
-                    const float dL_dG = g1[u].y * dL_dalpha;
-                    const float gdx = Gv * dx, gdy = Gv * dy;
-                    const float dG_ddelx = -gdx * g0[u].z - gdy * g0[u].w;
-                    const float dG_ddely = -gdy * g1[u].x - gdx * g0[u].w;
-                    R3DG_ACC(3, dL_dG * dG_ddelx * ddelx_dx);
-                    R3DG_ACC(4, dL_dG * dG_ddely * ddely_dy);
-                    R3DG_ACC(6, -0.5f * gdx * dx * dL_dG);
-                    R3DG_ACC(7, -0.5f * gdx * dy * dL_dG);
-                    R3DG_ACC(8, -0.5f * gdy * dy * dL_dG);
-                    R3DG_ACC(9, Gv * dL_dalpha);
-                }
-#undef R3DG_ACC
-                float vr[NVP];
-#pragma unroll
-                for (int k = 0; k < NVP; k++) vr[k] = v[k];
-                const float total = transpose_reduce<NVP, true>(vr);
-                // 32-bit element index: P * max(S, 4) < 2^32
-                if (dst_base != nullptr) atomicAdd(dst_base + (size_t)(__float_as_uint(g1[u].w) * dst_stride), total);
-            }
-          }
-        }
-    }
-}
-
-// ---- the same backward with DECOUPLED waves (R3DG_OPT_BWD_DECOUPLED; see render_forward_wave_kernel) ----------------------------
-// One wave = one workgroup = one 8x8 pixel block.  It walks the tile's list back to front from ITS OWN deepest contributor (the
-// four-wave kernel starts every wave at the tile's deepest one and masks), culls every entry against its own box, stages only the
-// survivors (compacted) in 7 KB of private LDS, and software-pipelines the rounds like the forward: no workgroup barrier.  Per
-// (pixel, entry) the arithmetic and its order are those of render_backward_kernel; the per-Gaussian sums leave through the same
-// transposing reduction + one atomic instruction per (wave, Gaussian).
+// One wave = one workgroup = one 8x8 pixel block (round 3; rounds 1-2 ran four waves per tile over a shared staging buffer with
+// two workgroup barriers per round -- see render_forward_wave_kernel).  The wave walks the tile's list back to front from ITS OWN
+// deepest contributor, culls every entry against its own box, stages only the survivors (compacted) in its private LDS, and
+// software-pipelines the rounds like the forward: no workgroup barrier.
+//   * only the feature channels with a non-zero upstream gradient are carried (ChannelList);
+//   * per-pixel state as float2 pairs so the per-channel recursions compile to packed fp32 ops (v_pk_fma_f32 / v_pk_mul_f32 /
+//     v_pk_add_f32: two channels per instruction); channel vector = payload layout [rgb0, rgb1, rgb2, depth, feature 0 ..];
+//   * branch-free over the lanes: a lane that does not blend this Gaussian has alpha == 0, which leaves its recursions unchanged
+//     (T *= 1, acc += 0 * d) and zeroes every gradient term once dL_dalpha and G are masked;
+//   * the 10 + S per-Gaussian sums leave through the transposing reduction + ONE atomic instruction per (wave, Gaussian):
+//     channel -> array: 0..2 dL_dcolors[g*3+c] | 3..5 dL_dmean2D[g*3+c] | 6,7,8 dL_dconic2D[g*4+{0,1,3}] | 9 dL_dopacity[g] |
+//     10.. dL_dfeature[g*S+c]; with 10 + n <= 16 live channels the reduction is half size (SMALLV).
+// Measured (300k Gaussians, 800x800): 0.363 -> 0.345 ms inside the iteration (3 live feature channels), 0.494 -> 0.440 ms with
+// all 16 live.
 template <int SPAD, bool SMALLV>
 __global__ void __launch_bounds__(64)
 render_backward_wave_kernel(const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list, int S,
@@ -581,8 +304,6 @@ render_backward_wave_kernel(const uint2* __restrict__ ranges, const uint32_t* __
 }
 
 extern int g_cull;
-extern int g_bwd_wave8x8;
-static inline int g_bwd_wave8x8_for_features() { return g_bwd_wave8x8; }
 
 // ---- feature gradients only (frozen geometry) -------------------------------------------------------------------------
 // The Synthetic4Relight / DTU stage-2 schedule (script/run_syn4.sh:27-33, run_dtu.sh) freezes positions, covariances, opacities
@@ -590,8 +311,9 @@ static inline int g_bwd_wave8x8_for_features() { return g_bwd_wave8x8; }
 // incident light).  Of the reference's backward (backward.cu:401-614) only
 //     dL_dfeature[g, c] += alpha * T * dL_dpixel_f[c]                                                   (backward.cu:566)
 // is then ever used: no accum_rec recursion, no dL_dalpha, no mean / conic / opacity / colour atomics, no payload staging
-// (the feature VALUES do not enter) and no per-Gaussian geometry backward behind it.  Same tiling, back-to-front walk, cull
-// masks and transposing wave reduction as render_backward_kernel; alpha and T are evaluated exactly as there.
+// (the feature VALUES do not enter) and no per-Gaussian geometry backward behind it.  Four waves per tile over a shared staging
+// buffer (the formulation of rounds 1-2, kept here: this kernel is a third of the full backward's time), back-to-front walk, per-wave
+// cull masks, the transposing wave reduction; alpha and T are evaluated exactly as in render_backward_wave_kernel.
 template <int SPAD, int U>
 __global__ void __launch_bounds__(256)
 render_backward_features_kernel(const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list, int S,
@@ -730,7 +452,7 @@ void launch_render_backward_features(hipStream_t s, int W, int H, int S, int n_a
     if (cl.n == 0) return;
 #define R3DG_BF(SP_)                                                                                                   \
     render_backward_features_kernel<SP_, 2><<<chunk * 8, 256, 0, s>>>(                                                 \
-        (const uint2*)ranges, point_list, S, cl, W, H, tiles_x, T, chunk, g_bwd_wave8x8_for_features(), g_cull, tile_order, \
+        (const uint2*)ranges, point_list, S, cl, W, H, tiles_x, T, chunk, /*wave8=*/1, g_cull, tile_order, \
         (const float4*)splat, final_Ts, n_contrib, dL_dpix_f, dL_dfeature)
     switch ((cl.n + 3) / 4) {
         case 1: R3DG_BF(4); break;
@@ -746,53 +468,6 @@ void launch_render_backward_features(hipStream_t s, int W, int H, int S, int n_a
 #undef R3DG_BF
 }
 
-extern int g_cull;
-int g_bwd_wave8x8 = 1;  // measured: 8x8 blocks -6% (fewer waves touched per Gaussian); the forward prefers strips
-int g_bwd_ppl = 1;
-int g_bwd_unroll = 1;   // staged entries evaluated per inner-loop step
-int g_bwd_decoupled = 0;   // R3DG_OPT_BWD_DECOUPLED: 1 = one wave per 8x8 block walks the list on its own (render_backward_wave_kernel)
-
-template <int SPAD, int PPL>
-static void launch_bwd_inst(hipStream_t s, int T, int tiles_x, const uint32_t* tile_order, const uint32_t* ranges,
-                            const uint32_t* point_list, int S, const ChannelList& cl, int W, int H, const float* bg,
-                            const float* splat,
-                            const float* features, const float* final_Ts, const uint32_t* n_contrib,
-                            const float* dL_dpix, const float* dL_dpix_o, const float* dL_dpix_d,
-                            const float* dL_dpix_f, float* dL_dmean2D, float* dL_dconic, float* dL_dopacity,
-                            float* dL_dcolor, float* dL_dfeature, int bg_geom)
-{
-    const int chunk = (T + 7) / 8;
-#define R3DG_BWD_WAVE(SV)                                                                                             \
-    render_backward_wave_kernel<SPAD, SV><<<chunk * 8 * 4, 64, 0, s>>>(                                               \
-        (const uint2*)ranges, point_list, S, cl, W, H, tiles_x, T, g_cull, tile_order, bg, (const float4*)splat, features,   \
-        final_Ts, n_contrib, dL_dpix, dL_dpix_o, dL_dpix_d, dL_dpix_f, dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolor,    \
-        dL_dfeature, bg_geom)
-    if (PPL == 1 && g_bwd_decoupled) {
-        if constexpr (SPAD == 4 || SPAD == 8) {
-            if (cl.n <= 6) { R3DG_BWD_WAVE(true); return; }
-        }
-        R3DG_BWD_WAVE(false);
-        return;
-    }
-#undef R3DG_BWD_WAVE
-#define R3DG_BWD_LAUNCH(UU, SV)                                                                                       \
-    render_backward_kernel<SPAD, PPL, UU, SV><<<chunk * 8, 256 / PPL, 0, s>>>(                                        \
-        (const uint2*)ranges, point_list, S, cl, W, H, tiles_x, T, chunk, g_bwd_wave8x8, g_cull, tile_order, bg,       \
-        (const float4*)splat, features, final_Ts, n_contrib, dL_dpix,   \
-        dL_dpix_o, dL_dpix_d, dL_dpix_f, dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolor, dL_dfeature, bg_geom)
-    // 10 + n <= 16 gradient channels: half-size reduction (only instantiated where it can occur: SPAD 4 and 8)
-    if constexpr (SPAD == 4 || SPAD == 8) {
-        if (cl.n <= 6 && PPL == 1) {
-            if (g_bwd_unroll >= 2) R3DG_BWD_LAUNCH(2, true);
-            else R3DG_BWD_LAUNCH(1, true);
-            return;
-        }
-    }
-    if (g_bwd_unroll >= 4) R3DG_BWD_LAUNCH(4, false);
-    else if (g_bwd_unroll >= 2) R3DG_BWD_LAUNCH(2, false);
-    else R3DG_BWD_LAUNCH(1, false);
-#undef R3DG_BWD_LAUNCH
-}
 
 void launch_render_backward(hipStream_t s, int W, int H, int S, int n_active, const int* active,
                             const uint32_t* tile_order, const uint32_t* ranges, const uint32_t* point_list,
@@ -814,27 +489,26 @@ void launch_render_backward(hipStream_t s, int W, int H, int S, int n_active, co
         for (int i = 0; i < R3DG_MAX_S_BWD; i++) cl.c[i] = i < n_active ? active[i] : 0;
     }
     const int SP = cl.n;                 // channels the kernel carries
-#define R3DG_BWD_ARGS s, T, tiles_x, tile_order, ranges, point_list, S, cl, W, H, bg, splat, \
-                      features, final_Ts, n_contrib, dL_dpix, dL_dpix_o, dL_dpix_d, dL_dpix_f, dL_dmean2D, dL_dconic,         \
-                      dL_dopacity, dL_dcolor, dL_dfeature, bg_geom
-#define R3DG_BWD_CASE(SP_)                                                       \
-    if (g_bwd_ppl >= 2 && (SP_) <= 20) launch_bwd_inst<SP_, 2>(R3DG_BWD_ARGS);   \
-    else launch_bwd_inst<SP_, 1>(R3DG_BWD_ARGS);                                 \
-    break;
+    const int grid = ((T + 7) / 8) * 8 * 4;       // 4 single-wave workgroups per tile, tile ranks padded to a multiple of 8
+#define R3DG_BWD(SP_, SV)                                                                                             \
+    render_backward_wave_kernel<SP_, SV><<<grid, 64, 0, s>>>(                                                         \
+        (const uint2*)ranges, point_list, S, cl, W, H, tiles_x, T, g_cull, tile_order, bg, (const float4*)splat, features,   \
+        final_Ts, n_contrib, dL_dpix, dL_dpix_o, dL_dpix_d, dL_dpix_f, dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolor,    \
+        dL_dfeature, bg_geom)
     switch ((SP + 3) / 4) {
-        case 0: R3DG_BWD_CASE(0)
-        case 1: R3DG_BWD_CASE(4)
-        case 2: R3DG_BWD_CASE(8)
-        case 3: R3DG_BWD_CASE(12)
-        case 4: R3DG_BWD_CASE(16)
-        case 5: R3DG_BWD_CASE(20)
-        case 6: R3DG_BWD_CASE(24)
-        case 7: R3DG_BWD_CASE(28)
-        case 8: R3DG_BWD_CASE(32)
-        default: R3DG_BWD_CASE(36)
+        case 0: R3DG_BWD(0, false); break;
+        // 10 + n <= 16 gradient channels: half-size reduction
+        case 1: if (cl.n <= 6) R3DG_BWD(4, true); else R3DG_BWD(4, false); break;
+        case 2: if (cl.n <= 6) R3DG_BWD(8, true); else R3DG_BWD(8, false); break;
+        case 3: R3DG_BWD(12, false); break;
+        case 4: R3DG_BWD(16, false); break;
+        case 5: R3DG_BWD(20, false); break;
+        case 6: R3DG_BWD(24, false); break;
+        case 7: R3DG_BWD(28, false); break;
+        case 8: R3DG_BWD(32, false); break;
+        default: R3DG_BWD(36, false); break;
     }
-#undef R3DG_BWD_CASE
-#undef R3DG_BWD_ARGS
+#undef R3DG_BWD
 }
 
 }  // namespace r3dg

@@ -147,15 +147,6 @@ def test_forward_parity(name):
     _check_forward(make_case(**CASES[name]), name)
 
 
-@pytest.mark.parametrize("ppl", [1, 2, 4])
-def test_forward_parity_pixels_per_lane(ppl, hip_lib):
-    _opt(FWD_PIXELS_PER_LANE=ppl)
-    try:
-        _check_forward(make_case(S=16, seed=11), "ppl%d" % ppl)
-    finally:
-        _opt(FWD_PIXELS_PER_LANE=1)
-
-
 def test_forward_empty_and_culled():
     from r3dg_rasterization import _C
     case = make_case(P=64, S=5)
@@ -250,101 +241,46 @@ def test_backward_no_geometry_flag():
     _check_backward(make_case(S=5, seed=31), "bg_geom_off", backward_geometry=False)
 
 
-@pytest.mark.parametrize("ppl", [1, 2])
-def test_backward_parity_variants(ppl, hip_lib):
-    _opt(BWD_PIXELS_PER_LANE=ppl)
+@pytest.mark.parametrize("order", [0, 1])
+def test_parity_tile_order(order, hip_lib):
+    """The block -> tile map (longest-tile-first or natural) is a scheduling knob: it must not change results."""
+    _opt(TILE_ORDER=order)
     try:
-        _check_backward(make_case(S=16, seed=41), "bwd_ppl%d" % ppl)
+        _check_backward(make_case(S=16, seed=61, P=4000), "order%d" % order)
+        _check_forward(make_case(S=5, seed=72, scale_log_mean=-2.0, P=1500), "order%d_big" % order)
     finally:
-        _opt(BWD_PIXELS_PER_LANE=1)
-
-
-@pytest.mark.parametrize("fu,bu,order", [(1, 1, 0), (2, 2, 1), (4, 4, 1), (4, 2, 0)])
-def test_parity_inner_loop_unroll_and_tile_order(fu, bu, order, hip_lib):
-    """Scheduling knobs (entries per inner-loop step, longest-tile-first block order) must not change results."""
-    _opt(FWD_UNROLL=fu, BWD_UNROLL=bu, TILE_ORDER=order)
-    try:
-        _check_backward(make_case(S=16, seed=61, P=4000), "unroll_f%d_b%d_order%d" % (fu, bu, order))
-    finally:
-        _opt(FWD_UNROLL=4, BWD_UNROLL=1, TILE_ORDER=1)
-
-
-@pytest.mark.parametrize("fw8,bw8,cull", [(0, 0, 0), (1, 1, 1), (0, 1, 0), (1, 0, 1)])
-def test_parity_wave_shape_and_cull(fw8, bw8, cull, hip_lib):
-    """Lane->pixel map (16x4 strips / 8x8 blocks) and the per-wave sub-tile cull must not change results."""
-    _opt(FWD_WAVE8X8=fw8, BWD_WAVE8X8=bw8, CULL=cull)
-    try:
-        _check_backward(make_case(S=16, seed=71, P=4000), "wave8_f%d_b%d_cull%d" % (fw8, bw8, cull))
-        _check_forward(make_case(S=5, seed=72, scale_log_mean=-2.0, P=1500), "wave8_f%d_cull%d_big" % (fw8, cull))
-    finally:
-        _opt(FWD_WAVE8X8=1, BWD_WAVE8X8=1, CULL=1)
+        _opt(TILE_ORDER=1)
 
 
 @pytest.mark.parametrize("name", ["S16", "big_splats", "ragged_image", "camera_inside", "S0", "S28", "S33"])
-@pytest.mark.parametrize("cull", [1, 0])
-def test_forward_with_decoupled_waves(name, cull, hip_lib):
-    """R3DG_OPT_FWD_DECOUPLED: one wave per 8x8 block walking the tile's list on its own (render_forward_wave_kernel) -- same
-    parity bar against the oracle as the default kernel, and the same outputs as the default kernel (same arithmetic per
-    (pixel, entry) in the same order: the blend buffers may differ by FMA contraction only)."""
+def test_forward_without_the_block_cull(name, hip_lib):
+    """The conservative per-block cull of the tile forward (render_forward_wave_kernel stages only entries that can reach
+    alpha >= 1/255 somewhere in the wave's 8x8 block) must not change a single output: CULL=0 evaluates every entry."""
     case = make_case(**CASES[name])
     ref = _run_forward(case)
-    _opt(FWD_DECOUPLED=1, CULL=cull)
+    _opt(CULL=0)
     try:
-        out, _ = _check_forward(case, "%s_decoupled_cull%d" % (name, cull))
+        out, _ = _check_forward(case, "%s_cull0" % name)
     finally:
-        _opt(FWD_DECOUPLED=0, CULL=1)
+        _opt(CULL=1)
     torch.cuda.synchronize()
-    assert torch.equal(out[1], ref[1]), "n_contrib differs from the default forward kernel"
-    for i in (2, 3, 4, 5, 8):
+    assert torch.equal(out[1], ref[1]), "n_contrib depends on the cull"
+    for i in (2, 3, 4, 5):
         if ref[i].numel():
-            assert torch.allclose(out[i], ref[i], rtol=2e-6, atol=2e-6), (i, float((out[i] - ref[i]).abs().max()))
+            assert torch.equal(out[i], ref[i]), (i, float((out[i] - ref[i]).abs().max()))
+    assert torch.allclose(out[8], ref[8], rtol=1e-5, atol=1e-6)        # (float atomics: order)
 
 
 @pytest.mark.parametrize("name", list(BWD_CASES))
-@pytest.mark.parametrize("cull", [1, 0])
-def test_backward_with_decoupled_waves(name, cull, hip_lib):
-    """R3DG_OPT_BWD_DECOUPLED (render_backward_wave_kernel): the oracle's gradients, like the default kernel."""
-    _opt(BWD_DECOUPLED=1, CULL=cull)
+def test_backward_without_the_block_cull(name, hip_lib):
+    """The same for the tile backward (render_backward_wave_kernel): the oracle's gradients with CULL=0."""
+    _opt(CULL=0)
     try:
-        _check_backward(make_case(**BWD_CASES[name]), "%s_decoupled_cull%d" % (name, cull))
+        _check_backward(make_case(**BWD_CASES[name]), "%s_cull0" % name)
         if name == "S5":
-            _check_backward(make_case(S=5, seed=31), "bg_geom_off_decoupled", backward_geometry=False)
+            _check_backward(make_case(S=5, seed=31), "bg_geom_off_cull0", backward_geometry=False)
     finally:
-        _opt(BWD_DECOUPLED=0, CULL=1)
-
-
-@pytest.mark.parametrize("S,active", [(16, (2, 3, 4)), (16, (2, 3, 4, 5, 6, 7)), (16, (15, 0, 9, 1, 2, 3, 4, 5)), (28, tuple(range(3, 20))),
-                                      (16, ()), (7, (6,))])
-def test_backward_with_decoupled_waves_active_subset(S, active, hip_lib):
-    """The decoupled backward with `active_features` (the half-size reduction for <= 6 channels included) against the default
-    four-wave kernel on the same state."""
-    from r3dg_rasterization import _C
-    from relightable3dgaussian_amd import rasterizer_ops
-    case = make_case(S=S, seed=181 + S, P=4000)
-    a = fwd_args(case, DEV)
-    out = _C.rasterize_gaussians(*a)
-    H, W = case["H"], case["W"]
-    g = torch.Generator().manual_seed(6)
-    gC, gO, gD = [torch.randn(c, H, W, generator=g).to(DEV) for c in (3, 1, 1)]
-    gF = torch.zeros(S, H, W, device=DEV)
-    for ch in active:
-        gF[ch] = torch.randn(H, W, generator=g).to(DEV)
-
-    def run():
-        return rasterizer_ops.rasterize_gaussians_backward(
-            a[0], a[1], a[2], out[9], a[3], a[5], a[6], 1.0, a[8], a[9], a[10], a[11], a[12], gC, gO, gD, gF, a[17],
-            a[18], a[19], out[10], out[0], out[11], out[12], True, False, active_features=active)
-    ref = run()
-    _opt(BWD_DECOUPLED=1)
-    try:
-        new = run()
-    finally:
-        _opt(BWD_DECOUPLED=0)
-    torch.cuda.synchronize()
-    for nm, x, y in zip(("dL_dmeans2D", "dL_dcolors", "dL_dopacity", "dL_dmeans3D", "dL_dfeatures", "dL_dcov3D", "dL_dsh",
-                         "dL_dscales", "dL_drotations"), ref, new):
-        ok, msg = report(nm, y, x, 1e-4, 1e-9)        # float-atomic summation order differs between the two kernels
-        assert ok, msg
+        _opt(CULL=1)
 
 
 @pytest.mark.parametrize("name", ["S16", "big_splats", "ragged_image", "camera_inside", "S0"])
@@ -606,7 +542,7 @@ def test_cull_is_exact(name, hip_lib):
         _opt(CULL=1)
         b = _run_forward(case)
     finally:
-        _opt(FWD_WAVE8X8=1, BWD_WAVE8X8=1, CULL=1)
+        _opt(CULL=1)
     torch.cuda.synchronize()
     assert a[0] == b[0]
     for i, nm in ((1, "n_contrib"), (2, "color"), (3, "opacity"), (4, "depth"), (5, "feature"), (6, "normal"),

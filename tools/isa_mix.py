@@ -26,8 +26,8 @@ KERNELS = [
     ("shading.hip", "shade_forward_row_kernel<7, true, 1, true, false>"),
     ("shading.hip", "shade_forward_row_kernel<19, false, 2, true, false>"),
     ("shading.hip", "shade_forward_transport_kernel"),
-    ("rasterizer_render_fwd.hip", "render_forward_kernel<16, 1, 4>"),
-    ("rasterizer_render_bwd.hip", "render_backward_kernel<4, 1, 1, true>"),
+    ("rasterizer_render_fwd.hip", "render_forward_wave_kernel<16, 4>"),
+    ("rasterizer_render_bwd.hip", "render_backward_wave_kernel<4, true>"),
 ]
 TRANS = ("v_exp_", "v_log_", "v_rcp_", "v_rsq_", "v_sqrt_", "v_sin_", "v_cos_")
 
