@@ -13,7 +13,7 @@ def main():
     n = int(sys.argv[2]) if len(sys.argv) > 2 else 10
     cur = sqlite3.connect(db).cursor()
     rows = list(cur.execute("select name, start, end from kernels order by start"))
-    marks = [i for i, r in enumerate(rows) if "render_backward_kernel" in r[0]]
+    marks = [i for i, r in enumerate(rows) if "r3dg::render_backward_" in r[0] and "features" not in r[0]]
     marks = marks[-(n + 1):]
     if len(marks) < 2:
         print("not enough steps")
@@ -60,7 +60,7 @@ def sequence():
     """Print the kernel sequence (name, us) of the last full step."""
     cur = sqlite3.connect(sys.argv[1]).cursor()
     rows = list(cur.execute("select name, start, end from kernels order by start"))
-    marks = [i for i, r in enumerate(rows) if "render_backward_kernel" in r[0]]
+    marks = [i for i, r in enumerate(rows) if "r3dg::render_backward_" in r[0] and "features" not in r[0]]
     a, b = marks[-2], marks[-1]
     t0 = rows[a][1]
     for name, s, e in rows[a:b]:
