@@ -94,7 +94,7 @@ frs_build_tables_kernel(int K, int nblk, const float* __restrict__ zsamples /*[K
     tables[idx] = val;
 }
 
-// ---- coefficient rotation (thread per Gaussian; rows through LDS with coalesced 16-byte accesses, common.hpp) ---------------
+// ---- coefficient rotation (thread per Gaussian, the row in registers) -----------------------------------------------------------
 // band l of the function is sampled at the rotated points R p_j and re-expanded: c'_l = A_l^{-1} [sum_i c_{l,i} Y_{l,i}(R p_j)]_j
 template <int A0, int N, bool BACK>
 __device__ __forceinline__ void frs_rotate_band(const float (&R)[9], const float (*pts)[3], const float (*ainv)[N], float* row)
@@ -164,23 +164,28 @@ template <bool BACK>
 __global__ void __launch_bounds__(256)
 frs_rotate_kernel(int P, const float* __restrict__ ray_normals, const float* __restrict__ src, float* __restrict__ dst)
 {
-    __shared__ float s_rows[256 * 49];
-    __shared__ uint8_t s_live[256];
-    const int first = blockIdx.x * 256, g = first + (int)threadIdx.x;
-    s_live[threadIdx.x] = 1;
-    __syncthreads();
-    stage_rows_in_256(src, first, P, 48, s_live, s_rows);
-    __syncthreads();
-    if (g < P) {
-        float R[9];
-        frs_rotation(ray_normals[3 * (size_t)g], ray_normals[3 * (size_t)g + 1], ray_normals[3 * (size_t)g + 2], R);
-        float* row = s_rows + threadIdx.x * 49;                 // band 0 (the constant) is rotation invariant
-        frs_rotate_band<1, 3, BACK>(R, kShRotPoints1, kShRotAinv1, row);
-        frs_rotate_band<4, 5, BACK>(R, kShRotPoints2, kShRotAinv2, row);
-        frs_rotate_band<9, 7, BACK>(R, kShRotPoints3, kShRotAinv3, row);
+    // Thread per Gaussian, its 192-byte row in registers: twelve 16-byte loads in flight per lane, twelve 16-byte stores.  (The
+    // first version staged 256 rows through 50 KB of LDS for coalescing: 3 workgroups per CU, two barriers, 44 us for 115 MB.
+    // A wave's 16-byte accesses to 64 different rows cost the texture-address unit 64 cycles each -- 12 us for the whole array --
+    // and the lines are used completely by the other 11 accesses of the same lanes.)
+    const int g = blockIdx.x * 256 + (int)threadIdx.x;
+    if (g >= P) return;
+    float row[48];
+    const float4* s4 = reinterpret_cast<const float4*>(src + (size_t)g * 48);
+#pragma unroll
+    for (int q = 0; q < 12; q++) {
+        const float4 v = s4[q];
+        row[4 * q] = v.x; row[4 * q + 1] = v.y; row[4 * q + 2] = v.z; row[4 * q + 3] = v.w;
     }
-    __syncthreads();
-    stage_rows_out_256(dst, first, P, 48, s_rows);
+    float R[9];
+    frs_rotation(ray_normals[3 * (size_t)g], ray_normals[3 * (size_t)g + 1], ray_normals[3 * (size_t)g + 2], R);
+    // band 0 (the constant) is rotation invariant
+    frs_rotate_band<1, 3, BACK>(R, kShRotPoints1, kShRotAinv1, row);
+    frs_rotate_band<4, 5, BACK>(R, kShRotPoints2, kShRotAinv2, row);
+    frs_rotate_band<9, 7, BACK>(R, kShRotPoints3, kShRotAinv3, row);
+    float4* d4 = reinterpret_cast<float4*>(dst + (size_t)g * 48);
+#pragma unroll
+    for (int q = 0; q < 12; q++) d4[q] = make_float4(row[4 * q], row[4 * q + 1], row[4 * q + 2], row[4 * q + 3]);
 }
 
 // ---- per-lane sample block: 4 consecutive samples of one Gaussian ------------------------------------------------------------
