@@ -18,6 +18,7 @@
 //   * backward only: record + samples of the wave's NEXT 64-sample block arrive by LDS-DMA (global_load_lds_dwordx4),
 //     double buffered, while the current block is computed (three passes per block, 12 parked floats per lane).
 #include "common.hpp"
+#include <cstdlib>
 #include <map>
 #include <mutex>
 #include <stdexcept>
@@ -1251,7 +1252,10 @@ void launch_shade_frs_forward_main(hipStream_t s, int P, int K, const float* bas
     const float4* env4 = reinterpret_cast<const float4*>(stream_scratch(s, 1, ntexel * sizeof(float4)));   // (written by _aux)
     const size_t smem = frs_forward_lds_bytes(He, We);
     int grid = frs_grid(P, (const void*)shade_forward_frs_kernel, smem);
-    if (leave_room) grid = grid > shade_cus() * 2 ? shade_cus() * 2 : grid;      // the instance ordering runs beside it
+    // beside the instance ordering (fused iteration) ONE workgroup per CU: the ordering chain (projection -> binning -> tile sort) is
+    // the longer of the two concurrent paths and every wave this kernel keeps resident slows it -- measured per CU cap: 1 -> 618-627,
+    // 2 -> 598-610, 3 -> 597-607 it/s (this kernel alone 0.21 / 0.195 / 0.21 ms; a high-priority ordering stream: no effect)
+    if (leave_room) grid = grid > shade_cus() ? shade_cus() : grid;
     shade_forward_frs_kernel<<<grid, 64 * FRS_WAVES, smem, s>>>(P, K, base_color, roughness, normals, viewdirs, cprime, env4,
                                                                 He, We, visibility, dirs, frs_area(uniform_area), taps, tables, valid,
                                                                 out);
