@@ -530,10 +530,13 @@ shade_backward_frs_kernel(int P, int K, const float* __restrict__ base_color, co
             // table words first, then the prefetch (see the forward); with the tables in LDS (K <= FRS_TAB_LDS_MAX_K) no vector
             // memory load at all sits between the prefetch and the end of the block
             const float* tb = (TAB_LDS ? s_tab : tables) + (size_t)b * 512 + lane;
-            float a[4] = {0.f, 0.f, 0.f, 0.f};
-            if (!TAB_LDS) {
+            float a[4] = {0.f, 0.f, 0.f, 0.f}, a2[4] = {0.f, 0.f, 0.f, 0.f};
+            if (!TAB_LDS) {                       // (K > 128: all eight words of the block before the prefetch)
 #pragma unroll
-                for (int s = 0; s < 4; s++) a[s] = tb[64 * s];
+                for (int s = 0; s < 4; s++) {
+                    a[s] = tb[64 * s];
+                    a2[s] = tb[64 * (4 + s)];
+                }
             }
             const bool last = b + 1 == nblk;
             if (!last) {
@@ -650,7 +653,7 @@ shade_backward_frs_kernel(int P, int K, const float* __restrict__ base_color, co
                 accb[5] += (dVy - G.V[1] * vd) / G.vlen;
                 accb[6] += (dVz - G.V[2] * vd) / G.vlen;
                 // gradient product: dc'[i][c] += Yz[k][i] dl[c] over the 4 samples (one per q) of this v
-                const float a2v = tb[64 * (4 + v)];
+                const float a2v = TAB_LDS ? tb[64 * (4 + v)] : a2[v];
 #pragma unroll
                 for (int c = 0; c < 3; c++) dcq[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(a2v, dl[c], dcq[c], 0, 0, 0);
             }
