@@ -311,41 +311,31 @@ extern int g_cull;
 // incident light).  Of the reference's backward (backward.cu:401-614) only
 //     dL_dfeature[g, c] += alpha * T * dL_dpixel_f[c]                                                   (backward.cu:566)
 // is then ever used: no accum_rec recursion, no dL_dalpha, no mean / conic / opacity / colour atomics, no payload staging
-// (the feature VALUES do not enter) and no per-Gaussian geometry backward behind it.  Four waves per tile over a shared staging
-// buffer (the formulation of rounds 1-2, kept here: this kernel is a third of the full backward's time), back-to-front walk, per-wave
-// cull masks, the transposing wave reduction; alpha and T are evaluated exactly as in render_backward_wave_kernel.
-template <int SPAD, int U>
-__global__ void __launch_bounds__(256)
+// (the feature VALUES do not enter) and no per-Gaussian geometry backward behind it.  One wave per 8x8 block like
+// render_backward_wave_kernel (back-to-front walk from the block's own deepest contributor, per-block cull, compacted geometry in
+// 2 KB of private LDS, records one round ahead), the transposing wave reduction; alpha and T are evaluated exactly as there.
+template <int SPAD>
+__global__ void __launch_bounds__(64)
 render_backward_features_kernel(const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list, int S,
-                                ChannelList chan_list, int W, int H, int tiles_x, int num_tiles, int xcd_chunk, int wave8,
-                                int cull, const uint32_t* __restrict__ tile_order, const float4* __restrict__ splat,
+                                ChannelList chan_list, int W, int H, int tiles_x, int num_tiles, int cull,
+                                const uint32_t* __restrict__ tile_order, const float4* __restrict__ splat,
                                 const float* __restrict__ final_Ts, const uint32_t* __restrict__ n_contrib,
                                 const float* __restrict__ dL_dpixels_f, float* __restrict__ dL_dfeature)
 {
-    constexpr int NT = 256, NW = 4;
     constexpr int NVP = next_pow2(SPAD);
     const int SA = chan_list.n;
-    int tile;
-    if (tile_order != nullptr) {
-        if ((int)blockIdx.x >= num_tiles) return;
-        tile = (int)tile_order[blockIdx.x];
-    } else {
-        tile = (int)(blockIdx.x & 7u) * xcd_chunk + (int)(blockIdx.x >> 3);
-        if (tile >= num_tiles) return;
-    }
+    const int xcd = (int)(blockIdx.x & 7u), j = (int)(blockIdx.x >> 3), sub = j & 3, rank = (j >> 2) * 8 + xcd;
+    if (rank >= num_tiles) return;
+    const int tile = tile_order != nullptr ? (int)tile_order[rank] : rank;
     const int tile_x = tile % tiles_x, tile_y = tile / tiles_x;
-    __shared__ float4 s_geo0[NT];
-    __shared__ float4 s_geo1[NT];
-    __shared__ uint32_t s_max[NW];
-    __shared__ unsigned long long s_cand[NW][NW];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    int lx = lane & 15, ly = wave * 4 + (lane >> 4);
-    if (wave8) {
-        lx = (lane & 7) + 8 * (wave & 1);
-        ly = (lane >> 3) + 8 * (wave >> 1);
-    }
-    const int px = tile_x * R3DG_TILE_X + lx, py = tile_y * R3DG_TILE_Y + ly;
+    __shared__ float4 s_geo0[64];                 // mean.x, mean.y, conic.x, conic.y
+    __shared__ float4 s_geo1[64];                 // conic.z, opacity, front index bits, id bits
+    const int lane = threadIdx.x;
+    const int bx = 8 * (sub & 1), by = 8 * (sub >> 1);
+    const int px = tile_x * R3DG_TILE_X + bx + (lane & 7);
+    const int py = tile_y * R3DG_TILE_Y + by + (lane >> 3);
     const float pxf = (float)px, pyf = (float)py;
+    const float x0 = (float)(tile_x * R3DG_TILE_X + bx), y0 = (float)(tile_y * R3DG_TILE_Y + by);
     const size_t HW = (size_t)H * W;
     const uint2 range = ranges[tile];
     const int chan = transposed_channel<NVP>(lane);
@@ -358,77 +348,56 @@ render_backward_features_kernel(const uint2* __restrict__ ranges, const uint32_t
     float dl[SPAD];
 #pragma unroll
     for (int ch = 0; ch < SPAD; ch++) dl[ch] = (inside && ch < SA) ? dL_dpixels_f[(size_t)chan_list.c[ch] * HW + pix] : 0.f;
-    uint32_t my_max = lastc;
+    uint32_t mx = lastc;
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) my_max = max(my_max, (uint32_t)__shfl_xor((int)my_max, o, 64));
-    if (lane == 0) s_max[wave] = my_max;
-    __syncthreads();
-    uint32_t m = 0;
-#pragma unroll
-    for (int w = 0; w < NW; w++) m = max(m, s_max[w]);
-    const int n = (int)m;
-    for (int base = 0; base < n; base += NT) {
-        __syncthreads();
-        float4 my_geo = make_float4(0.f, 0.f, 0.f, 0.f);
-        float2 my_co = make_float2(0.f, 0.f);
-        if (base + tid < n) {
-            const uint32_t g = point_list[range.x + (uint32_t)(n - 1 - (base + tid))];
-            const float4* rec = splat + 4 * (size_t)g;
-            const float4 r0 = rec[0], r1 = rec[1];
-            s_geo0[tid] = my_geo = r0;
-            s_geo1[tid] = make_float4(r1.x, r1.y, r1.z, __uint_as_float(g));
-            my_co = make_float2(r1.x, r1.y);
+    for (int o = 32; o > 0; o >>= 1) mx = max(mx, (uint32_t)__shfl_xor((int)mx, o, 64));
+    const int n = (int)mx;                        // this block's deepest contributor: the walk covers front indices [0, n)
+
+    auto load_index = [&](int e0) -> uint32_t {
+        return e0 + lane < n ? point_list[range.x + (uint32_t)(n - 1 - (e0 + lane))] : 0u;
+    };
+    auto stage = [&](const float4& a0, const float4& a1, uint32_t g, int e0) -> int {
+        const bool cand = e0 + lane < n &&
+                          (cull == 0 || splat_may_touch(a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, x0, x0 + 7.f, y0, y0 + 7.f));
+        const unsigned long long m = __ballot(cand);
+        if (cand) {
+            const int slot = __popcll(m & ((1ull << lane) - 1ull));
+            s_geo0[slot] = a0;
+            s_geo1[slot] = make_float4(a1.x, a1.y, __uint_as_float((uint32_t)(n - 1 - (e0 + lane))), __uint_as_float(g));
         }
-#pragma unroll
-        for (int w = 0; w < NW; w++) {
-            int bx = 0, by = w * 4, bw = 15, bh = 3;
-            if (wave8) { bx = 8 * (w & 1); by = 8 * (w >> 1); bw = 7; bh = 7; }
-            const float x0 = (float)(tile_x * R3DG_TILE_X + bx), y0 = (float)(tile_y * R3DG_TILE_Y + by);
-            bool c = base + tid < n && (uint32_t)(n - 1 - (base + tid)) < s_max[w];
-            if (cull) c = c && splat_may_touch(my_geo.x, my_geo.y, my_geo.z, my_geo.w, my_co.x, my_co.y, x0,
-                                               x0 + (float)bw, y0, y0 + (float)bh);
-            const unsigned long long mk = __ballot(c);
-            if (lane == 0) s_cand[w][wave] = mk;
+        return __popcll(m);
+    };
+    // records one round ahead, index two (render_backward_wave_kernel's pipeline without a payload)
+    uint32_t g_cur = load_index(0);
+    float4 r0 = splat[4 * (size_t)g_cur], r1 = splat[4 * (size_t)g_cur + 1];
+    uint32_t g_nxt = load_index(64);
+    for (int base = 0; base < n; base += 64) {
+        const int ncand = stage(r0, r1, g_cur, base);
+        g_cur = g_nxt;
+        if (base + 64 < n) {
+            r0 = splat[4 * (size_t)g_cur];
+            r1 = splat[4 * (size_t)g_cur + 1];
+            g_nxt = load_index(base + 128);
         }
-        __syncthreads();
-        for (int grp = 0; grp < NW; grp++) {
-            const unsigned long long mv = s_cand[wave][grp];
-            unsigned long long cm = ((unsigned long long)__builtin_amdgcn_readfirstlane((int)(mv >> 32)) << 32) |
-                                    (unsigned int)__builtin_amdgcn_readfirstlane((int)(unsigned int)mv);
-            while (cm != 0ull) {
-                float4 g1[U];
-                float alpha[U];
-                bool any_hit = false;
+        __builtin_amdgcn_wave_barrier();
+        for (int k = 0; k < ncand; k++) {
+            const float4 g0 = s_geo0[k], g1 = s_geo1[k];
+            const uint32_t front = __float_as_uint(g1.z);
+            const float dx = g0.x - pxf, dy = g0.y - pyf;
+            const float power = -0.5f * (g0.z * dx * dx + g1.x * dy * dy) - g0.w * dx * dy;
+            float a = fminf(0.99f, g1.y * fast_exp_b(power));
+            if (!(front < lastc) || power > 0.0f || a < 1.0f / 255.0f) a = 0.f;
+            if (__ballot(a != 0.f) == 0ull) continue;
+            // back to front: T before this Gaussian = T after it / (1 - alpha)   (backward.cu:533)
+            T = T * __builtin_amdgcn_rcpf(1.f - a);
+            const float wgt = a * T;
+            float vr[NVP];
 #pragma unroll
-                for (int u = 0; u < U; u++) {
-                    const bool valid = cm != 0ull;
-                    const int jj = valid ? grp * 64 + __builtin_ctzll(cm) : 0;
-                    if (valid) cm &= cm - 1ull;
-                    const float4 g0 = s_geo0[jj];
-                    g1[u] = s_geo1[jj];
-                    const uint32_t front = (uint32_t)(n - 1 - (base + jj));
-                    const float dx = g0.x - pxf, dy = g0.y - pyf;
-                    const float power = -0.5f * (g0.z * dx * dx + g1[u].x * dy * dy) - g0.w * dx * dy;
-                    float a = fminf(0.99f, g1[u].y * fast_exp_b(power));
-                    if (!(front < lastc) || power > 0.0f || a < 1.0f / 255.0f || !valid) a = 0.f;
-                    alpha[u] = a;
-                    any_hit = any_hit || (a != 0.f);
-                }
-                if (__ballot(any_hit) == 0ull) continue;
-#pragma unroll
-                for (int u = 0; u < U; u++) {
-                    if (__ballot(alpha[u] != 0.f) == 0ull) continue;
-                    // back to front: T before this Gaussian = T after it / (1 - alpha)   (backward.cu:533)
-                    T = T * __builtin_amdgcn_rcpf(1.f - alpha[u]);
-                    const float wgt = alpha[u] * T;
-                    float vr[NVP];
-#pragma unroll
-                    for (int k = 0; k < NVP; k++) vr[k] = k < SPAD ? wgt * dl[k] : 0.f;
-                    const float total = transpose_reduce<NVP, true>(vr);
-                    if (dst_base != nullptr) atomicAdd(dst_base + (size_t)__float_as_uint(g1[u].w) * (size_t)S, total);
-                }
-            }
+            for (int q = 0; q < NVP; q++) vr[q] = q < SPAD ? wgt * dl[q] : 0.f;
+            const float total = transpose_reduce<NVP, true>(vr);
+            if (dst_base != nullptr) atomicAdd(dst_base + (size_t)__float_as_uint(g1.w) * (size_t)S, total);
         }
+        __builtin_amdgcn_wave_barrier();
     }
 }
 
@@ -451,9 +420,9 @@ void launch_render_backward_features(hipStream_t s, int W, int H, int S, int n_a
     }
     if (cl.n == 0) return;
 #define R3DG_BF(SP_)                                                                                                   \
-    render_backward_features_kernel<SP_, 2><<<chunk * 8, 256, 0, s>>>(                                                 \
-        (const uint2*)ranges, point_list, S, cl, W, H, tiles_x, T, chunk, /*wave8=*/1, g_cull, tile_order, \
-        (const float4*)splat, final_Ts, n_contrib, dL_dpix_f, dL_dfeature)
+    render_backward_features_kernel<SP_><<<chunk * 8 * 4, 64, 0, s>>>(                                                 \
+        (const uint2*)ranges, point_list, S, cl, W, H, tiles_x, T, g_cull, tile_order, (const float4*)splat, final_Ts,   \
+        n_contrib, dL_dpix_f, dL_dfeature)
     switch ((cl.n + 3) / 4) {
         case 1: R3DG_BF(4); break;
         case 2: R3DG_BF(8); break;
