@@ -170,7 +170,13 @@ def ptr(t):
 
 
 def current_stream():
+    """The raw HIP stream torch launches on right now (of the current device).  torch.cuda.current_stream() builds a Stream
+    object through half a dozen Python layers (10 us; the fused iteration asks 16 times): the C accessor it ends in is used
+    directly when this torch has it."""
     import torch
+    raw = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+    if raw is not None:
+        return raw(torch._C._cuda_getDevice())
     return torch.cuda.current_stream().cuda_stream
 
 
