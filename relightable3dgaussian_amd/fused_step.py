@@ -435,7 +435,11 @@ class FusedStage2Step(_BoundedForward):
             if self._frs is not None:
                 self._frs.forward(self.a_base, self.a_rough, self.a_normal, self.a_viewdirs, self.incidents, env_c,
                                   self.visibility, self.incident_dirs, self.incident_areas, taps, self.shade_out,
-                                  uniform_area=self._uniform_area, leave_room=self._order_stream is not None)
+                                  uniform_area=self._uniform_area,
+                                  # (one workgroup per CU beside the instance ordering, which is the longer path -- unless the
+                                  # deferred incident-light update of a data-parallel run sits in front of this kernel: then this
+                                  # path is the longer one and takes every CU it can get: 558 -> 568 it/s on one rank)
+                                  leave_room=self._order_stream is not None and not self.dp)
             else:
                 _lib.check(L.r3dg_shade_forward_cached(
                     stream(), P, self.K, self.M, self.a_base.data_ptr(), self.a_rough.data_ptr(), self.a_normal.data_ptr(),
