@@ -275,7 +275,10 @@ int r3dg_shade_frs_backward(void* stream, int P, int K, const float* d_base_colo
                             const int32_t* d_invalid_list, int n_invalid, const float* d_cprime, float* d_dcprime,
                             const float* d_dL_dpbr, const float* d_dL_ddiffuse_light, float* d_dL_dbase_color,
                             float* d_dL_droughness, float* d_dL_dviewdirs, float* d_dL_dincidents, float* d_dL_denv,
-                            const float* d_block_absmax, int n_block_absmax);
+                            const float* d_block_absmax, int n_block_absmax, void* rotate_stream);
+/*   rotate_stream: NULL, or a second stream for the rotation of the coefficient gradient back to d_dL_dincidents (ordered after the
+ *   main kernel by an event; it overlaps the general kernel's launch on the listed Gaussians and the caller's next launches on
+ *   `stream`).  The caller joins rotate_stream before anything reads d_dL_dincidents. */
 
 int r3dg_shade_backward(void* stream, int P, int K, int M, const float* d_base_color, const float* d_roughness,
                         const float* d_normals, const float* d_viewdirs, const float* d_incidents, const float* d_env,

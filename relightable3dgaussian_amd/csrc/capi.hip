@@ -63,25 +63,26 @@ size_t shade_frs_table_floats(int K);
 bool shade_frs_supported(int K, int M, int He, int We);
 void launch_shade_frs_build_tables(hipStream_t s, int K, const float* zsamples, float* tables);
 void launch_shade_frs_classify(hipStream_t s, int P, const float* ray_normals, uint8_t* valid);
-void launch_shade_frs_forward_aux(hipStream_t s, int P, const float* incidents, const float* env, int He, int We,
-                                  const float* ray_normals, float* cprime);
+void launch_shade_frs_forward_aux(hipStream_t s, int P, const float* incidents, const float* ray_normals, float* cprime);
 void launch_shade_frs_forward_main(hipStream_t s, int P, int K, const float* base_color, const float* roughness,
-                                   const float* normals, const float* viewdirs, int He, int We, const float* visibility,
+                                   const float* normals, const float* viewdirs, const float* env, int He, int We,
+                                   const float* visibility,
                                    const float* dirs, float uniform_area, const uint32_t* taps, const float* tables,
                                    const uint8_t* valid, const float* cprime, bool leave_room, float* out);
 void launch_shade_frs_forward_listed(hipStream_t s, int P, int K, const float* base_color, const float* roughness,
                                      const float* normals, const float* viewdirs, const float* incidents, const float* env, int He,
                                      int We, const float* visibility, const float* dirs, const float* areas, float uniform_area,
                                      const uint32_t* taps, const int* invalid_list, int n_invalid, bool leave_room, float* out);
-const unsigned int* launch_shade_frs_backward_aux(hipStream_t s, int P, const float* env, int He, int We, const float* g_pbr,
-                                                  const float* g_diff, const float* block_absmax, int n_block_absmax,
-                                                  int* gmax_n);
+const unsigned int* launch_shade_frs_backward_aux(hipStream_t s, int P, const float* g_pbr, const float* g_diff,
+                                                  const float* block_absmax, int n_block_absmax, int* gmax_n);
 void launch_shade_frs_backward_main(hipStream_t s, int P, int K, const float* base_color, const float* roughness,
-                                    const float* normals, const float* viewdirs, int He, int We, const float* visibility,
+                                    const float* normals, const float* viewdirs, const float* env, int He, int We,
+                                    const float* visibility,
                                     const float* dirs, float uniform_area, const uint32_t* taps, const float* tables,
                                     const uint8_t* valid, const float* cprime, float* dcp, const float* g_pbr, const float* g_diff,
                                     float* d_base, float* d_rough, float* d_view, float* d_env, const unsigned int* gmax, int gmax_n);
-void launch_shade_frs_backward_rotate(hipStream_t s, int P, const float* ray_normals, const float* dcp, float* d_inc);
+void launch_shade_frs_backward_rotate(hipStream_t s, int P, const float* ray_normals, const float* dcp, float* d_inc,
+                                      const uint8_t* valid);
 void launch_shade_frs_backward_listed(hipStream_t s, int P, int K, const float* base_color, const float* roughness,
                                       const float* normals, const float* viewdirs, const float* incidents, const float* env, int He,
                                       int We, const float* visibility, const float* dirs, const float* areas, const uint32_t* taps,
@@ -1234,11 +1235,11 @@ int r3dg_shade_frs_forward(void* stream_, int P, int K, const float* base_color,
         const bool leave_room = (flags & R3DG_SHADE_LEAVE_ROOM) != 0;
         {
             StageTimer t(stream, ST_SHADE_AUX);
-            launch_shade_frs_forward_aux(stream, P, incidents, env, He, We, ray_normals, cprime);
+            launch_shade_frs_forward_aux(stream, P, incidents, ray_normals, cprime);
         }
         {
             StageTimer t(stream, ST_SHADE_FWD);
-            launch_shade_frs_forward_main(stream, P, K, base_color, roughness, normals, viewdirs, He, We, visibility, incident_dirs,
+            launch_shade_frs_forward_main(stream, P, K, base_color, roughness, normals, viewdirs, env, He, We, visibility, incident_dirs,
                                           uniform_area, taps, tables, valid, cprime, leave_room, out);
         }
         if (n_invalid > 0) {
@@ -1258,7 +1259,7 @@ int r3dg_shade_frs_backward(void* stream_, int P, int K, const float* base_color
                             const uint8_t* valid, const int32_t* invalid_list, int n_invalid, const float* cprime,
                             float* dcprime, const float* dL_dpbr, const float* dL_ddiffuse_light, float* dL_dbase_color,
                             float* dL_droughness, float* dL_dviewdirs, float* dL_dincidents, float* dL_denv,
-                            const float* block_absmax, int n_block_absmax)
+                            const float* block_absmax, int n_block_absmax, void* rotate_stream_)
 {
     if (P < 0 || K <= 0 || He <= 0 || We <= 0 || n_invalid < 0 || n_invalid > P || n_block_absmax < 0)
         return invalid("shade_frs_backward: bad sizes");
@@ -1275,18 +1276,28 @@ int r3dg_shade_frs_backward(void* stream_, int P, int K, const float* base_color
         const unsigned int* gmax;
         {
             StageTimer t(stream, ST_SHADE_AUX);
-            gmax = launch_shade_frs_backward_aux(stream, P, env, He, We, dL_dpbr, dL_ddiffuse_light, block_absmax, n_block_absmax,
-                                                 &gmax_n);
+            gmax = launch_shade_frs_backward_aux(stream, P, dL_dpbr, dL_ddiffuse_light, block_absmax, n_block_absmax, &gmax_n);
         }
         {
             StageTimer t(stream, ST_SHADE_BWD);
-            launch_shade_frs_backward_main(stream, P, K, base_color, roughness, normals, viewdirs, He, We, visibility, incident_dirs,
+            launch_shade_frs_backward_main(stream, P, K, base_color, roughness, normals, viewdirs, env, He, We, visibility, incident_dirs,
                                            uniform_area, taps, tables, valid, cprime, dcprime, dL_dpbr, dL_ddiffuse_light,
                                            dL_dbase_color, dL_droughness, dL_dviewdirs, dL_denv, gmax, gmax_n);
         }
+        // the rotation back may run on a second stream (ordered after the main kernel by an event; the CALLER joins that stream
+        // before anything reads dL_dincidents): it then overlaps the general kernel on the listed Gaussians and whatever the
+        // caller queues next on `stream`
+        hipStream_t rstream = rotate_stream_ != nullptr ? (hipStream_t)rotate_stream_ : stream;
+        if (rstream != stream) {
+            hipEvent_t ev;
+            R3DG_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+            R3DG_HIP(hipEventRecord(ev, stream));
+            R3DG_HIP(hipStreamWaitEvent(rstream, ev, 0));
+            R3DG_HIP(hipEventDestroy(ev));
+        }
         {
-            StageTimer t(stream, ST_SHADE_AUX);
-            launch_shade_frs_backward_rotate(stream, P, ray_normals, dcprime, dL_dincidents);
+            StageTimer t(rstream, ST_SHADE_AUX);
+            launch_shade_frs_backward_rotate(rstream, P, ray_normals, dcprime, dL_dincidents, rstream != stream ? valid : nullptr);
         }
         if (n_invalid > 0) {
             StageTimer t(stream, ST_SHADE_LISTED);

@@ -1227,36 +1227,31 @@ static inline float frs_area(float uniform_area) { return uniform_area > 0.f ? u
 
 // A fixed-ray-set call is three groups of launches, timed as three stages by the C ABI (capi.hip) so that the profile's
 // "shade_forward" / "shade_backward" rows are ONE kernel each:
-//   aux     the texture padded to float4 texels, the coefficient rotation (forward: incidents -> cprime, kept for the backward;
-//           backward: dcprime -> d_inc), the max |upstream gradient| reduction when the caller has none
+//   aux     the coefficient rotation (forward: incidents -> cprime, kept for the backward; backward: dcprime -> d_inc), the
+//           max |upstream gradient| reduction when the caller has none
 //   main    the MFMA kernel for the Gaussians on the rotated path
 //   listed  the general kernels for the listed rest
-void launch_shade_frs_forward_aux(hipStream_t s, int P, const float* incidents, const float* env, int He, int We,
-                                  const float* ray_normals, float* cprime)
+void launch_shade_frs_forward_aux(hipStream_t s, int P, const float* incidents, const float* ray_normals, float* cprime)
 {
     if (P == 0) return;
-    const size_t ntexel = (size_t)He * We;
-    float4* env4 = reinterpret_cast<float4*>(stream_scratch(s, 1, ntexel * sizeof(float4)));
-    shade_pad_env_kernel<<<(int)((ntexel + 255) / 256), 256, 0, s>>>((int)ntexel, env, env4);
-    frs_rotate_kernel<false><<<(P + 255) / 256, 256, 0, s>>>(P, ray_normals, incidents, cprime);
+    frs_rotate_kernel<false><<<(P + 255) / 256, 256, 0, s>>>(P, ray_normals, incidents, cprime, nullptr);
     check_launch(s, false, "frs_rotate_kernel");
 }
 
 void launch_shade_frs_forward_main(hipStream_t s, int P, int K, const float* base_color, const float* roughness,
-                                   const float* normals, const float* viewdirs, int He, int We, const float* visibility,
+                                   const float* normals, const float* viewdirs, const float* env, int He, int We,
+                                   const float* visibility,
                                    const float* dirs, float uniform_area, const uint32_t* taps, const float* tables,
                                    const uint8_t* valid, const float* cprime, bool leave_room, float* out)
 {
     if (P == 0) return;
-    const size_t ntexel = (size_t)He * We;
-    const float4* env4 = reinterpret_cast<const float4*>(stream_scratch(s, 1, ntexel * sizeof(float4)));   // (written by _aux)
     const size_t smem = frs_forward_lds_bytes(He, We);
     int grid = frs_grid(P, (const void*)shade_forward_frs_kernel, smem);
     // beside the instance ordering (fused iteration) ONE workgroup per CU: the ordering chain (projection -> binning -> tile sort) is
     // the longer of the two concurrent paths and every wave this kernel keeps resident slows it -- measured per CU cap: 1 -> 618-627,
     // 2 -> 598-610, 3 -> 597-607 it/s (this kernel alone 0.21 / 0.195 / 0.21 ms; a high-priority ordering stream: no effect)
     if (leave_room) grid = grid > shade_cus() ? shade_cus() : grid;
-    shade_forward_frs_kernel<<<grid, 64 * FRS_WAVES, smem, s>>>(P, K, base_color, roughness, normals, viewdirs, cprime, env4,
+    shade_forward_frs_kernel<<<grid, 64 * FRS_WAVES, smem, s>>>(P, K, base_color, roughness, normals, viewdirs, cprime, env,
                                                                 He, We, visibility, dirs, frs_area(uniform_area), taps, tables, valid,
                                                                 out);
     check_launch(s, false, "shade_forward_frs_kernel");
@@ -1273,9 +1268,8 @@ void launch_shade_frs_forward_listed(hipStream_t s, int P, int K, const float* b
 }
 
 // (before _main) -> the words the main kernel scales its fixed-point texture accumulation by
-const unsigned int* launch_shade_frs_backward_aux(hipStream_t s, int P, const float* env, int He, int We, const float* g_pbr,
-                                                  const float* g_diff, const float* block_absmax, int n_block_absmax,
-                                                  int* gmax_n)
+const unsigned int* launch_shade_frs_backward_aux(hipStream_t s, int P, const float* g_pbr, const float* g_diff,
+                                                  const float* block_absmax, int n_block_absmax, int* gmax_n)
 {
     unsigned int* scratch = shade_scratch();
     const unsigned int* gmax = scratch;
@@ -1288,43 +1282,41 @@ const unsigned int* launch_shade_frs_backward_aux(hipStream_t s, int P, const fl
         const int nb = (3 * P + 255) / 256;
         grad_absmax_kernel<<<nb < 256 ? nb : 256, 256, 0, s>>>(3 * P, g_pbr, g_diff, scratch);
     }
-    const size_t ntexel = (size_t)He * We;
-    float4* env4 = reinterpret_cast<float4*>(stream_scratch(s, 1, ntexel * sizeof(float4)));
-    shade_pad_env_kernel<<<(int)((ntexel + 255) / 256), 256, 0, s>>>((int)ntexel, env, env4);
     return gmax;
 }
 
 void launch_shade_frs_backward_main(hipStream_t s, int P, int K, const float* base_color, const float* roughness,
-                                    const float* normals, const float* viewdirs, int He, int We, const float* visibility,
+                                    const float* normals, const float* viewdirs, const float* env, int He, int We,
+                                    const float* visibility,
                                     const float* dirs, float uniform_area, const uint32_t* taps, const float* tables,
                                     const uint8_t* valid, const float* cprime, float* dcp, const float* g_pbr, const float* g_diff,
                                     float* d_base, float* d_rough, float* d_view, float* d_env, const unsigned int* gmax, int gmax_n)
 {
     if (P == 0) return;
-    const size_t ntexel = (size_t)He * We;
-    const float4* env4 = reinterpret_cast<const float4*>(stream_scratch(s, 1, ntexel * sizeof(float4)));
     const bool tab_lds = K <= FRS_TAB_LDS_MAX_K;
     const size_t smem = frs_backward_lds_bytes(K, He, We);
     if (tab_lds) {
         const int grid = frs_grid(P, (const void*)shade_backward_frs_kernel<true>, smem);
         shade_backward_frs_kernel<true><<<grid, 64 * FRS_WAVES, smem, s>>>(
-            P, K, base_color, roughness, normals, viewdirs, cprime, g_pbr, g_diff, env4, He, We, visibility, dirs,
+            P, K, base_color, roughness, normals, viewdirs, cprime, g_pbr, g_diff, env, He, We, visibility, dirs,
             frs_area(uniform_area), taps, tables, valid, d_base, d_rough, d_view, dcp, d_env, gmax, gmax_n);
     } else {
         const int grid = frs_grid(P, (const void*)shade_backward_frs_kernel<false>, smem);
         shade_backward_frs_kernel<false><<<grid, 64 * FRS_WAVES, smem, s>>>(
-            P, K, base_color, roughness, normals, viewdirs, cprime, g_pbr, g_diff, env4, He, We, visibility, dirs,
+            P, K, base_color, roughness, normals, viewdirs, cprime, g_pbr, g_diff, env, He, We, visibility, dirs,
             frs_area(uniform_area), taps, tables, valid, d_base, d_rough, d_view, dcp, d_env, gmax, gmax_n);
     }
     check_launch(s, false, "shade_backward_frs_kernel");
 }
 
-// gradient back to the unrotated coefficients: every row of d_inc is written (garbage for Gaussians off the rotated path:
-// the general kernel overwrites their rows next)
-void launch_shade_frs_backward_rotate(hipStream_t s, int P, const float* ray_normals, const float* dcp, float* d_inc)
+// gradient back to the unrotated coefficients.  valid == nullptr: every row of d_inc is written (garbage for Gaussians off the
+// rotated path: the general kernel overwrites their rows next, on the same stream); valid != nullptr: only the rows on the
+// rotated path are written -- the form that may run on a second stream beside the general kernel's launch on the listed rest
+void launch_shade_frs_backward_rotate(hipStream_t s, int P, const float* ray_normals, const float* dcp, float* d_inc,
+                                      const uint8_t* valid)
 {
     if (P == 0) return;
-    frs_rotate_kernel<true><<<(P + 255) / 256, 256, 0, s>>>(P, ray_normals, dcp, d_inc);
+    frs_rotate_kernel<true><<<(P + 255) / 256, 256, 0, s>>>(P, ray_normals, dcp, d_inc, valid);
     check_launch(s, false, "frs_rotate_kernel");
 }
 

@@ -162,7 +162,8 @@ __device__ __forceinline__ void frs_rotate_band(const float (&R)[9], const float
 //                not on the rotated path hold garbage and are overwritten by the general kernel afterwards)
 template <bool BACK>
 __global__ void __launch_bounds__(256)
-frs_rotate_kernel(int P, const float* __restrict__ ray_normals, const float* __restrict__ src, float* __restrict__ dst)
+frs_rotate_kernel(int P, const float* __restrict__ ray_normals, const float* __restrict__ src, float* __restrict__ dst,
+                  const uint8_t* __restrict__ only_valid /* optional: rows with only_valid[g] == 0 are left untouched */)
 {
     // Thread per Gaussian, its 192-byte row in registers: twelve 16-byte loads in flight per lane, twelve 16-byte stores.  (The
     // first version staged 256 rows through 50 KB of LDS for coalescing: 3 workgroups per CU, two barriers, 44 us for 115 MB.
@@ -170,6 +171,7 @@ frs_rotate_kernel(int P, const float* __restrict__ ray_normals, const float* __r
     // and the lines are used completely by the other 11 accesses of the same lanes.)
     const int g = blockIdx.x * 256 + (int)threadIdx.x;
     if (g >= P) return;
+    if (only_valid != nullptr && only_valid[g] == 0) return;
     float row[48];
     const float4* s4 = reinterpret_cast<const float4*>(src + (size_t)g * 48);
 #pragma unroll
@@ -306,14 +308,15 @@ __device__ __forceinline__ FrsBlock frs_staged_block(const float* st, int gl, in
 __global__ void __launch_bounds__(64 * FRS_WAVES, 3)
 shade_forward_frs_kernel(int P, int K, const float* __restrict__ base_color, const float* __restrict__ roughness,
                          const float* __restrict__ normals, const float* __restrict__ viewdirs,
-                         const float* __restrict__ cprime, const float4* __restrict__ env4, int He, int We,
+                         const float* __restrict__ cprime, const float* __restrict__ env /* [He*We][3] */, int He, int We,
                          const float* __restrict__ visibility, const float* __restrict__ dirs, float uniform_area,
                          const uint32_t* __restrict__ taps, const float* __restrict__ tables,
                          const uint8_t* __restrict__ valid, float* __restrict__ out)
 {
     extern __shared__ __attribute__((aligned(16))) float s_mem[];
     float4* s_env4 = reinterpret_cast<float4*>(s_mem);
-    for (int i = threadIdx.x; i < He * We; i += blockDim.x) s_env4[i] = env4[i];
+    for (int i = threadIdx.x; i < He * We; i += blockDim.x)            // (a tap is one ds_read_b128: texels padded to float4 here)
+        s_env4[i] = make_float4(env[3 * i], env[3 * i + 1], env[3 * i + 2], 0.f);
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int gl = lane & 15, q = lane >> 4;
@@ -454,7 +457,7 @@ __global__ void __launch_bounds__(64 * FRS_WAVES, 2)
 shade_backward_frs_kernel(int P, int K, const float* __restrict__ base_color, const float* __restrict__ roughness,
                           const float* __restrict__ normals, const float* __restrict__ viewdirs,
                           const float* __restrict__ cprime, const float* __restrict__ g_pbr,
-                          const float* __restrict__ g_diff, const float4* __restrict__ env4, int He, int We,
+                          const float* __restrict__ g_diff, const float* __restrict__ env /* [He*We][3] */, int He, int We,
                           const float* __restrict__ visibility, const float* __restrict__ dirs, float uniform_area,
                           const uint32_t* __restrict__ taps, const float* __restrict__ tables,
                           const uint8_t* __restrict__ valid, float* __restrict__ d_base, float* __restrict__ d_rough,
@@ -473,7 +476,7 @@ shade_backward_frs_kernel(int P, int K, const float* __restrict__ base_color, co
     const int nblk = (K + 15) >> 4;
     float* s_stage = s_mem + ((10 * ntexel + 3) & ~3);                           // FRS_WAVES x FRS_ST_BWD floats (16-byte aligned)
     float* s_tab = s_stage + FRS_WAVES * FRS_ST_BWD;                             // TAB_LDS: the nblk x 512 table words
-    for (int i = threadIdx.x; i < ntexel; i += blockDim.x) s_env4[i] = env4[i];
+    for (int i = threadIdx.x; i < ntexel; i += blockDim.x) s_env4[i] = make_float4(env[3 * i], env[3 * i + 1], env[3 * i + 2], 0.f);
     for (int i = threadIdx.x; i < 3 * ntexel; i += blockDim.x) s_denv[i] = 0;
     if (TAB_LDS)
         for (int i = threadIdx.x; i < nblk * 512; i += blockDim.x) s_tab[i] = tables[i];

@@ -560,7 +560,11 @@ class FusedStage2Step(_BoundedForward):
                     self.a_base, self.a_rough, self.a_normal, self.a_viewdirs, self.incidents, env_c, self.visibility,
                     self.incident_dirs, self.incident_areas, taps, self.d_pbr, self.d_diffuse,
                     uniform_area=self._uniform_area, out_incidents=self.grads["incidents"], out_env=self._d_env,
-                    block_absmax=self._absmax)
+                    block_absmax=self._absmax,
+                    # whole iterations on one GPU: the rotation back of the coefficient gradient goes to the stream that already
+                    # carries the SH group's early Adam (optimizer_step joins it before any Adam launch reads the gradient) and
+                    # runs beside the listed Gaussians' general kernel and the activation chain rule
+                    rotate_stream=self._early_stream if self._early and not self.dp else None)
             else:
                 d_base, d_rough, d_view, _d_inc, d_env = shading_ops.shade_backward(
                     self.a_base, self.a_rough, self.a_normal, self.a_viewdirs, self.incidents, env_c, self.visibility,

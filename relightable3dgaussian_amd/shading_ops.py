@@ -189,9 +189,12 @@ class FixedRaySet:
         return out
 
     def backward(self, base_color, roughness, normals, viewdirs, incidents, env, visibility, incident_dirs, incident_areas,
-                 taps, dL_dpbr, dL_ddiffuse_light, uniform_area=None, out_incidents=None, out_env=None, block_absmax=None):
+                 taps, dL_dpbr, dL_ddiffuse_light, uniform_area=None, out_incidents=None, out_env=None, block_absmax=None,
+                 rotate_stream=None):
         """-> (dL_dbase_color, dL_droughness, dL_dviewdirs, dL_dincidents, dL_denv) as shade_backward; `forward` must have run
-        on the same parameters (it left the rotated coefficients)."""
+        on the same parameters (it left the rotated coefficients).  `rotate_stream` (a torch.cuda.Stream): the rotation of the
+        coefficient gradient back to dL_dincidents runs there, beside whatever the caller queues next on the current stream; the
+        caller waits for that stream before reading dL_dincidents."""
         head, _keep = self._common(base_color, roughness, normals, viewdirs, incidents, env, visibility, incident_dirs,
                                    incident_areas, uniform_area, taps)
         if uniform_area is not None and self.n_invalid:
@@ -210,7 +213,8 @@ class FixedRaySet:
                 _lib.current_stream(), *head, self.cprime.data_ptr(), self.dcprime.data_ptr(), gp.data_ptr(), gd.data_ptr(),
                 d_base.data_ptr(), d_rough.data_ptr(), d_view.data_ptr(), d_inc.data_ptr(), d_env.data_ptr(),
                 block_absmax.data_ptr() if block_absmax is not None else None,
-                block_absmax.numel() if block_absmax is not None else 0)
+                block_absmax.numel() if block_absmax is not None else 0,
+                rotate_stream.cuda_stream if rotate_stream is not None else None)
         _lib.check(st, "shade_frs_backward")
         return d_base, d_rough, d_view, d_inc, d_env
 
