@@ -17,6 +17,12 @@ import os
 import sys
 import time
 
+# the GPU boxes give the container a CPU quota well below the host's core count: OpenMP pools sized for the host (256 spinning
+# threads after every parallel CPU op of the scene setup) run into it and the kernel then stalls EVERY thread of the process,
+# the one enqueueing kernels included, for the rest of the 100 ms period
+os.environ.setdefault("OMP_NUM_THREADS", "8")
+os.environ.setdefault("MKL_NUM_THREADS", "8")
+
 import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))

@@ -431,6 +431,22 @@ def relight_bench(params, cams, dev, frames, K):
                              "relight_rotating_light: nothing is reused (lookup in the kernel)")
 
 
+def host_cpu_quota():
+    """The container's CPU quota and how often it was enforced so far (cgroup v2 cpu.max / cpu.stat; {} when the files are
+    absent): a timed region that ran into the quota was stalled by the host, not by the GPU, and the line says so."""
+    out = {}
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        out["quota_cores"] = None if quota == "max" else round(float(quota) / float(period), 2)
+        for ln in open("/sys/fs/cgroup/cpu.stat"):
+            k, v = ln.split()
+            if k in ("nr_throttled", "throttled_usec"):
+                out[k] = int(v)
+    except (OSError, ValueError):
+        pass
+    return out
+
+
 def _finite_json(x):
     """A child's JSON document with every non-finite float replaced by a string: the ONE line the parent prints must stay
     strict JSON whatever a side measurement produced (Python's json would print a bare NaN)."""
@@ -737,6 +753,7 @@ def run(args):
     if dp and fused and hasattr(step_fn, "measure_comm"):
         step_fn.measure_comm = True          # (two event records per waited bucket: what the compute stream stalls on)
     torch.cuda.synchronize()
+    quota0 = host_cpu_quota()
     t0 = time.perf_counter()
     # per-kernel HIP-event timing is live inside the timed region but sampled (every 8th step): each event pair costs
     # ~2 us of host time, ~40 pairs per step, and the events themselves sit between the kernels on the stream
@@ -750,6 +767,13 @@ def run(args):
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    quota1 = host_cpu_quota()
+    host_cpu = dict(quota_cores=quota1.get("quota_cores"),
+                    throttled_periods_in_timed_region=quota1.get("nr_throttled", 0) - quota0.get("nr_throttled", 0),
+                    throttled_ms_in_timed_region=round(1e-3 * (quota1.get("throttled_usec", 0) - quota0.get("throttled_usec", 0)), 1),
+                    throttled_periods_before=quota0.get("nr_throttled"),
+                    what="cgroup cpu.max / cpu.stat around the timed region: periods in which the container's CPU quota "
+                         "stalled its threads (a host effect; 0 = the timed steps were not held up by it)") if quota1 else None
     prof = _lib.profile_read()
     L.r3dg_profile_enable(0)
     exposed_comm = None
@@ -819,7 +843,7 @@ def run(args):
                                        "shading fwd/bwd (K=%d) + " % args.sample_num if stage2 else "", S,
                                        P, W_img, H_img, R_mean),
                        "parallelism": "dp%d (views sharded over ranks; bucketed async RCCL all-reduce of per-Gaussian grads)" % world},
-            "roofline": roofline, "kernels": kernels, "spread_iters_per_s": spread,
+            "roofline": roofline, "kernels": kernels, "spread_iters_per_s": spread, "host_cpu": host_cpu,
         }
         if dp:
             # rank 0's compute stream: mean time per iteration it stood waiting for gradient all-reduce buckets (C, then the

@@ -3,6 +3,11 @@ import sys
 
 import pytest
 
+# (before torch is imported) OpenMP pools sized for the host's 256 logical CPUs run into the container's CPU quota on the GPU
+# boxes, which then stalls every thread of the process; see bench.py
+os.environ.setdefault("OMP_NUM_THREADS", "16")
+os.environ.setdefault("MKL_NUM_THREADS", "16")
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
