@@ -266,7 +266,11 @@ int r3dg_shade_frs_forward(void* stream, int P, int K, const float* d_base_color
                            int He, int We, const float* d_visibility, const float* d_incident_dirs,
                            const float* d_incident_areas, float uniform_area, const uint32_t* d_taps,
                            const float* d_ray_normals, const float* d_tables, const uint8_t* d_valid,
-                           const int32_t* d_invalid_list, int n_invalid, float* d_cprime, int flags, float* d_out);
+                           const int32_t* d_invalid_list, int n_invalid, float* d_cprime, int flags, float* d_out,
+                           void* listed_stream);
+/*   listed_stream: NULL, or a second stream for the general kernel on the listed Gaussians (ordered after everything queued on
+ *   `stream` before the call; it then runs beside the rotation and the main kernel).  The caller joins listed_stream before anything
+ *   reads d_out. */
 int r3dg_shade_frs_backward(void* stream, int P, int K, const float* d_base_color, const float* d_roughness,
                             const float* d_normals, const float* d_viewdirs, const float* d_incidents, const float* d_env,
                             int He, int We, const float* d_visibility, const float* d_incident_dirs,
@@ -276,9 +280,11 @@ int r3dg_shade_frs_backward(void* stream, int P, int K, const float* d_base_colo
                             const float* d_dL_dpbr, const float* d_dL_ddiffuse_light, float* d_dL_dbase_color,
                             float* d_dL_droughness, float* d_dL_dviewdirs, float* d_dL_dincidents, float* d_dL_denv,
                             const float* d_block_absmax, int n_block_absmax, void* rotate_stream);
-/*   rotate_stream: NULL, or a second stream for the rotation of the coefficient gradient back to d_dL_dincidents (ordered after the
- *   main kernel by an event; it overlaps the general kernel's launch on the listed Gaussians and the caller's next launches on
- *   `stream`).  The caller joins rotate_stream before anything reads d_dL_dincidents. */
+/*   Launch order on `stream`: the general kernel on the listed Gaussians, then the main kernel (a caller that has other work
+ *   running on another stream when it calls this gets the small latency-bound launch beside that work).
+ *   rotate_stream: NULL, or a second stream for the rotation of the coefficient gradient back to d_dL_dincidents (ordered after the
+ *   main kernel by an event; it overlaps the caller's next launches on `stream`).  The caller joins rotate_stream before anything
+ *   reads d_dL_dincidents. */
 
 int r3dg_shade_backward(void* stream, int P, int K, int M, const float* d_base_color, const float* d_roughness,
                         const float* d_normals, const float* d_viewdirs, const float* d_incidents, const float* d_env,

@@ -1220,7 +1220,7 @@ int r3dg_shade_frs_forward(void* stream_, int P, int K, const float* base_color,
                            int We, const float* visibility, const float* incident_dirs, const float* incident_areas,
                            float uniform_area, const uint32_t* taps, const float* ray_normals, const float* tables,
                            const uint8_t* valid, const int32_t* invalid_list, int n_invalid, float* cprime, int flags,
-                           float* out)
+                           float* out, void* listed_stream_)
 {
     if (P < 0 || K <= 0 || He <= 0 || We <= 0 || n_invalid < 0 || n_invalid > P) return invalid("shade_frs_forward: bad sizes");
     if (!shade_frs_supported(K, 16, He, We))
@@ -1233,6 +1233,23 @@ int r3dg_shade_frs_forward(void* stream_, int P, int K, const float* base_color,
     return guarded([&]() -> int {
         hipStream_t stream = (hipStream_t)stream_;
         const bool leave_room = (flags & R3DG_SHADE_LEAVE_ROOM) != 0;
+        // the general kernel on the listed Gaussians (disjoint rows of `out`) may run on a second stream, ordered after everything
+        // queued on `stream` so far: it then runs beside the rotation and the main kernel instead of after them (the CALLER
+        // joins that stream before anything reads `out`)
+        hipStream_t lstream = listed_stream_ != nullptr ? (hipStream_t)listed_stream_ : stream;
+        if (n_invalid > 0) {
+            if (lstream != stream) {
+                hipEvent_t ev;
+                R3DG_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+                R3DG_HIP(hipEventRecord(ev, stream));
+                R3DG_HIP(hipStreamWaitEvent(lstream, ev, 0));
+                R3DG_HIP(hipEventDestroy(ev));
+            }
+            StageTimer t(lstream, ST_SHADE_LISTED);
+            launch_shade_frs_forward_listed(lstream, P, K, base_color, roughness, normals, viewdirs, incidents, env, He, We,
+                                            visibility, incident_dirs, incident_areas, uniform_area, taps, invalid_list, n_invalid,
+                                            leave_room, out);
+        }
         {
             StageTimer t(stream, ST_SHADE_AUX);
             launch_shade_frs_forward_aux(stream, P, incidents, ray_normals, cprime);
@@ -1241,12 +1258,6 @@ int r3dg_shade_frs_forward(void* stream_, int P, int K, const float* base_color,
             StageTimer t(stream, ST_SHADE_FWD);
             launch_shade_frs_forward_main(stream, P, K, base_color, roughness, normals, viewdirs, env, He, We, visibility, incident_dirs,
                                           uniform_area, taps, tables, valid, cprime, leave_room, out);
-        }
-        if (n_invalid > 0) {
-            StageTimer t(stream, ST_SHADE_LISTED);
-            launch_shade_frs_forward_listed(stream, P, K, base_color, roughness, normals, viewdirs, incidents, env, He, We,
-                                            visibility, incident_dirs, incident_areas, uniform_area, taps, invalid_list, n_invalid,
-                                            leave_room, out);
         }
         return R3DG_OK;
     });
@@ -1278,6 +1289,17 @@ int r3dg_shade_frs_backward(void* stream_, int P, int K, const float* base_color
             StageTimer t(stream, ST_SHADE_AUX);
             gmax = launch_shade_frs_backward_aux(stream, P, dL_dpbr, dL_ddiffuse_light, block_absmax, n_block_absmax, &gmax_n);
         }
+        // the general kernel on the listed Gaussians goes FIRST (its rows of the per-Gaussian outputs are disjoint from the main
+        // kernel's, the texture gradient is accumulated by both): a latency-bound launch over a few hundred Gaussians that a caller
+        // can put beside whatever it has running on another stream at this point (fused_step: the rasterizer's per-Gaussian
+        // geometry backward) instead of alone behind the main kernel
+        if (n_invalid > 0) {
+            StageTimer t(stream, ST_SHADE_LISTED);
+            launch_shade_frs_backward_listed(stream, P, K, base_color, roughness, normals, viewdirs, incidents, env, He, We,
+                                             visibility, incident_dirs, incident_areas, taps, invalid_list, n_invalid, dL_dpbr,
+                                             dL_ddiffuse_light, dL_dbase_color, dL_droughness, dL_dviewdirs, dL_dincidents, dL_denv,
+                                             block_absmax, n_block_absmax);
+        }
         {
             StageTimer t(stream, ST_SHADE_BWD);
             launch_shade_frs_backward_main(stream, P, K, base_color, roughness, normals, viewdirs, env, He, We, visibility, incident_dirs,
@@ -1285,8 +1307,8 @@ int r3dg_shade_frs_backward(void* stream_, int P, int K, const float* base_color
                                            dL_dbase_color, dL_droughness, dL_dviewdirs, dL_denv, gmax, gmax_n);
         }
         // the rotation back may run on a second stream (ordered after the main kernel by an event; the CALLER joins that stream
-        // before anything reads dL_dincidents): it then overlaps the general kernel on the listed Gaussians and whatever the
-        // caller queues next on `stream`
+        // before anything reads dL_dincidents): it then overlaps whatever the caller queues next on `stream`.  It leaves the
+        // listed Gaussians' rows (written above) alone.
         hipStream_t rstream = rotate_stream_ != nullptr ? (hipStream_t)rotate_stream_ : stream;
         if (rstream != stream) {
             hipEvent_t ev;
@@ -1297,14 +1319,7 @@ int r3dg_shade_frs_backward(void* stream_, int P, int K, const float* base_color
         }
         {
             StageTimer t(rstream, ST_SHADE_AUX);
-            launch_shade_frs_backward_rotate(rstream, P, ray_normals, dcprime, dL_dincidents, rstream != stream ? valid : nullptr);
-        }
-        if (n_invalid > 0) {
-            StageTimer t(stream, ST_SHADE_LISTED);
-            launch_shade_frs_backward_listed(stream, P, K, base_color, roughness, normals, viewdirs, incidents, env, He, We,
-                                             visibility, incident_dirs, incident_areas, taps, invalid_list, n_invalid, dL_dpbr,
-                                             dL_ddiffuse_light, dL_dbase_color, dL_droughness, dL_dviewdirs, dL_dincidents, dL_denv,
-                                             block_absmax, n_block_absmax);
+            launch_shade_frs_backward_rotate(rstream, P, ray_normals, dcprime, dL_dincidents, n_invalid > 0 ? valid : nullptr);
         }
         return R3DG_OK;
     });

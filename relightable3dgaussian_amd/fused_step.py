@@ -304,6 +304,7 @@ class FusedStage2Step(_BoundedForward):
         # backward fills the register file (2 waves/SIMD x 221 VGPRs); capping the geometry kernel at 64 VGPRs so that it
         # fits beside it spills 35 registers and slows both (2.13 -> 2.20 ms/step).  Off by default.
         self._side = torch.cuda.Stream(device=dev) if overlap_geometry else None
+        self._geo_done = None
         self.group = process_group
         self.world, self.dp = _world_of(process_group)
         if self.dp:
@@ -394,6 +395,16 @@ class FusedStage2Step(_BoundedForward):
                 self._frs = shading_ops.FixedRaySet.try_build(getattr(self, "_ray_normals", None), src)
         return self._taps
 
+    def _listed_stream(self):
+        """The early-Adam stream when the fixed-ray-set path has Gaussians off the rotated path (their general kernels run there
+        in the forward, and the rasterizer's geometry backward beside them in the backward); None otherwise and under data
+        parallelism (that stream then carries the buckets' waits)."""
+        if self._frs is None or self.dp or self._frs.n_invalid == 0:
+            return None
+        if self._adam_stream is None:
+            self._adam_stream = torch.cuda.Stream(device=self.dev)
+        return self._adam_stream
+
     def forward_backward(self, cam, bg, gt, early_adam=False, image_mask=None):
         """One forward + loss + backward; gradients land in self.grads.  Returns the rasterizer's 10 public outputs.
         `image_mask` [1,H,W]: the view's object mask (Camera.image_mask; None = all ones) of the normal and smoothness terms.
@@ -439,7 +450,10 @@ class FusedStage2Step(_BoundedForward):
                                   # (one workgroup per CU beside the instance ordering, which is the longer path -- unless the
                                   # deferred incident-light update of a data-parallel run sits in front of this kernel: then this
                                   # path is the longer one and takes every CU it can get: 558 -> 568 it/s on one rank)
-                                  leave_room=self._order_stream is not None and not self.dp)
+                                  leave_room=self._order_stream is not None and not self.dp,
+                                  # the few hundred Gaussians off the rotated path: their general kernel on the (idle) early-Adam
+                                  # stream beside the rotation and the main kernel, joined below before the features are packed
+                                  listed_stream=self._listed_stream())
             else:
                 _lib.check(L.r3dg_shade_forward_cached(
                     stream(), P, self.K, self.M, self.a_base.data_ptr(), self.a_rough.data_ptr(), self.a_normal.data_ptr(),
@@ -449,6 +463,8 @@ class FusedStage2Step(_BoundedForward):
                     taps.data_ptr(), 1 | (4 if self._order_stream is not None else 0),     # train outputs | leave room
                     self.shade_out.data_ptr()), "shade_forward")
             self.sums.zero_()
+            if self._frs is not None and self._listed_stream() is not None:
+                torch.cuda.current_stream().wait_stream(self._listed_stream())
             _lib.check(L.r3dg_stage2_pack_features(
                 stream(), P, self.xyz.data_ptr(), vm.data_ptr(), self.a_normal.data_ptr(), self.a_base.data_ptr(),
                 self.a_rough.data_ptr(), self.shade_out.data_ptr(), self.features.data_ptr(),
@@ -501,6 +517,7 @@ class FusedStage2Step(_BoundedForward):
                 active += ([8, 9, 10] if w_bc != 0.0 else []) + ([11] if w_r != 0.0 else [])
                 if w_ls != 0.0:
                     active += [12, 13, 14] + ([5, 6, 7] if self.w["normal"] == 0.0 else [])
+            geo_stream = None
             if self.frozen_geometry:
                 # nothing but the feature gradients is consumed (the normal maps' gradient belongs to the frozen normal)
                 active = [a for a in active if a not in (5, 6, 7)]
@@ -508,19 +525,30 @@ class FusedStage2Step(_BoundedForward):
                     P, 16, H, W, g[4:20], geom, R, binning, img, active_features=sorted(active))
                 dL_dmeans2D = None
             else:
+                geo_stream = self._side
+                if geo_stream is None and early_adam and self._listed_stream() is not None:
+                    # whole iterations on one GPU with Gaussians off the rotated path: the per-Gaussian geometry backward goes
+                    # to the early-Adam stream and runs beside the gradient unpack and the general shading backward on those few
+                    # hundred Gaussians (a latency-bound launch that r3dg_shade_frs_backward queues FIRST) instead of in front
+                    # of them; the main shading backward, which fills the register file, starts when both are about done
+                    geo_stream = self._listed_stream()
                 bw = rasterizer_ops.rasterize_gaussians_backward(
                     bg, self.xyz, self.features, radii, empty, self.a_scales, self.a_rot, 1.0, empty, vm,
                     cam.full_proj_transform, cam.tanfovx, cam.tanfovy, g[0:3], g[3:4], self._zero_depth_grad, g[4:20],
                     self.shs, 3, campos, geom, R, binning, img, True, False, dL_dsh_out=self.grads["shs"],
-                    geometry_stream=self._side, active_features=sorted(active))
+                    geometry_stream=geo_stream, active_features=sorted(active))
                 dL_dmeans2D, _dcol, dL_dopacity, dL_dmeans3D, dL_dfeatures, _dcov, _dsh, dL_dscales, dL_drot = bw
+                if geo_stream is not None:
+                    if self._geo_done is None:
+                        self._geo_done = torch.cuda.Event()
+                    self._geo_done.record(geo_stream)
             handle_a = None
             if self._side is None and self._bucket_a is not None:
                 handle_a = self._allreduce_async(self._bucket_a)     # travels under the shading backward
             self._early = False
             if early_adam and not self.dp and self._groups_a:
                 # Adam of the SH group on a side stream, behind the geometry backward that produces its gradient
-                side = self._side
+                side = geo_stream
                 if side is None:
                     if self._adam_stream is None:
                         self._adam_stream = torch.cuda.Stream(device=dev)
@@ -571,9 +599,10 @@ class FusedStage2Step(_BoundedForward):
                     self.incident_dirs, self.incident_areas, self.d_pbr, self.d_diffuse,
                     out_incidents=self.grads["incidents"], taps=taps, out_env=self._d_env, block_absmax=self._absmax)
             gr = self.grads
-            if self._side is not None and not self.frozen_geometry:          # join the geometry backward
-                torch.cuda.current_stream().wait_stream(self._side)
-                handle_a = self._allreduce_async(self._bucket_a)
+            if geo_stream is not None:                                       # join the geometry backward (and nothing
+                torch.cuda.current_stream().wait_event(self._geo_done)       # queued behind it on that stream)
+                if self._side is not None:
+                    handle_a = self._allreduce_async(self._bucket_a)
             if self.frozen_geometry:
                 _lib.check(L.r3dg_stage2_activate_backward(
                     stream(), P, None, None, None, None, None, self.base_color.data_ptr(), self.roughness.data_ptr(), None,

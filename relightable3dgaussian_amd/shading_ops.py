@@ -177,14 +177,16 @@ class FixedRaySet:
         return head, t
 
     def forward(self, base_color, roughness, normals, viewdirs, incidents, env, visibility, incident_dirs, incident_areas,
-                taps, out, uniform_area=None, leave_room=False):
+                taps, out, uniform_area=None, leave_room=False, listed_stream=None):
         """Writes columns 0..5 and 18 of out [P,19] (pbr, diffuse_light, mean visibility); keeps the rotated coefficients
-        for `backward`."""
+        for `backward`.  `listed_stream` (a torch.cuda.Stream): the general kernel on the Gaussians off the rotated path runs there,
+        beside the main kernel; the caller waits for that stream before reading `out`."""
         head, _keep = self._common(base_color, roughness, normals, viewdirs, incidents, env, visibility, incident_dirs,
                                    incident_areas, uniform_area, taps)
         with torch.cuda.device(base_color.device):
             st = _lib.lib().r3dg_shade_frs_forward(_lib.current_stream(), *head, self.cprime.data_ptr(),
-                                                   1 | (4 if leave_room else 0), out.data_ptr())
+                                                   1 | (4 if leave_room else 0), out.data_ptr(),
+                                                   listed_stream.cuda_stream if listed_stream is not None else None)
         _lib.check(st, "shade_frs_forward")
         return out
 

@@ -57,14 +57,22 @@ def main():
 
 
 def sequence():
-    """Print the kernel sequence (name, us) of the last full step."""
+    """Print the kernel sequence of the last full step: start (us from the step's first launch), duration (us), the queue the
+    launch went to (one per HIP stream), the idle time on the whole device before it when nothing else was running, name."""
     cur = sqlite3.connect(sys.argv[1]).cursor()
-    rows = list(cur.execute("select name, start, end from kernels order by start"))
+    cols = [r[1] for r in cur.execute("pragma table_info(kernels)")]
+    qcol = "queue_id" if "queue_id" in cols else ("stream_id" if "stream_id" in cols else "0")
+    rows = list(cur.execute("select name, start, end, %s from kernels order by start" % qcol))
     marks = [i for i, r in enumerate(rows) if "r3dg::render_backward_" in r[0] and "features" not in r[0]]
     a, b = marks[-2], marks[-1]
     t0 = rows[a][1]
-    for name, s, e in rows[a:b]:
-        print("%9.1f %7.1f  %s" % ((s - t0) / 1e3, (e - s) / 1e3, name[:150]))
+    queues = {}
+    hi = rows[a][1]
+    for name, s, e, q in rows[a:b]:
+        gap = (s - hi) / 1e3 if s > hi else 0.0
+        hi = max(hi, e)
+        print("%9.1f %7.1f  q%-2d %s %s" % ((s - t0) / 1e3, (e - s) / 1e3, queues.setdefault(q, len(queues)),
+                                           ("gap %5.1f" % gap) if gap > 0 else "         ", name[:110]))
 
 
 if __name__ == "__main__":
