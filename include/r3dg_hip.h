@@ -104,11 +104,12 @@ int r3dg_rasterize_forward_finish(void* ticket, int* num_rendered_out);
 int r3dg_rasterize_forward_finish_on(void* ticket, void* ordering_stream, int* num_rendered_out);
 
 /* The forward WITHOUT the host read-back of num_rendered (the reference's one synchronisation per forward,
- * rasterizer_impl.cu:291).  _begin_bounded queues the projection on `stream` AND the instance ordering behind it on
- * `ordering_stream` (NULL = `stream`) at once, with the binning state laid out for `capacity` instances (the value to pass
- * as num_rendered to the backward, whose state layout it selects); _finish_bounded makes `main_stream` wait for the
- * ordering and renders there -- kernels the caller queued on `stream` after _begin_ (the feature rows) run beside the
- * ordering when the two streams differ.
+ * rasterizer_impl.cu:291).  _begin_bounded queues the projection AND the instance ordering behind it at once on
+ * `ordering_stream` (NULL = `stream`; otherwise ordered after everything queued on `stream` before the call), with the binning
+ * state laid out for `capacity` instances (the value to pass as num_rendered to the backward, whose state layout it selects);
+ * _finish_bounded makes `main_stream` wait for the ordering and renders there -- kernels the caller queues on `stream` after
+ * _begin_ (the feature rows) run beside the whole front end when the two streams differ; the per-Gaussian outputs of the
+ * projection (d_radii, the geometry state) are valid on `main_stream` after _finish_bounded.
  * A frame that needs MORE than `capacity` instances is dropped on the device: every tile list comes out empty (the
  * images are background only, n_contrib 0, all gradients of that frame zero) and *d_overflow_flag = 1.0f; otherwise the
  * flag is set to 0.0f (may be NULL); *d_overflow_count (may be NULL) is incremented for every dropped frame and never
@@ -210,6 +211,7 @@ int r3dg_shade_forward(void* stream, int P, int K, int M, const float* d_base_co
 #define R3DG_SHADE_TRAIN_OUTPUTS 1
 #define R3DG_SHADE_TAPS_ARE_RADIANCE 2
 #define R3DG_SHADE_LEAVE_ROOM 4      /* the caller runs other kernels beside this one: occupy half of each CU */
+#define R3DG_SHADE_ROTATED 8         /* r3dg_shade_frs_forward only: d_cprime already holds r3dg_shade_frs_rotate's result */
 int r3dg_shade_forward_cached(void* stream, int P, int K, int M, const float* d_base_color, const float* d_roughness,
                               const float* d_normals, const float* d_viewdirs, const float* d_incidents,
                               const float* d_env, int He, int We, const float* d_env_transform,
@@ -261,6 +263,10 @@ int r3dg_shade_frs_supported(int K, int M, int He, int We);
 size_t r3dg_shade_frs_tables_bytes(int K);
 int r3dg_shade_frs_build_tables(void* stream, int K, const float* d_zsamples, float* d_tables);
 int r3dg_shade_frs_classify(void* stream, int P, const float* d_ray_normals, uint8_t* d_valid);
+/* The first step of r3dg_shade_frs_forward on its own: d_cprime [P,48] = the incident-light coefficients rotated into each
+ * Gaussian's ray frame.  It depends on d_incidents and d_ray_normals only, so a caller can queue it (on another stream) as soon
+ * as the coefficients are final and pass R3DG_SHADE_ROTATED to the forward. */
+int r3dg_shade_frs_rotate(void* stream, int P, const float* d_incidents, const float* d_ray_normals, float* d_cprime);
 int r3dg_shade_frs_forward(void* stream, int P, int K, const float* d_base_color, const float* d_roughness,
                            const float* d_normals, const float* d_viewdirs, const float* d_incidents, const float* d_env,
                            int He, int We, const float* d_visibility, const float* d_incident_dirs,

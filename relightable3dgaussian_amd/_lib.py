@@ -62,6 +62,7 @@ _SIGNATURES = {
     "r3dg_shade_frs_tables_bytes": (C.c_size_t, [_i]),
     "r3dg_shade_frs_build_tables": (_i, [_p, _i, _p, _p]),
     "r3dg_shade_frs_classify": (_i, [_p, _i, _p, _p]),
+    "r3dg_shade_frs_rotate": (_i, [_p, _i, _p, _p, _p]),
     "r3dg_shade_frs_forward": (_i, [_p, _i, _i] + [_p] * 6 + [_i, _i, _p, _p, _p, _f] + [_p] * 5 + [_i, _p, _i, _p, _p]),
     "r3dg_shade_frs_backward": (_i, [_p, _i, _i] + [_p] * 6 + [_i, _i, _p, _p, _p, _f] + [_p] * 5 + [_i] + [_p] * 10 + [_i, _p]),
     "r3dg_shade_build_transport": (_i, [_p, _i, _i, _i, _p, _p, _p, _p, _p, _f, _p, _p]),

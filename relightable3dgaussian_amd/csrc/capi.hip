@@ -613,15 +613,24 @@ static int forward_begin_impl(void* stream_, r3dg_alloc_fn geometry_alloc, r3dg_
         uint32_t* g_block = (uint32_t*)(gbuf + G.block_sums);
         unsigned long long* g_total = (unsigned long long*)(gbuf + G.total);
 
-        StageTimer t_pre(stream, ST_PREPROCESS);
-        launch_preprocess(stream, P, D, M, means3D, scales, scale_modifier, rotations, opacities, shs,
+        ForwardTicket* t = ticket_acquire();
+        struct Release { ForwardTicket* t; ~Release() { if (t) ticket_release(t); } } on_error{t};      // (a launch check may throw)
+        // bounded with an ordering stream: the projection goes there too, behind everything the caller has queued on `stream`
+        // so far -- the whole front end of the rasterizer then runs beside what the caller queues on `stream` next, and
+        // r3dg_rasterize_forward_finish_bounded joins it
+        const hipStream_t order_stream = capacity >= 0 && ordering_stream_ ? (hipStream_t)ordering_stream_ : stream;
+        if (order_stream != stream) {
+            R3DG_HIP(hipEventRecord(t->ready, stream));
+            R3DG_HIP(hipStreamWaitEvent(order_stream, t->ready, 0));
+        }
+        StageTimer t_pre(order_stream, ST_PREPROCESS);
+        launch_preprocess(order_stream, P, D, M, means3D, scales, scale_modifier, rotations, opacities, shs,
                           (uint8_t*)(gbuf + G.clamped), cov3D_precomp, colors_precomp, viewmatrix, projmatrix, cam_pos,
                           width, height, tan_fovx, tan_fovy, focal_x, focal_y, radii_p, g_means2D, g_depths,
                           (float*)(gbuf + G.cov3D), g_rgb, g_conic, (float*)(gbuf + G.splat), gx, gy, g_tiles, g_block, g_total);
-        check_launch(stream, debug, "preprocess");
+        check_launch(order_stream, debug, "preprocess");
         t_pre.stop();
 
-        ForwardTicket* t = ticket_acquire();
         t->stream = stream; t->binning_alloc = binning_alloc; t->user = user;
         t->P = P; t->S = S; t->D = D; t->M = M; t->width = width; t->height = height;
         t->compute_pseudo_normal = compute_pseudo_normal; t->debug = debug_;
@@ -633,22 +642,18 @@ static int forward_begin_impl(void* stream_, r3dg_alloc_fn geometry_alloc, r3dg_
         t->radii_p = radii_p; t->gbuf = gbuf; t->ibuf = ibuf;
         t->capacity = capacity; t->overflow_flag = overflow_flag; t->overflow_count = overflow_count; t->bbuf = nullptr;
         if (capacity >= 0) {
-            // bounded: nobody reads the count; the ordering follows the projection right away, on its own stream if the
-            // caller has one for it (so that it runs beside what the caller queues on `stream` next)
-            const hipStream_t order_stream = ordering_stream_ ? (hipStream_t)ordering_stream_ : stream;
-            if (order_stream != stream) {
-                R3DG_HIP(hipEventRecord(t->ready, stream));
-                R3DG_HIP(hipStreamWaitEvent(order_stream, t->ready, 0));
-            }
+            // bounded: nobody reads the count; the ordering follows the projection right away
             const int st_order = enqueue_ordering(t, order_stream, (int)capacity);
-            if (st_order != R3DG_OK) { ticket_release(t); return st_order; }
+            if (st_order != R3DG_OK) return st_order;
             R3DG_HIP(hipEventRecord(t->ready, order_stream));
+            on_error.t = nullptr;
             *ticket_out = t;
             return R3DG_OK;
         }
         // the one device->host read-back of the forward (reference rasterizer_impl.cu:291), asynchronous here
         R3DG_HIP(hipMemcpyAsync(t->host_total, g_total, sizeof(unsigned long long), hipMemcpyDeviceToHost, stream));
         R3DG_HIP(hipEventRecord(t->ready, stream));
+        on_error.t = nullptr;
         *ticket_out = t;
         return R3DG_OK;
     });
@@ -1215,6 +1220,19 @@ int r3dg_shade_frs_classify(void* stream_, int P, const float* ray_normals, uint
     });
 }
 
+int r3dg_shade_frs_rotate(void* stream_, int P, const float* incidents, const float* ray_normals, float* cprime)
+{
+    if (P < 0) return invalid("shade_frs_rotate: bad sizes");
+    if (P == 0) return R3DG_OK;
+    if (!incidents || !ray_normals || !cprime) return invalid("shade_frs_rotate: null buffer");
+    return guarded([&]() -> int {
+        hipStream_t stream = (hipStream_t)stream_;
+        StageTimer t(stream, ST_SHADE_AUX);
+        launch_shade_frs_forward_aux(stream, P, incidents, ray_normals, cprime);
+        return R3DG_OK;
+    });
+}
+
 int r3dg_shade_frs_forward(void* stream_, int P, int K, const float* base_color, const float* roughness,
                            const float* normals, const float* viewdirs, const float* incidents, const float* env, int He,
                            int We, const float* visibility, const float* incident_dirs, const float* incident_areas,
@@ -1250,7 +1268,7 @@ int r3dg_shade_frs_forward(void* stream_, int P, int K, const float* base_color,
                                             visibility, incident_dirs, incident_areas, uniform_area, taps, invalid_list, n_invalid,
                                             leave_room, out);
         }
-        {
+        if ((flags & R3DG_SHADE_ROTATED) == 0) {
             StageTimer t(stream, ST_SHADE_AUX);
             launch_shade_frs_forward_aux(stream, P, incidents, ray_normals, cprime);
         }

@@ -395,15 +395,19 @@ class FusedStage2Step(_BoundedForward):
                 self._frs = shading_ops.FixedRaySet.try_build(getattr(self, "_ray_normals", None), src)
         return self._taps
 
-    def _listed_stream(self):
-        """The early-Adam stream when the fixed-ray-set path has Gaussians off the rotated path (their general kernels run there
-        in the forward, and the rasterizer's geometry backward beside them in the backward); None otherwise and under data
-        parallelism (that stream then carries the buckets' waits)."""
-        if self._frs is None or self.dp or self._frs.n_invalid == 0:
+    def _aux_stream(self):
+        """The early-Adam stream, for the side work of the fixed-ray-set path on one GPU; None without that path and under data
+        parallelism (the stream then carries the buckets' waits and the coefficients are updated late, in flush())."""
+        if self._frs is None or self.dp:
             return None
         if self._adam_stream is None:
             self._adam_stream = torch.cuda.Stream(device=self.dev)
         return self._adam_stream
+
+    def _listed_stream(self):
+        """_aux_stream() when the fixed-ray-set path has Gaussians off the rotated path: their general kernels run there in the
+        forward, and the rasterizer's geometry backward beside them in the backward."""
+        return self._aux_stream() if self._frs is not None and self._frs.n_invalid > 0 else None
 
     def forward_backward(self, cam, bg, gt, early_adam=False, image_mask=None):
         """One forward + loss + backward; gradients land in self.grads.  Returns the rasterizer's 10 public outputs.
@@ -420,6 +424,18 @@ class FusedStage2Step(_BoundedForward):
         campos = cam.camera_center.contiguous()
         empty = torch.Tensor([])
         with torch.cuda.device(dev):
+            # the rotation of the incident-light coefficients into the ray frames depends on nothing of this view: it goes to the
+            # side stream now and runs beside the activations and the projection instead of in front of the shading forward
+            rotated_for = None
+            env_c = None
+            aux = self._aux_stream()
+            if aux is not None:
+                aux.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(aux):
+                    self._frs.rotate(self.incidents)
+                    env_c = F.softplus(self.env)[0]                              # DirectLightMap.get_env
+                    self.sums.zero_()
+                rotated_for = self._frs
             self.refresh_activations(cam)
             self._iter += 1
             use_bounded = self._use_bounded(W, H)
@@ -440,10 +456,15 @@ class FusedStage2Step(_BoundedForward):
                     cam.full_proj_transform, cam.tanfovx, cam.tanfovy, cam.cx, cam.cy, H, W, self.shs, 3, campos, False,
                     True, False, want_weights=False)       # (stage 2 does not densify: nobody reads the blend weights)
             self.flush()        # (world > 1) the previous iteration's incident-light update lands here
-            env_c = F.softplus(self.env)[0]                                      # DirectLightMap.get_env
+            if aux is None:
+                self.sums.zero_()
+                env_c = F.softplus(self.env)[0]                                  # DirectLightMap.get_env
+            else:
+                torch.cuda.current_stream().wait_stream(aux)
             He, We = env_c.shape[0], env_c.shape[1]
             taps = self.taps(He, We)
             if self._frs is not None:
+                rotated = rotated_for is self._frs            # (taps() may have rebuilt the ray set: then it rotates itself)
                 self._frs.forward(self.a_base, self.a_rough, self.a_normal, self.a_viewdirs, self.incidents, env_c,
                                   self.visibility, self.incident_dirs, self.incident_areas, taps, self.shade_out,
                                   uniform_area=self._uniform_area,
@@ -453,7 +474,7 @@ class FusedStage2Step(_BoundedForward):
                                   leave_room=self._order_stream is not None and not self.dp,
                                   # the few hundred Gaussians off the rotated path: their general kernel on the (idle) early-Adam
                                   # stream beside the rotation and the main kernel, joined below before the features are packed
-                                  listed_stream=self._listed_stream())
+                                  listed_stream=self._listed_stream(), rotated=rotated)
             else:
                 _lib.check(L.r3dg_shade_forward_cached(
                     stream(), P, self.K, self.M, self.a_base.data_ptr(), self.a_rough.data_ptr(), self.a_normal.data_ptr(),
@@ -462,7 +483,6 @@ class FusedStage2Step(_BoundedForward):
                     None if self._uniform_area is not None else self.incident_areas.data_ptr(), self._uniform_area or 0.0,
                     taps.data_ptr(), 1 | (4 if self._order_stream is not None else 0),     # train outputs | leave room
                     self.shade_out.data_ptr()), "shade_forward")
-            self.sums.zero_()
             if self._frs is not None and self._listed_stream() is not None:
                 torch.cuda.current_stream().wait_stream(self._listed_stream())
             _lib.check(L.r3dg_stage2_pack_features(

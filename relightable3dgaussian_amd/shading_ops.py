@@ -176,8 +176,19 @@ class FixedRaySet:
                                                                    self.n_invalid]
         return head, t
 
+    def rotate(self, incidents):
+        """The first step of `forward` on its own (on the current stream): the rotated coefficients of `incidents` [P,16,3].
+        A caller that queues it early passes rotated=True to `forward`."""
+        inc = _c(incidents)
+        if inc.shape != (self.P, 16, 3):
+            raise RuntimeError("FixedRaySet: needs [P,16,3] incident-light coefficients")
+        with torch.cuda.device(inc.device):
+            st = _lib.lib().r3dg_shade_frs_rotate(_lib.current_stream(), self.P, inc.data_ptr(), self.ray_normals.data_ptr(),
+                                                  self.cprime.data_ptr())
+        _lib.check(st, "shade_frs_rotate")
+
     def forward(self, base_color, roughness, normals, viewdirs, incidents, env, visibility, incident_dirs, incident_areas,
-                taps, out, uniform_area=None, leave_room=False, listed_stream=None):
+                taps, out, uniform_area=None, leave_room=False, listed_stream=None, rotated=False):
         """Writes columns 0..5 and 18 of out [P,19] (pbr, diffuse_light, mean visibility); keeps the rotated coefficients
         for `backward`.  `listed_stream` (a torch.cuda.Stream): the general kernel on the Gaussians off the rotated path runs there,
         beside the main kernel; the caller waits for that stream before reading `out`."""
@@ -185,7 +196,7 @@ class FixedRaySet:
                                    incident_areas, uniform_area, taps)
         with torch.cuda.device(base_color.device):
             st = _lib.lib().r3dg_shade_frs_forward(_lib.current_stream(), *head, self.cprime.data_ptr(),
-                                                   1 | (4 if leave_room else 0), out.data_ptr(),
+                                                   1 | (4 if leave_room else 0) | (8 if rotated else 0), out.data_ptr(),
                                                    listed_stream.cuda_stream if listed_stream is not None else None)
         _lib.check(st, "shade_frs_forward")
         return out

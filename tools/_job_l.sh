@@ -1,4 +1,4 @@
-timeout 900 python -m pytest tests/test_shading_gpu.py tests/test_fused_step_gpu.py tests/test_fused_dp_gpu.py -m gpu -q -x -p no:cacheprovider 2>&1 | tail -4
+timeout 1200 python -m pytest tests -m gpu -q -x -p no:cacheprovider 2>&1 | tail -4
 B="python bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --no-other-configs --relight-frames 0"
 for i in 1 2; do
   $B 2>/dev/null | grep '^{"metric' | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('K20W5', d['value'], d['spread_iters_per_s']['min'], d['spread_iters_per_s']['median'], d['spread_iters_per_s']['max'])"
