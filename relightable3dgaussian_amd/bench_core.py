@@ -431,6 +431,10 @@ def relight_bench(params, cams, dev, frames, K):
                              "relight_rotating_light: nothing is reused (lookup in the kernel)")
 
 
+# (see bench.py: an OpenMP pool sized for the host runs into the container's CPU quota; tools that import this module directly
+# get the cap here)
+torch.set_num_threads(min(torch.get_num_threads(), 8))
+
 # the per-kernel HIP events are live on every EVENT_EVERY-th step of the timed region (a step with ~40 event pairs between its
 # kernels runs ~13 % slower: at every 8th step the timed block measured 624 it/s against 636 without events)
 EVENT_EVERY = 10

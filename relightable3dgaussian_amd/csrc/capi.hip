@@ -22,7 +22,7 @@ void launch_preprocess(hipStream_t s, int P, int D, int M, const float* means3D,
                        const float* pm, const float* cam_pos, int W, int H, float tan_fovx, float tan_fovy,
                        float focal_x, float focal_y, int* radii, float* means2D, float* depths, float* cov3Ds,
                        float* rgb, float* conic_opacity, float* splat, int gx, int gy, uint32_t* tiles_touched,
-                       uint32_t* block_sums, unsigned long long* total);
+                       uint32_t* block_sums, unsigned long long* total, bool scan_now, uint32_t* zero_words, int zero_n);
 void launch_duplicate_with_keys(hipStream_t s, int P, const float* means2D, const float* depths,
                                 const uint32_t* tiles_touched, const uint32_t* block_offsets,
                                 uint32_t* point_offsets, uint64_t* keys, uint32_t* values, const int* radii, int gx,
@@ -170,10 +170,11 @@ uint32_t tile_sort_small_cap();
 void launch_tile_sort(hipStream_t s, int T, const uint32_t* tile_order, const uint32_t* ranges, const uint32_t* big_list,
                       uint32_t* big_count, uint64_t* keys, uint32_t* vals, uint64_t* scratch, bool entries);
 void launch_tile_binning(hipStream_t s, int P, int T, const float* means2D, const float* depths, const int* radii,
-                         const uint32_t* tiles_touched, const uint32_t* block_offsets, int gx, int gy,
+                         const uint32_t* tiles_touched, uint32_t* block_offsets, int gx, int gy,
                          uint32_t* tile_counts, uint32_t* cursor, uint32_t* ranges, uint32_t* point_offsets,
-                         uint64_t* entries, const unsigned long long* total, long long capacity, float* overflow_flag,
-                         unsigned int* overflow_count);
+                         uint64_t* entries, unsigned long long* total, long long capacity, float* overflow_flag,
+                         unsigned int* overflow_count, bool fused, uint32_t* order, uint32_t small_cap, uint32_t* big_list,
+                         uint32_t* big_count);
 int tile_binning_max_tiles();
 extern int g_bin_iters;
 void launch_densify_accumulate(hipStream_t s, int P, const float* viewspace_grad, const float* normal_grad,
@@ -536,6 +537,7 @@ struct ForwardTicket {
     float* overflow_flag;
     unsigned int* overflow_count;
     char* bbuf;
+    bool fused_front;                    // _begin_ allocated bbuf and launched the folded front end (forward_begin_impl)
 };
 
 static std::mutex g_ticket_mutex;
@@ -623,11 +625,27 @@ static int forward_begin_impl(void* stream_, r3dg_alloc_fn geometry_alloc, r3dg_
             R3DG_HIP(hipEventRecord(t->ready, stream));
             R3DG_HIP(hipStreamWaitEvent(order_stream, t->ready, 0));
         }
+        // bounded + direct binning: the front end is one chain whose launches do not depend on the count, so three of them fold
+        // into their neighbours (launch_tile_binning `fused`): the projection zeroes the tile counters, the tile scan also scans
+        // the projection's block sums, an extra block of the emit kernel orders the tiles
+        t->bbuf = nullptr;
+        t->fused_front = false;
+        uint32_t* zero_words = nullptr;
+        int zero_n = 0;
+        if (capacity >= 0 && g_tile_binning == 2 && (int)T <= tile_binning_max_tiles()) {
+            BinningLayout B = BinningLayout::make((size_t)capacity);
+            t->bbuf = (char*)binning_alloc(user, B.bytes);
+            if (!t->bbuf) { set_error("rasterize_forward: binning resize callback returned NULL"); return R3DG_EALLOC; }
+            t->fused_front = true;
+            zero_words = (uint32_t*)(t->bbuf + B.sort_temp);
+            zero_n = (int)T;
+        }
         StageTimer t_pre(order_stream, ST_PREPROCESS);
         launch_preprocess(order_stream, P, D, M, means3D, scales, scale_modifier, rotations, opacities, shs,
                           (uint8_t*)(gbuf + G.clamped), cov3D_precomp, colors_precomp, viewmatrix, projmatrix, cam_pos,
                           width, height, tan_fovx, tan_fovy, focal_x, focal_y, radii_p, g_means2D, g_depths,
-                          (float*)(gbuf + G.cov3D), g_rgb, g_conic, (float*)(gbuf + G.splat), gx, gy, g_tiles, g_block, g_total);
+                          (float*)(gbuf + G.cov3D), g_rgb, g_conic, (float*)(gbuf + G.splat), gx, gy, g_tiles, g_block, g_total,
+                          !t->fused_front, zero_words, zero_n);
         check_launch(order_stream, debug, "preprocess");
         t_pre.stop();
 
@@ -640,7 +658,7 @@ static int forward_begin_impl(void* stream_, r3dg_alloc_fn geometry_alloc, r3dg_
         t->out_color = out_color; t->out_opacity = out_opacity; t->out_depth = out_depth; t->out_feature = out_feature;
         t->out_normal = out_normal; t->out_surface_xyz = out_surface_xyz; t->out_weights = out_weights;
         t->radii_p = radii_p; t->gbuf = gbuf; t->ibuf = ibuf;
-        t->capacity = capacity; t->overflow_flag = overflow_flag; t->overflow_count = overflow_count; t->bbuf = nullptr;
+        t->capacity = capacity; t->overflow_flag = overflow_flag; t->overflow_count = overflow_count;
         if (capacity >= 0) {
             // bounded: nobody reads the count; the ordering follows the projection right away
             const int st_order = enqueue_ordering(t, order_stream, (int)capacity);
@@ -762,7 +780,7 @@ static int enqueue_ordering(ForwardTicket* t, hipStream_t stream, int R)
         return R3DG_EINVAL;
     }
         BinningLayout B = BinningLayout::make((size_t)R);
-        char* bbuf = (char*)binning_alloc(user, B.bytes);
+        char* bbuf = t->fused_front ? t->bbuf : (char*)binning_alloc(user, B.bytes);     // (fused: allocated by _begin)
         t->bbuf = bbuf;
         if (!bbuf) { set_error("rasterize_forward: binning resize callback returned NULL"); return R3DG_EALLOC; }
         uint64_t* keys_u = (uint64_t*)(bbuf + B.keys_unsorted);
@@ -779,16 +797,18 @@ static int enqueue_ordering(ForwardTicket* t, hipStream_t stream, int R)
             uint32_t* big_count = (uint32_t*)(ibuf + I.big_count);
             uint32_t* tile_counts = (uint32_t*)(bbuf + B.sort_temp);
             StageTimer t_dup(stream, ST_DUPKEYS);
+            uint32_t* order = tile_order ? tile_order : (uint32_t*)(ibuf + I.tile_order);
             launch_tile_binning(stream, P, (int)T, g_means2D, g_depths, radii_p, g_tiles, g_block, gx, gy, tile_counts,
                                 tile_counts + T, ranges, (uint32_t*)(gbuf + G.point_offsets), keys_u,
-                                (const unsigned long long*)(gbuf + G.total), t->capacity, t->overflow_flag,
-                                t->overflow_count);
+                                (unsigned long long*)(gbuf + G.total), t->capacity, t->overflow_flag,
+                                t->overflow_count, t->fused_front, order, tile_sort_small_cap(), big_list, big_count);
             check_launch(stream, debug, "tile_binning");
             t_dup.stop();
             StageTimer t_sort(stream, ST_SORT);
-            uint32_t* order = tile_order ? tile_order : (uint32_t*)(ibuf + I.tile_order);
-            launch_tile_order(stream, (int)T, ranges, order, tile_sort_small_cap(), big_list, big_count);
-            check_launch(stream, debug, "tile_order");
+            if (!t->fused_front) {
+                launch_tile_order(stream, (int)T, ranges, order, tile_sort_small_cap(), big_list, big_count);
+                check_launch(stream, debug, "tile_order");
+            }
             launch_tile_sort(stream, (int)T, order, ranges, big_list, big_count, keys, vals, keys_u, true);
             check_launch(stream, debug, "tile_sort");
             t_sort.stop();

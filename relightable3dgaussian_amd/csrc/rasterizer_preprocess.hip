@@ -88,11 +88,14 @@ preprocess_kernel(int P, int D, int M, const float* __restrict__ means3D, const 
                   float tan_fovy, float focal_x, float focal_y, int* __restrict__ radii,
                   float2* __restrict__ means2D, float* __restrict__ depths, float* __restrict__ cov3Ds,
                   float* __restrict__ rgb, float4* __restrict__ conic_opacity, float4* __restrict__ splat, int gx, int gy,
-                  uint32_t* __restrict__ tiles_touched, uint32_t* __restrict__ block_sums)
+                  uint32_t* __restrict__ tiles_touched, uint32_t* __restrict__ block_sums,
+                  uint32_t* __restrict__ zero_words, int zero_n)
 {
     extern __shared__ float s_rows[];                  // STAGED: 256 SH rows
     __shared__ uint8_t s_live[256];
     const int idx = blockIdx.x * 256 + threadIdx.x;
+    // (bounded forward: the tile counters of the direct binning, which runs right behind this kernel -- instead of a memset launch)
+    if (idx < zero_n) zero_words[idx] = 0u;
     uint32_t my_tiles = 0;
     bool shade = false;                                // survived every cull and needs its colour from SH
     float px = 0.f, py = 0.f, pz = 0.f;
@@ -239,8 +242,7 @@ preprocess_kernel(int P, int D, int M, const float* __restrict__ means3D, const 
 
 // K3: exclusive scan of the per-block sums (one 1024-thread block; nb = ceil(P/256) is ~1.2k at P=300k).
 // Writes block_sums[i] <- exclusive prefix and total[0] <- num_rendered (64-bit to detect u32 overflow).
-__global__ void __launch_bounds__(1024) scan_block_sums_kernel(int nb, uint32_t* __restrict__ block_sums,
-                                                               unsigned long long* __restrict__ total)
+__device__ __forceinline__ unsigned long long scan_block_sums_body(int nb, uint32_t* __restrict__ block_sums)
 {
     __shared__ unsigned long long s_wave[16];
     __shared__ unsigned long long s_carry;
@@ -269,7 +271,14 @@ __global__ void __launch_bounds__(1024) scan_block_sums_kernel(int nb, uint32_t*
         if (tid == 0) s_carry = carry + chunk_total;
         __syncthreads();
     }
-    if (tid == 0) total[0] = s_carry;
+    return s_carry;
+}
+
+__global__ void __launch_bounds__(1024) scan_block_sums_kernel(int nb, uint32_t* __restrict__ block_sums,
+                                                               unsigned long long* __restrict__ total)
+{
+    const unsigned long long sum = scan_block_sums_body(nb, block_sums);
+    if (threadIdx.x == 0) total[0] = sum;
 }
 
 // K5: reference duplicateWithKeys (rasterizer_impl.cu:70-111).  Also materialises the inclusive prefix sum
@@ -356,9 +365,9 @@ __global__ void identify_tile_ranges_kernel(int L, const uint64_t* __restrict__ 
 
 // Longest-tile-first block order for the two tile kernels: one block buckets the T tile lengths into 256 classes
 // (descending) with LDS counters.  Order inside a class is arbitrary -- it only affects scheduling, never results.
-__global__ void __launch_bounds__(1024)
-tile_order_kernel(int T, const uint2* __restrict__ ranges, uint32_t* __restrict__ order, uint32_t small_cap,
-                  uint32_t* __restrict__ big_list, uint32_t* __restrict__ big_count)
+__device__ __forceinline__ void tile_order_body(int T, const uint2* __restrict__ ranges, uint32_t* __restrict__ order,
+                                                uint32_t small_cap, uint32_t* __restrict__ big_list,
+                                                uint32_t* __restrict__ big_count)
 {
     __shared__ uint32_t s_nbig;
     __shared__ uint32_t s_cnt[256];
@@ -401,6 +410,13 @@ tile_order_kernel(int T, const uint2* __restrict__ ranges, uint32_t* __restrict_
         big_count[0] = s_nbig;
         big_count[1] = 0;               // the long-tile sort's work cursor (radix_sort.hip)
     }
+}
+
+__global__ void __launch_bounds__(1024)
+tile_order_kernel(int T, const uint2* __restrict__ ranges, uint32_t* __restrict__ order, uint32_t small_cap,
+                  uint32_t* __restrict__ big_list, uint32_t* __restrict__ big_count)
+{
+    tile_order_body(T, ranges, order, small_cap, big_list, big_count);
 }
 
 // ---- direct tile binning (R3DG_OPT_TILE_BINNING = 2, default) -----------------------------------------------------------------
@@ -474,15 +490,24 @@ tile_count_kernel(int P, int T, int iters, const float2* __restrict__ means2D, c
 // one 1024-thread block: ranges[t] = (start, end), cursor[t] = start
 __global__ void __launch_bounds__(1024)
 tile_scan_kernel(int T, const uint32_t* __restrict__ tile_counts, uint2* __restrict__ ranges, uint32_t* __restrict__ cursor,
-                 const unsigned long long* __restrict__ total, long long capacity, float* __restrict__ overflow_flag,
-                 unsigned int* __restrict__ overflow_count)
+                 unsigned long long* __restrict__ total, long long capacity, float* __restrict__ overflow_flag,
+                 unsigned int* __restrict__ overflow_count, int nb_block_sums, uint32_t* __restrict__ block_sums)
 {
     __shared__ uint32_t s_wave[16];
     __shared__ uint32_t s_carry;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // nb_block_sums > 0: the projection left its per-block instance counts unscanned (launch_preprocess with scan_now = false):
+    // their exclusive scan and the total are produced here, one launch earlier than the kernels that read them (tile_emit_kernel)
+    unsigned long long count;
+    if (nb_block_sums > 0) {
+        count = scan_block_sums_body(nb_block_sums, block_sums);
+        if (tid == 0) total[0] = count;
+    } else {
+        count = *total;
+    }
     // bounded forward (capacity >= 0): the binning state holds `capacity` instance slots and the host did NOT look at the
     // count; a frame that needs more is dropped on the device -- every tile list empty, *overflow_flag = 1 for the caller
-    const bool over = capacity >= 0 && *total > (unsigned long long)capacity;
+    const bool over = capacity >= 0 && count > (unsigned long long)capacity;
     if (tid == 0 && overflow_flag != nullptr) *overflow_flag = over ? 1.0f : 0.0f;
     if (tid == 0 && over && overflow_count != nullptr) *overflow_count += 1u;       // running count, never reset here
     if (tid == 0) s_carry = 0;
@@ -512,10 +537,18 @@ tile_emit_kernel(int P, int T, int iters, const float2* __restrict__ means2D, co
                  const int* __restrict__ radii, const uint32_t* __restrict__ tiles_touched,
                  const uint32_t* __restrict__ block_offsets, int gx, int gy, uint32_t* __restrict__ cursor,
                  uint32_t* __restrict__ point_offsets, uint64_t* __restrict__ entries,
-                 const unsigned long long* __restrict__ total, long long capacity)
+                 const unsigned long long* __restrict__ total, long long capacity, int emit_blocks,
+                 const uint2* __restrict__ ranges, uint32_t* __restrict__ order, uint32_t small_cap,
+                 uint32_t* __restrict__ big_list, uint32_t* __restrict__ big_count)
 {
     extern __shared__ uint32_t s_bins[];
     __shared__ uint32_t s_wave[BIN_THREADS / 64];
+    // one block past the emitting ones (when the caller asked for it): the longest-tile-first order of the tile kernels, which
+    // needs the ranges only -- beside the emission instead of a launch of its own behind it
+    if ((int)blockIdx.x >= emit_blocks) {
+        tile_order_body(T, ranges, order, small_cap, big_list, big_count);
+        return;
+    }
     const bool over = capacity >= 0 && *total > (unsigned long long)capacity;      // see tile_scan_kernel
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     for (int t = threadIdx.x; t < T; t += BIN_THREADS) s_bins[t] = 0;
@@ -554,13 +587,17 @@ tile_emit_kernel(int P, int T, int iters, const float2* __restrict__ means2D, co
 
 int g_bin_iters = 2;
 
+// `fused` (the bounded forward): tile_counts arrive zeroed (launch_preprocess zero_words), block_sums arrive UNSCANNED
+// (launch_preprocess scan_now = false: the scan kernel scans them and writes *total), and the tile order (launch_tile_order's
+// outputs) is produced by one extra block of the emit kernel -- three launches fewer on the ordering stream's chain.
 void launch_tile_binning(hipStream_t s, int P, int T, const float* means2D, const float* depths, const int* radii,
-                         const uint32_t* tiles_touched, const uint32_t* block_offsets, int gx, int gy,
+                         const uint32_t* tiles_touched, uint32_t* block_offsets, int gx, int gy,
                          uint32_t* tile_counts /* T, scratch */, uint32_t* cursor /* T, scratch */, uint32_t* ranges,
-                         uint32_t* point_offsets, uint64_t* entries, const unsigned long long* total, long long capacity,
-                         float* overflow_flag, unsigned int* overflow_count)
+                         uint32_t* point_offsets, uint64_t* entries, unsigned long long* total, long long capacity,
+                         float* overflow_flag, unsigned int* overflow_count, bool fused, uint32_t* order, uint32_t small_cap,
+                         uint32_t* big_list, uint32_t* big_count)
 {
-    R3DG_HIP(hipMemsetAsync(tile_counts, 0, (size_t)T * 4, s));
+    if (!fused) R3DG_HIP(hipMemsetAsync(tile_counts, 0, (size_t)T * 4, s));
     const int iters = g_bin_iters;
     const int per_block = iters * BIN_THREADS;
     const int nb = (P + per_block - 1) / per_block;
@@ -573,9 +610,10 @@ void launch_tile_binning(hipStream_t s, int P, int T, const float* means2D, cons
     }
     tile_count_kernel<<<nb, BIN_THREADS, smem, s>>>(P, T, iters, (const float2*)means2D, radii, gx, gy, tile_counts);
     tile_scan_kernel<<<1, 1024, 0, s>>>(T, tile_counts, (uint2*)ranges, cursor, total, capacity, overflow_flag,
-                                        overflow_count);
-    tile_emit_kernel<<<nb, BIN_THREADS, smem, s>>>(P, T, iters, (const float2*)means2D, depths, radii, tiles_touched,
-                                                  block_offsets, gx, gy, cursor, point_offsets, entries, total, capacity);
+                                        overflow_count, fused ? (P + 255) / 256 : 0, block_offsets);
+    tile_emit_kernel<<<nb + (fused ? 1 : 0), BIN_THREADS, smem, s>>>(
+        P, T, iters, (const float2*)means2D, depths, radii, tiles_touched, block_offsets, gx, gy, cursor, point_offsets, entries,
+        total, capacity, nb, (const uint2*)ranges, order, small_cap, big_list, big_count);
 }
 
 int tile_binning_max_tiles() { return BIN_MAX_TILES; }
@@ -601,21 +639,25 @@ void launch_preprocess(hipStream_t s, int P, int D, int M, const float* means3D,
                        const float* pm, const float* cam_pos, int W, int H, float tan_fovx, float tan_fovy,
                        float focal_x, float focal_y, int* radii, float* means2D, float* depths, float* cov3Ds,
                        float* rgb, float* conic_opacity, float* splat, int gx, int gy, uint32_t* tiles_touched,
-                       uint32_t* block_sums, unsigned long long* total)
+                       uint32_t* block_sums, unsigned long long* total, bool scan_now, uint32_t* zero_words, int zero_n)
 {
     const int nb = (P + 255) / 256;
+    if (zero_n > nb * 256) {                   // (fewer threads than words: a memset after all)
+        R3DG_HIP(hipMemsetAsync(zero_words, 0, (size_t)zero_n * 4, s));
+        zero_n = 0;
+    }
     const bool staged = g_stage_sh_rows && shs != nullptr && colors_precomp == nullptr && M >= 1 && M <= 16;
     if (staged)
         preprocess_kernel<true><<<nb, 256, 256 * ((3 * M) | 1) * sizeof(float), s>>>(
             P, D, M, means3D, scales, scale_modifier, rotations, opacities, shs, clamped, cov3D_precomp, colors_precomp,
             vm, pm, cam_pos, W, H, tan_fovx, tan_fovy, focal_x, focal_y, radii, (float2*)means2D, depths, cov3Ds, rgb,
-            (float4*)conic_opacity, (float4*)splat, gx, gy, tiles_touched, block_sums);
+            (float4*)conic_opacity, (float4*)splat, gx, gy, tiles_touched, block_sums, zero_words, zero_n);
     else
         preprocess_kernel<false><<<nb, 256, 0, s>>>(
             P, D, M, means3D, scales, scale_modifier, rotations, opacities, shs, clamped, cov3D_precomp, colors_precomp,
             vm, pm, cam_pos, W, H, tan_fovx, tan_fovy, focal_x, focal_y, radii, (float2*)means2D, depths, cov3Ds, rgb,
-            (float4*)conic_opacity, (float4*)splat, gx, gy, tiles_touched, block_sums);
-    scan_block_sums_kernel<<<1, 1024, 0, s>>>(nb, block_sums, total);
+            (float4*)conic_opacity, (float4*)splat, gx, gy, tiles_touched, block_sums, zero_words, zero_n);
+    if (scan_now) scan_block_sums_kernel<<<1, 1024, 0, s>>>(nb, block_sums, total);
 }
 
 void launch_duplicate_with_keys(hipStream_t s, int P, const float* means2D, const float* depths,

@@ -427,12 +427,15 @@ class FusedStage2Step(_BoundedForward):
             # the rotation of the incident-light coefficients into the ray frames depends on nothing of this view: it goes to the
             # side stream now and runs beside the activations and the projection instead of in front of the shading forward
             rotated_for = None
-            env_c = None
             aux = self._aux_stream()
             if aux is not None:
                 aux.wait_stream(torch.cuda.current_stream())
                 with torch.cuda.stream(aux):
                     self._frs.rotate(self.incidents)
+                    # (also on the side stream, BEHIND the rotation.  Measured: with these two tiny launches on the main stream the
+                    # shading forward starts ~20 us earlier, inside the projection, and the step loses 15-20 it/s; gating the
+                    # shading forward on the projection's end with an event loses 12.  The persistent forward and the front
+                    # end's kernels share the CUs best with this stagger.)
                     env_c = F.softplus(self.env)[0]                              # DirectLightMap.get_env
                     self.sums.zero_()
                 rotated_for = self._frs
