@@ -263,6 +263,11 @@ int r3dg_shade_frs_supported(int K, int M, int He, int We);
 size_t r3dg_shade_frs_tables_bytes(int K);
 int r3dg_shade_frs_build_tables(void* stream, int K, const float* d_zsamples, float* d_tables);
 int r3dg_shade_frs_classify(void* stream, int P, const float* d_ray_normals, uint8_t* d_valid);
+/* Stream plumbing for callers that spread one iteration over several streams of one device: `waiter` waits for everything queued
+ * on `signaller` so far (hipEventRecord + hipStreamWaitEvent on a pooled event -- what the library's own entry points use between
+ * the streams they are handed). */
+int r3dg_stream_wait_stream(void* waiter, void* signaller);
+
 /* The first step of r3dg_shade_frs_forward on its own: d_cprime [P,48] = the incident-light coefficients rotated into each
  * Gaussian's ray frame.  It depends on d_incidents and d_ray_normals only, so a caller can queue it (on another stream) as soon
  * as the coefficients are final and pass R3DG_SHADE_ROTATED to the forward. */

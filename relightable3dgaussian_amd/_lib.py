@@ -63,6 +63,7 @@ _SIGNATURES = {
     "r3dg_shade_frs_build_tables": (_i, [_p, _i, _p, _p]),
     "r3dg_shade_frs_classify": (_i, [_p, _i, _p, _p]),
     "r3dg_shade_frs_rotate": (_i, [_p, _i, _p, _p, _p]),
+    "r3dg_stream_wait_stream": (_i, [_p, _p]),
     "r3dg_shade_frs_forward": (_i, [_p, _i, _i] + [_p] * 6 + [_i, _i, _p, _p, _p, _f] + [_p] * 5 + [_i, _p, _i, _p, _p]),
     "r3dg_shade_frs_backward": (_i, [_p, _i, _i] + [_p] * 6 + [_i, _i, _p, _p, _p, _f] + [_p] * 5 + [_i] + [_p] * 10 + [_i, _p]),
     "r3dg_shade_build_transport": (_i, [_p, _i, _i, _i, _p, _p, _p, _p, _p, _f, _p, _p]),
@@ -179,6 +180,12 @@ def current_stream():
     if raw is not None:
         return raw(torch._C._cuda_getDevice())
     return torch.cuda.current_stream().cuda_stream
+
+
+def stream_wait(waiter, signaller):
+    """`waiter` (a torch.cuda.Stream) waits for everything queued on `signaller` so far: torch's waiter.wait_stream(signaller)
+    through the library's pooled events (r3dg_stream_wait_stream)."""
+    check(lib().r3dg_stream_wait_stream(waiter.cuda_stream, signaller.cuda_stream), "stream_wait_stream")
 
 
 def profile_read():

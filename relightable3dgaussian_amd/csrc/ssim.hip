@@ -16,6 +16,7 @@ constexpr int SSIM_R = 5;                    // window radius (window_size 11)
 constexpr int SSIM_T = 32;                   // tile edge (outputs)
 constexpr int SSIM_E = SSIM_T + 2 * SSIM_R;  // 42: tile + halo
 constexpr int SSIM_B = 4;                    // outputs per thread along the filtered axis (sliding window in registers)
+constexpr int SSIM_NLOAD = (SSIM_E * SSIM_E + 255) / 256;     // halo-region elements per thread (7)
 
 // gaussian(11, 1.5) / sum, the fp32 values the reference's create_window produces (loss_utils.py:20-29)
 __constant__ float kSsimWin[11] = {1.028380124e-03f, 7.598758209e-03f, 3.600077331e-02f, 1.093606874e-01f,
@@ -69,13 +70,29 @@ ssim_forward_kernel(int W, int H, int C, SsimBatch batch)
     const float* xc = x + c * HW;
     const float* yc = y + c * HW;
     const int bx = blockIdx.x * SSIM_T, by = blockIdx.y * SSIM_T;
-    for (int i = threadIdx.x; i < SSIM_E * SSIM_E; i += 256) {
-        const int r = i / SSIM_E, q = i % SSIM_E;
-        const int gy = by + r - SSIM_R, gx = bx + q - SSIM_R;
-        const bool in = gx >= 0 && gx < W && gy >= 0 && gy < H;                 // zero padding
-        const size_t o = (size_t)(in ? gy : 0) * W + (in ? gx : 0);
-        s_x[r][q] = in ? xc[o] : 0.f;
-        s_y[r][q] = in ? yc[o] : 0.f;
+    // (every load of the halo region is issued before the first one is used: written as a plain loop the compiler waits for
+    // each load before it issues the next -- 14 memory latencies in a row per workgroup, which was most of this kernel's time)
+    {
+        float xv[SSIM_NLOAD], yv[SSIM_NLOAD];
+#pragma unroll
+        for (int j = 0; j < SSIM_NLOAD; j++) {
+            const int i = threadIdx.x + j * 256;
+            const int r = i / SSIM_E, q = i % SSIM_E;
+            const int gy = by + r - SSIM_R, gx = bx + q - SSIM_R;
+            const bool in = i < SSIM_E * SSIM_E && gx >= 0 && gx < W && gy >= 0 && gy < H;     // zero padding
+            const size_t o = (size_t)(in ? gy : 0) * W + (in ? gx : 0);
+            const float vx = xc[o], vy = yc[o];
+            xv[j] = in ? vx : 0.f;
+            yv[j] = in ? vy : 0.f;
+        }
+#pragma unroll
+        for (int j = 0; j < SSIM_NLOAD; j++) {
+            const int i = threadIdx.x + j * 256;
+            if (i < SSIM_E * SSIM_E) {
+                s_x[i / SSIM_E][i % SSIM_E] = xv[j];
+                s_y[i / SSIM_E][i % SSIM_E] = yv[j];
+            }
+        }
     }
     __syncthreads();
     float w[11];
@@ -175,14 +192,42 @@ ssim_backward_kernel(int W, int H, int C, SsimBatch batch)
     const int c = blockIdx.z % C;
     const float* pc = partials + (size_t)c * 3 * HW;
     const int bx = blockIdx.x * SSIM_T, by = blockIdx.y * SSIM_T;
-    for (int i = threadIdx.x; i < SSIM_E * SSIM_E; i += 256) {
-        const int r = i / SSIM_E, q = i % SSIM_E;
-        const int gy = by + r - SSIM_R, gx = bx + q - SSIM_R;
-        const bool in = gx >= 0 && gx < W && gy >= 0 && gy < H;      // windows centred outside the image do not exist
-        const size_t o = (size_t)(in ? gy : 0) * W + (in ? gx : 0);
-        s_p[0][r][q] = in ? pc[o] : 0.f;
-        s_p[1][r][q] = in ? pc[HW + o] : 0.f;
-        s_p[2][r][q] = in ? pc[2 * HW + o] : 0.f;
+    // the thread's own four output pixels of x and y (read by the last step): requested first, they arrive under everything else
+    const int tx = threadIdx.x % SSIM_T, ty0 = (threadIdx.x / SSIM_T) * SSIM_B;
+    const int px = bx + tx;
+    float xo[SSIM_B], yo[SSIM_B];
+#pragma unroll
+    for (int o = 0; o < SSIM_B; o++) {
+        const int py = by + ty0 + o;
+        const bool in = px < W && py < H;
+        const size_t off = in ? (size_t)py * W + px : 0;
+        xo[o] = x[c * HW + off];
+        yo[o] = y[c * HW + off];
+    }
+    {
+        float pv[3][SSIM_NLOAD];               // (all loads in flight at once, see ssim_forward_kernel)
+#pragma unroll
+        for (int j = 0; j < SSIM_NLOAD; j++) {
+            const int i = threadIdx.x + j * 256;
+            const int r = i / SSIM_E, q = i % SSIM_E;
+            const int gy = by + r - SSIM_R, gx = bx + q - SSIM_R;
+            // windows centred outside the image do not exist
+            const bool in = i < SSIM_E * SSIM_E && gx >= 0 && gx < W && gy >= 0 && gy < H;
+            const size_t o = (size_t)(in ? gy : 0) * W + (in ? gx : 0);
+            const float v0 = pc[o], v1 = pc[HW + o], v2 = pc[2 * HW + o];
+            pv[0][j] = in ? v0 : 0.f;
+            pv[1][j] = in ? v1 : 0.f;
+            pv[2][j] = in ? v2 : 0.f;
+        }
+#pragma unroll
+        for (int j = 0; j < SSIM_NLOAD; j++) {
+            const int i = threadIdx.x + j * 256;
+            if (i < SSIM_E * SSIM_E) {
+                s_p[0][i / SSIM_E][i % SSIM_E] = pv[0][j];
+                s_p[1][i / SSIM_E][i % SSIM_E] = pv[1][j];
+                s_p[2][i / SSIM_E][i % SSIM_E] = pv[2][j];
+            }
+        }
     }
     __syncthreads();
     float w[11];
@@ -223,8 +268,6 @@ ssim_backward_kernel(int W, int H, int C, SsimBatch batch)
         }
     }
     __syncthreads();
-    const int tx = threadIdx.x % SSIM_T, ty0 = (threadIdx.x / SSIM_T) * SSIM_B;
-    const int px = bx + tx;
     float acc[3][SSIM_B];
 #pragma unroll
     for (int m = 0; m < 3; m++) {
@@ -244,8 +287,7 @@ ssim_backward_kernel(int W, int H, int C, SsimBatch batch)
         const int py = by + ty0 + o;
         if (px < W && py < H) {
             const size_t off = (size_t)py * W + px;
-            const float xv = x[c * HW + off], yv = y[c * HW + off];
-            grad_x[c * HW + off] = scale * (acc[0][o] + 2.f * xv * acc[1][o] + yv * acc[2][o]);
+            grad_x[c * HW + off] = scale * (acc[0][o] + 2.f * xo[o] * acc[1][o] + yo[o] * acc[2][o]);
         }
     }
 }

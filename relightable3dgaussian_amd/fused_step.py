@@ -429,7 +429,7 @@ class FusedStage2Step(_BoundedForward):
             rotated_for = None
             aux = self._aux_stream()
             if aux is not None:
-                aux.wait_stream(torch.cuda.current_stream())
+                _lib.stream_wait(aux, torch.cuda.current_stream())
                 with torch.cuda.stream(aux):
                     self._frs.rotate(self.incidents)
                     # (also on the side stream, BEHIND the rotation.  Measured: with these two tiny launches on the main stream the
@@ -463,7 +463,7 @@ class FusedStage2Step(_BoundedForward):
                 self.sums.zero_()
                 env_c = F.softplus(self.env)[0]                                  # DirectLightMap.get_env
             else:
-                torch.cuda.current_stream().wait_stream(aux)
+                _lib.stream_wait(torch.cuda.current_stream(), aux)
             He, We = env_c.shape[0], env_c.shape[1]
             taps = self.taps(He, We)
             if self._frs is not None:
@@ -487,7 +487,7 @@ class FusedStage2Step(_BoundedForward):
                     taps.data_ptr(), 1 | (4 if self._order_stream is not None else 0),     # train outputs | leave room
                     self.shade_out.data_ptr()), "shade_forward")
             if self._frs is not None and self._listed_stream() is not None:
-                torch.cuda.current_stream().wait_stream(self._listed_stream())
+                _lib.stream_wait(torch.cuda.current_stream(), self._listed_stream())
             _lib.check(L.r3dg_stage2_pack_features(
                 stream(), P, self.xyz.data_ptr(), vm.data_ptr(), self.a_normal.data_ptr(), self.a_base.data_ptr(),
                 self.a_rough.data_ptr(), self.shade_out.data_ptr(), self.features.data_ptr(),
@@ -705,7 +705,7 @@ class FusedStage2Step(_BoundedForward):
         grads = [self.grads[k] for k in self._opt_order]
         if not self.dp:
             if self._early:              # the SH group was updated under the shading backward (forward_backward)
-                torch.cuda.current_stream().wait_stream(self._early_stream)
+                _lib.stream_wait(torch.cuda.current_stream(), self._early_stream)
                 self._early = False
                 todo = self._groups_c + self._groups_b
             else:

@@ -555,6 +555,8 @@ def test_fused_stage2_iteration_host_logic_with_a_recording_library(monkeypatch)
     monkeypatch.setattr(torch.cuda, "stream", lambda s: contextlib.nullcontext())
 
     class FakeStream:
+        cuda_stream = 0
+
         def wait_stream(self, other):
             pass
     monkeypatch.setattr(torch.cuda, "Stream", lambda device=None: FakeStream())
