@@ -751,9 +751,23 @@ shade_backward_kernel(int P, int K, int M, ShadeSrc src, const float* __restrict
     const float fx_scale = fixed ? 34359738368.0f / gmax : 0.f;          // 2^35 / max|g|
     const float fx_clamp = gmax * 8192.0f;                               // |contribution| <= max|g| * 2^13
     if (ENV_LDS) {
-        for (int i = threadIdx.x; i < ntex_raw; i += blockDim.x) {
-            s_env[i] = env[i];
-            s_denv[i] = 0;
+        // (four loads in flight per thread: as a plain loop every load is waited for before the next one is issued, and with a
+        // few hundred listed Gaussians -- one pass per workgroup -- this prologue is a visible part of the kernel)
+        for (int i0 = threadIdx.x; i0 < ntex_raw; i0 += 4 * (int)blockDim.x) {
+            float v[4];
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const int i = i0 + j * (int)blockDim.x;
+                v[j] = env[i < ntex_raw ? i : 0];
+            }
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const int i = i0 + j * (int)blockDim.x;
+                if (i < ntex_raw) {
+                    s_env[i] = v[j];
+                    s_denv[i] = 0;
+                }
+            }
         }
         __syncthreads();
     }

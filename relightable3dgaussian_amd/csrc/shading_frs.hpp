@@ -190,6 +190,19 @@ frs_rotate_kernel(int P, const float* __restrict__ ray_normals, const float* __r
     for (int q = 0; q < 12; q++) d4[q] = make_float4(row[4 * q], row[4 * q + 1], row[4 * q + 2], row[4 * q + 3]);
 }
 
+// texture [ntexel,3] -> LDS as float4 texels; two texels (six loads) in flight per thread -- as a plain loop the loads of one
+// texel are waited for before the next texel's are issued
+__device__ __forceinline__ void frs_stage_texture(const float* __restrict__ env, int ntexel, float4* s_env4)
+{
+    for (int i0 = threadIdx.x; i0 < ntexel; i0 += 2 * (int)blockDim.x) {
+        const int i1 = i0 + (int)blockDim.x, j1 = i1 < ntexel ? i1 : i0;
+        const float a0 = env[3 * i0], a1 = env[3 * i0 + 1], a2 = env[3 * i0 + 2];
+        const float b0 = env[3 * j1], b1 = env[3 * j1 + 1], b2 = env[3 * j1 + 2];
+        s_env4[i0] = make_float4(a0, a1, a2, 0.f);
+        if (i1 < ntexel) s_env4[i1] = make_float4(b0, b1, b2, 0.f);
+    }
+}
+
 // ---- per-lane sample block: 4 consecutive samples of one Gaussian ------------------------------------------------------------
 struct FrsBlock {
     float4 d0, d1, d2;      // 4 directions (12 floats)
@@ -315,8 +328,7 @@ shade_forward_frs_kernel(int P, int K, const float* __restrict__ base_color, con
 {
     extern __shared__ __attribute__((aligned(16))) float s_mem[];
     float4* s_env4 = reinterpret_cast<float4*>(s_mem);
-    for (int i = threadIdx.x; i < He * We; i += blockDim.x)            // (a tap is one ds_read_b128: texels padded to float4 here)
-        s_env4[i] = make_float4(env[3 * i], env[3 * i + 1], env[3 * i + 2], 0.f);
+    frs_stage_texture(env, He * We, s_env4);              // (a tap is one ds_read_b128: texels padded to float4 here)
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int gl = lane & 15, q = lane >> 4;
@@ -476,7 +488,7 @@ shade_backward_frs_kernel(int P, int K, const float* __restrict__ base_color, co
     const int nblk = (K + 15) >> 4;
     float* s_stage = s_mem + ((10 * ntexel + 3) & ~3);                           // FRS_WAVES x FRS_ST_BWD floats (16-byte aligned)
     float* s_tab = s_stage + FRS_WAVES * FRS_ST_BWD;                             // TAB_LDS: the nblk x 512 table words
-    for (int i = threadIdx.x; i < ntexel; i += blockDim.x) s_env4[i] = make_float4(env[3 * i], env[3 * i + 1], env[3 * i + 2], 0.f);
+    frs_stage_texture(env, ntexel, s_env4);
     for (int i = threadIdx.x; i < 3 * ntexel; i += blockDim.x) s_denv[i] = 0;
     if (TAB_LDS)
         for (int i = threadIdx.x; i < nblk * 512; i += blockDim.x) s_tab[i] = tables[i];

@@ -142,7 +142,13 @@ class _BoundedForward:
         self._geom = geom
         slot = self._count_ring[(self._iter - 1) % self._count_ring.numel()]
         if used_bounded:
-            slot.copy_(rasterizer_ops.num_rendered_of(geom, self.P), non_blocking=True)
+            # (on the ordering stream, which wrote the count and is idle by now: 5 us that would sit between the backward and Adam)
+            side = getattr(self, "_order_stream", None)
+            if side is not None and self.dev.type == "cuda":
+                with torch.cuda.stream(side):
+                    slot.copy_(rasterizer_ops.num_rendered_of(geom, self.P), non_blocking=True)
+            else:
+                slot.copy_(rasterizer_ops.num_rendered_of(geom, self.P), non_blocking=True)
         else:
             slot.fill_(int(R))
             if self.bounded:
