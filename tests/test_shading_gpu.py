@@ -253,6 +253,38 @@ def test_fixed_ray_set_kernels_equal_the_general_kernels(P, K, He):
     assert not so.FixedRaySet.supported(K, 16, 256, 512)
 
 
+def test_fixed_ray_set_side_streams_and_early_rotation_change_nothing():
+    """The optional streams of the fixed-ray-set entry points (listed Gaussians' general kernel beside the main kernel, rotation
+    back on a second stream) and the rotation queued ahead of the forward (r3dg_shade_frs_rotate + R3DG_SHADE_ROTATED) only move
+    launches: outputs identical to the plain calls (the texture gradient up to the order of its atomics)."""
+    from relightable3dgaussian_amd import _lib, shading_ops as so
+    P, K, He = 3000, 64, 16
+    inp = _frs_inputs(P, K, He, seed=5)
+    frs = so.FixedRaySet.try_build(inp["normals"], inp["incident_dirs"])
+    assert frs is not None and frs.n_invalid >= 2
+    taps = so.build_taps(inp["incident_dirs"], He, 2 * He)
+    args = (inp["base_color"], inp["roughness"], inp["normals"], inp["viewdirs"], inp["incidents"], inp["env"],
+            inp["visibility"], inp["incident_dirs"], inp["incident_areas"])
+    want = frs.forward(*args, taps, torch.full((P, so.NOUT), -7.0, device=DEV)).clone()
+    grads = [g.clone() for g in frs.backward(*args, taps, inp["g_pbr"], inp["g_diff"])]
+    torch.cuda.synchronize()
+    side, main = torch.cuda.Stream(), torch.cuda.current_stream()
+    frs.cprime.fill_(float("nan"))
+    _lib.stream_wait(side, main)
+    with torch.cuda.stream(side):
+        frs.rotate(inp["incidents"])
+    _lib.stream_wait(main, side)
+    got = frs.forward(*args, taps, torch.full((P, so.NOUT), -7.0, device=DEV), listed_stream=side, rotated=True)
+    _lib.stream_wait(main, side)
+    assert torch.equal(got, want)
+    new = frs.backward(*args, taps, inp["g_pbr"], inp["g_diff"], rotate_stream=side)
+    _lib.stream_wait(main, side)
+    torch.cuda.synchronize()
+    for name, x, y in zip(("d_base", "d_rough", "d_view", "d_inc"), new, grads):
+        assert torch.equal(x, y), name
+    _ok("d_env", new[4], grads[4], 1e-5, 1e-9)
+
+
 @pytest.mark.parametrize("poison", [float("nan"), float("inf"), float("-inf")])
 @pytest.mark.parametrize("path,row", [("general", 10), ("frs", 10), ("frs", 2)])
 def test_non_finite_upstream_gradient_is_propagated_not_hidden(poison, path, row):

@@ -4,7 +4,7 @@
 set -x
 cd /root/repo
 mkdir -p gpurun_out
-export TMPDIR=/tmp HSA_ENABLE_IPC_MODE_LEGACY=0
+export TMPDIR=/tmp HSA_ENABLE_IPC_MODE_LEGACY=0 OMP_NUM_THREADS=8 MKL_NUM_THREADS=8      # (threads: the container's CPU quota, see bench.py)
 timeout 300 python -c "import __graft_entry__ as g; g.smoke()" < /dev/null > gpurun_out/smoke.log 2>&1; tail -1 gpurun_out/smoke.log
 timeout 1500 python -m pytest tests -m gpu -q -p no:cacheprovider < /dev/null > gpurun_out/pytest_gpu.log 2>&1; tail -3 gpurun_out/pytest_gpu.log
 timeout 600 python -m pytest tests/test_reference_gpu.py -q -s -p no:cacheprovider -k "baseline_sizes or bvh" < /dev/null > gpurun_out/parity_reference.log 2>&1; tail -2 gpurun_out/parity_reference.log
