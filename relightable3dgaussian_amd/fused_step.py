@@ -411,9 +411,14 @@ class FusedStage2Step(_BoundedForward):
         return self._adam_stream
 
     def _listed_stream(self):
-        """_aux_stream() when the fixed-ray-set path has Gaussians off the rotated path: their general kernels run there in the
-        forward, and the rasterizer's geometry backward beside them in the backward."""
-        return self._aux_stream() if self._frs is not None and self._frs.n_invalid > 0 else None
+        """The early-Adam stream when the fixed-ray-set path has Gaussians off the rotated path: their general kernels run there in
+        the forward, and the rasterizer's geometry backward beside them in the backward (data-parallel runs too: the stream is
+        idle during the forward, and in the backward bucket A's all-reduce is issued from it, behind the geometry backward)."""
+        if self._frs is None or self._frs.n_invalid == 0:
+            return None
+        if self._adam_stream is None:
+            self._adam_stream = torch.cuda.Stream(device=self.dev)
+        return self._adam_stream
 
     def forward_backward(self, cam, bg, gt, early_adam=False, image_mask=None):
         """One forward + loss + backward; gradients land in self.grads.  Returns the rasterizer's 10 public outputs.
@@ -573,7 +578,12 @@ class FusedStage2Step(_BoundedForward):
                     self._geo_done.record(geo_stream)
             handle_a = None
             if self._side is None and self._bucket_a is not None:
-                handle_a = self._allreduce_async(self._bucket_a)     # travels under the shading backward
+                # bucket A (SH gradient + flag) travels under the shading backward; issued from the stream that produced it
+                if geo_stream is not None:
+                    with torch.cuda.stream(geo_stream):
+                        handle_a = self._allreduce_async(self._bucket_a)
+                else:
+                    handle_a = self._allreduce_async(self._bucket_a)
             self._early = False
             if early_adam and not self.dp and self._groups_a:
                 # Adam of the SH group on a side stream, behind the geometry backward that produces its gradient
@@ -618,10 +628,10 @@ class FusedStage2Step(_BoundedForward):
                     self.incident_dirs, self.incident_areas, taps, self.d_pbr, self.d_diffuse,
                     uniform_area=self._uniform_area, out_incidents=self.grads["incidents"], out_env=self._d_env,
                     block_absmax=self._absmax,
-                    # whole iterations on one GPU: the rotation back of the coefficient gradient goes to the stream that already
-                    # carries the SH group's early Adam (optimizer_step joins it before any Adam launch reads the gradient) and
-                    # runs beside the listed Gaussians' general kernel and the activation chain rule
-                    rotate_stream=self._early_stream if self._early and not self.dp else None)
+                    # whole iterations: the rotation back of the coefficient gradient goes to the stream that already carries the
+                    # SH group's early Adam (optimizer_step joins it before any Adam launch reads the gradient; under data
+                    # parallelism bucket B's all-reduce is issued from it) and runs beside the activation chain rule
+                    rotate_stream=self._early_stream if self._early else None)
             else:
                 d_base, d_rough, d_view, _d_inc, d_env = shading_ops.shade_backward(
                     self.a_base, self.a_rough, self.a_normal, self.a_viewdirs, self.incidents, env_c, self.visibility,
@@ -654,7 +664,11 @@ class FusedStage2Step(_BoundedForward):
             self._handles = None
             if self.dp:
                 handle_c = self._allreduce_async(self._bucket_c)
-                handle_b = self._allreduce_async(self._bucket_b)
+                if self._early:       # the incident-light gradient is finished by the rotation back, on the early stream
+                    with torch.cuda.stream(self._early_stream):
+                        handle_b = self._allreduce_async(self._bucket_b)
+                else:
+                    handle_b = self._allreduce_async(self._bucket_b)
                 self._handles = (handle_a, handle_c, handle_b)
         self.viewspace_grad = dL_dmeans2D
         # a bounded forward returned its capacity as R (the backward's layout); the count itself goes to a pinned ring
