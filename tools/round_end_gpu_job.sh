@@ -17,6 +17,15 @@ f=$(find /tmp/prof -name "*.db" | head -1)
 cd /root/repo
 python tools/rocpd_summary.py "$f" gpurun_out/stage2_fused_stats.md "rocprofv3 --kernel-trace --stats -- python bench.py --steps 20 --warmup 5 --no-cpu-baseline --relight-frames 0 --no-other-configs --repeats 0" < /dev/null
 python tools/rocpd_timeline.py "$f" 15 < /dev/null > gpurun_out/timeline.txt 2>&1
+python tools/rocpd_timeline.py "$f" seq < /dev/null > gpurun_out/sequence.txt 2>&1
+# the same for the data-parallel path over a one-rank RCCL group
+cd /tmp
+rm -rf /tmp/prof_dp
+R3DG_DP_SINGLE_RANK=1 R3DG_DIST_BACKEND=nccl timeout 300 rocprofv3 --kernel-trace -d /tmp/prof_dp -o bench -- $CMD < /dev/null > /root/repo/gpurun_out/prof_bench_dp.log 2>&1
+fd=$(find /tmp/prof_dp -name "*.db" | head -1)
+cd /root/repo
+python tools/rocpd_timeline.py "$fd" 15 < /dev/null > gpurun_out/timeline_dp.txt 2>&1
+python tools/rocpd_timeline.py "$fd" seq < /dev/null > gpurun_out/sequence_dp.txt 2>&1
 cd /tmp
 CMD2="python /root/repo/bench.py --steps 2 --warmup 1 --no-cpu-baseline --relight-frames 40 --no-other-configs --repeats 0"
 rm -rf /tmp/prof2
