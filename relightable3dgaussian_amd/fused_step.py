@@ -100,6 +100,22 @@ def _world_of(process_group):
     return world, world > 1 or os.environ.get("R3DG_DP_SINGLE_RANK") == "1"
 
 
+_STREAMS = {}
+
+
+def shared_stream(dev, role):
+    """The process's ONE side stream of `role` ("order", "early", "geometry") on `dev`, created at first use and shared by every
+    step object.  torch hands out pool streams round robin and HIP maps them onto GPU_MAX_HW_QUEUES hardware queues round robin,
+    so every NEW stream lands on another queue -- sooner or later on the one the main stream uses, and two streams on one queue run
+    their kernels in turn (measured: a later step object in the same process 15 % slower than the first).  Step objects never run
+    concurrently inside a process, so they can share the three streams the first one got."""
+    dev = torch.device(dev)
+    key = (dev.type, dev.index if dev.index is not None else (torch.cuda.current_device() if dev.type == "cuda" else 0), role)
+    if key not in _STREAMS:
+        _STREAMS[key] = torch.cuda.Stream(device=dev)
+    return _STREAMS[key]
+
+
 class _BoundedForward:
     """Host side of the bounded rasterizer forward (r3dg_rasterize_forward_begin_bounded), shared by the fused iterations:
     capacity bookkeeping, the pinned ring the counts go to, and the poll that notices dropped views."""
@@ -303,13 +319,13 @@ class FusedStage2Step(_BoundedForward):
         self._zero_depth_grad = None
         # instance ordering of the rasterizer runs here, under the shading forward (register-light, latency-bound kernels
         # next to a VALU-bound one)
-        self._order_stream = torch.cuda.Stream(device=dev) if overlap_ordering else None
+        self._order_stream = shared_stream(dev, "order") if overlap_ordering else None
         self._adam_stream = None
         self._early = False
         # Optional second stream for the per-Gaussian geometry backward.  Measured on MI355X: a loss -- the shading
         # backward fills the register file (2 waves/SIMD x 221 VGPRs); capping the geometry kernel at 64 VGPRs so that it
         # fits beside it spills 35 registers and slows both (2.13 -> 2.20 ms/step).  Off by default.
-        self._side = torch.cuda.Stream(device=dev) if overlap_geometry else None
+        self._side = shared_stream(dev, "geometry") if overlap_geometry else None
         self._geo_done = None
         self.group = process_group
         self.world, self.dp = _world_of(process_group)
@@ -407,7 +423,7 @@ class FusedStage2Step(_BoundedForward):
         if self._frs is None or self.dp:
             return None
         if self._adam_stream is None:
-            self._adam_stream = torch.cuda.Stream(device=self.dev)
+            self._adam_stream = shared_stream(self.dev, "early")
         return self._adam_stream
 
     def _listed_stream(self):
@@ -417,7 +433,7 @@ class FusedStage2Step(_BoundedForward):
         if self._frs is None or self._frs.n_invalid == 0:
             return None
         if self._adam_stream is None:
-            self._adam_stream = torch.cuda.Stream(device=self.dev)
+            self._adam_stream = shared_stream(self.dev, "early")
         return self._adam_stream
 
     def forward_backward(self, cam, bg, gt, early_adam=False, image_mask=None):
@@ -590,7 +606,7 @@ class FusedStage2Step(_BoundedForward):
                 side = geo_stream
                 if side is None:
                     if self._adam_stream is None:
-                        self._adam_stream = torch.cuda.Stream(device=dev)
+                        self._adam_stream = shared_stream(dev, "early")
                     side = self._adam_stream
                     side.wait_stream(torch.cuda.current_stream())
                 self.opt.begin_step()
@@ -605,7 +621,7 @@ class FusedStage2Step(_BoundedForward):
                 # one-rank RCCL group: 510 -> see DESIGN.md section 5).  The reduced overflow flag is snapshotted there,
                 # right after the all-reduce that carries it.
                 if self._adam_stream is None:
-                    self._adam_stream = torch.cuda.Stream(device=dev)
+                    self._adam_stream = shared_stream(dev, "early")
                 side = self._adam_stream
                 self.opt.begin_step()
                 with torch.cuda.stream(side):
