@@ -12,10 +12,8 @@ one RCCL all-reduce per step.  value = iterations/s summed over all ranks.  Inpu
 timed region.  rank 0 prints ONE JSON line.
 """
 import argparse
-import json
 import os
 import sys
-import time
 
 # the GPU boxes give the container a CPU quota well below the host's core count: OpenMP pools sized for the host (256 spinning
 # threads after every parallel CPU op of the scene setup) run into it and the kernel then stalls EVERY thread of the process,
