@@ -643,3 +643,144 @@ def test_fused_stage2_iteration_host_logic_with_a_recording_library(monkeypatch)
     assert [a[1] for a in adam] == [1, 8]                                      # shs early, then the other nine minus xyz
     with pytest.raises(RuntimeError):
         fused_step.FusedStage2Step(params, K, loss_weights={"no_such_term": 1.0})
+
+
+def test_fused_stage2_iteration_spreads_the_fixed_ray_set_path_over_three_streams(monkeypatch):
+    """The schedule of the single-GPU stage-2 iteration when the fixed-ray-set kernels are on and some Gaussians are off the
+    rotated path, with recorders in place of the library, the rasterizer and the ray-set object -- nothing
+    runs on a GPU.  From the second iteration on: the coefficient rotation is queued on the early-Adam stream BEFORE the
+    activations and the forward is told so; the listed Gaussians' forward kernel gets that stream; the rasterizer's geometry
+    backward gets it too; the rotation back as well; every join goes through the library's pooled events; the side streams are
+    the process-wide ones, shared by a second step object."""
+    import contextlib
+    import types
+    from relightable3dgaussian_amd import _lib, fused_step, rasterizer_ops, shading_ops
+    events = []
+
+    class Recorder:
+        def __getattr__(self, name):
+            def fn(*args):
+                events.append((name, args))
+                return 1 if name == "r3dg_bounded_forward_supported" else 0
+            return fn
+
+    P, K, H, W = 6, 8, 4, 4
+    z = torch.zeros
+    streams = []
+
+    class FakeStream:
+        def __init__(self):
+            self.cuda_stream = 1000 + len(streams)
+            streams.append(self)
+
+        def wait_stream(self, other):
+            events.append(("torch.wait_stream", (self.cuda_stream, other.cuda_stream)))
+
+    class FakeEvent:
+        def record(self, stream):
+            events.append(("event.record", (stream.cuda_stream,)))
+
+    main = FakeStream()
+
+    class FakeStreamContext:
+        def __init__(self, s):
+            self.s = s
+
+        def __enter__(self):
+            events.append(("enter", (self.s.cuda_stream,)))
+
+        def __exit__(self, *a):
+            events.append(("exit", (self.s.cuda_stream,)))
+            return False
+
+    def wait_event(ev):
+        events.append(("main.wait_event", ()))
+    main.wait_event = wait_event
+
+    class FakeRaySet:
+        n_invalid = 2
+
+        def rotate(self, incidents):
+            events.append(("frs.rotate", ()))
+
+        def forward(self, *a, uniform_area=None, leave_room=False, listed_stream=None, rotated=False):
+            events.append(("frs.forward", (listed_stream, rotated, leave_room)))
+
+        def backward(self, *a, uniform_area=None, out_incidents=None, out_env=None, block_absmax=None, rotate_stream=None):
+            events.append(("frs.backward", (rotate_stream,)))
+            return z(P, 3), z(P, 1), z(P, 3), out_incidents, out_env
+
+    monkeypatch.setattr(fused_step, "_STREAMS", {})
+    monkeypatch.setattr(_lib, "lib", lambda: Recorder())
+    monkeypatch.setattr(_lib, "current_stream", lambda: 0)
+    monkeypatch.setattr(torch.cuda, "device", lambda d: contextlib.nullcontext())
+    monkeypatch.setattr(torch.cuda, "stream", lambda s: FakeStreamContext(s))
+    monkeypatch.setattr(torch.cuda, "Stream", lambda device=None: FakeStream())
+    monkeypatch.setattr(torch.cuda, "Event", lambda *a, **k: FakeEvent())
+    monkeypatch.setattr(torch.cuda, "current_stream", lambda *a: main)
+    monkeypatch.setattr(fused_step, "update_visibility", lambda *a, **k: (torch.ones(P, K, 1), torch.ones(P, K, 3),
+                                                                          torch.full((P, K, 1), 2.0), None))
+    monkeypatch.setattr(shading_ops, "build_taps", lambda dirs, He, We, *a, **k: z(P * K * 3))
+    monkeypatch.setattr(shading_ops.FixedRaySet, "supported", staticmethod(lambda K_, M_, He, We: True))
+    monkeypatch.setattr(shading_ops.FixedRaySet, "try_build", classmethod(lambda cls, normals, dirs, **k: FakeRaySet()))
+    geometry_streams = []
+
+    class Pending:
+        def finish(self, ordering_stream=None):
+            events.append(("raster.finish", (ordering_stream,)))
+            return (17, z(H, W, dtype=torch.int32), z(3, H, W), z(1, H, W), z(1, H, W), z(16, H, W), z(3, H, W), z(3, H, W),
+                    z(P, 1), z(P, dtype=torch.int32), z(64, dtype=torch.uint8), z(8, dtype=torch.uint8), z(8, dtype=torch.uint8))
+
+    def begin(*a, **k):
+        events.append(("raster.begin", (k.get("ordering_stream"),)))
+        return Pending()
+
+    def backward(*a, **k):
+        geometry_streams.append(k.get("geometry_stream"))
+        events.append(("raster.backward", ()))
+        return (z(P, 3), z(P, 3), z(P, 1), z(P, 3), z(P, 16), z(P, 6), z(P, 16, 3), z(P, 3), z(P, 4))
+    monkeypatch.setattr(rasterizer_ops, "rasterize_gaussians_begin", begin)
+    monkeypatch.setattr(rasterizer_ops, "rasterize_gaussians_backward", backward)
+    monkeypatch.setattr(rasterizer_ops, "num_rendered_of", lambda geom, P_: torch.tensor(17))
+    params = types.SimpleNamespace(xyz=z(P, 3), normal=z(P, 3), scaling=z(P, 3), rotation=z(P, 4), opacity=z(P, 1),
+                                   features_dc=z(P, 1, 3), features_rest=z(P, 15, 3), base_color=z(P, 3), roughness=z(P, 1),
+                                   incidents_dc=z(P, 1, 3), incidents_rest=z(P, 15, 3), env=z(1, 16, 32, 3))
+    cam = types.SimpleNamespace(image_height=H, image_width=W, world_view_transform=torch.eye(4), full_proj_transform=torch.eye(4),
+                                camera_center=z(3), tanfovx=0.5, tanfovy=0.5, cx=2.0, cy=2.0)
+    step = fused_step.FusedStage2Step(params, K)
+    order_stream = step._order_stream
+    for _ in range(2):
+        step(cam, torch.ones(3), z(3, H, W))
+    assert isinstance(step._frs, FakeRaySet)
+    early = step._adam_stream
+    assert early is not None and early is not order_stream and early is not main
+    # ---- the second iteration ----------------------------------------------------------------------------------------------
+    names = [e[0] for e in events]
+    start = len(names) - 1 - names[::-1].index("frs.rotate") - 2          # (the fork and the stream context in front of it)
+    it, args = names[start:], [e[1] for e in events[start:]]
+    pos = {n: it.index(n) for n in ("frs.rotate", "r3dg_stage2_activate", "raster.begin", "frs.forward", "r3dg_stage2_pack_features",
+                                    "raster.finish", "raster.backward", "r3dg_stage2_unpack_gradients", "frs.backward",
+                                    "r3dg_stage2_activate_backward")}
+    assert sorted(pos, key=pos.get) == ["frs.rotate", "r3dg_stage2_activate", "raster.begin", "frs.forward",
+                                        "r3dg_stage2_pack_features", "raster.finish", "raster.backward",
+                                        "r3dg_stage2_unpack_gradients", "frs.backward", "r3dg_stage2_activate_backward"]
+    # the rotation (and the softplus / sum reset behind it) runs inside the early stream's context, behind a pooled-event fork
+    assert it[pos["frs.rotate"] - 1] == "enter" and args[pos["frs.rotate"] - 1] == (early.cuda_stream,)
+    joins = [a for n, a in zip(it, args) if n == "r3dg_stream_wait_stream"]
+    assert joins[0] == (early.cuda_stream, main.cuda_stream)                 # fork at the top of the iteration
+    assert (main.cuda_stream, early.cuda_stream) in joins[1:]                 # joined in front of the shading forward / the pack
+    assert args[pos["raster.begin"]] == (order_stream,) and args[pos["raster.finish"]] == (order_stream,)
+    listed, rotated, leave_room = args[pos["frs.forward"]]
+    assert listed is early and rotated is True and leave_room is True
+    assert geometry_streams[-1] is early                                       # geometry backward beside the listed backward
+    assert args[pos["frs.backward"]] == (early,)                               # rotation back on the same stream
+    assert "main.wait_event" in it[pos["frs.backward"]:pos["r3dg_stage2_activate_backward"]]     # geometry joined by its event
+    assert "torch.wait_stream" not in it                                       # no per-call event objects on the hot path
+    # one Adam launch inside the early stream's context (the SH group), one on the main stream after the last join
+    adam = [i for i, n in enumerate(it) if n == "r3dg_adam_step"]
+    assert len(adam) == 2 and it[adam[0] - 1] == "enter" and adam[1] > max(i for i, n in enumerate(it) if n == "r3dg_stream_wait_stream")
+    # ---- a second step object gets the same side streams -------------------------------------------------------------------
+    other = fused_step.FusedStage2Step(params, K)
+    other(cam, torch.ones(3), z(3, H, W))
+    other(cam, torch.ones(3), z(3, H, W))
+    assert other._order_stream is order_stream and other._adam_stream is early
