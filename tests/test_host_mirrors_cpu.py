@@ -784,3 +784,131 @@ def test_fused_stage2_iteration_spreads_the_fixed_ray_set_path_over_three_stream
     other(cam, torch.ones(3), z(3, H, W))
     other(cam, torch.ones(3), z(3, H, W))
     assert other._order_stream is order_stream and other._adam_stream is early
+
+
+def test_fused_stage2_data_parallel_iteration_issues_its_buckets_from_the_streams_that_finish_them(monkeypatch):
+    """The same recorders around the DATA-PARALLEL iteration (two ranks pretended): bucket A's all-reduce is issued inside the
+    early stream's context right behind the geometry backward that runs there, bucket C's from the main stream, bucket B's
+    inside the early stream's context behind the rotation back; the deferred incident-light update waits for B at the top of
+    the next iteration's forward, and the coefficient rotation is NOT queued ahead of it (the coefficients are not final yet)."""
+    import contextlib
+    import types
+    from relightable3dgaussian_amd import _lib, fused_step, rasterizer_ops, shading_ops
+    events = []
+    depth = []            # stack of stream contexts
+
+    class Recorder:
+        def __getattr__(self, name):
+            def fn(*args):
+                events.append((name, tuple(depth)))
+                return 1 if name == "r3dg_bounded_forward_supported" else 0
+            return fn
+
+    P, K, H, W = 6, 8, 4, 4
+    z = torch.zeros
+    n_streams = [0]
+
+    class FakeStream:
+        def __init__(self):
+            n_streams[0] += 1
+            self.cuda_stream = 2000 + n_streams[0]
+
+        def wait_stream(self, other):
+            pass
+
+        def wait_event(self, ev):
+            pass
+
+    main = FakeStream()
+
+    class Ctx:
+        def __init__(self, s):
+            self.s = s
+
+        def __enter__(self):
+            depth.append(self.s.cuda_stream)
+
+        def __exit__(self, *a):
+            depth.pop()
+            return False
+
+    class Handle:
+        def __init__(self, tag):
+            self.tag = tag
+
+        def wait(self):
+            events.append(("wait " + self.tag, tuple(depth)))
+
+    class FakeRaySet:
+        n_invalid = 1
+
+        def rotate(self, incidents):
+            events.append(("frs.rotate", tuple(depth)))
+
+        def forward(self, *a, listed_stream=None, rotated=False, **k):
+            events.append(("frs.forward rotated=%s" % rotated, tuple(depth)))
+
+        def backward(self, *a, out_incidents=None, out_env=None, rotate_stream=None, **k):
+            events.append(("frs.backward", (rotate_stream.cuda_stream if rotate_stream is not None else None,)))
+            return z(P, 3), z(P, 1), z(P, 3), out_incidents, out_env
+
+    monkeypatch.setattr(fused_step, "_STREAMS", {})
+    monkeypatch.setattr(fused_step, "_world_of", lambda group: (2, True))
+    monkeypatch.setattr(_lib, "lib", lambda: Recorder())
+    monkeypatch.setattr(_lib, "current_stream", lambda: 0)
+    monkeypatch.setattr(torch.cuda, "device", lambda d: contextlib.nullcontext())
+    monkeypatch.setattr(torch.cuda, "stream", lambda s: Ctx(s))
+    monkeypatch.setattr(torch.cuda, "Stream", lambda device=None: FakeStream())
+    monkeypatch.setattr(torch.cuda, "Event", lambda *a, **k: types.SimpleNamespace(record=lambda s: None))
+    monkeypatch.setattr(torch.cuda, "current_stream", lambda *a: main)
+    monkeypatch.setattr(fused_step, "update_visibility", lambda *a, **k: (torch.ones(P, K, 1), torch.ones(P, K, 3),
+                                                                          torch.full((P, K, 1), 2.0), None))
+    monkeypatch.setattr(shading_ops, "build_taps", lambda dirs, He, We, *a, **k: z(P * K * 3))
+    monkeypatch.setattr(shading_ops.FixedRaySet, "supported", staticmethod(lambda K_, M_, He, We: True))
+    monkeypatch.setattr(shading_ops.FixedRaySet, "try_build", classmethod(lambda cls, normals, dirs, **k: FakeRaySet()))
+
+    class Pending:
+        def finish(self, ordering_stream=None):
+            return (17, z(H, W, dtype=torch.int32), z(3, H, W), z(1, H, W), z(1, H, W), z(16, H, W), z(3, H, W), z(3, H, W),
+                    z(P, 1), z(P, dtype=torch.int32), z(64, dtype=torch.uint8), z(8, dtype=torch.uint8), z(8, dtype=torch.uint8))
+    monkeypatch.setattr(rasterizer_ops, "rasterize_gaussians_begin", lambda *a, **k: Pending())
+
+    def backward(*a, **k):
+        events.append(("raster.backward geometry_stream=%s" % getattr(k.get("geometry_stream"), "cuda_stream", None), tuple(depth)))
+        return (z(P, 3), z(P, 3), z(P, 1), z(P, 3), z(P, 16), z(P, 6), z(P, 16, 3), z(P, 3), z(P, 4))
+    monkeypatch.setattr(rasterizer_ops, "rasterize_gaussians_backward", backward)
+    monkeypatch.setattr(rasterizer_ops, "num_rendered_of", lambda geom, P_: torch.tensor(17))
+    buckets = {}
+
+    def all_reduce(flat, group=None, async_op=False):
+        tag = buckets.get(flat.data_ptr(), "?")
+        events.append(("all_reduce " + tag, tuple(depth)))
+        return Handle(tag)
+    monkeypatch.setattr(torch.distributed, "all_reduce", all_reduce)
+    params = types.SimpleNamespace(xyz=z(P, 3), normal=z(P, 3), scaling=z(P, 3), rotation=z(P, 4), opacity=z(P, 1),
+                                   features_dc=z(P, 1, 3), features_rest=z(P, 15, 3), base_color=z(P, 3), roughness=z(P, 1),
+                                   incidents_dc=z(P, 1, 3), incidents_rest=z(P, 15, 3), env=z(1, 16, 32, 3))
+    cam = types.SimpleNamespace(image_height=H, image_width=W, world_view_transform=torch.eye(4), full_proj_transform=torch.eye(4),
+                                camera_center=z(3), tanfovx=0.5, tanfovy=0.5, cx=2.0, cy=2.0)
+    step = fused_step.FusedStage2Step(params, K, process_group=object())
+    assert step.dp and step.world == 2
+    buckets.update({step._bucket_a.data_ptr(): "A", step._bucket_c.data_ptr(): "C", step._bucket_b.data_ptr(): "B"})
+    for _ in range(3):
+        step(cam, torch.ones(3), z(3, H, W))
+    early = step._adam_stream.cuda_stream
+    names = [e[0] for e in events]
+    start = len(names) - 1 - names[::-1].index("r3dg_stage2_activate")        # the third iteration
+    it = events[start:]
+    seq = [(n, d) for n, d in it if n.split()[0] in ("all_reduce", "wait", "frs.rotate", "frs.forward", "frs.backward", "raster.backward")]
+    assert seq == [
+        ("wait B", ()),                                     # flush(): the previous iteration's incident-light update
+        ("frs.forward rotated=False", ()),                  # ... so the forward rotates the coefficients itself, after it
+        ("raster.backward geometry_stream=%d" % early, ()),
+        ("all_reduce A", (early,)),                         # behind the geometry backward, on its stream
+        ("wait A", (early,)),                               # the SH group's early Adam waits there, not on the main stream
+        ("frs.backward", (early,)),                         # rotation back on the early stream
+        ("all_reduce C", ()),
+        ("all_reduce B", (early,)),                         # behind the rotation that finishes the incident-light gradient
+        ("wait C", ()),
+    ], seq
+    assert "frs.rotate" not in names
