@@ -12,6 +12,18 @@ from relightable3dgaussian_amd import checkpoint as ck
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 
+@pytest.fixture(autouse=True)
+def _no_side_streams_shared_between_tests():
+    """fused_step keeps ONE set of side streams per process (shared_stream); the tests below hand it fake stream objects, which
+    must not outlive the test that made them."""
+    from relightable3dgaussian_amd import fused_step
+    saved = dict(fused_step._STREAMS)
+    fused_step._STREAMS.clear()
+    yield
+    fused_step._STREAMS.clear()
+    fused_step._STREAMS.update(saved)
+
+
 def _load(stage):
     path = os.path.join(GOLDEN, "checkpoint_reference_stage%d.pth" % stage)
     return path, torch.load(path, map_location="cpu", weights_only=False)
@@ -710,7 +722,6 @@ def test_fused_stage2_iteration_spreads_the_fixed_ray_set_path_over_three_stream
             events.append(("frs.backward", (rotate_stream,)))
             return z(P, 3), z(P, 1), z(P, 3), out_incidents, out_env
 
-    monkeypatch.setattr(fused_step, "_STREAMS", {})
     monkeypatch.setattr(_lib, "lib", lambda: Recorder())
     monkeypatch.setattr(_lib, "current_stream", lambda: 0)
     monkeypatch.setattr(torch.cuda, "device", lambda d: contextlib.nullcontext())
@@ -852,7 +863,6 @@ def test_fused_stage2_data_parallel_iteration_issues_its_buckets_from_the_stream
             events.append(("frs.backward", (rotate_stream.cuda_stream if rotate_stream is not None else None,)))
             return z(P, 3), z(P, 1), z(P, 3), out_incidents, out_env
 
-    monkeypatch.setattr(fused_step, "_STREAMS", {})
     monkeypatch.setattr(fused_step, "_world_of", lambda group: (2, True))
     monkeypatch.setattr(_lib, "lib", lambda: Recorder())
     monkeypatch.setattr(_lib, "current_stream", lambda: 0)
