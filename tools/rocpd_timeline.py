@@ -68,6 +68,8 @@ def sequence():
     t0 = rows[a][1]
     queues = {}
     hi = rows[a][1]
+    print("# one step (from a render_backward launch to the next): start us | duration us | hardware queue (q0 = the main stream's) | "
+          "idle: time with NO kernel running on the device in front of this launch | kernel")
     for name, s, e, q in rows[a:b]:
         gap = (s - hi) / 1e3 if s > hi else 0.0
         hi = max(hi, e)
