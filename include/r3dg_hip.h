@@ -243,26 +243,38 @@ int r3dg_shade_forward_transport(void* stream, int P, int K, const float* d_base
 /* ---- the same integral over a FIXED RAY SET (csrc/shading_frs.hpp) -----------------------------------------------------------
  * For callers whose cached directions are the Fibonacci set rotated to each Gaussian's normal, d_k = normalize(R(n) z_k) --
  * what GaussianModel.update_visibility produces (scene/gaussian_model.py:312-342 -> utils/graphics_utils.py:9-37,
- * rotation_between_z utils/sh_utils.py:36-68).  The local incident light sum_i c_i Y_i(R z_k) equals sum_i c'_i Y_i(z_k) for the
- * ROTATED coefficients c', and Y_i(z_k) is one K x 16 table for all Gaussians: the two SH contractions of the integral run on
- * the matrix cores against that constant table instead of ~225 VALU instructions per sample.  Same inputs, outputs and values
- * (fp32 rounding) as r3dg_shade_forward_cached / r3dg_shade_backward_cached with R3DG_SHADE_TRAIN_OUTPUTS, lookup-record taps
- * and no light rotation; 16 incident-light coefficients, K % 4 == 0, a texture that fits LDS: r3dg_shade_frs_supported.
+ * rotation_between_z utils/sh_utils.py:36-68).  Then NOTHING per sample depends on a stored direction (SURVEY section 8f n2:
+ * "store the frozen-normal snapshot, 12 B per Gaussian, instead of the [P,K,3] cache"):
+ *   - the local incident light sum_i c_i Y_i(R z_k) equals sum_i c'_i Y_i(z_k) for the ROTATED coefficients c', and Y_i(z_k) is
+ *     one K x 16 table for all Gaussians: both SH contractions run on the matrix cores against that constant table;
+ *   - every dot product of d_k with a per-Gaussian vector w (the shading normal, the view vector) is z_k . (R^T w): one more
+ *     matrix product per vector against the direction rows of the same table; the GGX half-vector terms follow from N.L, N.V
+ *     and L.V alone;
+ *   - the lat-long lookup of d_k is a constant between visibility updates: 8 bytes per sample (r3dg_shade_frs_build_taps).
+ * What the kernels stream per sample: visibility (4 B) + the lookup record (8 B) -- round 3 read 28 B (direction 12, a 12-byte
+ * record, visibility 4).  Same outputs and values (fp32 rounding) as r3dg_shade_forward_cached / r3dg_shade_backward_cached
+ * with R3DG_SHADE_TRAIN_OUTPUTS and no light rotation; 16 incident-light coefficients, K % 4 == 0, a texture that fits LDS:
+ * r3dg_shade_frs_supported.
  *   d_ray_normals [P,3]: the normals the ray set was GENERATED from (the snapshot update_visibility used, not the trained
- *     normal); d_tables: r3dg_shade_frs_build_tables(K, d_zsamples [K,3] = the z set, r3dg_shade_frs_tables_bytes(K) bytes);
+ *     normal); d_zsamples [K,3]: the z set; d_tables: r3dg_shade_frs_build_tables(K, d_zsamples, r3dg_shade_frs_tables_bytes(K)
+ *     bytes); d_taps [P,K,2] uint32: r3dg_shade_frs_build_taps for THIS texture size (rebuilt per visibility update);
  *   d_valid [P] bytes from r3dg_shade_frs_classify: 1 where R(n) is orthonormal to 2e-5 in fp32 -- normals within ~2.5 degrees of
- *     -z lose that to cancellation, their cached directions are not a rigid copy of the z set, and those Gaussians (d_invalid_list
- *     [n_invalid] int32 row indices, built by the caller from d_valid) go through the general kernels inside the same call;
+ *     -z lose that to cancellation, their directions are not a rigid copy of the z set, and those Gaussians (d_invalid_list
+ *     [n_invalid] int32 row indices, built by the caller from d_valid) are shaded inside the same call by wave-per-Gaussian
+ *     kernels that regenerate their directions from the ray normal and evaluate the SH basis there;
  *   d_cprime [P,48]: scratch written by _forward (the rotated coefficients) and read by _backward of the same parameters;
  *   d_dcprime [P,48]: scratch of _backward.
  *   Sample areas: the fixed ray set has ONE area for every sample -- uniform_area, or 2*pi (what fibonacci_sphere_sampling assigns,
- *     utils/graphics_utils.py:36) when uniform_area == 0; d_incident_areas [P,K] is read only for the Gaussians of d_invalid_list:
- *     _backward needs it when n_invalid > 0 (the general backward reads areas per sample), _forward takes uniform_area for them
- *     when it is NULL. */
+ *     utils/graphics_utils.py:36) when uniform_area == 0. */
 int r3dg_shade_frs_supported(int K, int M, int He, int We);
 size_t r3dg_shade_frs_tables_bytes(int K);
 int r3dg_shade_frs_build_tables(void* stream, int K, const float* d_zsamples, float* d_tables);
 int r3dg_shade_frs_classify(void* stream, int P, const float* d_ray_normals, uint8_t* d_valid);
+/* d_taps [P,K,2]: per sample (x0 + 1) << 23 | mantissa(1 + wx1), (y0 + 1) << 23 | mantissa(1 + wy1) -- the texel corner and the
+ * two bilinear weights (23-bit fixed point) of the lat-long lookup (direct_light_map.py:70-83) of d_k = normalize(R(n) z_k),
+ * regenerated from the ray normal: no [P,K,3] direction array is read.  He, We <= 511. */
+int r3dg_shade_frs_build_taps(void* stream, int P, int K, const float* d_ray_normals, const float* d_zsamples, int He, int We,
+                              uint32_t* d_taps);
 /* Stream plumbing for callers that spread one iteration over several streams of one device: `waiter` waits for everything queued
  * on `signaller` so far (hipEventRecord + hipStreamWaitEvent on a pooled event -- what the library's own entry points use between
  * the streams they are handed). */
@@ -274,25 +286,23 @@ int r3dg_stream_wait_stream(void* waiter, void* signaller);
 int r3dg_shade_frs_rotate(void* stream, int P, const float* d_incidents, const float* d_ray_normals, float* d_cprime);
 int r3dg_shade_frs_forward(void* stream, int P, int K, const float* d_base_color, const float* d_roughness,
                            const float* d_normals, const float* d_viewdirs, const float* d_incidents, const float* d_env,
-                           int He, int We, const float* d_visibility, const float* d_incident_dirs,
-                           const float* d_incident_areas, float uniform_area, const uint32_t* d_taps,
-                           const float* d_ray_normals, const float* d_tables, const uint8_t* d_valid,
-                           const int32_t* d_invalid_list, int n_invalid, float* d_cprime, int flags, float* d_out,
-                           void* listed_stream);
-/*   listed_stream: NULL, or a second stream for the general kernel on the listed Gaussians (ordered after everything queued on
+                           int He, int We, const float* d_visibility, float uniform_area, const uint32_t* d_taps,
+                           const float* d_ray_normals, const float* d_zsamples, const float* d_tables,
+                           const uint8_t* d_valid, const int32_t* d_invalid_list, int n_invalid, float* d_cprime, int flags,
+                           float* d_out, void* listed_stream);
+/*   listed_stream: NULL, or a second stream for the kernel on the listed Gaussians (ordered after everything queued on
  *   `stream` before the call; it then runs beside the rotation and the main kernel).  The caller joins listed_stream before anything
  *   reads d_out. */
 int r3dg_shade_frs_backward(void* stream, int P, int K, const float* d_base_color, const float* d_roughness,
                             const float* d_normals, const float* d_viewdirs, const float* d_incidents, const float* d_env,
-                            int He, int We, const float* d_visibility, const float* d_incident_dirs,
-                            const float* d_incident_areas, float uniform_area, const uint32_t* d_taps,
-                            const float* d_ray_normals, const float* d_tables, const uint8_t* d_valid,
-                            const int32_t* d_invalid_list, int n_invalid, const float* d_cprime, float* d_dcprime,
-                            const float* d_dL_dpbr, const float* d_dL_ddiffuse_light, float* d_dL_dbase_color,
-                            float* d_dL_droughness, float* d_dL_dviewdirs, float* d_dL_dincidents, float* d_dL_denv,
-                            const float* d_block_absmax, int n_block_absmax, void* rotate_stream);
-/*   Launch order on `stream`: the general kernel on the listed Gaussians, then the main kernel (a caller that has other work
- *   running on another stream when it calls this gets the small latency-bound launch beside that work).
+                            int He, int We, const float* d_visibility, float uniform_area, const uint32_t* d_taps,
+                            const float* d_ray_normals, const float* d_zsamples, const float* d_tables,
+                            const uint8_t* d_valid, const int32_t* d_invalid_list, int n_invalid, const float* d_cprime,
+                            float* d_dcprime, const float* d_dL_dpbr, const float* d_dL_ddiffuse_light,
+                            float* d_dL_dbase_color, float* d_dL_droughness, float* d_dL_dviewdirs, float* d_dL_dincidents,
+                            float* d_dL_denv, const float* d_block_absmax, int n_block_absmax, void* rotate_stream);
+/*   Launch order on `stream`: the kernel on the listed Gaussians, then the main kernel (a caller that has other work
+ *   running on another stream when it calls this gets the small launch beside that work).
  *   rotate_stream: NULL, or a second stream for the rotation of the coefficient gradient back to d_dL_dincidents (ordered after the
  *   main kernel by an event; it overlaps the caller's next launches on `stream`).  The caller joins rotate_stream before anything
  *   reads d_dL_dincidents. */

@@ -58,37 +58,38 @@ void launch_shade_forward(hipStream_t s, int P, int K, int M, const float* base_
                           const float* normals, const float* viewdirs, const float* incidents, const float* env, int He,
                           int We, const float* tr, const float* visibility, const float* dirs, const float* areas,
                           float* out, const uint32_t* taps, bool train_outputs, float uniform_area, bool taps_are_radiance,
-                          bool leave_room, const int* list = nullptr, int n_list = 0);
+                          bool leave_room);
 size_t shade_frs_table_floats(int K);
 bool shade_frs_supported(int K, int M, int He, int We);
 void launch_shade_frs_build_tables(hipStream_t s, int K, const float* zsamples, float* tables);
 void launch_shade_frs_classify(hipStream_t s, int P, const float* ray_normals, uint8_t* valid);
+void launch_shade_frs_build_taps(hipStream_t s, int P, int K, const float* ray_normals, const float* zsamples, int He, int We,
+                                 uint32_t* taps);
 void launch_shade_frs_forward_aux(hipStream_t s, int P, const float* incidents, const float* ray_normals, float* cprime);
 void launch_shade_frs_forward_main(hipStream_t s, int P, int K, const float* base_color, const float* roughness,
                                    const float* normals, const float* viewdirs, const float* env, int He, int We,
-                                   const float* visibility,
-                                   const float* dirs, float uniform_area, const uint32_t* taps, const float* tables,
-                                   const uint8_t* valid, const float* cprime, bool leave_room, float* out);
-void launch_shade_frs_forward_listed(hipStream_t s, int P, int K, const float* base_color, const float* roughness,
+                                   const float* visibility, float uniform_area, const uint32_t* taps, const float* ray_normals,
+                                   const float* tables, const uint8_t* valid, const float* cprime, bool leave_room, float* out);
+void launch_shade_frs_forward_listed(hipStream_t s, int K, const float* base_color, const float* roughness,
                                      const float* normals, const float* viewdirs, const float* incidents, const float* env, int He,
-                                     int We, const float* visibility, const float* dirs, const float* areas, float uniform_area,
-                                     const uint32_t* taps, const int* invalid_list, int n_invalid, bool leave_room, float* out);
+                                     int We, const float* visibility, const float* ray_normals, const float* zsamples,
+                                     float uniform_area, const int* invalid_list, int n_invalid, float* out);
 const unsigned int* launch_shade_frs_backward_aux(hipStream_t s, int P, const float* g_pbr, const float* g_diff,
                                                   const float* block_absmax, int n_block_absmax, int* gmax_n);
 void launch_shade_frs_backward_main(hipStream_t s, int P, int K, const float* base_color, const float* roughness,
                                     const float* normals, const float* viewdirs, const float* env, int He, int We,
-                                    const float* visibility,
-                                    const float* dirs, float uniform_area, const uint32_t* taps, const float* tables,
-                                    const uint8_t* valid, const float* cprime, float* dcp, const float* g_pbr, const float* g_diff,
-                                    float* d_base, float* d_rough, float* d_view, float* d_env, const unsigned int* gmax, int gmax_n);
+                                    const float* visibility, float uniform_area, const uint32_t* taps, const float* ray_normals,
+                                    const float* tables, const uint8_t* valid, const float* cprime, float* dcp, const float* g_pbr,
+                                    const float* g_diff, float* d_base, float* d_rough, float* d_view, float* d_env,
+                                    const unsigned int* gmax, int gmax_n);
 void launch_shade_frs_backward_rotate(hipStream_t s, int P, const float* ray_normals, const float* dcp, float* d_inc,
                                       const uint8_t* valid);
-void launch_shade_frs_backward_listed(hipStream_t s, int P, int K, const float* base_color, const float* roughness,
+void launch_shade_frs_backward_listed(hipStream_t s, int K, const float* base_color, const float* roughness,
                                       const float* normals, const float* viewdirs, const float* incidents, const float* env, int He,
-                                      int We, const float* visibility, const float* dirs, const float* areas, const uint32_t* taps,
-                                      const int* invalid_list, int n_invalid, const float* g_pbr, const float* g_diff,
-                                      float* d_base, float* d_rough, float* d_view, float* d_inc, float* d_env,
-                                      const float* block_absmax, int n_block_absmax);
+                                      int We, const float* visibility, const float* ray_normals, const float* zsamples,
+                                      float uniform_area, const int* invalid_list, int n_invalid, const float* g_pbr,
+                                      const float* g_diff, float* d_base, float* d_rough, float* d_view, float* d_inc, float* d_env,
+                                      const unsigned int* gmax, int gmax_n);
 void launch_shade_build_taps(hipStream_t s, size_t n, const float* dirs, const float* tr, int He, int We, const float* env,
                              uint32_t* taps);
 void launch_shade_build_transport(hipStream_t s, int P, int K, int M, const float* normals, const float* incidents,
@@ -103,8 +104,7 @@ void launch_shade_backward(hipStream_t s, int P, int K, int M, const float* base
                            const float* normals, const float* viewdirs, const float* incidents, const float* env,
                            int He, int We, const float* tr, const float* visibility, const float* dirs,
                            const float* areas, const float* g_pbr, const float* g_diff, float* d_base, float* d_rough,
-                           float* d_view, float* d_inc, float* d_env, const uint32_t* taps, const float* block_absmax, int n_block_absmax,
-                           const int* list = nullptr, int n_list = 0);
+                           float* d_view, float* d_inc, float* d_env, const uint32_t* taps, const float* block_absmax, int n_block_absmax);
 void launch_re_forward(hipStream_t s, bool complex_, int P, int Si, int Sd, int Sv, const float* base_color,
                        const float* roughness, const float* metallic, const float* normals, const float* viewdirs,
                        const float* inc, const float* direct, const float* vis, int K, const float* rand_float,
@@ -1282,25 +1282,36 @@ int r3dg_shade_frs_rotate(void* stream_, int P, const float* incidents, const fl
     });
 }
 
+int r3dg_shade_frs_build_taps(void* stream_, int P, int K, const float* ray_normals, const float* zsamples, int He, int We,
+                              uint32_t* taps)
+{
+    if (P < 0 || K <= 0 || He <= 0 || We <= 0 || He > 511 || We > 511) return invalid("shade_frs_build_taps: bad sizes");
+    if (P == 0) return R3DG_OK;
+    if (!ray_normals || !zsamples || !taps) return invalid("shade_frs_build_taps: null buffer");
+    return guarded([&]() -> int {
+        launch_shade_frs_build_taps((hipStream_t)stream_, P, K, ray_normals, zsamples, He, We, taps);
+        return R3DG_OK;
+    });
+}
+
 int r3dg_shade_frs_forward(void* stream_, int P, int K, const float* base_color, const float* roughness,
                            const float* normals, const float* viewdirs, const float* incidents, const float* env, int He,
-                           int We, const float* visibility, const float* incident_dirs, const float* incident_areas,
-                           float uniform_area, const uint32_t* taps, const float* ray_normals, const float* tables,
-                           const uint8_t* valid, const int32_t* invalid_list, int n_invalid, float* cprime, int flags,
-                           float* out, void* listed_stream_)
+                           int We, const float* visibility, float uniform_area, const uint32_t* taps,
+                           const float* ray_normals, const float* zsamples, const float* tables, const uint8_t* valid,
+                           const int32_t* invalid_list, int n_invalid, float* cprime, int flags, float* out,
+                           void* listed_stream_)
 {
     if (P < 0 || K <= 0 || He <= 0 || We <= 0 || n_invalid < 0 || n_invalid > P) return invalid("shade_frs_forward: bad sizes");
     if (!shade_frs_supported(K, 16, He, We))
         return invalid("shade_frs_forward: needs K % 4 == 0 and an environment texture that fits LDS (r3dg_shade_frs_supported)");
     if (P == 0) return R3DG_OK;
-    if (!base_color || !roughness || !normals || !viewdirs || !incidents || !env || !visibility || !incident_dirs || !taps ||
-        !ray_normals || !tables || !valid || !cprime || !out || (n_invalid > 0 && !invalid_list))
+    if (!base_color || !roughness || !normals || !viewdirs || !incidents || !env || !visibility || !taps || !ray_normals ||
+        !zsamples || !tables || !valid || !cprime || !out || (n_invalid > 0 && !invalid_list))
         return invalid("shade_frs_forward: null buffer");
-    if (n_invalid > 0 && !incident_areas && !(uniform_area > 0.f)) return invalid("shade_frs_forward: no sample areas");
     return guarded([&]() -> int {
         hipStream_t stream = (hipStream_t)stream_;
         const bool leave_room = (flags & R3DG_SHADE_LEAVE_ROOM) != 0;
-        // the general kernel on the listed Gaussians (disjoint rows of `out`) may run on a second stream, ordered after everything
+        // the kernel on the listed Gaussians (disjoint rows of `out`) may run on a second stream, ordered after everything
         // queued on `stream` so far: it then runs beside the rotation and the main kernel instead of after them (the CALLER
         // joins that stream before anything reads `out`)
         hipStream_t lstream = listed_stream_ != nullptr ? (hipStream_t)listed_stream_ : stream;
@@ -1309,9 +1320,8 @@ int r3dg_shade_frs_forward(void* stream_, int P, int K, const float* base_color,
                 stream_wait_stream(lstream, stream);
             }
             StageTimer t(lstream, ST_SHADE_LISTED);
-            launch_shade_frs_forward_listed(lstream, P, K, base_color, roughness, normals, viewdirs, incidents, env, He, We,
-                                            visibility, incident_dirs, incident_areas, uniform_area, taps, invalid_list, n_invalid,
-                                            leave_room, out);
+            launch_shade_frs_forward_listed(lstream, K, base_color, roughness, normals, viewdirs, incidents, env, He, We,
+                                            visibility, ray_normals, zsamples, uniform_area, invalid_list, n_invalid, out);
         }
         if ((flags & R3DG_SHADE_ROTATED) == 0) {
             StageTimer t(stream, ST_SHADE_AUX);
@@ -1319,8 +1329,8 @@ int r3dg_shade_frs_forward(void* stream_, int P, int K, const float* base_color,
         }
         {
             StageTimer t(stream, ST_SHADE_FWD);
-            launch_shade_frs_forward_main(stream, P, K, base_color, roughness, normals, viewdirs, env, He, We, visibility, incident_dirs,
-                                          uniform_area, taps, tables, valid, cprime, leave_room, out);
+            launch_shade_frs_forward_main(stream, P, K, base_color, roughness, normals, viewdirs, env, He, We, visibility,
+                                          uniform_area, taps, ray_normals, tables, valid, cprime, leave_room, out);
         }
         return R3DG_OK;
     });
@@ -1328,10 +1338,10 @@ int r3dg_shade_frs_forward(void* stream_, int P, int K, const float* base_color,
 
 int r3dg_shade_frs_backward(void* stream_, int P, int K, const float* base_color, const float* roughness,
                             const float* normals, const float* viewdirs, const float* incidents, const float* env, int He,
-                            int We, const float* visibility, const float* incident_dirs, const float* incident_areas,
-                            float uniform_area, const uint32_t* taps, const float* ray_normals, const float* tables,
-                            const uint8_t* valid, const int32_t* invalid_list, int n_invalid, const float* cprime,
-                            float* dcprime, const float* dL_dpbr, const float* dL_ddiffuse_light, float* dL_dbase_color,
+                            int We, const float* visibility, float uniform_area, const uint32_t* taps,
+                            const float* ray_normals, const float* zsamples, const float* tables, const uint8_t* valid,
+                            const int32_t* invalid_list, int n_invalid, const float* cprime, float* dcprime,
+                            const float* dL_dpbr, const float* dL_ddiffuse_light, float* dL_dbase_color,
                             float* dL_droughness, float* dL_dviewdirs, float* dL_dincidents, float* dL_denv,
                             const float* block_absmax, int n_block_absmax, void* rotate_stream_)
 {
@@ -1340,9 +1350,9 @@ int r3dg_shade_frs_backward(void* stream_, int P, int K, const float* base_color
     if (!shade_frs_supported(K, 16, He, We))
         return invalid("shade_frs_backward: needs K % 4 == 0 and an environment texture that fits LDS (r3dg_shade_frs_supported)");
     if (P == 0) return R3DG_OK;
-    if (!base_color || !roughness || !normals || !viewdirs || !incidents || !env || !visibility || !incident_dirs || !taps ||
-        !ray_normals || !tables || !valid || !cprime || !dcprime || !dL_dpbr || !dL_ddiffuse_light || !dL_dbase_color ||
-        !dL_droughness || !dL_dviewdirs || !dL_dincidents || !dL_denv || (n_invalid > 0 && (!invalid_list || !incident_areas)))
+    if (!base_color || !roughness || !normals || !viewdirs || !incidents || !env || !visibility || !taps || !ray_normals ||
+        !zsamples || !tables || !valid || !cprime || !dcprime || !dL_dpbr || !dL_ddiffuse_light || !dL_dbase_color ||
+        !dL_droughness || !dL_dviewdirs || !dL_dincidents || !dL_denv || (n_invalid > 0 && !invalid_list))
         return invalid("shade_frs_backward: null buffer");
     return guarded([&]() -> int {
         hipStream_t stream = (hipStream_t)stream_;
@@ -1352,22 +1362,21 @@ int r3dg_shade_frs_backward(void* stream_, int P, int K, const float* base_color
             StageTimer t(stream, ST_SHADE_AUX);
             gmax = launch_shade_frs_backward_aux(stream, P, dL_dpbr, dL_ddiffuse_light, block_absmax, n_block_absmax, &gmax_n);
         }
-        // the general kernel on the listed Gaussians goes FIRST (its rows of the per-Gaussian outputs are disjoint from the main
-        // kernel's, the texture gradient is accumulated by both): a latency-bound launch over a few hundred Gaussians that a caller
-        // can put beside whatever it has running on another stream at this point (fused_step: the rasterizer's per-Gaussian
-        // geometry backward) instead of alone behind the main kernel
+        // the kernel on the listed Gaussians goes FIRST (its rows of the per-Gaussian outputs are disjoint from the main
+        // kernel's, the texture gradient is accumulated by both): a small launch that a caller can put beside whatever it has
+        // running on another stream at this point (fused_step: the rasterizer's per-Gaussian geometry backward)
         if (n_invalid > 0) {
             StageTimer t(stream, ST_SHADE_LISTED);
-            launch_shade_frs_backward_listed(stream, P, K, base_color, roughness, normals, viewdirs, incidents, env, He, We,
-                                             visibility, incident_dirs, incident_areas, taps, invalid_list, n_invalid, dL_dpbr,
-                                             dL_ddiffuse_light, dL_dbase_color, dL_droughness, dL_dviewdirs, dL_dincidents, dL_denv,
-                                             block_absmax, n_block_absmax);
+            launch_shade_frs_backward_listed(stream, K, base_color, roughness, normals, viewdirs, incidents, env, He, We,
+                                             visibility, ray_normals, zsamples, uniform_area, invalid_list, n_invalid, dL_dpbr,
+                                             dL_ddiffuse_light, dL_dbase_color, dL_droughness, dL_dviewdirs, dL_dincidents,
+                                             dL_denv, gmax, gmax_n);
         }
         {
             StageTimer t(stream, ST_SHADE_BWD);
-            launch_shade_frs_backward_main(stream, P, K, base_color, roughness, normals, viewdirs, env, He, We, visibility, incident_dirs,
-                                           uniform_area, taps, tables, valid, cprime, dcprime, dL_dpbr, dL_ddiffuse_light,
-                                           dL_dbase_color, dL_droughness, dL_dviewdirs, dL_denv, gmax, gmax_n);
+            launch_shade_frs_backward_main(stream, P, K, base_color, roughness, normals, viewdirs, env, He, We, visibility,
+                                           uniform_area, taps, ray_normals, tables, valid, cprime, dcprime, dL_dpbr,
+                                           dL_ddiffuse_light, dL_dbase_color, dL_droughness, dL_dviewdirs, dL_denv, gmax, gmax_n);
         }
         // the rotation back may run on a second stream (ordered after the main kernel by an event; the CALLER joins that stream
         // before anything reads dL_dincidents): it then overlaps whatever the caller queues next on `stream`.  It leaves the

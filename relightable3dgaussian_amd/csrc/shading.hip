@@ -312,13 +312,7 @@ constexpr int SB_U = 0, SB_DIRS = 272, SB_VIS = 1040, SB_AREA = 1296, SB_FLOATS 
 struct ShadeSrc {
     const float *base_color, *roughness, *normals, *viewdirs, *incidents, *g_pbr, *g_diff, *zero;
     const float *dirs, *vis, *areas;
-    const int* list;         // optional: the kernel's Gaussian i is row list[i] of every array (a subset of the Gaussians)
 };
-// LIST is a template parameter of the kernels on purpose: in the default instance nothing of this exists -- a (conditional) load
-// in front of the LDS-DMA issue makes hipcc wait for the vector-memory queue there, which drains the prefetch that was just
-// issued (measured: +20 % on the whole backward with a run-time `list != nullptr` test)
-template <bool LIST>
-__device__ __forceinline__ int shade_row_of(const ShadeSrc& p, int i) { return LIST ? p.list[i] : i; }
 
 __device__ __forceinline__ const float* uniform_src(int e, int g, int M, const ShadeSrc& p)
 {
@@ -333,23 +327,23 @@ __device__ __forceinline__ const float* uniform_src(int e, int g, int M, const S
     return q;
 }
 
-template <bool VEC16, bool LIST>
+template <bool VEC16>
 __device__ __forceinline__ void issue_block_loads(int lane, int gb, int k0, int P, int K, int M, const ShadeSrc& p,
                                                   float* sb /* one SB_FLOATS buffer of this wave */, size_t total /* samples in the arrays */)
 {
 #pragma unroll
     for (int t = 0; t < SH_GW; t++)
-        R3DG_GLDS(uniform_src(lane, shade_row_of<LIST>(p, min(gb + t, P - 1)), M, p), sb + SB_U + SB_USTRIDE * t, 4);
+        R3DG_GLDS(uniform_src(lane, min(gb + t, P - 1), M, p), sb + SB_U + SB_USTRIDE * t, 4);
     if (VEC16) {
 #pragma unroll
         for (int j = 0; j < 3; j++) {
             const int f = (j * 64 + lane) * 4, grp = f / 192, w = f % 192;
-            size_t idx = ((size_t)shade_row_of<LIST>(p, min(gb + grp, P - 1)) * K + k0) * 3 + w;
+            size_t idx = ((size_t)min(gb + grp, P - 1) * K + k0) * 3 + w;
             idx = idx < 3 * total - 4 ? idx : 3 * total - 4;          // ragged last block: stay inside the array
             R3DG_GLDS(p.dirs + idx, sb + SB_DIRS + 256 * j, 16);
         }
         const int f = lane * 4, grp = f / 64, w = f % 64;
-        size_t idx = (size_t)shade_row_of<LIST>(p, min(gb + grp, P - 1)) * K + k0 + w;
+        size_t idx = (size_t)min(gb + grp, P - 1) * K + k0 + w;
         idx = idx < total - 4 ? idx : total - 4;
         R3DG_GLDS(p.vis + idx, sb + SB_VIS, 16);
         R3DG_GLDS(p.areas + idx, sb + SB_AREA, 16);
@@ -357,14 +351,14 @@ __device__ __forceinline__ void issue_block_loads(int lane, int gb, int k0, int 
 #pragma unroll
         for (int j = 0; j < 12; j++) {
             const int f = j * 64 + lane, grp = f / 192, w = f % 192;
-            size_t idx = ((size_t)shade_row_of<LIST>(p, min(gb + grp, P - 1)) * K + k0) * 3 + w;
+            size_t idx = ((size_t)min(gb + grp, P - 1) * K + k0) * 3 + w;
             idx = idx < 3 * total - 1 ? idx : 3 * total - 1;
             R3DG_GLDS(p.dirs + idx, sb + SB_DIRS + 64 * j, 4);
         }
 #pragma unroll
         for (int j = 0; j < 4; j++) {
             const int f = j * 64 + lane, grp = f / 64, w = f % 64;
-            size_t idx = (size_t)shade_row_of<LIST>(p, min(gb + grp, P - 1)) * K + k0 + w;
+            size_t idx = (size_t)min(gb + grp, P - 1) * K + k0 + w;
             idx = idx < total - 1 ? idx : total - 1;
             R3DG_GLDS(p.vis + idx, sb + SB_VIS + 64 * j, 4);
             R3DG_GLDS(p.areas + idx, sb + SB_AREA + 64 * j, 4);
@@ -400,12 +394,10 @@ constexpr int REC = 64;      // floats per Gaussian record
 // lanes 48..63 read these 16 (a copying version of this kernel cost 0.05 ms per iteration for 115 MB of pure copy).
 __global__ void __launch_bounds__(256)
 shade_prepare_kernel(int n, const float* __restrict__ base_color, const float* __restrict__ roughness,
-                     const float* __restrict__ normals, const float* __restrict__ viewdirs, float* __restrict__ rec16,
-                     const int* __restrict__ list /* optional: only these rows */)
+                     const float* __restrict__ normals, const float* __restrict__ viewdirs, float* __restrict__ rec16)
 {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
-    const int g = list != nullptr ? list[i] : i;
+    const int g = blockIdx.x * 256 + threadIdx.x;
+    if (g >= n) return;
     float u[64];
 #pragma unroll
     for (int c = 0; c < 3; c++) {
@@ -531,16 +523,14 @@ __device__ __forceinline__ RowSample load_row_sample(bool live, int g, int lane,
 // Software pipeline per wave: [wait for block i's samples] -> [issue the loads of block i+1: they fly during the ~250
 // instructions below] -> [record of block i: one ds_write_b32 per lane, read back as wave-uniform broadcasts] -> compute ->
 // (last block of the Gaussian) transposing wave reduction + store.
-template <int NOUT, bool ENV_LDS, int TAPS /* 0 lookup in kernel, 1 cached lookup, 2 cached radiance */, bool M16,
-          bool LIST = false>
+template <int NOUT, bool ENV_LDS, int TAPS /* 0 lookup in kernel, 1 cached lookup, 2 cached radiance */, bool M16>
 __global__ void __launch_bounds__(64 * ROW_WAVES)
 shade_forward_row_kernel(int P, int K, int M_, const float* __restrict__ rec, const float* __restrict__ incidents,
                          const float4* __restrict__ env4, int He, int We,
                          const float* __restrict__ tr, const float* __restrict__ visibility,
                          const float* __restrict__ dirs, const float* __restrict__ areas, float uniform_area,
-                         const uint32_t* __restrict__ taps, float* __restrict__ out, const int* __restrict__ list)
+                         const uint32_t* __restrict__ taps, float* __restrict__ out)
 {
-    // `list` != nullptr: P counts the listed Gaussians and Gaussian i of this launch is row list[i] of every array
     static_assert(NOUT == 7 || NOUT == 19, "training (pbr, diffuse_light, mean visibility) or all 19 outputs");
     constexpr int NV = NOUT == 7 ? 8 : 32;
     const int M = M16 ? 16 : M_;                 // degree-3 incident light (the reference's only configuration) folds the
@@ -566,8 +556,7 @@ shade_forward_row_kernel(int P, int K, int M_, const float* __restrict__ rec, co
     };
     auto fetch = [&](int ag, int akb) {
         const int k = akb * 64 + lane;
-        int gg = min(ag, P - 1);
-        if (LIST) gg = __builtin_amdgcn_readfirstlane(list[gg]);
+        const int gg = min(ag, P - 1);
         return load_row_sample<TAPS>(ag < P && k < K, gg, lane, (unsigned)k, K, rec, dirs, visibility, areas,
                                      uniform_area, taps, 16, incidents, M);
     };
@@ -732,7 +721,7 @@ grad_absmax_kernel(int n, const float* __restrict__ a, const float* __restrict__
 // fewer than 2^14 of them per texel, so the sum stays below 2^62; the resolution is 3e-11 * max|g| -- finer than the
 // fp32 accumulation it replaces -- and the per-block sum is order-independent.  Non-finite upstream gradients fall
 // back to float atomics so NaN/inf still propagate.
-template <bool ENV_LDS, bool VEC16, bool TAPS, bool LIST = false>
+template <bool ENV_LDS, bool VEC16, bool TAPS>
 __global__ void __launch_bounds__(64 * SHADE_WAVES)
 shade_backward_kernel(int P, int K, int M, ShadeSrc src, const float* __restrict__ env, int He, int We,
                       const float* __restrict__ tr, float* __restrict__ d_base, float* __restrict__ d_rough,
@@ -783,7 +772,7 @@ shade_backward_kernel(int P, int K, int M, ShadeSrc src, const float* __restrict
     const int nblk = (K + 63) / 64;
     const int g_stride = gridDim.x * SH_GB;
     int gb = (blockIdx.x * SHADE_WAVES + wave) * SH_GW, kb = 0, buf = 0;
-    if (gb < P) issue_block_loads<VEC16, LIST>(lane, gb, 0, P, K, M, src, s_buf[wave][0], total_samples);
+    if (gb < P) issue_block_loads<VEC16>(lane, gb, 0, P, K, M, src, s_buf[wave][0], total_samples);
     // per-lane accumulators over this lane's samples: 48 SH gradient channels (f = i*3 + c), albedo, roughness, view.
     // Each 64-sample block (4 samples per lane) is walked three times to keep the live register set small: pass 0
     // evaluates the SH sums of the local light, pass 1 the full sample + BRDF / view / env gradients, pass 2 rebuilds
@@ -798,11 +787,11 @@ shade_backward_kernel(int P, int K, int M, ShadeSrc src, const float* __restrict
         wait_block_loads();
         int ngb = gb, nkb = kb + 1;
         if (nkb == nblk) { nkb = 0; ngb = gb + g_stride; }
-        if (ngb < P) issue_block_loads<VEC16, LIST>(lane, ngb, nkb * 64, P, K, M, src, s_buf[wave][buf ^ 1], total_samples);
+        if (ngb < P) issue_block_loads<VEC16>(lane, ngb, nkb * 64, P, K, M, src, s_buf[wave][buf ^ 1], total_samples);
         const float* sb = s_buf[wave][buf];
         const float* s_u = sb + SB_U + grp * SB_USTRIDE;
         const bool live = gb + grp < P;
-        const int g = shade_row_of<LIST>(src, min(gb + grp, P - 1));  // row of this 16-lane group's Gaussian in every array
+        const int g = min(gb + grp, P - 1);                // row of this 16-lane group's Gaussian in every array
         GaussFwd G;
         gauss_setup(G, s_u);
         const float gp[3] = {s_u[58] * invK, s_u[59] * invK, s_u[60] * invK};
@@ -1043,20 +1032,18 @@ void launch_shade_build_taps(hipStream_t s, size_t n, const float* dirs, const f
 
 // `taps`: optional cache of r3dg_shade_build_taps for THESE dirs / env size / transform; `train_outputs`: write only
 // pbr (0..2), diffuse_light (3..5) and the mean visibility (18) of the 19 outputs.
-// `list` / `n_list`: when list != nullptr only the Gaussians list[0 .. n_list) are shaded (rows of all arrays are indexed by
-// the listed ids; the other rows of `out` are left untouched)
 void launch_shade_forward(hipStream_t s, int P, int K, int M, const float* base_color, const float* roughness,
                           const float* normals, const float* viewdirs, const float* incidents, const float* env, int He,
                           int We, const float* tr, const float* visibility, const float* dirs, const float* areas,
                           float* out, const uint32_t* taps, bool train_outputs, float uniform_area, bool taps_are_radiance,
-                          bool leave_room, const int* list, int n_list)
+                          bool leave_room)
 {
-    if (P == 0 || (list != nullptr && n_list <= 0)) return;
+    if (P == 0) return;
     const size_t ntexel = (size_t)He * We;
     float* rec = shade_records(s, (((size_t)P * 16 + 3) & ~(size_t)3) + ntexel * 4);   // [P][16] derived floats, then the padded texture
     float4* env4 = reinterpret_cast<float4*>(rec + (((size_t)P * 16 + 3) & ~(size_t)3));
-    const int n = list != nullptr ? n_list : P;
-    shade_prepare_kernel<<<(n + 255) / 256, 256, 0, s>>>(n, base_color, roughness, normals, viewdirs, rec, list);
+    const int n = P;
+    shade_prepare_kernel<<<(n + 255) / 256, 256, 0, s>>>(n, base_color, roughness, normals, viewdirs, rec);
     shade_pad_env_kernel<<<(int)((ntexel + 255) / 256), 256, 0, s>>>((int)ntexel, env, env4);
     const int mode = taps == nullptr ? 0 : (taps_are_radiance ? 2 : 1);
     const bool lds = mode != 2 && He * We * 4 <= ENV_LDS_MAX;          // float4 per texel
@@ -1084,18 +1071,12 @@ void launch_shade_forward(hipStream_t s, int P, int K, int M, const float* base_
         if (leave_room && g_shade_row_blocks_per_cu == 0 && bpc > 3) bpc = 3;                                         \
         const int cap = shade_cus() * bpc;                                                                            \
         const int grid = want < cap ? want : cap;                                                                     \
-        if (list != nullptr) {                                                                                        \
-            /* the fixed-ray-set entry point is the only caller: training outputs, cached lookups, 16 coefficients */   \
-            if (!(N == 7 && T == 1 && M == 16))                                                                       \
-                throw std::runtime_error("shade_forward: a Gaussian list needs the fixed-ray-set configuration");     \
-            shade_forward_row_kernel<7, L, 1, true, true><<<grid, 64 * ROW_WAVES, smem, s>>>(                         \
-                n, K, M, rec, incidents, env4, He, We, tr, visibility, dirs, areas, uniform_area, taps, out, list);   \
-        } else if (M == 16)                                                                                           \
+        if (M == 16)                                                                                                  \
             shade_forward_row_kernel<N, L, T, true><<<grid, 64 * ROW_WAVES, smem, s>>>(                               \
-                n, K, M, rec, incidents, env4, He, We, tr, visibility, dirs, areas, uniform_area, taps, out, list);   \
+                n, K, M, rec, incidents, env4, He, We, tr, visibility, dirs, areas, uniform_area, taps, out);         \
         else                                                                                                          \
             shade_forward_row_kernel<N, L, T, false><<<grid, 64 * ROW_WAVES, smem, s>>>(                              \
-                n, K, M, rec, incidents, env4, He, We, tr, visibility, dirs, areas, uniform_area, taps, out, list);   \
+                n, K, M, rec, incidents, env4, He, We, tr, visibility, dirs, areas, uniform_area, taps, out);         \
     } while (0)
 #define R3DG_ROW_MODE(N, L)                                                                                           \
     do {                                                                                                              \
@@ -1107,16 +1088,13 @@ void launch_shade_forward(hipStream_t s, int P, int K, int M, const float* base_
 #undef R3DG_ROW
 }
 
-// `list` / `n_list` as in launch_shade_forward (rows of d_base / d_rough / d_view / d_inc that are not listed stay untouched;
-// d_env is accumulated into either way)
 void launch_shade_backward(hipStream_t s, int P, int K, int M, const float* base_color, const float* roughness,
                            const float* normals, const float* viewdirs, const float* incidents, const float* env,
                            int He, int We, const float* tr, const float* visibility, const float* dirs,
                            const float* areas, const float* g_pbr, const float* g_diff, float* d_base, float* d_rough,
                            float* d_view, float* d_inc, float* d_env, const uint32_t* taps, const float* block_absmax,
-                           int n_block_absmax, const int* list, int n_list)
+                           int n_block_absmax)
 {
-    if (list != nullptr && n_list <= 0) return;
     unsigned int* scratch = shade_scratch();
     // scale of the fixed-point texture accumulation: max |upstream gradient|, either handed over as block maxima by the
     // producer of g_pbr / g_diff (r3dg_stage2_unpack_gradients) or reduced here
@@ -1131,9 +1109,9 @@ void launch_shade_backward(hipStream_t s, int P, int K, int M, const float* base
         grad_absmax_kernel<<<nb < 256 ? nb : 256, 256, 0, s>>>(3 * P, g_pbr, g_diff, scratch);
     }
     const int ntex = He * We * 3;
-    const int n = list != nullptr ? n_list : P;
+    const int n = P;
     const ShadeSrc src = {base_color, roughness, normals, viewdirs, incidents, g_pbr, g_diff,
-                          reinterpret_cast<const float*>(scratch + 16), dirs, visibility, areas, list};
+                          reinterpret_cast<const float*>(scratch + 16), dirs, visibility, areas};
     // persistent blocks so the LDS-privatised env gradient is flushed once per block, not once per Gaussian
     const int grid = shade_grid(n);
     const bool lds = 3 * ntex <= ENV_LDS_MAX, vec = (K % 4) == 0 && (size_t)P * K >= 4;
@@ -1151,12 +1129,7 @@ void launch_shade_backward(hipStream_t s, int P, int K, int M, const float* base
     do {                                                                                                              \
         if (taps != nullptr) R3DG_SB3(L, V, true); else R3DG_SB3(L, V, false);                                        \
     } while (0)
-    if (list != nullptr) {
-        // (the fixed-ray-set entry points are the only callers: texture in LDS, K % 4 == 0, cached lookups)
-        if (!(lds && vec && taps != nullptr)) throw std::runtime_error("shade_backward: a Gaussian list needs the fixed-ray-set configuration");
-        shade_backward_kernel<true, true, true, true><<<grid, 64 * SHADE_WAVES, smem, s>>>(
-            n, K, M, src, env, He, We, tr, d_base, d_rough, d_view, d_inc, d_env, gmax, gmax_n, taps, (size_t)P * K);
-    } else if (lds) { if (vec) R3DG_SB(true, true); else R3DG_SB(true, false); }
+    if (lds) { if (vec) R3DG_SB(true, true); else R3DG_SB(true, false); }
     else { if (vec) R3DG_SB(false, true); else R3DG_SB(false, false); }
 #undef R3DG_SB
 #undef R3DG_SB3
@@ -1185,10 +1158,20 @@ void launch_shade_frs_classify(hipStream_t s, int P, const float* ray_normals, u
     check_launch(s, false, "frs_classify_kernel");
 }
 
+void launch_shade_frs_build_taps(hipStream_t s, int P, int K, const float* ray_normals, const float* zsamples, int He, int We,
+                                 uint32_t* taps)
+{
+    const size_t n = (size_t)P * K;
+    if (n == 0) return;
+    frs_build_taps_kernel<<<(unsigned)((n + 255) / 256), 256, 0, s>>>(P, K, ray_normals, zsamples, He, We, taps);
+    check_launch(s, false, "frs_build_taps_kernel");
+}
+
 // can the fixed-ray-set kernels take this configuration?  (everything else goes through the general kernels)
 bool shade_frs_supported(int K, int M, int He, int We)
 {
-    return M == 16 && K >= 4 && (K % 4) == 0 && (size_t)He * We * (16 + 24) <= (size_t)ENV_LDS_MAX * 4;
+    return M == 16 && K >= 4 && (K % 4) == 0 && He <= 511 && We <= 511 &&
+           (size_t)He * We * (16 + 24) <= (size_t)ENV_LDS_MAX * 4;
 }
 
 // dynamic LDS of the two kernels: the texture as float4 texels (+ its 3 x 64-bit gradient accumulators), the per-wave staging
@@ -1236,7 +1219,7 @@ static int frs_grid(int P, const void* kernel, size_t smem)
 }
 
 // every sample of the Fibonacci set carries the same area, 2 pi (fibonacci_sphere_sampling, utils/graphics_utils.py:26-37);
-// a caller that passes the per-sample array instead of the constant (uniform_area == 0) means that value
+// uniform_area == 0 means that value
 static inline float frs_area(float uniform_area) { return uniform_area > 0.f ? uniform_area : 6.283185307179586f; }
 
 // A fixed-ray-set call is three groups of launches, timed as three stages by the C ABI (capi.hip) so that the profile's
@@ -1244,7 +1227,7 @@ static inline float frs_area(float uniform_area) { return uniform_area > 0.f ? u
 //   aux     the coefficient rotation (forward: incidents -> cprime, kept for the backward; backward: dcprime -> d_inc), the
 //           max |upstream gradient| reduction when the caller has none
 //   main    the MFMA kernel for the Gaussians on the rotated path
-//   listed  the general kernels for the listed rest
+//   listed  the wave-per-Gaussian kernels for the listed rest
 void launch_shade_frs_forward_aux(hipStream_t s, int P, const float* incidents, const float* ray_normals, float* cprime)
 {
     if (P == 0) return;
@@ -1254,9 +1237,8 @@ void launch_shade_frs_forward_aux(hipStream_t s, int P, const float* incidents, 
 
 void launch_shade_frs_forward_main(hipStream_t s, int P, int K, const float* base_color, const float* roughness,
                                    const float* normals, const float* viewdirs, const float* env, int He, int We,
-                                   const float* visibility,
-                                   const float* dirs, float uniform_area, const uint32_t* taps, const float* tables,
-                                   const uint8_t* valid, const float* cprime, bool leave_room, float* out)
+                                   const float* visibility, float uniform_area, const uint32_t* taps, const float* ray_normals,
+                                   const float* tables, const uint8_t* valid, const float* cprime, bool leave_room, float* out)
 {
     if (P == 0) return;
     const size_t smem = frs_forward_lds_bytes(He, We);
@@ -1265,20 +1247,30 @@ void launch_shade_frs_forward_main(hipStream_t s, int P, int K, const float* bas
     // the longer of the two concurrent paths and every wave this kernel keeps resident slows it -- measured per CU cap: 1 -> 618-627,
     // 2 -> 598-610, 3 -> 597-607 it/s (this kernel alone 0.21 / 0.195 / 0.21 ms; a high-priority ordering stream: no effect)
     if (leave_room) grid = grid > shade_cus() ? shade_cus() : grid;
-    shade_forward_frs_kernel<<<grid, 64 * FRS_WAVES, smem, s>>>(P, K, base_color, roughness, normals, viewdirs, cprime, env,
-                                                                He, We, visibility, dirs, frs_area(uniform_area), taps, tables, valid,
-                                                                out);
+    const FrsSrc src = {base_color, roughness, normals, viewdirs, ray_normals, cprime, nullptr, nullptr, visibility, taps};
+    shade_forward_frs_kernel<<<grid, 64 * FRS_WAVES, smem, s>>>(P, K, src, env, He, We, frs_area(uniform_area), tables, valid, out);
     check_launch(s, false, "shade_forward_frs_kernel");
 }
 
-void launch_shade_frs_forward_listed(hipStream_t s, int P, int K, const float* base_color, const float* roughness,
-                                     const float* normals, const float* viewdirs, const float* incidents, const float* env, int He,
-                                     int We, const float* visibility, const float* dirs, const float* areas, float uniform_area,
-                                     const uint32_t* taps, const int* invalid_list, int n_invalid, bool leave_room, float* out)
+// grid of the listed kernels: one wave per Gaussian up to a few hundred waves, grid-stride beyond
+static int frs_listed_grid(int n_list)
 {
-    if (P == 0 || n_invalid <= 0) return;
-    launch_shade_forward(s, P, K, 16, base_color, roughness, normals, viewdirs, incidents, env, He, We, nullptr, visibility,
-                         dirs, areas, out, taps, true, uniform_area, false, leave_room, invalid_list, n_invalid);
+    const int want = (n_list + FRS_LISTED_WAVES - 1) / FRS_LISTED_WAVES;
+    const int cap = shade_cus();
+    return want < cap ? (want > 0 ? want : 1) : cap;
+}
+
+void launch_shade_frs_forward_listed(hipStream_t s, int K, const float* base_color, const float* roughness,
+                                     const float* normals, const float* viewdirs, const float* incidents, const float* env, int He,
+                                     int We, const float* visibility, const float* ray_normals, const float* zsamples,
+                                     float uniform_area, const int* invalid_list, int n_invalid, float* out)
+{
+    if (n_invalid <= 0) return;
+    const FrsSrc src = {base_color, roughness, normals, viewdirs, ray_normals, nullptr, nullptr, nullptr, visibility, nullptr};
+    const size_t smem = ((((size_t)3 * He * We + 3) & ~(size_t)3) + 64 * FRS_LISTED_WAVES) * sizeof(float);
+    shade_forward_frs_listed_kernel<<<frs_listed_grid(n_invalid), 64 * FRS_LISTED_WAVES, smem, s>>>(
+        n_invalid, invalid_list, K, src, incidents, env, He, We, zsamples, frs_area(uniform_area), out);
+    check_launch(s, false, "shade_forward_frs_listed_kernel");
 }
 
 // (before _main) -> the words the main kernel scales its fixed-point texture accumulation by
@@ -1301,31 +1293,29 @@ const unsigned int* launch_shade_frs_backward_aux(hipStream_t s, int P, const fl
 
 void launch_shade_frs_backward_main(hipStream_t s, int P, int K, const float* base_color, const float* roughness,
                                     const float* normals, const float* viewdirs, const float* env, int He, int We,
-                                    const float* visibility,
-                                    const float* dirs, float uniform_area, const uint32_t* taps, const float* tables,
-                                    const uint8_t* valid, const float* cprime, float* dcp, const float* g_pbr, const float* g_diff,
-                                    float* d_base, float* d_rough, float* d_view, float* d_env, const unsigned int* gmax, int gmax_n)
+                                    const float* visibility, float uniform_area, const uint32_t* taps, const float* ray_normals,
+                                    const float* tables, const uint8_t* valid, const float* cprime, float* dcp, const float* g_pbr,
+                                    const float* g_diff, float* d_base, float* d_rough, float* d_view, float* d_env,
+                                    const unsigned int* gmax, int gmax_n)
 {
     if (P == 0) return;
     const bool tab_lds = K <= FRS_TAB_LDS_MAX_K;
     const size_t smem = frs_backward_lds_bytes(K, He, We);
+    const FrsSrc src = {base_color, roughness, normals, viewdirs, ray_normals, cprime, g_pbr, g_diff, visibility, taps};
     if (tab_lds) {
         const int grid = frs_grid(P, (const void*)shade_backward_frs_kernel<true>, smem);
         shade_backward_frs_kernel<true><<<grid, 64 * FRS_WAVES, smem, s>>>(
-            P, K, base_color, roughness, normals, viewdirs, cprime, g_pbr, g_diff, env, He, We, visibility, dirs,
-            frs_area(uniform_area), taps, tables, valid, d_base, d_rough, d_view, dcp, d_env, gmax, gmax_n);
+            P, K, src, env, He, We, frs_area(uniform_area), tables, valid, d_base, d_rough, d_view, dcp, d_env, gmax, gmax_n);
     } else {
         const int grid = frs_grid(P, (const void*)shade_backward_frs_kernel<false>, smem);
         shade_backward_frs_kernel<false><<<grid, 64 * FRS_WAVES, smem, s>>>(
-            P, K, base_color, roughness, normals, viewdirs, cprime, g_pbr, g_diff, env, He, We, visibility, dirs,
-            frs_area(uniform_area), taps, tables, valid, d_base, d_rough, d_view, dcp, d_env, gmax, gmax_n);
+            P, K, src, env, He, We, frs_area(uniform_area), tables, valid, d_base, d_rough, d_view, dcp, d_env, gmax, gmax_n);
     }
     check_launch(s, false, "shade_backward_frs_kernel");
 }
 
-// gradient back to the unrotated coefficients.  valid == nullptr: every row of d_inc is written (garbage for Gaussians off the
-// rotated path: the general kernel overwrites their rows next, on the same stream); valid != nullptr: only the rows on the
-// rotated path are written -- the form that may run on a second stream beside the general kernel's launch on the listed rest
+// gradient back to the unrotated coefficients.  valid == nullptr: every row of d_inc is written; valid != nullptr: only the rows
+// on the rotated path are written (the listed Gaussians' rows come from their own kernel, possibly on another stream)
 void launch_shade_frs_backward_rotate(hipStream_t s, int P, const float* ray_normals, const float* dcp, float* d_inc,
                                       const uint8_t* valid)
 {
@@ -1334,17 +1324,26 @@ void launch_shade_frs_backward_rotate(hipStream_t s, int P, const float* ray_nor
     check_launch(s, false, "frs_rotate_kernel");
 }
 
-void launch_shade_frs_backward_listed(hipStream_t s, int P, int K, const float* base_color, const float* roughness,
+void launch_shade_frs_backward_listed(hipStream_t s, int K, const float* base_color, const float* roughness,
                                       const float* normals, const float* viewdirs, const float* incidents, const float* env, int He,
-                                      int We, const float* visibility, const float* dirs, const float* areas, const uint32_t* taps,
-                                      const int* invalid_list, int n_invalid, const float* g_pbr, const float* g_diff,
-                                      float* d_base, float* d_rough, float* d_view, float* d_inc, float* d_env,
-                                      const float* block_absmax, int n_block_absmax)
+                                      int We, const float* visibility, const float* ray_normals, const float* zsamples,
+                                      float uniform_area, const int* invalid_list, int n_invalid, const float* g_pbr,
+                                      const float* g_diff, float* d_base, float* d_rough, float* d_view, float* d_inc, float* d_env,
+                                      const unsigned int* gmax, int gmax_n)
 {
-    if (P == 0 || n_invalid <= 0) return;
-    launch_shade_backward(s, P, K, 16, base_color, roughness, normals, viewdirs, incidents, env, He, We, nullptr, visibility,
-                          dirs, areas, g_pbr, g_diff, d_base, d_rough, d_view, d_inc, d_env, taps, block_absmax,
-                          n_block_absmax, invalid_list, n_invalid);
+    if (n_invalid <= 0) return;
+    const FrsSrc src = {base_color, roughness, normals, viewdirs, ray_normals, nullptr, g_pbr, g_diff, visibility, nullptr};
+    const size_t smem = (3 * (((size_t)3 * He * We + 3) & ~(size_t)3) + 64 * FRS_LISTED_WAVES) * sizeof(float);
+    // (the texture gradient is flushed once per workgroup: a quarter of the forward's grid keeps that under the kernel's own time)
+    int grid = frs_listed_grid(n_invalid);
+    grid = grid > 64 ? 64 + (grid - 64) / 4 : grid;
+    if (smem > 65536)
+        R3DG_HIP(hipFuncSetAttribute((const void*)shade_backward_frs_listed_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                     (int)smem));
+    shade_backward_frs_listed_kernel<<<grid, 64 * FRS_LISTED_WAVES, smem, s>>>(
+        n_invalid, invalid_list, K, src, incidents, env, He, We, zsamples, frs_area(uniform_area), d_base, d_rough, d_view, d_inc,
+        d_env, gmax, gmax_n);
+    check_launch(s, false, "shade_backward_frs_listed_kernel");
 }
 
 void launch_shade_build_transport(hipStream_t s, int P, int K, int M, const float* normals, const float* incidents,

@@ -21,8 +21,15 @@
 // The rotation itself is done per Gaussian by two streaming kernels (coefficients there, gradient back) with the sampling
 // construction of tools/gen_sh_rotation_tables.py.  R is evaluated in fp32 exactly as the ray set was generated; where
 // cancellation makes it measurably non-orthonormal (normals within ~2.5 degrees of -z: 0.3 % of uniformly distributed
-// normals) the cached directions are not a rigid copy of the z set and the Gaussian is left to the general kernels, which
-// the launcher runs on the list of those Gaussians (same entry point, bit-for-bit the old path for them).
+// normals) the directions are not a rigid copy of the z set and the Gaussian is left to wave-per-Gaussian kernels at the end of
+// this file, which the launcher runs on the list of those Gaussians (same entry point).
+//
+// Round 4: NO per-sample direction is read any more (the [P,K,3] cache is replaced by the 12-byte ray-normal
+// snapshot).  Round 3's kernels still streamed the cached direction (12 B) and a 12-byte lookup record beside the visibility
+// (4 B): 28 B per sample, 1.85x / 1.81x of their algorithmic bytes in HBM traffic, on kernels that were latency-bound.  With
+// d_k = R z_k / |R z_k| every per-sample dot product is a product against the z table (see FrsFrame below), the half vector
+// drops out of the GGX terms, and the lookup record is 8 bytes (frs_pack_axis): 12 B per sample, ~20 VALU instructions fewer
+// per sample in the forward and ~45 in the backward.
 #pragma once
 #include "sh_rotation_tables.hpp"
 
@@ -203,36 +210,72 @@ __device__ __forceinline__ void frs_stage_texture(const float* __restrict__ env,
     }
 }
 
-// ---- per-lane sample block: 4 consecutive samples of one Gaussian ------------------------------------------------------------
+// ---- the 8-byte lookup record of a sample -------------------------------------------------------------------------------------
+// The lat-long lookup of a fixed direction is a constant between visibility updates (direct_light_map.py:70-83: texel corner +
+// two bilinear weights).  Round 3 cached it as 12 bytes (corner, fp32 weight, fp32 weight) next to the 12-byte direction; the
+// direction is gone (see the kernels) and the record is two dwords:
+//     dword 0 = (x0 + 1) << 23 | mantissa of (1 + wx1)        dword 1 = (y0 + 1) << 23 | mantissa of (1 + wy1)
+// A weight w in [0, 1) is stored as the 23 mantissa bits of 1 + w -- fixed point with 2^-23 steps, the resolution fp32 itself has
+// on [0.5, 1) -- and comes back as (0x3f800000 | bits) - 1 in two instructions; x0 + 1 in [0, We], y0 + 1 in [0, He] take the 9
+// bits above (He, We <= 511: far beyond the textures that fit LDS).
+__device__ __forceinline__ uint32_t frs_pack_axis(int corner /* >= -1 */, float w1 /* [0, 1) */)
+{
+    const float f = fminf(1.0f + w1, __uint_as_float(0x3fffffffu));                 // (1 + w rounds to 2.0 for w > 1 - 2^-24)
+    return ((uint32_t)(corner + 1) << 23) | (__float_as_uint(f) & 0x7fffffu);
+}
+__device__ __forceinline__ PackedTap frs_unpack_tap(uint32_t lo, uint32_t hi)
+{
+    PackedTap t;
+    t.xy = (lo >> 23) | ((hi >> 23) << 16);
+    t.wx1 = __uint_as_float(0x3f800000u | (lo & 0x7fffffu)) - 1.0f;
+    t.wy1 = __uint_as_float(0x3f800000u | (hi & 0x7fffffu)) - 1.0f;
+    return t;
+}
+
+// the records of all P x K samples from the ray normals alone: d_k = normalize(R(n) z_k) evaluated as sampling.py /
+// graphics_utils.py:9-37 evaluate it (matrix product, then x / max(|x|, 1e-12)), then the lookup of make_tap
+__global__ void __launch_bounds__(256)
+frs_build_taps_kernel(int P, int K, const float* __restrict__ ray_normals, const float* __restrict__ zsamples /*[K,3]*/, int He,
+                      int We, uint32_t* __restrict__ taps /*[P,K,2]*/)
+{
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (size_t)P * K) return;
+    const int g = (int)(i / (size_t)K), k = (int)(i - (size_t)g * K);
+    float R[9];
+    frs_rotation(ray_normals[3 * (size_t)g], ray_normals[3 * (size_t)g + 1], ray_normals[3 * (size_t)g + 2], R);
+    const float zx = zsamples[3 * k], zy = zsamples[3 * k + 1], zz = zsamples[3 * k + 2];
+    float dx = R[0] * zx + R[1] * zy + R[2] * zz, dy = R[3] * zx + R[4] * zy + R[5] * zz, dz = R[6] * zx + R[7] * zy + R[8] * zz;
+    const float len = fmaxf(sqrtf(dx * dx + dy * dy + dz * dz), 1e-12f);
+    dx /= len; dy /= len; dz /= len;
+    const PackedTap t = make_tap(dx, dy, dz, nullptr, He, We);
+    taps[2 * i] = frs_pack_axis((int)(t.xy & 0xffffu) - 1, t.wx1);
+    taps[2 * i + 1] = frs_pack_axis((int)(t.xy >> 16) - 1, t.wy1);
+}
+
+// ---- per-lane sample block: 4 consecutive samples of one Gaussian: 16 bytes of visibility + 32 bytes of lookup records ---------
 struct FrsBlock {
-    float4 d0, d1, d2;      // 4 directions (12 floats)
     float4 vis;
-    uint4 t0, t1, t2;       // 4 lookup records (12 dwords)
+    uint4 t0, t1;           // 4 records (8 dwords)
 };
 
-__device__ __forceinline__ FrsBlock frs_load_block(size_t row /* g * K */, int k0, int K, const float* __restrict__ dirs,
-                                                   const float* __restrict__ visibility, const uint32_t* __restrict__ taps)
+__device__ __forceinline__ FrsBlock frs_load_block(size_t row /* g * K */, int k0, int K, const float* __restrict__ visibility,
+                                                   const uint32_t* __restrict__ taps)
 {
     FrsBlock b;
     const int kc = k0 + 4 <= K ? k0 : K - 4;                         // (K % 4 == 0, K >= 4): clamped loads stay inside the row
     const size_t o = row + (size_t)kc;
-    const float4* dp = reinterpret_cast<const float4*>(dirs + 3 * o);
-    b.d0 = dp[0]; b.d1 = dp[1]; b.d2 = dp[2];
     b.vis = *reinterpret_cast<const float4*>(visibility + o);
-    const uint4* tp = reinterpret_cast<const uint4*>(taps + 3 * o);
-    b.t0 = tp[0]; b.t1 = tp[1]; b.t2 = tp[2];
+    const uint4* tp = reinterpret_cast<const uint4*>(taps + 2 * o);
+    b.t0 = tp[0]; b.t1 = tp[1];
     return b;
 }
 
-__device__ __forceinline__ void frs_sample_of(const FrsBlock& b, int v, float& dx, float& dy, float& dz, float& vis,
-                                              PackedTap& t)
+__device__ __forceinline__ void frs_sample_of(const FrsBlock& b, int v, float& vis, PackedTap& t)
 {
-    const float d[12] = {b.d0.x, b.d0.y, b.d0.z, b.d0.w, b.d1.x, b.d1.y, b.d1.z, b.d1.w, b.d2.x, b.d2.y, b.d2.z, b.d2.w};
-    const uint32_t u[12] = {b.t0.x, b.t0.y, b.t0.z, b.t0.w, b.t1.x, b.t1.y, b.t1.z, b.t1.w, b.t2.x, b.t2.y, b.t2.z, b.t2.w};
+    const uint32_t u[8] = {b.t0.x, b.t0.y, b.t0.z, b.t0.w, b.t1.x, b.t1.y, b.t1.z, b.t1.w};
     const float vs[4] = {b.vis.x, b.vis.y, b.vis.z, b.vis.w};
-    dx = d[3 * v]; dy = d[3 * v + 1]; dz = d[3 * v + 2];
     vis = vs[v];
-    t.xy = u[3 * v]; t.wx1 = __uint_as_float(u[3 * v + 1]); t.wy1 = __uint_as_float(u[3 * v + 2]);
+    t = frs_unpack_tap(u[2 * v], u[2 * v + 1]);
 }
 
 __device__ __forceinline__ float frs_sum4(float x)       // sum over the 4 lanes of a Gaussian: lanes l, l^16, l^32, l^48
@@ -243,88 +286,144 @@ __device__ __forceinline__ float frs_sum4(float x)       // sum over the 4 lanes
 }
 
 // ---- the NEXT group's per-Gaussian data, staged per wave by LDS-DMA -----------------------------------------------------------
-// A group of 16 Gaussians is only K / 16 sample blocks long (4 at K = 64), and its per-Gaussian data -- the material record and
-// the lane's 12 rotated coefficients -- sit in front of every sample of it: loaded at the top of the group, one memory latency
-// per group is exposed on a dependent chain.  Instead the wave issues them for the NEXT group during the LAST sample block of
-// the current one, straight into LDS (global_load_lds, no registers: the backward has none to spare), together with the next
-// group's first sample block (into the `nxt` registers the block loop already owns): the top of a group is one
+// A group of 16 Gaussians is only K / 16 sample blocks long (4 at K = 64), and its per-Gaussian data -- the material record, the
+// ray normal and the lane's 12 rotated coefficients -- sit in front of every sample of it: loaded at the top of the group, one
+// memory latency per group is exposed on a dependent chain.  Instead the wave issues them for the NEXT group during the LAST sample
+// block of the current one, straight into LDS (global_load_lds, no registers: the backward has none to spare), together with the
+// next group's first sample block (into the `nxt` registers the block loop already owns): the top of a group is one
 // s_waitcnt + a handful of LDS reads.  Issued there and not earlier on purpose: vmcnt completes in order and the compiler,
 // which does not see the DMA, waits with vmcnt(0) for its own sample-block loads at the top of every block -- anything issued
 // before that wait has to land by then.
-constexpr int FRS_ST_CP = 0, FRS_ST_DIRS = 768, FRS_ST_TAPS = 1536, FRS_ST_VIS = 2304, FRS_ST_BASE = 2560, FRS_ST_NRM = 2624,
-              FRS_ST_VIEW = 2688, FRS_ST_RGH = 2752, FRS_ST_GP = 2816, FRS_ST_GD = 2880;
-constexpr int FRS_ST_FWD = 2816, FRS_ST_BWD = 2944;          // floats per wave (11 / 11.5 KB)
+constexpr int FRS_ST_CP = 0, FRS_ST_TAPS = 768, FRS_ST_VIS = 1280, FRS_ST_BASE = 1536, FRS_ST_NRM = 1600, FRS_ST_VIEW = 1664,
+              FRS_ST_RGH = 1728, FRS_ST_RNRM = 1792, FRS_ST_GP = 1856, FRS_ST_GD = 1920;
+constexpr int FRS_ST_FWD = 1856, FRS_ST_BWD = 1984;          // floats per wave (7.25 / 7.75 KB)
+
+struct FrsSrc {              // the per-Gaussian and per-sample arrays of one call
+    const float *base_color, *roughness, *normals, *viewdirs, *ray_normals, *cprime, *g_pbr, *g_diff, *visibility;
+    const uint32_t* taps;
+};
 
 template <bool BWD>
 __device__ __forceinline__ void frs_stage_group(unsigned int sb /* LDS byte address of the wave's area, SGPR */, int grp, int P,
-                                                int lane, const float* __restrict__ cprime,
-                                                const float* __restrict__ base_color, const float* __restrict__ normals,
-                                                const float* __restrict__ viewdirs, const float* __restrict__ roughness,
-                                                const float* __restrict__ g_pbr, const float* __restrict__ g_diff,
-                                                int K, const float* __restrict__ dirs, const float* __restrict__ visibility,
-                                                const uint32_t* __restrict__ taps)
+                                                int K, int lane, const FrsSrc& p)
 {
     const int g0 = grp * FRS_G;
-    // the group's FIRST sample block (16 samples of 16 rows): 48 direction floats, 48 lookup words, 16 visibilities per row, same
-    // [j][row][16] image as the coefficients.  K < 16: the chunks past the row's end belong to the next row (masked by k < K in the
-    // kernels); the very last rows of the arrays are clamped to stay inside them
+    // the group's FIRST sample block (16 samples of 16 rows): 32 lookup dwords and 16 visibilities per row, same [j][row][16] image
+    // as the coefficients.  K < 16: the chunks past the row's end belong to the next row (masked by k < K in the kernels); the very
+    // last rows of the arrays are clamped to stay inside them
     {
         const size_t total = (size_t)P * (size_t)K;
         const size_t r0 = (size_t)min(g0 + (lane >> 2), P - 1) * (size_t)K;
 #pragma unroll
-        for (int j = 0; j < 3; j++) {
-            const size_t o = min(3 * r0 + 16 * j + 4 * (lane & 3), 3 * total - 4);
-            lds_dma_at<16>(dirs + o, sb + 4u * (FRS_ST_DIRS + 256 * j));
-            lds_dma_at<16>(reinterpret_cast<const float*>(taps) + o, sb + 4u * (FRS_ST_TAPS + 256 * j));
+        for (int j = 0; j < 2; j++) {
+            const size_t o = min(2 * r0 + 16 * j + 4 * (lane & 3), 2 * total - 4);
+            lds_dma_at<16>(reinterpret_cast<const float*>(p.taps) + o, sb + 4u * (FRS_ST_TAPS + 256 * j));
         }
-        lds_dma_at<16>(visibility + min(r0 + 4 * (lane & 3), total - 4), sb + 4u * FRS_ST_VIS);
+        lds_dma_at<16>(p.visibility + min(r0 + 4 * (lane & 3), total - 4), sb + 4u * FRS_ST_VIS);
     }
     // 16 rows of 48 coefficients: DMA j moves floats [16 j, 16 j + 16) of every row, lane = (row, 16-byte chunk), so the LDS image
     // is [j][row][16 floats]: coefficient float f of row t sits at (f >> 4) * 256 + t * 16 + (f & 15)
-    const float* cp = cprime + (size_t)min(g0 + (lane >> 2), P - 1) * 48 + 4 * (lane & 3);
+    const float* cp = p.cprime + (size_t)min(g0 + (lane >> 2), P - 1) * 48 + 4 * (lane & 3);
 #pragma unroll
     for (int j = 0; j < 3; j++) lds_dma_at<16>(cp + 16 * j, sb + 4u * (FRS_ST_CP + 256 * j));
     const int l3 = lane < 48 ? lane : 47, t3 = l3 / 3, c3 = l3 - 3 * t3;
     const size_t o3 = 3 * (size_t)min(g0 + t3, P - 1) + c3;
-    lds_dma_at<4>(base_color + o3, sb + 4u * FRS_ST_BASE);
-    lds_dma_at<4>(normals + o3, sb + 4u * FRS_ST_NRM);
-    lds_dma_at<4>(viewdirs + o3, sb + 4u * FRS_ST_VIEW);
-    lds_dma_at<4>(roughness + min(g0 + (lane & 15), P - 1), sb + 4u * FRS_ST_RGH);
+    lds_dma_at<4>(p.base_color + o3, sb + 4u * FRS_ST_BASE);
+    lds_dma_at<4>(p.normals + o3, sb + 4u * FRS_ST_NRM);
+    lds_dma_at<4>(p.viewdirs + o3, sb + 4u * FRS_ST_VIEW);
+    lds_dma_at<4>(p.ray_normals + o3, sb + 4u * FRS_ST_RNRM);
+    lds_dma_at<4>(p.roughness + min(g0 + (lane & 15), P - 1), sb + 4u * FRS_ST_RGH);
     if (BWD) {
-        lds_dma_at<4>(g_pbr + o3, sb + 4u * FRS_ST_GP);
-        lds_dma_at<4>(g_diff + o3, sb + 4u * FRS_ST_GD);
+        lds_dma_at<4>(p.g_pbr + o3, sb + 4u * FRS_ST_GP);
+        lds_dma_at<4>(p.g_diff + o3, sb + 4u * FRS_ST_GD);
     }
 }
 
-// the staged first block as the register image frs_load_block gives (lane (gl, q): samples 4 q .. 4 q + 3 = floats 12 q .. of row gl)
+// the staged first block as the register image frs_load_block gives (lane (gl, q): samples 4 q .. 4 q + 3 = dwords 8 q .. of row gl)
 __device__ __forceinline__ FrsBlock frs_staged_block(const float* st, int gl, int q, int K)
 {
     FrsBlock b;
     const int kq = 4 * q + 4 <= K ? q : (K >> 2) - 1;                 // K < 16: the same clamp as frs_load_block
-    float4 d[3];
-    uint4 t[3];
+    uint4 t[2];
 #pragma unroll
-    for (int i = 0; i < 3; i++) {
-        const int c = 3 * kq + i, o = (c >> 2) * 256 + gl * 16 + (c & 3) * 4;
-        d[i] = *reinterpret_cast<const float4*>(st + FRS_ST_DIRS + o);
+    for (int i = 0; i < 2; i++) {
+        const int c = 2 * kq + i, o = (c >> 2) * 256 + gl * 16 + (c & 3) * 4;
         t[i] = *reinterpret_cast<const uint4*>(st + FRS_ST_TAPS + o);
     }
-    b.d0 = d[0]; b.d1 = d[1]; b.d2 = d[2];
-    b.t0 = t[0]; b.t1 = t[1]; b.t2 = t[2];
+    b.t0 = t[0]; b.t1 = t[1];
     b.vis = *reinterpret_cast<const float4*>(st + FRS_ST_VIS + gl * 16 + 4 * kq);
     return b;
+}
+
+// ---- a Gaussian in its ray frame ------------------------------------------------------------------------------------------------
+// The sample directions are d_k = R z_k / |R z_k| with ONE z set for everybody, so every dot product of d_k with a per-Gaussian
+// vector w is (R^T w) . z_k -- a [K x 3] x [3 x 16 Gaussians] product against a constant matrix, and the three direction rows of
+// the Y_i(z_k) table (Y_1 = -C1 y, Y_2 = C1 z, Y_3 = -C1 x: slot 0 of a block) already ARE that matrix: one more
+// v_mfma_f32_16x16x4_f32 per vector and block against the B operand (0, -w'_y / C1, w'_z / C1, -w'_x / C1)[q].  Two vectors are
+// needed: the shading normal n (n . d_k; N . L is the same number times sign / |n|) and the unit view vector V (L . V).  The
+// half vector never appears: with unit L and V, |(L + V) / 2|^2 = (1 + L.V) / 2, N.H = (N.L + N.V) / (2 |u|), V.H = |u|.
+// R(n) is evaluated in fp32 and is orthonormal only to FRS_MAX_DEFECT on this path; that matters for ONE thing, the length of
+// R z_k (a 1e-5 error of N.H moves the GGX lobe of a smooth Gaussian by per cents): 1 / |R z_k| = 1 - q_k / 2 to 1e-9 with
+// q_k = z_k^T (R^T R - I) z_k, a quadratic form in z_k and therefore a combination of Y_0 and Y_4..8 -- two more products
+// (slots 1 and 2) with the constant term as the accumulator's start value.
+struct FrsFrame {
+    float bn, bv;            // B operands of the two dot products (this lane's q)
+    float bq1, bq2, q0;      // B operands / start value of the length correction
+};
+
+__device__ __forceinline__ void frs_frame(FrsFrame& f, const float (&R)[9], const float nx, const float ny, const float nz,
+                                          const float Vx, const float Vy, const float Vz, int q)
+{
+    constexpr float C1 = 0.4886025119029199f, K4 = 1.0925484305920792f, K6 = 0.31539156525252005f, K8 = 0.5462742152960396f;
+    constexpr float C0 = 0.28209479177387814f;
+    (void)C0;
+    // R^T w: columns of R
+    const float npx = R[0] * nx + R[3] * ny + R[6] * nz, npy = R[1] * nx + R[4] * ny + R[7] * nz,
+                npz = R[2] * nx + R[5] * ny + R[8] * nz;
+    const float vpx = R[0] * Vx + R[3] * Vy + R[6] * Vz, vpy = R[1] * Vx + R[4] * Vy + R[7] * Vz,
+                vpz = R[2] * Vx + R[5] * Vy + R[8] * Vz;
+    f.bn = q == 1 ? -npy / C1 : (q == 2 ? npz / C1 : (q == 3 ? -npx / C1 : 0.f));
+    f.bv = q == 1 ? -vpy / C1 : (q == 2 ? vpz / C1 : (q == 3 ? -vpx / C1 : 0.f));
+    // E = R^T R - I
+    const float e00 = R[0] * R[0] + R[3] * R[3] + R[6] * R[6] - 1.f, e11 = R[1] * R[1] + R[4] * R[4] + R[7] * R[7] - 1.f,
+                e22 = R[2] * R[2] + R[5] * R[5] + R[8] * R[8] - 1.f;
+    const float e01 = R[0] * R[1] + R[3] * R[4] + R[6] * R[7], e02 = R[0] * R[2] + R[3] * R[5] + R[6] * R[8],
+                e12 = R[1] * R[2] + R[4] * R[5] + R[7] * R[8];
+    // z^T E z = tr E / 3 + [Y4 2 e01 - Y5 2 e12 - Y7 2 e02] / K4 + Y6 (2 e22 - e00 - e11) / (6 K6) + Y8 (e00 - e11) / (2 K8)
+    f.bq1 = q == 0 ? 2.f * e01 / K4 : (q == 1 ? -2.f * e12 / K4 : (q == 2 ? (2.f * e22 - e00 - e11) / (6.f * K6) : -2.f * e02 / K4));
+    f.bq2 = q == 0 ? (e00 - e11) / (2.f * K8) : 0.f;
+    f.q0 = (e00 + e11 + e22) / 3.f;
+}
+
+// the per-sample geometry of a block: n . d, L . V for the lane's four samples from the block's first three table words
+struct FrsGeom {
+    f32x4 dn, lov, sk;       // n . d_k, L_k . V, 1 / |R z_k|
+};
+__device__ __forceinline__ FrsGeom frs_block_geometry(const FrsFrame& f, float a0, float a1, float a2)
+{
+    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+    FrsGeom o;
+    o.dn = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, f.bn, zero, 0, 0, 0);
+    o.lov = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, f.bv, zero, 0, 0, 0);
+    f32x4 qf = {f.q0, f.q0, f.q0, f.q0};
+    qf = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, f.bq1, qf, 0, 0, 0);
+    qf = __builtin_amdgcn_mfma_f32_16x16x4f32(a2, f.bq2, qf, 0, 0, 0);
+#pragma unroll
+    for (int v = 0; v < 4; v++) {
+        o.sk[v] = 1.f - 0.5f * qf[v];
+        o.dn[v] *= o.sk[v];
+        o.lov[v] *= o.sk[v];
+    }
+    return o;
 }
 
 // =====================================================================================================================
 // Forward (training outputs: pbr, diffuse_light, mean visibility -- columns 0..5 and 18 of the 19; neilf.py:120-122)
 // =====================================================================================================================
 __global__ void __launch_bounds__(64 * FRS_WAVES, 3)
-shade_forward_frs_kernel(int P, int K, const float* __restrict__ base_color, const float* __restrict__ roughness,
-                         const float* __restrict__ normals, const float* __restrict__ viewdirs,
-                         const float* __restrict__ cprime, const float* __restrict__ env /* [He*We][3] */, int He, int We,
-                         const float* __restrict__ visibility, const float* __restrict__ dirs, float uniform_area,
-                         const uint32_t* __restrict__ taps, const float* __restrict__ tables,
-                         const uint8_t* __restrict__ valid, float* __restrict__ out)
+shade_forward_frs_kernel(int P, int K, FrsSrc src, const float* __restrict__ env /* [He*We][3] */, int He, int We,
+                         float uniform_area, const float* __restrict__ tables, const uint8_t* __restrict__ valid,
+                         float* __restrict__ out)
 {
     extern __shared__ __attribute__((aligned(16))) float s_mem[];
     float4* s_env4 = reinterpret_cast<float4*>(s_mem);
@@ -346,8 +445,7 @@ shade_forward_frs_kernel(int P, int K, const float* __restrict__ base_color, con
     uint8_t nvalid = 0;
     if (grp < ngroups) {
         nvalid = valid[min(grp * FRS_G + gl, P - 1)];
-        frs_stage_group<false>(st_addr, grp, P, lane, cprime, base_color, normals, viewdirs, roughness, nullptr, nullptr, K, dirs,
-                               visibility, taps);
+        frs_stage_group<false>(st_addr, grp, P, K, lane, src);
     }
     for (; grp < ngroups; grp += gstride) {
         const int g = grp * FRS_G + gl;
@@ -363,6 +461,7 @@ shade_forward_frs_kernel(int P, int K, const float* __restrict__ base_color, con
             u[55 + c] = st[FRS_ST_VIEW + 3 * gl + c];
         }
         u[51] = st[FRS_ST_RGH + gl];
+        const float rn0 = st[FRS_ST_RNRM + 3 * gl], rn1 = st[FRS_ST_RNRM + 3 * gl + 1], rn2 = st[FRS_ST_RNRM + 3 * gl + 2];
         // B operand of the local-light product: rotated coefficients 4 s + q of the lane's Gaussian
         float bc[4][3];
 #pragma unroll
@@ -375,6 +474,12 @@ shade_forward_frs_kernel(int P, int K, const float* __restrict__ base_color, con
         FrsBlock nxt = frs_staged_block(st, gl, q, K);
         GaussFwd G;
         gauss_setup(G, u);
+        FrsFrame F;
+        {
+            float R[9];
+            frs_rotation(rn0, rn1, rn2, R);
+            frs_frame(F, R, G.n[0], G.n[1], G.n[2], G.V[0], G.V[1], G.V[2], q);
+        }
         const float fd[3] = {G.base[0] / kPi, G.base[1] / kPi, G.base[2] / kPi};
         const float nom1 = G.NoV * (1.f - G.kk) + G.kk;
         float acc[7] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
@@ -392,7 +497,7 @@ shade_forward_frs_kernel(int P, int K, const float* __restrict__ base_color, con
             for (int s = 0; s < 4; s++) a[s] = tb[64 * s];
             const bool last = b + 1 == nblk;
             if (!last) {
-                nxt = frs_load_block(row, 16 * (b + 1) + 4 * q, K, dirs, visibility, taps);
+                nxt = frs_load_block(row, 16 * (b + 1) + 4 * q, K, src.visibility, src.taps);
             } else {
                 // (the empty asm keeps the compiler from hoisting the next group's address computations out of the block loop,
                 // where they would be live -- 2 VGPRs each -- through every block of the group)
@@ -406,31 +511,28 @@ shade_forward_frs_kernel(int P, int K, const float* __restrict__ base_color, con
             for (int s = 0; s < 4; s++)
 #pragma unroll
                 for (int c = 0; c < 3; c++) l[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s], bc[s][c], l[c], 0, 0, 0);
+            const FrsGeom geo = frs_block_geometry(F, a[0], a[1], a[2]);
             // the next group's per-Gaussian data: behind the last compiler-visible wait of the group (see frs_stage_group)
-            if (last)
-                frs_stage_group<false>(st_addr, ngrp_l, P, lane, cprime, base_color, normals, viewdirs, roughness, nullptr, nullptr, K,
-                                       dirs, visibility, taps);
+            if (last) frs_stage_group<false>(st_addr, ngrp_l, P, K, lane, src);
 #pragma unroll
             for (int v = 0; v < 4; v++) {
                 const int k = 16 * b + 4 * q + v;
                 const bool ok = live_g && k < K;
-                float dx, dy, dz, vis;
+                float vis;
                 PackedTap t;
-                frs_sample_of(cur, v, dx, dy, dz, vis, t);
+                frs_sample_of(cur, v, vis, t);
                 float e[3], w4[4];
                 int tex[4];
                 env_fetch(t, s_env4, He, We, e, tex, w4);
                 const float lv = ok ? 1.f : 0.f;
-                const float ndi = fmaxf(G.n[0] * dx + G.n[1] * dy + G.n[2] * dz, 0.f);
-                const float area_ndi = uniform_area * ndi * lv;
-                const float dinv = __builtin_amdgcn_rsqf(fmaxf(dx * dx + dy * dy + dz * dz, 1e-24f));
-                const float Lx = dx * dinv, Ly = dy * dinv, Lz = dz * dinv;
-                const float ux = (Lx + G.V[0]) / 2.0f, uy = (Ly + G.V[1]) / 2.0f, uz = (Lz + G.V[2]) / 2.0f;
-                const float uinv = __builtin_amdgcn_rsqf(fmaxf(ux * ux + uy * uy + uz * uz, 1e-24f));
-                const float Hx = ux * uinv, Hy = uy * uinv, Hz = uz * uinv;
-                const float NoL = fminf(fmaxf(G.N[0] * Lx + G.N[1] * Ly + G.N[2] * Lz, 1e-6f), 1.f);
-                const float NoH = fminf(fmaxf(G.N[0] * Hx + G.N[1] * Hy + G.N[2] * Hz, 1e-6f), 1.f);
-                const float VoH = fminf(fmaxf(G.V[0] * Hx + G.V[1] * Hy + G.V[2] * Hz, 1e-6f), 1.f);
+                const float dn = geo.dn[v], lov = geo.lov[v];
+                const float area_ndi = uniform_area * fmaxf(dn, 0.f) * lv;
+                const float rawNoL = dn * G.nscale;
+                const float uu = fmaxf(0.5f * lov + 0.5f, 1e-24f);                   // |(L + V) / 2|^2
+                const float uinv = __builtin_amdgcn_rsqf(uu);
+                const float NoL = fminf(fmaxf(rawNoL, 1e-6f), 1.f);
+                const float NoH = fminf(fmaxf((rawNoL + G.rawNoV) * (0.5f * uinv), 1e-6f), 1.f);
+                const float VoH = fminf(fmaxf(uu * uinv, 1e-6f), 1.f);
                 const float p2 = exp2f((-5.55473f * VoH - 6.98316f) * VoH);
                 const float frac = (0.04f + 0.96f * p2) * G.a2;
                 const float nom0 = NoH * NoH * (G.a2 - 1.f) + 1.f;
@@ -461,20 +563,19 @@ shade_forward_frs_kernel(int P, int K, const float* __restrict__ base_color, con
 // =====================================================================================================================
 // Backward: gradients of <pbr, g_pbr> + <diffuse_light, g_diff> w.r.t. base colour, roughness, view direction, the ROTATED
 // incident-light coefficients (dcp [P,16,3]; frs_rotate_kernel<true> takes them back) and the environment texture.
-// Per-sample arithmetic = the general kernels' (neilf.py:339-407 differentiated); the texture gradient goes through the same
-// 64-bit fixed-point LDS accumulators.
+// Per-sample arithmetic = the general kernels' (neilf.py:339-407 differentiated) in the ray frame; the view gradient is
+//     dL/dV = sum_k gLoV_k L_k + (sum_k gNoV_k) N,      gLoV = dVoH / (4 |u|) - dNoH N.H / (4 |u|^2),   gNoV = dNoV + dNoH / (2 |u|)
+// (projected onto the tangent plane of V afterwards, as normalize() does): sum_k gLoV_k s_k z_k is one more product against the
+// table -- rows 1..3 of the gradient layout -- and is rotated to world space once per Gaussian.  The texture gradient goes
+// through the same 64-bit fixed-point LDS accumulators as in the general backward.
 // =====================================================================================================================
 template <bool TAB_LDS>
 __global__ void __launch_bounds__(64 * FRS_WAVES, 2)
-shade_backward_frs_kernel(int P, int K, const float* __restrict__ base_color, const float* __restrict__ roughness,
-                          const float* __restrict__ normals, const float* __restrict__ viewdirs,
-                          const float* __restrict__ cprime, const float* __restrict__ g_pbr,
-                          const float* __restrict__ g_diff, const float* __restrict__ env /* [He*We][3] */, int He, int We,
-                          const float* __restrict__ visibility, const float* __restrict__ dirs, float uniform_area,
-                          const uint32_t* __restrict__ taps, const float* __restrict__ tables,
-                          const uint8_t* __restrict__ valid, float* __restrict__ d_base, float* __restrict__ d_rough,
-                          float* __restrict__ d_view, float* __restrict__ dcp, float* __restrict__ d_env,
-                          const unsigned int* __restrict__ gmax_bits, int gmax_n)
+shade_backward_frs_kernel(int P, int K, FrsSrc src, const float* __restrict__ env /* [He*We][3] */, int He, int We,
+                          float uniform_area, const float* __restrict__ tables, const uint8_t* __restrict__ valid,
+                          float* __restrict__ d_base, float* __restrict__ d_rough, float* __restrict__ d_view,
+                          float* __restrict__ dcp, float* __restrict__ d_env, const unsigned int* __restrict__ gmax_bits,
+                          int gmax_n)
 {
     extern __shared__ __attribute__((aligned(16))) float s_mem[];
     const int ntexel = He * We;
@@ -504,8 +605,7 @@ shade_backward_frs_kernel(int P, int K, const float* __restrict__ base_color, co
     uint8_t nvalid = 0;
     if (grp < ngroups) {
         nvalid = valid[min(grp * FRS_G + gl, P - 1)];
-        frs_stage_group<true>(st_addr, grp, P, lane, cprime, base_color, normals, viewdirs, roughness, g_pbr, g_diff, K, dirs,
-                              visibility, taps);
+        frs_stage_group<true>(st_addr, grp, P, K, lane, src);
     }
     for (; grp < ngroups; grp += gstride) {
         const int g = grp * FRS_G + gl;
@@ -520,6 +620,7 @@ shade_backward_frs_kernel(int P, int K, const float* __restrict__ base_color, co
             u[55 + c] = st[FRS_ST_VIEW + 3 * gl + c];
         }
         u[51] = st[FRS_ST_RGH + gl];
+        const float rn0 = st[FRS_ST_RNRM + 3 * gl], rn1 = st[FRS_ST_RNRM + 3 * gl + 1], rn2 = st[FRS_ST_RNRM + 3 * gl + 2];
         const float gp[3] = {st[FRS_ST_GP + 3 * gl] * invK, st[FRS_ST_GP + 3 * gl + 1] * invK, st[FRS_ST_GP + 3 * gl + 2] * invK};
         const float gd[3] = {st[FRS_ST_GD + 3 * gl] * invK, st[FRS_ST_GD + 3 * gl + 1] * invK, st[FRS_ST_GD + 3 * gl + 2] * invK};
         float bc[4][3];
@@ -533,10 +634,17 @@ shade_backward_frs_kernel(int P, int K, const float* __restrict__ base_color, co
         FrsBlock nxt = frs_staged_block(st, gl, q, K);
         GaussFwd G;
         gauss_setup(G, u);
+        FrsFrame F;
+        {
+            float R[9];
+            frs_rotation(rn0, rn1, rn2, R);
+            frs_frame(F, R, G.n[0], G.n[1], G.n[2], G.V[0], G.V[1], G.V[2], q);
+        }
         const float fd[3] = {G.base[0] / kPi, G.base[1] / kPi, G.base[2] / kPi};
         const float nom1 = G.NoV * (1.f - G.kk) + G.kk;
         f32x4 dcq[3] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};   // dL/dc'[4 q + v'][c]
-        float accb[7] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};     // albedo 3, roughness, view direction 3
+        f32x4 dvq = {0.f, 0.f, 0.f, 0.f};          // q == 0: (., -C1 sum y g, C1 sum z g, -C1 sum x g), g = gLoV_k s_k
+        float accb[5] = {0.f, 0.f, 0.f, 0.f, 0.f};               // albedo 3, roughness, sum_k gNoV_k
         const size_t row = (size_t)gc * (size_t)K;
         int ngrp_l = min(grp + gstride, ngroups - 1);                            // (past the end: a harmless reload of the last group)
         int ngc_l = min(ngrp_l * FRS_G + gl, P - 1);
@@ -555,41 +663,40 @@ shade_backward_frs_kernel(int P, int K, const float* __restrict__ base_color, co
             }
             const bool last = b + 1 == nblk;
             if (!last) {
-                nxt = frs_load_block(row, 16 * (b + 1) + 4 * q, K, dirs, visibility, taps);
+                nxt = frs_load_block(row, 16 * (b + 1) + 4 * q, K, src.visibility, src.taps);
             } else {
                 asm volatile("" : "+v"(ngrp_l), "+v"(ngc_l));         // (not hoisted out of the block loop: see the forward)
                 nvalid = valid[ngc_l];
             }
             __builtin_amdgcn_sched_barrier(0);
+            if (TAB_LDS) {
+#pragma unroll
+                for (int s = 0; s < 4; s++) a[s] = tb[64 * s];
+            }
             f32x4 l[3] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
 #pragma unroll
-            for (int s = 0; s < 4; s++) {
-                const float av = TAB_LDS ? tb[64 * s] : a[s];
+            for (int s = 0; s < 4; s++)
 #pragma unroll
-                for (int c = 0; c < 3; c++) l[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bc[s][c], l[c], 0, 0, 0);
-            }
-            if (last)
-                frs_stage_group<true>(st_addr, ngrp_l, P, lane, cprime, base_color, normals, viewdirs, roughness, g_pbr, g_diff, K, dirs,
-                                      visibility, taps);
+                for (int c = 0; c < 3; c++) l[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s], bc[s][c], l[c], 0, 0, 0);
+            const FrsGeom geo = frs_block_geometry(F, a[0], a[1], a[2]);
+            if (last) frs_stage_group<true>(st_addr, ngrp_l, P, K, lane, src);
 #pragma unroll
             for (int v = 0; v < 4; v++) {
                 const int k = 16 * b + 4 * q + v;
                 const bool ok = live_g && k < K;
-                float dx, dy, dz, vis;
+                float vis;
                 PackedTap t;
-                frs_sample_of(cur, v, dx, dy, dz, vis, t);
+                frs_sample_of(cur, v, vis, t);
                 float e[3], w4[4];
                 int tex[4];
                 env_fetch(t, s_env4, He, We, e, tex, w4);
-                const float ndi = fmaxf(G.n[0] * dx + G.n[1] * dy + G.n[2] * dz, 0.f);
-                const float area_ndi = ok ? uniform_area * ndi : 0.f;
-                const float dinv = __builtin_amdgcn_rsqf(fmaxf(dx * dx + dy * dy + dz * dz, 1e-24f));
-                const float Lx = dx * dinv, Ly = dy * dinv, Lz = dz * dinv;
-                const float ux = (Lx + G.V[0]) / 2.0f, uy = (Ly + G.V[1]) / 2.0f, uz = (Lz + G.V[2]) / 2.0f;
-                const float uinv = __builtin_amdgcn_rsqf(fmaxf(ux * ux + uy * uy + uz * uz, 1e-24f));
-                const float Hx = ux * uinv, Hy = uy * uinv, Hz = uz * uinv;
-                const float NoL = fminf(fmaxf(G.N[0] * Lx + G.N[1] * Ly + G.N[2] * Lz, 1e-6f), 1.f);
-                const float rawNoH = G.N[0] * Hx + G.N[1] * Hy + G.N[2] * Hz, rawVoH = G.V[0] * Hx + G.V[1] * Hy + G.V[2] * Hz;
+                const float dn = geo.dn[v], lov = geo.lov[v];
+                const float area_ndi = ok ? uniform_area * fmaxf(dn, 0.f) : 0.f;
+                const float rawNoL = dn * G.nscale;
+                const float uu = fmaxf(0.5f * lov + 0.5f, 1e-24f);
+                const float uinv = __builtin_amdgcn_rsqf(uu);
+                const float NoL = fminf(fmaxf(rawNoL, 1e-6f), 1.f);
+                const float rawNoH = (rawNoL + G.rawNoV) * (0.5f * uinv), rawVoH = uu * uinv;
                 const float NoH = fminf(fmaxf(rawNoH, 1e-6f), 1.f), VoH = fminf(fmaxf(rawVoH, 1e-6f), 1.f);
                 const float p2 = exp2f((-5.55473f * VoH - 6.98316f) * VoH);
                 const float frac0 = 0.04f + 0.96f * p2;
@@ -656,31 +763,32 @@ shade_backward_frs_kernel(int P, int K, const float* __restrict__ base_color, co
                 if (!(rawNoH >= 1e-6f && rawNoH <= 1.f)) dNoH = 0.f;
                 if (!(rawVoH >= 1e-6f && rawVoH <= 1.f)) dVoH = 0.f;
                 if (!(G.rawNoV >= 1e-6f && G.rawNoV <= 1.f)) dNoV = 0.f;
-                const float dHx = dNoH * G.N[0] + dVoH * G.V[0], dHy = dNoH * G.N[1] + dVoH * G.V[1],
-                            dHz = dNoH * G.N[2] + dVoH * G.V[2];
-                float dVx = dVoH * Hx + dNoV * G.N[0], dVy = dVoH * Hy + dNoV * G.N[1], dVz = dVoH * Hz + dNoV * G.N[2];
-                const float hd = Hx * dHx + Hy * dHy + Hz * dHz;
-                dVx += 0.5f * (dHx - Hx * hd) * uinv;
-                dVy += 0.5f * (dHy - Hy * hd) * uinv;
-                dVz += 0.5f * (dHz - Hz * hd) * uinv;
-                const float vd = G.V[0] * dVx + G.V[1] * dVy + G.V[2] * dVz;
-                accb[4] += (dVx - G.V[0] * vd) / G.vlen;
-                accb[5] += (dVy - G.V[1] * vd) / G.vlen;
-                accb[6] += (dVz - G.V[2] * vd) / G.vlen;
-                // gradient product: dc'[i][c] += Yz[k][i] dl[c] over the 4 samples (one per q) of this v
+                const float q4 = 0.25f * uinv;
+                const float gLoV = dVoH * q4 - dNoH * rawNoH * (q4 * uinv);
+                accb[4] += dNoV + dNoH * (0.5f * uinv);
+                // gradient products: dc'[i][c] += Yz[k][i] dl[c]; view: L_k = s_k R z_k, so the weight of z_k is gLoV_k s_k
                 const float a2v = TAB_LDS ? tb[64 * (4 + v)] : a2[v];
 #pragma unroll
                 for (int c = 0; c < 3; c++) dcq[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(a2v, dl[c], dcq[c], 0, 0, 0);
+                dvq = __builtin_amdgcn_mfma_f32_16x16x4f32(a2v, gLoV * geo.sk[v], dvq, 0, 0, 0);
             }
         }
 #pragma unroll
-        for (int i = 0; i < 7; i++) accb[i] = frs_sum4(accb[i]);
+        for (int i = 0; i < 5; i++) accb[i] = frs_sum4(accb[i]);
         if (live_g) {
             if (q == 0) {
+                constexpr float C1 = 0.4886025119029199f;
+                float R[9];
+                frs_rotation(rn0, rn1, rn2, R);
+                const float cx = -dvq[3] / C1, cy = -dvq[1] / C1, cz = dvq[2] / C1;            // sum_k gLoV_k s_k z_k (ray frame)
+                float dV[3];
+#pragma unroll
+                for (int m = 0; m < 3; m++) dV[m] = R[3 * m] * cx + R[3 * m + 1] * cy + R[3 * m + 2] * cz + accb[4] * G.N[m];
+                const float vd = G.V[0] * dV[0] + G.V[1] * dV[1] + G.V[2] * dV[2];
 #pragma unroll
                 for (int c = 0; c < 3; c++) {
                     d_base[3 * (size_t)g + c] = accb[c];
-                    d_view[3 * (size_t)g + c] = accb[4 + c];
+                    d_view[3 * (size_t)g + c] = (dV[c] - G.V[c] * vd) / G.vlen;
                 }
                 d_rough[g] = accb[3];
             }
@@ -695,6 +803,214 @@ shade_backward_frs_kernel(int P, int K, const float* __restrict__ base_color, co
         __syncthreads();
         const float inv = 1.0f / fx_scale;
         for (int i = threadIdx.x; i < 3 * ntexel; i += blockDim.x) {
+            const long long v64 = s_denv[i];
+            if (v64 != 0) atomicAdd(&d_env[i], (float)((double)v64 * (double)inv));
+        }
+    }
+}
+
+// =====================================================================================================================
+// The Gaussians OFF the rotated path (R(n) not orthonormal to FRS_MAX_DEFECT: ~0.3 % of them): one wave per Gaussian, lane =
+// sample, the general per-sample arithmetic of shading.hip (SH basis evaluated at the true direction) on directions that are
+// REGENERATED from the ray normal and the z set exactly as the cache was generated -- nothing per sample is read but the
+// visibility.  Rounds 3's launch of the general persistent kernels on a list cost 25 + 46..87 us per iteration for 772 Gaussians
+// (prologues, DMA pipeline and flush of a grid sized for 300k) and 0.88 ms at 2M Gaussians; these are plain grid-stride
+// kernels over a few hundred waves.
+// =====================================================================================================================
+constexpr int FRS_LISTED_WAVES = 4;
+
+// record u[64] of one listed Gaussian -> LDS (lane l loads element l: 0..47 incidents, 48..50 albedo, 51 roughness, 52..54 normal,
+// 55..57 view direction, 58..60 ray normal, BWD: 61..63 unused; the upstream gradients are loaded by the caller)
+__device__ __forceinline__ float frs_listed_record(int lane, int g, const FrsSrc& p, const float* __restrict__ incidents)
+{
+    const float* q = incidents + (size_t)g * 48 + lane;
+    if (lane >= 48) q = p.base_color + 3 * (size_t)g + (lane - 48);
+    if (lane == 51) q = p.roughness + g;
+    if (lane >= 52) q = p.normals + 3 * (size_t)g + (lane - 52);
+    if (lane >= 55) q = p.viewdirs + 3 * (size_t)g + (lane - 55);
+    if (lane >= 58) q = p.ray_normals + 3 * (size_t)g + (lane - 58);
+    return lane < 61 ? *q : 0.f;
+}
+
+// sample k of the ray set of R: normalize(R z_k), as frs_build_taps_kernel
+__device__ __forceinline__ void frs_listed_direction(const float (&R)[9], const float* __restrict__ zsamples, int k, float& dx,
+                                                     float& dy, float& dz)
+{
+    const float zx = zsamples[3 * k], zy = zsamples[3 * k + 1], zz = zsamples[3 * k + 2];
+    dx = R[0] * zx + R[1] * zy + R[2] * zz; dy = R[3] * zx + R[4] * zy + R[5] * zz; dz = R[6] * zx + R[7] * zy + R[8] * zz;
+    const float len = fmaxf(sqrtf(dx * dx + dy * dy + dz * dz), 1e-12f);
+    dx /= len; dy /= len; dz /= len;
+}
+
+__global__ void __launch_bounds__(64 * FRS_LISTED_WAVES)
+shade_forward_frs_listed_kernel(int n_list, const int* __restrict__ list, int K, FrsSrc src,
+                                const float* __restrict__ incidents, const float* __restrict__ env, int He, int We,
+                                const float* __restrict__ zsamples, float uniform_area, float* __restrict__ out)
+{
+    extern __shared__ __attribute__((aligned(16))) float s_mem[];
+    float* s_env = s_mem;                                                // [ntexel][3]
+    const int ntex = 3 * He * We;
+    for (int i = threadIdx.x; i < ntex; i += blockDim.x) s_env[i] = env[i];
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float* u = s_mem + ((ntex + 3) & ~3) + wave * 64;
+    const float invK = 1.0f / (float)K;
+    for (int i = blockIdx.x * FRS_LISTED_WAVES + wave; i < n_list; i += gridDim.x * FRS_LISTED_WAVES) {
+        const int g = __builtin_amdgcn_readfirstlane(list[i]);
+        u[lane] = frs_listed_record(lane, g, src, incidents);            // same wave, in-order LDS: no barrier needed
+        GaussFwd G;
+        gauss_setup(G, u);
+        float R[9];
+        frs_rotation(u[58], u[59], u[60], R);
+        float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        for (int kb = 0; kb < K; kb += 64) {
+            const int k = kb + lane, kc = min(k, K - 1);
+            float dx, dy, dz;
+            frs_listed_direction(R, zsamples, kc, dx, dy, dz);
+            const float vis = src.visibility[(size_t)g * K + kc];
+            SampleFwd s;
+            shade_sample<true>(s, G, u, 16, dx, dy, dz, vis, uniform_area, nullptr, s_env, nullptr, He, We);
+            if (k < K) {
+#pragma unroll
+                for (int c = 0; c < 3; c++) {
+                    v[c] += (G.base[c] / kPi + s.spec) * s.transport[c];
+                    v[3 + c] += s.transport[c];
+                }
+                v[6] += vis;
+            }
+        }
+        const float r = transpose_reduce<8, true>(v);
+        const int ch = transposed_channel<8>(lane);
+        if (transposed_owner<8>(lane) && ch < 7) out[(size_t)g * SHADE_NOUT + (ch < 6 ? ch : 18)] = r * invK;
+    }
+}
+
+// d_base / d_rough / d_view / d_inc rows of the listed Gaussians are written, d_env is accumulated (through 64-bit fixed-point
+// LDS accumulators per workgroup, flushed once: the grid is small)
+__global__ void __launch_bounds__(64 * FRS_LISTED_WAVES)
+shade_backward_frs_listed_kernel(int n_list, const int* __restrict__ list, int K, FrsSrc src,
+                                 const float* __restrict__ incidents, const float* __restrict__ env, int He, int We,
+                                 const float* __restrict__ zsamples, float uniform_area, float* __restrict__ d_base,
+                                 float* __restrict__ d_rough, float* __restrict__ d_view, float* __restrict__ d_inc,
+                                 float* __restrict__ d_env, const unsigned int* __restrict__ gmax_bits, int gmax_n)
+{
+    extern __shared__ __attribute__((aligned(16))) float s_mem[];
+    const int ntex = 3 * He * We, ntex4 = (ntex + 3) & ~3;
+    float* s_env = s_mem;
+    long long* s_denv = reinterpret_cast<long long*>(s_mem + ntex4);
+    const unsigned int gmax_word = wave_gmax_bits(gmax_bits, gmax_n);
+    const float gmax = __uint_as_float(gmax_word);
+    const bool fixed = gmax_usable(gmax_word);
+    const float fx_scale = fixed ? 34359738368.0f / gmax : 0.f;          // 2^35 / max|g|
+    const float fx_clamp = gmax * 8192.0f;
+    for (int i = threadIdx.x; i < ntex; i += blockDim.x) {
+        s_env[i] = env[i];
+        s_denv[i] = 0;
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float* u = s_mem + 3 * ntex4 + wave * 64;
+    const float invK = 1.0f / (float)K;
+    for (int i = blockIdx.x * FRS_LISTED_WAVES + wave; i < n_list; i += gridDim.x * FRS_LISTED_WAVES) {
+        const int g = __builtin_amdgcn_readfirstlane(list[i]);
+        u[lane] = frs_listed_record(lane, g, src, incidents);
+        GaussFwd G;
+        gauss_setup(G, u);
+        float R[9];
+        frs_rotation(u[58], u[59], u[60], R);
+        float gp[3], gd[3];
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+            gp[c] = src.g_pbr[3 * (size_t)g + c] * invK;
+            gd[c] = src.g_diff[3 * (size_t)g + c] * invK;
+        }
+        // 48 coefficient gradients (f = i * 3 + c), albedo 3, roughness, view 3 -- 55 of the 64 channels of one transposing reduction
+        float acc[64];
+#pragma unroll
+        for (int f = 0; f < 64; f++) acc[f] = 0.f;
+        for (int kb = 0; kb < K; kb += 64) {
+            const int k = kb + lane, kc = min(k, K - 1);
+            float dx, dy, dz;
+            frs_listed_direction(R, zsamples, kc, dx, dy, dz);
+            const float vis = src.visibility[(size_t)g * K + kc];
+            SampleFwd s;
+            shade_sample<true>(s, G, u, 16, dx, dy, dz, vis, k < K ? uniform_area : 0.f, nullptr, s_env, nullptr, He, We);
+            float gspec = 0.f, dlin[3], dl[3];
+#pragma unroll
+            for (int c = 0; c < 3; c++) {
+                const float dT = gp[c] * (G.base[c] / kPi + s.spec) + gd[c];
+                gspec += gp[c] * s.transport[c];
+                acc[48 + c] += gp[c] * s.transport[c] / kPi;
+                dlin[c] = dT * s.area_ndi;
+                dl[c] = s.shsum[c] >= 0.f ? dlin[c] : 0.f;
+            }
+            if (s.vis != 0.f && s.area_ndi != 0.f) {
+                const float ev[3] = {dlin[0] * s.vis, dlin[1] * s.vis, dlin[2] * s.vis};
+                const double scale_d = (double)fx_scale;
+#pragma unroll
+                for (int tt = 0; tt < 4; tt++) {
+                    if (s.taps.idx[tt] < 0) continue;
+#pragma unroll
+                    for (int c = 0; c < 3; c++) {
+                        const float val = ev[c] * s.taps.w[tt];
+                        if (fixed) {
+                            const float cl = __builtin_amdgcn_fmed3f(val, -fx_clamp, fx_clamp);
+                            const double dsum = __builtin_fma((double)cl, scale_d, 6755399441055744.0);
+                            const unsigned long long bits = (unsigned long long)__double_as_longlong(dsum) - 0x4338000000000000ull;
+                            atomicAdd(reinterpret_cast<unsigned long long*>(&s_denv[3 * s.taps.idx[tt] + c]), bits);
+                        } else {
+                            atomicAdd(&d_env[3 * (size_t)s.taps.idx[tt] + c], val);
+                        }
+                    }
+                }
+            }
+            const float frac = s.frac0 * G.a2;
+            const bool nom_free = s.nomr >= 1e-6f && s.nomr <= 4.f * kPi;
+            const float nom = fminf(fmaxf(s.nomr, 1e-6f), 4.f * kPi);
+            const float dfrac = gspec / nom;
+            const float dnom = nom_free ? -gspec * frac / (nom * nom) : 0.f;
+            float da2 = dfrac * s.frac0;
+            const float dFMi = dfrac * G.a2 * 0.96f * 0.6931471805599453f * s.p2;
+            float dVoH = dFMi * (-2.f * 5.55473f * s.VoH - 6.98316f);
+            const float c4 = 4.f * kPi;
+            const float dnom0 = dnom * c4 * 2.f * s.nom0 * s.nom1 * s.nom2;
+            const float dnom1 = dnom * c4 * s.nom0 * s.nom0 * s.nom2;
+            const float dnom2 = dnom * c4 * s.nom0 * s.nom0 * s.nom1;
+            float dNoH = dnom0 * 2.f * s.NoH * (G.a2 - 1.f);
+            da2 += dnom0 * s.NoH * s.NoH;
+            float dNoV = dnom1 * (1.f - G.kk);
+            const float dkk = dnom1 * (1.f - G.NoV) + dnom2 * (1.f - s.NoL);
+            const float da = dkk / 8.f + da2 * 2.f * G.a;
+            acc[51] += dkk * 2.f / 8.f + da * 2.f * G.r;
+            if (!(s.rawNoH >= 1e-6f && s.rawNoH <= 1.f)) dNoH = 0.f;
+            if (!(s.rawVoH >= 1e-6f && s.rawVoH <= 1.f)) dVoH = 0.f;
+            if (!(G.rawNoV >= 1e-6f && G.rawNoV <= 1.f)) dNoV = 0.f;
+            float dH[3], dV[3];
+#pragma unroll
+            for (int c = 0; c < 3; c++) {
+                dH[c] = dNoH * G.N[c] + dVoH * G.V[c];
+                dV[c] = dVoH * s.Hh[c] + dNoV * G.N[c];
+            }
+            const float hd = s.Hh[0] * dH[0] + s.Hh[1] * dH[1] + s.Hh[2] * dH[2];
+#pragma unroll
+            for (int c = 0; c < 3; c++) dV[c] += 0.5f * (dH[c] - s.Hh[c] * hd) / s.ulen;
+            const float vd = G.V[0] * dV[0] + G.V[1] * dV[1] + G.V[2] * dV[2];
+#pragma unroll
+            for (int c = 0; c < 3; c++) acc[52 + c] += (dV[c] - G.V[c] * vd) / G.vlen;
+#pragma unroll
+            for (int f = 0; f < 48; f++) acc[f] += dl[f % 3] * s.Y[f / 3];
+        }
+        const float r = transpose_reduce<64, true>(acc);
+        const int ch = transposed_channel<64>(lane);
+        if (ch < 48) d_inc[(size_t)g * 48 + ch] = r;
+        else if (ch < 51) d_base[3 * (size_t)g + (ch - 48)] = r;
+        else if (ch == 51) d_rough[g] = r;
+        else if (ch < 55) d_view[3 * (size_t)g + (ch - 52)] = r;
+    }
+    if (fixed) {
+        __syncthreads();
+        const float inv = 1.0f / fx_scale;
+        for (int i = threadIdx.x; i < ntex; i += blockDim.x) {
             const long long v64 = s_denv[i];
             if (v64 != 0) atomicAdd(&d_env[i], (float)((double)v64 * (double)inv));
         }

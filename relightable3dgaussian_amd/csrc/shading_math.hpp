@@ -39,6 +39,7 @@ __device__ __forceinline__ void sh_basis16(float x, float y, float z, int M, flo
 
 struct GaussFwd {            // wave-uniform per-Gaussian quantities
     float base[3], r, n[3], V[3], vlen, N[3], NoV, rawNoV, a, a2, kk;
+    float nscale;            // N = n * nscale (sign(N0 . V) / |n|)
     float v_raw[3];
 };
 
@@ -64,6 +65,7 @@ __device__ __forceinline__ void gauss_setup(GaussFwd& G, const float* u)
     const float sgn = d0 > 0.f ? 1.f : (d0 < 0.f ? -1.f : 0.f);
 #pragma unroll
     for (int c = 0; c < 3; c++) G.N[c] = N0[c] * sgn;
+    G.nscale = sgn / nlen;
     G.rawNoV = G.N[0] * G.V[0] + G.N[1] * G.V[1] + G.N[2] * G.V[2];
     G.NoV = fminf(fmaxf(G.rawNoV, 1e-6f), 1.f);
     G.a = G.r * G.r;

@@ -396,25 +396,31 @@ class FusedStage2Step(_BoundedForward):
         _lib.check(st, "stage2_activate")
 
     def taps(self, He, We):
-        """Lat-long lookup cache of the incident directions for a He x We environment texture (shading_ops.build_taps):
-        rebuilt only when the direction cache is replaced (a visibility update) or the texture size changes."""
+        """The per-sample lookup cache of the general shading kernels for a He x We environment texture
+        (shading_ops.build_taps: 12 bytes per sample, read beside the [P,K,3] directions) -- or None when the direction cache IS
+        the Fibonacci set of the snapshot normals and the fixed-ray-set kernels run (`self._frs`: they read neither; their own
+        8-byte records come from the ray normals, shading_ops.FixedRaySet.taps).  Decided once per visibility update / texture
+        size."""
         # keyed by the direction tensor ITSELF (held in _taps_src for as long as its taps are: a replaced cache can then never
         # come back at the address of the old one and pass for it) + its version counter (in-place updates)
         src = self.incident_dirs
         key = (src._version, tuple(src.shape), He, We)
-        if self._taps is None or getattr(self, "_taps_src", None) is not src or self._taps_key != key:
-            self._taps = shading_ops.build_taps(src, He, We)
+        if getattr(self, "_taps_src", None) is not src or self._taps_key != key:
             self._taps_key, self._taps_src = key, src
             # fibonacci_sphere_sampling gives every sample the area 2 pi: then the area cache need not be read at all
             lo, hi = float(self.incident_areas.min()), float(self.incident_areas.max())
             self._uniform_area = lo if lo == hi else None
-            # fixed-ray-set kernels (SH contractions on the matrix cores, csrc/shading_frs.hpp) when the cache IS the
-            # Fibonacci set of the snapshot normals -- checked here, once per visibility update -- and fits their limits;
-            # otherwise (caches handed in from elsewhere, other K / texture sizes, R3DG_SHADE_FRS=0) the general kernels
-            self._frs = None
+            # fixed-ray-set kernels (csrc/shading_frs.hpp) when the cache IS the Fibonacci set of the snapshot normals --
+            # checked here, once per visibility update -- and fits their limits; otherwise (caches handed in from elsewhere,
+            # other K / texture sizes, R3DG_SHADE_FRS=0) the general kernels
+            self._frs, self._taps = None, None
             if (os.environ.get("R3DG_SHADE_FRS", "1") != "0" and self._uniform_area is not None and
                     shading_ops.FixedRaySet.supported(self.K, self.M, He, We)):
                 self._frs = shading_ops.FixedRaySet.try_build(getattr(self, "_ray_normals", None), src)
+            if self._frs is None:
+                self._taps = shading_ops.build_taps(src, He, We)
+            else:
+                self._frs.taps(He, We)
         return self._taps
 
     def _aux_stream(self):
@@ -496,8 +502,7 @@ class FusedStage2Step(_BoundedForward):
             if self._frs is not None:
                 rotated = rotated_for is self._frs            # (taps() may have rebuilt the ray set: then it rotates itself)
                 self._frs.forward(self.a_base, self.a_rough, self.a_normal, self.a_viewdirs, self.incidents, env_c,
-                                  self.visibility, self.incident_dirs, self.incident_areas, taps, self.shade_out,
-                                  uniform_area=self._uniform_area,
+                                  self.visibility, self.shade_out, uniform_area=self._uniform_area,
                                   # (one workgroup per CU beside the instance ordering, which is the longer path -- unless the
                                   # deferred incident-light update of a data-parallel run sits in front of this kernel: then this
                                   # path is the longer one and takes every CU it can get: 558 -> 568 it/s on one rank)
@@ -641,7 +646,7 @@ class FusedStage2Step(_BoundedForward):
             if self._frs is not None:
                 d_base, d_rough, d_view, _d_inc, d_env = self._frs.backward(
                     self.a_base, self.a_rough, self.a_normal, self.a_viewdirs, self.incidents, env_c, self.visibility,
-                    self.incident_dirs, self.incident_areas, taps, self.d_pbr, self.d_diffuse,
+                    self.d_pbr, self.d_diffuse,
                     uniform_area=self._uniform_area, out_incidents=self.grads["incidents"], out_env=self._d_env,
                     block_absmax=self._absmax,
                     # whole iterations: the rotation back of the coefficient gradient goes to the stream that already carries the

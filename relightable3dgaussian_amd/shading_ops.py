@@ -114,9 +114,10 @@ def shade_backward(base_color, roughness, normals, viewdirs, incidents, env, vis
 
 class FixedRaySet:
     """State of the fixed-ray-set shading kernels (include/r3dg_hip.h "fixed ray set", csrc/shading_frs.hpp) for ONE
-    visibility update: the normals the cached directions were generated from, the Y_i(z_k) tables, which Gaussians take
-    the rotated path, scratch for the rotated coefficients.  `forward` / `backward` compute what shade_forward(...,
-    train_outputs=True) / shade_backward(...) compute for the same caches -- for directions that ARE
+    visibility update: the normals the cached directions were generated from (12 bytes per Gaussian -- the kernels read NO
+    per-sample direction), the z set and its Y_i(z_k) tables, which Gaussians take the rotated path, the 8-byte lookup
+    records of the current texture size, scratch for the rotated coefficients.  `forward` / `backward` compute what
+    shade_forward(..., train_outputs=True) / shade_backward(...) compute for caches that ARE
     sampling.fibonacci_sphere_sampling(ray_normals, K); `try_build` checks that and returns None otherwise."""
 
     def __init__(self, ray_normals, K):
@@ -125,18 +126,19 @@ class FixedRaySet:
         self.ray_normals = _c(ray_normals).clone()
         self.P, self.K = self.ray_normals.shape[0], int(K)
         dev = self.ray_normals.device
-        z = sampling.fibonacci_z_samples(self.K, dev)[0].t().contiguous()                        # [K,3]
+        self.zsamples = sampling.fibonacci_z_samples(self.K, dev)[0].t().contiguous()            # [K,3]
         self.tables = torch.empty(int(L.r3dg_shade_frs_tables_bytes(self.K)) // 4, dtype=torch.float32, device=dev)
         self.valid = torch.zeros(max(self.P, 1), dtype=torch.uint8, device=dev)
         with torch.cuda.device(dev):
-            _lib.check(L.r3dg_shade_frs_build_tables(_lib.current_stream(), self.K, z.data_ptr(), self.tables.data_ptr()),
-                       "shade_frs_build_tables")
+            _lib.check(L.r3dg_shade_frs_build_tables(_lib.current_stream(), self.K, self.zsamples.data_ptr(),
+                                                     self.tables.data_ptr()), "shade_frs_build_tables")
             _lib.check(L.r3dg_shade_frs_classify(_lib.current_stream(), self.P, self.ray_normals.data_ptr(),
                                                  self.valid.data_ptr()), "shade_frs_classify")
         self.invalid_list = torch.nonzero(self.valid[:self.P] == 0).to(torch.int32).reshape(-1).contiguous()
         self.n_invalid = int(self.invalid_list.numel())                   # (one read-back per visibility update)
         self.cprime = torch.empty(self.P, 48, dtype=torch.float32, device=dev)
         self.dcprime = torch.empty(self.P, 48, dtype=torch.float32, device=dev)
+        self._taps, self._taps_size = None, None
 
     @staticmethod
     def supported(K, M, He, We):
@@ -158,19 +160,27 @@ class FixedRaySet:
             return None
         return cls(ray_normals, K)
 
-    def _common(self, base_color, roughness, normals, viewdirs, incidents, env, visibility, incident_dirs, incident_areas,
-                uniform_area, taps):
-        t = [_c(x) for x in (base_color, roughness, normals, viewdirs, incidents, env, visibility, incident_dirs)]
-        if incidents.shape[1] != 16 or incident_dirs.shape[:2] != (self.P, self.K):
-            raise RuntimeError("FixedRaySet: needs [P,16,3] incident-light coefficients and the [P,K,3] caches it was built for")
-        if taps is None or taps.dtype != torch.int32 or taps.numel() != 3 * self.P * self.K or not taps.is_contiguous():
-            raise RuntimeError("FixedRaySet: taps must be build_taps(incident_dirs, He, We) (lookup records)")
-        areas = None if uniform_area is not None else _c(incident_areas)
+    def taps(self, He, We):
+        """The 8-byte lat-long lookup records [P,K,2] (int32) of this ray set for a He x We texture
+        (r3dg_shade_frs_build_taps: regenerated from the ray normals, no direction array is read); kept until the size changes."""
+        if self._taps is None or self._taps_size != (int(He), int(We)):
+            taps = torch.empty((self.P, self.K, 2), dtype=torch.int32, device=self.ray_normals.device)
+            with torch.cuda.device(taps.device):
+                _lib.check(_lib.lib().r3dg_shade_frs_build_taps(
+                    _lib.current_stream(), self.P, self.K, self.ray_normals.data_ptr(), self.zsamples.data_ptr(), int(He), int(We),
+                    taps.data_ptr()), "shade_frs_build_taps")
+            self._taps, self._taps_size = taps, (int(He), int(We))
+        return self._taps
+
+    def _common(self, base_color, roughness, normals, viewdirs, incidents, env, visibility, uniform_area):
+        t = [_c(x) for x in (base_color, roughness, normals, viewdirs, incidents, env, visibility)]
+        if tuple(incidents.shape) != (self.P, 16, 3) or visibility.numel() != self.P * self.K:
+            raise RuntimeError("FixedRaySet: needs [P,16,3] incident-light coefficients and the [P,K] visibility it was built for")
         He, We = env.shape[-3], env.shape[-2]
-        head = [self.P, self.K] + [x.data_ptr() for x in t[:6]] + [He, We, t[6].data_ptr(), t[7].data_ptr(),
-                                                                   areas.data_ptr() if areas is not None else None,
-                                                                   float(uniform_area or 0.0), taps.data_ptr(),
-                                                                   self.ray_normals.data_ptr(), self.tables.data_ptr(),
+        taps = self.taps(He, We)
+        head = [self.P, self.K] + [x.data_ptr() for x in t[:6]] + [He, We, t[6].data_ptr(), float(uniform_area or 0.0),
+                                                                   taps.data_ptr(), self.ray_normals.data_ptr(),
+                                                                   self.zsamples.data_ptr(), self.tables.data_ptr(),
                                                                    self.valid.data_ptr(),
                                                                    self.invalid_list.data_ptr() if self.n_invalid else None,
                                                                    self.n_invalid]
@@ -187,13 +197,13 @@ class FixedRaySet:
                                                   self.cprime.data_ptr())
         _lib.check(st, "shade_frs_rotate")
 
-    def forward(self, base_color, roughness, normals, viewdirs, incidents, env, visibility, incident_dirs, incident_areas,
-                taps, out, uniform_area=None, leave_room=False, listed_stream=None, rotated=False):
+    def forward(self, base_color, roughness, normals, viewdirs, incidents, env, visibility, out, uniform_area=None,
+                leave_room=False, listed_stream=None, rotated=False):
         """Writes columns 0..5 and 18 of out [P,19] (pbr, diffuse_light, mean visibility); keeps the rotated coefficients
-        for `backward`.  `listed_stream` (a torch.cuda.Stream): the general kernel on the Gaussians off the rotated path runs there,
-        beside the main kernel; the caller waits for that stream before reading `out`."""
-        head, _keep = self._common(base_color, roughness, normals, viewdirs, incidents, env, visibility, incident_dirs,
-                                   incident_areas, uniform_area, taps)
+        for `backward`.  `uniform_area`: the area of every sample (None = 2 pi, what fibonacci_sphere_sampling assigns).
+        `listed_stream` (a torch.cuda.Stream): the kernel on the Gaussians off the rotated path runs there, beside the main
+        kernel; the caller waits for that stream before reading `out`."""
+        head, _keep = self._common(base_color, roughness, normals, viewdirs, incidents, env, visibility, uniform_area)
         with torch.cuda.device(base_color.device):
             st = _lib.lib().r3dg_shade_frs_forward(_lib.current_stream(), *head, self.cprime.data_ptr(),
                                                    1 | (4 if leave_room else 0) | (8 if rotated else 0), out.data_ptr(),
@@ -201,18 +211,13 @@ class FixedRaySet:
         _lib.check(st, "shade_frs_forward")
         return out
 
-    def backward(self, base_color, roughness, normals, viewdirs, incidents, env, visibility, incident_dirs, incident_areas,
-                 taps, dL_dpbr, dL_ddiffuse_light, uniform_area=None, out_incidents=None, out_env=None, block_absmax=None,
-                 rotate_stream=None):
+    def backward(self, base_color, roughness, normals, viewdirs, incidents, env, visibility, dL_dpbr, dL_ddiffuse_light,
+                 uniform_area=None, out_incidents=None, out_env=None, block_absmax=None, rotate_stream=None):
         """-> (dL_dbase_color, dL_droughness, dL_dviewdirs, dL_dincidents, dL_denv) as shade_backward; `forward` must have run
         on the same parameters (it left the rotated coefficients).  `rotate_stream` (a torch.cuda.Stream): the rotation of the
         coefficient gradient back to dL_dincidents runs there, beside whatever the caller queues next on the current stream; the
         caller waits for that stream before reading dL_dincidents."""
-        head, _keep = self._common(base_color, roughness, normals, viewdirs, incidents, env, visibility, incident_dirs,
-                                   incident_areas, uniform_area, taps)
-        if uniform_area is not None and self.n_invalid:
-            # the general kernel that takes the Gaussians off the rotated path reads per-sample areas in its backward
-            head[12] = _c(incident_areas).data_ptr()
+        head, _keep = self._common(base_color, roughness, normals, viewdirs, incidents, env, visibility, uniform_area)
         dev = base_color.device
         P = self.P
         d_base = torch.empty((P, 3), dtype=torch.float32, device=dev)

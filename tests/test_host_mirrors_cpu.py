@@ -712,6 +712,9 @@ def test_fused_stage2_iteration_spreads_the_fixed_ray_set_path_over_three_stream
     class FakeRaySet:
         n_invalid = 2
 
+        def taps(self, He, We):
+            events.append(("frs.taps", (He, We)))
+
         def rotate(self, incidents):
             events.append(("frs.rotate", ()))
 
@@ -852,6 +855,9 @@ def test_fused_stage2_data_parallel_iteration_issues_its_buckets_from_the_stream
 
     class FakeRaySet:
         n_invalid = 1
+
+        def taps(self, He, We):
+            pass
 
         def rotate(self, incidents):
             events.append(("frs.rotate", tuple(depth)))

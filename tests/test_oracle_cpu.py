@@ -126,6 +126,28 @@ def test_oracle_shading_matches_reference_rendering_equation():
         _ok("d_" + k, leaves[k].grad, t["d_" + k], 1e-4, 1e-6)
 
 
+def test_oracle_shading_matches_reference_on_the_fixed_ray_set_fixture():
+    """tests/golden/shading_reference_frs.npz (make_frs_golden.py): the reference's rendering_equation on an UNPERTURBED Fibonacci
+    ray set, shading normal != ray normal, ray normals next to -z, smooth Gaussians -- the fixture the fixed-ray-set kernels are
+    pinned to on the GPU; here: the oracle reproduces it, and its ray set is the product's (sampling.py) ray set."""
+    from oracle import shading
+    from relightable3dgaussian_amd import sampling
+    gd = _gold("shading_reference_frs.npz")
+    t = {k: torch.from_numpy(v) for k, v in gd.items()}
+    dirs, areas = sampling.fibonacci_sphere_sampling(t["ray_normals"], t["incident_dirs"].shape[1])
+    assert float((dirs - t["incident_dirs"]).abs().max()) < 2e-6 and torch.equal(areas, t["incident_areas"])
+    leaves = {k: t[k].clone().requires_grad_(True) for k in ("base_color", "roughness", "viewdirs", "incidents", "env_raw")}
+    env = torch.nn.functional.softplus(leaves["env_raw"])[0]
+    out = shading.rendering_equation(leaves["base_color"], leaves["roughness"], t["normals"], leaves["viewdirs"],
+                                     leaves["incidents"], env, t["visibility"], t["incident_dirs"], t["incident_areas"])
+    # (fp32 vs fp32 with smooth Gaussians: the GGX denominator is the ill-conditioned term, see tests/test_shading_gpu.py)
+    _ok("pbr", out["pbr"], t["pbr"], 2e-4, 1e-6)
+    _ok("diffuse_light", out["diffuse_light"], t["diffuse_light"], 2e-5, 1e-6)
+    ((out["pbr"] * t["g_pbr"]).sum() + (out["diffuse_light"] * t["g_diffuse_light"]).sum()).backward()
+    for k in ("base_color", "roughness", "viewdirs", "incidents", "env_raw"):
+        _ok("d_" + k, leaves[k].grad, t["d_" + k], 1e-3, 1e-6)
+
+
 def test_oracle_env_lookup_matches_reference_envlight():
     from oracle import shading
     gd = _gold("envlight_reference.npz")

@@ -216,45 +216,137 @@ def _frs_inputs(P, K, He, seed):
     return inp
 
 
+def _frs_args(inp):
+    return (inp["base_color"], inp["roughness"], inp["normals"], inp["viewdirs"], inp["incidents"], inp["env"],
+            inp["visibility"])
+
+
 @pytest.mark.parametrize("P,K,He", [(2500, 64, 16), (1000, 384, 16), (333, 100, 16), (50, 8, 8), (17, 32, 16), (4097, 16, 4)])
 def test_fixed_ray_set_kernels_equal_the_general_kernels(P, K, He):
-    """shading_ops.FixedRaySet (csrc/shading_frs.hpp: rotated SH coefficients, both SH contractions on the matrix cores,
-    4 lanes per Gaussian) vs the general kernels on the same caches: the training outputs of the forward and all five
-    gradients of the backward.  P not a multiple of 16, K not a multiple of 16 or 64, Gaussians off the rotated path."""
+    """shading_ops.FixedRaySet (csrc/shading_frs.hpp: rotated SH coefficients, every per-sample product against the z table on
+    the matrix cores, 4 lanes per Gaussian, NO direction stream) vs the general kernels on the cached directions: the training
+    outputs of the forward and all five gradients of the backward.  P not a multiple of 16, K not a multiple of 16 or 64,
+    Gaussians off the rotated path (wave-per-Gaussian kernels that regenerate their directions).
+    A cross-check of two fp32 evaluations with different operation orders -- the parity claim of the fixed-ray-set kernels is
+    test_fixed_ray_set_kernels_match_oracle (float64) and ..._match_reference_golden; the bounds here are the sum of the two
+    sides' bounds against the oracle on the ill-conditioned GGX terms (pbr 2 x 5e-4; roughness / view gradient: observed up to
+    5e-3 of the largest gradient on single Gaussians with roughness ~0.1, both sides within 2e-3..3e-3 of float64)."""
     from relightable3dgaussian_amd import shading_ops as so
     inp = _frs_inputs(P, K, He, seed=7 * P + K)
     assert so.FixedRaySet.supported(K, 16, He, 2 * He)
     frs = so.FixedRaySet.try_build(inp["normals"], inp["incident_dirs"])
     assert frs is not None and 2 <= frs.n_invalid <= 2 + P // 50 and frs.n_invalid == int((frs.valid[:P] == 0).sum())
     # n = -z (and the normalised (1e-4, 0, -1), whose z rounds to -1): R = -I, an improper rotation but orthonormal -> rotated
-    # like any other; (0, 3e-3, -1) and (2e-2, 1e-2, -1): cancellation in 1 + n_z -> the general kernel
+    # like any other; (0, 3e-3, -1) and (2e-2, 1e-2, -1): cancellation in 1 + n_z -> off the rotated path
     assert [int(v) for v in frs.valid[:6]] == [1, 1, 0, 1, 0, 1]
-    # (n = -z exactly takes R = -I, which IS orthonormal -- an improper rotation, rotated like any other; n = +z: R = I)
     taps = so.build_taps(inp["incident_dirs"], He, 2 * He)
-    args = (inp["base_color"], inp["roughness"], inp["normals"], inp["viewdirs"], inp["incidents"], inp["env"],
-            inp["visibility"], inp["incident_dirs"], inp["incident_areas"])
+    args = _frs_args(inp) + (inp["incident_dirs"], inp["incident_areas"])
     cols = [0, 1, 2, 3, 4, 5, 18]
     for uniform in (None, 6.283185307179586):
         want = so.shade_forward(*args, taps=taps, train_outputs=True, uniform_area=uniform)
-        got = frs.forward(*args, taps, torch.full((P, so.NOUT), -7.0, device=DEV), uniform_area=uniform)
+        got = frs.forward(*_frs_args(inp), torch.full((P, so.NOUT), -7.0, device=DEV), uniform_area=uniform)
         torch.cuda.synchronize()
         assert (got[:, [c for c in range(so.NOUT) if c not in cols]] == -7.0).all()
-        _ok("frs forward pbr", got[:, :3], want[:, :3], 2e-4, 1e-6)
+        _ok("frs forward pbr", got[:, :3], want[:, :3], 1e-3, 1e-6)
         _ok("frs forward diffuse / vis", got[:, [3, 4, 5, 18]], want[:, [3, 4, 5, 18]], 2e-5, 1e-6)
         old = so.shade_backward(*args, inp["g_pbr"], inp["g_diff"], taps=taps)
-        new = frs.backward(*args, taps, inp["g_pbr"], inp["g_diff"], uniform_area=uniform)
+        new = frs.backward(*_frs_args(inp), inp["g_pbr"], inp["g_diff"], uniform_area=uniform)
         torch.cuda.synchronize()
         for name, x, y in zip(("d_base", "d_rough", "d_view", "d_inc", "d_env"), new, old):
             # (roughness / view: the fp32 GGX denominator is ill-conditioned -- two evaluation orders differ by up to ~1e-3)
-            _ok("frs backward " + name, x, y, 2e-3 if name in ("d_rough", "d_view") else 2e-4, 1e-7)
+            _ok("frs backward " + name, x, y, 1e-2 if name in ("d_rough", "d_view") else 2e-4, 1e-7)
     # caches that are NOT the Fibonacci set of these normals are refused (the caller then keeps the general kernels)
     assert so.FixedRaySet.try_build(torch.roll(inp["normals"], 1, 0), inp["incident_dirs"]) is None
     assert not so.FixedRaySet.supported(K + 1, 16, He, 2 * He) and not so.FixedRaySet.supported(K, 9, He, 2 * He)
     assert not so.FixedRaySet.supported(K, 16, 256, 512)
 
 
+@pytest.mark.parametrize("P,K,He", [(1003, 16, 8), (777, 32, 16), (2999, 64, 16), (333, 100, 16), (501, 384, 16)])
+def test_fixed_ray_set_kernels_match_oracle(P, K, He):
+    """The kernels the training iteration runs, DIRECTLY against oracle/shading.rendering_equation in float64 + autograd (the
+    tolerances of test_shading_matches_oracle: forward 1e-4, 5e-4 for the GGX-carrying pbr; gradients 2e-3) -- not through the
+    general kernels.  The ray normals are a snapshot: the shading normal has moved on (as in training between two visibility
+    updates); P is not a multiple of 16; six ray normals sit on and next to -z (two of them off the rotated path)."""
+    from oracle import shading
+    from relightable3dgaussian_amd import sampling, shading_ops as so
+    inp = _frs_inputs(P, K, He, seed=11 * P + K)
+    ray_normals = inp["normals"]
+    g = torch.Generator().manual_seed(P)
+    inp["normals"] = torch.nn.functional.normalize(ray_normals + 0.1 * torch.randn(P, 3, generator=g).to(DEV), dim=-1)
+    frs = so.FixedRaySet.try_build(ray_normals, inp["incident_dirs"])
+    assert frs is not None and frs.n_invalid >= 2
+    names = ("base_color", "roughness", "viewdirs", "incidents", "env")
+    o = {k: v.double().cpu() for k, v in inp.items()}
+    ol = {k: o[k].clone().requires_grad_(True) for k in names}
+    ref = shading.rendering_equation(ol["base_color"], ol["roughness"], o["normals"], ol["viewdirs"], ol["incidents"], ol["env"],
+                                     o["visibility"], o["incident_dirs"], o["incident_areas"])
+    ((ref["pbr"] * o["g_pbr"]).sum() + (ref["diffuse_light"] * o["g_diff"]).sum()).backward()
+    out = frs.forward(*_frs_args(inp), torch.zeros((P, so.NOUT), device=DEV))
+    grads = frs.backward(*_frs_args(inp), inp["g_pbr"], inp["g_diff"])
+    torch.cuda.synchronize()
+    _ok("pbr", out[:, 0:3], ref["pbr"], 5e-4, 1e-6)
+    _ok("diffuse_light", out[:, 3:6], ref["diffuse_light"], 1e-4, 1e-6)
+    _ok("incident_visibility", out[:, 18:19], ref["incident_visibility"], 1e-4, 1e-6)
+    for name, got, k in zip(("d_base_color", "d_roughness", "d_viewdirs", "d_incidents", "d_env"), grads, names):
+        _ok(name, got, ol[k].grad.reshape(got.shape), 2e-3, 1e-6)
+    # rows of the Gaussians off the rotated path, on their own (a few rows cannot hide behind the maximum over all of them)
+    rows = frs.invalid_list.long()
+    _ok("pbr, listed rows", out[rows, 0:3], ref["pbr"][rows.cpu()], 5e-4, 1e-6)
+    _ok("d_incidents, listed rows", grads[3][rows], ol["incidents"].grad[rows.cpu()], 2e-3, 1e-6)
+    _ok("d_viewdirs, listed rows", grads[2][rows], ol["viewdirs"].grad[rows.cpu()], 2e-3, 1e-6)
+
+
+def test_fixed_ray_set_kernels_match_reference_golden():
+    """... and against the reference's OWN rendering_equation (gaussian_renderer/neilf.py:339-407) executed on an unperturbed
+    Fibonacci ray set (tests/golden/shading_reference_frs.npz, make_frs_golden.py): values and autograd gradients."""
+    from relightable3dgaussian_amd import shading_ops as so
+    gd = dict(np.load(os.path.join(GOLD, "shading_reference_frs.npz")))
+    t = {k: torch.from_numpy(v).to(DEV) for k, v in gd.items()}
+    P = t["base_color"].shape[0]
+    frs = so.FixedRaySet.try_build(t["ray_normals"], t["incident_dirs"])
+    assert frs is not None and 2 <= frs.n_invalid <= 4, "the fixture has ray normals off the rotated path"
+    env_raw = t["env_raw"].clone().requires_grad_(True)
+    env = torch.nn.functional.softplus(env_raw)[0]
+    args = (t["base_color"], t["roughness"], t["normals"], t["viewdirs"], t["incidents"], env.detach(), t["visibility"])
+    out = frs.forward(*args, torch.zeros((P, so.NOUT), device=DEV))
+    d_base, d_rough, d_view, d_inc, d_env = frs.backward(*args, t["g_pbr"], t["g_diffuse_light"])
+    env.backward(d_env)
+    torch.cuda.synchronize()
+    _ok("pbr", out[:, 0:3], gd["pbr"], 5e-4, 1e-6)
+    _ok("diffuse_light", out[:, 3:6], gd["diffuse_light"], 1e-4, 1e-6)
+    _ok("visibility", out[:, 18:19], gd["incident_visibility_mean"], 1e-4, 1e-6)
+    _ok("d_base_color", d_base, gd["d_base_color"], 2e-3, 1e-6)
+    _ok("d_roughness", d_rough, gd["d_roughness"], 2e-3, 1e-6)
+    _ok("d_viewdirs", d_view, gd["d_viewdirs"], 2e-3, 1e-6)
+    _ok("d_incidents", d_inc, gd["d_incidents"], 2e-3, 1e-6)
+    _ok("d_env_raw", env_raw.grad, gd["d_env_raw"], 2e-3, 1e-6)
+
+
+def test_fixed_ray_set_lookup_records_hold_the_general_lookup():
+    """r3dg_shade_frs_build_taps (8 bytes per sample, regenerated from the ray normals) vs r3dg_shade_build_taps on the cached
+    directions (12 bytes): same texel corner, weights to 2^-23 -- except where the lookup coordinate sits within rounding of a
+    texel boundary (then corner and weight flip together: same bilinear value)."""
+    from relightable3dgaussian_amd import shading_ops as so
+    P, K, He = 3000, 64, 16
+    inp = _frs_inputs(P, K, He, seed=9)
+    frs = so.FixedRaySet.try_build(inp["normals"], inp["incident_dirs"])
+    t8 = frs.taps(He, 2 * He).view(P, K, 2)
+    t12 = so.build_taps(inp["incident_dirs"], He, 2 * He).view(P, K, 3)
+    x8, y8 = (t8[..., 0] >> 23) & 0x1ff, (t8[..., 1] >> 23) & 0x1ff
+    w8 = ((t8 & 0x7fffff) | 0x3f800000).view(torch.float32) - 1.0
+    x12, y12 = t12[..., 0] & 0xffff, (t12[..., 0] >> 16) & 0xffff
+    w12 = t12[..., 1:3].contiguous().view(torch.float32)
+    px8, px12 = x8.float() + w8[..., 0], x12.float() + w12[..., 0]               # continuous lookup coordinates (+1)
+    py8, py12 = y8.float() + w8[..., 1], y12.float() + w12[..., 1]
+    assert float((px8 - px12).abs().max()) < 2e-4 and float((py8 - py12).abs().max()) < 2e-4
+    same = (x8 == x12) & (y8 == y12)
+    assert float(same.float().mean()) > 0.999
+    assert float((w8 - w12)[same].abs().max()) < 2e-4          # (the longitude is ill-conditioned next to the poles)
+    assert float((w8 - w12)[same].abs().mean()) < 1e-6
+
+
 def test_fixed_ray_set_side_streams_and_early_rotation_change_nothing():
-    """The optional streams of the fixed-ray-set entry points (listed Gaussians' general kernel beside the main kernel, rotation
+    """The optional streams of the fixed-ray-set entry points (listed Gaussians' kernel beside the main kernel, rotation
     back on a second stream) and the rotation queued ahead of the forward (r3dg_shade_frs_rotate + R3DG_SHADE_ROTATED) only move
     launches: outputs identical to the plain calls (the texture gradient up to the order of its atomics)."""
     from relightable3dgaussian_amd import _lib, shading_ops as so
@@ -262,11 +354,9 @@ def test_fixed_ray_set_side_streams_and_early_rotation_change_nothing():
     inp = _frs_inputs(P, K, He, seed=5)
     frs = so.FixedRaySet.try_build(inp["normals"], inp["incident_dirs"])
     assert frs is not None and frs.n_invalid >= 2
-    taps = so.build_taps(inp["incident_dirs"], He, 2 * He)
-    args = (inp["base_color"], inp["roughness"], inp["normals"], inp["viewdirs"], inp["incidents"], inp["env"],
-            inp["visibility"], inp["incident_dirs"], inp["incident_areas"])
-    want = frs.forward(*args, taps, torch.full((P, so.NOUT), -7.0, device=DEV)).clone()
-    grads = [g.clone() for g in frs.backward(*args, taps, inp["g_pbr"], inp["g_diff"])]
+    args = _frs_args(inp)
+    want = frs.forward(*args, torch.full((P, so.NOUT), -7.0, device=DEV)).clone()
+    grads = [g.clone() for g in frs.backward(*args, inp["g_pbr"], inp["g_diff"])]
     torch.cuda.synchronize()
     side, main = torch.cuda.Stream(), torch.cuda.current_stream()
     frs.cprime.fill_(float("nan"))
@@ -274,10 +364,10 @@ def test_fixed_ray_set_side_streams_and_early_rotation_change_nothing():
     with torch.cuda.stream(side):
         frs.rotate(inp["incidents"])
     _lib.stream_wait(main, side)
-    got = frs.forward(*args, taps, torch.full((P, so.NOUT), -7.0, device=DEV), listed_stream=side, rotated=True)
+    got = frs.forward(*args, torch.full((P, so.NOUT), -7.0, device=DEV), listed_stream=side, rotated=True)
     _lib.stream_wait(main, side)
     assert torch.equal(got, want)
-    new = frs.backward(*args, taps, inp["g_pbr"], inp["g_diff"], rotate_stream=side)
+    new = frs.backward(*args, inp["g_pbr"], inp["g_diff"], rotate_stream=side)
     _lib.stream_wait(main, side)
     torch.cuda.synchronize()
     for name, x, y in zip(("d_base", "d_rough", "d_view", "d_inc"), new, grads):
@@ -293,22 +383,22 @@ def test_non_finite_upstream_gradient_is_propagated_not_hidden(poison, path, row
     accumulation carries +inf as "not finite": the kernels then accumulate the texture gradient with float atomics).  The
     contract, as torch.autograd gives it to the reference (neilf.py:339-371 under loss.backward()): one Gaussian with a
     non-finite upstream gradient gets non-finite gradients, so does the texture it lit, and NO other Gaussian's gradients change
-    by a single bit.  Row 2 of the fixed-ray-set inputs is a Gaussian off the rotated path (general kernel on a list)."""
+    by a single bit.  Row 2 of the fixed-ray-set inputs is a Gaussian off the rotated path (wave-per-Gaussian kernel)."""
     from relightable3dgaussian_amd import shading_ops as so
     P, K, He = 700, 64, 16
     inp = _frs_inputs(P, K, He, seed=23)
-    taps = so.build_taps(inp["incident_dirs"], He, 2 * He)
-    args = (inp["base_color"], inp["roughness"], inp["normals"], inp["viewdirs"], inp["incidents"], inp["env"],
-            inp["visibility"], inp["incident_dirs"], inp["incident_areas"])
     g_bad = inp["g_pbr"].clone()
     g_bad[row, 1] = poison
     if path == "frs":
         frs = so.FixedRaySet.try_build(inp["normals"], inp["incident_dirs"])
         assert frs is not None and int(frs.valid[10]) == 1 and int(frs.valid[2]) == 0
-        frs.forward(*args, taps, torch.empty((P, so.NOUT), device=DEV))
-        clean = frs.backward(*args, taps, inp["g_pbr"], inp["g_diff"])
-        dirty = frs.backward(*args, taps, g_bad, inp["g_diff"])
+        args = _frs_args(inp)
+        frs.forward(*args, torch.empty((P, so.NOUT), device=DEV))
+        clean = frs.backward(*args, inp["g_pbr"], inp["g_diff"])
+        dirty = frs.backward(*args, g_bad, inp["g_diff"])
     else:
+        taps = so.build_taps(inp["incident_dirs"], He, 2 * He)
+        args = _frs_args(inp) + (inp["incident_dirs"], inp["incident_areas"])
         clean = so.shade_backward(*args, inp["g_pbr"], inp["g_diff"], taps=taps)
         dirty = so.shade_backward(*args, g_bad, inp["g_diff"], taps=taps)
     torch.cuda.synchronize()
@@ -349,34 +439,39 @@ def test_fixed_ray_set_tables_hold_the_basis_in_the_two_mfma_layouts():
         assert float((tab.double() - want).abs().max()) < 2e-6
 
 
-@pytest.mark.parametrize("P,K,He", [(1200, 64, 16), (300, 100, 64)])
-def test_general_kernels_on_a_list_of_gaussians(P, K, He):
-    """The general forward / backward restricted to a list of Gaussians (what the fixed-ray-set entry points use for the
-    Gaussians off the rotated path): listed rows equal the full launch, all other rows stay untouched."""
-    import ctypes as C
-    from relightable3dgaussian_amd import _lib, shading_ops as so
+@pytest.mark.parametrize("P,K,He", [(1200, 64, 16), (300, 100, 8), (200, 384, 16)])
+def test_listed_kernels_on_a_list_of_gaussians(P, K, He):
+    """The wave-per-Gaussian kernels the fixed-ray-set entry points run on the Gaussians off the rotated path
+    (shade_forward_frs_listed_kernel / shade_backward_frs_listed_kernel: directions regenerated from the ray normal, SH basis
+    evaluated there) on an arbitrary list: listed rows equal the general kernels on the cached directions to fp32 rounding, all
+    other rows stay untouched."""
+    from relightable3dgaussian_amd import shading_ops as so
     inp = _frs_inputs(P, K, He, seed=3)
     frs = so.FixedRaySet(inp["normals"], K)
-    lst = torch.tensor([5, 0, P - 1, 17, 18, 19, 400 % P], dtype=torch.int32, device=DEV)
+    lst = torch.tensor([5, 0, P - 1, 17, 18, 19, 2, 400 % P], dtype=torch.int32, device=DEV)
     frs.invalid_list, frs.n_invalid = lst, int(lst.numel())
     frs.valid.fill_(0)                                    # nobody on the rotated path: only the listed rows are produced
     taps = so.build_taps(inp["incident_dirs"], He, 2 * He)
-    args = (inp["base_color"], inp["roughness"], inp["normals"], inp["viewdirs"], inp["incidents"], inp["env"],
-            inp["visibility"], inp["incident_dirs"], inp["incident_areas"])
-    if not so.FixedRaySet.supported(K, 16, He, 2 * He):
-        pytest.skip("texture too large for the fixed-ray-set entry points")
+    args = _frs_args(inp) + (inp["incident_dirs"], inp["incident_areas"])
+    assert so.FixedRaySet.supported(K, 16, He, 2 * He)
     want = so.shade_forward(*args, taps=taps, train_outputs=True)
-    got = frs.forward(*args, taps, torch.full((P, so.NOUT), -7.0, device=DEV))
+    got = frs.forward(*_frs_args(inp), torch.full((P, so.NOUT), -7.0, device=DEV))
     torch.cuda.synchronize()
     rows = lst.long()
     cols = [0, 1, 2, 3, 4, 5, 18]
-    assert torch.equal(got[rows][:, cols], want[rows][:, cols])
+    _ok("listed forward", got[rows][:, cols], want[rows][:, cols], 5e-5, 1e-6)
     mask = torch.ones(P, dtype=torch.bool, device=DEV)
     mask[rows] = False
     assert (got[mask] == -7.0).all()
-    old = so.shade_backward(*args, inp["g_pbr"], inp["g_diff"], taps=taps)
-    new = frs.backward(*args, taps, inp["g_pbr"], inp["g_diff"])
+    # the backward of ONLY these rows: a general launch on a gathered copy of the listed Gaussians
+    sub = tuple(a[rows].contiguous() for a in args[:5]) + (args[5],) + tuple(a[rows].contiguous() for a in args[6:])
+    old = so.shade_backward(*sub, inp["g_pbr"][rows].contiguous(), inp["g_diff"][rows].contiguous(),
+                            taps=taps.view(P, K, 3)[rows].contiguous())
+    keep = [torch.full((P, n), -7.0, device=DEV) for n in (3, 1, 3)]
+    new = frs.backward(*_frs_args(inp), inp["g_pbr"], inp["g_diff"], out_incidents=torch.full((P, 16, 3), -7.0, device=DEV))
     torch.cuda.synchronize()
-    for name, x, y in zip(("d_base", "d_rough", "d_view"), new, old):
-        assert torch.equal(x[rows], y[rows]), name
-    assert torch.equal(new[3][rows], old[3][rows])        # d_inc rows of the listed Gaussians (the others hold the rotated path's)
+    for name, x, y in zip(("d_base", "d_rough", "d_view", "d_inc"), new, old):
+        _ok("listed backward " + name, x[rows], y, 2e-4 if name != "d_inc" else 5e-5, 1e-7)
+    _ok("listed backward d_env", new[4], old[4], 5e-5, 1e-8)
+    assert (new[3][mask] == -7.0).all()                   # (valid == 0 everywhere: the rotation back writes no row)
+    del keep

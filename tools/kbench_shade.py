@@ -49,24 +49,27 @@ for K, He in CASES:
         pr = _lib.profile_read(); L.r3dg_profile_enable(0)
         res["backward (cached taps)"] = pr["shade_backward"][0] / max(pr["shade_backward"][1], 1)
     # the fixed-ray-set kernels on the same caches (csrc/shading_frs.hpp): coefficient rotation + MFMA kernel (+ the
-    # general kernel on the few Gaussians off the rotated path) in one profiled stage each
+    # wave-per-Gaussian
+    # kernels on the few Gaussians off the rotated path) in one profiled stage each
     if so.FixedRaySet.supported(K, 16, He, 2 * He):
         frs = so.FixedRaySet.try_build(nrm, dirs)
         out = torch.empty(P, so.NOUT, device=dev)
-        args = (base, rough, nrm, view, inc, env, vis, dirs, areas)
+        args = (base, rough, nrm, view, inc, env, vis)
         for it in range(8):
             if it == 3:
                 torch.cuda.synchronize(); L.r3dg_profile_enable(1)
-            frs.forward(*args, taps, out, uniform_area=6.283185307179586)
+            frs.forward(*args, out, uniform_area=6.283185307179586)
         torch.cuda.synchronize()
         pr = _lib.profile_read(); L.r3dg_profile_enable(0)
-        res["frs forward (train outputs; %d Gaussians on the general kernel)" % frs.n_invalid] = pr["shade_forward"][0] / max(pr["shade_forward"][1], 1)
+        res["frs forward (train outputs; %d Gaussians off the rotated path)" % frs.n_invalid] = pr["shade_forward"][0] / max(pr["shade_forward"][1], 1)
+        res["frs forward listed"] = pr["shade_frs_listed"][0] / max(pr["shade_frs_listed"][1], 1)
         if K == 64:
             for it in range(8):
                 if it == 3:
                     torch.cuda.synchronize(); L.r3dg_profile_enable(1)
-                frs.backward(*args, taps, gp, gd, uniform_area=6.283185307179586)
+                frs.backward(*args, gp, gd, uniform_area=6.283185307179586)
             torch.cuda.synchronize()
             pr = _lib.profile_read(); L.r3dg_profile_enable(0)
             res["frs backward"] = pr["shade_backward"][0] / max(pr["shade_backward"][1], 1)
+            res["frs backward listed"] = pr["shade_frs_listed"][0] / max(pr["shade_frs_listed"][1], 1)
     print("K=%d He=%d  " % (K, He) + "  ".join("%s %.4f ms" % kv for kv in res.items()))
