@@ -144,10 +144,15 @@ class FixedRaySet:
     def supported(K, M, He, We):
         return bool(_lib.lib().r3dg_shade_frs_supported(int(K), int(M), int(He), int(We)))
 
+    last_mismatch = None         # max |cached - regenerated| direction component of the latest try_build (diagnostics)
+
     @classmethod
-    def try_build(cls, ray_normals, incident_dirs, tol=2e-5, chunk=1 << 16):
+    def try_build(cls, ray_normals, incident_dirs, tol=5e-5, chunk=1 << 16):
         """-> FixedRaySet, or None when `incident_dirs` [P,K,3] is not the Fibonacci set of `ray_normals` (checked once per
-        visibility update; chunked so that the transient stays small)."""
+        visibility update; chunked so that the transient stays small).  `tol` only has to tell THIS ray set from any other one:
+        a cache generated by the same formulas on another device (the CPU-generated reference fixtures of
+        tests/test_reference_pipeline_gpu.py: sin / cos of angles up to 60 rad through another libm) sits ~2e-5 away, a
+        different normal or sample count sits at O(1)."""
         from . import sampling
         P, K = incident_dirs.shape[0], incident_dirs.shape[1]
         if ray_normals is None or ray_normals.shape[0] != P or K < 4 or K % 4 != 0:
@@ -156,7 +161,8 @@ class FixedRaySet:
         for o in range(0, P, chunk):
             want, _ = sampling.fibonacci_sphere_sampling(ray_normals[o:o + chunk], K)
             worst = torch.maximum(worst, (want - incident_dirs[o:o + chunk]).abs().max())
-        if not float(worst) <= tol:
+        cls.last_mismatch = float(worst)
+        if not cls.last_mismatch <= tol:
             return None
         return cls(ray_normals, K)
 

@@ -78,11 +78,49 @@ def _compare_rasterizer(name, case, backward=True):
     st = decode_state(ours[10], ours[11], ours[12], P, ours[0], H, W)
     same_lists = ours[0] == ref["num_rendered"] and torch.equal(st["point_list"], ref["point_list"][:ours[0]])
     msgs.append("sorted point lists identical: %s" % same_lists)
+    list_exempt_tiles = np.zeros(0, np.int64)
     if same_lists:
         assert torch.equal(st["ranges"], ref["ranges"]), "tile ranges differ"
         # keys = tile<<32 | depth bits: the reference build contracts the depth dot product to FMAs, this repo does not
         # (oracle bit-parity), so the low word may differ by an ulp while the ORDER (point_list) is identical
         assert torch.equal(st["keys"] >> 32, ref["keys"][:ours[0]] >> 32), "tile ids of the sorted keys differ"
+    else:
+        # No silent skip: the two lists are compared as (tile, Gaussian) instances.  Their symmetric difference must consist of
+        # instances of Gaussians whose tile rectangle (getRect, auxiliary.h:46-56: int((p - r) / 16), int((p + r + 15) / 16)
+        # on the FMA-contracted pixel centre in the reference build) sits within rounding of a tile edge with EQUAL radii, or of
+        # Gaussians whose radius differs; those tiles are exempt from the pixel comparison below; with the differing instances
+        # removed the two sorted lists -- tile ids and order inside every tile -- must be identical.
+        Ro, Rr = int(ours[0]), int(ref["num_rendered"])
+        t_o = (st["keys"][:Ro] >> 32).cpu().numpy().astype(np.int64)
+        t_r = (ref["keys"][:Rr] >> 32).cpu().numpy().astype(np.int64)
+        g_o = st["point_list"][:Ro].cpu().numpy().astype(np.int64)
+        g_r = ref["point_list"][:Rr].cpu().numpy().astype(np.int64)
+        i_o, i_r = t_o * P + g_o, t_r * P + g_r
+        diff = np.setxor1d(i_o, i_r)
+        msgs.append("(tile, Gaussian) instances in exactly one of the two lists: %d of %d / %d" % (len(diff), Ro, Rr))
+        ok &= len(diff) <= max(8, int(2e-5 * Ro))
+        dg = np.unique(diff % P)
+        m2d = st["means2D"].cpu().numpy().astype(np.float64)[dg]
+        rad = ours[9].cpu().numpy().astype(np.float64)[dg]
+        edge = np.stack([m2d[:, 0] - rad, m2d[:, 0] + rad + 15.0, m2d[:, 1] - rad, m2d[:, 1] + rad + 15.0], 1)
+        dist = np.abs(edge - 16.0 * np.round(edge / 16.0)).min(1)
+        radius_differs = (ours[9] != ref["radii"]).cpu().numpy()[dg]
+        unexplained_g = dg[(dist > 2e-4) & ~radius_differs]
+        msgs.append("Gaussians owning them: %d, of which the rectangle is NOT within 2e-4 px of a tile edge (and the radius is equal): %d"
+                    % (len(dg), len(unexplained_g)))
+        ok &= len(unexplained_g) == 0
+        list_exempt_tiles = np.unique(diff // P)
+        keep_o, keep_r = ~np.isin(i_o, diff), ~np.isin(i_r, diff)
+        same_rest = keep_o.sum() == keep_r.sum() and np.array_equal(i_o[keep_o], i_r[keep_r])
+        msgs.append("the lists without those instances (tile ids and order inside every tile) identical: %s" % same_rest)
+        ok &= bool(same_rest)
+        T = st["ranges"].shape[0]
+        len_o = (st["ranges"][:, 1] - st["ranges"][:, 0]).cpu().numpy()
+        len_r = (ref["ranges"][:, 1] - ref["ranges"][:, 0]).cpu().numpy()
+        other = np.ones(T, bool)
+        other[list_exempt_tiles] = False
+        msgs.append("tile range lengths equal on the %d other tiles: %s" % (other.sum(), np.array_equal(len_o[other], len_r[other])))
+        ok &= np.array_equal(len_o[other], len_r[other])
     # Every difference must be EXPLAINED, not merely rare.  The CPU oracle (bit-identical to the HIP path in every discrete
     # decision) reports per pixel how close any of its threshold decisions (alpha vs 1/255, T vs 1e-4; forward.cu:343-352) came
     # to the threshold; the reference build evaluates the same expressions with FMA contraction, so its decision can differ only
@@ -107,6 +145,10 @@ def _compare_rasterizer(name, case, backward=True):
         x0, x1 = int((m2[gidx, 0] - rad) // 16) * 16, (int((m2[gidx, 0] + rad + 15) // 16) + 1) * 16
         y0, y1 = int((m2[gidx, 1] - rad) // 16) * 16, (int((m2[gidx, 1] + rad + 15) // 16) + 1) * 16
         exempt[max(y0, 0):max(y1, 0), max(x0, 0):max(x1, 0)] = True
+    tiles_x = (W + 15) // 16
+    for t in list_exempt_tiles:                                   # tiles whose instance lists differ (see above)
+        ty, tx = divmod(int(t), tiles_x)
+        exempt[16 * ty:16 * ty + 16, 16 * tx:16 * tx + 16] = True
     explained = border | exempt
     msgs.append("pixels with a threshold decision within 1e-4 of its threshold: %d, in tiles of a radius-mismatch Gaussian: %d (of %d)"
                 % (border.sum(), exempt.sum(), H * W))
@@ -158,8 +200,16 @@ def _compare_rasterizer(name, case, backward=True):
         o_, r_ = o_.reshape(P, -1)[same_r], r_.reshape(P, -1)[same_r]
         scale = max(np.abs(r_).max(), 1e-30)
         bad = np.abs(o_ - r_) > 1e-6 + 2e-3 * scale
-        msgs.append("%-14s max|err| %.3e scale %.3e bad %d/%d" % (nm, np.abs(o_ - r_).max(), scale, bad.sum(), r_.size))
+        # ... and RELATIVE to each Gaussian's own gradient, for the bulk that the array maximum says nothing about: rows whose
+        # reference gradient is above 1e-3 of the largest, 99.9th percentile of max|err| / max|ref| per row
+        row_ref = np.abs(r_).max(1)
+        rows = row_ref > 1e-3 * scale
+        rel = np.abs(o_ - r_).max(1)[rows] / row_ref[rows] if rows.any() else np.zeros(1)
+        p999 = float(np.percentile(rel, 99.9))
+        msgs.append("%-14s max|err| %.3e scale %.3e bad %d/%d; per-Gaussian relative error over %d rows: median %.1e, 99.9th percentile %.1e"
+                    % (nm, np.abs(o_ - r_).max(), scale, bad.sum(), r_.size, rows.sum(), float(np.median(rel)), p999))
         ok &= not bad.any()
+        ok &= p999 <= 1e-3
     text = "\n".join(["[real reference / %s] P=%d %dx%d S=%d" % (name, P, W, H, S)] + msgs)
     print(text)
     assert ok, text
@@ -180,7 +230,16 @@ def test_bvh_matches_real_reference(P, seed, K):
     ref = rg.bvh_build(d["xyz"], d["scales"], d["rotations"], n2, a2)
     torch.cuda.synchronize()
     assert torch.equal(ours[2], ref[2]), "Morton codes differ from the reference build"
-    assert torch.equal(ours[0], ref[0]), "node table differs from the reference build"
+    assert torch.equal(ours[0][:, :4], ref[0][:, :4]), "node table (parent, left, right, object) differs from the reference build"
+    # leaf counts (column 4) travel up the reference's tree with the boxes, through the same unfenced hand-over
+    # (construct.cu:243-258): on gfx950 they can come out stale in ITS build (observed once in ~10 runs at P = 300k: root count
+    # 299899).  Ours must be exact -- the sum of the children's -- and bound the reference's from above.
+    cnt = ours[0][:, 4].long()
+    if P > 1:
+        assert torch.equal(cnt[:P - 1], cnt[ours[0][:P - 1, 1].long()] + cnt[ours[0][:P - 1, 2].long()]) and bool((cnt[P - 1:] == 1).all())
+    stale_counts = int((ref[0][:, 4] != ours[0][:, 4]).sum())
+    print("P=%d reference leaf counts differing from the exact ones: %d / %d" % (P, stale_counts, 2 * P - 1))
+    assert bool((ref[0][:, 4] <= ours[0][:, 4]).all()) and stale_counts <= max(1, P // 1000)
     assert torch.equal(ours[1][P - 1:], ref[1][P - 1:]), "sorted leaf boxes differ from the reference build"
     # Internal boxes: the reference's bottom-up merge hands child boxes between threads with a bare atomicCAS and no
     # fence (construct.cu:243-258).  On gfx950 (non-coherent per-XCD L2s) that race materialises: its internal boxes

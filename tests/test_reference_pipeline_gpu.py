@@ -78,7 +78,7 @@ def test_cameras_of_the_fixtures_are_the_reference_cameras():
     assert np.abs(z["campos"] - z["ref_campos"]).max() < 2e-6
 
 
-def test_stage2_iteration_matches_the_reference_python():
+def test_stage2_iteration_matches_the_reference_python(monkeypatch):
     from relightable3dgaussian_amd.fused_step import FusedStage2Step
     from relightable3dgaussian_amd.train_step import Stage2Step
     z = _load(2)
@@ -107,19 +107,36 @@ def test_stage2_iteration_matches_the_reference_python():
              "incidents_dc": p.incidents_dc, "incidents_rest": p.incidents_rest, "env": p.env}
     for k, t in names.items():
         chk("autograd g_" + k, t.grad, z["g_" + k], 2e-3, 1e-9, outliers=4e-3)
-    # ---- fused iteration
-    fused = FusedStage2Step(_params(z, True), K)
-    fused.visibility, fused.incident_dirs, fused.incident_areas = vis, dirs, areas
-    fo = fused.forward_backward(cam, bg, gt)
-    torch.cuda.synchronize()
-    chk("fused render", fo[2], z["map_render"], 2e-5, 1e-5)
-    chk("fused loss", fused.loss().reshape(1), np.array([z["loss"]], np.float32), 1e-5)
-    g = fused.grads
-    for k in ("xyz", "normal", "scaling", "rotation", "opacity", "base_color", "roughness", "env"):
-        chk("fused g_" + k, g[k], z["g_" + k], 2e-3, 1e-9, outliers=4e-3)
-    chk("fused g_shs", g["shs"], np.concatenate([z["g_shs_dc"], z["g_shs_rest"]], 1), 2e-3, 1e-9, outliers=4e-3)
-    chk("fused g_incidents", g["incidents"], np.concatenate([z["g_incidents_dc"], z["g_incidents_rest"]], 1), 2e-3, 1e-9,
-        outliers=4e-3)
+    # ---- fused iteration, on BOTH shading paths; which one ran is asserted, not assumed: the fixture's directions were generated
+    # on the CPU and sit ~2e-5 from the device's ray set (FixedRaySet.try_build admits 5e-5) -- a silent fall-back to the
+    # general kernels would otherwise pass for a test of the fixed-ray-set kernels
+    for want_frs in (True, False):
+        monkeypatch.setenv("R3DG_SHADE_FRS", "1" if want_frs else "0")
+        fused = FusedStage2Step(_params(z, True), K)
+        fused.visibility, fused.incident_dirs, fused.incident_areas = vis, dirs, areas
+        # ... and the normals those cached directions were generated FROM: the reference's get_normal on the CPU (F.normalize,
+        # eps 1e-3).  The device's activation kernel differs from it by an ulp on six Gaussians whose normal is (0, 0, -c):
+        # -1 there, -0.99999994 here -- and next to -z an ulp of the normal is a different rotation_between_z altogether
+        fused._ray_normals = torch.nn.functional.normalize(torch.from_numpy(z["raw_normal"]), dim=-1, eps=1e-3).to(DEV)
+        fo = fused.forward_backward(cam, bg, gt)
+        torch.cuda.synchronize()
+        from relightable3dgaussian_amd.shading_ops import FixedRaySet
+        assert (fused._frs is not None) == want_frs, "shading path: wanted %s, ran %s (cached vs regenerated directions: %s)" % (
+            "fixed ray set" if want_frs else "general", "fixed ray set" if fused._frs is not None else "general",
+            FixedRaySet.last_mismatch)
+        tag = "fused[%s]" % ("fixed-ray-set kernels, %d Gaussians off the rotated path" % fused._frs.n_invalid if want_frs
+                             else "general kernels")
+        chk.msgs.append("---- " + tag + ("; cached (CPU-generated) vs regenerated directions: %.2e" % FixedRaySet.last_mismatch
+                                         if want_frs else ""))
+        tag = "fused[frs]" if want_frs else "fused[general]"
+        chk(tag + " render", fo[2], z["map_render"], 2e-5, 1e-5)
+        chk(tag + " loss", fused.loss().reshape(1), np.array([z["loss"]], np.float32), 1e-5)
+        g = fused.grads
+        for k in ("xyz", "normal", "scaling", "rotation", "opacity", "base_color", "roughness", "env"):
+            chk(tag + " g_" + k, g[k], z["g_" + k], 2e-3, 1e-9, outliers=4e-3)
+        chk(tag + " g_shs", g["shs"], np.concatenate([z["g_shs_dc"], z["g_shs_rest"]], 1), 2e-3, 1e-9, outliers=4e-3)
+        chk(tag + " g_incidents", g["incidents"], np.concatenate([z["g_incidents_dc"], z["g_incidents_rest"]], 1), 2e-3, 1e-9,
+            outliers=4e-3)
     chk.done()
 
 
