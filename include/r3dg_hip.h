@@ -279,6 +279,10 @@ int r3dg_shade_frs_build_taps(void* stream, int P, int K, const float* d_ray_nor
  * on `signaller` so far (hipEventRecord + hipStreamWaitEvent on a pooled event -- what the library's own entry points use between
  * the streams they are handed). */
 int r3dg_stream_wait_stream(void* waiter, void* signaller);
+/* Occupies `stream` (ONE wave, no memory traffic) for `microseconds` of the device's constant-rate wall clock.  Rehearsal tool:
+ * fused_step prices an all-reduce it cannot run on a one-GPU box by queueing this behind each bucket's one-rank (identity)
+ * collective, sized to the ring time of an assumed bus bandwidth (R3DG_DP_FAKE_COMM_GBS). */
+int r3dg_spin(void* stream, float microseconds);
 
 /* The first step of r3dg_shade_frs_forward on its own: d_cprime [P,48] = the incident-light coefficients rotated into each
  * Gaussian's ray frame.  It depends on d_incidents and d_ray_normals only, so a caller can queue it (on another stream) as soon

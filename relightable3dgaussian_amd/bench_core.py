@@ -83,8 +83,10 @@ def loss_stage1(outs, gt, image_mask=None, weights=None, iteration=0):
     return stage1_loss(outs, gt, image_mask, weights, iteration)
 
 
-def _algorithmic_bytes(stage, P, R, N, S, K=64):
-    """SURVEY.md 8(d) per-unit figures x the units one launch processes (fp32).  The instance-ordering stages are priced with
+def _algorithmic_bytes(stage, P, R, N, S, K=64, S_bwd=None):
+    """SURVEY.md 8(d) per-unit figures x the units one launch processes (fp32).  `S_bwd`: the feature channels the TIMED
+    backward launch carries (the iteration passes `active_features`: channels whose upstream gradient is zero are neither read
+    nor written) -- round 3 priced the launch with all S channels, twice what it moves.  The instance-ordering stages are priced with
     the bytes of the formulation that RUNS (direct tile binning), not with the reference formulation's
     (its 152 R for the global radix sort is kept in `reference_formulation_MB` of the bench line):
       duplicate_with_keys (profile stage of tile_count + tile_scan + tile_emit): the projection outputs of every Gaussian are
@@ -99,11 +101,16 @@ def _algorithmic_bytes(stage, P, R, N, S, K=64):
         "identify_tile_ranges": 8.0 * R,
         "render_forward": (44.0 + 4 * S + 8.0) * R + (28.0 + 4 * S) * N,
         "pseudo_normal": 44.0 * N,
-        "render_backward": (124.0 + 12 * S) * R + (28.0 + 4 * S) * N,
+        "render_backward": (124.0 + 12 * (S if S_bwd is None else S_bwd)) * R + (28.0 + 4 * (S if S_bwd is None else S_bwd)) * N,
         "preprocess_backward": (679.0 + 4 * S) * P,
-        # live shading model: fwd (260+16K) B, bwd (476+16K) B per Gaussian
-        "shade_forward": (260.0 + 16 * K) * P,
-        "shade_backward": (476.0 + 16 * K) * P,
+        # live shading model over the fixed ray set (round 4: no direction stream): per sample visibility 4 + lookup record 8;
+        # per Gaussian: material 28 + normal 12 + view 12 + ray normal 12 + rotated coefficients 192 + validity 1 + 7 outputs 28
+        # (285), backward + upstream gradients 24 + gradients written 28 + coefficient gradient 192 (529).  (SURVEY 8d priced the
+        # reference's cache layout, direction 12 + visibility 4 per sample: (260+16K) / (476+16K) -- what the GENERAL kernels move.)
+        "shade_forward": (285.0 + 12 * K) * P,
+        "shade_backward": (529.0 + 12 * K) * P,
+        "shade_forward_general": (260.0 + 16 * K) * P,
+        "shade_backward_general": (476.0 + 16 * K) * P,
         # fixed ray set: the coefficient rotation, once each way (48 floats + the normal read, 48 floats written)
         "shade_frs_aux": 2 * (48.0 + 3 + 48) * 4 * P,
         # relight under a fixed light: 12 B of cached transport per sample; per Gaussian albedo, roughness, normal, view
@@ -236,6 +243,7 @@ def _kernel_names(stage):
             # other caches gets)
             "shade_forward": ["shade_forward_frs_kernel", "shade_forward_row_kernel"],
             "shade_backward": ["shade_backward_frs_kernel", "shade_backward_kernel"],
+            "shade_forward_general": ["shade_forward_row_kernel"], "shade_backward_general": ["shade_backward_kernel"],
             "shade_frs_aux": ["frs_rotate_kernel"],
             "render_forward": ["render_forward_wave_kernel", "render_forward_kernel"],
             "render_backward": ["render_backward_wave_kernel", "render_backward_kernel"],
@@ -293,7 +301,7 @@ def pmc_valu(stage):
     return None
 
 
-def kernel_table(prof, n_sampled, P, R, N, S, K, rename=None):
+def kernel_table(prof, n_sampled, P, R, N, S, K, rename=None, S_bwd=None):
     """{stage: avg_ms, launches, ms per iteration/frame, algorithmic MB, achieved GB/s, fraction of the 8 TB/s HBM peak,
     VALU-issue fraction (committed PMC evidence)} from the in-library HIP-event timing."""
     kernels = {}
@@ -307,7 +315,7 @@ def kernel_table(prof, n_sampled, P, R, N, S, K, rename=None):
         avg_ms = ms / cnt
         step_ms = avg_ms * per_iter
         try:
-            by = _algorithmic_bytes(name, P, R, N, S, K)
+            by = _algorithmic_bytes(name, P, R, N, S, K, S_bwd)
         except KeyError:
             by = None
         row = dict(avg_ms=round(avg_ms, 4), launches=cnt, launches_per_iteration=per_iter,
@@ -324,14 +332,50 @@ def kernel_table(prof, n_sampled, P, R, N, S, K, rename=None):
     return kernels
 
 
+def valu_bound_of(stage, measured_ms):
+    """The VALU-issue bound of `stage`'s kernel from the committed SQ-counter pass (profiles/*_pmc_valu.json, collected on the
+    launch configuration the iteration runs): a wave64 VALU instruction occupies its SIMD's issue port for 4 cycles (16 lanes
+    per cycle; v_pk_* and transcendentals longer, so this is a LOWER bound on the time), the device has 1024 SIMDs:
+        bound_ms = SQ_INSTS_VALU x 4 / (1024 x clock);   frac = bound_ms / the launch's HIP-event time in the iteration."""
+    import glob
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    files = sorted(glob.glob(os.path.join(root, "profiles", "*_pmc_valu.json")))
+    if not files:
+        return None
+    try:
+        doc = json.load(open(files[-1]))
+        for name in _kernel_names(stage):
+            v = doc["kernels"].get(name)
+            if v is None or "SQ_INSTS_VALU" not in v.get("counters_mean_per_dispatch", {}) or not v.get("clock_ghz"):
+                continue
+            wi = float(v["counters_mean_per_dispatch"]["SQ_INSTS_VALU"])
+            clock = float(v["clock_ghz"])
+            bound_ms = wi * 4.0 / (1024.0 * clock * 1e9) * 1e3
+            return dict(wave_instr=round(wi), cycles_per_instr=4, simds=1024, clock_ghz=clock, bound_ms=round(bound_ms, 4),
+                        frac=None if not measured_ms else round(bound_ms / measured_ms, 4), valu_busy_frac=v.get("valu_busy_frac"),
+                        duration_ms_under_pmc=None if v.get("duration_us_under_pmc") is None else round(v["duration_us_under_pmc"] / 1e3, 4),
+                        kernel=name, source=os.path.basename(files[-1]))
+    except Exception:
+        return None
+    return None
+
+
 def roofline_of(kernels, note):
+    """The dominant kernel of the timed region.  `achieved` / `peak` / `frac` are the HBM figures the contract asks for
+    (algorithmic bytes of THIS launch configuration / HIP-event time / 8 TB/s); `bound` names what the counters say limits the
+    kernel: "valu" when its VALU-issue bound (`valu_bound`) explains more of the launch's time than its HBM fraction does."""
     dom = max(kernels, key=lambda k: kernels[k].get("ms_per_iteration", 0.0))
     ach = kernels[dom]["achieved_GBs"]
     tr = pmc_traffic(dom)
-    return dict(bound="hbm", kernel=dom, achieved=ach, peak=HBM_PEAK_GBS, unit="GB/s",
-                frac=None if ach is None else round(ach / HBM_PEAK_GBS, 4),
-                traffic=None if tr is None else tr["bytes_corrected"], traffic_detail=tr,
-                valu=kernels[dom].get("valu"), avg_kernel_ms=kernels[dom]["ms_per_iteration"], note=note)
+    vb = valu_bound_of(dom, kernels[dom]["ms_per_iteration"])
+    frac = None if ach is None else round(ach / HBM_PEAK_GBS, 4)
+    bound = "hbm"
+    if vb is not None and vb.get("frac") is not None and (frac is None or vb["frac"] > frac):
+        bound = "valu"
+    return dict(bound=bound, kernel=dom, achieved=ach, peak=HBM_PEAK_GBS, unit="GB/s", frac=frac,
+                traffic=None if tr is None else tr["bytes_corrected"], traffic_detail=tr, valu_bound=vb,
+                valu=kernels[dom].get("valu"), avg_kernel_ms=kernels[dom]["ms_per_iteration"],
+                algorithmic_MB=kernels[dom].get("algorithmic_MB"), note=note)
 
 
 @torch.no_grad()
@@ -468,7 +512,7 @@ def _finite_json(x):
     return x
 
 
-def dp_path_one_rank(args, timeout_s=180):
+def dp_path_one_rank(args, timeout_s=180, fake_comm_gbs=None, steps=None):
     """The data-parallel iteration (bucketed async all-reduces on RCCL's stream, reduced skip flag, deferred incident-light
     update) over a ONE-rank RCCL group -- what the path's own structure costs before any byte crosses xGMI -- measured by a
     child `bench.py` with R3DG_DP_SINGLE_RANK=1 (fused_step._world_of) on the same workload."""
@@ -476,9 +520,14 @@ def dp_path_one_rank(args, timeout_s=180):
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, R3DG_DP_SINGLE_RANK="1", R3DG_DIST_BACKEND="nccl")
+    if fake_comm_gbs is not None:
+        # priced rehearsal: every bucket's identity all-reduce is followed by a spin of its 8-rank ring time at this bus
+        # bandwidth (fused_step._allreduce_async)
+        env["R3DG_DP_FAKE_COMM_GBS"] = str(fake_comm_gbs)
+        env["R3DG_DP_FAKE_COMM_WORLD"] = "8"
     for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
-    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--steps", str(args.steps), "--warmup",
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--steps", str(steps or args.steps), "--warmup",
            str(args.warmup), "--points", str(args.points), "--res", str(args.res), "--width", str(getattr(args, "width", 0)), "--height",
            str(getattr(args, "height", 0)), "--objective", getattr(args, "objective", "nerf"), "--sample-num", str(args.sample_num),
            "--no-cpu-baseline", "--no-other-configs", "--relight-frames", "0", "--repeats", "0"]
@@ -488,6 +537,9 @@ def dp_path_one_rank(args, timeout_s=180):
         if r.returncode != 0 or not line:
             return {"failed": (r.stderr or r.stdout)[-400:]}
         doc = _finite_json(json.loads(line[-1]))
+        if fake_comm_gbs is not None:
+            return dict(assumed_bus_GBs=fake_comm_gbs, iters_per_s_one_rank=doc["value"], ms_per_step=doc["ms_per_step"],
+                        exposed_comm_ms=doc.get("exposed_comm_ms"), predicted_8gpu_iters_per_s=round(8.0 * doc["value"], 1))
         return dict(iters_per_s=doc["value"], ms_per_step=doc["ms_per_step"], exposed_comm_ms=doc.get("exposed_comm_ms"),
                     reserved_cus_for_comm=doc.get("reserved_cus_for_comm"),
                     what="the same iteration through the data-parallel path over a ONE-rank RCCL group (identity collectives; "
@@ -575,6 +627,53 @@ def config_rate(dev, points, width, height, stage=2, sample_num=64, objective="n
         out.update(relight_fps=round(1.0 / dtf, 2), relight_ms_per_frame=round(1e3 * dtf, 3), relight_samples=relight_samples,
                    relight_num_rendered=round(nr / relight_frames), visibility_rays=points * relight_samples,
                    visibility_seconds=round(t_vis, 3))
+    return out
+
+
+def unfused_rate(dev, points, width, height, sample_num=64, shading="hip", steps=10, warmup=3):
+    """The REFERENCE'S loop shape over the drop-in ops (train.py:114-127 with the flags of script/run_nerf.sh:20-39): per
+    iteration the Python glue of gaussian_renderer/neilf.py (activations, feature row, losses as PyTorch ops), the three
+    extension calls through autograd, loss.backward(), one torch.optim.Adam step over the parameter groups, zero_grad -- what a
+    user gets who only swaps the extension packages (north_star: "train.py drops in unchanged").  `shading`: "hip" = the
+    shading integral is this repo's op (INTEGRATION.md's one-line rendering_equation patch); "pytorch" = the reference's own
+    pure-PyTorch rendering_equation (no patch at all).  iters/s of `steps` iterations, host-synchronous like train.py
+    (loss.item() every iteration for the progress bar: train.py:133)."""
+    from . import train_step
+    scene = syn.make_scene(P=points, seed=0, stage2=True)
+    cams = [c.to(dev) for c in syn.orbit_cameras(100, width=width, height=height)[:4]]
+    bg = torch.ones(3, device=dev)
+    params = GaussianParams(scene, dev, True)
+    with torch.no_grad():
+        teacher = GaussianParams(syn.make_scene(P=points, seed=0, stage2=False), dev, False)
+        teacher.features_dc.add_(0.05 * torch.randn_like(teacher.features_dc))
+        gts = [render_stage1(teacher, c, bg)[2].clone() for c in cams]
+        del teacher
+    step_fn = train_step.Stage2Step(params, scene, dev, sample_num, shading=shading)
+    opt = torch.optim.Adam([{"params": [q], "lr": 1e-4} for q in params.parameters()], eps=1e-15)   # (one group per tensor,
+    #                                                                     foreach implementation: gaussian_model.py:465-497)
+
+    def one(i):
+        loss, outs = step_fn(cams[i % 4], bg, gts[i % 4])
+        loss.backward()
+        opt.step()
+        opt.zero_grad(set_to_none=True)
+        return float(loss)                                   # (the reference reads the loss every iteration: train.py:133)
+    for i in range(warmup):
+        one(i)
+    torch.cuda.synchronize()
+    peak0 = torch.cuda.max_memory_allocated()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        one(warmup + i)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    out = dict(points=points, image="%dx%d" % (width, height), sample_num=sample_num, iters_per_s=round(1.0 / dt, 2),
+               ms_per_step=round(1e3 * dt, 3), target_iters_per_s=40, meets_target=bool(1.0 / dt >= 40.0),
+               peak_memory_GB=round(max(peak0, torch.cuda.max_memory_allocated()) / 2 ** 30, 2),
+               shading="this repo's op (shading_ops.rendering_equation)" if shading == "hip"
+               else "the reference's pure-PyTorch rendering_equation (neilf.py:339-407), unpatched")
+    del step_fn, opt, params
+    torch.cuda.empty_cache()
     return out
 
 
@@ -830,13 +929,21 @@ def run(args):
         P, N = args.points, W_img * H_img
         R_mean = float(sum(R_seen[-args.steps:])) / max(1, args.steps)
         n_sampled = max(1, sum(1 for i in range(args.steps) if i % EVENT_EVERY == 0))     # steps whose launches were timed
-        kernels = kernel_table(prof, n_sampled, P, R_mean, N, S, args.sample_num)
+        # feature channels the timed backward launch carried (FusedStage2Step: 3 of 16 under the run_nerf.sh objective)
+        S_bwd = getattr(step_fn, "last_active_features", None)
+        S_bwd = None if S_bwd is None else len(S_bwd)
+        general = fused and stage2 and getattr(step_fn, "_frs", None) is None
+        kernels = kernel_table(prof, n_sampled, P, R_mean, N, S, args.sample_num, S_bwd=S_bwd,
+                               rename={"shade_forward": "shade_forward_general", "shade_backward": "shade_backward_general"}
+                               if general else None)
         if not kernels:                   # experiments with the in-library event timing switched off
             kernels = {"none": dict(avg_ms=0.0, launches=0, ms_per_iteration=0.0, algorithmic_MB=None, achieved_GBs=None)}
-        roofline = roofline_of(kernels, "achieved = SURVEY.md 8(d) algorithmic bytes per launch / HIP-event kernel time, "
-                               "measured inside the iteration (kernels of the ordering stream run beside the shading "
-                               "forward, so its time here includes that sharing); the kernel is VALU-bound (`valu`), the "
-                               "HBM fraction is reported as required")
+        roofline = roofline_of(kernels, "achieved = algorithmic bytes of the TIMED launch (SURVEY.md 8(d) per-unit figures with "
+                               "the %s feature channels this launch carries) / HIP-event kernel time inside the iteration; "
+                               "`bound` = what the SQ counters of the same launch configuration say (`valu_bound`: wave "
+                               "instructions x 4 cycles / 1024 SIMDs); the HBM fraction is reported as the contract requires" % (
+                                   "S" if S_bwd is None else str(S_bwd)))
+        roofline["feature_channels_in_backward"] = S_bwd
         iters_s = world * args.steps / elapsed
         result = {
             "metric": "train iters/s, synthetic lego-like %dx%d, %d Gaussians (stage-%d hot path)" % (
@@ -885,10 +992,29 @@ def run(args):
                         config_rate(dev, 2_000_000, 1800, 700, sample_num=64, steps=8, warmup=3, relight_samples=384,
                                     relight_frames=6, stage_ms=True)
                 oc["stage1_densify_and_prune (one call at the bench size)"] = densify_bench(args.points, args.res, dev)
+                if args.stage == 2 and side_budget(40):
+                    # north_star's literal mode: the reference's loop over the drop-in ops, at the headline size
+                    oc["reference loop shape (drop-in ops + autograd + torch.optim.Adam), rendering_equation = this repo's op"] = \
+                        unfused_rate(dev, args.points, W_img, H_img, args.sample_num, "hip")
+                    oc["reference loop shape, rendering_equation = the reference's pure-PyTorch one (unpatched train.py)"] = \
+                        unfused_rate(dev, args.points, W_img, H_img, args.sample_num, "pytorch", steps=6, warmup=2)
                 if args.stage == 2 and not getattr(args, "unfused", False):
                     skipped = {"skipped": "time budget of the default run used up (or R3DG_BENCH_NO_CHILDREN=1)"}
                     b = side_budget(150)
                     oc["data_parallel_path_one_rank_rccl"] = dp_path_one_rank(args, timeout_s=b) if b else skipped
+                    # ... and PRICED: what the three buckets (58 / 22 / 58 MB at 300k Gaussians) would cost over 8 ranks at an
+                    # assumed all-reduce bus bandwidth (xGMI: 7 links x ~153 GB/s per GPU; ring collectives are per-link bound),
+                    # each bucket's identity collective followed by a spin of 2 (7/8) bytes / B on the communication stream
+                    priced = {}
+                    for gbs in (75, 150, 300, 500):
+                        b = side_budget(60)
+                        priced["%d GB/s" % gbs] = dp_path_one_rank(args, timeout_s=b, fake_comm_gbs=gbs, steps=12) if b else skipped
+                    if isinstance(oc["data_parallel_path_one_rank_rccl"], dict):
+                        oc["data_parallel_path_one_rank_rccl"]["priced_all_reduce_8_ranks"] = priced
+                        oc["data_parallel_path_one_rank_rccl"]["priced_note"] = (
+                            "rehearsal, not a measurement of xGMI: predicted_8gpu_iters_per_s = 8 views per step / the one-rank "
+                            "step time with every bucket's all-reduce replaced by a spin of its ring time at the assumed bus "
+                            "bandwidth; exposed_comm_ms = what the compute stream waits for buckets C and B")
             except Exception as e:
                 result["other_configs"] = {"failed": repr(e)}
         if not args.no_cpu_baseline and world == 1:

@@ -909,14 +909,7 @@ int r3dg_rasterize_forward_finish_on(void* ticket_, void* ordering_stream_, int*
         ImageLayout I = ImageLayout::make(N, T);
         char* gbuf = t->gbuf;
         char* ibuf = t->ibuf;
-        int* radii_p = t->radii_p;
-        float* g_depths = (float*)(gbuf + G.depths);
-        float* g_means2D = (float*)(gbuf + G.means2D);
         const float* g_splat = (const float*)(gbuf + G.splat);
-        uint32_t* g_tiles = (uint32_t*)(gbuf + G.tiles_touched);
-        uint32_t* g_block = (uint32_t*)(gbuf + G.block_sums);
-        r3dg_alloc_fn binning_alloc = t->binning_alloc;
-        void* user = t->user;
         const float* features = t->features;
         const float* background = t->background;
         const float* viewmatrix = t->viewmatrix;
@@ -1265,6 +1258,27 @@ int r3dg_stream_wait_stream(void* waiter, void* signaller)
 {
     return guarded([&]() -> int {
         stream_wait_stream((hipStream_t)waiter, (hipStream_t)signaller);
+        return R3DG_OK;
+    });
+}
+
+// one wave that does nothing for `us` microseconds of the device's constant-rate wall clock (s_memrealtime)
+__global__ void __launch_bounds__(64) spin_kernel(unsigned long long ticks)
+{
+    const unsigned long long t0 = wall_clock64();
+    while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(32);
+}
+
+int r3dg_spin(void* stream_, float microseconds)
+{
+    if (!(microseconds >= 0.f) || microseconds > 1e6f) return invalid("spin: 0 .. 1e6 microseconds");
+    return guarded([&]() -> int {
+        int dev = 0, khz = 100000;
+        R3DG_HIP(hipGetDevice(&dev));
+        if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, dev) != hipSuccess || khz <= 0) khz = 100000;
+        const unsigned long long ticks = (unsigned long long)((double)microseconds * 1e-3 * (double)khz);
+        spin_kernel<<<1, 64, 0, (hipStream_t)stream_>>>(ticks);
+        check_launch((hipStream_t)stream_, false, "spin_kernel");
         return R3DG_OK;
     });
 }

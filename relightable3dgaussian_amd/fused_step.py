@@ -36,6 +36,22 @@ class AdamGroup(C.Structure):
                 ("split", C.c_uint32)]
 
 
+def _fake_comm_gbs():
+    v = os.environ.get("R3DG_DP_FAKE_COMM_GBS")
+    return float(v) if v else None
+
+
+class _FakeCommHandle:
+    """What torch.distributed's Work is to the callers of _allreduce_async: wait() orders the current stream behind the
+    (priced) end of the collective."""
+
+    def __init__(self, event):
+        self.event = event
+
+    def wait(self):
+        torch.cuda.current_stream().wait_event(self.event)
+
+
 class FusedAdam:
     """torch.optim.Adam semantics (no weight decay / amsgrad) over a fixed set of tensors, one kernel launch per step.
     `groups`: list of dicts {param, grad (callable or tensor), lr, lr_tail=None, period=0, split=0}."""
@@ -573,6 +589,7 @@ class FusedStage2Step(_BoundedForward):
                 if w_ls != 0.0:
                     active += [12, 13, 14] + ([5, 6, 7] if self.w["normal"] == 0.0 else [])
             geo_stream = None
+            self.last_active_features = sorted(set(active))      # (bench.py prices the backward launch with these)
             if self.frozen_geometry:
                 # nothing but the feature gradients is consumed (the normal maps' gradient belongs to the frozen normal)
                 active = [a for a in active if a not in (5, 6, 7)]
@@ -702,7 +719,23 @@ class FusedStage2Step(_BoundedForward):
     def _allreduce_async(self, flat):
         if not self.dp:
             return None
-        return torch.distributed.all_reduce(flat, group=self.group, async_op=True)
+        gbs = _fake_comm_gbs()
+        if gbs is None:
+            return torch.distributed.all_reduce(flat, group=self.group, async_op=True)
+        # PRICED REHEARSAL (R3DG_DP_FAKE_COMM_GBS=<bus GB/s>, one-rank groups only): the identity collective, then a spin of
+        # the time a ring all-reduce of this bucket takes over `world_assumed` ranks at that bus bandwidth --
+        # 2 (W - 1) / W x bytes / B -- on ONE communication stream, so that the buckets serialise like RCCL's kernels do.
+        # The returned handle's wait() makes the current stream wait for the end of the spin.
+        W = int(os.environ.get("R3DG_DP_FAKE_COMM_WORLD", "8"))
+        us = 2.0 * (W - 1) / W * flat.numel() * 4 / (gbs * 1e9) * 1e6
+        comm = shared_stream(self.dev, "fake_comm")
+        comm.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(comm):
+            torch.distributed.all_reduce(flat, group=self.group, async_op=True).wait()
+            _lib.check(_lib.lib().r3dg_spin(comm.cuda_stream, float(us)), "spin")
+            done = torch.cuda.Event()
+            done.record(comm)
+        return _FakeCommHandle(done)
 
     def _wait(self, handle):
         """Make the current stream wait for a bucket's all-reduce; with `measure_comm` the wait is bracketed by events so that

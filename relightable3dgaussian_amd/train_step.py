@@ -216,11 +216,78 @@ def stage2_smoothness(feat, gt, image_mask, w, maps_are_srgb=False):
     return loss
 
 
+# ---- the shading integral in plain PyTorch: what an UNPATCHED train.py runs between the drop-in ops ---------------------------
+# The reference's `rendering_equation` (gaussian_renderer/neilf.py:339-371, GGX_specular :374-407, eval_sh utils/sh_utils.py:71-128,
+# DirectLightMap.direct_light scene/direct_light_map.py:70-83) is pure PyTorch over [P,K,3] temporaries -- it is NOT one of the
+# three extensions this repo replaces, so a user who only swaps the extension packages keeps running it.  This restatement (same
+# sequence of elementwise / reduction ops over the same temporaries, autograd for the backward) exists so that bench.py can put
+# a number on that mode at the headline size (`other_configs["reference loop shape"]`); the product path is shading_ops.shade.
+_SH_C0, _SH_C1 = 0.28209479177387814, 0.4886025119029199
+_SH_C2 = (1.0925484305920792, -1.0925484305920792, 0.31539156525252005, -1.0925484305920792, 0.5462742152960396)
+_SH_C3 = (-0.5900435899266435, 2.890611442640554, -0.4570457994644658, 0.3731763325901154, -0.4570457994644658,
+          1.445305721320277, -0.5900435899266435)
+
+
+def _eval_sh3(sh, dirs):
+    """sh [P,1,3,16] (channels, coefficients), dirs [P,K,3] -> [P,K,3] (degree 3, reference sign convention)."""
+    x, y, z = dirs[..., 0:1], dirs[..., 1:2], dirs[..., 2:3]
+    r = _SH_C0 * sh[..., 0]
+    r = r - _SH_C1 * y * sh[..., 1] + _SH_C1 * z * sh[..., 2] - _SH_C1 * x * sh[..., 3]
+    xx, yy, zz, xy, yz, xz = x * x, y * y, z * z, x * y, y * z, x * z
+    r = (r + _SH_C2[0] * xy * sh[..., 4] + _SH_C2[1] * yz * sh[..., 5] + _SH_C2[2] * (2.0 * zz - xx - yy) * sh[..., 6] +
+         _SH_C2[3] * xz * sh[..., 7] + _SH_C2[4] * (xx - yy) * sh[..., 8])
+    r = (r + _SH_C3[0] * y * (3 * xx - yy) * sh[..., 9] + _SH_C3[1] * xy * z * sh[..., 10] +
+         _SH_C3[2] * y * (4 * zz - xx - yy) * sh[..., 11] + _SH_C3[3] * z * (2 * zz - 3 * xx - 3 * yy) * sh[..., 12] +
+         _SH_C3[4] * x * (4 * zz - xx - yy) * sh[..., 13] + _SH_C3[5] * z * (xx - yy) * sh[..., 14] +
+         _SH_C3[6] * x * (xx - 3 * yy) * sh[..., 15])
+    return r
+
+
+def rendering_equation_pytorch(base_color, roughness, normals, viewdirs, incidents, env, visibility, incident_dirs,
+                               incident_areas):
+    """-> (pbr [P,3], diffuse_light [P,3], mean visibility [P,1]); env [He,We,3] activated (get_env[0])."""
+    import math
+    P, K = incident_dirs.shape[:2]
+    # DirectLightMap.direct_light: lat-long lookup, bilinear, align_corners=True
+    phi = torch.arccos(incident_dirs[..., 2]).reshape(-1) - 1e-6
+    theta = torch.atan2(incident_dirs[..., 1], incident_dirs[..., 0]).reshape(-1)
+    grid = torch.stack([-theta / math.pi, (phi / math.pi) * 2 - 1], -1).view(1, 1, -1, 2)
+    glob = F.grid_sample(env.permute(2, 0, 1)[None], grid, align_corners=True).view(3, -1).t().view(P, K, 3)
+    local = _eval_sh3(incidents.transpose(1, 2).view(P, 1, 3, -1), incident_dirs).clamp_min(0)
+    lights = local + glob * visibility
+    n_d_i = (normals[:, None] * incident_dirs).sum(-1, keepdim=True).clamp(min=0)
+    f_d = base_color[:, None] / math.pi
+    # GGX_specular
+    L = F.normalize(incident_dirs, dim=-1)
+    V = F.normalize(viewdirs, dim=-1)
+    H = F.normalize((L + V[:, None]) / 2.0, dim=-1)
+    N = F.normalize(normals, dim=-1)
+    NoV = torch.sum(V * N, dim=-1, keepdim=True)
+    N = N * NoV.sign()
+    NoL = torch.sum(N[:, None] * L, dim=-1, keepdim=True).clamp(1e-6, 1)
+    NoV = torch.sum(N * V, dim=-1, keepdim=True).clamp(1e-6, 1)
+    NoH = torch.sum(N[:, None] * H, dim=-1, keepdim=True).clamp(1e-6, 1)
+    VoH = torch.sum(V[:, None] * H, dim=-1, keepdim=True).clamp(1e-6, 1)
+    alpha = roughness * roughness
+    alpha2 = alpha * alpha
+    k = (alpha + 2 * roughness + 1.0) / 8.0
+    FMi = ((-5.55473) * VoH - 6.98316) * VoH
+    frac = (0.04 + 0.96 * torch.pow(2.0, FMi)) * alpha2[:, None]
+    nom0 = NoH * NoH * (alpha2[:, None] - 1) + 1
+    nom = (4 * math.pi * nom0 * nom0 * (NoV * (1 - k) + k)[:, None] * (NoL * (1 - k[:, None]) + k[:, None])).clamp(1e-6, 4 * math.pi)
+    f_s = frac / nom
+    transport = lights * incident_areas * n_d_i
+    return ((f_d + f_s) * transport).mean(-2), transport.mean(-2), visibility.mean(-2)
+
+
 class Stage2Step:
-    def __init__(self, params, scene, device, sample_num, loss_weights=None):
+    def __init__(self, params, scene, device, sample_num, loss_weights=None, shading="hip"):
         """`loss_weights`: as fused_step.FusedStage2Step (defaults = script/run_nerf.sh:20-39, i.e. the
-        normal_render_depth term and the three smoothness terms off; STAGE2_WEIGHTS_SYN4 = run_syn4.sh / run_dtu.sh)."""
+        normal_render_depth term and the three smoothness terms off; STAGE2_WEIGHTS_SYN4 = run_syn4.sh / run_dtu.sh).
+        `shading`: "hip" = shading_ops.shade (INTEGRATION.md's one-line rendering_equation patch), "pytorch" = the reference's
+        own pure-PyTorch rendering_equation restated above (what an unpatched train.py keeps running)."""
         self.p = params
+        self.shading = shading
         self.K = sample_num
         self.w = dict(STAGE2_WEIGHTS)
         if loss_weights:
@@ -241,12 +308,18 @@ class Stage2Step:
         incidents = torch.cat([p.incidents_dc, p.incidents_rest], 1)
         viewdirs = F.normalize(cam.camera_center - means3D, dim=-1)
         env = F.softplus(p.env)[0]                                       # DirectLightMap.get_env
-        pbr, diffuse_light, rest = shade(base_color, roughness, normal.detach(), viewdirs, incidents, env,
-                                         self.visibility, self.incident_dirs, self.incident_areas)
+        if self.shading == "pytorch":
+            pbr, diffuse_light, mean_vis = rendering_equation_pytorch(base_color, roughness, normal.detach(), viewdirs, incidents,
+                                                                      env, self.visibility, self.incident_dirs,
+                                                                      self.incident_areas)
+        else:
+            pbr, diffuse_light, rest = shade(base_color, roughness, normal.detach(), viewdirs, incidents, env,
+                                             self.visibility, self.incident_dirs, self.incident_areas)
+            mean_vis = rest[:, 12:13]
         xyz_h = torch.cat([means3D, torch.ones_like(means3D[:, :1])], -1)
         depths = (xyz_h @ cam.world_view_transform)[:, 2:3]
         features = torch.cat([depths, depths.square(), pbr, normal, base_color, roughness, diffuse_light,
-                              rest[:, 12:13]], -1)                        # S = 16 (neilf.py:120-122)
+                              mean_vis], -1)                              # S = 16 (neilf.py:120-122)
         rs = GaussianRasterizationSettings(cam.image_height, cam.image_width, cam.tanfovx, cam.tanfovy, cam.cx, cam.cy,
                                            bg, 1.0, cam.world_view_transform, cam.full_proj_transform, 3,
                                            cam.camera_center, False, True, True, False)

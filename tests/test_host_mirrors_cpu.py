@@ -928,3 +928,27 @@ def test_fused_stage2_data_parallel_iteration_issues_its_buckets_from_the_stream
         ("wait C", ()),
     ], seq
     assert "frs.rotate" not in names
+
+
+def test_pytorch_rendering_equation_restatement_equals_the_oracle():
+    """train_step.rendering_equation_pytorch (the reference's pure-PyTorch shading integral, restated for bench.py's "reference
+    loop shape" rows) against oracle/shading.py, which is pinned to the reference's own function: values and autograd gradients."""
+    from oracle import shading
+    from relightable3dgaussian_amd import sampling, train_step as ts
+    g = torch.Generator().manual_seed(0)
+    P, K, He = 60, 24, 8
+    n = torch.nn.functional.normalize(torch.randn(P, 3, generator=g), dim=-1)
+    dirs, areas = sampling.fibonacci_sphere_sampling(n, K)
+    vis = (torch.rand(P, K, 1, generator=g) > 0.3).float()
+    leaves = [torch.rand(P, 3, generator=g), 0.1 + 0.8 * torch.rand(P, 1, generator=g), torch.randn(P, 3, generator=g),
+              0.3 * torch.randn(P, 16, 3, generator=g), torch.rand(He, 2 * He, 3, generator=g)]
+    gp, gd = torch.randn(P, 3, generator=g), torch.randn(P, 3, generator=g)
+    grads = []
+    for fn in (lambda b, r, v, i, e: ts.rendering_equation_pytorch(b, r, n, v, i, e, vis, dirs, areas)[:2],
+               lambda b, r, v, i, e: (lambda o: (o["pbr"], o["diffuse_light"]))(shading.rendering_equation(b, r, n, v, i, e, vis, dirs, areas))):
+        ls = [t.clone().requires_grad_(True) for t in leaves]
+        pbr, diff = fn(*ls)
+        ((pbr * gp).sum() + (diff * gd).sum()).backward()
+        grads.append([pbr.detach(), diff.detach()] + [t.grad for t in ls])
+    for a, b in zip(*grads):
+        assert float((a - b).abs().max()) <= 1e-6 + 2e-5 * float(b.abs().max())

@@ -55,6 +55,89 @@ def write_dataset(root, n_views, res, P, n_points):
     return len(cams)
 
 
+def headline(ns, ref):
+    """the reference's UNMODIFIED train.py, stage 2 (script/run_nerf.sh:20-39 flags), at the headline size --
+    300 000 Gaussians, 800x800, sample_num 64 -- for `--stage2-iterations` iterations, once as is (its pure-PyTorch
+    rendering_equation between the drop-in ops) and once with INTEGRATION.md's one-line rendering_equation patch applied from
+    outside (tools/run_reference.py --patch-rendering-equation).  The stage-1 checkpoint it starts from is written in the
+    reference's format by checkpoint.capture from a 300 000-Gaussian synthetic scene (bench.py's), the views are rendered from
+    the same scene by the HIP rasterizer."""
+    from relightable3dgaussian_amd import checkpoint, fused_step, synthetic as syn
+    from relightable3dgaussian_amd.bench_core import GaussianParams, render_stage1
+    import reference_shims as shims
+    dev = torch.device("cuda", 0)
+    P, res, I1 = ns.points, ns.res, 30000
+    tmp = tempfile.mkdtemp(prefix="n4head_")
+    data, s1 = os.path.join(tmp, "data"), os.path.join(tmp, "stage1")
+    os.makedirs(data)
+    os.makedirs(s1)
+    sc = syn.make_scene(P=P, seed=0, stage2=False)
+    teacher = GaussianParams(sc, dev, False)
+    cams = syn.orbit_cameras(ns.views, width=res, height=res)
+    bg = torch.ones(3, device=dev)
+    with torch.no_grad():
+        images = [render_stage1(teacher, c.to(dev), bg)[2].clamp(0, 1).cpu() for c in cams]
+    syn.write_blender_dataset(data, cams, images, split="train")
+    syn.write_blender_dataset(data, cams[::8], images[::8], split="test")
+    n_points = 4000
+    g = np.random.default_rng(3)
+    keep = g.permutation(P)[:n_points]
+    pts = np.empty(n_points, dtype=[("x", "f4"), ("y", "f4"), ("z", "f4"), ("nx", "f4"), ("ny", "f4"), ("nz", "f4"),
+                                    ("red", "u1"), ("green", "u1"), ("blue", "u1")])
+    for i, n in enumerate(("x", "y", "z")):
+        pts[n], pts["n" + n] = sc["xyz"].numpy()[keep, i], sc["normal"].numpy()[keep, i]
+    pts["red"] = pts["green"] = pts["blue"] = 128
+    shims.PlyData([shims.PlyElement.describe(pts, "vertex")]).write(os.path.join(data, "points3d.ply"))
+    step = fused_step.FusedStage1Step(GaussianParams(sc, dev, False), lr=1e-4)
+    torch.save(checkpoint.capture(step, I1), os.path.join(s1, "chkpnt%d.pth" % I1))
+    del step, teacher
+    torch.cuda.empty_cache()
+    from relightable3dgaussian_amd import _lib
+    print("device: %s   library: %s" % (torch.cuda.get_device_name(0), _lib.LIB_PATH))
+    print("reference checkout: %s  train.py sha256 %s" % (ns.reference, hashlib.sha256(open(os.path.join(ref, "train.py"), "rb").read()).hexdigest()[:16]))
+    print("headline size: %d Gaussians (checkpoint.capture of bench.py's synthetic scene as chkpnt%d.pth), %d views %dx%d, sample_num %d, "
+          "%d stage-2 iterations; target of BASELINE.json: >= 40 train iters/s" % (P, I1, ns.views, res, res, ns.sample_num,
+                                                                                    ns.stage2_iterations))
+    i2 = ns.stage2_iterations
+    for title, extra in (("train.py UNPATCHED (pure-PyTorch rendering_equation, neilf.py:339-407)", []),
+                         ("train.py with INTEGRATION.md's one-line rendering_equation patch (applied from outside)",
+                          ["--patch-rendering-equation"])):
+        s2 = os.path.join(tmp, "stage2" + ("_patched" if extra else ""))
+        args = ["train.py", "-s", data, "-m", s2, "-c", os.path.join(s1, "chkpnt%d.pth" % I1), "-t", "neilf",
+                "--sample_num", str(ns.sample_num), "--position_lr_init", "0.000016", "--position_lr_final", "0.00000016",
+                "--normal_lr", "0.001", "--sh_lr", "0.00025", "--opacity_lr", "0.005", "--scaling_lr", "0.0005", "--rotation_lr",
+                "0.0001", "--iterations", str(I1 + i2), "--lambda_base_color_smooth", "0", "--lambda_roughness_smooth", "0",
+                "--lambda_light_smooth", "0", "--lambda_light", "0.01", "--lambda_env_smooth", "0.01", "--test_interval",
+                str(10 * i2), "--checkpoint_interval", str(10 * i2), "--save_interval", str(10 * i2), "--densify_until_iter", "10"]
+        cmd = [sys.executable, os.path.join(ROOT, "tools", "run_reference.py"), "--reference", ref] + extra + ["--"] + args
+        t0 = time.time()
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=ns.timeout, env=dict(os.environ, PYTHONPATH=ROOT), cwd=ROOT,
+                           stdin=subprocess.DEVNULL)
+        dt = time.time() - t0
+        print("\n== %s ==\n$ python tools/run_reference.py --reference %s %s-- %s" % (
+            title, ns.reference, " ".join(extra) + (" " if extra else ""), " ".join(a.replace(tmp, "$TMP") for a in args)))
+        print("exit code %d, %.1f s wall (process start + data loading + visibility trace + %d iterations + saving)" % (
+            r.returncode, dt, i2))
+        for line in r.stdout.splitlines():
+            if re.search(r"run_reference\]|Training complete|Number of points|Found|\[ITER", line):
+                print("  " + line.strip().replace(tmp, "$TMP"))
+        bar = re.findall(r"(\d+)/(\d+) \[(\d+):(\d+)<[^,\]]*, *([0-9.]+)(it/s|s/it)[^\r\n]*?num=(\d+)[^\r\n]*?psnr=([0-9.]+)(?:, psnr_pbr=([0-9.]+))?",
+                         r.stderr)
+        if bar:
+            # tqdm's rate is smoothed over the last updates; the mean rate = iterations done / elapsed at the last update
+            f, l = bar[0], bar[-1]
+            done, elapsed = int(l[0]) - I1, 60 * int(l[2]) + int(l[3])
+            rate = float(l[4]) if l[5] == "it/s" else 1.0 / max(float(l[4]), 1e-9)
+            print("  progress bar: num=%s, psnr %s -> %s (ema), psnr_pbr %s -> %s (ema); tqdm rate at the end %.1f it/s%s -- target 40: %s"
+                  % (l[6], f[7], l[7], f[8], l[8], rate, (", %d iterations in %d s" % (done, elapsed)) if elapsed else "",
+                     "met" if rate >= 40 else "NOT met"))
+        if r.returncode != 0:
+            print(r.stdout[-3000:])
+            print(r.stderr[-6000:])
+            sys.exit(1)
+    shutil.rmtree(tmp, ignore_errors=True)
+
+
 def run(reference, args, timeout):
     cmd = [sys.executable, os.path.join(ROOT, "tools", "run_reference.py"), "--reference", reference, "--"] + args
     env = dict(os.environ, PYTHONPATH=ROOT)
@@ -71,8 +154,13 @@ def main():
     ap.add_argument("--stage2-iterations", type=int, default=400)
     ap.add_argument("--sample-num", type=int, default=24)
     ap.add_argument("--timeout", type=int, default=600)
+    ap.add_argument("--headline", action="store_true",
+                    help="stage 2 only, at --points / --res / --sample-num (VERDICT r3 item 4): unpatched and patched train.py")
+    ap.add_argument("--points", type=int, default=300000)
     ns = ap.parse_args()
     ref = os.path.abspath(ns.reference)
+    if ns.headline:
+        return headline(ns, ref)
     tmp = tempfile.mkdtemp(prefix="n4gpu_")
     data, s1, s2 = (os.path.join(tmp, d) for d in ("data", "stage1", "stage2"))
     os.makedirs(data)

@@ -30,6 +30,9 @@ def main(argv=None):
                     help="checkout of NJU-3DV/Relightable3DGaussian (default: $R3DG_REFERENCE or /root/reference)")
     ap.add_argument("--cpu-oracle", action="store_true", help="(tests only) CPU oracle behind the extension modules")
     ap.add_argument("--quiet-shims", action="store_true")
+    ap.add_argument("--patch-rendering-equation", action="store_true",
+                    help="apply INTEGRATION.md's optional one-line patch from outside the checkout: "
+                         "gaussian_renderer.neilf.rendering_equation = this repo's fused op (same signature)")
     ap.add_argument("script", help="script inside the checkout, e.g. train.py")
     ap.add_argument("args", nargs=argparse.REMAINDER)
     ns = ap.parse_args(argv)
@@ -55,6 +58,11 @@ def main(argv=None):
     # `python train.py` puts the script's directory first; the reference's own packages (scene, utils, arguments, bvh, ...)
     # must win over same-named directories elsewhere, the three extension packages are not shadowed by anything in it
     sys.path.insert(0, os.path.dirname(script))
+    if ns.patch_rendering_equation:
+        import gaussian_renderer.neilf as neilf                      # (the reference's module, found through sys.path[0])
+        from relightable3dgaussian_amd import shading_ops
+        neilf.rendering_equation = shading_ops.rendering_equation    # same signature as neilf.py:339-371
+        print("[run_reference] gaussian_renderer.neilf.rendering_equation -> relightable3dgaussian_amd.shading_ops.rendering_equation")
     sys.argv = [script] + [a for a in ns.args if a != "--"]
     runpy.run_path(script, run_name="__main__")
 
