@@ -676,8 +676,17 @@ enum r3dg_option {
                                          * beside them (default 0; the data-parallel iteration sets it) */
     R3DG_OPT_COUNT
 };
-int r3dg_set_option(int option, int value);
-int r3dg_get_option(int option, int* value);
+int r3dg_set_option(int option, int value);       /* the PROCESS default */
+int r3dg_get_option(int option, int* value);      /* what a launch issued by the calling thread would see right now */
+/* Option contexts -- settings that belong to an OBJECT (a training step, a renderer, a tracer), not to the process.  A context
+ * overrides the process defaults for the options set on it; r3dg_context_make_current installs it for the CALLING THREAD (every
+ * entry point of this library launches on its caller's thread and reads its knobs at launch time), NULL removes it; *previous
+ * (may be NULL) receives the context that was current, so calls nest.  Two objects with different settings in one process, or two
+ * threads, never see each other's values -- r3dg_set_option alone is process-global mutable state. */
+void* r3dg_context_create(void);
+void r3dg_context_destroy(void* ctx);
+int r3dg_context_set_option(void* ctx, int option, int value);
+int r3dg_context_make_current(void* ctx, void** previous);
 /* r3dg_selftest_transpose_reduce: one wave reduces d_in[64][N] -> d_out[64] (+ channel / owner maps) with the transposing
  * DPP / permlane reduction (dpp != 0) or the __shfl_xor one. */
 int r3dg_selftest_transpose_reduce(void* stream, int N, int dpp, const float* d_in, float* d_out, int* d_chan,

@@ -53,6 +53,10 @@ _SIGNATURES = {
     "r3dg_sort_temp_bytes": (C.c_size_t, [C.c_int64]),
     "r3dg_sort_pairs": (_i, [_p, C.c_int64, _p, _p, _p, _p, _i, _p]),
     "r3dg_set_option": (_i, [_i, _i]),
+    "r3dg_context_create": (_p, []),
+    "r3dg_context_destroy": (None, [_p]),
+    "r3dg_context_set_option": (_i, [_p, _i, _i]),
+    "r3dg_context_make_current": (_i, [_p, C.POINTER(_p)]),
     "r3dg_get_option": (_i, [_i, C.POINTER(_i)]),
     "r3dg_selftest_transpose_reduce": (_i, [_p, _i, _i, _p, _p, _p, _p]),
     "r3dg_shade_forward": (_i, [_p, _i, _i, _i, _p, _p, _p, _p, _p, _p, _i, _i, _p, _p, _p, _p, _p]),
@@ -151,6 +155,41 @@ OPTIONS = ("TILE_ORDER", "CULL", "TILE_BINNING", "BINNING_BLOCK_K", "STAGE_SH_RO
 def set_option(name, value):
     """r3dg_set_option by name (experiments / tests): set_option("CULL", 0)."""
     check(lib().r3dg_set_option(OPTIONS.index(name), int(value)), "set_option(%s)" % name)
+
+
+class OptionContext:
+    """Tuning options that belong to ONE object (include/r3dg_hip.h "option contexts"): `ctx.set("RESERVE_CUS", 8)`, then
+    `with ctx:` around the object's library calls -- inside, launches of the calling thread see the context's values where it
+    sets them and the process defaults elsewhere; the previous context is restored on exit (contexts nest)."""
+
+    def __init__(self, **options):
+        self._h = lib().r3dg_context_create()
+        if self._h is None:                      # (NULL)
+            raise RuntimeError("r3dg_context_create failed")
+        self._prev = []
+        for k, v in options.items():
+            self.set(k, v)
+
+    def set(self, name, value):
+        check(lib().r3dg_context_set_option(self._h, OPTIONS.index(name), int(value)), "context_set_option(%s)" % name)
+
+    def __enter__(self):
+        prev = _p()
+        check(lib().r3dg_context_make_current(self._h, C.byref(prev)), "context_make_current")
+        self._prev.append(prev.value)
+        return self
+
+    def __exit__(self, *exc):
+        check(lib().r3dg_context_make_current(self._prev.pop(), None), "context_make_current")
+        return False
+
+    def __del__(self):
+        try:
+            if self._h:
+                lib().r3dg_context_destroy(self._h)
+                self._h = None
+        except Exception:
+            pass
 
 
 def get_option(name):

@@ -1161,21 +1161,21 @@ void bvh_trace_opacity_packed(hipStream_t s, int num_rays, int P, void* records,
     TLeaf* tl = reinterpret_cast<TLeaf*>(rec + (size_t)P * 64);
     int* queues = reinterpret_cast<int*>(rec + (size_t)P * 128);               // 8 x 64 bytes behind the records
     const int nblk = (num_rays + 255) / 256, chunk = (nblk + 7) / 8;
-    if (g_trace_packet >= 3 || g_trace_packet < 2) {
+    if (opt(R3DG_OPT_TRACE_FORMULATION) >= 3 || opt(R3DG_OPT_TRACE_FORMULATION) < 2) {
         int dev = 0, cus = 256;
         R3DG_HIP(hipGetDevice(&dev));
         (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-        cus = cus > g_reserve_cus ? cus - g_reserve_cus : 1;                    // leave CUs to a concurrent collective
+        cus = cus > opt(R3DG_OPT_RESERVE_CUS) ? cus - opt(R3DG_OPT_RESERVE_CUS) : 1;                    // leave CUs to a concurrent collective
         R3DG_HIP(hipMemsetAsync(queues, 0, 8 * 64, s));
         const int cap = cus * 8;                                                // 8 waves per SIMD, all resident
         const int grid = chunk * 8 < cap ? chunk * 8 : cap;
-        if (g_trace_packet == 3)
+        if (opt(R3DG_OPT_TRACE_FORMULATION) == 3)
             trace_opacity_persistent_kernel<<<grid, 256, 0, s>>>(num_rays, P, tn, tl, rays_o, rays_d, contributes, out,
                                                                 overflow, queues);
         else
             trace_opacity_phased_kernel<<<grid, 256, 0, s>>>(num_rays, P, tn, tl, rays_o, rays_d, contributes, out,
-                                                            overflow, queues, g_trace_refill, g_trace_node_weight,
-                                                            g_trace_leaf_weight);
+                                                            overflow, queues, opt(R3DG_OPT_TRACE_REFILL), opt(R3DG_OPT_TRACE_NODE_WEIGHT),
+                                                            opt(R3DG_OPT_TRACE_LEAF_WEIGHT));
     } else {
         trace_opacity_packed_kernel<<<chunk * 8, 256, 0, s>>>(num_rays, P, chunk, tn, tl, rays_o, rays_d, contributes,
                                                              out, overflow);
@@ -1191,11 +1191,11 @@ void bvh_trace_opacity(hipStream_t s, int num_rays, int P, const int32_t* nodes,
                        const float* normals, int32_t* contributes, float* out, int* overflow)
 {
     if (num_rays <= 0) return;
-    if (g_trace_packet >= 2 && P > 0) {
+    if (opt(R3DG_OPT_TRACE_FORMULATION) >= 2 && P > 0) {
         void* rec = trace_scratch(s, bvh_trace_records_bytes((size_t)P));
         bvh_pack_traversal(s, P, nodes, aabbs, means, covs, opac, normals, rec);
         bvh_trace_opacity_packed(s, num_rays, P, rec, rays_o, rays_d, contributes, out, overflow);
-    } else if (g_trace_packet == 1)
+    } else if (opt(R3DG_OPT_TRACE_FORMULATION) == 1)
         trace_opacity_packet_kernel<<<(num_rays + 255) / 256, 256, 0, s>>>(num_rays, nodes, aabbs, rays_o, rays_d, means,
                                                                           covs, opac, normals, contributes, out, overflow);
     else

@@ -2,6 +2,7 @@
 // state-buffer layouts, error plumbing.  Mirrors CudaRasterizer::Rasterizer::forward/backward
 // (rasterizer_impl.cu:199-380, :384-491) in the order of work, not in code.
 #include "common.hpp"
+#include <new>
 #include "../../include/r3dg_hip.h"
 
 #include <map>
@@ -380,7 +381,7 @@ int r3dg_bounded_forward_supported(int width, int height)
 {
     if (width <= 0 || height <= 0) return 0;
     const long long gx = (width + R3DG_TILE_X - 1) / R3DG_TILE_X, gy = (height + R3DG_TILE_Y - 1) / R3DG_TILE_Y;
-    return g_tile_binning == 2 && gx * gy <= (long long)tile_binning_max_tiles() ? 1 : 0;
+    return opt(R3DG_OPT_TILE_BINNING) == 2 && gx * gy <= (long long)tile_binning_max_tiles() ? 1 : 0;
 }
 
 
@@ -410,14 +411,67 @@ static int* option_slot(int option)
     }
 }
 
-int r3dg_set_option(int option, int value)
+static bool option_in_range(int option, int value)
 {
     static const int lo[R3DG_OPT_COUNT] = {0, 0, 0, 1, 0, 0, 0, 1, 1, 1, 0};
     static const int hi[R3DG_OPT_COUNT] = {1, 1, 2, 64, 1, 8, 4, 64, 15, 15, 128};
+    return value >= lo[option] && value <= hi[option];
+}
+
+int r3dg_set_option(int option, int value)
+{
     int* slot = option_slot(option);
     if (slot == nullptr) return invalid("set_option: unknown option");
-    if (value < lo[option] || value > hi[option]) return invalid("set_option: value out of range");
+    if (!option_in_range(option, value)) return invalid("set_option: value out of range");
     *slot = value;
+    return R3DG_OK;
+}
+
+// ---- option contexts: per-object settings instead of process-global ones ------------------------------------------------------
+struct r3dg_context_ {
+    int value[R3DG_OPT_COUNT];
+    unsigned int set_mask;
+};
+static thread_local const r3dg_context_* tl_context = nullptr;
+
+}  // extern "C"
+namespace r3dg {
+int opt(int option)
+{
+    const r3dg_context_* c = tl_context;
+    if (c != nullptr && ((c->set_mask >> option) & 1u)) return c->value[option];
+    return *option_slot(option);
+}
+}  // namespace r3dg
+extern "C" {
+
+void* r3dg_context_create(void)
+{
+    r3dg_context_* c = new (std::nothrow) r3dg_context_();
+    if (c != nullptr) c->set_mask = 0u;
+    return c;
+}
+
+void r3dg_context_destroy(void* ctx)
+{
+    if (tl_context == ctx) tl_context = nullptr;
+    delete static_cast<r3dg_context_*>(ctx);
+}
+
+int r3dg_context_set_option(void* ctx, int option, int value)
+{
+    if (ctx == nullptr || option_slot(option) == nullptr) return invalid("context_set_option: null context or unknown option");
+    if (!option_in_range(option, value)) return invalid("context_set_option: value out of range");
+    r3dg_context_* c = static_cast<r3dg_context_*>(ctx);
+    c->value[option] = value;
+    c->set_mask |= 1u << option;
+    return R3DG_OK;
+}
+
+int r3dg_context_make_current(void* ctx, void** previous)
+{
+    if (previous != nullptr) *previous = const_cast<r3dg_context_*>(tl_context);
+    tl_context = static_cast<const r3dg_context_*>(ctx);
     return R3DG_OK;
 }
 
@@ -425,7 +479,7 @@ int r3dg_get_option(int option, int* value)
 {
     int* slot = option_slot(option);
     if (slot == nullptr || value == nullptr) return invalid("get_option: unknown option or null pointer");
-    *value = *slot;
+    *value = r3dg::opt(option);              // (what a launch on this thread would see right now)
     return R3DG_OK;
 }
 
@@ -661,7 +715,7 @@ static int forward_begin_impl(void* stream_, r3dg_alloc_fn geometry_alloc, r3dg_
         t->fused_front = false;
         uint32_t* zero_words = nullptr;
         int zero_n = 0;
-        if (capacity >= 0 && g_tile_binning == 2 && (int)T <= tile_binning_max_tiles()) {
+        if (capacity >= 0 && opt(R3DG_OPT_TILE_BINNING) == 2 && (int)T <= tile_binning_max_tiles()) {
             BinningLayout B = BinningLayout::make((size_t)capacity);
             t->bbuf = (char*)binning_alloc(user, B.bytes);
             if (!t->bbuf) { set_error("rasterize_forward: binning resize callback returned NULL"); return R3DG_EALLOC; }
@@ -760,7 +814,7 @@ int r3dg_rasterize_forward_finish_bounded(void* ticket_, void* main_stream_)
         // join: the tile kernel needs the ordering (begin's stream) AND whatever the caller queued on `stream` (feature rows)
         R3DG_HIP(hipStreamWaitEvent(stream, t->ordered, 0));
         StageTimer t_rf(stream, ST_RENDER_FWD);
-        launch_render_forward(stream, width, height, S, g_tile_order ? (uint32_t*)(t->ibuf + I.tile_order) : nullptr,
+        launch_render_forward(stream, width, height, S, opt(R3DG_OPT_TILE_ORDER) ? (uint32_t*)(t->ibuf + I.tile_order) : nullptr,
                               (uint32_t*)(t->ibuf + I.ranges), (uint32_t*)(t->bbuf + B.vals),
                               (const float*)(t->gbuf + G.splat), t->features, (float*)(t->ibuf + I.final_T),
                               (uint32_t*)(t->ibuf + I.n_contrib), t->background, t->out_color, t->out_opacity,
@@ -804,7 +858,7 @@ static int enqueue_ordering(ForwardTicket* t, hipStream_t stream, int R)
     uint32_t* g_block = (uint32_t*)(gbuf + G.block_sums);
     r3dg_alloc_fn binning_alloc = t->binning_alloc;
     void* user = t->user;
-    if (t->capacity >= 0 && !(g_tile_binning == 2 && (int)T <= tile_binning_max_tiles())) {
+    if (t->capacity >= 0 && !(opt(R3DG_OPT_TILE_BINNING) == 2 && (int)T <= tile_binning_max_tiles())) {
         set_error("rasterize_forward (bounded): needs the direct tile binning and at most 16384 tiles: ask r3dg_bounded_forward_supported(width, height) first");
         return R3DG_EINVAL;
     }
@@ -818,8 +872,8 @@ static int enqueue_ordering(ForwardTicket* t, hipStream_t stream, int R)
         uint32_t* vals = (uint32_t*)(bbuf + B.vals);
 
         uint32_t* ranges = (uint32_t*)(ibuf + I.ranges);
-        uint32_t* tile_order = g_tile_order ? (uint32_t*)(ibuf + I.tile_order) : nullptr;
-        if (g_tile_binning == 2 && (int)T <= tile_binning_max_tiles()) {
+        uint32_t* tile_order = opt(R3DG_OPT_TILE_ORDER) ? (uint32_t*)(ibuf + I.tile_order) : nullptr;
+        if (opt(R3DG_OPT_TILE_BINNING) == 2 && (int)T <= tile_binning_max_tiles()) {
             // direct binning (rasterizer_preprocess.hip): count -> scan (= the tile ranges) -> emit into the segments, then
             // the per-tile sort by (depth, index): same final lists as the global stable sort
             uint32_t* big_list = (uint32_t*)(ibuf + I.big_list);
@@ -841,7 +895,7 @@ static int enqueue_ordering(ForwardTicket* t, hipStream_t stream, int R)
             launch_tile_sort(stream, (int)T, order, ranges, big_list, big_count, keys, vals, keys_u, true);
             check_launch(stream, debug, "tile_sort");
             t_sort.stop();
-        } else if (g_tile_binning) {
+        } else if (opt(R3DG_OPT_TILE_BINNING)) {
             // stable partition by tile id (one radix pass over the tile bits), then a per-tile depth sort in LDS: same
             // final order as the global 44-bit sort (radix_sort.hip)
             uint32_t* big_list = (uint32_t*)(ibuf + I.big_list);
@@ -932,7 +986,7 @@ int r3dg_rasterize_forward_finish_on(void* ticket_, void* ordering_stream_, int*
         BinningLayout B = BinningLayout::make((size_t)R);
         uint32_t* vals = (uint32_t*)(t->bbuf + B.vals);
         uint32_t* ranges = (uint32_t*)(ibuf + I.ranges);
-        uint32_t* tile_order = g_tile_order ? (uint32_t*)(ibuf + I.tile_order) : nullptr;
+        uint32_t* tile_order = opt(R3DG_OPT_TILE_ORDER) ? (uint32_t*)(ibuf + I.tile_order) : nullptr;
         if (order_stream != main_stream) {          // join: the tile kernel needs the ordering AND the feature rows
             stream_wait_stream(main_stream, order_stream);
         }
@@ -1043,7 +1097,7 @@ int r3dg_rasterize_backward_split(void* stream_, void* geometry_stream_, int P, 
         if (R > 0) {
             StageTimer t_rb(stream, ST_RENDER_BWD);
             launch_render_backward(stream, width, height, S, n_active_features, active_features,
-                                   g_tile_order ? (const uint32_t*)(ibuf + I.tile_order) : nullptr,
+                                   opt(R3DG_OPT_TILE_ORDER) ? (const uint32_t*)(ibuf + I.tile_order) : nullptr,
                                    (const uint32_t*)(ibuf + I.ranges),
                                    (const uint32_t*)(bbuf + B.vals), background, (const float*)(gbuf + G.splat),
                                    features, (const float*)(ibuf + I.final_T), (const uint32_t*)(ibuf + I.n_contrib),
@@ -1098,7 +1152,7 @@ int r3dg_rasterize_backward_features(void* stream_, int P, int S, int R, int wid
         const char* bbuf = (const char*)binning_buffer;
         StageTimer t_rb(stream, ST_RENDER_BWD);
         launch_render_backward_features(stream, width, height, S, n_active_features, active_features,
-                                        g_tile_order ? (const uint32_t*)(ibuf + I.tile_order) : nullptr,
+                                        opt(R3DG_OPT_TILE_ORDER) ? (const uint32_t*)(ibuf + I.tile_order) : nullptr,
                                         (const uint32_t*)(ibuf + I.ranges), (const uint32_t*)(bbuf + B.vals),
                                         (const float*)(gbuf + G.splat), (const float*)(ibuf + I.final_T),
                                         (const uint32_t*)(ibuf + I.n_contrib), dL_dpix_f, dL_dfeature);

@@ -53,6 +53,12 @@ static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; 
 // (r3dg_set_option(R3DG_OPT_RESERVE_CUS)).
 extern int g_reserve_cus;
 
+// The value of a tuning option (enum r3dg_option) for THIS call: the calling thread's current option context
+// (r3dg_context_make_current) where it sets the option, the process default (r3dg_set_option) otherwise.  Every launcher reads
+// its knobs through this, at launch time, on the caller's thread -- two objects with different settings in one process (or two
+// threads) therefore never see each other's values (capi.hip).
+int opt(int option);
+
 // Library-internal device scratch: one grow-only buffer per (device, stream, slot); the pointer stays valid until the next
 // call with the same key asks for more (growth synchronises THAT stream only, so nothing else can still be using the old
 // buffer).  Kernels of different streams or host threads never share scratch.  (capi.hip)

@@ -616,7 +616,13 @@ void launch_tile_sort(hipStream_t s, int T, const uint32_t* tile_order, const ui
                       uint32_t* big_count, uint64_t* keys, uint32_t* vals, uint64_t* scratch, bool entries)
 {
     const uint2* rg = (const uint2*)ranges;
-    const int grid = 2 * (256 - g_reserve_cus);       // 2 x 1024 threads fill a CU; most exit at once when few tiles are long
+    // persistent grid: 2 x 1024 threads fill a CU (most workgroups exit at once when few tiles are long); the device's CU count
+    // minus the CUs left to a collective
+    int dev = 0, cus = 256;
+    (void)hipGetDevice(&dev);
+    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    const int reserve = opt(R3DG_OPT_RESERVE_CUS);
+    const int grid = 2 * (cus > reserve ? cus - reserve : 1);
     if (entries) {
         tile_sort_small_kernel<true><<<T, 256, TILE_SORT_SMALL_CAP * 8, s>>>(T, tile_order, rg, TILE_SORT_SMALL_CAP, keys, vals, scratch);
         tile_sort_long_kernel<true><<<grid, LONG_THREADS, 0, s>>>(big_list, big_count, rg, keys, vals, scratch);

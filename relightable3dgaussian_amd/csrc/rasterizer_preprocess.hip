@@ -598,7 +598,7 @@ void launch_tile_binning(hipStream_t s, int P, int T, const float* means2D, cons
                          uint32_t* big_list, uint32_t* big_count)
 {
     if (!fused) R3DG_HIP(hipMemsetAsync(tile_counts, 0, (size_t)T * 4, s));
-    const int iters = g_bin_iters;
+    const int iters = opt(R3DG_OPT_BINNING_BLOCK_K);
     const int per_block = iters * BIN_THREADS;
     const int nb = (P + per_block - 1) / per_block;
     const size_t smem = (size_t)T * 4;
@@ -646,7 +646,7 @@ void launch_preprocess(hipStream_t s, int P, int D, int M, const float* means3D,
         R3DG_HIP(hipMemsetAsync(zero_words, 0, (size_t)zero_n * 4, s));
         zero_n = 0;
     }
-    const bool staged = g_stage_sh_rows && shs != nullptr && colors_precomp == nullptr && M >= 1 && M <= 16;
+    const bool staged = opt(R3DG_OPT_STAGE_SH_ROWS) && shs != nullptr && colors_precomp == nullptr && M >= 1 && M <= 16;
     if (staged)
         preprocess_kernel<true><<<nb, 256, 256 * ((3 * M) | 1) * sizeof(float), s>>>(
             P, D, M, means3D, scales, scale_modifier, rotations, opacities, shs, clamped, cov3D_precomp, colors_precomp,

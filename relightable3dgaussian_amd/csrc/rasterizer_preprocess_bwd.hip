@@ -306,7 +306,7 @@ void launch_preprocess_backward(hipStream_t s, int P, int D, int M, const float*
 {
     if (P <= 0) return;
     // SH rows through LDS when there are SH coefficients of at most degree 3 (256 x 49 words = 49 KB per block)
-    const bool staged = g_stage_sh_rows && shs != nullptr && M >= 1 && M <= 16;
+    const bool staged = opt(R3DG_OPT_STAGE_SH_ROWS) && shs != nullptr && M >= 1 && M <= 16;
     if (staged)
         preprocess_backward_kernel<true><<<(P + 255) / 256, 256, 256 * staged_row_stride_host(3 * M) * sizeof(float), s>>>(
             P, D, M, means, radii, shs, clamped, scales, rotations, scale_modifier, cov3Ds, vm, proj, h_x, h_y, tan_fovx,

@@ -421,7 +421,7 @@ void launch_render_backward_features(hipStream_t s, int W, int H, int S, int n_a
     if (cl.n == 0) return;
 #define R3DG_BF(SP_)                                                                                                   \
     render_backward_features_kernel<SP_><<<chunk * 8 * 4, 64, 0, s>>>(                                                 \
-        (const uint2*)ranges, point_list, S, cl, W, H, tiles_x, T, g_cull, tile_order, (const float4*)splat, final_Ts,   \
+        (const uint2*)ranges, point_list, S, cl, W, H, tiles_x, T, opt(R3DG_OPT_CULL), tile_order, (const float4*)splat, final_Ts,   \
         n_contrib, dL_dpix_f, dL_dfeature)
     switch ((cl.n + 3) / 4) {
         case 1: R3DG_BF(4); break;
@@ -461,7 +461,7 @@ void launch_render_backward(hipStream_t s, int W, int H, int S, int n_active, co
     const int grid = ((T + 7) / 8) * 8 * 4;       // 4 single-wave workgroups per tile, tile ranks padded to a multiple of 8
 #define R3DG_BWD(SP_, SV)                                                                                             \
     render_backward_wave_kernel<SP_, SV><<<grid, 64, 0, s>>>(                                                         \
-        (const uint2*)ranges, point_list, S, cl, W, H, tiles_x, T, g_cull, tile_order, bg, (const float4*)splat, features,   \
+        (const uint2*)ranges, point_list, S, cl, W, H, tiles_x, T, opt(R3DG_OPT_CULL), tile_order, bg, (const float4*)splat, features,   \
         final_Ts, n_contrib, dL_dpix, dL_dpix_o, dL_dpix_d, dL_dpix_f, dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolor,    \
         dL_dfeature, bg_geom)
     switch ((SP + 3) / 4) {

@@ -299,7 +299,7 @@ void launch_render_forward(hipStream_t s, int W, int H, int S, const uint32_t* t
     const int T = tiles_x * tiles_y;
     const int grid = ((T + 7) / 8) * 8 * 4;       // 4 single-wave workgroups per tile, tile ranks padded to a multiple of 8
 #define R3DG_FWD(SP)                                                                                                  \
-    render_forward_wave_kernel<SP, 4><<<grid, 64, 0, s>>>((const uint2*)ranges, point_list, S, W, H, tiles_x, T, g_cull,   \
+    render_forward_wave_kernel<SP, 4><<<grid, 64, 0, s>>>((const uint2*)ranges, point_list, S, W, H, tiles_x, T, opt(R3DG_OPT_CULL),   \
                                                          tile_order, (const float4*)splat, features, final_T, n_contrib, \
                                                          bg, out_color, out_opacity, out_depth, out_feature, out_weights)
     switch ((S + 3) / 4) {

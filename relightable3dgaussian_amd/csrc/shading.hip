@@ -988,7 +988,7 @@ static int shade_cus()
     (void)hipGetDevice(&dev);
     (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
     // persistent grids leave g_reserve_cus CUs to a collective running beside them (common.hpp)
-    return cus > g_reserve_cus ? cus - g_reserve_cus : 1;
+    return cus > opt(R3DG_OPT_RESERVE_CUS) ? cus - opt(R3DG_OPT_RESERVE_CUS) : 1;
 }
 
 static int shade_grid(int P, int blocks_per_cu = 2)
@@ -1064,11 +1064,11 @@ void launch_shade_forward(hipStream_t s, int P, int K, int M, const float* base_
             nb = nb < by_vgpr ? nb : by_vgpr;                                                                         \
             per_cu[L] = nb > 0 ? (nb < 8 ? nb : 8) : 1;                                                               \
         }                                                                                                             \
-        int bpc = g_shade_row_blocks_per_cu > 0 && g_shade_row_blocks_per_cu < per_cu[L] ? g_shade_row_blocks_per_cu   \
+        int bpc = opt(R3DG_OPT_SHADE_FWD_BLOCKS_PER_CU) > 0 && opt(R3DG_OPT_SHADE_FWD_BLOCKS_PER_CU) < per_cu[L] ? opt(R3DG_OPT_SHADE_FWD_BLOCKS_PER_CU)   \
                                                                                          : per_cu[L];                 \
         /* beside the instance ordering (fused iteration): 3 of the ~6 resident blocks per CU measured best for the     \
            iteration as a whole (2.05 -> 1.97 ms: the ordering kernels get CU time earlier) */                        \
-        if (leave_room && g_shade_row_blocks_per_cu == 0 && bpc > 3) bpc = 3;                                         \
+        if (leave_room && opt(R3DG_OPT_SHADE_FWD_BLOCKS_PER_CU) == 0 && bpc > 3) bpc = 3;                                         \
         const int cap = shade_cus() * bpc;                                                                            \
         const int grid = want < cap ? want : cap;                                                                     \
         if (M == 16)                                                                                                  \

@@ -36,6 +36,21 @@ class AdamGroup(C.Structure):
                 ("split", C.c_uint32)]
 
 
+def _in_context(method):
+    """Run a step object's method inside its option context (`self._ctx`, _lib.OptionContext): the library calls it issues see
+    THIS object's tuning options (CUs reserved for a collective, ...), not whatever another object of the process set last."""
+    import functools
+
+    @functools.wraps(method)
+    def wrapped(self, *a, **k):
+        ctx = getattr(self, "_ctx", None)
+        if ctx is None:
+            return method(self, *a, **k)
+        with ctx:
+            return method(self, *a, **k)
+    return wrapped
+
+
 def _fake_comm_gbs():
     v = os.environ.get("R3DG_DP_FAKE_COMM_GBS")
     return float(v) if v else None
@@ -160,10 +175,9 @@ class _BoundedForward:
         forward every time instead of raising on its second iteration)."""
         if not (self.bounded and self._capacity is not None):
             return False
-        key = (W, H)
-        if self._bounded_ok.get(key) is None:
-            self._bounded_ok[key] = bool(_lib.lib().r3dg_bounded_forward_supported(int(W), int(H)))
-        return self._bounded_ok[key]
+        # (asked every iteration: trivial host code, and the answer depends on the TILE_BINNING option, which an experiment or
+        # a test may change between two frames -- a cached answer then raised instead of falling back to the two-phase forward)
+        return bool(_lib.lib().r3dg_bounded_forward_supported(int(W), int(H)))
 
     @staticmethod
     def _capacity_for(R):
@@ -196,6 +210,7 @@ class _BoundedForward:
         slot.copy_(self._flag)
         return slot
 
+    @_in_context
     def poll_overflow(self):
         """Did the device drop a view since the last call?  (One 4-byte read-back; synchronises.)  If THIS rank's view did
         not fit, its capacity is doubled -- at least to twice the count that did not fit; every dropped iteration (under
@@ -345,16 +360,26 @@ class FusedStage2Step(_BoundedForward):
         self._geo_done = None
         self.group = process_group
         self.world, self.dp = _world_of(process_group)
+        # tuning options of THIS object (include/r3dg_hip.h "option contexts"): every library call of the step runs inside it
+        self._ctx = _lib.OptionContext()
         if self.dp:
             # The shading kernels and the visibility trace are PERSISTENT grids that fill every CU (the backward: 2 workgroups
             # x ~60 KB LDS, ~2 x 230 VGPRs per SIMD); RCCL's workgroups could then only start when one of them retires and
             # bucket A's "hidden" all-reduce would serialise behind the shading backward.  Under data parallelism the
             # persistent grids leave a few CUs free (r3dg_set_option(R3DG_OPT_RESERVE_CUS); R3DG_RESERVE_CUS_FOR_COMM
             # overrides, 0 = off); the cost on one rank is measured by bench.py (`data_parallel_path_one_rank_rccl`).
-            _lib.set_option("RESERVE_CUS", int(os.environ.get("R3DG_RESERVE_CUS_FOR_COMM", "8")))
+            self._ctx.set("RESERVE_CUS", int(os.environ.get("R3DG_RESERVE_CUS_FOR_COMM", "8")))
+            # the side-stream schedule needs one hardware queue per stream: HIP maps a process's streams onto GPU_MAX_HW_QUEUES
+            # queues (default 4) round robin and two streams on one queue run their kernels in turn (DESIGN.md section 5:
+            # 575 -> 621 it/s on one rank); the variable is read when the runtime starts, so it can only be checked here
+            if int(os.environ.get("GPU_MAX_HW_QUEUES", "4")) < 8:
+                import warnings
+                warnings.warn("FusedStage2Step under data parallelism: GPU_MAX_HW_QUEUES=%s (< 8) -- RCCL's streams and this "
+                              "iteration's three streams will share hardware queues and serialise; export GPU_MAX_HW_QUEUES=8 "
+                              "before the process starts (bench.py does)" % os.environ.get("GPU_MAX_HW_QUEUES", "unset (4)"))
         self.measure_comm = False                   # bench.py: time the main stream spends waiting for all-reduce buckets
         self._comm_events = []
-        with torch.no_grad():
+        with torch.no_grad(), self._ctx:
             self.refresh_activations()
             self.visibility, self.incident_dirs, self.incident_areas, self.tracer = update_visibility(
                 self.xyz, self.a_scales, self.a_rot, self.a_opacity, self.a_normal, sample_num, group=process_group)
@@ -458,6 +483,7 @@ class FusedStage2Step(_BoundedForward):
             self._adam_stream = shared_stream(self.dev, "early")
         return self._adam_stream
 
+    @_in_context
     def forward_backward(self, cam, bg, gt, early_adam=False, image_mask=None):
         """One forward + loss + backward; gradients land in self.grads.  Returns the rasterizer's 10 public outputs.
         `image_mask` [1,H,W]: the view's object mask (Camera.image_mask; None = all ones) of the normal and smoothness terms.
@@ -773,6 +799,7 @@ class FusedStage2Step(_BoundedForward):
                           self.w["light_smooth"] / (3.0 * N)], device=self.dev)
         return (self.sums.sum(1) * w).sum() + lam * (self.w["l1"] + self.w["pbr"])
 
+    @_in_context
     def optimizer_step(self):
         """Adam on every group that trains (groups with learning rate 0 get no launch): _groups_a = shs, _groups_c = the small
         per-Gaussian groups + env, _groups_b = incidents -- indices into self.opt.groups, one tuple per gradient bucket."""
@@ -808,6 +835,7 @@ class FusedStage2Step(_BoundedForward):
             self.opt.step_groups(self._groups_c, grads, scale, skip_flag=self._skip_cur)
         self._pending_b = (handle_b, grads, scale, self._skip_cur)
 
+    @_in_context
     def flush(self):
         """Complete a deferred incident-light update (data-parallel runs only; a no-op otherwise)."""
         if self._pending_b is not None:
@@ -817,6 +845,7 @@ class FusedStage2Step(_BoundedForward):
             if self._groups_b:
                 self.opt.step_groups(self._groups_b, grads, scale, skip_flag=skip)
 
+    @_in_context
     def __call__(self, cam, bg, gt, image_mask=None):
         outs = self.forward_backward(cam, bg, gt, early_adam=True, image_mask=image_mask)
         self.optimizer_step()
@@ -853,6 +882,7 @@ class FusedStage1Step(_BoundedForward):
         self._zero_depth_grad = None
         self.group = process_group
         self.world, self.dp = _world_of(process_group)
+        self._ctx = _lib.OptionContext()
         lrs = dict(lrs or {})
         rate = lambda k: float(lrs.get(k, lr))
         rest = float(lrs.get("shs_rest", rate("shs") * lr_rest_scale))
@@ -916,6 +946,7 @@ class FusedStage1Step(_BoundedForward):
         self.stats = new_stats
         self._allocate()
 
+    @_in_context
     def densify_and_prune(self, max_grad, min_opacity, extent, max_screen_size, max_grad_normal, percent_dense=0.01,
                           generator=None):
         """GaussianModel.densify_and_prune on the raw parameters and their Adam moments.  Under data parallelism the
@@ -931,6 +962,7 @@ class FusedStage1Step(_BoundedForward):
         self._rebind(new, new_stats)
         return info
 
+    @_in_context
     def prune(self, min_opacity, extent, max_screen_size):
         from . import densify
         if self.stats is None:
@@ -940,6 +972,7 @@ class FusedStage1Step(_BoundedForward):
         self._rebind(new, new_stats)
         return info
 
+    @_in_context
     def reset_opacity(self):
         """GaussianModel.reset_opacity.  The reference swaps in a fresh parameter object, so the optimizer step of the same
         iteration leaves the opacity alone (its .grad is None): the pending opacity gradient is cleared here, which with
@@ -960,6 +993,7 @@ class FusedStage1Step(_BoundedForward):
         return ((1.0 - LAMBDA_DSSIM) * w["l1"] / (3.0 * N), w["mask_entropy"] / N, w["normal_render_depth"] / (3.0 * N),
                 w["normal_smooth"] / (3.0 * N), depth_var_weight(w["depth_var"], self.iteration) / N)
 
+    @_in_context
     def forward_backward(self, cam, bg, gt, image_mask=None):
         """`image_mask` [1,H,W] (the view's object mask, scene/cameras.py image_mask; None = all ones)."""
         L = _lib.lib()
@@ -1041,14 +1075,17 @@ class FusedStage1Step(_BoundedForward):
         w = torch.tensor([w_l1, w_nrm, w_ent, -lam * self.w["l1"] / (3.0 * N), w_smooth, w_var], device=self.dev)
         return (self.sums.sum(1) * w).sum() + lam * self.w["l1"]
 
+    @_in_context
     def optimizer_step(self):
         self._drain()
         skip = self._snapshot_flag() if (self.dp and self.bounded) else self._flag
         self.opt.step([self.grads[k] for k in self._opt_order], 1.0 / self.world, skip_flag=skip)
 
+    @_in_context
     def flush(self):
         pass
 
+    @_in_context
     def __call__(self, cam, bg, gt, image_mask=None):
         self.iteration += 1
         outs = self.forward_backward(cam, bg, gt, image_mask)

@@ -496,3 +496,60 @@ def test_bounded_stage1_iterations_equal_two_phase_iterations():
     step(cam, bg, gt)
     torch.cuda.synchronize()
     assert step.poll_overflow() == 0 and not torch.equal(step.xyz, before[0])
+
+
+def test_option_contexts_keep_two_objects_apart():
+    """include/r3dg_hip.h "option contexts" (r3dg_set_option alone is process-global state that two step
+    objects race on).  A context's values are seen by launches of the thread that made it current, only where the context sets
+    them, only while it is current; contexts nest; another thread is not affected.  Then two step objects with DIFFERENT
+    instance-ordering formulations in one process, interleaved: each trains exactly as the same object does alone."""
+    import threading
+    from relightable3dgaussian_amd import _lib
+    from relightable3dgaussian_amd.fused_step import FusedStage2Step
+    assert _lib.get_option("CULL") == 1 and _lib.get_option("TILE_BINNING") == 2
+    a, b = _lib.OptionContext(CULL=0), _lib.OptionContext(TILE_BINNING=0, RESERVE_CUS=8)
+    with a:
+        assert (_lib.get_option("CULL"), _lib.get_option("TILE_BINNING"), _lib.get_option("RESERVE_CUS")) == (0, 2, 0)
+        with b:
+            assert (_lib.get_option("CULL"), _lib.get_option("TILE_BINNING"), _lib.get_option("RESERVE_CUS")) == (1, 0, 8)
+            seen = []
+            t = threading.Thread(target=lambda: seen.append((_lib.get_option("TILE_BINNING"), _lib.get_option("RESERVE_CUS"))))
+            t.start()
+            t.join()
+            assert seen == [(2, 0)], "another thread sees this thread's context"
+        assert _lib.get_option("CULL") == 0 and _lib.get_option("TILE_BINNING") == 2
+    assert _lib.get_option("CULL") == 1
+    with pytest.raises(RuntimeError):
+        a.set("CULL", 7)
+
+    P, res, K = 4000, 128, 8
+
+    def make(binning):
+        params, ref, fused, cam, bg, gt = _setup(P=P, res=res, K=K, seed=11)
+        step = FusedStage2Step(params, K)
+        step._ctx.set("TILE_BINNING", binning)          # 0: the reference's global radix sort (two-phase forward), 2: direct binning
+        step.visibility, step.incident_dirs, step.incident_areas = ref.visibility, ref.incident_dirs, ref.incident_areas
+        return step, cam, bg, gt
+    alone = {}
+    for binning in (0, 2):
+        step, cam, bg, gt = make(binning)
+        for it in range(4):
+            step(cam, bg, gt)
+        alone[binning] = (float(step.loss()), step.xyz.clone(), step.shs.clone(), step._capacity)
+    (s0, cam, bg, gt), (s2, _, _, _) = make(0), make(2)
+    for it in range(4):                                  # interleaved in ONE process: each call runs inside its own context
+        s0(cam, bg, gt)
+        s2(cam, bg, gt)
+    assert _lib.get_option("TILE_BINNING") == 2, "a step object leaked its option into the process"
+    for binning, step in ((0, s0), (2, s2)):
+        want = alone[binning]
+        assert abs(float(step.loss()) - want[0]) <= 2e-5 * abs(want[0])
+        for name, x, y in (("xyz", step.xyz, want[1]), ("shs", step.shs, want[2])):
+            ok, msg = report("binning %d %s" % (binning, name), x, y, 1e-4, 1e-6)
+            assert ok, msg
+    # the bounded forward exists only for the direct binning: the object that selected the global sort never took it
+    assert s0._use_bounded.__self__ is s0
+    with s0._ctx:
+        assert not s0._use_bounded(res, res)
+    with s2._ctx:
+        assert s2._use_bounded(res, res)
