@@ -75,7 +75,12 @@ def capture(step, iteration, spatial_lr_scale=1.0, active_sh_degree=3, learning_
     Optimizer.load_state_dict ADOPTS the saved groups' hyper-parameters, so a reference GaussianModel.restore(is_training=
     True) on this file trains with exactly these rates; the default is what the step itself trains with
     (step_learning_rates: the scheduled xyz rate, the stage-2 rates of the run script), and the reference's own training_setup
-    values (reference_learning_rates) for the groups the step does not own."""
+    values (reference_learning_rates) for the groups the step does not own.
+    Frozen groups (learning rate 0: every geometry group under script/run_syn4.sh / run_dtu.sh): the fused iteration launches
+    no Adam for them, so their moments are written as they were when the group froze (zeros for a group that never trained),
+    whereas the reference's torch.optim.Adam keeps accumulating exp_avg / exp_avg_sq (and `step`) for lr = 0 groups.  The
+    PARAMETERS are identical either way; a reference run that restores this file and then RAISES those rates starts from
+    different optimizer state than it would from its own chkpnt."""
     named = _named_tensors(step)
     P = step.xyz.shape[0]
     dev = step.xyz.device

@@ -46,7 +46,9 @@ def _in_context(method):
         ctx = getattr(self, "_ctx", None)
         if ctx is None:
             return method(self, *a, **k)
-        with ctx:
+        # (... and with the step's device current: the library's pooled join events belong to the CURRENT device, so a step on
+        # cuda:N in a process that never called torch.cuda.set_device(N) must not record them from device 0)
+        with ctx, torch.cuda.device(self.dev):
             return method(self, *a, **k)
     return wrapped
 

@@ -91,6 +91,7 @@ def train_stage1(init, cameras, images, background, extent, schedule=None, itera
     gen = torch.Generator(device=step.dev).manual_seed(seed)
     history = []
     xyz_group = step.opt.groups[step._opt_order.index("xyz")]
+    last_densify = None
     for it in range(1, n_iter + 1):
         # gaussians.update_learning_rate(iteration) (train.py:101): the position rate decays log-linearly
         xyz_group["lr"] = position_lr(it, sch.position_lr_init * extent, sch.position_lr_final * extent,
@@ -102,7 +103,11 @@ def train_stage1(init, cameras, images, background, extent, schedule=None, itera
         step.iteration = it                                                  # depth-variance schedule, render.py:202
         step.forward_backward(cameras[v], background, images[v], None if masks is None else masks[v])
         densify_now = collecting and it > sch.densify_from_iter and it % sch.densification_interval == 0
-        if densify_now or (poll_interval and it % poll_interval == 0) or it == n_iter:
+        # (also on the two iterations behind a densification: P has just grown, and so has the instance count the bounded
+        # forward's capacity was sized for -- a dropped view is then counted back out of Adam's step count at once instead of
+        # up to poll_interval iterations later)
+        after_densify = last_densify is not None and it - last_densify in (1, 2)
+        if densify_now or after_densify or (poll_interval and it % poll_interval == 0) or it == n_iter:
             dropped = step.poll_overflow()
             if dropped:
                 history.append((it, "dropped_views", dropped))
@@ -115,6 +120,7 @@ def train_stage1(init, cameras, images, background, extent, schedule=None, itera
                 info = step.densify_and_prune(sch.densify_grad_threshold, sch.min_opacity, extent, size_threshold,
                                               normal_thr, percent_dense=sch.percent_dense, generator=gen)
                 history.append((it, "densify", info["rows_out"]))
+                last_densify = it
                 skip_step = True
             else:
                 skip_step = False
