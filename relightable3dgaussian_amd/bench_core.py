@@ -965,7 +965,8 @@ def run(args):
             # rank 0's compute stream: mean time per iteration it stood waiting for gradient all-reduce buckets (C, then the
             # deferred B in front of the next shading forward; A is waited for on a side stream, under the shading backward)
             result["exposed_comm_ms"] = None if exposed_comm is None else round(exposed_comm, 4)
-            result["reserved_cus_for_comm"] = _lib.get_option("RESERVE_CUS")
+            with step_fn._ctx:                   # (the step's own option context: the process default stays 0)
+                result["reserved_cus_for_comm"] = _lib.get_option("RESERVE_CUS")
         if relight is not None:
             result["roofline_relight"] = relight.pop("roofline_relight")
         if relight is not None:

@@ -757,12 +757,13 @@ class FusedStage2Step(_BoundedForward):
         W = int(os.environ.get("R3DG_DP_FAKE_COMM_WORLD", "8"))
         us = 2.0 * (W - 1) / W * flat.numel() * 4 / (gbs * 1e9) * 1e6
         comm = shared_stream(self.dev, "fake_comm")
-        comm.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(comm):
-            torch.distributed.all_reduce(flat, group=self.group, async_op=True).wait()
-            _lib.check(_lib.lib().r3dg_spin(comm.cuda_stream, float(us)), "spin")
-            done = torch.cuda.Event()
-            done.record(comm)
+        _lib.stream_wait(comm, torch.cuda.current_stream())
+        if os.environ.get("R3DG_DP_FAKE_COMM_WITH_RCCL", "0") != "0":
+            with torch.cuda.stream(comm):              # (the identity collective too: its launch + two stream joins)
+                torch.distributed.all_reduce(flat, group=self.group, async_op=True).wait()
+        _lib.check(_lib.lib().r3dg_spin(comm.cuda_stream, float(us)), "spin")
+        done = torch.cuda.Event()
+        done.record(comm)
         return _FakeCommHandle(done)
 
     def _wait(self, handle):

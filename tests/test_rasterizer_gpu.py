@@ -672,7 +672,7 @@ def test_bounded_forward_equals_the_two_phase_forward(name, side_stream, hip_lib
     torch.cuda.synchronize()
     for i, (x, y) in enumerate(zip(ga, gb)):
         scale = float(x.abs().max()) + 1e-30
-        assert float((x - y).abs().max()) <= 1e-4 * scale, "gradient %d differs (atomics order only)" % i
+        assert float((x - y).abs().max()) <= 2e-4 * scale, "gradient %d differs (atomics order only)" % i
 
 
 def test_bounded_forward_drops_a_frame_that_does_not_fit(hip_lib):
