@@ -15,6 +15,10 @@
 #include "common.hpp"
 #include "wave_reduce.hpp"
 
+#ifndef R3DG_BWD_WAVES_SMALL
+#define R3DG_BWD_WAVES_SMALL 4     // waves per SIMD the <= 4-channel instances are compiled for (measured: 4 -> 0.333 ms, 5 -> 0.367 with 5 spilled registers, 6 -> 0.467)
+#endif
+
 namespace r3dg {
 
 typedef float f2 __attribute__((ext_vector_type(2)));
@@ -69,7 +73,7 @@ struct ChannelList {
 // Measured (300k Gaussians, 800x800): 0.363 -> 0.345 ms inside the iteration (3 live feature channels), 0.494 -> 0.440 ms with
 // all 16 live.
 template <int SPAD, bool SMALLV>
-__global__ void __launch_bounds__(64)
+__global__ void __launch_bounds__(64, (SPAD <= 4 ? R3DG_BWD_WAVES_SMALL : 1))
 render_backward_wave_kernel(const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list, int S,
                             ChannelList chan_list, int W, int H, int tiles_x, int num_tiles, int cull,
                             const uint32_t* __restrict__ tile_order, const float* __restrict__ bg_color,
