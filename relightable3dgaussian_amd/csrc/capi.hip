@@ -93,6 +93,14 @@ void launch_shade_frs_backward_listed(hipStream_t s, int K, const float* base_co
                                       const unsigned int* gmax, int gmax_n);
 void launch_shade_build_taps(hipStream_t s, size_t n, const float* dirs, const float* tr, int He, int We, const float* env,
                              uint32_t* taps);
+void launch_shade_build_split(hipStream_t s, int P, int K, const int* perm, const float* normals, const float* incidents,
+                              const float* visibility, const float* dirs, const float* zsamples, float uniform_area, float* lt,
+                              float* vis_t, float* consts);
+void launch_shade_forward_split(hipStream_t s, int P, int K, const int* perm, const float* base_color, const float* roughness,
+                                const float* normals, const float* viewdirs, const float* lt, const float* vis_t,
+                                const float* consts, const float* zsamples, const float* tr, const float* env4, int He, int We,
+                                float* out);
+void launch_shade_pad_env(hipStream_t s, int ntexel, const float* env, float* env4);
 void launch_shade_build_transport(hipStream_t s, int P, int K, int M, const float* normals, const float* incidents,
                                   const float* visibility, const float* dirs, const float* areas, float uniform_area,
                                   float* radiance_to_transport, float* consts);
@@ -1234,6 +1242,49 @@ int r3dg_shade_build_transport(void* stream_, int P, int K, int M, const float* 
     return guarded([&]() -> int {
         launch_shade_build_transport((hipStream_t)stream_, P, K, M, normals, incidents, visibility, incident_dirs,
                                      incident_areas, uniform_area, radiance_inout, consts);
+        return R3DG_OK;
+    });
+}
+
+int r3dg_shade_build_split(void* stream_, int P, int K, const int32_t* perm, const float* normals, const float* incidents,
+                           const float* visibility, const float* incident_dirs, const float* zsamples, float uniform_area,
+                           float* lt, float* vis_t, float* consts)
+{
+    if (P < 0 || K <= 0) return invalid("shade_build_split: bad P/K");
+    if (P == 0) return R3DG_OK;
+    if (!perm || !normals || !incidents || !visibility || (!incident_dirs && !zsamples) || !lt || !vis_t || !consts)
+        return invalid("shade_build_split: null buffer");
+    return guarded([&]() -> int {
+        launch_shade_build_split((hipStream_t)stream_, P, K, perm, normals, incidents, visibility, incident_dirs, zsamples,
+                                 uniform_area, lt, vis_t, consts);
+        return R3DG_OK;
+    });
+}
+
+int r3dg_shade_pad_env(void* stream_, int He, int We, const float* env, float* env4)
+{
+    if (He <= 0 || We <= 0 || He > 32767 || We > 32767 || !env || !env4) return invalid("shade_pad_env: bad size or null buffer");
+    return guarded([&]() -> int {
+        launch_shade_pad_env((hipStream_t)stream_, He * We, env, env4);
+        return R3DG_OK;
+    });
+}
+
+int r3dg_shade_forward_split(void* stream_, int P, int K, const int32_t* perm, const float* base_color, const float* roughness,
+                             const float* normals, const float* viewdirs, const float* lt, const float* vis_t,
+                             const float* consts, const float* zsamples, const float* env_transform, const float* env4, int He,
+                             int We, float* out)
+{
+    if (P < 0 || K <= 0 || He <= 0 || We <= 0 || He > 32767 || We > 32767) return invalid("shade_forward_split: bad sizes");
+    if (P == 0) return R3DG_OK;
+    if (!perm || !base_color || !roughness || !normals || !viewdirs || !lt || !vis_t || !consts || !zsamples || !env4 || !out)
+        return invalid("shade_forward_split: null buffer");
+    return guarded([&]() -> int {
+        hipStream_t stream = (hipStream_t)stream_;
+        StageTimer t(stream, ST_SHADE_FWD);
+        launch_shade_forward_split(stream, P, K, perm, base_color, roughness, normals, viewdirs, lt, vis_t, consts, zsamples,
+                                   env_transform, env4, He, We, out);
+        t.stop();
         return R3DG_OK;
     });
 }

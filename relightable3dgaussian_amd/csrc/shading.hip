@@ -1138,6 +1138,7 @@ void launch_shade_backward(hipStream_t s, int P, int K, int M, const float* base
 
 }  // namespace r3dg
 #include "shading_transport.hpp"
+#include "shading_split.hpp"
 #include "shading_frs.hpp"
 namespace r3dg {
 
@@ -1344,6 +1345,35 @@ void launch_shade_frs_backward_listed(hipStream_t s, int K, const float* base_co
         n_invalid, invalid_list, K, src, incidents, env, He, We, zsamples, frs_area(uniform_area), d_base, d_rough, d_view, d_inc,
         d_env, gmax, gmax_n);
     check_launch(s, false, "shade_backward_frs_listed_kernel");
+}
+
+void launch_shade_build_split(hipStream_t s, int P, int K, const int* perm, const float* normals, const float* incidents,
+                              const float* visibility, const float* dirs, const float* zsamples, float uniform_area, float* lt,
+                              float* vis_t, float* consts)
+{
+    if (P == 0) return;
+    shade_build_split_kernel<<<(P + 255) / 256, 256, 0, s>>>(P, K, perm, normals, incidents, visibility, dirs, zsamples,
+                                                           frs_area(uniform_area), reinterpret_cast<float4*>(lt), vis_t, consts);
+    check_launch(s, false, "shade_build_split_kernel");
+}
+
+void launch_shade_forward_split(hipStream_t s, int P, int K, const int* perm, const float* base_color, const float* roughness,
+                                const float* normals, const float* viewdirs, const float* lt, const float* vis_t,
+                                const float* consts, const float* zsamples, const float* tr, const float* env4, int He, int We,
+                                float* out)
+{
+    if (P == 0) return;
+    shade_forward_split_kernel<<<(P + 255) / 256, 256, 0, s>>>(P, K, perm, base_color, roughness, normals, viewdirs,
+                                                             reinterpret_cast<const float4*>(lt), vis_t, consts, zsamples, tr,
+                                                             reinterpret_cast<const float4*>(env4), He, We, out);
+    check_launch(s, false, "shade_forward_split_kernel");
+}
+
+void launch_shade_pad_env(hipStream_t s, int ntexel, const float* env, float* env4)
+{
+    if (ntexel <= 0) return;
+    shade_pad_env_kernel<<<(ntexel + 255) / 256, 256, 0, s>>>(ntexel, env, reinterpret_cast<float4*>(env4));
+    check_launch(s, false, "shade_pad_env_kernel");
 }
 
 void launch_shade_build_transport(hipStream_t s, int P, int K, int M, const float* normals, const float* incidents,

@@ -22,6 +22,26 @@ def _shs_of(model):
     return torch.cat([model.features_dc.detach(), model.features_rest.detach()], 1).contiguous()
 
 
+def normal_order(normals, bits=10):
+    """Permutation [P] (int32) that visits the Gaussians in an order in which neighbours have NEIGHBOURING normals: Morton code
+    of the octahedral image of the unit normal (2 x `bits` bits).  Used by the split-transport relight kernels, whose 64 lanes
+    look up the environment map for the same sample index of 64 consecutive Gaussians."""
+    n = F.normalize(normals.detach().float(), dim=-1, eps=1e-12)
+    p = n / n.abs().sum(-1, keepdim=True).clamp_min(1e-12)
+    u, v = p[:, 0], p[:, 1]
+    fold = p[:, 2] < 0
+    uf = torch.where(fold, (1 - v.abs()) * torch.where(u >= 0, 1.0, -1.0), u)
+    vf = torch.where(fold, (1 - u.abs()) * torch.where(v >= 0, 1.0, -1.0), v)
+    q = (1 << bits) - 1
+    iu = ((uf * 0.5 + 0.5) * q).round().clamp(0, q).long()
+    iv = ((vf * 0.5 + 0.5) * q).round().clamp(0, q).long()
+    code = torch.zeros_like(iu)
+    for b in range(bits):
+        code |= ((iu >> b) & 1) << (2 * b)
+        code |= ((iv >> b) & 1) << (2 * b + 1)
+    return torch.argsort(code).to(torch.int32).contiguous()
+
+
 def _incidents_of(model):
     if hasattr(model, "incidents"):
         return model.incidents
@@ -53,6 +73,7 @@ class RelightRenderer:
         self._light_changes = 0
         self._area_key, self._uniform_area = None, None
         self._consts = self._zsamples = None
+        self._split = None                          # split-transport cache of a light that turns with every frame (_split_cache)
         d = lambda t: t.detach().clone().contiguous()       # a snapshot: the caches below are only valid for THESE values
         self.xyz, self.normal = d(model.xyz), d(model.normal)
         self.scaling, self.rotation, self.opacity = d(model.scaling), d(model.rotation), d(model.opacity)
@@ -133,6 +154,36 @@ class RelightRenderer:
                         self._uniform_area or 0.0, self._taps.data_ptr(), self._consts.data_ptr()), "shade_build_transport")
         return self._taps
 
+    def _split_cache(self):
+        """The light-independent half of the transport, for a light that turns with every frame (relighting.py:160-161 with
+        configs/nerf_syn_light / configs/tnt light_transform.json): per sample (local light x a, a) and the visibility,
+        sample-major, in an order sorted by normal; the per-frame kernel (r3dg_shade_forward_split) does the lat-long lookup
+        of the rotated direction itself.  Built once -- the renderer works on a snapshot of the parameters -- and only for the
+        configuration the reference's relighting uses (16 incident-light coefficients, the Fibonacci ray set with its uniform
+        area); None otherwise (the general kernel with the lookup inside then runs, as before)."""
+        if self._split is not None:
+            return self._split or None
+        self._split = False
+        if self.M != 16 or self._uniform_area is None:
+            return None
+        P, K, dev = self.P, self.K, self.dev
+        f = dict(dtype=torch.float32, device=dev)
+        perm = normal_order(self.a_normal)
+        lt, vis_t, consts = torch.empty(K, P, 4, **f), torch.empty(K, P, **f), torch.empty(P, 4, **f)
+        zs = sampling.fibonacci_z_samples(K, dev)[0].t().contiguous()
+        He, We = self.envmap.shape[0], self.envmap.shape[1]
+        env4 = torch.empty(He, We, 4, **f)
+        L = _lib.lib()
+        with torch.cuda.device(dev):
+            _lib.check(L.r3dg_shade_build_split(
+                _lib.current_stream(), P, K, perm.data_ptr(), self.a_normal.data_ptr(), self.incidents.data_ptr(),
+                self.visibility.data_ptr(), None if self.regenerate_dirs else self.incident_dirs.data_ptr(), zs.data_ptr(),
+                float(self._uniform_area), lt.data_ptr(), vis_t.data_ptr(), consts.data_ptr()), "shade_build_split")
+            _lib.check(L.r3dg_shade_pad_env(_lib.current_stream(), He, We, self.envmap.data_ptr(), env4.data_ptr()),
+                       "shade_pad_env")
+        self._split = dict(perm=perm, lt=lt, vis_t=vis_t, consts=consts, zsamples=zs, env4=env4)
+        return self._split
+
     def _activate(self, campos):
         with torch.cuda.device(self.dev):
             st = _lib.lib().r3dg_stage2_activate(
@@ -177,6 +228,15 @@ class RelightRenderer:
                     self.a_viewdirs.data_ptr(), taps.data_ptr(), self._consts.data_ptr(), self._zsamples.data_ptr(),
                     None if self.regenerate_dirs else self.incident_dirs.data_ptr(), self.shade_out.data_ptr()),
                     "shade_forward_transport")
+            elif taps is None and self._split_cache() is not None:
+                # a light that turns with every frame: the light-independent half of the transport is cached, the lookup of the
+                # rotated direction happens in the kernel (lane = Gaussian, sorted by normal)
+                sp = self._split
+                _lib.check(L.r3dg_shade_forward_split(
+                    stream(), P, self.K, sp["perm"].data_ptr(), self.a_base.data_ptr(), self.a_rough.data_ptr(),
+                    self.a_normal.data_ptr(), self.a_viewdirs.data_ptr(), sp["lt"].data_ptr(), sp["vis_t"].data_ptr(),
+                    sp["consts"].data_ptr(), sp["zsamples"].data_ptr(), _lib.ptr(tr), sp["env4"].data_ptr(), He, We,
+                    self.shade_out.data_ptr()), "shade_forward_split")
             else:
                 self._shade_cached(L, stream, P, He, We, tr, taps)
             _lib.check(L.r3dg_relight_pack_features(

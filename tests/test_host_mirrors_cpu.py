@@ -221,13 +221,17 @@ def test_relight_renderer_host_logic_with_a_recording_library(monkeypatch):
     assert cached[-2] == 2 and cached[-3] is not None and cached[16] == 2.0 and cached[15] is None     # radiance taps, uniform area
     assert set(out) >= {"render", "feature", "pbr_env", "num_rendered"} and out["num_rendered"] == 3
     assert wanted and not any(wanted)                       # frames never ask for the per-Gaussian blend weights
-    # a light that turns with every frame: cache on the first change only, in-kernel lookup afterwards
+    # a light that turns with every frame: cache on the first change only, afterwards the split transport (built once) with the
+    # lookup inside the per-frame kernel
     calls.clear()
     del built[:]
     for i in range(4):
         r.frame(cam, z(3), env_transform=torch.eye(3) * (1.0 + i))
     flags = [c[1][-2] for c in calls if c[0] == "r3dg_shade_forward_cached"]
-    assert len(built) == 1 and flags == [2, 0, 0, 0], (len(built), flags)
+    assert len(built) == 1 and flags == [2], (len(built), flags)
+    assert names().count("r3dg_shade_build_split") == 1 and names().count("r3dg_shade_forward_split") == 3
+    sp = [c for c in calls if c[0] == "r3dg_shade_forward_split"][-1][1]
+    assert len(sp) == 17 and sp[1:3] == (P, K) and sp[12] is not None and sp[14:16] == (8, 16)      # the rotation; He, We
     # the same with DEVICE matrices built per frame (relighting.py:162-163): keyed by storage identity, and the renderer keeps
     # the tensors it keyed on alive, so a recycled address cannot pass for "the light did not move"
     r2 = relight.RelightRenderer(model, env, K, cache="radiance")
@@ -236,12 +240,14 @@ def test_relight_renderer_host_logic_with_a_recording_library(monkeypatch):
     for i in range(6):
         r2.frame(cam, z(3), env_transform=dt(torch.eye(3) * (1.0 + i)))
     flags = [c[1][-2] for c in calls if c[0] == "r3dg_shade_forward_cached"]
-    assert len(built) == 1 and flags == [2, 0, 0, 0, 0, 0], (len(built), flags)
+    assert len(built) == 1 and flags == [2] and names().count("r3dg_shade_forward_split") == 5, (len(built), flags)
     fixed = dt(torch.eye(3) * 9.0)
     for i in range(3):
         r2.frame(cam, z(3), env_transform=fixed)
-    flags = [c[1][-2] for c in calls if c[0] == "r3dg_shade_forward_cached"][6:]
-    assert len(built) == 2 and flags == [0, 2, 2], (len(built), flags)       # stopped: cached again from its second frame
+    flags = [c[1][-2] for c in calls if c[0] == "r3dg_shade_forward_cached"][1:]
+    # stopped: its first frame is still a change (split kernel), cached again from the second one
+    assert len(built) == 2 and flags == [2, 2] and names().count("r3dg_shade_forward_split") == 6, (len(built), flags)
+    assert names().count("r3dg_shade_build_split") == 1
     # the default, transport cache: one build (radiance -> transport in place + constants), then the transport kernel per frame
     r = relight.RelightRenderer(model, env, K)
     assert r.cache == "transport" and r.xyz is not model.xyz            # (works on a snapshot of the parameters)
