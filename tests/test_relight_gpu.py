@@ -99,7 +99,7 @@ def test_a_light_that_turns_every_frame_takes_the_split_transport_and_a_stopped_
             ok, msg = report(k, got[k], want[k], rtol, atol)
             assert ok, msg
     assert cached == [True, False, False, False, True, True], cached
-    assert split == [False, False, True, True, True, True], split        # built at the second consecutive change, kept
+    assert split == [False, True, True, True, True, True], split         # built at the second consecutive change, kept
     # the order the split kernels visit the Gaussians in: a permutation, neighbours have neighbouring normals
     perm = r._split["perm"].long()
     assert sorted(perm.tolist()) == list(range(r.P))
