@@ -242,21 +242,24 @@ int r3dg_shade_forward_transport(void* stream, int P, int K, const float* d_base
                                  float* d_out);
 /* Relighting under a light that TURNS WITH EVERY FRAME (relighting.py:160-161 with configs/nerf_syn_light or configs/tnt
  * light_transform.json) and static Gaussians: the "split transport" cache holds what does NOT depend on the light --
- *   d_lt [K,P,4]: per sample (max(SH_incident(d), 0) * a, a) with a = area * max(n . d, 0);  d_vis_t [K,P]: the visibility;
+ *   d_lt [K,P,4]: per sample (max(SH_incident(d), 0) * a, a) with a = area * max(n . d, 0);  d_vis_t [K/4,P,4]: the visibility
+ *   (K % 4 == 0);
  *   d_consts [P,4]: mean local light, mean visibility
  * sample-major and in the order d_perm [P] lists the Gaussians (the caller sorts them by normal: all lanes of a wave then look up
  * neighbouring texels) -- and r3dg_shade_forward_split evaluates, per frame, the lat-long lookup of the rotated direction
- * (d_env4: the map as float4 texels, r3dg_shade_pad_env), the transport and the GGX lobe: the 19 columns of r3dg_shade_forward
+ * (d_env_footprints: the map as 48-byte bilinear footprints, r3dg_shade_env_footprints into r3dg_shade_env_footprints_bytes(He, We)
+ * bytes: a lookup is three 16-byte loads of one record instead of four gathers), the transport and the GGX lobe: the 19 columns of r3dg_shade_forward
  * for 16 incident-light coefficients, a uniform sample area and Fibonacci directions (d_incident_dirs, or NULL to regenerate them
  * from the normals and d_zsamples as the cache was generated). */
 int r3dg_shade_build_split(void* stream, int P, int K, const int32_t* d_perm, const float* d_normals, const float* d_incidents,
                            const float* d_visibility, const float* d_incident_dirs, const float* d_zsamples,
                            float uniform_area, float* d_lt, float* d_vis_t, float* d_consts);
-int r3dg_shade_pad_env(void* stream, int He, int We, const float* d_env, float* d_env4);
+size_t r3dg_shade_env_footprints_bytes(int He, int We);
+int r3dg_shade_env_footprints(void* stream, int He, int We, const float* d_env, float* d_env_footprints);
 int r3dg_shade_forward_split(void* stream, int P, int K, const int32_t* d_perm, const float* d_base_color,
                              const float* d_roughness, const float* d_normals, const float* d_viewdirs, const float* d_lt,
                              const float* d_vis_t, const float* d_consts, const float* d_zsamples,
-                             const float* d_env_transform, const float* d_env4, int He, int We, float* d_out);
+                             const float* d_env_transform, const float* d_env_footprints, int He, int We, float* d_out);
 /* ---- the same integral over a FIXED RAY SET (csrc/shading_frs.hpp) -----------------------------------------------------------
  * For callers whose cached directions are the Fibonacci set rotated to each Gaussian's normal, d_k = normalize(R(n) z_k) --
  * what GaussianModel.update_visibility produces (scene/gaussian_model.py:312-342 -> utils/graphics_utils.py:9-37,

@@ -75,7 +75,8 @@ _SIGNATURES = {
     "r3dg_shade_build_transport": (_i, [_p, _i, _i, _i, _p, _p, _p, _p, _p, _f, _p, _p]),
     "r3dg_shade_forward_transport": (_i, [_p, _i, _i] + [_p] * 9),
     "r3dg_shade_build_split": (_i, [_p, _i, _i] + [_p] * 6 + [_f, _p, _p, _p]),
-    "r3dg_shade_pad_env": (_i, [_p, _i, _i, _p, _p]),
+    "r3dg_shade_env_footprints_bytes": (C.c_size_t, [_i, _i]),
+    "r3dg_shade_env_footprints": (_i, [_p, _i, _i, _p, _p]),
     "r3dg_shade_forward_split": (_i, [_p, _i, _i] + [_p] * 11 + [_i, _i, _p]),
     "r3dg_shade_backward": (_i, [_p, _i, _i, _i, _p, _p, _p, _p, _p, _p, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p,
                                  _p, _p]),

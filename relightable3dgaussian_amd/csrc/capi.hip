@@ -100,7 +100,7 @@ void launch_shade_forward_split(hipStream_t s, int P, int K, const int* perm, co
                                 const float* normals, const float* viewdirs, const float* lt, const float* vis_t,
                                 const float* consts, const float* zsamples, const float* tr, const float* env4, int He, int We,
                                 float* out);
-void launch_shade_pad_env(hipStream_t s, int ntexel, const float* env, float* env4);
+void launch_shade_env_footprints(hipStream_t s, int He, int We, const float* env, float* fp);
 void launch_shade_build_transport(hipStream_t s, int P, int K, int M, const float* normals, const float* incidents,
                                   const float* visibility, const float* dirs, const float* areas, float uniform_area,
                                   float* radiance_to_transport, float* consts);
@@ -1250,7 +1250,7 @@ int r3dg_shade_build_split(void* stream_, int P, int K, const int32_t* perm, con
                            const float* visibility, const float* incident_dirs, const float* zsamples, float uniform_area,
                            float* lt, float* vis_t, float* consts)
 {
-    if (P < 0 || K <= 0) return invalid("shade_build_split: bad P/K");
+    if (P < 0 || K <= 0 || (K % 4) != 0) return invalid("shade_build_split: bad P/K (K must be a multiple of 4)");
     if (P == 0) return R3DG_OK;
     if (!perm || !normals || !incidents || !visibility || (!incident_dirs && !zsamples) || !lt || !vis_t || !consts)
         return invalid("shade_build_split: null buffer");
@@ -1261,11 +1261,17 @@ int r3dg_shade_build_split(void* stream_, int P, int K, const int32_t* perm, con
     });
 }
 
-int r3dg_shade_pad_env(void* stream_, int He, int We, const float* env, float* env4)
+size_t r3dg_shade_env_footprints_bytes(int He, int We)
 {
-    if (He <= 0 || We <= 0 || He > 32767 || We > 32767 || !env || !env4) return invalid("shade_pad_env: bad size or null buffer");
+    return He > 0 && We > 0 ? (size_t)(He + 1) * (size_t)(We + 1) * 48 : 0;
+}
+
+int r3dg_shade_env_footprints(void* stream_, int He, int We, const float* env, float* footprints)
+{
+    if (He <= 0 || We <= 0 || He > 4095 || We > 4095 || !env || !footprints)
+        return invalid("shade_env_footprints: bad size or null buffer");
     return guarded([&]() -> int {
-        launch_shade_pad_env((hipStream_t)stream_, He * We, env, env4);
+        launch_shade_env_footprints((hipStream_t)stream_, He, We, env, footprints);
         return R3DG_OK;
     });
 }
@@ -1275,7 +1281,8 @@ int r3dg_shade_forward_split(void* stream_, int P, int K, const int32_t* perm, c
                              const float* consts, const float* zsamples, const float* env_transform, const float* env4, int He,
                              int We, float* out)
 {
-    if (P < 0 || K <= 0 || He <= 0 || We <= 0 || He > 32767 || We > 32767) return invalid("shade_forward_split: bad sizes");
+    if (P < 0 || K <= 0 || (K % 4) != 0 || He <= 0 || We <= 0 || He > 4095 || We > 4095)
+        return invalid("shade_forward_split: bad sizes (K must be a multiple of 4)");
     if (P == 0) return R3DG_OK;
     if (!perm || !base_color || !roughness || !normals || !viewdirs || !lt || !vis_t || !consts || !zsamples || !env4 || !out)
         return invalid("shade_forward_split: null buffer");

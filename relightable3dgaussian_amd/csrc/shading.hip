@@ -1359,21 +1359,30 @@ void launch_shade_build_split(hipStream_t s, int P, int K, const int* perm, cons
 
 void launch_shade_forward_split(hipStream_t s, int P, int K, const int* perm, const float* base_color, const float* roughness,
                                 const float* normals, const float* viewdirs, const float* lt, const float* vis_t,
-                                const float* consts, const float* zsamples, const float* tr, const float* env4, int He, int We,
+                                const float* consts, const float* zsamples, const float* tr, const float* env_fp, int He, int We,
                                 float* out)
 {
     if (P == 0) return;
-    shade_forward_split_kernel<<<(P + 255) / 256, 256, 0, s>>>(P, K, perm, base_color, roughness, normals, viewdirs,
-                                                             reinterpret_cast<const float4*>(lt), vis_t, consts, zsamples, tr,
-                                                             reinterpret_cast<const float4*>(env4), He, We, out);
+    // sample range split into parts (shading_split.hpp): ~12+ waves per SIMD in the launch, parts a multiple of 4 samples long
+    const int waves = (P + 63) / 64;
+    int parts = (12 * 4 * shade_cus() + waves - 1) / waves;
+    parts = parts < 1 ? 1 : (parts > 8 ? 8 : parts);
+    int Kp = ((K + parts - 1) / parts + 3) & ~3;
+    parts = (K + Kp - 1) / Kp;
+    float4* partial = reinterpret_cast<float4*>(stream_scratch(s, 1, (size_t)parts * P * 3 * sizeof(float4)));
+    const dim3 grid((P + 255) / 256, parts);
+    shade_forward_split_kernel<<<grid, 256, 0, s>>>(P, K, Kp, perm, base_color, roughness, normals, viewdirs,
+                                                   reinterpret_cast<const float4*>(lt), vis_t, zsamples, tr,
+                                                   reinterpret_cast<const float4*>(env_fp), He, We, partial);
+    shade_split_combine_kernel<<<(P + 255) / 256, 256, 0, s>>>(P, K, parts, perm, base_color, partial, consts, out);
     check_launch(s, false, "shade_forward_split_kernel");
 }
 
-void launch_shade_pad_env(hipStream_t s, int ntexel, const float* env, float* env4)
+void launch_shade_env_footprints(hipStream_t s, int He, int We, const float* env, float* fp)
 {
-    if (ntexel <= 0) return;
-    shade_pad_env_kernel<<<(ntexel + 255) / 256, 256, 0, s>>>(ntexel, env, reinterpret_cast<float4*>(env4));
-    check_launch(s, false, "shade_pad_env_kernel");
+    const int n = (He + 1) * (We + 1);
+    shade_env_footprints_kernel<<<(n + 255) / 256, 256, 0, s>>>(He, We, env, reinterpret_cast<float4*>(fp));
+    check_launch(s, false, "shade_env_footprints_kernel");
 }
 
 void launch_shade_build_transport(hipStream_t s, int P, int K, int M, const float* normals, const float* incidents,

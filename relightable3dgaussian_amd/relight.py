@@ -74,6 +74,7 @@ class RelightRenderer:
         self._area_key, self._uniform_area = None, None
         self._consts = self._zsamples = None
         self._split = None                          # split-transport cache of a light that turns with every frame (_split_cache)
+        self._order_stream = None                   # the instance ordering of a frame runs there, beside the shading kernel
         d = lambda t: t.detach().clone().contiguous()       # a snapshot: the caches below are only valid for THESE values
         self.xyz, self.normal = d(model.xyz), d(model.normal)
         self.scaling, self.rotation, self.opacity = d(model.scaling), d(model.rotation), d(model.opacity)
@@ -97,6 +98,9 @@ class RelightRenderer:
         self.a_viewdirs = torch.empty(P, 3, **f)
         self.shade_out = torch.empty(P, shading_ops.NOUT, **f)
         self.features = torch.empty(P, 28, **f)
+        if dev.type == "cuda" and torch.cuda.is_available():
+            from .fused_step import shared_stream
+            self._order_stream = shared_stream(dev, "order")
         with torch.no_grad():
             self._activate(torch.zeros(3, device=dev))
             self.visibility, self.incident_dirs, self.incident_areas, self.tracer = update_visibility(
@@ -164,23 +168,23 @@ class RelightRenderer:
         if self._split is not None:
             return self._split or None
         self._split = False
-        if self.M != 16 or self._uniform_area is None:
+        if self.M != 16 or self._uniform_area is None or self.K % 4 != 0:
             return None
         P, K, dev = self.P, self.K, self.dev
         f = dict(dtype=torch.float32, device=dev)
         perm = normal_order(self.a_normal)
-        lt, vis_t, consts = torch.empty(K, P, 4, **f), torch.empty(K, P, **f), torch.empty(P, 4, **f)
+        lt, vis_t, consts = torch.empty(K, P, 4, **f), torch.empty(K // 4, P, 4, **f), torch.empty(P, 4, **f)
         zs = sampling.fibonacci_z_samples(K, dev)[0].t().contiguous()
         He, We = self.envmap.shape[0], self.envmap.shape[1]
-        env4 = torch.empty(He, We, 4, **f)
+        env4 = torch.empty(int(_lib.lib().r3dg_shade_env_footprints_bytes(He, We)) // 4, **f)      # 48-byte bilinear footprints
         L = _lib.lib()
         with torch.cuda.device(dev):
             _lib.check(L.r3dg_shade_build_split(
                 _lib.current_stream(), P, K, perm.data_ptr(), self.a_normal.data_ptr(), self.incidents.data_ptr(),
                 self.visibility.data_ptr(), None if self.regenerate_dirs else self.incident_dirs.data_ptr(), zs.data_ptr(),
                 float(self._uniform_area), lt.data_ptr(), vis_t.data_ptr(), consts.data_ptr()), "shade_build_split")
-            _lib.check(L.r3dg_shade_pad_env(_lib.current_stream(), He, We, self.envmap.data_ptr(), env4.data_ptr()),
-                       "shade_pad_env")
+            _lib.check(L.r3dg_shade_env_footprints(_lib.current_stream(), He, We, self.envmap.data_ptr(), env4.data_ptr()),
+                       "shade_env_footprints")
         self._split = dict(perm=perm, lt=lt, vis_t=vis_t, consts=consts, zsamples=zs, env4=env4)
         return self._split
 
@@ -220,6 +224,13 @@ class RelightRenderer:
         stream = _lib.current_stream
         with torch.cuda.device(dev):
             self._activate(campos)
+            # The rasterizer's front end depends on the camera and the geometry only: its projection is queued NOW, and
+            # finish() below puts the instance ordering on the ordering stream -- both run beside the shading kernel instead of
+            # behind it (the feature rows, which the shading produces, are first read by the tile kernel inside finish()).
+            pending = rasterizer_ops.rasterize_gaussians_begin(
+                bg, self.xyz, self.features, empty, self.a_opacity, self.a_scales, self.a_rot, 1.0, empty, vm,
+                cam.full_proj_transform, cam.tanfovx, cam.tanfovy, cam.cx, cam.cy, H, W, self.shs, 3, campos, False,
+                True, False, want_weights=False)                   # (a frame has no use for the per-Gaussian blend weights)
             # the lat-long lookups of the cached directions are constant for a fixed light rotation: cached per transform
             taps = self._taps_for(tr, He, We, env_transform)
             if taps is not None and self.cache == "transport":
@@ -242,10 +253,7 @@ class RelightRenderer:
             _lib.check(L.r3dg_relight_pack_features(
                 stream(), P, self.xyz.data_ptr(), vm.data_ptr(), self.a_normal.data_ptr(), self.a_base.data_ptr(),
                 self.a_rough.data_ptr(), self.shade_out.data_ptr(), self.features.data_ptr()), "relight_pack_features")
-            fw = rasterizer_ops.rasterize_gaussians_begin(
-                bg, self.xyz, self.features, empty, self.a_opacity, self.a_scales, self.a_rot, 1.0, empty, vm,
-                cam.full_proj_transform, cam.tanfovx, cam.tanfovy, cam.cx, cam.cy, H, W, self.shs, 3, campos, False,
-                True, False, want_weights=False).finish()          # (a frame has no use for the per-Gaussian blend weights)
+            fw = pending.finish(self._order_stream)
             R, n_contrib, image, opacity, depth, feature, pseudo_normal, sxyz, weights, radii = fw[:10]
             res = dict(num_rendered=R, num_contrib=n_contrib, render=image, opacity=opacity, depth=depth, feature=feature,
                        pseudo_normal=pseudo_normal, surface_xyz=sxyz, radii=radii)

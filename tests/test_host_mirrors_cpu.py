@@ -188,7 +188,7 @@ def test_relight_renderer_host_logic_with_a_recording_library(monkeypatch):
         is_cuda = property(lambda self: True)
 
     dt = lambda t: t.as_subclass(DeviceTensor)
-    P, K = 7, 5
+    P, K = 7, 8
     monkeypatch.setattr(_lib, "lib", lambda: Recorder())
     monkeypatch.setattr(_lib, "current_stream", lambda: 0)
     import contextlib
@@ -200,7 +200,7 @@ def test_relight_renderer_host_logic_with_a_recording_library(monkeypatch):
                         built.append(tr) or torch.zeros(P * K * 3))
     z = torch.zeros
     class _Pending:
-        def finish(self):
+        def finish(self, ordering_stream=None):
             return (3, z(1), z(3, 4, 4), z(1, 4, 4), z(1, 4, 4), z(28, 4, 4), z(3, 4, 4), z(3, 4, 4), None, z(P))
     wanted = []
     monkeypatch.setattr(rasterizer_ops, "rasterize_gaussians_begin",

@@ -67,7 +67,7 @@ def test_a_light_that_turns_every_frame_takes_the_split_transport_and_a_stopped_
     (relighting.py:162-163 with a light_transform.json) stops building it from the second consecutive change on: the
     light-INDEPENDENT half of the transport is cached once (r3dg_shade_build_split) and the per-frame kernel looks the rotated
     directions up itself (r3dg_shade_forward_split, lane = Gaussian in normal order); a light that stops gets its cache back.
-    All frames -- and all 19 shading columns -- equal the PyTorch-glue frame / the general kernel."""
+    All frames equal the PyTorch-glue frame, all 19 shading columns the float64 oracle."""
     import math
     from relightable3dgaussian_amd import relight, shading_ops as so, synthetic as syn
     from relightable3dgaussian_amd.bench_core import GaussianParams
@@ -87,15 +87,24 @@ def test_a_light_that_turns_every_frame_takes_the_split_transport_and_a_stopped_
         got = r.frame(cam, bg, env_transform=tr, outputs=("pbr_env",))
         cached.append(r._taps_key == r._light_key)
         split.append(bool(r._split))
-        # the 19 shading columns against the general kernel on the cached directions (lookup in the kernel)
-        want_cols = so.shade_forward(r.a_base, r.a_rough, r.a_normal, r.a_viewdirs, r.incidents, r.envmap, r.visibility,
-                                     r.incident_dirs, r.incident_areas, env_transform=tr)
-        for c0, c1, name, tol in ((0, 3, "pbr", 2e-4), (3, 6, "diffuse_light", 2e-5), (6, 9, "specular", 2e-4),
-                                  (9, 18, "lights", 2e-5), (18, 19, "vis", 2e-5)):
-            ok, msg = report(name, r.shade_out[:, c0:c1], want_cols[:, c0:c1], tol, 1e-6)
+        # the 19 shading columns against the float64 oracle (oracle/shading.py, pinned to the reference's rendering_equation and
+        # EnvLight.direct_light) on the cached directions, with the tolerances of tests/test_shading_gpu.py
+        from oracle import shading
+        c64 = lambda t: t.detach().double().cpu()
+        ref = shading.rendering_equation(c64(r.a_base), c64(r.a_rough), c64(r.a_normal), c64(r.a_viewdirs), c64(r.incidents),
+                                         c64(r.envmap), c64(r.visibility), c64(r.incident_dirs), c64(r.incident_areas), c64(tr))
+        # (pbr / specular: 1e-3 here -- with regenerate_dirs the directions are rebuilt from the normal, 1e-7 off the cached
+        # ones the oracle sees, K is only 20 and the synthetic roughness goes down to 0.09, where the GGX lobe amplifies a
+        # direction error by 2 / alpha^2 = 3e4: observed 6e-4 on 2 of 9003 entries)
+        for c0, name, tol in ((0, "pbr", 1e-3), (3, "diffuse_light", 1e-4), (6, "specular", 1e-3), (9, "incident_lights", 1e-4),
+                              (12, "local_incident_lights", 1e-4), (15, "global_incident_lights", 1e-4)):
+            ok, msg = report(name, r.shade_out[:, c0:c0 + 3], ref[name], tol, 1e-6)
             assert ok, msg
+        ok, msg = report("incident_visibility", r.shade_out[:, 18:19], ref["incident_visibility"], 1e-4, 1e-6)
+        assert ok, msg
         want = relight.frame_reference(r, cam, bg, env_transform=tr, exact_activations=True)
-        for k, rtol, atol in (("feature", 2e-4, 1e-6), ("pbr_env", 0.0, 4e-4)):
+        # (frame_reference shades with the general HIP op: two fp32 evaluations of the ill-conditioned GGX term)
+        for k, rtol, atol in (("feature", 1e-3, 1e-6), ("pbr_env", 0.0, 4e-4)):
             ok, msg = report(k, got[k], want[k], rtol, atol)
             assert ok, msg
     assert cached == [True, False, False, False, True, True], cached
