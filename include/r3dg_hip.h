@@ -463,6 +463,13 @@ int r3dg_stage2_smooth_backward(void* stream, int width, int height, const float
                                 const int32_t* d_n_contrib, const float* d_image_mask, const float* d_scratch,
                                 float w_base_color, float w_roughness, float w_light, int accumulate_normal,
                                 float* d_dL_dopacity, float* d_dL_dfeature);
+/* _forward + _backward as ONE kernel over 32 x 8 pixel tiles held in LDS (the divided maps, the stencil outputs and the
+ * adjoint inputs never exist in HBM: no d_scratch): same arithmetic, same outputs (d_sums3 += the three unweighted sums,
+ * d_dL_dopacity added to, d_dL_dfeature maps written / added to as described above). */
+int r3dg_stage2_smooth_fused(void* stream, int width, int height, const float* d_opacity, const float* d_feature,
+                             const int32_t* d_n_contrib, const float* d_gt, const float* d_image_mask, float w_base_color,
+                             float w_roughness, float w_light, int accumulate_normal, float* d_dL_dopacity,
+                             float* d_dL_dfeature, float* d_sums3);
 /* sRGB-mapped PBR image [3,HW] exactly as r3dg_stage2_loss forms it (input of the SSIM term on the PBR image). */
 int r3dg_stage2_pbr_srgb(void* stream, int width, int height, const float* d_opacity, const float* d_feature,
                          const int32_t* d_n_contrib, const float* d_background, float* d_srgb);

@@ -92,6 +92,7 @@ _SIGNATURES = {
     "r3dg_stage2_loss": (_i, [_p, _i, _i] + [_p] * 8 + [_f, _f, _f] + [_p] * 6 + [_i]),
     "r3dg_stage2_smooth_forward": (_i, [_p, _i, _i] + [_p] * 5 + [_f, _f, _f, _p, _p]),
     "r3dg_stage2_smooth_backward": (_i, [_p, _i, _i] + [_p] * 5 + [_f, _f, _f, _i, _p, _p]),
+    "r3dg_stage2_smooth_fused": (_i, [_p, _i, _i] + [_p] * 5 + [_f, _f, _f, _i, _p, _p, _p]),
     "r3dg_stage2_pbr_srgb": (_i, [_p, _i, _i] + [_p] * 5),
     "r3dg_ssim_forward": (_i, [_p, _i, _i, _i, _p, _p, _p, _p]),
     "r3dg_ssim_backward": (_i, [_p, _i, _i, _i, _p, _p, _p, _f, _p]),

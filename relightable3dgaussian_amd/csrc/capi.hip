@@ -150,6 +150,9 @@ void launch_s2_loss(hipStream_t s, int HW, const float* image, const float* opac
 void launch_s2_smooth_forward(hipStream_t s, int W, int H, const float* opacity, const float* feature, const int* n_contrib,
                               const float* gt, const float* image_mask, float w_base, float w_rough, float w_light,
                               float* scratch, float* sums3);
+void launch_s2_smooth_fused(hipStream_t s, int W, int H, const float* opacity, const float* feature, const int* n_contrib,
+                            const float* gt, const float* image_mask, float w_base, float w_rough, float w_light,
+                            int accumulate_normal, float* dL_dopacity, float* dL_dfeature, float* sums3);
 void launch_s2_smooth_backward(hipStream_t s, int W, int H, const float* opacity, const float* feature, const int* n_contrib,
                                const float* image_mask, const float* scratch, int has_base, int has_rough, int has_light,
                                int accumulate_normal, float* dL_dopacity, float* dL_dfeature);
@@ -1725,6 +1728,23 @@ int r3dg_stage2_smooth_backward(void* stream_, int width, int height, const floa
         launch_s2_smooth_backward((hipStream_t)stream_, width, height, opacity, feature, n_contrib, image_mask, scratch,
                                   w_base_color != 0.f, w_roughness != 0.f, w_light != 0.f, accumulate_normal, dL_dopacity,
                                   dL_dfeature);
+        return R3DG_OK;
+    });
+}
+
+int r3dg_stage2_smooth_fused(void* stream_, int width, int height, const float* opacity, const float* feature,
+                             const int32_t* n_contrib, const float* gt, const float* image_mask, float w_base_color,
+                             float w_roughness, float w_light, int accumulate_normal, float* dL_dopacity, float* dL_dfeature,
+                             float* sums3)
+{
+    if (width < 0 || height < 0) return invalid("stage2_smooth_fused: bad image size");
+    if ((long long)width * height == 0) return R3DG_OK;
+    if (!opacity || !feature || !n_contrib || !gt || !dL_dopacity || !dL_dfeature || !sums3)
+        return invalid("stage2_smooth_fused: null buffer");
+    return guarded([&]() -> int {
+        StageTimer t((hipStream_t)stream_, ST_S2_LOSS);
+        launch_s2_smooth_fused((hipStream_t)stream_, width, height, opacity, feature, n_contrib, gt, image_mask, w_base_color,
+                               w_roughness, w_light, accumulate_normal, dL_dopacity, dL_dfeature, sums3);
         return R3DG_OK;
     });
 }

@@ -745,6 +745,212 @@ s2_smooth_backward_kernel(int W, int H, const float* __restrict__ opacity, const
     }
 }
 
+// ---- the three passes above as ONE kernel over LDS tiles (round 4) ------------------------------------------------------------
+// maps -> edge -> backward move, per pixel, 10 divided maps out and back in, 20 adjoint inputs out and -- nine times, through the
+// caches -- back in: 0.41 ms of the 2.0 ms DTU iteration (1600x1200).  None of that has to exist in HBM: a
+// workgroup owns a 32 x 8 pixel tile and
+//   (1) builds the ten divided / masked / sRGB-mapped maps and the three target channels for the tile + a halo of 2 in LDS,
+//       replicate padding resolved here (a cell outside the image holds the clamped pixel's value);
+//   (2) evaluates the Sobel stencils for the tile + a halo of 1 and leaves the 20 adjoint inputs in LDS (the loss sums count
+//       the tile's own pixels only);
+//   (3) gathers the adjoint for its own pixels from LDS and applies the chain rule -- the same arithmetic, expression for
+//       expression, as the three kernels, which stay as the reference formulation (r3dg_stage2_smooth_forward / _backward: the
+//       parity tests run both).
+constexpr int SM_TX = 32, SM_TY = 8;
+constexpr int SM_IW = SM_TX + 4, SM_IH = SM_TY + 4;      // inputs: halo 2
+constexpr int SM_EW = SM_TX + 2, SM_EH = SM_TY + 2;      // adjoint inputs: halo 1
+
+__global__ void __launch_bounds__(256)
+s2_smooth_fused_kernel(int W, int H, const float* __restrict__ opacity, const float* __restrict__ feature,
+                       const int* __restrict__ n_contrib, const float* __restrict__ gt, const float* __restrict__ image_mask,
+                       float w_base, float w_rough, float w_light, int accumulate_normal, float* __restrict__ dL_dopacity,
+                       float* __restrict__ dL_dfeature, float* __restrict__ sums3)
+{
+    __shared__ float s_in[13][SM_IH][SM_IW];             // rend 0..9 (layout of s2_smooth_maps_kernel), target 10..12
+    __shared__ float s_edge[20][SM_EH][SM_EW];
+    __shared__ float s_part[4];
+    const size_t HW = (size_t)W * H;
+    const int tx0 = blockIdx.x * SM_TX, ty0 = blockIdx.y * SM_TY;
+    const int tid = threadIdx.x;
+    // (1)  (both cells of a thread are requested before either is used: as a plain loop the second cell's 15 loads wait for the
+    //       first cell's arithmetic)
+    {
+        constexpr int NCELL = (SM_IH * SM_IW + 255) / 256;
+        float raw[NCELL][13], sc[NCELL], mk[NCELL];
+#pragma unroll
+        for (int it = 0; it < NCELL; it++) {
+            const int idx = min(tid + it * 256, SM_IH * SM_IW - 1);
+            const int ly = idx / SM_IW, lx = idx - ly * SM_IW;
+            const int gy = min(max(ty0 - 2 + ly, 0), H - 1), gx = min(max(tx0 - 2 + lx, 0), W - 1);
+            const size_t i = (size_t)gy * W + gx;
+            sc[it] = n_contrib[i] > 0 ? opacity[i] : -1.f;
+            mk[it] = image_mask ? image_mask[i] : 1.f;
+#pragma unroll
+            for (int c = 0; c < 10; c++) raw[it][c] = feature[(size_t)(5 + c) * HW + i];
+#pragma unroll
+            for (int c = 0; c < 3; c++) raw[it][10 + c] = gt[(size_t)c * HW + i];
+        }
+#pragma unroll
+        for (int it = 0; it < NCELL; it++) {
+            const int idx = tid + it * 256;
+            if (idx < SM_IH * SM_IW) {
+                const int ly = idx / SM_IW, lx = idx - ly * SM_IW;
+                const float scale = sc[it] >= 0.f ? 1.f / fmaxf(sc[it], 1e-5f) : 0.f;
+#pragma unroll
+                for (int c = 0; c < 7; c++) {
+                    const float x = raw[it][3 + c] * scale;
+                    s_in[c][ly][lx] = (c == 3 ? x : srgb_clip(x)) * mk[it];
+                }
+#pragma unroll
+                for (int c = 0; c < 3; c++) {
+                    s_in[7 + c][ly][lx] = raw[it][c] * scale;
+                    s_in[10 + c][ly][lx] = raw[it][10 + c];
+                }
+            }
+        }
+    }
+    __syncthreads();
+    // (2)
+    auto sobel = [&](int map, int cy, int cx, float& gx_, float& gy_) {
+        const float v00 = s_in[map][cy - 1][cx - 1], v01 = s_in[map][cy - 1][cx], v02 = s_in[map][cy - 1][cx + 1];
+        const float v10 = s_in[map][cy][cx - 1], v12 = s_in[map][cy][cx + 1];
+        const float v20 = s_in[map][cy + 1][cx - 1], v21 = s_in[map][cy + 1][cx], v22 = s_in[map][cy + 1][cx + 1];
+        gx_ = ((v02 - v00) + 2.f * (v12 - v10) + (v22 - v20)) * 0.125f;
+        gy_ = ((v20 - v00) + 2.f * (v21 - v01) + (v22 - v02)) * 0.125f;
+    };
+    float a_base = 0.f, a_rough = 0.f, a_light = 0.f;
+    for (int idx = tid; idx < SM_EH * SM_EW; idx += 256) {
+        const int ey = idx / SM_EW, ex_ = idx - ey * SM_EW;
+        const int gy = ty0 - 1 + ey, gx = tx0 - 1 + ex_;
+        if (gy < 0 || gy >= H || gx < 0 || gx >= W) continue;                  // (never read: the adjoint skips them too)
+        const bool own = ey >= 1 && ey <= SM_TY && ex_ >= 1 && ex_ <= SM_TX;    // this tile's pixel: counted in the sums
+        const int cy = ey + 1, cx = ex_ + 1;
+        float ex[3], ey3[3];
+        if (w_base != 0.f || w_rough != 0.f) {
+#pragma unroll
+            for (int c = 0; c < 3; c++) {
+                float gx1, gy1;
+                sobel(10 + c, cy, cx, gx1, gy1);
+                ex[c] = __expf(-fabsf(gx1));
+                ey3[c] = __expf(-fabsf(gy1));
+            }
+        }
+        if (w_base != 0.f) {
+#pragma unroll
+            for (int c = 0; c < 3; c++) {
+                float dx, dy;
+                sobel(c, cy, cx, dx, dy);
+                if (own) a_base += fabsf(dx) * ex[c] + fabsf(dy) * ey3[c];
+                s_edge[2 * c][ey][ex_] = w_base * signf_(dx) * ex[c];
+                s_edge[2 * c + 1][ey][ex_] = w_base * signf_(dy) * ey3[c];
+            }
+        }
+        if (w_rough != 0.f) {
+            float dx, dy;
+            sobel(3, cy, cx, dx, dy);
+            const float sx = ex[0] + ex[1] + ex[2], sy = ey3[0] + ey3[1] + ey3[2];
+            if (own) a_rough += fabsf(dx) * sx + fabsf(dy) * sy;
+            s_edge[6][ey][ex_] = w_rough * signf_(dx) * sx;
+            s_edge[7][ey][ex_] = w_rough * signf_(dy) * sy;
+        }
+        if (w_light != 0.f) {
+#pragma unroll
+            for (int c = 0; c < 3; c++) {
+                float dx, dy, nx, ny;
+                sobel(4 + c, cy, cx, dx, dy);
+                sobel(7 + c, cy, cx, nx, ny);
+                const float gx1 = __expf(-fabsf(nx)), gy1 = __expf(-fabsf(ny));
+                if (own) a_light += fabsf(dx) * gx1 + fabsf(dy) * gy1;
+                s_edge[8 + 2 * c][ey][ex_] = w_light * signf_(dx) * gx1;
+                s_edge[9 + 2 * c][ey][ex_] = w_light * signf_(dy) * gy1;
+                s_edge[14 + 2 * c][ey][ex_] = -w_light * fabsf(dx) * gx1 * signf_(nx);
+                s_edge[15 + 2 * c][ey][ex_] = -w_light * fabsf(dy) * gy1 * signf_(ny);
+            }
+        }
+    }
+    __syncthreads();
+    // (3)
+    const int ly = tid / SM_TX, lx = tid - ly * SM_TX;
+    const int y = ty0 + ly, x = tx0 + lx;
+    if (y < H && x < W) {
+        const size_t i = (size_t)y * W + x;
+        float d[10];
+#pragma unroll
+        for (int k = 0; k < 10; k++) d[k] = 0.f;
+#pragma unroll
+        for (int a = -1; a <= 1; a++) {
+            const int qy = y + a;
+            if (qy < 0 || qy >= H) continue;
+            const float sy = s1_adj1(qy, y, H, 1.f, 2.f, 1.f), dy = s1_adj1(qy, y, H, -1.f, 0.f, 1.f);
+#pragma unroll
+            for (int b = -1; b <= 1; b++) {
+                const int qx = x + b;
+                if (qx < 0 || qx >= W) continue;
+                const float sx = s1_adj1(qx, x, W, 1.f, 2.f, 1.f), dx = s1_adj1(qx, x, W, -1.f, 0.f, 1.f);
+                const float wx = sy * dx * 0.125f, wy = dy * sx * 0.125f;
+                const int qe = ly + 1 + a, qf = lx + 1 + b;
+                if (w_base != 0.f) {
+#pragma unroll
+                    for (int c = 0; c < 3; c++) d[c] += wx * s_edge[2 * c][qe][qf] + wy * s_edge[2 * c + 1][qe][qf];
+                }
+                if (w_rough != 0.f) d[3] += wx * s_edge[6][qe][qf] + wy * s_edge[7][qe][qf];
+                if (w_light != 0.f) {
+#pragma unroll
+                    for (int c = 0; c < 3; c++) {
+                        d[4 + c] += wx * s_edge[8 + 2 * c][qe][qf] + wy * s_edge[9 + 2 * c][qe][qf];
+                        d[7 + c] += wx * s_edge[14 + 2 * c][qe][qf] + wy * s_edge[15 + 2 * c][qe][qf];
+                    }
+                }
+            }
+        }
+        const float op = opacity[i];
+        const bool mask = n_contrib[i] > 0;
+        const float opc = fmaxf(op, 1e-5f);
+        const float scale = mask ? 1.f / opc : 0.f;
+        const float dscale_dop = (mask && op >= 1e-5f) ? -1.f / (opc * opc) : 0.f;
+        const float m = image_mask ? image_mask[i] : 1.f;
+        float g_op = 0.f;
+        if (w_base != 0.f) {
+#pragma unroll
+            for (int c = 0; c < 3; c++) {
+                const float F = feature[(size_t)(8 + c) * HW + i];
+                const float g = d[c] * m * srgb_clip_derivative(F * scale);
+                dL_dfeature[(size_t)(8 + c) * HW + i] = g * scale;
+                g_op += g * F * dscale_dop;
+            }
+        }
+        if (w_rough != 0.f) {
+            const float g = d[3] * m;
+            dL_dfeature[(size_t)11 * HW + i] = g * scale;
+            g_op += g * feature[(size_t)11 * HW + i] * dscale_dop;
+        }
+        if (w_light != 0.f) {
+#pragma unroll
+            for (int c = 0; c < 3; c++) {
+                const float Fd = feature[(size_t)(12 + c) * HW + i];
+                const float g = d[4 + c] * m * srgb_clip_derivative(Fd * scale);
+                dL_dfeature[(size_t)(12 + c) * HW + i] = g * scale;
+                g_op += g * Fd * dscale_dop;
+                const float gn = d[7 + c];
+                const size_t o = (size_t)(5 + c) * HW + i;
+                dL_dfeature[o] = (accumulate_normal ? dL_dfeature[o] : 0.f) + gn * scale;
+                g_op += gn * feature[o] * dscale_dop;
+            }
+        }
+        dL_dopacity[i] += g_op;
+    }
+    const float t0 = block_sum_256(a_base, s_part);
+    __syncthreads();
+    const float t1 = block_sum_256(a_rough, s_part);
+    __syncthreads();
+    const float t2 = block_sum_256(a_light, s_part);
+    if (threadIdx.x == 0) {
+        atomicAdd(sum_slot(sums3 + 0 * R3DG_SUM_SLOTS), t0);
+        atomicAdd(sum_slot(sums3 + 1 * R3DG_SUM_SLOTS), t1);
+        atomicAdd(sum_slot(sums3 + 2 * R3DG_SUM_SLOTS), t2);
+    }
+}
+
 __global__ void __launch_bounds__(256)
 s1_activate_backward_kernel(int P, const float* __restrict__ xyz, const float* __restrict__ scaling_raw,
                             const float* __restrict__ rotation_raw, const float* __restrict__ opacity_raw,
@@ -956,6 +1162,16 @@ void launch_s2_smooth_backward(hipStream_t s, int W, int H, const float* opacity
         W, H, opacity, feature, n_contrib, image_mask, scratch + 10 * HW, has_base, has_rough, has_light, accumulate_normal,
         dL_dopacity, dL_dfeature);
     check_launch(s, false, "s2_smooth_backward_kernel");
+}
+
+void launch_s2_smooth_fused(hipStream_t s, int W, int H, const float* opacity, const float* feature, const int* n_contrib,
+                            const float* gt, const float* image_mask, float w_base, float w_rough, float w_light,
+                            int accumulate_normal, float* dL_dopacity, float* dL_dfeature, float* sums3)
+{
+    const dim3 grid((W + SM_TX - 1) / SM_TX, (H + SM_TY - 1) / SM_TY);
+    s2_smooth_fused_kernel<<<grid, 256, 0, s>>>(W, H, opacity, feature, n_contrib, gt, image_mask, w_base, w_rough, w_light,
+                                                accumulate_normal, dL_dopacity, dL_dfeature, sums3);
+    check_launch(s, false, "s2_smooth_fused_kernel");
 }
 
 void launch_s1_pack(hipStream_t s, int P, const float* xyz, const float* viewmatrix, const float* normal, float* features)

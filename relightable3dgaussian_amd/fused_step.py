@@ -603,16 +603,23 @@ class FusedStage2Step(_BoundedForward):
             active = [2, 3, 4] + ([5, 6, 7] if self.w["normal"] != 0.0 else [])
             w_bc, w_r, w_ls = (self.w[k] / (3.0 * N) for k in ("base_color_smooth", "roughness_smooth", "light_smooth"))
             if w_bc != 0.0 or w_r != 0.0 or w_ls != 0.0:
-                if self._smooth_scratch is None or self._smooth_scratch.numel() != 30 * N:
-                    self._smooth_scratch = torch.empty(30 * N, dtype=torch.float32, device=dev)
-                sc = self._smooth_scratch
-                _lib.check(L.r3dg_stage2_smooth_forward(
-                    stream(), W, H, opacity.data_ptr(), feature.data_ptr(), n_contrib.data_ptr(), gt_c.data_ptr(),
-                    _lib.ptr(mask_c), w_bc, w_r, w_ls, sc.data_ptr(), self.sums[7].data_ptr()), "stage2_smooth_forward")
-                _lib.check(L.r3dg_stage2_smooth_backward(
-                    stream(), W, H, opacity.data_ptr(), feature.data_ptr(), n_contrib.data_ptr(), _lib.ptr(mask_c),
-                    sc.data_ptr(), w_bc, w_r, w_ls, 1 if self.w["normal"] != 0.0 else 0, g[3:4].data_ptr(),
-                    g[4:20].data_ptr()), "stage2_smooth_backward")
+                if os.environ.get("R3DG_SMOOTH_FUSED", "1") != "0":
+                    # one kernel over LDS tiles: the divided maps and the adjoint inputs never exist in HBM
+                    _lib.check(L.r3dg_stage2_smooth_fused(
+                        stream(), W, H, opacity.data_ptr(), feature.data_ptr(), n_contrib.data_ptr(), gt_c.data_ptr(),
+                        _lib.ptr(mask_c), w_bc, w_r, w_ls, 1 if self.w["normal"] != 0.0 else 0, g[3:4].data_ptr(),
+                        g[4:20].data_ptr(), self.sums[7].data_ptr()), "stage2_smooth_fused")
+                else:                                      # (the three-kernel reference formulation: parity tests, A/B)
+                    if self._smooth_scratch is None or self._smooth_scratch.numel() != 30 * N:
+                        self._smooth_scratch = torch.empty(30 * N, dtype=torch.float32, device=dev)
+                    sc = self._smooth_scratch
+                    _lib.check(L.r3dg_stage2_smooth_forward(
+                        stream(), W, H, opacity.data_ptr(), feature.data_ptr(), n_contrib.data_ptr(), gt_c.data_ptr(),
+                        _lib.ptr(mask_c), w_bc, w_r, w_ls, sc.data_ptr(), self.sums[7].data_ptr()), "stage2_smooth_forward")
+                    _lib.check(L.r3dg_stage2_smooth_backward(
+                        stream(), W, H, opacity.data_ptr(), feature.data_ptr(), n_contrib.data_ptr(), _lib.ptr(mask_c),
+                        sc.data_ptr(), w_bc, w_r, w_ls, 1 if self.w["normal"] != 0.0 else 0, g[3:4].data_ptr(),
+                        g[4:20].data_ptr()), "stage2_smooth_backward")
                 active += ([8, 9, 10] if w_bc != 0.0 else []) + ([11] if w_r != 0.0 else [])
                 if w_ls != 0.0:
                     active += [12, 13, 14] + ([5, 6, 7] if self.w["normal"] == 0.0 else [])

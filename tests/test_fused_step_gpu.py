@@ -553,3 +553,48 @@ def test_option_contexts_keep_two_objects_apart():
         assert not s0._use_bounded(res, res)
     with s2._ctx:
         assert s2._use_bounded(res, res)
+
+
+@pytest.mark.parametrize("H,W", [(64, 64), (37, 50), (5, 7), (120, 161)])
+@pytest.mark.parametrize("weights,acc_normal,masked", [((1.0, 0.5, 1.0), 0, True), ((1.0, 0.0, 0.0), 0, False),
+                                                       ((0.0, 0.5, 1.0), 1, True), ((0.0, 0.0, 1.0), 1, False)])
+def test_fused_smoothness_kernel_equals_the_three_pass_formulation(H, W, weights, acc_normal, masked):
+    """r3dg_stage2_smooth_fused (one kernel over 32 x 8 LDS tiles: maps, stencils and adjoint never touch HBM) against
+    r3dg_stage2_smooth_forward + _backward -- the three-pass formulation that is pinned to the reference's calculate_loss
+    (tests/test_reference_pipeline_gpu.py::test_stage2_syn4_objective_matches_the_reference_python).  The per-pixel arithmetic
+    is the same, expression for expression: gradients bit-identical, the three sums up to the order of their float atomics;
+    image sizes that are not multiples of the tile, every border, every subset of the three terms."""
+    from relightable3dgaussian_amd import _lib
+    L = _lib.lib()
+    g = torch.Generator().manual_seed(H * 1000 + W)
+    N = H * W
+    opacity = torch.rand(1, H, W, generator=g).to(DEV)
+    opacity[0, : H // 4] *= 1e-6                                             # (the clamp of the division at 1e-5)
+    feature = (torch.rand(16, H, W, generator=g) * 1.5 - 0.2).to(DEV) * opacity
+    n_contrib = (torch.rand(H, W, generator=g) > 0.15).to(torch.int32).to(DEV)
+    gt = torch.rand(3, H, W, generator=g).to(DEV)
+    mask = torch.rand(1, H, W, generator=g).to(DEV) if masked else None
+    wb, wr, wl = (w / (3.0 * N) for w in weights)
+    s = _lib.current_stream()
+    outs = []
+    for fused in (False, True):
+        d_op = torch.full((1, H, W), 0.25, device=DEV)
+        d_f = torch.full((16, H, W), -3.0, device=DEV)
+        sums = torch.zeros(3, 32, device=DEV)
+        args = (W, H, opacity.data_ptr(), feature.data_ptr(), n_contrib.data_ptr())
+        if fused:
+            _lib.check(L.r3dg_stage2_smooth_fused(s, *args, gt.data_ptr(), _lib.ptr(mask), wb, wr, wl, acc_normal, d_op.data_ptr(),
+                                                  d_f.data_ptr(), sums.data_ptr()), "smooth_fused")
+        else:
+            scratch = torch.empty(30 * N, device=DEV)
+            _lib.check(L.r3dg_stage2_smooth_forward(s, *args, gt.data_ptr(), _lib.ptr(mask), wb, wr, wl, scratch.data_ptr(),
+                                                    sums.data_ptr()), "smooth_forward")
+            _lib.check(L.r3dg_stage2_smooth_backward(s, *args, _lib.ptr(mask), scratch.data_ptr(), wb, wr, wl, acc_normal,
+                                                     d_op.data_ptr(), d_f.data_ptr()), "smooth_backward")
+        torch.cuda.synchronize()
+        outs.append((d_op, d_f, sums.sum(1)))
+    (o0, f0, s0), (o1, f1, s1) = outs
+    assert torch.equal(f0, f1), "feature gradient maps differ: max %g" % float((f0 - f1).abs().max())
+    assert torch.equal(o0, o1), "opacity gradient differs"
+    assert torch.allclose(s0, s1, rtol=2e-5, atol=1e-6), (s0, s1)
+    assert float(f1.abs().max()) > 0 and bool((f1[0:5] == -3.0).all())       # untouched maps stay untouched
