@@ -607,7 +607,14 @@ tile_sort_long_kernel(const uint32_t* __restrict__ big_list, uint32_t* __restric
     }
 }
 
-constexpr uint32_t TILE_SORT_SMALL_CAP = 4096;     // 32 KB of LDS per workgroup
+// Tiles up to this many entries take the bitonic network in LDS (x 8 bytes per workgroup), longer ones the segmented radix sort.
+// 4096 (rounds 2-3): a 2049..4096-entry tile pads to 4096 -- 78 dependent stages of 8 pairs per thread at 5 workgroups per CU --
+// and those tiles, dispatched first, set the kernel's length: 104.6 us at 300k Gaussians / 800x800.  2048: 80.9 us (16 KB of LDS,
+// 10 workgroups per CU; the ~10 % of tiles above it cost the radix kernel less than they cost the network); 1024: 87.0 us.
+#ifndef R3DG_TILE_SORT_SMALL_CAP
+#define R3DG_TILE_SORT_SMALL_CAP 2048
+#endif
+constexpr uint32_t TILE_SORT_SMALL_CAP = R3DG_TILE_SORT_SMALL_CAP;
 
 uint32_t tile_sort_small_cap() { return TILE_SORT_SMALL_CAP; }
 

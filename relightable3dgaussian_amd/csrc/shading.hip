@@ -1247,7 +1247,11 @@ void launch_shade_frs_forward_main(hipStream_t s, int P, int K, const float* bas
     // beside the instance ordering (fused iteration) ONE workgroup per CU: the ordering chain (projection -> binning -> tile sort) is
     // the longer of the two concurrent paths and every wave this kernel keeps resident slows it -- measured per CU cap: 1 -> 618-627,
     // 2 -> 598-610, 3 -> 597-607 it/s (this kernel alone 0.21 / 0.195 / 0.21 ms; a high-priority ordering stream: no effect)
-    if (leave_room) grid = grid > shade_cus() ? shade_cus() : grid;
+    // (R3DG_OPT_SHADE_FWD_BLOCKS_PER_CU > 0 replaces the 1 for A/B runs)
+    if (leave_room) {
+        const int per_cu = opt(R3DG_OPT_SHADE_FWD_BLOCKS_PER_CU) > 0 ? opt(R3DG_OPT_SHADE_FWD_BLOCKS_PER_CU) : 1;
+        grid = grid > per_cu * shade_cus() ? per_cu * shade_cus() : grid;
+    }
     const FrsSrc src = {base_color, roughness, normals, viewdirs, ray_normals, cprime, nullptr, nullptr, visibility, taps};
     shade_forward_frs_kernel<<<grid, 64 * FRS_WAVES, smem, s>>>(P, K, src, env, He, We, frs_area(uniform_area), tables, valid, out);
     check_launch(s, false, "shade_forward_frs_kernel");
