@@ -2,6 +2,7 @@
 // state-buffer layouts, error plumbing.  Mirrors CudaRasterizer::Rasterizer::forward/backward
 // (rasterizer_impl.cu:199-380, :384-491) in the order of work, not in code.
 #include "common.hpp"
+#include <cstdlib>
 #include <new>
 #include "../../include/r3dg_hip.h"
 
@@ -1494,13 +1495,17 @@ int r3dg_shade_frs_backward(void* stream_, int P, int K, const float* base_color
         // the kernel on the listed Gaussians goes FIRST (its rows of the per-Gaussian outputs are disjoint from the main
         // kernel's, the texture gradient is accumulated by both): a small launch that a caller can put beside whatever it has
         // running on another stream at this point (fused_step: the rasterizer's per-Gaussian geometry backward)
-        if (n_invalid > 0) {
+        // (measured the other way round, round 4: listed AFTER the main kernel lets the geometry backward and the SH group's Adam run
+        // into the main kernel's start instead -- shading backward 0.243 -> 0.355 ms, 687 -> 642 it/s)
+        auto listed = [&]() {
+            if (n_invalid <= 0) return;
             StageTimer t(stream, ST_SHADE_LISTED);
             launch_shade_frs_backward_listed(stream, K, base_color, roughness, normals, viewdirs, incidents, env, He, We,
                                              visibility, ray_normals, zsamples, uniform_area, invalid_list, n_invalid, dL_dpbr,
                                              dL_ddiffuse_light, dL_dbase_color, dL_droughness, dL_dviewdirs, dL_dincidents,
                                              dL_denv, gmax, gmax_n);
-        }
+        };
+        listed();
         {
             StageTimer t(stream, ST_SHADE_BWD);
             launch_shade_frs_backward_main(stream, P, K, base_color, roughness, normals, viewdirs, env, He, We, visibility,
