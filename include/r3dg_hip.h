@@ -463,8 +463,9 @@ int r3dg_stage2_smooth_backward(void* stream, int width, int height, const float
                                 const int32_t* d_n_contrib, const float* d_image_mask, const float* d_scratch,
                                 float w_base_color, float w_roughness, float w_light, int accumulate_normal,
                                 float* d_dL_dopacity, float* d_dL_dfeature);
-/* _forward + _backward as ONE kernel over 32 x 8 pixel tiles held in LDS (the divided maps, the stencil outputs and the
- * adjoint inputs never exist in HBM: no d_scratch): same arithmetic, same outputs (d_sums3 += the three unweighted sums,
+/* _forward + _backward as ONE kernel that streams the image through registers (lane = column, the wave walks down 60-column
+ * strips; neighbours by DPP lane shifts; the divided maps, the stencil outputs and the adjoint inputs never exist in HBM or
+ * LDS: no d_scratch): same arithmetic bit for bit, same outputs (d_sums3 += the three unweighted sums,
  * d_dL_dopacity added to, d_dL_dfeature maps written / added to as described above). */
 int r3dg_stage2_smooth_fused(void* stream, int width, int height, const float* d_opacity, const float* d_feature,
                              const int32_t* d_n_contrib, const float* d_gt, const float* d_image_mask, float w_base_color,
@@ -691,7 +692,7 @@ enum r3dg_option {
                                          * entry is evaluated; identical results */
     R3DG_OPT_TILE_BINNING,              /* instance ordering: 2 = direct tile binning + per-tile sort (default), 1 = radix partition by
                                          * tile + per-tile sort, 0 = the reference's one global radix sort; identical lists either way */
-    R3DG_OPT_BINNING_BLOCK_K,           /* direct binning: Gaussians per workgroup / 1024 (default 2) */
+    R3DG_OPT_BINNING_BLOCK_K,           /* direct binning: Gaussians per workgroup / 1024 (1..4, default 2) */
     R3DG_OPT_STAGE_SH_ROWS,             /* per-Gaussian kernels move SH / dL_dsh rows through LDS (1, default) or walk them in HBM (0) */
     R3DG_OPT_SHADE_FWD_BLOCKS_PER_CU,   /* persistent workgroups per CU of the general shading forward; 0 = as many as fit (default) */
     R3DG_OPT_TRACE_FORMULATION,         /* visibility trace: 4 = phase-separated persistent waves (default), 3 = persistent waves,

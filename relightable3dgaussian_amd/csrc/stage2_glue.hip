@@ -11,10 +11,19 @@
 //                                 SH image, L1 on the sRGB-mapped PBR image, normal-vs-pseudo-normal MSE)
 //   adam_kernel                   multi-group Adam step, all parameter groups in one launch (gaussian_model.py:465-497)
 // Parity target: the plain-PyTorch restatement in relightable3dgaussian_amd/train_step.py (Stage2Step), fp32 tolerance.
+#include <type_traits>
+
 #include "common.hpp"
 #include "r3dg_hip.h"
 
 namespace r3dg {
+
+// x^y for the sRGB curve (x >= 0.0031308): v_log_f32 * y -> v_exp_f32, 3 instructions and ~4 ulp.  HIP's __powf is the
+// full-precision library routine (~155 instructions, a software logarithm): 18 of them per pixel were three quarters of the
+// smoothness kernels' instructions and most of s2_pbr_srgb_kernel.  (torch.pow in the reference's rgb_to_srgb,
+// utils/graphics_utils.py, is itself good to ~2 ulp; the parity tolerances are 1e-5 and wider.)
+__device__ __forceinline__ float srgb_pow(float x, float y) { return __builtin_amdgcn_exp2f(y * __builtin_amdgcn_logf(x)); }
+
 
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + __expf(-x)); }
 
@@ -252,7 +261,7 @@ s2_pbr_srgb_kernel(int HW, const float* __restrict__ opacity, const float* __res
 #pragma unroll
     for (int c = 0; c < 3; c++) {
         const float x = feature[(size_t)(2 + c) * HW + i] * scale * op + (1.f - op) * bg[c];
-        const float v = x <= 0.0031308f ? 12.92f * x : 1.055f * __powf(fmaxf(x, 0.0031308f), 1.f / 2.4f) - 0.055f;
+        const float v = x <= 0.0031308f ? 12.92f * x : 1.055f * srgb_pow(fmaxf(x, 0.0031308f), 1.f / 2.4f) - 0.055f;
         srgb[(size_t)c * HW + i] = fminf(fmaxf(v, 0.f), 1.f);      // rgb_to_srgb clips (utils/graphics_utils.py:211-212)
     }
 }
@@ -297,12 +306,12 @@ s2_loss_kernel(int HW, const float* __restrict__ image, const float* __restrict_
             const float xs = fmaxf(x, 0.0031308f);
             // rgb_to_srgb with clip=True (utils/graphics_utils.py:207-213): the curve, then clamp to [0,1]; the clamp passes
             // the gradient only where 0 <= curve <= 1 (torch.clamp), so saturated HDR highlights stop pulling
-            const float curve = lin ? 12.92f * x : 1.055f * __powf(xs, 1.f / 2.4f) - 0.055f;
+            const float curve = lin ? 12.92f * x : 1.055f * srgb_pow(xs, 1.f / 2.4f) - 0.055f;
             const bool unclipped = curve >= 0.f && curve <= 1.f;
             const float srgb = fminf(fmaxf(curve, 0.f), 1.f);
             const float d1 = srgb - g;
             s_pbr += fabsf(d1);
-            const float dsrgb = !unclipped ? 0.f : (lin ? 12.92f : 1.055f / 2.4f * __powf(xs, 1.f / 2.4f - 1.f));
+            const float dsrgb = !unclipped ? 0.f : (lin ? 12.92f : 1.055f / 2.4f * srgb_pow(xs, 1.f / 2.4f - 1.f));
             const float gx = (w_pbr * signf_(d1) + (extra_dsrgb ? extra_dsrgb[(size_t)c * HW + i] : 0.f)) * dsrgb;   // dL/dx
             dL_dfeature[(size_t)(2 + c) * HW + i] = gx * op * scale;
             g_op += gx * (r - bg[c] + op * F * dscale_dop);
@@ -558,16 +567,90 @@ s1_loss_kernel(int W, int H, const float* __restrict__ image, const float* __res
 // rgb_to_srgb with clip=True (utils/graphics_utils.py:207-213) and its derivative (0 where the clamp is active)
 __device__ __forceinline__ float srgb_clip(float x)
 {
-    const float curve = x <= 0.0031308f ? 12.92f * x : 1.055f * __powf(fmaxf(x, 0.0031308f), 1.f / 2.4f) - 0.055f;
+    const float curve = x <= 0.0031308f ? 12.92f * x : 1.055f * srgb_pow(fmaxf(x, 0.0031308f), 1.f / 2.4f) - 0.055f;
     return fminf(fmaxf(curve, 0.f), 1.f);
 }
 __device__ __forceinline__ float srgb_clip_derivative(float x)
 {
     const bool lin = x <= 0.0031308f;
     const float xs = fmaxf(x, 0.0031308f);
-    const float curve = lin ? 12.92f * x : 1.055f * __powf(xs, 1.f / 2.4f) - 0.055f;
+    const float curve = lin ? 12.92f * x : 1.055f * srgb_pow(xs, 1.f / 2.4f) - 0.055f;
     if (!(curve >= 0.f && curve <= 1.f)) return 0.f;
-    return lin ? 12.92f : 1.055f / 2.4f * __powf(xs, 1.f / 2.4f - 1.f);
+    return lin ? 12.92f : 1.055f / 2.4f * srgb_pow(xs, 1.f / 2.4f - 1.f);
+}
+
+// One tap of the stencils' adjoint and the chain rule behind it, shared by the three formulations of the smoothness terms below
+// (three passes / LDS tiles / streamed): written with contraction off, so that the formulations agree bit for bit whatever
+// contraction the compiler would pick for a * b + c * d in each context.
+__device__ __forceinline__ float smooth_tap(float d, float wx, float ex, float wy, float ey)
+{
+#pragma clang fp contract(off)          // (HIP's __fmul_rn / __fadd_rn are inline operators that still fuse: this pins the roundings)
+    const float t = wx * ex;
+    const float u = __builtin_fmaf(wy, ey, t);
+    return d + u;
+}
+// d[0..9]: dL / d (rend 0..9) of s2_smooth_maps_kernel at one pixel; f[0..9]: feature 5..14 there.  gf[0..9]: dL / d feature 5..14
+// (normal 3 | base colour 3 | roughness | diffuse light 3; entries of absent terms untouched), returns dL / d opacity.
+__device__ __forceinline__ float smooth_chain(bool base, bool rough, bool light, const float (&d)[10], float op, int nc, float m,
+                                              const float (&f)[10], float (&gf)[10])
+{
+#pragma clang fp contract(off)
+    const bool mask = nc > 0;
+    const float opc = fmaxf(op, 1e-5f);
+    const float scale = mask ? 1.f / opc : 0.f;
+    const float dscale_dop = (mask && op >= 1e-5f) ? -1.f / (opc * opc) : 0.f;
+    float g_op = 0.f;
+    if (base) {
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+            const float F = f[3 + c];
+            const float g = d[c] * m * srgb_clip_derivative(F * scale);       // dL / d (linear base colour map)
+            gf[3 + c] = g * scale;
+            const float t = g * F * dscale_dop;
+            g_op = g_op + t;
+        }
+    }
+    if (rough) {
+        const float g = d[3] * m;
+        gf[6] = g * scale;
+        const float t = g * f[6] * dscale_dop;
+        g_op = g_op + t;
+    }
+    if (light) {
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+            const float Fd = f[7 + c];
+            const float g = d[4 + c] * m * srgb_clip_derivative(Fd * scale);   // dL / d (linear diffuse map)
+            gf[7 + c] = g * scale;
+            const float t = g * Fd * dscale_dop;
+            g_op = g_op + t;
+            const float gn = d[7 + c];
+            gf[c] = gn * scale;
+            const float u = gn * f[c] * dscale_dop;
+            g_op = g_op + u;
+        }
+    }
+    return g_op;
+}
+
+__device__ __forceinline__ void smooth_store(bool base, bool rough, bool light, int accumulate_normal, const float (&gf)[10],
+                                             size_t HW, size_t i, float* __restrict__ dL_dfeature)
+{
+#pragma clang fp contract(off)
+    if (base) {
+#pragma unroll
+        for (int c = 0; c < 3; c++) dL_dfeature[(size_t)(8 + c) * HW + i] = gf[3 + c];
+    }
+    if (rough) dL_dfeature[(size_t)11 * HW + i] = gf[6];
+    if (light) {
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+            dL_dfeature[(size_t)(12 + c) * HW + i] = gf[7 + c];
+            const size_t o = (size_t)(5 + c) * HW + i;
+            const float old = accumulate_normal ? dL_dfeature[o] : 0.f;
+            dL_dfeature[o] = old + gf[c];
+        }
+    }
 }
 
 __global__ void __launch_bounds__(256)
@@ -692,262 +775,261 @@ s2_smooth_backward_kernel(int W, int H, const float* __restrict__ opacity, const
                 const float sx = s1_adj1(qx, x, W, 1.f, 2.f, 1.f), dx = s1_adj1(qx, x, W, -1.f, 0.f, 1.f);
                 const float wx = sy * dx * 0.125f, wy = dy * sx * 0.125f;
                 const size_t q = (size_t)qy * W + qx;
+                auto E = [&](int k) { return edge[(size_t)k * HW + q]; };
                 if (has_base) {
 #pragma unroll
-                    for (int c = 0; c < 3; c++)
-                        d[c] += wx * edge[(size_t)(2 * c) * HW + q] + wy * edge[(size_t)(2 * c + 1) * HW + q];
+                    for (int c = 0; c < 3; c++) d[c] = smooth_tap(d[c], wx, E(2 * c), wy, E(2 * c + 1));
                 }
-                if (has_rough) d[3] += wx * edge[(size_t)6 * HW + q] + wy * edge[(size_t)7 * HW + q];
+                if (has_rough) d[3] = smooth_tap(d[3], wx, E(6), wy, E(7));
                 if (has_light) {
 #pragma unroll
                     for (int c = 0; c < 3; c++) {
-                        d[4 + c] += wx * edge[(size_t)(8 + 2 * c) * HW + q] + wy * edge[(size_t)(9 + 2 * c) * HW + q];
-                        d[7 + c] += wx * edge[(size_t)(14 + 2 * c) * HW + q] + wy * edge[(size_t)(15 + 2 * c) * HW + q];
+                        d[4 + c] = smooth_tap(d[4 + c], wx, E(8 + 2 * c), wy, E(9 + 2 * c));
+                        d[7 + c] = smooth_tap(d[7 + c], wx, E(14 + 2 * c), wy, E(15 + 2 * c));
                     }
                 }
             }
         }
-        const float op = opacity[i];
-        const bool mask = n_contrib[i] > 0;
-        const float opc = fmaxf(op, 1e-5f);
-        const float scale = mask ? 1.f / opc : 0.f;
-        const float dscale_dop = (mask && op >= 1e-5f) ? -1.f / (opc * opc) : 0.f;
-        const float m = image_mask ? image_mask[i] : 1.f;
-        float g_op = 0.f;
-        if (has_base) {
+        float f[10], gf[10];
 #pragma unroll
-            for (int c = 0; c < 3; c++) {
-                const float F = feature[(size_t)(8 + c) * HW + i];
-                const float g = d[c] * m * srgb_clip_derivative(F * scale);       // dL / d (linear base colour map)
-                dL_dfeature[(size_t)(8 + c) * HW + i] = g * scale;
-                g_op += g * F * dscale_dop;
-            }
+        for (int c = 0; c < 10; c++) {
+            const bool used = (c < 3) ? has_light : (c < 6) ? has_base : (c == 6) ? has_rough : has_light;
+            f[c] = used ? feature[(size_t)(5 + c) * HW + i] : 0.f;
         }
-        if (has_rough) {
-            const float g = d[3] * m;
-            dL_dfeature[(size_t)11 * HW + i] = g * scale;
-            g_op += g * feature[(size_t)11 * HW + i] * dscale_dop;
-        }
-        if (has_light) {
-#pragma unroll
-            for (int c = 0; c < 3; c++) {
-                const float Fd = feature[(size_t)(12 + c) * HW + i];
-                const float g = d[4 + c] * m * srgb_clip_derivative(Fd * scale);   // dL / d (linear diffuse map)
-                dL_dfeature[(size_t)(12 + c) * HW + i] = g * scale;
-                g_op += g * Fd * dscale_dop;
-                const float gn = d[7 + c];
-                const size_t o = (size_t)(5 + c) * HW + i;
-                dL_dfeature[o] = (accumulate_normal ? dL_dfeature[o] : 0.f) + gn * scale;
-                g_op += gn * feature[o] * dscale_dop;
-            }
-        }
+        const float g_op = smooth_chain(has_base, has_rough, has_light, d, opacity[i], n_contrib[i],
+                                        image_mask ? image_mask[i] : 1.f, f, gf);
+        smooth_store(has_base, has_rough, has_light, accumulate_normal, gf, HW, i, dL_dfeature);
         dL_dopacity[i] += g_op;
     }
 }
 
-// ---- the three passes above as ONE kernel over LDS tiles (round 4) ------------------------------------------------------------
+// ---- the three passes above as ONE kernel, streamed through registers (round 4) -------------------------------------------------
 // maps -> edge -> backward move, per pixel, 10 divided maps out and back in, 20 adjoint inputs out and -- nine times, through the
-// caches -- back in: 0.41 ms of the 2.0 ms DTU iteration (1600x1200).  None of that has to exist in HBM: a
-// workgroup owns a 32 x 8 pixel tile and
-//   (1) builds the ten divided / masked / sRGB-mapped maps and the three target channels for the tile + a halo of 2 in LDS,
-//       replicate padding resolved here (a cell outside the image holds the clamped pixel's value);
-//   (2) evaluates the Sobel stencils for the tile + a halo of 1 and leaves the 20 adjoint inputs in LDS (the loss sums count
-//       the tile's own pixels only);
-//   (3) gathers the adjoint for its own pixels from LDS and applies the chain rule -- the same arithmetic, expression for
-//       expression, as the three kernels, which stay as the reference formulation (r3dg_stage2_smooth_forward / _backward: the
-//       parity tests run both).
-constexpr int SM_TX = 32, SM_TY = 8;
-constexpr int SM_IW = SM_TX + 4, SM_IH = SM_TY + 4;      // inputs: halo 2
-constexpr int SM_EW = SM_TX + 2, SM_EH = SM_TY + 2;      // adjoint inputs: halo 1
+// caches -- back in: 0.41 ms of the 2.0 ms DTU iteration (1600x1200).  None of that has to exist in HBM.  (A
+// first fused version staged 32 x 8 pixel tiles + halo in 50 KB of LDS: 1.69x the loads for the halo of 2, two thirds empty
+// second rounds, three barriers per 256 pixels, three workgroups per CU -- 0.148 ms where this one takes 0.102; deleted.)
+// Nothing of the stencil needs a tile: lane = COLUMN, the wave walks DOWN the image.  The left / right neighbours of a value are one DPP lane shift away (wave_shr:1 / wave_shl:1 fold
+// into the consuming instruction), the rows above live in registers:
+//   per input row   13 maps of this column (divided / masked / sRGB-mapped as in s2_smooth_maps_kernel), their horizontal
+//                   differences; with the two rows before: the Sobel pair of the row in the middle (gx from the three rows'
+//                   differences, gy from the lane-shifted difference of the outer rows -- the reference expression, term by term),
+//                   its 20 adjoint inputs;
+//   two rows later  the adjoint of the row whose three edge rows are now complete: nine (row, lane shift) taps in the order of
+//                   s2_smooth_backward_kernel, then the chain rule, written once.
+// A wave owns 60 columns (lanes 2..61; the two lanes either side are the halo of the two stencil levels) x `rows` rows (+4 rows
+// of run-in); replicate padding = clamped load coordinates.  No LDS, no barrier, every load a full 256-byte row segment.
+constexpr int SS_OWN = 60;
 
-__global__ void __launch_bounds__(256)
-s2_smooth_fused_kernel(int W, int H, const float* __restrict__ opacity, const float* __restrict__ feature,
-                       const int* __restrict__ n_contrib, const float* __restrict__ gt, const float* __restrict__ image_mask,
-                       float w_base, float w_rough, float w_light, int accumulate_normal, float* __restrict__ dL_dopacity,
-                       float* __restrict__ dL_dfeature, float* __restrict__ sums3)
+__device__ __forceinline__ float lane_left(float v)      // the value of lane - 1 (wave_shr:1)
 {
-    __shared__ float s_in[13][SM_IH][SM_IW];             // rend 0..9 (layout of s2_smooth_maps_kernel), target 10..12
-    __shared__ float s_edge[20][SM_EH][SM_EW];
-    __shared__ float s_part[4];
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x138, 0xF, 0xF, true));
+}
+__device__ __forceinline__ float lane_right(float v)     // the value of lane + 1 (wave_shl:1)
+{
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x130, 0xF, 0xF, true));
+}
+
+struct SmoothRow {            // what one pixel of a row contributes, as loaded
+    float op, mk;
+    int nc;
+    float f[10];              // feature 5..14: normal 3 | base colour 3 | roughness | diffuse light 3
+    float t[3];               // target
+};
+
+template <bool BASE, bool ROUGH, bool LIGHT, bool TARGET>
+__device__ __forceinline__ SmoothRow smooth_load_row(size_t i, size_t HW, const float* __restrict__ opacity,
+                                                     const float* __restrict__ feature, const int* __restrict__ n_contrib,
+                                                     const float* __restrict__ gt, const float* __restrict__ image_mask)
+{
+    SmoothRow r;
+    r.op = opacity[i];
+    r.nc = n_contrib[i];
+    r.mk = image_mask ? image_mask[i] : 1.f;
+#pragma unroll
+    for (int c = 0; c < 10; c++) {
+        const bool used = (c < 3) ? LIGHT : (c < 6) ? BASE : (c == 6) ? ROUGH : LIGHT;
+        r.f[c] = used ? feature[(size_t)(5 + c) * HW + i] : 0.f;
+    }
+#pragma unroll
+    for (int c = 0; c < 3; c++) r.t[c] = (TARGET && (BASE || ROUGH)) ? gt[(size_t)c * HW + i] : 0.f;
+    return r;
+}
+
+template <bool BASE, bool ROUGH, bool LIGHT>
+__global__ void __launch_bounds__(256, 2)      // (two waves per SIMD: all three terms together hold ~250 registers)
+s2_smooth_stream_kernel(int W, int H, int rows, int strips_x, const float* __restrict__ opacity,
+                        const float* __restrict__ feature, const int* __restrict__ n_contrib, const float* __restrict__ gt,
+                        const float* __restrict__ image_mask, float w_base, float w_rough, float w_light, int accumulate_normal,
+                        float* __restrict__ dL_dopacity, float* __restrict__ dL_dfeature, float* __restrict__ sums3)
+{
+    const int lane = threadIdx.x & 63;
+    const int wid = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int strip = wid % strips_x, y0 = (wid / strips_x) * rows;
+    if (y0 >= H) return;                                   // (whole waves; nothing below synchronises a workgroup)
+    const int y1 = min(y0 + rows, H);
+    const int x = strip * SS_OWN - 2 + lane;               // this lane's column; lanes 0, 1, 62, 63 are halo
+    const int xc = min(max(x, 0), W - 1);
+    const bool own_col = lane >= 2 && lane < 2 + SS_OWN && x < W;
     const size_t HW = (size_t)W * H;
-    const int tx0 = blockIdx.x * SM_TX, ty0 = blockIdx.y * SM_TY;
-    const int tid = threadIdx.x;
-    // (1)  (both cells of a thread are requested before either is used: as a plain loop the second cell's 15 loads wait for the
-    //       first cell's arithmetic)
-    {
-        constexpr int NCELL = (SM_IH * SM_IW + 255) / 256;
-        float raw[NCELL][13], sc[NCELL], mk[NCELL];
+    constexpr int NM = 13;                                 // rend 0..9 (layout of s2_smooth_maps_kernel), target 10..12
+    auto used = [](int m) { return m < 3 ? BASE : m == 3 ? ROUGH : m < 10 ? LIGHT : (BASE || ROUGH); };
+    // weights with which the stencils of columns x-1, x, x+1 read column x (replicate padding folded in); 0 outside the image
+    float sxw[3], dxw[3];
 #pragma unroll
-        for (int it = 0; it < NCELL; it++) {
-            const int idx = min(tid + it * 256, SM_IH * SM_IW - 1);
-            const int ly = idx / SM_IW, lx = idx - ly * SM_IW;
-            const int gy = min(max(ty0 - 2 + ly, 0), H - 1), gx = min(max(tx0 - 2 + lx, 0), W - 1);
-            const size_t i = (size_t)gy * W + gx;
-            sc[it] = n_contrib[i] > 0 ? opacity[i] : -1.f;
-            mk[it] = image_mask ? image_mask[i] : 1.f;
+    for (int b = -1; b <= 1; b++) {
+        const int qx = x + b;
+        const bool in = qx >= 0 && qx < W;
+        sxw[b + 1] = in ? s1_adj1(qx, x, W, 1.f, 2.f, 1.f) : 0.f;
+        dxw[b + 1] = in ? s1_adj1(qx, x, W, -1.f, 0.f, 1.f) : 0.f;
+    }
+    // three rows in flight: values, right - left, adjoint inputs.  Row r lives in slot r % 3; the loop is unrolled by three so
+    // that the slots are compile-time names (registers), not copies
+    float V[3][NM], D[3][NM], E[3][20];
 #pragma unroll
-            for (int c = 0; c < 10; c++) raw[it][c] = feature[(size_t)(5 + c) * HW + i];
+    for (int q = 0; q < 3; q++) {
 #pragma unroll
-            for (int c = 0; c < 3; c++) raw[it][10 + c] = gt[(size_t)c * HW + i];
+        for (int m = 0; m < NM; m++) V[q][m] = D[q][m] = 0.f;
+#pragma unroll
+        for (int k = 0; k < 20; k++) E[q][k] = 0.f;
+    }
+    float a_base = 0.f, a_rough = 0.f, a_light = 0.f;
+    const int nrows = y1 - y0;
+    SmoothRow nxt = smooth_load_row<BASE, ROUGH, LIGHT, true>((size_t)min(max(y0 - 2, 0), H - 1) * W + xc, HW, opacity, feature,
+                                                              n_contrib, gt, image_mask);
+    auto step = [&](auto slot, int r) {
+        constexpr int P2 = decltype(slot)::value, P1 = (P2 + 2) % 3, P0 = (P2 + 1) % 3;
+        float (&v2)[NM] = V[P2], (&v0)[NM] = V[P0];
+        float (&h2)[NM] = D[P2], (&h1)[NM] = D[P1], (&h0)[NM] = D[P0];
+        float (&E2)[20] = E[P2], (&E1)[20] = E[P1], (&E0)[20] = E[P0];
+        const int yy = y0 - 2 + r;                         // incoming row; edge row yy - 1; adjoint row yy - 2
+        const SmoothRow in = nxt;
+        if (r + 1 < nrows + 4)
+            nxt = smooth_load_row<BASE, ROUGH, LIGHT, true>((size_t)min(max(yy + 1, 0), H - 1) * W + xc, HW, opacity, feature,
+                                                            n_contrib, gt, image_mask);
+        const int py = yy - 2;
+        const bool adjoint = r >= 4 && own_col;
+        // (1) the incoming row's maps
+        {
+            const float scale = in.nc > 0 ? 1.f / fmaxf(in.op, 1e-5f) : 0.f;
+#pragma unroll
+            for (int c = 0; c < 7; c++) {
+                const float xv = in.f[3 + c] * scale;
+                v2[c] = (c == 3 ? xv : srgb_clip(xv)) * in.mk;
+            }
+#pragma unroll
+            for (int c = 0; c < 3; c++) {
+                v2[7 + c] = in.f[c] * scale;
+                v2[10 + c] = in.t[c];
+            }
+#pragma unroll
+            for (int m = 0; m < NM; m++) h2[m] = used(m) ? lane_right(v2[m]) - lane_left(v2[m]) : 0.f;
         }
-#pragma unroll
-        for (int it = 0; it < NCELL; it++) {
-            const int idx = tid + it * 256;
-            if (idx < SM_IH * SM_IW) {
-                const int ly = idx / SM_IW, lx = idx - ly * SM_IW;
-                const float scale = sc[it] >= 0.f ? 1.f / fmaxf(sc[it], 1e-5f) : 0.f;
-#pragma unroll
-                for (int c = 0; c < 7; c++) {
-                    const float x = raw[it][3 + c] * scale;
-                    s_in[c][ly][lx] = (c == 3 ? x : srgb_clip(x)) * mk[it];
-                }
+        // (2) the edge row in the middle of the three
+        const int cy = yy - 1;
+        if (r >= 2 && cy >= 0 && cy < H) {
+            const bool own = own_col && cy >= y0 && cy < y1;
+            auto sobel = [&](int m, float& gx_, float& gy_) {
+                const float vd = v2[m] - v0[m];
+                gx_ = ((h0[m]) + 2.f * (h1[m]) + (h2[m])) * 0.125f;
+                gy_ = ((lane_left(vd)) + 2.f * (vd) + (lane_right(vd))) * 0.125f;
+            };
+            float ex[3], ey3[3];
+            if (BASE || ROUGH) {
 #pragma unroll
                 for (int c = 0; c < 3; c++) {
-                    s_in[7 + c][ly][lx] = raw[it][c] * scale;
-                    s_in[10 + c][ly][lx] = raw[it][10 + c];
+                    float gx1, gy1;
+                    sobel(10 + c, gx1, gy1);
+                    ex[c] = __expf(-fabsf(gx1));
+                    ey3[c] = __expf(-fabsf(gy1));
                 }
             }
-        }
-    }
-    __syncthreads();
-    // (2)
-    auto sobel = [&](int map, int cy, int cx, float& gx_, float& gy_) {
-        const float v00 = s_in[map][cy - 1][cx - 1], v01 = s_in[map][cy - 1][cx], v02 = s_in[map][cy - 1][cx + 1];
-        const float v10 = s_in[map][cy][cx - 1], v12 = s_in[map][cy][cx + 1];
-        const float v20 = s_in[map][cy + 1][cx - 1], v21 = s_in[map][cy + 1][cx], v22 = s_in[map][cy + 1][cx + 1];
-        gx_ = ((v02 - v00) + 2.f * (v12 - v10) + (v22 - v20)) * 0.125f;
-        gy_ = ((v20 - v00) + 2.f * (v21 - v01) + (v22 - v02)) * 0.125f;
-    };
-    float a_base = 0.f, a_rough = 0.f, a_light = 0.f;
-    for (int idx = tid; idx < SM_EH * SM_EW; idx += 256) {
-        const int ey = idx / SM_EW, ex_ = idx - ey * SM_EW;
-        const int gy = ty0 - 1 + ey, gx = tx0 - 1 + ex_;
-        if (gy < 0 || gy >= H || gx < 0 || gx >= W) continue;                  // (never read: the adjoint skips them too)
-        const bool own = ey >= 1 && ey <= SM_TY && ex_ >= 1 && ex_ <= SM_TX;    // this tile's pixel: counted in the sums
-        const int cy = ey + 1, cx = ex_ + 1;
-        float ex[3], ey3[3];
-        if (w_base != 0.f || w_rough != 0.f) {
+            if (BASE) {
 #pragma unroll
-            for (int c = 0; c < 3; c++) {
-                float gx1, gy1;
-                sobel(10 + c, cy, cx, gx1, gy1);
-                ex[c] = __expf(-fabsf(gx1));
-                ey3[c] = __expf(-fabsf(gy1));
+                for (int c = 0; c < 3; c++) {
+                    float dx, dy;
+                    sobel(c, dx, dy);
+                    if (own) a_base += fabsf(dx) * ex[c] + fabsf(dy) * ey3[c];
+                    E2[2 * c] = w_base * signf_(dx) * ex[c];
+                    E2[2 * c + 1] = w_base * signf_(dy) * ey3[c];
+                }
             }
-        }
-        if (w_base != 0.f) {
-#pragma unroll
-            for (int c = 0; c < 3; c++) {
+            if (ROUGH) {
                 float dx, dy;
-                sobel(c, cy, cx, dx, dy);
-                if (own) a_base += fabsf(dx) * ex[c] + fabsf(dy) * ey3[c];
-                s_edge[2 * c][ey][ex_] = w_base * signf_(dx) * ex[c];
-                s_edge[2 * c + 1][ey][ex_] = w_base * signf_(dy) * ey3[c];
+                sobel(3, dx, dy);
+                const float sx = ex[0] + ex[1] + ex[2], sy = ey3[0] + ey3[1] + ey3[2];
+                if (own) a_rough += fabsf(dx) * sx + fabsf(dy) * sy;
+                E2[6] = w_rough * signf_(dx) * sx;
+                E2[7] = w_rough * signf_(dy) * sy;
             }
-        }
-        if (w_rough != 0.f) {
-            float dx, dy;
-            sobel(3, cy, cx, dx, dy);
-            const float sx = ex[0] + ex[1] + ex[2], sy = ey3[0] + ey3[1] + ey3[2];
-            if (own) a_rough += fabsf(dx) * sx + fabsf(dy) * sy;
-            s_edge[6][ey][ex_] = w_rough * signf_(dx) * sx;
-            s_edge[7][ey][ex_] = w_rough * signf_(dy) * sy;
-        }
-        if (w_light != 0.f) {
+            if (LIGHT) {
 #pragma unroll
-            for (int c = 0; c < 3; c++) {
-                float dx, dy, nx, ny;
-                sobel(4 + c, cy, cx, dx, dy);
-                sobel(7 + c, cy, cx, nx, ny);
-                const float gx1 = __expf(-fabsf(nx)), gy1 = __expf(-fabsf(ny));
-                if (own) a_light += fabsf(dx) * gx1 + fabsf(dy) * gy1;
-                s_edge[8 + 2 * c][ey][ex_] = w_light * signf_(dx) * gx1;
-                s_edge[9 + 2 * c][ey][ex_] = w_light * signf_(dy) * gy1;
-                s_edge[14 + 2 * c][ey][ex_] = -w_light * fabsf(dx) * gx1 * signf_(nx);
-                s_edge[15 + 2 * c][ey][ex_] = -w_light * fabsf(dy) * gy1 * signf_(ny);
-            }
-        }
-    }
-    __syncthreads();
-    // (3)
-    const int ly = tid / SM_TX, lx = tid - ly * SM_TX;
-    const int y = ty0 + ly, x = tx0 + lx;
-    if (y < H && x < W) {
-        const size_t i = (size_t)y * W + x;
-        float d[10];
-#pragma unroll
-        for (int k = 0; k < 10; k++) d[k] = 0.f;
-#pragma unroll
-        for (int a = -1; a <= 1; a++) {
-            const int qy = y + a;
-            if (qy < 0 || qy >= H) continue;
-            const float sy = s1_adj1(qy, y, H, 1.f, 2.f, 1.f), dy = s1_adj1(qy, y, H, -1.f, 0.f, 1.f);
-#pragma unroll
-            for (int b = -1; b <= 1; b++) {
-                const int qx = x + b;
-                if (qx < 0 || qx >= W) continue;
-                const float sx = s1_adj1(qx, x, W, 1.f, 2.f, 1.f), dx = s1_adj1(qx, x, W, -1.f, 0.f, 1.f);
-                const float wx = sy * dx * 0.125f, wy = dy * sx * 0.125f;
-                const int qe = ly + 1 + a, qf = lx + 1 + b;
-                if (w_base != 0.f) {
-#pragma unroll
-                    for (int c = 0; c < 3; c++) d[c] += wx * s_edge[2 * c][qe][qf] + wy * s_edge[2 * c + 1][qe][qf];
+                for (int c = 0; c < 3; c++) {
+                    float dx, dy, nx, ny;
+                    sobel(4 + c, dx, dy);
+                    sobel(7 + c, nx, ny);
+                    const float gx1 = __expf(-fabsf(nx)), gy1 = __expf(-fabsf(ny));
+                    if (own) a_light += fabsf(dx) * gx1 + fabsf(dy) * gy1;
+                    E2[8 + 2 * c] = w_light * signf_(dx) * gx1;
+                    E2[9 + 2 * c] = w_light * signf_(dy) * gy1;
+                    E2[14 + 2 * c] = -w_light * fabsf(dx) * gx1 * signf_(nx);
+                    E2[15 + 2 * c] = -w_light * fabsf(dy) * gy1 * signf_(ny);
                 }
-                if (w_rough != 0.f) d[3] += wx * s_edge[6][qe][qf] + wy * s_edge[7][qe][qf];
-                if (w_light != 0.f) {
+            }
+        }
+        // (3) the adjoint of row yy - 2 and the chain rule
+        if (r >= 4) {
+            // the adjoint row's own pixel again (cache hits; requested here, used after the nine taps)
+            const SmoothRow pr = smooth_load_row<BASE, ROUGH, LIGHT, false>((size_t)py * W + xc, HW, opacity, feature, n_contrib,
+                                                                            gt, image_mask);
+            float d[10];
 #pragma unroll
-                    for (int c = 0; c < 3; c++) {
-                        d[4 + c] += wx * s_edge[8 + 2 * c][qe][qf] + wy * s_edge[9 + 2 * c][qe][qf];
-                        d[7 + c] += wx * s_edge[14 + 2 * c][qe][qf] + wy * s_edge[15 + 2 * c][qe][qf];
+            for (int k = 0; k < 10; k++) d[k] = 0.f;
+#pragma unroll
+            for (int a = -1; a <= 1; a++) {
+                const int qy = py + a;
+                if (qy < 0 || qy >= H) continue;
+                const float sy = s1_adj1(qy, py, H, 1.f, 2.f, 1.f), dy = s1_adj1(qy, py, H, -1.f, 0.f, 1.f);
+                const float (&Er)[20] = a < 0 ? E0 : a == 0 ? E1 : E2;
+#pragma unroll
+                for (int b = -1; b <= 1; b++) {
+                    const float wx = sy * dxw[b + 1] * 0.125f, wy = dy * sxw[b + 1] * 0.125f;
+                    auto tap = [&](int k) { return b < 0 ? lane_left(Er[k]) : b == 0 ? Er[k] : lane_right(Er[k]); };
+                    if (BASE) {
+#pragma unroll
+                        for (int c = 0; c < 3; c++) d[c] = smooth_tap(d[c], wx, tap(2 * c), wy, tap(2 * c + 1));
+                    }
+                    if (ROUGH) d[3] = smooth_tap(d[3], wx, tap(6), wy, tap(7));
+                    if (LIGHT) {
+#pragma unroll
+                        for (int c = 0; c < 3; c++) {
+                            d[4 + c] = smooth_tap(d[4 + c], wx, tap(8 + 2 * c), wy, tap(9 + 2 * c));
+                            d[7 + c] = smooth_tap(d[7 + c], wx, tap(14 + 2 * c), wy, tap(15 + 2 * c));
+                        }
                     }
                 }
             }
-        }
-        const float op = opacity[i];
-        const bool mask = n_contrib[i] > 0;
-        const float opc = fmaxf(op, 1e-5f);
-        const float scale = mask ? 1.f / opc : 0.f;
-        const float dscale_dop = (mask && op >= 1e-5f) ? -1.f / (opc * opc) : 0.f;
-        const float m = image_mask ? image_mask[i] : 1.f;
-        float g_op = 0.f;
-        if (w_base != 0.f) {
-#pragma unroll
-            for (int c = 0; c < 3; c++) {
-                const float F = feature[(size_t)(8 + c) * HW + i];
-                const float g = d[c] * m * srgb_clip_derivative(F * scale);
-                dL_dfeature[(size_t)(8 + c) * HW + i] = g * scale;
-                g_op += g * F * dscale_dop;
+            if (adjoint) {
+                const size_t i = (size_t)py * W + x;
+                float gf[10];
+                const float g_op = smooth_chain(BASE, ROUGH, LIGHT, d, pr.op, pr.nc, pr.mk, pr.f, gf);
+                smooth_store(BASE, ROUGH, LIGHT, accumulate_normal, gf, HW, i, dL_dfeature);
+                dL_dopacity[i] += g_op;
             }
         }
-        if (w_rough != 0.f) {
-            const float g = d[3] * m;
-            dL_dfeature[(size_t)11 * HW + i] = g * scale;
-            g_op += g * feature[(size_t)11 * HW + i] * dscale_dop;
-        }
-        if (w_light != 0.f) {
-#pragma unroll
-            for (int c = 0; c < 3; c++) {
-                const float Fd = feature[(size_t)(12 + c) * HW + i];
-                const float g = d[4 + c] * m * srgb_clip_derivative(Fd * scale);
-                dL_dfeature[(size_t)(12 + c) * HW + i] = g * scale;
-                g_op += g * Fd * dscale_dop;
-                const float gn = d[7 + c];
-                const size_t o = (size_t)(5 + c) * HW + i;
-                dL_dfeature[o] = (accumulate_normal ? dL_dfeature[o] : 0.f) + gn * scale;
-                g_op += gn * feature[o] * dscale_dop;
-            }
-        }
-        dL_dopacity[i] += g_op;
+    };
+    const int total = nrows + 4;
+    for (int r = 0; r < total; r += 3) {
+        step(std::integral_constant<int, 0>{}, r);
+        if (r + 1 < total) step(std::integral_constant<int, 1>{}, r + 1);
+        if (r + 2 < total) step(std::integral_constant<int, 2>{}, r + 2);
     }
-    const float t0 = block_sum_256(a_base, s_part);
-    __syncthreads();
-    const float t1 = block_sum_256(a_rough, s_part);
-    __syncthreads();
-    const float t2 = block_sum_256(a_light, s_part);
-    if (threadIdx.x == 0) {
-        atomicAdd(sum_slot(sums3 + 0 * R3DG_SUM_SLOTS), t0);
-        atomicAdd(sum_slot(sums3 + 1 * R3DG_SUM_SLOTS), t1);
-        atomicAdd(sum_slot(sums3 + 2 * R3DG_SUM_SLOTS), t2);
+    a_base = wave_sum_to_lane63(a_base);
+    a_rough = wave_sum_to_lane63(a_rough);
+    a_light = wave_sum_to_lane63(a_light);
+    if (lane == 63) {
+        if (BASE) atomicAdd(sum_slot(sums3 + 0 * R3DG_SUM_SLOTS), a_base);
+        if (ROUGH) atomicAdd(sum_slot(sums3 + 1 * R3DG_SUM_SLOTS), a_rough);
+        if (LIGHT) atomicAdd(sum_slot(sums3 + 2 * R3DG_SUM_SLOTS), a_light);
     }
 }
 
@@ -1164,14 +1246,45 @@ void launch_s2_smooth_backward(hipStream_t s, int W, int H, const float* opacity
     check_launch(s, false, "s2_smooth_backward_kernel");
 }
 
+template <bool BASE, bool ROUGH, bool LIGHT>
+static void launch_s2_smooth_stream_t(hipStream_t s, int W, int H, int rows, const float* opacity, const float* feature,
+                                      const int* n_contrib, const float* gt, const float* image_mask, float w_base, float w_rough,
+                                      float w_light, int accumulate_normal, float* dL_dopacity, float* dL_dfeature, float* sums3)
+{
+    const int strips_x = (W + SS_OWN - 1) / SS_OWN, strips_y = (H + rows - 1) / rows;
+    const int waves = strips_x * strips_y;
+    s2_smooth_stream_kernel<BASE, ROUGH, LIGHT><<<(waves + 3) / 4, 256, 0, s>>>(
+        W, H, rows, strips_x, opacity, feature, n_contrib, gt, image_mask, w_base, w_rough, w_light, accumulate_normal,
+        dL_dopacity, dL_dfeature, sums3);
+}
+
 void launch_s2_smooth_fused(hipStream_t s, int W, int H, const float* opacity, const float* feature, const int* n_contrib,
                             const float* gt, const float* image_mask, float w_base, float w_rough, float w_light,
                             int accumulate_normal, float* dL_dopacity, float* dL_dfeature, float* sums3)
 {
-    const dim3 grid((W + SM_TX - 1) / SM_TX, (H + SM_TY - 1) / SM_TY);
-    s2_smooth_fused_kernel<<<grid, 256, 0, s>>>(W, H, opacity, feature, n_contrib, gt, image_mask, w_base, w_rough, w_light,
-                                                accumulate_normal, dL_dopacity, dL_dfeature, sums3);
-    check_launch(s, false, "s2_smooth_fused_kernel");
+    // rows per wave: every wave pays 4 rows of run-in; one full round of two waves per SIMD is ~2048 waves
+    static const int rows_env = getenv("R3DG_SMOOTH_ROWS") ? atoi(getenv("R3DG_SMOOTH_ROWS")) : 0;
+    const int strips_x = (W + SS_OWN - 1) / SS_OWN;
+    int rows = rows_env > 0 ? rows_env : (int)std::min<long long>(32, std::max<long long>(8, ((long long)strips_x * H + 2047) / 2048));
+    rows = std::max(1, std::min(rows, H));
+    const int sel = (w_base != 0.f ? 1 : 0) | (w_rough != 0.f ? 2 : 0) | (w_light != 0.f ? 4 : 0);
+#define R3DG_SMOOTH_CASE(n, B, R, L)                                                                                        \
+    case n:                                                                                                                 \
+        launch_s2_smooth_stream_t<B, R, L>(s, W, H, rows, opacity, feature, n_contrib, gt, image_mask, w_base, w_rough,     \
+                                           w_light, accumulate_normal, dL_dopacity, dL_dfeature, sums3);                    \
+        break;
+    switch (sel) {
+        R3DG_SMOOTH_CASE(1, true, false, false)
+        R3DG_SMOOTH_CASE(2, false, true, false)
+        R3DG_SMOOTH_CASE(3, true, true, false)
+        R3DG_SMOOTH_CASE(4, false, false, true)
+        R3DG_SMOOTH_CASE(5, true, false, true)
+        R3DG_SMOOTH_CASE(6, false, true, true)
+        R3DG_SMOOTH_CASE(7, true, true, true)
+        default: return;                             // no term: nothing to add
+    }
+#undef R3DG_SMOOTH_CASE
+    check_launch(s, false, "s2_smooth_stream_kernel");
 }
 
 void launch_s1_pack(hipStream_t s, int P, const float* xyz, const float* viewmatrix, const float* normal, float* features)

@@ -364,6 +364,7 @@ class FusedStage2Step(_BoundedForward):
         self.world, self.dp = _world_of(process_group)
         # tuning options of THIS object (include/r3dg_hip.h "option contexts"): every library call of the step runs inside it
         self._ctx = _lib.OptionContext()
+        self._stagger = os.environ.get("R3DG_FWD_STAGGER", "1") != "0"      # (see forward_backward: where the two tiny launches go)
         if self.dp:
             # The shading kernels and the visibility trace are PERSISTENT grids that fill every CU (the backward: 2 workgroups
             # x ~60 KB LDS, ~2 x 230 VGPRs per SIMD); RCCL's workgroups could then only start when one of them retires and
@@ -513,9 +514,13 @@ class FusedStage2Step(_BoundedForward):
                     # shading forward starts ~20 us earlier, inside the projection, and the step loses 15-20 it/s; gating the
                     # shading forward on the projection's end with an event loses 12.  The persistent forward and the front
                     # end's kernels share the CUs best with this stagger.)
-                    env_c = F.softplus(self.env)[0]                              # DirectLightMap.get_env
-                    self.sums.zero_()
+                    if self._stagger:
+                        env_c = F.softplus(self.env)[0]                          # DirectLightMap.get_env
+                        self.sums.zero_()
                 rotated_for = self._frs
+            if aux is not None and not self._stagger:
+                env_c = F.softplus(self.env)[0]
+                self.sums.zero_()
             self.refresh_activations(cam)
             self._iter += 1
             use_bounded = self._use_bounded(W, H)
@@ -604,7 +609,7 @@ class FusedStage2Step(_BoundedForward):
             w_bc, w_r, w_ls = (self.w[k] / (3.0 * N) for k in ("base_color_smooth", "roughness_smooth", "light_smooth"))
             if w_bc != 0.0 or w_r != 0.0 or w_ls != 0.0:
                 if os.environ.get("R3DG_SMOOTH_FUSED", "1") != "0":
-                    # one kernel over LDS tiles: the divided maps and the adjoint inputs never exist in HBM
+                    # one streaming kernel: the divided maps and the adjoint inputs never exist in HBM
                     _lib.check(L.r3dg_stage2_smooth_fused(
                         stream(), W, H, opacity.data_ptr(), feature.data_ptr(), n_contrib.data_ptr(), gt_c.data_ptr(),
                         _lib.ptr(mask_c), w_bc, w_r, w_ls, 1 if self.w["normal"] != 0.0 else 0, g[3:4].data_ptr(),

@@ -555,15 +555,16 @@ def test_option_contexts_keep_two_objects_apart():
         assert s2._use_bounded(res, res)
 
 
-@pytest.mark.parametrize("H,W", [(64, 64), (37, 50), (5, 7), (120, 161)])
+@pytest.mark.parametrize("H,W", [(64, 64), (37, 50), (5, 7), (120, 161), (70, 121), (3, 61)])
 @pytest.mark.parametrize("weights,acc_normal,masked", [((1.0, 0.5, 1.0), 0, True), ((1.0, 0.0, 0.0), 0, False),
                                                        ((0.0, 0.5, 1.0), 1, True), ((0.0, 0.0, 1.0), 1, False)])
 def test_fused_smoothness_kernel_equals_the_three_pass_formulation(H, W, weights, acc_normal, masked):
-    """r3dg_stage2_smooth_fused (one kernel over 32 x 8 LDS tiles: maps, stencils and adjoint never touch HBM) against
+    """r3dg_stage2_smooth_fused (one kernel, the image streamed through registers in 60-column strips: maps, stencils and adjoint
+    never touch HBM or LDS) against
     r3dg_stage2_smooth_forward + _backward -- the three-pass formulation that is pinned to the reference's calculate_loss
     (tests/test_reference_pipeline_gpu.py::test_stage2_syn4_objective_matches_the_reference_python).  The per-pixel arithmetic
     is the same, expression for expression: gradients bit-identical, the three sums up to the order of their float atomics;
-    image sizes that are not multiples of the tile, every border, every subset of the three terms."""
+    image sizes that are not multiples of the strip (one strip, three strips, a last strip of one column), every border, every subset of the three terms."""
     from relightable3dgaussian_amd import _lib
     L = _lib.lib()
     g = torch.Generator().manual_seed(H * 1000 + W)
