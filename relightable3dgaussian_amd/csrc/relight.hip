@@ -51,7 +51,9 @@ relight_pack_features_kernel(int P, const float* __restrict__ xyz, const float* 
 __device__ __forceinline__ float srgb_of(float x)
 {
     // rgb_to_srgb (utils/graphics_utils.py:207-213), clip=True
-    const float y = x > 0.0031308f ? powf(fmaxf(x, 0.0031308f), 1.0f / 2.4f) * 1.055f - 0.055f : 12.92f * x;
+    // (x^(1/2.4) as v_log_f32 * y -> v_exp_f32, ~4 ulp: the library powf is ~155 instructions per channel of every pixel)
+    const float p = __builtin_amdgcn_exp2f((1.0f / 2.4f) * __builtin_amdgcn_logf(fmaxf(x, 0.0031308f)));
+    const float y = x > 0.0031308f ? p * 1.055f - 0.055f : 12.92f * x;
     return fminf(fmaxf(y, 0.f), 1.f);
 }
 

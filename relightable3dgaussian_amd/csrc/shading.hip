@@ -1247,9 +1247,12 @@ void launch_shade_frs_forward_main(hipStream_t s, int P, int K, const float* bas
     // beside the instance ordering (fused iteration) ONE workgroup per CU: the ordering chain (projection -> binning -> tile sort) is
     // the longer of the two concurrent paths and every wave this kernel keeps resident slows it -- measured per CU cap: 1 -> 618-627,
     // 2 -> 598-610, 3 -> 597-607 it/s (this kernel alone 0.21 / 0.195 / 0.21 ms; a high-priority ordering stream: no effect)
-    // (R3DG_OPT_SHADE_FWD_BLOCKS_PER_CU > 0 replaces the 1 for A/B runs)
+    // That holds while this kernel is the SHORTER path.  With more samples it becomes the longer one and the cap costs more
+    // than it buys: 300k x 384 samples 339 (one per CU) / 365 (two) / 365 (three) it/s, 2M x 64 samples 152 / 158 / 155 -- two
+    // per CU above 40 M samples per launch.  (R3DG_OPT_SHADE_FWD_BLOCKS_PER_CU > 0 replaces the choice for A/B runs)
     if (leave_room) {
-        const int per_cu = opt(R3DG_OPT_SHADE_FWD_BLOCKS_PER_CU) > 0 ? opt(R3DG_OPT_SHADE_FWD_BLOCKS_PER_CU) : 1;
+        const int by_size = (long long)P * K > 40000000ll ? 2 : 1;
+        const int per_cu = opt(R3DG_OPT_SHADE_FWD_BLOCKS_PER_CU) > 0 ? opt(R3DG_OPT_SHADE_FWD_BLOCKS_PER_CU) : by_size;
         grid = grid > per_cu * shade_cus() ? per_cu * shade_cus() : grid;
     }
     const FrsSrc src = {base_color, roughness, normals, viewdirs, ray_normals, cprime, nullptr, nullptr, visibility, taps};

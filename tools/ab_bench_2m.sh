@@ -1,0 +1,14 @@
+#!/bin/bash
+# A/B of the 2M-Gaussian configuration (configs[4]) under environment settings: tools/ab_bench_2m.sh "<label>=<env assignments>" ...
+cd "${GRAFT_REPO_ROOT:-/root/repo}"
+for spec in "$@"; do
+  label="${spec%%=*}"; envs="${spec#*=}"
+  env $envs python bench.py --points 2000000 --width 1800 --height 700 --steps 12 --warmup 4 --no-cpu-baseline --no-other-configs --relight-frames 0 --repeats 1 2>/dev/null | grep '^{' | tail -1 > /tmp/ab.json
+  python - "$label" <<'PY'
+import json, sys
+d = json.loads(open("/tmp/ab.json").read())
+k = d["kernels"]
+print("%-14s %7.1f it/s  " % (sys.argv[1], d["value"]),
+      {n: k[n]["avg_ms"] for n in ("shade_forward", "sort_pairs", "duplicate_with_keys", "render_forward", "shade_backward", "render_backward") if n in k})
+PY
+done
