@@ -313,10 +313,14 @@ int r3dg_shade_frs_forward(void* stream, int P, int K, const float* d_base_color
                            int He, int We, const float* d_visibility, float uniform_area, const uint32_t* d_taps,
                            const float* d_ray_normals, const float* d_zsamples, const float* d_tables,
                            const uint8_t* d_valid, const int32_t* d_invalid_list, int n_invalid, float* d_cprime, int flags,
-                           float* d_out, void* listed_stream);
+                           float* d_out, void* listed_stream, float* d_feature_rows);
 /*   listed_stream: NULL, or a second stream for the kernel on the listed Gaussians (ordered after everything queued on
  *   `stream` before the call; it then runs beside the rotation and the main kernel).  The caller joins listed_stream before anything
- *   reads d_out. */
+ *   reads d_out.
+ *   d_feature_rows: NULL, or the rasterizer's [P,16] feature rows (neilf.py:115-122): the kernels then ALSO write pbr, diffuse
+ *   light and mean visibility into columns 2..4, 12..14, 15 of each row -- with r3dg_stage2_activate(..., d_features) writing the
+ *   other nine columns this replaces r3dg_stage2_pack_features (one launch and one pass over d_out less between the shading
+ *   integral and the rasterizer; the light-smoothness sum then comes from r3dg_stage2_unpack_gradients). */
 int r3dg_shade_frs_backward(void* stream, int P, int K, const float* d_base_color, const float* d_roughness,
                             const float* d_normals, const float* d_viewdirs, const float* d_incidents, const float* d_env,
                             int He, int We, const float* d_visibility, float uniform_area, const uint32_t* d_taps,
@@ -395,13 +399,16 @@ int r3dg_render_equation_backward(void* stream, int P, int Si, int Sd, int Sv, c
  * r3dg_stage2_activate: GaussianModel.get_scaling/get_rotation/get_opacity/get_normal/get_base_color/get_roughness
  *   (scene/gaussian_model.py:183-232; exp, F.normalize, sigmoid, 0.03+0.77s, 0.09+0.9s) and
  *   viewdirs = normalize(campos - xyz) (gaussian_renderer/neilf.py:74-76).  base_raw == NULL skips the stage-2 outputs.
+ *   d_features (may be NULL; needs d_viewmatrix and the stage-2 inputs): the columns of the feature row that do not depend on
+ *   the shading integral are written here -- depth, depth^2 (0, 1), normal (5..7), base colour (8..10), roughness (11).
  * r3dg_stage2_pack_features: the S=16 feature row of neilf.py:115-122 = depth, depth^2, pbr, normal, base_color,
  *   roughness, diffuse_light, mean visibility; *light_l1_sum (may be NULL) += sum_p sum_c |diffuse_c - mean_c diffuse|
  *   (light-smoothness term, neilf.py:286-292).
  * r3dg_stage2_unpack_gradients: dL_dfeatures[P,16] -> the shading op's upstream gradients dL_dpbr[P,3] and
  *   dL_ddiffuse_light[P,3], the latter including light_weight * d(sum_c |diffuse_c - mean|)/d diffuse;
  *   d_block_absmax (may be NULL): [ceil(P/256)] floats, max |.| of the rows written by each block (+inf: not finite),
- *   for r3dg_shade_backward_cached.
+ *   for r3dg_shade_backward_cached.  d_light_l1_sum (may be NULL): += sum_p sum_c |diffuse_c - mean_c diffuse|, the term's
+ *   value, for callers that did not run r3dg_stage2_pack_features (which adds the same sum).
  * r3dg_stage2_activate_backward: chain rule of every activation above; combines the rasterizer's dL_dscales, dL_drot,
  *   dL_dopacity, dL_dmeans3D, dL_dfeatures and the shading op's dL_dbase_color, dL_droughness, dL_dviewdirs into the
  *   raw-parameter gradients (all seven outputs fully written).  d_g_xyz == NULL = frozen geometry (run_syn4.sh / run_dtu.sh:
@@ -421,13 +428,13 @@ int r3dg_stage2_activate(void* stream, int P, const float* d_xyz, const float* d
                          const float* d_rotation_raw, const float* d_opacity_raw, const float* d_normal_raw,
                          const float* d_base_raw, const float* d_rough_raw, const float* d_campos, float* d_scales,
                          float* d_rotations, float* d_opacity, float* d_normal, float* d_base_color,
-                         float* d_roughness, float* d_viewdirs);
+                         float* d_roughness, float* d_viewdirs, const float* d_viewmatrix, float* d_features);
 int r3dg_stage2_pack_features(void* stream, int P, const float* d_xyz, const float* d_viewmatrix, const float* d_normal,
                               const float* d_base_color, const float* d_roughness, const float* d_shade_out,
                               float* d_features, float* d_light_l1_sum);
 int r3dg_stage2_unpack_gradients(void* stream, int P, const float* d_dL_dfeatures, const float* d_shade_out,
                                  float light_weight, float* d_dL_dpbr, float* d_dL_ddiffuse_light,
-                                 float* d_block_absmax);
+                                 float* d_block_absmax, float* d_light_l1_sum);
 int r3dg_stage2_activate_backward(void* stream, int P, const float* d_xyz, const float* d_scaling_raw,
                                   const float* d_rotation_raw, const float* d_opacity_raw, const float* d_normal_raw,
                                   const float* d_base_raw, const float* d_rough_raw, const float* d_viewmatrix,

@@ -70,7 +70,7 @@ _SIGNATURES = {
     "r3dg_stream_wait_stream": (_i, [_p, _p]),
     "r3dg_spin": (_i, [_p, _f]),
     "r3dg_shade_frs_build_taps": (_i, [_p, _i, _i, _p, _p, _i, _i, _p]),
-    "r3dg_shade_frs_forward": (_i, [_p, _i, _i] + [_p] * 6 + [_i, _i, _p, _f] + [_p] * 6 + [_i, _p, _i, _p, _p]),
+    "r3dg_shade_frs_forward": (_i, [_p, _i, _i] + [_p] * 6 + [_i, _i, _p, _f] + [_p] * 6 + [_i, _p, _i, _p, _p, _p]),
     "r3dg_shade_frs_backward": (_i, [_p, _i, _i] + [_p] * 6 + [_i, _i, _p, _f] + [_p] * 6 + [_i] + [_p] * 10 + [_i, _p]),
     "r3dg_shade_build_transport": (_i, [_p, _i, _i, _i, _p, _p, _p, _p, _p, _f, _p, _p]),
     "r3dg_shade_forward_transport": (_i, [_p, _i, _i] + [_p] * 9),
@@ -85,9 +85,9 @@ _SIGNATURES = {
     "r3dg_render_equation_forward": (_i, [_p, _i, _i, _i, _i] + [_p] * 8 + [_i] + [_p] * 4),
     "r3dg_render_equation_forward_complex": (_i, [_p, _i, _i, _i, _i] + [_p] * 8 + [_i] + [_p] * 11),
     "r3dg_render_equation_backward": (_i, [_p, _i, _i, _i, _i] + [_p] * 8 + [_i] + [_p] * 11),
-    "r3dg_stage2_activate": (_i, [_p, _i] + [_p] * 15),
+    "r3dg_stage2_activate": (_i, [_p, _i] + [_p] * 17),
     "r3dg_stage2_pack_features": (_i, [_p, _i] + [_p] * 8),
-    "r3dg_stage2_unpack_gradients": (_i, [_p, _i, _p, _p, _f, _p, _p, _p]),
+    "r3dg_stage2_unpack_gradients": (_i, [_p, _i, _p, _p, _f, _p, _p, _p, _p]),
     "r3dg_stage2_activate_backward": (_i, [_p, _i] + [_p] * 24),
     "r3dg_stage2_loss": (_i, [_p, _i, _i] + [_p] * 8 + [_f, _f, _f] + [_p] * 6 + [_i]),
     "r3dg_stage2_smooth_forward": (_i, [_p, _i, _i] + [_p] * 5 + [_f, _f, _f, _p, _p]),

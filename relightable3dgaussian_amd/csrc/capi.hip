@@ -71,11 +71,12 @@ void launch_shade_frs_forward_aux(hipStream_t s, int P, const float* incidents, 
 void launch_shade_frs_forward_main(hipStream_t s, int P, int K, const float* base_color, const float* roughness,
                                    const float* normals, const float* viewdirs, const float* env, int He, int We,
                                    const float* visibility, float uniform_area, const uint32_t* taps, const float* ray_normals,
-                                   const float* tables, const uint8_t* valid, const float* cprime, bool leave_room, float* out);
+                                   const float* tables, const uint8_t* valid, const float* cprime, bool leave_room, float* out,
+                                   float* feat);
 void launch_shade_frs_forward_listed(hipStream_t s, int K, const float* base_color, const float* roughness,
                                      const float* normals, const float* viewdirs, const float* incidents, const float* env, int He,
                                      int We, const float* visibility, const float* ray_normals, const float* zsamples,
-                                     float uniform_area, const int* invalid_list, int n_invalid, float* out);
+                                     float uniform_area, const int* invalid_list, int n_invalid, float* out, float* feat);
 const unsigned int* launch_shade_frs_backward_aux(hipStream_t s, int P, const float* g_pbr, const float* g_diff,
                                                   const float* block_absmax, int n_block_absmax, int* gmax_n);
 void launch_shade_frs_backward_main(hipStream_t s, int P, int K, const float* base_color, const float* roughness,
@@ -129,12 +130,13 @@ void launch_re_backward(hipStream_t s, int P, int Si, int Sd, int Sv, const floa
 void launch_s2_activate(hipStream_t s, int P, const float* xyz, const float* scaling_raw, const float* rotation_raw,
                         const float* opacity_raw, const float* normal_raw, const float* base_raw,
                         const float* rough_raw, const float* campos, float* scales, float* rot, float* opacity,
-                        float* normal, float* base_color, float* roughness, float* viewdirs);
+                        float* normal, float* base_color, float* roughness, float* viewdirs, const float* viewmatrix,
+                        float* features);
 void launch_s2_pack(hipStream_t s, int P, const float* xyz, const float* viewmatrix, const float* normal,
                     const float* base_color, const float* roughness, const float* shade_out, float* features,
                     float* light_l1_sum);
 void launch_s2_unpack(hipStream_t s, int P, const float* dL_dfeatures, const float* shade_out, float light_weight,
-                      float* dL_dpbr, float* dL_ddiffuse, float* block_absmax);
+                      float* dL_dpbr, float* dL_ddiffuse, float* block_absmax, float* light_l1_sum);
 void launch_s2_activate_backward(hipStream_t s, int P, const float* xyz, const float* scaling_raw,
                                  const float* rotation_raw, const float* opacity_raw, const float* normal_raw,
                                  const float* base_raw, const float* rough_raw, const float* viewmatrix,
@@ -1429,7 +1431,7 @@ int r3dg_shade_frs_forward(void* stream_, int P, int K, const float* base_color,
                            int We, const float* visibility, float uniform_area, const uint32_t* taps,
                            const float* ray_normals, const float* zsamples, const float* tables, const uint8_t* valid,
                            const int32_t* invalid_list, int n_invalid, float* cprime, int flags, float* out,
-                           void* listed_stream_)
+                           void* listed_stream_, float* feature_rows)
 {
     if (P < 0 || K <= 0 || He <= 0 || We <= 0 || n_invalid < 0 || n_invalid > P) return invalid("shade_frs_forward: bad sizes");
     if (!shade_frs_supported(K, 16, He, We))
@@ -1451,7 +1453,8 @@ int r3dg_shade_frs_forward(void* stream_, int P, int K, const float* base_color,
             }
             StageTimer t(lstream, ST_SHADE_LISTED);
             launch_shade_frs_forward_listed(lstream, K, base_color, roughness, normals, viewdirs, incidents, env, He, We,
-                                            visibility, ray_normals, zsamples, uniform_area, invalid_list, n_invalid, out);
+                                            visibility, ray_normals, zsamples, uniform_area, invalid_list, n_invalid, out,
+                                            feature_rows);
         }
         if ((flags & R3DG_SHADE_ROTATED) == 0) {
             StageTimer t(stream, ST_SHADE_AUX);
@@ -1460,7 +1463,7 @@ int r3dg_shade_frs_forward(void* stream_, int P, int K, const float* base_color,
         {
             StageTimer t(stream, ST_SHADE_FWD);
             launch_shade_frs_forward_main(stream, P, K, base_color, roughness, normals, viewdirs, env, He, We, visibility,
-                                          uniform_area, taps, ray_normals, tables, valid, cprime, leave_room, out);
+                                          uniform_area, taps, ray_normals, tables, valid, cprime, leave_room, out, feature_rows);
         }
         return R3DG_OK;
     });
@@ -1611,7 +1614,8 @@ int r3dg_render_equation_backward(void* stream_, int P, int Si, int Sd, int Sv, 
 int r3dg_stage2_activate(void* stream_, int P, const float* xyz, const float* scaling_raw, const float* rotation_raw,
                          const float* opacity_raw, const float* normal_raw, const float* base_raw,
                          const float* rough_raw, const float* campos, float* scales, float* rot, float* opacity,
-                         float* normal, float* base_color, float* roughness, float* viewdirs)
+                         float* normal, float* base_color, float* roughness, float* viewdirs, const float* viewmatrix,
+                         float* features)
 {
     if (P < 0) return invalid("stage2_activate: bad P");
     if (P == 0) return R3DG_OK;
@@ -1619,10 +1623,11 @@ int r3dg_stage2_activate(void* stream_, int P, const float* xyz, const float* sc
         return invalid("stage2_activate: null buffer");
     if (base_raw && (!rough_raw || !campos || !base_color || !roughness || !viewdirs))
         return invalid("stage2_activate: stage-2 inputs/outputs incomplete");
+    if (features && (!base_raw || !viewmatrix)) return invalid("stage2_activate: feature rows need the stage-2 inputs and the view matrix");
     return guarded([&]() -> int {
         StageTimer t((hipStream_t)stream_, ST_S2_ACTIVATE);
         launch_s2_activate((hipStream_t)stream_, P, xyz, scaling_raw, rotation_raw, opacity_raw, normal_raw, base_raw,
-                           rough_raw, campos, scales, rot, opacity, normal, base_color, roughness, viewdirs);
+                           rough_raw, campos, scales, rot, opacity, normal, base_color, roughness, viewdirs, viewmatrix, features);
         return R3DG_OK;
     });
 }
@@ -1644,14 +1649,16 @@ int r3dg_stage2_pack_features(void* stream_, int P, const float* xyz, const floa
 }
 
 int r3dg_stage2_unpack_gradients(void* stream_, int P, const float* dL_dfeatures, const float* shade_out,
-                                 float light_weight, float* dL_dpbr, float* dL_ddiffuse, float* block_absmax)
+                                 float light_weight, float* dL_dpbr, float* dL_ddiffuse, float* block_absmax,
+                                 float* light_l1_sum)
 {
     if (P < 0) return invalid("stage2_unpack_gradients: bad P");
     if (P == 0) return R3DG_OK;
     if (!dL_dfeatures || !shade_out || !dL_dpbr || !dL_ddiffuse) return invalid("stage2_unpack_gradients: null buffer");
     return guarded([&]() -> int {
         StageTimer t((hipStream_t)stream_, ST_S2_UNPACK);
-        launch_s2_unpack((hipStream_t)stream_, P, dL_dfeatures, shade_out, light_weight, dL_dpbr, dL_ddiffuse, block_absmax);
+        launch_s2_unpack((hipStream_t)stream_, P, dL_dfeatures, shade_out, light_weight, dL_dpbr, dL_ddiffuse, block_absmax,
+                         light_l1_sum);
         return R3DG_OK;
     });
 }

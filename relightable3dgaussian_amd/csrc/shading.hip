@@ -1239,7 +1239,8 @@ void launch_shade_frs_forward_aux(hipStream_t s, int P, const float* incidents, 
 void launch_shade_frs_forward_main(hipStream_t s, int P, int K, const float* base_color, const float* roughness,
                                    const float* normals, const float* viewdirs, const float* env, int He, int We,
                                    const float* visibility, float uniform_area, const uint32_t* taps, const float* ray_normals,
-                                   const float* tables, const uint8_t* valid, const float* cprime, bool leave_room, float* out)
+                                   const float* tables, const uint8_t* valid, const float* cprime, bool leave_room, float* out,
+                                   float* feat)
 {
     if (P == 0) return;
     const size_t smem = frs_forward_lds_bytes(He, We);
@@ -1256,7 +1257,8 @@ void launch_shade_frs_forward_main(hipStream_t s, int P, int K, const float* bas
         grid = grid > per_cu * shade_cus() ? per_cu * shade_cus() : grid;
     }
     const FrsSrc src = {base_color, roughness, normals, viewdirs, ray_normals, cprime, nullptr, nullptr, visibility, taps};
-    shade_forward_frs_kernel<<<grid, 64 * FRS_WAVES, smem, s>>>(P, K, src, env, He, We, frs_area(uniform_area), tables, valid, out);
+    shade_forward_frs_kernel<<<grid, 64 * FRS_WAVES, smem, s>>>(P, K, src, env, He, We, frs_area(uniform_area), tables, valid, out,
+                                                                feat);
     check_launch(s, false, "shade_forward_frs_kernel");
 }
 
@@ -1271,13 +1273,13 @@ static int frs_listed_grid(int n_list)
 void launch_shade_frs_forward_listed(hipStream_t s, int K, const float* base_color, const float* roughness,
                                      const float* normals, const float* viewdirs, const float* incidents, const float* env, int He,
                                      int We, const float* visibility, const float* ray_normals, const float* zsamples,
-                                     float uniform_area, const int* invalid_list, int n_invalid, float* out)
+                                     float uniform_area, const int* invalid_list, int n_invalid, float* out, float* feat)
 {
     if (n_invalid <= 0) return;
     const FrsSrc src = {base_color, roughness, normals, viewdirs, ray_normals, nullptr, nullptr, nullptr, visibility, nullptr};
     const size_t smem = ((((size_t)3 * He * We + 3) & ~(size_t)3) + 64 * FRS_LISTED_WAVES) * sizeof(float);
     shade_forward_frs_listed_kernel<<<frs_listed_grid(n_invalid), 64 * FRS_LISTED_WAVES, smem, s>>>(
-        n_invalid, invalid_list, K, src, incidents, env, He, We, zsamples, frs_area(uniform_area), out);
+        n_invalid, invalid_list, K, src, incidents, env, He, We, zsamples, frs_area(uniform_area), out, feat);
     check_launch(s, false, "shade_forward_frs_listed_kernel");
 }
 

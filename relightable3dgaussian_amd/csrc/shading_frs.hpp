@@ -423,7 +423,7 @@ __device__ __forceinline__ FrsGeom frs_block_geometry(const FrsFrame& f, float a
 __global__ void __launch_bounds__(64 * FRS_WAVES, 3)
 shade_forward_frs_kernel(int P, int K, FrsSrc src, const float* __restrict__ env /* [He*We][3] */, int He, int We,
                          float uniform_area, const float* __restrict__ tables, const uint8_t* __restrict__ valid,
-                         float* __restrict__ out)
+                         float* __restrict__ out, float* __restrict__ feat /* NULL, or the [P,16] feature rows */)
 {
     extern __shared__ __attribute__((aligned(16))) float s_mem[];
     float4* s_env4 = reinterpret_cast<float4*>(s_mem);
@@ -556,6 +556,13 @@ shade_forward_frs_kernel(int P, int K, FrsSrc src, const float* __restrict__ env
 #pragma unroll
             for (int i = 0; i < 6; i++) o[i] = acc[i];
             o[18] = acc[6];
+            if (feat != nullptr) {
+                // straight into the rasterizer's feature row (columns pbr 2..4 | diffuse light 12..14 | mean visibility 15: what
+                // s2_pack_features_kernel copies there; the other columns were written with the activations)
+                float* f = feat + (size_t)g * 16;
+                f[2] = acc[0]; f[3] = acc[1]; f[4] = acc[2];
+                *reinterpret_cast<float4*>(f + 12) = make_float4(acc[3], acc[4], acc[5], acc[6]);
+            }
         }
     }
 }
@@ -845,7 +852,8 @@ __device__ __forceinline__ void frs_listed_direction(const float (&R)[9], const 
 __global__ void __launch_bounds__(64 * FRS_LISTED_WAVES)
 shade_forward_frs_listed_kernel(int n_list, const int* __restrict__ list, int K, FrsSrc src,
                                 const float* __restrict__ incidents, const float* __restrict__ env, int He, int We,
-                                const float* __restrict__ zsamples, float uniform_area, float* __restrict__ out)
+                                const float* __restrict__ zsamples, float uniform_area, float* __restrict__ out,
+                                float* __restrict__ feat)
 {
     extern __shared__ __attribute__((aligned(16))) float s_mem[];
     float* s_env = s_mem;                                                // [ntexel][3]
@@ -881,7 +889,10 @@ shade_forward_frs_listed_kernel(int n_list, const int* __restrict__ list, int K,
         }
         const float r = transpose_reduce<8, true>(v);
         const int ch = transposed_channel<8>(lane);
-        if (transposed_owner<8>(lane) && ch < 7) out[(size_t)g * SHADE_NOUT + (ch < 6 ? ch : 18)] = r * invK;
+        if (transposed_owner<8>(lane) && ch < 7) {
+            out[(size_t)g * SHADE_NOUT + (ch < 6 ? ch : 18)] = r * invK;
+            if (feat != nullptr) feat[(size_t)g * 16 + (ch < 3 ? 2 + ch : 9 + ch)] = r * invK;      // (3..5 -> 12..14, 6 -> 15)
+        }
     }
 }
 

@@ -58,7 +58,7 @@ s2_activate_kernel(int P, const float* __restrict__ xyz, const float* __restrict
                    const float* __restrict__ rough_raw, const float* __restrict__ campos,
                    float* __restrict__ scales, float* __restrict__ rot, float* __restrict__ opacity,
                    float* __restrict__ normal, float* __restrict__ base_color, float* __restrict__ roughness,
-                   float* __restrict__ viewdirs)
+                   float* __restrict__ viewdirs, const float* __restrict__ viewmatrix, float* __restrict__ features)
 {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= P) return;
@@ -72,21 +72,32 @@ s2_activate_kernel(int P, const float* __restrict__ xyz, const float* __restrict
         for (int c = 0; c < 4; c++) rot[i4 + c] = q[c] * inv;
     }
     opacity[i] = sigmoidf_(opacity_raw[i]);
-    float inv;
+    float inv, nrm[3];
     {
         const float v[3] = {normal_raw[i3], normal_raw[i3 + 1], normal_raw[i3 + 2]};
-        float o[3];
-        normalize3(v, 1e-3f, o, inv);
-        normal[i3] = o[0]; normal[i3 + 1] = o[1]; normal[i3 + 2] = o[2];
+        normalize3(v, 1e-3f, nrm, inv);
+        normal[i3] = nrm[0]; normal[i3 + 1] = nrm[1]; normal[i3 + 2] = nrm[2];
     }
     if (base_raw != nullptr) {
+        float bc[3];
 #pragma unroll
-        for (int c = 0; c < 3; c++) base_color[i3 + c] = 0.03f + 0.77f * sigmoidf_(base_raw[i3 + c]);
-        roughness[i] = 0.09f + 0.9f * sigmoidf_(rough_raw[i]);
-        const float d[3] = {campos[0] - xyz[i3], campos[1] - xyz[i3 + 1], campos[2] - xyz[i3 + 2]};
+        for (int c = 0; c < 3; c++) base_color[i3 + c] = bc[c] = 0.03f + 0.77f * sigmoidf_(base_raw[i3 + c]);
+        const float rg = 0.09f + 0.9f * sigmoidf_(rough_raw[i]);
+        roughness[i] = rg;
+        const float p[3] = {xyz[i3], xyz[i3 + 1], xyz[i3 + 2]};
+        const float d[3] = {campos[0] - p[0], campos[1] - p[1], campos[2] - p[2]};
         float o[3];
         normalize3(d, 1e-12f, o, inv);
         viewdirs[i3] = o[0]; viewdirs[i3 + 1] = o[1]; viewdirs[i3 + 2] = o[2];
+        if (features != nullptr) {
+            // the columns of the S=16 feature row that do not wait for the shading integral (s2_pack_features_kernel's, value for
+            // value): depth, depth^2 | . . . | normal | base colour | roughness | . . . .   The shading kernels fill in the rest
+            const float depth = p[0] * viewmatrix[2] + p[1] * viewmatrix[6] + p[2] * viewmatrix[10] + viewmatrix[14];
+            float* f = features + 16 * (size_t)i;
+            *reinterpret_cast<float2*>(f) = make_float2(depth, depth * depth);
+            f[5] = nrm[0]; f[6] = nrm[1]; f[7] = nrm[2];
+            *reinterpret_cast<float4*>(f + 8) = make_float4(bc[0], bc[1], bc[2], rg);
+        }
     }
 }
 
@@ -134,11 +145,13 @@ __device__ __forceinline__ float signf_(float x) { return x > 0.f ? 1.f : (x < 0
 // the scale of the shading backward's fixed-point texture accumulation (shading.hip), so that op needs no reduction pass
 __global__ void __launch_bounds__(256)
 s2_unpack_kernel(int P, const float* __restrict__ dL_dfeatures, const float* __restrict__ shade_out, float light_weight,
-                 float* __restrict__ dL_dpbr, float* __restrict__ dL_ddiffuse, float* __restrict__ block_absmax)
+                 float* __restrict__ dL_dpbr, float* __restrict__ dL_ddiffuse, float* __restrict__ block_absmax,
+                 float* __restrict__ light_l1_sum)
 {
     __shared__ float s_m[4];
+    __shared__ float s_l1[4];
     const int i = blockIdx.x * 256 + threadIdx.x;
-    float m = 0.f;
+    float m = 0.f, l1 = 0.f;
     bool bad = false;
     if (i < P) {
         const float4* g = reinterpret_cast<const float4*>(dL_dfeatures + 16 * (size_t)i);
@@ -150,6 +163,7 @@ s2_unpack_kernel(int P, const float* __restrict__ dL_dfeatures, const float* __r
         const float mean = (dl[0] + dl[1] + dl[2]) / 3.f;
         const float s[3] = {signf_(dl[0] - mean), signf_(dl[1] - mean), signf_(dl[2] - mean)};
         const float sm = (s[0] + s[1] + s[2]) / 3.f;
+        l1 = fabsf(dl[0] - mean) + fabsf(dl[1] - mean) + fabsf(dl[2] - mean);
         const float d0 = g3.x + light_weight * (s[0] - sm), d1 = g3.y + light_weight * (s[1] - sm),
                     d2 = g3.z + light_weight * (s[2] - sm);
         dL_ddiffuse[i3] = d0; dL_ddiffuse[i3 + 1] = d1; dL_ddiffuse[i3 + 2] = d2;
@@ -159,6 +173,10 @@ s2_unpack_kernel(int P, const float* __restrict__ dL_dfeatures, const float* __r
             bad = bad || !(v[c] <= 3.0e38f);
             m = fmaxf(m, v[c]);
         }
+    }
+    if (light_l1_sum != nullptr) {      // the term's VALUE, when no s2_pack_features_kernel ran in front (it adds the same sum)
+        const float tot = block_sum_256(l1, s_l1);
+        if (threadIdx.x == 0) atomicAdd(sum_slot(light_l1_sum), tot);
     }
     if (block_absmax == nullptr) return;
 #pragma unroll
@@ -1145,11 +1163,12 @@ adam_kernel(AdamTable t, float beta1, float beta2, float eps, float bias1, float
 void launch_s2_activate(hipStream_t s, int P, const float* xyz, const float* scaling_raw, const float* rotation_raw,
                         const float* opacity_raw, const float* normal_raw, const float* base_raw,
                         const float* rough_raw, const float* campos, float* scales, float* rot, float* opacity,
-                        float* normal, float* base_color, float* roughness, float* viewdirs)
+                        float* normal, float* base_color, float* roughness, float* viewdirs, const float* viewmatrix,
+                        float* features)
 {
     s2_activate_kernel<<<(P + 255) / 256, 256, 0, s>>>(P, xyz, scaling_raw, rotation_raw, opacity_raw, normal_raw,
                                                        base_raw, rough_raw, campos, scales, rot, opacity, normal,
-                                                       base_color, roughness, viewdirs);
+                                                       base_color, roughness, viewdirs, viewmatrix, features);
     check_launch(s, false, "s2_activate_kernel");
 }
 
@@ -1163,10 +1182,10 @@ void launch_s2_pack(hipStream_t s, int P, const float* xyz, const float* viewmat
 }
 
 void launch_s2_unpack(hipStream_t s, int P, const float* dL_dfeatures, const float* shade_out, float light_weight,
-                      float* dL_dpbr, float* dL_ddiffuse, float* block_absmax)
+                      float* dL_dpbr, float* dL_ddiffuse, float* block_absmax, float* light_l1_sum)
 {
     s2_unpack_kernel<<<(P + 255) / 256, 256, 0, s>>>(P, dL_dfeatures, shade_out, light_weight, dL_dpbr, dL_ddiffuse,
-                                                    block_absmax);
+                                                    block_absmax, light_l1_sum);
     check_launch(s, false, "s2_unpack_kernel");
 }
 

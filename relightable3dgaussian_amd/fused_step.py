@@ -365,6 +365,10 @@ class FusedStage2Step(_BoundedForward):
         # tuning options of THIS object (include/r3dg_hip.h "option contexts"): every library call of the step runs inside it
         self._ctx = _lib.OptionContext()
         self._stagger = os.environ.get("R3DG_FWD_STAGGER", "1") != "0"      # (see forward_backward: where the two tiny launches go)
+        # feature rows without a pack kernel: the activations write the columns they own, the fixed-ray-set shading kernels
+        # theirs (r3dg_shade_frs_forward d_feature_rows) -- one launch and its join less between the shading integral and the
+        # rasterizer.  The general shading kernels keep r3dg_stage2_pack_features.
+        self._direct_rows = os.environ.get("R3DG_DIRECT_ROWS", "1") != "0"
         if self.dp:
             # The shading kernels and the visibility trace are PERSISTENT grids that fill every CU (the backward: 2 workgroups
             # x ~60 KB LDS, ~2 x 230 VGPRs per SIMD); RCCL's workgroups could then only start when one of them retires and
@@ -436,7 +440,10 @@ class FusedStage2Step(_BoundedForward):
                 self.opacity.data_ptr(), self.normal.data_ptr(), self.base_color.data_ptr(), self.roughness.data_ptr(),
                 campos.contiguous().data_ptr(), self.a_scales.data_ptr(), self.a_rot.data_ptr(),
                 self.a_opacity.data_ptr(), self.a_normal.data_ptr(), self.a_base.data_ptr(), self.a_rough.data_ptr(),
-                self.a_viewdirs.data_ptr())
+                self.a_viewdirs.data_ptr(),
+                # the nine columns of the feature rows that do not wait for the shading integral (see forward_backward)
+                cam.world_view_transform.contiguous().data_ptr() if cam is not None and self._direct_rows else None,
+                self.features.data_ptr() if cam is not None and self._direct_rows else None)
         _lib.check(st, "stage2_activate")
 
     def taps(self, He, We):
@@ -558,7 +565,8 @@ class FusedStage2Step(_BoundedForward):
                                   leave_room=self._order_stream is not None and not self.dp,
                                   # the few hundred Gaussians off the rotated path: their general kernel on the (idle) early-Adam
                                   # stream beside the rotation and the main kernel, joined below before the features are packed
-                                  listed_stream=self._listed_stream(), rotated=rotated)
+                                  listed_stream=self._listed_stream(), rotated=rotated,
+                                  feature_rows=self.features if self._direct_rows else None)
             else:
                 _lib.check(L.r3dg_shade_forward_cached(
                     stream(), P, self.K, self.M, self.a_base.data_ptr(), self.a_rough.data_ptr(), self.a_normal.data_ptr(),
@@ -569,10 +577,12 @@ class FusedStage2Step(_BoundedForward):
                     self.shade_out.data_ptr()), "shade_forward")
             if self._frs is not None and self._listed_stream() is not None:
                 _lib.stream_wait(torch.cuda.current_stream(), self._listed_stream())
-            _lib.check(L.r3dg_stage2_pack_features(
-                stream(), P, self.xyz.data_ptr(), vm.data_ptr(), self.a_normal.data_ptr(), self.a_base.data_ptr(),
-                self.a_rough.data_ptr(), self.shade_out.data_ptr(), self.features.data_ptr(),
-                self.sums[3].data_ptr()), "stage2_pack_features")
+            packed = not (self._frs is not None and self._direct_rows)
+            if packed:
+                _lib.check(L.r3dg_stage2_pack_features(
+                    stream(), P, self.xyz.data_ptr(), vm.data_ptr(), self.a_normal.data_ptr(), self.a_base.data_ptr(),
+                    self.a_rough.data_ptr(), self.shade_out.data_ptr(), self.features.data_ptr(),
+                    self.sums[3].data_ptr()), "stage2_pack_features")
             fw = pending.finish(self._order_stream)
             R, n_contrib, image, opacity, depth, feature, pseudo_normal, sxyz, weights, radii, geom, binning, img = fw
             # the Adam launches of this iteration skip themselves when the view was dropped; under data parallelism they
@@ -695,7 +705,9 @@ class FusedStage2Step(_BoundedForward):
                 self._early = True
             _lib.check(L.r3dg_stage2_unpack_gradients(
                 stream(), P, dL_dfeatures.data_ptr(), self.shade_out.data_ptr(), self.w["light"] / (3.0 * P),
-                self.d_pbr.data_ptr(), self.d_diffuse.data_ptr(), self._absmax.data_ptr()), "stage2_unpack_gradients")
+                self.d_pbr.data_ptr(), self.d_diffuse.data_ptr(), self._absmax.data_ptr(),
+                # (the light-smoothness term's value, when no pack kernel added it)
+                None if packed else self.sums[3].data_ptr()), "stage2_unpack_gradients")
             # the texture-gradient accumulator comes back zeroed from r3dg_stage2_env_backward (consume), the gradient
             # scale from the unpack kernel: nothing sits between that kernel and the shading backward
             if self._d_env is None or self._d_env.shape != env_c.shape:
@@ -1023,7 +1035,7 @@ class FusedStage1Step(_BoundedForward):
             _lib.check(L.r3dg_stage2_activate(
                 stream(), P, self.xyz.data_ptr(), self.scaling.data_ptr(), self.rotation.data_ptr(),
                 self.opacity.data_ptr(), self.normal.data_ptr(), None, None, None, self.a_scales.data_ptr(),
-                self.a_rot.data_ptr(), self.a_opacity.data_ptr(), self.a_normal.data_ptr(), None, None, None),
+                self.a_rot.data_ptr(), self.a_opacity.data_ptr(), self.a_normal.data_ptr(), None, None, None, None, None),
                 "stage2_activate")
             self._iter += 1
             use_bounded = self._use_bounded(W, H)

@@ -195,7 +195,7 @@ class RelightRenderer:
                 self.opacity.data_ptr(), self.normal.data_ptr(), self.base_color.data_ptr(), self.roughness.data_ptr(),
                 campos.contiguous().data_ptr(), self.a_scales.data_ptr(), self.a_rot.data_ptr(),
                 self.a_opacity.data_ptr(), self.a_normal.data_ptr(), self.a_base.data_ptr(), self.a_rough.data_ptr(),
-                self.a_viewdirs.data_ptr())
+                self.a_viewdirs.data_ptr(), None, None)
         _lib.check(st, "stage2_activate")
 
     def _shade_cached(self, L, stream, P, He, We, tr, taps):

@@ -204,16 +204,21 @@ class FixedRaySet:
         _lib.check(st, "shade_frs_rotate")
 
     def forward(self, base_color, roughness, normals, viewdirs, incidents, env, visibility, out, uniform_area=None,
-                leave_room=False, listed_stream=None, rotated=False):
+                leave_room=False, listed_stream=None, rotated=False, feature_rows=None):
         """Writes columns 0..5 and 18 of out [P,19] (pbr, diffuse_light, mean visibility); keeps the rotated coefficients
         for `backward`.  `uniform_area`: the area of every sample (None = 2 pi, what fibonacci_sphere_sampling assigns).
         `listed_stream` (a torch.cuda.Stream): the kernel on the Gaussians off the rotated path runs there, beside the main
-        kernel; the caller waits for that stream before reading `out`."""
+        kernel; the caller waits for that stream before reading `out`.  `feature_rows` ([P,16], optional): the same three
+        results also go straight into columns 2..4, 12..14, 15 of the rasterizer's feature rows (neilf.py:115-122)."""
+        if feature_rows is not None and (tuple(feature_rows.shape) != (self.P, 16) or not feature_rows.is_contiguous() or
+                                         feature_rows.dtype != torch.float32):
+            raise RuntimeError("feature_rows must be a contiguous float32 [P,16] tensor")
         head, _keep = self._common(base_color, roughness, normals, viewdirs, incidents, env, visibility, uniform_area)
         with torch.cuda.device(base_color.device):
             st = _lib.lib().r3dg_shade_frs_forward(_lib.current_stream(), *head, self.cprime.data_ptr(),
                                                    1 | (4 if leave_room else 0) | (8 if rotated else 0), out.data_ptr(),
-                                                   listed_stream.cuda_stream if listed_stream is not None else None)
+                                                   listed_stream.cuda_stream if listed_stream is not None else None,
+                                                   _lib.ptr(feature_rows))
         _lib.check(st, "shade_frs_forward")
         return out
 

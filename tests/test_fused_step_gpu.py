@@ -423,6 +423,38 @@ def test_bounded_iterations_equal_two_phase_iterations():
         assert ok, msg
 
 
+def test_feature_rows_written_in_place_equal_the_packed_rows(monkeypatch):
+    """Without r3dg_stage2_pack_features (the default when the fixed-ray-set kernels run): r3dg_stage2_activate writes the nine
+    columns of the [P,16] feature rows that do not wait for the shading integral, r3dg_shade_frs_forward (main and listed
+    kernels) the other seven, and r3dg_stage2_unpack_gradients adds the light-smoothness sum.  The rows are the packed rows bit
+    for bit (neilf.py:115-122), the loss trajectory and the first iteration's gradients the same up to the order of float sums."""
+    from relightable3dgaussian_amd.fused_step import FusedStage2Step
+    P, res, K = 4000, 128, 8
+    runs = {}
+    for direct in ("0", "1"):
+        monkeypatch.setenv("R3DG_DIRECT_ROWS", direct)
+        params, ref, fused, cam, bg, gt = _setup(P=P, res=res, K=K, seed=11, weights={"light": 0.01})
+        step = FusedStage2Step(params, K, loss_weights={"light": 0.01})      # (its own visibility update: the Fibonacci ray set)
+        step.features.fill_(float("nan"))                      # every element has to be written by somebody
+        step(cam, bg, gt)
+        assert step._frs is not None and step._frs.n_invalid > 0, "the test wants the rotated path with listed Gaussians"
+        rows = step.features.clone()
+        grads = {k: step.grads[k].clone() for k in ("incidents", "base_color", "roughness", "xyz", "env")}
+        losses = [float(step.loss())]
+        for it in range(3):
+            step(cam, bg, gt)
+            losses.append(float(step.loss()))
+        runs[direct] = (rows, losses, grads)
+    assert torch.equal(runs["0"][0], runs["1"][0]), "feature rows differ: max %g" % float((runs["0"][0] - runs["1"][0]).abs().max())
+    assert np.allclose(runs["0"][1], runs["1"][1], rtol=2e-6), (runs["0"][1], runs["1"][1])
+    # (gradients, not parameters: Adam turns a gradient of 1e-14 -- the noise floor of the float atomics, which differs between
+    # two runs of the SAME configuration -- into a step of the size of the learning rate)
+    for k, g0 in runs["0"][2].items():
+        g1 = runs["1"][2][k]
+        tol = 1e-4 * float(g0.abs().max()) + 1e-12
+        assert float((g0 - g1).abs().max()) <= tol, (k, float((g0 - g1).abs().max()), tol)
+
+
 def test_bounded_iteration_that_overflows_is_dropped_not_applied():
     """A view that needs more instance slots than the bounded forward has: the iteration's Adam launches update nothing,
     poll_overflow() reports it, takes the step count back and doubles the capacity; the next iteration trains again."""

@@ -632,15 +632,16 @@ def test_fused_stage2_iteration_host_logic_with_a_recording_library(monkeypatch)
     for _ in range(2):
         step(cam, torch.ones(3), z(3, H, W), image_mask=mask)
     names = [c[0] for c in calls]
-    assert names.count("r3dg_stage2_smooth_forward") == 2 and names.count("r3dg_stage2_smooth_backward") == 2
-    assert names.index("r3dg_stage2_loss") < names.index("r3dg_stage2_smooth_forward") < names.index("r3dg_stage2_smooth_backward")
+    # the smoothness terms: one streaming kernel behind the loss kernel (the three-pass formulation only under R3DG_SMOOTH_FUSED=0)
+    assert names.count("r3dg_stage2_smooth_fused") == 2 and names.count("r3dg_stage2_smooth_forward") == 0
+    assert names.index("r3dg_stage2_loss") < names.index("r3dg_stage2_smooth_fused")
     # pbr 2-4, base colour 8-10, roughness 11, diffuse light 12-14; the normal maps' gradient has no consumer
     assert feats == [(2, 3, 4, 8, 9, 10, 11, 12, 13, 14)] * 2
     adam = [c[1] for c in calls if c[0] == "r3dg_adam_step"]
     assert len(adam) == 2 and all(a[1] == 4 for a in adam)                     # ONE launch per iteration, four groups that train
     ab = [c[1] for c in calls if c[0] == "r3dg_stage2_activate_backward"][0]
     assert ab[2] is None and ab[19] is None and ab[24] == step.grads["base_color"].data_ptr()   # no geometry in or out
-    sm = [c[1] for c in calls if c[0] == "r3dg_stage2_smooth_forward"][0]
+    sm = [c[1] for c in calls if c[0] == "r3dg_stage2_smooth_fused"][0]
     N_ = H * W
     assert sm[7] == mask.data_ptr() and abs(sm[8] - 1.0 / (3 * N_)) < 1e-9 and abs(sm[9] - 0.5 / (3 * N_)) < 1e-9
     loss_args = [c[1] for c in calls if c[0] == "r3dg_stage2_loss"][0]
@@ -673,7 +674,7 @@ def test_fused_stage2_iteration_spreads_the_fixed_ray_set_path_over_three_stream
     import contextlib
     import types
     from relightable3dgaussian_amd import _lib, fused_step, rasterizer_ops, shading_ops
-    events = []
+    events, rows = [], []
 
     class Recorder:
         def __getattr__(self, name):
@@ -724,8 +725,9 @@ def test_fused_stage2_iteration_spreads_the_fixed_ray_set_path_over_three_stream
         def rotate(self, incidents):
             events.append(("frs.rotate", ()))
 
-        def forward(self, *a, uniform_area=None, leave_room=False, listed_stream=None, rotated=False):
+        def forward(self, *a, uniform_area=None, leave_room=False, listed_stream=None, rotated=False, feature_rows=None):
             events.append(("frs.forward", (listed_stream, rotated, leave_room)))
+            rows.append(feature_rows)
 
         def backward(self, *a, uniform_area=None, out_incidents=None, out_env=None, block_absmax=None, rotate_stream=None):
             events.append(("frs.backward", (rotate_stream,)))
@@ -778,12 +780,17 @@ def test_fused_stage2_iteration_spreads_the_fixed_ray_set_path_over_three_stream
     names = [e[0] for e in events]
     start = len(names) - 1 - names[::-1].index("frs.rotate") - 2          # (the fork and the stream context in front of it)
     it, args = names[start:], [e[1] for e in events[start:]]
-    pos = {n: it.index(n) for n in ("frs.rotate", "r3dg_stage2_activate", "raster.begin", "frs.forward", "r3dg_stage2_pack_features",
+    pos = {n: it.index(n) for n in ("frs.rotate", "r3dg_stage2_activate", "raster.begin", "frs.forward",
                                     "raster.finish", "raster.backward", "r3dg_stage2_unpack_gradients", "frs.backward",
                                     "r3dg_stage2_activate_backward")}
     assert sorted(pos, key=pos.get) == ["frs.rotate", "r3dg_stage2_activate", "raster.begin", "frs.forward",
-                                        "r3dg_stage2_pack_features", "raster.finish", "raster.backward",
+                                        "raster.finish", "raster.backward",
                                         "r3dg_stage2_unpack_gradients", "frs.backward", "r3dg_stage2_activate_backward"]
+    # no pack kernel on this path: the activations and the shading kernels write the feature rows between them, and the
+    # light-smoothness sum comes from the unpack kernel (its last argument)
+    assert "r3dg_stage2_pack_features" not in it and rows[-1] is step.features
+    assert args[pos["r3dg_stage2_activate"]][-1] == step.features.data_ptr()
+    assert args[pos["r3dg_stage2_unpack_gradients"]][-1] == step.sums[3].data_ptr()
     # the rotation (and the softplus / sum reset behind it) runs inside the early stream's context, behind a pooled-event fork
     assert it[pos["frs.rotate"] - 1] == "enter" and args[pos["frs.rotate"] - 1] == (early.cuda_stream,)
     joins = [a for n, a in zip(it, args) if n == "r3dg_stream_wait_stream"]
