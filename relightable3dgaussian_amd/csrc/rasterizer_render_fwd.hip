@@ -236,39 +236,44 @@ render_forward_wave_kernel(const uint2* __restrict__ ranges, const uint32_t* __r
     }
 }
 
-// K9: surface point in camera space from the premultiplied depth / opacity buffers (forward.cu:398-425)
-__global__ void __launch_bounds__(256)
-surface_xyz_kernel(int W, int H, float focal_x, float focal_y, float cx, float cy, const float* __restrict__ opacities,
-                   const float* __restrict__ depths, float* __restrict__ surface_xyz)
+// K9 + K10 in one launch.  K9: surface point in camera space from the premultiplied depth / opacity buffers (forward.cu:398-425);
+// K10: pseudo normal from a 3x3 edge-clamped stencil on those points (forward.cu:427-491).  The reference runs K10 behind a
+// grid-wide barrier on K9's output; here every thread forms the nine points of its stencil itself, with K9's expression (the
+// same values bit for bit: nine divisions instead of one per pixel, on a launch that waits for memory), and stores its own.
+__device__ __forceinline__ void surface_point(int x, int y, int W, float focal_x, float focal_y, float cx, float cy,
+                                              const float* __restrict__ opacities, const float* __restrict__ depths, float (&p)[3])
 {
-    const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
-    if (x >= W || y >= H) return;
-    const size_t HW = (size_t)H * W, id = (size_t)y * W + x;
+    const size_t id = (size_t)y * W + x;
     const float depth = depths[id] / fmaxf(opacities[id], 0.0000001f);
-    surface_xyz[id] = (x - cx) / focal_x * depth;
-    surface_xyz[HW + id] = (y - cy) / focal_y * depth;
-    surface_xyz[2 * HW + id] = depth;
+    p[0] = (x - cx) / focal_x * depth;
+    p[1] = (y - cy) / focal_y * depth;
+    p[2] = depth;
 }
 
-// K10: pseudo normal from a 3x3 edge-clamped stencil on surface_xyz (forward.cu:427-491); needs K9 complete.
 __global__ void __launch_bounds__(256)
-pseudo_normal_kernel(int W, int H, const float* __restrict__ vm, float* __restrict__ normals,
-                     const float* __restrict__ surface_xyz)
+pseudo_normal_kernel(int W, int H, float focal_x, float focal_y, float cx, float cy, const float* __restrict__ vm,
+                     const float* __restrict__ opacities, const float* __restrict__ depths, float* __restrict__ normals,
+                     float* __restrict__ surface_xyz)
 {
     const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
     if (x >= W || y >= H) return;
     const size_t HW = (size_t)H * W;
-    const int ym = y == 0 ? 0 : y - 1, yp = y == H - 1 ? H - 1 : y + 1;
-    const int xm = x == 0 ? 0 : x - 1, xp = x == W - 1 ? W - 1 : x + 1;
-    const size_t i00 = (size_t)W * ym + xm, i01 = (size_t)W * ym + x, i02 = (size_t)W * ym + xp;
-    const size_t i10 = (size_t)W * y + xm, i11 = (size_t)W * y + x, i12 = (size_t)W * y + xp;
-    const size_t i20 = (size_t)W * yp + xm, i21 = (size_t)W * yp + x, i22 = (size_t)W * yp + xp;
+    const int ys[3] = {y == 0 ? 0 : y - 1, y, y == H - 1 ? H - 1 : y + 1};
+    const int xs[3] = {x == 0 ? 0 : x - 1, x, x == W - 1 ? W - 1 : x + 1};
+    float s[3][3][3];                                        // [row][column][component]
+#pragma unroll
+    for (int a = 0; a < 3; a++)
+#pragma unroll
+        for (int b = 0; b < 3; b++) surface_point(xs[b], ys[a], W, focal_x, focal_y, cx, cy, opacities, depths, s[a][b]);
+    const size_t i11 = (size_t)W * y + x;
     float ga[3], gb[3];
 #pragma unroll
     for (int i = 0; i < 3; i++) {
-        const float* s = surface_xyz + i * HW;
-        ga[i] = -0.125f * s[i00] + 0.125f * s[i02] - 0.25f * s[i10] + 0.25f * s[i12] - 0.125f * s[i20] + 0.125f * s[i22];
-        gb[i] = -0.125f * s[i00] - 0.25f * s[i01] - 0.125f * s[i02] + 0.125f * s[i20] + 0.25f * s[i21] + 0.125f * s[i22];
+        surface_xyz[i * HW + i11] = s[1][1][i];
+        ga[i] = -0.125f * s[0][0][i] + 0.125f * s[0][2][i] - 0.25f * s[1][0][i] + 0.25f * s[1][2][i] - 0.125f * s[2][0][i] +
+                0.125f * s[2][2][i];
+        gb[i] = -0.125f * s[0][0][i] - 0.25f * s[0][1][i] - 0.125f * s[0][2][i] + 0.125f * s[2][0][i] + 0.25f * s[2][1][i] +
+                0.125f * s[2][2][i];
     }
     float nx = ga[1] * gb[2] - ga[2] * gb[1];
     float ny = -ga[0] * gb[2] + ga[2] * gb[0];
@@ -322,9 +327,7 @@ void launch_pseudo_normal(hipStream_t s, int W, int H, const float* vm, float fo
                           bool debug)
 {
     dim3 grid((W + 63) / 64, (H + 3) / 4);
-    surface_xyz_kernel<<<grid, 256, 0, s>>>(W, H, focal_x, focal_y, cx, cy, opacities, depths, surface_xyz);
-    check_launch(s, debug, "surface_xyz_kernel");
-    pseudo_normal_kernel<<<grid, 256, 0, s>>>(W, H, vm, normals, surface_xyz);
+    pseudo_normal_kernel<<<grid, 256, 0, s>>>(W, H, focal_x, focal_y, cx, cy, vm, opacities, depths, normals, surface_xyz);
     check_launch(s, debug, "pseudo_normal_kernel");
 }
 

@@ -874,7 +874,11 @@ class FusedStage2Step(_BoundedForward):
 
     @_in_context
     def __call__(self, cam, bg, gt, image_mask=None):
-        outs = self.forward_backward(cam, bg, gt, early_adam=True, image_mask=image_mask)
+        # the SH group's Adam under the shading backward: pays while the group's 64 bytes x 48 per Gaussian mostly live in the
+        # 256 MB last-level cache (300k Gaussians: 58 us of Adam for 31 us of slower shading backward); streamed from HBM it
+        # costs the latency-sensitive shading kernel nearly its whole duration (2M: 0.99 ms of Adam for +0.85 ms, 159 vs 163 it/s)
+        early = os.environ.get("R3DG_EARLY_ADAM", "1" if self.P <= 1_000_000 else "0") != "0"
+        outs = self.forward_backward(cam, bg, gt, early_adam=early, image_mask=image_mask)
         self.optimizer_step()
         return outs
 
