@@ -83,9 +83,14 @@ class _PendingForward:
                     st = L.r3dg_rasterize_forward_finish_on(self.ticket, C.c_void_p(ordering_stream.cuda_stream),
                                                             C.byref(rendered))
         self.ticket = None
+        geomBuffer, binningBuffer, imgBuffer = self.rs.buffers
+        # the resize callbacks are closures over the resizer, which holds them: a reference cycle around the frame's scratch
+        # buffers that only the garbage collector would break (hundreds of MB of device memory per frame in the meantime).
+        # The library does not call them after this point
+        self.rs.callbacks = None
+        self.rs = None
         _lib.check(st, "rasterize_gaussians")
         out_color, out_opacity, out_depth, out_feature, out_normal, out_surface_xyz, out_weights, radii = self.outs
-        geomBuffer, binningBuffer, imgBuffer = self.rs.buffers
         H, W = self.H, self.W
         if imgBuffer.numel() == 0:
             imgBuffer = torch.zeros(int(L.r3dg_image_state_bytes(W, H)), dtype=torch.uint8, device=self.dev)

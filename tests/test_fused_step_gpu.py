@@ -455,6 +455,36 @@ def test_feature_rows_written_in_place_equal_the_packed_rows(monkeypatch):
         assert float((g0 - g1).abs().max()) <= tol, (k, float((g0 - g1).abs().max()), tol)
 
 
+def test_iterations_leave_no_device_memory_to_the_garbage_collector():
+    """A frame's scratch buffers (geometry / binning / image state) are freed by reference counting when the iteration is over:
+    no reference cycle holds a device tensor (the resize callbacks used to be closures over the object that owns them and the
+    buffers -- hundreds of MB per frame that only a generation-2 collection released)."""
+    import gc
+    from relightable3dgaussian_amd.fused_step import FusedStage2Step
+    params, ref, fused, cam, bg, gt = _setup(P=4000, res=128, K=8, seed=11)
+    step = FusedStage2Step(params, 8)
+    for it in range(3):
+        step(cam, bg, gt)
+    del ref, fused
+    gc.collect()
+    was = gc.isenabled()
+    gc.disable()
+    gc.set_debug(gc.DEBUG_SAVEALL)
+    try:
+        for it in range(6):
+            step(cam, bg, gt)
+        torch.cuda.synchronize()
+        gc.collect()
+        held = [o for o in gc.garbage if isinstance(o, torch.Tensor) and o.is_cuda]
+        nbytes = sum(t.numel() * t.element_size() for t in held)
+    finally:
+        gc.garbage.clear()
+        gc.set_debug(0)
+        if was:
+            gc.enable()
+    assert not held, "%d device tensors (%.1f MB) were only reachable through reference cycles" % (len(held), nbytes / 2**20)
+
+
 def test_bounded_iteration_that_overflows_is_dropped_not_applied():
     """A view that needs more instance slots than the bounded forward has: the iteration's Adam launches update nothing,
     poll_overflow() reports it, takes the step count back and doubles the capacity; the next iteration trains again."""
