@@ -616,6 +616,14 @@ def test_fused_stage2_iteration_host_logic_with_a_recording_library(monkeypatch)
     assert order == [fwd, "r3dg_stage2_pack_features", "r3dg_ssim_forward_pair", "r3dg_stage2_loss", "r3dg_adam_step",
                      "r3dg_stage2_unpack_gradients", bwd, "r3dg_stage2_activate_backward", "r3dg_adam_step"], order
     assert "r3dg_stage2_smooth_forward" not in names                          # run_nerf.sh's objective has no smoothness terms
+    # above a million Gaussians (R3DG_EARLY_ADAM overrides the size rule) the SH group is NOT updated under the shading backward:
+    # one Adam launch per iteration, all ten groups, behind the chain rule
+    monkeypatch.setenv("R3DG_EARLY_ADAM", "0")
+    calls.clear()
+    step(cam, torch.ones(3), z(3, H, W))
+    late = [c for c in calls if c[0] == "r3dg_adam_step"]
+    assert len(late) == 1 and late[0][1][1] == 10 and calls[-1][0] in ("r3dg_adam_step", "r3dg_context_make_current")
+    monkeypatch.delenv("R3DG_EARLY_ADAM")
     # ---- the Synthetic4Relight / DTU schedule (run_syn4.sh:22-42): smoothness terms on, every geometry rate 0 ----------------
     from relightable3dgaussian_amd import train_step
     feats = []
