@@ -107,7 +107,8 @@ def _algorithmic_bytes(stage, P, R, N, S, K=64, S_bwd=None):
         # per Gaussian: material 28 + normal 12 + view 12 + ray normal 12 + rotated coefficients 192 + validity 1 + 7 outputs 28
         # (285), backward + upstream gradients 24 + gradients written 28 + coefficient gradient 192 (529).  (SURVEY 8d priced the
         # reference's cache layout, direction 12 + visibility 4 per sample: (260+16K) / (476+16K) -- what the GENERAL kernels move.)
-        "shade_forward": (285.0 + 12 * K) * P,
+        # (+ 28: the seven results a second time, straight into the rasterizer's feature rows -- no pack kernel)
+        "shade_forward": (313.0 + 12 * K) * P,
         "shade_backward": (529.0 + 12 * K) * P,
         "shade_forward_general": (260.0 + 16 * K) * P,
         "shade_backward_general": (476.0 + 16 * K) * P,
@@ -118,8 +119,9 @@ def _algorithmic_bytes(stage, P, R, N, S, K=64, S_bwd=None):
         "shade_forward_transport": (180.0 + 12 * K) * P,
         # Adam: 28 B per parameter float (p, g, m, v read; p, m, v written); 127 floats per Gaussian in stage 2
         "adam_step": 28.0 * 127 * P,
-        # glue: activations 68 B read + 72 B written; feature row 40+76 read, 64 written; loss 27 maps read, 20 written
-        "stage2_activate": 140.0 * P,
+        # glue: activations 68 B read + 72 B written + the nine feature-row columns they own (36 B); feature row (general
+        # shading kernels only) 40+76 read, 64 written; loss 27 maps read, 20 written
+        "stage2_activate": 176.0 * P,
         "stage2_pack_features": 180.0 * P,
         "stage2_unpack_gradients": 164.0 * P,
         "stage2_activate_backward": (68.0 + 64 + 28 + 44 + 72) * P,
