@@ -303,6 +303,11 @@ int r3dg_stream_wait_stream(void* waiter, void* signaller);
  * fused_step prices an all-reduce it cannot run on a one-GPU box by queueing this behind each bucket's one-rank (identity)
  * collective, sized to the ring time of an assumed bus bandwidth (R3DG_DP_FAKE_COMM_GBS). */
 int r3dg_spin(void* stream, float microseconds);
+/* Measurement aid: a device-filling grid of VALU-only waves (iters x 16 fp32 FMAs per lane) that read the shader-clock counter and
+ * the constant-rate wall clock on both sides.  d_out3[0] += shader cycles, [1] += wall ticks, [2] += waves (zeroed here);
+ * shader clock under VALU load = d_out3[0] / d_out3[1] x *wall_clock_khz.  bench.py reports it beside the headline, so that a box
+ * that ran at a lower clock says so (two boxes of the pool differed by 8 % on identical code in round 4).  d_sink: one float. */
+int r3dg_clock_probe(void* stream, int iters, unsigned long long* d_out3, float* d_sink, int* wall_clock_khz);
 
 /* The first step of r3dg_shade_frs_forward on its own: d_cprime [P,48] = the incident-light coefficients rotated into each
  * Gaussian's ray frame.  It depends on d_incidents and d_ray_normals only, so a caller can queue it (on another stream) as soon

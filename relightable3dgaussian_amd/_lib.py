@@ -85,6 +85,7 @@ _SIGNATURES = {
     "r3dg_render_equation_forward": (_i, [_p, _i, _i, _i, _i] + [_p] * 8 + [_i] + [_p] * 4),
     "r3dg_render_equation_forward_complex": (_i, [_p, _i, _i, _i, _i] + [_p] * 8 + [_i] + [_p] * 11),
     "r3dg_render_equation_backward": (_i, [_p, _i, _i, _i, _i] + [_p] * 8 + [_i] + [_p] * 11),
+    "r3dg_clock_probe": (_i, [_p, _i, _p, _p, C.POINTER(C.c_int)]),
     "r3dg_stage2_activate": (_i, [_p, _i] + [_p] * 17),
     "r3dg_stage2_pack_features": (_i, [_p, _i] + [_p] * 8),
     "r3dg_stage2_unpack_gradients": (_i, [_p, _i, _p, _p, _f, _p, _p, _p, _p]),
@@ -232,6 +233,20 @@ def stream_wait(waiter, signaller):
     """`waiter` (a torch.cuda.Stream) waits for everything queued on `signaller` so far: torch's waiter.wait_stream(signaller)
     through the library's pooled events (r3dg_stream_wait_stream)."""
     check(lib().r3dg_stream_wait_stream(waiter.cuda_stream, signaller.cuda_stream), "stream_wait_stream")
+
+
+def shader_clock_ghz(device="cuda", iters=4000):
+    """The shader clock under VALU load, measured on the device itself (r3dg_clock_probe): cycles of the shader-clock counter per
+    tick of the constant-rate wall clock, summed over a device-filling grid of FMA-only waves.  -> (GHz, waves that reported)."""
+    import torch
+    out = torch.zeros(3, dtype=torch.int64, device=device)
+    sink = torch.zeros(1, dtype=torch.float32, device=device)
+    khz = C.c_int(0)
+    with torch.cuda.device(out.device):
+        check(lib().r3dg_clock_probe(current_stream(), int(iters), out.data_ptr(), sink.data_ptr(), C.byref(khz)), "clock_probe")
+        torch.cuda.synchronize()
+    cyc, ticks, waves = (int(v) for v in out.tolist())
+    return (cyc / max(ticks, 1)) * khz.value * 1e-6, waves
 
 
 def profile_read():

@@ -886,6 +886,15 @@ def run(args):
                          "stalled its threads (a host effect; 0 = the timed steps were not held up by it)") if quota1 else None
     prof = _lib.profile_read()
     L.r3dg_profile_enable(0)
+    # the shader clock this box sustains under VALU load, measured on the device right behind the timed region (boxes of the pool
+    # differed by 8 % on identical code): what `roofline.valu_bound` and a comparison between two bench lines should be read with
+    try:
+        ghz, nwaves = _lib.shader_clock_ghz(dev)
+        device_clock = dict(shader_clock_ghz_under_valu_load=round(ghz, 3), waves=nwaves,
+                            what="r3dg_clock_probe behind the timed region: shader-clock cycles per wall-clock tick over a "
+                                 "device-filling grid of FMA-only waves")
+    except Exception as e:                         # (never the reason a bench line is missing)
+        device_clock = dict(error=str(e)[:120])
     exposed_comm = None
     if dp and fused and hasattr(step_fn, "exposed_comm_ms"):
         exposed_comm = step_fn.exposed_comm_ms()
@@ -962,6 +971,7 @@ def run(args):
                                        P, W_img, H_img, R_mean),
                        "parallelism": "dp%d (views sharded over ranks; bucketed async RCCL all-reduce of per-Gaussian grads)" % world},
             "roofline": roofline, "kernels": kernels, "spread_iters_per_s": spread, "host_cpu": host_cpu,
+            "device_clock": device_clock,
         }
         if dp:
             # rank 0's compute stream: mean time per iteration it stood waiting for gradient all-reduce buckets (C, then the

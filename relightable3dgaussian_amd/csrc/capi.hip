@@ -1401,6 +1401,50 @@ int r3dg_spin(void* stream_, float microseconds)
     });
 }
 
+// every wave of a device-filling grid: `iters` x 16 independent fp32 FMAs per lane (VALU issue is the only thing it does), the
+// shader-clock counter (s_memtime) and the constant-rate wall clock (s_memrealtime) read on both sides.  out[0] += shader cycles,
+// out[1] += wall ticks, out[2] += 1 per wave: sum(cycles) / sum(ticks) x wall-clock rate = the shader clock UNDER VALU LOAD.
+__global__ void __launch_bounds__(256) clock_probe_kernel(int iters, unsigned long long* __restrict__ out, float* __restrict__ sink)
+{
+    float a[16];
+#pragma unroll
+    for (int i = 0; i < 16; i++) a[i] = (float)(threadIdx.x + i) * 1e-3f;
+    const float m = 0.999f, c = 1e-4f;
+    const unsigned long long w0 = wall_clock64();
+    const long long t0 = clock64();
+    for (int it = 0; it < iters; it++) {
+#pragma unroll
+        for (int i = 0; i < 16; i++) a[i] = __builtin_fmaf(a[i], m, c);
+    }
+    const long long t1 = clock64();
+    const unsigned long long w1 = wall_clock64();
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; i++) s += a[i];
+    if (s == 123456.789f) sink[0] = s;                       // (keeps the loop)
+    if ((threadIdx.x & 63) == 0) {
+        atomicAdd(&out[0], (unsigned long long)(t1 - t0));
+        atomicAdd(&out[1], w1 - w0);
+        atomicAdd(&out[2], 1ull);
+    }
+}
+
+int r3dg_clock_probe(void* stream_, int iters, unsigned long long* d_out3, float* d_sink, int* wall_clock_khz)
+{
+    if (iters <= 0 || !d_out3 || !d_sink) return invalid("clock_probe: bad arguments");
+    return guarded([&]() -> int {
+        int dev = 0, khz = 100000, cus = 256;
+        R3DG_HIP(hipGetDevice(&dev));
+        if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, dev) != hipSuccess || khz <= 0) khz = 100000;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+        if (wall_clock_khz) *wall_clock_khz = khz;
+        R3DG_HIP(hipMemsetAsync(d_out3, 0, 3 * sizeof(unsigned long long), (hipStream_t)stream_));
+        clock_probe_kernel<<<cus * 8, 256, 0, (hipStream_t)stream_>>>(iters, d_out3, d_sink);      // 8 waves per SIMD
+        check_launch((hipStream_t)stream_, false, "clock_probe_kernel");
+        return R3DG_OK;
+    });
+}
+
 int r3dg_shade_frs_rotate(void* stream_, int P, const float* incidents, const float* ray_normals, float* cprime)
 {
     if (P < 0) return invalid("shade_frs_rotate: bad sizes");

@@ -485,6 +485,16 @@ def test_iterations_leave_no_device_memory_to_the_garbage_collector():
     assert not held, "%d device tensors (%.1f MB) were only reachable through reference cycles" % (len(held), nbytes / 2**20)
 
 
+def test_clock_probe_reports_a_plausible_shader_clock():
+    """r3dg_clock_probe (bench.py's `device_clock`): every wave of a device-filling FMA-only grid reports, and the ratio of the
+    shader-clock counter to the constant-rate wall clock is a clock an MI355X can run at."""
+    from relightable3dgaussian_amd import _lib
+    ghz, waves = _lib.shader_clock_ghz(DEV, 2000)
+    cus = torch.cuda.get_device_properties(0).multi_processor_count
+    assert waves == cus * 8 * 4
+    assert 0.8 < ghz < 3.2, ghz
+
+
 def test_bounded_iteration_that_overflows_is_dropped_not_applied():
     """A view that needs more instance slots than the bounded forward has: the iteration's Adam launches update nothing,
     poll_overflow() reports it, takes the step count back and doubles the capacity; the next iteration trains again."""

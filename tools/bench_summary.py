@@ -28,3 +28,4 @@ for k, v in (d.get("other_configs") or {}).items():
 cb = d.get("cpu_baseline") or {}
 print("cpu_baseline:", {k: cb.get(k) for k in ("value", "unit", "cores", "kind")})
 print("host_cpu:", d.get("host_cpu"))
+print("device_clock:", d.get("device_clock"))
