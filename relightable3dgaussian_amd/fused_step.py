@@ -504,7 +504,9 @@ class FusedStage2Step(_BoundedForward):
         P, dev = self.P, self.dev
         H, W = cam.image_height, cam.image_width
         N = H * W
-        stream = _lib.current_stream
+        main = torch.cuda.current_stream(dev)           # (looked up ONCE: 10 us of Python per lookup, this method had six)
+        main_raw = main.cuda_stream
+        stream = lambda: main_raw
         vm = cam.world_view_transform.contiguous()
         campos = cam.camera_center.contiguous()
         empty = torch.Tensor([])
@@ -514,7 +516,7 @@ class FusedStage2Step(_BoundedForward):
             rotated_for = None
             aux = self._aux_stream()
             if aux is not None:
-                _lib.stream_wait(aux, torch.cuda.current_stream())
+                _lib.stream_wait(aux, main)
                 with torch.cuda.stream(aux):
                     self._frs.rotate(self.incidents)
                     # (also on the side stream, BEHIND the rotation.  Measured: with these two tiny launches on the main stream the
@@ -552,7 +554,7 @@ class FusedStage2Step(_BoundedForward):
                 self.sums.zero_()
                 env_c = F.softplus(self.env)[0]                                  # DirectLightMap.get_env
             else:
-                _lib.stream_wait(torch.cuda.current_stream(), aux)
+                _lib.stream_wait(main, aux)
             He, We = env_c.shape[0], env_c.shape[1]
             taps = self.taps(He, We)
             if self._frs is not None:
@@ -576,7 +578,7 @@ class FusedStage2Step(_BoundedForward):
                     taps.data_ptr(), 1 | (4 if self._order_stream is not None else 0),     # train outputs | leave room
                     self.shade_out.data_ptr()), "shade_forward")
             if self._frs is not None and self._listed_stream() is not None:
-                _lib.stream_wait(torch.cuda.current_stream(), self._listed_stream())
+                _lib.stream_wait(main, self._listed_stream())
             packed = not (self._frs is not None and self._direct_rows)
             if packed:
                 _lib.check(L.r3dg_stage2_pack_features(
@@ -680,7 +682,7 @@ class FusedStage2Step(_BoundedForward):
                     if self._adam_stream is None:
                         self._adam_stream = shared_stream(dev, "early")
                     side = self._adam_stream
-                    side.wait_stream(torch.cuda.current_stream())
+                    side.wait_stream(main)
                 self.opt.begin_step()
                 with torch.cuda.stream(side):
                     self.opt.step_groups(self._groups_a, [self.grads[k] for k in self._opt_order],
@@ -729,7 +731,7 @@ class FusedStage2Step(_BoundedForward):
                     out_incidents=self.grads["incidents"], taps=taps, out_env=self._d_env, block_absmax=self._absmax)
             gr = self.grads
             if geo_stream is not None:                                       # join the geometry backward (and nothing
-                torch.cuda.current_stream().wait_event(self._geo_done)       # queued behind it on that stream)
+                main.wait_event(self._geo_done)       # queued behind it on that stream)
                 if self._side is not None:
                     handle_a = self._allreduce_async(self._bucket_a)
             if self.frozen_geometry:

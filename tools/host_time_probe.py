@@ -27,3 +27,4 @@ pr = cProfile.Profile(); pr.enable()
 for i in range(100): step(cams[i % 8], bg, gts[i % 8])
 pr.disable(); torch.cuda.synchronize()
 pstats.Stats(pr).sort_stats("cumulative").print_stats(28)
+pstats.Stats(pr).sort_stats("tottime").print_stats(45)
