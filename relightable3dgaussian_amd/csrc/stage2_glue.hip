@@ -651,8 +651,11 @@ __device__ __forceinline__ float smooth_chain(bool base, bool rough, bool light,
     return g_op;
 }
 
+// `old_normal`: the three values the normal maps' gradient already holds at this pixel when the caller has read them ahead of
+// time (the streamed kernel requests them before its nine taps: a load used straight away costs a wave its full latency), else NULL
 __device__ __forceinline__ void smooth_store(bool base, bool rough, bool light, int accumulate_normal, const float (&gf)[10],
-                                             size_t HW, size_t i, float* __restrict__ dL_dfeature)
+                                             size_t HW, size_t i, float* __restrict__ dL_dfeature,
+                                             const float* old_normal = nullptr)
 {
 #pragma clang fp contract(off)
     if (base) {
@@ -665,7 +668,7 @@ __device__ __forceinline__ void smooth_store(bool base, bool rough, bool light, 
         for (int c = 0; c < 3; c++) {
             dL_dfeature[(size_t)(12 + c) * HW + i] = gf[7 + c];
             const size_t o = (size_t)(5 + c) * HW + i;
-            const float old = accumulate_normal ? dL_dfeature[o] : 0.f;
+            const float old = accumulate_normal ? (old_normal != nullptr ? old_normal[c] : dL_dfeature[o]) : 0.f;
             dL_dfeature[o] = old + gf[c];
         }
     }
@@ -878,8 +881,14 @@ __global__ void __launch_bounds__(256, 2)      // (two waves per SIMD: all three
 s2_smooth_stream_kernel(int W, int H, int rows, int strips_x, const float* __restrict__ opacity,
                         const float* __restrict__ feature, const int* __restrict__ n_contrib, const float* __restrict__ gt,
                         const float* __restrict__ image_mask, float w_base, float w_rough, float w_light, int accumulate_normal,
-                        float* __restrict__ dL_dopacity, float* __restrict__ dL_dfeature, float* __restrict__ sums3)
+                        float* __restrict__ dL_dopacity, float* __restrict__ dL_dfeature, float* __restrict__ sums3,
+                        const float* __restrict__ dL_dopacity_old, const float* __restrict__ dL_dfeature_old)
 {
+    // dL_dopacity_old / dL_dfeature_old are the SAME buffers as dL_dopacity / dL_dfeature, passed a second time for the values the
+    // two read-modify-write outputs already hold.  Every element is read (through the _old name) before it is written (through the
+    // other), by the one lane that owns the pixel, and never read again; telling the compiler that the two names do not alias only
+    // takes away the wait it otherwise puts between one row's stores and the next row's loads from the same array (different rows:
+    // it cannot know) -- a full memory round trip per row with two waves per SIMD to cover it.
     const int lane = threadIdx.x & 63;
     const int wid = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int strip = wid % strips_x, y0 = (wid / strips_x) * rows;
@@ -921,11 +930,13 @@ s2_smooth_stream_kernel(int W, int H, int rows, int strips_x, const float* __res
         float (&E2)[20] = E[P2], (&E1)[20] = E[P1], (&E0)[20] = E[P0];
         const int yy = y0 - 2 + r;                         // incoming row; edge row yy - 1; adjoint row yy - 2
         const SmoothRow in = nxt;
-        if (r + 1 < nrows + 4)
-            nxt = smooth_load_row<BASE, ROUGH, LIGHT, true>((size_t)min(max(yy + 1, 0), H - 1) * W + xc, HW, opacity, feature,
-                                                            n_contrib, gt, image_mask);
+        // (unconditionally -- the row index is clamped anyway: under `if (r + 1 < total)` the compiler merges the loaded
+        // registers with the untouched ones INSIDE the branch, i.e. waits for the loads it has just issued: 44 % of the
+        // wave-cycles of the first version)
+        nxt = smooth_load_row<BASE, ROUGH, LIGHT, true>((size_t)min(max(yy + 1, 0), H - 1) * W + xc, HW, opacity, feature,
+                                                        n_contrib, gt, image_mask);
         const int py = yy - 2;
-        const bool adjoint = r >= 4 && own_col;
+        const bool adjoint = r >= 4 && own_col && py < y1;
         // (1) the incoming row's maps
         {
             const float scale = in.nc > 0 ? 1.f / fmaxf(in.op, 1e-5f) : 0.f;
@@ -995,10 +1006,18 @@ s2_smooth_stream_kernel(int W, int H, int rows, int strips_x, const float* __res
             }
         }
         // (3) the adjoint of row yy - 2 and the chain rule
-        if (r >= 4) {
+        if (r >= 4 && py < y1) {
             // the adjoint row's own pixel again (cache hits; requested here, used after the nine taps)
             const SmoothRow pr = smooth_load_row<BASE, ROUGH, LIGHT, false>((size_t)py * W + xc, HW, opacity, feature, n_contrib,
                                                                             gt, image_mask);
+            // ... and what the two read-modify-write outputs hold there (requested now, used after the nine taps: read where
+            // they are used, these loads were 44 % of the wave-cycles -- `s_waitcnt` with two waves per SIMD to cover it)
+            const float old_dop = dL_dopacity_old[(size_t)py * W + xc];
+            float old_n[3] = {0.f, 0.f, 0.f};
+            if (LIGHT && accumulate_normal) {
+#pragma unroll
+                for (int c = 0; c < 3; c++) old_n[c] = dL_dfeature_old[(size_t)(5 + c) * HW + (size_t)py * W + xc];
+            }
             float d[10];
 #pragma unroll
             for (int k = 0; k < 10; k++) d[k] = 0.f;
@@ -1030,16 +1049,19 @@ s2_smooth_stream_kernel(int W, int H, int rows, int strips_x, const float* __res
                 const size_t i = (size_t)py * W + x;
                 float gf[10];
                 const float g_op = smooth_chain(BASE, ROUGH, LIGHT, d, pr.op, pr.nc, pr.mk, pr.f, gf);
-                smooth_store(BASE, ROUGH, LIGHT, accumulate_normal, gf, HW, i, dL_dfeature);
-                dL_dopacity[i] += g_op;
+                smooth_store(BASE, ROUGH, LIGHT, accumulate_normal, gf, HW, i, dL_dfeature, old_n);
+                dL_dopacity[i] = old_dop + g_op;
             }
         }
     };
-    const int total = nrows + 4;
+    // nrows + 4 steps, rounded up to whole rounds of three: a step past the end loads clamped rows and stores nothing, and a
+    // straight-line round has no control-flow merge in it -- at a merge the compiler copies the prefetched row's registers, which
+    // means waiting for everything in flight including the stores just issued (a write round trip per step)
+    const int total = (nrows + 4 + 2) / 3 * 3;
     for (int r = 0; r < total; r += 3) {
         step(std::integral_constant<int, 0>{}, r);
-        if (r + 1 < total) step(std::integral_constant<int, 1>{}, r + 1);
-        if (r + 2 < total) step(std::integral_constant<int, 2>{}, r + 2);
+        step(std::integral_constant<int, 1>{}, r + 1);
+        step(std::integral_constant<int, 2>{}, r + 2);
     }
     a_base = wave_sum_to_lane63(a_base);
     a_rough = wave_sum_to_lane63(a_rough);
@@ -1274,7 +1296,7 @@ static void launch_s2_smooth_stream_t(hipStream_t s, int W, int H, int rows, con
     const int waves = strips_x * strips_y;
     s2_smooth_stream_kernel<BASE, ROUGH, LIGHT><<<(waves + 3) / 4, 256, 0, s>>>(
         W, H, rows, strips_x, opacity, feature, n_contrib, gt, image_mask, w_base, w_rough, w_light, accumulate_normal,
-        dL_dopacity, dL_dfeature, sums3);
+        dL_dopacity, dL_dfeature, sums3, dL_dopacity, dL_dfeature);
 }
 
 void launch_s2_smooth_fused(hipStream_t s, int W, int H, const float* opacity, const float* feature, const int* n_contrib,
