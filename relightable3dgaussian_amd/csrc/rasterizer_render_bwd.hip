@@ -72,7 +72,7 @@ struct ChannelList {
 //     10.. dL_dfeature[g*S+c]; with 10 + n <= 16 live channels the reduction is half size (SMALLV).
 // Measured (300k Gaussians, 800x800): 0.363 -> 0.345 ms inside the iteration (3 live feature channels), 0.494 -> 0.440 ms with
 // all 16 live.
-template <int SPAD, bool SMALLV>
+template <int SPAD, bool SMALLV, bool ROW4>
 __global__ void __launch_bounds__(64, (SPAD <= 4 ? R3DG_BWD_WAVES_SMALL : 1))
 render_backward_wave_kernel(const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list, int S,
                             ChannelList chan_list, int W, int H, int tiles_x, int num_tiles, int cull,
@@ -152,6 +152,9 @@ render_backward_wave_kernel(const uint2* __restrict__ ranges, const uint32_t* __
     const int n = (int)mx;
     const float ddelx_dx = 0.5f * W, ddely_dy = 0.5f * H;
 
+    int cidx[SPAD > 0 ? SPAD : 1];                        // (uniform: scalar registers)
+#pragma unroll
+    for (int jc = 0; jc < (SPAD > 0 ? SPAD : 1); jc++) cidx[jc] = chan_list.c[jc < R3DG_MAX_S_BWD ? jc : 0];
     // entry `e` of the walk (0 = deepest) is list position n - 1 - e
     auto load_index = [&](int e0) -> uint32_t {
         return e0 + lane < n ? point_list[range.x + (uint32_t)(n - 1 - (e0 + lane))] : 0u;
@@ -159,24 +162,22 @@ render_backward_wave_kernel(const uint2* __restrict__ ranges, const uint32_t* __
     auto cull_ok = [&](const float4& a0, const float4& a1) -> bool {
         return cull == 0 || splat_may_touch(a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, x0, x0 + 7.f, y0, y0 + 7.f);
     };
+    // No branch and no select around these loads: a branch (uniform or not) ends in a merge, a select consumes the value -- either
+    // way the compiler waits for the load right there, and the survivors' rows were requested one round early precisely so that
+    // they arrive under this round's arithmetic.  Channels >= SA of the padded vector read channel c[j] = 0 of the list (the
+    // launcher fills the tail with 0): a finite value that meets a zero upstream gradient, i.e. contributes nothing.
     auto load_payload = [&](uint32_t g, float4& c4, float4 (&f4)[SPAD > 0 ? SPAD / 4 : 1]) {
         const float4 r2 = splat[4 * (size_t)g + 2];
         c4 = make_float4(r2.x, r2.y, r2.z, 0.f);
         if constexpr (SPAD > 0) {
             const float* f = features + (size_t)g * S;
-            if (chan_list.identity && (S & 3) == 0) {
+            if constexpr (ROW4) {                     // identity list, S == SPAD: the row as float4s
 #pragma unroll
-                for (int q = 0; q < SPAD / 4; q++) {
-                    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                    if (4 * q < S) v = *reinterpret_cast<const float4*>(f + 4 * q);
-                    f4[q] = v;
-                }
+                for (int q = 0; q < SPAD / 4; q++) f4[q] = *reinterpret_cast<const float4*>(f + 4 * q);
             } else {
 #pragma unroll
                 for (int q = 0; q < SPAD / 4; q++)
-                    f4[q] = make_float4(4 * q < SA ? f[chan_list.c[4 * q]] : 0.f, 4 * q + 1 < SA ? f[chan_list.c[4 * q + 1]] : 0.f,
-                                        4 * q + 2 < SA ? f[chan_list.c[4 * q + 2]] : 0.f,
-                                        4 * q + 3 < SA ? f[chan_list.c[4 * q + 3]] : 0.f);
+                    f4[q] = make_float4(f[cidx[4 * q]], f[cidx[4 * q + 1]], f[cidx[4 * q + 2]], f[cidx[4 * q + 3]]);
             }
         }
     };
@@ -222,15 +223,18 @@ render_backward_wave_kernel(const uint2* __restrict__ ranges, const uint32_t* __
         const unsigned long long m1 = __ballot(cand1);
         const uint32_t g1n = g_cur;
         const float4 n0 = r0, n1 = r1;
-        float4 nc4 = make_float4(0.f, 0.f, 0.f, 0.f);
-        float4 nf4[SPAD > 0 ? SPAD / 4 : 1];
-        if (cand1) load_payload(g1n, nc4, nf4);
+        // the records of the round after next FIRST: their index (g_nxt) is still in flight, and a wait placed behind the
+        // branch-skippable loads of load_payload would have to be vmcnt(0) (the two paths into it carry different numbers of
+        // loads) -- it drained the survivors' rows in front of every round
         g_cur = g_nxt;
         if (base + 128 < n) {
             r0 = splat[4 * (size_t)g_cur];
             r1 = splat[4 * (size_t)g_cur + 1];
             g_nxt = load_index(base + 192);
         }
+        float4 nc4 = make_float4(0.f, 0.f, 0.f, 0.f);
+        float4 nf4[SPAD > 0 ? SPAD / 4 : 1];
+        if (cand1) load_payload(g1n, nc4, nf4);
 
         for (int k = 0; k < ncand; k++) {
             const float4 g0 = s_geo0[k], g1 = s_geo1[k];
@@ -463,13 +467,19 @@ void launch_render_backward(hipStream_t s, int W, int H, int S, int n_active, co
     }
     const int SP = cl.n;                 // channels the kernel carries
     const int grid = ((T + 7) / 8) * 8 * 4;       // 4 single-wave workgroups per tile, tile ranks padded to a multiple of 8
-#define R3DG_BWD(SP_, SV)                                                                                             \
-    render_backward_wave_kernel<SP_, SV><<<grid, 64, 0, s>>>(                                                         \
-        (const uint2*)ranges, point_list, S, cl, W, H, tiles_x, T, opt(R3DG_OPT_CULL), tile_order, bg, (const float4*)splat, features,   \
+    // ROW4: every feature channel is carried and the rows are float4-aligned (S == SPAD): the payload is read as float4s
+    const bool row4 = cl.identity != 0 && (S & 3) == 0;
+#define R3DG_BWD_ARGS                                                                                                  \
+    (const uint2*)ranges, point_list, S, cl, W, H, tiles_x, T, opt(R3DG_OPT_CULL), tile_order, bg, (const float4*)splat, features,       \
         final_Ts, n_contrib, dL_dpix, dL_dpix_o, dL_dpix_d, dL_dpix_f, dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolor,    \
-        dL_dfeature, bg_geom)
+        dL_dfeature, bg_geom
+#define R3DG_BWD(SP_, SV)                                                                                             \
+    do {                                                                                                               \
+        if (row4) render_backward_wave_kernel<SP_, SV, true><<<grid, 64, 0, s>>>(R3DG_BWD_ARGS);                       \
+        else render_backward_wave_kernel<SP_, SV, false><<<grid, 64, 0, s>>>(R3DG_BWD_ARGS);                           \
+    } while (0)
     switch ((SP + 3) / 4) {
-        case 0: R3DG_BWD(0, false); break;
+        case 0: render_backward_wave_kernel<0, false, false><<<grid, 64, 0, s>>>(R3DG_BWD_ARGS); break;
         // 10 + n <= 16 gradient channels: half-size reduction
         case 1: if (cl.n <= 6) R3DG_BWD(4, true); else R3DG_BWD(4, false); break;
         case 2: if (cl.n <= 6) R3DG_BWD(8, true); else R3DG_BWD(8, false); break;
@@ -482,6 +492,7 @@ void launch_render_backward(hipStream_t s, int W, int H, int S, int n_active, co
         default: R3DG_BWD(36, false); break;
     }
 #undef R3DG_BWD
+#undef R3DG_BWD_ARGS
 }
 
 }  // namespace r3dg

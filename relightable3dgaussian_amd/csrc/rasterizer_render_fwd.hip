@@ -33,7 +33,32 @@ __device__ __forceinline__ float fast_exp(float x)
 // four blocks of a tile are placed on ONE XCD so the repeats are L2 hits) and the cull arithmetic is not shared.  Measured
 // (300k Gaussians, 800x800, S = 16): 0.252 -> 0.193 ms inside the iteration, 0.290 -> 0.254 ms alone; identical outputs
 // (same arithmetic per (pixel, entry) in the same order).
-template <int SPAD, int U>
+// One Gaussian's feature row, padded to SPAD = 4 * ceil(S / 4) floats.  ROW4 (a template parameter, not a test of S: any branch
+// around the loads, uniform or not, ends in a merge where the compiler copies the loaded registers and therefore WAITS for them --
+// under `if (4 * q < S)` that was SPAD / 4 memory round trips in a row, where one was meant to run under the previous round's
+// arithmetic): S == SPAD, every float4 exists and is loaded unconditionally.
+template <int SPAD>
+struct FeatureRow {
+    float4 v[SPAD > 0 ? SPAD / 4 : 1];
+};
+template <int SPAD, bool ROW4>
+__device__ __forceinline__ FeatureRow<SPAD> load_feature_row(const float* __restrict__ f, int S)
+{
+    FeatureRow<SPAD> r;
+    if constexpr (ROW4) {
+#pragma unroll
+        for (int q = 0; q < SPAD / 4; q++) r.v[q] = *reinterpret_cast<const float4*>(f + 4 * q);
+    } else {
+#pragma unroll
+        for (int q = 0; q < SPAD / 4; q++) {
+            // clamped addresses, no selects: the padding channels are blended but never written, any finite value will do
+            r.v[q] = make_float4(f[min(4 * q, S - 1)], f[min(4 * q + 1, S - 1)], f[min(4 * q + 2, S - 1)], f[min(4 * q + 3, S - 1)]);
+        }
+    }
+    return r;
+}
+
+template <int SPAD, int U, bool ROW4>
 __global__ void __launch_bounds__(64)
 render_forward_wave_kernel(const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list, int S, int W, int H,
                            int tiles_x, int num_tiles, int cull, const uint32_t* __restrict__ tile_order,
@@ -94,16 +119,9 @@ render_forward_wave_kernel(const uint2* __restrict__ ranges, const uint32_t* __r
             *reinterpret_cast<float4*>(pay) = make_float4(r2.x, r2.y, r2.z, __uint_as_float((uint32_t)lane));
             if constexpr (SPAD > 0) {
                 const float* f = features + (size_t)g_cur * S;
+                const FeatureRow<SPAD> fv = load_feature_row<SPAD, ROW4>(f, S);
 #pragma unroll
-                for (int q = 0; q < SPAD / 4; q++) {
-                    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                    if ((S & 3) == 0) { if (4 * q < S) v = *reinterpret_cast<const float4*>(f + 4 * q); }
-                    else {
-                        v.x = 4 * q < S ? f[4 * q] : 0.f; v.y = 4 * q + 1 < S ? f[4 * q + 1] : 0.f;
-                        v.z = 4 * q + 2 < S ? f[4 * q + 2] : 0.f; v.w = 4 * q + 3 < S ? f[4 * q + 3] : 0.f;
-                    }
-                    *reinterpret_cast<float4*>(pay + 4 + 4 * q) = v;
-                }
+                for (int q = 0; q < SPAD / 4; q++) *reinterpret_cast<float4*>(pay + 4 + 4 * q) = fv.v[q];
             }
         }
     }
@@ -123,30 +141,23 @@ render_forward_wave_kernel(const uint2* __restrict__ ranges, const uint32_t* __r
         const unsigned long long m1 = __ballot(cand1);
         const uint32_t g1n = g_cur;
         const float4 n0 = r0, n1 = r1;
-        float4 n2 = make_float4(0.f, 0.f, 0.f, 0.f);
-        float4 nf[SPAD > 0 ? SPAD / 4 : 1];
-        if (cand1) {
-            n2 = splat[4 * (size_t)g1n + 2];
-            if constexpr (SPAD > 0) {
-                const float* f = features + (size_t)g1n * S;
-#pragma unroll
-                for (int q = 0; q < SPAD / 4; q++) {
-                    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                    if ((S & 3) == 0) { if (4 * q < S) v = *reinterpret_cast<const float4*>(f + 4 * q); }
-                    else {
-                        v.x = 4 * q < S ? f[4 * q] : 0.f; v.y = 4 * q + 1 < S ? f[4 * q + 1] : 0.f;
-                        v.z = 4 * q + 2 < S ? f[4 * q + 2] : 0.f; v.w = 4 * q + 3 < S ? f[4 * q + 3] : 0.f;
-                    }
-                    nf[q] = v;
-                }
-            }
-        }
-        // ---- records of the round after next, index of the one after that ----
+        // ---- records of the round after next, index of the one after that: BEFORE the survivors' rows are requested.  The index
+        // (g_nxt) is still in flight here; waited for behind the branch-skippable loads below, that wait would be vmcnt(0) -- the
+        // two paths into it carry different numbers of loads -- and drain the very prefetch that is meant to run under the round ----
         g_cur = g_nxt;
         if (base + 128 < n) {
             r0 = splat[4 * (size_t)g_cur];
             r1 = splat[4 * (size_t)g_cur + 1];
             g_nxt = load_index(base + 192);
+        }
+        float4 n2 = make_float4(0.f, 0.f, 0.f, 0.f);
+        FeatureRow<SPAD> nf;
+        if (cand1) {
+            n2 = splat[4 * (size_t)g1n + 2];
+            if constexpr (SPAD > 0) {
+                const float* f = features + (size_t)g1n * S;
+                nf = load_feature_row<SPAD, ROW4>(f, S);
+            }
         }
 
         for (int k0 = 0; k0 < ncand; k0 += U) {
@@ -215,7 +226,7 @@ render_forward_wave_kernel(const uint2* __restrict__ ranges, const uint32_t* __r
             *reinterpret_cast<float4*>(pay) = make_float4(n2.x, n2.y, n2.z, __uint_as_float((uint32_t)lane));
             if constexpr (SPAD > 0) {
 #pragma unroll
-                for (int q = 0; q < SPAD / 4; q++) *reinterpret_cast<float4*>(pay + 4 + 4 * q) = nf[q];
+                for (int q = 0; q < SPAD / 4; q++) *reinterpret_cast<float4*>(pay + 4 + 4 * q) = nf.v[q];
             }
         }
         __builtin_amdgcn_wave_barrier();
@@ -304,9 +315,16 @@ void launch_render_forward(hipStream_t s, int W, int H, int S, const uint32_t* t
     const int T = tiles_x * tiles_y;
     const int grid = ((T + 7) / 8) * 8 * 4;       // 4 single-wave workgroups per tile, tile ranks padded to a multiple of 8
 #define R3DG_FWD(SP)                                                                                                  \
-    render_forward_wave_kernel<SP, 4><<<grid, 64, 0, s>>>((const uint2*)ranges, point_list, S, W, H, tiles_x, T, opt(R3DG_OPT_CULL),   \
-                                                         tile_order, (const float4*)splat, features, final_T, n_contrib, \
-                                                         bg, out_color, out_opacity, out_depth, out_feature, out_weights)
+    do {                                                                                                               \
+        if ((S & 3) == 0)                                                                                              \
+            render_forward_wave_kernel<SP, 4, true><<<grid, 64, 0, s>>>(                                               \
+                (const uint2*)ranges, point_list, S, W, H, tiles_x, T, opt(R3DG_OPT_CULL), tile_order, (const float4*)splat,     \
+                features, final_T, n_contrib, bg, out_color, out_opacity, out_depth, out_feature, out_weights);        \
+        else                                                                                                           \
+            render_forward_wave_kernel<SP, 4, false><<<grid, 64, 0, s>>>(                                              \
+                (const uint2*)ranges, point_list, S, W, H, tiles_x, T, opt(R3DG_OPT_CULL), tile_order, (const float4*)splat,     \
+                features, final_T, n_contrib, bg, out_color, out_opacity, out_depth, out_feature, out_weights);        \
+    } while (0)
     switch ((S + 3) / 4) {
         case 0: R3DG_FWD(0); break;
         case 1: R3DG_FWD(4); break;
