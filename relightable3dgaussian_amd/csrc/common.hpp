@@ -175,13 +175,28 @@ __device__ __forceinline__ void stage_rows_in_256(const float* __restrict__ g, i
     const float* __restrict__ src = g + (size_t)first * row_floats;
     if ((row_floats & 3) == 0 && ((size_t)src & 15) == 0) {
         const int q_per_row = row_floats >> 2, nq = nrows * q_per_row;
-#pragma unroll 4
-        for (int q = threadIdx.x; q < nq; q += 256) {
-            const int row = q / q_per_row, c = (q - row * q_per_row) * 4;
-            if (s_live[row]) {
-                const float4 v = *reinterpret_cast<const float4*>(src + 4 * (size_t)q);
-                float* d = s_rows + row * stride + c;
-                d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+        // six loads in flight per thread before the first one is stored, and NO branch around a load: written as one loop of
+        // `if (live) { load; store }` every load sits in its own branch and is waited for there -- 12 memory round trips in a row
+        // for the 192-byte SH rows, most of the projection kernel's time.  A dead row's slot reads the block's first float4
+        // instead (one cached line for all of them: still nothing of a culled Gaussian's row comes from HBM).
+        constexpr int B = 6;
+        for (int q0 = threadIdx.x; q0 < nq; q0 += 256 * B) {
+            float4 v[B];
+            int dst[B];
+#pragma unroll
+            for (int j = 0; j < B; j++) {
+                const int q = min(q0 + j * 256, nq - 1);
+                const int row = q / q_per_row, c = (q - row * q_per_row) * 4;
+                const bool live = q0 + j * 256 < nq && s_live[row] != 0;
+                dst[j] = live ? row * stride + c : -1;
+                v[j] = *reinterpret_cast<const float4*>(src + (live ? 4 * (size_t)q : (size_t)0));
+            }
+#pragma unroll
+            for (int j = 0; j < B; j++) {
+                if (dst[j] >= 0) {
+                    float* d = s_rows + dst[j];
+                    d[0] = v[j].x; d[1] = v[j].y; d[2] = v[j].z; d[3] = v[j].w;
+                }
             }
         }
     } else {
