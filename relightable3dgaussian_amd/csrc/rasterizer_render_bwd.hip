@@ -173,7 +173,10 @@ render_backward_wave_kernel(const uint2* __restrict__ ranges, const uint32_t* __
             const float* f = features + (size_t)g * S;
             if constexpr (ROW4) {                     // identity list, S == SPAD: the row as float4s
 #pragma unroll
-                for (int q = 0; q < SPAD / 4; q++) f4[q] = *reinterpret_cast<const float4*>(f + 4 * q);
+                for (int q = 0; q < SPAD / 4; q++) {
+                    const float4 t = *reinterpret_cast<const float4*>(f + 4 * q);
+                    f4[q] = make_float4(t.x, t.y, t.z, t.w);          // (component-wise: the array stays in registers)
+                }
             } else {
 #pragma unroll
                 for (int q = 0; q < SPAD / 4; q++)

@@ -37,27 +37,7 @@ __device__ __forceinline__ float fast_exp(float x)
 // around the loads, uniform or not, ends in a merge where the compiler copies the loaded registers and therefore WAITS for them --
 // under `if (4 * q < S)` that was SPAD / 4 memory round trips in a row, where one was meant to run under the previous round's
 // arithmetic): S == SPAD, every float4 exists and is loaded unconditionally.
-template <int SPAD>
-struct FeatureRow {
-    float4 v[SPAD > 0 ? SPAD / 4 : 1];
-};
-template <int SPAD, bool ROW4>
-__device__ __forceinline__ FeatureRow<SPAD> load_feature_row(const float* __restrict__ f, int S)
-{
-    FeatureRow<SPAD> r;
-    if constexpr (ROW4) {
-#pragma unroll
-        for (int q = 0; q < SPAD / 4; q++) r.v[q] = *reinterpret_cast<const float4*>(f + 4 * q);
-    } else {
-#pragma unroll
-        for (int q = 0; q < SPAD / 4; q++) {
-            // clamped addresses, no selects: the padding channels are blended but never written, any finite value will do
-            r.v[q] = make_float4(f[min(4 * q, S - 1)], f[min(4 * q + 1, S - 1)], f[min(4 * q + 2, S - 1)], f[min(4 * q + 3, S - 1)]);
-        }
-    }
-    return r;
-}
-
+// (written out at both sites: returned by value from a helper, a row of more than 16 floats stays in scratch memory)
 template <int SPAD, int U, bool ROW4>
 __global__ void __launch_bounds__(64)
 render_forward_wave_kernel(const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list, int S, int W, int H,
@@ -119,9 +99,19 @@ render_forward_wave_kernel(const uint2* __restrict__ ranges, const uint32_t* __r
             *reinterpret_cast<float4*>(pay) = make_float4(r2.x, r2.y, r2.z, __uint_as_float((uint32_t)lane));
             if constexpr (SPAD > 0) {
                 const float* f = features + (size_t)g_cur * S;
-                const FeatureRow<SPAD> fv = load_feature_row<SPAD, ROW4>(f, S);
+                float4 fv[SPAD / 4];
 #pragma unroll
-                for (int q = 0; q < SPAD / 4; q++) *reinterpret_cast<float4*>(pay + 4 + 4 * q) = fv.v[q];
+                for (int q = 0; q < SPAD / 4; q++) {
+                    if constexpr (ROW4) {
+                        const float4 t = *reinterpret_cast<const float4*>(f + 4 * q);
+                        fv[q] = make_float4(t.x, t.y, t.z, t.w);      // (component-wise: the array stays in registers)
+                    }
+                    else          // clamped addresses, no selects: the padding channels are blended but never written
+                        fv[q] = make_float4(f[min(4 * q, S - 1)], f[min(4 * q + 1, S - 1)], f[min(4 * q + 2, S - 1)],
+                                            f[min(4 * q + 3, S - 1)]);
+                }
+#pragma unroll
+                for (int q = 0; q < SPAD / 4; q++) *reinterpret_cast<float4*>(pay + 4 + 4 * q) = fv[q];
             }
         }
     }
@@ -151,12 +141,21 @@ render_forward_wave_kernel(const uint2* __restrict__ ranges, const uint32_t* __r
             g_nxt = load_index(base + 192);
         }
         float4 n2 = make_float4(0.f, 0.f, 0.f, 0.f);
-        FeatureRow<SPAD> nf;
+        float4 nf[SPAD > 0 ? SPAD / 4 : 1];
         if (cand1) {
             n2 = splat[4 * (size_t)g1n + 2];
             if constexpr (SPAD > 0) {
                 const float* f = features + (size_t)g1n * S;
-                nf = load_feature_row<SPAD, ROW4>(f, S);
+#pragma unroll
+                for (int q = 0; q < SPAD / 4; q++) {
+                    if constexpr (ROW4) {
+                        const float4 t = *reinterpret_cast<const float4*>(f + 4 * q);
+                        nf[q] = make_float4(t.x, t.y, t.z, t.w);      // (component-wise: the array stays in registers)
+                    }
+                    else          // clamped addresses, no selects: the padding channels are blended but never written
+                        nf[q] = make_float4(f[min(4 * q, S - 1)], f[min(4 * q + 1, S - 1)], f[min(4 * q + 2, S - 1)],
+                                            f[min(4 * q + 3, S - 1)]);
+                }
             }
         }
 
@@ -226,7 +225,7 @@ render_forward_wave_kernel(const uint2* __restrict__ ranges, const uint32_t* __r
             *reinterpret_cast<float4*>(pay) = make_float4(n2.x, n2.y, n2.z, __uint_as_float((uint32_t)lane));
             if constexpr (SPAD > 0) {
 #pragma unroll
-                for (int q = 0; q < SPAD / 4; q++) *reinterpret_cast<float4*>(pay + 4 + 4 * q) = nf.v[q];
+                for (int q = 0; q < SPAD / 4; q++) *reinterpret_cast<float4*>(pay + 4 + 4 * q) = nf[q];
             }
         }
         __builtin_amdgcn_wave_barrier();
