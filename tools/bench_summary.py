@@ -2,7 +2,11 @@
 import json
 import sys
 
+import os
+
 d = json.loads([l for l in open(sys.argv[1]).read().splitlines() if l.startswith("{")][-1])
+if "kernels" not in d and "full" in d:          # the compact stdout line: the document behind it is in gpurun_out/bench_full.json
+    d = json.load(open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out", "bench_full.json")))
 print("value %.1f %s  %.3f ms/step  spread %s" % (d["value"], d["unit"], d["ms_per_step"],
                                                   {k: d.get("spread_iters_per_s", {}).get(k) for k in ("min", "median", "max")}))
 r = d["roofline"]
