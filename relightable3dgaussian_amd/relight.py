@@ -147,46 +147,49 @@ class RelightRenderer:
             if self.cache == "transport":
                 # radiance -> transport in place, + the per-Gaussian constants (the buffer must not be handed to
                 # r3dg_shade_forward_cached any more: frame() takes the transport kernel whenever this cache is live)
-                if self._consts is None:
-                    self._consts = torch.empty(self.P, 16, dtype=torch.float32, device=self.dev)
+                if self._zsamples is None:
                     self._zsamples = sampling.fibonacci_z_samples(self.K, self.dev)[0].t().contiguous()      # [K,3]
-                with torch.cuda.device(self.dev):
-                    _lib.check(_lib.lib().r3dg_shade_build_transport(
-                        _lib.current_stream(), self.P, self.K, self.M, self.a_normal.data_ptr(), self.incidents.data_ptr(),
-                        self.visibility.data_ptr(), self.incident_dirs.data_ptr(),
-                        None if self._uniform_area is not None else self.incident_areas.data_ptr(),
-                        self._uniform_area or 0.0, self._taps.data_ptr(), self._consts.data_ptr()), "shade_build_transport")
+                self._consts = shading_ops.build_transport(
+                    self.a_normal, self.incidents, self.visibility, self.incident_dirs, self.incident_areas, self._uniform_area,
+                    self._taps, self._consts)
         return self._taps
 
-    def _split_cache(self):
+    def _split_cache(self, tr=None, given=None):
         """The light-independent half of the transport, for a light that turns with every frame (relighting.py:160-161 with
         configs/nerf_syn_light / configs/tnt light_transform.json): per sample (local light x a, a) and the visibility,
         sample-major, in an order sorted by normal; the per-frame kernel (r3dg_shade_forward_split) does the lat-long lookup
-        of the rotated direction itself.  Built once -- the renderer works on a snapshot of the parameters -- and only for the
-        configuration the reference's relighting uses (16 incident-light coefficients, the Fibonacci ray set with its uniform
-        area); None otherwise (the general kernel with the lookup inside then runs, as before)."""
-        if self._split is not None:
-            return self._split or None
-        self._split = False
-        if self.M != 16 or self._uniform_area is None or self.K % 4 != 0:
-            return None
-        P, K, dev = self.P, self.K, self.dev
-        f = dict(dtype=torch.float32, device=dev)
-        perm = normal_order(self.a_normal)
-        lt, vis_t, consts = torch.empty(K, P, 4, **f), torch.empty(K // 4, P, 4, **f), torch.empty(P, 4, **f)
-        zs = sampling.fibonacci_z_samples(K, dev)[0].t().contiguous()
+        of the rotated direction itself.  Only for the configuration the reference's relighting uses (16 incident-light
+        coefficients, the Fibonacci ray set with its uniform area, a map of at most 4095 x 4095 texels) and only for a light
+        transform that is a ROTATION (the kernel evaluates the GGX lobe in the light's frame; a transform given on the host is
+        checked here, one on the device is the caller's promise); None otherwise (the general kernel with the lookup inside
+        then runs).  Like _taps_for's entry, the cache is KEYED: the sample half on the direction / visibility caches
+        (address + version) and `regenerate_dirs`, the footprints on the map (address + version + size) -- a caller that swaps
+        or edits `envmap`, `visibility` or `incident_dirs` between two frames gets the rebuilt half, and the tensors keyed on
+        are referenced for as long as they are the key."""
         He, We = self.envmap.shape[0], self.envmap.shape[1]
-        env4 = torch.empty(int(_lib.lib().r3dg_shade_env_footprints_bytes(He, We)) // 4, **f)      # 48-byte bilinear footprints
-        L = _lib.lib()
-        with torch.cuda.device(dev):
-            _lib.check(L.r3dg_shade_build_split(
-                _lib.current_stream(), P, K, perm.data_ptr(), self.a_normal.data_ptr(), self.incidents.data_ptr(),
-                self.visibility.data_ptr(), None if self.regenerate_dirs else self.incident_dirs.data_ptr(), zs.data_ptr(),
-                float(self._uniform_area), lt.data_ptr(), vis_t.data_ptr(), consts.data_ptr()), "shade_build_split")
-            _lib.check(L.r3dg_shade_env_footprints(_lib.current_stream(), He, We, self.envmap.data_ptr(), env4.data_ptr()),
-                       "shade_env_footprints")
-        self._split = dict(perm=perm, lt=lt, vis_t=vis_t, consts=consts, zsamples=zs, env4=env4)
-        return self._split
+        if not shading_ops.split_supported(self.K, self.M, He, We, self._uniform_area):
+            self._split = False
+            return None
+        if given is not None and not given.is_cuda:
+            t = given.detach().to(torch.float64).reshape(3, 3)
+            if float((t @ t.t() - torch.eye(3, dtype=torch.float64)).abs().max()) > 1e-4:
+                return None                       # scaled / sheared light transform: the general kernel handles it
+        sample_key = (self.incident_dirs.data_ptr(), self.incident_dirs._version, self.visibility.data_ptr(),
+                      self.visibility._version, self.regenerate_dirs)
+        env_key = (self.envmap.data_ptr(), self.envmap._version, He, We)
+        sp = self._split if isinstance(self._split, dict) else None
+        if sp is None or sp["sample_key"] != sample_key:
+            zs = sampling.fibonacci_z_samples(self.K, self.dev)[0].t().contiguous()
+            new = shading_ops.build_split(normal_order(self.a_normal), self.a_normal, self.incidents, self.visibility,
+                                          None if self.regenerate_dirs else self.incident_dirs, zs, float(self._uniform_area))
+            new.update(sample_key=sample_key, sample_ref=(self.incident_dirs, self.visibility),
+                       env4=None if sp is None else sp["env4"], env_key=None if sp is None else sp["env_key"],
+                       env_ref=None if sp is None else sp["env_ref"])
+            sp = self._split = new
+        if sp["env_key"] != env_key:
+            sp["env4"] = shading_ops.env_footprints(self.envmap)
+            sp["env_key"], sp["env_ref"] = env_key, self.envmap
+        return sp
 
     def _activate(self, campos):
         with torch.cuda.device(self.dev):
@@ -233,21 +236,16 @@ class RelightRenderer:
                 True, False, want_weights=False)                   # (a frame has no use for the per-Gaussian blend weights)
             # the lat-long lookups of the cached directions are constant for a fixed light rotation: cached per transform
             taps = self._taps_for(tr, He, We, env_transform)
+            sp = None
             if taps is not None and self.cache == "transport":
-                _lib.check(L.r3dg_shade_forward_transport(
-                    stream(), P, self.K, self.a_base.data_ptr(), self.a_rough.data_ptr(), self.a_normal.data_ptr(),
-                    self.a_viewdirs.data_ptr(), taps.data_ptr(), self._consts.data_ptr(), self._zsamples.data_ptr(),
-                    None if self.regenerate_dirs else self.incident_dirs.data_ptr(), self.shade_out.data_ptr()),
-                    "shade_forward_transport")
-            elif taps is None and self._split_cache() is not None:
+                shading_ops.shade_forward_transport(
+                    self.a_base, self.a_rough, self.a_normal, self.a_viewdirs, taps, self._consts, self._zsamples,
+                    None if self.regenerate_dirs else self.incident_dirs, self.shade_out)
+            elif taps is None and (sp := self._split_cache(tr, env_transform)) is not None:
                 # a light that turns with every frame: the light-independent half of the transport is cached, the lookup of the
                 # rotated direction happens in the kernel (lane = Gaussian, sorted by normal)
-                sp = self._split
-                _lib.check(L.r3dg_shade_forward_split(
-                    stream(), P, self.K, sp["perm"].data_ptr(), self.a_base.data_ptr(), self.a_rough.data_ptr(),
-                    self.a_normal.data_ptr(), self.a_viewdirs.data_ptr(), sp["lt"].data_ptr(), sp["vis_t"].data_ptr(),
-                    sp["consts"].data_ptr(), sp["zsamples"].data_ptr(), _lib.ptr(tr), sp["env4"].data_ptr(), He, We,
-                    self.shade_out.data_ptr()), "shade_forward_split")
+                shading_ops.shade_forward_split(sp, self.a_base, self.a_rough, self.a_normal, self.a_viewdirs, tr, sp["env4"],
+                                                He, We, self.shade_out)
             else:
                 self._shade_cached(L, stream, P, He, We, tr, taps)
             _lib.check(L.r3dg_relight_pack_features(

@@ -112,6 +112,87 @@ def shade_backward(base_color, roughness, normals, viewdirs, incidents, env, vis
     return d_base, d_rough, d_view, d_inc, d_env
 
 
+# ---- relight caches (fixed / turning light over static Gaussians): thin wrappers of the C ABI, used by relight.RelightRenderer
+# and driven directly by tests/test_shading_gpu.py::test_relight_kernels_match_oracle -------------------------------------------
+def build_transport(normals, incidents, visibility, incident_dirs, incident_areas, uniform_area, radiance_inout, consts=None):
+    """r3dg_shade_build_transport: `radiance_inout` (build_taps(..., radiance_of=env) of THESE directions) is rewritten in place
+    with the per-sample transport; -> consts [P,16] (per Gaussian diffuse_light, mean lights, mean visibility)."""
+    P, K, M = incident_dirs.shape[0], incident_dirs.shape[1], incidents.shape[1]
+    if radiance_inout.numel() != 3 * P * K or not radiance_inout.is_contiguous():
+        raise RuntimeError("radiance_inout must be the contiguous [P,K,3] record tensor of build_taps(..., radiance_of=env)")
+    if consts is None:
+        consts = torch.empty(P, 16, dtype=torch.float32, device=normals.device)
+    with torch.cuda.device(normals.device):
+        _lib.check(_lib.lib().r3dg_shade_build_transport(
+            _lib.current_stream(), P, K, M, _c(normals).data_ptr(), _c(incidents).data_ptr(), _c(visibility).data_ptr(),
+            _c(incident_dirs).data_ptr(), None if uniform_area is not None else _c(incident_areas).data_ptr(),
+            float(uniform_area or 0.0), radiance_inout.data_ptr(), consts.data_ptr()), "shade_build_transport")
+    return consts
+
+
+def shade_forward_transport(base_color, roughness, normals, viewdirs, transport, consts, zsamples, incident_dirs=None, out=None):
+    """r3dg_shade_forward_transport: the GGX lobe of every sample against the cached transport -> out[P,19].
+    `incident_dirs` None: the directions are regenerated from the normals and `zsamples` [K,3]."""
+    P, K = consts.shape[0], zsamples.shape[0]
+    if out is None:
+        out = torch.empty((P, NOUT), dtype=torch.float32, device=consts.device)
+    with torch.cuda.device(consts.device):
+        _lib.check(_lib.lib().r3dg_shade_forward_transport(
+            _lib.current_stream(), P, K, _c(base_color).data_ptr(), _c(roughness).data_ptr(), _c(normals).data_ptr(),
+            _c(viewdirs).data_ptr(), transport.data_ptr(), consts.data_ptr(), zsamples.data_ptr(),
+            None if incident_dirs is None else _c(incident_dirs).data_ptr(), out.data_ptr()), "shade_forward_transport")
+    return out
+
+
+SPLIT_MAX_ENV = 4095        # r3dg_shade_env_footprints / r3dg_shade_forward_split pack a texel coordinate into 12 bits
+
+
+def split_supported(K, M, He, We, uniform_area):
+    """What the split-transport kernels implement: the reference's relighting configuration (16 incident-light coefficients, the
+    Fibonacci ray set with its uniform area), K a multiple of 4 and a map of at most 4095 x 4095 texels."""
+    return M == 16 and uniform_area is not None and K % 4 == 0 and 0 < He <= SPLIT_MAX_ENV and 0 < We <= SPLIT_MAX_ENV
+
+
+def env_footprints(env):
+    """r3dg_shade_env_footprints: the map [He,We,3] as (He+1)(We+1) 48-byte bilinear footprints."""
+    He, We = env.shape[0], env.shape[1]
+    L = _lib.lib()
+    env4 = torch.empty(int(L.r3dg_shade_env_footprints_bytes(He, We)) // 4, dtype=torch.float32, device=env.device)
+    with torch.cuda.device(env.device):
+        _lib.check(L.r3dg_shade_env_footprints(_lib.current_stream(), He, We, _c(env).data_ptr(), env4.data_ptr()),
+                   "shade_env_footprints")
+    return env4
+
+
+def build_split(perm, normals, incidents, visibility, incident_dirs, zsamples, uniform_area):
+    """r3dg_shade_build_split: the light-independent half of the transport, sample-major, Gaussians in the order `perm` lists
+    them -> dict(lt [K,P,4], vis_t [K/4,P,4], consts [P,4]).  `incident_dirs` None: regenerated from normals and zsamples."""
+    P, K = normals.shape[0], zsamples.shape[0]
+    f = dict(dtype=torch.float32, device=normals.device)
+    lt, vis_t, consts = torch.empty(K, P, 4, **f), torch.empty(K // 4, P, 4, **f), torch.empty(P, 4, **f)
+    with torch.cuda.device(normals.device):
+        _lib.check(_lib.lib().r3dg_shade_build_split(
+            _lib.current_stream(), P, K, perm.data_ptr(), _c(normals).data_ptr(), _c(incidents).data_ptr(),
+            _c(visibility).data_ptr(), None if incident_dirs is None else _c(incident_dirs).data_ptr(), zsamples.data_ptr(),
+            float(uniform_area), lt.data_ptr(), vis_t.data_ptr(), consts.data_ptr()), "shade_build_split")
+    return dict(perm=perm, lt=lt, vis_t=vis_t, consts=consts, zsamples=zsamples)
+
+
+def shade_forward_split(split, base_color, roughness, normals, viewdirs, env_transform, env4, He, We, out=None):
+    """r3dg_shade_forward_split: per frame the lat-long lookup of the ROTATED direction (`env_transform` [3,3] on the device or
+    None; must be a rotation -- the lobe is evaluated in the light's frame), the transport and the GGX lobe -> out[P,19]."""
+    P, K = split["consts"].shape[0], split["zsamples"].shape[0]
+    if out is None:
+        out = torch.empty((P, NOUT), dtype=torch.float32, device=env4.device)
+    with torch.cuda.device(env4.device):
+        _lib.check(_lib.lib().r3dg_shade_forward_split(
+            _lib.current_stream(), P, K, split["perm"].data_ptr(), _c(base_color).data_ptr(), _c(roughness).data_ptr(),
+            _c(normals).data_ptr(), _c(viewdirs).data_ptr(), split["lt"].data_ptr(), split["vis_t"].data_ptr(),
+            split["consts"].data_ptr(), split["zsamples"].data_ptr(), _lib.ptr(env_transform), env4.data_ptr(), int(He), int(We),
+            out.data_ptr()), "shade_forward_split")
+    return out
+
+
 class FixedRaySet:
     """State of the fixed-ray-set shading kernels (include/r3dg_hip.h "fixed ray set", csrc/shading_frs.hpp) for ONE
     visibility update: the normals the cached directions were generated from (12 bytes per Gaussian -- the kernels read NO

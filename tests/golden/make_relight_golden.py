@@ -1,0 +1,104 @@
+"""Golden fixture of the EVAL / RELIGHT frame from the REFERENCE'S OWN, UNMODIFIED Python (this container only).
+
+    python tests/golden/make_relight_golden.py     # needs /root/reference; writes tests/golden/pipeline_reference_relight.npz
+
+What runs, unmodified, from /root/reference (on top of what make_pipeline_golden.py lists):
+    gaussian_renderer/neilf.py   render_view(is_training=False): the chunked eval shading (:98-113), the 28-channel feature row
+                                 (:121-130), split + sRGB (:147-163), render_env / pbr_env / env_only (:198-203)
+    scene/envmap.py              EnvLight.direct_light (:35-53) with `light.transform` set per frame as relighting.py:160-161 does
+    scene/cameras.py             Camera.get_world_directions (:79-91)
+    scene/gaussian_model.py      update_visibility(sample_num) (:312-342)
+EnvLight.__init__ only loads an image file (imageio / pyexr, absent here): the object is made with __new__ and given a synthetic
+HDR map -- `direct_light` is the reference's.  The compiled extensions are the CPU oracle behind the extension names, exactly as
+in make_pipeline_golden.py; the wrapper around `_C.rasterize_gaussians` below only RECORDS the per-Gaussian feature rows the
+reference's Python hands to the rasterizer (the direct parity target of the relight shading kernels) and the raw feature image.
+Three frames: light.transform = T_a (bg 0; every map), T_b (bg 0), None (bg 1) (feature rows + composites).  Nothing of the reference is copied: inputs and outputs only.
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+import make_golden as mg  # noqa: E402
+import make_pipeline_golden as mp  # noqa: E402
+
+REF = "/root/reference"
+
+
+def main():
+    sys.meta_path.append(mg._Finder())
+    mp.install_oracle_extensions()
+    sys.path.insert(0, REF)
+    for p in mg._cpu_factories():
+        p.start()
+    torch.cuda.empty_cache = lambda: None
+    from scene.gaussian_model import GaussianModel
+    from scene.envmap import EnvLight
+    import gaussian_renderer.neilf as nf
+    from relightable3dgaussian_amd import synthetic as syn
+
+    rc = sys.modules["r3dg_rasterization._C"]
+    inner = rc.rasterize_gaussians
+    seen = {}
+
+    def recording(*a):
+        out = inner(*a)
+        seen["features"] = a[2].detach().clone().numpy()
+        seen["feature_image"] = out[5].detach().clone().numpy()
+        seen["num_contrib"] = out[1].detach().clone().numpy()
+        return out
+    rc.rasterize_gaussians = recording
+
+    P, W, H, K = 1200, 96, 64, 32
+    raw, _, _, _, _ = mp.make_inputs(P, 96, seed=47, stage2=True)
+    cam = syn.look_at_camera((4.0, -1.9, 2.3), width=W, height=H)         # (far enough for the environment to show)
+    pc = mp.to_model(GaussianModel, raw, True)
+    g = torch.Generator().manual_seed(4711)
+    hdr = (3.0 * torch.rand(32, 64, 3, generator=g) ** 2).contiguous()
+    Ta = torch.linalg.qr(torch.randn(3, 3, generator=g)).Q.contiguous()
+    Tb = torch.linalg.qr(torch.randn(3, 3, generator=g)).Q.contiguous()
+    if torch.det(Ta) < 0:                       # rotations, as light_transform.json holds them
+        Ta = -Ta
+    if torch.det(Tb) < 0:
+        Tb = -Tb
+    light = EnvLight.__new__(EnvLight)
+    torch.nn.Module.__init__(light)
+    light.device, light.scale, light.envmap, light.transform = "cpu", 1.0, hdr, None
+    _, pipe = mp.options(True, {})
+    rcam = mp.reference_camera(cam, torch.zeros(3, H, W), torch.ones(1, H, W))
+    pc.update_visibility(K)
+    out = {("raw_" + k): v.numpy() for k, v in raw.items()}
+    out.update(K=K, W=W, H=H, envmap=hdr.numpy(), T_a=Ta.numpy(), T_b=Tb.numpy(),
+               wvt=cam.world_view_transform.numpy(), fpt=cam.full_proj_transform.numpy(), campos=cam.camera_center.numpy(),
+               cam_scalars=np.array([cam.FoVx, cam.FoVy, cam.tanfovx, cam.tanfovy, cam.cx, cam.cy], np.float64),
+               ref_wvt=rcam.world_view_transform.numpy(), ref_fpt=rcam.full_proj_transform.numpy(),
+               visibility=pc._visibility_tracing.numpy(), incident_dirs=pc._incident_dirs.numpy(),
+               incident_areas=pc._incident_areas.numpy())
+    maps = ("render", "opacity", "depth", "pbr", "normal", "pseudo_normal", "base_color", "roughness", "diffuse", "specular",
+            "lights", "local_lights", "global_lights", "visibility", "render_env", "pbr_env", "env_only")
+    for tag, tr, bgv in (("a", Ta, 0.0), ("b", Tb, 0.0), ("n", None, 1.0)):
+        light.transform = tr                                    # relighting.py:160-161
+        bg = torch.full((3,), bgv)
+        with torch.no_grad():
+            res = nf.render_view(rcam, pc, pipe, bg, is_training=False, dict_params={"env_light": light, "sample_num": K})
+        # frame a: every map; frames b / n: the composites only (fixture size)
+        for k in (maps if tag == "a" else ("pbr", "opacity", "render_env", "pbr_env", "env_only")):
+            out["%s_map_%s" % (tag, k)] = res[k].detach().numpy().astype(np.float32)
+        out["%s_features" % tag] = seen["features"]
+        if tag == "a":
+            out["a_feature_image"] = seen["feature_image"]
+            out["a_num_contrib"] = seen["num_contrib"]
+        out["%s_num_rendered" % tag] = np.int64(res["num_rendered"])
+        out["%s_diffuse_light" % tag] = res["diffuse_light"].detach().numpy()
+        out["%s_bg" % tag] = bg.numpy()
+        print("frame %s: num_rendered %d, mean opacity %.3f, pbr_env mean %.4f" % (
+            tag, res["num_rendered"], float(res["opacity"].mean()), float(res["pbr_env"].mean())))
+    np.savez_compressed(os.path.join(HERE, "pipeline_reference_relight.npz"), **out)
+    print("wrote pipeline_reference_relight.npz: %d arrays" % len(out))
+
+
+if __name__ == "__main__":
+    main()

@@ -191,6 +191,7 @@ def test_relight_renderer_host_logic_with_a_recording_library(monkeypatch):
     P, K = 7, 8
     monkeypatch.setattr(_lib, "lib", lambda: Recorder())
     monkeypatch.setattr(_lib, "current_stream", lambda: 0)
+    monkeypatch.setattr(shading_ops, "_c", lambda t: t.contiguous())          # (the renderer's own buffers are CPU tensors here)
     import contextlib
     monkeypatch.setattr(torch.cuda, "device", lambda d: contextlib.nullcontext())
     monkeypatch.setattr(relight, "update_visibility", lambda *a, **k: (torch.ones(P, K, 1), torch.ones(P, K, 3),
@@ -225,8 +226,13 @@ def test_relight_renderer_host_logic_with_a_recording_library(monkeypatch):
     # lookup inside the per-frame kernel
     calls.clear()
     del built[:]
+    import math
+
+    def rot(i):
+        a = 0.3 * i
+        return torch.tensor([[math.cos(a), -math.sin(a), 0.0], [math.sin(a), math.cos(a), 0.0], [0.0, 0.0, 1.0]])
     for i in range(4):
-        r.frame(cam, z(3), env_transform=torch.eye(3) * (1.0 + i))
+        r.frame(cam, z(3), env_transform=rot(i))
     flags = [c[1][-2] for c in calls if c[0] == "r3dg_shade_forward_cached"]
     assert len(built) == 1 and flags == [2], (len(built), flags)
     assert names().count("r3dg_shade_build_split") == 1 and names().count("r3dg_shade_forward_split") == 3
@@ -238,16 +244,40 @@ def test_relight_renderer_host_logic_with_a_recording_library(monkeypatch):
     calls.clear()
     del built[:]
     for i in range(6):
-        r2.frame(cam, z(3), env_transform=dt(torch.eye(3) * (1.0 + i)))
+        r2.frame(cam, z(3), env_transform=dt(rot(i)))
     flags = [c[1][-2] for c in calls if c[0] == "r3dg_shade_forward_cached"]
     assert len(built) == 1 and flags == [2] and names().count("r3dg_shade_forward_split") == 5, (len(built), flags)
-    fixed = dt(torch.eye(3) * 9.0)
+    fixed = dt(rot(9))
     for i in range(3):
         r2.frame(cam, z(3), env_transform=fixed)
     flags = [c[1][-2] for c in calls if c[0] == "r3dg_shade_forward_cached"][1:]
     # stopped: its first frame is still a change (split kernel), cached again from the second one
     assert len(built) == 2 and flags == [2, 2] and names().count("r3dg_shade_forward_split") == 6, (len(built), flags)
     assert names().count("r3dg_shade_build_split") == 1
+    # the split cache is keyed like the lookup cache.  A map edited in place / swapped in between two frames of a
+    # turning light rebuilds the footprints (and only them); swapped visibility rebuilds the sample half; a HOST transform that
+    # is not a rotation (scaled) never takes the split kernel, which evaluates the lobe in the light's frame
+    r2.frame(cam, z(3), env_transform=dt(rot(18)))         # (the light turns again: the first change still builds a lookup cache)
+    calls.clear()
+    r2.frame(cam, z(3), env_transform=dt(rot(20)))
+    r2.frame(cam, z(3), env_transform=dt(rot(21)))
+    assert names().count("r3dg_shade_env_footprints") == 0 and names().count("r3dg_shade_forward_split") == 2
+    r2.envmap.add_(1.0)                                    # edited in place: version counter
+    r2.frame(cam, z(3), env_transform=dt(rot(22)))
+    assert names().count("r3dg_shade_env_footprints") == 1 and names().count("r3dg_shade_build_split") == 0
+    r2.envmap = dt(z(8, 16, 3))                            # swapped
+    r2.frame(cam, z(3), env_transform=dt(rot(23)))
+    assert names().count("r3dg_shade_env_footprints") == 2 and names().count("r3dg_shade_build_split") == 0
+    r2.visibility = torch.ones(P, K, 1)
+    r2.frame(cam, z(3), env_transform=dt(rot(24)))
+    assert names().count("r3dg_shade_build_split") == 1 and names().count("r3dg_shade_env_footprints") == 2
+    n_split = names().count("r3dg_shade_forward_split")
+    r2.frame(cam, z(3), env_transform=torch.eye(3) * 2.0)              # scaled, given on the host: general kernel
+    assert names().count("r3dg_shade_forward_split") == n_split and calls[-4][0] != "r3dg_shade_forward_split"
+    assert [c for c in calls if c[0] == "r3dg_shade_forward_cached"][-1][1][-2] == 0
+    r2.envmap = dt(z(4096, 8, 3))                          # taller than the footprint records address: general kernel, no error
+    r2.frame(cam, z(3), env_transform=dt(rot(25)))
+    assert names().count("r3dg_shade_forward_split") == n_split
     # the default, transport cache: one build (radiance -> transport in place + constants), then the transport kernel per frame
     r = relight.RelightRenderer(model, env, K)
     assert r.cache == "transport" and r.xyz is not model.xyz            # (works on a snapshot of the parameters)

@@ -166,3 +166,127 @@ def test_feature_row_layout_and_errors():
     torch.testing.assert_close(f[:, 1], depth.square(), rtol=1e-5, atol=1e-6)
     with pytest.raises(RuntimeError):
         r.frame(cam, torch.zeros(3, device=DEV), outputs=("nonsense",))
+
+
+# ---- the eval / relight frame against the REFERENCE'S OWN Python -------------------------------------------
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def _relight_fixture():
+    import numpy as np
+    from relightable3dgaussian_amd.synthetic import SynthCamera
+    z = dict(np.load(os.path.join(GOLD, "pipeline_reference_relight.npz")))
+    t = lambda k: torch.from_numpy(z[k]).to(DEV)
+    fovx, fovy, tanx, tany, cx, cy = [float(v) for v in z["cam_scalars"]]
+    cam = SynthCamera(int(z["H"]), int(z["W"]), fovx, fovy, tanx, tany, cx, cy, t("wvt"), t("fpt"), t("campos"))
+    import types
+    model = types.SimpleNamespace(xyz=t("raw_xyz"), normal=t("raw_normal"), scaling=t("raw_scaling"), rotation=t("raw_rotation"),
+                                  opacity=t("raw_opacity"), base_color=t("raw_base_color"), roughness=t("raw_roughness"),
+                                  features_dc=t("raw_shs_dc"), features_rest=t("raw_shs_rest"),
+                                  incidents_dc=t("raw_incidents_dc"), incidents_rest=t("raw_incidents_rest"))
+    return z, cam, model, t
+
+
+def _reference_maps_from(res, bg, rgb_to_srgb):
+    """What neilf.py:144-163,172-173 derives from the rasterizer's raw outputs (the renderer returns the raw premultiplied
+    feature image, like the op does)."""
+    op = res["opacity"]
+    feat = res["feature"] / op.clamp_min(1e-5) * (res["num_contrib"] > 0)
+    d = dict(depth=feat[0:1], normal=feat[5:8], base_color=rgb_to_srgb(feat[8:11]), roughness=feat[11:12],
+             diffuse=rgb_to_srgb(feat[12:15]), specular=rgb_to_srgb(feat[15:18]), lights=rgb_to_srgb(feat[18:21]),
+             local_lights=rgb_to_srgb(feat[21:24]), global_lights=rgb_to_srgb(feat[24:27]), visibility=feat[27:28],
+             pbr=rgb_to_srgb(feat[2:5] * op + (1 - op) * bg[:, None, None]))
+    return d
+
+
+@pytest.mark.parametrize("cache,regenerate_dirs", [("transport", True), ("transport", False), ("radiance", True)])
+def test_relight_frames_match_the_reference_python(cache, regenerate_dirs):
+    """tests/golden/pipeline_reference_relight.npz (make_relight_golden.py): the reference's unmodified
+    render_view(is_training=False) (gaussian_renderer/neilf.py:98-209) with its EnvLight (scene/envmap.py:35-53) and
+    `light.transform` set per frame (relighting.py:160-161), three frames (two rotations, none).  RelightRenderer.frame must give
+    the same per-Gaussian 28-channel feature rows, the same raw images and the same composites on EVERY path it can take:
+    the fixed-light cache (first frame of a light: transport / radiance kernel), the split transport (a light that turned twice),
+    the lookup-in-kernel general op (split switched off), and relight.frame_reference (the drop-in ops + PyTorch glue).
+    Tolerances: feature rows / images 1e-4 of the channel group's maximum (5e-4 on the GGX-carrying pbr / specular, 1e-3 where
+    the directions are regenerated), composites 4e-4 absolute behind the sRGB curve."""
+    import numpy as np
+    from relightable3dgaussian_amd import relight
+    z, cam, model, t = _relight_fixture()
+    K = int(z["K"])
+    r = relight.RelightRenderer(model, t("envmap"), K, cache=cache, regenerate_dirs=regenerate_dirs)
+    vis, dirs, areas = t("visibility"), t("incident_dirs"), t("incident_areas")
+    # the renderer traced its own visibility with the HIP BVH: same classes as the reference's (oracle-traced) caches except at
+    # the 0.9 threshold; from here on identical caches
+    near = (vis - 0.9).abs() < 1e-4
+    assert (((r.visibility == 0) != (vis == 0)) & ~near).float().mean().item() <= 1e-4
+    ok, msg = report("incident_dirs", r.incident_dirs, dirs, 0, 5e-5)
+    assert ok, msg
+    r.visibility, r.incident_dirs, r.incident_areas = vis, dirs, areas
+    ggx = 1e-3 if (cache == "transport" and regenerate_dirs) else 5e-4
+    msgs, ok_all = [], [True]
+
+    def chk(name, got, want, rtol, atol):
+        ok, msg = report(name, got, torch.as_tensor(np.asarray(want)).reshape(got.shape), rtol, atol)
+        msgs.append(msg)
+        ok_all[0] &= ok
+
+    def check_frame(tag, what, res, feats, split_ggx=None):
+        gg = split_ggx or ggx
+        f = z[tag + "_features"]
+        for c0, c1, name, tol in ((0, 2, "depth,depth^2", 1e-5), (2, 5, "pbr", gg), (5, 12, "normal,base,rough", 1e-5),
+                                  (12, 15, "diffuse_light", 1e-4), (15, 18, "specular", gg), (18, 27, "lights", 1e-4),
+                                  (27, 28, "visibility", 1e-4)):
+            chk("%s %s rows[%s]" % (tag, what, name), feats[:, c0:c1], f[:, c0:c1], tol, 1e-6)
+        assert res["num_rendered"] == int(z[tag + "_num_rendered"]), (tag, what)
+        bg = torch.from_numpy(z[tag + "_bg"]).to(DEV)
+        for k in ("pbr_env", "render_env", "env_only"):
+            chk("%s %s %s" % (tag, what, k), res[k], z["%s_map_%s" % (tag, k)], 0.0, 4e-4)
+        chk("%s %s opacity" % (tag, what), res["opacity"], z[tag + "_map_opacity"], 2e-5, 1e-6)
+        derived = _reference_maps_from(res, bg, relight.rgb_to_srgb)
+        chk("%s %s pbr map" % (tag, what), derived["pbr"], z[tag + "_map_pbr"], 0.0, 4e-4)
+        if tag == "a":
+            chk("a %s render" % what, res["render"], z["a_map_render"], 2e-5, 1e-6)
+            chk("a %s pseudo_normal" % what, res["pseudo_normal"], z["a_map_pseudo_normal"], 1e-3, 1e-4)
+            assert torch.equal(res["num_contrib"].reshape(-1).cpu(), torch.from_numpy(z["a_num_contrib"]).reshape(-1))
+            fi = torch.from_numpy(z["a_feature_image"]).to(DEV)
+            for c0, c1, name, tol in ((0, 2, "depth", 2e-5), (2, 5, "pbr", gg), (5, 15, "material", 1e-4), (15, 18, "specular", gg),
+                                      (18, 28, "lights", 1e-4)):
+                chk("a %s feature image[%s]" % (what, name), res["feature"][c0:c1], fi[c0:c1], tol, 1e-6)
+            for k in ("depth", "normal", "roughness", "visibility"):
+                chk("a %s map %s" % (what, k), derived[k], z["a_map_" + k], 1e-4, 1e-5)
+            for k in ("base_color", "diffuse", "specular", "lights", "local_lights", "global_lights"):
+                chk("a %s map %s" % (what, k), derived[k], z["a_map_" + k], 0.0, 4e-4)
+
+    outs = ("pbr_env", "render_env", "env_only")
+    Ta, Tb = t("T_a"), t("T_b")
+    bg0, bg1 = torch.zeros(3, device=DEV), torch.ones(3, device=DEV)
+    # (1) first frame of a light: the fixed-light cache
+    res = r.frame(cam, bg0, env_transform=Ta, outputs=outs)
+    assert r._taps_key == r._light_key
+    check_frame("a", "fixed-light cache (%s)" % cache, res, r.features)
+    # (2) the light turns: from the second consecutive change on the split transport
+    res = r.frame(cam, bg0, env_transform=Tb, outputs=outs)
+    assert isinstance(r._split, dict) and r._taps_key != r._light_key
+    check_frame("b", "split transport", res, r.features, 1e-3 if regenerate_dirs else 5e-4)
+    res = r.frame(cam, bg0, env_transform=Ta.clone(), outputs=outs)
+    check_frame("a", "split transport", res, r.features, 1e-3 if regenerate_dirs else 5e-4)
+    res = r.frame(cam, bg1, env_transform=None, outputs=outs)
+    check_frame("n", "split transport, no rotation", res, r.features, 1e-3 if regenerate_dirs else 5e-4)
+    # (3) the light stands still again: cached from the second identical frame on
+    res = r.frame(cam, bg1, env_transform=None, outputs=outs)
+    assert r._taps_key == r._light_key
+    check_frame("n", "fixed-light cache, no rotation", res, r.features)
+    # (4) the general kernel with the lookup inside (what a configuration outside the split kernels' gets)
+    r._split_cache = lambda *a, **k: None
+    r.frame(cam, bg0, env_transform=Tb.clone(), outputs=outs)
+    res = r.frame(cam, bg0, env_transform=Tb.clone(), outputs=outs)
+    assert r._taps_key != r._light_key
+    check_frame("b", "lookup in the general kernel", res, r.features, 5e-4)
+    # (5) the drop-in ops + PyTorch glue
+    for tag, tr, bg in (("a", Ta, bg0), ("n", None, bg1)):
+        ref = relight.frame_reference(r, cam, bg, env_transform=tr)
+        for k in ("pbr_env", "render_env", "env_only"):
+            chk("%s frame_reference %s" % (tag, k), ref[k], z["%s_map_%s" % (tag, k)], 0.0, 4e-4)
+        assert ref["num_rendered"] == int(z[tag + "_num_rendered"])
+    print("\n".join(msgs))
+    assert ok_all[0], "\n".join(m for m in msgs)
