@@ -674,6 +674,11 @@ int r3dg_bvh_pack_traversal(void* stream, int num_gaussians, const int32_t* d_no
 int r3dg_bvh_trace_opacity_packed(void* stream, int64_t num_rays, int num_gaussians, void* d_records, const float* d_rays_o,
                                   const float* d_rays_d, int32_t* d_num_contributes, float* d_rendered_opacity,
                                   int32_t* d_stack_overflow);
+/* Measurement ("report rays/s and node-visits/s"): with R3DG_OPT_TRACE_COUNT_VISITS = 1 the phased trace counts
+ * its node steps (one slab test of both children of a node, trace.cu:228-246) and leaf steps (one Gaussian evaluated,
+ * :247-276); r3dg_bvh_trace_visits synchronises `stream` and returns the two sums of the LAST trace over `d_records` in
+ * node_and_leaf_steps[0..1] (host memory).  Results of the trace itself are unchanged. */
+int r3dg_bvh_trace_visits(void* stream, int num_gaussians, const void* d_records, uint64_t* node_and_leaf_steps);
 
 /* trace_bvh (bvh/include/bvh.h:8-12, bvh/src/trace.cu:8-192; no caller in the reference's Python): per-ray hit lists.
  *   r3dg_bvh_trace_count: num_contributes[r] = number of leaves in the <=4-leaf subtrees ray r reaches (trace.cu:21-58);
@@ -714,6 +719,7 @@ enum r3dg_option {
     R3DG_OPT_TRACE_LEAF_WEIGHT,
     R3DG_OPT_RESERVE_CUS,               /* CUs the persistent kernels (shading, trace, long-tile sort) leave free for a collective running
                                          * beside them (default 0; the data-parallel iteration sets it) */
+    R3DG_OPT_TRACE_COUNT_VISITS,        /* 1 = the phased trace counts node and leaf steps (measurement: r3dg_bvh_trace_visits); default 0 */
     R3DG_OPT_COUNT
 };
 int r3dg_set_option(int option, int value);       /* the PROCESS default */

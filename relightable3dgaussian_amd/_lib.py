@@ -119,6 +119,7 @@ _SIGNATURES = {
     "r3dg_bvh_trace_records_bytes": (C.c_size_t, [_i]),
     "r3dg_bvh_pack_traversal": (_i, [_p, _i] + [_p] * 7),
     "r3dg_bvh_trace_opacity_packed": (_i, [_p, C.c_int64, _i] + [_p] * 6),
+    "r3dg_bvh_trace_visits": (_i, [_p, _i, _p, C.POINTER(C.c_uint64)]),
     "r3dg_profile_enable": (_i, [_i]),
     "r3dg_profile_pause": (_i, [_i]),
     "r3dg_profile_num_stages": (_i, []),
@@ -155,7 +156,7 @@ def lib():
 
 # enum r3dg_option (include/r3dg_hip.h); tests/test_oracle_cpu.py checks the numbering against the header
 OPTIONS = ("TILE_ORDER", "CULL", "TILE_BINNING", "BINNING_BLOCK_K", "STAGE_SH_ROWS", "SHADE_FWD_BLOCKS_PER_CU", "TRACE_FORMULATION",
-           "TRACE_REFILL", "TRACE_NODE_WEIGHT", "TRACE_LEAF_WEIGHT", "RESERVE_CUS")
+           "TRACE_REFILL", "TRACE_NODE_WEIGHT", "TRACE_LEAF_WEIGHT", "RESERVE_CUS", "TRACE_COUNT_VISITS")
 
 
 def set_option(name, value):

@@ -381,6 +381,30 @@ def roofline_of(kernels, note):
 
 
 @torch.no_grad()
+def trace_visit_stats(renderer, seconds):
+    """SURVEY.md 8(d) K18 "report rays/s and node-visits/s": the renderer's visibility update once more with the COUNTING
+    instantiation of the trace kernel (R3DG_OPT_TRACE_COUNT_VISITS; same traversal, results discarded) -- node steps (a slab test
+    of both children) and leaf steps (one Gaussian evaluated) per ray, and per second of the UNCOUNTED update that took
+    `seconds` (the time `visibility_Mrays_per_s` is quoted on: tree build + ray generation + trace)."""
+    from . import bvh_ops
+    from .train_step import update_visibility
+    r = renderer
+    try:
+        _lib.set_option("TRACE_COUNT_VISITS", 1)
+        bvh_ops.VISITS[:] = [0, 0, 0]
+        update_visibility(r.xyz, r.a_scales, r.a_rot, r.a_opacity, r.a_normal, r.K)
+        nodes, leaves, rays = bvh_ops.VISITS
+    finally:
+        _lib.set_option("TRACE_COUNT_VISITS", 0)
+        bvh_ops.VISITS[:] = [0, 0, 0]
+    if rays == 0:
+        return None
+    return dict(rays=rays, node_steps=nodes, leaf_steps=leaves, node_steps_per_ray=round(nodes / rays, 2),
+                leaf_steps_per_ray=round(leaves / rays, 2), node_visits_per_s=round((nodes + leaves) / seconds),
+                note="node_visits_per_s = (node steps + leaf steps) / visibility_seconds; a node step tests both children")
+
+
+@torch.no_grad()
 def relight_bench(params, cams, dev, frames, K):
     """Relight / eval rendering (relighting.py:114-170, neilf.py:98-209 eval branch): per frame the shading integral at
     K samples under a fixed HDR environment map + rasterize forward with the S=28 eval feature row + the environment
@@ -397,6 +421,10 @@ def relight_bench(params, cams, dev, frames, K):
                                        cache=cache, regenerate_dirs=os.environ.get("R3DG_RELIGHT_DIRS", "regen") != "load")
     torch.cuda.synchronize()
     t_vis = time.perf_counter() - t0
+    try:
+        visits = trace_visit_stats(renderer, t_vis)
+    except Exception as e:                        # (a side measurement)
+        visits = {"failed": repr(e)}
     bg = torch.zeros(3, device=dev)
 
     def timed(fn, n):
@@ -470,6 +498,7 @@ def relight_bench(params, cams, dev, frames, K):
                 relight_fps_radiance_cache=radiance_fps,
                 relight_features=28, relight_fps_pytorch_glue=round(1.0 / dt_ref, 2), visibility_rays=P * K,
                 visibility_seconds=round(t_vis, 3), visibility_Mrays_per_s=round(P * K / t_vis / 1e6, 1),
+                visibility_node_visits_per_s=(visits or {}).get("node_visits_per_s"), visibility_trace_visits=visits,
                 num_rendered=R_mean, roofline_relight=roof, kernels=kernels, relight_rotating_light=rotating,
                 relight_note="relight_fps: moving camera under a FIXED light (configs/teaser, configs/nerf_syn): the "
                              "view-independent part of the integral is cached per sample (RelightRenderer's default, "
@@ -616,6 +645,10 @@ def config_rate(dev, points, width, height, stage=2, sample_num=64, objective="n
         r = relight.RelightRenderer(step_fn, envmap, relight_samples)
         torch.cuda.synchronize()
         t_vis = time.perf_counter() - t0
+        try:
+            visits = trace_visit_stats(r, t_vis)
+        except Exception as e:
+            visits = {"failed": repr(e)}
         zbg = torch.zeros(3, device=dev)
         for i in range(2):
             r.frame(cams[i], zbg)
@@ -628,7 +661,8 @@ def config_rate(dev, points, width, height, stage=2, sample_num=64, objective="n
         dtf = (time.perf_counter() - t0) / relight_frames
         out.update(relight_fps=round(1.0 / dtf, 2), relight_ms_per_frame=round(1e3 * dtf, 3), relight_samples=relight_samples,
                    relight_num_rendered=round(nr / relight_frames), visibility_rays=points * relight_samples,
-                   visibility_seconds=round(t_vis, 3))
+                   visibility_seconds=round(t_vis, 3), visibility_Mrays_per_s=round(points * relight_samples / t_vis / 1e6, 1),
+                   visibility_trace_visits=visits)
     return out
 
 

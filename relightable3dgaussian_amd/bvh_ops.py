@@ -62,6 +62,16 @@ def trace_bvh_opacity(nodes, aabbs, rays_o, rays_d, means3D, covs3D, opacities, 
                 st = L.r3dg_bvh_trace_opacity_packed(_lib.current_stream(), num_rays, means3D.shape[0], records.data_ptr(),
                                                      ro.data_ptr(), rd.data_ptr(), num_contributes.data_ptr(),
                                                      rendered_opacity.data_ptr(), overflow.data_ptr())
+                if st == 0 and _lib.get_option("TRACE_COUNT_VISITS"):
+                    # measurement runs (bench.py: node visits per second): the counting instantiation of the trace ran; add
+                    # its node / leaf step sums to the module's accumulators (synchronises)
+                    import ctypes
+                    v = (ctypes.c_uint64 * 2)()
+                    _lib.check(L.r3dg_bvh_trace_visits(_lib.current_stream(), means3D.shape[0], records.data_ptr(), v),
+                               "bvh_trace_visits")
+                    VISITS[0] += int(v[0])
+                    VISITS[1] += int(v[1])
+                    VISITS[2] += int(num_rays)
             else:
                 t = [x.contiguous() for x in (nodes, aabbs, rays_o, rays_d, means3D, covs3D, opacities, normals)]
                 P = means3D.shape[0] if nodes.shape[0] == 2 * means3D.shape[0] - 1 else 0
@@ -71,6 +81,9 @@ def trace_bvh_opacity(nodes, aabbs, rays_o, rays_d, means3D, covs3D, opacities, 
         _lib.check(st, "trace_bvh_opacity")
         trace_bvh_opacity.last_overflow = overflow
     return num_contributes, rendered_opacity
+
+
+VISITS = [0, 0, 0]         # node steps, leaf steps, rays of the traces run with R3DG_OPT_TRACE_COUNT_VISITS = 1 (reset by the reader)
 
 
 def trace_bvh(nodes, aabbs, rays_o, rays_d, means3D, covs3D, opacities):

@@ -783,6 +783,10 @@ trace_opacity_persistent_kernel(int num_rays, int P, const TNode* __restrict__ t
 // more ready lanes runs, the other lanes wait one turn.  The register also halves the stack traffic (a node whose children
 // are both hit pushes one and continues with the other instead of push, push, pop).  Per-ray visit order, arithmetic and
 // the overflow accounting are those of the kernels above, so results are identical.
+// COUNT (R3DG_OPT_TRACE_COUNT_VISITS, measurement builds of the same kernel): every lane counts the node steps (one slab test of
+// both children) and leaf steps (one Gaussian evaluated) of its rays; one 64-bit atomic pair per wave at the end, into words
+// 8..11 of the wave's own queue line (zeroed with the queue heads before the launch; read by r3dg_bvh_trace_visits).
+template <bool COUNT>
 __global__ void __launch_bounds__(256)
 trace_opacity_phased_kernel(int num_rays, int P, const TNode* __restrict__ tn, const TLeaf* __restrict__ tl,
                             const float* __restrict__ rays_o, const float* __restrict__ rays_d,
@@ -798,6 +802,8 @@ trace_opacity_phased_kernel(int num_rays, int P, const TNode* __restrict__ tn, c
     int q_turn = 0;
     int q_lo = min(num_rays, xcd * per), q_hi = min(num_rays, q_lo + per);
     int* next_ray = queues + 16 * xcd;
+    unsigned long long* visit_words = reinterpret_cast<unsigned long long*>(queues + 16 * xcd + 8);
+    unsigned int n_node_steps = 0u, n_leaf_steps = 0u;
     int stack[TRACE_STACK];
     int sp = 0, ray = -1, count = 0, cur = -1;
     float ox = 0.f, oy = 0.f, oz = 0.f, dx = 0.f, dy = 0.f, dz = 1.f, T = 1.0f;
@@ -868,6 +874,7 @@ trace_opacity_phased_kernel(int num_rays, int P, const TNode* __restrict__ tn, c
             }
             if (at_node) {
                 stepped = true;
+                if (COUNT) ++n_node_steps;
                 const int lid = __float_as_int(q0.x), rid = __float_as_int(q0.y);
                 const int first = tl_ > tr_ ? lid : rid, second = tl_ > tr_ ? rid : lid;
                 const float tf = tl_ > tr_ ? tl_ : tr_, ts = tl_ > tr_ ? tr_ : tl_;
@@ -884,6 +891,7 @@ trace_opacity_phased_kernel(int num_rays, int P, const TNode* __restrict__ tn, c
             }
         } else if (at_leaf) {
             stepped = true;
+            if (COUNT) ++n_leaf_steps;
             const float4* q = reinterpret_cast<const float4*>(tl + (cur - first_leaf));
             const float4 q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3];
             const float op = q2.y;
@@ -929,8 +937,20 @@ trace_opacity_phased_kernel(int num_rays, int P, const TNode* __restrict__ tn, c
         }
     }
     if (lost) atomicAdd(overflow, 1);
+    if (COUNT) {
+        unsigned long long a = n_node_steps, b = n_leaf_steps;
+        for (int d = 32; d > 0; d >>= 1) {
+            a += __shfl_xor(a, d);
+            b += __shfl_xor(b, d);
+        }
+        if (lane == 0) {
+            atomicAdd(visit_words, a);
+            atomicAdd(visit_words + 1, b);
+        }
+    }
 }
 
+int g_trace_count_visits = 0;        // R3DG_OPT_TRACE_COUNT_VISITS
 int g_trace_packet = 4;
 int g_trace_refill = REFILL_MIN_IDLE, g_trace_node_weight = 1, g_trace_leaf_weight = 1;     // R3DG_OPT_TRACE_*: 4 = 3 + phase-separated bodies, 3 = packed records + persistent waves, 2 = packed records, 1 = wave-cooperative, 0 = round-1 kernel
 
@@ -1172,13 +1192,30 @@ void bvh_trace_opacity_packed(hipStream_t s, int num_rays, int P, void* records,
         if (opt(R3DG_OPT_TRACE_FORMULATION) == 3)
             trace_opacity_persistent_kernel<<<grid, 256, 0, s>>>(num_rays, P, tn, tl, rays_o, rays_d, contributes, out,
                                                                 overflow, queues);
+        else if (opt(R3DG_OPT_TRACE_COUNT_VISITS))
+            trace_opacity_phased_kernel<true><<<grid, 256, 0, s>>>(num_rays, P, tn, tl, rays_o, rays_d, contributes, out,
+                                                                  overflow, queues, opt(R3DG_OPT_TRACE_REFILL),
+                                                                  opt(R3DG_OPT_TRACE_NODE_WEIGHT), opt(R3DG_OPT_TRACE_LEAF_WEIGHT));
         else
-            trace_opacity_phased_kernel<<<grid, 256, 0, s>>>(num_rays, P, tn, tl, rays_o, rays_d, contributes, out,
-                                                            overflow, queues, opt(R3DG_OPT_TRACE_REFILL), opt(R3DG_OPT_TRACE_NODE_WEIGHT),
-                                                            opt(R3DG_OPT_TRACE_LEAF_WEIGHT));
+            trace_opacity_phased_kernel<false><<<grid, 256, 0, s>>>(num_rays, P, tn, tl, rays_o, rays_d, contributes, out,
+                                                                   overflow, queues, opt(R3DG_OPT_TRACE_REFILL),
+                                                                   opt(R3DG_OPT_TRACE_NODE_WEIGHT), opt(R3DG_OPT_TRACE_LEAF_WEIGHT));
     } else {
         trace_opacity_packed_kernel<<<chunk * 8, 256, 0, s>>>(num_rays, P, chunk, tn, tl, rays_o, rays_d, contributes,
                                                              out, overflow);
+    }
+}
+
+// node / leaf steps of the LAST counting trace over these records (sums over the eight queue lines; synchronises the stream)
+void bvh_trace_visits(hipStream_t s, int P, const void* records, unsigned long long out[2])
+{
+    unsigned long long lines[8 * 8];
+    R3DG_HIP(hipStreamSynchronize(s));
+    R3DG_HIP(hipMemcpy(lines, reinterpret_cast<const char*>(records) + (size_t)P * 128, sizeof(lines), hipMemcpyDeviceToHost));
+    out[0] = out[1] = 0ull;
+    for (int q = 0; q < 8; ++q) {
+        out[0] += lines[8 * q + 4];
+        out[1] += lines[8 * q + 5];
     }
 }
 

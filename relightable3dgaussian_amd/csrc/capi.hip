@@ -109,7 +109,7 @@ void launch_shade_build_transport(hipStream_t s, int P, int K, int M, const floa
 void launch_shade_forward_transport(hipStream_t s, int P, int K, const float* base_color, const float* roughness,
                                     const float* normals, const float* viewdirs, const float* transport, const float* consts,
                                     const float* zsamples, const float* dirs, float* out);
-extern int g_trace_packet, g_trace_refill, g_trace_node_weight, g_trace_leaf_weight;
+extern int g_trace_packet, g_trace_refill, g_trace_node_weight, g_trace_leaf_weight, g_trace_count_visits;
 extern int g_shade_row_blocks_per_cu;
 void launch_shade_backward(hipStream_t s, int P, int K, int M, const float* base_color, const float* roughness,
                            const float* normals, const float* viewdirs, const float* incidents, const float* env,
@@ -225,6 +225,7 @@ void bvh_trace_opacity(hipStream_t s, int num_rays, int P, const int32_t* nodes,
 size_t bvh_trace_records_bytes(size_t P);
 void bvh_pack_traversal(hipStream_t s, int P, const int32_t* nodes, const float* aabbs, const float* means, const float* covs,
                         const float* opac, const float* normals, void* records);
+void bvh_trace_visits(hipStream_t s, int P, const void* records, unsigned long long out[2]);
 void bvh_trace_opacity_packed(hipStream_t s, int num_rays, int P, void* records, const float* rays_o, const float* rays_d,
                               int32_t* contributes, float* out, int* overflow);
 int g_reserve_cus = 0;
@@ -421,14 +422,15 @@ static int* option_slot(int option)
         case R3DG_OPT_TRACE_NODE_WEIGHT: return &g_trace_node_weight;
         case R3DG_OPT_TRACE_LEAF_WEIGHT: return &g_trace_leaf_weight;
         case R3DG_OPT_RESERVE_CUS: return &g_reserve_cus;
+        case R3DG_OPT_TRACE_COUNT_VISITS: return &g_trace_count_visits;
         default: return nullptr;
     }
 }
 
 static bool option_in_range(int option, int value)
 {
-    static const int lo[R3DG_OPT_COUNT] = {0, 0, 0, 1, 0, 0, 0, 1, 1, 1, 0};
-    static const int hi[R3DG_OPT_COUNT] = {1, 1, 2, 64, 1, 8, 4, 64, 15, 15, 128};
+    static const int lo[R3DG_OPT_COUNT] = {0, 0, 0, 1, 0, 0, 0, 1, 1, 1, 0, 0};
+    static const int hi[R3DG_OPT_COUNT] = {1, 1, 2, 64, 1, 8, 4, 64, 15, 15, 128, 1};
     return value >= lo[option] && value <= hi[option];
 }
 
@@ -2158,6 +2160,18 @@ int r3dg_bvh_trace_opacity_packed(void* stream_, int64_t num_rays, int num_gauss
                                  rendered_opacity, stack_overflow);
         check_launch(stream, false, "bvh_trace_opacity_packed");
         t.stop();
+        return R3DG_OK;
+    });
+}
+
+int r3dg_bvh_trace_visits(void* stream_, int num_gaussians, const void* records, uint64_t* node_and_leaf_steps)
+{
+    if (num_gaussians <= 0 || !records || !node_and_leaf_steps) return invalid("bvh_trace_visits: bad arguments");
+    return guarded([&]() -> int {
+        unsigned long long v[2];
+        bvh_trace_visits((hipStream_t)stream_, num_gaussians, records, v);
+        node_and_leaf_steps[0] = v[0];
+        node_and_leaf_steps[1] = v[1];
         return R3DG_OK;
     });
 }

@@ -143,6 +143,25 @@ def test_trace_formulations_give_identical_results(P, seed, K):
     for mode in (2, 3, 4):
         assert torch.equal(got[mode][0], got[0][0]), "visibility differs in mode %d" % mode
         assert torch.equal(got[mode][1], got[0][1]), "hit counts differ in mode %d" % mode
+    # the COUNTING instantiation of the default kernel (R3DG_OPT_TRACE_COUNT_VISITS, bench.py's node-visits/s): same results; every
+    # ray takes at least the root's node step (P > 1), a leaf step per accepted Gaussian at least, and the sums are the
+    # traversal's, i.e. the same on a second run
+    from relightable3dgaussian_amd import bvh_ops
+    counts = []
+    try:
+        _lib.set_option("TRACE_COUNT_VISITS", 1)
+        for _ in range(2):
+            bvh_ops.VISITS[:] = [0, 0, 0]
+            res = rt.trace_visibility(o, d, sc["xyz"].to(DEV), cinv.to(DEV), sc["opacity"][:, 0].contiguous().to(DEV),
+                                      sc["normal"].to(DEV))
+            counts.append(tuple(bvh_ops.VISITS))
+            assert torch.equal(res["visibility"], got[4][0]) and torch.equal(res["contribute"], got[4][1])
+    finally:
+        _lib.set_option("TRACE_COUNT_VISITS", 0)
+        bvh_ops.VISITS[:] = [0, 0, 0]
+    nodes, leaves, rays = counts[0]
+    assert counts[0] == counts[1] and rays == P * (K - 1)
+    assert nodes >= rays and leaves >= int(got[4][1].sum()) and nodes < 2000 * rays
 
 
 @pytest.mark.parametrize("P", [2, 700, 70_000])
