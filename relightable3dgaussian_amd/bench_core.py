@@ -254,59 +254,91 @@ def _kernel_names(stage):
             }.get(stage, [stage + "_kernel", stage])
 
 
-def pmc_traffic(stage):
-    """HBM bytes per launch of `stage`'s kernel from the committed rocprofv3 PMC passes (profiles/*_pmc_traffic.json;
-    FETCH_SIZE / WRITE_SIZE collected in separate passes on the same workload), or None."""
+def _pmc_file_rows(kind, stage, workload=None):
+    """(kernel name, its row, file name, stale?) from the newest committed counter file profiles/rNN_pmc_<kind>[_<workload>].json
+    that holds one of `stage`'s kernels (`workload`: None = the training kernels' pass, "relight" = the relight frame's pass --
+    the same kernel runs with other template instances and sizes there; falls back to the training pass).  stale: the file carries the sha256 of the kernel's source at collection time (tools/pmc_*.py,
+    kernel_sources.stamp) and it differs from the tree this process runs from -- None when the file predates the stamps."""
     import glob
+    from . import kernel_sources
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    files = sorted(glob.glob(os.path.join(root, "profiles", "*_pmc_traffic.json")))
-    if not files:
-        return None
-    try:
-        doc = json.load(open(files[-1]))
+    paths = []
+    for w in ([workload] if workload else []) + [None]:
+        paths += sorted(glob.glob(os.path.join(root, "profiles", "r[0-9][0-9]_pmc_%s%s.json" % (kind, "_" + w if w else ""))),
+                        reverse=True)
+    for path in paths:
+        try:
+            doc = json.load(open(path))
+        except Exception:
+            continue
         for name in _kernel_names(stage):
-            v = doc["kernels"].get(name)
-            if v is not None:
-                return dict(bytes_corrected=v["hbm_bytes_corrected"], bytes_raw=v["hbm_bytes_raw"], kernel=name,
-                            source=os.path.basename(files[-1]),
-                            note="corrected = 2 x FETCH_SIZE + WRITE_SIZE (MI355X_MICROARCH.md); profiles/r02_pmc_calibration.json: "
-                                 "the factor 2 holds for streaming reads, random sub-line gathers are counted at 64 B per "
-                                 "request (factor 1) and a 4-byte atomic as 32 written bytes, so for the gather / atomic "
-                                 "heavy tile kernels the truth lies between bytes_raw and bytes_corrected")
-    except Exception:
-        return None
+            v = doc.get("kernels", {}).get(name)
+            if v is None:
+                continue
+            stamp = (doc.get("sources") or {}).get(name)
+            stale = None if not stamp else bool(stamp.get("sha256") != kernel_sources.source_of(name)[1])
+            return name, v, os.path.basename(path), stale
     return None
 
 
-def pmc_valu(stage):
-    """VALU-issue evidence for `stage`'s kernel from the committed rocprofv3 SQ-counter passes (profiles/*_pmc_valu.json,
+def pmc_traffic(stage, workload=None):
+    """HBM bytes per launch of `stage`'s kernel from the committed rocprofv3 PMC passes (profiles/*_pmc_traffic*.json;
+    FETCH_SIZE / WRITE_SIZE collected in separate passes on the same workload), or None."""
+    hit = _pmc_file_rows("traffic", stage, workload)
+    if hit is None:
+        return None
+    name, v, source, stale = hit
+    return dict(bytes_corrected=v["hbm_bytes_corrected"], bytes_raw=v["hbm_bytes_raw"], kernel=name, source=source, stale=stale,
+                note="corrected = 2 x FETCH_SIZE + WRITE_SIZE (MI355X_MICROARCH.md); profiles/r02_pmc_calibration.json: "
+                     "the factor 2 holds for streaming reads, random sub-line gathers are counted at 64 B per "
+                     "request (factor 1) and a 4-byte atomic as 32 written bytes, so for the gather / atomic "
+                     "heavy tile kernels the truth lies between bytes_raw and bytes_corrected")
+
+
+def pmc_valu(stage, workload=None):
+    """VALU-issue evidence for `stage`'s kernel from the committed rocprofv3 SQ-counter passes (profiles/*_pmc_valu*.json,
     tools/pmc_valu.py): fraction of the kernel's duration the SIMDs spend issuing VALU instructions, occupancy, LDS bank
     conflicts -- shown beside every HBM fraction because the tile and shading kernels are VALU-bound -- or None."""
-    import glob
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    files = sorted(glob.glob(os.path.join(root, "profiles", "*_pmc_valu.json")))
-    if not files:
+    hit = _pmc_file_rows("valu", stage, workload)
+    if hit is None:
         return None
-    try:
-        doc = json.load(open(files[-1]))
-        for name in _kernel_names(stage):
-            v = doc["kernels"].get(name)
-            if v is not None:
-                out = {k: v[k] for k in ("valu_issue_frac", "valu_busy_frac", "waves_per_simd", "lds_bank_conflict_frac",
-                                         "lds_issue_frac", "trans_frac", "mfma_busy_frac", "salu_issue_frac", "wait_frac",
-                                         "issue_stall_frac", "wait_lds_frac", "vgprs", "lds_bytes") if k in v}
-                out["kernel"] = name
-                out["source"] = os.path.basename(files[-1])
-                return out
-    except Exception:
-        return None
-    return None
+    name, v, source, stale = hit
+    out = {k: v[k] for k in ("valu_issue_frac", "valu_busy_frac", "waves_per_simd", "lds_bank_conflict_frac",
+                             "lds_issue_frac", "trans_frac", "mfma_busy_frac", "salu_issue_frac", "wait_frac",
+                             "issue_stall_frac", "wait_lds_frac", "vgprs", "lds_bytes") if k in v}
+    out.update(kernel=name, source=source, stale=stale)
+    return out
 
 
-def kernel_table(prof, n_sampled, P, R, N, S, K, rename=None, S_bwd=None):
+def valu_bound_of(stage, measured_ms, workload=None):
+    """The VALU-issue bound of `stage`'s kernel from the committed SQ-counter pass (profiles/*_pmc_valu*.json, collected on the
+    launch configuration the iteration runs): a wave64 VALU instruction occupies its SIMD's issue port for 4 cycles (16 lanes
+    per cycle; v_pk_* and transcendentals longer, so this is a LOWER bound on the time), the device has 1024 SIMDs:
+        bound_ms = SQ_INSTS_VALU x 4 / (1024 x clock);   frac = bound_ms / the launch's HIP-event time in the iteration."""
+    hit = _pmc_file_rows("valu", stage, workload)
+    if hit is None:
+        return None
+    name, v, source, stale = hit
+    if "SQ_INSTS_VALU" not in v.get("counters_mean_per_dispatch", {}) or not v.get("clock_ghz"):
+        return None
+    wi = float(v["counters_mean_per_dispatch"]["SQ_INSTS_VALU"])
+    clock = float(v["clock_ghz"])
+    bound_ms = wi * 4.0 / (1024.0 * clock * 1e9) * 1e3
+    return dict(wave_instr=round(wi), cycles_per_instr=4, simds=1024, clock_ghz=clock, bound_ms=round(bound_ms, 4),
+                frac=None if not measured_ms else round(bound_ms / measured_ms, 4), valu_busy_frac=v.get("valu_busy_frac"),
+                duration_ms_under_pmc=None if v.get("duration_us_under_pmc") is None else round(v["duration_us_under_pmc"] / 1e3, 4),
+                kernel=name, source=source, stale=stale)
+
+
+def kernel_table(prof, n_sampled, P, R, N, S, K, rename=None, S_bwd=None, workload=None, alone=None):
     """{stage: avg_ms, launches, ms per iteration/frame, algorithmic MB, achieved GB/s, fraction of the 8 TB/s HBM peak,
-    VALU-issue fraction (committed PMC evidence)} from the in-library HIP-event timing."""
+    VALU-issue fraction (committed PMC evidence)} from the in-library HIP-event timing.
+    `alone` = (prof, n_sampled) of a few more iterations / frames run with every launch on ONE stream: `alone_ms_per_iteration`
+    is then the stage's time with nothing beside it -- an event bracket on a side stream also counts the time its kernel spent
+    sharing the CUs with another stream's kernel (round 4: the 0.03 ms emit kernel read 0.415 ms beside the relight shading
+    kernel and was named the dominant kernel of the frame)."""
     kernels = {}
+    alone_prof, alone_n = alone if alone is not None else ({}, 1)
     for name, (ms, cnt) in prof.items():
         if cnt == 0:
             continue
@@ -327,57 +359,48 @@ def kernel_table(prof, n_sampled, P, R, N, S, K, rename=None, S_bwd=None):
         if name == "sort_pairs":
             # what the reference's formulation (one global radix sort of 44-bit keys, K6) would move for the same instances
             row["reference_formulation_MB"] = round(152.0 * R / 1e6, 1)
-        v = pmc_valu(name)
+        v = pmc_valu(name, workload)
         if v is not None:
             row["valu"] = v
         kernels[name] = row
+    for name, (ms, cnt) in alone_prof.items():
+        name = (rename or {}).get(name, name)
+        if cnt and name in kernels:
+            kernels[name]["alone_ms_per_iteration"] = round(ms / cnt * max(1, round(cnt / max(1, alone_n))), 4)
     return kernels
 
 
-def valu_bound_of(stage, measured_ms):
-    """The VALU-issue bound of `stage`'s kernel from the committed SQ-counter pass (profiles/*_pmc_valu.json, collected on the
-    launch configuration the iteration runs): a wave64 VALU instruction occupies its SIMD's issue port for 4 cycles (16 lanes
-    per cycle; v_pk_* and transcendentals longer, so this is a LOWER bound on the time), the device has 1024 SIMDs:
-        bound_ms = SQ_INSTS_VALU x 4 / (1024 x clock);   frac = bound_ms / the launch's HIP-event time in the iteration."""
-    import glob
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    files = sorted(glob.glob(os.path.join(root, "profiles", "*_pmc_valu.json")))
-    if not files:
-        return None
-    try:
-        doc = json.load(open(files[-1]))
-        for name in _kernel_names(stage):
-            v = doc["kernels"].get(name)
-            if v is None or "SQ_INSTS_VALU" not in v.get("counters_mean_per_dispatch", {}) or not v.get("clock_ghz"):
-                continue
-            wi = float(v["counters_mean_per_dispatch"]["SQ_INSTS_VALU"])
-            clock = float(v["clock_ghz"])
-            bound_ms = wi * 4.0 / (1024.0 * clock * 1e9) * 1e3
-            return dict(wave_instr=round(wi), cycles_per_instr=4, simds=1024, clock_ghz=clock, bound_ms=round(bound_ms, 4),
-                        frac=None if not measured_ms else round(bound_ms / measured_ms, 4), valu_busy_frac=v.get("valu_busy_frac"),
-                        duration_ms_under_pmc=None if v.get("duration_us_under_pmc") is None else round(v["duration_us_under_pmc"] / 1e3, 4),
-                        kernel=name, source=os.path.basename(files[-1]))
-    except Exception:
-        return None
-    return None
-
-
-def roofline_of(kernels, note):
+def roofline_of(kernels, note, workload=None):
     """The dominant kernel of the timed region.  `achieved` / `peak` / `frac` are the HBM figures the contract asks for
-    (algorithmic bytes of THIS launch configuration / HIP-event time / 8 TB/s); `bound` names what the counters say limits the
-    kernel: "valu" when its VALU-issue bound (`valu_bound`) explains more of the launch's time than its HBM fraction does."""
-    dom = max(kernels, key=lambda k: kernels[k].get("ms_per_iteration", 0.0))
-    ach = kernels[dom]["achieved_GBs"]
-    tr = pmc_traffic(dom)
-    vb = valu_bound_of(dom, kernels[dom]["ms_per_iteration"])
+    (algorithmic bytes of THIS launch configuration / HIP-event time in the timed region / 8 TB/s); `bound` names what the
+    counters say limits the kernel: "valu" when its VALU-issue bound (`valu_bound`) explains more of the launch's time than its
+    HBM fraction does -- "unknown" when the committed counters describe an OLDER source of the kernel than the one just timed
+    (`stale`).  WHICH kernel is dominant is decided on durations that stream concurrency does not inflate: the smaller of the
+    time inside the iteration and the time on one stream (`alone_ms_per_iteration`, see kernel_table) when the latter exists."""
+    def own_time(k):
+        row = kernels[k]
+        t = row.get("ms_per_iteration", 0.0)
+        return min(t, row["alone_ms_per_iteration"]) if row.get("alone_ms_per_iteration") else t
+    dom = max(kernels, key=own_time)
+    row = kernels[dom]
+    ach = row["achieved_GBs"]
+    tr = pmc_traffic(dom, workload)
+    vb = valu_bound_of(dom, row["ms_per_iteration"], workload)
     frac = None if ach is None else round(ach / HBM_PEAK_GBS, 4)
+    stale = bool((tr or {}).get("stale") or (vb or {}).get("stale"))
     bound = "hbm"
     if vb is not None and vb.get("frac") is not None and (frac is None or vb["frac"] > frac):
         bound = "valu"
+    if stale:
+        bound = "unknown"
     return dict(bound=bound, kernel=dom, achieved=ach, peak=HBM_PEAK_GBS, unit="GB/s", frac=frac,
                 traffic=None if tr is None else tr["bytes_corrected"], traffic_detail=tr, valu_bound=vb,
-                valu=kernels[dom].get("valu"), avg_kernel_ms=kernels[dom]["ms_per_iteration"],
-                algorithmic_MB=kernels[dom].get("algorithmic_MB"), note=note)
+                valu=row.get("valu"), avg_kernel_ms=row["ms_per_iteration"], alone_kernel_ms=row.get("alone_ms_per_iteration"),
+                algorithmic_MB=row.get("algorithmic_MB"), stale=stale,
+                counters_source=", ".join(sorted({x["source"] for x in (tr, vb) if x})) or None,
+                selected_by="largest own time (min of in-iteration and one-stream HIP-event time)" if any(
+                    "alone_ms_per_iteration" in v for v in kernels.values()) else "largest HIP-event time in the timed region",
+                note=note)
 
 
 @torch.no_grad()
@@ -452,6 +475,24 @@ def relight_bench(params, cams, dev, frames, K):
     dt = (time.perf_counter() - t) / frames
     prof = _lib.profile_read()
     L.r3dg_profile_enable(0)
+    # the same frames with every launch on ONE stream (kernel_table `alone`): what each kernel takes with nothing beside it
+    alone = None
+    try:
+        keep = renderer._order_stream
+        renderer._order_stream = None
+        renderer.frame(cams[0], bg)
+        torch.cuda.synchronize()
+        L.r3dg_profile_enable(1)
+        n_alone = 6
+        for i in range(n_alone):
+            renderer.frame(cams[(3 + i) % len(cams)], bg)
+        torch.cuda.synchronize()
+        alone = (_lib.profile_read(), n_alone)
+    except Exception:
+        alone = None
+    finally:
+        renderer._order_stream = keep
+        L.r3dg_profile_enable(0)
     dt_ref = timed(lambda cam: relight.frame_reference(renderer, cam, bg), max(3, frames // 4))
     # the same frames with only the sampled radiance cached (the full integral per frame: what a light that changes now and
     # then, or parameters that are still being trained, would pay) -- same process, same visibility caches
@@ -489,11 +530,12 @@ def relight_bench(params, cams, dev, frames, K):
     H, W = cams[0].image_height, cams[0].image_width
     R_mean = float(sum(R_seen)) / max(1, len(R_seen))
     kernels = kernel_table(prof, max(1, sum(1 for i in range(frames) if i % 4 == 0)), P, R_mean, H * W, 28, K,
-                           rename={"shade_forward": "shade_forward_transport"} if cache == "transport" else None)
+                           rename={"shade_forward": "shade_forward_transport"} if cache == "transport" else None,
+                           workload="relight", alone=alone)
     roof = roofline_of(kernels, "relight frame (%s at K=%d + rasterize forward S=28 + composite): achieved = "
                        "algorithmic bytes per launch / HIP-event kernel time" % (
                            "GGX lobe against the cached transport, 12 B per sample," if cache == "transport"
-                           else "shading forward", K))
+                           else "shading forward", K), workload="relight")
     return dict(relight_fps=round(1.0 / dt, 2), relight_ms_per_frame=round(1e3 * dt, 3), relight_K=K, relight_cache=cache,
                 relight_fps_radiance_cache=radiance_fps,
                 relight_features=28, relight_fps_pytorch_glue=round(1.0 / dt_ref, 2), visibility_rays=P * K,
@@ -767,7 +809,7 @@ def _roofline_compact(r):
         out["traffic"] = round(out["traffic"])
     vb = r.get("valu_bound") or {}
     out["valu_bound"] = {k: vb.get(k) for k in ("frac", "bound_ms", "wave_instr")} if vb else None
-    for k in ("stale", "counters_source", "selected_by"):
+    for k in ("stale", "counters_source", "alone_kernel_ms"):
         if r.get(k) is not None:
             out[k] = r[k]
     return out
@@ -1071,6 +1113,27 @@ def run(args):
                   note="iters/s of the timed block (`value`, event timing on every %dth step) and of %d more blocks "
                        "(event timing off)" % (EVENT_EVERY, len(blocks) - 1))
 
+    # a few more iterations with every launch on ONE stream (FusedStage2Step.serial_streams): each stage's time with nothing
+    # beside it, for the choice of the dominant kernel (kernel_table `alone`, roofline_of)
+    alone = None
+    if fused and stage2 and world == 1 and not dp and hasattr(step_fn, "serial_streams") and not os.environ.get("R3DG_BENCH_NOPROFILE"):
+        try:
+            step_fn.serial_streams = True
+            one_step(args.warmup)
+            torch.cuda.synchronize()
+            L.r3dg_profile_pause(0)
+            L.r3dg_profile_enable(1)
+            n_alone = 4
+            for i in range(n_alone):
+                one_step(args.warmup + 1 + i)
+            torch.cuda.synchronize()
+            alone = (_lib.profile_read(), n_alone)
+        except Exception:
+            alone = None
+        finally:
+            step_fn.serial_streams = False
+            L.r3dg_profile_enable(0)
+
     relight = None
     if stage2 and args.relight_frames > 0 and world == 1:       # relight: replicas only -- measured at N=1
         step_fn.visibility = step_fn.incident_dirs = step_fn.incident_areas = None   # free the K=train caches
@@ -1089,7 +1152,7 @@ def run(args):
         general = fused and stage2 and getattr(step_fn, "_frs", None) is None
         kernels = kernel_table(prof, n_sampled, P, R_mean, N, S, args.sample_num, S_bwd=S_bwd,
                                rename={"shade_forward": "shade_forward_general", "shade_backward": "shade_backward_general"}
-                               if general else None)
+                               if general else None, alone=alone)
         if not kernels:                   # experiments with the in-library event timing switched off
             kernels = {"none": dict(avg_ms=0.0, launches=0, ms_per_iteration=0.0, algorithmic_MB=None, achieved_GBs=None)}
         roofline = roofline_of(kernels, "achieved = algorithmic bytes of the TIMED launch (SURVEY.md 8(d) per-unit figures with "

@@ -384,6 +384,9 @@ class FusedStage2Step(_BoundedForward):
                 warnings.warn("FusedStage2Step under data parallelism: GPU_MAX_HW_QUEUES=%s (< 8) -- RCCL's streams and this "
                               "iteration's three streams will share hardware queues and serialise; export GPU_MAX_HW_QUEUES=8 "
                               "before the process starts (bench.py does)" % os.environ.get("GPU_MAX_HW_QUEUES", "unset (4)"))
+        # bench.py's one-stream pass: every launch of the iteration on the caller's stream (no ordering / early-Adam / geometry
+        # side streams), so that each stage's HIP-event bracket times its kernel with nothing beside it
+        self.serial_streams = False
         self.measure_comm = False                   # bench.py: time the main stream spends waiting for all-reduce buckets
         self._comm_events = []
         with torch.no_grad(), self._ctx:
@@ -477,7 +480,7 @@ class FusedStage2Step(_BoundedForward):
     def _aux_stream(self):
         """The early-Adam stream, for the side work of the fixed-ray-set path on one GPU; None without that path and under data
         parallelism (the stream then carries the buckets' waits and the coefficients are updated late, in flush())."""
-        if self._frs is None or self.dp:
+        if self._frs is None or self.dp or self.serial_streams:
             return None
         if self._adam_stream is None:
             self._adam_stream = shared_stream(self.dev, "early")
@@ -487,7 +490,7 @@ class FusedStage2Step(_BoundedForward):
         """The early-Adam stream when the fixed-ray-set path has Gaussians off the rotated path: their general kernels run there in
         the forward, and the rasterizer's geometry backward beside them in the backward (data-parallel runs too: the stream is
         idle during the forward, and in the backward bucket A's all-reduce is issued from it, behind the geometry backward)."""
-        if self._frs is None or self._frs.n_invalid == 0:
+        if self._frs is None or self._frs.n_invalid == 0 or self.serial_streams:
             return None
         if self._adam_stream is None:
             self._adam_stream = shared_stream(self.dev, "early")
@@ -510,6 +513,7 @@ class FusedStage2Step(_BoundedForward):
         vm = cam.world_view_transform.contiguous()
         campos = cam.camera_center.contiguous()
         empty = torch.Tensor([])
+        order_stream = None if self.serial_streams else self._order_stream
         with torch.cuda.device(dev):
             # the rotation of the incident-light coefficients into the ray frames depends on nothing of this view: it goes to the
             # side stream now and runs beside the activations and the projection instead of in front of the shading forward
@@ -540,7 +544,7 @@ class FusedStage2Step(_BoundedForward):
                     bg, self.xyz, self.features, empty, self.a_opacity, self.a_scales, self.a_rot, 1.0, empty, vm,
                     cam.full_proj_transform, cam.tanfovx, cam.tanfovy, cam.cx, cam.cy, H, W, self.shs, 3, campos, False,
                     True, False, capacity=self._capacity, overflow_flag=self._flag,
-                    overflow_count=self._overflow_count, ordering_stream=self._order_stream, want_weights=False)
+                    overflow_count=self._overflow_count, ordering_stream=order_stream, want_weights=False)
             else:
                 # first half of the rasterizer (projection + async read-back of num_rendered): the shading kernels below
                 # run while the host waits for the count and enqueues the second half
@@ -564,7 +568,7 @@ class FusedStage2Step(_BoundedForward):
                                   # (one workgroup per CU beside the instance ordering, which is the longer path -- unless the
                                   # deferred incident-light update of a data-parallel run sits in front of this kernel: then this
                                   # path is the longer one and takes every CU it can get: 558 -> 568 it/s on one rank)
-                                  leave_room=self._order_stream is not None and not self.dp,
+                                  leave_room=order_stream is not None and not self.dp,
                                   # the few hundred Gaussians off the rotated path: their general kernel on the (idle) early-Adam
                                   # stream beside the rotation and the main kernel, joined below before the features are packed
                                   listed_stream=self._listed_stream(), rotated=rotated,
@@ -575,7 +579,7 @@ class FusedStage2Step(_BoundedForward):
                     self.a_viewdirs.data_ptr(), self.incidents.data_ptr(), env_c.data_ptr(), He, We, None,
                     self.visibility.data_ptr(), self.incident_dirs.data_ptr(),
                     None if self._uniform_area is not None else self.incident_areas.data_ptr(), self._uniform_area or 0.0,
-                    taps.data_ptr(), 1 | (4 if self._order_stream is not None else 0),     # train outputs | leave room
+                    taps.data_ptr(), 1 | (4 if order_stream is not None else 0),     # train outputs | leave room
                     self.shade_out.data_ptr()), "shade_forward")
             if self._frs is not None and self._listed_stream() is not None:
                 _lib.stream_wait(main, self._listed_stream())
@@ -585,7 +589,7 @@ class FusedStage2Step(_BoundedForward):
                     stream(), P, self.xyz.data_ptr(), vm.data_ptr(), self.a_normal.data_ptr(), self.a_base.data_ptr(),
                     self.a_rough.data_ptr(), self.shade_out.data_ptr(), self.features.data_ptr(),
                     self.sums[3].data_ptr()), "stage2_pack_features")
-            fw = pending.finish(self._order_stream)
+            fw = pending.finish(order_stream)
             R, n_contrib, image, opacity, depth, feature, pseudo_normal, sxyz, weights, radii, geom, binning, img = fw
             # the Adam launches of this iteration skip themselves when the view was dropped; under data parallelism they
             # read a snapshot of the flag taken after bucket A's all-reduce (optimizer_step)
@@ -649,7 +653,7 @@ class FusedStage2Step(_BoundedForward):
                     P, 16, H, W, g[4:20], geom, R, binning, img, active_features=sorted(active))
                 dL_dmeans2D = None
             else:
-                geo_stream = self._side
+                geo_stream = None if self.serial_streams else self._side
                 if geo_stream is None and early_adam and self._listed_stream() is not None:
                     # whole iterations on one GPU with Gaussians off the rotated path: the per-Gaussian geometry backward goes
                     # to the early-Adam stream and runs beside the gradient unpack and the general shading backward on those few
@@ -879,7 +883,7 @@ class FusedStage2Step(_BoundedForward):
         # the SH group's Adam under the shading backward: pays while the group's 64 bytes x 48 per Gaussian mostly live in the
         # 256 MB last-level cache (300k Gaussians: 58 us of Adam for 31 us of slower shading backward); streamed from HBM it
         # costs the latency-sensitive shading kernel nearly its whole duration (2M: 0.99 ms of Adam for +0.85 ms, 159 vs 163 it/s)
-        early = os.environ.get("R3DG_EARLY_ADAM", "1" if self.P <= 1_000_000 else "0") != "0"
+        early = os.environ.get("R3DG_EARLY_ADAM", "1" if self.P <= 1_000_000 else "0") != "0" and not self.serial_streams
         outs = self.forward_backward(cam, bg, gt, early_adam=early, image_mask=image_mask)
         self.optimizer_step()
         return outs

@@ -38,7 +38,12 @@ def main():
         w = d["WRITE_SIZE"][0] / max(d["WRITE_SIZE"][1], 1)
         kernels[k] = {"FETCH_SIZE_KB": round(f, 2), "WRITE_SIZE_KB": round(w, 2),
                       "hbm_bytes_raw": (f + w) * 1024, "hbm_bytes_corrected": (2 * f + w) * 1024}
-    json.dump({"note": note, "kernels": kernels}, open(out, "w"), indent=1)
+    # which SOURCE these counters describe: sha256 of each kernel's defining file (+ its local headers) at collection time;
+    # bench.py compares it with the tree it runs from and marks the figures stale when they differ
+    import os
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from relightable3dgaussian_amd import kernel_sources
+    json.dump({"note": note, "sources": kernel_sources.stamp(sorted(kernels)), "kernels": kernels}, open(out, "w"), indent=1)
     print("wrote", out, len(kernels), "kernels")
 
 

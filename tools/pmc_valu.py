@@ -111,7 +111,12 @@ def main():
                 if len(cands) > 1:
                     row["resources_note"] = "%d template instances; sets of values over all of them" % len(cands)
         kernels[k] = row
-    json.dump({"note": note, "kernels": kernels}, open(out, "w"), indent=1)
+    # which SOURCE these counters describe: sha256 of each kernel's defining file (+ its local headers) at collection time;
+    # bench.py compares it with the tree it runs from and marks the figures stale when they differ
+    import os
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from relightable3dgaussian_amd import kernel_sources
+    json.dump({"note": note, "sources": kernel_sources.stamp(sorted(kernels)), "kernels": kernels}, open(out, "w"), indent=1)
     print("wrote", out, len(kernels), "kernels")
 
 
