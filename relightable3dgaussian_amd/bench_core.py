@@ -387,7 +387,9 @@ def roofline_of(kernels, note, workload=None):
     tr = pmc_traffic(dom, workload)
     vb = valu_bound_of(dom, row["ms_per_iteration"], workload)
     frac = None if ach is None else round(ach / HBM_PEAK_GBS, 4)
-    stale = bool((tr or {}).get("stale") or (vb or {}).get("stale"))
+    flags = [x.get("stale") for x in (tr, vb) if x]
+    # True: a counter file describes an older source of this kernel; None: no file says which source it describes; False: current
+    stale = True if any(f is True for f in flags) else (None if (not flags or any(f is None for f in flags)) else False)
     bound = "hbm"
     if vb is not None and vb.get("frac") is not None and (frac is None or vb["frac"] > frac):
         bound = "valu"

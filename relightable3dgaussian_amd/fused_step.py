@@ -273,12 +273,12 @@ class FusedStage2Step(_BoundedForward):
         self.scaling, self.rotation, self.opacity = d(params.scaling), d(params.rotation), d(params.opacity)
         self.shs = torch.cat([params.features_dc.detach(), params.features_rest.detach()], 1).contiguous()
         self.base_color, self.roughness = d(params.base_color), d(params.roughness)
-        self.incidents = torch.cat([params.incidents_dc.detach(), params.incidents_rest.detach()], 1).contiguous()
+        self._incidents = torch.cat([params.incidents_dc.detach(), params.incidents_rest.detach()], 1).contiguous()
         self.env = d(params.env)
         self.P = P = self.xyz.shape[0]
         self.K = sample_num
         self.M = self.shs.shape[1]
-        if self.incidents.shape[1] != self.M:      # the reference gives both the same degree (gaussian_model.py:421, :450)
+        if self._incidents.shape[1] != self.M:      # the reference gives both the same degree (gaussian_model.py:421, :450)
             raise RuntimeError("FusedStage2Step: colour and incident-light SH must hold the same number of coefficients")
         # script/run_nerf.sh:20-39 (stage 2): lambda_pbr 1, lambda_light 0.01, lambda_env_smooth 0.01; the command does not
         # pass --lambda_normal_render_depth, so that term is off (arguments/__init__.py:115) -- opt in with
@@ -349,6 +349,9 @@ class FusedStage2Step(_BoundedForward):
             self._bucket_c = self.grad_flat[start["xyz"]:start["incidents"]]
             self._bucket_b = self.grad_flat[start["incidents"]:]
         self._pending_b = None
+        self._early_pending = False                 # the early-Adam stream holds work no other stream has been ordered behind yet
+        self._b_early = False
+        self._flag_b = torch.zeros(4, dtype=torch.float32, device=dev)
         self._zero_depth_grad = None
         # instance ordering of the rasterizer runs here, under the shading forward (register-light, latency-bound kernels
         # next to a VALU-bound one)
@@ -397,13 +400,17 @@ class FusedStage2Step(_BoundedForward):
             self._ray_normals = self.a_normal.clone()
         self._taps, self._taps_key = None, None
         self._frs = None                            # shading_ops.FixedRaySet of the current direction cache, or None
+        # incident-light chain of a whole single-GPU iteration: (ray set, coefficient tensor, its version) the rotated coefficients
+        # in the ray set were computed FROM, when that was done ahead of the next iteration; work still running on the early stream
+        self._pre_rotated = None
+        self._defer_b = os.environ.get("R3DG_EARLY_INCIDENTS", "1") != "0"
         self.opt = FusedAdam([
             dict(param=self.xyz, lr=rate("xyz")), dict(param=self.normal, lr=rate("normal")),
             dict(param=self.scaling, lr=rate("scaling")), dict(param=self.rotation, lr=rate("rotation")),
             dict(param=self.opacity, lr=rate("opacity")),
             dict(param=self.shs, lr=rate("shs"), lr_tail=tail("shs"), period=3 * self.M, split=3),
             dict(param=self.base_color, lr=rate("base_color")), dict(param=self.roughness, lr=rate("roughness")),
-            dict(param=self.incidents, lr=rate("incidents"), lr_tail=tail("incidents"), period=3 * self.M, split=3),
+            dict(param=self._incidents, lr=rate("incidents"), lr_tail=tail("incidents"), period=3 * self.M, split=3),
             dict(param=self.env, lr=rate("env"))])
         self._opt_order = ("xyz", "normal", "scaling", "rotation", "opacity", "shs", "base_color", "roughness",
                            "incidents", "env")
@@ -417,6 +424,22 @@ class FusedStage2Step(_BoundedForward):
     features_rest = property(lambda self: self.shs[:, 1:])
     incidents_dc = property(lambda self: self.incidents[:, :1])
     incidents_rest = property(lambda self: self.incidents[:, 1:])
+
+    # The incident-light coefficients as everybody OUTSIDE the iteration sees them.  A whole single-GPU iteration (__call__) leaves
+    # their Adam update -- and the rotation of the new coefficients for the next iteration -- running on the early-Adam stream
+    # (see forward_backward: "incident-light chain"); a reader on any other stream must be ordered behind it first.
+    @property
+    def incidents(self):
+        if getattr(self, "_early_pending", False):
+            self.flush()
+        return self._incidents
+
+    @incidents.setter
+    def incidents(self, value):
+        if getattr(self, "_early_pending", False):
+            self.flush()
+        self._incidents = value
+        self._pre_rotated = None
 
     # GaussianModel-style accessors (plain PyTorch; used by eval / relight code, not by the fused iteration)
     def get_scaling(self):
@@ -477,6 +500,14 @@ class FusedStage2Step(_BoundedForward):
                 self._frs.taps(He, We)
         return self._taps
 
+    def _rotation_is_current(self):
+        """The ray set already holds the rotation of the CURRENT coefficients (queued on the early-Adam stream right behind their
+        Adam update, at the end of the previous iteration)?  Keyed on the tensor and its version counter: anything that replaces or
+        edits the coefficients in between (a checkpoint load, a test) invalidates it -- the Adam kernel itself writes through the raw
+        pointer and does not count."""
+        pr = self._pre_rotated
+        return pr is not None and pr[0] is self._frs and pr[1] is self._incidents and pr[2] == self._incidents._version
+
     def _aux_stream(self):
         """The early-Adam stream, for the side work of the fixed-ray-set path on one GPU; None without that path and under data
         parallelism (the stream then carries the buckets' waits and the coefficients are updated late, in flush())."""
@@ -522,7 +553,8 @@ class FusedStage2Step(_BoundedForward):
             if aux is not None:
                 _lib.stream_wait(aux, main)
                 with torch.cuda.stream(aux):
-                    self._frs.rotate(self.incidents)
+                    if not self._rotation_is_current():
+                        self._frs.rotate(self._incidents)
                     # (also on the side stream, BEHIND the rotation.  Measured: with these two tiny launches on the main stream the
                     # shading forward starts ~20 us earlier, inside the projection, and the step loses 15-20 it/s; gating the
                     # shading forward on the projection's end with an event loses 12.  The persistent forward and the front
@@ -537,6 +569,11 @@ class FusedStage2Step(_BoundedForward):
             self.refresh_activations(cam)
             self._iter += 1
             use_bounded = self._use_bounded(W, H)
+            if self._early_pending and (aux is None or not (use_bounded and order_stream is not None)):
+                # (the previous iteration left work on the early stream that only the bounded, three-stream schedule is ordered
+                # behind by construction: any other schedule joins it here)
+                _lib.stream_wait(main, self._early_stream)
+                self._early_pending = False
             if use_bounded:
                 # bounded forward: projection + instance ordering go to the ordering stream NOW and run beside the
                 # shading kernels queued below; nobody waits for the count
@@ -553,17 +590,19 @@ class FusedStage2Step(_BoundedForward):
                     bg, self.xyz, self.features, empty, self.a_opacity, self.a_scales, self.a_rot, 1.0, empty, vm,
                     cam.full_proj_transform, cam.tanfovx, cam.tanfovy, cam.cx, cam.cy, H, W, self.shs, 3, campos, False,
                     True, False, want_weights=False)       # (stage 2 does not densify: nobody reads the blend weights)
-            self.flush()        # (world > 1) the previous iteration's incident-light update lands here
+            if self._pending_b is not None:
+                self.flush()    # (world > 1) the previous iteration's incident-light update lands here
             if aux is None:
                 self.sums.zero_()
                 env_c = F.softplus(self.env)[0]                                  # DirectLightMap.get_env
             else:
                 _lib.stream_wait(main, aux)
+                self._early_pending = False          # (aux IS the early stream: the main stream is behind all of it now)
             He, We = env_c.shape[0], env_c.shape[1]
             taps = self.taps(He, We)
             if self._frs is not None:
                 rotated = rotated_for is self._frs            # (taps() may have rebuilt the ray set: then it rotates itself)
-                self._frs.forward(self.a_base, self.a_rough, self.a_normal, self.a_viewdirs, self.incidents, env_c,
+                self._frs.forward(self.a_base, self.a_rough, self.a_normal, self.a_viewdirs, self._incidents, env_c,
                                   self.visibility, self.shade_out, uniform_area=self._uniform_area,
                                   # (one workgroup per CU beside the instance ordering, which is the longer path -- unless the
                                   # deferred incident-light update of a data-parallel run sits in front of this kernel: then this
@@ -576,7 +615,7 @@ class FusedStage2Step(_BoundedForward):
             else:
                 _lib.check(L.r3dg_shade_forward_cached(
                     stream(), P, self.K, self.M, self.a_base.data_ptr(), self.a_rough.data_ptr(), self.a_normal.data_ptr(),
-                    self.a_viewdirs.data_ptr(), self.incidents.data_ptr(), env_c.data_ptr(), He, We, None,
+                    self.a_viewdirs.data_ptr(), self._incidents.data_ptr(), env_c.data_ptr(), He, We, None,
                     self.visibility.data_ptr(), self.incident_dirs.data_ptr(),
                     None if self._uniform_area is not None else self.incident_areas.data_ptr(), self._uniform_area or 0.0,
                     taps.data_ptr(), 1 | (4 if order_stream is not None else 0),     # train outputs | leave room
@@ -693,6 +732,25 @@ class FusedStage2Step(_BoundedForward):
                                          skip_flag=self._skip_cur)
                 self._early_stream = side
                 self._early = True
+                self._early_pending = True
+                self._b_early = False
+                if self._defer_b and self._frs is not None and order_stream is not None and use_bounded:
+                    # INCIDENT-LIGHT CHAIN (round 5).  The incident-light group's gradient is finished by the rotation back, which
+                    # already runs on this stream behind the main shading backward; its Adam update and the rotation of the NEW
+                    # coefficients into the ray frames (the first thing the next iteration's shading forward needs, and
+                    # independent of the next view) follow it right here -- beside the activation chain rule, the other groups'
+                    # Adam and the next iteration's activations + projection on the main / ordering streams -- instead of
+                    # Adam(all groups) -> activations -> rotation -> shading forward in a row (round 4: ~100 us in which only small
+                    # launches ran).  The main stream is NOT joined with this stream at the end of the iteration:
+                    #   * the ordering stream, which reads the SH colour coefficients in the next projection, is ordered behind the
+                    #     SH group's Adam HERE (an event recorded now: it does not wait for what is queued on this stream later);
+                    #   * the main stream joins this stream in front of the next shading forward, as it always did;
+                    #   * anybody else goes through `incidents` / flush().
+                    # The overflow flag the group's Adam reads is copied now: the slab's slot is rewritten by the next forward.
+                    with torch.cuda.stream(side):
+                        self._flag_b.copy_(self._flag)
+                    _lib.stream_wait(order_stream, side)
+                    self._b_early = True
             elif early_adam and handle_a is not None and self._groups_a:
                 # data parallel: the same update on the side stream, behind bucket A's all-reduce -- whenever that lands
                 # while the shading backward is still running, the SH group's Adam runs under it too (measured with a
@@ -720,7 +778,7 @@ class FusedStage2Step(_BoundedForward):
                 self._d_env = torch.zeros_like(env_c)
             if self._frs is not None:
                 d_base, d_rough, d_view, _d_inc, d_env = self._frs.backward(
-                    self.a_base, self.a_rough, self.a_normal, self.a_viewdirs, self.incidents, env_c, self.visibility,
+                    self.a_base, self.a_rough, self.a_normal, self.a_viewdirs, self._incidents, env_c, self.visibility,
                     self.d_pbr, self.d_diffuse,
                     uniform_area=self._uniform_area, out_incidents=self.grads["incidents"], out_env=self._d_env,
                     block_absmax=self._absmax,
@@ -728,9 +786,15 @@ class FusedStage2Step(_BoundedForward):
                     # SH group's early Adam (optimizer_step joins it before any Adam launch reads the gradient; under data
                     # parallelism bucket B's all-reduce is issued from it) and runs beside the activation chain rule
                     rotate_stream=self._early_stream if self._early else None)
+                if self._early and self._b_early:
+                    with torch.cuda.stream(self._early_stream):
+                        if self._groups_b:
+                            self.opt.step_groups(self._groups_b, [self.grads[k] for k in self._opt_order], skip_flag=self._flag_b)
+                        self._frs.rotate(self._incidents)
+                    self._pre_rotated = (self._frs, self._incidents, self._incidents._version)
             else:
                 d_base, d_rough, d_view, _d_inc, d_env = shading_ops.shade_backward(
-                    self.a_base, self.a_rough, self.a_normal, self.a_viewdirs, self.incidents, env_c, self.visibility,
+                    self.a_base, self.a_rough, self.a_normal, self.a_viewdirs, self._incidents, env_c, self.visibility,
                     self.incident_dirs, self.incident_areas, self.d_pbr, self.d_diffuse,
                     out_incidents=self.grads["incidents"], taps=taps, out_env=self._d_env, block_absmax=self._absmax)
             gr = self.grads
@@ -838,9 +902,15 @@ class FusedStage2Step(_BoundedForward):
         per-Gaussian groups + env, _groups_b = incidents -- indices into self.opt.groups, one tuple per gradient bucket."""
         grads = [self.grads[k] for k in self._opt_order]
         if not self.dp:
-            if self._early:              # the SH group was updated under the shading backward (forward_backward)
+            if self._early and self._b_early:
+                # the SH group was updated under the shading backward and the incident-light group is being updated on the early
+                # stream (forward_backward, "incident-light chain"): no join here
+                self._early = self._b_early = False
+                todo = self._groups_c
+            elif self._early:            # the SH group was updated under the shading backward (forward_backward)
                 _lib.stream_wait(torch.cuda.current_stream(), self._early_stream)
                 self._early = False
+                self._early_pending = False
                 todo = self._groups_c + self._groups_b
             else:
                 self.opt.begin_step()
@@ -870,7 +940,11 @@ class FusedStage2Step(_BoundedForward):
 
     @_in_context
     def flush(self):
-        """Complete a deferred incident-light update (data-parallel runs only; a no-op otherwise)."""
+        """Complete a deferred incident-light update: data-parallel runs apply it here; a single-GPU iteration that left it running
+        on the early-Adam stream gets the CURRENT stream ordered behind it (no host wait).  A no-op otherwise."""
+        if self._early_pending:
+            _lib.stream_wait(torch.cuda.current_stream(self.dev), self._early_stream)
+            self._early_pending = False
         if self._pending_b is not None:
             handle_b, grads, scale, skip = self._pending_b
             self._pending_b = None

@@ -749,10 +749,11 @@ def test_fused_stage2_iteration_host_logic_with_a_recording_library(monkeypatch)
 def test_fused_stage2_iteration_spreads_the_fixed_ray_set_path_over_three_streams(monkeypatch):
     """The schedule of the single-GPU stage-2 iteration when the fixed-ray-set kernels are on and some Gaussians are off the
     rotated path, with recorders in place of the library, the rasterizer and the ray-set object -- nothing
-    runs on a GPU.  From the second iteration on: the coefficient rotation is queued on the early-Adam stream BEFORE the
-    activations and the forward is told so; the listed Gaussians' forward kernel gets that stream; the rasterizer's geometry
-    backward gets it too; the rotation back as well; every join goes through the library's pooled events; the side streams are
-    the process-wide ones, shared by a second step object."""
+    runs on a GPU.  From the second iteration on: the listed Gaussians' forward kernel gets the early-Adam stream; the rasterizer's
+    geometry backward gets it too, the SH group's Adam behind it, the rotation back as well -- and (round 5) behind that the
+    incident-light group's Adam and the rotation of the NEW coefficients for the next iteration, whose forward is told that the
+    rotation is done; the main stream joins that stream once, in front of the shading forward; every join goes through the
+    library's pooled events; the side streams are the process-wide ones, shared by a second step object."""
     import contextlib
     import types
     from relightable3dgaussian_amd import _lib, fused_step, rasterizer_ops, shading_ops
@@ -853,31 +854,41 @@ def test_fused_stage2_iteration_spreads_the_fixed_ray_set_path_over_three_stream
                                 camera_center=z(3), tanfovx=0.5, tanfovy=0.5, cx=2.0, cy=2.0)
     step = fused_step.FusedStage2Step(params, K)
     order_stream = step._order_stream
-    for _ in range(2):
+    marks = []
+    for _ in range(3):
+        marks.append(len(events))
         step(cam, torch.ones(3), z(3, H, W))
     assert isinstance(step._frs, FakeRaySet)
     early = step._adam_stream
     assert early is not None and early is not order_stream and early is not main
-    # ---- the second iteration ----------------------------------------------------------------------------------------------
-    names = [e[0] for e in events]
-    start = len(names) - 1 - names[::-1].index("frs.rotate") - 2          # (the fork and the stream context in front of it)
-    it, args = names[start:], [e[1] for e in events[start:]]
-    pos = {n: it.index(n) for n in ("frs.rotate", "r3dg_stage2_activate", "raster.begin", "frs.forward",
+    # ---- the third iteration (bounded forward, fixed-ray-set path, incident-light chain of round 5) ---------------------------
+    it, args = [e[0] for e in events[marks[2]:]], [e[1] for e in events[marks[2]:]]
+    pos = {n: it.index(n) for n in ("r3dg_stage2_activate", "raster.begin", "frs.forward",
                                     "raster.finish", "raster.backward", "r3dg_stage2_unpack_gradients", "frs.backward",
-                                    "r3dg_stage2_activate_backward")}
-    assert sorted(pos, key=pos.get) == ["frs.rotate", "r3dg_stage2_activate", "raster.begin", "frs.forward",
-                                        "raster.finish", "raster.backward",
-                                        "r3dg_stage2_unpack_gradients", "frs.backward", "r3dg_stage2_activate_backward"]
+                                    "frs.rotate", "r3dg_stage2_activate_backward")}
+    assert sorted(pos, key=pos.get) == ["r3dg_stage2_activate", "raster.begin", "frs.forward", "raster.finish", "raster.backward",
+                                        "r3dg_stage2_unpack_gradients", "frs.backward", "frs.rotate",
+                                        "r3dg_stage2_activate_backward"]
+    # the coefficient rotation is NOT at the top of the iteration any more: the previous iteration queued it on the early stream
+    # behind the incident-light group's Adam, and the ray set still holds the rotation of the current coefficients
+    assert it.count("frs.rotate") == 1 and step._rotation_is_current()
     # no pack kernel on this path: the activations and the shading kernels write the feature rows between them, and the
     # light-smoothness sum comes from the unpack kernel (its last argument)
     assert "r3dg_stage2_pack_features" not in it and rows[-1] is step.features
     assert args[pos["r3dg_stage2_activate"]][-1] == step.features.data_ptr()
     assert args[pos["r3dg_stage2_unpack_gradients"]][-1] == step.sums[3].data_ptr()
-    # the rotation (and the softplus / sum reset behind it) runs inside the early stream's context, behind a pooled-event fork
-    assert it[pos["frs.rotate"] - 1] == "enter" and args[pos["frs.rotate"] - 1] == (early.cuda_stream,)
-    joins = [a for n, a in zip(it, args) if n == "r3dg_stream_wait_stream"]
-    assert joins[0] == (early.cuda_stream, main.cuda_stream)                 # fork at the top of the iteration
-    assert (main.cuda_stream, early.cuda_stream) in joins[1:]                 # joined in front of the shading forward / the pack
+    joins = [(i, a) for i, (n, a) in enumerate(zip(it, args)) if n == "r3dg_stream_wait_stream"]
+    assert joins[0][1] == (early.cuda_stream, main.cuda_stream)              # fork at the top of the iteration (softplus, sum reset)
+    # the main stream joins the early stream in front of the shading forward (behind it: the previous iteration's incident-light
+    # chain) and behind the listed Gaussians' forward kernel; there is no join at the end of the iteration any more
+    main_joins = [i for i, a in joins if a == (main.cuda_stream, early.cuda_stream)]
+    assert len(main_joins) == 2 and pos["raster.begin"] < main_joins[0] < pos["frs.forward"] < main_joins[1] < pos["raster.finish"]
+    # the ordering stream (next projection reads the SH colour coefficients) is ordered behind the SH group's Adam when that is
+    # queued -- before the rotation back, the incident-light group's Adam and the next rotation go to the early stream
+    order_joins = [i for i, a in joins if a == (order_stream.cuda_stream, early.cuda_stream)]
+    adam = [i for i, n in enumerate(it) if n == "r3dg_adam_step"]
+    assert len(order_joins) == 1 and len(adam) == 3
+    assert adam[0] < order_joins[0] < pos["frs.backward"] < adam[1] < pos["frs.rotate"] < adam[2]
     assert args[pos["raster.begin"]] == (order_stream,) and args[pos["raster.finish"]] == (order_stream,)
     listed, rotated, leave_room = args[pos["frs.forward"]]
     assert listed is early and rotated is True and leave_room is True
@@ -885,9 +896,21 @@ def test_fused_stage2_iteration_spreads_the_fixed_ray_set_path_over_three_stream
     assert args[pos["frs.backward"]] == (early,)                               # rotation back on the same stream
     assert "main.wait_event" in it[pos["frs.backward"]:pos["r3dg_stage2_activate_backward"]]     # geometry joined by its event
     assert "torch.wait_stream" not in it                                       # no per-call event objects on the hot path
-    # one Adam launch inside the early stream's context (the SH group), one on the main stream after the last join
-    adam = [i for i, n in enumerate(it) if n == "r3dg_adam_step"]
-    assert len(adam) == 2 and it[adam[0] - 1] == "enter" and adam[1] > max(i for i, n in enumerate(it) if n == "r3dg_stream_wait_stream")
+    # Adam: the SH group and the incident-light group inside the early stream's context, the other groups on the main stream
+    assert it[adam[0] - 1] == "enter" and args[adam[0] - 1] == (early.cuda_stream,)
+    assert "enter" in it[pos["frs.backward"]:adam[1]] and "exit" not in it[adam[1]:pos["frs.rotate"]]
+    assert adam[2] > pos["r3dg_stage2_activate_backward"] and "enter" not in it[pos["frs.rotate"] + 2:adam[2]]
+    # anybody outside the iteration is ordered behind the chain before it sees the coefficients; an edited tensor is re-rotated
+    assert step._early_pending
+    n_joins = sum(1 for e in events if e[0] == "r3dg_stream_wait_stream")
+    _ = step.incidents
+    assert not step._early_pending and sum(1 for e in events if e[0] == "r3dg_stream_wait_stream") == n_joins + 1
+    step.incidents.add_(1.0)
+    assert not step._rotation_is_current()
+    marks.append(len(events))
+    step(cam, torch.ones(3), z(3, H, W))
+    it4 = [e[0] for e in events[marks[3]:]]
+    assert it4.count("frs.rotate") == 2 and it4.index("frs.rotate") < it4.index("r3dg_stage2_activate")
     # ---- a second step object gets the same side streams -------------------------------------------------------------------
     other = fused_step.FusedStage2Step(params, K)
     other(cam, torch.ones(3), z(3, H, W))

@@ -9,8 +9,8 @@ target image and object mask go through this repo's pipeline on the GPU:
     train_step.stage1_loss), and
   * the fused iterations (fused_step.FusedStage2Step / FusedStage1Step),
 and every rendered map, the loss and the gradient of every parameter must agree.  Tolerances: maps 2e-5 * max (+1e-5), loss
-1e-5 relative, gradients 2e-3 * max with at most 0.4 % outliers (borderline alpha >= 1/255 decisions between exp
-implementations, as in tests/test_fused_step_gpu.py)."""
+1e-5 relative, gradients 2e-3 * max on EVERY entry (round 5: the 0.4 % outlier allowance of earlier rounds was never used --
+gpurun_out/r05_a_pipeline.log: 0 entries above the bound, largest 6.6e-4 of the scale -- and is gone)."""
 import os
 import types
 
@@ -55,7 +55,7 @@ class _Checker:
     def __init__(self):
         self.msgs, self.ok = [], True
 
-    def __call__(self, name, got, want, rtol, atol=0.0, outliers=0.0):
+    def __call__(self, name, got, want, rtol, atol=0.0):
         want = torch.as_tensor(np.asarray(want)).reshape(got.shape)
         ok, msg = report(name, got, want, rtol, atol)
         if not ok and outliers > 0.0:
@@ -100,13 +100,13 @@ def test_stage2_iteration_matches_the_reference_python(monkeypatch):
     assert outs[0] == int(z["num_rendered"])
     chk("render", outs[2], z["map_render"], 2e-5, 1e-5)
     chk("opacity", outs[3], z["map_opacity"], 2e-5, 1e-5)
-    chk("pseudo_normal", outs[6], z["map_pseudo_normal"], 1e-3, 1e-4, outliers=2e-3)
+    chk("pseudo_normal", outs[6], z["map_pseudo_normal"], 1e-3, 1e-4)
     chk("loss", loss.detach().reshape(1), np.array([z["loss"]], np.float32), 1e-5)
     names = {"xyz": p.xyz, "normal": p.normal, "scaling": p.scaling, "rotation": p.rotation, "opacity": p.opacity,
              "shs_dc": p.features_dc, "shs_rest": p.features_rest, "base_color": p.base_color, "roughness": p.roughness,
              "incidents_dc": p.incidents_dc, "incidents_rest": p.incidents_rest, "env": p.env}
     for k, t in names.items():
-        chk("autograd g_" + k, t.grad, z["g_" + k], 2e-3, 1e-9, outliers=4e-3)
+        chk("autograd g_" + k, t.grad, z["g_" + k], 2e-3, 1e-9)
     # ---- fused iteration, on BOTH shading paths; which one ran is asserted, not assumed: the fixture's directions were generated
     # on the CPU and sit ~2e-5 from the device's ray set (FixedRaySet.try_build admits 5e-5) -- a silent fall-back to the
     # general kernels would otherwise pass for a test of the fixed-ray-set kernels
@@ -133,10 +133,9 @@ def test_stage2_iteration_matches_the_reference_python(monkeypatch):
         chk(tag + " loss", fused.loss().reshape(1), np.array([z["loss"]], np.float32), 1e-5)
         g = fused.grads
         for k in ("xyz", "normal", "scaling", "rotation", "opacity", "base_color", "roughness", "env"):
-            chk(tag + " g_" + k, g[k], z["g_" + k], 2e-3, 1e-9, outliers=4e-3)
-        chk(tag + " g_shs", g["shs"], np.concatenate([z["g_shs_dc"], z["g_shs_rest"]], 1), 2e-3, 1e-9, outliers=4e-3)
-        chk(tag + " g_incidents", g["incidents"], np.concatenate([z["g_incidents_dc"], z["g_incidents_rest"]], 1), 2e-3, 1e-9,
-            outliers=4e-3)
+            chk(tag + " g_" + k, g[k], z["g_" + k], 2e-3, 1e-9)
+        chk(tag + " g_shs", g["shs"], np.concatenate([z["g_shs_dc"], z["g_shs_rest"]], 1), 2e-3, 1e-9)
+        chk(tag + " g_incidents", g["incidents"], np.concatenate([z["g_incidents_dc"], z["g_incidents_rest"]], 1), 2e-3, 1e-9)
     chk.done()
 
 
@@ -164,7 +163,7 @@ def test_stage2_syn4_objective_matches_the_reference_python():
              "shs_dc": p.features_dc, "shs_rest": p.features_rest, "base_color": p.base_color, "roughness": p.roughness,
              "incidents_dc": p.incidents_dc, "incidents_rest": p.incidents_rest, "env": p.env}
     for k, t in names.items():
-        chk("autograd g_" + k, t.grad, y["g_" + k], 2e-3, 1e-9, outliers=4e-3)
+        chk("autograd g_" + k, t.grad, y["g_" + k], 2e-3, 1e-9)
     cat = lambda a, b: np.concatenate([y[a], y[b]], 1)
     # fused iteration, everything trains: every gradient
     fused = FusedStage2Step(_params(z, True), K, loss_weights=STAGE2_WEIGHTS_SYN4)
@@ -177,9 +176,9 @@ def test_stage2_syn4_objective_matches_the_reference_python():
     sm = fused.sums.sum(1)[7:10].cpu().numpy() / (3.0 * N)
     chk("fused smoothness terms", torch.from_numpy(sm), tb[6:9].astype(np.float32), 1e-4)
     for k in ("xyz", "normal", "scaling", "rotation", "opacity", "base_color", "roughness", "env"):
-        chk("fused g_" + k, fused.grads[k], y["g_" + k], 2e-3, 1e-9, outliers=4e-3)
-    chk("fused g_shs", fused.grads["shs"], cat("g_shs_dc", "g_shs_rest"), 2e-3, 1e-9, outliers=4e-3)
-    chk("fused g_incidents", fused.grads["incidents"], cat("g_incidents_dc", "g_incidents_rest"), 2e-3, 1e-9, outliers=4e-3)
+        chk("fused g_" + k, fused.grads[k], y["g_" + k], 2e-3, 1e-9)
+    chk("fused g_shs", fused.grads["shs"], cat("g_shs_dc", "g_shs_rest"), 2e-3, 1e-9)
+    chk("fused g_incidents", fused.grads["incidents"], cat("g_incidents_dc", "g_incidents_rest"), 2e-3, 1e-9)
     # frozen geometry (the scripts' learning rates): the groups that train get the reference's gradients, the others none
     lrs = dict(xyz=0.0, normal=0.0, scaling=0.0, rotation=0.0, opacity=0.0, shs=0.0, shs_rest=0.0, base_color=0.01,
                roughness=0.01, incidents=0.001, incidents_rest=0.0001, env=0.1)
@@ -190,8 +189,8 @@ def test_stage2_syn4_objective_matches_the_reference_python():
     torch.cuda.synchronize()
     chk("frozen loss", fr.loss().reshape(1), np.array([y["loss"]], np.float32), 1e-5)
     for k in ("base_color", "roughness", "env"):
-        chk("frozen g_" + k, fr.grads[k], y["g_" + k], 2e-3, 1e-9, outliers=4e-3)
-    chk("frozen g_incidents", fr.grads["incidents"], cat("g_incidents_dc", "g_incidents_rest"), 2e-3, 1e-9, outliers=4e-3)
+        chk("frozen g_" + k, fr.grads[k], y["g_" + k], 2e-3, 1e-9)
+    chk("frozen g_incidents", fr.grads["incidents"], cat("g_incidents_dc", "g_incidents_rest"), 2e-3, 1e-9)
     assert all(float(fr.grads[k].abs().max()) == 0.0 for k in ("xyz", "normal", "scaling", "rotation", "opacity", "shs"))
     chk.done()
 
@@ -219,7 +218,7 @@ def test_stage1_iteration_matches_the_reference_python():
     names = {"xyz": p.xyz, "normal": p.normal, "scaling": p.scaling, "rotation": p.rotation, "opacity": p.opacity,
              "shs_dc": p.features_dc, "shs_rest": p.features_rest}
     for k, t in names.items():
-        chk("autograd g_" + k, t.grad, z["g_" + k], 2e-3, 1e-9, outliers=4e-3)
+        chk("autograd g_" + k, t.grad, z["g_" + k], 2e-3, 1e-9)
     fused = FusedStage1Step(_params(z, False))
     fused.iteration = it
     fo = fused.forward_backward(cam, bg, gt, mask)
@@ -228,7 +227,7 @@ def test_stage1_iteration_matches_the_reference_python():
     chk("fused loss", fused.loss().reshape(1), np.array([z["loss"]], np.float32), 1e-5)
     g = fused.grads
     for k in ("xyz", "normal", "scaling", "rotation", "opacity"):
-        chk("fused g_" + k, g[k], z["g_" + k], 2e-3, 1e-9, outliers=4e-3)
-    chk("fused g_shs", g["shs"], np.concatenate([z["g_shs_dc"], z["g_shs_rest"]], 1), 2e-3, 1e-9, outliers=4e-3)
-    chk("viewspace gradient", fused.viewspace_grad, z["g_viewspace"], 2e-3, 1e-9, outliers=4e-3)
+        chk("fused g_" + k, g[k], z["g_" + k], 2e-3, 1e-9)
+    chk("fused g_shs", g["shs"], np.concatenate([z["g_shs_dc"], z["g_shs_rest"]], 1), 2e-3, 1e-9)
+    chk("viewspace gradient", fused.viewspace_grad, z["g_viewspace"], 2e-3, 1e-9)
     chk.done()

@@ -217,8 +217,14 @@ def test_relight_frames_match_the_reference_python(cache, regenerate_dirs):
     vis, dirs, areas = t("visibility"), t("incident_dirs"), t("incident_areas")
     # the renderer traced its own visibility with the HIP BVH: same classes as the reference's (oracle-traced) caches except at
     # the 0.9 threshold; from here on identical caches
-    near = (vis - 0.9).abs() < 1e-4
-    assert (((r.visibility == 0) != (vis == 0)) & ~near).float().mean().item() <= 1e-4
+    # (a ray's class flips where its transmittance product crosses 0.9; the two direction sets differ by up to 5e-5 -- device vs
+    # CPU sin / cos -- which moves a product by ~1e-3: rays whose product is within 2e-3 of the threshold ON EITHER SIDE are
+    # the expected flips, everything else must agree)
+    mism = (r.visibility == 0) != (vis == 0)
+    near = ((vis - 0.9).abs() < 2e-3) | ((r.visibility - 0.9).abs() < 2e-3)
+    print("visibility classes: %.3e of the rays differ, %.3e away from the 0.9 threshold" % (
+        mism.float().mean().item(), (mism & ~near).float().mean().item()))
+    assert (mism & ~near).float().mean().item() <= 1e-4
     ok, msg = report("incident_dirs", r.incident_dirs, dirs, 0, 5e-5)
     assert ok, msg
     r.visibility, r.incident_dirs, r.incident_areas = vis, dirs, areas
