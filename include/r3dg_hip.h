@@ -133,7 +133,9 @@ int r3dg_rasterize_forward_begin_bounded(void* stream, r3dg_alloc_fn geometry_al
                                          unsigned int* d_overflow_count, void** ticket);
 int r3dg_rasterize_forward_finish_bounded(void* ticket, void* main_stream);
 
-/* Backward.  d_dL_dmean2D [P,3] (z = depth side channel), d_dL_dconic [P,4] (x,y,-,w), d_dL_dopacity, d_dL_dcolor and
+/* Backward.  d_dL_dpix_d == NULL: the depth image carries no gradient (the caller's promise; the tile kernel then takes its
+ * instances without a depth slot).  d_dL_dmean2D [P,3] (z = depth side channel), d_dL_dconic [P,4] (x,y,-,w: SCRATCH -- it holds
+ * the second moments the tile kernel accumulates, not the reference's intermediate), d_dL_dopacity, d_dL_dcolor and
  * d_dL_dfeature are accumulated with atomics and must be zero-filled by the caller; d_dL_dmean3D, d_dL_dcov3D and --
  * when SHs / scales+rotations are the active inputs -- d_dL_dsh, d_dL_dscale, d_dL_drot are fully written (zeros for
  * invisible Gaussians) and may be uninitialised; otherwise they are left untouched (the reference zero-fills all ten,
@@ -720,6 +722,8 @@ enum r3dg_option {
     R3DG_OPT_RESERVE_CUS,               /* CUs the persistent kernels (shading, trace, long-tile sort) leave free for a collective running
                                          * beside them (default 0; the data-parallel iteration sets it) */
     R3DG_OPT_TRACE_COUNT_VISITS,        /* 1 = the phased trace counts node and leaf steps (measurement: r3dg_bvh_trace_visits); default 0 */
+    R3DG_OPT_BWD_LEAN,                  /* 1 (default) = the tile backward takes its lean instances (no depth slot) when the caller passed no
+                                         * depth gradient; 0 = never (A/B and parity tests: same gradients up to rounding order) */
     R3DG_OPT_COUNT
 };
 int r3dg_set_option(int option, int value);       /* the PROCESS default */

@@ -1118,7 +1118,8 @@ def run(args):
     # a few more iterations with every launch on ONE stream (FusedStage2Step.serial_streams): each stage's time with nothing
     # beside it, for the choice of the dominant kernel (kernel_table `alone`, roofline_of)
     alone = None
-    if fused and stage2 and world == 1 and not dp and hasattr(step_fn, "serial_streams") and not os.environ.get("R3DG_BENCH_NOPROFILE"):
+    if fused and stage2 and world == 1 and not dp and hasattr(step_fn, "serial_streams") and not os.environ.get("R3DG_BENCH_NOPROFILE") \
+            and not os.environ.get("R3DG_BENCH_NO_ALONE"):          # (rocprofv3 runs: keep the trace to the pipelined iterations)
         try:
             step_fn.serial_streams = True
             one_step(args.warmup)

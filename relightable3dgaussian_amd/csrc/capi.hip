@@ -53,9 +53,9 @@ void launch_render_backward_features(hipStream_t s, int W, int H, int S, int n_a
 void launch_preprocess_backward(hipStream_t s, int P, int D, int M, const float* means, const int* radii,
                                 const float* shs, const uint8_t* clamped, const float* scales, const float* rotations,
                                 float scale_modifier, const float* cov3Ds, const float* vm, const float* proj, float h_x,
-                                float h_y, float tan_fovx, float tan_fovy, const float* campos, const float* dL_dmean2D,
-                                const float* dL_dconic, float* dL_dmeans, const float* dL_dcolor, float* dL_dcov3D,
-                                float* dL_dsh, float* dL_dscale, float* dL_drot);
+                                float h_y, float tan_fovx, float tan_fovy, const float* campos, float* dL_dmean2D,
+                                const float* dL_dconic, const float* conic_opacity, int W, int H, float* dL_dmeans,
+                                const float* dL_dcolor, float* dL_dcov3D, float* dL_dsh, float* dL_dscale, float* dL_drot);
 void launch_shade_forward(hipStream_t s, int P, int K, int M, const float* base_color, const float* roughness,
                           const float* normals, const float* viewdirs, const float* incidents, const float* env, int He,
                           int We, const float* tr, const float* visibility, const float* dirs, const float* areas,
@@ -110,6 +110,7 @@ void launch_shade_forward_transport(hipStream_t s, int P, int K, const float* ba
                                     const float* normals, const float* viewdirs, const float* transport, const float* consts,
                                     const float* zsamples, const float* dirs, float* out);
 extern int g_trace_packet, g_trace_refill, g_trace_node_weight, g_trace_leaf_weight, g_trace_count_visits;
+extern int g_bwd_lean;
 extern int g_shade_row_blocks_per_cu;
 void launch_shade_backward(hipStream_t s, int P, int K, int M, const float* base_color, const float* roughness,
                            const float* normals, const float* viewdirs, const float* incidents, const float* env,
@@ -423,14 +424,15 @@ static int* option_slot(int option)
         case R3DG_OPT_TRACE_LEAF_WEIGHT: return &g_trace_leaf_weight;
         case R3DG_OPT_RESERVE_CUS: return &g_reserve_cus;
         case R3DG_OPT_TRACE_COUNT_VISITS: return &g_trace_count_visits;
+        case R3DG_OPT_BWD_LEAN: return &g_bwd_lean;
         default: return nullptr;
     }
 }
 
 static bool option_in_range(int option, int value)
 {
-    static const int lo[R3DG_OPT_COUNT] = {0, 0, 0, 1, 0, 0, 0, 1, 1, 1, 0, 0};
-    static const int hi[R3DG_OPT_COUNT] = {1, 1, 2, 64, 1, 8, 4, 64, 15, 15, 128, 1};
+    static const int lo[R3DG_OPT_COUNT] = {0, 0, 0, 1, 0, 0, 0, 1, 1, 1, 0, 0, 0};
+    static const int hi[R3DG_OPT_COUNT] = {1, 1, 2, 64, 1, 8, 4, 64, 15, 15, 128, 1, 1};
     return value >= lo[option] && value <= hi[option];
 }
 
@@ -1088,6 +1090,7 @@ int r3dg_rasterize_backward_split(void* stream_, void* geometry_stream_, int P, 
     if (S < 0 || S > R3DG_MAX_S_BWD) return invalid("rasterize_backward: feature channels S must be in [0,36]");
     if (P == 0) return R3DG_OK;
     if (!geom_buffer || !img_buffer || (R > 0 && !binning_buffer)) return invalid("rasterize_backward: null state buffer");
+    if (!dL_dpix || !dL_dpix_o || (S > 0 && !dL_dpix_f)) return invalid("rasterize_backward: null upstream gradient");
     if (n_active_features >= 0) {
         if (n_active_features > S || !active_features) return invalid("rasterize_backward: bad active feature list");
         for (int i = 0; i < n_active_features; i++)
@@ -1133,8 +1136,8 @@ int r3dg_rasterize_backward_split(void* stream_, void* geometry_stream_, int P, 
         launch_preprocess_backward(stream, P, D, M, means3D, radii_p, colors_precomp == nullptr ? shs : nullptr,
                                    (const uint8_t*)(gbuf + G.clamped), cov3D_precomp == nullptr ? scales : nullptr,
                                    rotations, scale_modifier, cov3D_ptr, viewmatrix, projmatrix, focal_x, focal_y,
-                                   tan_fovx, tan_fovy, campos, dL_dmean2D, dL_dconic, dL_dmean3D, dL_dcolor, dL_dcov3D,
-                                   dL_dsh, dL_dscale, dL_drot);
+                                   tan_fovx, tan_fovy, campos, dL_dmean2D, dL_dconic, (const float*)(gbuf + G.conic_opacity),
+                                   width, height, dL_dmean3D, dL_dcolor, dL_dcov3D, dL_dsh, dL_dscale, dL_drot);
         check_launch(stream, debug, "preprocess_backward");
         t_pb.stop();
         return R3DG_OK;

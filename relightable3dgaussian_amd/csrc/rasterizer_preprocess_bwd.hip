@@ -48,7 +48,8 @@ preprocess_backward_kernel(int P, int D, int M, const float* __restrict__ means,
                            const float* __restrict__ scales, const float* __restrict__ rotations, float scale_modifier,
                            const float* __restrict__ cov3Ds, const float* __restrict__ vm, const float* __restrict__ proj,
                            float h_x, float h_y, float tan_fovx, float tan_fovy, const float* __restrict__ campos,
-                           const float* __restrict__ dL_dmean2D, const float* __restrict__ dL_dconics,
+                           float* __restrict__ dL_dmean2D, const float* __restrict__ dL_dconics,
+                           const float4* __restrict__ conic_opacity, float half_w, float half_h,
                            float* __restrict__ dL_dmeans, const float* __restrict__ dL_dcolor,
                            float* __restrict__ dL_dcov3D, float* __restrict__ dL_dsh, float* __restrict__ dL_dscale,
                            float* __restrict__ dL_drot)
@@ -89,11 +90,21 @@ preprocess_backward_kernel(int P, int D, int M, const float* __restrict__ means,
     }
 
     const float mx = means[3 * idx], my = means[3 * idx + 1], mz = means[3 * idx + 2];
-    const float g2x = dL_dmean2D[3 * idx], g2y = dL_dmean2D[3 * idx + 1], g2z = dL_dmean2D[3 * idx + 2];
+    // moments_to_gradients (round 5).  The tile kernel (render_backward_wave_kernel) leaves the RAW moments of m = G dL_dG in the
+    // mean / conic slots -- S_x, S_y in dL_dmean2D.xy, S_xx, S_xy, S_yy in dL_dconic.{x,y,w} -- because the conic they are to be
+    // multiplied with is a constant of the Gaussian (backward.cu:579-601 multiplies per pixel):
+    //     dL_dmean2D.x = -W/2 (A S_x + B S_y)   dL_dmean2D.y = -H/2 (C S_y + B S_x)   dL_dconic = -1/2 (S_xx, S_xy, S_yy)
+    // with (A, B, C) the conic the forward stored (GeometryState::conic_opacity, the values the tile kernels blended with).  The
+    // final dL_dmean2D goes back to its slot: it is an OUTPUT of the op (the viewspace gradient the densification reads).
+    const float4 co = conic_opacity[idx];
+    const float s_x = dL_dmean2D[3 * idx], s_y = dL_dmean2D[3 * idx + 1], g2z = dL_dmean2D[3 * idx + 2];
+    const float g2x = -half_w * (co.x * s_x + co.y * s_y), g2y = -half_h * (co.z * s_y + co.y * s_x);
+    dL_dmean2D[3 * idx] = g2x;
+    dL_dmean2D[3 * idx + 1] = g2y;
 
     // ---------------- K12: conic -> cov2D -> cov3D / mean (backward.cu:144-276) ----------------
     const float* c3 = cov3Ds + 6 * idx;
-    const float dcx = dL_dconics[4 * idx], dcy = dL_dconics[4 * idx + 1], dcw = dL_dconics[4 * idx + 3];
+    const float dcx = -0.5f * dL_dconics[4 * idx], dcy = -0.5f * dL_dconics[4 * idx + 1], dcw = -0.5f * dL_dconics[4 * idx + 3];
     float tx = vm[0] * mx + vm[4] * my + vm[8] * mz + vm[12];
     float ty = vm[1] * mx + vm[5] * my + vm[9] * mz + vm[13];
     const float tz = vm[2] * mx + vm[6] * my + vm[10] * mz + vm[14];
@@ -300,9 +311,9 @@ static inline int staged_row_stride_host(int row_floats) { return row_floats | 1
 void launch_preprocess_backward(hipStream_t s, int P, int D, int M, const float* means, const int* radii,
                                 const float* shs, const uint8_t* clamped, const float* scales, const float* rotations,
                                 float scale_modifier, const float* cov3Ds, const float* vm, const float* proj, float h_x,
-                                float h_y, float tan_fovx, float tan_fovy, const float* campos, const float* dL_dmean2D,
-                                const float* dL_dconic, float* dL_dmeans, const float* dL_dcolor, float* dL_dcov3D,
-                                float* dL_dsh, float* dL_dscale, float* dL_drot)
+                                float h_y, float tan_fovx, float tan_fovy, const float* campos, float* dL_dmean2D,
+                                const float* dL_dconic, const float* conic_opacity, int W, int H, float* dL_dmeans,
+                                const float* dL_dcolor, float* dL_dcov3D, float* dL_dsh, float* dL_dscale, float* dL_drot)
 {
     if (P <= 0) return;
     // SH rows through LDS when there are SH coefficients of at most degree 3 (256 x 49 words = 49 KB per block)
@@ -310,11 +321,13 @@ void launch_preprocess_backward(hipStream_t s, int P, int D, int M, const float*
     if (staged)
         preprocess_backward_kernel<true><<<(P + 255) / 256, 256, 256 * staged_row_stride_host(3 * M) * sizeof(float), s>>>(
             P, D, M, means, radii, shs, clamped, scales, rotations, scale_modifier, cov3Ds, vm, proj, h_x, h_y, tan_fovx,
-            tan_fovy, campos, dL_dmean2D, dL_dconic, dL_dmeans, dL_dcolor, dL_dcov3D, dL_dsh, dL_dscale, dL_drot);
+            tan_fovy, campos, dL_dmean2D, dL_dconic, (const float4*)conic_opacity, 0.5f * W, 0.5f * H, dL_dmeans, dL_dcolor, dL_dcov3D,
+            dL_dsh, dL_dscale, dL_drot);
     else
         preprocess_backward_kernel<false><<<(P + 255) / 256, 256, 0, s>>>(
             P, D, M, means, radii, shs, clamped, scales, rotations, scale_modifier, cov3Ds, vm, proj, h_x, h_y, tan_fovx,
-            tan_fovy, campos, dL_dmean2D, dL_dconic, dL_dmeans, dL_dcolor, dL_dcov3D, dL_dsh, dL_dscale, dL_drot);
+            tan_fovy, campos, dL_dmean2D, dL_dconic, (const float4*)conic_opacity, 0.5f * W, 0.5f * H, dL_dmeans, dL_dcolor, dL_dcov3D,
+            dL_dsh, dL_dscale, dL_drot);
 }
 
 }  // namespace r3dg

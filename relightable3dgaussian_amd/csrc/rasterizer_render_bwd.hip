@@ -64,15 +64,28 @@ struct ChannelList {
 // software-pipelines the rounds like the forward: no workgroup barrier.
 //   * only the feature channels with a non-zero upstream gradient are carried (ChannelList);
 //   * per-pixel state as float2 pairs so the per-channel recursions compile to packed fp32 ops (v_pk_fma_f32 / v_pk_mul_f32 /
-//     v_pk_add_f32: two channels per instruction); channel vector = payload layout [rgb0, rgb1, rgb2, depth, feature 0 ..];
+//     v_pk_add_f32: two channels per instruction);
 //   * branch-free over the lanes: a lane that does not blend this Gaussian has alpha == 0, which leaves its recursions unchanged
-//     (T *= 1, acc += 0 * d) and zeroes every gradient term once dL_dalpha and G are masked;
-//   * the 10 + S per-Gaussian sums leave through the transposing reduction + ONE atomic instruction per (wave, Gaussian):
-//     channel -> array: 0..2 dL_dcolors[g*3+c] | 3..5 dL_dmean2D[g*3+c] | 6,7,8 dL_dconic2D[g*4+{0,1,3}] | 9 dL_dopacity[g] |
-//     10.. dL_dfeature[g*S+c]; with 10 + n <= 16 live channels the reduction is half size (SMALLV).
-// Measured (300k Gaussians, 800x800): 0.363 -> 0.345 ms inside the iteration (3 live feature channels), 0.494 -> 0.440 ms with
-// all 16 live.
-template <int SPAD, bool SMALLV, bool ROW4>
+//     (T *= 1, acc += 0 * d) and zeroes every gradient term;
+//   * the per-Gaussian sums leave through the transposing reduction + ONE atomic instruction per (wave, Gaussian).
+// Round 5 (the kernel is VALU-bound, cut instructions):
+//   * GEOMETRY MOMENTS.  With m = G * dL_dG per lane, the five mean / conic gradients of backward.cu:579-601 are linear in the
+//     five moments  S_x = sum m dx, S_y = sum m dy, S_xx = sum m dx^2, S_xy = sum m dx dy, S_yy = sum m dy^2:
+//         dL_dmean2D.x = -W/2 (A S_x + B S_y)    dL_dmean2D.y = -H/2 (C S_y + B S_x)    dL_dconic = -1/2 (S_xx, S_xy, S_yy)
+//     with the conic (A, B, C) a per-GAUSSIAN constant.  The lanes accumulate the raw moments (6 multiplications instead of the
+//     ~16 of the expanded terms) into the dL_dmean2D / dL_dconic slots, and preprocess_backward_kernel -- which reads those slots
+//     once per Gaussian anyway -- applies the conic (`moments_to_gradients`, rasterizer_preprocess_bwd.hip) and writes the final
+//     dL_dmean2D back.  Same sums in another order of rounding.
+//   * ONE LDS RECORD per staged entry (geometry 32 B + payload), one address register, immediate offsets; the NEXT entry's
+//     geometry is requested before the current entry's arithmetic (the loop used to wait for three separate LDS reads per entry,
+//     one of them -- the Gaussian's index for the atomic -- at the very end).
+//   * LEAN instances (no depth gradient -- dL_dpixels_d == nullptr, what the stage-2 objectives pass -- and at least one padding
+//     feature slot): the channel vector of the packed recursions is [r g b f0 ..] without the depth slot, one packed pair and one
+//     reduction channel fewer (3 live features: 3 pairs instead of 4; up to 7 live features still reduce 16-wide).
+// Channel vector:  !LEAN  [r g b depth f0 .. f(SPAD-1)]      LEAN  [r g b f0 .. f(SPAD-2)]
+// Reduction channels -> array:  0..2 dL_dcolors[g*3+c] | 3,4 moments S_x, S_y -> dL_dmean2D[g*3+{0,1}] | (!LEAN) 5 dL_dmean2D[g*3+2]
+// | next 3: S_xx, S_xy, S_yy -> dL_dconic2D[g*4+{0,1,3}] | next: dL_dopacity[g] | rest: dL_dfeature[g*S+c].
+template <int SPAD, bool SMALLV, bool ROW4, bool LEAN>
 __global__ void __launch_bounds__(64, (SPAD <= 4 ? R3DG_BWD_WAVES_SMALL : 1))
 render_backward_wave_kernel(const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list, int S,
                             ChannelList chan_list, int W, int H, int tiles_x, int num_tiles, int cull,
@@ -84,20 +97,28 @@ render_backward_wave_kernel(const uint2* __restrict__ ranges, const uint32_t* __
                             float* __restrict__ dL_dmean2D, float* __restrict__ dL_dconic2D, float* __restrict__ dL_dopacity,
                             float* __restrict__ dL_dcolors, float* __restrict__ dL_dfeature, int backward_geometry)
 {
-    constexpr int PAY = 4 + SPAD;
-    constexpr int NV = 10 + SPAD;
+    static_assert(!LEAN || SPAD >= 4, "a lean instance needs a padding feature slot");
+    constexpr int NC = LEAN ? 2 + SPAD : 4 + SPAD;        // channels of the packed recursions (even)
+    constexpr int NF = LEAN ? SPAD - 1 : SPAD;            // feature slots among them
+    constexpr int F0 = LEAN ? 3 : 4;                      // first feature channel
+    constexpr int NCOL = F0;                              // colour (+ depth) channels: their part of dL_dalpha is unconditional
+    constexpr int PAYF = (NC + 3) / 4 * 4;                // payload floats of a record (whole float4 rows)
+    constexpr int REC = 8 + PAYF;                         // floats per LDS record: geometry 8 | payload
+    constexpr int V_CONIC = LEAN ? 5 : 6;
+    constexpr int V_OPAC = V_CONIC + 3;
+    constexpr int V_FEAT = V_OPAC + 1;
+    constexpr int NV = V_FEAT + NF;
     constexpr int NVP = SMALLV ? 16 : next_pow2(NV);
-    constexpr int NC = 4 + SPAD;
+    // (SMALLV with NV > 16: the channels past 15 are padding feature slots -- the launcher guarantees it -- and are dropped)
     const int SA = chan_list.n;
     const int xcd = (int)(blockIdx.x & 7u), j = (int)(blockIdx.x >> 3), sub = j & 3, rank = (j >> 2) * 8 + xcd;
     if (rank >= num_tiles) return;
     const int tile = tile_order != nullptr ? (int)tile_order[rank] : rank;
     const int tile_x = tile % tiles_x, tile_y = tile / tiles_x;
 
-    __shared__ float4 s_geo0[64];
-    __shared__ float4 s_geo1[64];
-    __shared__ __attribute__((aligned(16))) float s_pay[64 * PAY];
-    __shared__ uint32_t s_front[64];              // index of the staged entry from the front of the tile's list
+    // record k: [mean.x mean.y conic.x conic.y | conic.z opacity front-index id | payload]; one spare record behind the 64
+    // (the loop requests entry k + 1 unconditionally)
+    __shared__ __attribute__((aligned(16))) float s_rec[65 * REC];
 
     const int lane = threadIdx.x;
     const int bx = 8 * (sub & 1), by = 8 * (sub >> 1);
@@ -113,10 +134,11 @@ render_backward_wave_kernel(const uint2* __restrict__ ranges, const uint32_t* __
     uint32_t dst_stride = 0;
     if (transposed_owner<NVP>(lane)) {
         if (chan < 3) { dst_base = dL_dcolors + chan; dst_stride = 3; }
-        else if (chan < 6) { dst_base = dL_dmean2D + (chan - 3); dst_stride = 3; }
-        else if (chan < 9) { dst_base = dL_dconic2D + (chan == 8 ? 3 : chan - 6); dst_stride = 4; }
-        else if (chan == 9) { dst_base = dL_dopacity; dst_stride = 1; }
-        else if (chan - 10 < SA) { dst_base = dL_dfeature + chan_list.c[chan - 10]; dst_stride = (uint32_t)S; }
+        else if (chan < 5) { dst_base = dL_dmean2D + (chan - 3); dst_stride = 3; }
+        else if (!LEAN && chan == 5) { dst_base = dL_dmean2D + 2; dst_stride = 3; }
+        else if (chan < V_OPAC) { dst_base = dL_dconic2D + (chan - V_CONIC == 2 ? 3 : chan - V_CONIC); dst_stride = 4; }
+        else if (chan == V_OPAC) { dst_base = dL_dopacity; dst_stride = 1; }
+        else if (chan - V_FEAT < SA && chan - V_FEAT < NF) { dst_base = dL_dfeature + chan_list.c[chan - V_FEAT]; dst_stride = (uint32_t)S; }
     }
 
     const bool inside = px < W && py < H;
@@ -134,11 +156,11 @@ render_backward_wave_kernel(const uint2* __restrict__ ranges, const uint32_t* __
             bg_dot += bg_color[ch] * dl[ch];
         }
         bgT = -T * bg_dot;
-        dl[3] = inside ? dL_dpixels_d[pix] : 0.f;
+        if constexpr (!LEAN) dl[3] = (inside && dL_dpixels_d != nullptr) ? dL_dpixels_d[pix] : 0.f;
         dLo = inside ? dL_dpixels_o[pix] : 0.f;
 #pragma unroll
-        for (int ch = 0; ch < SPAD; ch++)
-            dl[4 + ch] = (inside && ch < SA) ? dL_dpixels_f[(size_t)chan_list.c[ch] * HW + pix] : 0.f;
+        for (int ch = 0; ch < NF; ch++)
+            dl[F0 + ch] = (inside && ch < SA) ? dL_dpixels_f[(size_t)chan_list.c[ch] * HW + pix] : 0.f;
 #pragma unroll
         for (int q = 0; q < NC / 2; q++) {
             dL2[q] = f2{dl[2 * q], dl[2 * q + 1]};
@@ -150,7 +172,6 @@ render_backward_wave_kernel(const uint2* __restrict__ ranges, const uint32_t* __
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) mx = max(mx, (uint32_t)__shfl_xor((int)mx, o, 64));
     const int n = (int)mx;
-    const float ddelx_dx = 0.5f * W, ddely_dy = 0.5f * H;
 
     int cidx[SPAD > 0 ? SPAD : 1];                        // (uniform: scalar registers)
 #pragma unroll
@@ -188,15 +209,27 @@ render_backward_wave_kernel(const uint2* __restrict__ ranges, const uint32_t* __
                      const float4 (&f4)[SPAD > 0 ? SPAD / 4 : 1], int e0) {
         if (cand) {
             const int slot = __popcll(m & ((1ull << lane) - 1ull));
-            s_geo0[slot] = a0;
-            s_geo1[slot] = make_float4(a1.x, a1.y, a1.z, __uint_as_float(g));
-            s_front[slot] = (uint32_t)(n - 1 - (e0 + lane));
-            float* pay = s_pay + slot * PAY;
-            *reinterpret_cast<float4*>(pay) = make_float4(c4.x, c4.y, c4.z, a1.z);       // rgb, depth
+            float* rec = s_rec + slot * REC;
+            *reinterpret_cast<float4*>(rec) = a0;
+            *reinterpret_cast<float4*>(rec + 4) =
+                make_float4(a1.x, a1.y, __uint_as_float((uint32_t)(n - 1 - (e0 + lane))), __uint_as_float(g));
+            float pv[PAYF];
+#pragma unroll
+            for (int q = 0; q < PAYF; q++) pv[q] = 0.f;
+            pv[0] = c4.x; pv[1] = c4.y; pv[2] = c4.z;
+            if constexpr (!LEAN) pv[3] = a1.z;                                   // depth
             if constexpr (SPAD > 0) {
 #pragma unroll
-                for (int q = 0; q < SPAD / 4; q++) *reinterpret_cast<float4*>(pay + 4 + 4 * q) = f4[q];
+                for (int q = 0; q < SPAD / 4; q++) {
+                    const float fv[4] = {f4[q].x, f4[q].y, f4[q].z, f4[q].w};
+#pragma unroll
+                    for (int c = 0; c < 4; c++)
+                        if (4 * q + c < NF) pv[F0 + 4 * q + c] = fv[c];
+                }
             }
+#pragma unroll
+            for (int q = 0; q < PAYF / 4; q++)
+                *reinterpret_cast<float4*>(rec + 8 + 4 * q) = make_float4(pv[4 * q], pv[4 * q + 1], pv[4 * q + 2], pv[4 * q + 3]);
         }
     };
 
@@ -239,73 +272,82 @@ render_backward_wave_kernel(const uint2* __restrict__ ranges, const uint32_t* __
         float4 nf4[SPAD > 0 ? SPAD / 4 : 1];
         if (cand1) load_payload(g1n, nc4, nf4);
 
+        float4 g0 = *reinterpret_cast<const float4*>(s_rec), g1 = *reinterpret_cast<const float4*>(s_rec + 4);
         for (int k = 0; k < ncand; k++) {
-            const float4 g0 = s_geo0[k], g1 = s_geo1[k];
-            const uint32_t front = s_front[k];
+            // the next entry's geometry is requested now (slot ncand <= 64 exists; what it holds is never used)
+            const float* rec = s_rec + k * REC;
+            const float4 g0n = *reinterpret_cast<const float4*>(rec + REC), g1n = *reinterpret_cast<const float4*>(rec + REC + 4);
+            const uint32_t front = __float_as_uint(g1.z);
             const float dx = g0.x - pxf, dy = g0.y - pyf;
             const float power = -0.5f * (g0.z * dx * dx + g1.x * dy * dy) - g0.w * dx * dy;
             const float Gv0 = fast_exp_b(power);
             float al = fminf(0.99f, g1.y * Gv0);
             // reference: skip while contributor >= last_contributor, power > 0, alpha < 1/255
             if (!(front < lastc) || power > 0.0f || al < 1.0f / 255.0f) al = 0.f;
-            if (__ballot(al != 0.f) == 0ull) continue;
-
-            const float* pay = s_pay + k * PAY;
-            constexpr int NVA = NV > NVP ? NV : NVP;
-            float v[NVA];
+            if (__ballot(al != 0.f) != 0ull) {
+                const float* pay = rec + 8;
+                constexpr int NVA = NV > NVP ? NV : NVP;
+                float v[NVA];
 #pragma unroll
-            for (int q = NV; q < NVA; q++) v[q] = 0.f;
-            const bool hit = al != 0.f;
-            const float rcp = __builtin_amdgcn_rcpf(1.f - al);
-            T = T * rcp;
-            const float wgt = al * T;
-            const f2 al2 = f2{al, al}, w2 = f2{wgt, wgt};
-            f2 sa = f2{0.f, 0.f}, sf = f2{0.f, 0.f};
+                for (int q = NV; q < NVA; q++) v[q] = 0.f;
+                const bool hit = al != 0.f;
+                const float rcp = __builtin_amdgcn_rcpf(1.f - al);
+                T = T * rcp;
+                const float wgt = al * T;
+                const f2 al2 = f2{al, al}, w2 = f2{wgt, wgt};
+                f2 sc = f2{0.f, 0.f}, sf = f2{0.f, 0.f};       // dL_dalpha: colour (+depth) part | feature part
 #pragma unroll
-            for (int q = 0; q < NC / 4; q++) {
-                const float4 p4 = *reinterpret_cast<const float4*>(pay + 4 * q);
-                const f2 da = f2{p4.x, p4.y} - acc2[2 * q], db = f2{p4.z, p4.w} - acc2[2 * q + 1];
-                if (q == 0) {
-                    sa += da * dL2[0];
-                    sa += db * dL2[1];
-                } else {
-                    sf += da * dL2[2 * q];
-                    sf += db * dL2[2 * q + 1];
+                for (int q = 0; q < PAYF / 4; q++) {
+                    const float4 p4 = *reinterpret_cast<const float4*>(pay + 4 * q);
+                    const f2 pv2[2] = {f2{p4.x, p4.y}, f2{p4.z, p4.w}};
+#pragma unroll
+                    for (int h = 0; h < 2; h++) {
+                        const int pr = 2 * q + h;                       // pair index: channels 2 pr, 2 pr + 1
+                        if (2 * pr >= NC) continue;
+                        const f2 d = pv2[h] - acc2[pr];
+                        const f2 t = d * dL2[pr];
+                        // which part of dL_dalpha a channel belongs to is a compile-time property of its index
+                        if (2 * pr + 1 < NCOL) sc += t;
+                        else if (2 * pr >= NCOL) sf += t;
+                        else { sc.x += t.x; sf.y += t.y; }
+                        acc2[pr] += al2 * d;
+                        const f2 vv = w2 * dL2[pr];
+                        const float vc[2] = {vv.x, vv.y};
+#pragma unroll
+                        for (int c = 0; c < 2; c++) {
+                            const int ch = 2 * pr + c;
+                            if (ch < 3) v[ch] = vc[c];
+                            else if (!LEAN && ch == 3) v[5] = vc[c];               // depth -> dL_dmean2D.z
+                            else v[V_FEAT + (ch - F0)] = vc[c];
+                        }
+                    }
                 }
-                acc2[2 * q] += al2 * da;
-                acc2[2 * q + 1] += al2 * db;
-                const f2 va = w2 * dL2[2 * q], vb = w2 * dL2[2 * q + 1];
-                if (q == 0) {
-                    v[0] = va.x; v[1] = va.y; v[2] = vb.x; v[5] = vb.y;          // rgb; depth -> dL_dmean2D.z
-                } else {
-                    v[10 + 4 * (q - 1) + 0] = va.x; v[10 + 4 * (q - 1) + 1] = va.y;
-                    v[10 + 4 * (q - 1) + 2] = vb.x; v[10 + 4 * (q - 1) + 3] = vb.y;
-                }
+                float dL_dalpha = sc.x + sc.y;
+                if (backward_geometry) dL_dalpha += sf.x + sf.y;
+                const float d_o = 1.0f - acc_o;
+                dL_dalpha += d_o * dLo;
+                acc_o += al * d_o;
+                dL_dalpha *= T;
+                dL_dalpha += bgT * rcp;
+                // moments of m = G dL_dG (dL_dG = opacity dL_dalpha); a lane that does not blend contributes nothing (its
+                // exp may have overflowed: selected away, not multiplied by zero)
+                const float t9 = hit ? Gv0 * dL_dalpha : 0.f;          // dL_dopacity term (backward.cu:597)
+                const float mm = g1.y * t9;
+                const float mdx = mm * dx, mdy = mm * dy;
+                v[3] = mdx;
+                v[4] = mdy;
+                v[V_CONIC] = mdx * dx;
+                v[V_CONIC + 1] = mdx * dy;
+                v[V_CONIC + 2] = mdy * dy;
+                v[V_OPAC] = t9;
+                float vr[NVP];
+#pragma unroll
+                for (int q = 0; q < NVP; q++) vr[q] = v[q];
+                const float total = transpose_reduce<NVP, true>(vr);
+                if (dst_base != nullptr) atomicAdd(dst_base + (size_t)(__float_as_uint(g1.w) * dst_stride), total);
             }
-            float dL_dalpha = sa.x + sa.y;
-            if (backward_geometry) dL_dalpha += sf.x + sf.y;
-            const float d_o = 1.0f - acc_o;
-            dL_dalpha += d_o * dLo;
-            acc_o += al * d_o;
-            dL_dalpha *= T;
-            dL_dalpha += bgT * rcp;
-            dL_dalpha = hit ? dL_dalpha : 0.f;
-            const float Gv = hit ? Gv0 : 0.f;
-            const float dL_dG = g1.y * dL_dalpha;
-            const float gdx = Gv * dx, gdy = Gv * dy;
-            const float dG_ddelx = -gdx * g0.z - gdy * g0.w;
-            const float dG_ddely = -gdy * g1.x - gdx * g0.w;
-            v[3] = dL_dG * dG_ddelx * ddelx_dx;
-            v[4] = dL_dG * dG_ddely * ddely_dy;
-            v[6] = -0.5f * gdx * dx * dL_dG;
-            v[7] = -0.5f * gdx * dy * dL_dG;
-            v[8] = -0.5f * gdy * dy * dL_dG;
-            v[9] = Gv * dL_dalpha;
-            float vr[NVP];
-#pragma unroll
-            for (int q = 0; q < NVP; q++) vr[q] = v[q];
-            const float total = transpose_reduce<NVP, true>(vr);
-            if (dst_base != nullptr) atomicAdd(dst_base + (size_t)(__float_as_uint(g1.w) * dst_stride), total);
+            g0 = g0n;
+            g1 = g1n;
         }
         __builtin_amdgcn_wave_barrier();          // (reads of this round before the next round's staging writes)
         ncand = __popcll(m1);
@@ -315,6 +357,7 @@ render_backward_wave_kernel(const uint2* __restrict__ ranges, const uint32_t* __
 }
 
 extern int g_cull;
+int g_bwd_lean = 1;          // R3DG_OPT_BWD_LEAN
 
 // ---- feature gradients only (frozen geometry) -------------------------------------------------------------------------
 // The Synthetic4Relight / DTU stage-2 schedule (script/run_syn4.sh:27-33, run_dtu.sh) freezes positions, covariances, opacities
@@ -472,19 +515,29 @@ void launch_render_backward(hipStream_t s, int W, int H, int S, int n_active, co
     const int grid = ((T + 7) / 8) * 8 * 4;       // 4 single-wave workgroups per tile, tile ranks padded to a multiple of 8
     // ROW4: every feature channel is carried and the rows are float4-aligned (S == SPAD): the payload is read as float4s
     const bool row4 = cl.identity != 0 && (S & 3) == 0;
+    const int spad = (SP + 3) / 4 * 4;
+    // LEAN: no depth gradient (the caller passed no dL_dout_depth), at least one padding slot among the SPAD feature slots, the
+    // geometry part of dL_dalpha on (what every caller passes); only instantiated where it pays: up to 8 feature slots
+    const bool lean = dL_dpix_d == nullptr && bg_geom != 0 && SP >= 1 && SP < spad && spad <= 8 && !row4;
 #define R3DG_BWD_ARGS                                                                                                  \
     (const uint2*)ranges, point_list, S, cl, W, H, tiles_x, T, opt(R3DG_OPT_CULL), tile_order, bg, (const float4*)splat, features,       \
         final_Ts, n_contrib, dL_dpix, dL_dpix_o, dL_dpix_d, dL_dpix_f, dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolor,    \
         dL_dfeature, bg_geom
 #define R3DG_BWD(SP_, SV)                                                                                             \
     do {                                                                                                               \
-        if (row4) render_backward_wave_kernel<SP_, SV, true><<<grid, 64, 0, s>>>(R3DG_BWD_ARGS);                       \
-        else render_backward_wave_kernel<SP_, SV, false><<<grid, 64, 0, s>>>(R3DG_BWD_ARGS);                           \
+        if (row4) render_backward_wave_kernel<SP_, SV, true, false><<<grid, 64, 0, s>>>(R3DG_BWD_ARGS);                \
+        else render_backward_wave_kernel<SP_, SV, false, false><<<grid, 64, 0, s>>>(R3DG_BWD_ARGS);                    \
     } while (0)
+    if (lean && opt(R3DG_OPT_BWD_LEAN) != 0) {
+        // 9 + (SPAD - 1) reduction channels: 12 (SPAD 4) and 16 (SPAD 8) -- both reduce 16-wide
+        if (spad == 4) render_backward_wave_kernel<4, true, false, true><<<grid, 64, 0, s>>>(R3DG_BWD_ARGS);
+        else render_backward_wave_kernel<8, true, false, true><<<grid, 64, 0, s>>>(R3DG_BWD_ARGS);
+        return;
+    }
     switch ((SP + 3) / 4) {
-        case 0: render_backward_wave_kernel<0, false, false><<<grid, 64, 0, s>>>(R3DG_BWD_ARGS); break;
+        case 0: render_backward_wave_kernel<0, false, false, false><<<grid, 64, 0, s>>>(R3DG_BWD_ARGS); break;
         // 10 + n <= 16 gradient channels: half-size reduction
-        case 1: if (cl.n <= 6) R3DG_BWD(4, true); else R3DG_BWD(4, false); break;
+        case 1: R3DG_BWD(4, true); break;
         case 2: if (cl.n <= 6) R3DG_BWD(8, true); else R3DG_BWD(8, false); break;
         case 3: R3DG_BWD(12, false); break;
         case 4: R3DG_BWD(16, false); break;

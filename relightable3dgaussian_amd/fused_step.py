@@ -701,7 +701,8 @@ class FusedStage2Step(_BoundedForward):
                     geo_stream = self._listed_stream()
                 bw = rasterizer_ops.rasterize_gaussians_backward(
                     bg, self.xyz, self.features, radii, empty, self.a_scales, self.a_rot, 1.0, empty, vm,
-                    cam.full_proj_transform, cam.tanfovx, cam.tanfovy, g[0:3], g[3:4], self._zero_depth_grad, g[4:20],
+                    # (no depth gradient: an EMPTY tensor = NULL = the caller's promise that the depth image carries no loss term)
+                    cam.full_proj_transform, cam.tanfovx, cam.tanfovy, g[0:3], g[3:4], empty, g[4:20],
                     self.shs, 3, campos, geom, R, binning, img, True, False, dL_dsh_out=self.grads["shs"],
                     geometry_stream=geo_stream, active_features=sorted(active))
                 dL_dmeans2D, _dcol, dL_dopacity, dL_dmeans3D, dL_dfeatures, _dcov, _dsh, dL_dscales, dL_drot = bw
@@ -1155,7 +1156,7 @@ class FusedStage1Step(_BoundedForward):
                 self.sums.data_ptr()), "stage1_loss")
             bw = rasterizer_ops.rasterize_gaussians_backward(
                 bg, self.xyz, self.features, radii, empty, self.a_scales, self.a_rot, 1.0, empty, vm,
-                cam.full_proj_transform, cam.tanfovx, cam.tanfovy, g[0:3], g[3:4], self._zero_depth_grad, g[4:9],
+                cam.full_proj_transform, cam.tanfovx, cam.tanfovy, g[0:3], g[3:4], empty, g[4:9],        # (empty: no depth gradient)
                 self.shs, 3, campos, geom, R, binning, img, True, False, dL_dsh_out=self.grads["shs"],
                 # the normal maps carry the two normal terms, depth / depth^2 the variance term
                 active_features=(0, 1, 2, 3, 4) if w_var != 0.0 else (0, 1, 2))

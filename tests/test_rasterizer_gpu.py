@@ -498,6 +498,58 @@ def test_backward_active_feature_subset(S, active):
         run((S,))
 
 
+@pytest.mark.parametrize("S,active", [(16, (2, 3, 4)), (16, (2, 3, 4, 5, 6, 7)), (16, (1, 2, 3, 4, 5, 6, 7)), (5, (0, 1, 2)),
+                                      (5, (0, 1, 2, 3, 4)), (7, (6,)), (16, (0, 3, 5, 7, 9, 11, 13))])
+def test_backward_without_a_depth_gradient_takes_the_lean_instances(S, active):
+    """Round 5: a caller that passes NO depth gradient (an empty tensor = NULL, what the fused iterations do) gets the tile
+    backward's lean instances -- channel vector without the depth slot, one reduction channel fewer (1..7 live feature channels
+    with at least one padding slot; R3DG_OPT_BWD_LEAN = 0 switches them off).  Same nine gradients as (i) the same call with the
+    lean instances off, (ii) the call with an all-zero depth-gradient IMAGE (the general instances), and (iii) the float64 CPU
+    oracle; dL_dmeans2D is the FINAL gradient again after the per-Gaussian kernel converted the moments the tile kernel
+    accumulates (csrc/rasterizer_preprocess_bwd.hip moments_to_gradients)."""
+    import numpy as np
+    from oracle import rasterizer as orc
+    from r3dg_rasterization import _C
+    from relightable3dgaussian_amd import _lib, rasterizer_ops
+    case = make_case(S=S, seed=91 + S, P=3000, W=112, H=96)
+    a = fwd_args(case, DEV)
+    out = _C.rasterize_gaussians(*a)
+    H, W = case["H"], case["W"]
+    g = torch.Generator().manual_seed(7)
+    gC, gO = [torch.randn(c, H, W, generator=g).to(DEV) for c in (3, 1)]
+    gF = torch.zeros(S, H, W, device=DEV)
+    for ch in active:
+        gF[ch] = torch.randn(H, W, generator=g).to(DEV)
+    empty = torch.Tensor([])
+
+    def run(gD, act=active):
+        return rasterizer_ops.rasterize_gaussians_backward(
+            a[0], a[1], a[2], out[9], a[3], a[5], a[6], 1.0, a[8], a[9], a[10], a[11], a[12], gC, gO, gD, gF, a[17],
+            a[18], a[19], out[10], out[0], out[11], out[12], True, False, active_features=act)
+    lean = run(empty)
+    try:
+        _lib.set_option("BWD_LEAN", 0)
+        plain = run(empty)
+    finally:
+        _lib.set_option("BWD_LEAN", 1)
+    zeros = run(torch.zeros(1, H, W, device=DEV))
+    torch.cuda.synchronize()
+    names = ("dL_dmeans2D", "dL_dcolors", "dL_dopacity", "dL_dmeans3D", "dL_dfeatures", "dL_dcov3D", "dL_dsh",
+             "dL_dscales", "dL_drotations")
+    for nm, x, y, z in zip(names, lean, plain, zeros):
+        for tag, other in (("lean off", y), ("zero depth image", z)):
+            ok, msg = report(nm + " vs " + tag, x, other, 1e-4, 1e-9)     # float-atomic summation order differs
+            assert ok, msg
+    assert float(lean[0][:, 2].abs().max()) == 0.0                       # no depth gradient: the z side channel stays zero
+    c = fwd_args(case)
+    ref = orc.rasterize_gaussians(*c[:-3])
+    oref = orc.rasterize_gaussians_backward(c[0], c[1], c[2], ref[9], c[3], c[5], c[6], 1.0, c[8], c[9], c[10], c[11], c[12],
+                                            gC.cpu(), gO.cpu(), torch.zeros(1, H, W), gF.cpu(), c[17], c[18], c[19], ref[-1], True)
+    for nm, x, y in zip(names, lean, oref[:9]):
+        ok, msg = report(nm + " vs oracle", x, np.asarray(y, np.float64).reshape(tuple(x.shape)), 2e-3, 1e-7)
+        assert ok, msg
+
+
 @pytest.mark.parametrize("S,active,size", [(16, None, (128, 128)), (16, (2, 3, 4, 8, 9, 10, 11, 12, 13, 14), (150, 97)),
                                            (5, (0,), (128, 128)), (28, tuple(range(3, 20)), (64, 200)), (36, None, (96, 96)),
                                            (16, (), (128, 128))])

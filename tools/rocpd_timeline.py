@@ -57,14 +57,20 @@ def main():
 
 
 def sequence():
-    """Print the kernel sequence of the last full step: start (us from the step's first launch), duration (us), the queue the
+    """Print the kernel sequence of one full step (see the comment on argv[3] below): start (us from the step's first launch), duration (us), the queue the
     launch went to (one per HIP stream), the idle time on the whole device before it when nothing else was running, name."""
     cur = sqlite3.connect(sys.argv[1]).cursor()
     cols = [r[1] for r in cur.execute("pragma table_info(kernels)")]
     qcol = "queue_id" if "queue_id" in cols else ("stream_id" if "stream_id" in cols else "0")
     rows = list(cur.execute("select name, start, end, %s from kernels order by start" % qcol))
     marks = [i for i, r in enumerate(rows) if "r3dg::render_backward_" in r[0] and "features" not in r[0]]
-    a, b = marks[-2], marks[-1]
+    # argv[3] = which step (0-based index into the render_backward launches; negative from the end).  Default: the step in the
+    # MIDDLE of the run -- the last steps of a bench.py run are the one-stream pass that measures each kernel alone
+    # (FusedStage2Step.serial_streams), not the pipelined iteration
+    k = int(sys.argv[3]) if len(sys.argv) > 3 else len(marks) // 2
+    a, b = marks[k], marks[k + 1] if k + 1 < len(marks) and k != -1 else marks[-1]
+    if k < 0:
+        a, b = marks[k - 1], marks[k]
     t0 = rows[a][1]
     queues = {}
     hi = rows[a][1]
