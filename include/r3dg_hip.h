@@ -134,12 +134,13 @@ int r3dg_rasterize_forward_begin_bounded(void* stream, r3dg_alloc_fn geometry_al
 int r3dg_rasterize_forward_finish_bounded(void* ticket, void* main_stream);
 
 /* Backward.  d_dL_dpix_d == NULL: the depth image carries no gradient (the caller's promise; the tile kernel then takes its
- * instances without a depth slot).  d_dL_dmean2D [P,3] (z = depth side channel), d_dL_dconic [P,4] (x,y,-,w: SCRATCH -- it holds
- * the second moments the tile kernel accumulates, not the reference's intermediate), d_dL_dopacity, d_dL_dcolor and
- * d_dL_dfeature are accumulated with atomics and must be zero-filled by the caller; d_dL_dmean3D, d_dL_dcov3D and --
- * when SHs / scales+rotations are the active inputs -- d_dL_dsh, d_dL_dscale, d_dL_drot are fully written (zeros for
- * invisible Gaussians) and may be uninitialised; otherwise they are left untouched (the reference zero-fills all ten,
- * rasterize_points.cu:179-188). */
+ * instances without a depth slot).  Every output is FULLY WRITTEN (zeros for invisible Gaussians, for feature channels outside
+ * `active_features` and when nothing was rendered) and may be uninitialised: d_dL_dmean2D [P,3] (z = depth side channel),
+ * d_dL_dopacity, d_dL_dcolor, d_dL_dfeature [P,S], d_dL_dmean3D, d_dL_dcov3D and -- when SHs / scales+rotations are the active
+ * inputs -- d_dL_dsh, d_dL_dscale, d_dL_drot (otherwise those three are left untouched; the reference zero-fills all ten,
+ * rasterize_points.cu:179-188).  d_dL_dconic [P,4] is SCRATCH (it receives the second moments the tile pass accumulates, not the
+ * reference's intermediate).  Rounds 1-4 accumulated the first five with atomics into caller-zeroed memory; since round 5 the tile
+ * kernel adds into one 64-byte record per Gaussian (library scratch) and a scatter pass writes the arrays. */
 int r3dg_rasterize_backward(void* stream, int P, int S, int D, int M, int R, const float* d_background, int width,
                             int height, const float* d_means3D, const float* d_shs, const float* d_features,
                             const float* d_colors_precomp, const float* d_scales, float scale_modifier,

@@ -39,7 +39,7 @@ void launch_render_forward(hipStream_t s, int W, int H, int S, const uint32_t* t
 void launch_pseudo_normal(hipStream_t s, int W, int H, const float* vm, float focal_x, float focal_y, float cx,
                           float cy, const float* opacities, const float* depths, float* normals, float* surface_xyz,
                           bool debug);
-void launch_render_backward(hipStream_t s, int W, int H, int S, int n_active, const int* active,
+void launch_render_backward(hipStream_t s, int P, int W, int H, int S, int n_active, const int* active,
                             const uint32_t* tile_order, const uint32_t* ranges,
                             const uint32_t* point_list,
                             const float* bg, const float* splat, const float* features, const float* final_Ts,
@@ -1115,7 +1115,7 @@ int r3dg_rasterize_backward_split(void* stream_, void* geometry_stream_, int P, 
 
         if (R > 0) {
             StageTimer t_rb(stream, ST_RENDER_BWD);
-            launch_render_backward(stream, width, height, S, n_active_features, active_features,
+            launch_render_backward(stream, P, width, height, S, n_active_features, active_features,
                                    opt(R3DG_OPT_TILE_ORDER) ? (const uint32_t*)(ibuf + I.tile_order) : nullptr,
                                    (const uint32_t*)(ibuf + I.ranges),
                                    (const uint32_t*)(bbuf + B.vals), background, (const float*)(gbuf + G.splat),
@@ -1124,6 +1124,13 @@ int r3dg_rasterize_backward_split(void* stream_, void* geometry_stream_, int P, 
                                    dL_dcolor, dL_dfeature, backward_geometry);
             check_launch(stream, debug, "render_backward");
             t_rb.stop();
+        } else {
+            // nothing was rendered: the five per-Gaussian outputs the tile pass writes are zero
+            R3DG_HIP(hipMemsetAsync(dL_dmean2D, 0, (size_t)P * 3 * sizeof(float), stream));
+            R3DG_HIP(hipMemsetAsync(dL_dconic, 0, (size_t)P * 4 * sizeof(float), stream));
+            R3DG_HIP(hipMemsetAsync(dL_dopacity, 0, (size_t)P * sizeof(float), stream));
+            R3DG_HIP(hipMemsetAsync(dL_dcolor, 0, (size_t)P * 3 * sizeof(float), stream));
+            if (S > 0 && dL_dfeature != nullptr) R3DG_HIP(hipMemsetAsync(dL_dfeature, 0, (size_t)P * S * sizeof(float), stream));
         }
         const float* cov3D_ptr = cov3D_precomp != nullptr ? cov3D_precomp : (const float*)(gbuf + G.cov3D);
         // the per-Gaussian geometry backward may run on a second stream, ordered after the tile kernel by an event

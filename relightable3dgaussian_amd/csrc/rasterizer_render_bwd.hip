@@ -15,6 +15,10 @@
 #include "common.hpp"
 #include "wave_reduce.hpp"
 
+#include <map>
+#include <mutex>
+#include <utility>
+
 #ifndef R3DG_BWD_WAVES_SMALL
 #define R3DG_BWD_WAVES_SMALL 4     // waves per SIMD the <= 4-channel instances are compiled for (measured: 4 -> 0.333 ms, 5 -> 0.367 with 5 spilled registers, 6 -> 0.467)
 #endif
@@ -82,9 +86,17 @@ struct ChannelList {
 //   * LEAN instances (no depth gradient -- dL_dpixels_d == nullptr, what the stage-2 objectives pass -- and at least one padding
 //     feature slot): the channel vector of the packed recursions is [r g b f0 ..] without the depth slot, one packed pair and one
 //     reduction channel fewer (3 live features: 3 pairs instead of 4; up to 7 live features still reduce 16-wide).
+//   * ONE GRADIENT RECORD PER GAUSSIAN.  Rounds 1-4 sent the (wave, Gaussian) sums straight to the op's five output arrays: one
+//     atomic instruction, but its 10 + S lanes hit FIVE different cache lines (colours, mean2D, conic, opacity, feature row).
+//     Ablation builds (tools/variants_bwd.py, profiles/r05_bwd_ablation.txt): without the atomics the kernel takes 0.253 instead
+//     of 0.417 ms -- and with all lanes of an entry aimed at ONE 64-byte row per Gaussian 0.258 ms: the device-scope atomics, not
+//     the VALU work, were 40 % of the launch, and nearly all of that is the number of LINES touched.  The sums now go to channel
+//     `chan` of a record of NVP floats per Gaussian (library scratch, zero between calls), and render_backward_scatter_kernel
+//     -- one coalesced pass per Gaussian behind the tile kernel -- writes the five output arrays from it (and zeroes the record).
 // Channel vector:  !LEAN  [r g b depth f0 .. f(SPAD-1)]      LEAN  [r g b f0 .. f(SPAD-2)]
-// Reduction channels -> array:  0..2 dL_dcolors[g*3+c] | 3,4 moments S_x, S_y -> dL_dmean2D[g*3+{0,1}] | (!LEAN) 5 dL_dmean2D[g*3+2]
-// | next 3: S_xx, S_xy, S_yy -> dL_dconic2D[g*4+{0,1,3}] | next: dL_dopacity[g] | rest: dL_dfeature[g*S+c].
+// Record channels (= reduction channels) -> array, applied by the scatter kernel:  0..2 dL_dcolors[g*3+c] | 3,4 moments S_x, S_y ->
+// dL_dmean2D[g*3+{0,1}] | (!LEAN) 5 dL_dmean2D[g*3+2] | next 3: S_xx, S_xy, S_yy -> dL_dconic2D[g*4+{0,1,3}] | next: dL_dopacity[g] |
+// rest: dL_dfeature[g*S+c].
 template <int SPAD, bool SMALLV, bool ROW4, bool LEAN>
 __global__ void __launch_bounds__(64, (SPAD <= 4 ? R3DG_BWD_WAVES_SMALL : 1))
 render_backward_wave_kernel(const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list, int S,
@@ -94,8 +106,7 @@ render_backward_wave_kernel(const uint2* __restrict__ ranges, const uint32_t* __
                             const float* __restrict__ final_Ts, const uint32_t* __restrict__ n_contrib,
                             const float* __restrict__ dL_dpixels, const float* __restrict__ dL_dpixels_o,
                             const float* __restrict__ dL_dpixels_d, const float* __restrict__ dL_dpixels_f,
-                            float* __restrict__ dL_dmean2D, float* __restrict__ dL_dconic2D, float* __restrict__ dL_dopacity,
-                            float* __restrict__ dL_dcolors, float* __restrict__ dL_dfeature, int backward_geometry)
+                            float* __restrict__ grad_records, int backward_geometry)
 {
     static_assert(!LEAN || SPAD >= 4, "a lean instance needs a padding feature slot");
     constexpr int NC = LEAN ? 2 + SPAD : 4 + SPAD;        // channels of the packed recursions (even)
@@ -129,17 +140,10 @@ render_backward_wave_kernel(const uint2* __restrict__ ranges, const uint32_t* __
     const size_t HW = (size_t)H * W;
     const uint2 range = ranges[tile];
 
+    // the lane that owns channel `chan` after the transposing reduction adds it to word `chan` of the Gaussian's record
     const int chan = transposed_channel<NVP>(lane);
     float* dst_base = nullptr;
-    uint32_t dst_stride = 0;
-    if (transposed_owner<NVP>(lane)) {
-        if (chan < 3) { dst_base = dL_dcolors + chan; dst_stride = 3; }
-        else if (chan < 5) { dst_base = dL_dmean2D + (chan - 3); dst_stride = 3; }
-        else if (!LEAN && chan == 5) { dst_base = dL_dmean2D + 2; dst_stride = 3; }
-        else if (chan < V_OPAC) { dst_base = dL_dconic2D + (chan - V_CONIC == 2 ? 3 : chan - V_CONIC); dst_stride = 4; }
-        else if (chan == V_OPAC) { dst_base = dL_dopacity; dst_stride = 1; }
-        else if (chan - V_FEAT < SA && chan - V_FEAT < NF) { dst_base = dL_dfeature + chan_list.c[chan - V_FEAT]; dst_stride = (uint32_t)S; }
-    }
+    if (transposed_owner<NVP>(lane) && (chan < V_FEAT || (chan - V_FEAT < SA && chan - V_FEAT < NF))) dst_base = grad_records + chan;
 
     const bool inside = px < W && py < H;
     const size_t pix = (size_t)py * W + px;
@@ -344,7 +348,7 @@ render_backward_wave_kernel(const uint2* __restrict__ ranges, const uint32_t* __
 #pragma unroll
                 for (int q = 0; q < NVP; q++) vr[q] = v[q];
                 const float total = transpose_reduce<NVP, true>(vr);
-                if (dst_base != nullptr) atomicAdd(dst_base + (size_t)(__float_as_uint(g1.w) * dst_stride), total);
+                if (dst_base != nullptr) atomicAdd(dst_base + (size_t)__float_as_uint(g1.w) * NVP, total);
             }
             g0 = g0n;
             g1 = g1n;
@@ -354,6 +358,87 @@ render_backward_wave_kernel(const uint2* __restrict__ ranges, const uint32_t* __
         stage(cand1, m1, n0, n1, g1n, nc4, nf4, base + 64);
         __builtin_amdgcn_wave_barrier();
     }
+}
+
+// Record -> output arrays (see render_backward_wave_kernel): thread per Gaussian, the NVP-float record in as float4s (and zeros
+// back: the scratch is zero between calls), every element of the five arrays written -- the caller's zero fill of the atomically
+// accumulated outputs is no longer needed (it does no harm: `=`, not `+=`).  NVP / LEAN / NF as the tile kernel that filled the
+// records was instantiated.
+template <int NVP, bool LEAN>
+__global__ void __launch_bounds__(256)
+render_backward_scatter_kernel(int P, int S, int NF, ChannelList chan_list, float4* __restrict__ grad_records,
+                               float* __restrict__ dL_dmean2D, float* __restrict__ dL_dconic2D, float* __restrict__ dL_dopacity,
+                               float* __restrict__ dL_dcolors, float* __restrict__ dL_dfeature)
+{
+    constexpr int V_CONIC = LEAN ? 5 : 6, V_OPAC = V_CONIC + 3, V_FEAT = V_OPAC + 1;
+    const int g = blockIdx.x * 256 + threadIdx.x;
+    if (g >= P) return;
+    float v[NVP];
+    float4* rec = grad_records + (size_t)g * (NVP / 4);
+#pragma unroll
+    for (int q = 0; q < NVP / 4; q++) {
+        const float4 t = rec[q];
+        v[4 * q] = t.x; v[4 * q + 1] = t.y; v[4 * q + 2] = t.z; v[4 * q + 3] = t.w;
+    }
+#pragma unroll
+    for (int q = 0; q < NVP / 4; q++) rec[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int c = 0; c < 3; c++) dL_dcolors[3 * (size_t)g + c] = v[c];
+    dL_dmean2D[3 * (size_t)g] = v[3];
+    dL_dmean2D[3 * (size_t)g + 1] = v[4];
+    dL_dmean2D[3 * (size_t)g + 2] = LEAN ? 0.f : v[5];
+    dL_dconic2D[4 * (size_t)g] = v[V_CONIC];                      // (scalar stores: the caller's slab need not be 16-byte aligned)
+    dL_dconic2D[4 * (size_t)g + 1] = v[V_CONIC + 1];
+    dL_dconic2D[4 * (size_t)g + 2] = 0.f;
+    dL_dconic2D[4 * (size_t)g + 3] = v[V_CONIC + 2];
+    dL_dopacity[g] = v[V_OPAC];
+    if (S > 0) {
+        float* row = dL_dfeature + (size_t)g * S;
+        const int n = chan_list.n < NF ? chan_list.n : NF;
+        if (chan_list.identity) {
+            // every channel is live and in order: channel j is feature j (n == S)
+#pragma unroll
+            for (int j = 0; j < NVP - V_FEAT; j++)
+                if (j < n) row[j] = v[V_FEAT + j];
+        } else {
+            for (int c = 0; c < S; c++) row[c] = 0.f;
+#pragma unroll
+            for (int j = 0; j < NVP - V_FEAT; j++)
+                if (j < n) row[chan_list.c[j]] = v[V_FEAT + j];
+        }
+    }
+}
+
+// The records: library scratch per (device, stream), zero whenever no backward is in flight on that stream -- the scatter kernel
+// zeroes what the tile kernel may have written.  `dirty` guards the invariant on the host: set before the tile kernel is
+// enqueued, cleared once the scatter kernel is; a call that finds it set (an enqueue in between failed) clears the buffer itself.
+static float* gradient_records(hipStream_t s, size_t floats, bool** dirty_out)
+{
+    struct State { float* p = nullptr; size_t cap = 0; bool dirty = false; };
+    static std::mutex mu;
+    static std::map<std::pair<int, hipStream_t>, State> states;
+    int dev = 0;
+    R3DG_HIP(hipGetDevice(&dev));
+    std::lock_guard<std::mutex> lk(mu);
+    State& st = states[std::make_pair(dev, s)];
+    if (st.cap < floats) {
+        if (st.p != nullptr) {
+            R3DG_HIP(hipStreamSynchronize(s));
+            R3DG_HIP(hipFree(st.p));
+            st.p = nullptr;
+            st.cap = 0;
+        }
+        const size_t want = floats + floats / 8 + 1024;
+        R3DG_HIP(hipMalloc((void**)&st.p, want * sizeof(float)));
+        st.cap = want;
+        st.dirty = true;
+    }
+    if (st.dirty) {
+        R3DG_HIP(hipMemsetAsync(st.p, 0, st.cap * sizeof(float), s));
+        st.dirty = false;
+    }
+    *dirty_out = &st.dirty;
+    return st.p;
 }
 
 extern int g_cull;
@@ -492,7 +577,7 @@ void launch_render_backward_features(hipStream_t s, int W, int H, int S, int n_a
 }
 
 
-void launch_render_backward(hipStream_t s, int W, int H, int S, int n_active, const int* active,
+void launch_render_backward(hipStream_t s, int P, int W, int H, int S, int n_active, const int* active,
                             const uint32_t* tile_order, const uint32_t* ranges, const uint32_t* point_list,
                             const float* bg, const float* splat, const float* features, const float* final_Ts,
                             const uint32_t* n_contrib, const float* dL_dpix, const float* dL_dpix_o,
@@ -519,34 +604,53 @@ void launch_render_backward(hipStream_t s, int W, int H, int S, int n_active, co
     // LEAN: no depth gradient (the caller passed no dL_dout_depth), at least one padding slot among the SPAD feature slots, the
     // geometry part of dL_dalpha on (what every caller passes); only instantiated where it pays: up to 8 feature slots
     const bool lean = dL_dpix_d == nullptr && bg_geom != 0 && SP >= 1 && SP < spad && spad <= 8 && !row4;
+    // reduction / record width of the instance that runs (the channels past it, if any, are padding feature slots)
+    const bool use_lean = lean && opt(R3DG_OPT_BWD_LEAN) != 0;
+    const int nv = use_lean ? 8 + spad : 10 + spad;
+    const bool smallv = use_lean || spad == 4 || (spad == 8 && cl.n <= 6);
+    const int nvp = smallv ? 16 : next_pow2(nv);
+    bool* dirty = nullptr;
+    float* rec = gradient_records(s, (size_t)P * nvp, &dirty);
+    *dirty = true;
 #define R3DG_BWD_ARGS                                                                                                  \
     (const uint2*)ranges, point_list, S, cl, W, H, tiles_x, T, opt(R3DG_OPT_CULL), tile_order, bg, (const float4*)splat, features,       \
-        final_Ts, n_contrib, dL_dpix, dL_dpix_o, dL_dpix_d, dL_dpix_f, dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolor,    \
-        dL_dfeature, bg_geom
+        final_Ts, n_contrib, dL_dpix, dL_dpix_o, dL_dpix_d, dL_dpix_f, rec, bg_geom
 #define R3DG_BWD(SP_, SV)                                                                                             \
     do {                                                                                                               \
         if (row4) render_backward_wave_kernel<SP_, SV, true, false><<<grid, 64, 0, s>>>(R3DG_BWD_ARGS);                \
         else render_backward_wave_kernel<SP_, SV, false, false><<<grid, 64, 0, s>>>(R3DG_BWD_ARGS);                    \
     } while (0)
-    if (lean && opt(R3DG_OPT_BWD_LEAN) != 0) {
+    if (use_lean) {
         // 9 + (SPAD - 1) reduction channels: 12 (SPAD 4) and 16 (SPAD 8) -- both reduce 16-wide
         if (spad == 4) render_backward_wave_kernel<4, true, false, true><<<grid, 64, 0, s>>>(R3DG_BWD_ARGS);
         else render_backward_wave_kernel<8, true, false, true><<<grid, 64, 0, s>>>(R3DG_BWD_ARGS);
-        return;
+    } else {
+        switch (spad / 4) {
+            case 0: render_backward_wave_kernel<0, false, false, false><<<grid, 64, 0, s>>>(R3DG_BWD_ARGS); break;
+            // 10 + n <= 16 gradient channels: half-size reduction
+            case 1: R3DG_BWD(4, true); break;
+            case 2: if (cl.n <= 6) R3DG_BWD(8, true); else R3DG_BWD(8, false); break;
+            case 3: R3DG_BWD(12, false); break;
+            case 4: R3DG_BWD(16, false); break;
+            case 5: R3DG_BWD(20, false); break;
+            case 6: R3DG_BWD(24, false); break;
+            case 7: R3DG_BWD(28, false); break;
+            case 8: R3DG_BWD(32, false); break;
+            default: R3DG_BWD(36, false); break;
+        }
     }
-    switch ((SP + 3) / 4) {
-        case 0: render_backward_wave_kernel<0, false, false, false><<<grid, 64, 0, s>>>(R3DG_BWD_ARGS); break;
-        // 10 + n <= 16 gradient channels: half-size reduction
-        case 1: R3DG_BWD(4, true); break;
-        case 2: if (cl.n <= 6) R3DG_BWD(8, true); else R3DG_BWD(8, false); break;
-        case 3: R3DG_BWD(12, false); break;
-        case 4: R3DG_BWD(16, false); break;
-        case 5: R3DG_BWD(20, false); break;
-        case 6: R3DG_BWD(24, false); break;
-        case 7: R3DG_BWD(28, false); break;
-        case 8: R3DG_BWD(32, false); break;
-        default: R3DG_BWD(36, false); break;
-    }
+    // records -> the op's output arrays
+    const int nf = use_lean ? spad - 1 : spad;
+    const int sgrid = (P + 255) / 256;
+#define R3DG_SCATTER(NVP_, LEAN_)                                                                                      \
+    render_backward_scatter_kernel<NVP_, LEAN_><<<sgrid, 256, 0, s>>>(P, S, nf, cl, (float4*)rec, dL_dmean2D, dL_dconic, dL_dopacity, \
+                                                                       dL_dcolor, dL_dfeature)
+    if (use_lean) R3DG_SCATTER(16, true);
+    else if (nvp == 16) R3DG_SCATTER(16, false);
+    else if (nvp == 32) R3DG_SCATTER(32, false);
+    else R3DG_SCATTER(64, false);
+#undef R3DG_SCATTER
+    *dirty = false;
 #undef R3DG_BWD
 #undef R3DG_BWD_ARGS
 }

@@ -349,6 +349,7 @@ class FusedStage2Step(_BoundedForward):
             self._bucket_c = self.grad_flat[start["xyz"]:start["incidents"]]
             self._bucket_b = self.grad_flat[start["incidents"]:]
         self._pending_b = None
+        self._acc = None                            # the tile backward's accumulator slab, zero-filled off the critical path
         self._early_pending = False                 # the early-Adam stream holds work no other stream has been ordered behind yet
         self._b_early = False
         self._flag_b = torch.zeros(4, dtype=torch.float32, device=dev)
@@ -549,6 +550,7 @@ class FusedStage2Step(_BoundedForward):
             # the rotation of the incident-light coefficients into the ray frames depends on nothing of this view: it goes to the
             # side stream now and runs beside the activations and the projection instead of in front of the shading forward
             rotated_for = None
+            acc_ready = False
             aux = self._aux_stream()
             if aux is not None:
                 _lib.stream_wait(aux, main)
@@ -562,6 +564,14 @@ class FusedStage2Step(_BoundedForward):
                     if self._stagger:
                         env_c = F.softplus(self.env)[0]                          # DirectLightMap.get_env
                         self.sums.zero_()
+                    # the zero fill of the backward's atomic accumulators (32 MB at 300k Gaussians) sat between the loss and the
+                    # tile backward, alone on the device (8 us); here it runs beside the activations / the projection.  (The slab
+                    # is this iteration's own: the previous one's consumers ran on the main / this stream, both behind us now.)
+                    acc_n = (11 + 16) * P
+                    if self._acc is None or self._acc.numel() != acc_n:
+                        self._acc = torch.empty(acc_n, dtype=torch.float32, device=dev)
+                    self._acc.zero_()
+                    acc_ready = True
                 rotated_for = self._frs
             if aux is not None and not self._stagger:
                 env_c = F.softplus(self.env)[0]
@@ -704,7 +714,8 @@ class FusedStage2Step(_BoundedForward):
                     # (no depth gradient: an EMPTY tensor = NULL = the caller's promise that the depth image carries no loss term)
                     cam.full_proj_transform, cam.tanfovx, cam.tanfovy, g[0:3], g[3:4], empty, g[4:20],
                     self.shs, 3, campos, geom, R, binning, img, True, False, dL_dsh_out=self.grads["shs"],
-                    geometry_stream=geo_stream, active_features=sorted(active))
+                    geometry_stream=geo_stream, active_features=sorted(active),
+                    zeroed_accumulators=self._acc if acc_ready else None)
                 dL_dmeans2D, _dcol, dL_dopacity, dL_dmeans3D, dL_dfeatures, _dcov, _dsh, dL_dscales, dL_drot = bw
                 if geo_stream is not None:
                     if self._geo_done is None:

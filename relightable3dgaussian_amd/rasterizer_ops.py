@@ -191,13 +191,15 @@ def rasterize_gaussians_backward(background, means3D, features, radii, colors, s
                                  cov3D_precomp, viewmatrix, projmatrix, tan_fovx, tan_fovy, dL_dout_color,
                                  dL_dout_opacity, dL_dout_depth, dL_dout_feature, sh, degree, campos, geomBuffer, R,
                                  binningBuffer, imageBuffer, backward_geometry, debug, dL_dsh_out=None,
-                                 geometry_stream=None, active_features=None):
+                                 geometry_stream=None, active_features=None, zeroed_accumulators=None):
     """`dL_dsh_out` (not in the reference signature): optional preallocated [P,M,3] buffer the SH gradient is written
     into (every element is written), e.g. a view of a flat gradient bucket.  `geometry_stream`: optional torch stream
     for the per-Gaussian geometry backward (dL_dmeans3D, dL_dcov3D, dL_dsh, dL_dscales, dL_drotations are then only
     valid after the caller joins that stream; see r3dg_rasterize_backward_split).  `active_features`: optional list of
     the feature channels whose upstream gradient can be non-zero -- the caller's promise that all other channels of
-    dL_dout_feature are zero; they are then skipped by the tile kernel (same results)."""
+    dL_dout_feature are zero; they are then skipped by the tile kernel (same results).  `zeroed_accumulators`: optional float32
+    tensor of (11 + S) * P ZEROS (the caller filled it earlier, off its critical path) that takes the place of the slab
+    zero-filled here; the five atomically accumulated outputs are views of it."""
     L = _lib.lib()
     P = means3D.size(0)
     S = features.size(1)
@@ -210,7 +212,12 @@ def rasterize_gaussians_backward(background, means3D, features, radii, colors, s
     # gradients accumulated with atomics share ONE zero-filled slab; the per-Gaussian outputs of the fused
     # preprocess-backward kernel are fully written (zeros for invisible Gaussians) and start uninitialised
     # (dL_dfeatures first: its rows stay 16-byte aligned for S % 4 == 0 whatever P is)
-    acc = torch.zeros((11 + S) * P, **fopt)
+    if zeroed_accumulators is not None:
+        acc = zeroed_accumulators
+        if acc.numel() != (11 + S) * P or acc.dtype != torch.float32 or not acc.is_contiguous() or acc.device != dev:
+            raise RuntimeError("zeroed_accumulators must be a contiguous float32 tensor of (11 + S) * P zeros on the device")
+    else:
+        acc = torch.zeros((11 + S) * P, **fopt)
     dL_dfeatures = acc[0:S * P].view(P, S)
     o = S * P
     dL_dconic = acc[o:o + 4 * P].view(P, 2, 2); o += 4 * P

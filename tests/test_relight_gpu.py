@@ -222,13 +222,20 @@ def test_relight_frames_match_the_reference_python(cache, regenerate_dirs):
     # Gaussian next to the origin sits on an acceptance threshold (t >= 0.01, n.d <= 0: trace.cu:247-262) -- reported, bounded
     # at 1 %.  From here on identical caches.
     from relightable3dgaussian_amd.train_step import inverse_covariance
-    ok, msg = report("incident_dirs", r.incident_dirs, dirs, 0, 1e-4)
+    # (Gaussians whose raw normal is (0, 0, -c): F.normalize gives n_z = -1 exactly on the CPU and -0.99999994 in the device's
+    # activation kernel, and rotation_between_z (sh_utils.py:36-68) takes its "n_z + 1 <= 0 -> -I" branch for one and the
+    # cancelling formula for the other -- an ulp of the normal is a different frame there, as in tests/test_reference_pipeline_gpu.py;
+    # their rows are compared through the fixture's own directions only)
+    n_cpu = torch.nn.functional.normalize(torch.from_numpy(z["raw_normal"]), dim=-1, eps=1e-3)
+    regular = ((n_cpu[:, 2] + 1).abs() > 1e-6).to(DEV)
+    assert int((~regular).sum()) <= 64          # (the synthetic scene plants a few per cent of its normals on -z)
+    ok, msg = report("incident_dirs", r.incident_dirs[regular], dirs[regular], 0, 1e-4)
     assert ok, msg
     same = r.tracer.trace_visibility(r.xyz[:, None].expand_as(dirs), dirs, r.xyz, inverse_covariance(r.a_scales, r.a_rot),
                                      r.a_opacity[:, 0].contiguous(), r.a_normal)["visibility"]
     near = ((vis - 0.9).abs() < 1e-3) | ((same - 0.9).abs() < 1e-3)
     mism_same = (((same == 0) != (vis == 0)) & ~near).float().mean().item()
-    mism_own = ((r.visibility == 0) != (vis == 0)).float().mean().item()
+    mism_own = ((r.visibility == 0) != (vis == 0))[regular].float().mean().item()
     print("visibility classes vs the reference fixture: %.2e of the rays differ along the fixture's own directions, %.2e along "
           "the device-generated ones" % (mism_same, mism_own))
     assert mism_same <= 1e-4 and mism_own <= 1e-2

@@ -21,6 +21,8 @@ if ACTIVE is not None:
     keep[ACTIVE] = 1.0
     gF = gF * keep
     gD = torch.zeros_like(gD)                     # (the depth image carries no loss term in stage 2)
+    if os.environ.get("NODEPTH"):
+        gD = empty                                # ... and the fused iterations say so: no depth gradient at all
 L.r3dg_profile_enable(1)
 for name in _lib.OPTIONS:                                # R3DG_OPT_<NAME>=<value>, e.g. R3DG_OPT_CULL=0
     if os.environ.get("R3DG_OPT_" + name):
