@@ -42,8 +42,23 @@ __global__ void transpose_reduce_selftest_kernel(const float* __restrict__ in, f
     owner_out[threadIdx.x] = transposed_owner<N>(threadIdx.x) ? 1 : 0;
 }
 
+__global__ void transpose_reduce12_selftest_kernel(const float* __restrict__ in, float* __restrict__ out, int* __restrict__ chan_out,
+                                                   int* __restrict__ owner_out)
+{
+    float v[12];
+#pragma unroll
+    for (int k = 0; k < 12; k++) v[k] = in[threadIdx.x * 12 + k];
+    out[threadIdx.x] = transpose_reduce12(v);
+    chan_out[threadIdx.x] = transposed_channel12(threadIdx.x);
+    owner_out[threadIdx.x] = transposed_owner12(threadIdx.x) ? 1 : 0;
+}
+
 void launch_transpose_selftest(hipStream_t s, int N, int dpp, const float* in, float* out, int* chan, int* owner)
 {
+    if (N == 12) {
+        transpose_reduce12_selftest_kernel<<<1, 64, 0, s>>>(in, out, chan, owner);
+        return;
+    }
 #define R3DG_ST(NN)                                                                              \
     if (dpp) transpose_reduce_selftest_kernel<NN, true><<<1, 64, 0, s>>>(in, out, chan, owner);  \
     else transpose_reduce_selftest_kernel<NN, false><<<1, 64, 0, s>>>(in, out, chan, owner);
@@ -141,9 +156,11 @@ render_backward_wave_kernel(const uint2* __restrict__ ranges, const uint32_t* __
     const uint2 range = ranges[tile];
 
     // the lane that owns channel `chan` after the transposing reduction adds it to word `chan` of the Gaussian's record
-    const int chan = transposed_channel<NVP>(lane);
+    constexpr bool R12 = NV == 12;                         // exactly twelve channels: the 25-instruction reduction (wave_reduce.hpp)
+    const int chan = R12 ? transposed_channel12(lane) : transposed_channel<NVP>(lane);
+    const bool owner = R12 ? transposed_owner12(lane) : transposed_owner<NVP>(lane);
     float* dst_base = nullptr;
-    if (transposed_owner<NVP>(lane) && (chan < V_FEAT || (chan - V_FEAT < SA && chan - V_FEAT < NF))) dst_base = grad_records + chan;
+    if (owner && (chan < V_FEAT || (chan - V_FEAT < SA && chan - V_FEAT < NF))) dst_base = grad_records + chan;
 
     const bool inside = px < W && py < H;
     const size_t pix = (size_t)py * W + px;
@@ -344,10 +361,18 @@ render_backward_wave_kernel(const uint2* __restrict__ ranges, const uint32_t* __
                 v[V_CONIC + 1] = mdx * dy;
                 v[V_CONIC + 2] = mdy * dy;
                 v[V_OPAC] = t9;
-                float vr[NVP];
+                float total;
+                if constexpr (R12) {
+                    float vr[12];
 #pragma unroll
-                for (int q = 0; q < NVP; q++) vr[q] = v[q];
-                const float total = transpose_reduce<NVP, true>(vr);
+                    for (int q = 0; q < 12; q++) vr[q] = v[q];
+                    total = transpose_reduce12(vr);
+                } else {
+                    float vr[NVP];
+#pragma unroll
+                    for (int q = 0; q < NVP; q++) vr[q] = v[q];
+                    total = transpose_reduce<NVP, true>(vr);
+                }
                 if (dst_base != nullptr) atomicAdd(dst_base + (size_t)__float_as_uint(g1.w) * NVP, total);
             }
             g0 = g0n;
@@ -360,10 +385,12 @@ render_backward_wave_kernel(const uint2* __restrict__ ranges, const uint32_t* __
     }
 }
 
-// Record -> output arrays (see render_backward_wave_kernel): thread per Gaussian, the NVP-float record in as float4s (and zeros
-// back: the scratch is zero between calls), every element of the five arrays written -- the caller's zero fill of the atomically
-// accumulated outputs is no longer needed (it does no harm: `=`, not `+=`).  NVP / LEAN / NF as the tile kernel that filled the
-// records was instantiated.
+// Record -> output arrays (see render_backward_wave_kernel).  A workgroup takes 256 consecutive Gaussians: their records come in
+// as one contiguous run of float4s (and zeros go back: the scratch is zero between calls) into LDS, rows padded to NVP + 1 words;
+// then each output array's slice of the workgroup -- contiguous in memory -- is written by consecutive threads (the first version,
+// one thread per Gaussian with 64-byte strides between the lanes of every load and store, took 28 us for 56 MB).  Every element of
+// the five arrays is written: the caller's zero fill of the formerly atomically accumulated outputs is no longer needed.
+// NVP / LEAN / NF as the tile kernel that filled the records was instantiated.
 template <int NVP, bool LEAN>
 __global__ void __launch_bounds__(256)
 render_backward_scatter_kernel(int P, int S, int NF, ChannelList chan_list, float4* __restrict__ grad_records,
@@ -371,41 +398,48 @@ render_backward_scatter_kernel(int P, int S, int NF, ChannelList chan_list, floa
                                float* __restrict__ dL_dcolors, float* __restrict__ dL_dfeature)
 {
     constexpr int V_CONIC = LEAN ? 5 : 6, V_OPAC = V_CONIC + 3, V_FEAT = V_OPAC + 1;
-    const int g = blockIdx.x * 256 + threadIdx.x;
-    if (g >= P) return;
-    float v[NVP];
-    float4* rec = grad_records + (size_t)g * (NVP / 4);
-#pragma unroll
-    for (int q = 0; q < NVP / 4; q++) {
-        const float4 t = rec[q];
-        v[4 * q] = t.x; v[4 * q + 1] = t.y; v[4 * q + 2] = t.z; v[4 * q + 3] = t.w;
-    }
-#pragma unroll
-    for (int q = 0; q < NVP / 4; q++) rec[q] = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-    for (int c = 0; c < 3; c++) dL_dcolors[3 * (size_t)g + c] = v[c];
-    dL_dmean2D[3 * (size_t)g] = v[3];
-    dL_dmean2D[3 * (size_t)g + 1] = v[4];
-    dL_dmean2D[3 * (size_t)g + 2] = LEAN ? 0.f : v[5];
-    dL_dconic2D[4 * (size_t)g] = v[V_CONIC];                      // (scalar stores: the caller's slab need not be 16-byte aligned)
-    dL_dconic2D[4 * (size_t)g + 1] = v[V_CONIC + 1];
-    dL_dconic2D[4 * (size_t)g + 2] = 0.f;
-    dL_dconic2D[4 * (size_t)g + 3] = v[V_CONIC + 2];
-    dL_dopacity[g] = v[V_OPAC];
-    if (S > 0) {
-        float* row = dL_dfeature + (size_t)g * S;
+    constexpr int LD = NVP + 1;                                   // odd row stride: conflict-free column walks
+    __shared__ float s_v[256 * LD];
+    __shared__ int s_col[R3DG_MAX_S_BWD];                         // feature column -> record channel, or -1 (written as zero)
+    const int tid = threadIdx.x;
+    const int g0 = blockIdx.x * 256;
+    const int ng = min(256, P - g0);
+    if (tid < R3DG_MAX_S_BWD) s_col[tid] = -1;
+    __syncthreads();
+    {
         const int n = chan_list.n < NF ? chan_list.n : NF;
-        if (chan_list.identity) {
-            // every channel is live and in order: channel j is feature j (n == S)
+        if (tid < n && tid < NVP - V_FEAT) s_col[chan_list.identity ? tid : chan_list.c[tid]] = V_FEAT + tid;
+    }
+    float4* rec = grad_records + (size_t)g0 * (NVP / 4);
+    constexpr int Q = NVP / 4;                                    // float4s per record
 #pragma unroll
-            for (int j = 0; j < NVP - V_FEAT; j++)
-                if (j < n) row[j] = v[V_FEAT + j];
-        } else {
-            for (int c = 0; c < S; c++) row[c] = 0.f;
-#pragma unroll
-            for (int j = 0; j < NVP - V_FEAT; j++)
-                if (j < n) row[chan_list.c[j]] = v[V_FEAT + j];
+    for (int i = 0; i < Q; i++) {
+        const int e = tid + 256 * i;                              // float4 index inside the workgroup's run
+        if (e < ng * Q) {
+            const float4 t = rec[e];
+            rec[e] = make_float4(0.f, 0.f, 0.f, 0.f);
+            float* d = s_v + (e / Q) * LD + 4 * (e % Q);
+            d[0] = t.x; d[1] = t.y; d[2] = t.z; d[3] = t.w;
         }
+    }
+    __syncthreads();
+    // dL_dcolors [ng,3]
+    for (int e = tid; e < 3 * ng; e += 256) dL_dcolors[3 * (size_t)g0 + e] = s_v[(e / 3) * LD + e % 3];
+    // dL_dmean2D [ng,3]: S_x, S_y, depth side channel
+    for (int e = tid; e < 3 * ng; e += 256) {
+        const int c = e % 3;
+        dL_dmean2D[3 * (size_t)g0 + e] = (c == 2 && LEAN) ? 0.f : s_v[(e / 3) * LD + 3 + c];
+    }
+    // dL_dconic [ng,4]: S_xx, S_xy, -, S_yy
+    for (int e = tid; e < 4 * ng; e += 256) {
+        const int c = e & 3;
+        dL_dconic2D[4 * (size_t)g0 + e] = c == 2 ? 0.f : s_v[(e >> 2) * LD + V_CONIC + (c == 3 ? 2 : c)];
+    }
+    if (tid < ng) dL_dopacity[g0 + tid] = s_v[tid * LD + V_OPAC];
+    // dL_dfeature [ng,S]
+    for (int e = tid; e < S * ng; e += 256) {
+        const int col = s_col[e % S];
+        dL_dfeature[(size_t)g0 * S + e] = col < 0 ? 0.f : s_v[(e / S) * LD + col];
     }
 }
 

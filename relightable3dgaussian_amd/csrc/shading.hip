@@ -18,6 +18,7 @@
 //   * backward only: record + samples of the wave's NEXT 64-sample block arrive by LDS-DMA (global_load_lds_dwordx4),
 //     double buffered, while the current block is computed (three passes per block, 12 parked floats per lane).
 #include "common.hpp"
+#include <cmath>
 #include <cstdlib>
 #include <map>
 #include <mutex>
@@ -1332,6 +1333,20 @@ void launch_shade_frs_backward_rotate(hipStream_t s, int P, const float* ray_nor
     if (P == 0) return;
     frs_rotate_kernel<true><<<(P + 255) / 256, 256, 0, s>>>(P, ray_normals, dcp, d_inc, valid);
     check_launch(s, false, "frs_rotate_kernel");
+}
+
+void launch_shade_frs_incident_chain(hipStream_t s, int P, const float* ray_normals, const uint8_t* valid, const float* dcp,
+                                     float* d_inc, float* incidents, float* exp_avg, float* exp_avg_sq, float* cprime, float lr,
+                                     float lr_tail, float beta1, float beta2, float eps, int step, float grad_scale,
+                                     const float* skip_flag)
+{
+    if (P == 0) return;
+    // (bias corrections exactly as launch_adam forms them, stage2_glue.hip)
+    const double b1 = 1.0 - pow((double)beta1, (double)step), b2 = 1.0 - pow((double)beta2, (double)step);
+    FrsAdam a = {lr, lr_tail, beta1, beta2, eps, (float)b1, (float)(1.0 / sqrt(b2)), grad_scale};
+    frs_incident_chain_kernel<<<(P + 255) / 256, 256, 0, s>>>(P, ray_normals, valid, dcp, d_inc, incidents, exp_avg, exp_avg_sq,
+                                                              cprime, a, skip_flag);
+    check_launch(s, false, "frs_incident_chain_kernel");
 }
 
 void launch_shade_frs_backward_listed(hipStream_t s, int K, const float* base_color, const float* roughness,

@@ -133,6 +133,46 @@ __device__ __forceinline__ float transpose_reduce(float (&v)[N])
     return r;
 }
 
+// ---- twelve channels ------------------------------------------------------------------------------------------------------
+// The tile backward's lean instances carry 12 gradient channels (3 colour, 2 + 3 geometry moments, 1 opacity, 3 features).  Padded
+// to 16 the generic reduction spends 15 pair steps (two instructions each) + 2 butterflies; twelve need only 11 pair steps when the
+// levels split 12 -> 6 -> 3 -> (2 + 1) -> 1:
+//   D = 32  permlane32_swap: pairs (c, c + 6); lanes with bit 5 clear keep channels 0..5, the others 6..11      6 x (swap, add)
+//   D = 16  permlane16_swap: pairs (j, j + 3) of the six; bit 4 picks the first or the last three               3 x (swap, add)
+//   D = 8   the first two of the three as one banked-DPP transposing step (bit 3 picks), the third one as a plain butterfly
+//           (row_ror:8 = lane ^ 8 inside a 16-lane row, folded into the add)                                     2 + 1
+//   D = 4   (that pair's value, the third one) as one banked-DPP transposing step: bit 2 picks                  2
+//   D = 2, 1  plain butterflies                                                                                  1 + 1
+// 25 VALU instructions instead of ~37.  chan(lane) = 6 b5 + 3 b4 + (b2 ? 2 : b3); the total of a channel sits in four lanes
+// (bits 1, 0 free) -- and for the "third" channels in eight (bit 3 free too): the OWNER is the one with those bits clear.
+__device__ __forceinline__ int transposed_channel12(int lane)
+{
+    return 6 * ((lane >> 5) & 1) + 3 * ((lane >> 4) & 1) + ((lane & 4) ? 2 : ((lane >> 3) & 1));
+}
+__device__ __forceinline__ bool transposed_owner12(int lane) { return (lane & 3) == 0 && !((lane & 4) && (lane & 8)); }
+
+__device__ __forceinline__ float transpose_reduce12(float (&v)[12])
+{
+    float u[6], w[3];
+#pragma unroll
+    for (int c = 0; c < 6; c++) {
+        auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v[c]), __float_as_uint(v[c + 6]), false, false);
+        u[c] = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+    }
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+        auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(u[c]), __float_as_uint(u[c + 3]), false, false);
+        w[c] = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+    }
+    const float x = transpose_step_banked<8>(w[0], w[1]);
+    float y;
+    asm("s_nop 1\n\tv_add_f32_dpp %0, %1, %1 row_ror:8 row_mask:0xf bank_mask:0xf" : "=v"(y) : "v"(w[2]));
+    float z = transpose_step_banked<4>(x, y);
+    z += lane_xor_dpp<2>(z);
+    z += lane_xor_dpp<1>(z);
+    return z;
+}
+
 // ---- the same within each HALF-wave (32 lanes): lanes 0..31 and 32..63 reduce independent value sets --------------------
 // N (power of two, 2..32) values per lane; every lane ends with the 32-lane total of channel
 // chan(lane) = sum_t bit_{4-t}(lane) * (N >> (t+1)), t < log2 N; exchange distances 16, 8, 4, 2, 1 (no distance-32 level).

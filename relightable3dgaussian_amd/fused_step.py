@@ -368,7 +368,7 @@ class FusedStage2Step(_BoundedForward):
         self.world, self.dp = _world_of(process_group)
         # tuning options of THIS object (include/r3dg_hip.h "option contexts"): every library call of the step runs inside it
         self._ctx = _lib.OptionContext()
-        self._stagger = os.environ.get("R3DG_FWD_STAGGER", "1") != "0"      # (see forward_backward: where the two tiny launches go)
+        self._stagger = os.environ.get("R3DG_FWD_STAGGER", "1")             # (see forward_backward: where the small launches go)
         # feature rows without a pack kernel: the activations write the columns they own, the fixed-ray-set shading kernels
         # theirs (r3dg_shade_frs_forward d_feature_rows) -- one launch and its join less between the shading integral and the
         # rasterizer.  The general shading kernels keep r3dg_stage2_pack_features.
@@ -405,6 +405,8 @@ class FusedStage2Step(_BoundedForward):
         # in the ray set were computed FROM, when that was done ahead of the next iteration; work still running on the early stream
         self._pre_rotated = None
         self._defer_b = os.environ.get("R3DG_EARLY_INCIDENTS", "1") != "0"
+        self._chain_kernel = os.environ.get("R3DG_INCIDENT_CHAIN_KERNEL", "1") != "0"   # (A/B: one kernel or three launches)
+        self._leave_room = os.environ.get("R3DG_SHADE_LEAVE_ROOM", "1") != "0"      # (A/B: one workgroup per CU for the shading forward)
         self.opt = FusedAdam([
             dict(param=self.xyz, lr=rate("xyz")), dict(param=self.normal, lr=rate("normal")),
             dict(param=self.scaling, lr=rate("scaling")), dict(param=self.rotation, lr=rate("rotation")),
@@ -557,25 +559,30 @@ class FusedStage2Step(_BoundedForward):
                 with torch.cuda.stream(aux):
                     if not self._rotation_is_current():
                         self._frs.rotate(self._incidents)
-                    # (also on the side stream, BEHIND the rotation.  Measured: with these two tiny launches on the main stream the
-                    # shading forward starts ~20 us earlier, inside the projection, and the step loses 15-20 it/s; gating the
-                    # shading forward on the projection's end with an event loses 12.  The persistent forward and the front
-                    # end's kernels share the CUs best with this stagger.)
-                    if self._stagger:
-                        env_c = F.softplus(self.env)[0]                          # DirectLightMap.get_env
-                        self.sums.zero_()
-                    # the zero fill of the backward's atomic accumulators (32 MB at 300k Gaussians) sat between the loss and the
-                    # tile backward, alone on the device (8 us); here it runs beside the activations / the projection.  (The slab
-                    # is this iteration's own: the previous one's consumers ran on the main / this stream, both behind us now.)
-                    acc_n = (11 + 16) * P
-                    if self._acc is None or self._acc.numel() != acc_n:
-                        self._acc = torch.empty(acc_n, dtype=torch.float32, device=dev)
-                    self._acc.zero_()
-                    acc_ready = True
                 rotated_for = self._frs
-            if aux is not None and not self._stagger:
-                env_c = F.softplus(self.env)[0]
+            # The small view-independent launches of the iteration -- softplus of the texture, the loss-sum reset, the zero fill of
+            # the tile backward's accumulator slab (32 MB at 300k Gaussians; it used to sit between the loss and the tile backward,
+            # alone on the device) -- go to the MAIN stream behind the front end's launches (`small_launches` below): the main stream
+            # has nothing to do there but wait for the early stream, and they run beside the projection and the tail of the
+            # incident-light chain.  R3DG_FWD_STAGGER=aux: on the early stream behind the rotation (rounds 3-4: with the main
+            # stream otherwise idle until the rotation was done that made the shading forward start inside the instance ordering
+            # instead of inside the projection); =0: on the main stream in front of the activations.
+            acc_n = (11 + 16) * P
+            if self._acc is None or self._acc.numel() != acc_n:
+                self._acc = torch.empty(acc_n, dtype=torch.float32, device=dev)
+
+            def small_launches():
+                env = F.softplus(self.env)[0]                                    # DirectLightMap.get_env
                 self.sums.zero_()
+                self._acc.zero_()
+                return env
+            env_c = None
+            if aux is not None and self._stagger == "aux":
+                with torch.cuda.stream(aux):
+                    env_c = small_launches()
+            elif self._stagger == "0":
+                env_c = small_launches()
+            acc_ready = True
             self.refresh_activations(cam)
             self._iter += 1
             use_bounded = self._use_bounded(W, H)
@@ -602,10 +609,9 @@ class FusedStage2Step(_BoundedForward):
                     True, False, want_weights=False)       # (stage 2 does not densify: nobody reads the blend weights)
             if self._pending_b is not None:
                 self.flush()    # (world > 1) the previous iteration's incident-light update lands here
-            if aux is None:
-                self.sums.zero_()
-                env_c = F.softplus(self.env)[0]                                  # DirectLightMap.get_env
-            else:
+            if env_c is None:
+                env_c = small_launches()
+            if aux is not None:
                 _lib.stream_wait(main, aux)
                 self._early_pending = False          # (aux IS the early stream: the main stream is behind all of it now)
             He, We = env_c.shape[0], env_c.shape[1]
@@ -617,7 +623,7 @@ class FusedStage2Step(_BoundedForward):
                                   # (one workgroup per CU beside the instance ordering, which is the longer path -- unless the
                                   # deferred incident-light update of a data-parallel run sits in front of this kernel: then this
                                   # path is the longer one and takes every CU it can get: 558 -> 568 it/s on one rank)
-                                  leave_room=order_stream is not None and not self.dp,
+                                  leave_room=order_stream is not None and not self.dp and self._leave_room,
                                   # the few hundred Gaussians off the rotated path: their general kernel on the (idle) early-Adam
                                   # stream beside the rotation and the main kernel, joined below before the features are packed
                                   listed_stream=self._listed_stream(), rotated=rotated,
@@ -789,6 +795,9 @@ class FusedStage2Step(_BoundedForward):
             if self._d_env is None or self._d_env.shape != env_c.shape:
                 self._d_env = torch.zeros_like(env_c)
             if self._frs is not None:
+                # (incident-light chain as ONE kernel -- rotation back, Adam, rotation of the new coefficients: the main shading
+                # backward then leaves the coefficient gradient in the rotated frame)
+                chain = self._early and self._b_early and self._chain_kernel and len(self._groups_b) == 1
                 d_base, d_rough, d_view, _d_inc, d_env = self._frs.backward(
                     self.a_base, self.a_rough, self.a_normal, self.a_viewdirs, self._incidents, env_c, self.visibility,
                     self.d_pbr, self.d_diffuse,
@@ -797,12 +806,22 @@ class FusedStage2Step(_BoundedForward):
                     # whole iterations: the rotation back of the coefficient gradient goes to the stream that already carries the
                     # SH group's early Adam (optimizer_step joins it before any Adam launch reads the gradient; under data
                     # parallelism bucket B's all-reduce is issued from it) and runs beside the activation chain rule
-                    rotate_stream=self._early_stream if self._early else None)
+                    rotate_stream=self._early_stream if self._early else None, rotation_back=not chain)
                 if self._early and self._b_early:
+                    if chain:
+                        _lib.stream_wait(self._early_stream, main)          # behind the main shading backward
                     with torch.cuda.stream(self._early_stream):
-                        if self._groups_b:
-                            self.opt.step_groups(self._groups_b, [self.grads[k] for k in self._opt_order], skip_flag=self._flag_b)
-                        self._frs.rotate(self._incidents)
+                        if chain:
+                            grp = self.opt.groups[self._groups_b[0]]
+                            self._frs.incident_chain(
+                                self._incidents, self.grads["incidents"], grp["exp_avg"], grp["exp_avg_sq"], grp["lr"],
+                                grp.get("lr_tail") if grp.get("lr_tail") is not None else grp["lr"], self.opt.betas,
+                                self.opt.eps, self.opt.step_count, 1.0, skip_flag=self._flag_b)
+                        else:
+                            if self._groups_b:
+                                self.opt.step_groups(self._groups_b, [self.grads[k] for k in self._opt_order],
+                                                     skip_flag=self._flag_b)
+                            self._frs.rotate(self._incidents)
                     self._pre_rotated = (self._frs, self._incidents, self._incidents._version)
             else:
                 d_base, d_rough, d_view, _d_inc, d_env = shading_ops.shade_backward(

@@ -605,7 +605,7 @@ def test_cull_is_exact(name, hip_lib):
     assert torch.allclose(a[8], b[8], rtol=1e-5, atol=1e-6)
 
 
-@pytest.mark.parametrize("N", [16, 32, 64])
+@pytest.mark.parametrize("N", [12, 16, 32, 64])
 @pytest.mark.parametrize("dpp", [0, 1])
 def test_transpose_reduce_selftest(N, dpp, hip_lib):
     from relightable3dgaussian_amd import _lib

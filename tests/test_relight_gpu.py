@@ -227,7 +227,9 @@ def test_relight_frames_match_the_reference_python(cache, regenerate_dirs):
     # cancelling formula for the other -- an ulp of the normal is a different frame there, as in tests/test_reference_pipeline_gpu.py;
     # their rows are compared through the fixture's own directions only)
     n_cpu = torch.nn.functional.normalize(torch.from_numpy(z["raw_normal"]), dim=-1, eps=1e-3)
-    regular = ((n_cpu[:, 2] + 1).abs() > 1e-6).to(DEV)
+    # (... and next to -z the frame is the ill-conditioned (1 + n_z) formula: within 2.5 degrees of the pole -- the rows the
+    # fixed-ray-set classification also sets aside -- the two direction sets differ by up to 7e-4)
+    regular = (n_cpu[:, 2] > -0.999).to(DEV)
     assert int((~regular).sum()) <= 64          # (the synthetic scene plants a few per cent of its normals on -z)
     ok, msg = report("incident_dirs", r.incident_dirs[regular], dirs[regular], 0, 1e-4)
     assert ok, msg
@@ -244,7 +246,8 @@ def test_relight_frames_match_the_reference_python(cache, regenerate_dirs):
     msgs, ok_all = [], [True]
 
     def chk(name, got, want, rtol, atol):
-        ok, msg = report(name, got, torch.as_tensor(np.asarray(want)).reshape(got.shape), rtol, atol)
+        want = want.detach().cpu() if torch.is_tensor(want) else torch.as_tensor(np.asarray(want))
+        ok, msg = report(name, got, want.reshape(got.shape), rtol, atol)
         msgs.append(msg)
         ok_all[0] &= ok
 

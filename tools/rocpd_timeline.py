@@ -13,7 +13,7 @@ def main():
     n = int(sys.argv[2]) if len(sys.argv) > 2 else 10
     cur = sqlite3.connect(db).cursor()
     rows = list(cur.execute("select name, start, end from kernels order by start"))
-    marks = [i for i, r in enumerate(rows) if "r3dg::render_backward_" in r[0] and "features" not in r[0]]
+    marks = [i for i, r in enumerate(rows) if "r3dg::render_backward_wave" in r[0] or "r3dg::render_backward_kernel" in r[0]]
     marks = marks[-(n + 1):]
     if len(marks) < 2:
         print("not enough steps")
@@ -63,7 +63,7 @@ def sequence():
     cols = [r[1] for r in cur.execute("pragma table_info(kernels)")]
     qcol = "queue_id" if "queue_id" in cols else ("stream_id" if "stream_id" in cols else "0")
     rows = list(cur.execute("select name, start, end, %s from kernels order by start" % qcol))
-    marks = [i for i, r in enumerate(rows) if "r3dg::render_backward_" in r[0] and "features" not in r[0]]
+    marks = [i for i, r in enumerate(rows) if "r3dg::render_backward_wave" in r[0] or "r3dg::render_backward_kernel" in r[0]]
     # argv[3] = which step (0-based index into the render_backward launches; negative from the end).  Default: the step in the
     # MIDDLE of the run -- the last steps of a bench.py run are the one-stream pass that measures each kernel alone
     # (FusedStage2Step.serial_streams), not the pipelined iteration

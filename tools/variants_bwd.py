@@ -18,8 +18,10 @@ SRC = "rasterizer_render_bwd.hip"
 ATOMIC = "                if (dst_base != nullptr) atomicAdd(dst_base + (size_t)__float_as_uint(g1.w) * NVP, total);\n"
 VARIANTS = {
     "bwd_no_atomics": [(ATOMIC, "                if (dst_base != nullptr && total == 12345.678f) atomicAdd(dst_base, total);\n")],
-    "bwd_no_reduce": [("                const float total = transpose_reduce<NVP, true>(vr);\n",
-                       "                float total = vr[0];\n#pragma unroll\n                for (int q = 1; q < NVP; q++) total += vr[q];\n")],
+    "bwd_no_reduce": [("                    total = transpose_reduce12(vr);\n",
+                       "                    total = vr[0];\n#pragma unroll\n                    for (int q = 1; q < 12; q++) total += vr[q];\n")],
+    # the generic 16-wide reduction in the twelve-channel instance (what the custom one replaced)
+    "bwd_reduce16": [("    constexpr bool R12 = NV == 12; ", "    constexpr bool R12 = false; ")],
 }
 
 
