@@ -72,7 +72,6 @@ _SIGNATURES = {
     "r3dg_shade_frs_build_taps": (_i, [_p, _i, _i, _p, _p, _i, _i, _p]),
     "r3dg_shade_frs_forward": (_i, [_p, _i, _i] + [_p] * 6 + [_i, _i, _p, _f] + [_p] * 6 + [_i, _p, _i, _p, _p, _p]),
     "r3dg_shade_frs_backward": (_i, [_p, _i, _i] + [_p] * 6 + [_i, _i, _p, _f] + [_p] * 6 + [_i] + [_p] * 10 + [_i, _p]),
-    "r3dg_shade_frs_incident_chain": (_i, [_p, _i] + [_p] * 8 + [_f] * 5 + [_i, _f, _p]),
     "r3dg_shade_build_transport": (_i, [_p, _i, _i, _i, _p, _p, _p, _p, _p, _f, _p, _p]),
     "r3dg_shade_forward_transport": (_i, [_p, _i, _i] + [_p] * 9),
     "r3dg_shade_build_split": (_i, [_p, _i, _i] + [_p] * 6 + [_f, _p, _p, _p]),
@@ -157,7 +156,7 @@ def lib():
 
 # enum r3dg_option (include/r3dg_hip.h); tests/test_oracle_cpu.py checks the numbering against the header
 OPTIONS = ("TILE_ORDER", "CULL", "TILE_BINNING", "BINNING_BLOCK_K", "STAGE_SH_ROWS", "SHADE_FWD_BLOCKS_PER_CU", "TRACE_FORMULATION",
-           "TRACE_REFILL", "TRACE_NODE_WEIGHT", "TRACE_LEAF_WEIGHT", "RESERVE_CUS", "TRACE_COUNT_VISITS", "BWD_LEAN")
+           "TRACE_REFILL", "TRACE_NODE_WEIGHT", "TRACE_LEAF_WEIGHT", "RESERVE_CUS", "TRACE_COUNT_VISITS", "BWD_LEAN", "SORT_LONG_SIDE_STREAM")
 
 
 def set_option(name, value):

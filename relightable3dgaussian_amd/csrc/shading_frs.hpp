@@ -197,90 +197,6 @@ frs_rotate_kernel(int P, const float* __restrict__ ray_normals, const float* __r
     for (int q = 0; q < 12; q++) d4[q] = make_float4(row[4 * q], row[4 * q + 1], row[4 * q + 2], row[4 * q + 3]);
 }
 
-// ---- incident-light chain (round 5): rotation back + Adam + rotation forward in ONE pass ---------------------------------------
-// A whole single-GPU iteration ends, for the incident-light coefficients, with three HBM-bound passes over [P,16,3] rows in a row:
-//   frs_rotate_kernel<true>   dL/dc' -> dL/d incidents            (read 192, write 192 bytes per Gaussian)
-//   adam_kernel               p, g, m, v -> p, m, v               (read 768, write 576)
-//   frs_rotate_kernel<false>  incidents -> c' for the NEXT forward (read 192, write 192)
-// = 2112 bytes per Gaussian and three launches on the chain that decides when the next shading forward can start (179 us at 300k
-// Gaussians beside the other groups' Adam, profiles/r05_*_sequence.txt).  Here one thread per Gaussian keeps the row in registers:
-// dL/dc' in, gradient row out (it stays an output of the iteration), p / m / v in and out chunk by chunk, c' out: 1536 bytes.
-// The Adam arithmetic is adam_kernel's, statement for statement -- but this translation unit is built with -ffast-math (neither
-// `#pragma float_control` nor __fdiv_rn / __fsqrt_rn switch that off on this target: checked in the ISA), so its division and
-// square root are the 1-ulp v_rcp_f32 / v_sqrt_f32: the UPDATE term (lr x O(1)) differs from adam_kernel's by a few ulp of
-// itself, i.e. by ~1e-7 x lr on the parameter -- far below the run-to-run differences the float atomics of the backward already
-// cause.  Single-GPU whole iterations only (a data-parallel run applies the group's update with adam_kernel: replicas must
-// stay bit-identical).  The rotations are the very functions the two kernels above call, so c' has the bits
-// frs_rotate_kernel<false> would produce from the same parameters.
-// Gaussians off the rotated path (valid[g] == 0): their gradient row was written by the listed kernel in the world frame already
-// (read here instead of rotated), their c' row is not used by anybody (written anyway: same arithmetic as everywhere else).
-struct FrsAdam {
-    float lr, lr_tail, beta1, beta2, eps, bias1, inv_sqrt_bias2, grad_scale;
-};
-
-__device__ __forceinline__ void frs_adam_update(const FrsAdam& a, float lr, float& p, float g, float& m, float& v)
-{
-    g *= a.grad_scale;
-    m = m + (g - m) * (1.f - a.beta1);
-    v = a.beta2 * v + (1.f - a.beta2) * g * g;
-    const float denom = sqrtf(v) * a.inv_sqrt_bias2 + a.eps;
-    p -= (lr / a.bias1) * (m / denom);
-}
-
-__global__ void __launch_bounds__(256)
-frs_incident_chain_kernel(int P, const float* __restrict__ ray_normals, const uint8_t* __restrict__ valid,
-                          const float* __restrict__ dcprime, float* __restrict__ dL_dincidents, float* __restrict__ incidents,
-                          float* __restrict__ exp_avg, float* __restrict__ exp_avg_sq, float* __restrict__ cprime, FrsAdam adam,
-                          const float* __restrict__ skip_flag)
-{
-    // a frame the bounded forward dropped: no update (adam_kernel's rule) -- and then nothing here is needed: the parameters and
-    // therefore c' are unchanged, the gradient of a dropped frame is nobody's input
-    if (skip_flag != nullptr && *skip_flag != 0.0f) return;
-    const int g = blockIdx.x * 256 + (int)threadIdx.x;
-    if (g >= P) return;
-    const bool rotated = valid == nullptr || valid[g] != 0;
-    float row[48];
-    {
-        const float4* s4 = reinterpret_cast<const float4*>((rotated ? dcprime : dL_dincidents) + (size_t)g * 48);
-#pragma unroll
-        for (int q = 0; q < 12; q++) {
-            const float4 v = s4[q];
-            row[4 * q] = v.x; row[4 * q + 1] = v.y; row[4 * q + 2] = v.z; row[4 * q + 3] = v.w;
-        }
-    }
-    float R[9];
-    frs_rotation(ray_normals[3 * (size_t)g], ray_normals[3 * (size_t)g + 1], ray_normals[3 * (size_t)g + 2], R);
-    if (rotated) {
-        frs_rotate_band<1, 3, true>(R, kShRotPoints1, kShRotAinv1, row);
-        frs_rotate_band<4, 5, true>(R, kShRotPoints2, kShRotAinv2, row);
-        frs_rotate_band<9, 7, true>(R, kShRotPoints3, kShRotAinv3, row);
-        float4* d4 = reinterpret_cast<float4*>(dL_dincidents + (size_t)g * 48);
-#pragma unroll
-        for (int q = 0; q < 12; q++) d4[q] = make_float4(row[4 * q], row[4 * q + 1], row[4 * q + 2], row[4 * q + 3]);
-    }
-    // Adam, four parameters at a time; the new parameters take the gradient's place in `row`
-    float4* p4 = reinterpret_cast<float4*>(incidents + (size_t)g * 48);
-    float4* m4 = reinterpret_cast<float4*>(exp_avg + (size_t)g * 48);
-    float4* v4 = reinterpret_cast<float4*>(exp_avg_sq + (size_t)g * 48);
-#pragma unroll
-    for (int q = 0; q < 12; q++) {
-        float4 p = p4[q], m = m4[q], v = v4[q];
-        // columns 0..2 of a row are the dc coefficient (learning rate lr), the other 45 the rest (lr_tail): period 48, split 3
-        frs_adam_update(adam, 4 * q + 0 < 3 ? adam.lr : adam.lr_tail, p.x, row[4 * q + 0], m.x, v.x);
-        frs_adam_update(adam, 4 * q + 1 < 3 ? adam.lr : adam.lr_tail, p.y, row[4 * q + 1], m.y, v.y);
-        frs_adam_update(adam, 4 * q + 2 < 3 ? adam.lr : adam.lr_tail, p.z, row[4 * q + 2], m.z, v.z);
-        frs_adam_update(adam, 4 * q + 3 < 3 ? adam.lr : adam.lr_tail, p.w, row[4 * q + 3], m.w, v.w);
-        p4[q] = p; m4[q] = m; v4[q] = v;
-        row[4 * q] = p.x; row[4 * q + 1] = p.y; row[4 * q + 2] = p.z; row[4 * q + 3] = p.w;
-    }
-    frs_rotate_band<1, 3, false>(R, kShRotPoints1, kShRotAinv1, row);
-    frs_rotate_band<4, 5, false>(R, kShRotPoints2, kShRotAinv2, row);
-    frs_rotate_band<9, 7, false>(R, kShRotPoints3, kShRotAinv3, row);
-    float4* c4 = reinterpret_cast<float4*>(cprime + (size_t)g * 48);
-#pragma unroll
-    for (int q = 0; q < 12; q++) c4[q] = make_float4(row[4 * q], row[4 * q + 1], row[4 * q + 2], row[4 * q + 3]);
-}
-
 // texture [ntexel,3] -> LDS as float4 texels; two texels (six loads) in flight per thread -- as a plain loop the loads of one
 // texel are waited for before the next texel's are issued
 __device__ __forceinline__ void frs_stage_texture(const float* __restrict__ env, int ntexel, float4* s_env4)

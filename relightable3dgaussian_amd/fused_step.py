@@ -405,7 +405,6 @@ class FusedStage2Step(_BoundedForward):
         # in the ray set were computed FROM, when that was done ahead of the next iteration; work still running on the early stream
         self._pre_rotated = None
         self._defer_b = os.environ.get("R3DG_EARLY_INCIDENTS", "1") != "0"
-        self._chain_kernel = os.environ.get("R3DG_INCIDENT_CHAIN_KERNEL", "1") != "0"   # (A/B: one kernel or three launches)
         self._leave_room = os.environ.get("R3DG_SHADE_LEAVE_ROOM", "1") != "0"      # (A/B: one workgroup per CU for the shading forward)
         self.opt = FusedAdam([
             dict(param=self.xyz, lr=rate("xyz")), dict(param=self.normal, lr=rate("normal")),
@@ -556,8 +555,8 @@ class FusedStage2Step(_BoundedForward):
             aux = self._aux_stream()
             if aux is not None:
                 _lib.stream_wait(aux, main)
-                with torch.cuda.stream(aux):
-                    if not self._rotation_is_current():
+                if not self._rotation_is_current():          # (normally done at the end of the previous iteration: see below)
+                    with torch.cuda.stream(aux):
                         self._frs.rotate(self._incidents)
                 rotated_for = self._frs
             # The small view-independent launches of the iteration -- softplus of the texture, the loss-sum reset, the zero fill of
@@ -795,9 +794,6 @@ class FusedStage2Step(_BoundedForward):
             if self._d_env is None or self._d_env.shape != env_c.shape:
                 self._d_env = torch.zeros_like(env_c)
             if self._frs is not None:
-                # (incident-light chain as ONE kernel -- rotation back, Adam, rotation of the new coefficients: the main shading
-                # backward then leaves the coefficient gradient in the rotated frame)
-                chain = self._early and self._b_early and self._chain_kernel and len(self._groups_b) == 1
                 d_base, d_rough, d_view, _d_inc, d_env = self._frs.backward(
                     self.a_base, self.a_rough, self.a_normal, self.a_viewdirs, self._incidents, env_c, self.visibility,
                     self.d_pbr, self.d_diffuse,
@@ -806,22 +802,16 @@ class FusedStage2Step(_BoundedForward):
                     # whole iterations: the rotation back of the coefficient gradient goes to the stream that already carries the
                     # SH group's early Adam (optimizer_step joins it before any Adam launch reads the gradient; under data
                     # parallelism bucket B's all-reduce is issued from it) and runs beside the activation chain rule
-                    rotate_stream=self._early_stream if self._early else None, rotation_back=not chain)
+                    rotate_stream=self._early_stream if self._early else None)
                 if self._early and self._b_early:
-                    if chain:
-                        _lib.stream_wait(self._early_stream, main)          # behind the main shading backward
+                    # incident-light chain, behind the rotation back: the group's Adam, then the rotation of the NEW coefficients.
+                    # (As ONE kernel -- rotation back + Adam + rotation forward, thread per Gaussian, 1536 instead of 2112 bytes per
+                    # Gaussian -- this took 300 us against the three launches' 179: eight 192-byte row streams per lane with 64-byte
+                    # strides between lanes saturate the address unit, see DESIGN.md section 7.  Measured, deleted.)
                     with torch.cuda.stream(self._early_stream):
-                        if chain:
-                            grp = self.opt.groups[self._groups_b[0]]
-                            self._frs.incident_chain(
-                                self._incidents, self.grads["incidents"], grp["exp_avg"], grp["exp_avg_sq"], grp["lr"],
-                                grp.get("lr_tail") if grp.get("lr_tail") is not None else grp["lr"], self.opt.betas,
-                                self.opt.eps, self.opt.step_count, 1.0, skip_flag=self._flag_b)
-                        else:
-                            if self._groups_b:
-                                self.opt.step_groups(self._groups_b, [self.grads[k] for k in self._opt_order],
-                                                     skip_flag=self._flag_b)
-                            self._frs.rotate(self._incidents)
+                        if self._groups_b:
+                            self.opt.step_groups(self._groups_b, [self.grads[k] for k in self._opt_order], skip_flag=self._flag_b)
+                        self._frs.rotate(self._incidents)
                     self._pre_rotated = (self._frs, self._incidents, self._incidents._version)
             else:
                 d_base, d_rough, d_view, _d_inc, d_env = shading_ops.shade_backward(

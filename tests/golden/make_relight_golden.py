@@ -54,6 +54,15 @@ def main():
 
     P, W, H, K = 1200, 96, 64, 32
     raw, _, _, _, _ = mp.make_inputs(P, 96, seed=47, stage2=True)
+    # The synthetic scene plants a few per cent of its normals exactly on -z.  There rotation_between_z (sh_utils.py:36-68) is
+    # discontinuous in the last bit of the normal (n_z + 1 <= 0 -> -I, else a formula that cancels): a renderer whose normalize
+    # differs from torch's by an ulp builds a different -- equally valid -- ray frame for those Gaussians, and a frame-level
+    # fixture cannot pin that.  (The behaviour on and next to -z is pinned where it can be: tests/golden/fibonacci_reference.npz,
+    # shading_reference_frs.npz.)  Here those normals are tilted away from the pole.
+    n = torch.nn.functional.normalize(raw["normal"], dim=-1)
+    pole = n[:, 2] < -0.97
+    raw["normal"][pole, 0] += 0.6 * raw["normal"][pole].norm(dim=-1)
+    assert float(torch.nn.functional.normalize(raw["normal"], dim=-1)[:, 2].min()) > -0.97
     cam = syn.look_at_camera((4.0, -1.9, 2.3), width=W, height=H)         # (far enough for the environment to show)
     pc = mp.to_model(GaussianModel, raw, True)
     g = torch.Generator().manual_seed(4711)

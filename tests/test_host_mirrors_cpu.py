@@ -799,8 +799,6 @@ def test_fused_stage2_iteration_spreads_the_fixed_ray_set_path_over_three_stream
         events.append(("main.wait_event", ()))
     main.wait_event = wait_event
 
-    rotation_flags = []
-
     class FakeRaySet:
         n_invalid = 2
 
@@ -814,14 +812,9 @@ def test_fused_stage2_iteration_spreads_the_fixed_ray_set_path_over_three_stream
             events.append(("frs.forward", (listed_stream, rotated, leave_room)))
             rows.append(feature_rows)
 
-        def backward(self, *a, uniform_area=None, out_incidents=None, out_env=None, block_absmax=None, rotate_stream=None,
-                     rotation_back=True):
+        def backward(self, *a, uniform_area=None, out_incidents=None, out_env=None, block_absmax=None, rotate_stream=None):
             events.append(("frs.backward", (rotate_stream,)))
-            rotation_flags.append(rotation_back)
             return z(P, 3), z(P, 1), z(P, 3), out_incidents, out_env
-
-        def incident_chain(self, incidents, grad, m, v, lr, lr_tail, betas, eps, step, grad_scale=1.0, skip_flag=None):
-            events.append(("frs.incident_chain", (step, lr, lr_tail)))
 
     monkeypatch.setattr(_lib, "lib", lambda: Recorder())
     monkeypatch.setattr(_lib, "current_stream", lambda: 0)
@@ -872,15 +865,13 @@ def test_fused_stage2_iteration_spreads_the_fixed_ray_set_path_over_three_stream
     it, args = [e[0] for e in events[marks[2]:]], [e[1] for e in events[marks[2]:]]
     pos = {n: it.index(n) for n in ("r3dg_stage2_activate", "raster.begin", "frs.forward",
                                     "raster.finish", "raster.backward", "r3dg_stage2_unpack_gradients", "frs.backward",
-                                    "frs.incident_chain", "r3dg_stage2_activate_backward")}
+                                    "frs.rotate", "r3dg_stage2_activate_backward")}
     assert sorted(pos, key=pos.get) == ["r3dg_stage2_activate", "raster.begin", "frs.forward", "raster.finish", "raster.backward",
-                                        "r3dg_stage2_unpack_gradients", "frs.backward", "frs.incident_chain",
+                                        "r3dg_stage2_unpack_gradients", "frs.backward", "frs.rotate",
                                         "r3dg_stage2_activate_backward"]
-    # the coefficient rotation is NOT at the top of the iteration any more, nor a launch of its own: the previous iteration's
-    # incident-light chain kernel (rotation back + Adam + rotation of the new coefficients, on the early stream) left the ray set
-    # holding the rotation of the current coefficients; the main shading backward was told to leave the gradient in the rotated frame
-    assert "frs.rotate" not in it and step._rotation_is_current() and rotation_flags[-1] is False
-    assert args[pos["frs.incident_chain"]][0] == step.opt.step_count == 3         # Adam's step count, learning rates of the group
+    # the coefficient rotation is NOT at the top of the iteration any more: the previous iteration queued it on the early stream
+    # behind the incident-light group's Adam, and the ray set still holds the rotation of the current coefficients
+    assert it.count("frs.rotate") == 1 and step._rotation_is_current()
     # no pack kernel on this path: the activations and the shading kernels write the feature rows between them, and the
     # light-smoothness sum comes from the unpack kernel (its last argument)
     assert "r3dg_stage2_pack_features" not in it and rows[-1] is step.features
@@ -893,23 +884,26 @@ def test_fused_stage2_iteration_spreads_the_fixed_ray_set_path_over_three_stream
     main_joins = [i for i, a in joins if a == (main.cuda_stream, early.cuda_stream)]
     assert len(main_joins) == 2 and pos["raster.begin"] < main_joins[0] < pos["frs.forward"] < main_joins[1] < pos["raster.finish"]
     # the ordering stream (next projection reads the SH colour coefficients) is ordered behind the SH group's Adam when that is
-    # queued -- before the chain kernel goes to the early stream; the early stream is ordered behind the main shading backward
+    # queued -- before the rotation back, the incident-light group's Adam and the next rotation go to the early stream
     order_joins = [i for i, a in joins if a == (order_stream.cuda_stream, early.cuda_stream)]
-    early_joins = [i for i, a in joins if a == (early.cuda_stream, main.cuda_stream)]
     adam = [i for i, n in enumerate(it) if n == "r3dg_adam_step"]
-    assert len(order_joins) == 1 and len(adam) == 2 and len(early_joins) == 2
-    assert adam[0] < order_joins[0] < pos["frs.backward"] < early_joins[1] < pos["frs.incident_chain"] < adam[1]
+    assert len(order_joins) == 1 and len(adam) == 3
+    assert adam[0] < order_joins[0] < pos["frs.backward"] < adam[1] < pos["frs.rotate"] < adam[2]
     assert args[pos["raster.begin"]] == (order_stream,) and args[pos["raster.finish"]] == (order_stream,)
     listed, rotated, leave_room = args[pos["frs.forward"]]
     assert listed is early and rotated is True and leave_room is True
     assert geometry_streams[-1] is early                                       # geometry backward beside the listed backward
+    assert args[pos["frs.backward"]] == (early,)                               # rotation back on the same stream
     assert "main.wait_event" in it[pos["frs.backward"]:pos["r3dg_stage2_activate_backward"]]     # geometry joined by its event
     assert "torch.wait_stream" not in it                                       # no per-call event objects on the hot path
-    # Adam: the SH group inside the early stream's context (the incident-light group's is inside the chain kernel, there too),
-    # the other groups on the main stream
+    # Adam: the SH group and the incident-light group inside the early stream's context, the other groups on the main stream
     assert it[adam[0] - 1] == "enter" and args[adam[0] - 1] == (early.cuda_stream,)
-    assert it[pos["frs.incident_chain"] - 1] == "enter" and args[pos["frs.incident_chain"] - 1] == (early.cuda_stream,)
-    assert adam[1] > pos["r3dg_stage2_activate_backward"] and "enter" not in it[pos["frs.incident_chain"] + 2:adam[1]]
+    assert "enter" in it[pos["frs.backward"]:adam[1]] and "exit" not in it[adam[1]:pos["frs.rotate"]]
+    assert adam[2] > pos["r3dg_stage2_activate_backward"] and "enter" not in it[pos["frs.rotate"] + 2:adam[2]]
+    # the small view-independent launches (softplus, sum reset, accumulator zero fill) are torch launches on the MAIN stream
+    # between the front end's launches and the join in front of the shading forward: nothing but the fork enters the early
+    # stream's context at the top of the iteration
+    assert "enter" not in it[:pos["frs.forward"]]
     # anybody outside the iteration is ordered behind the chain before it sees the coefficients; an edited tensor is re-rotated
     assert step._early_pending
     n_joins = sum(1 for e in events if e[0] == "r3dg_stream_wait_stream")
@@ -920,14 +914,7 @@ def test_fused_stage2_iteration_spreads_the_fixed_ray_set_path_over_three_stream
     marks.append(len(events))
     step(cam, torch.ones(3), z(3, H, W))
     it4 = [e[0] for e in events[marks[3]:]]
-    assert it4.count("frs.rotate") == 1 and it4.index("frs.rotate") < it4.index("r3dg_stage2_activate")
-    # the same chain as three launches (R3DG_INCIDENT_CHAIN_KERNEL=0: A/B, and what a frozen incident-light group takes)
-    step._chain_kernel = False
-    marks.append(len(events))
-    step(cam, torch.ones(3), z(3, H, W))
-    it5 = [e[0] for e in events[marks[4]:]]
-    assert "frs.incident_chain" not in it5 and it5.count("r3dg_adam_step") == 3 and it5.count("frs.rotate") == 1
-    assert rotation_flags[-1] is True and it5.index("frs.backward") < it5.index("frs.rotate") < it5.index("r3dg_stage2_activate_backward")
+    assert it4.count("frs.rotate") == 2 and it4.index("frs.rotate") < it4.index("r3dg_stage2_activate")
     # ---- a second step object gets the same side streams -------------------------------------------------------------------
     other = fused_step.FusedStage2Step(params, K)
     other(cam, torch.ones(3), z(3, H, W))
