@@ -725,8 +725,6 @@ enum r3dg_option {
     R3DG_OPT_TRACE_COUNT_VISITS,        /* 1 = the phased trace counts node and leaf steps (measurement: r3dg_bvh_trace_visits); default 0 */
     R3DG_OPT_BWD_LEAN,                  /* 1 (default) = the tile backward takes its lean instances (no depth slot) when the caller passed no
                                          * depth gradient; 0 = never (A/B and parity tests: same gradients up to rounding order) */
-    R3DG_OPT_SORT_LONG_SIDE_STREAM,     /* 1 (default) = the long tiles' depth sort runs on a side stream of the library beside the small
-                                         * tiles' sort; 0 = behind it on the caller's stream; identical lists */
     R3DG_OPT_COUNT
 };
 int r3dg_set_option(int option, int value);       /* the PROCESS default */

@@ -156,7 +156,7 @@ def lib():
 
 # enum r3dg_option (include/r3dg_hip.h); tests/test_oracle_cpu.py checks the numbering against the header
 OPTIONS = ("TILE_ORDER", "CULL", "TILE_BINNING", "BINNING_BLOCK_K", "STAGE_SH_ROWS", "SHADE_FWD_BLOCKS_PER_CU", "TRACE_FORMULATION",
-           "TRACE_REFILL", "TRACE_NODE_WEIGHT", "TRACE_LEAF_WEIGHT", "RESERVE_CUS", "TRACE_COUNT_VISITS", "BWD_LEAN", "SORT_LONG_SIDE_STREAM")
+           "TRACE_REFILL", "TRACE_NODE_WEIGHT", "TRACE_LEAF_WEIGHT", "RESERVE_CUS", "TRACE_COUNT_VISITS", "BWD_LEAN")
 
 
 def set_option(name, value):

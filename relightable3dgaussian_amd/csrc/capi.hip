@@ -111,7 +111,6 @@ void launch_shade_forward_transport(hipStream_t s, int P, int K, const float* ba
                                     const float* zsamples, const float* dirs, float* out);
 extern int g_trace_packet, g_trace_refill, g_trace_node_weight, g_trace_leaf_weight, g_trace_count_visits;
 extern int g_bwd_lean;
-extern int g_sort_long_side;
 extern int g_shade_row_blocks_per_cu;
 void launch_shade_backward(hipStream_t s, int P, int K, int M, const float* base_color, const float* roughness,
                            const float* normals, const float* viewdirs, const float* incidents, const float* env,
@@ -426,15 +425,14 @@ static int* option_slot(int option)
         case R3DG_OPT_RESERVE_CUS: return &g_reserve_cus;
         case R3DG_OPT_TRACE_COUNT_VISITS: return &g_trace_count_visits;
         case R3DG_OPT_BWD_LEAN: return &g_bwd_lean;
-        case R3DG_OPT_SORT_LONG_SIDE_STREAM: return &g_sort_long_side;
         default: return nullptr;
     }
 }
 
 static bool option_in_range(int option, int value)
 {
-    static const int lo[R3DG_OPT_COUNT] = {0, 0, 0, 1, 0, 0, 0, 1, 1, 1, 0, 0, 0, 0};
-    static const int hi[R3DG_OPT_COUNT] = {1, 1, 2, 64, 1, 8, 4, 64, 15, 15, 128, 1, 1, 1};
+    static const int lo[R3DG_OPT_COUNT] = {0, 0, 0, 1, 0, 0, 0, 1, 1, 1, 0, 0, 0};
+    static const int hi[R3DG_OPT_COUNT] = {1, 1, 2, 64, 1, 8, 4, 64, 15, 15, 128, 1, 1};
     return value >= lo[option] && value <= hi[option];
 }
 

@@ -620,7 +620,6 @@ tile_sort_long_kernel(const uint32_t* __restrict__ big_list, uint32_t* __restric
 constexpr uint32_t TILE_SORT_SMALL_CAP = R3DG_TILE_SORT_SMALL_CAP;
 
 uint32_t tile_sort_small_cap() { return TILE_SORT_SMALL_CAP; }
-int g_sort_long_side = 1;       // R3DG_OPT_SORT_LONG_SIDE_STREAM
 
 // entries == true: `scratch` holds the (depth << 32 | index) entries of the direct tile binning, already in their tiles' segments
 void launch_tile_sort(hipStream_t s, int T, const uint32_t* tile_order, const uint32_t* ranges, const uint32_t* big_list,
@@ -634,41 +633,15 @@ void launch_tile_sort(hipStream_t s, int T, const uint32_t* tile_order, const ui
     (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
     const int reserve = opt(R3DG_OPT_RESERVE_CUS);
     const int grid = 2 * (cus > reserve ? cus - reserve : 1);
-    // The two kernels sort DISJOINT sets of tiles (at most / more than TILE_SORT_SMALL_CAP entries): nothing orders them but the
-    // stream.  Round 5: the long tiles' kernel goes to a side stream of the library (one per device, forked from and joined back
-    // into `s` with pooled events) and runs beside the small tiles' kernel instead of behind it -- the instance ordering is the
-    // longest chain of the forward window, and the 35 us of the few long tiles at the headline size sat at its end
-    // (R3DG_OPT_SORT_LONG_SIDE_STREAM = 0: one stream, as before; same lists either way).
-    hipStream_t sl = s;
-    hipEvent_t fork = nullptr, join = nullptr;
-    if (opt(R3DG_OPT_SORT_LONG_SIDE_STREAM) != 0) {
-        struct Side { hipStream_t stream = nullptr; std::vector<hipEvent_t> ev; int next = 0; };
-        static std::mutex mu;
-        static std::map<int, Side> sides;
-        std::lock_guard<std::mutex> lk(mu);
-        Side& sd = sides[dev];
-        if (sd.stream == nullptr) {
-            R3DG_HIP(hipStreamCreateWithFlags(&sd.stream, hipStreamNonBlocking));
-            sd.ev.resize(32);
-            for (auto& e : sd.ev) R3DG_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-        }
-        fork = sd.ev[sd.next];
-        join = sd.ev[sd.next + 1];
-        sd.next = (sd.next + 2) % (int)sd.ev.size();
-        sl = sd.stream;
-        R3DG_HIP(hipEventRecord(fork, s));
-        R3DG_HIP(hipStreamWaitEvent(sl, fork, 0));
-    }
+    // (Round 5, measured and not kept: the long tiles' kernel on a side stream of the library beside the small tiles' kernel -- the
+    // two sort disjoint tiles.  Beside each other the long kernel takes 82 us instead of 30, the pair ends where the sequence did:
+    // 772-774 against 776-777 it/s.  One stream.)
     if (entries) {
-        tile_sort_long_kernel<true><<<grid, LONG_THREADS, 0, sl>>>(big_list, big_count, rg, keys, vals, scratch);
         tile_sort_small_kernel<true><<<T, 256, TILE_SORT_SMALL_CAP * 8, s>>>(T, tile_order, rg, TILE_SORT_SMALL_CAP, keys, vals, scratch);
+        tile_sort_long_kernel<true><<<grid, LONG_THREADS, 0, s>>>(big_list, big_count, rg, keys, vals, scratch);
     } else {
-        tile_sort_long_kernel<false><<<grid, LONG_THREADS, 0, sl>>>(big_list, big_count, rg, keys, vals, scratch);
         tile_sort_small_kernel<false><<<T, 256, TILE_SORT_SMALL_CAP * 8, s>>>(T, tile_order, rg, TILE_SORT_SMALL_CAP, keys, vals, scratch);
-    }
-    if (sl != s) {
-        R3DG_HIP(hipEventRecord(join, sl));
-        R3DG_HIP(hipStreamWaitEvent(s, join, 0));
+        tile_sort_long_kernel<false><<<grid, LONG_THREADS, 0, s>>>(big_list, big_count, rg, keys, vals, scratch);
     }
 }
 

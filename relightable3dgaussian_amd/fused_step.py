@@ -352,7 +352,12 @@ class FusedStage2Step(_BoundedForward):
         self._acc = None                            # the tile backward's accumulator slab, zero-filled off the critical path
         self._early_pending = False                 # the early-Adam stream holds work no other stream has been ordered behind yet
         self._b_early = False
-        self._flag_b = torch.zeros(4, dtype=torch.float32, device=dev)
+        # single GPU: the overflow flag alternates between two slots by iteration parity -- the incident-light group's Adam may
+        # still be reading iteration i's flag on the early stream when iteration i + 1's tile scan writes its own (under data
+        # parallelism the flag rides in the gradient slab and the launches read a snapshot: _snapshot_flag)
+        self._flag_pair = torch.zeros(2, 4, dtype=torch.float32, device=dev)
+        # softplus of the environment texture, refreshed behind the Adam launch that updates the texture (see optimizer_step)
+        self._env_c = self._env_c_key = None
         self._zero_depth_grad = None
         # instance ordering of the rasterizer runs here, under the shading forward (register-light, latency-bound kernels
         # next to a VALU-bound one)
@@ -368,7 +373,6 @@ class FusedStage2Step(_BoundedForward):
         self.world, self.dp = _world_of(process_group)
         # tuning options of THIS object (include/r3dg_hip.h "option contexts"): every library call of the step runs inside it
         self._ctx = _lib.OptionContext()
-        self._stagger = os.environ.get("R3DG_FWD_STAGGER", "1")             # (see forward_backward: where the small launches go)
         # feature rows without a pack kernel: the activations write the columns they own, the fixed-ray-set shading kernels
         # theirs (r3dg_shade_frs_forward d_feature_rows) -- one launch and its join less between the shading integral and the
         # rasterizer.  The general shading kernels keep r3dg_stage2_pack_features.
@@ -502,6 +506,16 @@ class FusedStage2Step(_BoundedForward):
                 self._frs.taps(He, We)
         return self._taps
 
+    def _refresh_env(self):
+        """softplus of the environment texture (DirectLightMap.get_env), cached: recomputed when the texture tensor was replaced or
+        edited through torch, and by optimizer_step behind the Adam launch that updates it (the Adam kernel writes through the raw
+        pointer, which the version counter does not see)."""
+        key = (self.env, self.env._version)
+        if self._env_c is None or self._env_c_key is None or self._env_c_key[0] is not key[0] or self._env_c_key[1] != key[1]:
+            self._env_c = F.softplus(self.env)[0]
+            self._env_c_key = key
+        return self._env_c
+
     def _rotation_is_current(self):
         """The ray set already holds the rotation of the CURRENT coefficients (queued on the early-Adam stream right behind their
         Adam update, at the end of the previous iteration)?  Keyed on the tensor and its version counter: anything that replaces or
@@ -559,31 +573,28 @@ class FusedStage2Step(_BoundedForward):
                     with torch.cuda.stream(aux):
                         self._frs.rotate(self._incidents)
                 rotated_for = self._frs
-            # The small view-independent launches of the iteration -- softplus of the texture, the loss-sum reset, the zero fill of
-            # the tile backward's accumulator slab (32 MB at 300k Gaussians; it used to sit between the loss and the tile backward,
-            # alone on the device) -- go to the MAIN stream behind the front end's launches (`small_launches` below): the main stream
-            # has nothing to do there but wait for the early stream, and they run beside the projection and the tail of the
-            # incident-light chain.  R3DG_FWD_STAGGER=aux: on the early stream behind the rotation (rounds 3-4: with the main
-            # stream otherwise idle until the rotation was done that made the shading forward start inside the instance ordering
-            # instead of inside the projection); =0: on the main stream in front of the activations.
+            # The small view-independent launches of the iteration:
+            #   * softplus of the environment texture: done behind the Adam launch that updates the texture, at the end of the
+            #     previous iteration (optimizer_step -> _refresh_env); here only when somebody replaced or edited the texture;
+            #   * the loss-sum reset and the zero fill of the tile backward's accumulator slab (32 MB at 300k Gaussians; it used to sit
+            #     between the loss and the tile backward, alone on the device): nobody reads either before the image-space loss, so
+            #     they go to the early stream BEHIND the listed Gaussians' forward kernel and run under the shading forward / the
+            #     instance ordering (`late_zero_fills`); the join that follows that kernel covers them.  Without that stream: on
+            #     the main stream, in front of the shading forward.
+            # (Rounds 3-4 had all three on the early stream behind the coefficient rotation, round 5 first on the main stream behind
+            # the front end's launches: 52 us under contention, in front of the shading forward either way.)
             acc_n = (11 + 16) * P
             if self._acc is None or self._acc.numel() != acc_n:
                 self._acc = torch.empty(acc_n, dtype=torch.float32, device=dev)
+            env_c = self._refresh_env()
 
-            def small_launches():
-                env = F.softplus(self.env)[0]                                    # DirectLightMap.get_env
+            def late_zero_fills():
                 self.sums.zero_()
                 self._acc.zero_()
-                return env
-            env_c = None
-            if aux is not None and self._stagger == "aux":
-                with torch.cuda.stream(aux):
-                    env_c = small_launches()
-            elif self._stagger == "0":
-                env_c = small_launches()
             acc_ready = True
             self.refresh_activations(cam)
             self._iter += 1
+            flag_cur = self._flag if self.dp else self._flag_pair[self._iter & 1]
             use_bounded = self._use_bounded(W, H)
             if self._early_pending and (aux is None or not (use_bounded and order_stream is not None)):
                 # (the previous iteration left work on the early stream that only the bounded, three-stream schedule is ordered
@@ -596,20 +607,21 @@ class FusedStage2Step(_BoundedForward):
                 pending = rasterizer_ops.rasterize_gaussians_begin(
                     bg, self.xyz, self.features, empty, self.a_opacity, self.a_scales, self.a_rot, 1.0, empty, vm,
                     cam.full_proj_transform, cam.tanfovx, cam.tanfovy, cam.cx, cam.cy, H, W, self.shs, 3, campos, False,
-                    True, False, capacity=self._capacity, overflow_flag=self._flag,
+                    True, False, capacity=self._capacity, overflow_flag=flag_cur,
                     overflow_count=self._overflow_count, ordering_stream=order_stream, want_weights=False)
             else:
                 # first half of the rasterizer (projection + async read-back of num_rendered): the shading kernels below
                 # run while the host waits for the count and enqueues the second half
-                self._flag.zero_()
+                flag_cur.zero_()
                 pending = rasterizer_ops.rasterize_gaussians_begin(
                     bg, self.xyz, self.features, empty, self.a_opacity, self.a_scales, self.a_rot, 1.0, empty, vm,
                     cam.full_proj_transform, cam.tanfovx, cam.tanfovy, cam.cx, cam.cy, H, W, self.shs, 3, campos, False,
                     True, False, want_weights=False)       # (stage 2 does not densify: nobody reads the blend weights)
             if self._pending_b is not None:
                 self.flush()    # (world > 1) the previous iteration's incident-light update lands here
-            if env_c is None:
-                env_c = small_launches()
+            zero_stream = self._listed_stream()
+            if zero_stream is None:
+                late_zero_fills()
             if aux is not None:
                 _lib.stream_wait(main, aux)
                 self._early_pending = False          # (aux IS the early stream: the main stream is behind all of it now)
@@ -635,6 +647,11 @@ class FusedStage2Step(_BoundedForward):
                     None if self._uniform_area is not None else self.incident_areas.data_ptr(), self._uniform_area or 0.0,
                     taps.data_ptr(), 1 | (4 if order_stream is not None else 0),     # train outputs | leave room
                     self.shade_out.data_ptr()), "shade_forward")
+            if zero_stream is not None:
+                # (the early stream: idle but for the listed Gaussians' forward kernel; ordered behind everything the previous
+                # iteration's consumers of the two buffers did -- they ran on the main stream, which the fork at the top followed)
+                with torch.cuda.stream(zero_stream):
+                    late_zero_fills()
             if self._frs is not None and self._listed_stream() is not None:
                 _lib.stream_wait(main, self._listed_stream())
             packed = not (self._frs is not None and self._direct_rows)
@@ -647,7 +664,7 @@ class FusedStage2Step(_BoundedForward):
             R, n_contrib, image, opacity, depth, feature, pseudo_normal, sxyz, weights, radii, geom, binning, img = fw
             # the Adam launches of this iteration skip themselves when the view was dropped; under data parallelism they
             # read a snapshot of the flag taken after bucket A's all-reduce (optimizer_step)
-            self._skip_cur = self._flag            # (world > 1: replaced by the reduced snapshot in optimizer_step)
+            self._skip_cur = flag_cur              # (world > 1: replaced by the reduced snapshot in optimizer_step)
             # image-space loss terms and their gradients.  One slab: dL_dimage 3 | dL_dopacity 1 | dL_dfeature 16 | sRGB PBR
             # image 3 | SSIM partials 2x9 | SSIM gradients 2x3 (the depth image carries no loss)
             g = torch.empty((47, H, W), dtype=torch.float32, device=dev)
@@ -763,9 +780,7 @@ class FusedStage2Step(_BoundedForward):
                     #     SH group's Adam HERE (an event recorded now: it does not wait for what is queued on this stream later);
                     #   * the main stream joins this stream in front of the next shading forward, as it always did;
                     #   * anybody else goes through `incidents` / flush().
-                    # The overflow flag the group's Adam reads is copied now: the slab's slot is rewritten by the next forward.
-                    with torch.cuda.stream(side):
-                        self._flag_b.copy_(self._flag)
+                    # (The overflow flag the group's Adam reads later is this iteration's own slot of `_flag_pair`.)
                     _lib.stream_wait(order_stream, side)
                     self._b_early = True
             elif early_adam and handle_a is not None and self._groups_a:
@@ -810,7 +825,7 @@ class FusedStage2Step(_BoundedForward):
                     # strides between lanes saturate the address unit, see DESIGN.md section 7.  Measured, deleted.)
                     with torch.cuda.stream(self._early_stream):
                         if self._groups_b:
-                            self.opt.step_groups(self._groups_b, [self.grads[k] for k in self._opt_order], skip_flag=self._flag_b)
+                            self.opt.step_groups(self._groups_b, [self.grads[k] for k in self._opt_order], skip_flag=self._skip_cur)
                         self._frs.rotate(self._incidents)
                     self._pre_rotated = (self._frs, self._incidents, self._incidents._version)
             else:
@@ -938,6 +953,11 @@ class FusedStage2Step(_BoundedForward):
                 todo = self._groups_a + self._groups_c + self._groups_b
             if todo:                     # ONE launch for every remaining group
                 self.opt.step_groups(todo, grads, skip_flag=self._skip_cur)
+            if "env" not in self.frozen:
+                # the next iteration's texture, behind the launch that updated it (one tiny launch at the END of the iteration,
+                # where the main stream has nothing else to do, instead of in front of the next shading forward)
+                self._env_c = F.softplus(self.env)[0]
+                self._env_c_key = (self.env, self.env._version)
             return
         # data parallel: update each bucket when its (sum) all-reduce has landed; 1/world is applied inside the kernel
         scale = 1.0 / self.world
@@ -957,6 +977,7 @@ class FusedStage2Step(_BoundedForward):
                 self._wait(handle_c)
         if self._groups_c:
             self.opt.step_groups(self._groups_c, grads, scale, skip_flag=self._skip_cur)
+        self._env_c_key = None           # (the texture moved: the next forward recomputes its softplus)
         self._pending_b = (handle_b, grads, scale, self._skip_cur)
 
     @_in_context
