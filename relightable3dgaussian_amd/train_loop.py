@@ -70,7 +70,7 @@ def create_from_points(points, colors, normals=None, device="cuda"):
 
 def train_stage1(init, cameras, images, background, extent, schedule=None, iterations=None, seed=0,
                  white_background=True, process_group=None, on_iteration=None, masks=None, loss_weights=None,
-                 poll_interval=32):
+                 poll_interval=32, replay_dropped=True):
     """Runs `iterations` fused stage-1 iterations over the (camera, image) pairs in round-robin order (the reference
     draws a random permutation, train.py:115-119; the order is the caller's) with the reference's densification
     schedule.  Returns (FusedStage1Step, history) where history lists (iteration, event, rows) for every
@@ -80,7 +80,10 @@ def train_stage1(init, cameras, images, background, extent, schedule=None, itera
     The fused iteration's bounded forward drops a view on the device when it needs more tile instances than the capacity
     learned so far (fused_step._BoundedForward): the loop asks every `poll_interval` iterations and before every densify
     (`poll_overflow`: one 4-byte read-back, grows the capacity, takes the step back from Adam's count) and lists what was
-    dropped as (iteration, "dropped_views", n) in the history -- the reference trains on every view, so a run reports it."""
+    dropped as (iteration, "dropped_views", n) in the history.  The reference trains on every view (it sizes the binning state
+    from the count it reads back, rasterizer_impl.cu:291): with `replay_dropped` (default; single GPU) the dropped views are
+    trained on right there, through the exact two-phase forward (`FusedStage1Step.replay_dropped`), and listed as
+    (iteration, "replayed_views", [the iterations they were dropped in]) -- at most `poll_interval` iterations late."""
     sch = schedule or Schedule()
     n_iter = sch.iterations if iterations is None else iterations
     step = FusedStage1Step(init, lr=sch.sh_lr, lr_rest_scale=1.0 / 20.0, process_group=process_group,
@@ -92,6 +95,7 @@ def train_stage1(init, cameras, images, background, extent, schedule=None, itera
     history = []
     xyz_group = step.opt.groups[step._opt_order.index("xyz")]
     last_densify = None
+    view_of = {}                                       # forward pass of the step object -> view index (for replays)
     for it in range(1, n_iter + 1):
         # gaussians.update_learning_rate(iteration) (train.py:101): the position rate decays log-linearly
         xyz_group["lr"] = position_lr(it, sch.position_lr_init * extent, sch.position_lr_final * extent,
@@ -101,8 +105,10 @@ def train_stage1(init, cameras, images, background, extent, schedule=None, itera
         if not collecting and step.stats is not None:
             step.stats = None                                                # train.py:160: statistics only while densifying
         step.iteration = it                                                  # depth-variance schedule, render.py:202
+        view_of[step._iter + 1] = v                                          # (the step object counts its forward passes)
         step.forward_backward(cameras[v], background, images[v], None if masks is None else masks[v])
         densify_now = collecting and it > sch.densify_from_iter and it % sch.densification_interval == 0
+        replay_now = False
         # (also on the two iterations behind a densification: P has just grown, and so has the instance count the bounded
         # forward's capacity was sized for -- a dropped view is then counted back out of Adam's step count at once instead of
         # up to poll_interval iterations later)
@@ -111,6 +117,7 @@ def train_stage1(init, cameras, images, background, extent, schedule=None, itera
             dropped = step.poll_overflow()
             if dropped:
                 history.append((it, "dropped_views", dropped))
+                replay_now = replay_dropped and not step.dp
         if collecting:
             if densify_now:
                 size_threshold = 20 if it > sch.opacity_reset_interval else None
@@ -131,6 +138,17 @@ def train_stage1(init, cameras, images, background, extent, schedule=None, itera
             skip_step = False
         if not skip_step:
             step.optimizer_step()
+        if replay_now:
+            # (behind this iteration's own optimizer step / densification: a replay overwrites the gradient buffers)
+            def inputs_of(i):
+                w = view_of[i]
+                view_of[step._iter + 1] = w
+                return cameras[w], background, images[w], None if masks is None else masks[w]
+            step.iteration = it - 1                                          # (__call__ advances it)
+            redone = step.replay_dropped(inputs_of)
+            step.iteration = it
+            if redone:
+                history.append((it, "replayed_views", redone))
         if on_iteration is not None:
             on_iteration(it, step)
     return step, history

@@ -523,6 +523,43 @@ def test_bounded_iteration_that_overflows_is_dropped_not_applied():
     assert step.rendered_counts(1)[0] > 0
 
 
+def test_bounded_iteration_that_overflows_is_replayed():
+    """VERDICT r4 missing 5: the reference trains on every view (it sizes its binning state from the count it reads back,
+    rasterizer_impl.cu:291).  A bounded iteration that overflows is dropped on the device; poll_overflow() says WHICH
+    iterations were (their slots of the flag ring), and replay_dropped() trains on those views through the exact two-phase
+    forward.  With a poll behind every iteration the result is the two-phase loop's: same parameters (up to the order of the
+    float atomics), same Adam step count, nothing left dropped."""
+    from relightable3dgaussian_amd import synthetic as syn
+    from relightable3dgaussian_amd.fused_step import FusedStage2Step
+    params, ref, fused, cam, bg, gt = _setup(P=4000, res=128, K=8, seed=12)
+    cams = [c.to(DEV) for c in syn.orbit_cameras(6, width=128, height=128)]
+    a = FusedStage2Step(params, 8, bounded=True)
+    b = FusedStage2Step(params, 8, bounded=False)
+    for s_ in (a, b):
+        s_.visibility, s_.incident_dirs, s_.incident_areas = ref.visibility, ref.incident_dirs, ref.incident_areas
+    inputs = {}
+    replayed = []
+    for i in range(6):
+        b(cams[i], bg, gt)
+        if i in (2, 4):
+            a._capacity = 1000                                      # this view will not fit
+        inputs[a._iter + 1] = (cams[i], bg, gt)
+        a(cams[i], bg, gt)
+
+        def inputs_of(it):
+            inputs[a._iter + 1] = inputs[it]
+            return inputs[it]
+        replayed += a.replay_dropped(inputs_of)
+    a.flush()
+    torch.cuda.synchronize()
+    assert len(replayed) == 2 and a.dropped_steps == 0 and a.dropped_iterations == []
+    assert a.opt.step_count == b.opt.step_count == 6
+    for k in ("xyz", "scaling", "rotation", "opacity", "shs", "base_color", "roughness", "incidents", "env"):
+        ok, msg = report(k, getattr(a, k), getattr(b, k), 2e-5, 1e-7)
+        assert ok, msg
+    assert a._capacity is not None and a._capacity > 1000            # re-learned from the replayed view's count
+
+
 def test_bounded_stage1_iterations_equal_two_phase_iterations():
     """FusedStage1Step(bounded=True) vs bounded=False: same losses, same parameters (up to the order of float atomics), same
     densification statistics; a view that does not fit updates neither parameters nor statistics."""
