@@ -490,6 +490,38 @@ int r3dg_stage2_smooth_fused(void* stream, int width, int height, const float* d
 int r3dg_stage2_pbr_srgb(void* stream, int width, int height, const float* d_opacity, const float* d_feature,
                          const int32_t* d_n_contrib, const float* d_background, float* d_srgb);
 
+/* Launches folded into their neighbours (round 5; each was 5-20 us alone on the iteration's critical stream):
+ * r3dg_stage2_activate_with: r3dg_stage2_activate + two SIDE JOBS that ride as extra workgroups of the same launch:
+ *   d_env[0..n_env) = softplus(d_env_raw[..]) (DirectLightMap.get_env, scene/direct_light_map.py:18-23; beta 1, threshold 20 as
+ *   torch.nn.functional.softplus) and d_zero[0..n_zero) = 0 (the iteration's loss sums).  n_env == 0 / n_zero == 0: that job is
+ *   skipped.
+ * r3dg_stage2_activate_backward_with: r3dg_stage2_activate_backward + r3dg_stage2_env_backward (same arguments, same results)
+ *   in one launch; He * We == 0: no texture job.
+ * r3dg_stage2_normals_srgb: the rasterizer forward's surface-point + pseudo-normal pass (forward.cu:398-491; what
+ *   r3dg_rasterize_forward computes when compute_pseudo_normal != 0 -- call the forward with 0 and this afterwards) and
+ *   r3dg_stage2_pbr_srgb as one per-pixel kernel.  d_pseudo_normal, d_surface_xyz [3,HW] and d_srgb [3,HW] are fully written;
+ *   tan_fovx/tan_fovy/cx/cy as passed to the forward. */
+int r3dg_stage2_activate_with(void* stream, int P, const float* d_xyz, const float* d_scaling_raw,
+                              const float* d_rotation_raw, const float* d_opacity_raw, const float* d_normal_raw,
+                              const float* d_base_raw, const float* d_rough_raw, const float* d_campos, float* d_scales,
+                              float* d_rotations, float* d_opacity, float* d_normal, float* d_base_color,
+                              float* d_roughness, float* d_viewdirs, const float* d_viewmatrix, float* d_features,
+                              int n_env, const float* d_env_raw, float* d_env, float* d_zero, int n_zero);
+int r3dg_stage2_activate_backward_with(void* stream, int P, const float* d_xyz, const float* d_scaling_raw,
+                                       const float* d_rotation_raw, const float* d_opacity_raw, const float* d_normal_raw,
+                                       const float* d_base_raw, const float* d_rough_raw, const float* d_viewmatrix,
+                                       const float* d_campos, const float* d_dL_dfeatures, const float* d_dL_dbase_color,
+                                       const float* d_dL_droughness, const float* d_dL_dviewdirs, const float* d_dL_dscales,
+                                       const float* d_dL_drot, const float* d_dL_dopacity, const float* d_dL_dmeans3D,
+                                       float* d_g_xyz, float* d_g_scaling, float* d_g_rotation, float* d_g_opacity,
+                                       float* d_g_normal, float* d_g_base, float* d_g_rough, int He, int We,
+                                       const float* d_env_raw, const float* d_env, float* d_dL_denv, float w_tv,
+                                       float* d_g_env_raw, float* d_tv_sum, int consume);
+int r3dg_stage2_normals_srgb(void* stream, int width, int height, const float* d_viewmatrix, float tan_fovx, float tan_fovy,
+                             float cx, float cy, const float* d_opacity, const float* d_depth, float* d_pseudo_normal,
+                             float* d_surface_xyz, const float* d_feature, const int32_t* d_n_contrib,
+                             const float* d_background, float* d_srgb);
+
 /* SSIM (utils/loss_utils.py:20-63: 11x11 Gaussian window, sigma 1.5, zero padding) of x against y, both [C,H,W].
  * _forward: *d_sum += sum of the SSIM map (divide by C*H*W for the reference's mean); d_partials [C,3,H,W] receives the
  * per-pixel partial derivatives the backward needs.  _backward: d_grad_x [C,H,W] = scale * d(sum SSIM)/dx (overwritten);

@@ -87,14 +87,17 @@ _SIGNATURES = {
     "r3dg_render_equation_backward": (_i, [_p, _i, _i, _i, _i] + [_p] * 8 + [_i] + [_p] * 11),
     "r3dg_clock_probe": (_i, [_p, _i, _p, _p, C.POINTER(C.c_int)]),
     "r3dg_stage2_activate": (_i, [_p, _i] + [_p] * 17),
+    "r3dg_stage2_activate_with": (_i, [_p, _i] + [_p] * 17 + [_i, _p, _p, _p, _i]),
     "r3dg_stage2_pack_features": (_i, [_p, _i] + [_p] * 8),
     "r3dg_stage2_unpack_gradients": (_i, [_p, _i, _p, _p, _f, _p, _p, _p, _p]),
     "r3dg_stage2_activate_backward": (_i, [_p, _i] + [_p] * 24),
+    "r3dg_stage2_activate_backward_with": (_i, [_p, _i] + [_p] * 24 + [_i, _i, _p, _p, _p, _f, _p, _p, _i]),
     "r3dg_stage2_loss": (_i, [_p, _i, _i] + [_p] * 8 + [_f, _f, _f] + [_p] * 6 + [_i]),
     "r3dg_stage2_smooth_forward": (_i, [_p, _i, _i] + [_p] * 5 + [_f, _f, _f, _p, _p]),
     "r3dg_stage2_smooth_backward": (_i, [_p, _i, _i] + [_p] * 5 + [_f, _f, _f, _i, _p, _p]),
     "r3dg_stage2_smooth_fused": (_i, [_p, _i, _i] + [_p] * 5 + [_f, _f, _f, _i, _p, _p, _p]),
     "r3dg_stage2_pbr_srgb": (_i, [_p, _i, _i] + [_p] * 5),
+    "r3dg_stage2_normals_srgb": (_i, [_p, _i, _i, _p, _f, _f, _f, _f] + [_p] * 8),
     "r3dg_ssim_forward": (_i, [_p, _i, _i, _i, _p, _p, _p, _p]),
     "r3dg_ssim_backward": (_i, [_p, _i, _i, _i, _p, _p, _p, _f, _p]),
     "r3dg_ssim_forward_pair": (_i, [_p, _i, _i, _i] + [_p] * 7),

@@ -132,7 +132,7 @@ void launch_s2_activate(hipStream_t s, int P, const float* xyz, const float* sca
                         const float* opacity_raw, const float* normal_raw, const float* base_raw,
                         const float* rough_raw, const float* campos, float* scales, float* rot, float* opacity,
                         float* normal, float* base_color, float* roughness, float* viewdirs, const float* viewmatrix,
-                        float* features);
+                        float* features, int n_env, const float* env_raw, float* env, float* zero, int n_zero);
 void launch_s2_pack(hipStream_t s, int P, const float* xyz, const float* viewmatrix, const float* normal,
                     const float* base_color, const float* roughness, const float* shade_out, float* features,
                     float* light_l1_sum);
@@ -145,7 +145,8 @@ void launch_s2_activate_backward(hipStream_t s, int P, const float* xyz, const f
                                  const float* dL_drough_shade, const float* dL_dviewdirs, const float* dL_dscales,
                                  const float* dL_drot, const float* dL_dopacity, const float* dL_dmeans3D, float* g_xyz,
                                  float* g_scaling, float* g_rotation, float* g_opacity, float* g_normal, float* g_base,
-                                 float* g_rough);
+                                 float* g_rough, int He, int We, const float* env_raw, const float* env, float* dL_denv,
+                                 float w_tv, float* g_env_raw, float* tv_sum, int consume);
 void launch_s2_loss(hipStream_t s, int HW, const float* image, const float* opacity, const float* feature,
                     const float* pseudo_normal, const int* n_contrib, const float* gt, const float* bg,
                     const float* image_mask, float w_l1, float w_pbr, float w_normal, const float* extra_dimage,
@@ -162,6 +163,9 @@ void launch_s2_smooth_backward(hipStream_t s, int W, int H, const float* opacity
                                int accumulate_normal, float* dL_dopacity, float* dL_dfeature);
 void launch_s2_pbr_srgb(hipStream_t s, int HW, const float* opacity, const float* feature, const int* n_contrib,
                         const float* bg, float* srgb);
+void launch_s2_normals_srgb(hipStream_t s, int W, int H, const float* vm, float focal_x, float focal_y, float cx, float cy,
+                            const float* opacity, const float* depths, float* normals, float* surface_xyz, const float* feature,
+                            const int* n_contrib, const float* bg, float* srgb);
 void launch_ssim_forward(hipStream_t s, int W, int H, int C, int n_images, const float* const* x, const float* y,
                          float* const* partials, float* const* sum);
 void launch_ssim_backward(hipStream_t s, int W, int H, int C, int n_images, const float* const* x, const float* y,
@@ -1674,8 +1678,30 @@ int r3dg_stage2_activate(void* stream_, int P, const float* xyz, const float* sc
                          float* normal, float* base_color, float* roughness, float* viewdirs, const float* viewmatrix,
                          float* features)
 {
+    return r3dg_stage2_activate_with(stream_, P, xyz, scaling_raw, rotation_raw, opacity_raw, normal_raw, base_raw, rough_raw,
+                                     campos, scales, rot, opacity, normal, base_color, roughness, viewdirs, viewmatrix, features,
+                                     0, nullptr, nullptr, nullptr, 0);
+}
+
+int r3dg_stage2_activate_with(void* stream_, int P, const float* xyz, const float* scaling_raw, const float* rotation_raw,
+                              const float* opacity_raw, const float* normal_raw, const float* base_raw,
+                              const float* rough_raw, const float* campos, float* scales, float* rot, float* opacity,
+                              float* normal, float* base_color, float* roughness, float* viewdirs, const float* viewmatrix,
+                              float* features, int n_env, const float* env_raw, float* env, float* zero, int n_zero)
+{
     if (P < 0) return invalid("stage2_activate: bad P");
-    if (P == 0) return R3DG_OK;
+    if (n_env < 0 || n_zero < 0) return invalid("stage2_activate: bad side-job size");
+    if (n_env > 0 && (!env_raw || !env)) return invalid("stage2_activate: null texture buffer");
+    if (n_zero > 0 && !zero) return invalid("stage2_activate: null buffer to zero");
+    if (P == 0 && n_env == 0 && n_zero == 0) return R3DG_OK;
+    if (P == 0) {                      // (only side jobs: run them behind zero Gaussian workgroups)
+        return guarded([&]() -> int {
+            launch_s2_activate((hipStream_t)stream_, 0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
+                               nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, n_env, env_raw,
+                               env, zero, n_zero);
+            return R3DG_OK;
+        });
+    }
     if (!xyz || !scaling_raw || !rotation_raw || !opacity_raw || !normal_raw || !scales || !rot || !opacity || !normal)
         return invalid("stage2_activate: null buffer");
     if (base_raw && (!rough_raw || !campos || !base_color || !roughness || !viewdirs))
@@ -1684,7 +1710,8 @@ int r3dg_stage2_activate(void* stream_, int P, const float* xyz, const float* sc
     return guarded([&]() -> int {
         StageTimer t((hipStream_t)stream_, ST_S2_ACTIVATE);
         launch_s2_activate((hipStream_t)stream_, P, xyz, scaling_raw, rotation_raw, opacity_raw, normal_raw, base_raw,
-                           rough_raw, campos, scales, rot, opacity, normal, base_color, roughness, viewdirs, viewmatrix, features);
+                           rough_raw, campos, scales, rot, opacity, normal, base_color, roughness, viewdirs, viewmatrix, features,
+                           n_env, env_raw, env, zero, n_zero);
         return R3DG_OK;
     });
 }
@@ -1729,8 +1756,29 @@ int r3dg_stage2_activate_backward(void* stream_, int P, const float* xyz, const 
                                   float* g_scaling, float* g_rotation, float* g_opacity, float* g_normal, float* g_base,
                                   float* g_rough)
 {
+    return r3dg_stage2_activate_backward_with(stream_, P, xyz, scaling_raw, rotation_raw, opacity_raw, normal_raw, base_raw,
+                                              rough_raw, viewmatrix, campos, dL_dfeatures, dL_dbase_shade, dL_drough_shade,
+                                              dL_dviewdirs, dL_dscales, dL_drot, dL_dopacity, dL_dmeans3D, g_xyz, g_scaling,
+                                              g_rotation, g_opacity, g_normal, g_base, g_rough, 0, 0, nullptr, nullptr, nullptr,
+                                              0.f, nullptr, nullptr, 0);
+}
+
+int r3dg_stage2_activate_backward_with(void* stream_, int P, const float* xyz, const float* scaling_raw,
+                                  const float* rotation_raw, const float* opacity_raw, const float* normal_raw,
+                                  const float* base_raw, const float* rough_raw, const float* viewmatrix,
+                                  const float* campos, const float* dL_dfeatures, const float* dL_dbase_shade,
+                                  const float* dL_drough_shade, const float* dL_dviewdirs, const float* dL_dscales,
+                                  const float* dL_drot, const float* dL_dopacity, const float* dL_dmeans3D, float* g_xyz,
+                                  float* g_scaling, float* g_rotation, float* g_opacity, float* g_normal, float* g_base,
+                                  float* g_rough, int He, int We,
+                                       const float* env_raw, const float* env, float* dL_denv, float w_tv,
+                                       float* g_env_raw, float* tv_sum, int consume)
+{
     if (P < 0) return invalid("stage2_activate_backward: bad P");
-    if (P == 0) return R3DG_OK;
+    if (He < 0 || We < 0) return invalid("stage2_activate_backward: bad texture size");
+    const bool env_job = He * We != 0;
+    if (env_job && (!env_raw || !env || !dL_denv || !g_env_raw)) return invalid("stage2_activate_backward: null texture buffer");
+    if (P == 0) return env_job ? r3dg_stage2_env_backward(stream_, He, We, env_raw, env, dL_denv, w_tv, g_env_raw, tv_sum, consume) : R3DG_OK;
     if (!base_raw || !rough_raw || !dL_dfeatures || !dL_dbase_shade || !dL_drough_shade || !g_base || !g_rough)
         return invalid("stage2_activate_backward: null buffer");
     // g_xyz == NULL: frozen geometry -- only g_base / g_rough are produced and the geometry inputs are not read
@@ -1743,7 +1791,8 @@ int r3dg_stage2_activate_backward(void* stream_, int P, const float* xyz, const 
         launch_s2_activate_backward((hipStream_t)stream_, P, xyz, scaling_raw, rotation_raw, opacity_raw, normal_raw,
                                     base_raw, rough_raw, viewmatrix, campos, dL_dfeatures, dL_dbase_shade,
                                     dL_drough_shade, dL_dviewdirs, dL_dscales, dL_drot, dL_dopacity, dL_dmeans3D, g_xyz,
-                                    g_scaling, g_rotation, g_opacity, g_normal, g_base, g_rough);
+                                    g_scaling, g_rotation, g_opacity, g_normal, g_base, g_rough, env_job ? He : 0, env_job ? We : 0,
+                                    env_job ? env_raw : nullptr, env, dL_denv, w_tv, g_env_raw, tv_sum, consume);
         return R3DG_OK;
     });
 }
@@ -1883,6 +1932,25 @@ int r3dg_stage2_pbr_srgb(void* stream_, int width, int height, const float* opac
     if (!opacity || !feature || !n_contrib || !bg || !srgb) return invalid("stage2_pbr_srgb: null buffer");
     return guarded([&]() -> int {
         launch_s2_pbr_srgb((hipStream_t)stream_, width * height, opacity, feature, n_contrib, bg, srgb);
+        return R3DG_OK;
+    });
+}
+
+int r3dg_stage2_normals_srgb(void* stream_, int width, int height, const float* viewmatrix, float tan_fovx, float tan_fovy,
+                             float cx, float cy, const float* opacity, const float* depth, float* pseudo_normal,
+                             float* surface_xyz, const float* feature, const int32_t* n_contrib, const float* bg, float* srgb)
+{
+    if (width < 0 || height < 0) return invalid("stage2_normals_srgb: bad image size");
+    if ((long long)width * height == 0) return R3DG_OK;
+    if ((long long)width * height > 0x7fffffffLL) return invalid("stage2_normals_srgb: image too large");
+    if (!viewmatrix || !opacity || !depth || !pseudo_normal || !surface_xyz || !feature || !n_contrib || !bg || !srgb)
+        return invalid("stage2_normals_srgb: null buffer");
+    return guarded([&]() -> int {
+        StageTimer t((hipStream_t)stream_, ST_NORMAL);
+        // focal lengths exactly as the rasterizer forward derives them (rasterizer_impl.cu:239-240)
+        const float focal_y = height / (2.0f * tan_fovy), focal_x = width / (2.0f * tan_fovx);
+        launch_s2_normals_srgb((hipStream_t)stream_, width, height, viewmatrix, focal_x, focal_y, cx, cy, opacity, depth,
+                               pseudo_normal, surface_xyz, feature, n_contrib, bg, srgb);
         return R3DG_OK;
     });
 }

@@ -14,6 +14,7 @@
 //     (the reference issues one atomic per contributing pixel, forward.cu:374);
 //   * early-out: a wave stops walking when all its pixels are done (64-bit ballot).
 #include "common.hpp"
+#include "pseudo_normal.hpp"
 
 namespace r3dg {
 
@@ -246,20 +247,7 @@ render_forward_wave_kernel(const uint2* __restrict__ ranges, const uint32_t* __r
     }
 }
 
-// K9 + K10 in one launch.  K9: surface point in camera space from the premultiplied depth / opacity buffers (forward.cu:398-425);
-// K10: pseudo normal from a 3x3 edge-clamped stencil on those points (forward.cu:427-491).  The reference runs K10 behind a
-// grid-wide barrier on K9's output; here every thread forms the nine points of its stencil itself, with K9's expression (the
-// same values bit for bit: nine divisions instead of one per pixel, on a launch that waits for memory), and stores its own.
-__device__ __forceinline__ void surface_point(int x, int y, int W, float focal_x, float focal_y, float cx, float cy,
-                                              const float* __restrict__ opacities, const float* __restrict__ depths, float (&p)[3])
-{
-    const size_t id = (size_t)y * W + x;
-    const float depth = depths[id] / fmaxf(opacities[id], 0.0000001f);
-    p[0] = (x - cx) / focal_x * depth;
-    p[1] = (y - cy) / focal_y * depth;
-    p[2] = depth;
-}
-
+// K9 + K10 in one launch (pseudo_normal.hpp).
 __global__ void __launch_bounds__(256)
 pseudo_normal_kernel(int W, int H, float focal_x, float focal_y, float cx, float cy, const float* __restrict__ vm,
                      const float* __restrict__ opacities, const float* __restrict__ depths, float* __restrict__ normals,
@@ -267,38 +255,7 @@ pseudo_normal_kernel(int W, int H, float focal_x, float focal_y, float cx, float
 {
     const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
     if (x >= W || y >= H) return;
-    const size_t HW = (size_t)H * W;
-    const int ys[3] = {y == 0 ? 0 : y - 1, y, y == H - 1 ? H - 1 : y + 1};
-    const int xs[3] = {x == 0 ? 0 : x - 1, x, x == W - 1 ? W - 1 : x + 1};
-    float s[3][3][3];                                        // [row][column][component]
-#pragma unroll
-    for (int a = 0; a < 3; a++)
-#pragma unroll
-        for (int b = 0; b < 3; b++) surface_point(xs[b], ys[a], W, focal_x, focal_y, cx, cy, opacities, depths, s[a][b]);
-    const size_t i11 = (size_t)W * y + x;
-    float ga[3], gb[3];
-#pragma unroll
-    for (int i = 0; i < 3; i++) {
-        surface_xyz[i * HW + i11] = s[1][1][i];
-        ga[i] = -0.125f * s[0][0][i] + 0.125f * s[0][2][i] - 0.25f * s[1][0][i] + 0.25f * s[1][2][i] - 0.125f * s[2][0][i] +
-                0.125f * s[2][2][i];
-        gb[i] = -0.125f * s[0][0][i] - 0.25f * s[0][1][i] - 0.125f * s[0][2][i] + 0.125f * s[2][0][i] + 0.25f * s[2][1][i] +
-                0.125f * s[2][2][i];
-    }
-    float nx = ga[1] * gb[2] - ga[2] * gb[1];
-    float ny = -ga[0] * gb[2] + ga[2] * gb[0];
-    float nz = ga[0] * gb[1] - ga[1] * gb[0];
-    const float norm = sqrtf(nx * nx + ny * ny + nz * nz);
-    if (norm <= 0.0f) {            // the reference leaves its zero-initialised output untouched here
-        normals[i11] = 0.f;
-        normals[HW + i11] = 0.f;
-        normals[2 * HW + i11] = 0.f;
-        return;
-    }
-    nx = -nx / norm; ny = -ny / norm; nz = -nz / norm;
-    normals[i11] = vm[0] * nx + vm[1] * ny + vm[2] * nz;
-    normals[HW + i11] = vm[4] * nx + vm[5] * ny + vm[6] * nz;
-    normals[2 * HW + i11] = vm[8] * nx + vm[9] * ny + vm[10] * nz;
+    pseudo_normal_pixel(x, y, W, H, focal_x, focal_y, cx, cy, vm, opacities, depths, normals, surface_xyz);
 }
 
 // ---- launchers ------------------------------------------------------------------------------------------

@@ -14,6 +14,7 @@
 #include <type_traits>
 
 #include "common.hpp"
+#include "pseudo_normal.hpp"
 #include "r3dg_hip.h"
 
 namespace r3dg {
@@ -51,6 +52,20 @@ __device__ __forceinline__ void normalize3_backward(const float v[3], float eps,
     }
 }
 
+// Side jobs of the activation kernel: microseconds of work that would otherwise be launches of their own on the iteration's critical
+// stream (5-20 us each there).  They ride as EXTRA WORKGROUPS behind the nb_main workgroups of the Gaussians:
+//   * env[i] = softplus(env_raw[i]) for the n_env floats of the environment texture (DirectLightMap.get_env,
+//     scene/direct_light_map.py:18-23; torch's softplus: beta 1, threshold 20);
+//   * zero[0..n_zero) = 0 (the iteration's loss sums).
+struct ActivateSide {
+    int nb_main;
+    int n_env;
+    const float* env_raw;
+    float* env;
+    float* zero;
+    int n_zero;
+};
+
 __global__ void __launch_bounds__(256)
 s2_activate_kernel(int P, const float* __restrict__ xyz, const float* __restrict__ scaling_raw,
                    const float* __restrict__ rotation_raw, const float* __restrict__ opacity_raw,
@@ -58,8 +73,19 @@ s2_activate_kernel(int P, const float* __restrict__ xyz, const float* __restrict
                    const float* __restrict__ rough_raw, const float* __restrict__ campos,
                    float* __restrict__ scales, float* __restrict__ rot, float* __restrict__ opacity,
                    float* __restrict__ normal, float* __restrict__ base_color, float* __restrict__ roughness,
-                   float* __restrict__ viewdirs, const float* __restrict__ viewmatrix, float* __restrict__ features)
+                   float* __restrict__ viewdirs, const float* __restrict__ viewmatrix, float* __restrict__ features,
+                   ActivateSide side)
 {
+    if ((int)blockIdx.x >= side.nb_main) {
+        const int nb_side = (int)gridDim.x - side.nb_main;
+        for (int k = ((int)blockIdx.x - side.nb_main) * 256 + (int)threadIdx.x; k < side.n_env; k += nb_side * 256) {
+            const float r = side.env_raw[k];
+            side.env[k] = r > 20.f ? r : log1pf(expf(r));
+        }
+        for (int k = ((int)blockIdx.x - side.nb_main) * 256 + (int)threadIdx.x; k < side.n_zero; k += nb_side * 256)
+            side.zero[k] = 0.f;
+        return;
+    }
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= P) return;
     const size_t i3 = 3 * (size_t)i, i4 = 4 * (size_t)i;
@@ -187,6 +213,56 @@ s2_unpack_kernel(int P, const float* __restrict__ dL_dfeatures, const float* __r
     if (threadIdx.x == 0) block_absmax[blockIdx.x] = fmaxf(fmaxf(s_m[0], s_m[1]), fmaxf(s_m[2], s_m[3]));
 }
 
+// DirectLightMap: env = softplus(raw) (direct_light_map.py:18-23) and the total-variation smoothness term on it
+// (neilf.py:294-300): g_raw = (dL_denv + w_tv * dTV/denv) * softplus'(raw); *tv_sum += TV(env) (unweighted).
+// env layout [He,We,3]; TV = mean (d/dh)^2 + mean (d/dw)^2 over the 3 x He x We image (the reference's tv_loss,
+// utils/loss_utils.py:113-117, pinned by tests/golden/ssim_reference.npz).
+// One workgroup of 256 threads per 256 texture floats (`block` = its index); a launch of its own (s2_env_backward_kernel) or the
+// extra workgroups of s2_activate_backward_kernel (the texture is 1536 floats: six workgroups that took 11-20 us as a launch on
+// the critical stream between the activation chain rule and Adam).
+struct EnvBackward {
+    int He, We;
+    const float* raw;
+    const float* env;
+    float* dL_denv;
+    float w_tv;
+    float* g_raw;
+    float* tv_sum;
+    int consume;
+};
+
+__device__ __forceinline__ void env_backward_block(int block, const EnvBackward& a)
+{
+    __shared__ float s_part[4];
+    const int He = a.He, We = a.We;
+    const int n = He * We * 3;
+    const int i = block * 256 + threadIdx.x;
+    float tv = 0.f;
+    if (i < n) {
+        const int w = (i / 3) % We, h = i / (3 * We);
+        const float inv_v = He > 1 ? 1.f / (3.f * (He - 1) * We) : 0.f, inv_h = We > 1 ? 1.f / (3.f * He * (We - 1)) : 0.f;
+        const float x = a.env[i];
+        float g = 0.f;
+        // tv_loss (utils/loss_utils.py:113-117): mean SQUARED forward difference along h plus the same along w
+        if (h > 0) g += inv_v * 2.f * (x - a.env[i - 3 * We]);
+        if (h < He - 1) { const float d = a.env[i + 3 * We] - x; g -= inv_v * 2.f * d; tv += inv_v * d * d; }
+        if (w > 0) g += inv_h * 2.f * (x - a.env[i - 3]);
+        if (w < We - 1) { const float d = a.env[i + 3] - x; g -= inv_h * 2.f * d; tv += inv_h * d * d; }
+        const float r = a.raw[i];
+        const float dsoft = r > 20.f ? 1.f : sigmoidf_(r);
+        a.g_raw[i] = (a.dL_denv[i] + a.w_tv * g) * dsoft;
+        if (a.consume) a.dL_denv[i] = 0.f;        // the accumulator is handed back zeroed for the next shading backward
+    }
+    const float tot = block_sum_256(tv, s_part);
+    if (threadIdx.x == 0 && a.tv_sum != nullptr) atomicAdd(sum_slot(a.tv_sum), tot);
+}
+
+__global__ void __launch_bounds__(256)
+s2_env_backward_kernel(EnvBackward a)
+{
+    env_backward_block((int)blockIdx.x, a);
+}
+
 __global__ void __launch_bounds__(256)
 s2_activate_backward_kernel(int P, const float* __restrict__ xyz, const float* __restrict__ scaling_raw,
                             const float* __restrict__ rotation_raw, const float* __restrict__ opacity_raw,
@@ -199,8 +275,12 @@ s2_activate_backward_kernel(int P, const float* __restrict__ xyz, const float* _
                             const float* __restrict__ dL_dmeans3D, float* __restrict__ g_xyz,
                             float* __restrict__ g_scaling, float* __restrict__ g_rotation,
                             float* __restrict__ g_opacity, float* __restrict__ g_normal, float* __restrict__ g_base,
-                            float* __restrict__ g_rough)
+                            float* __restrict__ g_rough, int nb_main, EnvBackward env_job)
 {
+    if ((int)blockIdx.x >= nb_main) {             // side job: the environment texture's chain rule (EnvBackward)
+        env_backward_block((int)blockIdx.x - nb_main, env_job);
+        return;
+    }
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= P) return;
     const size_t i3 = 3 * (size_t)i, i4 = 4 * (size_t)i;
@@ -284,6 +364,31 @@ s2_pbr_srgb_kernel(int HW, const float* __restrict__ opacity, const float* __res
     }
 }
 
+// pseudo_normal_kernel (the rasterizer forward's K9 + K10, pseudo_normal.hpp) and s2_pbr_srgb_kernel as ONE launch, pixel by pixel:
+// the two are independent per-pixel passes over the tile forward's outputs that followed each other on the critical stream (10 + 7
+// us at 800x800).  Same values as the two kernels (same device functions).
+__global__ void __launch_bounds__(256)
+s2_normals_srgb_kernel(int W, int H, float focal_x, float focal_y, float cx, float cy, const float* __restrict__ vm,
+                       const float* __restrict__ opacity, const float* __restrict__ depths, float* __restrict__ normals,
+                       float* __restrict__ surface_xyz, const float* __restrict__ feature, const int* __restrict__ n_contrib,
+                       const float* __restrict__ bg, float* __restrict__ srgb)
+{
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= W || y >= H) return;
+    const int HW = W * H, i = y * W + x;
+    {
+        const float op = opacity[i];
+        const float scale = n_contrib[i] > 0 ? 1.f / fmaxf(op, 1e-5f) : 0.f;
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+            const float v0 = feature[(size_t)(2 + c) * HW + i] * scale * op + (1.f - op) * bg[c];
+            const float v = v0 <= 0.0031308f ? 12.92f * v0 : 1.055f * srgb_pow(fmaxf(v0, 0.0031308f), 1.f / 2.4f) - 0.055f;
+            srgb[(size_t)c * HW + i] = fminf(fmaxf(v, 0.f), 1.f);
+        }
+    }
+    pseudo_normal_pixel(x, y, W, H, focal_x, focal_y, cx, cy, vm, opacity, depths, normals, surface_xyz);
+}
+
 // Image-space loss + gradient in one pass.  sums[0..2] += sum|image-gt|, sum|srgb(pbr)-gt|, sum (n_render - n_pseudo)^2
 // (unweighted); gradients carry the weights w_* (already divided by the element counts).
 // SPARSE: only the feature-gradient maps that carry a loss term are written (2-4; 5-7 when w_normal != 0) -- for callers
@@ -363,39 +468,6 @@ s2_loss_kernel(int HW, const float* __restrict__ image, const float* __restrict_
         atomicAdd(sum_slot(sums + 1 * R3DG_SUM_SLOTS), t1);
         atomicAdd(sum_slot(sums + 2 * R3DG_SUM_SLOTS), t2);
     }
-}
-
-// DirectLightMap: env = softplus(raw) (direct_light_map.py:18-23) and the total-variation smoothness term on it
-// (neilf.py:294-300): g_raw = (dL_denv + w_tv * dTV/denv) * softplus'(raw); *tv_sum += TV(env) (unweighted).
-// env layout [He,We,3]; TV = mean (d/dh)^2 + mean (d/dw)^2 over the 3 x He x We image (the reference's tv_loss,
-// utils/loss_utils.py:113-117, pinned by tests/golden/ssim_reference.npz).
-__global__ void __launch_bounds__(256)
-s2_env_backward_kernel(int He, int We, const float* __restrict__ raw, const float* __restrict__ env,
-                       float* __restrict__ dL_denv, float w_tv, float* __restrict__ g_raw,
-                       float* __restrict__ tv_sum, int consume)
-{
-    __shared__ float s_part[4];
-    const int n = He * We * 3;
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    float tv = 0.f;
-    if (i < n) {
-        const int c = i % 3, w = (i / 3) % We, h = i / (3 * We);
-        (void)c;
-        const float inv_v = He > 1 ? 1.f / (3.f * (He - 1) * We) : 0.f, inv_h = We > 1 ? 1.f / (3.f * He * (We - 1)) : 0.f;
-        const float x = env[i];
-        float g = 0.f;
-        // tv_loss (utils/loss_utils.py:113-117): mean SQUARED forward difference along h plus the same along w
-        if (h > 0) g += inv_v * 2.f * (x - env[i - 3 * We]);
-        if (h < He - 1) { const float d = env[i + 3 * We] - x; g -= inv_v * 2.f * d; tv += inv_v * d * d; }
-        if (w > 0) g += inv_h * 2.f * (x - env[i - 3]);
-        if (w < We - 1) { const float d = env[i + 3] - x; g -= inv_h * 2.f * d; tv += inv_h * d * d; }
-        const float r = raw[i];
-        const float dsoft = r > 20.f ? 1.f : sigmoidf_(r);
-        g_raw[i] = (dL_denv[i] + w_tv * g) * dsoft;
-        if (consume) dL_denv[i] = 0.f;            // the accumulator is handed back zeroed for the next shading backward
-    }
-    const float tot = block_sum_256(tv, s_part);
-    if (threadIdx.x == 0 && tv_sum != nullptr) atomicAdd(sum_slot(tv_sum), tot);
 }
 
 // ---- stage 1 (plain 3DGS + normals, gaussian_renderer/render.py:15-130): S = 5 feature row [normal, depth, depth^2] ---
@@ -1186,11 +1258,20 @@ void launch_s2_activate(hipStream_t s, int P, const float* xyz, const float* sca
                         const float* opacity_raw, const float* normal_raw, const float* base_raw,
                         const float* rough_raw, const float* campos, float* scales, float* rot, float* opacity,
                         float* normal, float* base_color, float* roughness, float* viewdirs, const float* viewmatrix,
-                        float* features)
+                        float* features, int n_env, const float* env_raw, float* env, float* zero, int n_zero)
 {
-    s2_activate_kernel<<<(P + 255) / 256, 256, 0, s>>>(P, xyz, scaling_raw, rotation_raw, opacity_raw, normal_raw,
-                                                       base_raw, rough_raw, campos, scales, rot, opacity, normal,
-                                                       base_color, roughness, viewdirs, viewmatrix, features);
+    ActivateSide side;
+    side.nb_main = (P + 255) / 256;
+    side.n_env = env_raw != nullptr && env != nullptr ? n_env : 0;
+    side.env_raw = env_raw;
+    side.env = env;
+    side.zero = zero;
+    side.n_zero = zero != nullptr ? n_zero : 0;
+    const int work = side.n_env > side.n_zero ? side.n_env : side.n_zero;
+    const int nb_side = work > 0 ? (work + 255) / 256 < 8 ? (work + 255) / 256 : 8 : 0;
+    s2_activate_kernel<<<side.nb_main + nb_side, 256, 0, s>>>(P, xyz, scaling_raw, rotation_raw, opacity_raw, normal_raw,
+                                                              base_raw, rough_raw, campos, scales, rot, opacity, normal,
+                                                              base_color, roughness, viewdirs, viewmatrix, features, side);
     check_launch(s, false, "s2_activate_kernel");
 }
 
@@ -1218,13 +1299,29 @@ void launch_s2_activate_backward(hipStream_t s, int P, const float* xyz, const f
                                  const float* dL_drough_shade, const float* dL_dviewdirs, const float* dL_dscales,
                                  const float* dL_drot, const float* dL_dopacity, const float* dL_dmeans3D, float* g_xyz,
                                  float* g_scaling, float* g_rotation, float* g_opacity, float* g_normal, float* g_base,
-                                 float* g_rough)
+                                 float* g_rough, int He, int We, const float* env_raw, const float* env, float* dL_denv,
+                                 float w_tv, float* g_env_raw, float* tv_sum, int consume)
 {
-    s2_activate_backward_kernel<<<(P + 255) / 256, 256, 0, s>>>(
+    EnvBackward job;
+    job.He = He; job.We = We; job.raw = env_raw; job.env = env; job.dL_denv = dL_denv; job.w_tv = w_tv; job.g_raw = g_env_raw;
+    job.tv_sum = tv_sum; job.consume = consume;
+    const int nb_main = (P + 255) / 256;
+    const int nb_env = env_raw != nullptr ? (He * We * 3 + 255) / 256 : 0;
+    s2_activate_backward_kernel<<<nb_main + nb_env, 256, 0, s>>>(
         P, xyz, scaling_raw, rotation_raw, opacity_raw, normal_raw, base_raw, rough_raw, viewmatrix, campos,
         dL_dfeatures, dL_dbase_shade, dL_drough_shade, dL_dviewdirs, dL_dscales, dL_drot, dL_dopacity, dL_dmeans3D, g_xyz,
-        g_scaling, g_rotation, g_opacity, g_normal, g_base, g_rough);
+        g_scaling, g_rotation, g_opacity, g_normal, g_base, g_rough, nb_main, job);
     check_launch(s, false, "s2_activate_backward_kernel");
+}
+
+void launch_s2_normals_srgb(hipStream_t s, int W, int H, const float* vm, float focal_x, float focal_y, float cx, float cy,
+                            const float* opacity, const float* depths, float* normals, float* surface_xyz, const float* feature,
+                            const int* n_contrib, const float* bg, float* srgb)
+{
+    dim3 grid((W + 63) / 64, (H + 3) / 4);
+    s2_normals_srgb_kernel<<<grid, 256, 0, s>>>(W, H, focal_x, focal_y, cx, cy, vm, opacity, depths, normals, surface_xyz,
+                                                feature, n_contrib, bg, srgb);
+    check_launch(s, false, "s2_normals_srgb_kernel");
 }
 
 void launch_s2_pbr_srgb(hipStream_t s, int HW, const float* opacity, const float* feature, const int* n_contrib,
@@ -1257,8 +1354,10 @@ void launch_s2_loss(hipStream_t s, int HW, const float* image, const float* opac
 void launch_s2_env_backward(hipStream_t s, int He, int We, const float* raw, const float* env, float* dL_denv,
                             float w_tv, float* g_raw, float* tv_sum, int consume)
 {
-    s2_env_backward_kernel<<<(He * We * 3 + 255) / 256, 256, 0, s>>>(He, We, raw, env, dL_denv, w_tv, g_raw, tv_sum,
-                                                                    consume);
+    EnvBackward job;
+    job.He = He; job.We = We; job.raw = raw; job.env = env; job.dL_denv = dL_denv; job.w_tv = w_tv; job.g_raw = g_raw;
+    job.tv_sum = tv_sum; job.consume = consume;
+    s2_env_backward_kernel<<<(He * We * 3 + 255) / 256, 256, 0, s>>>(job);
     check_launch(s, false, "s2_env_backward_kernel");
 }
 

@@ -391,7 +391,7 @@ class FusedStage2Step(_BoundedForward):
         self._early_pending = False                 # the early-Adam stream holds work no other stream has been ordered behind yet
         self._b_early = False
         # softplus of the environment texture, refreshed behind the Adam launch that updates the texture (see optimizer_step)
-        self._env_c = self._env_c_key = None
+        self._env_c = None                          # softplus(environment texture), see _env_buffer
         self._zero_depth_grad = None
         # instance ordering of the rasterizer runs here, under the shading forward (register-light, latency-bound kernels
         # next to a VALU-bound one)
@@ -497,11 +497,14 @@ class FusedStage2Step(_BoundedForward):
     def get_normal(self):
         return F.normalize(self.normal, dim=-1, eps=1e-3)
 
-    def refresh_activations(self, cam=None):
+    def refresh_activations(self, cam=None, env_out=None, zero=None):
+        """GaussianModel's activations + view directions (+ the feature-row columns that do not wait for the shading integral).
+        `env_out` / `zero` (the iteration): the softplus of the environment texture into `env_out` and a zero fill of `zero` ride
+        as extra workgroups of the same launch (r3dg_stage2_activate_with) instead of two launches on the critical stream."""
         L = _lib.lib()
         campos = cam.camera_center if cam is not None else torch.zeros(3, device=self.dev)
         with torch.cuda.device(self.dev):
-            st = L.r3dg_stage2_activate(
+            st = L.r3dg_stage2_activate_with(
                 _lib.current_stream(), self.P, self.xyz.data_ptr(), self.scaling.data_ptr(), self.rotation.data_ptr(),
                 self.opacity.data_ptr(), self.normal.data_ptr(), self.base_color.data_ptr(), self.roughness.data_ptr(),
                 campos.contiguous().data_ptr(), self.a_scales.data_ptr(), self.a_rot.data_ptr(),
@@ -509,7 +512,10 @@ class FusedStage2Step(_BoundedForward):
                 self.a_viewdirs.data_ptr(),
                 # the nine columns of the feature rows that do not wait for the shading integral (see forward_backward)
                 cam.world_view_transform.contiguous().data_ptr() if cam is not None and self._direct_rows else None,
-                self.features.data_ptr() if cam is not None and self._direct_rows else None)
+                self.features.data_ptr() if cam is not None and self._direct_rows else None,
+                0 if env_out is None else env_out.numel(), None if env_out is None else self.env.data_ptr(),
+                None if env_out is None else env_out.data_ptr(), None if zero is None else zero.data_ptr(),
+                0 if zero is None else zero.numel())
         _lib.check(st, "stage2_activate")
 
     def taps(self, He, We):
@@ -540,14 +546,12 @@ class FusedStage2Step(_BoundedForward):
                 self._frs.taps(He, We)
         return self._taps
 
-    def _refresh_env(self):
-        """softplus of the environment texture (DirectLightMap.get_env), cached: recomputed when the texture tensor was replaced or
-        edited through torch, and by optimizer_step behind the Adam launch that updates it (the Adam kernel writes through the raw
-        pointer, which the version counter does not see)."""
-        key = (self.env, self.env._version)
-        if self._env_c is None or self._env_c_key is None or self._env_c_key[0] is not key[0] or self._env_c_key[1] != key[1]:
-            self._env_c = F.softplus(self.env)[0]
-            self._env_c_key = key
+    def _env_buffer(self):
+        """Where the iteration keeps softplus(environment texture) (DirectLightMap.get_env) [He,We,3]: filled by the activation
+        launch of every iteration (refresh_activations(env_out=)), read by the shading kernels and the texture's chain rule."""
+        shape = tuple(self.env.shape[1:])
+        if self._env_c is None or tuple(self._env_c.shape) != shape:
+            self._env_c = torch.empty(shape, dtype=torch.float32, device=self.dev)
         return self._env_c
 
     def _rotation_is_current(self):
@@ -607,26 +611,16 @@ class FusedStage2Step(_BoundedForward):
                     with torch.cuda.stream(aux):
                         self._frs.rotate(self._incidents)
                 rotated_for = self._frs
-            # The small view-independent launches of the iteration:
-            #   * softplus of the environment texture: done behind the Adam launch that updates the texture, at the end of the
-            #     previous iteration (optimizer_step -> _refresh_env); here only when somebody replaced or edited the texture;
-            #   * the loss-sum reset and the zero fill of the tile backward's accumulator slab (32 MB at 300k Gaussians; it used to sit
-            #     between the loss and the tile backward, alone on the device): nobody reads either before the image-space loss, so
-            #     they go to the early stream BEHIND the listed Gaussians' forward kernel and run under the shading forward / the
-            #     instance ordering (`late_zero_fills`); the join that follows that kernel covers them.  Without that stream: on
-            #     the main stream, in front of the shading forward.
-            # (Rounds 3-4 had all three on the early stream behind the coefficient rotation, round 5 first on the main stream behind
-            # the front end's launches: 52 us under contention, in front of the shading forward either way.)
+            # The small view-independent jobs of the iteration -- softplus of the environment texture, the loss-sum reset -- ride
+            # as extra workgroups of the activation launch (rounds 3-4: three launches on the early stream behind the coefficient
+            # rotation; round 5 first on the main stream behind the front end's launches: 52 us under contention).  The tile
+            # backward's accumulator slab needs no zero fill any more: its scatter pass writes every element.
             acc_n = (11 + 16) * P
             if self._acc is None or self._acc.numel() != acc_n:
                 self._acc = torch.empty(acc_n, dtype=torch.float32, device=dev)
-            env_c = self._refresh_env()
-
-            def late_zero_fills():
-                self.sums.zero_()
-                self._acc.zero_()
+            env_c = self._env_buffer()
             acc_ready = True
-            self.refresh_activations(cam)
+            self.refresh_activations(cam, env_out=env_c, zero=self.sums)
             self._iter += 1
             flag_cur = self._flag_of_iteration()
             use_bounded = self._use_bounded(W, H)
@@ -642,7 +636,8 @@ class FusedStage2Step(_BoundedForward):
                     bg, self.xyz, self.features, empty, self.a_opacity, self.a_scales, self.a_rot, 1.0, empty, vm,
                     cam.full_proj_transform, cam.tanfovx, cam.tanfovy, cam.cx, cam.cy, H, W, self.shs, 3, campos, False,
                     True, False, capacity=self._capacity, overflow_flag=flag_cur,
-                    overflow_count=self._overflow_count, ordering_stream=order_stream, want_weights=False)
+                    overflow_count=self._overflow_count, ordering_stream=order_stream, want_weights=False,
+                    defer_pseudo_normal=True)
             else:
                 # first half of the rasterizer (projection + async read-back of num_rendered): the shading kernels below
                 # run while the host waits for the count and enqueues the second half
@@ -650,12 +645,10 @@ class FusedStage2Step(_BoundedForward):
                 pending = rasterizer_ops.rasterize_gaussians_begin(
                     bg, self.xyz, self.features, empty, self.a_opacity, self.a_scales, self.a_rot, 1.0, empty, vm,
                     cam.full_proj_transform, cam.tanfovx, cam.tanfovy, cam.cx, cam.cy, H, W, self.shs, 3, campos, False,
-                    True, False, want_weights=False)       # (stage 2 does not densify: nobody reads the blend weights)
+                    True, False, want_weights=False,       # (stage 2 does not densify: nobody reads the blend weights)
+                    defer_pseudo_normal=True)
             if self._pending_b is not None:
                 self.flush()    # (world > 1) the previous iteration's incident-light update lands here
-            zero_stream = self._listed_stream()
-            if zero_stream is None:
-                late_zero_fills()
             if aux is not None:
                 _lib.stream_wait(main, aux)
                 self._early_pending = False          # (aux IS the early stream: the main stream is behind all of it now)
@@ -681,11 +674,6 @@ class FusedStage2Step(_BoundedForward):
                     None if self._uniform_area is not None else self.incident_areas.data_ptr(), self._uniform_area or 0.0,
                     taps.data_ptr(), 1 | (4 if order_stream is not None else 0),     # train outputs | leave room
                     self.shade_out.data_ptr()), "shade_forward")
-            if zero_stream is not None:
-                # (the early stream: idle but for the listed Gaussians' forward kernel; ordered behind everything the previous
-                # iteration's consumers of the two buffers did -- they ran on the main stream, which the fork at the top followed)
-                with torch.cuda.stream(zero_stream):
-                    late_zero_fills()
             if self._frs is not None and self._listed_stream() is not None:
                 _lib.stream_wait(main, self._listed_stream())
             packed = not (self._frs is not None and self._direct_rows)
@@ -707,8 +695,11 @@ class FusedStage2Step(_BoundedForward):
             gt_c, bg_c = gt.contiguous(), bg.contiguous()
             srgb, part_i, part_p, gs_i, gs_p = g[20:23], g[23:32], g[32:41], g[41:44], g[44:47]
             lam = LAMBDA_DSSIM
-            _lib.check(L.r3dg_stage2_pbr_srgb(stream(), W, H, opacity.data_ptr(), feature.data_ptr(),
-                                              n_contrib.data_ptr(), bg_c.data_ptr(), srgb.data_ptr()), "stage2_pbr_srgb")
+            # the rasterizer forward's pseudo-normal pass (deferred above) and the sRGB-mapped PBR image: one per-pixel launch
+            _lib.check(L.r3dg_stage2_normals_srgb(
+                stream(), W, H, vm.data_ptr(), float(cam.tanfovx), float(cam.tanfovy), float(cam.cx), float(cam.cy),
+                opacity.data_ptr(), depth.data_ptr(), pseudo_normal.data_ptr(), sxyz.data_ptr(), feature.data_ptr(),
+                n_contrib.data_ptr(), bg_c.data_ptr(), srgb.data_ptr()), "stage2_normals_srgb")
             # SSIM terms of both images: one forward and one backward launch for the pair
             _lib.check(L.r3dg_ssim_forward_pair(stream(), W, H, 3, image.data_ptr(), srgb.data_ptr(), gt_c.data_ptr(),
                                                 part_i.data_ptr(), part_p.data_ptr(), self.sums[5].data_ptr(),
@@ -872,25 +863,25 @@ class FusedStage2Step(_BoundedForward):
                 main.wait_event(self._geo_done)       # queued behind it on that stream)
                 if self._side is not None:
                     handle_a = self._allreduce_async(self._bucket_a)
+            # the environment texture's chain rule (softplus' + total-variation term; r3dg_stage2_env_backward) rides as six
+            # extra workgroups of the activation chain rule's launch
+            env_job = (He, We, self.env.data_ptr(), env_c.data_ptr(), d_env.data_ptr(), self.w["env_smooth"],
+                       gr["env"].data_ptr(), self.sums[4].data_ptr(), 1)
             if self.frozen_geometry:
-                _lib.check(L.r3dg_stage2_activate_backward(
+                _lib.check(L.r3dg_stage2_activate_backward_with(
                     stream(), P, None, None, None, None, None, self.base_color.data_ptr(), self.roughness.data_ptr(), None,
                     None, dL_dfeatures.data_ptr(), d_base.data_ptr(), d_rough.data_ptr(), None, None, None, None, None,
-                    None, None, None, None, None, gr["base_color"].data_ptr(), gr["roughness"].data_ptr()),
+                    None, None, None, None, None, gr["base_color"].data_ptr(), gr["roughness"].data_ptr(), *env_job),
                     "stage2_activate_backward")
             else:
-                _lib.check(L.r3dg_stage2_activate_backward(
+                _lib.check(L.r3dg_stage2_activate_backward_with(
                     stream(), P, self.xyz.data_ptr(), self.scaling.data_ptr(), self.rotation.data_ptr(),
                     self.opacity.data_ptr(), self.normal.data_ptr(), self.base_color.data_ptr(), self.roughness.data_ptr(),
                     vm.data_ptr(), campos.data_ptr(), dL_dfeatures.data_ptr(), d_base.data_ptr(), d_rough.data_ptr(),
                     d_view.data_ptr(), dL_dscales.data_ptr(), dL_drot.data_ptr(), dL_dopacity.data_ptr(),
                     dL_dmeans3D.data_ptr(), gr["xyz"].data_ptr(), gr["scaling"].data_ptr(), gr["rotation"].data_ptr(),
                     gr["opacity"].data_ptr(), gr["normal"].data_ptr(), gr["base_color"].data_ptr(),
-                    gr["roughness"].data_ptr()), "stage2_activate_backward")
-            # environment texture: softplus chain rule + total-variation term
-            _lib.check(L.r3dg_stage2_env_backward(
-                stream(), He, We, self.env.data_ptr(), env_c.data_ptr(), d_env.data_ptr(), self.w["env_smooth"],
-                gr["env"].data_ptr(), self.sums[4].data_ptr(), 1), "stage2_env_backward")
+                    gr["roughness"].data_ptr(), *env_job), "stage2_activate_backward")
             self._handles = None
             if self.dp:
                 handle_c = self._allreduce_async(self._bucket_c)
@@ -987,11 +978,6 @@ class FusedStage2Step(_BoundedForward):
                 todo = self._groups_a + self._groups_c + self._groups_b
             if todo:                     # ONE launch for every remaining group
                 self.opt.step_groups(todo, grads, skip_flag=self._skip_cur)
-            if "env" not in self.frozen:
-                # the next iteration's texture, behind the launch that updated it (one tiny launch at the END of the iteration,
-                # where the main stream has nothing else to do, instead of in front of the next shading forward)
-                self._env_c = F.softplus(self.env)[0]
-                self._env_c_key = (self.env, self.env._version)
             return
         # data parallel: update each bucket when its (sum) all-reduce has landed; 1/world is applied inside the kernel
         scale = 1.0 / self.world
@@ -1011,7 +997,6 @@ class FusedStage2Step(_BoundedForward):
                 self._wait(handle_c)
         if self._groups_c:
             self.opt.step_groups(self._groups_c, grads, scale, skip_flag=self._skip_cur)
-        self._env_c_key = None           # (the texture moved: the next forward recomputes its softplus)
         self._pending_b = (handle_b, grads, scale, self._skip_cur)
 
     @_in_context

@@ -105,7 +105,7 @@ def rasterize_gaussians_begin(background, means3D, features, colors, opacity, sc
                               cov3D_precomp, viewmatrix, projmatrix, tan_fovx, tan_fovy, cx, cy, image_height,
                               image_width, sh, degree, campos, prefiltered, computer_pseudo_normal, debug,
                               capacity=None, overflow_flag=None, overflow_count=None, ordering_stream=None,
-                              want_weights=True):
+                              want_weights=True, defer_pseudo_normal=False):
     """First half of rasterize_gaussians (same arguments): projection + asynchronous read-back of num_rendered.  Returns
     an object whose .finish() completes the call and returns the 13-tuple.  Kernels launched on the current stream in
     between (e.g. the ones that fill `features`, whose CONTENTS are first read by .finish()'s kernels) overlap the wait.
@@ -116,7 +116,9 @@ def rasterize_gaussians_begin(background, means3D, features, colors, opacity, sc
     `overflow_flag` (float32 tensor, >= 1 element) is set to 1 when the frame needed more and was dropped, else 0;
     `overflow_count` (int32 tensor) counts dropped frames.  All tensors are allocated on the current stream.
     `want_weights=False` (not in the reference): the per-Gaussian blend weights -- which only the densification statistics
-    read -- are not computed; the `weights` slot of the result is None."""
+    read -- are not computed; the `weights` slot of the result is None.
+    `defer_pseudo_normal=True` (not in the reference): the pseudo-normal / surface-point maps are allocated and returned but NOT
+    computed (and not zero-filled): the caller runs r3dg_stage2_normals_srgb on them, fused with its own per-pixel pass."""
     L = _lib.lib()
     if means3D.ndimension() != 2 or means3D.size(1) != 3:
         raise RuntimeError("means3D must have dimensions (num_points, 3)")
@@ -134,7 +136,9 @@ def rasterize_gaussians_begin(background, means3D, features, colors, opacity, sc
     slab = (torch.zeros if P == 0 else torch.empty)((11 + S, H, W), **fopt)
     out_color, out_opacity, out_depth = slab[0:3], slab[3:4], slab[4:5]
     out_feature, out_normal, out_surface_xyz = slab[5:5 + S], slab[5 + S:8 + S], slab[8 + S:11 + S]
-    if not computer_pseudo_normal:
+    if defer_pseudo_normal:
+        computer_pseudo_normal = False
+    elif not computer_pseudo_normal:
         slab[5 + S:].zero_()
     out_weights = torch.zeros((P, 1), **fopt) if want_weights else None
     radii = torch.empty((P,), dtype=torch.int32, device=dev)
@@ -198,8 +202,8 @@ def rasterize_gaussians_backward(background, means3D, features, radii, colors, s
     valid after the caller joins that stream; see r3dg_rasterize_backward_split).  `active_features`: optional list of
     the feature channels whose upstream gradient can be non-zero -- the caller's promise that all other channels of
     dL_dout_feature are zero; they are then skipped by the tile kernel (same results).  `zeroed_accumulators`: optional float32
-    tensor of (11 + S) * P ZEROS (the caller filled it earlier, off its critical path) that takes the place of the slab
-    zero-filled here; the five atomically accumulated outputs are views of it."""
+    tensor of (11 + S) * P floats (any contents since round 5 -- the name is from when it had to be zeros) that takes the place
+    of the slab allocated here; dL_dmeans2D, dL_dconic, dL_dopacity, dL_dcolors and dL_dfeatures are views of it."""
     L = _lib.lib()
     P = means3D.size(0)
     S = features.size(1)
@@ -215,9 +219,13 @@ def rasterize_gaussians_backward(background, means3D, features, radii, colors, s
     if zeroed_accumulators is not None:
         acc = zeroed_accumulators
         if acc.numel() != (11 + S) * P or acc.dtype != torch.float32 or not acc.is_contiguous() or acc.device != dev:
-            raise RuntimeError("zeroed_accumulators must be a contiguous float32 tensor of (11 + S) * P zeros on the device")
+            raise RuntimeError("zeroed_accumulators must be a contiguous float32 tensor of (11 + S) * P floats on the device")
     else:
-        acc = torch.zeros((11 + S) * P, **fopt)
+        # (round 5: the tile backward accumulates into per-Gaussian records of the library and its scatter pass WRITES every
+        # element of these five arrays -- zeros for Gaussians nothing touched, and for P == 0 / num_rendered == 0 the library
+        # fills them -- so the slab starts uninitialised; rounds 1-4 zero-filled it here, the reference fills five tensors,
+        # rasterize_points.cu:183-192)
+        acc = torch.empty((11 + S) * P, **fopt)
     dL_dfeatures = acc[0:S * P].view(P, S)
     o = S * P
     dL_dconic = acc[o:o + 4 * P].view(P, 2, 2); o += 4 * P

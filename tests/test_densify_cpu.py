@@ -113,13 +113,21 @@ def test_training_loop_follows_the_reference_schedule(monkeypatch):
             self.dev, self.P, self.stats, self.lrs = torch.device("cpu"), 10, None, lrs
             self.opt = types.SimpleNamespace(groups=[dict(lr=lrs["xyz"]), dict(lr=lrs["normal"])])
             self.xyz_lrs = []
+            self._iter, self.dp = 0, False            # (the step object counts its forward passes; single GPU)
 
         def enable_densification(self):
             self.stats = object()
 
         def forward_backward(self, cam, bg, gt, image_mask=None):
+            self._iter += 1
             log.append(("fb", cam, self.stats is not None))
             self.xyz_lrs.append(self.opt.groups[0]["lr"])
+
+        def replay_dropped(self, inputs_of):        # (FusedStage1Step.replay_dropped: the dropped forward passes, trained on again)
+            cam = inputs_of(10)[0]
+            self._iter += 1
+            log.append(("replay", 10, cam))
+            return [10]
 
         def densify_and_prune(self, max_grad, min_opacity, extent, max_screen_size, max_grad_normal, percent_dense,
                               generator):
@@ -151,7 +159,12 @@ def test_training_loop_follows_the_reference_schedule(monkeypatch):
     # one (the instance count has just grown with P) and at the end, and reported
     assert [n for tag, n in (x for x in log if x[0] == "poll")] == [5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16]
     assert [h for h in history if h[1] == "dropped_views"] == [(10, "dropped_views", 1)]
-    history = [h for h in history if h[1] != "dropped_views"]
+    # ... and trained on again right there: the view of forward pass 10 (c0), behind that iteration's own
+    # optimizer step, in front of the next iteration's forward
+    assert [h for h in history if h[1] == "replayed_views"] == [(10, "replayed_views", [10])]
+    ir = log.index(("replay", 10, "c0"))
+    assert log[ir - 1] == ("step",) and log[ir + 1][0] == "fb"
+    history = [h for h in history if h[1] not in ("dropped_views", "replayed_views")]
     # reference: for it in 1..16: stats while it < 14; densify if it > 4 and it % 3 == 0 (and it < 14): 6, 9, 12;
     # reset if it % 8 == 0 or (white and it == 4), only while it < 14: 4, 8
     assert [(i, e) for i, e, _ in history] == [(4, "reset_opacity"), (6, "densify"), (8, "reset_opacity"),

@@ -455,6 +455,82 @@ def test_feature_rows_written_in_place_equal_the_packed_rows(monkeypatch):
         assert float((g0 - g1).abs().max()) <= tol, (k, float((g0 - g1).abs().max()), tol)
 
 
+def test_folded_launches_equal_the_launches_they_replace():
+    """Round 5: r3dg_stage2_activate_with (softplus of the texture + a zero fill as extra workgroups), r3dg_stage2_activate_backward_with
+    (the texture's chain rule as extra workgroups) and r3dg_stage2_normals_srgb (the rasterizer forward's pseudo-normal pass + the
+    sRGB-mapped PBR image, pixel by pixel) against the separate launches / torch: same bits from the shared device code, the softplus
+    within an ulp of torch.nn.functional.softplus (direct_light_map.py:18-23)."""
+    import torch.nn.functional as F
+    from relightable3dgaussian_amd import _lib, rasterizer_ops
+    params, ref, fused, cam, bg, gt = _setup(P=3001, res=150, K=8, seed=5)
+    L = _lib.lib()
+    S = lambda: _lib.current_stream()
+    P = fused.P
+    # ---- activations + side jobs
+    with torch.no_grad():
+        fused.env.copy_(torch.linspace(-30.0, 30.0, fused.env.numel(), device=DEV).view_as(fused.env))     # both branches of softplus
+    fused.refresh_activations(cam)
+    plain = [t.clone() for t in (fused.a_scales, fused.a_rot, fused.a_opacity, fused.a_normal, fused.a_base, fused.a_rough,
+                                 fused.a_viewdirs, fused.features)]
+    for t in (fused.a_scales, fused.a_rot, fused.a_opacity, fused.a_normal, fused.a_base, fused.a_rough, fused.a_viewdirs):
+        t.fill_(float("nan"))
+    env_out = torch.full(tuple(fused.env.shape[1:]), float("nan"), device=DEV)
+    junk = torch.full((1000,), 7.0, device=DEV)
+    fused.refresh_activations(cam, env_out=env_out, zero=junk[:777])
+    after = (fused.a_scales, fused.a_rot, fused.a_opacity, fused.a_normal, fused.a_base, fused.a_rough, fused.a_viewdirs, fused.features)
+    for a, b in zip(plain, after):
+        assert torch.equal(a, b)
+    want = F.softplus(fused.env)[0]
+    assert float(((env_out - want).abs() / want.abs().clamp_min(1e-30)).max()) < 4e-7
+    assert float(junk[:777].abs().max()) == 0.0 and float(junk[777:].min()) == 7.0
+    # ---- chain rule + the texture's
+    fused.forward_backward(cam, bg, gt)
+    torch.cuda.synchronize()
+    He, We = fused.env.shape[1], fused.env.shape[2]
+    env_c = F.softplus(fused.env)[0].contiguous()
+    d_env = torch.randn_like(env_c)
+    g = [torch.randn(P, n, device=DEV) for n in (16, 3, 1, 3, 3, 4, 1, 3)]       # dL_dfeatures, d_base, d_rough, d_view, dscales, drot, dop, dmeans
+    vm, campos = cam.world_view_transform.contiguous(), cam.camera_center.contiguous()
+    def run(entry, extra, outs, d_env_buf, g_env, tv):
+        args = [S(), P, fused.xyz.data_ptr(), fused.scaling.data_ptr(), fused.rotation.data_ptr(), fused.opacity.data_ptr(),
+                fused.normal.data_ptr(), fused.base_color.data_ptr(), fused.roughness.data_ptr(), vm.data_ptr(), campos.data_ptr()]
+        args += [t.data_ptr() for t in g] + [o.data_ptr() for o in outs]
+        _lib.check(getattr(L, entry)(*args, *extra), entry)
+    shapes = ((P, 3), (P, 3), (P, 4), (P, 1), (P, 3), (P, 3), (P, 1))
+    outs_a = [torch.full(s, float("nan"), device=DEV) for s in shapes]
+    outs_b = [torch.full(s, float("nan"), device=DEV) for s in shapes]
+    da, db = d_env.clone(), d_env.clone()
+    ga, gb = torch.full_like(env_c, float("nan")), torch.full_like(env_c, float("nan"))
+    tva, tvb = torch.zeros(32, device=DEV), torch.zeros(32, device=DEV)
+    run("r3dg_stage2_activate_backward", (), outs_a, None, None, None)
+    _lib.check(L.r3dg_stage2_env_backward(S(), He, We, fused.env.data_ptr(), env_c.data_ptr(), da.data_ptr(), 0.37, ga.data_ptr(),
+                                          tva.data_ptr(), 1), "env_backward")
+    run("r3dg_stage2_activate_backward_with", (He, We, fused.env.data_ptr(), env_c.data_ptr(), db.data_ptr(), 0.37, gb.data_ptr(),
+                                                tvb.data_ptr(), 1), outs_b, None, None, None)
+    for a, b in zip(outs_a, outs_b):
+        assert torch.equal(a, b)
+    assert torch.equal(ga, gb) and float(db.abs().max()) == 0.0 and float(da.abs().max()) == 0.0
+    assert abs(float(tva.sum()) - float(tvb.sum())) <= 1e-6 * abs(float(tva.sum())) and float(tva.sum()) > 0
+    # ---- pseudo normals + sRGB map
+    empty = torch.Tensor([])
+    fw = rasterizer_ops.rasterize_gaussians(
+        bg, fused.xyz, fused.features, empty, fused.a_opacity, fused.a_scales, fused.a_rot, 1.0, empty, vm,
+        cam.full_proj_transform, cam.tanfovx, cam.tanfovy, cam.cx, cam.cy, cam.image_height, cam.image_width, fused.shs, 3, campos,
+        False, True, False)
+    R, n_contrib, image, opacity, depth, feature, pseudo_normal, sxyz = fw[:8]
+    H, W = cam.image_height, cam.image_width
+    srgb = torch.empty(3, H, W, device=DEV)
+    _lib.check(L.r3dg_stage2_pbr_srgb(S(), W, H, opacity.data_ptr(), feature.data_ptr(), n_contrib.data_ptr(), bg.data_ptr(),
+                                      srgb.data_ptr()), "pbr_srgb")
+    n2, x2, s2 = (torch.full((3, H, W), float("nan"), device=DEV) for _ in range(3))
+    _lib.check(L.r3dg_stage2_normals_srgb(S(), W, H, vm.data_ptr(), float(cam.tanfovx), float(cam.tanfovy), float(cam.cx),
+                                          float(cam.cy), opacity.data_ptr(), depth.data_ptr(), n2.data_ptr(), x2.data_ptr(),
+                                          feature.data_ptr(), n_contrib.data_ptr(), bg.data_ptr(), s2.data_ptr()), "normals_srgb")
+    assert torch.equal(s2, srgb) and torch.equal(x2, sxyz)
+    assert float((n2 - pseudo_normal).abs().max()) <= 1e-6 and float(pseudo_normal.abs().max()) > 0.5
+    print("folded launches: normals max diff %.2e" % float((n2 - pseudo_normal).abs().max()))
+
+
 def test_iterations_leave_no_device_memory_to_the_garbage_collector():
     """A frame's scratch buffers (geometry / binning / image state) are freed by reference counting when the iteration is over:
     no reference cycle holds a device tensor (the resize callbacks used to be closures over the object that owns them and the

@@ -684,11 +684,11 @@ def test_fused_stage2_iteration_host_logic_with_a_recording_library(monkeypatch)
     assert begun[0] is None and begun[1] == begun[2] == step._capacity_for(17)      # two-phase first, bounded afterwards
     fwd, bwd = "r3dg_shade_forward_cached", "r3dg_shade_backward_cached"
     assert names.count(fwd) == 3 and names.count(bwd) == 3 and names.count("r3dg_adam_step") == 6
-    one = names[names.index("r3dg_stage2_activate"):]
+    one = names[names.index("r3dg_stage2_activate_with"):]
     order = [n for n in one if n in (fwd, "r3dg_stage2_pack_features", "r3dg_ssim_forward_pair", "r3dg_stage2_loss",
-                                     "r3dg_stage2_unpack_gradients", bwd, "r3dg_stage2_activate_backward", "r3dg_adam_step")][:9]
+                                     "r3dg_stage2_unpack_gradients", bwd, "r3dg_stage2_activate_backward_with", "r3dg_adam_step")][:9]
     assert order == [fwd, "r3dg_stage2_pack_features", "r3dg_ssim_forward_pair", "r3dg_stage2_loss", "r3dg_adam_step",
-                     "r3dg_stage2_unpack_gradients", bwd, "r3dg_stage2_activate_backward", "r3dg_adam_step"], order
+                     "r3dg_stage2_unpack_gradients", bwd, "r3dg_stage2_activate_backward_with", "r3dg_adam_step"], order
     assert "r3dg_stage2_smooth_forward" not in names                          # run_nerf.sh's objective has no smoothness terms
     # above a million Gaussians (R3DG_EARLY_ADAM overrides the size rule) the SH group is NOT updated under the shading backward:
     # one Adam launch per iteration, all ten groups, behind the chain rule
@@ -721,7 +721,7 @@ def test_fused_stage2_iteration_host_logic_with_a_recording_library(monkeypatch)
     assert feats == [(2, 3, 4, 8, 9, 10, 11, 12, 13, 14)] * 2
     adam = [c[1] for c in calls if c[0] == "r3dg_adam_step"]
     assert len(adam) == 2 and all(a[1] == 4 for a in adam)                     # ONE launch per iteration, four groups that train
-    ab = [c[1] for c in calls if c[0] == "r3dg_stage2_activate_backward"][0]
+    ab = [c[1] for c in calls if c[0] == "r3dg_stage2_activate_backward_with"][0]
     assert ab[2] is None and ab[19] is None and ab[24] == step.grads["base_color"].data_ptr()   # no geometry in or out
     sm = [c[1] for c in calls if c[0] == "r3dg_stage2_smooth_fused"][0]
     N_ = H * W
@@ -863,19 +863,27 @@ def test_fused_stage2_iteration_spreads_the_fixed_ray_set_path_over_three_stream
     assert early is not None and early is not order_stream and early is not main
     # ---- the third iteration (bounded forward, fixed-ray-set path, incident-light chain of round 5) ---------------------------
     it, args = [e[0] for e in events[marks[2]:]], [e[1] for e in events[marks[2]:]]
-    pos = {n: it.index(n) for n in ("r3dg_stage2_activate", "raster.begin", "frs.forward",
+    pos = {n: it.index(n) for n in ("r3dg_stage2_activate_with", "raster.begin", "frs.forward",
                                     "raster.finish", "raster.backward", "r3dg_stage2_unpack_gradients", "frs.backward",
-                                    "frs.rotate", "r3dg_stage2_activate_backward")}
-    assert sorted(pos, key=pos.get) == ["r3dg_stage2_activate", "raster.begin", "frs.forward", "raster.finish", "raster.backward",
+                                    "frs.rotate", "r3dg_stage2_activate_backward_with")}
+    assert sorted(pos, key=pos.get) == ["r3dg_stage2_activate_with", "raster.begin", "frs.forward", "raster.finish", "raster.backward",
                                         "r3dg_stage2_unpack_gradients", "frs.backward", "frs.rotate",
-                                        "r3dg_stage2_activate_backward"]
+                                        "r3dg_stage2_activate_backward_with"]
     # the coefficient rotation is NOT at the top of the iteration any more: the previous iteration queued it on the early stream
     # behind the incident-light group's Adam, and the ray set still holds the rotation of the current coefficients
     assert it.count("frs.rotate") == 1 and step._rotation_is_current()
     # no pack kernel on this path: the activations and the shading kernels write the feature rows between them, and the
     # light-smoothness sum comes from the unpack kernel (its last argument)
     assert "r3dg_stage2_pack_features" not in it and rows[-1] is step.features
-    assert args[pos["r3dg_stage2_activate"]][-1] == step.features.data_ptr()
+    act = args[pos["r3dg_stage2_activate_with"]]
+    assert act[-6] == step.features.data_ptr()
+    # the softplus of the environment texture and the loss-sum reset ride in the activation launch: texture in, activated texture
+    # out, the sums to zero -- and the texture's chain rule rides in the activation chain rule's launch (consume = 1)
+    assert act[-5:] == (step.env.numel(), step.env.data_ptr(), step._env_c.data_ptr(), step.sums.data_ptr(), step.sums.numel())
+    bwd_args = args[pos["r3dg_stage2_activate_backward_with"]]
+    assert bwd_args[-9:-7] == (16, 32) and bwd_args[-7] == step.env.data_ptr() and bwd_args[-6] == step._env_c.data_ptr()
+    assert bwd_args[-3] == step.grads["env"].data_ptr() and bwd_args[-2] == step.sums[4].data_ptr() and bwd_args[-1] == 1
+    assert "r3dg_stage2_env_backward" not in it and "r3dg_stage2_pbr_srgb" not in it and "r3dg_stage2_normals_srgb" in it
     assert args[pos["r3dg_stage2_unpack_gradients"]][-1] == step.sums[3].data_ptr()
     joins = [(i, a) for i, (n, a) in enumerate(zip(it, args)) if n == "r3dg_stream_wait_stream"]
     assert joins[0][1] == (early.cuda_stream, main.cuda_stream)              # fork at the top of the iteration
@@ -894,15 +902,14 @@ def test_fused_stage2_iteration_spreads_the_fixed_ray_set_path_over_three_stream
     assert listed is early and rotated is True and leave_room is True
     assert geometry_streams[-1] is early                                       # geometry backward beside the listed backward
     assert args[pos["frs.backward"]] == (early,)                               # rotation back on the same stream
-    assert "main.wait_event" in it[pos["frs.backward"]:pos["r3dg_stage2_activate_backward"]]     # geometry joined by its event
+    assert "main.wait_event" in it[pos["frs.backward"]:pos["r3dg_stage2_activate_backward_with"]]     # geometry joined by its event
     assert "torch.wait_stream" not in it                                       # no per-call event objects on the hot path
     # Adam: the SH group and the incident-light group inside the early stream's context, the other groups on the main stream
     assert it[adam[0] - 1] == "enter" and args[adam[0] - 1] == (early.cuda_stream,)
     assert "enter" in it[pos["frs.backward"]:adam[1]] and "exit" not in it[adam[1]:pos["frs.rotate"]]
-    assert adam[2] > pos["r3dg_stage2_activate_backward"] and "enter" not in it[pos["frs.rotate"] + 2:adam[2]]
-    # the small view-independent launches (softplus, sum reset, accumulator zero fill) are torch launches on the MAIN stream
-    # between the front end's launches and the join in front of the shading forward: nothing but the fork enters the early
-    # stream's context at the top of the iteration
+    assert adam[2] > pos["r3dg_stage2_activate_backward_with"] and "enter" not in it[pos["frs.rotate"] + 2:adam[2]]
+    # the small view-independent jobs (softplus, sum reset) ride in the activation launch and the accumulator slab needs no zero
+    # fill: nothing but the fork enters the early stream's context at the top of the iteration
     assert "enter" not in it[:pos["frs.forward"]]
     # anybody outside the iteration is ordered behind the chain before it sees the coefficients; an edited tensor is re-rotated
     assert step._early_pending
@@ -914,7 +921,7 @@ def test_fused_stage2_iteration_spreads_the_fixed_ray_set_path_over_three_stream
     marks.append(len(events))
     step(cam, torch.ones(3), z(3, H, W))
     it4 = [e[0] for e in events[marks[3]:]]
-    assert it4.count("frs.rotate") == 2 and it4.index("frs.rotate") < it4.index("r3dg_stage2_activate")
+    assert it4.count("frs.rotate") == 2 and it4.index("frs.rotate") < it4.index("r3dg_stage2_activate_with")
     # ---- a second step object gets the same side streams -------------------------------------------------------------------
     other = fused_step.FusedStage2Step(params, K)
     other(cam, torch.ones(3), z(3, H, W))
@@ -1035,7 +1042,7 @@ def test_fused_stage2_data_parallel_iteration_issues_its_buckets_from_the_stream
         step(cam, torch.ones(3), z(3, H, W))
     early = step._adam_stream.cuda_stream
     names = [e[0] for e in events]
-    start = len(names) - 1 - names[::-1].index("r3dg_stage2_activate")        # the third iteration
+    start = len(names) - 1 - names[::-1].index("r3dg_stage2_activate_with")        # the third iteration
     it = events[start:]
     seq = [(n, d) for n, d in it if n.split()[0] in ("all_reduce", "wait", "frs.rotate", "frs.forward", "frs.backward", "raster.backward")]
     assert seq == [
