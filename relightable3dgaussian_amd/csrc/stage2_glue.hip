@@ -407,22 +407,47 @@ s2_loss_kernel(int HW, const float* __restrict__ image, const float* __restrict_
     float s_l1 = 0.f, s_pbr = 0.f, s_n = 0.f;
     // grid-stride: a few hundred blocks, so the three same-address atomics per block do not serialise the kernel
     for (int i = blockIdx.x * 256 + threadIdx.x; i < HW; i += gridDim.x * 256) {
+        // every load of the pixel first (up to 20 of them, no branch around any: as written per channel -- load, use, store, next
+        // channel -- the compiler kept that order and the kernel waited for memory eight times per pixel: tools/isa_waits.py)
         const float op = opacity[i];
-        const bool mask = n_contrib[i] > 0;
+        const int nc = n_contrib[i];
+        float v_gt[3], v_im[3], v_ei[3], v_F[3], v_es[3], v_Fn[3], v_pn[3];
+        const bool normal_on = !SPARSE || w_normal != 0.f;
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+            v_gt[c] = gt[(size_t)c * HW + i];
+            v_im[c] = image[(size_t)c * HW + i];
+            v_F[c] = feature[(size_t)(2 + c) * HW + i];
+        }
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+            v_ei[c] = extra_dimage ? extra_dimage[(size_t)c * HW + i] : 0.f;
+            v_es[c] = extra_dsrgb ? extra_dsrgb[(size_t)c * HW + i] : 0.f;
+        }
+        float mk = 1.f;
+        if (normal_on) {
+            mk = image_mask ? image_mask[i] : 1.f;
+#pragma unroll
+            for (int c = 0; c < 3; c++) {
+                v_Fn[c] = feature[(size_t)(5 + c) * HW + i];
+                v_pn[c] = pseudo_normal[(size_t)c * HW + i];
+            }
+        }
+        const bool mask = nc > 0;
         const float opc = fmaxf(op, 1e-5f);
         const float scale = mask ? 1.f / opc : 0.f;                 // feat = feature * scale
         const float dscale_dop = (mask && op >= 1e-5f) ? -1.f / (opc * opc) : 0.f;
         float g_op = 0.f;
 #pragma unroll
         for (int c = 0; c < 3; c++) {
-            const float g = gt[(size_t)c * HW + i];
+            const float g = v_gt[c];
             // L1 on the SH image
-            const float d0 = image[(size_t)c * HW + i] - g;
+            const float d0 = v_im[c] - g;
             s_l1 += fabsf(d0);
             // extra_*: gradients of further terms on the same two images (the SSIM terms, r3dg_ssim_backward)
-            dL_dimage[(size_t)c * HW + i] = w_l1 * signf_(d0) + (extra_dimage ? extra_dimage[(size_t)c * HW + i] : 0.f);
+            dL_dimage[(size_t)c * HW + i] = w_l1 * signf_(d0) + v_ei[c];
             // L1 on the sRGB-mapped PBR image: pbr_img = r_pbr * op + (1 - op) * bg
-            const float F = feature[(size_t)(2 + c) * HW + i];
+            const float F = v_F[c];
             const float r = F * scale;
             const float x = r * op + (1.f - op) * bg[c];
             const bool lin = x <= 0.0031308f;
@@ -435,15 +460,14 @@ s2_loss_kernel(int HW, const float* __restrict__ image, const float* __restrict_
             const float d1 = srgb - g;
             s_pbr += fabsf(d1);
             const float dsrgb = !unclipped ? 0.f : (lin ? 12.92f : 1.055f / 2.4f * srgb_pow(xs, 1.f / 2.4f - 1.f));
-            const float gx = (w_pbr * signf_(d1) + (extra_dsrgb ? extra_dsrgb[(size_t)c * HW + i] : 0.f)) * dsrgb;   // dL/dx
+            const float gx = (w_pbr * signf_(d1) + v_es[c]) * dsrgb;   // dL/dx
             dL_dfeature[(size_t)(2 + c) * HW + i] = gx * op * scale;
             g_op += gx * (r - bg[c] + op * F * dscale_dop);
             // normal consistency: mse(r_normal, pseudo_normal)
-            if (!SPARSE || w_normal != 0.f) {
+            if (normal_on) {
                 // mse(normal * m, pseudo_normal * m), m = the view's object mask (neilf.py:258-264; NULL = all ones)
-                const float mk = image_mask ? image_mask[i] : 1.f;
-                const float Fn = feature[(size_t)(5 + c) * HW + i];
-                const float dn = (Fn * scale - pseudo_normal[(size_t)c * HW + i]) * mk;
+                const float Fn = v_Fn[c];
+                const float dn = (Fn * scale - v_pn[c]) * mk;
                 s_n += dn * dn;
                 const float gn = 2.f * w_normal * dn * mk;
                 dL_dfeature[(size_t)(5 + c) * HW + i] = gn * scale;

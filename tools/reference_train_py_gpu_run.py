@@ -135,7 +135,71 @@ def headline(ns, ref):
             print(r.stdout[-3000:])
             print(r.stderr[-6000:])
             sys.exit(1)
+    if ns.profile:
+        host_profile(ns, ref, tmp, args)
     shutil.rmtree(tmp, ignore_errors=True)
+
+
+def host_profile(ns, ref, tmp, args):
+    """where the reference's loop spends its HOST time at the headline size -- cProfile over the patched run,
+    self time (tottime) partitioned by the file a function lives in: the reference's own Python, this repo's wrappers (the three
+    drop-in packages + relightable3dgaussian_amd), torch / everything else.  cProfile inflates small Python calls, so the shares
+    matter more than the absolute numbers; the unprofiled rate is printed above."""
+    import pstats
+    prof = os.path.join(tmp, "patched.prof")
+    args = [a.replace("stage2_patched", "stage2_profiled") for a in args]
+    cmd = [sys.executable, "-m", "cProfile", "-o", prof, os.path.join(ROOT, "tools", "run_reference.py"), "--reference", ref,
+           "--patch-rendering-equation", "--"] + args
+    t0 = time.time()
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=ns.timeout, env=dict(os.environ, PYTHONPATH=ROOT), cwd=ROOT,
+                       stdin=subprocess.DEVNULL)
+    print("\n== host profile of the patched run (python -m cProfile; %d iterations; exit code %d, %.1f s wall) ==" % (
+        ns.stage2_iterations, r.returncode, time.time() - t0))
+    if r.returncode != 0:
+        print(r.stderr[-3000:])
+        return
+    st = pstats.Stats(prof)
+    groups = {"reference (reference_scratch/)": 0.0, "this repo's wrappers (relightable3dgaussian_amd/, r3dg_rasterization/, bvh_tracing/, simple_knn/)": 0.0,
+              "torch (python side)": 0.0, "built-ins / C calls (kernel launches, ctypes calls, .item() waits)": 0.0, "other python": 0.0}
+    ours = ("relightable3dgaussian_amd", "r3dg_rasterization", "bvh_tracing", "simple_knn")
+    rows = []
+    for (fn, line, name), (cc, nc, tt, ct, callers) in st.stats.items():
+        if "reference_scratch" in fn:
+            k = "reference (reference_scratch/)"
+        elif any(("/" + o + "/") in fn for o in ours):
+            k = [g for g in groups if g.startswith("this repo")][0]
+        elif "/torch/" in fn:
+            k = "torch (python side)"
+        elif fn.startswith("~") or fn.startswith("<"):
+            k = [g for g in groups if g.startswith("built-ins")][0]
+        else:
+            k = "other python"
+        groups[k] += tt
+        rows.append((tt, ct, nc, fn, line, name))
+    total = sum(groups.values())
+    n = ns.stage2_iterations
+    print("self time by where the function lives (whole process: start-up, data loading, the visibility trace and %d iterations):" % n)
+    for k, v in groups.items():
+        print("  %6.2f s  %5.1f %%   %s" % (v, 100 * v / total, k))
+    def cum(pred):
+        return sum(ct for tt, ct, nc, fn, line, name in rows if pred(fn, name))
+    print("cumulative time of the calls a training iteration makes (ms per iteration, %d iterations):" % n)
+    for label, pred in (
+            ("train.py: training loop body (whole run)", lambda fn, nm: fn.endswith("train.py") and nm == "training"),
+            ("reference render_view (gaussian_renderer/neilf.py)", lambda fn, nm: "reference_scratch" in fn and fn.endswith("neilf.py") and nm == "render_view"),
+            ("reference calculate_loss (neilf.py)", lambda fn, nm: "reference_scratch" in fn and fn.endswith("neilf.py") and nm == "calculate_loss"),
+            ("this repo: rasterize_gaussians (forward wrapper)", lambda fn, nm: "rasterizer_ops" in fn and nm == "rasterize_gaussians"),
+            ("this repo: rasterize_gaussians_backward (wrapper)", lambda fn, nm: "rasterizer_ops" in fn and nm == "rasterize_gaussians_backward"),
+            ("this repo: rendering_equation (shading_ops)", lambda fn, nm: "shading_ops" in fn and nm == "rendering_equation"),
+            ("torch: Tensor.backward", lambda fn, nm: fn.endswith("torch/_tensor.py") and nm == "backward"),
+            ("torch: optimizer step (Adam, 13 groups)", lambda fn, nm: fn.endswith("optim/adam.py") and nm == "step"),
+            ("Tensor.item (host waits for the GPU here)", lambda fn, nm: "item" in nm and fn.startswith("~")),
+    ):
+        print("  %8.2f   %s" % (1e3 * cum(pred) / n, label))
+    print("largest self times:")
+    for tt, ct, nc, fn, line, name in sorted(rows, reverse=True)[:22]:
+        short = fn.replace(ROOT, ".").replace(ref, "reference_scratch")
+        print("  %6.2f s self %6.2f s cum %8d calls  %s:%d %s" % (tt, ct, nc, short[-70:], line, name))
 
 
 def run(reference, args, timeout):
@@ -157,6 +221,7 @@ def main():
     ap.add_argument("--headline", action="store_true",
                     help="stage 2 only, at --points / --res / --sample-num (VERDICT r3 item 4): unpatched and patched train.py")
     ap.add_argument("--points", type=int, default=300000)
+    ap.add_argument("--profile", action="store_true", help="with --headline: cProfile of the patched run, split by code owner")
     ns = ap.parse_args()
     ref = os.path.abspath(ns.reference)
     if ns.headline:
