@@ -436,7 +436,7 @@ static int* option_slot(int option)
 static bool option_in_range(int option, int value)
 {
     static const int lo[R3DG_OPT_COUNT] = {0, 0, 0, 1, 0, 0, 0, 1, 1, 1, 0, 0, 0};
-    static const int hi[R3DG_OPT_COUNT] = {1, 1, 2, 64, 1, 8, 4, 64, 15, 15, 128, 1, 1};
+    static const int hi[R3DG_OPT_COUNT] = {1, 1, 2, 4, 1, 8, 4, 64, 15, 15, 128, 1, 1};
     return value >= lo[option] && value <= hi[option];
 }
 

@@ -437,34 +437,49 @@ constexpr int BIN_MAX_TILES = 16384;           // 64 KB of LDS counters
 constexpr int BIN_THREADS = 1024;
 constexpr int BIN_MAX_ITERS = 4;            // Gaussians per block = R3DG_OPT_BINNING_BLOCK_K (1..4) x 1024
 
-// the tiles of Gaussian `idx` (one per lane; whole waves call this together)
+// The tile rectangle of Gaussian `idx`, loaded ONCE per kernel and kept in registers for every pass over it (round 5: each pass
+// used to read radii[idx], wait, then means2D[idx] under `if (live)`, wait again -- two dependent round trips x Gaussians per
+// thread x passes, in kernels whose VALU is busy 9 % of the time; tools/isa_waits.py).  Both loads are unconditional (clamped
+// index) so that they leave together.
+struct TileRect {
+    int x0, y0, w, h;          // w * h == 0: culled / past the end
+};
+
+__device__ __forceinline__ TileRect load_tile_rect(int idx, int P, const float2* __restrict__ means2D,
+                                                   const int* __restrict__ radii, int gx, int gy)
+{
+    const int i = idx < P ? idx : P - 1;
+    const int r = radii[i];
+    const float2 p = means2D[i];
+    TileRect t;
+    int x0 = 0, y0 = 0, x1 = 0, y1 = 0;
+    if (idx < P && r > 0) tile_rect(p.x, p.y, r, gx, gy, x0, y0, x1, y1);
+    t.x0 = x0; t.y0 = y0; t.w = x1 - x0; t.h = y1 - y0;
+    return t;
+}
+
+// the tiles of Gaussian `idx` (one per lane; whole waves call this together): f(tile, Gaussian, that Gaussian's payload)
 template <typename F>
-__device__ __forceinline__ void for_each_tile(int idx, int P, const float2* __restrict__ means2D,
-                                              const int* __restrict__ radii, int gx, int gy, F&& f)
+__device__ __forceinline__ void for_each_tile(const TileRect& rc, int idx, uint32_t payload, int gx, F&& f)
 {
     const int lane = threadIdx.x & 63;
-    int x0 = 0, y0 = 0, x1 = 0, y1 = 0;
-    const bool live = idx < P && radii[idx] > 0;
-    if (live) {
-        const float2 p = means2D[idx];
-        tile_rect(p.x, p.y, radii[idx], gx, gy, x0, y0, x1, y1);
-    }
-    const int w_rect = x1 - x0;
-    const uint32_t cnt = (uint32_t)(w_rect * (y1 - y0));
-    const bool big = live && cnt > 32u;
+    const uint32_t cnt = (uint32_t)(rc.w * rc.h);
+    const bool live = cnt != 0u;
+    const bool big = cnt > 32u;
     if (live && !big)
-        for (int y = y0; y < y1; y++)
-            for (int x = x0; x < x1; x++) f((uint32_t)(y * gx + x), (uint32_t)idx);
+        for (int y = rc.y0; y < rc.y0 + rc.h; y++)
+            for (int x = rc.x0; x < rc.x0 + rc.w; x++) f((uint32_t)(y * gx + x), (uint32_t)idx, payload);
     // rectangles larger than 32 tiles are expanded by the whole wave (one screen-filling Gaussian cannot serialise it)
     unsigned long long todo = __ballot(big);
     while (todo) {
         const int src = __ffsll((long long)todo) - 1;
         todo &= todo - 1;
-        const int bx0 = __shfl(x0, src, 64), by0 = __shfl(y0, src, 64), bw = __shfl(w_rect, src, 64);
+        const int bx0 = __shfl(rc.x0, src, 64), by0 = __shfl(rc.y0, src, 64), bw = __shfl(rc.w, src, 64);
         const uint32_t bcnt = (uint32_t)__shfl((int)cnt, src, 64);
+        const uint32_t bpay = (uint32_t)__shfl((int)payload, src, 64);
         const uint32_t bid = (uint32_t)((idx & ~63) + src);
         for (uint32_t k = lane; k < bcnt; k += 64)
-            f((uint32_t)((by0 + (int)(k / (uint32_t)bw)) * gx + bx0 + (int)(k % (uint32_t)bw)), bid);
+            f((uint32_t)((by0 + (int)(k / (uint32_t)bw)) * gx + bx0 + (int)(k % (uint32_t)bw)), bid, bpay);
     }
 }
 
@@ -475,12 +490,18 @@ tile_count_kernel(int P, int T, int iters, const float2* __restrict__ means2D, c
                   uint32_t* __restrict__ tile_counts)
 {
     extern __shared__ uint32_t s_bins[];
+    const int base = blockIdx.x * iters * BIN_THREADS + threadIdx.x;
+    TileRect rc[BIN_MAX_ITERS];
+#pragma unroll
+    for (int it = 0; it < BIN_MAX_ITERS; it++)            // (the loads of every pass leave before the zero fill is waited for)
+        rc[it] = load_tile_rect(it < iters ? base + it * BIN_THREADS : P, P, means2D, radii, gx, gy);
     for (int t = threadIdx.x; t < T; t += BIN_THREADS) s_bins[t] = 0;
     __syncthreads();
-    const int base = blockIdx.x * iters * BIN_THREADS + threadIdx.x;
-    for (int it = 0; it < iters; it++)
-        for_each_tile(base + it * BIN_THREADS, P, means2D, radii, gx, gy,
-                      [&](uint32_t tile, uint32_t) { atomicAdd(&s_bins[tile], 1u); });
+#pragma unroll
+    for (int it = 0; it < BIN_MAX_ITERS; it++)
+        if (it < iters)
+            for_each_tile(rc[it], base + it * BIN_THREADS, 0u, gx,
+                          [&](uint32_t tile, uint32_t, uint32_t) { atomicAdd(&s_bins[tile], 1u); });
     __syncthreads();
     for (int t = threadIdx.x; t < T; t += BIN_THREADS) {
         const uint32_t c = s_bins[t];
@@ -579,7 +600,16 @@ tile_emit_kernel(int P, int T, int iters, const float2* __restrict__ means2D, co
     const int base = blockIdx.x * iters * BIN_THREADS + threadIdx.x;
     // GeometryState::point_offsets (inclusive scan of tiles_touched, rasterizer_impl.cu:283-287): part of the state parity.
     // block_offsets are preprocess' exclusive sums per 256 Gaussians = 4 waves.  All loads first, one barrier for all passes.
-    uint32_t inc[BIN_MAX_ITERS], boff[BIN_MAX_ITERS];
+    // ... and the rectangle + depth of every Gaussian of this thread, for both passes below
+    uint32_t inc[BIN_MAX_ITERS], boff[BIN_MAX_ITERS], dbits[BIN_MAX_ITERS];
+    TileRect rc[BIN_MAX_ITERS];
+#pragma unroll
+    for (int it = 0; it < BIN_MAX_ITERS; it++) {
+        const int idx = base + it * BIN_THREADS;
+        const bool in = it < iters && idx < P;
+        rc[it] = load_tile_rect(it < iters ? idx : P, P, means2D, radii, gx, gy);
+        dbits[it] = __float_as_uint(depths[in ? idx : P - 1]);
+    }
 #pragma unroll
     for (int it = 0; it < BIN_MAX_ITERS; it++) {
         const int idx = base + it * BIN_THREADS;
@@ -600,23 +630,27 @@ tile_emit_kernel(int P, int T, int iters, const float2* __restrict__ means2D, co
         }
     }
     if (over) return;
-    for (int it = 0; it < iters; it++)
-        for_each_tile(base + it * BIN_THREADS, P, means2D, radii, gx, gy,
-                      [&](uint32_t tile, uint32_t) { atomicAdd(&s_bins[tile], 1u); });
+#pragma unroll
+    for (int it = 0; it < BIN_MAX_ITERS; it++)
+        if (it < iters)
+            for_each_tile(rc[it], base + it * BIN_THREADS, 0u, gx,
+                          [&](uint32_t tile, uint32_t, uint32_t) { atomicAdd(&s_bins[tile], 1u); });
     __syncthreads();
     for (int t = threadIdx.x; t < T; t += BIN_THREADS) {
         const uint32_t c = s_bins[t];
         if (c) s_bins[t] = atomicAdd(&cursor[t], c);           // this block's run inside tile t's segment
     }
     __syncthreads();
-    for (int it = 0; it < iters; it++)
-        for_each_tile(base + it * BIN_THREADS, P, means2D, radii, gx, gy, [&](uint32_t tile, uint32_t g) {
-            const uint32_t pos = atomicAdd(&s_bins[tile], 1u);
-            entries[pos] = ((uint64_t)__float_as_uint(depths[g]) << 32) | (uint64_t)g;
-        });
+#pragma unroll
+    for (int it = 0; it < BIN_MAX_ITERS; it++)
+        if (it < iters)
+            for_each_tile(rc[it], base + it * BIN_THREADS, dbits[it], gx, [&](uint32_t tile, uint32_t g, uint32_t depth_bits) {
+                const uint32_t pos = atomicAdd(&s_bins[tile], 1u);
+                entries[pos] = ((uint64_t)depth_bits << 32) | (uint64_t)g;
+            });
 }
 
-int g_bin_iters = 2;
+int g_bin_iters = 2;       // R3DG_OPT_BINNING_BLOCK_K (measured at 2M Gaussians too: 2 / 3 / 4 -> 163 / 156 / 161 it/s, no trend)
 
 // `fused` (the bounded forward): tile_counts arrive zeroed (launch_preprocess zero_words), block_sums arrive UNSCANNED
 // (launch_preprocess scan_now = false: the scan kernel scans them and writes *total), and the tile order (launch_tile_order's

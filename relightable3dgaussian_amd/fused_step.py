@@ -582,12 +582,17 @@ class FusedStage2Step(_BoundedForward):
         return self._adam_stream
 
     @_in_context
-    def forward_backward(self, cam, bg, gt, early_adam=False, image_mask=None):
+    def forward_backward(self, cam, bg, gt, early_adam=False, image_mask=None, split_geometry=None):
         """One forward + loss + backward; gradients land in self.grads.  Returns the rasterizer's 10 public outputs.
         `image_mask` [1,H,W]: the view's object mask (Camera.image_mask; None = all ones) of the normal and smoothness terms.
         `early_adam` (single-GPU whole iterations only, see __call__): the SH colour coefficients, whose gradient is final
         after the rasterizer backward, get their Adam update on a side stream UNDER the shading backward (an HBM-bound,
-        register-light kernel next to a VALU-bound one); optimizer_step() then updates the remaining groups."""
+        register-light kernel next to a VALU-bound one); optimizer_step() then updates the remaining groups.
+        `split_geometry` (default: `early_adam`): the rasterizer's per-Gaussian geometry backward on the early stream, beside the
+        gradient unpack and the listed Gaussians' shading backward.  (Measured on its own at 2M Gaussians, where the early Adam is
+        off: 160.7 vs 166.3 it/s -- both kernels stream from HBM there and slow each other by more than the overlap buys.)"""
+        if split_geometry is None:
+            split_geometry = early_adam
         L = _lib.lib()
         P, dev = self.P, self.dev
         H, W = cam.image_height, cam.image_width
@@ -750,7 +755,7 @@ class FusedStage2Step(_BoundedForward):
                 dL_dmeans2D = None
             else:
                 geo_stream = None if self.serial_streams else self._side
-                if geo_stream is None and early_adam and self._listed_stream() is not None:
+                if geo_stream is None and split_geometry and self._listed_stream() is not None:
                     # whole iterations on one GPU with Gaussians off the rotated path: the per-Gaussian geometry backward goes
                     # to the early-Adam stream and runs beside the gradient unpack and the general shading backward on those few
                     # hundred Gaussians (a latency-bound launch that r3dg_shade_frs_backward queues FIRST) instead of in front
