@@ -1,6 +1,7 @@
 """ctypes binding of libr3dg_hip.so (include/r3dg_hip.h).  There is NO fallback: if the HIP library is missing
 or a call fails, the op raises -- a silent CPU/eager path would void every parity claim."""
 import ctypes as C
+import threading
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
@@ -167,6 +168,10 @@ def set_option(name, value):
     check(lib().r3dg_set_option(OPTIONS.index(name), int(value)), "set_option(%s)" % name)
 
 
+_live_lock = threading.Lock()
+_live_entries = {}          # context handle -> number of `with` blocks (any thread) currently inside it
+
+
 class OptionContext:
     """Tuning options that belong to ONE object (include/r3dg_hip.h "option contexts"): `ctx.set("RESERVE_CUS", 8)`, then
     `with ctx:` around the object's library calls -- inside, launches of the calling thread see the context's values where it
@@ -176,7 +181,9 @@ class OptionContext:
         self._h = lib().r3dg_context_create()
         if self._h is None:                      # (NULL)
             raise RuntimeError("r3dg_context_create failed")
-        self._prev = []
+        # the restore stack is PER THREAD, like the library's "current context": two threads inside the same object's context
+        # (a worker polling while the main thread is in an iteration) must not pop each other's saved handles
+        self._tls = threading.local()
         for k, v in options.items():
             self.set(k, v)
 
@@ -186,17 +193,33 @@ class OptionContext:
     def __enter__(self):
         prev = _p()
         check(lib().r3dg_context_make_current(self._h, C.byref(prev)), "context_make_current")
-        self._prev.append(prev.value)
+        stack = getattr(self._tls, "prev", None)
+        if stack is None:
+            stack = self._tls.prev = []
+        stack.append(prev.value)
+        with _live_lock:
+            _live_entries[self._h] = _live_entries.get(self._h, 0) + 1
         return self
 
     def __exit__(self, *exc):
-        check(lib().r3dg_context_make_current(self._prev.pop(), None), "context_make_current")
+        check(lib().r3dg_context_make_current(self._tls.prev.pop(), None), "context_make_current")
+        with _live_lock:
+            n = _live_entries.get(self._h, 0) - 1
+            if n > 0:
+                _live_entries[self._h] = n
+            else:
+                _live_entries.pop(self._h, None)
         return False
 
     def __del__(self):
+        # (a context that some thread is still inside -- current there, or saved as another context's "previous" -- is leaked
+        # rather than destroyed: the library would dereference the freed handle at that thread's next launch)
         try:
             if self._h:
-                lib().r3dg_context_destroy(self._h)
+                with _live_lock:
+                    busy = _live_entries.get(self._h, 0) > 0
+                if not busy:
+                    lib().r3dg_context_destroy(self._h)
                 self._h = None
         except Exception:
             pass

@@ -984,7 +984,11 @@ s2_smooth_stream_kernel(int W, int H, int rows, int strips_x, const float* __res
     // two read-modify-write outputs already hold.  Every element is read (through the _old name) before it is written (through the
     // other), by the one lane that owns the pixel, and never read again; telling the compiler that the two names do not alias only
     // takes away the wait it otherwise puts between one row's stores and the next row's loads from the same array (different rows:
-    // it cannot know) -- a full memory round trip per row with two waves per SIMD to cover it.
+    // it cannot know) -- a full memory round trip per row with two waves per SIMD to cover it.  (Strictly, writing through one
+    // restrict-qualified name what is read through another is outside the language's guarantees; the guard is
+    // tests/test_fused_step_gpu.py::test_fused_smoothness_kernel_equals_the_three_pass_formulation, which compares this kernel with
+    // accumulate_normal = 1 BIT FOR BIT against the three-pass kernels that use plain read-modify-write: a compiler that moved a
+    // store in front of its own element's load fails it.)
     const int lane = threadIdx.x & 63;
     const int wid = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int strip = wid % strips_x, y0 = (wid / strips_x) * rows;

@@ -437,7 +437,7 @@ class FusedStage2Step(_BoundedForward):
                 self.xyz, self.a_scales, self.a_rot, self.a_opacity, self.a_normal, sample_num, group=process_group)
             # the normals the ray set was generated from (the trained normal moves on; the cached directions do not)
             self._ray_normals = self.a_normal.clone()
-        self._taps, self._taps_key = None, None
+        self._taps, self._taps_key, self._taps_size, self._frs_built = None, None, None, None
         self._frs = None                            # shading_ops.FixedRaySet of the current direction cache, or None
         # incident-light chain of a whole single-GPU iteration: (ray set, coefficient tensor, its version) the rotated coefficients
         # in the ray set were computed FROM, when that was done ahead of the next iteration; work still running on the early stream
@@ -525,24 +525,34 @@ class FusedStage2Step(_BoundedForward):
         8-byte records come from the ray normals, shading_ops.FixedRaySet.taps).  Decided once per visibility update / texture
         size."""
         # keyed by the direction tensor ITSELF (held in _taps_src for as long as its taps are: a replaced cache can then never
-        # come back at the address of the old one and pass for it) + its version counter (in-place updates)
+        # come back at the address of the old one and pass for it) + its version counter (in-place updates).  The texture size is a
+        # key of its own: only the lookup records depend on it, the ray set (P x K directions regenerated and classified, a host
+        # read-back) does not
         src = self.incident_dirs
-        key = (src._version, tuple(src.shape), He, We)
-        if getattr(self, "_taps_src", None) is not src or self._taps_key != key:
-            self._taps_key, self._taps_src = key, src
+        dir_key, size_key = (src._version, tuple(src.shape)), (He, We)
+        fresh = getattr(self, "_taps_src", None) is not src or self._taps_key != dir_key
+        if fresh:
+            self._taps_key, self._taps_src, self._taps_size = dir_key, src, None
             # fibonacci_sphere_sampling gives every sample the area 2 pi: then the area cache need not be read at all
             lo, hi = float(self.incident_areas.min()), float(self.incident_areas.max())
             self._uniform_area = lo if lo == hi else None
             # fixed-ray-set kernels (csrc/shading_frs.hpp) when the cache IS the Fibonacci set of the snapshot normals --
             # checked here, once per visibility update -- and fits their limits; otherwise (caches handed in from elsewhere,
-            # other K / texture sizes, R3DG_SHADE_FRS=0) the general kernels
-            self._frs, self._taps = None, None
+            # other K, R3DG_SHADE_FRS=0) the general kernels
+            self._frs_built, self._taps = None, None
             if (os.environ.get("R3DG_SHADE_FRS", "1") != "0" and self._uniform_area is not None and
-                    shading_ops.FixedRaySet.supported(self.K, self.M, He, We)):
-                self._frs = shading_ops.FixedRaySet.try_build(getattr(self, "_ray_normals", None), src)
+                    shading_ops.FixedRaySet.supported(self.K, self.M, 16, 32)):      # (K and the SH degree; the size: below)
+                self._frs_built = shading_ops.FixedRaySet.try_build(getattr(self, "_ray_normals", None), src)
+        if fresh or self._taps_size != size_key:
+            # a new texture size: new lookup records for the ray set that is already there (FixedRaySet.taps is keyed on the size
+            # itself) if the fixed-ray-set kernels take that size, the general kernels' 12-byte taps otherwise
+            self._taps_size = size_key
+            built = self._frs_built
+            self._frs = built if built is not None and shading_ops.FixedRaySet.supported(self.K, self.M, He, We) else None
             if self._frs is None:
                 self._taps = shading_ops.build_taps(src, He, We)
             else:
+                self._taps = None
                 self._frs.taps(He, We)
         return self._taps
 

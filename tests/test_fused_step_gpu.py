@@ -531,6 +531,45 @@ def test_folded_launches_equal_the_launches_they_replace():
     print("folded launches: normals max diff %.2e" % float((n2 - pseudo_normal).abs().max()))
 
 
+def test_texture_resize_keeps_the_ray_set_and_rebuilds_only_its_lookup_records(monkeypatch):
+    """only the 8-byte lookup records depend on the environment texture's size.  Swapping the texture for one of another
+    size between two iterations must not regenerate and re-classify the P x K directions (FixedRaySet.try_build: a host read-back);
+    the iteration after the swap equals the iteration of a step object that was built with the new texture."""
+    from relightable3dgaussian_amd import shading_ops
+    from relightable3dgaussian_amd.fused_step import FusedStage2Step
+    params, ref, fused, cam, bg, gt = _setup(P=3000, res=128, K=16, seed=9)
+    step = FusedStage2Step(params, 16)
+    step(cam, bg, gt)
+    assert step._frs is not None
+    built = []
+    orig = shading_ops.FixedRaySet.try_build
+    monkeypatch.setattr(shading_ops.FixedRaySet, "try_build", classmethod(lambda cls, *a, **k: built.append(1) or orig(*a, **k)))
+    ray_set = step._frs
+    small = torch.nn.functional.interpolate(step.env.permute(0, 3, 1, 2), size=(8, 16), mode="bilinear").permute(0, 2, 3, 1).contiguous()
+    fresh = FusedStage2Step(params, 16)
+    for s_ in (step, fresh):
+        s_.env = small.clone()
+        s_.grads["env"] = torch.zeros_like(s_.env)
+    # (the texture's Adam group follows the tensor: rebuild it for both the same way)
+    for s_ in (step, fresh):
+        g = s_.opt.groups[s_._opt_order.index("env")]
+        g["param"], g["exp_avg"], g["exp_avg_sq"] = s_.env, torch.zeros_like(s_.env), torch.zeros_like(s_.env)
+    fresh.xyz.copy_(step.xyz); fresh.normal.copy_(step.normal); fresh.scaling.copy_(step.scaling); fresh.rotation.copy_(step.rotation)
+    fresh.opacity.copy_(step.opacity); fresh.shs.copy_(step.shs); fresh.base_color.copy_(step.base_color)
+    fresh.roughness.copy_(step.roughness); fresh.incidents.copy_(step.incidents)
+    fresh.visibility, fresh.incident_dirs, fresh.incident_areas = step.visibility, step.incident_dirs, step.incident_areas
+    fresh._ray_normals = step._ray_normals
+    n_before = len(built)
+    step.forward_backward(cam, bg, gt)
+    assert len(built) == n_before and step._frs is ray_set, "the ray set was rebuilt for a texture resize"
+    fresh.forward_backward(cam, bg, gt)
+    torch.cuda.synchronize()
+    assert abs(float(step.loss()) - float(fresh.loss())) <= 1e-6 * abs(float(fresh.loss()))
+    for k in ("env", "base_color", "incidents"):
+        a, b = step.grads[k], fresh.grads[k]
+        assert float((a - b).abs().max()) <= 1e-5 * float(b.abs().max()) + 1e-12, k
+
+
 def test_iterations_leave_no_device_memory_to_the_garbage_collector():
     """A frame's scratch buffers (geometry / binning / image state) are freed by reference counting when the iteration is over:
     no reference cycle holds a device tensor (the resize callbacks used to be closures over the object that owns them and the

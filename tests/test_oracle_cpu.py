@@ -244,6 +244,50 @@ def test_hip_library_exports_every_declared_symbol():
     assert lib.r3dg_shade_frs_supported(30, 16, 16, 32) == 0 and lib.r3dg_shade_frs_tables_bytes(64) == 4 * 512 * 4
 
 
+def test_option_context_restore_stack_is_per_thread():
+    """the library's current context is thread-local, so the Python object's restore stack has to be too.  Two threads
+    enter the SAME context object in an interleaved order (A in, B in, A out, B out -- with one shared stack A would pop B's saved
+    handle); afterwards each thread is back at the context it started from, and the context sees its own values inside.  No
+    kernel is launched: option contexts are host state."""
+    import ctypes as C
+    import threading
+    from relightable3dgaussian_amd import _lib
+    outer, ctx = _lib.OptionContext(CULL=0), _lib.OptionContext(CULL=1, RESERVE_CUS=8)
+    step = [threading.Event() for _ in range(4)]
+    seen = {}
+
+    def current():
+        prev = C.c_void_p()
+        _lib.check(_lib.lib().r3dg_context_make_current(None, C.byref(prev)), "probe")      # -> previous; install it again
+        _lib.check(_lib.lib().r3dg_context_make_current(prev, None), "probe")
+        return prev.value
+
+    def thread_a():
+        with outer:                                    # A starts inside another context, B at the process defaults
+            base = current()
+            with ctx:
+                step[0].set(); step[1].wait(5)         # B enters while A is inside
+                seen["a_in"] = current()
+            step[2].set(); step[3].wait(5)             # A has left; B still inside, then leaves
+            seen["a_out"] = (current(), base)
+
+    def thread_b():
+        step[0].wait(5)
+        base = current()
+        with ctx:
+            step[1].set(); step[2].wait(5)
+            seen["b_in"] = current()
+        seen["b_out"] = (current(), base)
+        step[3].set()
+
+    ta, tb = threading.Thread(target=thread_a), threading.Thread(target=thread_b)
+    ta.start(); tb.start(); ta.join(10); tb.join(10)
+    assert not ta.is_alive() and not tb.is_alive()
+    assert seen["a_in"] == seen["b_in"] == ctx._h
+    assert seen["a_out"][0] == seen["a_out"][1] == outer._h and seen["b_out"][0] == seen["b_out"][1] and not seen["b_out"][0]
+    assert not _lib._live_entries                       # nobody is inside any context any more
+
+
 def test_host_mirror_rejects_bad_inputs_without_gpu():
     from relightable3dgaussian_amd import rasterizer_ops
     import pytest
