@@ -443,7 +443,7 @@ class FusedStage2Step(_BoundedForward):
         # in the ray set were computed FROM, when that was done ahead of the next iteration; work still running on the early stream
         self._pre_rotated = None
         self._defer_b = os.environ.get("R3DG_EARLY_INCIDENTS", "1") != "0"
-        self._leave_room = os.environ.get("R3DG_SHADE_LEAVE_ROOM", "1") != "0"      # (A/B: one workgroup per CU for the shading forward)
+        self._leave_room = os.environ.get("R3DG_SHADE_LEAVE_ROOM", "auto")          # (A/B: "1" / "0" = one workgroup per CU for the shading forward always / never)
         self.opt = FusedAdam([
             dict(param=self.xyz, lr=rate("xyz")), dict(param=self.normal, lr=rate("normal")),
             dict(param=self.scaling, lr=rate("scaling")), dict(param=self.rotation, lr=rate("rotation")),
@@ -620,9 +620,11 @@ class FusedStage2Step(_BoundedForward):
             rotated_for = None
             acc_ready = False
             aux = self._aux_stream()
+            chained = False          # this iteration's rotated coefficients come from the previous iteration's incident-light chain
             if aux is not None:
                 _lib.stream_wait(aux, main)
-                if not self._rotation_is_current():          # (normally done at the end of the previous iteration: see below)
+                chained = self._rotation_is_current()
+                if not chained:                              # (normally done at the end of the previous iteration: see below)
                     with torch.cuda.stream(aux):
                         self._frs.rotate(self._incidents)
                 rotated_for = self._frs
@@ -673,10 +675,14 @@ class FusedStage2Step(_BoundedForward):
                 rotated = rotated_for is self._frs            # (taps() may have rebuilt the ray set: then it rotates itself)
                 self._frs.forward(self.a_base, self.a_rough, self.a_normal, self.a_viewdirs, self._incidents, env_c,
                                   self.visibility, self.shade_out, uniform_area=self._uniform_area,
-                                  # (one workgroup per CU beside the instance ordering, which is the longer path -- unless the
-                                  # deferred incident-light update of a data-parallel run sits in front of this kernel: then this
-                                  # path is the longer one and takes every CU it can get: 558 -> 568 it/s on one rank)
-                                  leave_room=order_stream is not None and not self.dp and self._leave_room,
+                                  # (one workgroup per CU beside the instance ordering while THAT is the longer path.  It is not
+                                  # when something sits in front of this kernel: the deferred incident-light update of a
+                                  # data-parallel run (558 -> 568 it/s on one rank without the cap), or -- since the small launches
+                                  # left the main stream -- the incident-light chain of a whole single-GPU iteration, which ends
+                                  # ~50 us after the projection has started: 781 -> 789 it/s without the cap, while the iterations
+                                  # without a chain (frozen geometry: run_syn4.sh) keep it, 835 vs 826)
+                                  leave_room=(order_stream is not None and not self.dp and
+                                              (self._leave_room == "1" or (self._leave_room == "auto" and not chained))),
                                   # the few hundred Gaussians off the rotated path: their general kernel on the (idle) early-Adam
                                   # stream beside the rotation and the main kernel, joined below before the features are packed
                                   listed_stream=self._listed_stream(), rotated=rotated,
