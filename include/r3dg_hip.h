@@ -337,6 +337,18 @@ int r3dg_shade_frs_backward(void* stream, int P, int K, const float* d_base_colo
                             float* d_dcprime, const float* d_dL_dpbr, const float* d_dL_ddiffuse_light,
                             float* d_dL_dbase_color, float* d_dL_droughness, float* d_dL_dviewdirs, float* d_dL_dincidents,
                             float* d_dL_denv, const float* d_block_absmax, int n_block_absmax, void* rotate_stream);
+/* rotate_stream == R3DG_SHADE_NO_ROTATION_BACK: r3dg_shade_frs_backward leaves the coefficient gradient in the rotated frame
+ * (d_dcprime) and does NOT write d_dL_dincidents for the Gaussians on the rotated path; the caller follows with
+ * r3dg_shade_frs_incident_chain -- ONE pass per Gaussian that rotates the gradient back (writing d_dL_dincidents), applies the
+ * Adam update of the incident-light group (the arithmetic of r3dg_adam_step for ONE group of [P,16,3] rows: columns 0..2 with
+ * `lr`, the rest with `lr_tail`; `step` counts from 1; d_skip_flag as there) and rotates the NEW coefficients into the ray frames
+ * (d_cprime, what r3dg_shade_frs_rotate would produce): 1536 instead of 2112 bytes per Gaussian and one launch instead of
+ * three at the end of a whole training iteration (fused_step.py, "incident-light chain"). */
+#define R3DG_SHADE_NO_ROTATION_BACK ((void*)(intptr_t)-1)
+int r3dg_shade_frs_incident_chain(void* stream, int P, const float* d_ray_normals, const uint8_t* d_valid,
+                                  const float* d_dcprime, float* d_dL_dincidents, float* d_incidents, float* d_exp_avg,
+                                  float* d_exp_avg_sq, float* d_cprime, float lr, float lr_tail, float beta1, float beta2,
+                                  float eps, int step, float grad_scale, const float* d_skip_flag);
 /*   Launch order on `stream`: the kernel on the listed Gaussians, then the main kernel (a caller that has other work
  *   running on another stream when it calls this gets the small launch beside that work).
  *   rotate_stream: NULL, or a second stream for the rotation of the coefficient gradient back to d_dL_dincidents (ordered after the

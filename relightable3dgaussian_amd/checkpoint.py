@@ -34,6 +34,8 @@ def reference_learning_rates(spatial_lr_scale=1.0):
 def _named_tensors(step):
     """Reference group name -> (parameter, exp_avg, exp_avg_sq) views of a fused step object (its single [P,16,3] SH /
     incident tensors are split into the dc / rest groups the reference keeps)."""
+    if getattr(step, "_chain_deferred", None) is not None or getattr(step, "_early_pending", False):
+        step.flush()             # (a single-GPU iteration left the incident-light group's update pending or running)
     order = step._opt_order
     mom = {k: (step.opt.groups[i]["exp_avg"], step.opt.groups[i]["exp_avg_sq"]) for i, k in enumerate(order)}
     out = {}

@@ -77,6 +77,10 @@ void launch_shade_frs_forward_listed(hipStream_t s, int K, const float* base_col
                                      const float* normals, const float* viewdirs, const float* incidents, const float* env, int He,
                                      int We, const float* visibility, const float* ray_normals, const float* zsamples,
                                      float uniform_area, const int* invalid_list, int n_invalid, float* out, float* feat);
+void launch_shade_frs_incident_chain(hipStream_t s, int P, const float* ray_normals, const uint8_t* valid, const float* dcp,
+                                     float* d_inc, float* incidents, float* exp_avg, float* exp_avg_sq, float* cprime, float lr,
+                                     float lr_tail, float beta1, float beta2, float eps, int step, float grad_scale,
+                                     const float* skip_flag);
 const unsigned int* launch_shade_frs_backward_aux(hipStream_t s, int P, const float* g_pbr, const float* g_diff,
                                                   const float* block_absmax, int n_block_absmax, int* gmax_n);
 void launch_shade_frs_backward_main(hipStream_t s, int P, int K, const float* base_color, const float* roughness,
@@ -1538,7 +1542,9 @@ int r3dg_shade_frs_backward(void* stream_, int P, int K, const float* base_color
                             float* dL_droughness, float* dL_dviewdirs, float* dL_dincidents, float* dL_denv,
                             const float* block_absmax, int n_block_absmax, void* rotate_stream_)
 {
-
+    // rotate_stream_ == R3DG_SHADE_NO_ROTATION_BACK: the caller finishes dL_dincidents itself (r3dg_shade_frs_incident_chain)
+    const bool no_rotation_back = rotate_stream_ == R3DG_SHADE_NO_ROTATION_BACK;
+    if (no_rotation_back) rotate_stream_ = nullptr;
     if (P < 0 || K <= 0 || He <= 0 || We <= 0 || n_invalid < 0 || n_invalid > P || n_block_absmax < 0)
         return invalid("shade_frs_backward: bad sizes");
     if (!shade_frs_supported(K, 16, He, We))
@@ -1579,6 +1585,7 @@ int r3dg_shade_frs_backward(void* stream_, int P, int K, const float* base_color
         // the rotation back may run on a second stream (ordered after the main kernel by an event; the CALLER joins that stream
         // before anything reads dL_dincidents): it then overlaps whatever the caller queues next on `stream`.  It leaves the
         // listed Gaussians' rows (written above) alone.
+        if (no_rotation_back) return R3DG_OK;
         hipStream_t rstream = rotate_stream_ != nullptr ? (hipStream_t)rotate_stream_ : stream;
         if (rstream != stream) {
             stream_wait_stream(rstream, stream);
@@ -1587,6 +1594,25 @@ int r3dg_shade_frs_backward(void* stream_, int P, int K, const float* base_color
             StageTimer t(rstream, ST_SHADE_AUX);
             launch_shade_frs_backward_rotate(rstream, P, ray_normals, dcprime, dL_dincidents, n_invalid > 0 ? valid : nullptr);
         }
+        return R3DG_OK;
+    });
+}
+
+int r3dg_shade_frs_incident_chain(void* stream_, int P, const float* ray_normals, const uint8_t* valid, const float* dcprime,
+                                  float* dL_dincidents, float* incidents, float* exp_avg, float* exp_avg_sq, float* cprime,
+                                  float lr, float lr_tail, float beta1, float beta2, float eps, int step, float grad_scale,
+                                  const float* skip_flag)
+{
+    if (P < 0) return invalid("shade_frs_incident_chain: bad sizes");
+    if (step < 1) return invalid("shade_frs_incident_chain: step counts from 1");
+    if (P == 0) return R3DG_OK;
+    if (!ray_normals || !dcprime || !dL_dincidents || !incidents || !exp_avg || !exp_avg_sq || !cprime)
+        return invalid("shade_frs_incident_chain: null buffer");
+    return guarded([&]() -> int {
+        hipStream_t stream = (hipStream_t)stream_;
+        StageTimer t(stream, ST_SHADE_AUX);
+        launch_shade_frs_incident_chain(stream, P, ray_normals, valid, dcprime, dL_dincidents, incidents, exp_avg, exp_avg_sq,
+                                        cprime, lr, lr_tail, beta1, beta2, eps, step, grad_scale, skip_flag);
         return R3DG_OK;
     });
 }

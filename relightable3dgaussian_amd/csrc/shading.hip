@@ -1335,6 +1335,20 @@ void launch_shade_frs_backward_rotate(hipStream_t s, int P, const float* ray_nor
     check_launch(s, false, "frs_rotate_kernel");
 }
 
+void launch_shade_frs_incident_chain(hipStream_t s, int P, const float* ray_normals, const uint8_t* valid, const float* dcp,
+                                     float* d_inc, float* incidents, float* exp_avg, float* exp_avg_sq, float* cprime, float lr,
+                                     float lr_tail, float beta1, float beta2, float eps, int step, float grad_scale,
+                                     const float* skip_flag)
+{
+    if (P == 0) return;
+    // (bias corrections exactly as launch_adam forms them, stage2_glue.hip)
+    const double b1 = 1.0 - pow((double)beta1, (double)step), b2 = 1.0 - pow((double)beta2, (double)step);
+    FrsAdam a = {lr, lr_tail, beta1, beta2, eps, (float)b1, (float)(1.0 / sqrt(b2)), grad_scale, 1.f - beta1, 1.f - beta2};
+    frs_incident_chain_kernel<<<(P + 255) / 256, 256, 0, s>>>(P, ray_normals, valid, dcp, d_inc, incidents, exp_avg, exp_avg_sq,
+                                                              cprime, a, skip_flag);
+    check_launch(s, false, "frs_incident_chain_kernel");
+}
+
 void launch_shade_frs_backward_listed(hipStream_t s, int K, const float* base_color, const float* roughness,
                                       const float* normals, const float* viewdirs, const float* incidents, const float* env, int He,
                                       int We, const float* visibility, const float* ray_normals, const float* zsamples,

@@ -197,6 +197,165 @@ frs_rotate_kernel(int P, const float* __restrict__ ray_normals, const float* __r
     for (int q = 0; q < 12; q++) d4[q] = make_float4(row[4 * q], row[4 * q + 1], row[4 * q + 2], row[4 * q + 3]);
 }
 
+// ---- incident-light chain (round 5): rotation back + Adam + rotation forward in ONE pass ---------------------------------------
+// A whole single-GPU iteration ends, for the incident-light coefficients, with three passes over [P,16,3] rows in a row:
+//   frs_rotate_kernel<true>   dL/dc' -> dL/d incidents            (read 192, write 192 bytes per Gaussian)
+//   adam_kernel               p, g, m, v -> p, m, v               (read 768, write 576)
+//   frs_rotate_kernel<false>  incidents -> c' for the NEXT forward (read 192, write 192)
+// = 2112 bytes per Gaussian and three launches on the chain that decides when the next shading forward can start (48 + 94 + 36 us
+// at 300k Gaussians beside the other groups' Adam: the critical path of the iteration, profiles/r05_*_sequence.txt).  One kernel:
+// 1728 bytes per Gaussian, no launch boundaries.
+// FIRST VERSION (thread per Gaussian, the row in registers, p / m / v walked row-wise by every lane): 300 us -- eight 192-byte row
+// streams per lane with 192-byte strides between the lanes of every load: the address unit, not HBM, was the limit.  THIS VERSION
+// keeps the thread-per-Gaussian ROTATIONS (they need a whole row per lane) but makes every global access of the wave a contiguous
+// run: a wave owns 64 consecutive Gaussians = 12 KB of each array; rows travel through 12.25 KB of wave-private LDS (row stride 49
+// words: a lane walking its row and the wave walking a float4 column are both conflict-free), the Adam update runs on the
+// COALESCED layout (lane = float4 index inside the wave's run, exactly adam_kernel's access pattern).  No workgroup barrier: the
+// four waves of a workgroup only share the LDS allocation.
+// The Adam arithmetic is adam_kernel's, statement for statement -- but this translation unit is built with -ffast-math (neither
+// `#pragma float_control` nor __fdiv_rn / __fsqrt_rn switch that off on this target: checked in the ISA), so its division and
+// square root are the 1-ulp v_rcp_f32 / v_sqrt_f32: the UPDATE term (lr x O(1)) differs from adam_kernel's by a few ulp of
+// itself, i.e. by ~1e-7 x lr on the parameter -- far below the run-to-run differences the float atomics of the backward already
+// cause.  Single-GPU whole iterations only (a data-parallel run applies the group's update with adam_kernel: replicas must
+// stay bit-identical).  The rotations are the very functions the two kernels above call.
+// Gaussians off the rotated path (valid[g] == 0): their gradient row was written by the listed kernel in the world frame already
+// (read here instead of rotated), their c' row is not used by anybody (written anyway: same arithmetic as everywhere else).
+struct FrsAdam {
+    float lr, lr_tail, beta1, beta2, eps, bias1, inv_sqrt_bias2, grad_scale;
+    float omb1, omb2;          // 1 - beta1, 1 - beta2, formed in fp32 on the host: under -ffast-math the compiler rewrites
+                               // (1 - b) * x as x - b * x, whose cancellation costs 6e-5 of the (1 - beta2) g^2 term
+};
+
+__device__ __forceinline__ void frs_adam_update(const FrsAdam& a, float lr, float& p, float g, float& m, float& v)
+{
+    g *= a.grad_scale;
+    m = m + (g - m) * a.omb1;
+    v = a.beta2 * v + a.omb2 * g * g;
+    const float denom = sqrtf(v) * a.inv_sqrt_bias2 + a.eps;
+    p -= (lr / a.bias1) * (m / denom);
+}
+
+constexpr int FRS_CHAIN_LD = 49;           // LDS row stride in words
+
+__global__ void __launch_bounds__(256)
+frs_incident_chain_kernel(int P, const float* __restrict__ ray_normals, const uint8_t* __restrict__ valid,
+                          const float* __restrict__ dcprime, float* __restrict__ dL_dincidents, float* __restrict__ incidents,
+                          float* __restrict__ exp_avg, float* __restrict__ exp_avg_sq, float* __restrict__ cprime, FrsAdam adam,
+                          const float* __restrict__ skip_flag)
+{
+    // a frame the bounded forward dropped: no update (adam_kernel's rule) -- and then nothing here is needed: the parameters and
+    // therefore c' are unchanged, the gradient of a dropped frame is nobody's input
+    if (skip_flag != nullptr && *skip_flag != 0.0f) return;
+    __shared__ float s_rows[4][64 * FRS_CHAIN_LD];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float* s = s_rows[wave];
+    const int g0 = (blockIdx.x * 4 + wave) * 64;                  // this wave's 64 consecutive Gaussians
+    if (g0 >= P) return;
+    const int ng = min(64, P - g0);
+    const int n4 = ng * 12;                                       // float4s in the wave's run of every [P,48] array
+    const int g = g0 + lane;
+    const bool live = lane < ng;
+    const size_t run = (size_t)g0 * 48;
+    // position of float4 number e4 of the run inside the LDS rows (a float4 never straddles a row: 48 = 12 x 4)
+    auto lds_of = [&](int e4) -> float* { return s + (e4 / 12) * FRS_CHAIN_LD + 4 * (e4 % 12); };
+    // ---- the coefficient gradient in the rotated frame, coalesced, into the rows
+    {
+        const float4* src = reinterpret_cast<const float4*>(dcprime + run);
+        float4 t[12];
+#pragma unroll
+        for (int i = 0; i < 12; i++) {
+            const int e4 = i * 64 + lane;
+            t[i] = src[e4 < n4 ? e4 : 0];
+        }
+#pragma unroll
+        for (int i = 0; i < 12; i++) {
+            const int e4 = i * 64 + lane;
+            if (e4 < n4) {
+                float* d = lds_of(e4);
+                d[0] = t[i].x; d[1] = t[i].y; d[2] = t[i].z; d[3] = t[i].w;
+            }
+        }
+    }
+    float R[9];
+    const int gc = live ? g : g0;
+    frs_rotation(ray_normals[3 * (size_t)gc], ray_normals[3 * (size_t)gc + 1], ray_normals[3 * (size_t)gc + 2], R);
+    const bool rotated = valid == nullptr || valid[gc] != 0;
+    __builtin_amdgcn_wave_barrier();
+    // ---- rotation back, thread per Gaussian; the world-frame gradient row replaces the rotated one in the LDS row
+    if (live) {
+        float row[48];
+        float* mine = s + lane * FRS_CHAIN_LD;
+        if (rotated) {
+#pragma unroll
+            for (int c = 0; c < 48; c++) row[c] = mine[c];
+            frs_rotate_band<1, 3, true>(R, kShRotPoints1, kShRotAinv1, row);
+            frs_rotate_band<4, 5, true>(R, kShRotPoints2, kShRotAinv2, row);
+            frs_rotate_band<9, 7, true>(R, kShRotPoints3, kShRotAinv3, row);
+        } else {
+            // (a few hundred Gaussians per launch: the listed kernel's world-frame row, read in place)
+            const float4* s4 = reinterpret_cast<const float4*>(dL_dincidents + (size_t)g * 48);
+#pragma unroll
+            for (int q = 0; q < 12; q++) {
+                const float4 v = s4[q];
+                row[4 * q] = v.x; row[4 * q + 1] = v.y; row[4 * q + 2] = v.z; row[4 * q + 3] = v.w;
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < 48; c++) mine[c] = row[c];
+    }
+    __builtin_amdgcn_wave_barrier();
+    // ---- Adam on the coalesced layout (adam_kernel's access pattern); the gradient row goes out, the NEW parameters take its
+    // place in the LDS rows.  Columns 0..2 of a row are the dc coefficient (learning rate lr), the other 45 the rest (lr_tail)
+    {
+        float4* p4 = reinterpret_cast<float4*>(incidents + run);
+        float4* m4 = reinterpret_cast<float4*>(exp_avg + run);
+        float4* v4 = reinterpret_cast<float4*>(exp_avg_sq + run);
+        float4* g4 = reinterpret_cast<float4*>(dL_dincidents + run);
+#pragma unroll 4
+        for (int i = 0; i < 12; i++) {
+            const int e4 = i * 64 + lane;
+            if (e4 < n4) {
+                float4 p = p4[e4], m = m4[e4], v = v4[e4];
+                float* d = lds_of(e4);
+                const float4 gr = make_float4(d[0], d[1], d[2], d[3]);
+                const bool dc = (e4 % 12) == 0;                          // this float4 holds columns 0..3 of its row
+                frs_adam_update(adam, dc ? adam.lr : adam.lr_tail, p.x, gr.x, m.x, v.x);
+                frs_adam_update(adam, dc ? adam.lr : adam.lr_tail, p.y, gr.y, m.y, v.y);
+                frs_adam_update(adam, dc ? adam.lr : adam.lr_tail, p.z, gr.z, m.z, v.z);
+                frs_adam_update(adam, adam.lr_tail, p.w, gr.w, m.w, v.w);
+                p4[e4] = p; m4[e4] = m; v4[e4] = v;
+                g4[e4] = gr;
+                d[0] = p.x; d[1] = p.y; d[2] = p.z; d[3] = p.w;
+            }
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+    // ---- rotation forward of the new coefficients, thread per Gaussian
+    if (live) {
+        float row[48];
+        float* mine = s + lane * FRS_CHAIN_LD;
+#pragma unroll
+        for (int c = 0; c < 48; c++) row[c] = mine[c];
+        frs_rotate_band<1, 3, false>(R, kShRotPoints1, kShRotAinv1, row);
+        frs_rotate_band<4, 5, false>(R, kShRotPoints2, kShRotAinv2, row);
+        frs_rotate_band<9, 7, false>(R, kShRotPoints3, kShRotAinv3, row);
+#pragma unroll
+        for (int c = 0; c < 48; c++) mine[c] = row[c];
+    }
+    __builtin_amdgcn_wave_barrier();
+    {
+        float4* dst = reinterpret_cast<float4*>(cprime + run);
+#pragma unroll
+        for (int i = 0; i < 12; i++) {
+            const int e4 = i * 64 + lane;
+            if (e4 < n4) {
+                const float* d = lds_of(e4);
+                dst[e4] = make_float4(d[0], d[1], d[2], d[3]);
+            }
+        }
+    }
+}
+
 // texture [ntexel,3] -> LDS as float4 texels; two texels (six loads) in flight per thread -- as a plain loop the loads of one
 // texel are waited for before the next texel's are issued
 __device__ __forceinline__ void frs_stage_texture(const float* __restrict__ env, int ntexel, float4* s_env4)

@@ -443,6 +443,9 @@ class FusedStage2Step(_BoundedForward):
         # in the ray set were computed FROM, when that was done ahead of the next iteration; work still running on the early stream
         self._pre_rotated = None
         self._defer_b = os.environ.get("R3DG_EARLY_INCIDENTS", "1") != "0"
+        self._chain_kernel = os.environ.get("R3DG_INCIDENT_CHAIN_KERNEL", "1") != "0"   # (A/B: one kernel or three launches)
+        self._chain_late = os.environ.get("R3DG_INCIDENT_CHAIN_LATE", "1") != "0"       # (A/B: behind the other groups' Adam)
+        self._chain_deferred = None
         self._leave_room = os.environ.get("R3DG_SHADE_LEAVE_ROOM", "auto")          # (A/B: "1" / "0" = one workgroup per CU for the shading forward always / never)
         self.opt = FusedAdam([
             dict(param=self.xyz, lr=rate("xyz")), dict(param=self.normal, lr=rate("normal")),
@@ -621,6 +624,8 @@ class FusedStage2Step(_BoundedForward):
             acc_ready = False
             aux = self._aux_stream()
             chained = False          # this iteration's rotated coefficients come from the previous iteration's incident-light chain
+            if self._chain_deferred is not None:
+                self.flush()         # (forward_backward was called twice without optimizer_step: the pending chain runs now)
             if aux is not None:
                 _lib.stream_wait(aux, main)
                 chained = self._rotation_is_current()
@@ -677,12 +682,14 @@ class FusedStage2Step(_BoundedForward):
                                   self.visibility, self.shade_out, uniform_area=self._uniform_area,
                                   # (one workgroup per CU beside the instance ordering while THAT is the longer path.  It is not
                                   # when something sits in front of this kernel: the deferred incident-light update of a
-                                  # data-parallel run (558 -> 568 it/s on one rank without the cap), or -- since the small launches
-                                  # left the main stream -- the incident-light chain of a whole single-GPU iteration, which ends
-                                  # ~50 us after the projection has started: 781 -> 789 it/s without the cap, while the iterations
-                                  # without a chain (frozen geometry: run_syn4.sh) keep it, 835 vs 826)
+                                  # data-parallel run (558 -> 568 it/s on one rank without the cap), or the incident-light chain of
+                                  # a whole single-GPU iteration AS THREE LAUNCHES, which ends ~50 us after the projection has
+                                  # started: 781 -> 789 it/s without the cap.  The chain as one kernel ends before the projection
+                                  # starts and the cap pays again (806 vs 801 it/s), as it does for the iterations without a chain
+                                  # (frozen geometry, run_syn4.sh: 835 vs 826))
                                   leave_room=(order_stream is not None and not self.dp and
-                                              (self._leave_room == "1" or (self._leave_room == "auto" and not chained))),
+                                              (self._leave_room == "1" or
+                                               (self._leave_room == "auto" and not (chained and not self._chain_kernel)))),
                                   # the few hundred Gaussians off the rotated path: their general kernel on the (idle) early-Adam
                                   # stream beside the rotation and the main kernel, joined below before the features are packed
                                   listed_stream=self._listed_stream(), rotated=rotated,
@@ -855,6 +862,9 @@ class FusedStage2Step(_BoundedForward):
             if self._d_env is None or self._d_env.shape != env_c.shape:
                 self._d_env = torch.zeros_like(env_c)
             if self._frs is not None:
+                # (incident-light chain as ONE kernel -- rotation back, Adam, rotation of the new coefficients, every global access a
+                # contiguous run per wave: the main shading backward then leaves the coefficient gradient in the rotated frame)
+                chain = self._early and self._b_early and self._chain_kernel and len(self._groups_b) == 1
                 d_base, d_rough, d_view, _d_inc, d_env = self._frs.backward(
                     self.a_base, self.a_rough, self.a_normal, self.a_viewdirs, self._incidents, env_c, self.visibility,
                     self.d_pbr, self.d_diffuse,
@@ -863,17 +873,37 @@ class FusedStage2Step(_BoundedForward):
                     # whole iterations: the rotation back of the coefficient gradient goes to the stream that already carries the
                     # SH group's early Adam (optimizer_step joins it before any Adam launch reads the gradient; under data
                     # parallelism bucket B's all-reduce is issued from it) and runs beside the activation chain rule
-                    rotate_stream=self._early_stream if self._early else None)
+                    rotate_stream=self._early_stream if self._early else None, rotation_back=not chain)
                 if self._early and self._b_early:
                     # incident-light chain, behind the rotation back: the group's Adam, then the rotation of the NEW coefficients.
                     # (As ONE kernel -- rotation back + Adam + rotation forward, thread per Gaussian, 1536 instead of 2112 bytes per
                     # Gaussian -- this took 300 us against the three launches' 179: eight 192-byte row streams per lane with 64-byte
                     # strides between lanes saturate the address unit, see DESIGN.md section 7.  Measured, deleted.)
-                    with torch.cuda.stream(self._early_stream):
-                        if self._groups_b:
-                            self.opt.step_groups(self._groups_b, [self.grads[k] for k in self._opt_order], skip_flag=self._skip_cur)
-                        self._frs.rotate(self._incidents)
-                    self._pre_rotated = (self._frs, self._incidents, self._incidents._version)
+                    def run_chain(frs=self._frs, skip=self._skip_cur, chain=chain, count=self.opt.step_count):
+                        early = self._early_stream
+                        if chain or self._chain_late:
+                            _lib.stream_wait(early, torch.cuda.current_stream(dev))     # behind what the caller's stream holds now
+                        with torch.cuda.stream(early):
+                            if chain:
+                                grp = self.opt.groups[self._groups_b[0]]
+                                frs.incident_chain(
+                                    self._incidents, self.grads["incidents"], grp["exp_avg"], grp["exp_avg_sq"], grp["lr"],
+                                    grp.get("lr_tail") if grp.get("lr_tail") is not None else grp["lr"], self.opt.betas,
+                                    self.opt.eps, count, 1.0, skip_flag=skip)
+                            else:
+                                if self._groups_b:
+                                    now, self.opt.step_count = self.opt.step_count, count       # (the iteration's own step count)
+                                    self.opt.step_groups(self._groups_b, [self.grads[k] for k in self._opt_order], skip_flag=skip)
+                                    self.opt.step_count = now
+                                frs.rotate(self._incidents)
+                        self._pre_rotated = (frs, self._incidents, self._incidents._version)
+                    if self._chain_late:
+                        # LATE: optimizer_step launches the chain BEHIND the other groups' Adam.  Both are HBM streams; side by
+                        # side the activation chain rule + that Adam -- which the whole front end of the next iteration waits for --
+                        # took 68 + 45 us instead of 20 + 40, while the chain only gates the shading forward
+                        self._chain_deferred = run_chain
+                    else:
+                        run_chain()
             else:
                 d_base, d_rough, d_view, _d_inc, d_env = shading_ops.shade_backward(
                     self.a_base, self.a_rough, self.a_normal, self.a_viewdirs, self._incidents, env_c, self.visibility,
@@ -999,6 +1029,9 @@ class FusedStage2Step(_BoundedForward):
                 todo = self._groups_a + self._groups_c + self._groups_b
             if todo:                     # ONE launch for every remaining group
                 self.opt.step_groups(todo, grads, skip_flag=self._skip_cur)
+            if self._chain_deferred is not None:
+                run, self._chain_deferred = self._chain_deferred, None
+                run()
             return
         # data parallel: update each bucket when its (sum) all-reduce has landed; 1/world is applied inside the kernel
         scale = 1.0 / self.world
@@ -1024,6 +1057,9 @@ class FusedStage2Step(_BoundedForward):
     def flush(self):
         """Complete a deferred incident-light update: data-parallel runs apply it here; a single-GPU iteration that left it running
         on the early-Adam stream gets the CURRENT stream ordered behind it (no host wait).  A no-op otherwise."""
+        if self._chain_deferred is not None:          # (somebody asks for the coefficients between forward_backward and optimizer_step)
+            run, self._chain_deferred = self._chain_deferred, None
+            run()
         if self._early_pending:
             _lib.stream_wait(torch.cuda.current_stream(self.dev), self._early_stream)
             self._early_pending = False

@@ -6,6 +6,8 @@ swaps the op in without editing the reference file.  The per-sample [P,K,*] tens
 consumed through `.mean(-2)` (neilf.py:119-130); they are returned already reduced with a singleton sample axis
 ([P,1,C]) so that `.mean(-2)` and the eval-time `torch.cat(..., dim=0)` keep working on unchanged caller code.
 """
+import ctypes
+
 import torch
 
 from . import _lib
@@ -304,11 +306,14 @@ class FixedRaySet:
         return out
 
     def backward(self, base_color, roughness, normals, viewdirs, incidents, env, visibility, dL_dpbr, dL_ddiffuse_light,
-                 uniform_area=None, out_incidents=None, out_env=None, block_absmax=None, rotate_stream=None):
+                 uniform_area=None, out_incidents=None, out_env=None, block_absmax=None, rotate_stream=None,
+                 rotation_back=True):
         """-> (dL_dbase_color, dL_droughness, dL_dviewdirs, dL_dincidents, dL_denv) as shade_backward; `forward` must have run
         on the same parameters (it left the rotated coefficients).  `rotate_stream` (a torch.cuda.Stream): the rotation of the
         coefficient gradient back to dL_dincidents runs there, beside whatever the caller queues next on the current stream; the
-        caller waits for that stream before reading dL_dincidents."""
+        caller waits for that stream before reading dL_dincidents.  `rotation_back=False`: the coefficient gradient stays in the
+        rotated frame (`self.dcprime`) and dL_dincidents is NOT written for the Gaussians on the rotated path -- the caller follows
+        with `incident_chain`."""
         head, _keep = self._common(base_color, roughness, normals, viewdirs, incidents, env, visibility, uniform_area)
         dev = base_color.device
         P = self.P
@@ -324,9 +329,26 @@ class FixedRaySet:
                 d_base.data_ptr(), d_rough.data_ptr(), d_view.data_ptr(), d_inc.data_ptr(), d_env.data_ptr(),
                 block_absmax.data_ptr() if block_absmax is not None else None,
                 block_absmax.numel() if block_absmax is not None else 0,
-                rotate_stream.cuda_stream if rotate_stream is not None else None)
+                (ctypes.c_void_p(-1) if not rotation_back else
+                 (rotate_stream.cuda_stream if rotate_stream is not None else None)))
         _lib.check(st, "shade_frs_backward")
         return d_base, d_rough, d_view, d_inc, d_env
+
+    def incident_chain(self, incidents, dL_dincidents, exp_avg, exp_avg_sq, lr, lr_tail, betas, eps, step, grad_scale=1.0,
+                       skip_flag=None):
+        """r3dg_shade_frs_incident_chain on the current stream, behind backward(rotation_back=False): the gradient rotated back
+        into `dL_dincidents`, the Adam step of the incident-light group (`incidents`, its two moment tensors; FusedAdam's
+        arithmetic), the NEW coefficients rotated into `self.cprime` for the next forward."""
+        for t in (incidents, dL_dincidents, exp_avg, exp_avg_sq):
+            if tuple(t.shape) != (self.P, 16, 3) or t.dtype != torch.float32 or not t.is_contiguous():
+                raise RuntimeError("FixedRaySet.incident_chain: needs contiguous float32 [P,16,3] tensors")
+        with torch.cuda.device(incidents.device):
+            st = _lib.lib().r3dg_shade_frs_incident_chain(
+                _lib.current_stream(), self.P, self.ray_normals.data_ptr(), self.valid.data_ptr(), self.dcprime.data_ptr(),
+                dL_dincidents.data_ptr(), incidents.data_ptr(), exp_avg.data_ptr(), exp_avg_sq.data_ptr(), self.cprime.data_ptr(),
+                float(lr), float(lr_tail), float(betas[0]), float(betas[1]), float(eps), int(step), float(grad_scale),
+                skip_flag.data_ptr() if skip_flag is not None else None)
+        _lib.check(st, "shade_frs_incident_chain")
 
 
 class _Shade(torch.autograd.Function):

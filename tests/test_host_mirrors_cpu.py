@@ -812,9 +812,13 @@ def test_fused_stage2_iteration_spreads_the_fixed_ray_set_path_over_three_stream
             events.append(("frs.forward", (listed_stream, rotated, leave_room)))
             rows.append(feature_rows)
 
-        def backward(self, *a, uniform_area=None, out_incidents=None, out_env=None, block_absmax=None, rotate_stream=None):
-            events.append(("frs.backward", (rotate_stream,)))
+        def backward(self, *a, uniform_area=None, out_incidents=None, out_env=None, block_absmax=None, rotate_stream=None,
+                     rotation_back=True):
+            events.append(("frs.backward", (rotate_stream, rotation_back)))
             return z(P, 3), z(P, 1), z(P, 3), out_incidents, out_env
+
+        def incident_chain(self, incidents, grad, m, v, lr, lr_tail, betas, eps, step, grad_scale=1.0, skip_flag=None):
+            events.append(("frs.chain", (step, lr, lr_tail)))
 
     monkeypatch.setattr(_lib, "lib", lambda: Recorder())
     monkeypatch.setattr(_lib, "current_stream", lambda: 0)
@@ -865,13 +869,14 @@ def test_fused_stage2_iteration_spreads_the_fixed_ray_set_path_over_three_stream
     it, args = [e[0] for e in events[marks[2]:]], [e[1] for e in events[marks[2]:]]
     pos = {n: it.index(n) for n in ("r3dg_stage2_activate_with", "raster.begin", "frs.forward",
                                     "raster.finish", "raster.backward", "r3dg_stage2_unpack_gradients", "frs.backward",
-                                    "frs.rotate", "r3dg_stage2_activate_backward_with")}
+                                    "r3dg_stage2_activate_backward_with", "frs.chain")}
     assert sorted(pos, key=pos.get) == ["r3dg_stage2_activate_with", "raster.begin", "frs.forward", "raster.finish", "raster.backward",
-                                        "r3dg_stage2_unpack_gradients", "frs.backward", "frs.rotate",
-                                        "r3dg_stage2_activate_backward_with"]
-    # the coefficient rotation is NOT at the top of the iteration any more: the previous iteration queued it on the early stream
-    # behind the incident-light group's Adam, and the ray set still holds the rotation of the current coefficients
-    assert it.count("frs.rotate") == 1 and step._rotation_is_current()
+                                        "r3dg_stage2_unpack_gradients", "frs.backward", "r3dg_stage2_activate_backward_with",
+                                        "frs.chain"]
+    # the coefficient rotation is NOT at the top of the iteration any more, nor a launch of its own: the previous iteration's
+    # incident-light chain (rotation back + the group's Adam + rotation forward: ONE kernel on the early stream, queued by
+    # optimizer_step behind the other groups' Adam) left the rotation of the current coefficients in the ray set
+    assert it.count("frs.rotate") == 0 and step._rotation_is_current()
     # no pack kernel on this path: the activations and the shading kernels write the feature rows between them, and the
     # light-smoothness sum comes from the unpack kernel (its last argument)
     assert "r3dg_stage2_pack_features" not in it and rows[-1] is step.features
@@ -895,23 +900,27 @@ def test_fused_stage2_iteration_spreads_the_fixed_ray_set_path_over_three_stream
     # queued -- before the rotation back, the incident-light group's Adam and the next rotation go to the early stream
     order_joins = [i for i, a in joins if a == (order_stream.cuda_stream, early.cuda_stream)]
     adam = [i for i, n in enumerate(it) if n == "r3dg_adam_step"]
-    assert len(order_joins) == 1 and len(adam) == 3
-    assert adam[0] < order_joins[0] < pos["frs.backward"] < adam[1] < pos["frs.rotate"] < adam[2]
+    assert len(order_joins) == 1 and len(adam) == 2
+    assert adam[0] < order_joins[0] < pos["frs.backward"] < pos["r3dg_stage2_activate_backward_with"] < adam[1] < pos["frs.chain"]
     assert args[pos["raster.begin"]] == (order_stream,) and args[pos["raster.finish"]] == (order_stream,)
     listed, rotated, leave_room = args[pos["frs.forward"]]
-    # the kernel runs behind the previous iteration's incident-light chain: it takes every CU (no one-workgroup-per-CU cap); the
-    # second iteration -- no chain in front of it yet: its rotation was queued at the top -- kept the cap beside the ordering chain
-    assert listed is early and rotated is True and leave_room is False
-    it2 = [e for e in events[marks[1]:marks[2]] if e[0] == "frs.forward"]
-    assert it2 and it2[0][1][2] is True
+    # the chain as one kernel ends before the projection starts: the shading forward keeps its one-workgroup-per-CU cap beside the
+    # ordering chain (it loses it behind a chain of three launches: R3DG_INCIDENT_CHAIN_KERNEL=0)
+    assert listed is early and rotated is True and leave_room is True
     assert geometry_streams[-1] is early                                       # geometry backward beside the listed backward
-    assert args[pos["frs.backward"]] == (early,)                               # rotation back on the same stream
+    # the main shading backward leaves the coefficient gradient in the rotated frame: the chain kernel rotates it back
+    assert args[pos["frs.backward"]] == (early, False)
     assert "main.wait_event" in it[pos["frs.backward"]:pos["r3dg_stage2_activate_backward_with"]]     # geometry joined by its event
     assert "torch.wait_stream" not in it                                       # no per-call event objects on the hot path
-    # Adam: the SH group and the incident-light group inside the early stream's context, the other groups on the main stream
+    # Adam: the SH group inside the early stream's context, the other groups on the main stream; the chain kernel behind THAT
+    # launch (a join early <- main in front of it), inside the early stream's context, with the iteration's own step count and the
+    # incident-light group's two learning rates
     assert it[adam[0] - 1] == "enter" and args[adam[0] - 1] == (early.cuda_stream,)
-    assert "enter" in it[pos["frs.backward"]:adam[1]] and "exit" not in it[adam[1]:pos["frs.rotate"]]
-    assert adam[2] > pos["r3dg_stage2_activate_backward_with"] and "enter" not in it[pos["frs.rotate"] + 2:adam[2]]
+    assert "enter" not in it[pos["frs.backward"]:adam[1]]
+    assert it[pos["frs.chain"] - 1] == "enter" and args[pos["frs.chain"] - 1] == (early.cuda_stream,)
+    assert it[pos["frs.chain"] - 2] == "r3dg_stream_wait_stream" and args[pos["frs.chain"] - 2] == (early.cuda_stream, main.cuda_stream)
+    grp = step.opt.groups[step._opt_order.index("incidents")]
+    assert args[pos["frs.chain"]] == (step.opt.step_count, grp["lr"], grp["lr_tail"])
     # the small view-independent jobs (softplus, sum reset) ride in the activation launch and the accumulator slab needs no zero
     # fill: nothing but the fork enters the early stream's context at the top of the iteration
     assert "enter" not in it[:pos["frs.forward"]]
@@ -925,7 +934,19 @@ def test_fused_stage2_iteration_spreads_the_fixed_ray_set_path_over_three_stream
     marks.append(len(events))
     step(cam, torch.ones(3), z(3, H, W))
     it4 = [e[0] for e in events[marks[3]:]]
-    assert it4.count("frs.rotate") == 2 and it4.index("frs.rotate") < it4.index("r3dg_stage2_activate_with")
+    assert it4.count("frs.rotate") == 1 and it4.index("frs.rotate") < it4.index("r3dg_stage2_activate_with")
+    # R3DG_INCIDENT_CHAIN_KERNEL=0: the chain as three launches -- rotation back by the shading backward's call, the group's Adam and
+    # the next rotation behind the other groups' Adam -- and the shading forward uncapped behind it
+    monkeypatch.setenv("R3DG_INCIDENT_CHAIN_KERNEL", "0")
+    three = fused_step.FusedStage2Step(params, K)
+    for _ in range(3):
+        mark = len(events)
+        three(cam, torch.ones(3), z(3, H, W))
+    it5, args5 = [e[0] for e in events[mark:]], [e[1] for e in events[mark:]]
+    assert "frs.chain" not in it5 and it5.count("frs.rotate") == 1 and it5.count("r3dg_adam_step") == 3
+    assert args5[it5.index("frs.backward")] == (early, True) and args5[it5.index("frs.forward")][2] is False
+    assert it5.index("r3dg_stage2_activate_backward_with") < it5.index("frs.rotate")
+    monkeypatch.delenv("R3DG_INCIDENT_CHAIN_KERNEL")
     # ---- a second step object gets the same side streams -------------------------------------------------------------------
     other = fused_step.FusedStage2Step(params, K)
     other(cam, torch.ones(3), z(3, H, W))

@@ -394,6 +394,78 @@ def test_relight_kernels_match_oracle(P, K, He, transform):
             _ok(name + " rest", out[:, [3, 4, 5] + list(range(9, 19))], want[:, [3, 4, 5] + list(range(9, 19))], 1e-4, 1e-6)
 
 
+@pytest.mark.parametrize("P,step", [(2500, 1), (333, 7), (17, 120)])
+def test_incident_chain_kernel_equals_its_three_launches(P, step):
+    """r3dg_shade_frs_incident_chain (round 5: rotation back of the coefficient gradient + the incident-light group's Adam + rotation
+    of the NEW coefficients, one pass) against the three launches it replaces at the end of a whole iteration -- frs_rotate<back>,
+    r3dg_adam_step on the group (columns 0..2 with lr, the rest with lr_tail), frs_rotate<forward>: the gradient rows bit for bit
+    (same rotation code), the moments and parameters to a few ulp of the update (this kernel's translation unit is built with
+    -ffast-math: 1-ulp v_rcp / v_sqrt in the Adam quotient), c' likewise; rows of Gaussians off the rotated path take their
+    gradient from dL_dincidents; a set skip flag leaves everything untouched."""
+    from relightable3dgaussian_amd import shading_ops as so
+    from relightable3dgaussian_amd.fused_step import FusedAdam
+    inp = _frs_inputs(P, 16, 16, seed=5 * P + step)
+    frs = so.FixedRaySet.try_build(inp["normals"], inp["incident_dirs"])
+    assert frs is not None and frs.n_invalid >= 1
+    g = torch.Generator().manual_seed(step)
+    rnd = lambda *sh: torch.randn(*sh, generator=g).to(DEV)
+    inc0, m0, v0 = 0.3 * rnd(P, 16, 3), 0.01 * rnd(P, 16, 3), (0.01 * rnd(P, 16, 3)) ** 2
+    dcp, listed_rows = rnd(P, 16, 3), rnd(P, 16, 3)
+    lr, lr_tail, betas, eps = 1e-3, 1e-4, (0.9, 0.999), 1e-15
+
+    # reference: (1) the chain kernel with learning rate 0 writes the rotated-back gradient rows (checked against the rows the
+    # fused-step tests already pin); (2) FusedAdam on those rows; (3) r3dg_shade_frs_rotate of the updated parameters
+    frs.dcprime.copy_(dcp.reshape(P, 48))
+    grad = listed_rows.clone()
+    inc_a, m_a, v_a = inc0.clone(), m0.clone(), v0.clone()
+    frs.incident_chain(inc_a, grad, m_a, v_a, 0.0, 0.0, betas, eps, step)
+    torch.cuda.synchronize()
+    assert torch.equal(inc_a, inc0), "learning rate 0 must leave the parameters alone"
+    off = (frs.valid[:P] == 0)
+    assert torch.equal(grad[off], listed_rows[off]), "rows off the rotated path keep the listed kernel's gradient"
+    assert not torch.equal(grad[~off], listed_rows[~off])
+    # ... and those rows ARE the rotation back: it is the transpose of the rotation forward (frs_rotate_kernel<false>, an
+    # independent instantiation): <D c, g'> == <c, D^T g'> per Gaussian, for an arbitrary coefficient row c
+    c_rand = rnd(P, 16, 3)
+    frs.rotate(c_rand)
+    torch.cuda.synchronize()
+    lhs = (frs.cprime[:P].reshape(P, 48).double() * dcp.reshape(P, 48).double()).sum(1)[~off]
+    rhs = (c_rand.reshape(P, 48).double() * grad.reshape(P, 48).double()).sum(1)[~off]
+    assert float((lhs - rhs).abs().max()) <= 1e-5 * float(lhs.abs().max()), "rotation back is not the transpose of the rotation"
+    opt = FusedAdam([dict(param=inc0.clone(), lr=lr, lr_tail=lr_tail, period=48, split=3)], betas=betas, eps=eps)
+    opt.groups[0]["exp_avg"].copy_(m0)
+    opt.groups[0]["exp_avg_sq"].copy_(v0)
+    opt.step_count = step - 1
+    opt.step([grad])
+    want_inc, want_m, want_v = opt.groups[0]["param"], opt.groups[0]["exp_avg"], opt.groups[0]["exp_avg_sq"]
+    frs.rotate(want_inc)
+    torch.cuda.synchronize()
+    want_cp = frs.cprime.clone()
+    # the chain, for real
+    frs.dcprime.copy_(dcp.reshape(P, 48))
+    grad_b = listed_rows.clone()
+    inc_b, m_b, v_b = inc0.clone(), m0.clone(), v0.clone()
+    frs.cprime.fill_(float("nan"))
+    frs.incident_chain(inc_b, grad_b, m_b, v_b, lr, lr_tail, betas, eps, step)
+    torch.cuda.synchronize()
+    assert torch.equal(grad_b, grad), "gradient rows differ between two runs of the same rotation"
+    _ok("exp_avg", m_b, want_m, 1e-6, 0.0)
+    _ok("exp_avg_sq", v_b, want_v, 1e-6, 0.0)
+    upd = (want_inc - inc0).abs().max().item()
+    assert upd > 0
+    err = (inc_b - want_inc).abs().max().item()
+    print("incident chain: largest update %.3e, largest difference to adam_kernel %.3e" % (upd, err))
+    # (a few ulp of the UPDATE, + one rounding of the parameter itself: |p| ~ 1 has an ulp of 6e-8, twelve times the former)
+    assert err <= 2e-6 * upd + 1.2e-7 * float(inc0.abs().max())
+    _ok("cprime", frs.cprime[:P][~off], want_cp[:P][~off], 1e-5, 1e-7)
+    # dropped frame: nothing moves
+    flag = torch.ones(4, device=DEV)
+    inc_c, m_c, v_c, grad_c = inc0.clone(), m0.clone(), v0.clone(), listed_rows.clone()
+    frs.incident_chain(inc_c, grad_c, m_c, v_c, lr, lr_tail, betas, eps, step, skip_flag=flag)
+    torch.cuda.synchronize()
+    assert torch.equal(inc_c, inc0) and torch.equal(m_c, m0) and torch.equal(v_c, v0) and torch.equal(grad_c, listed_rows)
+
+
 def test_fixed_ray_set_kernels_match_reference_golden():
     """... and against the reference's OWN rendering_equation (gaussian_renderer/neilf.py:339-407) executed on an unperturbed
     Fibonacci ray set (tests/golden/shading_reference_frs.npz, make_frs_golden.py): values and autograd gradients."""
