@@ -83,7 +83,7 @@ def loss_stage1(outs, gt, image_mask=None, weights=None, iteration=0):
     return stage1_loss(outs, gt, image_mask, weights, iteration)
 
 
-def _algorithmic_bytes(stage, P, R, N, S, K=64, S_bwd=None):
+def _algorithmic_bytes(stage, P, R, N, S, K=64, S_bwd=None, chain_kernel=False):
     """SURVEY.md 8(d) per-unit figures x the units one launch processes (fp32).  `S_bwd`: the feature channels the TIMED
     backward launch carries (the iteration passes `active_features`: channels whose upstream gradient is zero are neither read
     nor written) -- round 3 priced the launch with all S channels, twice what it moves.  The instance-ordering stages are priced with
@@ -113,12 +113,14 @@ def _algorithmic_bytes(stage, P, R, N, S, K=64, S_bwd=None):
         "shade_forward_general": (260.0 + 16 * K) * P,
         "shade_backward_general": (476.0 + 16 * K) * P,
         # fixed ray set: the coefficient rotation, once each way (48 floats + the normal read, 48 floats written)
-        "shade_frs_aux": 2 * (48.0 + 3 + 48) * 4 * P,
+        # (chain_kernel: the incident-light chain as one kernel -- rotated gradient 192 + p, m, v 576 in; p, m, v 576 + gradient
+        # 192 + rotated coefficients 192 out; normal 12, validity 1 -- whose Adam traffic then leaves `adam_step`)
+        "shade_frs_aux": 1741.0 * P if chain_kernel else 2 * (48.0 + 3 + 48) * 4 * P,
         # relight under a fixed light: 12 B of cached transport per sample; per Gaussian albedo, roughness, normal, view
         # direction (40 B) + 16 cached constants (64 B) read, 19 outputs (76 B) written
         "shade_forward_transport": (180.0 + 12 * K) * P,
         # Adam: 28 B per parameter float (p, g, m, v read; p, m, v written); 127 floats per Gaussian in stage 2
-        "adam_step": 28.0 * 127 * P,
+        "adam_step": 28.0 * (127 - (48 if chain_kernel else 0)) * P,
         # glue: activations 68 B read + 72 B written + the nine feature-row columns they own (36 B); feature row (general
         # shading kernels only) 40+76 read, 64 written; loss 27 maps read, 20 written
         "stage2_activate": 176.0 * P,
@@ -246,7 +248,7 @@ def _kernel_names(stage):
             "shade_forward": ["shade_forward_frs_kernel", "shade_forward_row_kernel"],
             "shade_backward": ["shade_backward_frs_kernel", "shade_backward_kernel"],
             "shade_forward_general": ["shade_forward_row_kernel"], "shade_backward_general": ["shade_backward_kernel"],
-            "shade_frs_aux": ["frs_rotate_kernel"],
+            "shade_frs_aux": ["frs_incident_chain_kernel", "frs_rotate_kernel"],
             "render_forward": ["render_forward_wave_kernel", "render_forward_kernel"],
             "render_backward": ["render_backward_wave_kernel", "render_backward_kernel"],
             "shade_forward_transport": ["shade_forward_transport_kernel"],
@@ -330,7 +332,7 @@ def valu_bound_of(stage, measured_ms, workload=None):
                 kernel=name, source=source, stale=stale)
 
 
-def kernel_table(prof, n_sampled, P, R, N, S, K, rename=None, S_bwd=None, workload=None, alone=None):
+def kernel_table(prof, n_sampled, P, R, N, S, K, rename=None, S_bwd=None, workload=None, alone=None, chain_kernel=False):
     """{stage: avg_ms, launches, ms per iteration/frame, algorithmic MB, achieved GB/s, fraction of the 8 TB/s HBM peak,
     VALU-issue fraction (committed PMC evidence)} from the in-library HIP-event timing.
     `alone` = (prof, n_sampled) of a few more iterations / frames run with every launch on ONE stream: `alone_ms_per_iteration`
@@ -349,7 +351,7 @@ def kernel_table(prof, n_sampled, P, R, N, S, K, rename=None, S_bwd=None, worklo
         avg_ms = ms / cnt
         step_ms = avg_ms * per_iter
         try:
-            by = _algorithmic_bytes(name, P, R, N, S, K, S_bwd)
+            by = _algorithmic_bytes(name, P, R, N, S, K, S_bwd, chain_kernel)
         except KeyError:
             by = None
         row = dict(avg_ms=round(avg_ms, 4), launches=cnt, launches_per_iteration=per_iter,
@@ -1155,7 +1157,10 @@ def run(args):
         general = fused and stage2 and getattr(step_fn, "_frs", None) is None
         kernels = kernel_table(prof, n_sampled, P, R_mean, N, S, args.sample_num, S_bwd=S_bwd,
                                rename={"shade_forward": "shade_forward_general", "shade_backward": "shade_backward_general"}
-                               if general else None, alone=alone)
+                               if general else None, alone=alone,
+                               # (whole single-GPU iterations run the incident-light chain as one kernel: fused_step.py)
+                               chain_kernel=bool(fused and stage2 and getattr(step_fn, "_chain_kernel", False) and
+                                                 getattr(step_fn, "_pre_rotated", None) is not None and not dp))
         if not kernels:                   # experiments with the in-library event timing switched off
             kernels = {"none": dict(avg_ms=0.0, launches=0, ms_per_iteration=0.0, algorithmic_MB=None, achieved_GBs=None)}
         roofline = roofline_of(kernels, "achieved = algorithmic bytes of the TIMED launch (SURVEY.md 8(d) per-unit figures with "

@@ -72,4 +72,13 @@ for K, He in CASES:
             pr = _lib.profile_read(); L.r3dg_profile_enable(0)
             res["frs backward"] = pr["shade_backward"][0] / max(pr["shade_backward"][1], 1)
             res["frs backward listed"] = pr["shade_frs_listed"][0] / max(pr["shade_frs_listed"][1], 1)
+            # the incident-light chain as one kernel (rotation back + Adam + rotation forward), alone
+            grad, m, v = torch.zeros_like(inc), torch.zeros_like(inc), torch.zeros_like(inc)
+            for it in range(8):
+                if it == 3:
+                    torch.cuda.synchronize(); L.r3dg_profile_enable(1)
+                frs.incident_chain(inc, grad, m, v, 1e-4, 1e-5, (0.9, 0.999), 1e-15, it + 1)
+            torch.cuda.synchronize()
+            pr = _lib.profile_read(); L.r3dg_profile_enable(0)
+            res["frs incident chain"] = pr["shade_frs_aux"][0] / max(pr["shade_frs_aux"][1], 1)
     print("K=%d He=%d  " % (K, He) + "  ".join("%s %.4f ms" % kv for kv in res.items()))
