@@ -1344,8 +1344,16 @@ void launch_shade_frs_incident_chain(hipStream_t s, int P, const float* ray_norm
     // (bias corrections exactly as launch_adam forms them, stage2_glue.hip)
     const double b1 = 1.0 - pow((double)beta1, (double)step), b2 = 1.0 - pow((double)beta2, (double)step);
     FrsAdam a = {lr, lr_tail, beta1, beta2, eps, (float)b1, (float)(1.0 / sqrt(b2)), grad_scale, 1.f - beta1, 1.f - beta2};
-    frs_incident_chain_kernel<<<(P + 255) / 256, 256, 0, s>>>(P, ray_normals, valid, dcp, d_inc, incidents, exp_avg, exp_avg_sq,
-                                                              cprime, a, skip_flag);
+    // 49 KB of LDS per workgroup = three per CU: measured against two (56 KB) and one (81 KB) per CU, which are gentler on the
+    // activation / projection kernels running beside it but make the chain the longer path: 805 / 797 / 771 it/s
+    const size_t lds = 4 * 64 * FRS_CHAIN_LD * sizeof(float);
+    static bool attr = false;
+    if (!attr) {
+        R3DG_HIP(hipFuncSetAttribute((const void*)frs_incident_chain_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr = true;
+    }
+    frs_incident_chain_kernel<<<(P + 255) / 256, 256, lds, s>>>(P, ray_normals, valid, dcp, d_inc, incidents, exp_avg, exp_avg_sq,
+                                                                cprime, a, skip_flag);
     check_launch(s, false, "frs_incident_chain_kernel");
 }
 

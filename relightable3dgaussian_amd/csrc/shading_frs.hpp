@@ -246,9 +246,9 @@ frs_incident_chain_kernel(int P, const float* __restrict__ ray_normals, const ui
     // a frame the bounded forward dropped: no update (adam_kernel's rule) -- and then nothing here is needed: the parameters and
     // therefore c' are unchanged, the gradient of a dropped frame is nobody's input
     if (skip_flag != nullptr && *skip_flag != 0.0f) return;
-    __shared__ float s_rows[4][64 * FRS_CHAIN_LD];
+    extern __shared__ float s_rows[];             // 4 x 64 x FRS_CHAIN_LD floats (+ padding that limits the workgroups per CU)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    float* s = s_rows[wave];
+    float* s = s_rows + wave * 64 * FRS_CHAIN_LD;
     const int g0 = (blockIdx.x * 4 + wave) * 64;                  // this wave's 64 consecutive Gaussians
     if (g0 >= P) return;
     const int ng = min(64, P - g0);
