@@ -836,6 +836,20 @@ class FusedStage2Step(_BoundedForward):
                     # (The overflow flag the group's Adam reads later is this iteration's own slot of the flag ring.)
                     _lib.stream_wait(order_stream, side)
                     self._b_early = True
+            elif (early_adam and not self.dp and not self._groups_a and self._groups_b and self._defer_b and self._chain_kernel
+                  and self._frs is not None and order_stream is not None and use_bounded and P * self.K <= 40_000_000):
+                # frozen SH colour (run_syn4.sh / run_dtu.sh) but a training incident-light group: no early Adam, but the
+                # incident-light chain -- one kernel on the early stream behind the other groups' Adam -- all the same, instead of
+                # rotation back (main stream) -> Adam (all groups) -> ... -> rotation at the top of the next iteration: 831 -> 843
+                # it/s at sample_num 64, 606 -> 610 on the DTU frame.  (Not at sample_num 384, 399 -> 392: there the shading
+                # forward is the long path of the forward window and the chain in front of it costs more than the launches it saves.)
+                if self._adam_stream is None:
+                    self._adam_stream = shared_stream(dev, "early")
+                self.opt.begin_step()
+                self._early_stream = self._adam_stream
+                self._early = True
+                self._early_pending = True
+                self._b_early = True
             elif early_adam and handle_a is not None and self._groups_a:
                 # data parallel: the same update on the side stream, behind bucket A's all-reduce -- whenever that lands
                 # while the shading backward is still running, the SH group's Adam runs under it too (measured with a
