@@ -526,8 +526,9 @@ def relight_bench(params, cams, dev, frames, K):
         it = iter(rots)
         dt_rot = timed(lambda cam: renderer.frame(cam, bg, env_transform=next(it)), n_rot)
         rotating = dict(fps=round(1.0 / dt_rot, 2), ms_per_frame=round(1e3 * dt_rot, 3), frames=n_rot,
-                        what="one new light rotation per frame: the per-sample lat-long lookups + radiance are rebuilt "
-                             "every frame (r3dg_shade_build_taps) instead of reused")
+                        what="one new light rotation per frame (relighting.py:160-161): the light-independent half of the "
+                             "transport is cached once (r3dg_shade_build_split), the lat-long lookup of every sample happens "
+                             "inside the per-frame kernel (r3dg_shade_forward_split)")
     except Exception as e:                     # a side measurement: never fail the bench on it
         rotating = {"failed": repr(e)}
     P = params.xyz.shape[0]
@@ -549,7 +550,8 @@ def relight_bench(params, cams, dev, frames, K):
                 relight_note="relight_fps: moving camera under a FIXED light (configs/teaser, configs/nerf_syn): the "
                              "view-independent part of the integral is cached per sample (RelightRenderer's default, "
                              "cache='transport'); relight_fps_radiance_cache: only the looked-up radiance is reused; "
-                             "relight_rotating_light: nothing is reused (lookup in the kernel)")
+                             "relight_rotating_light: the light turns with every frame -- the light-independent half of the "
+                             "transport is reused, the lookup happens in the kernel")
 
 
 # (see bench.py: an OpenMP pool sized for the host runs into the container's CPU quota; tools that import this module directly
