@@ -636,9 +636,21 @@ tile_emit_kernel(int P, int T, int iters, const float2* __restrict__ means2D, co
             for_each_tile(rc[it], base + it * BIN_THREADS, 0u, gx,
                           [&](uint32_t tile, uint32_t, uint32_t) { atomicAdd(&s_bins[tile], 1u); });
     __syncthreads();
-    for (int t = threadIdx.x; t < T; t += BIN_THREADS) {
-        const uint32_t c = s_bins[t];
-        if (c) s_bins[t] = atomicAdd(&cursor[t], c);           // this block's run inside tile t's segment
+    // this block's run inside every touched tile's segment: ONE returning global atomic per (block, tile) -- four of a thread's in
+    // flight at a time (as a plain loop each waited for its predecessor's return, a device-scope round trip of several us: half
+    // of the block's lifetime at 2500 tiles)
+    for (int t0 = threadIdx.x; t0 < T; t0 += 4 * BIN_THREADS) {
+        uint32_t c[4], r[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int t = t0 + k * BIN_THREADS;
+            c[k] = t < T ? s_bins[t] : 0u;
+        }
+#pragma unroll
+        for (int k = 0; k < 4; k++) r[k] = c[k] ? atomicAdd(&cursor[t0 + k * BIN_THREADS], c[k]) : 0u;
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+            if (c[k]) s_bins[t0 + k * BIN_THREADS] = r[k];
     }
     __syncthreads();
 #pragma unroll
