@@ -32,6 +32,19 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 
+# BASELINE.json configs as named workloads (the default, no --config, is the headline: 300k Gaussians, 800x800, run_nerf.sh stage 2)
+CONFIG_PRESETS = {
+    "dtu4": ("configs[3]: DTU stage-2 (run_dtu.sh: 1600x1200, sample_num 32, smoothness terms, geometry frozen), one view per "
+             "rank -- meant for --gpus 4", dict(width=1600, height=1200, objective="syn4", sample_num=32)),
+    "teaser8": ("configs[4]: composition scale, 2M Gaussians, 1800x700 (configs/teaser), relight at sample_num 384, frames "
+                "sharded over the ranks -- meant for --gpus 8", dict(points=2_000_000, width=1800, height=700, relight_samples=384,
+                                                                      relight_frames=12, steps=12, warmup=4)),
+    "syn4": ("configs[2]: Synthetic4Relight stage-2 (run_syn4.sh objective + schedule), sample_num 384 as BASELINE.json states",
+             dict(objective="syn4", sample_num=384, steps=20, warmup=4)),
+    "stage1": ("configs[1]: stage-1 3DGS train iteration, 800x800", dict(stage=1)),
+}
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -57,9 +70,19 @@ def parse():
     ap.add_argument("--relight-samples", type=int, default=384)
     ap.add_argument("--repeats", type=int, default=5,
                     help="N=1 only: extra timed blocks of --steps iterations after the headline block (min/median/max)")
+    ap.add_argument("--config", default=None, choices=sorted(CONFIG_PRESETS),
+                    help="one of the other BASELINE.json configurations as the timed workload (sets the size / objective flags; "
+                         "flags given after it still override): " + "; ".join("%s = %s" % (k, v[0]) for k, v in sorted(CONFIG_PRESETS.items())))
     ap.add_argument("--plumbing-only", action="store_true",
                     help="launch/rendezvous/reduction path only, no kernels (CPU test of the --gpus N launcher)")
-    return ap.parse_args()
+    args = ap.parse_args()
+    if args.config:
+        # a preset fills in every flag the command line left at its default
+        given = {a.lstrip("-").split("=")[0].replace("-", "_") for a in sys.argv[1:] if a.startswith("--")}
+        for k, v in CONFIG_PRESETS[args.config][1].items():
+            if k not in given:
+                setattr(args, k, v)
+    return args
 
 
 def _free_port():

@@ -554,6 +554,58 @@ def relight_bench(params, cams, dev, frames, K):
                              "transport is reused, the lookup happens in the kernel")
 
 
+@torch.no_grad()
+def relight_bench_sharded(model, cams, dev, frames, K, rank, world, group=None):
+    """Relight / eval rendering over `world` ranks (BASELINE.json configs[4] "view-sharded render"): the frames of
+    the trajectory are independent units -- the reference walks them one after another (relighting.py:114-185) -- so rank r renders
+    frames r, r + W, r + 2W, ... of a trajectory of `frames` x W frames on its own replica of the scene, with NO data-path
+    collective.  The one exchange is in the set-up: `update_visibility` traces ceil(P/W) ray bundles per rank against the
+    replicated BVH and ONE all-gather assembles the [P,K,1] visibility (train_step.update_visibility).  Timing as the contract
+    asks: barrier + synchronize on both sides, MAX over ranks; relight_fps = all frames of all ranks / that time (weak scaling:
+    `frames` per rank)."""
+    from . import relight
+    g = torch.Generator().manual_seed(7)
+    envmap = (3.0 * torch.rand(256, 512, 3, generator=g) ** 2).to(dev)
+    torch.cuda.synchronize()
+    dist.barrier(group=group)
+    t0 = time.perf_counter()
+    renderer = relight.RelightRenderer(model, envmap, K, process_group=group)       # sharded trace + all-gather
+    torch.cuda.synchronize()
+    t_vis = time.perf_counter() - t0
+    bg = torch.zeros(3, device=dev)
+    mine = list(range(rank, frames * world, world))           # this rank's frames of the trajectory
+    for i in range(3):
+        renderer.frame(cams[(rank + i * world) % len(cams)], bg)
+    torch.cuda.synchronize()
+    dist.barrier(group=group)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    nr = 0
+    for f in mine:
+        nr += renderer.frame(cams[f % len(cams)], bg)["num_rendered"]
+    torch.cuda.synchronize()
+    own = time.perf_counter() - t0
+    dist.barrier(group=group)
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    cpu = dist.get_backend(group) == "gloo"
+    t = torch.tensor([elapsed, t_vis], dtype=torch.float64, device="cpu" if cpu else dev)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
+    per_rank = [torch.zeros(2, dtype=torch.float64, device=t.device) for _ in range(world)]
+    dist.all_gather(per_rank, torch.tensor([own, float(nr)], dtype=torch.float64, device=t.device), group=group)
+    elapsed, t_vis = float(t[0]), float(t[1])
+    fps_rank = [len(mine) / float(x[0]) for x in per_rank]
+    P = renderer.P
+    return dict(relight_fps=round(world * len(mine) / elapsed, 2), relight_ms_per_frame=round(1e3 * elapsed / len(mine), 3),
+                relight_K=K, relight_cache=renderer.cache, relight_features=28, frames_per_rank=len(mine),
+                per_rank_fps_min=round(min(fps_rank), 2), per_rank_fps_max=round(max(fps_rank), 2),
+                num_rendered=float(sum(float(x[1]) for x in per_rank)) / max(1, world * len(mine)),
+                visibility_rays=P * K, visibility_seconds=round(t_vis, 3),
+                visibility_Mrays_per_s=round(P * K / t_vis / 1e6, 1),
+                sharding="frames rank::world of a %d-frame trajectory, replicas only (no data-path collective); visibility: "
+                         "ceil(P/W) ray bundles per rank + one all-gather" % (frames * world))
+
+
 # (see bench.py: an OpenMP pool sized for the host runs into the container's CPU quota; tools that import this module directly
 # get the cap here)
 torch.set_num_threads(min(torch.get_num_threads(), 8))
@@ -826,15 +878,22 @@ def compact(result):
     < COMPACT_LIMIT bytes so that a driver that keeps only the tail of stdout still holds a parseable headline (round 4's
     23 KB document left `BENCH_r04.parsed` null).  The full document goes to gpurun_out/bench_full.json and to stderr."""
     keep = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
-            "dtype", "data", "exposed_comm_ms", "reserved_cus_for_comm", "plumbing_only")
+            "dtype", "data", "exposed_comm_ms", "exposed_comm_ms_by_bucket", "dp_buckets", "reserved_cus_for_comm", "plumbing_only")
     c = {k: result[k] for k in keep if k in result}
     cfg = result.get("config") or {}
     c["config"] = {"workload": str(cfg.get("workload", ""))[:260], "parallelism": str(cfg.get("parallelism", "")).split(" ")[0]}
     c["roofline"] = _roofline_compact(result.get("roofline"))
     if result.get("roofline_relight"):
         c["roofline_relight"] = _roofline_compact(result["roofline_relight"])
+    cbk = result.get("comm_buckets")
+    if cbk:
+        c["comm_buckets"] = {k: {a: v.get(a) for a in ("MB", "ready_us", "done_us", "collective_ms", "bus_GBs")} for k, v in cbk.items()}
     rl = result.get("relight") or {}
-    if rl:
+    if rl and "frames_per_rank" in rl:
+        c["relight_fps"] = rl.get("relight_fps")
+        c["relight"] = {k: rl.get(k) for k in ("relight_K", "frames_per_rank", "per_rank_fps_min", "per_rank_fps_max",
+                                               "visibility_Mrays_per_s", "visibility_seconds")}
+    elif rl:
         c["relight_fps"] = rl.get("relight_fps")
         c["relight"] = {"K": rl.get("relight_K"), "fps_radiance_cache": rl.get("relight_fps_radiance_cache"),
                         "fps_turning_light": (rl.get("relight_rotating_light") or {}).get("fps"),
@@ -1087,8 +1146,9 @@ def run(args):
     except Exception as e:                         # (never the reason a bench line is missing)
         device_clock = dict(error=str(e)[:120])
     exposed_comm = None
+    exposed_by_bucket = {}
     if dp and fused and hasattr(step_fn, "exposed_comm_ms"):
-        exposed_comm = step_fn.exposed_comm_ms()
+        exposed_comm, exposed_by_bucket = step_fn.exposed_comm_ms(split=True)
         step_fn.measure_comm = False
     if fused and hasattr(step_fn, "rendered_counts"):
         R_seen = step_fn.rendered_counts(args.steps)
@@ -1142,12 +1202,20 @@ def run(args):
             L.r3dg_profile_enable(0)
 
     relight = None
-    if stage2 and args.relight_frames > 0 and world == 1:       # relight: replicas only -- measured at N=1
+    comm_buckets = exposed_split = None
+    if dp and fused and hasattr(step_fn, "comm_table"):
+        comm_buckets = step_fn.comm_table()
+    if stage2 and args.relight_frames > 0:
         step_fn.visibility = step_fn.incident_dirs = step_fn.incident_areas = None   # free the K=train caches
         if hasattr(step_fn, "_taps"):
             step_fn._taps = step_fn._taps_src = None
         torch.cuda.empty_cache()
-        relight = relight_bench(step_fn if fused else params, cams, dev, args.relight_frames, args.relight_samples)
+        if world == 1:
+            relight = relight_bench(step_fn if fused else params, cams, dev, args.relight_frames, args.relight_samples)
+        else:
+            # the other half of BASELINE.json's metric at N > 1: frames sharded over the ranks (replicas only)
+            relight = relight_bench_sharded(step_fn if fused else params, cams, dev, args.relight_frames, args.relight_samples,
+                                            rank, world)
     result = None
     if rank == 0:
         P, N = args.points, W_img * H_img
@@ -1193,9 +1261,16 @@ def run(args):
             # rank 0's compute stream: mean time per iteration it stood waiting for gradient all-reduce buckets (C, then the
             # deferred B in front of the next shading forward; A is waited for on a side stream, under the shading backward)
             result["exposed_comm_ms"] = None if exposed_comm is None else round(exposed_comm, 4)
+            # ... split by the bucket the stream stood waiting for, and every bucket's collective bracketed by events on a probe
+            # stream (FusedStage2Step.comm_table): bytes, ready / done times inside the iteration, the collective's own time and
+            # the ring bus bandwidth it amounts to -- what tells a lost 8-GPU factor apart into bandwidth (bus_GBs low), message
+            # size (R3DG_DP_BUCKETS=1 against the default 3) and schedule (exposed_comm_ms_by_bucket high at a good bus_GBs)
+            result["exposed_comm_ms_by_bucket"] = {k: round(v, 4) for k, v in sorted(exposed_by_bucket.items())}
+            result["comm_buckets"] = comm_buckets
+            result["dp_buckets"] = 1 if getattr(step_fn, "_single_bucket", False) else 3
             with step_fn._ctx:                   # (the step's own option context: the process default stays 0)
                 result["reserved_cus_for_comm"] = _lib.get_option("RESERVE_CUS")
-        if relight is not None:
+        if relight is not None and "roofline_relight" in relight:
             result["roofline_relight"] = relight.pop("roofline_relight")
         if relight is not None:
             result["relight"] = relight

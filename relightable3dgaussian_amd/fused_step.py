@@ -382,10 +382,12 @@ class FusedStage2Step(_BoundedForward):
             self._bucket_a = None                                               # (no SH colour gradient to send early)
             self._bucket_c = self.grad_flat[:start["incidents"]]                # flag + base colour, roughness, env texture
             self._bucket_b = self.grad_flat[start["incidents"]:start["shs"]]
+            self._bucket_all = self.grad_flat[:start["shs"]]
         else:
             self._bucket_a = self.grad_flat[:start["xyz"]]
             self._bucket_c = self.grad_flat[start["xyz"]:start["incidents"]]
             self._bucket_b = self.grad_flat[start["incidents"]:]
+            self._bucket_all = self.grad_flat
         self._pending_b = None
         self._acc = None                            # the tile backward's accumulator slab, zero-filled off the critical path
         self._early_pending = False                 # the early-Adam stream holds work no other stream has been ordered behind yet
@@ -431,6 +433,11 @@ class FusedStage2Step(_BoundedForward):
         self.serial_streams = False
         self.measure_comm = False                   # bench.py: time the main stream spends waiting for all-reduce buckets
         self._comm_events = []
+        self._bucket_events = []                    # (iteration, bucket, bytes, ready event, done event): comm_table()
+        self.comm_probe_every = 4                   # with measure_comm: every n-th iteration's buckets get the two probe events
+        # R3DG_DP_BUCKETS=1 (A/B, message size against overlap): ONE all-reduce of the whole gradient slab behind the backward
+        # and one Adam launch behind it, instead of the three buckets A / C / B each sent the moment it is final
+        self._single_bucket = self.dp and os.environ.get("R3DG_DP_BUCKETS", "3") == "1"
         with torch.no_grad(), self._ctx:
             self.refresh_activations()
             self.visibility, self.incident_dirs, self.incident_areas, self.tracer = update_visibility(
@@ -797,13 +804,13 @@ class FusedStage2Step(_BoundedForward):
                         self._geo_done = torch.cuda.Event()
                     self._geo_done.record(geo_stream)
             handle_a = None
-            if self._side is None and self._bucket_a is not None:
+            if self._side is None and self._bucket_a is not None and not self._single_bucket:
                 # bucket A (SH gradient + flag) travels under the shading backward; issued from the stream that produced it
                 if geo_stream is not None:
                     with torch.cuda.stream(geo_stream):
-                        handle_a = self._allreduce_async(self._bucket_a)
+                        handle_a = self._allreduce_async(self._bucket_a, "A")
                 else:
-                    handle_a = self._allreduce_async(self._bucket_a)
+                    handle_a = self._allreduce_async(self._bucket_a, "A")
             self._early = False
             if early_adam and not self.dp and self._groups_a:
                 # Adam of the SH group on a side stream, behind the geometry backward that produces its gradient
@@ -926,8 +933,8 @@ class FusedStage2Step(_BoundedForward):
             gr = self.grads
             if geo_stream is not None:                                       # join the geometry backward (and nothing
                 main.wait_event(self._geo_done)       # queued behind it on that stream)
-                if self._side is not None:
-                    handle_a = self._allreduce_async(self._bucket_a)
+                if self._side is not None and not self._single_bucket:
+                    handle_a = self._allreduce_async(self._bucket_a, "A")
             # the environment texture's chain rule (softplus' + total-variation term; r3dg_stage2_env_backward) rides as six
             # extra workgroups of the activation chain rule's launch
             env_job = (He, We, self.env.data_ptr(), env_c.data_ptr(), d_env.data_ptr(), self.w["env_smooth"],
@@ -948,13 +955,17 @@ class FusedStage2Step(_BoundedForward):
                     gr["opacity"].data_ptr(), gr["normal"].data_ptr(), gr["base_color"].data_ptr(),
                     gr["roughness"].data_ptr(), *env_job), "stage2_activate_backward")
             self._handles = None
-            if self.dp:
-                handle_c = self._allreduce_async(self._bucket_c)
+            if self._single_bucket:
+                # (R3DG_DP_BUCKETS=1) the whole slab in one collective: everything is final on this stream here (no early Adam
+                # without bucket A's handle, so the rotation back of the coefficient gradient ran on this stream too)
+                self._handles = (None, self._allreduce_async(self._bucket_all, "ALL"), None)
+            elif self.dp:
+                handle_c = self._allreduce_async(self._bucket_c, "C")
                 if self._early:       # the incident-light gradient is finished by the rotation back, on the early stream
                     with torch.cuda.stream(self._early_stream):
-                        handle_b = self._allreduce_async(self._bucket_b)
+                        handle_b = self._allreduce_async(self._bucket_b, "B")
                 else:
-                    handle_b = self._allreduce_async(self._bucket_b)
+                    handle_b = self._allreduce_async(self._bucket_b, "B")
                 self._handles = (handle_a, handle_c, handle_b)
         self.viewspace_grad = dL_dmeans2D
         # a bounded forward returned its capacity as R (the backward's layout); the count itself goes to a pinned ring
@@ -964,9 +975,28 @@ class FusedStage2Step(_BoundedForward):
         self._N = N
         return self.last_outs
 
-    def _allreduce_async(self, flat):
+    def _allreduce_async(self, flat, name="?"):
         if not self.dp:
             return None
+        if self.measure_comm and self._probe_this_iteration():
+            # per-bucket attribution (bench.py): `ready` = the moment the issuing stream has the bucket final; `done` = the end of
+            # its collective, seen by a probe stream that carries nothing else (comm_table)
+            ready = torch.cuda.Event(enable_timing=True)
+            ready.record()
+            handle = self._allreduce_issue(flat)
+            probe = shared_stream(self.dev, "comm_probe")
+            done = torch.cuda.Event(enable_timing=True)
+            with torch.cuda.stream(probe):
+                handle.wait()
+                done.record()
+            self._bucket_events.append((self._iter, name, flat.numel() * 4, ready, done))
+            return handle
+        return self._allreduce_issue(flat)
+
+    def _probe_this_iteration(self):
+        return self.comm_probe_every > 0 and self._iter % self.comm_probe_every == 0
+
+    def _allreduce_issue(self, flat):
         gbs = _fake_comm_gbs()
         if gbs is None:
             return torch.distributed.all_reduce(flat, group=self.group, async_op=True)
@@ -986,7 +1016,7 @@ class FusedStage2Step(_BoundedForward):
         done.record(comm)
         return _FakeCommHandle(done)
 
-    def _wait(self, handle):
+    def _wait(self, handle, name="?"):
         """Make the current stream wait for a bucket's all-reduce; with `measure_comm` the wait is bracketed by events so that
         the time the stream actually stalls on it (the EXPOSED communication) can be read back (exposed_comm_ms)."""
         if not self.measure_comm:
@@ -996,19 +1026,65 @@ class FusedStage2Step(_BoundedForward):
         e0.record()
         handle.wait()
         e1.record()
-        self._comm_events.append((self._iter, e0, e1))
+        self._comm_events.append((self._iter, e0, e1, name))
 
-    def exposed_comm_ms(self):
+    def exposed_comm_ms(self, split=False):
         """Mean per iteration of the time the compute stream waited for gradient all-reduces since measure_comm was set
-        (synchronises).  The early bucket A is waited for on a side stream and is not part of it by construction."""
+        (synchronises).  The early bucket A is waited for on a side stream and is not part of it by construction.
+        `split`: -> (total, {bucket name: mean ms per iteration})."""
         if not self._comm_events:
+            return (None, {}) if split else None
+        torch.cuda.synchronize(self.dev)
+        per_iter, per_name = {}, {}
+        for it, e0, e1, name in self._comm_events:
+            ms = e0.elapsed_time(e1)
+            per_iter[it] = per_iter.get(it, 0.0) + ms
+            per_name[name] = per_name.get(name, 0.0) + ms
+        self._comm_events = []
+        n = max(1, len(per_iter))
+        total = sum(per_iter.values()) / n
+        return (total, {k: v / n for k, v in per_name.items()}) if split else total
+
+    def comm_table(self, world_assumed=None):
+        """Per-bucket attribution of the gradient all-reduces of the probed iterations since measure_comm was set (synchronises):
+        for each bucket its bytes, when it became final (`ready_us`, relative to the first bucket of its iteration), when its
+        collective ended (`done_us`), the collective's own time `collective_ms` = done - max(ready, previous bucket's done) -- the
+        buckets share ONE communication stream, so a bucket that became final while its predecessor was still travelling starts
+        when that one ends -- and the bus bandwidth that time amounts to for a ring all-reduce over the group's ranks,
+        2 (W-1)/W x bytes / collective_ms.  Means over the probed iterations; None when nothing was probed."""
+        if not self._bucket_events:
             return None
         torch.cuda.synchronize(self.dev)
-        per_iter = {}
-        for it, e0, e1 in self._comm_events:
-            per_iter[it] = per_iter.get(it, 0.0) + e0.elapsed_time(e1)
-        self._comm_events = []
-        return sum(per_iter.values()) / max(1, len(per_iter))
+        W = world_assumed or (int(os.environ.get("R3DG_DP_FAKE_COMM_WORLD", "8")) if _fake_comm_gbs() is not None else self.world)
+        by_iter = {}
+        for it, name, nbytes, ready, done in self._bucket_events:
+            by_iter.setdefault(it, []).append((name, nbytes, ready, done))
+        self._bucket_events = []
+        acc = {}
+        for it, rows in by_iter.items():
+            base = rows[0][2]
+            timed = sorted(((base.elapsed_time(ready), base.elapsed_time(done), name, nbytes) for name, nbytes, ready, done in rows),
+                           key=lambda r: r[1])
+            prev_done = None
+            for t_ready, t_done, name, nbytes in timed:
+                start = t_ready if prev_done is None else max(t_ready, prev_done)
+                a = acc.setdefault(name, dict(bytes=nbytes, n=0, ready=0.0, done=0.0, coll=0.0, queued=0.0))
+                a["n"] += 1
+                a["ready"] += t_ready
+                a["done"] += t_done
+                a["coll"] += max(t_done - start, 0.0)
+                a["queued"] += start - t_ready
+                prev_done = t_done
+        out = {}
+        for name, a in acc.items():
+            n = a["n"]
+            coll = a["coll"] / n
+            out[name] = dict(MB=round(a["bytes"] / 1e6, 2), ready_us=round(1e3 * a["ready"] / n, 1),
+                             done_us=round(1e3 * a["done"] / n, 1), queued_behind_previous_us=round(1e3 * a["queued"] / n, 1),
+                             collective_ms=round(coll, 4),
+                             bus_GBs=None if coll <= 0 or W < 2 else round(2.0 * (W - 1) / W * a["bytes"] / (coll * 1e-3) / 1e9, 1),
+                             alg_GBs=None if coll <= 0 else round(a["bytes"] / (coll * 1e-3) / 1e9, 1), probed_iterations=n)
+        return out
 
     def loss(self):
         """Loss value of the last forward_backward (a 0-d tensor; costs a few tiny kernels, so it is on demand)."""
@@ -1050,19 +1126,27 @@ class FusedStage2Step(_BoundedForward):
         # data parallel: update each bucket when its (sum) all-reduce has landed; 1/world is applied inside the kernel
         scale = 1.0 / self.world
         handle_a, handle_c, handle_b = self._handles
+        if self._single_bucket:
+            self.opt.begin_step()
+            self._wait(handle_c, "ALL")
+            self._skip_cur = self._snapshot_flag()
+            todo = self._groups_a + self._groups_c + self._groups_b
+            if todo:
+                self.opt.step_groups(todo, grads, scale, skip_flag=self._skip_cur)
+            return
         if self._early:                  # bucket A was waited for and applied on the side stream (forward_backward)
             torch.cuda.current_stream().wait_stream(self._early_stream)
             self._early = False
-            self._wait(handle_c)
+            self._wait(handle_c, "C")
         else:
             self.opt.begin_step()
             # the overflow flag rides in the first bucket that is reduced: A, or C when the geometry is frozen
-            self._wait(handle_a if handle_a is not None else handle_c)
+            self._wait(handle_a if handle_a is not None else handle_c, "A" if handle_a is not None else "C")
             self._skip_cur = self._snapshot_flag()      # > 0 on every rank when any rank dropped its view
             if handle_a is not None:
                 if self._groups_a:
                     self.opt.step_groups(self._groups_a, grads, scale, skip_flag=self._skip_cur)
-                self._wait(handle_c)
+                self._wait(handle_c, "C")
         if self._groups_c:
             self.opt.step_groups(self._groups_c, grads, scale, skip_flag=self._skip_cur)
         self._pending_b = (handle_b, grads, scale, self._skip_cur)
@@ -1080,7 +1164,7 @@ class FusedStage2Step(_BoundedForward):
         if self._pending_b is not None:
             handle_b, grads, scale, skip = self._pending_b
             self._pending_b = None
-            self._wait(handle_b)
+            self._wait(handle_b, "B")
             if self._groups_b:
                 self.opt.step_groups(self._groups_b, grads, scale, skip_flag=skip)
 

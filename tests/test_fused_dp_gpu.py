@@ -170,14 +170,100 @@ SMALL = ["--steps", "3", "--warmup", "1", "--points", "20000", "--res", "160", "
          "--relight-frames", "0", "--no-other-configs", "--repeats", "0"]
 
 
+def _with_relight(flags, frames="3", samples="32"):
+    out = list(flags)
+    out[out.index("--relight-frames") + 1] = frames
+    return out + ["--relight-samples", samples]
+
+
 def test_bench_gpus_2_runs_two_ranks_on_the_gpu():
     """The driver's literal `python bench.py --gpus 2 ...` (no launcher): two ranks, real kernels, one JSON line with
-    n_gpus 2.  The test box has ONE GPU, so the ranks share it through the gloo test backend (RCCL refuses two ranks on
-    one device); the RCCL variant below runs wherever two devices exist."""
-    r, doc = _bench(["--gpus", "2"] + SMALL, {"R3DG_DIST_BACKEND": "gloo"})
+    n_gpus 2 that carries the WHOLE metric -- train iters/s, the view-sharded relight FPS (frames rank::world, visibility traced
+    in halves + one all-gather) and the per-bucket attribution of the gradient all-reduces.  The test box has ONE GPU, so the
+    ranks share it through the gloo test backend (RCCL refuses two ranks on one device); the RCCL variant below runs wherever
+    two devices exist."""
+    r, doc = _bench(["--gpus", "2"] + _with_relight(SMALL), {"R3DG_DIST_BACKEND": "gloo"})
     assert r.returncode == 0, r.stderr[-3000:]
     assert doc["n_gpus"] == 2 and doc["value"] > 0 and "dp2" in doc["config"]["parallelism"]
     assert sum(1 for x in r.stdout.splitlines() if x.startswith("{")) == 1
+    assert doc["relight_fps"] > 0 and doc["relight"]["frames_per_rank"] == 3
+    assert doc["relight"]["per_rank_fps_min"] <= doc["relight"]["per_rank_fps_max"]
+    assert doc["dp_buckets"] == 3 and set(doc["comm_buckets"]) == {"A", "B", "C"}
+    for row in doc["comm_buckets"].values():
+        assert row["MB"] > 0 and row["collective_ms"] > 0 and row["bus_GBs"] > 0
+    assert set(doc["exposed_comm_ms_by_bucket"]) <= {"A", "B", "C"} and doc["exposed_comm_ms"] is not None
+
+
+def test_bench_gpus_2_one_bucket_knob():
+    """R3DG_DP_BUCKETS=1: the same launch with the whole gradient slab as ONE all-reduce (the A/B of message size against
+    overlap the first real multi-GPU run is meant to make)."""
+    r, doc = _bench(["--gpus", "2"] + SMALL, {"R3DG_DIST_BACKEND": "gloo", "R3DG_DP_BUCKETS": "1"})
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert doc["n_gpus"] == 2 and doc["value"] > 0 and doc["dp_buckets"] == 1 and set(doc["comm_buckets"]) == {"ALL"}
+
+
+def test_bench_config_presets_name_the_other_baseline_workloads():
+    """`--config dtu4` = BASELINE configs[3] (1600x1200, run_dtu.sh objective, sample_num 32), with later flags still
+    overriding: run small here, two ranks."""
+    flags = [f for f in SMALL]
+    for k in ("--res", "--sample-num"):
+        i = flags.index(k)
+        del flags[i:i + 2]
+    r, doc = _bench(["--gpus", "2", "--config", "dtu4", "--width", "160", "--height", "120"] + flags, {"R3DG_DIST_BACKEND": "gloo"})
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert doc["n_gpus"] == 2 and "160x120" in doc["config"]["workload"] and "run_syn4.sh" in doc["config"]["workload"]
+    assert "K=32" in doc["config"]["workload"]
+    assert set(doc["comm_buckets"]) == {"B", "C"}               # frozen geometry: no SH colour bucket
+
+
+def _relight_worker(rank, world, port, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    frames = _relight_frames(dev, range(rank, 6, world))
+    torch.save(frames, os.path.join(out_dir, "relight%d.pt" % rank))
+    dist.destroy_process_group()
+
+
+def _relight_frames(dev, which):
+    from relightable3dgaussian_amd import relight, synthetic as syn
+    from relightable3dgaussian_amd.bench_core import GaussianParams
+    scene = syn.make_scene(P=3001, seed=5, stage2=True, scale_log_mean=-3.2)
+    cams = [c.to(dev) for c in syn.orbit_cameras(6, width=112, height=96)]
+    params = GaussianParams(scene, dev, True)
+    envmap = (3.0 * torch.rand(32, 64, 3, generator=torch.Generator().manual_seed(7)) ** 2).to(dev)
+    r = relight.RelightRenderer(params, envmap, 24)           # (initialised group: ray bundles sharded, one all-gather)
+    bg = torch.zeros(3, device=dev)
+    out = {}
+    for f in which:
+        res = r.frame(cams[f], bg, outputs=("pbr_env", "render_env"))
+        out[f] = {k: res[k].cpu().clone() for k in ("pbr_env", "render_env", "render", "feature", "num_contrib")}
+        out[f]["num_rendered"] = int(res["num_rendered"])
+    out["visibility"] = r.visibility.cpu().clone()
+    return out
+
+
+def test_sharded_relight_frames_equal_single_rank_frames(tmp_path):
+    """BASELINE configs[4] "view-sharded render": rank r of W renders frames r, r + W, ... of the trajectory on its replica
+    (relighting.py:114-185 walks them in one process).  Two ranks on the one test GPU: every frame -- composites, the S=28
+    feature image, the contributor counts -- is bit-identical to the frame a single process renders, and the all-gathered
+    visibility equals the single-process trace."""
+    mp.spawn(_relight_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    single = _relight_frames(torch.device("cuda", 0), range(6))
+    seen = set()
+    for rank in range(2):
+        got = torch.load(os.path.join(tmp_path, "relight%d.pt" % rank))
+        assert torch.equal(got.pop("visibility"), single["visibility"])
+        for f, frame in got.items():
+            assert f % 2 == rank
+            seen.add(f)
+            assert frame["num_rendered"] == single[f]["num_rendered"]
+            for k in ("pbr_env", "render_env", "render", "feature", "num_contrib"):
+                assert torch.equal(frame[k], single[f][k]), "frame %d of rank %d: %s differs from the single-process frame" % (f, rank, k)
+    assert seen == set(range(6))
 
 
 @pytest.mark.skipif(torch.cuda.device_count() < 2, reason="RCCL needs one device per rank")

@@ -1082,6 +1082,53 @@ def test_fused_stage2_data_parallel_iteration_issues_its_buckets_from_the_stream
         ("wait C", ()),
     ], seq
     assert "frs.rotate" not in names
+    # ---- per-bucket attribution (bench.py: measure_comm): every probed bucket gets a `ready` event on the stream that issues it
+    # and a `done` event behind handle.wait() inside the PROBE stream's context; the waits of the compute stream carry the bucket's
+    # name; comm_table() turns the event times into collective time and bus bandwidth per bucket -----------------------------------
+    clock = [0.0]
+
+    class TimedEvent:
+        def __init__(self, *a, **k):
+            self.t = None
+
+        def record(self, s=None):
+            clock[0] += 0.25
+            self.t = clock[0]
+
+        def elapsed_time(self, other):
+            return other.t - self.t
+    monkeypatch.setattr(torch.cuda, "Event", TimedEvent)
+    monkeypatch.setattr(torch.cuda, "synchronize", lambda *a: None)
+    step.measure_comm, step.comm_probe_every = True, 1
+    del events[:]
+    step(cam, torch.ones(3), z(3, H, W))
+    step.flush()
+    probe = fused_step.shared_stream(step.dev, "comm_probe").cuda_stream
+    waits = [(n, d) for n, d in events if n.startswith("wait")]
+    assert ("wait A", (early, probe)) in waits and ("wait C", (probe,)) in waits and ("wait B", (early, probe)) in waits
+    total, by_bucket = step.exposed_comm_ms(split=True)
+    assert set(by_bucket) == {"B", "C"} and abs(total - sum(by_bucket.values())) < 1e-9       # (A is waited for on the side stream)
+    table = step.comm_table()
+    assert set(table) == {"A", "B", "C"}
+    assert table["A"]["MB"] == round(step._bucket_a.numel() * 4 / 1e6, 2) and table["A"]["ready_us"] == 0.0
+    for row in table.values():
+        assert row["collective_ms"] > 0 and row["bus_GBs"] is not None and row["done_us"] > row["ready_us"]
+    assert step.comm_table() is None                                    # read once
+    step.measure_comm = False
+    # ---- R3DG_DP_BUCKETS=1 (the A/B of message size against overlap): ONE all-reduce of the whole slab behind the backward, every
+    # group's Adam in one launch behind it, nothing deferred into the next iteration ------------------------------------------------
+    monkeypatch.setenv("R3DG_DP_BUCKETS", "1")
+    one = fused_step.FusedStage2Step(params, K, process_group=object())
+    assert one._single_bucket and one._bucket_all.numel() == one.grad_flat.numel()
+    buckets[one._bucket_all.data_ptr()] = "ALL"        # (same address as bucket A: the slab starts there)
+    calls_before = len(events)
+    for _ in range(2):
+        one(cam, torch.ones(3), z(3, H, W))
+    names = [e[0] for e in events[calls_before:]]
+    last = names[len(names) - 1 - names[::-1].index("r3dg_stage2_activate_with"):]
+    seq = [n for n in last if n.split()[0] in ("all_reduce", "wait", "r3dg_adam_step", "frs.backward")]
+    assert seq == ["frs.backward", "all_reduce ALL", "wait ALL", "r3dg_adam_step"], seq
+    assert one._pending_b is None
 
 
 def test_pytorch_rendering_equation_restatement_equals_the_oracle():
