@@ -116,3 +116,115 @@ def patch_model_step(model, reducer):
     model.step = step
     model._r3dg_unpatched_step = inner
     return model
+
+
+def allreduce_optimizer_grads(optimizer, process_group=None, average=True, bucket_bytes=64 << 20):
+    """Average (or sum) the gradients of every parameter an optimizer holds, in flat buckets of <= `bucket_bytes` launched
+    asynchronously one after the other and waited for together.  Looks the parameters up at call time, so it keeps working
+    when densification has replaced the optimizer's tensors (gaussian_model.py:718-750 cat_tensors_to_optimizer /
+    _prune_optimizer).  Parameters without a gradient are skipped -- every rank runs the same graph on its own view, so the
+    set is the same on all ranks (e.g. the iteration in which densify_and_prune rebuilt the parameters: train.py:166-176
+    runs it BEFORE gaussians.step(), and the fresh tensors have no gradient yet)."""
+    if not dist.is_initialized():
+        return 0
+    world = dist.get_world_size(process_group)
+    if world == 1:
+        return 0
+    grads = [p.grad for g in optimizer.param_groups for p in g["params"] if p.grad is not None]
+    buckets, cur, cur_bytes = [], [], 0
+    for g in grads:
+        nbytes = g.numel() * g.element_size()
+        if cur and (cur_bytes + nbytes > bucket_bytes or g.dtype != cur[0].dtype):
+            buckets.append(cur)
+            cur, cur_bytes = [], 0
+        cur.append(g)
+        cur_bytes += nbytes
+    if cur:
+        buckets.append(cur)
+    pending = []
+    for b in buckets:
+        flat = torch.cat([g.reshape(-1) for g in b])
+        pending.append((b, flat, dist.all_reduce(flat, group=process_group, async_op=True)))
+    for b, flat, handle in pending:
+        handle.wait()
+        if average:
+            flat.div_(world)
+        off = 0
+        for g in b:
+            g.copy_(flat[off:off + g.numel()].view_as(g))
+            off += g.numel()
+    return len(buckets)
+
+
+def patch_reference_classes(Scene, GaussianModel, DirectLightMap=None, rank=None, world=None, process_group=None):
+    """data parallelism over camera views for the reference's UNMODIFIED train.py, applied to its classes from
+    outside (tools/run_reference.py --dp N executes train.py afterwards; the file itself is not touched):
+      * Scene.getTrainCameras (scene/__init__.py:103-104) returns cameras rank, rank + W, ... of the list every rank shuffled
+        alike (random.seed(0), utils/general_utils.py:164; scene/__init__.py:81-83) -- train.py:114-119 then draws from ITS shard;
+      * GaussianModel.step / DirectLightMap.step (gaussian_model.py:495-497, direct_light_map.py:25-27) average the gradients
+        over the ranks in front of optimizer.step();
+      * GaussianModel.add_densification_stats (gaussian_model.py:931-937) adds the SUM over the ranks of what this iteration's
+        views contribute to xyz_gradient_accum, normal_gradient_accum, denom and weights_accum (each rank computes its increment
+        from its own view's gradients, one fused all-reduce of the four increments); max_radii2D, which train.py:164-165 updates
+        itself right behind that call, is max-reduced in front of its consumer densify_and_prune (:890-914) and in front of every
+        step().  All five are therefore the same on every rank at every iteration boundary: clone / split / prune decisions are
+        identical, torch.normal in densify_and_split (:816) draws the same numbers (same seed, same sequence of generator
+        calls), and a checkpoint written by rank 0 holds the statistics of ALL views, as a single-process run's does.
+    Returns the previous attributes (restore with `unpatch_reference_classes`)."""
+    rank = dist.get_rank(process_group) if rank is None else rank
+    world = dist.get_world_size(process_group) if world is None else world
+    saved = dict(Scene=(Scene, "getTrainCameras", Scene.getTrainCameras), step=(GaussianModel, "step", GaussianModel.step),
+                 densify=(GaussianModel, "densify_and_prune", GaussianModel.densify_and_prune),
+                 stats=(GaussianModel, "add_densification_stats", GaussianModel.add_densification_stats))
+    get_cameras, model_step, densify = Scene.getTrainCameras, GaussianModel.step, GaussianModel.densify_and_prune
+    add_stats = GaussianModel.add_densification_stats
+    live = dist.is_initialized() and dist.get_world_size(process_group) > 1
+    SUMS = ("xyz_gradient_accum", "normal_gradient_accum", "denom", "weights_accum")
+
+    def getTrainCameras(self, *a, **k):
+        return shard_views(get_cameras(self, *a, **k), rank, world)
+
+    def reduce_radii(self):
+        if live and getattr(self, "_r3dg_radii_dirty", False) and self.max_radii2D.numel():
+            dist.all_reduce(self.max_radii2D, op=dist.ReduceOp.MAX, group=process_group)
+        self._r3dg_radii_dirty = False
+
+    def add_densification_stats(self, *a, **k):
+        if not live:
+            return add_stats(self, *a, **k)
+        before = [getattr(self, n).clone() for n in SUMS]
+        out = add_stats(self, *a, **k)
+        delta = torch.cat([(getattr(self, n) - b).reshape(-1) for n, b in zip(SUMS, before)])
+        dist.all_reduce(delta, group=process_group)
+        off = 0
+        for n, b in zip(SUMS, before):
+            t = getattr(self, n)
+            t.copy_(b + delta[off:off + t.numel()].view_as(t))
+            off += t.numel()
+        self._r3dg_radii_dirty = True              # train.py:164-165 touches max_radii2D right behind this call
+        return out
+
+    def step(self):
+        reduce_radii(self)
+        allreduce_optimizer_grads(self.optimizer, process_group)
+        return model_step(self)
+
+    def densify_and_prune(self, *a, **k):
+        reduce_radii(self)
+        return densify(self, *a, **k)
+    Scene.getTrainCameras, GaussianModel.step, GaussianModel.densify_and_prune = getTrainCameras, step, densify_and_prune
+    GaussianModel.add_densification_stats = add_densification_stats
+    if DirectLightMap is not None:
+        light_step = DirectLightMap.step
+        saved["light"] = (DirectLightMap, "step", light_step)
+
+        def step_light(self):
+            allreduce_optimizer_grads(self.optimizer, process_group)
+            return light_step(self)
+        DirectLightMap.step = step_light
+    return saved
+
+
+def unpatch_reference_classes(saved):
+    for cls, name, fn in saved.values():
+        setattr(cls, name, fn)

@@ -1,5 +1,5 @@
 """TEST INFRASTRUCTURE (never imported by the product): lets the reference's unmodified Python run in THIS container, which
-has no GPU -- behind `tools/run_reference.py --cpu-oracle` and tests/test_reference_scripts_cpu.py.
+has no GPU -- behind `tools/run_reference.py the CPU-oracle launcher tests/run_reference_cpu.py` and tests/test_reference_scripts_cpu.py.
 
 * the three extension modules the reference imports (`r3dg_rasterization._C`, `bvh_tracing._C`, `simple_knn._C`) are backed
   by the CPU oracle (oracle/rasterizer_oracle.c, bvh_oracle.c, knn_oracle.c: restatements pinned to the real reference

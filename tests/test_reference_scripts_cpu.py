@@ -1,6 +1,6 @@
 """the reference's OWN `train.py`, byte for byte, run end to end across this repo's extension
 boundary -- in this container, where /root/reference exists and no GPU does, so the three extension modules are backed by
-the CPU oracle (tools/run_reference.py --cpu-oracle; tests/reference_cpu_backend.py).  What this proves is the seam, not
+the CPU oracle (tests/run_reference_cpu.py = tools/run_reference.py + tests/reference_cpu_backend.py).  What this proves is the seam, not
 the kernels (those are pinned on the GPU by tests/test_reference_gpu.py and test_reference_pipeline_gpu.py): the module
 names, call signatures, tuple layouts, opaque state buffers, dtype / shape conventions and the data formats either side
 (Blender-format dataset written by synthetic.write_blender_dataset, `points3d.ply`, `chkpnt*.pth`) are what an unmodified
@@ -54,9 +54,11 @@ def _write_dataset(root, n_views=6, res=40, P=900):
     return len(cams)
 
 
-def _run(args, timeout=900):
-    cmd = [sys.executable, os.path.join(ROOT, "tools", "run_reference.py"), "--reference", REF, "--cpu-oracle", "--"] + args
-    env = dict(os.environ, OMP_NUM_THREADS="4", PYTHONPATH=ROOT)
+def _run(args, timeout=900, launcher=()):
+    cmd = [sys.executable, os.path.join(ROOT, "tests", "run_reference_cpu.py"), "--reference", REF] + list(launcher) + ["--"] + args
+    env = dict(os.environ, OMP_NUM_THREADS="4" if not launcher else "2", PYTHONPATH=ROOT)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "R3DG_DP_RANK"):
+        env.pop(k, None)
     return subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, env=env, cwd=ROOT, stdin=subprocess.DEVNULL)
 
 
@@ -142,3 +144,107 @@ def test_reference_train_py_and_relighting_py_run_unchanged(tmp_path):
         for i in range(3):
             img = np.asarray(Image.open(os.path.join(cap, kind, "frame_%d.png" % i)))
             assert img.shape[:2] == (32, 40) and img.std() > 0, (kind, i)
+
+
+def _flat_tensors(obj, prefix=""):
+    """(name, tensor) of everything tensor-like inside a captured checkpoint (tuples, lists, dicts, Parameters)."""
+    if isinstance(obj, torch.Tensor):
+        yield prefix, obj.detach()
+    elif isinstance(obj, dict):
+        for k in sorted(obj, key=str):
+            yield from _flat_tensors(obj[k], "%s.%s" % (prefix, k))
+    elif isinstance(obj, (list, tuple)):
+        for i, v in enumerate(obj):
+            yield from _flat_tensors(v, "%s[%d]" % (prefix, i))
+
+
+def test_reference_train_py_data_parallel_keeps_replicas_identical(tmp_path):
+    """`run_reference.py --dp 2` around the reference's unmodified train.py -- two processes (gloo here, RCCL on
+    a GPU node), cameras rank::2 of the identically shuffled list, gradients averaged in front of GaussianModel.step /
+    DirectLightMap.step, the densification statistics summed over the ranks inside add_densification_stats, file outputs on rank 0 only.
+    Stage 1 across three densifications and an opacity reset, then stage 2 from its checkpoint: the replicas' checkpoints
+    (parameters, Adam moments, statistics) are bit-identical and the model directory holds ONE set of files."""
+    data, out1, out2, rep1, rep2 = (os.path.join(tmp_path, d) for d in ("data", "stage1", "stage2", "replicas1", "replicas2"))
+    os.makedirs(data)
+    _write_dataset(data)
+    dp = ["--dp", "2", "--dp-backend", "gloo", "--dp-share-device", "--quiet-shims"]
+    r = _run(["train.py", "-s", data, "-m", out1, "--data_device", "cpu", "--lambda_normal_render_depth", "0.01",
+              "--lambda_normal_smooth", "0.01", "--lambda_mask_entropy", "0.1", "--lambda_depth_var", "1e-2",
+              "--iterations", "14", "--densify_from_iter", "3", "--densification_interval", "4",
+              "--opacity_reset_interval", "9", "--test_interval", "7", "--checkpoint_interval", "14", "--save_interval", "14",
+              "--save_training_vis", "--save_training_vis_iteration", "7"], launcher=dp + ["--dp-replica-dir", rep1])
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    assert "rank 0 of 2: cameras 0::2" in r.stdout and "Training complete." in r.stdout
+    ck1 = os.path.join(out1, "chkpnt14.pth")
+    other1 = os.path.join(rep1, "rank1", "chkpnt14.pth")
+    assert os.path.isfile(ck1) and os.path.isfile(other1)
+    a, b = torch.load(ck1, weights_only=False), torch.load(other1, weights_only=False)
+    assert a[1] == b[1] == 14
+    ta, tb = dict(_flat_tensors(a[0])), dict(_flat_tensors(b[0]))
+    assert ta.keys() == tb.keys() and len(ta) > 20
+    for k in ta:
+        assert ta[k].shape == tb[k].shape and torch.equal(ta[k], tb[k]), "replicas diverged in stage 1: " + k
+    rows = [t.shape[0] for k, t in ta.items() if t.dim() == 2 and t.shape[1] == 3][0]
+    assert rows != 600, "densify_and_prune never changed the row count"
+    # the other rank left nothing in the model directory: one checkpoint, one point cloud, one visualisation per saved iteration
+    listing = sorted(os.path.relpath(os.path.join(d, f), out1) for d, _, fs in os.walk(out1) for f in fs)
+    assert listing.count("chkpnt14.pth") == 1 and not any("rank" in f for f in listing), listing
+    assert os.path.isfile(os.path.join(out1, "point_cloud", "iteration_14", "point_cloud.ply"))
+    assert "Training complete." in open(os.path.join(rep1, "rank1.log")).read()
+    # a data-parallel run is a different optimisation path than one process (two views per step), not a reordering of it:
+    # the two ranks really saw different cameras
+    assert "cameras 1::2" in open(os.path.join(rep1, "rank1.log")).read()
+    # ---- stage 2 from the stage-1 checkpoint: environment light (DirectLightMap.step) included -----------------------------
+    r = _run(["train.py", "-s", data, "-m", out2, "-c", ck1, "--data_device", "cpu", "-t", "neilf", "--sample_num", "16",
+              "--position_lr_init", "0.000016", "--position_lr_final", "0.00000016", "--normal_lr", "0.001", "--sh_lr",
+              "0.00025", "--opacity_lr", "0.005", "--scaling_lr", "0.0005", "--rotation_lr", "0.0001", "--iterations", "18",
+              "--lambda_base_color_smooth", "0", "--lambda_roughness_smooth", "0", "--lambda_light_smooth", "0",
+              "--lambda_light", "0.01", "--lambda_env_smooth", "0.01", "--test_interval", "1000", "--checkpoint_interval",
+              "18", "--save_interval", "18", "--densify_until_iter", "10"], launcher=dp + ["--dp-replica-dir", rep2])
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    for name in ("chkpnt18.pth", "env_light_chkpnt18.pth"):
+        a = torch.load(os.path.join(out2, name), weights_only=False)
+        b = torch.load(os.path.join(rep2, "rank1", name), weights_only=False)
+        ta, tb = dict(_flat_tensors(a[0])), dict(_flat_tensors(b[0]))
+        assert ta.keys() == tb.keys() and ta
+        for k in ta:
+            assert torch.equal(ta[k], tb[k]), "replicas diverged in stage 2 (%s): %s" % (name, k)
+    env = torch.load(os.path.join(out2, "env_light_chkpnt18.pth"), weights_only=False)[0][0]
+    assert float(env.detach().std()) > 0
+
+
+def test_data_parallel_reference_patches_on_stand_in_classes():
+    """relightable3dgaussian_amd.dp.patch_reference_classes on stand-ins with the reference's attribute names, one process
+    (no group: the collectives are skipped): the camera shard, and that step() / densify_and_prune still reach the originals."""
+    from relightable3dgaussian_amd import dp
+    calls = []
+
+    class Scene:
+        def getTrainCameras(self, scale=1.0):
+            return list(range(10))
+
+    class Model:
+        def __init__(self):
+            self.optimizer = torch.optim.Adam([torch.nn.Parameter(torch.zeros(3))], lr=0.1)
+            self.xyz_gradient_accum = self.normal_gradient_accum = self.denom = self.weights_accum = torch.zeros(4, 1)
+            self.max_radii2D = torch.zeros(4)
+
+        def step(self):
+            calls.append("step")
+
+        def densify_and_prune(self, a, b=2):
+            calls.append(("densify", a, b))
+
+        def add_densification_stats(self, v, f, w):
+            calls.append("stats")
+
+    class Light(Model):
+        def step(self):
+            calls.append("light")
+    saved = dp.patch_reference_classes(Scene, Model, Light, rank=1, world=4)
+    assert Scene().getTrainCameras() == [1, 5, 9] and Scene().getTrainCameras(2.0) == [1, 5, 9]
+    m, l = Model(), Light()
+    m.step(), l.step(), m.densify_and_prune(7, b=3), m.add_densification_stats(None, None, None)
+    assert calls == ["step", "light", ("densify", 7, 3), "stats"]
+    dp.unpatch_reference_classes(saved)
+    assert Scene().getTrainCameras() == list(range(10))

@@ -1,5 +1,5 @@
 #!/usr/bin/env python
-"""Evidence run for SURVEY.md 8(f) n4 (this container only: needs /root/reference; no GPU here, so `--cpu-oracle`):
+"""Evidence run for SURVEY.md 8(f) n4 (this container only: needs /root/reference; no GPU here, so the tests' CPU-oracle launcher tests/run_reference_cpu.py):
 the reference's unmodified train.py, stage 1 then stage 2 from its checkpoint, on a small synthetic Blender-format scene, then
 its unmodified relighting.py on a composition of the trained result.
 
@@ -24,7 +24,7 @@ def main():
     data, s1, s2 = (os.path.join(tmp, d) for d in ("data", "stage1", "stage2"))
     os.makedirs(data)
     n = t._write_dataset(data, n_views=8, res=48, P=1200)
-    print("reference: %s  train.py sha256 %s (run as is through tools/run_reference.py --cpu-oracle)" % (
+    print("reference: %s  train.py sha256 %s (run as is through tests/run_reference_cpu.py)" % (
         REF, hashlib.sha256(open(os.path.join(REF, "train.py"), "rb").read()).hexdigest()[:16]))
     print("dataset: %d train views 48x48 rendered from a 1200-Gaussian teacher by the CPU oracle, points3d.ply with 600 points" % n)
     runs = [
@@ -45,7 +45,7 @@ def main():
     for title, args in runs:
         t0 = time.time()
         r = t._run(args, timeout=3000)
-        print("\n== %s ==\n$ python tools/run_reference.py --reference %s --cpu-oracle -- %s" % (
+        print("\n== %s ==\n$ python tests/run_reference_cpu.py --reference %s -- %s" % (
             title, REF, " ".join(a.replace(tmp, "$TMP") for a in args)))
         print("exit code %d, %.1f s" % (r.returncode, time.time() - t0))
         for line in r.stdout.splitlines():
@@ -84,7 +84,7 @@ def main():
     t0 = time.time()
     r = t._run(args, timeout=3000)
     print("\n== relighting.py (relighting.py:102-170): composition of two objects from the point_cloud.ply train.py wrote, "
-          "envmap3.png, a light that turns with the frames ==\n$ python tools/run_reference.py --reference %s --cpu-oracle -- %s"
+          "envmap3.png, a light that turns with the frames ==\n$ python tests/run_reference_cpu.py --reference %s -- %s"
           % (REF, " ".join(a.replace(tmp, "$TMP") for a in args)))
     print("exit code %d, %.1f s" % (r.returncode, time.time() - t0))
     for line in r.stdout.splitlines():
