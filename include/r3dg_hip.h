@@ -40,6 +40,11 @@ extern "C" {
 typedef void* (*r3dg_alloc_fn)(void* user, size_t bytes);
 
 const char* r3dg_last_error(void);
+/* Frees every scratch buffer the library holds (grow-only buffers per (device, stream): the tile backward's gradient records,
+ * the shading kernels' records, the trace kernel's ray records; raw hipMalloc, outside any caching allocator).  Synchronises the
+ * device.  Call it after a stream the library ran on has been destroyed, or to hand the memory back between phases; the next call
+ * that needs a buffer allocates it again.  Not for use during stream capture (hipMalloc / hipFree). */
+int r3dg_release_scratch(void);
 int r3dg_version(void);
 
 /* Limits (reference: forward F[33] forward.cu:312, backward 24 backward.cu:449). Ours: both 36. */
@@ -153,14 +158,23 @@ int r3dg_rasterize_backward(void* stream, int P, int S, int D, int M, int R, con
                             float* d_dL_dmean3D, float* d_dL_dcov3D, float* d_dL_dsh, float* d_dL_dscale,
                             float* d_dL_drot, int backward_geometry, int debug);
 
-/* Same as r3dg_rasterize_backward, but the per-Gaussian geometry backward (K12+K13: d_dL_dmean3D, d_dL_dcov3D, d_dL_dsh,
- * d_dL_dscale, d_dL_drot) is launched on `geometry_stream`, ordered after the tile kernel by an event, so work that
- * only needs the tile kernel's outputs (d_dL_dfeature, ...) can follow on `stream` concurrently.  The caller joins the
- * two streams before reading the geometry outputs.  geometry_stream == stream is exactly r3dg_rasterize_backward.
+/* Same as r3dg_rasterize_backward, but the per-Gaussian geometry backward (K12+K13) is launched on `geometry_stream`, ordered
+ * after the tile kernel by an event, so work that only needs the tile pass's FINAL outputs can follow on `stream` concurrently.
+ * geometry_stream == stream is exactly r3dg_rasterize_backward.
+ *   final on `stream` (behind the tile kernel + its scatter pass):  d_dL_dfeature, d_dL_dopacity, d_dL_dcolor;
+ *   valid ONLY AFTER JOINING geometry_stream:  d_dL_dmean3D, d_dL_dcov3D, d_dL_dsh, d_dL_dscale, d_dL_drot -- AND d_dL_dmean2D
+ *     and d_dL_dconic: since round 5 the tile pass leaves RAW MOMENTS in those two (S_x, S_y / the second moments) and the
+ *     per-Gaussian geometry kernel turns them into the viewspace gradient IN PLACE (rasterizer_preprocess_bwd.hip).  A consumer on
+ *     `stream` that has not joined (e.g. densification statistics reading dL_dmeans2D) would read raw moments or race with that
+ *     rewrite.  r3dg_stream_wait_stream(stream, geometry_stream) is the join.
  * active_features (HOST array of n_active_features distinct channel indices, or n_active_features < 0 for "all"): the
  * caller's promise that every OTHER channel of d_dL_dpix_f is zero everywhere; those channels are then not carried
- * through the tile kernel at all (their d_dL_dfeature columns keep the caller's zero fill).  Same results, less work:
- * a loss normally reads a few of the S feature maps. */
+ * through the tile kernel at all and the scatter pass WRITES ZEROS into their d_dL_dfeature columns (every output is fully
+ * written: no zero fill by the caller is needed or relied upon).  Same results, less work: a loss normally reads a few of
+ * the S feature maps.
+ * Scratch: the tile pass adds into one gradient record per Gaussian, P x (16 or, with all S = 16 channels live, 32) floats of
+ * LIBRARY scratch per (device, stream) that ever ran a backward -- 64 / 128 bytes per Gaussian (2M Gaussians: 128 / 256 MB),
+ * grown geometrically and kept until r3dg_release_scratch(). */
 int r3dg_rasterize_backward_split(void* stream, void* geometry_stream, int P, int S, int D, int M, int R,
                                   const float* d_background, int width, int height, const float* d_means3D,
                                   const float* d_shs, const float* d_features, const float* d_colors_precomp,

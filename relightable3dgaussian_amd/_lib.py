@@ -19,6 +19,7 @@ _p = C.c_void_p
 _SIGNATURES = {
     "r3dg_last_error": (C.c_char_p, []),
     "r3dg_version": (_i, []),
+    "r3dg_release_scratch": (_i, []),
     "r3dg_max_features_forward": (_i, []),
     "r3dg_max_features_backward": (_i, []),
     "r3dg_bounded_forward_supported": (_i, [_i, _i]),

@@ -368,27 +368,46 @@ static int invalid(const std::string& msg)
     return R3DG_EINVAL;
 }
 
+namespace {
+struct ScratchBuf { void* p = nullptr; size_t cap = 0; };
+std::mutex g_scratch_mu;
+std::map<std::tuple<int, hipStream_t, int>, ScratchBuf> g_scratch;
+}
+
 void* stream_scratch(hipStream_t stream, int slot, size_t bytes)
 {
-    struct Buf { void* p = nullptr; size_t cap = 0; };
-    static std::mutex mu;
-    static std::map<std::tuple<int, hipStream_t, int>, Buf> bufs;
     int dev = 0;
     R3DG_HIP(hipGetDevice(&dev));
-    std::lock_guard<std::mutex> lk(mu);
-    Buf& b = bufs[std::make_tuple(dev, stream, slot)];
+    std::lock_guard<std::mutex> lk(g_scratch_mu);
+    ScratchBuf& b = g_scratch[std::make_tuple(dev, stream, slot)];
     if (b.cap < bytes) {
+        // geometric growth: a scene that densifies outgrows its buffer O(log) times, not at every 12 % (each growth is a stream
+        // synchronise + hipFree, a device-wide wait)
+        const size_t want = b.p == nullptr ? bytes + bytes / 8 + 4096 : std::max(bytes + 4096, 2 * b.cap);
         if (b.p != nullptr) {
             R3DG_HIP(hipStreamSynchronize(stream));        // only this stream ever used the old buffer
             R3DG_HIP(hipFree(b.p));
             b.p = nullptr;
             b.cap = 0;
         }
-        const size_t want = bytes + bytes / 8 + 4096;
         R3DG_HIP(hipMalloc(&b.p, want));
         b.cap = want;
     }
     return b.p;
+}
+
+void release_gradient_records();        // rasterizer_render_bwd.hip
+
+static void release_all_scratch()
+{
+    R3DG_HIP(hipDeviceSynchronize());
+    {
+        std::lock_guard<std::mutex> lk(g_scratch_mu);
+        for (auto& kv : g_scratch)
+            if (kv.second.p != nullptr) (void)hipFree(kv.second.p);
+        g_scratch.clear();
+    }
+    release_gradient_records();
 }
 
 }  // namespace r3dg
@@ -398,6 +417,13 @@ using namespace r3dg;
 extern "C" {
 
 const char* r3dg_last_error(void) { return g_last_error.c_str(); }
+int r3dg_release_scratch(void)
+{
+    return guarded([&]() {
+        release_all_scratch();
+        return R3DG_OK;
+    });
+}
 int r3dg_version(void) { return 100; }
 int r3dg_max_features_forward(void) { return R3DG_MAX_S_FWD; }
 int r3dg_max_features_backward(void) { return R3DG_MAX_S_BWD; }

@@ -679,12 +679,7 @@ void launch_tile_binning(hipStream_t s, int P, int T, const float* means2D, cons
     const int per_block = iters * BIN_THREADS;
     const int nb = (P + per_block - 1) / per_block;
     const size_t smem = (size_t)T * 4;
-    static bool attr = false;
-    if (!attr) {
-        R3DG_HIP(hipFuncSetAttribute((const void*)tile_count_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, BIN_MAX_TILES * 4));
-        R3DG_HIP(hipFuncSetAttribute((const void*)tile_emit_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, BIN_MAX_TILES * 4));
-        attr = true;
-    }
+    // (T <= BIN_MAX_TILES: at most 64 KB of dynamic LDS, what every launch may ask for -- no function attribute needed)
     tile_count_kernel<<<nb, BIN_THREADS, smem, s>>>(P, T, iters, (const float2*)means2D, radii, gx, gy, tile_counts);
     tile_scan_kernel<<<1, 1024, 0, s>>>(T, tile_counts, (uint2*)ranges, cursor, total, capacity, overflow_flag,
                                         overflow_count, fused ? (P + 255) / 256 : 0, block_offsets);

@@ -446,23 +446,28 @@ render_backward_scatter_kernel(int P, int S, int NF, ChannelList chan_list, floa
 // The records: library scratch per (device, stream), zero whenever no backward is in flight on that stream -- the scatter kernel
 // zeroes what the tile kernel may have written.  `dirty` guards the invariant on the host: set before the tile kernel is
 // enqueued, cleared once the scatter kernel is; a call that finds it set (an enqueue in between failed) clears the buffer itself.
+namespace {
+struct RecordState { float* p = nullptr; size_t cap = 0; bool dirty = false; };
+std::mutex g_records_mu;
+std::map<std::pair<int, hipStream_t>, RecordState> g_records;
+}
+
 static float* gradient_records(hipStream_t s, size_t floats, bool** dirty_out)
 {
-    struct State { float* p = nullptr; size_t cap = 0; bool dirty = false; };
-    static std::mutex mu;
-    static std::map<std::pair<int, hipStream_t>, State> states;
     int dev = 0;
     R3DG_HIP(hipGetDevice(&dev));
-    std::lock_guard<std::mutex> lk(mu);
-    State& st = states[std::make_pair(dev, s)];
+    std::lock_guard<std::mutex> lk(g_records_mu);
+    RecordState& st = g_records[std::make_pair(dev, s)];
     if (st.cap < floats) {
+        // geometric growth (first allocation: + 12 %): each growth costs a stream synchronise, a hipFree (device-wide wait),
+        // a hipMalloc and a full memset -- a densifying scene must not pay that at every step of its growth
+        const size_t want = st.p == nullptr ? floats + floats / 8 + 1024 : std::max(floats + 1024, 2 * st.cap);
         if (st.p != nullptr) {
             R3DG_HIP(hipStreamSynchronize(s));
             R3DG_HIP(hipFree(st.p));
             st.p = nullptr;
             st.cap = 0;
         }
-        const size_t want = floats + floats / 8 + 1024;
         R3DG_HIP(hipMalloc((void**)&st.p, want * sizeof(float)));
         st.cap = want;
         st.dirty = true;
@@ -473,6 +478,15 @@ static float* gradient_records(hipStream_t s, size_t floats, bool** dirty_out)
     }
     *dirty_out = &st.dirty;
     return st.p;
+}
+
+// r3dg_release_scratch (capi.hip): the device is idle when this runs
+void release_gradient_records()
+{
+    std::lock_guard<std::mutex> lk(g_records_mu);
+    for (auto& kv : g_records)
+        if (kv.second.p != nullptr) (void)hipFree(kv.second.p);
+    g_records.clear();
 }
 
 extern int g_cull;

@@ -1347,11 +1347,7 @@ void launch_shade_frs_incident_chain(hipStream_t s, int P, const float* ray_norm
     // 49 KB of LDS per workgroup = three per CU: measured against two (56 KB) and one (81 KB) per CU, which are gentler on the
     // activation / projection kernels running beside it but make the chain the longer path: 805 / 797 / 771 it/s
     const size_t lds = 4 * 64 * FRS_CHAIN_LD * sizeof(float);
-    static bool attr = false;
-    if (!attr) {
-        R3DG_HIP(hipFuncSetAttribute((const void*)frs_incident_chain_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr = true;
-    }
+    // (49 KB of dynamic LDS: under the 64 KB every launch may ask for, so no per-device function attribute is needed)
     frs_incident_chain_kernel<<<(P + 255) / 256, 256, lds, s>>>(P, ray_normals, valid, dcp, d_inc, incidents, exp_avg, exp_avg_sq,
                                                                 cprime, a, skip_flag);
     check_launch(s, false, "frs_incident_chain_kernel");

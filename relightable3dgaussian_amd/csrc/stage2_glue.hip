@@ -750,7 +750,7 @@ __device__ __forceinline__ float smooth_chain(bool base, bool rough, bool light,
 // `old_normal`: the three values the normal maps' gradient already holds at this pixel when the caller has read them ahead of
 // time (the streamed kernel requests them before its nine taps: a load used straight away costs a wave its full latency), else NULL
 __device__ __forceinline__ void smooth_store(bool base, bool rough, bool light, int accumulate_normal, const float (&gf)[10],
-                                             size_t HW, size_t i, float* __restrict__ dL_dfeature,
+                                             size_t HW, size_t i, float* dL_dfeature,
                                              const float* old_normal = nullptr)
 {
 #pragma clang fp contract(off)
@@ -977,18 +977,13 @@ __global__ void __launch_bounds__(256, 2)      // (two waves per SIMD: all three
 s2_smooth_stream_kernel(int W, int H, int rows, int strips_x, const float* __restrict__ opacity,
                         const float* __restrict__ feature, const int* __restrict__ n_contrib, const float* __restrict__ gt,
                         const float* __restrict__ image_mask, float w_base, float w_rough, float w_light, int accumulate_normal,
-                        float* __restrict__ dL_dopacity, float* __restrict__ dL_dfeature, float* __restrict__ sums3,
-                        const float* __restrict__ dL_dopacity_old, const float* __restrict__ dL_dfeature_old)
+                        float* dL_dopacity, float* dL_dfeature, float* __restrict__ sums3)
 {
-    // dL_dopacity_old / dL_dfeature_old are the SAME buffers as dL_dopacity / dL_dfeature, passed a second time for the values the
-    // two read-modify-write outputs already hold.  Every element is read (through the _old name) before it is written (through the
-    // other), by the one lane that owns the pixel, and never read again; telling the compiler that the two names do not alias only
-    // takes away the wait it otherwise puts between one row's stores and the next row's loads from the same array (different rows:
-    // it cannot know) -- a full memory round trip per row with two waves per SIMD to cover it.  (Strictly, writing through one
-    // restrict-qualified name what is read through another is outside the language's guarantees; the guard is
-    // tests/test_fused_step_gpu.py::test_fused_smoothness_kernel_equals_the_three_pass_formulation, which compares this kernel with
-    // accumulate_normal = 1 BIT FOR BIT against the three-pass kernels that use plain read-modify-write: a compiler that moved a
-    // store in front of its own element's load fails it.)
+    // dL_dopacity and dL_dfeature (planes 5-7 with accumulate_normal) are READ-MODIFY-WRITE: every element is read before it is
+    // written, by the one lane that owns the pixel, and never read again.  They carry no __restrict__ (rounds 4-5 passed each buffer
+    // a second time under a second restrict-qualified name for the reads -- outside the language's guarantees): the
+    // compiler must now keep a row's stores in front of the next row's loads from the same array, which is the order the source
+    // has them in anyway -- the old values are requested at the top of part (3), a full row of arithmetic ahead of their use.
     const int lane = threadIdx.x & 63;
     const int wid = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int strip = wid % strips_x, y0 = (wid / strips_x) * rows;
@@ -1112,11 +1107,11 @@ s2_smooth_stream_kernel(int W, int H, int rows, int strips_x, const float* __res
                                                                             gt, image_mask);
             // ... and what the two read-modify-write outputs hold there (requested now, used after the nine taps: read where
             // they are used, these loads were 44 % of the wave-cycles -- `s_waitcnt` with two waves per SIMD to cover it)
-            const float old_dop = dL_dopacity_old[(size_t)py * W + xc];
+            const float old_dop = dL_dopacity[(size_t)py * W + xc];
             float old_n[3] = {0.f, 0.f, 0.f};
             if (LIGHT && accumulate_normal) {
 #pragma unroll
-                for (int c = 0; c < 3; c++) old_n[c] = dL_dfeature_old[(size_t)(5 + c) * HW + (size_t)py * W + xc];
+                for (int c = 0; c < 3; c++) old_n[c] = dL_dfeature[(size_t)(5 + c) * HW + (size_t)py * W + xc];
             }
             float d[10];
 #pragma unroll
@@ -1423,7 +1418,7 @@ static void launch_s2_smooth_stream_t(hipStream_t s, int W, int H, int rows, con
     const int waves = strips_x * strips_y;
     s2_smooth_stream_kernel<BASE, ROUGH, LIGHT><<<(waves + 3) / 4, 256, 0, s>>>(
         W, H, rows, strips_x, opacity, feature, n_contrib, gt, image_mask, w_base, w_rough, w_light, accumulate_normal,
-        dL_dopacity, dL_dfeature, sums3, dL_dopacity, dL_dfeature);
+        dL_dopacity, dL_dfeature, sums3);
 }
 
 void launch_s2_smooth_fused(hipStream_t s, int W, int H, const float* opacity, const float* feature, const int* n_contrib,
