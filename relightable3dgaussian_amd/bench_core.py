@@ -947,6 +947,33 @@ def compact(result):
     return line
 
 
+def flush_c_stdio():
+    """Push out what C libraries hold in their stdio buffers.  RCCL prints its version banner to stdout through C stdio when the
+    communicator is created; with stdout a pipe that text sits in a buffer until the process exits -- i.e. it would land BEHIND the
+    JSON line, and a driver that parses the last stdout line of `bench.py --gpus N` would find "Librccl path : ..." there
+    (measured on the one-rank RCCL group, round 6)."""
+    import ctypes
+    import sys
+    try:
+        ctypes.CDLL(None).fflush(None)
+    except Exception:
+        pass
+    sys.stdout.flush()
+
+
+def close_stdout():
+    """Nothing this process writes to fd 1 from here on reaches the terminal / pipe (ranks > 0 after their part is done; rank 0
+    behind its JSON line): library teardown messages cannot follow the ONE line the contract promises."""
+    import sys
+    try:
+        flush_c_stdio()
+        fd = os.open(os.devnull, os.O_WRONLY)
+        os.dup2(fd, 1)
+        os.close(fd)
+    except OSError:
+        pass
+
+
 def emit(result):
     """rank 0: the full document to gpurun_out/bench_full.json and stderr, then the compact line -- the ONE JSON line on stdout."""
     full = json.dumps(_finite_json(result), allow_nan=False)
@@ -961,7 +988,9 @@ def emit(result):
     sys.stdout.flush()
     sys.stderr.write("bench_full: " + full + "\n")          # (stderr: stdout carries exactly ONE JSON line, the contract's)
     sys.stderr.flush()
+    flush_c_stdio()                                          # RCCL's buffered banner first, so that the JSON line is the LAST one
     print(compact(result), flush=True)
+    close_stdout()
 
 
 def _plumbing_only(args, world, rank, backend):
@@ -1327,6 +1356,14 @@ def run(args):
             except Exception as e:  # the oracle is only a reported baseline; never fail the bench on it
                 result["cpu_baseline"] = {"value": None, "unit": "views/s (rasterize forward)", "cores": None, "kind": "port",
                                           "sample": "failed: %r" % (e,)}
+    if dp:
+        # every rank's buffered library output (RCCL's banner) is out before rank 0 prints the line; the other ranks then close
+        # their stdout for good
+        flush_c_stdio()
+        dist.barrier()
+        if rank != 0:
+            close_stdout()
+    if rank == 0:
         emit(result)
     if dp:
         dist.destroy_process_group()

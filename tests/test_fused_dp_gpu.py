@@ -479,3 +479,7 @@ def test_bench_single_rank_over_rccl():
     r, doc = _bench(["--gpus", "1"] + SMALL, {"R3DG_DIST_BACKEND": "nccl", "R3DG_DP_SINGLE_RANK": "1"})
     assert r.returncode == 0, r.stderr[-3000:]
     assert doc["n_gpus"] == 1 and doc["value"] > 0
+    # RCCL prints its version banner to stdout through C stdio; captured (a pipe, as under the driver) it used to be flushed at
+    # exit, BEHIND the JSON line: the line must be the last thing on stdout
+    assert r.stdout.strip().splitlines()[-1].startswith("{"), r.stdout[-400:]
+    assert set(doc["comm_buckets"]) == {"A", "B", "C"} and doc["comm_buckets"]["A"]["collective_ms"] > 0

@@ -24,15 +24,18 @@ def _pbr_image(outs, bg):
     return rgb_to_srgb(feat[2:5] * opacity + (1 - opacity) * bg[:, None, None])
 
 
-# The second case is the HEADLINE size (BASELINE.json: 300 000 Gaussians, 800x800, sample_num 64; bench.py's scene scale): 16
-# views, 1000 iterations, the bounded forward on (dropped views are reported).  The reference pipeline takes ~2 GPU-minutes at
-# that size, so it only runs when asked for (R3DG_PSNR_HEADLINE=1: tools/round_end_gpu_job.sh, log under profiles/).
-@pytest.mark.parametrize("P,res,K,views,iters,scale", [(50_000, 320, 64, 8, 240, -3.9), (300_000, 800, 64, 16, 1000, -4.6)],
-                         ids=["50k_320", "headline_300k_800"])
+# The second case is the HEADLINE size (BASELINE.json: 300 000 Gaussians, 800x800, sample_num 64; bench.py's scene scale), cut to
+# what fits the suite: 8 views, 300 iterations, the bounded forward on (dropped views are reported) -- about 1.5 GPU-minutes, most
+# of it the reference pipeline.  It always runs (the driver's GPU run must see the headline-size comparison);
+# the 16-view / 1000-iteration variant of rounds 4-5 stays opt-in (R3DG_PSNR_HEADLINE=1, ~4.5 GPU-minutes, log under profiles/).
+@pytest.mark.parametrize("P,res,K,views,iters,scale", [(50_000, 320, 64, 8, 240, -3.9), (300_000, 800, 64, 8, 300, -4.6),
+                                                       (300_000, 800, 64, 16, 1000, -4.6)],
+                         ids=["50k_320", "headline_300k_800", "headline_300k_800_1000it"])
 def test_fused_training_matches_reference_pipeline_psnr(P, res, K, views, iters, scale):
     import os
-    if P >= 300_000 and os.environ.get("R3DG_PSNR_HEADLINE", "0") == "0":
-        pytest.skip("headline-size PSNR run: set R3DG_PSNR_HEADLINE=1 (about 3 GPU-minutes)")
+    if iters >= 1000 and os.environ.get("R3DG_PSNR_HEADLINE", "0") == "0":
+        pytest.skip("opt-in: the 1000-iteration headline-size PSNR run, set R3DG_PSNR_HEADLINE=1 (about 4.5 GPU-minutes; the "
+                    "300-iteration run at the same size always runs)")
     from oracle import reference_gpu as rg
     if not rg.available():
         pytest.skip("oracle/_ref/libr3dg_reference.so not built (python -m oracle.build_ref needs /root/reference)")
