@@ -887,7 +887,7 @@ def compact(result):
         c["roofline_relight"] = _roofline_compact(result["roofline_relight"])
     cbk = result.get("comm_buckets")
     if cbk:
-        c["comm_buckets"] = {k: {a: v.get(a) for a in ("MB", "ready_us", "done_us", "collective_ms", "bus_GBs")} for k, v in cbk.items()}
+        c["comm_buckets"] = {k: {a: v.get(a) for a in ("MB", "ready_us", "released_us", "collective_ms", "bus_GBs")} for k, v in cbk.items()}
     rl = result.get("relight") or {}
     if rl and "frames_per_rank" in rl:
         c["relight_fps"] = rl.get("relight_fps")
@@ -1049,6 +1049,9 @@ def run(args):
                 port = sock.getsockname()[1]
             os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1")
         torch.cuda.set_device(dev_index)
+        # the process group then brackets every collective with timed events on RCCL's own stream (Work._get_duration): what
+        # FusedStage2Step.comm_table reads the per-bucket collective time from
+        os.environ.setdefault("TORCH_NCCL_ENABLE_TIMING", "1")
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index))
         else:

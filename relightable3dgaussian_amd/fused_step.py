@@ -62,11 +62,17 @@ class _FakeCommHandle:
     """What torch.distributed's Work is to the callers of _allreduce_async: wait() orders the current stream behind the
     (priced) end of the collective."""
 
-    def __init__(self, event):
-        self.event = event
+    def __init__(self, event, begin=None):
+        self.event, self.begin = event, begin
 
     def wait(self):
         torch.cuda.current_stream().wait_event(self.event)
+
+    def _get_duration(self):
+        """ms the priced collective held the communication stream (same name as torch.distributed.Work's)."""
+        if self.begin is None:
+            raise RuntimeError("the priced collective was not timed")
+        return self.begin.elapsed_time(self.event)
 
 
 class FusedAdam:
@@ -434,7 +440,8 @@ class FusedStage2Step(_BoundedForward):
         self.measure_comm = False                   # bench.py: time the main stream spends waiting for all-reduce buckets
         self._comm_events = []
         self._bucket_events = []                    # (iteration, bucket, bytes, ready event, done event): comm_table()
-        self.comm_probe_every = 4                   # with measure_comm: every n-th iteration's buckets get the two probe events
+        # with measure_comm: every n-th iteration's buckets get the two probe events (0 = never; R3DG_COMM_PROBE_EVERY)
+        self.comm_probe_every = int(os.environ.get("R3DG_COMM_PROBE_EVERY", "4"))
         # R3DG_DP_BUCKETS=1 (A/B, message size against overlap): ONE all-reduce of the whole gradient slab behind the backward
         # and one Adam launch behind it, instead of the three buckets A / C / B each sent the moment it is final
         self._single_bucket = self.dp and os.environ.get("R3DG_DP_BUCKETS", "3") == "1"
@@ -867,7 +874,7 @@ class FusedStage2Step(_BoundedForward):
                 side = self._adam_stream
                 self.opt.begin_step()
                 with torch.cuda.stream(side):
-                    handle_a.wait()                       # the SIDE stream waits for RCCL's stream
+                    self._wait(handle_a, "A", side)       # the SIDE stream waits for RCCL's stream
                     self._skip_cur = self._snapshot_flag()
                     self.opt.step_groups(self._groups_a, [self.grads[k] for k in self._opt_order], 1.0 / self.world,
                                          skip_flag=self._skip_cur)
@@ -979,17 +986,16 @@ class FusedStage2Step(_BoundedForward):
         if not self.dp:
             return None
         if self.measure_comm and self._probe_this_iteration():
-            # per-bucket attribution (bench.py): `ready` = the moment the issuing stream has the bucket final; `done` = the end of
-            # its collective, seen by a probe stream that carries nothing else (comm_table)
+            # per-bucket attribution (bench.py): `ready` = the moment the issuing stream has the bucket final (one event record on a
+            # stream that exists anyway).  The collective's own time comes from the events RCCL's process group brackets it with
+            # on ITS stream (Work._get_duration, TORCH_NCCL_ENABLE_TIMING=1), read in comm_table once the work is complete.
+            # (A first version recorded a `done` event behind handle.wait() on a probe stream of its own: the extra stream moved
+            # the round-robin assignment of the iteration's streams to hardware queues -- 756 -> 513 it/s on the one-rank RCCL path,
+            # whether every iteration was probed or every fourth.  No new stream here.)
             ready = torch.cuda.Event(enable_timing=True)
             ready.record()
             handle = self._allreduce_issue(flat)
-            probe = shared_stream(self.dev, "comm_probe")
-            done = torch.cuda.Event(enable_timing=True)
-            with torch.cuda.stream(probe):
-                handle.wait()
-                done.record()
-            self._bucket_events.append((self._iter, name, flat.numel() * 4, ready, done))
+            self._bucket_events.append((self._iter, name, flat.numel() * 4, ready, handle))
             return handle
         return self._allreduce_issue(flat)
 
@@ -1011,14 +1017,19 @@ class FusedStage2Step(_BoundedForward):
         if os.environ.get("R3DG_DP_FAKE_COMM_WITH_RCCL", "0") != "0":
             with torch.cuda.stream(comm):              # (the identity collective too: its launch + two stream joins)
                 torch.distributed.all_reduce(flat, group=self.group, async_op=True).wait()
+        begin = torch.cuda.Event(enable_timing=True) if self.measure_comm else None
+        if begin is not None:
+            begin.record(comm)
         _lib.check(_lib.lib().r3dg_spin(comm.cuda_stream, float(us)), "spin")
-        done = torch.cuda.Event()
+        done = torch.cuda.Event(enable_timing=self.measure_comm)
         done.record(comm)
-        return _FakeCommHandle(done)
+        return _FakeCommHandle(done, begin)
 
-    def _wait(self, handle, name="?"):
+    def _wait(self, handle, name="?", side=None, it=None):
         """Make the current stream wait for a bucket's all-reduce; with `measure_comm` the wait is bracketed by events so that
-        the time the stream actually stalls on it (the EXPOSED communication) can be read back (exposed_comm_ms)."""
+        the time the stream actually stalls on it (the EXPOSED communication) can be read back (exposed_comm_ms).  `side`: the
+        wait sits on this side stream (bucket A: under the shading backward), not on the compute stream -- it is then only
+        recorded for comm_table's `released_us`, not counted as exposed."""
         if not self.measure_comm:
             handle.wait()
             return
@@ -1026,7 +1037,8 @@ class FusedStage2Step(_BoundedForward):
         e0.record()
         handle.wait()
         e1.record()
-        self._comm_events.append((self._iter, e0, e1, name))
+        # (`it`: the iteration the bucket belongs to -- bucket B is waited for at the top of the NEXT iteration)
+        self._comm_events.append((self._iter if it is None else it, e0, e1, name, side is not None))
 
     def exposed_comm_ms(self, split=False):
         """Mean per iteration of the time the compute stream waited for gradient all-reduces since measure_comm was set
@@ -1036,7 +1048,11 @@ class FusedStage2Step(_BoundedForward):
             return (None, {}) if split else None
         torch.cuda.synchronize(self.dev)
         per_iter, per_name = {}, {}
-        for it, e0, e1, name in self._comm_events:
+        self._released = {}
+        for it, e0, e1, name, on_side in self._comm_events:
+            self._released[(it, name)] = e1
+            if on_side:
+                continue
             ms = e0.elapsed_time(e1)
             per_iter[it] = per_iter.get(it, 0.0) + ms
             per_name[name] = per_name.get(name, 0.0) + ms
@@ -1046,42 +1062,44 @@ class FusedStage2Step(_BoundedForward):
         return (total, {k: v / n for k, v in per_name.items()}) if split else total
 
     def comm_table(self, world_assumed=None):
-        """Per-bucket attribution of the gradient all-reduces of the probed iterations since measure_comm was set (synchronises):
-        for each bucket its bytes, when it became final (`ready_us`, relative to the first bucket of its iteration), when its
-        collective ended (`done_us`), the collective's own time `collective_ms` = done - max(ready, previous bucket's done) -- the
-        buckets share ONE communication stream, so a bucket that became final while its predecessor was still travelling starts
-        when that one ends -- and the bus bandwidth that time amounts to for a ring all-reduce over the group's ranks,
-        2 (W-1)/W x bytes / collective_ms.  Means over the probed iterations; None when nothing was probed."""
+        """Per-bucket attribution of the gradient all-reduces of the probed iterations since measure_comm was set (call after
+        exposed_comm_ms; synchronises): for each bucket its bytes, when it became final on the stream that issued it (`ready_us`,
+        relative to the first bucket of its iteration), when its first consumer's stream got past the wait (`released_us`), the
+        collective's OWN time `collective_ms` -- bracketed by the events the process group records on RCCL's stream
+        (Work._get_duration; needs TORCH_NCCL_ENABLE_TIMING=1 before the group is created, bench.py sets it); for a backend without
+        them (gloo: the tests) the ready -> released interval, an upper bound -- and the bus bandwidth that time amounts to for a
+        ring all-reduce over the group's ranks, 2 (W-1)/W x bytes / collective_ms.  Means over the probed iterations; None when
+        nothing was probed."""
         if not self._bucket_events:
             return None
         torch.cuda.synchronize(self.dev)
         W = world_assumed or (int(os.environ.get("R3DG_DP_FAKE_COMM_WORLD", "8")) if _fake_comm_gbs() is not None else self.world)
-        by_iter = {}
-        for it, name, nbytes, ready, done in self._bucket_events:
-            by_iter.setdefault(it, []).append((name, nbytes, ready, done))
+        released = getattr(self, "_released", {})
+        base_of, acc = {}, {}
+        for it, name, nbytes, ready, handle in self._bucket_events:
+            base = base_of.setdefault(it, ready)
+            a = acc.setdefault(name, dict(bytes=nbytes, n=0, ready=0.0, released=0.0, n_rel=0, coll=0.0, timed_by=None))
+            a["n"] += 1
+            a["ready"] += base.elapsed_time(ready)
+            rel = released.get((it, name))
+            if rel is not None:
+                a["released"] += base.elapsed_time(rel)
+                a["n_rel"] += 1
+            try:
+                ms, by = float(handle._get_duration()), "collective's own events"
+            except Exception:
+                ms, by = (ready.elapsed_time(rel) if rel is not None else 0.0), "ready -> released (upper bound)"
+            a["coll"] += ms
+            a["timed_by"] = by
         self._bucket_events = []
-        acc = {}
-        for it, rows in by_iter.items():
-            base = rows[0][2]
-            timed = sorted(((base.elapsed_time(ready), base.elapsed_time(done), name, nbytes) for name, nbytes, ready, done in rows),
-                           key=lambda r: r[1])
-            prev_done = None
-            for t_ready, t_done, name, nbytes in timed:
-                start = t_ready if prev_done is None else max(t_ready, prev_done)
-                a = acc.setdefault(name, dict(bytes=nbytes, n=0, ready=0.0, done=0.0, coll=0.0, queued=0.0))
-                a["n"] += 1
-                a["ready"] += t_ready
-                a["done"] += t_done
-                a["coll"] += max(t_done - start, 0.0)
-                a["queued"] += start - t_ready
-                prev_done = t_done
+        self._released = {}
         out = {}
         for name, a in acc.items():
             n = a["n"]
             coll = a["coll"] / n
             out[name] = dict(MB=round(a["bytes"] / 1e6, 2), ready_us=round(1e3 * a["ready"] / n, 1),
-                             done_us=round(1e3 * a["done"] / n, 1), queued_behind_previous_us=round(1e3 * a["queued"] / n, 1),
-                             collective_ms=round(coll, 4),
+                             released_us=None if not a["n_rel"] else round(1e3 * a["released"] / a["n_rel"], 1),
+                             collective_ms=round(coll, 4), timed_by=a["timed_by"],
                              bus_GBs=None if coll <= 0 or W < 2 else round(2.0 * (W - 1) / W * a["bytes"] / (coll * 1e-3) / 1e9, 1),
                              alg_GBs=None if coll <= 0 else round(a["bytes"] / (coll * 1e-3) / 1e9, 1), probed_iterations=n)
         return out
@@ -1149,7 +1167,7 @@ class FusedStage2Step(_BoundedForward):
                 self._wait(handle_c, "C")
         if self._groups_c:
             self.opt.step_groups(self._groups_c, grads, scale, skip_flag=self._skip_cur)
-        self._pending_b = (handle_b, grads, scale, self._skip_cur)
+        self._pending_b = (handle_b, grads, scale, self._skip_cur, self._iter)
 
     @_in_context
     def flush(self):
@@ -1162,9 +1180,9 @@ class FusedStage2Step(_BoundedForward):
             _lib.stream_wait(torch.cuda.current_stream(self.dev), self._early_stream)
             self._early_pending = False
         if self._pending_b is not None:
-            handle_b, grads, scale, skip = self._pending_b
+            handle_b, grads, scale, skip, it_b = self._pending_b
             self._pending_b = None
-            self._wait(handle_b, "B")
+            self._wait(handle_b, "B", it=it_b)
             if self._groups_b:
                 self.opt.step_groups(self._groups_b, grads, scale, skip_flag=skip)
 
