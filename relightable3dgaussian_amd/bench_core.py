@@ -688,18 +688,21 @@ SYN4_LRS = dict(xyz=0.0, normal=0.0, scaling=0.0, rotation=0.0, opacity=0.0, shs
 
 
 def config_rate(dev, points, width, height, stage=2, sample_num=64, objective="nerf", steps=16, warmup=4, relight_samples=0,
-                relight_frames=0, stage_ms=False):
+                relight_frames=0, stage_ms=False, scene=None):
     """One of the other BASELINE configurations on the synthetic scene (single GPU, short run): iters/s of the fused training
     iteration with that configuration's objective and schedule (`objective`: "nerf" = script/run_nerf.sh, "syn4" =
     script/run_syn4.sh / run_dtu.sh: edge-aware smoothness terms + frozen geometry), the measured num_rendered, and optionally
     relight FPS at `relight_samples` rays per Gaussian."""
     from . import fused_step, relight, train_step
-    scene = syn.make_scene(P=points, seed=0, stage2=stage == 2)
+    given = scene is not None            # (`scene`: a make_scene-format dict instead of the i.i.d. synthetic one, e.g. trained_scene.py)
+    if not given:
+        scene = syn.make_scene(P=points, seed=0, stage2=stage == 2)
+    points = scene["xyz"].shape[0]
     cams = [c.to(dev) for c in syn.orbit_cameras(100, width=width, height=height)[:4]]
     bg = torch.ones(3, device=dev)
     params = GaussianParams(scene, dev, stage == 2)
     with torch.no_grad():
-        teacher = GaussianParams(syn.make_scene(P=points, seed=0, stage2=False), dev, False)
+        teacher = GaussianParams(scene if given else syn.make_scene(P=points, seed=0, stage2=False), dev, False)
         teacher.features_dc.add_(0.05 * torch.randn_like(teacher.features_dc))
         gts = [render_stage1(teacher, c, bg)[2].clone() for c in cams]
         del teacher
@@ -764,6 +767,55 @@ def config_rate(dev, points, width, height, stage=2, sample_num=64, objective="n
                    visibility_seconds=round(t_vis, 3), visibility_Mrays_per_s=round(points * relight_samples / t_vis / 1e6, 1),
                    visibility_trace_visits=visits)
     return out
+
+
+def distribution_rows(dev, width, height, sample_num=64, relight_samples=384, iid=None):
+    """Workloads whose splat statistics are not the i.i.d. log-normal ones every other number is quoted on (VERDICT r5 weak 8;
+    trained_scene.py): a scene TRAINED here from 4 000 random points with the reference's densification schedule, and the
+    synthetic scene with 1 % of its splats 20 x larger.  For each: what the front end sees in view 0 (`binning`: num_rendered,
+    tile-list lengths, rectangle sizes), the stage-2 training rate with its per-stage times, relight FPS, views dropped by the
+    bounded forward -- and, against the i.i.d. scene's row `iid` (config_rate(..., stage_ms=True) of the headline scene), every
+    stage's time PER MILLION INSTANCES relative to the i.i.d. scene's (`per_instance_vs_iid`; > 2 = a cliff to explain)."""
+    from . import trained_scene as ts
+    rows = {}
+    cam0 = syn.orbit_cameras(100, width=width, height=height)[0].to(dev)
+    if iid is None:
+        iid = config_rate(dev, 300_000, width, height, sample_num=sample_num, stage_ms=True)
+    iid_R = float(iid["num_rendered"])
+
+    def relative(row):
+        out = {}
+        for k, ms in (row.get("stage_ms") or {}).items():
+            base = (iid.get("stage_ms") or {}).get(k)
+            if base and ms and k in ("duplicate_with_keys", "sort_pairs", "render_forward", "render_backward", "identify_tile_ranges"):
+                out[k] = round((ms / row["num_rendered"]) / (base / iid_R), 2)
+        if row.get("ms_per_step") and iid.get("ms_per_step"):
+            out["whole_step"] = round((row["ms_per_step"] / row["num_rendered"]) / (iid["ms_per_step"] / iid_R), 2)
+        return out
+    for name, make in (("trained_scene", lambda: ts.train_scene(dev, res=max(width, height) if width == height else 800)),
+                       ("heavy_tail_1pct_x20", lambda: ts.heavy_tail_scene())):
+        try:
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            sc = make()
+            torch.cuda.synchronize()
+            t_make = time.perf_counter() - t0
+            row = config_rate(dev, 0, width, height, sample_num=sample_num, steps=12, warmup=4, relight_samples=relight_samples,
+                              relight_frames=6, stage_ms=True, scene=sc)
+            row["binning"] = ts.binning_stats(sc, cam0, dev)
+            row["scene_seconds"] = round(t_make, 2)
+            row["per_instance_vs_iid"] = relative(row)
+            row.pop("visibility_trace_visits", None)
+            rows[name] = row
+            del sc
+            torch.cuda.empty_cache()
+        except Exception as e:                   # a side measurement
+            rows[name] = {"failed": repr(e)}
+    rows["iid_reference_row"] = {k: iid.get(k) for k in ("points", "iters_per_s", "ms_per_step", "num_rendered", "stage_ms")}
+    rows["what"] = ("trained_scene: stage 1 from 4 000 random points, 3 000 iterations, densify_and_prune every 100 from 200 to 2 600 "
+                    "(train.py:158-175 compressed), position-gradient threshold 5e-5, against 24 views of a hidden 60 000-splat teacher "
+                    "(trained_scene.train_scene); heavy_tail: make_scene with a seeded 1 % of the splats x 20")
+    return rows
 
 
 def unfused_rate(dev, points, width, height, sample_num=64, shading="hip", steps=10, warmup=3):
@@ -853,7 +905,7 @@ COMPACT_LIMIT = 4096      # bytes: the LAST stdout line must stay a document the
 _OTHER_SHORT = (("configs[1] stage-1", "stage1_800"), ("sample_num 384 as BASELINE", "syn4_K384"),
                 ("the same at the script's own sample_num 64", "syn4_K64"), ("stage-2 run_nerf.sh objective at sample_num 384", "nerf_K384"),
                 ("configs[3] DTU", "dtu_1600x1200"), ("configs[4] composition", "compose_2M"),
-                ("stage1_densify_and_prune", "densify_call_ms"),
+                ("stage1_densify_and_prune", "densify_call_ms"), ("splat distributions", "distributions"),
                 ("rendering_equation = this repo's op", "dropin_loop_patched"),
                 ("rendering_equation = the reference's pure-PyTorch", "dropin_loop_unpatched"),
                 ("data_parallel_path_one_rank_rccl", "dp_one_rank_rccl"))
@@ -916,6 +968,13 @@ def compact(result):
                 short[name] = v
             elif "failed" in v or "skipped" in v:
                 short[name] = "failed" if "failed" in v else "skipped"
+            elif name == "distributions":
+                for sub in ("trained_scene", "heavy_tail_1pct_x20"):
+                    r = v.get(sub) or {}
+                    short[sub] = {"iters_per_s": r.get("iters_per_s"), "points": r.get("points"), "num_rendered": r.get("num_rendered"),
+                                  "relight_fps": r.get("relight_fps"), "dropped": r.get("dropped_steps"),
+                                  "step_per_instance_vs_iid": (r.get("per_instance_vs_iid") or {}).get("whole_step")} \
+                        if "failed" not in r else "failed"
             elif name == "densify_call_ms":
                 short[name] = v.get("call_ms")
             else:
@@ -1327,6 +1386,9 @@ def run(args):
                     oc["configs[4] composition scale: 2M Gaussians, 1800x700 (configs/teaser), train sample_num 64 + relight sample_num 384"] = \
                         config_rate(dev, 2_000_000, 1800, 700, sample_num=64, steps=8, warmup=3, relight_samples=384,
                                     relight_frames=6, stage_ms=True)
+                if side_budget(50):
+                    oc["splat distributions other than the i.i.d. one (trained scene, heavy tail)"] = distribution_rows(
+                        dev, W_img, H_img, sample_num=args.sample_num)
                 oc["stage1_densify_and_prune (one call at the bench size)"] = densify_bench(args.points, args.res, dev)
                 if args.stage == 2 and side_budget(40):
                     # north_star's literal mode: the reference's loop over the drop-in ops, at the headline size

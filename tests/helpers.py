@@ -51,6 +51,17 @@ def make_case(P=3000, W=128, H=128, S=5, seed=1, scale_log_mean=-3.0, eye=(3.2, 
     return case
 
 
+def case_from_scene(sc, W=128, H=128, S=5, seed=1, eye=(3.2, 1.0, 1.5), bg=(1.0, 0.5, 0.2), sh_degree=3):
+    """make_case for a GIVEN scene (synthetic.make_scene's format; e.g. relightable3dgaussian_amd.trained_scene)."""
+    P = sc["xyz"].shape[0]
+    g = torch.Generator().manual_seed(seed + 100)
+    feat = torch.rand(P, S, generator=g) if S > 0 else torch.zeros(P, 0)
+    cpu = lambda t: t.detach().cpu().contiguous()
+    return dict(P=P, W=W, H=H, S=S, bg=torch.tensor(bg, dtype=torch.float32), means3D=cpu(sc["xyz"]), features=feat,
+                opacity=cpu(sc["opacity"]), scales=cpu(sc["scales"]), rotations=cpu(sc["rotations"]), shs=cpu(sc["shs"]),
+                degree=sh_degree, cam=syn.look_at_camera(eye, width=W, height=H), colors=None, cov3D=None)
+
+
 def fwd_args(case, device=None, debug=False):
     """Positional args of `_C.rasterize_gaussians` for a case (optionals as empty CPU tensors, like the reference)."""
     cam = case["cam"]

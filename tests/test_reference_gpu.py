@@ -53,9 +53,35 @@ BASELINE_CASES = [
 ]
 
 
-@pytest.mark.parametrize("name,kw,backward", BASELINE_CASES, ids=[c[0] for c in BASELINE_CASES])
+# Splat statistics other than the i.i.d. log-normal ones (relightable3dgaussian_amd/trained_scene.py): a scene
+# TRAINED at test time from 4 000 random points with the reference's densification schedule (~380k rows, rectangles up to the whole
+# grid, 37 % of the instances from rectangles above 32 tiles, tile lists of ~4 000) and the synthetic scene with 1 % of its splats
+# 20 x larger -- the long-tile sort, the wave-cooperative rectangle expansion and the longest-tile-first order under real load.
+DISTRIBUTION_CASES = [
+    ("trained_scene_800x800_S16", dict(kind="trained", S=16, W=800, H=800, eye=ORBIT0), True),
+    ("heavy_tail_300k_800x800_S16", dict(kind="heavy_tail", S=16, W=800, H=800, eye=ORBIT0), True),
+]
+_scene_cache = {}
+
+
+def _distribution_scene(kind):
+    from relightable3dgaussian_amd import trained_scene as ts
+    if kind not in _scene_cache:
+        _scene_cache[kind] = ts.train_scene(torch.device(DEV, 0), stage2=False) if kind == "trained" else \
+            ts.heavy_tail_scene(stage2=False)
+    return _scene_cache[kind]
+
+
+@pytest.mark.parametrize("name,kw,backward", BASELINE_CASES + DISTRIBUTION_CASES,
+                         ids=[c[0] for c in BASELINE_CASES + DISTRIBUTION_CASES])
 def test_rasterizer_matches_real_reference_at_baseline_sizes(name, kw, backward):
-    _compare_rasterizer(name, make_case(**kw), backward=backward)
+    if "kind" in kw:
+        from tests.helpers import case_from_scene
+        kw = dict(kw)
+        case = case_from_scene(_distribution_scene(kw.pop("kind")), **kw)
+    else:
+        case = make_case(**kw)
+    _compare_rasterizer(name, case, backward=backward)
 
 
 def _compare_rasterizer(name, case, backward=True):
