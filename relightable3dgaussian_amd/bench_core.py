@@ -1387,8 +1387,11 @@ def run(args):
                         config_rate(dev, 2_000_000, 1800, 700, sample_num=64, steps=8, warmup=3, relight_samples=384,
                                     relight_frames=6, stage_ms=True)
                 if side_budget(50):
+                    # (the i.i.d. row they are compared with is the headline itself: the timed block's step time and stage times)
+                    iid = dict(points=P, iters_per_s=result["value"], ms_per_step=result["ms_per_step"], num_rendered=R_mean,
+                               stage_ms={k: v.get("ms_per_iteration") for k, v in kernels.items()})
                     oc["splat distributions other than the i.i.d. one (trained scene, heavy tail)"] = distribution_rows(
-                        dev, W_img, H_img, sample_num=args.sample_num)
+                        dev, W_img, H_img, sample_num=args.sample_num, iid=iid)
                 oc["stage1_densify_and_prune (one call at the bench size)"] = densify_bench(args.points, args.res, dev)
                 if args.stage == 2 and side_budget(40):
                     # north_star's literal mode: the reference's loop over the drop-in ops, at the headline size

@@ -5,6 +5,8 @@
 // INTEGER outputs (tiles_touched, keys, sort order), which must be bit-identical to the CPU oracle, so every
 // fp32 operation keeps the reference's order (forward.cu:74-258, auxiliary.h:41-164) with no fused
 // multiply-add.  These kernels are HBM-bound (236 B read + ~75 B written per Gaussian); VALU cost is irrelevant.
+#include <atomic>
+
 #include "common.hpp"
 
 namespace r3dg {
@@ -432,7 +434,7 @@ tile_order_kernel(int T, const uint2* __restrict__ ranges, uint32_t* __restrict_
 //                       sort entry (depth bits << 32 | Gaussian index) the per-tile sort wants.
 // Order inside a tile is arbitrary here; the per-tile sort by the unique (depth, index) key makes the final lists
 // bit-identical to the reference's stable global sort.  Falls back to the round-1 path when T exceeds the LDS histogram.
-constexpr int BIN_MAX_TILES = 16384;           // 64 KB of LDS counters
+constexpr int BIN_MAX_TILES = 16384;           // 64 KB of LDS counters (+ the 8 KB list of large rectangles behind them)
 
 constexpr int BIN_THREADS = 1024;
 constexpr int BIN_MAX_ITERS = 4;            // Gaussians per block = R3DG_OPT_BINNING_BLOCK_K (1..4) x 1024
@@ -458,50 +460,107 @@ __device__ __forceinline__ TileRect load_tile_rect(int idx, int P, const float2*
     return t;
 }
 
-// the tiles of Gaussian `idx` (one per lane; whole waves call this together): f(tile, Gaussian, that Gaussian's payload)
-template <typename F>
-__device__ __forceinline__ void for_each_tile(const TileRect& rc, int idx, uint32_t payload, int gx, F&& f)
+// WHICH Gaussians a block takes (round 6).  Rounds 2-5: block b took the 2048 CONSECUTIVE Gaussians b * 2048 ... -- fine for the
+// synthetic scene, whose index order is random in space and in size.  A scene that was DENSIFIED keeps its oldest Gaussians at the
+// lowest indices, and the oldest are the largest: on a scene trained here from 4 000 points (trained_scene.py: 380k rows, 4.9 M
+// instances) the first block held 1.0 M of the instances, one CU expanded them while 185 others had finished theirs, and the count
+// + emit kernels took 0.90 ms (the i.i.d. scene: 0.07).  Now the 64-Gaussian wave chunks are DEALT round robin over the blocks
+// (chunk q -> block q mod nb): loads stay coalesced per wave and any index-clustered tail is spread over all blocks (heaviest
+// block of that scene: 62 k instances, mean 27 k).
+__device__ __forceinline__ int dealt_index_of(int it, int thread, int nb)
 {
-    const int lane = threadIdx.x & 63;
+    const int q = (it * (BIN_THREADS / 64) + (thread >> 6)) * nb + (int)blockIdx.x;
+    return q * 64 + (thread & 63);
+}
+__device__ __forceinline__ int dealt_index(int it, int nb) { return dealt_index_of(it, (int)threadIdx.x, nb); }
+
+// The tiles of the block's Gaussians: f(tile, Gaussian, that Gaussian's payload).
+//   * rectangles of up to 32 tiles: one per lane, ONE flat loop (as a y / x loop nest the wave ran max-over-lanes(h) x
+//     max-over-lanes(w) rounds -- up to 32 x 32 when one lane holds a 2 x 16 and another a 16 x 2 rectangle);
+//   * larger rectangles go on the BLOCK's list (s_big: pass << 10 | thread, 16 bits) and, behind a barrier, are expanded by whole
+//     waves -- every wave of the block takes every 16th entry, whichever wave loaded it: rounds 2-5 expanded them inside the wave
+//     that owned them, one after the other (a wave of 64 screen-filling Gaussians: 39 k instances on one wave of the scene above).
+//     The rectangle (and the payload) of a listed Gaussian is derived again from its index: two broadcast loads per >= 33 tiles.
+// Every thread of the block must call both halves (they synchronise).
+template <typename F>
+__device__ __forceinline__ void small_rect_tiles(const TileRect& rc, int it, int idx, uint32_t payload, int gx, uint16_t* s_big,
+                                                 uint32_t* s_nbig, F&& f)
+{
     const uint32_t cnt = (uint32_t)(rc.w * rc.h);
-    const bool live = cnt != 0u;
     const bool big = cnt > 32u;
-    if (live && !big)
-        for (int y = rc.y0; y < rc.y0 + rc.h; y++)
-            for (int x = rc.x0; x < rc.x0 + rc.w; x++) f((uint32_t)(y * gx + x), (uint32_t)idx, payload);
-    // rectangles larger than 32 tiles are expanded by the whole wave (one screen-filling Gaussian cannot serialise it)
-    unsigned long long todo = __ballot(big);
-    while (todo) {
-        const int src = __ffsll((long long)todo) - 1;
-        todo &= todo - 1;
-        const int bx0 = __shfl(rc.x0, src, 64), by0 = __shfl(rc.y0, src, 64), bw = __shfl(rc.w, src, 64);
-        const uint32_t bcnt = (uint32_t)__shfl((int)cnt, src, 64);
-        const uint32_t bpay = (uint32_t)__shfl((int)payload, src, 64);
-        const uint32_t bid = (uint32_t)((idx & ~63) + src);
-        for (uint32_t k = lane; k < bcnt; k += 64)
-            f((uint32_t)((by0 + (int)(k / (uint32_t)bw)) * gx + bx0 + (int)(k % (uint32_t)bw)), bid, bpay);
+    if (cnt != 0u && !big) {
+        int x = rc.x0, y = rc.y0;
+        const int x1 = rc.x0 + rc.w;
+        for (uint32_t k = 0; k < cnt; k++) {
+            f((uint32_t)(y * gx + x), (uint32_t)idx, payload);
+            if (++x == x1) {
+                x = rc.x0;
+                y++;
+            }
+        }
+    }
+    const unsigned long long m = __ballot(big);
+    if (m) {
+        const int lane = threadIdx.x & 63;
+        uint32_t base = 0;
+        if (lane == 0) base = atomicAdd(s_nbig, (uint32_t)__popcll(m));
+        base = (uint32_t)__shfl((int)base, 0, 64);
+        if (big) s_big[base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = (uint16_t)((it << 10) | (int)threadIdx.x);
     }
 }
 
-// each block takes `iters` x 1024 consecutive Gaussians: the more Gaussians share one LDS histogram, the fewer global
+template <bool PAYLOAD_IS_DEPTH, typename F>
+__device__ __forceinline__ void big_rect_tiles(const uint16_t* s_big, uint32_t n_big, int nb, const float2* __restrict__ means2D,
+                                               const int* __restrict__ radii, const float* __restrict__ depths, int gx, int gy, F&& f)
+{
+    const int lane = threadIdx.x & 63;
+    for (uint32_t r = threadIdx.x >> 6; r < n_big; r += BIN_THREADS / 64) {
+        const int e = (int)s_big[r];
+        const uint32_t g = (uint32_t)dealt_index_of(e >> 10, e & 1023, nb);
+        const float2 p = means2D[g];
+        int x0, y0, x1, y1;
+        tile_rect(p.x, p.y, radii[g], gx, gy, x0, y0, x1, y1);
+        const uint32_t pay = PAYLOAD_IS_DEPTH ? __float_as_uint(depths[g]) : 0u;
+        const int w = x1 - x0;
+        const uint32_t cnt = (uint32_t)(w * (y1 - y0));
+        // lane k of round j takes tile 64 j + k of the rectangle: (x, y) advance by 64 tiles per round without a division
+        int y = y0 + lane / w, x = x0 + lane % w;
+        const int dy = 64 / w, dx = 64 % w;
+        for (uint32_t k = lane; k < cnt; k += 64) {
+            f((uint32_t)(y * gx + x), g, pay);
+            x += dx;
+            y += dy;
+            if (x >= x1) {
+                x -= w;
+                y++;
+            }
+        }
+    }
+}
+
+// each block takes `iters` x 1024 Gaussians (dealt_index): the more Gaussians share one LDS histogram, the fewer global
 // atomics (one per block and touched tile; an unordered cloud touches nearly every tile from every block)
 __global__ void __launch_bounds__(BIN_THREADS)
 tile_count_kernel(int P, int T, int iters, const float2* __restrict__ means2D, const int* __restrict__ radii, int gx, int gy,
                   uint32_t* __restrict__ tile_counts)
 {
-    extern __shared__ uint32_t s_bins[];
-    const int base = blockIdx.x * iters * BIN_THREADS + threadIdx.x;
+    extern __shared__ uint32_t s_bins[];                       // T counters, then the list of large rectangles
+    uint16_t* s_big = reinterpret_cast<uint16_t*>(s_bins + T);
+    __shared__ uint32_t s_nbig;
+    const int nb = gridDim.x;
     TileRect rc[BIN_MAX_ITERS];
 #pragma unroll
     for (int it = 0; it < BIN_MAX_ITERS; it++)            // (the loads of every pass leave before the zero fill is waited for)
-        rc[it] = load_tile_rect(it < iters ? base + it * BIN_THREADS : P, P, means2D, radii, gx, gy);
+        rc[it] = load_tile_rect(it < iters ? dealt_index(it, nb) : P, P, means2D, radii, gx, gy);
     for (int t = threadIdx.x; t < T; t += BIN_THREADS) s_bins[t] = 0;
+    if (threadIdx.x == 0) s_nbig = 0;
     __syncthreads();
+    auto count = [&](uint32_t tile, uint32_t, uint32_t) { atomicAdd(&s_bins[tile], 1u); };
 #pragma unroll
     for (int it = 0; it < BIN_MAX_ITERS; it++)
-        if (it < iters)
-            for_each_tile(rc[it], base + it * BIN_THREADS, 0u, gx,
-                          [&](uint32_t tile, uint32_t, uint32_t) { atomicAdd(&s_bins[tile], 1u); });
+        if (it < iters) small_rect_tiles(rc[it], it, dealt_index(it, nb), 0u, gx, s_big, &s_nbig, count);
+    __syncthreads();
+    big_rect_tiles<false>(s_big, s_nbig, nb, means2D, radii, nullptr, gx, gy, count);
     __syncthreads();
     for (int t = threadIdx.x; t < T; t += BIN_THREADS) {
         const uint32_t c = s_bins[t];
@@ -586,8 +645,10 @@ tile_emit_kernel(int P, int T, int iters, const float2* __restrict__ means2D, co
                  const uint2* __restrict__ ranges, uint32_t* __restrict__ order, uint32_t small_cap,
                  uint32_t* __restrict__ big_list, uint32_t* __restrict__ big_count)
 {
-    extern __shared__ uint32_t s_bins[];
+    extern __shared__ uint32_t s_bins[];                       // T counters, then the list of large rectangles
+    uint16_t* s_big = reinterpret_cast<uint16_t*>(s_bins + T);
     __shared__ uint32_t s_wave[BIN_MAX_ITERS][BIN_THREADS / 64];
+    __shared__ uint32_t s_nbig;
     // one block past the emitting ones (when the caller asked for it): the longest-tile-first order of the tile kernels, which
     // needs the ranges only -- beside the emission instead of a launch of its own behind it
     if ((int)blockIdx.x >= emit_blocks) {
@@ -597,22 +658,23 @@ tile_emit_kernel(int P, int T, int iters, const float2* __restrict__ means2D, co
     const bool over = capacity >= 0 && *total > (unsigned long long)capacity;      // see tile_scan_kernel
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     for (int t = threadIdx.x; t < T; t += BIN_THREADS) s_bins[t] = 0;
-    const int base = blockIdx.x * iters * BIN_THREADS + threadIdx.x;
+    if (threadIdx.x == 0) s_nbig = 0;
     // GeometryState::point_offsets (inclusive scan of tiles_touched, rasterizer_impl.cu:283-287): part of the state parity.
-    // block_offsets are preprocess' exclusive sums per 256 Gaussians = 4 waves.  All loads first, one barrier for all passes.
-    // ... and the rectangle + depth of every Gaussian of this thread, for both passes below
+    // block_offsets are preprocess' exclusive sums per 256 Gaussians = 4 waves -- this part keeps the CONSECUTIVE mapping of
+    // Gaussians to blocks (the four waves of a 256-chunk share s_wave); the rectangles below are those of the DEALT Gaussians.
+    // All loads first, one barrier for all passes.
+    const int lin = blockIdx.x * iters * BIN_THREADS + threadIdx.x;
     uint32_t inc[BIN_MAX_ITERS], boff[BIN_MAX_ITERS], dbits[BIN_MAX_ITERS];
     TileRect rc[BIN_MAX_ITERS];
 #pragma unroll
     for (int it = 0; it < BIN_MAX_ITERS; it++) {
-        const int idx = base + it * BIN_THREADS;
-        const bool in = it < iters && idx < P;
-        rc[it] = load_tile_rect(it < iters ? idx : P, P, means2D, radii, gx, gy);
-        dbits[it] = __float_as_uint(depths[in ? idx : P - 1]);
+        const int idx = it < iters ? dealt_index(it, emit_blocks) : P;
+        rc[it] = load_tile_rect(idx, P, means2D, radii, gx, gy);
+        dbits[it] = __float_as_uint(depths[idx < P ? idx : P - 1]);
     }
 #pragma unroll
     for (int it = 0; it < BIN_MAX_ITERS; it++) {
-        const int idx = base + it * BIN_THREADS;
+        const int idx = lin + it * BIN_THREADS;
         const bool in = it < iters && idx < P;
         const uint32_t cnt = in ? tiles_touched[idx] : 0u;
         boff[it] = in ? block_offsets[idx >> 8] : 0u;
@@ -622,7 +684,7 @@ tile_emit_kernel(int P, int T, int iters, const float2* __restrict__ means2D, co
     __syncthreads();
 #pragma unroll
     for (int it = 0; it < BIN_MAX_ITERS; it++) {
-        const int idx = base + it * BIN_THREADS;
+        const int idx = lin + it * BIN_THREADS;
         if (it < iters && idx < P) {
             uint32_t off = boff[it];
             for (int w = wave & ~3; w < wave; w++) off += s_wave[it][w];
@@ -630,11 +692,13 @@ tile_emit_kernel(int P, int T, int iters, const float2* __restrict__ means2D, co
         }
     }
     if (over) return;
+    auto count = [&](uint32_t tile, uint32_t, uint32_t) { atomicAdd(&s_bins[tile], 1u); };
 #pragma unroll
     for (int it = 0; it < BIN_MAX_ITERS; it++)
-        if (it < iters)
-            for_each_tile(rc[it], base + it * BIN_THREADS, 0u, gx,
-                          [&](uint32_t tile, uint32_t, uint32_t) { atomicAdd(&s_bins[tile], 1u); });
+        if (it < iters) small_rect_tiles(rc[it], it, dealt_index(it, emit_blocks), 0u, gx, s_big, &s_nbig, count);
+    __syncthreads();
+    const uint32_t n_big = s_nbig;
+    big_rect_tiles<false>(s_big, n_big, emit_blocks, means2D, radii, depths, gx, gy, count);
     __syncthreads();
     // this block's run inside every touched tile's segment: ONE returning global atomic per (block, tile) -- four of a thread's in
     // flight at a time (as a plain loop each waited for its predecessor's return, a device-scope round trip of several us: half
@@ -653,13 +717,30 @@ tile_emit_kernel(int P, int T, int iters, const float2* __restrict__ means2D, co
             if (c[k]) s_bins[t0 + k * BIN_THREADS] = r[k];
     }
     __syncthreads();
+    auto emit = [&](uint32_t tile, uint32_t g, uint32_t depth_bits) {
+        const uint32_t pos = atomicAdd(&s_bins[tile], 1u);
+        entries[pos] = ((uint64_t)depth_bits << 32) | (uint64_t)g;
+    };
+    // (the list is kept from the counting pass: the second pass over the small rectangles does not append again)
 #pragma unroll
     for (int it = 0; it < BIN_MAX_ITERS; it++)
-        if (it < iters)
-            for_each_tile(rc[it], base + it * BIN_THREADS, dbits[it], gx, [&](uint32_t tile, uint32_t g, uint32_t depth_bits) {
-                const uint32_t pos = atomicAdd(&s_bins[tile], 1u);
-                entries[pos] = ((uint64_t)depth_bits << 32) | (uint64_t)g;
-            });
+        if (it < iters) {
+            const TileRect& q = rc[it];
+            const uint32_t cnt = (uint32_t)(q.w * q.h);
+            if (cnt != 0u && cnt <= 32u) {
+                int x = q.x0, y = q.y0;
+                const int x1 = q.x0 + q.w;
+                const uint32_t g = (uint32_t)dealt_index(it, emit_blocks);
+                for (uint32_t k = 0; k < cnt; k++) {
+                    emit((uint32_t)(y * gx + x), g, dbits[it]);
+                    if (++x == x1) {
+                        x = q.x0;
+                        y++;
+                    }
+                }
+            }
+        }
+    big_rect_tiles<true>(s_big, n_big, emit_blocks, means2D, radii, depths, gx, gy, emit);
 }
 
 int g_bin_iters = 2;       // R3DG_OPT_BINNING_BLOCK_K (measured at 2M Gaussians too: 2 / 3 / 4 -> 163 / 156 / 161 it/s, no trend)
@@ -678,8 +759,20 @@ void launch_tile_binning(hipStream_t s, int P, int T, const float* means2D, cons
     const int iters = std::min(std::max(opt(R3DG_OPT_BINNING_BLOCK_K), 1), BIN_MAX_ITERS);
     const int per_block = iters * BIN_THREADS;
     const int nb = (P + per_block - 1) / per_block;
-    const size_t smem = (size_t)T * 4;
-    // (T <= BIN_MAX_TILES: at most 64 KB of dynamic LDS, what every launch may ask for -- no function attribute needed)
+    const size_t smem = (size_t)T * 4 + (size_t)iters * BIN_THREADS * 2;       // tile counters + the list of large rectangles
+    // above 64 KB (more than ~14 000 tiles, e.g. 2048 x 2048) the kernels need the per-device function attribute, asked for once
+    if (smem + 1024 > 65536) {
+        static std::atomic<unsigned long long> done{0};
+        int dev = 0;
+        R3DG_HIP(hipGetDevice(&dev));
+        const unsigned long long bit = 1ull << (dev & 63);
+        if (!(done.load(std::memory_order_acquire) & bit)) {
+            const int want = BIN_MAX_TILES * 4 + BIN_MAX_ITERS * BIN_THREADS * 2;
+            R3DG_HIP(hipFuncSetAttribute((const void*)tile_count_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, want));
+            R3DG_HIP(hipFuncSetAttribute((const void*)tile_emit_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, want));
+            done.fetch_or(bit, std::memory_order_release);
+        }
+    }
     tile_count_kernel<<<nb, BIN_THREADS, smem, s>>>(P, T, iters, (const float2*)means2D, radii, gx, gy, tile_counts);
     tile_scan_kernel<<<1, 1024, 0, s>>>(T, tile_counts, (uint2*)ranges, cursor, total, capacity, overflow_flag,
                                         overflow_count, fused ? (P + 255) / 256 : 0, block_offsets);
