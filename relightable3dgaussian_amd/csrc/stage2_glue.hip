@@ -1226,6 +1226,43 @@ struct AdamTable {
     int n_groups;
 };
 
+// One float4 per thread and array (ADAM_UNROLL = 1) with NONTEMPORAL accesses for what is touched once per iteration -- the
+// gradient and both moments: measured cold (tools/kbench_adam.py: the last-level cache evicted between launches, 958 MB per launch
+// at 300k Gaussians): 0.180 ms = 5.33 TB/s = 0.67 of the HBM peak with plain accesses (rounds 1-5), 0.154 ms = 6.21 TB/s = 0.78
+// with nontemporal ones -- the rate the guide measures as achievable for a streaming kernel.  More floats per thread do NOT help
+// (2 / 4 / 8 float4 per thread and array, all loads issued first: 0.164 / 0.168 / 0.178 ms -- fewer, longer workgroups leave a
+// longer tail); the knob stays for the A/B (tools/build_variant.py, -DR3DG_ADAM_UNROLL=n).
+#ifndef R3DG_ADAM_UNROLL
+#define R3DG_ADAM_UNROLL 1
+#endif
+#ifndef R3DG_ADAM_NT
+#define R3DG_ADAM_NT 1              // the moments are read and written ONCE per iteration: nontemporal accesses
+#endif
+constexpr int ADAM_UNROLL = R3DG_ADAM_UNROLL;
+constexpr int ADAM_BLOCK_FLOATS = 1024 * ADAM_UNROLL;
+
+__device__ __forceinline__ float4 adam_load(const float* p, bool nt)
+{
+    if (nt && R3DG_ADAM_NT) {
+        const float4* q = reinterpret_cast<const float4*>(p);
+        return make_float4(__builtin_nontemporal_load(&q->x), __builtin_nontemporal_load(&q->y), __builtin_nontemporal_load(&q->z),
+                           __builtin_nontemporal_load(&q->w));
+    }
+    return *reinterpret_cast<const float4*>(p);
+}
+__device__ __forceinline__ void adam_store(float* p, const float (&v)[4], bool nt)
+{
+    if (nt && R3DG_ADAM_NT) {
+        float4* q = reinterpret_cast<float4*>(p);
+        __builtin_nontemporal_store(v[0], &q->x);
+        __builtin_nontemporal_store(v[1], &q->y);
+        __builtin_nontemporal_store(v[2], &q->z);
+        __builtin_nontemporal_store(v[3], &q->w);
+        return;
+    }
+    *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
+}
+
 __global__ void __launch_bounds__(256)
 adam_kernel(AdamTable t, float beta1, float beta2, float eps, float bias1, float inv_sqrt_bias2, float grad_scale,
             const float* __restrict__ skip_flag)
@@ -1237,42 +1274,50 @@ adam_kernel(AdamTable t, float beta1, float beta2, float eps, float bias1, float
 #pragma unroll 1
     while (gi + 1 < t.n_groups && blockIdx.x >= t.first_block[gi + 1]) gi++;
     const r3dg_adam_group grp = t.g[gi];
-    const size_t base = (size_t)(blockIdx.x - t.first_block[gi]) * 1024 + threadIdx.x * 4;
-    if (base >= grp.n) return;
+    const size_t block_base = (size_t)(blockIdx.x - t.first_block[gi]) * ADAM_BLOCK_FLOATS + threadIdx.x * 4;
     float* __restrict__ p = grp.param;
     const float* __restrict__ g = grp.grad;
     float* __restrict__ m = grp.exp_avg;
     float* __restrict__ v = grp.exp_avg_sq;
-    float pv[4], gv[4], mv[4], vv[4];
-    const bool full = base + 4 <= grp.n;
-    if (full) {
-        *reinterpret_cast<float4*>(pv) = *reinterpret_cast<const float4*>(p + base);
-        *reinterpret_cast<float4*>(gv) = *reinterpret_cast<const float4*>(g + base);
-        *reinterpret_cast<float4*>(mv) = *reinterpret_cast<const float4*>(m + base);
-        *reinterpret_cast<float4*>(vv) = *reinterpret_cast<const float4*>(v + base);
-    } else {
-        for (int k = 0; k < 4; k++)
-            if (base + k < grp.n) { pv[k] = p[base + k]; gv[k] = g[base + k]; mv[k] = m[base + k]; vv[k] = v[base + k]; }
+    float pv[ADAM_UNROLL][4], gv[ADAM_UNROLL][4], mv[ADAM_UNROLL][4], vv[ADAM_UNROLL][4];
+    // every full float4 of this thread first (four arrays x ADAM_UNROLL loads in flight), the ragged tail element-wise
+#pragma unroll
+    for (int u = 0; u < ADAM_UNROLL; u++) {
+        const size_t base = block_base + (size_t)u * 1024;
+        if (base + 4 <= grp.n) {
+            *reinterpret_cast<float4*>(pv[u]) = *reinterpret_cast<const float4*>(p + base);
+            *reinterpret_cast<float4*>(gv[u]) = adam_load(g + base, true);
+            *reinterpret_cast<float4*>(mv[u]) = adam_load(m + base, true);
+            *reinterpret_cast<float4*>(vv[u]) = adam_load(v + base, true);
+        } else {
+            for (int k = 0; k < 4; k++)
+                if (base + k < grp.n) { pv[u][k] = p[base + k]; gv[u][k] = g[base + k]; mv[u][k] = m[base + k]; vv[u][k] = v[base + k]; }
+        }
     }
 #pragma unroll
-    for (int k = 0; k < 4; k++) {
-        // two learning rates per group: elements whose index modulo `period` is below `split` use lr, the rest lr_tail
-        // (one [P,16,3] SH tensor = dc columns + rest columns with different rates, gaussian_model.py:470-471)
-        float lr = grp.lr;
-        if (grp.period != 0 && ((unsigned int)(base + k) % grp.period) >= grp.split) lr = grp.lr_tail;   // n < 2^32
-        gv[k] *= grad_scale;                  // e.g. 1 / world_size after a sum all-reduce
-        mv[k] = mv[k] + (gv[k] - mv[k]) * (1.f - beta1);
-        vv[k] = beta2 * vv[k] + (1.f - beta2) * gv[k] * gv[k];
-        const float denom = sqrtf(vv[k]) * inv_sqrt_bias2 + eps;
-        pv[k] -= (lr / bias1) * (mv[k] / denom);
-    }
-    if (full) {
-        *reinterpret_cast<float4*>(p + base) = *reinterpret_cast<float4*>(pv);
-        *reinterpret_cast<float4*>(m + base) = *reinterpret_cast<float4*>(mv);
-        *reinterpret_cast<float4*>(v + base) = *reinterpret_cast<float4*>(vv);
-    } else {
-        for (int k = 0; k < 4; k++)
-            if (base + k < grp.n) { p[base + k] = pv[k]; m[base + k] = mv[k]; v[base + k] = vv[k]; }
+    for (int u = 0; u < ADAM_UNROLL; u++) {
+        const size_t base = block_base + (size_t)u * 1024;
+        if (base >= grp.n) continue;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            // two learning rates per group: elements whose index modulo `period` is below `split` use lr, the rest lr_tail
+            // (one [P,16,3] SH tensor = dc columns + rest columns with different rates, gaussian_model.py:470-471)
+            float lr = grp.lr;
+            if (grp.period != 0 && ((unsigned int)(base + k) % grp.period) >= grp.split) lr = grp.lr_tail;   // n < 2^32
+            float gk = gv[u][k] * grad_scale;                  // e.g. 1 / world_size after a sum all-reduce
+            mv[u][k] = mv[u][k] + (gk - mv[u][k]) * (1.f - beta1);
+            vv[u][k] = beta2 * vv[u][k] + (1.f - beta2) * gk * gk;
+            const float denom = sqrtf(vv[u][k]) * inv_sqrt_bias2 + eps;
+            pv[u][k] -= (lr / bias1) * (mv[u][k] / denom);
+        }
+        if (base + 4 <= grp.n) {
+            *reinterpret_cast<float4*>(p + base) = *reinterpret_cast<float4*>(pv[u]);
+            adam_store(m + base, mv[u], true);
+            adam_store(v + base, vv[u], true);
+        } else {
+            for (int k = 0; k < 4; k++)
+                if (base + k < grp.n) { p[base + k] = pv[u][k]; m[base + k] = mv[u][k]; v[base + k] = vv[u][k]; }
+        }
     }
 }
 
@@ -1499,7 +1544,7 @@ void launch_adam(hipStream_t s, int n_groups, const r3dg_adam_group* groups, flo
     for (int i = 0; i < n_groups; i++) {
         t.g[i] = groups[i];
         t.first_block[i] = blocks;
-        blocks += (unsigned int)((groups[i].n + 1023) / 1024);
+        blocks += (unsigned int)((groups[i].n + ADAM_BLOCK_FLOATS - 1) / ADAM_BLOCK_FLOATS);
     }
     t.first_block[n_groups] = blocks;
     if (blocks == 0) return;
