@@ -237,6 +237,19 @@ __device__ __forceinline__ void frs_adam_update(const FrsAdam& a, float lr, floa
 
 constexpr int FRS_CHAIN_LD = 49;           // LDS row stride in words
 
+__device__ __forceinline__ float4 frs_nt_load4(const float4* q)
+{
+    return make_float4(__builtin_nontemporal_load(&q->x), __builtin_nontemporal_load(&q->y), __builtin_nontemporal_load(&q->z),
+                       __builtin_nontemporal_load(&q->w));
+}
+__device__ __forceinline__ void frs_nt_store4(float4* q, const float4& v)
+{
+    __builtin_nontemporal_store(v.x, &q->x);
+    __builtin_nontemporal_store(v.y, &q->y);
+    __builtin_nontemporal_store(v.z, &q->z);
+    __builtin_nontemporal_store(v.w, &q->w);
+}
+
 __global__ void __launch_bounds__(256)
 frs_incident_chain_kernel(int P, const float* __restrict__ ray_normals, const uint8_t* __restrict__ valid,
                           const float* __restrict__ dcprime, float* __restrict__ dL_dincidents, float* __restrict__ incidents,
@@ -315,7 +328,8 @@ frs_incident_chain_kernel(int P, const float* __restrict__ ray_normals, const ui
         for (int i = 0; i < 12; i++) {
             const int e4 = i * 64 + lane;
             if (e4 < n4) {
-                float4 p = p4[e4], m = m4[e4], v = v4[e4];
+                // (the moments are touched once per iteration: nontemporal, as in adam_kernel)
+                float4 p = p4[e4], m = frs_nt_load4(m4 + e4), v = frs_nt_load4(v4 + e4);
                 float* d = lds_of(e4);
                 const float4 gr = make_float4(d[0], d[1], d[2], d[3]);
                 const bool dc = (e4 % 12) == 0;                          // this float4 holds columns 0..3 of its row
@@ -323,7 +337,9 @@ frs_incident_chain_kernel(int P, const float* __restrict__ ray_normals, const ui
                 frs_adam_update(adam, dc ? adam.lr : adam.lr_tail, p.y, gr.y, m.y, v.y);
                 frs_adam_update(adam, dc ? adam.lr : adam.lr_tail, p.z, gr.z, m.z, v.z);
                 frs_adam_update(adam, adam.lr_tail, p.w, gr.w, m.w, v.w);
-                p4[e4] = p; m4[e4] = m; v4[e4] = v;
+                p4[e4] = p;
+                frs_nt_store4(m4 + e4, m);
+                frs_nt_store4(v4 + e4, v);
                 g4[e4] = gr;
                 d[0] = p.x; d[1] = p.y; d[2] = p.z; d[3] = p.w;
             }
