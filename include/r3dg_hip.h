@@ -320,6 +320,11 @@ int r3dg_stream_wait_stream(void* waiter, void* signaller);
  * fused_step prices an all-reduce it cannot run on a one-GPU box by queueing this behind each bucket's one-rank (identity)
  * collective, sized to the ring time of an assumed bus bandwidth (R3DG_DP_FAKE_COMM_GBS). */
 int r3dg_spin(void* stream, float microseconds);
+/* *h_pinned_dst = *d_src (8 bytes) behind everything queued on `stream`, written by a one-thread kernel straight into PINNED,
+ * device-mapped host memory (hipHostMalloc / torch's pin_memory()) -- how a caller gets a count off the device without waiting
+ * for it and without the runtime's blit path (an 8-byte hipMemcpyAsync to pinned memory runs as `__amd_rocclr_copyBuffer`, which
+ * showed as 128 us on a hardware queue of the training iteration).  The host reads the slot after synchronising with the stream. */
+int r3dg_store_u64_to_host(void* stream, const void* d_src, void* h_pinned_dst);
 /* Measurement aid: a device-filling grid of VALU-only waves (iters x 16 fp32 FMAs per lane) that read the shader-clock counter and
  * the constant-rate wall clock on both sides.  d_out3[0] += shader cycles, [1] += wall ticks, [2] += waves (zeroed here);
  * shader clock under VALU load = d_out3[0] / d_out3[1] x *wall_clock_khz.  bench.py reports it beside the headline, so that a box

@@ -71,6 +71,7 @@ _SIGNATURES = {
     "r3dg_shade_frs_rotate": (_i, [_p, _i, _p, _p, _p]),
     "r3dg_stream_wait_stream": (_i, [_p, _p]),
     "r3dg_spin": (_i, [_p, _f]),
+    "r3dg_store_u64_to_host": (_i, [_p, _p, _p]),
     "r3dg_shade_frs_build_taps": (_i, [_p, _i, _i, _p, _p, _i, _i, _p]),
     "r3dg_shade_frs_forward": (_i, [_p, _i, _i] + [_p] * 6 + [_i, _i, _p, _f] + [_p] * 6 + [_i, _p, _i, _p, _p, _p]),
     "r3dg_shade_frs_backward": (_i, [_p, _i, _i] + [_p] * 6 + [_i, _i, _p, _f] + [_p] * 6 + [_i] + [_p] * 10 + [_i, _p]),

@@ -1433,6 +1433,21 @@ __global__ void __launch_bounds__(64) spin_kernel(unsigned long long ticks)
     while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(32);
 }
 
+// one thread: *dst = *src (dst: device address of pinned host memory)
+__global__ void store_u64_kernel(const unsigned long long* __restrict__ src, volatile unsigned long long* dst) { *dst = *src; }
+
+int r3dg_store_u64_to_host(void* stream_, const void* d_src, void* h_pinned_dst)
+{
+    if (d_src == nullptr || h_pinned_dst == nullptr) return invalid("store_u64_to_host: null pointer");
+    return guarded([&]() -> int {
+        void* mapped = nullptr;
+        R3DG_HIP(hipHostGetDevicePointer(&mapped, h_pinned_dst, 0));
+        store_u64_kernel<<<1, 1, 0, (hipStream_t)stream_>>>((const unsigned long long*)d_src, (volatile unsigned long long*)mapped);
+        check_launch((hipStream_t)stream_, false, "store_u64_kernel");
+        return R3DG_OK;
+    });
+}
+
 int r3dg_spin(void* stream_, float microseconds)
 {
     if (!(microseconds >= 0.f) || microseconds > 1e6f) return invalid("spin: 0 .. 1e6 microseconds");

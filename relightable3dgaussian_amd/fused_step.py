@@ -205,11 +205,14 @@ class _BoundedForward:
         if used_bounded:
             # (on the ordering stream, which wrote the count and is idle by now: 5 us that would sit between the backward and Adam)
             side = getattr(self, "_order_stream", None)
-            if side is not None and self.dev.type == "cuda":
-                with torch.cuda.stream(side):
-                    slot.copy_(rasterizer_ops.num_rendered_of(geom, self.P), non_blocking=True)
+            count = rasterizer_ops.num_rendered_of(geom, self.P)
+            if self.dev.type == "cuda":
+                # (a one-thread kernel storing into the pinned slot: the runtime's 8-byte copy ran as __amd_rocclr_copyBuffer and
+                # held a hardware queue for up to 128 us of the step)
+                stream = side if side is not None else torch.cuda.current_stream(self.dev)
+                _lib.check(_lib.lib().r3dg_store_u64_to_host(stream.cuda_stream, count.data_ptr(), slot.data_ptr()), "store_u64_to_host")
             else:
-                slot.copy_(rasterizer_ops.num_rendered_of(geom, self.P), non_blocking=True)
+                slot.copy_(count, non_blocking=True)
         else:
             slot.fill_(int(R))
             if self.bounded:
