@@ -680,8 +680,10 @@ def dp_path_one_rank(args, timeout_s=180, fake_comm_gbs=None, steps=None):
         doc = _finite_json(json.loads(line[-1]))
         if fake_comm_gbs is not None:
             return dict(assumed_bus_GBs=fake_comm_gbs, iters_per_s_one_rank=doc["value"], ms_per_step=doc["ms_per_step"],
-                        exposed_comm_ms=doc.get("exposed_comm_ms"), predicted_8gpu_iters_per_s=round(8.0 * doc["value"], 1))
+                        exposed_comm_ms=doc.get("exposed_comm_ms"), exposed_comm_ms_by_bucket=doc.get("exposed_comm_ms_by_bucket"),
+                        comm_buckets=doc.get("comm_buckets"), predicted_8gpu_iters_per_s=round(8.0 * doc["value"], 1))
         return dict(iters_per_s=doc["value"], ms_per_step=doc["ms_per_step"], exposed_comm_ms=doc.get("exposed_comm_ms"),
+                    exposed_comm_ms_by_bucket=doc.get("exposed_comm_ms_by_bucket"), comm_buckets=doc.get("comm_buckets"),
                     reserved_cus_for_comm=doc.get("reserved_cus_for_comm"),
                     what="the same iteration through the data-parallel path over a ONE-rank RCCL group (identity collectives; "
                          "the persistent kernels leave `reserved_cus_for_comm` CUs to RCCL)")

@@ -4,8 +4,8 @@
 # pass) and SQ counters (ONE group per pass), every pass with --kernel-trace only -- on the kernels as the ITERATION launches them
 # (tools/kbench_raster.py ACTIVE=2,3,4 NODEPTH=1; tools/kbench_shade.py) and on the relight frame, the tile backward's ablation
 # builds, the default bench line.  Outputs: gpurun_out/<round>_*; the summaries to be judged are copied to profiles/ afterwards.
-#   ROUND=r05 bash tools/round_end_gpu_job.sh [quick]      ("quick": no full pytest run)
-RD=${ROUND:-r05}
+#   ROUND=r06 bash tools/round_end_gpu_job.sh [quick]      ("quick": no full pytest run)
+RD=${ROUND:-r06}
 cd "${GRAFT_REPO_ROOT:-/root/repo}" || exit 1
 mkdir -p gpurun_out
 export TMPDIR=/tmp HSA_ENABLE_IPC_MODE_LEGACY=0 OMP_NUM_THREADS=8 MKL_NUM_THREADS=8      # (threads: the container's CPU quota, see bench.py)
@@ -87,6 +87,9 @@ python tools/pmc_traffic.py $O/${RD}_pmc_traffic_relight.json "the same command,
 if [ -d relightable3dgaussian_amd/lib/variants/bwd_no_atomics ]; then
   timeout 300 python tools/variants_bwd.py run > $O/${RD}_bwd_ablation_product.txt 2>&1; cat $O/${RD}_bwd_ablation_product.txt | cut -c1-200
 fi
+# ---- Adam cold (the last-level cache evicted between launches) and the L2 / fabric request counters of the tile kernels
+timeout 200 python tools/kbench_adam.py < /dev/null > $O/${RD}_adam_cold.txt 2>&1; tail -2 $O/${RD}_adam_cold.txt
+ROUND=$RD bash tools/gpu_job.sh pmc l2_raster "TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_EA0_RDREQ_64B_sum TCC_EA0_RDREQ_128B_sum" "TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum TCC_WRITE_sum TCC_WRITEBACK_sum" "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_READ_sum" -- env ACTIVE=2,3,4 NODEPTH=1 ITERS=4 python $R/tools/kbench_raster.py > /dev/null 2>&1
 # ---- the default bench line (the counter files the line quotes must be the ones just collected: they are read from profiles/)
 cp $O/${RD}_pmc_valu.json $O/${RD}_pmc_traffic.json $O/${RD}_pmc_valu_relight.json $O/${RD}_pmc_traffic_relight.json profiles/
 timeout 900 python bench.py < /dev/null > $O/${RD}_bench_default.out 2> $O/${RD}_bench_default.err; tail -1 $O/${RD}_bench_default.out > $O/${RD}_bench_default_compact.json

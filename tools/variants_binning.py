@@ -1,10 +1,12 @@
 #!/usr/bin/env python
-"""Ablation builds of the direct tile binning's count kernel (tools/build_variant.py; the variants' RESULTS ARE WRONG -- they exist to
-attribute the kernel's time at 2M Gaussians, where it takes 0.25 ms for 24 MB of input):
-    count_no_flush     the per-(workgroup, tile) global atomics removed
-    count_no_hist      the LDS histogram pass removed (zero fill + flush stay)
+"""Ablation builds of the direct tile binning's kernels (tools/build_variant.py; the variants' RESULTS ARE WRONG -- they exist to
+attribute the kernels' time at 2M Gaussians, where count + emit take 0.18 + 0.34 ms inside the iteration):
+    count_no_flush     count: the per-(workgroup, tile) global atomics removed
+  (Ablations of the EMIT kernel were tried in round 6 and removed: entries that are missing or misplaced leave uninitialised
+  Gaussian indices in the tile lists, and the tile kernels behind them fault on the gathers -- a wrong-result variant is only safe
+  when everything downstream becomes empty, as with count_no_flush.)
     python tools/variants_binning.py build
-    python tools/variants_binning.py run      # GPU box: rocprofv3 kernel stats of a forward at 2M per variant
+    python tools/variants_binning.py run      # GPU box: stage times of a forward at 2M per variant (tools/kbench_raster.py)
 """
 import os
 import subprocess
@@ -15,8 +17,6 @@ sys.path.insert(0, ROOT)
 SRC = "rasterizer_preprocess.hip"
 VARIANTS = {
     "count_no_flush": [("        if (c) atomicAdd(&tile_counts[t], c);\n", "        if (c == 0xffffffffu) atomicAdd(&tile_counts[t], c);\n")],
-    "count_no_hist": [("                          [&](uint32_t tile, uint32_t, uint32_t) { atomicAdd(&s_bins[tile], 1u); });\n    __syncthreads();\n    for (int t = threadIdx.x; t < T; t += BIN_THREADS) {\n        const uint32_t c = s_bins[t];\n        if (c) atomicAdd(&tile_counts[t], c);",
-                       "                          [&](uint32_t tile, uint32_t, uint32_t) { if (tile == 0xffffffffu) atomicAdd(&s_bins[tile & 1023u], 1u); });\n    __syncthreads();\n    for (int t = threadIdx.x; t < T; t += BIN_THREADS) {\n        const uint32_t c = s_bins[t] + 1u;\n        if (c) atomicAdd(&tile_counts[t], c);")],
 }
 
 
@@ -29,7 +29,7 @@ def build():
 def run():
     from tools.build_variant import VARIANTS as VDIR
     for name in [None] + list(VARIANTS):
-        env = dict(os.environ, P="2000000", W="1800", H="700", ITERS="6")
+        env = dict(os.environ, P="2000000", RES="1120", ITERS="6")          # (1120^2 ~ the 1800x700 pixels of the composition configuration)
         if name:
             env["R3DG_LIB_PATH"] = os.path.join(VDIR, name, "libr3dg_hip.so")
         r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "kbench_raster.py")], env=env, capture_output=True, text=True)
