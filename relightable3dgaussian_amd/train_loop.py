@@ -146,15 +146,15 @@ def train_stage1(init, cameras, images, background, extent, schedule=None, itera
                 step.iteration = it - 1       # (__call__ advances it: EVERY replayed view runs with this iteration's schedule weight)
                 return cameras[w], background, images[w], None if masks is None else masks[w]
             # on_iteration(it, step) must still see iteration `it`'s outputs, not those of the last replayed view
-            keep = (step.last_outs, getattr(step, "viewspace_grad", None))
+            keep = (getattr(step, "last_outs", None), getattr(step, "viewspace_grad", None))
             redone = step.replay_dropped(inputs_of)
             step.iteration = it
             step.last_outs, step.viewspace_grad = keep
             if redone:
                 history.append((it, "replayed_views", redone))
         # forward passes the last poll has looked at and not reported as dropped can never be replayed: forget their views
-        pending = set(step.dropped_iterations)
-        for k in [k for k in view_of if k <= step._drop_polled and k not in pending]:
+        pending = set(getattr(step, "dropped_iterations", ()))
+        for k in [k for k in view_of if k <= getattr(step, "_drop_polled", 0) and k not in pending]:
             del view_of[k]
         if on_iteration is not None:
             on_iteration(it, step)
