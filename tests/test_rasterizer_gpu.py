@@ -409,6 +409,71 @@ def test_tile_binned_order_falls_back_above_the_lds_histogram(hip_lib):
         assert torch.equal(torch.as_tensor(sa[k]), torch.as_tensor(sb[k])), k
 
 
+def _same_lists_as_the_global_sort(case):
+    a = _run_forward(case)
+    _opt(TILE_BINNING=0)
+    try:
+        b = _run_forward(case)
+    finally:
+        _opt(TILE_BINNING=2)
+    torch.cuda.synchronize()
+    from relightable3dgaussian_amd.rasterizer_ops import decode_state
+    P, H, W = case["P"], case["H"], case["W"]
+    assert a[0] == b[0] and a[0] > 0
+    sa, sb = decode_state(a[10], a[11], a[12], P, a[0], H, W), decode_state(b[10], b[11], b[12], P, b[0], H, W)
+    for k in ("keys", "point_list", "ranges", "point_offsets"):
+        assert torch.equal(torch.as_tensor(sa[k]), torch.as_tensor(sb[k])), k
+    return a, sa
+
+
+def test_tile_binned_order_large_rectangles_clustered_at_low_indices(hip_lib):
+    """What a densified scene looks like to the binning kernels (round 6): the oldest Gaussians sit at the lowest indices and are
+    the largest.  The first 3 000 of 30 000 splats are 25 x larger (hundreds to thousands of tiles each, some the whole grid):
+    the wave chunks dealt round robin over the workgroups and the workgroup-shared list of rectangles above 32 tiles must give
+    the lists of the global sort -- with P not a multiple of 64 or of a workgroup's share."""
+    case = make_case(P=30011, W=800, H=800, S=0, scale_log_mean=-3.6, seed=131)
+    case["scales"] = case["scales"].clone()
+    case["scales"][:3000] *= 25.0
+    a, st = _same_lists_as_the_global_sort(case)
+    touched = torch.as_tensor(st["tiles_touched"]).long()
+    assert int((touched[:3000] > 32).sum()) > 2000 and int(touched.max()) >= 2000         # the case is what it claims to be
+    # ... and with EVERY rectangle of a workgroup large (2048 list entries per workgroup: the list's capacity)
+    case["scales"][:] = case["scales"].clamp_min(0.5)
+    small = dict(case, P=4100)
+    for k in ("means3D", "features", "opacity", "scales", "rotations", "shs"):
+        small[k] = case[k][:4100].contiguous()
+    _same_lists_as_the_global_sort(small)
+
+
+def test_tile_binned_order_at_the_lds_limit(hip_lib):
+    """2048 x 2048 = 16 384 tiles: the largest grid the direct binning takes -- 64 KB of LDS counters + the list of large
+    rectangles behind them, i.e. more dynamic LDS than a launch may ask for without the per-device function attribute."""
+    case = make_case(P=9001, W=2048, H=2048, S=0, scale_log_mean=-2.4, seed=137)
+    case["scales"] = case["scales"].clone()
+    case["scales"][:200] *= 12.0
+    _same_lists_as_the_global_sort(case)
+
+
+def test_release_scratch_and_count_store(hip_lib):
+    """r3dg_release_scratch frees the library's per-(device, stream) buffers and the next call allocates them again;
+    r3dg_store_u64_to_host writes 8 bytes into pinned host memory behind the stream's work."""
+    import ctypes as C
+    from relightable3dgaussian_amd import _lib
+    case = make_case(P=3000, W=128, H=128, S=5, seed=11)
+    before = _run_forward(case)
+    torch.cuda.synchronize()
+    assert hip_lib.r3dg_release_scratch() == 0
+    after = _run_forward(case)
+    torch.cuda.synchronize()
+    assert before[0] == after[0] and torch.equal(before[2], after[2])
+    src = torch.tensor([0x1122334455667788], dtype=torch.int64, device=DEV)
+    ring = torch.zeros(4, dtype=torch.int64).pin_memory()
+    _lib.check(hip_lib.r3dg_store_u64_to_host(_lib.current_stream(), src.data_ptr(), ring[2:].data_ptr()), "store")
+    torch.cuda.synchronize()
+    assert ring.tolist() == [0, 0, 0x1122334455667788, 0]
+    assert hip_lib.r3dg_store_u64_to_host(_lib.current_stream(), None, ring.data_ptr()) != 0      # NULL source: R3DG_EINVAL
+
+
 def test_full_size_properties(hip_lib):
     """BASELINE size (300k Gaussians, 800x800, S=16): size-independent properties of the forward state and outputs, and
     linearity of the backward in its upstream gradient."""
