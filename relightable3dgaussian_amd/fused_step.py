@@ -401,6 +401,7 @@ class FusedStage2Step(_BoundedForward):
         self._acc = None                            # the tile backward's accumulator slab, zero-filled off the critical path
         self._early_pending = False                 # the early-Adam stream holds work no other stream has been ordered behind yet
         self._b_early = False
+        self._a_late = False
         # softplus of the environment texture, refreshed behind the Adam launch that updates the texture (see optimizer_step)
         self._env_c = None                          # softplus(environment texture), see _env_buffer
         self._zero_depth_grad = None
@@ -612,7 +613,7 @@ class FusedStage2Step(_BoundedForward):
         return self._adam_stream
 
     @_in_context
-    def forward_backward(self, cam, bg, gt, early_adam=False, image_mask=None, split_geometry=None):
+    def forward_backward(self, cam, bg, gt, early_adam=False, image_mask=None, split_geometry=None, chain_incidents=False):
         """One forward + loss + backward; gradients land in self.grads.  Returns the rasterizer's 10 public outputs.
         `image_mask` [1,H,W]: the view's object mask (Camera.image_mask; None = all ones) of the normal and smoothness terms.
         `early_adam` (single-GPU whole iterations only, see __call__): the SH colour coefficients, whose gradient is final
@@ -621,6 +622,9 @@ class FusedStage2Step(_BoundedForward):
         `split_geometry` (default: `early_adam`): the rasterizer's per-Gaussian geometry backward on the early stream, beside the
         gradient unpack and the listed Gaussians' shading backward.  (Measured on its own at 2M Gaussians, where the early Adam is
         off: 160.7 vs 166.3 it/s -- both kernels stream from HBM there and slow each other by more than the overlap buys.)"""
+        # `chain_incidents` (whole iterations only, see __call__; implied by `early_adam`): the incident-light gradient may stay in the
+        # rotated frame for the chain kernel that optimizer_step launches -- a caller of a bare forward_backward reads
+        # grads["incidents"] in the world frame, always
         if split_geometry is None:
             split_geometry = early_adam
         L = _lib.lib()
@@ -867,6 +871,21 @@ class FusedStage2Step(_BoundedForward):
                 self._early = True
                 self._early_pending = True
                 self._b_early = True
+            elif (chain_incidents and not early_adam and not self.dp and not self.serial_streams and self._groups_b and self._defer_b and self._chain_kernel
+                  and self._frs is not None and order_stream is not None and use_bounded
+                  and os.environ.get("R3DG_CHAIN_WITHOUT_EARLY_ADAM", "1") != "0"):
+                # above a million Gaussians (no early Adam of the SH group: __call__) the incident-light chain all the same, as ONE
+                # kernel on the early stream behind the other groups' Adam (round 6): at 2M Gaussians the three launches it replaces
+                # -- rotation back, the incident-light group's share of the Adam launch, rotation of the new coefficients at the top
+                # of the next iteration -- stream 2112 bytes per Gaussian, the chain 1741, with every access a contiguous run per wave
+                if self._adam_stream is None:
+                    self._adam_stream = shared_stream(dev, "early")
+                self.opt.begin_step()
+                self._early_stream = self._adam_stream
+                self._early = True
+                self._early_pending = True
+                self._b_early = True
+                self._a_late = True              # (the SH group was NOT updated early: optimizer_step takes it with the others)
             elif early_adam and handle_a is not None and self._groups_a:
                 # data parallel: the same update on the side stream, behind bucket A's all-reduce -- whenever that lands
                 # while the shading backward is still running, the SH group's Adam runs under it too (measured with a
@@ -1129,7 +1148,8 @@ class FusedStage2Step(_BoundedForward):
                 # the SH group was updated under the shading backward and the incident-light group is being updated on the early
                 # stream (forward_backward, "incident-light chain"): no join here
                 self._early = self._b_early = False
-                todo = self._groups_c
+                todo = (self._groups_a if self._a_late else ()) + self._groups_c
+                self._a_late = False
             elif self._early:            # the SH group was updated under the shading backward (forward_backward)
                 _lib.stream_wait(torch.cuda.current_stream(), self._early_stream)
                 self._early = False
@@ -1195,7 +1215,7 @@ class FusedStage2Step(_BoundedForward):
         # 256 MB last-level cache (300k Gaussians: 58 us of Adam for 31 us of slower shading backward); streamed from HBM it
         # costs the latency-sensitive shading kernel nearly its whole duration (2M: 0.99 ms of Adam for +0.85 ms, 159 vs 163 it/s)
         early = os.environ.get("R3DG_EARLY_ADAM", "1" if self.P <= 1_000_000 else "0") != "0" and not self.serial_streams
-        outs = self.forward_backward(cam, bg, gt, early_adam=early, image_mask=image_mask)
+        outs = self.forward_backward(cam, bg, gt, early_adam=early, image_mask=image_mask, chain_incidents=True)
         self.optimizer_step()
         return outs
 

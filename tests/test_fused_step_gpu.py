@@ -423,6 +423,40 @@ def test_bounded_iterations_equal_two_phase_iterations():
         assert ok, msg
 
 
+def test_every_schedule_of_the_whole_iteration_trains_alike(monkeypatch):
+    """A whole iteration picks one of several schedules for its two large parameter groups: the SH group's Adam under the shading
+    backward or with the others (R3DG_EARLY_ADAM: the size rule takes the second above a million Gaussians), the incident-light
+    chain as one kernel, as three launches, or not at all (round 6: also WITHOUT the early Adam, what a 2M-Gaussian scene runs).
+    Same losses and parameters after five iterations up to the order of the float atomics and the chain kernel's fast-math Adam."""
+    from relightable3dgaussian_amd.fused_step import FusedStage2Step
+    P, res, K = 4000, 128, 16
+    settings = {"default": {}, "no early Adam, chain kernel": {"R3DG_EARLY_ADAM": "0"},
+                "no early Adam, no chain": {"R3DG_EARLY_ADAM": "0", "R3DG_CHAIN_WITHOUT_EARLY_ADAM": "0"},
+                "early Adam, three launches": {"R3DG_INCIDENT_CHAIN_KERNEL": "0"}}
+    runs = {}
+    for name, env in settings.items():
+        for k in ("R3DG_EARLY_ADAM", "R3DG_CHAIN_WITHOUT_EARLY_ADAM", "R3DG_INCIDENT_CHAIN_KERNEL"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        params, ref, fused, cam, bg, gt = _setup(P=P, res=res, K=K, seed=11)
+        step = FusedStage2Step(params, K, lr=1e-3)
+        losses = []
+        for it in range(5):
+            step(cam, bg, gt)
+            losses.append(float(step.loss()))
+        assert step._frs is not None, "the fixed-ray-set path must be the one under test"
+        if name == "no early Adam, chain kernel":
+            assert step._pre_rotated is not None, "the chain kernel did not run"
+        runs[name] = (losses, step.shs.clone(), step.incidents.clone(), step.base_color.clone(), step.xyz.clone())
+    base = runs["default"]
+    for name, r in runs.items():
+        assert np.allclose(r[0], base[0], rtol=2e-5), (name, r[0], base[0])
+        for i in (1, 2, 3, 4):
+            ok, msg = report("%s: param %d" % (name, i), r[i], base[i], 1e-4, 1e-6)
+            assert ok, msg
+
+
 def test_feature_rows_written_in_place_equal_the_packed_rows(monkeypatch):
     """Without r3dg_stage2_pack_features (the default when the fixed-ray-set kernels run): r3dg_stage2_activate writes the nine
     columns of the [P,16] feature rows that do not wait for the shading integral, r3dg_shade_frs_forward (main and listed
