@@ -64,19 +64,29 @@ def spawn_ranks(ns, argv, entry):
         log = None if r == 0 else open(os.path.join(logdir, "rank%d.log" % r), "w")
         procs.append((subprocess.Popen([sys.executable, entry] + list(argv), env=env, stdin=subprocess.DEVNULL,
                                        stdout=log, stderr=subprocess.STDOUT if log else None), log))
-    code = 0
-    for r, (p, log) in enumerate(procs):
-        rc = p.wait()
+    # poll ALL ranks: a rank that dies leaves the others waiting in a collective -- possibly for ever -- so the first non-zero
+    # exit ends the run, whichever rank it was
+    import time
+    code, failed, live = 0, None, set(range(ns.dp))
+    while live:
+        for r in sorted(live):
+            rc = procs[r][0].poll()
+            if rc is None:
+                continue
+            live.discard(r)
+            if rc != 0 and code == 0:
+                code, failed = rc, r
+                for q, _ in procs:
+                    if q.poll() is None:
+                        q.terminate()
+        if live:
+            time.sleep(0.2)
+    for p, log in procs:
         if log:
             log.close()
-        if rc != 0 and code == 0:
-            code = rc
-            for q, _ in procs:                       # a rank died: the others would wait in a collective forever
-                if q.poll() is None:
-                    q.terminate()
-            if r > 0:
-                sys.stderr.write("[run_reference] rank %d failed (%d):\n%s\n" % (
-                    r, rc, open(os.path.join(logdir, "rank%d.log" % r)).read()[-4000:]))
+    if failed is not None and failed > 0:
+        sys.stderr.write("[run_reference] rank %d failed (%d):\n%s\n" % (
+            failed, code, open(os.path.join(logdir, "rank%d.log" % failed)).read()[-4000:]))
     return code
 
 
