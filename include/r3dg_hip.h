@@ -137,11 +137,6 @@ int r3dg_rasterize_forward_begin_bounded(void* stream, r3dg_alloc_fn geometry_al
                                          void* ordering_stream, long long capacity, float* d_overflow_flag,
                                          unsigned int* d_overflow_count, void** ticket);
 int r3dg_rasterize_forward_finish_bounded(void* ticket, void* main_stream);
-/* Between _begin[_bounded] and _finish: orders `stream` behind the PROJECTION kernel of this forward (an event recorded right
- * behind it on the stream it was queued on), not behind the instance ordering queued after it.  For a caller that wants to start
- * bandwidth-hungry side work only once the projection -- the head of the forward's critical chain -- has had the memory system to
- * itself (the fused iteration above a million Gaussians: the incident-light chain kernel). */
-int r3dg_rasterize_forward_wait_projection(void* ticket, void* stream);
 
 /* Backward.  d_dL_dpix_d == NULL: the depth image carries no gradient (the caller's promise; the tile kernel then takes its
  * instances without a depth slot).  Every output is FULLY WRITTEN (zeros for invisible Gaussians, for feature channels outside

@@ -40,7 +40,6 @@ _SIGNATURES = {
                                             _p, _p, _p, _f, _p, _p, _p, _p, _p, _f, _f, _f, _f, _i, _i, _p, _p, _p, _p,
                                             _p, _p, _p, _p, _i, _p, C.c_longlong, _p, _p, C.POINTER(_p)]),
     "r3dg_rasterize_forward_finish_bounded": (_i, [_p, _p]),
-    "r3dg_rasterize_forward_wait_projection": (_i, [_p, _p]),
     "r3dg_rasterize_forward_finish": (_i, [_p, C.POINTER(_i)]),
     "r3dg_rasterize_forward_finish_on": (_i, [_p, _p, C.POINTER(_i)]),
     "r3dg_rasterize_backward": (_i, [_p, _i, _i, _i, _i, _i, _p, _i, _i, _p, _p, _p, _p, _p, _f, _p, _p, _p, _p, _p,

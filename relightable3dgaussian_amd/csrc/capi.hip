@@ -665,7 +665,6 @@ struct ForwardTicket {
     int32_t* radii_p;
     char *gbuf, *ibuf;
     hipEvent_t ready, ordered;           // two-phase forward: the count has arrived | bounded forward: the ordering is queued
-    hipEvent_t projected;                // behind the projection kernel on the stream it was queued on (r3dg_rasterize_forward_wait_projection)
     unsigned long long* host_total;      // pinned
     // bounded forward (r3dg_rasterize_forward_begin_bounded): the binning state is laid out for `capacity` instances, the
     // ordering was enqueued by _begin_ and `ready` marks its end; capacity < 0: the exact two-phase forward
@@ -692,7 +691,6 @@ static ForwardTicket* ticket_acquire()
     ForwardTicket* t = new ForwardTicket();
     R3DG_HIP(hipEventCreateWithFlags(&t->ready, hipEventDisableTiming));     // (the host synchronises on this one: system scope)
     R3DG_HIP(hipEventCreateWithFlags(&t->ordered, event_flags()));
-    R3DG_HIP(hipEventCreateWithFlags(&t->projected, event_flags()));
     R3DG_HIP(hipHostMalloc((void**)&t->host_total, sizeof(unsigned long long), hipHostMallocDefault));
     return t;
 }
@@ -785,7 +783,6 @@ static int forward_begin_impl(void* stream_, r3dg_alloc_fn geometry_alloc, r3dg_
                           !t->fused_front, zero_words, zero_n);
         check_launch(order_stream, debug, "preprocess");
         t_pre.stop();
-        R3DG_HIP(hipEventRecord(t->projected, order_stream));
 
         t->stream = stream; t->binning_alloc = binning_alloc; t->user = user;
         t->P = P; t->S = S; t->D = D; t->M = M; t->width = width; t->height = height;
@@ -851,16 +848,6 @@ int r3dg_rasterize_forward_begin_bounded(void* stream_, r3dg_alloc_fn geometry_a
     return forward_begin_impl(R3DG_FORWARD_ARGS, capacity, overflow_flag, overflow_count, ordering_stream);
 }
 #undef R3DG_FORWARD_ARGS
-
-int r3dg_rasterize_forward_wait_projection(void* ticket_, void* stream_)
-{
-    if (!ticket_) return R3DG_OK;                // P == 0: nothing was queued
-    ForwardTicket* t = (ForwardTicket*)ticket_;
-    return guarded([&]() -> int {
-        R3DG_HIP(hipStreamWaitEvent((hipStream_t)stream_, t->projected, 0));
-        return R3DG_OK;
-    });
-}
 
 int r3dg_rasterize_forward_finish_bounded(void* ticket_, void* main_stream_)
 {

@@ -464,7 +464,6 @@ class FusedStage2Step(_BoundedForward):
         self._chain_kernel = os.environ.get("R3DG_INCIDENT_CHAIN_KERNEL", "1") != "0"   # (A/B: one kernel or three launches)
         self._chain_late = os.environ.get("R3DG_INCIDENT_CHAIN_LATE", "1") != "0"       # (A/B: behind the other groups' Adam)
         self._chain_deferred = None
-        self._chain_wait_projection = False         # the deferred chain is launched by the NEXT forward, behind its projection
         self._leave_room = os.environ.get("R3DG_SHADE_LEAVE_ROOM", "auto")          # (A/B: "1" / "0" = one workgroup per CU for the shading forward always / never)
         self.opt = FusedAdam([
             dict(param=self.xyz, lr=rate("xyz")), dict(param=self.normal, lr=rate("normal")),
@@ -646,15 +645,11 @@ class FusedStage2Step(_BoundedForward):
             acc_ready = False
             aux = self._aux_stream()
             chained = False          # this iteration's rotated coefficients come from the previous iteration's incident-light chain
-            # a chain kernel that optimizer_step left for THIS forward to launch behind its projection (see optimizer_step)
-            chain_behind_projection = self._chain_deferred if (self._chain_deferred is not None and self._chain_wait_projection
-                                                               and aux is not None) else None
-            if self._chain_deferred is not None and chain_behind_projection is None:
+            if self._chain_deferred is not None:
                 self.flush()         # (forward_backward was called twice without optimizer_step: the pending chain runs now)
             if aux is not None:
                 _lib.stream_wait(aux, main)
-                # (a chain that is still to be launched WILL leave the rotation of the updated coefficients in the ray set)
-                chained = chain_behind_projection is not None or self._rotation_is_current()
+                chained = self._rotation_is_current()
                 if not chained:                              # (normally done at the end of the previous iteration: see below)
                     with torch.cuda.stream(aux):
                         self._frs.rotate(self._incidents)
@@ -695,16 +690,6 @@ class FusedStage2Step(_BoundedForward):
                     cam.full_proj_transform, cam.tanfovx, cam.tanfovy, cam.cx, cam.cy, H, W, self.shs, 3, campos, False,
                     True, False, want_weights=False,       # (stage 2 does not densify: nobody reads the blend weights)
                     defer_pseudo_normal=True)
-            if chain_behind_projection is not None:
-                # the incident-light chain of the PREVIOUS iteration (rotation back + Adam + rotation of the new coefficients:
-                # 1741 bytes per Gaussian), launched only now and ordered behind this forward's projection: above a million
-                # Gaussians the ordering chain is the long path of the forward window, and the projection at its head took 0.60 ms
-                # beside the chain kernel where it takes 0.19 ms alone (both stream from HBM)
-                self._chain_deferred = None
-                self._chain_wait_projection = False
-                if use_bounded and order_stream is not None:
-                    pending.wait_projection(self._early_stream)
-                chain_behind_projection()
             if self._pending_b is not None:
                 self.flush()    # (world > 1) the previous iteration's incident-light update lands here
             if aux is not None:
@@ -901,7 +886,6 @@ class FusedStage2Step(_BoundedForward):
                 self._early_pending = True
                 self._b_early = True
                 self._a_late = True              # (the SH group was NOT updated early: optimizer_step takes it with the others)
-                self._chain_wait_projection = os.environ.get("R3DG_CHAIN_BEHIND_PROJECTION", "1") != "0"
             elif early_adam and handle_a is not None and self._groups_a:
                 # data parallel: the same update on the side stream, behind bucket A's all-reduce -- whenever that lands
                 # while the shading backward is still running, the SH group's Adam runs under it too (measured with a
@@ -1176,11 +1160,9 @@ class FusedStage2Step(_BoundedForward):
                 todo = self._groups_a + self._groups_c + self._groups_b
             if todo:                     # ONE launch for every remaining group
                 self.opt.step_groups(todo, grads, skip_flag=self._skip_cur)
-            if self._chain_deferred is not None and not self._chain_wait_projection:
+            if self._chain_deferred is not None:
                 run, self._chain_deferred = self._chain_deferred, None
                 run()
-            # (else: the next forward_backward launches it behind its projection; flush() / the `incidents` property run it at
-            # once for anybody who asks for the coefficients in between)
             return
         # data parallel: update each bucket when its (sum) all-reduce has landed; 1/world is applied inside the kernel
         scale = 1.0 / self.world
@@ -1216,7 +1198,6 @@ class FusedStage2Step(_BoundedForward):
         on the early-Adam stream gets the CURRENT stream ordered behind it (no host wait).  A no-op otherwise."""
         if self._chain_deferred is not None:          # (somebody asks for the coefficients between forward_backward and optimizer_step)
             run, self._chain_deferred = self._chain_deferred, None
-            self._chain_wait_projection = False
             run()
         if self._early_pending:
             _lib.stream_wait(torch.cuda.current_stream(self.dev), self._early_stream)

@@ -65,12 +65,6 @@ class _PendingForward:
         self.ticket, self.rs, self.outs, self.dev, self.H, self.W = ticket, rs, outs, dev, H, W
         self.capacity = capacity
 
-    def wait_projection(self, stream):
-        """Order torch stream `stream` behind this forward's projection kernel (not behind the ordering queued after it)."""
-        with torch.cuda.device(self.dev):
-            _lib.check(_lib.lib().r3dg_rasterize_forward_wait_projection(self.ticket, C.c_void_p(stream.cuda_stream)),
-                       "rasterize_forward_wait_projection")
-
     def finish(self, ordering_stream=None):
         """`ordering_stream`: optional torch stream for the instance ordering (sort) part, which then overlaps whatever
         was queued on the forward's stream since begin; the binning buffer is allocated from that stream's pool.

@@ -426,18 +426,16 @@ def test_bounded_iterations_equal_two_phase_iterations():
 def test_every_schedule_of_the_whole_iteration_trains_alike(monkeypatch):
     """A whole iteration picks one of several schedules for its two large parameter groups: the SH group's Adam under the shading
     backward or with the others (R3DG_EARLY_ADAM: the size rule takes the second above a million Gaussians), the incident-light
-    chain as one kernel, as three launches, or not at all (round 6: also WITHOUT the early Adam, what a 2M-Gaussian scene runs -- launched
-    by the next forward behind its projection, or at once).
+    chain as one kernel, as three launches, or not at all (round 6: also WITHOUT the early Adam, what a 2M-Gaussian scene runs).
     Same losses and parameters after five iterations up to the order of the float atomics and the chain kernel's fast-math Adam."""
     from relightable3dgaussian_amd.fused_step import FusedStage2Step
     P, res, K = 4000, 128, 16
     settings = {"default": {}, "no early Adam, chain kernel": {"R3DG_EARLY_ADAM": "0"},
-                "no early Adam, chain kernel at once": {"R3DG_EARLY_ADAM": "0", "R3DG_CHAIN_BEHIND_PROJECTION": "0"},
                 "no early Adam, no chain": {"R3DG_EARLY_ADAM": "0", "R3DG_CHAIN_WITHOUT_EARLY_ADAM": "0"},
                 "early Adam, three launches": {"R3DG_INCIDENT_CHAIN_KERNEL": "0"}}
     runs = {}
     for name, env in settings.items():
-        for k in ("R3DG_EARLY_ADAM", "R3DG_CHAIN_WITHOUT_EARLY_ADAM", "R3DG_INCIDENT_CHAIN_KERNEL", "R3DG_CHAIN_BEHIND_PROJECTION"):
+        for k in ("R3DG_EARLY_ADAM", "R3DG_CHAIN_WITHOUT_EARLY_ADAM", "R3DG_INCIDENT_CHAIN_KERNEL"):
             monkeypatch.delenv(k, raising=False)
         for k, v in env.items():
             monkeypatch.setenv(k, v)
@@ -449,11 +447,7 @@ def test_every_schedule_of_the_whole_iteration_trains_alike(monkeypatch):
             losses.append(float(step.loss()))
         assert step._frs is not None, "the fixed-ray-set path must be the one under test"
         if name == "no early Adam, chain kernel":
-            # (round 6) the last iteration's chain is still waiting for the NEXT forward's projection: asking for the coefficients
-            # launches it at once
-            assert step._chain_deferred is not None and step._chain_wait_projection
-            step.incidents
-            assert step._chain_deferred is None and step._pre_rotated is not None, "the chain kernel did not run"
+            assert step._pre_rotated is not None, "the chain kernel did not run"
         runs[name] = (losses, step.shs.clone(), step.incidents.clone(), step.base_color.clone(), step.xyz.clone())
     base = runs["default"]
     for name, r in runs.items():
