@@ -190,3 +190,27 @@ def test_bench_gpus_flag_fails_loudly_without_enough_devices():
 def test_bench_rejects_world_size_mismatch():
     r, doc = _run_bench(["--gpus", "4", "--plumbing-only"], env={"WORLD_SIZE": "1", "RANK": "0"})
     assert r.returncode != 0 and "WORLD_SIZE" in (r.stderr + r.stdout)
+
+
+def test_bench_config_presets_fill_in_what_the_command_line_left_open(monkeypatch):
+    """`--config teaser8` = BASELINE configs[4] (2M Gaussians, 1800x700, relight at sample_num 384); `--config dtu4` = configs[3]
+    (1600x1200, run_dtu.sh objective, sample_num 32).  A flag given on the command line wins over the preset, in either order
+    and in both spellings."""
+    import importlib.util
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_under_test", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "8", "--config", "teaser8"])
+    a = bench.parse()
+    assert (a.points, a.width, a.height, a.relight_samples, a.gpus, a.sample_num) == (2_000_000, 1800, 700, 384, 8, 64)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--points=500000", "--config", "teaser8", "--relight-samples", "128"])
+    a = bench.parse()
+    assert (a.points, a.width, a.relight_samples) == (500_000, 1800, 128)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--config", "dtu4", "--gpus", "4"])
+    a = bench.parse()
+    assert (a.width, a.height, a.objective, a.sample_num, a.points, a.gpus) == (1600, 1200, "syn4", 32, 300_000, 4)
+    monkeypatch.setattr(sys, "argv", ["bench.py"])
+    a = bench.parse()
+    assert a.config is None and (a.points, a.res, a.sample_num, a.stage) == (300_000, 800, 64, 2)
