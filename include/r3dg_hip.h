@@ -362,12 +362,17 @@ int r3dg_shade_frs_backward(void* stream, int P, int K, const float* d_base_colo
  * Adam update of the incident-light group (the arithmetic of r3dg_adam_step for ONE group of [P,16,3] rows: columns 0..2 with
  * `lr`, the rest with `lr_tail`; `step` counts from 1; d_skip_flag as there) and rotates the NEW coefficients into the ray frames
  * (d_cprime, what r3dg_shade_frs_rotate would produce): 1536 instead of 2112 bytes per Gaussian and one launch instead of
- * three at the end of a whole training iteration (fused_step.py, "incident-light chain"). */
+ * three at the end of a whole training iteration (fused_step.py, "incident-light chain").
+ * listed_rows_in_dcprime != 0: the world-frame gradient rows of the Gaussians OFF the rotated path (d_valid[g] == 0) are read from
+ * their rows of d_dcprime instead of d_dL_dincidents -- for a caller that handed d_dcprime to r3dg_shade_frs_backward as
+ * d_dL_dincidents too, so that ONE [P,48] buffer holds the whole coefficient gradient (rotated frame on the rotated path, world
+ * frame off it) and can be summed over ranks as it is: the rotation is linear and the same on every rank (data-parallel
+ * iterations, round 6: grad_scale = 1 / world). */
 #define R3DG_SHADE_NO_ROTATION_BACK ((void*)(intptr_t)-1)
 int r3dg_shade_frs_incident_chain(void* stream, int P, const float* d_ray_normals, const uint8_t* d_valid,
                                   const float* d_dcprime, float* d_dL_dincidents, float* d_incidents, float* d_exp_avg,
                                   float* d_exp_avg_sq, float* d_cprime, float lr, float lr_tail, float beta1, float beta2,
-                                  float eps, int step, float grad_scale, const float* d_skip_flag);
+                                  float eps, int step, float grad_scale, const float* d_skip_flag, int listed_rows_in_dcprime);
 /*   Launch order on `stream`: the kernel on the listed Gaussians, then the main kernel (a caller that has other work
  *   running on another stream when it calls this gets the small launch beside that work).
  *   rotate_stream: NULL, or a second stream for the rotation of the coefficient gradient back to d_dL_dincidents (ordered after the

@@ -75,7 +75,7 @@ _SIGNATURES = {
     "r3dg_shade_frs_build_taps": (_i, [_p, _i, _i, _p, _p, _i, _i, _p]),
     "r3dg_shade_frs_forward": (_i, [_p, _i, _i] + [_p] * 6 + [_i, _i, _p, _f] + [_p] * 6 + [_i, _p, _i, _p, _p, _p]),
     "r3dg_shade_frs_backward": (_i, [_p, _i, _i] + [_p] * 6 + [_i, _i, _p, _f] + [_p] * 6 + [_i] + [_p] * 10 + [_i, _p]),
-    "r3dg_shade_frs_incident_chain": (_i, [_p, _i] + [_p] * 8 + [_f] * 5 + [_i, _f, _p]),
+    "r3dg_shade_frs_incident_chain": (_i, [_p, _i] + [_p] * 8 + [_f] * 5 + [_i, _f, _p, _i]),
     "r3dg_shade_build_transport": (_i, [_p, _i, _i, _i, _p, _p, _p, _p, _p, _f, _p, _p]),
     "r3dg_shade_forward_transport": (_i, [_p, _i, _i] + [_p] * 9),
     "r3dg_shade_build_split": (_i, [_p, _i, _i] + [_p] * 6 + [_f, _p, _p, _p]),

@@ -80,7 +80,7 @@ void launch_shade_frs_forward_listed(hipStream_t s, int K, const float* base_col
 void launch_shade_frs_incident_chain(hipStream_t s, int P, const float* ray_normals, const uint8_t* valid, const float* dcp,
                                      float* d_inc, float* incidents, float* exp_avg, float* exp_avg_sq, float* cprime, float lr,
                                      float lr_tail, float beta1, float beta2, float eps, int step, float grad_scale,
-                                     const float* skip_flag);
+                                     const float* skip_flag, int listed_in_dcprime);
 const unsigned int* launch_shade_frs_backward_aux(hipStream_t s, int P, const float* g_pbr, const float* g_diff,
                                                   const float* block_absmax, int n_block_absmax, int* gmax_n);
 void launch_shade_frs_backward_main(hipStream_t s, int P, int K, const float* base_color, const float* roughness,
@@ -1642,7 +1642,7 @@ int r3dg_shade_frs_backward(void* stream_, int P, int K, const float* base_color
 int r3dg_shade_frs_incident_chain(void* stream_, int P, const float* ray_normals, const uint8_t* valid, const float* dcprime,
                                   float* dL_dincidents, float* incidents, float* exp_avg, float* exp_avg_sq, float* cprime,
                                   float lr, float lr_tail, float beta1, float beta2, float eps, int step, float grad_scale,
-                                  const float* skip_flag)
+                                  const float* skip_flag, int listed_rows_in_dcprime)
 {
     if (P < 0) return invalid("shade_frs_incident_chain: bad sizes");
     if (step < 1) return invalid("shade_frs_incident_chain: step counts from 1");
@@ -1653,7 +1653,8 @@ int r3dg_shade_frs_incident_chain(void* stream_, int P, const float* ray_normals
         hipStream_t stream = (hipStream_t)stream_;
         StageTimer t(stream, ST_SHADE_AUX);
         launch_shade_frs_incident_chain(stream, P, ray_normals, valid, dcprime, dL_dincidents, incidents, exp_avg, exp_avg_sq,
-                                        cprime, lr, lr_tail, beta1, beta2, eps, step, grad_scale, skip_flag);
+                                        cprime, lr, lr_tail, beta1, beta2, eps, step, grad_scale, skip_flag,
+                                        listed_rows_in_dcprime != 0 ? 1 : 0);
         return R3DG_OK;
     });
 }

@@ -1338,7 +1338,7 @@ void launch_shade_frs_backward_rotate(hipStream_t s, int P, const float* ray_nor
 void launch_shade_frs_incident_chain(hipStream_t s, int P, const float* ray_normals, const uint8_t* valid, const float* dcp,
                                      float* d_inc, float* incidents, float* exp_avg, float* exp_avg_sq, float* cprime, float lr,
                                      float lr_tail, float beta1, float beta2, float eps, int step, float grad_scale,
-                                     const float* skip_flag)
+                                     const float* skip_flag, int listed_in_dcprime)
 {
     if (P == 0) return;
     // (bias corrections exactly as launch_adam forms them, stage2_glue.hip)
@@ -1349,7 +1349,7 @@ void launch_shade_frs_incident_chain(hipStream_t s, int P, const float* ray_norm
     const size_t lds = 4 * 64 * FRS_CHAIN_LD * sizeof(float);
     // (49 KB of dynamic LDS: under the 64 KB every launch may ask for, so no per-device function attribute is needed)
     frs_incident_chain_kernel<<<(P + 255) / 256, 256, lds, s>>>(P, ray_normals, valid, dcp, d_inc, incidents, exp_avg, exp_avg_sq,
-                                                                cprime, a, skip_flag);
+                                                                cprime, a, skip_flag, listed_in_dcprime);
     check_launch(s, false, "frs_incident_chain_kernel");
 }
 

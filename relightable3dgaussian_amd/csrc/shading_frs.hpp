@@ -254,7 +254,7 @@ __global__ void __launch_bounds__(256)
 frs_incident_chain_kernel(int P, const float* __restrict__ ray_normals, const uint8_t* __restrict__ valid,
                           const float* __restrict__ dcprime, float* __restrict__ dL_dincidents, float* __restrict__ incidents,
                           float* __restrict__ exp_avg, float* __restrict__ exp_avg_sq, float* __restrict__ cprime, FrsAdam adam,
-                          const float* __restrict__ skip_flag)
+                          const float* __restrict__ skip_flag, int listed_in_dcprime)
 {
     // a frame the bounded forward dropped: no update (adam_kernel's rule) -- and then nothing here is needed: the parameters and
     // therefore c' are unchanged, the gradient of a dropped frame is nobody's input
@@ -304,6 +304,11 @@ frs_incident_chain_kernel(int P, const float* __restrict__ ray_normals, const ui
             frs_rotate_band<1, 3, true>(R, kShRotPoints1, kShRotAinv1, row);
             frs_rotate_band<4, 5, true>(R, kShRotPoints2, kShRotAinv2, row);
             frs_rotate_band<9, 7, true>(R, kShRotPoints3, kShRotAinv3, row);
+        } else if (listed_in_dcprime) {
+            // (data parallel, round 6: the listed kernel wrote its world-frame row into the Gaussian's row of `dcprime` -- ONE buffer
+            // is all-reduced -- and that row sits in the LDS row already)
+#pragma unroll
+            for (int c = 0; c < 48; c++) row[c] = mine[c];
         } else {
             // (a few hundred Gaussians per launch: the listed kernel's world-frame row, read in place)
             const float4* s4 = reinterpret_cast<const float4*>(dL_dincidents + (size_t)g * 48);

@@ -402,6 +402,7 @@ class FusedStage2Step(_BoundedForward):
         self._early_pending = False                 # the early-Adam stream holds work no other stream has been ordered behind yet
         self._b_early = False
         self._a_late = False
+        self._dp_chain = None                       # data parallel: the ray set whose chain kernel closes this iteration's bucket B
         # softplus of the environment texture, refreshed behind the Adam launch that updates the texture (see optimizer_step)
         self._env_c = None                          # softplus(environment texture), see _env_buffer
         self._zero_depth_grad = None
@@ -698,7 +699,8 @@ class FusedStage2Step(_BoundedForward):
             He, We = env_c.shape[0], env_c.shape[1]
             taps = self.taps(He, We)
             if self._frs is not None:
-                rotated = rotated_for is self._frs            # (taps() may have rebuilt the ray set: then it rotates itself)
+                # (taps() may have rebuilt the ray set: then it rotates itself; data parallel: flush() above ran the chain kernel)
+                rotated = rotated_for is self._frs or (self.dp and self._rotation_is_current())
                 self._frs.forward(self.a_base, self.a_rough, self.a_normal, self.a_viewdirs, self._incidents, env_c,
                                   self.visibility, self.shade_out, uniform_area=self._uniform_area,
                                   # (one workgroup per CU beside the instance ordering while THAT is the longer path.  It is not
@@ -915,15 +917,25 @@ class FusedStage2Step(_BoundedForward):
                 # (incident-light chain as ONE kernel -- rotation back, Adam, rotation of the new coefficients, every global access a
                 # contiguous run per wave: the main shading backward then leaves the coefficient gradient in the rotated frame)
                 chain = self._early and self._b_early and self._chain_kernel and len(self._groups_b) == 1
+                # DATA PARALLEL (round 6): the same kernel closes the incident-light group there too.  The coefficient gradient
+                # stays in the rotated frame (the Gaussians off the rotated path: their world-frame rows, in the same buffer), THAT
+                # buffer is bucket B -- the rotation is linear and the same on every rank, so the sum over ranks of the rotated
+                # gradients is the rotated sum -- and the chain kernel behind the all-reduce rotates it back, applies Adam with
+                # 1 / world and rotates the new coefficients: bucket B is final one rotation launch (40 us) earlier, two launches
+                # fewer sit between its arrival and the shading forward.  Whole iterations only (`chain_incidents`).
+                dp_chain = (self.dp and chain_incidents and not chain and self._chain_kernel and len(self._groups_b) == 1
+                            and not self._single_bucket and os.environ.get("R3DG_DP_CHAIN", "1") != "0")
                 d_base, d_rough, d_view, _d_inc, d_env = self._frs.backward(
                     self.a_base, self.a_rough, self.a_normal, self.a_viewdirs, self._incidents, env_c, self.visibility,
                     self.d_pbr, self.d_diffuse,
-                    uniform_area=self._uniform_area, out_incidents=self.grads["incidents"], out_env=self._d_env,
+                    uniform_area=self._uniform_area,
+                    out_incidents=self._frs.dcprime_rows() if dp_chain else self.grads["incidents"], out_env=self._d_env,
                     block_absmax=self._absmax,
                     # whole iterations: the rotation back of the coefficient gradient goes to the stream that already carries the
                     # SH group's early Adam (optimizer_step joins it before any Adam launch reads the gradient; under data
                     # parallelism bucket B's all-reduce is issued from it) and runs beside the activation chain rule
-                    rotate_stream=self._early_stream if self._early else None, rotation_back=not chain)
+                    rotate_stream=self._early_stream if self._early else None, rotation_back=not (chain or dp_chain))
+                self._dp_chain = self._frs if dp_chain else None
                 if self._early and self._b_early:
                     # incident-light chain, behind the rotation back: the group's Adam, then the rotation of the NEW coefficients.
                     # (As ONE kernel -- rotation back + Adam + rotation forward, thread per Gaussian, 1536 instead of 2112 bytes per
@@ -990,7 +1002,12 @@ class FusedStage2Step(_BoundedForward):
                 self._handles = (None, self._allreduce_async(self._bucket_all, "ALL"), None)
             elif self.dp:
                 handle_c = self._allreduce_async(self._bucket_c, "C")
-                if self._early:       # the incident-light gradient is finished by the rotation back, on the early stream
+                if self._dp_chain is not None:
+                    # (BEHIND bucket C although it was final first: the collectives run in the order they are issued, and C is the
+                    # bucket the main stream waits for -- issued right behind the shading backward, B cost the priced rehearsal
+                    # 397 -> 374 it/s per rank at 150 GB/s, 590 -> 543 at 300)
+                    handle_b = self._allreduce_async(self._dp_chain.dcprime.view(-1), "B")
+                elif self._early:       # the incident-light gradient is finished by the rotation back, on the early stream
                     with torch.cuda.stream(self._early_stream):
                         handle_b = self._allreduce_async(self._bucket_b, "B")
                 else:
@@ -1160,6 +1177,10 @@ class FusedStage2Step(_BoundedForward):
                 todo = self._groups_a + self._groups_c + self._groups_b
             if todo:                     # ONE launch for every remaining group
                 self.opt.step_groups(todo, grads, skip_flag=self._skip_cur)
+                if set(todo) & set(self._groups_b):
+                    # the coefficients change under a rotation some earlier iteration's chain may have left behind (the kernel writes
+                    # through the raw pointer: the version counter _rotation_is_current() looks at does not move)
+                    self._pre_rotated = None
             if self._chain_deferred is not None:
                 run, self._chain_deferred = self._chain_deferred, None
                 run()
@@ -1174,6 +1195,7 @@ class FusedStage2Step(_BoundedForward):
             todo = self._groups_a + self._groups_c + self._groups_b
             if todo:
                 self.opt.step_groups(todo, grads, scale, skip_flag=self._skip_cur)
+                self._pre_rotated = None
             return
         if self._early:                  # bucket A was waited for and applied on the side stream (forward_backward)
             torch.cuda.current_stream().wait_stream(self._early_stream)
@@ -1206,8 +1228,18 @@ class FusedStage2Step(_BoundedForward):
             handle_b, grads, scale, skip, it_b = self._pending_b
             self._pending_b = None
             self._wait(handle_b, "B", it=it_b)
-            if self._groups_b:
+            frs, self._dp_chain = self._dp_chain, None
+            if frs is not None:
+                # rotation back of the REDUCED gradient (into grads["incidents"]) + Adam with 1 / world + rotation of the new
+                # coefficients, one kernel; the next shading forward finds its rotated coefficients in place
+                grp = self.opt.groups[self._groups_b[0]]
+                frs.incident_chain(self._incidents, self.grads["incidents"], grp["exp_avg"], grp["exp_avg_sq"], grp["lr"],
+                                   grp.get("lr_tail") if grp.get("lr_tail") is not None else grp["lr"], self.opt.betas,
+                                   self.opt.eps, self.opt.step_count, scale, skip_flag=skip, listed_in_dcprime=True)
+                self._pre_rotated = (frs, self._incidents, self._incidents._version)
+            elif self._groups_b:
                 self.opt.step_groups(self._groups_b, grads, scale, skip_flag=skip)
+                self._pre_rotated = None           # (see optimizer_step)
 
     @_in_context
     def __call__(self, cam, bg, gt, image_mask=None):

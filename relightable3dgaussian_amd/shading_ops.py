@@ -335,10 +335,12 @@ class FixedRaySet:
         return d_base, d_rough, d_view, d_inc, d_env
 
     def incident_chain(self, incidents, dL_dincidents, exp_avg, exp_avg_sq, lr, lr_tail, betas, eps, step, grad_scale=1.0,
-                       skip_flag=None):
+                       skip_flag=None, listed_in_dcprime=False):
         """r3dg_shade_frs_incident_chain on the current stream, behind backward(rotation_back=False): the gradient rotated back
         into `dL_dincidents`, the Adam step of the incident-light group (`incidents`, its two moment tensors; FusedAdam's
-        arithmetic), the NEW coefficients rotated into `self.cprime` for the next forward."""
+        arithmetic), the NEW coefficients rotated into `self.cprime` for the next forward.  `listed_in_dcprime`: backward() was
+        given `out_incidents=self.dcprime_rows()` -- the world-frame rows of the Gaussians off the rotated path sit in `dcprime`
+        too (ONE buffer to all-reduce under data parallelism)."""
         for t in (incidents, dL_dincidents, exp_avg, exp_avg_sq):
             if tuple(t.shape) != (self.P, 16, 3) or t.dtype != torch.float32 or not t.is_contiguous():
                 raise RuntimeError("FixedRaySet.incident_chain: needs contiguous float32 [P,16,3] tensors")
@@ -347,8 +349,12 @@ class FixedRaySet:
                 _lib.current_stream(), self.P, self.ray_normals.data_ptr(), self.valid.data_ptr(), self.dcprime.data_ptr(),
                 dL_dincidents.data_ptr(), incidents.data_ptr(), exp_avg.data_ptr(), exp_avg_sq.data_ptr(), self.cprime.data_ptr(),
                 float(lr), float(lr_tail), float(betas[0]), float(betas[1]), float(eps), int(step), float(grad_scale),
-                skip_flag.data_ptr() if skip_flag is not None else None)
+                skip_flag.data_ptr() if skip_flag is not None else None, 1 if listed_in_dcprime else 0)
         _lib.check(st, "shade_frs_incident_chain")
+
+    def dcprime_rows(self):
+        """`dcprime` as the [P,16,3] tensor backward(out_incidents=...) takes."""
+        return self.dcprime.view(self.P, 16, 3)
 
 
 class _Shade(torch.autograd.Function):

@@ -457,6 +457,36 @@ def test_every_schedule_of_the_whole_iteration_trains_alike(monkeypatch):
             assert ok, msg
 
 
+def test_switching_schedules_between_iterations_keeps_the_rotated_coefficients_current(monkeypatch):
+    """The chain kernel leaves the rotation of the NEW incident-light coefficients behind for the next forward (`_pre_rotated`).  An
+    iteration that updates the coefficients through the plain Adam launch instead must invalidate that record -- the kernel writes
+    through the raw pointer, the tensor's version counter does not move -- or the iteration after it shades with coefficients that
+    are one update old (a latent bug until round 6: bench.py's one-stream pass toggled schedules, nothing compared results across
+    the toggle).  Alternating schedules must train like one schedule throughout."""
+    from relightable3dgaussian_amd.fused_step import FusedStage2Step
+    P, res, K = 4000, 128, 16
+    plain = {"R3DG_EARLY_ADAM": "0", "R3DG_CHAIN_WITHOUT_EARLY_ADAM": "0"}
+    runs = {}
+    for name, pattern in (("default", [{}] * 6), ("alternating", [{}, plain, {}, plain, plain, {}])):
+        params, ref, fused, cam, bg, gt = _setup(P=P, res=res, K=K, seed=11)
+        step = FusedStage2Step(params, K, lr=2e-3)
+        losses = []
+        for env in pattern:
+            for k in plain:
+                monkeypatch.delenv(k, raising=False)
+            for k, v in env.items():
+                monkeypatch.setenv(k, v)
+            step(cam, bg, gt)
+            losses.append(float(step.loss()))
+        runs[name] = (losses, step.incidents.clone(), step.base_color.clone())
+    for k in plain:
+        monkeypatch.delenv(k, raising=False)
+    assert np.allclose(runs["alternating"][0], runs["default"][0], rtol=2e-5), (runs["alternating"][0], runs["default"][0])
+    for i in (1, 2):
+        ok, msg = report("param %d" % i, runs["alternating"][i], runs["default"][i], 1e-4, 1e-6)
+        assert ok, msg
+
+
 def test_feature_rows_written_in_place_equal_the_packed_rows(monkeypatch):
     """Without r3dg_stage2_pack_features (the default when the fixed-ray-set kernels run): r3dg_stage2_activate writes the nine
     columns of the [P,16] feature rows that do not wait for the shading integral, r3dg_shade_frs_forward (main and listed

@@ -956,9 +956,10 @@ def test_fused_stage2_iteration_spreads_the_fixed_ray_set_path_over_three_stream
 
 def test_fused_stage2_data_parallel_iteration_issues_its_buckets_from_the_streams_that_finish_them(monkeypatch):
     """The same recorders around the DATA-PARALLEL iteration (two ranks pretended): bucket A's all-reduce is issued inside the
-    early stream's context right behind the geometry backward that runs there, bucket C's from the main stream, bucket B's
-    inside the early stream's context behind the rotation back; the deferred incident-light update waits for B at the top of
-    the next iteration's forward, and the coefficient rotation is NOT queued ahead of it (the coefficients are not final yet)."""
+    early stream's context right behind the geometry backward that runs there, bucket C's from the main stream; bucket B (round 6)
+    is the ray set's ROTATED-frame gradient buffer, issued from the main stream behind C (no rotation back in front of it); the deferred incident-light update waits for B at the top of the next iteration's forward and closes the
+    group with ONE chain kernel (rotation back of the reduced gradient + Adam + rotation of the new coefficients), so the forward
+    is told that its rotated coefficients are in place.  R3DG_DP_CHAIN=0: the three-launch path of rounds 2-5."""
     import contextlib
     import types
     from relightable3dgaussian_amd import _lib, fused_step, rasterizer_ops, shading_ops
@@ -1010,6 +1011,12 @@ def test_fused_stage2_data_parallel_iteration_issues_its_buckets_from_the_stream
     class FakeRaySet:
         n_invalid = 1
 
+        def __init__(self):
+            self.dcprime = z(P, 48)
+
+        def dcprime_rows(self):
+            return self.dcprime.view(P, 16, 3)
+
         def taps(self, He, We):
             pass
 
@@ -1019,10 +1026,16 @@ def test_fused_stage2_data_parallel_iteration_issues_its_buckets_from_the_stream
         def forward(self, *a, listed_stream=None, rotated=False, **k):
             events.append(("frs.forward rotated=%s" % rotated, tuple(depth)))
 
-        def backward(self, *a, out_incidents=None, out_env=None, rotate_stream=None, **k):
-            events.append(("frs.backward", (rotate_stream.cuda_stream if rotate_stream is not None else None,)))
+        def backward(self, *a, out_incidents=None, out_env=None, rotate_stream=None, rotation_back=True, **k):
+            events.append(("frs.backward rotation_back=%s into_dcprime=%s" % (
+                rotation_back, out_incidents is not None and out_incidents.data_ptr() == self.dcprime.data_ptr()),
+                (rotate_stream.cuda_stream if rotate_stream is not None else None,)))
             return z(P, 3), z(P, 1), z(P, 3), out_incidents, out_env
 
+        def incident_chain(self, *a, listed_in_dcprime=False, **k):
+            events.append(("frs.incident_chain listed_in_dcprime=%s grad_scale=%s" % (listed_in_dcprime, a[9]), tuple(depth)))
+
+    the_ray_set = FakeRaySet()
     monkeypatch.setattr(fused_step, "_world_of", lambda group: (2, True))
     monkeypatch.setattr(_lib, "lib", lambda: Recorder())
     monkeypatch.setattr(_lib, "current_stream", lambda: 0)
@@ -1035,7 +1048,7 @@ def test_fused_stage2_data_parallel_iteration_issues_its_buckets_from_the_stream
                                                                           torch.full((P, K, 1), 2.0), None))
     monkeypatch.setattr(shading_ops, "build_taps", lambda dirs, He, We, *a, **k: z(P * K * 3))
     monkeypatch.setattr(shading_ops.FixedRaySet, "supported", staticmethod(lambda K_, M_, He, We: True))
-    monkeypatch.setattr(shading_ops.FixedRaySet, "try_build", classmethod(lambda cls, normals, dirs, **k: FakeRaySet()))
+    monkeypatch.setattr(shading_ops.FixedRaySet, "try_build", classmethod(lambda cls, normals, dirs, **k: the_ray_set))
 
     class Pending:
         def finish(self, ordering_stream=None):
@@ -1062,26 +1075,50 @@ def test_fused_stage2_data_parallel_iteration_issues_its_buckets_from_the_stream
                                 camera_center=z(3), tanfovx=0.5, tanfovy=0.5, cx=2.0, cy=2.0)
     step = fused_step.FusedStage2Step(params, K, process_group=object())
     assert step.dp and step.world == 2
-    buckets.update({step._bucket_a.data_ptr(): "A", step._bucket_c.data_ptr(): "C", step._bucket_b.data_ptr(): "B"})
+    buckets.update({step._bucket_a.data_ptr(): "A", step._bucket_c.data_ptr(): "C", step._bucket_b.data_ptr(): "B (slab)",
+                    the_ray_set.dcprime.data_ptr(): "B"})
     for _ in range(3):
         step(cam, torch.ones(3), z(3, H, W))
     early = step._adam_stream.cuda_stream
     names = [e[0] for e in events]
     start = len(names) - 1 - names[::-1].index("r3dg_stage2_activate_with")        # the third iteration
     it = events[start:]
-    seq = [(n, d) for n, d in it if n.split()[0] in ("all_reduce", "wait", "frs.rotate", "frs.forward", "frs.backward", "raster.backward")]
+    kinds = ("all_reduce", "wait", "frs.rotate", "frs.forward", "frs.backward", "frs.incident_chain", "raster.backward")
+    seq = [(n, d) for n, d in it if n.split()[0] in kinds]
     assert seq == [
-        ("wait B", ()),                                     # flush(): the previous iteration's incident-light update
-        ("frs.forward rotated=False", ()),                  # ... so the forward rotates the coefficients itself, after it
+        ("wait B", ()),                                     # flush(): the previous iteration's incident-light update ...
+        ("frs.incident_chain listed_in_dcprime=True grad_scale=0.5", ()),      # ... ONE kernel, 1 / world inside
+        ("frs.forward rotated=True", ()),                   # the chain left the rotated coefficients in place
         ("raster.backward geometry_stream=%d" % early, ()),
         ("all_reduce A", (early,)),                         # behind the geometry backward, on its stream
         ("wait A", (early,)),                               # the SH group's early Adam waits there, not on the main stream
-        ("frs.backward", (early,)),                         # rotation back on the early stream
-        ("all_reduce C", ()),
-        ("all_reduce B", (early,)),                         # behind the rotation that finishes the incident-light gradient
+        ("frs.backward rotation_back=False into_dcprime=True", (early,)),
+        ("all_reduce C", ()),                               # C first: it is the bucket the main stream waits for
+        ("all_reduce B", ()),                               # the rotated-frame buffer, from the main stream (no rotation back)
         ("wait C", ()),
     ], seq
     assert "frs.rotate" not in names
+    # R3DG_DP_CHAIN=0: rotation back on the early stream, bucket B = the slab's incident-light region behind it, Adam + the forward's
+    # own rotation in the next iteration
+    monkeypatch.setenv("R3DG_DP_CHAIN", "0")
+    del events[:]
+    for _ in range(2):
+        step(cam, torch.ones(3), z(3, H, W))
+    names = [e[0] for e in events]
+    it = events[len(names) - 1 - names[::-1].index("r3dg_stage2_activate_with"):]
+    seq = [(n, d) for n, d in it if n.split()[0] in kinds]
+    assert seq == [
+        ("wait B (slab)", ()),
+        ("frs.forward rotated=False", ()),
+        ("raster.backward geometry_stream=%d" % early, ()),
+        ("all_reduce A", (early,)),
+        ("wait A", (early,)),
+        ("frs.backward rotation_back=True into_dcprime=False", (early,)),
+        ("all_reduce C", ()),
+        ("all_reduce B (slab)", (early,)),
+        ("wait C", ()),
+    ], seq
+    monkeypatch.delenv("R3DG_DP_CHAIN")
     # ---- per-bucket attribution (bench.py: measure_comm): every probed bucket gets a `ready` event on the stream that issues it
     # (no stream of its own: that perturbed the schedule); the waits carry the bucket's name; comm_table() reads the collective's own
     # time from the work handle where the backend times it, else the ready -> released interval -----------------------------------
@@ -1128,7 +1165,7 @@ def test_fused_stage2_data_parallel_iteration_issues_its_buckets_from_the_stream
     names = [e[0] for e in events[calls_before:]]
     last = names[len(names) - 1 - names[::-1].index("r3dg_stage2_activate_with"):]
     seq = [n for n in last if n.split()[0] in ("all_reduce", "wait", "r3dg_adam_step", "frs.backward")]
-    assert seq == ["frs.backward", "all_reduce ALL", "wait ALL", "r3dg_adam_step"], seq
+    assert seq == ["frs.backward rotation_back=True into_dcprime=False", "all_reduce ALL", "wait ALL", "r3dg_adam_step"], seq
     assert one._pending_b is None
 
 
