@@ -730,16 +730,22 @@ def config_rate(dev, points, width, height, stage=2, sample_num=64, objective="n
         out.update(objective="script/run_nerf.sh stage 1 (the reference's real regularisers)")
     for i in range(warmup):
         step_fn(cams[i % 4], bg, gts[i % 4])
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for i in range(steps):
-        step_fn(cams[(warmup + i) % 4], bg, gts[(warmup + i) % 4])
-    step_fn.flush()
-    torch.cuda.synchronize()
-    dt = (time.perf_counter() - t0) / steps
+    # two timed blocks, the faster one reported (both listed): these short side rows run once inside a long process, and a single
+    # host hiccup inside ten timed steps -- seen once in round 6: 360 it/s for the DTU row between runs of 607-619 on the same
+    # tree -- must not stand as the configuration's rate
+    blocks = []
+    for b in range(2):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(steps):
+            step_fn(cams[(warmup + i) % 4], bg, gts[(warmup + i) % 4])
+        step_fn.flush()
+        torch.cuda.synchronize()
+        blocks.append((time.perf_counter() - t0) / steps)
+    dt = min(blocks)
     counts = step_fn.rendered_counts(steps)
     out.update(iters_per_s=round(1.0 / dt, 2), ms_per_step=round(1e3 * dt, 3), num_rendered=round(sum(counts) / max(1, len(counts))),
-               dropped_steps=step_fn.poll_overflow())
+               iters_per_s_blocks=[round(1.0 / x, 2) for x in blocks], dropped_steps=step_fn.poll_overflow())
     if stage_ms:
         # per-stage HIP-event times of 3 more iterations (outside the timed region: the event pairs cost host time)
         L = _lib.lib()
